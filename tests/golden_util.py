@@ -1,0 +1,136 @@
+"""Shared definitions for golden-vector cases (used by tools/gen_golden.py and tests/).
+
+Weights and inputs are regenerated from seeds (legacy ``RandomState`` -- bit-stable
+across NumPy versions) so the committed fixtures only hold *outputs* of the
+reference classes plus the (key, shape) list of the reference state dict.
+"""
+import os
+import zlib
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+# keys whose value is a deterministic closed form (kept as constructed, and
+# compared against the reference's value stored in the fixture)
+CLOSED_FORM_SUFFIXES = ('.grid', 'enc_t_pe')
+
+
+def seeded_tensor(key, shape, seed):
+    rs = np.random.RandomState((zlib.crc32(key.encode()) ^ seed) & 0x7fffffff)
+    shape = tuple(shape)
+    if key.endswith('init_latents'):
+        a = rs.standard_normal(shape)
+    elif 'bias' in key.rsplit('.', 1)[-1]:
+        a = 0.1 * (rs.rand(*shape) * 2 - 1)
+    elif len(shape) >= 2:
+        fan_in = int(np.prod(shape[1:]))
+        a = (rs.rand(*shape) * 2 - 1) * (1.5 / np.sqrt(fan_in))
+    else:  # 1-D "weight" = LayerNorm gamma
+        a = 1.0 + 0.1 * rs.standard_normal(shape)
+    return torch.from_numpy(a.astype(np.float32))
+
+
+def seeded_state_dict(shapes, seed, keep=None):
+    """shapes: list of (key, shape).  keep: dict of closed-form tensors to reuse."""
+    sd = {}
+    for key, shape in shapes:
+        if key.endswith(CLOSED_FORM_SUFFIXES):
+            assert keep is not None and key in keep, key
+            sd[key] = keep[key].clone()
+        else:
+            sd[key] = seeded_tensor(key, shape, seed)
+    return sd
+
+
+def seeded_img(B, T, res, seed=1234):
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy((rs.rand(B, T, 3, res, res) * 2 - 1).astype(np.float32))
+
+
+def seeded_normal(shape, seed):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32))
+
+
+# ---------------------------------------------------------------------------
+# model configs (dict form of the reference's *_params.py)
+# ---------------------------------------------------------------------------
+def savi_cfg(res, num_slots, slot_size=128, mlp=256, iters=2, kernel_mlp=True, pred='transformer',
+             rnn=True, kld='none', enc_out=128, pred_layers=2, pred_heads=4, pred_ffn=512,
+             dec_res=(8, 8)):
+    return dict(
+        model='StoSAVi',
+        resolution=(res, res),
+        input_frames=6,
+        slot_dict=dict(num_slots=num_slots, slot_size=slot_size, slot_mlp_size=mlp,
+                       num_iterations=iters, kernel_mlp=kernel_mlp),
+        enc_dict=dict(enc_channels=(3, 64, 64, 64, 64), enc_ks=5, enc_out_channels=enc_out,
+                      enc_norm=''),
+        dec_dict=dict(dec_channels=(slot_size, 64, 64, 64, 64), dec_resolution=dec_res, dec_ks=5,
+                      dec_norm=''),
+        pred_dict=dict(pred_type=pred, pred_rnn=rnn, pred_norm_first=True,
+                       pred_num_layers=pred_layers, pred_num_heads=pred_heads,
+                       pred_ffn_dim=pred_ffn, pred_sg_every=None),
+        loss_dict=dict(use_post_recon_loss=True, kld_method=kld),
+    )
+
+
+def rollout_cfg(num_slots, slot_size, hist, d_model, layers, heads, ffn, cond_len=None,
+                rollout_len=10, model='SlotFormer', res=64):
+    rd = dict(num_slots=num_slots, slot_size=slot_size, history_len=hist, t_pe='sin', slots_pe='',
+              d_model=d_model, num_layers=layers, num_heads=heads, ffn_dim=ffn, norm_first=True)
+    if cond_len is not None:
+        rd['cond_len'] = cond_len
+    return dict(
+        model=model,
+        resolution=(res, res),
+        input_frames=hist,
+        slot_dict=dict(num_slots=num_slots, slot_size=slot_size),
+        rollout_dict=rd,
+        dec_dict=dict(dec_channels=(slot_size, 64, 64, 64, 64), dec_resolution=(8, 8), dec_ks=5,
+                      dec_norm='', dec_ckp_path=''),
+        loss_dict=dict(rollout_len=rollout_len, use_img_recon_loss=False),
+    )
+
+
+# C1: OBJ3D SAVi (savi_obj3d_params.py) -- deterministic, Transformer+LSTM predictor
+C1_SAVI = savi_cfg(64, 6, iters=2, kernel_mlp=True, pred='transformer', rnn=True, kld='none')
+C1_SAVI_IT3 = savi_cfg(64, 6, iters=3, kernel_mlp=True, pred='transformer', rnn=True, kld='none')
+# C2: CLEVRER StoSAVi (stosavi_clevrer_params.py) at 128x128 -- stochastic, MLP predictor
+C2_SAVI = savi_cfg(128, 7, iters=2, kernel_mlp=False, pred='mlp', rnn=False, kld='var-0.01')
+# C4: Physion STEVE encoder side (steve_physion_params.py)
+C4_STEVE = savi_cfg(128, 6, slot_size=192, mlp=384, iters=2, pred='transformer', rnn=True,
+                    enc_out=192, pred_ffn=768)
+C4_STEVE['model'] = 'STEVE'
+# C5: PHYRE SAVi (savi_phyre_params-fold0.py)
+C5_SAVI = savi_cfg(128, 8, iters=2, kernel_mlp=True, pred='transformer', rnn=True, kld='none',
+                   dec_res=(16, 16))
+
+C1_ROLL = rollout_cfg(6, 128, 6, 128, 4, 8, 512, rollout_len=10)
+C2_ROLL = rollout_cfg(7, 128, 6, 256, 4, 8, 1024, rollout_len=50)
+C4_ROLL = rollout_cfg(6, 192, 6, 256, 8, 8, 1024, rollout_len=40)
+C4_ROLL_REF = rollout_cfg(6, 192, 15, 256, 8, 8, 1024, rollout_len=10)
+C5_ROLL = rollout_cfg(8, 128, 1, 256, 8, 8, 1024, cond_len=6, rollout_len=80,
+                      model='SingleStepSlotFormer', res=128)
+
+
+class ParamsView:
+    """Attribute view of a cfg dict -- what ``build_model(params)`` consumes."""
+
+    def __init__(self, cfg):
+        self.__dict__.update(cfg)
+
+    def get(self, k, default=None):
+        return self.__dict__.get(k, default)
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN_DIR, name + '.npz'), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def shapes_from_golden(g):
+    keys = [str(k) for k in g['sd_keys']]
+    shapes = [tuple(int(v) for v in s.split('x')) if s else () for s in (str(x) for x in g['sd_shapes'])]
+    return list(zip(keys, shapes))
