@@ -1,0 +1,150 @@
+/* slotformer_hip.h -- C ABI of libslotformer_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (pairlab/SlotFormer) has NO native/FFI boundary: its hot path is Python
+ * nn.Modules calling ATen/cuDNN.  This header is therefore the boundary a maintainer would
+ * bind (ctypes); every entry point cites the reference call site whose
+ * arithmetic it replaces (file:line under the reference tree).
+ *
+ * Conventions: extern "C"; int return (0 = ok, <0 = argument error, >0 = hipError_t);
+ * sf_last_error_string() describes the last failure on the calling thread; every pointer is a
+ * DEVICE pointer to row-major contiguous fp32 unless stated; the caller owns every buffer
+ * (inputs, outputs, workspace -- query *_workspace_bytes()); `stream` is a hipStream_t passed
+ * as void*; calls are asynchronous on that stream, re-entrant, never synchronise, and never
+ * allocate device memory.
+ */
+#ifndef SLOTFORMER_HIP_H
+#define SLOTFORMER_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int sf_version(void);
+const char* sf_last_error_string(void);
+
+/* ---- building blocks ------------------------------------------------------------------ */
+
+/* C[M,N] = act( LN?(A)[M,K] @ W[N,K]^T + bias ) + residual.   nn.Linear / F.layer_norm call
+ * sites: savi.py:66-70,80,245-250; predictor.py:58-73; slotformer.py:115,121; torch
+ * TransformerEncoderLayer linears.  W is the torch weight as stored ([out,in]).  ln_gamma/
+ * ln_beta (both or neither) fuse a LayerNorm over K into the A load; residual may be NULL. */
+int sf_linear_f32(const float* A, int lda, const float* W, const float* bias, const float* ln_gamma,
+                  const float* ln_beta, float ln_eps, const float* residual, int ldr, float* C, int ldc,
+                  int M, int N, int K, int relu, void* stream);
+
+/* nn.LayerNorm over the last dim (savi.py:41,50,66; predictor.py:57). */
+int sf_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int rows, int D,
+                     float eps, void* stream);
+
+/* First encoder conv (savi.py:231-239, i == 0): NCHW image, frame f at img + f*frame_stride
+ * floats; weight [Cout,Cin,ks,ks]; padding ks/2; output NHWC [F,Ho,Wo,Cout]; optional `add`
+ * table [Ho*Wo,Cout] added after the activation. */
+int sf_conv2d_nchw_in_f32(const float* img, long long frame_stride, const float* weight, const float* bias,
+                          const float* add, float* out, int F, int Cin, int Hin, int Win, int Cout, int ks,
+                          int stride, int relu, void* stream);
+
+/* Encoder convs i > 0 (savi.py:231-239): stride 1, padding ks/2, NHWC in -> NHWC out,
+ * w_packed [Cout,ks,ks,Cin] (sf_pack_conv_weight_f32); `add` as above (used for the soft
+ * position embedding, utils.py:60-63 / savi.py:370). */
+int sf_conv2d_nhwc_f32(const float* in, const float* w_packed, const float* bias, const float* add, float* out,
+                       int F, int H, int W, int Cin, int Cout, int ks, int relu, void* stream);
+int sf_pack_conv_weight_f32(const float* w_oihw, float* w_ohwi, int Cout, int Cin, int ks, void* stream);
+
+/* table[HW,C] = dense(grid)  (SoftPositionEmbed, utils.py:52-63; grid [HW,4]). */
+int sf_pos_embed_table_f32(const float* grid, const float* dense_w, const float* dense_b, float* table, int HW,
+                           int C, void* stream);
+
+/* One Slot-Attention iteration, attention half (savi.py:82-89 / steve.py:50-60): logits,
+ * softmax over slots, +eps, and the per-slot sums over pixels as P partial records per batch.
+ * k,v rows have leading dimension ld and batch_stride floats between batches. */
+int sf_slot_attn_num_partials(int HW);
+int sf_slot_attn_iter_f32(const float* k, const float* v, int ld, long long batch_stride, const float* q,
+                          float* part_num, float* part_den, float* attn_out, int B, int HW, int N, int D,
+                          float scale, float eps, void* stream);
+
+/* Slot update (savi.py:95-100): updates = sum(num)/sum(den); GRUCell (r,z,n); slots + MLP(LN(slots)). */
+int sf_slot_update_f32(const float* part_num, const float* part_den, int P, const float* slots_prev,
+                       const float* gru_w_ih, const float* gru_w_hh, const float* gru_b_ih,
+                       const float* gru_b_hh, const float* ln_g, const float* ln_b, const float* mlp_w1,
+                       const float* mlp_b1, const float* mlp_w2, const float* mlp_b2, float* slots_out, int B,
+                       int N, int D, int H, float ln_eps, void* stream);
+
+/* nn.MultiheadAttention core for short sequences: qkv [B*L,3d] (q|k|v), out [B*Lq,d]; queries
+ * are the last Lq rows of each sequence (Lq == L: all). */
+int sf_mha_f32(const float* qkv, float* out, int B, int L, int Lq, int d_model, int num_heads, void* stream);
+
+/* nn.LSTM single step pointwise part (predictor.py:116-117), gates [R,4H] (i,f,g,o) pre-summed. */
+int sf_lstm_pointwise_f32(const float* gates, const float* c_prev, float* h_out, float* c_out, int R, int H,
+                          void* stream);
+
+/* StoSAVi._sample_dist (savi.py:355-365): out = mu (+ noise*exp(logvar/2)); noise may be NULL. */
+int sf_sample_dist_f32(const float* dist, const float* noise, float* out, int R, int D, void* stream);
+
+/* F.interpolate(bilinear, align_corners=False) on R planes (steve.py:230-238). */
+int sf_bilinear_resize_f32(const float* in, float* out, long long R, int Hi, int Wi, int Ho, int Wo,
+                           void* stream);
+
+/* ---- whole-path engines ------------------------------------------------------------------ */
+
+/* One nn.TransformerEncoderLayer (relu, batch_first); all pointers device, torch layouts. */
+typedef struct {
+  const float *norm1_g, *norm1_b, *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;
+  const float *norm2_g, *norm2_b, *lin1_w, *lin1_b, *lin2_w, *lin2_b;
+} sf_tfm_layer;
+
+/* SlotRollouter / SingleStepSlotRollouter (slotformer.py:48-134, single_step_slotformer.py:6-90). */
+typedef struct {
+  int num_slots, slot_size, d_model, num_layers, num_heads, ffn_dim, norm_first;
+  int window_len;   /* history_len (sliding window) or cond_len (single-step growing window) */
+  int single_step;  /* 0: SlotRollouter, 1: SingleStepSlotRollouter */
+  const float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;
+  const float* pe_tok;          /* [window_len*num_slots, d_model]: enc_t_pe per slot (+ enc_slots_pe) */
+  const sf_tfm_layer* layers;   /* HOST array [num_layers] */
+} sf_rollouter;
+
+size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B);
+/* slots: [B, T_total, N, C]; the first n_in frames hold the burn-in slots (n_in = window_len, or 1
+ * for single_step); frames n_in .. n_in+pred_len-1 are written.  T_total >= n_in + pred_len. */
+int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws,
+                   size_t ws_bytes, void* stream);
+
+/* StoSAVi / STEVE encoder side (savi.py:177-250,295-322,367-416; steve.py:198-240). */
+typedef struct {
+  int resolution;      /* input H == W (64 or 128) */
+  int enc_layers;      /* number of convs (<= 8) */
+  int enc_channels[9]; /* enc_channels[0] = 3 */
+  int enc_ks;
+  int enc_out_channels, num_slots, slot_size, slot_mlp_size, num_iterations;
+  const float* conv_w[8]; /* [0]: torch [C1,3,ks,ks]; [i>0]: packed [Cout,ks,ks,Cin] */
+  const float* conv_b[8]; /* may be NULL */
+  const float* pos_table; /* [64*64, C_last] */
+  const float *enc_ln_g, *enc_ln_b, *enc_fc1_w, *enc_fc1_b, *enc_fc2_w, *enc_fc2_b;
+  const float *sa_norm_in_g, *sa_norm_in_b, *sa_q_ln_g, *sa_q_ln_b, *sa_q_w;
+  const float* sa_kv_w; /* [2*slot_size, enc_out_channels] = cat(project_k.weight, project_v.weight) */
+  const float *gru_w_ih, *gru_w_hh, *gru_b_ih, *gru_b_hh;
+  const float *mlp_ln_g, *mlp_ln_b, *mlp_w1, *mlp_b1, *mlp_w2, *mlp_b2;
+  const float* init_latents; /* [N, D] */
+  int kd_mode;               /* 0: none (STEVE), 1: Linear, 2: Linear-LN-ReLU-Linear (kernel_mlp) */
+  const float *kd_w0, *kd_b0, *kd_ln_g, *kd_ln_b, *kd_w3, *kd_b3;
+  int pred_type;             /* 0: ResidualMLPPredictor, 1: TransformerPredictor */
+  int pred_rnn, pred_norm_first, pred_num_layers, pred_num_heads, pred_ffn_dim, pred_hidden;
+  const float *pm_ln_g, *pm_ln_b, *pm_w0, *pm_b0, *pm_w2, *pm_b2;
+  const sf_tfm_layer* pred_layers; /* HOST array */
+  const float *lstm_w_ih, *lstm_w_hh, *lstm_b_ih, *lstm_b_hh, *proj_w, *proj_b;
+  float sa_eps;
+} sf_savi_encoder;
+
+size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B);
+/* img [B,T,3,H,W]; noise [B,T,N,D] or NULL (deterministic / STEVE); prev_slots [B,N,D] or NULL
+ * (NULL: frame 0 starts from init_latents and the LSTM state is reset, savi.py:474-475);
+ * lstm_h/lstm_c [B*N, pred_hidden] in/out (used iff pred_rnn; state_valid == 0: zeros);
+ * outputs: post_slots [B,T,N,D], kernel_dist [B,T,N,2D] or NULL, attn [B,T,N,64*64] or NULL. */
+int sf_savi_encode_f32(const sf_savi_encoder* m, const float* img, const float* noise, const float* prev_slots,
+                       float* lstm_h, float* lstm_c, int state_valid, float* post_slots, float* kernel_dist,
+                       float* attn, int B, int T, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,102 @@
+"""ctypes binding of libslotformer_hip.so (include/slotformer_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, a
+RuntimeError is raised.  Nothing here imports oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libslotformer_hip.so')
+
+FP = C.c_void_p  # device float*
+
+
+class sf_tfm_layer(C.Structure):
+    _fields_ = [(n, FP) for n in (
+        'norm1_g', 'norm1_b', 'in_proj_w', 'in_proj_b', 'out_proj_w', 'out_proj_b',
+        'norm2_g', 'norm2_b', 'lin1_w', 'lin1_b', 'lin2_w', 'lin2_b')]
+
+
+class sf_rollouter(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        'num_slots', 'slot_size', 'd_model', 'num_layers', 'num_heads', 'ffn_dim', 'norm_first',
+        'window_len', 'single_step')] + [(n, FP) for n in (
+            'in_proj_w', 'in_proj_b', 'out_proj_w', 'out_proj_b', 'pe_tok')] + [
+                ('layers', C.POINTER(sf_tfm_layer))]
+
+
+class sf_savi_encoder(C.Structure):
+    _fields_ = (
+        [('resolution', C.c_int), ('enc_layers', C.c_int), ('enc_channels', C.c_int * 9),
+         ('enc_ks', C.c_int)] +
+        [(n, C.c_int) for n in ('enc_out_channels', 'num_slots', 'slot_size', 'slot_mlp_size',
+                                'num_iterations')] +
+        [('conv_w', FP * 8), ('conv_b', FP * 8), ('pos_table', FP)] +
+        [(n, FP) for n in ('enc_ln_g', 'enc_ln_b', 'enc_fc1_w', 'enc_fc1_b', 'enc_fc2_w', 'enc_fc2_b',
+                           'sa_norm_in_g', 'sa_norm_in_b', 'sa_q_ln_g', 'sa_q_ln_b', 'sa_q_w', 'sa_kv_w',
+                           'gru_w_ih', 'gru_w_hh', 'gru_b_ih', 'gru_b_hh',
+                           'mlp_ln_g', 'mlp_ln_b', 'mlp_w1', 'mlp_b1', 'mlp_w2', 'mlp_b2',
+                           'init_latents')] +
+        [('kd_mode', C.c_int)] +
+        [(n, FP) for n in ('kd_w0', 'kd_b0', 'kd_ln_g', 'kd_ln_b', 'kd_w3', 'kd_b3')] +
+        [(n, C.c_int) for n in ('pred_type', 'pred_rnn', 'pred_norm_first', 'pred_num_layers',
+                                'pred_num_heads', 'pred_ffn_dim', 'pred_hidden')] +
+        [(n, FP) for n in ('pm_ln_g', 'pm_ln_b', 'pm_w0', 'pm_b0', 'pm_w2', 'pm_b2')] +
+        [('pred_layers', C.POINTER(sf_tfm_layer))] +
+        [(n, FP) for n in ('lstm_w_ih', 'lstm_w_hh', 'lstm_b_ih', 'lstm_b_hh', 'proj_w', 'proj_b')] +
+        [('sa_eps', C.c_float)])
+
+
+I, LL, F32, SZ, VP = C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_void_p
+
+# name -> (restype, argtypes): exactly the declarations of include/slotformer_hip.h
+SIGNATURES = {
+    'sf_version': (I, []),
+    'sf_last_error_string': (C.c_char_p, []),
+    'sf_linear_f32': (I, [FP, I, FP, FP, FP, FP, F32, FP, I, FP, I, I, I, I, I, VP]),
+    'sf_layernorm_f32': (I, [FP, FP, FP, FP, I, I, F32, VP]),
+    'sf_conv2d_nchw_in_f32': (I, [FP, LL, FP, FP, FP, FP, I, I, I, I, I, I, I, I, VP]),
+    'sf_conv2d_nhwc_f32': (I, [FP, FP, FP, FP, FP, I, I, I, I, I, I, I, VP]),
+    'sf_pack_conv_weight_f32': (I, [FP, FP, I, I, I, VP]),
+    'sf_pos_embed_table_f32': (I, [FP, FP, FP, FP, I, I, VP]),
+    'sf_slot_attn_num_partials': (I, [I]),
+    'sf_slot_attn_iter_f32': (I, [FP, FP, I, LL, FP, FP, FP, FP, I, I, I, I, F32, F32, VP]),
+    'sf_slot_update_f32': (I, [FP, FP, I, FP] + [FP] * 10 + [FP, I, I, I, I, F32, VP]),
+    'sf_mha_f32': (I, [FP, FP, I, I, I, I, I, VP]),
+    'sf_lstm_pointwise_f32': (I, [FP, FP, FP, FP, I, I, VP]),
+    'sf_sample_dist_f32': (I, [FP, FP, FP, I, I, VP]),
+    'sf_bilinear_resize_f32': (I, [FP, FP, LL, I, I, I, I, VP]),
+    'sf_rollout_workspace_bytes': (SZ, [C.POINTER(sf_rollouter), I]),
+    'sf_rollout_f32': (I, [C.POINTER(sf_rollouter), FP, I, I, I, VP, SZ, VP]),
+    'sf_savi_encode_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I]),
+    'sf_savi_encode_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
+                               VP]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} not found: the HIP extension is not built. Run '
+                '`python -m slotformer_amd.build` (or __graft_entry__.build()). There is no fallback path.')
+        try:
+            h = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise RuntimeError(f'cannot load {LIB_PATH}: {e}') from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().sf_last_error_string().decode(errors='replace')
+        raise RuntimeError(f'libslotformer_hip: {msg}')

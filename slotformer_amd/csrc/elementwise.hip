@@ -1,0 +1,279 @@
+// Small fused kernels around the GEMM core: LayerNorm, multi-head self-attention for short
+// sequences (L <= ~128 tokens: rollout window / slot predictor), LSTM cell pointwise part,
+// stochastic-kernel sampling, row copies, weight packing, position-embedding table, bilinear
+// mask resize.  gfx950 only.
+#include "sf_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm over the last dim, one wave per row (nn.LayerNorm, biased variance).
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, SfRowMap xmap,
+                                                        const float* __restrict__ g,
+                                                        const float* __restrict__ b, float* __restrict__ y,
+                                                        SfRowMap ymap, int rows, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + sf_row_off(xmap, row);
+  float* yr = y + sf_row_off(ymap, row);
+  float s = 0.f;
+  for (int k = lane; k < D; k += 64) s += xr[k];
+  const float mean = sf_wave_sum(s) / (float)D;
+  float v = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const float d = xr[k] - mean;
+    v += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(sf_wave_sum(v) / (float)D + eps);
+  for (int k = lane; k < D; k += 64) yr[k] = (xr[k] - mean) * rstd * g[k] + b[k];
+}
+
+int sf_layernorm_ex(const float* x, SfRowMap xmap, const float* g, const float* b, float* y, SfRowMap ymap,
+                    int rows, int D, float eps, hipStream_t st) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, xmap, g, b, y, ymap, rows, D,
+                     eps);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Multi-head self-attention for short sequences (nn.MultiheadAttention, no mask, eval).
+// qkv: [B*L, 3d] packed (q|k|v), head h owns columns [h*HD, (h+1)*HD).  One workgroup per
+// (head, batch); K and V of the head live in LDS; one thread per query row; two-pass softmax
+// (max, then exp/sum) as torch computes it.  Queries may be restricted to the last Lq rows.
+template <int HD>
+__global__ __launch_bounds__(128) void mha_small_kernel(const float* __restrict__ qkv, int ld,
+                                                        float* __restrict__ out, int ldo, int L, int Lq,
+                                                        int d, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;            // [L][HD]
+  float* Vs = smem + L * HD;   // [L][HD]
+  const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const float* base = qkv + (long long)b * L * ld + h * HD;
+  for (int idx = t; idx < L * (HD / 4); idx += blockDim.x) {
+    const int j = idx / (HD / 4), c = idx - j * (HD / 4);
+    *(f32x4*)(Ks + j * HD + 4 * c) = *(const f32x4*)(base + (long long)j * ld + d + 4 * c);
+    *(f32x4*)(Vs + j * HD + 4 * c) = *(const f32x4*)(base + (long long)j * ld + 2 * d + 4 * c);
+  }
+  __syncthreads();
+  for (int iq = t; iq < Lq; iq += blockDim.x) {
+    const int i = L - Lq + iq;
+    float q[HD];
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+      const f32x4 v = *(const f32x4*)(base + (long long)i * ld + 4 * c);
+      q[4 * c] = v[0] * scale;
+      q[4 * c + 1] = v[1] * scale;
+      q[4 * c + 2] = v[2] * scale;
+      q[4 * c + 3] = v[3] * scale;
+    }
+    float mx = -INFINITY;
+    for (int j = 0; j < L; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) s = fmaf(q[c], Ks[j * HD + c], s);
+      mx = fmaxf(mx, s);
+    }
+    float acc[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) acc[c] = 0.f;
+    float sum = 0.f;
+    for (int j = 0; j < L; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) s = fmaf(q[c], Ks[j * HD + c], s);
+      const float p = expf(s - mx);
+      sum += p;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) acc[c] = fmaf(p, Vs[j * HD + c], acc[c]);
+    }
+    const float inv = 1.0f / sum;
+    float* o = out + ((long long)b * Lq + iq) * ldo + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+      f32x4 v = {acc[4 * c] * inv, acc[4 * c + 1] * inv, acc[4 * c + 2] * inv, acc[4 * c + 3] * inv};
+      *(f32x4*)(o + 4 * c) = v;
+    }
+  }
+}
+
+int sf_mha_ex(const float* qkv, float* out, int B, int L, int Lq, int d, int nheads, hipStream_t st) {
+  if (B <= 0 || L <= 0) return 0;
+  SF_REQUIRE(nheads > 0 && d % nheads == 0, "d_model must be divisible by num_heads");
+  const int hd = d / nheads;
+  SF_REQUIRE(hd == 16 || hd == 32 || hd == 48 || hd == 64, "head_dim must be 16/32/48/64");
+  SF_REQUIRE(Lq >= 1 && Lq <= L && L <= 512, "bad sequence length");
+  const float scale = 1.0f / sqrtf((float)hd);
+  const size_t lds = (size_t)2 * L * hd * sizeof(float);
+  SF_REQUIRE(lds <= 64 * 1024, "sequence too long for the short-sequence attention kernel");
+  dim3 grid(nheads, B), block(Lq <= 64 ? 64 : 128);
+#define MHA_LAUNCH(HD) \
+  hipLaunchKernelGGL(mha_small_kernel<HD>, grid, block, lds, st, qkv, 3 * d, out, d, L, Lq, d, scale)
+  switch (hd) {
+    case 16: MHA_LAUNCH(16); break;
+    case 32: MHA_LAUNCH(32); break;
+    case 48: MHA_LAUNCH(48); break;
+    default: MHA_LAUNCH(64); break;
+  }
+#undef MHA_LAUNCH
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// LSTM cell pointwise part (gate order i,f,g,o):  gates [R,4H] already = x W_ih^T + b_ih + h W_hh^T + b_hh
+__global__ void lstm_pointwise_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
+                                      float* __restrict__ h_out, float* __restrict__ c_out, int R, int H) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * H) return;
+  const int r = idx / H, j = idx - r * H;
+  const float* g = gates + (long long)r * 4 * H;
+  const float i = sf_sigmoid(g[j]), f = sf_sigmoid(g[H + j]), gg = tanhf(g[2 * H + j]), o = sf_sigmoid(g[3 * H + j]);
+  const float c = f * (c_prev ? c_prev[idx] : 0.f) + i * gg;
+  c_out[idx] = c;
+  h_out[idx] = o * tanhf(c);
+}
+
+int sf_lstm_pointwise_ex(const float* gates, const float* c_prev, float* h_out, float* c_out, int R, int H,
+                         hipStream_t st) {
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL(lstm_pointwise_kernel, dim3((R * H + 255) / 256), dim3(256), 0, st, gates, c_prev, h_out,
+                     c_out, R, H);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// kernels = mu (+ noise * exp(0.5 * logvar))  (savi.py:355-365); dist rows [R, 2D]; noise row map
+__global__ void sample_dist_kernel(const float* __restrict__ dist, const float* __restrict__ noise,
+                                   SfRowMap nmap, float* __restrict__ out, int R, int D) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * D) return;
+  const int r = idx / D, j = idx - r * D;
+  const float mu = dist[(long long)r * 2 * D + j];
+  float v = mu;
+  if (noise) v = mu + noise[sf_row_off(nmap, r) + j] * expf(dist[(long long)r * 2 * D + D + j] * 0.5f);
+  out[idx] = v;
+}
+
+int sf_sample_dist_ex(const float* dist, const float* noise, SfRowMap nmap, float* out, int R, int D,
+                      hipStream_t st) {
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL(sample_dist_kernel, dim3((R * D + 255) / 256), dim3(256), 0, st, dist, noise, nmap, out, R,
+                     D);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ void copy_rows_kernel(const float* __restrict__ src, SfRowMap smap, float* __restrict__ dst,
+                                 SfRowMap dmap, int rows, int cols) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  const int r = idx / cols, j = idx - r * cols;
+  dst[sf_row_off(dmap, r) + j] = src[sf_row_off(smap, r) + j];
+}
+
+int sf_copy_rows_ex(const float* src, SfRowMap smap, float* dst, SfRowMap dmap, int rows, int cols,
+                    hipStream_t st) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, st, src, smap, dst, dmap,
+                     rows, cols);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// [Cout][Cin][ks][ks] -> [Cout][ks][ks][Cin]
+__global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int ks) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = Cout * Cin * ks * ks;
+  if (idx >= total) return;
+  const int ci = idx % Cin, rem = idx / Cin, tap = rem % (ks * ks), co = rem / (ks * ks);
+  out[idx] = w[((long long)co * Cin + ci) * ks * ks + tap];
+}
+
+// table[p, c] = sum_j grid[p, j] * w[c, j] + b[c]      (SoftPositionEmbed, utils.py:52-63)
+__global__ void pos_table_kernel(const float* __restrict__ grid, const float* __restrict__ w,
+                                 const float* __restrict__ b, float* __restrict__ out, int HW, int C) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= HW * C) return;
+  const int p = idx / C, c = idx - p * C;
+  float acc = 0.f;
+  for (int j = 0; j < 4; ++j) acc = fmaf(grid[p * 4 + j], w[c * 4 + j], acc);
+  out[idx] = acc + b[c];
+}
+
+// F.interpolate(mode='bilinear', align_corners=False) of [R, Hi, Wi] planes to [R, Ho, Wo] (steve.py:230-238)
+__global__ void bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Hi, int Wi,
+                                int Ho, int Wo) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)R * Ho * Wo) return;
+  const int x = idx % Wo, y = (idx / Wo) % Ho;
+  const long long r = idx / ((long long)Wo * Ho);
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
+  fy = fy < 0.f ? 0.f : fy;
+  fx = fx < 0.f ? 0.f : fx;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+  const float* p = in + r * Hi * Wi;
+  out[idx] = hy * (hx * p[y0 * Wi + x0] + lx * p[y0 * Wi + x1]) + ly * (hx * p[y1 * Wi + x0] + lx * p[y1 * Wi + x1]);
+}
+
+extern "C" {
+
+int sf_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int rows, int D,
+                     float eps, void* stream) {
+  SF_REQUIRE(x && gamma && beta && y && rows >= 0 && D > 0, "bad layernorm arguments");
+  return sf_layernorm_ex(x, sf_rows(D), gamma, beta, y, sf_rows(D), rows, D, eps, (hipStream_t)stream);
+}
+
+int sf_mha_f32(const float* qkv, float* out, int B, int L, int Lq, int d_model, int num_heads, void* stream) {
+  SF_REQUIRE(qkv && out, "null pointer");
+  return sf_mha_ex(qkv, out, B, L, Lq, d_model, num_heads, (hipStream_t)stream);
+}
+
+int sf_lstm_pointwise_f32(const float* gates, const float* c_prev, float* h_out, float* c_out, int R, int H,
+                          void* stream) {
+  SF_REQUIRE(gates && h_out && c_out && R >= 0 && H > 0, "bad lstm arguments");
+  return sf_lstm_pointwise_ex(gates, c_prev, h_out, c_out, R, H, (hipStream_t)stream);
+}
+
+int sf_sample_dist_f32(const float* dist, const float* noise, float* out, int R, int D, void* stream) {
+  SF_REQUIRE(dist && out && R >= 0 && D > 0, "bad sample_dist arguments");
+  return sf_sample_dist_ex(dist, noise, sf_rows(D), out, R, D, (hipStream_t)stream);
+}
+
+int sf_pack_conv_weight_f32(const float* w_oihw, float* w_ohwi, int Cout, int Cin, int ks, void* stream) {
+  SF_REQUIRE(w_oihw && w_ohwi && Cout > 0 && Cin > 0 && ks > 0, "bad pack arguments");
+  const int total = Cout * Cin * ks * ks;
+  hipLaunchKernelGGL(pack_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                     w_ohwi, Cout, Cin, ks);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+int sf_pos_embed_table_f32(const float* grid, const float* dense_w, const float* dense_b, float* table, int HW,
+                           int C, void* stream) {
+  SF_REQUIRE(grid && dense_w && dense_b && table && HW > 0 && C > 0, "bad pos-embed arguments");
+  hipLaunchKernelGGL(pos_table_kernel, dim3((HW * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, grid,
+                     dense_w, dense_b, table, HW, C);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+int sf_bilinear_resize_f32(const float* in, float* out, long long R, int Hi, int Wi, int Ho, int Wo,
+                           void* stream) {
+  SF_REQUIRE(in && out && R >= 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "bad resize arguments");
+  const long long total = R * Ho * Wo;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     in, out, (int)R, Hi, Wi, Ho, Wo);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,387 @@
+// Whole-path engines: SAVi/STEVE slot extraction and SlotFormer autoregressive rollout.
+// Host-side C++ that sequences the HIP kernels on one stream (hipGraph-capturable: no
+// allocation, no synchronisation, no host<->device copies).
+//
+//   sf_savi_encode_f32 : StoSAVi.encode / STEVE.encode  (savi.py:379-416, steve.py:198-240)
+//   sf_rollout_f32     : SlotRollouter.forward / SingleStepSlotRollouter.forward
+//                        (slotformer.py:85-126, single_step_slotformer.py:49-90)
+//
+// The encoder works one time step at a time (all B frames of step t): CNN -> per-pixel MLP ->
+// K/V -> Slot-Attention iterations, so every intermediate of a step stays resident in the
+// 256 MB Infinity Cache and memory is O(1) in T (the reference's OOM-probing temporal chunking,
+// savi.py:431-463, is unnecessary; results are identical for any chunking).
+// The rollout keeps all slots in one [B, T_total, N, C] buffer: the Transformer window of step
+// s is a strided view of it (no torch.cat, slotformer.py:124), and predictions are written in
+// place by the out_proj GEMM epilogue.
+#include "../../include/slotformer_hip.h"
+#include "sf_internal.h"
+
+namespace {
+
+struct Bump {
+  char* p;
+  size_t left;
+  bool ok = true;
+  float* take(size_t nfloat) {
+    size_t bytes = ((nfloat * sizeof(float)) + 255) & ~(size_t)255;
+    if (bytes > left) {
+      ok = false;
+      return nullptr;
+    }
+    float* r = (float*)p;
+    p += bytes;
+    left -= bytes;
+    return r;
+  }
+};
+
+inline size_t pad256(size_t nfloat) { return ((nfloat * sizeof(float)) + 255) & ~(size_t)255; }
+
+struct TfmWs {
+  float *x2, *qkv, *att, *hid, *y;
+};
+
+size_t tfm_ws_bytes(int M, int d, int ffn) {
+  return pad256((size_t)M * d) * 3 + pad256((size_t)M * 3 * d) + pad256((size_t)M * ffn);
+}
+
+bool tfm_ws_take(Bump& bp, TfmWs& w, int M, int d, int ffn) {
+  w.x2 = bp.take((size_t)M * d);
+  w.qkv = bp.take((size_t)M * 3 * d);
+  w.att = bp.take((size_t)M * d);
+  w.hid = bp.take((size_t)M * ffn);
+  w.y = bp.take((size_t)M * d);
+  return bp.ok;
+}
+
+// One nn.TransformerEncoderLayer on x [B*L, d] (in place unless Lq < L).
+// Lq < L (norm_first only): only the last Lq rows of every sequence are produced, into ws.y
+// ([B*Lq, d]) -- used for the final layer of a rollout step, whose other rows are never read
+// (slotformer.py:121).  Returns the output pointer through *out.
+int tfm_layer(const sf_tfm_layer& w, float* x, TfmWs& ws, int B, int L, int Lq, int d, int heads, int ffn,
+              int norm_first, hipStream_t st, float** out) {
+  const int M = B * L, Mq = B * Lq;
+  const float eps = 1e-5f;
+  const SfRowMap rd = sf_rows(d);
+  if (norm_first) {
+    SF_TRY(sf_linear_ex(x, rd, w.in_proj_w, w.in_proj_b, w.norm1_g, w.norm1_b, eps, nullptr, rd, 0, ws.qkv,
+                        sf_rows(3 * d), M, 3 * d, d, 0, st));
+    SF_TRY(sf_mha_ex(ws.qkv, ws.att, B, L, Lq, d, heads, st));
+    // residual rows: last Lq rows of each sequence of x
+    const SfRowMap xr = (Lq == L) ? rd : sf_rows_batched(d, Lq, (long long)L * d, (long long)(L - Lq) * d);
+    SF_TRY(sf_linear_ex(ws.att, rd, w.out_proj_w, w.out_proj_b, nullptr, nullptr, eps, x, xr, 0, ws.x2, rd, Mq,
+                        d, d, 0, st));
+    SF_TRY(sf_linear_ex(ws.x2, rd, w.lin1_w, w.lin1_b, w.norm2_g, w.norm2_b, eps, nullptr, rd, 0, ws.hid,
+                        sf_rows(ffn), Mq, ffn, d, 1, st));
+    float* dst = (Lq == L) ? x : ws.y;
+    SF_TRY(sf_linear_ex(ws.hid, sf_rows(ffn), w.lin2_w, w.lin2_b, nullptr, nullptr, eps, ws.x2, rd, 0, dst, rd,
+                        Mq, d, ffn, 0, st));
+    *out = dst;
+  } else {
+    if (Lq != L) return sf_set_err(-1, "row pruning requires norm_first", __FILE__, __LINE__);
+    SF_TRY(sf_linear_ex(x, rd, w.in_proj_w, w.in_proj_b, nullptr, nullptr, eps, nullptr, rd, 0, ws.qkv,
+                        sf_rows(3 * d), M, 3 * d, d, 0, st));
+    SF_TRY(sf_mha_ex(ws.qkv, ws.att, B, L, L, d, heads, st));
+    SF_TRY(sf_linear_ex(ws.att, rd, w.out_proj_w, w.out_proj_b, nullptr, nullptr, eps, x, rd, 0, ws.y, rd, M, d,
+                        d, 0, st));
+    SF_TRY(sf_layernorm_ex(ws.y, rd, w.norm1_g, w.norm1_b, ws.x2, rd, M, d, eps, st));
+    SF_TRY(sf_linear_ex(ws.x2, rd, w.lin1_w, w.lin1_b, nullptr, nullptr, eps, nullptr, rd, 0, ws.hid,
+                        sf_rows(ffn), M, ffn, d, 1, st));
+    SF_TRY(sf_linear_ex(ws.hid, sf_rows(ffn), w.lin2_w, w.lin2_b, nullptr, nullptr, eps, ws.x2, rd, 0, ws.y, rd,
+                        M, d, ffn, 0, st));
+    SF_TRY(sf_layernorm_ex(ws.y, rd, w.norm2_g, w.norm2_b, x, rd, M, d, eps, st));
+    *out = x;
+  }
+  return 0;
+}
+
+int check_layers(const sf_tfm_layer* l, int n) {
+  if (n > 0 && !l) return -1;
+  for (int i = 0; i < n; ++i) {
+    const sf_tfm_layer& w = l[i];
+    if (!w.norm1_g || !w.norm1_b || !w.in_proj_w || !w.in_proj_b || !w.out_proj_w || !w.out_proj_b ||
+        !w.norm2_g || !w.norm2_b || !w.lin1_w || !w.lin1_b || !w.lin2_w || !w.lin2_b)
+      return -1;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------
+size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B) {
+  if (!m || B <= 0) return 0;
+  const int Lmax = m->window_len * m->num_slots;
+  const size_t M = (size_t)B * Lmax;
+  return pad256(M * m->d_model) + tfm_ws_bytes((int)M, m->d_model, m->ffn_dim) + 4096;
+}
+
+int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws,
+                   size_t ws_bytes, void* stream) {
+  SF_REQUIRE(m && slots && ws, "null pointer");
+  SF_REQUIRE(B >= 1 && pred_len >= 0, "bad batch / pred_len");
+  SF_REQUIRE(m->num_slots >= 1 && m->slot_size > 0 && (m->slot_size % 4) == 0 && m->d_model > 0 &&
+                 (m->d_model % 4) == 0 && m->ffn_dim > 0 && (m->ffn_dim % 4) == 0 && m->num_layers >= 1 &&
+                 m->window_len >= 1, "bad rollouter shape");
+  SF_REQUIRE(m->in_proj_w && m->in_proj_b && m->out_proj_w && m->out_proj_b && m->pe_tok, "null weight");
+  SF_REQUIRE(check_layers(m->layers, m->num_layers) == 0, "null transformer-layer weight");
+  const int n_in = m->single_step ? 1 : m->window_len;
+  SF_REQUIRE(T_total >= n_in + pred_len, "slots buffer shorter than burn-in + pred_len");
+  SF_REQUIRE(ws_bytes >= sf_rollout_workspace_bytes(m, B), "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int N = m->num_slots, C = m->slot_size, d = m->d_model, W = m->window_len;
+  const int Lmax = W * N;
+  Bump bp{(char*)ws, ws_bytes};
+  float* x = bp.take((size_t)B * Lmax * d);
+  TfmWs tw;
+  if (!x || !tfm_ws_take(bp, tw, B * Lmax, d, m->ffn_dim))
+    return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
+  const long long bs = (long long)T_total * N * C;
+  for (int s = 0; s < pred_len; ++s) {
+    int nf, f0;
+    if (!m->single_step) {
+      nf = W;
+      f0 = s;
+    } else {
+      const int have = s + 1;
+      nf = have < W ? have : W;
+      f0 = have - nf;
+    }
+    const int L = nf * N, M = B * L, pe_off = (W - nf) * N;
+    // x = in_proj(window) + pe   (slotformer.py:115-117; single_step_slotformer.py:79-81)
+    SfRowMap pmap = sf_rows(d);
+    pmap.base = (long long)pe_off * d;
+    SF_TRY(sf_linear_ex(slots, sf_rows_batched(C, L, bs, (long long)f0 * N * C), m->in_proj_w, m->in_proj_b,
+                        nullptr, nullptr, 0.f, m->pe_tok, pmap, L, x, sf_rows(d), M, d, C, 0, st));
+    float* cur = x;
+    int Lc = L;
+    for (int l = 0; l < m->num_layers; ++l) {
+      const bool last = (l == m->num_layers - 1);
+      const int Lq = (last && m->norm_first) ? N : Lc;
+      float* outp = nullptr;
+      SF_TRY(tfm_layer(m->layers[l], cur, tw, B, Lc, Lq, d, m->num_heads, m->ffn_dim, m->norm_first, st, &outp));
+      cur = outp;
+      Lc = Lq;
+    }
+    // pred = out_proj(x[:, -N:]) written straight into frame n_in + s   (slotformer.py:121-124)
+    const SfRowMap lastmap =
+        (Lc == N) ? sf_rows(d) : sf_rows_batched(d, N, (long long)Lc * d, (long long)(Lc - N) * d);
+    SF_TRY(sf_linear_ex(cur, lastmap, m->out_proj_w, m->out_proj_b, nullptr, nullptr, 0.f, nullptr, sf_rows(C), 0,
+                        slots, sf_rows_batched(C, N, bs, (long long)(n_in + s) * N * C), B * N, C, d, 0, st));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int enc_chunk(int B) { return B < 32 ? B : 32; }
+
+size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B) {
+  if (!m || B <= 0) return 0;
+  const size_t HW = 64 * 64;
+  int cmax = 0;
+  for (int i = 1; i <= m->enc_layers && i < 9; ++i) cmax = m->enc_channels[i] > cmax ? m->enc_channels[i] : cmax;
+  const int Bc = enc_chunk(B), N = m->num_slots, D = m->slot_size, Ce = m->enc_out_channels;
+  const int P = sf_sa_pick_partials((int)HW);
+  const int R = B * N;
+  const int hidp = m->pred_ffn_dim > 2 * D ? m->pred_ffn_dim : 2 * D;
+  size_t t = 0;
+  t += 2 * pad256((size_t)Bc * HW * cmax);
+  t += 2 * pad256((size_t)Bc * HW * Ce);
+  t += pad256((size_t)B * HW * 2 * D);
+  t += 6 * pad256((size_t)R * D) + 2 * pad256((size_t)R * 2 * D);
+  t += pad256((size_t)B * P * N * D) + pad256((size_t)B * P * N);
+  t += tfm_ws_bytes(R, D, hidp) + pad256((size_t)R * 4 * (m->pred_hidden > 0 ? m->pred_hidden : 1));
+  return t + 8192;
+}
+
+int sf_savi_encode_f32(const sf_savi_encoder* m, const float* img, const float* noise, const float* prev_slots,
+                       float* lstm_h, float* lstm_c, int state_valid, float* post_slots, float* kernel_dist,
+                       float* attn, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+  SF_REQUIRE(m && img && post_slots && ws, "null pointer");
+  SF_REQUIRE(B >= 1 && T >= 1, "bad batch / clip length");
+  SF_REQUIRE(m->resolution == 64 || m->resolution == 128, "resolution must be 64 or 128 (savi.py:226,236)");
+  SF_REQUIRE(m->enc_layers >= 1 && m->enc_layers <= 8 && m->enc_channels[0] > 0 && (m->enc_ks & 1), "bad CNN config");
+  SF_REQUIRE(m->num_slots >= 1 && m->num_slots <= 8 && m->num_iterations >= 1, "bad slot config");
+  SF_REQUIRE(m->pos_table && m->enc_ln_g && m->enc_ln_b && m->enc_fc1_w && m->enc_fc1_b && m->enc_fc2_w &&
+                 m->enc_fc2_b && m->sa_norm_in_g && m->sa_norm_in_b && m->sa_q_ln_g && m->sa_q_ln_b &&
+                 m->sa_q_w && m->sa_kv_w && m->init_latents, "null encoder weight");
+  SF_REQUIRE(m->kd_mode >= 0 && m->kd_mode <= 2, "bad kd_mode");
+  SF_REQUIRE(m->kd_mode == 0 || (m->kd_w0 && m->kd_b0), "null kernel_dist weight");
+  SF_REQUIRE(m->kd_mode != 2 || (m->kd_ln_g && m->kd_ln_b && m->kd_w3 && m->kd_b3), "null kernel_dist weight");
+  SF_REQUIRE(noise == nullptr || m->kd_mode != 0, "noise given but the model has no kernel_dist layer");
+  if (m->pred_type == 0)
+    SF_REQUIRE(m->pm_ln_g && m->pm_ln_b && m->pm_w0 && m->pm_b0 && m->pm_w2 && m->pm_b2, "null predictor weight");
+  else
+    SF_REQUIRE(check_layers(m->pred_layers, m->pred_num_layers) == 0, "null predictor weight");
+  if (m->pred_rnn)
+    SF_REQUIRE(lstm_h && lstm_c && m->pred_hidden > 0 && m->lstm_w_ih && m->lstm_w_hh && m->lstm_b_ih &&
+                   m->lstm_b_hh && m->proj_w && m->proj_b, "null LSTM state / weight");
+  SF_REQUIRE(ws_bytes >= sf_savi_encode_workspace_bytes(m, B), "workspace too small");
+  for (int i = 0; i < m->enc_layers; ++i) SF_REQUIRE(m->conv_w[i] != nullptr, "null conv weight");
+
+  hipStream_t st = (hipStream_t)stream;
+  const int HW = 64 * 64, res = m->resolution;
+  const int N = m->num_slots, D = m->slot_size, Ce = m->enc_out_channels, Hm = m->slot_mlp_size;
+  const int R = B * N, Bc = enc_chunk(B), P = sf_sa_pick_partials(HW);
+  int cmax = 0;
+  for (int i = 1; i <= m->enc_layers; ++i) cmax = m->enc_channels[i] > cmax ? m->enc_channels[i] : cmax;
+  const int hidp = m->pred_ffn_dim > 2 * D ? m->pred_ffn_dim : 2 * D;
+
+  Bump bp{(char*)ws, ws_bytes};
+  float* featA = bp.take((size_t)Bc * HW * cmax);
+  float* featB = bp.take((size_t)Bc * HW * cmax);
+  float* h1 = bp.take((size_t)Bc * HW * Ce);
+  float* h2 = bp.take((size_t)Bc * HW * Ce);
+  float* kv = bp.take((size_t)B * HW * 2 * D);
+  float* slotsA = bp.take((size_t)R * D);
+  float* slotsB = bp.take((size_t)R * D);
+  float* latents = bp.take((size_t)R * D);
+  float* q = bp.take((size_t)R * D);
+  float* lnbuf = bp.take((size_t)R * D);
+  float* px = bp.take((size_t)R * D);
+  float* kdist = bp.take((size_t)R * 2 * D);
+  float* kdtmp = bp.take((size_t)R * 2 * D);
+  float* pnum = bp.take((size_t)B * P * N * D);
+  float* pden = bp.take((size_t)B * P * N);
+  TfmWs tw;
+  bool ok = tfm_ws_take(bp, tw, R, D, hidp);
+  float* gates = bp.take((size_t)R * 4 * (m->pred_hidden > 0 ? m->pred_hidden : 1));
+  if (!ok || !bp.ok) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
+
+  const float* prev = prev_slots;
+  if (m->pred_rnn && (prev == nullptr || !state_valid)) {
+    // RNNPredictorWrapper.reset(): hidden_state = None -> zeros on first use (predictor.py:132-135)
+    hipError_t e1 = hipMemsetAsync(lstm_h, 0, (size_t)R * m->pred_hidden * sizeof(float), st);
+    hipError_t e2 = hipMemsetAsync(lstm_c, 0, (size_t)R * m->pred_hidden * sizeof(float), st);
+    if (e1 != hipSuccess || e2 != hipSuccess) return sf_set_err((int)(e1 != hipSuccess ? e1 : e2), "hipMemsetAsync failed", __FILE__, __LINE__);
+  }
+  const long long frame_elems = (long long)3 * res * res;
+  const float ln_eps = 1e-5f;
+
+  for (int t = 0; t < T; ++t) {
+    // ---- CNN encoder + per-pixel MLP + K/V for the B frames of step t ---------------------
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+      const int nb = (B - b0 < Bc) ? (B - b0) : Bc;
+      const float* src = img + ((long long)b0 * T + t) * frame_elems;
+      float* cur = featA;
+      float* nxt = featB;
+      for (int i = 0; i < m->enc_layers; ++i) {
+        const bool lastc = (i == m->enc_layers - 1);
+        const int cin = m->enc_channels[i], cout = m->enc_channels[i + 1];
+        const float* add = lastc ? m->pos_table : nullptr;
+        if (i == 0) {
+          SF_TRY(sf_conv2d_nchw_in_f32(src, (long long)T * frame_elems, m->conv_w[0], m->conv_b[0], add, cur, nb,
+                                       cin, res, res, cout, m->enc_ks, res == 128 ? 2 : 1, lastc ? 0 : 1, st));
+        } else {
+          SF_TRY(sf_conv2d_nhwc_f32(cur, m->conv_w[i], m->conv_b[i], add, nxt, nb, 64, 64, cin, cout, m->enc_ks,
+                                    lastc ? 0 : 1, st));
+          float* tmp = cur;
+          cur = nxt;
+          nxt = tmp;
+        }
+      }
+      const int Cl = m->enc_channels[m->enc_layers];
+      const int Mp = nb * HW;
+      // encoder_out_layer: LN -> Linear -> ReLU -> Linear  (savi.py:245-250)
+      SF_TRY(sf_linear_ex(cur, sf_rows(Cl), m->enc_fc1_w, m->enc_fc1_b, m->enc_ln_g, m->enc_ln_b, ln_eps, nullptr,
+                          sf_rows(Ce), 0, h1, sf_rows(Ce), Mp, Ce, Cl, 1, st));
+      SF_TRY(sf_linear_ex(h1, sf_rows(Ce), m->enc_fc2_w, m->enc_fc2_b, nullptr, nullptr, ln_eps, nullptr,
+                          sf_rows(Ce), 0, h2, sf_rows(Ce), Mp, Ce, Ce, 0, st));
+      // k|v = [Wk;Wv] LN(inputs)  (savi.py:66-70)
+      SF_TRY(sf_linear_ex(h2, sf_rows(Ce), m->sa_kv_w, nullptr, m->sa_norm_in_g, m->sa_norm_in_b, ln_eps, nullptr,
+                          sf_rows(2 * D), 0, kv + (long long)b0 * HW * 2 * D, sf_rows(2 * D), Mp, 2 * D, Ce, 0,
+                          st));
+    }
+    // ---- slot initialisation: init_latents or predictor(prev_slots)  (savi.py:393-398) ------
+    const float* lat;
+    if (prev == nullptr) {
+      SF_TRY(sf_copy_rows_ex(m->init_latents, sf_rows_batched(D, N, 0, 0), latents, sf_rows(D), R, D, st));
+      lat = latents;
+    } else {
+      const float* pout;
+      if (m->pred_type == 0) {
+        // ResidualMLPPredictor (predictor.py:65-73)
+        SF_TRY(sf_layernorm_ex(prev, sf_rows(D), m->pm_ln_g, m->pm_ln_b, lnbuf, sf_rows(D), R, D, ln_eps, st));
+        SF_TRY(sf_linear_ex(lnbuf, sf_rows(D), m->pm_w0, m->pm_b0, nullptr, nullptr, ln_eps, nullptr, sf_rows(D), 0,
+                            tw.hid, sf_rows(2 * D), R, 2 * D, D, 1, st));
+        SF_TRY(sf_linear_ex(tw.hid, sf_rows(2 * D), m->pm_w2, m->pm_b2, nullptr, nullptr, ln_eps,
+                            m->pred_norm_first ? lnbuf : prev, sf_rows(D), 0, px, sf_rows(D), R, D, 2 * D, 0, st));
+        pout = px;
+      } else {
+        // TransformerPredictor over the N slots (predictor.py:20-44)
+        SF_TRY(sf_copy_rows_ex(prev, sf_rows(D), px, sf_rows(D), R, D, st));
+        float* cur = px;
+        for (int l = 0; l < m->pred_num_layers; ++l) {
+          float* outp = nullptr;
+          SF_TRY(tfm_layer(m->pred_layers[l], cur, tw, B, N, N, D, m->pred_num_heads, m->pred_ffn_dim,
+                           m->pred_norm_first, st, &outp));
+          cur = outp;
+        }
+        pout = cur;
+      }
+      if (m->pred_rnn) {
+        // nn.LSTM, seq len 1, batch B*N (predictor.py:113-120)
+        const int Hh = m->pred_hidden;
+        SF_TRY(sf_linear_ex(pout, sf_rows(D), m->lstm_w_ih, m->lstm_b_ih, nullptr, nullptr, ln_eps, nullptr,
+                            sf_rows(4 * Hh), 0, gates, sf_rows(4 * Hh), R, 4 * Hh, D, 0, st));
+        SF_TRY(sf_linear_ex(lstm_h, sf_rows(Hh), m->lstm_w_hh, m->lstm_b_hh, nullptr, nullptr, ln_eps, gates,
+                            sf_rows(4 * Hh), 0, gates, sf_rows(4 * Hh), R, 4 * Hh, Hh, 0, st));
+        SF_TRY(sf_lstm_pointwise_ex(gates, lstm_c, lstm_h, lstm_c, R, Hh, st));
+        SF_TRY(sf_linear_ex(lstm_h, sf_rows(Hh), m->proj_w, m->proj_b, nullptr, nullptr, ln_eps, nullptr,
+                            sf_rows(D), 0, latents, sf_rows(D), R, D, Hh, 0, st));
+        lat = latents;
+      } else {
+        lat = pout;
+      }
+    }
+    // ---- kernel distribution + sampling (savi.py:401-402) --------------------------------------
+    float* s_in = slotsA;
+    float* s_out = slotsB;
+    if (m->kd_mode == 0) {
+      SF_TRY(sf_copy_rows_ex(lat, sf_rows(D), s_in, sf_rows(D), R, D, st));
+    } else {
+      if (m->kd_mode == 1) {
+        SF_TRY(sf_linear_ex(lat, sf_rows(D), m->kd_w0, m->kd_b0, nullptr, nullptr, ln_eps, nullptr, sf_rows(2 * D), 0,
+                            kdist, sf_rows(2 * D), R, 2 * D, D, 0, st));
+      } else {
+        SF_TRY(sf_linear_ex(lat, sf_rows(D), m->kd_w0, m->kd_b0, nullptr, nullptr, ln_eps, nullptr, sf_rows(2 * D), 0,
+                            kdtmp, sf_rows(2 * D), R, 2 * D, D, 0, st));
+        SF_TRY(sf_linear_ex(kdtmp, sf_rows(2 * D), m->kd_w3, m->kd_b3, m->kd_ln_g, m->kd_ln_b, ln_eps, nullptr,
+                            sf_rows(2 * D), 0, kdist, sf_rows(2 * D), R, 2 * D, 2 * D, 0, st, /*ln_relu=*/1));
+      }
+      const SfRowMap nmap = sf_rows_batched(D, N, (long long)T * N * D, (long long)t * N * D);
+      SF_TRY(sf_sample_dist_ex(kdist, noise, nmap, s_in, R, D, st));
+      if (kernel_dist)
+        SF_TRY(sf_copy_rows_ex(kdist, sf_rows(2 * D), kernel_dist,
+                               sf_rows_batched(2 * D, N, (long long)T * N * 2 * D, (long long)t * N * 2 * D), R,
+                               2 * D, st));
+    }
+    // ---- Slot Attention iterations (savi.py:76-100) -------------------------------------------
+    const float scale = 1.0f / sqrtf((float)D);
+    for (int it = 0; it < m->num_iterations; ++it) {
+      SF_TRY(sf_linear_ex(s_in, sf_rows(D), m->sa_q_w, nullptr, m->sa_q_ln_g, m->sa_q_ln_b, ln_eps, nullptr,
+                          sf_rows(D), 0, q, sf_rows(D), R, D, D, 0, st));
+      float* aout = (attn && it == m->num_iterations - 1) ? attn + (long long)t * N * HW : nullptr;
+      SF_TRY(sf_slot_attn_iter_ex(kv, kv + D, 2 * D, (long long)HW * 2 * D, q, pnum, pden, aout,
+                                  (long long)T * N * HW, B, HW, N, D, scale, m->sa_eps, st));
+      SF_TRY(sf_slot_update_f32(pnum, pden, P, s_in, m->gru_w_ih, m->gru_w_hh, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g,
+                                m->mlp_ln_b, m->mlp_w1, m->mlp_b1, m->mlp_w2, m->mlp_b2, s_out, B, N, D, Hm, ln_eps,
+                                st));
+      float* tmp = s_in;
+      s_in = s_out;
+      s_out = tmp;
+    }
+    // s_in now holds post_slots of step t
+    SF_TRY(sf_copy_rows_ex(s_in, sf_rows(D), post_slots,
+                           sf_rows_batched(D, N, (long long)T * N * D, (long long)t * N * D), R, D, st));
+    // prev_slots for the next step must not alias the ping-pong buffers that step overwrites:
+    // keep it in `lnbuf`-independent storage (q is rewritten first, so use latents' twin `px`?)
+    // -> simplest: the next step reads `prev` only before it writes slotsA/slotsB.
+    prev = s_in;
+  }
+  return 0;
+}
+
+}  // extern "C"

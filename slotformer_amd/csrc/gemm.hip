@@ -1,0 +1,420 @@
+// Fused f32 GEMM core for gfx950:  C = epi( LN?(A) . W^T + bias ) (+ residual)
+//
+//   * exact-f32 MFMA (v_mfma_f32_32x32x2_f32): bitwise an fmaf chain, 157 TF peak.
+//   * A [M,K] and W [N,K] are both K-contiguous (torch nn.Linear layout), so both
+//     operands are staged as rows x k into LDS and read back with ds_read_b128;
+//     the contraction index is permuted identically for A and B (k = 8*kb+4*h+s).
+//   * A-loaders: plain rows (with a batched row map), im2col over an NHWC feature
+//     map (5x5 conv as implicit GEMM) and im2col over the NCHW input image.
+//   * prologue: per-row LayerNorm over K; epilogue: bias, ReLU, residual (with an
+//     optional row modulo: position-embedding add), batched row map on C.
+//
+// Replaces the ATen/cuDNN call sites of SURVEY.md 2.3: conv2d (savi.py:230-240),
+// per-pixel MLP (savi.py:245-250, 372-375), K/V projection (savi.py:66-70) and
+// every nn.Linear of the rollout Transformer (slotformer.py:115-121).
+#include "sf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { ALOAD_PLAIN = 0, ALOAD_CONV_NHWC = 1, ALOAD_CONV_NCHW = 2 };
+
+struct SfGemmArgs {
+  const float* A;
+  SfRowMap amap;
+  const float* W;
+  int ldw;
+  const float* bias;
+  const float* ln_g;
+  const float* ln_b;
+  float ln_eps;
+  int ln_relu;
+  const float* res;
+  SfRowMap rmap;
+  int res_mod;
+  float* C;
+  SfRowMap cmap;
+  int M, N, K, relu;
+  // conv (im2col loaders): output cH x cW, input cInH x cInW, cCin channels, cKs taps, stride
+  int cH, cW, cInH, cInW, cCin, cKs, cStride;
+  long long cFrameStride;
+};
+
+template <int BM, int BN, int WM, int WN, int KW, int ALOAD, bool LN>
+__global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
+  constexpr int NT = 256;
+  static_assert(WM * WN * KW * 64 == NT, "4 waves");
+  constexpr int RM = BM / (32 * WM), RN = BN / (32 * WN);
+  constexpr int BKT = 32 * KW;
+  constexpr int LSTR = BKT + 4;
+  constexpr int C4N = BKT / 4;
+  constexpr int RS = NT / C4N;
+  constexpr int A_IT = BM * C4N / NT;
+  constexpr int B_IT = BN * C4N / NT;
+  constexpr int RS_SC = NT / BKT;
+  constexpr int A_SC = BM * BKT / NT;
+  constexpr int B_SC = BN * BKT / NT;
+  constexpr bool SCALAR = (ALOAD == ALOAD_CONV_NCHW);
+  static_assert(A_IT >= 1 && B_IT >= 1, "tile too small");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * BM * LSTR;
+  float* stats = Bs + 2 * BN * LSTR;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wk = wave % KW, wn = (wave / KW) % WN, wm = wave / (KW * WN);
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int M = p.M, N = p.N, K = p.K;
+
+  // ---- LayerNorm statistics for this tile's rows --------------------------------
+  if constexpr (LN) {
+    for (int r = wave; r < BM; r += NT / 64) {
+      const int m = m0 + r;
+      float mean = 0.f, rstd = 0.f;
+      if (m < M) {
+        const float* rowp = p.A + sf_row_off(p.amap, m);
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) s += rowp[k];
+        mean = sf_wave_sum(s) / (float)K;
+        float v = 0.f;
+        for (int k = lane; k < K; k += 64) {
+          const float d = rowp[k] - mean;
+          v += d * d;
+        }
+        rstd = 1.0f / sqrtf(sf_wave_sum(v) / (float)K + p.ln_eps);
+      }
+      if (lane == 0) {
+        stats[r] = mean;
+        stats[BM + r] = rstd;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- per-thread loader state ---------------------------------------------------
+  const int c4 = t % C4N, r0 = t / C4N;     // vector loader
+  const int kk = t % BKT, r0s = t / BKT;    // scalar loader
+  const float* arow[SCALAR ? 1 : A_IT];     // plain: row base (or null)
+  int cf[SCALAR ? A_SC : A_IT], cy[SCALAR ? A_SC : A_IT], cx[SCALAR ? A_SC : A_IT];
+  if constexpr (ALOAD == ALOAD_PLAIN) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int m = m0 + r0 + i * RS;
+      arow[i] = (m < M) ? p.A + sf_row_off(p.amap, m) : nullptr;
+    }
+  } else {
+    constexpr int NI = SCALAR ? A_SC : A_IT;
+    const int hw = p.cH * p.cW;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int m = m0 + (SCALAR ? (r0s + i * RS_SC) : (r0 + i * RS));
+      if (m < M) {
+        const int f = m / hw, rem = m - f * hw;
+        cf[i] = f;
+        cy[i] = rem / p.cW;
+        cx[i] = rem - cy[i] * p.cW;
+      } else {
+        cf[i] = 0;
+        cy[i] = -100000;
+        cx[i] = 0;
+      }
+    }
+  }
+  const float* wrow[SCALAR ? 1 : B_IT];
+  if constexpr (!SCALAR) {
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int n = n0 + r0 + i * RS;
+      wrow[i] = (n < N) ? p.W + (long long)n * p.ldw : nullptr;
+    }
+  }
+
+  f32x4 ra[SCALAR ? 1 : A_IT], rb[SCALAR ? 1 : B_IT];
+  float sa[SCALAR ? A_SC : 1], sb[SCALAR ? B_SC : 1];
+
+  auto load_tiles = [&](int kc) {
+    if constexpr (!SCALAR) {
+      const int k = kc * BKT + 4 * c4;
+      const bool kok = k < K;
+      if constexpr (ALOAD == ALOAD_PLAIN) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+          ra[i] = (kok && arow[i]) ? *(const f32x4*)(arow[i] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      } else {  // NHWC im2col: k = tap * Cin + cin
+        const int tap = k / p.cCin, cin = k - tap * p.cCin;
+        const int ky = tap / p.cKs, kx = tap - ky * p.cKs, pad = p.cKs >> 1;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+          const int yy = cy[i] + ky - pad, xx = cx[i] + kx - pad;
+          const bool ok = kok && (unsigned)yy < (unsigned)p.cInH && (unsigned)xx < (unsigned)p.cInW;
+          const float* src = p.A + (long long)cf[i] * p.cFrameStride +
+                             ((long long)(yy * p.cInW + xx) * p.cCin + cin);
+          ra[i] = ok ? *(const f32x4*)src : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        rb[i] = (kok && wrow[i]) ? *(const f32x4*)(wrow[i] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {  // NCHW image im2col, scalar: k = (c * ks + ky) * ks + kx
+      const int k = kc * BKT + kk;
+      const bool kok = k < K;
+      const int ks2 = p.cKs * p.cKs;
+      const int c = k / ks2, r = k - c * ks2;
+      const int ky = r / p.cKs, kx = r - ky * p.cKs, pad = p.cKs >> 1;
+#pragma unroll
+      for (int i = 0; i < A_SC; ++i) {
+        const int yy = cy[i] * p.cStride + ky - pad, xx = cx[i] * p.cStride + kx - pad;
+        const bool ok = kok && (unsigned)yy < (unsigned)p.cInH && (unsigned)xx < (unsigned)p.cInW;
+        const float* src = p.A + (long long)cf[i] * p.cFrameStride +
+                           ((long long)(c * p.cInH + yy) * p.cInW + xx);
+        sa[i] = ok ? *src : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < B_SC; ++i) {
+        const int n = n0 + r0s + i * RS_SC;
+        sb[i] = (kok && n < N) ? p.W[(long long)n * p.ldw + k] : 0.f;
+      }
+    }
+  };
+
+  auto store_tiles = [&](int buf, int kc) {
+    float* as = As + buf * BM * LSTR;
+    float* bs = Bs + buf * BN * LSTR;
+    if constexpr (!SCALAR) {
+      if constexpr (LN) {
+        const int k = kc * BKT + 4 * c4;
+        if (k < K) {
+          const f32x4 g = *(const f32x4*)(p.ln_g + k);
+          const f32x4 b = *(const f32x4*)(p.ln_b + k);
+#pragma unroll
+          for (int i = 0; i < A_IT; ++i) {
+            const int r = r0 + i * RS;
+            const float mean = stats[r], rstd = stats[BM + r];
+            ra[i] = (ra[i] - mean) * rstd * g + b;
+            if (p.ln_relu) {
+              ra[i][0] = fmaxf(ra[i][0], 0.f);
+              ra[i][1] = fmaxf(ra[i][1], 0.f);
+              ra[i][2] = fmaxf(ra[i][2], 0.f);
+              ra[i][3] = fmaxf(ra[i][3], 0.f);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) *(f32x4*)(as + (r0 + i * RS) * LSTR + 4 * c4) = ra[i];
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) *(f32x4*)(bs + (r0 + i * RS) * LSTR + 4 * c4) = rb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_SC; ++i) as[(r0s + i * RS_SC) * LSTR + kk] = sa[i];
+#pragma unroll
+      for (int i = 0; i < B_SC; ++i) bs[(r0s + i * RS_SC) * LSTR + kk] = sb[i];
+    }
+  };
+
+  // ---- main loop -------------------------------------------------------------------
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (K + BKT - 1) / BKT;
+  load_tiles(0);
+  store_tiles(0, 0);
+  __syncthreads();
+  const int a_off = (wm * RM * 32 + (lane & 31)) * LSTR + wk * 32 + 4 * (lane >> 5);
+  const int b_off = (wn * RN * 32 + (lane & 31)) * LSTR + wk * 32 + 4 * (lane >> 5);
+  for (int kc = 0; kc < nk; ++kc) {
+    const bool has_next = kc + 1 < nk;
+    if (has_next) load_tiles(kc + 1);
+    const float* as = As + (kc & 1) * BM * LSTR + a_off;
+    const float* bs = Bs + (kc & 1) * BN * LSTR + b_off;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      f32x4 a[RM], b[RN];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) a[i] = *(const f32x4*)(as + i * 32 * LSTR + kb * 8);
+#pragma unroll
+      for (int j = 0; j < RN; ++j) b[j] = *(const f32x4*)(bs + j * 32 * LSTR + kb * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int j = 0; j < RN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (has_next) store_tiles((kc + 1) & 1, kc + 1);
+    __syncthreads();
+  }
+
+  // ---- split-K (across waves) reduction through LDS ------------------------------------
+  if constexpr (KW > 1) {
+    float* red = smem;  // [(KW-1)][WM*WN][RM*RN*16][64]
+    if (wk > 0) {
+      float* dst = red + ((long long)((wk - 1) * WM * WN + wm * WN + wn) * RM * RN * 16) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((i * RN + j) * 16 + r) * 64] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int q = 0; q < KW - 1; ++q) {
+      const float* src = red + ((long long)(q * WM * WN + wm * WN + wn) * RM * RN * 16) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += src[((i * RN + j) * 16 + r) * 64];
+    }
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < RN; ++j) {
+    const int col = n0 + (wn * RN + j) * 32 + (lane & 31);
+    if (col >= N) continue;
+    const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < RM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * RM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= M) continue;
+        float v = acc[i][j][r] + bias;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.res) {
+          const int rr = p.res_mod > 0 ? row % p.res_mod : row;
+          v += p.res[sf_row_off(p.rmap, rr) + col];
+        }
+        p.C[sf_row_off(p.cmap, row) + col] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int KW, int ALOAD, bool LN>
+static int launch_cfg(const SfGemmArgs& a, hipStream_t stream) {
+  constexpr int BKT = 32 * KW, LSTR = BKT + 4;
+  constexpr size_t lds = (size_t)(2 * (BM + BN) * LSTR + 2 * BM) * sizeof(float);
+  auto kern = sf_gemm_kernel<BM, BN, WM, WN, KW, ALOAD, LN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    attr_set = true;
+  }
+  dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int ALOAD, bool LN>
+static int dispatch_tiles(const SfGemmArgs& a, hipStream_t stream) {
+  auto tiles = [&](int bm, int bn) {
+    return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
+  };
+  if constexpr (ALOAD != ALOAD_PLAIN) {
+    return launch_cfg<128, 64, 4, 1, 1, ALOAD, false>(a, stream);
+  } else {
+    if (a.N > 64 && tiles(128, 128) >= 384) return launch_cfg<128, 128, 2, 2, 1, ALOAD, LN>(a, stream);
+    if (tiles(128, 64) >= 384) return launch_cfg<128, 64, 4, 1, 1, ALOAD, LN>(a, stream);
+    if (tiles(64, 64) >= 192) return launch_cfg<64, 64, 2, 2, 1, ALOAD, LN>(a, stream);
+    if (a.K >= 512 || tiles(32, 64) < 128) return launch_cfg<32, 32, 1, 1, 4, ALOAD, LN>(a, stream);
+    return launch_cfg<32, 64, 1, 2, 2, ALOAD, LN>(a, stream);
+  }
+}
+
+int sf_gemm_dispatch(const SfGemmArgs& a, int aload, hipStream_t stream) {
+  if (a.M <= 0 || a.N <= 0) return 0;
+  const bool ln = a.ln_g != nullptr;
+  if (aload == ALOAD_PLAIN) return ln ? dispatch_tiles<ALOAD_PLAIN, true>(a, stream)
+                                      : dispatch_tiles<ALOAD_PLAIN, false>(a, stream);
+  if (aload == ALOAD_CONV_NHWC) return dispatch_tiles<ALOAD_CONV_NHWC, false>(a, stream);
+  return dispatch_tiles<ALOAD_CONV_NCHW, false>(a, stream);
+}
+
+// internal C++ helper used by the engine
+int sf_linear_ex(const float* A, SfRowMap amap, const float* W, const float* bias, const float* ln_g,
+                 const float* ln_b, float ln_eps, const float* res, SfRowMap rmap, int res_mod,
+                 float* C, SfRowMap cmap, int M, int N, int K, int relu, hipStream_t stream, int ln_relu) {
+  SfGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.amap = amap; a.W = W; a.ldw = K; a.bias = bias;
+  a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = ln_eps; a.ln_relu = ln_relu;
+  a.res = res; a.rmap = rmap; a.res_mod = res_mod;
+  a.C = C; a.cmap = cmap; a.M = M; a.N = N; a.K = K; a.relu = relu;
+  return sf_gemm_dispatch(a, ALOAD_PLAIN, stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int sf_linear_f32(const float* A, int lda, const float* W, const float* bias, const float* ln_gamma,
+                  const float* ln_beta, float ln_eps, const float* residual, int ldr, float* C, int ldc,
+                  int M, int N, int K, int relu, void* stream) {
+  SF_REQUIRE(A && W && C, "null pointer");
+  SF_REQUIRE(M >= 0 && N > 0 && K > 0 && (K % 4) == 0, "K must be a positive multiple of 4");
+  SF_REQUIRE(lda >= K && ldc >= N && (lda % 4) == 0, "bad leading dimension");
+  SF_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "ln_gamma/ln_beta must come together");
+  SF_REQUIRE(residual == nullptr || ldr >= N, "bad residual leading dimension");
+  return sf_linear_ex(A, sf_rows(lda), W, bias, ln_gamma, ln_beta, ln_eps, residual, sf_rows(ldr), 0, C,
+                      sf_rows(ldc), M, N, K, relu, (hipStream_t)stream, 0);
+}
+
+// 5x5 (ks x ks) conv, stride 1, "same" padding, NHWC in -> NHWC out, Cin multiple of 4.
+// w_packed: [Cout][ks][ks][Cin]  (= torch weight.permute(0,2,3,1)); add: optional [H*W][Cout] table
+// added after the activation (soft position embedding, utils.py:60-63).
+int sf_conv2d_nhwc_f32(const float* in, const float* w_packed, const float* bias, const float* add,
+                       float* out, int F, int H, int W, int Cin, int Cout, int ks, int relu,
+                       void* stream) {
+  SF_REQUIRE(in && w_packed && out, "null pointer");
+  SF_REQUIRE(F >= 0 && H > 0 && W > 0 && Cin > 0 && (Cin % 4) == 0 && Cout > 0 && (ks & 1), "bad conv shape");
+  SfGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = in; a.W = w_packed; a.ldw = ks * ks * Cin; a.bias = bias;
+  a.res = add; a.rmap = sf_rows(Cout); a.res_mod = H * W;
+  a.C = out; a.cmap = sf_rows(Cout);
+  a.M = F * H * W; a.N = Cout; a.K = ks * ks * Cin; a.relu = relu;
+  a.cH = H; a.cW = W; a.cInH = H; a.cInW = W; a.cCin = Cin; a.cKs = ks; a.cStride = 1;
+  a.cFrameStride = (long long)H * W * Cin;
+  return sf_gemm_dispatch(a, ALOAD_CONV_NHWC, (hipStream_t)stream);
+}
+
+// first conv: NCHW image (frame f at img + f*frame_stride floats) -> NHWC, "same" padding k//2.
+// weight: torch layout [Cout][Cin][ks][ks].
+int sf_conv2d_nchw_in_f32(const float* img, long long frame_stride, const float* weight,
+                          const float* bias, const float* add, float* out, int F, int Cin, int Hin,
+                          int Win, int Cout, int ks, int stride, int relu, void* stream) {
+  SF_REQUIRE(img && weight && out, "null pointer");
+  SF_REQUIRE(F >= 0 && Cin > 0 && Hin > 0 && Win > 0 && Cout > 0 && (ks & 1) && stride >= 1, "bad conv shape");
+  const int pad = ks / 2;
+  const int Ho = (Hin + 2 * pad - ks) / stride + 1, Wo = (Win + 2 * pad - ks) / stride + 1;
+  SfGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = img; a.W = weight; a.ldw = Cin * ks * ks; a.bias = bias;
+  a.res = add; a.rmap = sf_rows(Cout); a.res_mod = Ho * Wo;
+  a.C = out; a.cmap = sf_rows(Cout);
+  a.M = F * Ho * Wo; a.N = Cout; a.K = Cin * ks * ks; a.relu = relu;
+  a.cH = Ho; a.cW = Wo; a.cInH = Hin; a.cInW = Win; a.cCin = Cin; a.cKs = ks; a.cStride = stride;
+  a.cFrameStride = frame_stride;
+  return sf_gemm_dispatch(a, ALOAD_CONV_NCHW, (hipStream_t)stream);
+}
+
+}  // extern "C"

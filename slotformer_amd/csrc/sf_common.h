@@ -1,0 +1,67 @@
+// Shared helpers for the slotformer_amd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define SF_WAVE 64
+
+extern thread_local char sf_err_buf[512];
+
+static inline int sf_set_err(int code, const char* msg, const char* file, int line) {
+  snprintf(sf_err_buf, sizeof(sf_err_buf), "%s (%s:%d, code %d)", msg, file, line, code);
+  return code;
+}
+
+// argument errors are negative, hipError_t values positive.
+#define SF_REQUIRE(cond, msg)                                             \
+  do {                                                                    \
+    if (!(cond)) return sf_set_err(-1, "invalid argument: " msg, __FILE__, __LINE__); \
+  } while (0)
+
+#define SF_CHECK_LAUNCH()                                                 \
+  do {                                                                    \
+    hipError_t e_ = hipGetLastError();                                    \
+    if (e_ != hipSuccess) return sf_set_err((int)e_, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+#define SF_TRY(expr)                \
+  do {                              \
+    int rc_ = (expr);               \
+    if (rc_ != 0) return rc_;       \
+  } while (0)
+
+// row m of a logical [M, *] matrix -> element offset.  rows_per_batch <= 0: m * ld.
+struct SfRowMap {
+  long long batch_stride;
+  int rows_per_batch;
+  int ld;
+  long long base;  // element offset added to every row
+};
+
+static inline SfRowMap sf_rows(int ld) { return SfRowMap{0, 0, ld, 0}; }
+static inline SfRowMap sf_rows_batched(int ld, int rows_per_batch, long long batch_stride,
+                                       long long base = 0) {
+  return SfRowMap{batch_stride, rows_per_batch, ld, base};
+}
+
+__device__ __forceinline__ long long sf_row_off(const SfRowMap& m, int row) {
+  if (m.rows_per_batch <= 0) return m.base + (long long)row * m.ld;
+  int b = row / m.rows_per_batch;
+  int r = row - b * m.rows_per_batch;
+  return m.base + (long long)b * m.batch_stride + (long long)r * m.ld;
+}
+
+__device__ __forceinline__ float sf_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float sf_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float sf_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

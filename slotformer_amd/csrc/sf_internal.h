@@ -1,0 +1,20 @@
+// Internal C++ entry points shared between the translation units of libslotformer_hip.so.
+#pragma once
+#include "sf_common.h"
+
+int sf_linear_ex(const float* A, SfRowMap amap, const float* W, const float* bias, const float* ln_g,
+                 const float* ln_b, float ln_eps, const float* res, SfRowMap rmap, int res_mod,
+                 float* C, SfRowMap cmap, int M, int N, int K, int relu, hipStream_t stream, int ln_relu = 0);
+int sf_layernorm_ex(const float* x, SfRowMap xmap, const float* g, const float* b, float* y, SfRowMap ymap,
+                    int rows, int D, float eps, hipStream_t st);
+int sf_mha_ex(const float* qkv, float* out, int B, int L, int Lq, int d, int nheads, hipStream_t st);
+int sf_lstm_pointwise_ex(const float* gates, const float* c_prev, float* h_out, float* c_out, int R, int H,
+                         hipStream_t st);
+int sf_sample_dist_ex(const float* dist, const float* noise, SfRowMap nmap, float* out, int R, int D,
+                      hipStream_t st);
+int sf_copy_rows_ex(const float* src, SfRowMap smap, float* dst, SfRowMap dmap, int rows, int cols,
+                    hipStream_t st);
+int sf_sa_pick_partials(int HW);
+int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch_stride, const float* q,
+                         float* part_num, float* part_den, float* attn_out, long long attn_batch_stride, int B,
+                         int HW, int N, int D, float scale, float eps, hipStream_t st);

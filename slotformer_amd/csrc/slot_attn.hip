@@ -1,0 +1,292 @@
+// Slot Attention iteration for gfx950 (savi.py:76-100 / steve.py:44-71).
+//
+// Kernel 1 (HBM-bound): one pass over K and V.  For every pixel: logits over the N slots,
+// softmax over slots, +eps, and accumulation of  num[n,:] += a_n * v  and  den[n] += a_n.
+// The reference's renormalisation over pixels (attn / attn.sum(dim=1)) followed by the
+// weighted mean is algebraically  updates[n,:] = num[n,:] / den[n],  so a single pass with
+// per-workgroup partials suffices.  One wave owns one pixel per step: the 64 lanes hold the
+// D channels (D/64 consecutive floats per lane, fully coalesced 512/768 B rows), the slot
+// queries live in registers, the per-pixel softmax is wave-uniform.
+//
+// Kernel 2 (fused wavefront slot update): reduce the partials, GRUCell (gate order r,z,n),
+// residual LayerNorm-MLP.  One workgroup per (batch, slot) row; each output feature is one
+// wave-wide dot product against a row of the torch-layout weight matrix.
+#include "sf_internal.h"
+
+#define SA_NMAX 8
+#define SA_DMAX 256
+#define SA_HMAX 512
+
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// full 64-lane sum, result in every lane
+__device__ __forceinline__ float wave_allsum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+template <int VPT>
+__global__ __launch_bounds__(256) void sa_attn_partial_kernel(
+    const float* __restrict__ k, const float* __restrict__ v, int ld, long long batch_stride,
+    const float* __restrict__ q, float scale, float eps, float* __restrict__ part_num,
+    float* __restrict__ part_den, float* __restrict__ attn_out, long long attn_bs, int HW, int N,
+    int P) {
+  constexpr int D = 64 * VPT;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pix_per_wg = HW / P, pix_per_wave = pix_per_wg / 4;
+  const int pix0 = chunk * pix_per_wg + wave * pix_per_wave;
+
+  float qr[SA_NMAX][VPT], num[SA_NMAX][VPT], den[SA_NMAX];
+#pragma unroll
+  for (int n = 0; n < SA_NMAX; ++n) {
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      qr[n][j] = (n < N) ? q[((long long)b * N + n) * D + lane * VPT + j] * scale : 0.f;
+      num[n][j] = 0.f;
+    }
+    den[n] = 0.f;
+  }
+  const float* kb = k + (long long)b * batch_stride + lane * VPT;
+  const float* vb = v + (long long)b * batch_stride + lane * VPT;
+
+  __shared__ float s_attn[4][SA_NMAX][64];  // attn staging for coalesced mask rows
+  __shared__ float s_red[4][SA_NMAX][D + 1];
+
+  constexpr int U = 4;
+  for (int p0 = 0; p0 < pix_per_wave; p0 += U) {
+    float kx[U][VPT], vx[U][VPT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long off = (long long)(pix0 + p0 + u) * ld;
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) {
+        kx[u][j] = kb[off + j];
+        vx[u][j] = vb[off + j];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float s[SA_NMAX];
+#pragma unroll
+      for (int n = 0; n < SA_NMAX; ++n) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) acc = fmaf(kx[u][j], qr[n][j], acc);
+        s[n] = acc;
+      }
+#pragma unroll
+      for (int n = 0; n < SA_NMAX; ++n)
+        if (n < N) s[n] = wave_allsum(s[n]);
+      float mx = s[0];
+#pragma unroll
+      for (int n = 1; n < SA_NMAX; ++n)
+        if (n < N) mx = fmaxf(mx, s[n]);
+      float sum = 0.f;
+#pragma unroll
+      for (int n = 0; n < SA_NMAX; ++n) {
+        s[n] = (n < N) ? expf(s[n] - mx) : 0.f;
+        sum += s[n];
+      }
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int n = 0; n < SA_NMAX; ++n) {
+        if (n < N) {
+          const float a0 = s[n] * inv;
+          if (attn_out) {
+            if (lane == ((p0 + u) & 63)) s_attn[wave][n][(p0 + u) & 63] = a0;
+          }
+          const float a = a0 + eps;
+          den[n] += a;
+#pragma unroll
+          for (int j = 0; j < VPT; ++j) num[n][j] = fmaf(a, vx[u][j], num[n][j]);
+        }
+      }
+    }
+    if (attn_out && (((p0 + U) & 63) == 0 || p0 + U >= pix_per_wave)) {
+      // flush up to 64 pixels of attention: rows of [B, N, HW]
+      __builtin_amdgcn_wave_barrier();
+      const int base = (p0 + U - 1) & ~63;
+      const int cnt = p0 + U - base;
+      for (int n = 0; n < N; ++n)
+        if (lane < cnt) attn_out[(long long)b * attn_bs + (long long)n * HW + pix0 + base + lane] = s_attn[wave][n][lane];
+    }
+  }
+
+  // cross-wave reduction, then one partial per workgroup
+#pragma unroll
+  for (int n = 0; n < SA_NMAX; ++n) {
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) s_red[wave][n][lane * VPT + j] = num[n][j];
+    if (lane == 0) s_red[wave][n][D] = den[n];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < N * (D + 1); idx += 256) {
+    const int n = idx / (D + 1), d = idx - n * (D + 1);
+    const float t = s_red[0][n][d] + s_red[1][n][d] + s_red[2][n][d] + s_red[3][n][d];
+    if (d < D)
+      part_num[(((long long)b * P + chunk) * N + n) * D + d] = t;
+    else
+      part_den[((long long)b * P + chunk) * N + n] = t;
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// wave-wide dot product of a weight row with an LDS vector
+__device__ __forceinline__ float wave_dot(const float* __restrict__ w, const float* x, int K, int lane) {
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc = fmaf(w[k], x[k], acc);
+  return sf_wave_sum(acc);
+}
+
+__global__ __launch_bounds__(256) void sa_slot_update_kernel(
+    const float* __restrict__ part_num, const float* __restrict__ part_den, int P,
+    const float* __restrict__ slots_prev, const float* __restrict__ w_ih,
+    const float* __restrict__ w_hh, const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+    const float* __restrict__ ln_g, const float* __restrict__ ln_b, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+    float* __restrict__ slots_out, int N, int D, int H, float ln_eps) {
+  const int row = blockIdx.x;  // b * N + n
+  const int b = row / N, n = row - b * N;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  __shared__ float s_u[SA_DMAX], s_h[SA_DMAX], s_gi[3 * SA_DMAX], s_gh[3 * SA_DMAX];
+  __shared__ float s_hn[SA_DMAX], s_ln[SA_DMAX], s_hid[SA_HMAX], s_stat[2];
+
+  // updates = sum_p num / sum_p den
+  float den = 0.f;
+  for (int p = 0; p < P; ++p) den += part_den[((long long)b * P + p) * N + n];
+  for (int d = t; d < D; d += 256) {
+    float a = 0.f;
+    for (int p = 0; p < P; ++p) a += part_num[(((long long)b * P + p) * N + n) * D + d];
+    s_u[d] = a / den;
+    s_h[d] = slots_prev[(long long)row * D + d];
+  }
+  __syncthreads();
+  // GRU gate pre-activations
+  for (int j = wave; j < 3 * D; j += 4) {
+    const float gi = wave_dot(w_ih + (long long)j * D, s_u, D, lane);
+    const float gh = wave_dot(w_hh + (long long)j * D, s_h, D, lane);
+    if (lane == 0) {
+      s_gi[j] = gi + b_ih[j];
+      s_gh[j] = gh + b_hh[j];
+    }
+  }
+  __syncthreads();
+  for (int d = t; d < D; d += 256) {
+    const float r = sf_sigmoid(s_gi[d] + s_gh[d]);
+    const float z = sf_sigmoid(s_gi[D + d] + s_gh[D + d]);
+    const float nn = tanhf(s_gi[2 * D + d] + r * s_gh[2 * D + d]);
+    s_hn[d] = (1.f - z) * nn + z * s_h[d];
+  }
+  __syncthreads();
+  // LayerNorm(h')
+  if (wave == 0) {
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += s_hn[d];
+    const float mean = sf_wave_sum(s) / (float)D;
+    float vv = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      const float c = s_hn[d] - mean;
+      vv += c * c;
+    }
+    const float rstd = 1.0f / sqrtf(sf_wave_sum(vv) / (float)D + ln_eps);
+    if (lane == 0) {
+      s_stat[0] = mean;
+      s_stat[1] = rstd;
+    }
+  }
+  __syncthreads();
+  for (int d = t; d < D; d += 256) s_ln[d] = (s_hn[d] - s_stat[0]) * s_stat[1] * ln_g[d] + ln_b[d];
+  __syncthreads();
+  for (int j = wave; j < H; j += 4) {
+    const float a = wave_dot(w1 + (long long)j * D, s_ln, D, lane);
+    if (lane == 0) s_hid[j] = fmaxf(a + b1[j], 0.f);
+  }
+  __syncthreads();
+  for (int j = wave; j < D; j += 4) {
+    const float a = wave_dot(w2 + (long long)j * H, s_hid, H, lane);
+    if (lane == 0) slots_out[(long long)row * D + j] = s_hn[j] + a + b2[j];
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+int sf_sa_pick_partials(int HW) {
+  // pixels per workgroup: 4 waves x (multiple of 4) pixels; keep >= 128 pixels per workgroup
+  int P = HW / 128;
+  while (P > 1 && (HW % P != 0 || (HW / P) % 16 != 0)) --P;
+  if (P < 1) P = 1;
+  return P;
+}
+
+extern "C" {
+
+// number of per-(batch) partial records the iteration kernel emits for HW keys
+int sf_slot_attn_num_partials(int HW) { return sf_sa_pick_partials(HW); }
+
+// One Slot-Attention iteration, attention half (savi.py:82-89).
+//   k, v     : [B, HW, D] rows with leading dimension ld floats and batch_stride floats per batch
+//   q        : [B, N, D] unscaled queries (project_q output); scale = D^-0.5 applied inside
+//   part_num : [B, P, N, D], part_den: [B, P, N]  (P = sf_slot_attn_num_partials(HW))
+//   attn_out : optional [B, N, HW] softmax-over-slots attention (STEVE seg mask, steve.py:54-55)
+int sf_slot_attn_iter_f32(const float* k, const float* v, int ld, long long batch_stride, const float* q,
+                          float* part_num, float* part_den, float* attn_out, int B, int HW, int N, int D,
+                          float scale, float eps, void* stream) {
+  return sf_slot_attn_iter_ex(k, v, ld, batch_stride, q, part_num, part_den, attn_out, (long long)N * HW, B, HW,
+                              N, D, scale, eps, (hipStream_t)stream);
+}
+}  // extern "C"
+
+int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch_stride, const float* q,
+                         float* part_num, float* part_den, float* attn_out, long long attn_batch_stride, int B,
+                         int HW, int N, int D, float scale, float eps, hipStream_t st) {
+  SF_REQUIRE(k && v && q && part_num && part_den, "null pointer");
+  SF_REQUIRE(B >= 0 && HW > 0 && N >= 1 && N <= SA_NMAX, "need 1 <= num_slots <= 8");
+  SF_REQUIRE(D == 64 || D == 128 || D == 192 || D == 256, "slot_size must be 64/128/192/256");
+  SF_REQUIRE(ld >= D, "bad leading dimension");
+  const int P = sf_sa_pick_partials(HW);
+  SF_REQUIRE((HW % P) == 0 && ((HW / P) % 16) == 0, "HW must be a multiple of 16");
+  if (B == 0) return 0;
+  dim3 grid(P, B), block(256);
+#define SA_LAUNCH(VPT)                                                                            \
+  hipLaunchKernelGGL(sa_attn_partial_kernel<VPT>, grid, block, 0, st, k, v, ld, batch_stride, q, \
+                     scale, eps, part_num, part_den, attn_out, attn_batch_stride, HW, N, P)
+  switch (D / 64) {
+    case 1: SA_LAUNCH(1); break;
+    case 2: SA_LAUNCH(2); break;
+    case 3: SA_LAUNCH(3); break;
+    default: SA_LAUNCH(4); break;
+  }
+#undef SA_LAUNCH
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" {
+// Slot update (savi.py:95-100): reduce partials -> GRUCell -> slots + MLP(LN(slots)).
+int sf_slot_update_f32(const float* part_num, const float* part_den, int P, const float* slots_prev,
+                       const float* gru_w_ih, const float* gru_w_hh, const float* gru_b_ih,
+                       const float* gru_b_hh, const float* ln_g, const float* ln_b, const float* mlp_w1,
+                       const float* mlp_b1, const float* mlp_w2, const float* mlp_b2, float* slots_out,
+                       int B, int N, int D, int H, float ln_eps, void* stream) {
+  SF_REQUIRE(part_num && part_den && slots_prev && slots_out, "null pointer");
+  SF_REQUIRE(gru_w_ih && gru_w_hh && gru_b_ih && gru_b_hh && ln_g && ln_b && mlp_w1 && mlp_b1 && mlp_w2 &&
+                 mlp_b2, "null weight pointer");
+  SF_REQUIRE(D > 0 && D <= SA_DMAX && H > 0 && H <= SA_HMAX && N >= 1 && P >= 1, "bad slot shape");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(sa_slot_update_kernel, dim3(B * N), dim3(256), 0, (hipStream_t)stream, part_num,
+                     part_den, P, slots_prev, gru_w_ih, gru_w_hh, gru_b_ih, gru_b_hh, ln_g, ln_b, mlp_w1,
+                     mlp_b1, mlp_w2, mlp_b2, slots_out, N, D, H, ln_eps);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

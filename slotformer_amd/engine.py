@@ -1,0 +1,245 @@
+"""Host-side glue between the nn.Module parameter containers and libslotformer_hip.
+
+Builds the ctypes model descriptors (sf_savi_encoder / sf_rollouter) from module parameters,
+packs the few derived constants (conv weights OHWI, [Wk;Wv], position tables) with the
+library's own kernels, owns the per-device workspace, and launches the whole-path engines on
+torch's current stream.  PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, sf_tfm_layer, sf_rollouter, sf_savi_encoder
+from . import ops
+
+_WORKSPACES = {}
+
+
+def workspace(device, nbytes):
+    """Grow-only per-device scratch buffer (never freed behind a running graph: buffers are
+    replaced, old ones stay alive while any captured graph references them via `keep`)."""
+    key = (device.type, device.index)
+    cur = _WORKSPACES.get(key)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = cur
+    return cur
+
+
+def _require_inference(module, *tensors):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise NotImplementedError(
+            'slotformer_amd: the HIP path is inference-only (backward kernels are row N1 of SURVEY.md 8f); '
+            'wrap the call in torch.no_grad()')
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('slotformer_amd: inputs must live on a HIP device; there is no CPU fallback')
+
+
+class _Plan:
+    """ctypes descriptor + the tensors it points to."""
+
+    def __init__(self):
+        self.keep = []
+        self.struct = None
+        self.sig = None
+
+    def dp(self, t):
+        if t is None:
+            return None
+        t = t.detach()
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.float().contiguous()
+        self.keep.append(t)
+        return t.data_ptr()
+
+
+def _signature(module):
+    return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
+
+
+def _tfm_layers(plan, encoder):
+    """nn.TransformerEncoder -> host array of sf_tfm_layer."""
+    n = len(encoder.layers)
+    arr = (sf_tfm_layer * n)()
+    for i, l in enumerate(encoder.layers):
+        a = arr[i]
+        a.norm1_g, a.norm1_b = plan.dp(l.norm1.weight), plan.dp(l.norm1.bias)
+        a.in_proj_w, a.in_proj_b = plan.dp(l.self_attn.in_proj_weight), plan.dp(l.self_attn.in_proj_bias)
+        a.out_proj_w, a.out_proj_b = plan.dp(l.self_attn.out_proj.weight), plan.dp(l.self_attn.out_proj.bias)
+        a.norm2_g, a.norm2_b = plan.dp(l.norm2.weight), plan.dp(l.norm2.bias)
+        a.lin1_w, a.lin1_b = plan.dp(l.linear1.weight), plan.dp(l.linear1.bias)
+        a.lin2_w, a.lin2_b = plan.dp(l.linear2.weight), plan.dp(l.linear2.bias)
+    plan.keep.append(arr)
+    return arr
+
+
+# ---------------------------------------------------------------------------------------------
+def rollouter_plan(r):
+    """r: SlotRollouter / SingleStepSlotRollouter container."""
+    sig = _signature(r)
+    plan = getattr(r, '_sf_plan', None)
+    if plan is not None and plan.sig == sig:
+        return plan
+    plan = _Plan()
+    s = sf_rollouter()
+    single = hasattr(r, 'cond_len')
+    W = r.cond_len if single else r.history_len
+    N = r.num_slots
+    s.num_slots, s.slot_size, s.d_model = N, r.in_proj.in_features, r.in_proj.out_features
+    enc = r.transformer_encoder
+    l0 = enc.layers[0]
+    s.num_layers, s.num_heads = len(enc.layers), l0.self_attn.num_heads
+    s.ffn_dim, s.norm_first = l0.linear1.out_features, int(l0.norm_first)
+    s.window_len, s.single_step = W, int(single)
+    s.in_proj_w, s.in_proj_b = plan.dp(r.in_proj.weight), plan.dp(r.in_proj.bias)
+    s.out_proj_w, s.out_proj_b = plan.dp(r.out_proj.weight), plan.dp(r.out_proj.bias)
+    # token PE: temporal PE repeated per slot (+ slots PE repeated per step)  slotformer.py:103-109
+    pe = r.enc_t_pe.detach()[0].repeat_interleave(N, dim=0)
+    if r.enc_slots_pe is not None:
+        pe = pe + r.enc_slots_pe.detach()[0].repeat(W, 1)
+    s.pe_tok = plan.dp(pe.contiguous())
+    s.layers = C.cast(_tfm_layers(plan, enc), C.POINTER(sf_tfm_layer))
+    plan.struct, plan.sig = s, sig
+    r._sf_plan = plan
+    return plan
+
+
+def rollout(r, slots_all, n_in, pred_len):
+    """In-place autoregressive rollout.  slots_all [B, T_total, N, C] float32 contiguous on device;
+    frames [0, n_in) hold the burn-in; frames [n_in, n_in+pred_len) are written."""
+    _require_inference(r, slots_all)
+    ops._chk(slots_all)
+    plan = rollouter_plan(r)
+    B, T_total = slots_all.shape[:2]
+    need = lib().sf_rollout_workspace_bytes(C.byref(plan.struct), B)
+    ws = workspace(slots_all.device, need)
+    check(lib().sf_rollout_f32(C.byref(plan.struct), slots_all.data_ptr(), B, T_total, pred_len, ws.data_ptr(),
+                               ws.numel(), torch.cuda.current_stream().cuda_stream))
+    return slots_all
+
+
+# ---------------------------------------------------------------------------------------------
+def encoder_plan(m):
+    """m: StoSAVi / STEVE container."""
+    sig = _signature(m)
+    plan = getattr(m, '_sf_plan', None)
+    if plan is not None and plan.sig == sig:
+        return plan
+    plan = _Plan()
+    s = sf_savi_encoder()
+    if m.resolution[0] != m.resolution[1] or m.resolution[0] not in (64, 128):
+        raise NotImplementedError(f'resolution {m.resolution}: the encoder needs 64x64 or 128x128 input '
+                                  '(visual_resolution is fixed to 64x64, savi.py:226)')
+    s.resolution = m.resolution[0]
+    ch = list(m.enc_channels)
+    n = len(ch) - 1
+    if n > 8:
+        raise NotImplementedError('at most 8 encoder convs')
+    s.enc_layers, s.enc_ks = n, m.enc_ks
+    for i, c in enumerate(ch):
+        s.enc_channels[i] = c
+    for i in range(n):
+        conv = m.encoder[i][0]
+        w = conv.weight.detach().float().contiguous()
+        s.conv_w[i] = plan.dp(w if i == 0 else ops.pack_conv_weight(w))
+        s.conv_b[i] = plan.dp(conv.bias)
+    pe = m.encoder_pos_embedding
+    s.pos_table = plan.dp(ops.pos_embed_table(pe.grid.detach().float(), pe.dense.weight.detach().float().contiguous(),
+                                              pe.dense.bias.detach().float().contiguous()))
+    eo = m.encoder_out_layer
+    s.enc_ln_g, s.enc_ln_b = plan.dp(eo[0].weight), plan.dp(eo[0].bias)
+    s.enc_fc1_w, s.enc_fc1_b = plan.dp(eo[1].weight), plan.dp(eo[1].bias)
+    s.enc_fc2_w, s.enc_fc2_b = plan.dp(eo[3].weight), plan.dp(eo[3].bias)
+    s.enc_out_channels = m.enc_out_channels
+    s.num_slots, s.slot_size, s.slot_mlp_size = m.num_slots, m.slot_size, m.slot_mlp_size
+    s.num_iterations = m.num_iterations
+    sa = m.slot_attention
+    s.sa_norm_in_g, s.sa_norm_in_b = plan.dp(sa.norm_inputs.weight), plan.dp(sa.norm_inputs.bias)
+    s.sa_q_ln_g, s.sa_q_ln_b = plan.dp(sa.project_q[0].weight), plan.dp(sa.project_q[0].bias)
+    s.sa_q_w = plan.dp(sa.project_q[1].weight)
+    s.sa_kv_w = plan.dp(torch.cat([sa.project_k.weight.detach(), sa.project_v.weight.detach()], 0).contiguous())
+    s.gru_w_ih, s.gru_w_hh = plan.dp(sa.gru.weight_ih), plan.dp(sa.gru.weight_hh)
+    s.gru_b_ih, s.gru_b_hh = plan.dp(sa.gru.bias_ih), plan.dp(sa.gru.bias_hh)
+    s.mlp_ln_g, s.mlp_ln_b = plan.dp(sa.mlp[0].weight), plan.dp(sa.mlp[0].bias)
+    s.mlp_w1, s.mlp_b1 = plan.dp(sa.mlp[1].weight), plan.dp(sa.mlp[1].bias)
+    s.mlp_w2, s.mlp_b2 = plan.dp(sa.mlp[3].weight), plan.dp(sa.mlp[3].bias)
+    s.init_latents = plan.dp(m.init_latents.detach()[0])
+    s.sa_eps = float(sa.eps)
+    kd = getattr(m, 'kernel_dist_layer', None)
+    if kd is None:
+        s.kd_mode = 0
+    elif len(kd) == 1:
+        s.kd_mode = 1
+        s.kd_w0, s.kd_b0 = plan.dp(kd[0].weight), plan.dp(kd[0].bias)
+    else:
+        s.kd_mode = 2
+        s.kd_w0, s.kd_b0 = plan.dp(kd[0].weight), plan.dp(kd[0].bias)
+        s.kd_ln_g, s.kd_ln_b = plan.dp(kd[1].weight), plan.dp(kd[1].bias)
+        s.kd_w3, s.kd_b3 = plan.dp(kd[3].weight), plan.dp(kd[3].bias)
+    pred = m.predictor
+    rnn = hasattr(pred, 'rnn')
+    base = pred.base_predictor if rnn else pred
+    s.pred_rnn = int(rnn)
+    s.pred_norm_first = int(base.norm_first)
+    if hasattr(base, 'transformer_encoder'):
+        s.pred_type = 1
+        s.pred_num_layers, s.pred_num_heads, s.pred_ffn_dim = base.num_layers, base.num_heads, base.ffn_dim
+        s.pred_layers = C.cast(_tfm_layers(plan, base.transformer_encoder), C.POINTER(sf_tfm_layer))
+    else:
+        s.pred_type = 0
+        s.pred_ffn_dim = 2 * m.slot_size
+        s.pm_ln_g, s.pm_ln_b = plan.dp(base.ln.weight), plan.dp(base.ln.bias)
+        s.pm_w0, s.pm_b0 = plan.dp(base.mlp[0].weight), plan.dp(base.mlp[0].bias)
+        s.pm_w2, s.pm_b2 = plan.dp(base.mlp[2].weight), plan.dp(base.mlp[2].bias)
+    if rnn:
+        s.pred_hidden = pred.hidden_size
+        s.lstm_w_ih, s.lstm_w_hh = plan.dp(pred.rnn.weight_ih_l0), plan.dp(pred.rnn.weight_hh_l0)
+        s.lstm_b_ih, s.lstm_b_hh = plan.dp(pred.rnn.bias_ih_l0), plan.dp(pred.rnn.bias_hh_l0)
+        s.proj_w, s.proj_b = plan.dp(pred.out_projector.weight), plan.dp(pred.out_projector.bias)
+    plan.struct, plan.sig = s, sig
+    m._sf_plan = plan
+    return plan
+
+
+def savi_encode(m, img, prev_slots=None, noise=None, want_attn=False):
+    """Run StoSAVi.encode / STEVE.encode on device.
+
+    Returns (post_slots [B,T,N,D], kernel_dist [B,T,N,2D] | None, attn [B,T,N,64*64] | None).
+    The predictor's LSTM state lives on `m.predictor.hidden_state` exactly as in the reference.
+    """
+    _require_inference(m, img)
+    img = img.float().contiguous()
+    ops._chk(img, prev_slots, noise)
+    plan = encoder_plan(m)
+    s = plan.struct
+    B, T = img.shape[:2]
+    if tuple(img.shape[2:]) != (3, s.resolution, s.resolution):
+        raise RuntimeError(f'img must be [B,T,3,{s.resolution},{s.resolution}], got {tuple(img.shape)}')
+    N, D = s.num_slots, s.slot_size
+    dev = img.device
+    post = torch.empty(B, T, N, D, device=dev, dtype=torch.float32)
+    kdist = torch.empty(B, T, N, 2 * D, device=dev, dtype=torch.float32) if s.kd_mode else None
+    attn = torch.empty(B, T, N, 64 * 64, device=dev, dtype=torch.float32) if want_attn else None
+    h = c = None
+    valid = 0
+    if s.pred_rnn:
+        pred = m.predictor
+        if prev_slots is None:
+            pred.reset()  # StoSAVi._reset_rnn at the first frame (savi.py:474-475)
+        st = pred.hidden_state
+        if st is not None and st[0].shape[1] == B * N and st[0].device == dev:
+            h, c, valid = st[0], st[1], 1
+        else:
+            h = torch.empty(1, B * N, s.pred_hidden, device=dev, dtype=torch.float32)
+            c = torch.empty_like(h)
+        pred.hidden_state = (h, c)
+        pred.step += T if prev_slots is not None else T - 1
+    need = lib().sf_savi_encode_workspace_bytes(C.byref(plan.struct), B)
+    ws = workspace(dev, need)
+    P = ops._p
+    check(lib().sf_savi_encode_f32(C.byref(plan.struct), img.data_ptr(), P(noise), P(prev_slots), P(h), P(c), valid,
+                                   post.data_ptr(), P(kdist), P(attn), B, T, ws.data_ptr(), ws.numel(),
+                                   torch.cuda.current_stream().cuda_stream))
+    return post, kdist, attn

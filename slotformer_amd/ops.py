@@ -1,0 +1,150 @@
+"""Torch-tensor wrappers over the C ABI building blocks (device memory + stream plumbing only).
+
+Every function requires contiguous float32 tensors on a HIP device and launches on torch's
+current stream.  There is no CPU path.
+"""
+import torch
+
+from ._lib import lib, check
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError('slotformer_amd ops need contiguous float32 tensors on a HIP device '
+                               f'(got {type(t).__name__} {getattr(t, "dtype", None)} '
+                               f'{getattr(t, "device", None)}); there is no CPU fallback')
+
+
+def linear(x, weight, bias=None, ln=None, residual=None, relu=False, ln_eps=1e-5):
+    """act(LN?(x) @ weight.T + bias) + residual;  x [..., K], weight [N, K]."""
+    _chk(x, weight, bias, residual, *(ln or ()))
+    K = x.shape[-1]
+    N = weight.shape[0]
+    M = x.numel() // K
+    out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+    g, b = (ln if ln is not None else (None, None))
+    check(lib().sf_linear_f32(_p(x), K, _p(weight), _p(bias), _p(g), _p(b), ln_eps, _p(residual), N, _p(out), N,
+                              M, N, K, int(relu), _stream()))
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    _chk(x, gamma, beta)
+    out = torch.empty_like(x)
+    D = x.shape[-1]
+    check(lib().sf_layernorm_f32(_p(x), _p(gamma), _p(beta), _p(out), x.numel() // D, D, eps, _stream()))
+    return out
+
+
+def pack_conv_weight(w):
+    """[Cout,Cin,k,k] -> [Cout,k,k,Cin]."""
+    _chk(w)
+    out = torch.empty(w.shape[0], w.shape[2], w.shape[3], w.shape[1], device=w.device, dtype=torch.float32)
+    check(lib().sf_pack_conv_weight_f32(_p(w), _p(out), w.shape[0], w.shape[1], w.shape[2], _stream()))
+    return out
+
+
+def pos_embed_table(grid, dense_w, dense_b):
+    """grid [1,H,W,4] -> [H*W, C]."""
+    grid = grid.reshape(-1, 4).contiguous()
+    _chk(grid, dense_w, dense_b)
+    out = torch.empty(grid.shape[0], dense_w.shape[0], device=grid.device, dtype=torch.float32)
+    check(lib().sf_pos_embed_table_f32(_p(grid), _p(dense_w), _p(dense_b), _p(out), grid.shape[0],
+                                       dense_w.shape[0], _stream()))
+    return out
+
+
+def conv2d_first(img, weight, bias, stride, relu=True, add=None):
+    """img [F,Cin,H,W] NCHW -> [F,Ho,Wo,Cout] NHWC."""
+    _chk(img, weight, bias, add)
+    F_, Cin, H, W = img.shape
+    Cout, ks = weight.shape[0], weight.shape[2]
+    Ho = (H + 2 * (ks // 2) - ks) // stride + 1
+    Wo = (W + 2 * (ks // 2) - ks) // stride + 1
+    out = torch.empty(F_, Ho, Wo, Cout, device=img.device, dtype=torch.float32)
+    check(lib().sf_conv2d_nchw_in_f32(_p(img), Cin * H * W, _p(weight), _p(bias), _p(add), _p(out), F_, Cin, H, W,
+                                      Cout, ks, stride, int(relu), _stream()))
+    return out
+
+
+def conv2d_nhwc(x, w_packed, bias, relu=True, add=None):
+    """x [F,H,W,Cin] NHWC, w_packed [Cout,k,k,Cin] -> [F,H,W,Cout]."""
+    _chk(x, w_packed, bias, add)
+    F_, H, W, Cin = x.shape
+    Cout, ks = w_packed.shape[0], w_packed.shape[1]
+    out = torch.empty(F_, H, W, Cout, device=x.device, dtype=torch.float32)
+    check(lib().sf_conv2d_nhwc_f32(_p(x), _p(w_packed), _p(bias), _p(add), _p(out), F_, H, W, Cin, Cout, ks,
+                                   int(relu), _stream()))
+    return out
+
+
+def slot_attn_iter(k, v, q, eps=1e-6, want_attn=False):
+    """k, v [B,HW,D]; q [B,N,D] -> (part_num [B,P,N,D], part_den [B,P,N], attn [B,N,HW] | None)."""
+    _chk(k, v, q)
+    B, HW, D = k.shape
+    N = q.shape[1]
+    P = lib().sf_slot_attn_num_partials(HW)
+    pn = torch.empty(B, P, N, D, device=k.device, dtype=torch.float32)
+    pd = torch.empty(B, P, N, device=k.device, dtype=torch.float32)
+    attn = torch.empty(B, N, HW, device=k.device, dtype=torch.float32) if want_attn else None
+    check(lib().sf_slot_attn_iter_f32(_p(k), _p(v), D, HW * D, _p(q), _p(pn), _p(pd), _p(attn), B, HW, N, D,
+                                      float(D)**-0.5, eps, _stream()))
+    return pn, pd, attn
+
+
+def slot_update(pn, pd, slots_prev, gru, ln_g, ln_b, w1, b1, w2, b2, ln_eps=1e-5):
+    """gru = (w_ih, w_hh, b_ih, b_hh)."""
+    _chk(pn, pd, slots_prev, *gru, ln_g, ln_b, w1, b1, w2, b2)
+    B, P, N, D = pn.shape
+    out = torch.empty_like(slots_prev)
+    check(lib().sf_slot_update_f32(_p(pn), _p(pd), P, _p(slots_prev), *[_p(t) for t in gru], _p(ln_g), _p(ln_b),
+                                   _p(w1), _p(b1), _p(w2), _p(b2), _p(out), B, N, D, w1.shape[0], ln_eps,
+                                   _stream()))
+    return out
+
+
+def mha(qkv, B, L, d_model, num_heads, Lq=None):
+    """qkv [B*L, 3d] -> [B*Lq, d]."""
+    _chk(qkv)
+    Lq = L if Lq is None else Lq
+    out = torch.empty(B * Lq, d_model, device=qkv.device, dtype=torch.float32)
+    check(lib().sf_mha_f32(_p(qkv), _p(out), B, L, Lq, d_model, num_heads, _stream()))
+    return out
+
+
+def lstm_pointwise(gates, c_prev):
+    _chk(gates, c_prev)
+    R, H4 = gates.shape
+    h = torch.empty(R, H4 // 4, device=gates.device, dtype=torch.float32)
+    c = torch.empty_like(h)
+    check(lib().sf_lstm_pointwise_f32(_p(gates), _p(c_prev), _p(h), _p(c), R, H4 // 4, _stream()))
+    return h, c
+
+
+def sample_dist(dist, noise=None):
+    _chk(dist, noise)
+    D = dist.shape[-1] // 2
+    out = torch.empty(*dist.shape[:-1], D, device=dist.device, dtype=torch.float32)
+    check(lib().sf_sample_dist_f32(_p(dist), _p(noise), _p(out), dist.numel() // (2 * D), D, _stream()))
+    return out
+
+
+def bilinear_resize(x, size):
+    """x [..., Hi, Wi] -> [..., Ho, Wo]  (F.interpolate bilinear, align_corners=False)."""
+    _chk(x)
+    Hi, Wi = x.shape[-2:]
+    out = torch.empty(*x.shape[:-2], size[0], size[1], device=x.device, dtype=torch.float32)
+    check(lib().sf_bilinear_resize_f32(_p(x), _p(out), x.numel() // (Hi * Wi), Hi, Wi, size[0], size[1],
+                                       _stream()))
+    return out

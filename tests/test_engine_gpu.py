@@ -1,0 +1,152 @@
+"""GPU parity of the whole-path engines (through the reference-shaped nn.Module API) against
+the committed golden vectors (outputs of the reference's own classes) and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3  # north-star bar: 1e-3 relative, fp32
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), torch.as_tensor(b).double()
+    return ((a - b).abs().max() / b.abs().max()).item()
+
+
+def build(cfg, golden, seed, dev, vp=False):
+    from slotformer_amd.base_slots import build_model as bb
+    from slotformer_amd.video_prediction import build_model as bv
+    shapes = gu.shapes_from_golden(golden)
+    if vp:
+        import os, tempfile  # noqa: E401
+        scfg = gu.savi_cfg(cfg['resolution'][0], cfg['slot_dict']['num_slots'], slot_size=cfg['slot_dict']['slot_size'])
+        scfg['dec_dict'] = {k: v for k, v in cfg['dec_dict'].items() if k != 'dec_ckp_path'}
+        savi = bb(gu.ParamsView(scfg))
+        path = os.path.join(tempfile.mkdtemp(), 'savi.pth')
+        torch.save({'state_dict': savi.state_dict()}, path)
+        full = {k: (dict(v) if isinstance(v, dict) else v) for k, v in cfg.items()}
+        full['dec_dict']['dec_ckp_path'] = path
+        m = bv(gu.ParamsView(full))
+    else:
+        full = dict(cfg)
+        if cfg['model'] == 'STEVE':
+            full.update(dvae_dict=dict(down_factor=4, vocab_size=64, dvae_ckp_path=''),
+                        dec_dict=dict(dec_type='slate', dec_num_layers=1, dec_num_heads=4, dec_d_model=64),
+                        loss_dict=dict(use_img_recon_loss=False))
+        m = bb(gu.ParamsView(full))
+    own = {k: v for k, v in m.state_dict().items()}
+    assert [(k, tuple(v.shape)) for k, v in own.items()] == shapes, 'state-dict keys/shapes differ from the reference'
+    sd = gu.seeded_state_dict(shapes, seed, keep=own)
+    m.load_state_dict(sd, strict=True)
+    return m.eval().to(dev), sd
+
+
+@pytest.mark.parametrize('name,cfg,B,T,seed,noise_seed', [
+    ('savi_c1', gu.C1_SAVI, 2, 3, 101, None),
+    ('savi_c1_it3', gu.C1_SAVI_IT3, 1, 2, 102, None),
+    ('savi_c2', gu.C2_SAVI, 2, 3, 103, 7),
+    ('savi_c5', gu.C5_SAVI, 2, 1, 105, None),
+])
+@torch.no_grad()
+def test_savi_golden(dev, name, cfg, B, T, seed, noise_seed):
+    g = gu.load_golden(name)
+    m, sd = build(cfg, g, seed, dev)
+    m.testing = True
+    img = gu.seeded_img(B, T, cfg['resolution'][0]).to(dev)
+    data = {'img': img}
+    if noise_seed is not None:
+        N, D = cfg['slot_dict']['num_slots'], cfg['slot_dict']['slot_size']
+        data['noise'] = gu.seeded_normal((B, T, N, D), noise_seed).to(dev)
+    out = m(data)
+    assert rel_err(out['post_slots'], g['post_slots']) < RTOL
+    assert rel_err(out['kernel_dist'], g['kernel_dist']) < RTOL
+    # tighter: fp32 reorder noise only
+    assert rel_err(out['post_slots'], g['post_slots']) < 5e-5
+
+
+@torch.no_grad()
+def test_savi_chunked_golden(dev):
+    """Long-video path (savi.py:431-463): golden produced by the reference's own chunking."""
+    g = gu.load_golden('savi_c1_chunked')
+    m, sd = build(gu.C1_SAVI, g, 106, dev)
+    m.testing = True
+    m.clip_len = 1
+    img = gu.seeded_img(1, 5, 64).to(dev)
+    out = m({'img': img})
+    assert rel_err(out['post_slots'], g['post_slots']) < 5e-5
+    # explicit chunks carrying prev_slots + predictor state reproduce it too
+    m._reset_rnn()
+    o1 = m._forward(img[:, :2], None)
+    o2 = m._forward(img[:, 2:], o1['post_slots'][:, -1].clone())
+    both = torch.cat([o1['post_slots'], o2['post_slots']], 1)
+    assert rel_err(both, g['post_slots']) < 5e-5
+
+
+@torch.no_grad()
+def test_steve_golden_and_masks(dev):
+    g = gu.load_golden('steve_c4')
+    m, sd = build(gu.C4_STEVE, g, 104, dev)
+    m.testing = True
+    out = m({'img': gu.seeded_img(1, 2, 128).to(dev)})
+    assert rel_err(out['slots'], g['slots']) < 5e-5
+    masks = out['masks'].cpu()
+    assert masks.shape == g['masks'].shape
+    assert (masks - torch.from_numpy(g['masks'])).abs().max() < 1e-5
+    # bit-exact argmax masks wherever the reference's own top-1/top-2 margin exceeds fp32 noise
+    am = masks.argmax(2).to(torch.uint8)
+    safe = torch.from_numpy(g['margin']) > 1e-5
+    assert torch.equal(am[safe], torch.from_numpy(g['argmax'])[safe])
+    n_unsafe = int((~safe).sum())
+    n_diff = int((am != torch.from_numpy(g['argmax'])).sum())
+    print(f'argmax: {n_unsafe} sub-margin pixels of {safe.numel()}, {n_diff} differ')
+    assert n_diff <= n_unsafe
+
+
+@pytest.mark.parametrize('name,cfg,B,pred_len,seed', [
+    ('roll_c1', gu.C1_ROLL, 3, 10, 201),
+    ('roll_c2', gu.C2_ROLL, 2, 50, 202),
+    ('roll_c4', gu.C4_ROLL, 2, 12, 204),
+    ('roll_c4_ref', gu.C4_ROLL_REF, 1, 4, 214),
+    ('roll_c5', gu.C5_ROLL, 2, 12, 205),
+])
+@torch.no_grad()
+def test_rollout_golden(dev, name, cfg, B, pred_len, seed):
+    g = gu.load_golden(name)
+    m, sd = build(cfg, g, seed, dev, vp=True)
+    rd = cfg['rollout_dict']
+    slots = gu.seeded_normal((B, rd['history_len'] + pred_len, rd['num_slots'], rd['slot_size']), seed + 1).to(dev)
+    m.rollout_len = pred_len
+    out = m({'slots': slots})
+    e = rel_err(out['pred_slots'], g['pred_slots'])
+    print(name, 'rel err', e)
+    assert e < RTOL
+    assert e < 2e-4
+    m.loss_decay_factor = 0.9
+    losses = m.calc_train_loss({'slots': slots}, out)
+    for k, v in zip(g['loss_names'], g['loss_vals']):
+        assert abs(float(losses[str(k)]) - float(v)) < 1e-3 * abs(float(v)) + 1e-6
+
+
+@torch.no_grad()
+def test_c2_full_size_vs_oracle(dev):
+    """BASELINE config C2 at reduced batch vs the oracle: encode 6 frames then roll 50 steps."""
+    scfg, rcfg = gu.C2_SAVI, gu.C2_ROLL
+    gs, gr = gu.load_golden('savi_c2'), gu.load_golden('roll_c2')
+    savi, ssd = build(scfg, gs, 103, dev)
+    sf, fsd = build(rcfg, gr, 202, dev, vp=True)
+    savi.testing = True
+    B, T, H = 2, 6, 50
+    img = gu.seeded_img(B, T, 128, seed=99)
+    noise = gu.seeded_normal((B, T, 7, 128), 5)
+    post = savi({'img': img.to(dev), 'noise': noise.to(dev)})['post_slots']
+    ref_post = oracle.savi_encode(img, ssd, scfg, noise=noise)['post_slots']
+    assert rel_err(post, ref_post) < 5e-5
+    pred = sf.rollout(post, H)
+    ref_pred = oracle.rollouter_forward(ref_post, H, fsd, rcfg['rollout_dict'])
+    e = rel_err(pred, ref_pred)
+    print('encode+rollout rel err', e)
+    assert e < RTOL

@@ -1,0 +1,153 @@
+"""GPU parity of every C-ABI building block against the oracle / plain fp32 torch ops.
+
+Tolerances: fp32 paths differ from the reference only by summation order; 1e-3 relative is the
+north-star bar, the asserts below are 10-100x tighter.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.from_numpy((np.random.RandomState(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+def close(a, b, rtol=2e-5, atol=2e-5):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= atol + rtol * ref, f'max abs err {err:.3e} (ref scale {ref:.3e})'
+
+
+@pytest.mark.parametrize('M,N,K', [(1344, 768, 256), (1344, 256, 1024), (224, 384, 128), (7, 128, 256),
+                                   (131072, 128, 64), (4096 * 3, 256, 128), (100, 36, 64), (33, 64, 192),
+                                   (1344, 1024, 256), (1344, 256, 256)])
+@pytest.mark.parametrize('mode', ['plain', 'ln_relu_res'])
+def test_linear(dev, M, N, K, mode):
+    from slotformer_amd import ops
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K**-0.5), rnd(N, seed=3, scale=0.1)
+    if mode == 'plain':
+        ref = F.linear(x, w, b)
+        out = ops.linear(x.to(dev), w.to(dev), b.to(dev))
+    else:
+        g, be, r = 1 + 0.1 * rnd(K, seed=4), 0.1 * rnd(K, seed=5), rnd(M, N, seed=6)
+        ref = F.relu(F.linear(F.layer_norm(x, (K, ), g, be), w, b)) + r
+        out = ops.linear(x.to(dev), w.to(dev), b.to(dev), ln=(g.to(dev), be.to(dev)), residual=r.to(dev), relu=True)
+    close(out, ref)
+
+
+def test_linear_transpose_detecting(dev):
+    """A = I with an asymmetric W catches a swapped C layout."""
+    from slotformer_amd import ops
+    K = 64
+    w = torch.arange(96 * K, dtype=torch.float32).reshape(96, K) / 100
+    out = ops.linear(torch.eye(K).to(dev), w.to(dev))
+    assert torch.equal(out.cpu(), w.t().contiguous())
+
+
+def test_layernorm(dev):
+    from slotformer_amd import ops
+    x, g, b = rnd(224, 192, seed=1), 1 + 0.1 * rnd(192, seed=2), rnd(192, seed=3)
+    close(ops.layernorm(x.to(dev), g.to(dev), b.to(dev)), F.layer_norm(x, (192, ), g, b))
+
+
+@pytest.mark.parametrize('res,stride', [(64, 1), (128, 2)])
+def test_conv_first(dev, res, stride):
+    from slotformer_amd import ops
+    img, w, b = rnd(3, 3, res, res, seed=1), rnd(64, 3, 5, 5, seed=2, scale=0.1), rnd(64, seed=3, scale=0.1)
+    ref = F.relu(F.conv2d(img, w, b, stride=stride, padding=2)).permute(0, 2, 3, 1)
+    close(ops.conv2d_first(img.to(dev), w.to(dev), b.to(dev), stride), ref)
+
+
+@pytest.mark.parametrize('relu,with_add', [(True, False), (False, True)])
+def test_conv_nhwc(dev, relu, with_add):
+    from slotformer_amd import ops
+    x, w, b = rnd(3, 64, 64, 64, seed=1), rnd(64, 64, 5, 5, seed=2, scale=0.03), rnd(64, seed=3, scale=0.1)
+    add = rnd(4096, 64, seed=4) if with_add else None
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=2)
+    ref = (F.relu(ref) if relu else ref).permute(0, 2, 3, 1)
+    if with_add:
+        ref = ref + add.view(1, 64, 64, 64)
+    wp = ops.pack_conv_weight(w.to(dev))
+    assert torch.equal(wp.cpu(), w.permute(0, 2, 3, 1).contiguous())
+    close(ops.conv2d_nhwc(x.to(dev), wp, b.to(dev), relu=relu, add=None if add is None else add.to(dev)), ref)
+
+
+def test_pos_table(dev):
+    from slotformer_amd import ops
+    grid = oracle.build_grid((64, 64))
+    w, b = rnd(64, 4, seed=1), rnd(64, seed=2)
+    close(ops.pos_embed_table(grid.to(dev), w.to(dev), b.to(dev)), F.linear(grid, w, b).reshape(4096, 64))
+
+
+@pytest.mark.parametrize('B,N,D', [(3, 7, 128), (2, 6, 192), (2, 8, 128), (1, 1, 64)])
+def test_slot_attn_iteration(dev, B, N, D):
+    """One iteration (attention half + slot update) vs the oracle's restatement of savi.py:76-100."""
+    from slotformer_amd import ops
+    HW, H = 4096, 2 * D
+    k, v, q = rnd(B, HW, D, seed=1), rnd(B, HW, D, seed=2), rnd(B, N, D, seed=3)
+    slots = rnd(B, N, D, seed=4)
+    pn, pd, attn = ops.slot_attn_iter(k.to(dev), v.to(dev), q.to(dev), want_attn=True)
+    logits = D**-0.5 * torch.einsum('bnc,bmc->bnm', k, q)
+    a = torch.softmax(logits, -1)
+    close(attn, a.permute(0, 2, 1), rtol=1e-5, atol=1e-6)
+    a = a + 1e-6
+    a = a / a.sum(1, keepdim=True)
+    upd = torch.einsum('bnm,bnc->bmc', a, v)
+    close(pn.sum(1) / pd.sum(1).unsqueeze(-1), upd, rtol=1e-5, atol=1e-6)
+    w_ih, w_hh = rnd(3 * D, D, seed=5, scale=D**-0.5), rnd(3 * D, D, seed=6, scale=D**-0.5)
+    b_ih, b_hh = rnd(3 * D, seed=7, scale=0.1), rnd(3 * D, seed=8, scale=0.1)
+    g, be = 1 + 0.1 * rnd(D, seed=9), 0.1 * rnd(D, seed=10)
+    w1, b1, w2, b2 = rnd(H, D, seed=11, scale=D**-0.5), rnd(H, seed=12, scale=0.1), rnd(D, H, seed=13, scale=H**-0.5), rnd(D, seed=14, scale=0.1)
+    h = oracle.gru_cell(upd.reshape(B * N, D), slots.reshape(B * N, D), w_ih, w_hh, b_ih, b_hh).view(B, N, D)
+    ref = h + F.linear(F.relu(F.linear(F.layer_norm(h, (D, ), g, be), w1, b1)), w2, b2)
+    t = lambda *xs: [x.to(dev) for x in xs]  # noqa: E731
+    out = ops.slot_update(pn, pd, slots.to(dev), t(w_ih, w_hh, b_ih, b_hh), *t(g, be, w1, b1, w2, b2))
+    close(out, ref)
+
+
+@pytest.mark.parametrize('B,L,d,h,Lq', [(3, 42, 256, 8, 42), (3, 42, 256, 8, 7), (2, 90, 256, 8, 90), (4, 6, 128, 4, 6),
+                                        (2, 6, 192, 4, 6), (2, 36, 128, 8, 36)])
+def test_mha(dev, B, L, d, h, Lq):
+    from slotformer_amd import ops
+    qkv = rnd(B * L, 3 * d, seed=1)
+    hd = d // h
+    q, k, v = [t.view(B, L, h, hd).transpose(1, 2) for t in qkv.view(B, L, 3 * d).chunk(3, -1)]
+    att = torch.softmax((q * hd**-0.5) @ k.transpose(-1, -2), -1)
+    ref = (att @ v).transpose(1, 2).reshape(B, L, d)[:, L - Lq:].reshape(B * Lq, d)
+    close(ops.mha(qkv.to(dev), B, L, d, h, Lq=Lq), ref)
+
+
+def test_lstm_and_sample(dev):
+    from slotformer_amd import ops
+    R, H, D = 12, 256, 128
+    gates, c = rnd(R, 4 * H, seed=1), rnd(R, H, seed=2)
+    i, f, g, o = gates.chunk(4, -1)
+    c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+    h2 = torch.sigmoid(o) * torch.tanh(c2)
+    hh, cc = ops.lstm_pointwise(gates.to(dev), c.to(dev))
+    close(hh, h2)
+    close(cc, c2)
+    dist, noise = rnd(R, 2 * D, seed=3), rnd(R, D, seed=4)
+    close(ops.sample_dist(dist.to(dev), noise.to(dev)), dist[:, :D] + noise * torch.exp(dist[:, D:] * 0.5))
+    assert torch.equal(ops.sample_dist(dist.to(dev)).cpu(), dist[:, :D])
+
+
+def test_bilinear(dev):
+    from slotformer_amd import ops
+    x = rnd(5, 64, 64, seed=1)
+    ref = F.interpolate(x.unsqueeze(1), (128, 128), mode='bilinear', align_corners=False).squeeze(1)
+    close(ops.bilinear_resize(x.to(dev), (128, 128)), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_errors_are_loud(dev):
+    from slotformer_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros(4, 6, device=dev), torch.zeros(8, 6, device=dev))  # K % 4 != 0
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros(4, 8), torch.zeros(8, 8))  # CPU tensors: no fallback
