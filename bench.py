@@ -1,0 +1,300 @@
+#!/usr/bin/env python
+"""bench.py -- SAVi-encode + SlotFormer rollout throughput on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic video resident in HBM:
+StoSAVi encode of B x 6 frames (128x128, 7 slots, 2 Slot-Attention iterations) followed by a
+50-step SlotFormer rollout (d=256, 4 layers, 8 heads) -- config C2 of SURVEY.md 8.
+frames/s = n_gpus * B * (6 + 50) * steps / wall.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: videos shard on the batch axis, one process per GPU, weights replicated, NO
+collective on the timed path -> weak scaling with B=32 per GPU.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBPS = 8000.0        # HBM3E spec peak (6.3 TB/s achievable)
+T_BURN, T_ROLL, RES = 6, 50, 128
+CLS_NAMES = ['conv_nhwc_implicit_gemm', 'conv_first', 'linear_gemm', 'slot_attn_iter', 'slot_update', 'mha_small']
+
+
+def c2_configs():
+    import golden_util as gu
+    return gu.C2_SAVI, gu.C2_ROLL
+
+
+def build_models(dev):
+    """Random-init weights of the C2 architecture (torch default initialisers, seed 0)."""
+    import golden_util as gu
+    from slotformer_amd.base_slots import build_model
+    from slotformer_amd.video_prediction.models import SlotRollouter
+    scfg, rcfg = c2_configs()
+    torch.manual_seed(0)
+    savi = build_model(gu.ParamsView(scfg)).eval()
+    savi.testing = True
+    roll = SlotRollouter(**rcfg['rollout_dict']).eval()
+    return savi.to(dev), roll.to(dev)
+
+
+def synthetic_img(B, seed=1234):
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy((rs.rand(B, T_BURN, 3, RES, RES) * 2 - 1).astype(np.float32))
+
+
+def read_profile(lib):
+    out = {}
+    for c, name in enumerate(CLS_NAMES):
+        ms, n, w = C.c_double(), C.c_longlong(), C.c_double()
+        lib.sf_profile_read(c, C.byref(ms), C.byref(n), C.byref(w))
+        if n.value:
+            out[name] = dict(launches=n.value, total_ms=ms.value, avg_us=1e3 * ms.value / n.value, work=w.value)
+    return out
+
+
+def cpu_baseline(sample_B):
+    """The oracle (CPU port of the reference path, torch fp32) timed on the host cores on a
+    bounded sample: sample_B videos of the same workload."""
+    import golden_util as gu
+    import oracle
+    scfg, rcfg = c2_configs()
+    savi, roll = build_models(torch.device('cpu')) if False else (None, None)
+    from slotformer_amd.base_slots import build_model
+    from slotformer_amd.video_prediction.models import SlotRollouter
+    torch.manual_seed(0)
+    savi = build_model(gu.ParamsView(scfg))
+    roll = SlotRollouter(**rcfg['rollout_dict'])
+    ssd = {k: v.detach() for k, v in savi.state_dict().items()}
+    rsd = {'rollouter.' + k: v.detach() for k, v in roll.state_dict().items()}
+    img = synthetic_img(sample_B)
+    noise = torch.randn(sample_B, T_BURN, 7, 128)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def run():
+        with torch.no_grad():
+            post = oracle.savi_encode(img, ssd, scfg, noise=noise)['post_slots']
+            return oracle.rollouter_forward(post, T_ROLL, rsd, rcfg['rollout_dict'])
+
+    run()
+    reps, t0 = 0, time.perf_counter()
+    while reps < 2 or (time.perf_counter() - t0 < 10.0 and reps < 8):
+        run()
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return dict(value=sample_B * (T_BURN + T_ROLL) / dt, unit='frames/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'oracle (torch-CPU fp32 restatement of the reference path), {sample_B} of 32 videos, '
+                f'{reps} passes of encode 6 frames + 50-step rollout, {dt:.2f} s per pass')
+
+
+def log(msg):
+    if int(os.environ.get('RANK', 0)) == 0:
+        print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='videos per GPU')
+    ap.add_argument('--no-graph', action='store_true', help='launch the rollout eagerly instead of hipGraph replay')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=4)
+    ap.add_argument('--rollout-streams', type=int, default=1, help='batch groups rolled out concurrently on separate HIP streams')
+    ap.add_argument('--breakdown', action='store_true', help='extra untimed pass with every kernel class timed')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    assert torch.cuda.is_available(), 'bench.py needs a HIP device'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)  # RCCL
+
+    from slotformer_amd import engine, _lib
+    lib = _lib.lib()
+    B = args.batch
+    savi, roll = build_models(dev)
+    img = synthetic_img(B, seed=1234 + rank).to(dev)
+    N, D = 7, 128
+    buf = torch.zeros(B, T_BURN + T_ROLL, N, D, device=dev)
+
+    def encode():
+        noise = torch.stack([torch.randn(B, N, D, device=dev) for _ in range(T_BURN)], 1)
+        post, _, _ = engine.savi_encode(savi, img, noise=noise)
+        buf[:, :T_BURN].copy_(post)
+
+    S = max(1, args.rollout_streams)
+    assert B % S == 0
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
+
+    def rollout_eager():
+        if S == 1:
+            engine.rollout(roll, buf, T_BURN, T_ROLL)
+            return
+        cur = torch.cuda.current_stream()
+        g = B // S
+        for i, st in enumerate(streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                engine.rollout(roll, buf[i * g:(i + 1) * g], T_BURN, T_ROLL, ws_slot=i)
+        for st in streams:
+            cur.wait_stream(st)
+
+    graph = None
+    with torch.no_grad():
+        log('first eager step')
+        encode()
+        torch.cuda.synchronize()
+        log('encode ok')
+        rollout_eager()
+        torch.cuda.synchronize()
+        log('rollout ok')
+        if not args.no_graph:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    rollout_eager()
+                graph.replay()
+                torch.cuda.synchronize()
+                log('graph captured + replayed')
+            except Exception as e:  # noqa: BLE001
+                if rank == 0:
+                    print(f'[bench] hipGraph capture failed ({e}); eager rollout', file=sys.stderr)
+                graph = None
+
+        def step():
+            encode()
+            if graph is not None:
+                graph.replay()
+            else:
+                rollout_eager()
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        log('warmup done')
+        # dominant kernel (conv implicit GEMM) + the HBM-bound SA iteration are event-timed live
+        lib.sf_profile_enable((1 << 0) | (1 << 3))
+        read_profile(lib)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        log(f'timed region done: {elapsed:.3f}s')
+        lib.sf_profile_enable(0)
+        prof = read_profile(lib)
+
+        # split timing (untimed extra): encode-only and rollout-only
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            encode()
+        torch.cuda.synchronize()
+        t_enc = (time.perf_counter() - t1) / 3
+        t1 = time.perf_counter()
+        for _ in range(3):
+            graph.replay() if graph is not None else rollout_eager()
+        torch.cuda.synchronize()
+        t_roll = (time.perf_counter() - t1) / 3
+        breakdown = None
+        if args.breakdown:
+            lib.sf_profile_enable(0x3f)
+            encode()
+            rollout_eager()
+            torch.cuda.synchronize()
+            lib.sf_profile_enable(0)
+            breakdown = read_profile(lib)
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        frames = world * B * (T_BURN + T_ROLL) * args.steps
+        res = {
+            'metric': 'rollout frames/sec at B=32, 128x128, 7 slots, 6+50 steps (SAVi-encode + SlotFormer rollout)',
+            'value': frames / elapsed,
+            'unit': 'frames/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'C2: CLEVRER StoSAVi 128x128 (7 slots, D=128, 2 SA iters, stochastic kernels, MLP '
+                'predictor) encode of 6 burn-in frames + SlotFormer (d=256, 4 layers, 8 heads, ffn 1024, L=42) '
+                '50-step rollout; random-init weights',
+                'batch_per_gpu': B, 'global_batch': B * world, 'burn_in': T_BURN, 'rollout': T_ROLL,
+                'parallelism': f'dp{world}: videos sharded on the batch axis, no collective on the timed path',
+                'rollout_launch': 'hipGraph replay' if graph is not None else 'eager', 'rollout_streams': S,
+            },
+            'encode_ms': 1e3 * t_enc,
+            'rollout_ms': 1e3 * t_roll,
+            'encoded_frames_per_s': B * T_BURN / t_enc,
+            'predicted_frames_per_s': B * T_ROLL / t_roll,
+        }
+        conv = prof.get('conv_nhwc_implicit_gemm')
+        if conv:
+            flops_per_launch = conv['work'] / conv['launches']
+            ach = flops_per_launch / (conv['avg_us'] * 1e-6) / 1e12
+            res['roofline'] = {
+                'kernel': 'sf_gemm_kernel<128,64,4,1,1,conv_nhwc> (5x5 conv 64->64 @64x64 as implicit GEMM, f32 MFMA)',
+                'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                'flops_per_launch': flops_per_launch, 'avg_launch_us': conv['avg_us'], 'launches': conv['launches'],
+            }
+        sa = prof.get('slot_attn_iter')
+        if sa:
+            bytes_per_launch = sa['work'] / sa['launches']
+            gbps = bytes_per_launch / (sa['avg_us'] * 1e-6) / 1e9
+            res['roofline_slot_attn'] = {
+                'kernel': 'sa_attn_partial_kernel<2> (one Slot-Attention iteration over K,V)', 'bound': 'hbm',
+                'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': gbps / PEAK_HBM_GBPS,
+                'traffic': None, 'bytes_per_launch': bytes_per_launch, 'avg_launch_us': sa['avg_us'],
+                'launches': sa['launches'],
+            }
+        if breakdown:
+            res['kernel_breakdown_one_step'] = breakdown
+        if world == 1 and not args.no_cpu_baseline:
+            log('cpu baseline ...')
+            res['cpu_baseline'] = cpu_baseline(args.cpu_sample)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

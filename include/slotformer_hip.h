@@ -23,6 +23,14 @@ extern "C" {
 int sf_version(void);
 const char* sf_last_error_string(void);
 
+/* Optional per-kernel-class HIP-event timer (bench.py roofline): events bracket every launch of a
+ * class on the launch stream while enabled (never during hipGraph capture).  Classes: 0 conv
+ * NHWC implicit GEMM, 1 first conv, 2 linear, 3 slot-attention iteration, 4 slot update, 5 MHA.
+ * sf_profile_read sums elapsed ms, launches and algorithmic work (FLOP, or bytes for class 3)
+ * since the last read. */
+int sf_profile_enable(int class_mask); /* bit c enables class c; 0 disables */
+int sf_profile_read(int kernel_class, double* total_ms, long long* launches, double* work);
+
 /* ---- building blocks ------------------------------------------------------------------ */
 
 /* C[M,N] = act( LN?(A)[M,K] @ W[N,K]^T + bias ) + residual.   nn.Linear / F.layer_norm call
@@ -63,7 +71,9 @@ int sf_slot_attn_iter_f32(const float* k, const float* v, int ld, long long batc
                           float* part_num, float* part_den, float* attn_out, int B, int HW, int N, int D,
                           float scale, float eps, void* stream);
 
-/* Slot update (savi.py:95-100): updates = sum(num)/sum(den); GRUCell (r,z,n); slots + MLP(LN(slots)). */
+/* Slot update (savi.py:95-100): updates = sum(num)/sum(den); GRUCell (r,z,n); slots + MLP(LN(slots)).
+ * The four weight MATRICES are passed transposed ([in,out] = torch weight.t().contiguous()):
+ * gru_w_ih [D,3D], gru_w_hh [D,3D], mlp_w1 [D,H], mlp_w2 [H,D]; biases / LN vectors as in torch. */
 int sf_slot_update_f32(const float* part_num, const float* part_den, int P, const float* slots_prev,
                        const float* gru_w_ih, const float* gru_w_hh, const float* gru_b_ih,
                        const float* gru_b_hh, const float* ln_g, const float* ln_b, const float* mlp_w1,
@@ -122,8 +132,8 @@ typedef struct {
   const float *enc_ln_g, *enc_ln_b, *enc_fc1_w, *enc_fc1_b, *enc_fc2_w, *enc_fc2_b;
   const float *sa_norm_in_g, *sa_norm_in_b, *sa_q_ln_g, *sa_q_ln_b, *sa_q_w;
   const float* sa_kv_w; /* [2*slot_size, enc_out_channels] = cat(project_k.weight, project_v.weight) */
-  const float *gru_w_ih, *gru_w_hh, *gru_b_ih, *gru_b_hh;
-  const float *mlp_ln_g, *mlp_ln_b, *mlp_w1, *mlp_b1, *mlp_w2, *mlp_b2;
+  const float *gru_w_ih, *gru_w_hh, *gru_b_ih, *gru_b_hh; /* matrices transposed: [D,3D] */
+  const float *mlp_ln_g, *mlp_ln_b, *mlp_w1, *mlp_b1, *mlp_w2, *mlp_b2; /* mlp_w1 [D,H], mlp_w2 [H,D] (transposed) */
   const float* init_latents; /* [N, D] */
   int kd_mode;               /* 0: none (STEVE), 1: Linear, 2: Linear-LN-ReLU-Linear (kernel_mlp) */
   const float *kd_w0, *kd_b0, *kd_ln_g, *kd_ln_b, *kd_w3, *kd_b3;

@@ -2,7 +2,7 @@
 // sequences (L <= ~128 tokens: rollout window / slot predictor), LSTM cell pointwise part,
 // stochastic-kernel sampling, row copies, weight packing, position-embedding table, bilinear
 // mask resize.  gfx950 only.
-#include "sf_common.h"
+#include "sf_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -98,6 +98,78 @@ __global__ __launch_bounds__(128) void mha_small_kernel(const float* __restrict_
   }
 }
 
+// Workgroup-parallel variant used whenever Q/K/V + the score matrix of one (head, batch) fit in
+// LDS: 256 threads share the L x L scores (QK^T), the row softmax and PV.  K rows are padded by
+// one float so the column-parallel score pass is bank-conflict free.
+template <int HD>
+__global__ __launch_bounds__(256) void mha_tile_kernel(const float* __restrict__ qkv, int ld,
+                                                       float* __restrict__ out, int ldo, int L, int Lq, int d,
+                                                       float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int KS = HD + 1;
+  float* Qs = smem;                 // [Lq][HD]   (pre-scaled)
+  float* Ks = Qs + Lq * HD;         // [L][HD+1]
+  float* Vs = Ks + L * KS;          // [L][HD]
+  float* Ss = Vs + L * HD;          // [Lq][L+1]
+  float* inv = Ss + Lq * (L + 1);   // [Lq]
+  const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const int SS = L + 1;
+  const float* base = qkv + (long long)b * L * ld + h * HD;
+  for (int idx = t; idx < L * (HD / 4); idx += 256) {
+    const int j = idx / (HD / 4), c = idx - j * (HD / 4);
+    const f32x4 kk = *(const f32x4*)(base + (long long)j * ld + d + 4 * c);
+    const f32x4 vv = *(const f32x4*)(base + (long long)j * ld + 2 * d + 4 * c);
+    Ks[j * KS + 4 * c] = kk[0];
+    Ks[j * KS + 4 * c + 1] = kk[1];
+    Ks[j * KS + 4 * c + 2] = kk[2];
+    Ks[j * KS + 4 * c + 3] = kk[3];
+    *(f32x4*)(Vs + j * HD + 4 * c) = vv;
+    if (j >= L - Lq) {
+      const f32x4 qq = *(const f32x4*)(base + (long long)j * ld + 4 * c) * scale;
+      *(f32x4*)(Qs + (j - (L - Lq)) * HD + 4 * c) = qq;
+    }
+  }
+  __syncthreads();
+  // scores: thread -> (query i, key j); lanes run over j (distinct padded K rows), Q row broadcast
+  for (int e = t; e < Lq * L; e += 256) {
+    const int i = e / L, j = e - i * L;
+    const float* qr = Qs + i * HD;
+    const float* kr = Ks + j * KS;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) s = fmaf(qr[c], kr[c], s);
+    Ss[i * SS + j] = s;
+  }
+  __syncthreads();
+  // row softmax (max, exp, sum) -- 4 lanes per row
+  for (int i = t >> 2; i < Lq; i += 64) {
+    const int sub = t & 3;
+    float* row = Ss + i * SS;
+    float mx = -INFINITY;
+    for (int j = sub; j < L; j += 4) mx = fmaxf(mx, row[j]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    float sum = 0.f;
+    for (int j = sub; j < L; j += 4) {
+      const float p = expf(row[j] - mx);
+      row[j] = p;
+      sum += p;
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    if (sub == 0) inv[i] = 1.0f / sum;
+  }
+  __syncthreads();
+  // O = P V: thread -> (query i, channel c); lanes run over c (contiguous V), P broadcast
+  for (int e = t; e < Lq * HD; e += 256) {
+    const int i = e / HD, c = e - i * HD;
+    const float* pr = Ss + i * SS;
+    float acc = 0.f;
+    for (int j = 0; j < L; ++j) acc = fmaf(pr[j], Vs[j * HD + c], acc);
+    out[((long long)b * Lq + i) * ldo + h * HD + c] = acc * inv[i];
+  }
+}
+
 int sf_mha_ex(const float* qkv, float* out, int B, int L, int Lq, int d, int nheads, hipStream_t st) {
   if (B <= 0 || L <= 0) return 0;
   SF_REQUIRE(nheads > 0 && d % nheads == 0, "d_model must be divisible by num_heads");
@@ -105,18 +177,35 @@ int sf_mha_ex(const float* qkv, float* out, int B, int L, int Lq, int d, int nhe
   SF_REQUIRE(hd == 16 || hd == 32 || hd == 48 || hd == 64, "head_dim must be 16/32/48/64");
   SF_REQUIRE(Lq >= 1 && Lq <= L && L <= 512, "bad sequence length");
   const float scale = 1.0f / sqrtf((float)hd);
-  const size_t lds = (size_t)2 * L * hd * sizeof(float);
-  SF_REQUIRE(lds <= 64 * 1024, "sequence too long for the short-sequence attention kernel");
-  dim3 grid(nheads, B), block(Lq <= 64 ? 64 : 128);
+  dim3 grid(nheads, B);
+  const size_t lds_tile = ((size_t)Lq * hd + (size_t)L * (hd + 1) + (size_t)L * hd + (size_t)Lq * (L + 1) + Lq) *
+                          sizeof(float);
+  sf_prof_begin(SF_K_MHA, st, 4.0 * (double)B * nheads * Lq * L * hd);
+  if (lds_tile <= 64 * 1024) {
+#define MHA_LAUNCH(HD) \
+  hipLaunchKernelGGL(mha_tile_kernel<HD>, grid, dim3(256), lds_tile, st, qkv, 3 * d, out, d, L, Lq, d, scale)
+    switch (hd) {
+      case 16: MHA_LAUNCH(16); break;
+      case 32: MHA_LAUNCH(32); break;
+      case 48: MHA_LAUNCH(48); break;
+      default: MHA_LAUNCH(64); break;
+    }
+#undef MHA_LAUNCH
+  } else {
+    const size_t lds = (size_t)2 * L * hd * sizeof(float);
+    SF_REQUIRE(lds <= 64 * 1024, "sequence too long for the short-sequence attention kernels");
+    dim3 block(Lq <= 64 ? 64 : 128);
 #define MHA_LAUNCH(HD) \
   hipLaunchKernelGGL(mha_small_kernel<HD>, grid, block, lds, st, qkv, 3 * d, out, d, L, Lq, d, scale)
-  switch (hd) {
-    case 16: MHA_LAUNCH(16); break;
-    case 32: MHA_LAUNCH(32); break;
-    case 48: MHA_LAUNCH(48); break;
-    default: MHA_LAUNCH(64); break;
-  }
+    switch (hd) {
+      case 16: MHA_LAUNCH(16); break;
+      case 32: MHA_LAUNCH(32); break;
+      case 48: MHA_LAUNCH(48); break;
+      default: MHA_LAUNCH(64); break;
+    }
 #undef MHA_LAUNCH
+  }
+  sf_prof_end(SF_K_MHA, st);
   SF_CHECK_LAUNCH();
   return 0;
 }

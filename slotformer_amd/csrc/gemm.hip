@@ -12,7 +12,9 @@
 // Replaces the ATen/cuDNN call sites of SURVEY.md 2.3: conv2d (savi.py:230-240),
 // per-pixel MLP (savi.py:245-250, 372-375), K/V projection (savi.py:66-70) and
 // every nn.Linear of the rollout Transformer (slotformer.py:115-121).
-#include "sf_common.h"
+#include <stdlib.h>
+
+#include "sf_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -40,12 +42,15 @@ struct SfGemmArgs {
   long long cFrameStride;
 };
 
-template <int BM, int BN, int WM, int WN, int KW, int ALOAD, bool LN>
+// BKT: k-chunk staged per barrier; KW waves split each chunk; PD: prefetch distance in chunks
+// (PD = 2 keeps two chunks of global loads in flight behind the one being computed).
+template <int BM, int BN, int WM, int WN, int KW, int BKT, int PD, int NBUF, int ALOAD, bool LN>
 __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
   constexpr int NT = 256;
   static_assert(WM * WN * KW * 64 == NT, "4 waves");
+  static_assert(BKT % (8 * KW) == 0 && (PD == 1 || PD == 2) && (NBUF == 2 || (NBUF == 1 && PD == 1)), "bad chunking");
   constexpr int RM = BM / (32 * WM), RN = BN / (32 * WN);
-  constexpr int BKT = 32 * KW;
+  constexpr int NKB = BKT / (8 * KW);  // 8-wide k blocks per wave per chunk
   constexpr int LSTR = BKT + 4;
   constexpr int C4N = BKT / 4;
   constexpr int RS = NT / C4N;
@@ -59,38 +64,13 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
-  float* Bs = smem + 2 * BM * LSTR;
-  float* stats = Bs + 2 * BN * LSTR;
+  float* Bs = smem + NBUF * BM * LSTR;
+  float* stats = Bs + NBUF * BN * LSTR;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wk = wave % KW, wn = (wave / KW) % WN, wm = wave / (KW * WN);
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int M = p.M, N = p.N, K = p.K;
-
-  // ---- LayerNorm statistics for this tile's rows --------------------------------
-  if constexpr (LN) {
-    for (int r = wave; r < BM; r += NT / 64) {
-      const int m = m0 + r;
-      float mean = 0.f, rstd = 0.f;
-      if (m < M) {
-        const float* rowp = p.A + sf_row_off(p.amap, m);
-        float s = 0.f;
-        for (int k = lane; k < K; k += 64) s += rowp[k];
-        mean = sf_wave_sum(s) / (float)K;
-        float v = 0.f;
-        for (int k = lane; k < K; k += 64) {
-          const float d = rowp[k] - mean;
-          v += d * d;
-        }
-        rstd = 1.0f / sqrtf(sf_wave_sum(v) / (float)K + p.ln_eps);
-      }
-      if (lane == 0) {
-        stats[r] = mean;
-        stats[BM + r] = rstd;
-      }
-    }
-    __syncthreads();
-  }
 
   // ---- per-thread loader state ---------------------------------------------------
   const int c4 = t % C4N, r0 = t / C4N;     // vector loader
@@ -130,10 +110,17 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
     }
   }
 
-  f32x4 ra[SCALAR ? 1 : A_IT], rb[SCALAR ? 1 : B_IT];
-  float sa[SCALAR ? A_SC : 1], sb[SCALAR ? B_SC : 1];
+  struct Regs {
+    f32x4 ra[SCALAR ? 1 : A_IT], rb[SCALAR ? 1 : B_IT];
+    float sa[SCALAR ? A_SC : 1], sb[SCALAR ? B_SC : 1];
+  };
+  Regs R0, R1;
 
-  auto load_tiles = [&](int kc) {
+  auto load_tiles = [&](int kc, Regs& R) {
+    f32x4(&ra)[SCALAR ? 1 : A_IT] = R.ra;
+    f32x4(&rb)[SCALAR ? 1 : B_IT] = R.rb;
+    float(&sa)[SCALAR ? A_SC : 1] = R.sa;
+    float(&sb)[SCALAR ? B_SC : 1] = R.sb;
     if constexpr (!SCALAR) {
       const int k = kc * BKT + 4 * c4;
       const bool kok = k < K;
@@ -180,7 +167,11 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
     }
   };
 
-  auto store_tiles = [&](int buf, int kc) {
+  auto store_tiles = [&](int buf, int kc, Regs& R) {
+    f32x4(&ra)[SCALAR ? 1 : A_IT] = R.ra;
+    f32x4(&rb)[SCALAR ? 1 : B_IT] = R.rb;
+    float(&sa)[SCALAR ? A_SC : 1] = R.sa;
+    float(&sb)[SCALAR ? B_SC : 1] = R.sb;
     float* as = As + buf * BM * LSTR;
     float* bs = Bs + buf * BN * LSTR;
     if constexpr (!SCALAR) {
@@ -225,18 +216,13 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (K + BKT - 1) / BKT;
-  load_tiles(0);
-  store_tiles(0, 0);
-  __syncthreads();
-  const int a_off = (wm * RM * 32 + (lane & 31)) * LSTR + wk * 32 + 4 * (lane >> 5);
-  const int b_off = (wn * RN * 32 + (lane & 31)) * LSTR + wk * 32 + 4 * (lane >> 5);
-  for (int kc = 0; kc < nk; ++kc) {
-    const bool has_next = kc + 1 < nk;
-    if (has_next) load_tiles(kc + 1);
-    const float* as = As + (kc & 1) * BM * LSTR + a_off;
-    const float* bs = Bs + (kc & 1) * BN * LSTR + b_off;
+  const int a_off = (wm * RM * 32 + (lane & 31)) * LSTR + wk * (NKB * 8) + 4 * (lane >> 5);
+  const int b_off = (wn * RN * 32 + (lane & 31)) * LSTR + wk * (NKB * 8) + 4 * (lane >> 5);
+  auto compute = [&](int buf) {
+    const float* as = As + buf * BM * LSTR + a_off;
+    const float* bs = Bs + buf * BN * LSTR + b_off;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
       f32x4 a[RM], b[RN];
 #pragma unroll
       for (int i = 0; i < RM; ++i) a[i] = *(const f32x4*)(as + i * 32 * LSTR + kb * 8);
@@ -250,8 +236,86 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
           for (int j = 0; j < RN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     }
-    if (has_next) store_tiles((kc + 1) & 1, kc + 1);
+  };
+  // first chunk(s) are requested BEFORE the LayerNorm statistics pass so that pass does not add a
+  // serial memory round trip in front of the main loop
+  load_tiles(0, R0);
+  if constexpr (PD == 2) {
+    if (nk > 1) load_tiles(1, R1);
+  }
+  // ---- LayerNorm statistics for this tile's rows --------------------------------
+  // NT/BM threads per row, every load of a pass independent (in flight together); the serial
+  // per-row version this replaces cost ~30 us per launch in dependent L2 round trips.
+  if constexpr (LN) {
+    constexpr int TPR = NT / BM;
+    const int r = t / TPR, sub = t % TPR;
+    const int m = m0 + r;
+    const float* rowp = (m < M) ? p.A + sf_row_off(p.amap, m) : nullptr;
+    float s = 0.f;
+    if (rowp) {
+#pragma unroll 4
+      for (int k = sub * 4; k < K; k += TPR * 4) {
+        const f32x4 v = *(const f32x4*)(rowp + k);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+    }
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)K;
+    float vs = 0.f;
+    if (rowp) {
+#pragma unroll 4
+      for (int k = sub * 4; k < K; k += TPR * 4) {
+        const f32x4 v = *(const f32x4*)(rowp + k) - mean;
+        vs += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+      }
+    }
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) vs += __shfl_xor(vs, o, 64);
+    if (sub == 0) {
+      stats[r] = mean;
+      stats[BM + r] = 1.0f / sqrtf(vs / (float)K + p.ln_eps);
+    }
     __syncthreads();
+  }
+
+  if constexpr (PD == 1 && NBUF == 2) {
+    store_tiles(0, 0, R0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+      const bool has_next = kc + 1 < nk;
+      if (has_next) load_tiles(kc + 1, R0);
+      compute(kc & 1);
+      if (has_next) store_tiles((kc + 1) & 1, kc + 1, R0);
+      __syncthreads();
+    }
+  } else if constexpr (PD == 1) {  // one LDS buffer holding a wide chunk (whole K when nk == 1)
+    store_tiles(0, 0, R0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+      const bool has_next = kc + 1 < nk;
+      if (has_next) load_tiles(kc + 1, R0);
+      compute(0);
+      if (has_next) {
+        __syncthreads();
+        store_tiles(0, kc + 1, R0);
+      }
+      __syncthreads();
+    }
+  } else {
+    store_tiles(0, 0, R0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; kc += 2) {
+      if (kc + 2 < nk) load_tiles(kc + 2, R0);
+      compute(0);
+      if (kc + 1 < nk) store_tiles(1, kc + 1, R1);
+      __syncthreads();
+      if (kc + 1 >= nk) break;
+      if (kc + 3 < nk) load_tiles(kc + 3, R1);
+      compute(1);
+      if (kc + 2 < nk) store_tiles(0, kc + 2, R0);
+      __syncthreads();
+    }
   }
 
   // ---- split-K (across waves) reduction through LDS ------------------------------------
@@ -305,11 +369,14 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int KW, int ALOAD, bool LN>
+template <int BM, int BN, int WM, int WN, int KW, int BKT, int PD, int NBUF, int ALOAD, bool LN>
 static int launch_cfg(const SfGemmArgs& a, hipStream_t stream) {
-  constexpr int BKT = 32 * KW, LSTR = BKT + 4;
-  constexpr size_t lds = (size_t)(2 * (BM + BN) * LSTR + 2 * BM) * sizeof(float);
-  auto kern = sf_gemm_kernel<BM, BN, WM, WN, KW, ALOAD, LN>;
+  constexpr int LSTR = BKT + 4;
+  constexpr size_t lds_main = (size_t)(NBUF * (BM + BN) * LSTR + 2 * BM) * sizeof(float);
+  constexpr size_t lds_red = (size_t)(KW - 1) * BM * BN * sizeof(float);
+  constexpr size_t lds = lds_main > lds_red ? lds_main : lds_red;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = sf_gemm_kernel<BM, BN, WM, WN, KW, BKT, PD, NBUF, ALOAD, LN>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -318,9 +385,47 @@ static int launch_cfg(const SfGemmArgs& a, hipStream_t stream) {
     attr_set = true;
   }
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
+  const int cls = ALOAD == ALOAD_PLAIN ? SF_K_LINEAR : (ALOAD == ALOAD_CONV_NHWC ? SF_K_CONV_NHWC : SF_K_CONV_FIRST);
+  sf_prof_begin(cls, stream, 2.0 * (double)a.M * (double)a.N * (double)a.K);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+  sf_prof_end(cls, stream);
   SF_CHECK_LAUNCH();
   return 0;
+}
+
+// tuning override (tools/gemm_bench.py): SF_GEMM_CFG=<id> forces a tile configuration
+static int forced_cfg() {
+  const char* e = getenv("SF_GEMM_CFG");
+  return e ? atoi(e) : -1;
+}
+
+template <int ALOAD, bool LN>
+static int launch_by_id(int id, const SfGemmArgs& a, hipStream_t st) {
+  switch (id) {
+    case 0: return launch_cfg<128, 128, 2, 2, 1, 32, 1, 2, ALOAD, LN>(a, st);
+    case 1: return launch_cfg<128, 64, 4, 1, 1, 32, 1, 2, ALOAD, LN>(a, st);
+    case 2: return launch_cfg<64, 64, 2, 2, 1, 32, 1, 2, ALOAD, LN>(a, st);
+    case 3: return launch_cfg<32, 32, 1, 1, 4, 128, 1, 2, ALOAD, LN>(a, st);
+    case 4: return launch_cfg<32, 64, 1, 2, 2, 64, 1, 2, ALOAD, LN>(a, st);
+    case 5: return launch_cfg<64, 64, 2, 2, 1, 64, 2, 2, ALOAD, LN>(a, st);
+    case 6: return launch_cfg<64, 64, 2, 2, 1, 128, 2, 2, ALOAD, LN>(a, st);
+    case 7: return launch_cfg<32, 32, 1, 1, 4, 128, 2, 2, ALOAD, LN>(a, st);
+    case 8: return launch_cfg<32, 32, 1, 1, 4, 256, 2, 2, ALOAD, LN>(a, st);
+    case 9: return launch_cfg<32, 64, 1, 2, 2, 128, 2, 2, ALOAD, LN>(a, st);
+    case 10: return launch_cfg<128, 64, 4, 1, 1, 64, 2, 2, ALOAD, LN>(a, st);
+    case 11: return launch_cfg<128, 128, 2, 2, 1, 64, 2, 2, ALOAD, LN>(a, st);
+    case 12: return launch_cfg<64, 32, 2, 1, 2, 128, 2, 2, ALOAD, LN>(a, st);
+    case 13: return launch_cfg<128, 64, 4, 1, 1, 32, 2, 2, ALOAD, LN>(a, st);
+    case 14: return launch_cfg<64, 64, 2, 2, 1, 64, 1, 2, ALOAD, LN>(a, st);
+    case 15: return launch_cfg<64, 128, 1, 4, 1, 64, 2, 2, ALOAD, LN>(a, st);
+    case 16: return launch_cfg<64, 64, 2, 2, 1, 256, 1, 1, ALOAD, LN>(a, st);
+    case 17: return launch_cfg<32, 32, 1, 1, 4, 512, 1, 1, ALOAD, LN>(a, st);
+    case 18: return launch_cfg<32, 64, 1, 2, 2, 256, 1, 1, ALOAD, LN>(a, st);
+    case 19: return launch_cfg<64, 64, 2, 2, 1, 128, 1, 1, ALOAD, LN>(a, st);
+    case 20: return launch_cfg<64, 32, 2, 1, 2, 256, 1, 1, ALOAD, LN>(a, st);
+    case 21: return launch_cfg<32, 32, 1, 1, 4, 256, 1, 1, ALOAD, LN>(a, st);
+    default: return sf_set_err(-1, "unknown SF_GEMM_CFG id", __FILE__, __LINE__);
+  }
 }
 
 template <int ALOAD, bool LN>
@@ -328,14 +433,22 @@ static int dispatch_tiles(const SfGemmArgs& a, hipStream_t stream) {
   auto tiles = [&](int bm, int bn) {
     return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
   };
-  if constexpr (ALOAD != ALOAD_PLAIN) {
-    return launch_cfg<128, 64, 4, 1, 1, ALOAD, false>(a, stream);
+  if constexpr (ALOAD == ALOAD_CONV_NCHW) {
+    return launch_cfg<128, 64, 4, 1, 1, 32, 1, 2, ALOAD, false>(a, stream);
   } else {
-    if (a.N > 64 && tiles(128, 128) >= 384) return launch_cfg<128, 128, 2, 2, 1, ALOAD, LN>(a, stream);
-    if (tiles(128, 64) >= 384) return launch_cfg<128, 64, 4, 1, 1, ALOAD, LN>(a, stream);
-    if (tiles(64, 64) >= 192) return launch_cfg<64, 64, 2, 2, 1, ALOAD, LN>(a, stream);
-    if (a.K >= 512 || tiles(32, 64) < 128) return launch_cfg<32, 32, 1, 1, 4, ALOAD, LN>(a, stream);
-    return launch_cfg<32, 64, 1, 2, 2, ALOAD, LN>(a, stream);
+    const int f = forced_cfg();
+    if (f >= 0) return launch_by_id<ALOAD, LN>(f, a, stream);
+    // choices below come from tools/gemm_bench.py on MI355X (profiles/r01_gemm_configs.txt)
+    if constexpr (ALOAD == ALOAD_CONV_NHWC) {
+      return launch_by_id<ALOAD, LN>(13, a, stream);
+    } else {
+      if (a.N > 64 && tiles(128, 128) >= 384) return launch_by_id<ALOAD, LN>(0, a, stream);
+      if (tiles(128, 64) >= 384) return launch_by_id<ALOAD, LN>(1, a, stream);
+      // small-M regime (rollout / slot-level GEMMs): latency-bound, favour many small workgroups
+      if (a.K >= 512) return launch_by_id<ALOAD, LN>(7, a, stream);
+      if (tiles(32, 64) >= 256) return launch_by_id<ALOAD, LN>(4, a, stream);
+      return launch_by_id<ALOAD, LN>(3, a, stream);
+    }
   }
 }
 

@@ -18,3 +18,9 @@ int sf_sa_pick_partials(int HW);
 int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch_stride, const float* q,
                          float* part_num, float* part_den, float* attn_out, long long attn_batch_stride, int B,
                          int HW, int N, int D, float scale, float eps, hipStream_t st);
+
+// kernel classes for the optional HIP-event timer (sf_runtime.cpp)
+enum { SF_K_CONV_NHWC = 0, SF_K_CONV_FIRST = 1, SF_K_LINEAR = 2, SF_K_SA_ITER = 3, SF_K_SA_UPDATE = 4,
+       SF_K_MHA = 5, SF_K_NUM = 6 };
+void sf_prof_begin(int cls, hipStream_t st, double work);
+void sf_prof_end(int cls, hipStream_t st);

@@ -1,0 +1,75 @@
+// Runtime bits of libslotformer_hip.so: error string, version, and the optional per-kernel-class
+// HIP-event timer used by bench.py for the roofline object (events are recorded on the stream the
+// kernel is launched on; nothing is recorded while the stream is being captured into a hipGraph).
+#include <mutex>
+#include <vector>
+
+#include "sf_internal.h"
+
+thread_local char sf_err_buf[512] = "";
+
+namespace {
+struct Rec {
+  hipEvent_t a, b;
+  double work;
+};
+std::mutex g_mu;
+unsigned g_mask = 0;
+std::vector<Rec> g_recs[SF_K_NUM];
+thread_local hipEvent_t t_pending = nullptr;
+}  // namespace
+
+void sf_prof_begin(int cls, hipStream_t st, double work) {
+  if (cls < 0 || cls >= SF_K_NUM || !(g_mask & (1u << cls))) return;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
+  Rec r;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  r.work = work;
+  hipEventRecord(r.a, st);
+  t_pending = r.b;
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_recs[cls].push_back(r);
+}
+
+void sf_prof_end(int cls, hipStream_t st) {
+  if (!t_pending) return;
+  hipEventRecord(t_pending, st);
+  t_pending = nullptr;
+}
+
+extern "C" {
+
+int sf_version(void) { return 101; }
+const char* sf_last_error_string(void) { return sf_err_buf; }
+
+int sf_profile_enable(int class_mask) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_mask = (unsigned)class_mask;
+  return 0;
+}
+
+// Sum of elapsed ms / launches / caller-declared algorithmic work of one kernel class since the
+// last read; synchronises on the recorded events and clears them.
+int sf_profile_read(int cls, double* total_ms, long long* launches, double* work) {
+  SF_REQUIRE(cls >= 0 && cls < SF_K_NUM && total_ms && launches && work, "bad profile class");
+  std::vector<Rec> recs;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    recs.swap(g_recs[cls]);
+  }
+  double ms = 0, w = 0;
+  for (auto& r : recs) {
+    float e = 0.f;
+    hipEventSynchronize(r.b);
+    if (hipEventElapsedTime(&e, r.a, r.b) == hipSuccess) ms += e;
+    w += r.work;
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  *total_ms = ms;
+  *launches = (long long)recs.size();
+  *work = w;
+  return 0;
+}
+}

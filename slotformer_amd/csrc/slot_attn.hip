@@ -8,9 +8,9 @@
 // D channels (D/64 consecutive floats per lane, fully coalesced 512/768 B rows), the slot
 // queries live in registers, the per-pixel softmax is wave-uniform.
 //
-// Kernel 2 (fused wavefront slot update): reduce the partials, GRUCell (gate order r,z,n),
-// residual LayerNorm-MLP.  One workgroup per (batch, slot) row; each output feature is one
-// wave-wide dot product against a row of the torch-layout weight matrix.
+// Kernel 2 (fused slot update): reduce the partials, GRUCell (gate order r,z,n), residual
+// LayerNorm-MLP.  One workgroup per (batch, slot) row, one thread per output feature, weights
+// pre-transposed to [in, out] so the k-loop is a stream of independent coalesced loads.
 #include "sf_internal.h"
 
 #define SA_NMAX 8
@@ -141,19 +141,31 @@ __global__ __launch_bounds__(256) void sa_attn_partial_kernel(
 }
 
 // -----------------------------------------------------------------------------------------
-// wave-wide dot product of a weight row with an LDS vector
-__device__ __forceinline__ float wave_dot(const float* __restrict__ w, const float* x, int K, int lane) {
+// Fused slot update.  One workgroup per (batch, slot) row, ONE THREAD PER OUTPUT FEATURE: the
+// weights are stored transposed ([in, out]) so consecutive threads read consecutive addresses
+// and every load of the k-loop is independent (deep unroll keeps them in flight); the input
+// vector is broadcast from LDS.  No cross-lane reductions at all.
+template <int UNR>
+__device__ __forceinline__ float col_dot(const float* __restrict__ wt, int ldw, int col, const float* x, int K) {
   float acc = 0.f;
-  for (int k = lane; k < K; k += 64) acc = fmaf(w[k], x[k], acc);
-  return sf_wave_sum(acc);
+  int k = 0;
+  for (; k + UNR <= K; k += UNR) {
+    float w[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) w[u] = wt[(long long)(k + u) * ldw + col];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) acc = fmaf(w[u], x[k + u], acc);
+  }
+  for (; k < K; ++k) acc = fmaf(wt[(long long)k * ldw + col], x[k], acc);
+  return acc;
 }
 
-__global__ __launch_bounds__(256) void sa_slot_update_kernel(
+__global__ __launch_bounds__(768) void sa_slot_update_kernel(
     const float* __restrict__ part_num, const float* __restrict__ part_den, int P,
-    const float* __restrict__ slots_prev, const float* __restrict__ w_ih,
-    const float* __restrict__ w_hh, const float* __restrict__ b_ih, const float* __restrict__ b_hh,
-    const float* __restrict__ ln_g, const float* __restrict__ ln_b, const float* __restrict__ w1,
-    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+    const float* __restrict__ slots_prev, const float* __restrict__ w_ih_t,
+    const float* __restrict__ w_hh_t, const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+    const float* __restrict__ ln_g, const float* __restrict__ ln_b, const float* __restrict__ w1_t,
+    const float* __restrict__ b1, const float* __restrict__ w2_t, const float* __restrict__ b2,
     float* __restrict__ slots_out, int N, int D, int H, float ln_eps) {
   const int row = blockIdx.x;  // b * N + n
   const int b = row / N, n = row - b * N;
@@ -162,30 +174,27 @@ __global__ __launch_bounds__(256) void sa_slot_update_kernel(
   __shared__ float s_hn[SA_DMAX], s_ln[SA_DMAX], s_hid[SA_HMAX], s_stat[2];
 
   // updates = sum_p num / sum_p den
-  float den = 0.f;
-  for (int p = 0; p < P; ++p) den += part_den[((long long)b * P + p) * N + n];
-  for (int d = t; d < D; d += 256) {
-    float a = 0.f;
-    for (int p = 0; p < P; ++p) a += part_num[(((long long)b * P + p) * N + n) * D + d];
-    s_u[d] = a / den;
-    s_h[d] = slots_prev[(long long)row * D + d];
-  }
-  __syncthreads();
-  // GRU gate pre-activations
-  for (int j = wave; j < 3 * D; j += 4) {
-    const float gi = wave_dot(w_ih + (long long)j * D, s_u, D, lane);
-    const float gh = wave_dot(w_hh + (long long)j * D, s_h, D, lane);
-    if (lane == 0) {
-      s_gi[j] = gi + b_ih[j];
-      s_gh[j] = gh + b_hh[j];
+  if (t < D) {
+    float den = 0.f, a = 0.f;
+    for (int p = 0; p < P; ++p) {
+      den += part_den[((long long)b * P + p) * N + n];
+      a += part_num[(((long long)b * P + p) * N + n) * D + t];
     }
+    s_u[t] = a / den;
+    s_h[t] = slots_prev[(long long)row * D + t];
   }
   __syncthreads();
-  for (int d = t; d < D; d += 256) {
-    const float r = sf_sigmoid(s_gi[d] + s_gh[d]);
-    const float z = sf_sigmoid(s_gi[D + d] + s_gh[D + d]);
-    const float nn = tanhf(s_gi[2 * D + d] + r * s_gh[2 * D + d]);
-    s_hn[d] = (1.f - z) * nn + z * s_h[d];
+  // GRU gate pre-activations: thread j owns gate feature j of both matrices
+  if (t < 3 * D) {
+    s_gi[t] = col_dot<8>(w_ih_t, 3 * D, t, s_u, D) + b_ih[t];
+    s_gh[t] = col_dot<8>(w_hh_t, 3 * D, t, s_h, D) + b_hh[t];
+  }
+  __syncthreads();
+  if (t < D) {
+    const float r = sf_sigmoid(s_gi[t] + s_gh[t]);
+    const float z = sf_sigmoid(s_gi[D + t] + s_gh[D + t]);
+    const float nn = tanhf(s_gi[2 * D + t] + r * s_gh[2 * D + t]);
+    s_hn[t] = (1.f - z) * nn + z * s_h[t];
   }
   __syncthreads();
   // LayerNorm(h')
@@ -205,17 +214,11 @@ __global__ __launch_bounds__(256) void sa_slot_update_kernel(
     }
   }
   __syncthreads();
-  for (int d = t; d < D; d += 256) s_ln[d] = (s_hn[d] - s_stat[0]) * s_stat[1] * ln_g[d] + ln_b[d];
+  if (t < D) s_ln[t] = (s_hn[t] - s_stat[0]) * s_stat[1] * ln_g[t] + ln_b[t];
   __syncthreads();
-  for (int j = wave; j < H; j += 4) {
-    const float a = wave_dot(w1 + (long long)j * D, s_ln, D, lane);
-    if (lane == 0) s_hid[j] = fmaxf(a + b1[j], 0.f);
-  }
+  if (t < H) s_hid[t] = fmaxf(col_dot<8>(w1_t, H, t, s_ln, D) + b1[t], 0.f);
   __syncthreads();
-  for (int j = wave; j < D; j += 4) {
-    const float a = wave_dot(w2 + (long long)j * H, s_hid, H, lane);
-    if (lane == 0) slots_out[(long long)row * D + j] = s_hn[j] + a + b2[j];
-  }
+  if (t < D) slots_out[(long long)row * D + t] = s_hn[t] + col_dot<8>(w2_t, D, t, s_hid, H) + b2[t];
 }
 
 // -----------------------------------------------------------------------------------------
@@ -259,6 +262,8 @@ int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch
 #define SA_LAUNCH(VPT)                                                                            \
   hipLaunchKernelGGL(sa_attn_partial_kernel<VPT>, grid, block, 0, st, k, v, ld, batch_stride, q, \
                      scale, eps, part_num, part_den, attn_out, attn_batch_stride, HW, N, P)
+  // algorithmic bytes: one read of K and V
+  sf_prof_begin(SF_K_SA_ITER, st, 2.0 * (double)B * HW * D * sizeof(float));
   switch (D / 64) {
     case 1: SA_LAUNCH(1); break;
     case 2: SA_LAUNCH(2); break;
@@ -266,12 +271,14 @@ int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch
     default: SA_LAUNCH(4); break;
   }
 #undef SA_LAUNCH
+  sf_prof_end(SF_K_SA_ITER, st);
   SF_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" {
 // Slot update (savi.py:95-100): reduce partials -> GRUCell -> slots + MLP(LN(slots)).
+// Weight matrices are TRANSPOSED torch weights ([in, out] = weight.t().contiguous()).
 int sf_slot_update_f32(const float* part_num, const float* part_den, int P, const float* slots_prev,
                        const float* gru_w_ih, const float* gru_w_hh, const float* gru_b_ih,
                        const float* gru_b_hh, const float* ln_g, const float* ln_b, const float* mlp_w1,
@@ -282,9 +289,13 @@ int sf_slot_update_f32(const float* part_num, const float* part_den, int P, cons
                  mlp_b2, "null weight pointer");
   SF_REQUIRE(D > 0 && D <= SA_DMAX && H > 0 && H <= SA_HMAX && N >= 1 && P >= 1, "bad slot shape");
   if (B == 0) return 0;
-  hipLaunchKernelGGL(sa_slot_update_kernel, dim3(B * N), dim3(256), 0, (hipStream_t)stream, part_num,
+  sf_prof_begin(SF_K_SA_UPDATE, (hipStream_t)stream, 0.0);
+  int threads = 3 * D > H ? 3 * D : H;
+  threads = (threads + 63) & ~63;
+  hipLaunchKernelGGL(sa_slot_update_kernel, dim3(B * N), dim3(threads), 0, (hipStream_t)stream, part_num,
                      part_den, P, slots_prev, gru_w_ih, gru_w_hh, gru_b_ih, gru_b_hh, ln_g, ln_b, mlp_w1,
                      mlp_b1, mlp_w2, mlp_b2, slots_out, N, D, H, ln_eps);
+  sf_prof_end(SF_K_SA_UPDATE, (hipStream_t)stream);
   SF_CHECK_LAUNCH();
   return 0;
 }

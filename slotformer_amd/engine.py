@@ -16,10 +16,10 @@ from . import ops
 _WORKSPACES = {}
 
 
-def workspace(device, nbytes):
-    """Grow-only per-device scratch buffer (never freed behind a running graph: buffers are
-    replaced, old ones stay alive while any captured graph references them via `keep`)."""
-    key = (device.type, device.index)
+def workspace(device, nbytes, slot=0):
+    """Grow-only per-(device, slot) scratch buffer.  Calls that may run concurrently on different
+    streams must use different slots."""
+    key = (device.type, device.index, slot)
     cur = _WORKSPACES.get(key)
     if cur is None or cur.numel() < nbytes:
         cur = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -106,7 +106,7 @@ def rollouter_plan(r):
     return plan
 
 
-def rollout(r, slots_all, n_in, pred_len):
+def rollout(r, slots_all, n_in, pred_len, ws_slot=0):
     """In-place autoregressive rollout.  slots_all [B, T_total, N, C] float32 contiguous on device;
     frames [0, n_in) hold the burn-in; frames [n_in, n_in+pred_len) are written."""
     _require_inference(r, slots_all)
@@ -114,7 +114,7 @@ def rollout(r, slots_all, n_in, pred_len):
     plan = rollouter_plan(r)
     B, T_total = slots_all.shape[:2]
     need = lib().sf_rollout_workspace_bytes(C.byref(plan.struct), B)
-    ws = workspace(slots_all.device, need)
+    ws = workspace(slots_all.device, need, ('roll', ws_slot))
     check(lib().sf_rollout_f32(C.byref(plan.struct), slots_all.data_ptr(), B, T_total, pred_len, ws.data_ptr(),
                                ws.numel(), torch.cuda.current_stream().cuda_stream))
     return slots_all
@@ -160,11 +160,12 @@ def encoder_plan(m):
     s.sa_q_ln_g, s.sa_q_ln_b = plan.dp(sa.project_q[0].weight), plan.dp(sa.project_q[0].bias)
     s.sa_q_w = plan.dp(sa.project_q[1].weight)
     s.sa_kv_w = plan.dp(torch.cat([sa.project_k.weight.detach(), sa.project_v.weight.detach()], 0).contiguous())
-    s.gru_w_ih, s.gru_w_hh = plan.dp(sa.gru.weight_ih), plan.dp(sa.gru.weight_hh)
+    tr = lambda w: w.detach().float().t().contiguous()  # noqa: E731  ([in, out] layout for the slot-update kernel)
+    s.gru_w_ih, s.gru_w_hh = plan.dp(tr(sa.gru.weight_ih)), plan.dp(tr(sa.gru.weight_hh))
     s.gru_b_ih, s.gru_b_hh = plan.dp(sa.gru.bias_ih), plan.dp(sa.gru.bias_hh)
     s.mlp_ln_g, s.mlp_ln_b = plan.dp(sa.mlp[0].weight), plan.dp(sa.mlp[0].bias)
-    s.mlp_w1, s.mlp_b1 = plan.dp(sa.mlp[1].weight), plan.dp(sa.mlp[1].bias)
-    s.mlp_w2, s.mlp_b2 = plan.dp(sa.mlp[3].weight), plan.dp(sa.mlp[3].bias)
+    s.mlp_w1, s.mlp_b1 = plan.dp(tr(sa.mlp[1].weight)), plan.dp(sa.mlp[1].bias)
+    s.mlp_w2, s.mlp_b2 = plan.dp(tr(sa.mlp[3].weight)), plan.dp(sa.mlp[3].bias)
     s.init_latents = plan.dp(m.init_latents.detach()[0])
     s.sa_eps = float(sa.eps)
     kd = getattr(m, 'kernel_dist_layer', None)
@@ -203,7 +204,7 @@ def encoder_plan(m):
     return plan
 
 
-def savi_encode(m, img, prev_slots=None, noise=None, want_attn=False):
+def savi_encode(m, img, prev_slots=None, noise=None, want_attn=False, ws_slot=0):
     """Run StoSAVi.encode / STEVE.encode on device.
 
     Returns (post_slots [B,T,N,D], kernel_dist [B,T,N,2D] | None, attn [B,T,N,64*64] | None).
@@ -237,7 +238,7 @@ def savi_encode(m, img, prev_slots=None, noise=None, want_attn=False):
         pred.hidden_state = (h, c)
         pred.step += T if prev_slots is not None else T - 1
     need = lib().sf_savi_encode_workspace_bytes(C.byref(plan.struct), B)
-    ws = workspace(dev, need)
+    ws = workspace(dev, need, ('enc', ws_slot))
     P = ops._p
     check(lib().sf_savi_encode_f32(C.byref(plan.struct), img.data_ptr(), P(noise), P(prev_slots), P(h), P(c), valid,
                                    post.data_ptr(), P(kdist), P(attn), B, T, ws.data_ptr(), ws.numel(),

@@ -104,13 +104,14 @@ def slot_attn_iter(k, v, q, eps=1e-6, want_attn=False):
 
 
 def slot_update(pn, pd, slots_prev, gru, ln_g, ln_b, w1, b1, w2, b2, ln_eps=1e-5):
-    """gru = (w_ih, w_hh, b_ih, b_hh)."""
+    """gru = (w_ih, w_hh, b_ih, b_hh); all weights in torch layout (transposed here for the kernel)."""
     _chk(pn, pd, slots_prev, *gru, ln_g, ln_b, w1, b1, w2, b2)
     B, P, N, D = pn.shape
     out = torch.empty_like(slots_prev)
-    check(lib().sf_slot_update_f32(_p(pn), _p(pd), P, _p(slots_prev), *[_p(t) for t in gru], _p(ln_g), _p(ln_b),
-                                   _p(w1), _p(b1), _p(w2), _p(b2), _p(out), B, N, D, w1.shape[0], ln_eps,
-                                   _stream()))
+    w_ih_t, w_hh_t, w1_t, w2_t = (w.t().contiguous() for w in (gru[0], gru[1], w1, w2))
+    check(lib().sf_slot_update_f32(_p(pn), _p(pd), P, _p(slots_prev), _p(w_ih_t), _p(w_hh_t), _p(gru[2]),
+                                   _p(gru[3]), _p(ln_g), _p(ln_b), _p(w1_t), _p(b1), _p(w2_t), _p(b2), _p(out),
+                                   B, N, D, w1.shape[0], ln_eps, _stream()))
     return out
 
 

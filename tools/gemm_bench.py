@@ -1,0 +1,84 @@
+"""Microbenchmark sf_linear_f32 / sf_conv2d_nhwc_f32 tile configurations on the GPU.
+
+    python tools/gemm_bench.py            # rollout + encoder shapes x config ids (SF_GEMM_CFG)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from slotformer_amd import ops  # noqa: E402
+
+dev = torch.device('cuda:0')
+
+
+def timeit(fn, iters=20, reps=5):
+    """Device time per call: capture `iters` back-to-back calls into a hipGraph, time replays."""
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / (iters * reps) * 1e3
+
+
+SHAPES = [  # name, M, N, K, ln
+    ('qkv', 1344, 768, 256, True), ('outp', 1344, 256, 256, False), ('ffn1', 1344, 1024, 256, True),
+    ('ffn2', 1344, 256, 1024, False), ('ffn1_last', 224, 1024, 256, True), ('ffn2_last', 224, 256, 1024, False),
+    ('inproj', 1344, 256, 128, False), ('q_sa', 224, 128, 128, True),
+    ('pix_fc1', 131072, 128, 64, True), ('pix_fc2', 131072, 128, 128, False), ('pix_kv', 131072, 256, 128, True),
+]
+CFGS = {'small': [2, 3, 4, 5, 6, 7, 9, 12, 14, 16, 17, 18, 19, 20, 21], 'big': [0, 1, 10, 11, 13, 15]}
+
+
+def main():
+    for name, M, N, K, ln in SHAPES:
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(N, K, device=dev) * K**-0.5
+        b = torch.randn(N, device=dev)
+        g, be = torch.ones(K, device=dev), torch.zeros(K, device=dev)
+        res = []
+        ref = None
+        for cfg in CFGS['big' if M > 10000 else 'small']:
+            os.environ['SF_GEMM_CFG'] = str(cfg)
+            try:
+                out = ops.linear(x, w, b, ln=(g, be) if ln else None)
+                if ref is None:
+                    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x, (K, )) if ln else x, w, b)
+                err = (out - ref).abs().max().item()
+                t = timeit(lambda: ops.linear(x, w, b, ln=(g, be) if ln else None))
+                res.append((t, cfg, err))
+            except RuntimeError as e:
+                res.append((float('inf'), cfg, str(e)[:40]))
+        res.sort()
+        gf = 2.0 * M * N * K
+        print(f'{name:10s} M={M} N={N} K={K} ln={ln}: ' + '  '.join(f'cfg{c}:{t:.1f}us' for t, c, _ in res) +
+              f'   best {gf / res[0][0] / 1e6:.1f} TF  maxerr {max(e for _, _, e in res if isinstance(e, float)):.1e}')
+    # conv
+    x = torch.randn(32, 64, 64, 64, device=dev)
+    w = ops.pack_conv_weight(torch.randn(64, 64, 5, 5, device=dev) * 0.03)
+    b = torch.randn(64, device=dev)
+    res = []
+    for cfg in [1, 10, 13, 0, 11, 2, 5]:
+        os.environ['SF_GEMM_CFG'] = str(cfg)
+        t = timeit(lambda: ops.conv2d_nhwc(x, w, b), iters=5)
+        res.append((t, cfg))
+    res.sort()
+    gf = 2.0 * 32 * 4096 * 64 * 1600
+    print('conv 32 frames: ' + '  '.join(f'cfg{c}:{t:.0f}us' for t, c in res) + f'   best {gf / res[0][0] / 1e6:.1f} TF')
+    os.environ.pop('SF_GEMM_CFG', None)
+
+
+if __name__ == '__main__':
+    main()
