@@ -73,41 +73,36 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
   const int M = p.M, N = p.N, K = p.K;
 
   // ---- per-thread loader state ---------------------------------------------------
+  // Every global load below is UNCONDITIONAL from a clamped (always valid) address and the value
+  // is zeroed by a select where it matters: a branch around a load makes hipcc drain vmcnt(0)
+  // at the join, which serialises the whole prefetch pipeline.  Rows >= M / >= N only feed
+  // outputs that are never stored, so they need no zeroing at all.
   const int c4 = t % C4N, r0 = t / C4N;     // vector loader
   const int kk = t % BKT, r0s = t / BKT;    // scalar loader
-  const float* arow[SCALAR ? 1 : A_IT];     // plain: row base (or null)
+  const float* arow[SCALAR ? 1 : A_IT];
   int cf[SCALAR ? A_SC : A_IT], cy[SCALAR ? A_SC : A_IT], cx[SCALAR ? A_SC : A_IT];
   if constexpr (ALOAD == ALOAD_PLAIN) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const int m = m0 + r0 + i * RS;
-      arow[i] = (m < M) ? p.A + sf_row_off(p.amap, m) : nullptr;
+      const int m = min(m0 + r0 + i * RS, M - 1);
+      arow[i] = p.A + sf_row_off(p.amap, m);
     }
   } else {
     constexpr int NI = SCALAR ? A_SC : A_IT;
     const int hw = p.cH * p.cW;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int m = m0 + (SCALAR ? (r0s + i * RS_SC) : (r0 + i * RS));
-      if (m < M) {
-        const int f = m / hw, rem = m - f * hw;
-        cf[i] = f;
-        cy[i] = rem / p.cW;
-        cx[i] = rem - cy[i] * p.cW;
-      } else {
-        cf[i] = 0;
-        cy[i] = -100000;
-        cx[i] = 0;
-      }
+      const int m = min(m0 + (SCALAR ? (r0s + i * RS_SC) : (r0 + i * RS)), M - 1);
+      const int f = m / hw, rem = m - f * hw;
+      cf[i] = f;
+      cy[i] = rem / p.cW;
+      cx[i] = rem - cy[i] * p.cW;
     }
   }
   const float* wrow[SCALAR ? 1 : B_IT];
   if constexpr (!SCALAR) {
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const int n = n0 + r0 + i * RS;
-      wrow[i] = (n < N) ? p.W + (long long)n * p.ldw : nullptr;
-    }
+    for (int i = 0; i < B_IT; ++i) wrow[i] = p.W + (long long)min(n0 + r0 + i * RS, N - 1) * p.ldw;
   }
 
   struct Regs {
@@ -121,48 +116,55 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
     f32x4(&rb)[SCALAR ? 1 : B_IT] = R.rb;
     float(&sa)[SCALAR ? A_SC : 1] = R.sa;
     float(&sb)[SCALAR ? B_SC : 1] = R.sb;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (!SCALAR) {
       const int k = kc * BKT + 4 * c4;
       const bool kok = k < K;
+      const int kc4 = kok ? k : 0;
       if constexpr (ALOAD == ALOAD_PLAIN) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-          ra[i] = (kok && arow[i]) ? *(const f32x4*)(arow[i] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+          const f32x4 v = *(const f32x4*)(arow[i] + kc4);
+          ra[i] = kok ? v : zero4;
         }
       } else {  // NHWC im2col: k = tap * Cin + cin
-        const int tap = k / p.cCin, cin = k - tap * p.cCin;
+        const int tap = kc4 / p.cCin, cin = kc4 - tap * p.cCin;
         const int ky = tap / p.cKs, kx = tap - ky * p.cKs, pad = p.cKs >> 1;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
           const int yy = cy[i] + ky - pad, xx = cx[i] + kx - pad;
           const bool ok = kok && (unsigned)yy < (unsigned)p.cInH && (unsigned)xx < (unsigned)p.cInW;
-          const float* src = p.A + (long long)cf[i] * p.cFrameStride +
-                             ((long long)(yy * p.cInW + xx) * p.cCin + cin);
-          ra[i] = ok ? *(const f32x4*)src : f32x4{0.f, 0.f, 0.f, 0.f};
+          const int yc = min(max(yy, 0), p.cInH - 1), xc = min(max(xx, 0), p.cInW - 1);
+          const f32x4 v = *(const f32x4*)(p.A + (long long)cf[i] * p.cFrameStride +
+                                          ((long long)(yc * p.cInW + xc) * p.cCin + cin));
+          ra[i] = ok ? v : zero4;
         }
       }
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
-        rb[i] = (kok && wrow[i]) ? *(const f32x4*)(wrow[i] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 v = *(const f32x4*)(wrow[i] + kc4);
+        rb[i] = kok ? v : zero4;
       }
     } else {  // NCHW image im2col, scalar: k = (c * ks + ky) * ks + kx
       const int k = kc * BKT + kk;
       const bool kok = k < K;
+      const int kcl = kok ? k : 0;
       const int ks2 = p.cKs * p.cKs;
-      const int c = k / ks2, r = k - c * ks2;
+      const int c = kcl / ks2, r = kcl - c * ks2;
       const int ky = r / p.cKs, kx = r - ky * p.cKs, pad = p.cKs >> 1;
 #pragma unroll
       for (int i = 0; i < A_SC; ++i) {
         const int yy = cy[i] * p.cStride + ky - pad, xx = cx[i] * p.cStride + kx - pad;
         const bool ok = kok && (unsigned)yy < (unsigned)p.cInH && (unsigned)xx < (unsigned)p.cInW;
-        const float* src = p.A + (long long)cf[i] * p.cFrameStride +
-                           ((long long)(c * p.cInH + yy) * p.cInW + xx);
-        sa[i] = ok ? *src : 0.f;
+        const int yc = min(max(yy, 0), p.cInH - 1), xc = min(max(xx, 0), p.cInW - 1);
+        const float v = p.A[(long long)cf[i] * p.cFrameStride + ((long long)(c * p.cInH + yc) * p.cInW + xc)];
+        sa[i] = ok ? v : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < B_SC; ++i) {
-        const int n = n0 + r0s + i * RS_SC;
-        sb[i] = (kok && n < N) ? p.W[(long long)n * p.ldw + k] : 0.f;
+        const int n = min(n0 + r0s + i * RS_SC, N - 1);
+        const float v = p.W[(long long)n * p.ldw + kcl];
+        sb[i] = kok ? v : 0.f;
       }
     }
   };
@@ -177,21 +179,20 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
     if constexpr (!SCALAR) {
       if constexpr (LN) {
         const int k = kc * BKT + 4 * c4;
-        if (k < K) {
-          const f32x4 g = *(const f32x4*)(p.ln_g + k);
-          const f32x4 b = *(const f32x4*)(p.ln_b + k);
+        const bool kok = k < K;
+        const f32x4 g = *(const f32x4*)(p.ln_g + (kok ? k : 0));
+        const f32x4 b = *(const f32x4*)(p.ln_b + (kok ? k : 0));
+        const float lo = p.ln_relu ? 0.f : -INFINITY;
 #pragma unroll
-          for (int i = 0; i < A_IT; ++i) {
-            const int r = r0 + i * RS;
-            const float mean = stats[r], rstd = stats[BM + r];
-            ra[i] = (ra[i] - mean) * rstd * g + b;
-            if (p.ln_relu) {
-              ra[i][0] = fmaxf(ra[i][0], 0.f);
-              ra[i][1] = fmaxf(ra[i][1], 0.f);
-              ra[i][2] = fmaxf(ra[i][2], 0.f);
-              ra[i][3] = fmaxf(ra[i][3], 0.f);
-            }
-          }
+        for (int i = 0; i < A_IT; ++i) {
+          const int r = r0 + i * RS;
+          const float mean = stats[r], rstd = stats[BM + r];
+          f32x4 v = (ra[i] - mean) * rstd * g + b;
+          v[0] = fmaxf(v[0], lo);
+          v[1] = fmaxf(v[1], lo);
+          v[2] = fmaxf(v[2], lo);
+          v[3] = fmaxf(v[3], lo);
+          ra[i] = kok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
 #pragma unroll
@@ -249,10 +250,10 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
   if constexpr (LN) {
     constexpr int TPR = NT / BM;
     const int r = t / TPR, sub = t % TPR;
-    const int m = m0 + r;
-    const float* rowp = (m < M) ? p.A + sf_row_off(p.amap, m) : nullptr;
+    const int m = min(m0 + r, M - 1);
+    const float* rowp = p.A + sf_row_off(p.amap, m);
     float s = 0.f;
-    if (rowp) {
+    {
 #pragma unroll 4
       for (int k = sub * 4; k < K; k += TPR * 4) {
         const f32x4 v = *(const f32x4*)(rowp + k);
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
     for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     const float mean = s / (float)K;
     float vs = 0.f;
-    if (rowp) {
+    {
 #pragma unroll 4
       for (int k = sub * 4; k < K; k += TPR * 4) {
         const f32x4 v = *(const f32x4*)(rowp + k) - mean;
@@ -345,24 +346,35 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
   }
 
   // ---- epilogue ----------------------------------------------------------------------
+  // All residual loads of a 32x32 block are issued together from clamped addresses (wave-uniform
+  // branch only); per-element branches here cost one serialized memory round trip each.
 #pragma unroll
   for (int j = 0; j < RN; ++j) {
     const int col = n0 + (wn * RN + j) * 32 + (lane & 31);
-    if (col >= N) continue;
-    const float bias = p.bias ? p.bias[col] : 0.f;
+    const bool colok = col < N;
+    const int colc = colok ? col : N - 1;
+    const float bias = p.bias ? p.bias[colc] : 0.f;
 #pragma unroll
     for (int i = 0; i < RM; ++i) {
+      const int rbase = m0 + (wm * RM + i) * 32 + 4 * (lane >> 5);
+      float rv[16];
+      if (p.res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rowc = min(rbase + (r & 3) + 8 * (r >> 2), M - 1);
+          const int rr = p.res_mod > 0 ? rowc % p.res_mod : rowc;
+          rv[r] = p.res[sf_row_off(p.rmap, rr) + colc];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+      }
+      const float lo = p.relu ? 0.f : -INFINITY;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + (wm * RM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= M) continue;
-        float v = acc[i][j][r] + bias;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.res) {
-          const int rr = p.res_mod > 0 ? row % p.res_mod : row;
-          v += p.res[sf_row_off(p.rmap, rr) + col];
-        }
-        p.C[sf_row_off(p.cmap, row) + col] = v;
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        const float v = fmaxf(acc[i][j][r] + bias, lo) + rv[r];
+        if (row < M && colok) p.C[sf_row_off(p.cmap, row) + col] = v;
       }
     }
   }

@@ -1,0 +1,56 @@
+"""Multi-GPU plumbing for the hot path: one process per GPU, videos sharded on the batch axis,
+weights replicated, NO collective on the data path.  torch.distributed (backend
+"nccl" == RCCL on ROCm; "gloo" in the CPU tests) is used only for the barrier / max-time /
+result gather around the sharded work.
+
+This replaces the reference's nn.DataParallel (per-forward weight broadcast + scatter/gather,
+extract_slots.py:128, rollout_clevrer_slots.py:109) and its manual --split/--total_split job
+sharding (extract_phyre_slots.py:41-53).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced [lo, hi) share of n_items for `rank` (first n%world ranks get one more)."""
+    q, r = divmod(n_items, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def max_over_ranks(seconds, device=None):
+    """Wall time of the slowest rank (the bench's timing rule)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_shards(local, n_items, dst=0):
+    """Gather per-rank result tensors [n_local, ...] (shard_range order) to `dst` -> [n_items, ...]."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_range(n_items, r, world) for r in range(world)]
+    maxn = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((maxn, ) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[:hi - lo] for b, (lo, hi) in zip(bufs, sizes)], 0)
+
+
+def sharded_extract(model, videos, batch_size=1):
+    """H1 across ranks: every rank encodes its contiguous share of the videos; rank 0 gets all slots."""
+    from .harness import extract_video_slots
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    lo, hi = shard_range(len(videos), rank, world)
+    local = extract_video_slots(model, videos[lo:hi], batch_size) if hi > lo else None
+    if local is None:
+        probe = videos[:1]
+        raise RuntimeError(f'rank {rank} has no videos ({len(probe)} probe): use world <= number of videos')
+    return gather_shards(local, len(videos))

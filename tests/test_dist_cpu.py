@@ -1,0 +1,48 @@
+"""CPU, world_size 2 over gloo: the batch-sharded multi-GPU path (no data-path collective)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from slotformer_amd.parallel import shard_range, max_over_ranks, gather_shards
+    n = 7
+    lo, hi = shard_range(n, rank, world)
+    # every rank "processes" its videos independently: result = f(video index), no communication
+    local = torch.stack([torch.full((3, ), float(i)) for i in range(lo, hi)])
+    full = gather_shards(local, n)
+    t = max_over_ranks(1.0 + rank)
+    dist.barrier()
+    if rank == 0:
+        q.put((full.tolist(), t))
+    dist.destroy_process_group()
+
+
+def test_sharded_gather_and_max_time():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, t = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert full == [[float(i)] * 3 for i in range(7)]
+    assert t == pytest.approx(2.0)

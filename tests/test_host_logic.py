@@ -1,0 +1,117 @@
+"""CPU: host-side mirror of the reference interface -- construction API, state-dict contract,
+closed forms, no-fallback behaviour, sharding helpers."""
+import os
+import tempfile
+
+import pytest
+import torch
+
+import golden_util as gu
+
+
+def vp_cfg_with_ckpt(cfg):
+    from slotformer_amd.base_slots import build_model as bb
+    scfg = gu.savi_cfg(cfg['resolution'][0], cfg['slot_dict']['num_slots'], slot_size=cfg['slot_dict']['slot_size'])
+    scfg['dec_dict'] = {k: v for k, v in cfg['dec_dict'].items() if k != 'dec_ckp_path'}
+    savi = bb(gu.ParamsView(scfg))
+    path = os.path.join(tempfile.mkdtemp(), 'savi.pth')
+    torch.save({'state_dict': savi.state_dict()}, path)
+    full = {k: (dict(v) if isinstance(v, dict) else v) for k, v in cfg.items()}
+    full['dec_dict']['dec_ckp_path'] = path
+    return full, savi
+
+
+@pytest.mark.parametrize('name,cfg', [('savi_c1', gu.C1_SAVI), ('savi_c2', gu.C2_SAVI), ('savi_c5', gu.C5_SAVI)])
+def test_savi_state_dict_contract(name, cfg):
+    """Same keys, order and shapes as the reference module => reference checkpoints load strict."""
+    from slotformer_amd.base_slots import build_model
+    m = build_model(gu.ParamsView(cfg))
+    g = gu.load_golden(name)
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == gu.shapes_from_golden(g)
+    assert torch.equal(m.state_dict()['encoder_pos_embedding.grid'], torch.from_numpy(g['closed::encoder_pos_embedding.grid']))
+
+
+@pytest.mark.parametrize('name,cfg', [('roll_c1', gu.C1_ROLL), ('roll_c2', gu.C2_ROLL), ('roll_c5', gu.C5_ROLL)])
+def test_slotformer_state_dict_contract(name, cfg):
+    from slotformer_amd.video_prediction import build_model
+    full, savi = vp_cfg_with_ckpt(cfg)
+    m = build_model(gu.ParamsView(full))
+    g = gu.load_golden(name)
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == gu.shapes_from_golden(g)
+    assert torch.equal(m.state_dict()['rollouter.enc_t_pe'], torch.from_numpy(g['closed::rollouter.enc_t_pe']))
+    # frozen decoder copied from the SAVi checkpoint by key prefix (slotformer.py:203-216)
+    assert torch.equal(m.decoder[0][0].weight, savi.decoder[0][0].weight)
+    assert not any(p.requires_grad for p in m.decoder.parameters())
+    assert not m.rollouter.enc_t_pe.requires_grad
+    m.train()
+    assert not m.decoder.training
+
+
+def test_steve_accepts_full_checkpoint():
+    """STEVE checkpoints carry dvae.* / trans_decoder.* keys (out of scope); strict load still works."""
+    from slotformer_amd.base_slots import build_model
+    cfg = dict(gu.C4_STEVE, dvae_dict=dict(down_factor=4, vocab_size=64, dvae_ckp_path=''),
+               dec_dict=dict(dec_type='slate', dec_num_layers=1, dec_num_heads=4, dec_d_model=64),
+               loss_dict=dict(use_img_recon_loss=False))
+    m = build_model(gu.ParamsView(cfg))
+    g = gu.load_golden('steve_c4')
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == gu.shapes_from_golden(g)
+    sd = dict(m.state_dict())
+    sd['dvae.encoder.0.weight'] = torch.zeros(3)
+    sd['trans_decoder.head.weight'] = torch.zeros(3)
+    m.load_state_dict(sd, strict=True)
+
+
+def test_build_model_errors_match_reference():
+    from slotformer_amd.base_slots import build_model as bb
+    from slotformer_amd.video_prediction import build_model as bv
+    with pytest.raises(NotImplementedError):
+        bb(gu.ParamsView(dict(gu.C1_SAVI, model='Nope')))
+    with pytest.raises(NotImplementedError):
+        bv(gu.ParamsView(dict(gu.C1_ROLL, model='Nope')))
+    with pytest.raises(AssertionError):  # 'Please provide pretrained decoder weight' (slotformer.py:201)
+        bv(gu.ParamsView(gu.C1_ROLL))
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly off-device; nothing routes through the oracle."""
+    from slotformer_amd.base_slots import build_model
+    m = build_model(gu.ParamsView(gu.C1_SAVI)).eval()
+    m.testing = True
+    with torch.no_grad(), pytest.raises(RuntimeError, match='no CPU fallback'):
+        m({'img': gu.seeded_img(1, 1, 64)})
+    with pytest.raises(NotImplementedError, match='inference-only'):
+        m({'img': gu.seeded_img(1, 1, 64)})  # grad enabled
+    import slotformer_amd
+    src_dir = os.path.dirname(slotformer_amd.__file__)
+    for root, _, files in os.walk(src_dir):
+        for f in files:
+            if f.endswith('.py'):
+                assert 'import oracle' not in open(os.path.join(root, f)).read(), f
+
+
+def test_rollouter_asserts():
+    from slotformer_amd.video_prediction.models import SlotRollouter, SingleStepSlotRollouter
+    r = SlotRollouter(**gu.C1_ROLL['rollout_dict'])
+    with pytest.raises(AssertionError, match='wrong burn-in steps'):
+        r(torch.zeros(1, 5, 6, 128), 2)
+    with pytest.raises(AssertionError):
+        SingleStepSlotRollouter(**dict(gu.C5_ROLL['rollout_dict'], history_len=2))
+
+
+def test_slotformer_alias_package():
+    import importlib
+    m = importlib.import_module('slotformer.base_slots')
+    assert hasattr(m, 'build_model') and hasattr(m, 'build_dataset') and hasattr(m, 'build_method')
+    from slotformer.video_prediction.models import SlotFormer  # noqa: F401
+
+
+def test_shard_range():
+    from slotformer_amd.parallel import shard_range
+    for n in (0, 1, 7, 32, 33):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): bench line + rocprofv3 kernel-trace stats + PMC passes.
+# Usage: tools/profile_round.sh <tag>     -> writes gpurun_out/<tag>_*
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+mkdir -p $OUT
+cd $R
+timeout 600 python bench.py --steps 20 --warmup 5 --breakdown > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.log
+tail -c 600 $OUT/${TAG}_bench.json | head -c 300; echo
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o trace -- $BENCH > $OUT/${TAG}_trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o pmc -- $BENCH > $OUT/${TAG}_pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o pmc -- $BENCH > $OUT/${TAG}_pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_mfma -o pmc -- $BENCH > $OUT/${TAG}_pmc_mfma.log 2>&1
+cd $R
+find $OUT -name "*.csv" | head -20
+python tools/summarize_profile.py $TAG

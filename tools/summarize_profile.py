@@ -1,0 +1,45 @@
+"""Condense rocprofv3 CSV output (kernel stats + PMC passes) into small text summaries."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(R, 'gpurun_out')
+
+
+def short(name):
+    return name.split('(')[0].replace('void ', '')[:70]
+
+
+def find(d, pat):
+    fs = glob.glob(os.path.join(OUT, d, '**', pat), recursive=True)
+    return fs[0] if fs else None
+
+
+lines = []
+f = find(f'{tag}_trace', '*kernel_stats.csv')
+if f:
+    lines.append(f'# rocprofv3 --kernel-trace --stats  (bench.py --steps 3 --warmup 1 --no-graph)  [{os.path.basename(f)}]')
+    lines.append(f'{"kernel":72s} {"calls":>7s} {"total_us":>12s} {"avg_us":>10s} {"pct":>6s}')
+    for r in csv.DictReader(open(f)):
+        lines.append(f'{short(r["Name"]):72s} {r["Calls"]:>7s} {float(r["TotalDurationNs"]) / 1e3:12.1f} '
+                     f'{float(r["AverageNs"]) / 1e3:10.2f} {float(r["Percentage"]):6.2f}')
+for cname, d in (('FETCH_SIZE', f'{tag}_pmc_fetch'), ('WRITE_SIZE', f'{tag}_pmc_write'), ('MFMA', f'{tag}_pmc_mfma')):
+    f = find(d, '*counter_collection.csv')
+    if not f:
+        lines.append(f'# {cname}: no counter csv found')
+        continue
+    agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for r in csv.DictReader(open(f)):
+        a = agg[short(r['Kernel_Name'])][r['Counter_Name']]
+        a[0] += float(r['Counter_Value'])
+        a[1] += 1
+    lines.append(f'# PMC pass {cname}: per-dispatch average  [{os.path.basename(f)}]')
+    for k, cs in sorted(agg.items(), key=lambda kv: -sum(v[0] for v in kv[1].values()))[:14]:
+        lines.append(f'{k:72s} ' + '  '.join(f'{c}={v[0] / v[1]:.4g} (n={v[1]})' for c, v in cs.items()))
+txt = '\n'.join(lines)
+open(os.path.join(OUT, f'{tag}_profile_summary.txt'), 'w').write(txt + '\n')
+print(txt)
