@@ -40,14 +40,15 @@ struct SfGemmArgs {
   // conv (im2col loaders): output cH x cW, input cInH x cInW, cCin channels, cKs taps, stride
   int cH, cW, cInH, cInW, cCin, cKs, cStride;
   long long cFrameStride;
+  int dbg;  // ablation bits (SF_GEMM_DBG, tools only): 1 no MFMA, 2 no main-loop loads, 4 no LN stats, 8 no stores
 };
 
 // BKT: k-chunk staged per barrier; KW waves split each chunk; PD: prefetch distance in chunks
 // (PD = 2 keeps two chunks of global loads in flight behind the one being computed).
 template <int BM, int BN, int WM, int WN, int KW, int BKT, int PD, int NBUF, int ALOAD, bool LN>
-__global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
-  constexpr int NT = 256;
-  static_assert(WM * WN * KW * 64 == NT, "4 waves");
+__global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) {
+  constexpr int NT = WM * WN * KW * 64;
+  static_assert(NT == 256 || NT == 512, "4 or 8 waves");
   static_assert(BKT % (8 * KW) == 0 && (PD == 1 || PD == 2) && (NBUF == 2 || (NBUF == 1 && PD == 1)), "bad chunking");
   constexpr int RM = BM / (32 * WM), RN = BN / (32 * WN);
   constexpr int NKB = BKT / (8 * KW);  // 8-wide k blocks per wave per chunk
@@ -69,7 +70,14 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wk = wave % KW, wn = (wave / KW) % WN, wm = wave / (KW * WN);
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order for the conv: workgroup b lands on XCD b % 8, so give each XCD a contiguous
+  // run of output tiles (neighbouring tiles share 4 of their 6 halo rows -> hits in that XCD's L2).
+  int bid = blockIdx.x;
+  if constexpr (ALOAD == ALOAD_CONV_NHWC) {
+    const int nb = gridDim.x;
+    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  }
+  const int m0 = bid * BM, n0 = blockIdx.y * BN;
   const int M = p.M, N = p.N, K = p.K;
 
   // ---- per-thread loader state ---------------------------------------------------
@@ -81,6 +89,7 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
   const int kk = t % BKT, r0s = t / BKT;    // scalar loader
   const float* arow[SCALAR ? 1 : A_IT];
   int cf[SCALAR ? A_SC : A_IT], cy[SCALAR ? A_SC : A_IT], cx[SCALAR ? A_SC : A_IT];
+  long long rowbase[SCALAR ? 1 : A_IT];  // NHWC im2col: element offset of the row's own pixel
   if constexpr (ALOAD == ALOAD_PLAIN) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -97,6 +106,7 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
       cf[i] = f;
       cy[i] = rem / p.cW;
       cx[i] = rem - cy[i] * p.cW;
+      if constexpr (ALOAD == ALOAD_CONV_NHWC) rowbase[i] = (long long)f * p.cFrameStride + (long long)rem * p.cCin;
     }
   }
   const float* wrow[SCALAR ? 1 : B_IT];
@@ -117,6 +127,7 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
     float(&sa)[SCALAR ? A_SC : 1] = R.sa;
     float(&sb)[SCALAR ? B_SC : 1] = R.sb;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if ((p.dbg & 2) && kc > 0) return;
     if constexpr (!SCALAR) {
       const int k = kc * BKT + 4 * c4;
       const bool kok = k < K;
@@ -128,15 +139,27 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
           ra[i] = kok ? v : zero4;
         }
       } else {  // NHWC im2col: k = tap * Cin + cin
-        const int tap = kc4 / p.cCin, cin = kc4 - tap * p.cCin;
-        const int ky = tap / p.cKs, kx = tap - ky * p.cKs, pad = p.cKs >> 1;
+        int tap, cin, ky, kx;
+        if (p.cCin == 64 && p.cKs == 5) {  // the reference's encoder shape: constant-folded index math
+          tap = kc4 >> 6;
+          cin = kc4 & 63;
+          ky = tap / 5;
+          kx = tap - ky * 5;
+        } else {
+          tap = kc4 / p.cCin;
+          cin = kc4 - tap * p.cCin;
+          ky = tap / p.cKs;
+          kx = tap - ky * p.cKs;
+        }
+        const int pad = p.cKs >> 1;
+        const int dy = ky - pad, dx = kx - pad;
+        const long long tapoff = (long long)(dy * p.cInW + dx) * p.cCin + cin;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-          const int yy = cy[i] + ky - pad, xx = cx[i] + kx - pad;
+          const int yy = cy[i] + dy, xx = cx[i] + dx;
           const bool ok = kok && (unsigned)yy < (unsigned)p.cInH && (unsigned)xx < (unsigned)p.cInW;
-          const int yc = min(max(yy, 0), p.cInH - 1), xc = min(max(xx, 0), p.cInW - 1);
-          const f32x4 v = *(const f32x4*)(p.A + (long long)cf[i] * p.cFrameStride +
-                                          ((long long)(yc * p.cInW + xc) * p.cCin + cin));
+          // out-of-image taps read the row's own pixel (always valid) and are zeroed by the select
+          const f32x4 v = *(const f32x4*)(p.A + rowbase[i] + (ok ? tapoff : (long long)cin));
           ra[i] = ok ? v : zero4;
         }
       }
@@ -238,6 +261,9 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     }
   };
+  auto compute_dbg = [&](int buf) {
+    if (!(p.dbg & 1)) compute(buf);
+  };
   // first chunk(s) are requested BEFORE the LayerNorm statistics pass so that pass does not add a
   // serial memory round trip in front of the main loop
   load_tiles(0, R0);
@@ -247,7 +273,13 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
   // ---- LayerNorm statistics for this tile's rows --------------------------------
   // NT/BM threads per row, every load of a pass independent (in flight together); the serial
   // per-row version this replaces cost ~30 us per launch in dependent L2 round trips.
-  if constexpr (LN) {
+  if (LN && (p.dbg & 4)) {
+    if (t < BM) {
+      stats[t] = 0.f;
+      stats[BM + t] = 1.f;
+    }
+    __syncthreads();
+  } else if constexpr (LN) {
     constexpr int TPR = NT / BM;
     const int r = t / TPR, sub = t % TPR;
     const int m = min(m0 + r, M - 1);
@@ -286,7 +318,7 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
     for (int kc = 0; kc < nk; ++kc) {
       const bool has_next = kc + 1 < nk;
       if (has_next) load_tiles(kc + 1, R0);
-      compute(kc & 1);
+      compute_dbg(kc & 1);
       if (has_next) store_tiles((kc + 1) & 1, kc + 1, R0);
       __syncthreads();
     }
@@ -296,7 +328,7 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
     for (int kc = 0; kc < nk; ++kc) {
       const bool has_next = kc + 1 < nk;
       if (has_next) load_tiles(kc + 1, R0);
-      compute(0);
+      compute_dbg(0);
       if (has_next) {
         __syncthreads();
         store_tiles(0, kc + 1, R0);
@@ -308,12 +340,12 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
     __syncthreads();
     for (int kc = 0; kc < nk; kc += 2) {
       if (kc + 2 < nk) load_tiles(kc + 2, R0);
-      compute(0);
+      compute_dbg(0);
       if (kc + 1 < nk) store_tiles(1, kc + 1, R1);
       __syncthreads();
       if (kc + 1 >= nk) break;
       if (kc + 3 < nk) load_tiles(kc + 3, R1);
-      compute(1);
+      compute_dbg(1);
       if (kc + 2 < nk) store_tiles(0, kc + 2, R0);
       __syncthreads();
     }
@@ -374,7 +406,7 @@ __global__ __launch_bounds__(256) void sf_gemm_kernel(SfGemmArgs p) {
       for (int r = 0; r < 16; ++r) {
         const int row = rbase + (r & 3) + 8 * (r >> 2);
         const float v = fmaxf(acc[i][j][r] + bias, lo) + rv[r];
-        if (row < M && colok) p.C[sf_row_off(p.cmap, row) + col] = v;
+        if (row < M && colok && !((p.dbg & 8) && v != 12345.f)) p.C[sf_row_off(p.cmap, row) + col] = v;
       }
     }
   }
@@ -399,7 +431,7 @@ static int launch_cfg(const SfGemmArgs& a, hipStream_t stream) {
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
   const int cls = ALOAD == ALOAD_PLAIN ? SF_K_LINEAR : (ALOAD == ALOAD_CONV_NHWC ? SF_K_CONV_NHWC : SF_K_CONV_FIRST);
   sf_prof_begin(cls, stream, 2.0 * (double)a.M * (double)a.N * (double)a.K);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * KW * 64), lds, stream, a);
   sf_prof_end(cls, stream);
   SF_CHECK_LAUNCH();
   return 0;
@@ -436,6 +468,17 @@ static int launch_by_id(int id, const SfGemmArgs& a, hipStream_t st) {
     case 19: return launch_cfg<64, 64, 2, 2, 1, 128, 1, 1, ALOAD, LN>(a, st);
     case 20: return launch_cfg<64, 32, 2, 1, 2, 256, 1, 1, ALOAD, LN>(a, st);
     case 21: return launch_cfg<32, 32, 1, 1, 4, 256, 1, 1, ALOAD, LN>(a, st);
+    // 8-wave workgroups: twice the loads in flight per CU (tools/probes/fill_probe.hip)
+    case 22: return launch_cfg<64, 64, 2, 2, 2, 128, 2, 2, ALOAD, LN>(a, st);
+    case 23: return launch_cfg<32, 32, 1, 1, 8, 128, 2, 2, ALOAD, LN>(a, st);
+    case 24: return launch_cfg<32, 64, 1, 2, 4, 128, 2, 2, ALOAD, LN>(a, st);
+    case 25: return launch_cfg<64, 64, 2, 2, 2, 256, 1, 1, ALOAD, LN>(a, st);
+    case 26: return launch_cfg<32, 32, 1, 1, 8, 256, 2, 2, ALOAD, LN>(a, st);
+    case 27: return launch_cfg<64, 32, 2, 1, 4, 128, 2, 2, ALOAD, LN>(a, st);
+    case 28: return launch_cfg<128, 64, 4, 2, 1, 32, 2, 2, ALOAD, LN>(a, st);
+    case 29: return launch_cfg<128, 128, 4, 2, 1, 32, 2, 2, ALOAD, LN>(a, st);
+    case 30: return launch_cfg<128, 64, 4, 2, 1, 64, 2, 2, ALOAD, LN>(a, st);
+    case 31: return launch_cfg<128, 128, 2, 4, 1, 32, 1, 2, ALOAD, LN>(a, st);
     default: return sf_set_err(-1, "unknown SF_GEMM_CFG id", __FILE__, __LINE__);
   }
 }
@@ -452,9 +495,9 @@ static int dispatch_tiles(const SfGemmArgs& a, hipStream_t stream) {
     if (f >= 0) return launch_by_id<ALOAD, LN>(f, a, stream);
     // choices below come from tools/gemm_bench.py on MI355X (profiles/r01_gemm_configs.txt)
     if constexpr (ALOAD == ALOAD_CONV_NHWC) {
-      return launch_by_id<ALOAD, LN>(13, a, stream);
+      return launch_by_id<ALOAD, LN>(28, a, stream);
     } else {
-      if (a.N > 64 && tiles(128, 128) >= 384) return launch_by_id<ALOAD, LN>(0, a, stream);
+      if (a.N > 64 && tiles(128, 128) >= 384) return launch_by_id<ALOAD, LN>(31, a, stream);
       if (tiles(128, 64) >= 384) return launch_by_id<ALOAD, LN>(1, a, stream);
       // small-M regime (rollout / slot-level GEMMs): latency-bound, favour many small workgroups
       if (a.K >= 512) return launch_by_id<ALOAD, LN>(7, a, stream);
@@ -464,8 +507,13 @@ static int dispatch_tiles(const SfGemmArgs& a, hipStream_t stream) {
   }
 }
 
-int sf_gemm_dispatch(const SfGemmArgs& a, int aload, hipStream_t stream) {
-  if (a.M <= 0 || a.N <= 0) return 0;
+int sf_gemm_dispatch(const SfGemmArgs& a_in, int aload, hipStream_t stream) {
+  if (a_in.M <= 0 || a_in.N <= 0) return 0;
+  SfGemmArgs a = a_in;
+  {
+    const char* e = getenv("SF_GEMM_DBG");
+    a.dbg = e ? atoi(e) : 0;
+  }
   const bool ln = a.ln_g != nullptr;
   if (aload == ALOAD_PLAIN) return ln ? dispatch_tiles<ALOAD_PLAIN, true>(a, stream)
                                       : dispatch_tiles<ALOAD_PLAIN, false>(a, stream);
