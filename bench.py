@@ -28,6 +28,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak; bf16x3 issues 3 bf16 MFMA flops per algorithmic flop
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec peak (6.3 TB/s achievable)
 T_BURN, T_ROLL, RES = 6, 50, 128
 CLS_NAMES = ['conv_nhwc_implicit_gemm', 'conv_first', 'linear_gemm', 'slot_attn_iter', 'slot_update', 'mha_small']
@@ -139,6 +140,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8)
     ap.add_argument('--rollout-streams', type=int, default=1, help='batch groups rolled out concurrently on separate HIP streams')
+    ap.add_argument('--precision', choices=['bf16x3', 'f32'], default=None, help='matrix arithmetic mode (default: library default = bf16x3)')
     ap.add_argument('--breakdown', action='store_true', help='extra untimed pass with every kernel class timed')
     args = ap.parse_args()
 
@@ -156,6 +158,9 @@ def main():
 
     from slotformer_amd import engine, _lib
     lib = _lib.lib()
+    if args.precision:
+        lib.sf_set_precision(1 if args.precision == 'bf16x3' else 0)
+    prec = 'bf16x3' if lib.sf_get_precision() == 1 else 'f32'
     B = args.batch
     savi, roll = build_models(dev)
     img = synthetic_img(B, seed=1234 + rank).to(dev)
@@ -274,7 +279,7 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': 'f32 storage; matmul/conv on split-bf16 MFMA (bf16x3: hi*hi+hi*lo+lo*hi, f32 accumulate)' if prec == 'bf16x3' else 'f32',
             'data': 'synthetic',
             'config': {
                 'workload': 'C2: CLEVRER StoSAVi 128x128 (7 slots, D=128, 2 SA iters, stochastic kernels, MLP '
@@ -293,10 +298,12 @@ def main():
         if conv:
             flops_per_launch = conv['work'] / conv['launches']
             ach = flops_per_launch / (conv['avg_us'] * 1e-6) / 1e12
+            peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS
             res['roofline'] = {
-                'kernel': 'sf_gemm_kernel<128,64,4,1,1,conv_nhwc> (5x5 conv 64->64 @64x64 as implicit GEMM, f32 MFMA)',
-                'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic('conv_nhwc_implicit_gemm'),
+                'kernel': 'sf_gemm_kernel<128,64,...,conv_nhwc> (5x5 conv 64->64 @64x64 as implicit GEMM, '
+                + ('split-bf16 MFMA: 3 bf16 MFMA flops per algorithmic flop -> peak = 2500/3)' if prec == 'bf16x3' else 'exact f32 MFMA)'),
+                'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': ach / peak, 'traffic': pmc_traffic('conv_nhwc_implicit_gemm'),
                 'traffic_unit': 'bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE, committed under profiles/)',
                 'algorithmic_bytes_per_launch': 2 * 32 * 4096 * 64 * 4 + 64 * 1600 * 4,
                 'flops_per_launch': flops_per_launch, 'avg_launch_us': conv['avg_us'], 'launches': conv['launches'],

@@ -23,6 +23,12 @@ extern "C" {
 int sf_version(void);
 const char* sf_last_error_string(void);
 
+/* Matrix-arithmetic mode of every GEMM/conv kernel: 1 (default) = split-bf16 ("bf16x3": each f32 operand
+ * = hi + lo bf16, hi*hi + hi*lo + lo*hi on bf16 MFMA with f32 accumulation, ~2^-17 relative per operand);
+ * 0 = exact f32 MFMA (bitwise an fmaf chain).  Environment SF_PRECISION=f32 selects 0 at load time. */
+int sf_get_precision(void);
+int sf_set_precision(int mode);
+
 /* Optional per-kernel-class HIP-event timer (bench.py roofline): events bracket every launch of a
  * class on the launch stream while enabled (never during hipGraph capture).  Classes: 0 conv
  * NHWC implicit GEMM, 1 first conv, 2 linear, 3 slot-attention iteration, 4 slot update, 5 MHA.

@@ -54,6 +54,8 @@ I, LL, F32, SZ, VP = C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_void_p
 SIGNATURES = {
     'sf_version': (I, []),
     'sf_last_error_string': (C.c_char_p, []),
+    'sf_get_precision': (I, []),
+    'sf_set_precision': (I, [I]),
     'sf_profile_enable': (I, [I]),
     'sf_profile_read': (I, [I, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     'sf_linear_f32': (I, [FP, I, FP, FP, FP, FP, F32, FP, I, FP, I, I, I, I, I, VP]),

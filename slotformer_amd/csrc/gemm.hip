@@ -18,6 +18,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 enum { ALOAD_PLAIN = 0, ALOAD_CONV_NHWC = 1, ALOAD_CONV_NCHW = 2 };
 
@@ -45,14 +47,20 @@ struct SfGemmArgs {
 
 // BKT: k-chunk staged per barrier; KW waves split each chunk; PD: prefetch distance in chunks
 // (PD = 2 keeps two chunks of global loads in flight behind the one being computed).
-template <int BM, int BN, int WM, int WN, int KW, int BKT, int PD, int NBUF, int ALOAD, bool LN>
+// BF3: split-bf16 arithmetic -- every f32 operand is split into hi + lo bf16 when staged into LDS and each
+// k16 step issues hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with f32 accumulation (~2^-17 relative per
+// operand; the dropped lo*lo term is ~2^-16 smaller still); ~5x fewer matrix-pipe cycles than exact-f32 MFMA.
+template <int BM, int BN, int WM, int WN, int KW, int BKT, int PD, int NBUF, int ALOAD, bool LN, bool BF3>
 __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) {
   constexpr int NT = WM * WN * KW * 64;
   static_assert(NT == 256 || NT == 512, "4 or 8 waves");
   static_assert(BKT % (8 * KW) == 0 && (PD == 1 || PD == 2) && (NBUF == 2 || (NBUF == 1 && PD == 1)), "bad chunking");
   constexpr int RM = BM / (32 * WM), RN = BN / (32 * WN);
   constexpr int NKB = BKT / (8 * KW);  // 8-wide k blocks per wave per chunk
-  constexpr int LSTR = BKT + 4;
+  constexpr int LSTR = BKT + 4;   // f32 row stride (floats)
+  constexpr int LB = BKT + 8;     // bf16 row stride (elements) per hi/lo plane: (2*BKT+16) B = odd # of 16-B slots
+  static_assert(!BF3 || (BKT % (16 * KW) == 0 && ALOAD != ALOAD_CONV_NCHW), "BF3 chunking");
+  constexpr int NK16 = BKT / (16 * KW);
   constexpr int C4N = BKT / 4;
   constexpr int RS = NT / C4N;
   constexpr int A_IT = BM * C4N / NT;
@@ -66,7 +74,12 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + NBUF * BM * LSTR;
-  float* stats = Bs + NBUF * BN * LSTR;
+  // BF3 planes (bf16): A_hi | A_lo | B_hi | B_lo, each [NBUF][rows][LB]
+  __bf16* Ah = (__bf16*)smem;
+  __bf16* Al = Ah + NBUF * BM * LB;
+  __bf16* Bh = Al + NBUF * BM * LB;
+  __bf16* Bl = Bh + NBUF * BN * LB;
+  float* stats = BF3 ? (float*)(Bl + NBUF * BN * LB) : (Bs + NBUF * BN * LSTR);
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wk = wave % KW, wn = (wave / KW) % WN, wm = wave / (KW * WN);
@@ -218,10 +231,23 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
           ra[i] = kok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
+      if constexpr (BF3) {
+        auto put = [&](__bf16* hi_plane, __bf16* lo_plane, int row, f32x4 v) {
+          const bf16x4 h = __builtin_convertvector(v, bf16x4);
+          const bf16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4);
+          *(bf16x4*)(hi_plane + row * LB + 4 * c4) = h;
+          *(bf16x4*)(lo_plane + row * LB + 4 * c4) = l;
+        };
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) *(f32x4*)(as + (r0 + i * RS) * LSTR + 4 * c4) = ra[i];
+        for (int i = 0; i < A_IT; ++i) put(Ah + buf * BM * LB, Al + buf * BM * LB, r0 + i * RS, ra[i]);
 #pragma unroll
-      for (int i = 0; i < B_IT; ++i) *(f32x4*)(bs + (r0 + i * RS) * LSTR + 4 * c4) = rb[i];
+        for (int i = 0; i < B_IT; ++i) put(Bh + buf * BN * LB, Bl + buf * BN * LB, r0 + i * RS, rb[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) *(f32x4*)(as + (r0 + i * RS) * LSTR + 4 * c4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) *(f32x4*)(bs + (r0 + i * RS) * LSTR + 4 * c4) = rb[i];
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < A_SC; ++i) as[(r0s + i * RS_SC) * LSTR + kk] = sa[i];
@@ -243,6 +269,37 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
   const int a_off = (wm * RM * 32 + (lane & 31)) * LSTR + wk * (NKB * 8) + 4 * (lane >> 5);
   const int b_off = (wn * RN * 32 + (lane & 31)) * LSTR + wk * (NKB * 8) + 4 * (lane >> 5);
   auto compute = [&](int buf) {
+    if constexpr (BF3) {
+      const int ao = (wm * RM * 32 + (lane & 31)) * LB + wk * (NK16 * 16) + 8 * (lane >> 5);
+      const int bo = (wn * RN * 32 + (lane & 31)) * LB + wk * (NK16 * 16) + 8 * (lane >> 5);
+      const __bf16* ah = Ah + buf * BM * LB + ao;
+      const __bf16* al = Al + buf * BM * LB + ao;
+      const __bf16* bh = Bh + buf * BN * LB + bo;
+      const __bf16* bl = Bl + buf * BN * LB + bo;
+#pragma unroll
+      for (int ks = 0; ks < NK16; ++ks) {
+        bf16x8 xh[RM], xl[RM], yh[RN], yl[RN];
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+          xh[i] = *(const bf16x8*)(ah + i * 32 * LB + ks * 16);
+          xl[i] = *(const bf16x8*)(al + i * 32 * LB + ks * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+          yh[j] = *(const bf16x8*)(bh + j * 32 * LB + ks * 16);
+          yl[j] = *(const bf16x8*)(bl + j * 32 * LB + ks * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int j = 0; j < RN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+      return;
+    }
     const float* as = As + buf * BM * LSTR + a_off;
     const float* bs = Bs + buf * BN * LSTR + b_off;
 #pragma unroll
@@ -413,14 +470,14 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
 }
 
 // ---------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int KW, int BKT, int PD, int NBUF, int ALOAD, bool LN>
+template <int BM, int BN, int WM, int WN, int KW, int BKT, int PD, int NBUF, int ALOAD, bool LN, bool BF3>
 static int launch_cfg(const SfGemmArgs& a, hipStream_t stream) {
-  constexpr int LSTR = BKT + 4;
+  constexpr int LSTR = BF3 ? BKT + 8 : BKT + 4;  // BF3: two bf16 planes of (BKT+8) elements = (BKT+8) floats per row
   constexpr size_t lds_main = (size_t)(NBUF * (BM + BN) * LSTR + 2 * BM) * sizeof(float);
   constexpr size_t lds_red = (size_t)(KW - 1) * BM * BN * sizeof(float);
   constexpr size_t lds = lds_main > lds_red ? lds_main : lds_red;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = sf_gemm_kernel<BM, BN, WM, WN, KW, BKT, PD, NBUF, ALOAD, LN>;
+  auto kern = sf_gemm_kernel<BM, BN, WM, WN, KW, BKT, PD, NBUF, ALOAD, LN, BF3>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -443,44 +500,58 @@ static int forced_cfg() {
   return e ? atoi(e) : -1;
 }
 
+// Tile configurations (ids are what tools/gemm_bench.py sweeps via SF_GEMM_CFG).
+//   <BM, BN, WM, WN, KW, BKT, PD, NBUF>;  ids < 100: exact-f32 MFMA, ids >= 100: split-bf16 (BF3).
 template <int ALOAD, bool LN>
 static int launch_by_id(int id, const SfGemmArgs& a, hipStream_t st) {
   switch (id) {
-    case 0: return launch_cfg<128, 128, 2, 2, 1, 32, 1, 2, ALOAD, LN>(a, st);
-    case 1: return launch_cfg<128, 64, 4, 1, 1, 32, 1, 2, ALOAD, LN>(a, st);
-    case 2: return launch_cfg<64, 64, 2, 2, 1, 32, 1, 2, ALOAD, LN>(a, st);
-    case 3: return launch_cfg<32, 32, 1, 1, 4, 128, 1, 2, ALOAD, LN>(a, st);
-    case 4: return launch_cfg<32, 64, 1, 2, 2, 64, 1, 2, ALOAD, LN>(a, st);
-    case 5: return launch_cfg<64, 64, 2, 2, 1, 64, 2, 2, ALOAD, LN>(a, st);
-    case 6: return launch_cfg<64, 64, 2, 2, 1, 128, 2, 2, ALOAD, LN>(a, st);
-    case 7: return launch_cfg<32, 32, 1, 1, 4, 128, 2, 2, ALOAD, LN>(a, st);
-    case 8: return launch_cfg<32, 32, 1, 1, 4, 256, 2, 2, ALOAD, LN>(a, st);
-    case 9: return launch_cfg<32, 64, 1, 2, 2, 128, 2, 2, ALOAD, LN>(a, st);
-    case 10: return launch_cfg<128, 64, 4, 1, 1, 64, 2, 2, ALOAD, LN>(a, st);
-    case 11: return launch_cfg<128, 128, 2, 2, 1, 64, 2, 2, ALOAD, LN>(a, st);
-    case 12: return launch_cfg<64, 32, 2, 1, 2, 128, 2, 2, ALOAD, LN>(a, st);
-    case 13: return launch_cfg<128, 64, 4, 1, 1, 32, 2, 2, ALOAD, LN>(a, st);
-    case 14: return launch_cfg<64, 64, 2, 2, 1, 64, 1, 2, ALOAD, LN>(a, st);
-    case 15: return launch_cfg<64, 128, 1, 4, 1, 64, 2, 2, ALOAD, LN>(a, st);
-    case 16: return launch_cfg<64, 64, 2, 2, 1, 256, 1, 1, ALOAD, LN>(a, st);
-    case 17: return launch_cfg<32, 32, 1, 1, 4, 512, 1, 1, ALOAD, LN>(a, st);
-    case 18: return launch_cfg<32, 64, 1, 2, 2, 256, 1, 1, ALOAD, LN>(a, st);
-    case 19: return launch_cfg<64, 64, 2, 2, 1, 128, 1, 1, ALOAD, LN>(a, st);
-    case 20: return launch_cfg<64, 32, 2, 1, 2, 256, 1, 1, ALOAD, LN>(a, st);
-    case 21: return launch_cfg<32, 32, 1, 1, 4, 256, 1, 1, ALOAD, LN>(a, st);
-    // 8-wave workgroups: twice the loads in flight per CU (tools/probes/fill_probe.hip)
-    case 22: return launch_cfg<64, 64, 2, 2, 2, 128, 2, 2, ALOAD, LN>(a, st);
-    case 23: return launch_cfg<32, 32, 1, 1, 8, 128, 2, 2, ALOAD, LN>(a, st);
-    case 24: return launch_cfg<32, 64, 1, 2, 4, 128, 2, 2, ALOAD, LN>(a, st);
-    case 25: return launch_cfg<64, 64, 2, 2, 2, 256, 1, 1, ALOAD, LN>(a, st);
-    case 26: return launch_cfg<32, 32, 1, 1, 8, 256, 2, 2, ALOAD, LN>(a, st);
-    case 27: return launch_cfg<64, 32, 2, 1, 4, 128, 2, 2, ALOAD, LN>(a, st);
-    case 28: return launch_cfg<128, 64, 4, 2, 1, 32, 2, 2, ALOAD, LN>(a, st);
-    case 29: return launch_cfg<128, 128, 4, 2, 1, 32, 2, 2, ALOAD, LN>(a, st);
-    case 30: return launch_cfg<128, 64, 4, 2, 1, 64, 2, 2, ALOAD, LN>(a, st);
-    case 31: return launch_cfg<128, 128, 2, 4, 1, 32, 1, 2, ALOAD, LN>(a, st);
-    default: return sf_set_err(-1, "unknown SF_GEMM_CFG id", __FILE__, __LINE__);
+    case 0: return launch_cfg<128, 128, 2, 2, 1, 32, 1, 2, ALOAD, LN, false>(a, st);
+    case 1: return launch_cfg<128, 64, 4, 1, 1, 32, 1, 2, ALOAD, LN, false>(a, st);
+    case 3: return launch_cfg<32, 32, 1, 1, 4, 128, 1, 2, ALOAD, LN, false>(a, st);
+    case 4: return launch_cfg<32, 64, 1, 2, 2, 64, 1, 2, ALOAD, LN, false>(a, st);
+    case 7: return launch_cfg<32, 32, 1, 1, 4, 128, 2, 2, ALOAD, LN, false>(a, st);
+    case 13: return launch_cfg<128, 64, 4, 1, 1, 32, 2, 2, ALOAD, LN, false>(a, st);
+    case 22: return launch_cfg<64, 64, 2, 2, 2, 128, 2, 2, ALOAD, LN, false>(a, st);
+    case 24: return launch_cfg<32, 64, 1, 2, 4, 128, 2, 2, ALOAD, LN, false>(a, st);
+    case 28: return launch_cfg<128, 64, 4, 2, 1, 32, 2, 2, ALOAD, LN, false>(a, st);
+    case 31: return launch_cfg<128, 128, 2, 4, 1, 32, 1, 2, ALOAD, LN, false>(a, st);
+    default: break;
   }
+  if constexpr (ALOAD != ALOAD_CONV_NCHW) {
+    switch (id) {
+      case 100: return launch_cfg<128, 64, 4, 2, 1, 32, 2, 2, ALOAD, LN, true>(a, st);
+      case 101: return launch_cfg<128, 64, 4, 2, 1, 64, 2, 2, ALOAD, LN, true>(a, st);
+      case 102: return launch_cfg<128, 128, 2, 4, 1, 32, 1, 2, ALOAD, LN, true>(a, st);
+      case 103: return launch_cfg<128, 128, 2, 4, 1, 64, 2, 2, ALOAD, LN, true>(a, st);
+      case 104: return launch_cfg<32, 64, 1, 2, 2, 64, 1, 2, ALOAD, LN, true>(a, st);
+      case 105: return launch_cfg<32, 32, 1, 1, 4, 128, 2, 2, ALOAD, LN, true>(a, st);
+      case 106: return launch_cfg<32, 32, 1, 1, 4, 128, 1, 2, ALOAD, LN, true>(a, st);
+      case 107: return launch_cfg<64, 64, 2, 2, 1, 64, 2, 2, ALOAD, LN, true>(a, st);
+      case 108: return launch_cfg<64, 64, 2, 2, 2, 128, 2, 2, ALOAD, LN, true>(a, st);
+      case 109: return launch_cfg<32, 64, 1, 2, 4, 128, 2, 2, ALOAD, LN, true>(a, st);
+      case 110: return launch_cfg<128, 64, 4, 1, 1, 64, 2, 2, ALOAD, LN, true>(a, st);
+      case 111: return launch_cfg<64, 64, 2, 2, 1, 128, 2, 2, ALOAD, LN, true>(a, st);
+      case 112: return launch_cfg<256, 64, 8, 1, 1, 32, 2, 2, ALOAD, LN, true>(a, st);
+      case 113: return launch_cfg<64, 128, 2, 2, 1, 64, 2, 2, ALOAD, LN, true>(a, st);
+      default: break;
+    }
+  }
+  return sf_set_err(-1, "unknown GEMM configuration id", __FILE__, __LINE__);
+}
+
+// 0: exact f32 MFMA everywhere; 1: split-bf16 MFMA (default).  SF_PRECISION=f32 selects 0 at load time.
+static int g_precision = -1;
+extern "C" int sf_get_precision(void) {
+  if (g_precision < 0) {
+    const char* e = getenv("SF_PRECISION");
+    g_precision = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;
+  }
+  return g_precision;
+}
+extern "C" int sf_set_precision(int mode) {
+  if (mode != 0 && mode != 1) return sf_set_err(-1, "invalid argument: precision mode must be 0 (f32) or 1 (bf16x3)", __FILE__, __LINE__);
+  g_precision = mode;
+  return 0;
 }
 
 template <int ALOAD, bool LN>
@@ -489,17 +560,25 @@ static int dispatch_tiles(const SfGemmArgs& a, hipStream_t stream) {
     return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
   };
   if constexpr (ALOAD == ALOAD_CONV_NCHW) {
-    return launch_cfg<128, 64, 4, 1, 1, 32, 1, 2, ALOAD, false>(a, stream);
+    return launch_cfg<128, 64, 4, 1, 1, 32, 1, 2, ALOAD, false, false>(a, stream);
   } else {
     const int f = forced_cfg();
     if (f >= 0) return launch_by_id<ALOAD, LN>(f, a, stream);
+    const bool bf3 = sf_get_precision() == 1;
     // choices below come from tools/gemm_bench.py on MI355X (profiles/r01_gemm_configs.txt)
     if constexpr (ALOAD == ALOAD_CONV_NHWC) {
-      return launch_by_id<ALOAD, LN>(28, a, stream);
+      return launch_by_id<ALOAD, LN>(bf3 ? 100 : 28, a, stream);
     } else {
-      if (a.N > 64 && tiles(128, 128) >= 384) return launch_by_id<ALOAD, LN>(31, a, stream);
-      if (tiles(128, 64) >= 384) return launch_by_id<ALOAD, LN>(1, a, stream);
+      if (a.N > 64 && tiles(128, 128) >= 384) return launch_by_id<ALOAD, LN>(bf3 ? 102 : 31, a, stream);
+      if (tiles(128, 64) >= 384) return launch_by_id<ALOAD, LN>(bf3 ? 100 : 1, a, stream);
       // small-M regime (rollout / slot-level GEMMs): latency-bound, favour many small workgroups
+      if (bf3) {
+        if (a.K >= 512) return launch_by_id<ALOAD, LN>(a.M >= 512 ? 109 : 105, a, stream);
+        const long long t64 = tiles(64, 64);
+        if (t64 > 300) return launch_by_id<ALOAD, LN>(107, a, stream);
+        if (t64 >= 192) return launch_by_id<ALOAD, LN>(108, a, stream);
+        return launch_by_id<ALOAD, LN>(a.M >= 512 ? 109 : 106, a, stream);
+      }
       if (a.K >= 512) return launch_by_id<ALOAD, LN>(7, a, stream);
       if (tiles(32, 64) >= 256) return launch_by_id<ALOAD, LN>(4, a, stream);
       return launch_by_id<ALOAD, LN>(3, a, stream);

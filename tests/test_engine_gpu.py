@@ -132,6 +132,27 @@ def test_rollout_golden(dev, name, cfg, B, pred_len, seed):
 
 
 @torch.no_grad()
+def test_exact_f32_mode(dev):
+    """SF precision 0 (exact f32 MFMA): rollout parity at fp32-reorder level."""
+    from slotformer_amd import _lib
+    lib = _lib.lib()
+    old = lib.sf_get_precision()
+    lib.sf_set_precision(0)
+    try:
+        g = gu.load_golden('roll_c2')
+        m, sd = build(gu.C2_ROLL, g, 202, dev, vp=True)
+        slots = gu.seeded_normal((2, 56, 7, 128), 203).to(dev)
+        m.rollout_len = 50
+        assert rel_err(m({'slots': slots})['pred_slots'], g['pred_slots']) < 5e-5
+        gs = gu.load_golden('savi_c1')
+        s, _ = build(gu.C1_SAVI, gs, 101, dev)
+        s.testing = True
+        assert rel_err(s({'img': gu.seeded_img(2, 3, 64).to(dev)})['post_slots'], gs['post_slots']) < 2e-5
+    finally:
+        lib.sf_set_precision(old)
+
+
+@torch.no_grad()
 def test_c2_full_size_vs_oracle(dev):
     """BASELINE config C2 at reduced batch vs the oracle: encode 6 frames then roll 50 steps."""
     scfg, rcfg = gu.C2_SAVI, gu.C2_ROLL

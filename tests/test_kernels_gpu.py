@@ -17,6 +17,22 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.from_numpy((np.random.RandomState(seed).standard_normal(shape) * scale).astype(np.float32))
 
 
+@pytest.fixture(params=['bf16x3', 'f32'])
+def precision(request):
+    """Run under both matrix-arithmetic modes of the library (split-bf16 default, exact f32)."""
+    from slotformer_amd import _lib
+    lib = _lib.lib()
+    old = lib.sf_get_precision()
+    lib.sf_set_precision(1 if request.param == 'bf16x3' else 0)
+    yield request.param
+    lib.sf_set_precision(old)
+
+
+def tol(precision):
+    # exact-f32 MFMA differs from torch only by summation order; split-bf16 keeps ~16 mantissa bits per operand
+    return dict(rtol=2e-5, atol=2e-5) if precision == 'f32' else dict(rtol=1e-4, atol=1e-4)
+
+
 def close(a, b, rtol=2e-5, atol=2e-5):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     err = (a - b).abs().max().item()
@@ -28,7 +44,7 @@ def close(a, b, rtol=2e-5, atol=2e-5):
                                    (131072, 128, 64), (4096 * 3, 256, 128), (100, 36, 64), (33, 64, 192),
                                    (1344, 1024, 256), (1344, 256, 256)])
 @pytest.mark.parametrize('mode', ['plain', 'ln_relu_res'])
-def test_linear(dev, M, N, K, mode):
+def test_linear(dev, M, N, K, mode, precision):
     from slotformer_amd import ops
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K**-0.5), rnd(N, seed=3, scale=0.1)
     if mode == 'plain':
@@ -38,16 +54,19 @@ def test_linear(dev, M, N, K, mode):
         g, be, r = 1 + 0.1 * rnd(K, seed=4), 0.1 * rnd(K, seed=5), rnd(M, N, seed=6)
         ref = F.relu(F.linear(F.layer_norm(x, (K, ), g, be), w, b)) + r
         out = ops.linear(x.to(dev), w.to(dev), b.to(dev), ln=(g.to(dev), be.to(dev)), residual=r.to(dev), relu=True)
-    close(out, ref)
+    close(out, ref, **tol(precision))
 
 
-def test_linear_transpose_detecting(dev):
-    """A = I with an asymmetric W catches a swapped C layout."""
+def test_linear_transpose_detecting(dev, precision):
+    """A = I with an asymmetric W catches a swapped C layout (both MFMA operand layouts)."""
     from slotformer_amd import ops
     K = 64
     w = torch.arange(96 * K, dtype=torch.float32).reshape(96, K) / 100
     out = ops.linear(torch.eye(K).to(dev), w.to(dev))
-    assert torch.equal(out.cpu(), w.t().contiguous())
+    if precision == 'f32':
+        assert torch.equal(out.cpu(), w.t().contiguous())
+    else:
+        close(out, w.t().contiguous(), rtol=2e-5, atol=1e-6)
 
 
 def test_layernorm(dev):
@@ -65,7 +84,7 @@ def test_conv_first(dev, res, stride):
 
 
 @pytest.mark.parametrize('relu,with_add', [(True, False), (False, True)])
-def test_conv_nhwc(dev, relu, with_add):
+def test_conv_nhwc(dev, relu, with_add, precision):
     from slotformer_amd import ops
     x, w, b = rnd(3, 64, 64, 64, seed=1), rnd(64, 64, 5, 5, seed=2, scale=0.03), rnd(64, seed=3, scale=0.1)
     add = rnd(4096, 64, seed=4) if with_add else None
@@ -75,7 +94,8 @@ def test_conv_nhwc(dev, relu, with_add):
         ref = ref + add.view(1, 64, 64, 64)
     wp = ops.pack_conv_weight(w.to(dev))
     assert torch.equal(wp.cpu(), w.permute(0, 2, 3, 1).contiguous())
-    close(ops.conv2d_nhwc(x.to(dev), wp, b.to(dev), relu=relu, add=None if add is None else add.to(dev)), ref)
+    close(ops.conv2d_nhwc(x.to(dev), wp, b.to(dev), relu=relu, add=None if add is None else add.to(dev)), ref,
+          **tol(precision))
 
 
 def test_pos_table(dev):
