@@ -90,6 +90,13 @@ int sf_slot_update_f32(const float* part_num, const float* part_den, int P, cons
  * are the last Lq rows of each sequence (Lq == L: all). */
 int sf_mha_f32(const float* qkv, float* out, int B, int L, int Lq, int d_model, int num_heads, void* stream);
 
+/* Fused self-attention block of one TransformerEncoderLayer (split-bf16 MFMA projection, f32 attention):
+ * att[B*Lq,d] = MHA(LN?(x)) before out_proj; x [B*L,d]; in_proj_w [3d,d], in_proj_b [3d] (torch packed q|k|v);
+ * ln_gamma/ln_beta may both be NULL.  Needs L <= 64, d % 64 == 0, head_dim in {16,32,48,64}. */
+int sf_qkv_attention_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                         const float* in_proj_w, const float* in_proj_b, float* out, int B, int L, int Lq, int d_model,
+                         int num_heads, void* stream);
+
 /* nn.LSTM single step pointwise part (predictor.py:116-117), gates [R,4H] (i,f,g,o) pre-summed. */
 int sf_lstm_pointwise_f32(const float* gates, const float* c_prev, float* h_out, float* c_out, int R, int H,
                           void* stream);

@@ -68,6 +68,7 @@ SIGNATURES = {
     'sf_slot_attn_iter_f32': (I, [FP, FP, I, LL, FP, FP, FP, FP, I, I, I, I, F32, F32, VP]),
     'sf_slot_update_f32': (I, [FP, FP, I, FP] + [FP] * 10 + [FP, I, I, I, I, F32, VP]),
     'sf_mha_f32': (I, [FP, FP, I, I, I, I, I, VP]),
+    'sf_qkv_attention_f32': (I, [FP, FP, FP, F32, FP, FP, FP, I, I, I, I, I, VP]),
     'sf_lstm_pointwise_f32': (I, [FP, FP, FP, FP, I, I, VP]),
     'sf_sample_dist_f32': (I, [FP, FP, FP, I, I, VP]),
     'sf_bilinear_resize_f32': (I, [FP, FP, LL, I, I, I, I, VP]),

@@ -1,0 +1,294 @@
+// Fused per-head attention block:  att[:, h] = MHA_h( LN?(x) )  for one (head, sequence) per workgroup.
+//
+//   LN1 -> q|k|v projection of head h (split-bf16 MFMA, f32 accumulate) -> scores -> softmax -> PV
+//
+// replaces three launches of the unfused chain (fused-LN QKV GEMM over all heads, then the
+// attention kernel) and the [B*L, 3d] qkv round trip through memory.  Each sequence has L <= 64
+// tokens (rollout window: 36-48; slot predictor: 6-8), so a (head, sequence) problem is a
+// [64 x d] . [d x 3*hd] GEMM plus a 64x64 attention -- it fits one CU's LDS.
+// Reference call sites: nn.TransformerEncoderLayer self-attention half (slotformer.py:72-80,119;
+// predictor.py:33-44).
+#include "sf_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int FA_ROWS = 64;  // padded sequence length (two 32-row MFMA blocks)
+constexpr int FA_KC = 64;    // k-chunk of d staged per barrier
+constexpr int FA_LB = FA_KC + 8;
+
+template <int HD>
+struct FaCfg {
+  static constexpr int NC = 3 * HD;                  // q|k|v columns of one head
+  static constexpr int NCP = (NC + 31) / 32 * 32;    // padded to MFMA blocks
+  static constexpr int CBLK = NCP / 32;
+  static constexpr int MAXB = (2 * CBLK + 3) / 4;    // 32x32 blocks per wave
+  static constexpr int B_IT = NCP * (FA_KC / 4) / 256;
+  static constexpr size_t plane_bytes = (size_t)2 * (FA_ROWS + NCP) * FA_LB * sizeof(__bf16);
+  static constexpr int QS = NCP + 1;                 // f32 qkv row stride (odd: conflict-free column access)
+};
+
+template <int HD>
+size_t fa_lds_bytes(int L, int Lq) {
+  using C = FaCfg<HD>;
+  const size_t qkv = (size_t)FA_ROWS * C::QS * 4 + (size_t)Lq * (L + 1) * 4 + (size_t)Lq * 4;
+  const size_t planes = C::plane_bytes + 2 * FA_ROWS * 4;
+  return planes > qkv ? planes : qkv;
+}
+}  // namespace
+
+// NK = d / 64 chunks; every chunk's global loads are issued before the first wait (NK*(4+B_IT) float4 in flight
+// per thread), so the projection pays one memory latency instead of NK.
+template <int HD, int NK>
+__global__ __launch_bounds__(256) void qkv_attn_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
+                                                       const float* __restrict__ ln_b, float ln_eps,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ out, int L, int Lq, int d) {
+  using C = FaCfg<HD>;
+  constexpr int NCP = C::NCP, CBLK = C::CBLK, MAXB = C::MAXB, B_IT = C::B_IT, QS = C::QS;
+  constexpr int A_IT = FA_ROWS * (FA_KC / 4) / 256;  // 4
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* Ah = (__bf16*)smem;
+  __bf16* Al = Ah + FA_ROWS * FA_LB;
+  __bf16* Bh = Al + FA_ROWS * FA_LB;
+  __bf16* Bl = Bh + NCP * FA_LB;
+  float* stats = (float*)(Bl + NCP * FA_LB);  // [2][64]
+  const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* xb = x + (long long)b * L * d;
+  const int c4 = t & 15, r0 = t >> 4;  // 16 float4 per 64-wide chunk row; 16 rows per pass
+
+  // ---- per-thread source rows (clamped; rows >= L are zeroed by a select) ----------------
+  const float* arow[A_IT];
+  bool aok[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int r = r0 + 16 * i;
+    aok[i] = r < L;
+    arow[i] = xb + (long long)min(r, L - 1) * d;
+  }
+  const float* wrow[B_IT];
+  bool wok[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int n = r0 + 16 * i;              // local column: which * HD + j
+    const int which = n / HD, j = n - which * HD;
+    wok[i] = n < C::NC;
+    wrow[i] = w + (long long)(wok[i] ? which * d + h * HD + j : 0) * d;
+  }
+  f32x4 ra[NK][A_IT], rb[NK][B_IT];
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc) {
+    const int k = kc * FA_KC + 4 * c4;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) ra[kc][i] = *(const f32x4*)(arow[i] + k);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) rb[kc][i] = *(const f32x4*)(wrow[i] + k);
+  }
+
+  // ---- LayerNorm statistics: 4 threads per row --------------------------------------------
+  if (ln_g) {
+    const int r = t >> 2, sub = t & 3;
+    const float* rowp = xb + (long long)min(r, L - 1) * d;
+    float s = 0.f;
+#pragma unroll 4
+    for (int k = sub * 4; k < d; k += 16) {
+      const f32x4 v = *(const f32x4*)(rowp + k);
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    const float mean = s / (float)d;
+    float vs = 0.f;
+#pragma unroll 4
+    for (int k = sub * 4; k < d; k += 16) {
+      const f32x4 v = *(const f32x4*)(rowp + k) - mean;
+      vs += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    vs += __shfl_xor(vs, 1, 64);
+    vs += __shfl_xor(vs, 2, 64);
+    if (sub == 0) {
+      stats[r] = mean;
+      stats[FA_ROWS + r] = 1.0f / sqrtf(vs / (float)d + ln_eps);
+    }
+  } else if (t < FA_ROWS) {
+    stats[t] = 0.f;
+    stats[FA_ROWS + t] = 1.f;
+  }
+  __syncthreads();
+
+  auto put = [&](__bf16* hp, __bf16* lp, int row, f32x4 v) {
+    const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+    const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+    *(bf16x4*)(hp + row * FA_LB + 4 * c4) = hi;
+    *(bf16x4*)(lp + row * FA_LB + 4 * c4) = lo;
+  };
+  auto store_chunk = [&](int kc, const f32x4(&rA)[A_IT], const f32x4(&rB)[B_IT]) {
+    const int k = kc * FA_KC + 4 * c4;
+    f32x4 g = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+    if (ln_g) {
+      g = *(const f32x4*)(ln_g + k);
+      be = *(const f32x4*)(ln_b + k);
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int r = r0 + 16 * i;
+      const f32x4 v = (rA[i] - stats[r]) * stats[FA_ROWS + r] * g + be;
+      put(Ah, Al, r, aok[i] ? v : zero4);
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) put(Bh, Bl, r0 + 16 * i, wok[i] ? rB[i] : zero4);
+  };
+
+  // ---- q|k|v = LN(x) . W_h^T on split-bf16 MFMA -----------------------------------------------
+  f32x16 acc[MAXB];
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  const int nblk = (L > 32 ? 2 : 1) * CBLK;  // row block 1 is skipped entirely when L <= 32
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc) {
+    store_chunk(kc, ra[kc], rb[kc]);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < MAXB; ++q) {
+      const int blk = wave + 4 * q;
+      if (blk < nblk) {
+        const int rbk = blk / CBLK, cbk = blk - rbk * CBLK;
+        const int ao = (rbk * 32 + (lane & 31)) * FA_LB + 8 * (lane >> 5);
+        const int bo = (cbk * 32 + (lane & 31)) * FA_LB + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < FA_KC / 16; ++ks) {
+          const bf16x8 xh = *(const bf16x8*)(Ah + ao + ks * 16), xl = *(const bf16x8*)(Al + ao + ks * 16);
+          const bf16x8 yh = *(const bf16x8*)(Bh + bo + ks * 16), yl = *(const bf16x8*)(Bl + bo + ks * 16);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[q], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- q|k|v (+bias, q scaled) to LDS as f32; the planes are dead now -----------------------------
+  float* QKV = smem;                          // [64][QS]
+  float* Ss = QKV + FA_ROWS * QS;             // [Lq][L+1]
+  float* inv = Ss + Lq * (L + 1);             // [Lq]
+  const float scale = 1.0f / sqrtf((float)HD);
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q) {
+    const int blk = wave + 4 * q;
+    if (blk < nblk) {
+      const int rbk = blk / CBLK, cbk = blk - rbk * CBLK;
+      const int n = cbk * 32 + (lane & 31);
+      const int which = n / HD, j = n - which * HD;
+      const float bv = (n < C::NC) ? bias[which * d + h * HD + j] : 0.f;
+      const float sc = which == 0 ? scale : 1.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        QKV[row * QS + n] = (acc[q][r] + bv) * sc;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- attention on the f32 q, k, v of this head (same arithmetic as mha_tile_kernel) --------------
+  const int SS = L + 1, q0 = L - Lq;
+  for (int e = t; e < Lq * L; e += 256) {
+    const int i = e / L, j = e - i * L;
+    const float* qr = QKV + (q0 + i) * QS;
+    const float* kr = QKV + j * QS + HD;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) s = fmaf(qr[c], kr[c], s);
+    Ss[i * SS + j] = s;
+  }
+  __syncthreads();
+  for (int i = t >> 2; i < Lq; i += 64) {
+    const int sub = t & 3;
+    float* row = Ss + i * SS;
+    float mx = -INFINITY;
+    for (int j = sub; j < L; j += 4) mx = fmaxf(mx, row[j]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    float sum = 0.f;
+    for (int j = sub; j < L; j += 4) {
+      const float p = expf(row[j] - mx);
+      row[j] = p;
+      sum += p;
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    if (sub == 0) inv[i] = 1.0f / sum;
+  }
+  __syncthreads();
+  for (int e = t; e < Lq * HD; e += 256) {
+    const int i = e / HD, c = e - i * HD;
+    const float* pr = Ss + i * SS;
+    const float* vcol = QKV + 2 * HD + c;
+    float a = 0.f;
+    for (int j = 0; j < L; ++j) a = fmaf(pr[j], vcol[j * QS], a);
+    out[((long long)b * Lq + i) * d + h * HD + c] = a * inv[i];
+  }
+}
+
+template <int HD, int NK>
+static int launch_fa(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* w,
+                     const float* bias, float* out, int B, int L, int Lq, int d, int nheads, hipStream_t st) {
+  const size_t lds = fa_lds_bytes<HD>(L, Lq);
+  if (lds > 160 * 1024) return sf_set_err(-1, "fused attention: LDS budget exceeded", __FILE__, __LINE__);
+  auto kern = qkv_attn_kernel<HD, NK>;
+  static size_t attr = 0;
+  if (lds > attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    attr = 160 * 1024;
+  }
+  sf_prof_begin(SF_K_MHA, st, 2.0 * B * L * 3.0 * d * d / nheads * nheads + 4.0 * (double)B * nheads * Lq * L * HD);
+  hipLaunchKernelGGL(kern, dim3(nheads, B), dim3(256), lds, st, x, ln_g, ln_b, ln_eps, w, bias, out, L, Lq, d);
+  sf_prof_end(SF_K_MHA, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// Returns 1 when the fused path does not apply (caller falls back to GEMM + attention kernels).
+int sf_qkv_attn_ex(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* in_proj_w,
+                   const float* in_proj_b, float* out, int B, int L, int Lq, int d, int nheads, hipStream_t st) {
+  if (B <= 0) return 0;
+  if (nheads <= 0 || d % nheads) return 1;
+  const int hd = d / nheads;
+  if (L > FA_ROWS || L < 1 || Lq < 1 || Lq > L || (d % FA_KC) != 0 || d > 256) return 1;
+#define FA_CASE(HD_, NK_) \
+  if (hd == HD_ && d == NK_ * FA_KC) \
+    return launch_fa<HD_, NK_>(x, ln_g, ln_b, ln_eps, in_proj_w, in_proj_b, out, B, L, Lq, d, nheads, st)
+  // the shapes the reference configures: rollout d=128/256 (8 heads), predictor d=128/192 (4 heads)
+  FA_CASE(16, 2);
+  FA_CASE(32, 2);
+  FA_CASE(32, 4);
+  FA_CASE(48, 3);
+  FA_CASE(64, 4);
+#undef FA_CASE
+  return 1;
+}
+
+extern "C" {
+// att[B*Lq, d] = concat_h softmax(q_h k_h^T / sqrt(hd)) v_h with [q|k|v] = LN?(x) in_proj_w^T + in_proj_b;
+// x [B*L, d]; queries are the last Lq tokens of each sequence; ln_gamma/ln_beta NULL = no LayerNorm.
+// Supported: L <= 64 and (d, head_dim) in {(128,16), (128,32), (256,32), (192,48), (256,64)}; negative code otherwise.
+int sf_qkv_attention_f32(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                         const float* in_proj_w, const float* in_proj_b, float* out, int B, int L, int Lq, int d_model,
+                         int num_heads, void* stream) {
+  SF_REQUIRE(x && in_proj_w && in_proj_b && out, "null pointer");
+  SF_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "ln_gamma/ln_beta must come together");
+  const int rc = sf_qkv_attn_ex(x, ln_gamma, ln_beta, ln_eps, in_proj_w, in_proj_b, out, B, L, Lq, d_model, num_heads,
+                                (hipStream_t)stream);
+  if (rc == 1) return sf_set_err(-1, "invalid argument: fused attention needs L <= 64, d % 64 == 0, head_dim 16/32/48/64",
+                                 __FILE__, __LINE__);
+  return rc;
+}
+}

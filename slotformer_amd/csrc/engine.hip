@@ -64,9 +64,16 @@ int tfm_layer(const sf_tfm_layer& w, float* x, TfmWs& ws, int B, int L, int Lq, 
   const float eps = 1e-5f;
   const SfRowMap rd = sf_rows(d);
   if (norm_first) {
-    SF_TRY(sf_linear_ex(x, rd, w.in_proj_w, w.in_proj_b, w.norm1_g, w.norm1_b, eps, nullptr, rd, 0, ws.qkv,
-                        sf_rows(3 * d), M, 3 * d, d, 0, st));
-    SF_TRY(sf_mha_ex(ws.qkv, ws.att, B, L, Lq, d, heads, st));
+    // split-bf16 mode: LN1 + per-head q|k|v projection + attention in one launch (attn_fused.hip)
+    int fused = 1;
+    if (sf_get_precision() == 1)
+      fused = sf_qkv_attn_ex(x, w.norm1_g, w.norm1_b, eps, w.in_proj_w, w.in_proj_b, ws.att, B, L, Lq, d, heads, st);
+    if (fused < 0 || fused > 1) return fused;
+    if (fused == 1) {
+      SF_TRY(sf_linear_ex(x, rd, w.in_proj_w, w.in_proj_b, w.norm1_g, w.norm1_b, eps, nullptr, rd, 0, ws.qkv,
+                          sf_rows(3 * d), M, 3 * d, d, 0, st));
+      SF_TRY(sf_mha_ex(ws.qkv, ws.att, B, L, Lq, d, heads, st));
+    }
     // residual rows: last Lq rows of each sequence of x
     const SfRowMap xr = (Lq == L) ? rd : sf_rows_batched(d, Lq, (long long)L * d, (long long)(L - Lq) * d);
     SF_TRY(sf_linear_ex(ws.att, rd, w.out_proj_w, w.out_proj_b, nullptr, nullptr, eps, x, xr, 0, ws.x2, rd, Mq,
@@ -79,9 +86,15 @@ int tfm_layer(const sf_tfm_layer& w, float* x, TfmWs& ws, int B, int L, int Lq, 
     *out = dst;
   } else {
     if (Lq != L) return sf_set_err(-1, "row pruning requires norm_first", __FILE__, __LINE__);
-    SF_TRY(sf_linear_ex(x, rd, w.in_proj_w, w.in_proj_b, nullptr, nullptr, eps, nullptr, rd, 0, ws.qkv,
-                        sf_rows(3 * d), M, 3 * d, d, 0, st));
-    SF_TRY(sf_mha_ex(ws.qkv, ws.att, B, L, L, d, heads, st));
+    int fused = 1;
+    if (sf_get_precision() == 1)
+      fused = sf_qkv_attn_ex(x, nullptr, nullptr, eps, w.in_proj_w, w.in_proj_b, ws.att, B, L, L, d, heads, st);
+    if (fused < 0 || fused > 1) return fused;
+    if (fused == 1) {
+      SF_TRY(sf_linear_ex(x, rd, w.in_proj_w, w.in_proj_b, nullptr, nullptr, eps, nullptr, rd, 0, ws.qkv,
+                          sf_rows(3 * d), M, 3 * d, d, 0, st));
+      SF_TRY(sf_mha_ex(ws.qkv, ws.att, B, L, L, d, heads, st));
+    }
     SF_TRY(sf_linear_ex(ws.att, rd, w.out_proj_w, w.out_proj_b, nullptr, nullptr, eps, x, rd, 0, ws.y, rd, M, d,
                         d, 0, st));
     SF_TRY(sf_layernorm_ex(ws.y, rd, w.norm1_g, w.norm1_b, ws.x2, rd, M, d, eps, st));

@@ -141,6 +141,126 @@ __global__ __launch_bounds__(256) void sa_attn_partial_kernel(
 }
 
 // -----------------------------------------------------------------------------------------
+// v2 of the iteration kernel (used when HW % 256 == 0): no cross-lane traffic in the hot loop.
+//   phase 1: ONE LANE PER PIXEL -- the lane walks its own K row (float4 loads), the N scaled
+//            queries are broadcast from LDS; logits, softmax over slots and +eps are lane-local.
+//   phase 2: the sums over pixels  num[n,d] = sum_p a[p,n] v[p,d]  are a [D x 64] . [64 x N]
+//            product per wave: v_mfma_f32_16x16x4_f32 with V loaded straight into A-operand
+//            layout (lane i owns the DB = D/16 consecutive channels DB*i .. DB*i+DB-1, so a
+//            wave reads whole 512/768-B rows) and the attention tile as B operand from LDS.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int D>
+__global__ __launch_bounds__(256) void sa_attn_mfma_kernel(
+    const float* __restrict__ k, const float* __restrict__ v, int ld, long long batch_stride,
+    const float* __restrict__ q, float scale, float eps, float* __restrict__ part_num,
+    float* __restrict__ part_den, float* __restrict__ attn_out, long long attn_bs, int HW, int N, int P) {
+  constexpr int DB = D / 16;  // channel blocks of the MFMA (each 16 channels wide, strided by DB)
+  constexpr int NS = SA_NMAX;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pix0 = chunk * 256 + wave * 64;  // 64 pixels per wave
+  __shared__ __attribute__((aligned(16))) float s_q[NS][D];
+  __shared__ float s_a[4][64][NS + 1];
+  __shared__ float s_red[4][NS][D + 1];
+  for (int idx = threadIdx.x; idx < NS * D; idx += 256) {
+    const int n = idx / D, d = idx - n * D;
+    s_q[n][d] = n < N ? q[((long long)b * N + n) * D + d] * scale : 0.f;
+  }
+  __syncthreads();
+
+  // ---- phase 1: lane = pixel ---------------------------------------------------------------
+  const float* krow = k + (long long)b * batch_stride + (long long)(pix0 + lane) * ld;
+  float s[NS];
+#pragma unroll
+  for (int n = 0; n < NS; ++n) s[n] = 0.f;
+#pragma unroll 2
+  for (int d0 = 0; d0 < D; d0 += 32) {
+    f32x4v kx[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) kx[u] = *(const f32x4v*)(krow + d0 + 4 * u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+      for (int n = 0; n < NS; ++n) {
+        const f32x4v qq = *(const f32x4v*)(&s_q[n][d0 + 4 * u]);
+        s[n] = fmaf(kx[u][0], qq[0], s[n]);
+        s[n] = fmaf(kx[u][1], qq[1], s[n]);
+        s[n] = fmaf(kx[u][2], qq[2], s[n]);
+        s[n] = fmaf(kx[u][3], qq[3], s[n]);
+      }
+    }
+  }
+  float mx = s[0];
+#pragma unroll
+  for (int n = 1; n < NS; ++n)
+    if (n < N) mx = fmaxf(mx, s[n]);
+  float sum = 0.f;
+#pragma unroll
+  for (int n = 0; n < NS; ++n) {
+    s[n] = n < N ? expf(s[n] - mx) : 0.f;
+    sum += s[n];
+  }
+  const float inv = 1.0f / sum;
+  float den[NS];
+#pragma unroll
+  for (int n = 0; n < NS; ++n) {
+    const float a0 = s[n] * inv;
+    if (attn_out && n < N) attn_out[(long long)b * attn_bs + (long long)n * HW + pix0 + lane] = a0;
+    const float a = n < N ? a0 + eps : 0.f;
+    den[n] = a;
+    s_a[wave][lane][n] = a;
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- phase 2: num^T[d, n] += V^T . A on the f32 MFMA ------------------------------------------
+  typedef float f32x4a __attribute__((ext_vector_type(4)));
+  f32x4a acc[DB];
+#pragma unroll
+  for (int j = 0; j < DB; ++j) acc[j] = f32x4a{0.f, 0.f, 0.f, 0.f};
+  const int li = lane & 15, lk = lane >> 4;  // A: row i = li (channels DB*li..), k = lk (pixel in group of 4)
+  const float* vbase = v + (long long)b * batch_stride + (long long)(pix0 + lk) * ld + DB * li;
+#pragma unroll 4
+  for (int ks = 0; ks < 16; ++ks) {
+    const float* vp = vbase + (long long)(4 * ks) * ld;
+    float vx[DB];
+#pragma unroll
+    for (int j = 0; j < DB; j += 4) {
+      const f32x4v t4 = *(const f32x4v*)(vp + j);
+      vx[j] = t4[0];
+      vx[j + 1] = t4[1];
+      vx[j + 2] = t4[2];
+      vx[j + 3] = t4[3];
+    }
+    const float bop = li < NS ? s_a[wave][4 * ks + lk][li] : 0.f;  // B[k = pixel][j = slot]
+#pragma unroll
+    for (int j = 0; j < DB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vx[j], bop, acc[j], 0, 0, 0);
+  }
+  // acc[j][r]: channel d = DB * (4*lk + r) + j, slot = li
+#pragma unroll
+  for (int n = 0; n < NS; ++n) den[n] = sf_wave_sum(den[n]);
+  if (li < NS) {
+#pragma unroll
+    for (int j = 0; j < DB; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_red[wave][li][DB * (4 * lk + r) + j] = acc[j][r];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int n = 0; n < NS; ++n) s_red[wave][n][D] = den[n];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < N * (D + 1); idx += 256) {
+    const int n = idx / (D + 1), d = idx - n * (D + 1);
+    const float t = s_red[0][n][d] + s_red[1][n][d] + s_red[2][n][d] + s_red[3][n][d];
+    if (d < D)
+      part_num[(((long long)b * P + chunk) * N + n) * D + d] = t;
+    else
+      part_den[((long long)b * P + chunk) * N + n] = t;
+  }
+}
+
+// -----------------------------------------------------------------------------------------
 // Fused slot update.  One workgroup per (batch, slot) row, ONE THREAD PER OUTPUT FEATURE: the
 // weights are stored transposed ([in, out]) so consecutive threads read consecutive addresses
 // and every load of the k-loop is independent (deep unroll keeps them in flight); the input
@@ -160,6 +280,33 @@ __device__ __forceinline__ float col_dot(const float* __restrict__ wt, int ldw, 
   return acc;
 }
 
+// two dot products sharing the loop: 2*UNR independent coalesced loads in flight per thread
+template <int UNR>
+__device__ __forceinline__ void col_dot2(const float* __restrict__ wa, const float* __restrict__ wb, int ldw, int col,
+                                         const float* xa, const float* xb, int K, float& ra, float& rb) {
+  float a = 0.f, b = 0.f;
+  int k = 0;
+  for (; k + UNR <= K; k += UNR) {
+    float va[UNR], vb[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      va[u] = wa[(long long)(k + u) * ldw + col];
+      vb[u] = wb[(long long)(k + u) * ldw + col];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      a = fmaf(va[u], xa[k + u], a);
+      b = fmaf(vb[u], xb[k + u], b);
+    }
+  }
+  for (; k < K; ++k) {
+    a = fmaf(wa[(long long)k * ldw + col], xa[k], a);
+    b = fmaf(wb[(long long)k * ldw + col], xb[k], b);
+  }
+  ra = a;
+  rb = b;
+}
+
 __global__ __launch_bounds__(768) void sa_slot_update_kernel(
     const float* __restrict__ part_num, const float* __restrict__ part_den, int P,
     const float* __restrict__ slots_prev, const float* __restrict__ w_ih_t,
@@ -176,6 +323,7 @@ __global__ __launch_bounds__(768) void sa_slot_update_kernel(
   // updates = sum_p num / sum_p den
   if (t < D) {
     float den = 0.f, a = 0.f;
+#pragma unroll 8
     for (int p = 0; p < P; ++p) {
       den += part_den[((long long)b * P + p) * N + n];
       a += part_num[(((long long)b * P + p) * N + n) * D + t];
@@ -186,8 +334,10 @@ __global__ __launch_bounds__(768) void sa_slot_update_kernel(
   __syncthreads();
   // GRU gate pre-activations: thread j owns gate feature j of both matrices
   if (t < 3 * D) {
-    s_gi[t] = col_dot<8>(w_ih_t, 3 * D, t, s_u, D) + b_ih[t];
-    s_gh[t] = col_dot<8>(w_hh_t, 3 * D, t, s_h, D) + b_hh[t];
+    float gi, gh;
+    col_dot2<32>(w_ih_t, w_hh_t, 3 * D, t, s_u, s_h, D, gi, gh);
+    s_gi[t] = gi + b_ih[t];
+    s_gh[t] = gh + b_hh[t];
   }
   __syncthreads();
   if (t < D) {
@@ -216,13 +366,14 @@ __global__ __launch_bounds__(768) void sa_slot_update_kernel(
   __syncthreads();
   if (t < D) s_ln[t] = (s_hn[t] - s_stat[0]) * s_stat[1] * ln_g[t] + ln_b[t];
   __syncthreads();
-  if (t < H) s_hid[t] = fmaxf(col_dot<8>(w1_t, H, t, s_ln, D) + b1[t], 0.f);
+  if (t < H) s_hid[t] = fmaxf(col_dot<32>(w1_t, H, t, s_ln, D) + b1[t], 0.f);
   __syncthreads();
-  if (t < D) slots_out[(long long)row * D + t] = s_hn[t] + col_dot<8>(w2_t, D, t, s_hid, H) + b2[t];
+  if (t < D) slots_out[(long long)row * D + t] = s_hn[t] + col_dot<32>(w2_t, D, t, s_hid, H) + b2[t];
 }
 
 // -----------------------------------------------------------------------------------------
 int sf_sa_pick_partials(int HW) {
+  if (HW % 256 == 0) return HW / 256;  // MFMA iteration kernel: 4 waves x 64 pixels per workgroup
   // pixels per workgroup: 4 waves x (multiple of 4) pixels; keep >= 128 pixels per workgroup
   int P = HW / 128;
   while (P > 1 && (HW % P != 0 || (HW / P) % 16 != 0)) --P;
@@ -257,6 +408,7 @@ int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch
   SF_REQUIRE(ld >= D, "bad leading dimension");
   const int P = sf_sa_pick_partials(HW);
   SF_REQUIRE((HW % P) == 0 && ((HW / P) % 16) == 0, "HW must be a multiple of 16");
+  SF_REQUIRE((ld % 4) == 0 && (batch_stride % 4) == 0, "k/v rows must be 16-byte aligned");
   if (B == 0) return 0;
   dim3 grid(P, B), block(256);
 #define SA_LAUNCH(VPT)                                                                            \
@@ -264,11 +416,24 @@ int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch
                      scale, eps, part_num, part_den, attn_out, attn_batch_stride, HW, N, P)
   // algorithmic bytes: one read of K and V
   sf_prof_begin(SF_K_SA_ITER, st, 2.0 * (double)B * HW * D * sizeof(float));
-  switch (D / 64) {
-    case 1: SA_LAUNCH(1); break;
-    case 2: SA_LAUNCH(2); break;
-    case 3: SA_LAUNCH(3); break;
-    default: SA_LAUNCH(4); break;
+  if (HW % 256 == 0) {
+#define SA_LAUNCH2(DD)                                                                                 \
+  hipLaunchKernelGGL(sa_attn_mfma_kernel<DD>, grid, block, 0, st, k, v, ld, batch_stride, q, scale, eps, \
+                     part_num, part_den, attn_out, attn_batch_stride, HW, N, P)
+    switch (D / 64) {
+      case 1: SA_LAUNCH2(64); break;
+      case 2: SA_LAUNCH2(128); break;
+      case 3: SA_LAUNCH2(192); break;
+      default: SA_LAUNCH2(256); break;
+    }
+#undef SA_LAUNCH2
+  } else {
+    switch (D / 64) {
+      case 1: SA_LAUNCH(1); break;
+      case 2: SA_LAUNCH(2); break;
+      case 3: SA_LAUNCH(3); break;
+      default: SA_LAUNCH(4); break;
+    }
   }
 #undef SA_LAUNCH
   sf_prof_end(SF_K_SA_ITER, st);

@@ -124,6 +124,18 @@ def mha(qkv, B, L, d_model, num_heads, Lq=None):
     return out
 
 
+def qkv_attention(x, in_proj_w, in_proj_b, B, L, num_heads, ln=None, Lq=None, ln_eps=1e-5):
+    """Fused LN? -> q|k|v projection -> attention;  x [B*L, d] -> [B*Lq, d] (before out_proj)."""
+    _chk(x, in_proj_w, in_proj_b, *(ln or ()))
+    d = x.shape[-1]
+    Lq = L if Lq is None else Lq
+    out = torch.empty(B * Lq, d, device=x.device, dtype=torch.float32)
+    g, b = ln if ln is not None else (None, None)
+    check(lib().sf_qkv_attention_f32(_p(x), _p(g), _p(b), ln_eps, _p(in_proj_w), _p(in_proj_b), _p(out), B, L, Lq, d,
+                                     num_heads, _stream()))
+    return out
+
+
 def lstm_pointwise(gates, c_prev):
     _chk(gates, c_prev)
     R, H4 = gates.shape

@@ -56,5 +56,5 @@ def test_argument_errors_without_gpu():
     lib = _lib.lib()
     assert lib.sf_linear_f32(None, 4, None, None, None, None, 1e-5, None, 4, None, 4, 1, 4, 4, 0, None) < 0
     assert b'null pointer' in lib.sf_last_error_string()
-    assert lib.sf_slot_attn_num_partials(4096) == 32
+    assert lib.sf_slot_attn_num_partials(4096) == 16
     assert lib.sf_rollout_workspace_bytes(None, 4) == 0

@@ -105,11 +105,12 @@ def test_pos_table(dev):
     close(ops.pos_embed_table(grid.to(dev), w.to(dev), b.to(dev)), F.linear(grid, w, b).reshape(4096, 64))
 
 
-@pytest.mark.parametrize('B,N,D', [(3, 7, 128), (2, 6, 192), (2, 8, 128), (1, 1, 64)])
-def test_slot_attn_iteration(dev, B, N, D):
+@pytest.mark.parametrize('B,N,D,HW', [(3, 7, 128, 4096), (2, 6, 192, 4096), (2, 8, 128, 4096), (1, 1, 64, 4096),
+                                      (2, 7, 128, 1024), (2, 5, 128, 2000), (1, 8, 256, 4096)])
+def test_slot_attn_iteration(dev, B, N, D, HW):
     """One iteration (attention half + slot update) vs the oracle's restatement of savi.py:76-100."""
     from slotformer_amd import ops
-    HW, H = 4096, 2 * D
+    H = 2 * D
     k, v, q = rnd(B, HW, D, seed=1), rnd(B, HW, D, seed=2), rnd(B, N, D, seed=3)
     slots = rnd(B, N, D, seed=4)
     pn, pd, attn = ops.slot_attn_iter(k.to(dev), v.to(dev), q.to(dev), want_attn=True)
@@ -141,6 +142,25 @@ def test_mha(dev, B, L, d, h, Lq):
     att = torch.softmax((q * hd**-0.5) @ k.transpose(-1, -2), -1)
     ref = (att @ v).transpose(1, 2).reshape(B, L, d)[:, L - Lq:].reshape(B * Lq, d)
     close(ops.mha(qkv.to(dev), B, L, d, h, Lq=Lq), ref)
+
+
+@pytest.mark.parametrize('B,L,d,h,Lq,ln', [(3, 42, 256, 8, 42, True), (3, 42, 256, 8, 7, True), (2, 48, 256, 8, 48, True),
+                                           (2, 36, 128, 8, 36, True), (4, 6, 128, 4, 6, True), (2, 6, 192, 4, 6, True),
+                                           (2, 8, 128, 4, 8, False), (1, 64, 256, 4, 64, True), (2, 33, 128, 8, 5, True)])  # (d, hd) pairs the engine fuses
+def test_fused_qkv_attention(dev, B, L, d, h, Lq, ln):
+    """LN -> in_proj -> MHA (before out_proj) vs torch fp32."""
+    from slotformer_amd import ops
+    x = rnd(B * L, d, seed=1)
+    w, b = rnd(3 * d, d, seed=2, scale=d**-0.5), rnd(3 * d, seed=3, scale=0.1)
+    g, be = 1 + 0.1 * rnd(d, seed=4), 0.1 * rnd(d, seed=5)
+    xin = F.layer_norm(x, (d, ), g, be) if ln else x
+    qkv = F.linear(xin, w, b)
+    hd = d // h
+    q, k, v = [t.view(B, L, h, hd).transpose(1, 2) for t in qkv.view(B, L, 3 * d).chunk(3, -1)]
+    att = torch.softmax((q * hd**-0.5) @ k.transpose(-1, -2), -1)
+    ref = (att @ v).transpose(1, 2).reshape(B, L, d)[:, L - Lq:].reshape(B * Lq, d)
+    out = ops.qkv_attention(x.to(dev), w.to(dev), b.to(dev), B, L, h, ln=(g.to(dev), be.to(dev)) if ln else None, Lq=Lq)
+    close(out, ref, rtol=1e-4, atol=1e-4)
 
 
 def test_lstm_and_sample(dev):
