@@ -16,40 +16,37 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
+constexpr int FA_NT = 512;   // 8 waves: the projection is fill-rate bound, more loads in flight per CU
 constexpr int FA_ROWS = 64;  // padded sequence length (two 32-row MFMA blocks)
 constexpr int FA_KC = 64;    // k-chunk of d staged per barrier
 constexpr int FA_LB = FA_KC + 8;
+constexpr int FA_SS = FA_ROWS + 4;  // row stride of the score / V^T tiles (17 16-B slots: conflict-free b128)
 
 template <int HD>
 struct FaCfg {
   static constexpr int NC = 3 * HD;                  // q|k|v columns of one head
   static constexpr int NCP = (NC + 31) / 32 * 32;    // padded to MFMA blocks
   static constexpr int CBLK = NCP / 32;
-  static constexpr int MAXB = (2 * CBLK + 3) / 4;    // 32x32 blocks per wave
-  static constexpr int B_IT = NCP * (FA_KC / 4) / 256;
-  static constexpr size_t plane_bytes = (size_t)2 * (FA_ROWS + NCP) * FA_LB * sizeof(__bf16);
-  static constexpr int QS = NCP + 1;                 // f32 qkv row stride (odd: conflict-free column access)
+  static constexpr int MAXB = (2 * CBLK + 7) / 8;    // 32x32 projection blocks per wave
+  static constexpr int B_IT = NCP * (FA_KC / 4) / FA_NT;
+  static constexpr int QSTR = HD + 4;                // f32 row stride of Q and K tiles ((HD+4)/4 is odd)
+  static constexpr int HDP = (HD + 31) / 32 * 32;    // V^T rows padded to MFMA blocks
+  static constexpr size_t plane_floats = (size_t)(FA_ROWS + NCP) * FA_LB + 2 * FA_ROWS;  // 2 bf16 planes + stats
+  static constexpr size_t attn_floats = (size_t)2 * FA_ROWS * QSTR + (size_t)HDP * FA_SS + (size_t)FA_ROWS * FA_SS + FA_ROWS;
+  static constexpr size_t lds_bytes = (plane_floats > attn_floats ? plane_floats : attn_floats) * sizeof(float);
 };
-
-template <int HD>
-size_t fa_lds_bytes(int L, int Lq) {
-  using C = FaCfg<HD>;
-  const size_t qkv = (size_t)FA_ROWS * C::QS * 4 + (size_t)Lq * (L + 1) * 4 + (size_t)Lq * 4;
-  const size_t planes = C::plane_bytes + 2 * FA_ROWS * 4;
-  return planes > qkv ? planes : qkv;
-}
 }  // namespace
 
-// NK = d / 64 chunks; every chunk's global loads are issued before the first wait (NK*(4+B_IT) float4 in flight
-// per thread), so the projection pays one memory latency instead of NK.
+// NK = d / 64 chunks; every chunk's global loads are issued before the first wait, so the projection
+// pays one memory latency instead of NK.  Attention (scores, PV) runs on the exact-f32 MFMA.
 template <int HD, int NK>
-__global__ __launch_bounds__(256) void qkv_attn_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
-                                                       const float* __restrict__ ln_b, float ln_eps,
-                                                       const float* __restrict__ w, const float* __restrict__ bias,
-                                                       float* __restrict__ out, int L, int Lq, int d) {
+__global__ __launch_bounds__(FA_NT) void qkv_attn_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
+                                                         const float* __restrict__ ln_b, float ln_eps,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int L, int Lq, int d) {
   using C = FaCfg<HD>;
-  constexpr int NCP = C::NCP, CBLK = C::CBLK, MAXB = C::MAXB, B_IT = C::B_IT, QS = C::QS;
-  constexpr int A_IT = FA_ROWS * (FA_KC / 4) / 256;  // 4
+  constexpr int NCP = C::NCP, CBLK = C::CBLK, MAXB = C::MAXB, B_IT = C::B_IT, QSTR = C::QSTR, HDP = C::HDP;
+  constexpr int A_IT = FA_ROWS * (FA_KC / 4) / FA_NT;  // 2
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __bf16* Ah = (__bf16*)smem;
   __bf16* Al = Ah + FA_ROWS * FA_LB;
@@ -58,14 +55,14 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const float* __restrict__
   float* stats = (float*)(Bl + NCP * FA_LB);  // [2][64]
   const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const float* xb = x + (long long)b * L * d;
-  const int c4 = t & 15, r0 = t >> 4;  // 16 float4 per 64-wide chunk row; 16 rows per pass
+  const int c4 = t & 15, r0 = t >> 4;  // 16 float4 per 64-wide chunk row; 32 rows per pass
 
   // ---- per-thread source rows (clamped; rows >= L are zeroed by a select) ----------------
   const float* arow[A_IT];
   bool aok[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const int r = r0 + 16 * i;
+    const int r = r0 + 32 * i;
     aok[i] = r < L;
     arow[i] = xb + (long long)min(r, L - 1) * d;
   }
@@ -73,7 +70,7 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const float* __restrict__
   bool wok[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    const int n = r0 + 16 * i;              // local column: which * HD + j
+    const int n = r0 + 32 * i;              // local column: which * HD + j
     const int which = n / HD, j = n - which * HD;
     wok[i] = n < C::NC;
     wrow[i] = w + (long long)(wok[i] ? which * d + h * HD + j : 0) * d;
@@ -88,27 +85,29 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const float* __restrict__
     for (int i = 0; i < B_IT; ++i) rb[kc][i] = *(const f32x4*)(wrow[i] + k);
   }
 
-  // ---- LayerNorm statistics: 4 threads per row --------------------------------------------
+  // ---- LayerNorm statistics: 8 threads per row --------------------------------------------
   if (ln_g) {
-    const int r = t >> 2, sub = t & 3;
+    const int r = t >> 3, sub = t & 7;
     const float* rowp = xb + (long long)min(r, L - 1) * d;
     float s = 0.f;
 #pragma unroll 4
-    for (int k = sub * 4; k < d; k += 16) {
+    for (int k = sub * 4; k < d; k += 32) {
       const f32x4 v = *(const f32x4*)(rowp + k);
       s += (v[0] + v[1]) + (v[2] + v[3]);
     }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
     const float mean = s / (float)d;
     float vs = 0.f;
 #pragma unroll 4
-    for (int k = sub * 4; k < d; k += 16) {
+    for (int k = sub * 4; k < d; k += 32) {
       const f32x4 v = *(const f32x4*)(rowp + k) - mean;
       vs += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
     vs += __shfl_xor(vs, 1, 64);
     vs += __shfl_xor(vs, 2, 64);
+    vs += __shfl_xor(vs, 4, 64);
     if (sub == 0) {
       stats[r] = mean;
       stats[FA_ROWS + r] = 1.0f / sqrtf(vs / (float)d + ln_eps);
@@ -135,12 +134,12 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const float* __restrict__
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const int r = r0 + 16 * i;
+      const int r = r0 + 32 * i;
       const f32x4 v = (rA[i] - stats[r]) * stats[FA_ROWS + r] * g + be;
       put(Ah, Al, r, aok[i] ? v : zero4);
     }
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) put(Bh, Bl, r0 + 16 * i, wok[i] ? rB[i] : zero4);
+    for (int i = 0; i < B_IT; ++i) put(Bh, Bl, r0 + 32 * i, wok[i] ? rB[i] : zero4);
   };
 
   // ---- q|k|v = LN(x) . W_h^T on split-bf16 MFMA -----------------------------------------------
@@ -149,14 +148,15 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const float* __restrict__
   for (int q = 0; q < MAXB; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-  const int nblk = (L > 32 ? 2 : 1) * CBLK;  // row block 1 is skipped entirely when L <= 32
+  const int nrb = L > 32 ? 2 : 1;   // row block 1 is skipped entirely when L <= 32
+  const int nblk = nrb * CBLK;
 #pragma unroll
   for (int kc = 0; kc < NK; ++kc) {
     store_chunk(kc, ra[kc], rb[kc]);
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < MAXB; ++q) {
-      const int blk = wave + 4 * q;
+      const int blk = wave + 8 * q;
       if (blk < nblk) {
         const int rbk = blk / CBLK, cbk = blk - rbk * CBLK;
         const int ao = (rbk * 32 + (lane & 31)) * FA_LB + 8 * (lane >> 5);
@@ -174,83 +174,130 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const float* __restrict__
     __syncthreads();
   }
 
-  // ---- q|k|v (+bias, q scaled) to LDS as f32; the planes are dead now -----------------------------
-  float* QKV = smem;                          // [64][QS]
-  float* Ss = QKV + FA_ROWS * QS;             // [Lq][L+1]
-  float* inv = Ss + Lq * (L + 1);             // [Lq]
+  // ---- spill q (scaled), k as [token][channel] and v transposed as [channel][token]; planes are dead ----
+  float* Qs = smem;                       // [64][QSTR]
+  float* Ks = Qs + FA_ROWS * QSTR;        // [64][QSTR]
+  float* VT = Ks + FA_ROWS * QSTR;        // [HDP][FA_SS]
+  float* Ss = VT + HDP * FA_SS;           // [64][FA_SS]
+  float* inv = Ss + FA_ROWS * FA_SS;      // [64]
   const float scale = 1.0f / sqrtf((float)HD);
+  if constexpr (HDP > HD) {               // zero the padded V^T rows (they feed the PV MFMA)
+    for (int idx = t; idx < (HDP - HD) * FA_SS; idx += FA_NT) VT[HD * FA_SS + idx] = 0.f;
+  }
 #pragma unroll
   for (int q = 0; q < MAXB; ++q) {
-    const int blk = wave + 4 * q;
+    const int blk = wave + 8 * q;
     if (blk < nblk) {
       const int rbk = blk / CBLK, cbk = blk - rbk * CBLK;
       const int n = cbk * 32 + (lane & 31);
       const int which = n / HD, j = n - which * HD;
-      const float bv = (n < C::NC) ? bias[which * d + h * HD + j] : 0.f;
-      const float sc = which == 0 ? scale : 1.f;
+      if (n < C::NC) {
+        const float bv = bias[which * d + h * HD + j];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        QKV[row * QS + n] = (acc[q][r] + bv) * sc;
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const float val = acc[q][r] + bv;
+          if (which == 0)
+            Qs[row * QSTR + j] = val * scale;
+          else if (which == 1)
+            Ks[row * QSTR + j] = val;
+          else
+            VT[j * FA_SS + row] = val;
+        }
       }
+    }
+  }
+  if (nrb == 1) {  // tokens 32..63 do not exist: their V^T columns must not inject garbage into PV
+    for (int idx = t; idx < HDP * 32; idx += FA_NT) VT[(idx >> 5) * FA_SS + 32 + (idx & 31)] = 0.f;
+  }
+  __syncthreads();
+
+  // ---- scores S = q k^T on the f32 MFMA: one 32x32 block per wave ----------------------------------
+  const int nsb = nrb * nrb;
+  if (wave < nsb) {
+    const int rbk = wave / nrb, cbk = wave - rbk * nrb;
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    const float* qp = Qs + (rbk * 32 + (lane & 31)) * QSTR + 4 * (lane >> 5);
+    const float* kp = Ks + (cbk * 32 + (lane & 31)) * QSTR + 4 * (lane >> 5);
+#pragma unroll
+    for (int kb = 0; kb < HD / 8; ++kb) {
+      const f32x4 a = *(const f32x4*)(qp + kb * 8), bq = *(const f32x4*)(kp + kb * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[s], sacc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      Ss[row * FA_SS + cbk * 32 + (lane & 31)] = sacc[r];
     }
   }
   __syncthreads();
 
-  // ---- attention on the f32 q, k, v of this head (same arithmetic as mha_tile_kernel) --------------
-  const int SS = L + 1, q0 = L - Lq;
-  for (int e = t; e < Lq * L; e += 256) {
-    const int i = e / L, j = e - i * L;
-    const float* qr = QKV + (q0 + i) * QS;
-    const float* kr = QKV + j * QS + HD;
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < HD; ++c) s = fmaf(qr[c], kr[c], s);
-    Ss[i * SS + j] = s;
-  }
-  __syncthreads();
-  for (int i = t >> 2; i < Lq; i += 64) {
-    const int sub = t & 3;
-    float* row = Ss + i * SS;
-    float mx = -INFINITY;
-    for (int j = sub; j < L; j += 4) mx = fmaxf(mx, row[j]);
-    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-    float sum = 0.f;
-    for (int j = sub; j < L; j += 4) {
-      const float p = expf(row[j] - mx);
-      row[j] = p;
-      sum += p;
+  // ---- row softmax over the L real keys, 8 lanes per query row; padded key columns become 0 ------------
+  {
+    const int i = t >> 3, sub = t & 7;
+    const int kmax = nrb * 32;
+    if (i >= L - Lq && i < L) {
+      float* row = Ss + i * FA_SS;
+      float mx = -INFINITY;
+      for (int j = sub; j < L; j += 8) mx = fmaxf(mx, row[j]);
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+      float sum = 0.f;
+      for (int j = sub; j < kmax; j += 8) {
+        const float p = j < L ? expf(row[j] - mx) : 0.f;
+        row[j] = p;
+        sum += p;
+      }
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      sum += __shfl_xor(sum, 4, 64);
+      if (sub == 0) inv[i] = 1.0f / sum;
     }
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
-    if (sub == 0) inv[i] = 1.0f / sum;
   }
   __syncthreads();
-  for (int e = t; e < Lq * HD; e += 256) {
-    const int i = e / HD, c = e - i * HD;
-    const float* pr = Ss + i * SS;
-    const float* vcol = QKV + 2 * HD + c;
-    float a = 0.f;
-    for (int j = 0; j < L; ++j) a = fmaf(pr[j], vcol[j * QS], a);
-    out[((long long)b * Lq + i) * d + h * HD + c] = a * inv[i];
+
+  // ---- O = P V on the f32 MFMA: block (row block, 32-channel block) per wave -----------------------------
+  constexpr int NVB = HDP / 32;
+  if (wave < nrb * NVB) {
+    const int rbk = wave / NVB, cbk = wave - rbk * NVB;
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    const float* pp = Ss + (rbk * 32 + (lane & 31)) * FA_SS + 4 * (lane >> 5);
+    const float* vp = VT + (cbk * 32 + (lane & 31)) * FA_SS + 4 * (lane >> 5);
+    for (int kb = 0; kb < nrb * 4; ++kb) {
+      const f32x4 a = *(const f32x4*)(pp + kb * 8), bq = *(const f32x4*)(vp + kb * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[s], oacc, 0, 0, 0);
+    }
+    const int c = cbk * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row >= L - Lq && row < L && c < HD)
+        out[((long long)b * Lq + (row - (L - Lq))) * d + h * HD + c] = oacc[r] * inv[row];
+    }
   }
 }
 
 template <int HD, int NK>
 static int launch_fa(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* w,
                      const float* bias, float* out, int B, int L, int Lq, int d, int nheads, hipStream_t st) {
-  const size_t lds = fa_lds_bytes<HD>(L, Lq);
-  if (lds > 160 * 1024) return sf_set_err(-1, "fused attention: LDS budget exceeded", __FILE__, __LINE__);
+  constexpr size_t lds = FaCfg<HD>::lds_bytes;
+  static_assert(lds <= 160 * 1024, "fused attention: LDS budget");
   auto kern = qkv_attn_kernel<HD, NK>;
-  static size_t attr = 0;
-  if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    attr = 160 * 1024;
+    attr = true;
   }
-  sf_prof_begin(SF_K_MHA, st, 2.0 * B * L * 3.0 * d * d / nheads * nheads + 4.0 * (double)B * nheads * Lq * L * HD);
-  hipLaunchKernelGGL(kern, dim3(nheads, B), dim3(256), lds, st, x, ln_g, ln_b, ln_eps, w, bias, out, L, Lq, d);
+  sf_prof_begin(SF_K_MHA, st, 6.0 * B * L * (double)d * d + 4.0 * (double)B * nheads * Lq * L * HD);
+  hipLaunchKernelGGL(kern, dim3(nheads, B), dim3(FA_NT), lds, st, x, ln_g, ln_b, ln_eps, w, bias, out, L, Lq, d);
   sf_prof_end(SF_K_MHA, st);
   SF_CHECK_LAUNCH();
   return 0;
