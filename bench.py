@@ -303,17 +303,28 @@ def main():
                 'kernel': 'sf_gemm_kernel<128,64,...,conv_nhwc> (5x5 conv 64->64 @64x64 as implicit GEMM, '
                 + ('split-bf16 MFMA: 3 bf16 MFMA flops per algorithmic flop -> peak = 2500/3)' if prec == 'bf16x3' else 'exact f32 MFMA)'),
                 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': ach / peak, 'traffic': pmc_traffic('conv_nhwc_implicit_gemm'),
+                'frac': ach / peak, 'frac_of_exact_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic('conv_nhwc_implicit_gemm'),
                 'traffic_unit': 'bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE, committed under profiles/)',
                 'algorithmic_bytes_per_launch': 2 * 32 * 4096 * 64 * 4 + 64 * 1600 * 4,
                 'flops_per_launch': flops_per_launch, 'avg_launch_us': conv['avg_us'], 'launches': conv['launches'],
             }
+        # the rollout replays as ONE hipGraph (900 launches), so it is reported as a unit: algorithmic
+        # FLOPs of SURVEY.md 8d (274.7 MFLOP per predicted frame per video, minus nothing: the last-layer
+        # row pruning is an exact saving we do not credit) over the graph's wall time
+        roll_flops = 274.7e6 * B * T_ROLL
+        res['roofline_rollout_graph'] = {
+            'kernel': 'hipGraph of the 50-step rollout (fused LN+QKV+attention, out-proj, FFN1, FFN2 per layer)',
+            'bound': 'latency (1000 dependent stages, M = B*L = 1344 rows); MFMA roof shown for scale',
+            'achieved': roll_flops / t_roll / 1e12, 'peak': (PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS),
+            'unit': 'TFLOP/s', 'frac': roll_flops / t_roll / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS),
+            'ms': 1e3 * t_roll, 'us_per_step': 1e6 * t_roll / T_ROLL,
+        }
         sa = prof.get('slot_attn_iter')
         if sa:
             bytes_per_launch = sa['work'] / sa['launches']
             gbps = bytes_per_launch / (sa['avg_us'] * 1e-6) / 1e9
             res['roofline_slot_attn'] = {
-                'kernel': 'sa_attn_partial_kernel<2> (one Slot-Attention iteration over K,V)', 'bound': 'hbm',
+                'kernel': 'sa_attn_mfma_kernel<128> (one Slot-Attention iteration over K,V)', 'bound': 'hbm',
                 'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': gbps / PEAK_HBM_GBPS,
                 'traffic': pmc_traffic('slot_attn_iter'), 'bytes_per_launch': bytes_per_launch, 'avg_launch_us': sa['avg_us'],
                 'launches': sa['launches'],

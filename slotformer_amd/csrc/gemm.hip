@@ -533,6 +533,9 @@ static int launch_by_id(int id, const SfGemmArgs& a, hipStream_t st) {
       case 111: return launch_cfg<64, 64, 2, 2, 1, 128, 2, 2, ALOAD, LN, true>(a, st);
       case 112: return launch_cfg<256, 64, 8, 1, 1, 32, 2, 2, ALOAD, LN, true>(a, st);
       case 113: return launch_cfg<64, 128, 2, 2, 1, 64, 2, 2, ALOAD, LN, true>(a, st);
+      case 114: return launch_cfg<32, 32, 1, 1, 8, 128, 2, 2, ALOAD, LN, true>(a, st);
+      case 115: return launch_cfg<32, 32, 1, 1, 8, 256, 2, 2, ALOAD, LN, true>(a, st);
+      case 116: return launch_cfg<32, 32, 1, 1, 8, 256, 1, 1, ALOAD, LN, true>(a, st);
       default: break;
     }
   }
@@ -573,7 +576,7 @@ static int dispatch_tiles(const SfGemmArgs& a, hipStream_t stream) {
       if (tiles(128, 64) >= 384) return launch_by_id<ALOAD, LN>(bf3 ? 100 : 1, a, stream);
       // small-M regime (rollout / slot-level GEMMs): latency-bound, favour many small workgroups
       if (bf3) {
-        if (a.K >= 512) return launch_by_id<ALOAD, LN>(a.M >= 512 ? 109 : 105, a, stream);
+        if (a.K >= 512) return launch_by_id<ALOAD, LN>(a.M >= 512 ? 109 : 115, a, stream);
         const long long t64 = tiles(64, 64);
         if (t64 > 300) return launch_by_id<ALOAD, LN>(107, a, stream);
         if (t64 >= 192) return launch_by_id<ALOAD, LN>(108, a, stream);

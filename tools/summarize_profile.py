@@ -40,6 +40,35 @@ for cname, d in (('FETCH_SIZE', f'{tag}_pmc_fetch'), ('WRITE_SIZE', f'{tag}_pmc_
     lines.append(f'# PMC pass {cname}: per-dispatch average  [{os.path.basename(f)}]')
     for k, cs in sorted(agg.items(), key=lambda kv: -sum(v[0] for v in kv[1].values()))[:14]:
         lines.append(f'{k:72s} ' + '  '.join(f'{c}={v[0] / v[1]:.4g} (n={v[1]})' for c, v in cs.items()))
+# ---- PMC traffic json for bench.py's roofline.traffic ------------------------------------------------
+import json
+import re
+
+
+def counter_avg(d, counter, pred):
+    f = find(d, '*counter_collection.csv')
+    if not f:
+        return None
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] == counter and pred(r['Kernel_Name']):
+            tot += float(r['Counter_Value'])
+            n += 1
+    return tot / n if n else None
+
+
+def is_conv(name):  # sf_gemm_kernel<..., ALOAD=1 (NHWC im2col), LN, BF3>
+    m = re.search(r'sf_gemm_kernel<([^>]*)>', name)
+    return bool(m) and m.group(1).replace(' ', '').split(',')[8] == '1'
+
+
+traffic = {'source': f'profiles/{tag}_profile_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)',
+           'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of wide coalesced reads)'}
+for key, pred in (('conv_nhwc_implicit_gemm', is_conv), ('slot_attn_iter', lambda n: 'sa_attn' in n)):
+    fe, wr = counter_avg(f'{tag}_pmc_fetch', 'FETCH_SIZE', pred), counter_avg(f'{tag}_pmc_write', 'WRITE_SIZE', pred)
+    if fe is not None and wr is not None:
+        traffic[key] = {'FETCH_SIZE_KB': fe, 'WRITE_SIZE_KB': wr, 'traffic_bytes_per_launch': (2 * fe + wr) * 1024}
+json.dump(traffic, open(os.path.join(OUT, f'{tag}_pmc_traffic.json'), 'w'), indent=1)
 txt = '\n'.join(lines)
 open(os.path.join(OUT, f'{tag}_profile_summary.txt'), 'w').write(txt + '\n')
 print(txt)
