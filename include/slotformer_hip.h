@@ -65,6 +65,19 @@ int sf_conv2d_nhwc_f32(const float* in, const float* w_packed, const float* bias
                        int F, int H, int W, int Cin, int Cout, int ks, int relu, void* stream);
 int sf_pack_conv_weight_f32(const float* w_oihw, float* w_ohwi, int Cout, int Cin, int ks, void* stream);
 
+/* Decoder building blocks (savi.py:252-293,504-525).  ConvTranspose2d(k, stride, padding=k/2,
+ * output_padding=stride-1) as a gather implicit GEMM: NHWC in [F,Hin,Win,Cin] -> [F,Hin*s,Win*s,Cout];
+ * w_packed [Cout,ks,ks,Cin] from the torch weight [Cin,Cout,ks,ks] (sf_pack_deconv_weight_f32). */
+int sf_conv_transpose2d_nhwc_f32(const float* in, const float* w_packed, const float* bias, float* out, int F,
+                                 int Hin, int Win, int Cin, int Cout, int ks, int stride, int relu, void* stream);
+int sf_pack_deconv_weight_f32(const float* w_iohw, float* w_ohwi, int Cin, int Cout, int ks, void* stream);
+/* out[R,P,D] = slots[R,D] (broadcast over the P = r*r positions) + table[P,D]  (savi.py:512-517). */
+int sf_slot_broadcast_f32(const float* slots, const float* table, float* out, int R, int P, int D, void* stream);
+/* dec [F*N,HW,4] (rgb + mask logit per slot) -> masks = softmax over slots [F,N,1,H,W], recons [F,N,3,H,W],
+ * recon_combined = sum_n recons*masks [F,3,H,W]  (savi.py:519-525); recons / masks may be NULL. */
+int sf_decode_combine_f32(const float* dec, float* recon_combined, float* recons, float* masks, int F, int N, int HW,
+                          void* stream);
+
 /* table[HW,C] = dense(grid)  (SoftPositionEmbed, utils.py:52-63; grid [HW,4]). */
 int sf_pos_embed_table_f32(const float* grid, const float* dense_w, const float* dense_b, float* table, int HW,
                            int C, void* stream);
@@ -166,6 +179,26 @@ size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B);
 int sf_savi_encode_f32(const sf_savi_encoder* m, const float* img, const float* noise, const float* prev_slots,
                        float* lstm_h, float* lstm_c, int state_valid, float* post_slots, float* kernel_dist,
                        float* attn, int B, int T, void* ws, size_t ws_bytes, void* stream);
+
+/* StoSAVi.decode (savi.py:504-525): spatial broadcast + position embedding -> transposed-conv stack -> 1x1 conv
+ * -> softmax-over-slots recombination. */
+typedef struct {
+  int resolution;      /* output H == W */
+  int dec_layers;      /* number of transposed convs (<= 8) */
+  int dec_channels[9]; /* dec_channels[0] == slot_size */
+  int dec_strides[8];
+  int dec_ks, dec_res; /* kernel size; broadcast resolution (square) */
+  int num_slots, slot_size;
+  const float* deconv_w[8]; /* packed [Cout,ks,ks,Cin] */
+  const float* deconv_b[8]; /* may be NULL */
+  const float *out_w, *out_b; /* final 1x1 conv: [4, C_last], [4] */
+  const float* pos_table;     /* [dec_res*dec_res, slot_size] */
+} sf_savi_decoder;
+
+size_t sf_savi_decode_workspace_bytes(const sf_savi_decoder* m, int F);
+/* slots [F,N,D] -> recon_combined [F,3,H,W], recons [F,N,3,H,W] (or NULL), masks [F,N,1,H,W] (or NULL). */
+int sf_savi_decode_f32(const sf_savi_decoder* m, const float* slots, float* recon_combined, float* recons,
+                       float* masks, int F, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

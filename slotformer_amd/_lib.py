@@ -48,6 +48,13 @@ class sf_savi_encoder(C.Structure):
         [('sa_eps', C.c_float)])
 
 
+class sf_savi_decoder(C.Structure):
+    _fields_ = ([('resolution', C.c_int), ('dec_layers', C.c_int), ('dec_channels', C.c_int * 9),
+                 ('dec_strides', C.c_int * 8), ('dec_ks', C.c_int), ('dec_res', C.c_int), ('num_slots', C.c_int),
+                 ('slot_size', C.c_int), ('deconv_w', FP * 8), ('deconv_b', FP * 8), ('out_w', FP), ('out_b', FP),
+                 ('pos_table', FP)])
+
+
 I, LL, F32, SZ, VP = C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_void_p
 
 # name -> (restype, argtypes): exactly the declarations of include/slotformer_hip.h
@@ -63,6 +70,12 @@ SIGNATURES = {
     'sf_conv2d_nchw_in_f32': (I, [FP, LL, FP, FP, FP, FP, I, I, I, I, I, I, I, I, VP]),
     'sf_conv2d_nhwc_f32': (I, [FP, FP, FP, FP, FP, I, I, I, I, I, I, I, VP]),
     'sf_pack_conv_weight_f32': (I, [FP, FP, I, I, I, VP]),
+    'sf_conv_transpose2d_nhwc_f32': (I, [FP, FP, FP, FP, I, I, I, I, I, I, I, I, VP]),
+    'sf_pack_deconv_weight_f32': (I, [FP, FP, I, I, I, VP]),
+    'sf_slot_broadcast_f32': (I, [FP, FP, FP, I, I, I, VP]),
+    'sf_decode_combine_f32': (I, [FP, FP, FP, FP, I, I, I, VP]),
+    'sf_savi_decode_workspace_bytes': (SZ, [C.POINTER(sf_savi_decoder), I]),
+    'sf_savi_decode_f32': (I, [C.POINTER(sf_savi_decoder), FP, FP, FP, FP, I, VP, SZ, VP]),
     'sf_pos_embed_table_f32': (I, [FP, FP, FP, FP, I, I, VP]),
     'sf_slot_attn_num_partials': (I, [I]),
     'sf_slot_attn_iter_f32': (I, [FP, FP, I, LL, FP, FP, FP, FP, I, I, I, I, F32, F32, VP]),

@@ -176,8 +176,7 @@ class StoSAVi(BaseModel):
         )
 
     def _build_decoder(self):
-        """Spatial-broadcast decoder parameters (savi.py:252-293).  Held for checkpoint
-        compatibility; decoding is row N2 ("next") of SURVEY.md 8f."""
+        """Spatial-broadcast decoder parameters (savi.py:252-293); arithmetic in sf_savi_decode_f32."""
         self.dec_channels = self.dec_dict['dec_channels']
         self.dec_resolution = self.dec_dict['dec_resolution']
         self.dec_ks = self.dec_dict['dec_ks']
@@ -295,9 +294,10 @@ class StoSAVi(BaseModel):
         return out_dict
 
     def decode(self, slots):
-        raise NotImplementedError(
-            'StoSAVi.decode (spatial-broadcast deconv decoder, savi.py:504-525) is row N2 of the scope table '
-            '(SURVEY.md 8f) and not built yet; set model.testing = True for slot extraction')
+        """slots [F,N,D] -> (recon_combined [F,3,H,W], recons [F,N,3,H,W], masks [F,N,1,H,W], slots);
+        reference savi.py:504-525, on the HIP decoder engine (sf_savi_decode_f32)."""
+        recon_combined, recons, masks = engine.savi_decode(self, slots)
+        return recon_combined, recons, masks, slots
 
     def _kld_loss(self, prior_dist, post_slots):
         """savi.py:337-353."""

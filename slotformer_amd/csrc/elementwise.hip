@@ -283,6 +283,55 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict_
   out[idx] = w[((long long)co * Cin + ci) * ks * ks + tap];
 }
 
+// [Cin][Cout][ks][ks] (ConvTranspose2d) -> [Cout][ks][ks][Cin]
+__global__ void pack_deconv_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout, int ks) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = Cout * Cin * ks * ks;
+  if (idx >= total) return;
+  const int ci = idx % Cin, rem = idx / Cin, tap = rem % (ks * ks), co = rem / (ks * ks);
+  out[idx] = w[((long long)ci * Cout + co) * ks * ks + tap];
+}
+
+// spatial broadcast + soft position embedding (savi.py:512-517): out[r, p, c] = slots[r, c] + table[p, c]
+__global__ void slot_broadcast_kernel(const float* __restrict__ slots, const float* __restrict__ table,
+                                      float* __restrict__ out, int R, int P, int D) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)R * P * D) return;
+  const int c = idx % D;
+  const long long rp = idx / D;
+  const int pp = rp % P;
+  const long long r = rp / P;
+  out[idx] = slots[r * D + c] + table[(long long)pp * D + c];
+}
+
+// decoder head (savi.py:519-525): dec [F*N, HW, 4] (r,g,b,mask-logit per slot) ->
+// masks = softmax over slots, recon_combined = sum_n recons * masks; all outputs NCHW-per-frame.
+__global__ void decode_combine_kernel(const float* __restrict__ dec, float* __restrict__ recon,
+                                      float* __restrict__ recons, float* __restrict__ masks, int F, int N, int HW) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)F * HW) return;
+  const int pix = idx % HW;
+  const long long f = idx / HW;
+  float mx = -INFINITY;
+  for (int n = 0; n < N; ++n) mx = fmaxf(mx, dec[((f * N + n) * HW + pix) * 4 + 3]);
+  float sum = 0.f;
+  for (int n = 0; n < N; ++n) sum += expf(dec[((f * N + n) * HW + pix) * 4 + 3] - mx);
+  const float inv = 1.0f / sum;
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int n = 0; n < N; ++n) {
+    const f32x4 v = *(const f32x4*)(dec + ((f * N + n) * HW + pix) * 4);
+    const float m = expf(v[3] - mx) * inv;
+    if (masks) masks[(f * N + n) * HW + pix] = m;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (recons) recons[((f * N + n) * 3 + c) * HW + pix] = v[c];
+      acc[c] = fmaf(v[c], m, acc[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) recon[(f * 3 + c) * HW + pix] = acc[c];
+}
+
 // table[p, c] = sum_j grid[p, j] * w[c, j] + b[c]      (SoftPositionEmbed, utils.py:52-63)
 __global__ void pos_table_kernel(const float* __restrict__ grid, const float* __restrict__ w,
                                  const float* __restrict__ b, float* __restrict__ out, int HW, int C) {
@@ -341,6 +390,36 @@ int sf_pack_conv_weight_f32(const float* w_oihw, float* w_ohwi, int Cout, int Ci
   const int total = Cout * Cin * ks * ks;
   hipLaunchKernelGGL(pack_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw,
                      w_ohwi, Cout, Cin, ks);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+int sf_pack_deconv_weight_f32(const float* w_iohw, float* w_ohwi, int Cin, int Cout, int ks, void* stream) {
+  SF_REQUIRE(w_iohw && w_ohwi && Cout > 0 && Cin > 0 && ks > 0, "bad pack arguments");
+  const int total = Cout * Cin * ks * ks;
+  hipLaunchKernelGGL(pack_deconv_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_iohw,
+                     w_ohwi, Cin, Cout, ks);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+int sf_slot_broadcast_f32(const float* slots, const float* table, float* out, int R, int P, int D, void* stream) {
+  SF_REQUIRE(slots && table && out && R >= 0 && P > 0 && D > 0, "bad broadcast arguments");
+  const long long total = (long long)R * P * D;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(slot_broadcast_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     slots, table, out, R, P, D);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+int sf_decode_combine_f32(const float* dec, float* recon_combined, float* recons, float* masks, int F, int N, int HW,
+                          void* stream) {
+  SF_REQUIRE(dec && recon_combined && F >= 0 && N >= 1 && HW > 0, "bad combine arguments");
+  const long long total = (long long)F * HW;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(decode_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     dec, recon_combined, recons, masks, F, N, HW);
   SF_CHECK_LAUNCH();
   return 0;
 }

@@ -397,4 +397,71 @@ int sf_savi_encode_f32(const sf_savi_encoder* m, const float* img, const float* 
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// StoSAVi.decode (savi.py:504-525)
+static int dec_cmax(const sf_savi_decoder* m) {
+  int c = 0;
+  for (int i = 0; i <= m->dec_layers && i < 9; ++i) c = m->dec_channels[i] > c ? m->dec_channels[i] : c;
+  return c;
+}
+// frames per chunk: keep one activation buffer around <= 256 MB
+static int dec_chunk(const sf_savi_decoder* m, int F) {
+  const double per_frame = (double)m->num_slots * m->resolution * m->resolution * dec_cmax(m);
+  int fc = (int)(64.0 * 1024 * 1024 / per_frame);
+  if (fc < 1) fc = 1;
+  return fc < F ? fc : F;
+}
+
+size_t sf_savi_decode_workspace_bytes(const sf_savi_decoder* m, int F) {
+  if (!m || F <= 0) return 0;
+  const size_t R = (size_t)dec_chunk(m, F) * m->num_slots, HW = (size_t)m->resolution * m->resolution;
+  return 2 * pad256(R * HW * dec_cmax(m)) + pad256(R * HW * 4) + 4096;
+}
+
+int sf_savi_decode_f32(const sf_savi_decoder* m, const float* slots, float* recon_combined, float* recons,
+                       float* masks, int F, void* ws, size_t ws_bytes, void* stream) {
+  SF_REQUIRE(m && slots && recon_combined && ws, "null pointer");
+  SF_REQUIRE(F >= 1 && m->dec_layers >= 1 && m->dec_layers <= 8 && m->num_slots >= 1 && m->dec_res >= 1 && (m->dec_ks & 1),
+             "bad decoder config");
+  SF_REQUIRE(m->dec_channels[0] == m->slot_size && (m->slot_size % 4) == 0, "dec_channels[0] must equal slot_size");
+  SF_REQUIRE(m->pos_table && m->out_w && m->out_b, "null decoder weight");
+  int size = m->dec_res;
+  for (int i = 0; i < m->dec_layers; ++i) {
+    SF_REQUIRE(m->deconv_w[i] != nullptr && m->dec_strides[i] >= 1 && (m->dec_channels[i + 1] % 4) == 0, "bad deconv layer");
+    size *= m->dec_strides[i];
+  }
+  SF_REQUIRE(size == m->resolution, "decoder output size does not match the resolution (savi.py:279-284)");
+  SF_REQUIRE(ws_bytes >= sf_savi_decode_workspace_bytes(m, F), "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int N = m->num_slots, D = m->slot_size, res = m->resolution, HW = res * res;
+  const int Fc = dec_chunk(m, F), cmax = dec_cmax(m);
+  Bump bp{(char*)ws, ws_bytes};
+  float* bufA = bp.take((size_t)Fc * N * HW * cmax);
+  float* bufB = bp.take((size_t)Fc * N * HW * cmax);
+  float* dec = bp.take((size_t)Fc * N * HW * 4);
+  if (!bp.ok) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
+  for (int f0 = 0; f0 < F; f0 += Fc) {
+    const int nf = (F - f0 < Fc) ? (F - f0) : Fc, R = nf * N;
+    SF_TRY(sf_slot_broadcast_f32(slots + (long long)f0 * N * D, m->pos_table, bufA, R, m->dec_res * m->dec_res, D, st));
+    float* cur = bufA;
+    float* nxt = bufB;
+    int hin = m->dec_res;
+    for (int i = 0; i < m->dec_layers; ++i) {
+      SF_TRY(sf_conv_transpose2d_nhwc_f32(cur, m->deconv_w[i], m->deconv_b[i], nxt, R, hin, hin, m->dec_channels[i],
+                                          m->dec_channels[i + 1], m->dec_ks, m->dec_strides[i], 1, st));
+      hin *= m->dec_strides[i];
+      float* tmp = cur;
+      cur = nxt;
+      nxt = tmp;
+    }
+    const int Cl = m->dec_channels[m->dec_layers];
+    SF_TRY(sf_linear_ex(cur, sf_rows(Cl), m->out_w, m->out_b, nullptr, nullptr, 0.f, nullptr, sf_rows(4), 0, dec,
+                        sf_rows(4), R * HW, 4, Cl, 0, st));
+    SF_TRY(sf_decode_combine_f32(dec, recon_combined + (long long)f0 * 3 * HW,
+                                 recons ? recons + (long long)f0 * N * 3 * HW : nullptr,
+                                 masks ? masks + (long long)f0 * N * HW : nullptr, nf, N, HW, st));
+  }
+  return 0;
+}
+
 }  // extern "C"

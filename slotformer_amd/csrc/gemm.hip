@@ -21,7 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-enum { ALOAD_PLAIN = 0, ALOAD_CONV_NHWC = 1, ALOAD_CONV_NCHW = 2 };
+enum { ALOAD_PLAIN = 0, ALOAD_CONV_NHWC = 1, ALOAD_CONV_NCHW = 2, ALOAD_DECONV_NHWC = 3 };
 
 struct SfGemmArgs {
   const float* A;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
   // XCD-aware tile order for the conv: workgroup b lands on XCD b % 8, so give each XCD a contiguous
   // run of output tiles (neighbouring tiles share 4 of their 6 halo rows -> hits in that XCD's L2).
   int bid = blockIdx.x;
-  if constexpr (ALOAD == ALOAD_CONV_NHWC) {
+  if constexpr (ALOAD == ALOAD_CONV_NHWC || ALOAD == ALOAD_DECONV_NHWC) {
     const int nb = gridDim.x;
     if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
   }
@@ -150,6 +150,21 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
         for (int i = 0; i < A_IT; ++i) {
           const f32x4 v = *(const f32x4*)(arow[i] + kc4);
           ra[i] = kok ? v : zero4;
+        }
+      } else if constexpr (ALOAD == ALOAD_DECONV_NHWC) {
+        // ConvTranspose2d gather: out(oy,ox) += in(iy,ix) * W[ky][kx] with oy = iy*s - pad + ky, i.e. the tap
+        // contributes iff (oy + pad - ky) is a non-negative multiple of s inside the input.  k = tap*Cin + cin.
+        const int tap = kc4 / p.cCin, cin = kc4 - tap * p.cCin;
+        const int ky = tap / p.cKs, kx = tap - ky * p.cKs, pad = p.cKs >> 1, st = p.cStride;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+          const int ny = cy[i] + pad - ky, nx = cx[i] + pad - kx;
+          const int iy = ny / st, ix = nx / st;
+          const bool ok = kok && ny >= 0 && nx >= 0 && iy * st == ny && ix * st == nx && iy < p.cInH && ix < p.cInW;
+          const int yc = min(max(iy, 0), p.cInH - 1), xc = min(max(ix, 0), p.cInW - 1);
+          const f32x4 v = *(const f32x4*)(p.A + (long long)cf[i] * p.cFrameStride +
+                                          ((long long)(yc * p.cInW + xc) * p.cCin + cin));
+          ra[i] = ok ? v : zero4;
         }
       } else {  // NHWC im2col: k = tap * Cin + cin
         int tap, cin, ky, kx;
@@ -486,7 +501,7 @@ static int launch_cfg(const SfGemmArgs& a, hipStream_t stream) {
     attr_set = true;
   }
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
-  const int cls = ALOAD == ALOAD_PLAIN ? SF_K_LINEAR : (ALOAD == ALOAD_CONV_NHWC ? SF_K_CONV_NHWC : SF_K_CONV_FIRST);
+  const int cls = ALOAD == ALOAD_PLAIN ? SF_K_LINEAR : (ALOAD == ALOAD_CONV_NCHW ? SF_K_CONV_FIRST : SF_K_CONV_NHWC);
   sf_prof_begin(cls, stream, 2.0 * (double)a.M * (double)a.N * (double)a.K);
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * KW * 64), lds, stream, a);
   sf_prof_end(cls, stream);
@@ -569,7 +584,7 @@ static int dispatch_tiles(const SfGemmArgs& a, hipStream_t stream) {
     if (f >= 0) return launch_by_id<ALOAD, LN>(f, a, stream);
     const bool bf3 = sf_get_precision() == 1;
     // choices below come from tools/gemm_bench.py on MI355X (profiles/r01_gemm_configs.txt)
-    if constexpr (ALOAD == ALOAD_CONV_NHWC) {
+    if constexpr (ALOAD == ALOAD_CONV_NHWC || ALOAD == ALOAD_DECONV_NHWC) {
       return launch_by_id<ALOAD, LN>(bf3 ? 100 : 28, a, stream);
     } else {
       if (a.N > 64 && tiles(128, 128) >= 384) return launch_by_id<ALOAD, LN>(bf3 ? 102 : 31, a, stream);
@@ -600,6 +615,7 @@ int sf_gemm_dispatch(const SfGemmArgs& a_in, int aload, hipStream_t stream) {
   if (aload == ALOAD_PLAIN) return ln ? dispatch_tiles<ALOAD_PLAIN, true>(a, stream)
                                       : dispatch_tiles<ALOAD_PLAIN, false>(a, stream);
   if (aload == ALOAD_CONV_NHWC) return dispatch_tiles<ALOAD_CONV_NHWC, false>(a, stream);
+  if (aload == ALOAD_DECONV_NHWC) return dispatch_tiles<ALOAD_DECONV_NHWC, false>(a, stream);
   return dispatch_tiles<ALOAD_CONV_NCHW, false>(a, stream);
 }
 
@@ -650,6 +666,24 @@ int sf_conv2d_nhwc_f32(const float* in, const float* w_packed, const float* bias
   a.cH = H; a.cW = W; a.cInH = H; a.cInW = W; a.cCin = Cin; a.cKs = ks; a.cStride = 1;
   a.cFrameStride = (long long)H * W * Cin;
   return sf_gemm_dispatch(a, ALOAD_CONV_NHWC, (hipStream_t)stream);
+}
+
+// ConvTranspose2d(k, stride, padding=k/2, output_padding=stride-1): NHWC in [F,Hin,Win,Cin] -> NHWC out
+// [F,Hin*stride,Win*stride,Cout]; w_packed [Cout][ks][ks][Cin] = torch weight[Cin,Cout,k,k].permute(1,2,3,0).
+int sf_conv_transpose2d_nhwc_f32(const float* in, const float* w_packed, const float* bias, float* out, int F,
+                                 int Hin, int Win, int Cin, int Cout, int ks, int stride, int relu, void* stream) {
+  SF_REQUIRE(in && w_packed && out, "null pointer");
+  SF_REQUIRE(F >= 0 && Hin > 0 && Win > 0 && Cin > 0 && (Cin % 4) == 0 && Cout > 0 && (ks & 1) && stride >= 1,
+             "bad deconv shape");
+  SfGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  const int Ho = Hin * stride, Wo = Win * stride;
+  a.A = in; a.W = w_packed; a.ldw = ks * ks * Cin; a.bias = bias;
+  a.C = out; a.cmap = sf_rows(Cout); a.rmap = sf_rows(Cout);
+  a.M = F * Ho * Wo; a.N = Cout; a.K = ks * ks * Cin; a.relu = relu;
+  a.cH = Ho; a.cW = Wo; a.cInH = Hin; a.cInW = Win; a.cCin = Cin; a.cKs = ks; a.cStride = stride;
+  a.cFrameStride = (long long)Hin * Win * Cin;
+  return sf_gemm_dispatch(a, ALOAD_DECONV_NHWC, (hipStream_t)stream);
 }
 
 // first conv: NCHW image (frame f at img + f*frame_stride floats) -> NHWC, "same" padding k//2.

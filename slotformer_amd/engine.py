@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import lib, check, sf_tfm_layer, sf_rollouter, sf_savi_encoder
+from ._lib import lib, check, sf_tfm_layer, sf_rollouter, sf_savi_encoder, sf_savi_decoder
 from . import ops
 
 _WORKSPACES = {}
@@ -244,3 +244,63 @@ def savi_encode(m, img, prev_slots=None, noise=None, want_attn=False, ws_slot=0)
                                    post.data_ptr(), P(kdist), P(attn), B, T, ws.data_ptr(), ws.numel(),
                                    torch.cuda.current_stream().cuda_stream))
     return post, kdist, attn
+
+
+# ---------------------------------------------------------------------------------------------
+def _module_sig(*mods):
+    return tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
+
+
+def decoder_plan(m):
+    """m: StoSAVi or SlotFormer (both hold `decoder`, `decoder_pos_embedding`, dec_* attributes)."""
+    sig = _module_sig(m.decoder, m.decoder_pos_embedding)
+    plan = getattr(m, '_sf_dec_plan', None)
+    if plan is not None and plan.sig == sig:
+        return plan
+    plan = _Plan()
+    s = sf_savi_decoder()
+    if m.resolution[0] != m.resolution[1] or m.dec_resolution[0] != m.dec_resolution[1]:
+        raise NotImplementedError('square resolutions only')
+    s.resolution, s.dec_res, s.dec_ks = m.resolution[0], m.dec_resolution[0], m.dec_ks
+    s.num_slots, s.slot_size = m.num_slots, m.slot_size
+    ch = list(m.dec_channels)
+    n = len(ch) - 1
+    s.dec_layers = n
+    for i, c in enumerate(ch):
+        s.dec_channels[i] = c
+    for i in range(n):
+        dc = m.decoder[i][0]
+        s.dec_strides[i] = dc.stride[0]
+        s.deconv_w[i] = plan.dp(ops.pack_deconv_weight(dc.weight.detach().float().contiguous()))
+        s.deconv_b[i] = plan.dp(dc.bias)
+    head = m.decoder[n]
+    s.out_w = plan.dp(head.weight.detach().float().reshape(head.out_channels, head.in_channels).contiguous())
+    s.out_b = plan.dp(head.bias)
+    pe = m.decoder_pos_embedding
+    s.pos_table = plan.dp(ops.pos_embed_table(pe.grid.detach().float(), pe.dense.weight.detach().float().contiguous(),
+                                              pe.dense.bias.detach().float().contiguous()))
+    plan.struct, plan.sig = s, sig
+    m._sf_dec_plan = plan
+    return plan
+
+
+def savi_decode(m, slots, ws_slot=0):
+    """StoSAVi.decode on device: slots [F,N,D] -> (recon_combined [F,3,H,W], recons [F,N,3,H,W], masks [F,N,1,H,W])."""
+    if torch.is_grad_enabled() and slots.requires_grad:
+        raise NotImplementedError('slotformer_amd: decode is inference-only (row N1); wrap in torch.no_grad()')
+    if not slots.is_cuda:
+        raise RuntimeError('slotformer_amd: inputs must live on a HIP device; there is no CPU fallback')
+    slots = slots.detach().float().contiguous()
+    plan = decoder_plan(m)
+    F_, N, D = slots.shape
+    H = plan.struct.resolution
+    dev = slots.device
+    recon = torch.empty(F_, 3, H, H, device=dev, dtype=torch.float32)
+    recons = torch.empty(F_, N, 3, H, H, device=dev, dtype=torch.float32)
+    masks = torch.empty(F_, N, 1, H, H, device=dev, dtype=torch.float32)
+    need = lib().sf_savi_decode_workspace_bytes(C.byref(plan.struct), F_)
+    ws = workspace(dev, need, ('dec', ws_slot))
+    check(lib().sf_savi_decode_f32(C.byref(plan.struct), slots.data_ptr(), recon.data_ptr(), recons.data_ptr(),
+                                   masks.data_ptr(), F_, ws.data_ptr(), ws.numel(),
+                                   torch.cuda.current_stream().cuda_stream))
+    return recon, recons, masks

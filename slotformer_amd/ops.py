@@ -55,6 +55,25 @@ def pack_conv_weight(w):
     return out
 
 
+def pack_deconv_weight(w):
+    """ConvTranspose2d weight [Cin,Cout,k,k] -> [Cout,k,k,Cin]."""
+    _chk(w)
+    out = torch.empty(w.shape[1], w.shape[2], w.shape[3], w.shape[0], device=w.device, dtype=torch.float32)
+    check(lib().sf_pack_deconv_weight_f32(_p(w), _p(out), w.shape[0], w.shape[1], w.shape[2], _stream()))
+    return out
+
+
+def conv_transpose2d_nhwc(x, w_packed, bias, stride, relu=True):
+    """x [F,H,W,Cin] NHWC, w_packed [Cout,k,k,Cin] -> [F,H*s,W*s,Cout] (padding k//2, output_padding s-1)."""
+    _chk(x, w_packed, bias)
+    F_, H, W, Cin = x.shape
+    Cout, ks = w_packed.shape[0], w_packed.shape[1]
+    out = torch.empty(F_, H * stride, W * stride, Cout, device=x.device, dtype=torch.float32)
+    check(lib().sf_conv_transpose2d_nhwc_f32(_p(x), _p(w_packed), _p(bias), _p(out), F_, H, W, Cin, Cout, ks, stride,
+                                             int(relu), _stream()))
+    return out
+
+
 def pos_embed_table(grid, dense_w, dense_b):
     """grid [1,H,W,4] -> [H*W, C]."""
     grid = grid.reshape(-1, 4).contiguous()

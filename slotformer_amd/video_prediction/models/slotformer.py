@@ -120,7 +120,7 @@ class SlotFormer(BaseModel):
 
     def _build_decoder(self):
         """Frozen SAVi decoder copy (slotformer.py:196-218): same parameters, loaded from
-        `dec_ckp_path` by key prefix.  Decoding itself is row N2 ("next")."""
+        `dec_ckp_path` by key prefix."""
         StoSAVi._build_decoder(self)
         ckp_path = self.dec_dict['dec_ckp_path']
         assert ckp_path, 'Please provide pretrained decoder weight'

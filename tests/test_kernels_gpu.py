@@ -98,6 +98,21 @@ def test_conv_nhwc(dev, relu, with_add, precision):
           **tol(precision))
 
 
+@pytest.mark.parametrize('hin,cin,cout,stride', [(8, 128, 64, 2), (16, 64, 64, 2), (32, 64, 64, 1), (5, 192, 64, 2)])
+def test_conv_transpose(dev, hin, cin, cout, stride, precision):
+    """ConvTranspose2d(k=5, stride, padding=2, output_padding=stride-1) + ReLU as a gather implicit GEMM."""
+    from slotformer_amd import ops
+    x = rnd(3, hin, hin, cin, seed=1)
+    w, b = rnd(cin, cout, 5, 5, seed=2, scale=(25 * cin)**-0.5 * 2), rnd(cout, seed=3, scale=0.1)
+    ref = F.relu(F.conv_transpose2d(x.permute(0, 3, 1, 2), w, b, stride=stride, padding=2,
+                                    output_padding=stride - 1)).permute(0, 2, 3, 1)
+    wp = ops.pack_deconv_weight(w.to(dev))
+    assert torch.equal(wp.cpu(), w.permute(1, 2, 3, 0).contiguous())
+    out = ops.conv_transpose2d_nhwc(x.to(dev), wp, b.to(dev), stride)
+    assert out.shape == ref.shape
+    close(out, ref, **tol(precision))
+
+
 def test_pos_table(dev):
     from slotformer_amd import ops
     grid = oracle.build_grid((64, 64))
