@@ -115,3 +115,27 @@ def test_shard_range():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_slot_file_formats(tmp_path):
+    """Row N3: pickle layout {split: {basename: [T,N,C] f32}} and per-sample PHYRE .npy files."""
+    import numpy as np
+    from slotformer_amd import slot_io
+    files = ['/data/CLEVRER/videos/train/video_00000.mp4', '/data/CLEVRER/videos/train/video_00001.mp4']
+    slots = np.random.RandomState(0).randn(2, 16, 7, 128)
+    d = slot_io.slots_to_dict(files, slots)
+    assert set(d) == {'video_00000.mp4', 'video_00001.mp4'} and d['video_00001.mp4'].dtype == np.float32
+    path = str(tmp_path / 'out' / 'slots.pkl')
+    slot_io.dump_slots(path, train=d, val={})
+    back = slot_io.load_slots(path)
+    assert set(back) == {'train', 'val'} and np.array_equal(back['train']['video_00000.mp4'], d['video_00000.mp4'])
+    clip = slot_io.read_clip(back['train'], files[1], start_idx=1, n_sample_frames=6, frame_offset=2)
+    assert clip.shape == (6, 7, 128) and np.array_equal(clip[2], d['video_00001.mp4'][5])
+    with pytest.raises(ValueError):
+        slot_io.read_clip(back['train'], '/x/missing.mp4', 0, 1, 1)
+    root = str(tmp_path / 'phyre')
+    assert slot_io.phyre_resume_index(root, 10, 20) == 10
+    for i in (10, 11, 12):
+        slot_io.save_phyre_slots(root, i, slots[0], vid_len=9)
+    assert np.load(slot_io.phyre_path(root, 11)).shape == (9, 7, 128)
+    assert slot_io.phyre_resume_index(root, 10, 20) == 12  # newest file is redone
