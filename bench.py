@@ -151,10 +151,12 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a HIP device'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('SF_BENCH_FORCE_DIST') == '1'  # the latter: exercise the RCCL path on one GPU
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)  # RCCL
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)  # RCCL
 
     from slotformer_amd import engine, _lib
     lib = _lib.lib()
@@ -219,7 +221,7 @@ def main():
                 rollout_eager()
 
         def barrier():
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
 
@@ -261,7 +263,7 @@ def main():
             lib.sf_profile_enable(0)
             breakdown = read_profile(lib)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -335,7 +337,7 @@ def main():
             log('cpu baseline ...')
             res['cpu_baseline'] = cpu_baseline(args.cpu_sample)
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -657,6 +657,14 @@ int sf_conv2d_nhwc_f32(const float* in, const float* w_packed, const float* bias
                        void* stream) {
   SF_REQUIRE(in && w_packed && out, "null pointer");
   SF_REQUIRE(F >= 0 && H > 0 && W > 0 && Cin > 0 && (Cin % 4) == 0 && Cout > 0 && (ks & 1), "bad conv shape");
+  if (sf_get_precision() == 1 && forced_cfg() < 0) {
+    // encoder shape (5x5, 64->64, 64-wide rows): halo-resident kernel (conv_halo.hip); SF_CONV_HALO=0 disables
+    static const bool halo_on = []() { const char* e = getenv("SF_CONV_HALO"); return !(e && e[0] == '0'); }();
+    if (halo_on) {
+      const int rc = sf_conv5x5_halo_ex(in, w_packed, bias, add, out, F, H, W, Cin, Cout, ks, relu, (hipStream_t)stream);
+      if (rc != 1) return rc;
+    }
+  }
   SfGemmArgs a;
   memset(&a, 0, sizeof(a));
   a.A = in; a.W = w_packed; a.ldw = ks * ks * Cin; a.bias = bias;

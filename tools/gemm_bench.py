@@ -74,6 +74,8 @@ def main():
         os.environ['SF_GEMM_CFG'] = str(cfg)
         t = timeit(lambda: ops.conv2d_nhwc(x, w, b), iters=5)
         res.append((t, cfg))
+    os.environ.pop('SF_GEMM_CFG', None)
+    res.append((timeit(lambda: ops.conv2d_nhwc(x, w, b), iters=5), 'halo'))
     res.sort()
     gf = 2.0 * 32 * 4096 * 64 * 1600
     print('conv 32 frames: ' + '  '.join(f'cfg{c}:{t:.0f}us' for t, c in res) + f'   best {gf / res[0][0] / 1e6:.1f} TF')
