@@ -139,6 +139,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch the rollout eagerly instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8)
+    ap.add_argument('--no-overlap', action='store_true', help='run encode and rollout of each batch back-to-back on one stream '
+                    '(default: encode of batch i+1 overlaps the rollout graph of batch i on a second HIP stream)')
     ap.add_argument('--rollout-streams', type=int, default=1, help='batch groups rolled out concurrently on separate HIP streams')
     ap.add_argument('--precision', choices=['bf16x3', 'f32'], default=None, help='matrix arithmetic mode (default: library default = bf16x3)')
     ap.add_argument('--breakdown', action='store_true', help='extra untimed pass with every kernel class timed')
@@ -167,12 +169,13 @@ def main():
     savi, roll = build_models(dev)
     img = synthetic_img(B, seed=1234 + rank).to(dev)
     N, D = 7, 128
-    buf = torch.zeros(B, T_BURN + T_ROLL, N, D, device=dev)
+    bufs = [torch.zeros(B, T_BURN + T_ROLL, N, D, device=dev) for _ in range(2)]
+    buf = bufs[0]
 
-    def encode():
+    def encode(dst=None):
         noise = torch.stack([torch.randn(B, N, D, device=dev) for _ in range(T_BURN)], 1)
         post, _, _ = engine.savi_encode(savi, img, noise=noise)
-        buf[:, :T_BURN].copy_(post)
+        (buf if dst is None else dst)[:, :T_BURN].copy_(post)
 
     S = max(1, args.rollout_streams)
     assert B % S == 0
@@ -220,13 +223,53 @@ def main():
             else:
                 rollout_eager()
 
+        # ---- software pipeline across batches: two streams, two slot buffers, one rollout graph per buffer ----
+        overlap = (not args.no_overlap) and graph is not None and S == 1
+        if overlap:
+            graphs = [graph]
+            try:
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    engine.rollout(roll, bufs[1], T_BURN, T_ROLL)
+                graphs.append(g1)
+            except Exception as e:  # noqa: BLE001
+                log(f'second graph capture failed ({e}); no overlap')
+                overlap = False
+        if overlap:
+            # the rollout is a chain of ~900 short dependent kernels: give it dispatch priority over the encode's
+            # long throughput kernels
+            prio = int(os.environ.get('SF_BENCH_ROLL_PRIO', '-1'))
+            s_enc, s_roll = torch.cuda.Stream(device=dev, priority=0), torch.cuda.Stream(device=dev, priority=prio)
+
+            def run_pipelined(n):
+                cur = torch.cuda.current_stream()
+                s_enc.wait_stream(cur)
+                s_roll.wait_stream(cur)
+                ev_enc = [torch.cuda.Event() for _ in range(n)]
+                ev_roll = [torch.cuda.Event() for _ in range(n)]
+                for j in range(n):
+                    with torch.cuda.stream(s_enc):
+                        if j >= 2:
+                            s_enc.wait_event(ev_roll[j - 2])  # slot buffer j%2 is free once rollout j-2 is done
+                        encode(bufs[j % 2])
+                        ev_enc[j].record(s_enc)
+                    with torch.cuda.stream(s_roll):
+                        s_roll.wait_event(ev_enc[j])
+                        graphs[j % 2].replay()
+                        ev_roll[j].record(s_roll)
+                cur.wait_stream(s_enc)
+                cur.wait_stream(s_roll)
+
         def barrier():
             if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
 
-        for _ in range(args.warmup):
-            step()
+        if overlap:
+            run_pipelined(args.warmup)
+        else:
+            for _ in range(args.warmup):
+                step()
         torch.cuda.synchronize()
         log('warmup done')
         # dominant kernel (conv implicit GEMM) + the HBM-bound SA iteration are event-timed live
@@ -234,8 +277,11 @@ def main():
         read_profile(lib)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        if overlap:
+            run_pipelined(args.steps)
+        else:
+            for _ in range(args.steps):
+                step()
         barrier()
         elapsed = time.perf_counter() - t0
         log(f'timed region done: {elapsed:.3f}s')
@@ -244,11 +290,14 @@ def main():
 
         # split timing (untimed extra): encode-only and rollout-only
         torch.cuda.synchronize()
+        lib.sf_profile_enable((1 << 0) | (1 << 3))
         t1 = time.perf_counter()
         for _ in range(3):
             encode()
         torch.cuda.synchronize()
         t_enc = (time.perf_counter() - t1) / 3
+        lib.sf_profile_enable(0)
+        prof_iso = read_profile(lib)  # same kernels with nothing else on the GPU
         t1 = time.perf_counter()
         for _ in range(3):
             graph.replay() if graph is not None else rollout_eager()
@@ -290,6 +339,8 @@ def main():
                 'batch_per_gpu': B, 'global_batch': B * world, 'burn_in': T_BURN, 'rollout': T_ROLL,
                 'parallelism': f'dp{world}: videos sharded on the batch axis, no collective on the timed path',
                 'rollout_launch': 'hipGraph replay' if graph is not None else 'eager', 'rollout_streams': S,
+                'pipelining': ('encode of batch i+1 (stream A) overlaps the rollout graph of batch i (stream B); every batch still '
+                               'runs its full encode + 50-step rollout inside the timed region') if overlap else 'none',
             },
             'encode_ms': 1e3 * t_enc,
             'rollout_ms': 1e3 * t_roll,
@@ -302,13 +353,18 @@ def main():
             ach = flops_per_launch / (conv['avg_us'] * 1e-6) / 1e12
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS
             res['roofline'] = {
-                'kernel': 'sf_gemm_kernel<128,64,...,conv_nhwc> (5x5 conv 64->64 @64x64 as implicit GEMM, '
+                'kernel': ('conv5x5_halo_kernel' if prec == 'bf16x3' else 'sf_gemm_kernel<128,64,...,conv_nhwc>') + ' (5x5 conv 64->64 @64x64, '
                 + ('split-bf16 MFMA: 3 bf16 MFMA flops per algorithmic flop -> peak = 2500/3)' if prec == 'bf16x3' else 'exact f32 MFMA)'),
                 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                 'frac': ach / peak, 'frac_of_exact_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic('conv_nhwc_implicit_gemm'),
                 'traffic_unit': 'bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE, committed under profiles/)',
                 'algorithmic_bytes_per_launch': 2 * 32 * 4096 * 64 * 4 + 64 * 1600 * 4,
                 'flops_per_launch': flops_per_launch, 'avg_launch_us': conv['avg_us'], 'launches': conv['launches'],
+                'avg_launch_us_isolated': prof_iso.get('conv_nhwc_implicit_gemm', {}).get('avg_us'),
+                'frac_isolated': (flops_per_launch / (prof_iso['conv_nhwc_implicit_gemm']['avg_us'] * 1e-6) / 1e12 / peak
+                                  if 'conv_nhwc_implicit_gemm' in prof_iso else None),
+                'note': 'achieved/frac are live over the timed region, where the encode overlaps the rollout graph of the '
+                        'previous batch; *_isolated is the same kernel with nothing else running',
             }
         # the rollout replays as ONE hipGraph (900 launches), so it is reported as a unit: algorithmic
         # FLOPs of SURVEY.md 8d (274.7 MFLOP per predicted frame per video, minus nothing: the last-layer
@@ -328,7 +384,8 @@ def main():
             res['roofline_slot_attn'] = {
                 'kernel': 'sa_attn_mfma_kernel<128> (one Slot-Attention iteration over K,V)', 'bound': 'hbm',
                 'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': gbps / PEAK_HBM_GBPS,
-                'traffic': pmc_traffic('slot_attn_iter'), 'bytes_per_launch': bytes_per_launch, 'avg_launch_us': sa['avg_us'],
+                'traffic': pmc_traffic('slot_attn_iter'), 'bytes_per_launch': bytes_per_launch,
+                'avg_launch_us_isolated': prof_iso.get('slot_attn_iter', {}).get('avg_us'), 'avg_launch_us': sa['avg_us'],
                 'launches': sa['launches'],
             }
         if breakdown:

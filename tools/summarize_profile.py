@@ -57,7 +57,9 @@ def counter_avg(d, counter, pred):
     return tot / n if n else None
 
 
-def is_conv(name):  # sf_gemm_kernel<..., ALOAD=1 (NHWC im2col), LN, BF3>
+def is_conv(name):  # conv5x5_halo_kernel, or sf_gemm_kernel<..., ALOAD=1 (NHWC im2col), LN, BF3>
+    if 'conv5x5_halo_kernel' in name:
+        return True
     m = re.search(r'sf_gemm_kernel<([^>]*)>', name)
     return bool(m) and m.group(1).replace(' ', '').split(',')[8] == '1'
 
