@@ -228,9 +228,11 @@ def main():
         if overlap:
             graphs = [graph]
             try:
+                engine.rollout(roll, bufs[1], T_BURN, T_ROLL, ws_slot=1)  # allocate the second workspace before capture
+                torch.cuda.synchronize()
                 g1 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1):
-                    engine.rollout(roll, bufs[1], T_BURN, T_ROLL)
+                    engine.rollout(roll, bufs[1], T_BURN, T_ROLL, ws_slot=1)  # own scratch: may run beside graph 0
                 graphs.append(g1)
             except Exception as e:  # noqa: BLE001
                 log(f'second graph capture failed ({e}); no overlap')
@@ -239,12 +241,17 @@ def main():
             # the rollout is a chain of ~900 short dependent kernels: give it dispatch priority over the encode's
             # long throughput kernels
             prio = int(os.environ.get('SF_BENCH_ROLL_PRIO', '-1'))
-            s_enc, s_roll = torch.cuda.Stream(device=dev, priority=0), torch.cuda.Stream(device=dev, priority=prio)
+            s_enc = torch.cuda.Stream(device=dev, priority=0)
+            # SF_BENCH_ROLL_STREAMS=2 (experiment, profiles/r01_probes.txt): rollout graphs of consecutive batches on
+            # alternating streams -- measured 24.2 ms/step vs 14.4 with one rollout stream, so the default is 1
+            n_rs = int(os.environ.get('SF_BENCH_ROLL_STREAMS', '1'))
+            s_rolls = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(n_rs)]
 
             def run_pipelined(n):
                 cur = torch.cuda.current_stream()
                 s_enc.wait_stream(cur)
-                s_roll.wait_stream(cur)
+                for sr in s_rolls:
+                    sr.wait_stream(cur)
                 ev_enc = [torch.cuda.Event() for _ in range(n)]
                 ev_roll = [torch.cuda.Event() for _ in range(n)]
                 for j in range(n):
@@ -253,12 +260,16 @@ def main():
                             s_enc.wait_event(ev_roll[j - 2])  # slot buffer j%2 is free once rollout j-2 is done
                         encode(bufs[j % 2])
                         ev_enc[j].record(s_enc)
+                    s_roll = s_rolls[j % n_rs]
                     with torch.cuda.stream(s_roll):
                         s_roll.wait_event(ev_enc[j])
+                        if j >= 2 and n_rs > 1:
+                            s_roll.wait_event(ev_roll[j - 2])  # same graph/buffer/workspace slot as batch j-2
                         graphs[j % 2].replay()
                         ev_roll[j].record(s_roll)
                 cur.wait_stream(s_enc)
-                cur.wait_stream(s_roll)
+                for sr in s_rolls:
+                    cur.wait_stream(sr)
 
         def barrier():
             if use_dist:
