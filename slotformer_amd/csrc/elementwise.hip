@@ -181,9 +181,18 @@ int sf_mha_ex(const float* qkv, float* out, int B, int L, int Lq, int d, int nhe
   const size_t lds_tile = ((size_t)Lq * hd + (size_t)L * (hd + 1) + (size_t)L * hd + (size_t)Lq * (L + 1) + Lq) *
                           sizeof(float);
   sf_prof_begin(SF_K_MHA, st, 4.0 * (double)B * nheads * Lq * L * hd);
-  if (lds_tile <= 64 * 1024) {
-#define MHA_LAUNCH(HD) \
-  hipLaunchKernelGGL(mha_tile_kernel<HD>, grid, dim3(256), lds_tile, st, qkv, 3 * d, out, d, L, Lq, d, scale)
+  if (lds_tile <= 160 * 1024) {
+#define MHA_LAUNCH(HD)                                                                                              \
+  {                                                                                                                 \
+    static bool attr = false;                                                                                       \
+    if (!attr) {                                                                                                    \
+      hipError_t e_ = hipFuncSetAttribute((const void*)mha_tile_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          160 * 1024);                                                              \
+      if (e_ != hipSuccess) return sf_set_err((int)e_, hipGetErrorString(e_), __FILE__, __LINE__);                   \
+      attr = true;                                                                                                  \
+    }                                                                                                               \
+    hipLaunchKernelGGL(mha_tile_kernel<HD>, grid, dim3(256), lds_tile, st, qkv, 3 * d, out, d, L, Lq, d, scale);     \
+  }
     switch (hd) {
       case 16: MHA_LAUNCH(16); break;
       case 32: MHA_LAUNCH(32); break;

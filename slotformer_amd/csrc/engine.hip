@@ -297,15 +297,23 @@ int sf_savi_encode_f32(const sf_savi_encoder* m, const float* img, const float* 
       }
       const int Cl = m->enc_channels[m->enc_layers];
       const int Mp = nb * HW;
-      // encoder_out_layer: LN -> Linear -> ReLU -> Linear  (savi.py:245-250)
-      SF_TRY(sf_linear_ex(cur, sf_rows(Cl), m->enc_fc1_w, m->enc_fc1_b, m->enc_ln_g, m->enc_ln_b, ln_eps, nullptr,
-                          sf_rows(Ce), 0, h1, sf_rows(Ce), Mp, Ce, Cl, 1, st));
-      SF_TRY(sf_linear_ex(h1, sf_rows(Ce), m->enc_fc2_w, m->enc_fc2_b, nullptr, nullptr, ln_eps, nullptr,
-                          sf_rows(Ce), 0, h2, sf_rows(Ce), Mp, Ce, Ce, 0, st));
-      // k|v = [Wk;Wv] LN(inputs)  (savi.py:66-70)
-      SF_TRY(sf_linear_ex(h2, sf_rows(Ce), m->sa_kv_w, nullptr, m->sa_norm_in_g, m->sa_norm_in_b, ln_eps, nullptr,
-                          sf_rows(2 * D), 0, kv + (long long)b0 * HW * 2 * D, sf_rows(2 * D), Mp, 2 * D, Ce, 0,
-                          st));
+      // encoder_out_layer (LN -> Linear -> ReLU -> Linear, savi.py:245-250) and k|v = [Wk;Wv] LN(inputs)
+      // (savi.py:66-70): one fused kernel per 128-pixel tile in split-bf16 mode (pixel_mlp.hip), else three GEMMs
+      float* kv_dst = kv + (long long)b0 * HW * 2 * D;
+      int fused = 1;
+      if (sf_get_precision() == 1)
+        fused = sf_pixel_mlp_kv_ex(cur, m->enc_ln_g, m->enc_ln_b, m->enc_fc1_w, m->enc_fc1_b, m->enc_fc2_w,
+                                   m->enc_fc2_b, m->sa_norm_in_g, m->sa_norm_in_b, m->sa_kv_w, kv_dst, Mp, Cl, Ce,
+                                   2 * D, ln_eps, st);
+      if (fused < 0 || fused > 1) return fused;
+      if (fused == 1) {
+        SF_TRY(sf_linear_ex(cur, sf_rows(Cl), m->enc_fc1_w, m->enc_fc1_b, m->enc_ln_g, m->enc_ln_b, ln_eps, nullptr,
+                            sf_rows(Ce), 0, h1, sf_rows(Ce), Mp, Ce, Cl, 1, st));
+        SF_TRY(sf_linear_ex(h1, sf_rows(Ce), m->enc_fc2_w, m->enc_fc2_b, nullptr, nullptr, ln_eps, nullptr,
+                            sf_rows(Ce), 0, h2, sf_rows(Ce), Mp, Ce, Ce, 0, st));
+        SF_TRY(sf_linear_ex(h2, sf_rows(Ce), m->sa_kv_w, nullptr, m->sa_norm_in_g, m->sa_norm_in_b, ln_eps, nullptr,
+                            sf_rows(2 * D), 0, kv_dst, sf_rows(2 * D), Mp, 2 * D, Ce, 0, st));
+      }
     }
     // ---- slot initialisation: init_latents or predictor(prev_slots)  (savi.py:393-398) ------
     const float* lat;

@@ -1,0 +1,230 @@
+// Fused per-pixel chain of the SAVi encoder for one 128-pixel tile per workgroup (split-bf16 MFMA):
+//
+//   x[128,64] -> LN(64) -> fc1 (64->128) + ReLU -> fc2 (128->128) -> LN(128) -> [Wk;Wv] (128->256) -> kv[128,256]
+//
+// (encoder_out_layer, savi.py:245-250,372-375, then SlotAttention.norm_inputs / project_k / project_v,
+// savi.py:66-70).  The three GEMMs of the unfused path move 436 MB per time step (B=32) through memory; here
+// the intermediates never leave LDS (they are kept as bf16 hi/lo planes, the LN(128) input as an f32 tile) and
+// only x (33.5 MB) is read and k|v (134 MB) written.  Weights (224 KB f32) are re-streamed per tile from L2 with
+// the next stage's weights prefetched into registers during the current stage's MFMAs.
+//
+// 8 waves: wave w owns rows 32*(w>>1) .. +31 and columns 64*(w&1) .. +63 of every 128-wide output (2 accumulators).
+#include "sf_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int PM_NT = 512, PM_ROWS = 128, PM_C0 = 64, PM_C1 = 128, PM_ND = 256;
+constexpr int PM_LB0 = PM_C0 + 8, PM_LB1 = PM_C1 + 8;                 // bf16 row strides (odd # of 16-B slots)
+constexpr int PM_PLANE = PM_ROWS * PM_LB1;                             // elements of one (largest) plane
+constexpr int PM_H2S = PM_C1 + 4;                                      // f32 row stride of the LN(128) input tile
+constexpr size_t PM_LDS = (size_t)4 * PM_PLANE * sizeof(__bf16) + 2 * PM_ROWS * sizeof(float);
+static_assert((size_t)PM_ROWS * PM_H2S * 4 <= (size_t)2 * PM_PLANE * 2, "f32 tile must fit in the B planes");
+}  // namespace
+
+__global__ __launch_bounds__(PM_NT) void pixel_mlp_kv_kernel(
+    const float* __restrict__ x, const float* __restrict__ ln0_g, const float* __restrict__ ln0_b,
+    const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+    const float* __restrict__ b2, const float* __restrict__ ln1_g, const float* __restrict__ ln1_b,
+    const float* __restrict__ wkv, float* __restrict__ kv, int M, float eps) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+  __bf16* Ah = lds;               // A planes (activations)
+  __bf16* Al = Ah + PM_PLANE;
+  __bf16* Bh = Al + PM_PLANE;     // B planes (weights); also the f32 h2 tile
+  __bf16* Bl = Bh + PM_PLANE;
+  float* stats = (float*)(Bl + PM_PLANE);  // [2][128]
+  float* H2 = (float*)Bh;                  // [128][PM_H2S] f32 (aliases both B planes)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m0 = blockIdx.x * PM_ROWS;
+
+  auto split4 = [&](f32x4 v, bf16x4& hi, bf16x4& lo) {
+    hi = __builtin_convertvector(v, bf16x4);
+    lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+  };
+
+  // ---- P0: x tile and W1 (16 float4 per 64-wide row); LN(64) statistics straight from the registers --------
+  const int c4 = t & 15, r0 = t >> 4;  // rows r0 + 32*i
+  f32x4 xr[4], wr1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = min(m0 + r0 + 32 * i, M - 1);
+    xr[i] = *(const f32x4*)(x + (long long)row * PM_C0 + 4 * c4);
+    wr1[i] = *(const f32x4*)(w1 + (long long)(r0 + 32 * i) * PM_C0 + 4 * c4);
+  }
+  // W2: 128 rows x 32 float4 -> 8 per thread (rows q0 + 16*i); requested now, consumed after GEMM1
+  const int d4 = t & 31, q0 = t >> 5;
+  f32x4 wr2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) wr2[i] = *(const f32x4*)(w2 + (long long)(q0 + 16 * i) * PM_C1 + 4 * d4);
+  {
+    const f32x4 g = *(const f32x4*)(ln0_g + 4 * c4), be = *(const f32x4*)(ln0_b + 4 * c4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = (xr[i][0] + xr[i][1]) + (xr[i][2] + xr[i][3]);
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);  // the 16 lanes holding this row
+      const float mean = s * (1.0f / PM_C0);
+      const f32x4 dv = xr[i] - mean;
+      float vs = (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) vs += __shfl_xor(vs, o, 64);
+      const float rstd = 1.0f / sqrtf(vs * (1.0f / PM_C0) + eps);
+      bf16x4 hi, lo;
+      split4(dv * rstd * g + be, hi, lo);
+      const int off = (r0 + 32 * i) * PM_LB0 + 4 * c4;
+      *(bf16x4*)(Ah + off) = hi;
+      *(bf16x4*)(Al + off) = lo;
+      split4(wr1[i], hi, lo);
+      *(bf16x4*)(Bh + off) = hi;
+      *(bf16x4*)(Bl + off) = lo;
+    }
+  }
+  __syncthreads();
+
+  const int rb = wave >> 1, cb0 = (wave & 1) * 2;  // row block, first of two column blocks
+  auto gemm = [&](int LB, int nk16, f32x16 (&acc)[2]) {
+    const int ao = (rb * 32 + (lane & 31)) * LB + 8 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int ks = 0; ks < nk16; ++ks) {
+      const bf16x8 xh = *(const bf16x8*)(Ah + ao + ks * 16), xl = *(const bf16x8*)(Al + ao + ks * 16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int bo = ((cb0 + j) * 32 + (lane & 31)) * LB + 8 * (lane >> 5) + ks * 16;
+        const bf16x8 yh = *(const bf16x8*)(Bh + bo), yl = *(const bf16x8*)(Bl + bo);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[j], 0, 0, 0);
+      }
+    }
+  };
+  auto store_w128 = [&](const f32x4 (&wr)[8]) {  // 128 x 128 f32 weights in registers -> B planes
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      bf16x4 hi, lo;
+      split4(wr[i], hi, lo);
+      const int off = (q0 + 16 * i) * PM_LB1 + 4 * d4;
+      *(bf16x4*)(Bh + off) = hi;
+      *(bf16x4*)(Bl + off) = lo;
+    }
+  };
+
+  // ---- P1: h1 = relu(LN(x) W1^T + b1) -> A planes (K = 128 layout) ----------------------------------------
+  f32x16 acc[2];
+  gemm(PM_LB0, PM_C0 / 16, acc);
+  __syncthreads();  // every wave is done with the K=64 planes
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = (cb0 + j) * 32 + (lane & 31);
+    const float bv = b1[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const float v = fmaxf(acc[j][r] + bv, 0.f);
+      const __bf16 hi = (__bf16)v;
+      Ah[row * PM_LB1 + n] = hi;
+      Al[row * PM_LB1 + n] = (__bf16)(v - (float)hi);
+    }
+  }
+  store_w128(wr2);
+  f32x4 wr3[8];  // first half of [Wk;Wv] (rows 0..127), consumed after the LN(128)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) wr3[i] = *(const f32x4*)(wkv + (long long)(q0 + 16 * i) * PM_C1 + 4 * d4);
+  __syncthreads();
+
+  // ---- P2: h2 = h1 W2^T + b2 -> f32 tile (over the B planes) ------------------------------------------------
+  gemm(PM_LB1, PM_C1 / 16, acc);
+  __syncthreads();  // W2 planes are dead
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = (cb0 + j) * 32 + (lane & 31);
+    const float bv = b2[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      H2[row * PM_H2S + n] = acc[j][r] + bv;
+    }
+  }
+  __syncthreads();
+
+  // ---- P3: LN(128) of every row (4 threads per row, 32 channels each) -> A planes ---------------------------
+  {
+    const int row = t >> 2, part = t & 3;
+    f32x4 hv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hv[i] = *(const f32x4*)(H2 + row * PM_H2S + part * 32 + 4 * i);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (hv[i][0] + hv[i][1]) + (hv[i][2] + hv[i][3]);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    const float mean = s * (1.0f / PM_C1);
+    float vs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 dv = hv[i] - mean;
+      vs += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+    }
+    vs += __shfl_xor(vs, 1, 64);
+    vs += __shfl_xor(vs, 2, 64);
+    const float rstd = 1.0f / sqrtf(vs * (1.0f / PM_C1) + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = part * 32 + 4 * i;
+      const f32x4 g = *(const f32x4*)(ln1_g + c), be = *(const f32x4*)(ln1_b + c);
+      bf16x4 hi, lo;
+      split4((hv[i] - mean) * rstd * g + be, hi, lo);
+      *(bf16x4*)(Ah + row * PM_LB1 + c) = hi;
+      *(bf16x4*)(Al + row * PM_LB1 + c) = lo;
+    }
+  }
+  __syncthreads();  // everyone has read its part of the f32 tile: the B planes may be overwritten
+
+  // ---- P4: k|v = LN(h2) [Wk;Wv]^T, two 128-column halves ---------------------------------------------------
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    store_w128(wr3);
+    if (half == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wr3[i] = *(const f32x4*)(wkv + (long long)(PM_C1 + q0 + 16 * i) * PM_C1 + 4 * d4);
+    }
+    __syncthreads();
+    gemm(PM_LB1, PM_C1 / 16, acc);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = half * PM_C1 + (cb0 + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M) kv[(long long)row * PM_ND + n] = acc[j][r];
+      }
+    }
+    __syncthreads();  // before the second half overwrites the weight planes
+  }
+}
+
+// Returns 1 when the fused kernel does not apply (caller runs the three GEMMs).
+int sf_pixel_mlp_kv_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1,
+                       const float* w2, const float* b2, const float* ln1_g, const float* ln1_b, const float* wkv,
+                       float* kv, int M, int C0, int C1, int ND, float eps, hipStream_t st) {
+  if (C0 != PM_C0 || C1 != PM_C1 || ND != PM_ND || M <= 0 || !b1 || !b2) return 1;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)pixel_mlp_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)PM_LDS);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    attr = true;
+  }
+  static_assert(PM_LDS <= 160 * 1024, "LDS budget");
+  sf_prof_begin(SF_K_LINEAR, st, 2.0 * M * (double)(PM_C0 * PM_C1 + PM_C1 * PM_C1 + PM_C1 * PM_ND));
+  hipLaunchKernelGGL(pixel_mlp_kv_kernel, dim3((M + PM_ROWS - 1) / PM_ROWS), dim3(PM_NT), PM_LDS, st, x, ln0_g, ln0_b,
+                     w1, b1, w2, b2, ln1_g, ln1_b, wkv, kv, M, eps);
+  sf_prof_end(SF_K_LINEAR, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}

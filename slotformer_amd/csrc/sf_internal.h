@@ -29,3 +29,6 @@ int sf_qkv_attn_ex(const float* x, const float* ln_g, const float* ln_b, float l
 extern "C" int sf_get_precision(void);
 int sf_conv5x5_halo_ex(const float* in, const float* w_packed, const float* bias, const float* add, float* out, int F,
                        int H, int W, int Cin, int Cout, int ks, int relu, hipStream_t st);
+int sf_pixel_mlp_kv_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1,
+                       const float* w2, const float* b2, const float* ln1_g, const float* ln1_b, const float* wkv,
+                       float* kv, int M, int C0, int C1, int ND, float eps, hipStream_t st);

@@ -220,3 +220,38 @@ def test_forward_with_decode_paths(dev):
     sf.rollout_len = 3
     o = sf({'slots': torch.cat([past, past[:, :3]], 1)})
     assert set(o) == {'recon_combined', 'recons', 'masks', 'pred_slots', 'gt_slots'}
+
+
+@torch.no_grad()
+def test_chunk_loops_and_small_batches(dev):
+    """Encoder frame chunks (B > 32), decoder frame chunks (F > 17 at 64x64x7 slots), B = 1, T = 1."""
+    g = gu.load_golden('savi_c2')
+    cfg = gu.savi_cfg(64, 7, kernel_mlp=False, pred='mlp', rnn=False, kld='none')
+    shapes = gu.shapes_from_golden(g)
+    m, sd = build(cfg, g, 103, dev)
+    m.testing = True
+    img = gu.seeded_img(33, 2, 64, seed=77)
+    out = m({'img': img.to(dev)})['post_slots']
+    ref = oracle.savi_encode(img, sd, cfg)['post_slots']
+    assert rel_err(out, ref) < 5e-5
+    # batch-size independence: video 32 alone gives the same slots as inside the batch of 33
+    one = m({'img': img[32:33].to(dev)})['post_slots']
+    assert rel_err(one, ref[32:33]) < 5e-5
+    t1 = m({'img': img[:2, :1].to(dev)})['post_slots']
+    assert t1.shape == (2, 1, 7, 128) and rel_err(t1, ref[:2, :1]) < 5e-5
+    # decoder: 20 slot-frames -> two chunks
+    slots = gu.seeded_normal((20, 7, 128), 9)
+    recon = m.decode(slots.to(dev))[0]
+    assert rel_err(recon, oracle.savi_decode(slots, sd, cfg)[0]) < 2e-4
+
+
+@torch.no_grad()
+def test_rollout_batch_one_and_zero_steps(dev):
+    g = gu.load_golden('roll_c2')
+    m, sd = build(gu.C2_ROLL, g, 202, dev, vp=True)
+    slots = gu.seeded_normal((2, 56, 7, 128), 203)
+    pred1 = m.rollout(slots[:1, :6].to(dev), 5)
+    assert rel_err(pred1, torch.as_tensor(g['pred_slots'])[:1, :5]) < 2e-4
+    assert m.rollout(slots[:, :6].to(dev), 0).shape == (2, 0, 7, 128)
+    with pytest.raises(AssertionError):
+        m({'slots': slots[:, :20].to(dev)})  # wrong length: rollout_len + history_len != T  (slotformer.py:266-267)

@@ -148,7 +148,7 @@ def test_slot_attn_iteration(dev, B, N, D, HW):
 
 
 @pytest.mark.parametrize('B,L,d,h,Lq', [(3, 42, 256, 8, 42), (3, 42, 256, 8, 7), (2, 90, 256, 8, 90), (4, 6, 128, 4, 6),
-                                        (2, 6, 192, 4, 6), (2, 36, 128, 8, 36), (1, 130, 128, 4, 130), (1, 48, 256, 8, 8)])
+                                        (2, 6, 192, 4, 6), (2, 36, 128, 8, 36), (1, 130, 128, 4, 130), (1, 48, 256, 8, 8), (1, 200, 128, 4, 200)])
 def test_mha(dev, B, L, d, h, Lq):
     from slotformer_amd import ops
     qkv = rnd(B * L, 3 * d, seed=1)
