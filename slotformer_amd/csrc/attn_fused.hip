@@ -85,32 +85,28 @@ __global__ __launch_bounds__(FA_NT) void qkv_attn_kernel(const float* __restrict
     for (int i = 0; i < B_IT; ++i) rb[kc][i] = *(const f32x4*)(wrow[i] + k);
   }
 
-  // ---- LayerNorm statistics: 8 threads per row --------------------------------------------
+  // ---- LayerNorm statistics straight from the registers: row r0+32*i is held by the 16 lanes c4 = 0..15 -------
   if (ln_g) {
-    const int r = t >> 3, sub = t & 7;
-    const float* rowp = xb + (long long)min(r, L - 1) * d;
-    float s = 0.f;
-#pragma unroll 4
-    for (int k = sub * 4; k < d; k += 32) {
-      const f32x4 v = *(const f32x4*)(rowp + k);
-      s += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    const float mean = s / (float)d;
-    float vs = 0.f;
-#pragma unroll 4
-    for (int k = sub * 4; k < d; k += 32) {
-      const f32x4 v = *(const f32x4*)(rowp + k) - mean;
-      vs += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-    }
-    vs += __shfl_xor(vs, 1, 64);
-    vs += __shfl_xor(vs, 2, 64);
-    vs += __shfl_xor(vs, 4, 64);
-    if (sub == 0) {
-      stats[r] = mean;
-      stats[FA_ROWS + r] = 1.0f / sqrtf(vs / (float)d + ln_eps);
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < NK; ++kc) s += (ra[kc][i][0] + ra[kc][i][1]) + (ra[kc][i][2] + ra[kc][i][3]);
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+      const float mean = s / (float)d;
+      float vs = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < NK; ++kc) {
+        const f32x4 dv = ra[kc][i] - mean;
+        vs += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) vs += __shfl_xor(vs, o, 64);
+      if (c4 == 0) {
+        stats[r0 + 32 * i] = mean;
+        stats[FA_ROWS + r0 + 32 * i] = 1.0f / sqrtf(vs / (float)d + ln_eps);
+      }
     }
   } else if (t < FA_ROWS) {
     stats[t] = 0.f;
