@@ -53,7 +53,7 @@ struct SfGemmArgs {
 template <int BM, int BN, int WM, int WN, int KW, int BKT, int PD, int NBUF, int ALOAD, bool LN, bool BF3>
 __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) {
   constexpr int NT = WM * WN * KW * 64;
-  static_assert(NT == 256 || NT == 512, "4 or 8 waves");
+  static_assert(NT == 256 || NT == 512 || NT == 1024, "4, 8 or 16 waves");
   static_assert(BKT % (8 * KW) == 0 && (PD == 1 || PD == 2) && (NBUF == 2 || (NBUF == 1 && PD == 1)), "bad chunking");
   constexpr int RM = BM / (32 * WM), RN = BN / (32 * WN);
   constexpr int NKB = BKT / (8 * KW);  // 8-wide k blocks per wave per chunk
@@ -551,6 +551,10 @@ static int launch_by_id(int id, const SfGemmArgs& a, hipStream_t st) {
       case 114: return launch_cfg<32, 32, 1, 1, 8, 128, 2, 2, ALOAD, LN, true>(a, st);
       case 115: return launch_cfg<32, 32, 1, 1, 8, 256, 2, 2, ALOAD, LN, true>(a, st);
       case 116: return launch_cfg<32, 32, 1, 1, 8, 256, 1, 1, ALOAD, LN, true>(a, st);
+      // 16-wave workgroups (1024 threads): highest per-CU fill rate in tools/probes/fill_probe.hip
+      case 117: return launch_cfg<32, 64, 1, 2, 8, 128, 2, 2, ALOAD, LN, true>(a, st);
+      case 118: return launch_cfg<64, 64, 2, 2, 4, 128, 2, 2, ALOAD, LN, true>(a, st);
+      case 119: return launch_cfg<64, 64, 2, 2, 4, 64, 2, 2, ALOAD, LN, true>(a, st);
       default: break;
     }
   }

@@ -255,3 +255,34 @@ def test_rollout_batch_one_and_zero_steps(dev):
     assert m.rollout(slots[:, :6].to(dev), 0).shape == (2, 0, 7, 128)
     with pytest.raises(AssertionError):
         m({'slots': slots[:, :20].to(dev)})  # wrong length: rollout_len + history_len != T  (slotformer.py:266-267)
+
+
+@torch.no_grad()
+def test_full_size_properties(dev):
+    """BASELINE config C2 at FULL size (B=32, 128x128, 6+50): size-independent properties instead of an oracle run.
+    (1) determinism: two runs are bitwise identical; (2) batch independence: a video's slots do not depend on
+    what else is in the batch; (3) composition: a 50-step rollout equals 25 steps + 25 steps restarted from the
+    last 6 frames; (4) finite outputs."""
+    from slotformer_amd.video_prediction.models import SlotRollouter
+    gs = gu.load_golden('savi_c2')
+    savi, _ = build(gu.C2_SAVI, gs, 103, dev)
+    savi.testing = True
+    roll = build(gu.C2_ROLL, gu.load_golden('roll_c2'), 202, dev, vp=True)[0].rollouter
+    B, T, H = 32, 6, 50
+    img = gu.seeded_img(B, T, 128, seed=5).to(dev)
+    noise = gu.seeded_normal((B, T, 7, 128), 6).to(dev)
+    a = savi({'img': img, 'noise': noise})['post_slots']
+    b = savi({'img': img, 'noise': noise})['post_slots']
+    assert torch.equal(a, b)
+    sub = savi({'img': img[8:12].contiguous(), 'noise': noise[8:12].contiguous()})['post_slots']
+    assert torch.equal(sub, a[8:12])
+    assert torch.isfinite(a).all()
+    p50 = roll(a, H)
+    assert torch.equal(p50, roll(a, H))
+    p25 = roll(a, 25)
+    assert torch.equal(p25, p50[:, :25])
+    hist = torch.cat([a, p25], 1)[:, -6:].contiguous()
+    assert torch.equal(roll(hist, 25), p50[:, 25:])
+    assert torch.isfinite(p50).all() and p50.shape == (B, H, 7, 128)
+    # a 2-video batch selects other GEMM tile / split-K configurations (different summation order, same math)
+    assert rel_err(roll(a[3:5].contiguous(), 10), p50[3:5, :10].cpu()) < 1e-4
