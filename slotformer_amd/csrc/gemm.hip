@@ -54,7 +54,8 @@ template <int BM, int BN, int WM, int WN, int KW, int BKT, int PD, int NBUF, int
 __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) {
   constexpr int NT = WM * WN * KW * 64;
   static_assert(NT == 256 || NT == 512 || NT == 1024, "4, 8 or 16 waves");
-  static_assert(BKT % (8 * KW) == 0 && (PD == 1 || PD == 2) && (NBUF == 2 || (NBUF == 1 && PD == 1)), "bad chunking");
+  static_assert(BKT % (8 * KW) == 0 && (PD == 0 || PD == 1 || PD == 2) && (NBUF == 2 || (NBUF == 1 && PD == 1)), "bad chunking");
+  static_assert(PD != 0 || ALOAD == ALOAD_PLAIN, "preload-all is for plain A rows");
   constexpr int RM = BM / (32 * WM), RN = BN / (32 * WN);
   constexpr int NKB = BKT / (8 * KW);  // 8-wide k blocks per wave per chunk
   constexpr int LSTR = BKT + 4;   // f32 row stride (floats)
@@ -338,14 +339,51 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
   };
   // first chunk(s) are requested BEFORE the LayerNorm statistics pass so that pass does not add a
   // serial memory round trip in front of the main loop
-  load_tiles(0, R0);
+  if constexpr (PD != 0) load_tiles(0, R0);
   if constexpr (PD == 2) {
     if (nk > 1) load_tiles(1, R1);
+  }
+  // PD == 0 ("preload all", K <= 4 chunks): every chunk is requested up front into its own register set and the
+  // LayerNorm statistics come from those registers (a row's chunk is held by C4N consecutive lanes), so the
+  // kernel pays a single memory latency and no separate statistics pass.
+  Regs RR[PD == 0 ? 4 : 1];
+  if constexpr (PD == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < nk) load_tiles(q, RR[q]);
+    if constexpr (LN) {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < nk) s += (RR[q].ra[i][0] + RR[q].ra[i][1]) + (RR[q].ra[i][2] + RR[q].ra[i][3]);  // k >= K loads are 0
+#pragma unroll
+        for (int o = 1; o < C4N; o <<= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s / (float)K;
+        float vs = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < nk && q * BKT + 4 * c4 < K) {
+            const f32x4 dv = RR[q].ra[i] - mean;
+            vs += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+          }
+#pragma unroll
+        for (int o = 1; o < C4N; o <<= 1) vs += __shfl_xor(vs, o, 64);
+        if (c4 == 0) {
+          stats[r0 + i * RS] = mean;
+          stats[BM + r0 + i * RS] = 1.0f / sqrtf(vs / (float)K + p.ln_eps);
+        }
+      }
+      __syncthreads();
+    }
   }
   // ---- LayerNorm statistics for this tile's rows --------------------------------
   // NT/BM threads per row, every load of a pass independent (in flight together); the serial
   // per-row version this replaces cost ~30 us per launch in dependent L2 round trips.
-  if (LN && (p.dbg & 4)) {
+  if (PD == 0) {
+    // statistics already in LDS (above)
+  } else if (LN && (p.dbg & 4)) {
     if (t < BM) {
       stats[t] = 0.f;
       stats[BM + t] = 1.f;
@@ -384,7 +422,17 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
     __syncthreads();
   }
 
-  if constexpr (PD == 1 && NBUF == 2) {
+  if constexpr (PD == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < nk) {
+        store_tiles(q & 1, q, RR[q]);  // buffer q&1 was last read two chunks ago; a barrier lies in between
+        __syncthreads();
+        compute_dbg(q & 1);
+      }
+    }
+    __syncthreads();
+  } else if constexpr (PD == 1 && NBUF == 2) {
     store_tiles(0, 0, R0);
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
@@ -558,6 +606,16 @@ static int launch_by_id(int id, const SfGemmArgs& a, hipStream_t st) {
       default: break;
     }
   }
+  if constexpr (ALOAD == ALOAD_PLAIN) {  // preload-all variants (K <= 4 chunks)
+    if ((id == 121 || id == 122 || id == 123) && a.K > 4 * (id == 123 ? 128 : 64))
+      return sf_set_err(-1, "preload-all GEMM configuration needs K <= 4 chunks", __FILE__, __LINE__);
+    switch (id) {
+      case 121: return launch_cfg<64, 64, 2, 2, 1, 64, 0, 2, ALOAD, LN, true>(a, st);
+      case 122: return launch_cfg<64, 64, 2, 2, 2, 64, 0, 2, ALOAD, LN, true>(a, st);
+      case 123: return launch_cfg<32, 64, 1, 2, 4, 128, 0, 2, ALOAD, LN, true>(a, st);
+      default: break;
+    }
+  }
   return sf_set_err(-1, "unknown GEMM configuration id", __FILE__, __LINE__);
 }
 
@@ -597,7 +655,7 @@ static int dispatch_tiles(const SfGemmArgs& a, hipStream_t stream) {
       if (bf3) {
         if (a.K >= 512) return launch_by_id<ALOAD, LN>(a.M >= 512 ? 109 : 115, a, stream);
         const long long t64 = tiles(64, 64);
-        if (t64 > 300) return launch_by_id<ALOAD, LN>(107, a, stream);
+        if (t64 > 300) return launch_by_id<ALOAD, LN>(a.K <= 256 ? 122 : 107, a, stream);
         if (t64 >= 192) return launch_by_id<ALOAD, LN>(108, a, stream);
         return launch_by_id<ALOAD, LN>(a.M >= 512 ? 109 : 106, a, stream);
       }

@@ -39,7 +39,7 @@ SHAPES = [  # name, M, N, K, ln
     ('inproj', 1344, 256, 128, False), ('q_sa', 224, 128, 128, True),
     ('pix_fc1', 131072, 128, 64, True), ('pix_fc2', 131072, 128, 128, False), ('pix_kv', 131072, 256, 128, True),
 ]
-CFGS = {'small': [106, 107, 108, 109, 115, 117, 118, 119], 'big': [31, 28, 100, 101, 102, 103, 110, 112, 113]}
+CFGS = {'small': [106, 107, 108, 109, 115, 121, 122, 123], 'big': [31, 28, 100, 101, 102, 103, 110, 112, 113]}
 
 
 def main():
