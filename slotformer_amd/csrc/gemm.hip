@@ -568,14 +568,10 @@ static int forced_cfg() {
 template <int ALOAD, bool LN>
 static int launch_by_id(int id, const SfGemmArgs& a, hipStream_t st) {
   switch (id) {
-    case 0: return launch_cfg<128, 128, 2, 2, 1, 32, 1, 2, ALOAD, LN, false>(a, st);
     case 1: return launch_cfg<128, 64, 4, 1, 1, 32, 1, 2, ALOAD, LN, false>(a, st);
     case 3: return launch_cfg<32, 32, 1, 1, 4, 128, 1, 2, ALOAD, LN, false>(a, st);
     case 4: return launch_cfg<32, 64, 1, 2, 2, 64, 1, 2, ALOAD, LN, false>(a, st);
     case 7: return launch_cfg<32, 32, 1, 1, 4, 128, 2, 2, ALOAD, LN, false>(a, st);
-    case 13: return launch_cfg<128, 64, 4, 1, 1, 32, 2, 2, ALOAD, LN, false>(a, st);
-    case 22: return launch_cfg<64, 64, 2, 2, 2, 128, 2, 2, ALOAD, LN, false>(a, st);
-    case 24: return launch_cfg<32, 64, 1, 2, 4, 128, 2, 2, ALOAD, LN, false>(a, st);
     case 28: return launch_cfg<128, 64, 4, 2, 1, 32, 2, 2, ALOAD, LN, false>(a, st);
     case 31: return launch_cfg<128, 128, 2, 4, 1, 32, 1, 2, ALOAD, LN, false>(a, st);
     default: break;
@@ -583,26 +579,14 @@ static int launch_by_id(int id, const SfGemmArgs& a, hipStream_t st) {
   if constexpr (ALOAD != ALOAD_CONV_NCHW) {
     switch (id) {
       case 100: return launch_cfg<128, 64, 4, 2, 1, 32, 2, 2, ALOAD, LN, true>(a, st);
-      case 101: return launch_cfg<128, 64, 4, 2, 1, 64, 2, 2, ALOAD, LN, true>(a, st);
       case 102: return launch_cfg<128, 128, 2, 4, 1, 32, 1, 2, ALOAD, LN, true>(a, st);
       case 103: return launch_cfg<128, 128, 2, 4, 1, 64, 2, 2, ALOAD, LN, true>(a, st);
-      case 104: return launch_cfg<32, 64, 1, 2, 2, 64, 1, 2, ALOAD, LN, true>(a, st);
       case 105: return launch_cfg<32, 32, 1, 1, 4, 128, 2, 2, ALOAD, LN, true>(a, st);
       case 106: return launch_cfg<32, 32, 1, 1, 4, 128, 1, 2, ALOAD, LN, true>(a, st);
       case 107: return launch_cfg<64, 64, 2, 2, 1, 64, 2, 2, ALOAD, LN, true>(a, st);
       case 108: return launch_cfg<64, 64, 2, 2, 2, 128, 2, 2, ALOAD, LN, true>(a, st);
       case 109: return launch_cfg<32, 64, 1, 2, 4, 128, 2, 2, ALOAD, LN, true>(a, st);
-      case 110: return launch_cfg<128, 64, 4, 1, 1, 64, 2, 2, ALOAD, LN, true>(a, st);
-      case 111: return launch_cfg<64, 64, 2, 2, 1, 128, 2, 2, ALOAD, LN, true>(a, st);
-      case 112: return launch_cfg<256, 64, 8, 1, 1, 32, 2, 2, ALOAD, LN, true>(a, st);
-      case 113: return launch_cfg<64, 128, 2, 2, 1, 64, 2, 2, ALOAD, LN, true>(a, st);
-      case 114: return launch_cfg<32, 32, 1, 1, 8, 128, 2, 2, ALOAD, LN, true>(a, st);
       case 115: return launch_cfg<32, 32, 1, 1, 8, 256, 2, 2, ALOAD, LN, true>(a, st);
-      case 116: return launch_cfg<32, 32, 1, 1, 8, 256, 1, 1, ALOAD, LN, true>(a, st);
-      // 16-wave workgroups (1024 threads): highest per-CU fill rate in tools/probes/fill_probe.hip
-      case 117: return launch_cfg<32, 64, 1, 2, 8, 128, 2, 2, ALOAD, LN, true>(a, st);
-      case 118: return launch_cfg<64, 64, 2, 2, 4, 128, 2, 2, ALOAD, LN, true>(a, st);
-      case 119: return launch_cfg<64, 64, 2, 2, 4, 64, 2, 2, ALOAD, LN, true>(a, st);
       default: break;
     }
   }
