@@ -241,7 +241,7 @@ def main():
             # the rollout is a chain of ~900 short dependent kernels: give it dispatch priority over the encode's
             # long throughput kernels
             prio = int(os.environ.get('SF_BENCH_ROLL_PRIO', '-1'))
-            s_enc = torch.cuda.Stream(device=dev, priority=0)
+            s_enc = torch.cuda.Stream(device=dev, priority=int(os.environ.get('SF_BENCH_ENC_PRIO', '0')))
             # SF_BENCH_ROLL_STREAMS=2 (experiment, profiles/r01_probes.txt): rollout graphs of consecutive batches on
             # alternating streams -- measured 24.2 ms/step vs 14.4 with one rollout stream, so the default is 1
             n_rs = int(os.environ.get('SF_BENCH_ROLL_STREAMS', '1'))

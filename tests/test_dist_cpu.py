@@ -26,6 +26,14 @@ def _worker(rank, world, port, q):
     local = torch.stack([torch.full((3, ), float(i)) for i in range(lo, hi)])
     full = gather_shards(local, n)
     t = max_over_ranks(1.0 + rank)
+    # flat-bucket gradient all-reduce (training config C3): rank r holds grads filled with r+1 -> mean 1.5
+    from slotformer_amd.parallel import allreduce_flat_bucket
+    ps = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2))]
+    ps[0].grad = torch.full((3, 4), float(rank + 1))
+    ps[1].grad = torch.full((5, ), float(rank + 1))
+    nbytes = allreduce_flat_bucket(ps)
+    assert nbytes == 17 * 4 and ps[2].grad is None
+    assert torch.allclose(ps[0].grad, torch.full((3, 4), 1.5)) and torch.allclose(ps[1].grad, torch.full((5, ), 1.5))
     dist.barrier()
     if rank == 0:
         q.put((full.tolist(), t))
