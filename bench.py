@@ -143,6 +143,7 @@ def main():
                     '(default: encode of batch i+1 overlaps the rollout graph of batch i on a second HIP stream)')
     ap.add_argument('--rollout-streams', type=int, default=1, help='batch groups rolled out concurrently on separate HIP streams')
     ap.add_argument('--precision', choices=['bf16x3', 'f32'], default=None, help='matrix arithmetic mode (default: library default = bf16x3)')
+    ap.add_argument('--pcie', action='store_true', help='also time a host-to-host (PCIe-inclusive) variant; reported separately')
     ap.add_argument('--breakdown', action='store_true', help='extra untimed pass with every kernel class timed')
     args = ap.parse_args()
 
@@ -173,7 +174,7 @@ def main():
     buf = bufs[0]
 
     def encode(dst=None):
-        noise = torch.stack([torch.randn(B, N, D, device=dev) for _ in range(T_BURN)], 1)
+        noise = torch.randn(B, T_BURN, N, D, device=dev)  # fresh eps ~ N(0,1) per frame (savi.py:363-365), one launch
         post, _, _ = engine.savi_encode(savi, img, noise=noise)
         (buf if dst is None else dst)[:, :T_BURN].copy_(post)
 
@@ -242,10 +243,33 @@ def main():
             # long throughput kernels
             prio = int(os.environ.get('SF_BENCH_ROLL_PRIO', '-1'))
             s_enc = torch.cuda.Stream(device=dev, priority=int(os.environ.get('SF_BENCH_ENC_PRIO', '0')))
+            # CU partition (SF_BENCH_CU_SPLIT = hex word E, 0 = off): the encode stream gets the CUs whose bit is set
+            # in E (repeated for each of the 8 mask words), the rollout stream the complement.  Measured
+            # (profiles/r01_probes.txt): E = ff (64 CUs = one shader engine of every XCD for the encode, 192 for the
+            # rollout chain) 139.5k frames/s vs 129.5k unpartitioned; partial bytes or per-word differences unbalance
+            # the shader engines and lose 20-60 %.
+            cu_words = [int(w, 16) for w in os.environ.get('SF_BENCH_CU_SPLIT', 'ff').split(',')]
+            cu_words = (cu_words * 8)[:8]
+            cu_split = any(cu_words)
+            masked = []
+            if cu_split:
+
+                def masked_stream(ws):
+                    words = (C.c_uint * 8)(*[w & 0xffffffff for w in ws])
+                    h = C.c_void_p()
+                    _lib.check(lib.sf_stream_create_cu_mask(C.byref(h), words, 8))
+                    masked.append(h)
+                    return torch.cuda.ExternalStream(h.value, device=dev)
+
+                s_enc = masked_stream(cu_words)
             # SF_BENCH_ROLL_STREAMS=2 (experiment, profiles/r01_probes.txt): rollout graphs of consecutive batches on
             # alternating streams -- measured 24.2 ms/step vs 14.4 with one rollout stream, so the default is 1
             n_rs = int(os.environ.get('SF_BENCH_ROLL_STREAMS', '1'))
             s_rolls = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(n_rs)]
+            if cu_split:
+                if os.environ.get('SF_BENCH_ROLL_UNMASKED', '0') != '1':  # experiment: rollout free to use every CU
+                    s_rolls = [masked_stream([~w for w in cu_words])]
+                n_rs = 1
 
             def run_pipelined(n):
                 cur = torch.cuda.current_stream()
@@ -314,6 +338,47 @@ def main():
             graph.replay() if graph is not None else rollout_eager()
         torch.cuda.synchronize()
         t_roll = (time.perf_counter() - t1) / 3
+        part_ms = None
+        if overlap and cu_split:
+            # the two halves of the partitioned pipeline, each alone on its CU subset
+            def timed_on(stream, fn, n=3):
+                stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(stream):
+                    fn()
+                    stream.synchronize()
+                    t = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    stream.synchronize()
+                return 1e3 * (time.perf_counter() - t) / n
+            part_ms = {'encode_ms_on_its_cus': timed_on(s_enc, encode), 'rollout_ms_on_its_cus': timed_on(s_rolls[0], graph.replay)}
+        pcie = None
+        if args.pcie:
+            # PCIe-inclusive variant (never `value`): frames start in pinned host memory and the slots end there
+            img_h = img.cpu().pin_memory()
+            out_h = torch.empty(bufs[0].shape, dtype=bufs[0].dtype).pin_memory()
+
+            def step_pcie():
+                img.copy_(img_h, non_blocking=True)
+                step()
+                out_h.copy_(buf, non_blocking=True)
+
+            step_pcie()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step_pcie()
+            torch.cuda.synchronize()
+            t_p = (time.perf_counter() - t1) / args.steps
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            t_s = (time.perf_counter() - t1) / args.steps
+            pcie = {'frames_per_s_host_to_host_serial': B * (T_BURN + T_ROLL) / t_p,
+                    'frames_per_s_device_resident_serial': B * (T_BURN + T_ROLL) / t_s,
+                    'h2d_bytes_per_batch': img.numel() * 4, 'd2h_bytes_per_batch': buf.numel() * 4,
+                    'note': 'serial (no batch pipelining, copies on the compute stream): upper bound on the PCIe cost'}
         breakdown = None
         if args.breakdown:
             lib.sf_profile_enable(0x3f)
@@ -352,9 +417,12 @@ def main():
                 'rollout_launch': 'hipGraph replay' if graph is not None else 'eager', 'rollout_streams': S,
                 'pipelining': ('encode of batch i+1 (stream A) overlaps the rollout graph of batch i (stream B); every batch still '
                                'runs its full encode + 50-step rollout inside the timed region') if overlap else 'none',
+                'cu_partition': (f'encode stream on CU mask {cu_words[0]:#x} x8 words ({8 * bin(cu_words[0]).count("1")} CUs), '
+                                 'rollout stream on the complement') if (overlap and cu_split) else 'none',
             },
             'encode_ms': 1e3 * t_enc,
             'rollout_ms': 1e3 * t_roll,
+            'partitioned_ms': part_ms,
             'encoded_frames_per_s': B * T_BURN / t_enc,
             'predicted_frames_per_s': B * T_ROLL / t_roll,
         }
@@ -362,20 +430,26 @@ def main():
         if conv:
             flops_per_launch = conv['work'] / conv['launches']
             ach = flops_per_launch / (conv['avg_us'] * 1e-6) / 1e12
-            peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS
+            peak_chip = PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS
+            # under the CU partition the encode stream owns a subset of the CUs during the timed region: the live
+            # figure is priced against the MFMA peak of THOSE CUs; the isolated figure (kernel alone, default stream,
+            # all 256 CUs) against the whole chip
+            enc_cus = 8 * bin(cu_words[0]).count('1') if (overlap and cu_split) else 256
+            peak = peak_chip * enc_cus / 256.0
             res['roofline'] = {
                 'kernel': ('conv5x5_halo_kernel' if prec == 'bf16x3' else 'sf_gemm_kernel<128,64,...,conv_nhwc>') + ' (5x5 conv 64->64 @64x64, '
                 + ('split-bf16 MFMA: 3 bf16 MFMA flops per algorithmic flop -> peak = 2500/3)' if prec == 'bf16x3' else 'exact f32 MFMA)'),
                 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': ach / peak, 'frac_of_exact_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic('conv_nhwc_implicit_gemm'),
+                'frac': ach / peak, 'cus': enc_cus, 'peak_full_chip': peak_chip, 'traffic': pmc_traffic('conv_nhwc_implicit_gemm'),
                 'traffic_unit': 'bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE, committed under profiles/)',
                 'algorithmic_bytes_per_launch': 2 * 32 * 4096 * 64 * 4 + 64 * 1600 * 4,
                 'flops_per_launch': flops_per_launch, 'avg_launch_us': conv['avg_us'], 'launches': conv['launches'],
                 'avg_launch_us_isolated': prof_iso.get('conv_nhwc_implicit_gemm', {}).get('avg_us'),
-                'frac_isolated': (flops_per_launch / (prof_iso['conv_nhwc_implicit_gemm']['avg_us'] * 1e-6) / 1e12 / peak
+                'frac_isolated': (flops_per_launch / (prof_iso['conv_nhwc_implicit_gemm']['avg_us'] * 1e-6) / 1e12 / peak_chip
                                   if 'conv_nhwc_implicit_gemm' in prof_iso else None),
-                'note': 'achieved/frac are live over the timed region, where the encode overlaps the rollout graph of the '
-                        'previous batch; *_isolated is the same kernel with nothing else running',
+                'note': 'achieved/frac are live over the timed region, where the encode runs on `cus` CUs beside the rollout graph '
+                        'of the previous batch (peak = whole-chip peak x cus/256); *_isolated is the same kernel alone on all 256 CUs '
+                        '(vs peak_full_chip)',
             }
         # the rollout replays as ONE hipGraph (900 launches), so it is reported as a unit: algorithmic
         # FLOPs of SURVEY.md 8d (274.7 MFLOP per predicted frame per video, minus nothing: the last-layer
@@ -401,6 +475,8 @@ def main():
             }
         if breakdown:
             res['kernel_breakdown_one_step'] = breakdown
+        if pcie:
+            res['pcie_inclusive'] = pcie
         if world == 1 and not args.no_cpu_baseline:
             log('cpu baseline ...')
             res['cpu_baseline'] = cpu_baseline(args.cpu_sample)

@@ -200,6 +200,45 @@ size_t sf_savi_decode_workspace_bytes(const sf_savi_decoder* m, int F);
 int sf_savi_decode_f32(const sf_savi_decoder* m, const float* slots, float* recon_combined, float* recons,
                        float* masks, int F, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- K/V producer (SURVEY.md 8(b2) sf_kv_producer_*) ---------------------------------------- */
+/* encoder_out_layer (savi.py:245-250: LN -> Linear -> ReLU -> Linear) followed by Slot Attention's
+ * norm_inputs + project_k / project_v (savi.py:66-70): feat [M,C0] channels-last CNN features (position
+ * embedding already added, savi.py:371-375) -> kv [M,2D] = (k | v).  kv_w = cat(project_k.weight,
+ * project_v.weight) [2D,C1].  One fused kernel in split-bf16 mode at (C0,C1,2D) = (64,128,256); otherwise
+ * three GEMMs through ws (sf_kv_producer_workspace_bytes). */
+size_t sf_kv_producer_workspace_bytes(int M, int C1);
+int sf_kv_producer_f32(const float* feat, const float* ln0_g, const float* ln0_b, const float* fc1_w,
+                       const float* fc1_b, const float* fc2_w, const float* fc2_b, const float* ln1_g,
+                       const float* ln1_b, const float* kv_w, float* kv, int M, int C0, int C1, int D, float ln_eps,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* ---- device-memory helpers and host-buffer twins (SURVEY.md 8(b2) "_host twin") -------------- */
+/* For callers without a HIP binding of their own (plain C, ctypes + numpy): place the weights on the GPU
+ * once with sf_device_alloc / sf_device_upload, fill the model structs with those device pointers, and call
+ * the *_host twins, whose DATA buffers (everything that is not inside a model struct) are host pointers.
+ * A twin has its device counterpart's signature; ws == NULL means "allocate the workspace for this call".
+ * Twins are synchronous (the results are in host memory on return) and allocate/free staging memory. */
+int sf_device_alloc(void** dev_out, size_t bytes);
+int sf_device_free(void* dev);
+int sf_device_upload(void* dev, const void* host, size_t bytes);
+int sf_device_download(void* host, const void* dev, size_t bytes);
+int sf_device_synchronize(void);
+/* A HIP stream restricted to a subset of the CUs (hipExtStreamCreateWithCUMask; bit i of cu_mask = CU i,
+ * n_words 32-bit words): partitions the GPU between the encode of batch i+1 and the rollout of batch i. */
+int sf_stream_create_cu_mask(void** stream_out, const unsigned int* cu_mask, int n_words);
+int sf_stream_destroy(void* stream);
+int sf_slot_attn_iter_f32_host(const float* k_host, const float* v_host, int ld, long long batch_stride,
+                               const float* q_host, float* part_num_host, float* part_den_host, float* attn_out_host,
+                               int B, int HW, int N, int D, float scale, float eps, void* stream);
+int sf_rollout_f32_host(const sf_rollouter* m, float* slots_host, int B, int T_total, int pred_len, void* ws,
+                        size_t ws_bytes, void* stream);
+int sf_savi_encode_f32_host(const sf_savi_encoder* m, const float* img_host, const float* noise_host,
+                            const float* prev_slots_host, float* lstm_h_host, float* lstm_c_host, int state_valid,
+                            float* post_slots_host, float* kernel_dist_host, float* attn_host, int B, int T, void* ws,
+                            size_t ws_bytes, void* stream);
+int sf_savi_decode_f32_host(const sf_savi_decoder* m, const float* slots_host, float* recon_combined_host,
+                            float* recons_host, float* masks_host, int F, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,21 @@ SIGNATURES = {
     'sf_savi_encode_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I]),
     'sf_savi_encode_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
                                VP]),
+    'sf_kv_producer_workspace_bytes': (SZ, [I, I]),
+    'sf_kv_producer_f32': (I, [FP] * 11 + [I, I, I, I, F32, VP, SZ, VP]),
+    # device-memory helpers + host-buffer twins (same signatures as the device entry points)
+    'sf_device_alloc': (I, [C.POINTER(VP), SZ]),
+    'sf_device_free': (I, [VP]),
+    'sf_device_upload': (I, [VP, VP, SZ]),
+    'sf_device_download': (I, [VP, VP, SZ]),
+    'sf_device_synchronize': (I, []),
+    'sf_stream_create_cu_mask': (I, [C.POINTER(VP), C.POINTER(C.c_uint), I]),
+    'sf_stream_destroy': (I, [VP]),
+    'sf_slot_attn_iter_f32_host': (I, [FP, FP, I, LL, FP, FP, FP, FP, I, I, I, I, F32, F32, VP]),
+    'sf_rollout_f32_host': (I, [C.POINTER(sf_rollouter), FP, I, I, I, VP, SZ, VP]),
+    'sf_savi_encode_f32_host': (I, [C.POINTER(sf_savi_encoder), FP, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
+                                    VP]),
+    'sf_savi_decode_f32_host': (I, [C.POINTER(sf_savi_decoder), FP, FP, FP, FP, I, VP, SZ, VP]),
 }
 
 _lib = None

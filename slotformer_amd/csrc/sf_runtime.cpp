@@ -40,7 +40,26 @@ void sf_prof_end(int cls, hipStream_t st) {
 
 extern "C" {
 
-int sf_version(void) { return 101; }
+int sf_version(void) { return 102; }
+
+// A stream restricted to a subset of the compute units (bit i of cu_mask = CU i of the device; n_words 32-bit
+// words).  Used to partition the 256 CUs between the throughput-bound encode and the latency-bound rollout chain
+// so that short rollout kernels never queue behind long convolution workgroups (batch pipelining).
+int sf_stream_create_cu_mask(void** stream_out, const unsigned int* cu_mask, int n_words) {
+  if (!stream_out || !cu_mask || n_words <= 0) return sf_set_err(-1, "invalid argument: sf_stream_create_cu_mask", __FILE__, __LINE__);
+  hipStream_t st = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, (const uint32_t*)cu_mask);
+  if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+  *stream_out = (void*)st;
+  return 0;
+}
+
+int sf_stream_destroy(void* stream) {
+  if (!stream) return 0;
+  hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+  return 0;
+}
 const char* sf_last_error_string(void) { return sf_err_buf; }
 
 int sf_profile_enable(int class_mask) {

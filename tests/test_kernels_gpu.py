@@ -17,17 +17,6 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.from_numpy((np.random.RandomState(seed).standard_normal(shape) * scale).astype(np.float32))
 
 
-@pytest.fixture(params=['bf16x3', 'f32'])
-def precision(request):
-    """Run under both matrix-arithmetic modes of the library (split-bf16 default, exact f32)."""
-    from slotformer_amd import _lib
-    lib = _lib.lib()
-    old = lib.sf_get_precision()
-    lib.sf_set_precision(1 if request.param == 'bf16x3' else 0)
-    yield request.param
-    lib.sf_set_precision(old)
-
-
 def tol(precision):
     # exact-f32 MFMA differs from torch only by summation order; split-bf16 keeps ~16 mantissa bits per operand
     return dict(rtol=2e-5, atol=2e-5) if precision == 'f32' else dict(rtol=1e-4, atol=1e-4)
