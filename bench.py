@@ -226,50 +226,56 @@ def main():
 
         # ---- software pipeline across batches: two streams, two slot buffers, one rollout graph per buffer ----
         overlap = (not args.no_overlap) and graph is not None and S == 1
+        # rollout streams: SF_BENCH_ROLL_MASKS = comma list of hex mask words, one rollout stream per entry (each word
+        # repeated over the 8 mask words); default = one stream on the complement of the encode mask
+        cu_words = [int(w, 16) for w in os.environ.get('SF_BENCH_CU_SPLIT', 'ff').split(',')]
+        cu_words = (cu_words * 8)[:8]
+        cu_split = any(cu_words)
+        roll_masks = [int(w, 16) for w in os.environ.get('SF_BENCH_ROLL_MASKS', '').split(',') if w]
+        n_rs = max(1, len(roll_masks)) if cu_split else int(os.environ.get('SF_BENCH_ROLL_STREAMS', '1'))
+        NB = n_rs + 1  # slot buffers / graphs / workspaces: one per rollout in flight + one being encoded
         if overlap:
             graphs = [graph]
+            while len(bufs) < NB:
+                bufs.append(torch.zeros_like(bufs[0]))
             try:
-                engine.rollout(roll, bufs[1], T_BURN, T_ROLL, ws_slot=1)  # allocate the second workspace before capture
-                torch.cuda.synchronize()
-                g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
-                    engine.rollout(roll, bufs[1], T_BURN, T_ROLL, ws_slot=1)  # own scratch: may run beside graph 0
-                graphs.append(g1)
+                for gi in range(1, NB):
+                    engine.rollout(roll, bufs[gi], T_BURN, T_ROLL, ws_slot=gi)  # allocate its workspace before capture
+                    torch.cuda.synchronize()
+                    g1 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1):
+                        engine.rollout(roll, bufs[gi], T_BURN, T_ROLL, ws_slot=gi)  # own scratch: may run beside the others
+                    graphs.append(g1)
             except Exception as e:  # noqa: BLE001
-                log(f'second graph capture failed ({e}); no overlap')
+                log(f'graph capture {len(graphs)} failed ({e}); no overlap')
                 overlap = False
         if overlap:
-            # the rollout is a chain of ~900 short dependent kernels: give it dispatch priority over the encode's
-            # long throughput kernels
             prio = int(os.environ.get('SF_BENCH_ROLL_PRIO', '-1'))
             s_enc = torch.cuda.Stream(device=dev, priority=int(os.environ.get('SF_BENCH_ENC_PRIO', '0')))
             # CU partition (SF_BENCH_CU_SPLIT = hex word E, 0 = off): the encode stream gets the CUs whose bit is set
-            # in E (repeated for each of the 8 mask words), the rollout stream the complement.  Measured
-            # (profiles/r01_probes.txt): E = ff (64 CUs = one shader engine of every XCD for the encode, 192 for the
-            # rollout chain) 139.5k frames/s vs 129.5k unpartitioned; partial bytes or per-word differences unbalance
-            # the shader engines and lose 20-60 %.
-            cu_words = [int(w, 16) for w in os.environ.get('SF_BENCH_CU_SPLIT', 'ff').split(',')]
-            cu_words = (cu_words * 8)[:8]
-            cu_split = any(cu_words)
+            # in E (repeated for each of the 8 mask words), the rollout stream(s) the complement.  Measured
+            # (profiles/r01_probes.txt): byte j of every word behaves as shader engine j of every XCD; E = ff (one SE
+            # = 64 CUs for the encode) beats the unpartitioned pipeline, partial bytes or per-word differences
+            # unbalance the shader engines and lose 20-60 %.
             masked = []
+
+            def masked_stream(ws):
+                words = (C.c_uint * 8)(*[w & 0xffffffff for w in ws])
+                h = C.c_void_p()
+                _lib.check(lib.sf_stream_create_cu_mask(C.byref(h), words, 8))
+                masked.append(h)
+                return torch.cuda.ExternalStream(h.value, device=dev)
+
             if cu_split:
-
-                def masked_stream(ws):
-                    words = (C.c_uint * 8)(*[w & 0xffffffff for w in ws])
-                    h = C.c_void_p()
-                    _lib.check(lib.sf_stream_create_cu_mask(C.byref(h), words, 8))
-                    masked.append(h)
-                    return torch.cuda.ExternalStream(h.value, device=dev)
-
                 s_enc = masked_stream(cu_words)
-            # SF_BENCH_ROLL_STREAMS=2 (experiment, profiles/r01_probes.txt): rollout graphs of consecutive batches on
-            # alternating streams -- measured 24.2 ms/step vs 14.4 with one rollout stream, so the default is 1
-            n_rs = int(os.environ.get('SF_BENCH_ROLL_STREAMS', '1'))
-            s_rolls = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(n_rs)]
-            if cu_split:
-                if os.environ.get('SF_BENCH_ROLL_UNMASKED', '0') != '1':  # experiment: rollout free to use every CU
+                if roll_masks:
+                    s_rolls = [masked_stream([w] * 8) for w in roll_masks]
+                elif os.environ.get('SF_BENCH_ROLL_UNMASKED', '0') == '1':  # experiment: rollout free to use every CU
+                    s_rolls = [torch.cuda.Stream(device=dev, priority=prio)]
+                else:
                     s_rolls = [masked_stream([~w for w in cu_words])]
-                n_rs = 1
+            else:
+                s_rolls = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(n_rs)]
 
             def run_pipelined(n):
                 cur = torch.cuda.current_stream()
@@ -280,16 +286,16 @@ def main():
                 ev_roll = [torch.cuda.Event() for _ in range(n)]
                 for j in range(n):
                     with torch.cuda.stream(s_enc):
-                        if j >= 2:
-                            s_enc.wait_event(ev_roll[j - 2])  # slot buffer j%2 is free once rollout j-2 is done
-                        encode(bufs[j % 2])
+                        if j >= NB:
+                            s_enc.wait_event(ev_roll[j - NB])  # slot buffer j % NB is free once rollout j-NB is done
+                        encode(bufs[j % NB])
                         ev_enc[j].record(s_enc)
                     s_roll = s_rolls[j % n_rs]
                     with torch.cuda.stream(s_roll):
                         s_roll.wait_event(ev_enc[j])
-                        if j >= 2 and n_rs > 1:
-                            s_roll.wait_event(ev_roll[j - 2])  # same graph/buffer/workspace slot as batch j-2
-                        graphs[j % 2].replay()
+                        if j >= NB:
+                            s_roll.wait_event(ev_roll[j - NB])  # same graph / buffer / workspace as batch j-NB
+                        graphs[j % NB].replay()
                         ev_roll[j].record(s_roll)
                 cur.wait_stream(s_enc)
                 for sr in s_rolls:
@@ -418,7 +424,8 @@ def main():
                 'pipelining': ('encode of batch i+1 (stream A) overlaps the rollout graph of batch i (stream B); every batch still '
                                'runs its full encode + 50-step rollout inside the timed region') if overlap else 'none',
                 'cu_partition': (f'encode stream on CU mask {cu_words[0]:#x} x8 words ({8 * bin(cu_words[0]).count("1")} CUs), '
-                                 'rollout stream on the complement') if (overlap and cu_split) else 'none',
+                                 + (f'{n_rs} rollout streams on masks ' + ','.join(f'{w:#x}' for w in roll_masks) if roll_masks
+                                    else 'rollout stream on the complement')) if (overlap and cu_split) else 'none',
             },
             'encode_ms': 1e3 * t_enc,
             'rollout_ms': 1e3 * t_roll,

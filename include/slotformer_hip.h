@@ -127,7 +127,16 @@ int sf_bilinear_resize_f32(const float* in, float* out, long long R, int Hi, int
 typedef struct {
   const float *norm1_g, *norm1_b, *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;
   const float *norm2_g, *norm2_b, *lin1_w, *lin1_b, *lin2_w, *lin2_b;
+  /* optional (NULL = absent): sf_pack_ffn_weights() copies of lin1_w / lin2_w.  When every layer of a rollouter
+   * has them (d_model 256, 8 heads, ffn 1024, norm_first, split-bf16 mode) sf_rollout_f32 runs each layer as two
+   * launches (attention + out-proj partials; FFN1 + FFN2) instead of four. */
+  const void *lin1_packed, *lin2_packed;
 } sf_tfm_layer;
+
+/* Pre-split (bf16 hi/lo) FFN weights in MFMA-fragment order; each output needs sf_ffn_packed_bytes() bytes. */
+size_t sf_ffn_packed_bytes(int d_model, int ffn);
+int sf_pack_ffn_weights(const float* lin1_w, const float* lin2_w, void* lin1_packed, void* lin2_packed, int d_model,
+                        int ffn, void* stream);
 
 /* SlotRollouter / SingleStepSlotRollouter (slotformer.py:48-134, single_step_slotformer.py:6-90). */
 typedef struct {

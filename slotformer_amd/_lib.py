@@ -15,7 +15,7 @@ FP = C.c_void_p  # device float*
 class sf_tfm_layer(C.Structure):
     _fields_ = [(n, FP) for n in (
         'norm1_g', 'norm1_b', 'in_proj_w', 'in_proj_b', 'out_proj_w', 'out_proj_b',
-        'norm2_g', 'norm2_b', 'lin1_w', 'lin1_b', 'lin2_w', 'lin2_b')]
+        'norm2_g', 'norm2_b', 'lin1_w', 'lin1_b', 'lin2_w', 'lin2_b', 'lin1_packed', 'lin2_packed')]
 
 
 class sf_rollouter(C.Structure):
@@ -90,6 +90,8 @@ SIGNATURES = {
     'sf_savi_encode_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I]),
     'sf_savi_encode_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
                                VP]),
+    'sf_ffn_packed_bytes': (SZ, [I, I]),
+    'sf_pack_ffn_weights': (I, [FP, FP, VP, VP, I, I, VP]),
     'sf_kv_producer_workspace_bytes': (SZ, [I, I]),
     'sf_kv_producer_f32': (I, [FP] * 11 + [I, I, I, I, F32, VP, SZ, VP]),
     # device-memory helpers + host-buffer twins (same signatures as the device entry points)

@@ -15,6 +15,8 @@
 // place by the out_proj GEMM epilogue.
 #include "../../include/slotformer_hip.h"
 #include "sf_internal.h"
+#include "layer_fused.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -128,7 +130,10 @@ size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B) {
   if (!m || B <= 0) return 0;
   const int Lmax = m->window_len * m->num_slots;
   const size_t M = (size_t)B * Lmax;
-  return pad256(M * m->d_model) + tfm_ws_bytes((int)M, m->d_model, m->ffn_dim) + 4096;
+  // + head partials [8][M][d], hidden-chunk partials [4][M][d], two layer-output buffers and the tile counters of the
+  // two-launch layer
+  return pad256(M * m->d_model) + tfm_ws_bytes((int)M, m->d_model, m->ffn_dim) + pad256(8 * M * m->d_model) +
+         pad256(4 * M * m->d_model) + 2 * pad256(M * m->d_model) + 4096 + 4096;
 }
 
 int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws,
@@ -151,6 +156,26 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   TfmWs tw;
   if (!x || !tfm_ws_take(bp, tw, B * Lmax, d, m->ffn_dim))
     return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
+  float* apb = bp.take((size_t)8 * B * Lmax * d);
+  float* xpb = bp.take((size_t)4 * B * Lmax * d);
+  float* xa = bp.take((size_t)B * Lmax * d);
+  float* xb2 = bp.take((size_t)B * Lmax * d);
+  int* counters = (int*)bp.take(1024);
+  if (!apb || !xpb || !xa || !xb2 || !counters) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
+  // two-launch layers (layer_fused.hip): split-bf16 mode, pre-LN, d=256 / 8 heads / ffn 1024, window <= 64 tokens
+  static const bool fused_env = [] {
+    const char* e = getenv("SF_LAYER_FUSED");
+    return !(e && e[0] == '0');
+  }();
+  bool packed = true;
+  for (int l = 0; l < m->num_layers; ++l) packed = packed && m->layers[l].lin1_packed && m->layers[l].lin2_packed;
+  const bool fused_layers = packed && fused_env && sf_get_precision() == 1 && m->norm_first &&
+                            sf_layer_fused_ok(d, m->num_heads, m->ffn_dim, Lmax);
+  if (fused_layers) {
+    SF_REQUIRE(sf_ffn_tiles(B * Lmax) <= 1024, "batch too large for the fused-layer tile counters");
+    hipError_t e = hipMemsetAsync(counters, 0, 1024 * sizeof(int), st);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+  }
   const long long bs = (long long)T_total * N * C;
   for (int s = 0; s < pred_len; ++s) {
     int nf, f0;
@@ -168,6 +193,21 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
     pmap.base = (long long)pe_off * d;
     SF_TRY(sf_linear_ex(slots, sf_rows_batched(C, L, bs, (long long)f0 * N * C), m->in_proj_w, m->in_proj_b,
                         nullptr, nullptr, 0.f, m->pe_tok, pmap, L, x, sf_rows(d), M, d, C, 0, st));
+    if (fused_layers) {
+      // every layer is two launches: attention + out-proj head partials, then the FFN (which also finishes the sums)
+      const float* cin = x;
+      for (int l = 0; l < m->num_layers; ++l) {
+        const int Lq = (l == m->num_layers - 1) ? N : L;   // last layer: only the newest frame's rows are read (slotformer.py:121)
+        const long long pst = (long long)B * Lq * d;
+        float* xo = (cin == xa) ? xb2 : xa;
+        SF_TRY(sf_attn_oproj_ex(cin, 0, 1, m->layers[l], 1e-5f, apb, pst, B, L, Lq, st));
+        SF_TRY(sf_ffn_partial_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st));
+        cin = xo;
+      }
+      SF_TRY(sf_linear_ex(cin, sf_rows(d), m->out_proj_w, m->out_proj_b, nullptr, nullptr, 0.f, nullptr, sf_rows(C), 0,
+                          slots, sf_rows_batched(C, N, bs, (long long)(n_in + s) * N * C), B * N, C, d, 0, st));
+      continue;
+    }
     float* cur = x;
     int Lc = L;
     for (int l = 0; l < m->num_layers; ++l) {

@@ -1,0 +1,639 @@
+// Two-launch Transformer encoder layer for the rollout (d_model 256, 8 heads of 32, ffn 1024, pre-LN, L <= 64).
+//
+// The rollout is a chain of ~900 short dependent kernels per 50-step job; at M = B*L = 1344 rows every GEMM is
+// bound by launch + first-load latency (~10-15 us each), not by MFMA or bandwidth.  This file halves the chain:
+//
+//   attn_oproj_kernel  (one WG per (head, video)):
+//       x = sum of the previous layer's FFN partials;  LN1 -> q|k|v of head h (split-bf16 MFMA) -> softmax(qk^T)v
+//       (f32 MFMA) -> partial_h = o_h . Wo[:, 32h:32h+32]^T  (+ x and the out-proj bias on column block h)
+//   ffn_partial_kernel (one WG per (32-row tile, 256-wide hidden chunk)):
+//       x2 = sum of the 8 head partials;  LN2 -> relu(. W1_c^T + b1_c) kept in LDS -> partial_c = h_c . W2[:, c]^T
+//       (+ x2 and the FFN bias for chunk 0)
+//
+// The cross-workgroup reductions (over heads, over hidden chunks) are DEFERRED to the consumer's prologue, which
+// sums the partial buffers while loading them -- deterministic (fixed order, no atomics) and it removes the
+// out-proj and FFN2 launches plus the hidden-activation round trip.  Weight loads are issued before anything
+// else in both kernels so the first-load latency overlaps the partial-sum prologue.
+// Reference call site: nn.TransformerEncoderLayer(norm_first=True) as configured at slotformer.py:72-80.
+#include "../../include/slotformer_hip.h"
+#include "sf_internal.h"
+#include "layer_fused.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int LF_NT = 512;
+constexpr int LF_D = 256, LF_HD = 32, LF_NH = 8;   // model width, head width, heads
+constexpr int LF_HC = 256;                          // hidden chunk of the FFN kernel
+constexpr int LF_NCH = 4;                           // ffn / LF_HC (ffn = 1024)
+
+// ---- attention kernel geometry (same tiles as attn_fused.hip at HD = 32, NK = 4) ----
+constexpr int FA_ROWS = 64, FA_KC = 64, FA_LB = FA_KC + 8, FA_SS = FA_ROWS + 4;
+constexpr int NK = LF_D / FA_KC;                    // 4
+constexpr int NC = 3 * LF_HD, NCP = 96, CBLK = 3;   // q|k|v columns of one head
+constexpr int A_IT = FA_ROWS * (FA_KC / 4) / LF_NT; // 2
+constexpr int B_IT = NCP * (FA_KC / 4) / LF_NT;     // 3
+constexpr int QSTR = LF_HD + 4;                     // 36
+constexpr int OP = LF_HD + 8;                       // bf16 row pitch of the O and Wo planes (80 B = 5 slots)
+constexpr int XS = LF_HD + 4;                       // f32 pitch of the residual stash
+constexpr size_t A_PLANES = (size_t)(2 * FA_ROWS + 2 * NCP) * FA_LB * 2 + 2 * FA_ROWS * 4;              // 46,592
+constexpr size_t A_ATTN = ((size_t)2 * FA_ROWS * QSTR + (size_t)LF_HD * FA_SS + (size_t)FA_ROWS * FA_SS + FA_ROWS) * 4;
+constexpr size_t A_OUT = (size_t)(2 * FA_ROWS + 2 * LF_D) * OP * 2;                                       // 51,200
+constexpr size_t A_MAX1 = A_PLANES > A_ATTN ? A_PLANES : A_ATTN;
+constexpr size_t A_STASH_OFF = ((A_MAX1 > A_OUT ? A_MAX1 : A_OUT) + 255) / 256 * 256;
+constexpr size_t A_LDS = A_STASH_OFF + (size_t)FA_ROWS * XS * 4;
+
+// ---- FFN kernel geometry ----
+constexpr int FB_ROWS = 32;
+constexpr int FB_AP = LF_D + 8;     // bf16 pitch of the A / H planes (528 B = 33 slots)
+constexpr int FB_XP = LF_D + 4;     // f32 pitch of the x2 stash
+constexpr size_t FB_LDS = (size_t)4 * FB_ROWS * FB_AP * 2 + (size_t)FB_ROWS * FB_XP * 4;   // A + H planes, x2 stash
+
+__device__ __forceinline__ void split4(__bf16* hp, __bf16* lp, int off, f32x4 v) {
+  const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+  const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+  *(bf16x4*)(hp + off) = hi;
+  *(bf16x4*)(lp + off) = lo;
+}
+}  // namespace
+
+// ================================================================================================
+// x [NPIN][B*L][256] partial buffers (xin_stride floats apart);  ap [8][B*Lq][256] head partials.
+template <int NPIN>
+__global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_oproj_kernel(const float* __restrict__ xin, long long xin_stride,
+                                                           const float* __restrict__ ln_g,
+                                                           const float* __restrict__ ln_b, float ln_eps,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           const float* __restrict__ wo, const float* __restrict__ bo,
+                                                           float* __restrict__ ap, long long ap_stride, int L, int Lq, int dbg) {
+  constexpr int d = LF_D, HD = LF_HD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* Ah = (__bf16*)smem;
+  __bf16* Al = Ah + FA_ROWS * FA_LB;
+  __bf16* Bh = Al + FA_ROWS * FA_LB;
+  __bf16* Bl = Bh + NCP * FA_LB;
+  float* stats = (float*)(Bl + NCP * FA_LB);  // [2][64]
+  float* Xs = (float*)((char*)smem + A_STASH_OFF);  // [64][XS]: x[:, 32h:32h+32] for the residual
+  const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* xb = xin + (long long)b * L * d;
+  const int c4 = t & 15, r0 = t >> 4;
+
+  // ---- issue every global load up front: weights first (they do not depend on the previous kernel's data) ----
+  const float* wrow[B_IT];
+  bool wok[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int n = r0 + 32 * i;
+    const int which = n / HD, j = n - which * HD;
+    wok[i] = n < NC;
+    wrow[i] = w + (long long)(wok[i] ? which * d + h * HD + j : 0) * d;
+  }
+  f32x4 rb[NK][B_IT];
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) rb[kc][i] = *(const f32x4*)(wrow[i] + kc * FA_KC + 4 * c4);
+  // activations: NPIN partial buffers summed in registers, two buffers in flight at a time (VGPR budget: the kernel
+  // must stay at <= 128 VGPRs so that two workgroups share a CU)
+  bool aok[A_IT];
+  const float* arow[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int r = r0 + 32 * i;
+    aok[i] = r < L;
+    arow[i] = xb + (long long)min(r, L - 1) * d + 4 * c4;
+  }
+  f32x4 ra[NK][A_IT];
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) ra[kc][i] = *(const f32x4*)(arow[i] + kc * FA_KC);
+  if constexpr (NPIN > 1) {
+#pragma unroll
+    for (int p = 1; p < NPIN; ++p) {
+      const long long po = ((dbg & 4) ? 0 : p) * xin_stride;
+      f32x4 tp[NK][A_IT];
+#pragma unroll
+      for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) tp[kc][i] = *(const f32x4*)(arow[i] + po + kc * FA_KC);
+#pragma unroll
+      for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) ra[kc][i] += tp[kc][i];
+    }
+  }
+  // residual stash: the 32 columns of block h live in chunk h/2, float4 columns 8*(h&1) .. +7
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc)
+    if (kc == (h >> 1) && (c4 >> 3) == (h & 1)) {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) *(f32x4*)(Xs + (r0 + 32 * i) * XS + 4 * (c4 & 7)) = ra[kc][i];
+    }
+
+  // ---- LayerNorm statistics from the registers (row r0+32*i is held by 16 consecutive lanes) ----
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc) s += (ra[kc][i][0] + ra[kc][i][1]) + (ra[kc][i][2] + ra[kc][i][3]);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)d;
+    float vs = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc) {
+      const f32x4 dv = ra[kc][i] - mean;
+      vs += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) vs += __shfl_xor(vs, o, 64);
+    if (c4 == 0) {
+      stats[r0 + 32 * i] = mean;
+      stats[FA_ROWS + r0 + 32 * i] = 1.0f / sqrtf(vs / (float)d + ln_eps);
+    }
+  }
+  __syncthreads();
+
+  // ---- q|k|v = LN(x) . W_h^T on split-bf16 MFMA: 6 blocks (2 row x 3 col) over waves 0..5 ----
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nrb = L > 32 ? 2 : 1;
+  const int nblk = nrb * CBLK;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc) {
+    const int k = kc * FA_KC + 4 * c4;
+    const f32x4 g = *(const f32x4*)(ln_g + k), be = *(const f32x4*)(ln_b + k);
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int r = r0 + 32 * i;
+      const f32x4 v = (ra[kc][i] - stats[r]) * stats[FA_ROWS + r] * g + be;
+      split4(Ah, Al, r * FA_LB + 4 * c4, aok[i] ? v : zero4);
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) split4(Bh, Bl, (r0 + 32 * i) * FA_LB + 4 * c4, wok[i] ? rb[kc][i] : zero4);
+    __syncthreads();
+    if (wave < nblk) {
+      const int rbk = wave / CBLK, cbk = wave - rbk * CBLK;
+      const int ao = (rbk * 32 + (lane & 31)) * FA_LB + 8 * (lane >> 5);
+      const int bo_ = (cbk * 32 + (lane & 31)) * FA_LB + 8 * (lane >> 5);
+#pragma unroll
+      for (int ks = 0; ks < FA_KC / 16; ++ks) {
+        const bf16x8 xh = *(const bf16x8*)(Ah + ao + ks * 16), xl = *(const bf16x8*)(Al + ao + ks * 16);
+        const bf16x8 yh = *(const bf16x8*)(Bh + bo_ + ks * 16), yl = *(const bf16x8*)(Bl + bo_ + ks * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // out-proj slice Wo[:, 32h:32h+32] (256 rows x 8 float4): requested now, consumed after the attention phases
+  f32x4 rwo[4];
+  const int c8 = t & 7, n0 = t >> 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rwo[i] = *(const f32x4*)(wo + (long long)(n0 + 64 * i) * d + h * HD + 4 * c8);
+
+  // ---- spill q (scaled), k, v^T; the planes are dead ----
+  float* Qs = smem;
+  float* Ks = Qs + FA_ROWS * QSTR;
+  float* VT = Ks + FA_ROWS * QSTR;        // [32][FA_SS]
+  float* Ss = VT + HD * FA_SS;            // [64][FA_SS]
+  float* inv = Ss + FA_ROWS * FA_SS;      // [64]
+  const float scale = 1.0f / sqrtf((float)HD);
+  if (wave < nblk) {
+    const int rbk = wave / CBLK, cbk = wave - rbk * CBLK;   // cbk = which (0 q, 1 k, 2 v) since HD == 32
+    const int j = lane & 31;
+    const float bv = bias[cbk * d + h * HD + j];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const float val = acc[r] + bv;
+      if (cbk == 0)
+        Qs[row * QSTR + j] = val * scale;
+      else if (cbk == 1)
+        Ks[row * QSTR + j] = val;
+      else
+        VT[j * FA_SS + row] = val;
+    }
+  }
+  if (nrb == 1) {
+    for (int idx = t; idx < HD * 32; idx += LF_NT) VT[(idx >> 5) * FA_SS + 32 + (idx & 31)] = 0.f;
+  }
+  __syncthreads();
+
+  // ---- scores on the f32 MFMA ----
+  if (wave < nrb * nrb) {
+    const int rbk = wave / nrb, cbk = wave - rbk * nrb;
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    const float* qp = Qs + (rbk * 32 + (lane & 31)) * QSTR + 4 * (lane >> 5);
+    const float* kp = Ks + (cbk * 32 + (lane & 31)) * QSTR + 4 * (lane >> 5);
+#pragma unroll
+    for (int kb = 0; kb < HD / 8; ++kb) {
+      const f32x4 a = *(const f32x4*)(qp + kb * 8), bq = *(const f32x4*)(kp + kb * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[s], sacc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      Ss[row * FA_SS + cbk * 32 + (lane & 31)] = sacc[r];
+    }
+  }
+  __syncthreads();
+
+  // ---- softmax over the L real keys, 8 lanes per query row ----
+  {
+    const int i = t >> 3, sub = t & 7;
+    const int kmax = nrb * 32;
+    if (i >= L - Lq && i < L) {
+      float* row = Ss + i * FA_SS;
+      float mx = -INFINITY;
+      for (int j = sub; j < L; j += 8) mx = fmaxf(mx, row[j]);
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+      float sum = 0.f;
+      for (int j = sub; j < kmax; j += 8) {
+        const float p = j < L ? expf(row[j] - mx) : 0.f;
+        row[j] = p;
+        sum += p;
+      }
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      sum += __shfl_xor(sum, 4, 64);
+      if (sub == 0) inv[i] = 1.0f / sum;
+    }
+  }
+  __syncthreads();
+
+  // ---- o = P v on the f32 MFMA (waves 0..nrb-1), kept in registers, rows outside the query range zeroed ----
+  f32x16 oacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+  if (wave < nrb) {
+    const float* pp = Ss + (wave * 32 + (lane & 31)) * FA_SS + 4 * (lane >> 5);
+    const float* vp = VT + (lane & 31) * FA_SS + 4 * (lane >> 5);
+    for (int kb = 0; kb < nrb * 4; ++kb) {
+      const f32x4 a = *(const f32x4*)(pp + kb * 8), bq = *(const f32x4*)(vp + kb * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[s], oacc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const bool q = row >= L - Lq && row < L;
+      oacc[r] = q ? oacc[r] * inv[q ? row : 0] : 0.f;
+    }
+  }
+  __syncthreads();  // Qs/Ks/VT/Ss are dead: the O and Wo planes take their place
+
+  __bf16* Oh = (__bf16*)smem;             // [64][OP]
+  __bf16* Ol = Oh + FA_ROWS * OP;
+  __bf16* WoH = Ol + FA_ROWS * OP;        // [256][OP]
+  __bf16* WoL = WoH + LF_D * OP;
+  if (wave < nrb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const __bf16 hi = (__bf16)oacc[r];
+      Oh[row * OP + (lane & 31)] = hi;
+      Ol[row * OP + (lane & 31)] = (__bf16)(oacc[r] - (float)hi);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) split4(WoH, WoL, (n0 + 64 * i) * OP + 4 * c8, rwo[i]);
+  __syncthreads();
+
+  // ---- partial_h = o_h . Wo_h^T: wave w owns output columns 32w..32w+31, both row blocks ----
+  const int nq0 = L - Lq;
+  const int n = wave * 32 + (lane & 31);
+  const float bov = bo[n];
+  const int wb = (wave * 32 + (lane & 31)) * OP + 8 * (lane >> 5);
+  for (int rbk = 0; rbk < nrb; ++rbk) {
+    if (rbk * 32 + 32 <= nq0) continue;   // no query rows in this block
+    f32x16 pacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+    const int ao = (rbk * 32 + (lane & 31)) * OP + 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {
+      const bf16x8 xh = *(const bf16x8*)(Oh + ao + ks * 16), xl = *(const bf16x8*)(Ol + ao + ks * 16);
+      const bf16x8 yh = *(const bf16x8*)(WoH + wb + ks * 16), yl = *(const bf16x8*)(WoL + wb + ks * 16);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, pacc, 0, 0, 0);
+    }
+    float* dst = ap + (long long)h * ap_stride + (long long)b * Lq * d + n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row >= nq0 && row < L && !((dbg & 8) && wave != h)) {
+        float v = pacc[r];
+        if (wave == h) v += Xs[row * XS + (lane & 31)] + bov;   // residual + bias live on column block h
+        dst[(long long)(row - nq0) * d] = v;
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// Packed FFN weights (sf_pack_ffn_weights): both matrices pre-split into bf16 hi/lo and stored in the order the
+// MFMA B-operand fragments are consumed, so that a wave loads its fragments straight from memory into registers
+// (1 KB contiguous per wave-wide load) and the weights never pass through LDS:
+//     uint4 index = ((((c * 16 + ks) * 8 + wave) * 2 + plane) * 64 + lane),   8 bf16 per uint4
+//     lin1_packed: element j = W1[c*256 + wave*32 + (lane & 31)][ks*16 + 8*(lane >> 5) + j]
+//     lin2_packed: element j = W2[wave*32 + (lane & 31)][c*256 + ks*16 + 8*(lane >> 5) + j]
+// c = hidden chunk (4), ks = 16-wide k step (16), plane 0 = hi, 1 = lo.
+__global__ void pack_ffn_kernel(const float* __restrict__ w1, const float* __restrict__ w2, uint4* __restrict__ p1,
+                                uint4* __restrict__ p2, int ffn) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one uint4 of each matrix
+  const int total = (ffn / LF_HC) * 16 * 8 * 2 * 64;
+  if (idx >= total) return;
+  const int lane = idx & 63, plane = (idx >> 6) & 1, wave = (idx >> 7) & 7, ks = (idx >> 10) & 15, c = idx >> 14;
+  const int nl = wave * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+  const float* s1 = w1 + (long long)(c * LF_HC + nl) * LF_D + k0;
+  const float* s2 = w2 + (long long)nl * ffn + c * LF_HC + k0;
+  union {
+    __bf16 h[8];
+    uint4 u;
+  } o1, o2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float a = s1[j], bq = s2[j];
+    const __bf16 ah = (__bf16)a, bh = (__bf16)bq;
+    o1.h[j] = plane ? (__bf16)(a - (float)ah) : ah;
+    o2.h[j] = plane ? (__bf16)(bq - (float)bh) : bh;
+  }
+  p1[idx] = o1.u;
+  p2[idx] = o2.u;
+}
+
+// ap [8][M][256] head partials -> xout [M][256] finished layer output (xp [4][M][256]: chunk-partial scratch);
+// grid = ceil(tiles/8) * 32 workgroups, tile = 32 rows, 4 hidden chunks per tile.
+__global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restrict__ ap, long long ap_stride,
+                                                            const float* __restrict__ ln_g,
+                                                            const float* __restrict__ ln_b, float ln_eps,
+                                                            const uint4* __restrict__ w1p, const float* __restrict__ b1,
+                                                            const uint4* __restrict__ w2p, const float* __restrict__ b2,
+                                                            float* __restrict__ xp, long long xp_stride,
+                                                            float* __restrict__ xout, int* __restrict__ counters,
+                                                            int ntiles, int M, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int s_last;
+  __bf16* Ah = (__bf16*)smem;                  // [32][FB_AP]  LN2(x2)
+  __bf16* Al = Ah + FB_ROWS * FB_AP;
+  __bf16* Hh = Al + FB_ROWS * FB_AP;           // [32][FB_AP]  relu(h_c)
+  __bf16* Hl = Hh + FB_ROWS * FB_AP;
+  float* X2 = (float*)(Hl + FB_ROWS * FB_AP);  // [32][FB_XP]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // block b runs on XCD b % 8: the four hidden chunks of a row tile share an XCD (one L2 fetch of the head partials,
+  // L2-local hand-over of the chunk partials); tiles are dealt round-robin over the XCDs
+  const int c = (blockIdx.x >> 3) & (LF_NCH - 1), tile = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7);
+  if (tile >= ntiles) return;
+  const int row0 = tile * FB_ROWS;
+
+  // ---- weight fragments: wf[ks][plane], 16 k-steps; FFN1's are requested now, FFN2's as FFN1 consumes them ----
+  const uint4* w1c = w1p + ((long long)(c * 16) * 8 + wave) * 128 + lane;
+  const uint4* w2c = w2p + ((long long)(c * 16) * 8 + wave) * 128 + lane;
+  bf16x8 wf[16][2];
+  auto ldw = [&](const uint4* base, int ks, int plane) {
+    return __builtin_bit_cast(bf16x8, base[(ks * 8) * 128 + plane * 64]);
+  };
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    wf[ks][0] = ldw(w1c, ks, 0);
+    wf[ks][1] = ldw(w1c, ks, 1);
+  }
+
+  // ---- x2 = sum of the head partials: wave `wave` owns rows wave + 8 i, lane = float4 column ----
+  f32x4 x2[4];
+  {
+    f32x4 pr[LF_NH][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gr = min(row0 + wave + 8 * i, M - 1);
+      const float* p = ap + (long long)gr * LF_D + 4 * lane;
+#pragma unroll
+      for (int q = 0; q < LF_NH; ++q) pr[q][i] = *(const f32x4*)(p + ((dbg & 1) ? 0 : q) * ap_stride);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 s = pr[0][i];
+#pragma unroll
+      for (int q = 1; q < LF_NH; ++q) s += pr[q][i];
+      x2[i] = s;
+    }
+  }
+#pragma unroll
+  for (int ks = 8; ks < 16; ++ks) {
+    wf[ks][0] = ldw(w1c, ks, 0);
+    wf[ks][1] = ldw(w1c, ks, 1);
+  }
+  {
+    const f32x4 g = *(const f32x4*)(ln_g + 4 * lane), be = *(const f32x4*)(ln_b + 4 * lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = wave + 8 * i;
+      const f32x4 v = x2[i];
+      const float mean = sf_wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / LF_D);
+      const f32x4 dv = v - mean;
+      const float var = sf_wave_sum((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3])) * (1.0f / LF_D);
+      const float rstd = 1.0f / sqrtf(var + ln_eps);
+      split4(Ah, Al, r * FB_AP + 4 * lane, dv * rstd * g + be);
+      if (c == 0) *(f32x4*)(X2 + r * FB_XP + 4 * lane) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- FFN1: h_c = relu(LN2(x2) . W1_c^T + b1_c); wave w owns hidden columns 32w..32w+31 of the chunk ----
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int ao = (lane & 31) * FB_AP + 8 * (lane >> 5);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const bf16x8 xh = *(const bf16x8*)(Ah + ao + ks * 16), xl = *(const bf16x8*)(Al + ao + ks * 16);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wf[ks][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wf[ks][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wf[ks][0], acc, 0, 0, 0);
+    if (!(dbg & 2)) {   // this step's registers are free again: request the matching FFN2 fragment
+      wf[ks][0] = ldw(w2c, ks, 0);
+      wf[ks][1] = ldw(w2c, ks, 1);
+    }
+  }
+  {
+    const int nloc = wave * 32 + (lane & 31);
+    const float bv = b1[c * LF_HC + nloc];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const float hv = fmaxf(acc[r] + bv, 0.f);
+      const __bf16 hi = (__bf16)hv;
+      Hh[row * FB_AP + nloc] = hi;
+      Hl[row * FB_AP + nloc] = (__bf16)(hv - (float)hi);
+    }
+  }
+  __syncthreads();
+
+  // ---- FFN2 partial: y_c = h_c . W2[:, chunk c]^T; wave w owns output columns 32w..32w+31 ----
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const bf16x8 xh = *(const bf16x8*)(Hh + ao + ks * 16), xl = *(const bf16x8*)(Hl + ao + ks * 16);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wf[ks][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wf[ks][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wf[ks][0], acc, 0, 0, 0);
+  }
+
+  // ---- chunk partial -> memory; the LAST of the tile's four workgroups to arrive sums them in fixed order
+  //      (c = 0..3, so the result does not depend on which one is last) and writes the finished rows ----
+  const int n = wave * 32 + (lane & 31);
+  const float bv = (c == 0) ? b2[n] : 0.f;
+  float vals[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    float v = acc[r] + bv;
+    if (c == 0) v += X2[row * FB_XP + n];
+    vals[r] = v;
+    // write-through store (agent-scope relaxed atomic = sc1): the value is at the device coherence point once the
+    // store is acknowledged, without the whole-L2 write-back a __threadfence() would cost (~30 us per launch here)
+    if (row0 + row < M)
+      __hip_atomic_store(xp + (long long)c * xp_stride + (long long)(row0 + row) * LF_D + n, v, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every partial store of this thread is acknowledged
+  __syncthreads();                                    // ... and of the whole workgroup
+  if (t == 0)
+    s_last = (__hip_atomic_fetch_add(counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == LF_NCH - 1);
+  __syncthreads();
+  if (s_last) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row0 + row < M) {
+        const long long off = (long long)(row0 + row) * LF_D + n;
+        float sum = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < LF_NCH; ++cc) {
+          const float pv = (cc == c) ? vals[r]
+                                     : __hip_atomic_load(xp + (long long)cc * xp_stride + off, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+          sum = (cc == 0) ? pv : sum + pv;
+        }
+        xout[off] = sum;
+      }
+    }
+    if (t == 0) __hip_atomic_store(counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  }
+}
+
+// y[i] = sum_c xp[c][i]  (float4 granules)
+__global__ void sum_partials_kernel(const float* __restrict__ xp, long long stride, int np, float* __restrict__ y,
+                                    long long n4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 s = *(const f32x4*)(xp + 4 * i);
+  for (int c = 1; c < np; ++c) s += *(const f32x4*)(xp + c * stride + 4 * i);
+  *(f32x4*)(y + 4 * i) = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// timing ablations (wrong results): 1 FFN reads one head partial, 2 FFN skips the W2 loads, 4 attention reads one
+// input partial, 8 attention stores one column block
+static int lf_dbg() {
+  static const int v = [] {
+    const char* e = getenv("SF_LF_DBG");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
+bool sf_layer_fused_ok(int d, int heads, int ffn, int L) {
+  return d == LF_D && heads == LF_NH && ffn == LF_NCH * LF_HC && L >= 1 && L <= FA_ROWS;
+}
+
+template <int NPIN>
+static int launch_attn(const float* xin, long long xin_stride, const sf_tfm_layer& w, float eps, float* ap,
+                       long long ap_stride, int B, int L, int Lq, hipStream_t st) {
+  auto kern = attn_oproj_kernel<NPIN>;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A_LDS);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    attr = true;
+  }
+  sf_prof_begin(SF_K_MHA, st, 6.0 * B * L * (double)LF_D * LF_D + 4.0 * (double)B * LF_NH * Lq * L * LF_HD +
+                                  2.0 * B * Lq * (double)LF_D * LF_D);
+  hipLaunchKernelGGL(kern, dim3(LF_NH, B), dim3(LF_NT), A_LDS, st, xin, xin_stride, w.norm1_g, w.norm1_b, eps,
+                     w.in_proj_w, w.in_proj_b, w.out_proj_w, w.out_proj_b, ap, ap_stride, L, Lq, lf_dbg());
+  sf_prof_end(SF_K_MHA, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// xin: np_in (1 or 4) partial buffers [B*L, 256]; ap: 8 buffers [B*Lq, 256]
+int sf_attn_oproj_ex(const float* xin, long long xin_stride, int np_in, const sf_tfm_layer& w, float eps, float* ap,
+                     long long ap_stride, int B, int L, int Lq, hipStream_t st) {
+  static_assert(A_LDS <= 80 * 1024, "attention+out-proj kernel: two workgroups per CU");
+  if (np_in == 1) return launch_attn<1>(xin, xin_stride, w, eps, ap, ap_stride, B, L, Lq, st);
+  if (np_in == LF_NCH) return launch_attn<LF_NCH>(xin, xin_stride, w, eps, ap, ap_stride, B, L, Lq, st);
+  return sf_set_err(-1, "invalid argument: sf_attn_oproj_ex partial count", __FILE__, __LINE__);
+}
+
+int sf_ffn_partial_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp,
+                      long long xp_stride, float* xout, int* counters, int M, int ffn, hipStream_t st) {
+  static_assert(FB_LDS <= 160 * 1024, "FFN kernel: LDS budget");
+  if (!w.lin1_packed || !w.lin2_packed || ffn != LF_NCH * LF_HC)
+    return sf_set_err(-1, "invalid argument: fused FFN needs packed weights (sf_pack_ffn_weights) and ffn == 1024", __FILE__, __LINE__);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)ffn_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)FB_LDS);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    attr = true;
+  }
+  const int tiles = (M + FB_ROWS - 1) / FB_ROWS;
+  const int groups = (tiles + 7) / 8;   // 8 tiles x 4 chunks per group of 32 consecutive blocks
+  sf_prof_begin(SF_K_LINEAR, st, 4.0 * M * (double)LF_D * ffn);
+  hipLaunchKernelGGL(ffn_partial_kernel, dim3(groups * 32), dim3(LF_NT), FB_LDS, st, ap, ap_stride, w.norm2_g,
+                     w.norm2_b, eps, (const uint4*)w.lin1_packed, w.lin1_b, (const uint4*)w.lin2_packed, w.lin2_b, xp,
+                     xp_stride, xout, counters, tiles, M, lf_dbg());
+  sf_prof_end(SF_K_LINEAR, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t sf_ffn_packed_bytes(int d_model, int ffn) { return (size_t)d_model * ffn * 4; }
+
+// lin1_w [ffn, d], lin2_w [d, ffn] (torch layouts) -> fragment-ordered split-bf16 copies (layout above).
+extern "C" int sf_pack_ffn_weights(const float* lin1_w, const float* lin2_w, void* lin1_packed, void* lin2_packed,
+                                   int d_model, int ffn, void* stream) {
+  SF_REQUIRE(lin1_w && lin2_w && lin1_packed && lin2_packed, "sf_pack_ffn_weights: null pointer");
+  SF_REQUIRE(d_model == LF_D && ffn > 0 && (ffn % LF_HC) == 0, "sf_pack_ffn_weights: needs d_model == 256 and ffn % 256 == 0");
+  const int total = (ffn / LF_HC) * 16 * 8 * 2 * 64;
+  hipLaunchKernelGGL(pack_ffn_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, lin1_w, lin2_w,
+                     (uint4*)lin1_packed, (uint4*)lin2_packed, ffn);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+int sf_ffn_tiles(int M) { return (M + FB_ROWS - 1) / FB_ROWS; }
+
+int sf_sum_partials_ex(const float* xp, long long stride, int np, float* y, long long n, hipStream_t st) {
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, xp, stride, np, y, n4);
+  SF_CHECK_LAUNCH();
+  return 0;
+}

@@ -32,3 +32,7 @@ int sf_conv5x5_halo_ex(const float* in, const float* w_packed, const float* bias
 int sf_pixel_mlp_kv_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1,
                        const float* w2, const float* b2, const float* ln1_g, const float* ln1_b, const float* wkv,
                        float* kv, int M, int C0, int C1, int ND, float eps, hipStream_t st);
+
+// two-launch Transformer layer of the rollout (layer_fused.hip); sf_tfm_layer comes from the public header
+bool sf_layer_fused_ok(int d, int heads, int ffn, int L);
+int sf_sum_partials_ex(const float* xp, long long stride, int np, float* y, long long n, hipStream_t st);

@@ -59,12 +59,22 @@ def _signature(module):
     return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
 
 
-def _tfm_layers(plan, encoder):
-    """nn.TransformerEncoder -> host array of sf_tfm_layer."""
+def _tfm_layers(plan, encoder, pack_ffn=False):
+    """nn.TransformerEncoder -> host array of sf_tfm_layer.  pack_ffn: also build the fragment-ordered split-bf16
+    copies of linear1 / linear2 that the two-launch rollout layer reads (d_model 256, ffn 1024 only)."""
     n = len(encoder.layers)
     arr = (sf_tfm_layer * n)()
     for i, l in enumerate(encoder.layers):
         a = arr[i]
+        d, ffn = l.linear1.in_features, l.linear1.out_features
+        if pack_ffn and d == 256 and ffn == 1024 and l.linear1.weight.is_cuda:
+            nb = lib().sf_ffn_packed_bytes(d, ffn)
+            p1 = torch.empty(nb, dtype=torch.uint8, device=l.linear1.weight.device)
+            p2 = torch.empty(nb, dtype=torch.uint8, device=l.linear1.weight.device)
+            check(lib().sf_pack_ffn_weights(plan.dp(l.linear1.weight), plan.dp(l.linear2.weight), p1.data_ptr(),
+                                            p2.data_ptr(), d, ffn, torch.cuda.current_stream().cuda_stream))
+            plan.keep += [p1, p2]
+            a.lin1_packed, a.lin2_packed = p1.data_ptr(), p2.data_ptr()
         a.norm1_g, a.norm1_b = plan.dp(l.norm1.weight), plan.dp(l.norm1.bias)
         a.in_proj_w, a.in_proj_b = plan.dp(l.self_attn.in_proj_weight), plan.dp(l.self_attn.in_proj_bias)
         a.out_proj_w, a.out_proj_b = plan.dp(l.self_attn.out_proj.weight), plan.dp(l.self_attn.out_proj.bias)
@@ -100,7 +110,7 @@ def rollouter_plan(r):
     if r.enc_slots_pe is not None:
         pe = pe + r.enc_slots_pe.detach()[0].repeat(W, 1)
     s.pe_tok = plan.dp(pe.contiguous())
-    s.layers = C.cast(_tfm_layers(plan, enc), C.POINTER(sf_tfm_layer))
+    s.layers = C.cast(_tfm_layers(plan, enc, pack_ffn=True), C.POINTER(sf_tfm_layer))
     plan.struct, plan.sig = s, sig
     r._sf_plan = plan
     return plan
