@@ -24,6 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 constexpr int LF_NT = 512;
@@ -45,7 +46,8 @@ constexpr size_t A_ATTN = ((size_t)2 * FA_ROWS * QSTR + (size_t)LF_HD * FA_SS + 
 constexpr size_t A_OUT = (size_t)(2 * FA_ROWS + 2 * LF_D) * OP * 2;                                       // 51,200
 constexpr size_t A_MAX1 = A_PLANES > A_ATTN ? A_PLANES : A_ATTN;
 constexpr size_t A_STASH_OFF = ((A_MAX1 > A_OUT ? A_MAX1 : A_OUT) + 255) / 256 * 256;
-constexpr size_t A_LDS = A_STASH_OFF + (size_t)FA_ROWS * XS * 4;
+constexpr size_t A_GB_OFF = A_STASH_OFF + (size_t)FA_ROWS * XS * 4;   // LN gamma | beta [2][256] f32
+constexpr size_t A_LDS = A_GB_OFF + 2 * LF_D * 4;
 
 // ---- FFN kernel geometry ----
 constexpr int FB_ROWS = 32;
@@ -60,6 +62,10 @@ __device__ __forceinline__ void split4(__bf16* hp, __bf16* lp, int off, f32x4 v)
   *(bf16x4*)(lp + off) = lo;
 }
 }  // namespace
+
+__device__ long long lf_ts[32];   // phase timestamps of one workgroup (SF_LF_DBG & 16), read by sf_debug_read_ts
+#define LF_TS(i) do { if ((dbg & 16) && blockIdx.x == 0 && threadIdx.x == 0) lf_ts[i] = wall_clock64(); } while (0)
+#define LF_TA(i) do { if ((dbg & 16) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) lf_ts[i] = wall_clock64(); } while (0)
 
 // ================================================================================================
 // x [NPIN][B*L][256] partial buffers (xin_stride floats apart);  ap [8][B*Lq][256] head partials.
@@ -81,6 +87,14 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const float* xb = xin + (long long)b * L * d;
   const int c4 = t & 15, r0 = t >> 4;
+  LF_TA(16);
+  // small parameter vectors first (vmcnt retires in order: a late request would queue behind the weight tiles):
+  // LN gamma/beta -> LDS, the q|k|v bias of this wave's column block and the out-proj bias -> registers
+  float* GB = (float*)((char*)smem + A_GB_OFF);
+  f32x4 gbv = {0.f, 0.f, 0.f, 0.f};
+  if (t < 128) gbv = *(const f32x4*)((t < 64 ? ln_g : ln_b) + 4 * (t & 63));
+  const float qkv_bias = bias[(wave % CBLK) * d + h * HD + (lane & 31)];
+  const float bov = bo[wave * 32 + (lane & 31)];
 
   // ---- issue every global load up front: weights first (they do not depend on the previous kernel's data) ----
   const float* wrow[B_IT];
@@ -135,14 +149,15 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
       for (int i = 0; i < A_IT; ++i) *(f32x4*)(Xs + (r0 + 32 * i) * XS + 4 * (c4 & 7)) = ra[kc][i];
     }
 
+  LF_TA(17);
+  if (t < 128) *(f32x4*)(GB + 4 * t) = gbv;
   // ---- LayerNorm statistics from the registers (row r0+32*i is held by 16 consecutive lanes) ----
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     float s = 0.f;
 #pragma unroll
     for (int kc = 0; kc < NK; ++kc) s += (ra[kc][i][0] + ra[kc][i][1]) + (ra[kc][i][2] + ra[kc][i][3]);
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+    s = sf_sum16(s);
     const float mean = s / (float)d;
     float vs = 0.f;
 #pragma unroll
@@ -150,14 +165,14 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
       const f32x4 dv = ra[kc][i] - mean;
       vs += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
     }
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) vs += __shfl_xor(vs, o, 64);
+    vs = sf_sum16(vs);
     if (c4 == 0) {
       stats[r0 + 32 * i] = mean;
       stats[FA_ROWS + r0 + 32 * i] = 1.0f / sqrtf(vs / (float)d + ln_eps);
     }
   }
   __syncthreads();
+  LF_TA(18);
 
   // ---- q|k|v = LN(x) . W_h^T on split-bf16 MFMA: 6 blocks (2 row x 3 col) over waves 0..5 ----
   f32x16 acc;
@@ -169,7 +184,7 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
   for (int kc = 0; kc < NK; ++kc) {
     const int k = kc * FA_KC + 4 * c4;
-    const f32x4 g = *(const f32x4*)(ln_g + k), be = *(const f32x4*)(ln_b + k);
+    const f32x4 g = *(const f32x4*)(GB + k), be = *(const f32x4*)(GB + LF_D + k);
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int r = r0 + 32 * i;
@@ -195,6 +210,7 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     __syncthreads();
   }
 
+  LF_TA(19);
   // out-proj slice Wo[:, 32h:32h+32] (256 rows x 8 float4): requested now, consumed after the attention phases
   f32x4 rwo[4];
   const int c8 = t & 7, n0 = t >> 3;
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   if (wave < nblk) {
     const int rbk = wave / CBLK, cbk = wave - rbk * CBLK;   // cbk = which (0 q, 1 k, 2 v) since HD == 32
     const int j = lane & 31;
-    const float bv = bias[cbk * d + h * HD + j];
+    const float bv = qkv_bias;   // cbk == wave % CBLK
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = rbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -228,6 +244,7 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     for (int idx = t; idx < HD * 32; idx += LF_NT) VT[(idx >> 5) * FA_SS + 32 + (idx & 31)] = 0.f;
   }
   __syncthreads();
+  LF_TA(20);
 
   // ---- scores on the f32 MFMA ----
   if (wave < nrb * nrb) {
@@ -250,6 +267,7 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     }
   }
   __syncthreads();
+  LF_TA(21);
 
   // ---- softmax over the L real keys, 8 lanes per query row ----
   {
@@ -259,22 +277,19 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
       float* row = Ss + i * FA_SS;
       float mx = -INFINITY;
       for (int j = sub; j < L; j += 8) mx = fmaxf(mx, row[j]);
-      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+      mx = sf_max8(mx);
       float sum = 0.f;
       for (int j = sub; j < kmax; j += 8) {
         const float p = j < L ? expf(row[j] - mx) : 0.f;
         row[j] = p;
         sum += p;
       }
-      sum += __shfl_xor(sum, 1, 64);
-      sum += __shfl_xor(sum, 2, 64);
-      sum += __shfl_xor(sum, 4, 64);
+      sum = sf_sum8(sum);
       if (sub == 0) inv[i] = 1.0f / sum;
     }
   }
   __syncthreads();
+  LF_TA(22);
 
   // ---- o = P v on the f32 MFMA (waves 0..nrb-1), kept in registers, rows outside the query range zeroed ----
   f32x16 oacc;
@@ -296,6 +311,7 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     }
   }
   __syncthreads();  // Qs/Ks/VT/Ss are dead: the O and Wo planes take their place
+  LF_TA(23);
 
   __bf16* Oh = (__bf16*)smem;             // [64][OP]
   __bf16* Ol = Oh + FA_ROWS * OP;
@@ -313,11 +329,11 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
   for (int i = 0; i < 4; ++i) split4(WoH, WoL, (n0 + 64 * i) * OP + 4 * c8, rwo[i]);
   __syncthreads();
+  LF_TA(24);
 
   // ---- partial_h = o_h . Wo_h^T: wave w owns output columns 32w..32w+31, both row blocks ----
   const int nq0 = L - Lq;
   const int n = wave * 32 + (lane & 31);
-  const float bov = bo[n];
   const int wb = (wave * 32 + (lane & 31)) * OP + 8 * (lane >> 5);
   for (int rbk = 0; rbk < nrb; ++rbk) {
     if (rbk * 32 + 32 <= nq0) continue;   // no query rows in this block
@@ -344,6 +360,7 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
       }
     }
   }
+  LF_TA(25);
 }
 
 // ================================================================================================
@@ -380,6 +397,10 @@ __global__ void pack_ffn_kernel(const float* __restrict__ w1, const float* __res
 
 // ap [8][M][256] head partials -> xout [M][256] finished layer output (xp [4][M][256]: chunk-partial scratch);
 // grid = ceil(tiles/8) * 32 workgroups, tile = 32 rows, 4 hidden chunks per tile.
+//
+// Both GEMMs run "transposed" (weights as the MFMA A operand, activations as B): a lane then owns 4 CONSECUTIVE
+// output columns of one token, so the hidden activations go to LDS as packed 8-byte stores and the results leave
+// as 16-byte vectors.
 __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restrict__ ap, long long ap_stride,
                                                             const float* __restrict__ ln_g,
                                                             const float* __restrict__ ln_b, float ln_eps,
@@ -394,14 +415,21 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
   __bf16* Al = Ah + FB_ROWS * FB_AP;
   __bf16* Hh = Al + FB_ROWS * FB_AP;           // [32][FB_AP]  relu(h_c)
   __bf16* Hl = Hh + FB_ROWS * FB_AP;
-  float* X2 = (float*)(Hl + FB_ROWS * FB_AP);  // [32][FB_XP]
+  float* X2 = (float*)(Hl + FB_ROWS * FB_AP);  // [32][FB_XP]  x2 (residual), later the output tile
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  // block b runs on XCD b % 8: the four hidden chunks of a row tile share an XCD (one L2 fetch of the head partials,
-  // L2-local hand-over of the chunk partials); tiles are dealt round-robin over the XCDs
+  // block b runs on XCD b % 8: the four hidden chunks of a row tile share an XCD (one L2 fetch of the head partials);
+  // tiles are dealt round-robin over the XCDs
   const int c = (blockIdx.x >> 3) & (LF_NCH - 1), tile = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7);
   if (tile >= ntiles) return;
   const int row0 = tile * FB_ROWS;
+  LF_TS(0);
 
+  // small parameter vectors first: vmcnt retires in order, so a late request would wait for every weight fragment
+  const int tok = lane & 31, nb = wave * 32 + 4 * (lane >> 5);   // FFN outputs: this lane's token and first column (+ 8 g)
+  const f32x4 lng = *(const f32x4*)(ln_g + 4 * lane), lnb = *(const f32x4*)(ln_b + 4 * lane);
+  f32x4 b1v[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) b1v[g] = *(const f32x4*)(b1 + c * LF_HC + nb + 8 * g);
   // ---- weight fragments: wf[ks][plane], 16 k-steps; FFN1's are requested now, FFN2's as FFN1 consumes them ----
   const uint4* w1c = w1p + ((long long)(c * 16) * 8 + wave) * 128 + lane;
   const uint4* w2c = w2p + ((long long)(c * 16) * 8 + wave) * 128 + lane;
@@ -434,28 +462,33 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
       x2[i] = s;
     }
   }
+  LF_TS(1);
 #pragma unroll
   for (int ks = 8; ks < 16; ++ks) {
     wf[ks][0] = ldw(w1c, ks, 0);
     wf[ks][1] = ldw(w1c, ks, 1);
   }
   {
-    const f32x4 g = *(const f32x4*)(ln_g + 4 * lane), be = *(const f32x4*)(ln_b + 4 * lane);
+    const f32x4 g = lng, be = lnb;
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mean[i] = sf_sum64((x2[i][0] + x2[i][1]) + (x2[i][2] + x2[i][3])) * (1.0f / LF_D);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 dv = x2[i] - mean[i];
+      rstd[i] = 1.0f / sqrtf(sf_sum64((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3])) * (1.0f / LF_D) + ln_eps);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = wave + 8 * i;
-      const f32x4 v = x2[i];
-      const float mean = sf_wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / LF_D);
-      const f32x4 dv = v - mean;
-      const float var = sf_wave_sum((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3])) * (1.0f / LF_D);
-      const float rstd = 1.0f / sqrtf(var + ln_eps);
-      split4(Ah, Al, r * FB_AP + 4 * lane, dv * rstd * g + be);
-      if (c == 0) *(f32x4*)(X2 + r * FB_XP + 4 * lane) = v;
+      split4(Ah, Al, r * FB_AP + 4 * lane, (x2[i] - mean[i]) * rstd[i] * g + be);
+      if (c == 0) *(f32x4*)(X2 + r * FB_XP + 4 * lane) = x2[i];
     }
   }
   __syncthreads();
+  LF_TS(2);
 
-  // ---- FFN1: h_c = relu(LN2(x2) . W1_c^T + b1_c); wave w owns hidden columns 32w..32w+31 of the chunk ----
+  // ---- FFN1 (transposed): acc[4g+q] = h[token = lane&31][hidden = 32 wave + 8g + 4(lane>>5) + q] ----
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -463,80 +496,89 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     const bf16x8 xh = *(const bf16x8*)(Ah + ao + ks * 16), xl = *(const bf16x8*)(Al + ao + ks * 16);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wf[ks][0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wf[ks][1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wf[ks][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh, acc, 0, 0, 0);
     if (!(dbg & 2)) {   // this step's registers are free again: request the matching FFN2 fragment
       wf[ks][0] = ldw(w2c, ks, 0);
       wf[ks][1] = ldw(w2c, ks, 1);
     }
   }
-  {
-    const int nloc = wave * 32 + (lane & 31);
-    const float bv = b1[c * LF_HC + nloc];
+  LF_TS(3);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const float hv = fmaxf(acc[r] + bv, 0.f);
-      const __bf16 hi = (__bf16)hv;
-      Hh[row * FB_AP + nloc] = hi;
-      Hl[row * FB_AP + nloc] = (__bf16)(hv - (float)hi);
-    }
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 bv = b1v[g];
+    f32x4 hv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hv[q] = fmaxf(acc[4 * g + q] + bv[q], 0.f);
+    split4(Hh, Hl, tok * FB_AP + nb + 8 * g, hv);
   }
   __syncthreads();
+  LF_TS(4);
 
-  // ---- FFN2 partial: y_c = h_c . W2[:, chunk c]^T; wave w owns output columns 32w..32w+31 ----
+  // ---- FFN2 partial (transposed): acc[4g+q] = y_c[token][out column 32 wave + 8g + 4(lane>>5) + q] ----
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     const bf16x8 xh = *(const bf16x8*)(Hh + ao + ks * 16), xl = *(const bf16x8*)(Hl + ao + ks * 16);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wf[ks][0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wf[ks][1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wf[ks][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh, acc, 0, 0, 0);
   }
+  LF_TS(5);
 
-  // ---- chunk partial -> memory; the LAST of the tile's four workgroups to arrive sums them in fixed order
-  //      (c = 0..3, so the result does not depend on which one is last) and writes the finished rows ----
-  const int n = wave * 32 + (lane & 31);
-  const float bv = (c == 0) ? b2[n] : 0.f;
-  float vals[16];
+  // ---- output tile -> LDS (in place over the x2 stash; chunk 0 adds the residual and the bias), re-read row-major ----
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    float v = acc[r] + bv;
-    if (c == 0) v += X2[row * FB_XP + n];
-    vals[r] = v;
-    // write-through store (agent-scope relaxed atomic = sc1): the value is at the device coherence point once the
-    // store is acknowledged, without the whole-L2 write-back a __threadfence() would cost (~30 us per launch here)
-    if (row0 + row < M)
-      __hip_atomic_store(xp + (long long)c * xp_stride + (long long)(row0 + row) * LF_D + n, v, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+  for (int g = 0; g < 4; ++g) {
+    float* o = X2 + tok * FB_XP + nb + 8 * g;
+    f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    if (c == 0) v += *(const f32x4*)o + *(const f32x4*)(b2 + nb + 8 * g);
+    *(f32x4*)o = v;
   }
+  __syncthreads();
+  // thread t owns float4 (row = wave + 8 i, column 4 lane): 1 KB contiguous per wave-wide access
+  const __amdgpu_buffer_rsrc_t xpr = __builtin_amdgcn_make_buffer_rsrc(xp, 0, 0x7fffffff, 0x00020000);
+  f32x4 mine[4];
+  unsigned off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave + 8 * i;
+    mine[i] = *(const f32x4*)(X2 + r * FB_XP + 4 * lane);
+    off[i] = (unsigned)(((long long)min(row0 + r, M - 1) * LF_D + 4 * lane) * 4);
+  }
+  // ---- chunk partial -> memory; the LAST of the tile's four workgroups to arrive sums them in fixed order
+  //      (c = 0..3, so the result does not depend on which one is last) and writes the finished rows.
+  //      Write-through (sc1) stores put the values at the device coherence point once acknowledged, without the
+  //      whole-L2 write-back a __threadfence() would cost (~30 us per launch here). ----
+  const unsigned cstride = (unsigned)(xp_stride * 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (row0 + wave + 8 * i < M)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mine[i]), xpr, off[i] + c * cstride, 0, 16);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every partial store of this thread is acknowledged
   __syncthreads();                                    // ... and of the whole workgroup
+  LF_TS(6);
   if (t == 0)
     s_last = (__hip_atomic_fetch_add(counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == LF_NCH - 1);
   __syncthreads();
+  LF_TS(7);
   if (s_last) {
+    f32x4 oth[LF_NCH][4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row0 + row < M) {
-        const long long off = (long long)(row0 + row) * LF_D + n;
-        float sum = 0.f;
+    for (int cc = 0; cc < LF_NCH; ++cc)
 #pragma unroll
-        for (int cc = 0; cc < LF_NCH; ++cc) {
-          const float pv = (cc == c) ? vals[r]
-                                     : __hip_atomic_load(xp + (long long)cc * xp_stride + off, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT);
-          sum = (cc == 0) ? pv : sum + pv;
-        }
-        xout[off] = sum;
-      }
+      for (int i = 0; i < 4; ++i)
+        oth[cc][i] = (cc == c) ? mine[i]
+                               : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xpr, off[i] + cc * cstride, 0, 16));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 sum = ((oth[0][i] + oth[1][i]) + oth[2][i]) + oth[3][i];
+      if (row0 + wave + 8 * i < M) *(f32x4*)(xout + (long long)(row0 + wave + 8 * i) * LF_D + 4 * lane) = sum;
     }
     if (t == 0) __hip_atomic_store(counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
   }
+  LF_TS(8);
 }
 
 // y[i] = sum_c xp[c][i]  (float4 granules)
@@ -613,6 +655,11 @@ int sf_ffn_partial_ex(const float* ap, long long ap_stride, const sf_tfm_layer& 
   sf_prof_end(SF_K_LINEAR, st);
   SF_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int sf_debug_read_ts(long long* out32) {
+  hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(lf_ts), sizeof(long long) * 32);
+  return e == hipSuccess ? 0 : (int)e;
 }
 
 extern "C" size_t sf_ffn_packed_bytes(int d_model, int ffn) { return (size_t)d_model * ffn * 4; }

@@ -64,4 +64,36 @@ __device__ __forceinline__ float sf_wave_max(float v) {
   return v;
 }
 
+// ---- DPP reductions (one v_add_f32_dpp per step instead of a ds_bpermute round trip through LDS) ----
+// quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
+template <int CTRL>
+__device__ __forceinline__ float sf_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// all-reduce over aligned groups of 8 / 16 lanes (every lane gets the group's result)
+__device__ __forceinline__ float sf_sum8(float v) {
+  v += sf_dpp<0xB1>(v);
+  v += sf_dpp<0x4E>(v);
+  v += sf_dpp<0x141>(v);
+  return v;
+}
+__device__ __forceinline__ float sf_max8(float v) {
+  v = fmaxf(v, sf_dpp<0xB1>(v));
+  v = fmaxf(v, sf_dpp<0x4E>(v));
+  v = fmaxf(v, sf_dpp<0x141>(v));
+  return v;
+}
+__device__ __forceinline__ float sf_sum16(float v) {
+  v = sf_sum8(v);
+  v += sf_dpp<0x140>(v);
+  return v;
+}
+// all-reduce over the 64 lanes: 16-lane rows by DPP, then the four row sums through scalar registers
+__device__ __forceinline__ float sf_sum64(float v) {
+  v = sf_sum16(v);
+  const int b = __builtin_bit_cast(int, v);
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
+
 __device__ __forceinline__ float sf_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
