@@ -31,7 +31,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dens
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak; bf16x3 issues 3 bf16 MFMA flops per algorithmic flop
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec peak (6.3 TB/s achievable)
 T_BURN, T_ROLL, RES = 6, 50, 128
-CLS_NAMES = ['conv_nhwc_implicit_gemm', 'conv_first', 'linear_gemm', 'slot_attn_iter', 'slot_update', 'mha_small']
+CLS_NAMES = ['conv_nhwc_implicit_gemm', 'conv_first', 'linear_gemm', 'slot_attn_iter', 'slot_update', 'attention', 'ffn_fused']
 
 
 def c2_configs():
@@ -385,9 +385,17 @@ def main():
                     'frames_per_s_device_resident_serial': B * (T_BURN + T_ROLL) / t_s,
                     'h2d_bytes_per_batch': img.numel() * 4, 'd2h_bytes_per_batch': buf.numel() * 4,
                     'note': 'serial (no batch pipelining, copies on the compute stream): upper bound on the PCIe cost'}
+        # the two kernels that make up a rollout layer, event-timed in one eager (un-graphed) rollout with nothing else
+        # running -- inside the timed region they replay from a hipGraph, where HIP events cannot be inserted
+        lib.sf_profile_enable((1 << 5) | (1 << 6))
+        read_profile(lib)
+        rollout_eager()
+        torch.cuda.synchronize()
+        lib.sf_profile_enable(0)
+        prof_roll = read_profile(lib)
         breakdown = None
         if args.breakdown:
-            lib.sf_profile_enable(0x3f)
+            lib.sf_profile_enable(0x7f)
             encode()
             rollout_eager()
             torch.cuda.synchronize()
@@ -463,12 +471,25 @@ def main():
         # row pruning is an exact saving we do not credit) over the graph's wall time
         roll_flops = 274.7e6 * B * T_ROLL
         res['roofline_rollout_graph'] = {
-            'kernel': 'hipGraph of the 50-step rollout (fused LN+QKV+attention, out-proj, FFN1, FFN2 per layer)',
-            'bound': 'latency (1000 dependent stages, M = B*L = 1344 rows); MFMA roof shown for scale',
+            'kernel': 'hipGraph of the 50-step rollout: per step in-proj, 4 x (attention + out-proj partials, fused FFN), out-proj = 550 launches',
+            'bound': 'latency (550 dependent launches, M = B*L = 1344 rows); MFMA roof shown for scale',
             'achieved': roll_flops / t_roll / 1e12, 'peak': (PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS),
             'unit': 'TFLOP/s', 'frac': roll_flops / t_roll / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS),
             'ms': 1e3 * t_roll, 'us_per_step': 1e6 * t_roll / T_ROLL,
         }
+        rk = {}
+        peak_bf3 = PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS
+        for key, name in (('attention', 'attn_oproj_kernel (LN1 + q|k|v of one head + softmax(qk^T)v + out-proj partial; one WG per head x video)'),
+                          ('ffn_fused', 'ffn_partial_kernel (sum of head partials + LN2 + FFN1 + ReLU + FFN2 chunk + last-arriver reduction)')):
+            pk = prof_roll.get(key)
+            if pk:
+                fl = pk['work'] / pk['launches']
+                tf = fl / (pk['avg_us'] * 1e-6) / 1e12
+                rk[key] = {'kernel': name, 'bound': 'latency (M = 1344 rows; see DESIGN.md phase timings); MFMA roof for scale',
+                           'achieved': tf, 'peak': peak_bf3, 'unit': 'TFLOP/s', 'frac': tf / peak_bf3, 'flops_per_launch': fl,
+                           'avg_launch_us_isolated': pk['avg_us'], 'launches': pk['launches']}
+        if rk:
+            res['roofline_rollout_kernels'] = rk
         sa = prof.get('slot_attn_iter')
         if sa:
             bytes_per_launch = sa['work'] / sa['launches']
@@ -478,6 +499,10 @@ def main():
                 'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': gbps / PEAK_HBM_GBPS,
                 'traffic': pmc_traffic('slot_attn_iter'), 'bytes_per_launch': bytes_per_launch,
                 'avg_launch_us_isolated': prof_iso.get('slot_attn_iter', {}).get('avg_us'), 'avg_launch_us': sa['avg_us'],
+                'frac_isolated': (bytes_per_launch / (prof_iso['slot_attn_iter']['avg_us'] * 1e-6) / 1e9 / PEAK_HBM_GBPS
+                                  if 'slot_attn_iter' in prof_iso else None),
+                'cus': enc_cus if conv else 256,
+                'note': 'live figure: the encode stream owns `cus` of the 256 CUs in the timed region; *_isolated: alone on the whole chip',
                 'launches': sa['launches'],
             }
         if breakdown:

@@ -31,7 +31,8 @@ int sf_set_precision(int mode);
 
 /* Optional per-kernel-class HIP-event timer (bench.py roofline): events bracket every launch of a
  * class on the launch stream while enabled (never during hipGraph capture).  Classes: 0 conv
- * NHWC implicit GEMM, 1 first conv, 2 linear, 3 slot-attention iteration, 4 slot update, 5 MHA.
+ * NHWC implicit GEMM, 1 first conv, 2 linear, 3 slot-attention iteration, 4 slot update, 5 attention (incl. the fused
+ * attention + out-proj kernel), 6 fused FFN.
  * sf_profile_read sums elapsed ms, launches and algorithmic work (FLOP, or bytes for class 3)
  * since the last read. */
 int sf_profile_enable(int class_mask); /* bit c enables class c; 0 disables */

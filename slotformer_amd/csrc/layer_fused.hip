@@ -648,11 +648,11 @@ int sf_ffn_partial_ex(const float* ap, long long ap_stride, const sf_tfm_layer& 
   }
   const int tiles = (M + FB_ROWS - 1) / FB_ROWS;
   const int groups = (tiles + 7) / 8;   // 8 tiles x 4 chunks per group of 32 consecutive blocks
-  sf_prof_begin(SF_K_LINEAR, st, 4.0 * M * (double)LF_D * ffn);
+  sf_prof_begin(SF_K_FFN, st, 4.0 * M * (double)LF_D * ffn);
   hipLaunchKernelGGL(ffn_partial_kernel, dim3(groups * 32), dim3(LF_NT), FB_LDS, st, ap, ap_stride, w.norm2_g,
                      w.norm2_b, eps, (const uint4*)w.lin1_packed, w.lin1_b, (const uint4*)w.lin2_packed, w.lin2_b, xp,
                      xp_stride, xout, counters, tiles, M, lf_dbg());
-  sf_prof_end(SF_K_LINEAR, st);
+  sf_prof_end(SF_K_FFN, st);
   SF_CHECK_LAUNCH();
   return 0;
 }

@@ -22,11 +22,26 @@ def find(d, pat):
 lines = []
 f = find(f'{tag}_trace', '*kernel_stats.csv')
 if f:
-    lines.append(f'# rocprofv3 --kernel-trace --stats  (bench.py --steps 3 --warmup 1 --no-graph)  [{os.path.basename(f)}]')
+    lines.append(f'# rocprofv3 --kernel-trace --stats  (bench.py --steps 5 --warmup 2 --no-cpu-baseline: the default hipGraph + CU-partitioned pipeline)  [{os.path.basename(f)}]')
     lines.append(f'{"kernel":72s} {"calls":>7s} {"total_us":>12s} {"avg_us":>10s} {"pct":>6s}')
     for r in csv.DictReader(open(f)):
         lines.append(f'{short(r["Name"]):72s} {r["Calls"]:>7s} {float(r["TotalDurationNs"]) / 1e3:12.1f} '
                      f'{float(r["AverageNs"]) / 1e3:10.2f} {float(r["Percentage"]):6.2f}')
+# the roofline kernels per HIP queue: the encode stream of the pipelined (timed) region is its own CU-masked queue, the
+# untimed split / isolated passes of bench.py run on the default stream with all 256 CUs
+f = find(f'{tag}_trace', '*kernel_trace.csv')
+if f:
+    per = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        n = short(r['Kernel_Name'])
+        if n.startswith(('conv5x5_halo_kernel', 'sa_attn_mfma_kernel', 'pixel_mlp_kv_kernel')):
+            per[(n, r['Queue_Id'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    lines.append('# per-queue durations of the encode kernels  [trace_kernel_trace.csv]  (queue with the most launches of a '
+                 'kernel = the CU-masked encode stream of the timed region = bench.py roofline.avg_launch_us; the others = '
+                 'full-chip passes = *_isolated)')
+    for (n, q), v in sorted(per.items()):
+        v.sort()
+        lines.append(f'{n:40s} queue {q:>3s}  calls {len(v):5d}  avg_us {sum(v) / len(v) / 1e3:9.2f}  median_us {v[len(v) // 2] / 1e3:9.2f}')
 for cname, d in (('FETCH_SIZE', f'{tag}_pmc_fetch'), ('WRITE_SIZE', f'{tag}_pmc_write'), ('MFMA', f'{tag}_pmc_mfma')):
     f = find(d, '*counter_collection.csv')
     if not f:
