@@ -7,8 +7,8 @@
 // per-tap staging of activations at all.  Only the weights (16 KB per tap) stream through a double
 // buffer.  Fill bytes per tile: 104 KB halo + 400 KB weights instead of 1.2 MB.
 //
-//   8 waves: (row 0/1) x (pixel block 0/1) x (cout block 0/1), one 32x32 accumulator each;
-//   per tap and wave: 4 k16-steps x (hi*hi + hi*lo + lo*hi) v_mfma_f32_32x32x16_bf16.
+//   8 waves: (row 0/1) x (pixel block 0/1) x (cin half 0/1), two 32x32 accumulators (both cout blocks) each;
+//   per tap and wave: 2 k16-steps x 2 cout blocks x (hi*hi + hi*lo + lo*hi) v_mfma_f32_32x32x16_bf16.
 //   LDS: halo planes 2 x 6*68*72 bf16 (pixel stride 144 B = 9 16-B slots: conflict-free b128)
 //        + weight planes 2 buffers x 2 x 64*72 bf16  = 154 KB.
 // Reference call site: the encoder convs i > 0, savi.py:231-239 (+ SoftPositionEmbed add, utils.py:60-63).
@@ -98,12 +98,18 @@ __global__ __launch_bounds__(NT) void conv5x5_halo_kernel(const float* __restric
   __syncthreads();
 
   // ---- 25 taps ---------------------------------------------------------------------------------------
-  const int row = wave >> 2, pxb = ((wave >> 1) & 1) * 32, cb = (wave & 1) * 32;
-  f32x16 acc;
+  // wave = (output row, 32-pixel block, half of the input channels): it accumulates BOTH 32-cout blocks over
+  // its 32 input channels, so one A fragment feeds two MFMA groups -- 12 ds_read_b128 per 12 MFMAs per tap
+  // instead of 16 (the loop is LDS-read-bound).  The two k-halves are added through LDS after the last tap.
+  // acc[0] = the cout block this wave finishes (block kh), acc[1] = the one it hands to its partner: the runtime
+  // choice sits in the weight ADDRESS, never in a register index (that turns every MFMA into select + hazard nops).
+  const int row = wave >> 2, pxb = ((wave >> 1) & 1) * 32, kh = wave & 1;
+  f32x16 acc[2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int a_lane = (lane & 31) * PS + 8 * (lane >> 5);             // pixel (or cout) row + k half
-  const int b_base = (cb + (lane & 31)) * PS + 8 * (lane >> 5);
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  const int a_lane = (lane & 31) * PS + 8 * (lane >> 5) + 32 * kh;   // pixel (or cout) row + k half, + this wave's cin half
   for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) {
@@ -113,15 +119,19 @@ __global__ __launch_bounds__(NT) void conv5x5_halo_kernel(const float* __restric
       if (tap + KS < KS * KS) load_w(tap + KS, wreg[kx]);
       const __bf16* ah = Hh + ((row + ky) * HWD + pxb + kx) * PS + a_lane;
       const __bf16* al = Hl + ((row + ky) * HWD + pxb + kx) * PS + a_lane;
-      const __bf16* bh = Wh + buf * WBUF + b_base;
-      const __bf16* bl = Wl + buf * WBUF + b_base;
+      const __bf16* bh = Wh + buf * WBUF + a_lane;
+      const __bf16* bl = Wl + buf * WBUF + a_lane;
+      const int cq[2] = {kh * 32 * PS, (1 - kh) * 32 * PS};
 #pragma unroll
-      for (int ks = 0; ks < CH / 16; ++ks) {
+      for (int ks = 0; ks < 2; ++ks) {
         const bf16x8 xh = *(const bf16x8*)(ah + ks * 16), xl = *(const bf16x8*)(al + ks * 16);
-        const bf16x8 yh = *(const bf16x8*)(bh + ks * 16), yl = *(const bf16x8*)(bl + ks * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const bf16x8 yh = *(const bf16x8*)(bh + cq[q] + ks * 16), yl = *(const bf16x8*)(bl + cq[q] + ks * 16);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[q], 0, 0, 0);
+        }
       }
       // weights of tap+1 (slot (kx+1)%5, requested four taps ago) -> the buffer last read one barrier ago
       if (tap + 1 < KS * KS) store_w(buf ^ 1, wreg[(kx + 1) % KS]);
@@ -129,8 +139,17 @@ __global__ __launch_bounds__(NT) void conv5x5_halo_kernel(const float* __restric
     }
   }
 
+  // ---- combine the two k-halves: wave kh keeps cout block kh and receives that block from its partner ----------
+  float* X = (float*)lds;   // [8 waves][16][64] f32 = 32 KB over the (now dead) halo
+#pragma unroll
+  for (int r = 0; r < 16; ++r) X[(wave * 16 + r) * 64 + lane] = acc[1][r];
+  __syncthreads();
+  f32x16 fin = acc[0];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) fin[r] += X[((wave ^ 1) * 16 + r) * 64 + lane];
+
   // ---- epilogue: bias, ReLU, optional per-position table, NHWC store ------------------------------------
-  const int co = cb + (lane & 31);
+  const int co = kh * 32 + (lane & 31);
   const float bv = bias ? bias[co] : 0.f;
   const float lo = relu ? 0.f : -INFINITY;
   const int y = y0 + row;
@@ -143,7 +162,7 @@ __global__ __launch_bounds__(NT) void conv5x5_halo_kernel(const float* __restric
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int px = pxb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    out[(((long long)f * H + y) * TW + px) * CH + co] = fmaxf(acc[r] + bv, lo) + av[r];
+    out[(((long long)f * H + y) * TW + px) * CH + co] = fmaxf(fin[r] + bv, lo) + av[r];
   }
 }
 
