@@ -147,7 +147,17 @@ typedef struct {
   const float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;
   const float* pe_tok;          /* [window_len*num_slots, d_model]: enc_t_pe per slot (+ enc_slots_pe) */
   const sf_tfm_layer* layers;   /* HOST array [num_layers] */
+  /* optional (NULL = absent): sf_pack_linear_weights() copies of in_proj_w [d_model, slot_size] and out_proj_w
+   * [slot_size, d_model].  With them (slot_size 128, d_model 256, packed FFN weights in every layer) a rollout step
+   * projects only the newly predicted frame (the in-projections of older frames are cached in the workspace) and
+   * out-proj + in-proj run as one launch. */
+  const void *in_proj_packed, *out_proj_packed;
 } sf_rollouter;
+
+/* nn.Linear weight W [N, K] -> split-bf16 copy in MFMA-fragment order (N % 32 == 0, K % 16 == 0);
+ * sf_packed_linear_bytes(N, K) bytes. */
+size_t sf_packed_linear_bytes(int N, int K);
+int sf_pack_linear_weights(const float* w, void* packed, int N, int K, void* stream);
 
 size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B);
 /* slots: [B, T_total, N, C]; the first n_in frames hold the burn-in slots (n_in = window_len, or 1

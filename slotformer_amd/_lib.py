@@ -23,7 +23,7 @@ class sf_rollouter(C.Structure):
         'num_slots', 'slot_size', 'd_model', 'num_layers', 'num_heads', 'ffn_dim', 'norm_first',
         'window_len', 'single_step')] + [(n, FP) for n in (
             'in_proj_w', 'in_proj_b', 'out_proj_w', 'out_proj_b', 'pe_tok')] + [
-                ('layers', C.POINTER(sf_tfm_layer))]
+                ('layers', C.POINTER(sf_tfm_layer)), ('in_proj_packed', C.c_void_p), ('out_proj_packed', C.c_void_p)]
 
 
 class sf_savi_encoder(C.Structure):
@@ -90,6 +90,8 @@ SIGNATURES = {
     'sf_savi_encode_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I]),
     'sf_savi_encode_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
                                VP]),
+    'sf_packed_linear_bytes': (SZ, [I, I]),
+    'sf_pack_linear_weights': (I, [FP, VP, I, I, VP]),
     'sf_ffn_packed_bytes': (SZ, [I, I]),
     'sf_pack_ffn_weights': (I, [FP, FP, VP, VP, I, I, VP]),
     'sf_kv_producer_workspace_bytes': (SZ, [I, I]),

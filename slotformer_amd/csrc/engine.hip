@@ -130,10 +130,11 @@ size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B) {
   if (!m || B <= 0) return 0;
   const int Lmax = m->window_len * m->num_slots;
   const size_t M = (size_t)B * Lmax;
-  // + head partials [8][M][d], hidden-chunk partials [4][M][d], two layer-output buffers and the tile counters of the
-  // two-launch layer
+  // + head partials [8][M][d], hidden-chunk partials [4][M][d], two layer-output buffers, the tile counters of the
+  // two-launch layer and the ring of cached in-projections [B][window_len + 1][N][d]
   return pad256(M * m->d_model) + tfm_ws_bytes((int)M, m->d_model, m->ffn_dim) + pad256(8 * M * m->d_model) +
-         pad256(4 * M * m->d_model) + 2 * pad256(M * m->d_model) + 4096 + 4096;
+         pad256(4 * M * m->d_model) + 2 * pad256(M * m->d_model) +
+         pad256((size_t)B * (m->window_len + 1) * m->num_slots * m->d_model) + 4096 + 4096;
 }
 
 int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws,
@@ -161,7 +162,9 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   float* xa = bp.take((size_t)B * Lmax * d);
   float* xb2 = bp.take((size_t)B * Lmax * d);
   int* counters = (int*)bp.take(1024);
-  if (!apb || !xpb || !xa || !xb2 || !counters) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
+  const int RF = W + 1;   // frames in the projection ring: the window being read + the frame being written
+  float* ring = bp.take((size_t)B * RF * N * d);
+  if (!apb || !xpb || !xa || !xb2 || !counters || !ring) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
   // two-launch layers (layer_fused.hip): split-bf16 mode, pre-LN, d=256 / 8 heads / ffn 1024, window <= 64 tokens
   static const bool fused_env = [] {
     const char* e = getenv("SF_LAYER_FUSED");
@@ -171,6 +174,13 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   for (int l = 0; l < m->num_layers; ++l) packed = packed && m->layers[l].lin1_packed && m->layers[l].lin2_packed;
   const bool fused_layers = packed && fused_env && sf_get_precision() == 1 && m->norm_first &&
                             sf_layer_fused_ok(d, m->num_heads, m->ffn_dim, Lmax);
+  // step boundary in one launch (out-proj of step s + in-proj of the new frame for step s+1) with cached in-projections
+  const bool ring_mode = fused_layers && m->in_proj_packed && m->out_proj_packed && sf_step_boundary_ok(d, C);
+  if (ring_mode) {
+    // in-projection (without PE) of the burn-in frames -> ring slots 0 .. n_in-1
+    SF_TRY(sf_ring_init_ex(m->out_proj_packed, m->out_proj_b, m->in_proj_packed, m->in_proj_b, slots,
+                           (long long)T_total * N * C, n_in, ring, RF, N, B, st));
+  }
   if (fused_layers) {
     SF_REQUIRE(sf_ffn_tiles(B * Lmax) <= 1024, "batch too large for the fused-layer tile counters");
     hipError_t e = hipMemsetAsync(counters, 0, 1024 * sizeof(int), st);
@@ -188,6 +198,25 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
       f0 = have - nf;
     }
     const int L = nf * N, M = B * L, pe_off = (W - nf) * N;
+    if (ring_mode) {
+      const float* cin = nullptr;
+      for (int l = 0; l < m->num_layers; ++l) {
+        const int Lq = (l == m->num_layers - 1) ? N : L;   // last layer: only the newest frame's rows are read (slotformer.py:121)
+        const long long pst = (long long)B * Lq * d;
+        float* xo = (cin == xa) ? xb2 : xa;
+        if (l == 0)
+          SF_TRY(sf_attn_oproj_ring_ex(ring, RF, N, f0, m->pe_tok + (long long)pe_off * d, m->layers[l], 1e-5f, apb, pst, B, L,
+                                       Lq, st));
+        else
+          SF_TRY(sf_attn_oproj_ex(cin, m->layers[l], 1e-5f, apb, pst, B, L, Lq, st));
+        SF_TRY(sf_ffn_partial_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st));
+        cin = xo;
+      }
+      // pred = out_proj(last rows) -> frame n_in + s; its in-projection -> the ring   (slotformer.py:121-124, :115)
+      SF_TRY(sf_step_boundary_ex(cin, m->out_proj_packed, m->out_proj_b, m->in_proj_packed, m->in_proj_b, slots, bs, n_in + s,
+                                 ring, RF, N, B, st));
+      continue;
+    }
     // x = in_proj(window) + pe   (slotformer.py:115-117; single_step_slotformer.py:79-81)
     SfRowMap pmap = sf_rows(d);
     pmap.base = (long long)pe_off * d;
@@ -197,10 +226,10 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
       // every layer is two launches: attention + out-proj head partials, then the FFN (which also finishes the sums)
       const float* cin = x;
       for (int l = 0; l < m->num_layers; ++l) {
-        const int Lq = (l == m->num_layers - 1) ? N : L;   // last layer: only the newest frame's rows are read (slotformer.py:121)
+        const int Lq = (l == m->num_layers - 1) ? N : L;
         const long long pst = (long long)B * Lq * d;
         float* xo = (cin == xa) ? xb2 : xa;
-        SF_TRY(sf_attn_oproj_ex(cin, 0, 1, m->layers[l], 1e-5f, apb, pst, B, L, Lq, st));
+        SF_TRY(sf_attn_oproj_ex(cin, m->layers[l], 1e-5f, apb, pst, B, L, Lq, st));
         SF_TRY(sf_ffn_partial_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st));
         cin = xo;
       }

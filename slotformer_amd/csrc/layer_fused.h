@@ -3,11 +3,22 @@
 #include "../../include/slotformer_hip.h"
 #include "sf_internal.h"
 
-// xin: np_in (1 or 4) partial buffers [B*L, 256] xin_stride floats apart; ap: 8 head-partial buffers [B*Lq, 256]
-int sf_attn_oproj_ex(const float* xin, long long xin_stride, int np_in, const sf_tfm_layer& w, float eps, float* ap,
-                     long long ap_stride, int B, int L, int Lq, hipStream_t st);
+// x [B][L][256] -> ap: 8 head-partial buffers [B*Lq, 256]
+int sf_attn_oproj_ex(const float* xin, const sf_tfm_layer& w, float eps, float* ap, long long ap_stride, int B, int L,
+                     int Lq, hipStream_t st);
+// layer 0 of a rollout step: x = ring[b][(f0 + r / nslots) % ring_frames][r % nslots] + pe[r]
+int sf_attn_oproj_ring_ex(const float* ring, int ring_frames, int nslots, int f0, const float* pe, const sf_tfm_layer& w,
+                          float eps, float* ap, long long ap_stride, int B, int L, int Lq, hipStream_t st);
+// out-proj of the finished rows y [B*nslots, 256] -> slots frame `frame`; in-proj of those rows -> projection ring
+bool sf_step_boundary_ok(int d, int slot_size);
+int sf_step_boundary_ex(const float* y, const void* wout_packed, const float* b_out, const void* win_packed,
+                        const float* b_in, float* slots, long long slots_bs, int frame, float* ring, int ring_frames,
+                        int nslots, int B, hipStream_t st);
 // ap: 8 head partials [M, 256] -> xout [M, 256] (finished layer output); xp: scratch for the 4 hidden-chunk partials
 // [4][M, 256]; counters: sf_ffn_tiles(M) ints, zero before the first launch (the kernel leaves them zero)
 int sf_ffn_partial_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp,
                       long long xp_stride, float* xout, int* counters, int M, int ffn, hipStream_t st);
 int sf_ffn_tiles(int M);
+// in-projection of the first n_frames frames of every video -> ring slots 0 .. n_frames-1 (same arithmetic as the step kernel)
+int sf_ring_init_ex(const void* wout_packed, const float* b_out, const void* win_packed, const float* b_in, float* slots,
+                    long long slots_bs, int n_frames, float* ring, int ring_frames, int nslots, int B, hipStream_t st);

@@ -68,9 +68,13 @@ __device__ long long lf_ts[32];   // phase timestamps of one workgroup (SF_LF_DB
 #define LF_TA(i) do { if ((dbg & 16) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) lf_ts[i] = wall_clock64(); } while (0)
 
 // ================================================================================================
-// x [NPIN][B*L][256] partial buffers (xin_stride floats apart);  ap [8][B*Lq][256] head partials.
-template <int NPIN>
-__global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_oproj_kernel(const float* __restrict__ xin, long long xin_stride,
+// x: layer input rows.  RING = false: xin [B][L][256] contiguous.  RING = true (layer 0 of a rollout step): the rows are
+// the cached in-projections of the window's frames, held in a ring of `ring_frames` frames per video
+// (xin [B][ring_frames][nslots][256], window starts at frame f0), plus the per-token position table pe [L][256]
+// (slotformer.py:115-117: x = in_proj(window) + pe).  ap [8][B*Lq][256] head partials.
+template <bool RING>
+__global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_oproj_kernel(const float* __restrict__ xin, long long x_batch_stride,
+                                                           const float* __restrict__ pe, int f0, int ring_frames, int nslots,
                                                            const float* __restrict__ ln_g,
                                                            const float* __restrict__ ln_b, float ln_eps,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   float* stats = (float*)(Bl + NCP * FA_LB);  // [2][64]
   float* Xs = (float*)((char*)smem + A_STASH_OFF);  // [64][XS]: x[:, 32h:32h+32] for the residual
   const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const float* xb = xin + (long long)b * L * d;
+  const float* xb = xin + (long long)b * x_batch_stride;
   const int c4 = t & 15, r0 = t >> 4;
   LF_TA(16);
   // small parameter vectors first (vmcnt retires in order: a late request would queue behind the weight tiles):
@@ -111,35 +115,39 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   for (int kc = 0; kc < NK; ++kc)
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) rb[kc][i] = *(const f32x4*)(wrow[i] + kc * FA_KC + 4 * c4);
-  // activations: NPIN partial buffers summed in registers, two buffers in flight at a time (VGPR budget: the kernel
-  // must stay at <= 128 VGPRs so that two workgroups share a CU)
+  // activations (+ position table in ring mode)
   bool aok[A_IT];
   const float* arow[A_IT];
+  const float* prow[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int r = r0 + 32 * i;
     aok[i] = r < L;
-    arow[i] = xb + (long long)min(r, L - 1) * d + 4 * c4;
+    const int rc = min(r, L - 1);
+    if constexpr (RING) {
+      const int fr = rc / nslots, sl = rc - fr * nslots;
+      arow[i] = xb + ((long long)((f0 + fr) % ring_frames) * nslots + sl) * d + 4 * c4;
+      prow[i] = pe + (long long)rc * d + 4 * c4;
+    } else {
+      arow[i] = xb + (long long)rc * d + 4 * c4;
+      prow[i] = nullptr;
+    }
   }
   f32x4 ra[NK][A_IT];
 #pragma unroll
   for (int kc = 0; kc < NK; ++kc)
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) ra[kc][i] = *(const f32x4*)(arow[i] + kc * FA_KC);
-  if constexpr (NPIN > 1) {
+  if constexpr (RING) {
+    f32x4 tp[NK][A_IT];
 #pragma unroll
-    for (int p = 1; p < NPIN; ++p) {
-      const long long po = ((dbg & 4) ? 0 : p) * xin_stride;
-      f32x4 tp[NK][A_IT];
+    for (int kc = 0; kc < NK; ++kc)
 #pragma unroll
-      for (int kc = 0; kc < NK; ++kc)
+      for (int i = 0; i < A_IT; ++i) tp[kc][i] = *(const f32x4*)(prow[i] + kc * FA_KC);
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) tp[kc][i] = *(const f32x4*)(arow[i] + po + kc * FA_KC);
+    for (int kc = 0; kc < NK; ++kc)
 #pragma unroll
-      for (int kc = 0; kc < NK; ++kc)
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) ra[kc][i] += tp[kc][i];
-    }
+      for (int i = 0; i < A_IT; ++i) ra[kc][i] += tp[kc][i];
   }
   // residual stash: the 32 columns of block h live in chunk h/2, float4 columns 8*(h&1) .. +7
 #pragma unroll
@@ -581,6 +589,142 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
   LF_TS(8);
 }
 
+// ================================================================================================
+// Generic fragment-order packing of an nn.Linear weight W [N][K] (N % 32 == 0, K % 16 == 0):
+//     uint4 index = (((ks * (N/32) + nb) * 2 + plane) * 64 + lane),  element j = W[nb*32 + (lane & 31)][ks*16 + 8*(lane >> 5) + j]
+__global__ void pack_linear_kernel(const float* __restrict__ w, uint4* __restrict__ out, int N, int K) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int NB = N / 32, total = (K / 16) * NB * 2 * 64;
+  if (idx >= total) return;
+  const int lane = idx & 63, plane = (idx >> 6) & 1, nb = (idx >> 7) % NB, ks = (idx >> 7) / NB;
+  const float* src = w + (long long)(nb * 32 + (lane & 31)) * K + ks * 16 + 8 * (lane >> 5);
+  union {
+    __bf16 h[8];
+    uint4 u;
+  } o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float a = src[j];
+    const __bf16 ah = (__bf16)a;
+    o.h[j] = plane ? (__bf16)(a - (float)ah) : ah;
+  }
+  out[idx] = o.u;
+}
+
+// Step boundary of the rollout (slotformer.py:121-124 then :115 of the next step), slot_size 128, d_model 256:
+//   pred = y . Wout^T + b_out            -> slots[b][frame][n][0:128]
+//   proj = pred . Win^T + b_in           -> ring[b][frame % ring_frames][n][0:256]   (cached in-projection, no PE)
+// y [M = B*nslots][256] are the finished rows of the last layer; one workgroup per 32 rows.  `nslots` is really "rows per
+// video": with proj_only != 0 the kernel skips the out-projection and in-projects rows that are already in `slots`
+// (the burn-in frames, rows per video = n_in * N) -- the same arithmetic as inside the rollout, so a rollout restarted
+// from its own output reproduces the original bit for bit.
+constexpr int SB_C = 128;                    // slot size
+constexpr int SB_YP = LF_D + 8, SB_PP = SB_C + 8;
+constexpr size_t SB_LDS = (size_t)2 * 32 * SB_YP * 2 + (size_t)4 * 16 * 64 * 4 + (size_t)2 * 32 * SB_PP * 2;
+__global__ __launch_bounds__(LF_NT) void step_boundary_kernel(const float* __restrict__ y, const uint4* __restrict__ wout_p,
+                                                              const float* __restrict__ b_out,
+                                                              const uint4* __restrict__ win_p,
+                                                              const float* __restrict__ b_in, float* __restrict__ slots,
+                                                              long long slots_bs, long long slots_off,
+                                                              float* __restrict__ ring, long long ring_bs, long long ring_off,
+                                                              int nslots, int M, int proj_only) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* Yh = (__bf16*)smem;                 // [32][SB_YP]
+  __bf16* Yl = Yh + 32 * SB_YP;
+  float* R = (float*)(Yl + 32 * SB_YP);       // [4][16][64] k-half exchange
+  __bf16* Ph = (__bf16*)(R + 4 * 16 * 64);    // [32][SB_PP]
+  __bf16* Pl = Ph + 32 * SB_PP;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int row0 = blockIdx.x * 32;
+  const int tok = lane & 31;
+  // GEMM1 (K = 256, N = 128): wave = (column block nb1 = wave & 3, k half = wave >> 2); GEMM2 (K = 128, N = 256): nb2 = wave
+  const int nb1 = wave & 3, kh = wave >> 2;
+  const int c1 = nb1 * 32 + 4 * (lane >> 5), c2 = wave * 32 + 4 * (lane >> 5);   // first output column (+ 8 g)
+  f32x4 bo4[4], bi4[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bo4[g] = *(const f32x4*)(b_out + c1 + 8 * g);
+    bi4[g] = *(const f32x4*)(b_in + c2 + 8 * g);
+  }
+  bf16x8 w1[8][2], w2[8][2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      w1[k][pl] = __builtin_bit_cast(bf16x8, wout_p[((((long long)(kh * 8 + k) * 4 + nb1) * 2 + pl) * 64) + lane]);
+      w2[k][pl] = __builtin_bit_cast(bf16x8, win_p[((((long long)k * 8 + wave) * 2 + pl) * 64) + lane]);
+    }
+  const int m = row0 + tok;                       // global row of this lane's token
+  const int mb = min(m, M - 1) / nslots, mn = min(m, M - 1) - mb * nslots;
+  f32x16 acc;
+  if (proj_only) {
+    // slot rows -> split-bf16 planes directly (2 float4 per thread: 32 rows x 32 float4)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = t + LF_NT * i, r = idx >> 5, q4 = idx & 31;
+      const int gm = min(row0 + r, M - 1), gb = gm / nslots, gn = gm - gb * nslots;
+      const f32x4 v = *(const f32x4*)(slots + gb * slots_bs + slots_off + (long long)gn * SB_C + 4 * q4);
+      split4(Ph, Pl, r * SB_PP + 4 * q4, v);
+    }
+  } else {
+    // y rows -> split-bf16 planes
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = wave + 8 * i;
+      const f32x4 v = *(const f32x4*)(y + (long long)min(row0 + r, M - 1) * LF_D + 4 * lane);
+      split4(Yh, Yl, r * SB_YP + 4 * lane, v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+      const int ao = tok * SB_YP + 8 * (lane >> 5) + kh * 128;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bf16x8 xh = *(const bf16x8*)(Yh + ao + k * 16), xl = *(const bf16x8*)(Yl + ao + k * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[k][0], xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[k][1], xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[k][0], xh, acc, 0, 0, 0);
+      }
+    }
+    if (kh == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) R[(nb1 * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = acc[4 * g + q] + R[(nb1 * 16 + 4 * g + q) * 64 + lane] + bo4[g][q];
+        split4(Ph, Pl, tok * SB_PP + c1 + 8 * g, v);
+        if (m < M) *(f32x4*)(slots + mb * slots_bs + slots_off + (long long)mn * SB_C + c1 + 8 * g) = v;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  {
+    const int ao = tok * SB_PP + 8 * (lane >> 5);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bf16x8 xh = *(const bf16x8*)(Ph + ao + k * 16), xl = *(const bf16x8*)(Pl + ao + k * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[k][0], xl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[k][1], xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[k][0], xh, acc, 0, 0, 0);
+    }
+  }
+  if (m < M) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = {acc[4 * g] + bi4[g][0], acc[4 * g + 1] + bi4[g][1], acc[4 * g + 2] + bi4[g][2], acc[4 * g + 3] + bi4[g][3]};
+      *(f32x4*)(ring + mb * ring_bs + ring_off + (long long)mn * LF_D + c2 + 8 * g) = v;
+    }
+  }
+}
+
 // y[i] = sum_c xp[c][i]  (float4 granules)
 __global__ void sum_partials_kernel(const float* __restrict__ xp, long long stride, int np, float* __restrict__ y,
                                     long long n4) {
@@ -606,10 +750,11 @@ bool sf_layer_fused_ok(int d, int heads, int ffn, int L) {
   return d == LF_D && heads == LF_NH && ffn == LF_NCH * LF_HC && L >= 1 && L <= FA_ROWS;
 }
 
-template <int NPIN>
-static int launch_attn(const float* xin, long long xin_stride, const sf_tfm_layer& w, float eps, float* ap,
-                       long long ap_stride, int B, int L, int Lq, hipStream_t st) {
-  auto kern = attn_oproj_kernel<NPIN>;
+template <bool RING>
+static int launch_attn(const float* xin, long long x_batch_stride, const float* pe, int f0, int ring_frames, int nslots,
+                       const sf_tfm_layer& w, float eps, float* ap, long long ap_stride, int B, int L, int Lq,
+                       hipStream_t st) {
+  auto kern = attn_oproj_kernel<RING>;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A_LDS);
@@ -618,20 +763,26 @@ static int launch_attn(const float* xin, long long xin_stride, const sf_tfm_laye
   }
   sf_prof_begin(SF_K_MHA, st, 6.0 * B * L * (double)LF_D * LF_D + 4.0 * (double)B * LF_NH * Lq * L * LF_HD +
                                   2.0 * B * Lq * (double)LF_D * LF_D);
-  hipLaunchKernelGGL(kern, dim3(LF_NH, B), dim3(LF_NT), A_LDS, st, xin, xin_stride, w.norm1_g, w.norm1_b, eps,
-                     w.in_proj_w, w.in_proj_b, w.out_proj_w, w.out_proj_b, ap, ap_stride, L, Lq, lf_dbg());
+  hipLaunchKernelGGL(kern, dim3(LF_NH, B), dim3(LF_NT), A_LDS, st, xin, x_batch_stride, pe, f0, ring_frames, nslots,
+                     w.norm1_g, w.norm1_b, eps, w.in_proj_w, w.in_proj_b, w.out_proj_w, w.out_proj_b, ap, ap_stride, L, Lq,
+                     lf_dbg());
   sf_prof_end(SF_K_MHA, st);
   SF_CHECK_LAUNCH();
   return 0;
 }
 
-// xin: np_in (1 or 4) partial buffers [B*L, 256]; ap: 8 buffers [B*Lq, 256]
-int sf_attn_oproj_ex(const float* xin, long long xin_stride, int np_in, const sf_tfm_layer& w, float eps, float* ap,
-                     long long ap_stride, int B, int L, int Lq, hipStream_t st) {
+// x [B][L][256] -> ap: 8 head-partial buffers [B*Lq, 256]
+int sf_attn_oproj_ex(const float* xin, const sf_tfm_layer& w, float eps, float* ap, long long ap_stride, int B, int L,
+                     int Lq, hipStream_t st) {
   static_assert(A_LDS <= 80 * 1024, "attention+out-proj kernel: two workgroups per CU");
-  if (np_in == 1) return launch_attn<1>(xin, xin_stride, w, eps, ap, ap_stride, B, L, Lq, st);
-  if (np_in == LF_NCH) return launch_attn<LF_NCH>(xin, xin_stride, w, eps, ap, ap_stride, B, L, Lq, st);
-  return sf_set_err(-1, "invalid argument: sf_attn_oproj_ex partial count", __FILE__, __LINE__);
+  return launch_attn<false>(xin, (long long)L * LF_D, nullptr, 0, 1, 1, w, eps, ap, ap_stride, B, L, Lq, st);
+}
+
+// layer 0 of a rollout step: x = ring[b][(f0 + r / nslots) % ring_frames][r % nslots] + pe[r]
+int sf_attn_oproj_ring_ex(const float* ring, int ring_frames, int nslots, int f0, const float* pe, const sf_tfm_layer& w,
+                          float eps, float* ap, long long ap_stride, int B, int L, int Lq, hipStream_t st) {
+  return launch_attn<true>(ring, (long long)ring_frames * nslots * LF_D, pe, f0, ring_frames, nslots, w, eps, ap, ap_stride,
+                           B, L, Lq, st);
 }
 
 int sf_ffn_partial_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp,
@@ -653,6 +804,55 @@ int sf_ffn_partial_ex(const float* ap, long long ap_stride, const sf_tfm_layer& 
                      w.norm2_b, eps, (const uint4*)w.lin1_packed, w.lin1_b, (const uint4*)w.lin2_packed, w.lin2_b, xp,
                      xp_stride, xout, counters, tiles, M, lf_dbg());
   sf_prof_end(SF_K_FFN, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+bool sf_step_boundary_ok(int d, int slot_size) { return d == LF_D && slot_size == SB_C; }
+
+static int launch_boundary(const float* y, const void* wout_packed, const float* b_out, const void* win_packed,
+                           const float* b_in, float* slots, long long slots_bs, long long slots_off, float* ring,
+                           long long ring_bs, long long ring_off, int rows_per_video, int M, int proj_only, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)step_boundary_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)SB_LDS);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    attr = true;
+  }
+  sf_prof_begin(SF_K_LINEAR, st, (proj_only ? 2.0 : 4.0) * M * (double)LF_D * SB_C);
+  hipLaunchKernelGGL(step_boundary_kernel, dim3((M + 31) / 32), dim3(LF_NT), SB_LDS, st, y, (const uint4*)wout_packed, b_out,
+                     (const uint4*)win_packed, b_in, slots, slots_bs, slots_off, ring, ring_bs, ring_off, rows_per_video, M,
+                     proj_only);
+  sf_prof_end(SF_K_LINEAR, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// frame index `frame` of the [B][T][N][128] slots buffer (slots_bs floats per video) and of the projection ring
+int sf_step_boundary_ex(const float* y, const void* wout_packed, const float* b_out, const void* win_packed,
+                        const float* b_in, float* slots, long long slots_bs, int frame, float* ring, int ring_frames,
+                        int nslots, int B, hipStream_t st) {
+  return launch_boundary(y, wout_packed, b_out, win_packed, b_in, slots, slots_bs, (long long)frame * nslots * SB_C, ring,
+                         (long long)ring_frames * nslots * LF_D, (long long)(frame % ring_frames) * nslots * LF_D, nslots,
+                         B * nslots, 0, st);
+}
+
+// in-projection of the first n_frames (<= ring_frames) frames of every video -> ring slots 0 .. n_frames-1
+int sf_ring_init_ex(const void* wout_packed, const float* b_out, const void* win_packed, const float* b_in, float* slots,
+                    long long slots_bs, int n_frames, float* ring, int ring_frames, int nslots, int B, hipStream_t st) {
+  return launch_boundary(nullptr, wout_packed, b_out, win_packed, b_in, slots, slots_bs, 0, ring,
+                         (long long)ring_frames * nslots * LF_D, 0, n_frames * nslots, B * n_frames * nslots, 1, st);
+}
+
+extern "C" size_t sf_packed_linear_bytes(int N, int K) { return (size_t)N * K * 4; }
+
+// W [N][K] (torch nn.Linear layout) -> fragment-ordered split-bf16 copy (layout above pack_linear_kernel).
+extern "C" int sf_pack_linear_weights(const float* w, void* packed, int N, int K, void* stream) {
+  SF_REQUIRE(w && packed, "sf_pack_linear_weights: null pointer");
+  SF_REQUIRE(N > 0 && K > 0 && (N % 32) == 0 && (K % 16) == 0, "sf_pack_linear_weights: needs N % 32 == 0 and K % 16 == 0");
+  const int total = (K / 16) * (N / 32) * 2 * 64;
+  hipLaunchKernelGGL(pack_linear_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (uint4*)packed, N, K);
   SF_CHECK_LAUNCH();
   return 0;
 }

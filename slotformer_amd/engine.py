@@ -111,6 +111,15 @@ def rollouter_plan(r):
         pe = pe + r.enc_slots_pe.detach()[0].repeat(W, 1)
     s.pe_tok = plan.dp(pe.contiguous())
     s.layers = C.cast(_tfm_layers(plan, enc, pack_ffn=True), C.POINTER(sf_tfm_layer))
+    if s.d_model == 256 and s.slot_size == 128 and r.in_proj.weight.is_cuda:
+        # fragment-ordered copies of in_proj / out_proj for the fused step-boundary kernel (layer_fused.hip)
+        st = torch.cuda.current_stream().cuda_stream
+        for name, lin in (('in_proj_packed', r.in_proj), ('out_proj_packed', r.out_proj)):
+            n, k = lin.weight.shape
+            buf = torch.empty(lib().sf_packed_linear_bytes(n, k), dtype=torch.uint8, device=lin.weight.device)
+            check(lib().sf_pack_linear_weights(plan.dp(lin.weight), buf.data_ptr(), n, k, st))
+            plan.keep.append(buf)
+            setattr(s, name, buf.data_ptr())
     plan.struct, plan.sig = s, sig
     r._sf_plan = plan
     return plan
