@@ -122,6 +122,24 @@ int sf_sample_dist_f32(const float* dist, const float* noise, float* out, int R,
 int sf_bilinear_resize_f32(const float* in, float* out, long long R, int Hi, int Wi, int Ho, int Wo,
                            void* stream);
 
+/* ---- STEVE image side (row N2, second half): dVAE blocks -------------------------------------- */
+/* Conv2dBlock's normalisation (steve_utils.py:124-126): F.group_norm(x, 1, gamma, beta, eps) over (C,H,W) per
+ * sample, then ReLU when `relu`; NHWC x [F,H,W,C].  pixel_shuffle == 2 also applies the nn.PixelShuffle(2) that
+ * follows the block in dVAE.py:44,49 (y [F,2H,2W,C/4]); 1 = none. */
+size_t sf_groupnorm1_workspace_bytes(int F);
+int sf_groupnorm1_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y, int F, int H, int W, int C,
+                           float eps, int relu, int pixel_shuffle, void* ws, size_t ws_bytes, void* stream);
+
+/* STEVE's slot-conditioned Transformer decoder (steve_transformer.py): attention core (bias-free projections are
+ * plain sf_linear_f32 calls), token + position embedding, greedy token pick, token cross-entropy. */
+int sf_slate_attention_f32(const float* q, const float* k, const float* v, float* out, int ldq, int ldk, int ldv, int ldo,
+                           int B, int Lq, int Lk, int num_heads, int head_dim, int causal, void* stream);
+int sf_embed_tokens_f32(const long long* idx, const float* tok_emb, const float* pos, float* out, int B, int L, int d,
+                        void* stream);
+int sf_argmax_rows_f32(const float* x, long long ld, long long* out, long long R, int V, void* stream);
+int sf_cross_entropy_f32(const float* x, const long long* target, float* loss_rows, float* mean_out, long long R, int V,
+                         void* stream);
+
 /* ---- whole-path engines ------------------------------------------------------------------ */
 
 /* One nn.TransformerEncoderLayer (relu, batch_first); all pointers device, torch layouts. */

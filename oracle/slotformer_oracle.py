@@ -19,7 +19,8 @@ __all__ = [
     'sample_dist', 'savi_encode', 'steve_encode', 'savi_forward_chunked',
     'rollouter_forward', 'single_step_rollouter_forward', 'slotformer_forward',
     'savi_decode', 'postproc_mask', 'rollout_video_slots', 'phyre_encode_rollout',
-    'slot_mse_losses',
+    'slot_mse_losses', 'dvae_logits', 'dvae_tokenize', 'dvae_detokenize', 'steve_decoder_forward',
+    'steve_decoder_generate', 'steve_forward_tokens',
 ]
 
 
@@ -441,3 +442,111 @@ def phyre_encode_rollout(img0, savi_sd, savi_cfg, sf_sd, sf_cfg, vid_len, noise=
     slots = torch.zeros(B, vid_len, N, C).type_as(slot0)
     slots[:, :1] = slot0
     return slotformer_forward(slots, sf_sd, sf_cfg, vid_len - 1, single_step=True)
+
+
+# ---------------------------------------------------------------------------
+# STEVE image side (row N2, second half): dVAE and the slot-conditioned Transformer decoder
+# ---------------------------------------------------------------------------
+def _conv_block(x, sd, p, stride=1, padding=0):
+    """Conv2dBlock: bias-free conv -> GroupNorm(1 group, affine) -> ReLU.  steve_utils.py:100-126."""
+    x = F.conv2d(x, sd[p + 'm.weight'], None, stride, padding)
+    return F.relu(F.group_norm(x, 1, sd[p + 'weight'], sd[p + 'bias']))
+
+
+def dvae_logits(img, sd, p=''):
+    """img [F,3,H,W] -> vocabulary logits [F,V,H/4,W/4].  dVAE.py:24-34 (encoder stack)."""
+    x = _conv_block(img, sd, p + 'encoder.0.', stride=4)
+    for i in range(1, 7):
+        x = _conv_block(x, sd, p + f'encoder.{i}.')
+    return F.conv2d(x, sd[p + 'encoder.7.weight'], sd[p + 'encoder.7.bias'])
+
+
+def dvae_tokenize(img, sd, p='', one_hot=True):
+    """dVAE.tokenize (dVAE.py:52-77): argmax ids [F,h,w], or the one-hot map [F,V,h,w] (steve_utils.py:10-13)."""
+    logits = dvae_logits(img, sd, p)
+    idx = logits.argmax(dim=1)
+    if not one_hot:
+        return idx
+    return torch.zeros_like(logits).scatter_(1, idx.unsqueeze(1), 1.)
+
+
+def dvae_detokenize(z, sd, p=''):
+    """z [F,V,h,w] (probabilities / one-hot) -> image [F,3,4h,4w].  dVAE.py:36-50,79-100 (decoder stack)."""
+    x = _conv_block(z, sd, p + 'decoder.0.')
+    x = _conv_block(x, sd, p + 'decoder.1.', padding=1)
+    x = _conv_block(x, sd, p + 'decoder.2.')
+    x = _conv_block(x, sd, p + 'decoder.3.')
+    x = F.pixel_shuffle(_conv_block(x, sd, p + 'decoder.4.'), 2)
+    x = _conv_block(x, sd, p + 'decoder.6.', padding=1)
+    x = _conv_block(x, sd, p + 'decoder.7.')
+    x = _conv_block(x, sd, p + 'decoder.8.')
+    x = F.pixel_shuffle(_conv_block(x, sd, p + 'decoder.9.'), 2)
+    return F.conv2d(x, sd[p + 'decoder.11.weight'], sd[p + 'decoder.11.bias'])
+
+
+def _slate_mha(q, k, v, sd, p, nheads, mask=None):
+    """MultiHeadAttention of steve_transformer.py:12-55: bias-free projections, q scaled by hd^-0.5, optional
+    boolean mask (True = blocked)."""
+    B, T, d = q.shape
+    S = k.shape[1]
+    hd = d // nheads
+    q = (q @ sd[p + 'proj_q.weight'].t()).view(B, T, nheads, hd).transpose(1, 2) * hd**-0.5
+    k = (k @ sd[p + 'proj_k.weight'].t()).view(B, S, nheads, hd).transpose(1, 2)
+    v = (v @ sd[p + 'proj_v.weight'].t()).view(B, S, nheads, hd).transpose(1, 2)
+    att = q @ k.transpose(-1, -2)
+    if mask is not None:
+        att = att.masked_fill(mask, float('-inf'))
+    out = (att.softmax(-1) @ v).transpose(1, 2).reshape(B, T, d)
+    return out @ sd[p + 'proj_o.weight'].t()
+
+
+def steve_decoder_forward(slots, idx, sd, nheads, num_layers, p='trans_decoder.'):
+    """STEVETransformerDecoder.forward (steve_transformer.py:275-303): slots [B,N,d], idx [B,t] int64 (without the last
+    target token) -> logits [B,1+t,V].  Blocks: steve_transformer.py:146-199 (first block normalises its input in
+    place, :186-190)."""
+    B, T = idx.shape
+    V = sd[p + 'head.weight'].shape[0]
+    mem = slots @ sd[p + 'in_proj.weight'].t() + sd[p + 'in_proj.bias']
+    idx = torch.cat([torch.full((B, 1), V, dtype=idx.dtype), idx], 1)
+    x = sd[p + 'tok_emb.weight'][idx] + sd[p + 'pos_emb.pe'][:, :T + 1]
+    L = T + 1
+    causal = torch.triu(torch.ones(L, L, dtype=torch.bool), diagonal=1)
+    for i in range(num_layers):
+        q = p + f'tf_dec.blocks.{i}.'
+        ln = lambda t, name: layer_norm(t, sd[q + name + '.weight'], sd[q + name + '.bias'])  # noqa: E731
+        if i == 0:
+            x = ln(x, 'self_attn_layer_norm')
+            x = x + _slate_mha(x, x, x, sd, q + 'self_attn.', nheads, causal)
+        else:
+            y = ln(x, 'self_attn_layer_norm')
+            x = x + _slate_mha(y, y, y, sd, q + 'self_attn.', nheads, causal)
+        y = ln(x, 'encoder_decoder_attn_layer_norm')
+        x = x + _slate_mha(y, mem, mem, sd, q + 'encoder_decoder_attn.', nheads)
+        y = ln(x, 'ffn_layer_norm')
+        y = F.relu(y @ sd[q + 'ffn.0.weight'].t() + sd[q + 'ffn.0.bias'])
+        x = x + y @ sd[q + 'ffn.2.weight'].t() + sd[q + 'ffn.2.bias']
+    x = layer_norm(x, sd[p + 'tf_dec.layer_norm.weight'], sd[p + 'tf_dec.layer_norm.bias'])
+    return x @ sd[p + 'head.weight'].t()
+
+
+def steve_decoder_generate(slots, steps, sd, nheads, num_layers, p='trans_decoder.'):
+    """STEVETransformerDecoder.generate with sample=False (steve_transformer.py:305-333): greedy tokens [B,steps] and
+    the per-step logits [B,steps,V]."""
+    B = slots.shape[0]
+    idx = torch.zeros(B, 0, dtype=torch.long)
+    logits_all = []
+    for _ in range(steps):
+        lg = steve_decoder_forward(slots, idx, sd, nheads, num_layers, p)[:, -1]
+        logits_all.append(lg)
+        idx = torch.cat([idx, lg.argmax(-1, keepdim=True)], 1)
+    return idx, torch.stack(logits_all, 1)
+
+
+def steve_forward_tokens(img, slots, sd, cfg):
+    """The token-prediction half of STEVE._forward (steve.py:306-322): dVAE ids of the frames as targets, teacher-forced
+    decoder logits, and the cross-entropy of steve.py:341-344.  img [B,T,3,H,W], slots [B,T,N,D]."""
+    tgt = dvae_tokenize(img.flatten(0, 1), sd, 'dvae.', one_hot=False).flatten(1, 2)
+    dd = cfg['dec_dict']
+    logits = steve_decoder_forward(slots.flatten(0, 1), tgt[:, :-1], sd, dd['dec_num_heads'], dd['dec_num_layers'])
+    loss = F.cross_entropy(logits.flatten(0, 1), tgt.flatten(0, 1))
+    return {'pred_token_id': logits, 'target_token_id': tgt, 'token_recon_loss': loss}

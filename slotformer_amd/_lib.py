@@ -90,6 +90,12 @@ SIGNATURES = {
     'sf_savi_encode_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I]),
     'sf_savi_encode_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
                                VP]),
+    'sf_groupnorm1_workspace_bytes': (SZ, [I]),
+    'sf_groupnorm1_nhwc_f32': (I, [FP, FP, FP, FP, I, I, I, I, F32, I, I, VP, SZ, VP]),
+    'sf_slate_attention_f32': (I, [FP, FP, FP, FP, I, I, I, I, I, I, I, I, I, I, VP]),
+    'sf_embed_tokens_f32': (I, [VP, FP, FP, FP, I, I, I, VP]),
+    'sf_argmax_rows_f32': (I, [FP, LL, VP, LL, I, VP]),
+    'sf_cross_entropy_f32': (I, [FP, VP, FP, FP, LL, I, VP]),
     'sf_packed_linear_bytes': (SZ, [I, I]),
     'sf_pack_linear_weights': (I, [FP, VP, I, I, VP]),
     'sf_ffn_packed_bytes': (SZ, [I, I]),

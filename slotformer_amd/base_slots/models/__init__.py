@@ -1,6 +1,8 @@
 """build_model for the slot-extraction models (reference: slotformer/base_slots/models/__init__.py:9-34)."""
 from .savi import StoSAVi, SlotAttention
+from .dVAE import dVAE
 from .steve import STEVE, SlotAttentionWMask
+from .steve_transformer import STEVETransformerDecoder
 from .utils import to_rgb_from_tensor, assert_shape, SoftPositionEmbed, build_grid
 
 
@@ -27,6 +29,6 @@ def build_model(params):
             loss_dict=params.loss_dict,
         )
     elif params.model == 'dVAE':
-        raise NotImplementedError('dVAE (image tokenizer) is outside the slot-extraction/rollout hot path')
+        return dVAE(vocab_size=params.vocab_size, img_channels=3)
     else:
         raise NotImplementedError(f'{params.model} is not implemented.')

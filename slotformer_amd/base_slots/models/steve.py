@@ -1,19 +1,18 @@
 """STEVE slot-extraction side on the MI355X engine (reference: slotformer/base_slots/models/steve.py).
 
-In scope: SlotAttentionWMask and STEVE.encode -- slots plus the
-last-iteration attention as segmentation masks (bilinearly resized to the input resolution
-in eval).  The dVAE tokenizer and the slot-conditioned Transformer decoder (training targets /
-image decoding) are rows N2/out-of-scope; their checkpoint keys (`dvae.*`, `trans_decoder.*`)
-are accepted and ignored when loading.
+SlotAttentionWMask and STEVE.encode -- slots plus the last-iteration attention as segmentation masks (bilinearly
+resized to the input resolution in eval) -- and the image side: dVAE token targets, the
+teacher-forced slot-conditioned Transformer decoder and the token cross-entropy of `_forward` / `calc_train_loss`
+(forward values only: the engine is inference-only, backward belongs to row N1).
 """
 import torch
 from torch import nn
 
 from ...nerv_compat import BaseModel
 from ... import engine, ops
+from .dVAE import dVAE
 from .savi import SlotAttention, StoSAVi
-
-_IGNORED_PREFIXES = ('dvae.', 'trans_decoder.')
+from .steve_transformer import STEVETransformerDecoder
 
 
 class SlotAttentionWMask(SlotAttention):
@@ -51,16 +50,40 @@ class STEVE(StoSAVi):
         self.loss_dict = loss_dict
 
         self._build_slot_attention()
+        self._build_dvae()
         self._build_encoder()
+        self._build_decoder()
         self._build_predictor()
         self._build_loss()
         self.testing = False
-        self._register_load_state_dict_pre_hook(self._drop_decoder_keys)
 
-    @staticmethod
-    def _drop_decoder_keys(state_dict, prefix, *args):
-        for k in [k for k in state_dict if k[len(prefix):].startswith(_IGNORED_PREFIXES)]:
-            del state_dict[k]
+    def _build_dvae(self):
+        """steve.py:148-160.  The reference asserts a checkpoint path; an empty path here leaves the tokenizer at its
+        initial weights (they normally arrive with the STEVE checkpoint's `dvae.*` keys)."""
+        self.vocab_size = self.dvae_dict['vocab_size']
+        self.down_factor = self.dvae_dict['down_factor']
+        self.dvae = dVAE(vocab_size=self.vocab_size, img_channels=3)
+        ckp_path = self.dvae_dict.get('dvae_ckp_path', '')
+        if ckp_path:
+            ckp = torch.load(ckp_path, map_location='cpu')
+            self.dvae.load_state_dict(ckp['state_dict'])
+        for p in self.dvae.parameters():
+            p.requires_grad = False
+        self.dvae.eval()
+
+    def _build_decoder(self):
+        """steve.py:162-176: GPT-style causal Transformer decoder over the h*w image tokens, conditioned on the slots."""
+        H, W = self.resolution
+        self.h, self.w = H // self.down_factor, W // self.down_factor
+        self.num_patches = self.h * self.w
+        self.trans_decoder = STEVETransformerDecoder(
+            vocab_size=self.vocab_size,
+            d_model=self.dec_dict['dec_d_model'],
+            n_head=self.dec_dict['dec_num_heads'],
+            max_len=self.num_patches - 1,
+            num_slots=self.num_slots,
+            num_layers=self.dec_dict['dec_num_layers'],
+        )
 
     def _build_slot_attention(self):
         self.enc_out_channels = self.enc_dict['enc_out_channels']
@@ -101,6 +124,28 @@ class STEVE(StoSAVi):
         out_dict = {'slots': slots, 'masks': masks}
         if self.testing:
             return out_dict
-        raise NotImplementedError(
-            'STEVE token prediction / image decoding (dVAE + Transformer decoder, steve.py:306-337) is outside '
-            'the slot-extraction hot path; set model.testing = True')
+        # token targets from the frozen dVAE, teacher-forced decoder logits (steve.py:306-322)
+        if img_token_id is None:
+            img_token_id = self.dvae.tokenize(img, one_hot=False).flatten(2, 3)
+        h, w = self.h, self.w
+        target_token_id = img_token_id.flatten(0, 1).long().contiguous()   # [B*T, h*w]
+        in_slots = slots.flatten(0, 1)
+        in_token_id = target_token_id[:, :-1].contiguous()
+        pred_token_id = self.trans_decoder(in_slots, in_token_id)[:, -(h * w):]
+        out_dict.update({'pred_token_id': pred_token_id, 'target_token_id': target_token_id})
+        if self.use_img_recon_loss:
+            raise NotImplementedError('use_img_recon_loss (Gumbel-softmax image reconstruction, steve.py:324-335) is a '
+                                      'training-only loss (row N1)')
+        return out_dict
+
+    def calc_train_loss(self, data_dict, out_dict):
+        """Token cross-entropy of steve.py:339-351 (value only; no autograd on this engine)."""
+        pred = out_dict['pred_token_id'].flatten(0, 1).contiguous()
+        target = out_dict['target_token_id'].flatten(0, 1).contiguous()
+        return {'token_recon_loss': ops.cross_entropy(pred, target)}
+
+    def train(self, mode=True):
+        """steve.py: the dVAE stays in eval mode."""
+        super().train(mode)
+        self.dvae.eval()
+        return self

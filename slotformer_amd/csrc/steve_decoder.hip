@@ -1,0 +1,306 @@
+// Kernels of the STEVE image side (second half): the dVAE tokenizer / detokenizer blocks
+// (reference: slotformer/base_slots/models/dVAE.py, steve_utils.py:100-126) and the slot-conditioned Transformer
+// decoder (steve_transformer.py).  The convolutions and linears run on the GEMM core (gemm.hip); this file holds
+// what is specific to these models.
+#include "../../include/slotformer_hip.h"
+#include "sf_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int GN_P = 64;   // partial records per sample
+
+// ---- GroupNorm(num_groups = 1) statistics: per sample, over all H*W*C elements (steve_utils.py:124-126) ----
+// grid (GN_P, F): block (p, f) reduces its slice to (sum, sum of squares) in double.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ part, long long n) {
+  const int p = blockIdx.x, f = blockIdx.y, t = threadIdx.x;
+  const long long n4 = n / 4, per = (n4 + GN_P - 1) / GN_P;
+  const long long lo = p * per, hi = lo + per < n4 ? lo + per : n4;
+  const f32x4* xs = (const f32x4*)(x + (long long)f * n);
+  float s = 0.f, q = 0.f;
+  for (long long i = lo + t; i < hi; i += 256) {
+    const f32x4 v = xs[i];
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+    q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  __shared__ double sh[2][4];
+  double ds = (double)sf_sum64(s), dq = (double)sf_sum64(q);
+  if ((t & 63) == 0) {
+    sh[0][t >> 6] = ds;
+    sh[1][t >> 6] = dq;
+  }
+  __syncthreads();
+  if (t == 0) {
+    part[((long long)f * GN_P + p) * 2 + 0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    part[((long long)f * GN_P + p) * 2 + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+  }
+}
+
+// y = act((x - mean) * rstd * gamma[c] + beta[c]); NHWC in.  shuffle == 2 also applies nn.PixelShuffle(2)
+// (dVAE.py:44,49): in channel c*4 + i*2 + j of pixel (yy, xx) -> out pixel (2yy + i, 2xx + j), channel c.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ part,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ y, int H, int W, int C, float eps, int relu,
+                                                       int shuffle) {
+  const int f = blockIdx.y, t = threadIdx.x;
+  const long long n = (long long)H * W * C;
+  __shared__ float stat[2];
+  if (t < 64) {
+    double s = part[((long long)f * GN_P + t) * 2], q = part[((long long)f * GN_P + t) * 2 + 1];
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o, 64);
+      q += __shfl_xor(q, o, 64);
+    }
+    if (t == 0) {
+      const double mean = s / (double)n;
+      const double var = q / (double)n - mean * mean;
+      stat[0] = (float)mean;
+      stat[1] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+    }
+  }
+  __syncthreads();
+  const float mean = stat[0], rstd = stat[1];
+  const long long i4 = (long long)blockIdx.x * 256 + t;
+  if (i4 * 4 >= n) return;
+  const long long e = i4 * 4;
+  const int c = (int)(e % C);
+  const f32x4 v = *(const f32x4*)(x + (long long)f * n + e);
+  const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+  f32x4 o = (v - mean) * rstd * g + b;
+  if (relu) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], 0.f);
+  }
+  if (shuffle == 1) {
+    *(f32x4*)(y + (long long)f * n + e) = o;
+  } else {
+    const long long pix = e / C;
+    const int yy = (int)(pix / W), xx = (int)(pix - (long long)yy * W);
+    const int Co = C / 4, co = c / 4;
+    float* yo = y + (long long)f * n;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)   // k = i*2 + j
+      yo[((long long)(2 * yy + (k >> 1)) * (2 * W) + 2 * xx + (k & 1)) * Co + co] = o[k];
+  }
+}
+
+// ---- attention of the slate Transformer decoder (steve_transformer.py:12-55): softmax(q k^T * hd^-0.5 [+ causal mask]) v.
+// One thread per query row, keys/values streamed through LDS in tiles of 64 with an online softmax, so the sequence
+// length (1 + 1023 image tokens at 128x128) is unbounded; the same kernel serves the cross-attention to the N slots.
+// q rows [B][Lq] (leading dim ldq), k/v rows [B][Lk]; head h uses columns h*HD .. h*HD+HD-1 of each.
+template <int HD>
+__global__ __launch_bounds__(256) void slate_attn_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, float* __restrict__ out, int ldq,
+                                                         int ldk, int ldv, int ldo, int Lq, int Lk, int causal, float scale) {
+  __shared__ __attribute__((aligned(16))) float Ks[64][HD];
+  __shared__ __attribute__((aligned(16))) float Vs[64][HD];
+  const int t = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int i = blockIdx.x * 256 + t;
+  const bool live = i < Lq;
+  const float* qr = q + ((long long)b * Lq + (live ? i : Lq - 1)) * ldq + h * HD;
+  float qv[HD], o[HD];
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    const f32x4 x = *(const f32x4*)(qr + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      qv[c + e] = x[e] * scale;
+      o[c + e] = 0.f;
+    }
+  }
+  float m = -INFINITY, l = 0.f;
+  const int kend = causal ? min(Lk, blockIdx.x * 256 + 256) : Lk;   // keys this block can see at all
+  const float* kb = k + (long long)b * Lk * ldk + h * HD;
+  const float* vb = v + (long long)b * Lk * ldv + h * HD;
+  for (int k0 = 0; k0 < kend; k0 += 64) {
+    constexpr int F4 = 64 * HD / 4;   // float4 per tile
+    for (int idx = t; idx < F4; idx += 256) {
+      const int r = idx / (HD / 4), c4 = idx - r * (HD / 4);
+      const int j = min(k0 + r, Lk - 1);
+      *(f32x4*)&Ks[r][4 * c4] = *(const f32x4*)(kb + (long long)j * ldk + 4 * c4);
+      *(f32x4*)&Vs[r][4 * c4] = *(const f32x4*)(vb + (long long)j * ldv + 4 * c4);
+    }
+    __syncthreads();
+    const int nj = min(64, kend - k0);
+    for (int jj = 0; jj < nj; ++jj) {
+      float sc = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) sc += qv[c] * Ks[jj][c];
+      const int j = k0 + jj;
+      if (live && (!causal || j <= i)) {
+        const float mn = fmaxf(m, sc);
+        const float corr = (m == -INFINITY) ? 0.f : expf(m - mn);
+        const float pj = expf(sc - mn);
+        l = l * corr + pj;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) o[c] = o[c] * corr + pj * Vs[jj][c];
+        m = mn;
+      }
+    }
+    __syncthreads();
+  }
+  if (live) {
+    const float inv = 1.0f / l;
+    float* orow = out + ((long long)b * Lq + i) * ldo + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) *(f32x4*)(orow + c) = f32x4{o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv};
+  }
+}
+
+// x[b, t] = tok_emb[idx[b, t]] + pos[t]   (steve_transformer.py:291-296: BOS already prepended by the caller)
+__global__ void embed_kernel(const long long* __restrict__ idx, const float* __restrict__ emb, const float* __restrict__ pos,
+                             float* __restrict__ out, int L, int d, long long total4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int d4 = d / 4;
+  const long long row = i / d4;
+  const int c4 = (int)(i - row * d4), tpos = (int)(row % L);
+  const f32x4 e = *(const f32x4*)(emb + idx[row] * d + 4 * c4), p = *(const f32x4*)(pos + (long long)tpos * d + 4 * c4);
+  *(f32x4*)(out + row * d + 4 * c4) = e + p;
+}
+
+// first index of the row maximum (torch.argmax / topk(k=1) tie rule); one wave per row
+__global__ __launch_bounds__(64) void argmax_rows_kernel(const float* __restrict__ x, long long ld, long long* __restrict__ out,
+                                                         int V) {
+  const long long r = blockIdx.x;
+  const float* xr = x + r * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = threadIdx.x; j < V; j += 64) {
+    const float v = xr[j];
+    if (v > best) {
+      best = v;
+      bi = j;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) {
+      best = ob;
+      bi = oi;
+    }
+  }
+  if (threadIdx.x == 0) out[r] = bi;
+}
+
+// per-row cross-entropy  -log softmax(x)[target]  (F.cross_entropy, steve.py:341-344); one workgroup per row
+__global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict__ x, const long long* __restrict__ tgt,
+                                                        float* __restrict__ loss, int V) {
+  const long long r = blockIdx.x;
+  const float* xr = x + r * (long long)V;
+  const int t = threadIdx.x;
+  __shared__ float sh[4];
+  float mx = -INFINITY;
+  for (int j = t; j < V; j += 256) mx = fmaxf(mx, xr[j]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((t & 63) == 0) sh[t >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int j = t; j < V; j += 256) se += expf(xr[j] - mx);
+  se = sf_sum64(se);
+  if ((t & 63) == 0) sh[t >> 6] = se;
+  __syncthreads();
+  if (t == 0) loss[r] = logf((sh[0] + sh[1]) + (sh[2] + sh[3])) + mx - xr[tgt[r]];
+}
+
+// mean of n floats in a fixed order (single workgroup, double accumulation)
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, float* __restrict__ out, long long n) {
+  __shared__ double sh[256];
+  double a = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 256) a += (double)x[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(sh[0] / (double)n);
+}
+}  // namespace
+
+extern "C" {
+
+// out[b, i, h*hd + c] = sum_j softmax_j(q[b,i,h] . k[b,j,h] * hd^-0.5 (j <= i if causal)) v[b,j,h,c]
+// q [B*Lq, ldq], k [B*Lk, ldk], v [B*Lk, ldv], out [B*Lq, ldo]; head_dim in {16, 32, 48, 64}.
+int sf_slate_attention_f32(const float* q, const float* k, const float* v, float* out, int ldq, int ldk, int ldv, int ldo,
+                           int B, int Lq, int Lk, int num_heads, int head_dim, int causal, void* stream) {
+  SF_REQUIRE(q && k && v && out, "sf_slate_attention_f32: null pointer");
+  SF_REQUIRE(B >= 0 && Lq > 0 && Lk > 0 && num_heads > 0, "sf_slate_attention_f32: bad shape");
+  SF_REQUIRE((ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (ldo % 4) == 0, "sf_slate_attention_f32: leading dims must be multiples of 4");
+  SF_REQUIRE(!causal || Lq == Lk, "sf_slate_attention_f32: causal attention needs Lq == Lk");
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((Lq + 255) / 256, num_heads, B);
+  const float scale = 1.0f / sqrtf((float)head_dim);
+#define SLATE_CASE(HD_)                                                                                              \
+  if (head_dim == HD_) {                                                                                             \
+    hipLaunchKernelGGL(slate_attn_kernel<HD_>, grid, dim3(256), 0, st, q, k, v, out, ldq, ldk, ldv, ldo, Lq, Lk, causal, scale); \
+    SF_CHECK_LAUNCH();                                                                                               \
+    return 0;                                                                                                        \
+  }
+  SLATE_CASE(16)
+  SLATE_CASE(32)
+  SLATE_CASE(48)
+  SLATE_CASE(64)
+#undef SLATE_CASE
+  return sf_set_err(-1, "invalid argument: sf_slate_attention_f32 head_dim must be 16, 32, 48 or 64", __FILE__, __LINE__);
+}
+
+// out [R = B*L, d] = tok_emb[idx] + pos[t];  idx int64 [B, L] (values < rows of tok_emb), pos [>= L, d]
+int sf_embed_tokens_f32(const long long* idx, const float* tok_emb, const float* pos, float* out, int B, int L, int d,
+                        void* stream) {
+  SF_REQUIRE(idx && tok_emb && pos && out && B >= 0 && L > 0 && d > 0 && (d % 4) == 0, "sf_embed_tokens_f32: bad arguments");
+  const long long total4 = (long long)B * L * (d / 4);
+  if (total4 == 0) return 0;
+  hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, tok_emb, pos,
+                     out, L, d, total4);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[r] = first index of max(x[r, 0:V]);  x rows ld floats apart
+int sf_argmax_rows_f32(const float* x, long long ld, long long* out, long long R, int V, void* stream) {
+  SF_REQUIRE(x && out && R >= 0 && V > 0 && ld >= V, "sf_argmax_rows_f32: bad arguments");
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)R), dim3(64), 0, (hipStream_t)stream, x, ld, out, V);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// loss_rows[r] = -log softmax(x[r])[target[r]];  mean_out[0] = mean over rows (F.cross_entropy default reduction)
+int sf_cross_entropy_f32(const float* x, const long long* target, float* loss_rows, float* mean_out, long long R, int V,
+                         void* stream) {
+  SF_REQUIRE(x && target && loss_rows && mean_out && R > 0 && V > 0, "sf_cross_entropy_f32: bad arguments");
+  hipLaunchKernelGGL(xent_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, target, loss_rows, V);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_rows, mean_out, R);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+
+size_t sf_groupnorm1_workspace_bytes(int F) { return (size_t)(F > 0 ? F : 0) * GN_P * 2 * sizeof(double); }
+
+// F.group_norm(x, 1, gamma, beta, eps) (+ ReLU) on NHWC x [F,H,W,C]; pixel_shuffle 1 (none) or 2
+// (y [F,2H,2W,C/4], nn.PixelShuffle(2) applied to the normalised map).
+int sf_groupnorm1_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y, int F, int H, int W, int C,
+                           float eps, int relu, int pixel_shuffle, void* ws, size_t ws_bytes, void* stream) {
+  SF_REQUIRE(x && gamma && beta && y && ws, "sf_groupnorm1_nhwc_f32: null pointer");
+  SF_REQUIRE(F >= 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "sf_groupnorm1_nhwc_f32: bad shape");
+  SF_REQUIRE(pixel_shuffle == 1 || (pixel_shuffle == 2 && (C % 16) == 0), "sf_groupnorm1_nhwc_f32: pixel_shuffle must be 1 or 2");
+  SF_REQUIRE(ws_bytes >= sf_groupnorm1_workspace_bytes(F), "sf_groupnorm1_nhwc_f32: workspace too small");
+  if (F == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)H * W * C;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(GN_P, F), dim3(256), 0, st, x, (double*)ws, n);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256), F), dim3(256), 0, st, x, (const double*)ws, gamma,
+                     beta, y, H, W, C, eps, relu, pixel_shuffle);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -180,3 +180,64 @@ def bilinear_resize(x, size):
     check(lib().sf_bilinear_resize_f32(_p(x), _p(out), x.numel() // (Hi * Wi), Hi, Wi, size[0], size[1],
                                        _stream()))
     return out
+
+
+def groupnorm1_nhwc(x, gamma, beta, eps=1e-5, relu=True, pixel_shuffle=1):
+    """F.group_norm(x, 1, gamma, beta) (+ReLU) on NHWC x [F,H,W,C]; pixel_shuffle=2 also applies nn.PixelShuffle(2)
+    (-> [F,2H,2W,C/4]).  steve_utils.py:124-126, dVAE.py:44,49."""
+    _chk(x, gamma, beta)
+    F_, H, W, C_ = x.shape
+    r = pixel_shuffle
+    out = torch.empty(F_, H * r, W * r, C_ // (r * r), device=x.device, dtype=torch.float32)
+    nb = lib().sf_groupnorm1_workspace_bytes(F_)
+    ws = torch.empty(max(nb, 8), dtype=torch.uint8, device=x.device)
+    check(lib().sf_groupnorm1_nhwc_f32(_p(x), _p(gamma), _p(beta), _p(out), F_, H, W, C_, eps, int(relu), r, ws.data_ptr(), nb,
+                                       _stream()))
+    return out
+
+
+def slate_attention(q, k, v, num_heads, causal, q_off=0, k_off=0, v_off=0, d_model=None):
+    """softmax(q k^T hd^-0.5 [causal]) v per head (steve_transformer.py:12-55).  q [B,Lq,ldq], k/v [B,Lk,ld*]: the head
+    block starts at column *_off of each row (so q|k|v may live side by side in one projection buffer)."""
+    _chk(q, k, v)
+    B, Lq, ldq = q.shape
+    Lk, ldk, ldv = k.shape[1], k.shape[2], v.shape[2]
+    d = d_model if d_model is not None else ldq
+    out = torch.empty(B, Lq, d, device=q.device, dtype=torch.float32)
+    check(lib().sf_slate_attention_f32(q.data_ptr() + 4 * q_off, k.data_ptr() + 4 * k_off, v.data_ptr() + 4 * v_off, _p(out),
+                                       ldq, ldk, ldv, d, B, Lq, Lk, num_heads, d // num_heads, int(causal), _stream()))
+    return out
+
+
+def embed_tokens(idx, tok_emb, pos):
+    """tok_emb[idx] + pos[:L];  idx int64 [B,L] on device."""
+    _chk(tok_emb, pos)
+    if idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous():
+        raise TypeError('embed_tokens: idx must be a contiguous int64 device tensor')
+    B, L = idx.shape
+    d = tok_emb.shape[1]
+    out = torch.empty(B, L, d, device=tok_emb.device, dtype=torch.float32)
+    check(lib().sf_embed_tokens_f32(idx.data_ptr(), _p(tok_emb), _p(pos), _p(out), B, L, d, _stream()))
+    return out
+
+
+def argmax_rows(x):
+    """First index of the maximum of each row of x [..., V] -> int64 [...]."""
+    _chk(x)
+    V = x.shape[-1]
+    R = x.numel() // V
+    out = torch.empty(x.shape[:-1], device=x.device, dtype=torch.int64)
+    check(lib().sf_argmax_rows_f32(_p(x), V, out.data_ptr(), R, V, _stream()))
+    return out
+
+
+def cross_entropy(logits, target):
+    """F.cross_entropy(logits [R,V], target int64 [R]) with mean reduction -> 0-dim tensor."""
+    _chk(logits)
+    if target.dtype != torch.int64 or not target.is_cuda or not target.is_contiguous():
+        raise TypeError('cross_entropy: target must be a contiguous int64 device tensor')
+    R, V = logits.shape
+    rows = torch.empty(R, device=logits.device, dtype=torch.float32)
+    mean = torch.empty(1, device=logits.device, dtype=torch.float32)
+    check(lib().sf_cross_entropy_f32(_p(logits), target.data_ptr(), _p(rows), _p(mean), R, V, _stream()))
+    return mean[0]

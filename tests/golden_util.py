@@ -14,7 +14,8 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 # keys whose value is a deterministic closed form (kept as constructed, and
 # compared against the reference's value stored in the fixture)
-CLOSED_FORM_SUFFIXES = ('.grid', 'enc_t_pe')
+CLOSED_FORM_SUFFIXES = ('.grid', 'enc_t_pe', 'self_attn_mask')
+CLOSED_FORM_NOSTORE = ('self_attn_mask', )  # boolean triu masks: taken from the module under test, never stored
 
 
 def seeded_tensor(key, shape, seed):
@@ -22,6 +23,8 @@ def seeded_tensor(key, shape, seed):
     shape = tuple(shape)
     if key.endswith('init_latents'):
         a = rs.standard_normal(shape)
+    elif key.endswith(('tok_emb.weight', 'pos_emb.pe')):  # embeddings: O(1) entries
+        a = 0.5 * rs.standard_normal(shape)
     elif 'bias' in key.rsplit('.', 1)[-1]:
         a = 0.1 * (rs.rand(*shape) * 2 - 1)
     elif len(shape) >= 2:
@@ -36,7 +39,9 @@ def seeded_state_dict(shapes, seed, keep=None):
     """shapes: list of (key, shape).  keep: dict of closed-form tensors to reuse."""
     sd = {}
     for key, shape in shapes:
-        if key.endswith(CLOSED_FORM_SUFFIXES):
+        if key.endswith(CLOSED_FORM_NOSTORE) and (keep is None or key not in keep):
+            sd[key] = torch.triu(torch.ones(tuple(shape), dtype=torch.bool), diagonal=1)  # steve_transformer.py:163-165
+        elif key.endswith(CLOSED_FORM_SUFFIXES):
             assert keep is not None and key in keep, key
             sd[key] = keep[key].clone()
         else:
@@ -99,6 +104,17 @@ C1_SAVI = savi_cfg(64, 6, iters=2, kernel_mlp=True, pred='transformer', rnn=True
 C1_SAVI_IT3 = savi_cfg(64, 6, iters=3, kernel_mlp=True, pred='transformer', rnn=True, kld='none')
 # C2: CLEVRER StoSAVi (stosavi_clevrer_params.py) at 128x128 -- stochastic, MLP predictor
 C2_SAVI = savi_cfg(128, 7, iters=2, kernel_mlp=False, pred='mlp', rnn=False, kld='var-0.01')
+# STEVE with its image side (dVAE tokens + Transformer decoder, row N2): a reduced steve_physion_params.py
+def steve_tokens_cfg():
+    cfg = savi_cfg(64, 4, slot_size=64, mlp=128, iters=2, pred='transformer', rnn=True, kld='none', enc_out=64,
+                   pred_layers=1, pred_heads=4, pred_ffn=128)
+    cfg['model'] = 'STEVE'
+    cfg['dvae_dict'] = dict(down_factor=4, vocab_size=64, dvae_ckp_path='')
+    cfg['dec_dict'] = dict(dec_type='slate', dec_num_layers=2, dec_num_heads=4, dec_d_model=64)
+    cfg['loss_dict'] = dict(use_img_recon_loss=False)
+    return cfg
+
+
 # C4: Physion STEVE encoder side (steve_physion_params.py)
 C4_STEVE = savi_cfg(128, 6, slot_size=192, mlp=384, iters=2, pred='transformer', rnn=True,
                     enc_out=192, pred_ffn=768)

@@ -33,15 +33,18 @@ def build(cfg, golden, seed, dev, vp=False):
         m = bv(gu.ParamsView(full))
     else:
         full = dict(cfg)
-        if cfg['model'] == 'STEVE':
+        if cfg['model'] == 'STEVE' and 'dvae_dict' not in cfg:
             full.update(dvae_dict=dict(down_factor=4, vocab_size=64, dvae_ckp_path=''),
                         dec_dict=dict(dec_type='slate', dec_num_layers=1, dec_num_heads=4, dec_d_model=64),
                         loss_dict=dict(use_img_recon_loss=False))
         m = bb(gu.ParamsView(full))
     own = {k: v for k, v in m.state_dict().items()}
-    assert [(k, tuple(v.shape)) for k, v in own.items()] == shapes, 'state-dict keys/shapes differ from the reference'
+    golden_keys = {k for k, _ in shapes}
+    # the encoder-only STEVE fixture lists the hot-path keys; the image side (dvae.*, trans_decoder.*) keeps its init
+    hot = {k: v for k, v in own.items() if k in golden_keys or not k.startswith(('dvae.', 'trans_decoder.'))}
+    assert [(k, tuple(v.shape)) for k, v in hot.items()] == shapes, 'state-dict keys/shapes differ from the reference'
     sd = gu.seeded_state_dict(shapes, seed, keep=own)
-    m.load_state_dict(sd, strict=True)
+    m.load_state_dict(sd, strict=len(hot) == len(own))
     return m.eval().to(dev), sd
 
 
@@ -104,6 +107,48 @@ def test_steve_golden_and_masks(dev):
     n_diff = int((am != torch.from_numpy(g['argmax'])).sum())
     print(f'argmax: {n_unsafe} sub-margin pixels of {safe.numel()}, {n_diff} differ')
     assert n_diff <= n_unsafe
+
+
+@torch.no_grad()
+def test_steve_image_side_golden(dev, precision):
+    """Row N2 (second half) through the reference-shaped API: dVAE tokens / reconstruction, teacher-forced Transformer
+    decoder logits, token cross-entropy and greedy generation vs the reference's own outputs."""
+    g = gu.load_golden('steve_tokens')
+    cfg = gu.steve_tokens_cfg()
+    m, sd = build(cfg, g, 601, dev)
+    img = gu.seeded_img(1, 2, 64, seed=602).to(dev)
+    flat = img.flatten(0, 1)
+    # dVAE
+    lg = m.dvae._logits_nhwc(flat.contiguous()).permute(0, 3, 1, 2)
+    print('dvae logits', rel_err(lg, g['dvae_logits']))
+    assert rel_err(lg, g['dvae_logits']) < 1e-4
+    ids = m.dvae.tokenize(flat, one_hot=False).cpu()
+    safe = torch.from_numpy(g['dvae_margin']) > 1e-4 * float(np.abs(g['dvae_logits']).max())
+    assert torch.equal(ids[safe], torch.from_numpy(g['dvae_ids'])[safe]) and int((~safe).sum()) < 8
+    z_hard = torch.zeros(2, 64, 16, 16).scatter_(1, torch.from_numpy(g['dvae_ids']).unsqueeze(1), 1.).to(dev)
+    assert rel_err(m.dvae.detokenize(z_hard), g['recon_hard']) < 1e-4
+    z_soft = torch.softmax(torch.from_numpy(g['dvae_logits']), 1).to(dev)
+    assert rel_err(m.dvae.detokenize(z_soft.unflatten(0, (1, 2))), g['recon_soft'][None]) < 1e-4
+    # full forward with the reference's token ids as targets (token_id input of steve.py:283-311)
+    m.testing = False
+    tok = torch.from_numpy(g['target_token_id']).to(dev).unflatten(0, (1, 2))
+    out = m({'img': img, 'token_id': tok})
+    print('slots', rel_err(out['slots'], g['slots']), 'logits', rel_err(out['pred_token_id'], g['pred_token_id']))
+    assert rel_err(out['slots'], g['slots']) < RTOL
+    assert rel_err(out['pred_token_id'], g['pred_token_id']) < RTOL
+    loss = m.calc_train_loss({'img': img}, out)['token_recon_loss']
+    assert abs(float(loss) - float(g['token_recon_loss'])) < 1e-3 * float(g['token_recon_loss'])
+    # tokens computed on the device give the same targets wherever the reference's margin is not a tie
+    out2 = m({'img': img})
+    same = out2['target_token_id'].cpu() == torch.from_numpy(g['target_token_id'])
+    assert int((~same).sum()) <= int((~safe).sum())
+    # greedy generation from the reference's slots
+    slots = torch.from_numpy(g['slots']).to(dev).flatten(0, 1)
+    idx, logits = m.trans_decoder.generate(slots, steps=g['gen_idx'].shape[1])
+    assert torch.equal(idx.cpu(), torch.from_numpy(g['gen_idx']))
+    assert not logits.is_cuda and rel_err(logits, g['gen_logits']) < RTOL
+    with pytest.raises(NotImplementedError):
+        m.trans_decoder.generate(slots, steps=2, sample=True)
 
 
 @pytest.mark.parametrize('name,cfg,B,pred_len,seed', [

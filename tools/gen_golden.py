@@ -236,6 +236,58 @@ def case_steve(name, cfg, B, T, seed):
          argmax=masks.argmax(2).to(torch.uint8), margin=margin, **meta)
 
 
+@torch.no_grad()
+def case_steve_tokens(name, B, T, seed):
+    """Reference STEVE with its image side: dVAE tokens as targets, teacher-forced Transformer-decoder logits and the
+    token cross-entropy (steve.py:282-344); greedy generation (steve_transformer.py:305-333); dVAE detokenisation."""
+    print(name)
+    cfg = gu.steve_tokens_cfg()
+    dv = dVAE(vocab_size=cfg['dvae_dict']['vocab_size'], img_channels=3)
+    dpath = os.path.join(TMP, 'dvae_tok.pth')
+    torch.save({'state_dict': dv.state_dict()}, dpath)
+    full = {k: (dict(v) if isinstance(v, dict) else v) for k, v in cfg.items()}
+    full['dvae_dict']['dvae_ckp_path'] = dpath
+    m = ref_build_base(gu.ParamsView(full)).eval()
+    sd = load_seeded(m, seed)
+    img = gu.seeded_img(B, T, cfg['resolution'][0], seed=seed + 1)
+    m.testing = False
+    out = m({'img': img})
+    loss = m.calc_train_loss({'img': img}, out)
+    slots = out['slots']
+    # dVAE alone
+    flat = img.flatten(0, 1)
+    logits = m.dvae.encoder(flat)
+    top2 = logits.topk(2, dim=1)[0]
+    margin = top2[:, 0] - top2[:, 1]
+    ids = m.dvae.tokenize(flat, one_hot=False)
+    z_hard = m.dvae.tokenize(flat, one_hot=True)
+    recon_hard = m.dvae.detokenize(z_hard)
+    z_soft = torch.softmax(logits, dim=1)
+    recon_soft = m.dvae.detokenize(z_soft)
+    # greedy generation of the first tokens
+    steps = 6
+    gen_idx, gen_logits = m.trans_decoder.generate(slots.flatten(0, 1), steps=steps, sample=False)
+    g2 = gen_logits.topk(2, dim=-1)[0]
+    # oracle agreement
+    o = oracle.steve_forward_tokens(img, slots, sd, cfg)
+    print('  oracle logits err', err(o['pred_token_id'], out['pred_token_id']), 'loss', float(o['token_recon_loss']),
+          float(loss['token_recon_loss']), 'targets equal', bool(torch.equal(o['target_token_id'], out['target_token_id'])))
+    print('  oracle dvae logits', err(oracle.dvae_logits(flat, sd, 'dvae.'), logits), 'detok',
+          err(oracle.dvae_detokenize(z_soft, sd, 'dvae.'), recon_soft))
+    oi, ol = oracle.steve_decoder_generate(slots.flatten(0, 1), steps, sd, cfg['dec_dict']['dec_num_heads'],
+                                           cfg['dec_dict']['dec_num_layers'])
+    print('  oracle generate ids equal', bool(torch.equal(oi, gen_idx)), 'logits', err(ol, gen_logits),
+          'min token margin', float(margin.min()), 'min gen margin', float((g2[..., 0] - g2[..., 1]).min()))
+    meta = pack_meta(m, sd)
+    for k in list(meta):
+        if k.startswith('closed::') and k.endswith(gu.CLOSED_FORM_NOSTORE):
+            del meta[k]
+    save(name, slots=slots, pred_token_id=out['pred_token_id'], target_token_id=out['target_token_id'],
+         token_recon_loss=np.float64(float(loss['token_recon_loss'])), dvae_logits=logits, dvae_margin=margin,
+         dvae_ids=ids, recon_hard=recon_hard, recon_soft=recon_soft, gen_idx=gen_idx, gen_logits=gen_logits,
+         gen_margin=(g2[..., 0] - g2[..., 1]), **meta)
+
+
 def build_slotformer(cfg, savi_seed=11):
     scfg = gu.savi_cfg(cfg['resolution'][0], cfg['slot_dict']['num_slots'],
                        slot_size=cfg['slot_dict']['slot_size'])
@@ -366,6 +418,9 @@ def case_phyre(name, scfg, rcfg, B, vid_len, seed):
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == 'steve_tokens':   # regenerate only this fixture
+        case_steve_tokens('steve_tokens', B=1, T=2, seed=601)
+        return
     case_savi('savi_c1', gu.C1_SAVI, B=2, T=3, seed=101)
     case_savi('savi_c1_it3', gu.C1_SAVI_IT3, B=1, T=2, seed=102)
     case_savi('savi_c2', gu.C2_SAVI, B=2, T=3, seed=103, noise_seed=7)
@@ -380,6 +435,7 @@ def main():
     case_h2('harness_h2', gu.C1_ROLL, B=2, seed=301, frame_offset=2)
     case_decode('decode_c2', gu.savi_cfg(64, 7, kernel_mlp=False, pred='mlp', rnn=False), Fr=2, seed=401)
     case_phyre('harness_h3', gu.C5_SAVI, gu.C5_ROLL, B=2, vid_len=5, seed=501)
+    case_steve_tokens('steve_tokens', B=1, T=2, seed=601)
 
 
 if __name__ == '__main__':
