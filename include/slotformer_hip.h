@@ -139,6 +139,9 @@ int sf_embed_tokens_f32(const long long* idx, const float* tok_emb, const float*
 int sf_argmax_rows_f32(const float* x, long long ld, long long* out, long long R, int V, void* stream);
 int sf_cross_entropy_f32(const float* x, const long long* target, float* loss_rows, float* mean_out, long long R, int V,
                          void* stream);
+/* y = softmax((x + add) * scale) per row (add may be NULL): the Gumbel-softmax relaxation of steve_utils.py:26-41 with
+ * add = Gumbel noise, scale = 1/tau (steve_slotformer.py:97-98). */
+int sf_softmax_rows_f32(const float* x, const float* add, float scale, float* y, long long R, int V, void* stream);
 
 /* ---- whole-path engines ------------------------------------------------------------------ */
 

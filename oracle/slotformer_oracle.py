@@ -20,7 +20,7 @@ __all__ = [
     'rollouter_forward', 'single_step_rollouter_forward', 'slotformer_forward',
     'savi_decode', 'postproc_mask', 'rollout_video_slots', 'phyre_encode_rollout',
     'slot_mse_losses', 'dvae_logits', 'dvae_tokenize', 'dvae_detokenize', 'steve_decoder_forward',
-    'steve_decoder_generate', 'steve_forward_tokens',
+    'steve_decoder_generate', 'steve_forward_tokens', 'steve_slotformer_decode',
 ]
 
 
@@ -550,3 +550,18 @@ def steve_forward_tokens(img, slots, sd, cfg):
     logits = steve_decoder_forward(slots.flatten(0, 1), tgt[:, :-1], sd, dd['dec_num_heads'], dd['dec_num_layers'])
     loss = F.cross_entropy(logits.flatten(0, 1), tgt.flatten(0, 1))
     return {'pred_token_id': logits, 'target_token_id': tgt, 'token_recon_loss': loss}
+
+
+def steve_slotformer_decode(slots, sd, cfg, gumbel):
+    """STEVESlotFormer.decode (steve_slotformer.py:86-103): greedy token generation with the frozen decoder, the
+    Gumbel-softmax relaxation at tau = 0.1 with the noise `gumbel` [B,V,h,w] injected, dVAE detokenisation of the soft
+    and of the one-hot token maps."""
+    dd = cfg['dec_dict']
+    h = cfg['resolution'][0] // cfg['dvae_dict']['down_factor']
+    w = cfg['resolution'][1] // cfg['dvae_dict']['down_factor']
+    _, logits = steve_decoder_generate(slots, h * w, sd, dd['dec_num_heads'], dd['dec_num_layers'], p='decoder.')
+    logits = logits.transpose(2, 1).unflatten(-1, (h, w)).contiguous()
+    z = F.softmax((F.log_softmax(logits, dim=1) + gumbel) / 0.1, dim=1)
+    soft = dvae_detokenize(z, sd, 'dvae.')
+    hard = dvae_detokenize(torch.zeros_like(logits).scatter_(1, logits.argmax(1, keepdim=True), 1.), sd, 'dvae.')
+    return soft, hard

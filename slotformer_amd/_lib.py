@@ -96,6 +96,7 @@ SIGNATURES = {
     'sf_embed_tokens_f32': (I, [VP, FP, FP, FP, I, I, I, VP]),
     'sf_argmax_rows_f32': (I, [FP, LL, VP, LL, I, VP]),
     'sf_cross_entropy_f32': (I, [FP, VP, FP, FP, LL, I, VP]),
+    'sf_softmax_rows_f32': (I, [FP, FP, F32, FP, LL, I, VP]),
     'sf_packed_linear_bytes': (SZ, [I, I]),
     'sf_pack_linear_weights': (I, [FP, VP, I, I, VP]),
     'sf_ffn_packed_bytes': (SZ, [I, I]),

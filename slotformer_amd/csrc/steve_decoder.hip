@@ -206,6 +206,35 @@ __global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict_
   if (t == 0) loss[r] = logf((sh[0] + sh[1]) + (sh[2] + sh[3])) + mx - xr[tgt[r]];
 }
 
+// y[r] = softmax((x[r] + add[r]) * scale) over V columns; add may be null.  One workgroup per row.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                           float scale, float* __restrict__ y, int V) {
+  const long long r = blockIdx.x;
+  const float* xr = x + r * (long long)V;
+  const float* ar = add ? add + r * (long long)V : nullptr;
+  float* yr = y + r * (long long)V;
+  const int t = threadIdx.x;
+  __shared__ float sh[4];
+  float mx = -INFINITY;
+  for (int j = t; j < V; j += 256) mx = fmaxf(mx, (xr[j] + (ar ? ar[j] : 0.f)) * scale);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((t & 63) == 0) sh[t >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int j = t; j < V; j += 256) {
+    const float e = expf((xr[j] + (ar ? ar[j] : 0.f)) * scale - mx);
+    yr[j] = e;
+    se += e;
+  }
+  se = sf_sum64(se);
+  if ((t & 63) == 0) sh[t >> 6] = se;
+  __syncthreads();
+  const float inv = 1.0f / ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+  for (int j = t; j < V; j += 256) yr[j] *= inv;
+}
+
 // mean of n floats in a fixed order (single workgroup, double accumulation)
 __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, float* __restrict__ out, long long n) {
   __shared__ double sh[256];
@@ -266,6 +295,16 @@ int sf_argmax_rows_f32(const float* x, long long ld, long long* out, long long R
   SF_REQUIRE(x && out && R >= 0 && V > 0 && ld >= V, "sf_argmax_rows_f32: bad arguments");
   if (R == 0) return 0;
   hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)R), dim3(64), 0, (hipStream_t)stream, x, ld, out, V);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// y[r, :] = softmax((x[r, :] + add[r, :]) * scale); add may be NULL.  With add = Gumbel noise and scale = 1/tau this is
+// steve_utils.py:26-41 gumbel_softmax(log_softmax(x), tau) (the log-partition shift cancels in the softmax).
+int sf_softmax_rows_f32(const float* x, const float* add, float scale, float* y, long long R, int V, void* stream) {
+  SF_REQUIRE(x && y && R >= 0 && V > 0, "sf_softmax_rows_f32: bad arguments");
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, add, scale, y, V);
   SF_CHECK_LAUNCH();
   return 0;
 }

@@ -241,3 +241,12 @@ def cross_entropy(logits, target):
     mean = torch.empty(1, device=logits.device, dtype=torch.float32)
     check(lib().sf_cross_entropy_f32(_p(logits), target.data_ptr(), _p(rows), _p(mean), R, V, _stream()))
     return mean[0]
+
+
+def softmax_rows(x, add=None, scale=1.0):
+    """softmax((x + add) * scale) over the last dim."""
+    _chk(x, add)
+    V = x.shape[-1]
+    out = torch.empty_like(x)
+    check(lib().sf_softmax_rows_f32(_p(x), _p(add), float(scale), _p(out), x.numel() // V, V, _stream()))
+    return out

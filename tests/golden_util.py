@@ -115,6 +115,18 @@ def steve_tokens_cfg():
     return cfg
 
 
+def steve_slotformer_cfg():
+    """A reduced slotformer_physion_params.py: STEVESlotFormer on the steve_tokens_cfg() STEVE."""
+    sc = steve_tokens_cfg()
+    return dict(
+        model='STEVESlotFormer', resolution=sc['resolution'], input_frames=3,
+        slot_dict=dict(num_slots=4, slot_size=64), dvae_dict=dict(sc['dvae_dict']),
+        dec_dict=dict(dec_num_layers=2, dec_num_heads=4, dec_d_model=64, dec_ckp_path=''),
+        rollout_dict=dict(num_slots=4, slot_size=64, history_len=3, t_pe='sin', slots_pe='', d_model=64, num_layers=2,
+                          num_heads=4, ffn_dim=256, norm_first=True),
+        loss_dict=dict(rollout_len=2, use_img_recon_loss=True))
+
+
 # C4: Physion STEVE encoder side (steve_physion_params.py)
 C4_STEVE = savi_cfg(128, 6, slot_size=192, mlp=384, iters=2, pred='transformer', rnn=True,
                     enc_out=192, pred_ffn=768)

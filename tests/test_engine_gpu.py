@@ -151,6 +151,42 @@ def test_steve_image_side_golden(dev, precision):
         m.trans_decoder.generate(slots, steps=2, sample=True)
 
 
+@torch.no_grad()
+def test_steve_slotformer_golden(dev, tmp_path):
+    """STEVESlotFormer through the reference-shaped API: rollout, token logits / losses, and decode (greedy generation of
+    the 16x16 token grid, Gumbel-softmax with the reference's captured noise, dVAE detokenisation)."""
+    from slotformer_amd.base_slots import build_model as bb
+    from slotformer_amd.video_prediction import build_model as bv
+    g = gu.load_golden('steve_slotformer')
+    steve = bb(gu.ParamsView(gu.steve_tokens_cfg()))
+    path = str(tmp_path / 'steve.pth')
+    torch.save({'state_dict': steve.state_dict()}, path)
+    cfg = gu.steve_slotformer_cfg()
+    cfg['dec_dict']['dec_ckp_path'] = path
+    m = bv(gu.ParamsView(cfg))
+    shapes = gu.shapes_from_golden(g)
+    own = dict(m.state_dict())
+    assert [(k, tuple(v.shape)) for k, v in own.items()] == shapes
+    m.load_state_dict(gu.seeded_state_dict(shapes, 701, keep=own), strict=True)
+    m = m.eval().to(dev)
+    rd = cfg['rollout_dict']
+    T = rd['history_len'] + cfg['loss_dict']['rollout_len']
+    slots = gu.seeded_normal((1, T, rd['num_slots'], rd['slot_size']), 702).to(dev)
+    img = gu.seeded_img(1, T, 64, seed=703).to(dev)
+    out = m({'slots': slots, 'img': img})
+    assert rel_err(out['pred_slots'], g['pred_slots']) < RTOL
+    assert torch.equal(out['target_token_id'].cpu(), torch.from_numpy(g['target_token_id']))
+    assert rel_err(out['pred_token_id'], g['pred_token_id']) < RTOL
+    loss = m.calc_train_loss({'slots': slots, 'img': img}, out)
+    assert abs(float(loss['slot_recon_loss']) - float(g['slot_recon_loss'])) < 1e-3 * float(g['slot_recon_loss'])
+    assert abs(float(loss['img_recon_loss']) - float(g['img_recon_loss'])) < 1e-3 * float(g['img_recon_loss'])
+    soft, hard = m.decode(torch.from_numpy(g['pred_slots'][:, 0]).to(dev), gumbel=torch.from_numpy(g['gumbel']))
+    print('decode soft', rel_err(soft, g['soft_recon']), 'hard', rel_err(hard, g['hard_recon']))
+    assert rel_err(hard, g['hard_recon']) < RTOL and rel_err(soft, g['soft_recon']) < 5 * RTOL
+    s2, h2 = m.decode(torch.from_numpy(g['pred_slots'][:, 0]).to(dev))   # noise drawn on the device
+    assert torch.equal(h2, hard) and torch.isfinite(s2).all() and s2.shape == hard.shape
+
+
 @pytest.mark.parametrize('name,cfg,B,pred_len,seed', [
     ('roll_c1', gu.C1_ROLL, 3, 10, 201),
     ('roll_c2', gu.C2_ROLL, 2, 50, 202),

@@ -65,6 +65,27 @@ def test_steve_state_dict_contract():
     assert hot == gu.shapes_from_golden(gu.load_golden('steve_c4'))
 
 
+def test_steve_slotformer_state_dict_contract(tmp_path):
+    """STEVESlotFormer: `dvae.*`, `decoder.*` (the STEVE Transformer decoder, loaded from the `trans_decoder.*` keys of
+    a STEVE checkpoint and frozen), `rollouter.*` -- names, order and shapes of the reference class."""
+    from slotformer_amd.base_slots import build_model as bb
+    from slotformer_amd.video_prediction import build_model as bv
+    steve = bb(gu.ParamsView(gu.steve_tokens_cfg()))
+    path = str(tmp_path / 'steve.pth')
+    torch.save({'state_dict': steve.state_dict()}, path)
+    cfg = gu.steve_slotformer_cfg()
+    with pytest.raises(AssertionError):  # 'Please provide pretrained Transformer decoder weight' (steve_slotformer.py:77)
+        bv(gu.ParamsView(cfg))
+    cfg['dec_dict']['dec_ckp_path'] = path
+    m = bv(gu.ParamsView(cfg))
+    g = gu.load_golden('steve_slotformer')
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == gu.shapes_from_golden(g)
+    assert torch.equal(m.decoder.head.weight, steve.trans_decoder.head.weight)
+    assert not any(p.requires_grad for p in m.decoder.parameters())
+    m.train()
+    assert not m.decoder.training and not m.dvae.training
+
+
 def test_build_model_errors_match_reference():
     from slotformer_amd.base_slots import build_model as bb
     from slotformer_amd.video_prediction import build_model as bv

@@ -288,6 +288,58 @@ def case_steve_tokens(name, B, T, seed):
          gen_margin=(g2[..., 0] - g2[..., 1]), **meta)
 
 
+@torch.no_grad()
+def case_steve_slotformer(name, B, seed):
+    """Reference STEVESlotFormer: rollout + token loss (steve_slotformer.py:111-161) and decode (:86-103) with the Gumbel
+    noise captured (torch.manual_seed before the call; the first RNG draw inside is the Exp(1) tensor)."""
+    print(name)
+    scfg = gu.steve_tokens_cfg()
+    dv = dVAE(vocab_size=scfg['dvae_dict']['vocab_size'], img_channels=3)
+    dpath = os.path.join(TMP, 'dvae_sf.pth')
+    torch.save({'state_dict': dv.state_dict()}, dpath)
+    sfull = {k: (dict(v) if isinstance(v, dict) else v) for k, v in scfg.items()}
+    sfull['dvae_dict']['dvae_ckp_path'] = dpath
+    steve = ref_build_base(gu.ParamsView(sfull))
+    spath = os.path.join(TMP, 'steve_sf.pth')
+    torch.save({'state_dict': steve.state_dict()}, spath)
+    cfg = gu.steve_slotformer_cfg()
+    full = {k: (dict(v) if isinstance(v, dict) else v) for k, v in cfg.items()}
+    full['dvae_dict']['dvae_ckp_path'] = dpath
+    full['dec_dict']['dec_ckp_path'] = spath
+    m = ref_build_vp(gu.ParamsView(full)).eval()
+    sd = load_seeded(m, seed)
+    rd = cfg['rollout_dict']
+    T = rd['history_len'] + cfg['loss_dict']['rollout_len']
+    slots = gu.seeded_normal((B, T, rd['num_slots'], rd['slot_size']), seed + 1)
+    img = gu.seeded_img(B, T, cfg['resolution'][0], seed=seed + 2)
+    out = m({'slots': slots, 'img': img})
+    loss = m.calc_train_loss({'slots': slots, 'img': img}, out)
+    # decode one frame's slots; `.cuda()` inside decode is a no-op here (CPU reference run)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        torch.manual_seed(777)
+        soft, hard = m.decode(out['pred_slots'][:, 0])
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    torch.manual_seed(777)
+    V, h, w = cfg['dvae_dict']['vocab_size'], m.h, m.w
+    gumbel = -(torch.empty(B, V, h, w).exponential_() + torch.finfo(torch.float32).tiny).log()
+    osoft, ohard = oracle.steve_slotformer_decode(out['pred_slots'][:, 0], sd, cfg, gumbel)
+    print('  oracle decode soft', err(osoft, soft), 'hard', err(ohard, hard))
+    tgt = oracle.dvae_tokenize(img[:, rd['history_len']:].flatten(0, 1), sd, 'dvae.', one_hot=False).flatten(1, 2)
+    ol = oracle.steve_decoder_forward(out['pred_slots'].flatten(0, 1), tgt[:, :-1], sd, cfg['dec_dict']['dec_num_heads'],
+                                      cfg['dec_dict']['dec_num_layers'], p='decoder.')
+    print('  oracle token logits', err(ol, out['pred_token_id']), 'targets equal', bool(torch.equal(tgt, out['target_token_id'])))
+    meta = pack_meta(m, sd)
+    for k in list(meta):
+        if k.startswith('closed::') and k.endswith(gu.CLOSED_FORM_NOSTORE):
+            del meta[k]
+    save(name, pred_slots=out['pred_slots'], pred_token_id=out['pred_token_id'], target_token_id=out['target_token_id'],
+         slot_recon_loss=np.float64(float(loss['slot_recon_loss'])), img_recon_loss=np.float64(float(loss['img_recon_loss'])),
+         gumbel=gumbel, soft_recon=soft, hard_recon=hard, **meta)
+
+
 def build_slotformer(cfg, savi_seed=11):
     scfg = gu.savi_cfg(cfg['resolution'][0], cfg['slot_dict']['num_slots'],
                        slot_size=cfg['slot_dict']['slot_size'])
@@ -421,6 +473,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'steve_tokens':   # regenerate only this fixture
         case_steve_tokens('steve_tokens', B=1, T=2, seed=601)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'steve_slotformer':
+        case_steve_slotformer('steve_slotformer', B=1, seed=701)
+        return
     case_savi('savi_c1', gu.C1_SAVI, B=2, T=3, seed=101)
     case_savi('savi_c1_it3', gu.C1_SAVI_IT3, B=1, T=2, seed=102)
     case_savi('savi_c2', gu.C2_SAVI, B=2, T=3, seed=103, noise_seed=7)
@@ -436,6 +491,7 @@ def main():
     case_decode('decode_c2', gu.savi_cfg(64, 7, kernel_mlp=False, pred='mlp', rnn=False), Fr=2, seed=401)
     case_phyre('harness_h3', gu.C5_SAVI, gu.C5_ROLL, B=2, vid_len=5, seed=501)
     case_steve_tokens('steve_tokens', B=1, T=2, seed=601)
+    case_steve_slotformer('steve_slotformer', B=1, seed=701)
 
 
 if __name__ == '__main__':
