@@ -42,12 +42,14 @@ constexpr int QSTR = LF_HD + 4;                     // 36
 constexpr int OP = LF_HD + 8;                       // bf16 row pitch of the O and Wo planes (80 B = 5 slots)
 constexpr int XS = LF_HD + 4;                       // f32 pitch of the residual stash
 constexpr size_t A_PLANES = (size_t)(2 * FA_ROWS + 2 * NCP) * FA_LB * 2 + 2 * FA_ROWS * 4;              // 46,592
-constexpr size_t A_ATTN = ((size_t)2 * FA_ROWS * QSTR + (size_t)LF_HD * FA_SS + (size_t)FA_ROWS * FA_SS + FA_ROWS) * 4;
+// attention phase (over the dead planes): Q, K, V as [token][QSTR] f32 + softmax statistics of the 4 score waves
+constexpr size_t A_ATTN = ((size_t)3 * FA_ROWS * QSTR + 2 * 4 * 32) * 4;                                // 28,672
 constexpr size_t A_OUT = (size_t)(2 * FA_ROWS + 2 * LF_D) * OP * 2;                                       // 51,200
 constexpr size_t A_MAX1 = A_PLANES > A_ATTN ? A_PLANES : A_ATTN;
-constexpr size_t A_STASH_OFF = ((A_MAX1 > A_OUT ? A_MAX1 : A_OUT) + 255) / 256 * 256;
-constexpr size_t A_GB_OFF = A_STASH_OFF + (size_t)FA_ROWS * XS * 4;   // LN gamma | beta [2][256] f32
-constexpr size_t A_LDS = A_GB_OFF + 2 * LF_D * 4;
+constexpr size_t A_OT_OFF = ((A_MAX1 > A_OUT ? A_MAX1 : A_OUT) + 255) / 256 * 256;   // PV partials [4][32][QSTR] f32
+constexpr size_t A_STASH_OFF = A_OT_OFF + (size_t)4 * 32 * QSTR * 4;
+constexpr size_t A_GB_OFF = A_STASH_OFF + (size_t)FA_ROWS * XS * 4;   // LN gamma | beta [2][256] f32, then q|k|v bias [96]
+constexpr size_t A_LDS = A_GB_OFF + (2 * LF_D + NCP) * 4;
 
 // ---- FFN kernel geometry ----
 constexpr int FB_ROWS = 32;
@@ -97,7 +99,8 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   float* GB = (float*)((char*)smem + A_GB_OFF);
   f32x4 gbv = {0.f, 0.f, 0.f, 0.f};
   if (t < 128) gbv = *(const f32x4*)((t < 64 ? ln_g : ln_b) + 4 * (t & 63));
-  const float qkv_bias = bias[(wave % CBLK) * d + h * HD + (lane & 31)];
+  float qkvb = 0.f;   // q|k|v bias of this head: 96 values, staged in LDS after gamma/beta
+  if (t >= 128 && t < 128 + NC) qkvb = bias[((t - 128) >> 5) * d + h * HD + ((t - 128) & 31)];
   const float bov = bo[wave * 32 + (lane & 31)];
 
   // ---- issue every global load up front: weights first (they do not depend on the previous kernel's data) ----
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 
   LF_TA(17);
   if (t < 128) *(f32x4*)(GB + 4 * t) = gbv;
+  if (t >= 128 && t < 128 + NC) GB[2 * LF_D + (t - 128)] = qkvb;
   // ---- LayerNorm statistics from the registers (row r0+32*i is held by 16 consecutive lanes) ----
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
@@ -182,7 +186,8 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   __syncthreads();
   LF_TA(18);
 
-  // ---- q|k|v = LN(x) . W_h^T on split-bf16 MFMA: 6 blocks (2 row x 3 col) over waves 0..5 ----
+  // ---- q|k|v^T = W_h . LN(x)^T on split-bf16 MFMA (weights as the A operand): 6 blocks (q|k|v x token block) over
+  //      waves 0..5; a lane ends up with 4 CONSECUTIVE channels of one token -> 16-byte spills ----
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -210,14 +215,13 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
       for (int ks = 0; ks < FA_KC / 16; ++ks) {
         const bf16x8 xh = *(const bf16x8*)(Ah + ao + ks * 16), xl = *(const bf16x8*)(Al + ao + ks * 16);
         const bf16x8 yh = *(const bf16x8*)(Bh + bo_ + ks * 16), yl = *(const bf16x8*)(Bl + bo_ + ks * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl, xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xh, acc, 0, 0, 0);
       }
     }
     __syncthreads();
   }
-
   LF_TA(19);
   // out-proj slice Wo[:, 32h:32h+32] (256 rows x 8 float4): requested now, consumed after the attention phases
   f32x4 rwo[4];
@@ -225,114 +229,117 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
   for (int i = 0; i < 4; ++i) rwo[i] = *(const f32x4*)(wo + (long long)(n0 + 64 * i) * d + h * HD + 4 * c8);
 
-  // ---- spill q (scaled), k, v^T; the planes are dead ----
-  float* Qs = smem;
+  // ---- spill q (scaled), k, v as [token][channel] f32; the planes are dead ----
+  float* Qs = smem;                       // [64][QSTR]
   float* Ks = Qs + FA_ROWS * QSTR;
-  float* VT = Ks + FA_ROWS * QSTR;        // [32][FA_SS]
-  float* Ss = VT + HD * FA_SS;            // [64][FA_SS]
-  float* inv = Ss + FA_ROWS * FA_SS;      // [64]
+  float* Vs = Ks + FA_ROWS * QSTR;
+  float* SM = Vs + FA_ROWS * QSTR;        // [4 waves][32 queries] running max
+  float* SL = SM + 4 * 32;                // [4 waves][32 queries] sum of exp
+  float* OT = (float*)((char*)smem + A_OT_OFF);   // [4 waves][32 queries][QSTR] PV partials
   const float scale = 1.0f / sqrtf((float)HD);
   if (wave < nblk) {
-    const int rbk = wave / CBLK, cbk = wave - rbk * CBLK;   // cbk = which (0 q, 1 k, 2 v) since HD == 32
-    const int j = lane & 31;
-    const float bv = qkv_bias;   // cbk == wave % CBLK
+    const int rbk = wave / CBLK, cbk = wave - rbk * CBLK;   // cbk: 0 q, 1 k, 2 v (HD == 32)
+    float* dstm = (cbk == 0 ? Qs : (cbk == 1 ? Ks : Vs)) + (rbk * 32 + (lane & 31)) * QSTR + 4 * (lane >> 5);
+    const float mul = cbk == 0 ? scale : 1.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = rbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const float val = acc[r] + bv;
-      if (cbk == 0)
-        Qs[row * QSTR + j] = val * scale;
-      else if (cbk == 1)
-        Ks[row * QSTR + j] = val;
-      else
-        VT[j * FA_SS + row] = val;
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bv = *(const f32x4*)(GB + 2 * LF_D + cbk * 32 + 8 * g + 4 * (lane >> 5));
+      const f32x4 v = {(acc[4 * g] + bv[0]) * mul, (acc[4 * g + 1] + bv[1]) * mul, (acc[4 * g + 2] + bv[2]) * mul,
+                       (acc[4 * g + 3] + bv[3]) * mul};
+      *(f32x4*)(dstm + 8 * g) = v;
     }
-  }
-  if (nrb == 1) {
-    for (int idx = t; idx < HD * 32; idx += LF_NT) VT[(idx >> 5) * FA_SS + 32 + (idx & 31)] = 0.f;
   }
   __syncthreads();
   LF_TA(20);
 
-  // ---- scores on the f32 MFMA ----
-  if (wave < nrb * nrb) {
-    const int rbk = wave / nrb, cbk = wave - rbk * nrb;
-    f32x16 sacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-    const float* qp = Qs + (rbk * 32 + (lane & 31)) * QSTR + 4 * (lane >> 5);
-    const float* kp = Ks + (cbk * 32 + (lane & 31)) * QSTR + 4 * (lane >> 5);
-#pragma unroll
-    for (int kb = 0; kb < HD / 8; ++kb) {
-      const f32x4 a = *(const f32x4*)(qp + kb * 8), bq = *(const f32x4*)(kp + kb * 8);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[s], sacc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = rbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      Ss[row * FA_SS + cbk * 32 + (lane & 31)] = sacc[r];
-    }
-  }
-  __syncthreads();
-  LF_TA(21);
-
-  // ---- softmax over the L real keys, 8 lanes per query row ----
-  {
-    const int i = t >> 3, sub = t & 7;
-    const int kmax = nrb * 32;
-    if (i >= L - Lq && i < L) {
-      float* row = Ss + i * FA_SS;
-      float mx = -INFINITY;
-      for (int j = sub; j < L; j += 8) mx = fmaxf(mx, row[j]);
-      mx = sf_max8(mx);
-      float sum = 0.f;
-      for (int j = sub; j < kmax; j += 8) {
-        const float p = j < L ? expf(row[j] - mx) : 0.f;
-        row[j] = p;
-        sum += p;
-      }
-      sum = sf_sum8(sum);
-      if (sub == 0) inv[i] = 1.0f / sum;
-    }
-  }
-  __syncthreads();
-  LF_TA(22);
-
-  // ---- o = P v on the f32 MFMA (waves 0..nrb-1), kept in registers, rows outside the query range zeroed ----
+  // ---- scores TRANSPOSED, S^T[key][query] = k q^T, on the f32 MFMA: wave (qb, kb) = (wave >> 1, wave & 1).
+  //      A lane then holds 16 keys of ONE query column, so the softmax over keys is a per-lane reduction plus one
+  //      exchange with lane ^ 32, and p feeds the PV MFMA straight from registers (B operand: key pair (k, k+4)). ----
+  const int nsw = nrb * nrb;              // score waves: 4 (L > 32) or 1
   f32x16 oacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
-  if (wave < nrb) {
-    const float* pp = Ss + (wave * 32 + (lane & 31)) * FA_SS + 4 * (lane >> 5);
-    const float* vp = VT + (lane & 31) * FA_SS + 4 * (lane >> 5);
-    for (int kb = 0; kb < nrb * 4; ++kb) {
-      const f32x4 a = *(const f32x4*)(pp + kb * 8), bq = *(const f32x4*)(vp + kb * 8);
+  float m_w = -INFINITY, l_w = 0.f;
+  const int qb = (nrb == 2) ? (wave >> 1) : 0, kb = (nrb == 2) ? (wave & 1) : 0;
+  if (wave < nsw) {
+    f32x16 sacc;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[s], oacc, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    const float* kp = Ks + (kb * 32 + (lane & 31)) * QSTR + 4 * (lane >> 5);
+    const float* qp = Qs + (qb * 32 + (lane & 31)) * QSTR + 4 * (lane >> 5);
+#pragma unroll
+    for (int kq = 0; kq < HD / 8; ++kq) {
+      const f32x4 a = *(const f32x4*)(kp + kq * 8), bq = *(const f32x4*)(qp + kq * 8);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], bq[s2], sacc, 0, 0, 0);
     }
+    // softmax over the keys of this block for query column (lane & 31)
+    float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const bool q = row >= L - Lq && row < L;
-      oacc[r] = q ? oacc[r] * inv[q ? row : 0] : 0.f;
+      const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      sacc[r] = key < L ? sacc[r] : -INFINITY;
+      mx = fmaxf(mx, sacc[r]);
     }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sacc[r] = (mx == -INFINITY) ? 0.f : expf(sacc[r] - mx);   // a key block past L contributes nothing
+      sum += sacc[r];
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    m_w = mx;
+    l_w = sum;
+    if (lane < 32) {
+      SM[wave * 32 + lane] = mx;
+      SL[wave * 32 + lane] = sum;
+    }
+    // o^T[ch][query] partial over this key block: A = v[key pair][ch = lane & 31], B = p (register r = keys (k_r, k_r + 4))
+    const float* vp = Vs + (kb * 32 + 4 * (lane >> 5)) * QSTR + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[((r & 3) + 8 * (r >> 2)) * QSTR], sacc[r], oacc, 0, 0, 0);
   }
-  __syncthreads();  // Qs/Ks/VT/Ss are dead: the O and Wo planes take their place
+  __syncthreads();
+  LF_TA(21);
+  if (wave < nsw) {
+    // merge the two key blocks of a query block: rescale by exp(m - m_global) / l_global
+    float fsc;
+    if (nrb == 2) {
+      const float m_o = SM[(wave ^ 1) * 32 + (lane & 31)], l_o = SL[(wave ^ 1) * 32 + (lane & 31)];
+      const float mg = fmaxf(m_w, m_o);
+      const float fw = (m_w == -INFINITY) ? 0.f : expf(m_w - mg), fo = (m_o == -INFINITY) ? 0.f : expf(m_o - mg);
+      fsc = fw / (l_w * fw + l_o * fo);
+    } else {
+      fsc = 1.0f / l_w;
+    }
+    // oacc[4g+q2] = o^T[ch = 8g + 4(lane>>5) + q2][query = lane & 31]
+    float* od = OT + ((wave * 32) + (lane & 31)) * QSTR + 4 * (lane >> 5);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *(f32x4*)(od + 8 * g) = f32x4{oacc[4 * g] * fsc, oacc[4 * g + 1] * fsc, oacc[4 * g + 2] * fsc, oacc[4 * g + 3] * fsc};
+  }
+  __syncthreads();  // Qs/Ks/Vs are dead: the O and Wo planes take their place
   LF_TA(23);
 
   __bf16* Oh = (__bf16*)smem;             // [64][OP]
   __bf16* Ol = Oh + FA_ROWS * OP;
   __bf16* WoH = Ol + FA_ROWS * OP;        // [256][OP]
   __bf16* WoL = WoH + LF_D * OP;
-  if (wave < nrb) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const __bf16 hi = (__bf16)oacc[r];
-      Oh[row * OP + (lane & 31)] = hi;
-      Ol[row * OP + (lane & 31)] = (__bf16)(oacc[r] - (float)hi);
+  {
+    // O planes: token row = qb*32 + q, 8 float4 per row; sum of the two key-block partials; rows outside the query
+    // range are zeroed (they are never stored, but must stay finite)
+    const int row = t >> 3, q4 = t & 7;   // 64 rows x 8 float4 = 512 threads
+    const int qbr = row >> 5, qq = row & 31;
+    f32x4 v = zero4;
+    if (row < nrb * 32 && row >= L - Lq && row < L) {
+      if (nrb == 2)
+        v = *(const f32x4*)(OT + ((2 * qbr) * 32 + qq) * QSTR + 4 * q4) + *(const f32x4*)(OT + ((2 * qbr + 1) * 32 + qq) * QSTR + 4 * q4);
+      else
+        v = *(const f32x4*)(OT + qq * QSTR + 4 * q4);
     }
+    split4(Oh, Ol, row * OP + 4 * q4, v);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) split4(WoH, WoL, (n0 + 64 * i) * OP + 4 * c8, rwo[i]);
