@@ -1,0 +1,148 @@
+// First encoder convolution: 5x5, Cin = 3 (NCHW image) -> 64 channels (NHWC), stride 1 or 2, output 64 pixels wide
+// (savi.py:231-239, i == 0: 64x64 inputs at stride 1, 128x128 at stride 2).
+//
+// The generic path (gemm.hip, NCHW im2col loader) gathers every A element of the [pixels x 75] patch matrix with its
+// own global load and is loader-bound (39 us on the whole chip, 132 us on the encode partition for 32 frames).  Here
+// a workgroup owns 2 output rows: the 3-channel input halo (7 x 131 pixels at stride 2) is loaded once into LDS, the
+// patch matrix [128 pixels x 80] is built from it in LDS as split-bf16 planes, and one 32x32 MFMA block per wave
+// produces the 128 x 64 outputs (K = 75 padded to 80: 5 k16-steps x 3 MFMAs).
+#include "sf_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int CF_NT = 512, CF_CO = 64, CF_CI = 3, CF_KS = 5, CF_K = CF_CI * CF_KS * CF_KS, CF_KP = 80;   // 75 -> 80
+constexpr int CF_TW = 64, CF_TR = 2;
+constexpr int CF_PP = CF_KP + 8;   // bf16 row pitch of the patch / weight planes: 176 B = 11 slots (odd)
+
+template <int STRIDE>
+struct CfGeo {
+  static constexpr int HR = (CF_TR - 1) * STRIDE + CF_KS;       // halo rows
+  static constexpr int HC = (CF_TW - 1) * STRIDE + CF_KS;       // halo columns
+  static constexpr int HCP = (HC + 3) / 4 * 4 + 4;              // padded row pitch (floats)
+  static constexpr size_t lds = (size_t)CF_CI * HR * HCP * 4 + (size_t)2 * (CF_TR * CF_TW + CF_CO) * CF_PP * 2;
+};
+
+__device__ __forceinline__ void put4(__bf16* hp, __bf16* lp, int off, f32x4 v) {
+  const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+  const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+  *(bf16x4*)(hp + off) = hi;
+  *(bf16x4*)(lp + off) = lo;
+}
+}  // namespace
+
+template <int STRIDE>
+__global__ __launch_bounds__(CF_NT) void conv_first_kernel(const float* __restrict__ img, long long frame_stride,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           const float* __restrict__ add, float* __restrict__ out, int Ho,
+                                                           int Hin, int Win, int relu) {
+  using G = CfGeo<STRIDE>;
+  constexpr int HR = G::HR, HC = G::HC, HCP = G::HCP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* In = smem;                                       // [3][HR][HCP]
+  __bf16* Ah = (__bf16*)(In + CF_CI * HR * HCP);          // [128][CF_PP] patch matrix
+  __bf16* Al = Ah + CF_TR * CF_TW * CF_PP;
+  __bf16* Wh = Al + CF_TR * CF_TW * CF_PP;                // [64][CF_PP]
+  __bf16* Wl = Wh + CF_CO * CF_PP;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int tiles = Ho / CF_TR;
+  const int f = blockIdx.x / tiles, y0 = (blockIdx.x - f * tiles) * CF_TR;
+  const float* inf = img + (long long)f * frame_stride;
+
+  // ---- weights [64][75] -> split planes, k 75..79 zero ----
+  for (int idx = t; idx < CF_CO * (CF_KP / 4); idx += CF_NT) {
+    const int co = idx / (CF_KP / 4), k4 = idx - co * (CF_KP / 4);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 4 * k4 + e;
+      v[e] = k < CF_K ? w[co * CF_K + k] : 0.f;
+    }
+    put4(Wh, Wl, co * CF_PP + 4 * k4, v);
+  }
+  // ---- input halo: rows 2*y0 - 2 .., columns -2 ..; zero outside the image ----
+  for (int idx = t; idx < CF_CI * HR * HC; idx += CF_NT) {
+    const int c = idx / (HR * HC), rem = idx - c * (HR * HC);
+    const int r = rem / HC, j = rem - r * HC;
+    const int gy = y0 * STRIDE - 2 + r, gx = j - 2;
+    const bool ok = (unsigned)gy < (unsigned)Hin && (unsigned)gx < (unsigned)Win;
+    const float v = inf[((long long)c * Hin + min(max(gy, 0), Hin - 1)) * Win + min(max(gx, 0), Win - 1)];
+    In[(c * HR + r) * HCP + j] = ok ? v : 0.f;
+  }
+  __syncthreads();
+  // ---- patch matrix: entry (p, k) = In[c][STRIDE*row + ky][STRIDE*x + kx], k = c*25 + ky*5 + kx ----
+  {
+    const int p = t & 127, kg = t >> 7;          // pixel, group of 20 k values
+    const int row = p >> 6, x = p & 63;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = kg * 20 + 4 * q + e;
+        const int c = k / 25, r2 = k - c * 25, ky = r2 / 5, kx = r2 - ky * 5;
+        v[e] = k < CF_K ? In[(c * HR + STRIDE * row + ky) * HCP + STRIDE * x + kx] : 0.f;
+      }
+      put4(Ah, Al, p * CF_PP + kg * 20 + 4 * q, v);
+    }
+  }
+  __syncthreads();
+  // ---- [128 x 80] . [80 x 64]: wave = (row, 32-pixel block, 32-cout block) ----
+  const int row = wave >> 2, pxb = ((wave >> 1) & 1) * 32, cb = (wave & 1) * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int ao = (row * 64 + pxb + (lane & 31)) * CF_PP + 8 * (lane >> 5);
+  const int bo = (cb + (lane & 31)) * CF_PP + 8 * (lane >> 5);
+#pragma unroll
+  for (int ks = 0; ks < CF_KP / 16; ++ks) {
+    const bf16x8 xh = *(const bf16x8*)(Ah + ao + ks * 16), xl = *(const bf16x8*)(Al + ao + ks * 16);
+    const bf16x8 yh = *(const bf16x8*)(Wh + bo + ks * 16), yl = *(const bf16x8*)(Wl + bo + ks * 16);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
+  }
+  const int co = cb + (lane & 31);
+  const float bv = bias ? bias[co] : 0.f;
+  const float lo = relu ? 0.f : -INFINITY;
+  const int y = y0 + row;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int px = pxb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    float v = fmaxf(acc[r] + bv, lo);
+    if (add) v += add[((long long)y * CF_TW + px) * CF_CO + co];
+    out[(((long long)f * Ho + y) * CF_TW + px) * CF_CO + co] = v;
+  }
+}
+
+template <int STRIDE>
+static int launch_cf(const float* img, long long frame_stride, const float* w, const float* bias, const float* add,
+                     float* out, int F, int Ho, int Hin, int Win, int relu, hipStream_t st) {
+  auto kern = conv_first_kernel<STRIDE>;
+  constexpr size_t lds = CfGeo<STRIDE>::lds;
+  static_assert(lds <= 80 * 1024, "first conv: two workgroups per CU");
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    attr = true;
+  }
+  sf_prof_begin(SF_K_CONV_FIRST, st, 2.0 * (double)F * Ho * CF_TW * CF_CO * CF_K);
+  hipLaunchKernelGGL(kern, dim3(F * (Ho / CF_TR)), dim3(CF_NT), lds, st, img, frame_stride, w, bias, add, out, Ho, Hin, Win,
+                     relu);
+  sf_prof_end(SF_K_CONV_FIRST, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// Returns 1 when the specialised kernel does not apply (caller uses the implicit-GEMM path).
+int sf_conv_first_ex(const float* img, long long frame_stride, const float* w, const float* bias, const float* add,
+                     float* out, int F, int Cin, int Hin, int Win, int Cout, int ks, int stride, int relu, hipStream_t st) {
+  if (Cin != CF_CI || Cout != CF_CO || ks != CF_KS || F <= 0) return 1;
+  if (stride == 2 && Hin == 128 && Win == 128) return launch_cf<2>(img, frame_stride, w, bias, add, out, F, 64, Hin, Win, relu, st);
+  if (stride == 1 && Hin == 64 && Win == 64) return launch_cf<1>(img, frame_stride, w, bias, add, out, F, 64, Hin, Win, relu, st);
+  return 1;
+}

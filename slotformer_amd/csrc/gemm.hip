@@ -747,6 +747,15 @@ int sf_conv2d_nchw_in_f32(const float* img, long long frame_stride, const float*
                           int Win, int Cout, int ks, int stride, int relu, void* stream) {
   SF_REQUIRE(img && weight && out, "null pointer");
   SF_REQUIRE(F >= 0 && Cin > 0 && Hin > 0 && Win > 0 && Cout > 0 && (ks & 1) && stride >= 1, "bad conv shape");
+  if (sf_get_precision() == 1 && forced_cfg() < 0) {
+    // 3 -> 64 channels, 5x5, 64-wide output: input halo + patch matrix in LDS (conv_first.hip); SF_CONV_FIRST=0 disables
+    static const bool on = []() { const char* e = getenv("SF_CONV_FIRST"); return !(e && e[0] == '0'); }();
+    if (on) {
+      const int rc = sf_conv_first_ex(img, frame_stride, weight, bias, add, out, F, Cin, Hin, Win, Cout, ks, stride, relu,
+                                      (hipStream_t)stream);
+      if (rc != 1) return rc;
+    }
+  }
   const int pad = ks / 2;
   const int Ho = (Hin + 2 * pad - ks) / stride + 1, Wo = (Win + 2 * pad - ks) / stride + 1;
   SfGemmArgs a;
