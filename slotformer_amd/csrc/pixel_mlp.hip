@@ -21,7 +21,7 @@ constexpr int PM_NT = 512, PM_ROWS = 128, PM_C0 = 64, PM_C1 = 128, PM_ND = 256;
 constexpr int PM_LB0 = PM_C0 + 8, PM_LB1 = PM_C1 + 8;                 // bf16 row strides (odd # of 16-B slots)
 constexpr int PM_PLANE = PM_ROWS * PM_LB1;                             // elements of one (largest) plane
 constexpr int PM_H2S = PM_C1 + 4;                                      // f32 row stride of the LN(128) input tile
-constexpr size_t PM_LDS = (size_t)4 * PM_PLANE * sizeof(__bf16) + 2 * PM_ROWS * sizeof(float);
+constexpr size_t PM_LDS = (size_t)4 * PM_PLANE * sizeof(__bf16) + (2 * PM_ROWS + 4 * PM_C1) * sizeof(float);
 static_assert((size_t)PM_ROWS * PM_H2S * 4 <= (size_t)2 * PM_PLANE * 2, "f32 tile must fit in the B planes");
 }  // namespace
 
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(PM_NT) void pixel_mlp_kv_kernel(
   __bf16* Bh = Al + PM_PLANE;     // B planes (weights); also the f32 h2 tile
   __bf16* Bl = Bh + PM_PLANE;
   float* stats = (float*)(Bl + PM_PLANE);  // [2][128]
+  float* PV = stats + 2 * PM_ROWS;         // b1 | b2 | ln1 gamma | ln1 beta, 128 floats each
   float* H2 = (float*)Bh;                  // [128][PM_H2S] f32 (aliases both B planes)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m0 = blockIdx.x * PM_ROWS;
@@ -45,8 +46,16 @@ __global__ __launch_bounds__(PM_NT) void pixel_mlp_kv_kernel(
     lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
   };
 
-  // ---- P0: x tile and W1 (16 float4 per 64-wide row); LN(64) statistics straight from the registers --------
+  // small parameter vectors first: vmcnt retires in order, so a request issued after the weight tiles would wait for
+  // all of them (measured on the rollout kernels: 2-4 us per late load)
   const int c4 = t & 15, r0 = t >> 4;  // rows r0 + 32*i
+  const f32x4 g0 = *(const f32x4*)(ln0_g + 4 * c4), be0 = *(const f32x4*)(ln0_b + 4 * c4);
+  float pvv = 0.f;
+  {
+    const float* src = (t < 128) ? b1 : (t < 256) ? b2 : (t < 384) ? ln1_g : ln1_b;
+    pvv = src[t & 127];
+  }
+  // ---- P0: x tile and W1 (16 float4 per 64-wide row); LN(64) statistics straight from the registers --------
   f32x4 xr[4], wr1[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -59,18 +68,15 @@ __global__ __launch_bounds__(PM_NT) void pixel_mlp_kv_kernel(
   f32x4 wr2[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) wr2[i] = *(const f32x4*)(w2 + (long long)(q0 + 16 * i) * PM_C1 + 4 * d4);
+  PV[t] = pvv;
   {
-    const f32x4 g = *(const f32x4*)(ln0_g + 4 * c4), be = *(const f32x4*)(ln0_b + 4 * c4);
+    const f32x4 g = g0, be = be0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float s = (xr[i][0] + xr[i][1]) + (xr[i][2] + xr[i][3]);
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);  // the 16 lanes holding this row
+      const float s = sf_sum16((xr[i][0] + xr[i][1]) + (xr[i][2] + xr[i][3]));  // the 16 lanes holding this row
       const float mean = s * (1.0f / PM_C0);
       const f32x4 dv = xr[i] - mean;
-      float vs = (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) vs += __shfl_xor(vs, o, 64);
+      const float vs = sf_sum16((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]));
       const float rstd = 1.0f / sqrtf(vs * (1.0f / PM_C0) + eps);
       bf16x4 hi, lo;
       split4(dv * rstd * g + be, hi, lo);
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(PM_NT) void pixel_mlp_kv_kernel(
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = (cb0 + j) * 32 + (lane & 31);
-    const float bv = b1[n];
+    const float bv = PV[n];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(PM_NT) void pixel_mlp_kv_kernel(
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = (cb0 + j) * 32 + (lane & 31);
-    const float bv = b2[n];
+    const float bv = PV[PM_C1 + n];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -161,8 +167,8 @@ __global__ __launch_bounds__(PM_NT) void pixel_mlp_kv_kernel(
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += (hv[i][0] + hv[i][1]) + (hv[i][2] + hv[i][3]);
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
+    s += sf_dpp<0xB1>(s);   // the 4 lanes holding this row
+    s += sf_dpp<0x4E>(s);
     const float mean = s * (1.0f / PM_C1);
     float vs = 0.f;
 #pragma unroll
@@ -170,13 +176,13 @@ __global__ __launch_bounds__(PM_NT) void pixel_mlp_kv_kernel(
       const f32x4 dv = hv[i] - mean;
       vs += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
     }
-    vs += __shfl_xor(vs, 1, 64);
-    vs += __shfl_xor(vs, 2, 64);
+    vs += sf_dpp<0xB1>(vs);
+    vs += sf_dpp<0x4E>(vs);
     const float rstd = 1.0f / sqrtf(vs * (1.0f / PM_C1) + eps);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c = part * 32 + 4 * i;
-      const f32x4 g = *(const f32x4*)(ln1_g + c), be = *(const f32x4*)(ln1_b + c);
+      const f32x4 g = *(const f32x4*)(PV + 2 * PM_C1 + c), be = *(const f32x4*)(PV + 3 * PM_C1 + c);
       bf16x4 hi, lo;
       split4((hv[i] - mean) * rstd * g + be, hi, lo);
       *(bf16x4*)(Ah + row * PM_LB1 + c) = hi;
