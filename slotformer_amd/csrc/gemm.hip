@@ -358,8 +358,7 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (q < nk) s += (RR[q].ra[i][0] + RR[q].ra[i][1]) + (RR[q].ra[i][2] + RR[q].ra[i][3]);  // k >= K loads are 0
-#pragma unroll
-        for (int o = 1; o < C4N; o <<= 1) s += __shfl_xor(s, o, 64);
+        s = sf_group_sum<C4N>(s);
         const float mean = s / (float)K;
         float vs = 0.f;
 #pragma unroll
@@ -368,8 +367,7 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
             const f32x4 dv = RR[q].ra[i] - mean;
             vs += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
           }
-#pragma unroll
-        for (int o = 1; o < C4N; o <<= 1) vs += __shfl_xor(vs, o, 64);
+        vs = sf_group_sum<C4N>(vs);
         if (c4 == 0) {
           stats[r0 + i * RS] = mean;
           stats[BM + r0 + i * RS] = 1.0f / sqrtf(vs / (float)K + p.ln_eps);
@@ -402,8 +400,7 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
         s += (v[0] + v[1]) + (v[2] + v[3]);
       }
     }
-#pragma unroll
-    for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    s = sf_group_sum<TPR>(s);
     const float mean = s / (float)K;
     float vs = 0.f;
     {
@@ -413,8 +410,7 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
         vs += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
       }
     }
-#pragma unroll
-    for (int o = TPR / 2; o > 0; o >>= 1) vs += __shfl_xor(vs, o, 64);
+    vs = sf_group_sum<TPR>(vs);
     if (sub == 0) {
       stats[r] = mean;
       stats[BM + r] = 1.0f / sqrtf(vs / (float)K + p.ln_eps);

@@ -53,17 +53,6 @@ __device__ __forceinline__ long long sf_row_off(const SfRowMap& m, int row) {
   return m.base + (long long)b * m.batch_stride + (long long)r * m.ld;
 }
 
-__device__ __forceinline__ float sf_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float sf_wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
 // ---- DPP reductions (one v_add_f32_dpp per step instead of a ds_bpermute round trip through LDS) ----
 // quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
 template <int CTRL>
@@ -94,6 +83,31 @@ __device__ __forceinline__ float sf_sum64(float v) {
   const int b = __builtin_bit_cast(int, v);
   return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
          (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
+
+__device__ __forceinline__ float sf_max16(float v) {
+  v = sf_max8(v);
+  return fmaxf(v, sf_dpp<0x140>(v));
+}
+// all-reduce over aligned groups of W lanes (W a power of two); all lanes of the group must be active
+template <int W>
+__device__ __forceinline__ float sf_group_sum(float v) {
+  static_assert(W >= 1 && W <= 64 && (W & (W - 1)) == 0, "group width");
+  if constexpr (W >= 2) v += sf_dpp<0xB1>(v);
+  if constexpr (W >= 4) v += sf_dpp<0x4E>(v);
+  if constexpr (W >= 8) v += sf_dpp<0x141>(v);
+  if constexpr (W >= 16) v += sf_dpp<0x140>(v);
+  if constexpr (W >= 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (W >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+// whole-wave all-reduces (every lane of a fully active wave gets the result)
+__device__ __forceinline__ float sf_wave_sum(float v) { return sf_sum64(v); }
+__device__ __forceinline__ float sf_wave_max(float v) {
+  v = sf_max16(v);
+  const int b = __builtin_bit_cast(int, v);
+  return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))),
+               fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48))));
 }
 
 __device__ __forceinline__ float sf_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
