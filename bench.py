@@ -267,14 +267,19 @@ def main():
                 return torch.cuda.ExternalStream(h.value, device=dev)
 
             if cu_split:
-                s_enc = masked_stream(cu_words)
-                if roll_masks:
-                    s_rolls = [masked_stream([w] * 8) for w in roll_masks]
-                elif os.environ.get('SF_BENCH_ROLL_UNMASKED', '0') == '1':  # experiment: rollout free to use every CU
-                    s_rolls = [torch.cuda.Stream(device=dev, priority=prio)]
-                else:
-                    s_rolls = [masked_stream([~w for w in cu_words])]
-            else:
+                try:
+                    s_enc = masked_stream(cu_words)
+                    if roll_masks:
+                        s_rolls = [masked_stream([w] * 8) for w in roll_masks]
+                    elif os.environ.get('SF_BENCH_ROLL_UNMASKED', '0') == '1':  # experiment: rollout free to use every CU
+                        s_rolls = [torch.cuda.Stream(device=dev, priority=prio)]
+                    else:
+                        s_rolls = [masked_stream([~w for w in cu_words])]
+                except RuntimeError as e:  # CU masking unavailable: keep the pipeline, on shared CUs (and say so)
+                    print(f'[bench] rank {rank}: CU-masked streams unavailable ({e}); pipelining on shared CUs', file=sys.stderr)
+                    cu_split = False
+            if not cu_split:
+                n_rs = min(n_rs, NB - 1)
                 s_rolls = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(n_rs)]
 
             def run_pipelined(n):
@@ -512,7 +517,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             log('cpu baseline ...')
             res['cpu_baseline'] = cpu_baseline(args.cpu_sample)
-        print(json.dumps(res))
+        # RCCL prints its version banner through C stdio (flushed at exit when stdout is a pipe): push it out first so
+        # that the JSON line is the last thing on stdout
+        try:
+            C.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()
 
