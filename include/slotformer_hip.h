@@ -153,7 +153,15 @@ typedef struct {
    * has them (d_model 256, 8 heads, ffn 1024, norm_first, split-bf16 mode) sf_rollout_f32 runs each layer as two
    * launches (attention + out-proj partials; FFN1 + FFN2) instead of four. */
   const void *lin1_packed, *lin2_packed;
+  /* optional, same rule: sf_pack_attn_weights() copies of in_proj_w / out_proj_w */
+  const void *attn_in_packed, *attn_out_packed;
 } sf_tfm_layer;
+
+/* Pre-split attention weights (d_model 256, 8 heads) in MFMA-fragment order: in_packed needs
+ * sf_attn_packed_bytes(d, 0) bytes, out_packed sf_attn_packed_bytes(d, 1). */
+size_t sf_attn_packed_bytes(int d_model, int which);
+int sf_pack_attn_weights(const float* in_proj_w, const float* out_proj_w, void* in_packed, void* out_packed, int d_model,
+                         int num_heads, void* stream);
 
 /* Pre-split (bf16 hi/lo) FFN weights in MFMA-fragment order; each output needs sf_ffn_packed_bytes() bytes. */
 size_t sf_ffn_packed_bytes(int d_model, int ffn);

@@ -15,7 +15,7 @@ FP = C.c_void_p  # device float*
 class sf_tfm_layer(C.Structure):
     _fields_ = [(n, FP) for n in (
         'norm1_g', 'norm1_b', 'in_proj_w', 'in_proj_b', 'out_proj_w', 'out_proj_b',
-        'norm2_g', 'norm2_b', 'lin1_w', 'lin1_b', 'lin2_w', 'lin2_b', 'lin1_packed', 'lin2_packed')]
+        'norm2_g', 'norm2_b', 'lin1_w', 'lin1_b', 'lin2_w', 'lin2_b', 'lin1_packed', 'lin2_packed', 'attn_in_packed', 'attn_out_packed')]
 
 
 class sf_rollouter(C.Structure):
@@ -99,6 +99,8 @@ SIGNATURES = {
     'sf_softmax_rows_f32': (I, [FP, FP, F32, FP, LL, I, VP]),
     'sf_packed_linear_bytes': (SZ, [I, I]),
     'sf_pack_linear_weights': (I, [FP, VP, I, I, VP]),
+    'sf_attn_packed_bytes': (SZ, [I, I]),
+    'sf_pack_attn_weights': (I, [FP, FP, VP, VP, I, I, VP]),
     'sf_ffn_packed_bytes': (SZ, [I, I]),
     'sf_pack_ffn_weights': (I, [FP, FP, VP, VP, I, I, VP]),
     'sf_kv_producer_workspace_bytes': (SZ, [I, I]),

@@ -157,7 +157,7 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   TfmWs tw;
   if (!x || !tfm_ws_take(bp, tw, B * Lmax, d, m->ffn_dim))
     return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
-  float* apb = bp.take((size_t)8 * B * Lmax * d);
+  float* apb = bp.take((size_t)8 * B * Lmax * d);   // head-pair partials use the first 4
   float* xpb = bp.take((size_t)4 * B * Lmax * d);
   float* xa = bp.take((size_t)B * Lmax * d);
   float* xb2 = bp.take((size_t)B * Lmax * d);
@@ -171,7 +171,8 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
     return !(e && e[0] == '0');
   }();
   bool packed = true;
-  for (int l = 0; l < m->num_layers; ++l) packed = packed && m->layers[l].lin1_packed && m->layers[l].lin2_packed;
+  for (int l = 0; l < m->num_layers; ++l)
+    packed = packed && m->layers[l].lin1_packed && m->layers[l].lin2_packed && m->layers[l].attn_in_packed && m->layers[l].attn_out_packed;
   const bool fused_layers = packed && fused_env && sf_get_precision() == 1 && m->norm_first &&
                             sf_layer_fused_ok(d, m->num_heads, m->ffn_dim, Lmax);
   // step boundary in one launch (out-proj of step s + in-proj of the new frame for step s+1) with cached in-projections

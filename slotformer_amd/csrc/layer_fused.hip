@@ -29,6 +29,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 constexpr int LF_NT = 512;
 constexpr int LF_D = 256, LF_HD = 32, LF_NH = 8;   // model width, head width, heads
+constexpr int LF_NP = 4;                            // head-PAIR partials written by the attention kernel
 constexpr int LF_HC = 256;                          // hidden chunk of the FFN kernel
 constexpr int LF_NCH = 4;                           // ffn / LF_HC (ffn = 1024)
 
@@ -70,55 +71,109 @@ __device__ long long lf_ts[32];   // phase timestamps of one workgroup (SF_LF_DB
 #define LF_TA(i) do { if ((dbg & 16) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) lf_ts[i] = wall_clock64(); } while (0)
 
 // ================================================================================================
+// Attention + out-projection of TWO heads per workgroup (grid: 4 head pairs x B videos = 128 workgroups at B = 32, so
+// every workgroup has a CU to itself even on the 192-CU rollout partition; with one head per workgroup 64 CUs ran two
+// and the kernel took 22 us there vs 16.7 us on the whole chip).
+//
 // x: layer input rows.  RING = false: xin [B][L][256] contiguous.  RING = true (layer 0 of a rollout step): the rows are
 // the cached in-projections of the window's frames, held in a ring of `ring_frames` frames per video
 // (xin [B][ring_frames][nslots][256], window starts at frame f0), plus the per-token position table pe [L][256]
-// (slotformer.py:115-117: x = in_proj(window) + pe).  ap [8][B*Lq][256] head partials.
+// (slotformer.py:115-117: x = in_proj(window) + pe).  ap [4][B*Lq][256]: head-pair partials of the out-projection.
+//
+// Packed weights (sf_pack_attn_weights), split-bf16 in MFMA-fragment order, loaded straight into registers:
+//   q|k|v:    uint4 index = ((((hp*6 + cb)*16 + ks)*2 + plane)*64 + lane)
+//             element j = in_proj_w[(cb % 3)*256 + (2 hp + cb / 3)*32 + (lane & 31)][ks*16 + 8 (lane >> 5) + j]
+//   out-proj: uint4 index = ((((hp*4 + ks)*8 + nb)*2 + plane)*64 + lane)
+//             element j = out_proj_w[nb*32 + (lane & 31)][hp*64 + ks*16 + 8 (lane >> 5) + j]
+constexpr int A2_AP = LF_D + 8;                 // bf16 pitch of the LN(x) planes (528 B = 33 slots)
+constexpr int A2_OP = 2 * LF_HD + 8;            // bf16 pitch of the O planes (144 B = 9 slots)
+constexpr int A2_XS = 2 * LF_HD + 4;            // f32 pitch of the residual stash
+constexpr size_t A2_QKV_OFF = 0;                                             // [2 heads][q,k,v][64][QSTR] f32 (over the planes)
+constexpr size_t A2_PLANES = (size_t)2 * FA_ROWS * A2_AP * 2;               // 67,584
+constexpr size_t A2_ST_OFF = A2_PLANES;                                      // softmax stats [2][8][32] f32
+constexpr size_t A2_OT_OFF = A2_ST_OFF + 2 * 8 * 32 * 4;                     // PV partials [8][32][QSTR] f32
+constexpr size_t A2_O_OFF = A2_OT_OFF + (size_t)8 * 32 * QSTR * 4;           // O planes [2][64][A2_OP] bf16
+constexpr size_t A2_XS_OFF = A2_O_OFF + (size_t)2 * FA_ROWS * A2_OP * 2;     // residual stash [64][A2_XS] f32
+constexpr size_t A2_GB_OFF = A2_XS_OFF + (size_t)FA_ROWS * A2_XS * 4;        // LN gamma | beta [2][256], q|k|v bias [192]
+constexpr size_t A2_LDS = A2_GB_OFF + (2 * LF_D + 6 * 32) * 4;
+static_assert((size_t)2 * 3 * FA_ROWS * QSTR * 4 <= A2_PLANES, "q/k/v tiles must fit over the dead LN(x) planes");
+
+__global__ void pack_attn_kernel(const float* __restrict__ win, const float* __restrict__ wo, uint4* __restrict__ pq,
+                                 uint4* __restrict__ po) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = idx & 63, plane = (idx >> 6) & 1;
+  union {
+    __bf16 h[8];
+    uint4 u;
+  } o;
+  if (idx < 4 * 6 * 16 * 2 * 64) {
+    const int ks = (idx >> 7) & 15, cb = (idx >> 11) % 6, hp = (idx >> 11) / 6;
+    const float* src = win + (long long)((cb % 3) * LF_D + (2 * hp + cb / 3) * LF_HD + (lane & 31)) * LF_D + ks * 16 + 8 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = src[j];
+      const __bf16 ah = (__bf16)a;
+      o.h[j] = plane ? (__bf16)(a - (float)ah) : ah;
+    }
+    pq[idx] = o.u;
+  }
+  if (idx < 4 * 4 * 8 * 2 * 64) {
+    const int nb = (idx >> 7) & 7, ks = (idx >> 10) & 3, hp = idx >> 12;
+    const float* src = wo + (long long)(nb * 32 + (lane & 31)) * LF_D + hp * 64 + ks * 16 + 8 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = src[j];
+      const __bf16 ah = (__bf16)a;
+      o.h[j] = plane ? (__bf16)(a - (float)ah) : ah;
+    }
+    po[idx] = o.u;
+  }
+}
+
 template <bool RING>
-__global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_oproj_kernel(const float* __restrict__ xin, long long x_batch_stride,
+__global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restrict__ xin, long long x_batch_stride,
                                                            const float* __restrict__ pe, int f0, int ring_frames, int nslots,
-                                                           const float* __restrict__ ln_g,
-                                                           const float* __restrict__ ln_b, float ln_eps,
-                                                           const float* __restrict__ w, const float* __restrict__ bias,
-                                                           const float* __restrict__ wo, const float* __restrict__ bo,
-                                                           float* __restrict__ ap, long long ap_stride, int L, int Lq, int dbg) {
+                                                           const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                           float ln_eps, const uint4* __restrict__ wqkv_p,
+                                                           const float* __restrict__ bias, const uint4* __restrict__ wo_p,
+                                                           const float* __restrict__ bo, float* __restrict__ ap,
+                                                           long long ap_stride, int L, int Lq, int dbg) {
   constexpr int d = LF_D, HD = LF_HD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __bf16* Ah = (__bf16*)smem;
-  __bf16* Al = Ah + FA_ROWS * FA_LB;
-  __bf16* Bh = Al + FA_ROWS * FA_LB;
-  __bf16* Bl = Bh + NCP * FA_LB;
-  float* stats = (float*)(Bl + NCP * FA_LB);  // [2][64]
-  float* Xs = (float*)((char*)smem + A_STASH_OFF);  // [64][XS]: x[:, 32h:32h+32] for the residual
-  const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  __bf16* Ah = (__bf16*)smem;                                  // [64][A2_AP]  LN1(x), all of K
+  __bf16* Al = Ah + FA_ROWS * A2_AP;
+  float* QKV = (float*)((char*)smem + A2_QKV_OFF);             // [2][3][64][QSTR]
+  float* SM = (float*)((char*)smem + A2_ST_OFF);               // [8][32] running max
+  float* SL = SM + 8 * 32;                                     // [8][32] sum of exp
+  float* OT = (float*)((char*)smem + A2_OT_OFF);               // [8][32][QSTR]
+  __bf16* Oh = (__bf16*)((char*)smem + A2_O_OFF);              // [64][A2_OP]  (k = head * 32 + channel)
+  __bf16* Ol = Oh + FA_ROWS * A2_OP;
+  float* Xs = (float*)((char*)smem + A2_XS_OFF);               // [64][A2_XS]: x[:, 64 hp : 64 hp + 64]
+  float* GB = (float*)((char*)smem + A2_GB_OFF);
+  const int hp = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const float* xb = xin + (long long)b * x_batch_stride;
   const int c4 = t & 15, r0 = t >> 4;
   LF_TA(16);
-  // small parameter vectors first (vmcnt retires in order: a late request would queue behind the weight tiles):
-  // LN gamma/beta -> LDS, the q|k|v bias of this wave's column block and the out-proj bias -> registers
-  float* GB = (float*)((char*)smem + A_GB_OFF);
+  // ---- small parameter vectors first (vmcnt retires in order) ----
   f32x4 gbv = {0.f, 0.f, 0.f, 0.f};
   if (t < 128) gbv = *(const f32x4*)((t < 64 ? ln_g : ln_b) + 4 * (t & 63));
-  float qkvb = 0.f;   // q|k|v bias of this head: 96 values, staged in LDS after gamma/beta
-  if (t >= 128 && t < 128 + NC) qkvb = bias[((t - 128) >> 5) * d + h * HD + ((t - 128) & 31)];
-  const float bov = bo[wave * 32 + (lane & 31)];
-
-  // ---- issue every global load up front: weights first (they do not depend on the previous kernel's data) ----
-  const float* wrow[B_IT];
-  bool wok[B_IT];
-#pragma unroll
-  for (int i = 0; i < B_IT; ++i) {
-    const int n = r0 + 32 * i;
-    const int which = n / HD, j = n - which * HD;
-    wok[i] = n < NC;
-    wrow[i] = w + (long long)(wok[i] ? which * d + h * HD + j : 0) * d;
+  float qkvb = 0.f;   // q|k|v bias of the two heads: column block cb = (head, which) -> 6 x 32 values
+  if (t >= 128 && t < 128 + 192) {
+    const int cb = (t - 128) >> 5, j = (t - 128) & 31;
+    qkvb = bias[(cb % 3) * d + (2 * hp + cb / 3) * HD + j];
   }
-  f32x4 rb[NK][B_IT];
+  const float bov = bo[wave * 32 + (lane & 31)];
+  // ---- q|k|v weight fragments of column block `wave` (waves 0..5): 16 k-steps x (hi, lo) = 128 VGPRs ----
+  bf16x8 wq[16][2];
+  if (wave < 6) {
+    const uint4* wp = wqkv_p + (((long long)(hp * 6 + wave) * 16) * 2) * 64 + lane;
 #pragma unroll
-  for (int kc = 0; kc < NK; ++kc)
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) rb[kc][i] = *(const f32x4*)(wrow[i] + kc * FA_KC + 4 * c4);
-  // activations (+ position table in ring mode)
+    for (int ks = 0; ks < 16; ++ks) {
+      wq[ks][0] = __builtin_bit_cast(bf16x8, wp[(ks * 2) * 64]);
+      wq[ks][1] = __builtin_bit_cast(bf16x8, wp[(ks * 2 + 1) * 64]);
+    }
+  }
+  // ---- activations (+ position table in ring mode) ----
   bool aok[A_IT];
   const float* arow[A_IT];
   const float* prow[A_IT];
@@ -152,47 +207,33 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) ra[kc][i] += tp[kc][i];
   }
-  // residual stash: the 32 columns of block h live in chunk h/2, float4 columns 8*(h&1) .. +7
-#pragma unroll
-  for (int kc = 0; kc < NK; ++kc)
-    if (kc == (h >> 1) && (c4 >> 3) == (h & 1)) {
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) *(f32x4*)(Xs + (r0 + 32 * i) * XS + 4 * (c4 & 7)) = ra[kc][i];
-    }
-
   LF_TA(17);
   if (t < 128) *(f32x4*)(GB + 4 * t) = gbv;
-  if (t >= 128 && t < 128 + NC) GB[2 * LF_D + (t - 128)] = qkvb;
-  // ---- LayerNorm statistics from the registers (row r0+32*i is held by 16 consecutive lanes) ----
+  if (t >= 128 && t < 128 + 192) GB[2 * LF_D + (t - 128)] = qkvb;
+  // residual stash: the 64 columns of this head pair are chunk kc == hp
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc)
+    if (kc == hp) {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) *(f32x4*)(Xs + (r0 + 32 * i) * A2_XS + 4 * c4) = ra[kc][i];
+    }
+  // LayerNorm statistics from the registers (row r0+32*i is held by 16 consecutive lanes; all of them get the result)
+  float mean[A_IT], rstd[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    float s = 0.f;
+    float sm = 0.f;
 #pragma unroll
-    for (int kc = 0; kc < NK; ++kc) s += (ra[kc][i][0] + ra[kc][i][1]) + (ra[kc][i][2] + ra[kc][i][3]);
-    s = sf_sum16(s);
-    const float mean = s / (float)d;
+    for (int kc = 0; kc < NK; ++kc) sm += (ra[kc][i][0] + ra[kc][i][1]) + (ra[kc][i][2] + ra[kc][i][3]);
+    mean[i] = sf_sum16(sm) / (float)d;
     float vs = 0.f;
 #pragma unroll
     for (int kc = 0; kc < NK; ++kc) {
-      const f32x4 dv = ra[kc][i] - mean;
+      const f32x4 dv = ra[kc][i] - mean[i];
       vs += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
     }
-    vs = sf_sum16(vs);
-    if (c4 == 0) {
-      stats[r0 + 32 * i] = mean;
-      stats[FA_ROWS + r0 + 32 * i] = 1.0f / sqrtf(vs / (float)d + ln_eps);
-    }
+    rstd[i] = 1.0f / sqrtf(sf_sum16(vs) / (float)d + ln_eps);
   }
-  __syncthreads();
-  LF_TA(18);
-
-  // ---- q|k|v^T = W_h . LN(x)^T on split-bf16 MFMA (weights as the A operand): 6 blocks (q|k|v x token block) over
-  //      waves 0..5; a lane ends up with 4 CONSECUTIVE channels of one token -> 16-byte spills ----
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int nrb = L > 32 ? 2 : 1;
-  const int nblk = nrb * CBLK;
+  __syncthreads();   // gamma / beta are in LDS
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kc = 0; kc < NK; ++kc) {
@@ -201,67 +242,84 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int r = r0 + 32 * i;
-      const f32x4 v = (ra[kc][i] - stats[r]) * stats[FA_ROWS + r] * g + be;
-      split4(Ah, Al, r * FA_LB + 4 * c4, aok[i] ? v : zero4);
+      const f32x4 v = (ra[kc][i] - mean[i]) * rstd[i] * g + be;
+      split4(Ah, Al, r * A2_AP + k, aok[i] ? v : zero4);
     }
+  }
+  __syncthreads();
+  LF_TA(18);
+
+  // ---- q|k|v^T = W . LN(x)^T (weights as the MFMA A operand): wave cb < 6 owns column block cb = (head, q|k|v) and
+  //      computes both token blocks with the same weight fragments; no weight planes, no barriers ----
+  const int nrb = L > 32 ? 2 : 1;
+  f32x16 acc[2];
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) split4(Bh, Bl, (r0 + 32 * i) * FA_LB + 4 * c4, wok[i] ? rb[kc][i] : zero4);
-    __syncthreads();
-    if (wave < nblk) {
-      const int rbk = wave / CBLK, cbk = wave - rbk * CBLK;
-      const int ao = (rbk * 32 + (lane & 31)) * FA_LB + 8 * (lane >> 5);
-      const int bo_ = (cbk * 32 + (lane & 31)) * FA_LB + 8 * (lane >> 5);
+  for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-      for (int ks = 0; ks < FA_KC / 16; ++ks) {
-        const bf16x8 xh = *(const bf16x8*)(Ah + ao + ks * 16), xl = *(const bf16x8*)(Al + ao + ks * 16);
-        const bf16x8 yh = *(const bf16x8*)(Bh + bo_ + ks * 16), yl = *(const bf16x8*)(Bl + bo_ + ks * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl, xh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xh, acc, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) acc[q2][r] = 0.f;
+  if (wave < 6) {
+    const int ao = (lane & 31) * A2_AP + 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const bf16x8 xh0 = *(const bf16x8*)(Ah + ao + ks * 16), xl0 = *(const bf16x8*)(Al + ao + ks * 16);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xl0, acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][1], xh0, acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xh0, acc[0], 0, 0, 0);
+      if (nrb == 2) {
+        const bf16x8 xh1 = *(const bf16x8*)(Ah + ao + 32 * A2_AP + ks * 16), xl1 = *(const bf16x8*)(Al + ao + 32 * A2_AP + ks * 16);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xl1, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][1], xh1, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xh1, acc[1], 0, 0, 0);
       }
     }
-    __syncthreads();
   }
+  // out-proj fragments of column block `wave` (K = 64: 4 k-steps): requested now, consumed at the end
+  bf16x8 wof[4][2];
+  {
+    const uint4* wp = wo_p + (((long long)(hp * 4) * 8 + wave) * 2) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      wof[ks][0] = __builtin_bit_cast(bf16x8, wp[((ks * 8) * 2) * 64]);
+      wof[ks][1] = __builtin_bit_cast(bf16x8, wp[((ks * 8) * 2 + 1) * 64]);
+    }
+  }
+  __syncthreads();   // every wave is done with the LN(x) planes: q, k, v take their place
   LF_TA(19);
-  // out-proj slice Wo[:, 32h:32h+32] (256 rows x 8 float4): requested now, consumed after the attention phases
-  f32x4 rwo[4];
-  const int c8 = t & 7, n0 = t >> 3;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) rwo[i] = *(const f32x4*)(wo + (long long)(n0 + 64 * i) * d + h * HD + 4 * c8);
-
-  // ---- spill q (scaled), k, v as [token][channel] f32; the planes are dead ----
-  float* Qs = smem;                       // [64][QSTR]
-  float* Ks = Qs + FA_ROWS * QSTR;
-  float* Vs = Ks + FA_ROWS * QSTR;
-  float* SM = Vs + FA_ROWS * QSTR;        // [4 waves][32 queries] running max
-  float* SL = SM + 4 * 32;                // [4 waves][32 queries] sum of exp
-  float* OT = (float*)((char*)smem + A_OT_OFF);   // [4 waves][32 queries][QSTR] PV partials
   const float scale = 1.0f / sqrtf((float)HD);
-  if (wave < nblk) {
-    const int rbk = wave / CBLK, cbk = wave - rbk * CBLK;   // cbk: 0 q, 1 k, 2 v (HD == 32)
-    float* dstm = (cbk == 0 ? Qs : (cbk == 1 ? Ks : Vs)) + (rbk * 32 + (lane & 31)) * QSTR + 4 * (lane >> 5);
-    const float mul = cbk == 0 ? scale : 1.f;
+  if (wave < 6) {
+    const int which = wave % 3, hh = wave / 3;
+    const float mul = which == 0 ? scale : 1.f;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 bv = *(const f32x4*)(GB + 2 * LF_D + cbk * 32 + 8 * g + 4 * (lane >> 5));
-      const f32x4 v = {(acc[4 * g] + bv[0]) * mul, (acc[4 * g + 1] + bv[1]) * mul, (acc[4 * g + 2] + bv[2]) * mul,
-                       (acc[4 * g + 3] + bv[3]) * mul};
-      *(f32x4*)(dstm + 8 * g) = v;
+    for (int rbk = 0; rbk < 2; ++rbk) {
+      if (rbk < nrb) {
+        float* dstm = QKV + ((hh * 3 + which) * FA_ROWS + rbk * 32 + (lane & 31)) * QSTR + 4 * (lane >> 5);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bv = *(const f32x4*)(GB + 2 * LF_D + wave * 32 + 8 * g + 4 * (lane >> 5));
+          *(f32x4*)(dstm + 8 * g) = f32x4{(acc[rbk][4 * g] + bv[0]) * mul, (acc[rbk][4 * g + 1] + bv[1]) * mul,
+                                         (acc[rbk][4 * g + 2] + bv[2]) * mul, (acc[rbk][4 * g + 3] + bv[3]) * mul};
+        }
+      }
     }
   }
   __syncthreads();
   LF_TA(20);
 
-  // ---- scores TRANSPOSED, S^T[key][query] = k q^T, on the f32 MFMA: wave (qb, kb) = (wave >> 1, wave & 1).
-  //      A lane then holds 16 keys of ONE query column, so the softmax over keys is a per-lane reduction plus one
-  //      exchange with lane ^ 32, and p feeds the PV MFMA straight from registers (B operand: key pair (k, k+4)). ----
-  const int nsw = nrb * nrb;              // score waves: 4 (L > 32) or 1
+  // ---- attention of both heads at once: wave = (head hh = wave >> 2, query block qb, key block kb).  Scores are computed
+  //      TRANSPOSED, S^T[key][query] = k q^T on the f32 MFMA: a lane then holds 16 keys of ONE query column, so the softmax
+  //      over keys is a per-lane reduction plus one exchange with lane ^ 32, and p feeds the PV MFMA straight from
+  //      registers (B operand: key pair (k, k+4)). ----
+  const int hh = wave >> 2, sub = wave & 3;
+  const int qb = (nrb == 2) ? (sub >> 1) : 0, kb = (nrb == 2) ? (sub & 1) : 0;
+  const bool score_wave = sub < nrb * nrb;
+  const float* Qs = QKV + (hh * 3 + 0) * FA_ROWS * QSTR;
+  const float* Ks = QKV + (hh * 3 + 1) * FA_ROWS * QSTR;
+  const float* Vs = QKV + (hh * 3 + 2) * FA_ROWS * QSTR;
   f32x16 oacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
   float m_w = -INFINITY, l_w = 0.f;
-  const int qb = (nrb == 2) ? (wave >> 1) : 0, kb = (nrb == 2) ? (wave & 1) : 0;
-  if (wave < nsw) {
+  if (score_wave) {
     f32x16 sacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
@@ -273,7 +331,6 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], bq[s2], sacc, 0, 0, 0);
     }
-    // softmax over the keys of this block for query column (lane & 31)
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -285,7 +342,7 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      sacc[r] = (mx == -INFINITY) ? 0.f : expf(sacc[r] - mx);   // a key block past L contributes nothing
+      sacc[r] = (mx == -INFINITY) ? 0.f : expf(sacc[r] - mx);
       sum += sacc[r];
     }
     sum += __shfl_xor(sum, 32, 64);
@@ -295,7 +352,6 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
       SM[wave * 32 + lane] = mx;
       SL[wave * 32 + lane] = sum;
     }
-    // o^T[ch][query] partial over this key block: A = v[key pair][ch = lane & 31], B = p (register r = keys (k_r, k_r + 4))
     const float* vp = Vs + (kb * 32 + 4 * (lane >> 5)) * QSTR + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -303,8 +359,7 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   }
   __syncthreads();
   LF_TA(21);
-  if (wave < nsw) {
-    // merge the two key blocks of a query block: rescale by exp(m - m_global) / l_global
+  if (score_wave) {
     float fsc;
     if (nrb == 2) {
       const float m_o = SM[(wave ^ 1) * 32 + (lane & 31)], l_o = SL[(wave ^ 1) * 32 + (lane & 31)];
@@ -314,63 +369,56 @@ __global__ __launch_bounds__(LF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     } else {
       fsc = 1.0f / l_w;
     }
-    // oacc[4g+q2] = o^T[ch = 8g + 4(lane>>5) + q2][query = lane & 31]
     float* od = OT + ((wave * 32) + (lane & 31)) * QSTR + 4 * (lane >> 5);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       *(f32x4*)(od + 8 * g) = f32x4{oacc[4 * g] * fsc, oacc[4 * g + 1] * fsc, oacc[4 * g + 2] * fsc, oacc[4 * g + 3] * fsc};
   }
-  __syncthreads();  // Qs/Ks/Vs are dead: the O and Wo planes take their place
+  __syncthreads();
   LF_TA(23);
-
-  __bf16* Oh = (__bf16*)smem;             // [64][OP]
-  __bf16* Ol = Oh + FA_ROWS * OP;
-  __bf16* WoH = Ol + FA_ROWS * OP;        // [256][OP]
-  __bf16* WoL = WoH + LF_D * OP;
   {
-    // O planes: token row = qb*32 + q, 8 float4 per row; sum of the two key-block partials; rows outside the query
-    // range are zeroed (they are never stored, but must stay finite)
-    const int row = t >> 3, q4 = t & 7;   // 64 rows x 8 float4 = 512 threads
-    const int qbr = row >> 5, qq = row & 31;
-    f32x4 v = zero4;
-    if (row < nrb * 32 && row >= L - Lq && row < L) {
-      if (nrb == 2)
-        v = *(const f32x4*)(OT + ((2 * qbr) * 32 + qq) * QSTR + 4 * q4) + *(const f32x4*)(OT + ((2 * qbr + 1) * 32 + qq) * QSTR + 4 * q4);
-      else
-        v = *(const f32x4*)(OT + qq * QSTR + 4 * q4);
-    }
-    split4(Oh, Ol, row * OP + 4 * q4, v);
-  }
+    // O planes [token][head*32 + ch]: thread = (row, head, float4 of 8): 64 x 2 x 8 = 1024 items, 2 per thread
 #pragma unroll
-  for (int i = 0; i < 4; ++i) split4(WoH, WoL, (n0 + 64 * i) * OP + 4 * c8, rwo[i]);
+    for (int it = 0; it < 2; ++it) {
+      const int idx = t + LF_NT * it;
+      const int row = idx >> 4, h2 = (idx >> 3) & 1, q4 = idx & 7;
+      const int qbr = row >> 5, qq = row & 31;
+      f32x4 v = zero4;
+      if (row < nrb * 32 && row >= L - Lq && row < L) {
+        const int w0 = h2 * 4 + (nrb == 2 ? 2 * qbr : 0);
+        v = *(const f32x4*)(OT + (w0 * 32 + qq) * QSTR + 4 * q4);
+        if (nrb == 2) v += *(const f32x4*)(OT + ((w0 + 1) * 32 + qq) * QSTR + 4 * q4);
+      }
+      split4(Oh, Ol, row * A2_OP + h2 * 32 + 4 * q4, v);
+    }
+  }
   __syncthreads();
   LF_TA(24);
 
-  // ---- partial_h = o_h . Wo_h^T: wave w owns output columns 32w..32w+31, both row blocks ----
+  // ---- head-pair partial = [o_h0 | o_h1] . Wo[:, 64 hp : 64 hp + 64]^T: wave w owns output columns 32w..32w+31 ----
   const int nq0 = L - Lq;
   const int n = wave * 32 + (lane & 31);
-  const int wb = (wave * 32 + (lane & 31)) * OP + 8 * (lane >> 5);
   for (int rbk = 0; rbk < nrb; ++rbk) {
     if (rbk * 32 + 32 <= nq0) continue;   // no query rows in this block
     f32x16 pacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
-    const int ao = (rbk * 32 + (lane & 31)) * OP + 8 * (lane >> 5);
+    const int ao = (rbk * 32 + (lane & 31)) * A2_OP + 8 * (lane >> 5);
 #pragma unroll
-    for (int ks = 0; ks < HD / 16; ++ks) {
+    for (int ks = 0; ks < 4; ++ks) {
       const bf16x8 xh = *(const bf16x8*)(Oh + ao + ks * 16), xl = *(const bf16x8*)(Ol + ao + ks * 16);
-      const bf16x8 yh = *(const bf16x8*)(WoH + wb + ks * 16), yl = *(const bf16x8*)(WoL + wb + ks * 16);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, pacc, 0, 0, 0);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, pacc, 0, 0, 0);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wof[ks][0], pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wof[ks][1], pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wof[ks][0], pacc, 0, 0, 0);
     }
-    float* dst = ap + (long long)h * ap_stride + (long long)b * Lq * d + n;
+    float* dst = ap + (long long)hp * ap_stride + (long long)b * Lq * d + n;
+    const bool mine = (wave >> 1) == hp;   // residual + bias live on the two column blocks of this head pair
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = rbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row >= nq0 && row < L && !((dbg & 8) && wave != h)) {
+      if (row >= nq0 && row < L && !((dbg & 8) && !mine)) {
         float v = pacc[r];
-        if (wave == h) v += Xs[row * XS + (lane & 31)] + bov;   // residual + bias live on column block h
+        if (mine) v += Xs[row * A2_XS + (wave & 1) * 32 + (lane & 31)] + bov;
         dst[(long long)(row - nq0) * d] = v;
       }
     }
@@ -461,19 +509,19 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
   // ---- x2 = sum of the head partials: wave `wave` owns rows wave + 8 i, lane = float4 column ----
   f32x4 x2[4];
   {
-    f32x4 pr[LF_NH][4];
+    f32x4 pr[LF_NP][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int gr = min(row0 + wave + 8 * i, M - 1);
       const float* p = ap + (long long)gr * LF_D + 4 * lane;
 #pragma unroll
-      for (int q = 0; q < LF_NH; ++q) pr[q][i] = *(const f32x4*)(p + ((dbg & 1) ? 0 : q) * ap_stride);
+      for (int q = 0; q < LF_NP; ++q) pr[q][i] = *(const f32x4*)(p + ((dbg & 1) ? 0 : q) * ap_stride);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f32x4 s = pr[0][i];
 #pragma unroll
-      for (int q = 1; q < LF_NH; ++q) s += pr[q][i];
+      for (int q = 1; q < LF_NP; ++q) s += pr[q][i];
       x2[i] = s;
     }
   }
@@ -761,18 +809,20 @@ template <bool RING>
 static int launch_attn(const float* xin, long long x_batch_stride, const float* pe, int f0, int ring_frames, int nslots,
                        const sf_tfm_layer& w, float eps, float* ap, long long ap_stride, int B, int L, int Lq,
                        hipStream_t st) {
+  if (!w.attn_in_packed || !w.attn_out_packed)
+    return sf_set_err(-1, "invalid argument: fused attention needs packed weights (sf_pack_attn_weights)", __FILE__, __LINE__);
   auto kern = attn_oproj_kernel<RING>;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A2_LDS);
     if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
     attr = true;
   }
   sf_prof_begin(SF_K_MHA, st, 6.0 * B * L * (double)LF_D * LF_D + 4.0 * (double)B * LF_NH * Lq * L * LF_HD +
                                   2.0 * B * Lq * (double)LF_D * LF_D);
-  hipLaunchKernelGGL(kern, dim3(LF_NH, B), dim3(LF_NT), A_LDS, st, xin, x_batch_stride, pe, f0, ring_frames, nslots,
-                     w.norm1_g, w.norm1_b, eps, w.in_proj_w, w.in_proj_b, w.out_proj_w, w.out_proj_b, ap, ap_stride, L, Lq,
-                     lf_dbg());
+  hipLaunchKernelGGL(kern, dim3(LF_NH / 2, B), dim3(LF_NT), A2_LDS, st, xin, x_batch_stride, pe, f0, ring_frames, nslots,
+                     w.norm1_g, w.norm1_b, eps, (const uint4*)w.attn_in_packed, w.in_proj_b, (const uint4*)w.attn_out_packed,
+                     w.out_proj_b, ap, ap_stride, L, Lq, lf_dbg());
   sf_prof_end(SF_K_MHA, st);
   SF_CHECK_LAUNCH();
   return 0;
@@ -781,7 +831,7 @@ static int launch_attn(const float* xin, long long x_batch_stride, const float* 
 // x [B][L][256] -> ap: 8 head-partial buffers [B*Lq, 256]
 int sf_attn_oproj_ex(const float* xin, const sf_tfm_layer& w, float eps, float* ap, long long ap_stride, int B, int L,
                      int Lq, hipStream_t st) {
-  static_assert(A_LDS <= 80 * 1024, "attention+out-proj kernel: two workgroups per CU");
+  static_assert(A2_LDS <= 160 * 1024, "attention+out-proj kernel: LDS budget");
   return launch_attn<false>(xin, (long long)L * LF_D, nullptr, 0, 1, 1, w, eps, ap, ap_stride, B, L, Lq, st);
 }
 
@@ -867,6 +917,21 @@ extern "C" int sf_pack_linear_weights(const float* w, void* packed, int N, int K
 extern "C" int sf_debug_read_ts(long long* out32) {
   hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(lf_ts), sizeof(long long) * 32);
   return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" size_t sf_attn_packed_bytes(int d_model, int which) { return (size_t)d_model * d_model * (which == 0 ? 3 : 1) * 4; }
+
+// in_proj_w [3d, d] and out_proj_w [d, d] of nn.MultiheadAttention (d = 256, 8 heads) -> fragment-ordered split-bf16 copies
+// for attn_oproj_kernel (layouts above it); outputs need sf_attn_packed_bytes(d, 0) and (d, 1) bytes.
+extern "C" int sf_pack_attn_weights(const float* in_proj_w, const float* out_proj_w, void* in_packed, void* out_packed,
+                                    int d_model, int num_heads, void* stream) {
+  SF_REQUIRE(in_proj_w && out_proj_w && in_packed && out_packed, "sf_pack_attn_weights: null pointer");
+  SF_REQUIRE(d_model == LF_D && num_heads == LF_NH, "sf_pack_attn_weights: needs d_model == 256 and 8 heads");
+  const int total = 4 * 6 * 16 * 2 * 64;
+  hipLaunchKernelGGL(pack_attn_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, in_proj_w, out_proj_w,
+                     (uint4*)in_packed, (uint4*)out_packed);
+  SF_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" size_t sf_ffn_packed_bytes(int d_model, int ffn) { return (size_t)d_model * ffn * 4; }

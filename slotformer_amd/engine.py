@@ -75,6 +75,13 @@ def _tfm_layers(plan, encoder, pack_ffn=False):
                                             p2.data_ptr(), d, ffn, torch.cuda.current_stream().cuda_stream))
             plan.keep += [p1, p2]
             a.lin1_packed, a.lin2_packed = p1.data_ptr(), p2.data_ptr()
+            if l.self_attn.num_heads == 8:
+                q1 = torch.empty(lib().sf_attn_packed_bytes(d, 0), dtype=torch.uint8, device=p1.device)
+                q2 = torch.empty(lib().sf_attn_packed_bytes(d, 1), dtype=torch.uint8, device=p1.device)
+                check(lib().sf_pack_attn_weights(plan.dp(l.self_attn.in_proj_weight), plan.dp(l.self_attn.out_proj.weight),
+                                                 q1.data_ptr(), q2.data_ptr(), d, 8, torch.cuda.current_stream().cuda_stream))
+                plan.keep += [q1, q2]
+                a.attn_in_packed, a.attn_out_packed = q1.data_ptr(), q2.data_ptr()
         a.norm1_g, a.norm1_b = plan.dp(l.norm1.weight), plan.dp(l.norm1.bias)
         a.in_proj_w, a.in_proj_b = plan.dp(l.self_attn.in_proj_weight), plan.dp(l.self_attn.in_proj_bias)
         a.out_proj_w, a.out_proj_b = plan.dp(l.self_attn.out_proj.weight), plan.dp(l.self_attn.out_proj.bias)
