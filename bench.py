@@ -173,9 +173,9 @@ def main():
     bufs = [torch.zeros(B, T_BURN + T_ROLL, N, D, device=dev) for _ in range(2)]
     buf = bufs[0]
 
-    def encode(dst=None):
+    def encode(dst=None, feat_pre=None):
         noise = torch.randn(B, T_BURN, N, D, device=dev)  # fresh eps ~ N(0,1) per frame (savi.py:363-365), one launch
-        post, _, _ = engine.savi_encode(savi, img, noise=noise)
+        post, _, _ = engine.savi_encode(savi, img, noise=noise, feat_pre=feat_pre)
         (buf if dst is None else dst)[:, :T_BURN].copy_(post)
 
     S = max(1, args.rollout_streams)
@@ -282,6 +282,17 @@ def main():
                 n_rs = min(n_rs, NB - 1)
                 s_rolls = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(n_rs)]
 
+            # Work stealing (SF_BENCH_STEAL = number of time steps): the encode partition is the slower half, and the
+            # rollout stream idles between its graph and the next encode's end -- so after the rollout of batch j it
+            # computes the CNN features of the first `steal` time steps of batch j+2 on its own (larger) CU partition;
+            # the encode of batch j+2 then skips those convolutions.  Two feature buffers.
+            steal = int(os.environ.get('SF_BENCH_STEAL', '1')) if n_rs == 1 else 0
+            steal = max(0, min(steal, T_BURN))
+            feat_bufs = None
+            if steal:
+                feat_bufs = [engine.savi_cnn(savi, img, 0, steal, ws_slot=1) for _ in range(2)]
+                torch.cuda.synchronize()
+
             def run_pipelined(n):
                 cur = torch.cuda.current_stream()
                 s_enc.wait_stream(cur)
@@ -289,11 +300,19 @@ def main():
                     sr.wait_stream(cur)
                 ev_enc = [torch.cuda.Event() for _ in range(n)]
                 ev_roll = [torch.cuda.Event() for _ in range(n)]
+                ev_pre = [torch.cuda.Event() for _ in range(n + 2)]
+                if steal:   # the first two batches' features are produced up front (inside the timed region)
+                    with torch.cuda.stream(s_rolls[0]):
+                        for j in range(min(2, n)):
+                            engine.savi_cnn(savi, img, 0, steal, out=feat_bufs[j % 2], ws_slot=1)
+                            ev_pre[j].record(s_rolls[0])
                 for j in range(n):
                     with torch.cuda.stream(s_enc):
                         if j >= NB:
                             s_enc.wait_event(ev_roll[j - NB])  # slot buffer j % NB is free once rollout j-NB is done
-                        encode(bufs[j % NB])
+                        if steal:
+                            s_enc.wait_event(ev_pre[j])
+                        encode(bufs[j % NB], feat_bufs[j % 2] if steal else None)
                         ev_enc[j].record(s_enc)
                     s_roll = s_rolls[j % n_rs]
                     with torch.cuda.stream(s_roll):
@@ -302,6 +321,10 @@ def main():
                             s_roll.wait_event(ev_roll[j - NB])  # same graph / buffer / workspace as batch j-NB
                         graphs[j % NB].replay()
                         ev_roll[j].record(s_roll)
+                        if steal and j + 2 < n:
+                            # feature buffer (j+2) % 2 == j % 2 was consumed by encode j, which this stream has waited for
+                            engine.savi_cnn(savi, img, 0, steal, out=feat_bufs[j % 2], ws_slot=1)
+                            ev_pre[j + 2].record(s_roll)
                 cur.wait_stream(s_enc)
                 for sr in s_rolls:
                     cur.wait_stream(sr)
@@ -436,6 +459,8 @@ def main():
                 'rollout_launch': 'hipGraph replay' if graph is not None else 'eager', 'rollout_streams': S,
                 'pipelining': ('encode of batch i+1 (stream A) overlaps the rollout graph of batch i (stream B); every batch still '
                                'runs its full encode + 50-step rollout inside the timed region') if overlap else 'none',
+                'work_stealing': (f'the CNN features of the first {steal} time step(s) of batch j+2 are computed on the rollout '
+                                  'stream after the rollout of batch j') if (overlap and steal) else 'none',
                 'cu_partition': (f'encode stream on CU mask {cu_words[0]:#x} x8 words ({8 * bin(cu_words[0]).count("1")} CUs), '
                                  + (f'{n_rs} rollout streams on masks ' + ','.join(f'{w:#x}' for w in roll_masks) if roll_masks
                                     else 'rollout stream on the complement')) if (overlap and cu_split) else 'none',

@@ -229,6 +229,18 @@ int sf_savi_encode_f32(const sf_savi_encoder* m, const float* img, const float* 
                        float* lstm_h, float* lstm_c, int state_valid, float* post_slots, float* kernel_dist,
                        float* attn, int B, int T, void* ws, size_t ws_bytes, void* stream);
 
+/* The CNN stack alone (savi.py:231-244,367-371: convs + soft position embedding) for time steps [t0, t1) of every
+ * video: feat [t1-t0][B][64*64][C_last] channels-last.  It does not depend on the slots, so it may run ahead of the
+ * encode on another stream; sf_savi_encode_pre_f32 is sf_savi_encode_f32 with the features of the first n_pre time
+ * steps taken from feat_pre (bench.py computes part of the NEXT batch's convolutions on the rollout stream's CUs while
+ * that stream would otherwise idle). */
+size_t sf_savi_cnn_workspace_bytes(const sf_savi_encoder* m, int B);
+int sf_savi_cnn_f32(const sf_savi_encoder* m, const float* img, int B, int T, int t0, int t1, float* feat, void* ws,
+                    size_t ws_bytes, void* stream);
+int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const float* feat_pre, int n_pre, const float* noise,
+                           const float* prev_slots, float* lstm_h, float* lstm_c, int state_valid, float* post_slots,
+                           float* kernel_dist, float* attn, int B, int T, void* ws, size_t ws_bytes, void* stream);
+
 /* StoSAVi.decode (savi.py:504-525): spatial broadcast + position embedding -> transposed-conv stack -> 1x1 conv
  * -> softmax-over-slots recombination. */
 typedef struct {

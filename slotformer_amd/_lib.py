@@ -103,6 +103,10 @@ SIGNATURES = {
     'sf_pack_attn_weights': (I, [FP, FP, VP, VP, I, I, VP]),
     'sf_ffn_packed_bytes': (SZ, [I, I]),
     'sf_pack_ffn_weights': (I, [FP, FP, VP, VP, I, I, VP]),
+    'sf_savi_cnn_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I]),
+    'sf_savi_cnn_f32': (I, [C.POINTER(sf_savi_encoder), FP, I, I, I, I, FP, VP, SZ, VP]),
+    'sf_savi_encode_pre_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, I, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
+                                   VP]),
     'sf_kv_producer_workspace_bytes': (SZ, [I, I]),
     'sf_kv_producer_f32': (I, [FP] * 11 + [I, I, I, I, F32, VP, SZ, VP]),
     # device-memory helpers + host-buffer twins (same signatures as the device entry points)

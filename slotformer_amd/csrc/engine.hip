@@ -279,10 +279,78 @@ size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B) {
   return t + 8192;
 }
 
+// CNN stack (savi.py:231-244: convs + soft position embedding) for `nb` frames: frame i at src + i*frame_stride;
+// the last conv writes into `dst` (NHWC [nb,64,64,C_last]); featA/featB are ping-pong scratch.
+static int run_cnn(const sf_savi_encoder* m, const float* src, long long frame_stride, int nb, float* dst, float* featA,
+                   float* featB, hipStream_t st) {
+  const int res = m->resolution;
+  const float* cur = nullptr;
+  for (int i = 0; i < m->enc_layers; ++i) {
+    const bool lastc = (i == m->enc_layers - 1);
+    const int cin = m->enc_channels[i], cout = m->enc_channels[i + 1];
+    const float* add = lastc ? m->pos_table : nullptr;
+    float* out = lastc ? dst : ((i & 1) ? featB : featA);
+    if (i == 0) {
+      SF_TRY(sf_conv2d_nchw_in_f32(src, frame_stride, m->conv_w[0], m->conv_b[0], add, out, nb, cin, res, res, cout,
+                                   m->enc_ks, res == 128 ? 2 : 1, lastc ? 0 : 1, st));
+    } else {
+      SF_TRY(sf_conv2d_nhwc_f32(cur, m->conv_w[i], m->conv_b[i], add, out, nb, 64, 64, cin, cout, m->enc_ks, lastc ? 0 : 1,
+                                st));
+    }
+    cur = out;
+  }
+  return 0;
+}
+
+size_t sf_savi_cnn_workspace_bytes(const sf_savi_encoder* m, int B) {
+  if (!m || B <= 0) return 0;
+  int cmax = 0;
+  for (int i = 1; i <= m->enc_layers && i < 9; ++i) cmax = m->enc_channels[i] > cmax ? m->enc_channels[i] : cmax;
+  return 2 * pad256((size_t)enc_chunk(B) * 64 * 64 * cmax) + 4096;
+}
+
+// CNN features of time steps [t0, t1) of every video: feat [t1-t0][B][64*64][C_last].  Independent of the slots, so a
+// caller may compute them ahead of sf_savi_encode_pre_f32 on another stream (bench.py runs part of the NEXT batch's
+// convolutions on the rollout stream's CUs while that stream would otherwise idle).
+int sf_savi_cnn_f32(const sf_savi_encoder* m, const float* img, int B, int T, int t0, int t1, float* feat, void* ws,
+                    size_t ws_bytes, void* stream) {
+  SF_REQUIRE(m && img && feat && ws, "null pointer");
+  SF_REQUIRE(B >= 1 && T >= 1 && t0 >= 0 && t1 >= t0 && t1 <= T, "bad batch / time range");
+  SF_REQUIRE(m->resolution == 64 || m->resolution == 128, "resolution must be 64 or 128 (savi.py:226,236)");
+  SF_REQUIRE(m->enc_layers >= 1 && m->enc_layers <= 8 && m->pos_table, "bad CNN config");
+  SF_REQUIRE(ws_bytes >= sf_savi_cnn_workspace_bytes(m, B), "workspace too small");
+  for (int i = 0; i < m->enc_layers; ++i) SF_REQUIRE(m->conv_w[i] != nullptr, "null conv weight");
+  int cmax = 0;
+  for (int i = 1; i <= m->enc_layers; ++i) cmax = m->enc_channels[i] > cmax ? m->enc_channels[i] : cmax;
+  const int Bc = enc_chunk(B), HW = 64 * 64, Cl = m->enc_channels[m->enc_layers];
+  Bump bp{(char*)ws, ws_bytes};
+  float* featA = bp.take((size_t)Bc * HW * cmax);
+  float* featB = bp.take((size_t)Bc * HW * cmax);
+  if (!featA || !featB) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
+  const long long frame_elems = (long long)3 * m->resolution * m->resolution;
+  for (int t = t0; t < t1; ++t)
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+      const int nb = (B - b0 < Bc) ? (B - b0) : Bc;
+      SF_TRY(run_cnn(m, img + ((long long)b0 * T + t) * frame_elems, (long long)T * frame_elems, nb,
+                     feat + ((long long)(t - t0) * B + b0) * HW * Cl, featA, featB, (hipStream_t)stream));
+    }
+  return 0;
+}
+
 int sf_savi_encode_f32(const sf_savi_encoder* m, const float* img, const float* noise, const float* prev_slots,
                        float* lstm_h, float* lstm_c, int state_valid, float* post_slots, float* kernel_dist,
                        float* attn, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+  return sf_savi_encode_pre_f32(m, img, nullptr, 0, noise, prev_slots, lstm_h, lstm_c, state_valid, post_slots, kernel_dist,
+                                attn, B, T, ws, ws_bytes, stream);
+}
+
+// As sf_savi_encode_f32, with the CNN features of the first n_pre time steps already computed by sf_savi_cnn_f32
+// (feat_pre [n_pre][B][64*64][C_last]; NULL / 0: compute everything here).
+int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const float* feat_pre, int n_pre, const float* noise,
+                           const float* prev_slots, float* lstm_h, float* lstm_c, int state_valid, float* post_slots,
+                           float* kernel_dist, float* attn, int B, int T, void* ws, size_t ws_bytes, void* stream) {
   SF_REQUIRE(m && img && post_slots && ws, "null pointer");
+  SF_REQUIRE(n_pre >= 0 && n_pre <= T && (n_pre == 0 || feat_pre != nullptr), "bad precomputed-feature arguments");
   SF_REQUIRE(B >= 1 && T >= 1, "bad batch / clip length");
   SF_REQUIRE(m->resolution == 64 || m->resolution == 128, "resolution must be 64 or 128 (savi.py:226,236)");
   SF_REQUIRE(m->enc_layers >= 1 && m->enc_layers <= 8 && m->enc_channels[0] > 0 && (m->enc_ks & 1), "bad CNN config");
@@ -347,23 +415,14 @@ int sf_savi_encode_f32(const sf_savi_encoder* m, const float* img, const float* 
     // ---- CNN encoder + per-pixel MLP + K/V for the B frames of step t ---------------------
     for (int b0 = 0; b0 < B; b0 += Bc) {
       const int nb = (B - b0 < Bc) ? (B - b0) : Bc;
-      const float* src = img + ((long long)b0 * T + t) * frame_elems;
-      float* cur = featA;
-      float* nxt = featB;
-      for (int i = 0; i < m->enc_layers; ++i) {
-        const bool lastc = (i == m->enc_layers - 1);
-        const int cin = m->enc_channels[i], cout = m->enc_channels[i + 1];
-        const float* add = lastc ? m->pos_table : nullptr;
-        if (i == 0) {
-          SF_TRY(sf_conv2d_nchw_in_f32(src, (long long)T * frame_elems, m->conv_w[0], m->conv_b[0], add, cur, nb,
-                                       cin, res, res, cout, m->enc_ks, res == 128 ? 2 : 1, lastc ? 0 : 1, st));
-        } else {
-          SF_TRY(sf_conv2d_nhwc_f32(cur, m->conv_w[i], m->conv_b[i], add, nxt, nb, 64, 64, cin, cout, m->enc_ks,
-                                    lastc ? 0 : 1, st));
-          float* tmp = cur;
-          cur = nxt;
-          nxt = tmp;
-        }
+      const int Cl0 = m->enc_channels[m->enc_layers];
+      const float* cur;
+      if (t < n_pre) {
+        cur = feat_pre + ((long long)t * B + b0) * HW * Cl0;   // computed ahead of time by sf_savi_cnn_f32
+      } else {
+        float* dstf = (m->enc_layers & 1) ? featA : featB;   // the buffer the last conv does not read
+        SF_TRY(run_cnn(m, img + ((long long)b0 * T + t) * frame_elems, (long long)T * frame_elems, nb, dstf, featA, featB, st));
+        cur = dstf;
       }
       const int Cl = m->enc_channels[m->enc_layers];
       const int Mp = nb * HW;

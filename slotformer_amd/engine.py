@@ -230,8 +230,9 @@ def encoder_plan(m):
     return plan
 
 
-def savi_encode(m, img, prev_slots=None, noise=None, want_attn=False, ws_slot=0):
-    """Run StoSAVi.encode / STEVE.encode on device.
+def savi_encode(m, img, prev_slots=None, noise=None, want_attn=False, ws_slot=0, feat_pre=None):
+    """Run StoSAVi.encode / STEVE.encode on device.  feat_pre [n_pre,B,4096,C]: CNN features of the first n_pre time
+    steps computed ahead of time by `savi_cnn` (possibly on another stream).
 
     Returns (post_slots [B,T,N,D], kernel_dist [B,T,N,2D] | None, attn [B,T,N,64*64] | None).
     The predictor's LSTM state lives on `m.predictor.hidden_state` exactly as in the reference.
@@ -266,10 +267,34 @@ def savi_encode(m, img, prev_slots=None, noise=None, want_attn=False, ws_slot=0)
     need = lib().sf_savi_encode_workspace_bytes(C.byref(plan.struct), B)
     ws = workspace(dev, need, ('enc', ws_slot))
     P = ops._p
-    check(lib().sf_savi_encode_f32(C.byref(plan.struct), img.data_ptr(), P(noise), P(prev_slots), P(h), P(c), valid,
-                                   post.data_ptr(), P(kdist), P(attn), B, T, ws.data_ptr(), ws.numel(),
-                                   torch.cuda.current_stream().cuda_stream))
+    n_pre = 0
+    if feat_pre is not None:
+        ops._chk(feat_pre)
+        n_pre = feat_pre.shape[0]
+        if feat_pre.shape[1] != B or feat_pre.shape[2] != 64 * 64:
+            raise RuntimeError(f'feat_pre must be [n_pre,{B},4096,C], got {tuple(feat_pre.shape)}')
+    check(lib().sf_savi_encode_pre_f32(C.byref(plan.struct), img.data_ptr(), P(feat_pre), n_pre, P(noise), P(prev_slots), P(h),
+                                       P(c), valid, post.data_ptr(), P(kdist), P(attn), B, T, ws.data_ptr(), ws.numel(),
+                                       torch.cuda.current_stream().cuda_stream))
     return post, kdist, attn
+
+
+def savi_cnn(m, img, t0, t1, out=None, ws_slot=0):
+    """CNN features (convs + soft position embedding) of time steps [t0, t1): [t1-t0, B, 4096, C_last] on the current
+    stream; they do not depend on the slots, so they can be produced ahead of `savi_encode(..., feat_pre=...)`."""
+    _require_inference(m, img)
+    ops._chk(img)
+    plan = encoder_plan(m)
+    s = plan.struct
+    B, T = img.shape[:2]
+    cl = s.enc_channels[s.enc_layers]
+    if out is None:
+        out = torch.empty(t1 - t0, B, 64 * 64, cl, device=img.device, dtype=torch.float32)
+    need = lib().sf_savi_cnn_workspace_bytes(C.byref(plan.struct), B)
+    ws = workspace(img.device, need, ('cnn', ws_slot))
+    check(lib().sf_savi_cnn_f32(C.byref(plan.struct), img.data_ptr(), B, T, t0, t1, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                torch.cuda.current_stream().cuda_stream))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------

@@ -110,6 +110,24 @@ def test_steve_golden_and_masks(dev):
 
 
 @torch.no_grad()
+def test_precomputed_cnn_features(dev):
+    """sf_savi_cnn_f32 + sf_savi_encode_pre_f32: encoding with the CNN features of the first time steps computed ahead
+    (the bench's work stealing) is bit-identical to the plain encode."""
+    from slotformer_amd import engine
+    g = gu.load_golden('savi_c2')
+    m, _ = build(gu.C2_SAVI, g, 103, dev)
+    img = gu.seeded_img(2, 3, 128).to(dev)
+    noise = gu.seeded_normal((2, 3, 7, 128), 7).to(dev)
+    ref, kd, _ = engine.savi_encode(m, img, noise=noise)
+    for n_pre in (1, 3):
+        feat = engine.savi_cnn(m, img, 0, n_pre)
+        assert feat.shape == (n_pre, 2, 4096, 64)
+        got, kd2, _ = engine.savi_encode(m, img, noise=noise, feat_pre=feat)
+        assert torch.equal(got, ref) and torch.equal(kd2, kd)
+    assert rel_err(ref, g['post_slots']) < RTOL
+
+
+@torch.no_grad()
 def test_steve_image_side_golden(dev, precision):
     """Row N2 (second half) through the reference-shaped API: dVAE tokens / reconstruction, teacher-forced Transformer
     decoder logits, token cross-entropy and greedy generation vs the reference's own outputs."""
