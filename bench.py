@@ -493,7 +493,8 @@ def main():
                 'frac_isolated': (flops_per_launch / (prof_iso['conv_nhwc_implicit_gemm']['avg_us'] * 1e-6) / 1e12 / peak_chip
                                   if 'conv_nhwc_implicit_gemm' in prof_iso else None),
                 'note': 'achieved/frac are live over the timed region, where the encode runs on `cus` CUs beside the rollout graph '
-                        'of the previous batch (peak = whole-chip peak x cus/256); *_isolated is the same kernel alone on all 256 CUs '
+                        'of the previous batch (peak = whole-chip peak x cus/256; the convolutions that work stealing moves to the '
+                        'rollout stream are not part of this average); *_isolated is the same kernel alone on all 256 CUs '
                         '(vs peak_full_chip)',
             }
         # the rollout replays as ONE hipGraph (900 launches), so it is reported as a unit: algorithmic

@@ -24,6 +24,7 @@ enum { SF_K_CONV_NHWC = 0, SF_K_CONV_FIRST = 1, SF_K_LINEAR = 2, SF_K_SA_ITER = 
        SF_K_MHA = 5, SF_K_FFN = 6, SF_K_NUM = 7 };
 void sf_prof_begin(int cls, hipStream_t st, double work);
 void sf_prof_end(int cls, hipStream_t st);
+void sf_prof_suppress(int on);
 int sf_qkv_attn_ex(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* in_proj_w,
                    const float* in_proj_b, float* out, int B, int L, int Lq, int d, int nheads, hipStream_t st);
 extern "C" int sf_get_precision(void);

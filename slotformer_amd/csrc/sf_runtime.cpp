@@ -17,10 +17,15 @@ std::mutex g_mu;
 unsigned g_mask = 0;
 std::vector<Rec> g_recs[SF_K_NUM];
 thread_local hipEvent_t t_pending = nullptr;
+thread_local int t_suppress = 0;
 }  // namespace
 
+// nested suppression of the class timer on the calling thread (used for launches that must not be mixed into a
+// per-class average, e.g. convolutions of another batch computed on a different CU partition)
+void sf_prof_suppress(int on) { t_suppress += on ? 1 : -1; }
+
 void sf_prof_begin(int cls, hipStream_t st, double work) {
-  if (cls < 0 || cls >= SF_K_NUM || !(g_mask & (1u << cls))) return;
+  if (cls < 0 || cls >= SF_K_NUM || !(g_mask & (1u << cls)) || t_suppress > 0) return;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
   Rec r;
