@@ -177,6 +177,11 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
                             sf_layer_fused_ok(d, m->num_heads, m->ffn_dim, Lmax);
   // step boundary in one launch (out-proj of step s + in-proj of the new frame for step s+1) with cached in-projections
   const bool ring_mode = fused_layers && m->in_proj_packed && m->out_proj_packed && sf_step_boundary_ok(d, C);
+  static const bool bfuse_env = [] {
+    const char* e = getenv("SF_BOUNDARY_FUSED");
+    return !(e && e[0] == '0');
+  }();
+  const bool boundary_fused = ring_mode && bfuse_env;
   if (ring_mode) {
     // in-projection (without PE) of the burn-in frames -> ring slots 0 .. n_in-1
     SF_TRY(sf_ring_init_ex(m->out_proj_packed, m->out_proj_b, m->in_proj_packed, m->in_proj_b, slots,
@@ -210,12 +215,20 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
                                        Lq, st));
         else
           SF_TRY(sf_attn_oproj_ex(cin, m->layers[l], 1e-5f, apb, pst, B, L, Lq, st));
-        SF_TRY(sf_ffn_partial_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st));
-        cin = xo;
+        if (l == m->num_layers - 1 && boundary_fused) {
+          // last layer: FFN + step boundary in one launch.  pred = out_proj(last rows) -> frame n_in + s; its
+          // in-projection -> the ring   (slotformer.py:121-124, :115)
+          SF_TRY(sf_ffn_boundary_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, counters, m->ffn_dim, m->out_proj_packed,
+                                    m->out_proj_b, m->in_proj_packed, m->in_proj_b, slots, bs, n_in + s, ring, RF, N, B, st));
+          cin = nullptr;
+        } else {
+          SF_TRY(sf_ffn_partial_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st));
+          cin = xo;
+        }
       }
-      // pred = out_proj(last rows) -> frame n_in + s; its in-projection -> the ring   (slotformer.py:121-124, :115)
-      SF_TRY(sf_step_boundary_ex(cin, m->out_proj_packed, m->out_proj_b, m->in_proj_packed, m->in_proj_b, slots, bs, n_in + s,
-                                 ring, RF, N, B, st));
+      if (cin != nullptr)
+        SF_TRY(sf_step_boundary_ex(cin, m->out_proj_packed, m->out_proj_b, m->in_proj_packed, m->in_proj_b, slots, bs, n_in + s,
+                                   ring, RF, N, B, st));
       continue;
     }
     // x = in_proj(window) + pe   (slotformer.py:115-117; single_step_slotformer.py:79-81)

@@ -22,3 +22,8 @@ int sf_ffn_tiles(int M);
 // in-projection of the first n_frames frames of every video -> ring slots 0 .. n_frames-1 (same arithmetic as the step kernel)
 int sf_ring_init_ex(const void* wout_packed, const float* b_out, const void* win_packed, const float* b_in, float* slots,
                     long long slots_bs, int n_frames, float* ring, int ring_frames, int nslots, int B, hipStream_t st);
+// last layer of a rollout step (M = B * nslots rows): FFN + fused step boundary in one launch
+int sf_ffn_boundary_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp, long long xp_stride,
+                       int* counters, int ffn, const void* wout_packed, const float* b_out, const void* win_packed,
+                       const float* b_in, float* slots, long long slots_bs, int frame, float* ring, int ring_frames, int nslots,
+                       int B, hipStream_t st);

@@ -19,6 +19,7 @@
 #include "sf_internal.h"
 #include "layer_fused.h"
 #include <stdlib.h>
+#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -458,6 +459,104 @@ __global__ void pack_ffn_kernel(const float* __restrict__ w1, const float* __res
   p2[idx] = o2.u;
 }
 
+// ---- step boundary (slotformer.py:121-124, then :115 of the next step) on 32 finished rows held as split-bf16 planes ----
+//   pred = y . Wout^T + b_out -> slots[b][frame][n][0:128];  proj = pred . Win^T + b_in -> ring[b][frame % R][n][0:256]
+// Used by step_boundary_kernel and, fused, by the last-arriving workgroup of ffn_partial_kernel on the last layer.
+struct SbArgs {
+  const uint4* wout_p;
+  const float* b_out;
+  const uint4* win_p;
+  const float* b_in;
+  float* slots;
+  long long slots_bs, slots_off;
+  float* ring;
+  long long ring_bs, ring_off;
+  int nslots, enabled;
+};
+constexpr int SB_C = 128;                    // slot size
+constexpr int SB_YP = LF_D + 8, SB_PP = SB_C + 8;
+
+struct SbFrags {
+  bf16x8 w1[8][2], w2[8][2];
+  f32x4 bo4[4], bi4[4];
+};
+
+__device__ __forceinline__ void sb_load(const SbArgs& a, SbFrags& f, int lane, int wave) {
+  const int nb1 = wave & 3, kh = wave >> 2;
+  const int c1 = nb1 * 32 + 4 * (lane >> 5), c2 = wave * 32 + 4 * (lane >> 5);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f.bo4[g] = *(const f32x4*)(a.b_out + c1 + 8 * g);
+    f.bi4[g] = *(const f32x4*)(a.b_in + c2 + 8 * g);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      f.w1[k][pl] = __builtin_bit_cast(bf16x8, a.wout_p[((((long long)(kh * 8 + k) * 4 + nb1) * 2 + pl) * 64) + lane]);
+      f.w2[k][pl] = __builtin_bit_cast(bf16x8, a.win_p[((((long long)k * 8 + wave) * 2 + pl) * 64) + lane]);
+    }
+}
+
+// Y planes [32][SB_YP] hold the rows (all threads must have passed a barrier after filling them); R [4][16][64] f32 and
+// P planes [32][SB_PP] are scratch.  Contains barriers: call from all 512 threads.
+__device__ __forceinline__ void sb_compute(const SbArgs& a, const SbFrags& f, const __bf16* Yh, const __bf16* Yl, float* R,
+                                           __bf16* Ph, __bf16* Pl, int row0, int M, int lane, int wave) {
+  const int tok = lane & 31, nb1 = wave & 3, kh = wave >> 2;
+  const int c1 = nb1 * 32 + 4 * (lane >> 5), c2 = wave * 32 + 4 * (lane >> 5);
+  const int m = row0 + tok;
+  const int mb = min(m, M - 1) / a.nslots, mn = min(m, M - 1) - mb * a.nslots;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  {
+    const int ao = tok * SB_YP + 8 * (lane >> 5) + kh * 128;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bf16x8 xh = *(const bf16x8*)(Yh + ao + k * 16), xl = *(const bf16x8*)(Yl + ao + k * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w1[k][0], xl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w1[k][1], xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w1[k][0], xh, acc, 0, 0, 0);
+    }
+  }
+  if (kh == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) R[(nb1 * 16 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (kh == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = acc[4 * g + q] + R[(nb1 * 16 + 4 * g + q) * 64 + lane] + f.bo4[g][q];
+      split4(Ph, Pl, tok * SB_PP + c1 + 8 * g, v);
+      if (m < M) *(f32x4*)(a.slots + mb * a.slots_bs + a.slots_off + (long long)mn * SB_C + c1 + 8 * g) = v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  {
+    const int ao = tok * SB_PP + 8 * (lane >> 5);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bf16x8 xh = *(const bf16x8*)(Ph + ao + k * 16), xl = *(const bf16x8*)(Pl + ao + k * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w2[k][0], xl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w2[k][1], xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w2[k][0], xh, acc, 0, 0, 0);
+    }
+  }
+  if (m < M) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = {acc[4 * g] + f.bi4[g][0], acc[4 * g + 1] + f.bi4[g][1], acc[4 * g + 2] + f.bi4[g][2],
+                       acc[4 * g + 3] + f.bi4[g][3]};
+      *(f32x4*)(a.ring + mb * a.ring_bs + a.ring_off + (long long)mn * LF_D + c2 + 8 * g) = v;
+    }
+  }
+}
+
 // ap [8][M][256] head partials -> xout [M][256] finished layer output (xp [4][M][256]: chunk-partial scratch);
 // grid = ceil(tiles/8) * 32 workgroups, tile = 32 rows, 4 hidden chunks per tile.
 //
@@ -471,7 +570,7 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
                                                             const uint4* __restrict__ w2p, const float* __restrict__ b2,
                                                             float* __restrict__ xp, long long xp_stride,
                                                             float* __restrict__ xout, int* __restrict__ counters,
-                                                            int ntiles, int M, int dbg) {
+                                                            int ntiles, int M, int dbg, SbArgs sb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int s_last;
   __bf16* Ah = (__bf16*)smem;                  // [32][FB_AP]  LN2(x2)
@@ -590,6 +689,10 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh, acc, 0, 0, 0);
   }
   LF_TS(5);
+  // last layer of a rollout step: the fragments of the fused step boundary are requested by every workgroup now (the
+  // FFN fragment registers are free) so that they have landed when the last-arriving one needs them
+  SbFrags sbf;
+  if (sb.enabled) sb_load(sb, sbf, lane, wave);
 
   // ---- output tile -> LDS (in place over the x2 stash; chunk 0 adds the residual and the bias), re-read row-major ----
 #pragma unroll
@@ -634,12 +737,22 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
       for (int i = 0; i < 4; ++i)
         oth[cc][i] = (cc == c) ? mine[i]
                                : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xpr, off[i] + cc * cstride, 0, 16));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x4 sum = ((oth[0][i] + oth[1][i]) + oth[2][i]) + oth[3][i];
-      if (row0 + wave + 8 * i < M) *(f32x4*)(xout + (long long)(row0 + wave + 8 * i) * LF_D + 4 * lane) = sum;
-    }
     if (t == 0) __hip_atomic_store(counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    if (!sb.enabled) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 sum = ((oth[0][i] + oth[1][i]) + oth[2][i]) + oth[3][i];
+        if (row0 + wave + 8 * i < M) *(f32x4*)(xout + (long long)(row0 + wave + 8 * i) * LF_D + 4 * lane) = sum;
+      }
+    } else {
+      // fused step boundary: the finished rows go straight into split-bf16 planes (over the dead LN2 planes), then
+      // out-proj -> slots and in-proj -> ring, by this workgroup alone (s_last is uniform: barriers are safe)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        split4(Ah, Al, (wave + 8 * i) * FB_AP + 4 * lane, ((oth[0][i] + oth[1][i]) + oth[2][i]) + oth[3][i]);
+      __syncthreads();
+      sb_compute(sb, sbf, Ah, Al, (float*)Hh, Hh + 4 * 16 * 64 * 2, Hh + 4 * 16 * 64 * 2 + 32 * SB_PP, row0, M, lane, wave);
+    }
   }
   LF_TS(8);
 }
@@ -666,23 +779,12 @@ __global__ void pack_linear_kernel(const float* __restrict__ w, uint4* __restric
   out[idx] = o.u;
 }
 
-// Step boundary of the rollout (slotformer.py:121-124 then :115 of the next step), slot_size 128, d_model 256:
-//   pred = y . Wout^T + b_out            -> slots[b][frame][n][0:128]
-//   proj = pred . Win^T + b_in           -> ring[b][frame % ring_frames][n][0:256]   (cached in-projection, no PE)
-// y [M = B*nslots][256] are the finished rows of the last layer; one workgroup per 32 rows.  `nslots` is really "rows per
-// video": with proj_only != 0 the kernel skips the out-projection and in-projects rows that are already in `slots`
-// (the burn-in frames, rows per video = n_in * N) -- the same arithmetic as inside the rollout, so a rollout restarted
-// from its own output reproduces the original bit for bit.
-constexpr int SB_C = 128;                    // slot size
-constexpr int SB_YP = LF_D + 8, SB_PP = SB_C + 8;
+// Stand-alone step boundary (one workgroup per 32 rows); y [M = B*rows_per_video][256] are the finished rows of the last
+// layer.  With proj_only != 0 the out-projection is skipped and rows that are already in `slots` are in-projected (the
+// burn-in frames, rows per video = n_in * N) -- the same arithmetic as inside the rollout, so a rollout restarted from
+// its own output reproduces the original bit for bit.
 constexpr size_t SB_LDS = (size_t)2 * 32 * SB_YP * 2 + (size_t)4 * 16 * 64 * 4 + (size_t)2 * 32 * SB_PP * 2;
-__global__ __launch_bounds__(LF_NT) void step_boundary_kernel(const float* __restrict__ y, const uint4* __restrict__ wout_p,
-                                                              const float* __restrict__ b_out,
-                                                              const uint4* __restrict__ win_p,
-                                                              const float* __restrict__ b_in, float* __restrict__ slots,
-                                                              long long slots_bs, long long slots_off,
-                                                              float* __restrict__ ring, long long ring_bs, long long ring_off,
-                                                              int nslots, int M, int proj_only) {
+__global__ __launch_bounds__(LF_NT) void step_boundary_kernel(const float* __restrict__ y, SbArgs sb, int M, int proj_only) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __bf16* Yh = (__bf16*)smem;                 // [32][SB_YP]
   __bf16* Yl = Yh + 32 * SB_YP;
@@ -691,93 +793,50 @@ __global__ __launch_bounds__(LF_NT) void step_boundary_kernel(const float* __res
   __bf16* Pl = Ph + 32 * SB_PP;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int row0 = blockIdx.x * 32;
-  const int tok = lane & 31;
-  // GEMM1 (K = 256, N = 128): wave = (column block nb1 = wave & 3, k half = wave >> 2); GEMM2 (K = 128, N = 256): nb2 = wave
-  const int nb1 = wave & 3, kh = wave >> 2;
-  const int c1 = nb1 * 32 + 4 * (lane >> 5), c2 = wave * 32 + 4 * (lane >> 5);   // first output column (+ 8 g)
-  f32x4 bo4[4], bi4[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    bo4[g] = *(const f32x4*)(b_out + c1 + 8 * g);
-    bi4[g] = *(const f32x4*)(b_in + c2 + 8 * g);
-  }
-  bf16x8 w1[8][2], w2[8][2];
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-      w1[k][pl] = __builtin_bit_cast(bf16x8, wout_p[((((long long)(kh * 8 + k) * 4 + nb1) * 2 + pl) * 64) + lane]);
-      w2[k][pl] = __builtin_bit_cast(bf16x8, win_p[((((long long)k * 8 + wave) * 2 + pl) * 64) + lane]);
-    }
-  const int m = row0 + tok;                       // global row of this lane's token
-  const int mb = min(m, M - 1) / nslots, mn = min(m, M - 1) - mb * nslots;
-  f32x16 acc;
+  SbFrags f;
+  sb_load(sb, f, lane, wave);
   if (proj_only) {
-    // slot rows -> split-bf16 planes directly (2 float4 per thread: 32 rows x 32 float4)
+    // slot rows -> split-bf16 planes directly (2 float4 per thread: 32 rows x 32 float4), then only the in-projection
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = t + LF_NT * i, r = idx >> 5, q4 = idx & 31;
-      const int gm = min(row0 + r, M - 1), gb = gm / nslots, gn = gm - gb * nslots;
-      const f32x4 v = *(const f32x4*)(slots + gb * slots_bs + slots_off + (long long)gn * SB_C + 4 * q4);
+      const int gm = min(row0 + r, M - 1), gb = gm / sb.nslots, gn = gm - gb * sb.nslots;
+      const f32x4 v = *(const f32x4*)(sb.slots + gb * sb.slots_bs + sb.slots_off + (long long)gn * SB_C + 4 * q4);
       split4(Ph, Pl, r * SB_PP + 4 * q4, v);
     }
-  } else {
-    // y rows -> split-bf16 planes
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = wave + 8 * i;
-      const f32x4 v = *(const f32x4*)(y + (long long)min(row0 + r, M - 1) * LF_D + 4 * lane);
-      split4(Yh, Yl, r * SB_YP + 4 * lane, v);
-    }
     __syncthreads();
+    const int tok = lane & 31, c2 = wave * 32 + 4 * (lane >> 5);
+    const int m = row0 + tok;
+    const int mb = min(m, M - 1) / sb.nslots, mn = min(m, M - 1) - mb * sb.nslots;
+    f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    {
-      const int ao = tok * SB_YP + 8 * (lane >> 5) + kh * 128;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const bf16x8 xh = *(const bf16x8*)(Yh + ao + k * 16), xl = *(const bf16x8*)(Yl + ao + k * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[k][0], xl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[k][1], xh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[k][0], xh, acc, 0, 0, 0);
-      }
-    }
-    if (kh == 1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) R[(nb1 * 16 + r) * 64 + lane] = acc[r];
-    }
-    __syncthreads();
-    if (kh == 0) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 v;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = acc[4 * g + q] + R[(nb1 * 16 + 4 * g + q) * 64 + lane] + bo4[g][q];
-        split4(Ph, Pl, tok * SB_PP + c1 + 8 * g, v);
-        if (m < M) *(f32x4*)(slots + mb * slots_bs + slots_off + (long long)mn * SB_C + c1 + 8 * g) = v;
-      }
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  {
     const int ao = tok * SB_PP + 8 * (lane >> 5);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const bf16x8 xh = *(const bf16x8*)(Ph + ao + k * 16), xl = *(const bf16x8*)(Pl + ao + k * 16);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[k][0], xl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[k][1], xh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[k][0], xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w2[k][0], xl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w2[k][1], xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w2[k][0], xh, acc, 0, 0, 0);
     }
-  }
-  if (m < M) {
+    if (m < M) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 v = {acc[4 * g] + bi4[g][0], acc[4 * g + 1] + bi4[g][1], acc[4 * g + 2] + bi4[g][2], acc[4 * g + 3] + bi4[g][3]};
-      *(f32x4*)(ring + mb * ring_bs + ring_off + (long long)mn * LF_D + c2 + 8 * g) = v;
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = {acc[4 * g] + f.bi4[g][0], acc[4 * g + 1] + f.bi4[g][1], acc[4 * g + 2] + f.bi4[g][2],
+                         acc[4 * g + 3] + f.bi4[g][3]};
+        *(f32x4*)(sb.ring + mb * sb.ring_bs + sb.ring_off + (long long)mn * LF_D + c2 + 8 * g) = v;
+      }
     }
+    return;
   }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave + 8 * i;
+    const f32x4 v = *(const f32x4*)(y + (long long)min(row0 + r, M - 1) * LF_D + 4 * lane);
+    split4(Yh, Yl, r * SB_YP + 4 * lane, v);
+  }
+  __syncthreads();
+  sb_compute(sb, f, Yh, Yl, R, Ph, Pl, row0, M, lane, wave);
 }
 
 // y[i] = sum_c xp[c][i]  (float4 granules)
@@ -842,9 +901,14 @@ int sf_attn_oproj_ring_ex(const float* ring, int ring_frames, int nslots, int f0
                            B, L, Lq, st);
 }
 
-int sf_ffn_partial_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp,
-                      long long xp_stride, float* xout, int* counters, int M, int ffn, hipStream_t st) {
+static SbArgs make_sb(const void* wout_packed, const float* b_out, const void* win_packed, const float* b_in, float* slots,
+                      long long slots_bs, long long slots_off, float* ring, long long ring_bs, long long ring_off,
+                      int rows_per_video);
+
+static int launch_ffn(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp, long long xp_stride,
+                      float* xout, int* counters, int M, int ffn, const SbArgs& sb, hipStream_t st) {
   static_assert(FB_LDS <= 160 * 1024, "FFN kernel: LDS budget");
+  static_assert((size_t)4 * 16 * 64 * 4 + (size_t)2 * 32 * SB_PP * 2 <= (size_t)2 * FB_ROWS * FB_AP * 2, "boundary scratch fits the H planes");
   if (!w.lin1_packed || !w.lin2_packed || ffn != LF_NCH * LF_HC)
     return sf_set_err(-1, "invalid argument: fused FFN needs packed weights (sf_pack_ffn_weights) and ffn == 1024", __FILE__, __LINE__);
   static bool attr = false;
@@ -859,17 +923,52 @@ int sf_ffn_partial_ex(const float* ap, long long ap_stride, const sf_tfm_layer& 
   sf_prof_begin(SF_K_FFN, st, 4.0 * M * (double)LF_D * ffn);
   hipLaunchKernelGGL(ffn_partial_kernel, dim3(groups * 32), dim3(LF_NT), FB_LDS, st, ap, ap_stride, w.norm2_g,
                      w.norm2_b, eps, (const uint4*)w.lin1_packed, w.lin1_b, (const uint4*)w.lin2_packed, w.lin2_b, xp,
-                     xp_stride, xout, counters, tiles, M, lf_dbg());
+                     xp_stride, xout, counters, tiles, M, lf_dbg(), sb);
   sf_prof_end(SF_K_FFN, st);
   SF_CHECK_LAUNCH();
   return 0;
 }
 
+int sf_ffn_partial_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp,
+                      long long xp_stride, float* xout, int* counters, int M, int ffn, hipStream_t st) {
+  SbArgs sb;
+  memset(&sb, 0, sizeof(sb));
+  return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, xout, counters, M, ffn, sb, st);
+}
+
+// last layer of a rollout step: the FFN's last-arriving workgroups also run the step boundary (out-proj -> slots frame
+// `frame`, in-proj -> ring); M must be B * nslots
+int sf_ffn_boundary_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp, long long xp_stride,
+                       int* counters, int ffn, const void* wout_packed, const float* b_out, const void* win_packed,
+                       const float* b_in, float* slots, long long slots_bs, int frame, float* ring, int ring_frames, int nslots,
+                       int B, hipStream_t st) {
+  const SbArgs sb = make_sb(wout_packed, b_out, win_packed, b_in, slots, slots_bs, (long long)frame * nslots * SB_C, ring,
+                            (long long)ring_frames * nslots * LF_D, (long long)(frame % ring_frames) * nslots * LF_D, nslots);
+  return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, nullptr, counters, B * nslots, ffn, sb, st);
+}
+
 bool sf_step_boundary_ok(int d, int slot_size) { return d == LF_D && slot_size == SB_C; }
 
-static int launch_boundary(const float* y, const void* wout_packed, const float* b_out, const void* win_packed,
-                           const float* b_in, float* slots, long long slots_bs, long long slots_off, float* ring,
-                           long long ring_bs, long long ring_off, int rows_per_video, int M, int proj_only, hipStream_t st) {
+static SbArgs make_sb(const void* wout_packed, const float* b_out, const void* win_packed, const float* b_in, float* slots,
+                      long long slots_bs, long long slots_off, float* ring, long long ring_bs, long long ring_off,
+                      int rows_per_video) {
+  SbArgs a;
+  a.wout_p = (const uint4*)wout_packed;
+  a.b_out = b_out;
+  a.win_p = (const uint4*)win_packed;
+  a.b_in = b_in;
+  a.slots = slots;
+  a.slots_bs = slots_bs;
+  a.slots_off = slots_off;
+  a.ring = ring;
+  a.ring_bs = ring_bs;
+  a.ring_off = ring_off;
+  a.nslots = rows_per_video;
+  a.enabled = 1;
+  return a;
+}
+
+static int launch_boundary(const float* y, const SbArgs& sb, int M, int proj_only, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)step_boundary_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -878,9 +977,7 @@ static int launch_boundary(const float* y, const void* wout_packed, const float*
     attr = true;
   }
   sf_prof_begin(SF_K_LINEAR, st, (proj_only ? 2.0 : 4.0) * M * (double)LF_D * SB_C);
-  hipLaunchKernelGGL(step_boundary_kernel, dim3((M + 31) / 32), dim3(LF_NT), SB_LDS, st, y, (const uint4*)wout_packed, b_out,
-                     (const uint4*)win_packed, b_in, slots, slots_bs, slots_off, ring, ring_bs, ring_off, rows_per_video, M,
-                     proj_only);
+  hipLaunchKernelGGL(step_boundary_kernel, dim3((M + 31) / 32), dim3(LF_NT), SB_LDS, st, y, sb, M, proj_only);
   sf_prof_end(SF_K_LINEAR, st);
   SF_CHECK_LAUNCH();
   return 0;
@@ -890,16 +987,17 @@ static int launch_boundary(const float* y, const void* wout_packed, const float*
 int sf_step_boundary_ex(const float* y, const void* wout_packed, const float* b_out, const void* win_packed,
                         const float* b_in, float* slots, long long slots_bs, int frame, float* ring, int ring_frames,
                         int nslots, int B, hipStream_t st) {
-  return launch_boundary(y, wout_packed, b_out, win_packed, b_in, slots, slots_bs, (long long)frame * nslots * SB_C, ring,
-                         (long long)ring_frames * nslots * LF_D, (long long)(frame % ring_frames) * nslots * LF_D, nslots,
-                         B * nslots, 0, st);
+  const SbArgs sb = make_sb(wout_packed, b_out, win_packed, b_in, slots, slots_bs, (long long)frame * nslots * SB_C, ring,
+                            (long long)ring_frames * nslots * LF_D, (long long)(frame % ring_frames) * nslots * LF_D, nslots);
+  return launch_boundary(y, sb, B * nslots, 0, st);
 }
 
 // in-projection of the first n_frames (<= ring_frames) frames of every video -> ring slots 0 .. n_frames-1
 int sf_ring_init_ex(const void* wout_packed, const float* b_out, const void* win_packed, const float* b_in, float* slots,
                     long long slots_bs, int n_frames, float* ring, int ring_frames, int nslots, int B, hipStream_t st) {
-  return launch_boundary(nullptr, wout_packed, b_out, win_packed, b_in, slots, slots_bs, 0, ring,
-                         (long long)ring_frames * nslots * LF_D, 0, n_frames * nslots, B * n_frames * nslots, 1, st);
+  const SbArgs sb = make_sb(wout_packed, b_out, win_packed, b_in, slots, slots_bs, 0, ring,
+                            (long long)ring_frames * nslots * LF_D, 0, n_frames * nslots);
+  return launch_boundary(nullptr, sb, B * n_frames * nslots, 1, st);
 }
 
 extern "C" size_t sf_packed_linear_bytes(int N, int K) { return (size_t)N * K * 4; }
@@ -947,6 +1045,7 @@ extern "C" int sf_pack_ffn_weights(const float* lin1_w, const float* lin2_w, voi
   SF_CHECK_LAUNCH();
   return 0;
 }
+
 
 int sf_ffn_tiles(int M) { return (M + FB_ROWS - 1) / FB_ROWS; }
 
