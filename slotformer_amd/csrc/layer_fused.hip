@@ -1,19 +1,23 @@
 // Two-launch Transformer encoder layer for the rollout (d_model 256, 8 heads of 32, ffn 1024, pre-LN, L <= 64).
 //
-// The rollout is a chain of ~900 short dependent kernels per 50-step job; at M = B*L = 1344 rows every GEMM is
-// bound by launch + first-load latency (~10-15 us each), not by MFMA or bandwidth.  This file halves the chain:
+// The rollout is a chain of short dependent kernels (50 steps x 4 layers); at M = B*L = 1344 rows every GEMM is bound
+// by launch + first-load latency (~10-15 us each), not by MFMA or bandwidth.  This file cuts the chain from 18 to 8
+// launches per step:
 //
-//   attn_oproj_kernel  (one WG per (head, video)):
-//       x = sum of the previous layer's FFN partials;  LN1 -> q|k|v of head h (split-bf16 MFMA) -> softmax(qk^T)v
-//       (f32 MFMA) -> partial_h = o_h . Wo[:, 32h:32h+32]^T  (+ x and the out-proj bias on column block h)
+//   attn_oproj_kernel  (one WG per (head pair, video)):
+//       LN1 -> q|k|v of two heads (split-bf16 MFMA, packed register-resident weights) -> softmax(qk^T)v (f32 MFMA,
+//       scores transposed so the softmax stays in registers) -> partial_hp = [o_h0 | o_h1] . Wo[:, 64hp:64hp+64]^T
+//       (+ x and the out-proj bias on the two column blocks of the pair)
 //   ffn_partial_kernel (one WG per (32-row tile, 256-wide hidden chunk)):
-//       x2 = sum of the 8 head partials;  LN2 -> relu(. W1_c^T + b1_c) kept in LDS -> partial_c = h_c . W2[:, c]^T
-//       (+ x2 and the FFN bias for chunk 0)
+//       x2 = sum of the 4 head-pair partials;  LN2 -> relu(. W1_c^T + b1_c) kept in LDS -> y_c = h_c . W2[:, c]^T;
+//       the last workgroup of a tile to arrive sums the 4 chunk partials in fixed order and, on the last layer, also
+//       runs the step boundary (out-proj -> slots, in-proj of the new frame -> projection ring)
+//   step_boundary_kernel: the same boundary stand-alone (ring initialisation from the burn-in frames, fallback).
 //
-// The cross-workgroup reductions (over heads, over hidden chunks) are DEFERRED to the consumer's prologue, which
-// sums the partial buffers while loading them -- deterministic (fixed order, no atomics) and it removes the
-// out-proj and FFN2 launches plus the hidden-activation round trip.  Weight loads are issued before anything
-// else in both kernels so the first-load latency overlaps the partial-sum prologue.
+// The reduction over heads is DEFERRED to the consumer's prologue, which sums the partial buffers while loading them;
+// the reduction over hidden chunks is finished inside the FFN launch by the last arriver -- both deterministic (fixed
+// order, no atomics on data).  Small parameter vectors are requested before the weight fragments in every kernel
+// (vmcnt retires in order), and wave reductions use DPP, not ds_bpermute.
 // Reference call site: nn.TransformerEncoderLayer(norm_first=True) as configured at slotformer.py:72-80.
 #include "../../include/slotformer_hip.h"
 #include "sf_internal.h"
@@ -34,24 +38,11 @@ constexpr int LF_NP = 4;                            // head-PAIR partials writte
 constexpr int LF_HC = 256;                          // hidden chunk of the FFN kernel
 constexpr int LF_NCH = 4;                           // ffn / LF_HC (ffn = 1024)
 
-// ---- attention kernel geometry (same tiles as attn_fused.hip at HD = 32, NK = 4) ----
-constexpr int FA_ROWS = 64, FA_KC = 64, FA_LB = FA_KC + 8, FA_SS = FA_ROWS + 4;
+// ---- attention kernel geometry ----
+constexpr int FA_ROWS = 64, FA_KC = 64;             // padded sequence length, width of an activation load chunk
 constexpr int NK = LF_D / FA_KC;                    // 4
-constexpr int NC = 3 * LF_HD, NCP = 96, CBLK = 3;   // q|k|v columns of one head
 constexpr int A_IT = FA_ROWS * (FA_KC / 4) / LF_NT; // 2
-constexpr int B_IT = NCP * (FA_KC / 4) / LF_NT;     // 3
-constexpr int QSTR = LF_HD + 4;                     // 36
-constexpr int OP = LF_HD + 8;                       // bf16 row pitch of the O and Wo planes (80 B = 5 slots)
-constexpr int XS = LF_HD + 4;                       // f32 pitch of the residual stash
-constexpr size_t A_PLANES = (size_t)(2 * FA_ROWS + 2 * NCP) * FA_LB * 2 + 2 * FA_ROWS * 4;              // 46,592
-// attention phase (over the dead planes): Q, K, V as [token][QSTR] f32 + softmax statistics of the 4 score waves
-constexpr size_t A_ATTN = ((size_t)3 * FA_ROWS * QSTR + 2 * 4 * 32) * 4;                                // 28,672
-constexpr size_t A_OUT = (size_t)(2 * FA_ROWS + 2 * LF_D) * OP * 2;                                       // 51,200
-constexpr size_t A_MAX1 = A_PLANES > A_ATTN ? A_PLANES : A_ATTN;
-constexpr size_t A_OT_OFF = ((A_MAX1 > A_OUT ? A_MAX1 : A_OUT) + 255) / 256 * 256;   // PV partials [4][32][QSTR] f32
-constexpr size_t A_STASH_OFF = A_OT_OFF + (size_t)4 * 32 * QSTR * 4;
-constexpr size_t A_GB_OFF = A_STASH_OFF + (size_t)FA_ROWS * XS * 4;   // LN gamma | beta [2][256] f32, then q|k|v bias [96]
-constexpr size_t A_LDS = A_GB_OFF + (2 * LF_D + NCP) * 4;
+constexpr int QSTR = LF_HD + 4;                     // f32 row pitch of the q / k / v tiles (36)
 
 // ---- FFN kernel geometry ----
 constexpr int FB_ROWS = 32;
@@ -839,16 +830,6 @@ __global__ __launch_bounds__(LF_NT) void step_boundary_kernel(const float* __res
   sb_compute(sb, f, Yh, Yl, R, Ph, Pl, row0, M, lane, wave);
 }
 
-// y[i] = sum_c xp[c][i]  (float4 granules)
-__global__ void sum_partials_kernel(const float* __restrict__ xp, long long stride, int np, float* __restrict__ y,
-                                    long long n4) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  f32x4 s = *(const f32x4*)(xp + 4 * i);
-  for (int c = 1; c < np; ++c) s += *(const f32x4*)(xp + c * stride + 4 * i);
-  *(f32x4*)(y + 4 * i) = s;
-}
-
 // ------------------------------------------------------------------------------------------------
 // timing ablations (wrong results): 1 FFN reads one head partial, 2 FFN skips the W2 loads, 4 attention reads one
 // input partial, 8 attention stores one column block
@@ -1048,10 +1029,3 @@ extern "C" int sf_pack_ffn_weights(const float* lin1_w, const float* lin2_w, voi
 
 
 int sf_ffn_tiles(int M) { return (M + FB_ROWS - 1) / FB_ROWS; }
-
-int sf_sum_partials_ex(const float* xp, long long stride, int np, float* y, long long n, hipStream_t st) {
-  const long long n4 = n / 4;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, xp, stride, np, y, n4);
-  SF_CHECK_LAUNCH();
-  return 0;
-}
