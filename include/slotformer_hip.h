@@ -134,6 +134,10 @@ int sf_groupnorm1_nhwc_f32(const float* x, const float* gamma, const float* beta
  * plain sf_linear_f32 calls), token + position embedding, greedy token pick, token cross-entropy. */
 int sf_slate_attention_f32(const float* q, const float* k, const float* v, float* out, int ldq, int ldk, int ldv, int ldo,
                            int B, int Lq, int Lk, int num_heads, int head_dim, int causal, void* stream);
+/* the same with explicit batch strides (floats), so that k/v may be a partially filled K/V cache */
+int sf_slate_attention_strided_f32(const float* q, const float* k, const float* v, float* out, int ldq, int ldk, int ldv,
+                                   int ldo, long long q_bs, long long k_bs, long long v_bs, long long o_bs, int B, int Lq,
+                                   int Lk, int num_heads, int head_dim, int causal, void* stream);
 int sf_embed_tokens_f32(const long long* idx, const float* tok_emb, const float* pos, float* out, int B, int L, int d,
                         void* stream);
 int sf_argmax_rows_f32(const float* x, long long ld, long long* out, long long R, int V, void* stream);

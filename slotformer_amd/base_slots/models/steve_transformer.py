@@ -146,6 +146,52 @@ class STEVETransformerDecoder(nn.Module):
         fin = self.tf_dec.layer_norm
         return ops.linear(x, self.head.weight.detach(), ln=(fin.weight.detach(), fin.bias.detach()))
 
+    def generate_cached(self, slots, steps):
+        """Greedy generation with a K/V cache: the same arithmetic as `generate(sample=False)` (one new token per step
+        instead of re-running the prefix -- O(steps) launches of O(t) work instead of O(steps) forwards of O(t^2));
+        returns (tokens [B,steps] on device, logits [B,steps,V] on the CPU)."""
+        if self.training or torch.is_grad_enabled():
+            raise RuntimeError('slotformer_amd STEVETransformerDecoder is inference-only: .eval() + torch.no_grad()')
+        B = slots.shape[0]
+        assert steps - 1 <= self.max_len
+        d, H, dev = self.d_model, self.n_head, slots.device
+        blocks = self.tf_dec.blocks
+        mem = ops.linear(slots.contiguous(), self.in_proj.weight.detach(), self.in_proj.bias.detach())
+        # cross-attention keys/values of the slots: once per layer
+        mem_kv = [ops.linear(mem, self._catw(f'ca{i}', b.encoder_decoder_attn.proj_k.weight, b.encoder_decoder_attn.proj_v.weight))
+                  for i, b in enumerate(blocks)]
+        cache = [torch.empty(B, steps, 3 * d, device=dev, dtype=torch.float32) for _ in blocks]   # rows: q|k|v of token t
+        tok = torch.full((B, 1), self.vocab_size, dtype=torch.int64, device=dev)                  # BOS
+        pos = self.pos_emb.pe.detach()[0]
+        fin = self.tf_dec.layer_norm
+        ids, all_logits = [], []
+        for t in range(steps):
+            x = ops.embed_tokens(tok, self.tok_emb.weight.detach(), pos[t:t + 1].contiguous())      # [B,1,d]
+            for i, blk in enumerate(blocks):
+                sa, ca = blk.self_attn, blk.encoder_decoder_attn
+                ln1 = (blk.self_attn_layer_norm.weight.detach(), blk.self_attn_layer_norm.bias.detach())
+                wqkv = self._catw(f'sa{i}', sa.proj_q.weight, sa.proj_k.weight, sa.proj_v.weight)
+                if blk.is_first:
+                    x = ops.layernorm(x, *ln1)
+                    qkv = ops.linear(x, wqkv)
+                else:
+                    qkv = ops.linear(x, wqkv, ln=ln1)
+                cache[i][:, t] = qkv[:, 0]
+                att = ops.slate_attention_cached(qkv, cache[i], t + 1, H, d, d, 2 * d)
+                x = ops.linear(att, sa.proj_o.weight.detach(), residual=x)
+                ln2 = (blk.encoder_decoder_attn_layer_norm.weight.detach(), blk.encoder_decoder_attn_layer_norm.bias.detach())
+                q = ops.linear(x, ca.proj_q.weight.detach(), ln=ln2)
+                att = ops.slate_attention(q, mem_kv[i], mem_kv[i], H, False, 0, 0, d, d_model=d)
+                x = ops.linear(att, ca.proj_o.weight.detach(), residual=x)
+                ln3 = (blk.ffn_layer_norm.weight.detach(), blk.ffn_layer_norm.bias.detach())
+                hdn = ops.linear(x, blk.ffn[0].weight.detach(), blk.ffn[0].bias.detach(), ln=ln3, relu=True)
+                x = ops.linear(hdn, blk.ffn[2].weight.detach(), blk.ffn[2].bias.detach(), residual=x)
+            logits = ops.linear(x, self.head.weight.detach(), ln=(fin.weight.detach(), fin.bias.detach()))[:, 0].contiguous()
+            all_logits.append(logits)   # stays on the device: one host copy at the end, no per-step synchronisation
+            tok = ops.argmax_rows(logits).unsqueeze(1)
+            ids.append(tok)
+        return torch.cat(ids, dim=1), torch.stack(all_logits, dim=1).cpu()
+
     def generate(self, slots, steps, sample=False, temperature=1.0):
         """Greedy autoregressive generation (steve_transformer.py:305-333): the whole prefix is re-run every step, as in
         the reference; returns (tokens [B,steps] on device, logits [B,steps,V] on the CPU like the reference)."""

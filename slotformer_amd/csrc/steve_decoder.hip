@@ -91,13 +91,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 template <int HD>
 __global__ __launch_bounds__(256) void slate_attn_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, float* __restrict__ out, int ldq,
-                                                         int ldk, int ldv, int ldo, int Lq, int Lk, int causal, float scale) {
+                                                         int ldk, int ldv, int ldo, long long q_bs, long long k_bs,
+                                                         long long v_bs, long long o_bs, int Lq, int Lk, int causal,
+                                                         float scale) {
   __shared__ __attribute__((aligned(16))) float Ks[64][HD];
   __shared__ __attribute__((aligned(16))) float Vs[64][HD];
   const int t = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int i = blockIdx.x * 256 + t;
   const bool live = i < Lq;
-  const float* qr = q + ((long long)b * Lq + (live ? i : Lq - 1)) * ldq + h * HD;
+  const float* qr = q + (long long)b * q_bs + (long long)(live ? i : Lq - 1) * ldq + h * HD;
   float qv[HD], o[HD];
 #pragma unroll
   for (int c = 0; c < HD; c += 4) {
@@ -110,8 +112,8 @@ __global__ __launch_bounds__(256) void slate_attn_kernel(const float* __restrict
   }
   float m = -INFINITY, l = 0.f;
   const int kend = causal ? min(Lk, blockIdx.x * 256 + 256) : Lk;   // keys this block can see at all
-  const float* kb = k + (long long)b * Lk * ldk + h * HD;
-  const float* vb = v + (long long)b * Lk * ldv + h * HD;
+  const float* kb = k + (long long)b * k_bs + h * HD;
+  const float* vb = v + (long long)b * v_bs + h * HD;
   for (int k0 = 0; k0 < kend; k0 += 64) {
     constexpr int F4 = 64 * HD / 4;   // float4 per tile
     for (int idx = t; idx < F4; idx += 256) {
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void slate_attn_kernel(const float* __restrict
   }
   if (live) {
     const float inv = 1.0f / l;
-    float* orow = out + ((long long)b * Lq + i) * ldo + h * HD;
+    float* orow = out + (long long)b * o_bs + (long long)i * ldo + h * HD;
 #pragma unroll
     for (int c = 0; c < HD; c += 4) *(f32x4*)(orow + c) = f32x4{o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv};
   }
@@ -253,22 +255,26 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, 
 extern "C" {
 
 // out[b, i, h*hd + c] = sum_j softmax_j(q[b,i,h] . k[b,j,h] * hd^-0.5 (j <= i if causal)) v[b,j,h,c]
-// q [B*Lq, ldq], k [B*Lk, ldk], v [B*Lk, ldv], out [B*Lq, ldo]; head_dim in {16, 32, 48, 64}.
-int sf_slate_attention_f32(const float* q, const float* k, const float* v, float* out, int ldq, int ldk, int ldv, int ldo,
-                           int B, int Lq, int Lk, int num_heads, int head_dim, int causal, void* stream) {
+// q rows [Lq] of batch b start at q + b*q_bs (leading dim ldq), k/v rows [Lk] at k + b*k_bs / v + b*v_bs, out at
+// out + b*o_bs; head_dim in {16, 32, 48, 64}.  Explicit batch strides let k/v be a partially filled K/V cache.
+int sf_slate_attention_strided_f32(const float* q, const float* k, const float* v, float* out, int ldq, int ldk, int ldv,
+                                   int ldo, long long q_bs, long long k_bs, long long v_bs, long long o_bs, int B, int Lq,
+                                   int Lk, int num_heads, int head_dim, int causal, void* stream) {
   SF_REQUIRE(q && k && v && out, "sf_slate_attention_f32: null pointer");
   SF_REQUIRE(B >= 0 && Lq > 0 && Lk > 0 && num_heads > 0, "sf_slate_attention_f32: bad shape");
-  SF_REQUIRE((ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (ldo % 4) == 0, "sf_slate_attention_f32: leading dims must be multiples of 4");
+  SF_REQUIRE((ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (ldo % 4) == 0 && (q_bs % 4) == 0 && (k_bs % 4) == 0 &&
+                 (v_bs % 4) == 0 && (o_bs % 4) == 0, "sf_slate_attention_f32: leading dims / strides must be multiples of 4");
   SF_REQUIRE(!causal || Lq == Lk, "sf_slate_attention_f32: causal attention needs Lq == Lk");
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((Lq + 255) / 256, num_heads, B);
   const float scale = 1.0f / sqrtf((float)head_dim);
-#define SLATE_CASE(HD_)                                                                                              \
-  if (head_dim == HD_) {                                                                                             \
-    hipLaunchKernelGGL(slate_attn_kernel<HD_>, grid, dim3(256), 0, st, q, k, v, out, ldq, ldk, ldv, ldo, Lq, Lk, causal, scale); \
-    SF_CHECK_LAUNCH();                                                                                               \
-    return 0;                                                                                                        \
+#define SLATE_CASE(HD_)                                                                                                  \
+  if (head_dim == HD_) {                                                                                                 \
+    hipLaunchKernelGGL(slate_attn_kernel<HD_>, grid, dim3(256), 0, st, q, k, v, out, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, \
+                       o_bs, Lq, Lk, causal, scale);                                                                     \
+    SF_CHECK_LAUNCH();                                                                                                   \
+    return 0;                                                                                                            \
   }
   SLATE_CASE(16)
   SLATE_CASE(32)
@@ -276,6 +282,13 @@ int sf_slate_attention_f32(const float* q, const float* k, const float* v, float
   SLATE_CASE(64)
 #undef SLATE_CASE
   return sf_set_err(-1, "invalid argument: sf_slate_attention_f32 head_dim must be 16, 32, 48 or 64", __FILE__, __LINE__);
+}
+
+// contiguous batches: q [B*Lq, ldq], k [B*Lk, ldk], v [B*Lk, ldv], out [B*Lq, ldo]
+int sf_slate_attention_f32(const float* q, const float* k, const float* v, float* out, int ldq, int ldk, int ldv, int ldo,
+                           int B, int Lq, int Lk, int num_heads, int head_dim, int causal, void* stream) {
+  return sf_slate_attention_strided_f32(q, k, v, out, ldq, ldk, ldv, ldo, (long long)Lq * ldq, (long long)Lk * ldk,
+                                        (long long)Lk * ldv, (long long)Lq * ldo, B, Lq, Lk, num_heads, head_dim, causal, stream);
 }
 
 // out [R = B*L, d] = tok_emb[idx] + pos[t];  idx int64 [B, L] (values < rows of tok_emb), pos [>= L, d]

@@ -250,3 +250,16 @@ def softmax_rows(x, add=None, scale=1.0):
     out = torch.empty_like(x)
     check(lib().sf_softmax_rows_f32(_p(x), _p(add), float(scale), _p(out), x.numel() // V, V, _stream()))
     return out
+
+
+def slate_attention_cached(q, kv_cache, Lk, num_heads, d_model, k_off, v_off):
+    """One-query-per-sequence attention over the first Lk rows of a K/V cache.  q [B,1,ldq] (head block at column 0),
+    kv_cache [B,Lmax,ld] holding k at column k_off and v at column v_off of each row."""
+    _chk(q, kv_cache)
+    B, Lq, ldq = q.shape
+    Lmax, ld = kv_cache.shape[1], kv_cache.shape[2]
+    out = torch.empty(B, Lq, d_model, device=q.device, dtype=torch.float32)
+    check(lib().sf_slate_attention_strided_f32(q.data_ptr(), kv_cache.data_ptr() + 4 * k_off, kv_cache.data_ptr() + 4 * v_off,
+                                               _p(out), ldq, ld, ld, d_model, Lq * ldq, Lmax * ld, Lmax * ld, Lq * d_model, B, Lq,
+                                               Lk, num_heads, d_model // num_heads, 0, _stream()))
+    return out

@@ -53,7 +53,8 @@ class STEVESlotFormer(SlotFormer):
     def decode(self, slots, gumbel=None):
         """steve_slotformer.py:86-103: slots [B,N,D] -> (soft_recon, hard_recon) [B,3,H,W].  `gumbel` [B,V,h,w] injects the
         Gumbel noise of the soft relaxation (the reference draws it internally: -(Exp(1) + tiny).log())."""
-        _, logits = self.decoder.generate(slots, steps=self.num_patches, sample=False)   # [B,P,V] on the CPU
+        # K/V-cached greedy generation: same tokens / logits as decoder.generate(sample=False), O(P) instead of O(P^2) work
+        _, logits = self.decoder.generate_cached(slots, steps=self.num_patches)   # [B,P,V] on the CPU
         logits = logits.to(slots.device).contiguous()
         B, P, V = logits.shape
         if gumbel is None:

@@ -167,6 +167,10 @@ def test_steve_image_side_golden(dev, precision):
     assert not logits.is_cuda and rel_err(logits, g['gen_logits']) < RTOL
     with pytest.raises(NotImplementedError):
         m.trans_decoder.generate(slots, steps=2, sample=True)
+    # K/V-cached generation = prefix re-run generation (the reference's algorithm), here over 40 tokens
+    i1, l1 = m.trans_decoder.generate(slots, steps=40)
+    i2, l2 = m.trans_decoder.generate_cached(slots, steps=40)
+    assert torch.equal(i1, i2) and rel_err(l2, l1) < 1e-5
 
 
 @torch.no_grad()

@@ -72,6 +72,19 @@ def main():
     res['decoder_gflop_per_frame'] = fl / 1e9
     res['decoder_tflops'] = fl * F_ / (res['decoder_forward_xent_ms'] * 1e-3) / 1e12
     res['decoder_frames_per_s'] = F_ / (res['decoder_forward_xent_ms'] * 1e-3)
+    # greedy generation of the whole 32x32 token grid (STEVESlotFormer.decode): K/V-cached vs the reference's algorithm
+    # (re-run the prefix every step; timed on the first 96 steps and on steps 928..1023 via the forward at those lengths)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gi, _ = m.trans_decoder.generate_cached(slots, steps=1024)
+    torch.cuda.synchronize()
+    res['generate_cached_1024_s'] = time.perf_counter() - t0
+    res['generate_cached_tokens_per_s'] = F_ * 1024 / res['generate_cached_1024_s']
+    prefix_cost = 0.0
+    for Lp in (1, 256, 512, 768, 1023):   # forward cost at a few prefix lengths -> trapezoid estimate of sum over 1024 steps
+        idp = gi[:, :Lp - 1].contiguous() if Lp > 1 else gi[:, :0].contiguous()
+        prefix_cost += timed(lambda: m.trans_decoder(slots, idp), 3) * (1024 / 5)
+    res['generate_prefix_rerun_1024_s_estimate'] = prefix_cost
     # CPU oracle on a bounded sample
     c = a.cpu_frames
     torch.set_num_threads(16)
