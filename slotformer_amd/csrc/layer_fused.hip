@@ -155,16 +155,6 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
     qkvb = bias[(cb % 3) * d + (2 * hp + cb / 3) * HD + j];
   }
   const float bov = bo[wave * 32 + (lane & 31)];
-  // ---- q|k|v weight fragments of column block `wave` (waves 0..5): 16 k-steps x (hi, lo) = 128 VGPRs ----
-  bf16x8 wq[16][2];
-  if (wave < 6) {
-    const uint4* wp = wqkv_p + (((long long)(hp * 6 + wave) * 16) * 2) * 64 + lane;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      wq[ks][0] = __builtin_bit_cast(bf16x8, wp[(ks * 2) * 64]);
-      wq[ks][1] = __builtin_bit_cast(bf16x8, wp[(ks * 2 + 1) * 64]);
-    }
-  }
   // ---- activations (+ position table in ring mode) ----
   bool aok[A_IT];
   const float* arow[A_IT];
@@ -198,6 +188,18 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
     for (int kc = 0; kc < NK; ++kc)
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) ra[kc][i] += tp[kc][i];
+  }
+  // (requested AFTER the activations: vmcnt retires in order and LayerNorm needs x first; the fragments land while the
+  //  statistics and the LN(x) planes are computed)
+  // ---- q|k|v weight fragments of column block `wave` (waves 0..5): 16 k-steps x (hi, lo) = 128 VGPRs ----
+  bf16x8 wq[16][2];
+  if (wave < 6) {
+    const uint4* wp = wqkv_p + (((long long)(hp * 6 + wave) * 16) * 2) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      wq[ks][0] = __builtin_bit_cast(bf16x8, wp[(ks * 2) * 64]);
+      wq[ks][1] = __builtin_bit_cast(bf16x8, wp[(ks * 2 + 1) * 64]);
+    }
   }
   LF_TA(17);
   if (t < 128) *(f32x4*)(GB + 4 * t) = gbv;
@@ -590,13 +592,8 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
   auto ldw = [&](const uint4* base, int ks, int plane) {
     return __builtin_bit_cast(bf16x8, base[(ks * 8) * 128 + plane * 64]);
   };
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    wf[ks][0] = ldw(w1c, ks, 0);
-    wf[ks][1] = ldw(w1c, ks, 1);
-  }
-
-  // ---- x2 = sum of the head partials: wave `wave` owns rows wave + 8 i, lane = float4 column ----
+  // ---- x2 = sum of the head partials: wave `wave` owns rows wave + 8 i, lane = float4 column.  Requested BEFORE the
+  //      weight fragments (vmcnt retires in order and the LayerNorm needs x2 first) ----
   f32x4 x2[4];
   {
     f32x4 pr[LF_NP][4];
@@ -606,6 +603,11 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
       const float* p = ap + (long long)gr * LF_D + 4 * lane;
 #pragma unroll
       for (int q = 0; q < LF_NP; ++q) pr[q][i] = *(const f32x4*)(p + ((dbg & 1) ? 0 : q) * ap_stride);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      wf[ks][0] = ldw(w1c, ks, 0);
+      wf[ks][1] = ldw(w1c, ks, 1);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
