@@ -133,8 +133,8 @@ def log(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='videos per GPU')
     ap.add_argument('--no-graph', action='store_true', help='launch the rollout eagerly instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -307,13 +307,22 @@ def main():
                             engine.savi_cnn(savi, img, 0, steal, out=feat_bufs[j % 2], ws_slot=1)
                             ev_pre[j].record(s_rolls[0])
                 for j in range(n):
-                    with torch.cuda.stream(s_enc):
-                        if j >= NB:
-                            s_enc.wait_event(ev_roll[j - NB])  # slot buffer j % NB is free once rollout j-NB is done
+                    if j == 0 and cu_split:
+                        # pipeline fill: nothing else is running yet, so the first encode takes the whole chip (the
+                        # calling stream) instead of the 64-CU partition; the masked encode stream starts after it
                         if steal:
-                            s_enc.wait_event(ev_pre[j])
-                        encode(bufs[j % NB], feat_bufs[j % 2] if steal else None)
-                        ev_enc[j].record(s_enc)
+                            cur.wait_event(ev_pre[0])
+                        encode(bufs[0], feat_bufs[0] if steal else None)
+                        ev_enc[0].record(cur)
+                        s_enc.wait_event(ev_enc[0])
+                    else:
+                        with torch.cuda.stream(s_enc):
+                            if j >= NB:
+                                s_enc.wait_event(ev_roll[j - NB])  # slot buffer j % NB is free once rollout j-NB is done
+                            if steal:
+                                s_enc.wait_event(ev_pre[j])
+                            encode(bufs[j % NB], feat_bufs[j % 2] if steal else None)
+                            ev_enc[j].record(s_enc)
                     s_roll = s_rolls[j % n_rs]
                     with torch.cuda.stream(s_roll):
                         s_roll.wait_event(ev_enc[j])
