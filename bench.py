@@ -301,27 +301,22 @@ def main():
                 ev_enc = [torch.cuda.Event() for _ in range(n)]
                 ev_roll = [torch.cuda.Event() for _ in range(n)]
                 ev_pre = [torch.cuda.Event() for _ in range(n + 2)]
-                if steal:   # the first two batches' features are produced up front (inside the timed region)
-                    with torch.cuda.stream(s_rolls[0]):
-                        for j in range(min(2, n)):
-                            engine.savi_cnn(savi, img, 0, steal, out=feat_bufs[j % 2], ws_slot=1)
-                            ev_pre[j].record(s_rolls[0])
+                # (the first two batches compute their own convolutions: stealing starts with batch 2, whose features are
+                #  produced after the rollout of batch 0)
                 for j in range(n):
                     if j == 0 and cu_split:
                         # pipeline fill: nothing else is running yet, so the first encode takes the whole chip (the
                         # calling stream) instead of the 64-CU partition; the masked encode stream starts after it
-                        if steal:
-                            cur.wait_event(ev_pre[0])
-                        encode(bufs[0], feat_bufs[0] if steal else None)
+                        encode(bufs[0], None)
                         ev_enc[0].record(cur)
                         s_enc.wait_event(ev_enc[0])
                     else:
                         with torch.cuda.stream(s_enc):
                             if j >= NB:
                                 s_enc.wait_event(ev_roll[j - NB])  # slot buffer j % NB is free once rollout j-NB is done
-                            if steal:
+                            if steal and j >= 2:
                                 s_enc.wait_event(ev_pre[j])
-                            encode(bufs[j % NB], feat_bufs[j % 2] if steal else None)
+                            encode(bufs[j % NB], feat_bufs[j % 2] if (steal and j >= 2) else None)
                             ev_enc[j].record(s_enc)
                     s_roll = s_rolls[j % n_rs]
                     with torch.cuda.stream(s_roll):
