@@ -195,3 +195,59 @@ def test_errors_are_loud(dev):
         ops.linear(torch.zeros(4, 6, device=dev), torch.zeros(8, 6, device=dev))  # K % 4 != 0
     with pytest.raises(RuntimeError):
         ops.linear(torch.zeros(4, 8), torch.zeros(8, 8))  # CPU tensors: no fallback
+
+
+# ---- STEVE image-side kernels (row N2) against plain PyTorch fp32 references of the same op -------------------------
+from slotformer_amd import ops  # noqa: E402
+
+@pytest.mark.parametrize('shuffle', [1, 2])
+def test_groupnorm1_nhwc(dev, shuffle):
+    import torch.nn.functional as F
+    F_, H, W, C_ = 3, 8, 16, 64
+    x = rnd(F_, H, W, C_, seed=1, scale=2.0) + 0.5
+    g, b = 1 + 0.1 * rnd(C_, seed=2), 0.1 * rnd(C_, seed=3)
+    ref = F.relu(F.group_norm(x.permute(0, 3, 1, 2), 1, g, b))
+    if shuffle == 2:
+        ref = F.pixel_shuffle(ref, 2)
+    out = ops.groupnorm1_nhwc(x.to(dev), g.to(dev), b.to(dev), relu=True, pixel_shuffle=shuffle)
+    close(out.permute(0, 3, 1, 2), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('hd,heads,Lq,Lk,causal', [(16, 4, 257, 257, True), (48, 4, 300, 300, True), (32, 2, 70, 6, False),
+                                                   (64, 2, 1, 33, False)])
+def test_slate_attention(dev, hd, heads, Lq, Lk, causal):
+    B, d = 2, hd * heads
+    q, k, v = rnd(B, Lq, d, seed=4), rnd(B, Lk, d, seed=5), rnd(B, Lk, d, seed=6)
+    qh, kh, vh = (t.view(B, -1, heads, hd).transpose(1, 2) for t in (q, k, v))
+    att = (qh * hd**-0.5) @ kh.transpose(-1, -2)
+    if causal:
+        att = att.masked_fill(torch.triu(torch.ones(Lq, Lk, dtype=torch.bool), 1), float('-inf'))
+    ref = (att.softmax(-1) @ vh).transpose(1, 2).reshape(B, Lq, d)
+    out = ops.slate_attention(q.to(dev), k.to(dev), v.to(dev), heads, causal)
+    close(out, ref, rtol=2e-5, atol=2e-5)
+    # side-by-side q|k|v buffer (column offsets) and a partially filled K/V cache (explicit batch strides)
+    if Lq == Lk:
+        qkv = torch.cat([q, k, v], -1).to(dev).contiguous()
+        close(ops.slate_attention(qkv, qkv, qkv, heads, causal, 0, d, 2 * d, d_model=d), ref, rtol=2e-5, atol=2e-5)
+    if Lq == 1:
+        cache = torch.zeros(B, Lk + 7, 3 * d)
+        cache[:, :Lk, d:2 * d], cache[:, :Lk, 2 * d:] = k, v
+        qq = torch.cat([q, torch.zeros(B, 1, 2 * d)], -1).to(dev).contiguous()
+        close(ops.slate_attention_cached(qq, cache.to(dev), Lk, heads, d, d, 2 * d), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_softmax_argmax_xent_embed(dev):
+    import torch.nn.functional as F
+    R, V = 37, 4096
+    x, g = rnd(R, V, seed=7, scale=3.0), rnd(R, V, seed=8)
+    close(ops.softmax_rows(x.to(dev), g.to(dev), 10.0), F.softmax((x + g) * 10.0, -1), rtol=1e-5, atol=1e-7)
+    close(ops.softmax_rows(x.to(dev)), F.softmax(x, -1), rtol=1e-5, atol=1e-8)
+    x[3, 100] = x[3, 2000] = 50.0   # tie: the first index wins (torch.argmax)
+    assert torch.equal(ops.argmax_rows(x.to(dev)).cpu(), x.argmax(-1)) and int(ops.argmax_rows(x.to(dev))[3]) == 100
+    tgt = torch.from_numpy(np.random.RandomState(9).randint(0, V, size=R)).long()
+    assert abs(float(ops.cross_entropy(x.to(dev), tgt.to(dev))) - float(F.cross_entropy(x, tgt))) < 1e-5
+    emb, pos = rnd(V + 1, 64, seed=10), rnd(50, 64, seed=11)
+    idx = torch.from_numpy(np.random.RandomState(12).randint(0, V + 1, size=(3, 41))).long()
+    close(ops.embed_tokens(idx.to(dev), emb.to(dev), pos.to(dev)), emb[idx] + pos[:41], rtol=0, atol=0)
+    with pytest.raises(TypeError):
+        ops.embed_tokens(idx.int().to(dev), emb.to(dev), pos.to(dev))
