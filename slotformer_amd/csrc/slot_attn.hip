@@ -169,16 +169,31 @@ __global__ __launch_bounds__(256) void sa_attn_mfma_kernel(
   }
   __syncthreads();
 
-  // ---- phase 1: lane = pixel ---------------------------------------------------------------
-  const float* krow = k + (long long)b * batch_stride + (long long)(pix0 + lane) * ld;
+  // ---- phase 1: lane = pixel.  The K rows reach their lanes through an LDS slab: a load instruction with one pixel row
+  //      per lane touches 64 separate cache lines (rows are 1 KB apart), so the wave instead loads a 32-channel slab of
+  //      its 64 rows with 8 lanes per row (8 x 128 B contiguous per instruction), parks it in LDS and every lane reads
+  //      ITS row back; the next slab is requested before the current one is consumed. ----
+  __shared__ __attribute__((aligned(16))) float s_k[4][64][36];
+  const float* kslab = k + (long long)b * batch_stride + (long long)(pix0 + (lane >> 3)) * ld + 4 * (lane & 7);
   float s[NS];
 #pragma unroll
   for (int n = 0; n < NS; ++n) s[n] = 0.f;
-#pragma unroll 2
+  f32x4v nx[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) nx[u] = *(const f32x4v*)(kslab + (long long)(8 * u) * ld);
+#pragma unroll 1
   for (int d0 = 0; d0 < D; d0 += 32) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) *(f32x4v*)&s_k[wave][(lane >> 3) + 8 * u][4 * (lane & 7)] = nx[u];
+    if (d0 + 32 < D) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) nx[u] = *(const f32x4v*)(kslab + (long long)(8 * u) * ld + d0 + 32);
+    }
+    __builtin_amdgcn_wave_barrier();
     f32x4v kx[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) kx[u] = *(const f32x4v*)(krow + d0 + 4 * u);
+    for (int u = 0; u < 8; ++u) kx[u] = *(const f32x4v*)&s_k[wave][lane][4 * u];
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
 #pragma unroll
