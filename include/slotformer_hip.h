@@ -147,6 +147,28 @@ int sf_cross_entropy_f32(const float* x, const long long* target, float* loss_ro
  * add = Gumbel noise, scale = 1/tau (steve_slotformer.py:97-98). */
 int sf_softmax_rows_f32(const float* x, const float* add, float scale, float* y, long long R, int V, void* stream);
 
+/* K/V-cached greedy generation of the dVAE token grid (STEVETransformerDecoder.generate, sample=False,
+ * steve_transformer.py:305-333; used by STEVESlotFormer.decode, steve_slotformer.py:92-93).  One token per step; the
+ * arithmetic of a step equals the reference's forward on the prefix.  All pointers device, torch layouts; wqkv =
+ * cat(proj_q, proj_k, proj_v).weight [3d,d], wkv_c = cat(proj_k, proj_v).weight of the cross-attention [2d,d]. */
+typedef struct {
+  const float *ln1_g, *ln1_b, *wqkv, *wo;          /* self-attention */
+  const float *ln2_g, *ln2_b, *wq_c, *wkv_c, *wo_c; /* encoder_decoder_attn (keys / values = the slots) */
+  const float *ln3_g, *ln3_b, *w1, *b1, *w2, *b2;   /* FFN */
+  int is_first;                                     /* first block: input normalised in place (steve_transformer.py:186) */
+} sf_slate_block;
+
+typedef struct {
+  int d_model, num_heads, num_layers, vocab_size, num_slots, max_len;
+  const float *in_proj_w, *in_proj_b, *tok_emb /*[V+1,d]*/, *pos_emb /*[max_len+1,d]*/, *lnf_g, *lnf_b, *head_w /*[V,d]*/;
+  const sf_slate_block* blocks; /* HOST array [num_layers] */
+} sf_slate_decoder;
+
+size_t sf_slate_generate_workspace_bytes(const sf_slate_decoder* m, int B, int steps);
+/* slots [B,N,d] -> tokens_out int64 [B,steps]; logits_out [B,steps,V] or NULL. */
+int sf_slate_generate_f32(const sf_slate_decoder* m, const float* slots, int B, int steps, long long* tokens_out,
+                          float* logits_out, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- whole-path engines ------------------------------------------------------------------ */
 
 /* One nn.TransformerEncoderLayer (relu, batch_first); all pointers device, torch layouts. */

@@ -48,6 +48,17 @@ class sf_savi_encoder(C.Structure):
         [('sa_eps', C.c_float)])
 
 
+class sf_slate_block(C.Structure):
+    _fields_ = [(n, FP) for n in ('ln1_g', 'ln1_b', 'wqkv', 'wo', 'ln2_g', 'ln2_b', 'wq_c', 'wkv_c', 'wo_c', 'ln3_g', 'ln3_b',
+                                  'w1', 'b1', 'w2', 'b2')] + [('is_first', C.c_int)]
+
+
+class sf_slate_decoder(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('d_model', 'num_heads', 'num_layers', 'vocab_size', 'num_slots', 'max_len')] + [
+        (n, FP) for n in ('in_proj_w', 'in_proj_b', 'tok_emb', 'pos_emb', 'lnf_g', 'lnf_b', 'head_w')] + [
+            ('blocks', C.POINTER(sf_slate_block))]
+
+
 class sf_savi_decoder(C.Structure):
     _fields_ = ([('resolution', C.c_int), ('dec_layers', C.c_int), ('dec_channels', C.c_int * 9),
                  ('dec_strides', C.c_int * 8), ('dec_ks', C.c_int), ('dec_res', C.c_int), ('num_slots', C.c_int),
@@ -98,6 +109,8 @@ SIGNATURES = {
     'sf_argmax_rows_f32': (I, [FP, LL, VP, LL, I, VP]),
     'sf_cross_entropy_f32': (I, [FP, VP, FP, FP, LL, I, VP]),
     'sf_softmax_rows_f32': (I, [FP, FP, F32, FP, LL, I, VP]),
+    'sf_slate_generate_workspace_bytes': (SZ, [C.POINTER(sf_slate_decoder), I, I]),
+    'sf_slate_generate_f32': (I, [C.POINTER(sf_slate_decoder), FP, I, I, VP, FP, VP, SZ, VP]),
     'sf_packed_linear_bytes': (SZ, [I, I]),
     'sf_pack_linear_weights': (I, [FP, VP, I, I, VP]),
     'sf_attn_packed_bytes': (SZ, [I, I]),

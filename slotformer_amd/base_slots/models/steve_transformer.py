@@ -146,51 +146,69 @@ class STEVETransformerDecoder(nn.Module):
         fin = self.tf_dec.layer_norm
         return ops.linear(x, self.head.weight.detach(), ln=(fin.weight.detach(), fin.bias.detach()))
 
+    def _slate_plan(self):
+        """sf_slate_decoder descriptor (device pointers of the weights + concatenated projections), rebuilt when a
+        parameter changes."""
+        import ctypes as C
+        from ..._lib import sf_slate_block, sf_slate_decoder
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        plan = getattr(self, '_plan', None)
+        if plan is not None and plan[0] == sig:
+            return plan[1]
+        keep = []
+
+        def dp(t):
+            t = t.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.float().contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        blocks = (sf_slate_block * len(self.tf_dec.blocks))()
+        for i, blk in enumerate(self.tf_dec.blocks):
+            sa, ca, k = blk.self_attn, blk.encoder_decoder_attn, blocks[i]
+            k.ln1_g, k.ln1_b = dp(blk.self_attn_layer_norm.weight), dp(blk.self_attn_layer_norm.bias)
+            k.wqkv = dp(torch.cat([sa.proj_q.weight, sa.proj_k.weight, sa.proj_v.weight], 0))
+            k.wo = dp(sa.proj_o.weight)
+            k.ln2_g, k.ln2_b = dp(blk.encoder_decoder_attn_layer_norm.weight), dp(blk.encoder_decoder_attn_layer_norm.bias)
+            k.wq_c, k.wo_c = dp(ca.proj_q.weight), dp(ca.proj_o.weight)
+            k.wkv_c = dp(torch.cat([ca.proj_k.weight, ca.proj_v.weight], 0))
+            k.ln3_g, k.ln3_b = dp(blk.ffn_layer_norm.weight), dp(blk.ffn_layer_norm.bias)
+            k.w1, k.b1, k.w2, k.b2 = dp(blk.ffn[0].weight), dp(blk.ffn[0].bias), dp(blk.ffn[2].weight), dp(blk.ffn[2].bias)
+            k.is_first = int(blk.is_first)
+        m = sf_slate_decoder()
+        m.d_model, m.num_heads, m.num_layers = self.d_model, self.n_head, len(self.tf_dec.blocks)
+        m.vocab_size, m.num_slots, m.max_len = self.vocab_size, self.num_slots, self.max_len
+        m.in_proj_w, m.in_proj_b = dp(self.in_proj.weight), dp(self.in_proj.bias)
+        m.tok_emb, m.pos_emb = dp(self.tok_emb.weight), dp(self.pos_emb.pe[0])
+        m.lnf_g, m.lnf_b = dp(self.tf_dec.layer_norm.weight), dp(self.tf_dec.layer_norm.bias)
+        m.head_w = dp(self.head.weight)
+        m.blocks = C.cast(blocks, C.POINTER(sf_slate_block))
+        keep.append(blocks)
+        self._plan = (sig, (m, keep))
+        return self._plan[1]
+
     def generate_cached(self, slots, steps):
-        """Greedy generation with a K/V cache: the same arithmetic as `generate(sample=False)` (one new token per step
-        instead of re-running the prefix -- O(steps) launches of O(t) work instead of O(steps) forwards of O(t^2));
-        returns (tokens [B,steps] on device, logits [B,steps,V] on the CPU)."""
+        """Greedy generation with a K/V cache (`sf_slate_generate_f32`): the same arithmetic as `generate(sample=False)`,
+        one new token per step instead of re-running the prefix, the whole loop inside one C call; returns (tokens
+        [B,steps] on device, logits [B,steps,V] on the CPU like the reference)."""
+        import ctypes as C
+        from ..._lib import check, lib
         if self.training or torch.is_grad_enabled():
             raise RuntimeError('slotformer_amd STEVETransformerDecoder is inference-only: .eval() + torch.no_grad()')
+        if not (slots.is_cuda and slots.dtype == torch.float32):
+            raise RuntimeError('generate_cached needs float32 slots on a HIP device; there is no CPU fallback')
+        assert slots.shape[1] == self.num_slots and steps - 1 <= self.max_len
+        slots = slots.contiguous()
         B = slots.shape[0]
-        assert steps - 1 <= self.max_len
-        d, H, dev = self.d_model, self.n_head, slots.device
-        blocks = self.tf_dec.blocks
-        mem = ops.linear(slots.contiguous(), self.in_proj.weight.detach(), self.in_proj.bias.detach())
-        # cross-attention keys/values of the slots: once per layer
-        mem_kv = [ops.linear(mem, self._catw(f'ca{i}', b.encoder_decoder_attn.proj_k.weight, b.encoder_decoder_attn.proj_v.weight))
-                  for i, b in enumerate(blocks)]
-        cache = [torch.empty(B, steps, 3 * d, device=dev, dtype=torch.float32) for _ in blocks]   # rows: q|k|v of token t
-        tok = torch.full((B, 1), self.vocab_size, dtype=torch.int64, device=dev)                  # BOS
-        pos = self.pos_emb.pe.detach()[0]
-        fin = self.tf_dec.layer_norm
-        ids, all_logits = [], []
-        for t in range(steps):
-            x = ops.embed_tokens(tok, self.tok_emb.weight.detach(), pos[t:t + 1].contiguous())      # [B,1,d]
-            for i, blk in enumerate(blocks):
-                sa, ca = blk.self_attn, blk.encoder_decoder_attn
-                ln1 = (blk.self_attn_layer_norm.weight.detach(), blk.self_attn_layer_norm.bias.detach())
-                wqkv = self._catw(f'sa{i}', sa.proj_q.weight, sa.proj_k.weight, sa.proj_v.weight)
-                if blk.is_first:
-                    x = ops.layernorm(x, *ln1)
-                    qkv = ops.linear(x, wqkv)
-                else:
-                    qkv = ops.linear(x, wqkv, ln=ln1)
-                cache[i][:, t] = qkv[:, 0]
-                att = ops.slate_attention_cached(qkv, cache[i], t + 1, H, d, d, 2 * d)
-                x = ops.linear(att, sa.proj_o.weight.detach(), residual=x)
-                ln2 = (blk.encoder_decoder_attn_layer_norm.weight.detach(), blk.encoder_decoder_attn_layer_norm.bias.detach())
-                q = ops.linear(x, ca.proj_q.weight.detach(), ln=ln2)
-                att = ops.slate_attention(q, mem_kv[i], mem_kv[i], H, False, 0, 0, d, d_model=d)
-                x = ops.linear(att, ca.proj_o.weight.detach(), residual=x)
-                ln3 = (blk.ffn_layer_norm.weight.detach(), blk.ffn_layer_norm.bias.detach())
-                hdn = ops.linear(x, blk.ffn[0].weight.detach(), blk.ffn[0].bias.detach(), ln=ln3, relu=True)
-                x = ops.linear(hdn, blk.ffn[2].weight.detach(), blk.ffn[2].bias.detach(), residual=x)
-            logits = ops.linear(x, self.head.weight.detach(), ln=(fin.weight.detach(), fin.bias.detach()))[:, 0].contiguous()
-            all_logits.append(logits)   # stays on the device: one host copy at the end, no per-step synchronisation
-            tok = ops.argmax_rows(logits).unsqueeze(1)
-            ids.append(tok)
-        return torch.cat(ids, dim=1), torch.stack(all_logits, dim=1).cpu()
+        m, _ = self._slate_plan()
+        tokens = torch.empty(B, steps, dtype=torch.int64, device=slots.device)
+        logits = torch.empty(B, steps, self.vocab_size, dtype=torch.float32, device=slots.device)
+        nb = lib().sf_slate_generate_workspace_bytes(C.byref(m), B, steps)
+        ws = torch.empty(nb, dtype=torch.uint8, device=slots.device)
+        check(lib().sf_slate_generate_f32(C.byref(m), slots.data_ptr(), B, steps, tokens.data_ptr(), logits.data_ptr(),
+                                          ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream))
+        return tokens, logits.cpu()
 
     def generate(self, slots, steps, sample=False, temperature=1.0):
         """Greedy autoregressive generation (steve_transformer.py:305-333): the whole prefix is re-run every step, as in

@@ -149,21 +149,87 @@ __global__ __launch_bounds__(256) void slate_attn_kernel(const float* __restrict
   }
 }
 
+// Single-query attention (K/V-cached decoding, Lq == 1): one workgroup per (head, batch), the KEYS are spread over the
+// 256 threads (online softmax per thread, then one block-wide merge), instead of one thread walking all keys.
+template <int HD>
+__global__ __launch_bounds__(256) void slate_decode_attn_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v, float* __restrict__ out, int ldk,
+                                                                int ldv, long long q_bs, long long k_bs, long long v_bs,
+                                                                long long o_bs, int Lk, float scale) {
+  const int t = threadIdx.x, h = blockIdx.x, b = blockIdx.y, lane = t & 63, wave = t >> 6;
+  const float* qr = q + (long long)b * q_bs + h * HD;
+  float qv[HD], o[HD];
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    const f32x4 x = *(const f32x4*)(qr + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      qv[c + e] = x[e] * scale;
+      o[c + e] = 0.f;
+    }
+  }
+  float m = -INFINITY, l = 0.f;
+  const float* kb = k + (long long)b * k_bs + h * HD;
+  const float* vb = v + (long long)b * v_bs + h * HD;
+  for (int j = t; j < Lk; j += 256) {
+    const float* kr = kb + (long long)j * ldk;
+    const float* vr = vb + (long long)j * ldv;
+    float sc = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const f32x4 x = *(const f32x4*)(kr + c);
+      sc += (qv[c] * x[0] + qv[c + 1] * x[1]) + (qv[c + 2] * x[2] + qv[c + 3] * x[3]);
+    }
+    const float mn = fmaxf(m, sc);
+    const float corr = (m == -INFINITY) ? 0.f : expf(m - mn), pj = expf(sc - mn);
+    l = l * corr + pj;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const f32x4 x = *(const f32x4*)(vr + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[c + e] = o[c + e] * corr + pj * x[e];
+    }
+    m = mn;
+  }
+  // block-wide merge: global max, rescale, sum
+  __shared__ float s_m[4], s_l[4], s_o[4][HD];
+  const float wm = sf_wave_max(m);
+  if (lane == 0) s_m[wave] = wm;
+  __syncthreads();
+  const float gm = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+  const float f = (m == -INFINITY) ? 0.f : expf(m - gm);
+  const float wl = sf_wave_sum(l * f);
+  if (lane == 0) s_l[wave] = wl;
+#pragma unroll
+  for (int c = 0; c < HD; ++c) {
+    const float wo = sf_wave_sum(o[c] * f);
+    if (lane == 0) s_o[wave][c] = wo;
+  }
+  __syncthreads();
+  if (t < HD) {
+    const float tl = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]);
+    out[(long long)b * o_bs + h * HD + t] = ((s_o[0][t] + s_o[1][t]) + (s_o[2][t] + s_o[3][t])) / tl;
+  }
+}
+
 // x[b, t] = tok_emb[idx[b, t]] + pos[t]   (steve_transformer.py:291-296: BOS already prepended by the caller)
-__global__ void embed_kernel(const long long* __restrict__ idx, const float* __restrict__ emb, const float* __restrict__ pos,
-                             float* __restrict__ out, int L, int d, long long total4) {
+// idx element of (batch b, position t) = idx[b * idx_bs + t]; const_tok >= 0 replaces the lookup (the BOS token)
+__global__ void embed_kernel(const long long* __restrict__ idx, long long idx_bs, long long const_tok,
+                             const float* __restrict__ emb, const float* __restrict__ pos, float* __restrict__ out, int L,
+                             int d, long long total4) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int d4 = d / 4;
   const long long row = i / d4;
   const int c4 = (int)(i - row * d4), tpos = (int)(row % L);
-  const f32x4 e = *(const f32x4*)(emb + idx[row] * d + 4 * c4), p = *(const f32x4*)(pos + (long long)tpos * d + 4 * c4);
+  const long long tok = const_tok >= 0 ? const_tok : idx[(row / L) * idx_bs + tpos];
+  const f32x4 e = *(const f32x4*)(emb + tok * d + 4 * c4), p = *(const f32x4*)(pos + (long long)tpos * d + 4 * c4);
   *(f32x4*)(out + row * d + 4 * c4) = e + p;
 }
 
 // first index of the row maximum (torch.argmax / topk(k=1) tie rule); one wave per row
 __global__ __launch_bounds__(64) void argmax_rows_kernel(const float* __restrict__ x, long long ld, long long* __restrict__ out,
-                                                         int V) {
+                                                         long long out_stride, int V) {
   const long long r = blockIdx.x;
   const float* xr = x + r * ld;
   float best = -INFINITY;
@@ -183,7 +249,7 @@ __global__ __launch_bounds__(64) void argmax_rows_kernel(const float* __restrict
       bi = oi;
     }
   }
-  if (threadIdx.x == 0) out[r] = bi;
+  if (threadIdx.x == 0) out[r * out_stride] = bi;
 }
 
 // per-row cross-entropy  -log softmax(x)[target]  (F.cross_entropy, steve.py:341-344); one workgroup per row
@@ -269,6 +335,20 @@ int sf_slate_attention_strided_f32(const float* q, const float* k, const float* 
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((Lq + 255) / 256, num_heads, B);
   const float scale = 1.0f / sqrtf((float)head_dim);
+  if (Lq == 1 && !causal) {   // K/V-cached decoding: spread the keys over a workgroup
+#define SLATE_DEC(HD_)                                                                                                       \
+  if (head_dim == HD_) {                                                                                                     \
+    hipLaunchKernelGGL(slate_decode_attn_kernel<HD_>, dim3(num_heads, B), dim3(256), 0, st, q, k, v, out, ldk, ldv, q_bs, k_bs, \
+                       v_bs, o_bs, Lk, scale);                                                                               \
+    SF_CHECK_LAUNCH();                                                                                                       \
+    return 0;                                                                                                                \
+  }
+    SLATE_DEC(16)
+    SLATE_DEC(32)
+    SLATE_DEC(48)
+    SLATE_DEC(64)
+#undef SLATE_DEC
+  }
 #define SLATE_CASE(HD_)                                                                                                  \
   if (head_dim == HD_) {                                                                                                 \
     hipLaunchKernelGGL(slate_attn_kernel<HD_>, grid, dim3(256), 0, st, q, k, v, out, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, \
@@ -297,8 +377,8 @@ int sf_embed_tokens_f32(const long long* idx, const float* tok_emb, const float*
   SF_REQUIRE(idx && tok_emb && pos && out && B >= 0 && L > 0 && d > 0 && (d % 4) == 0, "sf_embed_tokens_f32: bad arguments");
   const long long total4 = (long long)B * L * (d / 4);
   if (total4 == 0) return 0;
-  hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, tok_emb, pos,
-                     out, L, d, total4);
+  hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx,
+                     (long long)L, -1LL, tok_emb, pos, out, L, d, total4);
   SF_CHECK_LAUNCH();
   return 0;
 }
@@ -307,7 +387,7 @@ int sf_embed_tokens_f32(const long long* idx, const float* tok_emb, const float*
 int sf_argmax_rows_f32(const float* x, long long ld, long long* out, long long R, int V, void* stream) {
   SF_REQUIRE(x && out && R >= 0 && V > 0 && ld >= V, "sf_argmax_rows_f32: bad arguments");
   if (R == 0) return 0;
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)R), dim3(64), 0, (hipStream_t)stream, x, ld, out, V);
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)R), dim3(64), 0, (hipStream_t)stream, x, ld, out, 1LL, V);
   SF_CHECK_LAUNCH();
   return 0;
 }
@@ -352,6 +432,107 @@ int sf_groupnorm1_nhwc_f32(const float* x, const float* gamma, const float* beta
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256), F), dim3(256), 0, st, x, (const double*)ws, gamma,
                      beta, y, H, W, C, eps, relu, pixel_shuffle);
   SF_CHECK_LAUNCH();
+  return 0;
+}
+
+
+// ---- K/V-cached greedy generation (STEVETransformerDecoder.generate with sample=False, steve_transformer.py:305-333,
+//      computed one token per step; the arithmetic of a step is that of the reference's forward on the prefix) ----
+size_t sf_slate_generate_workspace_bytes(const sf_slate_decoder* m, int B, int steps) {
+  if (!m || B <= 0 || steps <= 0) return 0;
+  const size_t d = m->d_model, N = m->num_slots, L = m->num_layers;
+  auto pad = [](size_t nfloat) { return ((nfloat * sizeof(float)) + 255) & ~(size_t)255; };
+  return pad(B * N * d) + L * pad(B * N * 2 * d) + L * pad((size_t)B * steps * 3 * d) + 6 * pad(B * d) + pad(B * 4 * d) +
+         pad((size_t)B * m->vocab_size) + 4096;
+}
+
+int sf_slate_generate_f32(const sf_slate_decoder* m, const float* slots, int B, int steps, long long* tokens_out,
+                          float* logits_out, void* ws, size_t ws_bytes, void* stream) {
+  SF_REQUIRE(m && slots && tokens_out && ws, "sf_slate_generate_f32: null pointer");
+  SF_REQUIRE(B >= 1 && steps >= 1 && steps - 1 <= m->max_len, "sf_slate_generate_f32: bad batch / step count");
+  SF_REQUIRE(m->d_model > 0 && (m->d_model % 4) == 0 && m->num_heads > 0 && (m->d_model % m->num_heads) == 0 &&
+                 m->num_layers >= 0 && m->vocab_size > 0 && m->num_slots > 0, "sf_slate_generate_f32: bad decoder shape");
+  SF_REQUIRE(m->in_proj_w && m->in_proj_b && m->tok_emb && m->pos_emb && m->lnf_g && m->lnf_b && m->head_w &&
+                 (m->num_layers == 0 || m->blocks), "sf_slate_generate_f32: null weight");
+  SF_REQUIRE(ws_bytes >= sf_slate_generate_workspace_bytes(m, B, steps), "sf_slate_generate_f32: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int d = m->d_model, H = m->num_heads, N = m->num_slots, V = m->vocab_size, NL = m->num_layers;
+  const float eps = 1e-5f;
+  char* p = (char*)ws;
+  auto take = [&](size_t nfloat) {
+    float* r = (float*)p;
+    p += ((nfloat * sizeof(float)) + 255) & ~(size_t)255;
+    return r;
+  };
+  float* mem = take((size_t)B * N * d);
+  float* memkv[16];
+  float* cache[16];
+  SF_REQUIRE(NL <= 16, "sf_slate_generate_f32: at most 16 decoder blocks");
+  for (int i = 0; i < NL; ++i) memkv[i] = take((size_t)B * N * 2 * d);
+  for (int i = 0; i < NL; ++i) cache[i] = take((size_t)B * steps * 3 * d);
+  float* x = take((size_t)B * d);
+  float* xn = take((size_t)B * d);
+  float* att = take((size_t)B * d);
+  float* qc = take((size_t)B * d);
+  float* x2 = take((size_t)B * d);
+  float* x3 = take((size_t)B * d);
+  float* hid = take((size_t)B * 4 * d);
+  float* lg = take((size_t)B * V);
+  const SfRowMap rd = sf_rows(d);
+  // slots -> memory, and every block's cross-attention keys / values (once)
+  SF_TRY(sf_linear_ex(slots, rd, m->in_proj_w, m->in_proj_b, nullptr, nullptr, eps, nullptr, rd, 0, mem, rd, B * N, d, d, 0, st));
+  for (int i = 0; i < NL; ++i) {
+    const sf_slate_block& k = m->blocks[i];
+    SF_REQUIRE(k.ln1_g && k.ln1_b && k.wqkv && k.wo && k.ln2_g && k.ln2_b && k.wq_c && k.wkv_c && k.wo_c && k.ln3_g && k.ln3_b &&
+                   k.w1 && k.b1 && k.w2 && k.b2, "sf_slate_generate_f32: null block weight");
+    SF_TRY(sf_linear_ex(mem, rd, k.wkv_c, nullptr, nullptr, nullptr, eps, nullptr, rd, 0, memkv[i], sf_rows(2 * d), B * N, 2 * d, d,
+                        0, st));
+  }
+  const long long cbs = (long long)steps * 3 * d;
+  for (int t = 0; t < steps; ++t) {
+    // token t-1 (BOS at t = 0) + position t
+    {
+      const long long total4 = (long long)B * (d / 4);
+      hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, tokens_out + (t > 0 ? t - 1 : 0),
+                         (long long)steps, t == 0 ? (long long)V : -1LL, m->tok_emb, m->pos_emb + (long long)t * d, x, 1, d, total4);
+      SF_CHECK_LAUNCH();
+    }
+    float* cur = x;
+    float* nxt = x2;
+    for (int i = 0; i < NL; ++i) {
+      const sf_slate_block& k = m->blocks[i];
+      const SfRowMap crow = sf_rows_batched(3 * d, 1, cbs, (long long)t * 3 * d);   // row (b) of the cache at token t
+      if (k.is_first) {   // the first block normalises its input in place (steve_transformer.py:186-190)
+        SF_TRY(sf_layernorm_ex(cur, rd, k.ln1_g, k.ln1_b, xn, rd, B, d, eps, st));
+        SF_TRY(sf_linear_ex(xn, rd, k.wqkv, nullptr, nullptr, nullptr, eps, nullptr, rd, 0, cache[i], crow, B, 3 * d, d, 0, st));
+        cur = xn;
+      } else {
+        SF_TRY(sf_linear_ex(cur, rd, k.wqkv, nullptr, k.ln1_g, k.ln1_b, eps, nullptr, rd, 0, cache[i], crow, B, 3 * d, d, 0, st));
+      }
+      SF_TRY(sf_slate_attention_strided_f32(cache[i] + (long long)t * 3 * d, cache[i] + d, cache[i] + 2 * d, att, 3 * d, 3 * d,
+                                            3 * d, d, cbs, cbs, cbs, d, B, 1, t + 1, H, d / H, 0, stream));
+      SF_TRY(sf_linear_ex(att, rd, k.wo, nullptr, nullptr, nullptr, eps, cur, rd, 0, nxt, rd, B, d, d, 0, st));
+      // cross-attention to the slots
+      SF_TRY(sf_linear_ex(nxt, rd, k.wq_c, nullptr, k.ln2_g, k.ln2_b, eps, nullptr, rd, 0, qc, rd, B, d, d, 0, st));
+      SF_TRY(sf_slate_attention_strided_f32(qc, memkv[i], memkv[i] + d, att, d, 2 * d, 2 * d, d, d, (long long)N * 2 * d,
+                                            (long long)N * 2 * d, d, B, 1, N, H, d / H, 0, stream));
+      SF_TRY(sf_linear_ex(att, rd, k.wo_c, nullptr, nullptr, nullptr, eps, nxt, rd, 0, x3, rd, B, d, d, 0, st));
+      // FFN
+      SF_TRY(sf_linear_ex(x3, rd, k.w1, k.b1, k.ln3_g, k.ln3_b, eps, nullptr, rd, 0, hid, sf_rows(4 * d), B, 4 * d, d, 1, st));
+      float* dst = (cur == x || cur == xn) ? x2 : x;
+      if (dst == x3) dst = x;
+      SF_TRY(sf_linear_ex(hid, sf_rows(4 * d), k.w2, k.b2, nullptr, nullptr, eps, x3, rd, 0, dst, rd, B, d, 4 * d, 0, st));
+      cur = dst;
+      nxt = (cur == x) ? x2 : x;
+    }
+    // final LayerNorm + vocabulary head; logits of step t go to logits_out[b][t] (if wanted) and to the argmax
+    float* ldst = logits_out ? logits_out : lg;
+    const SfRowMap lmap = logits_out ? sf_rows_batched(V, 1, (long long)steps * V, (long long)t * V) : sf_rows(V);
+    SF_TRY(sf_linear_ex(cur, rd, m->head_w, nullptr, m->lnf_g, m->lnf_b, eps, nullptr, rd, 0, ldst, lmap, B, V, d, 0, st));
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)B), dim3(64), 0, st, logits_out ? logits_out + (long long)t * V : lg,
+                       logits_out ? (long long)steps * V : (long long)V, tokens_out + t, (long long)steps, V);
+    SF_CHECK_LAUNCH();
+  }
   return 0;
 }
 
