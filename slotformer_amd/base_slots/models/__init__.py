@@ -1,4 +1,5 @@
-"""build_model for the slot-extraction models (reference: slotformer/base_slots/models/__init__.py:9-34)."""
+"""Slot-extraction models and their factory (API of slotformer/base_slots/models/__init__.py)."""
+from ...host.registry import ModelTable, SLOT_MODEL_ARGS
 from .savi import StoSAVi, SlotAttention
 from .dVAE import dVAE
 from .steve import STEVE, SlotAttentionWMask
@@ -6,29 +7,19 @@ from .steve_transformer import STEVETransformerDecoder
 from .utils import to_rgb_from_tensor, assert_shape, SoftPositionEmbed, build_grid
 
 
+
+
+def _dvae_from_params(vocab_size):
+    """`params.vocab_size` is the only attribute the reference's factory reads for the dVAE."""
+    return dVAE(vocab_size=vocab_size, img_channels=3)
+
+
+_TABLE = (ModelTable()
+          .add('StoSAVi', StoSAVi, **SLOT_MODEL_ARGS)
+          .add('STEVE', STEVE, dvae_dict='dvae_dict', **SLOT_MODEL_ARGS)
+          .add('dVAE', _dvae_from_params, vocab_size='vocab_size'))
+
+
 def build_model(params):
-    if params.model == 'StoSAVi':
-        return StoSAVi(
-            resolution=params.resolution,
-            clip_len=params.input_frames,
-            slot_dict=params.slot_dict,
-            enc_dict=params.enc_dict,
-            dec_dict=params.dec_dict,
-            pred_dict=params.pred_dict,
-            loss_dict=params.loss_dict,
-        )
-    elif params.model == 'STEVE':
-        return STEVE(
-            resolution=params.resolution,
-            clip_len=params.input_frames,
-            slot_dict=params.slot_dict,
-            dvae_dict=params.dvae_dict,
-            enc_dict=params.enc_dict,
-            dec_dict=params.dec_dict,
-            pred_dict=params.pred_dict,
-            loss_dict=params.loss_dict,
-        )
-    elif params.model == 'dVAE':
-        return dVAE(vocab_size=params.vocab_size, img_channels=3)
-    else:
-        raise NotImplementedError(f'{params.model} is not implemented.')
+    """params.model in {'StoSAVi', 'STEVE', 'dVAE'} -> the model (NotImplementedError otherwise)."""
+    return _TABLE.build(params)

@@ -24,31 +24,28 @@ class SlotAttentionWMask(SlotAttention):
 
 
 class STEVE(StoSAVi):
+    """STEVE (steve.py:76-351): SAVi's encoder side with mask-returning Slot Attention, plus the frozen dVAE tokenizer and
+    the slot-conditioned Transformer decoder that predicts its tokens."""
 
-    def __init__(
-        self,
-        resolution,
-        clip_len,
+    DEFAULTS = dict(
         slot_dict=dict(num_slots=7, slot_size=128, slot_mlp_size=256, num_iterations=2),
         dvae_dict=dict(down_factor=4, vocab_size=4096, dvae_ckp_path=''),
         enc_dict=dict(enc_channels=(3, 64, 64, 64, 64), enc_ks=5, enc_out_channels=128, enc_norm=''),
         dec_dict=dict(dec_type='slate', dec_num_layers=4, dec_num_heads=4, dec_d_model=128),
-        pred_dict=dict(pred_rnn=True, pred_norm_first=True, pred_num_layers=2, pred_num_heads=4,
-                       pred_ffn_dim=512, pred_sg_every=None),
+        pred_dict=dict(pred_rnn=True, pred_norm_first=True, pred_num_layers=2, pred_num_heads=4, pred_ffn_dim=512,
+                       pred_sg_every=None),
         loss_dict=dict(use_img_recon_loss=False),
-        eps=1e-6,
-    ):
-        BaseModel.__init__(self)
-        self.resolution = resolution
-        self.clip_len = clip_len
-        self.eps = eps
-        self.slot_dict = slot_dict
-        self.dvae_dict = dvae_dict
-        self.enc_dict = enc_dict
-        self.dec_dict = dec_dict
-        self.pred_dict = pred_dict
-        self.loss_dict = loss_dict
+    )
 
+    def __init__(self, resolution, clip_len, slot_dict=None, dvae_dict=None, enc_dict=None, dec_dict=None, pred_dict=None,
+                 loss_dict=None, eps=1e-6):
+        BaseModel.__init__(self)
+        self.resolution, self.clip_len, self.eps = resolution, clip_len, eps
+        given = dict(slot_dict=slot_dict, dvae_dict=dvae_dict, enc_dict=enc_dict, dec_dict=dec_dict, pred_dict=pred_dict,
+                     loss_dict=loss_dict)
+        for name, value in given.items():
+            setattr(self, name, value if value is not None else dict(self.DEFAULTS[name]))
+        # registration order = state-dict order of the reference: slot attention, dvae, encoder, trans_decoder, predictor
         self._build_slot_attention()
         self._build_dvae()
         self._build_encoder()
@@ -56,6 +53,17 @@ class STEVE(StoSAVi):
         self._build_predictor()
         self._build_loss()
         self.testing = False
+
+    def _build_slot_attention(self):
+        sd = self.slot_dict
+        self.enc_out_channels = self.enc_dict['enc_out_channels']
+        self.num_slots, self.slot_size = sd['num_slots'], sd['slot_size']
+        self.slot_mlp_size, self.num_iterations = sd['slot_mlp_size'], sd['num_iterations']
+        # STEVE's slots start from learned embeddings and there are no stochastic kernels (no kernel_dist_layer)
+        self.init_latents = nn.Parameter(nn.init.normal_(torch.empty(1, self.num_slots, self.slot_size)))
+        self.slot_attention = SlotAttentionWMask(in_features=self.enc_out_channels, num_iterations=self.num_iterations,
+                                                 num_slots=self.num_slots, slot_size=self.slot_size,
+                                                 mlp_hidden_size=self.slot_mlp_size, eps=self.eps)
 
     def _build_dvae(self):
         """steve.py:148-160.  The reference asserts a checkpoint path; an empty path here leaves the tokenizer at its
@@ -83,22 +91,6 @@ class STEVE(StoSAVi):
             max_len=self.num_patches - 1,
             num_slots=self.num_slots,
             num_layers=self.dec_dict['dec_num_layers'],
-        )
-
-    def _build_slot_attention(self):
-        self.enc_out_channels = self.enc_dict['enc_out_channels']
-        self.num_slots = self.slot_dict['num_slots']
-        self.slot_size = self.slot_dict['slot_size']
-        self.slot_mlp_size = self.slot_dict['slot_mlp_size']
-        self.num_iterations = self.slot_dict['num_iterations']
-        self.init_latents = nn.Parameter(nn.init.normal_(torch.empty(1, self.num_slots, self.slot_size)))
-        self.slot_attention = SlotAttentionWMask(
-            in_features=self.enc_out_channels,
-            num_iterations=self.num_iterations,
-            num_slots=self.num_slots,
-            slot_size=self.slot_size,
-            mlp_hidden_size=self.slot_mlp_size,
-            eps=self.eps,
         )
 
     def _build_loss(self):

@@ -1,31 +1,15 @@
-"""build_model for the rollout models (reference: slotformer/video_prediction/models/__init__.py:6-36)."""
+"""Rollout models and their factory (API of slotformer/video_prediction/models/__init__.py)."""
+from ...host.registry import ModelTable, ROLLOUT_MODEL_ARGS
 from .slotformer import SlotFormer, SlotRollouter, get_sin_pos_enc, build_pos_enc
 from .single_step_slotformer import SingleStepSlotFormer, SingleStepSlotRollouter
 from .steve_slotformer import STEVESlotFormer
 
+_TABLE = (ModelTable()
+          .add('SlotFormer', SlotFormer, **ROLLOUT_MODEL_ARGS)
+          .add('SingleStepSlotFormer', SingleStepSlotFormer, **ROLLOUT_MODEL_ARGS)
+          .add('STEVESlotFormer', STEVESlotFormer, dvae_dict='dvae_dict', **ROLLOUT_MODEL_ARGS))
+
 
 def build_model(params):
-    kw = dict(
-        resolution=params.resolution,
-        clip_len=params.input_frames,
-        slot_dict=params.slot_dict,
-        dec_dict=params.dec_dict,
-        rollout_dict=params.rollout_dict,
-        loss_dict=params.loss_dict,
-    )
-    if params.model == 'SlotFormer':
-        return SlotFormer(**kw)
-    elif params.model == 'SingleStepSlotFormer':
-        return SingleStepSlotFormer(**kw)
-    elif params.model == 'STEVESlotFormer':
-        return STEVESlotFormer(
-            resolution=params.resolution,
-            clip_len=params.input_frames,
-            slot_dict=params.slot_dict,
-            dvae_dict=params.dvae_dict,
-            dec_dict=params.dec_dict,
-            rollout_dict=params.rollout_dict,
-            loss_dict=params.loss_dict,
-        )
-    else:
-        raise NotImplementedError(f'{params.model} is not implemented.')
+    """params.model in {'SlotFormer', 'SingleStepSlotFormer', 'STEVESlotFormer'} -> the model (NotImplementedError else)."""
+    return _TABLE.build(params)
