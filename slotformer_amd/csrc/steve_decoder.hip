@@ -6,6 +6,7 @@
 #include "sf_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 constexpr int GN_P = 64;   // partial records per sample
@@ -149,6 +150,135 @@ __global__ __launch_bounds__(256) void slate_attn_kernel(const float* __restrict
   }
 }
 
+// Causal self-attention for long sequences on the exact-f32 MFMA (flash style: online softmax over 64-key tiles, no
+// L x L score matrix).  One workgroup per (64-query tile, head, batch); wave = (query block qb of 32, key half kh of the
+// tile).  Scores are computed TRANSPOSED, S^T[key][query] = k q^T, so a lane holds 16 keys of ONE query column: the
+// softmax statistics are per-lane reductions plus one exchange with lane ^ 32, and the probabilities feed the PV MFMA
+// straight from registers (register r = the key pair (k_r, k_r + 4) of the B operand).  The two key halves of a query
+// block keep separate running (max, sum, O) and are merged through LDS at the end.
+template <int HD>
+__global__ __launch_bounds__(256) void slate_flash_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ v, float* __restrict__ out, int ldq,
+                                                          int ldk, int ldv, int ldo, long long q_bs, long long k_bs,
+                                                          long long v_bs, long long o_bs, int L, float scale) {
+  constexpr int P = HD + 4;                 // f32 row pitch of the tiles ((HD+4)/4 odd for HD = 16, 32, 48, 64)
+  constexpr int CB = (HD + 31) / 32;        // 32-channel blocks of the output
+  extern __shared__ __attribute__((aligned(16))) float fsm[];
+  float* Qs = fsm;                          // [64][P] (scaled)
+  float* Ks = Qs + 64 * P;                  // [64][P]
+  float* Vs = Ks + 64 * P;                  // [64][CB*32 + 4]  (channels padded to the MFMA block)
+  constexpr int PV = CB * 32 + 4;
+  float* SM = Vs + 64 * PV;                 // [4][32] running max, [4][32] running sum
+  float* OT = SM + 2 * 4 * 32;              // [4 waves][32 queries][PV]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int q0 = qt * 64;
+  const float* qb_ = q + (long long)b * q_bs + h * HD;
+  const float* kb_ = k + (long long)b * k_bs + h * HD;
+  const float* vb_ = v + (long long)b * v_bs + h * HD;
+  // Q tile (scaled) and zeroed channel padding of V
+  for (int idx = t; idx < 64 * (HD / 4); idx += 256) {
+    const int r = idx / (HD / 4), c4 = idx - r * (HD / 4);
+    const f32x4 x = *(const f32x4*)(qb_ + (long long)min(q0 + r, L - 1) * ldq + 4 * c4);
+    *(f32x4*)(Qs + r * P + 4 * c4) = x * scale;
+  }
+  if (CB * 32 > HD) {
+    for (int idx = t; idx < 64 * (CB * 32 - HD); idx += 256) {
+      const int r = idx / (CB * 32 - HD), c = idx - r * (CB * 32 - HD);
+      Vs[r * PV + HD + c] = 0.f;
+    }
+  }
+  const int qblk = wave >> 1, kh = wave & 1;
+  const int qcol = q0 + qblk * 32 + (lane & 31);            // this lane's query
+  f32x16 oacc[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[cb][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const int ntiles = qt + 1;                                // causal: key tiles 0 .. qt
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();                                        // previous tile fully consumed (and Q written)
+    const int k0 = kt * 64;
+    for (int idx = t; idx < 64 * (HD / 4); idx += 256) {
+      const int r = idx / (HD / 4), c4 = idx - r * (HD / 4);
+      const int j = min(k0 + r, L - 1);
+      *(f32x4*)(Ks + r * P + 4 * c4) = *(const f32x4*)(kb_ + (long long)j * ldk + 4 * c4);
+      *(f32x4*)(Vs + r * PV + 4 * c4) = *(const f32x4*)(vb_ + (long long)j * ldv + 4 * c4);
+    }
+    __syncthreads();
+    // S^T block: keys k0 + 32 kh + .., queries of block qblk
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    const float* kp = Ks + (kh * 32 + (lane & 31)) * P + 4 * (lane >> 5);
+    const float* qp = Qs + (qblk * 32 + (lane & 31)) * P + 4 * (lane >> 5);
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+      const f32x4 a = *(const f32x4*)(kp + c * 8), bq = *(const f32x4*)(qp + c * 8);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], bq[s2], sacc, 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      sacc[r] = (key <= qcol && key < L) ? sacc[r] : -INFINITY;
+      mx = fmaxf(mx, sacc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float corr = (m == -INFINITY) ? 0.f : expf(m - mn);
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sacc[r] = (mn == -INFINITY) ? 0.f : expf(sacc[r] - mn);
+      sum += sacc[r];
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    l = l * corr + sum;
+    m = mn;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[cb][r] *= corr;
+      const float* vp = Vs + (kh * 32 + 4 * (lane >> 5)) * PV + cb * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        oacc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[((r & 3) + 8 * (r >> 2)) * PV], sacc[r], oacc[cb], 0, 0, 0);
+    }
+  }
+  // merge the two key halves of each query block
+  if (lane < 32) {
+    SM[wave * 32 + lane] = m;
+    SM[4 * 32 + wave * 32 + lane] = l;
+  }
+  __syncthreads();
+  {
+    const float m_o = SM[(wave ^ 1) * 32 + (lane & 31)], l_o = SM[4 * 32 + (wave ^ 1) * 32 + (lane & 31)];
+    const float mg = fmaxf(m, m_o);
+    const float fw = (m == -INFINITY) ? 0.f : expf(m - mg), fo = (m_o == -INFINITY) ? 0.f : expf(m_o - mg);
+    const float fsc = fw / (l * fw + l_o * fo);
+    float* od = OT + (wave * 32 + (lane & 31)) * PV + 4 * (lane >> 5);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(f32x4*)(od + cb * 32 + 8 * g) = f32x4{oacc[cb][4 * g] * fsc, oacc[cb][4 * g + 1] * fsc, oacc[cb][4 * g + 2] * fsc,
+                                               oacc[cb][4 * g + 3] * fsc};
+  }
+  __syncthreads();
+  for (int idx = t; idx < 64 * (HD / 4); idx += 256) {
+    const int r = idx / (HD / 4), c4 = idx - r * (HD / 4);
+    const int qi = q0 + r;
+    if (qi < L) {
+      const int w0 = (r >> 5) * 2, qq = r & 31;
+      const f32x4 o = *(const f32x4*)(OT + (w0 * 32 + qq) * PV + 4 * c4) + *(const f32x4*)(OT + ((w0 + 1) * 32 + qq) * PV + 4 * c4);
+      *(f32x4*)(out + (long long)b * o_bs + (long long)qi * ldo + h * HD + 4 * c4) = o;
+    }
+  }
+}
+
 // Single-query attention (K/V-cached decoding, Lq == 1): one workgroup per (head, batch), the KEYS are spread over the
 // 256 threads (online softmax per thread, then one block-wide merge), instead of one thread walking all keys.
 template <int HD>
@@ -227,14 +357,15 @@ __global__ void embed_kernel(const long long* __restrict__ idx, long long idx_bs
   *(f32x4*)(out + row * d + 4 * c4) = e + p;
 }
 
-// first index of the row maximum (torch.argmax / topk(k=1) tie rule); one wave per row
-__global__ __launch_bounds__(64) void argmax_rows_kernel(const float* __restrict__ x, long long ld, long long* __restrict__ out,
-                                                         long long out_stride, int V) {
+// first index of the row maximum (torch.argmax / topk(k=1) tie rule); one workgroup of 256 threads per row
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, long long ld, long long* __restrict__ out,
+                                                          long long out_stride, int V) {
   const long long r = blockIdx.x;
   const float* xr = x + r * ld;
+  const int t = threadIdx.x;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int j = threadIdx.x; j < V; j += 64) {
+  for (int j = t; j < V; j += 256) {
     const float v = xr[j];
     if (v > best) {
       best = v;
@@ -249,7 +380,21 @@ __global__ __launch_bounds__(64) void argmax_rows_kernel(const float* __restrict
       bi = oi;
     }
   }
-  if (threadIdx.x == 0) out[r * out_stride] = bi;
+  __shared__ float sb[4];
+  __shared__ int si[4];
+  if ((t & 63) == 0) {
+    sb[t >> 6] = best;
+    si[t >> 6] = bi;
+  }
+  __syncthreads();
+  if (t == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sb[w] > best || (sb[w] == best && si[w] < bi)) {
+        best = sb[w];
+        bi = si[w];
+      }
+    out[r * out_stride] = bi;
+  }
 }
 
 // per-row cross-entropy  -log softmax(x)[target]  (F.cross_entropy, steve.py:341-344); one workgroup per row
@@ -335,6 +480,30 @@ int sf_slate_attention_strided_f32(const float* q, const float* k, const float* 
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((Lq + 255) / 256, num_heads, B);
   const float scale = 1.0f / sqrtf((float)head_dim);
+  if (causal && Lq >= 128) {   // long causal self-attention: MFMA flash kernel
+#define SLATE_FLASH(HD_)                                                                                                     \
+  if (head_dim == HD_) {                                                                                                     \
+    constexpr int CB_ = (HD_ + 31) / 32;                                                                                     \
+    constexpr size_t lds_ = ((size_t)2 * 64 * (HD_ + 4) + (size_t)64 * (CB_ * 32 + 4) + 2 * 4 * 32 +                          \
+                             (size_t)4 * 32 * (CB_ * 32 + 4)) * sizeof(float);                                               \
+    static bool attr_ = false;                                                                                               \
+    if (!attr_) {                                                                                                            \
+      hipError_t e_ = hipFuncSetAttribute((const void*)slate_flash_kernel<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                          (int)lds_);                                                                        \
+      if (e_ != hipSuccess) return sf_set_err((int)e_, hipGetErrorString(e_), __FILE__, __LINE__);                           \
+      attr_ = true;                                                                                                          \
+    }                                                                                                                        \
+    hipLaunchKernelGGL(slate_flash_kernel<HD_>, dim3((Lq + 63) / 64, num_heads, B), dim3(256), lds_, st, q, k, v, out, ldq,   \
+                       ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, Lq, scale);                                                    \
+    SF_CHECK_LAUNCH();                                                                                                       \
+    return 0;                                                                                                                \
+  }
+    SLATE_FLASH(16)
+    SLATE_FLASH(32)
+    SLATE_FLASH(48)
+    SLATE_FLASH(64)
+#undef SLATE_FLASH
+  }
   if (Lq == 1 && !causal) {   // K/V-cached decoding: spread the keys over a workgroup
 #define SLATE_DEC(HD_)                                                                                                       \
   if (head_dim == HD_) {                                                                                                     \
@@ -387,7 +556,7 @@ int sf_embed_tokens_f32(const long long* idx, const float* tok_emb, const float*
 int sf_argmax_rows_f32(const float* x, long long ld, long long* out, long long R, int V, void* stream) {
   SF_REQUIRE(x && out && R >= 0 && V > 0 && ld >= V, "sf_argmax_rows_f32: bad arguments");
   if (R == 0) return 0;
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)R), dim3(64), 0, (hipStream_t)stream, x, ld, out, 1LL, V);
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, ld, out, 1LL, V);
   SF_CHECK_LAUNCH();
   return 0;
 }
@@ -529,7 +698,7 @@ int sf_slate_generate_f32(const sf_slate_decoder* m, const float* slots, int B, 
     float* ldst = logits_out ? logits_out : lg;
     const SfRowMap lmap = logits_out ? sf_rows_batched(V, 1, (long long)steps * V, (long long)t * V) : sf_rows(V);
     SF_TRY(sf_linear_ex(cur, rd, m->head_w, nullptr, m->lnf_g, m->lnf_b, eps, nullptr, rd, 0, ldst, lmap, B, V, d, 0, st));
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)B), dim3(64), 0, st, logits_out ? logits_out + (long long)t * V : lg,
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)B), dim3(256), 0, st, logits_out ? logits_out + (long long)t * V : lg,
                        logits_out ? (long long)steps * V : (long long)V, tokens_out + t, (long long)steps, V);
     SF_CHECK_LAUNCH();
   }
