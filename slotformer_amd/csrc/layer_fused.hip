@@ -682,10 +682,7 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh, acc, 0, 0, 0);
   }
   LF_TS(5);
-  // last layer of a rollout step: the fragments of the fused step boundary are requested by every workgroup now (the
-  // FFN fragment registers are free) so that they have landed when the last-arriving one needs them
   SbFrags sbf;
-  if (sb.enabled) sb_load(sb, sbf, lane, wave);
 
   // ---- output tile -> LDS (in place over the x2 stash; chunk 0 adds the residual and the bias), re-read row-major ----
 #pragma unroll
@@ -718,6 +715,11 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every partial store of this thread is acknowledged
   __syncthreads();                                    // ... and of the whole workgroup
   LF_TS(6);
+  // last layer of a rollout step: the fragments of the fused step boundary are requested by every workgroup now -- after
+  // the store acknowledgement (vmcnt retires in order: requested earlier they would sit in front of the stores), early
+  // enough to land while the arrival counter and the other chunks' partials are fetched (requesting them only in the
+  // last arriver was measured slower: 18.4 vs 17.1 us)
+  if (sb.enabled) sb_load(sb, sbf, lane, wave);
   if (t == 0)
     s_last = (__hip_atomic_fetch_add(counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == LF_NCH - 1);
   __syncthreads();
