@@ -109,6 +109,21 @@ def test_steve_golden_and_masks(dev):
     assert n_diff <= n_unsafe
 
 
+@pytest.mark.parametrize('B', [1, 5, 33, 70])
+@torch.no_grad()
+def test_rollout_odd_batches(dev, B):
+    """The two-launch rollout layers at awkward batch sizes (row-tile counts that are not multiples of 8, more than 64
+    videos) for the sliding-window (C2) and the growing-window single-step (C5) rollouters, against the oracle."""
+    m, sd = build(gu.C2_ROLL, gu.load_golden('roll_c2'), 202, dev, vp=True)
+    slots = gu.seeded_normal((B, 6, 7, 128), 900 + B)
+    ref = oracle.rollouter_forward(slots, 4, sd, gu.C2_ROLL['rollout_dict'])
+    assert rel_err(m.rollouter(slots.to(dev), 4), ref) < 2e-4
+    m5, sd5 = build(gu.C5_ROLL, gu.load_golden('roll_c5'), 205, dev, vp=True)
+    s1 = gu.seeded_normal((B, 1, 8, 128), 800 + B)
+    ref5 = oracle.single_step_rollouter_forward(s1, 8, sd5, gu.C5_ROLL['rollout_dict'])
+    assert rel_err(m5.rollouter(s1.to(dev), 8), ref5) < 2e-4
+
+
 @torch.no_grad()
 def test_precomputed_cnn_features(dev):
     """sf_savi_cnn_f32 + sf_savi_encode_pre_f32: encoding with the CNN features of the first time steps computed ahead
