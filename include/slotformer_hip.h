@@ -220,6 +220,33 @@ size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B);
 int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws,
                    size_t ws_bytes, void* stream);
 
+/* ---- training of the rollout Transformer ------------------------------------
+ * SlotFormer.forward in train mode (slotformer.py:263-282) -> SlotRollouter.forward (:85-126) under autograd, i.e. what
+ * `loss.backward()` of calc_train_loss (:284-318) differentiates.  The forward keeps every activation of every rollout
+ * step in the caller's workspace; the backward pass reads them, so the workspace must stay untouched in between.
+ * Gradient buffers mirror the parameter leaves of sf_tfm_layer / sf_rollouter (same shapes) and are WRITTEN, not
+ * accumulated.  Dropout (nn.TransformerEncoderLayer default p = 0.1 in train mode): masks are a pure function of
+ * (seed, step, layer, site, element); pass the same dropout_p / seed to both calls.  Sliding-window rollouter,
+ * norm_first layers, slot_size / d_model / ffn_dim multiples of 64, window of at most 128 tokens. */
+typedef struct {
+  float *norm1_g, *norm1_b, *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;
+  float *norm2_g, *norm2_b, *lin1_w, *lin1_b, *lin2_w, *lin2_b;
+} sf_tfm_layer_grads;
+
+typedef struct {
+  float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;
+  const sf_tfm_layer_grads* layers; /* HOST array [num_layers] */
+} sf_rollouter_grads;
+
+size_t sf_rollout_train_workspace_bytes(const sf_rollouter* m, int B, int pred_len);
+/* x [B, history_len, N, C] burn-in slots -> pred [B, pred_len, N, C] */
+int sf_rollout_train_fwd_f32(const sf_rollouter* m, const float* x, float* pred, int B, int pred_len, float dropout_p,
+                             unsigned long long seed, void* ws, size_t ws_bytes, void* stream);
+/* d_pred [B, pred_len, N, C] -> parameter gradients in *g and (if d_x != NULL) d_x [B, history_len, N, C] */
+int sf_rollout_train_bwd_f32(const sf_rollouter* m, const float* d_pred, float* d_x, const sf_rollouter_grads* g, int B,
+                             int pred_len, float dropout_p, unsigned long long seed, void* ws, size_t ws_bytes,
+                             void* stream);
+
 /* StoSAVi / STEVE encoder side (savi.py:177-250,295-322,367-416; steve.py:198-240). */
 typedef struct {
   int resolution;      /* input H == W (64 or 128) */

@@ -17,7 +17,7 @@ __all__ = [
     'mha_self', 'transformer_encoder_layer', 'transformer_encoder',
     'savi_encoder_out', 'slot_attention', 'predictor_step', 'kernel_dist',
     'sample_dist', 'savi_encode', 'steve_encode', 'savi_forward_chunked',
-    'rollouter_forward', 'single_step_rollouter_forward', 'slotformer_forward',
+    'rollouter_forward', 'rollouter_forward_train', 'single_step_rollouter_forward', 'slotformer_forward',
     'savi_decode', 'postproc_mask', 'rollout_video_slots', 'phyre_encode_rollout',
     'slot_mse_losses', 'dvae_logits', 'dvae_tokenize', 'dvae_detokenize', 'steve_decoder_forward',
     'steve_decoder_generate', 'steve_forward_tokens', 'steve_slotformer_decode',
@@ -342,6 +342,38 @@ def single_step_rollouter_forward(x, pred_len, sd, rcfg, p='rollouter.'):
         pred = F.linear(h[:, -N:], sd[p + 'out_proj.weight'], sd[p + 'out_proj.bias'])
         out.append(pred)
         in_x = torch.cat([in_x, pred], dim=1)
+    return torch.stack(out, 1)
+
+
+def rollouter_forward_train(x, pred_len, sd, rcfg, drop, p='rollouter.'):
+    """SlotRollouter.forward in train() mode (slotformer.py:85-126): the four dropout sites of torch's pre-LN
+    nn.TransformerEncoderLayer made explicit -- 0: softmax weights inside nn.MultiheadAttention, 1: attention block output
+    (dropout1), 2: FFN hidden after ReLU (dropout), 3: FFN output (dropout2).  `drop(step, layer, site, t)` returns the
+    dropped tensor (t * mask / keep); torch ops throughout, so autograd of this function is the gradient oracle."""
+    B, hist, N, C = x.shape
+    assert hist == rcfg['history_len'] and rcfg['norm_first']
+    H, nl = rcfg['num_heads'], rcfg['num_layers']
+    in_x = x.flatten(1, 2)
+    pe = sd[p + 'enc_t_pe'].unsqueeze(2).repeat(B, 1, N, 1).flatten(1, 2)
+    out = []
+    for s in range(pred_len):
+        h = F.linear(in_x, sd[p + 'in_proj.weight'], sd[p + 'in_proj.bias']) + pe
+        for l in range(nl):
+            g = lambda k: sd[f'{p}transformer_encoder.layers.{l}.{k}']  # noqa: E731
+            d = h.shape[-1]
+            hd = d // H
+            y = layer_norm(h, g('norm1.weight'), g('norm1.bias'))
+            q, k, v = F.linear(y, g('self_attn.in_proj_weight'), g('self_attn.in_proj_bias')).chunk(3, -1)
+            q, k, v = (t.view(B, -1, H, hd).transpose(1, 2) for t in (q, k, v))
+            att = drop(s, l, 0, torch.softmax((q * hd**-0.5) @ k.transpose(-1, -2), dim=-1))
+            o = (att @ v).transpose(1, 2).reshape(B, -1, d)
+            h = h + drop(s, l, 1, F.linear(o, g('self_attn.out_proj.weight'), g('self_attn.out_proj.bias')))
+            y = layer_norm(h, g('norm2.weight'), g('norm2.bias'))
+            y = drop(s, l, 2, F.relu(F.linear(y, g('linear1.weight'), g('linear1.bias'))))
+            h = h + drop(s, l, 3, F.linear(y, g('linear2.weight'), g('linear2.bias')))
+        pred = F.linear(h[:, -N:], sd[p + 'out_proj.weight'], sd[p + 'out_proj.bias'])
+        out.append(pred)
+        in_x = torch.cat([in_x[:, N:], pred], dim=1)
     return torch.stack(out, 1)
 
 

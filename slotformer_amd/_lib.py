@@ -26,6 +26,17 @@ class sf_rollouter(C.Structure):
                 ('layers', C.POINTER(sf_tfm_layer)), ('in_proj_packed', C.c_void_p), ('out_proj_packed', C.c_void_p)]
 
 
+class sf_tfm_layer_grads(C.Structure):
+    _fields_ = [(n, FP) for n in (
+        'norm1_g', 'norm1_b', 'in_proj_w', 'in_proj_b', 'out_proj_w', 'out_proj_b',
+        'norm2_g', 'norm2_b', 'lin1_w', 'lin1_b', 'lin2_w', 'lin2_b')]
+
+
+class sf_rollouter_grads(C.Structure):
+    _fields_ = [(n, FP) for n in ('in_proj_w', 'in_proj_b', 'out_proj_w', 'out_proj_b')] + [
+        ('layers', C.POINTER(sf_tfm_layer_grads))]
+
+
 class sf_savi_encoder(C.Structure):
     _fields_ = (
         [('resolution', C.c_int), ('enc_layers', C.c_int), ('enc_channels', C.c_int * 9),
@@ -98,6 +109,10 @@ SIGNATURES = {
     'sf_bilinear_resize_f32': (I, [FP, FP, LL, I, I, I, I, VP]),
     'sf_rollout_workspace_bytes': (SZ, [C.POINTER(sf_rollouter), I]),
     'sf_rollout_f32': (I, [C.POINTER(sf_rollouter), FP, I, I, I, VP, SZ, VP]),
+    'sf_rollout_train_workspace_bytes': (SZ, [C.POINTER(sf_rollouter), I, I]),
+    'sf_rollout_train_fwd_f32': (I, [C.POINTER(sf_rollouter), FP, FP, I, I, F32, C.c_ulonglong, VP, SZ, VP]),
+    'sf_rollout_train_bwd_f32': (I, [C.POINTER(sf_rollouter), FP, FP, C.POINTER(sf_rollouter_grads), I, I, F32,
+                                     C.c_ulonglong, VP, SZ, VP]),
     'sf_savi_encode_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I]),
     'sf_savi_encode_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
                                VP]),

@@ -1,0 +1,926 @@
+// Training of the rollout Transformer: forward with saved activations and the backward pass of
+// SlotRollouter.forward (slotformer.py:85-126) with torch's pre-LN nn.TransformerEncoderLayer (slotformer.py:72-80),
+// dropout included (the reference trains with the layer's default p = 0.1).
+//
+// Design (MI355X, 288 GB of HBM): nothing is recomputed and nothing is reduced early.
+//   * every activation of every rollout step is kept, stacked over the steps ([S][M][width] per layer and kind), and so
+//     is every gradient that feeds a weight gradient;
+//   * the backward-through-time loop only runs the data-gradient chain (dX = dY . W on the forward GEMM core against
+//     transposed weight copies, LayerNorm / attention / dropout backward kernels);
+//   * after the loop each weight gradient is ONE contraction over all S*M rows: dW = dY^T . X on a split-bf16 MFMA kernel
+//     that reads both operands in their natural row-major layout (no transposes), split over row ranges into partial
+//     tiles that a second kernel sums in a fixed order (deterministic; no atomics);
+//   * bias and LayerNorm-parameter gradients are column sums over the same stacked buffers.
+// Gradients are written (not accumulated) into caller-owned buffers (sf_rollouter_grads), which the host lays out as one
+// flat bucket for the data-parallel all-reduce.
+//
+// Dropout masks are a pure function of (seed, rollout step, layer, site, element index): keep = mix32(idx ^ site_seed)
+// >> 8 >= p * 2^24, so the backward pass regenerates them and tests can rebuild them on the host.
+#include <math.h>
+#include <stdlib.h>
+
+#include "../../include/slotformer_hip.h"
+#include "sf_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dropout mask
+// ---------------------------------------------------------------------------------------------------------------------
+__host__ __device__ static inline uint32_t sf_mix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x7feb352du;
+  h ^= h >> 15;
+  h *= 0x846ca68bu;
+  h ^= h >> 16;
+  return h;
+}
+enum { SITE_ATTN_P = 0, SITE_ATTN_O = 1, SITE_FFN_H = 2, SITE_FFN_O = 3 };
+static inline uint32_t site_seed(unsigned long long seed, int step, int layer, int site) {
+  const uint32_t tag = (uint32_t)((step * 64 + layer) * 4 + site);
+  return sf_mix32((uint32_t)seed ^ sf_mix32((uint32_t)(seed >> 32) + 0x9e3779b9u * (tag + 1u)));
+}
+__device__ __forceinline__ bool sf_keep(uint32_t sseed, uint32_t idx, uint32_t thresh) {
+  return (sf_mix32(idx ^ sseed) >> 8) >= thresh;
+}
+static inline uint32_t drop_thresh(float p) { return (uint32_t)((double)p * 16777216.0); }
+
+// y = res + keep(x) / (1 - p)   (res may be NULL); n4 float4 elements
+__global__ __launch_bounds__(256) void residual_dropout_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                               float* __restrict__ y, long long n4, uint32_t sseed,
+                                                               uint32_t thresh, float inv_keep) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = reinterpret_cast<const float4*>(x)[i];
+  float4 r = res ? reinterpret_cast<const float4*>(res)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint32_t e = (uint32_t)(4 * i);
+  r.x += sf_keep(sseed, e, thresh) ? v.x * inv_keep : 0.f;
+  r.y += sf_keep(sseed, e + 1, thresh) ? v.y * inv_keep : 0.f;
+  r.z += sf_keep(sseed, e + 2, thresh) ? v.z * inv_keep : 0.f;
+  r.w += sf_keep(sseed, e + 3, thresh) ? v.w * inv_keep : 0.f;
+  reinterpret_cast<float4*>(y)[i] = r;
+}
+
+// dpre = hdn > 0 ? dh * inv_keep : 0   (hdn is the saved post-ReLU, post-dropout hidden activation)
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(float* __restrict__ dh, const float* __restrict__ hdn,
+                                                               long long n4, float inv_keep) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 g = reinterpret_cast<float4*>(dh)[i];
+  const float4 h = reinterpret_cast<const float4*>(hdn)[i];
+  g.x = h.x > 0.f ? g.x * inv_keep : 0.f;
+  g.y = h.y > 0.f ? g.y * inv_keep : 0.f;
+  g.z = h.z > 0.f ? g.z * inv_keep : 0.f;
+  g.w = h.w > 0.f ? g.w * inv_keep : 0.f;
+  reinterpret_cast<float4*>(dh)[i] = g;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// window assembly:  x0[b, l, :] = tok[s + l / N][b * N + l % N][:] + pe[l]   and its adjoint (dtok += dx)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void window_assemble_kernel(const float* __restrict__ tok, const float* __restrict__ pe,
+                                                              float* __restrict__ x0, int B, int L, int N, int d4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)B * L * d4;
+  if (i >= total) return;
+  const int c = (int)(i % d4);
+  const int row = (int)(i / d4);
+  const int b = row / L, l = row - b * L;
+  const int f = l / N, n = l - f * N;
+  const float4 t = reinterpret_cast<const float4*>(tok)[((long long)f * B * N + (long long)b * N + n) * d4 + c];
+  const float4 p = reinterpret_cast<const float4*>(pe)[(long long)l * d4 + c];
+  reinterpret_cast<float4*>(x0)[i] = make_float4(t.x + p.x, t.y + p.y, t.z + p.z, t.w + p.w);
+}
+__global__ __launch_bounds__(256) void window_scatter_kernel(const float* __restrict__ dx, float* __restrict__ dtok, int B,
+                                                             int L, int N, int d4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)B * L * d4;
+  if (i >= total) return;
+  const int c = (int)(i % d4);
+  const int row = (int)(i / d4);
+  const int b = row / L, l = row - b * L;
+  const int f = l / N, n = l - f * N;
+  float4* dst = reinterpret_cast<float4*>(dtok) + ((long long)f * B * N + (long long)b * N + n) * d4 + c;
+  const float4 g = reinterpret_cast<const float4*>(dx)[i];
+  float4 t = *dst;
+  t.x += g.x; t.y += g.y; t.z += g.z; t.w += g.w;
+  *dst = t;
+}
+
+// y += x  (float4)
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, long long n4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = reinterpret_cast<float4*>(y)[i];
+  const float4 b = reinterpret_cast<const float4*>(x)[i];
+  a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  reinterpret_cast<float4*>(y)[i] = a;
+}
+
+// out[c][r] = in[r][c]
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cn) {
+  __shared__ float t[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < R && c0 + tx < Cn) t[i][tx] = in[(long long)(r0 + i) * Cn + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < Cn && r0 + tx < R) out[(long long)(c0 + i) * R + r0 + tx] = t[tx][i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attention with saved-nothing backward: one workgroup per (head, video); L <= 128, head_dim <= 64.
+// qkv [B*L, 3d] (q|k|v); ctx / dctx [B*L, d]; dqkv [B*L, 3d].  Dropout acts on the softmax weights (nn.MultiheadAttention).
+// ---------------------------------------------------------------------------------------------------------------------
+struct AttnLds {
+  float *q, *k, *v, *g, *P, *dS;
+};
+__device__ __forceinline__ void attn_probs(const float* qkv, int L, int d, int hd, int b, int h, float scale, float* q,
+                                           float* k, float* v, float* P, int hp, int lp) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < L * hd; i += 256) {
+    const int r = i / hd, c = i - r * hd;
+    const float* row = qkv + ((long long)b * L + r) * 3 * d + h * hd + c;
+    q[r * hp + c] = row[0] * scale;
+    k[r * hp + c] = row[d];
+    v[r * hp + c] = row[2 * d];
+  }
+  __syncthreads();
+  for (int i = tid; i < L * L; i += 256) {
+    const int r = i / L, c = i - r * L;
+    float s = 0.f;
+    for (int e = 0; e < hd; ++e) s = fmaf(q[r * hp + e], k[c * hp + e], s);
+    P[r * lp + c] = s;
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int r = wave; r < L; r += 4) {
+    const float a0 = lane < L ? P[r * lp + lane] : -INFINITY;
+    const float a1 = lane + 64 < L ? P[r * lp + lane + 64] : -INFINITY;
+    const float mx = sf_wave_max(fmaxf(a0, a1));
+    const float e0 = lane < L ? __expf(a0 - mx) : 0.f;
+    const float e1 = lane + 64 < L ? __expf(a1 - mx) : 0.f;
+    const float inv = 1.f / sf_wave_sum(e0 + e1);
+    if (lane < L) P[r * lp + lane] = e0 * inv;
+    if (lane + 64 < L) P[r * lp + lane + 64] = e1 * inv;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void attn_train_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int L,
+                                                             int d, int hd, float scale, uint32_t sseed, uint32_t thresh,
+                                                             float inv_keep) {
+  extern __shared__ float lds[];
+  const int hp = hd + 1, lp = L + 1;
+  float* q = lds;
+  float* k = q + L * hp;
+  float* v = k + L * hp;
+  float* P = v + L * hp;
+  const int h = blockIdx.x, b = blockIdx.y, H = gridDim.x;
+  attn_probs(qkv, L, d, hd, b, h, scale, q, k, v, P, hp, lp);
+  const int tid = threadIdx.x;
+  const uint32_t base = (uint32_t)(((long long)b * H + h) * L * L);
+  for (int i = tid; i < L * hd; i += 256) {
+    const int r = i / hd, c = i - r * hd;
+    float s = 0.f;
+    for (int j = 0; j < L; ++j) {
+      float p = P[r * lp + j];
+      if (thresh) p = sf_keep(sseed, base + r * L + j, thresh) ? p * inv_keep : 0.f;
+      s = fmaf(p, v[j * hp + c], s);
+    }
+    ctx[((long long)b * L + r) * d + h * hd + c] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_train_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+                                                             float* __restrict__ dqkv, int L, int d, int hd, float scale,
+                                                             uint32_t sseed, uint32_t thresh, float inv_keep) {
+  extern __shared__ float lds[];
+  const int hp = hd + 1, lp = L + 1;
+  float* q = lds;
+  float* k = q + L * hp;
+  float* v = k + L * hp;
+  float* g = v + L * hp;
+  float* P = g + L * hp;
+  float* dS = P + L * lp;
+  const int h = blockIdx.x, b = blockIdx.y, H = gridDim.x;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < L * hd; i += 256) {
+    const int r = i / hd, c = i - r * hd;
+    g[r * hp + c] = dctx[((long long)b * L + r) * d + h * hd + c];
+  }
+  attn_probs(qkv, L, d, hd, b, h, scale, q, k, v, P, hp, lp);   // q holds q * scale
+  const uint32_t base = (uint32_t)(((long long)b * H + h) * L * L);
+  // dPd[i][j] = g[i] . v[j];  dP = mask * dPd / keep;  stash dP in dS
+  for (int i = tid; i < L * L; i += 256) {
+    const int r = i / L, c = i - r * L;
+    float s = 0.f;
+    for (int e = 0; e < hd; ++e) s = fmaf(g[r * hp + e], v[c * hp + e], s);
+    if (thresh) s = sf_keep(sseed, base + r * L + c, thresh) ? s * inv_keep : 0.f;
+    dS[r * lp + c] = s;
+  }
+  __syncthreads();
+  // dV[j][c] = sum_i Pd[i][j] g[i][c]   (Pd = dropped probabilities)
+  for (int i = tid; i < L * hd; i += 256) {
+    const int j = i / hd, c = i - j * hd;
+    float s = 0.f;
+    for (int r = 0; r < L; ++r) {
+      float p = P[r * lp + j];
+      if (thresh) p = sf_keep(sseed, base + r * L + j, thresh) ? p * inv_keep : 0.f;
+      s = fmaf(p, g[r * hp + c], s);
+    }
+    dqkv[((long long)b * L + j) * 3 * d + 2 * d + h * hd + c] = s;
+  }
+  __syncthreads();
+  // dS = P * (dP - rowsum(dP * P))
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int r = wave; r < L; r += 4) {
+    const float p0 = lane < L ? P[r * lp + lane] : 0.f, p1 = lane + 64 < L ? P[r * lp + lane + 64] : 0.f;
+    const float d0 = lane < L ? dS[r * lp + lane] : 0.f, d1 = lane + 64 < L ? dS[r * lp + lane + 64] : 0.f;
+    const float dot = sf_wave_sum(p0 * d0 + p1 * d1);
+    if (lane < L) dS[r * lp + lane] = p0 * (d0 - dot);
+    if (lane + 64 < L) dS[r * lp + lane + 64] = p1 * (d1 - dot);
+  }
+  __syncthreads();
+  // dq[i][c] = scale * sum_j dS[i][j] k[j][c];  dk[j][c] = sum_i dS[i][j] (q[i][c] * scale)
+  for (int i = tid; i < L * hd; i += 256) {
+    const int r = i / hd, c = i - r * hd;
+    float sq = 0.f, sk = 0.f;
+    for (int j = 0; j < L; ++j) {
+      sq = fmaf(dS[r * lp + j], k[j * hp + c], sq);
+      sk = fmaf(dS[j * lp + r], q[j * hp + c], sk);
+    }
+    float* o = dqkv + ((long long)b * L + r) * 3 * d + h * hd + c;
+    o[0] = sq * scale;
+    o[d] = sk;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm backward (one wave per row, D <= 1024, D % 4 == 0):  out = dres + dLN(dy; x, gamma)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                     float* __restrict__ out, int rows, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int n4 = D >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (long long)row * D);
+  const float4* gr = reinterpret_cast<const float4*>(dy + (long long)row * D);
+  const float4* gm = reinterpret_cast<const float4*>(gamma);
+  float4 xv[4], gv[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    xv[i] = c < n4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+  }
+  const float mean = sf_wave_sum(s) / D;
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < n4) {
+      xv[i].x -= mean; xv[i].y -= mean; xv[i].z -= mean; xv[i].w -= mean;
+      var += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
+    }
+  }
+  const float rstd = rsqrtf(sf_wave_sum(var) / D + eps);
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < n4) {
+      const float4 w = gm[c];
+      float4 g = gr[c];
+      g.x *= w.x; g.y *= w.y; g.z *= w.z; g.w *= w.w;
+      xv[i].x *= rstd; xv[i].y *= rstd; xv[i].z *= rstd; xv[i].w *= rstd;   // x-hat
+      gv[i] = g;
+      m1 += (g.x + g.y) + (g.z + g.w);
+      m2 += (g.x * xv[i].x + g.y * xv[i].y) + (g.z * xv[i].z + g.w * xv[i].w);
+    }
+  }
+  m1 = sf_wave_sum(m1) / D;
+  m2 = sf_wave_sum(m2) / D;
+  const float4* rr = dres ? reinterpret_cast<const float4*>(dres + (long long)row * D) : nullptr;
+  float4* orow = reinterpret_cast<float4*>(out + (long long)row * D);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < n4) {
+      float4 r = rr ? rr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      r.x += rstd * (gv[i].x - m1 - xv[i].x * m2);
+      r.y += rstd * (gv[i].y - m1 - xv[i].y * m2);
+      r.z += rstd * (gv[i].z - m1 - xv[i].z * m2);
+      r.w += rstd * (gv[i].w - m1 - xv[i].w * m2);
+      orow[c] = r;
+    }
+  }
+}
+
+// LayerNorm parameter gradients, stage 1: workgroup g handles rows [g*rpg, (g+1)*rpg); partial[g][0][D] = sum dy*xhat,
+// partial[g][1][D] = sum dy.  D <= 1024, D % 4 == 0.
+__global__ __launch_bounds__(256) void ln_param_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ partial, long long rows, int rpg, int D,
+                                                               float eps) {
+  __shared__ float red[3][2][1024];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n4 = D >> 2;
+  float4 ag[4], ab[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long r0 = (long long)blockIdx.x * rpg;
+  const long long r1 = r0 + rpg < rows ? r0 + rpg : rows;
+  for (long long row = r0 + wave; row < r1; row += 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + row * D);
+    const float4* gr = reinterpret_cast<const float4*>(dy + row * D);
+    float4 xv[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      xv[i] = c < n4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+    }
+    const float mean = sf_wave_sum(s) / D;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      if (c < n4) {
+        xv[i].x -= mean; xv[i].y -= mean; xv[i].z -= mean; xv[i].w -= mean;
+        var += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
+      }
+    }
+    const float rstd = rsqrtf(sf_wave_sum(var) / D + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      if (c < n4) {
+        const float4 g = gr[c];
+        ag[i].x += g.x * xv[i].x * rstd; ag[i].y += g.y * xv[i].y * rstd;
+        ag[i].z += g.z * xv[i].z * rstd; ag[i].w += g.w * xv[i].w * rstd;
+        ab[i].x += g.x; ab[i].y += g.y; ab[i].z += g.z; ab[i].w += g.w;
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      if (c < n4) {
+        reinterpret_cast<float4*>(red[wave - 1][0])[c] = ag[i];
+        reinterpret_cast<float4*>(red[wave - 1][1])[c] = ab[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      if (c < n4) {
+        for (int w = 0; w < 3; ++w) {
+          const float4 a = reinterpret_cast<float4*>(red[w][0])[c], b = reinterpret_cast<float4*>(red[w][1])[c];
+          ag[i].x += a.x; ag[i].y += a.y; ag[i].z += a.z; ag[i].w += a.w;
+          ab[i].x += b.x; ab[i].y += b.y; ab[i].z += b.z; ab[i].w += b.w;
+        }
+        reinterpret_cast<float4*>(partial + ((long long)blockIdx.x * 2) * D)[c] = ag[i];
+        reinterpret_cast<float4*>(partial + ((long long)blockIdx.x * 2 + 1) * D)[c] = ab[i];
+      }
+    }
+  }
+}
+
+// column sums, stage 1: partial[g][n] = sum over rows [g*rpg, (g+1)*rpg) of y[row][n]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ y, float* __restrict__ partial,
+                                                             long long rows, int rpg, int n) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  const long long r0 = (long long)blockIdx.y * rpg;
+  const long long r1 = r0 + rpg < rows ? r0 + rpg : rows;
+  float s0 = 0.f, s1 = 0.f;
+  long long r = r0;
+  for (; r + 1 < r1; r += 2) {
+    s0 += y[r * n + c];
+    s1 += y[(r + 1) * n + c];
+  }
+  if (r < r1) s0 += y[r * n + c];
+  partial[(long long)blockIdx.y * n + c] = s0 + s1;
+}
+
+// stage 2 of every split reduction: out[i] = sum_g partial[g][i]  (fixed order)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                              int G, long long n4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = reinterpret_cast<const float4*>(partial)[i];
+  for (int g = 1; g < G; ++g) {
+    const float4 b = reinterpret_cast<const float4*>(partial)[(long long)g * n4 + i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = a;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight-gradient contraction  dW[n][k] = sum_m Y[m][n] * X[m][k]   (Y [rows, N], X [rows, K], both row-major)
+// split-bf16 on v_mfma_f32_32x32x16_bf16; 64x64 output tile per workgroup (4 waves, one 32x32 quadrant each), the
+// contraction index is the row index: a chunk of 32 rows of both operands is staged in LDS as f32 and every lane reads
+// its 8 values per k16 step with a stride of one LDS row (pitch 68: the two half-waves hit disjoint banks).
+// grid (N/64 * K/64, splits): split z handles rows [z*rps, (z+1)*rps) and writes partial[z][N][K].
+// ---------------------------------------------------------------------------------------------------------------------
+#define TN_P 68
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void tn_split8(const f32x8 v, bf16x8& hi, bf16x8& lo) {
+  hi = __builtin_convertvector(v, bf16x8);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
+}
+template <bool EXACT>
+__global__ __launch_bounds__(256) void grad_gemm_tn_kernel(const float* __restrict__ Y, const float* __restrict__ X,
+                                                           float* __restrict__ partial, long long rows, int rps, int N,
+                                                           int K) {
+  __shared__ float Ys[32 * TN_P];
+  __shared__ float Xs[32 * TN_P];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tk = K / 64;
+  const int n0 = (blockIdx.x / tk) * 64, k0 = (blockIdx.x % tk) * 64;
+  const long long r0 = (long long)blockIdx.y * rps;
+  const long long r1 = r0 + rps < rows ? r0 + rps : rows;
+  const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;
+  // loader: thread -> (row = tid >> 4 (+16), float4 column = tid & 15)
+  const int lr = tid >> 4, lc = (tid & 15) * 4;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int nrows = (int)(r1 - r0);   // <= rps
+  const float* Yb = Y + r0 * N + n0 + lc;
+  const float* Xb = X + r0 * K + k0 + lc;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 py0 = zero4, py1 = zero4, px0 = zero4, px1 = zero4;
+  if (lr < nrows) {
+    py0 = *reinterpret_cast<const float4*>(Yb + (long long)lr * N);
+    px0 = *reinterpret_cast<const float4*>(Xb + (long long)lr * K);
+  }
+  if (lr + 16 < nrows) {
+    py1 = *reinterpret_cast<const float4*>(Yb + (long long)(lr + 16) * N);
+    px1 = *reinterpret_cast<const float4*>(Xb + (long long)(lr + 16) * K);
+  }
+  for (int rb = 0; rb < nrows; rb += 32) {
+    __syncthreads();
+    *reinterpret_cast<float4*>(&Ys[lr * TN_P + lc]) = py0;
+    *reinterpret_cast<float4*>(&Ys[(lr + 16) * TN_P + lc]) = py1;
+    *reinterpret_cast<float4*>(&Xs[lr * TN_P + lc]) = px0;
+    *reinterpret_cast<float4*>(&Xs[(lr + 16) * TN_P + lc]) = px1;
+    __syncthreads();
+    py0 = py1 = px0 = px1 = zero4;
+    const int ra = rb + 32 + lr;
+    if (ra < nrows) {
+      py0 = *reinterpret_cast<const float4*>(Yb + (long long)ra * N);
+      px0 = *reinterpret_cast<const float4*>(Xb + (long long)ra * K);
+    }
+    if (ra + 16 < nrows) {
+      py1 = *reinterpret_cast<const float4*>(Yb + (long long)(ra + 16) * N);
+      px1 = *reinterpret_cast<const float4*>(Xb + (long long)(ra + 16) * K);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float* ya = &Ys[(16 * t + 8 * (lane >> 5)) * TN_P + wn + (lane & 31)];
+      const float* xa = &Xs[(16 * t + 8 * (lane >> 5)) * TN_P + wk + (lane & 31)];
+      f32x8 a, b;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a[j] = ya[j * TN_P];
+        b[j] = xa[j * TN_P];
+      }
+      bf16x8 ah, al, bh, bl;
+      tn_split8(a, ah, al);
+      tn_split8(b, bh, bl);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      if (EXACT) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc, 0, 0, 0);
+    }
+  }
+  float* out = partial + (long long)blockIdx.y * N * K;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    out[(long long)n * K + k0 + wk + (lane & 31)] = acc[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
+
+struct Dims {
+  int B, S, hist, N, C, d, ffn, nl, H, L, M, R, T;
+};
+
+// workspace carve-up (in floats); identical for forward and backward
+struct Ws {
+  float *slots_all, *tok_all, *xf, *xlast, *tmp;
+  float *xin[16], *a1[16], *qkv[16], *ctx[16], *xmid[16], *a2[16], *hdn[16];
+  // backward only
+  float *dtok, *dpred, *dx, *dx2, *dctx, *dxlast;
+  float *dqkv[16], *dao[16], *dpre[16], *dfo[16], *da1[16], *da2[16];
+  float *wt_in[16], *wt_o[16], *wt_1[16], *wt_2[16], *wt_inproj, *wt_outproj;
+  float* partial;
+  size_t partial_floats;
+  size_t total_floats;
+};
+
+inline size_t tn_partial_floats(const Dims& D);
+
+Ws carve(const Dims& D, float* base) {
+  Ws w;
+  memset(&w, 0, sizeof(w));
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    float* p = base ? base + off : nullptr;
+    off += (n + 63) & ~(size_t)63;
+    return p;
+  };
+  const size_t M = D.M, R = D.R, S = D.S, d = D.d, f = D.ffn;
+  w.slots_all = take((size_t)D.T * R * D.C);
+  w.tok_all = take((size_t)D.T * R * d);
+  w.xf = take(S * M * d);
+  w.xlast = take(S * R * d);
+  w.tmp = take(M * (f > 3 * d ? f : 3 * d));
+  for (int l = 0; l < D.nl; ++l) {
+    w.xin[l] = take(S * M * d);
+    w.a1[l] = take(S * M * d);
+    w.qkv[l] = take(S * M * 3 * d);
+    w.ctx[l] = take(S * M * d);
+    w.xmid[l] = take(S * M * d);
+    w.a2[l] = take(S * M * d);
+    w.hdn[l] = take(S * M * f);
+  }
+  w.dtok = take((size_t)D.T * R * d);
+  w.dpred = take(S * R * D.C);
+  w.dx = take(M * d);
+  w.dx2 = take(M * d);
+  w.dctx = take(M * d);
+  w.dxlast = take(R * d);
+  for (int l = 0; l < D.nl; ++l) {
+    w.dqkv[l] = take(S * M * 3 * d);
+    w.dao[l] = take(S * M * d);
+    w.dpre[l] = take(S * M * f);
+    w.dfo[l] = take(S * M * d);
+    w.da1[l] = take(S * M * d);
+    w.da2[l] = take(S * M * d);
+    w.wt_in[l] = take(3 * d * d);
+    w.wt_o[l] = take(d * d);
+    w.wt_1[l] = take(f * d);
+    w.wt_2[l] = take(f * d);
+  }
+  w.wt_inproj = take((size_t)D.C * d);
+  w.wt_outproj = take((size_t)D.C * d);
+  w.partial_floats = tn_partial_floats(D);
+  w.partial = take(w.partial_floats);
+  w.total_floats = off;
+  return w;
+}
+
+// number of row splits of a weight-gradient contraction: enough workgroups to fill the chip a few times over
+inline int tn_splits(long long rows, int N, int K) {
+  const long long tiles = (long long)(N / 64) * (K / 64);
+  long long s = (1024 + tiles - 1) / tiles;
+  const long long max_s = (rows + 63) / 64;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+inline size_t tn_partial_floats(const Dims& D) {
+  const long long rows = (long long)D.S * D.M;
+  size_t best = 0;
+  auto upd = [&](long long r, int N, int K) {
+    const size_t n = (size_t)tn_splits(r, N, K) * N * K;
+    if (n > best) best = n;
+  };
+  upd(rows, 3 * D.d, D.d);
+  upd(rows, D.d, D.d);
+  upd(rows, D.ffn, D.d);
+  upd(rows, D.d, D.ffn);
+  upd((long long)D.T * D.R, D.d, D.C);
+  upd((long long)D.S * D.R, D.C, D.d);
+  // column-sum / LayerNorm partials share the buffer: at most 512 groups x 2 x max width
+  const size_t cs = (size_t)512 * 2 * (size_t)(D.ffn > 3 * D.d ? D.ffn : 3 * D.d);
+  return best > cs ? best : cs;
+}
+
+int check_model(const sf_rollouter* m, Dims& D, int B, int pred_len) {
+  SF_REQUIRE(m && m->layers, "null model");
+  SF_REQUIRE(!m->single_step, "training covers SlotRollouter (sliding window) only");
+  SF_REQUIRE(m->norm_first, "training needs norm_first layers (all reference configurations)");
+  SF_REQUIRE(B > 0 && pred_len > 0, "bad sizes");
+  D.B = B; D.S = pred_len; D.hist = m->window_len; D.N = m->num_slots; D.C = m->slot_size; D.d = m->d_model;
+  D.ffn = m->ffn_dim; D.nl = m->num_layers; D.H = m->num_heads;
+  D.L = D.hist * D.N; D.M = B * D.L; D.R = B * D.N; D.T = D.hist + pred_len;
+  SF_REQUIRE(D.nl >= 1 && D.nl <= 16, "1..16 layers");
+  SF_REQUIRE(D.d % 64 == 0 && D.ffn % 64 == 0 && D.C % 64 == 0, "slot_size, d_model and ffn_dim must be multiples of 64");
+  SF_REQUIRE(D.d <= 1024, "d_model <= 1024");
+  SF_REQUIRE(D.d % D.H == 0 && D.d / D.H <= 64, "head_dim <= 64");
+  SF_REQUIRE(D.L <= 128, "window of at most 128 tokens");
+  return 0;
+}
+
+int launch_transpose(const float* in, float* out, int R, int Cn, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cn, 32), cdiv(R, 32)), dim3(256), 0, st, in, out, R, Cn);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+int gemm(const float* A, const float* W, const float* bias, const float* res, float* Cc, int M, int N, int K, int relu,
+         hipStream_t st) {
+  return sf_linear_ex(A, sf_rows(K), W, bias, nullptr, nullptr, 0.f, res, sf_rows(N), 0, Cc, sf_rows(N), M, N, K, relu, st);
+}
+
+int attn_lds_bytes(int L, int hd, bool bwd) {
+  return (int)(((bwd ? 4 : 3) * L * (hd + 1) + (bwd ? 2 : 1) * L * (L + 1)) * sizeof(float));
+}
+
+// dW = Y^T X over `rows` rows, written to dW [N, K]
+int grad_weight(const float* Y, const float* X, float* dW, long long rows, int N, int K, const Ws& w, hipStream_t st) {
+  const int splits = tn_splits(rows, N, K);
+  int rps = (int)((rows + splits - 1) / splits);
+  rps = (rps + 31) & ~31;
+  float* dst = splits == 1 ? dW : w.partial;
+  const dim3 grid((N / 64) * (K / 64), splits);
+  if (sf_get_precision() == 0)
+    hipLaunchKernelGGL(grad_gemm_tn_kernel<true>, grid, dim3(256), 0, st, Y, X, dst, rows, rps, N, K);
+  else
+    hipLaunchKernelGGL(grad_gemm_tn_kernel<false>, grid, dim3(256), 0, st, Y, X, dst, rows, rps, N, K);
+  SF_CHECK_LAUNCH();
+  if (splits > 1) {
+    const long long n4 = (long long)N * K / 4;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, w.partial, dW, splits, n4);
+    SF_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+int grad_bias(const float* Y, float* db, long long rows, int n, const Ws& w, hipStream_t st) {
+  int G = (int)((rows + 127) / 128);
+  if (G > 512) G = 512;
+  const int rpg = (int)((rows + G - 1) / G);
+  G = (int)((rows + rpg - 1) / rpg);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(n, 256), G), dim3(256), 0, st, Y, w.partial, rows, rpg, n);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, w.partial, db, G, (long long)n / 4);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+int grad_ln(const float* x, const float* dy, float* dgamma, float* dbeta, long long rows, int D, float eps, const Ws& w,
+            hipStream_t st) {
+  int G = (int)((rows + 63) / 64);
+  if (G > 512) G = 512;
+  const int rpg = (int)((rows + G - 1) / G);
+  G = (int)((rows + rpg - 1) / rpg);
+  hipLaunchKernelGGL(ln_param_partial_kernel, dim3(G), dim3(256), 0, st, x, dy, w.partial, rows, rpg, D, eps);
+  SF_CHECK_LAUNCH();
+  // partial is [G][2][D]: reduce both rows at once into a [2][D] scratch behind the partials, then copy out
+  float* both = w.partial + (size_t)G * 2 * D;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * D / 4, 256)), dim3(256), 0, st, w.partial, both, G,
+                     (long long)2 * D / 4);
+  SF_CHECK_LAUNCH();
+  hipError_t e = hipMemcpyAsync(dgamma, both, D * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(dbeta, both + D, D * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sf_rollout_train_workspace_bytes(const sf_rollouter* m, int B, int pred_len) {
+  Dims D;
+  if (check_model(m, D, B, pred_len) != 0) return 0;
+  return carve(D, nullptr).total_floats * sizeof(float) + 256;
+}
+
+int sf_rollout_train_fwd_f32(const sf_rollouter* m, const float* x, float* pred, int B, int pred_len, float dropout_p,
+                             unsigned long long seed, void* ws, size_t ws_bytes, void* stream) {
+  Dims D;
+  SF_TRY(check_model(m, D, B, pred_len));
+  SF_REQUIRE(x && pred && ws, "null pointer");
+  SF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p in [0, 1)");
+  hipStream_t st = (hipStream_t)stream;
+  float* base = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  const Ws w = carve(D, base);
+  SF_REQUIRE(w.total_floats * sizeof(float) + 256 <= ws_bytes, "workspace too small");
+  const int d = D.d, f = D.ffn, M = D.M, R = D.R, N = D.N, C = D.C, L = D.L, hd = d / D.H;
+  const uint32_t thr = drop_thresh(dropout_p);
+  const float inv_keep = 1.f / (1.f - dropout_p);
+  const float scale = 1.f / sqrtf((float)hd);
+  const int albytes = attn_lds_bytes(L, hd, false);
+  SF_REQUIRE(albytes <= 64 * 1024, "attention tile does not fit LDS");
+
+  // burn-in frames -> frame-major slots_all, then their in-projections
+  for (int t = 0; t < D.hist; ++t)
+    SF_TRY(sf_copy_rows_ex(x, sf_rows_batched(C, N, (long long)D.hist * N * C, (long long)t * N * C),
+                           w.slots_all + (size_t)t * R * C, sf_rows(C), R, C, st));
+  SF_TRY(gemm(w.slots_all, m->in_proj_w, m->in_proj_b, nullptr, w.tok_all, D.hist * R, d, C, 0, st));
+
+  for (int s = 0; s < D.S; ++s) {
+    const size_t so = (size_t)s * M;
+    if (s > 0) {
+      const int fr = D.hist + s - 1;
+      SF_TRY(gemm(w.slots_all + (size_t)fr * R * C, m->in_proj_w, m->in_proj_b, nullptr, w.tok_all + (size_t)fr * R * d, R,
+                  d, C, 0, st));
+    }
+    hipLaunchKernelGGL(window_assemble_kernel, dim3(cdiv((long long)M * d / 4, 256)), dim3(256), 0, st,
+                       w.tok_all + (size_t)s * R * d, m->pe_tok, w.xin[0] + so * d, B, L, N, d / 4);
+    SF_CHECK_LAUNCH();
+    for (int l = 0; l < D.nl; ++l) {
+      const sf_tfm_layer& ly = m->layers[l];
+      float* xin = w.xin[l] + so * d;
+      float* a1 = w.a1[l] + so * d;
+      float* qkv = w.qkv[l] + so * 3 * d;
+      float* ctx = w.ctx[l] + so * d;
+      float* xmid = w.xmid[l] + so * d;
+      float* a2 = w.a2[l] + so * d;
+      float* hdn = w.hdn[l] + so * f;
+      float* xnext = (l + 1 < D.nl ? w.xin[l + 1] : w.xf) + so * d;
+      SF_TRY(sf_layernorm_ex(xin, sf_rows(d), ly.norm1_g, ly.norm1_b, a1, sf_rows(d), M, d, 1e-5f, st));
+      SF_TRY(gemm(a1, ly.in_proj_w, ly.in_proj_b, nullptr, qkv, M, 3 * d, d, 0, st));
+      hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(D.H, B), dim3(256), albytes, st, qkv, ctx, L, d, hd, scale,
+                         site_seed(seed, s, l, SITE_ATTN_P), thr, inv_keep);
+      SF_CHECK_LAUNCH();
+      if (thr == 0) {
+        SF_TRY(gemm(ctx, ly.out_proj_w, ly.out_proj_b, xin, xmid, M, d, d, 0, st));
+      } else {
+        SF_TRY(gemm(ctx, ly.out_proj_w, ly.out_proj_b, nullptr, w.tmp, M, d, d, 0, st));
+        hipLaunchKernelGGL(residual_dropout_kernel, dim3(cdiv((long long)M * d / 4, 256)), dim3(256), 0, st, w.tmp, xin,
+                           xmid, (long long)M * d / 4, site_seed(seed, s, l, SITE_ATTN_O), thr, inv_keep);
+        SF_CHECK_LAUNCH();
+      }
+      SF_TRY(sf_layernorm_ex(xmid, sf_rows(d), ly.norm2_g, ly.norm2_b, a2, sf_rows(d), M, d, 1e-5f, st));
+      if (thr == 0) {
+        SF_TRY(gemm(a2, ly.lin1_w, ly.lin1_b, nullptr, hdn, M, f, d, 1, st));
+        SF_TRY(gemm(hdn, ly.lin2_w, ly.lin2_b, xmid, xnext, M, d, f, 0, st));
+      } else {
+        SF_TRY(gemm(a2, ly.lin1_w, ly.lin1_b, nullptr, w.tmp, M, f, d, 1, st));
+        hipLaunchKernelGGL(residual_dropout_kernel, dim3(cdiv((long long)M * f / 4, 256)), dim3(256), 0, st, w.tmp,
+                           (const float*)nullptr, hdn, (long long)M * f / 4, site_seed(seed, s, l, SITE_FFN_H), thr,
+                           inv_keep);
+        SF_CHECK_LAUNCH();
+        SF_TRY(gemm(hdn, ly.lin2_w, ly.lin2_b, nullptr, w.tmp, M, d, f, 0, st));
+        hipLaunchKernelGGL(residual_dropout_kernel, dim3(cdiv((long long)M * d / 4, 256)), dim3(256), 0, st, w.tmp, xmid,
+                           xnext, (long long)M * d / 4, site_seed(seed, s, l, SITE_FFN_O), thr, inv_keep);
+        SF_CHECK_LAUNCH();
+      }
+    }
+    // last N tokens of every video -> xlast[s]; prediction = out_proj(xlast)  (slotformer.py:121)
+    SF_TRY(sf_copy_rows_ex(w.xf + so * d, sf_rows_batched(d, N, (long long)L * d, (long long)(L - N) * d),
+                           w.xlast + (size_t)s * R * d, sf_rows(d), R, d, st));
+    float* fr = w.slots_all + (size_t)(D.hist + s) * R * C;
+    SF_TRY(gemm(w.xlast + (size_t)s * R * d, m->out_proj_w, m->out_proj_b, nullptr, fr, R, C, d, 0, st));
+    SF_TRY(sf_copy_rows_ex(fr, sf_rows(C), pred, sf_rows_batched(C, N, (long long)D.S * N * C, (long long)s * N * C), R, C,
+                           st));
+  }
+  return 0;
+}
+
+int sf_rollout_train_bwd_f32(const sf_rollouter* m, const float* d_pred, float* d_x, const sf_rollouter_grads* g, int B,
+                             int pred_len, float dropout_p, unsigned long long seed, void* ws, size_t ws_bytes,
+                             void* stream) {
+  Dims D;
+  SF_TRY(check_model(m, D, B, pred_len));
+  SF_REQUIRE(d_pred && g && g->layers && ws, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  float* base = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  const Ws w = carve(D, base);
+  SF_REQUIRE(w.total_floats * sizeof(float) + 256 <= ws_bytes, "workspace too small");
+  const int d = D.d, f = D.ffn, M = D.M, R = D.R, N = D.N, C = D.C, L = D.L, hd = d / D.H;
+  const uint32_t thr = drop_thresh(dropout_p);
+  const float inv_keep = 1.f / (1.f - dropout_p);
+  const float scale = 1.f / sqrtf((float)hd);
+  const int albytes = attn_lds_bytes(L, hd, true);
+  SF_REQUIRE(albytes <= 64 * 1024, "attention tile does not fit LDS");
+  const long long Md4 = (long long)M * d / 4;
+
+  // transposed weight copies: the data-gradient GEMMs run on the forward core (C = A . W^T)
+  for (int l = 0; l < D.nl; ++l) {
+    const sf_tfm_layer& ly = m->layers[l];
+    SF_TRY(launch_transpose(ly.in_proj_w, w.wt_in[l], 3 * d, d, st));   // [3d,d] -> [d,3d]
+    SF_TRY(launch_transpose(ly.out_proj_w, w.wt_o[l], d, d, st));
+    SF_TRY(launch_transpose(ly.lin1_w, w.wt_1[l], f, d, st));           // [f,d] -> [d,f]
+    SF_TRY(launch_transpose(ly.lin2_w, w.wt_2[l], d, f, st));           // [d,f] -> [f,d]
+  }
+  SF_TRY(launch_transpose(m->in_proj_w, w.wt_inproj, d, C, st));        // [d,C] -> [C,d]
+  SF_TRY(launch_transpose(m->out_proj_w, w.wt_outproj, C, d, st));      // [C,d] -> [d,C]
+
+  hipError_t e = hipMemsetAsync(w.dtok, 0, (size_t)D.T * R * d * sizeof(float), st);
+  if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+  // d_pred [B,S,N,C] -> step-major dpred [S][R][C]
+  for (int s = 0; s < D.S; ++s)
+    SF_TRY(sf_copy_rows_ex(d_pred, sf_rows_batched(C, N, (long long)D.S * N * C, (long long)s * N * C),
+                           w.dpred + (size_t)s * R * C, sf_rows(C), R, C, st));
+
+  for (int s = D.S - 1; s >= 0; --s) {
+    const size_t so = (size_t)s * M;
+    float* dp = w.dpred + (size_t)s * R * C;
+    // feedback through the in-projection of the predicted frame (zero for the last step)
+    if (s + 1 < D.S) {
+      SF_TRY(gemm(w.dtok + (size_t)(D.hist + s) * R * d, w.wt_inproj, nullptr, dp, dp, R, C, d, 0, st));
+    }
+    // through out_proj into the last N tokens of the final layer output
+    SF_TRY(gemm(dp, w.wt_outproj, nullptr, nullptr, w.dxlast, R, d, C, 0, st));
+    e = hipMemsetAsync(w.dx, 0, (size_t)M * d * sizeof(float), st);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    SF_TRY(sf_copy_rows_ex(w.dxlast, sf_rows(d), w.dx, sf_rows_batched(d, N, (long long)L * d, (long long)(L - N) * d), R,
+                           d, st));
+    float* dx = w.dx;     // gradient w.r.t. the current layer's output
+    float* dxo = w.dx2;   // scratch for the next one
+    for (int l = D.nl - 1; l >= 0; --l) {
+      const sf_tfm_layer& ly = m->layers[l];
+      float* dfo = w.dfo[l] + so * d;
+      float* dpre = w.dpre[l] + so * f;
+      float* da2 = w.da2[l] + so * d;
+      float* dao = w.dao[l] + so * d;
+      float* dqkv = w.dqkv[l] + so * 3 * d;
+      float* da1 = w.da1[l] + so * d;
+      // x2 = xmid + drop(ffn_o)
+      if (thr == 0) {
+        e = hipMemcpyAsync(dfo, dx, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+      } else {
+        hipLaunchKernelGGL(residual_dropout_kernel, dim3(cdiv(Md4, 256)), dim3(256), 0, st, dx, (const float*)nullptr, dfo,
+                           Md4, site_seed(seed, s, l, SITE_FFN_O), thr, inv_keep);
+        SF_CHECK_LAUNCH();
+      }
+      SF_TRY(gemm(dfo, w.wt_2[l], nullptr, nullptr, dpre, M, f, d, 0, st));
+      hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(cdiv((long long)M * f / 4, 256)), dim3(256), 0, st, dpre,
+                         w.hdn[l] + so * f, (long long)M * f / 4, thr ? inv_keep : 1.f);
+      SF_CHECK_LAUNCH();
+      SF_TRY(gemm(dpre, w.wt_1[l], nullptr, nullptr, da2, M, d, f, 0, st));
+      hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, w.xmid[l] + so * d, da2, ly.norm2_g, dx, dxo, M,
+                         d, 1e-5f);
+      SF_CHECK_LAUNCH();
+      // xmid = xin + drop(attn_o);  dxo = gradient w.r.t. xmid
+      if (thr == 0) {
+        e = hipMemcpyAsync(dao, dxo, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+      } else {
+        hipLaunchKernelGGL(residual_dropout_kernel, dim3(cdiv(Md4, 256)), dim3(256), 0, st, dxo, (const float*)nullptr, dao,
+                           Md4, site_seed(seed, s, l, SITE_ATTN_O), thr, inv_keep);
+        SF_CHECK_LAUNCH();
+      }
+      SF_TRY(gemm(dao, w.wt_o[l], nullptr, nullptr, w.dctx, M, d, d, 0, st));
+      hipLaunchKernelGGL(attn_train_bwd_kernel, dim3(D.H, B), dim3(256), albytes, st, w.qkv[l] + so * 3 * d, w.dctx, dqkv, L,
+                         d, hd, scale, site_seed(seed, s, l, SITE_ATTN_P), thr, inv_keep);
+      SF_CHECK_LAUNCH();
+      SF_TRY(gemm(dqkv, w.wt_in[l], nullptr, nullptr, da1, M, d, 3 * d, 0, st));
+      hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, w.xin[l] + so * d, da1, ly.norm1_g, dxo, dx, M,
+                         d, 1e-5f);
+      SF_CHECK_LAUNCH();
+      // dx now holds the gradient w.r.t. this layer's input
+    }
+    hipLaunchKernelGGL(window_scatter_kernel, dim3(cdiv(Md4, 256)), dim3(256), 0, st, dx, w.dtok + (size_t)s * R * d, B, L,
+                       N, d / 4);
+    SF_CHECK_LAUNCH();
+  }
+
+  // gradient w.r.t. the burn-in slots
+  if (d_x) {
+    SF_TRY(gemm(w.dtok, w.wt_inproj, nullptr, nullptr, w.tmp, D.hist * R, C, d, 0, st));
+    for (int t = 0; t < D.hist; ++t)
+      SF_TRY(sf_copy_rows_ex(w.tmp + (size_t)t * R * C, sf_rows(C), d_x,
+                             sf_rows_batched(C, N, (long long)D.hist * N * C, (long long)t * N * C), R, C, st));
+  }
+
+  // parameter gradients: one contraction per weight over all stacked rows.  The in-projection saw frames 0 .. T-2 (the
+  // last predicted frame is never fed back).
+  const long long rows = (long long)D.S * M;
+  const long long in_rows = (long long)(D.T - 1) * R;
+  SF_TRY(grad_weight(w.dtok, w.slots_all, g->in_proj_w, in_rows, d, C, w, st));
+  SF_TRY(grad_bias(w.dtok, g->in_proj_b, in_rows, d, w, st));
+  SF_TRY(grad_weight(w.dpred, w.xlast, g->out_proj_w, (long long)D.S * R, C, d, w, st));
+  SF_TRY(grad_bias(w.dpred, g->out_proj_b, (long long)D.S * R, C, w, st));
+  for (int l = 0; l < D.nl; ++l) {
+    const sf_tfm_layer_grads& gl = g->layers[l];
+    SF_TRY(grad_weight(w.dqkv[l], w.a1[l], gl.in_proj_w, rows, 3 * d, d, w, st));
+    SF_TRY(grad_bias(w.dqkv[l], gl.in_proj_b, rows, 3 * d, w, st));
+    SF_TRY(grad_weight(w.dao[l], w.ctx[l], gl.out_proj_w, rows, d, d, w, st));
+    SF_TRY(grad_bias(w.dao[l], gl.out_proj_b, rows, d, w, st));
+    SF_TRY(grad_weight(w.dpre[l], w.a2[l], gl.lin1_w, rows, f, d, w, st));
+    SF_TRY(grad_bias(w.dpre[l], gl.lin1_b, rows, f, w, st));
+    SF_TRY(grad_weight(w.dfo[l], w.hdn[l], gl.lin2_w, rows, d, f, w, st));
+    SF_TRY(grad_bias(w.dfo[l], gl.lin2_b, rows, d, w, st));
+    SF_TRY(grad_ln(w.xin[l], w.da1[l], gl.norm1_g, gl.norm1_b, rows, d, 1e-5f, w, st));
+    SF_TRY(grad_ln(w.xmid[l], w.da2[l], gl.norm2_g, gl.norm2_b, rows, d, 1e-5f, w, st));
+  }
+  return 0;
+}
+
+}  // extern "C"

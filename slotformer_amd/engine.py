@@ -93,10 +93,13 @@ def _tfm_layers(plan, encoder, pack_ffn=False):
 
 
 # ---------------------------------------------------------------------------------------------
-def rollouter_plan(r):
-    """r: SlotRollouter / SingleStepSlotRollouter container."""
+def rollouter_plan(r, packed=True):
+    """r: SlotRollouter / SingleStepSlotRollouter container.  packed=False (training, train.py): plain torch-layout
+    weights only -- the fragment-ordered copies the inference kernels read would have to be rebuilt after every
+    optimizer step."""
     sig = _signature(r)
-    plan = getattr(r, '_sf_plan', None)
+    attr = '_sf_plan' if packed else '_sf_train_plan'
+    plan = getattr(r, attr, None)
     if plan is not None and plan.sig == sig:
         return plan
     plan = _Plan()
@@ -117,8 +120,8 @@ def rollouter_plan(r):
     if r.enc_slots_pe is not None:
         pe = pe + r.enc_slots_pe.detach()[0].repeat(W, 1)
     s.pe_tok = plan.dp(pe.contiguous())
-    s.layers = C.cast(_tfm_layers(plan, enc, pack_ffn=True), C.POINTER(sf_tfm_layer))
-    if s.d_model == 256 and s.slot_size == 128 and r.in_proj.weight.is_cuda:
+    s.layers = C.cast(_tfm_layers(plan, enc, pack_ffn=packed), C.POINTER(sf_tfm_layer))
+    if packed and s.d_model == 256 and s.slot_size == 128 and r.in_proj.weight.is_cuda:
         # fragment-ordered copies of in_proj / out_proj for the fused step-boundary kernel (layer_fused.hip)
         st = torch.cuda.current_stream().cuda_stream
         for name, lin in (('in_proj_packed', r.in_proj), ('out_proj_packed', r.out_proj)):
@@ -128,7 +131,7 @@ def rollouter_plan(r):
             plan.keep.append(buf)
             setattr(s, name, buf.data_ptr())
     plan.struct, plan.sig = s, sig
-    r._sf_plan = plan
+    setattr(r, attr, plan)
     return plan
 
 

@@ -1,0 +1,136 @@
+"""Training of the rollout Transformer on the HIP library.
+
+`SlotRollouter.forward` lands here when autograd is recording: the whole autoregressive rollout is ONE autograd node.
+Its forward is `sf_rollout_train_fwd_f32` (activations of all steps kept in a workspace owned by the node), its backward
+`sf_rollout_train_bwd_f32`, which writes every parameter gradient into one flat fp32 bucket -- the unit the data-parallel
+all-reduce works on (parallel.allreduce_flat_bucket's layout, without the pack / unpack copies).  This replaces
+torch autograd over the reference's per-step nn.TransformerEncoder calls (slotformer.py:110-124) and nerv's DDP wrap.
+
+Dropout follows nn.TransformerEncoderLayer: active iff the module is in train() mode, p read from the layer.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from ._lib import lib, check, sf_rollouter_grads, sf_tfm_layer_grads
+from . import engine
+
+_LAYER_LEAVES = ('norm1.weight', 'norm1.bias', 'self_attn.in_proj_weight', 'self_attn.in_proj_bias',
+                 'self_attn.out_proj.weight', 'self_attn.out_proj.bias', 'norm2.weight', 'norm2.bias', 'linear1.weight',
+                 'linear1.bias', 'linear2.weight', 'linear2.bias')
+_LAYER_FIELDS = ('norm1_g', 'norm1_b', 'in_proj_w', 'in_proj_b', 'out_proj_w', 'out_proj_b', 'norm2_g', 'norm2_b', 'lin1_w',
+                 'lin1_b', 'lin2_w', 'lin2_b')
+
+
+def _leaf(module, dotted):
+    for part in dotted.split('.'):
+        module = getattr(module, part)
+    return module
+
+
+def rollouter_parameters(r):
+    """The trainable leaves of a SlotRollouter in bucket order: in_proj, out_proj, then every layer's leaves."""
+    ps = [r.in_proj.weight, r.in_proj.bias, r.out_proj.weight, r.out_proj.bias]
+    for layer in r.transformer_encoder.layers:
+        ps += [_leaf(layer, n) for n in _LAYER_LEAVES]
+    return ps
+
+
+def _grad_descriptor(flat, params, num_layers):
+    """sf_rollouter_grads whose pointers are consecutive slices of `flat` (same order as rollouter_parameters)."""
+    ptrs, off = [], 0
+    for p in params:
+        ptrs.append(flat.data_ptr() + 4 * off)
+        off += p.numel()
+    g = sf_rollouter_grads()
+    g.in_proj_w, g.in_proj_b, g.out_proj_w, g.out_proj_b = ptrs[:4]
+    arr = (sf_tfm_layer_grads * num_layers)()
+    for i in range(num_layers):
+        for j, f in enumerate(_LAYER_FIELDS):
+            setattr(arr[i], f, ptrs[4 + i * len(_LAYER_FIELDS) + j])
+    g.layers = C.cast(arr, C.POINTER(sf_tfm_layer_grads))
+    return g, arr
+
+
+def _split(flat, params):
+    out, off = [], 0
+    for p in params:
+        out.append(flat[off:off + p.numel()].view_as(p))
+        off += p.numel()
+    return out
+
+
+class _Rollout(torch.autograd.Function):
+    """pred = rollouter(x, pred_len) as a single autograd node."""
+
+    @staticmethod
+    def forward(ctx, r, x, pred_len, p_drop, seed, *params):
+        x = x.detach().float().contiguous()
+        if not x.is_cuda:
+            raise RuntimeError('slotformer_amd: inputs must live on a HIP device; there is no CPU fallback')
+        plan = engine.rollouter_plan(r, packed=False)
+        B = x.shape[0]
+        nbytes = lib().sf_rollout_train_workspace_bytes(C.byref(plan.struct), B, pred_len)
+        if nbytes == 0:
+            check(-1)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=x.device)
+        pred = torch.empty(B, pred_len, *x.shape[2:], dtype=torch.float32, device=x.device)
+        check(lib().sf_rollout_train_fwd_f32(C.byref(plan.struct), x.data_ptr(), pred.data_ptr(), B, pred_len, float(p_drop),
+                                             int(seed), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+        ctx.r, ctx.plan, ctx.ws, ctx.args = r, plan, ws, (B, pred_len, float(p_drop), int(seed), tuple(x.shape))
+        ctx.params = params
+        return pred
+
+    @staticmethod
+    def backward(ctx, d_pred):
+        B, pred_len, p_drop, seed, xshape = ctx.args
+        r, plan, params = ctx.r, ctx.plan, ctx.params
+        d_pred = d_pred.float().contiguous()
+        flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=d_pred.device)
+        g, keep = _grad_descriptor(flat, params, len(r.transformer_encoder.layers))
+        d_x = torch.empty(xshape, dtype=torch.float32, device=d_pred.device) if ctx.needs_input_grad[1] else None
+        check(lib().sf_rollout_train_bwd_f32(C.byref(plan.struct), d_pred.data_ptr(), d_x.data_ptr() if d_x is not None else None,
+                                             C.byref(g), B, pred_len, p_drop, seed, ctx.ws.data_ptr(), ctx.ws.numel(),
+                                             torch.cuda.current_stream().cuda_stream))
+        del keep
+        ctx.ws = None
+        if getattr(r, 'ddp_flat_bucket', False) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # data-parallel training (config C3): ONE all-reduce of the whole bucket over RCCL / xGMI, averaged
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat /= dist.get_world_size()
+        r.last_grad_bucket = flat
+        grads = _split(flat, params)
+        return (None, d_x, None, None, None) + tuple(g_ if ctx.needs_input_grad[5 + i] else None for i, g_ in enumerate(grads))
+
+
+def rollout_with_grad(r, x, pred_len):
+    """SlotRollouter.forward under autograd (slotformer.py:85-126).  x [B, history_len, N, C] -> [B, pred_len, N, C]."""
+    layer0 = r.transformer_encoder.layers[0]
+    p_drop = float(layer0.dropout.p) if r.training else 0.0
+    seed = int(torch.randint(0, 2**62, (1, )).item()) if p_drop > 0 else 0
+    seed = getattr(r, 'dropout_seed_override', None) or seed
+    return _Rollout.apply(r, x, pred_len, p_drop, seed, *rollouter_parameters(r))
+
+
+def dropout_keep_mask(seed, step, layer, site, numel, p):
+    """Host restatement of the library's dropout mask (rollout_train.hip: sf_keep / site_seed) for tests and tools:
+    bool [numel], True = kept.  site: 0 attention weights, 1 attention output, 2 FFN hidden, 3 FFN output."""
+    import numpy as np
+
+    def mix(h):
+        h = h.astype(np.uint32)
+        h ^= h >> np.uint32(16)
+        h = (h * np.uint32(0x7feb352d)).astype(np.uint32)
+        h ^= h >> np.uint32(15)
+        h = (h * np.uint32(0x846ca68b)).astype(np.uint32)
+        h ^= h >> np.uint32(16)
+        return h
+
+    with np.errstate(over='ignore'):
+        tag = np.uint32((step * 64 + layer) * 4 + site)
+        inner = mix(np.array([np.uint32((seed >> 32) & 0xffffffff) + np.uint32(0x9e3779b9) * (tag + np.uint32(1))], dtype=np.uint32))
+        sseed = mix(np.array([np.uint32(seed & 0xffffffff)], dtype=np.uint32) ^ inner)[0]
+        idx = np.arange(numel, dtype=np.uint32)
+        u = mix(idx ^ sseed) >> np.uint32(8)
+    return u >= np.uint32(int(float(np.float32(p)) * 16777216.0))

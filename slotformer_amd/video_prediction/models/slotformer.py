@@ -11,7 +11,7 @@ import torch
 from torch import nn
 
 from ...nerv_compat import BaseModel
-from ... import engine
+from ... import engine, train
 from ...base_slots.models import StoSAVi
 from ...host import frozen, losses
 
@@ -74,6 +74,8 @@ class SlotRollouter(Rollouter):
     def forward(self, x, pred_len):
         """x [B, history_len, N, C] burn-in slots -> the pred_len predicted frames [B, pred_len, N, C]."""
         assert x.shape[1] == self.history_len, 'wrong burn-in steps'
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return train.rollout_with_grad(self, x, pred_len)   # one autograd node around the HIP forward / backward
         n_in = x.shape[1]
         frames = torch.empty(x.shape[0], n_in + pred_len, *x.shape[2:], device=x.device, dtype=torch.float32)
         frames[:, :n_in].copy_(x)

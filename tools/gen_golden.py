@@ -377,6 +377,43 @@ def case_rollout(name, cfg, B, pred_len, seed, single_step=False):
     return m, sd
 
 
+def case_rollout_grads(name, cfg, B, seed, decay=0.9):
+    """Gradients of the reference's training loss (SlotFormer.forward + calc_train_loss in train() mode,
+    slotformer.py:263-318, then loss.backward()) w.r.t. every rollouter parameter and the burn-in slots.  Dropout is the
+    only random part of that path; its probability is set to 0 on the reference modules so the fixture is reproducible
+    (the masked arithmetic is pinned separately against the oracle with host-rebuilt masks)."""
+    print(name)
+    with torch.enable_grad():
+        m = build_slotformer(cfg)
+        sd = load_seeded(m, seed)
+        m.train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.
+        rd = cfg['rollout_dict']
+        hist, N, C = rd['history_len'], rd['num_slots'], rd['slot_size']
+        S = cfg['loss_dict']['rollout_len']
+        slots = gu.seeded_normal((B, hist + S, N, C), seed + 1).requires_grad_(True)
+        m.loss_decay_factor = decay
+        out = m({'slots': slots})
+        loss = m.calc_train_loss({'slots': slots}, out)['slot_recon_loss']
+        loss.backward()
+        names = [n for n, p_ in m.named_parameters() if n.startswith('rollouter.') and p_.requires_grad]
+        grads = {n: dict(m.named_parameters())[n].grad.detach().clone() for n in names}
+        # the oracle under autograd
+        osd = {k: (v.clone().requires_grad_(True) if k in grads else v) for k, v in sd.items()}
+        oslots = slots.detach().clone().requires_grad_(True)
+        o = oracle.slotformer_forward(oslots, osd, cfg, S)
+        ol = oracle.slot_mse_losses(o['pred_slots'], o['gt_slots'], training=True, loss_decay_factor=decay)['slot_recon_loss']
+        ol.backward()
+        print('  loss', float(loss), 'oracle', float(ol))
+        print('  oracle grad err', max(err(osd[n].grad, grads[n]) for n in names), 'd_slots', err(oslots.grad, slots.grad))
+    save(name, loss=np.array(float(loss)), d_slots=slots.grad.detach().numpy(), pred_slots=out['pred_slots'].detach().numpy(),
+         grad_names=np.array(names), **{'grad.' + n: g.numpy() for n, g in grads.items()}, **pack_meta(m, sd))
+
+
 @torch.no_grad()
 def case_h2(name, cfg, B, seed, frame_offset=2):
     """Run the reference's own rollout_video_slots() (rollout_clevrer_slots.py:20-65) on CPU."""
@@ -476,6 +513,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'steve_slotformer':
         case_steve_slotformer('steve_slotformer', B=1, seed=701)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'roll_train':
+        case_rollout_grads('roll_train', gu.TRAIN_ROLL, B=2, seed=801)
+        return
     case_savi('savi_c1', gu.C1_SAVI, B=2, T=3, seed=101)
     case_savi('savi_c1_it3', gu.C1_SAVI_IT3, B=1, T=2, seed=102)
     case_savi('savi_c2', gu.C2_SAVI, B=2, T=3, seed=103, noise_seed=7)
@@ -492,6 +532,7 @@ def main():
     case_phyre('harness_h3', gu.C5_SAVI, gu.C5_ROLL, B=2, vid_len=5, seed=501)
     case_steve_tokens('steve_tokens', B=1, T=2, seed=601)
     case_steve_slotformer('steve_slotformer', B=1, seed=701)
+    case_rollout_grads('roll_train', gu.TRAIN_ROLL, B=2, seed=801)
 
 
 if __name__ == '__main__':
