@@ -42,6 +42,10 @@ struct SfGemmArgs {
   // conv (im2col loaders): output cH x cW, input cInH x cInW, cCin channels, cKs taps, stride
   int cH, cW, cInH, cInW, cCin, cKs, cStride;
   long long cFrameStride;
+  // dropout on act(acc + bias) before the residual (training, rollout_train.hip): element (row, col) is kept iff
+  // sf_mix32((row * N + col) ^ drop_seed) >> 8 >= drop_thresh and scaled by drop_scale; drop_thresh == 0: off
+  uint32_t drop_seed, drop_thresh;
+  float drop_scale;
   int dbg;  // ablation bits (SF_GEMM_DBG, tools only): 1 no MFMA, 2 no main-loop loads, 4 no LN stats, 8 no stores
 };
 
@@ -521,7 +525,9 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rbase + (r & 3) + 8 * (r >> 2);
-        const float v = fmaxf(acc[i][j][r] + bias, lo) + rv[r];
+        float t = fmaxf(acc[i][j][r] + bias, lo);
+        if (p.drop_thresh) t = (sf_mix32((uint32_t)(row * N + col) ^ p.drop_seed) >> 8) >= p.drop_thresh ? t * p.drop_scale : 0.f;
+        const float v = t + rv[r];
         if (row < M && colok && !((p.dbg & 8) && v != 12345.f)) p.C[sf_row_off(p.cmap, row) + col] = v;
       }
     }
@@ -671,6 +677,17 @@ int sf_linear_ex(const float* A, SfRowMap amap, const float* W, const float* bia
   a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = ln_eps; a.ln_relu = ln_relu;
   a.res = res; a.rmap = rmap; a.res_mod = res_mod;
   a.C = C; a.cmap = cmap; a.M = M; a.N = N; a.K = K; a.relu = relu;
+  return sf_gemm_dispatch(a, ALOAD_PLAIN, stream);
+}
+
+// C = res + dropout(act(A . W^T + bias)): the GEMM of a training forward pass
+int sf_linear_dropout_ex(const float* A, const float* W, const float* bias, const float* res, float* C, int M, int N, int K,
+                         int relu, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, hipStream_t stream) {
+  SfGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.amap = sf_rows(K); a.W = W; a.ldw = K; a.bias = bias;
+  a.res = res; a.rmap = sf_rows(N); a.C = C; a.cmap = sf_rows(N); a.M = M; a.N = N; a.K = K; a.relu = relu;
+  a.drop_seed = drop_seed; a.drop_thresh = drop_thresh; a.drop_scale = drop_scale;
   return sf_gemm_dispatch(a, ALOAD_PLAIN, stream);
 }
 

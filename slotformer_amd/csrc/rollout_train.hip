@@ -28,14 +28,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // ---------------------------------------------------------------------------------------------------------------------
 // dropout mask
 // ---------------------------------------------------------------------------------------------------------------------
-__host__ __device__ static inline uint32_t sf_mix32(uint32_t h) {
-  h ^= h >> 16;
-  h *= 0x7feb352du;
-  h ^= h >> 15;
-  h *= 0x846ca68bu;
-  h ^= h >> 16;
-  return h;
-}
 enum { SITE_ATTN_P = 0, SITE_ATTN_O = 1, SITE_FFN_H = 2, SITE_FFN_O = 3 };
 static inline uint32_t site_seed(unsigned long long seed, int step, int layer, int site) {
   const uint32_t tag = (uint32_t)((step * 64 + layer) * 4 + site);
@@ -259,11 +251,221 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The same two kernels on the exact-f32 matrix pipe (v_mfma_f32_32x32x2_f32) for head_dim 32 / 64 and windows of at most
+// 96 tokens: every product (q k^T, P v, g v^T, Pd^T g, dS k, dS^T q) is a set of 32x32 output tiles whose operands are
+// read from zero-padded LDS tiles through (row, k) -> address functors, one tile per wave at a time.
+// ---------------------------------------------------------------------------------------------------------------------
+template <class FA, class FB>
+__device__ __forceinline__ f32x16 mm32(FA a, FB b, int K, int lane) {
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int i0 = lane & 31, kk = lane >> 5;
+  for (int k = 0; k < K; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a(i0, k + kk), b(k + kk, i0), acc, 0, 0, 0);
+  return acc;
+}
+#define MM_ROW(r, lane) (((r) & 3) + 8 * ((r) >> 2) + 4 * ((lane) >> 5))
+
+// load q (scaled), k, v [L, HD] of (video b, head h) into zero-padded [Lp][HD + 1] tiles
+template <int HD>
+__device__ __forceinline__ void attn_load_qkv(const float* qkv, int L, int Lp, int d, int b, int h, float scale, float* q,
+                                              float* k, float* v) {
+  constexpr int HP = HD + 1, C4 = HD / 4;
+  for (int i = threadIdx.x; i < Lp * C4; i += 256) {
+    const int r = i / C4, c = (i - r * C4) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bb = a, cc = a;
+    if (r < L) {
+      const float* row = qkv + ((long long)b * L + r) * 3 * d + h * HD + c;
+      a = *reinterpret_cast<const float4*>(row);
+      bb = *reinterpret_cast<const float4*>(row + d);
+      cc = *reinterpret_cast<const float4*>(row + 2 * d);
+    }
+    float* qo = q + r * HP + c;
+    float* ko = k + r * HP + c;
+    float* vo = v + r * HP + c;
+    qo[0] = a.x * scale; qo[1] = a.y * scale; qo[2] = a.z * scale; qo[3] = a.w * scale;
+    ko[0] = bb.x; ko[1] = bb.y; ko[2] = bb.z; ko[3] = bb.w;
+    vo[0] = cc.x; vo[1] = cc.y; vo[2] = cc.z; vo[3] = cc.w;
+  }
+}
+
+// S = q k^T into P (all Lp x Lp tiles), then row softmax.  P <- probabilities (zero outside L x L); if Pd != nullptr it
+// receives the dropped probabilities, else (drop_in_place) P itself is dropped.
+template <int HD>
+__device__ __forceinline__ void attn_probs_mfma(const float* q, const float* k, float* P, float* Pd, bool drop_in_place, int L,
+                                                int Lp, uint32_t sseed, uint32_t thresh, float inv_keep, uint32_t base) {
+  constexpr int HP = HD + 1;
+  const int lp = Lp + 1, nt = Lp / 32;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int t = wave; t < nt * nt; t += 4) {
+    const int ti = (t / nt) * 32, tj = (t % nt) * 32;
+    const f32x16 acc = mm32([&](int i, int kk) { return q[(ti + i) * HP + kk]; },
+                            [&](int kk, int j) { return k[(tj + j) * HP + kk]; }, HD, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) P[(ti + MM_ROW(r, lane)) * lp + tj + (lane & 31)] = acc[r];
+  }
+  __syncthreads();
+  for (int r = wave; r < Lp; r += 4) {
+    float p0 = 0.f, p1 = 0.f;
+    if (r < L) {
+      const float a0 = lane < L ? P[r * lp + lane] : -INFINITY;
+      const float a1 = lane + 64 < L ? P[r * lp + lane + 64] : -INFINITY;
+      const float mx = sf_wave_max(fmaxf(a0, a1));
+      const float e0 = lane < L ? __expf(a0 - mx) : 0.f;
+      const float e1 = lane + 64 < L ? __expf(a1 - mx) : 0.f;
+      const float inv = 1.f / sf_wave_sum(e0 + e1);
+      p0 = e0 * inv;
+      p1 = e1 * inv;
+    }
+    float d0 = p0, d1 = p1;
+    if (thresh && r < L) {
+      d0 = sf_keep(sseed, base + r * L + lane, thresh) ? p0 * inv_keep : 0.f;
+      d1 = sf_keep(sseed, base + r * L + lane + 64, thresh) ? p1 * inv_keep : 0.f;
+    }
+    if (lane < Lp) {
+      P[r * lp + lane] = drop_in_place ? d0 : p0;
+      if (Pd) Pd[r * lp + lane] = d0;
+    }
+    if (lane + 64 < Lp) {
+      P[r * lp + lane + 64] = drop_in_place ? d1 : p1;
+      if (Pd) Pd[r * lp + lane + 64] = d1;
+    }
+  }
+  __syncthreads();
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_train_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, int L,
+                                                                  int Lp, int d, float scale, uint32_t sseed, uint32_t thresh,
+                                                                  float inv_keep) {
+  extern __shared__ float lds[];
+  constexpr int HP = HD + 1;
+  const int lp = Lp + 1, nt = Lp / 32;
+  float* q = lds;
+  float* k = q + Lp * HP;
+  float* v = k + Lp * HP;
+  float* P = v + Lp * HP;
+  const int h = blockIdx.x, b = blockIdx.y, H = gridDim.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  attn_load_qkv<HD>(qkv, L, Lp, d, b, h, scale, q, k, v);
+  __syncthreads();
+  attn_probs_mfma<HD>(q, k, P, nullptr, true, L, Lp, sseed, thresh, inv_keep, (uint32_t)(((long long)b * H + h) * L * L));
+  const int Le = (L + 1) & ~1;
+  for (int t = wave; t < nt * (HD / 32); t += 4) {
+    const int ti = (t / (HD / 32)) * 32, tj = (t % (HD / 32)) * 32;
+    const f32x16 acc = mm32([&](int i, int kk) { return P[(ti + i) * lp + kk]; },
+                            [&](int kk, int j) { return v[kk * HP + tj + j]; }, Le, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = ti + MM_ROW(r, lane);
+      if (row < L) ctx[((long long)b * L + row) * d + h * HD + tj + (lane & 31)] = acc[r];
+    }
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_train_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx,
+                                                                  float* __restrict__ dqkv, int L, int Lp, int d, float scale,
+                                                                  uint32_t sseed, uint32_t thresh, float inv_keep) {
+  extern __shared__ float lds[];
+  constexpr int HP = HD + 1, C4 = HD / 4, HT = HD / 32;
+  const int lp = Lp + 1, nt = Lp / 32;
+  float* q = lds;
+  float* k = q + Lp * HP;
+  float* v = k + Lp * HP;
+  float* g = v + Lp * HP;
+  float* P = g + Lp * HP;
+  float* dS = P + Lp * lp;
+  const int h = blockIdx.x, b = blockIdx.y, H = gridDim.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  attn_load_qkv<HD>(qkv, L, Lp, d, b, h, scale, q, k, v);
+  for (int i = threadIdx.x; i < Lp * C4; i += 256) {
+    const int r = i / C4, c = (i - r * C4) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < L) a = *reinterpret_cast<const float4*>(dctx + ((long long)b * L + r) * d + h * HD + c);
+    float* go = g + r * HP + c;
+    go[0] = a.x; go[1] = a.y; go[2] = a.z; go[3] = a.w;
+  }
+  __syncthreads();
+  // P = softmax, dS buffer = dropped probabilities Pd
+  attn_probs_mfma<HD>(q, k, P, dS, false, L, Lp, sseed, thresh, inv_keep, (uint32_t)(((long long)b * H + h) * L * L));
+  const int Le = (L + 1) & ~1;
+  // dPd = g v^T (kept in registers: at most 3 tiles per wave for Lp = 96)
+  f32x16 dp[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const int t = wave + 4 * n;
+    if (t < nt * nt) {
+      const int ti = (t / nt) * 32, tj = (t % nt) * 32;
+      dp[n] = mm32([&](int i, int kk) { return g[(ti + i) * HP + kk]; }, [&](int kk, int j) { return v[(tj + j) * HP + kk]; }, HD,
+                   lane);
+    }
+  }
+  // dV = Pd^T g
+  for (int t = wave; t < nt * HT; t += 4) {
+    const int ti = (t / HT) * 32, tj = (t % HT) * 32;
+    const f32x16 acc = mm32([&](int i, int kk) { return dS[kk * lp + ti + i]; },
+                            [&](int kk, int j) { return g[kk * HP + tj + j]; }, Le, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = ti + MM_ROW(r, lane);
+      if (row < L) dqkv[((long long)b * L + row) * 3 * d + 2 * d + h * HD + tj + (lane & 31)] = acc[r];
+    }
+  }
+  __syncthreads();
+  // dP = mask * dPd / keep  (the mask is where Pd is non-zero: softmax weights are strictly positive), over Pd in place
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const int t = wave + 4 * n;
+    if (t < nt * nt) {
+      const int ti = (t / nt) * 32, tj = (t % nt) * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float* e = &dS[(ti + MM_ROW(r, lane)) * lp + tj + (lane & 31)];
+        *e = (thresh == 0 || *e != 0.f) ? dp[n][r] * (thresh ? inv_keep : 1.f) : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  // dS = P * (dP - rowsum(dP * P))
+  for (int r = wave; r < L; r += 4) {
+    const float p0 = lane < L ? P[r * lp + lane] : 0.f, p1 = lane + 64 < L ? P[r * lp + lane + 64] : 0.f;
+    const float d0 = lane < L ? dS[r * lp + lane] : 0.f, d1 = lane + 64 < L ? dS[r * lp + lane + 64] : 0.f;
+    const float dot = sf_wave_sum(p0 * d0 + p1 * d1);
+    if (lane < Lp) dS[r * lp + lane] = p0 * (d0 - dot);
+    if (lane + 64 < Lp) dS[r * lp + lane + 64] = p1 * (d1 - dot);
+  }
+  __syncthreads();
+  // dq = scale * dS k (tiles 0 .. nt*HT-1), dk = dS^T (q * scale) (the next nt*HT tiles)
+  for (int t = wave; t < 2 * nt * HT; t += 4) {
+    const bool isk = t >= nt * HT;
+    const int tt = isk ? t - nt * HT : t;
+    const int ti = (tt / HT) * 32, tj = (tt % HT) * 32;
+    f32x16 acc;
+    if (!isk)
+      acc = mm32([&](int i, int kk) { return dS[(ti + i) * lp + kk]; }, [&](int kk, int j) { return k[kk * HP + tj + j]; }, Le,
+                 lane);
+    else
+      acc = mm32([&](int i, int kk) { return dS[kk * lp + ti + i]; }, [&](int kk, int j) { return q[kk * HP + tj + j]; }, Le,
+                 lane);
+    const float sc = isk ? 1.f : scale;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = ti + MM_ROW(r, lane);
+      if (row < L) dqkv[((long long)b * L + row) * 3 * d + (isk ? d : 0) + h * HD + tj + (lane & 31)] = acc[r] * sc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // LayerNorm backward (one wave per row, D <= 1024, D % 4 == 0):  out = dres + dLN(dy; x, gamma)
 // ---------------------------------------------------------------------------------------------------------------------
+// out2 (optional): the same gradient pushed through the dropout of the block below it (mask * out / keep), i.e. the
+// gradient w.r.t. that block's pre-dropout output -- saves a separate pass over the tensor.
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
-                                                     float* __restrict__ out, int rows, int D, float eps) {
+                                                     float* __restrict__ out, float* __restrict__ out2, uint32_t sseed2,
+                                                     uint32_t thresh, float inv_keep, int rows, int D, float eps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -318,8 +520,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
       r.z += rstd * (gv[i].z - m1 - xv[i].z * m2);
       r.w += rstd * (gv[i].w - m1 - xv[i].w * m2);
       orow[c] = r;
+      if (out2) {
+        if (thresh) {
+          const uint32_t e = (uint32_t)(row * D + 4 * c);
+          r.x = sf_keep(sseed2, e, thresh) ? r.x * inv_keep : 0.f;
+          r.y = sf_keep(sseed2, e + 1, thresh) ? r.y * inv_keep : 0.f;
+          r.z = sf_keep(sseed2, e + 2, thresh) ? r.z * inv_keep : 0.f;
+          r.w = sf_keep(sseed2, e + 3, thresh) ? r.w * inv_keep : 0.f;
+        }
+        reinterpret_cast<float4*>(out2 + (long long)row * D)[c] = r;
+      }
     }
   }
+}
+
+// gradient w.r.t. the final layer output: zero except the last N tokens of every video (dxlast [B*N, d]); dfo = the same
+// pushed through the top layer's FFN-output dropout
+__global__ __launch_bounds__(256) void scatter_last_kernel(const float* __restrict__ dxlast, float* __restrict__ dx,
+                                                           float* __restrict__ dfo, int B, int L, int N, int d4,
+                                                           uint32_t sseed, uint32_t thresh, float inv_keep) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * L * d4) return;
+  const int c = (int)(i % d4);
+  const int row = (int)(i / d4);
+  const int b = row / L, l = row - b * L;
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (l >= L - N) r = reinterpret_cast<const float4*>(dxlast)[((long long)b * N + (l - (L - N))) * d4 + c];
+  reinterpret_cast<float4*>(dx)[i] = r;
+  if (thresh) {
+    const uint32_t e = (uint32_t)(4 * i);
+    r.x = sf_keep(sseed, e, thresh) ? r.x * inv_keep : 0.f;
+    r.y = sf_keep(sseed, e + 1, thresh) ? r.y * inv_keep : 0.f;
+    r.z = sf_keep(sseed, e + 2, thresh) ? r.z * inv_keep : 0.f;
+    r.w = sf_keep(sseed, e + 3, thresh) ? r.w * inv_keep : 0.f;
+  }
+  reinterpret_cast<float4*>(dfo)[i] = r;
 }
 
 // LayerNorm parameter gradients, stage 1: workgroup g handles rows [g*rpg, (g+1)*rpg); partial[g][0][D] = sum dy*xhat,
@@ -413,17 +648,33 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   partial[(long long)blockIdx.y * n + c] = s0 + s1;
 }
 
-// stage 2 of every split reduction: out[i] = sum_g partial[g][i]  (fixed order)
+// stage 2 of every split reduction: out[i] = sum_g partial[g][i]  (fixed order: four interleaved chains, then their sum)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                               int G, long long n4) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
-  float4 a = reinterpret_cast<const float4*>(partial)[i];
-  for (int g = 1; g < G; ++g) {
-    const float4 b = reinterpret_cast<const float4*>(partial)[(long long)g * n4 + i];
-    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  const float4* p = reinterpret_cast<const float4*>(partial) + i;
+  float4 a[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int g = 0;
+  for (; g + 4 <= G; g += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4 b = p[(long long)(g + u) * n4];
+      a[u].x += b.x; a[u].y += b.y; a[u].z += b.z; a[u].w += b.w;
+    }
   }
-  reinterpret_cast<float4*>(out)[i] = a;
+  for (; g < G; ++g) {
+    const float4 b = p[(long long)g * n4];
+    a[0].x += b.x; a[0].y += b.y; a[0].z += b.z; a[0].w += b.w;
+  }
+  float4 r;
+  r.x = (a[0].x + a[1].x) + (a[2].x + a[3].x);
+  r.y = (a[0].y + a[1].y) + (a[2].y + a[3].y);
+  r.z = (a[0].z + a[1].z) + (a[2].z + a[3].z);
+  r.w = (a[0].w + a[1].w) + (a[2].w + a[3].w);
+  reinterpret_cast<float4*>(out)[i] = r;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -592,7 +843,7 @@ Ws carve(const Dims& D, float* base) {
 // number of row splits of a weight-gradient contraction: enough workgroups to fill the chip a few times over
 inline int tn_splits(long long rows, int N, int K) {
   const long long tiles = (long long)(N / 64) * (K / 64);
-  long long s = (1024 + tiles - 1) / tiles;
+  long long s = (512 + tiles - 1) / tiles;
   const long long max_s = (rows + 63) / 64;
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -645,6 +896,69 @@ int gemm(const float* A, const float* W, const float* bias, const float* res, fl
 
 int attn_lds_bytes(int L, int hd, bool bwd) {
   return (int)(((bwd ? 4 : 3) * L * (hd + 1) + (bwd ? 2 : 1) * L * (L + 1)) * sizeof(float));
+}
+
+// SF_TRAIN_ATTN=scalar forces the plain-FMA kernels (tools / tests)
+inline bool attn_use_mfma(int L, int hd) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("SF_TRAIN_ATTN");
+    forced = (e && strcmp(e, "scalar") == 0) ? 1 : 0;
+  }
+  return !forced && (hd == 32 || hd == 64) && L <= 96;
+}
+template <class Kern>
+int set_lds(Kern kern, size_t bytes) {
+  if (bytes <= 64 * 1024) return 0;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+  return 0;
+}
+int launch_attn_fwd(const float* qkv, float* ctx, int B, int H, int L, int d, uint32_t sseed, uint32_t thr, float inv_keep,
+                    hipStream_t st) {
+  const int hd = d / H;
+  const float scale = 1.f / sqrtf((float)hd);
+  if (attn_use_mfma(L, hd)) {
+    const int Lp = (L + 31) & ~31;
+    const size_t bytes = ((size_t)3 * Lp * (hd + 1) + (size_t)Lp * (Lp + 1)) * sizeof(float);
+    if (hd == 32) {
+      SF_TRY(set_lds(attn_train_fwd_mfma_kernel<32>, bytes));
+      hipLaunchKernelGGL(attn_train_fwd_mfma_kernel<32>, dim3(H, B), dim3(256), bytes, st, qkv, ctx, L, Lp, d, scale, sseed, thr,
+                         inv_keep);
+    } else {
+      SF_TRY(set_lds(attn_train_fwd_mfma_kernel<64>, bytes));
+      hipLaunchKernelGGL(attn_train_fwd_mfma_kernel<64>, dim3(H, B), dim3(256), bytes, st, qkv, ctx, L, Lp, d, scale, sseed, thr,
+                         inv_keep);
+    }
+  } else {
+    hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(H, B), dim3(256), attn_lds_bytes(L, hd, false), st, qkv, ctx, L, d, hd, scale,
+                       sseed, thr, inv_keep);
+  }
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+int launch_attn_bwd(const float* qkv, const float* dctx, float* dqkv, int B, int H, int L, int d, uint32_t sseed, uint32_t thr,
+                    float inv_keep, hipStream_t st) {
+  const int hd = d / H;
+  const float scale = 1.f / sqrtf((float)hd);
+  if (attn_use_mfma(L, hd)) {
+    const int Lp = (L + 31) & ~31;
+    const size_t bytes = ((size_t)4 * Lp * (hd + 1) + (size_t)2 * Lp * (Lp + 1)) * sizeof(float);
+    if (hd == 32) {
+      SF_TRY(set_lds(attn_train_bwd_mfma_kernel<32>, bytes));
+      hipLaunchKernelGGL(attn_train_bwd_mfma_kernel<32>, dim3(H, B), dim3(256), bytes, st, qkv, dctx, dqkv, L, Lp, d, scale, sseed,
+                         thr, inv_keep);
+    } else {
+      SF_TRY(set_lds(attn_train_bwd_mfma_kernel<64>, bytes));
+      hipLaunchKernelGGL(attn_train_bwd_mfma_kernel<64>, dim3(H, B), dim3(256), bytes, st, qkv, dctx, dqkv, L, Lp, d, scale, sseed,
+                         thr, inv_keep);
+    }
+  } else {
+    hipLaunchKernelGGL(attn_train_bwd_kernel, dim3(H, B), dim3(256), attn_lds_bytes(L, hd, true), st, qkv, dctx, dqkv, L, d, hd,
+                       scale, sseed, thr, inv_keep);
+  }
+  SF_CHECK_LAUNCH();
+  return 0;
 }
 
 // dW = Y^T X over `rows` rows, written to dW [N, K]
@@ -753,32 +1067,14 @@ int sf_rollout_train_fwd_f32(const sf_rollouter* m, const float* x, float* pred,
       float* xnext = (l + 1 < D.nl ? w.xin[l + 1] : w.xf) + so * d;
       SF_TRY(sf_layernorm_ex(xin, sf_rows(d), ly.norm1_g, ly.norm1_b, a1, sf_rows(d), M, d, 1e-5f, st));
       SF_TRY(gemm(a1, ly.in_proj_w, ly.in_proj_b, nullptr, qkv, M, 3 * d, d, 0, st));
-      hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(D.H, B), dim3(256), albytes, st, qkv, ctx, L, d, hd, scale,
-                         site_seed(seed, s, l, SITE_ATTN_P), thr, inv_keep);
-      SF_CHECK_LAUNCH();
-      if (thr == 0) {
-        SF_TRY(gemm(ctx, ly.out_proj_w, ly.out_proj_b, xin, xmid, M, d, d, 0, st));
-      } else {
-        SF_TRY(gemm(ctx, ly.out_proj_w, ly.out_proj_b, nullptr, w.tmp, M, d, d, 0, st));
-        hipLaunchKernelGGL(residual_dropout_kernel, dim3(cdiv((long long)M * d / 4, 256)), dim3(256), 0, st, w.tmp, xin,
-                           xmid, (long long)M * d / 4, site_seed(seed, s, l, SITE_ATTN_O), thr, inv_keep);
-        SF_CHECK_LAUNCH();
-      }
+      SF_TRY(launch_attn_fwd(qkv, ctx, B, D.H, L, d, site_seed(seed, s, l, SITE_ATTN_P), thr, inv_keep, st));
+      SF_TRY(sf_linear_dropout_ex(ctx, ly.out_proj_w, ly.out_proj_b, xin, xmid, M, d, d, 0, site_seed(seed, s, l, SITE_ATTN_O), thr,
+                                  inv_keep, st));
       SF_TRY(sf_layernorm_ex(xmid, sf_rows(d), ly.norm2_g, ly.norm2_b, a2, sf_rows(d), M, d, 1e-5f, st));
-      if (thr == 0) {
-        SF_TRY(gemm(a2, ly.lin1_w, ly.lin1_b, nullptr, hdn, M, f, d, 1, st));
-        SF_TRY(gemm(hdn, ly.lin2_w, ly.lin2_b, xmid, xnext, M, d, f, 0, st));
-      } else {
-        SF_TRY(gemm(a2, ly.lin1_w, ly.lin1_b, nullptr, w.tmp, M, f, d, 1, st));
-        hipLaunchKernelGGL(residual_dropout_kernel, dim3(cdiv((long long)M * f / 4, 256)), dim3(256), 0, st, w.tmp,
-                           (const float*)nullptr, hdn, (long long)M * f / 4, site_seed(seed, s, l, SITE_FFN_H), thr,
-                           inv_keep);
-        SF_CHECK_LAUNCH();
-        SF_TRY(gemm(hdn, ly.lin2_w, ly.lin2_b, nullptr, w.tmp, M, d, f, 0, st));
-        hipLaunchKernelGGL(residual_dropout_kernel, dim3(cdiv((long long)M * d / 4, 256)), dim3(256), 0, st, w.tmp, xmid,
-                           xnext, (long long)M * d / 4, site_seed(seed, s, l, SITE_FFN_O), thr, inv_keep);
-        SF_CHECK_LAUNCH();
-      }
+      SF_TRY(sf_linear_dropout_ex(a2, ly.lin1_w, ly.lin1_b, nullptr, hdn, M, f, d, 1, site_seed(seed, s, l, SITE_FFN_H), thr, inv_keep,
+                                  st));
+      SF_TRY(sf_linear_dropout_ex(hdn, ly.lin2_w, ly.lin2_b, xmid, xnext, M, d, f, 0, site_seed(seed, s, l, SITE_FFN_O), thr,
+                                  inv_keep, st));
     }
     // last N tokens of every video -> xlast[s]; prediction = out_proj(xlast)  (slotformer.py:121)
     SF_TRY(sf_copy_rows_ex(w.xf + so * d, sf_rows_batched(d, N, (long long)L * d, (long long)(L - N) * d),
@@ -836,55 +1132,37 @@ int sf_rollout_train_bwd_f32(const sf_rollouter* m, const float* d_pred, float* 
     }
     // through out_proj into the last N tokens of the final layer output
     SF_TRY(gemm(dp, w.wt_outproj, nullptr, nullptr, w.dxlast, R, d, C, 0, st));
-    e = hipMemsetAsync(w.dx, 0, (size_t)M * d * sizeof(float), st);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    SF_TRY(sf_copy_rows_ex(w.dxlast, sf_rows(d), w.dx, sf_rows_batched(d, N, (long long)L * d, (long long)(L - N) * d), R,
-                           d, st));
+    hipLaunchKernelGGL(scatter_last_kernel, dim3(cdiv(Md4, 256)), dim3(256), 0, st, w.dxlast, w.dx, w.dfo[D.nl - 1] + so * d, B, L, N,
+                       d / 4, site_seed(seed, s, D.nl - 1, SITE_FFN_O), thr, inv_keep);
+    SF_CHECK_LAUNCH();
     float* dx = w.dx;     // gradient w.r.t. the current layer's output
-    float* dxo = w.dx2;   // scratch for the next one
+    float* dxo = w.dx2;   // gradient w.r.t. the layer's mid-point (after the attention block)
     for (int l = D.nl - 1; l >= 0; --l) {
       const sf_tfm_layer& ly = m->layers[l];
-      float* dfo = w.dfo[l] + so * d;
+      float* dfo = w.dfo[l] + so * d;     // x2 = xmid + drop(ffn_o): filled by the stage above
       float* dpre = w.dpre[l] + so * f;
       float* da2 = w.da2[l] + so * d;
       float* dao = w.dao[l] + so * d;
       float* dqkv = w.dqkv[l] + so * 3 * d;
       float* da1 = w.da1[l] + so * d;
-      // x2 = xmid + drop(ffn_o)
-      if (thr == 0) {
-        e = hipMemcpyAsync(dfo, dx, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-      } else {
-        hipLaunchKernelGGL(residual_dropout_kernel, dim3(cdiv(Md4, 256)), dim3(256), 0, st, dx, (const float*)nullptr, dfo,
-                           Md4, site_seed(seed, s, l, SITE_FFN_O), thr, inv_keep);
-        SF_CHECK_LAUNCH();
-      }
       SF_TRY(gemm(dfo, w.wt_2[l], nullptr, nullptr, dpre, M, f, d, 0, st));
       hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(cdiv((long long)M * f / 4, 256)), dim3(256), 0, st, dpre,
                          w.hdn[l] + so * f, (long long)M * f / 4, thr ? inv_keep : 1.f);
       SF_CHECK_LAUNCH();
       SF_TRY(gemm(dpre, w.wt_1[l], nullptr, nullptr, da2, M, d, f, 0, st));
-      hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, w.xmid[l] + so * d, da2, ly.norm2_g, dx, dxo, M,
-                         d, 1e-5f);
+      // xmid = xin + drop(attn_o): dxo = gradient w.r.t. xmid, dao = the same through the attention-output dropout
+      hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, w.xmid[l] + so * d, da2, ly.norm2_g, dx, dxo, dao,
+                         site_seed(seed, s, l, SITE_ATTN_O), thr, inv_keep, M, d, 1e-5f);
       SF_CHECK_LAUNCH();
-      // xmid = xin + drop(attn_o);  dxo = gradient w.r.t. xmid
-      if (thr == 0) {
-        e = hipMemcpyAsync(dao, dxo, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-      } else {
-        hipLaunchKernelGGL(residual_dropout_kernel, dim3(cdiv(Md4, 256)), dim3(256), 0, st, dxo, (const float*)nullptr, dao,
-                           Md4, site_seed(seed, s, l, SITE_ATTN_O), thr, inv_keep);
-        SF_CHECK_LAUNCH();
-      }
       SF_TRY(gemm(dao, w.wt_o[l], nullptr, nullptr, w.dctx, M, d, d, 0, st));
-      hipLaunchKernelGGL(attn_train_bwd_kernel, dim3(D.H, B), dim3(256), albytes, st, w.qkv[l] + so * 3 * d, w.dctx, dqkv, L,
-                         d, hd, scale, site_seed(seed, s, l, SITE_ATTN_P), thr, inv_keep);
-      SF_CHECK_LAUNCH();
+      SF_TRY(launch_attn_bwd(w.qkv[l] + so * 3 * d, w.dctx, dqkv, B, D.H, L, d, site_seed(seed, s, l, SITE_ATTN_P), thr, inv_keep,
+                             st));
       SF_TRY(gemm(dqkv, w.wt_in[l], nullptr, nullptr, da1, M, d, 3 * d, 0, st));
-      hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, w.xin[l] + so * d, da1, ly.norm1_g, dxo, dx, M,
-                         d, 1e-5f);
+      // dx = gradient w.r.t. this layer's input = the output of layer l-1, whose FFN-output dropout is folded in
+      hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, w.xin[l] + so * d, da1, ly.norm1_g, dxo, dx,
+                         l > 0 ? w.dfo[l - 1] + so * d : (float*)nullptr, site_seed(seed, s, l > 0 ? l - 1 : 0, SITE_FFN_O), thr,
+                         inv_keep, M, d, 1e-5f);
       SF_CHECK_LAUNCH();
-      // dx now holds the gradient w.r.t. this layer's input
     }
     hipLaunchKernelGGL(window_scatter_kernel, dim3(cdiv(Md4, 256)), dim3(256), 0, st, dx, w.dtok + (size_t)s * R * d, B, L,
                        N, d / 4);

@@ -53,6 +53,16 @@ __device__ __forceinline__ long long sf_row_off(const SfRowMap& m, int row) {
   return m.base + (long long)b * m.batch_stride + (long long)r * m.ld;
 }
 
+// 32-bit finalizer used by the dropout masks of the training path (rollout_train.hip)
+__host__ __device__ static inline uint32_t sf_mix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x7feb352du;
+  h ^= h >> 15;
+  h *= 0x846ca68bu;
+  h ^= h >> 16;
+  return h;
+}
+
 // ---- DPP reductions (one v_add_f32_dpp per step instead of a ds_bpermute round trip through LDS) ----
 // quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
 template <int CTRL>

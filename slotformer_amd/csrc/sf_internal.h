@@ -5,6 +5,8 @@
 int sf_linear_ex(const float* A, SfRowMap amap, const float* W, const float* bias, const float* ln_g,
                  const float* ln_b, float ln_eps, const float* res, SfRowMap rmap, int res_mod,
                  float* C, SfRowMap cmap, int M, int N, int K, int relu, hipStream_t stream, int ln_relu = 0);
+int sf_linear_dropout_ex(const float* A, const float* W, const float* bias, const float* res, float* C, int M, int N, int K,
+                         int relu, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, hipStream_t stream);
 int sf_layernorm_ex(const float* x, SfRowMap xmap, const float* g, const float* b, float* y, SfRowMap ymap,
                     int rows, int D, float eps, hipStream_t st);
 int sf_mha_ex(const float* qkv, float* out, int B, int L, int Lq, int d, int nheads, hipStream_t st);

@@ -1,0 +1,145 @@
+"""Training-step benchmark of the rollout Transformer at the reference's CLEVRER training shape
+(slotformer_clevrer_params.py: 6 burn-in + 10 rollout frames, 7 slots, d_model 256, 4 layers, dropout 0.1, Adam 2e-4,
+batch 32 per GPU), slot-reconstruction loss only.
+
+  python tools/bench_train.py [--batch 32] [--steps 20] [--warmup 3] [--eager] [--cpu]
+
+Prints one JSON line: iterations/s and ms per iteration of the HIP path (forward + loss + backward + Adam step);
+--eager adds the same step written the reference's way (torch autograd over nn.TransformerEncoder calls on the ROCm
+PyTorch build, slotformer.py:110-124) on the same GPU, --cpu the oracle under autograd on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import torch  # noqa: E402
+
+import golden_util as gu  # noqa: E402
+
+
+def build(dev, S):
+    from slotformer_amd.base_slots import build_model as bb
+    from slotformer_amd.video_prediction import build_model as bv
+    cfg = {**gu.C2_ROLL, 'loss_dict': dict(rollout_len=S, use_img_recon_loss=False)}
+    scfg = gu.savi_cfg(64, 7)
+    scfg['dec_dict'] = {k: v for k, v in cfg['dec_dict'].items() if k != 'dec_ckp_path'}
+    torch.manual_seed(0)
+    savi = bb(gu.ParamsView(scfg))
+    path = os.path.join(tempfile.mkdtemp(), 'savi.pth')
+    torch.save({'state_dict': savi.state_dict()}, path)
+    full = {k: (dict(v) if isinstance(v, dict) else v) for k, v in cfg.items()}
+    full['dec_dict']['dec_ckp_path'] = path
+    return bv(gu.ParamsView(full)).to(dev).train(), cfg
+
+
+def eager_rollout(r, x, pred_len):
+    """The reference's formulation (slotformer.py:85-126) on torch's own ROCm kernels."""
+    B, N = x.shape[0], x.shape[2]
+    in_x = x.flatten(1, 2)
+    pe = r.enc_t_pe.unsqueeze(2).repeat(B, 1, N, 1).flatten(1, 2)
+    out = []
+    for _ in range(pred_len):
+        h = r.transformer_encoder(r.in_proj(in_x) + pe)
+        pred = r.out_proj(h[:, -N:])
+        out.append(pred)
+        in_x = torch.cat([in_x[:, N:], pred], dim=1)
+    return torch.stack(out, 1)
+
+
+def time_loop(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--rollout', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--eager', action='store_true')
+    ap.add_argument('--cpu', action='store_true')
+    ap.add_argument('--phases', action='store_true')
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    S, B = a.rollout, a.batch
+    m, cfg = build(dev, S)
+    slots = (0.5 * gu.seeded_normal((B, 6 + S, 7, 128), 1)).to(dev)
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=2e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = m({'slots': slots})
+        loss = m.calc_train_loss({'slots': slots}, out)['slot_recon_loss']
+        loss.backward()
+        opt.step()
+        return loss
+
+    ms = time_loop(step, a.steps, a.warmup)
+    res = {'metric': 'slotformer_training_iterations_per_sec', 'value': round(1e3 / ms, 2), 'unit': 'it/s', 'ms_per_iter': round(ms, 3),
+           'frames_per_sec': round(B * (6 + S) * 1e3 / ms, 1),
+           'config': {'workload': f'SlotFormer CLEVRER training step, B={B}, 6+{S} frames, 7 slots, d=256, 4 layers, '
+                                  'dropout 0.1, slot loss, Adam', 'dtype': 'f32 (split-bf16 MFMA)'}}
+    if a.phases:
+        def fwd():
+            with torch.no_grad():
+                pass
+            return m({'slots': slots})
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        opt.zero_grad(set_to_none=True)
+        ev[0].record()
+        out = m({'slots': slots})
+        ev[1].record()
+        loss = m.calc_train_loss({'slots': slots}, out)['slot_recon_loss']
+        loss.backward()
+        ev[2].record()
+        opt.step()
+        ev[3].record()
+        torch.cuda.synchronize()
+        res['phases_ms'] = {'forward': round(ev[0].elapsed_time(ev[1]), 3), 'loss_backward': round(ev[1].elapsed_time(ev[2]), 3),
+                            'adam': round(ev[2].elapsed_time(ev[3]), 3)}
+    if a.eager:
+        r = m.rollouter
+
+        def estep():
+            opt.zero_grad(set_to_none=True)
+            pred = eager_rollout(r, slots[:, :6], S)
+            loss = ((pred - slots[:, 6:])**2).mean()
+            loss.backward()
+            opt.step()
+
+        ems = time_loop(estep, a.steps, a.warmup)
+        res['torch_eager_same_gpu'] = {'ms_per_iter': round(ems, 3), 'speedup': round(ems / ms, 2)}
+    if a.cpu:
+        import oracle
+        sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and 'rollouter' in k and 'enc_t_pe' not in k)
+              for k, v in m.state_dict().items()}
+        xs = slots.cpu()
+        torch.set_num_threads(min(16, os.cpu_count()))
+        t0 = time.perf_counter()
+        n = 0
+        while n < 1:
+            pred = oracle.rollouter_forward(xs[:, :6], S, sd, cfg['rollout_dict'])
+            ((pred - xs[:, 6:])**2).mean().backward()
+            n += 1
+        cms = (time.perf_counter() - t0) / n * 1e3
+        res['cpu_oracle_autograd'] = {'ms_per_iter': round(cms, 1), 'cores': min(16, os.cpu_count()), 'note': 'no dropout, no optimizer'}
+    print(json.dumps(res))
+
+
+if __name__ == '__main__':
+    main()
