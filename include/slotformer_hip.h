@@ -91,6 +91,16 @@ int sf_slot_attn_iter_f32(const float* k, const float* v, int ld, long long batc
                           float* part_num, float* part_den, float* attn_out, int B, int HW, int N, int D,
                           float scale, float eps, void* stream);
 
+/* Backward of sf_slot_attn_iter_f32 (row N1: savi.py:82-94 under autograd).  Inputs of the forward call (k, v, q, the
+ * partial records it produced) plus d_updates [B,N,D], the gradient w.r.t. updates = sum(num) / sum(den).  Writes
+ * dq [B,N,D] and dk / dv (same row layout as k / v); accumulate != 0 adds into dk / dv instead (the iterations of one
+ * frame share k and v).  slot_size 64 or 128, at most 8 slots. */
+size_t sf_slot_attn_iter_bwd_workspace_bytes(int B, int HW, int N, int D);
+int sf_slot_attn_iter_bwd_f32(const float* k, const float* v, int ld, long long batch_stride, const float* q,
+                              const float* part_num, const float* part_den, int P, const float* d_updates, float* dk,
+                              float* dv, int accumulate, float* dq, int B, int HW, int N, int D, float scale, float eps,
+                              void* ws, size_t ws_bytes, void* stream);
+
 /* Slot update (savi.py:95-100): updates = sum(num)/sum(den); GRUCell (r,z,n); slots + MLP(LN(slots)).
  * The four weight MATRICES are passed transposed ([in,out] = torch weight.t().contiguous()):
  * gru_w_ih [D,3D], gru_w_hh [D,3D], mlp_w1 [D,H], mlp_w2 [H,D]; biases / LN vectors as in torch. */

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 __all__ = [
     'build_grid', 'get_sin_pos_enc', 'layer_norm', 'gru_cell', 'lstm_cell',
     'mha_self', 'transformer_encoder_layer', 'transformer_encoder',
-    'savi_encoder_out', 'slot_attention', 'predictor_step', 'kernel_dist',
+    'savi_encoder_out', 'slot_attention', 'slot_attention_updates', 'slot_update', 'predictor_step', 'kernel_dist',
     'sample_dist', 'savi_encode', 'steve_encode', 'savi_forward_chunked',
     'rollouter_forward', 'rollouter_forward_train', 'single_step_rollouter_forward', 'slotformer_forward',
     'savi_decode', 'postproc_mask', 'rollout_video_slots', 'phyre_encode_rollout',
@@ -177,6 +177,25 @@ def slot_attention(inputs, slots, sd, num_iterations, eps=1e-6, p='slot_attentio
     if return_mask:
         return slots, mask
     return slots
+
+
+def slot_attention_updates(k, v, q, eps=1e-6):
+    """The attention half of one iteration (savi.py:82-94): k, v [B,HW,D], q [B,N,D] -> updates [B,N,D].  Under
+    autograd this is the gradient oracle of sf_slot_attn_iter_bwd_f32."""
+    logits = q.shape[-1]**-0.5 * torch.einsum('bnc,bmc->bnm', k, q)
+    attn = torch.softmax(logits, dim=-1) + eps
+    attn = attn / attn.sum(dim=1, keepdim=True)
+    return torch.einsum('bnm,bnc->bmc', attn, v)
+
+
+def slot_update(updates, prev, sd, p='slot_attention.'):
+    """The update half (savi.py:95-100): GRUCell then residual LayerNorm-MLP.  updates, prev [B,N,D] -> slots."""
+    g = lambda k: sd[p + k]  # noqa: E731
+    B, N, D = prev.shape
+    h = gru_cell(updates.reshape(B * N, D), prev.reshape(B * N, D), g('gru.weight_ih'), g('gru.weight_hh'), g('gru.bias_ih'),
+                 g('gru.bias_hh')).view(B, N, D)
+    m = layer_norm(h, g('mlp.0.weight'), g('mlp.0.bias'))
+    return h + F.linear(F.relu(F.linear(m, g('mlp.1.weight'), g('mlp.1.bias'))), g('mlp.3.weight'), g('mlp.3.bias'))
 
 
 # ---------------------------------------------------------------------------

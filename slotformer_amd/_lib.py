@@ -109,6 +109,8 @@ SIGNATURES = {
     'sf_bilinear_resize_f32': (I, [FP, FP, LL, I, I, I, I, VP]),
     'sf_rollout_workspace_bytes': (SZ, [C.POINTER(sf_rollouter), I]),
     'sf_rollout_f32': (I, [C.POINTER(sf_rollouter), FP, I, I, I, VP, SZ, VP]),
+    'sf_slot_attn_iter_bwd_workspace_bytes': (SZ, [I, I, I, I]),
+    'sf_slot_attn_iter_bwd_f32': (I, [FP, FP, I, LL, FP, FP, FP, I, FP, FP, FP, I, FP, I, I, I, I, F32, F32, VP, SZ, VP]),
     'sf_rollout_train_workspace_bytes': (SZ, [C.POINTER(sf_rollouter), I, I]),
     'sf_rollout_train_fwd_f32': (I, [C.POINTER(sf_rollouter), FP, FP, I, I, F32, C.c_ulonglong, VP, SZ, VP]),
     'sf_rollout_train_bwd_f32': (I, [C.POINTER(sf_rollouter), FP, FP, C.POINTER(sf_rollouter_grads), I, I, F32,

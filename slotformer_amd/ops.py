@@ -122,6 +122,23 @@ def slot_attn_iter(k, v, q, eps=1e-6, want_attn=False):
     return pn, pd, attn
 
 
+def slot_attn_iter_bwd(k, v, q, pn, pd, d_updates, dk=None, dv=None, eps=1e-6):
+    """Backward of slot_attn_iter: gradient d_updates [B,N,D] of updates = sum(pn) / sum(pd) -> (dq, dk, dv).  Passing
+    dk / dv accumulates into them (the iterations of a frame share k and v)."""
+    _chk(k, v, q, pn, pd, d_updates)
+    B, HW, D = k.shape
+    N, P = q.shape[1], pn.shape[1]
+    acc = dk is not None
+    if not acc:
+        dk, dv = torch.empty_like(k), torch.empty_like(v)
+    dq = torch.empty_like(q)
+    nb = lib().sf_slot_attn_iter_bwd_workspace_bytes(B, HW, N, D)
+    ws = torch.empty(nb, dtype=torch.uint8, device=k.device)
+    check(lib().sf_slot_attn_iter_bwd_f32(_p(k), _p(v), D, HW * D, _p(q), _p(pn), _p(pd), P, _p(d_updates), _p(dk), _p(dv),
+                                          int(acc), _p(dq), B, HW, N, D, float(D)**-0.5, eps, ws.data_ptr(), nb, _stream()))
+    return dq, dk, dv
+
+
 def slot_update(pn, pd, slots_prev, gru, ln_g, ln_b, w1, b1, w2, b2, ln_eps=1e-5):
     """gru = (w_ih, w_hh, b_ih, b_hh); all weights in torch layout (transposed here for the kernel)."""
     _chk(pn, pd, slots_prev, *gru, ln_g, ln_b, w1, b1, w2, b2)

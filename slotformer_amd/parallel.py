@@ -75,3 +75,15 @@ def allreduce_flat_bucket(params, average=True):
         g.copy_(flat[off:off + n].view_as(g))
         off += n
     return flat.numel() * 4
+
+
+def allreduce_flat(flat, average=True):
+    """In-place all-reduce of a gradient bucket that is ALREADY flat (the rollout training path writes every parameter
+    gradient into one fp32 tensor, train.py): one RCCL call, no pack / unpack.  Returns the bytes reduced (0 when not
+    running distributed)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= dist.get_world_size()
+    return flat.numel() * flat.element_size()

@@ -11,10 +11,9 @@ Dropout follows nn.TransformerEncoderLayer: active iff the module is in train() 
 import ctypes as C
 
 import torch
-import torch.distributed as dist
 
 from ._lib import lib, check, sf_rollouter_grads, sf_tfm_layer_grads
-from . import engine
+from . import engine, parallel
 
 _LAYER_LEAVES = ('norm1.weight', 'norm1.bias', 'self_attn.in_proj_weight', 'self_attn.in_proj_bias',
                  'self_attn.out_proj.weight', 'self_attn.out_proj.bias', 'norm2.weight', 'norm2.bias', 'linear1.weight',
@@ -95,10 +94,9 @@ class _Rollout(torch.autograd.Function):
                                              torch.cuda.current_stream().cuda_stream))
         del keep
         ctx.ws = None
-        if getattr(r, 'ddp_flat_bucket', False) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if getattr(r, 'ddp_flat_bucket', False):
             # data-parallel training (config C3): ONE all-reduce of the whole bucket over RCCL / xGMI, averaged
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat /= dist.get_world_size()
+            parallel.allreduce_flat(flat)
         r.last_grad_bucket = flat
         grads = _split(flat, params)
         return (None, d_x, None, None, None) + tuple(g_ if ctx.needs_input_grad[5 + i] else None for i, g_ in enumerate(grads))

@@ -34,6 +34,14 @@ def _worker(rank, world, port, q):
     nbytes = allreduce_flat_bucket(ps)
     assert nbytes == 17 * 4 and ps[2].grad is None
     assert torch.allclose(ps[0].grad, torch.full((3, 4), 1.5)) and torch.allclose(ps[1].grad, torch.full((5, ), 1.5))
+    # the training path's bucket is born flat: views of it are the per-parameter gradients
+    from slotformer_amd.parallel import allreduce_flat
+    from slotformer_amd.train import _split
+    flat = torch.arange(17, dtype=torch.float32) * (rank + 1)
+    views = _split(flat, ps[:2])
+    assert allreduce_flat(flat) == 17 * 4
+    assert torch.allclose(flat, torch.arange(17, dtype=torch.float32) * 1.5)
+    assert views[0].shape == (3, 4) and torch.allclose(views[1], torch.arange(12, 17, dtype=torch.float32) * 1.5)
     dist.barrier()
     if rank == 0:
         q.put((full.tolist(), t))

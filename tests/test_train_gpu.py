@@ -153,3 +153,25 @@ def test_training_step_reduces_loss(dev):
     new_sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     ref = oracle.rollouter_forward(slots[:, :6].cpu(), S, new_sd, cfg['rollout_dict'])
     assert rel_err(pred, ref) < 1e-3
+
+
+@pytest.mark.parametrize('B,HW,N,D', [(3, 4096, 7, 128), (2, 4096, 6, 128), (2, 1024, 4, 64), (1, 4096, 8, 128)])
+def test_slot_attention_iteration_backward(dev, B, HW, N, D):
+    """sf_slot_attn_iter_bwd_f32 against autograd of the oracle's attention half (savi.py:82-94)."""
+    from slotformer_amd import ops
+    k = gu.seeded_normal((B, HW, D), 11)
+    v = gu.seeded_normal((B, HW, D), 12)
+    q = 2.0 * gu.seeded_normal((B, N, D), 13)
+    du = gu.seeded_normal((B, N, D), 14)
+    kk, vv, qq = (t.clone().requires_grad_(True) for t in (k, v, q))
+    upd = oracle.slot_attention_updates(kk, vv, qq)
+    upd.backward(du)
+    pn, pd, _ = ops.slot_attn_iter(k.to(dev), v.to(dev), q.to(dev))
+    assert rel_err(pn.sum(1) / pd.sum(1).unsqueeze(-1), upd) < 1e-4
+    dq, dk, dv = ops.slot_attn_iter_bwd(k.to(dev), v.to(dev), q.to(dev), pn, pd, du.to(dev))
+    assert rel_err(dq, qq.grad) < 1e-4
+    assert rel_err(dk, kk.grad) < 1e-4
+    assert rel_err(dv, vv.grad) < 1e-4
+    # second iteration of the same frame: gradients accumulate into dk / dv
+    dq2, dk2, dv2 = ops.slot_attn_iter_bwd(k.to(dev), v.to(dev), q.to(dev), pn, pd, du.to(dev), dk=dk.clone(), dv=dv.clone())
+    assert rel_err(dk2, 2 * kk.grad) < 1e-4 and rel_err(dv2, 2 * vv.grad) < 1e-4 and rel_err(dq2, qq.grad) < 1e-4
