@@ -230,6 +230,33 @@ size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B);
 int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws,
                    size_t ws_bytes, void* stream);
 
+/* ---- training of the Slot-Attention module ------------------------------------------------
+ * SlotAttention (savi.py:36-102) under autograd: parameters in torch layouts, gradients with the same shapes (written,
+ * not accumulated).  The forward keeps its activations in the caller's workspace for the backward call.
+ * slot_size 64 / 128, in_features and mlp_hidden multiples of 64, at most 8 slots and 8 iterations. */
+typedef struct {
+  int in_features, slot_size, mlp_hidden, num_slots;
+  const float *norm_in_g, *norm_in_b, *wk, *wv;                  /* norm_inputs, project_k / project_v [D, in] */
+  const float *q_ln_g, *q_ln_b, *wq;                             /* project_q = LayerNorm + Linear [D, D] */
+  const float *gru_w_ih, *gru_w_hh, *gru_b_ih, *gru_b_hh;        /* nn.GRUCell [3D, D] x2, [3D] x2 */
+  const float *mlp_ln_g, *mlp_ln_b, *mlp_w1, *mlp_b1, *mlp_w2, *mlp_b2;
+  float eps;
+} sf_slot_attention;
+
+typedef struct {
+  float *norm_in_g, *norm_in_b, *wk, *wv, *q_ln_g, *q_ln_b, *wq, *gru_w_ih, *gru_w_hh, *gru_b_ih, *gru_b_hh;
+  float *mlp_ln_g, *mlp_ln_b, *mlp_w1, *mlp_b1, *mlp_w2, *mlp_b2;
+} sf_slot_attention_grads;
+
+size_t sf_slot_attention_train_workspace_bytes(const sf_slot_attention* m, int B, int HW, int iters);
+/* inputs [B, HW, in_features], slots_in [B, N, D] -> slots_out [B, N, D] after `iters` iterations */
+int sf_slot_attention_train_fwd_f32(const sf_slot_attention* m, const float* inputs, const float* slots_in, int B, int HW,
+                                    int iters, float* slots_out, void* ws, size_t ws_bytes, void* stream);
+/* d_slots_out [B, N, D] -> d_slots_in, parameter gradients and (if d_inputs != NULL) d_inputs [B, HW, in_features] */
+int sf_slot_attention_train_bwd_f32(const sf_slot_attention* m, const float* inputs, const float* d_slots_out, float* d_inputs,
+                                    float* d_slots_in, const sf_slot_attention_grads* g, int B, int HW, int iters, void* ws,
+                                    size_t ws_bytes, void* stream);
+
 /* ---- training of the rollout Transformer ------------------------------------
  * SlotFormer.forward in train mode (slotformer.py:263-282) -> SlotRollouter.forward (:85-126) under autograd, i.e. what
  * `loss.backward()` of calc_train_loss (:284-318) differentiates.  The forward keeps every activation of every rollout

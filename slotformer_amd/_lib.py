@@ -37,6 +37,19 @@ class sf_rollouter_grads(C.Structure):
         ('layers', C.POINTER(sf_tfm_layer_grads))]
 
 
+_SA_LEAVES = ('norm_in_g', 'norm_in_b', 'wk', 'wv', 'q_ln_g', 'q_ln_b', 'wq', 'gru_w_ih', 'gru_w_hh', 'gru_b_ih', 'gru_b_hh',
+              'mlp_ln_g', 'mlp_ln_b', 'mlp_w1', 'mlp_b1', 'mlp_w2', 'mlp_b2')
+
+
+class sf_slot_attention(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('in_features', 'slot_size', 'mlp_hidden', 'num_slots')] + [
+        (n, FP) for n in _SA_LEAVES] + [('eps', C.c_float)]
+
+
+class sf_slot_attention_grads(C.Structure):
+    _fields_ = [(n, FP) for n in _SA_LEAVES]
+
+
 class sf_savi_encoder(C.Structure):
     _fields_ = (
         [('resolution', C.c_int), ('enc_layers', C.c_int), ('enc_channels', C.c_int * 9),
@@ -111,6 +124,10 @@ SIGNATURES = {
     'sf_rollout_f32': (I, [C.POINTER(sf_rollouter), FP, I, I, I, VP, SZ, VP]),
     'sf_slot_attn_iter_bwd_workspace_bytes': (SZ, [I, I, I, I]),
     'sf_slot_attn_iter_bwd_f32': (I, [FP, FP, I, LL, FP, FP, FP, I, FP, FP, FP, I, FP, I, I, I, I, F32, F32, VP, SZ, VP]),
+    'sf_slot_attention_train_workspace_bytes': (SZ, [C.POINTER(sf_slot_attention), I, I, I]),
+    'sf_slot_attention_train_fwd_f32': (I, [C.POINTER(sf_slot_attention), FP, FP, I, I, I, FP, VP, SZ, VP]),
+    'sf_slot_attention_train_bwd_f32': (I, [C.POINTER(sf_slot_attention), FP, FP, FP, FP, C.POINTER(sf_slot_attention_grads), I, I, I,
+                                            VP, SZ, VP]),
     'sf_rollout_train_workspace_bytes': (SZ, [C.POINTER(sf_rollouter), I, I]),
     'sf_rollout_train_fwd_f32': (I, [C.POINTER(sf_rollouter), FP, FP, I, I, F32, C.c_ulonglong, VP, SZ, VP]),
     'sf_rollout_train_bwd_f32': (I, [C.POINTER(sf_rollouter), FP, FP, C.POINTER(sf_rollouter_grads), I, I, F32,

@@ -68,6 +68,10 @@ class SlotAttention(nn.Module):
         return slots, mask
 
     def forward(self, inputs, slots):
+        if torch.is_grad_enabled() and (inputs.requires_grad or slots.requires_grad or
+                                        any(p.requires_grad for p in self.parameters())):
+            from ... import train
+            return train.slot_attention_with_grad(self, inputs, slots)   # one autograd node (row N1)
         return self._run(inputs, slots, False)[0]
 
     @property

@@ -1014,6 +1014,44 @@ int grad_ln(const float* x, const float* dy, float* dgamma, float* dbeta, long l
 
 }  // namespace
 
+// ---- the same building blocks for the other training nodes (slot_attn_train.hip); declared in sf_internal.h ----
+size_t sf_grad_partial_floats(long long rows, int N, int K) {
+  const size_t a = (size_t)tn_splits(rows, N, K) * N * K;
+  const size_t b = (size_t)513 * 2 * (size_t)(N > K ? N : K);   // column-sum / LayerNorm partials
+  return a > b ? a : b;
+}
+int sf_grad_weight_ex(const float* Y, const float* X, float* dW, long long rows, int N, int K, float* partial, hipStream_t st) {
+  SF_REQUIRE(N % 64 == 0 && K % 64 == 0, "weight-gradient contraction needs multiples of 64");
+  Ws w;
+  w.partial = partial;
+  return grad_weight(Y, X, dW, rows, N, K, w, st);
+}
+int sf_grad_bias_ex(const float* Y, float* db, long long rows, int n, float* partial, hipStream_t st) {
+  Ws w;
+  w.partial = partial;
+  return grad_bias(Y, db, rows, n, w, st);
+}
+int sf_grad_ln_ex(const float* x, const float* dy, float* dgamma, float* dbeta, long long rows, int D, float eps, float* partial,
+                  hipStream_t st) {
+  Ws w;
+  w.partial = partial;
+  return grad_ln(x, dy, dgamma, dbeta, rows, D, eps, w, st);
+}
+int sf_ln_bwd_ex(const float* x, const float* dy, const float* gamma, const float* dres, float* out, long long rows, int D,
+                 float eps, hipStream_t st) {
+  SF_REQUIRE(D % 4 == 0 && D <= 1024, "LayerNorm width");
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, dy, gamma, dres, out, (float*)nullptr, 0u, 0u, 1.f,
+                     (int)rows, D, eps);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+int sf_transpose_ex(const float* in, float* out, int R, int Cn, hipStream_t st) { return launch_transpose(in, out, R, Cn, st); }
+int sf_relu_bwd_ex(float* dh, const float* h, long long n, hipStream_t st) {
+  hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, dh, h, n / 4, 1.f);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" {
 
 size_t sf_rollout_train_workspace_bytes(const sf_rollouter* m, int B, int pred_len) {

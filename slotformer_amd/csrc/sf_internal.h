@@ -40,3 +40,14 @@ int sf_pixel_mlp_kv_ex(const float* x, const float* ln0_g, const float* ln0_b, c
 bool sf_layer_fused_ok(int d, int heads, int ffn, int L);
 int sf_conv_first_ex(const float* img, long long frame_stride, const float* w, const float* bias, const float* add,
                      float* out, int F, int Cin, int Hin, int Win, int Cout, int ks, int stride, int relu, hipStream_t st);
+
+// training building blocks (rollout_train.hip), shared with slot_attn_train.hip
+size_t sf_grad_partial_floats(long long rows, int N, int K);
+int sf_grad_weight_ex(const float* Y, const float* X, float* dW, long long rows, int N, int K, float* partial, hipStream_t st);
+int sf_grad_bias_ex(const float* Y, float* db, long long rows, int n, float* partial, hipStream_t st);
+int sf_grad_ln_ex(const float* x, const float* dy, float* dgamma, float* dbeta, long long rows, int D, float eps, float* partial,
+                  hipStream_t st);
+int sf_ln_bwd_ex(const float* x, const float* dy, const float* gamma, const float* dres, float* out, long long rows, int D,
+                 float eps, hipStream_t st);
+int sf_transpose_ex(const float* in, float* out, int R, int Cn, hipStream_t st);
+int sf_relu_bwd_ex(float* dh, const float* h, long long n, hipStream_t st);

@@ -12,7 +12,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import lib, check, sf_rollouter_grads, sf_tfm_layer_grads
+from ._lib import lib, check, sf_rollouter_grads, sf_tfm_layer_grads, sf_slot_attention, sf_slot_attention_grads, _SA_LEAVES
 from . import engine, parallel
 
 _LAYER_LEAVES = ('norm1.weight', 'norm1.bias', 'self_attn.in_proj_weight', 'self_attn.in_proj_bias',
@@ -109,6 +109,71 @@ def rollout_with_grad(r, x, pred_len):
     seed = int(torch.randint(0, 2**62, (1, )).item()) if p_drop > 0 else 0
     seed = getattr(r, 'dropout_seed_override', None) or seed
     return _Rollout.apply(r, x, pred_len, p_drop, seed, *rollouter_parameters(r))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Slot Attention (savi.py:36-102) under autograd
+# ---------------------------------------------------------------------------------------------------------------------
+def slot_attention_parameters(sa):
+    """Leaves of a SlotAttention container in the order of sf_slot_attention's pointer fields."""
+    return [sa.norm_inputs.weight, sa.norm_inputs.bias, sa.project_k.weight, sa.project_v.weight, sa.project_q[0].weight,
+            sa.project_q[0].bias, sa.project_q[1].weight, sa.gru.weight_ih, sa.gru.weight_hh, sa.gru.bias_ih, sa.gru.bias_hh,
+            sa.mlp[0].weight, sa.mlp[0].bias, sa.mlp[1].weight, sa.mlp[1].bias, sa.mlp[3].weight, sa.mlp[3].bias]
+
+
+class _SlotAttention(torch.autograd.Function):
+    """slots_out = SlotAttention(inputs, slots) as a single autograd node."""
+
+    @staticmethod
+    def forward(ctx, sa, inputs, slots, *params):
+        inputs, slots = inputs.detach().float().contiguous(), slots.detach().float().contiguous()
+        if not inputs.is_cuda:
+            raise RuntimeError('slotformer_amd: inputs must live on a HIP device; there is no CPU fallback')
+        keep = [p.detach().float().contiguous() for p in params]
+        m = sf_slot_attention()
+        m.in_features, m.slot_size, m.mlp_hidden, m.num_slots = sa.in_features, sa.slot_size, sa.mlp_hidden_size, slots.shape[1]
+        m.eps = float(sa.eps)
+        for name, t in zip(_SA_LEAVES, keep):
+            setattr(m, name, t.data_ptr())
+        B, HW = inputs.shape[:2]
+        nbytes = lib().sf_slot_attention_train_workspace_bytes(C.byref(m), B, HW, sa.num_iterations)
+        if nbytes == 0:
+            check(-1)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=inputs.device)
+        out = torch.empty_like(slots)
+        check(lib().sf_slot_attention_train_fwd_f32(C.byref(m), inputs.data_ptr(), slots.data_ptr(), B, HW, sa.num_iterations,
+                                                    out.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+        ctx.sa, ctx.m, ctx.keep, ctx.ws, ctx.inputs, ctx.params = sa, m, keep, ws, inputs, params
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        sa, m, params, inputs = ctx.sa, ctx.m, ctx.params, ctx.inputs
+        d_out = d_out.float().contiguous()
+        B, HW = inputs.shape[:2]
+        flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=d_out.device)
+        g, off = sf_slot_attention_grads(), 0
+        for name, p in zip(_SA_LEAVES, params):
+            setattr(g, name, flat.data_ptr() + 4 * off)
+            off += p.numel()
+        d_in = torch.empty_like(inputs) if ctx.needs_input_grad[1] else None
+        d_slots = torch.empty_like(d_out)
+        check(lib().sf_slot_attention_train_bwd_f32(C.byref(m), inputs.data_ptr(), d_out.data_ptr(),
+                                                    d_in.data_ptr() if d_in is not None else None, d_slots.data_ptr(), C.byref(g), B, HW,
+                                                    sa.num_iterations, ctx.ws.data_ptr(), ctx.ws.numel(),
+                                                    torch.cuda.current_stream().cuda_stream))
+        ctx.ws = None
+        if getattr(sa, 'ddp_flat_bucket', False):
+            parallel.allreduce_flat(flat)
+        sa.last_grad_bucket = flat
+        grads = _split(flat, params)
+        return (None, d_in, d_slots if ctx.needs_input_grad[2] else None) + tuple(
+            g_ if ctx.needs_input_grad[3 + i] else None for i, g_ in enumerate(grads))
+
+
+def slot_attention_with_grad(sa, inputs, slots):
+    """SlotAttention.forward under autograd (savi.py:56-102): inputs [B,HW,C], slots [B,N,D] -> slots [B,N,D]."""
+    return _SlotAttention.apply(sa, inputs, slots, *slot_attention_parameters(sa))
 
 
 def dropout_keep_mask(seed, step, layer, site, numel, p):

@@ -175,3 +175,43 @@ def test_slot_attention_iteration_backward(dev, B, HW, N, D):
     # second iteration of the same frame: gradients accumulate into dk / dv
     dq2, dk2, dv2 = ops.slot_attn_iter_bwd(k.to(dev), v.to(dev), q.to(dev), pn, pd, du.to(dev), dk=dk.clone(), dv=dv.clone())
     assert rel_err(dk2, 2 * kk.grad) < 1e-4 and rel_err(dv2, 2 * vv.grad) < 1e-4 and rel_err(dq2, qq.grad) < 1e-4
+
+
+@pytest.mark.parametrize('B,HW,N,D,Cin,H,iters', [(3, 4096, 7, 128, 128, 256, 2), (2, 1024, 4, 64, 64, 128, 3)])
+def test_slot_attention_module_backward(dev, precision, B, HW, N, D, Cin, H, iters):
+    """SlotAttention.forward under autograd (savi.py:56-102: LN + k/v projection, `iters` x [q projection, attention,
+    GRUCell, residual MLP]) against autograd of the oracle: output, gradients of all 17 parameter leaves, of the input
+    features and of the initial slots."""
+    from slotformer_amd.base_slots.models.savi import SlotAttention
+    torch.manual_seed(5)
+    sa = SlotAttention(Cin, iters, N, D, H).to(dev)
+    with torch.no_grad():
+        for p in sa.parameters():   # well away from the default LayerNorm (1, 0) so that every gradient path is exercised
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    x = gu.seeded_normal((B, HW, Cin), 21)
+    s0 = gu.seeded_normal((B, N, D), 22)
+    dout = gu.seeded_normal((B, N, D), 23)
+    sd = {'slot_attention.' + k: v.detach().cpu().clone().requires_grad_(True) for k, v in sa.state_dict().items()}
+    xo, so = x.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+    ref = oracle.slot_attention(xo, so, sd, iters)
+    ref.backward(dout)
+    xg, sg = x.to(dev).requires_grad_(True), s0.to(dev).requires_grad_(True)
+    out = sa(xg, sg)
+    out.backward(dout.to(dev))
+    assert rel_err(out, ref) < 1e-4
+    tol = L2TOL[precision]
+    for name, p in sa.named_parameters():
+        assert p.grad is not None, name
+        ref_g = sd['slot_attention.' + name].grad
+        if name == 'project_q.0.bias':
+            # a bias on LN_q shifts every slot's logits of a pixel by the same amount: the softmax over slots, hence the
+            # loss, does not depend on it -- both gradients are rounding noise around zero
+            assert ref_g.abs().max() < 1e-5 and p.grad.abs().max() < 1e-5
+            continue
+        assert l2_err(p.grad, ref_g) < tol, name
+    assert l2_err(sg.grad, so.grad) < tol
+    assert l2_err(xg.grad, xo.grad) < tol
+    # inference path unchanged and equal to the training forward
+    with torch.no_grad():
+        assert rel_err(sa(xg.detach(), sg.detach()), ref) < 1e-4
