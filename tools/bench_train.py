@@ -2,11 +2,11 @@
 (slotformer_clevrer_params.py: 6 burn-in + 10 rollout frames, 7 slots, d_model 256, 4 layers, dropout 0.1, Adam 2e-4,
 batch 32 per GPU), slot-reconstruction loss only.
 
-  python tools/bench_train.py [--batch 32] [--steps 20] [--warmup 3] [--eager] [--cpu]
+  python tools/bench_train.py [--batch 32] [--steps 20] [--warmup 3] [--eager] [--phases]
 
 Prints one JSON line: iterations/s and ms per iteration of the HIP path (forward + loss + backward + Adam step);
 --eager adds the same step written the reference's way (torch autograd over nn.TransformerEncoder calls on the ROCm
-PyTorch build, slotformer.py:110-124) on the same GPU, --cpu the oracle under autograd on the host cores.
+PyTorch build, slotformer.py:110-124) on the same GPU.
 """
 import argparse
 import json
@@ -71,7 +71,6 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--eager', action='store_true')
-    ap.add_argument('--cpu', action='store_true')
     ap.add_argument('--phases', action='store_true')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -124,20 +123,6 @@ def main():
 
         ems = time_loop(estep, a.steps, a.warmup)
         res['torch_eager_same_gpu'] = {'ms_per_iter': round(ems, 3), 'speedup': round(ems / ms, 2)}
-    if a.cpu:
-        import oracle
-        sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and 'rollouter' in k and 'enc_t_pe' not in k)
-              for k, v in m.state_dict().items()}
-        xs = slots.cpu()
-        torch.set_num_threads(min(16, os.cpu_count()))
-        t0 = time.perf_counter()
-        n = 0
-        while n < 1:
-            pred = oracle.rollouter_forward(xs[:, :6], S, sd, cfg['rollout_dict'])
-            ((pred - xs[:, 6:])**2).mean().backward()
-            n += 1
-        cms = (time.perf_counter() - t0) / n * 1e3
-        res['cpu_oracle_autograd'] = {'ms_per_iter': round(cms, 1), 'cores': min(16, os.cpu_count()), 'note': 'no dropout, no optimizer'}
     print(json.dumps(res))
 
 

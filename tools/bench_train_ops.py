@@ -1,5 +1,7 @@
 """Device time of the training-side kernels outside the rollout (row N1): Slot-Attention iteration backward at the CLEVRER
-encode shape (32 videos x 6 frames, 4096 pixels, 7 slots, D = 128) against its HBM roofline (read K, V; write dK, dV)."""
+encode shape (32 videos x 6 frames, 4096 pixels, 7 slots, D = 128) against its HBM roofline (read K, V; write dK, dV), and
+the whole SlotAttention module forward + backward next to the same step in torch eager (the reference's formulation,
+savi.py:56-102, on the ROCm PyTorch build of the same GPU)."""
 import json
 import os
 import sys
@@ -25,6 +27,42 @@ def timeit(fn, iters=20):
     return a.elapsed_time(b) / iters
 
 
+def eager_slot_attention(sa, inputs, slots):
+    """savi.py:56-102 with torch ops on the module's own parameters."""
+    import torch.nn.functional as F
+    x = sa.norm_inputs(inputs)
+    k, v = sa.project_k(x), sa.project_v(x)
+    B, N, D = slots.shape
+    for _ in range(sa.num_iterations):
+        prev = slots
+        q = sa.project_q(slots)
+        attn = F.softmax(sa.attn_scale * torch.einsum('bnc,bmc->bnm', k, q), dim=-1) + sa.eps
+        attn = attn / attn.sum(dim=1, keepdim=True)
+        upd = torch.einsum('bnm,bnc->bmc', attn, v)
+        slots = sa.gru(upd.reshape(B * N, D), prev.reshape(B * N, D)).view(B, N, D)
+        slots = slots + sa.mlp(slots)
+    return slots
+
+
+def module_bench(F_, HW=4096, N=7, D=128, H=256, iters=2):
+    from slotformer_amd.base_slots.models.savi import SlotAttention
+    torch.manual_seed(0)
+    sa = SlotAttention(D, iters, N, D, H).to(dev)
+    x = torch.randn(F_, HW, D, device=dev, requires_grad=True)
+    s0 = torch.randn(F_, N, D, device=dev, requires_grad=True)
+    dout = torch.randn(F_, N, D, device=dev)
+
+    def ours():
+        sa(x, s0).backward(dout)
+
+    def eager():
+        eager_slot_attention(sa, x, s0).backward(dout)
+
+    t_ours, t_eager = timeit(ours, 10), timeit(eager, 10)
+    return {'frames': F_, 'iters': iters, 'hip_ms': round(t_ours, 3), 'torch_eager_ms': round(t_eager, 3),
+            'speedup': round(t_eager / t_ours, 2)}
+
+
 def main():
     B, HW, N, D = 192, 4096, 7, 128
     g = torch.Generator(device='cpu').manual_seed(0)
@@ -40,7 +78,8 @@ def main():
                       'sa_iter_fwd': {'ms': round(fwd, 4), 'GBps': round(kv / fwd / 1e6, 1), 'bytes': kv},
                       'sa_iter_bwd': {'ms': round(bwd, 4), 'GBps': round(2 * kv / bwd / 1e6, 1), 'bytes': 2 * kv},
                       'sa_iter_bwd_accumulate': {'ms': round(acc, 4), 'GBps': round(3 * kv / acc / 1e6, 1), 'bytes': 3 * kv},
-                      'hbm_peak_GBps': 8000}))
+                      'hbm_peak_GBps': 8000,
+                      'slot_attention_module_fwd_bwd': [module_bench(32), module_bench(192)]}))
 
 
 if __name__ == '__main__':
