@@ -351,6 +351,18 @@ size_t sf_savi_decode_workspace_bytes(const sf_savi_decoder* m, int F);
 int sf_savi_decode_f32(const sf_savi_decoder* m, const float* slots, float* recon_combined, float* recons,
                        float* masks, int F, void* ws, size_t ws_bytes, void* stream);
 
+/* Row N1: the same decoder under autograd, data gradient only (the image term of SlotFormer's training loss,
+ * slotformer.py:313-326; the decoder is frozen there).  The forward keeps every layer output in the workspace; the
+ * backward maps d_recon_combined [F,3,H,W] to d_slots [F,N,D].  deconv_w_bwd: HOST array [dec_layers] of device pointers
+ * to sf_pack_conv_weight_f32(torch ConvTranspose2d weight [Cin,Cout,k,k]) = [Cin][k][k][Cout]: the adjoint of a
+ * transposed convolution is a strided convolution with the same weights. */
+size_t sf_savi_decode_train_workspace_bytes(const sf_savi_decoder* m, int F);
+int sf_savi_decode_train_fwd_f32(const sf_savi_decoder* m, const float* slots, float* recon_combined, float* recons,
+                                 float* masks, int F, void* ws, size_t ws_bytes, void* stream);
+int sf_savi_decode_train_bwd_f32(const sf_savi_decoder* m, const float* const* deconv_w_bwd, const float* d_recon,
+                                 float* d_slots, int F, void* ws, size_t ws_bytes, void* stream);
+
+
 /* ---- K/V producer (SURVEY.md 8(b2) sf_kv_producer_*) ---------------------------------------- */
 /* encoder_out_layer (savi.py:245-250: LN -> Linear -> ReLU -> Linear) followed by Slot Attention's
  * norm_inputs + project_k / project_v (savi.py:66-70): feat [M,C0] channels-last CNN features (position

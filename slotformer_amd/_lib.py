@@ -128,6 +128,9 @@ SIGNATURES = {
     'sf_slot_attention_train_fwd_f32': (I, [C.POINTER(sf_slot_attention), FP, FP, I, I, I, FP, VP, SZ, VP]),
     'sf_slot_attention_train_bwd_f32': (I, [C.POINTER(sf_slot_attention), FP, FP, FP, FP, C.POINTER(sf_slot_attention_grads), I, I, I,
                                             VP, SZ, VP]),
+    'sf_savi_decode_train_workspace_bytes': (SZ, [C.POINTER(sf_savi_decoder), I]),
+    'sf_savi_decode_train_fwd_f32': (I, [C.POINTER(sf_savi_decoder), FP, FP, FP, FP, I, VP, SZ, VP]),
+    'sf_savi_decode_train_bwd_f32': (I, [C.POINTER(sf_savi_decoder), C.POINTER(C.c_void_p), FP, FP, I, VP, SZ, VP]),
     'sf_rollout_train_workspace_bytes': (SZ, [C.POINTER(sf_rollouter), I, I]),
     'sf_rollout_train_fwd_f32': (I, [C.POINTER(sf_rollouter), FP, FP, I, I, F32, C.c_ulonglong, VP, SZ, VP]),
     'sf_rollout_train_bwd_f32': (I, [C.POINTER(sf_rollouter), FP, FP, C.POINTER(sf_rollouter_grads), I, I, F32,

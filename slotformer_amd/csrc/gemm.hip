@@ -124,7 +124,8 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
       cf[i] = f;
       cy[i] = rem / p.cW;
       cx[i] = rem - cy[i] * p.cW;
-      if constexpr (ALOAD == ALOAD_CONV_NHWC) rowbase[i] = (long long)f * p.cFrameStride + (long long)rem * p.cCin;
+      if constexpr (ALOAD == ALOAD_CONV_NHWC)   // the row's centre pixel in the input: (cy, cx) * stride
+        rowbase[i] = (long long)f * p.cFrameStride + ((long long)(cy[i] * p.cStride) * p.cInW + cx[i] * p.cStride) * p.cCin;
     }
   }
   const float* wrow[SCALAR ? 1 : B_IT];
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
         const long long tapoff = (long long)(dy * p.cInW + dx) * p.cCin + cin;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-          const int yy = cy[i] + dy, xx = cx[i] + dx;
+          const int yy = cy[i] * p.cStride + dy, xx = cx[i] * p.cStride + dx;
           const bool ok = kok && (unsigned)yy < (unsigned)p.cInH && (unsigned)xx < (unsigned)p.cInW;
           // out-of-image taps read the row's own pixel (always valid) and are zeroed by the select
           const f32x4 v = *(const f32x4*)(p.A + rowbase[i] + (ok ? tapoff : (long long)cin));
@@ -735,6 +736,28 @@ int sf_conv2d_nhwc_f32(const float* in, const float* w_packed, const float* bias
   return sf_gemm_dispatch(a, ALOAD_CONV_NHWC, (hipStream_t)stream);
 }
 
+}  // extern "C"
+
+// Conv2d(k, stride, padding=k/2) on NHWC, [F,Hin,Win,Cin] -> [F,Hin/stride,Win/stride,Cout]; w_packed [Cout][ks][ks][Cin].
+// With w_packed = pack_conv(torch ConvTranspose2d weight [Cin_t, Cout_t, k, k]) this is the backward-data pass of
+// sf_conv_transpose2d_nhwc_f32 (training of the image loss, savi_decode_train.hip).
+int sf_conv2d_nhwc_strided_ex(const float* in, const float* w_packed, const float* bias, float* out, int F, int Hin, int Win,
+                              int Cin, int Cout, int ks, int stride, int relu, hipStream_t stream) {
+  SF_REQUIRE(in && w_packed && out, "null pointer");
+  SF_REQUIRE(F >= 0 && Hin > 0 && Win > 0 && Cin > 0 && (Cin % 4) == 0 && Cout > 0 && (ks & 1) && stride >= 1 &&
+                 Hin % stride == 0 && Win % stride == 0, "bad strided conv shape");
+  SfGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  const int Ho = Hin / stride, Wo = Win / stride;
+  a.A = in; a.W = w_packed; a.ldw = ks * ks * Cin; a.bias = bias;
+  a.C = out; a.cmap = sf_rows(Cout); a.rmap = sf_rows(Cout);
+  a.M = F * Ho * Wo; a.N = Cout; a.K = ks * ks * Cin; a.relu = relu;
+  a.cH = Ho; a.cW = Wo; a.cInH = Hin; a.cInW = Win; a.cCin = Cin; a.cKs = ks; a.cStride = stride;
+  a.cFrameStride = (long long)Hin * Win * Cin;
+  return sf_gemm_dispatch(a, ALOAD_CONV_NHWC, stream);
+}
+
+extern "C" {
 // ConvTranspose2d(k, stride, padding=k/2, output_padding=stride-1): NHWC in [F,Hin,Win,Cin] -> NHWC out
 // [F,Hin*stride,Win*stride,Cout]; w_packed [Cout][ks][ks][Cin] = torch weight[Cin,Cout,k,k].permute(1,2,3,0).
 int sf_conv_transpose2d_nhwc_f32(const float* in, const float* w_packed, const float* bias, float* out, int F,

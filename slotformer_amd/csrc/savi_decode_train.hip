@@ -1,0 +1,173 @@
+// The SAVi spatial-broadcast decoder under autograd, data gradient only: what the image term of
+// SlotFormer's training loss (slotformer.py:313-326, `use_img_recon_loss`) back-propagates through -- the decoder is
+// frozen there (slotformer.py:203-210), so no weight gradients are needed.
+//
+//   forward  (savi.py:504-525): broadcast slots over the dec_res x dec_res grid + position table -> ConvTranspose2d+ReLU
+//            stack -> 1x1 head -> masks = softmax over slots, recon = sum_n rgb_n * mask_n.  Every layer output is kept.
+//   backward: head / recombination adjoint (one kernel), then per layer ReLU mask + the adjoint of the transposed
+//            convolution, which is a plain strided convolution of the gradient with the same weights
+//            (sf_conv2d_nhwc_strided_ex on the GEMM core's im2col loader), then the sum over the broadcast grid.
+#include "../../include/slotformer_hip.h"
+#include "sf_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// d_dec [F*N, HW, 4] from d_recon [F, 3, HW]:  d_rgb_n = m_n d_recon;  d_alpha_n = m_n (rgb_n.d_recon - sum_k m_k rgb_k.d_recon)
+__global__ __launch_bounds__(256) void decode_combine_bwd_kernel(const float* __restrict__ dec, const float* __restrict__ d_recon,
+                                                                 float* __restrict__ d_dec, int F, int N, int HW) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)F * HW) return;
+  const int pix = idx % HW;
+  const long long f = idx / HW;
+  float g[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) g[c] = d_recon[(f * 3 + c) * HW + pix];
+  float mx = -INFINITY;
+  for (int n = 0; n < N; ++n) mx = fmaxf(mx, dec[((f * N + n) * HW + pix) * 4 + 3]);
+  float sum = 0.f, dot = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const f32x4 v = *(const f32x4*)(dec + ((f * N + n) * HW + pix) * 4);
+    const float e = expf(v[3] - mx);
+    sum += e;
+    dot += e * (v[0] * g[0] + v[1] * g[1] + v[2] * g[2]);
+  }
+  const float inv = 1.f / sum;
+  dot *= inv;
+  for (int n = 0; n < N; ++n) {
+    const f32x4 v = *(const f32x4*)(dec + ((f * N + n) * HW + pix) * 4);
+    const float m = expf(v[3] - mx) * inv;
+    f32x4 o;
+    o[0] = m * g[0]; o[1] = m * g[1]; o[2] = m * g[2];
+    o[3] = m * ((v[0] * g[0] + v[1] * g[1] + v[2] * g[2]) - dot);
+    *(f32x4*)(d_dec + ((f * N + n) * HW + pix) * 4) = o;
+  }
+}
+
+// d_slots[r][c] = sum_p d_x[r][p][c]   (adjoint of the spatial broadcast; the position table is a constant)
+__global__ __launch_bounds__(256) void broadcast_bwd_kernel(const float* __restrict__ dx, float* __restrict__ d_slots, int P, int D) {
+  const int r = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float a = 0.f;
+    for (int p = 0; p < P; ++p) a += dx[((long long)r * P + p) * D + c];
+    d_slots[(long long)r * D + c] = a;
+  }
+}
+
+namespace {
+struct DecWs {
+  float* act[9];   // act[0]: broadcast input, act[l+1]: output of transposed conv l (post-ReLU)
+  float *dec, *ga, *gb, *wout_t;
+  size_t total;
+};
+size_t pad64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+DecWs carve(const sf_savi_decoder* m, int F, float* base) {
+  DecWs w;
+  memset(&w, 0, sizeof(w));
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    float* p = base ? base + off : nullptr;
+    off += pad64(n);
+    return p;
+  };
+  const size_t R = (size_t)F * m->num_slots;
+  int h = m->dec_res;
+  size_t gmax = R * h * h * m->dec_channels[0];
+  w.act[0] = take(gmax);
+  for (int l = 0; l < m->dec_layers; ++l) {
+    h *= m->dec_strides[l];
+    const size_t n = R * h * h * m->dec_channels[l + 1];
+    w.act[l + 1] = take(n);
+    gmax = n > gmax ? n : gmax;
+  }
+  w.dec = take(R * h * h * 4);
+  w.ga = take(gmax);
+  w.gb = take(gmax);
+  w.wout_t = take((size_t)4 * m->dec_channels[m->dec_layers]);
+  w.total = off;
+  return w;
+}
+
+int check(const sf_savi_decoder* m, int F) {
+  SF_REQUIRE(m, "null model");
+  SF_REQUIRE(F >= 1 && m->dec_layers >= 1 && m->dec_layers <= 8 && m->num_slots >= 1 && m->dec_res >= 1 && (m->dec_ks & 1),
+             "bad decoder config");
+  SF_REQUIRE(m->dec_channels[0] == m->slot_size && (m->slot_size % 4) == 0, "dec_channels[0] must equal slot_size");
+  SF_REQUIRE(m->pos_table && m->out_w && m->out_b, "null decoder weight");
+  int size = m->dec_res;
+  for (int i = 0; i < m->dec_layers; ++i) {
+    SF_REQUIRE(m->deconv_w[i] != nullptr && m->dec_strides[i] >= 1 && (m->dec_channels[i + 1] % 4) == 0, "bad deconv layer");
+    size *= m->dec_strides[i];
+  }
+  SF_REQUIRE(size == m->resolution, "decoder output size does not match the resolution (savi.py:279-284)");
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+size_t sf_savi_decode_train_workspace_bytes(const sf_savi_decoder* m, int F) {
+  if (check(m, F) != 0) return 0;
+  return carve(m, F, nullptr).total * sizeof(float) + 256;
+}
+
+int sf_savi_decode_train_fwd_f32(const sf_savi_decoder* m, const float* slots, float* recon_combined, float* recons, float* masks,
+                                 int F, void* ws, size_t ws_bytes, void* stream) {
+  SF_TRY(check(m, F));
+  SF_REQUIRE(slots && recon_combined && ws, "null pointer");
+  const DecWs w = carve(m, F, (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255));
+  SF_REQUIRE(w.total * sizeof(float) + 256 <= ws_bytes, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int N = m->num_slots, D = m->slot_size, R = F * N, HW = m->resolution * m->resolution;
+  SF_TRY(sf_slot_broadcast_f32(slots, m->pos_table, w.act[0], R, m->dec_res * m->dec_res, D, st));
+  int hin = m->dec_res;
+  for (int l = 0; l < m->dec_layers; ++l) {
+    SF_TRY(sf_conv_transpose2d_nhwc_f32(w.act[l], m->deconv_w[l], m->deconv_b[l], w.act[l + 1], R, hin, hin, m->dec_channels[l],
+                                        m->dec_channels[l + 1], m->dec_ks, m->dec_strides[l], 1, st));
+    hin *= m->dec_strides[l];
+  }
+  const int Cl = m->dec_channels[m->dec_layers];
+  SF_TRY(sf_linear_ex(w.act[m->dec_layers], sf_rows(Cl), m->out_w, m->out_b, nullptr, nullptr, 0.f, nullptr, sf_rows(4), 0, w.dec,
+                      sf_rows(4), R * HW, 4, Cl, 0, st));
+  return sf_decode_combine_f32(w.dec, recon_combined, recons, masks, F, N, HW, st);
+}
+
+int sf_savi_decode_train_bwd_f32(const sf_savi_decoder* m, const float* const* deconv_w_bwd, const float* d_recon, float* d_slots,
+                                 int F, void* ws, size_t ws_bytes, void* stream) {
+  SF_TRY(check(m, F));
+  SF_REQUIRE(deconv_w_bwd && d_recon && d_slots && ws, "null pointer");
+  const DecWs w = carve(m, F, (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255));
+  SF_REQUIRE(w.total * sizeof(float) + 256 <= ws_bytes, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int N = m->num_slots, D = m->slot_size, R = F * N, HW = m->resolution * m->resolution, L = m->dec_layers;
+  const int Cl = m->dec_channels[L];
+  {
+    const long long total = (long long)F * HW;
+    hipLaunchKernelGGL(decode_combine_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w.dec, d_recon, w.gb, F, N,
+                       HW);
+    SF_CHECK_LAUNCH();
+  }
+  // head: d_act[L] = d_dec . W_out   (W_out [4, Cl]; the GEMM core wants its transpose as the weight operand)
+  SF_TRY(sf_transpose_ex(m->out_w, w.wout_t, 4, Cl, st));
+  SF_TRY(sf_linear_ex(w.gb, sf_rows(4), w.wout_t, nullptr, nullptr, nullptr, 0.f, nullptr, sf_rows(Cl), 0, w.ga, sf_rows(Cl), R * HW, Cl,
+                      4, 0, st));
+  float* g = w.ga;
+  float* o = w.gb;
+  int h = m->resolution;
+  for (int l = L - 1; l >= 0; --l) {
+    SF_REQUIRE(deconv_w_bwd[l] != nullptr, "null backward weight");
+    const long long n = (long long)R * h * h * m->dec_channels[l + 1];
+    SF_TRY(sf_relu_bwd_ex(g, w.act[l + 1], n, st));
+    SF_TRY(sf_conv2d_nhwc_strided_ex(g, deconv_w_bwd[l], nullptr, o, R, h, h, m->dec_channels[l + 1], m->dec_channels[l], m->dec_ks,
+                                     m->dec_strides[l], 0, st));
+    h /= m->dec_strides[l];
+    float* t = g;
+    g = o;
+    o = t;
+  }
+  hipLaunchKernelGGL(broadcast_bwd_kernel, dim3(R), dim3(256), 0, st, g, d_slots, m->dec_res * m->dec_res, D);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

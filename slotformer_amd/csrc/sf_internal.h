@@ -51,3 +51,5 @@ int sf_ln_bwd_ex(const float* x, const float* dy, const float* gamma, const floa
                  float eps, hipStream_t st);
 int sf_transpose_ex(const float* in, float* out, int R, int Cn, hipStream_t st);
 int sf_relu_bwd_ex(float* dh, const float* h, long long n, hipStream_t st);
+int sf_conv2d_nhwc_strided_ex(const float* in, const float* w_packed, const float* bias, float* out, int F, int Hin, int Win,
+                              int Cin, int Cout, int ks, int stride, int relu, hipStream_t stream);

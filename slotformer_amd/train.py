@@ -176,6 +176,57 @@ def slot_attention_with_grad(sa, inputs, slots):
     return _SlotAttention.apply(sa, inputs, slots, *slot_attention_parameters(sa))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# SAVi decoder under autograd (data gradient only: the image term of SlotFormer's loss; the decoder is frozen there)
+# ---------------------------------------------------------------------------------------------------------------------
+class _Decode(torch.autograd.Function):
+    """(recon_combined, recons, masks) = decode(slots); only recon_combined carries a gradient (slotformer.py:313-326)."""
+
+    @staticmethod
+    def forward(ctx, m, slots):
+        from . import ops
+        slots = slots.detach().float().contiguous()
+        if not slots.is_cuda:
+            raise RuntimeError('slotformer_amd: inputs must live on a HIP device; there is no CPU fallback')
+        plan = engine.decoder_plan(m)
+        if not hasattr(plan, 'bwd_w'):
+            n = plan.struct.dec_layers
+            plan.bwd_keep = [ops.pack_conv_weight(m.decoder[i][0].weight.detach().float().contiguous()) for i in range(n)]
+            plan.bwd_w = (C.c_void_p * n)(*[t.data_ptr() for t in plan.bwd_keep])
+        F_, N, D = slots.shape
+        H = plan.struct.resolution
+        nbytes = lib().sf_savi_decode_train_workspace_bytes(C.byref(plan.struct), F_)
+        if nbytes == 0:
+            check(-1)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=slots.device)
+        recon = torch.empty(F_, 3, H, H, device=slots.device, dtype=torch.float32)
+        recons = torch.empty(F_, N, 3, H, H, device=slots.device, dtype=torch.float32)
+        masks = torch.empty(F_, N, 1, H, H, device=slots.device, dtype=torch.float32)
+        check(lib().sf_savi_decode_train_fwd_f32(C.byref(plan.struct), slots.data_ptr(), recon.data_ptr(), recons.data_ptr(),
+                                                 masks.data_ptr(), F_, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+        ctx.plan, ctx.ws, ctx.shape = plan, ws, (F_, N, D)
+        ctx.mark_non_differentiable(recons, masks)
+        return recon, recons, masks
+
+    @staticmethod
+    def backward(ctx, d_recon, _d_recons, _d_masks):
+        F_, N, D = ctx.shape
+        d_recon = d_recon.float().contiguous()
+        d_slots = torch.empty(F_, N, D, device=d_recon.device, dtype=torch.float32)
+        check(lib().sf_savi_decode_train_bwd_f32(C.byref(ctx.plan.struct), ctx.plan.bwd_w, d_recon.data_ptr(), d_slots.data_ptr(), F_,
+                                                 ctx.ws.data_ptr(), ctx.ws.numel(), torch.cuda.current_stream().cuda_stream))
+        ctx.ws = None
+        return None, d_slots
+
+
+def decode_with_grad(m, slots):
+    """StoSAVi.decode (savi.py:504-525) with d(recon_combined)/d(slots); the decoder's own parameters must be frozen."""
+    if any(p.requires_grad for p in list(m.decoder.parameters()) + list(m.decoder_pos_embedding.parameters())):
+        raise NotImplementedError('slotformer_amd: the decoder trains only its input (weight gradients of the transposed '
+                                  'convolutions are not built); freeze it as SlotFormer does (slotformer.py:203-210)')
+    return _Decode.apply(m, slots)
+
+
 def dropout_keep_mask(seed, step, layer, site, numel, p):
     """Host restatement of the library's dropout mask (rollout_train.hip: sf_keep / site_seed) for tests and tools:
     bool [numel], True = kept.  site: 0 attention weights, 1 attention output, 2 FFN hidden, 3 FFN output."""

@@ -143,6 +143,8 @@ C5_ROLL = rollout_cfg(8, 128, 1, 256, 8, 8, 1024, cond_len=6, rollout_len=80,
                       model='SingleStepSlotFormer', res=128)
 # row N1 (training): a reduced slotformer_clevrer_params.py whose gradients fit a small fixture
 TRAIN_ROLL = rollout_cfg(3, 64, 3, 64, 2, 2, 128, rollout_len=3)
+TRAIN_ROLL_IMG = rollout_cfg(3, 64, 3, 64, 2, 2, 128, rollout_len=2)   # with the image term (use_img_recon_loss=True)
+TRAIN_ROLL_IMG['loss_dict'] = dict(rollout_len=2, use_img_recon_loss=True)
 
 
 class ParamsView:

@@ -215,3 +215,49 @@ def test_slot_attention_module_backward(dev, precision, B, HW, N, D, Cin, H, ite
     # inference path unchanged and equal to the training forward
     with torch.no_grad():
         assert rel_err(sa(xg.detach(), sg.detach()), ref) < 1e-4
+
+
+def test_rollout_grads_with_image_loss_golden(dev, precision):
+    """The reference's default CLEVRER / OBJ3D training objective (use_img_recon_loss=True, slotformer.py:272-281,313-326):
+    slot loss + MSE of the frames decoded from the predicted slots by the frozen SAVi decoder.  Loss and gradients
+    against the fixture produced by the reference's own SlotFormer + torch autograd."""
+    g = gu.load_golden('roll_train_img')
+    cfg = gu.TRAIN_ROLL_IMG
+    m, sd = build(cfg, g, 811, dev, vp=True)
+    m.train()
+    _no_dropout(m)
+    rd = cfg['rollout_dict']
+    T = rd['history_len'] + 2
+    slots = gu.seeded_normal((1, T, rd['num_slots'], rd['slot_size']), 812)
+    data = {'slots': slots.to(dev).requires_grad_(True), 'img': gu.seeded_img(1, T, 64, 813).to(dev)}
+    m.loss_decay_factor = 0.9
+    out = m(data)
+    terms = m.calc_train_loss(data, out)
+    loss = terms['slot_recon_loss'] + terms['img_recon_loss']
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-5 * abs(float(g['loss']))
+    grads = {n: p.grad for n, p in m.named_parameters() if n.startswith('rollouter.') and p.requires_grad}
+    for n in (str(x) for x in g['grad_names']):
+        assert rel_err(grads[n], g['grad.' + n]) < GTOL, n
+    assert rel_err(data['slots'].grad, g['d_slots']) < GTOL
+    assert all(p.grad is None for n, p in m.named_parameters() if n.startswith('decoder'))
+
+
+@pytest.mark.parametrize('Fr', [2, 5])
+def test_decoder_data_gradient_vs_oracle(dev, precision, Fr):
+    """d(recon_combined)/d(slots) of the SAVi decoder at the CLEVRER decoder shape (7 slots, D=128, 8x8 -> 64x64)."""
+    cfg = gu.savi_cfg(64, 7, kernel_mlp=False, pred='mlp', rnn=False)
+    m, sd = build(cfg, gu.load_golden('decode_c2'), 401, dev)
+    for p in list(m.decoder.parameters()) + list(m.decoder_pos_embedding.parameters()):
+        p.requires_grad_(False)
+    slots = gu.seeded_normal((Fr, 7, 128), 31)
+    target = gu.seeded_img(1, Fr, 64, 32)[0]
+    so = slots.clone().requires_grad_(True)
+    ref = oracle.savi_decode(so, sd, cfg)[0]
+    ((ref - target)**2).mean().backward()
+    sg = slots.to(dev).requires_grad_(True)
+    recon, recons, masks, _ = m.decode(sg)
+    assert rel_err(recon, ref) < 1e-4 and not recons.requires_grad and not masks.requires_grad
+    ((recon - target.to(dev))**2).mean().backward()
+    # ~10^7 ReLU units per frame: the kink-flip noise of L2TOL's comment, larger here
+    assert l2_err(sg.grad, so.grad) < {'bf16x3': 1e-2, 'f32': 2e-3}[precision]

@@ -377,7 +377,7 @@ def case_rollout(name, cfg, B, pred_len, seed, single_step=False):
     return m, sd
 
 
-def case_rollout_grads(name, cfg, B, seed, decay=0.9):
+def case_rollout_grads(name, cfg, B, seed, decay=0.9, img=False):
     """Gradients of the reference's training loss (SlotFormer.forward + calc_train_loss in train() mode,
     slotformer.py:263-318, then loss.backward()) w.r.t. every rollouter parameter and the burn-in slots.  Dropout is the
     only random part of that path; its probability is set to 0 on the reference modules so the fixture is reproducible
@@ -397,8 +397,12 @@ def case_rollout_grads(name, cfg, B, seed, decay=0.9):
         S = cfg['loss_dict']['rollout_len']
         slots = gu.seeded_normal((B, hist + S, N, C), seed + 1).requires_grad_(True)
         m.loss_decay_factor = decay
-        out = m({'slots': slots})
-        loss = m.calc_train_loss({'slots': slots}, out)['slot_recon_loss']
+        data = {'slots': slots}
+        if img:   # image term on: forward decodes the predicted slots (slotformer.py:272-281), loss adds their MSE (:313-326)
+            data['img'] = gu.seeded_img(B, hist + S, cfg['resolution'][0], seed + 2)
+        out = m(data)
+        terms = m.calc_train_loss(data, out)
+        loss = terms['slot_recon_loss'] + (terms['img_recon_loss'] if img else 0.)
         loss.backward()
         names = [n for n, p_ in m.named_parameters() if n.startswith('rollouter.') and p_.requires_grad]
         grads = {n: dict(m.named_parameters())[n].grad.detach().clone() for n in names}
@@ -407,6 +411,9 @@ def case_rollout_grads(name, cfg, B, seed, decay=0.9):
         oslots = slots.detach().clone().requires_grad_(True)
         o = oracle.slotformer_forward(oslots, osd, cfg, S)
         ol = oracle.slot_mse_losses(o['pred_slots'], o['gt_slots'], training=True, loss_decay_factor=decay)['slot_recon_loss']
+        if img:
+            rec = oracle.savi_decode(o['pred_slots'].flatten(0, 1), osd, cfg)[0].unflatten(0, (B, S))
+            ol = ol + ((rec - data['img'][:, hist:])**2).mean()   # no temporal weighting on the image term (:313-326)
         ol.backward()
         print('  loss', float(loss), 'oracle', float(ol))
         print('  oracle grad err', max(err(osd[n].grad, grads[n]) for n in names), 'd_slots', err(oslots.grad, slots.grad))
@@ -515,6 +522,7 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'roll_train':
         case_rollout_grads('roll_train', gu.TRAIN_ROLL, B=2, seed=801)
+        case_rollout_grads('roll_train_img', gu.TRAIN_ROLL_IMG, B=1, seed=811, img=True)
         return
     case_savi('savi_c1', gu.C1_SAVI, B=2, T=3, seed=101)
     case_savi('savi_c1_it3', gu.C1_SAVI_IT3, B=1, T=2, seed=102)
@@ -533,6 +541,7 @@ def main():
     case_steve_tokens('steve_tokens', B=1, T=2, seed=601)
     case_steve_slotformer('steve_slotformer', B=1, seed=701)
     case_rollout_grads('roll_train', gu.TRAIN_ROLL, B=2, seed=801)
+    case_rollout_grads('roll_train_img', gu.TRAIN_ROLL_IMG, B=1, seed=811, img=True)
 
 
 if __name__ == '__main__':
