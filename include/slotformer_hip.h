@@ -344,6 +344,10 @@ typedef struct {
   const float* deconv_b[8]; /* may be NULL */
   const float *out_w, *out_b; /* final 1x1 conv: [4, C_last], [4] */
   const float* pos_table;     /* [dec_res*dec_res, slot_size] */
+  /* optional (NULL = absent), stride-1 layers only: deconv_w spatially flipped ([Cout][ks-1-ky][ks-1-kx][Cin]).  A
+   * stride-1 transposed convolution is an ordinary convolution with the flipped kernel, which lets those layers run on
+   * the encoder's halo-resident 5x5 kernel (64 -> 64 channels, 64 pixels wide). */
+  const float* deconv_w_flipped[8];
 } sf_savi_decoder;
 
 size_t sf_savi_decode_workspace_bytes(const sf_savi_decoder* m, int F);

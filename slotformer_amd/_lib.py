@@ -87,7 +87,7 @@ class sf_savi_decoder(C.Structure):
     _fields_ = ([('resolution', C.c_int), ('dec_layers', C.c_int), ('dec_channels', C.c_int * 9),
                  ('dec_strides', C.c_int * 8), ('dec_ks', C.c_int), ('dec_res', C.c_int), ('num_slots', C.c_int),
                  ('slot_size', C.c_int), ('deconv_w', FP * 8), ('deconv_b', FP * 8), ('out_w', FP), ('out_b', FP),
-                 ('pos_table', FP)])
+                 ('pos_table', FP), ('deconv_w_flipped', FP * 8)])
 
 
 I, LL, F32, SZ, VP = C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_void_p

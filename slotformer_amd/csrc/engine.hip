@@ -602,8 +602,12 @@ int sf_savi_decode_f32(const sf_savi_decoder* m, const float* slots, float* reco
     float* nxt = bufB;
     int hin = m->dec_res;
     for (int i = 0; i < m->dec_layers; ++i) {
-      SF_TRY(sf_conv_transpose2d_nhwc_f32(cur, m->deconv_w[i], m->deconv_b[i], nxt, R, hin, hin, m->dec_channels[i],
-                                          m->dec_channels[i + 1], m->dec_ks, m->dec_strides[i], 1, st));
+      if (m->dec_strides[i] == 1 && m->deconv_w_flipped[i])   // = convolution with the flipped kernel (halo-resident 5x5 path)
+        SF_TRY(sf_conv2d_nhwc_f32(cur, m->deconv_w_flipped[i], m->deconv_b[i], nullptr, nxt, R, hin, hin, m->dec_channels[i],
+                                  m->dec_channels[i + 1], m->dec_ks, 1, st));
+      else
+        SF_TRY(sf_conv_transpose2d_nhwc_f32(cur, m->deconv_w[i], m->deconv_b[i], nxt, R, hin, hin, m->dec_channels[i],
+                                            m->dec_channels[i + 1], m->dec_ks, m->dec_strides[i], 1, st));
       hin *= m->dec_strides[i];
       float* tmp = cur;
       cur = nxt;

@@ -42,6 +42,10 @@ struct SfGemmArgs {
   // conv (im2col loaders): output cH x cW, input cInH x cInW, cCin channels, cKs taps, stride
   int cH, cW, cInH, cInW, cCin, cKs, cStride;
   long long cFrameStride;
+  // transposed conv, one output-parity class per launch (cSub = stride, 0 = off): rows enumerate the outputs
+  // (cSub*cy + cPy, cSub*cx + cPx) of a cH x cW class grid; only the taps ky = cKy0 + cSub*ty, kx = cKx0 + cSub*tx that
+  // reach such an output are contracted (k = (ty*cNtx + tx)*cCin + cin), input pixel (cy + cQy - ty, cx + cQx - tx)
+  int cSub, cPy, cPx, cKy0, cKx0, cNtx, cQy, cQx;
   // dropout on act(acc + bias) before the residual (training, rollout_train.hip): element (row, col) is kept iff
   // sf_mix32((row * N + col) ^ drop_seed) >> 8 >= drop_thresh and scaled by drop_scale; drop_thresh == 0: off
   uint32_t drop_seed, drop_thresh;
@@ -151,6 +155,7 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
       const int k = kc * BKT + 4 * c4;
       const bool kok = k < K;
       const int kc4 = kok ? k : 0;
+      int kw4 = kc4;   // offset of this k in a weight row (differs from k only for the parity-class transposed conv)
       if constexpr (ALOAD == ALOAD_PLAIN) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
@@ -158,6 +163,20 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
           ra[i] = kok ? v : zero4;
         }
       } else if constexpr (ALOAD == ALOAD_DECONV_NHWC) {
+        if (p.cSub) {
+          const int tap = kc4 / p.cCin, cin = kc4 - tap * p.cCin;
+          const int ty = tap / p.cNtx, tx = tap - ty * p.cNtx;
+          kw4 = ((p.cKy0 + p.cSub * ty) * p.cKs + p.cKx0 + p.cSub * tx) * p.cCin + cin;
+#pragma unroll
+          for (int i = 0; i < A_IT; ++i) {
+            const int iy = cy[i] + p.cQy - ty, ix = cx[i] + p.cQx - tx;
+            const bool ok = kok && (unsigned)iy < (unsigned)p.cInH && (unsigned)ix < (unsigned)p.cInW;
+            const int yc = min(max(iy, 0), p.cInH - 1), xc = min(max(ix, 0), p.cInW - 1);
+            const f32x4 v = *(const f32x4*)(p.A + (long long)cf[i] * p.cFrameStride +
+                                            ((long long)(yc * p.cInW + xc) * p.cCin + cin));
+            ra[i] = ok ? v : zero4;
+          }
+        } else {
         // ConvTranspose2d gather: out(oy,ox) += in(iy,ix) * W[ky][kx] with oy = iy*s - pad + ky, i.e. the tap
         // contributes iff (oy + pad - ky) is a non-negative multiple of s inside the input.  k = tap*Cin + cin.
         const int tap = kc4 / p.cCin, cin = kc4 - tap * p.cCin;
@@ -171,6 +190,7 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
           const f32x4 v = *(const f32x4*)(p.A + (long long)cf[i] * p.cFrameStride +
                                           ((long long)(yc * p.cInW + xc) * p.cCin + cin));
           ra[i] = ok ? v : zero4;
+        }
         }
       } else {  // NHWC im2col: k = tap * Cin + cin
         int tap, cin, ky, kx;
@@ -199,7 +219,7 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
       }
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
-        const f32x4 v = *(const f32x4*)(wrow[i] + kc4);
+        const f32x4 v = *(const f32x4*)(wrow[i] + kw4);
         rb[i] = kok ? v : zero4;
       }
     } else {  // NCHW image im2col, scalar: k = (c * ks + ky) * ks + kx
@@ -529,7 +549,14 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
         float t = fmaxf(acc[i][j][r] + bias, lo);
         if (p.drop_thresh) t = (sf_mix32((uint32_t)(row * N + col) ^ p.drop_seed) >> 8) >= p.drop_thresh ? t * p.drop_scale : 0.f;
         const float v = t + rv[r];
-        if (row < M && colok && !((p.dbg & 8) && v != 12345.f)) p.C[sf_row_off(p.cmap, row) + col] = v;
+        int orow = row;
+        if constexpr (ALOAD == ALOAD_DECONV_NHWC) {
+          if (p.cSub) {   // class-grid row -> output pixel
+            const int hw = p.cH * p.cW, f = row / hw, rem = row - f * hw, yy = rem / p.cW, xx = rem - yy * p.cW;
+            orow = (f * p.cH * p.cSub + yy * p.cSub + p.cPy) * (p.cW * p.cSub) + xx * p.cSub + p.cPx;
+          }
+        }
+        if (row < M && colok && !((p.dbg & 8) && v != 12345.f)) p.C[sf_row_off(p.cmap, orow) + col] = v;
       }
     }
   }
@@ -746,6 +773,8 @@ int sf_conv2d_nhwc_strided_ex(const float* in, const float* w_packed, const floa
   SF_REQUIRE(in && w_packed && out, "null pointer");
   SF_REQUIRE(F >= 0 && Hin > 0 && Win > 0 && Cin > 0 && (Cin % 4) == 0 && Cout > 0 && (ks & 1) && stride >= 1 &&
                  Hin % stride == 0 && Win % stride == 0, "bad strided conv shape");
+  if (stride == 1)   // the plain "same" convolution, with its halo-resident fast path
+    return sf_conv2d_nhwc_f32(in, w_packed, bias, nullptr, out, F, Hin, Win, Cin, Cout, ks, relu, (void*)stream);
   SfGemmArgs a;
   memset(&a, 0, sizeof(a));
   const int Ho = Hin / stride, Wo = Win / stride;
@@ -767,12 +796,36 @@ int sf_conv_transpose2d_nhwc_f32(const float* in, const float* w_packed, const f
              "bad deconv shape");
   SfGemmArgs a;
   memset(&a, 0, sizeof(a));
-  const int Ho = Hin * stride, Wo = Win * stride;
+  const int Ho = Hin * stride, Wo = Win * stride, pad = ks / 2;
   a.A = in; a.W = w_packed; a.ldw = ks * ks * Cin; a.bias = bias;
   a.C = out; a.cmap = sf_rows(Cout); a.rmap = sf_rows(Cout);
-  a.M = F * Ho * Wo; a.N = Cout; a.K = ks * ks * Cin; a.relu = relu;
-  a.cH = Ho; a.cW = Wo; a.cInH = Hin; a.cInW = Win; a.cCin = Cin; a.cKs = ks; a.cStride = stride;
+  a.N = Cout; a.relu = relu;
+  a.cInH = Hin; a.cInW = Win; a.cCin = Cin; a.cKs = ks; a.cStride = stride;
   a.cFrameStride = (long long)Hin * Win * Cin;
+  static int by_class = -1;   // SF_DECONV_CLASSES=0: the single-launch gather over all ks*ks taps (tools)
+  if (by_class < 0) {
+    const char* e = getenv("SF_DECONV_CLASSES");
+    by_class = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (stride > 1 && by_class) {
+    // one launch per output-parity class: an output (oy, ox) only receives the taps with ky = (oy + pad) mod stride
+    // (mod stride), so the ks*ks-tap gather would multiply (stride^2 - 1) / stride^2 structural zeros
+    for (int py = 0; py < stride; ++py)
+      for (int px = 0; px < stride; ++px) {
+        SfGemmArgs c = a;
+        c.cSub = stride; c.cPy = py; c.cPx = px;
+        c.cKy0 = (py + pad) % stride; c.cKx0 = (px + pad) % stride;
+        const int nty = (ks - c.cKy0 + stride - 1) / stride, ntx = (ks - c.cKx0 + stride - 1) / stride;
+        c.cNtx = ntx;
+        c.cQy = (py + pad - c.cKy0) / stride; c.cQx = (px + pad - c.cKx0) / stride;
+        c.cH = Hin; c.cW = Win;   // class grid: Ho / stride x Wo / stride
+        c.M = F * Hin * Win; c.K = nty * ntx * Cin;
+        SF_TRY(sf_gemm_dispatch(c, ALOAD_DECONV_NHWC, (hipStream_t)stream));
+      }
+    return 0;
+  }
+  a.M = F * Ho * Wo; a.K = ks * ks * Cin;
+  a.cH = Ho; a.cW = Wo;
   return sf_gemm_dispatch(a, ALOAD_DECONV_NHWC, (hipStream_t)stream);
 }
 

@@ -122,8 +122,12 @@ int sf_savi_decode_train_fwd_f32(const sf_savi_decoder* m, const float* slots, f
   SF_TRY(sf_slot_broadcast_f32(slots, m->pos_table, w.act[0], R, m->dec_res * m->dec_res, D, st));
   int hin = m->dec_res;
   for (int l = 0; l < m->dec_layers; ++l) {
-    SF_TRY(sf_conv_transpose2d_nhwc_f32(w.act[l], m->deconv_w[l], m->deconv_b[l], w.act[l + 1], R, hin, hin, m->dec_channels[l],
-                                        m->dec_channels[l + 1], m->dec_ks, m->dec_strides[l], 1, st));
+    if (m->dec_strides[l] == 1 && m->deconv_w_flipped[l])   // = convolution with the flipped kernel (halo-resident 5x5 path)
+      SF_TRY(sf_conv2d_nhwc_f32(w.act[l], m->deconv_w_flipped[l], m->deconv_b[l], nullptr, w.act[l + 1], R, hin, hin,
+                                m->dec_channels[l], m->dec_channels[l + 1], m->dec_ks, 1, st));
+    else
+      SF_TRY(sf_conv_transpose2d_nhwc_f32(w.act[l], m->deconv_w[l], m->deconv_b[l], w.act[l + 1], R, hin, hin, m->dec_channels[l],
+                                          m->dec_channels[l + 1], m->dec_ks, m->dec_strides[l], 1, st));
     hin *= m->dec_strides[l];
   }
   const int Cl = m->dec_channels[m->dec_layers];

@@ -325,7 +325,10 @@ def decoder_plan(m):
     for i in range(n):
         dc = m.decoder[i][0]
         s.dec_strides[i] = dc.stride[0]
-        s.deconv_w[i] = plan.dp(ops.pack_deconv_weight(dc.weight.detach().float().contiguous()))
+        packed = ops.pack_deconv_weight(dc.weight.detach().float().contiguous())
+        s.deconv_w[i] = plan.dp(packed)
+        if dc.stride[0] == 1:   # [Cout, ks, ks, Cin] flipped over both kernel axes: the equivalent convolution kernel
+            s.deconv_w_flipped[i] = plan.dp(packed.flip(1, 2).contiguous())
         s.deconv_b[i] = plan.dp(dc.bias)
     head = m.decoder[n]
     s.out_w = plan.dp(head.weight.detach().float().reshape(head.out_channels, head.in_channels).contiguous())

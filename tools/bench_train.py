@@ -24,10 +24,10 @@ import torch  # noqa: E402
 import golden_util as gu  # noqa: E402
 
 
-def build(dev, S):
+def build(dev, S, img=False):
     from slotformer_amd.base_slots import build_model as bb
     from slotformer_amd.video_prediction import build_model as bv
-    cfg = {**gu.C2_ROLL, 'loss_dict': dict(rollout_len=S, use_img_recon_loss=False)}
+    cfg = {**gu.C2_ROLL, 'loss_dict': dict(rollout_len=S, use_img_recon_loss=img)}
     scfg = gu.savi_cfg(64, 7)
     scfg['dec_dict'] = {k: v for k, v in cfg['dec_dict'].items() if k != 'dec_ckp_path'}
     torch.manual_seed(0)
@@ -53,6 +53,18 @@ def eager_rollout(r, x, pred_len):
     return torch.stack(out, 1)
 
 
+def eager_decode(m, slots):
+    """StoSAVi.decode (savi.py:504-525) on torch's own kernels, with the model's (frozen) decoder modules."""
+    F_, N, D = slots.shape
+    r = m.dec_resolution[0]
+    x = slots.reshape(F_ * N, D, 1, 1).expand(-1, -1, r, r)
+    pe = m.decoder_pos_embedding
+    x = x + pe.dense(pe.grid).permute(0, 3, 1, 2)
+    out = m.decoder(x).view(F_, N, 4, m.resolution[0], m.resolution[1])
+    masks = torch.softmax(out[:, :, 3:], dim=1)
+    return (out[:, :, :3] * masks).sum(1)
+
+
 def time_loop(fn, steps, warmup):
     for _ in range(warmup):
         fn()
@@ -71,19 +83,24 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--eager', action='store_true')
+    ap.add_argument('--img', action='store_true', help='add the image term (use_img_recon_loss=True, 64x64 frames)')
     ap.add_argument('--phases', action='store_true')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     S, B = a.rollout, a.batch
-    m, cfg = build(dev, S)
+    m, cfg = build(dev, S, a.img)
     slots = (0.5 * gu.seeded_normal((B, 6 + S, 7, 128), 1)).to(dev)
+    data = {'slots': slots}
+    if a.img:
+        data['img'] = torch.rand(B, 6 + S, 3, 64, 64, device=dev) * 2 - 1
     params = [p for p in m.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=2e-4)
 
     def step():
         opt.zero_grad(set_to_none=True)
-        out = m({'slots': slots})
-        loss = m.calc_train_loss({'slots': slots}, out)['slot_recon_loss']
+        out = m(data)
+        terms = m.calc_train_loss(data, out)
+        loss = terms['slot_recon_loss'] + (terms['img_recon_loss'] if a.img else 0.)
         loss.backward()
         opt.step()
         return loss
@@ -92,7 +109,7 @@ def main():
     res = {'metric': 'slotformer_training_iterations_per_sec', 'value': round(1e3 / ms, 2), 'unit': 'it/s', 'ms_per_iter': round(ms, 3),
            'frames_per_sec': round(B * (6 + S) * 1e3 / ms, 1),
            'config': {'workload': f'SlotFormer CLEVRER training step, B={B}, 6+{S} frames, 7 slots, d=256, 4 layers, '
-                                  'dropout 0.1, slot loss, Adam', 'dtype': 'f32 (split-bf16 MFMA)'}}
+                                  'dropout 0.1, slot loss' + (' + image loss through the frozen SAVi decoder (64x64)' if a.img else '') + ', Adam', 'dtype': 'f32 (split-bf16 MFMA)'}}
     if a.phases:
         def fwd():
             with torch.no_grad():
@@ -101,9 +118,10 @@ def main():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         opt.zero_grad(set_to_none=True)
         ev[0].record()
-        out = m({'slots': slots})
+        out = m(data)
         ev[1].record()
-        loss = m.calc_train_loss({'slots': slots}, out)['slot_recon_loss']
+        terms = m.calc_train_loss(data, out)
+        loss = terms['slot_recon_loss'] + (terms['img_recon_loss'] if a.img else 0.)
         loss.backward()
         ev[2].record()
         opt.step()
@@ -118,6 +136,9 @@ def main():
             opt.zero_grad(set_to_none=True)
             pred = eager_rollout(r, slots[:, :6], S)
             loss = ((pred - slots[:, 6:])**2).mean()
+            if a.img:
+                rec = eager_decode(m, pred.flatten(0, 1)).unflatten(0, (B, S))
+                loss = loss + ((rec - data['img'][:, 6:])**2).mean()
             loss.backward()
             opt.step()
 
