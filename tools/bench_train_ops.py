@@ -63,7 +63,31 @@ def module_bench(F_, HW=4096, N=7, D=128, H=256, iters=2):
             'speedup': round(t_eager / t_ours, 2)}
 
 
+def decode_bench(res, frames):
+    """SAVi spatial-broadcast decoder (row N2) inference time: 7 slots, D = 128, 8x8 grid -> res x res."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import golden_util as gu
+    from slotformer_amd.base_slots import build_model
+    torch.manual_seed(0)
+    m = build_model(gu.ParamsView(gu.savi_cfg(res, 7, kernel_mlp=False, pred='mlp', rnn=False))).to(dev).eval()
+    slots = torch.randn(frames, 7, 128, device=dev)
+    with torch.no_grad():
+        ms = timeit(lambda: m.decode(slots), 5)
+    # dense-equivalent flops: every transposed conv as its useful taps only (Hout*Wout*Cout*Cin*ks*ks / stride^2)
+    ch, size, fl = list(m.dec_channels), m.dec_resolution[0], 0
+    for i in range(len(ch) - 1):
+        st = m.decoder[i][0].stride[0]
+        size *= st
+        fl += 2 * size * size * ch[i] * ch[i + 1] * 25 / (st * st)
+    fl = (fl + 2 * size * size * ch[-1] * 4) * 7 * frames
+    return {'res': res, 'frames': frames, 'ms': round(ms, 3), 'useful_TFLOPs': round(fl / ms / 1e9, 1),
+            'deconv_by_parity_class': os.environ.get('SF_DECONV_CLASSES', '1') != '0'}
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'decode':
+        print(json.dumps({'savi_decode': [decode_bench(128, 32), decode_bench(64, 320)]}))
+        return
     B, HW, N, D = 192, 4096, 7, 128
     g = torch.Generator(device='cpu').manual_seed(0)
     k, v = (torch.randn(B, HW, D, generator=g).to(dev) for _ in range(2))
