@@ -263,8 +263,8 @@ int sf_slot_attention_train_bwd_f32(const sf_slot_attention* m, const float* inp
  * step in the caller's workspace; the backward pass reads them, so the workspace must stay untouched in between.
  * Gradient buffers mirror the parameter leaves of sf_tfm_layer / sf_rollouter (same shapes) and are WRITTEN, not
  * accumulated.  Dropout (nn.TransformerEncoderLayer default p = 0.1 in train mode): masks are a pure function of
- * (seed, step, layer, site, element); pass the same dropout_p / seed to both calls.  Sliding-window rollouter,
- * norm_first layers, slot_size / d_model / ffn_dim multiples of 64, window of at most 128 tokens. */
+ * (seed, step, layer, site, element); pass the same dropout_p / seed to both calls.  Both rollouters (x holds
+ * history_len burn-in frames, or ONE frame for single_step), norm_first layers, slot_size / d_model / ffn_dim multiples of 64, window of at most 128 tokens. */
 typedef struct {
   float *norm1_g, *norm1_b, *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;
   float *norm2_g, *norm2_b, *lin1_w, *lin1_b, *lin2_w, *lin2_b;

@@ -772,7 +772,16 @@ namespace {
 inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
 struct Dims {
-  int B, S, hist, N, C, d, ffn, nl, H, L, M, R, T;
+  int B, S, hist, N, C, d, ffn, nl, H, L, M, R, T;   // L, M: the largest window (tokens per video, rows per step)
+  int W, single;                                      // window length in frames; growing-window (single-step) rollouter
+  // step s sees frames f0(s) .. f0(s) + Lw(s)/N - 1 (single_step_slotformer.py:79-88: the window grows to W frames first)
+  int Lw(int s) const { return (single ? (s + 1 < W ? s + 1 : W) : W) * N; }
+  int f0(int s) const { return single ? (s + 1 > W ? s + 1 - W : 0) : s; }
+  size_t off(int s) const {   // rows of all steps before s in the stacked buffers
+    size_t r = 0;
+    for (int i = 0; i < s; ++i) r += (size_t)B * Lw(i);
+    return r;
+  }
 };
 
 // workspace carve-up (in floats); identical for forward and backward
@@ -799,20 +808,20 @@ Ws carve(const Dims& D, float* base) {
     off += (n + 63) & ~(size_t)63;
     return p;
   };
-  const size_t M = D.M, R = D.R, S = D.S, d = D.d, f = D.ffn;
+  const size_t M = D.M, R = D.R, S = D.S, d = D.d, f = D.ffn, Mt = D.off(D.S);
   w.slots_all = take((size_t)D.T * R * D.C);
   w.tok_all = take((size_t)D.T * R * d);
-  w.xf = take(S * M * d);
+  w.xf = take(Mt * d);
   w.xlast = take(S * R * d);
   w.tmp = take(M * (f > 3 * d ? f : 3 * d));
   for (int l = 0; l < D.nl; ++l) {
-    w.xin[l] = take(S * M * d);
-    w.a1[l] = take(S * M * d);
-    w.qkv[l] = take(S * M * 3 * d);
-    w.ctx[l] = take(S * M * d);
-    w.xmid[l] = take(S * M * d);
-    w.a2[l] = take(S * M * d);
-    w.hdn[l] = take(S * M * f);
+    w.xin[l] = take(Mt * d);
+    w.a1[l] = take(Mt * d);
+    w.qkv[l] = take(Mt * 3 * d);
+    w.ctx[l] = take(Mt * d);
+    w.xmid[l] = take(Mt * d);
+    w.a2[l] = take(Mt * d);
+    w.hdn[l] = take(Mt * f);
   }
   w.dtok = take((size_t)D.T * R * d);
   w.dpred = take(S * R * D.C);
@@ -821,12 +830,12 @@ Ws carve(const Dims& D, float* base) {
   w.dctx = take(M * d);
   w.dxlast = take(R * d);
   for (int l = 0; l < D.nl; ++l) {
-    w.dqkv[l] = take(S * M * 3 * d);
-    w.dao[l] = take(S * M * d);
-    w.dpre[l] = take(S * M * f);
-    w.dfo[l] = take(S * M * d);
-    w.da1[l] = take(S * M * d);
-    w.da2[l] = take(S * M * d);
+    w.dqkv[l] = take(Mt * 3 * d);
+    w.dao[l] = take(Mt * d);
+    w.dpre[l] = take(Mt * f);
+    w.dfo[l] = take(Mt * d);
+    w.da1[l] = take(Mt * d);
+    w.da2[l] = take(Mt * d);
     w.wt_in[l] = take(3 * d * d);
     w.wt_o[l] = take(d * d);
     w.wt_1[l] = take(f * d);
@@ -850,7 +859,7 @@ inline int tn_splits(long long rows, int N, int K) {
   return (int)s;
 }
 inline size_t tn_partial_floats(const Dims& D) {
-  const long long rows = (long long)D.S * D.M;
+  const long long rows = (long long)D.off(D.S);
   size_t best = 0;
   auto upd = [&](long long r, int N, int K) {
     const size_t n = (size_t)tn_splits(r, N, K) * N * K;
@@ -869,12 +878,12 @@ inline size_t tn_partial_floats(const Dims& D) {
 
 int check_model(const sf_rollouter* m, Dims& D, int B, int pred_len) {
   SF_REQUIRE(m && m->layers, "null model");
-  SF_REQUIRE(!m->single_step, "training covers SlotRollouter (sliding window) only");
   SF_REQUIRE(m->norm_first, "training needs norm_first layers (all reference configurations)");
   SF_REQUIRE(B > 0 && pred_len > 0, "bad sizes");
-  D.B = B; D.S = pred_len; D.hist = m->window_len; D.N = m->num_slots; D.C = m->slot_size; D.d = m->d_model;
+  D.B = B; D.S = pred_len; D.W = m->window_len; D.single = m->single_step ? 1 : 0; D.hist = D.single ? 1 : D.W;
+  D.N = m->num_slots; D.C = m->slot_size; D.d = m->d_model;
   D.ffn = m->ffn_dim; D.nl = m->num_layers; D.H = m->num_heads;
-  D.L = D.hist * D.N; D.M = B * D.L; D.R = B * D.N; D.T = D.hist + pred_len;
+  D.L = D.W * D.N; D.M = B * D.L; D.R = B * D.N; D.T = D.hist + pred_len;
   SF_REQUIRE(D.nl >= 1 && D.nl <= 16, "1..16 layers");
   SF_REQUIRE(D.d % 64 == 0 && D.ffn % 64 == 0 && D.C % 64 == 0, "slot_size, d_model and ffn_dim must be multiples of 64");
   SF_REQUIRE(D.d <= 1024, "d_model <= 1024");
@@ -1070,11 +1079,11 @@ int sf_rollout_train_fwd_f32(const sf_rollouter* m, const float* x, float* pred,
   float* base = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   const Ws w = carve(D, base);
   SF_REQUIRE(w.total_floats * sizeof(float) + 256 <= ws_bytes, "workspace too small");
-  const int d = D.d, f = D.ffn, M = D.M, R = D.R, N = D.N, C = D.C, L = D.L, hd = d / D.H;
+  const int d = D.d, f = D.ffn, R = D.R, N = D.N, C = D.C, hd = d / D.H;
   const uint32_t thr = drop_thresh(dropout_p);
   const float inv_keep = 1.f / (1.f - dropout_p);
   const float scale = 1.f / sqrtf((float)hd);
-  const int albytes = attn_lds_bytes(L, hd, false);
+  const int albytes = attn_lds_bytes(D.L, hd, false);
   SF_REQUIRE(albytes <= 64 * 1024, "attention tile does not fit LDS");
 
   // burn-in frames -> frame-major slots_all, then their in-projections
@@ -1084,14 +1093,15 @@ int sf_rollout_train_fwd_f32(const sf_rollouter* m, const float* x, float* pred,
   SF_TRY(gemm(w.slots_all, m->in_proj_w, m->in_proj_b, nullptr, w.tok_all, D.hist * R, d, C, 0, st));
 
   for (int s = 0; s < D.S; ++s) {
-    const size_t so = (size_t)s * M;
+    const size_t so = D.off(s);
+    const int L = D.Lw(s), M = B * L;   // this step's window
     if (s > 0) {
       const int fr = D.hist + s - 1;
       SF_TRY(gemm(w.slots_all + (size_t)fr * R * C, m->in_proj_w, m->in_proj_b, nullptr, w.tok_all + (size_t)fr * R * d, R,
                   d, C, 0, st));
     }
     hipLaunchKernelGGL(window_assemble_kernel, dim3(cdiv((long long)M * d / 4, 256)), dim3(256), 0, st,
-                       w.tok_all + (size_t)s * R * d, m->pe_tok, w.xin[0] + so * d, B, L, N, d / 4);
+                       w.tok_all + (size_t)D.f0(s) * R * d, m->pe_tok + (size_t)(D.L - L) * d, w.xin[0] + so * d, B, L, N, d / 4);
     SF_CHECK_LAUNCH();
     for (int l = 0; l < D.nl; ++l) {
       const sf_tfm_layer& ly = m->layers[l];
@@ -1135,13 +1145,12 @@ int sf_rollout_train_bwd_f32(const sf_rollouter* m, const float* d_pred, float* 
   float* base = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   const Ws w = carve(D, base);
   SF_REQUIRE(w.total_floats * sizeof(float) + 256 <= ws_bytes, "workspace too small");
-  const int d = D.d, f = D.ffn, M = D.M, R = D.R, N = D.N, C = D.C, L = D.L, hd = d / D.H;
+  const int d = D.d, f = D.ffn, R = D.R, N = D.N, C = D.C, hd = d / D.H;
   const uint32_t thr = drop_thresh(dropout_p);
   const float inv_keep = 1.f / (1.f - dropout_p);
   const float scale = 1.f / sqrtf((float)hd);
-  const int albytes = attn_lds_bytes(L, hd, true);
+  const int albytes = attn_lds_bytes(D.L, hd, true);
   SF_REQUIRE(albytes <= 64 * 1024, "attention tile does not fit LDS");
-  const long long Md4 = (long long)M * d / 4;
 
   // transposed weight copies: the data-gradient GEMMs run on the forward core (C = A . W^T)
   for (int l = 0; l < D.nl; ++l) {
@@ -1162,7 +1171,9 @@ int sf_rollout_train_bwd_f32(const sf_rollouter* m, const float* d_pred, float* 
                            w.dpred + (size_t)s * R * C, sf_rows(C), R, C, st));
 
   for (int s = D.S - 1; s >= 0; --s) {
-    const size_t so = (size_t)s * M;
+    const size_t so = D.off(s);
+    const int L = D.Lw(s), M = B * L;   // this step's window
+    const long long Md4 = (long long)M * d / 4;
     float* dp = w.dpred + (size_t)s * R * C;
     // feedback through the in-projection of the predicted frame (zero for the last step)
     if (s + 1 < D.S) {
@@ -1202,7 +1213,7 @@ int sf_rollout_train_bwd_f32(const sf_rollouter* m, const float* d_pred, float* 
                          inv_keep, M, d, 1e-5f);
       SF_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(window_scatter_kernel, dim3(cdiv(Md4, 256)), dim3(256), 0, st, dx, w.dtok + (size_t)s * R * d, B, L,
+    hipLaunchKernelGGL(window_scatter_kernel, dim3(cdiv(Md4, 256)), dim3(256), 0, st, dx, w.dtok + (size_t)D.f0(s) * R * d, B, L,
                        N, d / 4);
     SF_CHECK_LAUNCH();
   }
@@ -1217,7 +1228,7 @@ int sf_rollout_train_bwd_f32(const sf_rollouter* m, const float* d_pred, float* 
 
   // parameter gradients: one contraction per weight over all stacked rows.  The in-projection saw frames 0 .. T-2 (the
   // last predicted frame is never fed back).
-  const long long rows = (long long)D.S * M;
+  const long long rows = (long long)D.off(D.S);
   const long long in_rows = (long long)(D.T - 1) * R;
   SF_TRY(grad_weight(w.dtok, w.slots_all, g->in_proj_w, in_rows, d, C, w, st));
   SF_TRY(grad_bias(w.dtok, g->in_proj_b, in_rows, d, w, st));

@@ -261,3 +261,33 @@ def test_decoder_data_gradient_vs_oracle(dev, precision, Fr):
     ((recon - target.to(dev))**2).mean().backward()
     # ~10^7 ReLU units per frame: the kink-flip noise of L2TOL's comment, larger here
     assert l2_err(sg.grad, so.grad) < {'bf16x3': 1e-2, 'f32': 2e-3}[precision]
+
+
+def test_single_step_rollouter_grads_vs_oracle(dev, precision):
+    """PHYRE's SingleStepSlotRollouter under autograd (single_step_slotformer.py:49-90): one burn-in frame, the window grows
+    to cond_len = 6 frames (8 .. 48 tokens) and then slides; 8 layers.  Gradients against autograd of the oracle."""
+    S, B = 8, 2
+    cfg = {**gu.C5_ROLL, 'loss_dict': dict(rollout_len=S, use_img_recon_loss=False)}
+    m, sd = build(cfg, gu.load_golden('roll_c5'), 205, dev, vp=True)
+    m.train()
+    _no_dropout(m)
+    slots = gu.seeded_normal((B, 1 + S, 8, 128), 970)
+    m.loss_decay_factor = 1.0
+    x = slots.to(dev).requires_grad_(True)
+    out = m({'slots': x})
+    loss = m.calc_train_loss({'slots': x}, out)['slot_recon_loss']
+    loss.backward()
+    grads = {n: p.grad for n, p in m.named_parameters() if n.startswith('rollouter.') and p.requires_grad}
+    osd = {k: (v.clone().requires_grad_(True) if k in grads else v) for k, v in sd.items()}
+    xo = slots.clone().requires_grad_(True)
+    pred = oracle.single_step_rollouter_forward(xo[:, :1], S, osd, cfg['rollout_dict'])
+    oloss = ((pred - xo[:, 1:])**2).mean()
+    oloss.backward()
+    assert rel_err(out['pred_slots'], pred) < 1e-4
+    assert abs(float(loss.detach()) - float(oloss.detach())) < 1e-5 * abs(float(oloss.detach()))
+    # the last layer's FFN only sees gradient on the 8 newest tokens of each window (128 rows in all), so one ReLU-kink
+    # flip weighs more there than in the 4-layer sliding-window case: 2.5 x L2TOL
+    tol = 2.5 * L2TOL[precision]
+    for n in grads:
+        assert l2_err(grads[n], osd[n].grad) < tol, n
+    assert l2_err(x.grad, xo.grad) < tol
