@@ -230,6 +230,32 @@ size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B);
 int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws,
                    size_t ws_bytes, void* stream);
 
+/* ---- the SAVi image encoder under autograd ------------------------------------------------
+ * conv stack + soft position embedding + per-pixel MLP (savi.py:220-250, 367-377; utils.py:52-63) with all weight
+ * gradients.  Parameters in TORCH layouts (conv weights [Cout,Cin,5,5] for every layer; the node packs what its kernels
+ * need into the workspace on every call, because an optimizer step changes them).  The reference encoder only: 64
+ * channels, 5x5 kernels, a 64x64 feature map (first conv stride 2 at 128x128 input). */
+typedef struct {
+  int resolution, layers, channels, ks, hidden, out_channels;
+  const float* conv_w[8];
+  const float* conv_b[8];
+  const float *pos_grid, *pos_w, *pos_b;   /* SoftPositionEmbed: grid [64*64, 4] (buffer), dense.weight [C,4], dense.bias [C] */
+  const float *ln_g, *ln_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;   /* encoder_out_layer */
+} sf_savi_features;
+
+typedef struct {
+  float* conv_w[8];
+  float* conv_b[8];
+  float *pos_w, *pos_b, *ln_g, *ln_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} sf_savi_features_grads;
+
+size_t sf_savi_features_train_workspace_bytes(const sf_savi_features* m, int F);
+/* frame f (NCHW [3,H,W]) at img + f*frame_stride floats -> out [F, 64*64, out_channels] */
+int sf_savi_features_train_fwd_f32(const sf_savi_features* m, const float* img, long long frame_stride, int F, float* out,
+                                   void* ws, size_t ws_bytes, void* stream);
+int sf_savi_features_train_bwd_f32(const sf_savi_features* m, const float* img, long long frame_stride, const float* d_out,
+                                   const sf_savi_features_grads* g, int F, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- training of the Slot-Attention module ------------------------------------------------
  * SlotAttention (savi.py:36-102) under autograd: parameters in torch layouts, gradients with the same shapes (written,
  * not accumulated).  The forward keeps its activations in the caller's workspace for the backward call.

@@ -12,6 +12,7 @@ import ctypes as C
 
 import torch
 
+from ._lib import sf_savi_features, sf_savi_features_grads
 from ._lib import lib, check, sf_rollouter_grads, sf_tfm_layer_grads, sf_slot_attention, sf_slot_attention_grads, _SA_LEAVES
 from . import engine, parallel
 
@@ -225,6 +226,80 @@ def decode_with_grad(m, slots):
         raise NotImplementedError('slotformer_amd: the decoder trains only its input (weight gradients of the transposed '
                                   'convolutions are not built); freeze it as SlotFormer does (slotformer.py:203-210)')
     return _Decode.apply(m, slots)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SAVi image encoder (conv stack + position embedding + per-pixel MLP, savi.py:220-250,367-377) under autograd
+# ---------------------------------------------------------------------------------------------------------------------
+def features_parameters(m):
+    """Leaves of a StoSAVi / STEVE container that the encoder node differentiates, in bucket order."""
+    ps = []
+    for i in range(len(m.enc_channels) - 1):
+        ps += [m.encoder[i][0].weight, m.encoder[i][0].bias]
+    pe, eo = m.encoder_pos_embedding, m.encoder_out_layer
+    return ps + [pe.dense.weight, pe.dense.bias, eo[0].weight, eo[0].bias, eo[1].weight, eo[1].bias, eo[3].weight, eo[3].bias]
+
+
+class _Features(torch.autograd.Function):
+    """encoder_out [F, 64*64, C_out] = encoder_out_layer(flatten(encoder(img) + pos)) as one node (no image gradient)."""
+
+    @staticmethod
+    def forward(ctx, m, img, *params):
+        img = img.detach().float().contiguous()
+        if not img.is_cuda:
+            raise RuntimeError('slotformer_amd: inputs must live on a HIP device; there is no CPU fallback')
+        keep = [p.detach().float().contiguous() for p in params]
+        n = len(m.enc_channels) - 1
+        s = sf_savi_features()
+        s.resolution, s.layers, s.channels, s.ks = m.resolution[0], n, m.enc_channels[1], m.enc_ks
+        s.hidden, s.out_channels = m.encoder_out_layer[1].out_features, m.encoder_out_layer[3].out_features
+        if any(c != s.channels for c in m.enc_channels[1:]):
+            raise NotImplementedError('slotformer_amd: encoder training needs equal conv widths (the reference uses 64 everywhere)')
+        for i in range(n):
+            s.conv_w[i], s.conv_b[i] = keep[2 * i].data_ptr(), keep[2 * i + 1].data_ptr()
+        grid = m.encoder_pos_embedding.grid.detach().float().reshape(-1, 4).contiguous()
+        keep.append(grid)
+        s.pos_grid = grid.data_ptr()
+        for name, t in zip(('pos_w', 'pos_b', 'ln_g', 'ln_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b'), keep[2 * n:2 * n + 8]):
+            setattr(s, name, t.data_ptr())
+        F_ = img.shape[0]
+        nbytes = lib().sf_savi_features_train_workspace_bytes(C.byref(s), F_)
+        if nbytes == 0:
+            check(-1)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=img.device)
+        out = torch.empty(F_, 64 * 64, s.out_channels, dtype=torch.float32, device=img.device)
+        check(lib().sf_savi_features_train_fwd_f32(C.byref(s), img.data_ptr(), img[0].numel(), F_, out.data_ptr(), ws.data_ptr(),
+                                                   ws.numel(), torch.cuda.current_stream().cuda_stream))
+        ctx.m, ctx.s, ctx.keep, ctx.ws, ctx.img, ctx.params = m, s, keep, ws, img, params
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        s, params, img = ctx.s, ctx.params, ctx.img
+        d_out = d_out.float().contiguous()
+        flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=d_out.device)
+        ptrs, off = [], 0
+        for p in params:
+            ptrs.append(flat.data_ptr() + 4 * off)
+            off += p.numel()
+        g = sf_savi_features_grads()
+        n = s.layers
+        for i in range(n):
+            g.conv_w[i], g.conv_b[i] = ptrs[2 * i], ptrs[2 * i + 1]
+        for name, ptr in zip(('pos_w', 'pos_b', 'ln_g', 'ln_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b'), ptrs[2 * n:]):
+            setattr(g, name, ptr)
+        check(lib().sf_savi_features_train_bwd_f32(C.byref(s), img.data_ptr(), img[0].numel(), d_out.data_ptr(), C.byref(g), img.shape[0],
+                                                   ctx.ws.data_ptr(), ctx.ws.numel(), torch.cuda.current_stream().cuda_stream))
+        ctx.ws = None
+        if getattr(ctx.m, 'ddp_flat_bucket', False):
+            parallel.allreduce_flat(flat)
+        grads = _split(flat, params)
+        return (None, None) + tuple(g_ if ctx.needs_input_grad[2 + i] else None for i, g_ in enumerate(grads))
+
+
+def features_with_grad(m, img):
+    """img [F, 3, H, W] -> encoder_out [F, 64*64, enc_out_channels] under autograd (savi.py:367-377)."""
+    return _Features.apply(m, img, *features_parameters(m))
 
 
 def dropout_keep_mask(seed, step, layer, site, numel, p):

@@ -291,3 +291,29 @@ def test_single_step_rollouter_grads_vs_oracle(dev, precision):
     for n in grads:
         assert l2_err(grads[n], osd[n].grad) < tol, n
     assert l2_err(x.grad, xo.grad) < tol
+
+
+@pytest.mark.parametrize('cfg_name,Fr', [('C2', 3), ('C1', 2)])
+def test_savi_encoder_features_backward(dev, precision, cfg_name, Fr):
+    """The SAVi image encoder under autograd (conv stack 3 -> 64 -> 64 -> 64 -> 64, position embedding, per-pixel MLP;
+    savi.py:220-250,367-377): output and every parameter gradient against autograd of the oracle.  C2: 128x128 input
+    (first conv stride 2), C1: 64x64."""
+    from slotformer_amd import train
+    cfg = gu.C2_SAVI if cfg_name == 'C2' else gu.C1_SAVI
+    m, sd = build(cfg, gu.load_golden('savi_c2' if cfg_name == 'C2' else 'savi_c1'), 103, dev)
+    m.train()
+    img = gu.seeded_img(1, Fr, cfg['resolution'][0], 77)[0]
+    dout = gu.seeded_normal((Fr, 4096, cfg['slot_dict'].get('enc_out', 128) if False else m.enc_out_channels), 78)
+    names = [n for n, _ in m.named_parameters() if n.startswith(('encoder.', 'encoder_pos_embedding.dense', 'encoder_out_layer.'))]
+    osd = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    ref = oracle.savi_encoder_out(img, osd, cfg)
+    ref.backward(dout)
+    out = train.features_with_grad(m, img.to(dev))
+    out.backward(dout.to(dev))
+    assert rel_err(out, ref) < 1e-4
+    tol = 2.5 * L2TOL[precision]   # millions of ReLU units: kink-flip noise, see L2TOL
+    got = dict(m.named_parameters())
+    assert len(names) == 2 * 4 + 2 + 6
+    for n in names:
+        assert got[n].grad is not None, n
+        assert l2_err(got[n].grad, osd[n].grad) < tol, n
