@@ -386,11 +386,20 @@ int sf_savi_decode_f32(const sf_savi_decoder* m, const float* slots, float* reco
  * backward maps d_recon_combined [F,3,H,W] to d_slots [F,N,D].  deconv_w_bwd: HOST array [dec_layers] of device pointers
  * to sf_pack_conv_weight_f32(torch ConvTranspose2d weight [Cin,Cout,k,k]) = [Cin][k][k][Cout]: the adjoint of a
  * transposed convolution is a strided convolution with the same weights. */
+typedef struct { /* gradients in torch layouts: ConvTranspose2d weight [Cin,Cout,k,k], head Conv2d [4,C,1,1], dense [D,4] */
+  float* deconv_w[8];
+  float* deconv_b[8];
+  float *out_w, *out_b, *pos_w, *pos_b;
+} sf_savi_decoder_grads;
+
 size_t sf_savi_decode_train_workspace_bytes(const sf_savi_decoder* m, int F);
 int sf_savi_decode_train_fwd_f32(const sf_savi_decoder* m, const float* slots, float* recon_combined, float* recons,
                                  float* masks, int F, void* ws, size_t ws_bytes, void* stream);
+/* g != NULL (SAVi's own training, savi.py:527-538): also the decoder's parameter gradients; pos_grid [dec_res^2, 4] is
+ * decoder_pos_embedding.grid.  Needs the reference decoder widths (64 channels after the first layer). */
 int sf_savi_decode_train_bwd_f32(const sf_savi_decoder* m, const float* const* deconv_w_bwd, const float* d_recon,
-                                 float* d_slots, int F, void* ws, size_t ws_bytes, void* stream);
+                                 float* d_slots, const float* pos_grid, const sf_savi_decoder_grads* g, int F, void* ws,
+                                 size_t ws_bytes, void* stream);
 
 
 /* ---- K/V producer (SURVEY.md 8(b2) sf_kv_producer_*) ---------------------------------------- */

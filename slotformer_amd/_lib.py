@@ -50,6 +50,10 @@ class sf_slot_attention_grads(C.Structure):
     _fields_ = [(n, FP) for n in _SA_LEAVES]
 
 
+class sf_savi_decoder_grads(C.Structure):
+    _fields_ = [('deconv_w', FP * 8), ('deconv_b', FP * 8)] + [(n, FP) for n in ('out_w', 'out_b', 'pos_w', 'pos_b')]
+
+
 class sf_savi_features(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('resolution', 'layers', 'channels', 'ks', 'hidden', 'out_channels')] + [
         ('conv_w', FP * 8), ('conv_b', FP * 8)] + [(n, FP) for n in ('pos_grid', 'pos_w', 'pos_b', 'ln_g', 'ln_b', 'fc1_w', 'fc1_b',
@@ -141,7 +145,8 @@ SIGNATURES = {
                                             VP, SZ, VP]),
     'sf_savi_decode_train_workspace_bytes': (SZ, [C.POINTER(sf_savi_decoder), I]),
     'sf_savi_decode_train_fwd_f32': (I, [C.POINTER(sf_savi_decoder), FP, FP, FP, FP, I, VP, SZ, VP]),
-    'sf_savi_decode_train_bwd_f32': (I, [C.POINTER(sf_savi_decoder), C.POINTER(C.c_void_p), FP, FP, I, VP, SZ, VP]),
+    'sf_savi_decode_train_bwd_f32': (I, [C.POINTER(sf_savi_decoder), C.POINTER(C.c_void_p), FP, FP, FP, C.POINTER(sf_savi_decoder_grads),
+                                         I, VP, SZ, VP]),
     'sf_savi_features_train_workspace_bytes': (SZ, [C.POINTER(sf_savi_features), I]),
     'sf_savi_features_train_fwd_f32': (I, [C.POINTER(sf_savi_features), FP, LL, I, FP, VP, SZ, VP]),
     'sf_savi_features_train_bwd_f32': (I, [C.POINTER(sf_savi_features), FP, LL, FP, C.POINTER(sf_savi_features_grads), I, VP, SZ, VP]),

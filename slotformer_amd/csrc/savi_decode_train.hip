@@ -53,10 +53,39 @@ __global__ __launch_bounds__(256) void broadcast_bwd_kernel(const float* __restr
   }
 }
 
+// head weight gradient: part[g][j][c] = sum over the rows of chunk g of d_dec[m][j] * act[m][c]   (j < 4, c < Cl <= 64)
+__global__ __launch_bounds__(256) void head_grad_partial_kernel(const float* __restrict__ d_dec, const float* __restrict__ act,
+                                                                float* __restrict__ part, long long rows, int rpg, int Cl) {
+  __shared__ float red[4][4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long long r0 = (long long)blockIdx.x * rpg, r1 = r0 + rpg < rows ? r0 + rpg : rows;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < Cl)
+    for (long long r = r0 + rl; r < r1; r += 4) {
+      const f32x4 d = *(const f32x4*)(d_dec + r * 4);
+      const float x = act[r * Cl + c];
+      a[0] += d[0] * x; a[1] += d[1] * x; a[2] += d[2] * x; a[3] += d[3] * x;
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[rl][j][c] = a[j];
+  __syncthreads();
+  if (rl == 0 && c < Cl)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      part[((long long)blockIdx.x * 4 + j) * Cl + c] = (red[0][j][c] + red[1][j][c]) + (red[2][j][c] + red[3][j][c]);
+}
+__global__ __launch_bounds__(256) void head_grad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int G, int n) {
+  const int i = threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int g = 0; g < G; ++g) a += part[(long long)g * n + i];
+  out[i] = a;
+}
+
 namespace {
 struct DecWs {
   float* act[9];   // act[0]: broadcast input, act[l+1]: output of transposed conv l (post-ReLU)
-  float *dec, *ga, *gb, *wout_t;
+  float *dec, *ga, *gb, *wout_t, *partial, *dtab;
   size_t total;
 };
 size_t pad64(size_t n) { return (n + 63) & ~(size_t)63; }
@@ -84,6 +113,15 @@ DecWs carve(const sf_savi_decoder* m, int F, float* base) {
   w.ga = take(gmax);
   w.gb = take(gmax);
   w.wout_t = take((size_t)4 * m->dec_channels[m->dec_layers]);
+  {
+    size_t pf = (size_t)513 * 2 * 256;   // bias column sums, head partials
+    for (int l = 0; l < m->dec_layers; ++l) {
+      const size_t a = sf_conv_wgrad_partial_floats(m->dec_channels[l], m->dec_ks);
+      pf = a > pf ? a : pf;
+    }
+    w.partial = take(pf);
+  }
+  w.dtab = take((size_t)m->dec_res * m->dec_res * m->slot_size);
   w.total = off;
   return w;
 }
@@ -137,9 +175,15 @@ int sf_savi_decode_train_fwd_f32(const sf_savi_decoder* m, const float* slots, f
 }
 
 int sf_savi_decode_train_bwd_f32(const sf_savi_decoder* m, const float* const* deconv_w_bwd, const float* d_recon, float* d_slots,
-                                 int F, void* ws, size_t ws_bytes, void* stream) {
+                                 const float* pos_grid, const sf_savi_decoder_grads* g_out, int F, void* ws, size_t ws_bytes,
+                                 void* stream) {
   SF_TRY(check(m, F));
   SF_REQUIRE(deconv_w_bwd && d_recon && d_slots && ws, "null pointer");
+  SF_REQUIRE(g_out == nullptr || pos_grid != nullptr, "weight gradients need the position grid");
+  if (g_out)
+    for (int l = 0; l < m->dec_layers; ++l)
+      SF_REQUIRE(m->dec_channels[l + 1] == 64 && m->dec_channels[l] % 64 == 0 && m->dec_channels[m->dec_layers] <= 64,
+                 "decoder weight gradients need 64-channel layers (the reference decoder)");
   const DecWs w = carve(m, F, (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255));
   SF_REQUIRE(w.total * sizeof(float) + 256 <= ws_bytes, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -150,6 +194,17 @@ int sf_savi_decode_train_bwd_f32(const sf_savi_decoder* m, const float* const* d
     hipLaunchKernelGGL(decode_combine_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w.dec, d_recon, w.gb, F, N,
                        HW);
     SF_CHECK_LAUNCH();
+  }
+  if (g_out) {   // 1x1 head: weight [4, Cl] and bias [4]
+    const long long rows = (long long)R * HW;
+    int G = 512;
+    const int rpg = (int)((rows + G - 1) / G);
+    G = (int)((rows + rpg - 1) / rpg);
+    hipLaunchKernelGGL(head_grad_partial_kernel, dim3(G), dim3(256), 0, st, w.gb, w.act[L], w.partial, rows, rpg, Cl);
+    SF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(head_grad_reduce_kernel, dim3(1), dim3(256), 0, st, w.partial, g_out->out_w, G, 4 * Cl);
+    SF_CHECK_LAUNCH();
+    SF_TRY(sf_grad_bias_ex(w.gb, g_out->out_b, rows, 4, w.partial, st));
   }
   // head: d_act[L] = d_dec . W_out   (W_out [4, Cl]; the GEMM core wants its transpose as the weight operand)
   SF_TRY(sf_transpose_ex(m->out_w, w.wout_t, 4, Cl, st));
@@ -162,6 +217,12 @@ int sf_savi_decode_train_bwd_f32(const sf_savi_decoder* m, const float* const* d
     SF_REQUIRE(deconv_w_bwd[l] != nullptr, "null backward weight");
     const long long n = (long long)R * h * h * m->dec_channels[l + 1];
     SF_TRY(sf_relu_bwd_ex(g, w.act[l + 1], n, st));
+    if (g_out) {   // transposed-conv weight [C_l, C_{l+1}, k, k] and bias: A = the layer input, X = this gradient on the finer grid
+      const int hin = h / m->dec_strides[l];
+      SF_TRY(sf_grad_bias_ex(g, g_out->deconv_b[l], (long long)R * h * h, m->dec_channels[l + 1], w.partial, st));
+      SF_TRY(sf_conv_wgrad_ex(w.act[l], m->dec_channels[l], hin, hin, g, h, h, m->dec_strides[l], m->dec_ks, (long long)R * hin * hin,
+                              g_out->deconv_w[l], w.partial, st));
+    }
     SF_TRY(sf_conv2d_nhwc_strided_ex(g, deconv_w_bwd[l], nullptr, o, R, h, h, m->dec_channels[l + 1], m->dec_channels[l], m->dec_ks,
                                      m->dec_strides[l], 0, st));
     h /= m->dec_strides[l];
@@ -169,6 +230,7 @@ int sf_savi_decode_train_bwd_f32(const sf_savi_decoder* m, const float* const* d
     g = o;
     o = t;
   }
+  if (g_out) SF_TRY(sf_pos_dense_grad_ex(g, R, m->dec_res * m->dec_res, D, pos_grid, g_out->pos_w, g_out->pos_b, w.dtab, st));
   hipLaunchKernelGGL(broadcast_bwd_kernel, dim3(R), dim3(256), 0, st, g, d_slots, m->dec_res * m->dec_res, D);
   SF_CHECK_LAUNCH();
   return 0;

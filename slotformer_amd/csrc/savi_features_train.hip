@@ -22,16 +22,19 @@ __device__ __forceinline__ void cw_split8(const f32x8 v, bf16x8& hi, bf16x8& lo)
   lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
 }
 
-// dW[co][tap][ci] = sum over pixels (f, y, x) of dY[f, y, x, co] * X[f, y + dy, x + dx, ci]   (64 -> 64 channels, "same" padding)
-// grid (ks*ks taps, splits); partial [split][64][ks*ks*64].  Same structure as grad_gemm_tn_kernel.
+// dW[n][tap][k] = sum over pixels (f, y, x) of A[f, y, x, n] * X[f, y*s + dy, x*s + dx, k]:  A [rows, CA] lives on an H x W
+// grid, X [*, 64] on an Hx x Wx grid, (dy, dx) = tap - ks/2, zero outside the image.
+//   conv weight gradient       : A = dY (n = c_out), X = the layer input (k = c_in), s = 1
+//   transposed-conv weight grad: A = the layer input (n = c_in), X = dY on the s-times finer output grid (k = c_out)
+// grid (ks*ks taps * CA/64, splits); partial [split][CA][ks*ks*64].  Same structure as grad_gemm_tn_kernel.
 template <bool EXACT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                          float* __restrict__ partial, long long rows, int rps, int H, int W,
-                                                         int ks) {
+                                                         int ks, int CA, int s, int Hx, int Wx) {
   __shared__ float Ys[32 * CW_P];
   __shared__ float Xs[32 * CW_P];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int tap = blockIdx.x, dy = tap / ks - ks / 2, dx = tap % ks - ks / 2;
+  const int nt = CA / 64, tap = blockIdx.x / nt, n0 = (blockIdx.x % nt) * 64, dy = tap / ks - ks / 2, dx = tap % ks - ks / 2;
   const long long r0 = (long long)blockIdx.y * rps;
   const long long r1 = r0 + rps < rows ? r0 + rps : rows;
   const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;
@@ -42,19 +45,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   const int nrows = (int)(r1 - r0);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const int hw = H * W;
-  auto xload = [&](long long r) {   // activation row of pixel r shifted by the tap, zero outside the image
-    const int rr = (int)(r % hw), y = rr / W, x = rr - y * W;
-    const bool ok = (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
-    const float4 v = *reinterpret_cast<const float4*>(X + (ok ? r + dy * W + dx : r) * 64 + lc);
+  auto xload = [&](long long r) {   // X row of pixel r moved by the tap, zero outside the image
+    const long long f = r / hw;
+    const int rr = (int)(r - f * hw), y = rr / W, x = rr - y * W;
+    const int yy = y * s + dy, xx = x * s + dx;
+    const bool ok = (unsigned)yy < (unsigned)Hx && (unsigned)xx < (unsigned)Wx;
+    const float4 v = *reinterpret_cast<const float4*>(X + ((f * Hx + (ok ? yy : 0)) * Wx + (ok ? xx : 0)) * 64 + lc);
     return ok ? v : zero4;
   };
   float4 py0 = zero4, py1 = zero4, px0 = zero4, px1 = zero4;
   if (lr < nrows) {
-    py0 = *reinterpret_cast<const float4*>(dY + (r0 + lr) * 64 + lc);
+    py0 = *reinterpret_cast<const float4*>(dY + (r0 + lr) * CA + n0 + lc);
     px0 = xload(r0 + lr);
   }
   if (lr + 16 < nrows) {
-    py1 = *reinterpret_cast<const float4*>(dY + (r0 + lr + 16) * 64 + lc);
+    py1 = *reinterpret_cast<const float4*>(dY + (r0 + lr + 16) * CA + n0 + lc);
     px1 = xload(r0 + lr + 16);
   }
   for (int rb = 0; rb < nrows; rb += 32) {
@@ -67,11 +72,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     py0 = py1 = px0 = px1 = zero4;
     const int ra = rb + 32 + lr;
     if (ra < nrows) {
-      py0 = *reinterpret_cast<const float4*>(dY + (r0 + ra) * 64 + lc);
+      py0 = *reinterpret_cast<const float4*>(dY + (r0 + ra) * CA + n0 + lc);
       px0 = xload(r0 + ra);
     }
     if (ra + 16 < nrows) {
-      py1 = *reinterpret_cast<const float4*>(dY + (r0 + ra + 16) * 64 + lc);
+      py1 = *reinterpret_cast<const float4*>(dY + (r0 + ra + 16) * CA + n0 + lc);
       px1 = xload(r0 + ra + 16);
     }
 #pragma unroll
@@ -94,10 +99,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     }
   }
   const int K = ks * ks * 64;
-  float* out = partial + (long long)blockIdx.y * 64 * K;
+  float* out = partial + (long long)blockIdx.y * CA * K;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int n = wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int n = n0 + wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     out[(long long)n * K + tap * 64 + wk + (lane & 31)] = acc[r];
   }
 }
@@ -182,6 +187,40 @@ __global__ __launch_bounds__(256) void pos_dense_grad_kernel(const float* __rest
   if (t == 4) db[c] = red[4][0];
 }
 
+// weight gradient of a 64-input-channel "same" convolution (s = 1, A = dY) or of a transposed convolution (A = its input, X = dY
+// on the finer grid), written in torch layout [CA][64][ks][ks]
+int sf_conv_wgrad_ex(const float* A, int CA, int H, int W, const float* X, int Hx, int Wx, int s, int ks, long long rows,
+                     float* out_oihw, float* partial, hipStream_t st) {
+  SF_REQUIRE(CA % 64 == 0 && ks * ks <= 25, "conv weight gradient: channel multiple of 64, at most 5x5");
+  const int taps = ks * ks, nt = CA / 64;
+  int splits = 512 / (taps * nt);
+  if (splits < 1) splits = 1;
+  if ((long long)splits * 64 > rows) splits = (int)((rows + 63) / 64);
+  int rps = (int)((rows + splits - 1) / splits);
+  rps = (rps + 31) & ~31;
+  const dim3 grid(taps * nt, splits);
+  if (sf_get_precision() == 0)
+    hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, ks, CA, s, Hx, Wx);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, ks, CA, s, Hx, Wx);
+  SF_CHECK_LAUNCH();
+  const int total = CA * 64 * taps;
+  hipLaunchKernelGGL(reduce_to_oihw_kernel, dim3((total + 255) / 256), dim3(256), 0, st, partial, out_oihw, splits, CA, 64, taps);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+size_t sf_conv_wgrad_partial_floats(int CA, int ks) { return (size_t)24 * CA * ks * ks * 64; }
+
+// SoftPositionEmbed gradients from d [F][HW][C] (the table is added to every frame); dtab: scratch [HW*C]
+int sf_pos_dense_grad_ex(const float* d, int F, int HW, int C, const float* grid, float* dw, float* db, float* dtab, hipStream_t st) {
+  const long long per = (long long)HW * C;
+  hipLaunchKernelGGL(frame_sum_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, d, dtab, F, per);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(pos_dense_grad_kernel, dim3(C), dim3(256), 0, st, dtab, grid, dw, db, HW, C);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
 namespace {
 struct FDims {
   int F, res, L, C, Hd, Co, stride;
@@ -219,7 +258,7 @@ FWs carve(const FDims& d, float* base) {
   w.dtab = take((size_t)4096 * C);
   w.dw0 = take((size_t)C * 128);
   size_t pf = sf_grad_partial_floats(d.M, d.Hd, d.C);
-  const size_t alt[] = {sf_grad_partial_floats(d.M, d.Co, d.Hd), sf_grad_partial_floats(d.M, C, 128), (size_t)64 * C * 25 * C};
+  const size_t alt[] = {sf_grad_partial_floats(d.M, d.Co, d.Hd), sf_grad_partial_floats(d.M, C, 128), sf_conv_wgrad_partial_floats(C, 5)};
   for (size_t x : alt) pf = x > pf ? x : pf;
   w.partial = take(pf);
   w.total = off;
@@ -294,33 +333,13 @@ int sf_savi_features_train_bwd_f32(const sf_savi_features* m, const float* img, 
   SF_TRY(sf_grad_ln_ex(w.a[L - 1], w.ga, g->ln_g, g->ln_b, M, C, 1e-5f, w.partial, st));
   SF_TRY(sf_ln_bwd_ex(w.a[L - 1], w.ga, m->ln_g, nullptr, w.gb, M, C, 1e-5f, st));   // gb = d(conv_last + table)
   // soft position embedding
-  {
-    const long long per = (long long)4096 * C;
-    hipLaunchKernelGGL(frame_sum_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, w.gb, w.dtab, F, per);
-    SF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pos_dense_grad_kernel, dim3(C), dim3(256), 0, st, w.dtab, m->pos_grid, g->pos_w, g->pos_b, 4096, C);
-    SF_CHECK_LAUNCH();
-  }
+  SF_TRY(sf_pos_dense_grad_ex(w.gb, F, 4096, C, m->pos_grid, g->pos_w, g->pos_b, w.dtab, st));
   // conv stack, last to first; cur = gradient w.r.t. the (pre-activation) output of conv i
   float* cur = w.gb;
   float* nxt = w.ga;
-  const int exact = sf_get_precision() == 0;
   for (int i = L - 1; i >= 1; --i) {
     SF_TRY(sf_grad_bias_ex(cur, g->conv_b[i], M, C, w.partial, st));
-    {
-      int splits = 20;   // 25 taps x 20 row ranges = 500 workgroups
-      int rps = (int)((M + splits - 1) / splits);
-      rps = (rps + 31) & ~31;
-      const dim3 grid(25, splits);
-      if (exact)
-        hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, st, cur, w.a[i - 1], w.partial, M, rps, 64, 64, 5);
-      else
-        hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, cur, w.a[i - 1], w.partial, M, rps, 64, 64, 5);
-      SF_CHECK_LAUNCH();
-      const int total = C * C * 25;
-      hipLaunchKernelGGL(reduce_to_oihw_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w.partial, g->conv_w[i], splits, C, C, 25);
-      SF_CHECK_LAUNCH();
-    }
+    SF_TRY(sf_conv_wgrad_ex(cur, C, 64, 64, w.a[i - 1], 64, 64, 1, 5, M, g->conv_w[i], w.partial, st));
     // data gradient: convolution with the flipped / transposed kernel, then the ReLU of the layer below
     hipLaunchKernelGGL(pack_conv_bwd_kernel, dim3((C * C * 25 + 255) / 256), dim3(256), 0, st, m->conv_w[i], w.wb[i], C, C, 5);
     SF_CHECK_LAUNCH();

@@ -53,3 +53,7 @@ int sf_transpose_ex(const float* in, float* out, int R, int Cn, hipStream_t st);
 int sf_relu_bwd_ex(float* dh, const float* h, long long n, hipStream_t st);
 int sf_conv2d_nhwc_strided_ex(const float* in, const float* w_packed, const float* bias, float* out, int F, int Hin, int Win,
                               int Cin, int Cout, int ks, int stride, int relu, hipStream_t stream);
+int sf_conv_wgrad_ex(const float* A, int CA, int H, int W, const float* X, int Hx, int Wx, int s, int ks, long long rows,
+                     float* out_oihw, float* partial, hipStream_t st);
+size_t sf_conv_wgrad_partial_floats(int CA, int ks);
+int sf_pos_dense_grad_ex(const float* d, int F, int HW, int C, const float* grid, float* dw, float* db, float* dtab, hipStream_t st);

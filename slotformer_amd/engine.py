@@ -343,7 +343,7 @@ def decoder_plan(m):
 
 def savi_decode(m, slots, ws_slot=0):
     """StoSAVi.decode on device: slots [F,N,D] -> (recon_combined [F,3,H,W], recons [F,N,3,H,W], masks [F,N,1,H,W])."""
-    if torch.is_grad_enabled() and slots.requires_grad:
+    if torch.is_grad_enabled() and (slots.requires_grad or any(p.requires_grad for p in m.decoder.parameters())):
         from . import train
         return train.decode_with_grad(m, slots)   # one autograd node, data gradient only (row N1)
     if not slots.is_cuda:

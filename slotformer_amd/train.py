@@ -12,7 +12,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import sf_savi_features, sf_savi_features_grads
+from ._lib import sf_savi_features, sf_savi_features_grads, sf_savi_decoder_grads
 from ._lib import lib, check, sf_rollouter_grads, sf_tfm_layer_grads, sf_slot_attention, sf_slot_attention_grads, _SA_LEAVES
 from . import engine, parallel
 
@@ -180,11 +180,22 @@ def slot_attention_with_grad(sa, inputs, slots):
 # ---------------------------------------------------------------------------------------------------------------------
 # SAVi decoder under autograd (data gradient only: the image term of SlotFormer's loss; the decoder is frozen there)
 # ---------------------------------------------------------------------------------------------------------------------
+def decoder_parameters(m):
+    """Leaves of the spatial-broadcast decoder in bucket order: (weight, bias) per transposed conv, the 1x1 head, the
+    position-embedding Linear."""
+    n = len(m.dec_channels) - 1
+    ps = []
+    for i in range(n):
+        ps += [m.decoder[i][0].weight, m.decoder[i][0].bias]
+    return ps + [m.decoder[n].weight, m.decoder[n].bias, m.decoder_pos_embedding.dense.weight, m.decoder_pos_embedding.dense.bias]
+
+
 class _Decode(torch.autograd.Function):
-    """(recon_combined, recons, masks) = decode(slots); only recon_combined carries a gradient (slotformer.py:313-326)."""
+    """(recon_combined, recons, masks) = decode(slots); only recon_combined carries a gradient (savi.py:527-538,
+    slotformer.py:313-326).  Parameter gradients are produced iff the decoder is not frozen."""
 
     @staticmethod
-    def forward(ctx, m, slots):
+    def forward(ctx, m, slots, *params):
         from . import ops
         slots = slots.detach().float().contiguous()
         if not slots.is_cuda:
@@ -205,27 +216,48 @@ class _Decode(torch.autograd.Function):
         masks = torch.empty(F_, N, 1, H, H, device=slots.device, dtype=torch.float32)
         check(lib().sf_savi_decode_train_fwd_f32(C.byref(plan.struct), slots.data_ptr(), recon.data_ptr(), recons.data_ptr(),
                                                  masks.data_ptr(), F_, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
-        ctx.plan, ctx.ws, ctx.shape = plan, ws, (F_, N, D)
+        ctx.m, ctx.plan, ctx.ws, ctx.shape, ctx.params = m, plan, ws, (F_, N, D), params
         ctx.mark_non_differentiable(recons, masks)
         return recon, recons, masks
 
     @staticmethod
     def backward(ctx, d_recon, _d_recons, _d_masks):
         F_, N, D = ctx.shape
+        params, m = ctx.params, ctx.m
         d_recon = d_recon.float().contiguous()
         d_slots = torch.empty(F_, N, D, device=d_recon.device, dtype=torch.float32)
-        check(lib().sf_savi_decode_train_bwd_f32(C.byref(ctx.plan.struct), ctx.plan.bwd_w, d_recon.data_ptr(), d_slots.data_ptr(), F_,
-                                                 ctx.ws.data_ptr(), ctx.ws.numel(), torch.cuda.current_stream().cuda_stream))
+        g, grid, flat = None, None, None
+        if params:
+            flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=d_recon.device)
+            ptrs, off = [], 0
+            for p in params:
+                ptrs.append(flat.data_ptr() + 4 * off)
+                off += p.numel()
+            g = sf_savi_decoder_grads()
+            n = ctx.plan.struct.dec_layers
+            for i in range(n):
+                g.deconv_w[i], g.deconv_b[i] = ptrs[2 * i], ptrs[2 * i + 1]
+            g.out_w, g.out_b, g.pos_w, g.pos_b = ptrs[2 * n:2 * n + 4]
+            grid = m.decoder_pos_embedding.grid.detach().float().reshape(-1, 4).contiguous()
+        check(lib().sf_savi_decode_train_bwd_f32(C.byref(ctx.plan.struct), ctx.plan.bwd_w, d_recon.data_ptr(), d_slots.data_ptr(),
+                                                 grid.data_ptr() if grid is not None else None, C.byref(g) if g is not None else None,
+                                                 F_, ctx.ws.data_ptr(), ctx.ws.numel(), torch.cuda.current_stream().cuda_stream))
         ctx.ws = None
-        return None, d_slots
+        grads = ()
+        if params:
+            if getattr(m, 'ddp_flat_bucket', False):
+                parallel.allreduce_flat(flat)
+            grads = tuple(g_ if ctx.needs_input_grad[2 + i] else None for i, g_ in enumerate(_split(flat, params)))
+        return (None, d_slots if ctx.needs_input_grad[1] else None) + grads
 
 
 def decode_with_grad(m, slots):
-    """StoSAVi.decode (savi.py:504-525) with d(recon_combined)/d(slots); the decoder's own parameters must be frozen."""
-    if any(p.requires_grad for p in list(m.decoder.parameters()) + list(m.decoder_pos_embedding.parameters())):
-        raise NotImplementedError('slotformer_amd: the decoder trains only its input (weight gradients of the transposed '
-                                  'convolutions are not built); freeze it as SlotFormer does (slotformer.py:203-210)')
-    return _Decode.apply(m, slots)
+    """StoSAVi.decode (savi.py:504-525) under autograd: d(recon_combined)/d(slots), plus the decoder's own parameter
+    gradients unless it is frozen (as in SlotFormer, slotformer.py:203-210)."""
+    params = decoder_parameters(m)
+    if not any(p.requires_grad for p in params):
+        params = []
+    return _Decode.apply(m, slots, *params)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -317,3 +317,28 @@ def test_savi_encoder_features_backward(dev, precision, cfg_name, Fr):
     for n in names:
         assert got[n].grad is not None, n
         assert l2_err(got[n].grad, osd[n].grad) < tol, n
+
+
+def test_decoder_parameter_gradients_vs_oracle(dev, precision):
+    """SAVi's own training objective back-propagates into the decoder (savi.py:527-538): gradients of the four transposed
+    convs, the 1x1 head, the position-embedding Linear and the slots at the CLEVRER decoder shape."""
+    cfg = gu.savi_cfg(64, 7, kernel_mlp=False, pred='mlp', rnn=False)
+    m, sd = build(cfg, gu.load_golden('decode_c2'), 401, dev)
+    m.train()
+    Fr = 3
+    slots = gu.seeded_normal((Fr, 7, 128), 41)
+    target = gu.seeded_img(1, Fr, 64, 42)[0]
+    names = [n for n, _ in m.named_parameters() if n.startswith(('decoder.', 'decoder_pos_embedding.dense'))]
+    osd = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    so = slots.clone().requires_grad_(True)
+    ((oracle.savi_decode(so, osd, cfg)[0] - target)**2).mean().backward()
+    sg = slots.to(dev).requires_grad_(True)
+    recon = m.decode(sg)[0]
+    ((recon - target.to(dev))**2).mean().backward()
+    tol = {'bf16x3': 1e-2, 'f32': 2e-3}[precision]
+    got = dict(m.named_parameters())
+    assert len(names) == 2 * 4 + 2 + 2
+    for n in names:
+        assert got[n].grad is not None, n
+        assert l2_err(got[n].grad, osd[n].grad) < tol, n
+    assert l2_err(sg.grad, so.grad) < tol
