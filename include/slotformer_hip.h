@@ -230,6 +230,17 @@ size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B);
 int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws,
                    size_t ws_bytes, void* stream);
 
+/* ---- differentiable building blocks for the slot-level layers --------------------------------
+ * (predictor, kernel distribution: savi.py:190-200, predictor.py:47-73).  Backward of y = act(x W^T + b): dW [N,K],
+ * db [N] (or NULL), dx [M,K] (or NULL); with relu != 0, dy is first masked in place by y > 0.  N, K multiples of 64. */
+size_t sf_linear_bwd_workspace_bytes(long long M, int N, int K);
+int sf_linear_bwd_f32(const float* x, const float* W, const float* y, float* dy, float* dx, float* dW, float* db, long long M,
+                      int N, int K, int relu, void* ws, size_t ws_bytes, void* stream);
+/* Backward of nn.LayerNorm over the last dimension (D <= 1024, D % 4 == 0). */
+size_t sf_layernorm_bwd_workspace_bytes(int D);
+int sf_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                         long long rows, int D, float eps, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- the SAVi image encoder under autograd ------------------------------------------------
  * conv stack + soft position embedding + per-pixel MLP (savi.py:220-250, 367-377; utils.py:52-63) with all weight
  * gradients.  Parameters in TORCH layouts (conv weights [Cout,Cin,5,5] for every layer; the node packs what its kernels

@@ -16,7 +16,7 @@ __all__ = [
     'build_grid', 'get_sin_pos_enc', 'layer_norm', 'gru_cell', 'lstm_cell',
     'mha_self', 'transformer_encoder_layer', 'transformer_encoder',
     'savi_encoder_out', 'slot_attention', 'slot_attention_updates', 'slot_update', 'predictor_step', 'kernel_dist',
-    'sample_dist', 'savi_encode', 'steve_encode', 'savi_forward_chunked',
+    'sample_dist', 'kernel_kld', 'savi_encode', 'steve_encode', 'savi_forward_chunked',
     'rollouter_forward', 'rollouter_forward_train', 'single_step_rollouter_forward', 'slotformer_forward',
     'savi_decode', 'postproc_mask', 'rollout_video_slots', 'phyre_encode_rollout',
     'slot_mse_losses', 'dvae_logits', 'dvae_tokenize', 'dvae_detokenize', 'steve_decoder_forward',
@@ -221,6 +221,19 @@ def sample_dist(dist, cfg, noise):
     if _kld_method(cfg) == 'none':
         return mu
     return mu + noise * torch.exp(dist[..., D:] * 0.5)
+
+
+def kernel_kld(dist, cfg):
+    """StoSAVi._kld_loss, savi.py:338-353: KL(N(mu, var) || N(mu, prior_var)) summed over channels, mean over the rest."""
+    if _kld_method(cfg) == 'none':
+        return torch.zeros((), dtype=dist.dtype)
+    import math
+    D = cfg['slot_dict']['slot_size']
+    parts = cfg['loss_dict']['kld_method'].split('-')
+    prior = math.log(float(parts[1])) if len(parts) > 1 else 0.0
+    log_var = dist[..., D:]
+    kld = 0.5 * (prior - log_var) + torch.exp(log_var) / (2. * math.exp(prior)) - 0.5
+    return kld.sum(-1).mean()
 
 
 def predictor_step(x, sd, cfg, state):

@@ -150,6 +150,10 @@ SIGNATURES = {
     'sf_savi_features_train_workspace_bytes': (SZ, [C.POINTER(sf_savi_features), I]),
     'sf_savi_features_train_fwd_f32': (I, [C.POINTER(sf_savi_features), FP, LL, I, FP, VP, SZ, VP]),
     'sf_savi_features_train_bwd_f32': (I, [C.POINTER(sf_savi_features), FP, LL, FP, C.POINTER(sf_savi_features_grads), I, VP, SZ, VP]),
+    'sf_linear_bwd_workspace_bytes': (SZ, [LL, I, I]),
+    'sf_linear_bwd_f32': (I, [FP, FP, FP, FP, FP, FP, FP, LL, I, I, I, VP, SZ, VP]),
+    'sf_layernorm_bwd_workspace_bytes': (SZ, [I]),
+    'sf_layernorm_bwd_f32': (I, [FP, FP, FP, FP, FP, FP, LL, I, F32, VP, SZ, VP]),
     'sf_rollout_train_workspace_bytes': (SZ, [C.POINTER(sf_rollouter), I, I]),
     'sf_rollout_train_fwd_f32': (I, [C.POINTER(sf_rollouter), FP, FP, I, I, F32, C.c_ulonglong, VP, SZ, VP]),
     'sf_rollout_train_bwd_f32': (I, [C.POINTER(sf_rollouter), FP, FP, C.POINTER(sf_rollouter_grads), I, I, F32,

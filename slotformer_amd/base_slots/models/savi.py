@@ -178,6 +178,37 @@ class StoSAVi(BaseModel):
             return None
         return torch.stack([torch.randn(B, self.num_slots, self.slot_size, device=device) for _ in range(T)], 1)
 
+    def _encode_with_grad(self, img, prev_slots, noise):
+        """The same recurrence (savi.py:379-416) as a chain of autograd nodes on the HIP library (row N1): one node for
+        the image encoder of all frames, then per frame predictor -> kernel distribution -> sample -> Slot Attention.
+        Only the tiny elementwise glue on [B,N,D] tensors (sampling, residual add) runs as torch ops."""
+        from ... import train
+        if not isinstance(self.predictor, ResidualMLPPredictor):
+            raise NotImplementedError('slotformer_amd: training covers the residual-MLP predictor (stosavi_clevrer_params.py); the '
+                                      'Transformer / LSTM predictors are inference-only')
+        B, T = img.shape[:2]
+        feats = train.features_with_grad(self, img.transpose(0, 1).flatten(0, 1))   # time-major: feats[t*B:(t+1)*B] is contiguous
+        feats = feats.unflatten(0, (T, B))
+        kd_layers, mlp, D = self.kernel_dist_layer, self.predictor.mlp, self.slot_size
+        dists, posts = [], []
+        for t in range(T):
+            if prev_slots is None:
+                latents = self.init_latents.repeat(B, 1, 1)
+            else:
+                x = train.layer_norm(prev_slots, self.predictor.ln)
+                latents = train.linear(train.linear(x, mlp[0], relu=True), mlp[2]) + (x if self.predictor.norm_first else prev_slots)
+            if len(kd_layers) == 1:
+                dist = train.linear(latents, kd_layers[0])
+            else:   # kernel_mlp: Linear -> LayerNorm -> ReLU -> Linear (savi.py:190-200)
+                dist = train.linear(torch.relu(train.layer_norm(train.linear(latents, kd_layers[0]), kd_layers[1])), kd_layers[3])
+            kernels = dist[..., :D]
+            if noise is not None:
+                kernels = kernels + noise[:, t] * torch.exp(0.5 * dist[..., D:])
+            prev_slots = self.slot_attention(feats[t], kernels.contiguous())
+            dists.append(dist)
+            posts.append(prev_slots)
+        return torch.stack(dists, 1), torch.stack(posts, 1), None
+
     def encode(self, img, prev_slots=None, noise=None):
         """img [B,T,3,H,W] -> (kernel_dist [B,T,N,2D], post_slots [B,T,N,D], None).  `noise` [B,T,N,D] injects the
         stochastic-kernel noise.  The third item is the reference's `encoder_out`, which nothing consumes
@@ -186,6 +217,8 @@ class StoSAVi(BaseModel):
             noise = None
         elif noise is None:
             noise = self._draw_noise(img.shape[0], img.shape[1], img.device)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._encode_with_grad(img.float().contiguous(), prev_slots, noise)
         post, kdist, _ = engine.savi_encode(self, img, prev_slots=prev_slots, noise=noise)
         return kdist, post, None
 

@@ -1063,6 +1063,43 @@ int sf_relu_bwd_ex(float* dh, const float* h, long long n, hipStream_t st) {
 
 extern "C" {
 
+// ---- differentiable building blocks for the slot-level layers (predictor, kernel distribution; savi.py:190-200,
+// predictor.py:47-73): backward of y = act(x W^T + b) and of LayerNorm, on the same kernels as the big nodes ----
+size_t sf_linear_bwd_workspace_bytes(long long M, int N, int K) {
+  return (sf_grad_partial_floats(M, N, K) + (size_t)N * K + 128) * sizeof(float) + 256;
+}
+// dy [M,N] is overwritten when relu != 0 (masked by y > 0).  dx [M,K] (may be NULL), dW [N,K], db [N] (may be NULL).
+int sf_linear_bwd_f32(const float* x, const float* W, const float* y, float* dy, float* dx, float* dW, float* db, long long M,
+                      int N, int K, int relu, void* ws, size_t ws_bytes, void* stream) {
+  SF_REQUIRE(x && W && dy && dW && ws && M > 0, "null pointer");
+  SF_REQUIRE(N % 64 == 0 && K % 64 == 0, "linear backward needs multiples of 64");
+  SF_REQUIRE(ws_bytes >= sf_linear_bwd_workspace_bytes(M, N, K), "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  float* wt = partial + ((sf_grad_partial_floats(M, N, K) + 63) & ~(size_t)63);
+  if (relu) {
+    SF_REQUIRE(y != nullptr, "relu backward needs the forward output");
+    SF_TRY(sf_relu_bwd_ex(dy, y, M * N, st));
+  }
+  SF_TRY(sf_grad_weight_ex(dy, x, dW, M, N, K, partial, st));
+  if (db) SF_TRY(sf_grad_bias_ex(dy, db, M, N, partial, st));
+  if (dx) {
+    SF_TRY(launch_transpose(W, wt, N, K, st));   // [N,K] -> [K,N]
+    SF_TRY(sf_linear_ex(dy, sf_rows(N), wt, nullptr, nullptr, nullptr, 0.f, nullptr, sf_rows(K), 0, dx, sf_rows(K), (int)M, K, N, 0, st));
+  }
+  return 0;
+}
+size_t sf_layernorm_bwd_workspace_bytes(int D) { return ((size_t)513 * 2 * D + 128) * sizeof(float) + 256; }
+int sf_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, long long rows,
+                         int D, float eps, void* ws, size_t ws_bytes, void* stream) {
+  SF_REQUIRE(x && dy && gamma && dx && dgamma && dbeta && ws && rows > 0, "null pointer");
+  SF_REQUIRE(ws_bytes >= sf_layernorm_bwd_workspace_bytes(D), "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  SF_TRY(sf_grad_ln_ex(x, dy, dgamma, dbeta, rows, D, eps, partial, st));
+  return sf_ln_bwd_ex(x, dy, gamma, nullptr, dx, rows, D, eps, st);
+}
+
 size_t sf_rollout_train_workspace_bytes(const sf_rollouter* m, int B, int pred_len) {
   Dims D;
   if (check_model(m, D, B, pred_len) != 0) return 0;

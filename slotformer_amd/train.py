@@ -334,6 +334,69 @@ def features_with_grad(m, img):
     return _Features.apply(m, img, *features_parameters(m))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# differentiable nn.Linear / nn.LayerNorm on the HIP library, for the slot-level layers (predictor, kernel distribution)
+# ---------------------------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b) with sf_linear_f32 / sf_linear_bwd_f32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        from . import ops
+        xd, wd = x.detach().float().contiguous(), weight.detach().float().contiguous()
+        y = ops.linear(xd, wd, bias.detach().float().contiguous() if bias is not None else None, relu=relu)
+        ctx.save_for_backward(xd, wd, y if relu else None)
+        ctx.relu, ctx.has_bias = bool(relu), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = dy.float().contiguous().clone() if ctx.relu else dy.float().contiguous()
+        N, K = w.shape
+        M = x.numel() // K
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty(N, dtype=torch.float32, device=w.device) if ctx.has_bias else None
+        nb = lib().sf_linear_bwd_workspace_bytes(M, N, K)
+        ws = torch.empty(nb, dtype=torch.uint8, device=w.device)
+        p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        check(lib().sf_linear_bwd_f32(p(x), p(w), p(y), p(dy), p(dx), p(dw), p(db), M, N, K, int(ctx.relu), ws.data_ptr(), nb,
+                                      torch.cuda.current_stream().cuda_stream))
+        return dx, dw, db, None
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        from . import ops
+        xd, g = x.detach().float().contiguous(), gamma.detach().float().contiguous()
+        ctx.save_for_backward(xd, g)
+        ctx.eps = float(eps)
+        return ops.layernorm(xd, g, beta.detach().float().contiguous(), eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        D = x.shape[-1]
+        dx, dg, db = torch.empty_like(x), torch.empty_like(g), torch.empty_like(g)
+        nb = lib().sf_layernorm_bwd_workspace_bytes(D)
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        check(lib().sf_layernorm_bwd_f32(x.data_ptr(), dy.data_ptr(), g.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                         x.numel() // D, D, ctx.eps, ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream))
+        return dx, dg, db, None
+
+
+def linear(x, layer, relu=False):
+    """nn.Linear `layer` applied to x under autograd, on the HIP kernels."""
+    return _Linear.apply(x, layer.weight, layer.bias, relu)
+
+
+def layer_norm(x, layer):
+    return _LayerNorm.apply(x, layer.weight, layer.bias, layer.eps)
+
+
 def dropout_keep_mask(seed, step, layer, site, numel, p):
     """Host restatement of the library's dropout mask (rollout_train.hip: sf_keep / site_seed) for tests and tools:
     bool [numel], True = kept.  site: 0 attention weights, 1 attention output, 2 FFN hidden, 3 FFN output."""

@@ -141,6 +141,8 @@ C4_ROLL = rollout_cfg(6, 192, 6, 256, 8, 8, 1024, rollout_len=40)
 C4_ROLL_REF = rollout_cfg(6, 192, 15, 256, 8, 8, 1024, rollout_len=10)
 C5_ROLL = rollout_cfg(8, 128, 1, 256, 8, 8, 1024, cond_len=6, rollout_len=80,
                       model='SingleStepSlotFormer', res=128)
+# row N1 (training of StoSAVi itself): stosavi_clevrer_params.py at its own 64x64 training resolution
+TRAIN_SAVI = savi_cfg(64, 7, iters=2, kernel_mlp=False, pred='mlp', rnn=False, kld='var-0.01')
 # row N1 (training): a reduced slotformer_clevrer_params.py whose gradients fit a small fixture
 TRAIN_ROLL = rollout_cfg(3, 64, 3, 64, 2, 2, 128, rollout_len=3)
 TRAIN_ROLL_IMG = rollout_cfg(3, 64, 3, 64, 2, 2, 128, rollout_len=2)   # with the image term (use_img_recon_loss=True)

@@ -342,3 +342,44 @@ def test_decoder_parameter_gradients_vs_oracle(dev, precision):
         assert got[n].grad is not None, n
         assert l2_err(got[n].grad, osd[n].grad) < tol, n
     assert l2_err(sg.grad, so.grad) < tol
+
+
+def test_savi_training_step_golden(dev, precision):
+    """StoSAVi trains end to end on the HIP path (stosavi_clevrer_params.py: residual-MLP predictor, stochastic kernels):
+    `model(batch)` in train() mode -> `calc_train_loss` -> `backward()` gives the reference's loss terms and gradients for
+    every parameter (fixture savi_train: norms + strided samples from the reference; the full element-wise comparison is
+    against autograd of the oracle, which the CPU suite pins to the same fixture)."""
+    g = gu.load_golden('savi_train')
+    cfg = gu.TRAIN_SAVI
+    m, sd = build(cfg, g, 901, dev)
+    m.train()
+    m.testing = False
+    img = gu.seeded_img(1, 2, 64, 902)
+    noise = gu.seeded_normal((1, 2, 7, 128), 9)
+    data = {'img': img.to(dev), 'noise': noise.to(dev)}
+    out = m(data)
+    terms = m.calc_train_loss(data, out)
+    loss = terms['post_recon_loss'] + float(g['kld_w']) * terms['kld_loss']
+    loss.backward()
+    assert abs(float(terms['kld_loss'].detach()) - float(g['kld_loss'])) < 1e-4 * float(g['kld_loss'])
+    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-4 * float(g['loss'])
+    assert rel_err(out['post_slots'], g['post_slots']) < 1e-4
+    names = [str(n) for n in g['grad_names']]
+    got = dict(m.named_parameters())
+    assert sorted(n for n, p in got.items() if p.grad is not None) == sorted(names)   # e.g. prior_slot_layer stays unused
+    # oracle gradients (full tensors)
+    osd = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    o = oracle.savi_encode(img, osd, cfg, noise=noise)
+    rec = oracle.savi_decode(o['post_slots'].flatten(0, 1), osd, cfg)[0].unflatten(0, (1, 2))
+    (((rec - img)**2).mean() + float(g['kld_w']) * oracle.kernel_kld(o['kernel_dist'], cfg)).backward()
+    tol = {'bf16x3': 1e-2, 'f32': 2e-3}[precision]   # ReLU-kink noise of the conv / decoder stacks, see above
+    st = int(g['stride'])
+    for n, norm in zip(names, g['grad_norms']):
+        if n == 'slot_attention.project_q.0.bias':
+            assert got[n].grad.abs().max() < 1e-5
+            continue
+        assert l2_err(got[n].grad, osd[n].grad) < tol, n
+        assert abs(float(got[n].grad.norm()) - float(norm)) < tol * float(norm), n
+        ref = torch.from_numpy(g['gs.' + n])
+        samp = got[n].grad.detach().cpu().flatten()[::st]
+        assert float((samp - ref).norm()) <= tol * max(float(ref.norm()), float(norm) * (ref.numel() / got[n].numel())**0.5) * 3, n

@@ -421,6 +421,43 @@ def case_rollout_grads(name, cfg, B, seed, decay=0.9, img=False):
          grad_names=np.array(names), **{'grad.' + n: g.numpy() for n, g in grads.items()}, **pack_meta(m, sd))
 
 
+def case_savi_train(name, cfg, B, T, seed, noise_seed, kld_w=1e-4, stride=53):
+    """StoSAVi's own training step (scripts/train.py -> SAVi method: forward in train() mode, calc_train_loss savi.py:527-538,
+    loss = post_recon_loss + kld_w * kld_loss, backward): the loss terms and, per parameter, the gradient's L2 norm and a
+    strided sample (a full gradient set would be megabytes; the oracle, checked here element by element, carries the full
+    comparison in the tests)."""
+    print(name)
+    with torch.enable_grad():
+        m = ref_build_base(gu.ParamsView(cfg)).train()
+        m.testing = False
+        sd = load_seeded(m, seed)
+        img = gu.seeded_img(B, T, cfg['resolution'][0], seed + 1)
+        N, D = cfg['slot_dict']['num_slots'], cfg['slot_dict']['slot_size']
+        noise = gu.seeded_normal((B, T, N, D), noise_seed)
+        with InjectedRandn(noise):
+            out = m({'img': img})
+        terms = m.calc_train_loss({'img': img}, out)
+        loss = terms['post_recon_loss'] + kld_w * terms['kld_loss']
+        loss.backward()
+        grads = {n: p_.grad.detach().clone() for n, p_ in m.named_parameters() if p_.grad is not None}
+        # oracle under autograd
+        osd = {k: (v.clone().requires_grad_(True) if k in grads else v) for k, v in sd.items()}
+        o = oracle.savi_encode(img, osd, cfg, noise=noise)
+        rec = oracle.savi_decode(o['post_slots'].flatten(0, 1), osd, cfg)[0].unflatten(0, (B, T))
+        okld = oracle.kernel_kld(o['kernel_dist'], cfg)
+        ol = ((rec - img)**2).mean() + kld_w * okld
+        ol.backward()
+        print('  loss', float(loss.detach()), 'oracle', float(ol.detach()), 'kld', float(terms['kld_loss'].detach()), float(okld.detach()))
+        worst = sorted(((((osd[n].grad - g).norm() / (g.norm() + 1e-30)).item(), n) for n, g in grads.items()), reverse=True)
+        print('  oracle grad rel-L2 err (worst 3; project_q.0.bias has a structurally zero gradient)', worst[:3], 'params with grad', len(grads))
+    names = sorted(grads)
+    save(name, loss=np.array(float(loss.detach())), post_recon_loss=np.array(float(terms['post_recon_loss'].detach())),
+         kld_loss=np.array(float(terms['kld_loss'].detach())), kld_w=np.array(kld_w), stride=np.int64(stride),
+         post_slots=out['post_slots'].detach().numpy(), grad_names=np.array(names),
+         grad_norms=np.array([float(grads[n].norm()) for n in names]),
+         **{'gs.' + n: grads[n].flatten()[::stride].numpy() for n in names}, **pack_meta(m, sd))
+
+
 @torch.no_grad()
 def case_h2(name, cfg, B, seed, frame_offset=2):
     """Run the reference's own rollout_video_slots() (rollout_clevrer_slots.py:20-65) on CPU."""
@@ -520,6 +557,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'steve_slotformer':
         case_steve_slotformer('steve_slotformer', B=1, seed=701)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'savi_train':
+        case_savi_train('savi_train', gu.TRAIN_SAVI, B=1, T=2, seed=901, noise_seed=9)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'roll_train':
         case_rollout_grads('roll_train', gu.TRAIN_ROLL, B=2, seed=801)
         case_rollout_grads('roll_train_img', gu.TRAIN_ROLL_IMG, B=1, seed=811, img=True)
@@ -542,6 +582,7 @@ def main():
     case_steve_slotformer('steve_slotformer', B=1, seed=701)
     case_rollout_grads('roll_train', gu.TRAIN_ROLL, B=2, seed=801)
     case_rollout_grads('roll_train_img', gu.TRAIN_ROLL_IMG, B=1, seed=811, img=True)
+    case_savi_train('savi_train', gu.TRAIN_SAVI, B=1, T=2, seed=901, noise_seed=9)
 
 
 if __name__ == '__main__':
