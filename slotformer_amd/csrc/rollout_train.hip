@@ -631,21 +631,37 @@ __global__ __launch_bounds__(256) void ln_param_partial_kernel(const float* __re
   }
 }
 
-// column sums, stage 1: partial[g][n] = sum over rows [g*rpg, (g+1)*rpg) of y[row][n]
+// column sums, stage 1: partial[g][n] = sum over rows [g*rpg, (g+1)*rpg) of y[row][n].  The 256 threads of a workgroup
+// cover min(n, 256) columns x 256 / that many row lanes (narrow matrices -- conv / head gradients have n = 4 .. 64 and
+// millions of rows -- keep every lane busy), four loads in flight per lane, row lanes combined through LDS.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ y, float* __restrict__ partial,
                                                              long long rows, int rpg, int n) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= n) return;
+  __shared__ float red[256];
+  int cols = 1;
+  while (cols < n && cols < 256) cols <<= 1;   // columns per workgroup (power of two)
+  const int lanes = 256 / cols;
+  const int cl = threadIdx.x % cols, rl = threadIdx.x / cols;
+  const int c = blockIdx.x * cols + cl;
   const long long r0 = (long long)blockIdx.y * rpg;
   const long long r1 = r0 + rpg < rows ? r0 + rpg : rows;
-  float s0 = 0.f, s1 = 0.f;
-  long long r = r0;
-  for (; r + 1 < r1; r += 2) {
-    s0 += y[r * n + c];
-    s1 += y[(r + 1) * n + c];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < n) {
+    long long r = r0 + rl;
+    for (; r + 3LL * lanes < r1; r += 4LL * lanes) {
+      s0 += y[r * n + c];
+      s1 += y[(r + lanes) * n + c];
+      s2 += y[(r + 2LL * lanes) * n + c];
+      s3 += y[(r + 3LL * lanes) * n + c];
+    }
+    for (; r < r1; r += lanes) s0 += y[r * n + c];
   }
-  if (r < r1) s0 += y[r * n + c];
-  partial[(long long)blockIdx.y * n + c] = s0 + s1;
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rl == 0 && c < n) {
+    float a = red[cl];
+    for (int i = 1; i < lanes; ++i) a += red[i * cols + cl];
+    partial[(long long)blockIdx.y * n + c] = a;
+  }
 }
 
 // stage 2 of every split reduction: out[i] = sum_g partial[g][i]  (fixed order: four interleaved chains, then their sum)
@@ -995,7 +1011,9 @@ int grad_bias(const float* Y, float* db, long long rows, int n, const Ws& w, hip
   if (G > 512) G = 512;
   const int rpg = (int)((rows + G - 1) / G);
   G = (int)((rows + rpg - 1) / rpg);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(n, 256), G), dim3(256), 0, st, Y, w.partial, rows, rpg, n);
+  int cols = 1;
+  while (cols < n && cols < 256) cols <<= 1;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(n, cols), G), dim3(256), 0, st, Y, w.partial, rows, rpg, n);
   SF_CHECK_LAUNCH();
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, w.partial, db, G, (long long)n / 4);
   SF_CHECK_LAUNCH();

@@ -14,6 +14,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define CW_P 68
@@ -26,85 +27,95 @@ __device__ __forceinline__ void cw_split8(const f32x8 v, bf16x8& hi, bf16x8& lo)
 // grid, X [*, 64] on an Hx x Wx grid, (dy, dx) = tap - ks/2, zero outside the image.
 //   conv weight gradient       : A = dY (n = c_out), X = the layer input (k = c_in), s = 1
 //   transposed-conv weight grad: A = the layer input (n = c_in), X = dY on the s-times finer output grid (k = c_out)
-// grid (ks*ks taps * CA/64, splits); partial [split][CA][ks*ks*64].  Same structure as grad_gemm_tn_kernel.
+// One workgroup owns ONE KERNEL ROW ky of one 64-wide n tile: the chunk of A rows is staged once and contracted against the
+// five kx-shifted copies of the X rows (loaded back to back, so the shifted re-reads hit in L2 -- with one tap per
+// workgroup the operands were streamed from HBM 25 times and the kernel sat at 59 TFLOP/s, HBM-bound).
+// grid (5 * CA/64, splits); partial [split][CA][25*64].  Structure of grad_gemm_tn_kernel otherwise.
 template <bool EXACT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                          float* __restrict__ partial, long long rows, int rps, int H, int W,
-                                                         int ks, int CA, int s, int Hx, int Wx) {
+                                                         int CA, int s, int Hx, int Wx) {
+  constexpr int KS = 5;
   __shared__ float Ys[32 * CW_P];
-  __shared__ float Xs[32 * CW_P];
+  __shared__ float Xs[KS][32 * CW_P];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nt = CA / 64, tap = blockIdx.x / nt, n0 = (blockIdx.x % nt) * 64, dy = tap / ks - ks / 2, dx = tap % ks - ks / 2;
+  const int nt = CA / 64, ky = blockIdx.x / nt, n0 = (blockIdx.x % nt) * 64, dy = ky - KS / 2;
   const long long r0 = (long long)blockIdx.y * rps;
   const long long r1 = r0 + rps < rows ? r0 + rps : rows;
   const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;
   const int lr = tid >> 4, lc = (tid & 15) * 4;
-  f32x16 acc;
+  f32x16 acc[KS];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   const int nrows = (int)(r1 - r0);
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const int hw = H * W;
-  auto xload = [&](long long r) {   // X row of pixel r moved by the tap, zero outside the image
-    const long long f = r / hw;
-    const int rr = (int)(r - f * hw), y = rr / W, x = rr - y * W;
-    const int yy = y * s + dy, xx = x * s + dx;
-    const bool ok = (unsigned)yy < (unsigned)Hx && (unsigned)xx < (unsigned)Wx;
-    const float4 v = *reinterpret_cast<const float4*>(X + ((f * Hx + (ok ? yy : 0)) * Wx + (ok ? xx : 0)) * 64 + lc);
-    return ok ? v : zero4;
-  };
-  float4 py0 = zero4, py1 = zero4, px0 = zero4, px1 = zero4;
-  if (lr < nrows) {
-    py0 = *reinterpret_cast<const float4*>(dY + (r0 + lr) * CA + n0 + lc);
-    px0 = xload(r0 + lr);
+  f32x4 py[2], px[2][KS];   // ext-vector types: arrays of HIP's float4 struct were kept in scratch memory
+  // Every load is UNCONDITIONAL from a clamped (always valid) address and zeroed by a select afterwards: a branch around a
+  // load makes the compiler wait for all outstanding loads at the join, which serialises the prefetch with the MFMAs.
+  const int rlast = (int)(rows - 1);
+  // rows rel + lr, rel + lr + 16 of this workgroup's range (a macro, not a lambda: captured arrays ended up in scratch)
+#define CW_FETCH(rel)                                                                                                    \
+  _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                                        \
+    const int rr0 = (rel) + lr + 16 * h;                                                                                 \
+    const bool rok = rr0 < nrows;                                                                                        \
+    const int r = min((int)r0 + rr0, rlast);                                                                             \
+    const f32x4 a_ = *reinterpret_cast<const f32x4*>(dY + (long long)r * CA + n0 + lc);                                \
+    py[h] = rok ? a_ : zero4;                                                                                            \
+    const int f = r / hw, rr = r - f * hw, y = rr / W, x = rr - y * W;                                                   \
+    const int yy = y * s + dy;                                                                                           \
+    const bool yok = rok && (unsigned)yy < (unsigned)Hx;                                                                 \
+    const float* xrow = X + ((long long)(f * Hx + min(max(yy, 0), Hx - 1)) * Wx) * 64 + lc;                              \
+    _Pragma("unroll") for (int t = 0; t < KS; ++t) {                                                                     \
+      const int xx = x * s + t - KS / 2;                                                                                 \
+      const f32x4 v_ = *reinterpret_cast<const f32x4*>(xrow + (long long)min(max(xx, 0), Wx - 1) * 64);                \
+      px[h][t] = (yok && (unsigned)xx < (unsigned)Wx) ? v_ : zero4;                                                      \
+    }                                                                                                                    \
   }
-  if (lr + 16 < nrows) {
-    py1 = *reinterpret_cast<const float4*>(dY + (r0 + lr + 16) * CA + n0 + lc);
-    px1 = xload(r0 + lr + 16);
-  }
+  CW_FETCH(0)
   for (int rb = 0; rb < nrows; rb += 32) {
     __syncthreads();
-    *reinterpret_cast<float4*>(&Ys[lr * CW_P + lc]) = py0;
-    *reinterpret_cast<float4*>(&Ys[(lr + 16) * CW_P + lc]) = py1;
-    *reinterpret_cast<float4*>(&Xs[lr * CW_P + lc]) = px0;
-    *reinterpret_cast<float4*>(&Xs[(lr + 16) * CW_P + lc]) = px1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<f32x4*>(&Ys[(lr + 16 * h) * CW_P + lc]) = py[h];
+#pragma unroll
+      for (int t = 0; t < KS; ++t) *reinterpret_cast<f32x4*>(&Xs[t][(lr + 16 * h) * CW_P + lc]) = px[h][t];
+    }
     __syncthreads();
-    py0 = py1 = px0 = px1 = zero4;
-    const int ra = rb + 32 + lr;
-    if (ra < nrows) {
-      py0 = *reinterpret_cast<const float4*>(dY + (r0 + ra) * CA + n0 + lc);
-      px0 = xload(r0 + ra);
-    }
-    if (ra + 16 < nrows) {
-      py1 = *reinterpret_cast<const float4*>(dY + (r0 + ra + 16) * CA + n0 + lc);
-      px1 = xload(r0 + ra + 16);
-    }
+    CW_FETCH(rb + 32)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const float* ya = &Ys[(16 * t + 8 * (lane >> 5)) * CW_P + wn + (lane & 31)];
-      const float* xa = &Xs[(16 * t + 8 * (lane >> 5)) * CW_P + wk + (lane & 31)];
-      f32x8 a, b;
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ro = (16 * kk + 8 * (lane >> 5)) * CW_P;
+      f32x8 a;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        a[j] = ya[j * CW_P];
-        b[j] = xa[j * CW_P];
-      }
-      bf16x8 ah, al, bh, bl;
+      for (int j = 0; j < 8; ++j) a[j] = Ys[ro + j * CW_P + wn + (lane & 31)];
+      bf16x8 ah, al;
       cw_split8(a, ah, al);
-      cw_split8(b, bh, bl);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-      if (EXACT) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < KS; ++t) {
+        f32x8 b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = Xs[t][ro + j * CW_P + wk + (lane & 31)];
+        bf16x8 bh, bl;
+        cw_split8(b, bh, bl);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+        if (EXACT) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc[t], 0, 0, 0);
+      }
     }
   }
-  const int K = ks * ks * 64;
+  const int K = KS * KS * 64;
   float* out = partial + (long long)blockIdx.y * CA * K;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int n = n0 + wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    out[(long long)n * K + tap * 64 + wk + (lane & 31)] = acc[r];
-  }
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      out[(long long)n * K + (ky * KS + t) * 64 + wk + (lane & 31)] = acc[t][r];
+    }
 }
 
 // out[i] = sum_g partial[g][i] written through an index map:  OHWI [Cout][taps][Cin] -> torch OIHW [Cout][Cin][taps]
@@ -191,25 +202,25 @@ __global__ __launch_bounds__(256) void pos_dense_grad_kernel(const float* __rest
 // on the finer grid), written in torch layout [CA][64][ks][ks]
 int sf_conv_wgrad_ex(const float* A, int CA, int H, int W, const float* X, int Hx, int Wx, int s, int ks, long long rows,
                      float* out_oihw, float* partial, hipStream_t st) {
-  SF_REQUIRE(CA % 64 == 0 && ks * ks <= 25, "conv weight gradient: channel multiple of 64, at most 5x5");
+  SF_REQUIRE(CA % 64 == 0 && ks == 5 && rows > 0 && rows < (1LL << 31), "conv weight gradient: channel multiple of 64, 5x5 kernels");
   const int taps = ks * ks, nt = CA / 64;
-  int splits = 512 / (taps * nt);
+  int splits = 768 / (ks * nt);
   if (splits < 1) splits = 1;
   if ((long long)splits * 64 > rows) splits = (int)((rows + 63) / 64);
   int rps = (int)((rows + splits - 1) / splits);
   rps = (rps + 31) & ~31;
-  const dim3 grid(taps * nt, splits);
+  const dim3 grid(ks * nt, splits);
   if (sf_get_precision() == 0)
-    hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, ks, CA, s, Hx, Wx);
+    hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, CA, s, Hx, Wx);
   else
-    hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, ks, CA, s, Hx, Wx);
+    hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, CA, s, Hx, Wx);
   SF_CHECK_LAUNCH();
   const int total = CA * 64 * taps;
   hipLaunchKernelGGL(reduce_to_oihw_kernel, dim3((total + 255) / 256), dim3(256), 0, st, partial, out_oihw, splits, CA, 64, taps);
   SF_CHECK_LAUNCH();
   return 0;
 }
-size_t sf_conv_wgrad_partial_floats(int CA, int ks) { return (size_t)24 * CA * ks * ks * 64; }
+size_t sf_conv_wgrad_partial_floats(int CA, int ks) { return (size_t)160 * CA * ks * ks * 64; }
 
 // SoftPositionEmbed gradients from d [F][HW][C] (the table is added to every frame); dtab: scratch [HW*C]
 int sf_pos_dense_grad_ex(const float* d, int F, int HW, int C, const float* grid, float* dw, float* db, float* dtab, hipStream_t st) {
