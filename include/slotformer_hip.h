@@ -236,6 +236,16 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
 size_t sf_linear_bwd_workspace_bytes(long long M, int N, int K);
 int sf_linear_bwd_f32(const float* x, const float* W, const float* y, float* dy, float* dx, float* dW, float* db, long long M,
                       int N, int K, int relu, void* ws, size_t ws_bytes, void* stream);
+/* Attention core of nn.MultiheadAttention under autograd (predictor.py:33-38 in train mode): qkv [B*L, 3d] (q|k|v) -> ctx
+ * [B*L, d]; dropout on the softmax weights with masks that are a pure function of (seed, element); the backward call
+ * recomputes the probabilities.  L <= 128, head_dim <= 64. */
+int sf_mha_train_fwd_f32(const float* qkv, float* ctx, int B, int L, int d_model, int num_heads, float dropout_p,
+                         unsigned long long seed, void* stream);
+int sf_mha_train_bwd_f32(const float* qkv, const float* d_ctx, float* d_qkv, int B, int L, int d_model, int num_heads,
+                         float dropout_p, unsigned long long seed, void* stream);
+/* y = res + dropout(x) (nn.Dropout in train mode; res may be NULL; n % 4 == 0).  Its backward is the same call on dy. */
+int sf_dropout_f32(const float* x, const float* res, float* y, long long n, float dropout_p, unsigned long long seed,
+                   void* stream);
 /* Backward of nn.LayerNorm over the last dimension (D <= 1024, D % 4 == 0). */
 size_t sf_layernorm_bwd_workspace_bytes(int D);
 int sf_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta,

@@ -152,6 +152,9 @@ SIGNATURES = {
     'sf_savi_features_train_bwd_f32': (I, [C.POINTER(sf_savi_features), FP, LL, FP, C.POINTER(sf_savi_features_grads), I, VP, SZ, VP]),
     'sf_linear_bwd_workspace_bytes': (SZ, [LL, I, I]),
     'sf_linear_bwd_f32': (I, [FP, FP, FP, FP, FP, FP, FP, LL, I, I, I, VP, SZ, VP]),
+    'sf_mha_train_fwd_f32': (I, [FP, FP, I, I, I, I, F32, C.c_ulonglong, VP]),
+    'sf_mha_train_bwd_f32': (I, [FP, FP, FP, I, I, I, I, F32, C.c_ulonglong, VP]),
+    'sf_dropout_f32': (I, [FP, FP, FP, LL, F32, C.c_ulonglong, VP]),
     'sf_layernorm_bwd_workspace_bytes': (SZ, [I]),
     'sf_layernorm_bwd_f32': (I, [FP, FP, FP, FP, FP, FP, LL, I, F32, VP, SZ, VP]),
     'sf_rollout_train_workspace_bytes': (SZ, [C.POINTER(sf_rollouter), I, I]),

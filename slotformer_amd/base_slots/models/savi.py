@@ -183,20 +183,16 @@ class StoSAVi(BaseModel):
         the image encoder of all frames, then per frame predictor -> kernel distribution -> sample -> Slot Attention.
         Only the tiny elementwise glue on [B,N,D] tensors (sampling, residual add) runs as torch ops."""
         from ... import train
-        if not isinstance(self.predictor, ResidualMLPPredictor):
-            raise NotImplementedError('slotformer_amd: training covers the residual-MLP predictor (stosavi_clevrer_params.py); the '
-                                      'Transformer / LSTM predictors are inference-only')
         B, T = img.shape[:2]
         feats = train.features_with_grad(self, img.transpose(0, 1).flatten(0, 1))   # time-major: feats[t*B:(t+1)*B] is contiguous
         feats = feats.unflatten(0, (T, B))
-        kd_layers, mlp, D = self.kernel_dist_layer, self.predictor.mlp, self.slot_size
+        kd_layers, D = self.kernel_dist_layer, self.slot_size
         dists, posts = [], []
         for t in range(T):
             if prev_slots is None:
                 latents = self.init_latents.repeat(B, 1, 1)
             else:
-                x = train.layer_norm(prev_slots, self.predictor.ln)
-                latents = train.linear(train.linear(x, mlp[0], relu=True), mlp[2]) + (x if self.predictor.norm_first else prev_slots)
+                latents = self._predict_with_grad(prev_slots, train)
             if len(kd_layers) == 1:
                 dist = train.linear(latents, kd_layers[0])
             else:   # kernel_mlp: Linear -> LayerNorm -> ReLU -> Linear (savi.py:190-200)
@@ -208,6 +204,33 @@ class StoSAVi(BaseModel):
             dists.append(dist)
             posts.append(prev_slots)
         return torch.stack(dists, 1), torch.stack(posts, 1), None
+
+    def _predict_with_grad(self, slots, train):
+        """predictor(prev_slots) under autograd (predictor.py:20-135): residual MLP, or Transformer over the slots, each
+        optionally followed by the one-step LSTM + projection of RNNPredictorWrapper (its state lives on the module and
+        carries the graph from frame to frame; `sg_every` detaches it on schedule)."""
+        pred = self.predictor
+        rnn = pred if isinstance(pred, RNNPredictorWrapper) else None
+        core = rnn.base_predictor if rnn is not None else pred
+        if rnn is not None and rnn.sg_every is not None and rnn.step % rnn.sg_every == 0 and rnn.step > 0:
+            slots = slots.detach()
+            if rnn.hidden_state is not None:
+                rnn.hidden_state = tuple(h.detach() for h in rnn.hidden_state)
+        if isinstance(core, ResidualMLPPredictor):
+            x = train.layer_norm(slots, core.ln)
+            out = train.linear(train.linear(x, core.mlp[0], relu=True), core.mlp[2]) + (x if core.norm_first else slots)
+        else:
+            out = slots
+            for layer in core.transformer_encoder.layers:
+                out = train.transformer_encoder_layer(out, layer)
+        if rnn is None:
+            return out
+        shape = out.shape
+        state = None if rnn.hidden_state is None else tuple(h.reshape(-1, rnn.hidden_size) for h in rnn.hidden_state)
+        h, state = train.lstm_step(out.reshape(-1, shape[-1]), state, rnn.rnn)
+        rnn.hidden_state = tuple(t_.unsqueeze(0) for t_ in state)   # nn.LSTM's [1, B*N, H] layout
+        rnn.step += 1
+        return train.linear(h, rnn.out_projector).view(shape)
 
     def encode(self, img, prev_slots=None, noise=None):
         """img [B,T,3,H,W] -> (kernel_dist [B,T,N,2D], post_slots [B,T,N,D], None).  `noise` [B,T,N,D] injects the

@@ -1107,6 +1107,34 @@ int sf_linear_bwd_f32(const float* x, const float* W, const float* y, float* dy,
   }
   return 0;
 }
+// attention core of nn.MultiheadAttention for training (qkv [B*L, 3d] -> ctx [B*L, d]; dropout on the softmax weights, masks
+// a pure function of (seed, element)) and its backward (recomputes the probabilities; nothing saved but qkv)
+int sf_mha_train_fwd_f32(const float* qkv, float* ctx, int B, int L, int d_model, int num_heads, float dropout_p,
+                         unsigned long long seed, void* stream) {
+  SF_REQUIRE(qkv && ctx && B > 0 && L > 0 && L <= 128 && num_heads > 0 && d_model % num_heads == 0 && d_model / num_heads <= 64,
+             "bad attention shape");
+  SF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p in [0, 1)");
+  return launch_attn_fwd(qkv, ctx, B, num_heads, L, d_model, site_seed(seed, 0, 0, SITE_ATTN_P), drop_thresh(dropout_p),
+                         1.f / (1.f - dropout_p), (hipStream_t)stream);
+}
+int sf_mha_train_bwd_f32(const float* qkv, const float* d_ctx, float* d_qkv, int B, int L, int d_model, int num_heads,
+                         float dropout_p, unsigned long long seed, void* stream) {
+  SF_REQUIRE(qkv && d_ctx && d_qkv && B > 0 && L > 0 && L <= 128 && num_heads > 0 && d_model % num_heads == 0 &&
+                 d_model / num_heads <= 64, "bad attention shape");
+  return launch_attn_bwd(qkv, d_ctx, d_qkv, B, num_heads, L, d_model, site_seed(seed, 0, 0, SITE_ATTN_P), drop_thresh(dropout_p),
+                         1.f / (1.f - dropout_p), (hipStream_t)stream);
+}
+// y = res + dropout(x) (res may be NULL); the backward of the dropout is the same call on the gradient
+int sf_dropout_f32(const float* x, const float* res, float* y, long long n, float dropout_p, unsigned long long seed, void* stream) {
+  SF_REQUIRE(x && y && n >= 0 && n % 4 == 0 && n < (1LL << 32), "bad dropout arguments");
+  SF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p in [0, 1)");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(residual_dropout_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, res, y, n / 4,
+                     site_seed(seed, 0, 0, SITE_ATTN_O), drop_thresh(dropout_p), 1.f / (1.f - dropout_p));
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
 size_t sf_layernorm_bwd_workspace_bytes(int D) { return ((size_t)513 * 2 * D + 128) * sizeof(float) + 256; }
 int sf_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, long long rows,
                          int D, float eps, void* ws, size_t ws_bytes, void* stream) {

@@ -388,6 +388,91 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dg, db, None
 
 
+class _MHA(torch.autograd.Function):
+    """Attention core of nn.MultiheadAttention (batch_first self-attention) on packed q|k|v rows."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, L, d, heads, p, seed):
+        qkv = qkv.detach().float().contiguous()
+        out = torch.empty(B * L, d, dtype=torch.float32, device=qkv.device)
+        check(lib().sf_mha_train_fwd_f32(qkv.data_ptr(), out.data_ptr(), B, L, d, heads, float(p), int(seed),
+                                         torch.cuda.current_stream().cuda_stream))
+        ctx.save_for_backward(qkv)
+        ctx.args = (B, L, d, heads, float(p), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        qkv, = ctx.saved_tensors
+        B, L, d, heads, p, seed = ctx.args
+        d_out = d_out.float().contiguous()
+        dqkv = torch.empty_like(qkv)
+        check(lib().sf_mha_train_bwd_f32(qkv.data_ptr(), d_out.data_ptr(), dqkv.data_ptr(), B, L, d, heads, p, seed,
+                                         torch.cuda.current_stream().cuda_stream))
+        return dqkv, None, None, None, None, None, None
+
+
+class _Dropout(torch.autograd.Function):
+    """nn.Dropout in train mode with the library's hashed masks (regenerated in the backward pass)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = x.detach().float().contiguous()
+        y = torch.empty_like(x)
+        check(lib().sf_dropout_f32(x.data_ptr(), None, y.data_ptr(), x.numel(), float(p), int(seed), torch.cuda.current_stream().cuda_stream))
+        ctx.args = (float(p), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(dy)
+        check(lib().sf_dropout_f32(dy.data_ptr(), None, dx.data_ptr(), dy.numel(), ctx.args[0], ctx.args[1], torch.cuda.current_stream().cuda_stream))
+        return dx, None, None
+
+
+def _new_seed():
+    return int(torch.randint(0, 2**62, (1, )).item())
+
+
+def dropout(x, p, training):
+    return _Dropout.apply(x, p, _new_seed()) if (training and p > 0) else x
+
+
+def transformer_encoder_layer(x, layer):
+    """nn.TransformerEncoderLayer (pre-LN, relu, batch_first; predictor.py:33-38) on x [B, L, d] as a chain of HIP-backed
+    autograd nodes, dropout included when the layer is in train() mode."""
+    if not layer.norm_first:
+        raise NotImplementedError('slotformer_amd: training needs norm_first Transformer layers (all reference configurations)')
+    B, L, d = x.shape
+    tr, att = layer.training, layer.self_attn
+    h = layer_norm(x, layer.norm1)
+    qkv = _Linear.apply(h, att.in_proj_weight, att.in_proj_bias, False)
+    p_att = float(att.dropout) if tr else 0.0
+    ctx = _MHA.apply(qkv.reshape(B * L, 3 * d), B, L, d, att.num_heads, p_att, _new_seed() if p_att > 0 else 0).view(B, L, d)
+    x = x + dropout(linear(ctx, att.out_proj), layer.dropout1.p, tr)
+    h = layer_norm(x, layer.norm2)
+    h = dropout(linear(h, layer.linear1, relu=True), layer.dropout.p, tr)
+    return x + dropout(linear(h, layer.linear2), layer.dropout2.p, tr)
+
+
+def lstm_step(x, state, rnn):
+    """One step of a 1-layer nn.LSTM on x [R, C] with state (h, c) [R, H] or None (predictor.py:116-117); the two gate
+    projections are HIP-backed nodes, the gate nonlinearities are elementwise glue."""
+    R = x.shape[0]
+    H = rnn.hidden_size
+    if state is None:
+        h = torch.zeros(R, H, dtype=torch.float32, device=x.device)
+        c = torch.zeros_like(h)
+    else:
+        h, c = state
+    gates = _Linear.apply(x, rnn.weight_ih_l0, rnn.bias_ih_l0, False) + _Linear.apply(h, rnn.weight_hh_l0, rnn.bias_hh_l0, False)
+    i, f, g, o = gates.chunk(4, -1)
+    c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+    h2 = torch.sigmoid(o) * torch.tanh(c2)
+    return h2, (h2, c2)
+
+
 def linear(x, layer, relu=False):
     """nn.Linear `layer` applied to x under autograd, on the HIP kernels."""
     return _Linear.apply(x, layer.weight, layer.bias, relu)

@@ -421,7 +421,7 @@ def case_rollout_grads(name, cfg, B, seed, decay=0.9, img=False):
          grad_names=np.array(names), **{'grad.' + n: g.numpy() for n, g in grads.items()}, **pack_meta(m, sd))
 
 
-def case_savi_train(name, cfg, B, T, seed, noise_seed, kld_w=1e-4, stride=53):
+def case_savi_train(name, cfg, B, T, seed, noise_seed, kld_w=1e-4, stride=53, no_dropout=False):
     """StoSAVi's own training step (scripts/train.py -> SAVi method: forward in train() mode, calc_train_loss savi.py:527-538,
     loss = post_recon_loss + kld_w * kld_loss, backward): the loss terms and, per parameter, the gradient's L2 norm and a
     strided sample (a full gradient set would be megabytes; the oracle, checked here element by element, carries the full
@@ -430,11 +430,20 @@ def case_savi_train(name, cfg, B, T, seed, noise_seed, kld_w=1e-4, stride=53):
     with torch.enable_grad():
         m = ref_build_base(gu.ParamsView(cfg)).train()
         m.testing = False
+        if no_dropout:   # the Transformer predictor's dropout is the only other random part of the step: switched off
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.
+                if isinstance(mod, torch.nn.MultiheadAttention):
+                    mod.dropout = 0.
         sd = load_seeded(m, seed)
         img = gu.seeded_img(B, T, cfg['resolution'][0], seed + 1)
         N, D = cfg['slot_dict']['num_slots'], cfg['slot_dict']['slot_size']
-        noise = gu.seeded_normal((B, T, N, D), noise_seed)
-        with InjectedRandn(noise):
+        noise = gu.seeded_normal((B, T, N, D), noise_seed) if noise_seed is not None else None
+        if noise is not None:
+            with InjectedRandn(noise):
+                out = m({'img': img})
+        else:
             out = m({'img': img})
         terms = m.calc_train_loss({'img': img}, out)
         loss = terms['post_recon_loss'] + kld_w * terms['kld_loss']
@@ -560,6 +569,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'savi_train':
         case_savi_train('savi_train', gu.TRAIN_SAVI, B=1, T=2, seed=901, noise_seed=9)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'savi_train_c1':
+        case_savi_train('savi_train_c1', gu.C1_SAVI, B=1, T=3, seed=911, noise_seed=None, no_dropout=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'roll_train':
         case_rollout_grads('roll_train', gu.TRAIN_ROLL, B=2, seed=801)
         case_rollout_grads('roll_train_img', gu.TRAIN_ROLL_IMG, B=1, seed=811, img=True)
@@ -583,6 +595,7 @@ def main():
     case_rollout_grads('roll_train', gu.TRAIN_ROLL, B=2, seed=801)
     case_rollout_grads('roll_train_img', gu.TRAIN_ROLL_IMG, B=1, seed=811, img=True)
     case_savi_train('savi_train', gu.TRAIN_SAVI, B=1, T=2, seed=901, noise_seed=9)
+    case_savi_train('savi_train_c1', gu.C1_SAVI, B=1, T=3, seed=911, noise_seed=None, no_dropout=True)
 
 
 if __name__ == '__main__':
