@@ -104,8 +104,12 @@ def test_no_cpu_fallback():
     m.testing = True
     with torch.no_grad(), pytest.raises(RuntimeError, match='no CPU fallback'):
         m({'img': gu.seeded_img(1, 1, 64)})
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m({'img': gu.seeded_img(1, 1, 64)})  # grad enabled: the training path (row N1) is HIP-only as well
+    steve = build_model(gu.ParamsView(gu.steve_tokens_cfg())).eval()
+    steve.testing = True
     with pytest.raises(NotImplementedError, match='inference-only'):
-        m({'img': gu.seeded_img(1, 1, 64)})  # grad enabled
+        steve({'img': gu.seeded_img(1, 1, 64)})  # STEVE has no training path yet and says so
     import slotformer_amd
     src_dir = os.path.dirname(slotformer_amd.__file__)
     for root, _, files in os.walk(src_dir):
