@@ -30,7 +30,7 @@ def workspace(device, nbytes, slot=0):
 def _require_inference(module, *tensors):
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
         raise NotImplementedError(
-            'slotformer_amd: the HIP path is inference-only (backward kernels are row N1 of SURVEY.md 8f); '
+            'slotformer_amd: this call is inference-only on the HIP path (the training nodes of row N1 live in train.py); '
             'wrap the call in torch.no_grad()')
     for t in tensors:
         if t is not None and not t.is_cuda:

@@ -1,5 +1,5 @@
-"""Loss VALUES of the reference models, computed on device tensors (the engine is inference-only: these are the numbers
-the reference's `calc_train_loss` / eval hooks report, not differentiable graphs)."""
+"""Loss terms of the reference models (`calc_train_loss` / eval hooks) as torch ops on device tensors.  They are plain
+differentiable reductions: in training (row N1) autograd carries their gradient into the HIP-backed nodes of train.py."""
 import torch
 
 
