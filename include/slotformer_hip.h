@@ -25,7 +25,9 @@ const char* sf_last_error_string(void);
 
 /* Matrix-arithmetic mode of every GEMM/conv kernel: 1 (default) = split-bf16 ("bf16x3": each f32 operand
  * = hi + lo bf16, hi*hi + hi*lo + lo*hi on bf16 MFMA with f32 accumulation, ~2^-17 relative per operand);
- * 0 = exact f32 MFMA (bitwise an fmaf chain).  Environment SF_PRECISION=f32 selects 0 at load time. */
+ * 0 = exact f32 MFMA (bitwise an fmaf chain); 2 = single-pass bf16 (hi*hi only, f32 accumulation, fp32 storage and master
+ * weights) in the GEMM / convolution / weight-gradient cores -- the AMP-bf16 policy of the training path (row N1); kernels
+ * without a single-pass variant keep mode 1.  Environment SF_PRECISION=f32 | bf16 selects 0 | 2 at load time. */
 int sf_get_precision(void);
 int sf_set_precision(int mode);
 

@@ -29,6 +29,7 @@ constexpr int NT = 512;
 constexpr size_t LDS_BYTES = (size_t)(2 * HALO + 4 * WBUF) * sizeof(__bf16);
 }  // namespace
 
+template <bool BF1>   // BF1: single-pass bf16 (precision mode 2): only the hi*hi product, no lo-plane reads
 __global__ __launch_bounds__(NT) void conv5x5_halo_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                           const float* __restrict__ bias, const float* __restrict__ add,
                                                           float* __restrict__ out, int H, int relu) {
@@ -124,13 +125,22 @@ __global__ __launch_bounds__(NT) void conv5x5_halo_kernel(const float* __restric
       const int cq[2] = {kh * 32 * PS, (1 - kh) * 32 * PS};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 xh = *(const bf16x8*)(ah + ks * 16), xl = *(const bf16x8*)(al + ks * 16);
+        const bf16x8 xh = *(const bf16x8*)(ah + ks * 16);
+        if constexpr (BF1) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const bf16x8 yh = *(const bf16x8*)(bh + cq[q] + ks * 16), yl = *(const bf16x8*)(bl + cq[q] + ks * 16);
-          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[q], 0, 0, 0);
-          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[q], 0, 0, 0);
-          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[q], 0, 0, 0);
+          for (int q = 0; q < 2; ++q) {
+            const bf16x8 yh = *(const bf16x8*)(bh + cq[q] + ks * 16);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[q], 0, 0, 0);
+          }
+        } else {
+          const bf16x8 xl = *(const bf16x8*)(al + ks * 16);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const bf16x8 yh = *(const bf16x8*)(bh + cq[q] + ks * 16), yl = *(const bf16x8*)(bl + cq[q] + ks * 16);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[q], 0, 0, 0);
+          }
         }
       }
       // weights of tap+1 (slot (kx+1)%5, requested four taps ago) -> the buffer last read one barrier ago
@@ -172,15 +182,21 @@ int sf_conv5x5_halo_ex(const float* in, const float* w_packed, const float* bias
   if (W != TW || Cin != CH || Cout != CH || ks != KS || (H % TR) != 0 || F <= 0) return 1;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv5x5_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)conv5x5_halo_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv5x5_halo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
     attr = true;
   }
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   sf_prof_begin(SF_K_CONV_NHWC, st, 2.0 * (double)F * H * W * Cout * ks * ks * Cin);
-  hipLaunchKernelGGL(conv5x5_halo_kernel, dim3(F * (H / TR)), dim3(NT), LDS_BYTES, st, in, w_packed, bias, add, out, H,
-                     relu);
+  if (sf_get_precision() == 2)
+    hipLaunchKernelGGL(conv5x5_halo_kernel<true>, dim3(F * (H / TR)), dim3(NT), LDS_BYTES, st, in, w_packed, bias, add, out, H,
+                       relu);
+  else
+    hipLaunchKernelGGL(conv5x5_halo_kernel<false>, dim3(F * (H / TR)), dim3(NT), LDS_BYTES, st, in, w_packed, bias, add, out, H,
+                       relu);
   sf_prof_end(SF_K_CONV_NHWC, st);
   SF_CHECK_LAUNCH();
   return 0;

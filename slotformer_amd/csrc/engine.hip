@@ -68,7 +68,7 @@ int tfm_layer(const sf_tfm_layer& w, float* x, TfmWs& ws, int B, int L, int Lq, 
   if (norm_first) {
     // split-bf16 mode: LN1 + per-head q|k|v projection + attention in one launch (attn_fused.hip)
     int fused = 1;
-    if (sf_get_precision() == 1)
+    if (sf_get_precision() >= 1)
       fused = sf_qkv_attn_ex(x, w.norm1_g, w.norm1_b, eps, w.in_proj_w, w.in_proj_b, ws.att, B, L, Lq, d, heads, st);
     if (fused < 0 || fused > 1) return fused;
     if (fused == 1) {
@@ -89,7 +89,7 @@ int tfm_layer(const sf_tfm_layer& w, float* x, TfmWs& ws, int B, int L, int Lq, 
   } else {
     if (Lq != L) return sf_set_err(-1, "row pruning requires norm_first", __FILE__, __LINE__);
     int fused = 1;
-    if (sf_get_precision() == 1)
+    if (sf_get_precision() >= 1)
       fused = sf_qkv_attn_ex(x, nullptr, nullptr, eps, w.in_proj_w, w.in_proj_b, ws.att, B, L, L, d, heads, st);
     if (fused < 0 || fused > 1) return fused;
     if (fused == 1) {
@@ -173,7 +173,7 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   bool packed = true;
   for (int l = 0; l < m->num_layers; ++l)
     packed = packed && m->layers[l].lin1_packed && m->layers[l].lin2_packed && m->layers[l].attn_in_packed && m->layers[l].attn_out_packed;
-  const bool fused_layers = packed && fused_env && sf_get_precision() == 1 && m->norm_first &&
+  const bool fused_layers = packed && fused_env && sf_get_precision() >= 1 && m->norm_first &&
                             sf_layer_fused_ok(d, m->num_heads, m->ffn_dim, Lmax);
   // step boundary in one launch (out-proj of step s + in-proj of the new frame for step s+1) with cached in-projections
   const bool ring_mode = fused_layers && m->in_proj_packed && m->out_proj_packed && sf_step_boundary_ok(d, C);
@@ -448,7 +448,7 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
       // (savi.py:66-70): one fused kernel per 128-pixel tile in split-bf16 mode (pixel_mlp.hip), else three GEMMs
       float* kv_dst = kv + (long long)b0 * HW * 2 * D;
       int fused = 1;
-      if (sf_get_precision() == 1)
+      if (sf_get_precision() >= 1)
         fused = sf_pixel_mlp_kv_ex(cur, m->enc_ln_g, m->enc_ln_b, m->enc_fc1_w, m->enc_fc1_b, m->enc_fc2_w,
                                    m->enc_fc2_b, m->sa_norm_in_g, m->sa_norm_in_b, m->sa_kv_w, kv_dst, Mp, Cl, Ce,
                                    2 * D, ln_eps, st);

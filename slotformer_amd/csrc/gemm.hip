@@ -50,6 +50,7 @@ struct SfGemmArgs {
   // sf_mix32((row * N + col) ^ drop_seed) >> 8 >= drop_thresh and scaled by drop_scale; drop_thresh == 0: off
   uint32_t drop_seed, drop_thresh;
   float drop_scale;
+  int bf1;  // split-bf16 kernels: contract the hi parts only (precision mode 2)
   int dbg;  // ablation bits (SF_GEMM_DBG, tools only): 1 no MFMA, 2 no main-loop loads, 4 no LN stats, 8 no stores
 };
 
@@ -334,8 +335,10 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
         for (int i = 0; i < RM; ++i)
 #pragma unroll
           for (int j = 0; j < RN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[j], acc[i][j], 0, 0, 0);
+            if (!p.bf1) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[j], acc[i][j], 0, 0, 0);
+            }
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yh[j], acc[i][j], 0, 0, 0);
           }
       }
@@ -633,17 +636,19 @@ static int launch_by_id(int id, const SfGemmArgs& a, hipStream_t st) {
   return sf_set_err(-1, "unknown GEMM configuration id", __FILE__, __LINE__);
 }
 
-// 0: exact f32 MFMA everywhere; 1: split-bf16 MFMA (default).  SF_PRECISION=f32 selects 0 at load time.
+// 0: exact f32 MFMA everywhere; 1: split-bf16 MFMA (default); 2: single-pass bf16 MFMA with f32 accumulation in the GEMM / conv
+// / weight-gradient cores (the "AMP-bf16" policy of the training path: fp32 storage and master weights, one bf16 rounding of
+// each operand; kernels without a single-pass variant keep mode 1).  SF_PRECISION=f32 | bf16 selects 0 | 2 at load time.
 static int g_precision = -1;
 extern "C" int sf_get_precision(void) {
   if (g_precision < 0) {
     const char* e = getenv("SF_PRECISION");
-    g_precision = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;
+    g_precision = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : ((e && strcmp(e, "bf16") == 0) ? 2 : 1);
   }
   return g_precision;
 }
 extern "C" int sf_set_precision(int mode) {
-  if (mode != 0 && mode != 1) return sf_set_err(-1, "invalid argument: precision mode must be 0 (f32) or 1 (bf16x3)", __FILE__, __LINE__);
+  if (mode < 0 || mode > 2) return sf_set_err(-1, "invalid argument: precision mode must be 0 (f32), 1 (bf16x3) or 2 (bf16)", __FILE__, __LINE__);
   g_precision = mode;
   return 0;
 }
@@ -658,7 +663,7 @@ static int dispatch_tiles(const SfGemmArgs& a, hipStream_t stream) {
   } else {
     const int f = forced_cfg();
     if (f >= 0) return launch_by_id<ALOAD, LN>(f, a, stream);
-    const bool bf3 = sf_get_precision() == 1;
+    const bool bf3 = sf_get_precision() >= 1;
     // choices below come from tools/gemm_bench.py on MI355X (profiles/r01_gemm_configs.txt)
     if constexpr (ALOAD == ALOAD_CONV_NHWC || ALOAD == ALOAD_DECONV_NHWC) {
       return launch_by_id<ALOAD, LN>(bf3 ? 100 : 28, a, stream);
@@ -687,6 +692,7 @@ int sf_gemm_dispatch(const SfGemmArgs& a_in, int aload, hipStream_t stream) {
     const char* e = getenv("SF_GEMM_DBG");
     a.dbg = e ? atoi(e) : 0;
   }
+  a.bf1 = sf_get_precision() == 2;
   const bool ln = a.ln_g != nullptr;
   if (aload == ALOAD_PLAIN) return ln ? dispatch_tiles<ALOAD_PLAIN, true>(a, stream)
                                       : dispatch_tiles<ALOAD_PLAIN, false>(a, stream);
@@ -744,7 +750,7 @@ int sf_conv2d_nhwc_f32(const float* in, const float* w_packed, const float* bias
                        void* stream) {
   SF_REQUIRE(in && w_packed && out, "null pointer");
   SF_REQUIRE(F >= 0 && H > 0 && W > 0 && Cin > 0 && (Cin % 4) == 0 && Cout > 0 && (ks & 1), "bad conv shape");
-  if (sf_get_precision() == 1 && forced_cfg() < 0) {
+  if (sf_get_precision() >= 1 && forced_cfg() < 0) {
     // encoder shape (5x5, 64->64, 64-wide rows): halo-resident kernel (conv_halo.hip); SF_CONV_HALO=0 disables
     static const bool halo_on = []() { const char* e = getenv("SF_CONV_HALO"); return !(e && e[0] == '0'); }();
     if (halo_on) {
@@ -836,7 +842,7 @@ int sf_conv2d_nchw_in_f32(const float* img, long long frame_stride, const float*
                           int Win, int Cout, int ks, int stride, int relu, void* stream) {
   SF_REQUIRE(img && weight && out, "null pointer");
   SF_REQUIRE(F >= 0 && Cin > 0 && Hin > 0 && Win > 0 && Cout > 0 && (ks & 1) && stride >= 1, "bad conv shape");
-  if (sf_get_precision() == 1 && forced_cfg() < 0) {
+  if (sf_get_precision() >= 1 && forced_cfg() < 0) {
     // 3 -> 64 channels, 5x5, 64-wide output: input halo + patch matrix in LDS (conv_first.hip); SF_CONV_FIRST=0 disables
     static const bool on = []() { const char* e = getenv("SF_CONV_FIRST"); return !(e && e[0] == '0'); }();
     if (on) {

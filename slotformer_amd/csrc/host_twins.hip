@@ -81,7 +81,7 @@ int sf_kv_producer_f32(const float* feat, const float* ln0_g, const float* ln0_b
   SF_REQUIRE(feat && fc1_w && fc2_w && kv_w && kv && M > 0 && C0 > 0 && C1 > 0 && D > 0, "sf_kv_producer_f32: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   int fused = 1;
-  if (sf_get_precision() == 1)
+  if (sf_get_precision() >= 1)
     fused = sf_pixel_mlp_kv_ex(feat, ln0_g, ln0_b, fc1_w, fc1_b, fc2_w, fc2_b, ln1_g, ln1_b, kv_w, kv, M, C0, C1, 2 * D,
                                ln_eps, st);
   if (fused != 1) return fused;

@@ -706,7 +706,7 @@ __device__ __forceinline__ void tn_split8(const f32x8 v, bf16x8& hi, bf16x8& lo)
   hi = __builtin_convertvector(v, bf16x8);
   lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
 }
-template <bool EXACT>
+template <int MODE>   // 0: hi*hi + hi*lo + lo*hi + lo*lo, 1: without lo*lo (split-bf16), 2: hi*hi only (single-pass bf16)
 __global__ __launch_bounds__(256) void grad_gemm_tn_kernel(const float* __restrict__ Y, const float* __restrict__ X,
                                                            float* __restrict__ partial, long long rows, int rps, int N,
                                                            int K) {
@@ -767,9 +767,11 @@ __global__ __launch_bounds__(256) void grad_gemm_tn_kernel(const float* __restri
       tn_split8(a, ah, al);
       tn_split8(b, bh, bl);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-      if (EXACT) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc, 0, 0, 0);
+      if (MODE != 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      }
+      if (MODE == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc, 0, 0, 0);
     }
   }
   float* out = partial + (long long)blockIdx.y * N * K;
@@ -994,9 +996,11 @@ int grad_weight(const float* Y, const float* X, float* dW, long long rows, int N
   float* dst = splits == 1 ? dW : w.partial;
   const dim3 grid((N / 64) * (K / 64), splits);
   if (sf_get_precision() == 0)
-    hipLaunchKernelGGL(grad_gemm_tn_kernel<true>, grid, dim3(256), 0, st, Y, X, dst, rows, rps, N, K);
+    hipLaunchKernelGGL(grad_gemm_tn_kernel<0>, grid, dim3(256), 0, st, Y, X, dst, rows, rps, N, K);
+  else if (sf_get_precision() == 1)
+    hipLaunchKernelGGL(grad_gemm_tn_kernel<1>, grid, dim3(256), 0, st, Y, X, dst, rows, rps, N, K);
   else
-    hipLaunchKernelGGL(grad_gemm_tn_kernel<false>, grid, dim3(256), 0, st, Y, X, dst, rows, rps, N, K);
+    hipLaunchKernelGGL(grad_gemm_tn_kernel<2>, grid, dim3(256), 0, st, Y, X, dst, rows, rps, N, K);
   SF_CHECK_LAUNCH();
   if (splits > 1) {
     const long long n4 = (long long)N * K / 4;

@@ -31,7 +31,7 @@ __device__ __forceinline__ void cw_split8(const f32x8 v, bf16x8& hi, bf16x8& lo)
 // five kx-shifted copies of the X rows (loaded back to back, so the shifted re-reads hit in L2 -- with one tap per
 // workgroup the operands were streamed from HBM 25 times and the kernel sat at 59 TFLOP/s, HBM-bound).
 // grid (5 * CA/64, splits); partial [split][CA][25*64].  Structure of grad_gemm_tn_kernel otherwise.
-template <bool EXACT>
+template <int MODE>   // 0: all four split products, 1: split-bf16 (no lo*lo), 2: single-pass bf16
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                          float* __restrict__ partial, long long rows, int rps, int H, int W,
                                                          int CA, int s, int Hx, int Wx) {
@@ -101,9 +101,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
         bf16x8 bh, bl;
         cw_split8(b, bh, bl);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-        if (EXACT) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc[t], 0, 0, 0);
+        if (MODE != 2) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+        }
+        if (MODE == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc[t], 0, 0, 0);
       }
     }
   }
@@ -211,9 +213,11 @@ int sf_conv_wgrad_ex(const float* A, int CA, int H, int W, const float* X, int H
   rps = (rps + 31) & ~31;
   const dim3 grid(ks * nt, splits);
   if (sf_get_precision() == 0)
-    hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, CA, s, Hx, Wx);
+    hipLaunchKernelGGL(conv_wgrad_kernel<0>, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, CA, s, Hx, Wx);
+  else if (sf_get_precision() == 1)
+    hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, CA, s, Hx, Wx);
   else
-    hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, CA, s, Hx, Wx);
+    hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, CA, s, Hx, Wx);
   SF_CHECK_LAUNCH();
   const int total = CA * 64 * taps;
   hipLaunchKernelGGL(reduce_to_oihw_kernel, dim3((total + 255) / 256), dim3(256), 0, st, partial, out_oihw, splits, CA, 64, taps);

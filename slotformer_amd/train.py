@@ -482,6 +482,21 @@ def layer_norm(x, layer):
     return _LayerNorm.apply(x, layer.weight, layer.bias, layer.eps)
 
 
+class amp_bf16:
+    """Context manager for the AMP-bf16 policy of the training path: inside it the GEMM / convolution / weight-gradient
+    cores contract single-pass bf16 operands with f32 accumulation (library precision mode 2); parameters, activations,
+    gradients and the optimizer state stay fp32.  The counterpart of the reference's `--fp16` autocast (train.py:84)."""
+
+    def __enter__(self):
+        self.old = lib().sf_get_precision()
+        check(lib().sf_set_precision(2))
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().sf_set_precision(self.old))
+        return False
+
+
 def dropout_keep_mask(seed, step, layer, site, numel, p):
     """Host restatement of the library's dropout mask (rollout_train.hip: sf_keep / site_seed) for tests and tools:
     bool [numel], True = kept.  site: 0 attention weights, 1 attention output, 2 FFN hidden, 3 FFN output."""

@@ -421,3 +421,45 @@ def test_dropout_and_attention_nodes(dev):
     ref.backward(dctx)
     assert rel_err(ctx, ref) < 1e-5
     assert rel_err(qg.grad, qo.grad) < 1e-4
+
+
+def test_amp_bf16_policy(dev):
+    """Precision mode 2 (train.amp_bf16): single-pass bf16 contractions (8 mantissa bits per operand), fp32 everything else.
+    Losses stay within 1 %, the gradients within ~10 % in L2 of the fp32 references on these fixtures (seeded weights much
+    larger than trained ones, plus ReLU-kink flips), and the mode is restored on exit."""
+    from slotformer_amd import train, _lib
+    before = _lib.lib().sf_get_precision()
+    # SlotFormer with the image loss
+    g = gu.load_golden('roll_train_img')
+    cfg = gu.TRAIN_ROLL_IMG
+    m, sd = build(cfg, g, 811, dev, vp=True)
+    m.train()
+    _no_dropout(m)
+    data = {'slots': gu.seeded_normal((1, 5, 3, 64), 812).to(dev).requires_grad_(True), 'img': gu.seeded_img(1, 5, 64, 813).to(dev)}
+    m.loss_decay_factor = 0.9
+    with train.amp_bf16():
+        assert _lib.lib().sf_get_precision() == 2
+        out = m(data)
+        terms = m.calc_train_loss(data, out)
+        loss = terms['slot_recon_loss'] + terms['img_recon_loss']
+        loss.backward()
+    assert _lib.lib().sf_get_precision() == before
+    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-2 * abs(float(g['loss']))
+    worst = max(l2_err(p.grad, g['grad.' + n]) for n, p in m.named_parameters() if n.startswith('rollouter.') and p.requires_grad)
+    assert worst < 0.15, worst
+    # StoSAVi
+    g = gu.load_golden('savi_train')
+    m, sd = build(gu.TRAIN_SAVI, g, 901, dev)
+    m.train()
+    m.testing = False
+    data = {'img': gu.seeded_img(1, 2, 64, 902).to(dev), 'noise': gu.seeded_normal((1, 2, 7, 128), 9).to(dev)}
+    with train.amp_bf16():
+        out = m(data)
+        terms = m.calc_train_loss(data, out)
+        loss = terms['post_recon_loss'] + float(g['kld_w']) * terms['kld_loss']
+        loss.backward()
+    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-2 * float(g['loss'])
+    got = dict(m.named_parameters())
+    errs = {n: abs(float(got[n].grad.norm()) - float(norm)) / float(norm) for n, norm in zip((str(x) for x in g['grad_names']), g['grad_norms'])
+            if n != 'slot_attention.project_q.0.bias'}
+    assert max(errs.values()) < 0.15, sorted(errs.items(), key=lambda kv: -kv[1])[:3]

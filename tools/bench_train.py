@@ -83,10 +83,14 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--eager', action='store_true')
+    ap.add_argument('--amp', action='store_true', help='AMP-bf16 policy: library precision mode 2 (train.amp_bf16)')
     ap.add_argument('--img', action='store_true', help='add the image term (use_img_recon_loss=True, 64x64 frames)')
     ap.add_argument('--phases', action='store_true')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
+    if a.amp:
+        from slotformer_amd import _lib
+        _lib.check(_lib.lib().sf_set_precision(2))
     S, B = a.rollout, a.batch
     m, cfg = build(dev, S, a.img)
     slots = (0.5 * gu.seeded_normal((B, 6 + S, 7, 128), 1)).to(dev)
@@ -109,7 +113,7 @@ def main():
     res = {'metric': 'slotformer_training_iterations_per_sec', 'value': round(1e3 / ms, 2), 'unit': 'it/s', 'ms_per_iter': round(ms, 3),
            'frames_per_sec': round(B * (6 + S) * 1e3 / ms, 1),
            'config': {'workload': f'SlotFormer CLEVRER training step, B={B}, 6+{S} frames, 7 slots, d=256, 4 layers, '
-                                  'dropout 0.1, slot loss' + (' + image loss through the frozen SAVi decoder (64x64)' if a.img else '') + ', Adam', 'dtype': 'f32 (split-bf16 MFMA)'}}
+                                  'dropout 0.1, slot loss' + (' + image loss through the frozen SAVi decoder (64x64)' if a.img else '') + ', Adam', 'dtype': 'f32 storage, single-pass bf16 MFMA (AMP policy)' if a.amp else 'f32 (split-bf16 MFMA)'}}
     if a.phases:
         def fwd():
             with torch.no_grad():

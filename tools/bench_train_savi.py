@@ -63,8 +63,12 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--eager', action='store_true')
+    ap.add_argument('--amp', action='store_true', help='AMP-bf16 policy: library precision mode 2 (train.amp_bf16)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
+    if a.amp:
+        from slotformer_amd import _lib
+        _lib.check(_lib.lib().sf_set_precision(2))
     from slotformer_amd.base_slots import build_model
     from slotformer_amd.host import losses
     torch.manual_seed(0)
@@ -88,7 +92,7 @@ def main():
     res = {'metric': 'stosavi_training_iterations_per_sec', 'value': round(1e3 / ms, 2), 'unit': 'it/s', 'ms_per_iter': round(ms, 2),
            'frames_per_sec': round(B * T * 1e3 / ms, 1),
            'config': {'workload': f'StoSAVi CLEVRER training step, B={B}, T={T}, 64x64, 7 slots, 2 SA iterations, MLP predictor, '
-                                  'recon + KLD loss, Adam', 'dtype': 'f32 (split-bf16 MFMA)'}}
+                                  'recon + KLD loss, Adam', 'dtype': 'f32 storage, single-pass bf16 MFMA (AMP policy)' if a.amp else 'f32 (split-bf16 MFMA)'}}
     if a.eager:
         def estep():
             opt.zero_grad(set_to_none=True)
