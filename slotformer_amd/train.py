@@ -7,6 +7,11 @@ all-reduce works on (parallel.allreduce_flat_bucket's layout, without the pack /
 torch autograd over the reference's per-step nn.TransformerEncoder calls (slotformer.py:110-124) and nerv's DDP wrap.
 
 Dropout follows nn.TransformerEncoderLayer: active iff the module is in train() mode, p read from the layer.
+
+Data-parallel training: SlotFormer's parameters all belong to ONE node, so `rollouter.ddp_flat_bucket = True` lets that node
+all-reduce its bucket inside backward().  StoSAVi's step is a chain of nodes (image encoder, one Slot-Attention node per
+frame, predictor layers, decoder) whose gradients autograd accumulates into `.grad`; there the step ends with one
+`parallel.allreduce_flat_bucket(model.parameters())` -- still a single RCCL call (4.8 MB).
 """
 import ctypes as C
 
@@ -164,9 +169,6 @@ class _SlotAttention(torch.autograd.Function):
                                                     sa.num_iterations, ctx.ws.data_ptr(), ctx.ws.numel(),
                                                     torch.cuda.current_stream().cuda_stream))
         ctx.ws = None
-        if getattr(sa, 'ddp_flat_bucket', False):
-            parallel.allreduce_flat(flat)
-        sa.last_grad_bucket = flat
         grads = _split(flat, params)
         return (None, d_in, d_slots if ctx.needs_input_grad[2] else None) + tuple(
             g_ if ctx.needs_input_grad[3 + i] else None for i, g_ in enumerate(grads))
@@ -245,8 +247,6 @@ class _Decode(torch.autograd.Function):
         ctx.ws = None
         grads = ()
         if params:
-            if getattr(m, 'ddp_flat_bucket', False):
-                parallel.allreduce_flat(flat)
             grads = tuple(g_ if ctx.needs_input_grad[2 + i] else None for i, g_ in enumerate(_split(flat, params)))
         return (None, d_slots if ctx.needs_input_grad[1] else None) + grads
 
@@ -323,8 +323,6 @@ class _Features(torch.autograd.Function):
         check(lib().sf_savi_features_train_bwd_f32(C.byref(s), img.data_ptr(), img[0].numel(), d_out.data_ptr(), C.byref(g), img.shape[0],
                                                    ctx.ws.data_ptr(), ctx.ws.numel(), torch.cuda.current_stream().cuda_stream))
         ctx.ws = None
-        if getattr(ctx.m, 'ddp_flat_bucket', False):
-            parallel.allreduce_flat(flat)
         grads = _split(flat, params)
         return (None, None) + tuple(g_ if ctx.needs_input_grad[2 + i] else None for i, g_ in enumerate(grads))
 
