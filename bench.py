@@ -299,7 +299,7 @@ def main():
                 for sr in s_rolls:
                     sr.wait_stream(cur)
                 ev_enc = [torch.cuda.Event() for _ in range(n)]
-                ev_roll = [torch.cuda.Event() for _ in range(n)]
+                ev_roll = [torch.cuda.Event(enable_timing=True) for _ in range(n)]   # also: completion time of every batch
                 ev_pre = [torch.cuda.Event() for _ in range(n + 2)]
                 # (the first two batches compute their own convolutions: stealing starts with batch 2, whose features are
                 #  produced after the rollout of batch 0)
@@ -332,6 +332,7 @@ def main():
                 cur.wait_stream(s_enc)
                 for sr in s_rolls:
                     cur.wait_stream(sr)
+                return ev_roll
 
         def barrier():
             if use_dist:
@@ -350,8 +351,9 @@ def main():
         read_profile(lib)
         barrier()
         t0 = time.perf_counter()
+        batch_done = None
         if overlap:
-            run_pipelined(args.steps)
+            batch_done = run_pipelined(args.steps)
         else:
             for _ in range(args.steps):
                 step()
@@ -441,6 +443,12 @@ def main():
 
     if rank == 0:
         frames = world * B * (T_BURN + T_ROLL) * args.steps
+        step_dist = None
+        if batch_done is not None and len(batch_done) > 2:
+            # device time between the completions of consecutive batches inside the timed region (rank 0)
+            gaps = sorted(batch_done[j - 1].elapsed_time(batch_done[j]) for j in range(1, len(batch_done)))
+            pick = lambda q: gaps[min(len(gaps) - 1, int(q * len(gaps)))]  # noqa: E731
+            step_dist = {'p10': pick(0.10), 'median': pick(0.50), 'p90': pick(0.90), 'n': len(gaps)}
         res = {
             'metric': 'rollout frames/sec at B=32, 128x128, 7 slots, 6+50 steps (SAVi-encode + SlotFormer rollout)',
             'value': frames / elapsed,
@@ -472,6 +480,7 @@ def main():
             'encode_ms': 1e3 * t_enc,
             'rollout_ms': 1e3 * t_roll,
             'partitioned_ms': part_ms,
+            'ms_per_step_distribution': step_dist,
             'encoded_frames_per_s': B * T_BURN / t_enc,
             'predicted_frames_per_s': B * T_ROLL / t_roll,
         }
