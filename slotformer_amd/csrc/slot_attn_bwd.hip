@@ -11,8 +11,10 @@
 // HBM-bound like the forward: one pass that reads K and V and writes (or accumulates into) dK and dV -- 4 D floats per
 // pixel against ~70 D flops.  16 lanes share a pixel (lane j owns the float4 channel groups j, j+16, ...: a 16-lane row
 // reads whole 256-byte segments), so the 2N dot products per pixel are 4-step DPP row reductions with no LDS or
-// cross-row traffic; q, g and the running dq sums live in registers.  Every workgroup emits one dq partial record,
-// summed in a fixed order by a second kernel (deterministic).
+// cross-row traffic.  The running dq sums live in registers; the scaled queries and g sit in LDS and are read as broadcasts
+// (the 16 lanes of a row read 16 consecutive float4, every row the same ones) -- with them in registers too the kernel
+// needed 348 VGPRs, one wave per SIMD, and reached 3.3 TB/s; this way two workgroups share a CU.  Every workgroup emits one
+// dq partial record, summed in a fixed order by a second kernel (deterministic).
 #include "../../include/slotformer_hip.h"
 #include "sf_internal.h"
 
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(64) void sa_bwd_prep_kernel(const float* __restrict
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void sa_iter_bwd_kernel(const float* __restrict__ k, const float* __restrict__ v, int ld,
+__global__ __launch_bounds__(256, 2) void sa_iter_bwd_kernel(const float* __restrict__ k, const float* __restrict__ v, int ld,
                                                           long long batch_stride, const float* __restrict__ q,
                                                           const float* __restrict__ g, const float* __restrict__ c,
                                                           float* __restrict__ dk, float* __restrict__ dv, int accumulate,
@@ -49,25 +51,25 @@ __global__ __launch_bounds__(256) void sa_iter_bwd_kernel(const float* __restric
   extern __shared__ float red[];
   const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
   const int tid = threadIdx.x, j = tid & 15, grp = tid >> 4;   // 16 pixel groups per workgroup
-  float4 qs[SAB_NMAX][C4], gg[SAB_NMAX][C4], dqa[SAB_NMAX][C4];
+  // red: [16][D] floats for the final dq reduction, then qs [NMAX][D] (scaled queries) and gg [NMAX][D]
+  float* qsl = red + 16 * D;
+  float* ggl = qsl + SAB_NMAX * D;
+  for (int i = tid; i < SAB_NMAX * D; i += 256) {
+    const int n = i / D;
+    qsl[i] = n < N ? q[(long long)b * N * D + i] * scale : 0.f;
+    ggl[i] = n < N ? g[(long long)b * N * D + i] : 0.f;
+  }
+  float4 dqa[SAB_NMAX][C4];
   float cc[SAB_NMAX];
 #pragma unroll
   for (int n = 0; n < SAB_NMAX; ++n) {
     cc[n] = n < N ? c[(long long)b * N + n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < C4; ++i) {
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 a = z, e = z;
-      if (n < N) {
-        a = *reinterpret_cast<const float4*>(q + ((long long)b * N + n) * D + 4 * (j + 16 * i));
-        e = *reinterpret_cast<const float4*>(g + ((long long)b * N + n) * D + 4 * (j + 16 * i));
-        a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
-      }
-      qs[n][i] = a;
-      gg[n][i] = e;
-      dqa[n][i] = z;
-    }
+    for (int i = 0; i < C4; ++i) dqa[n][i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  __syncthreads();
+#define QS(n, i) (*reinterpret_cast<const float4*>(&qsl[(n) * D + 4 * (j + 16 * (i))]))
+#define GG(n, i) (*reinterpret_cast<const float4*>(&ggl[(n) * D + 4 * (j + 16 * (i))]))
   const long long fb = (long long)b * batch_stride;
   const int p0 = chunk * SAB_PIX;
   float4 kk[C4], vv[C4];
@@ -114,8 +116,9 @@ __global__ __launch_bounds__(256) void sa_iter_bwd_kernel(const float* __restric
       float a = 0.f, e = 0.f;
 #pragma unroll
       for (int i = 0; i < C4; ++i) {
-        a += (kc[i].x * qs[n][i].x + kc[i].y * qs[n][i].y) + (kc[i].z * qs[n][i].z + kc[i].w * qs[n][i].w);
-        e += (vc[i].x * gg[n][i].x + vc[i].y * gg[n][i].y) + (vc[i].z * gg[n][i].z + vc[i].w * gg[n][i].w);
+        const float4 qv = QS(n, i), gv = GG(n, i);
+        a += (kc[i].x * qv.x + kc[i].y * qv.y) + (kc[i].z * qv.z + kc[i].w * qv.w);
+        e += (vc[i].x * gv.x + vc[i].y * gv.y) + (vc[i].z * gv.z + vc[i].w * gv.w);
       }
       s[n] = n < N ? sf_sum16(a) : -INFINITY;
       t[n] = sf_sum16(e);
@@ -141,8 +144,9 @@ __global__ __launch_bounds__(256) void sa_iter_bwd_kernel(const float* __restric
       const float ap = n < N ? s[n] + eps : 0.f;
 #pragma unroll
       for (int i = 0; i < C4; ++i) {
-        ok[i].x += dl * qs[n][i].x; ok[i].y += dl * qs[n][i].y; ok[i].z += dl * qs[n][i].z; ok[i].w += dl * qs[n][i].w;
-        ov[i].x += ap * gg[n][i].x; ov[i].y += ap * gg[n][i].y; ov[i].z += ap * gg[n][i].z; ov[i].w += ap * gg[n][i].w;
+        const float4 qv = QS(n, i), gv = GG(n, i);
+        ok[i].x += dl * qv.x; ok[i].y += dl * qv.y; ok[i].z += dl * qv.z; ok[i].w += dl * qv.w;
+        ov[i].x += ap * gv.x; ov[i].y += ap * gv.y; ov[i].z += ap * gv.z; ov[i].w += ap * gv.w;
         dqa[n][i].x += dl * kc[i].x; dqa[n][i].y += dl * kc[i].y; dqa[n][i].z += dl * kc[i].z; dqa[n][i].w += dl * kc[i].w;
       }
     }
@@ -209,7 +213,7 @@ int sf_slot_attn_iter_bwd_f32(const float* k, const float* v, int ld, long long 
   const int nchunks = (HW + SAB_PIX - 1) / SAB_PIX;
   hipLaunchKernelGGL(sa_bwd_prep_kernel, dim3(N, B), dim3(64), 0, st, part_num, part_den, P, d_updates, g, c, N, D);
   SF_CHECK_LAUNCH();
-  const size_t lds = (size_t)16 * D * sizeof(float);
+  const size_t lds = (size_t)(16 + 2 * SAB_NMAX) * D * sizeof(float);
   if (D == 64)
     hipLaunchKernelGGL(sa_iter_bwd_kernel<64>, dim3(nchunks, B), dim3(256), lds, st, k, v, ld, batch_stride, q, g, c, dk, dv,
                        accumulate, part, HW, N, scale, eps);
