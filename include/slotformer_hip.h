@@ -96,7 +96,7 @@ int sf_slot_attn_iter_f32(const float* k, const float* v, int ld, long long batc
 /* Backward of sf_slot_attn_iter_f32 (row N1: savi.py:82-94 under autograd).  Inputs of the forward call (k, v, q, the
  * partial records it produced) plus d_updates [B,N,D], the gradient w.r.t. updates = sum(num) / sum(den).  Writes
  * dq [B,N,D] and dk / dv (same row layout as k / v); accumulate != 0 adds into dk / dv instead (the iterations of one
- * frame share k and v).  slot_size 64 or 128, at most 8 slots. */
+ * frame share k and v).  slot_size 64 / 128 / 192 / 256, at most 8 slots. */
 size_t sf_slot_attn_iter_bwd_workspace_bytes(int B, int HW, int N, int D);
 int sf_slot_attn_iter_bwd_f32(const float* k, const float* v, int ld, long long batch_stride, const float* q,
                               const float* part_num, const float* part_den, int P, const float* d_updates, float* dk,
@@ -282,7 +282,7 @@ int sf_savi_features_train_bwd_f32(const sf_savi_features* m, const float* img, 
 /* ---- training of the Slot-Attention module ------------------------------------------------
  * SlotAttention (savi.py:36-102) under autograd: parameters in torch layouts, gradients with the same shapes (written,
  * not accumulated).  The forward keeps its activations in the caller's workspace for the backward call.
- * slot_size 64 / 128, in_features and mlp_hidden multiples of 64, at most 8 slots and 8 iterations. */
+ * slot_size 64 / 128 / 192 / 256, in_features and mlp_hidden multiples of 64, at most 8 slots and 8 iterations. */
 typedef struct {
   int in_features, slot_size, mlp_hidden, num_slots;
   const float *norm_in_g, *norm_in_b, *wk, *wv;                  /* norm_inputs, project_k / project_v [D, in] */

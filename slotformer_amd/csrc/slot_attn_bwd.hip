@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) void sa_bwd_prep_kernel(const float* __restrict
 }
 
 template <int D>
-__global__ __launch_bounds__(256, 2) void sa_iter_bwd_kernel(const float* __restrict__ k, const float* __restrict__ v, int ld,
+__global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void sa_iter_bwd_kernel(const float* __restrict__ k, const float* __restrict__ v, int ld,
                                                           long long batch_stride, const float* __restrict__ q,
                                                           const float* __restrict__ g, const float* __restrict__ c,
                                                           float* __restrict__ dk, float* __restrict__ dv, int accumulate,
@@ -202,7 +202,7 @@ int sf_slot_attn_iter_bwd_f32(const float* k, const float* v, int ld, long long 
                               size_t ws_bytes, void* stream) {
   SF_REQUIRE(k && v && q && part_num && part_den && d_updates && dk && dv && dq && ws, "null pointer");
   SF_REQUIRE(B >= 0 && HW > 0 && N >= 1 && N <= SAB_NMAX && P >= 1, "need 1 <= num_slots <= 8");
-  SF_REQUIRE(D == 64 || D == 128, "slot_size must be 64 or 128");
+  SF_REQUIRE(D == 64 || D == 128 || D == 192 || D == 256, "slot_size must be 64 / 128 / 192 / 256");
   SF_REQUIRE(ld >= D && (ld % 4) == 0 && (batch_stride % 4) == 0, "k/v rows must be 16-byte aligned");
   SF_REQUIRE(ws_bytes >= sf_slot_attn_iter_bwd_workspace_bytes(B, HW, N, D), "workspace too small");
   if (B == 0) return 0;
@@ -214,12 +214,16 @@ int sf_slot_attn_iter_bwd_f32(const float* k, const float* v, int ld, long long 
   hipLaunchKernelGGL(sa_bwd_prep_kernel, dim3(N, B), dim3(64), 0, st, part_num, part_den, P, d_updates, g, c, N, D);
   SF_CHECK_LAUNCH();
   const size_t lds = (size_t)(16 + 2 * SAB_NMAX) * D * sizeof(float);
-  if (D == 64)
-    hipLaunchKernelGGL(sa_iter_bwd_kernel<64>, dim3(nchunks, B), dim3(256), lds, st, k, v, ld, batch_stride, q, g, c, dk, dv,
-                       accumulate, part, HW, N, scale, eps);
-  else
-    hipLaunchKernelGGL(sa_iter_bwd_kernel<128>, dim3(nchunks, B), dim3(256), lds, st, k, v, ld, batch_stride, q, g, c, dk, dv,
-                       accumulate, part, HW, N, scale, eps);
+#define SAB_LAUNCH(DD)                                                                                                       \
+  hipLaunchKernelGGL(sa_iter_bwd_kernel<DD>, dim3(nchunks, B), dim3(256), lds, st, k, v, ld, batch_stride, q, g, c, dk, dv, \
+                     accumulate, part, HW, N, scale, eps)
+  switch (D) {
+    case 64: SAB_LAUNCH(64); break;
+    case 128: SAB_LAUNCH(128); break;
+    case 192: SAB_LAUNCH(192); break;
+    default: SAB_LAUNCH(256); break;
+  }
+#undef SAB_LAUNCH
   SF_CHECK_LAUNCH();
   hipLaunchKernelGGL(sa_bwd_dq_reduce_kernel, dim3((N * D + 255) / 256, B), dim3(256), 0, st, part, dq, nchunks, N * D, scale);
   SF_CHECK_LAUNCH();

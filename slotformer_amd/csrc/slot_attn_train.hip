@@ -121,7 +121,7 @@ int check(const sf_slot_attention* m, SaDims& d, int B, int HW, int iters) {
   SF_REQUIRE(m, "null model");
   SF_REQUIRE(B > 0 && HW > 0 && iters >= 1 && iters <= 8, "bad sizes");
   d.B = B; d.HW = HW; d.N = m->num_slots; d.D = m->slot_size; d.Cin = m->in_features; d.H = m->mlp_hidden; d.I = iters;
-  SF_REQUIRE(d.D == 64 || d.D == 128, "slot_size must be 64 or 128");
+  SF_REQUIRE(d.D == 64 || d.D == 128 || d.D == 192 || d.D == 256, "slot_size must be 64 / 128 / 192 / 256");
   SF_REQUIRE(d.Cin % 64 == 0 && d.H % 64 == 0 && d.Cin <= 1024, "in_features and mlp_hidden must be multiples of 64");
   SF_REQUIRE(d.N >= 1 && d.N <= 8, "1..8 slots");
   d.P = sf_slot_attn_num_partials(HW);

@@ -155,7 +155,7 @@ def test_training_step_reduces_loss(dev):
     assert rel_err(pred, ref) < 1e-3
 
 
-@pytest.mark.parametrize('B,HW,N,D', [(3, 4096, 7, 128), (2, 4096, 6, 128), (2, 1024, 4, 64), (1, 4096, 8, 128)])
+@pytest.mark.parametrize('B,HW,N,D', [(3, 4096, 7, 128), (2, 4096, 6, 128), (2, 1024, 4, 64), (1, 4096, 8, 128), (2, 4096, 6, 192), (1, 1024, 5, 256)])
 def test_slot_attention_iteration_backward(dev, B, HW, N, D):
     """sf_slot_attn_iter_bwd_f32 against autograd of the oracle's attention half (savi.py:82-94)."""
     from slotformer_amd import ops
@@ -177,7 +177,7 @@ def test_slot_attention_iteration_backward(dev, B, HW, N, D):
     assert rel_err(dk2, 2 * kk.grad) < 1e-4 and rel_err(dv2, 2 * vv.grad) < 1e-4 and rel_err(dq2, qq.grad) < 1e-4
 
 
-@pytest.mark.parametrize('B,HW,N,D,Cin,H,iters', [(3, 4096, 7, 128, 128, 256, 2), (2, 1024, 4, 64, 64, 128, 3)])
+@pytest.mark.parametrize('B,HW,N,D,Cin,H,iters', [(3, 4096, 7, 128, 128, 256, 2), (2, 1024, 4, 64, 64, 128, 3), (2, 4096, 6, 192, 192, 384, 2)])
 def test_slot_attention_module_backward(dev, precision, B, HW, N, D, Cin, H, iters):
     """SlotAttention.forward under autograd (savi.py:56-102: LN + k/v projection, `iters` x [q projection, attention,
     GRUCell, residual MLP]) against autograd of the oracle: output, gradients of all 17 parameter leaves, of the input
