@@ -248,6 +248,10 @@ int sf_mha_train_bwd_f32(const float* qkv, const float* d_ctx, float* d_qkv, int
 /* y = res + dropout(x) (nn.Dropout in train mode; res may be NULL; n % 4 == 0).  Its backward is the same call on dy. */
 int sf_dropout_f32(const float* x, const float* res, float* y, long long n, float dropout_p, unsigned long long seed,
                    void* stream);
+/* torch.optim.Adam (the reference's optimiser: slotformer_clevrer_params.py:16-19, stosavi_clevrer_params.py:14-17; no
+ * weight decay, no amsgrad) over one flat fp32 bucket of n elements; step is the 1-based step count. */
+int sf_adam_flat_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr,
+                     float beta1, float beta2, float eps, void* stream);
 /* Backward of nn.LayerNorm over the last dimension (D <= 1024, D % 4 == 0). */
 size_t sf_layernorm_bwd_workspace_bytes(int D);
 int sf_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta,

@@ -155,6 +155,7 @@ SIGNATURES = {
     'sf_mha_train_fwd_f32': (I, [FP, FP, I, I, I, I, F32, C.c_ulonglong, VP]),
     'sf_mha_train_bwd_f32': (I, [FP, FP, FP, I, I, I, I, F32, C.c_ulonglong, VP]),
     'sf_dropout_f32': (I, [FP, FP, FP, LL, F32, C.c_ulonglong, VP]),
+    'sf_adam_flat_f32': (I, [FP, FP, FP, FP, LL, I, F32, F32, F32, F32, VP]),
     'sf_layernorm_bwd_workspace_bytes': (SZ, [I]),
     'sf_layernorm_bwd_f32': (I, [FP, FP, FP, FP, FP, FP, LL, I, F32, VP, SZ, VP]),
     'sf_rollout_train_workspace_bytes': (SZ, [C.POINTER(sf_rollouter), I, I]),

@@ -1139,6 +1139,32 @@ int sf_dropout_f32(const float* x, const float* res, float* y, long long n, floa
   return 0;
 }
 
+// torch.optim.Adam (no amsgrad, no weight decay: the reference's optimiser, slotformer_clevrer_params.py:16-19) over ONE flat
+// fp32 bucket: p, g, m, v [n]; step = the 1-based step count.  One launch per optimiser step.
+__global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                        float bc1, float bc2_sqrt) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  // torch: denom = sqrt(v) / sqrt(bias_correction2) + eps;  p -= (lr / bias_correction1) * m / denom
+  p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+}
+int sf_adam_flat_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr, float beta1,
+                     float beta2, float eps, void* stream) {
+  SF_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "bad Adam arguments");
+  if (n == 0) return 0;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                     beta1, beta2, eps, bc1, sqrtf(bc2));
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
 size_t sf_layernorm_bwd_workspace_bytes(int D) { return ((size_t)513 * 2 * D + 128) * sizeof(float) + 256; }
 int sf_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, long long rows,
                          int D, float eps, void* ws, size_t ws_bytes, void* stream) {

@@ -480,6 +480,51 @@ def layer_norm(x, layer):
     return _LayerNorm.apply(x, layer.weight, layer.bias, layer.eps)
 
 
+class FlatAdam:
+    """Adam (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8, no weight decay -- the reference's optimiser) over ONE
+    flat bucket.  The parameters are re-pointed at views of a single fp32 tensor (their values are kept), gradients are
+    gathered into a matching flat tensor, and a step is one `sf_adam_flat_f32` launch -- plus, under data parallelism
+    (`allreduce=True`), one RCCL all-reduce of that gradient bucket first.  `lr` may be changed between steps (schedules)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, allreduce=False):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params or not self.params[0].is_cuda:
+            raise RuntimeError('slotformer_amd: FlatAdam needs parameters on a HIP device; there is no CPU fallback')
+        self.lr, self.betas, self.eps, self.allreduce, self.steps = float(lr), betas, float(eps), allreduce, 0
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.detach().reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p)   # same values, now a view of the bucket
+            off += k
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros_like(self.grad)
+        self.exp_avg_sq = torch.zeros_like(self.grad)
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None
+
+    def step(self):
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            if p.grad is None:
+                self.grad[off:off + k].zero_()
+            else:
+                self.grad[off:off + k].copy_(p.grad.reshape(-1))
+            off += k
+        if self.allreduce:
+            parallel.allreduce_flat(self.grad)
+        self.steps += 1
+        check(lib().sf_adam_flat_f32(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                     self.flat.numel(), self.steps, self.lr, float(self.betas[0]), float(self.betas[1]), self.eps,
+                                     torch.cuda.current_stream().cuda_stream))
+
+
 class amp_bf16:
     """Context manager for the AMP-bf16 policy of the training path: inside it the GEMM / convolution / weight-gradient
     cores contract single-pass bf16 operands with f32 accumulation (library precision mode 2); parameters, activations,

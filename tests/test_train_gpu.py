@@ -463,3 +463,31 @@ def test_amp_bf16_policy(dev):
     errs = {n: abs(float(got[n].grad.norm()) - float(norm)) / float(norm) for n, norm in zip((str(x) for x in g['grad_names']), g['grad_norms'])
             if n != 'slot_attention.project_q.0.bias'}
     assert max(errs.values()) < 0.15, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+
+
+def test_flat_adam_matches_torch(dev):
+    """train.FlatAdam (one sf_adam_flat_f32 launch over the flat parameter bucket) against torch.optim.Adam, the reference's
+    optimiser, over several steps on the rollouter's parameters with synthetic gradients."""
+    from slotformer_amd import train
+    from slotformer_amd.video_prediction.models import SlotRollouter
+    torch.manual_seed(3)
+    a = SlotRollouter(**gu.C1_ROLL['rollout_dict']).to(dev)
+    b = SlotRollouter(**gu.C1_ROLL['rollout_dict']).to(dev)
+    b.load_state_dict(a.state_dict())
+    ref = torch.optim.Adam([p for p in a.parameters() if p.requires_grad], lr=2e-4)
+    opt = train.FlatAdam(b.parameters(), lr=2e-4)
+    assert all(torch.equal(x, y) for x, y in zip(a.state_dict().values(), b.state_dict().values()))   # re-pointing kept the values
+    for step in range(5):
+        g = torch.Generator(device='cpu').manual_seed(100 + step)
+        for pa, pb in zip([p for p in a.parameters() if p.requires_grad], opt.params):
+            gr = torch.randn(pa.shape, generator=g).to(dev) * 0.1
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        ref.step()
+        opt.step()
+    for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+        assert rel_err(pb, pa.detach().cpu()) < 1e-5, n   # fp32 rounding of the bias corrections
+    # the parameters are views of one bucket, and the inference engine sees the updated values
+    assert opt.params[0].data_ptr() == opt.flat.data_ptr()
+    x = gu.seeded_normal((2, 6, 6, 128), 5).to(dev)
+    with torch.no_grad():
+        assert rel_err(b.eval()(x, 3), a.eval()(x, 3).cpu()) < 1e-5

@@ -83,6 +83,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--eager', action='store_true')
+    ap.add_argument('--flat-adam', action='store_true', help='train.FlatAdam (one HIP launch per step) instead of torch.optim.Adam')
     ap.add_argument('--amp', action='store_true', help='AMP-bf16 policy: library precision mode 2 (train.amp_bf16)')
     ap.add_argument('--img', action='store_true', help='add the image term (use_img_recon_loss=True, 64x64 frames)')
     ap.add_argument('--phases', action='store_true')
@@ -98,7 +99,11 @@ def main():
     if a.img:
         data['img'] = torch.rand(B, 6 + S, 3, 64, 64, device=dev) * 2 - 1
     params = [p for p in m.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=2e-4)
+    if a.flat_adam:
+        from slotformer_amd import train as sf_train
+        opt = sf_train.FlatAdam(params, lr=2e-4)
+    else:
+        opt = torch.optim.Adam(params, lr=2e-4)
 
     def step():
         opt.zero_grad(set_to_none=True)

@@ -63,6 +63,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--eager', action='store_true')
+    ap.add_argument('--flat-adam', action='store_true', help='train.FlatAdam (one HIP launch per step) instead of torch.optim.Adam')
     ap.add_argument('--amp', action='store_true', help='AMP-bf16 policy: library precision mode 2 (train.amp_bf16)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -78,7 +79,11 @@ def main():
     img = torch.rand(B, T, 3, 64, 64, device=dev) * 2 - 1
     noise = torch.randn(B, T, 7, 128, device=dev)
     data = {'img': img, 'noise': noise}
-    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+    if a.flat_adam:
+        from slotformer_amd import train as sf_train
+        opt = sf_train.FlatAdam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+    else:
+        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
     kld_w = 1e-4
 
     def step():
