@@ -161,18 +161,22 @@ __global__ __launch_bounds__(NT) void conv5x5_halo_kernel(const float* __restric
   // ---- epilogue: bias, ReLU, optional per-position table, NHWC store ------------------------------------
   const int co = kh * 32 + (lane & 31);
   const float bv = bias ? bias[co] : 0.f;
-  const float lo = relu ? 0.f : -INFINITY;
+  // relu == 2 (training, backward-data pass): `add` is the forward activation of the layer below, laid out like `out`, and
+  // acts as its ReLU mask -- out = add > 0 ? conv : 0
+  const bool mask = relu == 2;
+  const float lo = relu == 1 ? 0.f : -INFINITY;
   const int y = y0 + row;
   float av[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int px = pxb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    av[r] = add ? add[((long long)y * TW + px) * CH + co] : 0.f;
+    av[r] = add ? add[((long long)(mask ? f * H + y : y) * TW + px) * CH + co] : 0.f;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int px = pxb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    out[(((long long)f * H + y) * TW + px) * CH + co] = fmaxf(fin[r] + bv, lo) + av[r];
+    const float t = fmaxf(fin[r] + bv, lo);
+    out[(((long long)f * H + y) * TW + px) * CH + co] = mask ? (av[r] > 0.f ? t : 0.f) : t + av[r];
   }
 }
 

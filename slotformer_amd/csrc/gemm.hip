@@ -50,6 +50,10 @@ struct SfGemmArgs {
   // sf_mix32((row * N + col) ^ drop_seed) >> 8 >= drop_thresh and scaled by drop_scale; drop_thresh == 0: off
   uint32_t drop_seed, drop_thresh;
   float drop_scale;
+  // mask_mode (training backward passes): `res` is not added but gates the result, C = res > 0 ? act(acc + bias) * mask_scale : 0
+  // (the ReLU / dropout adjoint folded into the GEMM that produces the gradient)
+  int mask_mode;
+  float mask_scale;
   int bf1;  // split-bf16 kernels: contract the hi parts only (precision mode 2)
   int dbg;  // ablation bits (SF_GEMM_DBG, tools only): 1 no MFMA, 2 no main-loop loads, 4 no LN stats, 8 no stores
 };
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
         const int row = rbase + (r & 3) + 8 * (r >> 2);
         float t = fmaxf(acc[i][j][r] + bias, lo);
         if (p.drop_thresh) t = (sf_mix32((uint32_t)(row * N + col) ^ p.drop_seed) >> 8) >= p.drop_thresh ? t * p.drop_scale : 0.f;
-        const float v = t + rv[r];
+        const float v = p.mask_mode ? (rv[r] > 0.f ? t * p.mask_scale : 0.f) : t + rv[r];
         int orow = row;
         if constexpr (ALOAD == ALOAD_DECONV_NHWC) {
           if (p.cSub) {   // class-grid row -> output pixel
@@ -725,6 +729,17 @@ int sf_linear_dropout_ex(const float* A, const float* W, const float* bias, cons
   return sf_gemm_dispatch(a, ALOAD_PLAIN, stream);
 }
 
+// C = mask > 0 ? (A . W^T) * scale : 0   (the data-gradient GEMM of a ReLU(+dropout) layer; mask = its saved output)
+int sf_linear_masked_ex(const float* A, const float* W, const float* mask, float scale, float* C, long long M, int N, int K,
+                        hipStream_t stream) {
+  SfGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.amap = sf_rows(K); a.W = W; a.ldw = K;
+  a.res = mask; a.rmap = sf_rows(N); a.mask_mode = 1; a.mask_scale = scale;
+  a.C = C; a.cmap = sf_rows(N); a.M = (int)M; a.N = N; a.K = K;
+  return sf_gemm_dispatch(a, ALOAD_PLAIN, stream);
+}
+
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
@@ -764,6 +779,9 @@ int sf_conv2d_nhwc_f32(const float* in, const float* w_packed, const float* bias
   a.res = add; a.rmap = sf_rows(Cout); a.res_mod = H * W;
   a.C = out; a.cmap = sf_rows(Cout);
   a.M = F * H * W; a.N = Cout; a.K = ks * ks * Cin; a.relu = relu;
+  if (relu == 2) {   // `add` is a per-frame ReLU mask (see conv_halo.hip)
+    a.relu = 0; a.res_mod = 0; a.mask_mode = 1; a.mask_scale = 1.f;
+  }
   a.cH = H; a.cW = W; a.cInH = H; a.cInW = W; a.cCin = Cin; a.cKs = ks; a.cStride = 1;
   a.cFrameStride = (long long)H * W * Cin;
   return sf_gemm_dispatch(a, ALOAD_CONV_NHWC, (hipStream_t)stream);
@@ -775,18 +793,21 @@ int sf_conv2d_nhwc_f32(const float* in, const float* w_packed, const float* bias
 // With w_packed = pack_conv(torch ConvTranspose2d weight [Cin_t, Cout_t, k, k]) this is the backward-data pass of
 // sf_conv_transpose2d_nhwc_f32 (training of the image loss, savi_decode_train.hip).
 int sf_conv2d_nhwc_strided_ex(const float* in, const float* w_packed, const float* bias, float* out, int F, int Hin, int Win,
-                              int Cin, int Cout, int ks, int stride, int relu, hipStream_t stream) {
+                              int Cin, int Cout, int ks, int stride, int relu, hipStream_t stream, const float* relu_mask) {
   SF_REQUIRE(in && w_packed && out, "null pointer");
   SF_REQUIRE(F >= 0 && Hin > 0 && Win > 0 && Cin > 0 && (Cin % 4) == 0 && Cout > 0 && (ks & 1) && stride >= 1 &&
                  Hin % stride == 0 && Win % stride == 0, "bad strided conv shape");
   if (stride == 1)   // the plain "same" convolution, with its halo-resident fast path
-    return sf_conv2d_nhwc_f32(in, w_packed, bias, nullptr, out, F, Hin, Win, Cin, Cout, ks, relu, (void*)stream);
+    return sf_conv2d_nhwc_f32(in, w_packed, bias, relu_mask, out, F, Hin, Win, Cin, Cout, ks, relu_mask ? 2 : relu, (void*)stream);
   SfGemmArgs a;
   memset(&a, 0, sizeof(a));
   const int Ho = Hin / stride, Wo = Win / stride;
   a.A = in; a.W = w_packed; a.ldw = ks * ks * Cin; a.bias = bias;
   a.C = out; a.cmap = sf_rows(Cout); a.rmap = sf_rows(Cout);
   a.M = F * Ho * Wo; a.N = Cout; a.K = ks * ks * Cin; a.relu = relu;
+  if (relu_mask) {   // out = relu_mask > 0 ? conv : 0, relu_mask laid out like out
+    a.res = relu_mask; a.mask_mode = 1; a.mask_scale = 1.f;
+  }
   a.cH = Ho; a.cW = Wo; a.cInH = Hin; a.cInW = Win; a.cCin = Cin; a.cKs = ks; a.cStride = stride;
   a.cFrameStride = (long long)Hin * Win * Cin;
   return sf_gemm_dispatch(a, ALOAD_CONV_NHWC, stream);

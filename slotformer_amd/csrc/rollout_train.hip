@@ -1307,10 +1307,8 @@ int sf_rollout_train_bwd_f32(const sf_rollouter* m, const float* d_pred, float* 
       float* dao = w.dao[l] + so * d;
       float* dqkv = w.dqkv[l] + so * 3 * d;
       float* da1 = w.da1[l] + so * d;
-      SF_TRY(gemm(dfo, w.wt_2[l], nullptr, nullptr, dpre, M, f, d, 0, st));
-      hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(cdiv((long long)M * f / 4, 256)), dim3(256), 0, st, dpre,
-                         w.hdn[l] + so * f, (long long)M * f / 4, thr ? inv_keep : 1.f);
-      SF_CHECK_LAUNCH();
+      // through linear2, the hidden dropout and the ReLU in one GEMM: the saved hidden activation is the mask
+      SF_TRY(sf_linear_masked_ex(dfo, w.wt_2[l], w.hdn[l] + so * f, thr ? inv_keep : 1.f, dpre, M, f, d, st));
       SF_TRY(gemm(dpre, w.wt_1[l], nullptr, nullptr, da2, M, d, f, 0, st));
       // xmid = xin + drop(attn_o): dxo = gradient w.r.t. xmid, dao = the same through the attention-output dropout
       hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, w.xmid[l] + so * d, da2, ly.norm2_g, dx, dxo, dao,

@@ -206,25 +206,25 @@ int sf_savi_decode_train_bwd_f32(const sf_savi_decoder* m, const float* const* d
     SF_CHECK_LAUNCH();
     SF_TRY(sf_grad_bias_ex(w.gb, g_out->out_b, rows, 4, w.partial, st));
   }
-  // head: d_act[L] = d_dec . W_out   (W_out [4, Cl]; the GEMM core wants its transpose as the weight operand)
+  // head: d_act[L] = d_dec . W_out   (W_out [4, Cl]; the GEMM core wants its transpose as the weight operand), gated in the
+  // epilogue by the ReLU of the last transposed conv (mask = its saved output)
   SF_TRY(sf_transpose_ex(m->out_w, w.wout_t, 4, Cl, st));
-  SF_TRY(sf_linear_ex(w.gb, sf_rows(4), w.wout_t, nullptr, nullptr, nullptr, 0.f, nullptr, sf_rows(Cl), 0, w.ga, sf_rows(Cl), R * HW, Cl,
-                      4, 0, st));
-  float* g = w.ga;
+  SF_TRY(sf_linear_masked_ex(w.gb, w.wout_t, w.act[L], 1.f, w.ga, (long long)R * HW, Cl, 4, st));
+  float* g = w.ga;   // gradient w.r.t. the pre-activation output of layer l
   float* o = w.gb;
   int h = m->resolution;
   for (int l = L - 1; l >= 0; --l) {
     SF_REQUIRE(deconv_w_bwd[l] != nullptr, "null backward weight");
-    const long long n = (long long)R * h * h * m->dec_channels[l + 1];
-    SF_TRY(sf_relu_bwd_ex(g, w.act[l + 1], n, st));
     if (g_out) {   // transposed-conv weight [C_l, C_{l+1}, k, k] and bias: A = the layer input, X = this gradient on the finer grid
       const int hin = h / m->dec_strides[l];
       SF_TRY(sf_grad_bias_ex(g, g_out->deconv_b[l], (long long)R * h * h, m->dec_channels[l + 1], w.partial, st));
       SF_TRY(sf_conv_wgrad_ex(w.act[l], m->dec_channels[l], hin, hin, g, h, h, m->dec_strides[l], m->dec_ks, (long long)R * hin * hin,
                               g_out->deconv_w[l], w.partial, st));
     }
+    // adjoint of the transposed conv = strided conv of the gradient; its output is gated by the ReLU of the layer below
+    // (act[0] is the broadcast input: no ReLU there)
     SF_TRY(sf_conv2d_nhwc_strided_ex(g, deconv_w_bwd[l], nullptr, o, R, h, h, m->dec_channels[l + 1], m->dec_channels[l], m->dec_ks,
-                                     m->dec_strides[l], 0, st));
+                                     m->dec_strides[l], 0, st, l >= 1 ? w.act[l] : nullptr));
     h /= m->dec_strides[l];
     float* t = g;
     g = o;

@@ -339,8 +339,7 @@ int sf_savi_features_train_bwd_f32(const sf_savi_features* m, const float* img, 
   SF_TRY(sf_grad_weight_ex(d_out, w.h1, g->fc2_w, M, Co, Hd, w.partial, st));
   SF_TRY(sf_grad_bias_ex(d_out, g->fc2_b, M, Co, w.partial, st));
   SF_TRY(sf_transpose_ex(m->fc2_w, w.w2t, Co, Hd, st));   // [Co,Hd] -> [Hd,Co]
-  SF_TRY(gemm(d_out, w.w2t, nullptr, w.g1, M, Hd, Co, 0, st));
-  SF_TRY(sf_relu_bwd_ex(w.g1, w.h1, M * Hd, st));
+  SF_TRY(sf_linear_masked_ex(d_out, w.w2t, w.h1, 1.f, w.g1, M, Hd, Co, st));   // through fc2 and the ReLU (mask = its output)
   SF_TRY(sf_grad_weight_ex(w.g1, w.xn, g->fc1_w, M, Hd, C, w.partial, st));
   SF_TRY(sf_grad_bias_ex(w.g1, g->fc1_b, M, Hd, w.partial, st));
   SF_TRY(sf_transpose_ex(m->fc1_w, w.w1t, Hd, C, st));    // [Hd,C] -> [C,Hd]
@@ -358,8 +357,7 @@ int sf_savi_features_train_bwd_f32(const sf_savi_features* m, const float* img, 
     // data gradient: convolution with the flipped / transposed kernel, then the ReLU of the layer below
     hipLaunchKernelGGL(pack_conv_bwd_kernel, dim3((C * C * 25 + 255) / 256), dim3(256), 0, st, m->conv_w[i], w.wb[i], C, C, 5);
     SF_CHECK_LAUNCH();
-    SF_TRY(sf_conv2d_nhwc_f32(cur, w.wb[i], nullptr, nullptr, nxt, F, 64, 64, C, C, 5, 0, st));
-    SF_TRY(sf_relu_bwd_ex(nxt, w.a[i - 1], M * C, st));
+    SF_TRY(sf_conv2d_nhwc_f32(cur, w.wb[i], nullptr, w.a[i - 1], nxt, F, 64, 64, C, C, 5, 2, st));   // relu = 2: gated by a[i-1] > 0
     float* t = cur;
     cur = nxt;
     nxt = t;

@@ -52,7 +52,9 @@ int sf_ln_bwd_ex(const float* x, const float* dy, const float* gamma, const floa
 int sf_transpose_ex(const float* in, float* out, int R, int Cn, hipStream_t st);
 int sf_relu_bwd_ex(float* dh, const float* h, long long n, hipStream_t st);
 int sf_conv2d_nhwc_strided_ex(const float* in, const float* w_packed, const float* bias, float* out, int F, int Hin, int Win,
-                              int Cin, int Cout, int ks, int stride, int relu, hipStream_t stream);
+                              int Cin, int Cout, int ks, int stride, int relu, hipStream_t stream, const float* relu_mask = nullptr);
+int sf_linear_masked_ex(const float* A, const float* W, const float* mask, float scale, float* C, long long M, int N, int K,
+                        hipStream_t stream);
 int sf_conv_wgrad_ex(const float* A, int CA, int H, int W, const float* X, int Hx, int Wx, int s, int ks, long long rows,
                      float* out_oihw, float* partial, hipStream_t st);
 size_t sf_conv_wgrad_partial_floats(int CA, int ks);

@@ -216,8 +216,7 @@ int sf_slot_attention_train_bwd_f32(const sf_slot_attention* m, const float* inp
     float* ds = w.ds + o * D;
     SF_TRY(copy(ds, ds_in, (size_t)R * D, st));
     // slots = h + W2 relu(W1 LN_m(h) + b1) + b2
-    SF_TRY(gemm(ds, w.w2t, nullptr, nullptr, w.dpre + o * H, R, H, D, 0, st));
-    SF_TRY(sf_relu_bwd_ex(w.dpre + o * H, w.hid + o * H, R * H, st));
+    SF_TRY(sf_linear_masked_ex(ds, w.w2t, w.hid + o * H, 1.f, w.dpre + o * H, R, H, D, st));   // through W2 and the ReLU
     SF_TRY(gemm(w.dpre + o * H, w.w1t, nullptr, nullptr, w.dhn + o * D, R, D, H, 0, st));
     SF_TRY(sf_ln_bwd_ex(w.h + o * D, w.dhn + o * D, m->mlp_ln_g, ds, w.dh, R, D, 1e-5f, st));
     // GRUCell
