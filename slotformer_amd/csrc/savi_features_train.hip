@@ -120,6 +120,98 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     }
 }
 
+// The same contraction for grids whose rows are a multiple of 32 pixels wide (the 64x64 and 32x32 maps that carry nearly all
+// the work): a chunk of 32 A pixels lies in one image row, so the X rows its five kx taps need are ONE window of 31*S + 5
+// consecutive pixels of image row y*S + dy.  The window is loaded once into LDS and every tap reads its rows out of it
+// (row j*S + kx) -- 2.3x (S = 1) / 1.5x (S = 2) fewer global loads than fetching five shifted copies.
+template <int MODE, int S>
+__global__ __launch_bounds__(256) void conv_wgrad_win_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                             float* __restrict__ partial, long long rows, int rps, int H, int W,
+                                                             int CA, int Hx, int Wx) {
+  constexpr int KS = 5, WR = 31 * S + 5, NW = (WR * 16 + 255) / 256;
+  __shared__ float Ys[32 * CW_P];
+  __shared__ float Xw[(WR + 1) * CW_P];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nt = CA / 64, ky = blockIdx.x / nt, n0 = (blockIdx.x % nt) * 64, dy = ky - KS / 2;
+  const long long r0 = (long long)blockIdx.y * rps;
+  const long long r1 = r0 + rps < rows ? r0 + rps : rows;
+  const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;
+  const int lr = tid >> 4, lc = (tid & 15) * 4;
+  f32x16 acc[KS];
+#pragma unroll
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const int nrows = (int)(r1 - r0);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int hw = H * W, rlast = (int)(rows - 1);
+  f32x4 pa[2], pw[NW];
+  // unconditional loads from clamped addresses + selects (see conv_wgrad_kernel)
+#define CWW_FETCH(rel)                                                                                                  \
+  {                                                                                                                     \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                                     \
+      const int rr0 = (rel) + lr + 16 * h;                                                                              \
+      const f32x4 a_ = *reinterpret_cast<const f32x4*>(dY + (long long)min((int)r0 + rr0, rlast) * CA + n0 + lc);       \
+      pa[h] = rr0 < nrows ? a_ : zero4;                                                                                 \
+    }                                                                                                                   \
+    const int rc = min((int)r0 + (rel), rlast);                                                                         \
+    const int f = rc / hw, rr = rc - f * hw, y = rr / W, x0 = rr - y * W;                                               \
+    const int yy = y * S + dy;                                                                                          \
+    const bool yok = (rel) < nrows && (unsigned)yy < (unsigned)Hx;                                                      \
+    const float* xrow = X + ((long long)(f * Hx + min(max(yy, 0), Hx - 1)) * Wx) * 64 + lc;                             \
+    _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                                                    \
+      const int wr = lr + 16 * i;                                                                                       \
+      const int xx = x0 * S - KS / 2 + wr;                                                                              \
+      const f32x4 v_ = *reinterpret_cast<const f32x4*>(xrow + (long long)min(max(xx, 0), Wx - 1) * 64);                 \
+      pw[i] = (yok && wr < WR && (unsigned)xx < (unsigned)Wx) ? v_ : zero4;                                             \
+    }                                                                                                                   \
+  }
+  CWW_FETCH(0)
+  for (int rb = 0; rb < nrows; rb += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4*>(&Ys[(lr + 16 * h) * CW_P + lc]) = pa[h];
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+      if (lr + 16 * i <= WR) *reinterpret_cast<f32x4*>(&Xw[(lr + 16 * i) * CW_P + lc]) = pw[i];
+    __syncthreads();
+    CWW_FETCH(rb + 32)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int m0 = 16 * kk + 8 * (lane >> 5);
+      f32x8 a;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = Ys[(m0 + j) * CW_P + wn + (lane & 31)];
+      bf16x8 ah, al;
+      cw_split8(a, ah, al);
+#pragma unroll
+      for (int t = 0; t < KS; ++t) {
+        f32x8 b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = Xw[((m0 + j) * S + t) * CW_P + wk + (lane & 31)];
+        bf16x8 bh, bl;
+        cw_split8(b, bh, bl);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+        if (MODE != 2) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+        }
+        if (MODE == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc[t], 0, 0, 0);
+      }
+    }
+  }
+#undef CWW_FETCH
+  const int K = KS * KS * 64;
+  float* out = partial + (long long)blockIdx.y * CA * K;
+#pragma unroll
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      out[(long long)n * K + (ky * KS + t) * 64 + wk + (lane & 31)] = acc[t][r];
+    }
+}
+
 // out[i] = sum_g partial[g][i] written through an index map:  OHWI [Cout][taps][Cin] -> torch OIHW [Cout][Cin][taps]
 __global__ __launch_bounds__(256) void reduce_to_oihw_kernel(const float* __restrict__ partial, float* __restrict__ out, int G, int Cout,
                                                              int Cin, int taps) {
@@ -212,12 +304,26 @@ int sf_conv_wgrad_ex(const float* A, int CA, int H, int W, const float* X, int H
   int rps = (int)((rows + splits - 1) / splits);
   rps = (rps + 31) & ~31;
   const dim3 grid(ks * nt, splits);
-  if (sf_get_precision() == 0)
+  const int mode = sf_get_precision();
+  static const bool win_on = []() { const char* e = getenv("SF_WGRAD_WINDOW"); return !(e && e[0] == '0'); }();
+#define CW_LAUNCH(KERN) hipLaunchKernelGGL(KERN, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, CA, Hx, Wx)
+  if (win_on && W % 32 == 0 && (s == 1 || s == 2)) {   // one LDS window per chunk instead of five shifted fetches
+    if (s == 1) {
+      if (mode == 0) CW_LAUNCH((conv_wgrad_win_kernel<0, 1>));
+      else if (mode == 1) CW_LAUNCH((conv_wgrad_win_kernel<1, 1>));
+      else CW_LAUNCH((conv_wgrad_win_kernel<2, 1>));
+    } else {
+      if (mode == 0) CW_LAUNCH((conv_wgrad_win_kernel<0, 2>));
+      else if (mode == 1) CW_LAUNCH((conv_wgrad_win_kernel<1, 2>));
+      else CW_LAUNCH((conv_wgrad_win_kernel<2, 2>));
+    }
+  } else if (mode == 0)
     hipLaunchKernelGGL(conv_wgrad_kernel<0>, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, CA, s, Hx, Wx);
-  else if (sf_get_precision() == 1)
+  else if (mode == 1)
     hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, CA, s, Hx, Wx);
   else
     hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, CA, s, Hx, Wx);
+#undef CW_LAUNCH
   SF_CHECK_LAUNCH();
   const int total = CA * 64 * taps;
   hipLaunchKernelGGL(reduce_to_oihw_kernel, dim3((total + 255) / 256), dim3(256), 0, st, partial, out_oihw, splits, CA, 64, taps);
