@@ -20,6 +20,13 @@ class BaseModel(nn.Module):
     def calc_eval_loss(self, data_dict, out_dict):
         return self.calc_train_loss(data_dict, out_dict)
 
+    def loss_function(self, data_dict):
+        """forward + the loss dict of the current mode: what nerv's training loop calls on the model before it sums the
+        terms with the `<name>_w` weights of the params file (reconstructed from nerv v0.1.0's public behaviour -- the
+        package is not in the reference tree, so this wrapper is parity-unpinned)."""
+        out_dict = self.forward(data_dict)
+        return self.calc_train_loss(data_dict, out_dict) if self.training else self.calc_eval_loss(data_dict, out_dict)
+
     @property
     def dtype(self):
         return next(self.parameters()).dtype
