@@ -58,3 +58,39 @@ def test_argument_errors_without_gpu():
     assert b'null pointer' in lib.sf_last_error_string()
     assert lib.sf_slot_attn_num_partials(4096) == 16
     assert lib.sf_rollout_workspace_bytes(None, 4) == 0
+
+
+def test_training_entry_points_reject_bad_arguments():
+    """Argument errors of the row-N1 entry points are negative return codes with a message, raised before any HIP call
+    (so this runs without a GPU): the product path fails loudly instead of computing something else."""
+    import ctypes as C
+    from slotformer_amd import _lib
+    lib = _lib.lib()
+
+    def err():
+        return lib.sf_last_error_string().decode()
+
+    one = C.c_void_p(16)   # a non-null dummy pointer: every case below is rejected before it is dereferenced
+    # linear backward: widths must be multiples of 64
+    assert lib.sf_linear_bwd_f32(one, one, None, one, None, one, None, 8, 100, 64, 0, one, 1 << 30, None) < 0
+    assert 'multiples of 64' in err()
+    # Adam: the step count is 1-based
+    assert lib.sf_adam_flat_f32(one, one, one, one, 10, 0, 1e-3, 0.9, 0.999, 1e-8, None) < 0
+    assert 'Adam' in err()
+    # dropout probability range
+    assert lib.sf_dropout_f32(one, None, one, 8, 1.0, 0, None) < 0
+    assert 'dropout_p' in err()
+    # Slot-Attention backward: unsupported slot size, too many slots
+    assert lib.sf_slot_attn_iter_bwd_f32(one, one, 100, 409600, one, one, one, 1, one, one, one, 0, one, 1, 4096, 7, 100, 0.1, 1e-6, one,
+                                         1 << 30, None) < 0
+    assert 'slot_size' in err()
+    assert lib.sf_slot_attn_iter_bwd_f32(one, one, 128, 524288, one, one, one, 1, one, one, one, 0, one, 1, 4096, 9, 128, 0.1, 1e-6, one,
+                                         1 << 30, None) < 0
+    # rollout training: workspace query rejects a model it cannot train (no layers) by returning 0 bytes
+    m = _lib.sf_rollouter()
+    assert lib.sf_rollout_train_workspace_bytes(C.byref(m), 2, 3) == 0
+    # precision modes
+    assert lib.sf_set_precision(3) < 0 and 'precision' in err()
+    old = lib.sf_get_precision()
+    assert lib.sf_set_precision(2) == 0 and lib.sf_get_precision() == 2
+    assert lib.sf_set_precision(old) == 0
