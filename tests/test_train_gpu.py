@@ -491,3 +491,27 @@ def test_flat_adam_matches_torch(dev):
     x = gu.seeded_normal((2, 6, 6, 128), 5).to(dev)
     with torch.no_grad():
         assert rel_err(b.eval()(x, 3), a.eval()(x, 3).cpu()) < 1e-5
+
+
+def test_decoder_gradients_phyre_shape(dev):
+    """The PHYRE decoder (savi_phyre_params: 8 slots, 16x16 broadcast grid -> 128x128, so the stride-1 layer runs on the GEMM
+    core instead of the 64-wide halo kernel and the weight-gradient windows are 128 pixels wide): slot and parameter
+    gradients against autograd of the oracle."""
+    cfg = gu.C5_SAVI
+    m, sd = build(cfg, gu.load_golden('savi_c5'), 105, dev)
+    m.train()
+    slots = gu.seeded_normal((1, 8, 128), 61)
+    target = gu.seeded_img(1, 1, 128, 62)[0]
+    names = [n for n, _ in m.named_parameters() if n.startswith(('decoder.', 'decoder_pos_embedding.dense'))]
+    osd = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    so = slots.clone().requires_grad_(True)
+    ref = oracle.savi_decode(so, osd, cfg)[0]
+    ((ref - target)**2).mean().backward()
+    sg = slots.to(dev).requires_grad_(True)
+    recon = m.decode(sg)[0]
+    assert rel_err(recon, ref) < 1e-4
+    ((recon - target.to(dev))**2).mean().backward()
+    got = dict(m.named_parameters())
+    for n in names:
+        assert l2_err(got[n].grad, osd[n].grad) < 1e-2, n
+    assert l2_err(sg.grad, so.grad) < 1e-2
