@@ -515,3 +515,32 @@ def test_decoder_gradients_phyre_shape(dev):
     for n in names:
         assert l2_err(got[n].grad, osd[n].grad) < 1e-2, n
     assert l2_err(sg.grad, so.grad) < 1e-2
+
+
+def test_savi_training_step_128_vs_oracle(dev):
+    """StoSAVi at the north-star resolution (C2: 128x128 input, first conv stride 2, decoder 8x8 -> 128x128 in four stride-2
+    layers): one training step against autograd of the oracle."""
+    cfg = gu.C2_SAVI
+    m, sd = build(cfg, gu.load_golden('savi_c2'), 103, dev)
+    m.train()
+    m.testing = False
+    img = gu.seeded_img(1, 2, 128, 71)
+    noise = gu.seeded_normal((1, 2, 7, 128), 72)
+    data = {'img': img.to(dev), 'noise': noise.to(dev)}
+    out = m(data)
+    terms = m.calc_train_loss(data, out)
+    loss = terms['post_recon_loss'] + 1e-4 * terms['kld_loss']
+    loss.backward()
+    got = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    osd = {k: (v.clone().requires_grad_(True) if k in got else v) for k, v in sd.items()}
+    o = oracle.savi_encode(img, osd, cfg, noise=noise)
+    rec = oracle.savi_decode(o['post_slots'].flatten(0, 1), osd, cfg)[0].unflatten(0, (1, 2))
+    oloss = ((rec - img)**2).mean() + 1e-4 * oracle.kernel_kld(o['kernel_dist'], cfg)
+    oloss.backward()
+    assert abs(float(loss.detach()) - float(oloss.detach())) < 1e-4 * float(oloss.detach())
+    assert rel_err(out['post_slots'], o['post_slots']) < 1e-4
+    assert len(got) == 54
+    for n, g_ in got.items():
+        if n == 'slot_attention.project_q.0.bias':
+            continue
+        assert l2_err(g_, osd[n].grad) < 1.5e-2, n
