@@ -146,6 +146,15 @@ int sf_groupnorm1_nhwc_f32(const float* x, const float* gamma, const float* beta
  * plain sf_linear_f32 calls), token + position embedding, greedy token pick, token cross-entropy. */
 int sf_slate_attention_f32(const float* q, const float* k, const float* v, float* out, int ldq, int ldk, int ldv, int ldo,
                            int B, int Lq, int Lk, int num_heads, int head_dim, int causal, void* stream);
+/* Adjoint of sf_slate_attention_strided_f32 (row N1: the STEVE decoder's causal self-attention and slot cross-attention
+ * under autograd, steve_transformer.py:61-116), flash style: `out` is the forward result, d_out its gradient; dq / dk / dv
+ * have the layouts of q / k / v.  dq is cleared here and accumulated with float atomics.  head_dim even, <= 64; causal
+ * needs Lq == Lk. */
+size_t sf_slate_attention_bwd_workspace_bytes(int B, int Lq, int num_heads);
+int sf_slate_attention_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* d_out, float* dq,
+                               float* dk, float* dv, int ldq, int ldk, int ldv, int ldo, long long q_bs, long long k_bs,
+                               long long v_bs, long long o_bs, int B, int Lq, int Lk, int num_heads, int head_dim, int causal,
+                               void* ws, size_t ws_bytes, void* stream);
 /* the same with explicit batch strides (floats), so that k/v may be a partially filled K/V cache */
 int sf_slate_attention_strided_f32(const float* q, const float* k, const float* v, float* out, int ldq, int ldk, int ldv,
                                    int ldo, long long q_bs, long long k_bs, long long v_bs, long long o_bs, int B, int Lq,

@@ -1,0 +1,251 @@
+// Backward of the slot-conditioned decoder's attention (STEVE image side under autograd): the adjoint of
+// sf_slate_attention_strided_f32 (steve_transformer.py:61-116: causal self-attention over the patch tokens, cross-attention
+// from the tokens to the slots), flash style -- no L x L matrix ever reaches memory.
+//
+//   stats kernel : per 64-query block, one pass over its key blocks -> row log-sum-exp LSE_i and D_i = dO_i . O_i
+//   main kernel  : one workgroup per (64-key block j, head, sequence) keeps K_j, V_j and the dK_j, dV_j accumulators on chip and
+//                  walks the query blocks i (i >= j when causal): S = Q_i K_j^T, P = exp(S - LSE_i) (masked), dV_j += P^T dO_i,
+//                  dP = dO_i V_j^T, dS = P (dP - D_i), dK_j += dS^T Q_i, and dQ_i += dS K_j by float atomics.
+// Every product is a set of 32x32 tiles of exact-f32 MFMA (v_mfma_f32_32x32x2_f32) read from zero-padded LDS tiles.
+#include <math.h>
+
+#include "../../include/slotformer_hip.h"
+#include "sf_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <class FA, class FB>
+__device__ __forceinline__ f32x16 sab_mm32(FA a, FB b, int K, int lane) {
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int i0 = lane & 31, kk = lane >> 5;
+  for (int k = 0; k < K; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a(i0, k + kk), b(k + kk, i0), acc, 0, 0, 0);
+  return acc;
+}
+#define SAB_ROW(r, lane) (((r) & 3) + 8 * ((r) >> 2) + 4 * ((lane) >> 5))
+
+struct SabArgs {
+  const float *q, *k, *v, *o, *dout;
+  float *dq, *dk, *dv, *lse, *dsum;   // lse, dsum: [B][H][Lq]
+  int ldq, ldk, ldv, ldo;
+  long long q_bs, k_bs, v_bs, o_bs;
+  int Lq, Lk, H, causal;
+  float scale;
+};
+
+// rows [r0, r0 + 64) of a [L, ld] matrix (head slice at +hoff) -> zero-padded LDS tile [64][P]
+template <int HDP>
+__device__ __forceinline__ void sab_load(const float* base, int ld, int r0, int L, int hd, float mul, float* dst) {
+  constexpr int P = HDP + 1;
+  for (int i = threadIdx.x; i < 64 * HDP; i += 256) {
+    const int r = i / HDP, c = i - r * HDP;
+    dst[r * P + c] = (r0 + r < L && c < hd) ? base[(long long)(r0 + r) * ld + c] * mul : 0.f;
+  }
+}
+
+template <int HDP>
+__global__ __launch_bounds__(256) void slate_attn_stats_kernel(SabArgs p, int hd) {
+  constexpr int P = HDP + 1;
+  extern __shared__ float lds[];
+  float* Qs = lds;
+  float* Ks = Qs + 64 * P;
+  float* Ss = Ks + 64 * P;     // [64][65]
+  float* rm = Ss + 64 * 65;    // running max [64]
+  float* rl = rm + 64;         // running sum [64]
+  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int q0 = qb * 64;
+  sab_load<HDP>(p.q + (long long)b * p.q_bs + h * hd, p.ldq, q0, p.Lq, hd, p.scale, Qs);
+  if (tid < 64) {
+    rm[tid] = -INFINITY;
+    rl[tid] = 0.f;
+  }
+  const int nkb = p.causal ? qb + 1 : (p.Lk + 63) / 64;
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();
+    sab_load<HDP>(p.k + (long long)b * p.k_bs + h * hd, p.ldk, kb * 64, p.Lk, hd, 1.f, Ks);
+    __syncthreads();
+    {
+      const int ti = (wave >> 1) * 32, tj = (wave & 1) * 32;
+      const f32x16 acc = sab_mm32([&](int i, int kk) { return Qs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Ks[(tj + j) * P + kk]; },
+                                  HDP, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ss[(ti + SAB_ROW(r, lane)) * 65 + tj + (lane & 31)] = acc[r];
+    }
+    __syncthreads();
+    for (int r = wave; r < 64; r += 4) {   // online max / sum of row r over this key block
+      const int qi = q0 + r, kj = kb * 64 + lane;
+      const bool ok = qi < p.Lq && kj < p.Lk && (!p.causal || kj <= qi);
+      const float s = ok ? Ss[r * 65 + lane] : -INFINITY;
+      const float mx = sf_wave_max(s);
+      const float mo = rm[r], mn = fmaxf(mo, mx);
+      const float e = (ok && mn > -INFINITY) ? expf(s - mn) : 0.f;
+      const float sum = sf_wave_sum(e);
+      if (lane == 0) {
+        rl[r] = rl[r] * ((mo == -INFINITY) ? 0.f : expf(mo - mn)) + sum;
+        rm[r] = mn;
+      }
+    }
+  }
+  __syncthreads();
+  // LSE and D = dO . O  (one thread group of 4 per row)
+  for (int r = wave * 16 + (lane >> 2); r < 64; r += 64) {
+    const int qi = q0 + r;
+    float d = 0.f;
+    if (qi < p.Lq) {
+      const float* o = p.o + (long long)b * p.o_bs + (long long)qi * p.ldo + h * hd;
+      const float* g = p.dout + (long long)b * p.o_bs + (long long)qi * p.ldo + h * hd;
+      for (int c = lane & 3; c < hd; c += 4) d += o[c] * g[c];
+    }
+    d += sf_dpp<0xB1>(d);
+    d += sf_dpp<0x4E>(d);
+    if ((lane & 3) == 0 && qi < p.Lq) {
+      const long long idx = ((long long)b * p.H + h) * p.Lq + qi;
+      p.lse[idx] = rm[r] + logf(rl[r]);
+      p.dsum[idx] = d;
+    }
+  }
+}
+
+template <int HDP>
+__global__ __launch_bounds__(256) void slate_attn_bwd_kernel(SabArgs p, int hd) {
+  constexpr int P = HDP + 1, CT = HDP / 32;   // channel tiles
+  extern __shared__ float lds[];
+  float* Ks = lds;
+  float* Vs = Ks + 64 * P;
+  float* Qs = Vs + 64 * P;
+  float* Gs = Qs + 64 * P;     // dO
+  float* Ps = Gs + 64 * P;     // [64 queries][65]
+  float* Ds = Ps + 64 * 65;    // dS
+  float* ls = Ds + 64 * 65;    // lse [64], dsum [64]
+  const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int k0 = kb * 64;
+  sab_load<HDP>(p.k + (long long)b * p.k_bs + h * hd, p.ldk, k0, p.Lk, hd, 1.f, Ks);
+  sab_load<HDP>(p.v + (long long)b * p.v_bs + h * hd, p.ldv, k0, p.Lk, hd, 1.f, Vs);
+  // accumulators: dV_j and dK_j are [64 keys][HDP]: 2 * CT tiles each, tile t -> wave t % 4 (CT <= 2: at most one each per wave)
+  f32x16 dvacc, dkacc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dvacc[i] = dkacc[i] = 0.f;
+  const int at = wave;                           // accumulator tile of this wave (valid if at < 2 * CT)
+  const int ati = (at / CT) * 32, atj = (at % CT) * 32;
+  const int nqb = (p.Lq + 63) / 64;
+  for (int qb = p.causal ? kb : 0; qb < nqb; ++qb) {
+    const int q0 = qb * 64;
+    __syncthreads();
+    sab_load<HDP>(p.q + (long long)b * p.q_bs + h * hd, p.ldq, q0, p.Lq, hd, p.scale, Qs);
+    sab_load<HDP>(p.dout + (long long)b * p.o_bs + h * hd, p.ldo, q0, p.Lq, hd, 1.f, Gs);
+    if (tid < 64) {
+      const int qi = q0 + tid;
+      const long long idx = ((long long)b * p.H + h) * p.Lq + min(qi, p.Lq - 1);
+      ls[tid] = p.lse[idx];
+      ls[64 + tid] = p.dsum[idx];
+    }
+    __syncthreads();
+    const int ti = (wave >> 1) * 32, tj = (wave & 1) * 32;
+    // S tile and dP tile of this wave (queries ti.., keys tj..)
+    const f32x16 s = sab_mm32([&](int i, int kk) { return Qs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Ks[(tj + j) * P + kk]; },
+                              HDP, lane);
+    const f32x16 dp = sab_mm32([&](int i, int kk) { return Gs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Vs[(tj + j) * P + kk]; },
+                               HDP, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qr = ti + SAB_ROW(r, lane), kc = tj + (lane & 31);
+      const int qi = q0 + qr, kj = k0 + kc;
+      const bool ok = qi < p.Lq && kj < p.Lk && (!p.causal || kj <= qi);
+      const float pv = ok ? expf(s[r] - ls[qr]) : 0.f;
+      Ps[qr * 65 + kc] = pv;
+      Ds[qr * 65 + kc] = pv * (dp[r] - ls[64 + qr]);
+    }
+    __syncthreads();
+    // dV_j += P^T dO_i ; dK_j += dS^T (Q_i * scale)   (contraction over the 64 queries)
+    if (at < 2 * CT) {
+      // tiles 0 .. 2*CT-1 cover [64 keys][HDP]; ati = key offset, atj = channel offset
+      const f32x16 a1 = sab_mm32([&](int i, int kk) { return Ps[kk * 65 + ati + i]; }, [&](int kk, int j) { return Gs[kk * P + atj + j]; }, 64,
+                                 lane);
+      const f32x16 a2 = sab_mm32([&](int i, int kk) { return Ds[kk * 65 + ati + i]; }, [&](int kk, int j) { return Qs[kk * P + atj + j]; }, 64,
+                                 lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dvacc[r] += a1[r];
+        dkacc[r] += a2[r];
+      }
+    }
+    // dQ_i += scale * dS K_j  (tiles over [64 queries][HDP]; atomics: several key blocks add into the same rows)
+    for (int t = wave; t < 2 * CT; t += 4) {
+      const int qi0 = (t / CT) * 32, c0 = (t % CT) * 32;
+      const f32x16 a3 = sab_mm32([&](int i, int kk) { return Ds[(qi0 + i) * 65 + kk]; }, [&](int kk, int j) { return Ks[kk * P + c0 + j]; }, 64,
+                                 lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = q0 + qi0 + SAB_ROW(r, lane), c = c0 + (lane & 31);
+        if (qi < p.Lq && c < hd) atomicAdd(p.dq + (long long)b * p.q_bs + (long long)qi * p.ldq + h * hd + c, a3[r] * p.scale);
+      }
+    }
+  }
+  if (at < 2 * CT) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kj = k0 + ati + SAB_ROW(r, lane), c = atj + (lane & 31);
+      if (kj < p.Lk && c < hd) {
+        p.dv[(long long)b * p.v_bs + (long long)kj * p.ldv + h * hd + c] = dvacc[r];
+        p.dk[(long long)b * p.k_bs + (long long)kj * p.ldk + h * hd + c] = dkacc[r];   // Q was scaled when loaded
+      }
+    }
+  }
+}
+
+extern "C" {
+
+size_t sf_slate_attention_bwd_workspace_bytes(int B, int Lq, int num_heads) {
+  return (size_t)2 * B * num_heads * Lq * sizeof(float) + 256;
+}
+
+// Adjoint of sf_slate_attention_strided_f32: dq / dk / dv have the layouts of q / k / v, d_out and out the layout of out.
+// dq must not alias q (it is zeroed here and accumulated with float atomics: its low bits depend on the arrival order).
+int sf_slate_attention_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* d_out, float* dq,
+                               float* dk, float* dv, int ldq, int ldk, int ldv, int ldo, long long q_bs, long long k_bs,
+                               long long v_bs, long long o_bs, int B, int Lq, int Lk, int num_heads, int head_dim, int causal,
+                               void* ws, size_t ws_bytes, void* stream) {
+  SF_REQUIRE(q && k && v && out && d_out && dq && dk && dv && ws, "null pointer");
+  SF_REQUIRE(B > 0 && Lq > 0 && Lk > 0 && num_heads > 0, "bad sizes");
+  SF_REQUIRE(head_dim >= 2 && head_dim <= 64 && head_dim % 2 == 0, "head_dim must be even and <= 64");
+  SF_REQUIRE(!causal || Lq == Lk, "causal attention needs Lq == Lk");
+  SF_REQUIRE(ws_bytes >= sf_slate_attention_bwd_workspace_bytes(B, Lq, num_heads), "workspace too small");
+  SF_REQUIRE(q_bs >= (long long)(Lq - 1) * ldq + num_heads * head_dim, "dq is cleared over whole batches: q_bs too small");
+  hipStream_t st = (hipStream_t)stream;
+  SabArgs a;
+  a.q = q; a.k = k; a.v = v; a.o = out; a.dout = d_out; a.dq = dq; a.dk = dk; a.dv = dv;
+  a.lse = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  a.dsum = a.lse + (size_t)B * num_heads * Lq;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
+  a.Lq = Lq; a.Lk = Lk; a.H = num_heads; a.causal = causal; a.scale = 1.f / sqrtf((float)head_dim);
+  // clear the head columns of dq (row by row: dq may be a column slice of a wider packed tensor)
+  for (int b = 0; b < B; ++b) {
+    hipError_t e = hipMemset2DAsync(dq + (long long)b * q_bs, (size_t)ldq * sizeof(float), 0, (size_t)num_heads * head_dim * sizeof(float),
+                                    (size_t)Lq, st);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+  }
+  const int hdp = head_dim <= 32 ? 32 : 64;
+  const size_t lds1 = ((size_t)2 * 64 * (hdp + 1) + 64 * 65 + 128) * sizeof(float);
+  const size_t lds2 = ((size_t)4 * 64 * (hdp + 1) + 2 * 64 * 65 + 128) * sizeof(float);
+  const dim3 g1((Lq + 63) / 64, num_heads, B), g2((Lk + 63) / 64, num_heads, B);
+#define SAB_GO(HDP)                                                                                                          \
+  {                                                                                                                          \
+    static bool attr = false;                                                                                                \
+    if (!attr) {                                                                                                             \
+      hipError_t e = hipFuncSetAttribute((const void*)slate_attn_bwd_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         160 * 1024);                                                                        \
+      if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);                              \
+      attr = true;                                                                                                           \
+    }                                                                                                                        \
+    hipLaunchKernelGGL(slate_attn_stats_kernel<HDP>, g1, dim3(256), lds1, st, a, head_dim);                                  \
+    hipLaunchKernelGGL(slate_attn_bwd_kernel<HDP>, g2, dim3(256), lds2, st, a, head_dim);                                    \
+  }
+  if (hdp == 32) SAB_GO(32) else SAB_GO(64)
+#undef SAB_GO
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

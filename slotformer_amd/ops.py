@@ -226,6 +226,19 @@ def slate_attention(q, k, v, num_heads, causal, q_off=0, k_off=0, v_off=0, d_mod
     return out
 
 
+def slate_attention_bwd(q, k, v, out, d_out, num_heads, causal):
+    """Adjoint of slate_attention for contiguous q [B,Lq,d], k, v [B,Lk,d]: (dq, dk, dv)."""
+    _chk(q, k, v, out, d_out)
+    B, Lq, d = q.shape
+    Lk = k.shape[1]
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    nb = lib().sf_slate_attention_bwd_workspace_bytes(B, Lq, num_heads)
+    ws = torch.empty(nb, dtype=torch.uint8, device=q.device)
+    check(lib().sf_slate_attention_bwd_f32(_p(q), _p(k), _p(v), _p(out), _p(d_out), _p(dq), _p(dk), _p(dv), d, d, d, d, Lq * d, Lk * d,
+                                           Lk * d, Lq * d, B, Lq, Lk, num_heads, d // num_heads, int(causal), ws.data_ptr(), nb, _stream()))
+    return dq, dk, dv
+
+
 def embed_tokens(idx, tok_emb, pos):
     """tok_emb[idx] + pos[:L];  idx int64 [B,L] on device."""
     _chk(tok_emb, pos)

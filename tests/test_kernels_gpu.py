@@ -251,3 +251,35 @@ def test_softmax_argmax_xent_embed(dev):
     close(ops.embed_tokens(idx.to(dev), emb.to(dev), pos.to(dev)), emb[idx] + pos[:41], rtol=0, atol=0)
     with pytest.raises(TypeError):
         ops.embed_tokens(idx.int().to(dev), emb.to(dev), pos.to(dev))
+
+
+@pytest.mark.parametrize('B,Lq,Lk,H,hd,causal', [(2, 130, 130, 4, 16, True), (1, 257, 257, 2, 64, True), (2, 100, 6, 4, 32, False),
+                                                  (1, 1025, 1025, 1, 64, True), (3, 64, 7, 2, 48, False)])
+def test_slate_attention_backward(dev, B, Lq, Lk, H, hd, causal):
+    """sf_slate_attention_bwd_f32 (flash-style adjoint: causal self-attention over patch tokens, cross-attention to the slots)
+    against torch autograd of the plain softmax(q k^T / sqrt(hd)) v."""
+    from slotformer_amd import ops
+
+    import golden_util as gu
+
+    def rel_err(a, b):
+        a, b = a.detach().cpu().double(), b.detach().double()
+        return ((a - b).abs().max() / b.abs().max()).item()
+
+    d = H * hd
+    q, k, v = gu.seeded_normal((B, Lq, d), 1), gu.seeded_normal((B, Lk, d), 2), gu.seeded_normal((B, Lk, d), 3)
+    g = gu.seeded_normal((B, Lq, d), 4)
+    qo, ko, vo = (t.clone().requires_grad_(True) for t in (q, k, v))
+    qh, kh, vh = (t.view(B, -1, H, hd).transpose(1, 2) for t in (qo, ko, vo))
+    s = (qh @ kh.transpose(-1, -2)) * hd**-0.5
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(Lq, Lk, dtype=torch.bool), 1), float('-inf'))
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Lq, d)
+    ref.backward(g)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    out = ops.slate_attention(qd, kd, vd, H, causal)
+    assert rel_err(out, ref) < 1e-5
+    dq, dk, dv = ops.slate_attention_bwd(qd, kd, vd, out, g.to(dev), H, causal)
+    assert rel_err(dq, qo.grad) < 2e-5
+    assert rel_err(dk, ko.grad) < 2e-5
+    assert rel_err(dv, vo.grad) < 2e-5
