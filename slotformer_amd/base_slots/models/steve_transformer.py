@@ -114,11 +114,14 @@ class STEVETransformerDecoder(nn.Module):
 
     def forward(self, slots, idx):
         """slots [B,N,d], idx int64 [B,t] (targets without the last token) -> logits [B,1+t,V]."""
-        if self.training or torch.is_grad_enabled():
-            raise RuntimeError('slotformer_amd STEVETransformerDecoder is inference-only: .eval() + torch.no_grad()')
         assert slots.shape[1] == self.num_slots
         B, T = idx.shape
         assert T <= self.max_len
+        if torch.is_grad_enabled() and (slots.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from ... import train
+            return train.slate_decoder_forward(self, slots, idx)   # chain of HIP-backed autograd nodes (row N1)
+        if self.training:
+            raise RuntimeError('slotformer_amd STEVETransformerDecoder: train() mode without autograd; use .eval() + torch.no_grad()')
         d, H = self.d_model, self.n_head
         mem = ops.linear(slots.contiguous(), self.in_proj.weight.detach(), self.in_proj.bias.detach())   # [B,N,d]
         bos = torch.full((B, 1), self.vocab_size, dtype=torch.int64, device=idx.device)

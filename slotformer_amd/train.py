@@ -471,6 +471,102 @@ def lstm_step(x, state, rnn):
     return h2, (h2, c2)
 
 
+class _SlateAttention(torch.autograd.Function):
+    """softmax(q k^T / sqrt(hd) [causal]) v of the STEVE decoder (steve_transformer.py:12-55) on contiguous q [B,Lq,d],
+    k, v [B,Lk,d]: sf_slate_attention_f32 forward, the flash-style sf_slate_attention_bwd_f32 backward."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, causal):
+        from . import ops
+        q, k, v = (t.detach().float().contiguous() for t in (q, k, v))
+        out = ops.slate_attention(q, k, v, heads, causal)
+        ctx.save_for_backward(q, k, v, out)
+        ctx.args = (heads, bool(causal))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        from . import ops
+        q, k, v, out = ctx.saved_tensors
+        dq, dk, dv = ops.slate_attention_bwd(q, k, v, out, d_out.float().contiguous(), *ctx.args)
+        return dq, dk, dv, None, None
+
+
+class _Embed(torch.autograd.Function):
+    """tok_emb[idx] + pos[:L] (steve_transformer.py:58-74,286-289): HIP gather forward; the backward scatters the row
+    gradients back (index_add on the [V+1, d] table, batch sum for the position table)."""
+
+    @staticmethod
+    def forward(ctx, idx, tok_emb, pos):
+        from . import ops
+        ctx.save_for_backward(idx)
+        ctx.shapes = (tuple(tok_emb.shape), tuple(pos.shape))
+        return ops.embed_tokens(idx, tok_emb.detach().float().contiguous(), pos.detach().float().contiguous())
+
+    @staticmethod
+    def backward(ctx, dx):
+        idx, = ctx.saved_tensors
+        (V, d), pshape = ctx.shapes
+        dx = dx.float().contiguous()
+        d_tok = torch.zeros(V, d, dtype=torch.float32, device=dx.device).index_add_(0, idx.reshape(-1), dx.reshape(-1, d))
+        d_pos = torch.zeros(pshape, dtype=torch.float32, device=dx.device)
+        d_pos[:dx.shape[1]] = dx.sum(0)
+        return None, d_tok, d_pos
+
+
+class _TokenCrossEntropy(torch.autograd.Function):
+    """mean cross-entropy of logits [R,V] against int64 targets [R] (steve.py:341-344): sf_cross_entropy_f32 forward,
+    (softmax - onehot) / R backward on sf_softmax_rows_f32."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        from . import ops
+        logits = logits.detach().float().contiguous()
+        ctx.save_for_backward(logits, target)
+        return ops.cross_entropy(logits, target)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        logits, target = ctx.saved_tensors
+        p = ops.softmax_rows(logits)
+        p.scatter_add_(1, target.view(-1, 1), torch.full((target.numel(), 1), -1.0, device=p.device))
+        return p * (g / logits.shape[0]), None
+
+
+def slate_decoder_forward(dec, slots, idx):
+    """STEVETransformerDecoder.forward (steve_transformer.py:275-303) under autograd: slots [B,N,d], idx int64 [B,t] ->
+    logits [B,1+t,V], as a chain of HIP-backed nodes.  Dropout on the attention WEIGHTS is not supported (the flash kernels
+    never materialise them); the embedding / output / FFN dropouts follow the modules."""
+    tr = dec.training
+    B, T = idx.shape
+    H = dec.n_head
+    if tr and len(dec.tf_dec.blocks) and dec.tf_dec.blocks[0].self_attn.attn_dropout.p > 0:
+        raise NotImplementedError('slotformer_amd: dropout on the attention weights of the STEVE decoder is not built; set '
+                                  'attn_dropout.p = 0 on its MultiHeadAttention modules')
+    mem = linear(slots.float().contiguous(), dec.in_proj)
+    bos = torch.full((B, 1), dec.vocab_size, dtype=torch.int64, device=idx.device)
+    tokens = torch.cat([bos, idx.to(torch.int64)], 1).contiguous()
+    x = dropout(_Embed.apply(tokens, dec.tok_emb.weight, dec.pos_emb.pe[0]), dec.pos_emb.dropout.p, tr)
+    for blk in dec.tf_dec.blocks:
+        sa, ca = blk.self_attn, blk.encoder_decoder_attn
+        y = layer_norm(x, blk.self_attn_layer_norm)
+        if blk.is_first:   # the first block normalises its input in place (steve_transformer.py:186-190)
+            x = y
+        att = _SlateAttention.apply(linear(y, sa.proj_q), linear(y, sa.proj_k), linear(y, sa.proj_v), H, True)
+        x = x + dropout(linear(att, sa.proj_o), sa.output_dropout.p, tr)
+        y = layer_norm(x, blk.encoder_decoder_attn_layer_norm)
+        att = _SlateAttention.apply(linear(y, ca.proj_q), linear(mem, ca.proj_k), linear(mem, ca.proj_v), H, False)
+        x = x + dropout(linear(att, ca.proj_o), ca.output_dropout.p, tr)
+        y = layer_norm(x, blk.ffn_layer_norm)
+        x = x + dropout(linear(linear(y, blk.ffn[0], relu=True), blk.ffn[2]), blk.ffn[3].p, tr)
+    return linear(layer_norm(x, dec.tf_dec.layer_norm), dec.head)
+
+
+def token_cross_entropy(logits, target):
+    return _TokenCrossEntropy.apply(logits, target.to(torch.int64).contiguous())
+
+
 def linear(x, layer, relu=False):
     """nn.Linear `layer` applied to x under autograd, on the HIP kernels."""
     return _Linear.apply(x, layer.weight, layer.bias, relu)

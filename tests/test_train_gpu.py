@@ -544,3 +544,38 @@ def test_savi_training_step_128_vs_oracle(dev):
         if n == 'slot_attention.project_q.0.bias':
             continue
         assert l2_err(g_, osd[n].grad) < 1.5e-2, n
+
+
+def test_steve_decoder_training_vs_oracle(dev, precision):
+    """STEVETransformerDecoder.forward under autograd (steve_transformer.py:275-303: token + position embedding, blocks of
+    causal self-attention / slot cross-attention / FFN, head) with the token cross-entropy of steve.py:341-344: logits, loss
+    and the gradients of every decoder parameter and of the slots against autograd of the oracle.  257 tokens (16x16 patch
+    grid + BOS), 4 slots, 2 blocks."""
+    from slotformer_amd import train
+    g = gu.load_golden('steve_tokens')
+    cfg = gu.steve_tokens_cfg()
+    m, sd = build(cfg, g, 601, dev)
+    dec = m.trans_decoder
+    dec.train()
+    _no_dropout(dec)
+    slots = gu.seeded_normal((2, 4, 64), 81)
+    tgt = torch.from_numpy(g['target_token_id']).to(torch.int64)          # [2, 256]
+    names = [n for n, p_ in m.named_parameters() if n.startswith('trans_decoder.') and p_.requires_grad]
+    osd = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    so = slots.clone().requires_grad_(True)
+    dd = cfg['dec_dict']
+    ref = oracle.steve_decoder_forward(so, tgt[:, :-1], osd, dd['dec_num_heads'], dd['dec_num_layers'])
+    oloss = torch.nn.functional.cross_entropy(ref.flatten(0, 1), tgt.flatten(0, 1))
+    oloss.backward()
+    sg = slots.to(dev).requires_grad_(True)
+    logits = dec(sg, tgt[:, :-1].to(dev))
+    loss = train.token_cross_entropy(logits.flatten(0, 1), tgt.flatten(0, 1).to(dev))
+    loss.backward()
+    assert rel_err(logits, ref) < 1e-4
+    assert abs(float(loss.detach()) - float(oloss.detach())) < 1e-5 * float(oloss.detach())
+    got = dict(m.named_parameters())
+    tol = L2TOL[precision]
+    for n in names:
+        assert got[n].grad is not None, n
+        assert l2_err(got[n].grad, osd[n].grad) < tol, n
+    assert l2_err(sg.grad, so.grad) < tol
