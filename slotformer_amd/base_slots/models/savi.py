@@ -186,21 +186,24 @@ class StoSAVi(BaseModel):
         B, T = img.shape[:2]
         feats = train.features_with_grad(self, img.transpose(0, 1).flatten(0, 1))   # time-major: feats[t*B:(t+1)*B] is contiguous
         feats = feats.unflatten(0, (T, B))
-        kd_layers, D = self.kernel_dist_layer, self.slot_size
+        kd_layers, D = getattr(self, 'kernel_dist_layer', None), self.slot_size   # STEVE has no kernel distribution
         dists, posts = [], []
         for t in range(T):
             if prev_slots is None:
                 latents = self.init_latents.repeat(B, 1, 1)
             else:
                 latents = self._predict_with_grad(prev_slots, train)
-            if len(kd_layers) == 1:
-                dist = train.linear(latents, kd_layers[0])
-            else:   # kernel_mlp: Linear -> LayerNorm -> ReLU -> Linear (savi.py:190-200)
-                dist = train.linear(torch.relu(train.layer_norm(train.linear(latents, kd_layers[0]), kd_layers[1])), kd_layers[3])
-            kernels = dist[..., :D]
-            if noise is not None:
-                kernels = kernels + noise[:, t] * torch.exp(0.5 * dist[..., D:])
-            prev_slots = self.slot_attention(feats[t], kernels.contiguous())
+            if kd_layers is None:
+                dist = kernels = latents
+            else:
+                if len(kd_layers) == 1:
+                    dist = train.linear(latents, kd_layers[0])
+                else:   # kernel_mlp: Linear -> LayerNorm -> ReLU -> Linear (savi.py:190-200)
+                    dist = train.linear(torch.relu(train.layer_norm(train.linear(latents, kd_layers[0]), kd_layers[1])), kd_layers[3])
+                kernels = dist[..., :D]
+                if noise is not None:
+                    kernels = kernels + noise[:, t] * torch.exp(0.5 * dist[..., D:])
+            prev_slots = train.slot_attention_with_grad(self.slot_attention, feats[t], kernels.contiguous())
             dists.append(dist)
             posts.append(prev_slots)
         return torch.stack(dists, 1), torch.stack(posts, 1), None

@@ -100,6 +100,17 @@ class STEVE(StoSAVi):
     def encode(self, img, prev_slots=None):
         """steve.py:198-240 -> (slots [B,T,N,D], masks [B,T,N,H,W], encoder_out=None)."""
         B, T = img.shape[:2]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training (row N1): the slots come from the chain of autograd nodes shared with StoSAVi; the seg masks are
+            # detached in the reference (steve.py:54-55), so they come from the inference engine in a no-grad pass
+            state = None if not hasattr(self.predictor, 'hidden_state') else (self.predictor.step, self.predictor.hidden_state)
+            with torch.no_grad():
+                _, _, attn = engine.savi_encode(self, img, prev_slots=None if prev_slots is None else prev_slots.detach(), noise=None,
+                                                want_attn=True)
+            if state is not None:
+                self.predictor.step, self.predictor.hidden_state = state
+            _, slots, _ = self._encode_with_grad(img.float().contiguous(), prev_slots, None)
+            return slots, attn.view(B, T, self.num_slots, *self.visual_resolution), None
         slots, _, attn = engine.savi_encode(self, img, prev_slots=prev_slots, noise=None, want_attn=True)
         masks = attn.view(B, T, self.num_slots, *self.visual_resolution)
         if not self.training and tuple(self.visual_resolution) != tuple(self.resolution):
@@ -118,7 +129,8 @@ class STEVE(StoSAVi):
             return out_dict
         # token targets from the frozen dVAE, teacher-forced decoder logits (steve.py:306-322)
         if img_token_id is None:
-            img_token_id = self.dvae.tokenize(img, one_hot=False).flatten(2, 3)
+            with torch.no_grad():   # the dVAE is frozen: the tokens are targets, not part of the graph (steve.py:306-311)
+                img_token_id = self.dvae.tokenize(img, one_hot=False).flatten(2, 3)
         h, w = self.h, self.w
         target_token_id = img_token_id.flatten(0, 1).long().contiguous()   # [B*T, h*w]
         in_slots = slots.flatten(0, 1)
@@ -131,9 +143,12 @@ class STEVE(StoSAVi):
         return out_dict
 
     def calc_train_loss(self, data_dict, out_dict):
-        """Token cross-entropy of steve.py:339-351 (value only; no autograd on this engine)."""
+        """Token cross-entropy of steve.py:339-351; differentiable when the logits carry a graph (row N1)."""
         pred = out_dict['pred_token_id'].flatten(0, 1).contiguous()
         target = out_dict['target_token_id'].flatten(0, 1).contiguous()
+        if pred.requires_grad:
+            from ... import train
+            return {'token_recon_loss': train.token_cross_entropy(pred, target)}
         return {'token_recon_loss': ops.cross_entropy(pred, target)}
 
     def train(self, mode=True):

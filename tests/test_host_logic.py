@@ -108,8 +108,12 @@ def test_no_cpu_fallback():
         m({'img': gu.seeded_img(1, 1, 64)})  # grad enabled: the training path (row N1) is HIP-only as well
     steve = build_model(gu.ParamsView(gu.steve_tokens_cfg())).eval()
     steve.testing = True
-    with pytest.raises(NotImplementedError, match='inference-only'):
-        steve({'img': gu.seeded_img(1, 1, 64)})  # STEVE has no training path yet and says so
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        steve({'img': gu.seeded_img(1, 1, 64)})  # STEVE's training path is HIP-only too
+    # what is still inference-only says so: the dVAE's own (Gumbel-softmax) training forward
+    with pytest.raises((NotImplementedError, RuntimeError), match='inference-only|row N1|outside the inference engine'):
+        steve.dvae.train()
+        steve.dvae({'img': gu.seeded_img(1, 1, 64)[:, 0]})
     import slotformer_amd
     src_dir = os.path.dirname(slotformer_amd.__file__)
     for root, _, files in os.walk(src_dir):

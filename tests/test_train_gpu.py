@@ -579,3 +579,46 @@ def test_steve_decoder_training_vs_oracle(dev, precision):
         assert got[n].grad is not None, n
         assert l2_err(got[n].grad, osd[n].grad) < tol, n
     assert l2_err(sg.grad, so.grad) < tol
+
+
+def test_steve_training_step_golden(dev, precision):
+    """STEVE trains end to end on the HIP path (steve.py:242-351): encoder side (conv stack, Slot Attention, Transformer +
+    LSTM predictor) -> slots -> teacher-forced Transformer decoder -> token cross-entropy against the frozen dVAE's tokens.
+    Loss and gradients against the reference fixture (norms + strided samples) and, in full, against autograd of the oracle."""
+    g = gu.load_golden('steve_train')
+    cfg = gu.steve_tokens_cfg()
+    m, sd = build(cfg, g, 921, dev)
+    m.train()
+    _no_dropout(m)
+    m.testing = False
+    img = gu.seeded_img(1, 2, 64, seed=922)
+    tok = torch.from_numpy(g['target_token_id']).to(dev).unflatten(0, (1, 2))   # the reference's targets (argmax ties aside)
+    data = {'img': img.to(dev), 'token_id': tok}
+    out = m(data)
+    loss = m.calc_train_loss(data, out)['token_recon_loss']
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-4 * float(g['loss'])
+    assert rel_err(out['slots'], g['slots']) < 1e-4
+    assert out['masks'].shape == (1, 2, 4, 64, 64) and not out['masks'].requires_grad
+    names = [str(n) for n in g['grad_names']]
+    got = dict(m.named_parameters())
+    assert sorted(n for n, p in got.items() if p.grad is not None) == sorted(names)
+    osd = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    enc = oracle.steve_encode(img, osd, cfg, training=True)
+    oracle.steve_forward_tokens(img, enc['slots'], osd, cfg)['token_recon_loss'].backward()
+    tol = {'bf16x3': 1e-2, 'f32': 4e-3}[precision]
+    for n, norm in zip(names, g['grad_norms']):
+        if n == 'slot_attention.project_q.0.bias' or float(norm) == 0.:
+            # structurally zero gradients: the LN_q bias (see above) and, with a single predictor step from a zero LSTM
+            # state, weight_hh_l0
+            assert got[n].grad.abs().max() < 1e-5, n
+            continue
+        assert l2_err(got[n].grad, osd[n].grad) < tol, n
+        assert abs(float(got[n].grad.norm()) - float(norm)) < tol * float(norm), n
+    # the computed-on-device tokens path (no 'token_id' given) runs too and gives (almost) the same loss
+    for p_ in m.parameters():
+        p_.grad = None
+    out2 = m({'img': img.to(dev)})
+    l2 = m.calc_train_loss({'img': img.to(dev)}, out2)['token_recon_loss']
+    l2.backward()
+    assert abs(float(l2.detach()) - float(g['loss'])) < 2e-2 * float(g['loss'])

@@ -288,6 +288,50 @@ def case_steve_tokens(name, B, T, seed):
          gen_margin=(g2[..., 0] - g2[..., 1]), **meta)
 
 
+def case_steve_train(name, B, T, seed, stride=53):
+    """STEVE's own training step in the reference (steve.py:242-351 in train() mode: slots from the encoder side, frozen-dVAE
+    token targets, teacher-forced decoder logits, token cross-entropy, backward), dropout probabilities set to 0 (the only
+    random part).  Stored like savi_train: loss, per-parameter gradient norm + strided sample."""
+    print(name)
+    cfg = gu.steve_tokens_cfg()
+    with torch.enable_grad():
+        dv = dVAE(vocab_size=cfg['dvae_dict']['vocab_size'], img_channels=3)
+        dpath = os.path.join(TMP, 'dvae_train.pth')
+        torch.save({'state_dict': dv.state_dict()}, dpath)
+        full = {k: (dict(v) if isinstance(v, dict) else v) for k, v in cfg.items()}
+        full['dvae_dict']['dvae_ckp_path'] = dpath
+        m = ref_build_base(gu.ParamsView(full)).train()
+        m.testing = False
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.
+        sd = load_seeded(m, seed)
+        img = gu.seeded_img(B, T, cfg['resolution'][0], seed=seed + 1)
+        out = m({'img': img})
+        loss = m.calc_train_loss({'img': img}, out)['token_recon_loss']
+        loss.backward()
+        grads = {n: p_.grad.detach().clone() for n, p_ in m.named_parameters() if p_.grad is not None}
+        osd = {k: (v.clone().requires_grad_(True) if k in grads else v) for k, v in sd.items()}
+        enc = oracle.steve_encode(img, osd, cfg, training=True)
+        o = oracle.steve_forward_tokens(img, enc['slots'], osd, cfg)
+        o['token_recon_loss'].backward()
+        print('  loss', float(loss.detach()), 'oracle', float(o['token_recon_loss'].detach()), 'targets equal',
+              bool(torch.equal(o['target_token_id'], out['target_token_id'])))
+        worst = sorted(((((osd[n].grad - g).norm() / (g.norm() + 1e-30)).item(), n) for n, g in grads.items()), reverse=True)
+        print('  oracle grad rel-L2 err (worst 3)', worst[:3], 'params with grad', len(grads))
+    names = sorted(grads)
+    meta = pack_meta(m, sd)
+    for k in list(meta):
+        if k.startswith('closed::') and k.endswith(gu.CLOSED_FORM_NOSTORE):
+            del meta[k]
+    save(name, loss=np.array(float(loss.detach())), stride=np.int64(stride), slots=out['slots'].detach().numpy(),
+         target_token_id=out['target_token_id'].numpy(), grad_names=np.array(names),
+         grad_norms=np.array([float(grads[n].norm()) for n in names]),
+         **{'gs.' + n: grads[n].flatten()[::stride].numpy() for n in names}, **meta)
+
+
 @torch.no_grad()
 def case_steve_slotformer(name, B, seed):
     """Reference STEVESlotFormer: rollout + token loss (steve_slotformer.py:111-161) and decode (:86-103) with the Gumbel
@@ -566,6 +610,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'steve_slotformer':
         case_steve_slotformer('steve_slotformer', B=1, seed=701)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'steve_train':
+        case_steve_train('steve_train', B=1, T=2, seed=921)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'savi_train':
         case_savi_train('savi_train', gu.TRAIN_SAVI, B=1, T=2, seed=901, noise_seed=9)
         return
@@ -596,6 +643,7 @@ def main():
     case_rollout_grads('roll_train_img', gu.TRAIN_ROLL_IMG, B=1, seed=811, img=True)
     case_savi_train('savi_train', gu.TRAIN_SAVI, B=1, T=2, seed=901, noise_seed=9)
     case_savi_train('savi_train_c1', gu.C1_SAVI, B=1, T=3, seed=911, noise_seed=None, no_dropout=True)
+    case_steve_train('steve_train', B=1, T=2, seed=921)
 
 
 if __name__ == '__main__':
