@@ -151,6 +151,18 @@ int sf_slate_attention_f32(const float* q, const float* k, const float* v, float
  * have the layouts of q / k / v.  dq is cleared here and accumulated with float atomics.  head_dim even, <= 64; causal
  * needs Lq == Lk. */
 size_t sf_slate_attention_bwd_workspace_bytes(int B, int Lq, int num_heads);
+/* The same pair with dropout on the attention WEIGHTS (the nn.Dropout inside steve_transformer.py's MultiHeadAttention, active
+ * in train() mode): masks are a pure function of (seed, sequence, head, query, key).  The forward also returns the row
+ * log-sum-exp lse [B][H][Lq], which the backward takes instead of recomputing it (lse == NULL: recompute). */
+int sf_slate_attention_train_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse, int ldq, int ldk,
+                                     int ldv, int ldo, long long q_bs, long long k_bs, long long v_bs, long long o_bs, int B,
+                                     int Lq, int Lk, int num_heads, int head_dim, int causal, float dropout_p,
+                                     unsigned long long seed, void* stream);
+int sf_slate_attention_train_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* d_out,
+                                     const float* lse, float* dq, float* dk, float* dv, int ldq, int ldk, int ldv, int ldo,
+                                     long long q_bs, long long k_bs, long long v_bs, long long o_bs, int B, int Lq, int Lk,
+                                     int num_heads, int head_dim, int causal, float dropout_p, unsigned long long seed, void* ws,
+                                     size_t ws_bytes, void* stream);
 int sf_slate_attention_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* d_out, float* dq,
                                float* dk, float* dv, int ldq, int ldk, int ldv, int ldo, long long q_bs, long long k_bs,
                                long long v_bs, long long o_bs, int B, int Lq, int Lk, int num_heads, int head_dim, int causal,

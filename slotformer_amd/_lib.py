@@ -171,6 +171,9 @@ SIGNATURES = {
     'sf_slate_attention_strided_f32': (I, [FP, FP, FP, FP, I, I, I, I, LL, LL, LL, LL, I, I, I, I, I, I, VP]),
     'sf_slate_attention_bwd_workspace_bytes': (SZ, [I, I, I]),
     'sf_slate_attention_bwd_f32': (I, [FP, FP, FP, FP, FP, FP, FP, FP, I, I, I, I, LL, LL, LL, LL, I, I, I, I, I, I, VP, SZ, VP]),
+    'sf_slate_attention_train_fwd_f32': (I, [FP, FP, FP, FP, FP, I, I, I, I, LL, LL, LL, LL, I, I, I, I, I, I, F32, C.c_ulonglong, VP]),
+    'sf_slate_attention_train_bwd_f32': (I, [FP, FP, FP, FP, FP, FP, FP, FP, FP, I, I, I, I, LL, LL, LL, LL, I, I, I, I, I, I, F32,
+                                             C.c_ulonglong, VP, SZ, VP]),
     'sf_embed_tokens_f32': (I, [VP, FP, FP, FP, I, I, I, VP]),
     'sf_argmax_rows_f32': (I, [FP, LL, VP, LL, I, VP]),
     'sf_cross_entropy_f32': (I, [FP, VP, FP, FP, LL, I, VP]),

@@ -33,7 +33,15 @@ struct SabArgs {
   long long q_bs, k_bs, v_bs, o_bs;
   int Lq, Lk, H, causal;
   float scale;
+  uint32_t drop_seed, drop_thresh;   // dropout on the attention weights: element ((b*H + h)*Lq + q)*Lk + k, see rollout_train.hip
+  float drop_scale;
+  int have_lse;                      // lse was written by the training forward: the stats kernel only computes dsum
 };
+__device__ __forceinline__ float sab_drop(const SabArgs& p, int b, int h, int q, int k) {
+  if (!p.drop_thresh) return 1.f;
+  const uint32_t idx = (uint32_t)((((long long)b * p.H + h) * p.Lq + q) * p.Lk + k);
+  return (sf_mix32(idx ^ p.drop_seed) >> 8) >= p.drop_thresh ? p.drop_scale : 0.f;
+}
 
 // rows [r0, r0 + 64) of a [L, ld] matrix (head slice at +hoff) -> zero-padded LDS tile [64][P]
 template <int HDP>
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(256) void slate_attn_stats_kernel(SabArgs p, int hd
     rm[tid] = -INFINITY;
     rl[tid] = 0.f;
   }
-  const int nkb = p.causal ? qb + 1 : (p.Lk + 63) / 64;
+  const int nkb = p.have_lse ? 0 : (p.causal ? qb + 1 : (p.Lk + 63) / 64);
   for (int kb = 0; kb < nkb; ++kb) {
     __syncthreads();
     sab_load<HDP>(p.k + (long long)b * p.k_bs + h * hd, p.ldk, kb * 64, p.Lk, hd, 1.f, Ks);
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(256) void slate_attn_stats_kernel(SabArgs p, int hd
     d += sf_dpp<0x4E>(d);
     if ((lane & 3) == 0 && qi < p.Lq) {
       const long long idx = ((long long)b * p.H + h) * p.Lq + qi;
-      p.lse[idx] = rm[r] + logf(rl[r]);
+      if (!p.have_lse) p.lse[idx] = rm[r] + logf(rl[r]);
       p.dsum[idx] = d;
     }
   }
@@ -154,8 +162,9 @@ __global__ __launch_bounds__(256) void slate_attn_bwd_kernel(SabArgs p, int hd) 
       const int qi = q0 + qr, kj = k0 + kc;
       const bool ok = qi < p.Lq && kj < p.Lk && (!p.causal || kj <= qi);
       const float pv = ok ? expf(s[r] - ls[qr]) : 0.f;
-      Ps[qr * 65 + kc] = pv;
-      Ds[qr * 65 + kc] = pv * (dp[r] - ls[64 + qr]);
+      const float mk = ok ? sab_drop(p, b, h, qi, kj) : 0.f;   // dropout factor on this attention weight (1 when off)
+      Ps[qr * 65 + kc] = pv * mk;                               // what multiplied V in the forward pass
+      Ds[qr * 65 + kc] = pv * (dp[r] * mk - ls[64 + qr]);
     }
     __syncthreads();
     // dV_j += P^T dO_i ; dK_j += dS^T (Q_i * scale)   (contraction over the 64 queries)
@@ -195,7 +204,120 @@ __global__ __launch_bounds__(256) void slate_attn_bwd_kernel(SabArgs p, int hd) 
   }
 }
 
+// Training forward: the same attention with dropout on the weights and the row log-sum-exp kept for the backward pass.
+// One workgroup per (64-query block, head, sequence): S tiles -> LDS, online row max / sum, the (dropped) weights back to LDS,
+// O accumulated as 32x32 tiles in registers and rescaled per row when the running max moves.
+template <int HDP>
+__global__ __launch_bounds__(256) void slate_attn_fwd_train_kernel(SabArgs p, float* __restrict__ out, int hd) {
+  constexpr int P = HDP + 1, CT = HDP / 32;
+  extern __shared__ float lds[];
+  float* Qs = lds;
+  float* Ks = Qs + 64 * P;
+  float* Vs = Ks + 64 * P;
+  float* Ss = Vs + 64 * P;     // [64][65]
+  float* rm = Ss + 64 * 65;
+  float* rl = rm + 64;
+  float* rs = rl + 64;         // per-row rescale of this step
+  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int q0 = qb * 64;
+  sab_load<HDP>(p.q + (long long)b * p.q_bs + h * hd, p.ldq, q0, p.Lq, hd, p.scale, Qs);
+  if (tid < 64) {
+    rm[tid] = -INFINITY;
+    rl[tid] = 0.f;
+  }
+  f32x16 oacc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) oacc[i] = 0.f;
+  const int at = wave, ati = (at / CT) * 32, atj = (at % CT) * 32;   // O tile of this wave (valid if at < 2 * CT)
+  const int nkb = p.causal ? qb + 1 : (p.Lk + 63) / 64;
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();
+    sab_load<HDP>(p.k + (long long)b * p.k_bs + h * hd, p.ldk, kb * 64, p.Lk, hd, 1.f, Ks);
+    sab_load<HDP>(p.v + (long long)b * p.v_bs + h * hd, p.ldv, kb * 64, p.Lk, hd, 1.f, Vs);
+    __syncthreads();
+    {
+      const int ti = (wave >> 1) * 32, tj = (wave & 1) * 32;
+      const f32x16 acc = sab_mm32([&](int i, int kk) { return Qs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Ks[(tj + j) * P + kk]; },
+                                  HDP, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ss[(ti + SAB_ROW(r, lane)) * 65 + tj + (lane & 31)] = acc[r];
+    }
+    __syncthreads();
+    for (int r = wave; r < 64; r += 4) {
+      const int qi = q0 + r, kj = kb * 64 + lane;
+      const bool ok = qi < p.Lq && kj < p.Lk && (!p.causal || kj <= qi);
+      const float s = ok ? Ss[r * 65 + lane] : -INFINITY;
+      const float mx = sf_wave_max(s);
+      const float mo = rm[r], mn = fmaxf(mo, mx);
+      const float e = (ok && mn > -INFINITY) ? expf(s - mn) : 0.f;
+      const float sum = sf_wave_sum(e);
+      Ss[r * 65 + lane] = ok ? e * sab_drop(p, b, h, qi, kj) : 0.f;
+      if (lane == 0) {
+        const float sc = (mo == -INFINITY) ? 0.f : expf(mo - mn);
+        rl[r] = rl[r] * sc + sum;
+        rm[r] = mn;
+        rs[r] = sc;
+      }
+    }
+    __syncthreads();
+    if (at < 2 * CT) {
+      const f32x16 a = sab_mm32([&](int i, int kk) { return Ss[(ati + i) * 65 + kk]; }, [&](int kk, int j) { return Vs[kk * P + atj + j]; }, 64,
+                                lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[r] = oacc[r] * rs[ati + SAB_ROW(r, lane)] + a[r];
+    }
+  }
+  __syncthreads();
+  if (at < 2 * CT) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qr = ati + SAB_ROW(r, lane), qi = q0 + qr, c = atj + (lane & 31);
+      if (qi < p.Lq && c < hd) out[(long long)b * p.o_bs + (long long)qi * p.ldo + h * hd + c] = oacc[r] / rl[qr];
+    }
+  }
+  if (tid < 64 && q0 + tid < p.Lq) p.lse[((long long)b * p.H + h) * p.Lq + q0 + tid] = rm[tid] + logf(rl[tid]);
+}
+
+static uint32_t sab_site_seed(unsigned long long seed) {
+  return sf_mix32((uint32_t)seed ^ sf_mix32((uint32_t)(seed >> 32) + 0x9e3779b9u));
+}
+
 extern "C" {
+
+// Training forward with dropout on the attention weights (nn.Dropout inside steve_transformer.py's MultiHeadAttention, :46-48):
+// out as sf_slate_attention_strided_f32, lse [B][H][Lq] (kept for sf_slate_attention_train_bwd_f32).
+int sf_slate_attention_train_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse, int ldq, int ldk, int ldv,
+                                     int ldo, long long q_bs, long long k_bs, long long v_bs, long long o_bs, int B, int Lq, int Lk,
+                                     int num_heads, int head_dim, int causal, float dropout_p, unsigned long long seed, void* stream) {
+  SF_REQUIRE(q && k && v && out && lse, "null pointer");
+  SF_REQUIRE(B > 0 && Lq > 0 && Lk > 0 && num_heads > 0, "bad sizes");
+  SF_REQUIRE(head_dim >= 2 && head_dim <= 64 && head_dim % 2 == 0, "head_dim must be even and <= 64");
+  SF_REQUIRE(!causal || Lq == Lk, "causal attention needs Lq == Lk");
+  SF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p in [0, 1)");
+  SabArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = q; a.k = k; a.v = v; a.lse = lse;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
+  a.Lq = Lq; a.Lk = Lk; a.H = num_heads; a.causal = causal; a.scale = 1.f / sqrtf((float)head_dim);
+  a.drop_seed = sab_site_seed(seed); a.drop_thresh = (uint32_t)((double)dropout_p * 16777216.0); a.drop_scale = 1.f / (1.f - dropout_p);
+  const int hdp = head_dim <= 32 ? 32 : 64;
+  const size_t lds = ((size_t)3 * 64 * (hdp + 1) + 64 * 65 + 192) * sizeof(float);
+  const dim3 g((Lq + 63) / 64, num_heads, B);
+  if (hdp == 32) {
+    hipLaunchKernelGGL(slate_attn_fwd_train_kernel<32>, g, dim3(256), lds, (hipStream_t)stream, a, out, head_dim);
+  } else {
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)slate_attn_fwd_train_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024);
+      if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+      attr = true;
+    }
+    hipLaunchKernelGGL(slate_attn_fwd_train_kernel<64>, g, dim3(256), lds, (hipStream_t)stream, a, out, head_dim);
+  }
+  SF_CHECK_LAUNCH();
+  return 0;
+}
 
 size_t sf_slate_attention_bwd_workspace_bytes(int B, int Lq, int num_heads) {
   return (size_t)2 * B * num_heads * Lq * sizeof(float) + 256;
@@ -203,10 +325,12 @@ size_t sf_slate_attention_bwd_workspace_bytes(int B, int Lq, int num_heads) {
 
 // Adjoint of sf_slate_attention_strided_f32: dq / dk / dv have the layouts of q / k / v, d_out and out the layout of out.
 // dq must not alias q (it is zeroed here and accumulated with float atomics: its low bits depend on the arrival order).
-int sf_slate_attention_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* d_out, float* dq,
-                               float* dk, float* dv, int ldq, int ldk, int ldv, int ldo, long long q_bs, long long k_bs,
-                               long long v_bs, long long o_bs, int B, int Lq, int Lk, int num_heads, int head_dim, int causal,
-                               void* ws, size_t ws_bytes, void* stream) {
+int sf_slate_attention_train_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* d_out,
+                                     const float* lse, float* dq, float* dk, float* dv, int ldq, int ldk, int ldv, int ldo,
+                                     long long q_bs, long long k_bs, long long v_bs, long long o_bs, int B, int Lq, int Lk,
+                                     int num_heads, int head_dim, int causal, float dropout_p, unsigned long long seed, void* ws,
+                                     size_t ws_bytes, void* stream) {
+  SF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p in [0, 1)");
   SF_REQUIRE(q && k && v && out && d_out && dq && dk && dv && ws, "null pointer");
   SF_REQUIRE(B > 0 && Lq > 0 && Lk > 0 && num_heads > 0, "bad sizes");
   SF_REQUIRE(head_dim >= 2 && head_dim <= 64 && head_dim % 2 == 0, "head_dim must be even and <= 64");
@@ -215,9 +339,13 @@ int sf_slate_attention_bwd_f32(const float* q, const float* k, const float* v, c
   SF_REQUIRE(q_bs >= (long long)(Lq - 1) * ldq + num_heads * head_dim, "dq is cleared over whole batches: q_bs too small");
   hipStream_t st = (hipStream_t)stream;
   SabArgs a;
+  memset(&a, 0, sizeof(a));
   a.q = q; a.k = k; a.v = v; a.o = out; a.dout = d_out; a.dq = dq; a.dk = dk; a.dv = dv;
-  a.lse = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-  a.dsum = a.lse + (size_t)B * num_heads * Lq;
+  float* wsf = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  a.have_lse = lse != nullptr;
+  a.lse = lse ? const_cast<float*>(lse) : wsf;
+  a.dsum = wsf + (size_t)B * num_heads * Lq;
+  a.drop_seed = sab_site_seed(seed); a.drop_thresh = (uint32_t)((double)dropout_p * 16777216.0); a.drop_scale = 1.f / (1.f - dropout_p);
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
   a.Lq = Lq; a.Lk = Lk; a.H = num_heads; a.causal = causal; a.scale = 1.f / sqrtf((float)head_dim);
   // clear the head columns of dq (row by row: dq may be a column slice of a wider packed tensor)
@@ -246,6 +374,14 @@ int sf_slate_attention_bwd_f32(const float* q, const float* k, const float* v, c
 #undef SAB_GO
   SF_CHECK_LAUNCH();
   return 0;
+}
+
+int sf_slate_attention_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* d_out, float* dq,
+                               float* dk, float* dv, int ldq, int ldk, int ldv, int ldo, long long q_bs, long long k_bs,
+                               long long v_bs, long long o_bs, int B, int Lq, int Lk, int num_heads, int head_dim, int causal,
+                               void* ws, size_t ws_bytes, void* stream) {
+  return sf_slate_attention_train_bwd_f32(q, k, v, out, d_out, nullptr, dq, dk, dv, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, B, Lq,
+                                          Lk, num_heads, head_dim, causal, 0.f, 0ULL, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

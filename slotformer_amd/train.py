@@ -473,23 +473,43 @@ def lstm_step(x, state, rnn):
 
 class _SlateAttention(torch.autograd.Function):
     """softmax(q k^T / sqrt(hd) [causal]) v of the STEVE decoder (steve_transformer.py:12-55) on contiguous q [B,Lq,d],
-    k, v [B,Lk,d]: sf_slate_attention_f32 forward, the flash-style sf_slate_attention_bwd_f32 backward."""
+    k, v [B,Lk,d], with optional dropout on the attention weights (p > 0: the training forward, which also keeps the row
+    log-sum-exp; p == 0: the inference kernel).  Backward: the flash-style sf_slate_attention_train_bwd_f32."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, causal):
+    def forward(ctx, q, k, v, heads, causal, p, seed):
         from . import ops
         q, k, v = (t.detach().float().contiguous() for t in (q, k, v))
-        out = ops.slate_attention(q, k, v, heads, causal)
-        ctx.save_for_backward(q, k, v, out)
-        ctx.args = (heads, bool(causal))
+        B, Lq, d = q.shape
+        Lk = k.shape[1]
+        lse = None
+        if p > 0:
+            out = torch.empty_like(q)
+            lse = torch.empty(B, heads, Lq, dtype=torch.float32, device=q.device)
+            check(lib().sf_slate_attention_train_fwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), d, d, d, d,
+                                                         Lq * d, Lk * d, Lk * d, Lq * d, B, Lq, Lk, heads, d // heads, int(causal), float(p),
+                                                         int(seed), torch.cuda.current_stream().cuda_stream))
+        else:
+            out = ops.slate_attention(q, k, v, heads, causal)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.args = (heads, bool(causal), float(p), int(seed))
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        from . import ops
-        q, k, v, out = ctx.saved_tensors
-        dq, dk, dv = ops.slate_attention_bwd(q, k, v, out, d_out.float().contiguous(), *ctx.args)
-        return dq, dk, dv, None, None
+        q, k, v, out, lse = ctx.saved_tensors
+        heads, causal, p, seed = ctx.args
+        B, Lq, d = q.shape
+        Lk = k.shape[1]
+        d_out = d_out.float().contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        nb = lib().sf_slate_attention_bwd_workspace_bytes(B, Lq, heads)
+        ws = torch.empty(nb, dtype=torch.uint8, device=q.device)
+        check(lib().sf_slate_attention_train_bwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), d_out.data_ptr(),
+                                                     lse.data_ptr() if lse is not None else None, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                                     d, d, d, d, Lq * d, Lk * d, Lk * d, Lq * d, B, Lq, Lk, heads, d // heads, int(causal), p,
+                                                     seed, ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream))
+        return dq, dk, dv, None, None, None, None
 
 
 class _Embed(torch.autograd.Function):
@@ -536,14 +556,15 @@ class _TokenCrossEntropy(torch.autograd.Function):
 
 def slate_decoder_forward(dec, slots, idx):
     """STEVETransformerDecoder.forward (steve_transformer.py:275-303) under autograd: slots [B,N,d], idx int64 [B,t] ->
-    logits [B,1+t,V], as a chain of HIP-backed nodes.  Dropout on the attention WEIGHTS is not supported (the flash kernels
-    never materialise them); the embedding / output / FFN dropouts follow the modules."""
+    logits [B,1+t,V], as a chain of HIP-backed nodes; every dropout of the reference modules (embedding, attention weights,
+    attention output, FFN) is active iff the decoder is in train() mode."""
     tr = dec.training
     B, T = idx.shape
     H = dec.n_head
-    if tr and len(dec.tf_dec.blocks) and dec.tf_dec.blocks[0].self_attn.attn_dropout.p > 0:
-        raise NotImplementedError('slotformer_amd: dropout on the attention weights of the STEVE decoder is not built; set '
-                                  'attn_dropout.p = 0 on its MultiHeadAttention modules')
+
+    def attend(q, k, v, mha, causal):
+        p = float(mha.attn_dropout.p) if tr else 0.0
+        return _SlateAttention.apply(q, k, v, H, causal, p, _new_seed() if p > 0 else 0)
     mem = linear(slots.float().contiguous(), dec.in_proj)
     bos = torch.full((B, 1), dec.vocab_size, dtype=torch.int64, device=idx.device)
     tokens = torch.cat([bos, idx.to(torch.int64)], 1).contiguous()
@@ -553,10 +574,10 @@ def slate_decoder_forward(dec, slots, idx):
         y = layer_norm(x, blk.self_attn_layer_norm)
         if blk.is_first:   # the first block normalises its input in place (steve_transformer.py:186-190)
             x = y
-        att = _SlateAttention.apply(linear(y, sa.proj_q), linear(y, sa.proj_k), linear(y, sa.proj_v), H, True)
+        att = attend(linear(y, sa.proj_q), linear(y, sa.proj_k), linear(y, sa.proj_v), sa, True)
         x = x + dropout(linear(att, sa.proj_o), sa.output_dropout.p, tr)
         y = layer_norm(x, blk.encoder_decoder_attn_layer_norm)
-        att = _SlateAttention.apply(linear(y, ca.proj_q), linear(mem, ca.proj_k), linear(mem, ca.proj_v), H, False)
+        att = attend(linear(y, ca.proj_q), linear(mem, ca.proj_k), linear(mem, ca.proj_v), ca, False)
         x = x + dropout(linear(att, ca.proj_o), ca.output_dropout.p, tr)
         y = layer_norm(x, blk.ffn_layer_norm)
         x = x + dropout(linear(linear(y, blk.ffn[0], relu=True), blk.ffn[2]), blk.ffn[3].p, tr)

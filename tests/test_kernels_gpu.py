@@ -283,3 +283,33 @@ def test_slate_attention_backward(dev, B, Lq, Lk, H, hd, causal):
     assert rel_err(dq, qo.grad) < 2e-5
     assert rel_err(dk, ko.grad) < 2e-5
     assert rel_err(dv, vo.grad) < 2e-5
+
+
+@pytest.mark.parametrize('B,Lq,Lk,H,hd,causal', [(2, 130, 130, 4, 16, True), (1, 257, 257, 2, 64, True), (2, 100, 6, 4, 32, False)])
+def test_slate_attention_weight_dropout(dev, B, Lq, Lk, H, hd, causal):
+    """Training attention with dropout on the weights (sf_slate_attention_train_fwd/bwd_f32): the masks are rebuilt on the host
+    from the seed and drive a torch restatement under autograd."""
+    import golden_util as gu
+    from slotformer_amd import train
+
+    def rel_err(a, b):
+        a, b = a.detach().cpu().double(), b.detach().double()
+        return ((a - b).abs().max() / b.abs().max()).item()
+
+    p, seed, d = 0.1, 0x5eed_0000_1234_5678, H * hd
+    q, k, v = gu.seeded_normal((B, Lq, d), 1), gu.seeded_normal((B, Lk, d), 2), gu.seeded_normal((B, Lk, d), 3)
+    g = gu.seeded_normal((B, Lq, d), 4)
+    qo, ko, vo = (t.clone().requires_grad_(True) for t in (q, k, v))
+    qh, kh, vh = (t.view(B, -1, H, hd).transpose(1, 2) for t in (qo, ko, vo))
+    s = (qh @ kh.transpose(-1, -2)) * hd**-0.5
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(Lq, Lk, dtype=torch.bool), 1), float('-inf'))
+    keep = torch.from_numpy(train.dropout_keep_mask(seed, 0, 0, 0, B * H * Lq * Lk, p).astype(np.float32)).view(B, H, Lq, Lk)
+    att = torch.softmax(s, -1) * keep / (1.0 - float(np.float32(p)))
+    ref = (att @ vh).transpose(1, 2).reshape(B, Lq, d)
+    ref.backward(g)
+    qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    out = train._SlateAttention.apply(qd, kd, vd, H, causal, p, seed)
+    out.backward(g.to(dev))
+    assert rel_err(out, ref) < 2e-5
+    assert rel_err(qd.grad, qo.grad) < 5e-5 and rel_err(kd.grad, ko.grad) < 5e-5 and rel_err(vd.grad, vo.grad) < 5e-5

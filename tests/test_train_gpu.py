@@ -622,3 +622,27 @@ def test_steve_training_step_golden(dev, precision):
     l2 = m.calc_train_loss({'img': img.to(dev)}, out2)['token_recon_loss']
     l2.backward()
     assert abs(float(l2.detach()) - float(g['loss'])) < 2e-2 * float(g['loss'])
+
+
+def test_steve_training_with_all_dropouts(dev):
+    """STEVE in plain train() mode (the reference's default dropout 0.1 on the embedding, the attention weights, the attention
+    outputs and the FFN of the decoder, and inside the Transformer predictor): a few FlatAdam steps on one batch run and
+    bring the token loss down."""
+    from slotformer_amd import train
+    g = gu.load_golden('steve_train')
+    m, sd = build(gu.steve_tokens_cfg(), g, 921, dev)
+    m.train()
+    m.testing = False
+    assert m.trans_decoder.tf_dec.blocks[0].self_attn.attn_dropout.p > 0
+    data = {'img': gu.seeded_img(2, 2, 64, seed=923).to(dev)}
+    opt = train.FlatAdam([p for p in m.parameters() if p.requires_grad], lr=3e-4)
+    torch.manual_seed(0)
+    hist = []
+    for _ in range(6):
+        opt.zero_grad()
+        out = m(data)
+        loss = m.calc_train_loss(data, out)['token_recon_loss']
+        loss.backward()
+        opt.step()
+        hist.append(float(loss.detach()))
+    assert all(np.isfinite(hist)) and hist[-1] < hist[0], hist
