@@ -15,13 +15,36 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <class FA, class FB>
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// one 32x32 output tile, C[i][j] = sum_k a(i, k) b(k, j), operands read from LDS through the functors.
+// BF3 = false: exact-f32 MFMA (32x32x2, 64 cycles per 2 k).  BF3 = true (library precision modes 1 / 2): the operands are
+// split into bf16 hi + lo on the fly and contracted as hi*hi + hi*lo + lo*hi on the 32x32x16 bf16 MFMA -- 5x less
+// matrix-pipe time per k, which is what bounds these kernels (K must then be a multiple of 16).
+template <bool BF3, class FA, class FB>
 __device__ __forceinline__ f32x16 sab_mm32(FA a, FB b, int K, int lane) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   const int i0 = lane & 31, kk = lane >> 5;
-  for (int k = 0; k < K; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a(i0, k + kk), b(k + kk, i0), acc, 0, 0, 0);
+  if constexpr (BF3) {
+    for (int k = 0; k < K; k += 16) {
+      f32x8 av, bv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        av[j] = a(i0, k + 8 * kk + j);
+        bv[j] = b(k + 8 * kk + j, i0);
+      }
+      const bf16x8 ah = __builtin_convertvector(av, bf16x8), bh = __builtin_convertvector(bv, bf16x8);
+      const bf16x8 al = __builtin_convertvector(av - __builtin_convertvector(ah, f32x8), bf16x8);
+      const bf16x8 bl = __builtin_convertvector(bv - __builtin_convertvector(bh, f32x8), bf16x8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    }
+  } else {
+    for (int k = 0; k < K; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a(i0, k + kk), b(k + kk, i0), acc, 0, 0, 0);
+  }
   return acc;
 }
 #define SAB_ROW(r, lane) (((r) & 3) + 8 * ((r) >> 2) + 4 * ((lane) >> 5))
@@ -53,7 +76,7 @@ __device__ __forceinline__ void sab_load(const float* base, int ld, int r0, int 
   }
 }
 
-template <int HDP>
+template <int HDP, bool BF3>
 __global__ __launch_bounds__(256) void slate_attn_stats_kernel(SabArgs p, int hd) {
   constexpr int P = HDP + 1;
   extern __shared__ float lds[];
@@ -76,7 +99,7 @@ __global__ __launch_bounds__(256) void slate_attn_stats_kernel(SabArgs p, int hd
     __syncthreads();
     {
       const int ti = (wave >> 1) * 32, tj = (wave & 1) * 32;
-      const f32x16 acc = sab_mm32([&](int i, int kk) { return Qs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Ks[(tj + j) * P + kk]; },
+      const f32x16 acc = sab_mm32<BF3>([&](int i, int kk) { return Qs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Ks[(tj + j) * P + kk]; },
                                   HDP, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) Ss[(ti + SAB_ROW(r, lane)) * 65 + tj + (lane & 31)] = acc[r];
@@ -116,7 +139,7 @@ __global__ __launch_bounds__(256) void slate_attn_stats_kernel(SabArgs p, int hd
   }
 }
 
-template <int HDP>
+template <int HDP, bool BF3>
 __global__ __launch_bounds__(256) void slate_attn_bwd_kernel(SabArgs p, int hd) {
   constexpr int P = HDP + 1, CT = HDP / 32;   // channel tiles
   extern __shared__ float lds[];
@@ -152,9 +175,9 @@ __global__ __launch_bounds__(256) void slate_attn_bwd_kernel(SabArgs p, int hd) 
     __syncthreads();
     const int ti = (wave >> 1) * 32, tj = (wave & 1) * 32;
     // S tile and dP tile of this wave (queries ti.., keys tj..)
-    const f32x16 s = sab_mm32([&](int i, int kk) { return Qs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Ks[(tj + j) * P + kk]; },
+    const f32x16 s = sab_mm32<BF3>([&](int i, int kk) { return Qs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Ks[(tj + j) * P + kk]; },
                               HDP, lane);
-    const f32x16 dp = sab_mm32([&](int i, int kk) { return Gs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Vs[(tj + j) * P + kk]; },
+    const f32x16 dp = sab_mm32<BF3>([&](int i, int kk) { return Gs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Vs[(tj + j) * P + kk]; },
                                HDP, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -170,9 +193,9 @@ __global__ __launch_bounds__(256) void slate_attn_bwd_kernel(SabArgs p, int hd) 
     // dV_j += P^T dO_i ; dK_j += dS^T (Q_i * scale)   (contraction over the 64 queries)
     if (at < 2 * CT) {
       // tiles 0 .. 2*CT-1 cover [64 keys][HDP]; ati = key offset, atj = channel offset
-      const f32x16 a1 = sab_mm32([&](int i, int kk) { return Ps[kk * 65 + ati + i]; }, [&](int kk, int j) { return Gs[kk * P + atj + j]; }, 64,
+      const f32x16 a1 = sab_mm32<BF3>([&](int i, int kk) { return Ps[kk * 65 + ati + i]; }, [&](int kk, int j) { return Gs[kk * P + atj + j]; }, 64,
                                  lane);
-      const f32x16 a2 = sab_mm32([&](int i, int kk) { return Ds[kk * 65 + ati + i]; }, [&](int kk, int j) { return Qs[kk * P + atj + j]; }, 64,
+      const f32x16 a2 = sab_mm32<BF3>([&](int i, int kk) { return Ds[kk * 65 + ati + i]; }, [&](int kk, int j) { return Qs[kk * P + atj + j]; }, 64,
                                  lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -183,7 +206,7 @@ __global__ __launch_bounds__(256) void slate_attn_bwd_kernel(SabArgs p, int hd) 
     // dQ_i += scale * dS K_j  (tiles over [64 queries][HDP]; atomics: several key blocks add into the same rows)
     for (int t = wave; t < 2 * CT; t += 4) {
       const int qi0 = (t / CT) * 32, c0 = (t % CT) * 32;
-      const f32x16 a3 = sab_mm32([&](int i, int kk) { return Ds[(qi0 + i) * 65 + kk]; }, [&](int kk, int j) { return Ks[kk * P + c0 + j]; }, 64,
+      const f32x16 a3 = sab_mm32<BF3>([&](int i, int kk) { return Ds[(qi0 + i) * 65 + kk]; }, [&](int kk, int j) { return Ks[kk * P + c0 + j]; }, 64,
                                  lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -207,7 +230,7 @@ __global__ __launch_bounds__(256) void slate_attn_bwd_kernel(SabArgs p, int hd) 
 // Training forward: the same attention with dropout on the weights and the row log-sum-exp kept for the backward pass.
 // One workgroup per (64-query block, head, sequence): S tiles -> LDS, online row max / sum, the (dropped) weights back to LDS,
 // O accumulated as 32x32 tiles in registers and rescaled per row when the running max moves.
-template <int HDP>
+template <int HDP, bool BF3>
 __global__ __launch_bounds__(256) void slate_attn_fwd_train_kernel(SabArgs p, float* __restrict__ out, int hd) {
   constexpr int P = HDP + 1, CT = HDP / 32;
   extern __shared__ float lds[];
@@ -237,7 +260,7 @@ __global__ __launch_bounds__(256) void slate_attn_fwd_train_kernel(SabArgs p, fl
     __syncthreads();
     {
       const int ti = (wave >> 1) * 32, tj = (wave & 1) * 32;
-      const f32x16 acc = sab_mm32([&](int i, int kk) { return Qs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Ks[(tj + j) * P + kk]; },
+      const f32x16 acc = sab_mm32<BF3>([&](int i, int kk) { return Qs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Ks[(tj + j) * P + kk]; },
                                   HDP, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) Ss[(ti + SAB_ROW(r, lane)) * 65 + tj + (lane & 31)] = acc[r];
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(256) void slate_attn_fwd_train_kernel(SabArgs p, fl
     }
     __syncthreads();
     if (at < 2 * CT) {
-      const f32x16 a = sab_mm32([&](int i, int kk) { return Ss[(ati + i) * 65 + kk]; }, [&](int kk, int j) { return Vs[kk * P + atj + j]; }, 64,
+      const f32x16 a = sab_mm32<BF3>([&](int i, int kk) { return Ss[(ati + i) * 65 + kk]; }, [&](int kk, int j) { return Vs[kk * P + atj + j]; }, 64,
                                 lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[r] = oacc[r] * rs[ati + SAB_ROW(r, lane)] + a[r];
@@ -303,17 +326,23 @@ int sf_slate_attention_train_fwd_f32(const float* q, const float* k, const float
   const int hdp = head_dim <= 32 ? 32 : 64;
   const size_t lds = ((size_t)3 * 64 * (hdp + 1) + 64 * 65 + 192) * sizeof(float);
   const dim3 g((Lq + 63) / 64, num_heads, B);
+  const bool bf3 = sf_get_precision() >= 1;
   if (hdp == 32) {
-    hipLaunchKernelGGL(slate_attn_fwd_train_kernel<32>, g, dim3(256), lds, (hipStream_t)stream, a, out, head_dim);
+    if (bf3) hipLaunchKernelGGL((slate_attn_fwd_train_kernel<32, true>), g, dim3(256), lds, (hipStream_t)stream, a, out, head_dim);
+    else hipLaunchKernelGGL((slate_attn_fwd_train_kernel<32, false>), g, dim3(256), lds, (hipStream_t)stream, a, out, head_dim);
   } else {
     static bool attr = false;
     if (!attr) {
-      hipError_t e = hipFuncSetAttribute((const void*)slate_attn_fwd_train_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      hipError_t e = hipFuncSetAttribute((const void*)slate_attn_fwd_train_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)slate_attn_fwd_train_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
       if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
       attr = true;
     }
-    hipLaunchKernelGGL(slate_attn_fwd_train_kernel<64>, g, dim3(256), lds, (hipStream_t)stream, a, out, head_dim);
+    if (bf3) hipLaunchKernelGGL((slate_attn_fwd_train_kernel<64, true>), g, dim3(256), lds, (hipStream_t)stream, a, out, head_dim);
+    else hipLaunchKernelGGL((slate_attn_fwd_train_kernel<64, false>), g, dim3(256), lds, (hipStream_t)stream, a, out, head_dim);
   }
   SF_CHECK_LAUNCH();
   return 0;
@@ -358,19 +387,24 @@ int sf_slate_attention_train_bwd_f32(const float* q, const float* k, const float
   const size_t lds1 = ((size_t)2 * 64 * (hdp + 1) + 64 * 65 + 128) * sizeof(float);
   const size_t lds2 = ((size_t)4 * 64 * (hdp + 1) + 2 * 64 * 65 + 128) * sizeof(float);
   const dim3 g1((Lq + 63) / 64, num_heads, B), g2((Lk + 63) / 64, num_heads, B);
-#define SAB_GO(HDP)                                                                                                          \
-  {                                                                                                                          \
-    static bool attr = false;                                                                                                \
-    if (!attr) {                                                                                                             \
-      hipError_t e = hipFuncSetAttribute((const void*)slate_attn_bwd_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         160 * 1024);                                                                        \
-      if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);                              \
-      attr = true;                                                                                                           \
-    }                                                                                                                        \
-    hipLaunchKernelGGL(slate_attn_stats_kernel<HDP>, g1, dim3(256), lds1, st, a, head_dim);                                  \
-    hipLaunchKernelGGL(slate_attn_bwd_kernel<HDP>, g2, dim3(256), lds2, st, a, head_dim);                                    \
+#define SAB_GO(HDP, BF)                                                                                                          \
+  {                                                                                                                              \
+    static bool attr = false;                                                                                                    \
+    if (!attr) {                                                                                                                 \
+      hipError_t e = hipFuncSetAttribute((const void*)slate_attn_bwd_kernel<HDP, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         160 * 1024);                                                                            \
+      if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);                                  \
+      attr = true;                                                                                                               \
+    }                                                                                                                            \
+    hipLaunchKernelGGL((slate_attn_stats_kernel<HDP, BF>), g1, dim3(256), lds1, st, a, head_dim);                                \
+    hipLaunchKernelGGL((slate_attn_bwd_kernel<HDP, BF>), g2, dim3(256), lds2, st, a, head_dim);                                  \
   }
-  if (hdp == 32) SAB_GO(32) else SAB_GO(64)
+  const bool bf3 = sf_get_precision() >= 1;
+  if (hdp == 32) {
+    if (bf3) SAB_GO(32, true) else SAB_GO(32, false)
+  } else {
+    if (bf3) SAB_GO(64, true) else SAB_GO(64, false)
+  }
 #undef SAB_GO
   SF_CHECK_LAUNCH();
   return 0;

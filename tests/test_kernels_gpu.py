@@ -255,7 +255,7 @@ def test_softmax_argmax_xent_embed(dev):
 
 @pytest.mark.parametrize('B,Lq,Lk,H,hd,causal', [(2, 130, 130, 4, 16, True), (1, 257, 257, 2, 64, True), (2, 100, 6, 4, 32, False),
                                                   (1, 1025, 1025, 1, 64, True), (3, 64, 7, 2, 48, False)])
-def test_slate_attention_backward(dev, B, Lq, Lk, H, hd, causal):
+def test_slate_attention_backward(dev, precision, B, Lq, Lk, H, hd, causal):
     """sf_slate_attention_bwd_f32 (flash-style adjoint: causal self-attention over patch tokens, cross-attention to the slots)
     against torch autograd of the plain softmax(q k^T / sqrt(hd)) v."""
     from slotformer_amd import ops
@@ -280,13 +280,14 @@ def test_slate_attention_backward(dev, B, Lq, Lk, H, hd, causal):
     out = ops.slate_attention(qd, kd, vd, H, causal)
     assert rel_err(out, ref) < 1e-5
     dq, dk, dv = ops.slate_attention_bwd(qd, kd, vd, out, g.to(dev), H, causal)
-    assert rel_err(dq, qo.grad) < 2e-5
-    assert rel_err(dk, ko.grad) < 2e-5
-    assert rel_err(dv, vo.grad) < 2e-5
+    tol_ = {'f32': 2e-5, 'bf16x3': 2e-4}[precision]   # exact-f32 MFMA / split-bf16 tiles
+    assert rel_err(dq, qo.grad) < tol_
+    assert rel_err(dk, ko.grad) < tol_
+    assert rel_err(dv, vo.grad) < tol_
 
 
 @pytest.mark.parametrize('B,Lq,Lk,H,hd,causal', [(2, 130, 130, 4, 16, True), (1, 257, 257, 2, 64, True), (2, 100, 6, 4, 32, False)])
-def test_slate_attention_weight_dropout(dev, B, Lq, Lk, H, hd, causal):
+def test_slate_attention_weight_dropout(dev, precision, B, Lq, Lk, H, hd, causal):
     """Training attention with dropout on the weights (sf_slate_attention_train_fwd/bwd_f32): the masks are rebuilt on the host
     from the seed and drive a torch restatement under autograd."""
     import golden_util as gu
@@ -311,5 +312,6 @@ def test_slate_attention_weight_dropout(dev, B, Lq, Lk, H, hd, causal):
     qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
     out = train._SlateAttention.apply(qd, kd, vd, H, causal, p, seed)
     out.backward(g.to(dev))
-    assert rel_err(out, ref) < 2e-5
-    assert rel_err(qd.grad, qo.grad) < 5e-5 and rel_err(kd.grad, ko.grad) < 5e-5 and rel_err(vd.grad, vo.grad) < 5e-5
+    tol_ = {'f32': 5e-5, 'bf16x3': 3e-4}[precision]
+    assert rel_err(out, ref) < tol_
+    assert rel_err(qd.grad, qo.grad) < tol_ and rel_err(kd.grad, ko.grad) < tol_ and rel_err(vd.grad, vo.grad) < tol_
