@@ -59,3 +59,6 @@ int sf_conv_wgrad_ex(const float* A, int CA, int H, int W, const float* X, int H
                      float* out_oihw, float* partial, hipStream_t st);
 size_t sf_conv_wgrad_partial_floats(int CA, int ks);
 int sf_pos_dense_grad_ex(const float* d, int F, int HW, int C, const float* grid, float* dw, float* db, float* dtab, hipStream_t st);
+int sf_slate_flash_train_ex(const float* q, const float* k, const float* v, float* out, float* lse, int ldq, int ldk, int ldv, int ldo,
+                            long long q_bs, long long k_bs, long long v_bs, long long o_bs, int B, int L, int num_heads, int head_dim,
+                            unsigned drop_seed, unsigned drop_thresh, float drop_scale, hipStream_t st);

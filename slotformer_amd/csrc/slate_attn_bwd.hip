@@ -323,6 +323,11 @@ int sf_slate_attention_train_fwd_f32(const float* q, const float* k, const float
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
   a.Lq = Lq; a.Lk = Lk; a.H = num_heads; a.causal = causal; a.scale = 1.f / sqrtf((float)head_dim);
   a.drop_seed = sab_site_seed(seed); a.drop_thresh = (uint32_t)((double)dropout_p * 16777216.0); a.drop_scale = 1.f / (1.f - dropout_p);
+  if (causal) {   // the long causal self-attention runs on the inference flash kernel (scores in registers) with the mask added
+    const int rc = sf_slate_flash_train_ex(q, k, v, out, lse, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, B, Lq, num_heads, head_dim,
+                                           a.drop_seed, a.drop_thresh, a.drop_scale, (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
   const int hdp = head_dim <= 32 ? 32 : 64;
   const size_t lds = ((size_t)3 * 64 * (hdp + 1) + 64 * 65 + 192) * sizeof(float);
   const dim3 g((Lq + 63) / 64, num_heads, B);

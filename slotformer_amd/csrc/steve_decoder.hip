@@ -156,11 +156,18 @@ __global__ __launch_bounds__(256) void slate_attn_kernel(const float* __restrict
 // softmax statistics are per-lane reductions plus one exchange with lane ^ 32, and the probabilities feed the PV MFMA
 // straight from registers (register r = the key pair (k_r, k_r + 4) of the B operand).  The two key halves of a query
 // block keep separate running (max, sum, O) and are merged through LDS at the end.
-template <int HD>
+// TRAIN (row N1, sf_slate_attention_train_fwd_f32): dropout on the attention weights -- the register-resident probabilities are
+// scaled by a hashed keep mask before they feed the PV MFMA, the row sums stay undropped -- and the row log-sum-exp is stored.
+struct SlateTrainArgs {
+  float* lse;                       // [B][H][L]
+  unsigned drop_seed, drop_thresh;  // element ((b*H + h)*L + q)*L + k, as in slate_attn_bwd.hip
+  float drop_scale;
+};
+template <int HD, bool TRAIN>
 __global__ __launch_bounds__(256) void slate_flash_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                           const float* __restrict__ v, float* __restrict__ out, int ldq,
                                                           int ldk, int ldv, int ldo, long long q_bs, long long k_bs,
-                                                          long long v_bs, long long o_bs, int L, float scale) {
+                                                          long long v_bs, long long o_bs, int L, float scale, SlateTrainArgs ta) {
   constexpr int P = HD + 4;                 // f32 row pitch of the tiles ((HD+4)/4 odd for HD = 16, 32, 48, 64)
   constexpr int CB = (HD + 31) / 32;        // 32-channel blocks of the output
   extern __shared__ __attribute__((aligned(16))) float fsm[];
@@ -238,6 +245,16 @@ __global__ __launch_bounds__(256) void slate_flash_kernel(const float* __restric
     sum += __shfl_xor(sum, 32, 64);
     l = l * corr + sum;
     m = mn;
+    if constexpr (TRAIN) {
+      if (ta.drop_thresh) {
+        const unsigned base = (unsigned)((((long long)b * gridDim.y + h) * L + min(qcol, L - 1)) * L);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          sacc[r] = (sf_mix32((base + (unsigned)key) ^ ta.drop_seed) >> 8) >= ta.drop_thresh ? sacc[r] * ta.drop_scale : 0.f;
+        }
+      }
+    }
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
 #pragma unroll
@@ -259,6 +276,9 @@ __global__ __launch_bounds__(256) void slate_flash_kernel(const float* __restric
     const float mg = fmaxf(m, m_o);
     const float fw = (m == -INFINITY) ? 0.f : expf(m - mg), fo = (m_o == -INFINITY) ? 0.f : expf(m_o - mg);
     const float fsc = fw / (l * fw + l_o * fo);
+    if constexpr (TRAIN) {
+      if (kh == 0 && lane < 32 && qcol < L) ta.lse[((long long)b * gridDim.y + h) * L + qcol] = mg + logf(l * fw + l_o * fo);
+    }
     float* od = OT + (wave * 32 + (lane & 31)) * PV + 4 * (lane >> 5);
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
@@ -488,13 +508,13 @@ int sf_slate_attention_strided_f32(const float* q, const float* k, const float* 
                              (size_t)4 * 32 * (CB_ * 32 + 4)) * sizeof(float);                                               \
     static bool attr_ = false;                                                                                               \
     if (!attr_) {                                                                                                            \
-      hipError_t e_ = hipFuncSetAttribute((const void*)slate_flash_kernel<HD_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+      hipError_t e_ = hipFuncSetAttribute((const void*)slate_flash_kernel<HD_, false>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                           (int)lds_);                                                                        \
       if (e_ != hipSuccess) return sf_set_err((int)e_, hipGetErrorString(e_), __FILE__, __LINE__);                           \
       attr_ = true;                                                                                                          \
     }                                                                                                                        \
-    hipLaunchKernelGGL(slate_flash_kernel<HD_>, dim3((Lq + 63) / 64, num_heads, B), dim3(256), lds_, st, q, k, v, out, ldq,   \
-                       ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, Lq, scale);                                                    \
+    hipLaunchKernelGGL((slate_flash_kernel<HD_, false>), dim3((Lq + 63) / 64, num_heads, B), dim3(256), lds_, st, q, k, v, out, ldq,   \
+                       ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, Lq, scale, SlateTrainArgs{nullptr, 0u, 0u, 1.f});                   \
     SF_CHECK_LAUNCH();                                                                                                       \
     return 0;                                                                                                                \
   }
@@ -533,6 +553,41 @@ int sf_slate_attention_strided_f32(const float* q, const float* k, const float* 
   return sf_set_err(-1, "invalid argument: sf_slate_attention_f32 head_dim must be 16, 32, 48 or 64", __FILE__, __LINE__);
 }
 
+}  // extern "C"
+
+// causal self-attention training forward on the flash kernel; returns 1 when it does not apply (caller uses the generic kernel)
+int sf_slate_flash_train_ex(const float* q, const float* k, const float* v, float* out, float* lse, int ldq, int ldk, int ldv, int ldo,
+                            long long q_bs, long long k_bs, long long v_bs, long long o_bs, int B, int L, int num_heads, int head_dim,
+                            unsigned drop_seed, unsigned drop_thresh, float drop_scale, hipStream_t st) {
+  if (L < 128 || !(head_dim == 16 || head_dim == 32 || head_dim == 48 || head_dim == 64)) return 1;
+  const float scale = 1.0f / sqrtf((float)head_dim);
+  const SlateTrainArgs ta{lse, drop_seed, drop_thresh, drop_scale};
+#define SLATE_FLASH_T(HD_)                                                                                                     \
+  if (head_dim == HD_) {                                                                                                       \
+    constexpr int CB_ = (HD_ + 31) / 32;                                                                                       \
+    constexpr size_t lds_ = ((size_t)2 * 64 * (HD_ + 4) + (size_t)64 * (CB_ * 32 + 4) + 2 * 4 * 32 +                            \
+                             (size_t)4 * 32 * (CB_ * 32 + 4)) * sizeof(float);                                                 \
+    static bool attr_ = false;                                                                                                 \
+    if (!attr_) {                                                                                                              \
+      hipError_t e_ = hipFuncSetAttribute((const void*)slate_flash_kernel<HD_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)lds_);                                                                          \
+      if (e_ != hipSuccess) return sf_set_err((int)e_, hipGetErrorString(e_), __FILE__, __LINE__);                             \
+      attr_ = true;                                                                                                            \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((slate_flash_kernel<HD_, true>), dim3((L + 63) / 64, num_heads, B), dim3(256), lds_, st, q, k, v, out, ldq, \
+                       ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, L, scale, ta);                                                   \
+    SF_CHECK_LAUNCH();                                                                                                         \
+    return 0;                                                                                                                  \
+  }
+  SLATE_FLASH_T(16)
+  SLATE_FLASH_T(32)
+  SLATE_FLASH_T(48)
+  SLATE_FLASH_T(64)
+#undef SLATE_FLASH_T
+  return 1;
+}
+
+extern "C" {
 // contiguous batches: q [B*Lq, ldq], k [B*Lk, ldk], v [B*Lk, ldv], out [B*Lq, ldo]
 int sf_slate_attention_f32(const float* q, const float* k, const float* v, float* out, int ldq, int ldk, int ldv, int ldo,
                            int B, int Lq, int Lk, int num_heads, int head_dim, int causal, void* stream) {
