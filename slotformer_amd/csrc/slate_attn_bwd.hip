@@ -47,6 +47,33 @@ __device__ __forceinline__ f32x16 sab_mm32(FA a, FB b, int K, int lane) {
   }
   return acc;
 }
+// both operands k-contiguous in LDS (rows 16-byte aligned): A[i][k] at arow + i * pa, B[j][k] at brow + j * pb -- two ds_read_b128
+// per operand per k16 step instead of eight scalar reads
+template <bool BF3>
+__device__ __forceinline__ f32x16 sab_mm32_kk(const float* A, int pa, const float* Bm, int pb, int K, int lane) {
+  if constexpr (!BF3) {
+    return sab_mm32<false>([&](int i, int k) { return A[i * pa + k]; }, [&](int k, int j) { return Bm[j * pb + k]; }, K, lane);
+  } else {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float* ar = A + (lane & 31) * pa + 8 * (lane >> 5);
+    const float* br = Bm + (lane & 31) * pb + 8 * (lane >> 5);
+    for (int k = 0; k < K; k += 16) {
+      const f32x4 a0 = *(const f32x4*)(ar + k), a1 = *(const f32x4*)(ar + k + 4);
+      const f32x4 b0 = *(const f32x4*)(br + k), b1 = *(const f32x4*)(br + k + 4);
+      const f32x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const f32x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      const bf16x8 ah = __builtin_convertvector(av, bf16x8), bh = __builtin_convertvector(bv, bf16x8);
+      const bf16x8 al = __builtin_convertvector(av - __builtin_convertvector(ah, f32x8), bf16x8);
+      const bf16x8 bl = __builtin_convertvector(bv - __builtin_convertvector(bh, f32x8), bf16x8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    }
+    return acc;
+  }
+}
 #define SAB_ROW(r, lane) (((r) & 3) + 8 * ((r) >> 2) + 4 * ((lane) >> 5))
 
 struct SabArgs {
@@ -69,25 +96,52 @@ __device__ __forceinline__ float sab_drop(const SabArgs& p, int b, int h, int q,
 // rows [r0, r0 + 64) of a [L, ld] matrix (head slice at +hoff) -> zero-padded LDS tile [64][P]
 template <int HDP>
 __device__ __forceinline__ void sab_load(const float* base, int ld, int r0, int L, int hd, float mul, float* dst) {
-  constexpr int P = HDP + 1;
+  constexpr int P = HDP + 4;
   for (int i = threadIdx.x; i < 64 * HDP; i += 256) {
     const int r = i / HDP, c = i - r * HDP;
     dst[r * P + c] = (r0 + r < L && c < hd) ? base[(long long)(r0 + r) * ld + c] * mul : 0.f;
   }
 }
 
+// the same tile in two steps, so that the global loads of the NEXT tile fly while the current one is being used:
+// fetch -> registers (16-byte loads from clamped addresses, zeroed by a select), put -> LDS
+template <int HDP>
+struct SabTile {
+  f32x4 v[HDP / 16];
+};
+template <int HDP>
+__device__ __forceinline__ void sab_fetch(const float* base, int ld, int r0, int L, int hd, SabTile<HDP>& t) {
+  constexpr int C4 = HDP / 4;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int n = 0; n < HDP / 16; ++n) {
+    const int i = threadIdx.x + 256 * n, r = i / C4, c = (i - r * C4) * 4;
+    const f32x4 x = *(const f32x4*)(base + (long long)min(r0 + r, L - 1) * ld + min(c, hd - 4));
+    t.v[n] = (r0 + r < L && c < hd) ? x : z;
+  }
+}
+template <int HDP>
+__device__ __forceinline__ void sab_put(const SabTile<HDP>& t, float mul, float* dst) {
+  constexpr int C4 = HDP / 4, P = HDP + 4;
+#pragma unroll
+  for (int n = 0; n < HDP / 16; ++n) {
+    const int i = threadIdx.x + 256 * n, r = i / C4, c = (i - r * C4) * 4;
+    *(f32x4*)(dst + r * P + c) = t.v[n] * mul;
+  }
+}
+
 template <int HDP, bool BF3>
 __global__ __launch_bounds__(256) void slate_attn_stats_kernel(SabArgs p, int hd) {
-  constexpr int P = HDP + 1;
+  constexpr int P = HDP + 4;
   extern __shared__ float lds[];
   float* Qs = lds;
   float* Ks = Qs + 64 * P;
-  float* Ss = Ks + 64 * P;     // [64][65]
-  float* rm = Ss + 64 * 65;    // running max [64]
+  float* Ss = Ks + 64 * P;     // [64][68]
+  float* rm = Ss + 64 * 68;    // running max [64]
   float* rl = rm + 64;         // running sum [64]
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int q0 = qb * 64;
-  sab_load<HDP>(p.q + (long long)b * p.q_bs + h * hd, p.ldq, q0, p.Lq, hd, p.scale, Qs);
+  if (!p.have_lse) sab_load<HDP>(p.q + (long long)b * p.q_bs + h * hd, p.ldq, q0, p.Lq, hd, p.scale, Qs);
   if (tid < 64) {
     rm[tid] = -INFINITY;
     rl[tid] = 0.f;
@@ -99,16 +153,15 @@ __global__ __launch_bounds__(256) void slate_attn_stats_kernel(SabArgs p, int hd
     __syncthreads();
     {
       const int ti = (wave >> 1) * 32, tj = (wave & 1) * 32;
-      const f32x16 acc = sab_mm32<BF3>([&](int i, int kk) { return Qs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Ks[(tj + j) * P + kk]; },
-                                  HDP, lane);
+      const f32x16 acc = sab_mm32_kk<BF3>(Qs + ti * P, P, Ks + tj * P, P, HDP, lane);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Ss[(ti + SAB_ROW(r, lane)) * 65 + tj + (lane & 31)] = acc[r];
+      for (int r = 0; r < 16; ++r) Ss[(ti + SAB_ROW(r, lane)) * 68 + tj + (lane & 31)] = acc[r];
     }
     __syncthreads();
     for (int r = wave; r < 64; r += 4) {   // online max / sum of row r over this key block
       const int qi = q0 + r, kj = kb * 64 + lane;
       const bool ok = qi < p.Lq && kj < p.Lk && (!p.causal || kj <= qi);
-      const float s = ok ? Ss[r * 65 + lane] : -INFINITY;
+      const float s = ok ? Ss[r * 68 + lane] : -INFINITY;
       const float mx = sf_wave_max(s);
       const float mo = rm[r], mn = fmaxf(mo, mx);
       const float e = (ok && mn > -INFINITY) ? expf(s - mn) : 0.f;
@@ -141,15 +194,15 @@ __global__ __launch_bounds__(256) void slate_attn_stats_kernel(SabArgs p, int hd
 
 template <int HDP, bool BF3>
 __global__ __launch_bounds__(256) void slate_attn_bwd_kernel(SabArgs p, int hd) {
-  constexpr int P = HDP + 1, CT = HDP / 32;   // channel tiles
+  constexpr int P = HDP + 4, CT = HDP / 32;   // channel tiles
   extern __shared__ float lds[];
   float* Ks = lds;
   float* Vs = Ks + 64 * P;
   float* Qs = Vs + 64 * P;
   float* Gs = Qs + 64 * P;     // dO
   float* Ps = Gs + 64 * P;     // [64 queries][65]
-  float* Ds = Ps + 64 * 65;    // dS
-  float* ls = Ds + 64 * 65;    // lse [64], dsum [64]
+  float* Ds = Ps + 64 * 68;    // dS
+  float* ls = Ds + 64 * 68;    // lse [64], dsum [64]
   const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int k0 = kb * 64;
   sab_load<HDP>(p.k + (long long)b * p.k_bs + h * hd, p.ldk, k0, p.Lk, hd, 1.f, Ks);
@@ -161,24 +214,36 @@ __global__ __launch_bounds__(256) void slate_attn_bwd_kernel(SabArgs p, int hd) 
   const int at = wave;                           // accumulator tile of this wave (valid if at < 2 * CT)
   const int ati = (at / CT) * 32, atj = (at % CT) * 32;
   const int nqb = (p.Lq + 63) / 64;
-  for (int qb = p.causal ? kb : 0; qb < nqb; ++qb) {
+  const float* qbase = p.q + (long long)b * p.q_bs + h * hd;
+  const float* gbase = p.dout + (long long)b * p.o_bs + h * hd;
+  const int qb0 = p.causal ? kb : 0;
+  SabTile<HDP> tq, tg;
+  float pl = 0.f, pd = 0.f;   // lse / dsum of the prefetched block (threads < 64)
+  auto prefetch = [&](int qbn) {
+    sab_fetch<HDP>(qbase, p.ldq, qbn * 64, p.Lq, hd, tq);
+    sab_fetch<HDP>(gbase, p.ldo, qbn * 64, p.Lq, hd, tg);
+    if (tid < 64) {
+      const long long idx = ((long long)b * p.H + h) * p.Lq + min(qbn * 64 + tid, p.Lq - 1);
+      pl = p.lse[idx];
+      pd = p.dsum[idx];
+    }
+  };
+  if (qb0 < nqb) prefetch(qb0);
+  for (int qb = qb0; qb < nqb; ++qb) {
     const int q0 = qb * 64;
     __syncthreads();
-    sab_load<HDP>(p.q + (long long)b * p.q_bs + h * hd, p.ldq, q0, p.Lq, hd, p.scale, Qs);
-    sab_load<HDP>(p.dout + (long long)b * p.o_bs + h * hd, p.ldo, q0, p.Lq, hd, 1.f, Gs);
+    sab_put<HDP>(tq, p.scale, Qs);
+    sab_put<HDP>(tg, 1.f, Gs);
     if (tid < 64) {
-      const int qi = q0 + tid;
-      const long long idx = ((long long)b * p.H + h) * p.Lq + min(qi, p.Lq - 1);
-      ls[tid] = p.lse[idx];
-      ls[64 + tid] = p.dsum[idx];
+      ls[tid] = pl;
+      ls[64 + tid] = pd;
     }
     __syncthreads();
+    if (qb + 1 < nqb) prefetch(qb + 1);   // in flight during the five products below
     const int ti = (wave >> 1) * 32, tj = (wave & 1) * 32;
     // S tile and dP tile of this wave (queries ti.., keys tj..)
-    const f32x16 s = sab_mm32<BF3>([&](int i, int kk) { return Qs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Ks[(tj + j) * P + kk]; },
-                              HDP, lane);
-    const f32x16 dp = sab_mm32<BF3>([&](int i, int kk) { return Gs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Vs[(tj + j) * P + kk]; },
-                               HDP, lane);
+    const f32x16 s = sab_mm32_kk<BF3>(Qs + ti * P, P, Ks + tj * P, P, HDP, lane);
+    const f32x16 dp = sab_mm32_kk<BF3>(Gs + ti * P, P, Vs + tj * P, P, HDP, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qr = ti + SAB_ROW(r, lane), kc = tj + (lane & 31);
@@ -186,16 +251,16 @@ __global__ __launch_bounds__(256) void slate_attn_bwd_kernel(SabArgs p, int hd) 
       const bool ok = qi < p.Lq && kj < p.Lk && (!p.causal || kj <= qi);
       const float pv = ok ? expf(s[r] - ls[qr]) : 0.f;
       const float mk = ok ? sab_drop(p, b, h, qi, kj) : 0.f;   // dropout factor on this attention weight (1 when off)
-      Ps[qr * 65 + kc] = pv * mk;                               // what multiplied V in the forward pass
-      Ds[qr * 65 + kc] = pv * (dp[r] * mk - ls[64 + qr]);
+      Ps[qr * 68 + kc] = pv * mk;                               // what multiplied V in the forward pass
+      Ds[qr * 68 + kc] = pv * (dp[r] * mk - ls[64 + qr]);
     }
     __syncthreads();
     // dV_j += P^T dO_i ; dK_j += dS^T (Q_i * scale)   (contraction over the 64 queries)
     if (at < 2 * CT) {
       // tiles 0 .. 2*CT-1 cover [64 keys][HDP]; ati = key offset, atj = channel offset
-      const f32x16 a1 = sab_mm32<BF3>([&](int i, int kk) { return Ps[kk * 65 + ati + i]; }, [&](int kk, int j) { return Gs[kk * P + atj + j]; }, 64,
+      const f32x16 a1 = sab_mm32<BF3>([&](int i, int kk) { return Ps[kk * 68 + ati + i]; }, [&](int kk, int j) { return Gs[kk * P + atj + j]; }, 64,
                                  lane);
-      const f32x16 a2 = sab_mm32<BF3>([&](int i, int kk) { return Ds[kk * 65 + ati + i]; }, [&](int kk, int j) { return Qs[kk * P + atj + j]; }, 64,
+      const f32x16 a2 = sab_mm32<BF3>([&](int i, int kk) { return Ds[kk * 68 + ati + i]; }, [&](int kk, int j) { return Qs[kk * P + atj + j]; }, 64,
                                  lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -206,7 +271,7 @@ __global__ __launch_bounds__(256) void slate_attn_bwd_kernel(SabArgs p, int hd) 
     // dQ_i += scale * dS K_j  (tiles over [64 queries][HDP]; atomics: several key blocks add into the same rows)
     for (int t = wave; t < 2 * CT; t += 4) {
       const int qi0 = (t / CT) * 32, c0 = (t % CT) * 32;
-      const f32x16 a3 = sab_mm32<BF3>([&](int i, int kk) { return Ds[(qi0 + i) * 65 + kk]; }, [&](int kk, int j) { return Ks[kk * P + c0 + j]; }, 64,
+      const f32x16 a3 = sab_mm32<BF3>([&](int i, int kk) { return Ds[(qi0 + i) * 68 + kk]; }, [&](int kk, int j) { return Ks[kk * P + c0 + j]; }, 64,
                                  lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -232,13 +297,13 @@ __global__ __launch_bounds__(256) void slate_attn_bwd_kernel(SabArgs p, int hd) 
 // O accumulated as 32x32 tiles in registers and rescaled per row when the running max moves.
 template <int HDP, bool BF3>
 __global__ __launch_bounds__(256) void slate_attn_fwd_train_kernel(SabArgs p, float* __restrict__ out, int hd) {
-  constexpr int P = HDP + 1, CT = HDP / 32;
+  constexpr int P = HDP + 4, CT = HDP / 32;
   extern __shared__ float lds[];
   float* Qs = lds;
   float* Ks = Qs + 64 * P;
   float* Vs = Ks + 64 * P;
-  float* Ss = Vs + 64 * P;     // [64][65]
-  float* rm = Ss + 64 * 65;
+  float* Ss = Vs + 64 * P;     // [64][68]
+  float* rm = Ss + 64 * 68;
   float* rl = rm + 64;
   float* rs = rl + 64;         // per-row rescale of this step
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -260,21 +325,20 @@ __global__ __launch_bounds__(256) void slate_attn_fwd_train_kernel(SabArgs p, fl
     __syncthreads();
     {
       const int ti = (wave >> 1) * 32, tj = (wave & 1) * 32;
-      const f32x16 acc = sab_mm32<BF3>([&](int i, int kk) { return Qs[(ti + i) * P + kk]; }, [&](int kk, int j) { return Ks[(tj + j) * P + kk]; },
-                                  HDP, lane);
+      const f32x16 acc = sab_mm32_kk<BF3>(Qs + ti * P, P, Ks + tj * P, P, HDP, lane);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Ss[(ti + SAB_ROW(r, lane)) * 65 + tj + (lane & 31)] = acc[r];
+      for (int r = 0; r < 16; ++r) Ss[(ti + SAB_ROW(r, lane)) * 68 + tj + (lane & 31)] = acc[r];
     }
     __syncthreads();
     for (int r = wave; r < 64; r += 4) {
       const int qi = q0 + r, kj = kb * 64 + lane;
       const bool ok = qi < p.Lq && kj < p.Lk && (!p.causal || kj <= qi);
-      const float s = ok ? Ss[r * 65 + lane] : -INFINITY;
+      const float s = ok ? Ss[r * 68 + lane] : -INFINITY;
       const float mx = sf_wave_max(s);
       const float mo = rm[r], mn = fmaxf(mo, mx);
       const float e = (ok && mn > -INFINITY) ? expf(s - mn) : 0.f;
       const float sum = sf_wave_sum(e);
-      Ss[r * 65 + lane] = ok ? e * sab_drop(p, b, h, qi, kj) : 0.f;
+      Ss[r * 68 + lane] = ok ? e * sab_drop(p, b, h, qi, kj) : 0.f;
       if (lane == 0) {
         const float sc = (mo == -INFINITY) ? 0.f : expf(mo - mn);
         rl[r] = rl[r] * sc + sum;
@@ -284,7 +348,7 @@ __global__ __launch_bounds__(256) void slate_attn_fwd_train_kernel(SabArgs p, fl
     }
     __syncthreads();
     if (at < 2 * CT) {
-      const f32x16 a = sab_mm32<BF3>([&](int i, int kk) { return Ss[(ati + i) * 65 + kk]; }, [&](int kk, int j) { return Vs[kk * P + atj + j]; }, 64,
+      const f32x16 a = sab_mm32<BF3>([&](int i, int kk) { return Ss[(ati + i) * 68 + kk]; }, [&](int kk, int j) { return Vs[kk * P + atj + j]; }, 64,
                                 lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[r] = oacc[r] * rs[ati + SAB_ROW(r, lane)] + a[r];
@@ -329,7 +393,7 @@ int sf_slate_attention_train_fwd_f32(const float* q, const float* k, const float
     if (rc != 1) return rc;
   }
   const int hdp = head_dim <= 32 ? 32 : 64;
-  const size_t lds = ((size_t)3 * 64 * (hdp + 1) + 64 * 65 + 192) * sizeof(float);
+  const size_t lds = ((size_t)3 * 64 * (hdp + 4) + 64 * 68 + 192) * sizeof(float);
   const dim3 g((Lq + 63) / 64, num_heads, B);
   const bool bf3 = sf_get_precision() >= 1;
   if (hdp == 32) {
@@ -367,7 +431,8 @@ int sf_slate_attention_train_bwd_f32(const float* q, const float* k, const float
   SF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p in [0, 1)");
   SF_REQUIRE(q && k && v && out && d_out && dq && dk && dv && ws, "null pointer");
   SF_REQUIRE(B > 0 && Lq > 0 && Lk > 0 && num_heads > 0, "bad sizes");
-  SF_REQUIRE(head_dim >= 2 && head_dim <= 64 && head_dim % 2 == 0, "head_dim must be even and <= 64");
+  SF_REQUIRE(head_dim >= 4 && head_dim <= 64 && head_dim % 4 == 0, "head_dim must be a multiple of 4, at most 64");
+  SF_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0, "rows must be 16-byte aligned");
   SF_REQUIRE(!causal || Lq == Lk, "causal attention needs Lq == Lk");
   SF_REQUIRE(ws_bytes >= sf_slate_attention_bwd_workspace_bytes(B, Lq, num_heads), "workspace too small");
   SF_REQUIRE(q_bs >= (long long)(Lq - 1) * ldq + num_heads * head_dim, "dq is cleared over whole batches: q_bs too small");
@@ -389,8 +454,8 @@ int sf_slate_attention_train_bwd_f32(const float* q, const float* k, const float
     if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
   }
   const int hdp = head_dim <= 32 ? 32 : 64;
-  const size_t lds1 = ((size_t)2 * 64 * (hdp + 1) + 64 * 65 + 128) * sizeof(float);
-  const size_t lds2 = ((size_t)4 * 64 * (hdp + 1) + 2 * 64 * 65 + 128) * sizeof(float);
+  const size_t lds1 = ((size_t)2 * 64 * (hdp + 4) + 64 * 68 + 128) * sizeof(float);
+  const size_t lds2 = ((size_t)4 * 64 * (hdp + 4) + 2 * 64 * 68 + 128) * sizeof(float);
   const dim3 g1((Lq + 63) / 64, num_heads, B), g2((Lk + 63) / 64, num_heads, B);
 #define SAB_GO(HDP, BF)                                                                                                          \
   {                                                                                                                              \
