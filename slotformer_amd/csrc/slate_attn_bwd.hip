@@ -447,11 +447,17 @@ int sf_slate_attention_train_bwd_f32(const float* q, const float* k, const float
   a.drop_seed = sab_site_seed(seed); a.drop_thresh = (uint32_t)((double)dropout_p * 16777216.0); a.drop_scale = 1.f / (1.f - dropout_p);
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
   a.Lq = Lq; a.Lk = Lk; a.H = num_heads; a.causal = causal; a.scale = 1.f / sqrtf((float)head_dim);
-  // clear the head columns of dq (row by row: dq may be a column slice of a wider packed tensor)
-  for (int b = 0; b < B; ++b) {
-    hipError_t e = hipMemset2DAsync(dq + (long long)b * q_bs, (size_t)ldq * sizeof(float), 0, (size_t)num_heads * head_dim * sizeof(float),
-                                    (size_t)Lq, st);
+  // clear the head columns of dq: one memset when dq is a dense [B, Lq, H*hd] tensor, else row by row per sequence (dq may be a
+  // column slice of a wider packed tensor)
+  if (ldq == num_heads * head_dim && q_bs == (long long)Lq * ldq) {
+    hipError_t e = hipMemsetAsync(dq, 0, (size_t)B * Lq * ldq * sizeof(float), st);
     if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+  } else {
+    for (int b = 0; b < B; ++b) {
+      hipError_t e = hipMemset2DAsync(dq + (long long)b * q_bs, (size_t)ldq * sizeof(float), 0, (size_t)num_heads * head_dim * sizeof(float),
+                                      (size_t)Lq, st);
+      if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    }
   }
   const int hdp = head_dim <= 32 ? 32 : 64;
   const size_t lds1 = ((size_t)2 * 64 * (hdp + 4) + 64 * 68 + 128) * sizeof(float);
