@@ -83,7 +83,8 @@ class STEVESlotFormer(SlotFormer):
         if 'token_id' in data_dict:
             ids = data_dict['token_id']
         else:
-            ids = self.dvae.tokenize(data_dict['img'][:, self.history_len:], one_hot=False).flatten(2, 3)
+            with torch.no_grad():   # frozen tokenizer: the ids are targets, not part of the graph
+                ids = self.dvae.tokenize(data_dict['img'][:, self.history_len:], one_hot=False).flatten(2, 3)
         ids = ids.flatten(0, 1).long().contiguous()                                   # [B*T, h*w]
         logits = self.decoder(pred.flatten(0, 1), ids[:, :-1].contiguous())
         out['pred_token_id'] = logits[:, -(self.h * self.w):]
@@ -95,8 +96,13 @@ class STEVESlotFormer(SlotFormer):
         the reference's name 'img_recon_loss')."""
         terms = {'slot_recon_loss': ((out_dict['pred_slots'] - out_dict['gt_slots'])**2).mean()}
         if self.use_img_recon_loss:
-            terms['img_recon_loss'] = ops.cross_entropy(out_dict['pred_token_id'].flatten(0, 1).contiguous(),
-                                                        out_dict['target_token_id'].flatten(0, 1).contiguous())
+            logits = out_dict['pred_token_id'].flatten(0, 1).contiguous()
+            target = out_dict['target_token_id'].flatten(0, 1).contiguous()
+            if logits.requires_grad:   # training (row N1): the frozen decoder passes the gradient on to the predicted slots
+                from ... import train
+                terms['img_recon_loss'] = train.token_cross_entropy(logits, target)
+            else:
+                terms['img_recon_loss'] = ops.cross_entropy(logits, target)
         return terms
 
     def train(self, mode=True):

@@ -646,3 +646,44 @@ def test_steve_training_with_all_dropouts(dev):
         opt.step()
         hist.append(float(loss.detach()))
     assert all(np.isfinite(hist)) and hist[-1] < hist[0], hist
+
+
+def test_steve_slotformer_training_vs_oracle(dev, tmp_path):
+    """STEVESlotFormer's training objective (steve_slotformer.py:111-161): slot MSE of the rollout plus the token
+    cross-entropy of the FROZEN STEVE decoder on the frozen dVAE's tokens of the target frames -- the decoder only passes the
+    gradient on to the predicted slots.  Loss terms and rollouter gradients against autograd of the oracle."""
+    from slotformer_amd.base_slots import build_model as bb
+    from slotformer_amd.video_prediction import build_model as bv
+    g = gu.load_golden('steve_slotformer')
+    steve = bb(gu.ParamsView(gu.steve_tokens_cfg()))
+    path = str(tmp_path / 'steve.pth')
+    torch.save({'state_dict': steve.state_dict()}, path)
+    cfg = gu.steve_slotformer_cfg()
+    cfg['dec_dict']['dec_ckp_path'] = path
+    m = bv(gu.ParamsView(cfg))
+    shapes = gu.shapes_from_golden(g)
+    own = dict(m.state_dict())
+    sd = gu.seeded_state_dict(shapes, 701, keep=own)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).train()
+    _no_dropout(m)
+    rd = cfg['rollout_dict']
+    hist, S = rd['history_len'], cfg['loss_dict']['rollout_len']
+    slots = gu.seeded_normal((1, hist + S, rd['num_slots'], rd['slot_size']), 702)
+    tok = torch.from_numpy(g['target_token_id']).to(torch.int64)                  # [S, h*w], the reference's targets
+    data = {'slots': slots.to(dev), 'token_id': tok.to(dev).unflatten(0, (1, S))}
+    out = m(data)
+    terms = m.calc_train_loss(data, out)
+    assert abs(float(terms['img_recon_loss'].detach()) - float(g['img_recon_loss'])) < 1e-3 * float(g['img_recon_loss'])
+    (terms['slot_recon_loss'] + terms['img_recon_loss']).backward()
+    names = [n for n, p_ in m.named_parameters() if p_.requires_grad]
+    assert names and all(n.startswith('rollouter.') for n in names)
+    osd = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    pred = oracle.rollouter_forward(slots[:, :hist], S, osd, rd)
+    dd = cfg['dec_dict']
+    logits = oracle.steve_decoder_forward(pred.flatten(0, 1), tok[:, :-1], osd, dd['dec_num_heads'], dd['dec_num_layers'], p='decoder.')
+    (((pred - slots[:, hist:])**2).mean() + torch.nn.functional.cross_entropy(logits.flatten(0, 1), tok.flatten(0, 1))).backward()
+    got = dict(m.named_parameters())
+    for n in names:
+        assert l2_err(got[n].grad, osd[n].grad) < L2TOL['bf16x3'], n
+    assert all(p_.grad is None for n, p_ in m.named_parameters() if not n.startswith('rollouter.'))
