@@ -574,10 +574,10 @@ def slate_decoder_forward(dec, slots, idx):
         y = layer_norm(x, blk.self_attn_layer_norm)
         if blk.is_first:   # the first block normalises its input in place (steve_transformer.py:186-190)
             x = y
-        att = attend(linear(y, sa.proj_q), linear(y, sa.proj_k), linear(y, sa.proj_v), sa, True)
+        att = attend(*linear_cat(y, sa.proj_q, sa.proj_k, sa.proj_v), sa, True)
         x = x + dropout(linear(att, sa.proj_o), sa.output_dropout.p, tr)
         y = layer_norm(x, blk.encoder_decoder_attn_layer_norm)
-        att = attend(linear(y, ca.proj_q), linear(mem, ca.proj_k), linear(mem, ca.proj_v), ca, False)
+        att = attend(linear(y, ca.proj_q), *linear_cat(mem, ca.proj_k, ca.proj_v), ca, False)
         x = x + dropout(linear(att, ca.proj_o), ca.output_dropout.p, tr)
         y = layer_norm(x, blk.ffn_layer_norm)
         x = x + dropout(linear(linear(y, blk.ffn[0], relu=True), blk.ffn[2]), blk.ffn[3].p, tr)
@@ -586,6 +586,41 @@ def slate_decoder_forward(dec, slots, idx):
 
 def token_cross_entropy(logits, target):
     return _TokenCrossEntropy.apply(logits, target.to(torch.int64).contiguous())
+
+
+class _LinearCat(torch.autograd.Function):
+    """[x W1^T | x W2^T | ...] for bias-free projections that share their input (q|k|v of the STEVE decoder's attention,
+    steve_transformer.py:30-40): ONE GEMM on the concatenated weight, one weight-gradient contraction, one data-gradient GEMM,
+    instead of one of each per projection."""
+
+    @staticmethod
+    def forward(ctx, x, *weights):
+        from . import ops
+        xd = x.detach().float().contiguous()
+        wcat = torch.cat([w.detach().float() for w in weights], 0).contiguous()
+        ctx.save_for_backward(xd, wcat)
+        ctx.sizes = [w.shape[0] for w in weights]
+        return ops.linear(xd, wcat)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        N, K = w.shape
+        M = x.numel() // K
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        nb = lib().sf_linear_bwd_workspace_bytes(M, N, K)
+        ws = torch.empty(nb, dtype=torch.uint8, device=w.device)
+        check(lib().sf_linear_bwd_f32(x.data_ptr(), w.data_ptr(), None, dy.data_ptr(), dx.data_ptr() if dx is not None else None,
+                                      dw.data_ptr(), None, M, N, K, 0, ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream))
+        return (dx, ) + tuple(dw.split(ctx.sizes, 0))
+
+
+def linear_cat(x, *layers):
+    """x projected by several bias-free nn.Linear layers at once; returns the tuple of outputs (column slices)."""
+    out = _LinearCat.apply(x, *[l_.weight for l_ in layers])
+    return out.split([l_.weight.shape[0] for l_ in layers], -1)
 
 
 def linear(x, layer, relu=False):
