@@ -452,6 +452,9 @@ int sf_slate_attention_train_bwd_f32(const float* q, const float* k, const float
   if (ldq == num_heads * head_dim && q_bs == (long long)Lq * ldq) {
     hipError_t e = hipMemsetAsync(dq, 0, (size_t)B * Lq * ldq * sizeof(float), st);
     if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+  } else if (q_bs == (long long)Lq * ldq) {   // column slice of a packed [B, Lq, ldq] tensor: all B*Lq rows in one call
+    hipError_t e = hipMemset2DAsync(dq, (size_t)ldq * sizeof(float), 0, (size_t)num_heads * head_dim * sizeof(float), (size_t)B * Lq, st);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
   } else {
     for (int b = 0; b < B; ++b) {
       hipError_t e = hipMemset2DAsync(dq + (long long)b * q_bs, (size_t)ldq * sizeof(float), 0, (size_t)num_heads * head_dim * sizeof(float),

@@ -512,6 +512,57 @@ class _SlateAttention(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None
 
 
+class _SelfAttention(torch.autograd.Function):
+    """Self-attention of a STEVE decoder block from its input: q|k|v = x [Wq;Wk;Wv]^T in ONE GEMM into a packed [B,L,3d]
+    buffer that the attention kernels read in place (column offsets 0, d, 2d), and whose gradient the attention backward
+    writes in place -- no per-projection GEMMs, no copies of q, k, v or of their gradients."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, heads, causal, p, seed):
+        from . import ops
+        x = x.detach().float().contiguous()
+        B, L, d = x.shape
+        wcat = torch.cat([w.detach().float() for w in (wq, wk, wv)], 0).contiguous()
+        qkv = ops.linear(x, wcat)                                   # [B, L, 3d]
+        lse = None
+        if p > 0:
+            out = torch.empty(B, L, d, dtype=torch.float32, device=x.device)
+            lse = torch.empty(B, heads, L, dtype=torch.float32, device=x.device)
+            base = qkv.data_ptr()
+            check(lib().sf_slate_attention_train_fwd_f32(base, base + 4 * d, base + 8 * d, out.data_ptr(), lse.data_ptr(), 3 * d, 3 * d,
+                                                         3 * d, d, L * 3 * d, L * 3 * d, L * 3 * d, L * d, B, L, L, heads, d // heads,
+                                                         int(causal), float(p), int(seed), torch.cuda.current_stream().cuda_stream))
+        else:
+            out = ops.slate_attention(qkv, qkv, qkv, heads, causal, 0, d, 2 * d, d_model=d)
+        ctx.save_for_backward(x, wcat, qkv, out, lse)
+        ctx.args = (heads, bool(causal), float(p), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, wcat, qkv, out, lse = ctx.saved_tensors
+        heads, causal, p, seed = ctx.args
+        B, L, d = x.shape
+        d_out = d_out.float().contiguous()
+        dqkv = torch.empty_like(qkv)
+        st = torch.cuda.current_stream().cuda_stream
+        nb = lib().sf_slate_attention_bwd_workspace_bytes(B, L, heads)
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        b0, g0 = qkv.data_ptr(), dqkv.data_ptr()
+        check(lib().sf_slate_attention_train_bwd_f32(b0, b0 + 4 * d, b0 + 8 * d, out.data_ptr(), d_out.data_ptr(),
+                                                     lse.data_ptr() if lse is not None else None, g0, g0 + 4 * d, g0 + 8 * d, 3 * d, 3 * d,
+                                                     3 * d, d, L * 3 * d, L * 3 * d, L * 3 * d, L * d, B, L, L, heads, d // heads,
+                                                     int(causal), p, seed, ws.data_ptr(), nb, st))
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(wcat)
+        M = B * L
+        nb = lib().sf_linear_bwd_workspace_bytes(M, 3 * d, d)
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        check(lib().sf_linear_bwd_f32(x.data_ptr(), wcat.data_ptr(), None, dqkv.data_ptr(), dx.data_ptr(), dw.data_ptr(), None, M, 3 * d, d,
+                                      0, ws.data_ptr(), nb, st))
+        return (dx, ) + tuple(dw.split(d, 0)) + (None, None, None, None)
+
+
 class _Embed(torch.autograd.Function):
     """tok_emb[idx] + pos[:L] (steve_transformer.py:58-74,286-289): HIP gather forward; the backward scatters the row
     gradients back (index_add on the [V+1, d] table, batch sum for the position table)."""
@@ -574,7 +625,8 @@ def slate_decoder_forward(dec, slots, idx):
         y = layer_norm(x, blk.self_attn_layer_norm)
         if blk.is_first:   # the first block normalises its input in place (steve_transformer.py:186-190)
             x = y
-        att = attend(*linear_cat(y, sa.proj_q, sa.proj_k, sa.proj_v), sa, True)
+        p_sa = float(sa.attn_dropout.p) if tr else 0.0
+        att = _SelfAttention.apply(y, sa.proj_q.weight, sa.proj_k.weight, sa.proj_v.weight, H, True, p_sa, _new_seed() if p_sa > 0 else 0)
         x = x + dropout(linear(att, sa.proj_o), sa.output_dropout.p, tr)
         y = layer_norm(x, blk.encoder_decoder_attn_layer_norm)
         att = attend(linear(y, ca.proj_q), *linear_cat(mem, ca.proj_k, ca.proj_v), ca, False)
