@@ -141,6 +141,13 @@ int sf_bilinear_resize_f32(const float* in, float* out, long long R, int Hi, int
 size_t sf_groupnorm1_workspace_bytes(int F);
 int sf_groupnorm1_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y, int F, int H, int W, int C,
                            float eps, int relu, int pixel_shuffle, void* ws, size_t ws_bytes, void* stream);
+/* Adjoint of the call above (row N1: the dVAE under autograd, dVAE.py:113-139).  x is the INPUT of the forward call (the
+ * statistics and the ReLU gate are recomputed from it), dy the gradient of its output ([F,H,W,C], or [F,2H,2W,C/4] with
+ * pixel_shuffle 2); writes dx [F,H,W,C], dgamma [C], dbeta [C]. */
+size_t sf_groupnorm1_bwd_workspace_bytes(int F, int H, int W, int C);
+int sf_groupnorm1_nhwc_bwd_f32(const float* x, const float* gamma, const float* beta, const float* dy, float* dx, float* dgamma,
+                               float* dbeta, int F, int H, int W, int C, float eps, int relu, int pixel_shuffle, void* ws,
+                               size_t ws_bytes, void* stream);
 
 /* STEVE's slot-conditioned Transformer decoder (steve_transformer.py): attention core (bias-free projections are
  * plain sf_linear_f32 calls), token + position embedding, greedy token pick, token cross-entropy. */
@@ -179,6 +186,9 @@ int sf_cross_entropy_f32(const float* x, const long long* target, float* loss_ro
 /* y = softmax((x + add) * scale) per row (add may be NULL): the Gumbel-softmax relaxation of steve_utils.py:26-41 with
  * add = Gumbel noise, scale = 1/tau (steve_slotformer.py:97-98). */
 int sf_softmax_rows_f32(const float* x, const float* add, float scale, float* y, long long R, int V, void* stream);
+/* Adjoint of sf_softmax_rows_f32 w.r.t. x (and add) given its output y: dx = scale * y * (dy - sum(y * dy)) per row -- the
+ * Gumbel-softmax relaxation of steve_utils.py:26-41 under autograd. */
+int sf_softmax_rows_bwd_f32(const float* y, const float* dy, float scale, float* dx, long long R, int V, void* stream);
 
 /* K/V-cached greedy generation of the dVAE token grid (STEVETransformerDecoder.generate, sample=False,
  * steve_transformer.py:305-333; used by STEVESlotFormer.decode, steve_slotformer.py:92-93).  One token per step; the

@@ -19,7 +19,7 @@ __all__ = [
     'sample_dist', 'kernel_kld', 'savi_encode', 'steve_encode', 'savi_forward_chunked',
     'rollouter_forward', 'rollouter_forward_train', 'single_step_rollouter_forward', 'slotformer_forward',
     'savi_decode', 'postproc_mask', 'rollout_video_slots', 'phyre_encode_rollout',
-    'slot_mse_losses', 'dvae_logits', 'dvae_tokenize', 'dvae_detokenize', 'steve_decoder_forward',
+    'slot_mse_losses', 'dvae_logits', 'dvae_tokenize', 'dvae_detokenize', 'dvae_forward_train', 'steve_decoder_forward',
     'steve_decoder_generate', 'steve_forward_tokens', 'steve_slotformer_decode',
 ]
 
@@ -548,6 +548,21 @@ def dvae_detokenize(z, sd, p=''):
     return F.conv2d(x, sd[p + 'decoder.11.weight'], sd[p + 'decoder.11.bias'])
 
 
+def dvae_forward_train(img, gumbel, sd, tau=1., hard=False, p=''):
+    """dVAE.forward outside testing (dVAE.py:113-139) with the Gumbel noise of steve_utils.py:26-41 given: logits ->
+    log_softmax -> softmax((z_logits + gumbel) / tau) (straight-through one-hot when `hard`) -> decoder; the loss is
+    F.mse_loss(recon, img) (dVAE.py:141-146).  img [F,3,H,W], gumbel [F,V,h,w]."""
+    z_logits = F.log_softmax(dvae_logits(img, sd, p), dim=1)
+    y_soft = F.softmax((z_logits + gumbel) / tau, 1)
+    if hard:
+        y_hard = torch.zeros_like(y_soft).scatter_(1, y_soft.argmax(1, keepdim=True), 1.)
+        z = y_hard - y_soft.detach() + y_soft
+    else:
+        z = y_soft
+    recon = dvae_detokenize(z, sd, p)
+    return {'recon': recon, 'z_logits': z_logits, 'recon_loss': F.mse_loss(recon, img)}
+
+
 def _slate_mha(q, k, v, sd, p, nheads, mask=None):
     """MultiHeadAttention of steve_transformer.py:12-55: bias-free projections, q scaled by hd^-0.5, optional
     boolean mask (True = blocked)."""
@@ -606,14 +621,23 @@ def steve_decoder_generate(slots, steps, sd, nheads, num_layers, p='trans_decode
     return idx, torch.stack(logits_all, 1)
 
 
-def steve_forward_tokens(img, slots, sd, cfg):
+def steve_forward_tokens(img, slots, sd, cfg, gumbel=None):
     """The token-prediction half of STEVE._forward (steve.py:306-322): dVAE ids of the frames as targets, teacher-forced
-    decoder logits, and the cross-entropy of steve.py:341-344.  img [B,T,3,H,W], slots [B,T,N,D]."""
+    decoder logits, and the cross-entropy of steve.py:341-344.  img [B,T,3,H,W], slots [B,T,N,D].  With `gumbel`
+    [B*T,V,h,w] also the optional image term (use_img_recon_loss, steve.py:327-335, 345-349): relaxed sample of the predicted
+    token map at tau 0.1, decoded by the frozen dVAE, MSE against the frames."""
     tgt = dvae_tokenize(img.flatten(0, 1), sd, 'dvae.', one_hot=False).flatten(1, 2)
     dd = cfg['dec_dict']
     logits = steve_decoder_forward(slots.flatten(0, 1), tgt[:, :-1], sd, dd['dec_num_heads'], dd['dec_num_layers'])
     loss = F.cross_entropy(logits.flatten(0, 1), tgt.flatten(0, 1))
-    return {'pred_token_id': logits, 'target_token_id': tgt, 'token_recon_loss': loss}
+    out = {'pred_token_id': logits, 'target_token_id': tgt, 'token_recon_loss': loss}
+    if gumbel is not None:
+        h, w = gumbel.shape[-2:]
+        z_logits = F.log_softmax(logits.transpose(2, 1).unflatten(-1, (h, w)), dim=1)
+        z = F.softmax((z_logits + gumbel) / 0.1, 1)
+        out['recon_img'] = dvae_detokenize(z, sd, 'dvae.')
+        out['img_recon_loss'] = F.mse_loss(out['recon_img'], img.flatten(0, 1))
+    return out
 
 
 def steve_slotformer_decode(slots, sd, cfg, gumbel):

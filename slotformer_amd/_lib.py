@@ -167,6 +167,8 @@ SIGNATURES = {
                                VP]),
     'sf_groupnorm1_workspace_bytes': (SZ, [I]),
     'sf_groupnorm1_nhwc_f32': (I, [FP, FP, FP, FP, I, I, I, I, F32, I, I, VP, SZ, VP]),
+    'sf_groupnorm1_bwd_workspace_bytes': (SZ, [I, I, I, I]),
+    'sf_groupnorm1_nhwc_bwd_f32': (I, [FP, FP, FP, FP, FP, FP, FP, I, I, I, I, F32, I, I, VP, SZ, VP]),
     'sf_slate_attention_f32': (I, [FP, FP, FP, FP, I, I, I, I, I, I, I, I, I, I, VP]),
     'sf_slate_attention_strided_f32': (I, [FP, FP, FP, FP, I, I, I, I, LL, LL, LL, LL, I, I, I, I, I, I, VP]),
     'sf_slate_attention_bwd_workspace_bytes': (SZ, [I, I, I]),
@@ -178,6 +180,7 @@ SIGNATURES = {
     'sf_argmax_rows_f32': (I, [FP, LL, VP, LL, I, VP]),
     'sf_cross_entropy_f32': (I, [FP, VP, FP, FP, LL, I, VP]),
     'sf_softmax_rows_f32': (I, [FP, FP, F32, FP, LL, I, VP]),
+    'sf_softmax_rows_bwd_f32': (I, [FP, FP, F32, FP, LL, I, VP]),
     'sf_slate_generate_workspace_bytes': (SZ, [C.POINTER(sf_slate_decoder), I, I]),
     'sf_slate_generate_f32': (I, [C.POINTER(sf_slate_decoder), FP, I, I, VP, FP, VP, SZ, VP]),
     'sf_packed_linear_bytes': (SZ, [I, I]),

@@ -4,7 +4,8 @@ The modules below only hold parameters under the reference's state-dict names (`
 `encoder.{i}.weight/bias`, `decoder.…`); `tokenize` / `detokenize` run on the HIP library: 1x1 convolutions and the
 4x4/stride-4 patch embedding as GEMMs over channels-last pixels (`sf_linear_f32`), the 3x3 convolutions on the
 implicit-GEMM conv (`sf_conv2d_nhwc_f32`), GroupNorm(1)+ReLU(+PixelShuffle) in `sf_groupnorm1_nhwc_f32`, the token
-pick in `sf_argmax_rows_f32`.  Inference only (training the dVAE belongs to row N1)."""
+pick in `sf_argmax_rows_f32`.  In training (`forward` outside `testing`, row N1) the same kernels run as autograd nodes of
+`slotformer_amd.train` (`sf_linear_bwd_f32`, `sf_groupnorm1_nhwc_bwd_f32`, `sf_softmax_rows_bwd_f32`)."""
 import torch
 from torch import nn
 
@@ -72,8 +73,8 @@ class dVAE(BaseModel):
 
     def _logits_nhwc(self, imgs):
         """imgs [F,3,H,W] -> logits [F,h,w,V] (channels-last)."""
-        if self.training or torch.is_grad_enabled():
-            raise RuntimeError('slotformer_amd dVAE is inference-only: call .eval() under torch.no_grad()')
+        if torch.is_grad_enabled():
+            raise RuntimeError('slotformer_amd dVAE.tokenize is a hard argmax: call it under torch.no_grad()')
         F_, C_, H, W = imgs.shape
         h, w = H // 4, W // 4
         # 4x4 / stride-4 convolution = GEMM over (c, ky, kx) patch vectors (dVAE.py:26)
@@ -104,12 +105,13 @@ class dVAE(BaseModel):
     def detokenize(self, z):
         """dVAE.py:79-100: z [B,(T,)V,h,w] (probabilities over the vocabulary) -> image [B,(T,)3,4h,4w]."""
         assert z.shape[-3] == self.vocab_size
-        if self.training or torch.is_grad_enabled():
-            raise RuntimeError('slotformer_amd dVAE is inference-only: call .eval() under torch.no_grad()')
         B = z.shape[0]
         unflatten = z.dim() == 5
         if unflatten:
             z = z.flatten(0, 1)
+        if torch.is_grad_enabled():   # under autograd: the same arithmetic as a chain of differentiable nodes
+            recon = self.decode_nhwc(z.permute(0, 2, 3, 1).float()).permute(0, 3, 1, 2)
+            return recon.unflatten(0, (B, -1)) if unflatten else recon
         d = self.decoder
         x = z.permute(0, 2, 3, 1).contiguous().float()
         x = self._block(x, d[0])
@@ -126,14 +128,73 @@ class dVAE(BaseModel):
         recon = x.permute(0, 3, 1, 2).contiguous()
         return recon.unflatten(0, (B, -1)) if unflatten else recon
 
+    # ---- training forward (dVAE.py:113-139) ---------------------------------------------------------------
+    def _block_t(self, x, blk, pixel_shuffle=1):
+        from ... import train
+        w = blk.m.weight
+        y = train.linear_weight(x, w.reshape(w.shape[0], w.shape[1])) if w.shape[2] == 1 else train.conv3x3_nhwc(x, w)
+        return train.groupnorm1(y, blk.weight, blk.bias, relu=True, pixel_shuffle=pixel_shuffle)
+
+    def decode_nhwc(self, z):
+        """The decoder stack (dVAE.py:36-50) on a channels-last token map z [F,h,w,V] as autograd nodes -> image [F,4h,4w,3]
+        channels-last.  Also what STEVE's Gumbel image loss differentiates through with the dVAE frozen (steve.py:327-335)."""
+        from ... import train
+        d = self.decoder
+        y = self._block_t(z, d[0])
+        y = self._block_t(y, d[1])
+        y = self._block_t(y, d[2])
+        y = self._block_t(y, d[3])
+        y = self._block_t(y, d[4], pixel_shuffle=2)
+        y = self._block_t(y, d[6])
+        y = self._block_t(y, d[7])
+        y = self._block_t(y, d[8])
+        y = self._block_t(y, d[9], pixel_shuffle=2)
+        return train.linear_weight(y, d[11].weight.reshape(self.img_channels, 64), d[11].bias)
+
     def forward(self, data_dict):
+        """`img` [B,(T,)3,H,W]; optional `gumbel_tau`, `hard` as in the reference, and `gumbel` [B,(T,)V,h,w]: the Gumbel noise
+        to use instead of a fresh draw (the reference draws it inside steve_utils.gumbel_softmax)."""
         if self.testing:
             return self.tokenize(data_dict['img'], one_hot=False)
-        raise NotImplementedError('dVAE training forward (Gumbel-softmax sampling, dVAE.py:113-139) belongs to the training '
-                                  'row N1; use tokenize() / detokenize() or set testing = True')
+        from ... import train
+        x = data_dict['img']
+        if not x.is_cuda:
+            raise RuntimeError('slotformer_amd: inputs must live on a HIP device; there is no CPU fallback')
+        tau = data_dict.get('gumbel_tau', self.tau)
+        hard = data_dict.get('hard', False)
+        B = x.shape[0]
+        unflatten = x.dim() == 5
+        if unflatten:
+            x = x.flatten(0, 1)
+        F_, C_, H, W = x.shape
+        h, w = H // 4, W // 4
+        e = self.encoder
+        # encoder: 4x4 / stride-4 patch embedding as a GEMM over (c, ky, kx) patch vectors, six 1x1 blocks, logits
+        p = x.float().reshape(F_, C_, h, 4, w, 4).permute(0, 2, 4, 1, 3, 5).reshape(F_, h, w, C_ * 16)
+        y = train.linear_weight(p, e[0].m.weight.reshape(64, C_ * 16))
+        y = train.groupnorm1(y, e[0].weight, e[0].bias, relu=True)
+        for i in range(1, 7):
+            y = self._block_t(y, e[i])
+        logits = train.linear_weight(y, e[7].weight.reshape(self.vocab_size, 64), e[7].bias)     # [F,h,w,V]
+        # relaxed sample of the token map
+        g = data_dict.get('gumbel')
+        if g is None:
+            tiny = torch.finfo(torch.float32).tiny
+            g = -(torch.empty_like(logits).exponential_() + tiny).log()
+        else:
+            g = (g.flatten(0, 1) if unflatten else g).permute(0, 2, 3, 1)
+        z = train.gumbel_softmax(logits, g.to(logits.device).float().contiguous(), tau, hard)
+        recon = self.decode_nhwc(z).permute(0, 3, 1, 2)
+        # log-probabilities of the token map: reported, not part of the loss (a plain device reduction)
+        z_logits = torch.log_softmax(logits.detach(), -1).permute(0, 3, 1, 2)
+        if unflatten:
+            recon, z_logits = recon.unflatten(0, (B, -1)), z_logits.unflatten(0, (B, -1))
+        return {'recon': recon, 'z_logits': z_logits}
 
     def calc_train_loss(self, data_dict, out_dict):
-        raise NotImplementedError('dVAE training is outside the inference engine (row N1)')
+        """dVAE.py:141-146."""
+        from ...host import losses
+        return {'recon_loss': losses.image_recon_loss(out_dict['recon'], data_dict['img'])}
 
     @property
     def dtype(self):

@@ -118,9 +118,9 @@ class STEVE(StoSAVi):
         return slots, masks, None
 
     def forward(self, data_dict):
-        return self._forward(data_dict['img'], img_token_id=data_dict.get('token_id', None))
+        return self._forward(data_dict['img'], img_token_id=data_dict.get('token_id', None), gumbel=data_dict.get('gumbel', None))
 
-    def _forward(self, img, img_token_id=None, prev_slots=None):
+    def _forward(self, img, img_token_id=None, prev_slots=None, gumbel=None):
         if prev_slots is None:
             self._reset_rnn()
         slots, masks, _ = self.encode(img, prev_slots)
@@ -138,8 +138,17 @@ class STEVE(StoSAVi):
         pred_token_id = self.trans_decoder(in_slots, in_token_id)[:, -(h * w):]
         out_dict.update({'pred_token_id': pred_token_id, 'target_token_id': target_token_id})
         if self.use_img_recon_loss:
-            raise NotImplementedError('use_img_recon_loss (Gumbel-softmax image reconstruction, steve.py:324-335) is a '
-                                      'training-only loss (row N1)')
+            # steve.py:327-335: relaxed sample (tau 0.1) of the predicted token map, decoded by the frozen dVAE.  `gumbel`
+            # [B*T,V,h,w] fixes the noise the reference draws inside gumbel_softmax.
+            from ... import train
+            logits = pred_token_id.reshape(-1, h, w, self.vocab_size)
+            if gumbel is None:
+                g = -(torch.empty_like(logits).exponential_() + torch.finfo(torch.float32).tiny).log()
+            else:
+                g = gumbel.reshape(-1, self.vocab_size, h, w).permute(0, 2, 3, 1).to(logits.device).float().contiguous()
+            z = train.gumbel_softmax(logits, g, tau=0.1, hard=False)
+            out_dict['gt_img'] = img.flatten(0, 1)
+            out_dict['recon_img'] = self.dvae.decode_nhwc(z).permute(0, 3, 1, 2)
         return out_dict
 
     def calc_train_loss(self, data_dict, out_dict):
@@ -148,8 +157,13 @@ class STEVE(StoSAVi):
         target = out_dict['target_token_id'].flatten(0, 1).contiguous()
         if pred.requires_grad:
             from ... import train
-            return {'token_recon_loss': train.token_cross_entropy(pred, target)}
-        return {'token_recon_loss': ops.cross_entropy(pred, target)}
+            loss_dict = {'token_recon_loss': train.token_cross_entropy(pred, target)}
+        else:
+            loss_dict = {'token_recon_loss': ops.cross_entropy(pred, target)}
+        if self.use_img_recon_loss:
+            from ...host import losses
+            loss_dict['img_recon_loss'] = losses.image_recon_loss(out_dict['recon_img'], out_dict['gt_img'])
+        return loss_dict
 
     def train(self, mode=True):
         """steve.py: the dVAE stays in eval mode."""

@@ -481,6 +481,141 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, 
   }
   if (threadIdx.x == 0) out[0] = (float)(sh[0] / (double)n);
 }
+// ---- backward of GroupNorm(1 group) + ReLU (+ PixelShuffle) (row N1: the dVAE under autograd) ----
+// prep: g = dy (gathered back through the pixel shuffle) gated by the ReLU of the recomputed output; writes g and g * xhat
+// (their column sums are d_beta / d_gamma) and per-block partial sums of gamma*g and gamma*g*xhat (the two per-sample means
+// of the GroupNorm adjoint).  apply: dx = rstd * (gamma g - S1/n - xhat S2/n).
+__device__ __forceinline__ void gn_frame_stats(const double* part, int f, long long n, float eps, float* stat) {
+  const int t = threadIdx.x;
+  if (t < 64) {
+    double s = part[((long long)f * GN_P + t) * 2], q = part[((long long)f * GN_P + t) * 2 + 1];
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o, 64);
+      q += __shfl_xor(q, o, 64);
+    }
+    if (t == 0) {
+      const double mean = s / (double)n;
+      const double var = q / (double)n - mean * mean;
+      stat[0] = (float)mean;
+      stat[1] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+    }
+  }
+  __syncthreads();
+}
+__global__ __launch_bounds__(256) void gn_bwd_prep_kernel(const float* __restrict__ x, const double* __restrict__ part,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ dy, float* __restrict__ gb,
+                                                          float* __restrict__ gxb, float* __restrict__ sums, int H, int W, int C,
+                                                          float eps, int relu, int shuffle) {
+  const int f = blockIdx.y, t = threadIdx.x;
+  const long long n = (long long)H * W * C;
+  __shared__ float stat[2];
+  __shared__ float red[2][4];
+  gn_frame_stats(part, f, n, eps, stat);
+  const float mean = stat[0], rstd = stat[1];
+  const long long i4 = (long long)blockIdx.x * 256 + t;
+  float s1 = 0.f, s2 = 0.f;
+  if (i4 * 4 < n) {
+    const long long e = i4 * 4;
+    const int c = (int)(e % C);
+    const f32x4 v = *(const f32x4*)(x + (long long)f * n + e);
+    const f32x4 g4 = *(const f32x4*)(gamma + c), b4 = *(const f32x4*)(beta + c);
+    const f32x4 xh = (v - mean) * rstd;
+    const f32x4 o = xh * g4 + b4;
+    f32x4 d;
+    if (shuffle == 1) {
+      d = *(const f32x4*)(dy + (long long)f * n + e);
+    } else {
+      const long long pix = e / C;
+      const int yy = (int)(pix / W), xx = (int)(pix - (long long)yy * W);
+      const int Co = C / 4, co = c / 4;
+      const float* yo = dy + (long long)f * n;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] = yo[((long long)(2 * yy + (k >> 1)) * (2 * W) + 2 * xx + (k & 1)) * Co + co];
+    }
+    f32x4 g;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      g[k] = (relu && o[k] <= 0.f) ? 0.f : d[k];
+      s1 += g4[k] * g[k];
+      s2 += g4[k] * g[k] * xh[k];
+    }
+    *(f32x4*)(gb + (long long)f * n + e) = g;
+    *(f32x4*)(gxb + (long long)f * n + e) = g * xh;
+  }
+  s1 = sf_sum64(s1);
+  s2 = sf_sum64(s2);
+  if ((t & 63) == 0) {
+    red[0][t >> 6] = s1;
+    red[1][t >> 6] = s2;
+  }
+  __syncthreads();
+  if (t == 0) {
+    sums[((long long)f * gridDim.x + blockIdx.x) * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    sums[((long long)f * gridDim.x + blockIdx.x) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+// one block per frame: the frame's two sums from the per-block partials, in a fixed order, as means over the n elements
+__global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const float* __restrict__ sums, float* __restrict__ means, int nb,
+                                                          long long n) {
+  const int f = blockIdx.x, t = threadIdx.x;
+  __shared__ double sh[2][256];
+  double a = 0.0, b = 0.0;
+  for (int i = t; i < nb; i += 256) {
+    a += (double)sums[((long long)f * nb + i) * 2];
+    b += (double)sums[((long long)f * nb + i) * 2 + 1];
+  }
+  sh[0][t] = a;
+  sh[1][t] = b;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) {
+      sh[0][t] += sh[0][t + w];
+      sh[1][t] += sh[1][t + w];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    means[f * 2] = (float)(sh[0][0] / (double)n);
+    means[f * 2 + 1] = (float)(sh[1][0] / (double)n);
+  }
+}
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const double* __restrict__ part,
+                                                           const float* __restrict__ gamma, const float* __restrict__ gb,
+                                                           const float* __restrict__ means, float* __restrict__ dx, int H, int W,
+                                                           int C, float eps) {
+  const int f = blockIdx.y, t = threadIdx.x;
+  const long long n = (long long)H * W * C;
+  __shared__ float stat[2];
+  gn_frame_stats(part, f, n, eps, stat);
+  const float mean = stat[0], rstd = stat[1], m1 = means[f * 2], m2 = means[f * 2 + 1];
+  const long long i4 = (long long)blockIdx.x * 256 + t;
+  if (i4 * 4 >= n) return;
+  const long long e = i4 * 4;
+  const int c = (int)(e % C);
+  const f32x4 v = *(const f32x4*)(x + (long long)f * n + e);
+  const f32x4 g4 = *(const f32x4*)(gamma + c);
+  const f32x4 g = *(const f32x4*)(gb + (long long)f * n + e);
+  const f32x4 xh = (v - mean) * rstd;
+  *(f32x4*)(dx + (long long)f * n + e) = (g4 * g - m1 - xh * m2) * rstd;
+}
+
+// softmax backward over rows: dx = scale * y * (dy - sum(y * dy))   (y = softmax((x + add) * scale))
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ y, const float* __restrict__ dy, float scale,
+                                                               float* __restrict__ dx, int V) {
+  const long long r = blockIdx.x;
+  const float* yr = y + r * (long long)V;
+  const float* gr = dy + r * (long long)V;
+  const int t = threadIdx.x;
+  __shared__ float sh[4];
+  float d = 0.f;
+  for (int j = t; j < V; j += 256) d += yr[j] * gr[j];
+  d = sf_sum64(d);
+  if ((t & 63) == 0) sh[t >> 6] = d;
+  __syncthreads();
+  const float dot = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  for (int j = t; j < V; j += 256) dx[r * (long long)V + j] = scale * yr[j] * (gr[j] - dot);
+}
 }  // namespace
 
 extern "C" {
@@ -655,6 +790,64 @@ int sf_groupnorm1_nhwc_f32(const float* x, const float* gamma, const float* beta
   SF_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((n / 4 + 255) / 256), F), dim3(256), 0, st, x, (const double*)ws, gamma,
                      beta, y, H, W, C, eps, relu, pixel_shuffle);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+
+// ---- backward of the two calls above (row N1: the dVAE under autograd, dVAE.py:113-139) ----
+static size_t gn_bwd_blocks(int H, int W, int C) { return (((size_t)H * W * C) / 4 + 255) / 256; }
+static size_t gn_pad(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+size_t sf_groupnorm1_bwd_workspace_bytes(int F, int H, int W, int C) {
+  if (F <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+  const size_t n = (size_t)H * W * C, nb = gn_bwd_blocks(H, W, C);
+  return gn_pad(sf_groupnorm1_workspace_bytes(F)) + 2 * gn_pad((size_t)F * n * sizeof(float)) + gn_pad((size_t)F * nb * 2 * sizeof(float)) +
+         gn_pad((size_t)F * 2 * sizeof(float)) + gn_pad(sf_grad_partial_floats((long long)F * H * W, C, C) * sizeof(float)) + 256;
+}
+// x: the INPUT of the forward call; dy: gradient of its output ([F,H,W,C], or [F,2H,2W,C/4] with pixel_shuffle 2).
+// dx [F,H,W,C]; dgamma / dbeta [C] (overwritten).
+int sf_groupnorm1_nhwc_bwd_f32(const float* x, const float* gamma, const float* beta, const float* dy, float* dx, float* dgamma,
+                               float* dbeta, int F, int H, int W, int C, float eps, int relu, int pixel_shuffle, void* ws,
+                               size_t ws_bytes, void* stream) {
+  SF_REQUIRE(x && gamma && beta && dy && dx && dgamma && dbeta && ws, "sf_groupnorm1_nhwc_bwd_f32: null pointer");
+  SF_REQUIRE(F > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "sf_groupnorm1_nhwc_bwd_f32: bad shape");
+  SF_REQUIRE(pixel_shuffle == 1 || (pixel_shuffle == 2 && (C % 16) == 0), "sf_groupnorm1_nhwc_bwd_f32: pixel_shuffle must be 1 or 2");
+  SF_REQUIRE(ws_bytes >= sf_groupnorm1_bwd_workspace_bytes(F, H, W, C), "sf_groupnorm1_nhwc_bwd_f32: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)H * W * C;
+  const unsigned nb = (unsigned)gn_bwd_blocks(H, W, C);
+  char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  double* part = (double*)p;
+  p += gn_pad(sf_groupnorm1_workspace_bytes(F));
+  float* gb = (float*)p;
+  p += gn_pad((size_t)F * n * sizeof(float));
+  float* gxb = (float*)p;
+  p += gn_pad((size_t)F * n * sizeof(float));
+  float* sums = (float*)p;
+  p += gn_pad((size_t)F * nb * 2 * sizeof(float));
+  float* means = (float*)p;
+  p += gn_pad((size_t)F * 2 * sizeof(float));
+  float* partial = (float*)p;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(GN_P, F), dim3(256), 0, st, x, part, n);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_bwd_prep_kernel, dim3(nb, F), dim3(256), 0, st, x, (const double*)part, gamma, beta, dy, gb, gxb, sums, H, W, C,
+                     eps, relu, pixel_shuffle);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(F), dim3(256), 0, st, (const float*)sums, means, (int)nb, n);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nb, F), dim3(256), 0, st, x, (const double*)part, gamma, (const float*)gb,
+                     (const float*)means, dx, H, W, C, eps);
+  SF_CHECK_LAUNCH();
+  SF_TRY(sf_grad_bias_ex(gb, dbeta, (long long)F * H * W, C, partial, st));
+  SF_TRY(sf_grad_bias_ex(gxb, dgamma, (long long)F * H * W, C, partial, st));
+  return 0;
+}
+
+// dx[r, :] = scale * y[r, :] * (dy[r, :] - sum(y[r, :] * dy[r, :])): backward of sf_softmax_rows_f32 w.r.t. x given its output y
+int sf_softmax_rows_bwd_f32(const float* y, const float* dy, float scale, float* dx, long long R, int V, void* stream) {
+  SF_REQUIRE(y && dy && dx && R >= 0 && V > 0, "sf_softmax_rows_bwd_f32: bad arguments");
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, y, dy, scale, dx, V);
   SF_CHECK_LAUNCH();
   return 0;
 }

@@ -16,6 +16,7 @@ frame, predictor layers, decoder) whose gradients autograd accumulates into `.gr
 import ctypes as C
 
 import torch
+import torch.nn.functional as tnf
 
 from ._lib import sf_savi_features, sf_savi_features_grads, sf_savi_decoder_grads
 from ._lib import lib, check, sf_rollouter_grads, sf_tfm_layer_grads, sf_slot_attention, sf_slot_attention_grads, _SA_LEAVES
@@ -682,6 +683,97 @@ def linear(x, layer, relu=False):
 
 def layer_norm(x, layer):
     return _LayerNorm.apply(x, layer.weight, layer.bias, layer.eps)
+
+
+# ---- dVAE nodes (dVAE.py:113-139, steve_utils.py:26-41, 100-126) ------------------------------------------------------
+class _GroupNorm1(torch.autograd.Function):
+    """Conv2dBlock's GroupNorm(1 group) + ReLU (+ the PixelShuffle(2) that follows it) on NHWC maps:
+    sf_groupnorm1_nhwc_f32 / sf_groupnorm1_nhwc_bwd_f32 (statistics and ReLU gate recomputed from the saved input)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu, pixel_shuffle):
+        from . import ops
+        xd, g, b = x.detach().float().contiguous(), gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        ctx.save_for_backward(xd, g, b)
+        ctx.cfg = (float(eps), int(bool(relu)), int(pixel_shuffle))
+        return ops.groupnorm1_nhwc(xd, g, b, eps=eps, relu=relu, pixel_shuffle=pixel_shuffle)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, b = ctx.saved_tensors
+        eps, relu, r = ctx.cfg
+        dy = dy.float().contiguous()
+        F_, H, W, C_ = x.shape
+        dx, dg, db = torch.empty_like(x), torch.empty_like(g), torch.empty_like(b)
+        nb = lib().sf_groupnorm1_bwd_workspace_bytes(F_, H, W, C_)
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        check(lib().sf_groupnorm1_nhwc_bwd_f32(x.data_ptr(), g.data_ptr(), b.data_ptr(), dy.data_ptr(), dx.data_ptr(), dg.data_ptr(),
+                                               db.data_ptr(), F_, H, W, C_, eps, relu, r, ws.data_ptr(), nb,
+                                               torch.cuda.current_stream().cuda_stream))
+        return dx, dg, db, None, None, None
+
+
+def groupnorm1(x, gamma, beta, eps=1e-5, relu=True, pixel_shuffle=1):
+    return _GroupNorm1.apply(x, gamma, beta, eps, relu, pixel_shuffle)
+
+
+class _SoftmaxRows(torch.autograd.Function):
+    """softmax((x + add) * scale) over the last dim; with add = Gumbel noise and scale = 1/tau the relaxed one-hot sample of
+    steve_utils.py:26-41 (the log-partition shift of log_softmax cancels in the softmax)."""
+
+    @staticmethod
+    def forward(ctx, x, add, scale):
+        from . import ops
+        y = ops.softmax_rows(x.detach().float().contiguous(), None if add is None else add.detach().float().contiguous(), scale)
+        ctx.save_for_backward(y)
+        ctx.scale = float(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        V = y.shape[-1]
+        dx = torch.empty_like(y)
+        check(lib().sf_softmax_rows_bwd_f32(y.data_ptr(), dy.data_ptr(), ctx.scale, dx.data_ptr(), y.numel() // V, V,
+                                            torch.cuda.current_stream().cuda_stream))
+        return dx, None, None
+
+
+def gumbel_softmax(logits, gumbels, tau=1., hard=False):
+    """steve_utils.py:26-41 on the last dim, with the Gumbel noise given: relaxed sample, or the straight-through one-hot."""
+    from . import ops
+    y_soft = _SoftmaxRows.apply(logits, gumbels, 1. / tau)
+    if not hard:
+        return y_soft
+    idx = ops.argmax_rows(y_soft.detach())
+    y_hard = torch.zeros_like(y_soft).scatter_(-1, idx.unsqueeze(-1), 1.)
+    return y_hard - y_soft.detach() + y_soft
+
+
+def linear_weight(x, weight, bias=None, relu=False):
+    """act(x W^T + b) for a bare [N, K] weight under autograd.  The backward contractions work on multiples of 64, so other
+    widths (the dVAE's 48-wide patch vectors, its 3-channel output) are zero-padded up and the result sliced back."""
+    N, K = weight.shape
+    Np, Kp = -(-N // 64) * 64, -(-K // 64) * 64
+    if Kp != K:
+        x, weight = tnf.pad(x, (0, Kp - K)), tnf.pad(weight, (0, Kp - K))
+    if Np != N:
+        weight = tnf.pad(weight, (0, 0, 0, Np - N))
+        bias = tnf.pad(bias, (0, Np - N)) if bias is not None else None
+    y = _Linear.apply(x, weight, bias, relu)
+    return y[..., :N] if Np != N else y
+
+
+def conv3x3_nhwc(x, weight):
+    """Bias-free 3x3 / stride-1 / pad-1 convolution of an NHWC map under autograd (the two 3x3 Conv2dBlocks of the dVAE decoder,
+    dVAE.py:39,45) as ONE GEMM over the nine shifted copies of the map: the copies and their adjoint (shift-and-add) are data
+    movement, the contraction and both of its gradients run on the HIP GEMM kernels."""
+    F_, H, W, C_ = x.shape
+    xp = tnf.pad(x, (0, 0, 1, 1, 1, 1))
+    cols = torch.cat([xp[:, ky:ky + H, kx:kx + W] for ky in range(3) for kx in range(3)], -1)   # [F,H,W,9C], (ky, kx, c) order
+    w2 = weight.permute(0, 2, 3, 1).reshape(weight.shape[0], 9 * C_)
+    return linear_weight(cols, w2)
 
 
 class FlatAdam:

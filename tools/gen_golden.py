@@ -288,7 +288,7 @@ def case_steve_tokens(name, B, T, seed):
          gen_margin=(g2[..., 0] - g2[..., 1]), **meta)
 
 
-def case_steve_train(name, B, T, seed, stride=53):
+def case_steve_train(name, B, T, seed, stride=53, img_loss=False):
     """STEVE's own training step in the reference (steve.py:242-351 in train() mode: slots from the encoder side, frozen-dVAE
     token targets, teacher-forced decoder logits, token cross-entropy, backward), dropout probabilities set to 0 (the only
     random part).  Stored like savi_train: loss, per-parameter gradient norm + strided sample."""
@@ -300,6 +300,7 @@ def case_steve_train(name, B, T, seed, stride=53):
         torch.save({'state_dict': dv.state_dict()}, dpath)
         full = {k: (dict(v) if isinstance(v, dict) else v) for k, v in cfg.items()}
         full['dvae_dict']['dvae_ckp_path'] = dpath
+        full['loss_dict'] = dict(use_img_recon_loss=img_loss)
         m = ref_build_base(gu.ParamsView(full)).train()
         m.testing = False
         for mod in m.modules():
@@ -309,14 +310,26 @@ def case_steve_train(name, B, T, seed, stride=53):
                 mod.dropout = 0.
         sd = load_seeded(m, seed)
         img = gu.seeded_img(B, T, cfg['resolution'][0], seed=seed + 1)
+        extra, gumbel = {}, None
+        if img_loss:   # with dropout at p = 0 the Exp(1) draw of gumbel_softmax is the first RNG use of the forward
+            hw = cfg['resolution'][0] // cfg['dvae_dict']['down_factor']
+            torch.manual_seed(seed + 2)
+            expo = torch.empty(B * T, cfg['dvae_dict']['vocab_size'], hw, hw).exponential_()
+            gumbel = -(expo + torch.finfo(torch.float32).tiny).log()
+            torch.manual_seed(seed + 2)
         out = m({'img': img})
-        loss = m.calc_train_loss({'img': img}, out)['token_recon_loss']
+        terms = m.calc_train_loss({'img': img}, out)
+        loss = terms['token_recon_loss'] + (terms['img_recon_loss'] if img_loss else 0.)
         loss.backward()
         grads = {n: p_.grad.detach().clone() for n, p_ in m.named_parameters() if p_.grad is not None}
         osd = {k: (v.clone().requires_grad_(True) if k in grads else v) for k, v in sd.items()}
         enc = oracle.steve_encode(img, osd, cfg, training=True)
-        o = oracle.steve_forward_tokens(img, enc['slots'], osd, cfg)
-        o['token_recon_loss'].backward()
+        o = oracle.steve_forward_tokens(img, enc['slots'], osd, cfg, gumbel)
+        (o['token_recon_loss'] + (o['img_recon_loss'] if img_loss else 0.)).backward()
+        if img_loss:
+            print('  img loss', float(terms['img_recon_loss'].detach()), 'oracle', float(o['img_recon_loss'].detach()))
+            extra = dict(gumbel=gumbel.numpy(), img_loss=np.array(float(terms['img_recon_loss'].detach())),
+                         recon_img=out['recon_img'].detach().numpy())
         print('  loss', float(loss.detach()), 'oracle', float(o['token_recon_loss'].detach()), 'targets equal',
               bool(torch.equal(o['target_token_id'], out['target_token_id'])))
         worst = sorted(((((osd[n].grad - g).norm() / (g.norm() + 1e-30)).item(), n) for n, g in grads.items()), reverse=True)
@@ -326,10 +339,41 @@ def case_steve_train(name, B, T, seed, stride=53):
     for k in list(meta):
         if k.startswith('closed::') and k.endswith(gu.CLOSED_FORM_NOSTORE):
             del meta[k]
-    save(name, loss=np.array(float(loss.detach())), stride=np.int64(stride), slots=out['slots'].detach().numpy(),
-         target_token_id=out['target_token_id'].numpy(), grad_names=np.array(names),
+    save(name, loss=np.array(float(terms['token_recon_loss'].detach())), stride=np.int64(stride), slots=out['slots'].detach().numpy(),
+         target_token_id=out['target_token_id'].numpy(), grad_names=np.array(names), **extra,
          grad_norms=np.array([float(grads[n].norm()) for n in names]),
          **{'gs.' + n: grads[n].flatten()[::stride].numpy() for n in names}, **meta)
+
+
+def case_dvae_train(name, B, res, vocab, seed, tau=1., hard=False, stride=7):
+    """The reference dVAE's own training step (dVAE.py:102-146 in train() mode): Gumbel-softmax relaxed token map, decoder,
+    MSE image loss, backward.  The Exp(1) draw inside steve_utils.gumbel_softmax is the first RNG use of the forward, so
+    seeding torch right before the call and repeating the draw captures the noise."""
+    print(name)
+    with torch.enable_grad():
+        m = dVAE(vocab_size=vocab, img_channels=3).train()
+        sd = load_seeded(m, seed)
+        # GroupNorm affine parameters away from (1, 0) so their gradients are exercised through non-trivial values
+        img = gu.seeded_img(B, 1, res, seed=seed + 1)[:, 0]
+        torch.manual_seed(seed + 2)
+        expo = torch.empty(B, vocab, res // 4, res // 4).exponential_()
+        gumbel = -(expo + torch.finfo(torch.float32).tiny).log()
+        torch.manual_seed(seed + 2)
+        out = m({'img': img, 'gumbel_tau': tau, 'hard': hard})
+        loss = m.calc_train_loss({'img': img}, out)['recon_loss']
+        loss.backward()
+        grads = {n: p_.grad.detach().clone() for n, p_ in m.named_parameters() if p_.grad is not None}
+        osd = {k: (v.clone().requires_grad_(True) if k in grads else v) for k, v in sd.items()}
+        o = oracle.dvae_forward_train(img, gumbel, osd, tau, hard)
+        o['recon_loss'].backward()
+        print('  loss', float(loss.detach()), 'oracle', float(o['recon_loss'].detach()), 'recon err', err(o['recon'].detach(), out['recon'].detach()))
+        worst = sorted(((((osd[n].grad - g).norm() / (g.norm() + 1e-30)).item(), n) for n, g in grads.items()), reverse=True)
+        print('  oracle grad rel-L2 err (worst 3)', worst[:3], 'params with grad', len(grads))
+    names = sorted(grads)
+    save(name, loss=np.array(float(loss.detach())), stride=np.int64(stride), tau=np.array(tau), hard=np.array(int(hard)),
+         gumbel=gumbel.numpy(), recon=out['recon'].detach().numpy(), z_logits=out['z_logits'].detach().numpy()[:, ::5],
+         grad_names=np.array(names), grad_norms=np.array([float(grads[n].norm()) for n in names]),
+         **{'gs.' + n: grads[n].flatten()[::stride].numpy() for n in names}, **pack_meta(m, sd))
 
 
 @torch.no_grad()
@@ -609,6 +653,13 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'steve_slotformer':
         case_steve_slotformer('steve_slotformer', B=1, seed=701)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'steve_train_img':
+        case_steve_train('steve_train_img', B=1, T=2, seed=931, img_loss=True)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'dvae_train':
+        case_dvae_train('dvae_train', B=2, res=32, vocab=64, seed=71)
+        case_dvae_train('dvae_train_hard', B=1, res=16, vocab=128, seed=73, tau=0.5, hard=True)
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'steve_train':
         case_steve_train('steve_train', B=1, T=2, seed=921)
