@@ -23,6 +23,7 @@
 #include "sf_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -693,6 +694,35 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   reinterpret_cast<float4*>(out)[i] = r;
 }
 
+// the same reduction for few columns and many partials (bias / LayerNorm / 64x64 weight gradients: up to 512 partials of 16
+// to 1024 float4 columns, where one thread per column leaves the chip idle behind a handful of long serial chains): a
+// workgroup takes 16 columns, its 16 thread rows each sum every 16th partial, LDS combines the rows in a fixed tree.
+__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                   int G, long long n4) {
+  const int c = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const long long i = (long long)blockIdx.x * 16 + c;
+  __shared__ f32x4 sh[16][17];
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(partial) + i;
+    for (int g = q; g < G; g += 16) a += p[(long long)g * n4];
+  }
+  sh[q][c] = a;
+  __syncthreads();
+#pragma unroll
+  for (int w = 8; w > 0; w >>= 1) {
+    if (q < w) sh[q][c] += sh[q + w][c];
+    __syncthreads();
+  }
+  if (q == 0 && i < n4) reinterpret_cast<f32x4*>(out)[i] = sh[0][c];
+}
+inline void launch_reduce_partials(const float* partial, float* out, int G, long long n4, hipStream_t st) {
+  if (G >= 32 && n4 <= 16384)
+    hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, partial, out, G, n4);
+  else
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, partial, out, G, n4);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // weight-gradient contraction  dW[n][k] = sum_m Y[m][n] * X[m][k]   (Y [rows, N], X [rows, K], both row-major)
 // split-bf16 on v_mfma_f32_32x32x16_bf16; 64x64 output tile per workgroup (4 waves, one 32x32 quadrant each), the
@@ -1004,7 +1034,7 @@ int grad_weight(const float* Y, const float* X, float* dW, long long rows, int N
   SF_CHECK_LAUNCH();
   if (splits > 1) {
     const long long n4 = (long long)N * K / 4;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, w.partial, dW, splits, n4);
+    launch_reduce_partials(w.partial, dW, splits, n4, st);
     SF_CHECK_LAUNCH();
   }
   return 0;
@@ -1019,7 +1049,7 @@ int grad_bias(const float* Y, float* db, long long rows, int n, const Ws& w, hip
   while (cols < n && cols < 256) cols <<= 1;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(n, cols), G), dim3(256), 0, st, Y, w.partial, rows, rpg, n);
   SF_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, w.partial, db, G, (long long)n / 4);
+  launch_reduce_partials(w.partial, db, G, (long long)n / 4, st);
   SF_CHECK_LAUNCH();
   return 0;
 }
@@ -1034,8 +1064,7 @@ int grad_ln(const float* x, const float* dy, float* dgamma, float* dbeta, long l
   SF_CHECK_LAUNCH();
   // partial is [G][2][D]: reduce both rows at once into a [2][D] scratch behind the partials, then copy out
   float* both = w.partial + (size_t)G * 2 * D;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * D / 4, 256)), dim3(256), 0, st, w.partial, both, G,
-                     (long long)2 * D / 4);
+  launch_reduce_partials(w.partial, both, G, (long long)2 * D / 4, st);
   SF_CHECK_LAUNCH();
   hipError_t e = hipMemcpyAsync(dgamma, both, D * sizeof(float), hipMemcpyDeviceToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(dbeta, both + D, D * sizeof(float), hipMemcpyDeviceToDevice, st);
