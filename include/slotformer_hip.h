@@ -186,6 +186,12 @@ int sf_cross_entropy_f32(const float* x, const long long* target, float* loss_ro
 /* y = softmax((x + add) * scale) per row (add may be NULL): the Gumbel-softmax relaxation of steve_utils.py:26-41 with
  * add = Gumbel noise, scale = 1/tau (steve_slotformer.py:97-98). */
 int sf_softmax_rows_f32(const float* x, const float* add, float scale, float* y, long long R, int V, void* stream);
+/* y = log_softmax(x) per row (the z_logits of dVAE.py:127). */
+int sf_log_softmax_rows_f32(const float* x, float* y, long long R, int V, void* stream);
+/* y[r, :] = softmax((x[r, :] + g[r, :]) * scale), g ~ Gumbel(0, 1) generated inside the kernel as a pure function of
+ * (seed, r * V + j) -- g = -log(-log(u)), u = ((mix32(idx ^ s) >> 9) + 0.5) * 2^-23 -- so the noise of
+ * steve_utils.py:30-35 never travels through memory (training only; R * V < 2^32). */
+int sf_gumbel_softmax_rows_f32(const float* x, unsigned long long seed, float scale, float* y, long long R, int V, void* stream);
 /* Adjoint of sf_softmax_rows_f32 w.r.t. x (and add) given its output y: dx = scale * y * (dy - sum(y * dy)) per row -- the
  * Gumbel-softmax relaxation of steve_utils.py:26-41 under autograd. */
 int sf_softmax_rows_bwd_f32(const float* y, const float* dy, float scale, float* dx, long long R, int V, void* stream);

@@ -178,15 +178,12 @@ class dVAE(BaseModel):
         logits = train.linear_weight(y, e[7].weight.reshape(self.vocab_size, 64), e[7].bias)     # [F,h,w,V]
         # relaxed sample of the token map
         g = data_dict.get('gumbel')
-        if g is None:
-            tiny = torch.finfo(torch.float32).tiny
-            g = -(torch.empty_like(logits).exponential_() + tiny).log()
-        else:
-            g = (g.flatten(0, 1) if unflatten else g).permute(0, 2, 3, 1)
-        z = train.gumbel_softmax(logits, g.to(logits.device).float().contiguous(), tau, hard)
+        if g is not None:
+            g = (g.flatten(0, 1) if unflatten else g).permute(0, 2, 3, 1).to(logits.device).float().contiguous()
+        z = train.gumbel_softmax(logits, g, tau, hard)   # without `gumbel`: noise generated inside the softmax kernel
         recon = self.decode_nhwc(z).permute(0, 3, 1, 2)
-        # log-probabilities of the token map: reported, not part of the loss (a plain device reduction)
-        z_logits = torch.log_softmax(logits.detach(), -1).permute(0, 3, 1, 2)
+        # log-probabilities of the token map: reported, not part of the loss
+        z_logits = ops.log_softmax_rows(logits.detach()).permute(0, 3, 1, 2)
         if unflatten:
             recon, z_logits = recon.unflatten(0, (B, -1)), z_logits.unflatten(0, (B, -1))
         return {'recon': recon, 'z_logits': z_logits}

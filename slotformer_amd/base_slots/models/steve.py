@@ -142,9 +142,8 @@ class STEVE(StoSAVi):
             # [B*T,V,h,w] fixes the noise the reference draws inside gumbel_softmax.
             from ... import train
             logits = pred_token_id.reshape(-1, h, w, self.vocab_size)
-            if gumbel is None:
-                g = -(torch.empty_like(logits).exponential_() + torch.finfo(torch.float32).tiny).log()
-            else:
+            g = None   # no noise given: generated inside the softmax kernel
+            if gumbel is not None:
                 g = gumbel.reshape(-1, self.vocab_size, h, w).permute(0, 2, 3, 1).to(logits.device).float().contiguous()
             z = train.gumbel_softmax(logits, g, tau=0.1, hard=False)
             out_dict['gt_img'] = img.flatten(0, 1)

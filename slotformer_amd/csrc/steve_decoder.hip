@@ -440,8 +440,15 @@ __global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict_
 }
 
 // y[r] = softmax((x[r] + add[r]) * scale) over V columns; add may be null.  One workgroup per row.
+// Gumbel(0, 1) sample of element idx as a pure function of (seed, idx): -log(E) with E = -log(u) ~ Exp(1), u uniform on the 2^23
+// midpoints of (0, 1) -- the noise of steve_utils.py:30-35 without a trip through memory (tests rebuild it on the host).
+__device__ __forceinline__ float sf_gumbel(uint32_t idx, uint32_t sseed) {
+  const float u = ((float)(sf_mix32(idx ^ sseed) >> 9) + 0.5f) * 1.1920929e-7f;
+  return -logf(-logf(u));
+}
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, const float* __restrict__ add,
-                                                           float scale, float* __restrict__ y, int V) {
+                                                           float scale, float* __restrict__ y, int V, int noise, uint32_t sseed,
+                                                           int logout) {
   const long long r = blockIdx.x;
   const float* xr = x + r * (long long)V;
   const float* ar = add ? add + r * (long long)V : nullptr;
@@ -449,7 +456,17 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   const int t = threadIdx.x;
   __shared__ float sh[4];
   float mx = -INFINITY;
-  for (int j = t; j < V; j += 256) mx = fmaxf(mx, (xr[j] + (ar ? ar[j] : 0.f)) * scale);
+  if (noise) {   // y holds x + g between the passes
+    for (int j = t; j < V; j += 256) {
+      const float v = (xr[j] + sf_gumbel((uint32_t)(r * V + j), sseed)) * scale;
+      yr[j] = v;
+      mx = fmaxf(mx, v);
+    }
+    xr = yr;
+    scale = 1.f;
+  } else {
+    for (int j = t; j < V; j += 256) mx = fmaxf(mx, (xr[j] + (ar ? ar[j] : 0.f)) * scale);
+  }
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   if ((t & 63) == 0) sh[t >> 6] = mx;
   __syncthreads();
@@ -457,15 +474,97 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   __syncthreads();
   float se = 0.f;
   for (int j = t; j < V; j += 256) {
-    const float e = expf((xr[j] + (ar ? ar[j] : 0.f)) * scale - mx);
-    yr[j] = e;
+    const float c = (xr[j] + (ar ? ar[j] : 0.f)) * scale - mx;
+    const float e = expf(c);
+    yr[j] = logout ? c : e;
     se += e;
   }
   se = sf_sum64(se);
   if ((t & 63) == 0) sh[t >> 6] = se;
   __syncthreads();
-  const float inv = 1.0f / ((sh[0] + sh[1]) + (sh[2] + sh[3]));
-  for (int j = t; j < V; j += 256) yr[j] *= inv;
+  const float tot = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  const float inv = 1.0f / tot, lg = logf(tot);
+  for (int j = t; j < V; j += 256) yr[j] = logout ? yr[j] - lg : yr[j] * inv;
+}
+
+// the same for rows of at most 1024 * NV floats (V % 4 == 0, 16-byte aligned rows): the row lives in registers between the
+// passes, so x (and add) are read once and y is written once -- 3 row passes of HBM traffic instead of 7, 2 with hashed noise
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                               float scale, float* __restrict__ y, int V, int noise, uint32_t sseed,
+                                                               int logout) {
+  const long long r = blockIdx.x;
+  const int t = threadIdx.x;
+  __shared__ float sh[2][4];
+  f32x4 v[NV];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    const int j = (t + 256 * n) * 4;
+    if (j < V) {
+      f32x4 a = *(const f32x4*)(x + r * V + j);
+      if (add) a += *(const f32x4*)(add + r * V + j);
+      if (noise) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += sf_gumbel((uint32_t)(r * V + j + k), sseed);
+      }
+      v[n] = a * scale;
+      mx = fmaxf(fmaxf(mx, fmaxf(v[n][0], v[n][1])), fmaxf(v[n][2], v[n][3]));
+    } else {
+      v[n] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((t & 63) == 0) sh[0][t >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sh[0][0], sh[0][1]), fmaxf(sh[0][2], sh[0][3]));
+  float se = 0.f;
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float c = v[n][k] - mx, e = expf(c);
+      v[n][k] = logout ? c : e;
+      se += e;
+    }
+  }
+  se = sf_sum64(se);
+  if ((t & 63) == 0) sh[1][t >> 6] = se;
+  __syncthreads();
+  const float tot = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+  const float inv = 1.0f / tot, lg = logf(tot);
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    const int j = (t + 256 * n) * 4;
+    if (j < V) *(f32x4*)(y + r * V + j) = logout ? v[n] - lg : v[n] * inv;
+  }
+}
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_bwd_rows_reg_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                                   float scale, float* __restrict__ dx, int V) {
+  const long long r = blockIdx.x;
+  const int t = threadIdx.x;
+  __shared__ float sh[4];
+  f32x4 yv[NV], gv[NV];
+  float d = 0.f;
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    const int j = (t + 256 * n) * 4;
+    if (j < V) {
+      yv[n] = *(const f32x4*)(y + r * V + j);
+      gv[n] = *(const f32x4*)(dy + r * V + j);
+      d += (yv[n][0] * gv[n][0] + yv[n][1] * gv[n][1]) + (yv[n][2] * gv[n][2] + yv[n][3] * gv[n][3]);
+    }
+  }
+  d = sf_sum64(d);
+  if ((t & 63) == 0) sh[t >> 6] = d;
+  __syncthreads();
+  const float dot = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    const int j = (t + 256 * n) * 4;
+    if (j < V) *(f32x4*)(dx + r * V + j) = yv[n] * (gv[n] - dot) * scale;
+  }
 }
 
 // mean of n floats in a fixed order (single workgroup, double accumulation)
@@ -753,12 +852,37 @@ int sf_argmax_rows_f32(const float* x, long long ld, long long* out, long long R
 
 // y[r, :] = softmax((x[r, :] + add[r, :]) * scale); add may be NULL.  With add = Gumbel noise and scale = 1/tau this is
 // steve_utils.py:26-41 gumbel_softmax(log_softmax(x), tau) (the log-partition shift cancels in the softmax).
+static int softmax_rows_launch(const float* x, const float* add, float scale, float* y, long long R, int V, int noise,
+                               uint32_t sseed, hipStream_t st, int logout = 0) {
+  const bool vec = (V % 4) == 0 && V <= 4096 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)add) & 15) == 0;
+  if (vec && V <= 1024)
+    hipLaunchKernelGGL(softmax_rows_reg_kernel<1>, dim3((unsigned)R), dim3(256), 0, st, x, add, scale, y, V, noise, sseed, logout);
+  else if (vec)
+    hipLaunchKernelGGL(softmax_rows_reg_kernel<4>, dim3((unsigned)R), dim3(256), 0, st, x, add, scale, y, V, noise, sseed, logout);
+  else
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)R), dim3(256), 0, st, x, add, scale, y, V, noise, sseed, logout);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
 int sf_softmax_rows_f32(const float* x, const float* add, float scale, float* y, long long R, int V, void* stream) {
   SF_REQUIRE(x && y && R >= 0 && V > 0, "sf_softmax_rows_f32: bad arguments");
   if (R == 0) return 0;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, add, scale, y, V);
-  SF_CHECK_LAUNCH();
-  return 0;
+  return softmax_rows_launch(x, add, scale, y, R, V, 0, 0u, (hipStream_t)stream);
+}
+// y[r, :] = log_softmax(x[r, :]) (F.log_softmax over the last dim: the z_logits of dVAE.py:127)
+int sf_log_softmax_rows_f32(const float* x, float* y, long long R, int V, void* stream) {
+  SF_REQUIRE(x && y && R >= 0 && V > 0, "sf_log_softmax_rows_f32: bad arguments");
+  if (R == 0) return 0;
+  return softmax_rows_launch(x, nullptr, 1.f, y, R, V, 0, 0u, (hipStream_t)stream, 1);
+}
+// y[r, :] = softmax((x[r, :] + g[r, :]) * scale) with g ~ Gumbel(0, 1) generated in the kernel as a pure function of
+// (seed, r * V + j): steve_utils.py:26-41 with tau = 1 / scale, the noise never written to memory.  R * V < 2^32.
+int sf_gumbel_softmax_rows_f32(const float* x, unsigned long long seed, float scale, float* y, long long R, int V, void* stream) {
+  SF_REQUIRE(x && y && R >= 0 && V > 0, "sf_gumbel_softmax_rows_f32: bad arguments");
+  SF_REQUIRE(R * (long long)V < (1LL << 32), "sf_gumbel_softmax_rows_f32: more than 2^32 elements");
+  if (R == 0) return 0;
+  const uint32_t sseed = sf_mix32((uint32_t)seed ^ sf_mix32((uint32_t)(seed >> 32) + 0x9e3779b9u));
+  return softmax_rows_launch(x, nullptr, scale, y, R, V, 1, sseed, (hipStream_t)stream);
 }
 
 // loss_rows[r] = -log softmax(x[r])[target[r]];  mean_out[0] = mean over rows (F.cross_entropy default reduction)
@@ -847,7 +971,13 @@ int sf_groupnorm1_nhwc_bwd_f32(const float* x, const float* gamma, const float* 
 int sf_softmax_rows_bwd_f32(const float* y, const float* dy, float scale, float* dx, long long R, int V, void* stream) {
   SF_REQUIRE(y && dy && dx && R >= 0 && V > 0, "sf_softmax_rows_bwd_f32: bad arguments");
   if (R == 0) return 0;
-  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, y, dy, scale, dx, V);
+  const bool vec = (V % 4) == 0 && V <= 4096 && (((uintptr_t)y | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
+  if (vec && V <= 1024)
+    hipLaunchKernelGGL(softmax_bwd_rows_reg_kernel<1>, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, y, dy, scale, dx, V);
+  else if (vec)
+    hipLaunchKernelGGL(softmax_bwd_rows_reg_kernel<4>, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, y, dy, scale, dx, V);
+  else
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, y, dy, scale, dx, V);
   SF_CHECK_LAUNCH();
   return 0;
 }

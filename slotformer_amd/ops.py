@@ -282,6 +282,25 @@ def softmax_rows(x, add=None, scale=1.0):
     return out
 
 
+def log_softmax_rows(x):
+    """F.log_softmax over the last dim."""
+    _chk(x)
+    V = x.shape[-1]
+    out = torch.empty_like(x)
+    check(lib().sf_log_softmax_rows_f32(_p(x), _p(out), x.numel() // V, V, _stream()))
+    return out
+
+
+def gumbel_softmax_rows(x, seed, scale=1.0):
+    """softmax((x + g) * scale) over the last dim with Gumbel(0, 1) noise g generated inside the kernel from `seed`
+    (train.gumbel_noise rebuilds it on the host)."""
+    _chk(x)
+    V = x.shape[-1]
+    out = torch.empty_like(x)
+    check(lib().sf_gumbel_softmax_rows_f32(_p(x), int(seed) & 0xffffffffffffffff, float(scale), _p(out), x.numel() // V, V, _stream()))
+    return out
+
+
 def slate_attention_cached(q, kv_cache, Lk, num_heads, d_model, k_off, v_off):
     """One-query-per-sequence attention over the first Lk rows of a K/V cache.  q [B,1,ldq] (head block at column 0),
     kv_cache [B,Lmax,ld] holding k at column k_off and v at column v_off of each row."""

@@ -718,13 +718,19 @@ def groupnorm1(x, gamma, beta, eps=1e-5, relu=True, pixel_shuffle=1):
 
 
 class _SoftmaxRows(torch.autograd.Function):
-    """softmax((x + add) * scale) over the last dim; with add = Gumbel noise and scale = 1/tau the relaxed one-hot sample of
-    steve_utils.py:26-41 (the log-partition shift of log_softmax cancels in the softmax)."""
+    """softmax((x + noise) * scale) over the last dim; with Gumbel noise and scale = 1/tau the relaxed one-hot sample of
+    steve_utils.py:26-41 (the log-partition shift of log_softmax cancels in the softmax).  The noise is either the tensor
+    `add` or, with `seed`, generated inside the kernel (sf_gumbel_softmax_rows_f32) and never stored: the backward only
+    needs the output."""
 
     @staticmethod
-    def forward(ctx, x, add, scale):
+    def forward(ctx, x, add, scale, seed):
         from . import ops
-        y = ops.softmax_rows(x.detach().float().contiguous(), None if add is None else add.detach().float().contiguous(), scale)
+        xd = x.detach().float().contiguous()
+        if seed is not None and add is None:
+            y = ops.gumbel_softmax_rows(xd, seed, scale)
+        else:
+            y = ops.softmax_rows(xd, None if add is None else add.detach().float().contiguous(), scale)
         ctx.save_for_backward(y)
         ctx.scale = float(scale)
         return y
@@ -737,18 +743,42 @@ class _SoftmaxRows(torch.autograd.Function):
         dx = torch.empty_like(y)
         check(lib().sf_softmax_rows_bwd_f32(y.data_ptr(), dy.data_ptr(), ctx.scale, dx.data_ptr(), y.numel() // V, V,
                                             torch.cuda.current_stream().cuda_stream))
-        return dx, None, None
+        return dx, None, None, None
 
 
-def gumbel_softmax(logits, gumbels, tau=1., hard=False):
-    """steve_utils.py:26-41 on the last dim, with the Gumbel noise given: relaxed sample, or the straight-through one-hot."""
+def gumbel_softmax(logits, gumbels=None, tau=1., hard=False, seed=None):
+    """steve_utils.py:26-41 on the last dim: relaxed sample, or the straight-through one-hot.  The Gumbel noise is `gumbels`
+    when given, else drawn inside the kernel from `seed` (default: a fresh seed from torch's CPU generator)."""
     from . import ops
-    y_soft = _SoftmaxRows.apply(logits, gumbels, 1. / tau)
+    if gumbels is None and seed is None:
+        seed = _new_seed()
+    y_soft = _SoftmaxRows.apply(logits, gumbels, 1. / tau, seed)
     if not hard:
         return y_soft
     idx = ops.argmax_rows(y_soft.detach())
     y_hard = torch.zeros_like(y_soft).scatter_(-1, idx.unsqueeze(-1), 1.)
     return y_hard - y_soft.detach() + y_soft
+
+
+def gumbel_noise(seed, numel):
+    """Host restatement of the in-kernel Gumbel noise (steve_decoder.hip: sf_gumbel) for tests: float32 [numel]."""
+    import numpy as np
+
+    def mix(h):
+        h = h.astype(np.uint32)
+        h ^= h >> np.uint32(16)
+        h = (h * np.uint32(0x7feb352d)).astype(np.uint32)
+        h ^= h >> np.uint32(15)
+        h = (h * np.uint32(0x846ca68b)).astype(np.uint32)
+        h ^= h >> np.uint32(16)
+        return h
+
+    with np.errstate(over='ignore'):
+        inner = mix(np.array([np.uint32((seed >> 32) & 0xffffffff) + np.uint32(0x9e3779b9)], dtype=np.uint32))
+        sseed = mix(np.array([np.uint32(seed & 0xffffffff)], dtype=np.uint32) ^ inner)[0]
+        h = mix(np.arange(numel, dtype=np.uint32) ^ sseed)
+    u = ((h >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.1920929e-7)
+    return torch.from_numpy(-np.log(-np.log(u)))
 
 
 def linear_weight(x, weight, bias=None, relu=False):

@@ -874,3 +874,28 @@ def test_steve_training_step_with_image_loss_golden(dev, precision):
     with torch.no_grad():
         ev = m.calc_eval_loss({'img': img.to(dev)}, m({'img': img.to(dev)}))
     assert set(ev) == {'token_recon_loss', 'img_recon_loss'} and all(np.isfinite(float(v)) for v in ev.values())
+
+
+@pytest.mark.parametrize('V', [64, 1000, 4096, 4100, 5000])
+def test_in_kernel_gumbel_noise_and_log_softmax(dev, V):
+    """sf_gumbel_softmax_rows_f32 draws its noise inside the kernel: the same call with the host restatement of that noise
+    (train.gumbel_noise) as an explicit `add` tensor gives the same rows; the noise has Gumbel(0, 1) moments; log-softmax
+    rows against torch.  Row lengths on the register-resident path (<= 4096, multiple of 4) and on the generic one."""
+    from slotformer_amd import ops, train
+    R = 37
+    x = torch.from_numpy(np.random.RandomState(V).standard_normal((R, V)).astype(np.float32)).to(dev)
+    seed = 0x1234_5678_9abc_def1
+    noise = train.gumbel_noise(seed, R * V).reshape(R, V)
+    y = ops.gumbel_softmax_rows(x, seed, 1. / 0.7)
+    ref = ops.softmax_rows(x, noise.to(dev), 1. / 0.7)
+    assert rel_err(y, ref.cpu()) < 1e-4
+    assert rel_err(ref, torch.softmax((x.cpu() + noise) / 0.7, -1)) < 1e-5
+    assert abs(float(noise.mean()) - 0.5772) < 0.02 and abs(float(noise.var()) - np.pi**2 / 6) < 0.06
+    assert not torch.equal(y, ops.gumbel_softmax_rows(x, seed + 1, 1. / 0.7))
+    assert rel_err(ops.log_softmax_rows(x), torch.log_softmax(x.cpu(), -1)) < 1e-6
+    # the node: backward through the in-kernel noise path equals the backward with the noise given
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    dy = torch.from_numpy(np.random.RandomState(1).standard_normal((R, V)).astype(np.float32)).to(dev)
+    (train.gumbel_softmax(xa, None, 0.7, seed=seed) * dy).sum().backward()
+    (train.gumbel_softmax(xb, noise.to(dev), 0.7) * dy).sum().backward()
+    assert l2_err(xa.grad, xb.grad.cpu()) < 1e-4
