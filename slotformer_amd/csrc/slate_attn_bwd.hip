@@ -292,6 +292,155 @@ __global__ __launch_bounds__(256) void slate_attn_bwd_kernel(SabArgs p, int hd) 
   }
 }
 
+// The same kernel for 32 < head_dim <= 48 in the split-bf16 modes (the Physion decoder: width 192, 4 heads), shaped so that TWO
+// workgroups share a CU (two waves per SIMD hide each other's LDS / MFMA latencies; the 64-wide version above leaves one):
+//  * LDS tiles are 48 + 4 floats wide and the S / dP contractions run over 48 channels, not the zero-padded 64;
+//  * the K_j and V_j operand fragments of S and dP (fixed for the whole query loop) live in registers, already split into
+//    bf16 hi / lo, so V_j needs no LDS tile at all and those two products read one operand from LDS instead of two.
+// 3 tiles of [64][52] + P / dS [64][68] each = 75 KB per workgroup.  Output-channel tiles still span 64 columns: the reads
+// past column 51 of a row land in the next row and only feed output columns >= head_dim, which are never stored.
+struct SabFrag {
+  bf16x8 h[3], l[3];
+};
+__device__ __forceinline__ void sab_frag_load(const float* base, int ld, int row, int L, int hd, int lane, SabFrag& f) {
+  const float* src = base + (long long)min(row, L - 1) * ld;
+  const bool rok = row < L;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int c = 16 * s + 8 * (lane >> 5);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a = *(const f32x4*)(src + min(c, hd - 4)), b = *(const f32x4*)(src + min(c + 4, hd - 4));
+    a = (rok && c < hd) ? a : z;
+    b = (rok && c + 4 < hd) ? b : z;
+    const f32x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    f.h[s] = __builtin_convertvector(v, bf16x8);
+    f.l[s] = __builtin_convertvector(v - __builtin_convertvector(f.h[s], f32x8), bf16x8);
+  }
+}
+// 32x32 tile, A rows k-contiguous in LDS (pitch pa, 48 channels), B from pre-split register fragments
+__device__ __forceinline__ f32x16 sab_mm32_frag(const float* A, int pa, const SabFrag& f, int lane) {
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const float* ar = A + (lane & 31) * pa + 8 * (lane >> 5);
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const f32x4 a0 = *(const f32x4*)(ar + 16 * s), a1 = *(const f32x4*)(ar + 16 * s + 4);
+    const f32x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    const bf16x8 ah = __builtin_convertvector(av, bf16x8);
+    const bf16x8 al = __builtin_convertvector(av - __builtin_convertvector(ah, f32x8), bf16x8);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f.h[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f.l[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, f.h[s], acc, 0, 0, 0);
+  }
+  return acc;
+}
+// acc += A B for operands read element-wise through the functors (split-bf16); the k loop is kept rolled: with two workgroups
+// per CU each wave has 256 registers, and the other wave of the SIMD covers the latency an unrolled loop would hide
+template <class FA, class FB>
+__device__ __forceinline__ void sab_mm32_acc(f32x16& acc, FA a, FB b, int K, int lane) {
+  const int i0 = lane & 31, kk = lane >> 5;
+#pragma unroll 1
+  for (int k = 0; k < K; k += 16) {
+    f32x8 av, bv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      av[j] = a(i0, k + 8 * kk + j);
+      bv[j] = b(k + 8 * kk + j, i0);
+    }
+    const bf16x8 ah = __builtin_convertvector(av, bf16x8), bh = __builtin_convertvector(bv, bf16x8);
+    const bf16x8 al = __builtin_convertvector(av - __builtin_convertvector(ah, f32x8), bf16x8);
+    const bf16x8 bl = __builtin_convertvector(bv - __builtin_convertvector(bh, f32x8), bf16x8);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+  }
+}
+__global__ __launch_bounds__(256, 2) void slate_attn_bwd48_kernel(SabArgs p, int hd) {
+  constexpr int HDL = 48, P = HDL + 4;
+  extern __shared__ float lds[];
+  float* Ks = lds;
+  float* Qs = Ks + 64 * P;
+  float* Gs = Qs + 64 * P;     // dO
+  float* Ps = Gs + 64 * P;     // [64 queries][68]
+  float* Ds = Ps + 64 * 68;    // dS
+  float* ls = Ds + 64 * 68;    // lse [64], dsum [64]
+  const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int k0 = kb * 64;
+  const int ti = (wave >> 1) * 32, tj = (wave & 1) * 32;   // S / dP tile of this wave: queries ti.., keys tj..
+  sab_load<HDL>(p.k + (long long)b * p.k_bs + h * hd, p.ldk, k0, p.Lk, hd, 1.f, Ks);
+  SabFrag kf, vf;
+  sab_frag_load(p.k + (long long)b * p.k_bs + h * hd, p.ldk, k0 + tj + (lane & 31), p.Lk, hd, lane, kf);
+  sab_frag_load(p.v + (long long)b * p.v_bs + h * hd, p.ldv, k0 + tj + (lane & 31), p.Lk, hd, lane, vf);
+  f32x16 dvacc, dkacc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dvacc[i] = dkacc[i] = 0.f;
+  const int ati = (wave >> 1) * 32, atj = (wave & 1) * 32;   // dV / dK tile of this wave: keys ati.., channels atj..
+  const int nqb = (p.Lq + 63) / 64;
+  const float* qbase = p.q + (long long)b * p.q_bs + h * hd;
+  const float* gbase = p.dout + (long long)b * p.o_bs + h * hd;
+  const int qb0 = p.causal ? kb : 0;
+  SabTile<HDL> tq, tg;
+  float pl = 0.f, pd = 0.f;
+  auto prefetch = [&](int qbn) {
+    sab_fetch<HDL>(qbase, p.ldq, qbn * 64, p.Lq, hd, tq);
+    sab_fetch<HDL>(gbase, p.ldo, qbn * 64, p.Lq, hd, tg);
+    if (tid < 64) {
+      const long long idx = ((long long)b * p.H + h) * p.Lq + min(qbn * 64 + tid, p.Lq - 1);
+      pl = p.lse[idx];
+      pd = p.dsum[idx];
+    }
+  };
+  if (qb0 < nqb) prefetch(qb0);
+  for (int qb = qb0; qb < nqb; ++qb) {
+    const int q0 = qb * 64;
+    __syncthreads();
+    sab_put<HDL>(tq, p.scale, Qs);
+    sab_put<HDL>(tg, 1.f, Gs);
+    if (tid < 64) {
+      ls[tid] = pl;
+      ls[64 + tid] = pd;
+    }
+    __syncthreads();
+    if (qb + 1 < nqb) prefetch(qb + 1);
+    const f32x16 s = sab_mm32_frag(Qs + ti * P, P, kf, lane);
+    const f32x16 dp = sab_mm32_frag(Gs + ti * P, P, vf, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qr = ti + SAB_ROW(r, lane), kc = tj + (lane & 31);
+      const int qi = q0 + qr, kj = k0 + kc;
+      const bool ok = qi < p.Lq && kj < p.Lk && (!p.causal || kj <= qi);
+      const float pv = ok ? expf(s[r] - ls[qr]) : 0.f;
+      const float mk = ok ? sab_drop(p, b, h, qi, kj) : 0.f;
+      Ps[qr * 68 + kc] = pv * mk;
+      Ds[qr * 68 + kc] = pv * (dp[r] * mk - ls[64 + qr]);
+    }
+    __syncthreads();
+    sab_mm32_acc(dvacc, [&](int i, int kk) { return Ps[kk * 68 + ati + i]; }, [&](int kk, int j) { return Gs[kk * P + atj + j]; }, 64, lane);
+    sab_mm32_acc(dkacc, [&](int i, int kk) { return Ds[kk * 68 + ati + i]; }, [&](int kk, int j) { return Qs[kk * P + atj + j]; }, 64, lane);
+    {
+      const int qi0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+      f32x16 a3;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a3[i] = 0.f;
+      sab_mm32_acc(a3, [&](int i, int kk) { return Ds[(qi0 + i) * 68 + kk]; }, [&](int kk, int j) { return Ks[kk * P + c0 + j]; }, 64, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = q0 + qi0 + SAB_ROW(r, lane), c = c0 + (lane & 31);
+        if (qi < p.Lq && c < hd) atomicAdd(p.dq + (long long)b * p.q_bs + (long long)qi * p.ldq + h * hd + c, a3[r] * p.scale);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int kj = k0 + ati + SAB_ROW(r, lane), c = atj + (lane & 31);
+    if (kj < p.Lk && c < hd) {
+      p.dv[(long long)b * p.v_bs + (long long)kj * p.ldv + h * hd + c] = dvacc[r];
+      p.dk[(long long)b * p.k_bs + (long long)kj * p.ldk + h * hd + c] = dkacc[r];
+    }
+  }
+}
+
 // Training forward: the same attention with dropout on the weights and the row log-sum-exp kept for the backward pass.
 // One workgroup per (64-query block, head, sequence): S tiles -> LDS, online row max / sum, the (dropped) weights back to LDS,
 // O accumulated as 32x32 tiles in registers and rescaled per row when the running max moves.
@@ -479,7 +628,18 @@ int sf_slate_attention_train_bwd_f32(const float* q, const float* k, const float
     hipLaunchKernelGGL((slate_attn_bwd_kernel<HDP, BF>), g2, dim3(256), lds2, st, a, head_dim);                                  \
   }
   const bool bf3 = sf_get_precision() >= 1;
-  if (hdp == 32) {
+  static const bool bwd48 = !(getenv("SF_ATTN_BWD48") && getenv("SF_ATTN_BWD48")[0] == '0');
+  if (bf3 && head_dim > 32 && head_dim <= 48 && bwd48 && ldk % 4 == 0 && ldv % 4 == 0) {
+    constexpr size_t lds48 = ((size_t)3 * 64 * 52 + 2 * 64 * 68 + 128) * sizeof(float);
+    static bool attr48 = false;
+    if (!attr48) {
+      hipError_t e = hipFuncSetAttribute((const void*)slate_attn_bwd48_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds48);
+      if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+      attr48 = true;
+    }
+    hipLaunchKernelGGL((slate_attn_stats_kernel<64, true>), g1, dim3(256), lds1, st, a, head_dim);
+    hipLaunchKernelGGL(slate_attn_bwd48_kernel, g2, dim3(256), lds48, st, a, head_dim);
+  } else if (hdp == 32) {
     if (bf3) SAB_GO(32, true) else SAB_GO(32, false)
   } else {
     if (bf3) SAB_GO(64, true) else SAB_GO(64, false)

@@ -254,6 +254,7 @@ def test_softmax_argmax_xent_embed(dev):
 
 
 @pytest.mark.parametrize('B,Lq,Lk,H,hd,causal', [(2, 130, 130, 4, 16, True), (1, 257, 257, 2, 64, True), (2, 100, 6, 4, 32, False),
+                                                 (2, 200, 200, 4, 48, True), (1, 70, 131, 3, 48, False),
                                                   (1, 1025, 1025, 1, 64, True), (3, 64, 7, 2, 48, False)])
 def test_slate_attention_backward(dev, precision, B, Lq, Lk, H, hd, causal):
     """sf_slate_attention_bwd_f32 (flash-style adjoint: causal self-attention over patch tokens, cross-attention to the slots)
@@ -286,7 +287,8 @@ def test_slate_attention_backward(dev, precision, B, Lq, Lk, H, hd, causal):
     assert rel_err(dv, vo.grad) < tol_
 
 
-@pytest.mark.parametrize('B,Lq,Lk,H,hd,causal', [(2, 130, 130, 4, 16, True), (1, 257, 257, 2, 64, True), (2, 100, 6, 4, 32, False)])
+@pytest.mark.parametrize('B,Lq,Lk,H,hd,causal', [(2, 130, 130, 4, 16, True), (1, 257, 257, 2, 64, True), (2, 100, 6, 4, 32, False),
+                                                 (2, 200, 200, 4, 48, True)])
 def test_slate_attention_weight_dropout(dev, precision, B, Lq, Lk, H, hd, causal):
     """Training attention with dropout on the weights (sf_slate_attention_train_fwd/bwd_f32): the masks are rebuilt on the host
     from the seed and drive a torch restatement under autograd."""
