@@ -186,6 +186,9 @@ int sf_cross_entropy_f32(const float* x, const long long* target, float* loss_ro
 /* y = softmax((x + add) * scale) per row (add may be NULL): the Gumbel-softmax relaxation of steve_utils.py:26-41 with
  * add = Gumbel noise, scale = 1/tau (steve_slotformer.py:97-98). */
 int sf_softmax_rows_f32(const float* x, const float* add, float scale, float* y, long long R, int V, void* stream);
+/* Backward of sf_cross_entropy_f32's mean loss w.r.t. the logits: dx = (softmax(x) - onehot(target)) * g[0] / R, with g the
+ * upstream gradient as a DEVICE scalar (no host read); V <= 16384 (steve.py:341-344 under autograd). */
+int sf_cross_entropy_bwd_f32(const float* x, const long long* target, const float* g, float* dx, long long R, int V, void* stream);
 /* y = log_softmax(x) per row (the z_logits of dVAE.py:127). */
 int sf_log_softmax_rows_f32(const float* x, float* y, long long R, int V, void* stream);
 /* y[r, :] = softmax((x[r, :] + g[r, :]) * scale), g ~ Gumbel(0, 1) generated inside the kernel as a pure function of

@@ -182,6 +182,7 @@ SIGNATURES = {
     'sf_softmax_rows_f32': (I, [FP, FP, F32, FP, LL, I, VP]),
     'sf_softmax_rows_bwd_f32': (I, [FP, FP, F32, FP, LL, I, VP]),
     'sf_log_softmax_rows_f32': (I, [FP, FP, LL, I, VP]),
+    'sf_cross_entropy_bwd_f32': (I, [FP, VP, FP, FP, LL, I, VP]),
     'sf_gumbel_softmax_rows_f32': (I, [FP, C.c_ulonglong, F32, FP, LL, I, VP]),
     'sf_slate_generate_workspace_bytes': (SZ, [C.POINTER(sf_slate_decoder), I, I]),
     'sf_slate_generate_f32': (I, [C.POINTER(sf_slate_decoder), FP, I, I, VP, FP, VP, SZ, VP]),

@@ -135,7 +135,9 @@ class STEVE(StoSAVi):
         target_token_id = img_token_id.flatten(0, 1).long().contiguous()   # [B*T, h*w]
         in_slots = slots.flatten(0, 1)
         in_token_id = target_token_id[:, :-1].contiguous()
-        pred_token_id = self.trans_decoder(in_slots, in_token_id)[:, -(h * w):]
+        pred_token_id = self.trans_decoder(in_slots, in_token_id)
+        if pred_token_id.shape[1] != h * w:   # (a no-op slice would still cost autograd a zero-filled copy of the logits)
+            pred_token_id = pred_token_id[:, -(h * w):]
         out_dict.update({'pred_token_id': pred_token_id, 'target_token_id': target_token_id})
         if self.use_img_recon_loss:
             # steve.py:327-335: relaxed sample (tau 0.1) of the predicted token map, decoded by the frozen dVAE.  `gumbel`

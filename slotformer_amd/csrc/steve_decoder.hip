@@ -489,6 +489,50 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 // the same for rows of at most 1024 * NV floats (V % 4 == 0, 16-byte aligned rows): the row lives in registers between the
 // passes, so x (and add) are read once and y is written once -- 3 row passes of HBM traffic instead of 7, 2 with hashed noise
+// d/dx of mean_r(-log softmax(x[r])[target[r]]) times an upstream scalar: dx = (softmax(x) - onehot(target)) * g[0] * inv_rows
+// (F.cross_entropy's backward, steve.py:341-344), one read of x and one write of dx
+template <int NV>
+__global__ __launch_bounds__(256) void xent_bwd_rows_kernel(const float* __restrict__ x, const long long* __restrict__ target,
+                                                            const float* __restrict__ g, float inv_rows, float* __restrict__ dx, int V) {
+  const long long r = blockIdx.x;
+  const int t = threadIdx.x;
+  __shared__ float sh[2][4];
+  const int tg = (int)target[r];
+  f32x4 v[NV];
+  float mx = -INFINITY;
+  for (int n = 0; n < NV; ++n) {
+    for (int k = 0; k < 4; ++k) {
+      const int j = (t + 256 * n) * 4 + k;
+      v[n][k] = j < V ? x[r * V + j] : -INFINITY;
+      mx = fmaxf(mx, v[n][k]);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((t & 63) == 0) sh[0][t >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sh[0][0], sh[0][1]), fmaxf(sh[0][2], sh[0][3]));
+  float se = 0.f;
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[n][k] = expf(v[n][k] - mx);
+      se += v[n][k];
+    }
+  }
+  se = sf_sum64(se);
+  if ((t & 63) == 0) sh[1][t >> 6] = se;
+  __syncthreads();
+  const float inv = 1.0f / ((sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]));
+  const float gs = g[0] * inv_rows;
+  for (int n = 0; n < NV; ++n) {
+    for (int k = 0; k < 4; ++k) {
+      const int j = (t + 256 * n) * 4 + k;
+      if (j < V) dx[r * V + j] = (v[n][k] * inv - (j == tg ? 1.f : 0.f)) * gs;
+    }
+  }
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                                float scale, float* __restrict__ y, int V, int noise, uint32_t sseed,
@@ -868,6 +912,18 @@ int sf_softmax_rows_f32(const float* x, const float* add, float scale, float* y,
   SF_REQUIRE(x && y && R >= 0 && V > 0, "sf_softmax_rows_f32: bad arguments");
   if (R == 0) return 0;
   return softmax_rows_launch(x, add, scale, y, R, V, 0, 0u, (hipStream_t)stream);
+}
+// backward of sf_cross_entropy_f32's mean: dx[r, :] = (softmax(x[r, :]) - onehot(target[r])) * g[0] / R, g a DEVICE scalar (the
+// upstream gradient of the loss).  V <= 16384.
+int sf_cross_entropy_bwd_f32(const float* x, const long long* target, const float* g, float* dx, long long R, int V, void* stream) {
+  SF_REQUIRE(x && target && g && dx && R > 0 && V > 0 && V <= 16384, "sf_cross_entropy_bwd_f32: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const float inv_rows = 1.f / (float)R;
+  if (V <= 1024) hipLaunchKernelGGL(xent_bwd_rows_kernel<1>, dim3((unsigned)R), dim3(256), 0, st, x, target, g, inv_rows, dx, V);
+  else if (V <= 4096) hipLaunchKernelGGL(xent_bwd_rows_kernel<4>, dim3((unsigned)R), dim3(256), 0, st, x, target, g, inv_rows, dx, V);
+  else hipLaunchKernelGGL(xent_bwd_rows_kernel<16>, dim3((unsigned)R), dim3(256), 0, st, x, target, g, inv_rows, dx, V);
+  SF_CHECK_LAUNCH();
+  return 0;
 }
 // y[r, :] = log_softmax(x[r, :]) (F.log_softmax over the last dim: the z_logits of dVAE.py:127)
 int sf_log_softmax_rows_f32(const float* x, float* y, long long R, int V, void* stream) {

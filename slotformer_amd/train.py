@@ -601,9 +601,16 @@ class _TokenCrossEntropy(torch.autograd.Function):
     def backward(ctx, g):
         from . import ops
         logits, target = ctx.saved_tensors
-        p = ops.softmax_rows(logits)
-        p.scatter_add_(1, target.view(-1, 1), torch.full((target.numel(), 1), -1.0, device=p.device))
-        return p * (g / logits.shape[0]), None
+        R, V = logits.shape
+        if V > 16384:
+            p = ops.softmax_rows(logits)
+            p.scatter_add_(1, target.view(-1, 1), torch.full((target.numel(), 1), -1.0, device=p.device))
+            return p * (g / R), None
+        dx = torch.empty_like(logits)
+        gs = g.detach().float().reshape(1).contiguous()
+        check(lib().sf_cross_entropy_bwd_f32(logits.data_ptr(), target.data_ptr(), gs.data_ptr(), dx.data_ptr(), R, V,
+                                             torch.cuda.current_stream().cuda_stream))
+        return dx, None
 
 
 def slate_decoder_forward(dec, slots, idx):

@@ -87,7 +87,7 @@ class STEVESlotFormer(SlotFormer):
                 ids = self.dvae.tokenize(data_dict['img'][:, self.history_len:], one_hot=False).flatten(2, 3)
         ids = ids.flatten(0, 1).long().contiguous()                                   # [B*T, h*w]
         logits = self.decoder(pred.flatten(0, 1), ids[:, :-1].contiguous())
-        out['pred_token_id'] = logits[:, -(self.h * self.w):]
+        out['pred_token_id'] = logits if logits.shape[1] == self.h * self.w else logits[:, -(self.h * self.w):]
         out['target_token_id'] = ids
         return out
 
