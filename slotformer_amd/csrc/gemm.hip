@@ -672,7 +672,13 @@ static int dispatch_tiles(const SfGemmArgs& a, hipStream_t stream) {
     if constexpr (ALOAD == ALOAD_CONV_NHWC || ALOAD == ALOAD_DECONV_NHWC) {
       return launch_by_id<ALOAD, LN>(bf3 ? 100 : 28, a, stream);
     } else {
-      if (a.N > 64 && tiles(128, 128) >= 384) return launch_by_id<ALOAD, LN>(bf3 ? 102 : 31, a, stream);
+      if (a.N > 64 && tiles(128, 128) >= 384) {
+        if (!bf3) return launch_by_id<ALOAD, LN>(31, a, stream);
+        // training-size GEMMs (tools/gemm_bench.py train, profiles/r01_gemm_configs.txt): the 64-deep chunk wins for wide outputs
+        // or long contractions, the 128x64 tile for the rest; the 32-deep 128x128 tile only for the narrow pixel-MLP shapes
+        if (a.K % 64 == 0 && a.K >= 128 && (a.N >= 768 || a.K >= 2048)) return launch_by_id<ALOAD, LN>(103, a, stream);
+        return launch_by_id<ALOAD, LN>((a.N <= 256 && a.K <= 128) ? 102 : 100, a, stream);
+      }
       if (tiles(128, 64) >= 384) return launch_by_id<ALOAD, LN>(bf3 ? 100 : 1, a, stream);
       // small-M regime (rollout / slot-level GEMMs): latency-bound, favour many small workgroups
       if (bf3) {

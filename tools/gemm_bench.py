@@ -39,18 +39,24 @@ SHAPES = [  # name, M, N, K, ln
     ('inproj', 1344, 256, 128, False), ('q_sa', 224, 128, 128, True),
     ('pix_fc1', 131072, 128, 64, True), ('pix_fc2', 131072, 128, 128, False), ('pix_kv', 131072, 256, 128, True),
 ]
+TRAIN_SHAPES = [  # STEVE decoder at the Physion training shape (72 frames x 1024 tokens, width 192, vocab 4096) and the dVAE
+    ('head', 73728, 4096, 192, False), ('head_dx', 73728, 192, 4096, False), ('qkv', 73728, 576, 192, False),
+    ('proj', 73728, 192, 192, False), ('ffn1', 73728, 768, 192, False), ('ffn2', 73728, 192, 768, False),
+    ('dvae_1x1', 32768 * 4, 64, 64, False), ('dvae_logits', 32768, 4096, 64, False), ('dvae_z', 32768, 64, 4096, False),
+]
 CFGS = {'small': [3, 4, 7, 105, 106, 107, 108, 109, 115, 121, 122, 123], 'big': [31, 28, 1, 100, 102, 103]}
 
 
 def main():
-    for name, M, N, K, ln in SHAPES:
+    train = len(sys.argv) > 1 and sys.argv[1] == 'train'
+    for name, M, N, K, ln in (TRAIN_SHAPES if train else SHAPES):
         x = torch.randn(M, K, device=dev)
         w = torch.randn(N, K, device=dev) * K**-0.5
         b = torch.randn(N, device=dev)
         g, be = torch.ones(K, device=dev), torch.zeros(K, device=dev)
         res = []
         ref = None
-        for cfg in CFGS['big' if M > 10000 else 'small']:
+        for cfg in ([100, 102, 103, 107, 108, 122] if train else CFGS['big' if M > 10000 else 'small']):
             os.environ['SF_GEMM_CFG'] = str(cfg)
             try:
                 out = ops.linear(x, w, b, ln=(g, be) if ln else None)
@@ -65,6 +71,9 @@ def main():
         gf = 2.0 * M * N * K
         print(f'{name:10s} M={M} N={N} K={K} ln={ln}: ' + '  '.join(f'cfg{c}:{t:.1f}us' for t, c, _ in res) +
               f'   best {gf / res[0][0] / 1e6:.1f} TF  maxerr {max(e for _, _, e in res if isinstance(e, float)):.1e}')
+    if train:
+        os.environ.pop('SF_GEMM_CFG', None)
+        return
     # conv
     x = torch.randn(32, 64, 64, 64, device=dev)
     w = ops.pack_conv_weight(torch.randn(64, 64, 5, 5, device=dev) * 0.03)
