@@ -666,8 +666,9 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 }
 
 // stage 2 of every split reduction: out[i] = sum_g partial[g][i]  (fixed order: four interleaved chains, then their sum)
+// (columns >= n4a go to out2 when it is given: one launch writes d_gamma and d_beta of a LayerNorm)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                              int G, long long n4) {
+                                                              int G, long long n4, float* __restrict__ out2, long long n4a) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const float4* p = reinterpret_cast<const float4*>(partial) + i;
@@ -691,14 +692,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   r.y = (a[0].y + a[1].y) + (a[2].y + a[3].y);
   r.z = (a[0].z + a[1].z) + (a[2].z + a[3].z);
   r.w = (a[0].w + a[1].w) + (a[2].w + a[3].w);
-  reinterpret_cast<float4*>(out)[i] = r;
+  if (out2 && i >= n4a) reinterpret_cast<float4*>(out2)[i - n4a] = r;
+  else reinterpret_cast<float4*>(out)[i] = r;
 }
 
 // the same reduction for few columns and many partials (bias / LayerNorm / 64x64 weight gradients: up to 512 partials of 16
 // to 1024 float4 columns, where one thread per column leaves the chip idle behind a handful of long serial chains): a
 // workgroup takes 16 columns, its 16 thread rows each sum every 16th partial, LDS combines the rows in a fixed tree.
 __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                                   int G, long long n4) {
+                                                                   int G, long long n4, float* __restrict__ out2, long long n4a) {
   const int c = threadIdx.x & 15, q = threadIdx.x >> 4;
   const long long i = (long long)blockIdx.x * 16 + c;
   __shared__ f32x4 sh[16][17];
@@ -714,13 +716,17 @@ __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* 
     if (q < w) sh[q][c] += sh[q + w][c];
     __syncthreads();
   }
-  if (q == 0 && i < n4) reinterpret_cast<f32x4*>(out)[i] = sh[0][c];
+  if (q == 0 && i < n4) {
+    if (out2 && i >= n4a) reinterpret_cast<f32x4*>(out2)[i - n4a] = sh[0][c];
+    else reinterpret_cast<f32x4*>(out)[i] = sh[0][c];
+  }
 }
-inline void launch_reduce_partials(const float* partial, float* out, int G, long long n4, hipStream_t st) {
+inline void launch_reduce_partials(const float* partial, float* out, int G, long long n4, hipStream_t st, float* out2 = nullptr,
+                                   long long n4a = 0) {
   if (G >= 32 && n4 <= 16384)
-    hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, partial, out, G, n4);
+    hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, partial, out, G, n4, out2, n4a);
   else
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, partial, out, G, n4);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, partial, out, G, n4, out2, n4a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1062,7 +1068,13 @@ int grad_ln(const float* x, const float* dy, float* dgamma, float* dbeta, long l
   G = (int)((rows + rpg - 1) / rpg);
   hipLaunchKernelGGL(ln_param_partial_kernel, dim3(G), dim3(256), 0, st, x, dy, w.partial, rows, rpg, D, eps);
   SF_CHECK_LAUNCH();
-  // partial is [G][2][D]: reduce both rows at once into a [2][D] scratch behind the partials, then copy out
+  // partial is [G][2][D]: one reduction over both rows, the first D columns to d_gamma and the rest to d_beta
+  if ((((uintptr_t)dgamma | (uintptr_t)dbeta) & 15) == 0) {
+    launch_reduce_partials(w.partial, dgamma, G, (long long)2 * D / 4, st, dbeta, (long long)D / 4);
+    SF_CHECK_LAUNCH();
+    return 0;
+  }
+  // destinations that are not 16-byte aligned (views at odd offsets of a flat bucket): through a [2][D] scratch behind the partials
   float* both = w.partial + (size_t)G * 2 * D;
   launch_reduce_partials(w.partial, both, G, (long long)2 * D / 4, st);
   SF_CHECK_LAUNCH();
