@@ -624,6 +624,9 @@ static int launch_by_id(int id, const SfGemmArgs& a, hipStream_t st) {
       case 108: return launch_cfg<64, 64, 2, 2, 2, 128, 2, 2, ALOAD, LN, true>(a, st);
       case 109: return launch_cfg<32, 64, 1, 2, 4, 128, 2, 2, ALOAD, LN, true>(a, st);
       case 115: return launch_cfg<32, 32, 1, 1, 8, 256, 2, 2, ALOAD, LN, true>(a, st);
+      // single-buffered 128x64 tiles: 31 / 55 KB of LDS, several workgroups per CU cover each other's prologue / epilogue
+      case 132: return launch_cfg<128, 64, 4, 2, 1, 64, 1, 1, ALOAD, LN, true>(a, st);
+      case 133: return launch_cfg<128, 64, 4, 2, 1, 32, 1, 1, ALOAD, LN, true>(a, st);
       default: break;
     }
   }
@@ -634,6 +637,10 @@ static int launch_by_id(int id, const SfGemmArgs& a, hipStream_t st) {
       case 121: return launch_cfg<64, 64, 2, 2, 1, 64, 0, 2, ALOAD, LN, true>(a, st);
       case 122: return launch_cfg<64, 64, 2, 2, 2, 64, 0, 2, ALOAD, LN, true>(a, st);
       case 123: return launch_cfg<32, 64, 1, 2, 4, 128, 0, 2, ALOAD, LN, true>(a, st);
+      // single-buffered 128x128 tiles: 41 / 74 KB of LDS, so two or three workgroups share a CU and cover each other's
+      // prologue / epilogue (the double-buffered 128x128 tiles above own a CU alone)
+      case 130: return launch_cfg<128, 128, 2, 4, 1, 32, 1, 1, ALOAD, LN, true>(a, st);
+      case 131: return launch_cfg<128, 128, 2, 4, 1, 64, 1, 1, ALOAD, LN, true>(a, st);
       default: break;
     }
   }
@@ -670,16 +677,17 @@ static int dispatch_tiles(const SfGemmArgs& a, hipStream_t stream) {
     const bool bf3 = sf_get_precision() >= 1;
     // choices below come from tools/gemm_bench.py on MI355X (profiles/r01_gemm_configs.txt)
     if constexpr (ALOAD == ALOAD_CONV_NHWC || ALOAD == ALOAD_DECONV_NHWC) {
-      return launch_by_id<ALOAD, LN>(bf3 ? 100 : 28, a, stream);
+      static const int conv_cfg = getenv("SF_CONV_CFG") ? atoi(getenv("SF_CONV_CFG")) : 132;
+      return launch_by_id<ALOAD, LN>(bf3 ? conv_cfg : 28, a, stream);
     } else {
+      // big problems (tools/gemm_bench.py [train], profiles/r01_gemm_configs.txt): the single-buffered tiles win everywhere --
+      // with 31 .. 74 KB of LDS two or more workgroups share a CU, which hides the fill of the first chunk and the C store
+      // that a double-buffered 128x128 workgroup (147 KB, alone on its CU) leaves exposed
       if (a.N > 64 && tiles(128, 128) >= 384) {
         if (!bf3) return launch_by_id<ALOAD, LN>(31, a, stream);
-        // training-size GEMMs (tools/gemm_bench.py train, profiles/r01_gemm_configs.txt): the 64-deep chunk wins for wide outputs
-        // or long contractions, the 128x64 tile for the rest; the 32-deep 128x128 tile only for the narrow pixel-MLP shapes
-        if (a.K % 64 == 0 && a.K >= 128 && (a.N >= 768 || a.K >= 2048)) return launch_by_id<ALOAD, LN>(103, a, stream);
-        return launch_by_id<ALOAD, LN>((a.N <= 256 && a.K <= 128) ? 102 : 100, a, stream);
+        return launch_by_id<ALOAD, LN>((a.N % 128 == 0 || a.N >= 512) ? 131 : 133, a, stream);
       }
-      if (tiles(128, 64) >= 384) return launch_by_id<ALOAD, LN>(bf3 ? 100 : 1, a, stream);
+      if (tiles(128, 64) >= 384) return launch_by_id<ALOAD, LN>(bf3 ? (a.K >= 2048 ? 132 : 133) : 1, a, stream);
       // small-M regime (rollout / slot-level GEMMs): latency-bound, favour many small workgroups
       if (bf3) {
         if (a.K >= 512) return launch_by_id<ALOAD, LN>(a.M >= 512 ? 109 : 115, a, stream);

@@ -44,7 +44,7 @@ TRAIN_SHAPES = [  # STEVE decoder at the Physion training shape (72 frames x 102
     ('proj', 73728, 192, 192, False), ('ffn1', 73728, 768, 192, False), ('ffn2', 73728, 192, 768, False),
     ('dvae_1x1', 32768 * 4, 64, 64, False), ('dvae_logits', 32768, 4096, 64, False), ('dvae_z', 32768, 64, 4096, False),
 ]
-CFGS = {'small': [3, 4, 7, 105, 106, 107, 108, 109, 115, 121, 122, 123], 'big': [31, 28, 1, 100, 102, 103]}
+CFGS = {'small': [3, 4, 7, 105, 106, 107, 108, 109, 115, 121, 122, 123], 'big': [100, 102, 103, 130, 131, 132, 133]}
 
 
 def main():
@@ -56,7 +56,7 @@ def main():
         g, be = torch.ones(K, device=dev), torch.zeros(K, device=dev)
         res = []
         ref = None
-        for cfg in ([100, 102, 103, 107, 108, 122] if train else CFGS['big' if M > 10000 else 'small']):
+        for cfg in ([100, 102, 103, 107, 130, 131, 132, 133] if train else CFGS['big' if M > 10000 else 'small']):
             os.environ['SF_GEMM_CFG'] = str(cfg)
             try:
                 out = ops.linear(x, w, b, ln=(g, be) if ln else None)
