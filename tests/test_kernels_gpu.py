@@ -31,7 +31,9 @@ def close(a, b, rtol=2e-5, atol=2e-5):
 
 @pytest.mark.parametrize('M,N,K', [(1344, 768, 256), (1344, 256, 1024), (224, 384, 128), (7, 128, 256),
                                    (131072, 128, 64), (4096 * 3, 256, 128), (100, 36, 64), (33, 64, 192),
-                                   (1344, 1024, 256), (1344, 256, 256)])
+                                   (1344, 1024, 256), (1344, 256, 256),
+                                   # training-size problems: the single-buffered big tiles (ragged M, N not a multiple of the tile, long K)
+                                   (50000, 576, 192), (49157, 192, 192), (49152, 64, 2048)])
 @pytest.mark.parametrize('mode', ['plain', 'ln_relu_res'])
 def test_linear(dev, M, N, K, mode, precision):
     from slotformer_amd import ops
