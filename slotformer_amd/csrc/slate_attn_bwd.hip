@@ -317,40 +317,76 @@ __device__ __forceinline__ void sab_frag_load(const float* base, int ld, int row
     f.l[s] = __builtin_convertvector(v - __builtin_convertvector(f.h[s], f32x8), bf16x8);
   }
 }
-// 32x32 tile, A rows k-contiguous in LDS (pitch pa, 48 channels), B from pre-split register fragments
-__device__ __forceinline__ f32x16 sab_mm32_frag(const float* A, int pa, const SabFrag& f, int lane) {
+// Every LDS tile of this kernel holds its elements ALREADY split: one 32-bit word = bf16 hi (upper half) | bf16 lo (lower half),
+// produced once where the element is written.  An operand fragment is then 8 words -> two v_perm_b32 per word pair instead of
+// the ~24 conversion instructions per fragment that the f32 tiles cost every time a wave read them (30 fragments per block
+// pair and wave: the conversions were the largest share of this kernel's issue slots).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned sab_pack1(float v) {
+  const __bf16 h = (__bf16)v;
+  const __bf16 l = (__bf16)(v - (float)h);
+  return ((unsigned)__builtin_bit_cast(unsigned short, h) << 16) | (unsigned)__builtin_bit_cast(unsigned short, l);
+}
+__device__ __forceinline__ void sab_unpack8(const unsigned (&w)[8], bf16x8& h, bf16x8& l) {
+  u32x4 hv, lv;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    hv[q] = __builtin_amdgcn_perm(w[2 * q + 1], w[2 * q], 0x07060302u);
+    lv[q] = __builtin_amdgcn_perm(w[2 * q + 1], w[2 * q], 0x05040100u);
+  }
+  h = __builtin_bit_cast(bf16x8, hv);
+  l = __builtin_bit_cast(bf16x8, lv);
+}
+// 32x32 tile, A rows k-contiguous in a packed LDS tile (pitch pa words, 48 channels), B from pre-split register fragments
+__device__ __forceinline__ f32x16 sab_mm32_frag(const unsigned* A, int pa, const SabFrag& f, int lane) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const float* ar = A + (lane & 31) * pa + 8 * (lane >> 5);
+  const unsigned* ar = A + (lane & 31) * pa + 8 * (lane >> 5);
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
-    const f32x4 a0 = *(const f32x4*)(ar + 16 * s), a1 = *(const f32x4*)(ar + 16 * s + 4);
-    const f32x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-    const bf16x8 ah = __builtin_convertvector(av, bf16x8);
-    const bf16x8 al = __builtin_convertvector(av - __builtin_convertvector(ah, f32x8), bf16x8);
+    const u32x4 a0 = *(const u32x4*)(ar + 16 * s), a1 = *(const u32x4*)(ar + 16 * s + 4);
+    const unsigned w[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    bf16x8 ah, al;
+    sab_unpack8(w, ah, al);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f.h[s], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f.l[s], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, f.h[s], acc, 0, 0, 0);
   }
   return acc;
 }
-// acc += A B for operands read element-wise through the functors (split-bf16); the k loop is kept rolled: with two workgroups
+// packed variants of sab_load / sab_put for the 48-wide tiles
+__device__ __forceinline__ void sab_load_packed48(const float* base, int ld, int r0, int L, int hd, unsigned* dst) {
+  for (int i = threadIdx.x; i < 64 * 48; i += 256) {
+    const int r = i / 48, c = i - r * 48;
+    dst[r * 52 + c] = sab_pack1((r0 + r < L && c < hd) ? base[(long long)(r0 + r) * ld + c] : 0.f);
+  }
+}
+__device__ __forceinline__ void sab_put_packed48(const SabTile<48>& t, float mul, unsigned* dst) {
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const int i = threadIdx.x + 256 * n, r = i / 12, c = (i - r * 12) * 4;
+    const f32x4 v = t.v[n] * mul;
+    const u32x4 w = {sab_pack1(v[0]), sab_pack1(v[1]), sab_pack1(v[2]), sab_pack1(v[3])};
+    *(u32x4*)(dst + r * 52 + c) = w;
+  }
+}
+// acc += A B for operands read word-wise (packed hi|lo) through the functors; the k loop is kept rolled: with two workgroups
 // per CU each wave has 256 registers, and the other wave of the SIMD covers the latency an unrolled loop would hide
 template <class FA, class FB>
 __device__ __forceinline__ void sab_mm32_acc(f32x16& acc, FA a, FB b, int K, int lane) {
   const int i0 = lane & 31, kk = lane >> 5;
 #pragma unroll 1
   for (int k = 0; k < K; k += 16) {
-    f32x8 av, bv;
+    unsigned aw[8], bw[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      av[j] = a(i0, k + 8 * kk + j);
-      bv[j] = b(k + 8 * kk + j, i0);
+      aw[j] = a(i0, k + 8 * kk + j);
+      bw[j] = b(k + 8 * kk + j, i0);
     }
-    const bf16x8 ah = __builtin_convertvector(av, bf16x8), bh = __builtin_convertvector(bv, bf16x8);
-    const bf16x8 al = __builtin_convertvector(av - __builtin_convertvector(ah, f32x8), bf16x8);
-    const bf16x8 bl = __builtin_convertvector(bv - __builtin_convertvector(bh, f32x8), bf16x8);
+    bf16x8 ah, al, bh, bl;
+    sab_unpack8(aw, ah, al);
+    sab_unpack8(bw, bh, bl);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
@@ -359,16 +395,16 @@ __device__ __forceinline__ void sab_mm32_acc(f32x16& acc, FA a, FB b, int K, int
 __global__ __launch_bounds__(256, 2) void slate_attn_bwd48_kernel(SabArgs p, int hd) {
   constexpr int HDL = 48, P = HDL + 4;
   extern __shared__ float lds[];
-  float* Ks = lds;
-  float* Qs = Ks + 64 * P;
-  float* Gs = Qs + 64 * P;     // dO
-  float* Ps = Gs + 64 * P;     // [64 queries][68]
-  float* Ds = Ps + 64 * 68;    // dS
-  float* ls = Ds + 64 * 68;    // lse [64], dsum [64]
+  unsigned* Ks = (unsigned*)lds;   // every tile: packed bf16 hi | lo words
+  unsigned* Qs = Ks + 64 * P;
+  unsigned* Gs = Qs + 64 * P;      // dO
+  unsigned* Ps = Gs + 64 * P;      // [64 queries][68]
+  unsigned* Ds = Ps + 64 * 68;     // dS
+  float* ls = (float*)(Ds + 64 * 68);   // lse [64], dsum [64]
   const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int k0 = kb * 64;
   const int ti = (wave >> 1) * 32, tj = (wave & 1) * 32;   // S / dP tile of this wave: queries ti.., keys tj..
-  sab_load<HDL>(p.k + (long long)b * p.k_bs + h * hd, p.ldk, k0, p.Lk, hd, 1.f, Ks);
+  sab_load_packed48(p.k + (long long)b * p.k_bs + h * hd, p.ldk, k0, p.Lk, hd, Ks);
   SabFrag kf, vf;
   sab_frag_load(p.k + (long long)b * p.k_bs + h * hd, p.ldk, k0 + tj + (lane & 31), p.Lk, hd, lane, kf);
   sab_frag_load(p.v + (long long)b * p.v_bs + h * hd, p.ldv, k0 + tj + (lane & 31), p.Lk, hd, lane, vf);
@@ -395,8 +431,8 @@ __global__ __launch_bounds__(256, 2) void slate_attn_bwd48_kernel(SabArgs p, int
   for (int qb = qb0; qb < nqb; ++qb) {
     const int q0 = qb * 64;
     __syncthreads();
-    sab_put<HDL>(tq, p.scale, Qs);
-    sab_put<HDL>(tg, 1.f, Gs);
+    sab_put_packed48(tq, p.scale, Qs);
+    sab_put_packed48(tg, 1.f, Gs);
     if (tid < 64) {
       ls[tid] = pl;
       ls[64 + tid] = pd;
@@ -412,8 +448,8 @@ __global__ __launch_bounds__(256, 2) void slate_attn_bwd48_kernel(SabArgs p, int
       const bool ok = qi < p.Lq && kj < p.Lk && (!p.causal || kj <= qi);
       const float pv = ok ? expf(s[r] - ls[qr]) : 0.f;
       const float mk = ok ? sab_drop(p, b, h, qi, kj) : 0.f;
-      Ps[qr * 68 + kc] = pv * mk;
-      Ds[qr * 68 + kc] = pv * (dp[r] * mk - ls[64 + qr]);
+      Ps[qr * 68 + kc] = sab_pack1(pv * mk);
+      Ds[qr * 68 + kc] = sab_pack1(pv * (dp[r] * mk - ls[64 + qr]));
     }
     __syncthreads();
     sab_mm32_acc(dvacc, [&](int i, int kk) { return Ps[kk * 68 + ati + i]; }, [&](int kk, int j) { return Gs[kk * P + atj + j]; }, 64, lane);
