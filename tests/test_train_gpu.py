@@ -899,3 +899,20 @@ def test_in_kernel_gumbel_noise_and_log_softmax(dev, V):
     (train.gumbel_softmax(xa, None, 0.7, seed=seed) * dy).sum().backward()
     (train.gumbel_softmax(xb, noise.to(dev), 0.7) * dy).sum().backward()
     assert l2_err(xa.grad, xb.grad.cpu()) < 1e-4
+
+
+@pytest.mark.parametrize('R,V', [(37, 64), (100, 1000), (16, 4096), (9, 4097), (5, 10000)])
+def test_token_cross_entropy_backward_vs_torch(dev, R, V):
+    """sf_cross_entropy_bwd_f32 (one kernel: softmax - onehot, scaled by the upstream gradient read on the device) against
+    torch autograd of F.cross_entropy, on the register-resident row sizes and beyond, with a non-unit upstream factor."""
+    from slotformer_amd import train
+    rs = np.random.RandomState(R + V)
+    x = torch.from_numpy((rs.standard_normal((R, V)) * 3).astype(np.float32))
+    tgt = torch.from_numpy(rs.randint(0, V, size=R).astype(np.int64))
+    xr = x.clone().requires_grad_(True)
+    (torch.nn.functional.cross_entropy(xr, tgt) * 0.37).backward()
+    xd = x.to(dev).requires_grad_(True)
+    loss = train.token_cross_entropy(xd, tgt.to(dev))
+    (loss * 0.37).backward()
+    assert abs(float(loss.detach()) - float(torch.nn.functional.cross_entropy(x, tgt))) < 1e-5 * max(1., float(loss.detach()))
+    assert l2_err(xd.grad, xr.grad) < 1e-5
