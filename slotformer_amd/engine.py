@@ -45,6 +45,13 @@ class _Plan:
         self.struct = None
         self.sig = None
 
+    # plans hold ctypes structures with raw pointers: a copied / pickled module starts without one and rebuilds it
+    def __deepcopy__(self, memo):
+        return _Plan()
+
+    def __reduce__(self):
+        return (_Plan, ())
+
     def dp(self, t):
         if t is None:
             return None
@@ -53,6 +60,19 @@ class _Plan:
             t = t.float().contiguous()
         self.keep.append(t)
         return t.data_ptr()
+
+
+_PLAN_ATTRS = ('_sf_plan', '_sf_train_plan', '_sf_dec_plan', '_plan', '_cat', '_catw', '_slate_plan')
+
+
+def invalidate(module):
+    """Drop every cached plan (packed / derived weight copies) below `module`.  The caches are keyed on
+    (data_ptr, _version) of the parameters, which follows optimizer steps and ordinary in-place ops; writes that bypass
+    torch's version counter (`p.data.copy_()`, raw-pointer kernels) need this call -- or `torch._C._increment_version(p)`."""
+    for m in module.modules():
+        for a in _PLAN_ATTRS:
+            if a in m.__dict__:
+                del m.__dict__[a]
 
 
 def _signature(module):

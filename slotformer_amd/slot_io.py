@@ -51,7 +51,10 @@ def save_phyre_slots(save_root, data_idx, slots, vid_len):
 
 
 def phyre_resume_index(save_root, start, end):
-    """First index in [start, end) that still has to be processed: everything before the newest existing
-    file is kept, the newest one is redone (it may be corrupted) -- extract_phyre_slots.py:45-53."""
-    done = [i for i in range(start, end) if os.path.exists(phyre_path(save_root, i))]
-    return max(done) if done else start
+    """First index in [start, end) that still has to be processed (extract_phyre_slots.py:45-53): scan forward, stop at
+    the FIRST missing file and redo the one before it (it may have been truncated by the crash).  Files beyond a gap
+    are not trusted -- every index from the returned one on is (re)written."""
+    idx = start
+    while idx < end and os.path.exists(phyre_path(save_root, idx)):
+        idx += 1
+    return max(idx - 1, start)

@@ -111,6 +111,13 @@ class _Rollout(torch.autograd.Function):
 
 def rollout_with_grad(r, x, pred_len):
     """SlotRollouter.forward under autograd (slotformer.py:85-126).  x [B, history_len, N, C] -> [B, pred_len, N, C]."""
+    for name in ('enc_t_pe', 'enc_slots_pe'):
+        pe = getattr(r, name, None)
+        if isinstance(pe, torch.nn.Parameter) and pe.requires_grad:
+            # the position tables enter the kernels as one folded constant (engine.rollouter_plan: pe_tok) and
+            # sf_rollout_train_bwd_f32 produces no gradient for them: refuse rather than train with frozen tables
+            raise NotImplementedError(f'slotformer_amd: learnable position encodings ({name}.requires_grad) are not trained by the HIP '
+                                      "path; use t_pe='sin' / slots_pe='' (the reference's configs) or freeze the table")
     layer0 = r.transformer_encoder.layers[0]
     p_drop = float(layer0.dropout.p) if r.training else 0.0
     seed = int(torch.randint(0, 2**62, (1, )).item()) if p_drop > 0 else 0
@@ -856,6 +863,11 @@ class FlatAdam:
         check(lib().sf_adam_flat_f32(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                      self.flat.numel(), self.steps, self.lr, float(self.betas[0]), float(self.betas[1]), self.eps,
                                      torch.cuda.current_stream().cuda_stream))
+        # The kernel wrote the parameters through a raw pointer: tell torch (and, through `_version`, every plan cache
+        # in engine.py that is keyed on (data_ptr, _version)) that their contents changed -- otherwise derived / packed
+        # weight copies built before this step would keep being served.
+        for p in self.params:
+            torch._C._increment_version(p)
 
 
 class amp_bf16:

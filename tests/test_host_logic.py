@@ -171,3 +171,10 @@ def test_slot_file_formats(tmp_path):
         slot_io.save_phyre_slots(root, i, slots[0], vid_len=9)
     assert np.load(slot_io.phyre_path(root, 11)).shape == (9, 7, 128)
     assert slot_io.phyre_resume_index(root, 10, 20) == 12  # newest file is redone
+    # a gap (crashed worker, other split bounds): the reference's loop (extract_phyre_slots.py:45-51) stops at the FIRST
+    # missing file and restarts one before it -- files beyond the gap do not move the restart point
+    slot_io.save_phyre_slots(root, 15, slots[0], vid_len=9)
+    assert slot_io.phyre_resume_index(root, 10, 20) == 12
+    for i in range(13, 20):
+        slot_io.save_phyre_slots(root, i, slots[0], vid_len=9)
+    assert slot_io.phyre_resume_index(root, 10, 20) == 19   # everything present: the last one is redone
