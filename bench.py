@@ -10,6 +10,10 @@ frames/s = n_gpus * B * (6 + 50) * steps / wall.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+The timed schedule is the product one: `slotformer_amd.pipeline.EncodeRolloutPipeline` (the same object
+`harness.extract_and_rollout` uses, tested bit-identical to the serial path in tests/test_pipeline_gpu.py), fed from a
+ring of three DIFFERENT resident inputs, with the results of every batch copied out of the slot buffers.
+
 Multi-GPU: videos shard on the batch axis, one process per GPU, weights replicated, NO
 collective on the timed path -> weak scaling with B=32 per GPU.
 """
@@ -17,12 +21,12 @@ import argparse
 import ctypes as C
 import json
 import os
+import platform
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -31,22 +35,25 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dens
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak; bf16x3 issues 3 bf16 MFMA flops per algorithmic flop
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec peak (6.3 TB/s achievable)
 T_BURN, T_ROLL, RES = 6, 50, 128
+N_SLOTS, SLOT_D = 7, 128
 CLS_NAMES = ['conv_nhwc_implicit_gemm', 'conv_first', 'linear_gemm', 'slot_attn_iter', 'slot_update', 'attention', 'ffn_fused']
+ROLL_FLOPS_PER_FRAME = 274.7e6   # algorithmic FLOPs per predicted frame per video
+ENC_FLOPS_PER_FRAME = 3.06e9     # SURVEY.md 8d / DESIGN.md 4: per encoded frame
 
 
 def c2_configs():
-    import golden_util as gu
-    return gu.C2_SAVI, gu.C2_ROLL
+    from slotformer_amd import configs
+    return configs.C2_SAVI, configs.C2_ROLL
 
 
 def build_models(dev):
     """Random-init weights of the C2 architecture (torch default initialisers, seed 0)."""
-    import golden_util as gu
+    from slotformer_amd import configs
     from slotformer_amd.base_slots import build_model
     from slotformer_amd.video_prediction.models import SlotRollouter
     scfg, rcfg = c2_configs()
     torch.manual_seed(0)
-    savi = build_model(gu.ParamsView(scfg)).eval()
+    savi = build_model(configs.ParamsView(scfg)).eval()
     savi.testing = True
     roll = SlotRollouter(**rcfg['rollout_dict']).eval()
     return savi.to(dev), roll.to(dev)
@@ -57,17 +64,19 @@ def synthetic_img(B, seed=1234):
     return torch.from_numpy((rs.rand(B, T_BURN, 3, RES, RES) * 2 - 1).astype(np.float32))
 
 
-def pmc_traffic(kernel_key):
-    """HBM-side bytes per launch from the committed PMC passes (profiles/*_pmc_traffic.json, newest round);
-    None when no PMC summary has been committed."""
+def committed_profile(key):
+    """Entry `key` of the newest committed PMC summary (profiles/r*_pmc_traffic.json); {} when absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
     if not files:
-        return None
+        return {}
     try:
-        return json.load(open(files[-1]))[kernel_key]['traffic_bytes_per_launch']
-    except (KeyError, ValueError):
-        return None
+        d = json.load(open(files[-1])).get(key, {})
+        d = dict(d)
+        d['source'] = os.path.relpath(files[-1], ROOT)
+        return d
+    except ValueError:
+        return {}
 
 
 def read_profile(lib):
@@ -80,21 +89,31 @@ def read_profile(lib):
     return out
 
 
+def cpu_model_string():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(sample_B):
     """The oracle (CPU port of the reference path, torch fp32) timed on the host cores on a
     bounded sample: sample_B videos of the same workload."""
-    import golden_util as gu
     import oracle
+    from slotformer_amd import configs
     scfg, rcfg = c2_configs()
     from slotformer_amd.base_slots import build_model
     from slotformer_amd.video_prediction.models import SlotRollouter
     torch.manual_seed(0)
-    savi = build_model(gu.ParamsView(scfg))
+    savi = build_model(configs.ParamsView(scfg))
     roll = SlotRollouter(**rcfg['rollout_dict'])
     ssd = {k: v.detach() for k, v in savi.state_dict().items()}
     rsd = {'rollouter.' + k: v.detach() for k, v in roll.state_dict().items()}
     img = synthetic_img(sample_B)
-    noise = torch.randn(sample_B, T_BURN, 7, 128)
+    noise = torch.randn(sample_B, T_BURN, N_SLOTS, SLOT_D)
 
     def run():
         with torch.no_grad():
@@ -119,10 +138,10 @@ def cpu_baseline(sample_B):
         run()
         reps += 1
     dt = (time.perf_counter() - t0) / reps
-    return dict(value=sample_B * (T_BURN + T_ROLL) / dt, unit='frames/s', cores=best_t, kind='port',
+    return dict(value=sample_B * (T_BURN + T_ROLL) / dt, unit='frames/s', cores=best_t, kind='port', cpu=cpu_model_string(),
                 sample=f'oracle (torch-CPU fp32 restatement of the reference path), {sample_B} of 32 videos, '
                 f'{reps} passes of encode 6 frames + 50-step rollout, {dt:.2f} s per pass, '
-                f'{best_t} threads (fastest of 8/16/32/64) on a {ncpu}-hardware-thread host')
+                f'{best_t} threads (fastest of 8/16/32/64) on a {ncpu}-hardware-thread host ({cpu_model_string()})')
 
 
 def log(msg):
@@ -140,8 +159,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8)
     ap.add_argument('--no-overlap', action='store_true', help='run encode and rollout of each batch back-to-back on one stream '
-                    '(default: encode of batch i+1 overlaps the rollout graph of batch i on a second HIP stream)')
-    ap.add_argument('--rollout-streams', type=int, default=1, help='batch groups rolled out concurrently on separate HIP streams')
+                    '(default: the batch pipeline of slotformer_amd/pipeline.py)')
     ap.add_argument('--precision', choices=['bf16x3', 'f32'], default=None, help='matrix arithmetic mode (default: library default = bf16x3)')
     ap.add_argument('--pcie', action='store_true', help='also time a host-to-host (PCIe-inclusive) variant; reported separately')
     ap.add_argument('--breakdown', action='store_true', help='extra untimed pass with every kernel class timed')
@@ -162,276 +180,133 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)  # RCCL
 
     from slotformer_amd import engine, _lib
+    from slotformer_amd.pipeline import EncodeRolloutPipeline
     lib = _lib.lib()
     if args.precision:
         lib.sf_set_precision(1 if args.precision == 'bf16x3' else 0)
     prec = 'bf16x3' if lib.sf_get_precision() == 1 else 'f32'
     B = args.batch
     savi, roll = build_models(dev)
-    img = synthetic_img(B, seed=1234 + rank).to(dev)
-    N, D = 7, 128
-    bufs = [torch.zeros(B, T_BURN + T_ROLL, N, D, device=dev) for _ in range(2)]
-    buf = bufs[0]
+    # a ring of three DIFFERENT resident inputs: consecutive batches never see the same frames
+    ring = [synthetic_img(B, seed=1234 + 1000 * k + rank).to(dev) for k in range(3)]
+    cu_word = int(os.environ.get('SF_BENCH_CU_SPLIT', 'ff'), 16)
+    steal = int(os.environ.get('SF_BENCH_STEAL', '1'))
 
-    def encode(dst=None, feat_pre=None):
-        noise = torch.randn(B, T_BURN, N, D, device=dev)  # fresh eps ~ N(0,1) per frame (savi.py:363-365), one launch
-        post, _, _ = engine.savi_encode(savi, img, noise=noise, feat_pre=feat_pre)
-        (buf if dst is None else dst)[:, :T_BURN].copy_(post)
-
-    S = max(1, args.rollout_streams)
-    assert B % S == 0
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
-
-    def rollout_eager():
-        if S == 1:
-            engine.rollout(roll, buf, T_BURN, T_ROLL)
-            return
-        cur = torch.cuda.current_stream()
-        g = B // S
-        for i, st in enumerate(streams):
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                engine.rollout(roll, buf[i * g:(i + 1) * g], T_BURN, T_ROLL, ws_slot=i)
-        for st in streams:
-            cur.wait_stream(st)
-
-    graph = None
     with torch.no_grad():
-        log('first eager step')
-        encode()
-        torch.cuda.synchronize()
-        log('encode ok')
-        rollout_eager()
-        torch.cuda.synchronize()
-        log('rollout ok')
-        if not args.no_graph:
-            try:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    rollout_eager()
-                graph.replay()
-                torch.cuda.synchronize()
-                log('graph captured + replayed')
-            except Exception as e:  # noqa: BLE001
-                if rank == 0:
-                    print(f'[bench] hipGraph capture failed ({e}); eager rollout', file=sys.stderr)
-                graph = None
+        log('building the pipeline (first eager rollouts + graph capture)')
+        pipe = EncodeRolloutPipeline(savi, roll, B, T_BURN, T_ROLL, encode_cu_word=cu_word, steal_steps=steal,
+                                     use_graph=not args.no_graph)
+        overlap = not args.no_overlap
+        graph = pipe.graphs[0] if pipe.graphs else None
 
-        def step():
-            encode()
-            if graph is not None:
-                graph.replay()
-            else:
-                rollout_eager()
-
-        # ---- software pipeline across batches: two streams, two slot buffers, one rollout graph per buffer ----
-        overlap = (not args.no_overlap) and graph is not None and S == 1
-        # rollout streams: SF_BENCH_ROLL_MASKS = comma list of hex mask words, one rollout stream per entry (each word
-        # repeated over the 8 mask words); default = one stream on the complement of the encode mask
-        cu_words = [int(w, 16) for w in os.environ.get('SF_BENCH_CU_SPLIT', 'ff').split(',')]
-        cu_words = (cu_words * 8)[:8]
-        cu_split = any(cu_words)
-        roll_masks = [int(w, 16) for w in os.environ.get('SF_BENCH_ROLL_MASKS', '').split(',') if w]
-        n_rs = max(1, len(roll_masks)) if cu_split else int(os.environ.get('SF_BENCH_ROLL_STREAMS', '1'))
-        NB = n_rs + 1  # slot buffers / graphs / workspaces: one per rollout in flight + one being encoded
-        if overlap:
-            graphs = [graph]
-            while len(bufs) < NB:
-                bufs.append(torch.zeros_like(bufs[0]))
-            try:
-                for gi in range(1, NB):
-                    engine.rollout(roll, bufs[gi], T_BURN, T_ROLL, ws_slot=gi)  # allocate its workspace before capture
-                    torch.cuda.synchronize()
-                    g1 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g1):
-                        engine.rollout(roll, bufs[gi], T_BURN, T_ROLL, ws_slot=gi)  # own scratch: may run beside the others
-                    graphs.append(g1)
-            except Exception as e:  # noqa: BLE001
-                log(f'graph capture {len(graphs)} failed ({e}); no overlap')
-                overlap = False
-        if overlap:
-            prio = int(os.environ.get('SF_BENCH_ROLL_PRIO', '-1'))
-            s_enc = torch.cuda.Stream(device=dev, priority=int(os.environ.get('SF_BENCH_ENC_PRIO', '0')))
-            # CU partition (SF_BENCH_CU_SPLIT = hex word E, 0 = off): the encode stream gets the CUs whose bit is set
-            # in E (repeated for each of the 8 mask words), the rollout stream(s) the complement.  Measured
-            # (profiles/r01_probes.txt): byte j of every word behaves as shader engine j of every XCD; E = ff (one SE
-            # = 64 CUs for the encode) beats the unpartitioned pipeline, partial bytes or per-word differences
-            # unbalance the shader engines and lose 20-60 %.
-            masked = []
-
-            def masked_stream(ws):
-                words = (C.c_uint * 8)(*[w & 0xffffffff for w in ws])
-                h = C.c_void_p()
-                _lib.check(lib.sf_stream_create_cu_mask(C.byref(h), words, 8))
-                masked.append(h)
-                return torch.cuda.ExternalStream(h.value, device=dev)
-
-            if cu_split:
-                try:
-                    s_enc = masked_stream(cu_words)
-                    if roll_masks:
-                        s_rolls = [masked_stream([w] * 8) for w in roll_masks]
-                    elif os.environ.get('SF_BENCH_ROLL_UNMASKED', '0') == '1':  # experiment: rollout free to use every CU
-                        s_rolls = [torch.cuda.Stream(device=dev, priority=prio)]
-                    else:
-                        s_rolls = [masked_stream([~w for w in cu_words])]
-                except RuntimeError as e:  # CU masking unavailable: keep the pipeline, on shared CUs (and say so)
-                    print(f'[bench] rank {rank}: CU-masked streams unavailable ({e}); pipelining on shared CUs', file=sys.stderr)
-                    cu_split = False
-            if not cu_split:
-                n_rs = min(n_rs, NB - 1)
-                s_rolls = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(n_rs)]
-
-            # Work stealing (SF_BENCH_STEAL = number of time steps): the encode partition is the slower half, and the
-            # rollout stream idles between its graph and the next encode's end -- so after the rollout of batch j it
-            # computes the CNN features of the first `steal` time steps of batch j+2 on its own (larger) CU partition;
-            # the encode of batch j+2 then skips those convolutions.  Two feature buffers.
-            steal = int(os.environ.get('SF_BENCH_STEAL', '1')) if n_rs == 1 else 0
-            steal = max(0, min(steal, T_BURN))
-            feat_bufs = None
-            if steal:
-                feat_bufs = [engine.savi_cnn(savi, img, 0, steal, ws_slot=1) for _ in range(2)]
-                torch.cuda.synchronize()
-
-            def run_pipelined(n):
-                cur = torch.cuda.current_stream()
-                s_enc.wait_stream(cur)
-                for sr in s_rolls:
-                    sr.wait_stream(cur)
-                ev_enc = [torch.cuda.Event() for _ in range(n)]
-                ev_roll = [torch.cuda.Event(enable_timing=True) for _ in range(n)]   # also: completion time of every batch
-                ev_pre = [torch.cuda.Event() for _ in range(n + 2)]
-                # (the first two batches compute their own convolutions: stealing starts with batch 2, whose features are
-                #  produced after the rollout of batch 0)
-                for j in range(n):
-                    if j == 0 and cu_split:
-                        # pipeline fill: nothing else is running yet, so the first encode takes the whole chip (the
-                        # calling stream) instead of the 64-CU partition; the masked encode stream starts after it
-                        encode(bufs[0], None)
-                        ev_enc[0].record(cur)
-                        s_enc.wait_event(ev_enc[0])
-                    else:
-                        with torch.cuda.stream(s_enc):
-                            if j >= NB:
-                                s_enc.wait_event(ev_roll[j - NB])  # slot buffer j % NB is free once rollout j-NB is done
-                            if steal and j >= 2:
-                                s_enc.wait_event(ev_pre[j])
-                            encode(bufs[j % NB], feat_bufs[j % 2] if (steal and j >= 2) else None)
-                            ev_enc[j].record(s_enc)
-                    s_roll = s_rolls[j % n_rs]
-                    with torch.cuda.stream(s_roll):
-                        s_roll.wait_event(ev_enc[j])
-                        if j >= NB:
-                            s_roll.wait_event(ev_roll[j - NB])  # same graph / buffer / workspace as batch j-NB
-                        graphs[j % NB].replay()
-                        ev_roll[j].record(s_roll)
-                        if steal and j + 2 < n:
-                            # feature buffer (j+2) % 2 == j % 2 was consumed by encode j, which this stream has waited for
-                            engine.savi_cnn(savi, img, 0, steal, out=feat_bufs[j % 2], ws_slot=1)
-                            ev_pre[j + 2].record(s_roll)
-                cur.wait_stream(s_enc)
-                for sr in s_rolls:
-                    cur.wait_stream(sr)
-                return ev_roll
+        def run(n, out):
+            return pipe.run([ring[j % 3] for j in range(n)], None, out=out, serial=not overlap)
 
         def barrier():
             if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
 
-        if overlap:
-            run_pipelined(args.warmup)
-        else:
-            for _ in range(args.warmup):
-                step()
+        shape = (B, T_BURN + T_ROLL, N_SLOTS, SLOT_D)
+        out_w = torch.empty((max(args.warmup, 1), ) + shape, device=dev)
+        out_t = torch.empty((args.steps, ) + shape, device=dev)
+        run(args.warmup, out_w)
         torch.cuda.synchronize()
+        assert torch.isfinite(out_w[:args.warmup]).all(), 'non-finite slots in the warmup batches'
         log('warmup done')
-        # dominant kernel (conv implicit GEMM) + the HBM-bound SA iteration are event-timed live
+        # conv + Slot-Attention launches are event-timed live (library brackets on the launch stream)
         lib.sf_profile_enable((1 << 0) | (1 << 3))
         read_profile(lib)
         barrier()
         t0 = time.perf_counter()
-        batch_done = None
-        if overlap:
-            batch_done = run_pipelined(args.steps)
-        else:
-            for _ in range(args.steps):
-                step()
+        run(args.steps, out_t)
         barrier()
         elapsed = time.perf_counter() - t0
         log(f'timed region done: {elapsed:.3f}s')
         lib.sf_profile_enable(0)
         prof = read_profile(lib)
+        batch_done = pipe.completion_events if overlap else None
+        assert torch.isfinite(out_t).all(), 'non-finite slots in the timed batches'
+        # the three ring inputs give three different results (a stale slot buffer would repeat one)
+        if args.steps >= 3:
+            assert not torch.equal(out_t[0, :, :T_BURN], out_t[1, :, :T_BURN])
 
-        # split timing (untimed extra): encode-only and rollout-only
+        # ---- untimed extras: the two halves alone, per-kernel event timings ----
+        noise = torch.randn(B, T_BURN, N_SLOTS, SLOT_D, device=dev)
+
+        def encode():
+            post, _, _ = engine.savi_encode(savi, ring[0], noise=noise)
+            pipe.bufs[0][:, :T_BURN].copy_(post)
+
+        def rollout():
+            graph.replay() if graph is not None else engine.rollout(roll, pipe.bufs[0], T_BURN, T_ROLL, ws_slot=('pipe', 0))
+
+        def timed_on(stream, fn, n=3):
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                fn()
+                stream.synchronize()
+                t = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                stream.synchronize()
+            return (time.perf_counter() - t) / n
+
         torch.cuda.synchronize()
         lib.sf_profile_enable((1 << 0) | (1 << 3))
-        t1 = time.perf_counter()
-        for _ in range(3):
-            encode()
-        torch.cuda.synchronize()
-        t_enc = (time.perf_counter() - t1) / 3
+        t_enc = timed_on(torch.cuda.current_stream(), encode)
         lib.sf_profile_enable(0)
         prof_iso = read_profile(lib)  # same kernels with nothing else on the GPU
-        t1 = time.perf_counter()
-        for _ in range(3):
-            graph.replay() if graph is not None else rollout_eager()
-        torch.cuda.synchronize()
-        t_roll = (time.perf_counter() - t1) / 3
+        t_roll = timed_on(torch.cuda.current_stream(), rollout)
         part_ms = None
-        if overlap and cu_split:
-            # the two halves of the partitioned pipeline, each alone on its CU subset
-            def timed_on(stream, fn, n=3):
-                stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(stream):
-                    fn()
-                    stream.synchronize()
-                    t = time.perf_counter()
-                    for _ in range(n):
-                        fn()
-                    stream.synchronize()
-                return 1e3 * (time.perf_counter() - t) / n
-            part_ms = {'encode_ms_on_its_cus': timed_on(s_enc, encode), 'rollout_ms_on_its_cus': timed_on(s_rolls[0], graph.replay)}
+        if overlap and pipe.cu_split:
+            part_ms = {'encode_ms_on_its_cus': 1e3 * timed_on(pipe.s_enc, encode), 'rollout_ms_on_its_cus': 1e3 * timed_on(pipe.s_roll, rollout)}
+        # the rollout layer kernels, event-timed: (a) alone on the whole chip in one eager rollout, (b) LIVE in a pipelined
+        # pass with the product schedule (encode stream busy on its CUs) but eager launches -- inside the timed region they
+        # replay from a hipGraph, where HIP events cannot be inserted between the kernels
+        lib.sf_profile_enable((1 << 5) | (1 << 6))
+        read_profile(lib)
+        engine.rollout(roll, pipe.bufs[0], T_BURN, T_ROLL, ws_slot=('pipe', 0))
+        torch.cuda.synchronize()
+        prof_roll = read_profile(lib)
+        prof_roll_live = {}
+        if overlap:
+            graphs, pipe.graphs = pipe.graphs, []
+            pipe.run([ring[j % 3] for j in range(4)], None, out=out_w if out_w.shape[0] >= 4 else None)
+            torch.cuda.synchronize()
+            pipe.graphs = graphs
+            prof_roll_live = read_profile(lib)
+        lib.sf_profile_enable(0)
         pcie = None
         if args.pcie:
             # PCIe-inclusive variant (never `value`): frames start in pinned host memory and the slots end there
-            img_h = img.cpu().pin_memory()
-            out_h = torch.empty(bufs[0].shape, dtype=bufs[0].dtype).pin_memory()
+            img_h = [r.cpu().pin_memory() for r in ring]
+            out_h = torch.empty(shape, dtype=torch.float32).pin_memory()
+            stage = torch.empty_like(ring[0])
 
-            def step_pcie():
-                img.copy_(img_h, non_blocking=True)
-                step()
-                out_h.copy_(buf, non_blocking=True)
+            def step_pcie(j):
+                stage.copy_(img_h[j % 3], non_blocking=True)
+                post, _, _ = engine.savi_encode(savi, stage, noise=noise)
+                pipe.bufs[0][:, :T_BURN].copy_(post)
+                rollout()
+                out_h.copy_(pipe.bufs[0], non_blocking=True)
 
-            step_pcie()
+            step_pcie(0)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step_pcie()
+            for j in range(args.steps):
+                step_pcie(j)
             torch.cuda.synchronize()
             t_p = (time.perf_counter() - t1) / args.steps
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            t_s = (time.perf_counter() - t1) / args.steps
             pcie = {'frames_per_s_host_to_host_serial': B * (T_BURN + T_ROLL) / t_p,
-                    'frames_per_s_device_resident_serial': B * (T_BURN + T_ROLL) / t_s,
-                    'h2d_bytes_per_batch': img.numel() * 4, 'd2h_bytes_per_batch': buf.numel() * 4,
+                    'frames_per_s_device_resident_serial': B * (T_BURN + T_ROLL) / (t_enc + t_roll),
+                    'h2d_bytes_per_batch': ring[0].numel() * 4, 'd2h_bytes_per_batch': out_h.numel() * 4,
                     'note': 'serial (no batch pipelining, copies on the compute stream): upper bound on the PCIe cost'}
-        # the two kernels that make up a rollout layer, event-timed in one eager (un-graphed) rollout with nothing else
-        # running -- inside the timed region they replay from a hipGraph, where HIP events cannot be inserted
-        lib.sf_profile_enable((1 << 5) | (1 << 6))
-        read_profile(lib)
-        rollout_eager()
-        torch.cuda.synchronize()
-        lib.sf_profile_enable(0)
-        prof_roll = read_profile(lib)
         breakdown = None
         if args.breakdown:
             lib.sf_profile_enable(0x7f)
             encode()
-            rollout_eager()
+            engine.rollout(roll, pipe.bufs[0], T_BURN, T_ROLL, ws_slot=('pipe', 0))
             torch.cuda.synchronize()
             lib.sf_profile_enable(0)
             breakdown = read_profile(lib)
@@ -449,6 +324,12 @@ def main():
             gaps = sorted(batch_done[j - 1].elapsed_time(batch_done[j]) for j in range(1, len(batch_done)))
             pick = lambda q: gaps[min(len(gaps) - 1, int(q * len(gaps)))]  # noqa: E731
             step_dist = {'p10': pick(0.10), 'median': pick(0.50), 'p90': pick(0.90), 'n': len(gaps)}
+        peak_chip = PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS
+        peak_note = ('split-bf16 MFMA: 3 bf16 MFMA flops per algorithmic flop -> roof = 2500/3 TFLOP/s' if prec == 'bf16x3'
+                     else 'exact f32 MFMA')
+        nl = len(roll.transformer_encoder.layers)
+        launches_per_graph = 1 + T_ROLL * 2 * nl
+        step_flops = B * (T_BURN * ENC_FLOPS_PER_FRAME + T_ROLL * ROLL_FLOPS_PER_FRAME)
         res = {
             'metric': 'rollout frames/sec at B=32, 128x128, 7 slots, 6+50 steps (SAVi-encode + SlotFormer rollout)',
             'value': frames / elapsed,
@@ -468,14 +349,15 @@ def main():
                 '50-step rollout; random-init weights',
                 'batch_per_gpu': B, 'global_batch': B * world, 'burn_in': T_BURN, 'rollout': T_ROLL,
                 'parallelism': f'dp{world}: videos sharded on the batch axis, no collective on the timed path',
-                'rollout_launch': 'hipGraph replay' if graph is not None else 'eager', 'rollout_streams': S,
+                'inputs': 'ring of 3 different resident batches; the slots of every batch are copied out of the slot buffers',
+                'schedule': 'slotformer_amd.pipeline.EncodeRolloutPipeline (product code, tests/test_pipeline_gpu.py)',
+                'rollout_launch': f'hipGraph replay ({launches_per_graph} kernel nodes)' if graph is not None else 'eager',
                 'pipelining': ('encode of batch i+1 (stream A) overlaps the rollout graph of batch i (stream B); every batch still '
                                'runs its full encode + 50-step rollout inside the timed region') if overlap else 'none',
-                'work_stealing': (f'the CNN features of the first {steal} time step(s) of batch j+2 are computed on the rollout '
-                                  'stream after the rollout of batch j') if (overlap and steal) else 'none',
-                'cu_partition': (f'encode stream on CU mask {cu_words[0]:#x} x8 words ({8 * bin(cu_words[0]).count("1")} CUs), '
-                                 + (f'{n_rs} rollout streams on masks ' + ','.join(f'{w:#x}' for w in roll_masks) if roll_masks
-                                    else 'rollout stream on the complement')) if (overlap and cu_split) else 'none',
+                'work_stealing': (f'the CNN features of the first {pipe.steal} time step(s) of batch j+2 are computed on the rollout '
+                                  'stream after the rollout of batch j') if (overlap and pipe.steal) else 'none',
+                'cu_partition': (f'encode stream on CU mask {cu_word:#x} x8 words ({pipe.encode_cus} CUs), rollout stream on the '
+                                 'complement') if (overlap and pipe.cu_split) else 'none',
             },
             'encode_ms': 1e3 * t_enc,
             'rollout_ms': 1e3 * t_roll,
@@ -483,71 +365,83 @@ def main():
             'ms_per_step_distribution': step_dist,
             'encoded_frames_per_s': B * T_BURN / t_enc,
             'predicted_frames_per_s': B * T_ROLL / t_roll,
+            'whole_step_tflops': step_flops * args.steps * world / elapsed / 1e12,
+            'whole_step_flops': step_flops,
+        }
+        # ---- headline roofline: the kernel with the largest share of device time in the rocprof summary of this command
+        #      (profiles/r02_kernel_stats.csv): the fused FFN kernel of the rollout layers ----
+        rk = {}
+        for key, name in (('ffn_fused', 'ffn_partial_kernel (sum of the 4 head-pair partials + LN2 + FFN1 + ReLU + FFN2 on one 32-row tile x 256-wide '
+                           'hidden chunk + last-arriver reduction; on the last layer also the step boundary)'),
+                          ('attention', 'attn_oproj_kernel (LN1 + q|k|v of a head pair + softmax(qk^T)v + out-proj partial; one workgroup per '
+                           '(head pair, video))')):
+            iso, live = prof_roll.get(key), prof_roll_live.get(key)
+            if not iso:
+                continue
+            fl = iso['work'] / iso['launches']
+            src = live or iso
+            cus = (256 - pipe.encode_cus) if (live and pipe.cu_split) else 256
+            tf = fl / (src['avg_us'] * 1e-6) / 1e12
+            pm = committed_profile(key)
+            rk[key] = {
+                'kernel': name, 'bound': 'mfma', 'achieved': tf, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': tf / peak_chip,
+                'peak_note': peak_note + '; whole-chip roof (the launch has 128-168 workgroups, one per CU)',
+                'flops_per_launch': fl, 'avg_launch_us': src['avg_us'], 'launches': src['launches'], 'cus_available': cus,
+                'measured': ('HIP events around every launch on the rollout stream in a pipelined pass with the timed schedule '
+                             '(encode stream busy on its CUs), eager launches' if live else 'HIP events around every launch, kernel alone'),
+                'avg_launch_us_isolated': iso['avg_us'], 'frac_isolated': fl / (iso['avg_us'] * 1e-6) / 1e12 / peak_chip,
+                'traffic': pm.get('traffic_bytes_per_launch'),
+                'mfma_busy_frac': pm.get('mfma_busy_frac'), 'pmc_source': pm.get('source'),
+                'limiter': 'per-CU ingest (~100 GB/s per workgroup: weight fragments + activations re-fetched by every workgroup) and '
+                           'dependent-launch latency, not the matrix pipe (DESIGN.md 4)',
+            }
+        if 'ffn_fused' in rk:
+            res['roofline'] = rk.pop('ffn_fused')
+        if rk:
+            res['roofline_attention'] = rk['attention']
+        roll_flops = ROLL_FLOPS_PER_FRAME * B * T_ROLL
+        res['roofline_rollout_graph'] = {
+            'kernel': f'hipGraph of the 50-step rollout: ring init + 50 x {nl} x (attention + out-proj partials, fused FFN [+ step boundary on the '
+                      f'last layer]) = {launches_per_graph} launches',
+            'bound': f'latency ({launches_per_graph} dependent launches, M = B*L = {B * 42} rows); MFMA roof shown for scale',
+            'achieved': roll_flops / t_roll / 1e12, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': roll_flops / t_roll / 1e12 / peak_chip,
+            'ms': 1e3 * t_roll, 'us_per_step': 1e6 * t_roll / T_ROLL,
         }
         conv = prof.get('conv_nhwc_implicit_gemm')
         if conv:
             flops_per_launch = conv['work'] / conv['launches']
             ach = flops_per_launch / (conv['avg_us'] * 1e-6) / 1e12
-            peak_chip = PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS
-            # under the CU partition the encode stream owns a subset of the CUs during the timed region: the live
-            # figure is priced against the MFMA peak of THOSE CUs; the isolated figure (kernel alone, default stream,
-            # all 256 CUs) against the whole chip
-            enc_cus = 8 * bin(cu_words[0]).count('1') if (overlap and cu_split) else 256
-            peak = peak_chip * enc_cus / 256.0
-            res['roofline'] = {
-                'kernel': ('conv5x5_halo_kernel' if prec == 'bf16x3' else 'sf_gemm_kernel<128,64,...,conv_nhwc>') + ' (5x5 conv 64->64 @64x64, '
-                + ('split-bf16 MFMA: 3 bf16 MFMA flops per algorithmic flop -> peak = 2500/3)' if prec == 'bf16x3' else 'exact f32 MFMA)'),
-                'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': ach / peak, 'cus': enc_cus, 'peak_full_chip': peak_chip, 'traffic': pmc_traffic('conv_nhwc_implicit_gemm'),
-                'traffic_unit': 'bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE, committed under profiles/)',
-                'algorithmic_bytes_per_launch': 2 * 32 * 4096 * 64 * 4 + 64 * 1600 * 4,
-                'flops_per_launch': flops_per_launch, 'avg_launch_us': conv['avg_us'], 'launches': conv['launches'],
-                'avg_launch_us_isolated': prof_iso.get('conv_nhwc_implicit_gemm', {}).get('avg_us'),
-                'frac_isolated': (flops_per_launch / (prof_iso['conv_nhwc_implicit_gemm']['avg_us'] * 1e-6) / 1e12 / peak_chip
-                                  if 'conv_nhwc_implicit_gemm' in prof_iso else None),
-                'note': 'achieved/frac are live over the timed region, where the encode runs on `cus` CUs beside the rollout graph '
-                        'of the previous batch (peak = whole-chip peak x cus/256; the convolutions that work stealing moves to the '
-                        'rollout stream are not part of this average); *_isolated is the same kernel alone on all 256 CUs '
-                        '(vs peak_full_chip)',
+            enc_cus = pipe.encode_cus if (overlap and pipe.cu_split) else 256
+            iso = prof_iso.get('conv_nhwc_implicit_gemm')
+            ach_iso = flops_per_launch / (iso['avg_us'] * 1e-6) / 1e12 if iso else None
+            pm = committed_profile('conv_nhwc_implicit_gemm')
+            res['roofline_conv'] = {
+                'kernel': ('conv5x5_halo_kernel' if prec == 'bf16x3' else 'sf_gemm_kernel<128,64,...,conv_nhwc>') + ' (5x5 conv 64->64 @64x64; ' + peak_note + ')',
+                'bound': 'lds-read / mfma (matrix pipe busy ~42 % of the launch; the operand reads from LDS and the un-overlapped halo '
+                         'fill bound it, DESIGN.md 4)',
+                'achieved': ach_iso, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': (ach_iso / peak_chip) if ach_iso else None,
+                'avg_launch_us': iso['avg_us'] if iso else None,
+                'live': {'achieved': ach, 'cus': enc_cus, 'avg_launch_us': conv['avg_us'], 'launches': conv['launches'],
+                         'frac_of_partition_peak': ach / (peak_chip * enc_cus / 256.0),
+                         'note': 'inside the timed region the encode stream owns `cus` CUs beside the rollout graph of the previous batch; '
+                                 'stolen convolutions (rollout stream) are not part of this average'},
+                'traffic': pm.get('traffic_bytes_per_launch'), 'mfma_busy_frac': pm.get('mfma_busy_frac'), 'pmc_source': pm.get('source'),
+                'traffic_unit': 'bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE)',
+                'algorithmic_bytes_per_launch': 2 * 32 * 4096 * 64 * 4 + 64 * 1600 * 4, 'flops_per_launch': flops_per_launch,
             }
-        # the rollout replays as ONE hipGraph (900 launches), so it is reported as a unit: algorithmic
-        # FLOPs of SURVEY.md 8d (274.7 MFLOP per predicted frame per video, minus nothing: the last-layer
-        # row pruning is an exact saving we do not credit) over the graph's wall time
-        roll_flops = 274.7e6 * B * T_ROLL
-        res['roofline_rollout_graph'] = {
-            'kernel': 'hipGraph of the 50-step rollout: per step in-proj, 4 x (attention + out-proj partials, fused FFN), out-proj = 550 launches',
-            'bound': 'latency (550 dependent launches, M = B*L = 1344 rows); MFMA roof shown for scale',
-            'achieved': roll_flops / t_roll / 1e12, 'peak': (PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS),
-            'unit': 'TFLOP/s', 'frac': roll_flops / t_roll / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS),
-            'ms': 1e3 * t_roll, 'us_per_step': 1e6 * t_roll / T_ROLL,
-        }
-        rk = {}
-        peak_bf3 = PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS
-        for key, name in (('attention', 'attn_oproj_kernel (LN1 + q|k|v of one head + softmax(qk^T)v + out-proj partial; one WG per head x video)'),
-                          ('ffn_fused', 'ffn_partial_kernel (sum of head partials + LN2 + FFN1 + ReLU + FFN2 chunk + last-arriver reduction)')):
-            pk = prof_roll.get(key)
-            if pk:
-                fl = pk['work'] / pk['launches']
-                tf = fl / (pk['avg_us'] * 1e-6) / 1e12
-                rk[key] = {'kernel': name, 'bound': 'latency (M = 1344 rows; see DESIGN.md phase timings); MFMA roof for scale',
-                           'achieved': tf, 'peak': peak_bf3, 'unit': 'TFLOP/s', 'frac': tf / peak_bf3, 'flops_per_launch': fl,
-                           'avg_launch_us_isolated': pk['avg_us'], 'launches': pk['launches']}
-        if rk:
-            res['roofline_rollout_kernels'] = rk
         sa = prof.get('slot_attn_iter')
         if sa:
             bytes_per_launch = sa['work'] / sa['launches']
             gbps = bytes_per_launch / (sa['avg_us'] * 1e-6) / 1e9
+            iso = prof_iso.get('slot_attn_iter')
             res['roofline_slot_attn'] = {
                 'kernel': 'sa_attn_mfma_kernel<128> (one Slot-Attention iteration over K,V)', 'bound': 'hbm',
-                'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': gbps / PEAK_HBM_GBPS,
-                'traffic': pmc_traffic('slot_attn_iter'), 'bytes_per_launch': bytes_per_launch,
-                'avg_launch_us_isolated': prof_iso.get('slot_attn_iter', {}).get('avg_us'), 'avg_launch_us': sa['avg_us'],
-                'frac_isolated': (bytes_per_launch / (prof_iso['slot_attn_iter']['avg_us'] * 1e-6) / 1e9 / PEAK_HBM_GBPS
-                                  if 'slot_attn_iter' in prof_iso else None),
-                'cus': enc_cus if conv else 256,
-                'note': 'live figure: the encode stream owns `cus` of the 256 CUs in the timed region; *_isolated: alone on the whole chip',
-                'launches': sa['launches'],
+                'achieved': bytes_per_launch / (iso['avg_us'] * 1e-6) / 1e9 if iso else None, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                'frac': (bytes_per_launch / (iso['avg_us'] * 1e-6) / 1e9 / PEAK_HBM_GBPS) if iso else None,
+                'avg_launch_us': iso['avg_us'] if iso else None,
+                'traffic': committed_profile('slot_attn_iter').get('traffic_bytes_per_launch'), 'bytes_per_launch': bytes_per_launch,
+                'live': {'achieved': gbps, 'avg_launch_us': sa['avg_us'], 'launches': sa['launches'],
+                         'cus': pipe.encode_cus if (overlap and pipe.cu_split) else 256},
             }
         if breakdown:
             res['kernel_breakdown_one_step'] = breakdown
@@ -563,6 +457,7 @@ def main():
         except OSError:
             pass
         print(json.dumps(res), flush=True)
+    pipe.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -60,6 +60,7 @@ __device__ __forceinline__ void split4(__bf16* hp, __bf16* lp, int off, f32x4 v)
 
 __device__ long long lf_ts[32];   // phase timestamps of one workgroup (SF_LF_DBG & 16), read by sf_debug_read_ts
 #define LF_TS(i) do { if ((dbg & 16) && blockIdx.x == 0 && threadIdx.x == 0) lf_ts[i] = wall_clock64(); } while (0)
+#define LF_TL(i) do { if ((dbg & 16) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 256) lf_ts[i + 10] = wall_clock64(); } while (0)
 #define LF_TA(i) do { if ((dbg & 16) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) lf_ts[i] = wall_clock64(); } while (0)
 
 // ================================================================================================
@@ -146,7 +147,16 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
   const float* xb = xin + (long long)b * x_batch_stride;
   const int c4 = t & 15, r0 = t >> 4;
   LF_TA(16);
-  // ---- small parameter vectors first (vmcnt retires in order) ----
+  // ---- prologue.  A workgroup ingests ~100 GB/s through one in-order request path: the 196 KB of q|k|v weight fragments
+  //      take ~2 us to issue, a wave cannot run the LayerNorm arithmetic before its own last request has been accepted,
+  //      and the arithmetic itself needs all 8 waves (two per SIMD) to run at full VALU rate.  So every wave requests
+  //      its share of the layer input first, then only the fragments of k-steps 0..7, normalises, and requests
+  //      k-steps 8..15 afterwards -- they land while the projection consumes the first half.
+  //      Column blocks (32 of the 192 q|k|v columns of the head pair): waves 0..3 own cb = wave over all of K; blocks
+  //      4 / 5 are split over K between waves 4 / 5 (k-steps 0..7) and 6 / 7 (k-steps 8..15): waves w and w+4 share a
+  //      SIMD, so every SIMD runs 96 + 48 MFMAs. ----
+  const int nrb = L > 32 ? 2 : 1;
+  // small parameter vectors first (vmcnt retires in order)
   f32x4 gbv = {0.f, 0.f, 0.f, 0.f};
   if (t < 128) gbv = *(const f32x4*)((t < 64 ? ln_g : ln_b) + 4 * (t & 63));
   float qkvb = 0.f;   // q|k|v bias of the two heads: column block cb = (head, which) -> 6 x 32 values
@@ -189,16 +199,15 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) ra[kc][i] += tp[kc][i];
   }
-  // (requested AFTER the activations: vmcnt retires in order and LayerNorm needs x first; the fragments land while the
-  //  statistics and the LN(x) planes are computed)
-  // ---- q|k|v weight fragments of column block `wave` (waves 0..5): 16 k-steps x (hi, lo) = 128 VGPRs ----
+  // ---- weight fragments: wq[ks][plane]; waves >= 4 hold 8 k-steps (in wq[0..7]) ----
   bf16x8 wq[16][2];
+  const int wcb = wave < 4 ? wave : 4 + (wave & 1), wk0 = wave >= 6 ? 8 : 0;
+  const uint4* wqp = wqkv_p + (((long long)(hp * 6 + wcb) * 16 + wk0) * 2) * 64 + lane;
   if (wave < 6) {
-    const uint4* wp = wqkv_p + (((long long)(hp * 6 + wave) * 16) * 2) * 64 + lane;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      wq[ks][0] = __builtin_bit_cast(bf16x8, wp[(ks * 2) * 64]);
-      wq[ks][1] = __builtin_bit_cast(bf16x8, wp[(ks * 2 + 1) * 64]);
+    for (int ks = 0; ks < 8; ++ks) {
+      wq[ks][0] = __builtin_bit_cast(bf16x8, wqp[(ks * 2) * 64]);
+      wq[ks][1] = __builtin_bit_cast(bf16x8, wqp[(ks * 2 + 1) * 64]);
     }
   }
   LF_TA(17);
@@ -240,21 +249,36 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
       split4(Ah, Al, r * A2_AP + k, aok[i] ? v : zero4);
     }
   }
+  // second half of the fragments: k-steps 8..15 of waves 0..3, the (upper-K) halves of waves 6 / 7
+  __builtin_amdgcn_sched_barrier(0);   // keep these requests BEHIND the arithmetic above in the instruction stream
+  if (wave < 4) {
+#pragma unroll
+    for (int ks = 8; ks < 16; ++ks) {
+      wq[ks][0] = __builtin_bit_cast(bf16x8, wqp[(ks * 2) * 64]);
+      wq[ks][1] = __builtin_bit_cast(bf16x8, wqp[(ks * 2 + 1) * 64]);
+    }
+  } else if (wave >= 6) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      wq[ks][0] = __builtin_bit_cast(bf16x8, wqp[(ks * 2) * 64]);
+      wq[ks][1] = __builtin_bit_cast(bf16x8, wqp[(ks * 2 + 1) * 64]);
+    }
+  }
   __syncthreads();
   LF_TA(18);
 
-  // ---- q|k|v^T = W . LN(x)^T (weights as the MFMA A operand): wave cb < 6 owns column block cb = (head, q|k|v) and
-  //      computes both token blocks with the same weight fragments; no weight planes, no barriers ----
-  const int nrb = L > 32 ? 2 : 1;
+  // ---- q|k|v^T = W . LN(x)^T (weights as the MFMA A operand): a wave computes both token blocks of its column block
+  //      with the same weight fragments; no weight planes, no barriers ----
   f32x16 acc[2];
 #pragma unroll
   for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q2][r] = 0.f;
-  if (wave < 6) {
-    const int ao = (lane & 31) * A2_AP + 8 * (lane >> 5);
+  {
+    const int ao = (lane & 31) * A2_AP + 8 * (lane >> 5) + (wave >= 6 ? 8 * 16 : 0);
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
+      if (ks >= 8 && wave >= 4) continue;
       const bf16x8 xh0 = *(const bf16x8*)(Ah + ao + ks * 16), xl0 = *(const bf16x8*)(Al + ao + ks * 16);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xl0, acc[0], 0, 0, 0);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][1], xh0, acc[0], 0, 0, 0);
@@ -266,6 +290,14 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xh1, acc[1], 0, 0, 0);
       }
     }
+  }
+  // the upper k-half of column blocks 4 / 5 meets the lower half in LDS (scratch = the PV-partial tile, free until then)
+  float* PS = (float*)((char*)smem + A2_OT_OFF);   // [2 waves][2 token blocks][16][64]
+  if (wave >= 6) {
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) PS[(((wave - 6) * 2 + q2) * 16 + r) * 64 + lane] = acc[q2][r];
   }
   // out-proj fragments of column block `wave` (K = 64: 4 k-steps): requested now, consumed at the end
   bf16x8 wof[4][2];
@@ -280,6 +312,12 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
   __syncthreads();   // every wave is done with the LN(x) planes: q, k, v take their place
   LF_TA(19);
   const float scale = 1.0f / sqrtf((float)HD);
+  if (wave == 4 || wave == 5) {
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q2][r] += PS[(((wave - 4) * 2 + q2) * 16 + r) * 64 + lane];
+  }
   if (wave < 6) {
     const int which = wave % 3, hh = wave / 3;
     const float mul = which == 0 ? scale : 1.f;
@@ -581,19 +619,21 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
 
   // small parameter vectors first: vmcnt retires in order, so a late request would wait for every weight fragment
   const int tok = lane & 31, nb = wave * 32 + 4 * (lane >> 5);   // FFN outputs: this lane's token and first column (+ 8 g)
-  const f32x4 lng = *(const f32x4*)(ln_g + 4 * lane), lnb = *(const f32x4*)(ln_b + 4 * lane);
   f32x4 b1v[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) b1v[g] = *(const f32x4*)(b1 + c * LF_HC + nb + 8 * g);
-  // ---- weight fragments: wf[ks][plane], 16 k-steps; FFN1's are requested now, FFN2's as FFN1 consumes them ----
+  // ---- weight fragments: wf[ks][plane], 16 k-steps; FFN1's are requested in the prologue, FFN2's as FFN1 consumes them ----
   const uint4* w1c = w1p + ((long long)(c * 16) * 8 + wave) * 128 + lane;
   const uint4* w2c = w2p + ((long long)(c * 16) * 8 + wave) * 128 + lane;
   bf16x8 wf[16][2];
   auto ldw = [&](const uint4* base, int ks, int plane) {
     return __builtin_bit_cast(bf16x8, base[(ks * 8) * 128 + plane * 64]);
   };
-  // ---- x2 = sum of the head partials: wave `wave` owns rows wave + 8 i, lane = float4 column.  Requested BEFORE the
-  //      weight fragments (vmcnt retires in order and the LayerNorm needs x2 first) ----
+  // ---- prologue.  The workgroup ingests ~100 GB/s through one in-order request path and a wave cannot start the
+  //      LayerNorm arithmetic before its own last request has been accepted: the head-pair partials go first, then only
+  //      k-steps 0..7 of W1; x2 = sum of the partials, LayerNorm, LN2 planes; k-steps 8..15 are requested after the
+  //      arithmetic and land while FFN1 consumes the first half.  Wave `wave` owns rows wave + 8 i, lane = float4 column. ----
+  const f32x4 lng = *(const f32x4*)(ln_g + 4 * lane), lnb = *(const f32x4*)(ln_b + 4 * lane);
   f32x4 x2[4];
   {
     f32x4 pr[LF_NP][4];
@@ -618,11 +658,6 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
     }
   }
   LF_TS(1);
-#pragma unroll
-  for (int ks = 8; ks < 16; ++ks) {
-    wf[ks][0] = ldw(w1c, ks, 0);
-    wf[ks][1] = ldw(w1c, ks, 1);
-  }
   {
     const f32x4 g = lng, be = lnb;
     float mean[4], rstd[4];
@@ -639,6 +674,12 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
       split4(Ah, Al, r * FB_AP + 4 * lane, (x2[i] - mean[i]) * rstd[i] * g + be);
       if (c == 0) *(f32x4*)(X2 + r * FB_XP + 4 * lane) = x2[i];
     }
+  }
+  __builtin_amdgcn_sched_barrier(0);   // keep these requests BEHIND the arithmetic above in the instruction stream
+#pragma unroll
+  for (int ks = 8; ks < 16; ++ks) {
+    wf[ks][0] = ldw(w1c, ks, 0);
+    wf[ks][1] = ldw(w1c, ks, 1);
   }
   __syncthreads();
   LF_TS(2);

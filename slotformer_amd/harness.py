@@ -68,3 +68,40 @@ def encode_then_rollout(savi, slotformer, img0, vid_len, noise=None):
     slots[:, :T0] = slot0
     slotformer.rollout_len = vid_len - slotformer.history_len
     return slotformer({'slots': slots})
+
+
+@torch.no_grad()
+def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises=None, pipelined=True, **pipe_kw):
+    """Whole hot path over many videos: SAVi slot extraction of the burn-in frames followed by the SlotFormer rollout
+    (extract_slots.py:19-38 + rollout_clevrer_slots.py:20-65 / test_phyre_planning.py:159-174 as one on-device call).
+
+    videos [V, T_burn, 3, H, W] (device or host tensor); rollouter: the SlotRollouter / SingleStepSlotRollouter container
+    (e.g. `slotformer.rollouter`).  Returns slots [V, T_burn + pred_len, N, D] on the device.  Full batches go through
+    `pipeline.EncodeRolloutPipeline` (encode of batch i+1 overlapped with the rollout graph of batch i, CU-partitioned
+    streams, work stealing); a ragged last batch runs serially through the same kernels.  `noises` [V, T_burn, N, D]
+    fixes the kernel noise (default: fresh N(0,1) per frame as the reference draws it)."""
+    from . import engine
+    from .pipeline import EncodeRolloutPipeline
+    dev = next(rollouter.parameters()).device
+    videos = videos.float().to(dev)
+    V, T = videos.shape[:2]
+    N, D = rollouter.num_slots, rollouter.in_proj.in_features
+    out = torch.empty(V, T + pred_len, N, D, device=dev)
+    nfull = V // batch_size
+    if nfull:
+        pipe = EncodeRolloutPipeline(savi, rollouter, batch_size, T, pred_len, **pipe_kw)
+        imgs = [videos[j * batch_size:(j + 1) * batch_size] for j in range(nfull)]
+        nz = None if noises is None else [noises[j * batch_size:(j + 1) * batch_size].float().to(dev).contiguous() for j in range(nfull)]
+        pipe.run(imgs, nz, out=out[:nfull * batch_size].view(nfull, batch_size, T + pred_len, N, D), serial=not pipelined or nfull < 2)
+        pipe.close()
+    r0 = nfull * batch_size
+    if r0 < V:
+        nz = None if noises is None else noises[r0:].float().to(dev).contiguous()
+        if nz is None and getattr(savi, 'kernel_dist_layer', None) is not None:
+            nz = torch.randn(V - r0, T, N, D, device=dev)
+        post, _, _ = engine.savi_encode(savi, videos[r0:].contiguous(), noise=nz)
+        tail = torch.zeros(V - r0, T + pred_len, N, D, device=dev)
+        tail[:, :T] = post
+        engine.rollout(rollouter, tail, T, pred_len)
+        out[r0:] = tail
+    return out

@@ -1,0 +1,100 @@
+"""The batch pipeline (slotformer_amd/pipeline.py: encode of batch i+1 on a CU-masked stream beside the rollout hipGraph
+of batch i, double-buffered slots, work stealing) must give bit-identical results to the serial
+`savi({'img'}) -> rollout` sequence -- with DIFFERENT inputs and noise per batch, so that a slot-buffer, feature-buffer or
+event mistake shows (VERDICT r01 'pipeline correctness is untested')."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(dev, savi_cfg, roll_cfg, seed=0):
+    from slotformer_amd.base_slots import build_model
+    from slotformer_amd.video_prediction.models import SlotRollouter
+    torch.manual_seed(seed)
+    savi = build_model(gu.ParamsView(savi_cfg)).eval().to(dev)
+    savi.testing = True
+    roll = SlotRollouter(**roll_cfg['rollout_dict']).eval().to(dev)
+    return savi, roll
+
+
+def _serial_reference(savi, roll, imgs, noises, T, H):
+    """The plain module API, one batch after the other on the default stream."""
+    from slotformer_amd import engine
+    outs = []
+    for img, nz in zip(imgs, noises):
+        post = savi({'img': img, 'noise': nz})['post_slots']
+        buf = torch.zeros(post.shape[0], T + H, post.shape[2], post.shape[3], device=img.device)
+        buf[:, :T] = post
+        engine.rollout(roll, buf, T, H)
+        outs.append(buf)
+    return torch.stack(outs, 0)
+
+
+@pytest.mark.parametrize('B,steal,nbatch', [(32, 1, 6), (32, 0, 5), (5, 1, 5), (5, 2, 7)])
+def test_pipeline_matches_serial(dev, B, steal, nbatch):
+    from slotformer_amd.pipeline import EncodeRolloutPipeline
+    T, H = 6, 12
+    savi, roll = _models(dev, gu.C2_SAVI, gu.C2_ROLL)
+    rs = np.random.RandomState(7)
+    imgs = [torch.from_numpy((rs.rand(B, T, 3, 128, 128) * 2 - 1).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    noises = [torch.from_numpy(rs.standard_normal((B, T, 7, 128)).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    with torch.no_grad():
+        ref = _serial_reference(savi, roll, imgs, noises, T, H)
+        pipe = EncodeRolloutPipeline(savi, roll, B, T, H, steal_steps=steal)
+        out = pipe.run(imgs, noises)
+        torch.cuda.synchronize()
+        assert out.shape == ref.shape
+        assert torch.equal(out, ref), (out - ref).abs().max().item()
+        # batches differ from each other (so a stale-buffer bug could not hide) and a second run reproduces the first
+        assert not torch.equal(out[0], out[1])
+        out2 = pipe.run(imgs, noises)
+        torch.cuda.synchronize()
+        assert torch.equal(out2, ref)
+        # the serial schedule of the same object (graphs, one stream) agrees as well
+        out3 = pipe.run(imgs, noises, serial=True)
+        torch.cuda.synchronize()
+        assert torch.equal(out3, ref)
+        pipe.close()
+
+
+def test_pipeline_without_cu_partition_and_graph(dev):
+    from slotformer_amd.pipeline import EncodeRolloutPipeline
+    B, T, H, nbatch = 4, 6, 5, 4
+    savi, roll = _models(dev, gu.C2_SAVI, gu.C2_ROLL, seed=3)
+    rs = np.random.RandomState(11)
+    imgs = [torch.from_numpy((rs.rand(B, T, 3, 128, 128) * 2 - 1).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    noises = [torch.from_numpy(rs.standard_normal((B, T, 7, 128)).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    with torch.no_grad():
+        ref = _serial_reference(savi, roll, imgs, noises, T, H)
+        for kw in (dict(encode_cu_word=0), dict(use_graph=False), dict(encode_cu_word=0, use_graph=False, steal_steps=0)):
+            pipe = EncodeRolloutPipeline(savi, roll, B, T, H, **kw)
+            out = pipe.run(imgs, noises)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), kw
+            pipe.close()
+
+
+def test_extract_and_rollout_entry(dev):
+    """harness.extract_and_rollout: full batches through the pipeline + a ragged tail, equal to the serial module calls."""
+    from slotformer_amd import harness
+    T, H, bs, V = 6, 8, 4, 14     # 3 full batches + 2 videos
+    savi, roll = _models(dev, gu.C2_SAVI, gu.C2_ROLL, seed=5)
+    rs = np.random.RandomState(3)
+    videos = torch.from_numpy((rs.rand(V, T, 3, 128, 128) * 2 - 1).astype(np.float32))
+    noises = torch.from_numpy(rs.standard_normal((V, T, 7, 128)).astype(np.float32))
+    with torch.no_grad():
+        out = harness.extract_and_rollout(savi, roll, videos, H, batch_size=bs, noises=noises)
+        chunks = [(0, 4), (4, 8), (8, 12), (12, 14)]
+        ref = _serial_reference(savi, roll, [videos[a:b].to(dev) for a, b in chunks[:3]], [noises[a:b].to(dev) for a, b in chunks[:3]], T, H)
+        tail = _serial_reference(savi, roll, [videos[12:].to(dev)], [noises[12:].to(dev)], T, H)
+        torch.cuda.synchronize()
+        assert out.shape == (V, T + H, 7, 128)
+        assert torch.equal(out[:12], ref.reshape(12, T + H, 7, 128))
+        assert torch.equal(out[12:], tail[0])
+        # without fixed noise the call still runs (fresh kernel noise per frame) and differs from the fixed-noise run
+        out_r = harness.extract_and_rollout(savi, roll, videos, H, batch_size=bs)
+        assert out_r.shape == out.shape and torch.isfinite(out_r).all() and not torch.equal(out_r, out)
