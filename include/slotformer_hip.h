@@ -501,6 +501,25 @@ int sf_slot_attn_iter_f32_host(const float* k_host, const float* v_host, int ld,
                                int B, int HW, int N, int D, float scale, float eps, void* stream);
 int sf_rollout_f32_host(const sf_rollouter* m, float* slots_host, int B, int T_total, int pred_len, void* ws,
                         size_t ws_bytes, void* stream);
+/* Single-pass bf16 variant of sf_rollout_f32 (SURVEY.md 8(b2) `sf_rollout_bf16`; the reference's `--fp16` AMP,
+ * scripts/train.py:84,105, and BASELINE.json's literal "bf16"): same arguments and storage (f32), every matrix product with
+ * operands rounded to bf16 and f32 accumulation.  ~8e-3 relative on the 6+50 path of config C2 -- outside the 1e-3 parity
+ * bar, so it is an option, never the default. */
+int sf_rollout_bf16(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws, size_t ws_bytes,
+                    void* stream);
+int sf_rollout_bf16_host(const sf_rollouter* m, float* slots_host, int B, int T_total, int pred_len, void* ws,
+                         size_t ws_bytes, void* stream);
+/* host twins of the slot update (savi.py:95-100) and of the K/V producer (savi.py:245-250,66-70): data buffers on the host,
+ * weights on the device */
+int sf_slot_update_f32_host(const float* part_num_host, const float* part_den_host, int P, const float* slots_prev_host,
+                            const float* gru_w_ih, const float* gru_w_hh, const float* gru_b_ih, const float* gru_b_hh,
+                            const float* ln_g, const float* ln_b, const float* mlp_w1, const float* mlp_b1,
+                            const float* mlp_w2, const float* mlp_b2, float* slots_out_host, int B, int N, int D, int H,
+                            float ln_eps, void* stream);
+int sf_kv_producer_f32_host(const float* feat_host, const float* ln0_g, const float* ln0_b, const float* fc1_w,
+                            const float* fc1_b, const float* fc2_w, const float* fc2_b, const float* ln1_g,
+                            const float* ln1_b, const float* kv_w, float* kv_host, int M, int C0, int C1, int D, float ln_eps,
+                            void* ws, size_t ws_bytes, void* stream);
 int sf_savi_encode_f32_host(const sf_savi_encoder* m, const float* img_host, const float* noise_host,
                             const float* prev_slots_host, float* lstm_h_host, float* lstm_c_host, int state_valid,
                             float* post_slots_host, float* kernel_dist_host, float* attn_host, int B, int T, void* ws,

@@ -201,4 +201,67 @@ int sf_slot_attn_iter_f32_host(const float* k_host, const float* v_host, int ld,
   return 0;
 }
 
+// host twin of sf_slot_update_f32: the partial sums, the previous slots and the result are host buffers; the weights are
+// device pointers (sf_device_upload) like every model parameter
+int sf_slot_update_f32_host(const float* part_num_host, const float* part_den_host, int P, const float* slots_prev_host,
+                            const float* gru_w_ih, const float* gru_w_hh, const float* gru_b_ih, const float* gru_b_hh,
+                            const float* ln_g, const float* ln_b, const float* mlp_w1, const float* mlp_b1,
+                            const float* mlp_w2, const float* mlp_b2, float* slots_out_host, int B, int N, int D, int H,
+                            float ln_eps, void* stream) {
+  SF_REQUIRE(part_num_host && part_den_host && slots_prev_host && slots_out_host && B > 0 && P > 0, "sf_slot_update_f32_host: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t f4 = sizeof(float);
+  Staged pn, pd, sp, so;
+  SF_TRY(pn.init(part_num_host, nullptr, (size_t)B * P * N * D * f4, st));
+  SF_TRY(pd.init(part_den_host, nullptr, (size_t)B * P * N * f4, st));
+  SF_TRY(sp.init(slots_prev_host, nullptr, (size_t)B * N * D * f4, st));
+  SF_TRY(so.init(nullptr, slots_out_host, (size_t)B * N * D * f4, st));
+  SF_TRY(sf_slot_update_f32((const float*)pn.d, (const float*)pd.d, P, (const float*)sp.d, gru_w_ih, gru_w_hh, gru_b_ih, gru_b_hh,
+                            ln_g, ln_b, mlp_w1, mlp_b1, mlp_w2, mlp_b2, (float*)so.d, B, N, D, H, ln_eps, stream));
+  SF_TRY(so.flush(st));
+  SF_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+// host twin of sf_kv_producer_f32: feat / kv are host buffers, the weights device pointers; ws == NULL -> allocated here
+int sf_kv_producer_f32_host(const float* feat_host, const float* ln0_g, const float* ln0_b, const float* fc1_w,
+                            const float* fc1_b, const float* fc2_w, const float* fc2_b, const float* ln1_g,
+                            const float* ln1_b, const float* kv_w, float* kv_host, int M, int C0, int C1, int D, float ln_eps,
+                            void* ws, size_t ws_bytes, void* stream) {
+  SF_REQUIRE(feat_host && kv_host && M > 0 && C0 > 0 && C1 > 0 && D > 0, "sf_kv_producer_f32_host: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t f4 = sizeof(float);
+  Staged f, kv, w;
+  SF_TRY(f.init(feat_host, nullptr, (size_t)M * C0 * f4, st));
+  SF_TRY(kv.init(nullptr, kv_host, (size_t)M * 2 * D * f4, st));
+  if (ws == nullptr) {
+    ws_bytes = sf_kv_producer_workspace_bytes(M, C1);
+    if (ws_bytes) SF_HIP(hipMalloc(&w.d, ws_bytes));
+    ws = w.d;
+  }
+  SF_TRY(sf_kv_producer_f32((const float*)f.d, ln0_g, ln0_b, fc1_w, fc1_b, fc2_w, fc2_b, ln1_g, ln1_b, kv_w, (float*)kv.d, M, C0,
+                            C1, D, ln_eps, ws, ws_bytes, stream));
+  SF_TRY(kv.flush(st));
+  SF_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+int sf_rollout_bf16_host(const sf_rollouter* m, float* slots_host, int B, int T_total, int pred_len, void* ws,
+                         size_t ws_bytes, void* stream) {
+  SF_REQUIRE(m && slots_host && B > 0 && T_total > 0, "sf_rollout_bf16_host: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nb = (size_t)B * T_total * m->num_slots * m->slot_size * sizeof(float);
+  Staged s, w;
+  SF_TRY(s.init(slots_host, slots_host, nb, st));
+  if (ws == nullptr) {
+    ws_bytes = sf_rollout_workspace_bytes(m, B);
+    SF_HIP(hipMalloc(&w.d, ws_bytes));
+    ws = w.d;
+  }
+  SF_TRY(sf_rollout_bf16(m, (float*)s.d, B, T_total, pred_len, ws, ws_bytes, stream));
+  SF_TRY(s.flush(st));
+  SF_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
 }  // extern "C"

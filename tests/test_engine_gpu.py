@@ -107,6 +107,8 @@ def test_steve_golden_and_masks(dev):
     n_diff = int((am != torch.from_numpy(g['argmax'])).sum())
     print(f'argmax: {n_unsafe} sub-margin pixels of {safe.numel()}, {n_diff} differ')
     assert n_diff <= n_unsafe
+    # the escape hatch stays small: the fixture has a handful of near-ties (49152 mask pixels), a regression cannot hide there
+    assert n_unsafe <= 16 and n_diff <= 2, (n_unsafe, n_diff)
 
 
 @pytest.mark.parametrize('B', [1, 5, 33, 70])
@@ -230,6 +232,10 @@ def test_steve_slotformer_golden(dev, tmp_path):
     ('roll_c4', gu.C4_ROLL, 2, 12, 204),
     ('roll_c4_ref', gu.C4_ROLL_REF, 1, 4, 214),
     ('roll_c5', gu.C5_ROLL, 2, 12, 205),
+    # BASELINE.json's full horizons: C4 6+40 (8 layers, slot size 192) and C5 1+80 (window growing 8 -> 48 tokens, then
+    # sliding; single_step_slotformer.py:49-90), compared over the whole rollout
+    ('roll_c4_full', gu.C4_ROLL, 1, 40, 224),
+    ('roll_c5_full', gu.C5_ROLL, 1, 80, 225),
 ])
 @torch.no_grad()
 def test_rollout_golden(dev, name, cfg, B, pred_len, seed):
@@ -404,3 +410,61 @@ def test_full_size_properties(dev):
     assert torch.isfinite(p50).all() and p50.shape == (B, H, 7, 128)
     # a 2-video batch selects other GEMM tile / split-K configurations (different summation order, same math)
     assert rel_err(roll(a[3:5].contiguous(), 10), p50[3:5, :10].cpu()) < 1e-4
+
+
+@pytest.mark.parametrize('name,cfg,seed,B,H', [('C4', gu.C4_ROLL, 224, 16, 40), ('C5', gu.C5_ROLL, 225, 64, 80)])
+@torch.no_grad()
+def test_full_size_properties_c4_c5(dev, name, cfg, seed, B, H):
+    """BASELINE configs C4 (Physion, slot size 192, 8 layers, 6+40, B=16) and C5 (PHYRE, single-step rollouter, 1+80,
+    B=64) at FULL size and horizon: determinism, batch independence, restart composition (C4: a rollout restarted from its
+    own last 6 frames continues bit-identically; C5's growing window has no such restart rule -- prefix consistency
+    instead), finite outputs; plus the B=1 golden rows inside the big batch."""
+    g = gu.load_golden('roll_c4_full' if name == 'C4' else 'roll_c5_full')
+    m, _ = build(cfg, g, seed, dev, vp=True)
+    roll = m.rollouter
+    rd = cfg['rollout_dict']
+    hist, N, C = rd['history_len'], rd['num_slots'], rd['slot_size']
+    x = gu.seeded_normal((B, hist, N, C), seed + 50).to(dev)
+    # video 0 of the big batch = the burn-in of the B=1 reference fixture: its rows must match the reference's own output
+    x[0] = gu.seeded_normal((1, hist + H, N, C), seed + 1)[0, :hist].to(dev)
+    full = roll(x, H)
+    assert full.shape == (B, H, N, C) and torch.isfinite(full).all()
+    assert torch.equal(full, roll(x, H))                                   # determinism
+    e = rel_err(full[:1], g['pred_slots'])
+    print(name, 'video 0 of the full batch vs the reference fixture over the whole horizon: rel err', e)
+    assert e < 2e-4
+    half = roll(x, H // 2)
+    assert torch.equal(half, full[:, :H // 2])                             # prefix consistency
+    sub = roll(x[5:9].contiguous(), 12)                                    # other tile / split configurations: same math
+    assert rel_err(sub, full[5:9, :12].cpu()) < 1e-4
+    if name == 'C4':
+        histb = torch.cat([x, half], 1)[:, -hist:].contiguous()
+        assert torch.equal(roll(histb, H - H // 2), full[:, H // 2:])       # restart composition
+
+
+@torch.no_grad()
+def test_rollout_bf16_entry_point_error_is_measured(dev):
+    """`sf_rollout_bf16` (single-pass bf16 products = the reference's --fp16 AMP / BASELINE's literal "bf16")
+    on the 6+50 path of config C2 against the REFERENCE fixture: the error is an order of magnitude above the split-bf16
+    default and outside the 1e-3 parity bar -- the number DESIGN.md quotes for keeping bf16x3 as the product path."""
+    import ctypes as C
+    from slotformer_amd import engine, _lib
+    g = gu.load_golden('roll_c2')
+    m, _ = build(gu.C2_ROLL, g, 202, dev, vp=True)
+    rd = gu.C2_ROLL['rollout_dict']
+    W, N, Cs, H = rd['history_len'], rd['num_slots'], rd['slot_size'], 50
+    slots = gu.seeded_normal((2, W + H, N, Cs), 203).to(dev)
+    plan = engine.rollouter_plan(m.rollouter)
+    lib = _lib.lib()
+    ws = engine.workspace(dev, lib.sf_rollout_workspace_bytes(C.byref(plan.struct), 2), ('roll', 'bf16'))
+    buf = slots.clone()
+    _lib.check(lib.sf_rollout_bf16(C.byref(plan.struct), buf.data_ptr(), 2, W + H, H, ws.data_ptr(), ws.numel(),
+                                   torch.cuda.current_stream().cuda_stream))
+    e16 = rel_err(buf[:, W:], g['pred_slots'])
+    buf = slots.clone()
+    engine.rollout(m.rollouter, buf, W, H)
+    e3 = rel_err(buf[:, W:], g['pred_slots'])
+    print(f'6+50 rollout vs the reference fixture: single-pass bf16 {e16:.2e}, split-bf16 (default) {e3:.2e}')
+    assert e3 < 2e-4
+    assert 1e-3 < e16 < 5e-2, e16      # usable as an option, not as the parity path
+    assert lib.sf_get_precision() == 1  # the entry point restores the library mode

@@ -123,3 +123,56 @@ def test_kv_producer_matches_oracle(dev, precision):
     e = ((kv.cpu() - ref).abs().max() / ref.abs().max()).item()
     print('kv producer rel err', e)
     assert e < 5e-5
+
+
+def test_kv_producer_host_twin(dev):
+    """sf_kv_producer_f32_host: host feature / kv buffers, weights on the device, workspace allocated by the twin."""
+    M, C0, C1, D = 4096, 64, 128, 128
+    rs = np.random.RandomState(12)
+    t = lambda *s: rs.standard_normal(s).astype(np.float32)  # noqa: E731
+    feat = t(M, C0)
+    ln0g, ln0b, ln1g, ln1b = 1 + 0.1 * t(C0), 0.1 * t(C0), 1 + 0.1 * t(C1), 0.1 * t(C1)
+    w1, b1, w2, b2, wkv = t(C1, C0) / 8, 0.1 * t(C1), t(C1, C1) / 11, 0.1 * t(C1), t(2 * D, C1) / 11
+    T = torch.from_numpy
+    h = oracle.layer_norm(T(feat), T(ln0g), T(ln0b))
+    h = torch.relu(h @ T(w1).t() + T(b1)) @ T(w2).t() + T(b2)
+    ref = (oracle.layer_norm(h, T(ln1g), T(ln1b)) @ T(wkv).t()).numpy()
+    arena = DeviceArena()
+    try:
+        wd = [arena.put(np.ascontiguousarray(x)) for x in (ln0g, ln0b, w1, b1, w2, b2, ln1g, ln1b, wkv)]
+        kv = np.zeros((M, 2 * D), np.float32)
+        check(lib().sf_kv_producer_f32_host(host(feat), *wd, host(kv), M, C0, C1, D, 1e-5, None, 0, None))
+    finally:
+        arena.close()
+    e = np.abs(kv - ref).max() / np.abs(ref).max()
+    print('kv producer host twin rel err', e)
+    assert e < 5e-5
+
+
+def test_slot_update_host_twin(dev):
+    """sf_slot_update_f32_host vs savi.py:95-100 restated with torch's GRUCell / LayerNorm on the CPU."""
+    B, N, D, H, P = 3, 7, 128, 256, 16
+    rs = np.random.RandomState(13)
+    t = lambda *s: rs.standard_normal(s).astype(np.float32)  # noqa: E731
+    num, den = t(B, P, N, D), np.abs(t(B, P, N)) + 0.5
+    prev = t(B, N, D)
+    gru = torch.nn.GRUCell(D, D)
+    ln = torch.nn.LayerNorm(D)
+    fc1, fc2 = torch.nn.Linear(D, H), torch.nn.Linear(H, D)
+    with torch.no_grad():
+        upd = torch.from_numpy(num.sum(1) / den.sum(1)[..., None])
+        s = gru(upd.reshape(-1, D), torch.from_numpy(prev).reshape(-1, D))
+        ref = (s + fc2(torch.relu(fc1(ln(s))))).reshape(B, N, D).numpy()
+    tr = lambda w: np.ascontiguousarray(w.detach().numpy().T)  # noqa: E731  ([in, out] layout of the slot-update kernel)
+    vec = lambda w: np.ascontiguousarray(w.detach().numpy())  # noqa: E731
+    arena = DeviceArena()
+    try:
+        wd = [arena.put(x) for x in (tr(gru.weight_ih), tr(gru.weight_hh), vec(gru.bias_ih), vec(gru.bias_hh), vec(ln.weight),
+                                     vec(ln.bias), tr(fc1.weight), vec(fc1.bias), tr(fc2.weight), vec(fc2.bias))]
+        out = np.zeros((B, N, D), np.float32)
+        check(lib().sf_slot_update_f32_host(host(num), host(den), P, host(prev), *wd, host(out), B, N, D, H, 1e-5, None))
+    finally:
+        arena.close()
+    e = np.abs(out - ref).max() / np.abs(ref).max()
+    print('slot update host twin rel err', e)
+    assert e < 2e-5

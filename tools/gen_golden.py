@@ -670,6 +670,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'savi_train_c1':
         case_savi_train('savi_train_c1', gu.C1_SAVI, B=1, T=3, seed=911, noise_seed=None, no_dropout=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'roll_full':   # BASELINE horizons of C4 (6+40) and C5 (1+80), whole rollout
+        case_rollout('roll_c4_full', gu.C4_ROLL, B=1, pred_len=40, seed=224)
+        case_rollout('roll_c5_full', gu.C5_ROLL, B=1, pred_len=80, seed=225, single_step=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'roll_train':
         case_rollout_grads('roll_train', gu.TRAIN_ROLL, B=2, seed=801)
         case_rollout_grads('roll_train_img', gu.TRAIN_ROLL_IMG, B=1, seed=811, img=True)
@@ -685,6 +689,8 @@ def main():
     case_rollout('roll_c4', gu.C4_ROLL, B=2, pred_len=12, seed=204)
     case_rollout('roll_c4_ref', gu.C4_ROLL_REF, B=1, pred_len=4, seed=214)
     case_rollout('roll_c5', gu.C5_ROLL, B=2, pred_len=12, seed=205, single_step=True)
+    case_rollout('roll_c4_full', gu.C4_ROLL, B=1, pred_len=40, seed=224)
+    case_rollout('roll_c5_full', gu.C5_ROLL, B=1, pred_len=80, seed=225, single_step=True)
     case_h2('harness_h2', gu.C1_ROLL, B=2, seed=301, frame_offset=2)
     case_decode('decode_c2', gu.savi_cfg(64, 7, kernel_mlp=False, pred='mlp', rnn=False), Fr=2, seed=401)
     case_phyre('harness_h3', gu.C5_SAVI, gu.C5_ROLL, B=2, vid_len=5, seed=501)
