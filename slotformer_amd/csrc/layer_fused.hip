@@ -89,7 +89,11 @@ constexpr size_t A2_O_OFF = A2_OT_OFF + (size_t)8 * 32 * QSTR * 4;           // 
 constexpr size_t A2_XS_OFF = A2_O_OFF + (size_t)2 * FA_ROWS * A2_OP * 2;     // residual stash [64][A2_XS] f32
 constexpr size_t A2_GB_OFF = A2_XS_OFF + (size_t)FA_ROWS * A2_XS * 4;        // LN gamma | beta [2][256], q|k|v bias [192]
 constexpr size_t A2_LDS = A2_GB_OFF + (2 * LF_D + 6 * 32) * 4;
-static_assert((size_t)2 * 3 * FA_ROWS * QSTR * 4 <= A2_PLANES, "q/k/v tiles must fit over the dead LN(x) planes");
+// q / k / v^T of the attention core as split-bf16 planes: pitches of 80 / 144 bytes keep the 16-byte fragment reads of a
+// 16-lane group on distinct banks (5 r and 9 r are permutations mod 16)
+constexpr int AT_QP = LF_HD + 8, AT_QPL = FA_ROWS * AT_QP;     // q / k plane [64][40]
+constexpr int AT_VP = FA_ROWS + 8, AT_VPL = LF_HD * AT_VP;     // v^T plane [32][72]
+static_assert((size_t)(8 * AT_QPL + 4 * AT_VPL) * 2 <= A2_PLANES, "q/k/v tiles must fit over the dead LN(x) planes");
 
 __global__ void pack_attn_kernel(const float* __restrict__ win, const float* __restrict__ wo, uint4* __restrict__ pq,
                                  uint4* __restrict__ po) {
@@ -135,7 +139,8 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __bf16* Ah = (__bf16*)smem;                                  // [64][A2_AP]  LN1(x), all of K
   __bf16* Al = Ah + FA_ROWS * A2_AP;
-  float* QKV = (float*)((char*)smem + A2_QKV_OFF);             // [2][3][64][QSTR]
+  __bf16* QKp = (__bf16*)((char*)smem + A2_QKV_OFF);           // q, k: [2 heads][q,k][hi,lo][64][AT_QP] (over the dead planes)
+  __bf16* Vtp = QKp + 8 * AT_QPL;                              // v^T:  [2 heads][hi,lo][32][AT_VP]
   float* SM = (float*)((char*)smem + A2_ST_OFF);               // [8][32] running max
   float* SL = SM + 8 * 32;                                     // [8][32] sum of exp
   float* OT = (float*)((char*)smem + A2_OT_OFF);               // [8][32][QSTR]
@@ -319,17 +324,40 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
       for (int r = 0; r < 16; ++r) acc[q2][r] += PS[(((wave - 4) * 2 + q2) * 16 + r) * 64 + lane];
   }
   if (wave < 6) {
-    const int which = wave % 3, hh = wave / 3;
+    const int which = wave % 3, hh = wave / 3, kg = lane >> 5;
     const float mul = which == 0 ? scale : 1.f;
 #pragma unroll
     for (int rbk = 0; rbk < 2; ++rbk) {
       if (rbk < nrb) {
-        float* dstm = QKV + ((hh * 3 + which) * FA_ROWS + rbk * 32 + (lane & 31)) * QSTR + 4 * (lane >> 5);
+        const int tokn = rbk * 32 + (lane & 31);
+        if (which < 2) {
+          // q (pre-scaled) and k: split-bf16 planes [token][channel], 8-byte stores
+          __bf16* ph = QKp + ((hh * 2 + which) * 2) * AT_QPL;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 bv = *(const f32x4*)(GB + 2 * LF_D + wave * 32 + 8 * g + 4 * (lane >> 5));
-          *(f32x4*)(dstm + 8 * g) = f32x4{(acc[rbk][4 * g] + bv[0]) * mul, (acc[rbk][4 * g + 1] + bv[1]) * mul,
-                                         (acc[rbk][4 * g + 2] + bv[2]) * mul, (acc[rbk][4 * g + 3] + bv[3]) * mul};
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *(const f32x4*)(GB + 2 * LF_D + wave * 32 + 8 * g + 4 * kg);
+            split4(ph, ph + AT_QPL, tokn * AT_QP + 8 * g + 4 * kg,
+                   f32x4{(acc[rbk][4 * g] + bv[0]) * mul, (acc[rbk][4 * g + 1] + bv[1]) * mul, (acc[rbk][4 * g + 2] + bv[2]) * mul,
+                         (acc[rbk][4 * g + 3] + bv[3]) * mul});
+          }
+        } else {
+          // v: TRANSPOSED split-bf16 planes [channel][key position]; inside every group of 16 keys bits 2 and 3 of the key
+          // index are swapped, so that the 8 keys a lane of the PV MFMA contracts over (the keys its score registers hold)
+          // are one 16-byte read
+          __bf16* vh = Vtp + (hh * 2) * AT_VPL;
+          const int o = tokn & 15, kpos = (tokn & ~15) | (o & 3) | ((o & 4) << 1) | ((o & 8) >> 1);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *(const f32x4*)(GB + 2 * LF_D + wave * 32 + 8 * g + 4 * kg);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float val = acc[rbk][4 * g + q] + bv[q];
+              const __bf16 hi = (__bf16)val;
+              const int off = (8 * g + 4 * kg + q) * AT_VP + kpos;
+              vh[off] = hi;
+              vh[AT_VPL + off] = (__bf16)(val - (float)hi);
+            }
+          }
         }
       }
     }
@@ -344,9 +372,9 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
   const int hh = wave >> 2, sub = wave & 3;
   const int qb = (nrb == 2) ? (sub >> 1) : 0, kb = (nrb == 2) ? (sub & 1) : 0;
   const bool score_wave = sub < nrb * nrb;
-  const float* Qs = QKV + (hh * 3 + 0) * FA_ROWS * QSTR;
-  const float* Ks = QKV + (hh * 3 + 1) * FA_ROWS * QSTR;
-  const float* Vs = QKV + (hh * 3 + 2) * FA_ROWS * QSTR;
+  const __bf16* Qh = QKp + ((hh * 2 + 0) * 2) * AT_QPL;
+  const __bf16* Kh = QKp + ((hh * 2 + 1) * 2) * AT_QPL;
+  const __bf16* Vh = Vtp + (hh * 2) * AT_VPL;
   f32x16 oacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
@@ -355,13 +383,14 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
     f32x16 sacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-    const float* kp = Ks + (kb * 32 + (lane & 31)) * QSTR + 4 * (lane >> 5);
-    const float* qp = Qs + (qb * 32 + (lane & 31)) * QSTR + 4 * (lane >> 5);
+    const int ko = (kb * 32 + (lane & 31)) * AT_QP + 8 * (lane >> 5), qo = (qb * 32 + (lane & 31)) * AT_QP + 8 * (lane >> 5);
 #pragma unroll
-    for (int kq = 0; kq < HD / 8; ++kq) {
-      const f32x4 a = *(const f32x4*)(kp + kq * 8), bq = *(const f32x4*)(qp + kq * 8);
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], bq[s2], sacc, 0, 0, 0);
+    for (int ks = 0; ks < HD / 16; ++ks) {
+      const bf16x8 kh = *(const bf16x8*)(Kh + ko + 16 * ks), kl = *(const bf16x8*)(Kh + AT_QPL + ko + 16 * ks);
+      const bf16x8 qh = *(const bf16x8*)(Qh + qo + 16 * ks), ql = *(const bf16x8*)(Qh + AT_QPL + qo + 16 * ks);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, sacc, 0, 0, 0);
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -384,10 +413,24 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
       SM[wave * 32 + lane] = mx;
       SL[wave * 32 + lane] = sum;
     }
-    const float* vp = Vs + (kb * 32 + 4 * (lane >> 5)) * QSTR + (lane & 31);
+    // PV on the split-bf16 MFMA: register r of the score tile is key (r & 3) + 8 (r >> 2) + 4 (lane >> 5), so registers
+    // 8 s .. 8 s + 7 are exactly the 8 keys of k-step s that this lane contracts over (B operand), in the order the V^T
+    // planes were permuted to (A operand)
+    const int vo = (lane & 31) * AT_VP + kb * 32 + 8 * (lane >> 5);
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[((r & 3) + 8 * (r >> 2)) * QSTR], sacc[r], oacc, 0, 0, 0);
+    for (int ks = 0; ks < 2; ++ks) {
+      const f32x4 p0 = {sacc[8 * ks], sacc[8 * ks + 1], sacc[8 * ks + 2], sacc[8 * ks + 3]};
+      const f32x4 p1 = {sacc[8 * ks + 4], sacc[8 * ks + 5], sacc[8 * ks + 6], sacc[8 * ks + 7]};
+      const bf16x4 h0 = __builtin_convertvector(p0, bf16x4), h1 = __builtin_convertvector(p1, bf16x4);
+      const bf16x4 l0 = __builtin_convertvector(p0 - __builtin_convertvector(h0, f32x4), bf16x4);
+      const bf16x4 l1 = __builtin_convertvector(p1 - __builtin_convertvector(h1, f32x4), bf16x4);
+      const bf16x8 ph = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+      const bf16x8 pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+      const bf16x8 vh = *(const bf16x8*)(Vh + vo + 16 * ks), vl = *(const bf16x8*)(Vh + AT_VPL + vo + 16 * ks);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, oacc, 0, 0, 0);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, oacc, 0, 0, 0);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, oacc, 0, 0, 0);
+    }
   }
   __syncthreads();
   LF_TA(21);
