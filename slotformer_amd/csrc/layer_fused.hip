@@ -279,20 +279,40 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
   for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q2][r] = 0.f;
+  // v column blocks (cb % 3 == 2) run with the operands SWAPPED (LN(x) as A, weights as B): their accumulators then hold
+  // 16 tokens of ONE channel per lane, which is what the transposed V planes of the attention core are written from
+  const bool vblock = (wcb % 3) == 2;
   {
     const int ao = (lane & 31) * A2_AP + 8 * (lane >> 5) + (wave >= 6 ? 8 * 16 : 0);
+    if (!vblock) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      if (ks >= 8 && wave >= 4) continue;
-      const bf16x8 xh0 = *(const bf16x8*)(Ah + ao + ks * 16), xl0 = *(const bf16x8*)(Al + ao + ks * 16);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xl0, acc[0], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][1], xh0, acc[0], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xh0, acc[0], 0, 0, 0);
-      if (nrb == 2) {
-        const bf16x8 xh1 = *(const bf16x8*)(Ah + ao + 32 * A2_AP + ks * 16), xl1 = *(const bf16x8*)(Al + ao + 32 * A2_AP + ks * 16);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xl1, acc[1], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][1], xh1, acc[1], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xh1, acc[1], 0, 0, 0);
+      for (int ks = 0; ks < 16; ++ks) {
+        if (ks >= 8 && wave >= 4) continue;
+        const bf16x8 xh0 = *(const bf16x8*)(Ah + ao + ks * 16), xl0 = *(const bf16x8*)(Al + ao + ks * 16);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xl0, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][1], xh0, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xh0, acc[0], 0, 0, 0);
+        if (nrb == 2) {
+          const bf16x8 xh1 = *(const bf16x8*)(Ah + ao + 32 * A2_AP + ks * 16), xl1 = *(const bf16x8*)(Al + ao + 32 * A2_AP + ks * 16);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xl1, acc[1], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][1], xh1, acc[1], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xh1, acc[1], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        if (ks >= 8 && wave >= 4) continue;
+        const bf16x8 xh0 = *(const bf16x8*)(Ah + ao + ks * 16), xl0 = *(const bf16x8*)(Al + ao + ks * 16);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl0, wq[ks][0], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, wq[ks][1], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, wq[ks][0], acc[0], 0, 0, 0);
+        if (nrb == 2) {
+          const bf16x8 xh1 = *(const bf16x8*)(Ah + ao + 32 * A2_AP + ks * 16), xl1 = *(const bf16x8*)(Al + ao + 32 * A2_AP + ks * 16);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl1, wq[ks][0], acc[1], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh1, wq[ks][1], acc[1], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh1, wq[ks][0], acc[1], 0, 0, 0);
+        }
       }
     }
   }
@@ -341,22 +361,22 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
                          (acc[rbk][4 * g + 3] + bv[3]) * mul});
           }
         } else {
-          // v: TRANSPOSED split-bf16 planes [channel][key position]; inside every group of 16 keys bits 2 and 3 of the key
-          // index are swapped, so that the 8 keys a lane of the PV MFMA contracts over (the keys its score registers hold)
-          // are one 16-byte read
+          // v: TRANSPOSED split-bf16 planes [channel][key position].  The swapped-operand projection left token
+          // (r & 3) + 8 (r >> 2) + 4 kg of channel lane & 31 in register r, so registers 8 s .. 8 s + 7 go to key positions
+          // 16 s + 8 kg .. + 7 as ONE 16-byte store per plane -- i.e. inside every group of 16 keys bits 2 and 3 of the key
+          // index are swapped, which is exactly the order in which a lane of the PV MFMA holds its probabilities
           __bf16* vh = Vtp + (hh * 2) * AT_VPL;
-          const int o = tokn & 15, kpos = (tokn & ~15) | (o & 3) | ((o & 4) << 1) | ((o & 8) >> 1);
+          const float bch = GB[2 * LF_D + wave * 32 + (lane & 31)];
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 bv = *(const f32x4*)(GB + 2 * LF_D + wave * 32 + 8 * g + 4 * kg);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float val = acc[rbk][4 * g + q] + bv[q];
-              const __bf16 hi = (__bf16)val;
-              const int off = (8 * g + 4 * kg + q) * AT_VP + kpos;
-              vh[off] = hi;
-              vh[AT_VPL + off] = (__bf16)(val - (float)hi);
-            }
+          for (int sg = 0; sg < 2; ++sg) {
+            const f32x4 a0 = {acc[rbk][8 * sg] + bch, acc[rbk][8 * sg + 1] + bch, acc[rbk][8 * sg + 2] + bch, acc[rbk][8 * sg + 3] + bch};
+            const f32x4 a1 = {acc[rbk][8 * sg + 4] + bch, acc[rbk][8 * sg + 5] + bch, acc[rbk][8 * sg + 6] + bch, acc[rbk][8 * sg + 7] + bch};
+            const bf16x4 h0 = __builtin_convertvector(a0, bf16x4), h1 = __builtin_convertvector(a1, bf16x4);
+            const bf16x4 l0 = __builtin_convertvector(a0 - __builtin_convertvector(h0, f32x4), bf16x4);
+            const bf16x4 l1 = __builtin_convertvector(a1 - __builtin_convertvector(h1, f32x4), bf16x4);
+            const int off = (lane & 31) * AT_VP + rbk * 32 + 16 * sg + 8 * kg;
+            *(bf16x8*)(vh + off) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            *(bf16x8*)(vh + AT_VPL + off) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
           }
         }
       }
