@@ -401,6 +401,8 @@ typedef struct {
   const sf_tfm_layer* pred_layers; /* HOST array */
   const float *lstm_w_ih, *lstm_w_hh, *lstm_b_ih, *lstm_b_hh, *proj_w, *proj_b;
   float sa_eps;
+  const float* sa_q_w_t; /* optional: project_q weight transposed [in, out] (coalesced reads for the slot-update kernel, which
+                          * then also emits the next iteration's q); NULL: q comes from a separate LN-fused GEMM launch */
 } sf_savi_encoder;
 
 size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B);

@@ -548,22 +548,28 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
     }
     // ---- Slot Attention iterations (savi.py:76-100) -------------------------------------------
     const float scale = 1.0f / sqrtf((float)D);
+    // q of the first iteration: LN-fused GEMM; every later q comes out of the slot-update kernel, which also writes the
+    // last iteration's result straight into post_slots[:, t]
+    SF_TRY(sf_linear_ex(s_in, sf_rows(D), m->sa_q_w, nullptr, m->sa_q_ln_g, m->sa_q_ln_b, ln_eps, nullptr,
+                        sf_rows(D), 0, q, sf_rows(D), R, D, D, 0, st));
     for (int it = 0; it < m->num_iterations; ++it) {
-      SF_TRY(sf_linear_ex(s_in, sf_rows(D), m->sa_q_w, nullptr, m->sa_q_ln_g, m->sa_q_ln_b, ln_eps, nullptr,
-                          sf_rows(D), 0, q, sf_rows(D), R, D, D, 0, st));
-      float* aout = (attn && it == m->num_iterations - 1) ? attn + (long long)t * N * HW : nullptr;
+      const bool last_it = (it == m->num_iterations - 1);
+      float* aout = (attn && last_it) ? attn + (long long)t * N * HW : nullptr;
       SF_TRY(sf_slot_attn_iter_ex(kv, kv + D, 2 * D, (long long)HW * 2 * D, q, pnum, pden, aout,
                                   (long long)T * N * HW, B, HW, N, D, scale, m->sa_eps, st));
-      SF_TRY(sf_slot_update_f32(pnum, pden, P, s_in, m->gru_w_ih, m->gru_w_hh, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g,
-                                m->mlp_ln_b, m->mlp_w1, m->mlp_b1, m->mlp_w2, m->mlp_b2, s_out, B, N, D, Hm, ln_eps,
-                                st));
+      SF_TRY(sf_slot_update_ex(pnum, pden, P, s_in, m->gru_w_ih, m->gru_w_hh, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g,
+                               m->mlp_ln_b, m->mlp_w1, m->mlp_b1, m->mlp_w2, m->mlp_b2, s_out,
+                               last_it ? post_slots + (long long)t * N * D : nullptr, (long long)T * N * D,
+                               m->sa_q_ln_g, m->sa_q_ln_b, m->sa_q_w_t, (last_it || !m->sa_q_w_t) ? nullptr : q, B, N, D, Hm, ln_eps,
+                               st));
+      if (!last_it && !m->sa_q_w_t)   // no transposed copy of project_q given: the LN-fused GEMM produces q
+        SF_TRY(sf_linear_ex(s_out, sf_rows(D), m->sa_q_w, nullptr, m->sa_q_ln_g, m->sa_q_ln_b, ln_eps, nullptr, sf_rows(D), 0, q,
+                            sf_rows(D), R, D, D, 0, st));
       float* tmp = s_in;
       s_in = s_out;
       s_out = tmp;
     }
-    // s_in now holds post_slots of step t
-    SF_TRY(sf_copy_rows_ex(s_in, sf_rows(D), post_slots,
-                           sf_rows_batched(D, N, (long long)T * N * D, (long long)t * N * D), R, D, st));
+    // s_in now holds post_slots of step t (also written to post_slots[:, t] by the last slot update)
     // prev_slots for the next step must not alias the ping-pong buffers that step overwrites:
     // keep it in `lnbuf`-independent storage (q is rewritten first, so use latents' twin `px`?)
     // -> simplest: the next step reads `prev` only before it writes slotsA/slotsB.

@@ -17,6 +17,12 @@ int sf_sample_dist_ex(const float* dist, const float* noise, SfRowMap nmap, floa
 int sf_copy_rows_ex(const float* src, SfRowMap smap, float* dst, SfRowMap dmap, int rows, int cols,
                     hipStream_t st);
 int sf_sa_pick_partials(int HW);
+int sf_slot_update_ex(const float* part_num, const float* part_den, int P, const float* slots_prev,
+                      const float* gru_w_ih, const float* gru_w_hh, const float* gru_b_ih, const float* gru_b_hh,
+                      const float* ln_g, const float* ln_b, const float* mlp_w1, const float* mlp_b1, const float* mlp_w2,
+                      const float* mlp_b2, float* slots_out, float* out2, long long out2_bs, const float* q_ln_g,
+                      const float* q_ln_b, const float* q_w, float* q_out, int B, int N, int D, int H, float ln_eps,
+                      hipStream_t st);
 int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch_stride, const float* q,
                          float* part_num, float* part_den, float* attn_out, long long attn_batch_stride, int B,
                          int HW, int N, int D, float scale, float eps, hipStream_t st);

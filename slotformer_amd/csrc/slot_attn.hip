@@ -322,68 +322,220 @@ __device__ __forceinline__ void col_dot2(const float* __restrict__ wa, const flo
   rb = b;
 }
 
-__global__ __launch_bounds__(768) void sa_slot_update_kernel(
+// Slot update (savi.py:95-100) for SU_R rows (= slots) per workgroup: updates = sum(num) / sum(den); GRUCell; slots + MLP(LN).
+// One workgroup per slot (the first version) made every workgroup stream all 655 KB of GRU / MLP weights for a single
+// row -- 147 MB through the CUs for 224 rows, 27 us.  Here a thread still owns one output feature, but carries it for
+// 8 rows at once: every weight is loaded once per workgroup and used 8 times, the row vectors sit in LDS k-major
+// ([feature][row], two 16-byte broadcasts per k).  The accumulation order over k is the same as before, per row.
+// Optionally the kernel also emits q = LN_q(slots_out) Wq^T for the NEXT Slot-Attention iteration (savi.py:79, the
+// LN-fused GEMM launch it replaces) and a second copy of slots_out into a strided [B,T,N,D] tensor (the encode loop's
+// post_slots, replacing a copy launch).
+constexpr int SU_R = 8;
+
+template <int NG>   // NG = number of accumulator groups of the caller (1: one matrix, 2: two matrices sharing the loop)
+struct SuAcc {
+  float a[NG][SU_R];
+};
+
+// acc[r] += w * x[k][r] over k; x k-major in LDS ([K][SU_R]); w column `col` of a [K][ldw] matrix (coalesced over threads)
+template <int UNR>
+__device__ __forceinline__ void su_col_dot(const float* __restrict__ w, int ldw, int col, const float* x, int K, float (&acc)[SU_R]) {
+#pragma unroll
+  for (int r = 0; r < SU_R; ++r) acc[r] = 0.f;
+  for (int k = 0; k < K; k += UNR) {
+    float wv[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) wv[u] = w[(long long)(k + u) * ldw + col];
+    // every weight request of this batch is in flight before the first multiply: without the fence the scheduler (short of
+    // registers for the hoisted LDS reads) issued ONE load per group of multiplies and waited for it -- 128 round trips
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const f32x4v x0 = *(const f32x4v*)(x + (k + u) * SU_R), x1 = *(const f32x4v*)(x + (k + u) * SU_R + 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[r] = fmaf(wv[u], x0[r], acc[r]);
+        acc[r + 4] = fmaf(wv[u], x1[r], acc[r + 4]);
+      }
+    }
+  }
+}
+
+// LayerNorm statistics of the SU_R rows held k-major in `x` ([D][SU_R]) -> stat[r] = {mean, rstd}; wave w handles rows
+// w, w + nwaves, ...  (same summation order per row as the single-row kernel had: lane-strided partial sums, wave reduce)
+__device__ __forceinline__ void su_ln_stats(const float* x, float* stat, int D, float eps, int wave, int lane, int nwaves) {
+  for (int r = wave; r < SU_R; r += nwaves) {
+    float sm = 0.f;
+    for (int d = lane; d < D; d += 64) sm += x[d * SU_R + r];
+    const float mean = sf_wave_sum(sm) / (float)D;
+    float vv = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      const float c = x[d * SU_R + r] - mean;
+      vv += c * c;
+    }
+    const float rstd = 1.0f / sqrtf(sf_wave_sum(vv) / (float)D + eps);
+    if (lane == 0) {
+      stat[2 * r] = mean;
+      stat[2 * r + 1] = rstd;
+    }
+  }
+}
+
+struct SuExtra {
+  float* out2;              // optional second destination of slots_out: row (b, n) at out2 + b * out2_bs + n * D
+  long long out2_bs;
+  const float* q_ln_g;      // optional q projection of the result (all NULL: off)
+  const float* q_ln_b;
+  const float* q_w;         // [D][D] TRANSPOSED project_q weight ([in][out])
+  float* q_out;             // [R][D]
+};
+
+// number of K slices a [K x Nout] product is split into across the workgroup's threads: as many as there are spare threads,
+// while a slice keeps at least 64 k-steps (one batch of weight requests per thread = ONE memory round trip per phase)
+__host__ __device__ inline int su_kslices(int nthreads, int Nout, int K) {
+  int ks = 1;
+  while (2 * ks * Nout <= nthreads && K / (2 * ks) >= 64 && (K % (2 * ks * 64)) == 0) ks *= 2;
+  return ks;
+}
+
+// part[(slice * Nout + j) * SU_R + r] = sum over the slice's k of w[k][j] * x[k][r]
+__device__ __forceinline__ void su_gemm(const float* __restrict__ w, int Nout, int K, const float* x, float* part, int t, int nt) {
+  const int ks = su_kslices(nt, Nout, K);
+  if (t < Nout * ks) {
+    const int j = t % Nout, kh = t / Nout, kr = K / ks;
+    float acc[SU_R];
+    su_col_dot<64>(w + (long long)kh * kr * Nout, Nout, j, x + kh * kr * SU_R, kr, acc);
+#pragma unroll
+    for (int r = 0; r < SU_R; ++r) part[(kh * Nout + j) * SU_R + r] = acc[r];
+  }
+}
+// fixed-order sum of the K slices of output feature j, row r
+__device__ __forceinline__ float su_sum(const float* part, int ks, int Nout, int j, int r) {
+  float v = part[j * SU_R + r];
+  for (int kh = 1; kh < ks; ++kh) v += part[(kh * Nout + j) * SU_R + r];
+  return v;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void sa_slot_update_kernel(
     const float* __restrict__ part_num, const float* __restrict__ part_den, int P,
     const float* __restrict__ slots_prev, const float* __restrict__ w_ih_t,
     const float* __restrict__ w_hh_t, const float* __restrict__ b_ih, const float* __restrict__ b_hh,
     const float* __restrict__ ln_g, const float* __restrict__ ln_b, const float* __restrict__ w1_t,
     const float* __restrict__ b1, const float* __restrict__ w2_t, const float* __restrict__ b2,
-    float* __restrict__ slots_out, int N, int D, int H, float ln_eps) {
-  const int row = blockIdx.x;  // b * N + n
-  const int b = row / N, n = row - b * N;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  __shared__ float s_u[SA_DMAX], s_h[SA_DMAX], s_gi[3 * SA_DMAX], s_gh[3 * SA_DMAX];
-  __shared__ float s_hn[SA_DMAX], s_ln[SA_DMAX], s_hid[SA_HMAX], s_stat[2];
+    float* __restrict__ slots_out, SuExtra ex, int R, int N, int D, int H, int pmax, float ln_eps) {
+  extern __shared__ __attribute__((aligned(16))) float su_lds[];
+  float* s_u = su_lds;                    // [D][SU_R]   updates; later the finished rows (input of the q projection)
+  float* s_h = s_u + D * SU_R;            // [D][SU_R]   previous slots
+  float* s_hn = s_h + D * SU_R;           // [D][SU_R]   GRU output
+  float* s_ln = s_hn + D * SU_R;          // [D][SU_R]
+  float* s_hid = s_ln + D * SU_R;         // [H][SU_R]
+  float* s_stat = s_hid + H * SU_R;       // [SU_R][2]
+  float* s_pa = s_stat + 2 * SU_R;        // K-slice partials of the running product ([slices][Nout][SU_R], pmax floats)
+  float* s_pb = s_pa + pmax;              // second partial buffer (the GRU has two products)
+  const int row0 = blockIdx.x * SU_R;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nt = blockDim.x, nwaves = nt >> 6;
 
-  // updates = sum_p num / sum_p den
-  if (t < D) {
-    float den = 0.f, a = 0.f;
-#pragma unroll 8
-    for (int p = 0; p < P; ++p) {
-      den += part_den[((long long)b * P + p) * N + n];
-      a += part_num[(((long long)b * P + p) * N + n) * D + t];
+  // updates = sum_p num / sum_p den; previous slots (rows beyond R: zeros).  The per-row denominators first (one lane per
+  // partial), then every (row, feature) pair with its P numerator loads in flight at once.
+  for (int r = wave; r < SU_R; r += nwaves) {
+    const int row = row0 + r;
+    float dv = 0.f;
+    if (row < R && lane < P) {
+      const int b = row / N, n = row - b * N;
+      dv = part_den[((long long)b * P + lane) * N + n];
     }
-    s_u[t] = a / den;
-    s_h[t] = slots_prev[(long long)row * D + t];
+    s_pa[r * 64 + lane] = dv;
   }
   __syncthreads();
-  // GRU gate pre-activations: thread j owns gate feature j of both matrices
-  if (t < 3 * D) {
-    float gi, gh;
-    col_dot2<32>(w_ih_t, w_hh_t, 3 * D, t, s_u, s_h, D, gi, gh);
-    s_gi[t] = gi + b_ih[t];
-    s_gh[t] = gh + b_hh[t];
-  }
-  __syncthreads();
-  if (t < D) {
-    const float r = sf_sigmoid(s_gi[t] + s_gh[t]);
-    const float z = sf_sigmoid(s_gi[D + t] + s_gh[D + t]);
-    const float nn = tanhf(s_gi[2 * D + t] + r * s_gh[2 * D + t]);
-    s_hn[t] = (1.f - z) * nn + z * s_h[t];
-  }
-  __syncthreads();
-  // LayerNorm(h')
-  if (wave == 0) {
-    float s = 0.f;
-    for (int d = lane; d < D; d += 64) s += s_hn[d];
-    const float mean = sf_wave_sum(s) / (float)D;
-    float vv = 0.f;
-    for (int d = lane; d < D; d += 64) {
-      const float c = s_hn[d] - mean;
-      vv += c * c;
+  for (int idx = t; idx < SU_R * D; idx += nt) {
+    const int r = idx / D, d = idx - r * D, row = row0 + r;
+    float u = 0.f, h = 0.f;
+    if (row < R) {
+      const int b = row / N, n = row - b * N;
+      float den = 0.f, a = 0.f;
+      const float* pn = part_num + ((long long)b * P * N + n) * D + d;
+#pragma unroll 16
+      for (int p = 0; p < P; ++p) a += pn[(long long)p * N * D];
+      for (int p = 0; p < P; ++p) den += s_pa[r * 64 + p];
+      u = a / den;
+      h = slots_prev[(long long)row * D + d];
     }
-    const float rstd = 1.0f / sqrtf(sf_wave_sum(vv) / (float)D + ln_eps);
-    if (lane == 0) {
-      s_stat[0] = mean;
-      s_stat[1] = rstd;
+    s_u[d * SU_R + r] = u;
+    s_h[d * SU_R + r] = h;
+  }
+  __syncthreads();
+  // GRU gate pre-activations: gi = W_ih u, gh = W_hh h (K slices across the threads)
+  su_gemm(w_ih_t, 3 * D, D, s_u, s_pa, t, nt);
+  su_gemm(w_hh_t, 3 * D, D, s_h, s_pb, t, nt);
+  __syncthreads();
+  {
+    const int ks = su_kslices(nt, 3 * D, D);
+    for (int idx = t; idx < SU_R * D; idx += nt) {
+      const int d = idx / SU_R, r = idx - d * SU_R;
+      const float gir = su_sum(s_pa, ks, 3 * D, d, r) + b_ih[d], ghr = su_sum(s_pb, ks, 3 * D, d, r) + b_hh[d];
+      const float giz = su_sum(s_pa, ks, 3 * D, D + d, r) + b_ih[D + d], ghz = su_sum(s_pb, ks, 3 * D, D + d, r) + b_hh[D + d];
+      const float gin = su_sum(s_pa, ks, 3 * D, 2 * D + d, r) + b_ih[2 * D + d], ghn = su_sum(s_pb, ks, 3 * D, 2 * D + d, r) + b_hh[2 * D + d];
+      const float rr = sf_sigmoid(gir + ghr);
+      const float z = sf_sigmoid(giz + ghz);
+      const float nn = tanhf(gin + rr * ghn);
+      s_hn[idx] = (1.f - z) * nn + z * s_h[idx];
     }
   }
   __syncthreads();
-  if (t < D) s_ln[t] = (s_hn[t] - s_stat[0]) * s_stat[1] * ln_g[t] + ln_b[t];
+  su_ln_stats(s_hn, s_stat, D, ln_eps, wave, lane, nwaves);
   __syncthreads();
-  if (t < H) s_hid[t] = fmaxf(col_dot<32>(w1_t, H, t, s_ln, D) + b1[t], 0.f);
+  for (int idx = t; idx < SU_R * D; idx += nt) {
+    const int d = idx / SU_R, r = idx - d * SU_R;
+    s_ln[idx] = (s_hn[idx] - s_stat[2 * r]) * s_stat[2 * r + 1] * ln_g[d] + ln_b[d];
+  }
   __syncthreads();
-  if (t < D) slots_out[(long long)row * D + t] = s_hn[t] + col_dot<32>(w2_t, D, t, s_hid, H) + b2[t];
+  su_gemm(w1_t, H, D, s_ln, s_pa, t, nt);
+  __syncthreads();
+  {
+    const int ks = su_kslices(nt, H, D);
+    for (int idx = t; idx < SU_R * H; idx += nt) {
+      const int j = idx / SU_R, r = idx - j * SU_R;
+      s_hid[idx] = fmaxf(su_sum(s_pa, ks, H, j, r) + b1[j], 0.f);
+    }
+  }
+  __syncthreads();
+  su_gemm(w2_t, D, H, s_hid, s_pb, t, nt);
+  __syncthreads();
+  {
+    const int ks = su_kslices(nt, D, H);
+    for (int idx = t; idx < SU_R * D; idx += nt) {
+      const int r = idx / D, d = idx - r * D, row = row0 + r;    // consecutive threads = consecutive features: coalesced stores
+      const float v = s_hn[d * SU_R + r] + su_sum(s_pb, ks, D, d, r) + b2[d];
+      s_u[d * SU_R + r] = v;
+      if (row < R) {
+        slots_out[(long long)row * D + d] = v;
+        if (ex.out2) {
+          const int b = row / N, n = row - b * N;
+          ex.out2[(long long)b * ex.out2_bs + (long long)n * D + d] = v;
+        }
+      }
+    }
+  }
+  if (ex.q_out == nullptr) return;
+  // ---- q = LN_q(slots_out) Wq^T for the next iteration (project_q, savi.py:45-48,79) ----
+  __syncthreads();
+  su_ln_stats(s_u, s_stat, D, ln_eps, wave, lane, nwaves);
+  __syncthreads();
+  for (int idx = t; idx < SU_R * D; idx += nt) {
+    const int d = idx / SU_R, r = idx - d * SU_R;
+    s_ln[idx] = (s_u[idx] - s_stat[2 * r]) * s_stat[2 * r + 1] * ex.q_ln_g[d] + ex.q_ln_b[d];
+  }
+  __syncthreads();
+  su_gemm(ex.q_w, D, D, s_ln, s_pa, t, nt);   // q_w: project_q weight transposed ([in][out])
+  __syncthreads();
+  {
+    const int ks = su_kslices(nt, D, D);
+    for (int idx = t; idx < SU_R * D; idx += nt) {
+      const int r = idx / D, d = idx - r * D;
+      if (row0 + r < R) ex.q_out[(long long)(row0 + r) * D + d] = su_sum(s_pa, ks, D, d, r);
+    }
+  }
 }
 
 // -----------------------------------------------------------------------------------------
@@ -456,28 +608,61 @@ int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch
   return 0;
 }
 
+// Slot update (savi.py:95-100): reduce partials -> GRUCell -> slots + MLP(LN(slots)); optional extras (second strided
+// copy of the result, q projection for the next iteration).  Weight matrices are TRANSPOSED torch weights
+// ([in, out] = weight.t().contiguous()), q_w included.
+int sf_slot_update_ex(const float* part_num, const float* part_den, int P, const float* slots_prev,
+                      const float* gru_w_ih, const float* gru_w_hh, const float* gru_b_ih, const float* gru_b_hh,
+                      const float* ln_g, const float* ln_b, const float* mlp_w1, const float* mlp_b1, const float* mlp_w2,
+                      const float* mlp_b2, float* slots_out, float* out2, long long out2_bs, const float* q_ln_g,
+                      const float* q_ln_b, const float* q_w, float* q_out, int B, int N, int D, int H, float ln_eps,
+                      hipStream_t st) {
+  SF_REQUIRE(part_num && part_den && slots_prev && slots_out, "null pointer");
+  SF_REQUIRE(gru_w_ih && gru_w_hh && gru_b_ih && gru_b_hh && ln_g && ln_b && mlp_w1 && mlp_b1 && mlp_w2 &&
+                 mlp_b2, "null weight pointer");
+  SF_REQUIRE(D > 0 && D <= SA_DMAX && (D % 64) == 0 && H > 0 && H <= SA_HMAX && (H % 64) == 0 && N >= 1 && P >= 1 && P <= 64,
+             "bad slot shape (slot_size and slot_mlp_size must be multiples of 64, at most 64 partial records)");
+  SF_REQUIRE(q_out == nullptr || (q_ln_g && q_ln_b && q_w), "q projection requested without its weights");
+  if (B == 0) return 0;
+  // 768 threads whenever 3 D fits: the spare threads take K slices of every product (one round trip of weight requests per
+  // phase instead of two to four)
+  int threads = 3 * D > H ? 3 * D : H;
+  threads = (threads + 63) & ~63;
+  if (threads < 768) threads = 768;
+  const int R = B * N;
+  auto pmaxf = [&](int Nout, int K) { return su_kslices(threads, Nout, K) * Nout * SU_R; };
+  int pmax = pmaxf(3 * D, D);
+  if (pmaxf(H, D) > pmax) pmax = pmaxf(H, D);
+  if (pmaxf(D, H) > pmax) pmax = pmaxf(D, H);
+  if (pmaxf(D, D) > pmax) pmax = pmaxf(D, D);
+  if (pmax < SU_R * 64) pmax = SU_R * 64;
+  const size_t lds = ((size_t)4 * D * SU_R + (size_t)H * SU_R + 2 * SU_R + 2 * (size_t)pmax) * sizeof(float);
+  auto kern = sa_slot_update_kernel<768>;
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    lds_set = lds;
+  }
+  SuExtra ex{out2, out2_bs, q_ln_g, q_ln_b, q_w, q_out};
+  sf_prof_begin(SF_K_SA_UPDATE, st, 0.0);
+  hipLaunchKernelGGL(kern, dim3((R + SU_R - 1) / SU_R), dim3(threads), lds, st, part_num, part_den, P, slots_prev, gru_w_ih,
+                     gru_w_hh, gru_b_ih, gru_b_hh, ln_g, ln_b, mlp_w1, mlp_b1, mlp_w2, mlp_b2, slots_out, ex, R, N, D, H,
+                     pmax, ln_eps);
+  sf_prof_end(SF_K_SA_UPDATE, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" {
-// Slot update (savi.py:95-100): reduce partials -> GRUCell -> slots + MLP(LN(slots)).
-// Weight matrices are TRANSPOSED torch weights ([in, out] = weight.t().contiguous()).
 int sf_slot_update_f32(const float* part_num, const float* part_den, int P, const float* slots_prev,
                        const float* gru_w_ih, const float* gru_w_hh, const float* gru_b_ih,
                        const float* gru_b_hh, const float* ln_g, const float* ln_b, const float* mlp_w1,
                        const float* mlp_b1, const float* mlp_w2, const float* mlp_b2, float* slots_out,
                        int B, int N, int D, int H, float ln_eps, void* stream) {
-  SF_REQUIRE(part_num && part_den && slots_prev && slots_out, "null pointer");
-  SF_REQUIRE(gru_w_ih && gru_w_hh && gru_b_ih && gru_b_hh && ln_g && ln_b && mlp_w1 && mlp_b1 && mlp_w2 &&
-                 mlp_b2, "null weight pointer");
-  SF_REQUIRE(D > 0 && D <= SA_DMAX && H > 0 && H <= SA_HMAX && N >= 1 && P >= 1, "bad slot shape");
-  if (B == 0) return 0;
-  sf_prof_begin(SF_K_SA_UPDATE, (hipStream_t)stream, 0.0);
-  int threads = 3 * D > H ? 3 * D : H;
-  threads = (threads + 63) & ~63;
-  hipLaunchKernelGGL(sa_slot_update_kernel, dim3(B * N), dim3(threads), 0, (hipStream_t)stream, part_num,
-                     part_den, P, slots_prev, gru_w_ih, gru_w_hh, gru_b_ih, gru_b_hh, ln_g, ln_b, mlp_w1,
-                     mlp_b1, mlp_w2, mlp_b2, slots_out, N, D, H, ln_eps);
-  sf_prof_end(SF_K_SA_UPDATE, (hipStream_t)stream);
-  SF_CHECK_LAUNCH();
-  return 0;
+  return sf_slot_update_ex(part_num, part_den, P, slots_prev, gru_w_ih, gru_w_hh, gru_b_ih, gru_b_hh, ln_g, ln_b, mlp_w1,
+                           mlp_b1, mlp_w2, mlp_b2, slots_out, nullptr, 0, nullptr, nullptr, nullptr, nullptr, B, N, D, H,
+                           ln_eps, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -208,6 +208,7 @@ def encoder_plan(m):
     s.sa_norm_in_g, s.sa_norm_in_b = plan.dp(sa.norm_inputs.weight), plan.dp(sa.norm_inputs.bias)
     s.sa_q_ln_g, s.sa_q_ln_b = plan.dp(sa.project_q[0].weight), plan.dp(sa.project_q[0].bias)
     s.sa_q_w = plan.dp(sa.project_q[1].weight)
+    s.sa_q_w_t = plan.dp(sa.project_q[1].weight.detach().float().t().contiguous())   # [in, out] for the slot-update kernel
     s.sa_kv_w = plan.dp(torch.cat([sa.project_k.weight.detach(), sa.project_v.weight.detach()], 0).contiguous())
     tr = lambda w: w.detach().float().t().contiguous()  # noqa: E731  ([in, out] layout for the slot-update kernel)
     s.gru_w_ih, s.gru_w_hh = plan.dp(tr(sa.gru.weight_ih)), plan.dp(tr(sa.gru.weight_hh))
