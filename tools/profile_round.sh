@@ -2,12 +2,12 @@
 # Run on the GPU box (via gpurun): bench line + rocprofv3 kernel-trace stats + PMC passes.
 # Usage: tools/profile_round.sh <tag>     -> writes gpurun_out/<tag>_*
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd $R
-timeout 600 python bench.py --steps 20 --warmup 5 --breakdown > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.log
+timeout 600 python bench.py --steps 40 --warmup 5 --breakdown > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.log
 tail -c 600 $OUT/${TAG}_bench.json | head -c 300; echo
 cd /tmp && export TMPDIR=/tmp
 # the default bench command (hipGraph rollout, CU-partitioned pipeline), minus the CPU leg, so that the traced kernel

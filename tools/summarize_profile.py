@@ -5,7 +5,7 @@ import os
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(R, 'gpurun_out')
 
@@ -34,7 +34,7 @@ if f:
     per = defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = short(r['Kernel_Name'])
-        if n.startswith(('conv5x5_halo_kernel', 'sa_attn_mfma_kernel', 'pixel_mlp_kv_kernel')):
+        if n.startswith(('conv5x5_halo_kernel', 'sa_attn_mfma_kernel', 'pixel_mlp_kv_kernel', 'ffn_partial_kernel', 'attn_oproj_kernel', 'sa_slot_update_kernel')):
             per[(n, r['Queue_Id'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     lines.append('# per-queue durations of the encode kernels  [trace_kernel_trace.csv]  (queue with the most launches of a '
                  'kernel = the CU-masked encode stream of the timed region = bench.py roofline.avg_launch_us; the others = '
@@ -81,10 +81,20 @@ def is_conv(name):  # conv5x5_halo_kernel, or sf_gemm_kernel<..., ALOAD=1 (NHWC 
 
 traffic = {'source': f'profiles/{tag}_profile_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)',
            'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of wide coalesced reads)'}
-for key, pred in (('conv_nhwc_implicit_gemm', is_conv), ('slot_attn_iter', lambda n: 'sa_attn' in n)):
+# MFMA-busy fraction: SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs that ran the kernel; GRBM_GUI_ACTIVE is
+# the launch duration in cycles -> busy / (active * 1024 SIMDs) = share of the chip's matrix-pipe time that was used
+for key, pred in (('conv_nhwc_implicit_gemm', is_conv), ('slot_attn_iter', lambda n: 'sa_attn' in n),
+                  ('ffn_fused', lambda n: 'ffn_partial_kernel' in n), ('attention', lambda n: 'attn_oproj_kernel' in n),
+                  ('pixel_mlp', lambda n: 'pixel_mlp_kv_kernel' in n)):
     fe, wr = counter_avg(f'{tag}_pmc_fetch', 'FETCH_SIZE', pred), counter_avg(f'{tag}_pmc_write', 'WRITE_SIZE', pred)
+    ent = {}
     if fe is not None and wr is not None:
-        traffic[key] = {'FETCH_SIZE_KB': fe, 'WRITE_SIZE_KB': wr, 'traffic_bytes_per_launch': (2 * fe + wr) * 1024}
+        ent.update({'FETCH_SIZE_KB': fe, 'WRITE_SIZE_KB': wr, 'traffic_bytes_per_launch': (2 * fe + wr) * 1024})
+    busy, act = counter_avg(f'{tag}_pmc_mfma', 'SQ_VALU_MFMA_BUSY_CYCLES', pred), counter_avg(f'{tag}_pmc_mfma', 'GRBM_GUI_ACTIVE', pred)
+    if busy is not None and act:
+        ent.update({'SQ_VALU_MFMA_BUSY_CYCLES': busy, 'GRBM_GUI_ACTIVE': act, 'mfma_busy_frac': busy / (act * 1024.0)})
+    if ent:
+        traffic[key] = ent
 json.dump(traffic, open(os.path.join(OUT, f'{tag}_pmc_traffic.json'), 'w'), indent=1)
 txt = '\n'.join(lines)
 open(os.path.join(OUT, f'{tag}_profile_summary.txt'), 'w').write(txt + '\n')
