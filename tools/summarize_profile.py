@@ -34,7 +34,7 @@ if f:
     per = defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = short(r['Kernel_Name'])
-        if n.startswith(('conv5x5_halo_kernel', 'sa_attn_mfma_kernel', 'pixel_mlp_kv_kernel', 'ffn_partial_kernel', 'attn_oproj_kernel', 'sa_slot_update_kernel')):
+        if n.startswith(('conv5x5_halo_kernel', 'sa_attn_mfma_kernel', 'pixel_mlp_kv_kernel', 'ffn_partial_kernel', 'attn_oproj_kernel', 'sa_slot_update_kernel', 'conv5x5_halo256_kernel')):
             per[(n, r['Queue_Id'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     lines.append('# per-queue durations of the encode kernels  [trace_kernel_trace.csv]  (queue with the most launches of a '
                  'kernel = the CU-masked encode stream of the timed region = bench.py roofline.avg_launch_us; the others = '
@@ -72,8 +72,21 @@ def counter_avg(d, counter, pred):
     return tot / n if n else None
 
 
+def stats_avg_us(pred):
+    """call-weighted average duration (us) of the kernels matching `pred` in the kernel-trace stats of this round"""
+    f = find(f'{tag}_trace', '*kernel_stats.csv')
+    if not f:
+        return None
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(f)):
+        if pred(r['Name']):
+            tot += float(r['TotalDurationNs'])
+            n += int(r['Calls'])
+    return tot / n / 1e3 if n else None
+
+
 def is_conv(name):  # conv5x5_halo_kernel, or sf_gemm_kernel<..., ALOAD=1 (NHWC im2col), LN, BF3>
-    if 'conv5x5_halo_kernel' in name:
+    if 'conv5x5_halo' in name:
         return True
     m = re.search(r'sf_gemm_kernel<([^>]*)>', name)
     return bool(m) and m.group(1).replace(' ', '').split(',')[8] == '1'
@@ -90,9 +103,13 @@ for key, pred in (('conv_nhwc_implicit_gemm', is_conv), ('slot_attn_iter', lambd
     ent = {}
     if fe is not None and wr is not None:
         ent.update({'FETCH_SIZE_KB': fe, 'WRITE_SIZE_KB': wr, 'traffic_bytes_per_launch': (2 * fe + wr) * 1024})
-    busy, act = counter_avg(f'{tag}_pmc_mfma', 'SQ_VALU_MFMA_BUSY_CYCLES', pred), counter_avg(f'{tag}_pmc_mfma', 'GRBM_GUI_ACTIVE', pred)
-    if busy is not None and act:
-        ent.update({'SQ_VALU_MFMA_BUSY_CYCLES': busy, 'GRBM_GUI_ACTIVE': act, 'mfma_busy_frac': busy / (act * 1024.0)})
+    busy = counter_avg(f'{tag}_pmc_mfma', 'SQ_VALU_MFMA_BUSY_CYCLES', pred)
+    dur = stats_avg_us(pred)
+    if busy is not None and dur:
+        # SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of the 1024 SIMDs: / 1024 = matrix-pipe time per SIMD, at the 2.4 GHz
+        # peak clock (a lower bound of the time: the chip clocks lower under load) over the launch duration of the trace pass
+        ent.update({'SQ_VALU_MFMA_BUSY_CYCLES': busy, 'avg_launch_us_trace': dur,
+                    'mfma_busy_us_per_simd': busy / 1024.0 / 2400.0, 'mfma_busy_frac': busy / 1024.0 / 2400.0 / dur})
     if ent:
         traffic[key] = ent
 json.dump(traffic, open(os.path.join(OUT, f'{tag}_pmc_traffic.json'), 'w'), indent=1)
