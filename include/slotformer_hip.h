@@ -403,6 +403,10 @@ typedef struct {
   float sa_eps;
   const float* sa_q_w_t; /* optional: project_q weight transposed [in, out] (coalesced reads for the slot-update kernel, which
                           * then also emits the next iteration's q); NULL: q comes from a separate LN-fused GEMM launch */
+  /* optional transposed ([in, out]) copies of the ResidualMLPPredictor weights and of the single-Linear kernel_dist layer:
+   * with them (and sa_q_w_t) the per-frame slot prologue -- predictor, kernel distribution, sampling, q projection -- is ONE
+   * launch (pred_type 0, no LSTM, kd_mode 1); NULL: separate LayerNorm / GEMM / sampling launches */
+  const float *pm_w0_t, *pm_w2_t, *kd_w0_t;
 } sf_savi_encoder;
 
 size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B);

@@ -84,7 +84,7 @@ class sf_savi_encoder(C.Structure):
         [(n, FP) for n in ('pm_ln_g', 'pm_ln_b', 'pm_w0', 'pm_b0', 'pm_w2', 'pm_b2')] +
         [('pred_layers', C.POINTER(sf_tfm_layer))] +
         [(n, FP) for n in ('lstm_w_ih', 'lstm_w_hh', 'lstm_b_ih', 'lstm_b_hh', 'proj_w', 'proj_b')] +
-        [('sa_eps', C.c_float), ('sa_q_w_t', FP)])
+        [('sa_eps', C.c_float), ('sa_q_w_t', FP), ('pm_w0_t', FP), ('pm_w2_t', FP), ('kd_w0_t', FP)])
 
 
 class sf_slate_block(C.Structure):

@@ -482,76 +482,88 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
                             sf_rows(2 * D), 0, kv_dst, sf_rows(2 * D), Mp, 2 * D, Ce, 0, st));
       }
     }
-    // ---- slot initialisation: init_latents or predictor(prev_slots)  (savi.py:393-398) ------
-    const float* lat;
-    if (prev == nullptr) {
-      SF_TRY(sf_copy_rows_ex(m->init_latents, sf_rows_batched(D, N, 0, 0), latents, sf_rows(D), R, D, st));
-      lat = latents;
-    } else {
-      const float* pout;
-      if (m->pred_type == 0) {
-        // ResidualMLPPredictor (predictor.py:65-73)
-        SF_TRY(sf_layernorm_ex(prev, sf_rows(D), m->pm_ln_g, m->pm_ln_b, lnbuf, sf_rows(D), R, D, ln_eps, st));
-        SF_TRY(sf_linear_ex(lnbuf, sf_rows(D), m->pm_w0, m->pm_b0, nullptr, nullptr, ln_eps, nullptr, sf_rows(D), 0,
-                            tw.hid, sf_rows(2 * D), R, 2 * D, D, 1, st));
-        SF_TRY(sf_linear_ex(tw.hid, sf_rows(2 * D), m->pm_w2, m->pm_b2, nullptr, nullptr, ln_eps,
-                            m->pred_norm_first ? lnbuf : prev, sf_rows(D), 0, px, sf_rows(D), R, D, 2 * D, 0, st));
-        pout = px;
-      } else {
-        // TransformerPredictor over the N slots (predictor.py:20-44)
-        SF_TRY(sf_copy_rows_ex(prev, sf_rows(D), px, sf_rows(D), R, D, st));
-        float* cur = px;
-        for (int l = 0; l < m->pred_num_layers; ++l) {
-          float* outp = nullptr;
-          SF_TRY(tfm_layer(m->pred_layers[l], cur, tw, B, N, N, D, m->pred_num_heads, m->pred_ffn_dim,
-                           m->pred_norm_first, st, &outp));
-          cur = outp;
-        }
-        pout = cur;
-      }
-      if (m->pred_rnn) {
-        // nn.LSTM, seq len 1, batch B*N (predictor.py:113-120)
-        const int Hh = m->pred_hidden;
-        SF_TRY(sf_linear_ex(pout, sf_rows(D), m->lstm_w_ih, m->lstm_b_ih, nullptr, nullptr, ln_eps, nullptr,
-                            sf_rows(4 * Hh), 0, gates, sf_rows(4 * Hh), R, 4 * Hh, D, 0, st));
-        SF_TRY(sf_linear_ex(lstm_h, sf_rows(Hh), m->lstm_w_hh, m->lstm_b_hh, nullptr, nullptr, ln_eps, gates,
-                            sf_rows(4 * Hh), 0, gates, sf_rows(4 * Hh), R, 4 * Hh, Hh, 0, st));
-        SF_TRY(sf_lstm_pointwise_ex(gates, lstm_c, lstm_h, lstm_c, R, Hh, st));
-        SF_TRY(sf_linear_ex(lstm_h, sf_rows(Hh), m->proj_w, m->proj_b, nullptr, nullptr, ln_eps, nullptr,
-                            sf_rows(D), 0, latents, sf_rows(D), R, D, Hh, 0, st));
-        lat = latents;
-      } else {
-        lat = pout;
-      }
-    }
-    // ---- kernel distribution + sampling (savi.py:401-402) --------------------------------------
+    // ---- one-launch slot prologue (CLEVRER configuration: residual-MLP predictor without LSTM, single-Linear kernel
+    //      distribution): init / predictor -> kernel_dist -> sampling -> q of the first iteration (slot_attn.hip) ----
     float* s_in = slotsA;
     float* s_out = slotsB;
-    if (m->kd_mode == 0) {
-      SF_TRY(sf_copy_rows_ex(lat, sf_rows(D), s_in, sf_rows(D), R, D, st));
-    } else {
-      if (m->kd_mode == 1) {
-        SF_TRY(sf_linear_ex(lat, sf_rows(D), m->kd_w0, m->kd_b0, nullptr, nullptr, ln_eps, nullptr, sf_rows(2 * D), 0,
-                            kdist, sf_rows(2 * D), R, 2 * D, D, 0, st));
+    int prologue = 1;
+    if (m->pred_type == 0 && !m->pred_rnn && m->kd_mode == 1 && m->pm_w0_t && m->pm_w2_t && m->kd_w0_t && m->sa_q_w_t)
+      prologue = sf_slot_prologue_ex(prev, m->init_latents, m->pm_ln_g, m->pm_ln_b, m->pm_w0_t, m->pm_b0, m->pm_w2_t, m->pm_b2,
+                                     m->pred_norm_first, m->kd_w0_t, m->kd_b0, noise ? noise + (long long)t * N * D : nullptr,
+                                     (long long)T * N * D, kernel_dist ? kernel_dist + (long long)t * N * 2 * D : nullptr,
+                                     (long long)T * N * 2 * D, m->sa_q_ln_g, m->sa_q_ln_b, m->sa_q_w_t, s_in, q, B, N, D, ln_eps,
+                                     st);
+    if (prologue < 0 || prologue > 1) return prologue;
+    if (prologue == 1) {
+      // ---- slot initialisation: init_latents or predictor(prev_slots)  (savi.py:393-398) ------
+      const float* lat;
+      if (prev == nullptr) {
+        SF_TRY(sf_copy_rows_ex(m->init_latents, sf_rows_batched(D, N, 0, 0), latents, sf_rows(D), R, D, st));
+        lat = latents;
       } else {
-        SF_TRY(sf_linear_ex(lat, sf_rows(D), m->kd_w0, m->kd_b0, nullptr, nullptr, ln_eps, nullptr, sf_rows(2 * D), 0,
-                            kdtmp, sf_rows(2 * D), R, 2 * D, D, 0, st));
-        SF_TRY(sf_linear_ex(kdtmp, sf_rows(2 * D), m->kd_w3, m->kd_b3, m->kd_ln_g, m->kd_ln_b, ln_eps, nullptr,
-                            sf_rows(2 * D), 0, kdist, sf_rows(2 * D), R, 2 * D, 2 * D, 0, st, /*ln_relu=*/1));
+        const float* pout;
+        if (m->pred_type == 0) {
+          // ResidualMLPPredictor (predictor.py:65-73)
+          SF_TRY(sf_layernorm_ex(prev, sf_rows(D), m->pm_ln_g, m->pm_ln_b, lnbuf, sf_rows(D), R, D, ln_eps, st));
+          SF_TRY(sf_linear_ex(lnbuf, sf_rows(D), m->pm_w0, m->pm_b0, nullptr, nullptr, ln_eps, nullptr, sf_rows(D), 0,
+                              tw.hid, sf_rows(2 * D), R, 2 * D, D, 1, st));
+          SF_TRY(sf_linear_ex(tw.hid, sf_rows(2 * D), m->pm_w2, m->pm_b2, nullptr, nullptr, ln_eps,
+                              m->pred_norm_first ? lnbuf : prev, sf_rows(D), 0, px, sf_rows(D), R, D, 2 * D, 0, st));
+          pout = px;
+        } else {
+          // TransformerPredictor over the N slots (predictor.py:20-44)
+          SF_TRY(sf_copy_rows_ex(prev, sf_rows(D), px, sf_rows(D), R, D, st));
+          float* cur = px;
+          for (int l = 0; l < m->pred_num_layers; ++l) {
+            float* outp = nullptr;
+            SF_TRY(tfm_layer(m->pred_layers[l], cur, tw, B, N, N, D, m->pred_num_heads, m->pred_ffn_dim,
+                             m->pred_norm_first, st, &outp));
+            cur = outp;
+          }
+          pout = cur;
+        }
+        if (m->pred_rnn) {
+          // nn.LSTM, seq len 1, batch B*N (predictor.py:113-120)
+          const int Hh = m->pred_hidden;
+          SF_TRY(sf_linear_ex(pout, sf_rows(D), m->lstm_w_ih, m->lstm_b_ih, nullptr, nullptr, ln_eps, nullptr,
+                              sf_rows(4 * Hh), 0, gates, sf_rows(4 * Hh), R, 4 * Hh, D, 0, st));
+          SF_TRY(sf_linear_ex(lstm_h, sf_rows(Hh), m->lstm_w_hh, m->lstm_b_hh, nullptr, nullptr, ln_eps, gates,
+                              sf_rows(4 * Hh), 0, gates, sf_rows(4 * Hh), R, 4 * Hh, Hh, 0, st));
+          SF_TRY(sf_lstm_pointwise_ex(gates, lstm_c, lstm_h, lstm_c, R, Hh, st));
+          SF_TRY(sf_linear_ex(lstm_h, sf_rows(Hh), m->proj_w, m->proj_b, nullptr, nullptr, ln_eps, nullptr,
+                              sf_rows(D), 0, latents, sf_rows(D), R, D, Hh, 0, st));
+          lat = latents;
+        } else {
+          lat = pout;
+        }
       }
-      const SfRowMap nmap = sf_rows_batched(D, N, (long long)T * N * D, (long long)t * N * D);
-      SF_TRY(sf_sample_dist_ex(kdist, noise, nmap, s_in, R, D, st));
-      if (kernel_dist)
-        SF_TRY(sf_copy_rows_ex(kdist, sf_rows(2 * D), kernel_dist,
-                               sf_rows_batched(2 * D, N, (long long)T * N * 2 * D, (long long)t * N * 2 * D), R,
-                               2 * D, st));
+      // ---- kernel distribution + sampling (savi.py:401-402) --------------------------------------
+      if (m->kd_mode == 0) {
+        SF_TRY(sf_copy_rows_ex(lat, sf_rows(D), s_in, sf_rows(D), R, D, st));
+      } else {
+        if (m->kd_mode == 1) {
+          SF_TRY(sf_linear_ex(lat, sf_rows(D), m->kd_w0, m->kd_b0, nullptr, nullptr, ln_eps, nullptr, sf_rows(2 * D), 0,
+                              kdist, sf_rows(2 * D), R, 2 * D, D, 0, st));
+        } else {
+          SF_TRY(sf_linear_ex(lat, sf_rows(D), m->kd_w0, m->kd_b0, nullptr, nullptr, ln_eps, nullptr, sf_rows(2 * D), 0,
+                              kdtmp, sf_rows(2 * D), R, 2 * D, D, 0, st));
+          SF_TRY(sf_linear_ex(kdtmp, sf_rows(2 * D), m->kd_w3, m->kd_b3, m->kd_ln_g, m->kd_ln_b, ln_eps, nullptr,
+                              sf_rows(2 * D), 0, kdist, sf_rows(2 * D), R, 2 * D, 2 * D, 0, st, /*ln_relu=*/1));
+        }
+        const SfRowMap nmap = sf_rows_batched(D, N, (long long)T * N * D, (long long)t * N * D);
+        SF_TRY(sf_sample_dist_ex(kdist, noise, nmap, s_in, R, D, st));
+        if (kernel_dist)
+          SF_TRY(sf_copy_rows_ex(kdist, sf_rows(2 * D), kernel_dist,
+                                 sf_rows_batched(2 * D, N, (long long)T * N * 2 * D, (long long)t * N * 2 * D), R,
+                                 2 * D, st));
+      }
+      // q of the first iteration: LN-fused GEMM; every later q comes out of the slot-update kernel, which also writes the
+      // last iteration's result straight into post_slots[:, t]
+      SF_TRY(sf_linear_ex(s_in, sf_rows(D), m->sa_q_w, nullptr, m->sa_q_ln_g, m->sa_q_ln_b, ln_eps, nullptr,
+                          sf_rows(D), 0, q, sf_rows(D), R, D, D, 0, st));
     }
     // ---- Slot Attention iterations (savi.py:76-100) -------------------------------------------
     const float scale = 1.0f / sqrtf((float)D);
-    // q of the first iteration: LN-fused GEMM; every later q comes out of the slot-update kernel, which also writes the
-    // last iteration's result straight into post_slots[:, t]
-    SF_TRY(sf_linear_ex(s_in, sf_rows(D), m->sa_q_w, nullptr, m->sa_q_ln_g, m->sa_q_ln_b, ln_eps, nullptr,
-                        sf_rows(D), 0, q, sf_rows(D), R, D, D, 0, st));
     for (int it = 0; it < m->num_iterations; ++it) {
       const bool last_it = (it == m->num_iterations - 1);
       float* aout = (attn && last_it) ? attn + (long long)t * N * HW : nullptr;

@@ -23,6 +23,11 @@ int sf_slot_update_ex(const float* part_num, const float* part_den, int P, const
                       const float* mlp_b2, float* slots_out, float* out2, long long out2_bs, const float* q_ln_g,
                       const float* q_ln_b, const float* q_w, float* q_out, int B, int N, int D, int H, float ln_eps,
                       hipStream_t st);
+int sf_slot_prologue_ex(const float* prev, const float* init, const float* pm_ln_g, const float* pm_ln_b, const float* pm_w0_t,
+                        const float* pm_b0, const float* pm_w2_t, const float* pm_b2, int norm_first, const float* kd_w_t,
+                        const float* kd_b, const float* noise, long long noise_bs, float* kdist_out, long long kdist_bs,
+                        const float* q_ln_g, const float* q_ln_b, const float* q_w_t, float* slots_out, float* q_out, int B,
+                        int N, int D, float ln_eps, hipStream_t st);
 int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch_stride, const float* q,
                          float* part_num, float* part_den, float* attn_out, long long attn_batch_stride, int B,
                          int HW, int N, int D, float scale, float eps, hipStream_t st);

@@ -538,6 +538,149 @@ __global__ __launch_bounds__(NT) void sa_slot_update_kernel(
   }
 }
 
+// Slot prologue of one encoder time step in ONE launch (the per-frame chain of StoSAVi.encode before the Slot-Attention
+// iterations, savi.py:393-402, for the CLEVRER configuration):
+//   lat    = t == 0 ? init_latents : ResidualMLPPredictor(prev_slots)       (predictor.py:65-73)
+//   kdist  = kernel_dist_layer(lat)   (single Linear, savi.py:190-200)      -> also written to kernel_dist[:, t]
+//   slots  = mu + noise * exp(0.5 logvar)   (noise NULL: mu)                (savi.py:355-365)
+//   q      = project_q(slots) = LN_q(slots) Wq^T                            (savi.py:45-48,79)
+// It replaces LayerNorm + two predictor GEMMs + the kernel-distribution GEMM + the sampling kernel + a copy + the q GEMM (7
+// launches of 5-7 us on 224 rows).  Same machinery as the slot-update kernel: SU_R rows per workgroup, row vectors k-major in
+// LDS, a thread owns one output feature of a K slice, weights TRANSPOSED ([in][out]).
+struct SpArgs {
+  const float* prev;        // [R][D] previous slots, or NULL: lat = init_latents[n]
+  const float* init;        // [N][D]
+  const float *pm_ln_g, *pm_ln_b, *pm_w0_t, *pm_b0, *pm_w2_t, *pm_b2;   // w0_t [D][2D], w2_t [2D][D]
+  int norm_first;
+  const float *kd_w_t, *kd_b;   // [D][2D]
+  const float* noise;       // row (b, n) at noise + b * noise_bs + n * D, or NULL
+  long long noise_bs;
+  float* kdist_out;         // row (b, n) at kdist_out + b * kdist_bs + n * 2D, or NULL
+  long long kdist_bs;
+  const float *q_ln_g, *q_ln_b, *q_w_t;
+  float* slots_out;         // [R][D]
+  float* q_out;             // [R][D]
+};
+
+__global__ __launch_bounds__(768) void sa_slot_prologue_kernel(SpArgs a, int R, int N, int D, int pmax, float ln_eps) {
+  extern __shared__ __attribute__((aligned(16))) float su_lds[];
+  const int D2 = 2 * D;
+  float* s_x = su_lds;                    // [D][SU_R]   predictor input, later the sampled slots
+  float* s_ln = s_x + D * SU_R;           // [D][SU_R]
+  float* s_lat = s_ln + D * SU_R;         // [D][SU_R]
+  float* s_hid = s_lat + D * SU_R;        // [2D][SU_R]  predictor hidden, later the kernel distribution
+  float* s_stat = s_hid + D2 * SU_R;      // [SU_R][2]
+  float* s_pa = s_stat + 2 * SU_R;        // K-slice partials (pmax floats)
+  const int row0 = blockIdx.x * SU_R;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nt = blockDim.x, nwaves = nt >> 6;
+  for (int idx = t; idx < SU_R * D; idx += nt) {
+    const int r = idx / D, d = idx - r * D, row = row0 + r;
+    float v = 0.f;
+    if (row < R) v = a.prev ? a.prev[(long long)row * D + d] : a.init[(long long)(row % N) * D + d];
+    s_x[d * SU_R + r] = v;
+  }
+  __syncthreads();
+  if (a.prev) {
+    // ResidualMLPPredictor: x = LN(x); out = W2 relu(W0 x + b0) + b2 + (norm_first ? LN(x) : x)
+    su_ln_stats(s_x, s_stat, D, ln_eps, wave, lane, nwaves);
+    __syncthreads();
+    for (int idx = t; idx < SU_R * D; idx += nt) {
+      const int d = idx / SU_R, r = idx - d * SU_R;
+      s_ln[idx] = (s_x[idx] - s_stat[2 * r]) * s_stat[2 * r + 1] * a.pm_ln_g[d] + a.pm_ln_b[d];
+    }
+    __syncthreads();
+    su_gemm(a.pm_w0_t, D2, D, s_ln, s_pa, t, nt);
+    __syncthreads();
+    {
+      const int ks = su_kslices(nt, D2, D);
+      for (int idx = t; idx < SU_R * D2; idx += nt) {
+        const int j = idx / SU_R, r = idx - j * SU_R;
+        s_hid[idx] = fmaxf(su_sum(s_pa, ks, D2, j, r) + a.pm_b0[j], 0.f);
+      }
+    }
+    __syncthreads();
+    su_gemm(a.pm_w2_t, D, D2, s_hid, s_pa, t, nt);
+    __syncthreads();
+    {
+      const int ks = su_kslices(nt, D, D2);
+      for (int idx = t; idx < SU_R * D; idx += nt) {
+        const int d = idx / SU_R, r = idx - d * SU_R;
+        s_lat[idx] = su_sum(s_pa, ks, D, d, r) + a.pm_b2[d] + (a.norm_first ? s_ln[idx] : s_x[idx]);
+      }
+    }
+  } else {
+    for (int idx = t; idx < SU_R * D; idx += nt) s_lat[idx] = s_x[idx];
+  }
+  __syncthreads();
+  // kernel distribution + sampling
+  su_gemm(a.kd_w_t, D2, D, s_lat, s_pa, t, nt);
+  __syncthreads();
+  {
+    const int ks = su_kslices(nt, D2, D);
+    for (int idx = t; idx < SU_R * D2; idx += nt) {
+      const int r = idx / D2, j = idx - r * D2, row = row0 + r;      // consecutive threads = consecutive features
+      const float v = su_sum(s_pa, ks, D2, j, r) + a.kd_b[j];
+      s_hid[j * SU_R + r] = v;
+      if (a.kdist_out && row < R) a.kdist_out[(long long)(row / N) * a.kdist_bs + (long long)(row % N) * D2 + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int idx = t; idx < SU_R * D; idx += nt) {
+    const int r = idx / D, d = idx - r * D, row = row0 + r;
+    float v = s_hid[d * SU_R + r];
+    if (a.noise && row < R)
+      v += a.noise[(long long)(row / N) * a.noise_bs + (long long)(row % N) * D + d] * expf(s_hid[(D + d) * SU_R + r] * 0.5f);
+    s_x[d * SU_R + r] = v;
+    if (row < R) a.slots_out[(long long)row * D + d] = v;
+  }
+  __syncthreads();
+  // q = LN_q(slots) Wq^T
+  su_ln_stats(s_x, s_stat, D, ln_eps, wave, lane, nwaves);
+  __syncthreads();
+  for (int idx = t; idx < SU_R * D; idx += nt) {
+    const int d = idx / SU_R, r = idx - d * SU_R;
+    s_ln[idx] = (s_x[idx] - s_stat[2 * r]) * s_stat[2 * r + 1] * a.q_ln_g[d] + a.q_ln_b[d];
+  }
+  __syncthreads();
+  su_gemm(a.q_w_t, D, D, s_ln, s_pa, t, nt);
+  __syncthreads();
+  {
+    const int ks = su_kslices(nt, D, D);
+    for (int idx = t; idx < SU_R * D; idx += nt) {
+      const int r = idx / D, d = idx - r * D;
+      if (row0 + r < R) a.q_out[(long long)(row0 + r) * D + d] = su_sum(s_pa, ks, D, d, r);
+    }
+  }
+}
+
+// returns 1 when the fused prologue does not apply (D not a multiple of 64, more than 768 / 2 D ... see the requirements)
+int sf_slot_prologue_ex(const float* prev, const float* init, const float* pm_ln_g, const float* pm_ln_b, const float* pm_w0_t,
+                        const float* pm_b0, const float* pm_w2_t, const float* pm_b2, int norm_first, const float* kd_w_t,
+                        const float* kd_b, const float* noise, long long noise_bs, float* kdist_out, long long kdist_bs,
+                        const float* q_ln_g, const float* q_ln_b, const float* q_w_t, float* slots_out, float* q_out, int B,
+                        int N, int D, float ln_eps, hipStream_t st) {
+  if ((D % 64) != 0 || 2 * D > 768 || !kd_w_t || !kd_b || !q_w_t || !q_ln_g || !q_ln_b || !slots_out || !q_out || !init) return 1;
+  if (prev && (!pm_ln_g || !pm_ln_b || !pm_w0_t || !pm_b0 || !pm_w2_t || !pm_b2)) return 1;
+  if (B == 0) return 0;
+  const int threads = 768, R = B * N, D2 = 2 * D;
+  auto pmaxf = [&](int Nout, int K) { return su_kslices(threads, Nout, K) * Nout * SU_R; };
+  int pmax = pmaxf(D2, D);
+  if (pmaxf(D, D2) > pmax) pmax = pmaxf(D, D2);
+  if (pmaxf(D, D) > pmax) pmax = pmaxf(D, D);
+  const size_t lds = ((size_t)3 * D * SU_R + (size_t)D2 * SU_R + 2 * SU_R + (size_t)pmax) * sizeof(float);
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)sa_slot_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    lds_set = lds;
+  }
+  SpArgs a{prev, init, pm_ln_g, pm_ln_b, pm_w0_t, pm_b0, pm_w2_t, pm_b2, norm_first, kd_w_t, kd_b, noise, noise_bs, kdist_out,
+           kdist_bs, q_ln_g, q_ln_b, q_w_t, slots_out, q_out};
+  hipLaunchKernelGGL(sa_slot_prologue_kernel, dim3((R + SU_R - 1) / SU_R), dim3(threads), lds, st, a, R, N, D, pmax, ln_eps);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
 // -----------------------------------------------------------------------------------------
 int sf_sa_pick_partials(int HW) {
   if (HW % 256 == 0) return HW / 256;  // MFMA iteration kernel: 4 waves x 64 pixels per workgroup

@@ -224,6 +224,7 @@ def encoder_plan(m):
     elif len(kd) == 1:
         s.kd_mode = 1
         s.kd_w0, s.kd_b0 = plan.dp(kd[0].weight), plan.dp(kd[0].bias)
+        s.kd_w0_t = plan.dp(tr(kd[0].weight))   # [in, out] for the one-launch slot prologue
     else:
         s.kd_mode = 2
         s.kd_w0, s.kd_b0 = plan.dp(kd[0].weight), plan.dp(kd[0].bias)
@@ -244,6 +245,7 @@ def encoder_plan(m):
         s.pm_ln_g, s.pm_ln_b = plan.dp(base.ln.weight), plan.dp(base.ln.bias)
         s.pm_w0, s.pm_b0 = plan.dp(base.mlp[0].weight), plan.dp(base.mlp[0].bias)
         s.pm_w2, s.pm_b2 = plan.dp(base.mlp[2].weight), plan.dp(base.mlp[2].bias)
+        s.pm_w0_t, s.pm_w2_t = plan.dp(tr(base.mlp[0].weight)), plan.dp(tr(base.mlp[2].weight))
     if rnn:
         s.pred_hidden = pred.hidden_size
         s.lstm_w_ih, s.lstm_w_hh = plan.dp(pred.rnn.weight_ih_l0), plan.dp(pred.rnn.weight_hh_l0)
