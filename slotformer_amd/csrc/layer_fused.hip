@@ -169,7 +169,6 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
     const int cb = (t - 128) >> 5, j = (t - 128) & 31;
     qkvb = bias[(cb % 3) * d + (2 * hp + cb / 3) * HD + j];
   }
-  const float bov = bo[wave * 32 + (lane & 31)];
   // ---- activations (+ position table in ring mode) ----
   bool aok[A_IT];
   const float* arow[A_IT];
@@ -490,9 +489,16 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
   __syncthreads();
   LF_TA(24);
 
-  // ---- head-pair partial = [o_h0 | o_h1] . Wo[:, 64 hp : 64 hp + 64]^T: wave w owns output columns 32w..32w+31 ----
+  // ---- head-pair partial^T = Wo[32 w .. 32 w + 31, 64 hp : 64 hp + 64] . [o_h0 | o_h1]^T: wave w owns output columns 32 w ..
+  //      32 w + 31.  Transposed (weights as the MFMA A operand) so that a lane owns 4 CONSECUTIVE columns of one token: the
+  //      residual, the bias and the stores are 16-byte vectors, written through (sc1) -- nothing of the 5.5 MB of partials is
+  //      left dirty in the L2s for the kernel boundary to flush ----
   const int nq0 = L - Lq;
-  const int n = wave * 32 + (lane & 31);
+  const __amdgpu_buffer_rsrc_t apr = __builtin_amdgcn_make_buffer_rsrc(ap, 0, 0x7fffffff, 0x00020000);
+  const bool mine = (wave >> 1) == hp;   // residual + bias live on the two column blocks of this head pair
+  f32x4 bo4[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bo4[g] = *(const f32x4*)(bo + wave * 32 + 8 * g + 4 * (lane >> 5));
   for (int rbk = 0; rbk < nrb; ++rbk) {
     if (rbk * 32 + 32 <= nq0) continue;   // no query rows in this block
     f32x16 pacc;
@@ -502,19 +508,18 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const bf16x8 xh = *(const bf16x8*)(Oh + ao + ks * 16), xl = *(const bf16x8*)(Ol + ao + ks * 16);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wof[ks][0], pacc, 0, 0, 0);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wof[ks][1], pacc, 0, 0, 0);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wof[ks][0], pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wof[ks][0], xl, pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wof[ks][1], xh, pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wof[ks][0], xh, pacc, 0, 0, 0);
     }
-    float* dst = ap + (long long)hp * ap_stride + (long long)b * Lq * d + n;
-    const bool mine = (wave >> 1) == hp;   // residual + bias live on the two column blocks of this head pair
+    const int row = rbk * 32 + (lane & 31);
+    if (row >= nq0 && row < L && !((dbg & 8) && !mine)) {
+      const unsigned off = (unsigned)((((long long)hp * ap_stride + ((long long)b * Lq + (row - nq0)) * d + wave * 32 + 4 * (lane >> 5))) * 4);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = rbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row >= nq0 && row < L && !((dbg & 8) && !mine)) {
-        float v = pacc[r];
-        if (mine) v += Xs[row * A2_XS + (wave & 1) * 32 + (lane & 31)] + bov;
-        dst[(long long)(row - nq0) * d] = v;
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = {pacc[4 * g], pacc[4 * g + 1], pacc[4 * g + 2], pacc[4 * g + 3]};
+        if (mine) v += *(const f32x4*)(Xs + row * A2_XS + (wave & 1) * 32 + 8 * g + 4 * (lane >> 5)) + bo4[g];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), apr, off + 32 * g, 0, 16);
       }
     }
   }
@@ -959,6 +964,8 @@ static int launch_attn(const float* xin, long long x_batch_stride, const float* 
                        hipStream_t st) {
   if (!w.attn_in_packed || !w.attn_out_packed)
     return sf_set_err(-1, "invalid argument: fused attention needs packed weights (sf_pack_attn_weights)", __FILE__, __LINE__);
+  if ((long long)LF_NP * ap_stride * 4 >= 0x7fffffffLL)
+    return sf_set_err(-1, "invalid argument: head-pair partial buffer beyond the 2 GB a buffer descriptor addresses", __FILE__, __LINE__);
   auto kern = attn_oproj_kernel<RING>;
   static bool attr = false;
   if (!attr) {
