@@ -507,6 +507,11 @@ int sf_slot_attn_iter_f32_host(const float* k_host, const float* v_host, int ld,
                                int B, int HW, int N, int D, float scale, float eps, void* stream);
 int sf_rollout_f32_host(const sf_rollouter* m, float* slots_host, int B, int T_total, int pred_len, void* ws,
                         size_t ws_bytes, void* stream);
+/* Health check of the rollout's seam launches (the last FFN + step boundary of step s and the first attention of step s+1 run
+ * in one grid and hand 7 rows per video over through memory, slotformer.py:121-124 -> :115): number of hand-offs that gave up
+ * waiting since the library was loaded (synchronises the device).  Must be 0; SF_SEAM_FUSED=0 disables the seam launches. */
+int sf_seam_timeouts(void);
+
 /* Single-pass bf16 variant of sf_rollout_f32 (SURVEY.md 8(b2) `sf_rollout_bf16`; the reference's `--fp16` AMP,
  * scripts/train.py:84,105, and BASELINE.json's literal "bf16"): same arguments and storage (f32), every matrix product with
  * operands rounded to bf16 and f32 accumulation.  ~8e-3 relative on the 6+50 path of config C2 -- outside the 1e-3 parity

@@ -138,7 +138,7 @@ size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B) {
   // two-launch layer and the ring of cached in-projections [B][window_len + 1][N][d]
   return pad256(M * m->d_model) + tfm_ws_bytes((int)M, m->d_model, m->ffn_dim) + pad256(8 * M * m->d_model) +
          pad256(4 * M * m->d_model) + 2 * pad256(M * m->d_model) +
-         pad256((size_t)B * (m->window_len + 1) * m->num_slots * m->d_model) + 4096 + 4096;
+         pad256((size_t)B * (m->window_len + 1) * m->num_slots * m->d_model) + 4096 + 4096 + 4096;
 }
 
 int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws,
@@ -166,9 +166,10 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   float* xa = bp.take((size_t)B * Lmax * d);
   float* xb2 = bp.take((size_t)B * Lmax * d);
   int* counters = (int*)bp.take(1024);
+  unsigned* seam_flags = (unsigned*)bp.take(1024);   // per-tile epochs of the seam launches + an error word
   const int RF = W + 1;   // frames in the projection ring: the window being read + the frame being written
   float* ring = bp.take((size_t)B * RF * N * d);
-  if (!apb || !xpb || !xa || !xb2 || !counters || !ring) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
+  if (!apb || !xpb || !xa || !xb2 || !counters || !seam_flags || !ring) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
   // two-launch layers (layer_fused.hip): split-bf16 mode, pre-LN, d=256 / 8 heads / ffn 1024, window <= 64 tokens
   static const bool fused_env = [] {
     const char* e = getenv("SF_LAYER_FUSED");
@@ -186,6 +187,13 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
     return !(e && e[0] == '0');
   }();
   const bool boundary_fused = ring_mode && bfuse_env;
+  // seam launches (layer_fused.hip): the last-layer FFN + boundary of step s and the layer-0 attention of step s+1 in one
+  // grid; needs every workgroup of it co-resident at one per CU -- 160 leaves room on the 192-CU rollout partition
+  static const bool seam_env = [] {
+    const char* e = getenv("SF_SEAM_FUSED");
+    return !(e && e[0] == '0');
+  }();
+  const bool seam = boundary_fused && seam_env && sf_seam_blocks(B, N) <= 160;
   if (ring_mode) {
     // in-projection (without PE) of the burn-in frames -> ring slots 0 .. n_in-1
     SF_TRY(sf_ring_init_ex(m->out_proj_packed, m->out_proj_b, m->in_proj_packed, m->in_proj_b, slots,
@@ -194,11 +202,11 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   if (fused_layers) {
     SF_REQUIRE(sf_ffn_tiles(B * Lmax) <= 1024, "batch too large for the fused-layer tile counters");
     hipError_t e = hipMemsetAsync(counters, 0, 1024 * sizeof(int), st);
+    if (e == hipSuccess && seam) e = hipMemsetAsync(seam_flags, 0, 1024 * sizeof(unsigned), st);
     if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
   }
   const long long bs = (long long)T_total * N * C;
-  for (int s = 0; s < pred_len; ++s) {
-    int nf, f0;
+  auto window = [&](int s, int& nf, int& f0) {   // frames of the Transformer window of step s
     if (!m->single_step) {
       nf = W;
       f0 = s;
@@ -207,27 +215,54 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
       nf = have < W ? have : W;
       f0 = have - nf;
     }
+  };
+  float* apb2 = apb + (size_t)4 * B * Lmax * d;   // second set of head-pair partials (the seam's attention writes there)
+  float* ap_l0 = apb;                              // where the layer-0 attention of the CURRENT step put its partials
+  bool attn0_done = false;                         // ... and whether it already ran (inside the previous seam launch)
+  for (int s = 0; s < pred_len; ++s) {
+    int nf, f0;
+    window(s, nf, f0);
     const int L = nf * N, M = B * L, pe_off = (W - nf) * N;
     if (ring_mode) {
       const float* cin = nullptr;
       for (int l = 0; l < m->num_layers; ++l) {
-        const int Lq = (l == m->num_layers - 1) ? N : L;   // last layer: only the newest frame's rows are read (slotformer.py:121)
+        const bool lastl = (l == m->num_layers - 1);
+        const int Lq = lastl ? N : L;   // last layer: only the newest frame's rows are read (slotformer.py:121)
         const long long pst = (long long)B * Lq * d;
         float* xo = (cin == xa) ? xb2 : xa;
-        if (l == 0)
-          SF_TRY(sf_attn_oproj_ring_ex(ring, RF, N, f0, m->pe_tok + (long long)pe_off * d, m->layers[l], 1e-5f, apb, pst, B, L,
-                                       Lq, st));
-        else
-          SF_TRY(sf_attn_oproj_ex(cin, m->layers[l], 1e-5f, apb, pst, B, L, Lq, st));
-        if (l == m->num_layers - 1 && boundary_fused) {
+        float* apl = (l == 0) ? ap_l0 : apb;
+        if (l == 0) {
+          if (!attn0_done)
+            SF_TRY(sf_attn_oproj_ring_ex(ring, RF, N, f0, m->pe_tok + (long long)pe_off * d, m->layers[l], 1e-5f, apl, pst, B, L,
+                                         Lq, st));
+        } else {
+          SF_TRY(sf_attn_oproj_ex(cin, m->layers[l], 1e-5f, apl, pst, B, L, Lq, st));
+        }
+        attn0_done = false;
+        if (lastl && boundary_fused) {
           // last layer: FFN + step boundary in one launch.  pred = out_proj(last rows) -> frame n_in + s; its
           // in-projection -> the ring   (slotformer.py:121-124, :115)
-          SF_TRY(sf_ffn_boundary_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, counters, m->ffn_dim, m->out_proj_packed,
-                                    m->out_proj_b, m->in_proj_packed, m->in_proj_b, slots, bs, n_in + s, ring, RF, N, B, st));
+          if (seam && s + 1 < pred_len) {
+            int nf1, f01;
+            window(s + 1, nf1, f01);
+            const int L1 = nf1 * N, Lq1 = (m->num_layers == 1) ? N : L1;
+            float* ap_next = (apl == apb) ? apb2 : apb;
+            SF_TRY(sf_seam_ex(apl, pst, m->layers[l], 1e-5f, xpb, pst, counters, m->ffn_dim, m->out_proj_packed, m->out_proj_b,
+                              m->in_proj_packed, m->in_proj_b, slots, bs, n_in + s, ring, RF, N, B, m->layers[0], f01,
+                              m->pe_tok + (long long)((W - nf1) * N) * d, ap_next, (long long)B * Lq1 * d, L1, Lq1, seam_flags,
+                              (unsigned)(s + 1), st));
+            ap_l0 = ap_next;
+            attn0_done = true;
+          } else {
+            SF_TRY(sf_ffn_boundary_ex(apl, pst, m->layers[l], 1e-5f, xpb, pst, counters, m->ffn_dim, m->out_proj_packed,
+                                      m->out_proj_b, m->in_proj_packed, m->in_proj_b, slots, bs, n_in + s, ring, RF, N, B, st));
+            ap_l0 = apb;
+          }
           cin = nullptr;
         } else {
-          SF_TRY(sf_ffn_partial_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st));
+          SF_TRY(sf_ffn_partial_ex(apl, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st));
           cin = xo;
+          if (l == 0) ap_l0 = apb;
         }
       }
       if (cin != nullptr)

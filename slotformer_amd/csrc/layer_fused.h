@@ -27,3 +27,11 @@ int sf_ffn_boundary_ex(const float* ap, long long ap_stride, const sf_tfm_layer&
                        int* counters, int ffn, const void* wout_packed, const float* b_out, const void* win_packed,
                        const float* b_in, float* slots, long long slots_bs, int frame, float* ring, int ring_frames, int nslots,
                        int B, hipStream_t st);
+// ONE launch for the seam between two rollout steps: last-layer FFN + step boundary of step s (blocks [0, nffn)) and the
+// layer-0 attention of step s+1 (one block per (head pair, video)), handed over per 32-row tile through seam_flags
+int sf_seam_ex(const float* ap_ffn, long long pst_ffn, const sf_tfm_layer& wl, float eps, float* xp, long long xp_stride,
+               int* counters, int ffn, const void* wout_packed, const float* b_out, const void* win_packed, const float* b_in,
+               float* slots, long long slots_bs, int frame, float* ring, int ring_frames, int nslots, int B,
+               const sf_tfm_layer& w0, int f0_next, const float* pe, float* ap_attn, long long pst_attn, int L, int Lq,
+               unsigned* seam_flags, unsigned epoch, hipStream_t st);
+int sf_seam_blocks(int B, int nslots);

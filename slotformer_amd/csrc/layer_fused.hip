@@ -58,6 +58,7 @@ __device__ __forceinline__ void split4(__bf16* hp, __bf16* lp, int off, f32x4 v)
 }
 }  // namespace
 
+__device__ unsigned lf_seam_timeouts;   // seam hand-offs that gave up waiting (sf_seam_timeouts): must stay 0
 __device__ long long lf_ts[32];   // phase timestamps of one workgroup (SF_LF_DBG & 16), read by sf_debug_read_ts
 #define LF_TS(i) do { if ((dbg & 16) && blockIdx.x == 0 && threadIdx.x == 0) lf_ts[i] = wall_clock64(); } while (0)
 #define LF_TL(i) do { if ((dbg & 16) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 256) lf_ts[i + 10] = wall_clock64(); } while (0)
@@ -127,14 +128,49 @@ __global__ void pack_attn_kernel(const float* __restrict__ win, const float* __r
   }
 }
 
-template <bool RING>
-__global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restrict__ xin, long long x_batch_stride,
-                                                           const float* __restrict__ pe, int f0, int ring_frames, int nslots,
-                                                           const float* __restrict__ ln_g, const float* __restrict__ ln_b,
-                                                           float ln_eps, const uint4* __restrict__ wqkv_p,
-                                                           const float* __restrict__ bias, const uint4* __restrict__ wo_p,
-                                                           const float* __restrict__ bo, float* __restrict__ ap,
-                                                           long long ap_stride, int L, int Lq, int dbg) {
+// Seam between the last FFN launch of rollout step s and the layer-0 attention of step s+1 when both run in ONE launch
+// (seam_kernel below): the step boundary of a 32-row tile publishes `epoch` in seam.flags[tile] after its write-through ring
+// stores have been acknowledged; an attention workgroup polls the flags of the (at most two) tiles that hold its video's new
+// frame, then reads those rows with sc1 loads.  R1 form of cdna_hip_programming.md Guideline 16; every spin is bounded.
+struct SeamArgs {
+  unsigned* flags;      // [tiles] + error word at [SEAM_ERR]
+  unsigned epoch;       // 0: no seam in this launch
+  int rows_per_tile;    // 32
+};
+constexpr int SEAM_ERR = 1023;
+
+struct AttnArgs {
+  const float* xin;
+  long long x_batch_stride;
+  const float* pe;
+  int f0, ring_frames, nslots;
+  const float *ln_g, *ln_b;
+  float ln_eps;
+  const uint4* wqkv_p;
+  const float* bias;
+  const uint4* wo_p;
+  const float* bo;
+  float* ap;
+  long long ap_stride;
+  int L, Lq, dbg;
+};
+
+template <bool RING, bool SEAM>
+__device__ __forceinline__ void attn_body(const AttnArgs& A, const int hp, const int b, const SeamArgs seam) {
+  const float* __restrict__ xin = A.xin;
+  const long long x_batch_stride = A.x_batch_stride;
+  const float* __restrict__ pe = A.pe;
+  const int f0 = A.f0, ring_frames = A.ring_frames, nslots = A.nslots;
+  const float* __restrict__ ln_g = A.ln_g;
+  const float* __restrict__ ln_b = A.ln_b;
+  const float ln_eps = A.ln_eps;
+  const uint4* __restrict__ wqkv_p = A.wqkv_p;
+  const float* __restrict__ bias = A.bias;
+  const uint4* __restrict__ wo_p = A.wo_p;
+  const float* __restrict__ bo = A.bo;
+  float* __restrict__ ap = A.ap;
+  const long long ap_stride = A.ap_stride;
+  const int L = A.L, Lq = A.Lq, dbg = A.dbg;
   constexpr int d = LF_D, HD = LF_HD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __bf16* Ah = (__bf16*)smem;                                  // [64][A2_AP]  LN1(x), all of K
@@ -148,7 +184,7 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
   __bf16* Ol = Oh + FA_ROWS * A2_OP;
   float* Xs = (float*)((char*)smem + A2_XS_OFF);               // [64][A2_XS]: x[:, 64 hp : 64 hp + 64]
   float* GB = (float*)((char*)smem + A2_GB_OFF);
-  const int hp = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const float* xb = xin + (long long)b * x_batch_stride;
   const int c4 = t & 15, r0 = t >> 4;
   LF_TA(16);
@@ -187,11 +223,23 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
       prow[i] = nullptr;
     }
   }
+  // SEAM: the rows of the window's NEWEST frame (the last nslots rows) are being produced by the step boundary in this very
+  // launch; their loads wait for the flag (below) -- until then they read row 0 of the video so that every load stays
+  // unconditional
+  bool late[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    late[i] = false;
+    if constexpr (SEAM) {
+      const int r = r0 + 32 * i;
+      late[i] = r >= L - nslots && r < L;
+    }
+  }
   f32x4 ra[NK][A_IT];
 #pragma unroll
   for (int kc = 0; kc < NK; ++kc)
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) ra[kc][i] = *(const f32x4*)(arow[i] + kc * FA_KC);
+    for (int i = 0; i < A_IT; ++i) ra[kc][i] = *(const f32x4*)((late[i] ? arow[0] : arow[i]) + kc * FA_KC);
   if constexpr (RING) {
     f32x4 tp[NK][A_IT];
 #pragma unroll
@@ -201,7 +249,7 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
 #pragma unroll
     for (int kc = 0; kc < NK; ++kc)
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) ra[kc][i] += tp[kc][i];
+      for (int i = 0; i < A_IT; ++i) ra[kc][i] = late[i] ? tp[kc][i] : ra[kc][i] + tp[kc][i];   // late rows: pe only, so far
   }
   // ---- weight fragments: wq[ks][plane]; waves >= 4 hold 8 k-steps (in wq[0..7]) ----
   bf16x8 wq[16][2];
@@ -215,6 +263,37 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
     }
   }
   LF_TA(17);
+  if constexpr (SEAM) {
+    // the producers: the 32-row tiles of the last FFN launch that hold rows b * nslots .. b * nslots + nslots - 1
+    __shared__ int s_seam_ok;
+    if (t == 0) {
+      const int t0 = (b * nslots) / seam.rows_per_tile, t1 = (b * nslots + nslots - 1) / seam.rows_per_tile;
+      const long long c0 = wall_clock64();
+      int ok = 1;
+      while (__hip_atomic_load(seam.flags + t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seam.epoch ||
+             __hip_atomic_load(seam.flags + t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seam.epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - c0 > 20000000LL) {   // 0.2 s at 100 MHz: a producer is not resident -- give up, flag the error
+          __hip_atomic_store(seam.flags + SEAM_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicAdd(&lf_seam_timeouts, 1u);
+          ok = 0;
+          break;
+        }
+      }
+      s_seam_ok = ok;
+    }
+    __syncthreads();
+    (void)s_seam_ok;
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      if (late[i]) {
+        const unsigned off = (unsigned)((arow[i] - xin) * 4);
+#pragma unroll
+        for (int kc = 0; kc < NK; ++kc)
+          ra[kc][i] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off + kc * FA_KC * 4, 0, 16));
+      }
+  }
   if (t < 128) *(f32x4*)(GB + 4 * t) = gbv;
   if (t >= 128 && t < 128 + 192) GB[2 * LF_D + (t - 128)] = qkvb;
   // residual stash: the 64 columns of this head pair are chunk kc == hp
@@ -526,6 +605,11 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(const float* __restri
   LF_TA(25);
 }
 
+template <bool RING>
+__global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(AttnArgs A) {
+  attn_body<RING, false>(A, blockIdx.x, blockIdx.y, SeamArgs{nullptr, 0u, 32});
+}
+
 // ================================================================================================
 // Packed FFN weights (sf_pack_ffn_weights): both matrices pre-split into bf16 hi/lo and stored in the order the
 // MFMA B-operand fragments are consumed, so that a wave loads its fragments straight from memory into registers
@@ -571,6 +655,8 @@ struct SbArgs {
   float* ring;
   long long ring_bs, ring_off;
   int nslots, enabled;
+  unsigned* seam_flags;   // non-NULL: ring rows are written through and seam_flags[tile] = seam_epoch is published afterwards
+  unsigned seam_epoch;
 };
 constexpr int SB_C = 128;                    // slot size
 constexpr int SB_YP = LF_D + 8, SB_PP = SB_C + 8;
@@ -651,7 +737,12 @@ __device__ __forceinline__ void sb_compute(const SbArgs& a, const SbFrags& f, co
     for (int g = 0; g < 4; ++g) {
       const f32x4 v = {acc[4 * g] + f.bi4[g][0], acc[4 * g + 1] + f.bi4[g][1], acc[4 * g + 2] + f.bi4[g][2],
                        acc[4 * g + 3] + f.bi4[g][3]};
-      *(f32x4*)(a.ring + mb * a.ring_bs + a.ring_off + (long long)mn * LF_D + c2 + 8 * g) = v;
+      const long long eo = mb * a.ring_bs + a.ring_off + (long long)mn * LF_D + c2 + 8 * g;
+      if (a.seam_flags)   // read by another workgroup of this launch: write through (sc1), no L2-resident dirty line
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), __builtin_amdgcn_make_buffer_rsrc(a.ring, 0, 0x7fffffff, 0x00020000),
+                                               (unsigned)(eo * 4), 0, 16);
+      else
+        *(f32x4*)(a.ring + eo) = v;
     }
   }
 }
@@ -662,14 +753,39 @@ __device__ __forceinline__ void sb_compute(const SbArgs& a, const SbFrags& f, co
 // Both GEMMs run "transposed" (weights as the MFMA A operand, activations as B): a lane then owns 4 CONSECUTIVE
 // output columns of one token, so the hidden activations go to LDS as packed 8-byte stores and the results leave
 // as 16-byte vectors.
-__global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restrict__ ap, long long ap_stride,
-                                                            const float* __restrict__ ln_g,
-                                                            const float* __restrict__ ln_b, float ln_eps,
-                                                            const uint4* __restrict__ w1p, const float* __restrict__ b1,
-                                                            const uint4* __restrict__ w2p, const float* __restrict__ b2,
-                                                            float* __restrict__ xp, long long xp_stride,
-                                                            float* __restrict__ xout, int* __restrict__ counters,
-                                                            int ntiles, int M, int dbg, SbArgs sb) {
+struct FfnArgs {
+  const float* ap;
+  long long ap_stride;
+  const float *ln_g, *ln_b;
+  float ln_eps;
+  const uint4* w1p;
+  const float* b1;
+  const uint4* w2p;
+  const float* b2;
+  float* xp;
+  long long xp_stride;
+  float* xout;
+  int* counters;
+  int ntiles, M, dbg;
+  SbArgs sb;
+};
+
+__device__ __forceinline__ void ffn_body(const FfnArgs& F, const int blk) {
+  const float* __restrict__ ap = F.ap;
+  const long long ap_stride = F.ap_stride;
+  const float* __restrict__ ln_g = F.ln_g;
+  const float* __restrict__ ln_b = F.ln_b;
+  const float ln_eps = F.ln_eps;
+  const uint4* __restrict__ w1p = F.w1p;
+  const float* __restrict__ b1 = F.b1;
+  const uint4* __restrict__ w2p = F.w2p;
+  const float* __restrict__ b2 = F.b2;
+  float* __restrict__ xp = F.xp;
+  const long long xp_stride = F.xp_stride;
+  float* __restrict__ xout = F.xout;
+  int* __restrict__ counters = F.counters;
+  const int ntiles = F.ntiles, M = F.M, dbg = F.dbg;
+  const SbArgs& sb = F.sb;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int s_last;
   __bf16* Ah = (__bf16*)smem;                  // [32][FB_AP]  LN2(x2)
@@ -680,7 +796,7 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // block b runs on XCD b % 8: the four hidden chunks of a row tile share an XCD (one L2 fetch of the head partials);
   // tiles are dealt round-robin over the XCDs
-  const int c = (blockIdx.x >> 3) & (LF_NCH - 1), tile = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7);
+  const int c = (blk >> 3) & (LF_NCH - 1), tile = (blk >> 5) * 8 + (blk & 7);
   if (tile >= ntiles) return;
   const int row0 = tile * FB_ROWS;
   LF_TS(0);
@@ -856,9 +972,30 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(const float* __restr
         split4(Ah, Al, (wave + 8 * i) * FB_AP + 4 * lane, ((oth[0][i] + oth[1][i]) + oth[2][i]) + oth[3][i]);
       __syncthreads();
       sb_compute(sb, sbf, Ah, Al, (float*)Hh, Hh + 4 * 16 * 64 * 2, Hh + 4 * 16 * 64 * 2 + 32 * SB_PP, row0, M, lane, wave);
+      if (sb.seam_flags) {
+        // publish the tile: every storing wave drains its write-through ring stores, then ONE lane raises the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(sb.seam_flags + tile, sb.seam_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
   LF_TS(8);
+}
+
+__global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(FfnArgs F) { ffn_body(F, blockIdx.x); }
+
+// One launch for the seam between two rollout steps: blocks [0, nffn) run the last layer's FFN + step boundary of step s,
+// the others the layer-0 attention of step s+1 (one per (head pair, video)), which requests its weights and the five old
+// frames of its window at once and waits only for the 7 new rows of ITS video.  The producers have the lower block indices
+// (dispatched first); all nffn + 4 B workgroups are co-resident at one per CU on the 192-CU rollout partition for B <= 40.
+__global__ __launch_bounds__(LF_NT) void seam_kernel(FfnArgs F, AttnArgs A, SeamArgs seam, int nffn) {
+  if ((int)blockIdx.x < nffn) {
+    ffn_body(F, blockIdx.x);
+  } else {
+    const int u = blockIdx.x - nffn;
+    attn_body<true, true>(A, u & 3, u >> 2, seam);
+  }
 }
 
 // ================================================================================================
@@ -958,6 +1095,16 @@ bool sf_layer_fused_ok(int d, int heads, int ffn, int L) {
   return d == LF_D && heads == LF_NH && ffn == LF_NCH * LF_HC && L >= 1 && L <= FA_ROWS;
 }
 
+static AttnArgs make_attn_args(const float* xin, long long x_batch_stride, const float* pe, int f0, int ring_frames, int nslots,
+                               const sf_tfm_layer& w, float eps, float* ap, long long ap_stride, int L, int Lq) {
+  AttnArgs A;
+  A.xin = xin; A.x_batch_stride = x_batch_stride; A.pe = pe; A.f0 = f0; A.ring_frames = ring_frames; A.nslots = nslots;
+  A.ln_g = w.norm1_g; A.ln_b = w.norm1_b; A.ln_eps = eps; A.wqkv_p = (const uint4*)w.attn_in_packed; A.bias = w.in_proj_b;
+  A.wo_p = (const uint4*)w.attn_out_packed; A.bo = w.out_proj_b; A.ap = ap; A.ap_stride = ap_stride; A.L = L; A.Lq = Lq;
+  A.dbg = lf_dbg();
+  return A;
+}
+
 template <bool RING>
 static int launch_attn(const float* xin, long long x_batch_stride, const float* pe, int f0, int ring_frames, int nslots,
                        const sf_tfm_layer& w, float eps, float* ap, long long ap_stride, int B, int L, int Lq,
@@ -975,9 +1122,8 @@ static int launch_attn(const float* xin, long long x_batch_stride, const float* 
   }
   sf_prof_begin(SF_K_MHA, st, 6.0 * B * L * (double)LF_D * LF_D + 4.0 * (double)B * LF_NH * Lq * L * LF_HD +
                                   2.0 * B * Lq * (double)LF_D * LF_D);
-  hipLaunchKernelGGL(kern, dim3(LF_NH / 2, B), dim3(LF_NT), A2_LDS, st, xin, x_batch_stride, pe, f0, ring_frames, nslots,
-                     w.norm1_g, w.norm1_b, eps, (const uint4*)w.attn_in_packed, w.in_proj_b, (const uint4*)w.attn_out_packed,
-                     w.out_proj_b, ap, ap_stride, L, Lq, lf_dbg());
+  hipLaunchKernelGGL(kern, dim3(LF_NH / 2, B), dim3(LF_NT), A2_LDS, st,
+                     make_attn_args(xin, x_batch_stride, pe, f0, ring_frames, nslots, w, eps, ap, ap_stride, L, Lq));
   sf_prof_end(SF_K_MHA, st);
   SF_CHECK_LAUNCH();
   return 0;
@@ -1001,6 +1147,16 @@ static SbArgs make_sb(const void* wout_packed, const float* b_out, const void* w
                       long long slots_bs, long long slots_off, float* ring, long long ring_bs, long long ring_off,
                       int rows_per_video);
 
+static FfnArgs make_ffn_args(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp, long long xp_stride,
+                             float* xout, int* counters, int M, const SbArgs& sb) {
+  FfnArgs F;
+  F.ap = ap; F.ap_stride = ap_stride; F.ln_g = w.norm2_g; F.ln_b = w.norm2_b; F.ln_eps = eps;
+  F.w1p = (const uint4*)w.lin1_packed; F.b1 = w.lin1_b; F.w2p = (const uint4*)w.lin2_packed; F.b2 = w.lin2_b;
+  F.xp = xp; F.xp_stride = xp_stride; F.xout = xout; F.counters = counters;
+  F.ntiles = (M + FB_ROWS - 1) / FB_ROWS; F.M = M; F.dbg = lf_dbg(); F.sb = sb;
+  return F;
+}
+
 static int launch_ffn(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp, long long xp_stride,
                       float* xout, int* counters, int M, int ffn, const SbArgs& sb, hipStream_t st) {
   static_assert(FB_LDS <= 160 * 1024, "FFN kernel: LDS budget");
@@ -1017,9 +1173,8 @@ static int launch_ffn(const float* ap, long long ap_stride, const sf_tfm_layer& 
   const int tiles = (M + FB_ROWS - 1) / FB_ROWS;
   const int groups = (tiles + 7) / 8;   // 8 tiles x 4 chunks per group of 32 consecutive blocks
   sf_prof_begin(SF_K_FFN, st, 4.0 * M * (double)LF_D * ffn);
-  hipLaunchKernelGGL(ffn_partial_kernel, dim3(groups * 32), dim3(LF_NT), FB_LDS, st, ap, ap_stride, w.norm2_g,
-                     w.norm2_b, eps, (const uint4*)w.lin1_packed, w.lin1_b, (const uint4*)w.lin2_packed, w.lin2_b, xp,
-                     xp_stride, xout, counters, tiles, M, lf_dbg(), sb);
+  hipLaunchKernelGGL(ffn_partial_kernel, dim3(groups * 32), dim3(LF_NT), FB_LDS, st,
+                     make_ffn_args(ap, ap_stride, w, eps, xp, xp_stride, xout, counters, M, sb));
   sf_prof_end(SF_K_FFN, st);
   SF_CHECK_LAUNCH();
   return 0;
@@ -1043,6 +1198,45 @@ int sf_ffn_boundary_ex(const float* ap, long long ap_stride, const sf_tfm_layer&
   return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, nullptr, counters, B * nslots, ffn, sb, st);
 }
 
+// ONE launch: last-layer FFN + step boundary of step s (writes slots frame `frame`, ring frame `frame`) and the layer-0
+// attention of step s+1 (window starting at ring frame f0_next).  seam_flags: >= 1024 words zeroed at the start of the
+// rollout; epoch = s + 1.  ap_ffn: the last layer's head-pair partials (input); ap_attn: where the attention writes its own.
+int sf_seam_ex(const float* ap_ffn, long long pst_ffn, const sf_tfm_layer& wl, float eps, float* xp, long long xp_stride,
+               int* counters, int ffn, const void* wout_packed, const float* b_out, const void* win_packed, const float* b_in,
+               float* slots, long long slots_bs, int frame, float* ring, int ring_frames, int nslots, int B,
+               const sf_tfm_layer& w0, int f0_next, const float* pe, float* ap_attn, long long pst_attn, int L, int Lq,
+               unsigned* seam_flags, unsigned epoch, hipStream_t st) {
+  if (!wl.lin1_packed || !wl.lin2_packed || ffn != LF_NCH * LF_HC || !w0.attn_in_packed || !w0.attn_out_packed)
+    return sf_set_err(-1, "invalid argument: the seam launch needs packed weights", __FILE__, __LINE__);
+  static bool attr = false;
+  constexpr size_t LDS = A2_LDS > FB_LDS ? A2_LDS : FB_LDS;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)seam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    attr = true;
+  }
+  SbArgs sb = make_sb(wout_packed, b_out, win_packed, b_in, slots, slots_bs, (long long)frame * nslots * SB_C, ring,
+                      (long long)ring_frames * nslots * LF_D, (long long)(frame % ring_frames) * nslots * LF_D, nslots);
+  sb.seam_flags = seam_flags;
+  sb.seam_epoch = epoch;
+  const int M = B * nslots, tiles = (M + FB_ROWS - 1) / FB_ROWS, nffn = ((tiles + 7) / 8) * 32;
+  const FfnArgs F = make_ffn_args(ap_ffn, pst_ffn, wl, eps, xp, xp_stride, nullptr, counters, M, sb);
+  const AttnArgs A = make_attn_args(ring, (long long)ring_frames * nslots * LF_D, pe, f0_next, ring_frames, nslots, w0, eps, ap_attn,
+                                    pst_attn, L, Lq);
+  const SeamArgs seam{seam_flags, epoch, FB_ROWS};
+  sf_prof_begin(SF_K_FFN, st, 4.0 * M * (double)LF_D * ffn);
+  hipLaunchKernelGGL(seam_kernel, dim3(nffn + (LF_NH / 2) * B), dim3(LF_NT), LDS, st, F, A, seam, nffn);
+  sf_prof_end(SF_K_FFN, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// workgroups of a seam launch (producers + consumers): they must all be co-resident, one per CU
+int sf_seam_blocks(int B, int nslots) {
+  const int tiles = (B * nslots + FB_ROWS - 1) / FB_ROWS;
+  return ((tiles + 7) / 8) * 32 + (LF_NH / 2) * B;
+}
+
 bool sf_step_boundary_ok(int d, int slot_size) { return d == LF_D && slot_size == SB_C; }
 
 static SbArgs make_sb(const void* wout_packed, const float* b_out, const void* win_packed, const float* b_in, float* slots,
@@ -1061,6 +1255,8 @@ static SbArgs make_sb(const void* wout_packed, const float* b_out, const void* w
   a.ring_off = ring_off;
   a.nslots = rows_per_video;
   a.enabled = 1;
+  a.seam_flags = nullptr;
+  a.seam_epoch = 0;
   return a;
 }
 
@@ -1106,6 +1302,14 @@ extern "C" int sf_pack_linear_weights(const float* w, void* packed, int N, int K
   hipLaunchKernelGGL(pack_linear_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (uint4*)packed, N, K);
   SF_CHECK_LAUNCH();
   return 0;
+}
+
+// Number of seam hand-offs (rollout steps fused across the step boundary) that timed out waiting for their producer since
+// the library was loaded.  Anything but 0 means a rollout result is invalid (a producer workgroup was not resident).
+extern "C" int sf_seam_timeouts(void) {
+  unsigned v = 0;
+  hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(lf_seam_timeouts), sizeof(v));
+  return e == hipSuccess ? (int)v : -(int)e;
 }
 
 extern "C" int sf_debug_read_ts(long long* out32) {

@@ -57,6 +57,7 @@ with torch.no_grad():
         g.replay()
     torch.cuda.synchronize()
     tg = (time.perf_counter() - t0) / 10
+    print('seam timeouts:', lib.sf_seam_timeouts())
     print(f'B={B}: eager {1e3 * te:.3f} ms ({1e6 * te / 50:.1f} us/step)   graph {1e3 * tg:.3f} ms ({1e6 * tg / 50:.1f} us/step)')
     if int(os.environ.get('SF_LF_DBG', '0')) & 16:
         engine.rollout(roll, buf, 6, 3)
