@@ -242,9 +242,9 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
         if (lastl && boundary_fused) {
           // last layer: FFN + step boundary in one launch.  pred = out_proj(last rows) -> frame n_in + s; its
           // in-projection -> the ring   (slotformer.py:121-124, :115)
-          if (seam && s + 1 < pred_len) {
-            int nf1, f01;
-            window(s + 1, nf1, f01);
+          int nf1 = 0, f01 = 0;
+          if (s + 1 < pred_len) window(s + 1, nf1, f01);
+          if (seam && s + 1 < pred_len && sf_seam_window_ok(nf1 * N, N)) {
             const int L1 = nf1 * N, Lq1 = (m->num_layers == 1) ? N : L1;
             float* ap_next = (apl == apb) ? apb2 : apb;
             SF_TRY(sf_seam_ex(apl, pst, m->layers[l], 1e-5f, xpb, pst, counters, m->ffn_dim, m->out_proj_packed, m->out_proj_b,

@@ -35,3 +35,4 @@ int sf_seam_ex(const float* ap_ffn, long long pst_ffn, const sf_tfm_layer& wl, f
                const sf_tfm_layer& w0, int f0_next, const float* pe, float* ap_attn, long long pst_attn, int L, int Lq,
                unsigned* seam_flags, unsigned epoch, hipStream_t st);
 int sf_seam_blocks(int B, int nslots);
+bool sf_seam_window_ok(int L, int nslots);

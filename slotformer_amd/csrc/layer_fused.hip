@@ -23,6 +23,7 @@
 #include "sf_internal.h"
 #include "layer_fused.h"
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -62,6 +63,7 @@ __device__ unsigned lf_seam_timeouts;   // seam hand-offs that gave up waiting (
 __device__ long long lf_ts[32];   // phase timestamps of one workgroup (SF_LF_DBG & 16), read by sf_debug_read_ts
 #define LF_TS(i) do { if ((dbg & 16) && blockIdx.x == 0 && threadIdx.x == 0) lf_ts[i] = wall_clock64(); } while (0)
 #define LF_TL(i) do { if ((dbg & 16) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 256) lf_ts[i + 10] = wall_clock64(); } while (0)
+#define LF_TQ(i) do { if constexpr (SEAM) { if ((dbg & 16) && hp == 0 && b == 0 && threadIdx.x == 0) lf_ts[i] = wall_clock64(); } } while (0)
 #define LF_TA(i) do { if ((dbg & 16) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) lf_ts[i] = wall_clock64(); } while (0)
 
 // ================================================================================================
@@ -188,6 +190,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& A, const int hp, const
   const float* xb = xin + (long long)b * x_batch_stride;
   const int c4 = t & 15, r0 = t >> 4;
   LF_TA(16);
+  LF_TQ(9);
   // ---- prologue.  A workgroup ingests ~100 GB/s through one in-order request path: the 196 KB of q|k|v weight fragments
   //      take ~2 us to issue, a wave cannot run the LayerNorm arithmetic before its own last request has been accepted,
   //      and the arithmetic itself needs all 8 waves (two per SIMD) to run at full VALU rate.  So every wave requests
@@ -249,7 +252,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& A, const int hp, const
 #pragma unroll
     for (int kc = 0; kc < NK; ++kc)
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) ra[kc][i] = late[i] ? tp[kc][i] : ra[kc][i] + tp[kc][i];   // late rows: pe only, so far
+      for (int i = 0; i < A_IT; ++i) ra[kc][i] += tp[kc][i];   // (late rows: unused values)
   }
   // ---- weight fragments: wq[ks][plane]; waves >= 4 hold 8 k-steps (in wq[0..7]) ----
   bf16x8 wq[16][2];
@@ -263,136 +266,153 @@ __device__ __forceinline__ void attn_body(const AttnArgs& A, const int hp, const
     }
   }
   LF_TA(17);
-  if constexpr (SEAM) {
-    // the producers: the 32-row tiles of the last FFN launch that hold rows b * nslots .. b * nslots + nslots - 1
-    __shared__ int s_seam_ok;
-    if (t == 0) {
-      const int t0 = (b * nslots) / seam.rows_per_tile, t1 = (b * nslots + nslots - 1) / seam.rows_per_tile;
-      const long long c0 = wall_clock64();
-      int ok = 1;
-      while (__hip_atomic_load(seam.flags + t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seam.epoch ||
-             __hip_atomic_load(seam.flags + t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seam.epoch) {
-        __builtin_amdgcn_s_sleep(2);
-        if (wall_clock64() - c0 > 20000000LL) {   // 0.2 s at 100 MHz: a producer is not resident -- give up, flag the error
-          __hip_atomic_store(seam.flags + SEAM_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          atomicAdd(&lf_seam_timeouts, 1u);
-          ok = 0;
-          break;
-        }
-      }
-      s_seam_ok = ok;
-    }
-    __syncthreads();
-    (void)s_seam_ok;
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, 0x7fffffff, 0x00020000);
+  LF_TQ(10);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // LayerNorm of ONE row held by 16 consecutive lanes (statistics from the registers), residual stash (the 64 columns of this
+  // head pair are chunk kc == hp) and LN(x) planes.  One code path for the stand-alone and the seam kernel: a rollout restarted
+  // from its own output must reproduce the original bit for bit, whichever kernel ran the layer.
+  auto ln_row = [&](const f32x4& v0, const f32x4& v1, const f32x4& v2, const f32x4& v3, int r, bool ok) {
+    const f32x4 vv[NK] = {v0, v1, v2, v3};
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i)
-      if (late[i]) {
-        const unsigned off = (unsigned)((arow[i] - xin) * 4);
-#pragma unroll
-        for (int kc = 0; kc < NK; ++kc)
-          ra[kc][i] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off + kc * FA_KC * 4, 0, 16));
-      }
-  }
-  if (t < 128) *(f32x4*)(GB + 4 * t) = gbv;
-  if (t >= 128 && t < 128 + 192) GB[2 * LF_D + (t - 128)] = qkvb;
-  // residual stash: the 64 columns of this head pair are chunk kc == hp
-#pragma unroll
-  for (int kc = 0; kc < NK; ++kc)
-    if (kc == hp) {
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) *(f32x4*)(Xs + (r0 + 32 * i) * A2_XS + 4 * c4) = ra[kc][i];
-    }
-  // LayerNorm statistics from the registers (row r0+32*i is held by 16 consecutive lanes; all of them get the result)
-  float mean[A_IT], rstd[A_IT];
-#pragma unroll
-  for (int i = 0; i < A_IT; ++i) {
+    for (int kc = 0; kc < NK; ++kc)
+      if (kc == hp) *(f32x4*)(Xs + r * A2_XS + 4 * c4) = vv[kc];
     float sm = 0.f;
 #pragma unroll
-    for (int kc = 0; kc < NK; ++kc) sm += (ra[kc][i][0] + ra[kc][i][1]) + (ra[kc][i][2] + ra[kc][i][3]);
-    mean[i] = sf_sum16(sm) / (float)d;
+    for (int kc = 0; kc < NK; ++kc) sm += (vv[kc][0] + vv[kc][1]) + (vv[kc][2] + vv[kc][3]);
+    const float mu = sf_sum16(sm) / (float)d;
     float vs = 0.f;
 #pragma unroll
     for (int kc = 0; kc < NK; ++kc) {
-      const f32x4 dv = ra[kc][i] - mean[i];
+      const f32x4 dv = vv[kc] - mu;
       vs += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
     }
-    rstd[i] = 1.0f / sqrtf(sf_sum16(vs) / (float)d + ln_eps);
-  }
-  __syncthreads();   // gamma / beta are in LDS
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float rs = 1.0f / sqrtf(sf_sum16(vs) / (float)d + ln_eps);
 #pragma unroll
-  for (int kc = 0; kc < NK; ++kc) {
-    const int k = kc * FA_KC + 4 * c4;
-    const f32x4 g = *(const f32x4*)(GB + k), be = *(const f32x4*)(GB + LF_D + k);
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const int r = r0 + 32 * i;
-      const f32x4 v = (ra[kc][i] - mean[i]) * rstd[i] * g + be;
-      split4(Ah, Al, r * A2_AP + k, aok[i] ? v : zero4);
+    for (int kc = 0; kc < NK; ++kc) {
+      const int k = kc * FA_KC + 4 * c4;
+      const f32x4 g = *(const f32x4*)(GB + k), be = *(const f32x4*)(GB + LF_D + k);
+      split4(Ah, Al, r * A2_AP + k, ok ? (vv[kc] - mu) * rs * g + be : zero4);
     }
-  }
-  // second half of the fragments: k-steps 8..15 of waves 0..3, the (upper-K) halves of waves 6 / 7
-  __builtin_amdgcn_sched_barrier(0);   // keep these requests BEHIND the arithmetic above in the instruction stream
-  if (wave < 4) {
-#pragma unroll
-    for (int ks = 8; ks < 16; ++ks) {
-      wq[ks][0] = __builtin_bit_cast(bf16x8, wqp[(ks * 2) * 64]);
-      wq[ks][1] = __builtin_bit_cast(bf16x8, wqp[(ks * 2 + 1) * 64]);
-    }
-  } else if (wave >= 6) {
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      wq[ks][0] = __builtin_bit_cast(bf16x8, wqp[(ks * 2) * 64]);
-      wq[ks][1] = __builtin_bit_cast(bf16x8, wqp[(ks * 2 + 1) * 64]);
-    }
-  }
-  __syncthreads();
-  LF_TA(18);
-
-  // ---- q|k|v^T = W . LN(x)^T (weights as the MFMA A operand): a wave computes both token blocks of its column block
-  //      with the same weight fragments; no weight planes, no barriers ----
+  };
+  // q|k|v^T = W . LN(x)^T (weights as the MFMA A operand) for token block 0 (SEL 0), token block 1 (SEL 1) or both with the
+  // same fragment reads (SEL 2); no weight planes, no barriers.  v column blocks (cb % 3 == 2) run with the operands SWAPPED
+  // (LN(x) as A, weights as B): their accumulators then hold 16 tokens of ONE channel per lane, which is what the transposed
+  // V planes of the attention core are written from.
   f32x16 acc[2];
 #pragma unroll
   for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q2][r] = 0.f;
-  // v column blocks (cb % 3 == 2) run with the operands SWAPPED (LN(x) as A, weights as B): their accumulators then hold
-  // 16 tokens of ONE channel per lane, which is what the transposed V planes of the attention core are written from
   const bool vblock = (wcb % 3) == 2;
-  {
+  auto proj = [&](auto selc) {
+    constexpr int SEL = decltype(selc)::value;
     const int ao = (lane & 31) * A2_AP + 8 * (lane >> 5) + (wave >= 6 ? 8 * 16 : 0);
     if (!vblock) {
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         if (ks >= 8 && wave >= 4) continue;
-        const bf16x8 xh0 = *(const bf16x8*)(Ah + ao + ks * 16), xl0 = *(const bf16x8*)(Al + ao + ks * 16);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xl0, acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][1], xh0, acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xh0, acc[0], 0, 0, 0);
-        if (nrb == 2) {
+        if constexpr (SEL != 1) {
+          const bf16x8 xh0 = *(const bf16x8*)(Ah + ao + ks * 16), xl0 = *(const bf16x8*)(Al + ao + ks * 16);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xl0, acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][1], xh0, acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xh0, acc[0], 0, 0, 0);
+        }
+        if (SEL != 0 && nrb == 2) {
           const bf16x8 xh1 = *(const bf16x8*)(Ah + ao + 32 * A2_AP + ks * 16), xl1 = *(const bf16x8*)(Al + ao + 32 * A2_AP + ks * 16);
           acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xl1, acc[1], 0, 0, 0);
           acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][1], xh1, acc[1], 0, 0, 0);
           acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xh1, acc[1], 0, 0, 0);
         }
+        // SEAM variants: many values live across the hand-off (late rows, statistics): keep the scheduler from hoisting the
+        // fragment reads of the whole loop (it spilled 80 registers without the fence)
+        if (SEL != 2 && (ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         if (ks >= 8 && wave >= 4) continue;
-        const bf16x8 xh0 = *(const bf16x8*)(Ah + ao + ks * 16), xl0 = *(const bf16x8*)(Al + ao + ks * 16);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl0, wq[ks][0], acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, wq[ks][1], acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, wq[ks][0], acc[0], 0, 0, 0);
-        if (nrb == 2) {
+        if constexpr (SEL != 1) {
+          const bf16x8 xh0 = *(const bf16x8*)(Ah + ao + ks * 16), xl0 = *(const bf16x8*)(Al + ao + ks * 16);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl0, wq[ks][0], acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, wq[ks][1], acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, wq[ks][0], acc[0], 0, 0, 0);
+        }
+        if (SEL != 0 && nrb == 2) {
           const bf16x8 xh1 = *(const bf16x8*)(Ah + ao + 32 * A2_AP + ks * 16), xl1 = *(const bf16x8*)(Al + ao + 32 * A2_AP + ks * 16);
           acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl1, wq[ks][0], acc[1], 0, 0, 0);
           acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh1, wq[ks][1], acc[1], 0, 0, 0);
           acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh1, wq[ks][0], acc[1], 0, 0, 0);
         }
+        if (SEL != 2 && (ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
+  };
+  // second half of the fragments: k-steps 8..15 of waves 0..3, the (upper-K) halves of waves 6 / 7
+  auto second_half = [&]() {
+    __builtin_amdgcn_sched_barrier(0);   // keep these requests BEHIND the arithmetic above in the instruction stream
+    if (wave < 4) {
+#pragma unroll
+      for (int ks = 8; ks < 16; ++ks) {
+        wq[ks][0] = __builtin_bit_cast(bf16x8, wqp[(ks * 2) * 64]);
+        wq[ks][1] = __builtin_bit_cast(bf16x8, wqp[(ks * 2 + 1) * 64]);
+      }
+    } else if (wave >= 6) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        wq[ks][0] = __builtin_bit_cast(bf16x8, wqp[(ks * 2) * 64]);
+        wq[ks][1] = __builtin_bit_cast(bf16x8, wqp[(ks * 2 + 1) * 64]);
+      }
+    }
+  };
+  if (t < 128) *(f32x4*)(GB + 4 * t) = gbv;
+  if (t >= 128 && t < 128 + 192) GB[2 * LF_D + (t - 128)] = qkvb;
+  if constexpr (SEAM) {
+    // the newest frame lies entirely inside token block 1 (the host launches the seam only then; C2: rows 35..41): everything
+    // that does not depend on it -- LayerNorm of the old rows, the projection of token block 0 -- runs BEFORE the wait.  A thread
+    // holds at most one late row (i = 1); nothing of it is kept in registers across the wait.
+    __syncthreads();   // gamma / beta are in LDS
+    ln_row(ra[0][0], ra[1][0], ra[2][0], ra[3][0], r0, aok[0]);
+    if (!late[1]) ln_row(ra[0][1], ra[1][1], ra[2][1], ra[3][1], r0 + 32, aok[1]);
+    second_half();
+    __syncthreads();
+    proj(std::integral_constant<int, 0>{});
+    // ---- the hand-off: tile flags of this video's new frame, then its rows with sc1 loads (+ their position rows) ----
+    if (t == 0) {
+      const int t0 = (b * nslots) / seam.rows_per_tile, t1 = (b * nslots + nslots - 1) / seam.rows_per_tile;
+      const long long c0 = wall_clock64();
+      while (__hip_atomic_load(seam.flags + t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seam.epoch ||
+             __hip_atomic_load(seam.flags + t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seam.epoch) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - c0 > 20000000LL) {   // 0.2 s at 100 MHz: a producer is not resident -- give up, flag the error
+          __hip_atomic_store(seam.flags + SEAM_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicAdd(&lf_seam_timeouts, 1u);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    LF_TQ(11);
+    if (late[1]) {
+      const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, 0x7fffffff, 0x00020000);
+      const unsigned off = (unsigned)((arow[1] - xin) * 4);
+      f32x4 rl[NK];
+#pragma unroll
+      for (int kc = 0; kc < NK; ++kc)
+        rl[kc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off + kc * FA_KC * 4, 0, 16)) +
+                 *(const f32x4*)(prow[1] + kc * FA_KC);
+      ln_row(rl[0], rl[1], rl[2], rl[3], r0 + 32, true);
+    }
+    __syncthreads();
+    LF_TQ(12);
+    proj(std::integral_constant<int, 1>{});
+  } else {
+    __syncthreads();   // gamma / beta are in LDS
+    ln_row(ra[0][0], ra[1][0], ra[2][0], ra[3][0], r0, aok[0]);
+    ln_row(ra[0][1], ra[1][1], ra[2][1], ra[3][1], r0 + 32, aok[1]);
+    second_half();
+    __syncthreads();
+    LF_TA(18);
+    proj(std::integral_constant<int, 2>{});
   }
   // the upper k-half of column blocks 4 / 5 meets the lower half in LDS (scratch = the PV-partial tile, free until then)
   float* PS = (float*)((char*)smem + A2_OT_OFF);   // [2 waves][2 token blocks][16][64]
@@ -414,6 +434,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& A, const int hp, const
   }
   __syncthreads();   // every wave is done with the LN(x) planes: q, k, v take their place
   LF_TA(19);
+  LF_TQ(13);
   const float scale = 1.0f / sqrtf((float)HD);
   if (wave == 4 || wave == 5) {
 #pragma unroll
@@ -603,6 +624,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& A, const int hp, const
     }
   }
   LF_TA(25);
+  LF_TQ(14);
 }
 
 template <bool RING>
@@ -1230,6 +1252,9 @@ int sf_seam_ex(const float* ap_ffn, long long pst_ffn, const sf_tfm_layer& wl, f
   SF_CHECK_LAUNCH();
   return 0;
 }
+
+// the seam launch needs the next window's newest frame entirely inside token block 1 (rows >= 32)
+bool sf_seam_window_ok(int L, int nslots) { return L > 32 && L <= FA_ROWS && L - nslots >= 32; }
 
 // workgroups of a seam launch (producers + consumers): they must all be co-resident, one per CU
 int sf_seam_blocks(int B, int nslots) {

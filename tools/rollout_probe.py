@@ -67,4 +67,5 @@ with torch.no_grad():
         lib.sf_debug_read_ts(out)
         ts = list(out)
         print('ffn  ticks (10 ns):', [t - ts[0] for t in ts[:9]])
+        print('seam attn ticks vs the seam FFN block 0 entry (10 ns):', [t - ts[0] for t in ts[9:15]])
         print('attn ticks (10 ns):', [t - ts[16] for t in ts[16:30]])
