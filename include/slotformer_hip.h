@@ -93,6 +93,12 @@ int sf_slot_attn_iter_f32(const float* k, const float* v, int ld, long long batc
                           float* part_num, float* part_den, float* attn_out, int B, int HW, int N, int D,
                           float scale, float eps, void* stream);
 
+/* bf16-STORAGE variant (SURVEY.md 8(b2) `sf_slot_attn_iter_bf16`): k, v are bf16 rows (ld / batch_stride in elements), half the
+ * bytes of this HBM-bound kernel; logits, softmax, the weighted sums and every output stay f32.  Rounding K/V to bf16 costs
+ * ~2e-3 relative on the updates (tests/test_kernels_gpu.py) -- outside the encode path's 5e-5, hence an option only. */
+int sf_slot_attn_iter_bf16(const void* k, const void* v, int ld, long long batch_stride, const float* q, float* part_num,
+                           float* part_den, float* attn_out, int B, int HW, int N, int D, float scale, float eps, void* stream);
+
 /* Backward of sf_slot_attn_iter_f32 (row N1: savi.py:82-94 under autograd).  Inputs of the forward call (k, v, q, the
  * partial records it produced) plus d_updates [B,N,D], the gradient w.r.t. updates = sum(num) / sum(den).  Writes
  * dq [B,N,D] and dk / dv (same row layout as k / v); accumulate != 0 adds into dk / dv instead (the iterations of one

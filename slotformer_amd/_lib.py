@@ -212,6 +212,7 @@ SIGNATURES = {
                                     VP]),
     'sf_savi_decode_f32_host': (I, [C.POINTER(sf_savi_decoder), FP, FP, FP, FP, I, VP, SZ, VP]),
     'sf_seam_timeouts': (I, []),
+    'sf_slot_attn_iter_bf16': (I, [VP, VP, I, LL, FP, FP, FP, FP, I, I, I, I, F32, F32, VP]),
     'sf_rollout_bf16': (I, [C.POINTER(sf_rollouter), FP, I, I, I, VP, SZ, VP]),
     'sf_rollout_bf16_host': (I, [C.POINTER(sf_rollouter), FP, I, I, I, VP, SZ, VP]),
     'sf_slot_update_f32_host': (I, [FP, FP, I, FP] + [FP] * 10 + [FP, I, I, I, I, F32, VP]),

@@ -150,9 +150,21 @@ __global__ __launch_bounds__(256) void sa_attn_partial_kernel(
 //            wave reads whole 512/768-B rows) and the attention tile as B operand from LDS.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int D>
+// KT = float: f32 K/V rows (the product path).  KT = __bf16 (sf_slot_attn_iter_bf16): K/V STORED as bf16 -- half the HBM
+// bytes of this HBM-bound kernel -- widened to f32 when loaded; all arithmetic stays f32.
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+template <typename KT>
+__device__ __forceinline__ f32x4v sa_load4(const KT* p) {
+  if constexpr (sizeof(KT) == 4) {
+    return *(const f32x4v*)p;
+  } else {
+    return __builtin_convertvector(*(const bf16x4v*)p, f32x4v);
+  }
+}
+
+template <int D, typename KT = float>
 __global__ __launch_bounds__(256) void sa_attn_mfma_kernel(
-    const float* __restrict__ k, const float* __restrict__ v, int ld, long long batch_stride,
+    const KT* __restrict__ k, const KT* __restrict__ v, int ld, long long batch_stride,
     const float* __restrict__ q, float scale, float eps, float* __restrict__ part_num,
     float* __restrict__ part_den, float* __restrict__ attn_out, long long attn_bs, int HW, int N, int P) {
   constexpr int DB = D / 16;  // channel blocks of the MFMA (each 16 channels wide, strided by DB)
@@ -174,20 +186,20 @@ __global__ __launch_bounds__(256) void sa_attn_mfma_kernel(
   //      its 64 rows with 8 lanes per row (8 x 128 B contiguous per instruction), parks it in LDS and every lane reads
   //      ITS row back; the next slab is requested before the current one is consumed. ----
   __shared__ __attribute__((aligned(16))) float s_k[4][64][36];
-  const float* kslab = k + (long long)b * batch_stride + (long long)(pix0 + (lane >> 3)) * ld + 4 * (lane & 7);
+  const KT* kslab = k + (long long)b * batch_stride + (long long)(pix0 + (lane >> 3)) * ld + 4 * (lane & 7);
   float s[NS];
 #pragma unroll
   for (int n = 0; n < NS; ++n) s[n] = 0.f;
   f32x4v nx[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) nx[u] = *(const f32x4v*)(kslab + (long long)(8 * u) * ld);
+  for (int u = 0; u < 8; ++u) nx[u] = sa_load4<KT>(kslab + (long long)(8 * u) * ld);
 #pragma unroll 1
   for (int d0 = 0; d0 < D; d0 += 32) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) *(f32x4v*)&s_k[wave][(lane >> 3) + 8 * u][4 * (lane & 7)] = nx[u];
     if (d0 + 32 < D) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) nx[u] = *(const f32x4v*)(kslab + (long long)(8 * u) * ld + d0 + 32);
+      for (int u = 0; u < 8; ++u) nx[u] = sa_load4<KT>(kslab + (long long)(8 * u) * ld + d0 + 32);
     }
     __builtin_amdgcn_wave_barrier();
     f32x4v kx[8];
@@ -234,14 +246,14 @@ __global__ __launch_bounds__(256) void sa_attn_mfma_kernel(
 #pragma unroll
   for (int j = 0; j < DB; ++j) acc[j] = f32x4a{0.f, 0.f, 0.f, 0.f};
   const int li = lane & 15, lk = lane >> 4;  // A: row i = li (channels DB*li..), k = lk (pixel in group of 4)
-  const float* vbase = v + (long long)b * batch_stride + (long long)(pix0 + lk) * ld + DB * li;
+  const KT* vbase = v + (long long)b * batch_stride + (long long)(pix0 + lk) * ld + DB * li;
 #pragma unroll 4
   for (int ks = 0; ks < 16; ++ks) {
-    const float* vp = vbase + (long long)(4 * ks) * ld;
+    const KT* vp = vbase + (long long)(4 * ks) * ld;
     float vx[DB];
 #pragma unroll
     for (int j = 0; j < DB; j += 4) {
-      const f32x4v t4 = *(const f32x4v*)(vp + j);
+      const f32x4v t4 = sa_load4<KT>(vp + j);
       vx[j] = t4[0];
       vx[j + 1] = t4[1];
       vx[j + 2] = t4[2];
@@ -708,6 +720,38 @@ int sf_slot_attn_iter_f32(const float* k, const float* v, int ld, long long batc
                               N, D, scale, eps, (hipStream_t)stream);
 }
 }  // extern "C"
+
+// bf16-storage variant of the iteration (SURVEY.md 8(b2) `sf_slot_attn_iter_bf16`): k, v point to bf16 rows (ld, batch_stride in
+// ELEMENTS); q, the partial records and attn_out are f32 as in sf_slot_attn_iter_f32.  Needs HW % 256 == 0.
+extern "C" int sf_slot_attn_iter_bf16(const void* k, const void* v, int ld, long long batch_stride, const float* q,
+                                      float* part_num, float* part_den, float* attn_out, int B, int HW, int N, int D, float scale,
+                                      float eps, void* stream) {
+  SF_REQUIRE(k && v && q && part_num && part_den, "null pointer");
+  SF_REQUIRE(B >= 0 && HW > 0 && (HW % 256) == 0 && N >= 1 && N <= SA_NMAX, "need 1 <= num_slots <= 8 and HW % 256 == 0");
+  SF_REQUIRE(D == 64 || D == 128 || D == 192 || D == 256, "slot_size must be 64/128/192/256");
+  SF_REQUIRE(ld >= D && (ld % 4) == 0 && (batch_stride % 4) == 0, "k/v rows must be 8-byte aligned");
+  if (B == 0) return 0;
+  const int P = sf_sa_pick_partials(HW);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(P, B), block(256);
+  const __bf16* kb = (const __bf16*)k;
+  const __bf16* vb = (const __bf16*)v;
+  const long long abs_ = (long long)N * HW;
+  sf_prof_begin(SF_K_SA_ITER, st, 2.0 * (double)B * HW * D * sizeof(__bf16));
+#define SA_LAUNCHB(DD)                                                                                                   \
+  hipLaunchKernelGGL((sa_attn_mfma_kernel<DD, __bf16>), grid, block, 0, st, kb, vb, ld, batch_stride, q, scale, eps, part_num, \
+                     part_den, attn_out, abs_, HW, N, P)
+  switch (D / 64) {
+    case 1: SA_LAUNCHB(64); break;
+    case 2: SA_LAUNCHB(128); break;
+    case 3: SA_LAUNCHB(192); break;
+    default: SA_LAUNCHB(256); break;
+  }
+#undef SA_LAUNCHB
+  sf_prof_end(SF_K_SA_ITER, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
 
 int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch_stride, const float* q,
                          float* part_num, float* part_den, float* attn_out, long long attn_batch_stride, int B,
