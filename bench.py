@@ -36,7 +36,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak; bf16x3 issues 3 bf16 MFM
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec peak (6.3 TB/s achievable)
 T_BURN, T_ROLL, RES = 6, 50, 128
 N_SLOTS, SLOT_D = 7, 128
-CLS_NAMES = ['conv_nhwc_implicit_gemm', 'conv_first', 'linear_gemm', 'slot_attn_iter', 'slot_update', 'attention', 'ffn_fused']
+CLS_NAMES = ['conv_nhwc_implicit_gemm', 'conv_first', 'linear_gemm', 'slot_attn_iter', 'slot_update', 'attention', 'ffn_fused', 'seam']
 ROLL_FLOPS_PER_FRAME = 274.7e6   # algorithmic FLOPs per predicted frame per video
 ENC_FLOPS_PER_FRAME = 3.06e9     # SURVEY.md 8d / DESIGN.md 4: per encoded frame
 
@@ -77,6 +77,30 @@ def committed_profile(key):
         return d
     except ValueError:
         return {}
+
+
+def dominant_kernel():
+    """The kernel with the largest total device time in the newest committed rocprof summary of this command
+    (profiles/r*_kernel_stats.csv) -> key of the roofline object that becomes `roofline`."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_stats.csv')))
+    names = {'conv5x5_halo': 'conv', 'ffn_partial_kernel': 'ffn_fused', 'attn_oproj_kernel': 'attention', 'seam_kernel': 'seam',
+             'sa_attn_mfma_kernel': 'slot_attn'}
+    if not files:
+        return 'ffn_fused', None
+    tot = {}
+    try:
+        for r in csv.DictReader(open(files[-1])):
+            for pat, key in names.items():
+                if pat in r['Name']:
+                    tot[key] = tot.get(key, 0.0) + float(r['Percentage'])
+    except (KeyError, ValueError):
+        return 'ffn_fused', None
+    if not tot:
+        return 'ffn_fused', None
+    key = max(tot, key=tot.get)
+    return key, {'source': os.path.relpath(files[-1], ROOT), 'share_of_device_time_pct': {k: round(v, 2) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}}
 
 
 def read_profile(lib):
@@ -264,7 +288,7 @@ def main():
         # the rollout layer kernels, event-timed: (a) alone on the whole chip in one eager rollout, (b) LIVE in a pipelined
         # pass with the product schedule (encode stream busy on its CUs) but eager launches -- inside the timed region they
         # replay from a hipGraph, where HIP events cannot be inserted between the kernels
-        lib.sf_profile_enable((1 << 5) | (1 << 6))
+        lib.sf_profile_enable((1 << 5) | (1 << 6) | (1 << 7))
         read_profile(lib)
         engine.rollout(roll, pipe.bufs[0], T_BURN, T_ROLL, ws_slot=('pipe', 0))
         torch.cuda.synchronize()
@@ -304,7 +328,7 @@ def main():
                     'note': 'serial (no batch pipelining, copies on the compute stream): upper bound on the PCIe cost'}
         breakdown = None
         if args.breakdown:
-            lib.sf_profile_enable(0x7f)
+            lib.sf_profile_enable(0xff)
             encode()
             engine.rollout(roll, pipe.bufs[0], T_BURN, T_ROLL, ws_slot=('pipe', 0))
             torch.cuda.synchronize()
@@ -328,7 +352,7 @@ def main():
         peak_note = ('split-bf16 MFMA: 3 bf16 MFMA flops per algorithmic flop -> roof = 2500/3 TFLOP/s' if prec == 'bf16x3'
                      else 'exact f32 MFMA')
         nl = len(roll.transformer_encoder.layers)
-        launches_per_graph = 1 + T_ROLL * 2 * nl
+        launches_per_graph = 1 + T_ROLL * 2 * nl - (T_ROLL - 1)   # the seam launch carries two kernels' worth
         step_flops = B * (T_BURN * ENC_FLOPS_PER_FRAME + T_ROLL * ROLL_FLOPS_PER_FRAME)
         res = {
             'metric': 'rollout frames/sec at B=32, 128x128, 7 slots, 6+50 steps (SAVi-encode + SlotFormer rollout)',
@@ -368,13 +392,15 @@ def main():
             'whole_step_tflops': step_flops * args.steps * world / elapsed / 1e12,
             'whole_step_flops': step_flops,
         }
-        # ---- headline roofline: the kernel with the largest share of device time in the rocprof summary of this command
-        #      (profiles/r02_kernel_stats.csv): the fused FFN kernel of the rollout layers ----
-        rk = {}
+        # ---- roofline objects, one per hot kernel; `roofline` = the one that dominates the committed rocprof summary of this
+        #      command (profiles/r*_kernel_stats.csv), the others stay as secondary keys ----
+        objs = {}
         for key, name in (('ffn_fused', 'ffn_partial_kernel (sum of the 4 head-pair partials + LN2 + FFN1 + ReLU + FFN2 on one 32-row tile x 256-wide '
-                           'hidden chunk + last-arriver reduction; on the last layer also the step boundary)'),
+                           'hidden chunk + last-arriver reduction)'),
                           ('attention', 'attn_oproj_kernel (LN1 + q|k|v of a head pair + softmax(qk^T)v + out-proj partial; one workgroup per '
-                           '(head pair, video))')):
+                           '(head pair, video))'),
+                          ('seam', 'seam_kernel (last-layer FFN + step boundary of step s and the layer-0 attention of step s+1 in one grid, '
+                           'tile-local write-through hand-off)')):
             iso, live = prof_roll.get(key), prof_roll_live.get(key)
             if not iso:
                 continue
@@ -383,7 +409,7 @@ def main():
             cus = (256 - pipe.encode_cus) if (live and pipe.cu_split) else 256
             tf = fl / (src['avg_us'] * 1e-6) / 1e12
             pm = committed_profile(key)
-            rk[key] = {
+            objs[key] = {
                 'kernel': name, 'bound': 'mfma', 'achieved': tf, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': tf / peak_chip,
                 'peak_note': peak_note + '; whole-chip roof (the launch has 128-168 workgroups, one per CU)',
                 'flops_per_launch': fl, 'avg_launch_us': src['avg_us'], 'launches': src['launches'], 'cus_available': cus,
@@ -391,21 +417,18 @@ def main():
                              '(encode stream busy on its CUs), eager launches' if live else 'HIP events around every launch, kernel alone'),
                 'avg_launch_us_isolated': iso['avg_us'], 'frac_isolated': fl / (iso['avg_us'] * 1e-6) / 1e12 / peak_chip,
                 'traffic': pm.get('traffic_bytes_per_launch'),
-                'mfma_busy_frac': pm.get('mfma_busy_frac'), 'pmc_source': pm.get('source'),
+                'mfma_busy_frac': pm.get('mfma_busy_frac'), 'avg_launch_us_rocprof': pm.get('avg_launch_us_trace'), 'pmc_source': pm.get('source'),
                 'limiter': 'per-CU ingest (~100 GB/s per workgroup: weight fragments + activations re-fetched by every workgroup) and '
                            'dependent-launch latency, not the matrix pipe (DESIGN.md 4)',
             }
-        if 'ffn_fused' in rk:
-            res['roofline'] = rk.pop('ffn_fused')
-        if rk:
-            res['roofline_attention'] = rk['attention']
         roll_flops = ROLL_FLOPS_PER_FRAME * B * T_ROLL
+        launches_per_graph = 1 + T_ROLL * 2 * nl - (T_ROLL - 1 if 'seam' in prof_roll else 0)
         res['roofline_rollout_graph'] = {
-            'kernel': f'hipGraph of the 50-step rollout: ring init + 50 x {nl} x (attention + out-proj partials, fused FFN [+ step boundary on the '
-                      f'last layer]) = {launches_per_graph} launches',
+            'kernel': f'hipGraph of the 50-step rollout: ring init + per step {nl} x (attention + out-proj partials, fused FFN), the last FFN '
+                      f'(+ step boundary) sharing a launch with the next step\'s first attention = {launches_per_graph} launches',
             'bound': f'latency ({launches_per_graph} dependent launches, M = B*L = {B * 42} rows); MFMA roof shown for scale',
             'achieved': roll_flops / t_roll / 1e12, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': roll_flops / t_roll / 1e12 / peak_chip,
-            'ms': 1e3 * t_roll, 'us_per_step': 1e6 * t_roll / T_ROLL,
+            'ms': 1e3 * t_roll, 'us_per_step': 1e6 * t_roll / T_ROLL, 'seam_timeouts': int(lib.sf_seam_timeouts()),
         }
         conv = prof.get('conv_nhwc_implicit_gemm')
         if conv:
@@ -415,17 +438,20 @@ def main():
             iso = prof_iso.get('conv_nhwc_implicit_gemm')
             ach_iso = flops_per_launch / (iso['avg_us'] * 1e-6) / 1e12 if iso else None
             pm = committed_profile('conv_nhwc_implicit_gemm')
-            res['roofline_conv'] = {
+            objs['conv'] = {
                 'kernel': ('conv5x5_halo_kernel' if prec == 'bf16x3' else 'sf_gemm_kernel<128,64,...,conv_nhwc>') + ' (5x5 conv 64->64 @64x64; ' + peak_note + ')',
-                'bound': 'lds-read / mfma (matrix pipe busy ~42 % of the launch; the operand reads from LDS and the un-overlapped halo '
-                         'fill bound it, DESIGN.md 4)',
+                'bound': 'lds-read / mfma (matrix pipes busy ~40 % of the launch at 2.4 GHz, 55 % at the 1.86 GHz the chip sustains in this '
+                         'kernel; fragment reads from LDS and the un-overlapped halo fill bound it, DESIGN.md 4 and 7)',
                 'achieved': ach_iso, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': (ach_iso / peak_chip) if ach_iso else None,
                 'avg_launch_us': iso['avg_us'] if iso else None,
+                'measured': 'HIP events around every launch (library brackets on the launch stream): `achieved` = the kernel alone on the whole '
+                            'chip in the untimed pass of this run; `live` = inside the timed region on the encode partition',
                 'live': {'achieved': ach, 'cus': enc_cus, 'avg_launch_us': conv['avg_us'], 'launches': conv['launches'],
                          'frac_of_partition_peak': ach / (peak_chip * enc_cus / 256.0),
                          'note': 'inside the timed region the encode stream owns `cus` CUs beside the rollout graph of the previous batch; '
                                  'stolen convolutions (rollout stream) are not part of this average'},
-                'traffic': pm.get('traffic_bytes_per_launch'), 'mfma_busy_frac': pm.get('mfma_busy_frac'), 'pmc_source': pm.get('source'),
+                'traffic': pm.get('traffic_bytes_per_launch'), 'mfma_busy_frac': pm.get('mfma_busy_frac'),
+                'avg_launch_us_rocprof': pm.get('avg_launch_us_trace'), 'pmc_source': pm.get('source'),
                 'traffic_unit': 'bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE)',
                 'algorithmic_bytes_per_launch': 2 * 32 * 4096 * 64 * 4 + 64 * 1600 * 4, 'flops_per_launch': flops_per_launch,
             }
@@ -434,7 +460,7 @@ def main():
             bytes_per_launch = sa['work'] / sa['launches']
             gbps = bytes_per_launch / (sa['avg_us'] * 1e-6) / 1e9
             iso = prof_iso.get('slot_attn_iter')
-            res['roofline_slot_attn'] = {
+            objs['slot_attn'] = {
                 'kernel': 'sa_attn_mfma_kernel<128> (one Slot-Attention iteration over K,V)', 'bound': 'hbm',
                 'achieved': bytes_per_launch / (iso['avg_us'] * 1e-6) / 1e9 if iso else None, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
                 'frac': (bytes_per_launch / (iso['avg_us'] * 1e-6) / 1e9 / PEAK_HBM_GBPS) if iso else None,
@@ -443,6 +469,13 @@ def main():
                 'live': {'achieved': gbps, 'avg_launch_us': sa['avg_us'], 'launches': sa['launches'],
                          'cus': pipe.encode_cus if (overlap and pipe.cu_split) else 256},
             }
+        dom, dom_info = dominant_kernel()
+        if dom not in objs:
+            dom = 'ffn_fused' if 'ffn_fused' in objs else (next(iter(objs)) if objs else None)
+        if dom:
+            res['roofline'] = dict(objs.pop(dom), dominant_by=dom_info)
+        for k, v in objs.items():
+            res['roofline_' + k] = v
         if breakdown:
             res['kernel_breakdown_one_step'] = breakdown
         if pcie:

@@ -1246,9 +1246,11 @@ int sf_seam_ex(const float* ap_ffn, long long pst_ffn, const sf_tfm_layer& wl, f
   const AttnArgs A = make_attn_args(ring, (long long)ring_frames * nslots * LF_D, pe, f0_next, ring_frames, nslots, w0, eps, ap_attn,
                                     pst_attn, L, Lq);
   const SeamArgs seam{seam_flags, epoch, FB_ROWS};
-  sf_prof_begin(SF_K_FFN, st, 4.0 * M * (double)LF_D * ffn);
+  // algorithmic work: the last layer's FFN on M rows + the next step's layer-0 attention
+  sf_prof_begin(SF_K_SEAM, st, 4.0 * M * (double)LF_D * ffn + 6.0 * B * L * (double)LF_D * LF_D + 4.0 * (double)B * LF_NH * Lq * L * LF_HD +
+                                   2.0 * B * Lq * (double)LF_D * LF_D);
   hipLaunchKernelGGL(seam_kernel, dim3(nffn + (LF_NH / 2) * B), dim3(LF_NT), LDS, st, F, A, seam, nffn);
-  sf_prof_end(SF_K_FFN, st);
+  sf_prof_end(SF_K_SEAM, st);
   SF_CHECK_LAUNCH();
   return 0;
 }
