@@ -103,9 +103,10 @@ __global__ __launch_bounds__(PM_NT) void pixel_mlp_kv_kernel(
       for (int j = 0; j < 2; ++j) {
         const int bo = ((cb0 + j) * 32 + (lane & 31)) * LB + 8 * (lane >> 5) + ks * 16;
         const bf16x8 yh = *(const bf16x8*)(Bh + bo), yl = *(const bf16x8*)(Bl + bo);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[j], 0, 0, 0);
+        // transposed (weights as the A operand): acc[j][4 g + q] = out[pixel = lane & 31][column 8 g + 4 (lane >> 5) + q]
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl, xh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xh, acc[j], 0, 0, 0);
       }
     }
   };
@@ -126,15 +127,17 @@ __global__ __launch_bounds__(PM_NT) void pixel_mlp_kv_kernel(
   __syncthreads();  // every wave is done with the K=64 planes
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int n = (cb0 + j) * 32 + (lane & 31);
-    const float bv = PV[n];
+    const int row = rb * 32 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const float v = fmaxf(acc[j][r] + bv, 0.f);
-      const __bf16 hi = (__bf16)v;
-      Ah[row * PM_LB1 + n] = hi;
-      Al[row * PM_LB1 + n] = (__bf16)(v - (float)hi);
+    for (int g = 0; g < 4; ++g) {
+      const int n = (cb0 + j) * 32 + 8 * g + 4 * (lane >> 5);
+      const f32x4 bv = *(const f32x4*)(PV + n);
+      const f32x4 v = {fmaxf(acc[j][4 * g] + bv[0], 0.f), fmaxf(acc[j][4 * g + 1] + bv[1], 0.f), fmaxf(acc[j][4 * g + 2] + bv[2], 0.f),
+                       fmaxf(acc[j][4 * g + 3] + bv[3], 0.f)};
+      bf16x4 hi, lo;
+      split4(v, hi, lo);
+      *(bf16x4*)(Ah + row * PM_LB1 + n) = hi;
+      *(bf16x4*)(Al + row * PM_LB1 + n) = lo;
     }
   }
   store_w128(wr2);
@@ -148,12 +151,13 @@ __global__ __launch_bounds__(PM_NT) void pixel_mlp_kv_kernel(
   __syncthreads();  // W2 planes are dead
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int n = (cb0 + j) * 32 + (lane & 31);
-    const float bv = PV[PM_C1 + n];
+    const int row = rb * 32 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      H2[row * PM_H2S + n] = acc[j][r] + bv;
+    for (int g = 0; g < 4; ++g) {
+      const int n = (cb0 + j) * 32 + 8 * g + 4 * (lane >> 5);
+      const f32x4 bv = *(const f32x4*)(PV + PM_C1 + n);
+      *(f32x4*)(H2 + row * PM_H2S + n) = f32x4{acc[j][4 * g] + bv[0], acc[j][4 * g + 1] + bv[1], acc[j][4 * g + 2] + bv[2],
+                                             acc[j][4 * g + 3] + bv[3]};
     }
   }
   __syncthreads();
@@ -203,11 +207,12 @@ __global__ __launch_bounds__(PM_NT) void pixel_mlp_kv_kernel(
     gemm(PM_LB1, PM_C1 / 16, acc);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int n = half * PM_C1 + (cb0 + j) * 32 + (lane & 31);
+      const int row = m0 + rb * 32 + (lane & 31);
+      if (row < M) {
+        float* dst = kv + (long long)row * PM_ND + half * PM_C1 + (cb0 + j) * 32 + 4 * (lane >> 5);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < M) kv[(long long)row * PM_ND + n] = acc[j][r];
+        for (int g = 0; g < 4; ++g)
+          *(f32x4*)(dst + 8 * g) = f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
       }
     }
     __syncthreads();  // before the second half overwrites the weight planes
