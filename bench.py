@@ -213,13 +213,16 @@ def main():
     savi, roll = build_models(dev)
     # a ring of three DIFFERENT resident inputs: consecutive batches never see the same frames
     ring = [synthetic_img(B, seed=1234 + 1000 * k + rank).to(dev) for k in range(3)]
-    cu_word = int(os.environ.get('SF_BENCH_CU_SPLIT', 'ff'), 16)
-    steal = int(os.environ.get('SF_BENCH_STEAL', '1'))
+    cu_word = os.environ.get('SF_BENCH_CU_SPLIT', 'ff')          # hex mask word, or rows<R> (pipeline.encode_mask_words)
+    cu_word = cu_word if cu_word.startswith('rows') else int(cu_word, 16)
+    steal = os.environ.get('SF_BENCH_STEAL')                   # None: the partition's default
+    steal = None if steal is None else int(steal)
+    partition = os.environ.get('SF_BENCH_PARTITION', 'three')  # 'three' | 'two' | 'none' (pipeline.EncodeRolloutPipeline)
 
     with torch.no_grad():
         log('building the pipeline (first eager rollouts + graph capture)')
         pipe = EncodeRolloutPipeline(savi, roll, B, T_BURN, T_ROLL, encode_cu_word=cu_word, steal_steps=steal,
-                                     use_graph=not args.no_graph)
+                                     use_graph=not args.no_graph, partition=partition)
         overlap = not args.no_overlap
         graph = pipe.graphs[0] if pipe.graphs else None
 
@@ -239,7 +242,7 @@ def main():
         assert torch.isfinite(out_w[:args.warmup]).all(), 'non-finite slots in the warmup batches'
         log('warmup done')
         # conv + Slot-Attention launches are event-timed live (library brackets on the launch stream)
-        lib.sf_profile_enable((1 << 0) | (1 << 3))
+        lib.sf_profile_enable(int(os.environ.get('SF_BENCH_LIVE_MASK', str((1 << 0) | (1 << 3)))))
         read_profile(lib)
         barrier()
         t0 = time.perf_counter()
@@ -284,7 +287,14 @@ def main():
         t_roll = timed_on(torch.cuda.current_stream(), rollout)
         part_ms = None
         if overlap and pipe.cu_split:
-            part_ms = {'encode_ms_on_its_cus': 1e3 * timed_on(pipe.s_enc, encode), 'rollout_ms_on_its_cus': 1e3 * timed_on(pipe.s_roll, rollout)}
+            def lane_encode(li):
+                st, lo, hi = pipe.lanes[li]
+                return lambda: pipe._encode(ring[0], noise, pipe.bufs[0], None, lo, hi, li)
+
+            part_ms = {'encode_lane_ms_on_its_cus': [round(1e3 * timed_on(pipe.lanes[li][0], lane_encode(li)), 4) for li in range(len(pipe.lanes))],
+                       'encode_lane_videos': [hi - lo for _, lo, hi in pipe.lanes],
+                       'rollout_ms_on_its_cus': 1e3 * timed_on(pipe.s_roll, rollout)}
+            part_ms['encode_ms_on_its_cus'] = max(part_ms['encode_lane_ms_on_its_cus'])
         # the rollout layer kernels, event-timed: (a) alone on the whole chip in one eager rollout, (b) LIVE in a pipelined
         # pass with the product schedule (encode stream busy on its CUs) but eager launches -- inside the timed region they
         # replay from a hipGraph, where HIP events cannot be inserted between the kernels
@@ -380,8 +390,11 @@ def main():
                                'runs its full encode + 50-step rollout inside the timed region') if overlap else 'none',
                 'work_stealing': (f'the CNN features of the first {pipe.steal} time step(s) of batch j+2 are computed on the rollout '
                                   'stream after the rollout of batch j') if (overlap and pipe.steal) else 'none',
-                'cu_partition': (f'encode stream on CU mask {cu_word:#x} x8 words ({pipe.encode_cus} CUs), rollout stream on the '
-                                 'complement') if (overlap and pipe.cu_split) else 'none',
+                'cu_partition': (('rollout stream: CU rows 0-6 of shader engines 1-3 of every XCD (168 CUs); encode lane 0: shader engine 0 '
+                                  f'(64 CUs, {pipe.lanes[0][2] - pipe.lanes[0][1]} videos of every batch); encode lane 1: CU row 7 of shader engines 1-3 '
+                                  f'(24 CUs, {pipe.lanes[-1][2] - pipe.lanes[-1][1]} videos)') if pipe.partition == 'three' else
+                                 (f'encode stream on CU mask {cu_word if isinstance(cu_word, str) else hex(cu_word)} ({pipe.encode_cus} CUs, the same '
+                                  'number in every XCD), rollout stream on the complement')) if (overlap and pipe.cu_split) else 'none',
             },
             'encode_ms': 1e3 * t_enc,
             'rollout_ms': 1e3 * t_roll,
@@ -406,7 +419,7 @@ def main():
                 continue
             fl = iso['work'] / iso['launches']
             src = live or iso
-            cus = (256 - pipe.encode_cus) if (live and pipe.cu_split) else 256
+            cus = pipe.rollout_cus if (live and pipe.cu_split) else 256
             tf = fl / (src['avg_us'] * 1e-6) / 1e12
             pm = committed_profile(key)
             objs[key] = {
@@ -432,10 +445,12 @@ def main():
         }
         conv = prof.get('conv_nhwc_implicit_gemm')
         if conv:
-            flops_per_launch = conv['work'] / conv['launches']
-            ach = flops_per_launch / (conv['avg_us'] * 1e-6) / 1e12
-            enc_cus = pipe.encode_cus if (overlap and pipe.cu_split) else 256
+            flops_live = conv['work'] / conv['launches']        # mean over the lanes' launches (each a share of the batch)
+            ach = flops_live / (conv['avg_us'] * 1e-6) / 1e12
+            # CUs one live launch runs on: the lanes work side by side, each on its own CUs
+            enc_cus = pipe.encode_cus / len(pipe.lanes) if (overlap and pipe.cu_split) else 256
             iso = prof_iso.get('conv_nhwc_implicit_gemm')
+            flops_per_launch = iso['work'] / iso['launches'] if iso else flops_live
             ach_iso = flops_per_launch / (iso['avg_us'] * 1e-6) / 1e12 if iso else None
             pm = committed_profile('conv_nhwc_implicit_gemm')
             objs['conv'] = {
@@ -447,9 +462,10 @@ def main():
                 'measured': 'HIP events around every launch (library brackets on the launch stream): `achieved` = the kernel alone on the whole '
                             'chip in the untimed pass of this run; `live` = inside the timed region on the encode partition',
                 'live': {'achieved': ach, 'cus': enc_cus, 'avg_launch_us': conv['avg_us'], 'launches': conv['launches'],
-                         'frac_of_partition_peak': ach / (peak_chip * enc_cus / 256.0),
-                         'note': 'inside the timed region the encode stream owns `cus` CUs beside the rollout graph of the previous batch; '
-                                 'stolen convolutions (rollout stream) are not part of this average'},
+                         'flops_per_launch': flops_live, 'frac_of_partition_peak': ach / (peak_chip * enc_cus / 256.0),
+                         'note': 'inside the timed region, beside the rollout graph of the previous batch; `cus` = CUs per launch (the encode '
+                                 'lanes run side by side on their own CUs, each on its share of the videos: mean over the lanes); stolen '
+                                 'convolutions (rollout stream) are not part of this average'},
                 'traffic': pm.get('traffic_bytes_per_launch'), 'mfma_busy_frac': pm.get('mfma_busy_frac'),
                 'avg_launch_us_rocprof': pm.get('avg_launch_us_trace'), 'pmc_source': pm.get('source'),
                 'traffic_unit': 'bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE)',
@@ -457,9 +473,9 @@ def main():
             }
         sa = prof.get('slot_attn_iter')
         if sa:
-            bytes_per_launch = sa['work'] / sa['launches']
-            gbps = bytes_per_launch / (sa['avg_us'] * 1e-6) / 1e9
+            gbps = sa['work'] / sa['launches'] / (sa['avg_us'] * 1e-6) / 1e9
             iso = prof_iso.get('slot_attn_iter')
+            bytes_per_launch = iso['work'] / iso['launches'] if iso else sa['work'] / sa['launches']
             objs['slot_attn'] = {
                 'kernel': 'sa_attn_mfma_kernel<128> (one Slot-Attention iteration over K,V)', 'bound': 'hbm',
                 'achieved': bytes_per_launch / (iso['avg_us'] * 1e-6) / 1e9 if iso else None, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
@@ -467,7 +483,8 @@ def main():
                 'avg_launch_us': iso['avg_us'] if iso else None,
                 'traffic': committed_profile('slot_attn_iter').get('traffic_bytes_per_launch'), 'bytes_per_launch': bytes_per_launch,
                 'live': {'achieved': gbps, 'avg_launch_us': sa['avg_us'], 'launches': sa['launches'],
-                         'cus': pipe.encode_cus if (overlap and pipe.cu_split) else 256},
+                         'bytes_per_launch': sa['work'] / sa['launches'],
+                         'cus': pipe.encode_cus / len(pipe.lanes) if (overlap and pipe.cu_split) else 256},
             }
         dom, dom_info = dominant_kernel()
         if dom not in objs:

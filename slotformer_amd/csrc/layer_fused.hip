@@ -770,7 +770,7 @@ __device__ __forceinline__ void sb_compute(const SbArgs& a, const SbFrags& f, co
 }
 
 // ap [8][M][256] head partials -> xout [M][256] finished layer output (xp [4][M][256]: chunk-partial scratch);
-// grid = ceil(tiles/8) * 32 workgroups, tile = 32 rows, 4 hidden chunks per tile.
+// grid = ffn_blocks(tiles) workgroups, tile = 32 rows, 4 hidden chunks per tile.
 //
 // Both GEMMs run "transposed" (weights as the MFMA A operand, activations as B): a lane then owns 4 CONSECUTIVE
 // output columns of one token, so the hidden activations go to LDS as packed 8-byte stores and the results leave
@@ -818,7 +818,16 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& F, const int blk) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // block b runs on XCD b % 8: the four hidden chunks of a row tile share an XCD (one L2 fetch of the head partials);
   // tiles are dealt round-robin over the XCDs
-  const int c = (blk >> 3) & (LF_NCH - 1), tile = (blk >> 5) * 8 + (blk & 7);
+  // -- whole groups of 8 tiles.  The ntiles % 8 tiles left over would put 4 more workgroups on the first XCDs only
+  // (24 on XCDs 0 and 1 against 20 elsewhere for the 42 tiles of a B = 32 window): behind whole groups their chunks are
+  // dealt one per XCD instead (21 everywhere -- the launch then fits 21 CUs per XCD; the partial exchange is
+  // write-through, so a tile whose chunks sit in different XCDs is only a little slower, never wrong).
+  const int full = (ntiles >> 3) << 5;
+  int c = (blk >> 3) & (LF_NCH - 1), tile = (blk >> 5) * 8 + (blk & 7);
+  if (full > 0 && blk >= full) {
+    c = (blk - full) & (LF_NCH - 1);
+    tile = (ntiles & ~7) + ((blk - full) >> 2);
+  }
   if (tile >= ntiles) return;
   const int row0 = tile * FB_ROWS;
   LF_TS(0);
@@ -1005,7 +1014,20 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& F, const int blk) {
   LF_TS(8);
 }
 
-__global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(FfnArgs F) { ffn_body(F, blockIdx.x); }
+__device__ unsigned long long lf_wg[4 * 64];   // SF_LF_DBG & 32: {HW_ID, XCC_ID, start, end} of the first 64 FFN workgroups
+__global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(FfnArgs F) {
+  const unsigned long long t0 = (F.dbg & 32) ? wall_clock64() : 0ull;
+  ffn_body(F, blockIdx.x);
+  if ((F.dbg & 32) && threadIdx.x == 0 && blockIdx.x < 64) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    lf_wg[4 * blockIdx.x] = hw;
+    lf_wg[4 * blockIdx.x + 1] = xcc;
+    lf_wg[4 * blockIdx.x + 2] = t0;
+    lf_wg[4 * blockIdx.x + 3] = wall_clock64();
+  }
+}
 
 // One launch for the seam between two rollout steps: blocks [0, nffn) run the last layer's FFN + step boundary of step s,
 // the others the layer-0 attention of step s+1 (one per (head pair, video)), which requests its weights and the five old
@@ -1179,6 +1201,9 @@ static FfnArgs make_ffn_args(const float* ap, long long ap_stride, const sf_tfm_
   return F;
 }
 
+// 8 tiles x 4 chunks per group of 32 consecutive blocks; left-over tiles behind whole groups: 4 blocks each (ffn_body)
+static int ffn_blocks(int tiles) { return tiles < 8 ? 32 : (tiles / 8) * 32 + (tiles % 8) * 4; }
+
 static int launch_ffn(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp, long long xp_stride,
                       float* xout, int* counters, int M, int ffn, const SbArgs& sb, hipStream_t st) {
   static_assert(FB_LDS <= 160 * 1024, "FFN kernel: LDS budget");
@@ -1193,9 +1218,8 @@ static int launch_ffn(const float* ap, long long ap_stride, const sf_tfm_layer& 
     attr = true;
   }
   const int tiles = (M + FB_ROWS - 1) / FB_ROWS;
-  const int groups = (tiles + 7) / 8;   // 8 tiles x 4 chunks per group of 32 consecutive blocks
   sf_prof_begin(SF_K_FFN, st, 4.0 * M * (double)LF_D * ffn);
-  hipLaunchKernelGGL(ffn_partial_kernel, dim3(groups * 32), dim3(LF_NT), FB_LDS, st,
+  hipLaunchKernelGGL(ffn_partial_kernel, dim3(ffn_blocks(tiles)), dim3(LF_NT), FB_LDS, st,
                      make_ffn_args(ap, ap_stride, w, eps, xp, xp_stride, xout, counters, M, sb));
   sf_prof_end(SF_K_FFN, st);
   SF_CHECK_LAUNCH();
@@ -1241,7 +1265,7 @@ int sf_seam_ex(const float* ap_ffn, long long pst_ffn, const sf_tfm_layer& wl, f
                       (long long)ring_frames * nslots * LF_D, (long long)(frame % ring_frames) * nslots * LF_D, nslots);
   sb.seam_flags = seam_flags;
   sb.seam_epoch = epoch;
-  const int M = B * nslots, tiles = (M + FB_ROWS - 1) / FB_ROWS, nffn = ((tiles + 7) / 8) * 32;
+  const int M = B * nslots, tiles = (M + FB_ROWS - 1) / FB_ROWS, nffn = ffn_blocks(tiles);
   const FfnArgs F = make_ffn_args(ap_ffn, pst_ffn, wl, eps, xp, xp_stride, nullptr, counters, M, sb);
   const AttnArgs A = make_attn_args(ring, (long long)ring_frames * nslots * LF_D, pe, f0_next, ring_frames, nslots, w0, eps, ap_attn,
                                     pst_attn, L, Lq);
@@ -1261,7 +1285,7 @@ bool sf_seam_window_ok(int L, int nslots) { return L > 32 && L <= FA_ROWS && L -
 // workgroups of a seam launch (producers + consumers): they must all be co-resident, one per CU
 int sf_seam_blocks(int B, int nslots) {
   const int tiles = (B * nslots + FB_ROWS - 1) / FB_ROWS;
-  return ((tiles + 7) / 8) * 32 + (LF_NH / 2) * B;
+  return ffn_blocks(tiles) + (LF_NH / 2) * B;
 }
 
 bool sf_step_boundary_ok(int d, int slot_size) { return d == LF_D && slot_size == SB_C; }
@@ -1337,6 +1361,11 @@ extern "C" int sf_seam_timeouts(void) {
   unsigned v = 0;
   hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(lf_seam_timeouts), sizeof(v));
   return e == hipSuccess ? (int)v : -(int)e;
+}
+
+extern "C" int sf_debug_read_wg(unsigned long long* out256) {
+  hipError_t e = hipMemcpyFromSymbol(out256, HIP_SYMBOL(lf_wg), sizeof(unsigned long long) * 256);
+  return e == hipSuccess ? 0 : (int)e;
 }
 
 extern "C" int sf_debug_read_ts(long long* out32) {

@@ -6,10 +6,13 @@ so they run side by side on disjoint sets of CUs:
 
 * the rollout of every slot buffer is captured ONCE into a hipGraph (one graph, one slot buffer and one workspace per batch
   in flight) and replayed on the *rollout stream*;
-* the encode runs on the *encode stream*; both streams are created with CU masks (`sf_stream_create_cu_mask` ->
-  hipExtStreamCreateWithCUMask): the encode gets one shader engine of every XCD (mask byte 0xff in every word = 64 CUs),
-  the rollout the other three (192 CUs).  Measured in round 1 (profiles/r01_probes.txt): whole bytes, identical in all
-  words, are the only masks that do not unbalance the shader engines;
+* the encode runs on *encode lanes* -- streams created with CU masks (`sf_stream_create_cu_mask` ->
+  hipExtStreamCreateWithCUMask), each encoding its own share of the batch's videos.  Default partition ('three'): the
+  rollout gets CU rows 0-6 of shader engines 1-3 of every XCD (168 CUs: exactly what its widest launch, the 168
+  workgroups of a B = 32 FFN, needs -- 21 per XCD), lane 0 the whole shader engine 0 (64 CUs, 3/4 of the videos) and
+  lane 1 CU row 7 of shader engines 1-3 (24 CUs, 1/4 of the videos).  Every mask gives each shader engine it touches the
+  same number of CUs -- the rule for masks that do not unbalance the dispatch (encode_mask_words).  partition='two' is
+  the round-1 split (encode: shader engine 0, rollout: the other three, 192 CUs of which its launches use <= 168);
 * work stealing: the CNN features of the first `steal_steps` time steps of batch j+2 do not depend on any slots, so the
   rollout stream computes them on its larger partition after the rollout graph of batch j while it would otherwise idle,
   and the encode of batch j+2 skips those convolutions (`engine.savi_cnn` / `savi_encode(feat_pre=...)`);
@@ -27,15 +30,49 @@ import torch
 from . import _lib, engine
 
 
+def encode_mask_words(spec):
+    """The 8 x 32-bit CU mask of the encode stream.  `spec`: 'rows<R>' = CU rows 0..R-1 of every shader engine of every XCD
+    (32 R CUs; the rollout stream gets rows R..7), a sequence of 8 words, or one 32-bit word repeated 8 times (0xff = one
+    whole shader engine per XCD, the round-1 mask).
+
+    How the 256 mask bits reach the hardware (measured with tools/mask_probe.py, profiles/r02_probes.txt): bit b of word
+    w is XCD b % 8, shader engine b // 8, CU row w.  Workgroups are dealt out in EQUAL shares to the XCDs and, inside an
+    XCD, to every shader engine that has at least one CU enabled -- so the (XCD, shader engine) with the fewest enabled
+    CUs sets the pace: [0xffff, 0xff x 7] (72 CUs: one extra CU in a second shader engine) runs the encode 3.7x SLOWER
+    than 0xff x 8 (64 CUs).  A mask must give every shader engine it touches the same number of CUs, and so must its
+    complement: whole shader engines (0xff x 8) or whole CU rows ('rows<R>').  An XCD whose mask is empty runs on all CUs."""
+    if isinstance(spec, str) and spec.startswith('rows'):
+        r = int(spec[4:])
+        if not 1 <= r <= 7:
+            raise ValueError('slotformer_amd: rows<R> needs 1 <= R <= 7')
+        return [0xffffffff if w < r else 0 for w in range(8)]
+    if isinstance(spec, str):
+        spec = int(spec, 16)
+    if isinstance(spec, (list, tuple)):
+        if len(spec) != 8:
+            raise ValueError('slotformer_amd: a CU mask has 8 words')
+        return [int(w) & 0xffffffff for w in spec]
+    return [int(spec) & 0xffffffff] * 8
+
+
+# partition 'three' (word w = CU row w, byte s = shader engine s, all 8 XCDs alike)
+ROLL_WORDS_3 = [0xffffff00] * 7 + [0]          # rows 0-6 of shader engines 1-3: 21 CUs per XCD
+LANE0_WORDS_3 = [0x000000ff] * 8               # shader engine 0: 8 CUs per XCD
+LANE1_WORDS_3 = [0] * 7 + [0xffffff00]         # row 7 of shader engines 1-3: 3 CUs per XCD
+
+
 class EncodeRolloutPipeline:
     """savi: StoSAVi container (eval, testing=True); rollouter: SlotRollouter / SingleStepSlotRollouter container.
 
     batch: videos per batch (fixed: the rollout graphs are captured for it); burn_in: encoded frames per video
     (= rollouter.history_len, or 1 for the single-step rollouter); pred_len: rollout steps.
-    encode_cu_word: 32-bit CU mask word of the encode stream, repeated for all 8 words (0 = no CU partition).
+    partition: 'three' (default; see the module docstring), 'two' (one encode stream on `encode_cu_word`, the rollout on
+    the complement) or 'none' (plain streams, shared CUs).  encode_cu_word: see encode_mask_words.
+    steal_steps: None = 0 for 'three' (the rollout is the longer side there), 1 for 'two'.
     """
 
-    def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=1, use_graph=True):
+    def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=None, use_graph=True,
+                 partition='three'):
         self.savi, self.roll = savi, rollouter
         self.B, self.T, self.H = int(batch), int(burn_in), int(pred_len)
         p = next(rollouter.parameters())
@@ -44,6 +81,14 @@ class EncodeRolloutPipeline:
         self.dev = p.device
         self.N, self.D = rollouter.num_slots, rollouter.in_proj.in_features
         self.NB = 2                      # slot buffers / graphs / workspaces: one rolling out + one being encoded
+        if partition not in ('three', 'two', 'none'):
+            raise ValueError("slotformer_amd: partition must be 'three', 'two' or 'none'")
+        if not encode_cu_word:
+            partition = 'none'
+        if partition == 'three' and self.B < 4:
+            partition = 'two'
+        if steal_steps is None:
+            steal_steps = 0 if partition == 'three' else 1
         self.steal = max(0, min(int(steal_steps), self.T))
         self._masked = []
         self._lib = _lib.lib()
@@ -59,19 +104,34 @@ class EncodeRolloutPipeline:
                         engine.rollout(rollouter, self.bufs[gi], self.T, self.H, ws_slot=('pipe', gi))
                     self.graphs.append(g)
         self.cu_split = False
-        self.s_enc = self.s_roll = None
-        if encode_cu_word:
+        self.partition = 'none'
+        self.s_roll = None
+        self.lanes = []                  # encode lanes: (stream, first video, end video)
+        if partition != 'none':
             try:
-                words = [encode_cu_word & 0xffffffff] * 8
-                self.s_enc = self._masked_stream(words)
-                self.s_roll = self._masked_stream([~w & 0xffffffff for w in words])
+                if partition == 'three':
+                    nb = max(1, round(self.B * 24 / 88))
+                    self.s_roll = self._masked_stream(ROLL_WORDS_3)
+                    self.lanes = [(self._masked_stream(LANE0_WORDS_3), 0, self.B - nb),
+                                  (self._masked_stream(LANE1_WORDS_3), self.B - nb, self.B)]
+                    self.encode_cus, self.rollout_cus = 88, 168
+                else:
+                    words = encode_mask_words(encode_cu_word)
+                    self.s_roll = self._masked_stream([~w & 0xffffffff for w in words])
+                    self.lanes = [(self._masked_stream(words), 0, self.B)]
+                    self.encode_cus = sum(bin(w).count('1') for w in words)
+                    self.rollout_cus = 256 - self.encode_cus
                 self.cu_split = True
+                self.partition = partition
             except RuntimeError:      # CU masking unavailable on this runtime: keep the pipeline, on shared CUs
-                self.s_enc = self.s_roll = None
-        if self.s_enc is None:
-            self.s_enc = torch.cuda.Stream(device=self.dev)
+                self.close()
+                self.s_roll, self.lanes = None, []
+        if self.s_roll is None:
             self.s_roll = torch.cuda.Stream(device=self.dev, priority=-1)
-        self.encode_cus = 8 * bin(encode_cu_word & 0xffffffff).count('1') if self.cu_split else 256
+            self.lanes = [(torch.cuda.Stream(device=self.dev), 0, self.B)]
+            self.encode_cus = self.rollout_cus = 256
+        self.s_enc = self.lanes[0][0]
+        self.fill_whole_chip = True      # the first encode of a run on the calling stream (all CUs)
         self.feat_bufs = None
         self.completion_events = []
 
@@ -100,17 +160,23 @@ class EncodeRolloutPipeline:
         else:
             engine.rollout(self.roll, self.bufs[gi], self.T, self.H, ws_slot=('pipe', gi))
 
-    def _encode(self, img, noise, dst, feat_pre):
+    def _encode(self, img, noise, dst, feat_pre, lo=0, hi=None, lane=0):
+        """videos [lo, hi) of one batch -> dst[lo:hi, :burn_in] on the current stream"""
+        hi = self.B if hi is None else hi
+        if lo != 0 or hi != self.B:
+            img = img[lo:hi]
+            noise = None if noise is None else noise[lo:hi]
         if noise is None and getattr(self.savi, 'kernel_dist_layer', None) is not None:
             # fresh eps ~ N(0,1) per frame, as the reference draws it (savi.py:363-365)
-            noise = torch.randn(self.B, self.T, self.N, self.D, device=self.dev)
-        post, _, _ = engine.savi_encode(self.savi, img, noise=noise, feat_pre=feat_pre, ws_slot='pipe')
-        dst[:, :self.T].copy_(post)
+            noise = torch.randn(hi - lo, self.T, self.N, self.D, device=self.dev)
+        post, _, _ = engine.savi_encode(self.savi, img, noise=noise, feat_pre=feat_pre, ws_slot=('pipe', lane))
+        dst[lo:hi, :self.T].copy_(post)
 
     @torch.no_grad()
     def run(self, imgs, noises=None, out=None, serial=False):
         """imgs: sequence of n device tensors [B, burn_in, 3, H, W]; noises: None or n tensors [B, burn_in, N, D]
-        (the kernel noise of every frame, for reproducible runs).  Returns out [n, B, burn_in + pred_len, N, D].
+        (the kernel noise of every frame, for reproducible runs).  Returns out [n, B, burn_in + pred_len, N, D]; the
+        pipelined schedule returns when the last batch is finished (the host waits for it, see the end of this function).
         serial=True runs the same calls back to back on the calling stream (reference schedule for the tests)."""
         n = len(imgs)
         for im in imgs:
@@ -127,42 +193,57 @@ class EncodeRolloutPipeline:
                 out[j].copy_(self.bufs[0])
             return out
         NB, steal = self.NB, self.steal
-        s_enc, s_roll = self.s_enc, self.s_roll
+        s_roll, lanes = self.s_roll, self.lanes
+        nl = len(lanes)
         if steal and self.feat_bufs is None:
-            self.feat_bufs = [engine.savi_cnn(self.savi, imgs[0], 0, steal, ws_slot='pipe_steal') for _ in range(2)]
-        s_enc.wait_stream(cur)
+            self.feat_bufs = [[engine.savi_cnn(self.savi, imgs[0][lo:hi], 0, steal, ws_slot=('pipe_steal', li)) for _ in range(2)]
+                              for li, (_, lo, hi) in enumerate(lanes)]
+        for st, _, _ in lanes:
+            st.wait_stream(cur)
         s_roll.wait_stream(cur)
-        ev_enc = [torch.cuda.Event() for _ in range(n)]
+        ev_enc = [[torch.cuda.Event() for _ in range(nl)] for _ in range(n)]
         ev_roll = [torch.cuda.Event(enable_timing=True) for _ in range(n)]   # also: completion time of every batch
         ev_pre = [torch.cuda.Event() for _ in range(n + 2)]
         for j in range(n):
-            # (the first two batches compute their own convolutions: stealing starts with batch 2, whose features are
-            #  produced after the rollout of batch 0)
-            pre = self.feat_bufs[j % 2] if (steal and j >= 2) else None
-            if j == 0 and self.cu_split:
-                # pipeline fill: the first encode takes the whole chip (the calling stream); the masked encode stream
-                # starts after it
+            if j == 0 and self.cu_split and self.fill_whole_chip:
+                # pipeline fill: the first encode takes the whole chip (the calling stream); the masked lanes start after it
                 self._encode(imgs[0], nz(0), self.bufs[0], None)
-                ev_enc[0].record(cur)
-                s_enc.wait_event(ev_enc[0])
+                ev_enc[0][0].record(cur)
+                for st, _, _ in lanes:
+                    st.wait_event(ev_enc[0][0])
+                ev_wait = ev_enc[0][:1]
             else:
-                with torch.cuda.stream(s_enc):
-                    if j >= NB:
-                        s_enc.wait_event(ev_roll[j - NB])   # slot buffer j % NB is free once batch j-NB has left it
-                    if pre is not None:
-                        s_enc.wait_event(ev_pre[j])
-                    self._encode(imgs[j], nz(j), self.bufs[j % NB], pre)
-                    ev_enc[j].record(s_enc)
+                for li, (st, lo, hi) in enumerate(lanes):
+                    # (the first two batches compute their own convolutions: stealing starts with batch 2, whose features
+                    #  are produced after the rollout of batch 0)
+                    pre = self.feat_bufs[li][j % 2] if (steal and j >= 2) else None
+                    with torch.cuda.stream(st):
+                        if j >= NB:
+                            st.wait_event(ev_roll[j - NB])   # slot buffer j % NB is free once batch j-NB has left it
+                        if pre is not None:
+                            st.wait_event(ev_pre[j])
+                        self._encode(imgs[j], nz(j), self.bufs[j % NB], pre, lo, hi, li)
+                        ev_enc[j][li].record(st)
+                ev_wait = ev_enc[j]
             with torch.cuda.stream(s_roll):
-                s_roll.wait_event(ev_enc[j])
+                for e in ev_wait:
+                    s_roll.wait_event(e)
                 self._rollout(j % NB)
                 out[j].copy_(self.bufs[j % NB])
                 ev_roll[j].record(s_roll)
                 if steal and j + 2 < n:
-                    # feature buffer (j+2) % 2 == j % 2 was consumed by encode j, which this stream has waited for
-                    engine.savi_cnn(self.savi, imgs[j + 2], 0, steal, out=self.feat_bufs[j % 2], ws_slot='pipe_steal')
+                    # feature buffers (j+2) % 2 == j % 2 were consumed by encode j, which this stream has waited for
+                    for li, (_, lo, hi) in enumerate(lanes):
+                        engine.savi_cnn(self.savi, imgs[j + 2][lo:hi], 0, steal, out=self.feat_bufs[li][j % 2],
+                                        ws_slot=('pipe_steal', li))
                     ev_pre[j + 2].record(s_roll)
-        cur.wait_stream(s_enc)
+        # The host waits for the last batch HERE, before the calling stream is made to wait for the pipeline's streams: a
+        # wait that sits pending on the calling stream (PyTorch's default stream is the legacy null stream) for the whole
+        # run was measured to slow the kernels of the masked encode lane that shares shader engines with the rollout by
+        # 30 % (7.7 instead of 6.4 ms per batch, tools/lane_probe.py COPY=1) -- so run() returns when the results are done.
+        ev_roll[-1].synchronize()
+        for st, _, _ in lanes:
+            cur.wait_stream(st)
         cur.wait_stream(s_roll)
         self.completion_events = ev_roll
         return out

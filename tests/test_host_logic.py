@@ -178,3 +178,33 @@ def test_slot_file_formats(tmp_path):
     for i in range(13, 20):
         slot_io.save_phyre_slots(root, i, slots[0], vid_len=9)
     assert slot_io.phyre_resume_index(root, 10, 20) == 19   # everything present: the last one is redone
+
+
+def test_cu_mask_words_balance_every_shader_engine():
+    """pipeline.encode_mask_words / the 'three' partition: bit b of word w = XCD b % 8, shader engine b // 8, CU row w.
+    Every mask -- and what is left for the other streams -- must give each (XCD, shader engine) it touches the same
+    number of CUs (the dispatcher deals workgroups in equal shares to them), and the three masks must tile the chip."""
+    from slotformer_amd import pipeline as pl
+
+    def per_se(words):
+        cnt = {}
+        for w, word in enumerate(words):
+            for b in range(32):
+                if word >> b & 1:
+                    cnt[(b % 8, b // 8)] = cnt.get((b % 8, b // 8), 0) + 1
+        return cnt
+
+    for words, cus, ses in ((pl.ROLL_WORDS_3, 168, 3), (pl.LANE0_WORDS_3, 64, 1), (pl.LANE1_WORDS_3, 24, 3)):
+        c = per_se(words)
+        assert sum(c.values()) == cus and len(set(c.values())) == 1 and len(c) == 8 * ses
+    for w in range(8):
+        a, b, c = pl.ROLL_WORDS_3[w], pl.LANE0_WORDS_3[w], pl.LANE1_WORDS_3[w]
+        assert a & b == 0 and a & c == 0 and b & c == 0 and (a | b | c) == 0xffffffff
+    assert pl.encode_mask_words(0xff) == [0xff] * 8 and pl.encode_mask_words('ff') == [0xff] * 8
+    assert pl.encode_mask_words('rows3') == [0xffffffff] * 3 + [0] * 5
+    assert len(set(per_se(pl.encode_mask_words('rows3')).values())) == 1
+    assert pl.encode_mask_words([1, 2, 3, 4, 5, 6, 7, 8]) == [1, 2, 3, 4, 5, 6, 7, 8]
+    with pytest.raises(ValueError):
+        pl.encode_mask_words('rows9')
+    with pytest.raises(ValueError):
+        pl.encode_mask_words([1, 2, 3])

@@ -1,5 +1,5 @@
-"""The batch pipeline (slotformer_amd/pipeline.py: encode of batch i+1 on a CU-masked stream beside the rollout hipGraph
-of batch i, double-buffered slots, work stealing) must give bit-identical results to the serial
+"""The batch pipeline (slotformer_amd/pipeline.py: encode of batch i+1 on CU-masked lanes, each a share of the videos, beside the
+rollout hipGraph of batch i, double-buffered slots, work stealing) must give bit-identical results to the serial
 `savi({'img'}) -> rollout` sequence -- with DIFFERENT inputs and noise per batch, so that a slot-buffer, feature-buffer or
 event mistake shows (VERDICT r01 'pipeline correctness is untested')."""
 import numpy as np
@@ -34,8 +34,9 @@ def _serial_reference(savi, roll, imgs, noises, T, H):
     return torch.stack(outs, 0)
 
 
-@pytest.mark.parametrize('B,steal,nbatch', [(32, 1, 6), (32, 0, 5), (5, 1, 5), (5, 2, 7)])
-def test_pipeline_matches_serial(dev, B, steal, nbatch):
+@pytest.mark.parametrize('B,steal,nbatch,partition', [(32, None, 6, 'three'), (32, 1, 5, 'three'), (5, 2, 7, 'three'), (32, 1, 6, 'two'),
+                                                      (32, 0, 5, 'two'), (5, 1, 5, 'two'), (5, 2, 7, 'two')])
+def test_pipeline_matches_serial(dev, B, steal, nbatch, partition):
     from slotformer_amd.pipeline import EncodeRolloutPipeline
     T, H = 6, 12
     savi, roll = _models(dev, gu.C2_SAVI, gu.C2_ROLL)
@@ -44,7 +45,9 @@ def test_pipeline_matches_serial(dev, B, steal, nbatch):
     noises = [torch.from_numpy(rs.standard_normal((B, T, 7, 128)).astype(np.float32)).to(dev) for _ in range(nbatch)]
     with torch.no_grad():
         ref = _serial_reference(savi, roll, imgs, noises, T, H)
-        pipe = EncodeRolloutPipeline(savi, roll, B, T, H, steal_steps=steal)
+        pipe = EncodeRolloutPipeline(savi, roll, B, T, H, steal_steps=steal, partition=partition)
+        assert pipe.partition == partition and len(pipe.lanes) == (2 if partition == 'three' else 1)
+        assert [lo for _, lo, _ in pipe.lanes] + [pipe.lanes[-1][2]] == ([0, B - max(1, round(B * 24 / 88)), B] if partition == 'three' else [0, B])
         out = pipe.run(imgs, noises)
         torch.cuda.synchronize()
         assert out.shape == ref.shape
@@ -70,7 +73,8 @@ def test_pipeline_without_cu_partition_and_graph(dev):
     noises = [torch.from_numpy(rs.standard_normal((B, T, 7, 128)).astype(np.float32)).to(dev) for _ in range(nbatch)]
     with torch.no_grad():
         ref = _serial_reference(savi, roll, imgs, noises, T, H)
-        for kw in (dict(encode_cu_word=0), dict(use_graph=False), dict(encode_cu_word=0, use_graph=False, steal_steps=0)):
+        for kw in (dict(encode_cu_word=0), dict(use_graph=False), dict(encode_cu_word=0, use_graph=False, steal_steps=0),
+                   dict(partition='none', steal_steps=1), dict(partition='two', encode_cu_word='rows2')):
             pipe = EncodeRolloutPipeline(savi, roll, B, T, H, **kw)
             out = pipe.run(imgs, noises)
             torch.cuda.synchronize()
