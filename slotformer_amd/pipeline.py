@@ -209,6 +209,9 @@ class EncodeRolloutPipeline:
                 # pipeline fill: the first encode takes the whole chip (the calling stream); the masked lanes start after it
                 self._encode(imgs[0], nz(0), self.bufs[0], None)
                 ev_enc[0][0].record(cur)
+                # the host waits for it: with the three other queues parked in a wait on this event the encode was measured
+                # at 4.8 instead of 3.05 ms (a queue stalled in a cross-queue wait slows the queue that is running)
+                ev_enc[0][0].synchronize()
                 for st, _, _ in lanes:
                     st.wait_event(ev_enc[0][0])
                 ev_wait = ev_enc[0][:1]

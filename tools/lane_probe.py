@@ -79,7 +79,7 @@ with torch.no_grad():
         out = torch.empty(n, 32, 56, 7, 128, device=dev)
         imgs = [ring[j % 3] for j in range(n)]
 
-        def run_copy(prelude, epilogue, timed_wrap):
+        def run_copy(prelude, epilogue, timed_wrap, host_lane_wait=False):
             NB = 2
             cur = torch.cuda.current_stream(dev)
             s_roll, lanes = pipe.s_roll, pipe.lanes
@@ -92,9 +92,11 @@ with torch.no_grad():
             ev_roll = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
             recs = []
             for j in range(n):
+                if host_lane_wait and j >= NB:
+                    ev_roll[j - NB].synchronize()
                 for li, (st, lo, hi) in enumerate(lanes):
                     with torch.cuda.stream(st):
-                        if j >= NB:
+                        if j >= NB and not host_lane_wait:
                             st.wait_event(ev_roll[j - NB])
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         if timed_wrap:
@@ -121,14 +123,14 @@ with torch.no_grad():
                 cur.wait_stream(s_roll)
             torch.cuda.synchronize()
             iv = [ev_roll[i].elapsed_time(ev_roll[i + 1]) for i in range(n - 1)]
-            print(f'prelude {prelude} epilogue {epilogue} timed_wrap {timed_wrap}: intervals', ' '.join(f'{x:.2f}' for x in iv))
+            print(f'prelude {prelude} epilogue {epilogue} timed_wrap {timed_wrap} host_lane_wait {host_lane_wait}: intervals', ' '.join(f'{x:.2f}' for x in iv))
             for k in range(nl):
                 if recs:
                     print('    lane', k, ' '.join(f'{a.elapsed_time(b):.2f}' for n_, a, b in recs if n_ == k))
 
-        run_copy(True, False, False)
-        run_copy(False, True, False)
-        run_copy(False, 'host', False)
+        run_copy(True, 'host', False)
+        run_copy(True, 'host', False, host_lane_wait=True)
+        run_copy(True, 'host', True, host_lane_wait=True)
         sys.exit(0)
 
     if os.environ.get('FREE'):
