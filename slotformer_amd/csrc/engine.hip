@@ -194,6 +194,13 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
     return !(e && e[0] == '0');
   }();
   const bool seam = boundary_fused && seam_env && sf_seam_blocks(B, N) <= 160;
+  // layers 0 .. n-2 leave their output as four FFN chunk partials that the next attention sums while loading (SF_FFN_PARTS=0:
+  // the FFN's last-arriving workgroup sums them, as the last layer always does)
+  static const bool parts_env = [] {
+    const char* e = getenv("SF_FFN_PARTS");
+    return !(e && e[0] == '0');
+  }();
+  const bool parts_mode = ring_mode && parts_env;
   if (ring_mode) {
     // in-projection (without PE) of the burn-in frames -> ring slots 0 .. n_in-1
     SF_TRY(sf_ring_init_ex(m->out_proj_packed, m->out_proj_b, m->in_proj_packed, m->in_proj_b, slots,
@@ -225,6 +232,7 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
     const int L = nf * N, M = B * L, pe_off = (W - nf) * N;
     if (ring_mode) {
       const float* cin = nullptr;
+      bool parts_in = false;   // the current layer's input is still the previous layer's four FFN chunk partials in xpb
       for (int l = 0; l < m->num_layers; ++l) {
         const bool lastl = (l == m->num_layers - 1);
         const int Lq = lastl ? N : L;   // last layer: only the newest frame's rows are read (slotformer.py:121)
@@ -235,6 +243,8 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
           if (!attn0_done)
             SF_TRY(sf_attn_oproj_ring_ex(ring, RF, N, f0, m->pe_tok + (long long)pe_off * d, m->layers[l], 1e-5f, apl, pst, B, L,
                                          Lq, st));
+        } else if (parts_in) {
+          SF_TRY(sf_attn_oproj_parts_ex(xpb, (long long)B * L * d, m->layers[l], 1e-5f, apl, pst, B, L, Lq, st));
         } else {
           SF_TRY(sf_attn_oproj_ex(cin, m->layers[l], 1e-5f, apl, pst, B, L, Lq, st));
         }
@@ -259,9 +269,16 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
             ap_l0 = apb;
           }
           cin = nullptr;
+        } else if (parts_mode && !lastl) {
+          // the chunk partials are the layer output: the next attention sums them
+          SF_TRY(sf_ffn_parts_ex(apl, pst, m->layers[l], 1e-5f, xpb, pst, B * Lq, m->ffn_dim, st));
+          parts_in = true;
+          cin = nullptr;
+          if (l == 0) ap_l0 = apb;
         } else {
           SF_TRY(sf_ffn_partial_ex(apl, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st));
           cin = xo;
+          parts_in = false;
           if (l == 0) ap_l0 = apb;
         }
       }

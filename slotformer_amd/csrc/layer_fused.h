@@ -7,6 +7,10 @@
 int sf_attn_oproj_ex(const float* xin, const sf_tfm_layer& w, float eps, float* ap, long long ap_stride, int B, int L,
                      int Lq, hipStream_t st);
 // layer 0 of a rollout step: x = ring[b][(f0 + r / nslots) % ring_frames][r % nslots] + pe[r]
+int sf_attn_oproj_parts_ex(const float* xparts, long long xparts_stride, const sf_tfm_layer& w, float eps, float* ap,
+                           long long ap_stride, int B, int L, int Lq, hipStream_t st);
+int sf_ffn_parts_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp, long long xp_stride, int M,
+                    int ffn, hipStream_t st);
 int sf_attn_oproj_ring_ex(const float* ring, int ring_frames, int nslots, int f0, const float* pe, const sf_tfm_layer& w,
                           float eps, float* ap, long long ap_stride, int B, int L, int Lq, hipStream_t st);
 // out-proj of the finished rows y [B*nslots, 256] -> slots frame `frame`; in-proj of those rows -> projection ring

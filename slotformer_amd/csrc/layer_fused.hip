@@ -155,9 +155,15 @@ struct AttnArgs {
   float* ap;
   long long ap_stride;
   int L, Lq, dbg;
+  int nvideos;
+  long long xparts_stride;   // PART: xin is the first of the previous layer's LF_NCH FFN chunk partials, this many floats apart
 };
 
-template <bool RING, bool SEAM>
+// PART: the layer input is the sum of the previous layer's four FFN chunk partials, ((p0 + p1) + p2) + p3 -- the order the
+// FFN's own last-arriver reduction uses, so both ways of finishing a layer give the same bits.  It moves the reduction out
+// of the FFN launch (arrival counter + barrier + write-through reads of three partials on its critical path, ~4 us) into
+// the next attention's prologue (+129 KB of loads, ~1.3 us).
+template <bool RING, bool SEAM, bool PART = false>
 __device__ __forceinline__ void attn_body(const AttnArgs& A, const int hp, const int b, const SeamArgs seam) {
   const float* __restrict__ xin = A.xin;
   const long long x_batch_stride = A.x_batch_stride;
@@ -239,10 +245,22 @@ __device__ __forceinline__ void attn_body(const AttnArgs& A, const int hp, const
     }
   }
   f32x4 ra[NK][A_IT];
+  if constexpr (PART) {
+    const long long ps = A.xparts_stride;
 #pragma unroll
-  for (int kc = 0; kc < NK; ++kc)
+    for (int kc = 0; kc < NK; ++kc)
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) ra[kc][i] = *(const f32x4*)((late[i] ? arow[0] : arow[i]) + kc * FA_KC);
+      for (int i = 0; i < A_IT; ++i) {
+        const float* p = arow[i] + kc * FA_KC;
+        const f32x4 p0 = *(const f32x4*)p, p1 = *(const f32x4*)(p + ps), p2 = *(const f32x4*)(p + 2 * ps), p3 = *(const f32x4*)(p + 3 * ps);
+        ra[kc][i] = ((p0 + p1) + p2) + p3;
+      }
+  } else {
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) ra[kc][i] = *(const f32x4*)((late[i] ? arow[0] : arow[i]) + kc * FA_KC);
+  }
   if constexpr (RING) {
     f32x4 tp[NK][A_IT];
 #pragma unroll
@@ -627,9 +645,17 @@ __device__ __forceinline__ void attn_body(const AttnArgs& A, const int hp, const
   LF_TQ(14);
 }
 
-template <bool RING>
+template <bool RING, bool PART = false>
 __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(AttnArgs A) {
-  attn_body<RING, false>(A, blockIdx.x, blockIdx.y, SeamArgs{nullptr, 0u, 32});
+  if constexpr (PART) {
+    // 1-D grid: block i runs on XCD i % 8; the four head pairs of a video share an XCD, so the 172 KB of chunk partials a
+    // video's workgroups all read cross the fabric once (video b on XCD b % 8)
+    const int i = blockIdx.x, k = i >> 3, b = (i & 7) + 8 * (k >> 2);
+    if (b >= A.nvideos) return;
+    attn_body<RING, false, PART>(A, k & 3, b, SeamArgs{nullptr, 0u, 32});
+    return;
+  }
+  attn_body<RING, false, PART>(A, blockIdx.x, blockIdx.y, SeamArgs{nullptr, 0u, 32});
 }
 
 // ================================================================================================
@@ -789,6 +815,7 @@ struct FfnArgs {
   float* xout;
   int* counters;
   int ntiles, M, dbg;
+  int parts_only;   // the chunk partials are the output (the next attention sums them, attn_body<.., PART>): no reduction here
   SbArgs sb;
 };
 
@@ -964,6 +991,14 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& F, const int blk) {
   //      Write-through (sc1) stores put the values at the device coherence point once acknowledged, without the
   //      whole-L2 write-back a __threadfence() would cost (~30 us per launch here). ----
   const unsigned cstride = (unsigned)(xp_stride * 4);
+  if (F.parts_only) {   // plain stores: the kernel boundary publishes them
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (row0 + wave + 8 * i < M)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mine[i]), xpr, off[i] + c * cstride, 0, 0);
+    LF_TS(8);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     if (row0 + wave + 8 * i < M)
@@ -1146,18 +1181,20 @@ static AttnArgs make_attn_args(const float* xin, long long x_batch_stride, const
   A.ln_g = w.norm1_g; A.ln_b = w.norm1_b; A.ln_eps = eps; A.wqkv_p = (const uint4*)w.attn_in_packed; A.bias = w.in_proj_b;
   A.wo_p = (const uint4*)w.attn_out_packed; A.bo = w.out_proj_b; A.ap = ap; A.ap_stride = ap_stride; A.L = L; A.Lq = Lq;
   A.dbg = lf_dbg();
+  A.xparts_stride = 0;
+  A.nvideos = 0;
   return A;
 }
 
-template <bool RING>
+template <bool RING, bool PART = false>
 static int launch_attn(const float* xin, long long x_batch_stride, const float* pe, int f0, int ring_frames, int nslots,
                        const sf_tfm_layer& w, float eps, float* ap, long long ap_stride, int B, int L, int Lq,
-                       hipStream_t st) {
+                       hipStream_t st, long long xparts_stride = 0) {
   if (!w.attn_in_packed || !w.attn_out_packed)
     return sf_set_err(-1, "invalid argument: fused attention needs packed weights (sf_pack_attn_weights)", __FILE__, __LINE__);
   if ((long long)LF_NP * ap_stride * 4 >= 0x7fffffffLL)
     return sf_set_err(-1, "invalid argument: head-pair partial buffer beyond the 2 GB a buffer descriptor addresses", __FILE__, __LINE__);
-  auto kern = attn_oproj_kernel<RING>;
+  auto kern = attn_oproj_kernel<RING, PART>;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A2_LDS);
@@ -1166,8 +1203,10 @@ static int launch_attn(const float* xin, long long x_batch_stride, const float* 
   }
   sf_prof_begin(SF_K_MHA, st, 6.0 * B * L * (double)LF_D * LF_D + 4.0 * (double)B * LF_NH * Lq * L * LF_HD +
                                   2.0 * B * Lq * (double)LF_D * LF_D);
-  hipLaunchKernelGGL(kern, dim3(LF_NH / 2, B), dim3(LF_NT), A2_LDS, st,
-                     make_attn_args(xin, x_batch_stride, pe, f0, ring_frames, nslots, w, eps, ap, ap_stride, L, Lq));
+  AttnArgs A = make_attn_args(xin, x_batch_stride, pe, f0, ring_frames, nslots, w, eps, ap, ap_stride, L, Lq);
+  A.xparts_stride = xparts_stride;
+  A.nvideos = B;
+  hipLaunchKernelGGL(kern, PART ? dim3(((B + 7) / 8) * 8 * (LF_NH / 2)) : dim3(LF_NH / 2, B), dim3(LF_NT), A2_LDS, st, A);
   sf_prof_end(SF_K_MHA, st);
   SF_CHECK_LAUNCH();
   return 0;
@@ -1178,6 +1217,13 @@ int sf_attn_oproj_ex(const float* xin, const sf_tfm_layer& w, float eps, float* 
                      int Lq, hipStream_t st) {
   static_assert(A2_LDS <= 160 * 1024, "attention+out-proj kernel: LDS budget");
   return launch_attn<false>(xin, (long long)L * LF_D, nullptr, 0, 1, 1, w, eps, ap, ap_stride, B, L, Lq, st);
+}
+
+// the layer input is the sum of the previous layer's four FFN chunk partials xparts[c] ([B*L, 256] each, xparts_stride
+// floats apart; written by sf_ffn_parts_ex)
+int sf_attn_oproj_parts_ex(const float* xparts, long long xparts_stride, const sf_tfm_layer& w, float eps, float* ap,
+                           long long ap_stride, int B, int L, int Lq, hipStream_t st) {
+  return launch_attn<false, true>(xparts, (long long)L * LF_D, nullptr, 0, 1, 1, w, eps, ap, ap_stride, B, L, Lq, st, xparts_stride);
 }
 
 // layer 0 of a rollout step: x = ring[b][(f0 + r / nslots) % ring_frames][r % nslots] + pe[r]
@@ -1198,6 +1244,7 @@ static FfnArgs make_ffn_args(const float* ap, long long ap_stride, const sf_tfm_
   F.w1p = (const uint4*)w.lin1_packed; F.b1 = w.lin1_b; F.w2p = (const uint4*)w.lin2_packed; F.b2 = w.lin2_b;
   F.xp = xp; F.xp_stride = xp_stride; F.xout = xout; F.counters = counters;
   F.ntiles = (M + FB_ROWS - 1) / FB_ROWS; F.M = M; F.dbg = lf_dbg(); F.sb = sb;
+  F.parts_only = 0;
   return F;
 }
 
@@ -1205,7 +1252,7 @@ static FfnArgs make_ffn_args(const float* ap, long long ap_stride, const sf_tfm_
 static int ffn_blocks(int tiles) { return tiles < 8 ? 32 : (tiles / 8) * 32 + (tiles % 8) * 4; }
 
 static int launch_ffn(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp, long long xp_stride,
-                      float* xout, int* counters, int M, int ffn, const SbArgs& sb, hipStream_t st) {
+                      float* xout, int* counters, int M, int ffn, const SbArgs& sb, hipStream_t st, int parts_only = 0) {
   static_assert(FB_LDS <= 160 * 1024, "FFN kernel: LDS budget");
   static_assert((size_t)4 * 16 * 64 * 4 + (size_t)2 * 32 * SB_PP * 2 <= (size_t)2 * FB_ROWS * FB_AP * 2, "boundary scratch fits the H planes");
   if (!w.lin1_packed || !w.lin2_packed || ffn != LF_NCH * LF_HC)
@@ -1219,8 +1266,9 @@ static int launch_ffn(const float* ap, long long ap_stride, const sf_tfm_layer& 
   }
   const int tiles = (M + FB_ROWS - 1) / FB_ROWS;
   sf_prof_begin(SF_K_FFN, st, 4.0 * M * (double)LF_D * ffn);
-  hipLaunchKernelGGL(ffn_partial_kernel, dim3(ffn_blocks(tiles)), dim3(LF_NT), FB_LDS, st,
-                     make_ffn_args(ap, ap_stride, w, eps, xp, xp_stride, xout, counters, M, sb));
+  FfnArgs F = make_ffn_args(ap, ap_stride, w, eps, xp, xp_stride, xout, counters, M, sb);
+  F.parts_only = parts_only;
+  hipLaunchKernelGGL(ffn_partial_kernel, dim3(ffn_blocks(tiles)), dim3(LF_NT), FB_LDS, st, F);
   sf_prof_end(SF_K_FFN, st);
   SF_CHECK_LAUNCH();
   return 0;
@@ -1231,6 +1279,14 @@ int sf_ffn_partial_ex(const float* ap, long long ap_stride, const sf_tfm_layer& 
   SbArgs sb;
   memset(&sb, 0, sizeof(sb));
   return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, xout, counters, M, ffn, sb, st);
+}
+
+// the four chunk partials xp[c] ARE the output (summed by the next layer's sf_attn_oproj_parts_ex)
+int sf_ffn_parts_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp, long long xp_stride, int M,
+                    int ffn, hipStream_t st) {
+  SbArgs sb;
+  memset(&sb, 0, sizeof(sb));
+  return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, nullptr, nullptr, M, ffn, sb, st, 1);
 }
 
 // last layer of a rollout step: the FFN's last-arriving workgroups also run the step boundary (out-proj -> slots frame
