@@ -295,13 +295,24 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
     if (fused_layers) {
       // every layer is two launches: attention + out-proj head partials, then the FFN (which also finishes the sums)
       const float* cin = x;
+      bool parts_in = false;
       for (int l = 0; l < m->num_layers; ++l) {
-        const int Lq = (l == m->num_layers - 1) ? N : L;
+        const bool lastl = (l == m->num_layers - 1);
+        const int Lq = lastl ? N : L;
         const long long pst = (long long)B * Lq * d;
         float* xo = (cin == xa) ? xb2 : xa;
-        SF_TRY(sf_attn_oproj_ex(cin, m->layers[l], 1e-5f, apb, pst, B, L, Lq, st));
-        SF_TRY(sf_ffn_partial_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st));
-        cin = xo;
+        if (parts_in)
+          SF_TRY(sf_attn_oproj_parts_ex(xpb, (long long)B * L * d, m->layers[l], 1e-5f, apb, pst, B, L, Lq, st));
+        else
+          SF_TRY(sf_attn_oproj_ex(cin, m->layers[l], 1e-5f, apb, pst, B, L, Lq, st));
+        if (parts_env && !lastl) {
+          SF_TRY(sf_ffn_parts_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, B * Lq, m->ffn_dim, st));
+          parts_in = true;
+        } else {
+          SF_TRY(sf_ffn_partial_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st));
+          cin = xo;
+          parts_in = false;
+        }
       }
       SF_TRY(sf_linear_ex(cin, sf_rows(d), m->out_proj_w, m->out_proj_b, nullptr, nullptr, 0.f, nullptr, sf_rows(C), 0,
                           slots, sf_rows_batched(C, N, bs, (long long)(n_in + s) * N * C), B * N, C, d, 0, st));
