@@ -188,7 +188,7 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   }();
   const bool boundary_fused = ring_mode && bfuse_env;
   // seam launches (layer_fused.hip): the last-layer FFN + boundary of step s and the layer-0 attention of step s+1 in one
-  // grid; needs every workgroup of it co-resident at one per CU -- 160 leaves room on the 192-CU rollout partition
+  // grid; needs every workgroup of it co-resident at one per CU -- 160 fit the 168-CU rollout partition
   static const bool seam_env = [] {
     const char* e = getenv("SF_SEAM_FUSED");
     return !(e && e[0] == '0');

@@ -68,7 +68,7 @@ __device__ long long lf_ts[32];   // phase timestamps of one workgroup (SF_LF_DB
 
 // ================================================================================================
 // Attention + out-projection of TWO heads per workgroup (grid: 4 head pairs x B videos = 128 workgroups at B = 32, so
-// every workgroup has a CU to itself even on the 192-CU rollout partition; with one head per workgroup 64 CUs ran two
+// every workgroup has a CU to itself even on the 168-CU rollout partition; with one head per workgroup 64 CUs ran two
 // and the kernel took 22 us there vs 16.7 us on the whole chip).
 //
 // x: layer input rows.  RING = false: xin [B][L][256] contiguous.  RING = true (layer 0 of a rollout step): the rows are
@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(FfnArgs F) {
 // One launch for the seam between two rollout steps: blocks [0, nffn) run the last layer's FFN + step boundary of step s,
 // the others the layer-0 attention of step s+1 (one per (head pair, video)), which requests its weights and the five old
 // frames of its window at once and waits only for the 7 new rows of ITS video.  The producers have the lower block indices
-// (dispatched first); all nffn + 4 B workgroups are co-resident at one per CU on the 192-CU rollout partition for B <= 40.
+// (dispatched first); all nffn + 4 B workgroups are co-resident at one per CU on the 168-CU rollout partition for B <= 32.
 __global__ __launch_bounds__(LF_NT) void seam_kernel(FfnArgs F, AttnArgs A, SeamArgs seam, int nffn) {
   if ((int)blockIdx.x < nffn) {
     ffn_body(F, blockIdx.x);
