@@ -217,7 +217,7 @@ def main():
     cu_word = cu_word if cu_word.startswith('rows') else int(cu_word, 16)
     steal = os.environ.get('SF_BENCH_STEAL')                   # None: the partition's default
     steal = None if steal is None else int(steal)
-    partition = os.environ.get('SF_BENCH_PARTITION', 'three')  # 'three' | 'two' | 'none' (pipeline.EncodeRolloutPipeline)
+    partition = os.environ.get('SF_BENCH_PARTITION', 'pair')   # 'pair' | 'three' | 'two' | 'none' (pipeline.EncodeRolloutPipeline)
 
     with torch.no_grad():
         log('building the pipeline (first eager rollouts + graph capture)')
@@ -390,7 +390,9 @@ def main():
                                'runs its full encode + 50-step rollout inside the timed region') if overlap else 'none',
                 'work_stealing': (f'the CNN features of the first {pipe.steal} time step(s) of batch j+2 are computed on the rollout '
                                   'stream after the rollout of batch j') if (overlap and pipe.steal) else 'none',
-                'cu_partition': (('rollout stream: CU rows 0-6 of shader engines 1-3 of every XCD (168 CUs); encode lane 0: shader engine 0 '
+                'cu_partition': ('two rollout streams (batches j and j+1 roll out side by side) on CU rows 0-4 of all four shader engines of every '
+                                 'XCD (160 CUs), the encode stream on rows 5-7 (96 CUs)' if pipe.partition == 'pair' else
+                                 ('rollout stream: CU rows 0-6 of shader engines 1-3 of every XCD (168 CUs); encode lane 0: shader engine 0 '
                                   f'(64 CUs, {pipe.lanes[0][2] - pipe.lanes[0][1]} videos of every batch); encode lane 1: CU row 7 of shader engines 1-3 '
                                   f'(24 CUs, {pipe.lanes[-1][2] - pipe.lanes[-1][1]} videos)') if pipe.partition == 'three' else
                                  (f'encode stream on CU mask {cu_word if isinstance(cu_word, str) else hex(cu_word)} ({pipe.encode_cus} CUs, the same '

@@ -6,7 +6,13 @@ so they run side by side on disjoint sets of CUs:
 
 * the rollout of every slot buffer is captured ONCE into a hipGraph (one graph, one slot buffer and one workspace per batch
   in flight) and replayed on the *rollout stream*;
-* the encode runs on *encode lanes* -- streams created with CU masks (`sf_stream_create_cu_mask` ->
+* default partition 'pair' (round 2, late): the rollout is a latency chain -- a single one leaves most of its CUs idle most
+  of the time -- so TWO batches roll out side by side on two rollout streams that share CU rows 0-4 of all four shader
+  engines (160 CUs; 8.3 ms for two rollouts against 5.8 ms for one), the encode runs on rows 5-7 (96 CUs), and the
+  convolution features of the first `steal_steps` time steps of a batch are computed ahead of time on its rollout stream
+  (work stealing, below).  Four slot buffers / graphs.  More than three busy CU-masked queues degrade badly (four encode
+  queues + the rollout's: 25 ms per batch), which is why this is two rollout streams + ONE encode stream;
+* (partitions 'three' / 'two') the encode runs on *encode lanes* -- streams created with CU masks (`sf_stream_create_cu_mask` ->
   hipExtStreamCreateWithCUMask), each encoding its own share of the batch's videos.  Default partition ('three'): the
   rollout gets CU rows 0-6 of shader engines 1-3 of every XCD (168 CUs: exactly what its widest launch, the 168
   workgroups of a B = 32 FFN, needs -- 21 per XCD), lane 0 the whole shader engine 0 (64 CUs, 3/4 of the videos) and
@@ -59,6 +65,9 @@ def encode_mask_words(spec):
 ROLL_WORDS_3 = [0xffffff00] * 7 + [0]          # rows 0-6 of shader engines 1-3: 21 CUs per XCD
 LANE0_WORDS_3 = [0x000000ff] * 8               # shader engine 0: 8 CUs per XCD
 LANE1_WORDS_3 = [0] * 7 + [0xffffff00]         # row 7 of shader engines 1-3: 3 CUs per XCD
+# partition 'pair': two rollout streams share CU rows 0-4 of all four shader engines, the encode gets rows 5-7
+ROLL_WORDS_P = [0xffffffff] * 5 + [0] * 3      # 20 CUs per XCD
+ENC_WORDS_P = [0] * 5 + [0xffffffff] * 3       # 12 CUs per XCD
 
 
 class EncodeRolloutPipeline:
@@ -66,13 +75,13 @@ class EncodeRolloutPipeline:
 
     batch: videos per batch (fixed: the rollout graphs are captured for it); burn_in: encoded frames per video
     (= rollouter.history_len, or 1 for the single-step rollouter); pred_len: rollout steps.
-    partition: 'three' (default; see the module docstring), 'two' (one encode stream on `encode_cu_word`, the rollout on
-    the complement) or 'none' (plain streams, shared CUs).  encode_cu_word: see encode_mask_words.
-    steal_steps: None = 0 for 'three' (the rollout is the longer side there), 1 for 'two'.
+    partition: 'pair' (default; see the module docstring), 'three', 'two' (one encode stream on `encode_cu_word`, the
+    rollout on the complement) or 'none' (plain streams, shared CUs).  encode_cu_word: see encode_mask_words.
+    steal_steps: None = 1 for 'pair' and 'two', 0 for 'three' (the rollout is the longer side there).
     """
 
     def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=None, use_graph=True,
-                 partition='three'):
+                 partition='pair'):
         self.savi, self.roll = savi, rollouter
         self.B, self.T, self.H = int(batch), int(burn_in), int(pred_len)
         p = next(rollouter.parameters())
@@ -80,13 +89,14 @@ class EncodeRolloutPipeline:
             raise RuntimeError('slotformer_amd: the pipeline needs the models on a HIP device; there is no CPU fallback')
         self.dev = p.device
         self.N, self.D = rollouter.num_slots, rollouter.in_proj.in_features
-        self.NB = 2                      # slot buffers / graphs / workspaces: one rolling out + one being encoded
-        if partition not in ('three', 'two', 'none'):
-            raise ValueError("slotformer_amd: partition must be 'three', 'two' or 'none'")
+        if partition not in ('pair', 'three', 'two', 'none'):
+            raise ValueError("slotformer_amd: partition must be 'pair', 'three', 'two' or 'none'")
         if not encode_cu_word:
             partition = 'none'
         if partition == 'three' and self.B < 4:
             partition = 'two'
+        # slot buffers / graphs / workspaces: one per batch in flight -- 'pair': two rolling out + one being encoded + one spare
+        self.NB = 4 if partition == 'pair' else 2
         if steal_steps is None:
             steal_steps = 0 if partition == 'three' else 1
         self.steal = max(0, min(int(steal_steps), self.T))
@@ -106,10 +116,16 @@ class EncodeRolloutPipeline:
         self.cu_split = False
         self.partition = 'none'
         self.s_roll = None
+        self.roll_streams = []           # rollout streams: batch j rolls out on roll_streams[j % len]
         self.lanes = []                  # encode lanes: (stream, first video, end video)
         if partition != 'none':
             try:
-                if partition == 'three':
+                if partition == 'pair':
+                    self.roll_streams = [self._masked_stream(ROLL_WORDS_P), self._masked_stream(ROLL_WORDS_P)]
+                    self.s_roll = self.roll_streams[0]
+                    self.lanes = [(self._masked_stream(ENC_WORDS_P), 0, self.B)]
+                    self.encode_cus, self.rollout_cus = 96, 160
+                elif partition == 'three':
                     nb = max(1, round(self.B * 24 / 88))
                     self.s_roll = self._masked_stream(ROLL_WORDS_3)
                     self.lanes = [(self._masked_stream(LANE0_WORDS_3), 0, self.B - nb),
@@ -125,11 +141,14 @@ class EncodeRolloutPipeline:
                 self.partition = partition
             except RuntimeError:      # CU masking unavailable on this runtime: keep the pipeline, on shared CUs
                 self.close()
-                self.s_roll, self.lanes = None, []
+                self.s_roll, self.lanes, self.roll_streams = None, [], []
         if self.s_roll is None:
             self.s_roll = torch.cuda.Stream(device=self.dev, priority=-1)
             self.lanes = [(torch.cuda.Stream(device=self.dev), 0, self.B)]
             self.encode_cus = self.rollout_cus = 256
+        if not self.roll_streams:
+            self.roll_streams = [self.s_roll]
+        self.s_free = torch.cuda.Stream(device=self.dev) if len(self.roll_streams) > 1 else None   # unmasked: the drain
         self.s_enc = self.lanes[0][0]
         self.fill_whole_chip = True      # the first encode of a run on the calling stream (all CUs)
         self.feat_bufs = None
@@ -193,17 +212,21 @@ class EncodeRolloutPipeline:
                 out[j].copy_(self.bufs[0])
             return out
         NB, steal = self.NB, self.steal
-        s_roll, lanes = self.s_roll, self.lanes
+        lanes, rolls = self.lanes, self.roll_streams
         nl = len(lanes)
+        # work stealing: the features of batch j are computed `lead` batches earlier, on the rollout stream of batch j - lead
+        # (the same stream batch j will roll out on) right after that batch's rollout
+        lead = 2 * len(rolls)
         if steal and self.feat_bufs is None:
-            self.feat_bufs = [[engine.savi_cnn(self.savi, imgs[0][lo:hi], 0, steal, ws_slot=('pipe_steal', li)) for _ in range(2)]
+            self.feat_bufs = [[engine.savi_cnn(self.savi, imgs[0][lo:hi], 0, steal, ws_slot=('pipe_steal', li)) for _ in range(lead)]
                               for li, (_, lo, hi) in enumerate(lanes)]
         for st, _, _ in lanes:
             st.wait_stream(cur)
-        s_roll.wait_stream(cur)
+        for st in rolls:
+            st.wait_stream(cur)
         ev_enc = [[torch.cuda.Event() for _ in range(nl)] for _ in range(n)]
         ev_roll = [torch.cuda.Event(enable_timing=True) for _ in range(n)]   # also: completion time of every batch
-        ev_pre = [torch.cuda.Event() for _ in range(n + 2)]
+        ev_pre = [torch.cuda.Event() for _ in range(n + lead)]
         for j in range(n):
             if j == 0 and self.cu_split and self.fill_whole_chip:
                 # pipeline fill: the first encode takes the whole chip (the calling stream); the masked lanes start after it
@@ -217,9 +240,9 @@ class EncodeRolloutPipeline:
                 ev_wait = ev_enc[0][:1]
             else:
                 for li, (st, lo, hi) in enumerate(lanes):
-                    # (the first two batches compute their own convolutions: stealing starts with batch 2, whose features
-                    #  are produced after the rollout of batch 0)
-                    pre = self.feat_bufs[li][j % 2] if (steal and j >= 2) else None
+                    # (the first `lead` batches compute their own convolutions: stealing starts with batch `lead`, whose
+                    #  features are produced after the rollout of batch 0)
+                    pre = self.feat_bufs[li][j % lead] if (steal and (j >= lead or (j >= 2 and len(rolls) > 1))) else None
                     with torch.cuda.stream(st):
                         if j >= NB:
                             st.wait_event(ev_roll[j - NB])   # slot buffer j % NB is free once batch j-NB has left it
@@ -228,25 +251,42 @@ class EncodeRolloutPipeline:
                         self._encode(imgs[j], nz(j), self.bufs[j % NB], pre, lo, hi, li)
                         ev_enc[j][li].record(st)
                 ev_wait = ev_enc[j]
+            s_roll = rolls[j % len(rolls)]
+            if len(rolls) > 1 and j == n - 1 and self.s_free is not None:
+                # drain: the encode lane is idle from here on -- the last rollout takes an unmasked stream (all CUs) instead of
+                # sharing the rollout partition with the one before it
+                s_roll = self.s_free
+                s_roll.wait_stream(rolls[j % len(rolls)])   # (order behind batch j - 2 on the stream it would have used)
             with torch.cuda.stream(s_roll):
                 for e in ev_wait:
                     s_roll.wait_event(e)
                 self._rollout(j % NB)
                 out[j].copy_(self.bufs[j % NB])
                 ev_roll[j].record(s_roll)
-                if steal and j + 2 < n:
-                    # feature buffers (j+2) % 2 == j % 2 were consumed by encode j, which this stream has waited for
+                if steal and j + lead < n:
+                    # feature buffers (j + lead) % lead == j % lead were consumed by encode j, which this stream has waited for
                     for li, (_, lo, hi) in enumerate(lanes):
-                        engine.savi_cnn(self.savi, imgs[j + 2][lo:hi], 0, steal, out=self.feat_bufs[li][j % 2],
-                                        ws_slot=('pipe_steal', li))
-                    ev_pre[j + 2].record(s_roll)
+                        engine.savi_cnn(self.savi, imgs[j + lead][lo:hi], 0, steal, out=self.feat_bufs[li][j % lead],
+                                        ws_slot=('pipe_steal', li, j % len(rolls)))
+                    ev_pre[j + lead].record(s_roll)
+                if steal and j == 0 and len(rolls) > 1:
+                    # fill: the second rollout stream idles until batch 1 is encoded -- it computes the features of batches
+                    # 2 .. lead-1 now, so only batch 1 pays for its own convolutions
+                    with torch.cuda.stream(rolls[1]):
+                        for jj in range(2, min(lead, n)):
+                            for li, (_, lo, hi) in enumerate(lanes):
+                                engine.savi_cnn(self.savi, imgs[jj][lo:hi], 0, steal, out=self.feat_bufs[li][jj % lead],
+                                                ws_slot=('pipe_steal', li, 1))
+                            ev_pre[jj].record(rolls[1])
         # The host waits for the last batch HERE, before the calling stream is made to wait for the pipeline's streams: a
         # wait that sits pending on the calling stream (PyTorch's default stream is the legacy null stream) for the whole
         # run was measured to slow the kernels of the masked encode lane that shares shader engines with the rollout by
         # 30 % (7.7 instead of 6.4 ms per batch, tools/lane_probe.py COPY=1) -- so run() returns when the results are done.
-        ev_roll[-1].synchronize()
+        for e in ev_roll[-len(rolls):]:
+            e.synchronize()
         for st, _, _ in lanes:
             cur.wait_stream(st)
-        cur.wait_stream(s_roll)
+        for st in rolls + ([self.s_free] if self.s_free is not None else []):
+            cur.wait_stream(st)
         self.completion_events = ev_roll
         return out

@@ -34,7 +34,7 @@ def _serial_reference(savi, roll, imgs, noises, T, H):
     return torch.stack(outs, 0)
 
 
-@pytest.mark.parametrize('B,steal,nbatch,partition', [(32, None, 6, 'three'), (32, 1, 5, 'three'), (5, 2, 7, 'three'), (32, 1, 6, 'two'),
+@pytest.mark.parametrize('B,steal,nbatch,partition', [(32, None, 9, 'pair'), (32, 1, 11, 'pair'), (5, 2, 12, 'pair'), (5, None, 7, 'pair'), (32, None, 6, 'three'), (32, 1, 5, 'three'), (5, 2, 7, 'three'), (32, 1, 6, 'two'),
                                                       (32, 0, 5, 'two'), (5, 1, 5, 'two'), (5, 2, 7, 'two')])
 def test_pipeline_matches_serial(dev, B, steal, nbatch, partition):
     from slotformer_amd.pipeline import EncodeRolloutPipeline
@@ -47,6 +47,7 @@ def test_pipeline_matches_serial(dev, B, steal, nbatch, partition):
         ref = _serial_reference(savi, roll, imgs, noises, T, H)
         pipe = EncodeRolloutPipeline(savi, roll, B, T, H, steal_steps=steal, partition=partition)
         assert pipe.partition == partition and len(pipe.lanes) == (2 if partition == 'three' else 1)
+        assert len(pipe.roll_streams) == (2 if partition == 'pair' else 1) and len(pipe.bufs) == (4 if partition == 'pair' else 2)
         assert [lo for _, lo, _ in pipe.lanes] + [pipe.lanes[-1][2]] == ([0, B - max(1, round(B * 24 / 88)), B] if partition == 'three' else [0, B])
         out = pipe.run(imgs, noises)
         torch.cuda.synchronize()
