@@ -118,6 +118,17 @@ int sf_slot_update_f32(const float* part_num, const float* part_den, int P, cons
                        const float* mlp_b1, const float* mlp_w2, const float* mlp_b2, float* slots_out, int B,
                        int N, int D, int H, float ln_eps, void* stream);
 
+/* The same slot update on the matrix cores (split-bf16 products, slot size D = 128 and slot MLP size H = 256 only), plus the
+ * next iteration's q = project_q(slots_out) (savi.py:45-48,79) when q_out is not NULL.  The five matrices are
+ * sf_pack_linear_weights copies of the TORCH-layout weights: GRUCell weight_ih / weight_hh [3D, D], mlp[1].weight [H, D],
+ * mlp[3].weight [D, H], project_q[1].weight [D, D]. */
+int sf_slot_update_packed_f32(const float* part_num, const float* part_den, int P, const float* slots_prev,
+                              const void* gru_ih_packed, const void* gru_hh_packed, const float* gru_b_ih,
+                              const float* gru_b_hh, const float* ln_g, const float* ln_b, const void* mlp_w1_packed,
+                              const float* mlp_b1, const void* mlp_w2_packed, const float* mlp_b2, float* slots_out,
+                              const float* q_ln_g, const float* q_ln_b, const void* q_w_packed, float* q_out, int B, int N,
+                              int D, int H, float ln_eps, void* stream);
+
 /* nn.MultiheadAttention core for short sequences: qkv [B*L,3d] (q|k|v), out [B*Lq,d]; queries
  * are the last Lq rows of each sequence (Lq == L: all). */
 int sf_mha_f32(const float* qkv, float* out, int B, int L, int Lq, int d_model, int num_heads, void* stream);
@@ -413,6 +424,10 @@ typedef struct {
    * with them (and sa_q_w_t) the per-frame slot prologue -- predictor, kernel distribution, sampling, q projection -- is ONE
    * launch (pred_type 0, no LSTM, kd_mode 1); NULL: separate LayerNorm / GEMM / sampling launches */
   const float *pm_w0_t, *pm_w2_t, *kd_w0_t;
+  /* optional (slot size 128, slot MLP 256): sf_pack_linear_weights copies of the torch-layout GRUCell weight_ih / weight_hh
+   * [3D, D], Slot-Attention mlp[1].weight [H, D], mlp[3].weight [D, H] and project_q[1].weight [D, D]; with all five the slot
+   * update after every Slot-Attention iteration runs on the matrix cores (split-bf16, like the other bf16x3 kernels) */
+  const void *sa_gru_ih_p, *sa_gru_hh_p, *sa_mlp_w1_p, *sa_mlp_w2_p, *sa_q_w_p;
 } sf_savi_encoder;
 
 size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B);

@@ -84,7 +84,9 @@ class sf_savi_encoder(C.Structure):
         [(n, FP) for n in ('pm_ln_g', 'pm_ln_b', 'pm_w0', 'pm_b0', 'pm_w2', 'pm_b2')] +
         [('pred_layers', C.POINTER(sf_tfm_layer))] +
         [(n, FP) for n in ('lstm_w_ih', 'lstm_w_hh', 'lstm_b_ih', 'lstm_b_hh', 'proj_w', 'proj_b')] +
-        [('sa_eps', C.c_float), ('sa_q_w_t', FP), ('pm_w0_t', FP), ('pm_w2_t', FP), ('kd_w0_t', FP)])
+        [('sa_eps', C.c_float), ('sa_q_w_t', FP), ('pm_w0_t', FP), ('pm_w2_t', FP), ('kd_w0_t', FP),
+         ('sa_gru_ih_p', C.c_void_p), ('sa_gru_hh_p', C.c_void_p), ('sa_mlp_w1_p', C.c_void_p), ('sa_mlp_w2_p', C.c_void_p),
+         ('sa_q_w_p', C.c_void_p)])
 
 
 class sf_slate_block(C.Structure):
@@ -130,6 +132,7 @@ SIGNATURES = {
     'sf_slot_attn_num_partials': (I, [I]),
     'sf_slot_attn_iter_f32': (I, [FP, FP, I, LL, FP, FP, FP, FP, I, I, I, I, F32, F32, VP]),
     'sf_slot_update_f32': (I, [FP, FP, I, FP] + [FP] * 10 + [FP, I, I, I, I, F32, VP]),
+    'sf_slot_update_packed_f32': (I, [FP, FP, I, FP, VP, VP, FP, FP, FP, FP, VP, FP, VP, FP, FP, FP, FP, VP, FP, I, I, I, I, F32, VP]),
     'sf_mha_f32': (I, [FP, FP, I, I, I, I, I, VP]),
     'sf_qkv_attention_f32': (I, [FP, FP, FP, F32, FP, FP, FP, I, I, I, I, I, VP]),
     'sf_lstm_pointwise_f32': (I, [FP, FP, FP, FP, I, I, VP]),

@@ -627,11 +627,28 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
     }
     // ---- Slot Attention iterations (savi.py:76-100) -------------------------------------------
     const float scale = 1.0f / sqrtf((float)D);
+    // slot update on the matrix cores (slot_update_mfma.hip) when the packed copies are there; SF_SU_MFMA=0: the VALU kernel
+    static const bool su_env = [] {
+      const char* e = getenv("SF_SU_MFMA");
+      return !(e && e[0] == '0');
+    }();
+    const bool su_mfma = su_env && sf_get_precision() >= 1 && m->sa_gru_ih_p && m->sa_gru_hh_p && m->sa_mlp_w1_p && m->sa_mlp_w2_p &&
+                         m->sa_q_w_p && sf_slot_update_mfma_ok(D, Hm, P);
     for (int it = 0; it < m->num_iterations; ++it) {
       const bool last_it = (it == m->num_iterations - 1);
       float* aout = (attn && last_it) ? attn + (long long)t * N * HW : nullptr;
       SF_TRY(sf_slot_attn_iter_ex(kv, kv + D, 2 * D, (long long)HW * 2 * D, q, pnum, pden, aout,
                                   (long long)T * N * HW, B, HW, N, D, scale, m->sa_eps, st));
+      if (su_mfma) {
+        SF_TRY(sf_slot_update_mfma_ex(pnum, pden, P, s_in, m->sa_gru_ih_p, m->sa_gru_hh_p, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g,
+                                      m->mlp_ln_b, m->sa_mlp_w1_p, m->mlp_b1, m->sa_mlp_w2_p, m->mlp_b2, s_out,
+                                      last_it ? post_slots + (long long)t * N * D : nullptr, (long long)T * N * D, m->sa_q_ln_g,
+                                      m->sa_q_ln_b, m->sa_q_w_p, last_it ? nullptr : q, B, N, ln_eps, st));
+        float* tmp = s_in;
+        s_in = s_out;
+        s_out = tmp;
+        continue;
+      }
       SF_TRY(sf_slot_update_ex(pnum, pden, P, s_in, m->gru_w_ih, m->gru_w_hh, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g,
                                m->mlp_ln_b, m->mlp_w1, m->mlp_b1, m->mlp_w2, m->mlp_b2, s_out,
                                last_it ? post_slots + (long long)t * N * D : nullptr, (long long)T * N * D,

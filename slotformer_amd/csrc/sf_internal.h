@@ -17,6 +17,12 @@ int sf_sample_dist_ex(const float* dist, const float* noise, SfRowMap nmap, floa
 int sf_copy_rows_ex(const float* src, SfRowMap smap, float* dst, SfRowMap dmap, int rows, int cols,
                     hipStream_t st);
 int sf_sa_pick_partials(int HW);
+bool sf_slot_update_mfma_ok(int D, int H, int P);
+int sf_slot_update_mfma_ex(const float* part_num, const float* part_den, int P, const float* slots_prev, const void* gru_ih_p,
+                           const void* gru_hh_p, const float* gru_b_ih, const float* gru_b_hh, const float* ln_g, const float* ln_b,
+                           const void* w1_p, const float* b1, const void* w2_p, const float* b2, float* slots_out, float* out2,
+                           long long out2_bs, const float* q_ln_g, const float* q_ln_b, const void* q_w_p, float* q_out, int B, int N,
+                           float ln_eps, hipStream_t st);
 int sf_slot_update_ex(const float* part_num, const float* part_den, int P, const float* slots_prev,
                       const float* gru_w_ih, const float* gru_w_hh, const float* gru_b_ih, const float* gru_b_hh,
                       const float* ln_g, const float* ln_b, const float* mlp_w1, const float* mlp_b1, const float* mlp_w2,

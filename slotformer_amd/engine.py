@@ -216,6 +216,16 @@ def encoder_plan(m):
     s.mlp_ln_g, s.mlp_ln_b = plan.dp(sa.mlp[0].weight), plan.dp(sa.mlp[0].bias)
     s.mlp_w1, s.mlp_b1 = plan.dp(tr(sa.mlp[1].weight)), plan.dp(sa.mlp[1].bias)
     s.mlp_w2, s.mlp_b2 = plan.dp(tr(sa.mlp[3].weight)), plan.dp(sa.mlp[3].bias)
+    if m.slot_size == 128 and m.slot_mlp_size == 256 and sa.gru.weight_ih.is_cuda:
+        # fragment-ordered split-bf16 copies for the matrix-core slot update (slot_update_mfma.hip)
+        st = torch.cuda.current_stream().cuda_stream
+        for name, w in (('sa_gru_ih_p', sa.gru.weight_ih), ('sa_gru_hh_p', sa.gru.weight_hh), ('sa_mlp_w1_p', sa.mlp[1].weight),
+                        ('sa_mlp_w2_p', sa.mlp[3].weight), ('sa_q_w_p', sa.project_q[1].weight)):
+            n, k = w.shape
+            buf = torch.empty(lib().sf_packed_linear_bytes(n, k), dtype=torch.uint8, device=w.device)
+            check(lib().sf_pack_linear_weights(plan.dp(w), buf.data_ptr(), n, k, st))
+            plan.keep.append(buf)
+            setattr(s, name, buf.data_ptr())
     s.init_latents = plan.dp(m.init_latents.detach()[0])
     s.sa_eps = float(sa.eps)
     kd = getattr(m, 'kernel_dist_layer', None)

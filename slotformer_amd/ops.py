@@ -151,6 +151,30 @@ def slot_update(pn, pd, slots_prev, gru, ln_g, ln_b, w1, b1, w2, b2, ln_eps=1e-5
     return out
 
 
+def pack_linear(w):
+    """torch-layout weight [N, K] -> fragment-ordered split-bf16 copy (sf_pack_linear_weights)."""
+    _chk(w)
+    n, k = w.shape
+    buf = torch.empty(lib().sf_packed_linear_bytes(n, k), dtype=torch.uint8, device=w.device)
+    check(lib().sf_pack_linear_weights(_p(w.contiguous()), buf.data_ptr(), n, k, _stream()))
+    return buf
+
+
+def slot_update_packed(pn, pd, slots_prev, gru, ln_g, ln_b, w1, b1, w2, b2, q=None, ln_eps=1e-5):
+    """slot_update on the matrix cores (slot size 128, MLP 256); q = (q_ln_g, q_ln_b, q_w) also returns project_q(out)."""
+    _chk(pn, pd, slots_prev, *gru, ln_g, ln_b, w1, b1, w2, b2)
+    B, P, N, D = pn.shape
+    out = torch.empty_like(slots_prev)
+    packed = [pack_linear(w) for w in (gru[0], gru[1], w1, w2)]
+    q_out = torch.empty_like(slots_prev) if q is not None else None
+    qp = pack_linear(q[2]) if q is not None else None
+    check(lib().sf_slot_update_packed_f32(_p(pn), _p(pd), P, _p(slots_prev), packed[0].data_ptr(), packed[1].data_ptr(), _p(gru[2]),
+                                          _p(gru[3]), _p(ln_g), _p(ln_b), packed[2].data_ptr(), _p(b1), packed[3].data_ptr(), _p(b2),
+                                          _p(out), _p(q[0]) if q is not None else None, _p(q[1]) if q is not None else None,
+                                          qp.data_ptr() if qp is not None else None, _p(q_out), B, N, D, w1.shape[0], ln_eps, _stream()))
+    return (out, q_out) if q is not None else out
+
+
 def mha(qkv, B, L, d_model, num_heads, Lq=None):
     """qkv [B*L, 3d] -> [B*Lq, d]."""
     _chk(qkv)

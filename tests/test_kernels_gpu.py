@@ -138,6 +138,33 @@ def test_slot_attn_iteration(dev, B, N, D, HW):
     close(out, ref)
 
 
+@pytest.mark.parametrize('B,N,P', [(32, 7, 16), (5, 7, 16), (9, 8, 16), (1, 3, 4), (64, 8, 24)])
+def test_slot_update_on_the_matrix_cores(dev, B, N, P):
+    """sa_slot_update_mfma_kernel (split-bf16 MFMA, 32 rows per workgroup) against the torch-CPU restatement of
+    savi.py:95-100 + project_q, and against the VALU kernel on the same inputs; ragged row counts (B*N % 32 != 0)."""
+    from slotformer_amd import ops
+    D, H = 128, 256
+    pn, pd = rnd(B, P, N, D, seed=1), 0.5 + rnd(B, P, N, seed=2).abs()
+    slots = rnd(B, N, D, seed=4)
+    upd = pn.sum(1) / pd.sum(1).unsqueeze(-1)
+    w_ih, w_hh = rnd(3 * D, D, seed=5, scale=D**-0.5), rnd(3 * D, D, seed=6, scale=D**-0.5)
+    b_ih, b_hh = rnd(3 * D, seed=7, scale=0.1), rnd(3 * D, seed=8, scale=0.1)
+    g, be = 1 + 0.1 * rnd(D, seed=9), 0.1 * rnd(D, seed=10)
+    w1, b1, w2, b2 = rnd(H, D, seed=11, scale=D**-0.5), rnd(H, seed=12, scale=0.1), rnd(D, H, seed=13, scale=H**-0.5), rnd(D, seed=14, scale=0.1)
+    qg, qb, qw = 1 + 0.1 * rnd(D, seed=15), 0.1 * rnd(D, seed=16), rnd(D, D, seed=17, scale=D**-0.5)
+    h = oracle.gru_cell(upd.reshape(B * N, D), slots.reshape(B * N, D), w_ih, w_hh, b_ih, b_hh).view(B, N, D)
+    ref = h + F.linear(F.relu(F.linear(F.layer_norm(h, (D, ), g, be), w1, b1)), w2, b2)
+    ref_q = F.linear(F.layer_norm(ref, (D, ), qg, qb), qw)
+    t = lambda *xs: [x.to(dev) for x in xs]  # noqa: E731
+    out, q = ops.slot_update_packed(pn.to(dev), pd.to(dev), slots.to(dev), t(w_ih, w_hh, b_ih, b_hh), *t(g, be, w1, b1, w2, b2), q=t(qg, qb, qw))
+    close(out, ref, rtol=3e-5, atol=3e-5)
+    close(q, ref_q, rtol=5e-5, atol=5e-5)
+    valu = ops.slot_update(pn.to(dev), pd.to(dev), slots.to(dev), t(w_ih, w_hh, b_ih, b_hh), *t(g, be, w1, b1, w2, b2))
+    close(out, valu.cpu(), rtol=3e-5, atol=3e-5)
+    out2 = ops.slot_update_packed(pn.to(dev), pd.to(dev), slots.to(dev), t(w_ih, w_hh, b_ih, b_hh), *t(g, be, w1, b1, w2, b2))
+    assert torch.equal(out2, out)   # without the q projection: the same rows, bit for bit
+
+
 @pytest.mark.parametrize('B,L,d,h,Lq', [(3, 42, 256, 8, 42), (3, 42, 256, 8, 7), (2, 90, 256, 8, 90), (4, 6, 128, 4, 6),
                                         (2, 6, 192, 4, 6), (2, 36, 128, 8, 36), (1, 130, 128, 4, 130), (1, 48, 256, 8, 8), (1, 200, 128, 4, 200)])
 def test_mha(dev, B, L, d, h, Lq):
