@@ -242,6 +242,10 @@ def main():
         assert torch.isfinite(out_w[:args.warmup]).all(), 'non-finite slots in the warmup batches'
         log('warmup done')
         # conv + Slot-Attention launches are event-timed live (library brackets on the launch stream)
+        # (every LIVE_EVERY-th launch of the two classes: two event records around a launch cost its stream a few microseconds,
+        #  and the encode stream is the longer side of the pipeline)
+        LIVE_EVERY = int(os.environ.get('SF_BENCH_LIVE_EVERY', '4'))
+        lib.sf_profile_sample(LIVE_EVERY)
         lib.sf_profile_enable(int(os.environ.get('SF_BENCH_LIVE_MASK', str((1 << 0) | (1 << 3)))))
         read_profile(lib)
         barrier()
@@ -251,6 +255,7 @@ def main():
         elapsed = time.perf_counter() - t0
         log(f'timed region done: {elapsed:.3f}s')
         lib.sf_profile_enable(0)
+        lib.sf_profile_sample(1)
         prof = read_profile(lib)
         batch_done = pipe.completion_events if overlap else None
         assert torch.isfinite(out_t).all(), 'non-finite slots in the timed batches'
@@ -461,8 +466,9 @@ def main():
                          'kernel; fragment reads from LDS and the un-overlapped halo fill bound it, DESIGN.md 4 and 7)',
                 'achieved': ach_iso, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': (ach_iso / peak_chip) if ach_iso else None,
                 'avg_launch_us': iso['avg_us'] if iso else None,
-                'measured': 'HIP events around every launch (library brackets on the launch stream): `achieved` = the kernel alone on the whole '
-                            'chip in the untimed pass of this run; `live` = inside the timed region on the encode partition',
+                'measured': 'HIP events around the launches (library brackets on the launch stream): `achieved` = the kernel alone on the whole '
+                            'chip in the untimed pass of this run, every launch; `live` = inside the timed region on the encode partition, '
+                            f'every {LIVE_EVERY}th launch (the brackets cost the stream they sit on a few microseconds each)',
                 'live': {'achieved': ach, 'cus': enc_cus, 'avg_launch_us': conv['avg_us'], 'launches': conv['launches'],
                          'flops_per_launch': flops_live, 'frac_of_partition_peak': ach / (peak_chip * enc_cus / 256.0),
                          'note': 'inside the timed region, beside the rollout graph of the previous batch; `cus` = CUs per launch (the encode '

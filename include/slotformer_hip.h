@@ -38,6 +38,7 @@ int sf_set_precision(int mode);
  * sf_profile_read sums elapsed ms, launches and algorithmic work (FLOP, or bytes for class 3)
  * since the last read. */
 int sf_profile_enable(int class_mask); /* bit c enables class c; 0 disables */
+int sf_profile_sample(int every);      /* bracket every `every`-th launch of an enabled class only (default 1: all) */
 int sf_profile_read(int kernel_class, double* total_ms, long long* launches, double* work);
 
 /* ---- building blocks ------------------------------------------------------------------ */

@@ -15,6 +15,8 @@ struct Rec {
 };
 std::mutex g_mu;
 unsigned g_mask = 0;
+int g_every = 1;                       // sampling: every g_every-th launch of a class is bracketed
+unsigned g_seen[SF_K_NUM] = {0};
 std::vector<Rec> g_recs[SF_K_NUM];
 thread_local hipEvent_t t_pending = nullptr;
 thread_local int t_suppress = 0;
@@ -28,6 +30,10 @@ void sf_prof_begin(int cls, hipStream_t st, double work) {
   if (cls < 0 || cls >= SF_K_NUM || !(g_mask & (1u << cls)) || t_suppress > 0) return;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if ((g_seen[cls]++ % (unsigned)g_every) != 0) return;
+  }
   Rec r;
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
   r.work = work;
@@ -70,6 +76,16 @@ const char* sf_last_error_string(void) { return sf_err_buf; }
 int sf_profile_enable(int class_mask) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_mask = (unsigned)class_mask;
+  return 0;
+}
+
+// bracket only every `every`-th launch of an enabled class (1: all).  Two event records around a launch cost the stream a few
+// microseconds; sampling keeps a live measurement from slowing the stream it measures.
+int sf_profile_sample(int every) {
+  SF_REQUIRE(every >= 1, "sf_profile_sample: every >= 1");
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_every = every;
+  for (int c = 0; c < SF_K_NUM; ++c) g_seen[c] = 0;
   return 0;
 }
 
