@@ -216,7 +216,7 @@ def main():
     cu_word = os.environ.get('SF_BENCH_CU_SPLIT', 'ff')          # hex mask word, or rows<R> (pipeline.encode_mask_words)
     cu_word = cu_word if cu_word.startswith('rows') else int(cu_word, 16)
     steal = os.environ.get('SF_BENCH_STEAL')                   # None: the partition's default
-    steal = None if steal is None else int(steal)
+    steal = None if steal is None else float(steal)
     partition = os.environ.get('SF_BENCH_PARTITION', 'pair')   # 'pair' | 'three' | 'two' | 'none' (pipeline.EncodeRolloutPipeline)
 
     with torch.no_grad():
@@ -393,8 +393,8 @@ def main():
                 'rollout_launch': f'hipGraph replay ({launches_per_graph} kernel nodes)' if graph is not None else 'eager',
                 'pipelining': ('encode of batch i+1 (stream A) overlaps the rollout graph of batch i (stream B); every batch still '
                                'runs its full encode + 50-step rollout inside the timed region') if overlap else 'none',
-                'work_stealing': (f'the CNN features of the first {pipe.steal} time step(s) of batch j+2 are computed on the rollout '
-                                  'stream after the rollout of batch j') if (overlap and pipe.steal) else 'none',
+                'work_stealing': (f'the CNN features of the first {pipe.steal:g} time step(s) (average) of batch j+{2 * len(pipe.roll_streams)} are '
+                                  'computed on the rollout stream of batch j right after its rollout') if (overlap and pipe.steal) else 'none',
                 'cu_partition': ('two rollout streams (batches j and j+1 roll out side by side) on CU rows 0-4 of all four shader engines of every '
                                  'XCD (160 CUs), the encode stream on rows 5-7 (96 CUs)' if pipe.partition == 'pair' else
                                  ('rollout stream: CU rows 0-6 of shader engines 1-3 of every XCD (168 CUs); encode lane 0: shader engine 0 '

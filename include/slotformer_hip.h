@@ -38,6 +38,11 @@ int sf_set_precision(int mode);
  * sf_profile_read sums elapsed ms, launches and algorithmic work (FLOP, or bytes for class 3)
  * since the last read. */
 int sf_profile_enable(int class_mask); /* bit c enables class c; 0 disables */
+/* Seam launches of the rollout (last FFN + step boundary of step s and the first attention of step s+1 in one grid): on by
+ * default (SF_SEAM_FUSED=0 in the environment: off).  They shorten the critical path of ONE rollout; when several rollouts
+ * share the same CUs (pipeline partition 'pair') the spinning consumers waste CU time and the graphs are captured with it off. */
+int sf_set_seam_fused(int on);
+int sf_get_seam_fused(void);
 int sf_profile_sample(int every);      /* bracket every `every`-th launch of an enabled class only (default 1: all) */
 int sf_profile_read(int kernel_class, double* total_ms, long long* launches, double* work);
 

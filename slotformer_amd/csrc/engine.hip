@@ -141,6 +141,8 @@ size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B) {
          pad256((size_t)B * (m->window_len + 1) * m->num_slots * m->d_model) + 4096 + 4096 + 4096;
 }
 
+extern "C" int sf_get_seam_fused(void);
+
 int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws,
                    size_t ws_bytes, void* stream) {
   SF_REQUIRE(m && slots && ws, "null pointer");
@@ -189,11 +191,7 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   const bool boundary_fused = ring_mode && bfuse_env;
   // seam launches (layer_fused.hip): the last-layer FFN + boundary of step s and the layer-0 attention of step s+1 in one
   // grid; needs every workgroup of it co-resident at one per CU -- 160 fit the 168-CU rollout partition
-  static const bool seam_env = [] {
-    const char* e = getenv("SF_SEAM_FUSED");
-    return !(e && e[0] == '0');
-  }();
-  const bool seam = boundary_fused && seam_env && sf_seam_blocks(B, N) <= 160;
+  const bool seam = boundary_fused && sf_get_seam_fused() != 0 && sf_seam_blocks(B, N) <= 160;
   // layers 0 .. n-2 leave their output as four FFN chunk partials that the next attention sums while loading (SF_FFN_PARTS=0:
   // the FFN's last-arriving workgroup sums them, as the last layer always does)
   static const bool parts_env = [] {
@@ -342,6 +340,22 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
 // (scripts/train.py:84,105) and of BASELINE.json's literal "bf16".  Measured on the 6+50 path of config C2 against the
 // reference fixture: ~8e-3 relative (tools/precision_probe.py, tests/test_engine_gpu.py), i.e. OUTSIDE the 1e-3 parity bar --
 // which is why sf_rollout_f32 (split-bf16, 1e-5) is the default and the product path.  Same arguments as sf_rollout_f32.
+// Seam launches on / off (default: on unless SF_SEAM_FUSED=0).  A seam launch saves a kernel boundary on the critical path of
+// ONE rollout chain; its 128 consumer workgroups spin until the 28 producers are done, which is CU time a second chain running
+// on the same CUs could use -- the 'pair' pipeline captures its graphs with the seam off.
+static int g_seam_fused = -1;
+extern "C" int sf_get_seam_fused(void) {
+  if (g_seam_fused < 0) {
+    const char* e = getenv("SF_SEAM_FUSED");
+    g_seam_fused = !(e && e[0] == '0');
+  }
+  return g_seam_fused;
+}
+extern "C" int sf_set_seam_fused(int on) {
+  g_seam_fused = on ? 1 : 0;
+  return 0;
+}
+
 int sf_rollout_bf16(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws, size_t ws_bytes,
                     void* stream) {
   const int old = sf_get_precision();

@@ -77,7 +77,8 @@ class EncodeRolloutPipeline:
     (= rollouter.history_len, or 1 for the single-step rollouter); pred_len: rollout steps.
     partition: 'pair' (default; see the module docstring), 'three', 'two' (one encode stream on `encode_cu_word`, the
     rollout on the complement) or 'none' (plain streams, shared CUs).  encode_cu_word: see encode_mask_words.
-    steal_steps: None = 1 for 'pair' and 'two', 0 for 'three' (the rollout is the longer side there).
+    steal_steps: time steps of convolutions per batch computed on the rollout stream (may be fractional: 1.25 = one step,
+    two for every fourth batch); None = 1.25 for 'pair', 1 for 'two', 0 for 'three' (the rollout is the longer side there).
     """
 
     def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=None, use_graph=True,
@@ -98,20 +99,22 @@ class EncodeRolloutPipeline:
         # slot buffers / graphs / workspaces: one per batch in flight -- 'pair': two rolling out + one being encoded + one spare
         self.NB = 4 if partition == 'pair' else 2
         if steal_steps is None:
-            steal_steps = 0 if partition == 'three' else 1
-        self.steal = max(0, min(int(steal_steps), self.T))
+            steal_steps = {'pair': 1.25, 'two': 1, 'three': 0}.get(partition, 1)
+        self.steal = max(0.0, min(float(steal_steps), float(self.T)))   # may be fractional: see _steal_of
         self._masked = []
         self._lib = _lib.lib()
+        # 'pair': two chains share the rollout CUs -- seam launches (consumers spinning on a CU each) cost more than they save
+        self.seam = None if partition != 'pair' else 0
         with torch.no_grad():
             self.bufs = [torch.zeros(self.B, self.T + self.H, self.N, self.D, device=self.dev) for _ in range(self.NB)]
             self.graphs = []
             for gi in range(self.NB):
-                engine.rollout(rollouter, self.bufs[gi], self.T, self.H, ws_slot=('pipe', gi))   # allocates its workspace
+                self._rollout_eager(gi)   # allocates its workspace
                 torch.cuda.synchronize(self.dev)
                 if use_graph:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
-                        engine.rollout(rollouter, self.bufs[gi], self.T, self.H, ws_slot=('pipe', gi))
+                        self._rollout_eager(gi)
                     self.graphs.append(g)
         self.cu_split = False
         self.partition = 'none'
@@ -173,11 +176,27 @@ class EncodeRolloutPipeline:
             pass
 
     # ------------------------------------------------------------------------------------------------------------
+    def _steal_of(self, j):
+        """time steps of convolutions stolen for batch j: integers that average to self.steal (1.25 -> 1, 1, 1, 2, ...)"""
+        import math
+        return int(math.floor(self.steal * (j + 1) + 1e-9) - math.floor(self.steal * j + 1e-9))
+
+    def _rollout_eager(self, gi):
+        if self.seam is None:
+            engine.rollout(self.roll, self.bufs[gi], self.T, self.H, ws_slot=('pipe', gi))
+            return
+        old = self._lib.sf_get_seam_fused()
+        self._lib.sf_set_seam_fused(self.seam)
+        try:
+            engine.rollout(self.roll, self.bufs[gi], self.T, self.H, ws_slot=('pipe', gi))
+        finally:
+            self._lib.sf_set_seam_fused(old)
+
     def _rollout(self, gi):
         if self.graphs:
             self.graphs[gi].replay()
         else:
-            engine.rollout(self.roll, self.bufs[gi], self.T, self.H, ws_slot=('pipe', gi))
+            self._rollout_eager(gi)
 
     def _encode(self, img, noise, dst, feat_pre, lo=0, hi=None, lane=0):
         """videos [lo, hi) of one batch -> dst[lo:hi, :burn_in] on the current stream"""
@@ -217,8 +236,9 @@ class EncodeRolloutPipeline:
         # work stealing: the features of batch j are computed `lead` batches earlier, on the rollout stream of batch j - lead
         # (the same stream batch j will roll out on) right after that batch's rollout
         lead = 2 * len(rolls)
+        kmax = int(-(-steal // 1))
         if steal and self.feat_bufs is None:
-            self.feat_bufs = [[engine.savi_cnn(self.savi, imgs[0][lo:hi], 0, steal, ws_slot=('pipe_steal', li)) for _ in range(lead)]
+            self.feat_bufs = [[engine.savi_cnn(self.savi, imgs[0][lo:hi], 0, kmax, ws_slot=('pipe_steal', li)) for _ in range(lead)]
                               for li, (_, lo, hi) in enumerate(lanes)]
         for st, _, _ in lanes:
             st.wait_stream(cur)
@@ -242,7 +262,8 @@ class EncodeRolloutPipeline:
                 for li, (st, lo, hi) in enumerate(lanes):
                     # (the first `lead` batches compute their own convolutions: stealing starts with batch `lead`, whose
                     #  features are produced after the rollout of batch 0)
-                    pre = self.feat_bufs[li][j % lead] if (steal and (j >= lead or (j >= 2 and len(rolls) > 1))) else None
+                    kj = self._steal_of(j) if (steal and (j >= lead or (j >= 2 and len(rolls) > 1))) else 0
+                    pre = self.feat_bufs[li][j % lead][:kj] if kj else None
                     with torch.cuda.stream(st):
                         if j >= NB:
                             st.wait_event(ev_roll[j - NB])   # slot buffer j % NB is free once batch j-NB has left it
@@ -265,18 +286,22 @@ class EncodeRolloutPipeline:
                 ev_roll[j].record(s_roll)
                 if steal and j + lead < n:
                     # feature buffers (j + lead) % lead == j % lead were consumed by encode j, which this stream has waited for
+                    kj = self._steal_of(j + lead)
                     for li, (_, lo, hi) in enumerate(lanes):
-                        engine.savi_cnn(self.savi, imgs[j + lead][lo:hi], 0, steal, out=self.feat_bufs[li][j % lead],
-                                        ws_slot=('pipe_steal', li, j % len(rolls)))
+                        if kj:
+                            engine.savi_cnn(self.savi, imgs[j + lead][lo:hi], 0, kj, out=self.feat_bufs[li][j % lead][:kj],
+                                            ws_slot=('pipe_steal', li, j % len(rolls)))
                     ev_pre[j + lead].record(s_roll)
                 if steal and j == 0 and len(rolls) > 1:
                     # fill: the second rollout stream idles until batch 1 is encoded -- it computes the features of batches
                     # 2 .. lead-1 now, so only batch 1 pays for its own convolutions
                     with torch.cuda.stream(rolls[1]):
                         for jj in range(2, min(lead, n)):
+                            kj = self._steal_of(jj)
                             for li, (_, lo, hi) in enumerate(lanes):
-                                engine.savi_cnn(self.savi, imgs[jj][lo:hi], 0, steal, out=self.feat_bufs[li][jj % lead],
-                                                ws_slot=('pipe_steal', li, 1))
+                                if kj:
+                                    engine.savi_cnn(self.savi, imgs[jj][lo:hi], 0, kj, out=self.feat_bufs[li][jj % lead][:kj],
+                                                    ws_slot=('pipe_steal', li, 1))
                             ev_pre[jj].record(rolls[1])
         # The host waits for the last batch HERE, before the calling stream is made to wait for the pipeline's streams: a
         # wait that sits pending on the calling stream (PyTorch's default stream is the legacy null stream) for the whole

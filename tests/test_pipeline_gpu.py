@@ -34,7 +34,7 @@ def _serial_reference(savi, roll, imgs, noises, T, H):
     return torch.stack(outs, 0)
 
 
-@pytest.mark.parametrize('B,steal,nbatch,partition', [(32, None, 9, 'pair'), (32, 1, 11, 'pair'), (5, 2, 12, 'pair'), (5, None, 7, 'pair'), (32, None, 6, 'three'), (32, 1, 5, 'three'), (5, 2, 7, 'three'), (32, 1, 6, 'two'),
+@pytest.mark.parametrize('B,steal,nbatch,partition', [(32, None, 9, 'pair'), (32, 1, 11, 'pair'), (32, 1.25, 13, 'pair'), (5, 2, 12, 'pair'), (5, 0.5, 12, 'pair'), (5, None, 7, 'pair'), (32, None, 6, 'three'), (32, 1, 5, 'three'), (5, 2, 7, 'three'), (32, 1, 6, 'two'),
                                                       (32, 0, 5, 'two'), (5, 1, 5, 'two'), (5, 2, 7, 'two')])
 def test_pipeline_matches_serial(dev, B, steal, nbatch, partition):
     from slotformer_amd.pipeline import EncodeRolloutPipeline
