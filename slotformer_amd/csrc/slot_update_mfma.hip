@@ -96,6 +96,8 @@ struct UmArgs {
   float ln_eps;
 };
 
+}  // namespace
+
 constexpr size_t UM_LDS = (size_t)(4 * UM_ROWS * UM_DP + 2 * UM_ROWS * UM_HP) * 2   // U, H/LN planes (hi, lo each) + hidden planes
                           + (size_t)2 * UM_ROWS * UM_FP * 4                          // previous / new rows as f32
                           + (size_t)4 * 2 * 16 * 64 * 4                              // wave-pair exchange: [4 blocks][2][16][64]
@@ -341,8 +343,6 @@ __global__ __launch_bounds__(UM_NT) void sa_slot_update_mfma_kernel(UmArgs a) {
     }
   }
 }
-
-}  // namespace
 
 bool sf_slot_update_mfma_ok(int D, int H, int P) { return D == UM_D && H == UM_H && P >= 1 && P <= 64; }
 
