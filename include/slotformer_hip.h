@@ -43,6 +43,11 @@ int sf_profile_enable(int class_mask); /* bit c enables class c; 0 disables */
  * share the same CUs (pipeline partition 'pair') the spinning consumers waste CU time and the graphs are captured with it off. */
 int sf_set_seam_fused(int on);
 int sf_get_seam_fused(void);
+/* 64 rows per workgroup in the chunk-partial FFN launches of the rollout (two 32-row tiles against one load of the weight
+ * chunk: 40 % less CU time per launch, a slightly longer launch).  Off by default; the 'pair' pipeline, whose rollout CUs are
+ * shared by two rollouts and therefore throughput-bound, captures its graphs with it on.  Bit-identical results either way. */
+int sf_set_ffn_rows64(int on);
+int sf_get_ffn_rows64(void);
 int sf_profile_sample(int every);      /* bracket every `every`-th launch of an enabled class only (default 1: all) */
 int sf_profile_read(int kernel_class, double* total_ms, long long* launches, double* work);
 

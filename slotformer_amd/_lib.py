@@ -119,6 +119,8 @@ SIGNATURES = {
     'sf_profile_sample': (I, [I]),
     'sf_set_seam_fused': (I, [I]),
     'sf_get_seam_fused': (I, []),
+    'sf_set_ffn_rows64': (I, [I]),
+    'sf_get_ffn_rows64': (I, []),
     'sf_profile_read': (I, [I, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     'sf_linear_f32': (I, [FP, I, FP, FP, FP, FP, F32, FP, I, FP, I, I, I, I, I, VP]),
     'sf_layernorm_f32': (I, [FP, FP, FP, FP, I, I, F32, VP]),

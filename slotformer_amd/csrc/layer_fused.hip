@@ -1160,6 +1160,180 @@ __global__ __launch_bounds__(LF_NT) void step_boundary_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// 64-row variant of the chunk-partial FFN (sf_set_ffn_rows64): one workgroup runs TWO 32-row tiles against ONE load of its
+// 256-wide chunk of W1 / W2 (every fragment feeds the MFMAs of both token blocks before its registers take the matching W2
+// fragment).  Per pair of tiles a workgroup then ingests 524 + 256 KB instead of 2 x 652 KB and the launch has half the
+// workgroups.  Alone, a rollout gains nothing from it (84 workgroups of ~15 us instead of 168 of 12.5 us: the launch is a
+// little longer); with two rollouts sharing the CUs (pipeline partition 'pair') the CUs are the bound and the FFN's CU time
+// drops by 40 %.  Same arithmetic per row as ffn_body (k order, operands, LayerNorm), so the partials are bit-identical.
+// LDS: the LN2 planes, the hidden planes and the output tile take turns in one 67.6 KB region (two extra barriers); the
+// residual stash (chunk 0) has its own 66.6 KB.
+constexpr int F6_ROWS = 64;
+constexpr size_t F6_R1 = (size_t)2 * F6_ROWS * FB_AP * 2;                      // planes (hi, lo) >= the f32 output tile
+constexpr size_t F6_LDS = F6_R1 + (size_t)F6_ROWS * FB_XP * 4;
+static_assert((size_t)F6_ROWS * FB_XP * 4 <= F6_R1, "output tile must fit the plane region");
+
+__global__ __launch_bounds__(LF_NT) void ffn64_parts_kernel(FfnArgs F) {
+  const float* __restrict__ ap = F.ap;
+  const long long ap_stride = F.ap_stride;
+  const uint4* __restrict__ w1p = F.w1p;
+  const uint4* __restrict__ w2p = F.w2p;
+  const int M = F.M;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* Ph = (__bf16*)smem;                          // [64][FB_AP]  LN2(x2), later relu(h_c)
+  __bf16* Pl = Ph + F6_ROWS * FB_AP;
+  float* OT = (float*)smem;                            // [64][FB_XP]  output tile (over the dead planes)
+  float* X2 = (float*)((char*)smem + F6_R1);           // [64][FB_XP]  x2 (residual; chunk 0 only)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // pairs of tiles dealt like ffn_body's tiles: the four chunks of a pair share an XCD; left-over pairs one chunk per XCD
+  const int npairs = (F.ntiles + 1) >> 1, blk = blockIdx.x;
+  const int full = (npairs >> 3) << 5;
+  int c = (blk >> 3) & (LF_NCH - 1), tp = (blk >> 5) * 8 + (blk & 7);
+  if (full > 0 && blk >= full) {
+    c = (blk - full) & (LF_NCH - 1);
+    tp = (npairs & ~7) + ((blk - full) >> 2);
+  }
+  if (tp >= npairs) return;
+  const int row0 = tp * F6_ROWS;
+  const int tok = lane & 31, nb = wave * 32 + 4 * (lane >> 5);
+  f32x4 b1v[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) b1v[g] = *(const f32x4*)(F.b1 + c * LF_HC + nb + 8 * g);
+  const uint4* w1c = w1p + ((long long)(c * 16) * 8 + wave) * 128 + lane;
+  const uint4* w2c = w2p + ((long long)(c * 16) * 8 + wave) * 128 + lane;
+  bf16x8 wf[16][2];
+  auto ldw = [&](const uint4* base, int ks, int plane) { return __builtin_bit_cast(bf16x8, base[(ks * 8) * 128 + plane * 64]); };
+  const f32x4 lng = *(const f32x4*)(F.ln_g + 4 * lane), lnb = *(const f32x4*)(F.ln_b + 4 * lane);
+  // ---- prologue, one 32-row half at a time (wave owns rows wave + 8 i of the half, lane = float4 column): partials ->
+  //      x2 -> LayerNorm -> planes; the first half of W1 is requested between the two halves' partials, the second after ----
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+    f32x4 x2[4];
+    {
+      f32x4 pr[LF_NP][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gr = min(row0 + 32 * hb + wave + 8 * i, M - 1);
+        const float* p = ap + (long long)gr * LF_D + 4 * lane;
+#pragma unroll
+        for (int q = 0; q < LF_NP; ++q) pr[q][i] = *(const f32x4*)(p + q * ap_stride);
+      }
+      if (hb == 0) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          wf[ks][0] = ldw(w1c, ks, 0);
+          wf[ks][1] = ldw(w1c, ks, 1);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 sacc = pr[0][i];
+#pragma unroll
+        for (int q = 1; q < LF_NP; ++q) sacc += pr[q][i];
+        x2[i] = sacc;
+      }
+    }
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mean[i] = sf_sum64((x2[i][0] + x2[i][1]) + (x2[i][2] + x2[i][3])) * (1.0f / LF_D);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 dv = x2[i] - mean[i];
+      rstd[i] = 1.0f / sqrtf(sf_sum64((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3])) * (1.0f / LF_D) + F.ln_eps);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 32 * hb + wave + 8 * i;
+      split4(Ph, Pl, r * FB_AP + 4 * lane, (x2[i] - mean[i]) * rstd[i] * lng + lnb);
+      if (c == 0) *(f32x4*)(X2 + r * FB_XP + 4 * lane) = x2[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int ks = 8; ks < 16; ++ks) {
+    wf[ks][0] = ldw(w1c, ks, 0);
+    wf[ks][1] = ldw(w1c, ks, 1);
+  }
+  __syncthreads();
+
+  // ---- FFN1 for both token blocks; every fragment's registers then take the matching W2 fragment ----
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  const int ao = (lane & 31) * FB_AP + 8 * (lane >> 5);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const bf16x8 xh0 = *(const bf16x8*)(Ph + ao + ks * 16), xl0 = *(const bf16x8*)(Pl + ao + ks * 16);
+    const bf16x8 xh1 = *(const bf16x8*)(Ph + ao + 32 * FB_AP + ks * 16), xl1 = *(const bf16x8*)(Pl + ao + 32 * FB_AP + ks * 16);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl0, acc0, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh0, acc0, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl1, acc1, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh1, acc1, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh1, acc1, 0, 0, 0);
+    wf[ks][0] = ldw(w2c, ks, 0);
+    wf[ks][1] = ldw(w2c, ks, 1);
+  }
+  __syncthreads();   // every wave has read the LN2 planes: the hidden planes take their place
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 bv = b1v[g];
+    f32x4 h0, h1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      h0[q] = fmaxf(acc0[4 * g + q] + bv[q], 0.f);
+      h1[q] = fmaxf(acc1[4 * g + q] + bv[q], 0.f);
+    }
+    split4(Ph, Pl, tok * FB_AP + nb + 8 * g, h0);
+    split4(Ph, Pl, (32 + tok) * FB_AP + nb + 8 * g, h1);
+  }
+  __syncthreads();
+
+  // ---- FFN2 partial for both token blocks ----
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const bf16x8 xh0 = *(const bf16x8*)(Ph + ao + ks * 16), xl0 = *(const bf16x8*)(Pl + ao + ks * 16);
+    const bf16x8 xh1 = *(const bf16x8*)(Ph + ao + 32 * FB_AP + ks * 16), xl1 = *(const bf16x8*)(Pl + ao + 32 * FB_AP + ks * 16);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl0, acc0, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh0, acc0, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl1, acc1, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh1, acc1, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh1, acc1, 0, 0, 0);
+  }
+  __syncthreads();   // every wave has read the hidden planes: the output tile takes their place
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 v0 = {acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
+    f32x4 v1 = {acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
+    if (c == 0) {   // chunk 0 adds the residual and the bias
+      const f32x4 bb = *(const f32x4*)(F.b2 + nb + 8 * g);
+      v0 += *(const f32x4*)(X2 + tok * FB_XP + nb + 8 * g) + bb;
+      v1 += *(const f32x4*)(X2 + (32 + tok) * FB_XP + nb + 8 * g) + bb;
+    }
+    *(f32x4*)(OT + tok * FB_XP + nb + 8 * g) = v0;
+    *(f32x4*)(OT + (32 + tok) * FB_XP + nb + 8 * g) = v1;
+  }
+  __syncthreads();
+  // thread t owns float4 (row = wave + 8 i, column 4 lane): 1 KB contiguous per wave-wide store; the kernel boundary publishes
+  float* dst = F.xp + (long long)c * F.xp_stride + 4 * lane;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = wave + 8 * i;
+    if (row0 + r < M) *(f32x4*)(dst + (long long)(row0 + r) * LF_D) = *(const f32x4*)(OT + r * FB_XP + 4 * lane);
+  }
+}
+
+static int g_ffn_rows64 = 0;
+extern "C" int sf_set_ffn_rows64(int on) {
+  g_ffn_rows64 = on ? 1 : 0;
+  return 0;
+}
+extern "C" int sf_get_ffn_rows64(void) { return g_ffn_rows64; }
+
+// ------------------------------------------------------------------------------------------------
 // timing ablations (wrong results): 1 FFN reads one head partial, 2 FFN skips the W2 loads, 4 attention reads one
 // input partial, 8 attention stores one column block
 static int lf_dbg() {
@@ -1286,7 +1460,25 @@ int sf_ffn_parts_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w,
                     int ffn, hipStream_t st) {
   SbArgs sb;
   memset(&sb, 0, sizeof(sb));
-  return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, nullptr, nullptr, M, ffn, sb, st, 1);
+  if (!g_ffn_rows64 || M < 2 * FB_ROWS) return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, nullptr, nullptr, M, ffn, sb, st, 1);
+  // 64 rows per workgroup (ffn64_parts_kernel)
+  static_assert(F6_LDS <= 160 * 1024, "64-row FFN kernel: LDS budget");
+  if (!w.lin1_packed || !w.lin2_packed || ffn != LF_NCH * LF_HC)
+    return sf_set_err(-1, "invalid argument: fused FFN needs packed weights (sf_pack_ffn_weights) and ffn == 1024", __FILE__, __LINE__);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)ffn64_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F6_LDS);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    attr = true;
+  }
+  FfnArgs F = make_ffn_args(ap, ap_stride, w, eps, xp, xp_stride, nullptr, nullptr, M, sb);
+  F.parts_only = 1;
+  const int npairs = (F.ntiles + 1) / 2;
+  sf_prof_begin(SF_K_FFN, st, 4.0 * M * (double)LF_D * ffn);
+  hipLaunchKernelGGL(ffn64_parts_kernel, dim3(ffn_blocks(npairs)), dim3(LF_NT), F6_LDS, st, F);
+  sf_prof_end(SF_K_FFN, st);
+  SF_CHECK_LAUNCH();
+  return 0;
 }
 
 // last layer of a rollout step: the FFN's last-arriving workgroups also run the step boundary (out-proj -> slots frame

@@ -30,6 +30,7 @@ phyre_planning/test_phyre_planning.py:159-174 (encode -> pad -> rollout per batc
 followed by video_prediction/rollout_clevrer_slots.py:20-65.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -104,7 +105,7 @@ class EncodeRolloutPipeline:
         self._masked = []
         self._lib = _lib.lib()
         # 'pair': two chains share the rollout CUs -- seam launches (consumers spinning on a CU each) cost more than they save
-        self.seam = None if partition != 'pair' else 0
+        self.seam = None if partition != 'pair' else int(os.environ.get('SF_PIPE_SEAM', '0'))
         with torch.no_grad():
             self.bufs = [torch.zeros(self.B, self.T + self.H, self.N, self.D, device=self.dev) for _ in range(self.NB)]
             self.graphs = []
@@ -185,12 +186,15 @@ class EncodeRolloutPipeline:
         if self.seam is None:
             engine.rollout(self.roll, self.bufs[gi], self.T, self.H, ws_slot=('pipe', gi))
             return
-        old = self._lib.sf_get_seam_fused()
+        # throughput mode of the rollout kernels: no seam launches, 64-row FFN workgroups
+        old, old64 = self._lib.sf_get_seam_fused(), self._lib.sf_get_ffn_rows64()
         self._lib.sf_set_seam_fused(self.seam)
+        self._lib.sf_set_ffn_rows64(int(os.environ.get('SF_PIPE_FFN64', '1')))
         try:
             engine.rollout(self.roll, self.bufs[gi], self.T, self.H, ws_slot=('pipe', gi))
         finally:
             self._lib.sf_set_seam_fused(old)
+            self._lib.sf_set_ffn_rows64(old64)
 
     def _rollout(self, gi):
         if self.graphs:

@@ -13,6 +13,7 @@ dev = torch.device('cuda:0')
 savi, roll = bench.build_models(dev)
 lib = _lib.lib()
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+lib.sf_set_ffn_rows64(int(os.environ.get('FFN64', '0')))
 words = [0xffffffff if w < rows else 0 for w in range(8)]
 with torch.no_grad():
     for nroll in (1, 2, 3):
@@ -42,7 +43,7 @@ with torch.no_grad():
                         graphs[ri].replay()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-        print(f'{32 * rows} CUs, seam {os.environ.get("SF_SEAM_FUSED", "1")}, parts {os.environ.get("SF_FFN_PARTS", "1")}: {nroll} chain(s): '
+        print(f'{32 * rows} CUs, seam {os.environ.get("SF_SEAM_FUSED", "1")}, parts {os.environ.get("SF_FFN_PARTS", "1")}, ffn64 {os.environ.get("FFN64", "0")}: {nroll} chain(s): '
               f'{1e3 * dt / n:7.3f} ms per round = {1e3 * dt / n / nroll:6.3f} ms per rollout', flush=True)
         del graphs, sts
         torch.cuda.synchronize()

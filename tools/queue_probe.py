@@ -43,6 +43,8 @@ with torch.no_grad():
         'f roll r0-3 (128) | enc r4-7 (128)': (SE((0, 1, 2, 3), range(4)), [(SE((0, 1, 2, 3), (4, 5, 6, 7)), 128)]),
         'g roll SE1-3 r0-4 (120) | enc SE0 (64) + SE1-3 r5-7 (72)': (SE((1, 2, 3), range(5)), [(SE((0,), ALL), 64), (SE((1, 2, 3), (5, 6, 7)), 72)]),
     }
+    lib.sf_set_ffn_rows64(int(os.environ.get('FFN64', '0')))
+    NROLLS = [int(x) for x in os.environ.get('NROLLS', '1,2').split(',')]
     sel = sys.argv[1:] or list('abcdefg')
     for name, (rw, encs) in parts.items():
         if name[0] not in sel:
@@ -53,7 +55,7 @@ with torch.no_grad():
             acc += c
             cuts.append(round(32 * acc / tot))
         lanes = [(masked(w), cuts[i], cuts[i + 1]) for i, (w, _) in enumerate(encs)]
-        for nroll in (1, 2):
+        for nroll in NROLLS:
             rolls = [masked(rw) for _ in range(nroll)]
             bufs = [torch.randn(32, 56, 7, 128, device=dev) for _ in rolls]
             for ri, st in enumerate(rolls):
