@@ -1204,34 +1204,36 @@ __global__ __launch_bounds__(LF_NT) void ffn64_parts_kernel(FfnArgs F) {
   bf16x8 wf[16][2];
   auto ldw = [&](const uint4* base, int ks, int plane) { return __builtin_bit_cast(bf16x8, base[(ks * 8) * 128 + plane * 64]); };
   const f32x4 lng = *(const f32x4*)(F.ln_g + 4 * lane), lnb = *(const f32x4*)(F.ln_b + 4 * lane);
-  // ---- prologue, one 32-row half at a time (wave owns rows wave + 8 i of the half, lane = float4 column): partials ->
-  //      x2 -> LayerNorm -> planes; the first half of W1 is requested between the two halves' partials, the second after ----
+  // ---- prologue (wave owns rows wave + 8 i of each 32-row half, lane = float4 column).  All requests that the LayerNorm needs
+  //      go out first -- the partials of both halves with the first half of W1 between them -- then partials -> x2 ->
+  //      LayerNorm -> planes half by half, and the second half of W1 is requested after the arithmetic ----
+  f32x4 pr[2][LF_NP][4];
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gr = min(row0 + 32 * hb + wave + 8 * i, M - 1);
+      const float* p = ap + (long long)gr * LF_D + 4 * lane;
+#pragma unroll
+      for (int q = 0; q < LF_NP; ++q) pr[hb][q][i] = *(const f32x4*)(p + q * ap_stride);
+    }
+    if (hb == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        wf[ks][0] = ldw(w1c, ks, 0);
+        wf[ks][1] = ldw(w1c, ks, 1);
+      }
+    }
+  }
 #pragma unroll
   for (int hb = 0; hb < 2; ++hb) {
     f32x4 x2[4];
-    {
-      f32x4 pr[LF_NP][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gr = min(row0 + 32 * hb + wave + 8 * i, M - 1);
-        const float* p = ap + (long long)gr * LF_D + 4 * lane;
+    for (int i = 0; i < 4; ++i) {
+      f32x4 sacc = pr[hb][0][i];
 #pragma unroll
-        for (int q = 0; q < LF_NP; ++q) pr[q][i] = *(const f32x4*)(p + q * ap_stride);
-      }
-      if (hb == 0) {
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          wf[ks][0] = ldw(w1c, ks, 0);
-          wf[ks][1] = ldw(w1c, ks, 1);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f32x4 sacc = pr[0][i];
-#pragma unroll
-        for (int q = 1; q < LF_NP; ++q) sacc += pr[q][i];
-        x2[i] = sacc;
-      }
+      for (int q = 1; q < LF_NP; ++q) sacc += pr[hb][q][i];
+      x2[i] = sacc;
     }
     float mean[4], rstd[4];
 #pragma unroll
@@ -1247,8 +1249,8 @@ __global__ __launch_bounds__(LF_NT) void ffn64_parts_kernel(FfnArgs F) {
       split4(Ph, Pl, r * FB_AP + 4 * lane, (x2[i] - mean[i]) * rstd[i] * lng + lnb);
       if (c == 0) *(f32x4*)(X2 + r * FB_XP + 4 * lane) = x2[i];
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int ks = 8; ks < 16; ++ks) {
     wf[ks][0] = ldw(w1c, ks, 0);
