@@ -85,7 +85,8 @@ def dominant_kernel():
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_stats.csv')))
-    names = {'conv5x5_halo': 'conv', 'ffn_partial_kernel': 'ffn_fused', 'attn_oproj_kernel': 'attention', 'seam_kernel': 'seam',
+    names = {'conv5x5_halo': 'conv', 'ffn_partial_kernel': 'ffn_fused', 'ffn64_parts_kernel': 'ffn_fused', 'attn_oproj_kernel': 'attention',
+             'seam_kernel': 'seam',
              'sa_attn_mfma_kernel': 'slot_attn'}
     if not files:
         return 'ffn_fused', None
@@ -415,8 +416,8 @@ def main():
         # ---- roofline objects, one per hot kernel; `roofline` = the one that dominates the committed rocprof summary of this
         #      command (profiles/r*_kernel_stats.csv), the others stay as secondary keys ----
         objs = {}
-        for key, name in (('ffn_fused', 'ffn_partial_kernel (sum of the 4 head-pair partials + LN2 + FFN1 + ReLU + FFN2 on one 32-row tile x 256-wide '
-                           'hidden chunk + last-arriver reduction)'),
+        for key, name in (('ffn_fused', 'ffn_partial_kernel / ffn64_parts_kernel (sum of the 4 head-pair partials + LN2 + FFN1 + ReLU + FFN2 on a 32- or '
+                           '64-row tile x 256-wide hidden chunk; chunk partials out, last-arriver reduction on the last layer only)'),
                           ('attention', 'attn_oproj_kernel (LN1 + q|k|v of a head pair + softmax(qk^T)v + out-proj partial; one workgroup per '
                            '(head pair, video))'),
                           ('seam', 'seam_kernel (last-layer FFN + step boundary of step s and the layer-0 attention of step s+1 in one grid, '
