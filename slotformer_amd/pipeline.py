@@ -1,28 +1,30 @@
-"""Software pipeline over independent batches of videos: slot extraction of batch i+1 overlaps the rollout of batch i.
+"""Software pipeline over independent batches of videos: slot extraction of later batches overlaps the rollout of earlier ones.
 
 The two halves of the hot path have opposite shapes -- the SAVi encode is throughput work (convolutions, Slot Attention
-over 4096 pixels), the SlotFormer rollout a latency chain of short dependent kernels that cannot fill the chip at B = 32 --
-so they run side by side on disjoint sets of CUs:
+over 4096 pixels), the SlotFormer rollout a chain of ~350 short dependent launches whose 128-168 workgroups mostly wait for
+their weights -- so they run side by side on disjoint sets of CUs (streams created with CU masks, `sf_stream_create_cu_mask`
+-> hipExtStreamCreateWithCUMask):
 
 * the rollout of every slot buffer is captured ONCE into a hipGraph (one graph, one slot buffer and one workspace per batch
-  in flight) and replayed on the *rollout stream*;
-* default partition 'pair' (round 2, late): the rollout is a latency chain -- a single one leaves most of its CUs idle most
-  of the time -- so TWO batches roll out side by side on two rollout streams that share CU rows 0-4 of all four shader
-  engines (160 CUs; 8.3 ms for two rollouts against 5.8 ms for one), the encode runs on rows 5-7 (96 CUs), and the
-  convolution features of the first `steal_steps` time steps of a batch are computed ahead of time on its rollout stream
-  (work stealing, below).  Four slot buffers / graphs.  More than three busy CU-masked queues degrade badly (four encode
-  queues + the rollout's: 25 ms per batch), which is why this is two rollout streams + ONE encode stream;
-* (partitions 'three' / 'two') the encode runs on *encode lanes* -- streams created with CU masks (`sf_stream_create_cu_mask` ->
-  hipExtStreamCreateWithCUMask), each encoding its own share of the batch's videos.  Default partition ('three'): the
-  rollout gets CU rows 0-6 of shader engines 1-3 of every XCD (168 CUs: exactly what its widest launch, the 168
-  workgroups of a B = 32 FFN, needs -- 21 per XCD), lane 0 the whole shader engine 0 (64 CUs, 3/4 of the videos) and
-  lane 1 CU row 7 of shader engines 1-3 (24 CUs, 1/4 of the videos).  Every mask gives each shader engine it touches the
-  same number of CUs -- the rule for masks that do not unbalance the dispatch (encode_mask_words).  partition='two' is
-  the round-1 split (encode: shader engine 0, rollout: the other three, 192 CUs of which its launches use <= 168);
-* work stealing: the CNN features of the first `steal_steps` time steps of batch j+2 do not depend on any slots, so the
-  rollout stream computes them on its larger partition after the rollout graph of batch j while it would otherwise idle,
-  and the encode of batch j+2 skips those convolutions (`engine.savi_cnn` / `savi_encode(feat_pre=...)`);
-* the first encode of a run takes the whole chip (the calling stream): nothing else is active yet.
+  in flight) and replayed on a rollout stream;
+* partition 'pair' (default): a single rollout chain leaves most of its CUs idle most of the time, so TWO batches roll out
+  side by side on two rollout streams that share CU rows 0-4 of all four shader engines of every XCD (160 CUs: 8.4 ms for two
+  rollouts against 6.7 ms for one there), and the encode runs on rows 5-7 (96 CUs).  Four slot buffers / graphs.  The
+  rollout kernels run in their throughput settings for these graphs (no seam launches, 64-row FFN workgroups).  Three busy
+  CU-masked queues are the limit -- a fourth slows all of them (two encode lanes + two rollout streams: 8.9 ms per batch),
+  five collapse (25 ms) -- hence two rollout streams and ONE encode stream;
+* partition 'three': one rollout stream on CU rows 0-6 of shader engines 1-3 (168 CUs: what its widest launch needs, 21 per
+  XCD) and two encode *lanes*, each with its share of a batch's videos: shader engine 0 (64 CUs, 3/4 of the videos) and row 7
+  of shader engines 1-3 (24 CUs).  partition 'two' is the round-1 split (encode: shader engine 0, rollout: the other three);
+* every mask gives each shader engine it touches the same number of CUs -- the rule for masks that do not unbalance the
+  dispatch (encode_mask_words);
+* work stealing: the CNN features of the first time steps of a batch do not depend on any slots, so the rollout stream that
+  batch will roll out on computes them ahead of time, right after the rollout graph of an earlier batch (`engine.savi_cnn` ->
+  `savi_encode(feat_pre=...)`); `steal_steps` may be fractional (1.25 = one step per batch, two for every fourth);
+* fill and drain: the first encode of a run takes the whole chip (the calling stream) and is waited for on the host; while
+  the second rollout stream is still idle it computes the stolen features of the next batches; the last rollout of a run
+  goes to an unmasked stream; run() returns when the last batch is done (a wait left pending on the calling stream slows
+  the masked queues).
 
 Every batch still runs its complete encode + rollout; results are bit-identical to the serial
 `savi({'img'}) -> rollout` sequence (tests/test_pipeline_gpu.py).  Reference caller shapes this replaces:
