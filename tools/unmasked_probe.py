@@ -17,13 +17,27 @@ lib.sf_set_seam_fused(0)
 img = bench.synthetic_img(32).to(dev)
 noise = torch.randn(32, 6, 7, 128, device=dev)
 with torch.no_grad():
-    for enc_rows, nroll, prio in ((3, 2, 0), (3, 3, 0), (3, 4, 0), (3, 3, -1), (4, 3, 0), (4, 4, 0)):
+    MIX = os.environ.get('MIX')   # "m,u": m masked rollout chains on the complement + u unmasked ones
+    cfgs = ((3, 2, 0), (3, 3, 0), (3, 4, 0), (3, 3, -1), (4, 3, 0), (4, 4, 0))
+    if MIX:
+        m_, u_ = [int(x) for x in MIX.split(',')]
+        cfgs = ((3, m_ + u_, 0), )
+    for enc_rows, nroll, prio in cfgs:
         words = [0xffffffff if w >= 8 - enc_rows else 0 for w in range(8)]
         arr = (C.c_uint * 8)(*words)
         h = C.c_void_p()
         _lib.check(lib.sf_stream_create_cu_mask(C.byref(h), arr, 8))
         s_enc = torch.cuda.ExternalStream(h.value, device=dev)
         rolls = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(nroll)]
+        hm = []
+        if MIX:
+            rw = [~w & 0xffffffff for w in words]
+            for i in range(m_):
+                arr2 = (C.c_uint * 8)(*rw)
+                h2 = C.c_void_p()
+                _lib.check(lib.sf_stream_create_cu_mask(C.byref(h2), arr2, 8))
+                hm.append(h2)
+                rolls[i] = torch.cuda.ExternalStream(h2.value, device=dev)
         bufs = [torch.randn(32, 56, 7, 128, device=dev) for _ in rolls]
         graphs = []
         for ri in range(nroll):
@@ -49,8 +63,10 @@ with torch.no_grad():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         nb = n * nroll
-        print(f'encode on {32 * enc_rows} masked CUs, {nroll} unmasked rollout chains (priority {prio}): all done {1e3 * dt / nb:6.3f} ms per batch; '
+        print(f'encode on {32 * enc_rows} masked CUs, {nroll} rollout chains ({MIX or "all unmasked"}; priority {prio}): all done {1e3 * dt / nb:6.3f} ms per batch; '
               f'encode done after {1e3 * t_enc / nb:6.3f} ms per batch', flush=True)
         del graphs, rolls
         torch.cuda.synchronize()
         lib.sf_stream_destroy(h)
+        for h2 in hm:
+            lib.sf_stream_destroy(h2)
