@@ -156,7 +156,8 @@ class EncodeRolloutPipeline:
             self.roll_streams = [self.s_roll]
         self.s_free = torch.cuda.Stream(device=self.dev) if len(self.roll_streams) > 1 else None   # unmasked: the drain
         self.s_enc = self.lanes[0][0]
-        self.fill_whole_chip = True      # the first encode of a run on the calling stream (all CUs)
+        self.fill_whole_chip = True      # the first encode(s) of a run on the calling stream (all CUs)
+        self.fill_batches = 1            # (2 = batch 1 on the whole chip as well: measured worse, 311 vs 323 k frames/s at 20 steps)
         self.feat_bufs = None
         self.completion_events = []
 
@@ -254,16 +255,16 @@ class EncodeRolloutPipeline:
         ev_roll = [torch.cuda.Event(enable_timing=True) for _ in range(n)]   # also: completion time of every batch
         ev_pre = [torch.cuda.Event() for _ in range(n + lead)]
         for j in range(n):
-            if j == 0 and self.cu_split and self.fill_whole_chip:
+            if j < self.fill_batches and self.cu_split and self.fill_whole_chip:
                 # pipeline fill: the first encode takes the whole chip (the calling stream); the masked lanes start after it
-                self._encode(imgs[0], nz(0), self.bufs[0], None)
-                ev_enc[0][0].record(cur)
+                self._encode(imgs[j], nz(j), self.bufs[j % NB], None)
+                ev_enc[j][0].record(cur)
                 # the host waits for it: with the three other queues parked in a wait on this event the encode was measured
                 # at 4.8 instead of 3.05 ms (a queue stalled in a cross-queue wait slows the queue that is running)
-                ev_enc[0][0].synchronize()
+                ev_enc[j][0].synchronize()
                 for st, _, _ in lanes:
-                    st.wait_event(ev_enc[0][0])
-                ev_wait = ev_enc[0][:1]
+                    st.wait_event(ev_enc[j][0])
+                ev_wait = ev_enc[j][:1]
             else:
                 for li, (st, lo, hi) in enumerate(lanes):
                     # (the first `lead` batches compute their own convolutions: stealing starts with batch `lead`, whose
