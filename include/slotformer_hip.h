@@ -439,6 +439,14 @@ typedef struct {
    * [3D, D], Slot-Attention mlp[1].weight [H, D], mlp[3].weight [D, H] and project_q[1].weight [D, D]; with all five the slot
    * update after every Slot-Attention iteration runs on the matrix cores (split-bf16, like the other bf16x3 kernels) */
   const void *sa_gru_ih_p, *sa_gru_hh_p, *sa_mlp_w1_p, *sa_mlp_w2_p, *sa_q_w_p;
+  /* optional: Slot Attention with the key / value projections FOLDED away (project_k / project_v are bias-free Linears,
+   * savi.py:44-45, so  k.q = x.(Wk^T q)  and  sum_p a v = Wv (sum_p a x)):  the attention runs on the normalised pixel features x
+   * themselves -- half the bytes of k|v, and the [Wk;Wv] GEMM disappears -- with
+   *   sa_fold_q_w   = Wk^T Wq   [C, D]  in place of project_q[1].weight  (its transposed [D, C] and packed copies beside it)
+   *   sa_fold_gru_ih = W_ih Wv  [3D, C] in place of GRUCell.weight_ih    (transposed [C, 3D] and packed copies)
+   * Used when all are given, enc_out_channels == slot_size == 128 and the split-bf16 mode is on. */
+  const float *sa_fold_q_w, *sa_fold_q_w_t, *sa_fold_gru_ih_t;
+  const void *sa_fold_q_w_p, *sa_fold_gru_ih_p;
 } sf_savi_encoder;
 
 size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B);

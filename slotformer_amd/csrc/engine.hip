@@ -143,6 +143,12 @@ size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B) {
 
 extern "C" int sf_get_seam_fused(void);
 
+// block 0 clears a[0..1023], block 1 clears b[0..1023] (b may be NULL)
+__global__ void zero_words_kernel(unsigned* a, unsigned* b) {
+  unsigned* p = blockIdx.x == 0 ? a : b;
+  if (p) p[threadIdx.x] = 0u;
+}
+
 int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws,
                    size_t ws_bytes, void* stream) {
   SF_REQUIRE(m && slots && ws, "null pointer");
@@ -206,9 +212,11 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   }
   if (fused_layers) {
     SF_REQUIRE(sf_ffn_tiles(B * Lmax) <= 1024, "batch too large for the fused-layer tile counters");
-    hipError_t e = hipMemsetAsync(counters, 0, 1024 * sizeof(int), st);
-    if (e == hipSuccess && seam) e = hipMemsetAsync(seam_flags, 0, 1024 * sizeof(unsigned), st);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    // zeroed by a KERNEL, not hipMemsetAsync: the rollout is captured into hipGraphs, and the memset nodes of a graph were seen
+    // to stop clearing these words after an OLDER graph exec had been destroyed (stale seam epochs -> consumers read ring rows
+    // before they were written; found by tests/test_pipeline_gpu.py when a second pipeline followed a first in one process)
+    hipLaunchKernelGGL(zero_words_kernel, dim3(2), dim3(1024), 0, st, (unsigned*)counters, seam ? seam_flags : nullptr);
+    SF_CHECK_LAUNCH();
   }
   const long long bs = (long long)T_total * N * C;
   auto window = [&](int s, int& nf, int& f0) {   // frames of the Transformer window of step s
@@ -525,6 +533,19 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
   }
   const long long frame_elems = (long long)3 * res * res;
   const float ln_eps = 1e-5f;
+  // Slot Attention on the normalised pixel features with the key / value projections folded into project_q and the GRU input
+  // matrix (include/slotformer_hip.h, sa_fold_*); SF_SA_FOLD=0: k|v as the reference computes them
+  static const bool fold_env = [] {
+    const char* e = getenv("SF_SA_FOLD");
+    return !(e && e[0] == '0');
+  }();
+  const bool fold = fold_env && sf_get_precision() >= 1 && m->sa_fold_q_w && m->sa_fold_q_w_t && m->sa_fold_gru_ih_t && Ce == D &&
+                    sf_pixel_mlp_feat_ok(m->enc_channels[m->enc_layers], Ce);
+  const float* q_w = fold ? m->sa_fold_q_w : m->sa_q_w;
+  const float* q_w_t = fold ? m->sa_fold_q_w_t : m->sa_q_w_t;
+  const float* gru_ih_t = fold ? m->sa_fold_gru_ih_t : m->gru_w_ih;
+  const void* q_w_p = fold ? m->sa_fold_q_w_p : m->sa_q_w_p;
+  const void* gru_ih_p = fold ? m->sa_fold_gru_ih_p : m->sa_gru_ih_p;
 
   for (int t = 0; t < T; ++t) {
     // ---- CNN encoder + per-pixel MLP + K/V for the B frames of step t ---------------------
@@ -543,6 +564,11 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
       const int Mp = nb * HW;
       // encoder_out_layer (LN -> Linear -> ReLU -> Linear, savi.py:245-250) and k|v = [Wk;Wv] LN(inputs)
       // (savi.py:66-70): one fused kernel per 128-pixel tile in split-bf16 mode (pixel_mlp.hip), else three GEMMs
+      if (fold) {
+        SF_TRY(sf_pixel_mlp_feat_ex(cur, m->enc_ln_g, m->enc_ln_b, m->enc_fc1_w, m->enc_fc1_b, m->enc_fc2_w, m->enc_fc2_b,
+                                    m->sa_norm_in_g, m->sa_norm_in_b, kv + (long long)b0 * HW * Ce, Mp, ln_eps, st));
+        continue;
+      }
       float* kv_dst = kv + (long long)b0 * HW * 2 * D;
       int fused = 1;
       if (sf_get_precision() >= 1)
@@ -564,11 +590,11 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
     float* s_in = slotsA;
     float* s_out = slotsB;
     int prologue = 1;
-    if (m->pred_type == 0 && !m->pred_rnn && m->kd_mode == 1 && m->pm_w0_t && m->pm_w2_t && m->kd_w0_t && m->sa_q_w_t)
+    if (m->pred_type == 0 && !m->pred_rnn && m->kd_mode == 1 && m->pm_w0_t && m->pm_w2_t && m->kd_w0_t && q_w_t)
       prologue = sf_slot_prologue_ex(prev, m->init_latents, m->pm_ln_g, m->pm_ln_b, m->pm_w0_t, m->pm_b0, m->pm_w2_t, m->pm_b2,
                                      m->pred_norm_first, m->kd_w0_t, m->kd_b0, noise ? noise + (long long)t * N * D : nullptr,
                                      (long long)T * N * D, kernel_dist ? kernel_dist + (long long)t * N * 2 * D : nullptr,
-                                     (long long)T * N * 2 * D, m->sa_q_ln_g, m->sa_q_ln_b, m->sa_q_w_t, s_in, q, B, N, D, ln_eps,
+                                     (long long)T * N * 2 * D, m->sa_q_ln_g, m->sa_q_ln_b, q_w_t, s_in, q, B, N, D, ln_eps,
                                      st);
     if (prologue < 0 || prologue > 1) return prologue;
     if (prologue == 1) {
@@ -636,7 +662,7 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
       }
       // q of the first iteration: LN-fused GEMM; every later q comes out of the slot-update kernel, which also writes the
       // last iteration's result straight into post_slots[:, t]
-      SF_TRY(sf_linear_ex(s_in, sf_rows(D), m->sa_q_w, nullptr, m->sa_q_ln_g, m->sa_q_ln_b, ln_eps, nullptr,
+      SF_TRY(sf_linear_ex(s_in, sf_rows(D), q_w, nullptr, m->sa_q_ln_g, m->sa_q_ln_b, ln_eps, nullptr,
                           sf_rows(D), 0, q, sf_rows(D), R, D, D, 0, st));
     }
     // ---- Slot Attention iterations (savi.py:76-100) -------------------------------------------
@@ -646,30 +672,34 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
       const char* e = getenv("SF_SU_MFMA");
       return !(e && e[0] == '0');
     }();
-    const bool su_mfma = su_env && sf_get_precision() >= 1 && m->sa_gru_ih_p && m->sa_gru_hh_p && m->sa_mlp_w1_p && m->sa_mlp_w2_p &&
-                         m->sa_q_w_p && sf_slot_update_mfma_ok(D, Hm, P);
+    const bool su_mfma = su_env && sf_get_precision() >= 1 && gru_ih_p && m->sa_gru_hh_p && m->sa_mlp_w1_p && m->sa_mlp_w2_p &&
+                         q_w_p && sf_slot_update_mfma_ok(D, Hm, P);
     for (int it = 0; it < m->num_iterations; ++it) {
       const bool last_it = (it == m->num_iterations - 1);
       float* aout = (attn && last_it) ? attn + (long long)t * N * HW : nullptr;
-      SF_TRY(sf_slot_attn_iter_ex(kv, kv + D, 2 * D, (long long)HW * 2 * D, q, pnum, pden, aout,
-                                  (long long)T * N * HW, B, HW, N, D, scale, m->sa_eps, st));
+      if (fold)   // keys = values = the normalised features (q is Wk^T q here, the GRU input matrix is W_ih Wv)
+        SF_TRY(sf_slot_attn_iter_ex(kv, kv, Ce, (long long)HW * Ce, q, pnum, pden, aout, (long long)T * N * HW, B, HW, N, D, scale,
+                                    m->sa_eps, st));
+      else
+        SF_TRY(sf_slot_attn_iter_ex(kv, kv + D, 2 * D, (long long)HW * 2 * D, q, pnum, pden, aout,
+                                    (long long)T * N * HW, B, HW, N, D, scale, m->sa_eps, st));
       if (su_mfma) {
-        SF_TRY(sf_slot_update_mfma_ex(pnum, pden, P, s_in, m->sa_gru_ih_p, m->sa_gru_hh_p, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g,
+        SF_TRY(sf_slot_update_mfma_ex(pnum, pden, P, s_in, gru_ih_p, m->sa_gru_hh_p, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g,
                                       m->mlp_ln_b, m->sa_mlp_w1_p, m->mlp_b1, m->sa_mlp_w2_p, m->mlp_b2, s_out,
                                       last_it ? post_slots + (long long)t * N * D : nullptr, (long long)T * N * D, m->sa_q_ln_g,
-                                      m->sa_q_ln_b, m->sa_q_w_p, last_it ? nullptr : q, B, N, ln_eps, st));
+                                      m->sa_q_ln_b, q_w_p, last_it ? nullptr : q, B, N, ln_eps, st));
         float* tmp = s_in;
         s_in = s_out;
         s_out = tmp;
         continue;
       }
-      SF_TRY(sf_slot_update_ex(pnum, pden, P, s_in, m->gru_w_ih, m->gru_w_hh, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g,
+      SF_TRY(sf_slot_update_ex(pnum, pden, P, s_in, gru_ih_t, m->gru_w_hh, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g,
                                m->mlp_ln_b, m->mlp_w1, m->mlp_b1, m->mlp_w2, m->mlp_b2, s_out,
                                last_it ? post_slots + (long long)t * N * D : nullptr, (long long)T * N * D,
-                               m->sa_q_ln_g, m->sa_q_ln_b, m->sa_q_w_t, (last_it || !m->sa_q_w_t) ? nullptr : q, B, N, D, Hm, ln_eps,
+                               m->sa_q_ln_g, m->sa_q_ln_b, q_w_t, (last_it || !q_w_t) ? nullptr : q, B, N, D, Hm, ln_eps,
                                st));
-      if (!last_it && !m->sa_q_w_t)   // no transposed copy of project_q given: the LN-fused GEMM produces q
-        SF_TRY(sf_linear_ex(s_out, sf_rows(D), m->sa_q_w, nullptr, m->sa_q_ln_g, m->sa_q_ln_b, ln_eps, nullptr, sf_rows(D), 0, q,
+      if (!last_it && !q_w_t)   // no transposed copy of project_q given: the LN-fused GEMM produces q
+        SF_TRY(sf_linear_ex(s_out, sf_rows(D), q_w, nullptr, m->sa_q_ln_g, m->sa_q_ln_b, ln_eps, nullptr, sf_rows(D), 0, q,
                             sf_rows(D), R, D, D, 0, st));
       float* tmp = s_in;
       s_in = s_out;

@@ -25,6 +25,9 @@ constexpr size_t PM_LDS = (size_t)4 * PM_PLANE * sizeof(__bf16) + (2 * PM_ROWS +
 static_assert((size_t)PM_ROWS * PM_H2S * 4 <= (size_t)2 * PM_PLANE * 2, "f32 tile must fit in the B planes");
 }  // namespace
 
+// FEAT: stop after the LayerNorm of the Slot-Attention inputs and write those 128 features per pixel (f32) to `kv` instead of
+// k|v = [Wk;Wv] LN(h2) -- the folded Slot Attention (engine.hip) works on the normalised features directly.
+template <bool FEAT>
 __global__ __launch_bounds__(PM_NT) void pixel_mlp_kv_kernel(
     const float* __restrict__ x, const float* __restrict__ ln0_g, const float* __restrict__ ln0_b,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(PM_NT) void pixel_mlp_kv_kernel(
   store_w128(wr2);
   f32x4 wr3[8];  // first half of [Wk;Wv] (rows 0..127), consumed after the LN(128)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) wr3[i] = *(const f32x4*)(wkv + (long long)(q0 + 16 * i) * PM_C1 + 4 * d4);
+  for (int i = 0; i < 8; ++i) wr3[i] = FEAT ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(wkv + (long long)(q0 + 16 * i) * PM_C1 + 4 * d4);
   __syncthreads();
 
   // ---- P2: h2 = h1 W2^T + b2 -> f32 tile (over the B planes) ------------------------------------------------
@@ -187,12 +190,17 @@ __global__ __launch_bounds__(PM_NT) void pixel_mlp_kv_kernel(
     for (int i = 0; i < 8; ++i) {
       const int c = part * 32 + 4 * i;
       const f32x4 g = *(const f32x4*)(PV + 2 * PM_C1 + c), be = *(const f32x4*)(PV + 3 * PM_C1 + c);
-      bf16x4 hi, lo;
-      split4((hv[i] - mean) * rstd * g + be, hi, lo);
-      *(bf16x4*)(Ah + row * PM_LB1 + c) = hi;
-      *(bf16x4*)(Al + row * PM_LB1 + c) = lo;
+      if constexpr (FEAT) {
+        if (m0 + row < M) *(f32x4*)(kv + (long long)(m0 + row) * PM_C1 + c) = (hv[i] - mean) * rstd * g + be;
+      } else {
+        bf16x4 hi, lo;
+        split4((hv[i] - mean) * rstd * g + be, hi, lo);
+        *(bf16x4*)(Ah + row * PM_LB1 + c) = hi;
+        *(bf16x4*)(Al + row * PM_LB1 + c) = lo;
+      }
     }
   }
+  if constexpr (FEAT) return;
   __syncthreads();  // everyone has read its part of the f32 tile: the B planes may be overwritten
 
   // ---- P4: k|v = LN(h2) [Wk;Wv]^T, two 128-column halves ---------------------------------------------------
@@ -226,15 +234,35 @@ int sf_pixel_mlp_kv_ex(const float* x, const float* ln0_g, const float* ln0_b, c
   if (C0 != PM_C0 || C1 != PM_C1 || ND != PM_ND || M <= 0 || !b1 || !b2) return 1;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)pixel_mlp_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)pixel_mlp_kv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)PM_LDS);
     if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
     attr = true;
   }
   static_assert(PM_LDS <= 160 * 1024, "LDS budget");
   sf_prof_begin(SF_K_LINEAR, st, 2.0 * M * (double)(PM_C0 * PM_C1 + PM_C1 * PM_C1 + PM_C1 * PM_ND));
-  hipLaunchKernelGGL(pixel_mlp_kv_kernel, dim3((M + PM_ROWS - 1) / PM_ROWS), dim3(PM_NT), PM_LDS, st, x, ln0_g, ln0_b,
+  hipLaunchKernelGGL(pixel_mlp_kv_kernel<false>, dim3((M + PM_ROWS - 1) / PM_ROWS), dim3(PM_NT), PM_LDS, st, x, ln0_g, ln0_b,
                      w1, b1, w2, b2, ln1_g, ln1_b, wkv, kv, M, eps);
+  sf_prof_end(SF_K_LINEAR, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+bool sf_pixel_mlp_feat_ok(int C0, int C1) { return C0 == PM_C0 && C1 == PM_C1; }
+
+// encoder_out_layer + norm_inputs only: feat [M][128] = LN(fc2(relu(fc1(LN(x)))))
+int sf_pixel_mlp_feat_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
+                         const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st) {
+  if (M <= 0) return 0;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)pixel_mlp_kv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PM_LDS);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    attr = true;
+  }
+  sf_prof_begin(SF_K_LINEAR, st, 2.0 * M * (double)(PM_C0 * PM_C1 + PM_C1 * PM_C1));
+  hipLaunchKernelGGL(pixel_mlp_kv_kernel<true>, dim3((M + PM_ROWS - 1) / PM_ROWS), dim3(PM_NT), PM_LDS, st, x, ln0_g, ln0_b, w1, b1, w2,
+                     b2, ln1_g, ln1_b, nullptr, feat, M, eps);
   sf_prof_end(SF_K_LINEAR, st);
   SF_CHECK_LAUNCH();
   return 0;

@@ -17,6 +17,9 @@ int sf_sample_dist_ex(const float* dist, const float* noise, SfRowMap nmap, floa
 int sf_copy_rows_ex(const float* src, SfRowMap smap, float* dst, SfRowMap dmap, int rows, int cols,
                     hipStream_t st);
 int sf_sa_pick_partials(int HW);
+bool sf_pixel_mlp_feat_ok(int C0, int C1);
+int sf_pixel_mlp_feat_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
+                         const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st);
 bool sf_slot_update_mfma_ok(int D, int H, int P);
 int sf_slot_update_mfma_ex(const float* part_num, const float* part_den, int P, const float* slots_prev, const void* gru_ih_p,
                            const void* gru_hh_p, const float* gru_b_ih, const float* gru_b_hh, const float* ln_g, const float* ln_b,
