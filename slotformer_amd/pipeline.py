@@ -81,7 +81,7 @@ class EncodeRolloutPipeline:
     partition: 'pair' (default; see the module docstring), 'three', 'two' (one encode stream on `encode_cu_word`, the
     rollout on the complement) or 'none' (plain streams, shared CUs).  encode_cu_word: see encode_mask_words.
     steal_steps: time steps of convolutions per batch computed on the rollout stream (may be fractional: 1.25 = one step,
-    two for every fourth batch); None = 1.25 for 'pair', 1 for 'two', 0 for 'three' (the rollout is the longer side there).
+    two for every fourth batch); None = 0.75 for 'pair', 1 for 'two', 0 for 'three' (the rollout is the longer side there).
     """
 
     def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=None, use_graph=True,
@@ -102,7 +102,7 @@ class EncodeRolloutPipeline:
         # slot buffers / graphs / workspaces: one per batch in flight -- 'pair': two rolling out + one being encoded + one spare
         self.NB = 4 if partition == 'pair' else 2
         if steal_steps is None:
-            steal_steps = {'pair': 1.25, 'two': 1, 'three': 0}.get(partition, 1)
+            steal_steps = {'pair': 0.75, 'two': 1, 'three': 0}.get(partition, 1)
         self.steal = max(0.0, min(float(steal_steps), float(self.T)))   # may be fractional: see _steal_of
         self._masked = []
         self._lib = _lib.lib()
