@@ -1,21 +1,30 @@
 #!/usr/bin/env python
 """bench.py -- SAVi-encode + SlotFormer rollout throughput on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch of synthetic video resident in HBM:
-StoSAVi encode of B x 6 frames (128x128, 7 slots, 2 Slot-Attention iterations) followed by a
-50-step SlotFormer rollout (d=256, 4 layers, 8 heads) -- config C2 of SURVEY.md 8.
-frames/s = n_gpus * B * (6 + 50) * steps / wall.
+One "step" = one pass of the hot path over one batch of synthetic video resident in HBM: slot extraction of the burn-in
+frames (StoSAVi / STEVE encode) followed by the autoregressive SlotFormer rollout.  Default = config C2 of SURVEY.md 8
+(the configuration BASELINE.json's metric is quoted on): B = 32 videos of 128x128, 7 slots, 6 burn-in frames + 50 rollout
+steps, d = 256, 4 layers.      frames/s = n_gpus * B * (burn_in + rollout) * steps / wall.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --config C4        # Physion STEVE + 8-layer SlotFormer, B = 16, 6 + 40
+    python bench.py --config C5        # PHYRE SAVi + SingleStepSlotRollouter, B = 64 (--batch 8: the per-GPU share on 8 GPUs), 1 + 80
 
 The timed schedule is the product one: `slotformer_amd.pipeline.EncodeRolloutPipeline` (the same object
 `harness.extract_and_rollout` uses, tested bit-identical to the serial path in tests/test_pipeline_gpu.py), fed from a
 ring of three DIFFERENT resident inputs, with the results of every batch copied out of the slot buffers.
 
-Multi-GPU: videos shard on the batch axis, one process per GPU, weights replicated, NO
-collective on the timed path -> weak scaling with B=32 per GPU.
+Multi-GPU: videos shard on the batch axis, one process per GPU, weights replicated, NO collective on the timed path
+ -> weak scaling with B videos per GPU (`--batch 4 --gpus 8` is the strong-scaling split of one global batch
+of 32; the pipeline is not tuned for B = 4 and no 8-GPU node was available to measure either curve).
+
+Roofline objects: `frac` of every kernel object divides its algorithmic work per launch by the GRAPH-REPLAY launch
+duration of the committed rocprof trace of this command (profiles/r*_pmc_traffic.json: avg_launch_us_trace; the timed
+region replays hipGraphs, where HIP events cannot be placed between kernels) -- recomputable from the committed CSVs by
+division.  The durations measured live in this run with HIP events around eager launches are reported beside it
+(`avg_launch_us_events`; they carry 3-5 us of event overhead per launch).
 """
 import argparse
 import ctypes as C
@@ -34,34 +43,80 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak; bf16x3 issues 3 bf16 MFMA flops per algorithmic flop
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec peak (6.3 TB/s achievable)
-T_BURN, T_ROLL, RES = 6, 50, 128
-N_SLOTS, SLOT_D = 7, 128
 CLS_NAMES = ['conv_nhwc_implicit_gemm', 'conv_first', 'linear_gemm', 'slot_attn_iter', 'slot_update', 'attention', 'ffn_fused', 'seam']
-ROLL_FLOPS_PER_FRAME = 274.7e6   # algorithmic FLOPs per predicted frame per video
-ENC_FLOPS_PER_FRAME = 3.06e9     # SURVEY.md 8d / DESIGN.md 4: per encoded frame
 
 
-def c2_configs():
-    from slotformer_amd import configs
-    return configs.C2_SAVI, configs.C2_ROLL
+def bench_configs():
+    """name -> (savi cfg, rollout cfg, single-step?, default B, burn-in, rollout steps, resolution, description)"""
+    from slotformer_amd import configs as c
+    steve = dict(c.C4_STEVE)
+    # the image side (dVAE, token decoder) is not on this path: the reference's Physion sizes, never run here
+    steve.update(dvae_dict=dict(down_factor=4, vocab_size=4096, dvae_ckp_path=''),
+                 dec_dict=dict(dec_type='slate', dec_num_layers=4, dec_num_heads=4, dec_d_model=192),
+                 loss_dict=dict(use_img_recon_loss=False))
+    return {
+        'C2': (c.C2_SAVI, c.C2_ROLL, False, 32, 6, 50, 128,
+               'C2: CLEVRER StoSAVi 128x128 (7 slots, D=128, 2 SA iters, stochastic kernels, MLP predictor) encode of 6 burn-in '
+               'frames + SlotFormer (d=256, 4 layers, 8 heads, ffn 1024, L=42) 50-step rollout'),
+        'C4': (steve, c.C4_ROLL, False, 16, 6, 40, 128,
+               'C4: Physion STEVE 128x128 (6 slots, D=192, 2 SA iters, Transformer+LSTM predictor) encode of 6 burn-in frames + '
+               'SlotFormer (d=256, 8 layers, 8 heads, ffn 1024, L=36) 40-step rollout'),
+        'C5': (c.C5_SAVI, c.C5_ROLL, True, 64, 1, 80, 128,
+               'C5: PHYRE SAVi 128x128 (8 slots, D=128, Transformer+LSTM predictor, deterministic kernels) encode of 1 frame + '
+               'SingleStepSlotRollouter (d=256, 8 layers, window growing to 6 frames = 48 tokens) 80-step rollout'),
+    }
 
 
-def build_models(dev):
-    """Random-init weights of the C2 architecture (torch default initialisers, seed 0)."""
+def build_models(dev, cfg):
+    """Random-init weights of the configuration's architecture (torch default initialisers, seed 0)."""
     from slotformer_amd import configs
     from slotformer_amd.base_slots import build_model
-    from slotformer_amd.video_prediction.models import SlotRollouter
-    scfg, rcfg = c2_configs()
+    from slotformer_amd.video_prediction.models import SlotRollouter, SingleStepSlotRollouter
+    scfg, rcfg, single = cfg[0], cfg[1], cfg[2]
     torch.manual_seed(0)
     savi = build_model(configs.ParamsView(scfg)).eval()
     savi.testing = True
-    roll = SlotRollouter(**rcfg['rollout_dict']).eval()
-    return savi.to(dev), roll.to(dev)
+    roll = (SingleStepSlotRollouter if single else SlotRollouter)(**rcfg['rollout_dict']).eval()
+    return (savi.to(dev), roll.to(dev)) if dev is not None else (savi, roll)
 
 
-def synthetic_img(B, seed=1234):
+def synthetic_img(B, T, res, seed=1234):
     rs = np.random.RandomState(seed)
-    return torch.from_numpy((rs.rand(B, T_BURN, 3, RES, RES) * 2 - 1).astype(np.float32))
+    return torch.from_numpy((rs.rand(B, T, 3, res, res) * 2 - 1).astype(np.float32))
+
+
+def encode_flops_per_frame(savi, folded=False):
+    """Algorithmic FLOPs of the reference's encode per frame (savi.py:220-250, 66-102, 367-416): CNN, per-pixel MLP, k / v
+    projections, Slot-Attention iterations, slot update.  folded=True leaves out the k / v projection this library folds into
+    project_q / the GRU input matrix (exact algebra; the work is gone, not moved)."""
+    ch, ks = list(savi.enc_channels), savi.enc_ks
+    HW = 64 * 64
+    f = 0.0
+    for i in range(len(ch) - 1):
+        f += 2.0 * HW * ch[i + 1] * ch[i] * ks * ks
+    Ce, D, N, Hm = savi.enc_out_channels, savi.slot_size, savi.num_slots, savi.slot_mlp_size
+    f += 2.0 * HW * (ch[-1] * Ce + Ce * Ce)                      # encoder_out_layer
+    if not folded:
+        f += 2.0 * HW * Ce * D * 2                               # project_k, project_v
+    it = savi.num_iterations
+    f += it * (4.0 * HW * N * D)                                 # logits + weighted sum
+    f += it * N * (2.0 * D * D + 2.0 * 3 * D * D * 2 + 4.0 * D * Hm)   # project_q, GRUCell, residual MLP
+    return f
+
+
+def rollout_flops(roll, T, H):
+    """Algorithmic FLOPs of one video's H-step rollout as the reference computes it (slotformer.py:85-126,
+    single_step_slotformer.py:49-90): in_proj of the whole window, every layer on every row, out_proj of the newest frame."""
+    N, C_, d = roll.num_slots, roll.in_proj.in_features, roll.in_proj.out_features
+    nl, ffn = len(roll.transformer_encoder.layers), roll.transformer_encoder.layers[0].linear1.out_features
+    single = hasattr(roll, 'cond_len')
+    W = roll.cond_len if single else roll.history_len
+    tot = 0.0
+    for s in range(H):
+        nf = min(s + 1, W) if single else W
+        L = nf * N
+        tot += 2.0 * L * C_ * d + nl * (2.0 * L * d * 3 * d + 4.0 * L * L * d + 2.0 * L * d * d + 4.0 * L * d * ffn) + 2.0 * N * d * C_
+    return tot
 
 
 def committed_profile(key):
@@ -79,21 +134,23 @@ def committed_profile(key):
         return {}
 
 
+KERNEL_CLASS = {'conv5x5_halo': 'conv', 'ffn_partial_kernel': 'ffn_fused', 'ffn64_parts_kernel': 'ffn_fused', 'ffn_wide_parts_kernel': 'ffn_fused',
+                'attn_oproj_kernel': 'attention', 'seam_kernel': 'seam', 'sa_attn_mfma_kernel': 'slot_attn', 'sa_attn_fold_kernel': 'slot_attn'}
+
+
 def dominant_kernel():
-    """The kernel with the largest total device time in the newest committed rocprof summary of this command
+    """The kernel class with the largest total device time in the newest committed rocprof summary of this command
     (profiles/r*_kernel_stats.csv) -> key of the roofline object that becomes `roofline`."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_stats.csv')))
-    names = {'conv5x5_halo': 'conv', 'ffn_partial_kernel': 'ffn_fused', 'ffn64_parts_kernel': 'ffn_fused', 'attn_oproj_kernel': 'attention',
-             'seam_kernel': 'seam',
-             'sa_attn_mfma_kernel': 'slot_attn'}
+    files = [f for f in files if 'training' not in f]
     if not files:
         return 'ffn_fused', None
     tot = {}
     try:
         for r in csv.DictReader(open(files[-1])):
-            for pat, key in names.items():
+            for pat, key in KERNEL_CLASS.items():
                 if pat in r['Name']:
                     tot[key] = tot.get(key, 0.0) + float(r['Percentage'])
     except (KeyError, ValueError):
@@ -124,29 +181,34 @@ def cpu_model_string():
     return platform.processor() or platform.machine()
 
 
-def cpu_baseline(sample_B):
-    """The oracle (CPU port of the reference path, torch fp32) timed on the host cores on a
-    bounded sample: sample_B videos of the same workload."""
+def cpu_baseline(cfg, B_full, sample_B):
+    """The oracle (CPU port of the reference path, torch fp32) timed on the host cores on a bounded sample: sample_B videos of the
+    same workload at the fastest thread count, plus one pass each on ONE thread and on the full batch."""
     import oracle
-    from slotformer_amd import configs
-    scfg, rcfg = c2_configs()
-    from slotformer_amd.base_slots import build_model
-    from slotformer_amd.video_prediction.models import SlotRollouter
-    torch.manual_seed(0)
-    savi = build_model(configs.ParamsView(scfg))
-    roll = SlotRollouter(**rcfg['rollout_dict'])
+    scfg, rcfg, single, _, T, H, res, _ = cfg
+    savi, roll = build_models(None, cfg)
     ssd = {k: v.detach() for k, v in savi.state_dict().items()}
     rsd = {'rollouter.' + k: v.detach() for k, v in roll.state_dict().items()}
-    img = synthetic_img(sample_B)
-    noise = torch.randn(sample_B, T_BURN, N_SLOTS, SLOT_D)
+    N, D = roll.num_slots, roll.in_proj.in_features
+    steve = scfg['model'] == 'STEVE'
 
-    def run():
-        with torch.no_grad():
-            post = oracle.savi_encode(img, ssd, scfg, noise=noise)['post_slots']
-            return oracle.rollouter_forward(post, T_ROLL, rsd, rcfg['rollout_dict'])
+    def make(nv):
+        img = synthetic_img(nv, T, res)
+        noise = torch.randn(nv, T, N, D)
 
-    # pick the thread count that is fastest on this host (more threads than ~32 only add
-    # synchronisation cost at these sizes; 256 hardware threads ran >100x slower)
+        def run():
+            with torch.no_grad():
+                if steve:
+                    post = oracle.steve_encode(img, ssd, scfg)['slots']
+                else:
+                    post = oracle.savi_encode(img, ssd, scfg, noise=noise)['post_slots']
+                fwd = oracle.single_step_rollouter_forward if single else oracle.rollouter_forward
+                return fwd(post, H, rsd, rcfg['rollout_dict'])
+        return run
+
+    run = make(sample_B)
+    # pick the thread count that is fastest on this host (more threads than ~32 only add synchronisation cost at these
+    # sizes; 256 hardware threads ran >100x slower)
     ncpu = os.cpu_count() or 1
     best_t, best = None, None
     for th in [t for t in (8, 16, 32, 64) if t <= ncpu] or [ncpu]:
@@ -159,14 +221,30 @@ def cpu_baseline(sample_B):
             best, best_t = dt, th
     torch.set_num_threads(best_t)
     reps, t0 = 0, time.perf_counter()
-    while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 40):
+    while reps < 3 or (time.perf_counter() - t0 < 8.0 and reps < 40):
         run()
         reps += 1
     dt = (time.perf_counter() - t0) / reps
-    return dict(value=sample_B * (T_BURN + T_ROLL) / dt, unit='frames/s', cores=best_t, kind='port', cpu=cpu_model_string(),
-                sample=f'oracle (torch-CPU fp32 restatement of the reference path), {sample_B} of 32 videos, '
-                f'{reps} passes of encode 6 frames + 50-step rollout, {dt:.2f} s per pass, '
-                f'{best_t} threads (fastest of 8/16/32/64) on a {ncpu}-hardware-thread host ({cpu_model_string()})')
+    fr = T + H
+    # the full batch, one pass at the same thread count
+    runB = make(B_full)
+    t0 = time.perf_counter()
+    runB()
+    dtB = time.perf_counter() - t0
+    # ONE thread: one pass over a quarter of the sample (bounded: a single core needs seconds per video)
+    n1 = max(1, sample_B // 4)
+    run1 = make(n1)
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    run1()
+    dt1 = time.perf_counter() - t0
+    torch.set_num_threads(best_t)
+    return dict(value=sample_B * fr / dt, unit='frames/s', cores=best_t, kind='port', cpu=cpu_model_string(),
+                sample=f'oracle (torch-CPU fp32 restatement of the reference path), {sample_B} of {B_full} videos, '
+                f'{reps} passes of encode {T} frames + {H}-step rollout, {dt:.2f} s per pass, '
+                f'{best_t} threads (fastest of 8/16/32/64) on a {ncpu}-hardware-thread host ({cpu_model_string()})',
+                full_batch={'value': B_full * fr / dtB, 'videos': B_full, 'cores': best_t, 'seconds': dtB, 'passes': 1},
+                one_thread={'value': n1 * fr / dt1, 'videos': n1, 'cores': 1, 'seconds': dt1, 'passes': 1})
 
 
 def log(msg):
@@ -178,8 +256,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='videos per GPU')
+    ap.add_argument('--warmup', type=int, default=6)
+    ap.add_argument('--config', choices=['C2', 'C4', 'C5'], default='C2', help='BASELINE.json configuration (default C2: the one the metric is quoted on)')
+    ap.add_argument('--batch', type=int, default=None, help='videos per GPU (default: the configuration\'s batch)')
     ap.add_argument('--no-graph', action='store_true', help='launch the rollout eagerly instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8)
@@ -210,22 +289,29 @@ def main():
     if args.precision:
         lib.sf_set_precision(1 if args.precision == 'bf16x3' else 0)
     prec = 'bf16x3' if lib.sf_get_precision() == 1 else 'f32'
-    B = args.batch
-    savi, roll = build_models(dev)
+    cfg = bench_configs()[args.config]
+    scfg, rcfg, single, B_def, T_BURN, T_ROLL, RES, workload = cfg
+    B = args.batch or B_def
+    savi, roll = build_models(dev, cfg)
+    N_SLOTS, SLOT_D = roll.num_slots, roll.in_proj.in_features
     # a ring of three DIFFERENT resident inputs: consecutive batches never see the same frames
-    ring = [synthetic_img(B, seed=1234 + 1000 * k + rank).to(dev) for k in range(3)]
+    ring = [synthetic_img(B, T_BURN, RES, seed=1234 + 1000 * k + rank).to(dev) for k in range(3)]
     cu_word = os.environ.get('SF_BENCH_CU_SPLIT', 'ff')          # hex mask word, or rows<R> (pipeline.encode_mask_words)
     cu_word = cu_word if cu_word.startswith('rows') else int(cu_word, 16)
     steal = os.environ.get('SF_BENCH_STEAL')                   # None: the partition's default
     steal = None if steal is None else float(steal)
     partition = os.environ.get('SF_BENCH_PARTITION', 'pair')   # 'pair' | 'three' | 'two' | 'none' (pipeline.EncodeRolloutPipeline)
+    group = os.environ.get('SF_BENCH_GROUP')
+    group = None if group is None else int(group)
 
     with torch.no_grad():
         log('building the pipeline (first eager rollouts + graph capture)')
         pipe = EncodeRolloutPipeline(savi, roll, B, T_BURN, T_ROLL, encode_cu_word=cu_word, steal_steps=steal,
-                                     use_graph=not args.no_graph, partition=partition)
+                                     use_graph=not args.no_graph, partition=partition, group=group)
         overlap = not args.no_overlap
-        graph = pipe.graphs[0] if pipe.graphs else None
+        G = pipe.G                      # batches per rollout graph
+        unit0 = pipe.units[0]
+        graph = unit0.graph
 
         def run(n, out):
             return pipe.run([ring[j % 3] for j in range(n)], None, out=out, serial=not overlap)
@@ -236,43 +322,49 @@ def main():
             torch.cuda.synchronize()
 
         shape = (B, T_BURN + T_ROLL, N_SLOTS, SLOT_D)
-        out_w = torch.empty((max(args.warmup, 1), ) + shape, device=dev)
+        out_w = torch.empty((max(args.warmup, 6), ) + shape, device=dev)
         out_t = torch.empty((args.steps, ) + shape, device=dev)
         run(args.warmup, out_w)
         torch.cuda.synchronize()
         assert torch.isfinite(out_w[:args.warmup]).all(), 'non-finite slots in the warmup batches'
         log('warmup done')
-        # conv + Slot-Attention launches are event-timed live (library brackets on the launch stream)
-        # (every LIVE_EVERY-th launch of the two classes: two event records around a launch cost its stream a few microseconds,
-        #  and the encode stream is the longer side of the pipeline)
-        LIVE_EVERY = int(os.environ.get('SF_BENCH_LIVE_EVERY', '4'))
-        lib.sf_profile_sample(LIVE_EVERY)
-        lib.sf_profile_enable(int(os.environ.get('SF_BENCH_LIVE_MASK', str((1 << 0) | (1 << 3)))))
-        read_profile(lib)
+        # the timed region carries no measurement probes: HIP-event brackets around the conv / Slot-Attention launches of the encode
+        # stream cost that stream ~5 % even when only every 4th launch is bracketed (341 vs 359 k frames/s)
         barrier()
         t0 = time.perf_counter()
         run(args.steps, out_t)
         barrier()
         elapsed = time.perf_counter() - t0
         log(f'timed region done: {elapsed:.3f}s')
+        unit_done, unit_batches = (pipe.completion_events, pipe.completion_batches) if overlap else (None, None)
+        # conv + Slot-Attention launches LIVE: a second pass of the same schedule with library brackets (HIP events on the launch
+        # stream) around every LIVE_EVERY-th launch of the two classes
+        LIVE_EVERY = int(os.environ.get('SF_BENCH_LIVE_EVERY', '4'))
+        lib.sf_profile_sample(LIVE_EVERY)
+        lib.sf_profile_enable(int(os.environ.get('SF_BENCH_LIVE_MASK', str((1 << 0) | (1 << 3)))))
+        read_profile(lib)
+        run(max(args.warmup, 6), out_w)
+        torch.cuda.synchronize()
         lib.sf_profile_enable(0)
         lib.sf_profile_sample(1)
         prof = read_profile(lib)
-        batch_done = pipe.completion_events if overlap else None
         assert torch.isfinite(out_t).all(), 'non-finite slots in the timed batches'
         # the three ring inputs give three different results (a stale slot buffer would repeat one)
         if args.steps >= 3:
             assert not torch.equal(out_t[0, :, :T_BURN], out_t[1, :, :T_BURN])
 
         # ---- untimed extras: the two halves alone, per-kernel event timings ----
-        noise = torch.randn(B, T_BURN, N_SLOTS, SLOT_D, device=dev)
+        noise = engine.kernel_noise(savi, None, B, T_BURN, dev)
 
         def encode():
             post, _, _ = engine.savi_encode(savi, ring[0], noise=noise)
-            pipe.bufs[0][:, :T_BURN].copy_(post)
+            unit0.buf[:B, :T_BURN].copy_(post)
 
-        def rollout():
-            graph.replay() if graph is not None else engine.rollout(roll, pipe.bufs[0], T_BURN, T_ROLL, ws_slot=('pipe', 0))
+        def rollout_eager():
+            engine.rollout(roll, unit0.buf, T_BURN, T_ROLL, ws_slot=unit0.key, opts=pipe.rollout_opts)
+
+        def rollout():          # one rollout UNIT: G batches
+            graph.replay() if graph is not None else rollout_eager()
 
         def timed_on(stream, fn, n=3):
             stream.wait_stream(torch.cuda.current_stream())
@@ -290,63 +382,58 @@ def main():
         t_enc = timed_on(torch.cuda.current_stream(), encode)
         lib.sf_profile_enable(0)
         prof_iso = read_profile(lib)  # same kernels with nothing else on the GPU
-        t_roll = timed_on(torch.cuda.current_stream(), rollout)
+        t_roll = timed_on(torch.cuda.current_stream(), rollout)      # seconds per unit (G batches)
         part_ms = None
         if overlap and pipe.cu_split:
             def lane_encode(li):
                 st, lo, hi = pipe.lanes[li]
-                return lambda: pipe._encode(ring[0], noise, pipe.bufs[0], None, lo, hi, li)
+                return lambda: pipe._encode(ring[0], noise, unit0.buf[:B], None, lo, hi, li)
 
             part_ms = {'encode_lane_ms_on_its_cus': [round(1e3 * timed_on(pipe.lanes[li][0], lane_encode(li)), 4) for li in range(len(pipe.lanes))],
                        'encode_lane_videos': [hi - lo for _, lo, hi in pipe.lanes],
-                       'rollout_ms_on_its_cus': 1e3 * timed_on(pipe.s_roll, rollout)}
+                       'rollout_unit_ms_on_its_cus': 1e3 * timed_on(pipe.s_roll, rollout), 'batches_per_rollout_unit': G}
             part_ms['encode_ms_on_its_cus'] = max(part_ms['encode_lane_ms_on_its_cus'])
-        # the rollout layer kernels, event-timed: (a) alone on the whole chip in one eager rollout, (b) LIVE in a pipelined
+        # the rollout layer kernels, event-timed: (a) alone on the whole chip in one eager rollout unit, (b) LIVE in a pipelined
         # pass with the product schedule (encode stream busy on its CUs) but eager launches -- inside the timed region they
         # replay from a hipGraph, where HIP events cannot be inserted between the kernels
         lib.sf_profile_enable((1 << 5) | (1 << 6) | (1 << 7))
         read_profile(lib)
-        engine.rollout(roll, pipe.bufs[0], T_BURN, T_ROLL, ws_slot=('pipe', 0))
+        rollout_eager()
         torch.cuda.synchronize()
         prof_roll = read_profile(lib)
         prof_roll_live = {}
         if overlap:
-            graphs, pipe.graphs = pipe.graphs, []
-            pipe.run([ring[j % 3] for j in range(4)], None, out=out_w if out_w.shape[0] >= 4 else None)
+            saved = [(u, u.graph) for u in pipe.units]
+            for u in pipe.units:
+                u.graph = None
+            pipe.run([ring[j % 3] for j in range(4 * G)], None)
             torch.cuda.synchronize()
-            pipe.graphs = graphs
+            for u, g in saved:
+                u.graph = g
             prof_roll_live = read_profile(lib)
         lib.sf_profile_enable(0)
         pcie = None
         if args.pcie:
             # PCIe-inclusive variant (never `value`): frames start in pinned host memory and the slots end there
-            img_h = [r.cpu().pin_memory() for r in ring]
-            out_h = torch.empty(shape, dtype=torch.float32).pin_memory()
-            stage = torch.empty_like(ring[0])
-
-            def step_pcie(j):
-                stage.copy_(img_h[j % 3], non_blocking=True)
-                post, _, _ = engine.savi_encode(savi, stage, noise=noise)
-                pipe.bufs[0][:, :T_BURN].copy_(post)
-                rollout()
-                out_h.copy_(pipe.bufs[0], non_blocking=True)
-
-            step_pcie(0)
+            from slotformer_amd import harness
+            nv = args.steps * B
+            vids_h = torch.cat([ring[j % 3].cpu() for j in range(args.steps)], 0).pin_memory()
+            harness.extract_and_rollout(savi, roll, vids_h[:4 * B], T_ROLL, batch_size=B, to_host=True)   # warm-up
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for j in range(args.steps):
-                step_pcie(j)
+            out_h = harness.extract_and_rollout(savi, roll, vids_h, T_ROLL, batch_size=B, to_host=True)
             torch.cuda.synchronize()
-            t_p = (time.perf_counter() - t1) / args.steps
-            pcie = {'frames_per_s_host_to_host_serial': B * (T_BURN + T_ROLL) / t_p,
-                    'frames_per_s_device_resident_serial': B * (T_BURN + T_ROLL) / (t_enc + t_roll),
-                    'h2d_bytes_per_batch': ring[0].numel() * 4, 'd2h_bytes_per_batch': out_h.numel() * 4,
-                    'note': 'serial (no batch pipelining, copies on the compute stream): upper bound on the PCIe cost'}
+            t_p = time.perf_counter() - t1
+            assert out_h.shape[0] == nv and not out_h.is_cuda
+            pcie = {'frames_per_s_host_to_host': nv * (T_BURN + T_ROLL) / t_p, 'frames_per_s_device_resident': world * B * (T_BURN + T_ROLL) * args.steps / elapsed,
+                    'h2d_bytes_per_batch': ring[0].numel() * 4, 'd2h_bytes_per_batch': int(np.prod(shape)) * 4,
+                    'note': 'harness.extract_and_rollout(to_host=True): frames in pinned host memory, uploaded batch by batch on a copy stream ahead of '
+                            'the encode, slots downloaded behind the rollout; includes building the pipeline (graph capture)'}
         breakdown = None
         if args.breakdown:
             lib.sf_profile_enable(0xff)
             encode()
-            engine.rollout(roll, pipe.bufs[0], T_BURN, T_ROLL, ws_slot=('pipe', 0))
+            rollout_eager()
             torch.cuda.synchronize()
             lib.sf_profile_enable(0)
             breakdown = read_profile(lib)
@@ -359,19 +446,24 @@ def main():
     if rank == 0:
         frames = world * B * (T_BURN + T_ROLL) * args.steps
         step_dist = None
-        if batch_done is not None and len(batch_done) > 2:
-            # device time between the completions of consecutive batches inside the timed region (rank 0)
-            gaps = sorted(batch_done[j - 1].elapsed_time(batch_done[j]) for j in range(1, len(batch_done)))
+        if unit_done is not None and len(unit_done) > 2:
+            # device time between the completions of consecutive rollout units inside the timed region (rank 0), per batch
+            gaps = sorted(unit_done[j - 1].elapsed_time(unit_done[j]) / unit_batches[j] for j in range(1, len(unit_done)))
             pick = lambda q: gaps[min(len(gaps) - 1, int(q * len(gaps)))]  # noqa: E731
-            step_dist = {'p10': pick(0.10), 'median': pick(0.50), 'p90': pick(0.90), 'n': len(gaps)}
+            step_dist = {'p10': pick(0.10), 'median': pick(0.50), 'p90': pick(0.90), 'n': len(gaps), 'batches_per_unit': G,
+                         'note': 'gap between the completions of consecutive rollout units / batches per unit'}
         peak_chip = PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS
         peak_note = ('split-bf16 MFMA: 3 bf16 MFMA flops per algorithmic flop -> roof = 2500/3 TFLOP/s' if prec == 'bf16x3'
                      else 'exact f32 MFMA')
         nl = len(roll.transformer_encoder.layers)
-        launches_per_graph = 1 + T_ROLL * 2 * nl - (T_ROLL - 1)   # the seam launch carries two kernels' worth
-        step_flops = B * (T_BURN * ENC_FLOPS_PER_FRAME + T_ROLL * ROLL_FLOPS_PER_FRAME)
+        enc_f, enc_f_fold = encode_flops_per_frame(savi), encode_flops_per_frame(savi, folded=True)
+        roll_f = rollout_flops(roll, T_BURN, T_ROLL)             # per video
+        step_flops = B * (T_BURN * enc_f + roll_f)
+        step_flops_fold = B * (T_BURN * enc_f_fold + roll_f)
+        metric = ('rollout frames/sec at B=32, 128x128, 7 slots, 6+50 steps (SAVi-encode + SlotFormer rollout)' if args.config == 'C2' and B == 32 else
+                  f'rollout frames/sec, config {args.config} at B={B}, {RES}x{RES}, {N_SLOTS} slots, {T_BURN}+{T_ROLL} steps (slot extraction + SlotFormer rollout)')
         res = {
-            'metric': 'rollout frames/sec at B=32, 128x128, 7 slots, 6+50 steps (SAVi-encode + SlotFormer rollout)',
+            'metric': metric,
             'value': frames / elapsed,
             'unit': 'frames/s',
             'n_gpus': world,
@@ -384,20 +476,20 @@ def main():
             'dtype': 'f32 storage; matmul/conv on split-bf16 MFMA (bf16x3: hi*hi+hi*lo+lo*hi, f32 accumulate)' if prec == 'bf16x3' else 'f32',
             'data': 'synthetic',
             'config': {
-                'workload': 'C2: CLEVRER StoSAVi 128x128 (7 slots, D=128, 2 SA iters, stochastic kernels, MLP '
-                'predictor) encode of 6 burn-in frames + SlotFormer (d=256, 4 layers, 8 heads, ffn 1024, L=42) '
-                '50-step rollout; random-init weights',
+                'workload': workload + '; random-init weights',
+                'name': args.config,
                 'batch_per_gpu': B, 'global_batch': B * world, 'burn_in': T_BURN, 'rollout': T_ROLL,
                 'parallelism': f'dp{world}: videos sharded on the batch axis, no collective on the timed path',
                 'inputs': 'ring of 3 different resident batches; the slots of every batch are copied out of the slot buffers',
                 'schedule': 'slotformer_amd.pipeline.EncodeRolloutPipeline (product code, tests/test_pipeline_gpu.py)',
-                'rollout_launch': f'hipGraph replay ({launches_per_graph} kernel nodes)' if graph is not None else 'eager',
-                'pipelining': ('encode of batch i+1 (stream A) overlaps the rollout graph of batch i (stream B); every batch still '
-                               'runs its full encode + 50-step rollout inside the timed region') if overlap else 'none',
-                'work_stealing': (f'the CNN features of the first {pipe.steal:g} time step(s) (average) of batch j+{2 * len(pipe.roll_streams)} are '
-                                  'computed on the rollout stream of batch j right after its rollout') if (overlap and pipe.steal) else 'none',
-                'cu_partition': ('two rollout streams (batches j and j+1 roll out side by side) on CU rows 0-4 of all four shader engines of every '
-                                 'XCD (160 CUs), the encode stream on rows 5-7 (96 CUs)' if pipe.partition == 'pair' else
+                'rollout_launch': (f'hipGraph replay, one graph per rollout unit of {G} batch(es) = {G * B} videos') if graph is not None else 'eager',
+                'rollout_opts': None if pipe.rollout_opts is None else {k: getattr(pipe.rollout_opts, k) for k, _ in pipe.rollout_opts._fields_},
+                'pipelining': ('encode of later batches (stream A) overlaps the rollout graphs of earlier units (streams B, C); every batch still '
+                               'runs its full encode + rollout inside the timed region') if overlap else 'none',
+                'work_stealing': (f'the CNN features of the first {pipe.steal:g} time step(s) (average) of a batch are computed on a rollout stream, '
+                                  f'behind the rollout of the unit {pipe.lead} units earlier') if (overlap and pipe.steal) else 'none',
+                'cu_partition': ((f'two rollout streams (two units roll out side by side) on {pipe.rollout_cus} CUs (whole CU rows of all four shader '
+                                  f'engines of every XCD), the encode stream on the other {pipe.encode_cus}') if pipe.partition == 'pair' else
                                  ('rollout stream: CU rows 0-6 of shader engines 1-3 of every XCD (168 CUs); encode lane 0: shader engine 0 '
                                   f'(64 CUs, {pipe.lanes[0][2] - pipe.lanes[0][1]} videos of every batch); encode lane 1: CU row 7 of shader engines 1-3 '
                                   f'(24 CUs, {pipe.lanes[-1][2] - pipe.lanes[-1][1]} videos)') if pipe.partition == 'three' else
@@ -405,19 +497,24 @@ def main():
                                   'number in every XCD), rollout stream on the complement')) if (overlap and pipe.cu_split) else 'none',
             },
             'encode_ms': 1e3 * t_enc,
-            'rollout_ms': 1e3 * t_roll,
+            'rollout_ms': 1e3 * t_roll / G,
+            'rollout_unit_ms': 1e3 * t_roll,
             'partitioned_ms': part_ms,
             'ms_per_step_distribution': step_dist,
             'encoded_frames_per_s': B * T_BURN / t_enc,
-            'predicted_frames_per_s': B * T_ROLL / t_roll,
+            'predicted_frames_per_s': G * B * T_ROLL / t_roll,
             'whole_step_tflops': step_flops * args.steps * world / elapsed / 1e12,
             'whole_step_flops': step_flops,
+            'whole_step_flops_without_folded_kv_projection': step_flops_fold,
+            'whole_step_tflops_without_folded_kv_projection': step_flops_fold * args.steps * world / elapsed / 1e12,
+            'flops_per_encoded_frame': enc_f, 'flops_per_video_rollout': roll_f,
         }
         # ---- roofline objects, one per hot kernel; `roofline` = the one that dominates the committed rocprof summary of this
         #      command (profiles/r*_kernel_stats.csv), the others stay as secondary keys ----
         objs = {}
-        for key, name in (('ffn_fused', 'ffn_partial_kernel / ffn64_parts_kernel (sum of the 4 head-pair partials + LN2 + FFN1 + ReLU + FFN2 on a 32- or '
-                           '64-row tile x 256-wide hidden chunk; chunk partials out, last-arriver reduction on the last layer only)'),
+        W_FR = roll.cond_len if single else roll.history_len
+        for key, name in (('ffn_fused', 'ffn_wide_parts_kernel<2> / <1> / ffn_partial_kernel (sum of the 4 head-pair partials + LN2 + FFN1 + ReLU + FFN2 on a '
+                           '128- / 64- / 32-row tile x 256-wide hidden chunk; chunk partials out, last-arriver reduction + step boundary on the last layer)'),
                           ('attention', 'attn_oproj_kernel (LN1 + q|k|v of a head pair + softmax(qk^T)v + out-proj partial; one workgroup per '
                            '(head pair, video))'),
                           ('seam', 'seam_kernel (last-layer FFN + step boundary of step s and the layer-0 attention of step s+1 in one grid, '
@@ -426,28 +523,32 @@ def main():
             if not iso:
                 continue
             fl = iso['work'] / iso['launches']
-            src = live or iso
-            cus = pipe.rollout_cus if (live and pipe.cu_split) else 256
-            tf = fl / (src['avg_us'] * 1e-6) / 1e12
-            pm = committed_profile(key)
+            pm = committed_profile(key) if args.config == 'C2' else {}
+            us_trace = pm.get('avg_launch_us_trace')
+            us = us_trace or (live or iso)['avg_us']
+            tf = fl / (us * 1e-6) / 1e12
             objs[key] = {
                 'kernel': name, 'bound': 'mfma', 'achieved': tf, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': tf / peak_chip,
-                'peak_note': peak_note + '; whole-chip roof (the launch has 128-168 workgroups, one per CU)',
-                'flops_per_launch': fl, 'avg_launch_us': src['avg_us'], 'launches': src['launches'], 'cus_available': cus,
-                'measured': ('HIP events around every launch on the rollout stream in a pipelined pass with the timed schedule '
-                             '(encode stream busy on its CUs), eager launches' if live else 'HIP events around every launch, kernel alone'),
-                'avg_launch_us_isolated': iso['avg_us'], 'frac_isolated': fl / (iso['avg_us'] * 1e-6) / 1e12 / peak_chip,
+                'peak_note': peak_note + '; whole-chip roof',
+                'flops_per_launch': fl, 'avg_launch_us': us,
+                'measured': ('flops_per_launch (mean over the launches of one rollout unit, library accounting) / avg_launch_us_rocprof = the mean graph-replay '
+                             f'duration of this kernel class in the committed rocprofv3 --kernel-trace of this command ({pm.get("source")}); '
+                             'avg_launch_us_events = HIP events around eager launches in this run') if us_trace else
+                            'HIP events around eager launches in this run (no committed rocprof trace for this configuration)',
+                'avg_launch_us_rocprof': us_trace,
+                'avg_launch_us_events': (live or iso)['avg_us'], 'avg_launch_us_events_isolated': iso['avg_us'],
+                'frac_events': fl / ((live or iso)['avg_us'] * 1e-6) / 1e12 / peak_chip,
+                'launches_per_unit': iso['launches'], 'rows_per_launch_full_window': G * B * W_FR * N_SLOTS,
+                'cus_available': pipe.rollout_cus if pipe.cu_split else 256,
                 'traffic': pm.get('traffic_bytes_per_launch'),
-                'mfma_busy_frac': pm.get('mfma_busy_frac'), 'avg_launch_us_rocprof': pm.get('avg_launch_us_trace'), 'pmc_source': pm.get('source'),
-                'limiter': 'per-CU ingest (~100 GB/s per workgroup: weight fragments + activations re-fetched by every workgroup) and '
-                           'dependent-launch latency, not the matrix pipe (DESIGN.md 4)',
+                'mfma_busy_frac': pm.get('mfma_busy_frac'), 'pmc_source': pm.get('source'),
+                'limiter': 'per-CU ingest of weight fragments + partial activations and dependent-launch latency below ~128 rows per workgroup; '
+                           'the matrix pipe at 128 rows per workgroup (DESIGN.md 4)',
             }
-        roll_flops = ROLL_FLOPS_PER_FRAME * B * T_ROLL
-        launches_per_graph = 1 + T_ROLL * 2 * nl - (T_ROLL - 1 if 'seam' in prof_roll else 0)
+        roll_flops = roll_f * G * B
         res['roofline_rollout_graph'] = {
-            'kernel': f'hipGraph of the 50-step rollout: ring init + per step {nl} x (attention + out-proj partials, fused FFN), the last FFN '
-                      f'(+ step boundary) sharing a launch with the next step\'s first attention = {launches_per_graph} launches',
-            'bound': f'latency ({launches_per_graph} dependent launches, M = B*L = {B * 42} rows); MFMA roof shown for scale',
+            'kernel': f'hipGraph of one rollout unit ({G} batches, {G * B} videos): ring init + per step {nl} x (attention + out-proj partials, fused FFN)',
+            'bound': f'latency ({sum(v["launches"] for v in prof_roll.values())} dependent launches, {G * B} videos per launch); MFMA roof shown for scale',
             'achieved': roll_flops / t_roll / 1e12, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': roll_flops / t_roll / 1e12 / peak_chip,
             'ms': 1e3 * t_roll, 'us_per_step': 1e6 * t_roll / T_ROLL, 'seam_timeouts': int(lib.sf_seam_timeouts()),
         }
@@ -459,39 +560,46 @@ def main():
             enc_cus = pipe.encode_cus / len(pipe.lanes) if (overlap and pipe.cu_split) else 256
             iso = prof_iso.get('conv_nhwc_implicit_gemm')
             flops_per_launch = iso['work'] / iso['launches'] if iso else flops_live
-            ach_iso = flops_per_launch / (iso['avg_us'] * 1e-6) / 1e12 if iso else None
-            pm = committed_profile('conv_nhwc_implicit_gemm')
+            pm = committed_profile('conv_nhwc_implicit_gemm') if args.config == 'C2' else {}
+            us_trace = pm.get('avg_launch_us_trace')
+            us = us_trace or (iso['avg_us'] if iso else None)
+            ach_iso = flops_per_launch / (us * 1e-6) / 1e12 if us else None
             objs['conv'] = {
                 'kernel': ('conv5x5_halo_kernel' if prec == 'bf16x3' else 'sf_gemm_kernel<128,64,...,conv_nhwc>') + ' (5x5 conv 64->64 @64x64; ' + peak_note + ')',
-                'bound': 'lds-read / mfma (matrix pipes busy ~40 % of the launch at 2.4 GHz, 55 % at the 1.86 GHz the chip sustains in this '
-                         'kernel; fragment reads from LDS and the un-overlapped halo fill bound it, DESIGN.md 4 and 7)',
+                'bound': 'lds-read / mfma (matrix pipes busy ~40 % of the launch at 2.4 GHz; fragment reads from LDS and the un-overlapped halo '
+                         'fill bound it, DESIGN.md 4 and 7)',
                 'achieved': ach_iso, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': (ach_iso / peak_chip) if ach_iso else None,
-                'avg_launch_us': iso['avg_us'] if iso else None,
-                'measured': 'HIP events around the launches (library brackets on the launch stream): `achieved` = the kernel alone on the whole '
-                            'chip in the untimed pass of this run, every launch; `live` = inside the timed region on the encode partition, '
-                            f'every {LIVE_EVERY}th launch (the brackets cost the stream they sit on a few microseconds each)',
+                'avg_launch_us': us, 'avg_launch_us_rocprof': us_trace, 'avg_launch_us_events_isolated': iso['avg_us'] if iso else None,
+                'measured': 'flops_per_launch / avg_launch_us_rocprof (the whole-chip launches of the committed rocprof trace, default queue); '
+                            '`live` = HIP events (library brackets on the launch stream) in a second pass of the timed schedule, on the encode partition, '
+                            f'every {LIVE_EVERY}th launch',
                 'live': {'achieved': ach, 'cus': enc_cus, 'avg_launch_us': conv['avg_us'], 'launches': conv['launches'],
                          'flops_per_launch': flops_live, 'frac_of_partition_peak': ach / (peak_chip * enc_cus / 256.0),
-                         'note': 'inside the timed region, beside the rollout graph of the previous batch; `cus` = CUs per launch (the encode '
-                                 'lanes run side by side on their own CUs, each on its share of the videos: mean over the lanes); stolen '
-                                 'convolutions (rollout stream) are not part of this average'},
-                'traffic': pm.get('traffic_bytes_per_launch'), 'mfma_busy_frac': pm.get('mfma_busy_frac'),
-                'avg_launch_us_rocprof': pm.get('avg_launch_us_trace'), 'pmc_source': pm.get('source'),
+                         'note': 'a pipelined pass of the timed schedule, beside the rollout graphs; stolen convolutions (rollout streams) are not part of this average'},
+                'traffic': pm.get('traffic_bytes_per_launch'), 'mfma_busy_frac': pm.get('mfma_busy_frac'), 'pmc_source': pm.get('source'),
                 'traffic_unit': 'bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE)',
-                'algorithmic_bytes_per_launch': 2 * 32 * 4096 * 64 * 4 + 64 * 1600 * 4, 'flops_per_launch': flops_per_launch,
+                'algorithmic_bytes_per_launch': 2 * B * 4096 * 64 * 4 + 64 * 1600 * 4, 'flops_per_launch': flops_per_launch,
             }
         sa = prof.get('slot_attn_iter')
         if sa:
-            gbps = sa['work'] / sa['launches'] / (sa['avg_us'] * 1e-6) / 1e9
             iso = prof_iso.get('slot_attn_iter')
-            bytes_per_launch = iso['work'] / iso['launches'] if iso else sa['work'] / sa['launches']
+            ub = iso['work'] / iso['launches'] if iso else sa['work'] / sa['launches']   # unique bytes (library accounting: k == v counted once)
+            pm = committed_profile('slot_attn_iter') if args.config == 'C2' else {}
+            us_trace = pm.get('avg_launch_us_trace')
+            us = us_trace or (iso['avg_us'] if iso else None)
+            kv_bytes = 2.0 * B * 4096 * SLOT_D * 4
             objs['slot_attn'] = {
-                'kernel': 'sa_attn_mfma_kernel<128> (one Slot-Attention iteration over K,V)', 'bound': 'hbm',
-                'achieved': bytes_per_launch / (iso['avg_us'] * 1e-6) / 1e9 if iso else None, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
-                'frac': (bytes_per_launch / (iso['avg_us'] * 1e-6) / 1e9 / PEAK_HBM_GBPS) if iso else None,
-                'avg_launch_us': iso['avg_us'] if iso else None,
-                'traffic': committed_profile('slot_attn_iter').get('traffic_bytes_per_launch'), 'bytes_per_launch': bytes_per_launch,
-                'live': {'achieved': gbps, 'avg_launch_us': sa['avg_us'], 'launches': sa['launches'],
+                'kernel': 'Slot-Attention iteration (logits, softmax over slots, per-slot weighted sums) over the normalised pixel features -- keys and '
+                          'values are the SAME array after the k / v fold (savi.py:66-89)', 'bound': 'hbm',
+                'unique_bytes_per_launch': ub, 'bytes_per_launch': ub,
+                'achieved': ub / (us * 1e-6) / 1e9 if us else None, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                'frac': (ub / (us * 1e-6) / 1e9 / PEAK_HBM_GBPS) if us else None,
+                'frac_unique': (ub / (us * 1e-6) / 1e9 / PEAK_HBM_GBPS) if us else None,
+                'frac_vs_reference_kv_bytes': (kv_bytes / (us * 1e-6) / 1e9 / PEAK_HBM_GBPS) if us else None,
+                'reference_kv_bytes_per_launch': kv_bytes,
+                'avg_launch_us': us, 'avg_launch_us_rocprof': us_trace, 'avg_launch_us_events_isolated': iso['avg_us'] if iso else None,
+                'traffic': pm.get('traffic_bytes_per_launch'), 'pmc_source': pm.get('source'),
+                'live': {'achieved': sa['work'] / sa['launches'] / (sa['avg_us'] * 1e-6) / 1e9, 'avg_launch_us': sa['avg_us'], 'launches': sa['launches'],
                          'bytes_per_launch': sa['work'] / sa['launches'],
                          'cus': pipe.encode_cus / len(pipe.lanes) if (overlap and pipe.cu_split) else 256},
             }
@@ -503,12 +611,12 @@ def main():
         for k, v in objs.items():
             res['roofline_' + k] = v
         if breakdown:
-            res['kernel_breakdown_one_step'] = breakdown
+            res['kernel_breakdown_one_unit'] = breakdown
         if pcie:
             res['pcie_inclusive'] = pcie
         if world == 1 and not args.no_cpu_baseline:
             log('cpu baseline ...')
-            res['cpu_baseline'] = cpu_baseline(args.cpu_sample)
+            res['cpu_baseline'] = cpu_baseline(cfg, B, min(args.cpu_sample, B))
         # RCCL prints its version banner through C stdio (flushed at exit when stdout is a pipe): push it out first so
         # that the JSON line is the last thing on stdout
         try:

@@ -274,6 +274,15 @@ size_t sf_ffn_packed_bytes(int d_model, int ffn);
 int sf_pack_ffn_weights(const float* lin1_w, const float* lin2_w, void* lin1_packed, void* lin2_packed, int d_model,
                         int ffn, void* stream);
 
+/* FFN half of a pre-LN nn.TransformerEncoderLayer (d_model 256, ffn 1024; slotformer.py:72-80) on M rows whose input arrives
+ * as 4 partial sums ap [4][M][256] (ap_stride floats apart; the head-pair partials of the layer's attention launch):
+ *   x2 = ((ap0 + ap1) + ap2) + ap3;   y = x2 + lin2(relu(lin1(LN2(x2))))
+ * written as the four hidden-chunk partials xp [4][M][256] with y = ((xp0 + xp1) + xp2) + xp3 (the next layer's attention
+ * launch sums them while loading).  rows_per_wg: 32 / 64 / 128 rows per workgroup (0 = default); every choice gives the
+ * same bits.  Needs w->lin1_packed / lin2_packed. */
+int sf_ffn_chunk_partials_f32(const sf_tfm_layer* w, const float* ap, long long ap_stride, float* xp, long long xp_stride, int M,
+                              int ffn, int rows_per_wg, void* stream);
+
 /* SlotRollouter / SingleStepSlotRollouter (slotformer.py:48-134, single_step_slotformer.py:6-90). */
 typedef struct {
   int num_slots, slot_size, d_model, num_layers, num_heads, ffn_dim, norm_first;
@@ -299,6 +308,20 @@ size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B);
  * for single_step); frames n_in .. n_in+pred_len-1 are written.  T_total >= n_in + pred_len. */
 int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws,
                    size_t ws_bytes, void* stream);
+
+/* Per-call options of a rollout: they apply to THIS call on the calling thread only (thread-local inside the library; the
+ * reference drives forward() from one host thread per GPU, base_slots/extract_slots.py:128), whereas sf_set_precision /
+ * sf_set_seam_fused / sf_set_ffn_rows64 set process-wide DEFAULTS.  Every choice is bit-identical except `precision`. */
+typedef struct {
+  int precision;    /* -1: default; 0 exact f32, 1 split-bf16, 2 single-pass bf16 (= sf_rollout_bf16) */
+  int seam_fused;   /* -1: default; 0 / 1: seam launches off / on */
+  int ffn_rows;     /* 0: default; 32 / 64 / 128 rows per workgroup of the chunk-partial FFN launches */
+  int attn_videos;  /* 0: default (1); 1 / 2 videos per workgroup of the layer attention launches */
+} sf_rollout_opts;
+int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws, size_t ws_bytes,
+                        void* stream, const sf_rollout_opts* opts); /* opts == NULL: sf_rollout_f32 */
+/* 1 when sf_rollout_f32 would run seam launches for this model / batch with the calling thread's defaults */
+int sf_rollout_uses_seam(const sf_rollouter* m, int B);
 
 /* ---- differentiable building blocks for the slot-level layers --------------------------------
  * (predictor, kernel distribution: savi.py:190-200, predictor.py:47-73).  Backward of y = act(x W^T + b): dW [N,K],

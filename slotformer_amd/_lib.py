@@ -26,6 +26,10 @@ class sf_rollouter(C.Structure):
                 ('layers', C.POINTER(sf_tfm_layer)), ('in_proj_packed', C.c_void_p), ('out_proj_packed', C.c_void_p)]
 
 
+class sf_rollout_opts(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('precision', 'seam_fused', 'ffn_rows', 'attn_videos')]
+
+
 class sf_tfm_layer_grads(C.Structure):
     _fields_ = [(n, FP) for n in (
         'norm1_g', 'norm1_b', 'in_proj_w', 'in_proj_b', 'out_proj_w', 'out_proj_b',
@@ -146,6 +150,9 @@ SIGNATURES = {
     'sf_bilinear_resize_f32': (I, [FP, FP, LL, I, I, I, I, VP]),
     'sf_rollout_workspace_bytes': (SZ, [C.POINTER(sf_rollouter), I]),
     'sf_rollout_f32': (I, [C.POINTER(sf_rollouter), FP, I, I, I, VP, SZ, VP]),
+    'sf_rollout_opts_f32': (I, [C.POINTER(sf_rollouter), FP, I, I, I, VP, SZ, VP, C.POINTER(sf_rollout_opts)]),
+    'sf_rollout_uses_seam': (I, [C.POINTER(sf_rollouter), I]),
+    'sf_ffn_chunk_partials_f32': (I, [C.POINTER(sf_tfm_layer), FP, LL, FP, LL, I, I, I, VP]),
     'sf_slot_attn_iter_bwd_workspace_bytes': (SZ, [I, I, I, I]),
     'sf_slot_attn_iter_bwd_f32': (I, [FP, FP, I, LL, FP, FP, FP, I, FP, FP, FP, I, FP, I, I, I, I, F32, F32, VP, SZ, VP]),
     'sf_slot_attention_train_workspace_bytes': (SZ, [C.POINTER(sf_slot_attention), I, I, I]),

@@ -286,12 +286,7 @@ static int launch_fa(const float* x, const float* ln_g, const float* ln_b, float
   constexpr size_t lds = FaCfg<HD>::lds_bytes;
   static_assert(lds <= 160 * 1024, "fused attention: LDS budget");
   auto kern = qkv_attn_kernel<HD, NK>;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    attr = true;
-  }
+  SF_TRY(sf_ensure_dyn_lds((const void*)kern, (size_t)(lds)));
   sf_prof_begin(SF_K_MHA, st, 6.0 * B * L * (double)d * d + 4.0 * (double)B * nheads * Lq * L * HD);
   hipLaunchKernelGGL(kern, dim3(nheads, B), dim3(FA_NT), lds, st, x, ln_g, ln_b, ln_eps, w, bias, out, L, Lq, d);
   sf_prof_end(SF_K_MHA, st);

@@ -124,12 +124,7 @@ static int launch_cf(const float* img, long long frame_stride, const float* w, c
   auto kern = conv_first_kernel<STRIDE>;
   constexpr size_t lds = CfGeo<STRIDE>::lds;
   static_assert(lds <= 80 * 1024, "first conv: two workgroups per CU");
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    attr = true;
-  }
+  SF_TRY(sf_ensure_dyn_lds((const void*)kern, (size_t)(lds)));
   sf_prof_begin(SF_K_CONV_FIRST, st, 2.0 * (double)F * Ho * CF_TW * CF_CO * CF_K);
   hipLaunchKernelGGL(kern, dim3(F * (Ho / CF_TR)), dim3(CF_NT), lds, st, img, frame_stride, w, bias, add, out, Ho, Hin, Win,
                      relu);

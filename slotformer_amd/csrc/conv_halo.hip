@@ -184,15 +184,8 @@ __global__ __launch_bounds__(NT) void conv5x5_halo_kernel(const float* __restric
 int sf_conv5x5_halo_ex(const float* in, const float* w_packed, const float* bias, const float* add, float* out, int F,
                        int H, int W, int Cin, int Cout, int ks, int relu, hipStream_t st) {
   if (W != TW || Cin != CH || Cout != CH || ks != KS || (H % TR) != 0 || F <= 0) return 1;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv5x5_halo_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv5x5_halo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    attr = true;
-  }
+  SF_TRY(sf_ensure_dyn_lds((const void*)conv5x5_halo_kernel<false>, LDS_BYTES));
+  SF_TRY(sf_ensure_dyn_lds((const void*)conv5x5_halo_kernel<true>, LDS_BYTES));
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   sf_prof_begin(SF_K_CONV_NHWC, st, 2.0 * (double)F * H * W * Cout * ks * ks * Cin);
   if (sf_get_precision() == 2)

@@ -184,13 +184,7 @@ int sf_mha_ex(const float* qkv, float* out, int B, int L, int Lq, int d, int nhe
   if (lds_tile <= 160 * 1024) {
 #define MHA_LAUNCH(HD)                                                                                              \
   {                                                                                                                 \
-    static bool attr = false;                                                                                       \
-    if (!attr) {                                                                                                    \
-      hipError_t e_ = hipFuncSetAttribute((const void*)mha_tile_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                          160 * 1024);                                                              \
-      if (e_ != hipSuccess) return sf_set_err((int)e_, hipGetErrorString(e_), __FILE__, __LINE__);                   \
-      attr = true;                                                                                                  \
-    }                                                                                                               \
+    SF_TRY(sf_ensure_dyn_lds((const void*)mha_tile_kernel<HD>, (size_t)160 * 1024));                                   \
     hipLaunchKernelGGL(mha_tile_kernel<HD>, grid, dim3(256), lds_tile, st, qkv, 3 * d, out, d, L, Lq, d, scale);     \
   }
     switch (hd) {

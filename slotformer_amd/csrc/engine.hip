@@ -197,7 +197,8 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   const bool boundary_fused = ring_mode && bfuse_env;
   // seam launches (layer_fused.hip): the last-layer FFN + boundary of step s and the layer-0 attention of step s+1 in one
   // grid; needs every workgroup of it co-resident at one per CU -- 160 fit the 168-CU rollout partition
-  const bool seam = boundary_fused && sf_get_seam_fused() != 0 && sf_seam_blocks(B, N) <= 160;
+  const int seam_opt = sf_thread_opts().seam;
+  const bool seam = boundary_fused && (seam_opt >= 0 ? seam_opt != 0 : sf_get_seam_fused() != 0) && sf_seam_blocks(B, N) <= 160;
   // layers 0 .. n-2 leave their output as four FFN chunk partials that the next attention sums while loading (SF_FFN_PARTS=0:
   // the FFN's last-arriving workgroup sums them, as the last layer always does)
   static const bool parts_env = [] {
@@ -364,15 +365,57 @@ extern "C" int sf_set_seam_fused(int on) {
   return 0;
 }
 
+namespace {
+// the calling thread's options for the duration of one engine call
+struct OptsScope {
+  SfThreadOpts saved;
+  explicit OptsScope(const SfThreadOpts& o) : saved(sf_thread_opts()) { sf_thread_opts() = o; }
+  ~OptsScope() { sf_thread_opts() = saved; }
+};
+}  // namespace
+
+// sf_rollout_f32 with per-call options (include/slotformer_hip.h, sf_rollout_opts): arithmetic mode, seam launches, rows
+// per FFN workgroup, videos per attention workgroup.  The options live in thread-local state for the duration of the call,
+// so concurrent calls from other host threads (one per GPU in the reference's drivers, extract_slots.py:128) keep theirs.
+int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws, size_t ws_bytes,
+                        void* stream, const sf_rollout_opts* opts) {
+  if (!opts) return sf_rollout_f32(m, slots, B, T_total, pred_len, ws, ws_bytes, stream);
+  SF_REQUIRE(opts->precision >= -1 && opts->precision <= 2, "sf_rollout_opts: precision must be -1 (default), 0, 1 or 2");
+  SF_REQUIRE(opts->ffn_rows == 0 || opts->ffn_rows == 32 || opts->ffn_rows == 64 || opts->ffn_rows == 128,
+             "sf_rollout_opts: ffn_rows must be 0 (default), 32, 64 or 128");
+  SF_REQUIRE(opts->attn_videos >= 0 && opts->attn_videos <= 2, "sf_rollout_opts: attn_videos must be 0 (default), 1 or 2");
+  SfThreadOpts o = sf_thread_opts();
+  if (opts->precision >= 0) o.precision = opts->precision;
+  if (opts->seam_fused >= 0) o.seam = opts->seam_fused ? 1 : 0;
+  if (opts->ffn_rows > 0) o.ffn_rows = opts->ffn_rows;
+  if (opts->attn_videos > 0) o.attn_videos = opts->attn_videos;
+  OptsScope scope(o);
+  const bool plain = (o.precision == 2);
+  const bool old_plain = t_plain_gemms;
+  if (plain) t_plain_gemms = true;
+  const int rc = sf_rollout_f32(m, slots, B, T_total, pred_len, ws, ws_bytes, stream);
+  t_plain_gemms = old_plain;
+  return rc;
+}
+
+// 1 when sf_rollout_f32 would use seam launches for this model / batch with the calling thread's defaults (a caller that
+// wants to verify sf_seam_timeouts() after the call only needs to when this is non-zero)
+int sf_rollout_uses_seam(const sf_rollouter* m, int B) {
+  if (!m || B <= 0 || !m->layers) return 0;
+  bool packed = m->in_proj_packed && m->out_proj_packed;
+  for (int l = 0; l < m->num_layers; ++l)
+    packed = packed && m->layers[l].lin1_packed && m->layers[l].lin2_packed && m->layers[l].attn_in_packed && m->layers[l].attn_out_packed;
+  const int seam_opt = sf_thread_opts().seam;
+  return packed && sf_get_precision() >= 1 && m->norm_first &&
+         sf_layer_fused_ok(m->d_model, m->num_heads, m->ffn_dim, m->window_len * m->num_slots) &&
+         sf_step_boundary_ok(m->d_model, m->slot_size) && (seam_opt >= 0 ? seam_opt != 0 : sf_get_seam_fused() != 0) &&
+         sf_seam_blocks(B, m->num_slots) <= 160;
+}
+
 int sf_rollout_bf16(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws, size_t ws_bytes,
                     void* stream) {
-  const int old = sf_get_precision();
-  sf_set_precision(2);
-  t_plain_gemms = true;
-  const int rc = sf_rollout_f32(m, slots, B, T_total, pred_len, ws, ws_bytes, stream);
-  t_plain_gemms = false;
-  sf_set_precision(old);
-  return rc;
+  sf_rollout_opts o = {2, -1, 0, 0};
+  return sf_rollout_opts_f32(m, slots, B, T_total, pred_len, ws, ws_bytes, stream, &o);
 }
 
 // ---------------------------------------------------------------------------------------------

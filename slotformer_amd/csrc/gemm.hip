@@ -578,13 +578,7 @@ static int launch_cfg(const SfGemmArgs& a, hipStream_t stream) {
   constexpr size_t lds = lds_main > lds_red ? lds_main : lds_red;
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = sf_gemm_kernel<BM, BN, WM, WN, KW, BKT, PD, NBUF, ALOAD, LN, BF3>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    attr_set = true;
-  }
+  SF_TRY(sf_ensure_dyn_lds((const void*)kern, (size_t)(lds)));
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
   const int cls = ALOAD == ALOAD_PLAIN ? SF_K_LINEAR : (ALOAD == ALOAD_CONV_NCHW ? SF_K_CONV_FIRST : SF_K_CONV_NHWC);
   sf_prof_begin(cls, stream, 2.0 * (double)a.M * (double)a.N * (double)a.K);
@@ -652,6 +646,8 @@ static int launch_by_id(int id, const SfGemmArgs& a, hipStream_t st) {
 // each operand; kernels without a single-pass variant keep mode 1).  SF_PRECISION=f32 | bf16 selects 0 | 2 at load time.
 static int g_precision = -1;
 extern "C" int sf_get_precision(void) {
+  const int t = sf_thread_opts().precision;   // a per-call option of this thread (sf_rollout_opts) wins over the process default
+  if (t >= 0) return t;
   if (g_precision < 0) {
     const char* e = getenv("SF_PRECISION");
     g_precision = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : ((e && strcmp(e, "bf16") == 0) ? 2 : 1);

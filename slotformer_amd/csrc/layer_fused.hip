@@ -60,7 +60,7 @@ __device__ __forceinline__ void split4(__bf16* hp, __bf16* lp, int off, f32x4 v)
 }  // namespace
 
 __device__ unsigned lf_seam_timeouts;   // seam hand-offs that gave up waiting (sf_seam_timeouts): must stay 0
-__device__ long long lf_ts[32];   // phase timestamps of one workgroup (SF_LF_DBG & 16), read by sf_debug_read_ts
+__device__ long long lf_ts[64];   // phase timestamps of one workgroup (SF_LF_DBG & 16), read by sf_debug_read_ts
 #define LF_TS(i) do { if ((dbg & 16) && blockIdx.x == 0 && threadIdx.x == 0) lf_ts[i] = wall_clock64(); } while (0)
 #define LF_TL(i) do { if ((dbg & 16) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 256) lf_ts[i + 10] = wall_clock64(); } while (0)
 #define LF_TQ(i) do { if constexpr (SEAM) { if ((dbg & 16) && hp == 0 && b == 0 && threadIdx.x == 0) lf_ts[i] = wall_clock64(); } } while (0)
@@ -165,6 +165,9 @@ struct AttnArgs {
 // the next attention's prologue (+129 KB of loads, ~1.3 us).
 template <bool RING, bool SEAM, bool PART = false>
 __device__ __forceinline__ void attn_body(const AttnArgs& A, const int hp, const int b, const SeamArgs seam) {
+  // no floating-point contraction in this function: whether the compiler fuses a*b + c into an fma may differ between two
+  // instantiations / variants of the same source, and the variants must produce the same bits (LayerNorm statistics)
+#pragma clang fp contract(off)
   const float* __restrict__ xin = A.xin;
   const long long x_batch_stride = A.x_batch_stride;
   const float* __restrict__ pe = A.pe;
@@ -181,6 +184,8 @@ __device__ __forceinline__ void attn_body(const AttnArgs& A, const int hp, const
   const int L = A.L, Lq = A.Lq, dbg = A.dbg;
   constexpr int d = LF_D, HD = LF_HD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int s_seam_bad;
+  bool seam_bad = false;   // SEAM: the hand-off wait gave up
   __bf16* Ah = (__bf16*)smem;                                  // [64][A2_AP]  LN1(x), all of K
   __bf16* Al = Ah + FA_ROWS * A2_AP;
   __bf16* QKp = (__bf16*)((char*)smem + A2_QKV_OFF);           // q, k: [2 heads][q,k][hi,lo][64][AT_QP] (over the dead planes)
@@ -290,6 +295,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& A, const int hp, const
   // head pair are chunk kc == hp) and LN(x) planes.  One code path for the stand-alone and the seam kernel: a rollout restarted
   // from its own output must reproduce the original bit for bit, whichever kernel ran the layer.
   auto ln_row = [&](const f32x4& v0, const f32x4& v1, const f32x4& v2, const f32x4& v3, int r, bool ok) {
+#pragma clang fp contract(off)
     const f32x4 vv[NK] = {v0, v1, v2, v3};
 #pragma unroll
     for (int kc = 0; kc < NK; ++kc)
@@ -396,6 +402,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& A, const int hp, const
     proj(std::integral_constant<int, 0>{});
     // ---- the hand-off: tile flags of this video's new frame, then its rows with sc1 loads (+ their position rows) ----
     if (t == 0) {
+      s_seam_bad = 0;
       const int t0 = (b * nslots) / seam.rows_per_tile, t1 = (b * nslots + nslots - 1) / seam.rows_per_tile;
       const long long c0 = wall_clock64();
       while (__hip_atomic_load(seam.flags + t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seam.epoch ||
@@ -404,11 +411,13 @@ __device__ __forceinline__ void attn_body(const AttnArgs& A, const int hp, const
         if (wall_clock64() - c0 > 20000000LL) {   // 0.2 s at 100 MHz: a producer is not resident -- give up, flag the error
           __hip_atomic_store(seam.flags + SEAM_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           atomicAdd(&lf_seam_timeouts, 1u);
+          s_seam_bad = 1;   // the rows were never handed over: this workgroup's output becomes NaN (loud), see the stores
           break;
         }
       }
     }
     __syncthreads();
+    seam_bad = s_seam_bad != 0;
     LF_TQ(11);
     if (late[1]) {
       const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, 0x7fffffff, 0x00020000);
@@ -637,6 +646,10 @@ __device__ __forceinline__ void attn_body(const AttnArgs& A, const int hp, const
       for (int g = 0; g < 4; ++g) {
         f32x4 v = {pacc[4 * g], pacc[4 * g + 1], pacc[4 * g + 2], pacc[4 * g + 3]};
         if (mine) v += *(const f32x4*)(Xs + row * A2_XS + (wave & 1) * 32 + 8 * g + 4 * (lane >> 5)) + bo4[g];
+        if constexpr (SEAM) {
+          // a hand-off that timed out must not produce plausible numbers: NaN travels through the FFN into the slots
+          if (seam_bad) v = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+        }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), apr, off + 32 * g, 0, 16);
       }
     }
@@ -820,6 +833,9 @@ struct FfnArgs {
 };
 
 __device__ __forceinline__ void ffn_body(const FfnArgs& F, const int blk) {
+  // no floating-point contraction in this function: whether the compiler fuses a*b + c into an fma may differ between two
+  // instantiations / variants of the same source, and the variants must produce the same bits (LayerNorm statistics)
+#pragma clang fp contract(off)
   const float* __restrict__ ap = F.ap;
   const long long ap_stride = F.ap_stride;
   const float* __restrict__ ln_g = F.ln_g;
@@ -857,6 +873,9 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& F, const int blk) {
   }
   if (tile >= ntiles) return;
   const int row0 = tile * FB_ROWS;
+  // the residual x2 and the bias b2 ride on chunk 0 -- a rule that does not depend on where a row sits in the batch, so a
+  // video's bits are the same however videos are grouped into batches / rollout units
+  const bool carry = c == 0;
   LF_TS(0);
 
   // small parameter vectors first: vmcnt retires in order, so a late request would wait for every weight fragment
@@ -914,7 +933,7 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& F, const int blk) {
     for (int i = 0; i < 4; ++i) {
       const int r = wave + 8 * i;
       split4(Ah, Al, r * FB_AP + 4 * lane, (x2[i] - mean[i]) * rstd[i] * g + be);
-      if (c == 0) *(f32x4*)(X2 + r * FB_XP + 4 * lane) = x2[i];
+      if (carry) *(f32x4*)(X2 + r * FB_XP + 4 * lane) = x2[i];
     }
   }
   __builtin_amdgcn_sched_barrier(0);   // keep these requests BEHIND the arithmetic above in the instruction stream
@@ -967,12 +986,12 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& F, const int blk) {
   LF_TS(5);
   SbFrags sbf;
 
-  // ---- output tile -> LDS (in place over the x2 stash; chunk 0 adds the residual and the bias), re-read row-major ----
+  // ---- output tile -> LDS (in place over the x2 stash; the carrying chunk adds the residual and the bias), re-read row-major ----
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     float* o = X2 + tok * FB_XP + nb + 8 * g;
     f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-    if (c == 0) v += *(const f32x4*)o + *(const f32x4*)(b2 + nb + 8 * g);
+    if (carry) v += *(const f32x4*)o + *(const f32x4*)(b2 + nb + 8 * g);
     *(f32x4*)o = v;
   }
   __syncthreads();
@@ -1160,79 +1179,78 @@ __global__ __launch_bounds__(LF_NT) void step_boundary_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-// 64-row variant of the chunk-partial FFN (sf_set_ffn_rows64): one workgroup runs TWO 32-row tiles against ONE load of its
-// 256-wide chunk of W1 / W2 (every fragment feeds the MFMAs of both token blocks before its registers take the matching W2
-// fragment).  Per pair of tiles a workgroup then ingests 524 + 256 KB instead of 2 x 652 KB and the launch has half the
-// workgroups.  Alone, a rollout gains nothing from it (84 workgroups of ~15 us instead of 168 of 12.5 us: the launch is a
-// little longer); with two rollouts sharing the CUs (pipeline partition 'pair') the CUs are the bound and the FFN's CU time
-// drops by 40 %.  Same arithmetic per row as ffn_body (k order, operands, LayerNorm), so the partials are bit-identical.
-// LDS: the LN2 planes, the hidden planes and the output tile take turns in one 67.6 KB region (two extra barriers); the
-// residual stash (chunk 0) has its own 66.6 KB.
+// Wide variants of the chunk-partial FFN (per-call option ffn_rows / sf_set_ffn_rows64): one workgroup runs NH 64-row
+// halves -- 64 or 128 rows -- against ONE load of its 256-wide chunk of W1 / W2.  Every W1 fragment stays in registers
+// until the LAST half has consumed it and is then replaced by the matching W2 fragment (the W2 requests ride behind the
+// MFMAs of that half).  Per 128 rows a workgroup ingests 524 KB of weights + 512 KB of head-pair partials instead of
+// 4 x 652 KB with 32-row tiles, and the launch has a quarter of the workgroups: with several rollouts sharing the CUs
+// (pipeline partitions 'pair' / 'pair2') the CUs are the bound, and the FFN's CU time per row drops by 40 % (64 rows) /
+// ~60 % (128 rows).  Same arithmetic per row as ffn_body (k order, operands, LayerNorm), so the partials are
+// bit-identical.
+// LDS: per half one 67.6 KB region in which the LN2 planes, the hidden planes and the f32 output tile take turns.  The
+// residual needs neither LDS nor registers: chunk 0 (which carries x2 + b2, as in ffn_body) stores x2 + b2 into its OUTPUT
+// rows while it normalises them, and the thread that stored a float4 reads it back behind the last FFN2 MFMA (into the
+// registers the weight fragments have left) and adds the FFN2 partial: y_0 + (x2 + b2), the same sum as ffn_body's.
+// Prologue: the head-pair partials arrive in 32-row quarters through two register buffers (2 x 64 VGPRs), the first
+// half of W1 is requested behind the first two quarters, the second half once the last quarter is in flight.
 constexpr int F6_ROWS = 64;
-constexpr size_t F6_R1 = (size_t)2 * F6_ROWS * FB_AP * 2;                      // planes (hi, lo) >= the f32 output tile
-constexpr size_t F6_LDS = F6_R1 + (size_t)F6_ROWS * FB_XP * 4;
+constexpr size_t F6_R1 = (size_t)2 * F6_ROWS * FB_AP * 2;                      // planes (hi, lo) of one half >= its f32 output tile
 static_assert((size_t)F6_ROWS * FB_XP * 4 <= F6_R1, "output tile must fit the plane region");
 
-__global__ __launch_bounds__(LF_NT) void ffn64_parts_kernel(FfnArgs F) {
+template <int NH>
+__global__ __launch_bounds__(LF_NT) void ffn_wide_parts_kernel(FfnArgs F) {
+  // no floating-point contraction in this function: whether the compiler fuses a*b + c into an fma may differ between two
+  // instantiations / variants of the same source, and the variants must produce the same bits (LayerNorm statistics)
+#pragma clang fp contract(off)
+  constexpr int ROWS = F6_ROWS * NH, NQ = 2 * NH;
   const float* __restrict__ ap = F.ap;
   const long long ap_stride = F.ap_stride;
   const uint4* __restrict__ w1p = F.w1p;
   const uint4* __restrict__ w2p = F.w2p;
   const int M = F.M;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __bf16* Ph = (__bf16*)smem;                          // [64][FB_AP]  LN2(x2), later relu(h_c)
-  __bf16* Pl = Ph + F6_ROWS * FB_AP;
-  float* OT = (float*)smem;                            // [64][FB_XP]  output tile (over the dead planes)
-  float* X2 = (float*)((char*)smem + F6_R1);           // [64][FB_XP]  x2 (residual; chunk 0 only)
+  auto PH = [&](int h) { return (__bf16*)((char*)smem + (size_t)h * F6_R1); };   // [64][FB_AP] hi plane of half h (lo follows)
+  auto OTH = [&](int h) { return (float*)((char*)smem + (size_t)h * F6_R1); };   // [64][FB_XP] output tile of half h
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  // pairs of tiles dealt like ffn_body's tiles: the four chunks of a pair share an XCD; left-over pairs one chunk per XCD
-  const int npairs = (F.ntiles + 1) >> 1, blk = blockIdx.x;
-  const int full = (npairs >> 3) << 5;
+  // row tiles dealt like ffn_body's: the four chunks of a tile share an XCD; left-over tiles one chunk per XCD
+  const int ntw = (M + ROWS - 1) / ROWS, blk = blockIdx.x;
+  const int full = (ntw >> 3) << 5;
   int c = (blk >> 3) & (LF_NCH - 1), tp = (blk >> 5) * 8 + (blk & 7);
   if (full > 0 && blk >= full) {
     c = (blk - full) & (LF_NCH - 1);
-    tp = (npairs & ~7) + ((blk - full) >> 2);
+    tp = (ntw & ~7) + ((blk - full) >> 2);
   }
-  if (tp >= npairs) return;
-  const int row0 = tp * F6_ROWS;
+  if (tp >= ntw) return;
+  const int row0 = tp * ROWS;
+#define WTS(i) do { if ((F.dbg & 16) && blockIdx.x == 0 && threadIdx.x == 0) lf_ts[32 + i] = wall_clock64(); } while (0)
+  WTS(0);
   const int tok = lane & 31, nb = wave * 32 + 4 * (lane >> 5);
-  f32x4 b1v[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) b1v[g] = *(const f32x4*)(F.b1 + c * LF_HC + nb + 8 * g);
   const uint4* w1c = w1p + ((long long)(c * 16) * 8 + wave) * 128 + lane;
   const uint4* w2c = w2p + ((long long)(c * 16) * 8 + wave) * 128 + lane;
   bf16x8 wf[16][2];
   auto ldw = [&](const uint4* base, int ks, int plane) { return __builtin_bit_cast(bf16x8, base[(ks * 8) * 128 + plane * 64]); };
   const f32x4 lng = *(const f32x4*)(F.ln_g + 4 * lane), lnb = *(const f32x4*)(F.ln_b + 4 * lane);
-  // ---- prologue (wave owns rows wave + 8 i of each 32-row half, lane = float4 column).  All requests that the LayerNorm needs
-  //      go out first -- the partials of both halves with the first half of W1 between them -- then partials -> x2 ->
-  //      LayerNorm -> planes half by half, and the second half of W1 is requested after the arithmetic ----
+  // ---- prologue (wave owns rows wave + 8 i of each 32-row quarter, lane = float4 column) ----
   f32x4 pr[2][LF_NP][4];
-#pragma unroll
-  for (int hb = 0; hb < 2; ++hb) {
+  const f32x4 b2v = *(const f32x4*)(F.b2 + 4 * lane);
+  float* dst = F.xp + (long long)c * F.xp_stride + 4 * lane;   // thread t owns float4 (row = wave + 8 i, column 4 lane) of the output
+  auto request = [&](int q, f32x4 (&dst)[LF_NP][4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int gr = min(row0 + 32 * hb + wave + 8 * i, M - 1);
+      const int gr = min(row0 + 32 * q + wave + 8 * i, M - 1);
       const float* p = ap + (long long)gr * LF_D + 4 * lane;
 #pragma unroll
-      for (int q = 0; q < LF_NP; ++q) pr[hb][q][i] = *(const f32x4*)(p + q * ap_stride);
+      for (int pq = 0; pq < LF_NP; ++pq) dst[pq][i] = *(const f32x4*)(p + pq * ap_stride);
     }
-    if (hb == 0) {
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        wf[ks][0] = ldw(w1c, ks, 0);
-        wf[ks][1] = ldw(w1c, ks, 1);
-      }
-    }
-  }
-#pragma unroll
-  for (int hb = 0; hb < 2; ++hb) {
+  };
+  auto consume = [&](int q, const f32x4 (&src)[LF_NP][4]) {
+#pragma clang fp contract(off)
     f32x4 x2[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      f32x4 sacc = pr[hb][0][i];
+      f32x4 sacc = src[0][i];
 #pragma unroll
-      for (int q = 1; q < LF_NP; ++q) sacc += pr[hb][q][i];
+      for (int pq = 1; pq < LF_NP; ++pq) sacc += src[pq][i];
       x2[i] = sacc;
     }
     float mean[4], rstd[4];
@@ -1243,89 +1261,147 @@ __global__ __launch_bounds__(LF_NT) void ffn64_parts_kernel(FfnArgs F) {
       const f32x4 dv = x2[i] - mean[i];
       rstd[i] = 1.0f / sqrtf(sf_sum64((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3])) * (1.0f / LF_D) + F.ln_eps);
     }
+    __bf16* Ph = PH(q >> 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = 32 * hb + wave + 8 * i;
-      split4(Ph, Pl, r * FB_AP + 4 * lane, (x2[i] - mean[i]) * rstd[i] * lng + lnb);
-      if (c == 0) *(f32x4*)(X2 + r * FB_XP + 4 * lane) = x2[i];
+      const int r = 32 * (q & 1) + wave + 8 * i;
+      split4(Ph, Ph + F6_ROWS * FB_AP, r * FB_AP + 4 * lane, (x2[i] - mean[i]) * rstd[i] * lng + lnb);
+      // chunk 0 carries the residual and the bias (ffn_body's rule): parked in this thread's own output float4
+      if (c == 0 && row0 + 32 * q + wave + 8 * i < M) *(f32x4*)(dst + (long long)(row0 + 32 * q + wave + 8 * i) * LF_D) = x2[i] + b2v;
+    }
+  };
+  // W1 fragments: k-steps 0..7 behind the first quarter (64 rows) / the third quarter's request (128 rows: two
+  // partial buffers + all of W1 would not fit the 256 registers of a wave), k-steps 8..15 once the last quarter's
+  // partials are in flight or consumed
+  constexpr int Q_LO = NQ > 2 ? 1 : -1, Q_HI = NQ > 2 ? NQ - 2 : NQ - 1;
+  request(0, pr[0]);
+  WTS(1);
+  if (Q_LO < 0) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      wf[ks][0] = ldw(w1c, ks, 0);
+      wf[ks][1] = ldw(w1c, ks, 1);
     }
   }
-  __builtin_amdgcn_sched_barrier(0);
+  request(1, pr[1]);
 #pragma unroll
-  for (int ks = 8; ks < 16; ++ks) {
-    wf[ks][0] = ldw(w1c, ks, 0);
-    wf[ks][1] = ldw(w1c, ks, 1);
+  for (int q = 0; q < NQ; ++q) {
+    consume(q, pr[q & 1]);
+    __builtin_amdgcn_sched_barrier(0);   // requests stay BEHIND the arithmetic above in the instruction stream
+    if (q + 2 < NQ) request(q + 2, pr[q & 1]);
+    if (q == Q_LO) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        wf[ks][0] = ldw(w1c, ks, 0);
+        wf[ks][1] = ldw(w1c, ks, 1);
+      }
+    }
+    if (q == Q_HI) {
+#pragma unroll
+      for (int ks = 8; ks < 16; ++ks) {
+        wf[ks][0] = ldw(w1c, ks, 0);
+        wf[ks][1] = ldw(w1c, ks, 1);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
+  WTS(2);
+  // the FFN1 bias of this lane's hidden columns: requested behind the weights, needed after the first half's MFMAs
+  f32x4 b1v[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) b1v[g] = *(const f32x4*)(F.b1 + c * LF_HC + nb + 8 * g);
   __syncthreads();
 
-  // ---- FFN1 for both token blocks; every fragment's registers then take the matching W2 fragment ----
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
   const int ao = (lane & 31) * FB_AP + 8 * (lane >> 5);
+  f32x16 acc0, acc1;
+  // ---- FFN1, half by half; in the last half every fragment's registers then take the matching W2 fragment ----
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    const bf16x8 xh0 = *(const bf16x8*)(Ph + ao + ks * 16), xl0 = *(const bf16x8*)(Pl + ao + ks * 16);
-    const bf16x8 xh1 = *(const bf16x8*)(Ph + ao + 32 * FB_AP + ks * 16), xl1 = *(const bf16x8*)(Pl + ao + 32 * FB_AP + ks * 16);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl0, acc0, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh0, acc0, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl1, acc1, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh1, acc1, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh1, acc1, 0, 0, 0);
-    wf[ks][0] = ldw(w2c, ks, 0);
-    wf[ks][1] = ldw(w2c, ks, 1);
-  }
-  __syncthreads();   // every wave has read the LN2 planes: the hidden planes take their place
+  for (int h = 0; h < NH; ++h) {
+    const __bf16* Ph = PH(h);
+    const __bf16* Pl = Ph + F6_ROWS * FB_AP;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const f32x4 bv = b1v[g];
-    f32x4 h0, h1;
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      h0[q] = fmaxf(acc0[4 * g + q] + bv[q], 0.f);
-      h1[q] = fmaxf(acc1[4 * g + q] + bv[q], 0.f);
+    for (int ks = 0; ks < 16; ++ks) {
+      const bf16x8 xh0 = *(const bf16x8*)(Ph + ao + ks * 16), xl0 = *(const bf16x8*)(Pl + ao + ks * 16);
+      const bf16x8 xh1 = *(const bf16x8*)(Ph + ao + 32 * FB_AP + ks * 16), xl1 = *(const bf16x8*)(Pl + ao + 32 * FB_AP + ks * 16);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl0, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh0, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl1, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh1, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh1, acc1, 0, 0, 0);
+      if (h == NH - 1) {
+        wf[ks][0] = ldw(w2c, ks, 0);
+        wf[ks][1] = ldw(w2c, ks, 1);
+      }
+      if (h == 0 && (ks & 3) == 3 && ks < 15) WTS(10 + (ks >> 2));
     }
-    split4(Ph, Pl, tok * FB_AP + nb + 8 * g, h0);
-    split4(Ph, Pl, (32 + tok) * FB_AP + nb + 8 * g, h1);
+    WTS(3 + h);
+    __syncthreads();   // every wave has read the LN2 planes of this half: its hidden planes take their place
+    __bf16* Hh = PH(h);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bv = b1v[g];
+      f32x4 h0, h1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        h0[q] = fmaxf(acc0[4 * g + q] + bv[q], 0.f);
+        h1[q] = fmaxf(acc1[4 * g + q] + bv[q], 0.f);
+      }
+      split4(Hh, Hh + F6_ROWS * FB_AP, tok * FB_AP + nb + 8 * g, h0);
+      split4(Hh, Hh + F6_ROWS * FB_AP, (32 + tok) * FB_AP + nb + 8 * g, h1);
+    }
   }
   __syncthreads();
+  WTS(5);
 
-  // ---- FFN2 partial for both token blocks ----
+  // ---- FFN2 partial, half by half; the f32 output tile of a half replaces its hidden planes ----
+  f32x4 res[8 * NH];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  for (int i = 0; i < 8 * NH; ++i) res[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    const bf16x8 xh0 = *(const bf16x8*)(Ph + ao + ks * 16), xl0 = *(const bf16x8*)(Pl + ao + ks * 16);
-    const bf16x8 xh1 = *(const bf16x8*)(Ph + ao + 32 * FB_AP + ks * 16), xl1 = *(const bf16x8*)(Pl + ao + 32 * FB_AP + ks * 16);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl0, acc0, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh0, acc0, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl1, acc1, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh1, acc1, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh1, acc1, 0, 0, 0);
-  }
-  __syncthreads();   // every wave has read the hidden planes: the output tile takes their place
+  for (int h = 0; h < NH; ++h) {
+    const __bf16* Ph = PH(h);
+    const __bf16* Pl = Ph + F6_ROWS * FB_AP;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    f32x4 v0 = {acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
-    f32x4 v1 = {acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
-    if (c == 0) {   // chunk 0 adds the residual and the bias
-      const f32x4 bb = *(const f32x4*)(F.b2 + nb + 8 * g);
-      v0 += *(const f32x4*)(X2 + tok * FB_XP + nb + 8 * g) + bb;
-      v1 += *(const f32x4*)(X2 + (32 + tok) * FB_XP + nb + 8 * g) + bb;
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const bf16x8 xh0 = *(const bf16x8*)(Ph + ao + ks * 16), xl0 = *(const bf16x8*)(Pl + ao + ks * 16);
+      const bf16x8 xh1 = *(const bf16x8*)(Ph + ao + 32 * FB_AP + ks * 16), xl1 = *(const bf16x8*)(Pl + ao + 32 * FB_AP + ks * 16);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl0, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh0, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl1, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh1, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh1, acc1, 0, 0, 0);
     }
-    *(f32x4*)(OT + tok * FB_XP + nb + 8 * g) = v0;
-    *(f32x4*)(OT + (32 + tok) * FB_XP + nb + 8 * g) = v1;
+    WTS(6 + h);
+    if (h == NH - 1 && c == 0) {
+      // the weight fragments are dead: their registers take this thread's parked x2 + b2 back (same thread, same addresses)
+#pragma unroll
+      for (int i = 0; i < 8 * NH; ++i) res[i] = *(const f32x4*)(dst + (long long)min(row0 + wave + 8 * i, M - 1) * LF_D);
+    }
+    __syncthreads();   // every wave has read the hidden planes of this half
+    float* OT = OTH(h);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *(f32x4*)(OT + tok * FB_XP + nb + 8 * g) = f32x4{acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
+      *(f32x4*)(OT + (32 + tok) * FB_XP + nb + 8 * g) = f32x4{acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
+    }
   }
   __syncthreads();
-  // thread t owns float4 (row = wave + 8 i, column 4 lane): 1 KB contiguous per wave-wide store; the kernel boundary publishes
-  float* dst = F.xp + (long long)c * F.xp_stride + 4 * lane;
+  WTS(8);
+  // 1 KB contiguous per wave-wide store; the kernel boundary publishes.  Chunk 0: y_0 + (x2 + b2), ffn_body's sum.
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int r = wave + 8 * i;
-    if (row0 + r < M) *(f32x4*)(dst + (long long)(row0 + r) * LF_D) = *(const f32x4*)(OT + r * FB_XP + 4 * lane);
+  for (int i = 0; i < 8 * NH; ++i) {
+    const int r = wave + 8 * i;   // row of the tile; half i >> 3
+    f32x4 v = *(const f32x4*)(OTH(i >> 3) + (r & 63) * FB_XP + 4 * lane);
+    if (c == 0) v += res[i];
+    if (row0 + r < M) *(f32x4*)(dst + (long long)(row0 + r) * LF_D) = v;
   }
+  WTS(9);
 }
 
 static int g_ffn_rows64 = 0;
@@ -1371,12 +1447,7 @@ static int launch_attn(const float* xin, long long x_batch_stride, const float* 
   if ((long long)LF_NP * ap_stride * 4 >= 0x7fffffffLL)
     return sf_set_err(-1, "invalid argument: head-pair partial buffer beyond the 2 GB a buffer descriptor addresses", __FILE__, __LINE__);
   auto kern = attn_oproj_kernel<RING, PART>;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A2_LDS);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    attr = true;
-  }
+  SF_TRY(sf_ensure_dyn_lds((const void*)kern, (size_t)(A2_LDS)));
   sf_prof_begin(SF_K_MHA, st, 6.0 * B * L * (double)LF_D * LF_D + 4.0 * (double)B * LF_NH * Lq * L * LF_HD +
                                   2.0 * B * Lq * (double)LF_D * LF_D);
   AttnArgs A = make_attn_args(xin, x_batch_stride, pe, f0, ring_frames, nslots, w, eps, ap, ap_stride, L, Lq);
@@ -1433,13 +1504,7 @@ static int launch_ffn(const float* ap, long long ap_stride, const sf_tfm_layer& 
   static_assert((size_t)4 * 16 * 64 * 4 + (size_t)2 * 32 * SB_PP * 2 <= (size_t)2 * FB_ROWS * FB_AP * 2, "boundary scratch fits the H planes");
   if (!w.lin1_packed || !w.lin2_packed || ffn != LF_NCH * LF_HC)
     return sf_set_err(-1, "invalid argument: fused FFN needs packed weights (sf_pack_ffn_weights) and ffn == 1024", __FILE__, __LINE__);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)ffn_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)FB_LDS);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    attr = true;
-  }
+  SF_TRY(sf_ensure_dyn_lds((const void*)ffn_partial_kernel, (size_t)(FB_LDS)));
   const int tiles = (M + FB_ROWS - 1) / FB_ROWS;
   sf_prof_begin(SF_K_FFN, st, 4.0 * M * (double)LF_D * ffn);
   FfnArgs F = make_ffn_args(ap, ap_stride, w, eps, xp, xp_stride, xout, counters, M, sb);
@@ -1457,30 +1522,50 @@ int sf_ffn_partial_ex(const float* ap, long long ap_stride, const sf_tfm_layer& 
   return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, xout, counters, M, ffn, sb, st);
 }
 
-// the four chunk partials xp[c] ARE the output (summed by the next layer's sf_attn_oproj_parts_ex)
+// the four chunk partials xp[c] ARE the output (summed by the next layer's sf_attn_oproj_parts_ex).  Rows per workgroup:
+// the calling thread's option (sf_rollout_opts.ffn_rows), else 64 when sf_set_ffn_rows64(1), else 32; halved while the
+// launch would have fewer rows than one workgroup covers.
+template <int NH>
+static int launch_ffn_wide(const FfnArgs& F, int ffn, hipStream_t st) {
+  constexpr size_t LDS = (size_t)NH * F6_R1;
+  static_assert(LDS <= 160 * 1024, "wide FFN kernel: LDS budget");
+  SF_TRY(sf_ensure_dyn_lds((const void*)ffn_wide_parts_kernel<NH>, LDS));
+  const int ntw = (F.M + 64 * NH - 1) / (64 * NH);
+  sf_prof_begin(SF_K_FFN, st, 4.0 * F.M * (double)LF_D * ffn);
+  hipLaunchKernelGGL(ffn_wide_parts_kernel<NH>, dim3(ffn_blocks(ntw)), dim3(LF_NT), LDS, st, F);
+  sf_prof_end(SF_K_FFN, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
 int sf_ffn_parts_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp, long long xp_stride, int M,
                     int ffn, hipStream_t st) {
   SbArgs sb;
   memset(&sb, 0, sizeof(sb));
-  if (!g_ffn_rows64 || M < 2 * FB_ROWS) return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, nullptr, nullptr, M, ffn, sb, st, 1);
-  // 64 rows per workgroup (ffn64_parts_kernel)
-  static_assert(F6_LDS <= 160 * 1024, "64-row FFN kernel: LDS budget");
+  int rows = sf_thread_opts().ffn_rows > 0 ? sf_thread_opts().ffn_rows : (g_ffn_rows64 ? 64 : 32);
+  while (rows > 32 && M < rows) rows >>= 1;
+  if (rows <= 32) return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, nullptr, nullptr, M, ffn, sb, st, 1);
   if (!w.lin1_packed || !w.lin2_packed || ffn != LF_NCH * LF_HC)
     return sf_set_err(-1, "invalid argument: fused FFN needs packed weights (sf_pack_ffn_weights) and ffn == 1024", __FILE__, __LINE__);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)ffn64_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F6_LDS);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    attr = true;
-  }
   FfnArgs F = make_ffn_args(ap, ap_stride, w, eps, xp, xp_stride, nullptr, nullptr, M, sb);
   F.parts_only = 1;
-  const int npairs = (F.ntiles + 1) / 2;
-  sf_prof_begin(SF_K_FFN, st, 4.0 * M * (double)LF_D * ffn);
-  hipLaunchKernelGGL(ffn64_parts_kernel, dim3(ffn_blocks(npairs)), dim3(LF_NT), F6_LDS, st, F);
-  sf_prof_end(SF_K_FFN, st);
-  SF_CHECK_LAUNCH();
-  return 0;
+  return rows >= 128 ? launch_ffn_wide<2>(F, ffn, st) : launch_ffn_wide<1>(F, ffn, st);
+}
+
+// Building block behind the layers 0 .. n-2 of a rollout step, exported for kernel-level tests: head-pair partials
+// ap [4][M][256] (ap_stride floats apart) -> the four hidden-chunk partials xp [4][M][256] of
+//   x2 = sum(ap);  y = x2 + lin2(relu(lin1(LN2(x2))))      (nn.TransformerEncoderLayer, norm_first, slotformer.py:72-80)
+// whose sum ((p0 + p1) + p2) + p3 is y.  rows_per_wg: 32 / 64 / 128 (0 = the calling thread's default).
+extern "C" int sf_ffn_chunk_partials_f32(const sf_tfm_layer* w, const float* ap, long long ap_stride, float* xp, long long xp_stride,
+                                         int M, int ffn, int rows_per_wg, void* stream) {
+  SF_REQUIRE(w && ap && xp && M > 0, "sf_ffn_chunk_partials_f32: null pointer / empty problem");
+  SF_REQUIRE(rows_per_wg == 0 || rows_per_wg == 32 || rows_per_wg == 64 || rows_per_wg == 128, "sf_ffn_chunk_partials_f32: rows_per_wg must be 0, 32, 64 or 128");
+  SF_REQUIRE(w->norm2_g && w->norm2_b && w->lin1_b && w->lin2_b && w->lin1_packed && w->lin2_packed, "sf_ffn_chunk_partials_f32: null weight (packed FFN weights needed)");
+  SfThreadOpts saved = sf_thread_opts();
+  if (rows_per_wg) sf_thread_opts().ffn_rows = rows_per_wg;
+  const int rc = sf_ffn_parts_ex(ap, ap_stride, *w, 1e-5f, xp, xp_stride, M, ffn, (hipStream_t)stream);
+  sf_thread_opts() = saved;
+  return rc;
 }
 
 // last layer of a rollout step: the FFN's last-arriving workgroups also run the step boundary (out-proj -> slots frame
@@ -1504,13 +1589,8 @@ int sf_seam_ex(const float* ap_ffn, long long pst_ffn, const sf_tfm_layer& wl, f
                unsigned* seam_flags, unsigned epoch, hipStream_t st) {
   if (!wl.lin1_packed || !wl.lin2_packed || ffn != LF_NCH * LF_HC || !w0.attn_in_packed || !w0.attn_out_packed)
     return sf_set_err(-1, "invalid argument: the seam launch needs packed weights", __FILE__, __LINE__);
-  static bool attr = false;
   constexpr size_t LDS = A2_LDS > FB_LDS ? A2_LDS : FB_LDS;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)seam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    attr = true;
-  }
+  SF_TRY(sf_ensure_dyn_lds((const void*)seam_kernel, LDS));
   SbArgs sb = make_sb(wout_packed, b_out, win_packed, b_in, slots, slots_bs, (long long)frame * nslots * SB_C, ring,
                       (long long)ring_frames * nslots * LF_D, (long long)(frame % ring_frames) * nslots * LF_D, nslots);
   sb.seam_flags = seam_flags;
@@ -1562,13 +1642,7 @@ static SbArgs make_sb(const void* wout_packed, const float* b_out, const void* w
 }
 
 static int launch_boundary(const float* y, const SbArgs& sb, int M, int proj_only, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)step_boundary_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)SB_LDS);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    attr = true;
-  }
+  SF_TRY(sf_ensure_dyn_lds((const void*)step_boundary_kernel, (size_t)(SB_LDS)));
   sf_prof_begin(SF_K_LINEAR, st, (proj_only ? 2.0 : 4.0) * M * (double)LF_D * SB_C);
   hipLaunchKernelGGL(step_boundary_kernel, dim3((M + 31) / 32), dim3(LF_NT), SB_LDS, st, y, sb, M, proj_only);
   sf_prof_end(SF_K_LINEAR, st);
@@ -1618,8 +1692,8 @@ extern "C" int sf_debug_read_wg(unsigned long long* out256) {
   return e == hipSuccess ? 0 : (int)e;
 }
 
-extern "C" int sf_debug_read_ts(long long* out32) {
-  hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(lf_ts), sizeof(long long) * 32);
+extern "C" int sf_debug_read_ts(long long* out64) {
+  hipError_t e = hipMemcpyFromSymbol(out64, HIP_SYMBOL(lf_ts), sizeof(long long) * 64);
   return e == hipSuccess ? 0 : (int)e;
 }
 

@@ -232,13 +232,7 @@ int sf_pixel_mlp_kv_ex(const float* x, const float* ln0_g, const float* ln0_b, c
                        const float* w2, const float* b2, const float* ln1_g, const float* ln1_b, const float* wkv,
                        float* kv, int M, int C0, int C1, int ND, float eps, hipStream_t st) {
   if (C0 != PM_C0 || C1 != PM_C1 || ND != PM_ND || M <= 0 || !b1 || !b2) return 1;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)pixel_mlp_kv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)PM_LDS);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    attr = true;
-  }
+  SF_TRY(sf_ensure_dyn_lds((const void*)pixel_mlp_kv_kernel<false>, (size_t)(PM_LDS)));
   static_assert(PM_LDS <= 160 * 1024, "LDS budget");
   sf_prof_begin(SF_K_LINEAR, st, 2.0 * M * (double)(PM_C0 * PM_C1 + PM_C1 * PM_C1 + PM_C1 * PM_ND));
   hipLaunchKernelGGL(pixel_mlp_kv_kernel<false>, dim3((M + PM_ROWS - 1) / PM_ROWS), dim3(PM_NT), PM_LDS, st, x, ln0_g, ln0_b,
@@ -254,12 +248,7 @@ bool sf_pixel_mlp_feat_ok(int C0, int C1) { return C0 == PM_C0 && C1 == PM_C1; }
 int sf_pixel_mlp_feat_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
                          const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st) {
   if (M <= 0) return 0;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)pixel_mlp_kv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PM_LDS);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    attr = true;
-  }
+  SF_TRY(sf_ensure_dyn_lds((const void*)pixel_mlp_kv_kernel<true>, (size_t)(PM_LDS)));
   sf_prof_begin(SF_K_LINEAR, st, 2.0 * M * (double)(PM_C0 * PM_C1 + PM_C1 * PM_C1));
   hipLaunchKernelGGL(pixel_mlp_kv_kernel<true>, dim3((M + PM_ROWS - 1) / PM_ROWS), dim3(PM_NT), PM_LDS, st, x, ln0_g, ln0_b, w1, b1, w2,
                      b2, ln1_g, ln1_b, nullptr, feat, M, eps);

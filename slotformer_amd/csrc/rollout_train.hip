@@ -973,9 +973,7 @@ inline bool attn_use_mfma(int L, int hd) {
 template <class Kern>
 int set_lds(Kern kern, size_t bytes) {
   if (bytes <= 64 * 1024) return 0;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-  return 0;
+  return sf_ensure_dyn_lds((const void*)kern, (size_t)160 * 1024);
 }
 int launch_attn_fwd(const float* qkv, float* ctx, int B, int H, int L, int d, uint32_t sseed, uint32_t thr, float inv_keep,
                     hipStream_t st) {

@@ -1,7 +1,9 @@
 // Runtime bits of libslotformer_hip.so: error string, version, and the optional per-kernel-class
 // HIP-event timer used by bench.py for the roofline object (events are recorded on the stream the
 // kernel is launched on; nothing is recorded while the stream is being captured into a hipGraph).
+#include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "sf_internal.h"
@@ -21,6 +23,26 @@ std::vector<Rec> g_recs[SF_K_NUM];
 thread_local hipEvent_t t_pending = nullptr;
 thread_local int t_suppress = 0;
 }  // namespace
+
+SfThreadOpts& sf_thread_opts() {
+  static thread_local SfThreadOpts o;
+  return o;
+}
+
+int sf_ensure_dyn_lds(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = done.find({kernel, dev});
+  if (it != done.end() && it->second >= bytes) return 0;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+  done[{kernel, dev}] = bytes;
+  return 0;
+}
 
 // nested suppression of the class timer on the calling thread (used for launches that must not be mixed into a
 // per-class average, e.g. convolutions of another batch computed on a different CU partition)

@@ -585,16 +585,8 @@ int sf_slate_attention_train_fwd_f32(const float* q, const float* k, const float
     if (bf3) hipLaunchKernelGGL((slate_attn_fwd_train_kernel<32, true>), g, dim3(256), lds, (hipStream_t)stream, a, out, head_dim);
     else hipLaunchKernelGGL((slate_attn_fwd_train_kernel<32, false>), g, dim3(256), lds, (hipStream_t)stream, a, out, head_dim);
   } else {
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute((const void*)slate_attn_fwd_train_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)slate_attn_fwd_train_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024);
-      if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-      attr = true;
-    }
+    SF_TRY(sf_ensure_dyn_lds((const void*)slate_attn_fwd_train_kernel<64, true>, (size_t)160 * 1024));
+    SF_TRY(sf_ensure_dyn_lds((const void*)slate_attn_fwd_train_kernel<64, false>, (size_t)160 * 1024));
     if (bf3) hipLaunchKernelGGL((slate_attn_fwd_train_kernel<64, true>), g, dim3(256), lds, (hipStream_t)stream, a, out, head_dim);
     else hipLaunchKernelGGL((slate_attn_fwd_train_kernel<64, false>), g, dim3(256), lds, (hipStream_t)stream, a, out, head_dim);
   }
@@ -653,13 +645,7 @@ int sf_slate_attention_train_bwd_f32(const float* q, const float* k, const float
   const dim3 g1((Lq + 63) / 64, num_heads, B), g2((Lk + 63) / 64, num_heads, B);
 #define SAB_GO(HDP, BF)                                                                                                          \
   {                                                                                                                              \
-    static bool attr = false;                                                                                                    \
-    if (!attr) {                                                                                                                 \
-      hipError_t e = hipFuncSetAttribute((const void*)slate_attn_bwd_kernel<HDP, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         160 * 1024);                                                                            \
-      if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);                                  \
-      attr = true;                                                                                                               \
-    }                                                                                                                            \
+    SF_TRY(sf_ensure_dyn_lds((const void*)slate_attn_bwd_kernel<HDP, BF>, (size_t)160 * 1024));                                    \
     hipLaunchKernelGGL((slate_attn_stats_kernel<HDP, BF>), g1, dim3(256), lds1, st, a, head_dim);                                \
     hipLaunchKernelGGL((slate_attn_bwd_kernel<HDP, BF>), g2, dim3(256), lds2, st, a, head_dim);                                  \
   }
@@ -667,12 +653,7 @@ int sf_slate_attention_train_bwd_f32(const float* q, const float* k, const float
   static const bool bwd48 = !(getenv("SF_ATTN_BWD48") && getenv("SF_ATTN_BWD48")[0] == '0');
   if (bf3 && head_dim > 32 && head_dim <= 48 && bwd48 && ldk % 4 == 0 && ldv % 4 == 0) {
     constexpr size_t lds48 = ((size_t)3 * 64 * 52 + 2 * 64 * 68 + 128) * sizeof(float);
-    static bool attr48 = false;
-    if (!attr48) {
-      hipError_t e = hipFuncSetAttribute((const void*)slate_attn_bwd48_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds48);
-      if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-      attr48 = true;
-    }
+    SF_TRY(sf_ensure_dyn_lds((const void*)slate_attn_bwd48_kernel, (size_t)(lds48)));
     hipLaunchKernelGGL((slate_attn_stats_kernel<64, true>), g1, dim3(256), lds1, st, a, head_dim);
     hipLaunchKernelGGL(slate_attn_bwd48_kernel, g2, dim3(256), lds48, st, a, head_dim);
   } else if (hdp == 32) {

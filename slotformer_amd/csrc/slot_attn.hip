@@ -680,12 +680,7 @@ int sf_slot_prologue_ex(const float* prev, const float* init, const float* pm_ln
   if (pmaxf(D, D2) > pmax) pmax = pmaxf(D, D2);
   if (pmaxf(D, D) > pmax) pmax = pmaxf(D, D);
   const size_t lds = ((size_t)3 * D * SU_R + (size_t)D2 * SU_R + 2 * SU_R + (size_t)pmax) * sizeof(float);
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)sa_slot_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    lds_set = lds;
-  }
+  SF_TRY(sf_ensure_dyn_lds((const void*)sa_slot_prologue_kernel, lds));
   SpArgs a{prev, init, pm_ln_g, pm_ln_b, pm_w0_t, pm_b0, pm_w2_t, pm_b2, norm_first, kd_w_t, kd_b, noise, noise_bs, kdist_out,
            kdist_bs, q_ln_g, q_ln_b, q_w_t, slots_out, q_out};
   hipLaunchKernelGGL(sa_slot_prologue_kernel, dim3((R + SU_R - 1) / SU_R), dim3(threads), lds, st, a, R, N, D, pmax, ln_eps);
@@ -768,8 +763,9 @@ int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch
 #define SA_LAUNCH(VPT)                                                                            \
   hipLaunchKernelGGL(sa_attn_partial_kernel<VPT>, grid, block, 0, st, k, v, ld, batch_stride, q, \
                      scale, eps, part_num, part_den, attn_out, attn_batch_stride, HW, N, P)
-  // algorithmic bytes: one read of K and V
-  sf_prof_begin(SF_K_SA_ITER, st, 2.0 * (double)B * HW * D * sizeof(float));
+  // algorithmic bytes: one read of K and V -- of the ONE feature array when keys and values are the same rows
+  // (the folded form, engine.hip: k == v == the normalised pixel features)
+  sf_prof_begin(SF_K_SA_ITER, st, (k == v ? 1.0 : 2.0) * (double)B * HW * D * sizeof(float));
   if (HW % 256 == 0) {
 #define SA_LAUNCH2(DD)                                                                                 \
   hipLaunchKernelGGL(sa_attn_mfma_kernel<DD>, grid, block, 0, st, k, v, ld, batch_stride, q, scale, eps, \
@@ -825,12 +821,7 @@ int sf_slot_update_ex(const float* part_num, const float* part_den, int P, const
   if (pmax < SU_R * 64) pmax = SU_R * 64;
   const size_t lds = ((size_t)4 * D * SU_R + (size_t)H * SU_R + 2 * SU_R + 2 * (size_t)pmax) * sizeof(float);
   auto kern = sa_slot_update_kernel<768>;
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    lds_set = lds;
-  }
+  SF_TRY(sf_ensure_dyn_lds((const void*)kern, lds));
   SuExtra ex{out2, out2_bs, q_ln_g, q_ln_b, q_w, q_out};
   sf_prof_begin(SF_K_SA_UPDATE, st, 0.0);
   hipLaunchKernelGGL(kern, dim3((R + SU_R - 1) / SU_R), dim3(threads), lds, st, part_num, part_den, P, slots_prev, gru_w_ih,

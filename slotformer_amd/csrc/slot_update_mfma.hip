@@ -359,12 +359,7 @@ int sf_slot_update_mfma_ex(const float* part_num, const float* part_den, int P, 
   SF_REQUIRE(N >= 1 && P >= 1 && P <= 64, "bad slot shape");
   if (B == 0) return 0;
   static_assert(UM_LDS <= 160 * 1024, "slot update: LDS budget");
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)sa_slot_update_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)UM_LDS);
-    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
-    attr = true;
-  }
+  SF_TRY(sf_ensure_dyn_lds((const void*)sa_slot_update_mfma_kernel, (size_t)(UM_LDS)));
   UmArgs a;
   a.part_num = part_num; a.part_den = part_den; a.P = P; a.slots_prev = slots_prev;
   a.w_ih_p = (const uint4*)gru_ih_p; a.w_hh_p = (const uint4*)gru_hh_p; a.b_ih = gru_b_ih; a.b_hh = gru_b_hh; a.ln_g = ln_g; a.ln_b = ln_b;

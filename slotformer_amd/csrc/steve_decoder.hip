@@ -784,13 +784,7 @@ int sf_slate_attention_strided_f32(const float* q, const float* k, const float* 
     constexpr int CB_ = (HD_ + 31) / 32;                                                                                     \
     constexpr size_t lds_ = ((size_t)2 * 64 * (HD_ + 4) + (size_t)64 * (CB_ * 32 + 4) + 2 * 4 * 32 +                          \
                              (size_t)4 * 32 * (CB_ * 32 + 4)) * sizeof(float);                                               \
-    static bool attr_ = false;                                                                                               \
-    if (!attr_) {                                                                                                            \
-      hipError_t e_ = hipFuncSetAttribute((const void*)slate_flash_kernel<HD_, false>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                          (int)lds_);                                                                        \
-      if (e_ != hipSuccess) return sf_set_err((int)e_, hipGetErrorString(e_), __FILE__, __LINE__);                           \
-      attr_ = true;                                                                                                          \
-    }                                                                                                                        \
+    SF_TRY(sf_ensure_dyn_lds((const void*)slate_flash_kernel<HD_, false>, lds_));                                                       \
     hipLaunchKernelGGL((slate_flash_kernel<HD_, false>), dim3((Lq + 63) / 64, num_heads, B), dim3(256), lds_, st, q, k, v, out, ldq,   \
                        ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, Lq, scale, SlateTrainArgs{nullptr, 0u, 0u, 1.f});                   \
     SF_CHECK_LAUNCH();                                                                                                       \
@@ -845,13 +839,7 @@ int sf_slate_flash_train_ex(const float* q, const float* k, const float* v, floa
     constexpr int CB_ = (HD_ + 31) / 32;                                                                                       \
     constexpr size_t lds_ = ((size_t)2 * 64 * (HD_ + 4) + (size_t)64 * (CB_ * 32 + 4) + 2 * 4 * 32 +                            \
                              (size_t)4 * 32 * (CB_ * 32 + 4)) * sizeof(float);                                                 \
-    static bool attr_ = false;                                                                                                 \
-    if (!attr_) {                                                                                                              \
-      hipError_t e_ = hipFuncSetAttribute((const void*)slate_flash_kernel<HD_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                          (int)lds_);                                                                          \
-      if (e_ != hipSuccess) return sf_set_err((int)e_, hipGetErrorString(e_), __FILE__, __LINE__);                             \
-      attr_ = true;                                                                                                            \
-    }                                                                                                                          \
+    SF_TRY(sf_ensure_dyn_lds((const void*)slate_flash_kernel<HD_, true>, lds_));                                                       \
     hipLaunchKernelGGL((slate_flash_kernel<HD_, true>), dim3((L + 63) / 64, num_heads, B), dim3(256), lds_, st, q, k, v, out, ldq, \
                        ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, L, scale, ta);                                                   \
     SF_CHECK_LAUNCH();                                                                                                         \

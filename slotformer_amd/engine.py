@@ -28,6 +28,26 @@ def workspace(device, nbytes, slot=0):
     return cur
 
 
+def release_workspaces(prefix):
+    """Drop every workspace whose slot key starts with `prefix` (a tuple): an owner that captured raw pointers into its
+    workspaces (pipeline graphs) uses private slot keys and frees them when it is closed."""
+    n = len(prefix)
+    for key in [k for k in _WORKSPACES if isinstance(k[2], tuple) and len(k[2]) > 1 and isinstance(k[2][1], tuple) and k[2][1][:n] == prefix]:
+        del _WORKSPACES[key]
+
+
+def kernel_noise(m, noise, B, T, device):
+    """The stochastic-kernel noise an encode call of `m` uses: None when the model samples nothing -- no kernel_dist layer,
+    or `kld_method == 'none'`, where `_sample_dist` returns the mean (savi.py:355-365; the OBJ3D / PHYRE configurations) --
+    else the caller's tensor, else fresh eps ~ N(0,1) per frame as the reference draws it.  Every caller of savi_encode that
+    does not go through StoSAVi.encode (pipeline, harness) must use this, or an untrained log-variance head corrupts the slots."""
+    if getattr(m, 'kernel_dist_layer', None) is None or getattr(m, 'kld_method', None) == 'none':
+        return None
+    if noise is not None:
+        return noise
+    return torch.randn(B, T, m.num_slots, m.slot_size, device=device)
+
+
 def _require_inference(module, *tensors):
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
         raise NotImplementedError(
@@ -156,17 +176,43 @@ def rollouter_plan(r, packed=True):
     return plan
 
 
-def rollout(r, slots_all, n_in, pred_len, ws_slot=0):
+def rollout_opts(opts):
+    """dict / None -> ctypes sf_rollout_opts (None).  Keys: precision ('f32' | 'bf16x3' | 'bf16' | 0..2), seam (bool),
+    ffn_rows (32 | 64 | 128), attn_videos (1 | 2); per call and per thread, never process-wide."""
+    if opts is None:
+        return None
+    if isinstance(opts, _lib.sf_rollout_opts):
+        return opts
+    unknown = set(opts) - {'precision', 'seam', 'ffn_rows', 'attn_videos'}
+    if unknown:
+        raise ValueError(f'slotformer_amd: unknown rollout options {sorted(unknown)}')
+    prec = opts.get('precision', -1)
+    prec = {'f32': 0, 'bf16x3': 1, 'bf16': 2}.get(prec, prec)
+    seam = opts.get('seam', None)
+    return _lib.sf_rollout_opts(int(prec), -1 if seam is None else int(bool(seam)), int(opts.get('ffn_rows', 0)), int(opts.get('attn_videos', 0)))
+
+
+def burn_in_of(r):
+    """frames a rollout of `r` consumes: history_len, or 1 for the single-step rollouter (single_step_slotformer.py:49-63)"""
+    return 1 if hasattr(r, 'cond_len') else r.history_len
+
+
+def rollout(r, slots_all, n_in, pred_len, ws_slot=0, opts=None):
     """In-place autoregressive rollout.  slots_all [B, T_total, N, C] float32 contiguous on device;
-    frames [0, n_in) hold the burn-in; frames [n_in, n_in+pred_len) are written."""
+    frames [0, n_in) hold the burn-in; frames [n_in, n_in+pred_len) are written.  n_in must be the rollouter's burn-in
+    length (history_len; 1 for the single-step rollouter).  opts: see rollout_opts."""
     _require_inference(r, slots_all)
     ops._chk(slots_all)
+    if n_in != burn_in_of(r):
+        raise RuntimeError(f'slotformer_amd: burn-in of {n_in} frames, but this rollouter consumes {burn_in_of(r)} '
+                           '(history_len; 1 for SingleStepSlotRollouter)')
     plan = rollouter_plan(r)
     B, T_total = slots_all.shape[:2]
     need = lib().sf_rollout_workspace_bytes(C.byref(plan.struct), B)
     ws = workspace(slots_all.device, need, ('roll', ws_slot))
-    check(lib().sf_rollout_f32(C.byref(plan.struct), slots_all.data_ptr(), B, T_total, pred_len, ws.data_ptr(),
-                               ws.numel(), torch.cuda.current_stream().cuda_stream))
+    o = rollout_opts(opts)
+    check(lib().sf_rollout_opts_f32(C.byref(plan.struct), slots_all.data_ptr(), B, T_total, pred_len, ws.data_ptr(),
+                                    ws.numel(), torch.cuda.current_stream().cuda_stream, None if o is None else C.byref(o)))
     return slots_all
 
 

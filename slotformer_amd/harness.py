@@ -70,38 +70,65 @@ def encode_then_rollout(savi, slotformer, img0, vid_len, noise=None):
     return slotformer({'slots': slots})
 
 
+_PIPES = {}   # (id(savi), id(rollouter), batch, burn-in, pred_len, options) -> (weakrefs, pipeline): graphs are captured once
+
+
+def _pipeline_for(savi, rollouter, batch_size, T, pred_len, pipe_kw):
+    import weakref
+    from .pipeline import EncodeRolloutPipeline
+    for k in [k for k, (ws, wr, _) in _PIPES.items() if ws() is None or wr() is None]:
+        _PIPES.pop(k)[2].close()
+    key = (id(savi), id(rollouter), batch_size, T, pred_len, tuple(sorted((k, repr(v)) for k, v in pipe_kw.items())))
+    ent = _PIPES.get(key)
+    if ent is None:
+        ent = (weakref.ref(savi), weakref.ref(rollouter), EncodeRolloutPipeline(savi, rollouter, batch_size, T, pred_len, **pipe_kw))
+        _PIPES[key] = ent
+    return ent[2]
+
+
+def release_pipelines():
+    """Close the pipelines extract_and_rollout keeps between calls (graphs, CU-masked streams, workspaces)."""
+    for k in list(_PIPES):
+        _PIPES.pop(k)[2].close()
+
+
 @torch.no_grad()
-def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises=None, pipelined=True, **pipe_kw):
+def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises=None, pipelined=True, to_host=False, **pipe_kw):
     """Whole hot path over many videos: SAVi slot extraction of the burn-in frames followed by the SlotFormer rollout
     (extract_slots.py:19-38 + rollout_clevrer_slots.py:20-65 / test_phyre_planning.py:159-174 as one on-device call).
 
-    videos [V, T_burn, 3, H, W] (device or host tensor); rollouter: the SlotRollouter / SingleStepSlotRollouter container
-    (e.g. `slotformer.rollouter`).  Returns slots [V, T_burn + pred_len, N, D] on the device.  Full batches go through
-    `pipeline.EncodeRolloutPipeline` (encode of batch i+1 overlapped with the rollout graph of batch i, CU-partitioned
-    streams, work stealing); a ragged last batch runs serially through the same kernels.  `noises` [V, T_burn, N, D]
-    fixes the kernel noise (default: fresh N(0,1) per frame as the reference draws it)."""
+    videos [V, T_burn, 3, H, W]: a device tensor, or a HOST tensor -- then the frames stay on the host (pinned) and are
+    uploaded batch by batch by the pipeline's copy stage ahead of the encode, never the whole set at once.  rollouter: the
+    SlotRollouter / SingleStepSlotRollouter container (e.g. `slotformer.rollouter`).  Returns slots [V, T_burn + pred_len,
+    N, D] on the device, or in pinned host memory with to_host=True (downloaded behind each rollout; what the reference's
+    drivers do before pickling, extract_slots.py:36).  Full batches go through `pipeline.EncodeRolloutPipeline` (kept
+    between calls: the rollout graphs are captured once per (models, shape)); a ragged last batch runs serially through the
+    same kernels.  `noises` [V, T_burn, N, D] fixes the kernel noise (default: fresh N(0,1) per frame as the reference
+    draws it; ignored by models that sample nothing)."""
     from . import engine
-    from .pipeline import EncodeRolloutPipeline
     dev = next(rollouter.parameters()).device
-    videos = videos.float().to(dev)
+    videos = videos.float()
+    host_in = not videos.is_cuda
+    if host_in and not videos.is_pinned():
+        videos = videos.contiguous().pin_memory()
     V, T = videos.shape[:2]
     N, D = rollouter.num_slots, rollouter.in_proj.in_features
-    out = torch.empty(V, T + pred_len, N, D, device=dev)
+    out = torch.empty(V, T + pred_len, N, D, pin_memory=True) if to_host else torch.empty(V, T + pred_len, N, D, device=dev)
     nfull = V // batch_size
     if nfull:
-        pipe = EncodeRolloutPipeline(savi, rollouter, batch_size, T, pred_len, **pipe_kw)
+        pipe = _pipeline_for(savi, rollouter, batch_size, T, pred_len, pipe_kw)
         imgs = [videos[j * batch_size:(j + 1) * batch_size] for j in range(nfull)]
         nz = None if noises is None else [noises[j * batch_size:(j + 1) * batch_size].float().to(dev).contiguous() for j in range(nfull)]
         pipe.run(imgs, nz, out=out[:nfull * batch_size].view(nfull, batch_size, T + pred_len, N, D), serial=not pipelined or nfull < 2)
-        pipe.close()
     r0 = nfull * batch_size
     if r0 < V:
         nz = None if noises is None else noises[r0:].float().to(dev).contiguous()
-        if nz is None and getattr(savi, 'kernel_dist_layer', None) is not None:
-            nz = torch.randn(V - r0, T, N, D, device=dev)
-        post, _, _ = engine.savi_encode(savi, videos[r0:].contiguous(), noise=nz)
+        nz = engine.kernel_noise(savi, nz, V - r0, T, dev)   # None for models that sample nothing (kld_method 'none')
+        post, _, _ = engine.savi_encode(savi, videos[r0:].to(dev).contiguous(), noise=nz)
         tail = torch.zeros(V - r0, T + pred_len, N, D, device=dev)
         tail[:, :T] = post
         engine.rollout(rollouter, tail, T, pred_len)
-        out[r0:] = tail
+        out[r0:].copy_(tail)
+    if to_host:
+        torch.cuda.synchronize(dev)
     return out

@@ -1,28 +1,29 @@
 """Software pipeline over independent batches of videos: slot extraction of later batches overlaps the rollout of earlier ones.
 
 The two halves of the hot path have opposite shapes -- the SAVi encode is throughput work (convolutions, Slot Attention
-over 4096 pixels), the SlotFormer rollout a chain of ~350 short dependent launches whose 128-168 workgroups mostly wait for
-their weights -- so they run side by side on disjoint sets of CUs (streams created with CU masks, `sf_stream_create_cu_mask`
+over 4096 pixels), the SlotFormer rollout a chain of ~350 short dependent launches whose workgroups mostly wait for their
+weights -- so they run side by side on disjoint sets of CUs (streams created with CU masks, `sf_stream_create_cu_mask`
 -> hipExtStreamCreateWithCUMask):
 
-* the rollout of every slot buffer is captured ONCE into a hipGraph (one graph, one slot buffer and one workspace per batch
-  in flight) and replayed on a rollout stream;
-* partition 'pair' (default): a single rollout chain leaves most of its CUs idle most of the time, so TWO batches roll out
-  side by side on two rollout streams that share CU rows 0-4 of all four shader engines of every XCD (160 CUs: 8.4 ms for two
-  rollouts against 6.7 ms for one there), and the encode runs on rows 5-7 (96 CUs).  Four slot buffers / graphs.  The
-  rollout kernels run in their throughput settings for these graphs (no seam launches, 64-row FFN workgroups).  Three busy
-  CU-masked queues are the limit -- a fourth slows all of them (two encode lanes + two rollout streams: 8.9 ms per batch),
-  five collapse (25 ms) -- hence two rollout streams and ONE encode stream;
-* partition 'three': one rollout stream on CU rows 0-6 of shader engines 1-3 (168 CUs: what its widest launch needs, 21 per
-  XCD) and two encode *lanes*, each with its share of a batch's videos: shader engine 0 (64 CUs, 3/4 of the videos) and row 7
-  of shader engines 1-3 (24 CUs).  partition 'two' is the round-1 split (encode: shader engine 0, rollout: the other three);
+* a rollout UNIT is `group` consecutive batches rolled out by ONE hipGraph over one slot buffer [group * B, T, N, D]:
+  every launch of the chain then covers group * B * L rows, so the weights a workgroup drags through its CU, the launch
+  gaps and the first-load latencies are paid once per `group` batches (round 3: group = 2 with 128-row FFN workgroups;
+  the rollout kernels are per-video / per-row, so the results do not depend on how videos are grouped -- tested).  Every
+  unit buffer has its own graph and workspace, captured ONCE; a ragged last unit (fewer batches) gets its own graph;
+* partition 'pair' (default): a single rollout chain leaves most of its CUs idle most of the time, so TWO units roll out
+  side by side on two rollout streams that share CU rows 0-4 of all four shader engines of every XCD (160 CUs), and the
+  encode runs on rows 5-7 (96 CUs).  Three busy CU-masked queues are the limit on this platform -- a fourth slows all of
+  them, five collapse (profiles/r02_probes.txt) -- hence two rollout streams and ONE encode stream;
+* partition 'three': one rollout stream on CU rows 0-6 of shader engines 1-3 (168 CUs) and two encode *lanes*, each with
+  its share of a batch's videos: shader engine 0 (64 CUs, 3/4 of the videos) and row 7 of shader engines 1-3 (24 CUs).
+  partition 'two' is the round-1 split (encode: `encode_cu_word`, rollout: the complement);
 * every mask gives each shader engine it touches the same number of CUs -- the rule for masks that do not unbalance the
   dispatch (encode_mask_words);
-* work stealing: the CNN features of the first time steps of a batch do not depend on any slots, so the rollout stream that
-  batch will roll out on computes them ahead of time, right after the rollout graph of an earlier batch (`engine.savi_cnn` ->
+* work stealing: the CNN features of the first time steps of a batch do not depend on any slots, so a rollout stream
+  computes them ahead of time, right after the rollout graph of an earlier unit (`engine.savi_cnn` ->
   `savi_encode(feat_pre=...)`); `steal_steps` may be fractional (1.25 = one step per batch, two for every fourth);
-* fill and drain: the first encode of a run takes the whole chip (the calling stream) and is waited for on the host; while
-  the second rollout stream is still idle it computes the stolen features of the next batches; the last rollout of a run
+* fill and drain: the first encodes of a run take the whole chip (the calling stream) and are waited for on the host;
+  while the rollout streams are still idle they compute the stolen features of the next batches; the last unit of a run
   goes to an unmasked stream; run() returns when the last batch is done (a wait left pending on the calling stream slows
   the masked queues).
 
@@ -30,8 +31,14 @@ Every batch still runs its complete encode + rollout; results are bit-identical 
 `savi({'img'}) -> rollout` sequence (tests/test_pipeline_gpu.py).  Reference caller shapes this replaces:
 phyre_planning/test_phyre_planning.py:159-174 (encode -> pad -> rollout per batch), base_slots/extract_slots.py:19-38
 followed by video_prediction/rollout_clevrer_slots.py:20-65.
+
+Ownership: the captured graphs hold raw pointers into the slot buffers, the workspaces and the packed weight copies of
+the rollouter's plan.  The pipeline therefore owns private workspaces (slot keys carrying id(self); freed by close()),
+keeps the plan alive, and re-captures when the rollouter's parameters changed since the capture (run() compares the
+plan signature).
 """
 import ctypes as C
+import math
 import os
 
 import torch
@@ -41,7 +48,7 @@ from . import _lib, engine
 
 def encode_mask_words(spec):
     """The 8 x 32-bit CU mask of the encode stream.  `spec`: 'rows<R>' = CU rows 0..R-1 of every shader engine of every XCD
-    (32 R CUs; the rollout stream gets rows R..7), a sequence of 8 words, or one 32-bit word repeated 8 times (0xff = one
+    (32 R CUs; the rollout streams get rows R..7), a sequence of 8 words, or one 32-bit word repeated 8 times (0xff = one
     whole shader engine per XCD, the round-1 mask).
 
     How the 256 mask bits reach the hardware (measured with tools/mask_probe.py, profiles/r02_probes.txt): bit b of word
@@ -73,24 +80,39 @@ ROLL_WORDS_P = [0xffffffff] * 5 + [0] * 3      # 20 CUs per XCD
 ENC_WORDS_P = [0] * 5 + [0xffffffff] * 3       # 12 CUs per XCD
 
 
+class _Unit:
+    """One rollout unit: slot buffer [nb * B, T + H, N, D], its graph (None: eager) and the workspace slot key."""
+
+    def __init__(self, buf, key):
+        self.buf, self.key, self.graph = buf, key, None
+        self.busy = None   # event of the last rollout + copy-out that used the buffer in the current run()
+
+
 class EncodeRolloutPipeline:
-    """savi: StoSAVi container (eval, testing=True); rollouter: SlotRollouter / SingleStepSlotRollouter container.
+    """savi: StoSAVi / STEVE container (eval, testing=True); rollouter: SlotRollouter / SingleStepSlotRollouter container.
 
     batch: videos per batch (fixed: the rollout graphs are captured for it); burn_in: encoded frames per video
     (= rollouter.history_len, or 1 for the single-step rollouter); pred_len: rollout steps.
     partition: 'pair' (default; see the module docstring), 'three', 'two' (one encode stream on `encode_cu_word`, the
-    rollout on the complement) or 'none' (plain streams, shared CUs).  encode_cu_word: see encode_mask_words.
-    steal_steps: time steps of convolutions per batch computed on the rollout stream (may be fractional: 1.25 = one step,
-    two for every fourth batch); None = 0.75 for 'pair', 1 for 'two', 0 for 'three' (the rollout is the longer side there).
+    rollout on the complement) or 'none' (plain streams, shared CUs).  encode_cu_word: see encode_mask_words; for 'pair'
+    a 'rows<R>' string moves the split (encode on 32 R CUs; default: 96 for the encode, 160 for the rollouts).
+    group: batches per rollout unit / graph (None = 2 for 'pair', 1 otherwise).
+    steal_steps: time steps of convolutions per batch computed on the rollout streams (may be fractional: 1.25 = one step,
+    two for every fourth batch); None = the partition's tuned default.
+    rollout_opts: per-call kernel options of the captured rollouts (engine.rollout_opts); None = the partition's default
+    ('pair': no seam launches, 128-row FFN workgroups -- the throughput settings; otherwise the library defaults).
     """
 
     def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=None, use_graph=True,
-                 partition='pair'):
+                 partition='pair', group=None, rollout_opts=None):
         self.savi, self.roll = savi, rollouter
         self.B, self.T, self.H = int(batch), int(burn_in), int(pred_len)
         p = next(rollouter.parameters())
         if not p.is_cuda:
             raise RuntimeError('slotformer_amd: the pipeline needs the models on a HIP device; there is no CPU fallback')
+        if self.T != engine.burn_in_of(rollouter):
+            raise RuntimeError(f'slotformer_amd: burn_in = {self.T}, but this rollouter consumes {engine.burn_in_of(rollouter)} frames '
+                               '(history_len; 1 for SingleStepSlotRollouter)')
         self.dev = p.device
         self.N, self.D = rollouter.num_slots, rollouter.in_proj.in_features
         if partition not in ('pair', 'three', 'two', 'none'):
@@ -99,38 +121,52 @@ class EncodeRolloutPipeline:
             partition = 'none'
         if partition == 'three' and self.B < 4:
             partition = 'two'
-        # slot buffers / graphs / workspaces: one per batch in flight -- 'pair': two rolling out + one being encoded + one spare
-        self.NB = 4 if partition == 'pair' else 2
+        self.G = int(group) if group else (2 if partition == 'pair' else 1)
+        if self.G < 1:
+            raise ValueError('slotformer_amd: group >= 1')
+        nroll = 2 if partition == 'pair' else 1
+        # unit buffers / graphs / workspaces: per rollout stream one rolling out + one being filled or spare
+        self.NU = 2 * nroll
+        self.lead = 2 * nroll                    # stolen features of unit u are computed behind the rollout of unit u - lead
         if steal_steps is None:
-            steal_steps = {'pair': 0.75, 'two': 1, 'three': 0}.get(partition, 1)
+            steal_steps = float(os.environ.get('SF_PIPE_STEAL', {'pair': 0.75, 'two': 1, 'three': 0}.get(partition, 1)))
         self.steal = max(0.0, min(float(steal_steps), float(self.T)))   # may be fractional: see _steal_of
         self._masked = []
         self._lib = _lib.lib()
-        # 'pair': two chains share the rollout CUs -- seam launches (consumers spinning on a CU each) cost more than they save
-        self.seam = None if partition != 'pair' else int(os.environ.get('SF_PIPE_SEAM', '0'))
-        with torch.no_grad():
-            self.bufs = [torch.zeros(self.B, self.T + self.H, self.N, self.D, device=self.dev) for _ in range(self.NB)]
-            self.graphs = []
-            for gi in range(self.NB):
-                self._rollout_eager(gi)   # allocates its workspace
-                torch.cuda.synchronize(self.dev)
-                if use_graph:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        self._rollout_eager(gi)
-                    self.graphs.append(g)
+        if rollout_opts is None and partition == 'pair':
+            # several chains share the rollout CUs: seam launches (consumers spinning on a CU each) cost more than they
+            # save, and the CUs are the bound -- wide FFN workgroups (one load of the weight chunk per 128 rows)
+            rollout_opts = {'seam': bool(int(os.environ.get('SF_PIPE_SEAM', '0'))), 'ffn_rows': int(os.environ.get('SF_PIPE_FFN_ROWS', '128'))}
+        self.rollout_opts = engine.rollout_opts(rollout_opts)
+        # units of fewer batches (the ramp at both ends of a run) are on the critical path of fill and drain: narrower FFN
+        # workgroups (more of them) finish a launch sooner
+        self.tail_opts = self.rollout_opts
+        if self.rollout_opts is not None and self.rollout_opts.ffn_rows > 64:
+            self.tail_opts = _lib.sf_rollout_opts(self.rollout_opts.precision, self.rollout_opts.seam_fused, 64, self.rollout_opts.attn_videos)
+        self.use_graph = bool(use_graph)
+        self._key = ('pipe', id(self))
+        self._plan = None
+        self._sig = None
+        self.units = []
+        self._tails = {}
+        self._capture_all()
         self.cu_split = False
         self.partition = 'none'
         self.s_roll = None
-        self.roll_streams = []           # rollout streams: batch j rolls out on roll_streams[j % len]
+        self.roll_streams = []           # rollout streams: unit u rolls out on roll_streams[u % len]
         self.lanes = []                  # encode lanes: (stream, first video, end video)
         if partition != 'none':
             try:
                 if partition == 'pair':
-                    self.roll_streams = [self._masked_stream(ROLL_WORDS_P), self._masked_stream(ROLL_WORDS_P)]
+                    enc_words = ENC_WORDS_P
+                    if isinstance(encode_cu_word, str) and encode_cu_word.startswith('rows'):
+                        enc_words = encode_mask_words(encode_cu_word)
+                    roll_words = [~w & 0xffffffff for w in enc_words]
+                    self.roll_streams = [self._masked_stream(roll_words), self._masked_stream(roll_words)]
                     self.s_roll = self.roll_streams[0]
-                    self.lanes = [(self._masked_stream(ENC_WORDS_P), 0, self.B)]
-                    self.encode_cus, self.rollout_cus = 96, 160
+                    self.lanes = [(self._masked_stream(enc_words), 0, self.B)]
+                    self.encode_cus = sum(bin(w).count('1') for w in enc_words)
+                    self.rollout_cus = 256 - self.encode_cus
                 elif partition == 'three':
                     nb = max(1, round(self.B * 24 / 88))
                     self.s_roll = self._masked_stream(ROLL_WORDS_3)
@@ -146,7 +182,7 @@ class EncodeRolloutPipeline:
                 self.cu_split = True
                 self.partition = partition
             except RuntimeError:      # CU masking unavailable on this runtime: keep the pipeline, on shared CUs
-                self.close()
+                self._close_streams()
                 self.s_roll, self.lanes, self.roll_streams = None, [], []
         if self.s_roll is None:
             self.s_roll = torch.cuda.Stream(device=self.dev, priority=-1)
@@ -157,9 +193,24 @@ class EncodeRolloutPipeline:
         self.s_free = torch.cuda.Stream(device=self.dev) if len(self.roll_streams) > 1 else None   # unmasked: the drain
         self.s_enc = self.lanes[0][0]
         self.fill_whole_chip = True      # the first encode(s) of a run on the calling stream (all CUs)
-        self.fill_batches = 1            # (2 = batch 1 on the whole chip as well: measured worse, 311 vs 323 k frames/s at 20 steps)
+        # (group 1: a second whole-chip encode was measured worse, 311 vs 323 k frames/s at 20 steps; with group 2 the first
+        #  rollout cannot start before both batches of its unit are encoded)
+        self.ramp = bool(int(os.environ.get('SF_PIPE_RAMP', '1')))   # single-batch units at both ends of a run (_unit_plan)
+        self.fill_batches = int(os.environ.get('SF_PIPE_FILL', '0'))   # 0: the batches of the first unit
         self.feat_bufs = None
-        self.completion_events = []
+        self._stage, self._s_copy, self._s_out = None, None, None   # staging ring + copy streams for host-resident inputs / outputs
+        self.completion_events = []      # one event per unit of the last run() ...
+        self.completion_batches = []     # ... and the number of batches it completed
+
+    # ------------------------------------------------------------------------------------------------------------
+    @property
+    def bufs(self):
+        """slot buffers of the rollout units ([group * B, T + H, N, D] each)"""
+        return [u.buf for u in self.units]
+
+    @property
+    def graphs(self):
+        return [u.graph for u in self.units if u.graph is not None]
 
     def _masked_stream(self, words):
         arr = (C.c_uint * 8)(*words)
@@ -168,10 +219,15 @@ class EncodeRolloutPipeline:
         self._masked.append(h)
         return torch.cuda.ExternalStream(h.value, device=self.dev)
 
-    def close(self):
+    def _close_streams(self):
         for h in self._masked:
             self._lib.sf_stream_destroy(h)
         self._masked = []
+
+    def close(self):
+        self._close_streams()
+        self.units, self._tails = [], {}
+        engine.release_workspaces(self._key)
 
     def __del__(self):
         try:
@@ -180,30 +236,52 @@ class EncodeRolloutPipeline:
             pass
 
     # ------------------------------------------------------------------------------------------------------------
+    def _new_unit(self, nb, tag):
+        with torch.no_grad():
+            u = _Unit(torch.zeros(nb * self.B, self.T + self.H, self.N, self.D, device=self.dev), self._key + (tag, ))
+            self._rollout_eager(u)   # allocates its workspace, builds the plan
+            torch.cuda.synchronize(self.dev)
+            if self.use_graph:
+                g = torch.cuda.CUDAGraph()
+                # (thread_local: other host threads may keep allocating / synchronising while this one captures)
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    self._rollout_eager(u)
+                u.graph = g
+        return u
+
+    def _capture_all(self):
+        """(Re-)capture every unit graph for the rollouter's CURRENT parameters."""
+        self.units, self._tails = [], {}
+        self.units = [self._new_unit(self.G, k) for k in range(self.NU)]
+        self._plan = engine.rollouter_plan(self.roll)   # keeps the packed weight copies the graphs point to alive
+        self._sig = self._plan.sig
+
+    def _tail_unit(self, nb, k=0):
+        """a unit of fewer than `group` batches (the ramp at both ends of a run, a ragged remainder); k: which of the two"""
+        if (nb, k) not in self._tails:
+            self._tails[(nb, k)] = self._new_unit(nb, ('tail', nb, k))
+        return self._tails[(nb, k)]
+
+    def _check_plan(self):
+        if engine._signature(self.roll) != self._sig:
+            # parameters changed since the capture (optimizer step, load_state_dict, invalidate): the graphs point at the
+            # old packed weight copies
+            torch.cuda.synchronize(self.dev)
+            self._capture_all()
+
     def _steal_of(self, j):
         """time steps of convolutions stolen for batch j: integers that average to self.steal (1.25 -> 1, 1, 1, 2, ...)"""
-        import math
         return int(math.floor(self.steal * (j + 1) + 1e-9) - math.floor(self.steal * j + 1e-9))
 
-    def _rollout_eager(self, gi):
-        if self.seam is None:
-            engine.rollout(self.roll, self.bufs[gi], self.T, self.H, ws_slot=('pipe', gi))
-            return
-        # throughput mode of the rollout kernels: no seam launches, 64-row FFN workgroups
-        old, old64 = self._lib.sf_get_seam_fused(), self._lib.sf_get_ffn_rows64()
-        self._lib.sf_set_seam_fused(self.seam)
-        self._lib.sf_set_ffn_rows64(int(os.environ.get('SF_PIPE_FFN64', '1')))
-        try:
-            engine.rollout(self.roll, self.bufs[gi], self.T, self.H, ws_slot=('pipe', gi))
-        finally:
-            self._lib.sf_set_seam_fused(old)
-            self._lib.sf_set_ffn_rows64(old64)
+    def _rollout_eager(self, u):
+        opts = self.rollout_opts if u.buf.shape[0] >= self.G * self.B else self.tail_opts
+        engine.rollout(self.roll, u.buf, self.T, self.H, ws_slot=u.key, opts=opts)
 
-    def _rollout(self, gi):
-        if self.graphs:
-            self.graphs[gi].replay()
+    def _rollout(self, u):
+        if u.graph is not None:
+            u.graph.replay()
         else:
-            self._rollout_eager(gi)
+            self._rollout_eager(u)
 
     def _encode(self, img, noise, dst, feat_pre, lo=0, hi=None, lane=0):
         """videos [lo, hi) of one batch -> dst[lo:hi, :burn_in] on the current stream"""
@@ -211,11 +289,34 @@ class EncodeRolloutPipeline:
         if lo != 0 or hi != self.B:
             img = img[lo:hi]
             noise = None if noise is None else noise[lo:hi]
-        if noise is None and getattr(self.savi, 'kernel_dist_layer', None) is not None:
-            # fresh eps ~ N(0,1) per frame, as the reference draws it (savi.py:363-365)
-            noise = torch.randn(hi - lo, self.T, self.N, self.D, device=self.dev)
-        post, _, _ = engine.savi_encode(self.savi, img, noise=noise, feat_pre=feat_pre, ws_slot=('pipe', lane))
+        # None for models that sample nothing (kld_method 'none': OBJ3D / PHYRE SAVi; STEVE), the caller's tensor, or fresh
+        # eps ~ N(0,1) per frame as the reference draws it (savi.py:355-365)
+        noise = engine.kernel_noise(self.savi, noise, hi - lo, self.T, self.dev)
+        post, _, _ = engine.savi_encode(self.savi, img, noise=noise, feat_pre=feat_pre, ws_slot=self._key + ('enc', lane))
         dst[lo:hi, :self.T].copy_(post)
+
+    def _unit_plan(self, n):
+        """[(first batch, number of batches, _Unit)] of a run over n batches.  With `ramp` (group 2) a run starts and ends with
+        single-batch units: the first rollout starts after ONE encode instead of two, and the drain -- the last rollout,
+        which nothing overlaps -- covers one batch."""
+        G = self.G
+        if self.ramp and G == 2 and n >= 4:
+            rest = n - 1
+            tail = [1] if rest % 2 else [1, 1]
+            sizes = [1] + [2] * ((rest - len(tail)) // 2) + tail
+        else:
+            sizes = [G] * (n // G) + ([n % G] if n % G else [])
+        plan, u0, nfull, ntail = [], 0, 0, {}
+        for nb in sizes:
+            if nb == G:
+                u = self.units[nfull % self.NU]
+                nfull += 1
+            else:
+                u = self._tail_unit(nb, ntail.get(nb, 0) % 2)
+                ntail[nb] = ntail.get(nb, 0) + 1
+            plan.append((u0, nb, u))
+            u0 += nb
+        return plan
 
     @torch.no_grad()
     def run(self, imgs, noises=None, out=None, serial=False):
@@ -224,101 +325,199 @@ class EncodeRolloutPipeline:
         pipelined schedule returns when the last batch is finished (the host waits for it, see the end of this function).
         serial=True runs the same calls back to back on the calling stream (reference schedule for the tests)."""
         n = len(imgs)
+        B = self.B
+        host_in = n > 0 and not imgs[0].is_cuda
         for im in imgs:
-            if tuple(im.shape[:2]) != (self.B, self.T) or not im.is_cuda:
-                raise RuntimeError(f'every batch must be a device tensor [{self.B},{self.T},3,H,W], got {tuple(im.shape)}')
+            if tuple(im.shape[:2]) != (B, self.T) or im.is_cuda == host_in or im.dtype != torch.float32:
+                raise RuntimeError(f'every batch must be a float32 tensor [{B},{self.T},3,H,W], all on the device or all in (pinned) host '
+                                   f'memory, got {tuple(im.shape)} {im.dtype} on {im.device}')
         if out is None:
-            out = torch.empty(n, self.B, self.T + self.H, self.N, self.D, device=self.dev)
+            out = torch.empty(n, B, self.T + self.H, self.N, self.D, device=self.dev)
+        self._check_plan()
         nz = (lambda j: None) if noises is None else (lambda j: noises[j])
         cur = torch.cuda.current_stream(self.dev)
+        units = self._unit_plan(n)
         if serial or n == 0:
-            for j in range(n):
-                self._encode(imgs[j], nz(j), self.bufs[0], None)
-                self._rollout(0)
-                out[j].copy_(self.bufs[0])
+            for u0, nb, u in units:
+                for h in range(nb):
+                    im = imgs[u0 + h].to(self.dev, non_blocking=True) if host_in else imgs[u0 + h]
+                    self._encode(im, nz(u0 + h), u.buf[h * B:(h + 1) * B], None)
+                self._rollout(u)
+                for h in range(nb):
+                    out[u0 + h].copy_(u.buf[h * B:(h + 1) * B], non_blocking=True)
+            self._check_seam()
             return out
-        NB, steal = self.NB, self.steal
+        G, NU, steal = self.G, self.NU, self.steal
         lanes, rolls = self.lanes, self.roll_streams
-        nl = len(lanes)
-        # work stealing: the features of batch j are computed `lead` batches earlier, on the rollout stream of batch j - lead
-        # (the same stream batch j will roll out on) right after that batch's rollout
-        lead = 2 * len(rolls)
-        kmax = int(-(-steal // 1))
+        nl, nu = len(lanes), len(units)
+        # work stealing: the features of the batches of unit u are computed behind the rollout of unit u - lead, on its stream
+        lead = self.lead
+        NF = lead * G + G                # feature buffers per lane (slot of batch j: j % NF)
+        kmax = int(math.ceil(steal))
         if steal and self.feat_bufs is None:
-            self.feat_bufs = [[engine.savi_cnn(self.savi, imgs[0][lo:hi], 0, kmax, ws_slot=('pipe_steal', li)) for _ in range(lead)]
-                              for li, (_, lo, hi) in enumerate(lanes)]
+            cl = list(self.savi.enc_channels)[-1]
+            self.feat_bufs = [[torch.empty(kmax, hi - lo, 64 * 64, cl, device=self.dev) for _ in range(NF)] for _, lo, hi in lanes]
         for st, _, _ in lanes:
             st.wait_stream(cur)
-        for st in rolls:
+        for st in rolls + ([self.s_free] if self.s_free is not None else []):
             st.wait_stream(cur)
-        ev_enc = [[torch.cuda.Event() for _ in range(nl)] for _ in range(n)]
-        ev_roll = [torch.cuda.Event(enable_timing=True) for _ in range(n)]   # also: completion time of every batch
-        ev_pre = [torch.cuda.Event() for _ in range(n + lead)]
-        for j in range(n):
-            if j < self.fill_batches and self.cu_split and self.fill_whole_chip:
-                # pipeline fill: the first encode takes the whole chip (the calling stream); the masked lanes start after it
-                self._encode(imgs[j], nz(j), self.bufs[j % NB], None)
-                ev_enc[j][0].record(cur)
-                # the host waits for it: with the three other queues parked in a wait on this event the encode was measured
-                # at 4.8 instead of 3.05 ms (a queue stalled in a cross-queue wait slows the queue that is running)
-                ev_enc[j][0].synchronize()
-                for st, _, _ in lanes:
-                    st.wait_event(ev_enc[j][0])
-                ev_wait = ev_enc[j][:1]
-            else:
-                for li, (st, lo, hi) in enumerate(lanes):
-                    # (the first `lead` batches compute their own convolutions: stealing starts with batch `lead`, whose
-                    #  features are produced after the rollout of batch 0)
-                    kj = self._steal_of(j) if (steal and (j >= lead or (j >= 2 and len(rolls) > 1))) else 0
-                    pre = self.feat_bufs[li][j % lead][:kj] if kj else None
-                    with torch.cuda.stream(st):
-                        if j >= NB:
-                            st.wait_event(ev_roll[j - NB])   # slot buffer j % NB is free once batch j-NB has left it
-                        if pre is not None:
-                            st.wait_event(ev_pre[j])
-                        self._encode(imgs[j], nz(j), self.bufs[j % NB], pre, lo, hi, li)
-                        ev_enc[j][li].record(st)
-                ev_wait = ev_enc[j]
-            s_roll = rolls[j % len(rolls)]
-            if len(rolls) > 1 and j == n - 1 and self.s_free is not None:
+        if not out.is_cuda:
+            if self._s_out is None:
+                self._s_out = torch.cuda.Stream(device=self.dev)
+            self._s_out.wait_stream(cur)
+        trace = bool(int(os.environ.get('SF_PIPE_TRACE', '0')))   # timeline of a run (tools/pipe_timeline.py): timing events everywhere
+        ev_enc = [[torch.cuda.Event(enable_timing=trace) for _ in range(nl)] for _ in range(n)]
+        ev_roll = [torch.cuda.Event(enable_timing=True) for _ in range(nu)]   # also: completion time of every unit
+        ev_pre = [torch.cuda.Event() for _ in range(n)]
+        stolen = [0] * n                 # time steps of precomputed features batch j will find in its feature buffer
+        # host-resident inputs (pinned): an upload stage on its own stream runs ahead of the consumers -- far enough for the
+        # work stealing, which reads the frames of a batch lead * G + G batches before its encode (extract_slots.py:19-38 reads
+        # its videos from a DataLoader; this is the device side of that hand-over)
+        NS = NF + 2
+        ev_up, up_next = [], [0]
+        if host_in:
+            if self._stage is None or self._stage[0].shape != imgs[0].shape:
+                self._stage = [torch.empty(imgs[0].shape, device=self.dev) for _ in range(NS)]
+                self._s_copy = torch.cuda.Stream(device=self.dev)
+            self._s_copy.wait_stream(cur)
+            ev_up = [torch.cuda.Event() for _ in range(n)]
+
+        def img_of(j, stream):
+            """the frames of batch j as a device tensor `stream` may read"""
+            if not host_in:
+                return imgs[j]
+            while up_next[0] <= min(j, n - 1):
+                k = up_next[0]
+                with torch.cuda.stream(self._s_copy):
+                    if k >= NS:
+                        for e in ev_enc[k - NS]:            # the staging slot's previous batch has been encoded (issued long ago)
+                            self._s_copy.wait_event(e)
+                    self._stage[k % NS].copy_(imgs[k], non_blocking=True)
+                    ev_up[k].record(self._s_copy)
+                up_next[0] += 1
+            stream.wait_event(ev_up[j])
+            return self._stage[j % NS]
+
+        def steal_for(jj, stream, tag):
+            """features of the first steps of batch jj on `stream` (the current stream)"""
+            kj = self._steal_of(jj)
+            if kj:
+                im = img_of(jj, stream)
+                for li, (_, lo, hi) in enumerate(lanes):
+                    engine.savi_cnn(self.savi, im[lo:hi], 0, kj, out=self.feat_bufs[li][jj % NF][:kj],
+                                    ws_slot=self._key + ('steal', li, tag))
+            stolen[jj] = kj
+            ev_pre[jj].record(stream)
+
+        n_fill = min(self.fill_batches or units[0][1], n) if (self.cu_split and self.fill_whole_chip) else 0
+        for _, _, u in units:
+            u.busy = None
+        ev_t0 = torch.cuda.Event(enable_timing=True)
+        ev_t0.record(cur)
+        ev_rstart = [torch.cuda.Event(enable_timing=True) for _ in range(nu)] if trace else None
+        for ui, (u0, nb, u) in enumerate(units):
+            for h in range(nb):
+                j = u0 + h
+                dst = u.buf[h * B:(h + 1) * B]
+                if j < n_fill:
+                    # pipeline fill: the first encodes take the whole chip (the calling stream); the masked lanes start after
+                    # them.  The host waits: with the other queues parked in a wait on this event the encode was measured at 4.8
+                    # instead of 3.05 ms (a queue stalled in a cross-queue wait slows the queue that is running)
+                    self._encode(img_of(j, cur), nz(j), dst, None)
+                    ev_enc[j][0].record(cur)
+                    if j == 0 and steal and len(rolls) > 1:
+                        # the rollout streams idle until the first unit is encoded: they compute the stolen features of the
+                        # batches behind the fill now (round-robin), so that only the fill batches pay for their own convolutions
+                        # (all on the LAST rollout stream, whose first unit starts latest: on the first one they delayed the first
+                        #  rollout of a run by 3.3 ms, tools/pipe_timeline.py)
+                        first = max(n_fill, 1)
+                        fill_end = units[lead][0] if nu > lead else n      # (unit `lead` onwards: stolen behind the rollouts)
+                        for jj in range(first, fill_end):
+                            with torch.cuda.stream(rolls[-1]):
+                                steal_for(jj, rolls[-1], len(rolls) - 1)
+                    if j == n_fill - 1:
+                        ev_enc[j][0].synchronize()
+                        for st, _, _ in lanes:
+                            st.wait_event(ev_enc[j][0])
+                    ev_wait_j = ev_enc[j][:1]
+                else:
+                    for li, (st, lo, hi) in enumerate(lanes):
+                        with torch.cuda.stream(st):
+                            if u.busy is not None:
+                                st.wait_event(u.busy)   # the unit buffer is free once its previous rollout + copy-out are done
+                            pre = None
+                            if stolen[j]:
+                                st.wait_event(ev_pre[j])
+                                pre = self.feat_bufs[li][j % NF][:stolen[j]]
+                            self._encode(img_of(j, st), nz(j), dst, pre, lo, hi, li)
+                            ev_enc[j][li].record(st)
+                    ev_wait_j = ev_enc[j]
+                if h == 0:
+                    ev_wait = []
+                ev_wait = ev_wait + list(ev_wait_j)
+            s_roll = rolls[ui % len(rolls)]
+            if len(rolls) > 1 and ui == nu - 1 and self.s_free is not None:
                 # drain: the encode lane is idle from here on -- the last rollout takes an unmasked stream (all CUs) instead of
                 # sharing the rollout partition with the one before it
-                s_roll = self.s_free
-                s_roll.wait_stream(rolls[j % len(rolls)])   # (order behind batch j - 2 on the stream it would have used)
+                s_roll = self.s_free   # (its slot buffer and feature buffers are ordered by events, not by the stream it would have used)
             with torch.cuda.stream(s_roll):
                 for e in ev_wait:
                     s_roll.wait_event(e)
-                self._rollout(j % NB)
-                out[j].copy_(self.bufs[j % NB])
-                ev_roll[j].record(s_roll)
-                if steal and j + lead < n:
-                    # feature buffers (j + lead) % lead == j % lead were consumed by encode j, which this stream has waited for
-                    kj = self._steal_of(j + lead)
-                    for li, (_, lo, hi) in enumerate(lanes):
-                        if kj:
-                            engine.savi_cnn(self.savi, imgs[j + lead][lo:hi], 0, kj, out=self.feat_bufs[li][j % lead][:kj],
-                                            ws_slot=('pipe_steal', li, j % len(rolls)))
-                    ev_pre[j + lead].record(s_roll)
-                if steal and j == 0 and len(rolls) > 1:
-                    # fill: the second rollout stream idles until batch 1 is encoded -- it computes the features of batches
-                    # 2 .. lead-1 now, so only batch 1 pays for its own convolutions
-                    with torch.cuda.stream(rolls[1]):
-                        for jj in range(2, min(lead, n)):
-                            kj = self._steal_of(jj)
-                            for li, (_, lo, hi) in enumerate(lanes):
-                                if kj:
-                                    engine.savi_cnn(self.savi, imgs[jj][lo:hi], 0, kj, out=self.feat_bufs[li][jj % lead][:kj],
-                                                    ws_slot=('pipe_steal', li, 1))
-                            ev_pre[jj].record(rolls[1])
-        # The host waits for the last batch HERE, before the calling stream is made to wait for the pipeline's streams: a
+                if trace:
+                    ev_rstart[ui].record(s_roll)
+                self._rollout(u)
+                if out.is_cuda:
+                    for h in range(nb):
+                        out[u0 + h].copy_(u.buf[h * B:(h + 1) * B])
+                    ev_roll[ui].record(s_roll)
+                else:
+                    # pinned host output: the downloads run on a torch-owned stream -- PyTorch's host allocator records an event
+                    # on every stream a pinned block was used on when the block is freed, and the CU-masked streams of this
+                    # object may be gone by then (close())
+                    done = torch.cuda.Event()
+                    done.record(s_roll)
+                    with torch.cuda.stream(self._s_out):
+                        self._s_out.wait_event(done)
+                        for h in range(nb):
+                            out[u0 + h].copy_(u.buf[h * B:(h + 1) * B], non_blocking=True)
+                        ev_roll[ui].record(self._s_out)
+                u.busy = ev_roll[ui]
+                if steal and ui + lead < nu:
+                    # their feature buffers were last read by the encodes of batches <= u0 + nb - 1 ... (NF = lead*G + G apart),
+                    # which this stream has waited for
+                    tu0, tnb, _ = units[ui + lead]
+                    for jj in range(tu0, tu0 + tnb):
+                        steal_for(jj, s_roll, ui % len(rolls))
+        # The host waits for the last units HERE, before the calling stream is made to wait for the pipeline's streams: a
         # wait that sits pending on the calling stream (PyTorch's default stream is the legacy null stream) for the whole
         # run was measured to slow the kernels of the masked encode lane that shares shader engines with the rollout by
         # 30 % (7.7 instead of 6.4 ms per batch, tools/lane_probe.py COPY=1) -- so run() returns when the results are done.
-        for e in ev_roll[-len(rolls):]:
+        for e in ev_roll[-(len(rolls) + 1):]:   # (the drain unit on the unmasked stream may overtake the unit before it)
             e.synchronize()
         for st, _, _ in lanes:
             cur.wait_stream(st)
-        for st in rolls + ([self.s_free] if self.s_free is not None else []):
+        for st in rolls + ([self.s_free] if self.s_free is not None else []) + ([self._s_copy] if host_in else []) + ([self._s_out] if not out.is_cuda else []):
             cur.wait_stream(st)
         self.completion_events = ev_roll
+        self.completion_batches = [nb for _, nb, _ in units]
+        if trace:
+            torch.cuda.synchronize(self.dev)
+            self.timeline = {'encode_end_ms': [max(ev_t0.elapsed_time(e) for e in ev_enc[j][:1 if j < n_fill else nl]) for j in range(n)],
+                             'rollout_start_ms': [ev_t0.elapsed_time(e) for e in ev_rstart],
+                             'rollout_end_ms': [ev_t0.elapsed_time(e) for e in ev_roll],
+                             'units': [(u0, nb) for u0, nb, _ in units]}
+        self._check_seam()
         return out
+
+    def _check_seam(self):
+        """Seam launches (only when the rollout options turn them on) hand rows over inside a launch with a bounded wait; a
+        consumer that gave up has poisoned its outputs with NaN and counted itself -- raise instead of returning them."""
+        o = self.rollout_opts
+        if o is not None and o.seam_fused == 0:
+            return
+        if self._lib.sf_rollout_uses_seam(C.byref(self._plan.struct), self.G * self.B):
+            t = self._lib.sf_seam_timeouts()
+            if t != getattr(self, '_seam_seen', 0):
+                self._seam_seen = t
+                raise RuntimeError('slotformer_amd: a seam hand-off of the rollout timed out (a producer workgroup was not resident); '
+                                   'the affected slots are NaN -- run the pipeline with rollout_opts={"seam": False}')

@@ -48,6 +48,7 @@ def test_pipeline_matches_serial(dev, B, steal, nbatch, partition):
         pipe = EncodeRolloutPipeline(savi, roll, B, T, H, steal_steps=steal, partition=partition)
         assert pipe.partition == partition and len(pipe.lanes) == (2 if partition == 'three' else 1)
         assert len(pipe.roll_streams) == (2 if partition == 'pair' else 1) and len(pipe.bufs) == (4 if partition == 'pair' else 2)
+        assert pipe.G == (2 if partition == 'pair' else 1) and pipe.bufs[0].shape[0] == pipe.G * B
         assert [lo for _, lo, _ in pipe.lanes] + [pipe.lanes[-1][2]] == ([0, B - max(1, round(B * 24 / 88)), B] if partition == 'three' else [0, B])
         out = pipe.run(imgs, noises)
         torch.cuda.synchronize()
@@ -103,3 +104,113 @@ def test_extract_and_rollout_entry(dev):
         # without fixed noise the call still runs (fresh kernel noise per frame) and differs from the fixed-noise run
         out_r = harness.extract_and_rollout(savi, roll, videos, H, batch_size=bs)
         assert out_r.shape == out.shape and torch.isfinite(out_r).all() and not torch.equal(out_r, out)
+        # `videos` above was a HOST tensor: the frames were uploaded batch by batch by the pipeline's copy stage.  Device-resident
+        # input and host-resident output (pinned, downloaded behind each rollout) give the same slots; the pipeline object is
+        # reused between the calls (graphs captured once)
+        n_pipes = len(harness._PIPES)
+        out_d = harness.extract_and_rollout(savi, roll, videos.to(dev), H, batch_size=bs, noises=noises)
+        out_h = harness.extract_and_rollout(savi, roll, videos, H, batch_size=bs, noises=noises, to_host=True)
+        assert torch.equal(out_d, out) and not out_h.is_cuda and out_h.is_pinned() and torch.equal(out_h, out.cpu())
+        assert len(harness._PIPES) == n_pipes == 1
+        harness.release_pipelines()
+        assert not harness._PIPES
+
+
+@pytest.mark.parametrize('group,partition,nbatch', [(1, 'pair', 7), (3, 'pair', 8), (2, 'two', 5), (2, 'none', 3), (2, 'pair', 1)])
+def test_pipeline_groups(dev, group, partition, nbatch):
+    """batches per rollout graph (`group`): any grouping, ragged last unit included, gives the serial results bit for bit"""
+    from slotformer_amd.pipeline import EncodeRolloutPipeline
+    B, T, H = 6, 6, 9
+    savi, roll = _models(dev, gu.C2_SAVI, gu.C2_ROLL, seed=2)
+    rs = np.random.RandomState(17)
+    imgs = [torch.from_numpy((rs.rand(B, T, 3, 128, 128) * 2 - 1).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    noises = [torch.from_numpy(rs.standard_normal((B, T, 7, 128)).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    with torch.no_grad():
+        ref = _serial_reference(savi, roll, imgs, noises, T, H)
+        pipe = EncodeRolloutPipeline(savi, roll, B, T, H, partition=partition, group=group, steal_steps=1.5)
+        assert pipe.G == group
+        for _ in range(2):
+            out = pipe.run(imgs, noises)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), (out - ref).abs().max().item()
+        assert sum(pipe.completion_batches) == nbatch and len(pipe.completion_events) == len(pipe.completion_batches)
+        pipe.close()
+
+
+def _build_pair(dev, savi_cfg, roll_cfg, single_step=False, seed=0):
+    from slotformer_amd.base_slots import build_model
+    from slotformer_amd.video_prediction.models import SlotRollouter, SingleStepSlotRollouter
+    torch.manual_seed(seed)
+    savi_cfg = dict(savi_cfg)
+    if savi_cfg['model'] == 'STEVE' and 'dvae_dict' not in savi_cfg:   # the image side is not on this path: a small one
+        savi_cfg.update(dvae_dict=dict(down_factor=4, vocab_size=64, dvae_ckp_path=''),
+                        dec_dict=dict(dec_type='slate', dec_num_layers=1, dec_num_heads=4, dec_d_model=64),
+                        loss_dict=dict(use_img_recon_loss=False))
+    savi = build_model(gu.ParamsView(savi_cfg)).eval().to(dev)
+    savi.testing = True
+    cls = SingleStepSlotRollouter if single_step else SlotRollouter
+    rd = dict(roll_cfg['rollout_dict'])
+    roll = cls(**rd).eval().to(dev)
+    return savi, roll
+
+
+@pytest.mark.parametrize('name', ['C1', 'C4', 'C5'])
+def test_pipeline_other_configs(dev, name):
+    """The pipeline with the other BASELINE model pairs: C1 = OBJ3D SAVi with
+    kld_method 'none' (`_sample_dist` returns the mean, savi.py:355-365: NO noise may be applied, also not the caller's) +
+    SlotRollouter d_model 128; C4 = STEVE (no kernel distribution at all) + 8-layer SlotRollouter, slot size 192; C5 = PHYRE
+    SAVi (kld 'none', Transformer + LSTM predictor) + SingleStepSlotRollouter with burn-in 1.  Reference = the plain module
+    API (`savi({'img'})` applies the reference's own gating), batch by batch."""
+    from slotformer_amd import engine
+    from slotformer_amd.pipeline import EncodeRolloutPipeline
+    savi_cfg, roll_cfg, single, res, T, H, B = {'C1': (gu.C1_SAVI, gu.C1_ROLL, False, 64, 6, 5, 4),
+                                                 'C4': (gu.C4_STEVE, gu.C4_ROLL, False, 128, 6, 4, 3),
+                                                 'C5': (gu.C5_SAVI, gu.C5_ROLL, True, 128, 1, 9, 5)}[name]
+    savi, roll = _build_pair(dev, savi_cfg, roll_cfg, single_step=single, seed=4)
+    N, D = roll.num_slots, roll.in_proj.in_features
+    nbatch = 5
+    rs = np.random.RandomState(23)
+    imgs = [torch.from_numpy((rs.rand(B, T, 3, res, res) * 2 - 1).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    noises = [torch.from_numpy(rs.standard_normal((B, T, N, D)).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    key = 'post_slots' if hasattr(savi, 'kernel_dist_layer') else 'slots'
+    with torch.no_grad():
+        refs = []
+        for img in imgs:
+            post = savi({'img': img})[key]
+            buf = torch.zeros(B, T + H, N, D, device=dev)
+            buf[:, :T] = post
+            engine.rollout(roll, buf, T, H)
+            refs.append(buf)
+        ref = torch.stack(refs, 0)
+        assert torch.isfinite(ref).all()
+        for kw in (dict(), dict(partition='three'), dict(group=1, steal_steps=0)):
+            pipe = EncodeRolloutPipeline(savi, roll, B, T, H, **kw)
+            for nz in (None, noises):     # caller-supplied noise must be ignored too when the model samples nothing
+                out = pipe.run(imgs, nz)
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref), (name, kw, nz is None, (out - ref).abs().max().item())
+            pipe.close()
+        with pytest.raises(RuntimeError):
+            EncodeRolloutPipeline(savi, roll, B, T + 1, H)   # burn-in must be what the rollouter consumes
+
+
+def test_pipeline_recaptures_after_a_weight_update(dev):
+    """The graphs point at packed weight copies of the rollouter's plan: after an in-place parameter update run() must
+    notice (plan signature) and re-capture instead of replaying the old weights."""
+    from slotformer_amd.pipeline import EncodeRolloutPipeline
+    B, T, H, nbatch = 4, 6, 4, 3
+    savi, roll = _models(dev, gu.C2_SAVI, gu.C2_ROLL, seed=6)
+    rs = np.random.RandomState(29)
+    imgs = [torch.from_numpy((rs.rand(B, T, 3, 128, 128) * 2 - 1).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    noises = [torch.from_numpy(rs.standard_normal((B, T, 7, 128)).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    with torch.no_grad():
+        pipe = EncodeRolloutPipeline(savi, roll, B, T, H)
+        pipe2 = EncodeRolloutPipeline(savi, roll, 2 * B, T, H)   # a second live pipeline: private workspaces, no interference
+        out0 = pipe.run(imgs, noises).clone()
+        assert torch.equal(out0, _serial_reference(savi, roll, imgs, noises, T, H))
+        roll.out_proj.weight.mul_(1.5)     # bumps the version counter
+        ref1 = _serial_reference(savi, roll, imgs, noises, T, H)
+        out1 = pipe.run(imgs, noises)
+        assert torch.equal(out1, ref1) and not torch.equal(out1, out0)
+        pipe.close()
+        pipe2.close()

@@ -1,0 +1,177 @@
+"""Per-call rollout options (sf_rollout_opts_f32 / engine.rollout(opts=...)): the schedule choices -- rows per FFN workgroup,
+seam launches -- must not change a single bit, the throughput settings the bench times are checked against the REFERENCE
+fixture directly, and options are per call and per thread (the reference drives
+forward() from one host thread per GPU, base_slots/extract_slots.py:128)."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    return ((a - b).abs().max() / b.abs().max()).item()
+
+
+def _c2_rollouter(dev, seed=0):
+    from slotformer_amd.video_prediction.models import SlotRollouter
+    torch.manual_seed(seed)
+    return SlotRollouter(**gu.C2_ROLL['rollout_dict']).eval().to(dev)
+
+
+def _roll(r, x, H, opts=None, ws_slot=0):
+    from slotformer_amd import engine
+    buf = torch.zeros(x.shape[0], x.shape[1] + H, *x.shape[2:], device=x.device)
+    buf[:, :x.shape[1]] = x
+    engine.rollout(r, buf, x.shape[1], H, ws_slot=ws_slot, opts=opts)
+    return buf[:, x.shape[1]:].clone()
+
+
+@pytest.mark.parametrize('B', [64, 33, 5, 3])
+@torch.no_grad()
+def test_ffn_rows_and_seam_choices_are_bit_identical(dev, B):
+    """32 / 64 / 128 rows per FFN workgroup (one load of the weight chunk per 1 / 2 / 4 row blocks) and seam launches on / off:
+    the same arithmetic per row, so every combination gives the same bits -- including a ragged last tile (B = 33: 1386 rows
+    = 10 x 128 + 106) and batches smaller than one wide tile (B = 3: 126 rows)."""
+    r = _c2_rollouter(dev)
+    x = gu.seeded_normal((B, 6, 7, 128), 11).to(dev)
+    ref = _roll(r, x, 7, {'ffn_rows': 32, 'seam': False})
+    assert torch.isfinite(ref).all()
+    for opts in ({'ffn_rows': 64, 'seam': False}, {'ffn_rows': 128, 'seam': False}, {'ffn_rows': 128, 'seam': True},
+                 {'ffn_rows': 32, 'seam': True}, None):
+        out = _roll(r, x, 7, opts)
+        assert torch.equal(out, ref), (opts, (out - ref).abs().max().item())
+
+
+@pytest.mark.parametrize('opts', [{'ffn_rows': 128, 'seam': False}, {'ffn_rows': 64, 'seam': False}, {'ffn_rows': 32, 'seam': True}])
+@torch.no_grad()
+def test_throughput_settings_vs_reference_fixture(dev, opts):
+    """roll_c2 (6 + 50 steps, outputs of the reference's own SlotFormer) with the kernel settings of the pipelined bench:
+    the two fixture videos twice in one batch of 4 (168 rows: two 128-row tiles, the second ragged), every copy vs the fixture."""
+    from test_engine_gpu import build
+    g = gu.load_golden('roll_c2')
+    m, _ = build(gu.C2_ROLL, g, 202, dev, vp=True)
+    slots = gu.seeded_normal((2, 56, 7, 128), 203)[:, :6].to(dev)
+    x = torch.cat([slots, slots], 0).contiguous()
+    out = _roll(m.rollouter, x, 50, opts)
+    e0, e1 = rel_err(out[:2], g['pred_slots']), rel_err(out[2:], g['pred_slots'])
+    print('roll_c2 with', opts, 'rel err', e0, e1)
+    assert e0 < 2e-4 and e1 < 2e-4
+
+
+@torch.no_grad()
+def test_options_are_per_call_and_per_thread(dev):
+    """One thread captures and runs a 'pair' pipeline (throughput settings: no seam, 128-row FFN workgroups) while another
+    keeps calling engine.rollout with the defaults and a third with single-pass bf16: nobody sees anybody else's mode --
+    every result equals its single-threaded value bit for bit, and the process defaults are untouched."""
+    from slotformer_amd import _lib
+    from slotformer_amd.base_slots import build_model
+    from slotformer_amd.pipeline import EncodeRolloutPipeline
+    lib = _lib.lib()
+    B, T, H = 8, 6, 6
+    torch.manual_seed(0)
+    savi = build_model(gu.ParamsView(gu.C2_SAVI)).eval().to(dev)
+    savi.testing = True
+    r = _c2_rollouter(dev)
+    rs = np.random.RandomState(5)
+    imgs = [torch.from_numpy((rs.rand(B, T, 3, 128, 128) * 2 - 1).astype(np.float32)).to(dev) for _ in range(5)]
+    noises = [torch.from_numpy(rs.standard_normal((B, T, 7, 128)).astype(np.float32)).to(dev) for _ in range(5)]
+    x = gu.seeded_normal((B, 6, 7, 128), 21).to(dev)
+    ref_default = _roll(r, x, H)
+    ref_bf16 = _roll(r, x, H, {'precision': 'bf16'})
+    assert not torch.equal(ref_default, ref_bf16) and rel_err(ref_bf16, ref_default) < 0.05
+    pipe0 = EncodeRolloutPipeline(savi, r, B, T, H)
+    ref_pipe = pipe0.run(imgs, noises).clone()
+    pipe0.close()
+    before = (lib.sf_get_precision(), lib.sf_get_seam_fused(), lib.sf_get_ffn_rows64())
+    errors, results = [], {}
+
+    def worker_pipe():
+        try:
+            with torch.no_grad():
+                torch.cuda.set_device(dev)
+                for _ in range(2):
+                    pipe = EncodeRolloutPipeline(savi, r, B, T, H)
+                    results.setdefault('pipe', []).append(pipe.run(imgs, noises).clone())
+                    pipe.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    def worker_roll(name, opts, slot):
+        try:
+            with torch.no_grad():
+                torch.cuda.set_device(dev)
+                st = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(st):
+                    for _ in range(12):
+                        results.setdefault(name, []).append(_roll(r, x, H, opts, ws_slot=slot))
+                st.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker_pipe), threading.Thread(target=worker_roll, args=('default', None, 'thr_a')),
+               threading.Thread(target=worker_roll, args=('bf16', {'precision': 'bf16'}, 'thr_b'))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    assert all(torch.equal(o, ref_pipe) for o in results['pipe'])
+    assert all(torch.equal(o, ref_default) for o in results['default'])
+    assert all(torch.equal(o, ref_bf16) for o in results['bf16'])
+    assert (lib.sf_get_precision(), lib.sf_get_seam_fused(), lib.sf_get_ffn_rows64()) == before
+
+
+def test_bad_options_are_rejected(dev):
+    from slotformer_amd import engine
+    r = _c2_rollouter(dev)
+    x = torch.zeros(2, 6, 7, 128, device=dev)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError):
+            _roll(r, x, 2, {'ffn_rows': 48})
+        with pytest.raises(ValueError):
+            engine.rollout_opts({'rows': 64})
+        buf = torch.zeros(2, 9, 7, 128, device=dev)
+        with pytest.raises(RuntimeError):
+            engine.rollout(r, buf, 5, 3)   # burn-in must be the rollouter's history_len
+
+
+@pytest.mark.parametrize('M', [2688, 1386, 130, 70, 31])
+@torch.no_grad()
+def test_ffn_chunk_partials_kernel(dev, M):
+    """Kernel-level: the chunk-partial FFN launch (32 / 64 / 128 rows per workgroup) against a plain PyTorch fp32 reference
+    of the same op -- x2 = sum of the 4 input partials, y = x2 + lin2(relu(lin1(LN2(x2)))) -- and bit-identical chunk
+    partials between the three variants (ragged last tiles, M smaller than a tile)."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from slotformer_amd import _lib, engine
+    lib = _lib.lib()
+    r = _c2_rollouter(dev, seed=3)
+    plan = engine.rollouter_plan(r)
+    w = plan.struct.layers[1]
+    layer = r.transformer_encoder.layers[1]
+    g = torch.Generator().manual_seed(M)
+    ap = torch.randn(4, M, 256, generator=g).to(dev)
+    x2 = ((ap[0] + ap[1]) + ap[2]) + ap[3]
+    ref = x2 + F.linear(F.relu(F.linear(F.layer_norm(x2, (256, ), layer.norm2.weight, layer.norm2.bias), layer.linear1.weight, layer.linear1.bias)),
+                        layer.linear2.weight, layer.linear2.bias)
+    outs = {}
+    for rows in (32, 64, 128):
+        xp = torch.full((4, M, 256), float('nan'), device=dev)
+        _lib.check(lib.sf_ffn_chunk_partials_f32(C.byref(w), ap.data_ptr(), M * 256, xp.data_ptr(), M * 256, M, 1024, rows,
+                                                 torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert torch.isfinite(xp).all()
+        y = ((xp[0] + xp[1]) + xp[2]) + xp[3]
+        assert rel_err(y, ref.cpu()) < 3e-5, (rows, rel_err(y, ref.cpu()))
+        outs[rows] = xp
+    for rows in (64, 128):
+        for c in range(4):
+            d = (outs[rows][c] - outs[32][c]).abs()
+            assert torch.equal(outs[rows][c], outs[32][c]), (rows, c, d.max().item(), (d > 0).any(1).nonzero().flatten()[:20].tolist())

@@ -114,7 +114,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'gap':      # SF_LF_DBG=16: block 0 of t
             for _ in range(2):
                 engine.rollout(roll, buf, 6, 3)
             torch.cuda.synchronize()
-        out = (C.c_longlong * 32)()
+        out = (C.c_longlong * 64)()
         lib.sf_debug_read_ts(out)
         ts = list(out)
         a0, a1, f0, f1 = ts[16], ts[25], ts[0], ts[8]

@@ -34,7 +34,7 @@ if f:
     per = defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = short(r['Kernel_Name'])
-        if n.startswith(('conv5x5_halo_kernel', 'sa_attn_mfma_kernel', 'pixel_mlp_kv_kernel', 'ffn_partial_kernel', 'ffn64_parts_kernel', 'attn_oproj_kernel', 'sa_slot_update_kernel', 'conv5x5_halo256_kernel')):
+        if n.startswith(('conv5x5_halo_kernel', 'sa_attn_mfma_kernel', 'pixel_mlp_kv_kernel', 'ffn_partial_kernel', 'ffn64_parts_kernel', 'ffn_wide_parts_kernel', 'attn_oproj_kernel', 'sa_attn_fold_kernel', 'sa_slot_update_kernel', 'conv5x5_halo256_kernel')):
             per[(n, r['Queue_Id'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     lines.append('# per-queue durations of the encode kernels  [trace_kernel_trace.csv]  (queue with the most launches of a '
                  'kernel = the CU-masked encode stream of the timed region = bench.py roofline.avg_launch_us; the others = '
@@ -98,8 +98,8 @@ traffic = {'source': f'profiles/{tag}_profile_summary.txt (rocprofv3 --pmc FETCH
            'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of wide coalesced reads)'}
 # MFMA-busy fraction: SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs that ran the kernel; GRBM_GUI_ACTIVE is
 # the launch duration in cycles -> busy / (active * 1024 SIMDs) = share of the chip's matrix-pipe time that was used
-for key, pred in (('conv_nhwc_implicit_gemm', is_conv), ('slot_attn_iter', lambda n: 'sa_attn' in n),
-                  ('ffn_fused', lambda n: 'ffn_partial_kernel' in n or 'ffn64_parts_kernel' in n), ('attention', lambda n: 'attn_oproj_kernel' in n),
+for key, pred in (('conv_nhwc_implicit_gemm', is_conv), ('slot_attn_iter', lambda n: 'sa_attn_mfma' in n or 'sa_attn_fold' in n),
+                  ('ffn_fused', lambda n: 'ffn_partial_kernel' in n or 'ffn64_parts_kernel' in n or 'ffn_wide_parts_kernel' in n), ('attention', lambda n: 'attn_oproj_kernel' in n),
                   ('pixel_mlp', lambda n: 'pixel_mlp_kv_kernel' in n)):
     fe, wr = counter_avg(f'{tag}_pmc_fetch', 'FETCH_SIZE', pred), counter_avg(f'{tag}_pmc_write', 'WRITE_SIZE', pred)
     ent = {}
