@@ -283,6 +283,13 @@ int sf_pack_ffn_weights(const float* lin1_w, const float* lin2_w, void* lin1_pac
 int sf_ffn_chunk_partials_f32(const sf_tfm_layer* w, const float* ap, long long ap_stride, float* xp, long long xp_stride, int M,
                               int ffn, int rows_per_wg, void* stream);
 
+/* Attention half of the same layer on B sequences of L <= 64 tokens, x [B][L][256]: the last Lq rows of every sequence of
+ *   x2 = x + out_proj(MHA(LN1(x))) + b_o        (8 heads of 32)
+ * heads_per_wg = 8: one workgroup per sequence runs all heads, out [2][B*Lq][256]: out[0] = x2, out[1] scratch;  heads_per_wg = 2: one workgroup per
+ * (head pair, sequence), out [4][B*Lq][256] = the four head-pair partials with x2 = ((p0 + p1) + p2) + p3 -- the input format
+ * of sf_ffn_chunk_partials_f32.  Both forms give the same bits.  Needs w->attn_in_packed / attn_out_packed. */
+int sf_attn_block_f32(const sf_tfm_layer* w, const float* x, float* out, int B, int L, int Lq, int heads_per_wg, void* stream);
+
 /* SlotRollouter / SingleStepSlotRollouter (slotformer.py:48-134, single_step_slotformer.py:6-90). */
 typedef struct {
   int num_slots, slot_size, d_model, num_layers, num_heads, ffn_dim, norm_first;
@@ -316,10 +323,15 @@ typedef struct {
   int precision;    /* -1: default; 0 exact f32, 1 split-bf16, 2 single-pass bf16 (= sf_rollout_bf16) */
   int seam_fused;   /* -1: default; 0 / 1: seam launches off / on */
   int ffn_rows;     /* 0: default; 32 / 64 / 128 rows per workgroup of the chunk-partial FFN launches */
-  int attn_videos;  /* 0: default (1); 1 / 2 videos per workgroup of the layer attention launches */
+  int attn_heads_per_wg; /* 0: default (2: one workgroup per head pair and video, four partial outputs summed by the FFN launch);
+                          * 8: one workgroup per video runs all heads and writes finished rows -- fewer, longer workgroups with
+                          * a third of the bytes through a CU: the throughput form (the same bits as the default) */
 } sf_rollout_opts;
 int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws, size_t ws_bytes,
                         void* stream, const sf_rollout_opts* opts); /* opts == NULL: sf_rollout_f32 */
+/* 1 when sf_rollout_f32 runs this model's Transformer layers as the fused per-video / per-row launches (d_model 256, 8 heads,
+ * ffn 1024, window <= 64 tokens, packed weights, split-bf16 mode): a video's result then does not depend on the batch it is in */
+int sf_rollout_is_fused(const sf_rollouter* m);
 /* 1 when sf_rollout_f32 would run seam launches for this model / batch with the calling thread's defaults */
 int sf_rollout_uses_seam(const sf_rollouter* m, int B);
 

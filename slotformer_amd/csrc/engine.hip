@@ -198,7 +198,8 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   // seam launches (layer_fused.hip): the last-layer FFN + boundary of step s and the layer-0 attention of step s+1 in one
   // grid; needs every workgroup of it co-resident at one per CU -- 160 fit the 168-CU rollout partition
   const int seam_opt = sf_thread_opts().seam;
-  const bool seam = boundary_fused && (seam_opt >= 0 ? seam_opt != 0 : sf_get_seam_fused() != 0) && sf_seam_blocks(B, N) <= 160;
+  const bool seam = boundary_fused && (seam_opt >= 0 ? seam_opt != 0 : sf_get_seam_fused() != 0) && sf_seam_blocks(B, N) <= 160 &&
+                    sf_thread_opts().attn_heads != 8;
   // layers 0 .. n-2 leave their output as four FFN chunk partials that the next attention sums while loading (SF_FFN_PARTS=0:
   // the FFN's last-arriving workgroup sums them, as the last layer always does)
   static const bool parts_env = [] {
@@ -206,6 +207,10 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
     return !(e && e[0] == '0');
   }();
   const bool parts_mode = ring_mode && parts_env;
+  // throughput form of the attention block (per-call option attn_heads_per_wg = 8): one workgroup per video runs all 8 heads
+  // and writes finished rows; the FFN behind it reads one row instead of four head-pair partials (layer_fused.hip)
+  const bool all_heads = fused_layers && sf_thread_opts().attn_heads == 8;
+  const int np = all_heads ? 1 : 4;
   if (ring_mode) {
     // in-projection (without PE) of the burn-in frames -> ring slots 0 .. n_in-1
     SF_TRY(sf_ring_init_ex(m->out_proj_packed, m->out_proj_b, m->in_proj_packed, m->in_proj_b, slots,
@@ -246,7 +251,14 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
         const long long pst = (long long)B * Lq * d;
         float* xo = (cin == xa) ? xb2 : xa;
         float* apl = (l == 0) ? ap_l0 : apb;
-        if (l == 0) {
+        if (all_heads) {
+          if (l == 0)
+            SF_TRY(sf_attn_all_ring_ex(ring, RF, N, f0, m->pe_tok + (long long)pe_off * d, m->layers[l], 1e-5f, apl, B, L, Lq, st));
+          else if (parts_in)
+            SF_TRY(sf_attn_all_parts_ex(xpb, (long long)B * L * d, m->layers[l], 1e-5f, apl, B, L, Lq, st));
+          else
+            SF_TRY(sf_attn_all_ex(cin, m->layers[l], 1e-5f, apl, B, L, Lq, st));
+        } else if (l == 0) {
           if (!attn0_done)
             SF_TRY(sf_attn_oproj_ring_ex(ring, RF, N, f0, m->pe_tok + (long long)pe_off * d, m->layers[l], 1e-5f, apl, pst, B, L,
                                          Lq, st));
@@ -272,18 +284,18 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
             attn0_done = true;
           } else {
             SF_TRY(sf_ffn_boundary_ex(apl, pst, m->layers[l], 1e-5f, xpb, pst, counters, m->ffn_dim, m->out_proj_packed,
-                                      m->out_proj_b, m->in_proj_packed, m->in_proj_b, slots, bs, n_in + s, ring, RF, N, B, st));
+                                      m->out_proj_b, m->in_proj_packed, m->in_proj_b, slots, bs, n_in + s, ring, RF, N, B, st, np));
             ap_l0 = apb;
           }
           cin = nullptr;
         } else if (parts_mode && !lastl) {
           // the chunk partials are the layer output: the next attention sums them
-          SF_TRY(sf_ffn_parts_ex(apl, pst, m->layers[l], 1e-5f, xpb, pst, B * Lq, m->ffn_dim, st));
+          SF_TRY(sf_ffn_parts_ex(apl, pst, m->layers[l], 1e-5f, xpb, pst, B * Lq, m->ffn_dim, st, np));
           parts_in = true;
           cin = nullptr;
           if (l == 0) ap_l0 = apb;
         } else {
-          SF_TRY(sf_ffn_partial_ex(apl, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st));
+          SF_TRY(sf_ffn_partial_ex(apl, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st, np));
           cin = xo;
           parts_in = false;
           if (l == 0) ap_l0 = apb;
@@ -308,15 +320,21 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
         const int Lq = lastl ? N : L;
         const long long pst = (long long)B * Lq * d;
         float* xo = (cin == xa) ? xb2 : xa;
-        if (parts_in)
+        if (all_heads) {
+          if (parts_in)
+            SF_TRY(sf_attn_all_parts_ex(xpb, (long long)B * L * d, m->layers[l], 1e-5f, apb, B, L, Lq, st));
+          else
+            SF_TRY(sf_attn_all_ex(cin, m->layers[l], 1e-5f, apb, B, L, Lq, st));
+        } else if (parts_in) {
           SF_TRY(sf_attn_oproj_parts_ex(xpb, (long long)B * L * d, m->layers[l], 1e-5f, apb, pst, B, L, Lq, st));
-        else
+        } else {
           SF_TRY(sf_attn_oproj_ex(cin, m->layers[l], 1e-5f, apb, pst, B, L, Lq, st));
+        }
         if (parts_env && !lastl) {
-          SF_TRY(sf_ffn_parts_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, B * Lq, m->ffn_dim, st));
+          SF_TRY(sf_ffn_parts_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, B * Lq, m->ffn_dim, st, np));
           parts_in = true;
         } else {
-          SF_TRY(sf_ffn_partial_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st));
+          SF_TRY(sf_ffn_partial_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st, np));
           cin = xo;
           parts_in = false;
         }
@@ -383,12 +401,13 @@ int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total,
   SF_REQUIRE(opts->precision >= -1 && opts->precision <= 2, "sf_rollout_opts: precision must be -1 (default), 0, 1 or 2");
   SF_REQUIRE(opts->ffn_rows == 0 || opts->ffn_rows == 32 || opts->ffn_rows == 64 || opts->ffn_rows == 128,
              "sf_rollout_opts: ffn_rows must be 0 (default), 32, 64 or 128");
-  SF_REQUIRE(opts->attn_videos >= 0 && opts->attn_videos <= 2, "sf_rollout_opts: attn_videos must be 0 (default), 1 or 2");
+  SF_REQUIRE(opts->attn_heads_per_wg == 0 || opts->attn_heads_per_wg == 2 || opts->attn_heads_per_wg == 8,
+             "sf_rollout_opts: attn_heads_per_wg must be 0 (default), 2 or 8");
   SfThreadOpts o = sf_thread_opts();
   if (opts->precision >= 0) o.precision = opts->precision;
   if (opts->seam_fused >= 0) o.seam = opts->seam_fused ? 1 : 0;
   if (opts->ffn_rows > 0) o.ffn_rows = opts->ffn_rows;
-  if (opts->attn_videos > 0) o.attn_videos = opts->attn_videos;
+  if (opts->attn_heads_per_wg > 0) o.attn_heads = opts->attn_heads_per_wg;
   OptsScope scope(o);
   const bool plain = (o.precision == 2);
   const bool old_plain = t_plain_gemms;
@@ -396,6 +415,17 @@ int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total,
   const int rc = sf_rollout_f32(m, slots, B, T_total, pred_len, ws, ws_bytes, stream);
   t_plain_gemms = old_plain;
   return rc;
+}
+
+// 1 when sf_rollout_f32 runs this model's layers as the two fused launches of layer_fused.hip (per-video / per-row kernels whose
+// results do not depend on how videos are grouped into batches); 0: the generic GEMM path, whose tile / split-K choice -- and
+// with it the summation order -- follows the batch size
+int sf_rollout_is_fused(const sf_rollouter* m) {
+  if (!m || !m->layers) return 0;
+  bool packed = true;
+  for (int l = 0; l < m->num_layers; ++l)
+    packed = packed && m->layers[l].lin1_packed && m->layers[l].lin2_packed && m->layers[l].attn_in_packed && m->layers[l].attn_out_packed;
+  return packed && sf_get_precision() >= 1 && m->norm_first && sf_layer_fused_ok(m->d_model, m->num_heads, m->ffn_dim, m->window_len * m->num_slots);
 }
 
 // 1 when sf_rollout_f32 would use seam launches for this model / batch with the calling thread's defaults (a caller that

@@ -9,8 +9,15 @@ int sf_attn_oproj_ex(const float* xin, const sf_tfm_layer& w, float eps, float* 
 // layer 0 of a rollout step: x = ring[b][(f0 + r / nslots) % ring_frames][r % nslots] + pe[r]
 int sf_attn_oproj_parts_ex(const float* xparts, long long xparts_stride, const sf_tfm_layer& w, float eps, float* ap,
                            long long ap_stride, int B, int L, int Lq, hipStream_t st);
+// np: input partials per row -- 4 (head-pair partials of sf_attn_oproj_*_ex) or 1 (finished rows of sf_attn_all_*_ex)
 int sf_ffn_parts_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp, long long xp_stride, int M,
-                    int ffn, hipStream_t st);
+                    int ffn, hipStream_t st, int np = 4);
+// all 8 heads in ONE workgroup per video: x2 [B*Lq][256] = x + out_proj(MHA(LN1(x))) + b_o (finished rows, not partials)
+int sf_attn_all_ex(const float* xin, const sf_tfm_layer& w, float eps, float* x2, int B, int L, int Lq, hipStream_t st);
+int sf_attn_all_parts_ex(const float* xparts, long long xparts_stride, const sf_tfm_layer& w, float eps, float* x2, int B, int L,
+                         int Lq, hipStream_t st);
+int sf_attn_all_ring_ex(const float* ring, int ring_frames, int nslots, int f0, const float* pe, const sf_tfm_layer& w, float eps,
+                        float* x2, int B, int L, int Lq, hipStream_t st);
 int sf_attn_oproj_ring_ex(const float* ring, int ring_frames, int nslots, int f0, const float* pe, const sf_tfm_layer& w,
                           float eps, float* ap, long long ap_stride, int B, int L, int Lq, hipStream_t st);
 // out-proj of the finished rows y [B*nslots, 256] -> slots frame `frame`; in-proj of those rows -> projection ring
@@ -21,7 +28,7 @@ int sf_step_boundary_ex(const float* y, const void* wout_packed, const float* b_
 // ap: 8 head partials [M, 256] -> xout [M, 256] (finished layer output); xp: scratch for the 4 hidden-chunk partials
 // [4][M, 256]; counters: sf_ffn_tiles(M) ints, zero before the first launch (the kernel leaves them zero)
 int sf_ffn_partial_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp,
-                      long long xp_stride, float* xout, int* counters, int M, int ffn, hipStream_t st);
+                      long long xp_stride, float* xout, int* counters, int M, int ffn, hipStream_t st, int np = 4);
 int sf_ffn_tiles(int M);
 // in-projection of the first n_frames frames of every video -> ring slots 0 .. n_frames-1 (same arithmetic as the step kernel)
 int sf_ring_init_ex(const void* wout_packed, const float* b_out, const void* win_packed, const float* b_in, float* slots,
@@ -30,7 +37,7 @@ int sf_ring_init_ex(const void* wout_packed, const float* b_out, const void* win
 int sf_ffn_boundary_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp, long long xp_stride,
                        int* counters, int ffn, const void* wout_packed, const float* b_out, const void* win_packed,
                        const float* b_in, float* slots, long long slots_bs, int frame, float* ring, int ring_frames, int nslots,
-                       int B, hipStream_t st);
+                       int B, hipStream_t st, int np = 4);
 // ONE launch for the seam between two rollout steps: last-layer FFN + step boundary of step s (blocks [0, nffn)) and the
 // layer-0 attention of step s+1 (one block per (head pair, video)), handed over per 32-row tile through seam_flags
 int sf_seam_ex(const float* ap_ffn, long long pst_ffn, const sf_tfm_layer& wl, float eps, float* xp, long long xp_stride,

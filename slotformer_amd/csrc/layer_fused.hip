@@ -672,6 +672,449 @@ __global__ __launch_bounds__(LF_NT) void attn_oproj_kernel(AttnArgs A) {
 }
 
 // ================================================================================================
+// Attention block of a layer with ONE workgroup per video and ALL 8 heads (per-call option attn_heads_per_wg = 8): the
+// throughput form.  The head-pair kernel above gives a rollout chain short launches (128 workgroups of ~12 us at B = 32), at
+// the price that the four workgroups of a video each ingest the layer input (172 KB as chunk partials) and normalise it, and
+// that the FFN behind them ingests FOUR head-pair partials per row.  A CU ingests only ~70-100 GB/s, and with several rollout
+// units sharing the CUs (pipeline 'pair') CU time is what bounds the rollout.  Here the input is loaded and normalised once,
+// the LN(x) planes stay resident, the four head pairs run one after the other (their weight fragments arrive behind the
+// previous pair's attention core) and accumulate the out-projection in registers: the output is the FINISHED row
+//     x2 = x + out_proj(MHA(LN1(x))) + b_o          [B*Lq][256]
+// -- one tensor instead of four partials, so the FFN launch behind it ingests 1 KB per row instead of 4.
+// Every product, and the order in which the head pairs' out-projection partials are summed -- ((p0 + p1) + p2) + p3, with the
+// residual and the bias on the partial of the pair that owns the columns -- are the head-pair kernel's and its consumer's: the
+// two forms give the same bits.
+constexpr size_t A8_PLANES_OFF = 0;                                            // LN(x) planes [2][64][A2_AP] bf16, resident
+constexpr size_t A8_QK_OFF = A2_PLANES;                                        // q, k planes of one head pair; later OT
+constexpr size_t A8_VT_OFF = A8_QK_OFF + (size_t)8 * AT_QPL * 2;               // v^T planes of one head pair; later the O planes
+constexpr size_t A8_ST_OFF = A8_VT_OFF + (size_t)4 * AT_VPL * 2;               // softmax stats [2][8][32] f32
+constexpr size_t A8_PS_OFF = A8_ST_OFF + 2 * 8 * 32 * 4;                       // k-half exchange [2 waves][2][16][64] f32
+constexpr size_t A8_GB_OFF = A8_PS_OFF + (size_t)2 * 2 * 16 * 64 * 4;          // gamma | beta [2][256], q|k|v bias [768]
+constexpr size_t A8_LDS = A8_GB_OFF + (2 * LF_D + 3 * LF_D) * 4;
+static_assert((size_t)8 * 32 * QSTR * 4 <= (size_t)8 * AT_QPL * 2, "the PV partials must fit over the q / k planes");
+static_assert((size_t)2 * FA_ROWS * A2_OP * 2 <= (size_t)4 * AT_VPL * 2, "the O planes must fit over the v^T planes");
+static_assert(A8_LDS <= 160 * 1024, "all-heads attention kernel: LDS budget");
+
+template <bool RING, bool PART>
+__global__ __launch_bounds__(LF_NT) void attn_all_kernel(AttnArgs A) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.x;   // video (block i runs on XCD i % 8)
+#define ATS(i) do { if ((A.dbg & 16) && blockIdx.x == 0 && threadIdx.x == 0) lf_ts[48 + (i)] = wall_clock64(); } while (0)
+  ATS(0);
+  const float* __restrict__ xin = A.xin;
+  const float* __restrict__ pe = A.pe;
+  const int f0 = A.f0, ring_frames = A.ring_frames, nslots = A.nslots;
+  const uint4* __restrict__ wqkv_p = A.wqkv_p;
+  const uint4* __restrict__ wo_p = A.wo_p;
+  const int L = A.L, Lq = A.Lq;
+  constexpr int d = LF_D, HD = LF_HD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* Ah = (__bf16*)smem;                                  // [64][A2_AP]  LN1(x), all of K: resident
+  __bf16* Al = Ah + FA_ROWS * A2_AP;
+  __bf16* QKp = (__bf16*)((char*)smem + A8_QK_OFF);            // q, k: [2 heads][q,k][hi,lo][64][AT_QP]
+  __bf16* Vtp = (__bf16*)((char*)smem + A8_VT_OFF);            // v^T:  [2 heads][hi,lo][32][AT_VP]
+  float* OT = (float*)((char*)smem + A8_QK_OFF);               // [8][32][QSTR] PV partials (over the dead q / k planes)
+  __bf16* Oh = (__bf16*)((char*)smem + A8_VT_OFF);             // [64][A2_OP] O planes (over the dead v^T planes)
+  __bf16* Ol = Oh + FA_ROWS * A2_OP;
+  float* SM = (float*)((char*)smem + A8_ST_OFF);
+  float* SL = SM + 8 * 32;
+  float* PS = (float*)((char*)smem + A8_PS_OFF);
+  float* GB = (float*)((char*)smem + A8_GB_OFF);
+  const int t_ = threadIdx.x, lane_ = t_ & 63, wave_ = t_ >> 6;
+  const int t = t_, lane = lane_, wave = wave_;
+  const float* xb = xin + (long long)b * A.x_batch_stride;
+  const int c4 = t & 15, r0 = t >> 4;
+  const int nrb = L > 32 ? 2 : 1;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // ---- parameters first (vmcnt retires in order): gamma | beta, the q|k|v bias of all heads ----
+  f32x4 gbv = zero4, bqv = zero4;
+  if (t < 128) gbv = *(const f32x4*)((t < 64 ? A.ln_g : A.ln_b) + 4 * (t & 63));
+  if (t >= 128 && t < 128 + 192) bqv = *(const f32x4*)(A.bias + 4 * (t - 128));
+  // ---- the layer input, once ----
+  bool aok[A_IT];
+  const float* arow[A_IT];
+  const float* prow[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int r = r0 + 32 * i;
+    aok[i] = r < L;
+    const int rc = min(r, L - 1);
+    if constexpr (RING) {
+      const int fr = rc / nslots, sl = rc - fr * nslots;
+      arow[i] = xb + ((long long)((f0 + fr) % ring_frames) * nslots + sl) * d + 4 * c4;
+      prow[i] = pe + (long long)rc * d + 4 * c4;
+    } else {
+      arow[i] = xb + (long long)rc * d + 4 * c4;
+      prow[i] = nullptr;
+    }
+  }
+  f32x4 ra[NK][A_IT];
+  if constexpr (PART) {
+    const long long ps = A.xparts_stride;
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const float* p = arow[i] + kc * FA_KC;
+        const f32x4 p0 = *(const f32x4*)p, p1 = *(const f32x4*)(p + ps), p2 = *(const f32x4*)(p + 2 * ps), p3 = *(const f32x4*)(p + 3 * ps);
+        ra[kc][i] = ((p0 + p1) + p2) + p3;
+      }
+  } else {
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) ra[kc][i] = *(const f32x4*)(arow[i] + kc * FA_KC);
+  }
+  if constexpr (RING) {
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) ra[kc][i] += *(const f32x4*)(prow[i] + kc * FA_KC);
+  }
+  // ---- weight fragments of a head pair: wq[ks][plane]; waves >= 4 hold 8 k-steps (in wq[0..7]); column blocks as in
+  //      attn_body (waves 0..3 own one of the 6 q|k|v blocks over all of K, blocks 4 / 5 are split over K) ----
+  bf16x8 wq[16][2];
+  const int wcb = wave < 4 ? wave : 4 + (wave & 1), wk0 = wave >= 6 ? 8 : 0;
+  auto wq_ptr = [&](int hp) { return wqkv_p + (((long long)(hp * 6 + wcb) * 16 + wk0) * 2) * 64 + lane; };
+  auto load_first = [&](int hp) {   // k-steps 0..7 of waves 0..5
+    const uint4* wqp = wq_ptr(hp);
+    if (wave < 6) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        wq[ks][0] = __builtin_bit_cast(bf16x8, wqp[(ks * 2) * 64]);
+        wq[ks][1] = __builtin_bit_cast(bf16x8, wqp[(ks * 2 + 1) * 64]);
+      }
+    }
+  };
+  auto load_second = [&](int hp) {  // k-steps 8..15 of waves 0..3, the (upper-K) halves of waves 6 / 7
+    const uint4* wqp = wq_ptr(hp);
+    if (wave < 4) {
+#pragma unroll
+      for (int ks = 8; ks < 16; ++ks) {
+        wq[ks][0] = __builtin_bit_cast(bf16x8, wqp[(ks * 2) * 64]);
+        wq[ks][1] = __builtin_bit_cast(bf16x8, wqp[(ks * 2 + 1) * 64]);
+      }
+    } else if (wave >= 6) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        wq[ks][0] = __builtin_bit_cast(bf16x8, wqp[(ks * 2) * 64]);
+        wq[ks][1] = __builtin_bit_cast(bf16x8, wqp[(ks * 2 + 1) * 64]);
+      }
+    }
+  };
+  load_first(0);
+  ATS(1);
+  if (t < 128) *(f32x4*)(GB + 4 * t) = gbv;
+  if (t >= 128 && t < 128 + 192) *(f32x4*)(GB + 2 * LF_D + 4 * (t - 128)) = bqv;
+  __syncthreads();   // gamma / beta are in LDS
+  // LayerNorm of ONE row held by 16 consecutive lanes -> LN(x) planes (attn_body's arithmetic)
+  auto ln_row = [&](const f32x4& v0, const f32x4& v1, const f32x4& v2, const f32x4& v3, int r, bool ok) {
+#pragma clang fp contract(off)
+    const f32x4 vv[NK] = {v0, v1, v2, v3};
+    float sm = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc) sm += (vv[kc][0] + vv[kc][1]) + (vv[kc][2] + vv[kc][3]);
+    const float mu = sf_sum16(sm) / (float)d;
+    float vs = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc) {
+      const f32x4 dv = vv[kc] - mu;
+      vs += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+    }
+    const float rs = 1.0f / sqrtf(sf_sum16(vs) / (float)d + A.ln_eps);
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc) {
+      const int k = kc * FA_KC + 4 * c4;
+      const f32x4 g = *(const f32x4*)(GB + k), be = *(const f32x4*)(GB + LF_D + k);
+      split4(Ah, Al, r * A2_AP + k, ok ? (vv[kc] - mu) * rs * g + be : zero4);
+    }
+  };
+  ln_row(ra[0][0], ra[1][0], ra[2][0], ra[3][0], r0, aok[0]);
+  ln_row(ra[0][1], ra[1][1], ra[2][1], ra[3][1], r0 + 32, aok[1]);
+  const int nq0 = L - Lq;
+  // the residual x of the query rows is PARKED in the output rows (row-major ownership here, read back in the accumulator
+  // layout at the end: same workgroup, barriers in between, lines no CU has cached) -- it would cost 32 registers for the
+  // whole kernel, or a second pass over the input
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int r = r0 + 32 * i;
+    if (r >= nq0 && r < L) {
+#pragma unroll
+      for (int kc = 0; kc < NK; ++kc) *(f32x4*)(A.ap + ((long long)b * Lq + (r - nq0)) * d + kc * FA_KC + 4 * c4) = ra[kc][i];
+    }
+  }
+  __syncthreads();
+  ATS(2);
+  const float scale = 1.0f / sqrtf((float)HD);
+  // out-projection: wave w owns output columns 32 w .. 32 w + 31 of both token blocks.  Every head pair's partial is computed
+  // exactly as the head-pair kernel computes it (fresh accumulator; the residual and the bias ride on the partial of pair
+  // w >> 1) and the partials are summed in ITS consumer's order, ((p0 + p1) + p2) + p3 -- so x2 has the bits the FFN launch
+  // would have formed from the four partial buffers, and the two forms of the attention block are interchangeable.  The
+  // running sum lives in global scratch (A.ap + A.ap_stride; written and read back by the same thread, L2-resident) instead
+  // of 32 registers carried through the head-pair loop.
+#pragma unroll 1
+  for (int hp = 0; hp < LF_NH / 2; ++hp) {
+    // ---- q|k|v^T = W . LN(x)^T of this head pair for both token blocks (attn_body's proj, SEL 2).  The first half of its
+    //      weight fragments was requested behind the previous pair's projection; the second half is requested here and lands
+    //      while the first eight k-steps run (all sixteen in flight across the attention core would not fit the registers) ----
+    // LDS addresses are recomputed per head pair from these opaque copies: hoisted out of the loop, the dozens of
+    // loop-invariant addresses (regions more than 64 KB apart: no common base + immediate) were spilled to scratch
+    int lane = lane_, wave = wave_, t = t_;
+    asm volatile("" : "+v"(lane), "+v"(wave), "+v"(t));
+    if (hp == 1) ATS(3);
+    load_second(hp);
+    f32x16 acc[2];
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q2][r] = 0.f;
+    const bool vblock = (wcb % 3) == 2;
+    {
+      const int ao = (lane & 31) * A2_AP + 8 * (lane >> 5) + (wave >= 6 ? 8 * 16 : 0);
+      if (!vblock) {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          if (ks >= 8 && wave >= 4) continue;
+          const bf16x8 xh0 = *(const bf16x8*)(Ah + ao + ks * 16), xl0 = *(const bf16x8*)(Al + ao + ks * 16);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xl0, acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][1], xh0, acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xh0, acc[0], 0, 0, 0);
+          if (nrb == 2) {
+            const bf16x8 xh1 = *(const bf16x8*)(Ah + ao + 32 * A2_AP + ks * 16), xl1 = *(const bf16x8*)(Al + ao + 32 * A2_AP + ks * 16);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xl1, acc[1], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][1], xh1, acc[1], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xh1, acc[1], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          if (ks >= 8 && wave >= 4) continue;
+          const bf16x8 xh0 = *(const bf16x8*)(Ah + ao + ks * 16), xl0 = *(const bf16x8*)(Al + ao + ks * 16);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl0, wq[ks][0], acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, wq[ks][1], acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, wq[ks][0], acc[0], 0, 0, 0);
+          if (nrb == 2) {
+            const bf16x8 xh1 = *(const bf16x8*)(Ah + ao + 32 * A2_AP + ks * 16), xl1 = *(const bf16x8*)(Al + ao + 32 * A2_AP + ks * 16);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl1, wq[ks][0], acc[1], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh1, wq[ks][1], acc[1], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh1, wq[ks][0], acc[1], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (hp == 1) ATS(4);
+    // the upper k-half of column blocks 4 / 5 meets the lower half in LDS
+    if (wave >= 6) {
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) PS[(((wave - 6) * 2 + q2) * 16 + r) * 64 + lane] = acc[q2][r];
+    }
+    // the weight registers are free: the NEXT head pair's first half is requested now and lands behind the attention core;
+    // then the out-proj fragments of THIS pair (column block `wave`, K = 64: 4 k-steps)
+    __builtin_amdgcn_sched_barrier(0);
+    if (hp + 1 < LF_NH / 2) load_first(hp + 1);
+    bf16x8 wof[4][2];
+    {
+      const uint4* wp = wo_p + (((long long)(hp * 4) * 8 + wave) * 2) * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        wof[ks][0] = __builtin_bit_cast(bf16x8, wp[((ks * 8) * 2) * 64]);
+        wof[ks][1] = __builtin_bit_cast(bf16x8, wp[((ks * 8) * 2 + 1) * 64]);
+      }
+    }
+    __syncthreads();   // the exchange is visible; the previous pair's O planes / PV partials are dead (its out-proj is done)
+    if (wave == 4 || wave == 5) {
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q2][r] += PS[(((wave - 4) * 2 + q2) * 16 + r) * 64 + lane];
+    }
+    if (wave < 6) {
+      const int which = wave % 3, hh = wave / 3, kg = lane >> 5;
+      const float mul = which == 0 ? scale : 1.f;
+      const float* bq = GB + 2 * LF_D + which * LF_D + (2 * hp + hh) * HD;   // bias of this (q|k|v, head): 32 values
+#pragma unroll
+      for (int rbk = 0; rbk < 2; ++rbk) {
+        if (rbk < nrb) {
+          const int tokn = rbk * 32 + (lane & 31);
+          if (which < 2) {
+            __bf16* ph = QKp + ((hh * 2 + which) * 2) * AT_QPL;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 bv = *(const f32x4*)(bq + 8 * g + 4 * kg);
+              split4(ph, ph + AT_QPL, tokn * AT_QP + 8 * g + 4 * kg,
+                     f32x4{(acc[rbk][4 * g] + bv[0]) * mul, (acc[rbk][4 * g + 1] + bv[1]) * mul, (acc[rbk][4 * g + 2] + bv[2]) * mul,
+                           (acc[rbk][4 * g + 3] + bv[3]) * mul});
+            }
+          } else {
+            __bf16* vh = Vtp + (hh * 2) * AT_VPL;
+            const float bch = bq[lane & 31];
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {
+              const f32x4 a0 = {acc[rbk][8 * sg] + bch, acc[rbk][8 * sg + 1] + bch, acc[rbk][8 * sg + 2] + bch, acc[rbk][8 * sg + 3] + bch};
+              const f32x4 a1 = {acc[rbk][8 * sg + 4] + bch, acc[rbk][8 * sg + 5] + bch, acc[rbk][8 * sg + 6] + bch, acc[rbk][8 * sg + 7] + bch};
+              const bf16x4 h0 = __builtin_convertvector(a0, bf16x4), h1 = __builtin_convertvector(a1, bf16x4);
+              const bf16x4 l0 = __builtin_convertvector(a0 - __builtin_convertvector(h0, f32x4), bf16x4);
+              const bf16x4 l1 = __builtin_convertvector(a1 - __builtin_convertvector(h1, f32x4), bf16x4);
+              const int off = (lane & 31) * AT_VP + rbk * 32 + 16 * sg + 8 * kg;
+              *(bf16x8*)(vh + off) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+              *(bf16x8*)(vh + AT_VPL + off) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (hp == 1) ATS(5);
+    // ---- attention of both heads of the pair (attn_body's core): wave = (head, query block, key block) ----
+    const int hh = wave >> 2, sub = wave & 3;
+    const int qb = (nrb == 2) ? (sub >> 1) : 0, kb = (nrb == 2) ? (sub & 1) : 0;
+    const bool score_wave = sub < nrb * nrb;
+    const __bf16* Qh = QKp + ((hh * 2 + 0) * 2) * AT_QPL;
+    const __bf16* Kh = QKp + ((hh * 2 + 1) * 2) * AT_QPL;
+    const __bf16* Vh = Vtp + (hh * 2) * AT_VPL;
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    float m_w = -INFINITY, l_w = 0.f;
+    if (score_wave) {
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      const int ko = (kb * 32 + (lane & 31)) * AT_QP + 8 * (lane >> 5), qo = (qb * 32 + (lane & 31)) * AT_QP + 8 * (lane >> 5);
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks) {
+        const bf16x8 kh = *(const bf16x8*)(Kh + ko + 16 * ks), kl = *(const bf16x8*)(Kh + AT_QPL + ko + 16 * ks);
+        const bf16x8 qh = *(const bf16x8*)(Qh + qo + 16 * ks), ql = *(const bf16x8*)(Qh + AT_QPL + qo + 16 * ks);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, sacc, 0, 0, 0);
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        sacc[r] = key < L ? sacc[r] : -INFINITY;
+        mx = fmaxf(mx, sacc[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sacc[r] = (mx == -INFINITY) ? 0.f : expf(sacc[r] - mx);
+        sum += sacc[r];
+      }
+      sum += __shfl_xor(sum, 32, 64);
+      m_w = mx;
+      l_w = sum;
+      if (lane < 32) {
+        SM[wave * 32 + lane] = mx;
+        SL[wave * 32 + lane] = sum;
+      }
+      const int vo = (lane & 31) * AT_VP + kb * 32 + 8 * (lane >> 5);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const f32x4 p0 = {sacc[8 * ks], sacc[8 * ks + 1], sacc[8 * ks + 2], sacc[8 * ks + 3]};
+        const f32x4 p1 = {sacc[8 * ks + 4], sacc[8 * ks + 5], sacc[8 * ks + 6], sacc[8 * ks + 7]};
+        const bf16x4 h0 = __builtin_convertvector(p0, bf16x4), h1 = __builtin_convertvector(p1, bf16x4);
+        const bf16x4 l0 = __builtin_convertvector(p0 - __builtin_convertvector(h0, f32x4), bf16x4);
+        const bf16x4 l1 = __builtin_convertvector(p1 - __builtin_convertvector(h1, f32x4), bf16x4);
+        const bf16x8 ph = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 vh = *(const bf16x8*)(Vh + vo + 16 * ks), vl = *(const bf16x8*)(Vh + AT_VPL + vo + 16 * ks);
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, oacc, 0, 0, 0);
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, oacc, 0, 0, 0);
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, oacc, 0, 0, 0);
+      }
+    }
+    if (hp == 1) ATS(6);
+    __syncthreads();   // every wave is done with q, k, v^T: the PV partials take the q / k planes, the O planes the v^T planes
+    if (score_wave) {
+      float fsc;
+      if (nrb == 2) {
+        const float m_o = SM[(wave ^ 1) * 32 + (lane & 31)], l_o = SL[(wave ^ 1) * 32 + (lane & 31)];
+        const float mg = fmaxf(m_w, m_o);
+        const float fw = (m_w == -INFINITY) ? 0.f : expf(m_w - mg), fo = (m_o == -INFINITY) ? 0.f : expf(m_o - mg);
+        fsc = fw / (l_w * fw + l_o * fo);
+      } else {
+        fsc = 1.0f / l_w;
+      }
+      float* od = OT + ((wave * 32) + (lane & 31)) * QSTR + 4 * (lane >> 5);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(f32x4*)(od + 8 * g) = f32x4{oacc[4 * g] * fsc, oacc[4 * g + 1] * fsc, oacc[4 * g + 2] * fsc, oacc[4 * g + 3] * fsc};
+    }
+    __syncthreads();
+    {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = t + LF_NT * it;
+        const int row = idx >> 4, h2 = (idx >> 3) & 1, q4 = idx & 7;
+        const int qbr = row >> 5, qq = row & 31;
+        f32x4 v = zero4;
+        if (row < nrb * 32 && row >= L - Lq && row < L) {
+          const int w0 = h2 * 4 + (nrb == 2 ? 2 * qbr : 0);
+          v = *(const f32x4*)(OT + (w0 * 32 + qq) * QSTR + 4 * q4);
+          if (nrb == 2) v += *(const f32x4*)(OT + ((w0 + 1) * 32 + qq) * QSTR + 4 * q4);
+        }
+        split4(Oh, Ol, row * A2_OP + h2 * 32 + 4 * q4, v);
+      }
+    }
+    __syncthreads();
+    // ---- out-projection partial of this head pair: p^T = Wo[32 w .. 32 w + 31, 64 hp : 64 hp + 64] . [o_h0 | o_h1]^T (+ the parked
+    //      residual and the bias on the pair that owns these columns); running sum s = hp == 0 ? p : s + p; the last pair
+    //      writes the finished rows over the parked residual (a wave reads and writes only ITS 32 columns) ----
+    if (hp == 1) ATS(7);
+    const bool mine = (wave >> 1) == hp;
+#pragma unroll
+    for (int rbk = 0; rbk < 2; ++rbk) {
+      if (rbk >= nrb || rbk * 32 + 32 <= nq0) continue;   // no query rows in this block (uniform)
+      const int row = rbk * 32 + (lane & 31);
+      const bool ok = row >= nq0 && row < L;
+      float* o = A.ap + ((long long)b * Lq + (min(max(row, nq0), L - 1) - nq0)) * d + wave * 32 + 4 * (lane >> 5);
+      float* sb = o + A.ap_stride;
+      // unconditional loads (a branch around a load drains the memory pipeline): the parked residual, the bias, the running sum
+      f32x4 xr[4], sv[4], bv[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        xr[g] = *(const f32x4*)(o + 8 * g);
+        sv[g] = *(const f32x4*)(sb + 8 * g);
+        bv[g] = *(const f32x4*)(A.bo + wave * 32 + 8 * g + 4 * (lane >> 5));
+      }
+      f32x16 pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+      const int ao = row * A2_OP + 8 * (lane >> 5);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 xh = *(const bf16x8*)(Oh + ao + ks * 16), xl = *(const bf16x8*)(Ol + ao + ks * 16);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wof[ks][0], xl, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wof[ks][1], xh, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wof[ks][0], xh, pacc, 0, 0, 0);
+      }
+      float* dstp = hp == LF_NH / 2 - 1 ? o : sb;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 p = {pacc[4 * g], pacc[4 * g + 1], pacc[4 * g + 2], pacc[4 * g + 3]};
+        const f32x4 pm = p + (xr[g] + bv[g]);
+        f32x4 v, r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = mine ? pm[q] : p[q];
+        const f32x4 sp = sv[g] + v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = hp == 0 ? v[q] : sp[q];
+        if (ok) *(f32x4*)(dstp + 8 * g) = r;
+      }
+    }
+    if (hp == 1) ATS(8);
+    // (the barrier behind the next pair's projection orders these LDS reads before its plane writes)
+  }
+  ATS(9);
+}
+
+// ================================================================================================
 // Packed FFN weights (sf_pack_ffn_weights): both matrices pre-split into bf16 hi/lo and stored in the order the
 // MFMA B-operand fragments are consumed, so that a wave loads its fragments straight from memory into registers
 // (1 KB contiguous per wave-wide load) and the weights never pass through LDS:
@@ -829,9 +1272,11 @@ struct FfnArgs {
   int* counters;
   int ntiles, M, dbg;
   int parts_only;   // the chunk partials are the output (the next attention sums them, attn_body<.., PART>): no reduction here
+  int np;           // input partials per row: LF_NP (head-pair partials of attn_oproj_kernel) or 1 (finished rows of attn_all_kernel)
   SbArgs sb;
 };
 
+template <int NP>   // input partials per row (LF_NP, or 1: finished rows)
 __device__ __forceinline__ void ffn_body(const FfnArgs& F, const int blk) {
   // no floating-point contraction in this function: whether the compiler fuses a*b + c into an fma may differ between two
   // instantiations / variants of the same source, and the variants must produce the same bits (LayerNorm statistics)
@@ -897,13 +1342,13 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& F, const int blk) {
   const f32x4 lng = *(const f32x4*)(ln_g + 4 * lane), lnb = *(const f32x4*)(ln_b + 4 * lane);
   f32x4 x2[4];
   {
-    f32x4 pr[LF_NP][4];
+    f32x4 pr[NP][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int gr = min(row0 + wave + 8 * i, M - 1);
       const float* p = ap + (long long)gr * LF_D + 4 * lane;
 #pragma unroll
-      for (int q = 0; q < LF_NP; ++q) pr[q][i] = *(const f32x4*)(p + ((dbg & 1) ? 0 : q) * ap_stride);
+      for (int q = 0; q < NP; ++q) pr[q][i] = *(const f32x4*)(p + ((dbg & 1) ? 0 : q) * ap_stride);
     }
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -914,7 +1359,7 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& F, const int blk) {
     for (int i = 0; i < 4; ++i) {
       f32x4 s = pr[0][i];
 #pragma unroll
-      for (int q = 1; q < LF_NP; ++q) s += pr[q][i];
+      for (int q = 1; q < NP; ++q) s += pr[q][i];
       x2[i] = s;
     }
   }
@@ -1069,9 +1514,10 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& F, const int blk) {
 }
 
 __device__ unsigned long long lf_wg[4 * 64];   // SF_LF_DBG & 32: {HW_ID, XCC_ID, start, end} of the first 64 FFN workgroups
+template <int NP>
 __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(FfnArgs F) {
   const unsigned long long t0 = (F.dbg & 32) ? wall_clock64() : 0ull;
-  ffn_body(F, blockIdx.x);
+  ffn_body<NP>(F, blockIdx.x);
   if ((F.dbg & 32) && threadIdx.x == 0 && blockIdx.x < 64) {
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -1089,7 +1535,7 @@ __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(FfnArgs F) {
 // (dispatched first); all nffn + 4 B workgroups are co-resident at one per CU on the 168-CU rollout partition for B <= 32.
 __global__ __launch_bounds__(LF_NT) void seam_kernel(FfnArgs F, AttnArgs A, SeamArgs seam, int nffn) {
   if ((int)blockIdx.x < nffn) {
-    ffn_body(F, blockIdx.x);
+    ffn_body<LF_NP>(F, blockIdx.x);
   } else {
     const int u = blockIdx.x - nffn;
     attn_body<true, true>(A, u & 3, u >> 2, seam);
@@ -1197,7 +1643,7 @@ constexpr int F6_ROWS = 64;
 constexpr size_t F6_R1 = (size_t)2 * F6_ROWS * FB_AP * 2;                      // planes (hi, lo) of one half >= its f32 output tile
 static_assert((size_t)F6_ROWS * FB_XP * 4 <= F6_R1, "output tile must fit the plane region");
 
-template <int NH>
+template <int NH, int NP>
 __global__ __launch_bounds__(LF_NT) void ffn_wide_parts_kernel(FfnArgs F) {
   // no floating-point contraction in this function: whether the compiler fuses a*b + c into an fma may differ between two
   // instantiations / variants of the same source, and the variants must produce the same bits (LayerNorm statistics)
@@ -1225,32 +1671,40 @@ __global__ __launch_bounds__(LF_NT) void ffn_wide_parts_kernel(FfnArgs F) {
 #define WTS(i) do { if ((F.dbg & 16) && blockIdx.x == 0 && threadIdx.x == 0) lf_ts[32 + i] = wall_clock64(); } while (0)
   WTS(0);
   const int tok = lane & 31, nb = wave * 32 + 4 * (lane >> 5);
-  const uint4* w1c = w1p + ((long long)(c * 16) * 8 + wave) * 128 + lane;
-  const uint4* w2c = w2p + ((long long)(c * 16) * 8 + wave) * 128 + lane;
+  // every global access below is a buffer access: ONE 32-bit lane offset per stream (weights, partial rows, output rows) plus
+  // scalar offsets, instead of dozens of 64-bit lane addresses -- the registers are needed for data in flight
+  const __amdgpu_buffer_rsrc_t w1c = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(w1p), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2c = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(w2p), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t apr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ap), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xpr = __builtin_amdgcn_make_buffer_rsrc(F.xp, 0, 0x7fffffff, 0x00020000);
+  const unsigned wlane = (unsigned)((wave * 128 + lane) * 16);
   bf16x8 wf[16][2];
-  auto ldw = [&](const uint4* base, int ks, int plane) { return __builtin_bit_cast(bf16x8, base[(ks * 8) * 128 + plane * 64]); };
+  auto ldw = [&](const __amdgpu_buffer_rsrc_t& base, int ks, int plane) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(base, wlane, (unsigned)((((c * 16 + ks) * 8) * 128 + plane * 64) * 16), 0));
+  };
   const f32x4 lng = *(const f32x4*)(F.ln_g + 4 * lane), lnb = *(const f32x4*)(F.ln_b + 4 * lane);
   // ---- prologue (wave owns rows wave + 8 i of each 32-row quarter, lane = float4 column) ----
-  f32x4 pr[2][LF_NP][4];
+  f32x4 pr[2][NP][4];
   const f32x4 b2v = *(const f32x4*)(F.b2 + 4 * lane);
-  float* dst = F.xp + (long long)c * F.xp_stride + 4 * lane;   // thread t owns float4 (row = wave + 8 i, column 4 lane) of the output
-  auto request = [&](int q, f32x4 (&dst)[LF_NP][4]) {
+  // thread t owns float4 (row = wave + 8 i, column 4 lane) of the input partials and of the output: byte offset of (tile row r)
+  const unsigned aps = (unsigned)(ap_stride * 4), xps = (unsigned)((long long)c * F.xp_stride * 4);
+  auto rowoff = [&](int r) { return (unsigned)(((row0 + r) * LF_D + 4 * lane) * 4); };
+  auto request = [&](int q, f32x4 (&dst)[NP][4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int gr = min(row0 + 32 * q + wave + 8 * i, M - 1);
-      const float* p = ap + (long long)gr * LF_D + 4 * lane;
+      const unsigned off = (unsigned)((min(row0 + 32 * q + wave + 8 * i, M - 1) * LF_D + 4 * lane) * 4);
 #pragma unroll
-      for (int pq = 0; pq < LF_NP; ++pq) dst[pq][i] = *(const f32x4*)(p + pq * ap_stride);
+      for (int pq = 0; pq < NP; ++pq) dst[pq][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(apr, off, pq * aps, 0));
     }
   };
-  auto consume = [&](int q, const f32x4 (&src)[LF_NP][4]) {
+  auto consume = [&](int q, const f32x4 (&src)[NP][4]) {
 #pragma clang fp contract(off)
     f32x4 x2[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f32x4 sacc = src[0][i];
 #pragma unroll
-      for (int pq = 1; pq < LF_NP; ++pq) sacc += src[pq][i];
+      for (int pq = 1; pq < NP; ++pq) sacc += src[pq][i];
       x2[i] = sacc;
     }
     float mean[4], rstd[4];
@@ -1267,78 +1721,47 @@ __global__ __launch_bounds__(LF_NT) void ffn_wide_parts_kernel(FfnArgs F) {
       const int r = 32 * (q & 1) + wave + 8 * i;
       split4(Ph, Ph + F6_ROWS * FB_AP, r * FB_AP + 4 * lane, (x2[i] - mean[i]) * rstd[i] * lng + lnb);
       // chunk 0 carries the residual and the bias (ffn_body's rule): parked in this thread's own output float4
-      if (c == 0 && row0 + 32 * q + wave + 8 * i < M) *(f32x4*)(dst + (long long)(row0 + 32 * q + wave + 8 * i) * LF_D) = x2[i] + b2v;
+      if (c == 0 && row0 + 32 * q + wave + 8 * i < M)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x2[i] + b2v), xpr, rowoff(32 * q + wave + 8 * i), xps, 0);
     }
   };
-  // W1 fragments: k-steps 0..7 behind the first quarter (64 rows) / the third quarter's request (128 rows: two
-  // partial buffers + all of W1 would not fit the 256 registers of a wave), k-steps 8..15 once the last quarter's
-  // partials are in flight or consumed
-  constexpr int Q_LO = NQ > 2 ? 1 : -1, Q_HI = NQ > 2 ? NQ - 2 : NQ - 1;
-  request(0, pr[0]);
-  WTS(1);
-  if (Q_LO < 0) {
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      wf[ks][0] = ldw(w1c, ks, 0);
-      wf[ks][1] = ldw(w1c, ks, 1);
-    }
-  }
-  request(1, pr[1]);
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    consume(q, pr[q & 1]);
-    __builtin_amdgcn_sched_barrier(0);   // requests stay BEHIND the arithmetic above in the instruction stream
-    if (q + 2 < NQ) request(q + 2, pr[q & 1]);
-    if (q == Q_LO) {
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        wf[ks][0] = ldw(w1c, ks, 0);
-        wf[ks][1] = ldw(w1c, ks, 1);
-      }
-    }
-    if (q == Q_HI) {
-#pragma unroll
-      for (int ks = 8; ks < 16; ++ks) {
-        wf[ks][0] = ldw(w1c, ks, 0);
-        wf[ks][1] = ldw(w1c, ks, 1);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  WTS(2);
-  // the FFN1 bias of this lane's hidden columns: requested behind the weights, needed after the first half's MFMAs
-  f32x4 b1v[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) b1v[g] = *(const f32x4*)(F.b1 + c * LF_HC + nb + 8 * g);
-  __syncthreads();
-
   const int ao = (lane & 31) * FB_AP + 8 * (lane >> 5);
-  f32x16 acc0, acc1;
-  // ---- FFN1, half by half; in the last half every fragment's registers then take the matching W2 fragment ----
+  f32x4 b1v[4];
+  auto load_b1 = [&]() {   // the FFN1 bias of this lane's hidden columns
 #pragma unroll
-  for (int h = 0; h < NH; ++h) {
+    for (int g = 0; g < 4; ++g) b1v[g] = *(const f32x4*)(F.b1 + c * LF_HC + nb + 8 * g);
+  };
+  auto load_w1 = [&](int k0, int k1) {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      if (ks >= k0 && ks < k1) {
+        wf[ks][0] = ldw(w1c, ks, 0);
+        wf[ks][1] = ldw(w1c, ks, 1);
+      }
+  };
+  // FFN1 of half h over k-steps [k0, k1); REPL: every fragment's registers then take the matching W2 fragment
+  auto ffn1 = [&](int h, int k0, int k1, f32x16& a0, f32x16& a1, bool repl) {
     const __bf16* Ph = PH(h);
     const __bf16* Pl = Ph + F6_ROWS * FB_AP;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-#pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
+      if (ks < k0 || ks >= k1) continue;
       const bf16x8 xh0 = *(const bf16x8*)(Ph + ao + ks * 16), xl0 = *(const bf16x8*)(Pl + ao + ks * 16);
       const bf16x8 xh1 = *(const bf16x8*)(Ph + ao + 32 * FB_AP + ks * 16), xl1 = *(const bf16x8*)(Pl + ao + 32 * FB_AP + ks * 16);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl0, acc0, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh0, acc0, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl1, acc1, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh1, acc1, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh1, acc1, 0, 0, 0);
-      if (h == NH - 1) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl0, a0, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh0, a0, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh0, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xl1, a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][1], xh1, a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][0], xh1, a1, 0, 0, 0);
+      if (repl) {
         wf[ks][0] = ldw(w2c, ks, 0);
         wf[ks][1] = ldw(w2c, ks, 1);
       }
-      if (h == 0 && (ks & 3) == 3 && ks < 15) WTS(10 + (ks >> 2));
     }
-    WTS(3 + h);
-    __syncthreads();   // every wave has read the LN2 planes of this half: its hidden planes take their place
+  };
+  // relu(h + b1) of half h -> its hidden planes (over its LN2 planes: every wave must have read them)
+  auto hidden = [&](int h, const f32x16& a0, const f32x16& a1) {
     __bf16* Hh = PH(h);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1346,12 +1769,70 @@ __global__ __launch_bounds__(LF_NT) void ffn_wide_parts_kernel(FfnArgs F) {
       f32x4 h0, h1;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        h0[q] = fmaxf(acc0[4 * g + q] + bv[q], 0.f);
-        h1[q] = fmaxf(acc1[4 * g + q] + bv[q], 0.f);
+        h0[q] = fmaxf(a0[4 * g + q] + bv[q], 0.f);
+        h1[q] = fmaxf(a1[4 * g + q] + bv[q], 0.f);
       }
       split4(Hh, Hh + F6_ROWS * FB_AP, tok * FB_AP + nb + 8 * g, h0);
       split4(Hh, Hh + F6_ROWS * FB_AP, (32 + tok) * FB_AP + nb + 8 * g, h1);
     }
+  };
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  if constexpr (NH == 1) {
+    // ---- 64 rows: both quarters and k-steps 0..7 of W1 requested up front, k-steps 8..15 behind the LayerNorm arithmetic ----
+    request(0, pr[0]);
+    WTS(1);
+    load_w1(0, 8);
+    request(1, pr[1]);
+    consume(0, pr[0]);
+    consume(1, pr[1]);
+    __builtin_amdgcn_sched_barrier(0);   // requests stay BEHIND the arithmetic above in the instruction stream
+    load_w1(8, 16);
+    load_b1();
+    WTS(2);
+    __syncthreads();
+    ffn1(0, 0, 16, acc0, acc1, true);
+    WTS(3);
+    __syncthreads();   // every wave has read the LN2 planes: the hidden planes take their place
+    hidden(0, acc0, acc1);
+  } else {
+    // ---- 128 rows.  A workgroup ingests ~1 MB (512 KB of partials, 2 x 256 KB of weights) at ~100 GB/s: as long as the matrix
+    //      pipe waits for all of it the launch is twice as long as its MFMAs.  So the SECOND half's partials arrive behind the
+    //      first half's FFN1: half A's quarters + k-steps 0..7 of W1 go out first; FFN1 of half A over k-steps 0..7 runs while
+    //      half B's quarters land; k-steps 8..15 of W1 are requested behind half B's LayerNorm and consumed after FFN1 of half
+    //      B over k-steps 0..7 (whose fragment registers then take W2's); k-steps 8..15 of both halves follow. ----
+    f32x16 accB0, accB1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accB0[r] = accB1[r] = 0.f;
+    request(0, pr[0]);
+    WTS(1);
+    request(1, pr[1]);
+    load_w1(0, 8);
+    consume(0, pr[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    request(2, pr[0]);
+    consume(1, pr[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    request(3, pr[1]);
+    WTS(2);
+    __syncthreads();   // LN2 planes of half A complete
+    ffn1(0, 0, 8, acc0, acc1, false);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(2, pr[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    load_w1(8, 16);
+    consume(3, pr[1]);
+    load_b1();
+    WTS(3);
+    __syncthreads();   // LN2 planes of half B complete
+    ffn1(1, 0, 8, accB0, accB1, true);
+    ffn1(0, 8, 16, acc0, acc1, false);
+    ffn1(1, 8, 16, accB0, accB1, true);
+    WTS(4);
+    __syncthreads();   // every wave has read the LN2 planes: the hidden planes take their place
+    hidden(0, acc0, acc1);
+    hidden(1, accB0, accB1);
   }
   __syncthreads();
   WTS(5);
@@ -1381,7 +1862,8 @@ __global__ __launch_bounds__(LF_NT) void ffn_wide_parts_kernel(FfnArgs F) {
     if (h == NH - 1 && c == 0) {
       // the weight fragments are dead: their registers take this thread's parked x2 + b2 back (same thread, same addresses)
 #pragma unroll
-      for (int i = 0; i < 8 * NH; ++i) res[i] = *(const f32x4*)(dst + (long long)min(row0 + wave + 8 * i, M - 1) * LF_D);
+      for (int i = 0; i < 8 * NH; ++i)
+        res[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xpr, rowoff(min(wave + 8 * i, M - 1 - row0)), xps, 0));
     }
     __syncthreads();   // every wave has read the hidden planes of this half
     float* OT = OTH(h);
@@ -1399,7 +1881,7 @@ __global__ __launch_bounds__(LF_NT) void ffn_wide_parts_kernel(FfnArgs F) {
     const int r = wave + 8 * i;   // row of the tile; half i >> 3
     f32x4 v = *(const f32x4*)(OTH(i >> 3) + (r & 63) * FB_XP + 4 * lane);
     if (c == 0) v += res[i];
-    if (row0 + r < M) *(f32x4*)(dst + (long long)(row0 + r) * LF_D) = v;
+    if (row0 + r < M) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xpr, rowoff(r), xps, 0);
   }
   WTS(9);
 }
@@ -1480,6 +1962,37 @@ int sf_attn_oproj_ring_ex(const float* ring, int ring_frames, int nslots, int f0
                            B, L, Lq, st);
 }
 
+// ---- all 8 heads in one workgroup per video: x2 [B*Lq][256] = x + out_proj(MHA(LN1(x))) + b_o (finished rows) ----
+template <bool RING, bool PART>
+static int launch_attn_all(const float* xin, long long x_batch_stride, const float* pe, int f0, int ring_frames, int nslots,
+                           const sf_tfm_layer& w, float eps, float* x2, int B, int L, int Lq, hipStream_t st, long long xparts_stride = 0) {
+  if (!w.attn_in_packed || !w.attn_out_packed)
+    return sf_set_err(-1, "invalid argument: fused attention needs packed weights (sf_pack_attn_weights)", __FILE__, __LINE__);
+  auto kern = attn_all_kernel<RING, PART>;
+  SF_TRY(sf_ensure_dyn_lds((const void*)kern, A8_LDS));
+  sf_prof_begin(SF_K_MHA, st, 6.0 * B * L * (double)LF_D * LF_D + 4.0 * (double)B * LF_NH * Lq * L * LF_HD +
+                                  2.0 * B * Lq * (double)LF_D * LF_D);
+  // x2 [2][B*Lq][256]: the finished rows, and behind them the running sum of the head pairs' partials (scratch)
+  AttnArgs A = make_attn_args(xin, x_batch_stride, pe, f0, ring_frames, nslots, w, eps, x2, (long long)B * Lq * LF_D, L, Lq);
+  A.xparts_stride = xparts_stride;
+  A.nvideos = B;
+  hipLaunchKernelGGL(kern, dim3(B), dim3(LF_NT), A8_LDS, st, A);
+  sf_prof_end(SF_K_MHA, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+int sf_attn_all_ex(const float* xin, const sf_tfm_layer& w, float eps, float* x2, int B, int L, int Lq, hipStream_t st) {
+  return launch_attn_all<false, false>(xin, (long long)L * LF_D, nullptr, 0, 1, 1, w, eps, x2, B, L, Lq, st);
+}
+int sf_attn_all_parts_ex(const float* xparts, long long xparts_stride, const sf_tfm_layer& w, float eps, float* x2, int B, int L,
+                         int Lq, hipStream_t st) {
+  return launch_attn_all<false, true>(xparts, (long long)L * LF_D, nullptr, 0, 1, 1, w, eps, x2, B, L, Lq, st, xparts_stride);
+}
+int sf_attn_all_ring_ex(const float* ring, int ring_frames, int nslots, int f0, const float* pe, const sf_tfm_layer& w, float eps,
+                        float* x2, int B, int L, int Lq, hipStream_t st) {
+  return launch_attn_all<true, false>(ring, (long long)ring_frames * nslots * LF_D, pe, f0, ring_frames, nslots, w, eps, x2, B, L, Lq, st);
+}
+
 static SbArgs make_sb(const void* wout_packed, const float* b_out, const void* win_packed, const float* b_in, float* slots,
                       long long slots_bs, long long slots_off, float* ring, long long ring_bs, long long ring_off,
                       int rows_per_video);
@@ -1492,6 +2005,7 @@ static FfnArgs make_ffn_args(const float* ap, long long ap_stride, const sf_tfm_
   F.xp = xp; F.xp_stride = xp_stride; F.xout = xout; F.counters = counters;
   F.ntiles = (M + FB_ROWS - 1) / FB_ROWS; F.M = M; F.dbg = lf_dbg(); F.sb = sb;
   F.parts_only = 0;
+  F.np = LF_NP;
   return F;
 }
 
@@ -1499,57 +2013,66 @@ static FfnArgs make_ffn_args(const float* ap, long long ap_stride, const sf_tfm_
 static int ffn_blocks(int tiles) { return tiles < 8 ? 32 : (tiles / 8) * 32 + (tiles % 8) * 4; }
 
 static int launch_ffn(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp, long long xp_stride,
-                      float* xout, int* counters, int M, int ffn, const SbArgs& sb, hipStream_t st, int parts_only = 0) {
+                      float* xout, int* counters, int M, int ffn, const SbArgs& sb, hipStream_t st, int parts_only = 0, int np = LF_NP) {
   static_assert(FB_LDS <= 160 * 1024, "FFN kernel: LDS budget");
   static_assert((size_t)4 * 16 * 64 * 4 + (size_t)2 * 32 * SB_PP * 2 <= (size_t)2 * FB_ROWS * FB_AP * 2, "boundary scratch fits the H planes");
   if (!w.lin1_packed || !w.lin2_packed || ffn != LF_NCH * LF_HC)
     return sf_set_err(-1, "invalid argument: fused FFN needs packed weights (sf_pack_ffn_weights) and ffn == 1024", __FILE__, __LINE__);
-  SF_TRY(sf_ensure_dyn_lds((const void*)ffn_partial_kernel, (size_t)(FB_LDS)));
+  SF_TRY(sf_ensure_dyn_lds((const void*)ffn_partial_kernel<LF_NP>, (size_t)(FB_LDS)));
+  SF_TRY(sf_ensure_dyn_lds((const void*)ffn_partial_kernel<1>, (size_t)(FB_LDS)));
   const int tiles = (M + FB_ROWS - 1) / FB_ROWS;
   sf_prof_begin(SF_K_FFN, st, 4.0 * M * (double)LF_D * ffn);
   FfnArgs F = make_ffn_args(ap, ap_stride, w, eps, xp, xp_stride, xout, counters, M, sb);
   F.parts_only = parts_only;
-  hipLaunchKernelGGL(ffn_partial_kernel, dim3(ffn_blocks(tiles)), dim3(LF_NT), FB_LDS, st, F);
+  F.np = np;
+  if (np == 1)
+    hipLaunchKernelGGL(ffn_partial_kernel<1>, dim3(ffn_blocks(tiles)), dim3(LF_NT), FB_LDS, st, F);
+  else
+    hipLaunchKernelGGL(ffn_partial_kernel<LF_NP>, dim3(ffn_blocks(tiles)), dim3(LF_NT), FB_LDS, st, F);
   sf_prof_end(SF_K_FFN, st);
   SF_CHECK_LAUNCH();
   return 0;
 }
 
 int sf_ffn_partial_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp,
-                      long long xp_stride, float* xout, int* counters, int M, int ffn, hipStream_t st) {
+                      long long xp_stride, float* xout, int* counters, int M, int ffn, hipStream_t st, int np) {
   SbArgs sb;
   memset(&sb, 0, sizeof(sb));
-  return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, xout, counters, M, ffn, sb, st);
+  return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, xout, counters, M, ffn, sb, st, 0, np);
 }
 
 // the four chunk partials xp[c] ARE the output (summed by the next layer's sf_attn_oproj_parts_ex).  Rows per workgroup:
 // the calling thread's option (sf_rollout_opts.ffn_rows), else 64 when sf_set_ffn_rows64(1), else 32; halved while the
 // launch would have fewer rows than one workgroup covers.
-template <int NH>
+template <int NH, int NP>
 static int launch_ffn_wide(const FfnArgs& F, int ffn, hipStream_t st) {
   constexpr size_t LDS = (size_t)NH * F6_R1;
   static_assert(LDS <= 160 * 1024, "wide FFN kernel: LDS budget");
-  SF_TRY(sf_ensure_dyn_lds((const void*)ffn_wide_parts_kernel<NH>, LDS));
+  SF_TRY(sf_ensure_dyn_lds((const void*)ffn_wide_parts_kernel<NH, NP>, LDS));
+  if ((long long)LF_NP * F.ap_stride * 4 >= 0x7fffffffLL || (long long)LF_NCH * F.xp_stride * 4 >= 0x7fffffffLL)
+    return sf_set_err(-1, "invalid argument: partial buffers beyond the 2 GB a buffer descriptor addresses", __FILE__, __LINE__);
   const int ntw = (F.M + 64 * NH - 1) / (64 * NH);
   sf_prof_begin(SF_K_FFN, st, 4.0 * F.M * (double)LF_D * ffn);
-  hipLaunchKernelGGL(ffn_wide_parts_kernel<NH>, dim3(ffn_blocks(ntw)), dim3(LF_NT), LDS, st, F);
+  hipLaunchKernelGGL((ffn_wide_parts_kernel<NH, NP>), dim3(ffn_blocks(ntw)), dim3(LF_NT), LDS, st, F);
   sf_prof_end(SF_K_FFN, st);
   SF_CHECK_LAUNCH();
   return 0;
 }
 
 int sf_ffn_parts_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp, long long xp_stride, int M,
-                    int ffn, hipStream_t st) {
+                    int ffn, hipStream_t st, int np) {
   SbArgs sb;
   memset(&sb, 0, sizeof(sb));
   int rows = sf_thread_opts().ffn_rows > 0 ? sf_thread_opts().ffn_rows : (g_ffn_rows64 ? 64 : 32);
   while (rows > 32 && M < rows) rows >>= 1;
-  if (rows <= 32) return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, nullptr, nullptr, M, ffn, sb, st, 1);
+  if (rows <= 32) return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, nullptr, nullptr, M, ffn, sb, st, 1, np);
   if (!w.lin1_packed || !w.lin2_packed || ffn != LF_NCH * LF_HC)
     return sf_set_err(-1, "invalid argument: fused FFN needs packed weights (sf_pack_ffn_weights) and ffn == 1024", __FILE__, __LINE__);
   FfnArgs F = make_ffn_args(ap, ap_stride, w, eps, xp, xp_stride, nullptr, nullptr, M, sb);
   F.parts_only = 1;
-  return rows >= 128 ? launch_ffn_wide<2>(F, ffn, st) : launch_ffn_wide<1>(F, ffn, st);
+  F.np = np;
+  if (np == 1) return rows >= 128 ? launch_ffn_wide<2, 1>(F, ffn, st) : launch_ffn_wide<1, 1>(F, ffn, st);
+  return rows >= 128 ? launch_ffn_wide<2, LF_NP>(F, ffn, st) : launch_ffn_wide<1, LF_NP>(F, ffn, st);
 }
 
 // Building block behind the layers 0 .. n-2 of a rollout step, exported for kernel-level tests: head-pair partials
@@ -1563,9 +2086,24 @@ extern "C" int sf_ffn_chunk_partials_f32(const sf_tfm_layer* w, const float* ap,
   SF_REQUIRE(w->norm2_g && w->norm2_b && w->lin1_b && w->lin2_b && w->lin1_packed && w->lin2_packed, "sf_ffn_chunk_partials_f32: null weight (packed FFN weights needed)");
   SfThreadOpts saved = sf_thread_opts();
   if (rows_per_wg) sf_thread_opts().ffn_rows = rows_per_wg;
-  const int rc = sf_ffn_parts_ex(ap, ap_stride, *w, 1e-5f, xp, xp_stride, M, ffn, (hipStream_t)stream);
+  const int rc = sf_ffn_parts_ex(ap, ap_stride, *w, 1e-5f, xp, xp_stride, M, ffn, (hipStream_t)stream, LF_NP);
   sf_thread_opts() = saved;
   return rc;
+}
+
+// Attention block of a pre-LN layer, exported for kernel-level tests: x [B][L][256] -> the last Lq rows of every video of
+//   x2 = x + out_proj(MHA(LN1(x))) + b_o      (nn.TransformerEncoderLayer._sa_block + residual, norm_first; slotformer.py:72-80)
+// heads_per_wg = 8: `out` [2][B*Lq][256]: out[0] receives x2 (one workgroup per video, all heads), out[1] is scratch;
+// heads_per_wg = 2: `out` [4][B*Lq][256] receives the four head-pair partials whose sum ((p0 + p1) + p2) + p3 is x2.
+extern "C" int sf_attn_block_f32(const sf_tfm_layer* w, const float* x, float* out, int B, int L, int Lq, int heads_per_wg,
+                                 void* stream) {
+  SF_REQUIRE(w && x && out && B > 0, "sf_attn_block_f32: null pointer / empty problem");
+  SF_REQUIRE(L >= 1 && L <= FA_ROWS && Lq >= 1 && Lq <= L, "sf_attn_block_f32: needs 1 <= Lq <= L <= 64");
+  SF_REQUIRE(heads_per_wg == 2 || heads_per_wg == 8, "sf_attn_block_f32: heads_per_wg must be 2 or 8");
+  SF_REQUIRE(w->norm1_g && w->norm1_b && w->in_proj_b && w->out_proj_b && w->attn_in_packed && w->attn_out_packed,
+             "sf_attn_block_f32: null weight (packed attention weights needed)");
+  if (heads_per_wg == 8) return sf_attn_all_ex(x, *w, 1e-5f, out, B, L, Lq, (hipStream_t)stream);
+  return sf_attn_oproj_ex(x, *w, 1e-5f, out, (long long)B * Lq * LF_D, B, L, Lq, (hipStream_t)stream);
 }
 
 // last layer of a rollout step: the FFN's last-arriving workgroups also run the step boundary (out-proj -> slots frame
@@ -1573,10 +2111,10 @@ extern "C" int sf_ffn_chunk_partials_f32(const sf_tfm_layer* w, const float* ap,
 int sf_ffn_boundary_ex(const float* ap, long long ap_stride, const sf_tfm_layer& w, float eps, float* xp, long long xp_stride,
                        int* counters, int ffn, const void* wout_packed, const float* b_out, const void* win_packed,
                        const float* b_in, float* slots, long long slots_bs, int frame, float* ring, int ring_frames, int nslots,
-                       int B, hipStream_t st) {
+                       int B, hipStream_t st, int np) {
   const SbArgs sb = make_sb(wout_packed, b_out, win_packed, b_in, slots, slots_bs, (long long)frame * nslots * SB_C, ring,
                             (long long)ring_frames * nslots * LF_D, (long long)(frame % ring_frames) * nslots * LF_D, nslots);
-  return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, nullptr, counters, B * nslots, ffn, sb, st);
+  return launch_ffn(ap, ap_stride, w, eps, xp, xp_stride, nullptr, counters, B * nslots, ffn, sb, st, 0, np);
 }
 
 // ONE launch: last-layer FFN + step boundary of step s (writes slots frame `frame`, ring frame `frame`) and the layer-0

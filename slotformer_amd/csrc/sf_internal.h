@@ -4,13 +4,13 @@
 
 // Per-call options of the calling THREAD (the reference drives `forward` from one host thread per GPU,
 // base_slots/extract_slots.py:128): set by the *_opts entry points for the duration of a call, never process-wide.
-// precision / seam < 0 and ffn_rows / attn_videos == 0 mean "the process default" (sf_set_precision, sf_set_seam_fused,
+// precision / seam < 0 and ffn_rows / attn_heads == 0 mean "the process default" (sf_set_precision, sf_set_seam_fused,
 // sf_set_ffn_rows64).
 struct SfThreadOpts {
   int precision = -1;    // 0 exact f32, 1 split-bf16, 2 single-pass bf16
   int seam = -1;         // seam launches of the rollout off / on
   int ffn_rows = 0;      // rows per workgroup of the chunk-partial FFN launches: 32 / 64 / 128
-  int attn_videos = 0;   // videos per workgroup of the layer attention launches: 1 / 2
+  int attn_heads = 0;    // heads per workgroup of the layer attention launches: 2 (head pairs, four partials) / 8 (finished rows)
 };
 SfThreadOpts& sf_thread_opts();
 // hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device) -- a process may drive several GPUs

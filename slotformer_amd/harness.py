@@ -115,8 +115,10 @@ def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises
     N, D = rollouter.num_slots, rollouter.in_proj.in_features
     out = torch.empty(V, T + pred_len, N, D, pin_memory=True) if to_host else torch.empty(V, T + pred_len, N, D, device=dev)
     nfull = V // batch_size
+    tail_opts = None
     if nfull:
         pipe = _pipeline_for(savi, rollouter, batch_size, T, pred_len, pipe_kw)
+        tail_opts = pipe.rollout_opts   # the ragged tail runs the same kernel forms as the full batches
         imgs = [videos[j * batch_size:(j + 1) * batch_size] for j in range(nfull)]
         nz = None if noises is None else [noises[j * batch_size:(j + 1) * batch_size].float().to(dev).contiguous() for j in range(nfull)]
         pipe.run(imgs, nz, out=out[:nfull * batch_size].view(nfull, batch_size, T + pred_len, N, D), serial=not pipelined or nfull < 2)
@@ -127,7 +129,7 @@ def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises
         post, _, _ = engine.savi_encode(savi, videos[r0:].to(dev).contiguous(), noise=nz)
         tail = torch.zeros(V - r0, T + pred_len, N, D, device=dev)
         tail[:, :T] = post
-        engine.rollout(rollouter, tail, T, pred_len)
+        engine.rollout(rollouter, tail, T, pred_len, opts=tail_opts)
         out[r0:].copy_(tail)
     if to_host:
         torch.cuda.synchronize(dev)

@@ -75,9 +75,9 @@ def encode_mask_words(spec):
 ROLL_WORDS_3 = [0xffffff00] * 7 + [0]          # rows 0-6 of shader engines 1-3: 21 CUs per XCD
 LANE0_WORDS_3 = [0x000000ff] * 8               # shader engine 0: 8 CUs per XCD
 LANE1_WORDS_3 = [0] * 7 + [0xffffff00]         # row 7 of shader engines 1-3: 3 CUs per XCD
-# partition 'pair': two rollout streams share CU rows 0-4 of all four shader engines, the encode gets rows 5-7
-ROLL_WORDS_P = [0xffffffff] * 5 + [0] * 3      # 20 CUs per XCD
-ENC_WORDS_P = [0] * 5 + [0xffffffff] * 3       # 12 CUs per XCD
+# partition 'pair': two rollout streams share CU rows 0-3 of all four shader engines, the encode gets rows 4-7
+ROLL_WORDS_P = [0xffffffff] * 4 + [0] * 4      # 16 CUs per XCD
+ENC_WORDS_P = [0] * 4 + [0xffffffff] * 4       # 16 CUs per XCD
 
 
 class _Unit:
@@ -100,7 +100,8 @@ class EncodeRolloutPipeline:
     steal_steps: time steps of convolutions per batch computed on the rollout streams (may be fractional: 1.25 = one step,
     two for every fourth batch); None = the partition's tuned default.
     rollout_opts: per-call kernel options of the captured rollouts (engine.rollout_opts); None = the partition's default
-    ('pair': no seam launches, 128-row FFN workgroups -- the throughput settings; otherwise the library defaults).
+    ('pair': no seam launches, 128-row FFN workgroups, all-heads attention workgroups -- the throughput settings, the same
+    bits as the library defaults; otherwise the library defaults).
     """
 
     def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=None, use_graph=True,
@@ -121,7 +122,14 @@ class EncodeRolloutPipeline:
             partition = 'none'
         if partition == 'three' and self.B < 4:
             partition = 'two'
-        self.G = int(group) if group else (2 if partition == 'pair' else 1)
+        self._lib = _lib.lib()
+        # rollouters on the fused-layer path (per-video / per-row kernels) give a video the same bits in any batch: their
+        # batches can share a rollout unit.  The generic GEMM path picks tiles by problem size: one batch per unit there.
+        self.fused = bool(self._lib.sf_rollout_is_fused(C.byref(engine.rollouter_plan(rollouter).struct)))
+        if group and int(group) > 1 and not self.fused:
+            raise RuntimeError('slotformer_amd: group > 1 needs a rollouter on the fused-layer path (d_model 256, 8 heads, ffn 1024, '
+                               'window <= 64 tokens): the generic path\'s results depend on the batch size')
+        self.G = int(group) if group else (int(os.environ.get('SF_PIPE_GROUP', '4')) if (partition == 'pair' and self.fused) else 1)
         if self.G < 1:
             raise ValueError('slotformer_amd: group >= 1')
         nroll = 2 if partition == 'pair' else 1
@@ -129,20 +137,24 @@ class EncodeRolloutPipeline:
         self.NU = 2 * nroll
         self.lead = 2 * nroll                    # stolen features of unit u are computed behind the rollout of unit u - lead
         if steal_steps is None:
-            steal_steps = float(os.environ.get('SF_PIPE_STEAL', {'pair': 0.75, 'two': 1, 'three': 0}.get(partition, 1)))
+            steal_steps = float(os.environ.get('SF_PIPE_STEAL', {'pair': 0, 'two': 1, 'three': 0}.get(partition, 1)))
         self.steal = max(0.0, min(float(steal_steps), float(self.T)))   # may be fractional: see _steal_of
         self._masked = []
         self._lib = _lib.lib()
         if rollout_opts is None and partition == 'pair':
             # several chains share the rollout CUs: seam launches (consumers spinning on a CU each) cost more than they
             # save, and the CUs are the bound -- wide FFN workgroups (one load of the weight chunk per 128 rows)
-            rollout_opts = {'seam': bool(int(os.environ.get('SF_PIPE_SEAM', '0'))), 'ffn_rows': int(os.environ.get('SF_PIPE_FFN_ROWS', '128'))}
+            # -- wide FFN workgroups (one load of the weight chunk per 128 rows) and one attention workgroup per video running
+            # all 8 heads (the layer input ingested and normalised once, finished rows out instead of four partials)
+            rollout_opts = {'seam': bool(int(os.environ.get('SF_PIPE_SEAM', '0'))), 'ffn_rows': int(os.environ.get('SF_PIPE_FFN_ROWS', '128')),
+                            'attn_heads': int(os.environ.get('SF_PIPE_ATTN_HEADS', '8'))}
         self.rollout_opts = engine.rollout_opts(rollout_opts)
-        # units of fewer batches (the ramp at both ends of a run) are on the critical path of fill and drain: narrower FFN
-        # workgroups (more of them) finish a launch sooner
+        # units of fewer batches (the ramp at both ends of a run) are on the critical path of fill and drain: the latency forms
+        # of the kernels (head-pair attention workgroups, narrower FFN workgroups: more, shorter workgroups per launch) -- the
+        # same bits
         self.tail_opts = self.rollout_opts
-        if self.rollout_opts is not None and self.rollout_opts.ffn_rows > 64:
-            self.tail_opts = _lib.sf_rollout_opts(self.rollout_opts.precision, self.rollout_opts.seam_fused, 64, self.rollout_opts.attn_videos)
+        if self.rollout_opts is not None and (self.rollout_opts.ffn_rows > 64 or self.rollout_opts.attn_heads_per_wg == 8):
+            self.tail_opts = _lib.sf_rollout_opts(self.rollout_opts.precision, self.rollout_opts.seam_fused, min(self.rollout_opts.ffn_rows or 64, 64), 2)
         self.use_graph = bool(use_graph)
         self._key = ('pipe', id(self))
         self._plan = None
@@ -161,6 +173,8 @@ class EncodeRolloutPipeline:
                     enc_words = ENC_WORDS_P
                     if isinstance(encode_cu_word, str) and encode_cu_word.startswith('rows'):
                         enc_words = encode_mask_words(encode_cu_word)
+                    elif os.environ.get('SF_PIPE_CU_SPLIT'):
+                        enc_words = encode_mask_words(os.environ['SF_PIPE_CU_SPLIT'])
                     roll_words = [~w & 0xffffffff for w in enc_words]
                     self.roll_streams = [self._masked_stream(roll_words), self._masked_stream(roll_words)]
                     self.s_roll = self.roll_streams[0]
@@ -190,12 +204,15 @@ class EncodeRolloutPipeline:
             self.encode_cus = self.rollout_cus = 256
         if not self.roll_streams:
             self.roll_streams = [self.s_roll]
-        self.s_free = torch.cuda.Stream(device=self.dev) if len(self.roll_streams) > 1 else None   # unmasked: the drain
+        # unmasked streams for the drain units
+        self.s_free = [torch.cuda.Stream(device=self.dev) for _ in range(2)] if len(self.roll_streams) > 1 else []
         self.s_enc = self.lanes[0][0]
         self.fill_whole_chip = True      # the first encode(s) of a run on the calling stream (all CUs)
         # (group 1: a second whole-chip encode was measured worse, 311 vs 323 k frames/s at 20 steps; with group 2 the first
         #  rollout cannot start before both batches of its unit are encoded)
-        self.ramp = bool(int(os.environ.get('SF_PIPE_RAMP', '1')))   # single-batch units at both ends of a run (_unit_plan)
+        # smaller units at the end of a run (_unit_plan): measured WORSE with group 4 (unmasked drain units take CUs from the
+        # encode and the full units: 322 vs 376 k frames/s at 20 batches) -- off
+        self.ramp = bool(int(os.environ.get('SF_PIPE_RAMP', '0')))
         self.fill_batches = int(os.environ.get('SF_PIPE_FILL', '0'))   # 0: the batches of the first unit
         self.feat_bufs = None
         self._stage, self._s_copy, self._s_out = None, None, None   # staging ring + copy streams for host-resident inputs / outputs
@@ -296,25 +313,32 @@ class EncodeRolloutPipeline:
         dst[lo:hi, :self.T].copy_(post)
 
     def _unit_plan(self, n):
-        """[(first batch, number of batches, _Unit)] of a run over n batches.  With `ramp` (group 2) a run starts and ends with
-        single-batch units: the first rollout starts after ONE encode instead of two, and the drain -- the last rollout,
-        which nothing overlaps -- covers one batch."""
+        """[(first batch, number of batches, _Unit, drain?)] of a run over n batches.  With `ramp` the LAST batches of a run
+        go into ever smaller units (group 4: .., 4, 2, 1, 1): the drain -- the rollouts still running once the last encode
+        is done, which nothing overlaps -- then ends with short units in the kernels' latency forms, and those units run on
+        unmasked streams (the encode partition is about to fall idle)."""
         G = self.G
-        if self.ramp and G == 2 and n >= 4:
-            rest = n - 1
-            tail = [1] if rest % 2 else [1, 1]
-            sizes = [1] + [2] * ((rest - len(tail)) // 2) + tail
-        else:
-            sizes = [G] * (n // G) + ([n % G] if n % G else [])
+        sizes, tail = [], []
+        if self.ramp and G >= 2 and n >= 2 * G:
+            g = G // 2
+            while g >= 1:
+                tail.append(g)
+                g //= 2
+            tail.append(1)                      # G = 4: [2, 1, 1];  G = 2: [1, 1]
+            while sum(tail) > G:                # (G = 3: [1, 1, 1] -> [1, 1]; the tail replaces at most one full unit)
+                tail.pop(0)
+        rest = n - sum(tail)
+        sizes = [G] * (rest // G) + ([rest % G] if rest % G else []) + tail
         plan, u0, nfull, ntail = [], 0, 0, {}
-        for nb in sizes:
+        n_drain = len(tail)
+        for i, nb in enumerate(sizes):
             if nb == G:
                 u = self.units[nfull % self.NU]
                 nfull += 1
             else:
                 u = self._tail_unit(nb, ntail.get(nb, 0) % 2)
                 ntail[nb] = ntail.get(nb, 0) + 1
-            plan.append((u0, nb, u))
+            plan.append((u0, nb, u, i >= len(sizes) - max(n_drain, 1)))
             u0 += nb
         return plan
 
@@ -338,7 +362,7 @@ class EncodeRolloutPipeline:
         cur = torch.cuda.current_stream(self.dev)
         units = self._unit_plan(n)
         if serial or n == 0:
-            for u0, nb, u in units:
+            for u0, nb, u, _ in units:
                 for h in range(nb):
                     im = imgs[u0 + h].to(self.dev, non_blocking=True) if host_in else imgs[u0 + h]
                     self._encode(im, nz(u0 + h), u.buf[h * B:(h + 1) * B], None)
@@ -359,7 +383,7 @@ class EncodeRolloutPipeline:
             self.feat_bufs = [[torch.empty(kmax, hi - lo, 64 * 64, cl, device=self.dev) for _ in range(NF)] for _, lo, hi in lanes]
         for st, _, _ in lanes:
             st.wait_stream(cur)
-        for st in rolls + ([self.s_free] if self.s_free is not None else []):
+        for st in rolls + list(self.s_free):
             st.wait_stream(cur)
         if not out.is_cuda:
             if self._s_out is None:
@@ -410,12 +434,13 @@ class EncodeRolloutPipeline:
             ev_pre[jj].record(stream)
 
         n_fill = min(self.fill_batches or units[0][1], n) if (self.cu_split and self.fill_whole_chip) else 0
-        for _, _, u in units:
+        for _, _, u, _ in units:
             u.busy = None
         ev_t0 = torch.cuda.Event(enable_timing=True)
         ev_t0.record(cur)
         ev_rstart = [torch.cuda.Event(enable_timing=True) for _ in range(nu)] if trace else None
-        for ui, (u0, nb, u) in enumerate(units):
+        n_free = 0
+        for ui, (u0, nb, u, drain) in enumerate(units):
             for h in range(nb):
                 j = u0 + h
                 dst = u.buf[h * B:(h + 1) * B]
@@ -456,10 +481,11 @@ class EncodeRolloutPipeline:
                     ev_wait = []
                 ev_wait = ev_wait + list(ev_wait_j)
             s_roll = rolls[ui % len(rolls)]
-            if len(rolls) > 1 and ui == nu - 1 and self.s_free is not None:
-                # drain: the encode lane is idle from here on -- the last rollout takes an unmasked stream (all CUs) instead of
-                # sharing the rollout partition with the one before it
-                s_roll = self.s_free   # (its slot buffer and feature buffers are ordered by events, not by the stream it would have used)
+            if len(rolls) > 1 and drain and self.s_free:
+                # drain: the encode lane is (about to be) idle -- the last units take unmasked streams (all CUs) instead of queueing
+                # behind the full units on the rollout partition (their slot / feature buffers are ordered by events)
+                s_roll = self.s_free[n_free % len(self.s_free)]
+                n_free += 1
             with torch.cuda.stream(s_roll):
                 for e in ev_wait:
                     s_roll.wait_event(e)
@@ -485,27 +511,27 @@ class EncodeRolloutPipeline:
                 if steal and ui + lead < nu:
                     # their feature buffers were last read by the encodes of batches <= u0 + nb - 1 ... (NF = lead*G + G apart),
                     # which this stream has waited for
-                    tu0, tnb, _ = units[ui + lead]
+                    tu0, tnb = units[ui + lead][:2]
                     for jj in range(tu0, tu0 + tnb):
                         steal_for(jj, s_roll, ui % len(rolls))
         # The host waits for the last units HERE, before the calling stream is made to wait for the pipeline's streams: a
         # wait that sits pending on the calling stream (PyTorch's default stream is the legacy null stream) for the whole
         # run was measured to slow the kernels of the masked encode lane that shares shader engines with the rollout by
         # 30 % (7.7 instead of 6.4 ms per batch, tools/lane_probe.py COPY=1) -- so run() returns when the results are done.
-        for e in ev_roll[-(len(rolls) + 1):]:   # (the drain unit on the unmasked stream may overtake the unit before it)
+        for e in ev_roll[-(len(rolls) + 4):]:   # (the drain units on the unmasked streams may overtake the units before them)
             e.synchronize()
         for st, _, _ in lanes:
             cur.wait_stream(st)
-        for st in rolls + ([self.s_free] if self.s_free is not None else []) + ([self._s_copy] if host_in else []) + ([self._s_out] if not out.is_cuda else []):
+        for st in rolls + list(self.s_free) + ([self._s_copy] if host_in else []) + ([self._s_out] if not out.is_cuda else []):
             cur.wait_stream(st)
         self.completion_events = ev_roll
-        self.completion_batches = [nb for _, nb, _ in units]
+        self.completion_batches = [nb for _, nb, _, _ in units]
         if trace:
             torch.cuda.synchronize(self.dev)
             self.timeline = {'encode_end_ms': [max(ev_t0.elapsed_time(e) for e in ev_enc[j][:1 if j < n_fill else nl]) for j in range(n)],
                              'rollout_start_ms': [ev_t0.elapsed_time(e) for e in ev_rstart],
                              'rollout_end_ms': [ev_t0.elapsed_time(e) for e in ev_roll],
-                             'units': [(u0, nb) for u0, nb, _ in units]}
+                             'units': [(u0, nb) for u0, nb, _, _ in units]}
         self._check_seam()
         return out
 

@@ -21,17 +21,26 @@ def _models(dev, savi_cfg, roll_cfg, seed=0):
     return savi, roll
 
 
-def _serial_reference(savi, roll, imgs, noises, T, H):
-    """The plain module API, one batch after the other on the default stream."""
+PAIR_OPTS = {'attn_heads': 8}   # the 'pair' partition's throughput kernel forms (all-heads attention workgroups, 128-row FFN
+                                # workgroups, no seam launches) give the bits of the defaults -- asserted below
+
+
+def _serial_reference(savi, roll, imgs, noises, T, H, opts=None):
+    """The plain module API, one batch after the other on the default stream (opts: the kernel forms of the pipeline under
+    test; they give the same bits as the library defaults, checked below)."""
     from slotformer_amd import engine
     outs = []
     for img, nz in zip(imgs, noises):
         post = savi({'img': img, 'noise': nz})['post_slots']
         buf = torch.zeros(post.shape[0], T + H, post.shape[2], post.shape[3], device=img.device)
         buf[:, :T] = post
-        engine.rollout(roll, buf, T, H)
+        engine.rollout(roll, buf, T, H, opts=opts)
         outs.append(buf)
     return torch.stack(outs, 0)
+
+
+def _opts_of(partition):
+    return PAIR_OPTS if partition == 'pair' else None
 
 
 @pytest.mark.parametrize('B,steal,nbatch,partition', [(32, None, 9, 'pair'), (32, 1, 11, 'pair'), (32, 1.25, 13, 'pair'), (5, 2, 12, 'pair'), (5, 0.5, 12, 'pair'), (5, None, 7, 'pair'), (32, None, 6, 'three'), (32, 1, 5, 'three'), (5, 2, 7, 'three'), (32, 1, 6, 'two'),
@@ -44,11 +53,14 @@ def test_pipeline_matches_serial(dev, B, steal, nbatch, partition):
     imgs = [torch.from_numpy((rs.rand(B, T, 3, 128, 128) * 2 - 1).astype(np.float32)).to(dev) for _ in range(nbatch)]
     noises = [torch.from_numpy(rs.standard_normal((B, T, 7, 128)).astype(np.float32)).to(dev) for _ in range(nbatch)]
     with torch.no_grad():
-        ref = _serial_reference(savi, roll, imgs, noises, T, H)
+        ref = _serial_reference(savi, roll, imgs, noises, T, H, _opts_of(partition))
+        if partition == 'pair':   # the throughput kernel forms agree with the default ones to rounding
+            ref_default = _serial_reference(savi, roll, imgs[:2], noises[:2], T, H)
+            assert torch.equal(ref[:2], ref_default)
         pipe = EncodeRolloutPipeline(savi, roll, B, T, H, steal_steps=steal, partition=partition)
         assert pipe.partition == partition and len(pipe.lanes) == (2 if partition == 'three' else 1)
         assert len(pipe.roll_streams) == (2 if partition == 'pair' else 1) and len(pipe.bufs) == (4 if partition == 'pair' else 2)
-        assert pipe.G == (2 if partition == 'pair' else 1) and pipe.bufs[0].shape[0] == pipe.G * B
+        assert pipe.G == (4 if partition == 'pair' else 1) and pipe.bufs[0].shape[0] == pipe.G * B
         assert [lo for _, lo, _ in pipe.lanes] + [pipe.lanes[-1][2]] == ([0, B - max(1, round(B * 24 / 88)), B] if partition == 'three' else [0, B])
         out = pipe.run(imgs, noises)
         torch.cuda.synchronize()
@@ -74,13 +86,15 @@ def test_pipeline_without_cu_partition_and_graph(dev):
     imgs = [torch.from_numpy((rs.rand(B, T, 3, 128, 128) * 2 - 1).astype(np.float32)).to(dev) for _ in range(nbatch)]
     noises = [torch.from_numpy(rs.standard_normal((B, T, 7, 128)).astype(np.float32)).to(dev) for _ in range(nbatch)]
     with torch.no_grad():
-        ref = _serial_reference(savi, roll, imgs, noises, T, H)
+        refs = {False: _serial_reference(savi, roll, imgs, noises, T, H), True: _serial_reference(savi, roll, imgs, noises, T, H, PAIR_OPTS)}
         for kw in (dict(encode_cu_word=0), dict(use_graph=False), dict(encode_cu_word=0, use_graph=False, steal_steps=0),
-                   dict(partition='none', steal_steps=1), dict(partition='two', encode_cu_word='rows2')):
+                   dict(partition='none', steal_steps=1), dict(partition='two', encode_cu_word='rows2'),
+                   dict(partition='two', rollout_opts={'attn_heads': 8, 'ffn_rows': 64})):
             pipe = EncodeRolloutPipeline(savi, roll, B, T, H, **kw)
             out = pipe.run(imgs, noises)
             torch.cuda.synchronize()
-            assert torch.equal(out, ref), kw
+            all_heads = pipe.rollout_opts is not None and pipe.rollout_opts.attn_heads_per_wg == 8
+            assert torch.equal(out, refs[all_heads]), kw
             pipe.close()
 
 
@@ -95,8 +109,8 @@ def test_extract_and_rollout_entry(dev):
     with torch.no_grad():
         out = harness.extract_and_rollout(savi, roll, videos, H, batch_size=bs, noises=noises)
         chunks = [(0, 4), (4, 8), (8, 12), (12, 14)]
-        ref = _serial_reference(savi, roll, [videos[a:b].to(dev) for a, b in chunks[:3]], [noises[a:b].to(dev) for a, b in chunks[:3]], T, H)
-        tail = _serial_reference(savi, roll, [videos[12:].to(dev)], [noises[12:].to(dev)], T, H)
+        ref = _serial_reference(savi, roll, [videos[a:b].to(dev) for a, b in chunks[:3]], [noises[a:b].to(dev) for a, b in chunks[:3]], T, H, PAIR_OPTS)
+        tail = _serial_reference(savi, roll, [videos[12:].to(dev)], [noises[12:].to(dev)], T, H, PAIR_OPTS)
         torch.cuda.synchronize()
         assert out.shape == (V, T + H, 7, 128)
         assert torch.equal(out[:12], ref.reshape(12, T + H, 7, 128))
@@ -116,7 +130,8 @@ def test_extract_and_rollout_entry(dev):
         assert not harness._PIPES
 
 
-@pytest.mark.parametrize('group,partition,nbatch', [(1, 'pair', 7), (3, 'pair', 8), (2, 'two', 5), (2, 'none', 3), (2, 'pair', 1)])
+@pytest.mark.parametrize('group,partition,nbatch', [(1, 'pair', 7), (3, 'pair', 8), (2, 'two', 5), (2, 'none', 3), (2, 'pair', 1), (2, 'pair', 9), (4, 'pair', 21),
+                                                    (4, 'pair', 7)])
 def test_pipeline_groups(dev, group, partition, nbatch):
     """batches per rollout graph (`group`): any grouping, ragged last unit included, gives the serial results bit for bit"""
     from slotformer_amd.pipeline import EncodeRolloutPipeline
@@ -126,7 +141,7 @@ def test_pipeline_groups(dev, group, partition, nbatch):
     imgs = [torch.from_numpy((rs.rand(B, T, 3, 128, 128) * 2 - 1).astype(np.float32)).to(dev) for _ in range(nbatch)]
     noises = [torch.from_numpy(rs.standard_normal((B, T, 7, 128)).astype(np.float32)).to(dev) for _ in range(nbatch)]
     with torch.no_grad():
-        ref = _serial_reference(savi, roll, imgs, noises, T, H)
+        ref = _serial_reference(savi, roll, imgs, noises, T, H, _opts_of(partition))
         pipe = EncodeRolloutPipeline(savi, roll, B, T, H, partition=partition, group=group, steal_steps=1.5)
         assert pipe.G == group
         for _ in range(2):
@@ -174,17 +189,24 @@ def test_pipeline_other_configs(dev, name):
     noises = [torch.from_numpy(rs.standard_normal((B, T, N, D)).astype(np.float32)).to(dev) for _ in range(nbatch)]
     key = 'post_slots' if hasattr(savi, 'kernel_dist_layer') else 'slots'
     with torch.no_grad():
-        refs = []
-        for img in imgs:
-            post = savi({'img': img})[key]
-            buf = torch.zeros(B, T + H, N, D, device=dev)
-            buf[:, :T] = post
-            engine.rollout(roll, buf, T, H)
-            refs.append(buf)
-        ref = torch.stack(refs, 0)
-        assert torch.isfinite(ref).all()
-        for kw in (dict(), dict(partition='three'), dict(group=1, steal_steps=0)):
+        def reference(opts):
+            refs = []
+            for img in imgs:
+                post = savi({'img': img})[key]
+                buf = torch.zeros(B, T + H, N, D, device=dev)
+                buf[:, :T] = post
+                engine.rollout(roll, buf, T, H, opts=opts)
+                refs.append(buf)
+            return torch.stack(refs, 0)
+
+        ref_default = reference(None)
+        assert torch.isfinite(ref_default).all()
+        for kw in (dict(), dict(partition='three'), dict(group=1, steal_steps=0), dict(steal_steps=1.5)):
             pipe = EncodeRolloutPipeline(savi, roll, B, T, H, **kw)
+            # C1's d_model 128 is not on the fused-layer path: one batch per rollout unit (the generic GEMMs pick tiles by size)
+            assert pipe.fused == (name != 'C1') and (pipe.G == 1 or pipe.fused)
+            ref = ref_default if pipe.rollout_opts is None else reference(pipe.rollout_opts)   # the pipeline's kernel forms
+            assert torch.equal(ref, ref_default)
             for nz in (None, noises):     # caller-supplied noise must be ignored too when the model samples nothing
                 out = pipe.run(imgs, nz)
                 torch.cuda.synchronize()
@@ -207,9 +229,9 @@ def test_pipeline_recaptures_after_a_weight_update(dev):
         pipe = EncodeRolloutPipeline(savi, roll, B, T, H)
         pipe2 = EncodeRolloutPipeline(savi, roll, 2 * B, T, H)   # a second live pipeline: private workspaces, no interference
         out0 = pipe.run(imgs, noises).clone()
-        assert torch.equal(out0, _serial_reference(savi, roll, imgs, noises, T, H))
+        assert torch.equal(out0, _serial_reference(savi, roll, imgs, noises, T, H, PAIR_OPTS))
         roll.out_proj.weight.mul_(1.5)     # bumps the version counter
-        ref1 = _serial_reference(savi, roll, imgs, noises, T, H)
+        ref1 = _serial_reference(savi, roll, imgs, noises, T, H, PAIR_OPTS)
         out1 = pipe.run(imgs, noises)
         assert torch.equal(out1, ref1) and not torch.equal(out1, out0)
         pipe.close()

@@ -48,7 +48,55 @@ def test_ffn_rows_and_seam_choices_are_bit_identical(dev, B):
         assert torch.equal(out, ref), (opts, (out - ref).abs().max().item())
 
 
-@pytest.mark.parametrize('opts', [{'ffn_rows': 128, 'seam': False}, {'ffn_rows': 64, 'seam': False}, {'ffn_rows': 32, 'seam': True}])
+@pytest.mark.parametrize('B', [64, 33, 3])
+@torch.no_grad()
+def test_all_heads_attention_form(dev, B):
+    """attn_heads = 8 (one attention workgroup per video, finished rows instead of four head-pair partials) gives the bits of
+    the default form, whatever the FFN row variant and whatever batch a video sits in."""
+    r = _c2_rollouter(dev)
+    x = gu.seeded_normal((B, 6, 7, 128), 13).to(dev)
+    ref = _roll(r, x, 9)
+    a = _roll(r, x, 9, {'attn_heads': 8, 'ffn_rows': 128, 'seam': False})
+    assert torch.equal(a, ref), rel_err(a, ref)   # the head pairs' partials are summed in the default form's order: the same bits
+    for opts in ({'attn_heads': 8, 'ffn_rows': 64}, {'attn_heads': 8, 'ffn_rows': 32}, {'attn_heads': 8, 'ffn_rows': 128, 'seam': False}):
+        assert torch.equal(_roll(r, x, 9, opts), a), opts
+    sub = _roll(r, x[1:3].contiguous(), 9, {'attn_heads': 8})
+    assert torch.equal(sub, a[1:3])
+
+
+@pytest.mark.parametrize('L,Lq,B', [(42, 42, 5), (42, 7, 3), (48, 8, 2), (7, 7, 4), (64, 64, 2)])
+@torch.no_grad()
+def test_attention_block_kernels(dev, L, Lq, B):
+    """Kernel-level: both forms of the fused attention block (head-pair workgroups with four partial outputs; all-heads
+    workgroups with finished rows) against a plain PyTorch fp32 reference of the same op, x + out_proj(MHA(LN1(x)))."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from slotformer_amd import _lib, engine
+    lib = _lib.lib()
+    r = _c2_rollouter(dev, seed=5)
+    plan = engine.rollouter_plan(r)
+    w = plan.struct.layers[2]
+    layer = r.transformer_encoder.layers[2]
+    g = torch.Generator().manual_seed(L * 100 + Lq)
+    x = torch.randn(B, L, 256, generator=g).to(dev)
+    xn = F.layer_norm(x, (256, ), layer.norm1.weight, layer.norm1.bias)
+    att, _ = layer.self_attn(xn, xn, xn, need_weights=False)
+    ref = (x + att)[:, L - Lq:].reshape(B * Lq, 256)
+    st = torch.cuda.current_stream().cuda_stream
+    out8 = torch.full((2, B * Lq, 256), float('nan'), device=dev)   # [0]: x2, [1]: scratch
+    _lib.check(lib.sf_attn_block_f32(C.byref(w), x.data_ptr(), out8.data_ptr(), B, L, Lq, 8, st))
+    out2 = torch.full((4, B * Lq, 256), float('nan'), device=dev)
+    _lib.check(lib.sf_attn_block_f32(C.byref(w), x.data_ptr(), out2.data_ptr(), B, L, Lq, 2, st))
+    torch.cuda.synchronize()
+    y2 = ((out2[0] + out2[1]) + out2[2]) + out2[3]
+    e8, e2 = rel_err(out8[0], ref), rel_err(y2, ref)
+    print('attention block L', L, 'Lq', Lq, 'rel err all-heads', e8, 'head pairs', e2)
+    assert e8 < 3e-5 and e2 < 3e-5
+    assert torch.equal(out8[0], y2)   # both forms: the same bits
+
+
+@pytest.mark.parametrize('opts', [{'ffn_rows': 128, 'seam': False}, {'ffn_rows': 64, 'seam': False}, {'ffn_rows': 32, 'seam': True},
+                                  {'attn_heads': 8, 'ffn_rows': 128, 'seam': False}, {'attn_heads': 8, 'ffn_rows': 64}])
 @torch.no_grad()
 def test_throughput_settings_vs_reference_fixture(dev, opts):
     """roll_c2 (6 + 50 steps, outputs of the reference's own SlotFormer) with the kernel settings of the pipelined bench:
@@ -135,6 +183,8 @@ def test_bad_options_are_rejected(dev):
     with torch.no_grad():
         with pytest.raises(RuntimeError):
             _roll(r, x, 2, {'ffn_rows': 48})
+        with pytest.raises(RuntimeError):
+            _roll(r, x, 2, {'attn_heads': 4})
         with pytest.raises(ValueError):
             engine.rollout_opts({'rows': 64})
         buf = torch.zeros(2, 9, 7, 128, device=dev)

@@ -18,7 +18,7 @@ lib = _lib.lib()
 buf = torch.randn(B, 56, 7, 128, device=dev)
 with torch.no_grad():
     for _ in range(2):
-        engine.rollout(roll, buf, 6, 3, opts={'ffn_rows': rows, 'seam': False})
+        engine.rollout(roll, buf, 6, 3, opts={'ffn_rows': rows, 'seam': False, 'attn_heads': int(os.environ.get('ATTN', '2'))})
     torch.cuda.synchronize()
     out = (C.c_longlong * 64)()
     lib.sf_debug_read_ts.argtypes = [C.POINTER(C.c_longlong)]
@@ -30,3 +30,4 @@ with torch.no_grad():
     print('   (wide kernel: 0 entry, 1 first quarter requested, 2 prologue done, 3/4 FFN1 half 0/1, 5 hidden planes complete, 6/7 FFN2 half 0/1, 8 output tile, 9 end;')
     print('    ffn_body: 0 entry, 1 requests, 2 LN planes, 3 FFN1, 4 hidden, 5 FFN2, 6 partial stored, 7 counter, 8 end)')
     print('attn ticks (10 ns):', [t - ts[16] for t in ts[16:28]])
+    print('attn_all ticks (10 ns):', [t - ts[48] for t in ts[48:58]], '(0 entry, 1 requests, 2 LN planes; head pair 1: 3 start, 4 proj, 5 planes, 6 core, 7 O planes, 8 out-proj; 9 end)')
