@@ -86,6 +86,7 @@ class _Unit:
     def __init__(self, buf, key):
         self.buf, self.key, self.graph = buf, key, None
         self.busy = None   # event of the last rollout + copy-out that used the buffer in the current run()
+        self.latency_form = False   # captured with the kernels' latency forms (the drain unit of a run: alone on the whole chip)
 
 
 class EncodeRolloutPipeline:
@@ -156,6 +157,7 @@ class EncodeRolloutPipeline:
         if self.rollout_opts is not None and (self.rollout_opts.ffn_rows > 64 or self.rollout_opts.attn_heads_per_wg == 8):
             self.tail_opts = _lib.sf_rollout_opts(self.rollout_opts.precision, self.rollout_opts.seam_fused, min(self.rollout_opts.ffn_rows or 64, 64), 2)
         self.use_graph = bool(use_graph)
+        self.drain_latency_form = bool(int(os.environ.get('SF_PIPE_DRAIN_LAT', '1')))
         self._key = ('pipe', id(self))
         self._plan = None
         self._sig = None
@@ -214,6 +216,7 @@ class EncodeRolloutPipeline:
         # encode and the full units: 322 vs 376 k frames/s at 20 batches) -- off
         self.ramp = bool(int(os.environ.get('SF_PIPE_RAMP', '0')))
         self.fill_batches = int(os.environ.get('SF_PIPE_FILL', '0'))   # 0: the batches of the first unit
+        self.fill_steal = int(os.environ.get('SF_PIPE_FILL_STEAL', '0'))
         self.feat_bufs = None
         self._stage, self._s_copy, self._s_out = None, None, None   # staging ring + copy streams for host-resident inputs / outputs
         self.completion_events = []      # one event per unit of the last run() ...
@@ -253,9 +256,10 @@ class EncodeRolloutPipeline:
             pass
 
     # ------------------------------------------------------------------------------------------------------------
-    def _new_unit(self, nb, tag):
+    def _new_unit(self, nb, tag, latency_form=False):
         with torch.no_grad():
             u = _Unit(torch.zeros(nb * self.B, self.T + self.H, self.N, self.D, device=self.dev), self._key + (tag, ))
+            u.latency_form = latency_form
             self._rollout_eager(u)   # allocates its workspace, builds the plan
             torch.cuda.synchronize(self.dev)
             if self.use_graph:
@@ -270,6 +274,8 @@ class EncodeRolloutPipeline:
         """(Re-)capture every unit graph for the rollouter's CURRENT parameters."""
         self.units, self._tails = [], {}
         self.units = [self._new_unit(self.G, k) for k in range(self.NU)]
+        if self.G > 1 and self.NU > 2 and self.tail_opts is not self.rollout_opts and self.drain_latency_form:
+            self._tails['drain'] = self._new_unit(self.G, ('drain', ), latency_form=True)   # (not inside a timed run)
         self._plan = engine.rollouter_plan(self.roll)   # keeps the packed weight copies the graphs point to alive
         self._sig = self._plan.sig
 
@@ -291,7 +297,7 @@ class EncodeRolloutPipeline:
         return int(math.floor(self.steal * (j + 1) + 1e-9) - math.floor(self.steal * j + 1e-9))
 
     def _rollout_eager(self, u):
-        opts = self.rollout_opts if u.buf.shape[0] >= self.G * self.B else self.tail_opts
+        opts = self.rollout_opts if (u.buf.shape[0] >= self.G * self.B and not u.latency_form) else self.tail_opts
         engine.rollout(self.roll, u.buf, self.T, self.H, ws_slot=u.key, opts=opts)
 
     def _rollout(self, u):
@@ -338,7 +344,14 @@ class EncodeRolloutPipeline:
             else:
                 u = self._tail_unit(nb, ntail.get(nb, 0) % 2)
                 ntail[nb] = ntail.get(nb, 0) + 1
-            plan.append((u0, nb, u, i >= len(sizes) - max(n_drain, 1)))
+            drain = i >= len(sizes) - max(n_drain, 1)
+            if drain and nb == G and len(sizes) > 1 and self.tail_opts is not self.rollout_opts and self.drain_latency_form:
+                # the last unit of a run rolls out alone on the whole chip (unmasked stream): a graph of the same buffer size
+                # captured with the kernels' LATENCY forms (many short workgroups: 12.1 instead of 15.5 ms for 4 batches)
+                if 'drain' not in self._tails:
+                    self._tails['drain'] = self._new_unit(G, ('drain', ), latency_form=True)
+                u = self._tails['drain']
+            plan.append((u0, nb, u, drain))
             u0 += nb
         return plan
 
@@ -377,8 +390,11 @@ class EncodeRolloutPipeline:
         # work stealing: the features of the batches of unit u are computed behind the rollout of unit u - lead, on its stream
         lead = self.lead
         NF = lead * G + G                # feature buffers per lane (slot of batch j: j % NF)
-        kmax = int(math.ceil(steal))
-        if steal and self.feat_bufs is None:
+        # during the fill of a run the rollout partition is idle (the last rollout stream until the SECOND unit is encoded):
+        # it takes `fill_steal` whole time steps of convolutions off the encodes of the batches behind the fill
+        fill_k = min(self.fill_steal, self.T) if (len(rolls) > 1 and self.cu_split) else 0
+        kmax = max(int(math.ceil(steal)), fill_k)
+        if (steal or fill_k) and self.feat_bufs is None:
             cl = list(self.savi.enc_channels)[-1]
             self.feat_bufs = [[torch.empty(kmax, hi - lo, 64 * 64, cl, device=self.dev) for _ in range(NF)] for _, lo, hi in lanes]
         for st, _, _ in lanes:
@@ -422,9 +438,9 @@ class EncodeRolloutPipeline:
             stream.wait_event(ev_up[j])
             return self._stage[j % NS]
 
-        def steal_for(jj, stream, tag):
+        def steal_for(jj, stream, tag, kj=None):
             """features of the first steps of batch jj on `stream` (the current stream)"""
-            kj = self._steal_of(jj)
+            kj = self._steal_of(jj) if kj is None else kj
             if kj:
                 im = img_of(jj, stream)
                 for li, (_, lo, hi) in enumerate(lanes):
@@ -450,16 +466,18 @@ class EncodeRolloutPipeline:
                     # instead of 3.05 ms (a queue stalled in a cross-queue wait slows the queue that is running)
                     self._encode(img_of(j, cur), nz(j), dst, None)
                     ev_enc[j][0].record(cur)
-                    if j == 0 and steal and len(rolls) > 1:
+                    if j == 0 and (steal or fill_k) and len(rolls) > 1:
                         # the rollout streams idle until the first unit is encoded: they compute the stolen features of the
                         # batches behind the fill now (round-robin), so that only the fill batches pay for their own convolutions
                         # (all on the LAST rollout stream, whose first unit starts latest: on the first one they delayed the first
                         #  rollout of a run by 3.3 ms, tools/pipe_timeline.py)
                         first = max(n_fill, 1)
                         fill_end = units[lead][0] if nu > lead else n      # (unit `lead` onwards: stolen behind the rollouts)
+                        if fill_k:   # only what the last rollout stream can finish before its first unit is ready: the second unit's batches
+                            fill_end = min(fill_end, units[2][0] if nu > 2 else n)
                         for jj in range(first, fill_end):
                             with torch.cuda.stream(rolls[-1]):
-                                steal_for(jj, rolls[-1], len(rolls) - 1)
+                                steal_for(jj, rolls[-1], len(rolls) - 1, fill_k or None)
                     if j == n_fill - 1:
                         ev_enc[j][0].synchronize()
                         for st, _, _ in lanes:
