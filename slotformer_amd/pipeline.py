@@ -217,6 +217,13 @@ class EncodeRolloutPipeline:
         self.ramp = bool(int(os.environ.get('SF_PIPE_RAMP', '0')))
         self.fill_batches = int(os.environ.get('SF_PIPE_FILL', '0'))   # 0: the batches of the first unit
         self.fill_steal = int(os.environ.get('SF_PIPE_FILL_STEAL', '0'))
+        # pre_steal[h]: time steps of convolutions of batch h of the NEXT unit computed on a rollout stream right before a unit
+        # rolls out (group >= 2 only; batch 0 of the next unit starts encoding at once and cannot wait)
+        ps = os.environ.get('SF_PIPE_PRE_STEAL', '')
+        self.pre_steal = [int(x) for x in ps.split(',')] if ps else []   # (measured neutral at 20 batches: 381-383 k frames/s with [0,0,1,1] .. [0,1,1,1] and off)
+        self.pre_steal = [min(k, self.T) for k in self.pre_steal]
+        if not any(self.pre_steal):
+            self.pre_steal = []
         self.feat_bufs = None
         self._stage, self._s_copy, self._s_out = None, None, None   # staging ring + copy streams for host-resident inputs / outputs
         self.completion_events = []      # one event per unit of the last run() ...
@@ -393,8 +400,8 @@ class EncodeRolloutPipeline:
         # during the fill of a run the rollout partition is idle (the last rollout stream until the SECOND unit is encoded):
         # it takes `fill_steal` whole time steps of convolutions off the encodes of the batches behind the fill
         fill_k = min(self.fill_steal, self.T) if (len(rolls) > 1 and self.cu_split) else 0
-        kmax = max(int(math.ceil(steal)), fill_k)
-        if (steal or fill_k) and self.feat_bufs is None:
+        kmax = max([int(math.ceil(steal)), fill_k] + list(self.pre_steal))
+        if kmax and self.feat_bufs is None:
             cl = list(self.savi.enc_channels)[-1]
             self.feat_bufs = [[torch.empty(kmax, hi - lo, 64 * 64, cl, device=self.dev) for _ in range(NF)] for _, lo, hi in lanes]
         for st, _, _ in lanes:
@@ -507,6 +514,15 @@ class EncodeRolloutPipeline:
             with torch.cuda.stream(s_roll):
                 for e in ev_wait:
                     s_roll.wait_event(e)
+                if self.pre_steal and ui + 1 < nu and self.cu_split and not drain:
+                    # the rollout streams have a little slack per unit (the encode is the longer side): before this unit rolls
+                    # out, its stream takes pre_steal[h] time steps of convolutions off the LATER batches of the NEXT unit --
+                    # stealing behind a rollout is too late for units of several batches (the next unit is encoded meanwhile)
+                    nu0, nnb = units[ui + 1][:2]
+                    for h2 in range(nnb):
+                        k2 = self.pre_steal[min(h2, len(self.pre_steal) - 1)]
+                        if k2 and not stolen[nu0 + h2]:
+                            steal_for(nu0 + h2, s_roll, ui % len(rolls), k2)
                 if trace:
                     ev_rstart[ui].record(s_roll)
                 self._rollout(u)

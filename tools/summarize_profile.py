@@ -5,7 +5,7 @@ import os
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(R, 'gpurun_out')
 
@@ -22,7 +22,7 @@ def find(d, pat):
 lines = []
 f = find(f'{tag}_trace', '*kernel_stats.csv')
 if f:
-    lines.append(f'# rocprofv3 --kernel-trace --stats  (bench.py --steps 5 --warmup 2 --no-cpu-baseline: the default hipGraph + CU-partitioned pipeline)  [{os.path.basename(f)}]')
+    lines.append(f'# rocprofv3 --kernel-trace --stats  (bench.py --steps 8 --warmup 4 --no-cpu-baseline: the default hipGraph + CU-partitioned pipeline)  [{os.path.basename(f)}]')
     lines.append(f'{"kernel":72s} {"calls":>7s} {"total_us":>12s} {"avg_us":>10s} {"pct":>6s}')
     for r in csv.DictReader(open(f)):
         lines.append(f'{short(r["Name"]):72s} {r["Calls"]:>7s} {float(r["TotalDurationNs"]) / 1e3:12.1f} '
@@ -98,20 +98,46 @@ traffic = {'source': f'profiles/{tag}_profile_summary.txt (rocprofv3 --pmc FETCH
            'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of wide coalesced reads)'}
 # MFMA-busy fraction: SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs that ran the kernel; GRBM_GUI_ACTIVE is
 # the launch duration in cycles -> busy / (active * 1024 SIMDs) = share of the chip's matrix-pipe time that was used
-for key, pred in (('conv_nhwc_implicit_gemm', is_conv), ('slot_attn_iter', lambda n: 'sa_attn_mfma' in n or 'sa_attn_fold' in n),
-                  ('ffn_fused', lambda n: 'ffn_partial_kernel' in n or 'ffn64_parts_kernel' in n or 'ffn_wide_parts_kernel' in n), ('attention', lambda n: 'attn_oproj_kernel' in n),
-                  ('pixel_mlp', lambda n: 'pixel_mlp_kv_kernel' in n)):
+def stats_class_avg_us(pred):
+    """Call-weighted mean duration (us) of ALL launches of the kernels matching `pred` in the kernel trace (sum of total time /
+    sum of calls over the matching rows of *_kernel_stats.csv): the graph-replay launches of the timed schedule dominate it."""
+    f = find(f'{tag}_trace', '*kernel_stats.csv')
+    if not f:
+        return None, None
+    tot, calls, names = 0.0, 0, []
+    for r in csv.DictReader(open(f)):
+        if pred(r['Name']):
+            tot += float(r['TotalDurationNs'])
+            calls += int(r['Calls'])
+            names.append(short(r['Name']))
+    return (tot / calls / 1e3 if calls else None), names
+
+
+# rollout kernel classes = the kernels of the THROUGHPUT-form rollout units the timed region replays (all-heads attention
+# workgroups, wide FFN workgroups on finished rows + the last layer's 32-row FFN with the step boundary); the latency-form kernels
+# of the drain / tail units (attn_oproj_kernel, ffn_wide_parts_kernel<1, 4>, ffn_partial_kernel<4>) are not part of the class
+is_attn = lambda n: 'attn_all_kernel' in n  # noqa: E731
+is_ffn = lambda n: 'ffn_wide_parts_kernel<2, 1>' in n or 'ffn_partial_kernel<1>' in n  # noqa: E731
+for key, pred, whole_chip in (('conv_nhwc_implicit_gemm', is_conv, True), ('slot_attn_iter', lambda n: 'sa_attn_mfma' in n or 'sa_attn_fold' in n, True),
+                              ('ffn_fused', is_ffn, False), ('attention', is_attn, False), ('pixel_mlp', lambda n: 'pixel_mlp_kv_kernel' in n, True)):
     fe, wr = counter_avg(f'{tag}_pmc_fetch', 'FETCH_SIZE', pred), counter_avg(f'{tag}_pmc_write', 'WRITE_SIZE', pred)
     ent = {}
     if fe is not None and wr is not None:
         ent.update({'FETCH_SIZE_KB': fe, 'WRITE_SIZE_KB': wr, 'traffic_bytes_per_launch': (2 * fe + wr) * 1024})
     busy = counter_avg(f'{tag}_pmc_mfma', 'SQ_VALU_MFMA_BUSY_CYCLES', pred)
-    dur = stats_avg_us(pred)
+    if whole_chip:
+        dur, names = stats_avg_us(pred), None
+        rule = 'mean duration on the HIP queue where the kernel runs fastest (>= 8 launches): the whole-chip passes of bench.py'
+    else:
+        dur, names = stats_class_avg_us(pred)
+        rule = 'sum(TotalDurationNs) / sum(Calls) over the matching rows of the kernel_stats csv (all queues)'
     if busy is not None and dur:
         # SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of the 1024 SIMDs: / 1024 = matrix-pipe time per SIMD, at the 2.4 GHz
         # peak clock (a lower bound of the time: the chip clocks lower under load) over the launch duration of the trace pass
-        ent.update({'SQ_VALU_MFMA_BUSY_CYCLES': busy, 'avg_launch_us_trace': dur,
+        ent.update({'SQ_VALU_MFMA_BUSY_CYCLES': busy, 'avg_launch_us_trace': dur, 'avg_launch_us_rule': rule,
                     'mfma_busy_us_per_simd': busy / 1024.0 / 2400.0, 'mfma_busy_frac': busy / 1024.0 / 2400.0 / dur})
+        if names:
+            ent['kernels'] = names
     if ent:
         traffic[key] = ent
 json.dump(traffic, open(os.path.join(OUT, f'{tag}_pmc_traffic.json'), 'w'), indent=1)
