@@ -320,7 +320,8 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
  * reference drives forward() from one host thread per GPU, base_slots/extract_slots.py:128), whereas sf_set_precision /
  * sf_set_seam_fused / sf_set_ffn_rows64 set process-wide DEFAULTS.  Every choice is bit-identical except `precision`. */
 typedef struct {
-  int precision;    /* -1: default; 0 exact f32, 1 split-bf16, 2 single-pass bf16 (= sf_rollout_bf16) */
+  int precision;    /* -1: default; 0 exact f32, 1 split-bf16, 2 single-pass bf16 (= sf_rollout_bf16), 3 single-pass fp16 (a
+                     * measurement probe: the linear layers on one fp16 MFMA per product, profiles/r03_probes.txt) */
   int seam_fused;   /* -1: default; 0 / 1: seam launches off / on */
   int ffn_rows;     /* 0: default; 32 / 64 / 128 rows per workgroup of the chunk-partial FFN launches */
   int attn_heads_per_wg; /* 0: default (2: one workgroup per head pair and video, four partial outputs summed by the FFN launch);

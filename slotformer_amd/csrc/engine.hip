@@ -398,7 +398,7 @@ struct OptsScope {
 int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws, size_t ws_bytes,
                         void* stream, const sf_rollout_opts* opts) {
   if (!opts) return sf_rollout_f32(m, slots, B, T_total, pred_len, ws, ws_bytes, stream);
-  SF_REQUIRE(opts->precision >= -1 && opts->precision <= 2, "sf_rollout_opts: precision must be -1 (default), 0, 1 or 2");
+  SF_REQUIRE(opts->precision >= -1 && opts->precision <= 3, "sf_rollout_opts: precision must be -1 (default), 0, 1, 2 or 3");
   SF_REQUIRE(opts->ffn_rows == 0 || opts->ffn_rows == 32 || opts->ffn_rows == 64 || opts->ffn_rows == 128,
              "sf_rollout_opts: ffn_rows must be 0 (default), 32, 64 or 128");
   SF_REQUIRE(opts->attn_heads_per_wg == 0 || opts->attn_heads_per_wg == 2 || opts->attn_heads_per_wg == 8,
@@ -409,7 +409,7 @@ int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total,
   if (opts->ffn_rows > 0) o.ffn_rows = opts->ffn_rows;
   if (opts->attn_heads_per_wg > 0) o.attn_heads = opts->attn_heads_per_wg;
   OptsScope scope(o);
-  const bool plain = (o.precision == 2);
+  const bool plain = (o.precision == 2 || o.precision == 3);
   const bool old_plain = t_plain_gemms;
   if (plain) t_plain_gemms = true;
   const int rc = sf_rollout_f32(m, slots, B, T_total, pred_len, ws, ws_bytes, stream);

@@ -54,7 +54,7 @@ struct SfGemmArgs {
   // (the ReLU / dropout adjoint folded into the GEMM that produces the gradient)
   int mask_mode;
   float mask_scale;
-  int bf1;  // split-bf16 kernels: contract the hi parts only (precision mode 2)
+  int bf1;  // split-bf16 kernels: 1 = contract the hi parts only (precision mode 2); 2 = operands rounded to fp16, one fp16 MFMA (mode 3)
   int dbg;  // ablation bits (SF_GEMM_DBG, tools only): 1 no MFMA, 2 no main-loop loads, 4 no LN stats, 8 no stores
 };
 
@@ -279,6 +279,11 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
       }
       if constexpr (BF3) {
         auto put = [&](__bf16* hi_plane, __bf16* lo_plane, int row, f32x4 v) {
+          if (p.bf1 == 2) {   // precision mode 3 (probe): the hi plane holds the operand rounded to fp16, the lo plane is unused
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            *(f16x4*)(hi_plane + row * LB + 4 * c4) = __builtin_convertvector(v, f16x4);
+            return;
+          }
           const bf16x4 h = __builtin_convertvector(v, bf16x4);
           const bf16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4);
           *(bf16x4*)(hi_plane + row * LB + 4 * c4) = h;
@@ -339,6 +344,11 @@ __global__ __launch_bounds__(WM* WN* KW * 64) void sf_gemm_kernel(SfGemmArgs p) 
         for (int i = 0; i < RM; ++i)
 #pragma unroll
           for (int j = 0; j < RN; ++j) {
+            if (p.bf1 == 2) {   // single-pass fp16 (probe mode 3)
+              typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xh[i]), __builtin_bit_cast(f16x8, yh[j]), acc[i][j], 0, 0, 0);
+              continue;
+            }
             if (!p.bf1) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i], yh[j], acc[i][j], 0, 0, 0);
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i], yl[j], acc[i][j], 0, 0, 0);
@@ -655,7 +665,7 @@ extern "C" int sf_get_precision(void) {
   return g_precision;
 }
 extern "C" int sf_set_precision(int mode) {
-  if (mode < 0 || mode > 2) return sf_set_err(-1, "invalid argument: precision mode must be 0 (f32), 1 (bf16x3) or 2 (bf16)", __FILE__, __LINE__);
+  if (mode < 0 || mode > 2) return sf_set_err(-1, "invalid argument: precision mode must be 0 (f32), 1 (bf16x3) or 2 (bf16)", __FILE__, __LINE__);   // (3 = single-pass fp16 exists per call only: sf_rollout_opts.precision, a measurement probe)
   g_precision = mode;
   return 0;
 }
@@ -706,7 +716,7 @@ int sf_gemm_dispatch(const SfGemmArgs& a_in, int aload, hipStream_t stream) {
     const char* e = getenv("SF_GEMM_DBG");
     a.dbg = e ? atoi(e) : 0;
   }
-  a.bf1 = sf_get_precision() == 2;
+  a.bf1 = sf_get_precision() == 2 ? 1 : (sf_get_precision() == 3 ? 2 : 0);
   const bool ln = a.ln_g != nullptr;
   if (aload == ALOAD_PLAIN) return ln ? dispatch_tiles<ALOAD_PLAIN, true>(a, stream)
                                       : dispatch_tiles<ALOAD_PLAIN, false>(a, stream);

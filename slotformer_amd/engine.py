@@ -177,7 +177,7 @@ def rollouter_plan(r, packed=True):
 
 
 def rollout_opts(opts):
-    """dict / None -> ctypes sf_rollout_opts (None).  Keys: precision ('f32' | 'bf16x3' | 'bf16' | 0..2), seam (bool),
+    """dict / None -> ctypes sf_rollout_opts (None).  Keys: precision ('f32' | 'bf16x3' | 'bf16' | 'fp16' (probe) | 0..3), seam (bool),
     ffn_rows (32 | 64 | 128), attn_heads (2 | 8: heads per attention workgroup); per call and per thread, never process-wide."""
     if opts is None:
         return None
@@ -187,7 +187,7 @@ def rollout_opts(opts):
     if unknown:
         raise ValueError(f'slotformer_amd: unknown rollout options {sorted(unknown)}')
     prec = opts.get('precision', -1)
-    prec = {'f32': 0, 'bf16x3': 1, 'bf16': 2}.get(prec, prec)
+    prec = {'f32': 0, 'bf16x3': 1, 'bf16': 2, 'fp16': 3}.get(prec, prec)
     seam = opts.get('seam', None)
     return _lib.sf_rollout_opts(int(prec), -1 if seam is None else int(bool(seam)), int(opts.get('ffn_rows', 0)), int(opts.get('attn_heads', 0)))
 

@@ -465,7 +465,13 @@ def test_rollout_bf16_entry_point_error_is_measured(dev):
     buf = slots.clone()
     engine.rollout(m.rollouter, buf, W, H)
     e3 = rel_err(buf[:, W:], g['pred_slots'])
-    print(f'6+50 rollout vs the reference fixture: single-pass bf16 {e16:.2e}, split-bf16 (default) {e3:.2e}')
+    # single-pass fp16 (per-call precision 3, a measurement probe: VERDICT r02 -- the CPU emulation of round 2 put it at 5.6e-4
+    # after 50 steps, inside the 1e-3 bar with a thin margin; the linear layers run on ONE fp16 MFMA per product)
+    buf = slots.clone()
+    engine.rollout(m.rollouter, buf, W, H, opts={'precision': 'fp16'})
+    ef = rel_err(buf[:, W:], g['pred_slots'])
+    print(f'6+50 rollout vs the reference fixture: single-pass bf16 {e16:.2e}, single-pass fp16 {ef:.2e}, split-bf16 (default) {e3:.2e}')
     assert e3 < 2e-4
     assert 1e-3 < e16 < 5e-2, e16      # usable as an option, not as the parity path
-    assert lib.sf_get_precision() == 1  # the entry point restores the library mode
+    assert e3 < ef < e16 and ef < 5e-3, ef
+    assert lib.sf_get_precision() == 1  # the entry points restore the library mode
