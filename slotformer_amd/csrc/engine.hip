@@ -143,6 +143,15 @@ size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B) {
 
 extern "C" int sf_get_seam_fused(void);
 
+// a[0..n) = b[0..n) = 0 (n a multiple of 4, both 16-byte aligned)
+__global__ void zero_f32_kernel(float* a, float* b, long long n) {
+  const long long i = 4 * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < n) {
+    *(float4*)(a + i) = float4{0.f, 0.f, 0.f, 0.f};
+    *(float4*)(b + i) = float4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 // block 0 clears a[0..1023], block 1 clears b[0..1023] (b may be NULL)
 __global__ void zero_words_kernel(unsigned* a, unsigned* b) {
   unsigned* p = blockIdx.x == 0 ? a : b;
@@ -600,9 +609,11 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
   const float* prev = prev_slots;
   if (m->pred_rnn && (prev == nullptr || !state_valid)) {
     // RNNPredictorWrapper.reset(): hidden_state = None -> zeros on first use (predictor.py:132-135)
-    hipError_t e1 = hipMemsetAsync(lstm_h, 0, (size_t)R * m->pred_hidden * sizeof(float), st);
-    hipError_t e2 = hipMemsetAsync(lstm_c, 0, (size_t)R * m->pred_hidden * sizeof(float), st);
-    if (e1 != hipSuccess || e2 != hipSuccess) return sf_set_err((int)(e1 != hipSuccess ? e1 : e2), "hipMemsetAsync failed", __FILE__, __LINE__);
+    // (a KERNEL, not hipMemsetAsync: the encode may be captured into a hipGraph, and memset nodes were seen to stop clearing
+    //  after an older graph exec had been destroyed -- see zero_words_kernel above; pipeline encode graphs hit it at once)
+    const long long nz = (long long)R * m->pred_hidden;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((nz / 4 + 255) / 256)), dim3(256), 0, st, lstm_h, lstm_c, nz);
+    SF_CHECK_LAUNCH();
   }
   const long long frame_elems = (long long)3 * res * res;
   const float ln_eps = 1e-5f;

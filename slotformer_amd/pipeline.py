@@ -100,13 +100,15 @@ class EncodeRolloutPipeline:
     group: batches per rollout unit / graph (None = 2 for 'pair', 1 otherwise).
     steal_steps: time steps of convolutions per batch computed on the rollout streams (may be fractional: 1.25 = one step,
     two for every fourth batch); None = the partition's tuned default.
+    encode_graph: replay the encode of a batch from a hipGraph over fixed input buffers as well (frames / noise / stolen
+    features staged into them; bit-identical; default on, False: eager launches).
     rollout_opts: per-call kernel options of the captured rollouts (engine.rollout_opts); None = the partition's default
     ('pair': no seam launches, 128-row FFN workgroups, all-heads attention workgroups -- the throughput settings, the same
     bits as the library defaults; otherwise the library defaults).
     """
 
     def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=None, use_graph=True,
-                 partition='pair', group=None, rollout_opts=None):
+                 partition='pair', group=None, rollout_opts=None, encode_graph=None):
         self.savi, self.roll = savi, rollouter
         self.B, self.T, self.H = int(batch), int(burn_in), int(pred_len)
         p = next(rollouter.parameters())
@@ -157,6 +159,10 @@ class EncodeRolloutPipeline:
         if self.rollout_opts is not None and (self.rollout_opts.ffn_rows > 64 or self.rollout_opts.attn_heads_per_wg == 8):
             self.tail_opts = _lib.sf_rollout_opts(self.rollout_opts.precision, self.rollout_opts.seam_fused, min(self.rollout_opts.ffn_rows or 64, 64), 2)
         self.use_graph = bool(use_graph)
+        # the encode under a hipGraph too: the gaps between its ~60 short launches shrink (374-377 vs 373 k frames/s at 20
+        # batches, 399.5 vs 398.2 at 40) at the price of a 38 MB device copy of the frames into the fixed input buffer per batch
+        self.encode_graph = bool(int(os.environ.get('SF_PIPE_ENCODE_GRAPH', '1'))) if encode_graph is None else bool(encode_graph)
+        self._enc_graphs = {}
         self.drain_latency_form = bool(int(os.environ.get('SF_PIPE_DRAIN_LAT', '1')))
         self._key = ('pipe', id(self))
         self._plan = None
@@ -253,7 +259,7 @@ class EncodeRolloutPipeline:
 
     def close(self):
         self._close_streams()
-        self.units, self._tails = [], {}
+        self.units, self._tails, self._enc_graphs = [], {}, {}
         engine.release_workspaces(self._key)
 
     def __del__(self):
@@ -322,8 +328,43 @@ class EncodeRolloutPipeline:
         # None for models that sample nothing (kld_method 'none': OBJ3D / PHYRE SAVi; STEVE), the caller's tensor, or fresh
         # eps ~ N(0,1) per frame as the reference draws it (savi.py:355-365)
         noise = engine.kernel_noise(self.savi, noise, hi - lo, self.T, self.dev)
+        if self.encode_graph:
+            # the ~60 launches of an encode replayed from a hipGraph over fixed buffers (one graph per (lane, stolen steps)):
+            # frames, noise and stolen features are staged into them, the slots copied out
+            eg = self._encode_graph_for(lane, hi - lo, 0 if feat_pre is None else feat_pre.shape[0], img.shape[-1], noise is not None)
+            eg['img'].copy_(img)
+            if noise is not None:
+                eg['noise'].copy_(noise)
+            if feat_pre is not None:
+                eg['feat'].copy_(feat_pre)
+            eg['graph'].replay()
+            dst[lo:hi, :self.T].copy_(eg['post'])
+            return
         post, _, _ = engine.savi_encode(self.savi, img, noise=noise, feat_pre=feat_pre, ws_slot=self._key + ('enc', lane))
         dst[lo:hi, :self.T].copy_(post)
+
+    def _encode_graph_for(self, lane, nv, k, res, with_noise):
+        key = (lane, nv, k, res, with_noise)
+        eg = self._enc_graphs.get(key)
+        if eg is None:
+            cur = torch.cuda.current_stream(self.dev)
+            cl = list(self.savi.enc_channels)[-1]
+            eg = {'img': torch.zeros(nv, self.T, 3, res, res, device=self.dev),
+                  'noise': torch.zeros(nv, self.T, self.N, self.D, device=self.dev) if with_noise else None,
+                  'feat': torch.zeros(k, nv, 64 * 64, cl, device=self.dev) if k else None}
+            ws = self._key + ('encg', ) + key
+            side = torch.cuda.Stream(device=self.dev)   # (capture on a side stream: the caller may be inside a masked stream)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws)   # workspace, plans
+                side.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
+                    post, _, _ = engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws)
+            cur.wait_stream(side)
+            eg['graph'], eg['post'] = g, post
+            self._enc_graphs[key] = eg
+        return eg
 
     def _unit_plan(self, n):
         """[(first batch, number of batches, _Unit, drain?)] of a run over n batches.  With `ramp` the LAST batches of a run

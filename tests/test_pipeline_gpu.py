@@ -236,3 +236,32 @@ def test_pipeline_recaptures_after_a_weight_update(dev):
         assert torch.equal(out1, ref1) and not torch.equal(out1, out0)
         pipe.close()
         pipe2.close()
+
+
+@pytest.mark.parametrize('name', ['C2', 'C5'])
+def test_pipeline_with_the_encode_under_a_graph(dev, name):
+    """encode_graph=True: the ~60 launches of every encode are replayed from hipGraphs over fixed buffers (frames, injected kernel
+    noise and stolen features staged into them): bit-identical to the eager encode, also with the predictor's LSTM state
+    allocated inside the capture (C5) and with work stealing (its own graph per number of stolen steps)."""
+    from slotformer_amd.pipeline import EncodeRolloutPipeline
+    if name == 'C2':
+        savi, roll = _models(dev, gu.C2_SAVI, gu.C2_ROLL, seed=8)
+        B, T, H, res = 6, 6, 5, 128
+    else:
+        savi, roll = _build_pair(dev, gu.C5_SAVI, gu.C5_ROLL, single_step=True, seed=8)
+        B, T, H, res = 5, 1, 7, 128
+    N, D = roll.num_slots, roll.in_proj.in_features
+    rs = np.random.RandomState(31)
+    imgs = [torch.from_numpy((rs.rand(B, T, 3, res, res) * 2 - 1).astype(np.float32)).to(dev) for _ in range(9)]
+    noises = [torch.from_numpy(rs.standard_normal((B, T, N, D)).astype(np.float32)).to(dev) for _ in range(9)]
+    with torch.no_grad():
+        pipe = EncodeRolloutPipeline(savi, roll, B, T, H, steal_steps=1.25 if name == 'C2' else 0, encode_graph=False)
+        ref = pipe.run(imgs, noises).clone()
+        pipe.close()
+        pipe = EncodeRolloutPipeline(savi, roll, B, T, H, steal_steps=1.25 if name == 'C2' else 0, encode_graph=True)
+        for _ in range(2):
+            out = pipe.run(imgs, noises)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), (out - ref).abs().max().item()
+        assert len(pipe._enc_graphs) >= 1
+        pipe.close()
