@@ -17,17 +17,18 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 constexpr int FA_NT = 512;   // 8 waves: the projection is fill-rate bound, more loads in flight per CU
-constexpr int FA_ROWS = 64;  // padded sequence length (two 32-row MFMA blocks)
+// padded sequence length: template parameter ROWS = 64 (two 32-row MFMA blocks) or 128 (four: the 15-frame Physion window, 90 tokens)
 constexpr int FA_KC = 64;    // k-chunk of d staged per barrier
 constexpr int FA_LB = FA_KC + 8;
-constexpr int FA_SS = FA_ROWS + 4;  // row stride of the score / V^T tiles (17 16-B slots: conflict-free b128)
 
-template <int HD>
+template <int HD, int ROWS>
 struct FaCfg {
+  static constexpr int FA_ROWS = ROWS;
+  static constexpr int FA_SS = ROWS + 4;             // row stride of the score / V^T tiles (17 / 33 16-B slots: conflict-free b128)
   static constexpr int NC = 3 * HD;                  // q|k|v columns of one head
   static constexpr int NCP = (NC + 31) / 32 * 32;    // padded to MFMA blocks
   static constexpr int CBLK = NCP / 32;
-  static constexpr int MAXB = (2 * CBLK + 7) / 8;    // 32x32 projection blocks per wave
+  static constexpr int MAXB = ((ROWS / 32) * CBLK + 7) / 8;    // 32x32 projection blocks per wave
   static constexpr int B_IT = NCP * (FA_KC / 4) / FA_NT;
   static constexpr int QSTR = HD + 4;                // f32 row stride of Q and K tiles ((HD+4)/4 is odd)
   static constexpr int HDP = (HD + 31) / 32 * 32;    // V^T rows padded to MFMA blocks
@@ -39,13 +40,14 @@ struct FaCfg {
 
 // NK = d / 64 chunks; every chunk's global loads are issued before the first wait, so the projection
 // pays one memory latency instead of NK.  Attention (scores, PV) runs on the exact-f32 MFMA.
-template <int HD, int NK>
+template <int HD, int NK, int ROWS>
 __global__ __launch_bounds__(FA_NT) void qkv_attn_kernel(const float* __restrict__ x, const float* __restrict__ ln_g,
                                                          const float* __restrict__ ln_b, float ln_eps,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ out, int L, int Lq, int d) {
-  using C = FaCfg<HD>;
+  using C = FaCfg<HD, ROWS>;
   constexpr int NCP = C::NCP, CBLK = C::CBLK, MAXB = C::MAXB, B_IT = C::B_IT, QSTR = C::QSTR, HDP = C::HDP;
+  constexpr int FA_ROWS = ROWS, FA_SS = C::FA_SS;
   constexpr int A_IT = FA_ROWS * (FA_KC / 4) / FA_NT;  // 2
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __bf16* Ah = (__bf16*)smem;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(FA_NT) void qkv_attn_kernel(const float* __restrict
   for (int q = 0; q < MAXB; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-  const int nrb = L > 32 ? 2 : 1;   // row block 1 is skipped entirely when L <= 32
+  const int nrb = (L + 31) / 32;   // row blocks beyond the sequence are skipped entirely
   const int nblk = nrb * CBLK;
 #pragma unroll
   for (int kc = 0; kc < NK; ++kc) {
@@ -210,8 +212,8 @@ __global__ __launch_bounds__(FA_NT) void qkv_attn_kernel(const float* __restrict
 
   // ---- scores S = q k^T on the f32 MFMA: one 32x32 block per wave ----------------------------------
   const int nsb = nrb * nrb;
-  if (wave < nsb) {
-    const int rbk = wave / nrb, cbk = wave - rbk * nrb;
+  for (int sblk = wave; sblk < nsb; sblk += 8) {
+    const int rbk = sblk / nrb, cbk = sblk - rbk * nrb;
     f32x16 sacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
@@ -232,8 +234,9 @@ __global__ __launch_bounds__(FA_NT) void qkv_attn_kernel(const float* __restrict
   __syncthreads();
 
   // ---- row softmax over the L real keys, 8 lanes per query row; padded key columns become 0 ------------
-  {
-    const int i = t >> 3, sub = t & 7;
+#pragma unroll
+  for (int i0 = 0; i0 < FA_ROWS; i0 += 64) {
+    const int i = i0 + (t >> 3), sub = t & 7;
     const int kmax = nrb * 32;
     if (i >= L - Lq && i < L) {
       float* row = Ss + i * FA_SS;
@@ -280,12 +283,12 @@ __global__ __launch_bounds__(FA_NT) void qkv_attn_kernel(const float* __restrict
   }
 }
 
-template <int HD, int NK>
+template <int HD, int NK, int ROWS>
 static int launch_fa(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* w,
                      const float* bias, float* out, int B, int L, int Lq, int d, int nheads, hipStream_t st) {
-  constexpr size_t lds = FaCfg<HD>::lds_bytes;
+  constexpr size_t lds = FaCfg<HD, ROWS>::lds_bytes;
   static_assert(lds <= 160 * 1024, "fused attention: LDS budget");
-  auto kern = qkv_attn_kernel<HD, NK>;
+  auto kern = qkv_attn_kernel<HD, NK, ROWS>;
   SF_TRY(sf_ensure_dyn_lds((const void*)kern, (size_t)(lds)));
   sf_prof_begin(SF_K_MHA, st, 6.0 * B * L * (double)d * d + 4.0 * (double)B * nheads * Lq * L * HD);
   hipLaunchKernelGGL(kern, dim3(nheads, B), dim3(FA_NT), lds, st, x, ln_g, ln_b, ln_eps, w, bias, out, L, Lq, d);
@@ -300,10 +303,15 @@ int sf_qkv_attn_ex(const float* x, const float* ln_g, const float* ln_b, float l
   if (B <= 0) return 0;
   if (nheads <= 0 || d % nheads) return 1;
   const int hd = d / nheads;
-  if (L > FA_ROWS || L < 1 || Lq < 1 || Lq > L || (d % FA_KC) != 0 || d > 256) return 1;
+  if (L > 128 || L < 1 || Lq < 1 || Lq > L || (d % FA_KC) != 0 || d > 256) return 1;
+  // windows of 65..128 tokens (the reference's 15-frame Physion window: 90): four token blocks, head width 32 only
+  if (L > 64) {
+    if (hd == 32 && d == 4 * FA_KC) return launch_fa<32, 4, 128>(x, ln_g, ln_b, ln_eps, in_proj_w, in_proj_b, out, B, L, Lq, d, nheads, st);
+    return 1;
+  }
 #define FA_CASE(HD_, NK_) \
   if (hd == HD_ && d == NK_ * FA_KC) \
-    return launch_fa<HD_, NK_>(x, ln_g, ln_b, ln_eps, in_proj_w, in_proj_b, out, B, L, Lq, d, nheads, st)
+    return launch_fa<HD_, NK_, 64>(x, ln_g, ln_b, ln_eps, in_proj_w, in_proj_b, out, B, L, Lq, d, nheads, st)
   // the shapes the reference configures: rollout d=128/256 (8 heads), predictor d=128/192 (4 heads)
   FA_CASE(16, 2);
   FA_CASE(32, 2);

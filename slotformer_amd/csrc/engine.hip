@@ -64,8 +64,10 @@ bool tfm_ws_take(Bump& bp, TfmWs& w, int M, int d, int ffn) {
 // Lq < L (norm_first only): only the last Lq rows of every sequence are produced, into ws.y
 // ([B*Lq, d]) -- used for the final layer of a rollout step, whose other rows are never read
 // (slotformer.py:121).  Returns the output pointer through *out.
+// xp / counters non-NULL (pre-LN, d = 256, ffn = 1024, packed FFN weights): the FFN half runs as ONE launch of the fused kernel
+// of layer_fused.hip on the finished attention rows (xp [4][B*Lq][d] chunk-partial scratch, counters zeroed by the caller).
 int tfm_layer(const sf_tfm_layer& w, float* x, TfmWs& ws, int B, int L, int Lq, int d, int heads, int ffn,
-              int norm_first, hipStream_t st, float** out) {
+              int norm_first, hipStream_t st, float** out, float* xp = nullptr, int* counters = nullptr) {
   const int M = B * L, Mq = B * Lq;
   const float eps = 1e-5f;
   const SfRowMap rd = sf_rows(d);
@@ -84,11 +86,15 @@ int tfm_layer(const sf_tfm_layer& w, float* x, TfmWs& ws, int B, int L, int Lq, 
     const SfRowMap xr = (Lq == L) ? rd : sf_rows_batched(d, Lq, (long long)L * d, (long long)(L - Lq) * d);
     SF_TRY(sf_linear_ex(ws.att, rd, w.out_proj_w, w.out_proj_b, nullptr, nullptr, eps, x, xr, 0, ws.x2, rd, Mq,
                         d, d, 0, st));
-    SF_TRY(sf_linear_ex(ws.x2, rd, w.lin1_w, w.lin1_b, w.norm2_g, w.norm2_b, eps, nullptr, rd, 0, ws.hid,
-                        sf_rows(ffn), Mq, ffn, d, 1, st));
     float* dst = (Lq == L) ? x : ws.y;
-    SF_TRY(sf_linear_ex(ws.hid, sf_rows(ffn), w.lin2_w, w.lin2_b, nullptr, nullptr, eps, ws.x2, rd, 0, dst, rd,
-                        Mq, d, ffn, 0, st));
+    if (xp && counters) {
+      SF_TRY(sf_ffn_partial_ex(ws.x2, (long long)Mq * d, w, eps, xp, (long long)Mq * d, dst, counters, Mq, ffn, st, 1));
+    } else {
+      SF_TRY(sf_linear_ex(ws.x2, rd, w.lin1_w, w.lin1_b, w.norm2_g, w.norm2_b, eps, nullptr, rd, 0, ws.hid,
+                          sf_rows(ffn), Mq, ffn, d, 1, st));
+      SF_TRY(sf_linear_ex(ws.hid, sf_rows(ffn), w.lin2_w, w.lin2_b, nullptr, nullptr, eps, ws.x2, rd, 0, dst, rd,
+                          Mq, d, ffn, 0, st));
+    }
     *out = dst;
   } else {
     if (Lq != L) return sf_set_err(-1, "row pruning requires norm_first", __FILE__, __LINE__);
@@ -225,7 +231,12 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
     SF_TRY(sf_ring_init_ex(m->out_proj_packed, m->out_proj_b, m->in_proj_packed, m->in_proj_b, slots,
                            (long long)T_total * N * C, n_in, ring, RF, N, B, st));
   }
-  if (fused_layers) {
+  // windows of 65..128 tokens (the reference's Physion window: 15 frames x 6 slots): the attention kernels of layer_fused.hip
+  // hold two token blocks, so the layers run as LN1 + q|k|v + attention in one launch (attn_fused.hip, four token blocks), the
+  // out-projection GEMM, and the fused FFN kernel on its finished rows
+  const bool long_ffn = !fused_layers && packed && fused_env && !t_plain_gemms && sf_get_precision() >= 1 && m->norm_first &&
+                        sf_layer_fused_ok(d, m->num_heads, m->ffn_dim, 1) && Lmax > 64 && sf_ffn_tiles(B * Lmax) <= 1024;
+  if (fused_layers || long_ffn) {
     SF_REQUIRE(sf_ffn_tiles(B * Lmax) <= 1024, "batch too large for the fused-layer tile counters");
     // zeroed by a KERNEL, not hipMemsetAsync: the rollout is captured into hipGraphs, and the memset nodes of a graph were seen
     // to stop clearing these words after an OLDER graph exec had been destroyed (stale seam epochs -> consumers read ring rows
@@ -358,7 +369,8 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
       const bool last = (l == m->num_layers - 1);
       const int Lq = (last && m->norm_first) ? N : Lc;
       float* outp = nullptr;
-      SF_TRY(tfm_layer(m->layers[l], cur, tw, B, Lc, Lq, d, m->num_heads, m->ffn_dim, m->norm_first, st, &outp));
+      SF_TRY(tfm_layer(m->layers[l], cur, tw, B, Lc, Lq, d, m->num_heads, m->ffn_dim, m->norm_first, st, &outp,
+                       long_ffn ? xpb : nullptr, long_ffn ? counters : nullptr));
       cur = outp;
       Lc = Lq;
     }

@@ -52,6 +52,12 @@ def run(name, scfg, rcfg, B, T, H, single=False, steve=False):
 
 
 if __name__ == '__main__':
+    only = sys.argv[1] if len(sys.argv) > 1 else ''
+    _run = run
+
+    def run(name, *a, **k):   # noqa: F811  (optional filter: python tools/bench_configs.py "C4 ref")
+        if only in name:
+            _run(name, *a, **k)
     run('C1 OBJ3D SAVi 64^2, 6 slots', gu.C1_SAVI, gu.C1_ROLL, 4, 6, 10)
     run('C1 (batch 32)', gu.C1_SAVI, gu.C1_ROLL, 32, 6, 10)
     run('C2 CLEVRER StoSAVi 128^2', gu.C2_SAVI, gu.C2_ROLL, 32, 6, 50)
