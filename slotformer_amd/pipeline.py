@@ -183,6 +183,8 @@ class EncodeRolloutPipeline:
                         enc_words = encode_mask_words(encode_cu_word)
                     elif os.environ.get('SF_PIPE_CU_SPLIT'):
                         enc_words = encode_mask_words(os.environ['SF_PIPE_CU_SPLIT'])
+                    elif self._encode_rows() != 4:
+                        enc_words = encode_mask_words(f'rows{self._encode_rows()}')
                     roll_words = [~w & 0xffffffff for w in enc_words]
                     self.roll_streams = [self._masked_stream(roll_words), self._masked_stream(roll_words)]
                     self.s_roll = self.roll_streams[0]
@@ -244,6 +246,24 @@ class EncodeRolloutPipeline:
     @property
     def graphs(self):
         return [u.graph for u in self.units if u.graph is not None]
+
+    def _encode_rows(self):
+        """CU rows (of 8; 32 CUs each) of the encode partition when the caller names no split.  Both partitions are bound by CU
+        time (workgroups x time in the kernel), so the split follows the two sides' CU time per batch, estimated from the
+        per-launch figures of profiles/r03_kernel_stats.csv: encode 2.45 CU-ms per 128 x 128 frame at slot size 128 (more
+        with wider slots); rollout per video, step and layer 51 us (all-heads attention workgroup) + 28 us per 128 FFN rows.
+        Balanced pairs (C2: share 0.55; C4: 0.59) keep the even split, the one every other split lost to; a rollout-heavy pair
+        (C5, 1 + 80 frames: share 0.06) gives the encode one row: 305 k vs 221 k frames/s (profiles/r03_probes.txt)."""
+        if not self.fused:
+            return 4
+        res = getattr(self.savi, 'resolution', (128, 128))
+        slot = self.D
+        enc = self.B * self.T * (res[0] * res[1] / 16384.0) * 2.45 * (slot / 128.0) ** 1.5
+        hist = getattr(self.roll, 'cond_len', None) or getattr(self.roll, 'history_len', self.T)
+        L = self.N * hist
+        roll = self.B * self.H * len(self.roll.transformer_encoder.layers) * (0.051 + 0.028 * L / 128.0)
+        share = enc / (enc + roll)
+        return 4 if share >= 0.4 else max(1, round(8 * share))
 
     def _masked_stream(self, words):
         arr = (C.c_uint * 8)(*words)
