@@ -144,13 +144,27 @@ class EncodeRolloutPipeline:
         self.steal = max(0.0, min(float(steal_steps), float(self.T)))   # may be fractional: see _steal_of
         self._masked = []
         self._lib = _lib.lib()
+        # 'pair': the encode partition's CU mask (the rollout streams get the complement)
+        self._enc_words_pair = ENC_WORDS_P
+        if partition == 'pair':
+            if isinstance(encode_cu_word, str) and encode_cu_word.startswith('rows'):
+                self._enc_words_pair = encode_mask_words(encode_cu_word)
+            elif os.environ.get('SF_PIPE_CU_SPLIT'):
+                self._enc_words_pair = encode_mask_words(os.environ['SF_PIPE_CU_SPLIT'])
+            elif self._encode_rows() != 4:
+                self._enc_words_pair = encode_mask_words(f'rows{self._encode_rows()}')
         if rollout_opts is None and partition == 'pair':
             # several chains share the rollout CUs: seam launches (consumers spinning on a CU each) cost more than they
-            # save, and the CUs are the bound -- wide FFN workgroups (one load of the weight chunk per 128 rows)
-            # -- wide FFN workgroups (one load of the weight chunk per 128 rows) and one attention workgroup per video running
-            # all 8 heads (the layer input ingested and normalised once, finished rows out instead of four partials)
-            rollout_opts = {'seam': bool(int(os.environ.get('SF_PIPE_SEAM', '0'))), 'ffn_rows': int(os.environ.get('SF_PIPE_FFN_ROWS', '128')),
-                            'attn_heads': int(os.environ.get('SF_PIPE_ATTN_HEADS', '8'))}
+            # save.  When the attention workgroups of the two units in flight cover the rollout partition at one per video,
+            # the CUs are the bound: wide FFN workgroups (one load of the weight chunk per 128 rows) and one attention
+            # workgroup per video running all 8 heads (the layer input ingested and normalised once, finished rows out
+            # instead of four partials).  Smaller units (C5 at 8 or 16 videos per batch) would leave most of those CUs idle:
+            # the latency forms, four times the workgroups (224 vs 120 k frames/s at B = 8, 251 vs 219 k at B = 16).  Same bits.
+            roll_cus = 256 - sum(bin(w).count('1') for w in self._enc_words_pair)
+            wide = 2 * self.G * self.B >= roll_cus
+            rollout_opts = {'seam': bool(int(os.environ.get('SF_PIPE_SEAM', '0'))),
+                            'ffn_rows': int(os.environ.get('SF_PIPE_FFN_ROWS', '128' if wide else '64')),
+                            'attn_heads': int(os.environ.get('SF_PIPE_ATTN_HEADS', '8' if wide else '2'))}
         self.rollout_opts = engine.rollout_opts(rollout_opts)
         # units of fewer batches (the ramp at both ends of a run) are on the critical path of fill and drain: the latency forms
         # of the kernels (head-pair attention workgroups, narrower FFN workgroups: more, shorter workgroups per launch) -- the
@@ -178,13 +192,7 @@ class EncodeRolloutPipeline:
         if partition != 'none':
             try:
                 if partition == 'pair':
-                    enc_words = ENC_WORDS_P
-                    if isinstance(encode_cu_word, str) and encode_cu_word.startswith('rows'):
-                        enc_words = encode_mask_words(encode_cu_word)
-                    elif os.environ.get('SF_PIPE_CU_SPLIT'):
-                        enc_words = encode_mask_words(os.environ['SF_PIPE_CU_SPLIT'])
-                    elif self._encode_rows() != 4:
-                        enc_words = encode_mask_words(f'rows{self._encode_rows()}')
+                    enc_words = self._enc_words_pair
                     roll_words = [~w & 0xffffffff for w in enc_words]
                     self.roll_streams = [self._masked_stream(roll_words), self._masked_stream(roll_words)]
                     self.s_roll = self.roll_streams[0]
