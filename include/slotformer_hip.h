@@ -483,6 +483,12 @@ typedef struct {
    * Used when all are given, enc_out_channels == slot_size == 128 and the split-bf16 mode is on. */
   const float *sa_fold_q_w, *sa_fold_q_w_t, *sa_fold_gru_ih_t;
   const void *sa_fold_q_w_p, *sa_fold_gru_ih_p;
+  /* optional (pred_type 1, pre-LN, 4 heads, N <= 8; slot size / ffn / LSTM hidden 128 / 512 / 256 or 64 / 128 / 128):
+   * HOST array of sf_pack_linear_weights copies -- [4 l + 0..3] = predictor layer l's in_proj_weight [3D, D], out_proj.weight
+   * [D, D], linear1.weight [F, D], linear2.weight [D, F]; then, with the LSTM wrapper, weight_ih_l0 [4H, D], weight_hh_l0 [4H, H],
+   * out_projector.weight [D, H].  With it the predictor step of a frame (predictor.py:20-44,76-135) is ONE launch instead of
+   * 8 + 4 (split-bf16, like the other bf16x3 kernels); NULL: the unfused chain. */
+  const void** pred_packed;
 } sf_savi_encoder;
 
 size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B);

@@ -700,40 +700,55 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
         SF_TRY(sf_copy_rows_ex(m->init_latents, sf_rows_batched(D, N, 0, 0), latents, sf_rows(D), R, D, st));
         lat = latents;
       } else {
-        const float* pout;
-        if (m->pred_type == 0) {
-          // ResidualMLPPredictor (predictor.py:65-73)
-          SF_TRY(sf_layernorm_ex(prev, sf_rows(D), m->pm_ln_g, m->pm_ln_b, lnbuf, sf_rows(D), R, D, ln_eps, st));
-          SF_TRY(sf_linear_ex(lnbuf, sf_rows(D), m->pm_w0, m->pm_b0, nullptr, nullptr, ln_eps, nullptr, sf_rows(D), 0,
-                              tw.hid, sf_rows(2 * D), R, 2 * D, D, 1, st));
-          SF_TRY(sf_linear_ex(tw.hid, sf_rows(2 * D), m->pm_w2, m->pm_b2, nullptr, nullptr, ln_eps,
-                              m->pred_norm_first ? lnbuf : prev, sf_rows(D), 0, px, sf_rows(D), R, D, 2 * D, 0, st));
-          pout = px;
-        } else {
-          // TransformerPredictor over the N slots (predictor.py:20-44)
-          SF_TRY(sf_copy_rows_ex(prev, sf_rows(D), px, sf_rows(D), R, D, st));
-          float* cur = px;
-          for (int l = 0; l < m->pred_num_layers; ++l) {
-            float* outp = nullptr;
-            SF_TRY(tfm_layer(m->pred_layers[l], cur, tw, B, N, N, D, m->pred_num_heads, m->pred_ffn_dim,
-                             m->pred_norm_first, st, &outp));
-            cur = outp;
-          }
-          pout = cur;
-        }
-        if (m->pred_rnn) {
-          // nn.LSTM, seq len 1, batch B*N (predictor.py:113-120)
-          const int Hh = m->pred_hidden;
-          SF_TRY(sf_linear_ex(pout, sf_rows(D), m->lstm_w_ih, m->lstm_b_ih, nullptr, nullptr, ln_eps, nullptr,
-                              sf_rows(4 * Hh), 0, gates, sf_rows(4 * Hh), R, 4 * Hh, D, 0, st));
-          SF_TRY(sf_linear_ex(lstm_h, sf_rows(Hh), m->lstm_w_hh, m->lstm_b_hh, nullptr, nullptr, ln_eps, gates,
-                              sf_rows(4 * Hh), 0, gates, sf_rows(4 * Hh), R, 4 * Hh, Hh, 0, st));
-          SF_TRY(sf_lstm_pointwise_ex(gates, lstm_c, lstm_h, lstm_c, R, Hh, st));
-          SF_TRY(sf_linear_ex(lstm_h, sf_rows(Hh), m->proj_w, m->proj_b, nullptr, nullptr, ln_eps, nullptr,
-                              sf_rows(D), 0, latents, sf_rows(D), R, D, Hh, 0, st));
+        // Transformer predictor (+ LSTM wrapper) in one launch (pred_step.hip) when its packed weights are there
+        int pstep = 1;
+        static const bool pstep_env = [] {   // SF_PRED_STEP=0: the unfused chain (A/B measurements)
+          const char* e = getenv("SF_PRED_STEP");
+          return !(e && e[0] == '0');
+        }();
+        if (pstep_env && m->pred_type == 1 && m->pred_packed && sf_get_precision() >= 1 && !t_plain_gemms)
+          pstep = sf_pred_step_ex(prev, m->pred_layers, m->pred_num_layers, m->pred_num_heads, m->pred_ffn_dim, m->pred_norm_first,
+                                  m->pred_packed, m->lstm_b_ih, m->lstm_b_hh, m->proj_b, m->pred_hidden, m->pred_rnn ? lstm_h : nullptr,
+                                  m->pred_rnn ? lstm_c : nullptr, latents, B, N, D, 1e-5f, st);
+        if (pstep < 0 || pstep > 1) return pstep;
+        if (pstep == 0) {
           lat = latents;
         } else {
-          lat = pout;
+          const float* pout;
+          if (m->pred_type == 0) {
+            // ResidualMLPPredictor (predictor.py:65-73)
+            SF_TRY(sf_layernorm_ex(prev, sf_rows(D), m->pm_ln_g, m->pm_ln_b, lnbuf, sf_rows(D), R, D, ln_eps, st));
+            SF_TRY(sf_linear_ex(lnbuf, sf_rows(D), m->pm_w0, m->pm_b0, nullptr, nullptr, ln_eps, nullptr, sf_rows(D), 0,
+                                tw.hid, sf_rows(2 * D), R, 2 * D, D, 1, st));
+            SF_TRY(sf_linear_ex(tw.hid, sf_rows(2 * D), m->pm_w2, m->pm_b2, nullptr, nullptr, ln_eps,
+                                m->pred_norm_first ? lnbuf : prev, sf_rows(D), 0, px, sf_rows(D), R, D, 2 * D, 0, st));
+            pout = px;
+          } else {
+            // TransformerPredictor over the N slots (predictor.py:20-44)
+            SF_TRY(sf_copy_rows_ex(prev, sf_rows(D), px, sf_rows(D), R, D, st));
+            float* cur = px;
+            for (int l = 0; l < m->pred_num_layers; ++l) {
+              float* outp = nullptr;
+              SF_TRY(tfm_layer(m->pred_layers[l], cur, tw, B, N, N, D, m->pred_num_heads, m->pred_ffn_dim,
+                               m->pred_norm_first, st, &outp));
+              cur = outp;
+            }
+            pout = cur;
+          }
+          if (m->pred_rnn) {
+            // nn.LSTM, seq len 1, batch B*N (predictor.py:113-120)
+            const int Hh = m->pred_hidden;
+            SF_TRY(sf_linear_ex(pout, sf_rows(D), m->lstm_w_ih, m->lstm_b_ih, nullptr, nullptr, ln_eps, nullptr,
+                                sf_rows(4 * Hh), 0, gates, sf_rows(4 * Hh), R, 4 * Hh, D, 0, st));
+            SF_TRY(sf_linear_ex(lstm_h, sf_rows(Hh), m->lstm_w_hh, m->lstm_b_hh, nullptr, nullptr, ln_eps, gates,
+                                sf_rows(4 * Hh), 0, gates, sf_rows(4 * Hh), R, 4 * Hh, Hh, 0, st));
+            SF_TRY(sf_lstm_pointwise_ex(gates, lstm_c, lstm_h, lstm_c, R, Hh, st));
+            SF_TRY(sf_linear_ex(lstm_h, sf_rows(Hh), m->proj_w, m->proj_b, nullptr, nullptr, ln_eps, nullptr,
+                                sf_rows(D), 0, latents, sf_rows(D), R, D, Hh, 0, st));
+            lat = latents;
+          } else {
+            lat = pout;
+          }
         }
       }
       // ---- kernel distribution + sampling (savi.py:401-402) --------------------------------------

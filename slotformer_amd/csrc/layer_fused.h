@@ -3,6 +3,11 @@
 #include "../../include/slotformer_hip.h"
 #include "sf_internal.h"
 
+// pred_step.hip: Transformer predictor (+ LSTM wrapper) of one frame in one launch; 1 = shape not covered
+int sf_pred_step_ex(const float* prev, const sf_tfm_layer* layers, int nlayers, int heads, int ffn, int norm_first, const void* const* packed,
+                    const float* lstm_b_ih, const float* lstm_b_hh, const float* proj_b, int hidden, float* lstm_h, float* lstm_c,
+                    float* out, int B, int N, int D, float eps, hipStream_t st);
+
 // x [B][L][256] -> ap: 8 head-partial buffers [B*Lq, 256]
 int sf_attn_oproj_ex(const float* xin, const sf_tfm_layer& w, float eps, float* ap, long long ap_stride, int B, int L,
                      int Lq, hipStream_t st);

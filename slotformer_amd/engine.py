@@ -322,6 +322,24 @@ def encoder_plan(m):
         s.lstm_w_ih, s.lstm_w_hh = plan.dp(pred.rnn.weight_ih_l0), plan.dp(pred.rnn.weight_hh_l0)
         s.lstm_b_ih, s.lstm_b_hh = plan.dp(pred.rnn.bias_ih_l0), plan.dp(pred.rnn.bias_hh_l0)
         s.proj_w, s.proj_b = plan.dp(pred.out_projector.weight), plan.dp(pred.out_projector.bias)
+    if s.pred_type == 1 and base.norm_first and base.num_heads == 4 and m.init_latents.is_cuda:
+        # fragment-ordered split-bf16 copies for the one-launch predictor step (pred_step.hip)
+        mats = []
+        for layer in base.transformer_encoder.layers:
+            mats += [layer.self_attn.in_proj_weight, layer.self_attn.out_proj.weight, layer.linear1.weight, layer.linear2.weight]
+        if rnn:
+            mats += [pred.rnn.weight_ih_l0, pred.rnn.weight_hh_l0, pred.out_projector.weight]
+        if all(w.shape[0] % 32 == 0 and w.shape[1] % 16 == 0 for w in mats):
+            st = torch.cuda.current_stream().cuda_stream
+            arr = (C.c_void_p * len(mats))()
+            for i, w in enumerate(mats):
+                n, k = w.shape
+                buf = torch.empty(lib().sf_packed_linear_bytes(n, k), dtype=torch.uint8, device=w.device)
+                check(lib().sf_pack_linear_weights(plan.dp(w), buf.data_ptr(), n, k, st))
+                plan.keep.append(buf)
+                arr[i] = buf.data_ptr()
+            plan.keep.append(arr)
+            s.pred_packed = C.cast(arr, C.POINTER(C.c_void_p))
     plan.struct, plan.sig = s, sig
     m._sf_plan = plan
     return plan

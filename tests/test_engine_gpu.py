@@ -475,3 +475,27 @@ def test_rollout_bf16_entry_point_error_is_measured(dev):
     assert 1e-3 < e16 < 5e-2, e16      # usable as an option, not as the parity path
     assert e3 < ef < e16 and ef < 5e-3, ef
     assert lib.sf_get_precision() == 1  # the entry points restore the library mode
+
+
+@pytest.mark.parametrize('cfg,name,seed,res', [(gu.C1_SAVI, 'savi_c1', 101, 64), (gu.C5_SAVI, 'savi_c5', 105, 128)])
+@torch.no_grad()
+def test_predictor_step_one_launch_matches_the_unfused_chain(dev, cfg, name, seed, res):
+    """pred_step.hip (Transformer predictor + LSTM wrapper of a frame in one launch, predictor.py:20-44,76-135) against the
+    chain of GEMM / attention / pointwise launches it replaces, on a ragged number of videos (7 x 6 slots: two workgroups)."""
+    import ctypes as C
+    from slotformer_amd import engine
+    m, _ = build(cfg, gu.load_golden(name), seed, dev)
+    m.testing = True
+    img = gu.seeded_img(7, 4, res).to(dev)
+    key = 'slots' if cfg['model'] == 'STEVE' else 'post_slots'
+    fused = m({'img': img})[key].clone()
+    plan = engine.encoder_plan(m)
+    assert bool(plan.struct.pred_packed), 'the packed predictor weights are missing: the one-launch step did not run'
+    saved = plan.struct.pred_packed
+    plan.struct.pred_packed = C.POINTER(C.c_void_p)()
+    try:
+        chain = m({'img': img})[key].clone()
+    finally:
+        plan.struct.pred_packed = saved
+    assert not torch.equal(fused, chain)          # two different kernels ran
+    assert rel_err(fused, chain.cpu()) < 2e-5     # split-bf16 products in another summation order
