@@ -194,34 +194,22 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   float* ring = bp.take((size_t)B * RF * N * d);
   if (!apb || !xpb || !xa || !xb2 || !counters || !seam_flags || !ring) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
   // two-launch layers (layer_fused.hip): split-bf16 mode, pre-LN, d=256 / 8 heads / ffn 1024, window <= 64 tokens
-  static const bool fused_env = [] {
-    const char* e = getenv("SF_LAYER_FUSED");
-    return !(e && e[0] == '0');
-  }();
   bool packed = true;
   for (int l = 0; l < m->num_layers; ++l)
     packed = packed && m->layers[l].lin1_packed && m->layers[l].lin2_packed && m->layers[l].attn_in_packed && m->layers[l].attn_out_packed;
-  const bool fused_layers = packed && fused_env && !t_plain_gemms && sf_get_precision() >= 1 && m->norm_first &&
+  const bool fused_layers = packed && !t_plain_gemms && sf_get_precision() >= 1 && m->norm_first &&
                             sf_layer_fused_ok(d, m->num_heads, m->ffn_dim, Lmax);
   // step boundary in one launch (out-proj of step s + in-proj of the new frame for step s+1) with cached in-projections
   const bool ring_mode = fused_layers && m->in_proj_packed && m->out_proj_packed && sf_step_boundary_ok(d, C);
-  static const bool bfuse_env = [] {
-    const char* e = getenv("SF_BOUNDARY_FUSED");
-    return !(e && e[0] == '0');
-  }();
-  const bool boundary_fused = ring_mode && bfuse_env;
+  const bool boundary_fused = ring_mode;
   // seam launches (layer_fused.hip): the last-layer FFN + boundary of step s and the layer-0 attention of step s+1 in one
   // grid; needs every workgroup of it co-resident at one per CU -- 160 fit the 168-CU rollout partition
   const int seam_opt = sf_thread_opts().seam;
   const bool seam = boundary_fused && (seam_opt >= 0 ? seam_opt != 0 : sf_get_seam_fused() != 0) && sf_seam_blocks(B, N) <= 160 &&
                     sf_thread_opts().attn_heads != 8;
-  // layers 0 .. n-2 leave their output as four FFN chunk partials that the next attention sums while loading (SF_FFN_PARTS=0:
-  // the FFN's last-arriving workgroup sums them, as the last layer always does)
-  static const bool parts_env = [] {
-    const char* e = getenv("SF_FFN_PARTS");
-    return !(e && e[0] == '0');
-  }();
-  const bool parts_mode = ring_mode && parts_env;
+  // layers 0 .. n-2 leave their output as four FFN chunk partials that the next attention sums while loading (the last layer's
+  // FFN sums them itself: its last-arriving workgroup)
+  const bool parts_mode = ring_mode;
   // throughput form of the attention block (per-call option attn_heads_per_wg = 8): one workgroup per video runs all 8 heads
   // and writes finished rows; the FFN behind it reads one row instead of four head-pair partials (layer_fused.hip)
   const bool all_heads = fused_layers && sf_thread_opts().attn_heads == 8;
@@ -234,7 +222,7 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   // windows of 65..128 tokens (the reference's Physion window: 15 frames x 6 slots): the attention kernels of layer_fused.hip
   // hold two token blocks, so the layers run as LN1 + q|k|v + attention in one launch (attn_fused.hip, four token blocks), the
   // out-projection GEMM, and the fused FFN kernel on its finished rows
-  const bool long_ffn = !fused_layers && packed && fused_env && !t_plain_gemms && sf_get_precision() >= 1 && m->norm_first &&
+  const bool long_ffn = !fused_layers && packed && !t_plain_gemms && sf_get_precision() >= 1 && m->norm_first &&
                         sf_layer_fused_ok(d, m->num_heads, m->ffn_dim, 1) && Lmax > 64 && sf_ffn_tiles(B * Lmax) <= 1024;
   if (fused_layers || long_ffn) {
     SF_REQUIRE(sf_ffn_tiles(B * Lmax) <= 1024, "batch too large for the fused-layer tile counters");
@@ -350,7 +338,7 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
         } else {
           SF_TRY(sf_attn_oproj_ex(cin, m->layers[l], 1e-5f, apb, pst, B, L, Lq, st));
         }
-        if (parts_env && !lastl) {
+        if (!lastl) {
           SF_TRY(sf_ffn_parts_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, B * Lq, m->ffn_dim, st, np));
           parts_in = true;
         } else {
@@ -630,12 +618,8 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
   const long long frame_elems = (long long)3 * res * res;
   const float ln_eps = 1e-5f;
   // Slot Attention on the normalised pixel features with the key / value projections folded into project_q and the GRU input
-  // matrix (include/slotformer_hip.h, sa_fold_*); SF_SA_FOLD=0: k|v as the reference computes them
-  static const bool fold_env = [] {
-    const char* e = getenv("SF_SA_FOLD");
-    return !(e && e[0] == '0');
-  }();
-  const bool fold = fold_env && sf_get_precision() >= 1 && m->sa_fold_q_w && m->sa_fold_q_w_t && m->sa_fold_gru_ih_t && Ce == D &&
+  // matrix (include/slotformer_hip.h, sa_fold_*); without the folded copies, or at other widths (C4: 192): k|v as the reference computes them
+  const bool fold = sf_get_precision() >= 1 && m->sa_fold_q_w && m->sa_fold_q_w_t && m->sa_fold_gru_ih_t && Ce == D &&
                     sf_pixel_mlp_feat_ok(m->enc_channels[m->enc_layers], Ce);
   const float* q_w = fold ? m->sa_fold_q_w : m->sa_q_w;
   const float* q_w_t = fold ? m->sa_fold_q_w_t : m->sa_q_w_t;
@@ -702,11 +686,7 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
       } else {
         // Transformer predictor (+ LSTM wrapper) in one launch (pred_step.hip) when its packed weights are there
         int pstep = 1;
-        static const bool pstep_env = [] {   // SF_PRED_STEP=0: the unfused chain (A/B measurements)
-          const char* e = getenv("SF_PRED_STEP");
-          return !(e && e[0] == '0');
-        }();
-        if (pstep_env && m->pred_type == 1 && m->pred_packed && sf_get_precision() >= 1 && !t_plain_gemms)
+        if (m->pred_type == 1 && m->pred_packed && sf_get_precision() >= 1 && !t_plain_gemms)
           pstep = sf_pred_step_ex(prev, m->pred_layers, m->pred_num_layers, m->pred_num_heads, m->pred_ffn_dim, m->pred_norm_first,
                                   m->pred_packed, m->lstm_b_ih, m->lstm_b_hh, m->proj_b, m->pred_hidden, m->pred_rnn ? lstm_h : nullptr,
                                   m->pred_rnn ? lstm_c : nullptr, latents, B, N, D, 1e-5f, st);
@@ -778,12 +758,8 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
     }
     // ---- Slot Attention iterations (savi.py:76-100) -------------------------------------------
     const float scale = 1.0f / sqrtf((float)D);
-    // slot update on the matrix cores (slot_update_mfma.hip) when the packed copies are there; SF_SU_MFMA=0: the VALU kernel
-    static const bool su_env = [] {
-      const char* e = getenv("SF_SU_MFMA");
-      return !(e && e[0] == '0');
-    }();
-    const bool su_mfma = su_env && sf_get_precision() >= 1 && gru_ih_p && m->sa_gru_hh_p && m->sa_mlp_w1_p && m->sa_mlp_w2_p &&
+    // slot update on the matrix cores (slot_update_mfma.hip) when the packed copies are there (slot size 128); otherwise the VALU kernel
+    const bool su_mfma = sf_get_precision() >= 1 && gru_ih_p && m->sa_gru_hh_p && m->sa_mlp_w1_p && m->sa_mlp_w2_p &&
                          q_w_p && sf_slot_update_mfma_ok(D, Hm, P);
     for (int it = 0; it < m->num_iterations; ++it) {
       const bool last_it = (it == m->num_iterations - 1);
