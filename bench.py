@@ -135,7 +135,7 @@ def committed_profile(key):
 
 
 KERNEL_CLASS = {'conv5x5_halo': 'conv', 'ffn_partial_kernel': 'ffn_fused', 'ffn64_parts_kernel': 'ffn_fused', 'ffn_wide_parts_kernel': 'ffn_fused',
-                'attn_oproj_kernel': 'attention', 'seam_kernel': 'seam', 'sa_attn_mfma_kernel': 'slot_attn', 'sa_attn_fold_kernel': 'slot_attn'}
+                'attn_oproj_kernel': 'attention', 'attn_all_kernel': 'attention', 'seam_kernel': 'seam', 'sa_attn_mfma_kernel': 'slot_attn', 'sa_attn_fold_kernel': 'slot_attn'}
 
 
 def dominant_kernel():
@@ -515,8 +515,9 @@ def main():
         W_FR = roll.cond_len if single else roll.history_len
         for key, name in (('ffn_fused', 'ffn_wide_parts_kernel<2> / <1> / ffn_partial_kernel (sum of the 4 head-pair partials + LN2 + FFN1 + ReLU + FFN2 on a '
                            '128- / 64- / 32-row tile x 256-wide hidden chunk; chunk partials out, last-arriver reduction + step boundary on the last layer)'),
-                          ('attention', 'attn_oproj_kernel (LN1 + q|k|v of a head pair + softmax(qk^T)v + out-proj partial; one workgroup per '
-                           '(head pair, video))'),
+                          ('attention', 'attn_all_kernel (LN1 + q|k|v + softmax(qk^T)v of all 8 heads + out-projection + residual: finished rows; one '
+                           'workgroup per video) in the throughput units; attn_oproj_kernel (one workgroup per head pair and video, four partials) '
+                           'in the latency-form drain unit'),
                           ('seam', 'seam_kernel (last-layer FFN + step boundary of step s and the layer-0 attention of step s+1 in one grid, '
                            'tile-local write-through hand-off)')):
             iso, live = prof_roll.get(key), prof_roll_live.get(key)
@@ -542,8 +543,9 @@ def main():
                 'cus_available': pipe.rollout_cus if pipe.cu_split else 256,
                 'traffic': pm.get('traffic_bytes_per_launch'),
                 'mfma_busy_frac': pm.get('mfma_busy_frac'), 'pmc_source': pm.get('source'),
-                'limiter': 'per-CU ingest of weight fragments + partial activations and dependent-launch latency below ~128 rows per workgroup; '
-                           'the matrix pipe at 128 rows per workgroup (DESIGN.md 4)',
+                'limiter': 'FFN: per-CU ingest of weight fragments + rows (a CU takes in 70-100 GB/s) around ~10 us of MFMAs per 128-row workgroup; '
+                           'attention: a serial eight-wave workgroup per video -- per head pair 1.9 us of projection MFMAs inside 8.8 us of LDS '
+                           'round trips, softmax and barriers (DESIGN.md 4, 5)',
             }
         roll_flops = roll_f * G * B
         res['roofline_rollout_graph'] = {
