@@ -7,13 +7,15 @@ weights -- so they run side by side on disjoint sets of CUs (streams created wit
 
 * a rollout UNIT is `group` consecutive batches rolled out by ONE hipGraph over one slot buffer [group * B, T, N, D]:
   every launch of the chain then covers group * B * L rows, so the weights a workgroup drags through its CU, the launch
-  gaps and the first-load latencies are paid once per `group` batches (round 3: group = 2 with 128-row FFN workgroups;
-  the rollout kernels are per-video / per-row, so the results do not depend on how videos are grouped -- tested).  Every
-  unit buffer has its own graph and workspace, captured ONCE; a ragged last unit (fewer batches) gets its own graph;
+  gaps and the first-load latencies are paid once per `group` batches (round 3: group = 4 with all-heads attention and
+  128-row FFN workgroups; the rollout kernels are per-video / per-row, so the results do not depend on how videos are
+  grouped -- tested).  Every unit buffer has its own graph and workspace, captured ONCE; a ragged last unit (fewer batches)
+  gets its own graph; the encode of a batch replays from a hipGraph over fixed input buffers as well;
 * partition 'pair' (default): a single rollout chain leaves most of its CUs idle most of the time, so TWO units roll out
-  side by side on two rollout streams that share CU rows 0-4 of all four shader engines of every XCD (160 CUs), and the
-  encode runs on rows 5-7 (96 CUs).  Three busy CU-masked queues are the limit on this platform -- a fourth slows all of
-  them, five collapse (profiles/r02_probes.txt) -- hence two rollout streams and ONE encode stream;
+  side by side on two rollout streams that share whole CU rows of all four shader engines of every XCD, and the encode
+  runs on the other rows: 128 / 128 CUs for balanced model pairs, fewer encode rows for rollout-heavy ones (_encode_rows).
+  Three busy CU-masked queues are the limit on this platform -- a fourth slows all of them, five collapse
+  (profiles/r02_probes.txt) -- hence two rollout streams and ONE encode stream;
 * partition 'three': one rollout stream on CU rows 0-6 of shader engines 1-3 (168 CUs) and two encode *lanes*, each with
   its share of a batch's videos: shader engine 0 (64 CUs, 3/4 of the videos) and row 7 of shader engines 1-3 (24 CUs).
   partition 'two' is the round-1 split (encode: `encode_cu_word`, rollout: the complement);
@@ -96,15 +98,16 @@ class EncodeRolloutPipeline:
     (= rollouter.history_len, or 1 for the single-step rollouter); pred_len: rollout steps.
     partition: 'pair' (default; see the module docstring), 'three', 'two' (one encode stream on `encode_cu_word`, the
     rollout on the complement) or 'none' (plain streams, shared CUs).  encode_cu_word: see encode_mask_words; for 'pair'
-    a 'rows<R>' string moves the split (encode on 32 R CUs; default: 96 for the encode, 160 for the rollouts).
-    group: batches per rollout unit / graph (None = 2 for 'pair', 1 otherwise).
+    a 'rows<R>' string moves the split (encode on 32 R CUs; default: sized from the two sides' CU time, _encode_rows).
+    group: batches per rollout unit / graph (None = 4 for 'pair' with a rollouter on the fused-layer path, 1 otherwise).
     steal_steps: time steps of convolutions per batch computed on the rollout streams (may be fractional: 1.25 = one step,
     two for every fourth batch); None = the partition's tuned default.
     encode_graph: replay the encode of a batch from a hipGraph over fixed input buffers as well (frames / noise / stolen
     features staged into them; bit-identical; default on, False: eager launches).
     rollout_opts: per-call kernel options of the captured rollouts (engine.rollout_opts); None = the partition's default
-    ('pair': no seam launches, 128-row FFN workgroups, all-heads attention workgroups -- the throughput settings, the same
-    bits as the library defaults; otherwise the library defaults).
+    ('pair': no seam launches; 128-row FFN workgroups and all-heads attention workgroups -- the throughput settings -- when
+    the two units in flight cover the rollout CUs with one attention workgroup per video, else 64-row / head-pair workgroups;
+    the same bits as the library defaults either way; other partitions: the library defaults).
     """
 
     def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=None, use_graph=True,
