@@ -234,6 +234,7 @@ class EncodeRolloutPipeline:
         # smaller units at the end of a run (_unit_plan): measured WORSE with group 4 (unmasked drain units take CUs from the
         # encode and the full units: 322 vs 376 k frames/s at 20 batches) -- off
         self.ramp = bool(int(os.environ.get('SF_PIPE_RAMP', '0')))
+        self.fill_par = max(1, min(3, int(os.environ.get('SF_PIPE_FILL_PAR', '2'))))   # whole-chip encodes side by side during the fill
         self.fill_batches = int(os.environ.get('SF_PIPE_FILL', '0'))   # 0: the batches of the first unit
         self.fill_steal = int(os.environ.get('SF_PIPE_FILL_STEAL', '0'))
         # pre_steal[h]: time steps of convolutions of batch h of the NEXT unit computed on a rollout stream right before a unit
@@ -540,11 +541,17 @@ class EncodeRolloutPipeline:
                 j = u0 + h
                 dst = u.buf[h * B:(h + 1) * B]
                 if j < n_fill:
-                    # pipeline fill: the first encodes take the whole chip (the calling stream); the masked lanes start after
-                    # them.  The host waits: with the other queues parked in a wait on this event the encode was measured at 4.8
-                    # instead of 3.05 ms (a queue stalled in a cross-queue wait slows the queue that is running)
-                    self._encode(img_of(j, cur), nz(j), dst, None)
-                    ev_enc[j][0].record(cur)
+                    # pipeline fill: the first encodes take the whole chip (unmasked streams); the masked lanes start after them.  One
+                    # encode alone cannot fill 256 CUs (2.7 ms for 470 CU-ms of work), so `fill_par` of them run side by side,
+                    # each from its own graph / buffers (380-382 vs 375-378 k frames/s at 20 batches).  The host waits: with the
+                    # other queues parked in a wait on this event the encode was measured at 4.8 instead of 3.05 ms (a queue stalled
+                    # in a cross-queue wait slows the queue that is running)
+                    fill_par = self.fill_par if self.s_free else 1
+                    fi = j % fill_par
+                    fs = cur if fi == 0 else self.s_free[(fi - 1) % len(self.s_free)]
+                    with torch.cuda.stream(fs):
+                        self._encode(img_of(j, fs), nz(j), dst, None, lane=('fill', fi) if fill_par > 1 else 0)
+                        ev_enc[j][0].record(fs)
                     if j == 0 and (steal or fill_k) and len(rolls) > 1:
                         # the rollout streams idle until the first unit is encoded: they compute the stolen features of the
                         # batches behind the fill now (round-robin), so that only the fill batches pay for their own convolutions
@@ -558,9 +565,11 @@ class EncodeRolloutPipeline:
                             with torch.cuda.stream(rolls[-1]):
                                 steal_for(jj, rolls[-1], len(rolls) - 1, fill_k or None)
                     if j == n_fill - 1:
-                        ev_enc[j][0].synchronize()
+                        for jj in range(max(0, n_fill - fill_par), n_fill):
+                            ev_enc[jj][0].synchronize()
                         for st, _, _ in lanes:
-                            st.wait_event(ev_enc[j][0])
+                            for jj in range(max(0, n_fill - fill_par), n_fill):
+                                st.wait_event(ev_enc[jj][0])
                     ev_wait_j = ev_enc[j][:1]
                 else:
                     for li, (st, lo, hi) in enumerate(lanes):
