@@ -248,6 +248,18 @@ class EncodeRolloutPipeline:
         self._stage, self._s_copy, self._s_out = None, None, None   # staging ring + copy streams for host-resident inputs / outputs
         self.completion_events = []      # one event per unit of the last run() ...
         self.completion_batches = []     # ... and the number of batches it completed
+        if self.encode_graph and self.steal == 0 and not self.fill_steal and not self.pre_steal:
+            # the encode graphs of the lanes a run uses are captured NOW, not inside the first run that reaches them (a short
+            # warm-up only touches the fill lanes): full batches, no stolen features
+            res = getattr(self.savi, 'resolution', (128, 128))[0]
+            with_noise = engine.kernel_noise(self.savi, torch.empty(0), 1, self.T, self.dev) is not None   # (no draw: the gate only)
+            with torch.no_grad():
+                for li, (_, lo, hi) in enumerate(self.lanes if self.lanes else [(None, 0, self.B)]):
+                    self._encode_graph_for(li, hi - lo, 0, res, with_noise)
+                if self.cu_split and self.fill_whole_chip and self.s_free and self.fill_par > 1:
+                    for fi in range(self.fill_par):
+                        self._encode_graph_for(('fill', fi), self.B, 0, res, with_noise)
+            torch.cuda.synchronize(self.dev)
 
     # ------------------------------------------------------------------------------------------------------------
     @property

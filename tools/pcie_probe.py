@@ -1,0 +1,31 @@
+"""Host-to-host timing of harness.extract_and_rollout (pinned in, pinned out), call by call.   python tools/pcie_probe.py [batches]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from slotformer_amd import harness
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = torch.device('cuda:0')
+cfg = bench.bench_configs()['C2']
+savi, roll = bench.build_models(dev, cfg)[:2]
+B, T, H = cfg[3], cfg[4], cfg[5]
+vids = (torch.rand(n * B, T, 3, 128, 128) * 2 - 1).pin_memory()
+for it in range(4):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = harness.extract_and_rollout(savi, roll, vids, H, batch_size=B, to_host=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f'call {it}: {1e3 * dt:8.1f} ms  {n * B * (T + H) / dt / 1e3:7.1f} k frames/s  pinned={out.is_pinned()}', flush=True)
+    if it == 1:
+        del out
+vd = vids.to(dev)
+for it in range(2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = harness.extract_and_rollout(savi, roll, vd, H, batch_size=B)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f'device-resident call {it}: {1e3 * dt:8.1f} ms  {n * B * (T + H) / dt / 1e3:7.1f} k frames/s', flush=True)
