@@ -522,8 +522,11 @@ class EncodeRolloutPipeline:
                 k = up_next[0]
                 with torch.cuda.stream(self._s_copy):
                     if k >= NS:
-                        for e in ev_enc[k - NS]:            # the staging slot's previous batch has been encoded (issued long ago)
-                            self._s_copy.wait_event(e)
+                        # the staging slot's previous batch has been encoded (issued NS batches ago).  The HOST waits, not the copy
+                        # stream: a queue parked in a cross-queue wait slows the queues that are running on this platform (the
+                        # masked encode lane ran at 5.8 instead of 4.05 ms per batch with the wait on the stream)
+                        for e in ev_enc[k - NS]:
+                            e.synchronize() if os.environ.get('SF_PIPE_UPLOAD_WAIT', 'host') == 'host' else self._s_copy.wait_event(e)
                     self._stage[k % NS].copy_(imgs[k], non_blocking=True)
                     ev_up[k].record(self._s_copy)
                 up_next[0] += 1
@@ -548,7 +551,24 @@ class EncodeRolloutPipeline:
         ev_t0.record(cur)
         ev_rstart = [torch.cuda.Event(enable_timing=True) for _ in range(nu)] if trace else None
         n_free = 0
+        downloads = []   # host-resident output: units rolled out whose slots are not yet on their way to the host
+
+        def download_ready(for_unit=None, everything=False):
+            """enqueue the downloads of the units whose rollout is done (for_unit: WAIT for that unit buffer's rollout -- the buffer is
+            about to be encoded into again; everything: wait for all of them)"""
+            for d in list(downloads):
+                dui, du0, dnb, du, done = d
+                if everything or du is for_unit:
+                    done.synchronize()
+                if done.query():
+                    with torch.cuda.stream(self._s_out):
+                        for h in range(dnb):
+                            out[du0 + h].copy_(du.buf[h * B:(h + 1) * B], non_blocking=True)
+                        ev_roll[dui].record(self._s_out)
+                    downloads.remove(d)
+
         for ui, (u0, nb, u, drain) in enumerate(units):
+            download_ready(for_unit=u)
             for h in range(nb):
                 j = u0 + h
                 dst = u.buf[h * B:(h + 1) * B]
@@ -627,13 +647,12 @@ class EncodeRolloutPipeline:
                     # pinned host output: the downloads run on a torch-owned stream -- PyTorch's host allocator records an event
                     # on every stream a pinned block was used on when the block is freed, and the CU-masked streams of this
                     # object may be gone by then (close())
+                    # The download stream must not sit PARKED in a wait for the unit's rollout (a queue stalled in a cross-queue
+                    # wait slows the queues that are running on this platform: the masked encode lane ran at 5.7 instead of 4.05 ms
+                    # per batch, 312 vs 390 k frames/s) -- the host enqueues the copies once the rollout is done (download_ready)
                     done = torch.cuda.Event()
                     done.record(s_roll)
-                    with torch.cuda.stream(self._s_out):
-                        self._s_out.wait_event(done)
-                        for h in range(nb):
-                            out[u0 + h].copy_(u.buf[h * B:(h + 1) * B], non_blocking=True)
-                        ev_roll[ui].record(self._s_out)
+                    downloads.append((ui, u0, nb, u, done))
                 u.busy = ev_roll[ui]
                 if steal and ui + lead < nu:
                     # their feature buffers were last read by the encodes of batches <= u0 + nb - 1 ... (NF = lead*G + G apart),
@@ -645,6 +664,7 @@ class EncodeRolloutPipeline:
         # wait that sits pending on the calling stream (PyTorch's default stream is the legacy null stream) for the whole
         # run was measured to slow the kernels of the masked encode lane that shares shader engines with the rollout by
         # 30 % (7.7 instead of 6.4 ms per batch, tools/lane_probe.py COPY=1) -- so run() returns when the results are done.
+        download_ready(everything=True)
         for e in ev_roll[-(len(rolls) + 4):]:   # (the drain units on the unmasked streams may overtake the units before them)
             e.synchronize()
         for st, _, _ in lanes:
