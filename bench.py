@@ -270,6 +270,7 @@ def main():
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
+    pipe_closed = False
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
@@ -412,27 +413,6 @@ def main():
                 u.graph = g
             prof_roll_live = read_profile(lib)
         lib.sf_profile_enable(0)
-        pcie = None
-        if args.pcie:
-            # PCIe-inclusive variant (never `value`): frames start in pinned host memory and the slots end there
-            from slotformer_amd import harness
-            nv = args.steps * B
-            vids_h = torch.cat([ring[j % 3].cpu() for j in range(args.steps)], 0).pin_memory()
-            # warm-up with the same shapes: the pipeline is captured and kept, and the pinned output block of this size sits in
-            # PyTorch's host allocator cache afterwards (a fresh 128 MB hipHostMalloc costs tens of ms)
-            for _ in range(2):   # (the second call still allocates a second pinned block while the first result is alive)
-                warm = harness.extract_and_rollout(savi, roll, vids_h, T_ROLL, batch_size=B, to_host=True)
-            del warm
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            out_h = harness.extract_and_rollout(savi, roll, vids_h, T_ROLL, batch_size=B, to_host=True)
-            torch.cuda.synchronize()
-            t_p = time.perf_counter() - t1
-            assert out_h.shape[0] == nv and not out_h.is_cuda
-            pcie = {'frames_per_s_host_to_host': nv * (T_BURN + T_ROLL) / t_p, 'frames_per_s_device_resident': world * B * (T_BURN + T_ROLL) * args.steps / elapsed,
-                    'h2d_bytes_per_batch': ring[0].numel() * 4, 'd2h_bytes_per_batch': int(np.prod(shape)) * 4,
-                    'note': 'harness.extract_and_rollout(to_host=True): frames in pinned host memory, uploaded batch by batch on a copy stream ahead of '
-                            'the encode, slots downloaded behind the rollout; third call with these shapes (pipeline graphs and the pinned output blocks cached; tools/pcie_probe.py prints every call)'}
         breakdown = None
         if args.breakdown:
             lib.sf_profile_enable(0xff)
@@ -618,6 +598,31 @@ def main():
             res['roofline_' + k] = v
         if breakdown:
             res['kernel_breakdown_one_unit'] = breakdown
+        pcie = None
+        if args.pcie:
+            # (this process's own pipeline object is closed first: with two pipelines alive -- twice the CU-masked queues -- the
+            #  same call takes 120 instead of 94 ms)
+            pipe.close()
+            pipe_closed = True
+            # PCIe-inclusive variant (never `value`): frames start in pinned host memory and the slots end there
+            from slotformer_amd import harness
+            nv = args.steps * B
+            vids_h = torch.cat([ring[j % 3].cpu() for j in range(args.steps)], 0).pin_memory()
+            # warm-up with the same shapes: the pipeline is captured and kept, and the pinned output block of this size sits in
+            # PyTorch's host allocator cache afterwards (a fresh 128 MB hipHostMalloc costs tens of ms)
+            for _ in range(2):   # (the second call still allocates a second pinned block while the first result is alive)
+                warm = harness.extract_and_rollout(savi, roll, vids_h, T_ROLL, batch_size=B, to_host=True)
+            del warm
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            out_h = harness.extract_and_rollout(savi, roll, vids_h, T_ROLL, batch_size=B, to_host=True)
+            torch.cuda.synchronize()
+            t_p = time.perf_counter() - t1
+            assert out_h.shape[0] == nv and not out_h.is_cuda
+            pcie = {'frames_per_s_host_to_host': nv * (T_BURN + T_ROLL) / t_p, 'frames_per_s_device_resident': world * B * (T_BURN + T_ROLL) * args.steps / elapsed,
+                    'h2d_bytes_per_batch': ring[0].numel() * 4, 'd2h_bytes_per_batch': int(np.prod(shape)) * 4,
+                    'note': 'harness.extract_and_rollout(to_host=True): frames in pinned host memory, uploaded batch by batch on a copy stream ahead of '
+                            'the encode, slots downloaded behind the rollout; third call with these shapes (pipeline graphs and the pinned output blocks cached; tools/pcie_probe.py prints every call)'}
         if pcie:
             res['pcie_inclusive'] = pcie
         if world == 1 and not args.no_cpu_baseline:
@@ -630,7 +635,8 @@ def main():
         except OSError:
             pass
         print(json.dumps(res), flush=True)
-    pipe.close()
+    if not pipe_closed:
+        pipe.close()
     if use_dist:
         dist.destroy_process_group()
 
