@@ -480,7 +480,7 @@ typedef struct {
    * themselves -- half the bytes of k|v, and the [Wk;Wv] GEMM disappears -- with
    *   sa_fold_q_w   = Wk^T Wq   [C, D]  in place of project_q[1].weight  (its transposed [D, C] and packed copies beside it)
    *   sa_fold_gru_ih = W_ih Wv  [3D, C] in place of GRUCell.weight_ih    (transposed [C, 3D] and packed copies)
-   * Used when all are given, enc_out_channels == slot_size == 128 and the split-bf16 mode is on. */
+   * Used when all are given, enc_out_channels == slot_size == 128 (or 192 with enc_fc1_p / enc_fc2_p) and the split-bf16 mode is on. */
   const float *sa_fold_q_w, *sa_fold_q_w_t, *sa_fold_gru_ih_t;
   const void *sa_fold_q_w_p, *sa_fold_gru_ih_p;
   /* optional (pred_type 1, pre-LN, 4 heads, N <= 8; slot size / ffn / LSTM hidden 128 / 512 / 256 or 64 / 128 / 128):
@@ -489,6 +489,10 @@ typedef struct {
    * out_projector.weight [D, H].  With it the predictor step of a frame (predictor.py:20-44,76-135) is ONE launch instead of
    * 8 + 4 (split-bf16, like the other bf16x3 kernels); NULL: the unfused chain. */
   const void** pred_packed;
+  /* optional (encoder_out_layer 64 -> 192 -> 192, i.e. STEVE on Physion): sf_pack_linear_weights copies of enc_fc1_w [192, 64] and
+   * enc_fc2_w [192, 192]; with them and the sa_fold_* copies the per-pixel chain up to the normalised Slot-Attention inputs is one
+   * launch (pixel_mlp.hip) and Slot Attention runs folded at width 192 as well */
+  const void *enc_fc1_p, *enc_fc2_p;
 } sf_savi_encoder;
 
 size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B);

@@ -91,7 +91,7 @@ class sf_savi_encoder(C.Structure):
         [('sa_eps', C.c_float), ('sa_q_w_t', FP), ('pm_w0_t', FP), ('pm_w2_t', FP), ('kd_w0_t', FP),
          ('sa_gru_ih_p', C.c_void_p), ('sa_gru_hh_p', C.c_void_p), ('sa_mlp_w1_p', C.c_void_p), ('sa_mlp_w2_p', C.c_void_p),
          ('sa_q_w_p', C.c_void_p), ('sa_fold_q_w', FP), ('sa_fold_q_w_t', FP), ('sa_fold_gru_ih_t', FP), ('sa_fold_q_w_p', C.c_void_p),
-         ('sa_fold_gru_ih_p', C.c_void_p), ('pred_packed', C.POINTER(C.c_void_p))])
+         ('sa_fold_gru_ih_p', C.c_void_p), ('pred_packed', C.POINTER(C.c_void_p)), ('enc_fc1_p', C.c_void_p), ('enc_fc2_p', C.c_void_p)])
 
 
 class sf_slate_block(C.Structure):

@@ -618,9 +618,10 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
   const long long frame_elems = (long long)3 * res * res;
   const float ln_eps = 1e-5f;
   // Slot Attention on the normalised pixel features with the key / value projections folded into project_q and the GRU input
-  // matrix (include/slotformer_hip.h, sa_fold_*); without the folded copies, or at other widths (C4: 192): k|v as the reference computes them
+  // matrix (include/slotformer_hip.h, sa_fold_*; widths 128 and 192); without the folded copies, or at other widths: k|v as the reference computes them
+  const bool feat192 = m->enc_channels[m->enc_layers] == 64 && Ce == 192 && m->enc_fc1_p && m->enc_fc2_p;
   const bool fold = sf_get_precision() >= 1 && m->sa_fold_q_w && m->sa_fold_q_w_t && m->sa_fold_gru_ih_t && Ce == D &&
-                    sf_pixel_mlp_feat_ok(m->enc_channels[m->enc_layers], Ce);
+                    (sf_pixel_mlp_feat_ok(m->enc_channels[m->enc_layers], Ce) || feat192);
   const float* q_w = fold ? m->sa_fold_q_w : m->sa_q_w;
   const float* q_w_t = fold ? m->sa_fold_q_w_t : m->sa_q_w_t;
   const float* gru_ih_t = fold ? m->sa_fold_gru_ih_t : m->gru_w_ih;
@@ -644,6 +645,11 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
       const int Mp = nb * HW;
       // encoder_out_layer (LN -> Linear -> ReLU -> Linear, savi.py:245-250) and k|v = [Wk;Wv] LN(inputs)
       // (savi.py:66-70): one fused kernel per 128-pixel tile in split-bf16 mode (pixel_mlp.hip), else three GEMMs
+      if (fold && feat192) {
+        SF_TRY(sf_pixel_mlp_feat192_ex(cur, m->enc_ln_g, m->enc_ln_b, m->enc_fc1_p, m->enc_fc1_b, m->enc_fc2_p, m->enc_fc2_b,
+                                       m->sa_norm_in_g, m->sa_norm_in_b, kv + (long long)b0 * HW * Ce, Mp, ln_eps, st));
+        continue;
+      }
       if (fold) {
         SF_TRY(sf_pixel_mlp_feat_ex(cur, m->enc_ln_g, m->enc_ln_b, m->enc_fc1_w, m->enc_fc1_b, m->enc_fc2_w, m->enc_fc2_b,
                                     m->sa_norm_in_g, m->sa_norm_in_b, kv + (long long)b0 * HW * Ce, Mp, ln_eps, st));

@@ -256,3 +256,162 @@ int sf_pixel_mlp_feat_ex(const float* x, const float* ln0_g, const float* ln0_b,
   SF_CHECK_LAUNCH();
   return 0;
 }
+
+// ================================================================================================
+// The per-pixel chain at STEVE's width (steve_physion_params.py: encoder_out_layer 64 -> 192 -> 192, Slot-Attention inputs 192), for the
+// FOLDED Slot Attention (engine.hip): x [M][64] -> LN(64) -> fc1 + ReLU -> fc2 -> LN(192) -> features [M][192] (f32).  The three generic
+// GEMM launches this replaces move 317 MB per time step of 16 frames (244 us on the encode partition); here a workgroup holds 128
+// pixels as split-bf16 planes in LDS and streams the two weight matrices (packed once in fragment order, sf_pack_linear_weights)
+// from memory as the MFMA A operand (stream_mfma.h): 16.8 MB in, 50 MB out.
+//   fc1 / fc2: wave w < 6 owns column block w for all four token blocks (one set of fragment reads, four accumulators)
+//   LN(192): a token's 192 values sit in six waves' accumulators -- two rounds of partial sums through LDS (mean, then squared deviations)
+#include "stream_mfma.h"
+
+namespace {
+constexpr int PW_NT = 512, PW_ROWS = 128, PW_C0 = 64, PW_C1 = 192, PW_KP = PW_C1 + 8, PW_NB = PW_C1 / 32;
+constexpr size_t PW_LDS = (size_t)2 * PW_ROWS * PW_KP * 2 + (size_t)(2 * PW_NB * PW_ROWS + 4 * PW_C1) * 4;
+}  // namespace
+
+__global__ __launch_bounds__(PW_NT) void pixel_mlp_feat192_kernel(const float* __restrict__ x, const float* __restrict__ ln0_g,
+                                                                  const float* __restrict__ ln0_b, const uint4* __restrict__ w1p,
+                                                                  const float* __restrict__ b1, const uint4* __restrict__ w2p,
+                                                                  const float* __restrict__ b2, const float* __restrict__ ln1_g,
+                                                                  const float* __restrict__ ln1_b, float* __restrict__ feat, int M, float eps) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 pw_lds[];
+  __bf16* Ph = pw_lds;                       // [128][PW_KP]
+  __bf16* Pl = Ph + PW_ROWS * PW_KP;
+  float* S1 = (float*)(Pl + PW_ROWS * PW_KP);   // [6][128] partial sums
+  float* S2 = S1 + PW_NB * PW_ROWS;             // [6][128] partial sums of squared deviations
+  float* PV = S2 + PW_NB * PW_ROWS;             // b1 | b2 | ln1 gamma | ln1 beta
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int tok = lane & 31, kg = lane >> 5;
+  const int m0 = blockIdx.x * PW_ROWS;
+  const int c4 = t & 15, r0 = t >> 4;
+  // small vectors and the x tile first (the loads retire in order), then the first weight fragments
+  const f32x4 g0 = *(const f32x4*)(ln0_g + 4 * c4), be0 = *(const f32x4*)(ln0_b + 4 * c4);
+  float pvv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = t + PW_NT * i;   // 4 * 192 = 768 values
+    const float* src = j < PW_C1 ? b1 : j < 2 * PW_C1 ? b2 : j < 3 * PW_C1 ? ln1_g : ln1_b;
+    pvv[i] = j < 4 * PW_C1 ? src[j % PW_C1] : 0.f;
+  }
+  f32x4 xr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xr[i] = *(const f32x4*)(x + (long long)min(m0 + r0 + 32 * i, M - 1) * PW_C0 + 4 * c4);
+  PsBuf s;
+  constexpr int KS1 = PW_C0 / 16, KS2 = PW_C1 / 16;
+  if (wave < PW_NB) ps_prime<PsChunk<KS1>::CH>(s, w1p, PW_NB, wave, 0, lane);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (t + PW_NT * i < 4 * PW_C1) PV[t + PW_NT * i] = pvv[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float sm = sf_sum16((xr[i][0] + xr[i][1]) + (xr[i][2] + xr[i][3]));   // the 16 lanes holding this row
+    const float mean = sm * (1.0f / PW_C0);
+    const f32x4 dv = xr[i] - mean;
+    const float vs = sf_sum16((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]));
+    const float rstd = 1.0f / sqrtf(vs * (1.0f / PW_C0) + eps);
+    ps_split4(Ph, Pl, (r0 + 32 * i) * PW_KP + 4 * c4, dv * rstd * g0 + be0);
+  }
+  __syncthreads();
+  f32x16 acc[4];
+  // ---- h1 = relu(W1 LN(x) + b1) -> planes ----
+  if (wave < PW_NB) {
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+    ps_blockN<KS1, PsChunk<KS2>::CH, 4>(acc, s, w1p, PW_NB, wave, 0, w2p, PW_NB, wave, 0, Ph, Pl, PW_KP, lane);
+  }
+  __syncthreads();   // every wave is done with the LN(x) planes
+  if (wave < PW_NB) {
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = 32 * wave + 8 * g + 4 * kg;
+        const f32x4 bv = *(const f32x4*)(PV + n);
+        ps_split4(Ph, Pl, (32 * rb + tok) * PW_KP + n,
+                  f32x4{fmaxf(acc[rb][4 * g] + bv[0], 0.f), fmaxf(acc[rb][4 * g + 1] + bv[1], 0.f), fmaxf(acc[rb][4 * g + 2] + bv[2], 0.f),
+                        fmaxf(acc[rb][4 * g + 3] + bv[3], 0.f)});
+      }
+  }
+  __syncthreads();
+  // ---- h2 = W2 h1 + b2 (in the accumulators), LayerNorm over the 192 channels across the six waves, features out ----
+  if (wave < PW_NB) {
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+    ps_blockN<KS2, 1, 4>(acc, s, w2p, PW_NB, wave, 0, nullptr, 1, 0, 0, Ph, Pl, PW_KP, lane);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      float sm = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *(const f32x4*)(PV + PW_C1 + 32 * wave + 8 * g + 4 * kg);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[rb][4 * g + q] += bv[q];
+          sm += acc[rb][4 * g + q];
+        }
+      }
+      sm += __shfl_xor(sm, 32, 64);
+      if (kg == 0) S1[wave * PW_ROWS + 32 * rb + tok] = sm;
+    }
+  }
+  __syncthreads();
+  float mean[4];
+  if (wave < PW_NB) {
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      float sm = 0.f;
+#pragma unroll
+      for (int j = 0; j < PW_NB; ++j) sm += S1[j * PW_ROWS + 32 * rb + tok];
+      mean[rb] = sm * (1.0f / PW_C1);
+      float vs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = acc[rb][r] - mean[rb];
+        vs += d * d;
+      }
+      vs += __shfl_xor(vs, 32, 64);
+      if (kg == 0) S2[wave * PW_ROWS + 32 * rb + tok] = vs;
+    }
+  }
+  __syncthreads();
+  if (wave < PW_NB) {
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      float vs = 0.f;
+#pragma unroll
+      for (int j = 0; j < PW_NB; ++j) vs += S2[j * PW_ROWS + 32 * rb + tok];
+      const float rstd = 1.0f / sqrtf(vs * (1.0f / PW_C1) + eps);
+      const int row = m0 + 32 * rb + tok;
+      if (row < M) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = 32 * wave + 8 * g + 4 * kg;
+          const f32x4 gm = *(const f32x4*)(PV + 2 * PW_C1 + n), bt = *(const f32x4*)(PV + 3 * PW_C1 + n);
+          *(f32x4*)(feat + (long long)row * PW_C1 + n) =
+              f32x4{(acc[rb][4 * g] - mean[rb]) * rstd * gm[0] + bt[0], (acc[rb][4 * g + 1] - mean[rb]) * rstd * gm[1] + bt[1],
+                    (acc[rb][4 * g + 2] - mean[rb]) * rstd * gm[2] + bt[2], (acc[rb][4 * g + 3] - mean[rb]) * rstd * gm[3] + bt[3]};
+        }
+      }
+    }
+  }
+}
+
+// features of the folded Slot Attention at width 192 from the packed fc1 [192][64] / fc2 [192][192] copies
+int sf_pixel_mlp_feat192_ex(const float* x, const float* ln0_g, const float* ln0_b, const void* w1p, const float* b1, const void* w2p,
+                            const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st) {
+  static_assert(PW_LDS <= 160 * 1024, "LDS budget");
+  SF_TRY(sf_ensure_dyn_lds((const void*)pixel_mlp_feat192_kernel, PW_LDS));
+  sf_prof_begin(SF_K_LINEAR, st, 2.0 * M * (double)(PW_C0 * PW_C1 + PW_C1 * PW_C1));
+  hipLaunchKernelGGL(pixel_mlp_feat192_kernel, dim3((M + PW_ROWS - 1) / PW_ROWS), dim3(PW_NT), PW_LDS, st, x, ln0_g, ln0_b, (const uint4*)w1p, b1,
+                     (const uint4*)w2p, b2, ln1_g, ln1_b, feat, M, eps);
+  sf_prof_end(SF_K_LINEAR, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}

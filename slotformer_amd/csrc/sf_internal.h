@@ -32,6 +32,8 @@ int sf_copy_rows_ex(const float* src, SfRowMap smap, float* dst, SfRowMap dmap, 
                     hipStream_t st);
 int sf_sa_pick_partials(int HW);
 bool sf_pixel_mlp_feat_ok(int C0, int C1);
+int sf_pixel_mlp_feat192_ex(const float* x, const float* ln0_g, const float* ln0_b, const void* w1p, const float* b1, const void* w2p,
+                            const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st);
 int sf_pixel_mlp_feat_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
                          const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st);
 bool sf_slot_update_mfma_ok(int D, int H, int P);

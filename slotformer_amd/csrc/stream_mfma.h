@@ -86,4 +86,31 @@ __device__ __forceinline__ void ps_block(f32x16& acc, PsBuf& s, const uint4* p, 
 }
 
 
+
+// the same for NRB token blocks (rows 32 rb .. 32 rb + 31 -> acc[rb]) on one set of fragment reads
+template <int KS, int CHN, int NRB>
+__device__ __forceinline__ void ps_blockN(f32x16 (&acc)[NRB], PsBuf& s, const uint4* p, int nblocks, int nb, int ks0, const uint4* pn,
+                                          int nblocksn, int nbn, int ksn, const __bf16* Xh, const __bf16* Xl, int stride, int lane) {
+  constexpr int CH = PsChunk<KS>::CH, NC = KS / CH;
+  const int ao = (lane & 31) * stride + 8 * (lane >> 5);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    if (c + 3 < NC)
+      ps_load<CH>(s, (c + 3) & 3, p, nblocks, nb, ks0 + (c + 3) * CH, lane);
+    else if (pn)
+      ps_load<CHN>(s, (c + 3) & 3, pn, nblocksn, nbn, ksn + (c + 3 - NC) * CHN, lane);
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int ks = c * CH + k;
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        const bf16x8 xh = *(const bf16x8*)(Xh + ao + rb * 32 * stride + ks * 16), xl = *(const bf16x8*)(Xl + ao + rb * 32 * stride + ks * 16);
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s.w[c & 3][k][0], xl, acc[rb], 0, 0, 0);
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s.w[c & 3][k][1], xh, acc[rb], 0, 0, 0);
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s.w[c & 3][k][0], xh, acc[rb], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 }  // namespace

@@ -273,13 +273,22 @@ def encoder_plan(m):
             check(lib().sf_pack_linear_weights(plan.dp(w), buf.data_ptr(), n, k, st))
             plan.keep.append(buf)
             setattr(s, name, buf.data_ptr())
-    if m.slot_size == 128 and m.enc_out_channels == 128 and sa.project_k.bias is None and sa.project_v.bias is None:
+    if m.slot_size == m.enc_out_channels and m.slot_size in (128, 192) and sa.project_k.bias is None and sa.project_v.bias is None:
         # key / value projections folded into project_q and the GRU input matrix (include/slotformer_hip.h, sa_fold_*)
         wk, wv = sa.project_k.weight.detach().double(), sa.project_v.weight.detach().double()
         mq = (wk.t() @ sa.project_q[1].weight.detach().double()).float().contiguous()        # [C, D]
         gih = (sa.gru.weight_ih.detach().double() @ wv).float().contiguous()                 # [3D, C]
         s.sa_fold_q_w, s.sa_fold_q_w_t, s.sa_fold_gru_ih_t = plan.dp(mq), plan.dp(mq.t().contiguous()), plan.dp(gih.t().contiguous())
-        if mq.is_cuda:
+        if mq.is_cuda and m.slot_size == 192 and ch[-1] == 64:
+            # the 192-wide per-pixel chain as one launch needs fragment-ordered copies of its two matrices (pixel_mlp.hip)
+            st = torch.cuda.current_stream().cuda_stream
+            for name, w in (('enc_fc1_p', eo[1].weight), ('enc_fc2_p', eo[3].weight)):
+                n, k = w.shape
+                buf = torch.empty(lib().sf_packed_linear_bytes(n, k), dtype=torch.uint8, device=w.device)
+                check(lib().sf_pack_linear_weights(plan.dp(w), buf.data_ptr(), n, k, st))
+                plan.keep.append(buf)
+                setattr(s, name, buf.data_ptr())
+        if mq.is_cuda and m.slot_size == 128:
             st = torch.cuda.current_stream().cuda_stream
             for name, w in (('sa_fold_q_w_p', mq), ('sa_fold_gru_ih_p', gih)):
                 n, k = w.shape

@@ -499,3 +499,25 @@ def test_predictor_step_one_launch_matches_the_unfused_chain(dev, cfg, name, see
         plan.struct.pred_packed = saved
     assert not torch.equal(fused, chain)          # two different kernels ran
     assert rel_err(fused, chain.cpu()) < 2e-5     # split-bf16 products in another summation order
+
+
+@torch.no_grad()
+def test_folded_slot_attention_at_width_192_matches_the_kv_path(dev):
+    """STEVE on Physion (slot size = encoder width = 192): the one-launch per-pixel chain (pixel_mlp_feat192_kernel) + Slot Attention on
+    the normalised features with the key / value projections folded away (savi.py:44-45,66-89), against the k|v GEMM path."""
+    from slotformer_amd import engine
+    m, _ = build(gu.C4_STEVE, gu.load_golden('steve_c4'), 104, dev)
+    m.testing = True
+    img = gu.seeded_img(3, 3, 128).to(dev)
+    plan = engine.encoder_plan(m)
+    assert plan.struct.enc_fc1_p and plan.struct.enc_fc2_p and plan.struct.sa_fold_q_w, 'the folded / packed copies are missing'
+    a = m({'img': img})
+    saved = plan.struct.enc_fc1_p
+    plan.struct.enc_fc1_p = None
+    try:
+        b = m({'img': img})
+    finally:
+        plan.struct.enc_fc1_p = saved
+    assert not torch.equal(a['slots'], b['slots'])
+    assert rel_err(a['slots'], b['slots'].cpu()) < 5e-5
+    assert (a['masks'] - b['masks']).abs().max() < 1e-5
