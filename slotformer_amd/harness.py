@@ -71,6 +71,10 @@ def encode_then_rollout(savi, slotformer, img0, vid_len, noise=None):
 
 
 _PIPES = {}   # (id(savi), id(rollouter), batch, burn-in, pred_len, options) -> (weakrefs, pipeline): graphs are captured once
+# Pipelines kept alive between calls.  Every pipeline owns five or more hardware queues (CU-masked and plain streams), and idle queues
+# are not free on this platform: with a second pipeline object alive the same run took 120 instead of 94 ms (profiles/r03_probes.txt
+# section 10) -- so by default only the most recently used one is kept; a caller alternating between shapes may raise this.
+MAX_PIPELINES = 1
 
 
 def _pipeline_for(savi, rollouter, batch_size, T, pred_len, pipe_kw):
@@ -79,10 +83,12 @@ def _pipeline_for(savi, rollouter, batch_size, T, pred_len, pipe_kw):
     for k in [k for k, (ws, wr, _) in _PIPES.items() if ws() is None or wr() is None]:
         _PIPES.pop(k)[2].close()
     key = (id(savi), id(rollouter), batch_size, T, pred_len, tuple(sorted((k, repr(v)) for k, v in pipe_kw.items())))
-    ent = _PIPES.get(key)
+    ent = _PIPES.pop(key, None)
     if ent is None:
+        while len(_PIPES) >= max(1, MAX_PIPELINES):      # least recently used first (dicts keep insertion order)
+            _PIPES.pop(next(iter(_PIPES)))[2].close()
         ent = (weakref.ref(savi), weakref.ref(rollouter), EncodeRolloutPipeline(savi, rollouter, batch_size, T, pred_len, **pipe_kw))
-        _PIPES[key] = ent
+    _PIPES[key] = ent                                      # (re-inserted: most recently used last)
     return ent[2]
 
 
