@@ -126,6 +126,13 @@ def test_extract_and_rollout_entry(dev):
         out_h = harness.extract_and_rollout(savi, roll, videos, H, batch_size=bs, noises=noises, to_host=True)
         assert torch.equal(out_d, out) and not out_h.is_cuda and out_h.is_pinned() and torch.equal(out_h, out.cpu())
         assert len(harness._PIPES) == n_pipes == 1
+        # another shape: only the most recently used pipeline stays alive by default (MAX_PIPELINES = 1: idle hardware queues
+        # are not free on this platform), the earlier one is closed -- and rebuilt, with the same results, when its shape returns
+        first = next(iter(harness._PIPES.values()))[2]
+        out_2 = harness.extract_and_rollout(savi, roll, videos.to(dev), H, batch_size=2, noises=noises)
+        assert len(harness._PIPES) == 1 and next(iter(harness._PIPES.values()))[2] is not first
+        assert torch.equal(out_2, out)      # (per-video kernels: the slots do not depend on the batch size)
+        assert torch.equal(harness.extract_and_rollout(savi, roll, videos.to(dev), H, batch_size=bs, noises=noises), out)
         harness.release_pipelines()
         assert not harness._PIPES
 
