@@ -289,6 +289,11 @@ int sf_ffn_chunk_partials_f32(const sf_tfm_layer* w, const float* ap, long long 
  * (head pair, sequence), out [4][B*Lq][256] = the four head-pair partials with x2 = ((p0 + p1) + p2) + p3 -- the input format
  * of sf_ffn_chunk_partials_f32.  Both forms give the same bits.  Needs w->attn_in_packed / attn_out_packed. */
 int sf_attn_block_f32(const sf_tfm_layer* w, const float* x, float* out, int B, int L, int Lq, int heads_per_wg, void* stream);
+/* The same block in its row-tile form (sf_rollout_opts.attn_qkv_rows = 128; csrc/attn_rows.hip): LN1 + q|k|v on 128-row tiles of the
+ * whole batch, then one workgroup per sequence (wave = head) + out-projection.  out [B*Lq][256] = x2;  planes: scratch of
+ * sf_attn_rows_planes_bytes(B) bytes (q, k, v^T of every (sequence, head) as split-bf16 MFMA-fragment planes; cleared by the call). */
+size_t sf_attn_rows_planes_bytes(int B);
+int sf_attn_block_rows_f32(const sf_tfm_layer* w, const float* x, float* out, void* planes, int B, int L, int Lq, void* stream);
 
 /* SlotRollouter / SingleStepSlotRollouter (slotformer.py:48-134, single_step_slotformer.py:6-90). */
 typedef struct {
@@ -327,6 +332,10 @@ typedef struct {
   int attn_heads_per_wg; /* 0: default (2: one workgroup per head pair and video, four partial outputs summed by the FFN launch);
                           * 8: one workgroup per video runs all heads and writes finished rows -- fewer, longer workgroups with
                           * a third of the bytes through a CU: the throughput form (the same bits as the default) */
+  int attn_qkv_rows; /* 0: default (off); 128: the attention block as TWO launches -- LN1 + q|k|v on 128-row tiles of the whole
+                      * batch (no padding of a video to 64 rows, one weight load per 128 rows), then one workgroup per video
+                      * whose eight waves run the eight heads side by side + the out-projection: finished rows like
+                      * attn_heads_per_wg = 8, the same bits, less CU time per row (csrc/attn_rows.hip) */
 } sf_rollout_opts;
 int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws, size_t ws_bytes,
                         void* stream, const sf_rollout_opts* opts); /* opts == NULL: sf_rollout_f32 */

@@ -144,7 +144,8 @@ size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B) {
   // two-launch layer and the ring of cached in-projections [B][window_len + 1][N][d]
   return pad256(M * m->d_model) + tfm_ws_bytes((int)M, m->d_model, m->ffn_dim) + pad256(8 * M * m->d_model) +
          pad256(4 * M * m->d_model) + 2 * pad256(M * m->d_model) +
-         pad256((size_t)B * (m->window_len + 1) * m->num_slots * m->d_model) + 4096 + 4096 + 4096;
+         pad256((size_t)B * (m->window_len + 1) * m->num_slots * m->d_model) + 4096 + 4096 + 4096 +
+         pad256(sf_attn_rows_plane_bytes(B) / 4);   // q / k / v^T fragment planes of the row-tile attention form
 }
 
 extern "C" int sf_get_seam_fused(void);
@@ -192,7 +193,9 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   unsigned* seam_flags = (unsigned*)bp.take(1024);   // per-tile epochs of the seam launches + an error word
   const int RF = W + 1;   // frames in the projection ring: the window being read + the frame being written
   float* ring = bp.take((size_t)B * RF * N * d);
-  if (!apb || !xpb || !xa || !xb2 || !counters || !seam_flags || !ring) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
+  float* planes = bp.take(sf_attn_rows_plane_bytes(B) / 4);   // attn_rows.hip: q, k, v^T of every (video, head) as fragment planes
+  if (!apb || !xpb || !xa || !xb2 || !counters || !seam_flags || !ring || !planes)
+    return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
   // two-launch layers (layer_fused.hip): split-bf16 mode, pre-LN, d=256 / 8 heads / ffn 1024, window <= 64 tokens
   bool packed = true;
   for (int l = 0; l < m->num_layers; ++l)
@@ -205,14 +208,17 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   // seam launches (layer_fused.hip): the last-layer FFN + boundary of step s and the layer-0 attention of step s+1 in one
   // grid; needs every workgroup of it co-resident at one per CU -- 160 fit the 168-CU rollout partition
   const int seam_opt = sf_thread_opts().seam;
+  // row-tile form of the attention block (per-call option attn_qkv_rows = 128, attn_rows.hip): q|k|v projection on 128-row tiles
+  // of the batch + one core / out-projection workgroup per video; finished rows like the all-heads form
+  const bool attn_rows = fused_layers && sf_thread_opts().attn_rows == 128;
   const bool seam = boundary_fused && (seam_opt >= 0 ? seam_opt != 0 : sf_get_seam_fused() != 0) && sf_seam_blocks(B, N) <= 160 &&
-                    sf_thread_opts().attn_heads != 8;
+                    sf_thread_opts().attn_heads != 8 && !attn_rows;
   // layers 0 .. n-2 leave their output as four FFN chunk partials that the next attention sums while loading (the last layer's
   // FFN sums them itself: its last-arriving workgroup)
   const bool parts_mode = ring_mode;
   // throughput form of the attention block (per-call option attn_heads_per_wg = 8): one workgroup per video runs all 8 heads
   // and writes finished rows; the FFN behind it reads one row instead of four head-pair partials (layer_fused.hip)
-  const bool all_heads = fused_layers && sf_thread_opts().attn_heads == 8;
+  const bool all_heads = fused_layers && (sf_thread_opts().attn_heads == 8 || attn_rows);
   const int np = all_heads ? 1 : 4;
   if (ring_mode) {
     // in-projection (without PE) of the burn-in frames -> ring slots 0 .. n_in-1
@@ -231,6 +237,12 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
     // before they were written; found by tests/test_pipeline_gpu.py when a second pipeline followed a first in one process)
     hipLaunchKernelGGL(zero_words_kernel, dim3(2), dim3(1024), 0, st, (unsigned*)counters, seam ? seam_flags : nullptr);
     SF_CHECK_LAUNCH();
+    if (attn_rows) {
+      // key positions >= L of the v^T planes meet probability 0 in the PV product: they must hold finite values
+      const long long nfl = (long long)(sf_attn_rows_plane_bytes(B) / 4), half = nfl / 2;
+      hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((half / 4 + 255) / 256)), dim3(256), 0, st, planes, planes + half, half);
+      SF_CHECK_LAUNCH();
+    }
   }
   const long long bs = (long long)T_total * N * C;
   auto window = [&](int s, int& nf, int& f0) {   // frames of the Transformer window of step s
@@ -259,7 +271,16 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
         const long long pst = (long long)B * Lq * d;
         float* xo = (cin == xa) ? xb2 : xa;
         float* apl = (l == 0) ? ap_l0 : apb;
-        if (all_heads) {
+        if (attn_rows) {
+          if (l == 0)
+            SF_TRY(sf_attn_rows_ex(2, ring, (long long)RF * N * d, 0, m->pe_tok + (long long)pe_off * d, f0, RF, N, m->layers[l], 1e-5f, apl,
+                                   planes, B, L, Lq, st));
+          else if (parts_in)
+            SF_TRY(sf_attn_rows_ex(1, xpb, (long long)L * d, (long long)B * L * d, nullptr, 0, 1, 1, m->layers[l], 1e-5f, apl, planes, B, L,
+                                   Lq, st));
+          else
+            SF_TRY(sf_attn_rows_ex(0, cin, (long long)L * d, 0, nullptr, 0, 1, 1, m->layers[l], 1e-5f, apl, planes, B, L, Lq, st));
+        } else if (all_heads) {
           if (l == 0)
             SF_TRY(sf_attn_all_ring_ex(ring, RF, N, f0, m->pe_tok + (long long)pe_off * d, m->layers[l], 1e-5f, apl, B, L, Lq, st));
           else if (parts_in)
@@ -328,7 +349,13 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
         const int Lq = lastl ? N : L;
         const long long pst = (long long)B * Lq * d;
         float* xo = (cin == xa) ? xb2 : xa;
-        if (all_heads) {
+        if (attn_rows) {
+          if (parts_in)
+            SF_TRY(sf_attn_rows_ex(1, xpb, (long long)L * d, (long long)B * L * d, nullptr, 0, 1, 1, m->layers[l], 1e-5f, apb, planes, B, L,
+                                   Lq, st));
+          else
+            SF_TRY(sf_attn_rows_ex(0, cin, (long long)L * d, 0, nullptr, 0, 1, 1, m->layers[l], 1e-5f, apb, planes, B, L, Lq, st));
+        } else if (all_heads) {
           if (parts_in)
             SF_TRY(sf_attn_all_parts_ex(xpb, (long long)B * L * d, m->layers[l], 1e-5f, apb, B, L, Lq, st));
           else
@@ -412,11 +439,13 @@ int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total,
              "sf_rollout_opts: ffn_rows must be 0 (default), 32, 64 or 128");
   SF_REQUIRE(opts->attn_heads_per_wg == 0 || opts->attn_heads_per_wg == 2 || opts->attn_heads_per_wg == 8,
              "sf_rollout_opts: attn_heads_per_wg must be 0 (default), 2 or 8");
+  SF_REQUIRE(opts->attn_qkv_rows == 0 || opts->attn_qkv_rows == 128, "sf_rollout_opts: attn_qkv_rows must be 0 (off) or 128");
   SfThreadOpts o = sf_thread_opts();
   if (opts->precision >= 0) o.precision = opts->precision;
   if (opts->seam_fused >= 0) o.seam = opts->seam_fused ? 1 : 0;
   if (opts->ffn_rows > 0) o.ffn_rows = opts->ffn_rows;
   if (opts->attn_heads_per_wg > 0) o.attn_heads = opts->attn_heads_per_wg;
+  if (opts->attn_qkv_rows > 0) o.attn_rows = opts->attn_qkv_rows;
   OptsScope scope(o);
   const bool plain = (o.precision == 2 || o.precision == 3);
   const bool old_plain = t_plain_gemms;

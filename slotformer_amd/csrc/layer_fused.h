@@ -23,6 +23,12 @@ int sf_attn_all_parts_ex(const float* xparts, long long xparts_stride, const sf_
                          int Lq, hipStream_t st);
 int sf_attn_all_ring_ex(const float* ring, int ring_frames, int nslots, int f0, const float* pe, const sf_tfm_layer& w, float eps,
                         float* x2, int B, int L, int Lq, hipStream_t st);
+// row-tile form (attn_rows.hip): q|k|v projection on 128-row tiles of the batch + one core / out-projection workgroup per video;
+// mode 0: x [B][L][256], 1: four chunk partials, 2: ring rows + position table.  planes: sf_attn_rows_plane_bytes(B) bytes
+size_t sf_attn_rows_plane_bytes(int B);
+int sf_attn_rows_ex(int mode, const float* xin, long long x_batch_stride, long long xparts_stride, const float* pe, int f0,
+                    int ring_frames, int nslots, const sf_tfm_layer& w, float eps, float* x2, void* planes, int B, int L, int Lq,
+                    hipStream_t st);
 int sf_attn_oproj_ring_ex(const float* ring, int ring_frames, int nslots, int f0, const float* pe, const sf_tfm_layer& w,
                           float eps, float* ap, long long ap_stride, int B, int L, int Lq, hipStream_t st);
 // out-proj of the finished rows y [B*nslots, 256] -> slots frame `frame`; in-proj of those rows -> projection ring

@@ -11,6 +11,7 @@ struct SfThreadOpts {
   int seam = -1;         // seam launches of the rollout off / on
   int ffn_rows = 0;      // rows per workgroup of the chunk-partial FFN launches: 32 / 64 / 128
   int attn_heads = 0;    // heads per workgroup of the layer attention launches: 2 (head pairs, four partials) / 8 (finished rows)
+  int attn_rows = 0;     // 128: the attention block as q|k|v row tiles + one core workgroup per video (attn_rows.hip; finished rows)
 };
 SfThreadOpts& sf_thread_opts();
 // hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device) -- a process may drive several GPUs

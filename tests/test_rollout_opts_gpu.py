@@ -64,6 +64,23 @@ def test_all_heads_attention_form(dev, B):
     assert torch.equal(sub, a[1:3])
 
 
+@pytest.mark.parametrize('B', [64, 33, 3])
+@torch.no_grad()
+def test_row_tile_attention_form(dev, B):
+    """attn_rows = 128 (LN1 + q|k|v on 128-row tiles of the whole batch, then one core / out-projection workgroup per video with
+    the eight heads side by side) gives the bits of the default form, whatever the FFN row variant and whatever batch a video
+    sits in (tiles cut across videos: B = 33 is 1386 rows = 10 tiles + 106 rows, B = 3 one ragged tile)."""
+    r = _c2_rollouter(dev)
+    x = gu.seeded_normal((B, 6, 7, 128), 13).to(dev)
+    ref = _roll(r, x, 9)
+    a = _roll(r, x, 9, {'attn_rows': 128, 'ffn_rows': 128, 'seam': False})
+    assert torch.equal(a, ref), rel_err(a, ref)
+    for opts in ({'attn_rows': 128, 'ffn_rows': 64}, {'attn_rows': 128, 'ffn_rows': 32}, {'attn_rows': 128, 'attn_heads': 8}):
+        assert torch.equal(_roll(r, x, 9, opts), a), opts
+    sub = _roll(r, x[1:3].contiguous(), 9, {'attn_rows': 128})
+    assert torch.equal(sub, a[1:3])
+
+
 @pytest.mark.parametrize('L,Lq,B', [(42, 42, 5), (42, 7, 3), (48, 8, 2), (7, 7, 4), (64, 64, 2)])
 @torch.no_grad()
 def test_attention_block_kernels(dev, L, Lq, B):
@@ -93,10 +110,20 @@ def test_attention_block_kernels(dev, L, Lq, B):
     print('attention block L', L, 'Lq', Lq, 'rel err all-heads', e8, 'head pairs', e2)
     assert e8 < 3e-5 and e2 < 3e-5
     assert torch.equal(out8[0], y2)   # both forms: the same bits
+    # row-tile form (attn_rows.hip): q|k|v on 128-row tiles of the batch + one core workgroup per video
+    planes = torch.empty(lib.sf_attn_rows_planes_bytes(B), dtype=torch.uint8, device=dev)
+    outr = torch.full((B * Lq, 256), float('nan'), device=dev)
+    _lib.check(lib.sf_attn_block_rows_f32(C.byref(w), x.data_ptr(), outr.data_ptr(), planes.data_ptr(), B, L, Lq, st))
+    torch.cuda.synchronize()
+    er = rel_err(outr, ref)
+    print('row-tile form rel err', er, 'max diff vs all-heads', (outr - out8[0]).abs().max().item())
+    assert er < 3e-5
+    assert torch.equal(outr, out8[0])   # the same bits again
 
 
 @pytest.mark.parametrize('opts', [{'ffn_rows': 128, 'seam': False}, {'ffn_rows': 64, 'seam': False}, {'ffn_rows': 32, 'seam': True},
-                                  {'attn_heads': 8, 'ffn_rows': 128, 'seam': False}, {'attn_heads': 8, 'ffn_rows': 64}])
+                                  {'attn_heads': 8, 'ffn_rows': 128, 'seam': False}, {'attn_heads': 8, 'ffn_rows': 64},
+                                  {'attn_rows': 128, 'ffn_rows': 128, 'seam': False}])
 @torch.no_grad()
 def test_throughput_settings_vs_reference_fixture(dev, opts):
     """roll_c2 (6 + 50 steps, outputs of the reference's own SlotFormer) with the kernel settings of the pipelined bench:
