@@ -81,15 +81,18 @@ __device__ long long ar_ts[32];   // phase timestamps of workgroup 0 (SF_LF_DBG 
 #define RTS(i) do { if ((A.dbg & 16) && blockIdx.x == 0 && threadIdx.x == 0) ar_ts[i] = wall_clock64(); } while (0)
 
 // RING: the rows are the cached in-projections of the window's frames (ring of `ring_frames` frames per video) + the position table;
-// PART: the rows are the sum of the previous layer's four FFN chunk partials, ((p0 + p1) + p2) + p3.  G: 0 q, 1 k, 2 v.
-template <bool RING, bool PART, int G>
+// PART: the rows are the sum of the previous layer's four FFN chunk partials, ((p0 + p1) + p2) + p3.
+// One workgroup per 128-row tile runs the groups G0 .. G0 + NG - 1 (0 q, 1 k, 2 v) one after the other on ONE ingest and ONE
+// LayerNorm of its rows: wave w owns head w's 32 columns of every group and streams their weight fragments (2 KB per k-step)
+// through a ring of four two-k-step slots, three chunks in flight across group boundaries; each fragment feeds the four row
+// blocks of the tile (12 MFMAs).  QROWS: the tile's rows are the last Lq rows of every video (the q tiles of the last layer).
+template <bool RING, bool PART, int G0, int NG, bool QROWS>
 __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile) {
 #pragma clang fp contract(off)
   constexpr int NP = PART ? 4 : 1;
-  constexpr bool vblock = G == 2;
   RTS(0);
   const int L = A.L, Lq = A.Lq;
-  const int Lg = G == 0 ? Lq : L, tg = G == 0 ? L - Lq : 0, Mg = A.B * Lg, row0 = tile * TR;
+  const int Lg = QROWS ? Lq : L, tg = QROWS ? L - Lq : 0, Mg = A.B * Lg, row0 = tile * TR;
   const float invL = 1.0f / (float)Lg;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __bf16* Ah = (__bf16*)smem;             // [128][AP]
@@ -100,10 +103,10 @@ __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile)
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 gbv = zero4;
   if (t < 128) gbv = *(const f32x4*)((t < 64 ? A.ln_g : A.ln_b) + 4 * (t & 63));
-  // ---- rows: thread (r0, c4) owns float4 column c4 of every 64-wide chunk of rows r0 + 32 p; ONE register buffer: the next
-  //      pass is requested as soon as the current one has been summed, and lands behind its LayerNorm arithmetic ----
-  f32x4 pr[NP][NK], pev[NK];
-  auto request = [&](int p) {
+  // ---- rows: thread (r0, c4) owns float4 column c4 of every 64-wide chunk of rows r0 + 32 p; two register buffers, two passes
+  //      in flight ----
+  f32x4 pr[2][NP][NK], pev[2][NK];
+  auto request = [&](int p, int s) {
     const int mc = min(row0 + 32 * p + r0, Mg - 1);
     const int b = div_rows(mc, Lg, invL), tk = tg + mc - b * Lg;
     const float* row;
@@ -112,24 +115,24 @@ __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile)
       row = A.xin + (long long)b * A.x_batch_stride + ((long long)((A.f0 + fr) % A.ring_frames) * A.nslots + sl) * D + 4 * c4;
       const float* pp = A.pe + (long long)tk * D + 4 * c4;
 #pragma unroll
-      for (int kc = 0; kc < NK; ++kc) pev[kc] = *(const f32x4*)(pp + kc * KC);
+      for (int kc = 0; kc < NK; ++kc) pev[s][kc] = *(const f32x4*)(pp + kc * KC);
     } else {
       row = A.xin + (long long)b * A.x_batch_stride + (long long)tk * D + 4 * c4;
     }
 #pragma unroll
     for (int kc = 0; kc < NK; ++kc)
 #pragma unroll
-      for (int q = 0; q < NP; ++q) pr[q][kc] = *(const f32x4*)(row + (long long)q * A.xparts_stride + kc * KC);
+      for (int q = 0; q < NP; ++q) pr[s][q][kc] = *(const f32x4*)(row + (long long)q * A.xparts_stride + kc * KC);
   };
-  auto sum = [&](f32x4 (&vv)[NK]) {
+  auto sum = [&](int s, f32x4 (&vv)[NK]) {
 #pragma clang fp contract(off)
 #pragma unroll
     for (int kc = 0; kc < NK; ++kc) {
       if constexpr (PART)
-        vv[kc] = ((pr[0][kc] + pr[1][kc]) + pr[2][kc]) + pr[3][kc];
+        vv[kc] = ((pr[s][0][kc] + pr[s][1][kc]) + pr[s][2][kc]) + pr[s][3][kc];
       else
-        vv[kc] = pr[0][kc];
-      if constexpr (RING) vv[kc] += pev[kc];
+        vv[kc] = pr[s][0][kc];
+      if constexpr (RING) vv[kc] += pev[s][kc];
     }
   };
   auto ln = [&](int p, const f32x4 (&vv)[NK]) {
@@ -137,7 +140,7 @@ __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile)
     const int m = row0 + 32 * p + r0;
     const bool ok = m < Mg;
     // the residual of the query rows is parked in the output rows (picked up by attn_core_kernel)
-    if (G == 0 && ok) {
+    if (G0 == 0 && ok) {   // (tiles that run q hold query rows only: row m of the tile's row space is row m of x2)
 #pragma unroll
       for (int kc = 0; kc < NK; ++kc) *(f32x4*)(A.x2 + (long long)m * D + kc * KC + 4 * c4) = vv[kc];
     }
@@ -160,174 +163,168 @@ __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile)
       split4(Ah, Al, r * AP + k, ok ? (vv[kc] - mu) * rs * gm + be : zero4);
     }
   };
-  // ---- weight fragments of head `wave`: column block cb = G + 3 (wave & 1) of head pair wave >> 1, all 16 k-steps (buffer
-  //      loads: one 32-bit lane offset, scalar fragment offsets) ----
-  bf16x8 wq[16][2];
+  // ---- weight ring: slot = chunk & 3, chunk gc = group index * 8 + (k-step / 2); buffer loads with scalar fragment offsets ----
+  bf16x8 ring[4][2][2];
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(A.wqkv_p), 0, 0x7fffffff, 0x00020000);
-  const unsigned wbase = (unsigned)((((wave >> 1) * 6 + G + 3 * (wave & 1)) * 16) * 2 * 64 * 16);
-  auto load_w = [&](int k0, int k1) {
+  const unsigned hpb = (unsigned)(((wave >> 1) * 6 + 3 * (wave & 1)) * 16 * 2048);   // + g * 16 * 2048
+  auto load_chunk = [&](int gc) {
+    const int g = G0 + gc / 8, ks0 = (gc % 8) * 2;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-      if (ks >= k0 && ks < k1) {
-        wq[ks][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, (unsigned)(lane * 16), wbase + (ks * 2) * 1024, 0));
-        wq[ks][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, (unsigned)(lane * 16), wbase + (ks * 2 + 1) * 1024, 0));
-      }
-  };
-  // the k / v blocks of odd heads are split over K in attn_body (two waves, lower + upper half): same sum here
-  const bool splitk = (wave & 1) && G >= 1;
-  const int ao = (lane & 31) * AP + 8 * (lane >> 5);
-  auto mfma_half = [&](int h, int k0, int k1, f32x16& a0, f32x16& a1) {
-    const __bf16* Ph = Ah + h * 64 * AP;
-    const __bf16* Pl = Al + h * 64 * AP;
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      if (ks < k0 || ks >= k1) continue;
-      const bf16x8 xh0 = *(const bf16x8*)(Ph + ao + ks * 16), xl0 = *(const bf16x8*)(Pl + ao + ks * 16);
-      const bf16x8 xh1 = *(const bf16x8*)(Ph + ao + 32 * AP + ks * 16), xl1 = *(const bf16x8*)(Pl + ao + 32 * AP + ks * 16);
-      if constexpr (!vblock) {
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xl0, a0, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][1], xh0, a0, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xh0, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xl1, a1, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][1], xh1, a1, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[ks][0], xh1, a1, 0, 0, 0);
-      } else {
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl0, wq[ks][0], a0, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, wq[ks][1], a0, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, wq[ks][0], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl1, wq[ks][0], a1, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh1, wq[ks][1], a1, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh1, wq[ks][0], a1, 0, 0, 0);
-      }
-    }
+      for (int pl = 0; pl < 2; ++pl)
+        ring[gc & 3][k][pl] = __builtin_bit_cast(
+            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, (unsigned)(lane * 16), hpb + (unsigned)((g * 16 + ks0 + k) * 2048 + pl * 1024), 0));
   };
-  // ---- epilogue of one 32-row block: bias (+ scale on q), split, planes ----
   const float scale = 1.0f / sqrtf((float)HD);
-  const float* bq = A.bias + G * D + wave * HD;
   const int kg = lane >> 5;
-  auto store_block = [&](int rb, const f32x16& acc) {
-#pragma clang fp contract(off)
-    if constexpr (!vblock) {
-      const int m = row0 + rb * 32 + (lane & 31);
-      if (m < Mg) {
-        const int b = div_rows(m, Lg, invL), tk = tg + m - b * Lg;
-        __bf16* ph = A.planes + ((long long)(b * NH + wave) * 6 + 2 * G) * PL + tk * HD + 4 * kg;
-        const float mul = G == 0 ? scale : 1.f;
+  const int ao = (lane & 31) * AP + 8 * (lane >> 5);
+
+  // ---- ingest + LayerNorm ----
+  request(0, 0);
+  request(1, 1);
+  load_chunk(0);
+  load_chunk(1);
+  load_chunk(2);
+  if (t < 128) *(f32x4*)(GB + 4 * t) = gbv;
+  __syncthreads();   // gamma | beta
+  RTS(1);
+  {
+    f32x4 vv[NK];
+    sum(0, vv);
+    __builtin_amdgcn_sched_barrier(0);
+    request(2, 0);
+    ln(0, vv);
+    sum(1, vv);
+    __builtin_amdgcn_sched_barrier(0);
+    request(3, 1);
+    ln(1, vv);
+    sum(0, vv);
+    ln(2, vv);
+    sum(1, vv);
+    ln(3, vv);
+  }
+  __syncthreads();   // LN planes of the tile
+  RTS(2);
+
+  // ---- the groups ----
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const f32x4 bv = *(const f32x4*)(bq + 8 * gq + 4 * kg);
-          split4(ph, ph + PL, 8 * gq,
-                 f32x4{(acc[4 * gq] + bv[0]) * mul, (acc[4 * gq + 1] + bv[1]) * mul, (acc[4 * gq + 2] + bv[2]) * mul,
-                       (acc[4 * gq + 3] + bv[3]) * mul});
+  for (int gi = 0; gi < NG; ++gi) {
+    const int g = G0 + gi;
+    const bool vblock = g == 2;
+    // the k / v blocks of odd heads are split over K in attn_body (two waves, lower + upper half): same sum here
+    const bool splitk = (wave & 1) && g >= 1;
+    const float* bq = A.bias + g * D + wave * HD;
+    f32x4 bv4[4];
+    float bch = 0.f;
+    if (!vblock) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) bv4[gq] = *(const f32x4*)(bq + 8 * gq + 4 * kg);
+    } else {
+      bch = bq[lane & 31];
+    }
+    f32x16 acc[4], sav[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int gc = gi * 8 + c;
+      if (gc + 3 < NG * 8) load_chunk(gc + 3);
+      if (c == 4 && splitk) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          sav[rb] = acc[rb];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
         }
       }
-    } else {
-      // D[token][dim]: this lane holds dim lane & 31 of sixteen tokens, in pairs of consecutive rows
-      const float bch = bq[lane & 31];
-      const int dim = lane & 31;
 #pragma unroll
-      for (int rp = 0; rp < 8; ++rp) {
-        const int r = 2 * rp;
-        const int m = row0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        const float v0 = acc[r] + bch, v1 = acc[r + 1] + bch;
-        const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
-        const __bf16 l0 = (__bf16)(v0 - (float)h0), l1 = (__bf16)(v1 - (float)h1);
-        if (m >= Mg) continue;
-        const int b = div_rows(m, L, invL), tk = m - b * L;
-        __bf16* pv = A.planes + ((long long)(b * NH + wave) * 6 + 4) * PL + dim * 64;
-        if (!(L & 1)) {   // rows m, m + 1 belong to one video and sit side by side (even position)
-          *(bf16x2*)(pv + vpos(tk)) = bf16x2{h0, h1};
-          *(bf16x2*)(pv + PL + vpos(tk)) = bf16x2{l0, l1};
-        } else {
-          pv[vpos(tk)] = h0;
-          pv[PL + vpos(tk)] = l0;
-          if (m + 1 < Mg) {
-            const int b1 = div_rows(m + 1, L, invL), t1 = m + 1 - b1 * L;
-            __bf16* pv1 = A.planes + ((long long)(b1 * NH + wave) * 6 + 4) * PL + dim * 64;
-            pv1[vpos(t1)] = h1;
-            pv1[PL + vpos(t1)] = l1;
+      for (int k = 0; k < 2; ++k) {
+        const int ks = 2 * c + k;
+        const bf16x8 w0 = ring[gc & 3][k][0], w1 = ring[gc & 3][k][1];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          const bf16x8 xh = *(const bf16x8*)(Ah + ao + rb * 32 * AP + ks * 16), xl = *(const bf16x8*)(Al + ao + rb * 32 * AP + ks * 16);
+          if (!vblock) {
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xl, acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xh, acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xh, acc[rb], 0, 0, 0);
+          } else {
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, w0, acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, w1, acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, w0, acc[rb], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the requests stay one ring slot per chunk
+    }
+    if (splitk) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb] = sav[rb] + acc[rb];
+    }
+    if (gi == 0) RTS(3);
+    // ---- epilogue of the group: bias (+ scale on q), split, fragment planes ----
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      if (!vblock) {
+        const int m = row0 + rb * 32 + (lane & 31);
+        if (m < Mg) {
+          const int b = div_rows(m, Lg, invL), tk = tg + m - b * Lg;
+          __bf16* ph = A.planes + ((long long)(b * NH + wave) * 6 + 2 * g) * PL + tk * HD + 4 * kg;
+          const float mul = g == 0 ? scale : 1.f;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 bv = bv4[gq];
+            split4(ph, ph + PL, 8 * gq,
+                   f32x4{(acc[rb][4 * gq] + bv[0]) * mul, (acc[rb][4 * gq + 1] + bv[1]) * mul, (acc[rb][4 * gq + 2] + bv[2]) * mul,
+                         (acc[rb][4 * gq + 3] + bv[3]) * mul});
+          }
+        }
+      } else {
+        // D[token][dim]: this lane holds dim lane & 31 of sixteen tokens, in pairs of consecutive rows
+        const int dim = lane & 31;
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+          const int r = 2 * rp;
+          const int m = row0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+          const float v0 = acc[rb][r] + bch, v1 = acc[rb][r + 1] + bch;
+          const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+          const __bf16 l0 = (__bf16)(v0 - (float)h0), l1 = (__bf16)(v1 - (float)h1);
+          if (m >= Mg) continue;
+          const int b = div_rows(m, L, invL), tk = m - b * L;
+          __bf16* pv = A.planes + ((long long)(b * NH + wave) * 6 + 4) * PL + dim * 64;
+          if (!(L & 1)) {   // rows m, m + 1 belong to one video and sit side by side (even position)
+            *(bf16x2*)(pv + vpos(tk)) = bf16x2{h0, h1};
+            *(bf16x2*)(pv + PL + vpos(tk)) = bf16x2{l0, l1};
+          } else {
+            pv[vpos(tk)] = h0;
+            pv[PL + vpos(tk)] = l0;
+            if (m + 1 < Mg) {
+              const int b1 = div_rows(m + 1, L, invL), t1 = m + 1 - b1 * L;
+              __bf16* pv1 = A.planes + ((long long)(b1 * NH + wave) * 6 + 4) * PL + dim * 64;
+              pv1[vpos(t1)] = h1;
+              pv1[PL + vpos(t1)] = l1;
+            }
           }
         }
       }
     }
-  };
-  auto zero2 = [&](f32x16& a0, f32x16& a1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a0[r] = a1[r] = 0.f;
-  };
-  // one 64-row half over k-steps 8..15 with the split-K rule, then its epilogue
-  auto finish_half = [&](int h, f32x16& a0, f32x16& a1) {
-#pragma clang fp contract(off)
-    if (splitk) {
-      f32x16 u0, u1;
-      zero2(u0, u1);
-      mfma_half(h, 8, 16, u0, u1);
-      a0 = a0 + u0;
-      a1 = a1 + u1;
-    } else {
-      mfma_half(h, 8, 16, a0, a1);
-    }
-    store_block(2 * h, a0);
-    store_block(2 * h + 1, a1);
-  };
-
-  // ---- schedule: half A's rows + k-steps 0..7 first; half A's first eight k-steps run while half B's rows land ----
-  f32x4 vv[NK];
-  request(0);
-  load_w(0, 8);
-  if (t < 128) *(f32x4*)(GB + 4 * t) = gbv;
-  __syncthreads();   // gamma | beta
-  RTS(1);
-  sum(vv);
-  __builtin_amdgcn_sched_barrier(0);
-  request(1);
-  ln(0, vv);
-  sum(vv);
-  __builtin_amdgcn_sched_barrier(0);
-  request(2);
-  ln(1, vv);
-  __syncthreads();   // LN planes of half A
-  RTS(2);
-  f32x16 accA0, accA1;
-  zero2(accA0, accA1);
-  mfma_half(0, 0, 8, accA0, accA1);
-  __builtin_amdgcn_sched_barrier(0);
-  sum(vv);
-  __builtin_amdgcn_sched_barrier(0);
-  request(3);
-  load_w(8, 16);
-  ln(2, vv);
-  sum(vv);
-  ln(3, vv);
-  __syncthreads();   // LN planes of half B
-  RTS(3);
-  finish_half(0, accA0, accA1);
-  RTS(4);
-  f32x16 accB0, accB1;
-  zero2(accB0, accB1);
-  mfma_half(1, 0, 8, accB0, accB1);
-  finish_half(1, accB0, accB1);
+  }
   RTS(5);
 }
 
 template <bool RING, bool PART>
 __global__ __launch_bounds__(NT) void qkv_rows_kernel(RowsArgs A) {
-  // ---- which (tile, q | k | v): the groups of one tile are 8 blocks apart -> same XCD, the tile's rows are fetched into one L2 ----
   const int blk = blockIdx.x;
-  if (blk >= A.main_blocks) {   // last layer: q tiles over the newest frame's rows only
-    qkv_rows_body<RING, PART, 0>(A, blk - A.main_blocks);
-    return;
+  if (blk >= A.nt) {   // last layer: q over the newest frame's rows only
+    qkv_rows_body<RING, PART, 0, 1, true>(A, blk - A.nt);
+  } else if (A.ng == 3) {
+    qkv_rows_body<RING, PART, 0, 3, false>(A, blk);
+  } else {
+    qkv_rows_body<RING, PART, 1, 2, false>(A, blk);
   }
-  const int chunk = blk / (8 * A.ng), within = blk - chunk * 8 * A.ng;
-  const int g = (within >> 3) + (A.ng == 2 ? 1 : 0);
-  const int tile = chunk * 8 + (within & 7);
-  if (tile >= A.nt) return;
-  if (g == 0)
-    qkv_rows_body<RING, PART, 0>(A, tile);
-  else if (g == 1)
-    qkv_rows_body<RING, PART, 1>(A, tile);
-  else
-    qkv_rows_body<RING, PART, 2>(A, tile);
 }
 
 // ================================================================================================
@@ -469,45 +466,60 @@ __global__ __launch_bounds__(NT) void attn_core_kernel(CoreArgs A) {
   __syncthreads();   // the O planes of all heads
   // ---- out-projection: the four head pairs' partials, each from a fresh accumulator, summed ((p0 + p1) + p2) + p3 with the
   //      residual and the bias on the partial of the pair that owns these columns (attn_body / attn_all_kernel) ----
+  // Head pairs 0 and 1 of both row blocks first -- their fragments are resident -- while the fragments of pairs 2 and 3,
+  // requested behind the core, are still on their way.
+  f32x4 s[2][4], xr[2][4], bv[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bv[g] = *(const f32x4*)(A.bo + wave * 32 + 8 * g + 4 * (lane >> 5));
 #pragma unroll
   for (int rbk = 0; rbk < 2; ++rbk) {
     if (rbk >= nrb || rbk * 32 + 32 <= nq0) continue;   // no query rows in this block (uniform)
     const int row = rbk * 32 + (lane & 31);
-    const bool ok = row >= nq0 && row < L;
-    float* o = A.x2 + ((long long)b * Lq + (min(max(row, nq0), L - 1) - nq0)) * D + wave * 32 + 4 * (lane >> 5);
-    f32x4 xr[4], bv[4], s[4];
+    const float* o = A.x2 + ((long long)b * Lq + (min(max(row, nq0), L - 1) - nq0)) * D + wave * 32 + 4 * (lane >> 5);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      xr[g] = *(const f32x4*)(o + 8 * g);
-      bv[g] = *(const f32x4*)(A.bo + wave * 32 + 8 * g + 4 * (lane >> 5));
-    }
-    const int ao = row * AP + 8 * (lane >> 5);
+    for (int g = 0; g < 4; ++g) xr[rbk][g] = *(const f32x4*)(o + 8 * g);
+  }
 #pragma unroll
-    for (int hp = 0; hp < 4; ++hp) {
-      f32x16 pacc;
+  for (int half = 0; half < 2; ++half) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+    for (int rbk = 0; rbk < 2; ++rbk) {
+      if (rbk >= nrb || rbk * 32 + 32 <= nq0) continue;
+      const int row = rbk * 32 + (lane & 31);
+      const int ao = row * AP + 8 * (lane >> 5);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 xh = *(const bf16x8*)(Oh + ao + hp * 64 + ks * 16), xl = *(const bf16x8*)(Ol + ao + hp * 64 + ks * 16);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wof[hp][ks][0], xl, pacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wof[hp][ks][1], xh, pacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wof[hp][ks][0], xh, pacc, 0, 0, 0);
+      for (int hh = 0; hh < 2; ++hh) {
+        const int hp = 2 * half + hh;
+        f32x16 pacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 xh = *(const bf16x8*)(Oh + ao + hp * 64 + ks * 16), xl = *(const bf16x8*)(Ol + ao + hp * 64 + ks * 16);
+          pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wof[hp][ks][0], xl, pacc, 0, 0, 0);
+          pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wof[hp][ks][1], xh, pacc, 0, 0, 0);
+          pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wof[hp][ks][0], xh, pacc, 0, 0, 0);
+        }
+        const bool mine = (wave >> 1) == hp;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 p = {pacc[4 * g], pacc[4 * g + 1], pacc[4 * g + 2], pacc[4 * g + 3]};
+          const f32x4 pm = p + (xr[rbk][g] + bv[g]);
+          f32x4 v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = mine ? pm[q] : p[q];
+          s[rbk][g] = hp == 0 ? v : s[rbk][g] + v;
+        }
       }
-      const bool mine = (wave >> 1) == hp;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 p = {pacc[4 * g], pacc[4 * g + 1], pacc[4 * g + 2], pacc[4 * g + 3]};
-        const f32x4 pm = p + (xr[g] + bv[g]);
-        f32x4 v;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = mine ? pm[q] : p[q];
-        s[g] = hp == 0 ? v : s[g] + v;
-      }
     }
-    if (ok) {
+  }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) *(f32x4*)(o + 8 * g) = s[g];
+  for (int rbk = 0; rbk < 2; ++rbk) {
+    if (rbk >= nrb || rbk * 32 + 32 <= nq0) continue;
+    const int row = rbk * 32 + (lane & 31);
+    if (row >= nq0 && row < L) {
+      float* o = A.x2 + ((long long)b * Lq + (row - nq0)) * D + wave * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *(f32x4*)(o + 8 * g) = s[rbk][g];
     }
   }
   if ((A.dbg & 16) && b == 0 && t == 0) ar_ts[10] = wall_clock64();
@@ -549,8 +561,8 @@ int sf_attn_rows_ex(int mode, const float* xin, long long x_batch_stride, long l
     A.ng = 2;
     extra = ntq;
   }
-  A.main_blocks = ((A.nt + 7) / 8) * 8 * A.ng;
-  const int blocks = A.main_blocks + extra;
+  A.main_blocks = A.nt;
+  const int blocks = A.nt + extra;
   sf_prof_begin(SF_K_MHA, st, 6.0 * B * L * (double)D * D + 4.0 * (double)B * NH * Lq * L * HD + 2.0 * B * Lq * (double)D * D);
   if (mode == 2) {
     SF_TRY(sf_ensure_dyn_lds((const void*)qkv_rows_kernel<true, false>, K1_LDS));
