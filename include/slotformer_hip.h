@@ -78,6 +78,13 @@ int sf_conv2d_nchw_in_f32(const float* img, long long frame_stride, const float*
 int sf_conv2d_nhwc_f32(const float* in, const float* w_packed, const float* bias, const float* add, float* out,
                        int F, int H, int W, int Cin, int Cout, int ks, int relu, void* stream);
 int sf_pack_conv_weight_f32(const float* w_oihw, float* w_ohwi, int Cout, int Cin, int ks, void* stream);
+/* 64 -> 64 channel 5 x 5 convolutions on a 64-pixel-wide grid: w_ohwi (above) -> split-bf16 copy in MFMA-fragment order,
+ * sf_conv_frag_bytes(64, 64, 5) bytes; sf_conv5x5_frag_f32 is sf_conv2d_nhwc_f32 for that shape on the fragment copy (H % 4 == 0,
+ * split-bf16 mode; csrc/conv_rows4.hip).  relu / add as sf_conv2d_nhwc_f32. */
+size_t sf_conv_frag_bytes(int Cout, int Cin, int ks);
+int sf_pack_conv_frag_weights(const float* w_ohwi, void* frag, int Cout, int Cin, int ks, void* stream);
+int sf_conv5x5_frag_f32(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W,
+                        int relu, void* stream);
 
 /* Decoder building blocks (savi.py:252-293,504-525).  ConvTranspose2d(k, stride, padding=k/2,
  * output_padding=stride-1) as a gather implicit GEMM: NHWC in [F,Hin,Win,Cin] -> [F,Hin*s,Win*s,Cout];
@@ -502,6 +509,10 @@ typedef struct {
    * enc_fc2_w [192, 192]; with them and the sa_fold_* copies the per-pixel chain up to the normalised Slot-Attention inputs is one
    * launch (pixel_mlp.hip) and Slot Attention runs folded at width 192 as well */
   const void *enc_fc1_p, *enc_fc2_p;
+  /* optional (NULL = absent), per conv i > 0 with 64 -> 64 channels, 5 x 5, on the 64 x 64 grid: sf_pack_conv_frag_weights copies of
+   * conv_w[i].  With one, the conv runs on 4-row tiles with its weights streamed as MFMA fragments (csrc/conv_rows4.hip; split-bf16
+   * mode) instead of the 2-row tile kernel that passes every tap's weights through LDS -- the same products in the same order. */
+  const void* conv_w_frag[8];
 } sf_savi_encoder;
 
 size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B);

@@ -91,7 +91,8 @@ class sf_savi_encoder(C.Structure):
         [('sa_eps', C.c_float), ('sa_q_w_t', FP), ('pm_w0_t', FP), ('pm_w2_t', FP), ('kd_w0_t', FP),
          ('sa_gru_ih_p', C.c_void_p), ('sa_gru_hh_p', C.c_void_p), ('sa_mlp_w1_p', C.c_void_p), ('sa_mlp_w2_p', C.c_void_p),
          ('sa_q_w_p', C.c_void_p), ('sa_fold_q_w', FP), ('sa_fold_q_w_t', FP), ('sa_fold_gru_ih_t', FP), ('sa_fold_q_w_p', C.c_void_p),
-         ('sa_fold_gru_ih_p', C.c_void_p), ('pred_packed', C.POINTER(C.c_void_p)), ('enc_fc1_p', C.c_void_p), ('enc_fc2_p', C.c_void_p)])
+         ('sa_fold_gru_ih_p', C.c_void_p), ('pred_packed', C.POINTER(C.c_void_p)), ('enc_fc1_p', C.c_void_p), ('enc_fc2_p', C.c_void_p),
+         ('conv_w_frag', C.c_void_p * 8)])
 
 
 class sf_slate_block(C.Structure):
@@ -132,6 +133,9 @@ SIGNATURES = {
     'sf_conv2d_nchw_in_f32': (I, [FP, LL, FP, FP, FP, FP, I, I, I, I, I, I, I, I, VP]),
     'sf_conv2d_nhwc_f32': (I, [FP, FP, FP, FP, FP, I, I, I, I, I, I, I, VP]),
     'sf_pack_conv_weight_f32': (I, [FP, FP, I, I, I, VP]),
+    'sf_conv_frag_bytes': (SZ, [I, I, I]),
+    'sf_pack_conv_frag_weights': (I, [FP, VP, I, I, I, VP]),
+    'sf_conv5x5_frag_f32': (I, [FP, VP, FP, FP, FP, I, I, I, I, VP]),
     'sf_conv_transpose2d_nhwc_f32': (I, [FP, FP, FP, FP, I, I, I, I, I, I, I, I, VP]),
     'sf_pack_deconv_weight_f32': (I, [FP, FP, I, I, I, VP]),
     'sf_slot_broadcast_f32': (I, [FP, FP, FP, I, I, I, VP]),

@@ -215,14 +215,9 @@ __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile)
     // the k / v blocks of odd heads are split over K in attn_body (two waves, lower + upper half): same sum here
     const bool splitk = (wave & 1) && g >= 1;
     const float* bq = A.bias + g * D + wave * HD;
-    f32x4 bv4[4];
-    float bch = 0.f;
-    if (!vblock) {
+    f32x4 bv4[4];   // bias of this lane's output columns 8 gq + 4 kg .. + 3 of the head
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) bv4[gq] = *(const f32x4*)(bq + 8 * gq + 4 * kg);
-    } else {
-      bch = bq[lane & 31];
-    }
+    for (int gq = 0; gq < 4; ++gq) bv4[gq] = *(const f32x4*)(bq + 8 * gq + 4 * kg);
     f32x16 acc[4], sav[4];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
@@ -247,15 +242,9 @@ __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile)
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
           const bf16x8 xh = *(const bf16x8*)(Ah + ao + rb * 32 * AP + ks * 16), xl = *(const bf16x8*)(Al + ao + rb * 32 * AP + ks * 16);
-          if (!vblock) {
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xl, acc[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xh, acc[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xh, acc[rb], 0, 0, 0);
-          } else {
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, w0, acc[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, w1, acc[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, w0, acc[rb], 0, 0, 0);
-          }
+          acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xl, acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xh, acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xh, acc[rb], 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);   // the requests stay one ring slot per chunk
@@ -283,29 +272,23 @@ __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile)
           }
         }
       } else {
-        // D[token][dim]: this lane holds dim lane & 31 of sixteen tokens, in pairs of consecutive rows
-        const int dim = lane & 31;
-#pragma unroll
-        for (int rp = 0; rp < 8; ++rp) {
-          const int r = 2 * rp;
-          const int m = row0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-          const float v0 = acc[rb][r] + bch, v1 = acc[rb][r + 1] + bch;
-          const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
-          const __bf16 l0 = (__bf16)(v0 - (float)h0), l1 = (__bf16)(v1 - (float)h1);
-          if (m >= Mg) continue;
+        // v^T planes [dim][key position]: this lane holds sixteen dims of ONE token; the 32 lanes of a half wave write 32
+        // consecutive tokens -- neighbouring 2-byte words of the same dim row (a wave-wide store touches a few cache lines;
+        // with the accumulators transposed -- lane = dim, attn_body's way into ITS LDS planes -- it touched 64)
+        const int m = row0 + rb * 32 + (lane & 31);
+        if (m < Mg) {
           const int b = div_rows(m, L, invL), tk = m - b * L;
-          __bf16* pv = A.planes + ((long long)(b * NH + wave) * 6 + 4) * PL + dim * 64;
-          if (!(L & 1)) {   // rows m, m + 1 belong to one video and sit side by side (even position)
-            *(bf16x2*)(pv + vpos(tk)) = bf16x2{h0, h1};
-            *(bf16x2*)(pv + PL + vpos(tk)) = bf16x2{l0, l1};
-          } else {
-            pv[vpos(tk)] = h0;
-            pv[PL + vpos(tk)] = l0;
-            if (m + 1 < Mg) {
-              const int b1 = div_rows(m + 1, L, invL), t1 = m + 1 - b1 * L;
-              __bf16* pv1 = A.planes + ((long long)(b1 * NH + wave) * 6 + 4) * PL + dim * 64;
-              pv1[vpos(t1)] = h1;
-              pv1[PL + vpos(t1)] = l1;
+          __bf16* pv = A.planes + ((long long)(b * NH + wave) * 6 + 4) * PL + vpos(tk);
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 bv = bv4[gq];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float v = acc[rb][4 * gq + q] + bv[q];
+              const __bf16 h = (__bf16)v;
+              const int dim = 8 * gq + 4 * kg + q;
+              pv[dim * 64] = h;
+              pv[PL + dim * 64] = (__bf16)(v - (float)h);
             }
           }
         }

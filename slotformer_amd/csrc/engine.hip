@@ -523,8 +523,13 @@ static int run_cnn(const sf_savi_encoder* m, const float* src, long long frame_s
       SF_TRY(sf_conv2d_nchw_in_f32(src, frame_stride, m->conv_w[0], m->conv_b[0], add, out, nb, cin, res, res, cout,
                                    m->enc_ks, res == 128 ? 2 : 1, lastc ? 0 : 1, st));
     } else {
-      SF_TRY(sf_conv2d_nhwc_f32(cur, m->conv_w[i], m->conv_b[i], add, out, nb, 64, 64, cin, cout, m->enc_ks, lastc ? 0 : 1,
-                                st));
+      // 64 -> 64 channels with a fragment-ordered weight copy: 4-row tiles, weights streamed as MFMA fragments (conv_rows4.hip)
+      int rc = 1;
+      if (m->conv_w_frag[i])
+        rc = sf_conv5x5_rows4_ex(cur, m->conv_w_frag[i], m->conv_b[i], add, out, nb, 64, 64, cin, cout, m->enc_ks, lastc ? 0 : 1, st);
+      if (rc < 0 || rc > 1) return rc;
+      if (rc == 1)
+        SF_TRY(sf_conv2d_nhwc_f32(cur, m->conv_w[i], m->conv_b[i], add, out, nb, 64, 64, cin, cout, m->enc_ks, lastc ? 0 : 1, st));
     }
     cur = out;
   }

@@ -67,6 +67,8 @@ void sf_prof_suppress(int on);
 int sf_qkv_attn_ex(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* in_proj_w,
                    const float* in_proj_b, float* out, int B, int L, int Lq, int d, int nheads, hipStream_t st);
 extern "C" int sf_get_precision(void);
+int sf_conv5x5_rows4_ex(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W,
+                        int Cin, int Cout, int ks, int relu, hipStream_t st);
 int sf_conv5x5_halo_ex(const float* in, const float* w_packed, const float* bias, const float* add, float* out, int F,
                        int H, int W, int Cin, int Cout, int ks, int relu, hipStream_t st);
 int sf_pixel_mlp_kv_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1,

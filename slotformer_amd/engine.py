@@ -241,8 +241,12 @@ def encoder_plan(m):
     for i in range(n):
         conv = m.encoder[i][0]
         w = conv.weight.detach().float().contiguous()
-        s.conv_w[i] = plan.dp(w if i == 0 else ops.pack_conv_weight(w))
+        wp = w if i == 0 else ops.pack_conv_weight(w)
+        s.conv_w[i] = plan.dp(wp)
         s.conv_b[i] = plan.dp(conv.bias)
+        if i > 0 and w.is_cuda and tuple(w.shape) == (64, 64, 5, 5):
+            # fragment-ordered split-bf16 copy: the conv on 4-row tiles with streamed weight fragments (conv_rows4.hip)
+            s.conv_w_frag[i] = plan.dp(ops.pack_conv_frag(wp))
     pe = m.encoder_pos_embedding
     s.pos_table = plan.dp(ops.pos_embed_table(pe.grid.detach().float(), pe.dense.weight.detach().float().contiguous(),
                                               pe.dense.bias.detach().float().contiguous()))

@@ -55,6 +55,24 @@ def pack_conv_weight(w):
     return out
 
 
+def pack_conv_frag(w_packed):
+    """[64,5,5,64] (pack_conv_weight) -> split-bf16 copy in MFMA-fragment order (uint8 buffer) for conv5x5_frag."""
+    _chk(w_packed)
+    Cout, ks, _, Cin = w_packed.shape
+    out = torch.empty(lib().sf_conv_frag_bytes(Cout, Cin, ks), device=w_packed.device, dtype=torch.uint8)
+    check(lib().sf_pack_conv_frag_weights(_p(w_packed), out.data_ptr(), Cout, Cin, ks, _stream()))
+    return out
+
+
+def conv5x5_frag(x, w_frag, bias, relu=True, add=None):
+    """x [F,H,64,64] NHWC, w_frag = pack_conv_frag(...) -> [F,H,64,64] (4-row tiles, streamed weight fragments)."""
+    _chk(x, bias, add)
+    F_, H, W, Cin = x.shape
+    out = torch.empty(F_, H, W, 64, device=x.device, dtype=torch.float32)
+    check(lib().sf_conv5x5_frag_f32(_p(x), w_frag.data_ptr(), _p(bias), _p(add), _p(out), F_, H, W, int(relu), _stream()))
+    return out
+
+
 def pack_deconv_weight(w):
     """ConvTranspose2d weight [Cin,Cout,k,k] -> [Cout,k,k,Cin]."""
     _chk(w)

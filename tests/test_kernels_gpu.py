@@ -89,6 +89,26 @@ def test_conv_nhwc(dev, relu, with_add, precision):
           **tol(precision))
 
 
+@pytest.mark.parametrize('relu,with_add,H', [(True, False, 64), (False, True, 64), (True, False, 8)])
+def test_conv5x5_frag(dev, relu, with_add, H):
+    """The 4-row-tile convolution with streamed weight fragments (conv_rows4.hip) against torch's conv2d, and bit for bit against
+    the 2-row tile kernel it replaces on the encode path (same products in the same order)."""
+    from slotformer_amd import ops
+    x, w, b = rnd(3, H, 64, 64, seed=1), rnd(64, 64, 5, 5, seed=2, scale=0.03), rnd(64, seed=3, scale=0.1)
+    add = rnd(H * 64, 64, seed=4) if with_add else None
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=2)
+    ref = (F.relu(ref) if relu else ref).permute(0, 2, 3, 1)
+    if with_add:
+        ref = ref + add.view(1, H, 64, 64)
+    wp = ops.pack_conv_weight(w.to(dev))
+    wf = ops.pack_conv_frag(wp)
+    addd = None if add is None else add.to(dev)
+    out = ops.conv5x5_frag(x.to(dev), wf, b.to(dev), relu=relu, add=addd)
+    close(out, ref, **tol("bf16x3"))
+    old = ops.conv2d_nhwc(x.to(dev), wp, b.to(dev), relu=relu, add=addd)
+    assert torch.equal(out, old), (out - old).abs().max().item()
+
+
 @pytest.mark.parametrize('hin,cin,cout,stride', [(8, 128, 64, 2), (16, 64, 64, 2), (32, 64, 64, 1), (5, 192, 64, 2)])
 def test_conv_transpose(dev, hin, cin, cout, stride, precision):
     """ConvTranspose2d(k=5, stride, padding=2, output_padding=stride-1) + ReLU as a gather implicit GEMM."""
