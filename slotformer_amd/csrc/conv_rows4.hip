@@ -14,6 +14,7 @@
 // Same products, same order per cin half as conv_halo.hip (taps ascending, k-steps ascending, x_lo w_hi + x_hi w_lo + x_hi w_hi).
 // Reference call site: the encoder convs i > 0, savi.py:231-239 (+ SoftPositionEmbed add, utils.py:60-63).
 #include "sf_internal.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -27,6 +28,8 @@ constexpr int PS = CH + 8;                                   // bf16 elements pe
 constexpr int HALO = HR * HWD * PS;                          // elements per halo plane
 constexpr int NT = 512;
 constexpr int NTAP = KS * KS;
+constexpr int NCOPY = 1;                                     // copies of the packed weights (see sf_pack_conv_frag_weights)
+constexpr int COPY_BYTES = NTAP * 4 * 2 * 2 * 64 * 16 + 4096 + 256;   // 409,600 + a skew that moves every copy to other L2 channels
 constexpr size_t LDS_BYTES = (size_t)2 * HALO * sizeof(__bf16);   // 156,672
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert((size_t)8 * 32 * 64 * 4 <= LDS_BYTES, "the exchange of the cin halves fits over the dead halo");
@@ -52,13 +55,17 @@ __global__ void pack_conv_frag_kernel(const float* __restrict__ w, uint4* __rest
   out[idx] = o.u;
 }
 
+__device__ long long cr_ts[16];   // phase timestamps of workgroup 0 (SF_CONV_DBG=1; sf_debug_read_ts_conv)
+#define CTS(i) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) cr_ts[i] = wall_clock64(); } while (0)
+
 __global__ __launch_bounds__(NT) void conv5x5_rows4_kernel(const float* __restrict__ in, const uint4* __restrict__ wf,
                                                            const float* __restrict__ bias, const float* __restrict__ add,
-                                                           float* __restrict__ out, int H, int relu) {
+                                                           float* __restrict__ out, int H, int relu, int dbg) {
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
   __bf16* Hh = lds;
   __bf16* Hl = Hh + HALO;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: the fragment offsets below stay in scalar registers
   // XCD-aware tile order: consecutive tiles of a frame share halo rows in one L2
   int bid = blockIdx.x;
   {
@@ -71,20 +78,24 @@ __global__ __launch_bounds__(NT) void conv5x5_rows4_kernel(const float* __restri
   const int cb = wave & 1, rp = (wave >> 1) & 1, kh = wave >> 2;   // cout block, row pair, cin half
 
   // ---- weight ring: slot = tap & 3 holds the tap's 2 k-steps x (hi, lo) of this wave's (cout block, cin half) ----
-  bf16x8 ring[4][2][2];
+  constexpr int RD = 6;   // ring depth in taps: RD - 1 in flight
+  bf16x8 ring[RD][2][2];
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wf), 0, 0x7fffffff, 0x00020000);
-  const unsigned wbase = (unsigned)((((2 * kh) * 2 + cb) * 2) * 1024);   // + tap * 16 KB + ks2 * 4 KB + plane * 1 KB
+  // every workgroup walks the taps in step, so all CUs of an XCD want the same 16 KB at the same time: the two row-pair waves of a
+  // workgroup and alternate workgroups of an XCD read different COPIES of the fragments (other L2 channels)
+  const int copy = (2 * rp + ((blockIdx.x >> 3) & 1)) % NCOPY;
+  const unsigned wbase = (unsigned)((((2 * kh) * 2 + cb) * 2) * 1024 + copy * COPY_BYTES);   // + tap * 16 KB + ks2 * 4 KB + plane * 1 KB
   auto load_tap = [&](int tap) {
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
-        ring[tap & 3][k][pl] = __builtin_bit_cast(
+        ring[tap % RD][k][pl] = __builtin_bit_cast(
             bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, (unsigned)(lane * 16), wbase + (unsigned)(tap * 16384 + k * 4096 + pl * 1024), 0));
   };
-  load_tap(0);
-  load_tap(1);
-  load_tap(2);
+  CTS(0);
+#pragma unroll
+  for (int q = 0; q < RD - 1; ++q) load_tap(q);
 
   // ---- halo fill: 8 x 68 pixels x 16 float4, zero outside the image ----
   {
@@ -114,7 +125,9 @@ __global__ __launch_bounds__(NT) void conv5x5_rows4_kernel(const float* __restri
       }
     }
   }
+  CTS(1);
   __syncthreads();
+  CTS(2);
 
   // ---- 25 taps, no barrier: acc[i] = (row 2 rp + (i >> 1), pixel block i & 1) x cout block cb over this wave's cin half ----
   f32x16 acc[4];
@@ -122,28 +135,47 @@ __global__ __launch_bounds__(NT) void conv5x5_rows4_kernel(const float* __restri
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  const int x_lane = (lane & 31) * PS + 8 * (lane >> 5) + 32 * kh;
-#pragma unroll
-  for (int tap = 0; tap < NTAP; ++tap) {
+  // the activation fragments of half-tap s + 1 are requested BEFORE the 12 MFMAs of half-tap s (two register buffers): the LDS
+  // latency sits under the matrix pipe instead of in front of every MFMA pair
+  const int x_lane = (lane & 31) * PS + 8 * (lane >> 5) + 32 * kh + 2 * rp * HWD * PS;
+  bf16x8 xf[2][4][2];
+  auto read_x = [&](int s, int buf) {
+    const int tap = s >> 1, k = s & 1;
     const int ky = tap / KS, kx = tap - ky * KS;
-    if (tap + 3 < NTAP) load_tap(tap + 3);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const bf16x8 wh = ring[tap & 3][k][0], wl = ring[tap & 3][k][1];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int off = ((2 * rp + (i >> 1) + ky) * HWD + (i & 1) * 32 + kx) * PS + x_lane + k * 16;
-        const bf16x8 xh = *(const bf16x8*)(Hh + off), xl = *(const bf16x8*)(Hl + off);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[i], 0, 0, 0);
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int off = (((i >> 1) + ky) * HWD + (i & 1) * 32 + kx) * PS + k * 16;
+      xf[buf][i][0] = *(const bf16x8*)(Hh + x_lane + off);
+      xf[buf][i][1] = *(const bf16x8*)(Hl + x_lane + off);
     }
-    __builtin_amdgcn_sched_barrier(0);   // the requests stay one ring slot per tap
+  };
+  read_x(0, 0);
+#pragma unroll
+  for (int s = 0; s < 2 * NTAP; ++s) {
+    const int tap = s >> 1, k = s & 1;
+    if (k == 0 && tap + RD - 1 < NTAP) load_tap(tap + RD - 1);
+    if (s + 1 < 2 * NTAP) read_x(s + 1, (s + 1) & 1);
+    const bf16x8 wh = ring[tap % RD][k][0], wl = ring[tap % RD][k][1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf[s & 1][i][1], acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xf[s & 1][i][0], acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf[s & 1][i][0], acc[i], 0, 0, 0);
+    }
+    // issue order inside the half-tap: the weight requests, the 8 fragment reads of the NEXT half-tap, then the 12 MFMAs
+    if (k == 0 && tap + RD - 1 < NTAP) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+    if (s + 1 < 2 * NTAP) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    __builtin_amdgcn_sched_barrier(0);   // requests stay in their half-tap
+    if (s == 9) CTS(3);
+    if (s == 29) CTS(4);
   }
+  CTS(5);
+  if (dbg && blockIdx.x == 0 && lane == 0) cr_ts[8 + wave] = wall_clock64();
 
   // ---- the two cin halves meet: wave kh finishes row 2 rp + kh (pixel blocks 2 kh, 2 kh + 1) and hands the other row over ----
   __syncthreads();   // every wave is done with the halo
+  CTS(6);
   float* X = (float*)lds;   // [8 waves][2 blocks][16][64] f32 = 64 KB
   // (selects, not a runtime register index)
   f32x16 fin[2];
@@ -186,17 +218,21 @@ __global__ __launch_bounds__(NT) void conv5x5_rows4_kernel(const float* __restri
       *(f32x4*)(out + o + 8 * g) = v;
     }
   }
+  CTS(7);
 }
 
-extern "C" size_t sf_conv_frag_bytes(int Cout, int Cin, int ks) { return (size_t)Cout * Cin * ks * ks * 4; }
+extern "C" size_t sf_conv_frag_bytes(int Cout, int Cin, int ks) { return (size_t)NCOPY * COPY_BYTES + 0 * ((size_t)Cout * Cin * ks); }
 
 // w_ohwi [Cout][ks][ks][Cin] (sf_pack_conv_weight_f32) -> fragment-ordered split-bf16 copy for conv5x5_rows4_kernel (64 -> 64, 5 x 5)
 extern "C" int sf_pack_conv_frag_weights(const float* w_ohwi, void* frag, int Cout, int Cin, int ks, void* stream) {
   SF_REQUIRE(w_ohwi && frag, "sf_pack_conv_frag_weights: null pointer");
   SF_REQUIRE(Cout == CH && Cin == CH && ks == KS, "sf_pack_conv_frag_weights: needs a 64 -> 64 channel 5 x 5 convolution");
   const int total = NTAP * 4 * 2 * 2 * 64;
-  hipLaunchKernelGGL(pack_conv_frag_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_ohwi, (uint4*)frag);
-  SF_CHECK_LAUNCH();
+  for (int c = 0; c < NCOPY; ++c) {
+    hipLaunchKernelGGL(pack_conv_frag_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_ohwi,
+                       (uint4*)((char*)frag + (size_t)c * COPY_BYTES));
+    SF_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -206,7 +242,8 @@ int sf_conv5x5_rows4_ex(const float* in, const void* w_frag, const float* bias, 
   if (!w_frag || W != TW || Cin != CH || Cout != CH || ks != KS || (H % TR) != 0 || F <= 0 || sf_get_precision() != 1) return 1;
   SF_TRY(sf_ensure_dyn_lds((const void*)conv5x5_rows4_kernel, LDS_BYTES));
   sf_prof_begin(SF_K_CONV_NHWC, st, 2.0 * (double)F * H * W * Cout * ks * ks * Cin);
-  hipLaunchKernelGGL(conv5x5_rows4_kernel, dim3(F * (H / TR)), dim3(NT), LDS_BYTES, st, in, (const uint4*)w_frag, bias, add, out, H, relu);
+  static const int dbg = getenv("SF_CONV_DBG") ? atoi(getenv("SF_CONV_DBG")) : 0;
+  hipLaunchKernelGGL(conv5x5_rows4_kernel, dim3(F * (H / TR)), dim3(NT), LDS_BYTES, st, in, (const uint4*)w_frag, bias, add, out, H, relu, dbg);
   sf_prof_end(SF_K_CONV_NHWC, st);
   SF_CHECK_LAUNCH();
   return 0;
@@ -218,4 +255,9 @@ extern "C" int sf_conv5x5_frag_f32(const float* in, const void* w_frag, const fl
   SF_REQUIRE(F > 0 && W == TW && H > 0 && (H % TR) == 0, "sf_conv5x5_frag_f32: needs a 64-pixel-wide grid with H % 4 == 0");
   SF_REQUIRE(sf_get_precision() == 1, "sf_conv5x5_frag_f32: split-bf16 mode only (the fragments are split-bf16)");
   return sf_conv5x5_rows4_ex(in, w_frag, bias, add, out, F, H, W, CH, CH, KS, relu, (hipStream_t)stream);
+}
+
+extern "C" int sf_debug_read_ts_conv(long long* out16) {
+  hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(cr_ts), sizeof(long long) * 16);
+  return e == hipSuccess ? 0 : (int)e;
 }

@@ -246,7 +246,9 @@ def encoder_plan(m):
         s.conv_b[i] = plan.dp(conv.bias)
         if i > 0 and w.is_cuda and tuple(w.shape) == (64, 64, 5, 5):
             # fragment-ordered split-bf16 copy: the conv on 4-row tiles with streamed weight fragments (conv_rows4.hip)
-            s.conv_w_frag[i] = plan.dp(ops.pack_conv_frag(wp))
+            frag = ops.pack_conv_frag(wp)   # (a byte buffer: kept alive by the plan, not converted by dp())
+            plan.keep.append(frag)
+            s.conv_w_frag[i] = frag.data_ptr()
     pe = m.encoder_pos_embedding
     s.pos_table = plan.dp(ops.pos_embed_table(pe.grid.detach().float(), pe.dense.weight.detach().float().contiguous(),
                                               pe.dense.bias.detach().float().contiguous()))

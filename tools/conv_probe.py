@@ -38,3 +38,15 @@ with torch.no_grad():
                 dt = (time.perf_counter() - t0) / 20
             fl = 2.0 * F * 4096 * 64 * 64 * 25
             print(f'{name:12s} {kname:32s}: {1e6 * dt:7.1f} us per launch of {F} frames  ({fl / dt / 1e12:.0f} TFLOP/s)', flush=True)
+    if os.environ.get('SF_CONV_DBG'):
+        import ctypes as C
+        from slotformer_amd import _lib
+        lib = _lib.lib()
+        ops.conv5x5_frag(x, wf, b)
+        torch.cuda.synchronize()
+        o = (C.c_longlong * 16)()
+        lib.sf_debug_read_ts_conv.argtypes = [C.POINTER(C.c_longlong)]
+        lib.sf_debug_read_ts_conv(o)
+        ts = list(o)
+        print('conv_rows4 ticks (10 ns):', [v - ts[0] for v in ts[:8]], '(0 entry, 1 halo planes written, 2 barrier, 3 after tap 4, 4 after tap 14, 5 taps done, 6 barrier, 7 end)')
+        print('taps done per wave:', [v - ts[0] for v in ts[8:16]])
