@@ -299,6 +299,8 @@ int sf_attn_block_f32(const sf_tfm_layer* w, const float* x, float* out, int B, 
 /* The same block in its row-tile form (sf_rollout_opts.attn_qkv_rows = 128; csrc/attn_rows.hip): LN1 + q|k|v on 128-row tiles of the
  * whole batch, then one workgroup per sequence (wave = head) + out-projection.  out [B*Lq][256] = x2;  planes: scratch of
  * sf_attn_rows_planes_bytes(B) bytes (q, k, v^T of every (sequence, head) as split-bf16 MFMA-fragment planes; cleared by the call). */
+/* The FFN block y = x2 + lin2(relu(lin1(LN2(x2)))) on finished rows x2 [M][256] in its row-tile form (sf_rollout_opts.ffn_tile). */
+int sf_ffn_block_rows_f32(const sf_tfm_layer* w, const float* x2, float* y, int M, int ffn, void* stream);
 size_t sf_attn_rows_planes_bytes(int B);
 int sf_attn_block_rows_f32(const sf_tfm_layer* w, const float* x, float* out, void* planes, int B, int L, int Lq, void* stream);
 
@@ -343,6 +345,10 @@ typedef struct {
                       * batch (no padding of a video to 64 rows, one weight load per 128 rows), then one workgroup per video
                       * whose eight waves run the eight heads side by side + the out-projection: finished rows like
                       * attn_heads_per_wg = 8, the same bits, less CU time per row (csrc/attn_rows.hip) */
+  int ffn_tile;      /* 0: default (off); 1: behind an attention block that writes finished rows (attn_heads_per_wg = 8 or attn_qkv_rows),
+                      * the FFN block of the layers before the last as ONE workgroup per 64-row tile that runs all four hidden chunks
+                      * on one ingest / LayerNorm with streamed weight fragments and writes finished rows (csrc/ffn_tile.hip) instead of
+                      * one workgroup per (tile, hidden chunk) and four partial tensors: the same bits, half the CU time */
 } sf_rollout_opts;
 int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws, size_t ws_bytes,
                         void* stream, const sf_rollout_opts* opts); /* opts == NULL: sf_rollout_f32 */

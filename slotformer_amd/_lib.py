@@ -27,7 +27,7 @@ class sf_rollouter(C.Structure):
 
 
 class sf_rollout_opts(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ('precision', 'seam_fused', 'ffn_rows', 'attn_heads_per_wg', 'attn_qkv_rows')]
+    _fields_ = [(n, C.c_int) for n in ('precision', 'seam_fused', 'ffn_rows', 'attn_heads_per_wg', 'attn_qkv_rows', 'ffn_tile')]
 
 
 class sf_tfm_layer_grads(C.Structure):
@@ -159,6 +159,7 @@ SIGNATURES = {
     'sf_rollout_is_fused': (I, [C.POINTER(sf_rollouter)]),
     'sf_ffn_chunk_partials_f32': (I, [C.POINTER(sf_tfm_layer), FP, LL, FP, LL, I, I, I, VP]),
     'sf_attn_block_f32': (I, [C.POINTER(sf_tfm_layer), FP, FP, I, I, I, I, VP]),
+    'sf_ffn_block_rows_f32': (I, [C.POINTER(sf_tfm_layer), FP, FP, I, I, VP]),
     'sf_attn_rows_planes_bytes': (SZ, [I]),
     'sf_attn_block_rows_f32': (I, [C.POINTER(sf_tfm_layer), FP, FP, VP, I, I, I, VP]),
     'sf_slot_attn_iter_bwd_workspace_bytes': (SZ, [I, I, I, I]),

@@ -219,6 +219,8 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   // throughput form of the attention block (per-call option attn_heads_per_wg = 8): one workgroup per video runs all 8 heads
   // and writes finished rows; the FFN behind it reads one row instead of four head-pair partials (layer_fused.hip)
   const bool all_heads = fused_layers && (sf_thread_opts().attn_heads == 8 || attn_rows);
+  // row-tile form of the FFN block behind finished attention rows (per-call option ffn_tile, ffn_tile.hip): finished rows out
+  const bool ffn_tile = all_heads && sf_thread_opts().ffn_tile == 1;
   const int np = all_heads ? 1 : 4;
   if (ring_mode) {
     // in-projection (without PE) of the burn-in frames -> ring slots 0 .. n_in-1
@@ -317,6 +319,11 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
             ap_l0 = apb;
           }
           cin = nullptr;
+        } else if (ffn_tile && !lastl) {
+          SF_TRY(sf_ffn_tile_ex(apl, m->layers[l], 1e-5f, xo, B * Lq, m->ffn_dim, st));
+          cin = xo;
+          parts_in = false;
+          if (l == 0) ap_l0 = apb;
         } else if (parts_mode && !lastl) {
           // the chunk partials are the layer output: the next attention sums them
           SF_TRY(sf_ffn_parts_ex(apl, pst, m->layers[l], 1e-5f, xpb, pst, B * Lq, m->ffn_dim, st, np));
@@ -365,7 +372,11 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
         } else {
           SF_TRY(sf_attn_oproj_ex(cin, m->layers[l], 1e-5f, apb, pst, B, L, Lq, st));
         }
-        if (!lastl) {
+        if (!lastl && ffn_tile) {
+          SF_TRY(sf_ffn_tile_ex(apb, m->layers[l], 1e-5f, xo, B * Lq, m->ffn_dim, st));
+          cin = xo;
+          parts_in = false;
+        } else if (!lastl) {
           SF_TRY(sf_ffn_parts_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, B * Lq, m->ffn_dim, st, np));
           parts_in = true;
         } else {
@@ -440,12 +451,14 @@ int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total,
   SF_REQUIRE(opts->attn_heads_per_wg == 0 || opts->attn_heads_per_wg == 2 || opts->attn_heads_per_wg == 8,
              "sf_rollout_opts: attn_heads_per_wg must be 0 (default), 2 or 8");
   SF_REQUIRE(opts->attn_qkv_rows == 0 || opts->attn_qkv_rows == 128, "sf_rollout_opts: attn_qkv_rows must be 0 (off) or 128");
+  SF_REQUIRE(opts->ffn_tile == 0 || opts->ffn_tile == 1, "sf_rollout_opts: ffn_tile must be 0 or 1");
   SfThreadOpts o = sf_thread_opts();
   if (opts->precision >= 0) o.precision = opts->precision;
   if (opts->seam_fused >= 0) o.seam = opts->seam_fused ? 1 : 0;
   if (opts->ffn_rows > 0) o.ffn_rows = opts->ffn_rows;
   if (opts->attn_heads_per_wg > 0) o.attn_heads = opts->attn_heads_per_wg;
   if (opts->attn_qkv_rows > 0) o.attn_rows = opts->attn_qkv_rows;
+  if (opts->ffn_tile > 0) o.ffn_tile = 1;
   OptsScope scope(o);
   const bool plain = (o.precision == 2 || o.precision == 3);
   const bool old_plain = t_plain_gemms;

@@ -1,0 +1,242 @@
+// FFN block of a rollout layer in its ROW-TILE form (per-call option ffn_tile = 1): ONE workgroup per 64-row tile runs all four
+// 256-wide hidden chunks one after the other and writes FINISHED rows
+//     y = x2 + lin2(relu(lin1(LN2(x2))))            (nn.TransformerEncoderLayer, norm_first; slotformer.py:72-80)
+// The chunk-partial kernels of layer_fused.hip give every (row tile, hidden chunk) its own workgroup: each ingests and normalises
+// the tile's rows again, holds its CU for 24-28 us around 10 us of MFMAs, and leaves four partial tensors for the next launch to sum.
+// Here the rows are ingested and normalised once, the weight fragments of W1 / W2 (2 MB per tile) stream through a register ring
+// without touching LDS, the only workgroup barriers are the two hand-overs of the hidden planes per chunk, and the next launch reads
+// 1 KB per row instead of 4.
+// Same products in the same order as ffn_body / ffn_wide_parts_kernel, the four chunks' FFN2 partials each from a fresh
+// accumulator and summed ((p0 + p1) + p2) + p3 with the residual and the bias on p0 -- the bits of the chunk-partial forms.
+#include "../../include/slotformer_hip.h"
+#include "sf_internal.h"
+#include "layer_fused.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int NT = 512, D = 256, HC = 256, NCH = 4;
+constexpr int AP = D + 8;                          // bf16 pitch of the LN2 / hidden planes
+constexpr int ROWS = 64;
+constexpr size_t PLANES = (size_t)2 * ROWS * AP * 2;   // hi | lo planes of 64 rows: 67,584 B
+constexpr size_t FT_LDS = 2 * PLANES;                  // LN2 planes + hidden planes
+static_assert(FT_LDS <= 160 * 1024, "LDS budget");
+constexpr int RD = 5;                              // weight ring depth in two-k-step chunks: RD - 1 in flight
+
+__device__ __forceinline__ void split4(__bf16* hp, __bf16* lp, int off, f32x4 v) {
+  const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+  const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+  *(bf16x4*)(hp + off) = hi;
+  *(bf16x4*)(lp + off) = lo;
+}
+
+struct TileArgs {
+  const float* x2;          // [M][256] finished rows of the attention block
+  const float *ln_g, *ln_b;
+  float ln_eps;
+  const uint4* w1p;
+  const float* b1;
+  const uint4* w2p;
+  const float* b2;
+  float* y;                 // [M][256]
+  int M, dbg;
+};
+}  // namespace
+
+__device__ long long ft_ts[16];
+#define FTS(i) do { if (A.dbg && blockIdx.x == 0 && threadIdx.x == 0) ft_ts[i] = wall_clock64(); } while (0)
+
+__global__ __launch_bounds__(NT) void ffn_tile_kernel(TileArgs A) {
+#pragma clang fp contract(off)
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int row0 = blockIdx.x * ROWS, M = A.M;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* Xh = (__bf16*)smem;                          // LN2(x2) planes [64][AP], resident for the four chunks
+  __bf16* Xl = Xh + ROWS * AP;
+  __bf16* Hh = (__bf16*)((char*)smem + PLANES);        // hidden planes of the current chunk
+  __bf16* Hl = Hh + ROWS * AP;
+  FTS(0);
+  // ---- weight ring: global chunk index gc = (c * 2 + phase) * 8 + k-step pair; phase 0 = W1 of chunk c, 1 = W2 of chunk c ----
+  bf16x8 ring[RD][2][2];
+  const __amdgpu_buffer_rsrc_t w1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(A.w1p), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(A.w2p), 0, 0x7fffffff, 0x00020000);
+  const unsigned wlane = (unsigned)(lane * 16), wwave = (unsigned)(wave * 2048);
+  auto load_chunk = [&](int gc) {
+    const int c = gc >> 4, ph = (gc >> 3) & 1, ks0 = (gc & 7) * 2;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const unsigned so = wwave + (unsigned)(((c * 16 + ks0 + k) * 8) * 2048 + pl * 1024);
+        ring[gc % RD][k][pl] = __builtin_bit_cast(bf16x8, ph ? __builtin_amdgcn_raw_buffer_load_b128(w2r, wlane, so, 0)
+                                                              : __builtin_amdgcn_raw_buffer_load_b128(w1r, wlane, so, 0));
+      }
+  };
+  constexpr int NGC = NCH * 2 * 8;   // 64 ring chunks
+  // ---- rows: ffn_wide_parts_kernel's LayerNorm (wave owns rows wave + 8 i, lane = float4 column) ----
+  const f32x4 lng = *(const f32x4*)(A.ln_g + 4 * lane), lnb = *(const f32x4*)(A.ln_b + 4 * lane);
+  f32x4 xr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) xr[i] = *(const f32x4*)(A.x2 + (long long)min(row0 + wave + 8 * i, M - 1) * D + 4 * lane);
+#pragma unroll
+  for (int q = 0; q < RD - 1; ++q) load_chunk(q);
+  {
+    float mean[8], rstd[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mean[i] = sf_sum64((xr[i][0] + xr[i][1]) + (xr[i][2] + xr[i][3])) * (1.0f / D);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 dv = xr[i] - mean[i];
+      rstd[i] = 1.0f / sqrtf(sf_sum64((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3])) * (1.0f / D) + A.ln_eps);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) split4(Xh, Xl, (wave + 8 * i) * AP + 4 * lane, (xr[i] - mean[i]) * rstd[i] * lng + lnb);
+  }
+  const int tok = lane & 31, kg = lane >> 5, nb = wave * 32 + 4 * kg;
+  __syncthreads();   // LN2 planes
+  FTS(1);
+  const int ao = tok * AP + 8 * kg;
+  f32x4 ysum[2][4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    // ---- FFN1 of chunk c: hidden columns c * 256 + 32 wave .. + 31 of both row blocks ----
+    f32x4 b1v[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b1v[g] = *(const f32x4*)(A.b1 + c * HC + nb + 8 * g);
+    f32x16 a0, a1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a0[r] = a1[r] = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const int gc = (c * 2) * 8 + cc;
+      if (gc + RD - 1 < NGC) load_chunk(gc + RD - 1);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int ks = 2 * cc + k;
+        const bf16x8 w0 = ring[gc % RD][k][0], w1 = ring[gc % RD][k][1];
+        const bf16x8 xh0 = *(const bf16x8*)(Xh + ao + ks * 16), xl0 = *(const bf16x8*)(Xl + ao + ks * 16);
+        const bf16x8 xh1 = *(const bf16x8*)(Xh + ao + 32 * AP + ks * 16), xl1 = *(const bf16x8*)(Xl + ao + 32 * AP + ks * 16);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xl0, a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xh0, a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xh0, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xl1, a1, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xh1, a1, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xh1, a1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (c > 0) __syncthreads();   // every wave has read the hidden planes of chunk c - 1 (its FFN2)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bv = b1v[g];
+      f32x4 h0, h1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        h0[q] = fmaxf(a0[4 * g + q] + bv[q], 0.f);
+        h1[q] = fmaxf(a1[4 * g + q] + bv[q], 0.f);
+      }
+      split4(Hh, Hl, tok * AP + nb + 8 * g, h0);
+      split4(Hh, Hl, (32 + tok) * AP + nb + 8 * g, h1);
+    }
+    __syncthreads();   // hidden planes of chunk c
+    if (c == 0) FTS(2);
+    // ---- FFN2 partial of chunk c: output columns 32 wave .. + 31, fresh accumulators ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a0[r] = a1[r] = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const int gc = (c * 2 + 1) * 8 + cc;
+      // (chunk 0: no requests across its end -- the registers of the ring take the residual rows there, see below)
+      if (gc + RD - 1 < NGC && !(c == 0 && cc + RD - 1 >= 8)) load_chunk(gc + RD - 1);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int ks = 2 * cc + k;
+        const bf16x8 w0 = ring[gc % RD][k][0], w1 = ring[gc % RD][k][1];
+        const bf16x8 xh0 = *(const bf16x8*)(Hh + ao + ks * 16), xl0 = *(const bf16x8*)(Hl + ao + ks * 16);
+        const bf16x8 xh1 = *(const bf16x8*)(Hh + ao + 32 * AP + ks * 16), xl1 = *(const bf16x8*)(Hl + ao + 32 * AP + ks * 16);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xl0, a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xh0, a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xh0, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xl1, a1, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xh1, a1, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xh1, a1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // running sum of the chunk partials: p0 = y0 + (x2 + b2), then (s + p1) + p2 ... -- the consumer's order
+    if (c == 0) {
+      // the residual + bias ride on chunk 0: the rows just read for the LayerNorm (L2 hits), requested together with the first
+      // fragments of chunk 1 into the registers the ring has left (requested earlier they were spilled behind vmcnt(0) waits)
+#pragma unroll
+      for (int q = 0; q < RD - 1; ++q) load_chunk(16 + q);
+      // (an opaque zero that depends on the last MFMA: the row requests cannot be hoisted into the loop above)
+      int late = 0;
+      asm volatile("" : "+v"(late) : "v"(a0[0]), "v"(a1[0]));
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b2v = *(const f32x4*)(A.b2 + nb + 8 * g + late);
+        const f32x4 r0 = *(const f32x4*)(A.x2 + (long long)min(row0 + tok, M - 1) * D + nb + 8 * g + late);
+        const f32x4 r1 = *(const f32x4*)(A.x2 + (long long)min(row0 + 32 + tok, M - 1) * D + nb + 8 * g + late);
+        const f32x4 p0 = {a0[4 * g], a0[4 * g + 1], a0[4 * g + 2], a0[4 * g + 3]};
+        const f32x4 p1 = {a1[4 * g], a1[4 * g + 1], a1[4 * g + 2], a1[4 * g + 3]};
+        ysum[0][g] = p0 + (r0 + b2v);
+        ysum[1][g] = p1 + (r1 + b2v);
+        // (pinned here: left to the scheduler the sums sank to the end of the kernel and the rows were spilled meanwhile)
+        asm volatile("" : "+v"(ysum[0][g]), "+v"(ysum[1][g]));
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 p0 = {a0[4 * g], a0[4 * g + 1], a0[4 * g + 2], a0[4 * g + 3]};
+        const f32x4 p1 = {a1[4 * g], a1[4 * g + 1], a1[4 * g + 2], a1[4 * g + 3]};
+        ysum[0][g] = ysum[0][g] + p0;
+        ysum[1][g] = ysum[1][g] + p1;
+      }
+    }
+    if (c == 0) FTS(3);
+  }
+  FTS(4);
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int row = row0 + 32 * rb + tok;
+    if (row < M) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *(f32x4*)(A.y + (long long)row * D + nb + 8 * g) = ysum[rb][g];
+    }
+  }
+  FTS(5);
+}
+
+// x2 [M][256] (finished rows of the attention block) -> y [M][256] = x2 + FFN(LN2(x2)), one workgroup per 64 rows
+int sf_ffn_tile_ex(const float* x2, const sf_tfm_layer& w, float eps, float* y, int M, int ffn, hipStream_t st) {
+  if (!w.lin1_packed || !w.lin2_packed || ffn != NCH * HC)
+    return sf_set_err(-1, "invalid argument: the row-tile FFN needs packed weights (sf_pack_ffn_weights) and ffn == 1024", __FILE__, __LINE__);
+  static const int dbg = getenv("SF_LF_DBG") ? (atoi(getenv("SF_LF_DBG")) & 16) : 0;
+  TileArgs A;
+  A.x2 = x2; A.ln_g = w.norm2_g; A.ln_b = w.norm2_b; A.ln_eps = eps; A.w1p = (const uint4*)w.lin1_packed; A.b1 = w.lin1_b;
+  A.w2p = (const uint4*)w.lin2_packed; A.b2 = w.lin2_b; A.y = y; A.M = M; A.dbg = dbg;
+  SF_TRY(sf_ensure_dyn_lds((const void*)ffn_tile_kernel, FT_LDS));
+  sf_prof_begin(SF_K_FFN, st, 4.0 * M * (double)D * ffn);
+  hipLaunchKernelGGL(ffn_tile_kernel, dim3((M + ROWS - 1) / ROWS), dim3(NT), FT_LDS, st, A);
+  sf_prof_end(SF_K_FFN, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// Kernel-level entry point (include/slotformer_hip.h): the FFN block on finished rows, for tests against a plain reference.
+extern "C" int sf_ffn_block_rows_f32(const sf_tfm_layer* w, const float* x2, float* y, int M, int ffn, void* stream) {
+  SF_REQUIRE(w && x2 && y && M > 0, "sf_ffn_block_rows_f32: null pointer / empty problem");
+  SF_REQUIRE(w->norm2_g && w->norm2_b && w->lin1_b && w->lin2_b && w->lin1_packed && w->lin2_packed,
+             "sf_ffn_block_rows_f32: null weight (packed FFN weights needed)");
+  return sf_ffn_tile_ex(x2, *w, 1e-5f, y, M, ffn, (hipStream_t)stream);
+}
+
+extern "C" int sf_debug_read_ts_ffn_tile(long long* out16) {
+  hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(ft_ts), sizeof(long long) * 16);
+  return e == hipSuccess ? 0 : (int)e;
+}

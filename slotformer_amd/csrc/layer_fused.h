@@ -23,6 +23,8 @@ int sf_attn_all_parts_ex(const float* xparts, long long xparts_stride, const sf_
                          int Lq, hipStream_t st);
 int sf_attn_all_ring_ex(const float* ring, int ring_frames, int nslots, int f0, const float* pe, const sf_tfm_layer& w, float eps,
                         float* x2, int B, int L, int Lq, hipStream_t st);
+// row-tile form of the FFN block (ffn_tile.hip): x2 [M][256] finished rows -> y [M][256] finished rows, one workgroup per 64 rows
+int sf_ffn_tile_ex(const float* x2, const sf_tfm_layer& w, float eps, float* y, int M, int ffn, hipStream_t st);
 // row-tile form (attn_rows.hip): q|k|v projection on 128-row tiles of the batch + one core / out-projection workgroup per video;
 // mode 0: x [B][L][256], 1: four chunk partials, 2: ring rows + position table.  planes: sf_attn_rows_plane_bytes(B) bytes
 size_t sf_attn_rows_plane_bytes(int B);

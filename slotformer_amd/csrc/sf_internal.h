@@ -12,6 +12,7 @@ struct SfThreadOpts {
   int ffn_rows = 0;      // rows per workgroup of the chunk-partial FFN launches: 32 / 64 / 128
   int attn_heads = 0;    // heads per workgroup of the layer attention launches: 2 (head pairs, four partials) / 8 (finished rows)
   int attn_rows = 0;     // 128: the attention block as q|k|v row tiles + one core workgroup per video (attn_rows.hip; finished rows)
+  int ffn_tile = 0;      // 1: the FFN block as one workgroup per 64-row tile over all hidden chunks (ffn_tile.hip; finished rows)
 };
 SfThreadOpts& sf_thread_opts();
 // hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device) -- a process may drive several GPUs

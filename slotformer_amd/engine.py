@@ -179,19 +179,19 @@ def rollouter_plan(r, packed=True):
 def rollout_opts(opts):
     """dict / None -> ctypes sf_rollout_opts (None).  Keys: precision ('f32' | 'bf16x3' | 'bf16' | 'fp16' (probe) | 0..3), seam (bool),
     ffn_rows (32 | 64 | 128), attn_heads (2 | 8: heads per attention workgroup), attn_rows (0 | 128: q|k|v projection on row tiles of
-    the batch + one core workgroup per video); per call and per thread, never process-wide."""
+    the batch + one core workgroup per video), ffn_tile (bool: the FFN block as one workgroup per 64-row tile, finished rows); per call and per thread, never process-wide."""
     if opts is None:
         return None
     if isinstance(opts, _lib.sf_rollout_opts):
         return opts
-    unknown = set(opts) - {'precision', 'seam', 'ffn_rows', 'attn_heads', 'attn_rows'}
+    unknown = set(opts) - {'precision', 'seam', 'ffn_rows', 'attn_heads', 'attn_rows', 'ffn_tile'}
     if unknown:
         raise ValueError(f'slotformer_amd: unknown rollout options {sorted(unknown)}')
     prec = opts.get('precision', -1)
     prec = {'f32': 0, 'bf16x3': 1, 'bf16': 2, 'fp16': 3}.get(prec, prec)
     seam = opts.get('seam', None)
     return _lib.sf_rollout_opts(int(prec), -1 if seam is None else int(bool(seam)), int(opts.get('ffn_rows', 0)), int(opts.get('attn_heads', 0)),
-                                int(opts.get('attn_rows', 0)))
+                                int(opts.get('attn_rows', 0)), int(bool(opts.get('ffn_tile', 0))))
 
 
 def burn_in_of(r):

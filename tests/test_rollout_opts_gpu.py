@@ -75,7 +75,8 @@ def test_row_tile_attention_form(dev, B):
     ref = _roll(r, x, 9)
     a = _roll(r, x, 9, {'attn_rows': 128, 'ffn_rows': 128, 'seam': False})
     assert torch.equal(a, ref), rel_err(a, ref)
-    for opts in ({'attn_rows': 128, 'ffn_rows': 64}, {'attn_rows': 128, 'ffn_rows': 32}, {'attn_rows': 128, 'attn_heads': 8}):
+    for opts in ({'attn_rows': 128, 'ffn_rows': 64}, {'attn_rows': 128, 'ffn_rows': 32}, {'attn_rows': 128, 'attn_heads': 8},
+                 {'attn_rows': 128, 'ffn_tile': True}, {'attn_heads': 8, 'ffn_tile': True}):
         assert torch.equal(_roll(r, x, 9, opts), a), opts
     sub = _roll(r, x[1:3].contiguous(), 9, {'attn_rows': 128})
     assert torch.equal(sub, a[1:3])
@@ -123,7 +124,7 @@ def test_attention_block_kernels(dev, L, Lq, B):
 
 @pytest.mark.parametrize('opts', [{'ffn_rows': 128, 'seam': False}, {'ffn_rows': 64, 'seam': False}, {'ffn_rows': 32, 'seam': True},
                                   {'attn_heads': 8, 'ffn_rows': 128, 'seam': False}, {'attn_heads': 8, 'ffn_rows': 64},
-                                  {'attn_rows': 128, 'ffn_rows': 128, 'seam': False}])
+                                  {'attn_rows': 128, 'ffn_rows': 128, 'seam': False}, {'attn_rows': 128, 'ffn_tile': True, 'seam': False}])
 @torch.no_grad()
 def test_throughput_settings_vs_reference_fixture(dev, opts):
     """roll_c2 (6 + 50 steps, outputs of the reference's own SlotFormer) with the kernel settings of the pipelined bench:
@@ -252,3 +253,17 @@ def test_ffn_chunk_partials_kernel(dev, M):
         for c in range(4):
             d = (outs[rows][c] - outs[32][c]).abs()
             assert torch.equal(outs[rows][c], outs[32][c]), (rows, c, d.max().item(), (d > 0).any(1).nonzero().flatten()[:20].tolist())
+
+    # row-tile form (ffn_tile.hip): one workgroup per 64 rows over all four hidden chunks, finished rows in and out -- the bits of
+    # the chunk partials' ordered sum
+    yt = torch.full((M, 256), float('nan'), device=dev)
+    _lib.check(lib.sf_ffn_block_rows_f32(C.byref(w), x2.contiguous().data_ptr(), yt.data_ptr(), M, 1024, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rel_err(yt, ref.cpu()) < 3e-5, rel_err(yt, ref.cpu())
+    xp1 = torch.full((4, M, 256), float('nan'), device=dev)
+    ap1 = torch.zeros(4, M, 256, device=dev)
+    ap1[0] = x2
+    _lib.check(lib.sf_ffn_chunk_partials_f32(C.byref(w), ap1.data_ptr(), M * 256, xp1.data_ptr(), M * 256, M, 1024, 128,
+                                             torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(yt, ((xp1[0] + xp1[1]) + xp1[2]) + xp1[3])

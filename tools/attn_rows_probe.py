@@ -22,7 +22,9 @@ torch.manual_seed(1)
 x0 = torch.randn(B, 6, 7, 128, device=dev)
 FORMS = {'head pairs (default)': {'ffn_rows': 64, 'seam': False},
          'all heads': {'attn_heads': 8, 'ffn_rows': 128, 'seam': False},
-         'row tiles': {'attn_rows': 128, 'ffn_rows': 128, 'seam': False}}
+         'row tiles': {'attn_rows': 128, 'ffn_rows': 128, 'seam': False},
+         'row tiles + FFN tiles': {'attn_rows': 128, 'ffn_tile': True, 'seam': False},
+         'all heads + FFN tiles': {'attn_heads': 8, 'ffn_tile': True, 'seam': False}}
 
 
 def fresh():
@@ -62,3 +64,10 @@ with torch.no_grad():
         ts = list(out)
         print('qkv_rows ticks (10 ns):', [t - ts[0] for t in ts[:6]], '(0 entry, 1 gamma/beta, 2 half A planes, 3 half B planes, 4 half A done, 5 end)')
         print('attn_core ticks (10 ns):', [t - ts[8] for t in ts[8:11]], '(entry, core done + O planes, end)')
+        engine.rollout(roll, fresh(), 6, 3, opts=FORMS['row tiles + FFN tiles'])
+        torch.cuda.synchronize()
+        o2 = (C.c_longlong * 16)()
+        lib.sf_debug_read_ts_ffn_tile.argtypes = [C.POINTER(C.c_longlong)]
+        lib.sf_debug_read_ts_ffn_tile(o2)
+        t2 = list(o2)
+        print('ffn_tile ticks (10 ns):', [t - t2[0] for t in t2[:6]], '(0 entry, 1 LN planes, 2 hidden planes of chunk 0, 3 chunk 0 done, 4 all chunks, 5 end)')
