@@ -134,7 +134,7 @@ def committed_profile(key):
         return {}
 
 
-KERNEL_CLASS = {'conv5x5_halo': 'conv', 'ffn_partial_kernel': 'ffn_fused', 'ffn64_parts_kernel': 'ffn_fused', 'ffn_wide_parts_kernel': 'ffn_fused',
+KERNEL_CLASS = {'conv5x5_halo': 'conv', 'ffn_tile_kernel': 'ffn_fused', 'ffn_partial_kernel': 'ffn_fused', 'ffn64_parts_kernel': 'ffn_fused', 'ffn_wide_parts_kernel': 'ffn_fused',
                 'conv5x5_rows4_kernel': 'conv', 'qkv_rows_kernel': 'attention', 'attn_core_kernel': 'attention', 'attn_oproj_kernel': 'attention', 'attn_all_kernel': 'attention', 'seam_kernel': 'seam', 'sa_attn_mfma_kernel': 'slot_attn', 'sa_attn_fold_kernel': 'slot_attn'}
 
 
@@ -497,11 +497,19 @@ def main():
         #      command (profiles/r*_kernel_stats.csv), the others stay as secondary keys ----
         objs = {}
         W_FR = roll.cond_len if single else roll.history_len
-        for key, name in (('ffn_fused', 'ffn_wide_parts_kernel<2> / <1> / ffn_partial_kernel (sum of the 4 head-pair partials + LN2 + FFN1 + ReLU + FFN2 on a '
-                           '128- / 64- / 32-row tile x 256-wide hidden chunk; chunk partials out, last-arriver reduction + step boundary on the last layer)'),
-                          ('attention', 'attn_all_kernel (LN1 + q|k|v + softmax(qk^T)v of all 8 heads + out-projection + residual: finished rows; one '
-                           'workgroup per video) in the throughput units; attn_oproj_kernel (one workgroup per head pair and video, four partials) '
-                           'in the latency-form drain unit'),
+        tile_forms = pipe.rollout_opts is not None and pipe.rollout_opts.ffn_tile == 1
+        rows_forms = pipe.rollout_opts is not None and pipe.rollout_opts.attn_qkv_rows == 128
+        for key, name in (('ffn_fused', ('ffn_tile_kernel (LN2 + FFN1 + ReLU + FFN2 over all four hidden chunks on a 64-row tile of finished rows, weights streamed as '
+                                         'MFMA fragments; finished rows out) on the layers before the last, ffn_partial_kernel<1> (32-row tile x 256-wide hidden chunk, '
+                                         'last-arriver reduction + step boundary) on the last layer') if tile_forms else
+                           ('ffn_wide_parts_kernel<2> / <1> / ffn_partial_kernel (sum of the 4 head-pair partials + LN2 + FFN1 + ReLU + FFN2 on a '
+                            '128- / 64- / 32-row tile x 256-wide hidden chunk; chunk partials out, last-arriver reduction + step boundary on the last layer)')),
+                          ('attention', ('qkv_rows_kernel (LN1 + q|k|v of all heads on 128-row tiles of the whole unit, weights streamed as MFMA fragments) + '
+                                         'attn_core_kernel (one workgroup per video, wave = head: softmax(qk^T)v in registers, out-projection + residual: finished '
+                                         'rows) -- TWO launches per attention block, timed and counted as one') if rows_forms else
+                           ('attn_all_kernel (LN1 + q|k|v + softmax(qk^T)v of all 8 heads + out-projection + residual: finished rows; one '
+                            'workgroup per video) in the throughput units; attn_oproj_kernel (one workgroup per head pair and video, four partials) '
+                            'in the latency-form drain unit')),
                           ('seam', 'seam_kernel (last-layer FFN + step boundary of step s and the layer-0 attention of step s+1 in one grid, '
                            'tile-local write-through hand-off)')):
             iso, live = prof_roll.get(key), prof_roll_live.get(key)
@@ -527,9 +535,12 @@ def main():
                 'cus_available': pipe.rollout_cus if pipe.cu_split else 256,
                 'traffic': pm.get('traffic_bytes_per_launch'),
                 'mfma_busy_frac': pm.get('mfma_busy_frac'), 'pmc_source': pm.get('source'),
-                'limiter': 'FFN: per-CU ingest of weight fragments + rows (a CU takes in 70-100 GB/s) around ~10 us of MFMAs per 128-row workgroup; '
-                           'attention: a serial eight-wave workgroup per video -- per head pair 1.9 us of projection MFMAs inside 8.8 us of LDS '
-                           'round trips, softmax and barriers (DESIGN.md 4, 5)',
+                'limiter': ('row-tile forms: the matrix pipe inside the streamed products (q|k|v: 5.2 us per 128 rows x 256 columns = the MFMA bound; FFN: 7.1 us '
+                            'per 64 rows x hidden chunk against 5.1), the un-overlapped ingest + LayerNorm in front of them (8 / 3.5 us) and the plane / row '
+                            'stores behind them; attention core: 9.5 us per video around 2 us of MFMAs (fragment + weight ingest) (DESIGN.md 4, 5)') if tile_forms else
+                           ('FFN: per-CU ingest of weight fragments + rows (a CU takes in 70-100 GB/s) around ~10 us of MFMAs per 128-row workgroup; '
+                            'attention: a serial eight-wave workgroup per video -- per head pair 1.9 us of projection MFMAs inside 8.8 us of LDS '
+                            'round trips, softmax and barriers (DESIGN.md 4, 5)'),
             }
         roll_flops = roll_f * G * B
         res['roofline_rollout_graph'] = {
@@ -551,9 +562,9 @@ def main():
             us = us_trace or (iso['avg_us'] if iso else None)
             ach_iso = flops_per_launch / (us * 1e-6) / 1e12 if us else None
             objs['conv'] = {
-                'kernel': ('conv5x5_halo_kernel' if prec == 'bf16x3' else 'sf_gemm_kernel<128,64,...,conv_nhwc>') + ' (5x5 conv 64->64 @64x64; ' + peak_note + ')',
-                'bound': 'lds-read / mfma (matrix pipes busy ~40 % of the launch at 2.4 GHz; fragment reads from LDS and the un-overlapped halo '
-                         'fill bound it, DESIGN.md 4 and 7)',
+                'kernel': ('conv5x5_rows4_kernel' if prec == 'bf16x3' else 'sf_gemm_kernel<128,64,...,conv_nhwc>') + ' (5x5 conv 64->64 @64x64; ' + peak_note + ')',
+                'bound': 'mfma (inside the 25 taps a wave issues an MFMA every ~59 cycles at 2.4 GHz whole-chip, two waves per SIMD share the pipe unevenly; '
+                         'the un-overlapped halo fill, the exchange of the cin halves and the epilogue take a third of a workgroup\'s time, DESIGN.md 4 and 7)',
                 'achieved': ach_iso, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': (ach_iso / peak_chip) if ach_iso else None,
                 'avg_launch_us': us, 'avg_launch_us_rocprof': us_trace, 'avg_launch_us_events_isolated': iso['avg_us'] if iso else None,
                 'measured': 'flops_per_launch / avg_launch_us_rocprof (the whole-chip launches of the committed rocprof trace, default queue); '

@@ -168,19 +168,24 @@ class EncodeRolloutPipeline:
             rollout_opts = {'seam': bool(int(os.environ.get('SF_PIPE_SEAM', '0'))),
                             'ffn_rows': int(os.environ.get('SF_PIPE_FFN_ROWS', '128' if wide else '64')),
                             'attn_heads': int(os.environ.get('SF_PIPE_ATTN_HEADS', '8' if wide else '2')),
-                            # rollout-heavy pairs (the encode partition is down to fewer than four CU rows: C5) are bound by the
-                            # rollout's CU time: the attention block as q|k|v row tiles of the whole unit + one core workgroup per
-                            # video (attn_rows.hip: half the CU time of the all-heads workgroup; C5 305 -> 337 k frames/s).  Balanced
-                            # pairs are bound by the encode lane: no gain (C2 404 / 404 k, C4 172 / 170 k), the fewer launches win
-                            'attn_rows': int(os.environ.get('SF_PIPE_ATTN_ROWS', '128' if (wide and roll_cus > 128) else '0')),
-                            'ffn_tile': int(os.environ.get('SF_PIPE_FFN_TILE', '0'))}
+                            'attn_rows': 0, 'ffn_tile': 0}
+            # units of >= 4096 token rows (C2: 128 videos x 42 rows; C5: 256 x 48) run both blocks of a layer in their ROW-TILE
+            # forms: LN1 + q|k|v on 128-row tiles of the whole unit + one attention-core workgroup per video (attn_rows.hip), and
+            # the FFN as one workgroup per 64-row tile over all hidden chunks (ffn_tile.hip) -- rows packed across videos, each
+            # row ingested and normalised once per block, weights streamed as fragments: about half the CU time of the all-heads /
+            # chunk-partial workgroups (C5 305 -> 383 k frames/s, C2 405 -> 415-419 k).  Smaller units (C4: 64 videos x 36 rows)
+            # leave too few tiles per launch: 172 vs 169 k.  Same bits.
+            hist = getattr(self.roll, 'cond_len', None) or getattr(self.roll, 'history_len', self.T)
+            tiles = wide and self.G * self.B * self.N * hist >= 4096
+            rollout_opts['attn_rows'] = int(os.environ.get('SF_PIPE_ATTN_ROWS', '128' if tiles else '0'))
+            rollout_opts['ffn_tile'] = int(os.environ.get('SF_PIPE_FFN_TILE', '1' if tiles else '0'))
         self.rollout_opts = engine.rollout_opts(rollout_opts)
         # units of fewer batches (the ramp at both ends of a run) are on the critical path of fill and drain: the latency forms
         # of the kernels (head-pair attention workgroups, narrower FFN workgroups: more, shorter workgroups per launch) -- the
         # same bits
         self.tail_opts = self.rollout_opts
         if self.rollout_opts is not None and (self.rollout_opts.ffn_rows > 64 or self.rollout_opts.attn_heads_per_wg == 8 or
-                                              self.rollout_opts.attn_qkv_rows):
+                                              self.rollout_opts.attn_qkv_rows or self.rollout_opts.ffn_tile):
             self.tail_opts = _lib.sf_rollout_opts(self.rollout_opts.precision, self.rollout_opts.seam_fused, min(self.rollout_opts.ffn_rows or 64, 64), 2, 0, 0)
         self.use_graph = bool(use_graph)
         # the encode under a hipGraph too: the gaps between its ~60 short launches shrink (374-377 vs 373 k frames/s at 20

@@ -89,7 +89,10 @@ def test_pipeline_without_cu_partition_and_graph(dev):
         refs = {False: _serial_reference(savi, roll, imgs, noises, T, H), True: _serial_reference(savi, roll, imgs, noises, T, H, PAIR_OPTS)}
         for kw in (dict(encode_cu_word=0), dict(use_graph=False), dict(encode_cu_word=0, use_graph=False, steal_steps=0),
                    dict(partition='none', steal_steps=1), dict(partition='two', encode_cu_word='rows2'),
-                   dict(partition='two', rollout_opts={'attn_heads': 8, 'ffn_rows': 64})):
+                   dict(partition='two', rollout_opts={'attn_heads': 8, 'ffn_rows': 64}),
+                   # the row-tile forms of both layer blocks (the default of units of >= 4096 token rows: bench.py's C2 / C5 units)
+                   dict(rollout_opts={'attn_rows': 128, 'ffn_tile': True, 'seam': False}),
+                   dict(partition='two', rollout_opts={'attn_rows': 128, 'ffn_tile': True})):
             pipe = EncodeRolloutPipeline(savi, roll, B, T, H, **kw)
             out = pipe.run(imgs, noises)
             torch.cuda.synchronize()

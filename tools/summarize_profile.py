@@ -34,7 +34,7 @@ if f:
     per = defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = short(r['Kernel_Name'])
-        if n.startswith(('conv5x5_halo_kernel', 'sa_attn_mfma_kernel', 'pixel_mlp_kv_kernel', 'ffn_partial_kernel', 'ffn64_parts_kernel', 'ffn_wide_parts_kernel', 'attn_oproj_kernel', 'sa_attn_fold_kernel', 'sa_slot_update_kernel', 'conv5x5_halo256_kernel')):
+        if n.startswith(('conv5x5_rows4_kernel', 'qkv_rows_kernel', 'attn_core_kernel', 'ffn_tile_kernel', 'conv5x5_halo_kernel', 'sa_attn_mfma_kernel', 'pixel_mlp_kv_kernel', 'ffn_partial_kernel', 'ffn64_parts_kernel', 'ffn_wide_parts_kernel', 'attn_oproj_kernel', 'sa_attn_fold_kernel', 'sa_slot_update_kernel', 'conv5x5_halo256_kernel')):
             per[(n, r['Queue_Id'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     lines.append('# per-queue durations of the encode kernels  [trace_kernel_trace.csv]  (queue with the most launches of a '
                  'kernel = the CU-masked encode stream of the timed region = bench.py roofline.avg_launch_us; the others = '
@@ -88,7 +88,7 @@ def stats_avg_us(pred):
 
 
 def is_conv(name):  # conv5x5_halo_kernel, or sf_gemm_kernel<..., ALOAD=1 (NHWC im2col), LN, BF3>
-    if 'conv5x5_halo' in name:
+    if 'conv5x5_halo' in name or 'conv5x5_rows4' in name:
         return True
     m = re.search(r'sf_gemm_kernel<([^>]*)>', name)
     return bool(m) and m.group(1).replace(' ', '').split(',')[8] == '1'
@@ -116,21 +116,42 @@ def stats_class_avg_us(pred):
 # rollout kernel classes = the kernels of the THROUGHPUT-form rollout units the timed region replays (all-heads attention
 # workgroups, wide FFN workgroups on finished rows + the last layer's 32-row FFN with the step boundary); the latency-form kernels
 # of the drain / tail units (attn_oproj_kernel, ffn_wide_parts_kernel<1, 4>, ffn_partial_kernel<4>) are not part of the class
-is_attn = lambda n: 'attn_all_kernel' in n  # noqa: E731
-is_ffn = lambda n: 'ffn_wide_parts_kernel<2, 1>' in n or 'ffn_partial_kernel<1>' in n  # noqa: E731
+# Row-tile forms (attn_rows.hip / ffn_tile.hip): an attention block is TWO launches (qkv_rows_kernel + attn_core_kernel); the class figures are
+# per BLOCK: summed over both kernels and divided by the launches of attn_core_kernel (one per block)
+def _has(pat):
+    f = find(f'{tag}_trace', '*kernel_stats.csv')
+    return bool(f) and any(pat in r['Name'] for r in csv.DictReader(open(f)))
+
+
+ROWS_FORMS = _has('attn_core_kernel')
+is_attn = (lambda n: 'qkv_rows_kernel' in n or 'attn_core_kernel' in n) if ROWS_FORMS else (lambda n: 'attn_all_kernel' in n)  # noqa: E731
+is_ffn = (lambda n: 'ffn_tile_kernel' in n or 'ffn_partial_kernel<1>' in n) if _has('ffn_tile_kernel') else (lambda n: 'ffn_wide_parts_kernel<2, 1>' in n or 'ffn_partial_kernel<1>' in n)  # noqa: E731
+
+
+def per_block(key, total_per_launch_avg, pred):
+    """attention in the row-tile forms: per-launch averages over two kernels -> per attention block (x launches / blocks)"""
+    if key != 'attention' or not ROWS_FORMS or total_per_launch_avg is None:
+        return total_per_launch_avg
+    f = find(f'{tag}_trace', '*kernel_stats.csv')
+    calls = sum(int(r['Calls']) for r in csv.DictReader(open(f)) if pred(r['Name']))
+    blocks = sum(int(r['Calls']) for r in csv.DictReader(open(f)) if 'attn_core_kernel' in r['Name'])
+    return total_per_launch_avg * calls / blocks if blocks else total_per_launch_avg
 for key, pred, whole_chip in (('conv_nhwc_implicit_gemm', is_conv, True), ('slot_attn_iter', lambda n: 'sa_attn_mfma' in n or 'sa_attn_fold' in n, True),
                               ('ffn_fused', is_ffn, False), ('attention', is_attn, False), ('pixel_mlp', lambda n: 'pixel_mlp_kv_kernel' in n, True)):
     fe, wr = counter_avg(f'{tag}_pmc_fetch', 'FETCH_SIZE', pred), counter_avg(f'{tag}_pmc_write', 'WRITE_SIZE', pred)
+    fe, wr = per_block(key, fe, pred), per_block(key, wr, pred)
     ent = {}
     if fe is not None and wr is not None:
         ent.update({'FETCH_SIZE_KB': fe, 'WRITE_SIZE_KB': wr, 'traffic_bytes_per_launch': (2 * fe + wr) * 1024})
-    busy = counter_avg(f'{tag}_pmc_mfma', 'SQ_VALU_MFMA_BUSY_CYCLES', pred)
+    busy = per_block(key, counter_avg(f'{tag}_pmc_mfma', 'SQ_VALU_MFMA_BUSY_CYCLES', pred), pred)
     if whole_chip:
         dur, names = stats_avg_us(pred), None
         rule = 'mean duration on the HIP queue where the kernel runs fastest (>= 8 launches): the whole-chip passes of bench.py'
     else:
         dur, names = stats_class_avg_us(pred)
-        rule = 'sum(TotalDurationNs) / sum(Calls) over the matching rows of the kernel_stats csv (all queues)'
+        dur = per_block(key, dur, pred)
+        rule = 'sum(TotalDurationNs) / sum(Calls) over the matching rows of the kernel_stats csv (all queues)' + (
+            '; x launches / attention blocks (two launches per block: qkv_rows_kernel + attn_core_kernel)' if (key == 'attention' and ROWS_FORMS) else '')
     if busy is not None and dur:
         # SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of the 1024 SIMDs: / 1024 = matrix-pipe time per SIMD, at the 2.4 GHz
         # peak clock (a lower bound of the time: the chip clocks lower under load) over the launch duration of the trace pass
