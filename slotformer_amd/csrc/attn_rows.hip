@@ -23,6 +23,7 @@
 #include "../../include/slotformer_hip.h"
 #include "sf_internal.h"
 #include "layer_fused.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -34,10 +35,10 @@ namespace {
 constexpr int NT = 512;
 constexpr int D = 256, HD = 32, NH = 8;
 constexpr int AP = D + 8;                       // bf16 pitch of the LN(x) / O planes (528 B = 33 slots)
-constexpr int TR = 128;                         // rows per projection tile
+constexpr int TRMAX = 128;                      // rows per projection tile: 128 or 64 (template parameter TR)
 constexpr int KC = 64, NK = D / KC;             // width of an activation load chunk
 constexpr int PL = 2048;                        // bf16 elements of one plane
-constexpr size_t K1_PLANES = (size_t)2 * TR * AP * 2;             // hi | lo planes of the tile: 135,168 B
+constexpr size_t K1_PLANES = (size_t)2 * TRMAX * AP * 2;          // hi | lo planes of a 128-row tile: 135,168 B
 constexpr size_t K1_LDS = K1_PLANES + 2 * D * 4;                  // + gamma | beta
 constexpr size_t K2_LDS = (size_t)2 * 64 * AP * 2;                // O planes [hi, lo][64][AP]
 static_assert(K1_LDS <= 160 * 1024 && K2_LDS <= 160 * 1024, "LDS budget");
@@ -86,9 +87,10 @@ __device__ long long ar_ts[32];   // phase timestamps of workgroup 0 (SF_LF_DBG 
 // LayerNorm of its rows: wave w owns head w's 32 columns of every group and streams their weight fragments (2 KB per k-step)
 // through a ring of four two-k-step slots, three chunks in flight across group boundaries; each fragment feeds the four row
 // blocks of the tile (12 MFMAs).  QROWS: the tile's rows are the last Lq rows of every video (the q tiles of the last layer).
-template <bool RING, bool PART, int G0, int NG, bool QROWS>
+template <bool RING, bool PART, int G0, int NG, bool QROWS, int TR>
 __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile) {
 #pragma clang fp contract(off)
+  constexpr int NRB = TR / 32;   // 32-row blocks of the tile
   constexpr int NP = PART ? 4 : 1;
   RTS(0);
   const int L = A.L, Lq = A.Lq;
@@ -97,7 +99,7 @@ __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __bf16* Ah = (__bf16*)smem;             // [128][AP]
   __bf16* Al = Ah + TR * AP;
-  float* GB = (float*)((char*)smem + K1_PLANES);
+  float* GB = (float*)((char*)smem + (size_t)2 * TR * AP * 2);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int c4 = t & 15, r0 = t >> 4;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -193,16 +195,18 @@ __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile)
     f32x4 vv[NK];
     sum(0, vv);
     __builtin_amdgcn_sched_barrier(0);
-    request(2, 0);
+    if constexpr (NRB > 2) request(2, 0);
     ln(0, vv);
     sum(1, vv);
     __builtin_amdgcn_sched_barrier(0);
-    request(3, 1);
+    if constexpr (NRB > 2) request(3, 1);
     ln(1, vv);
-    sum(0, vv);
-    ln(2, vv);
-    sum(1, vv);
-    ln(3, vv);
+    if constexpr (NRB > 2) {
+      sum(0, vv);
+      ln(2, vv);
+      sum(1, vv);
+      ln(3, vv);
+    }
   }
   __syncthreads();   // LN planes of the tile
   RTS(2);
@@ -218,9 +222,9 @@ __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile)
     f32x4 bv4[4];   // bias of this lane's output columns 8 gq + 4 kg .. + 3 of the head
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) bv4[gq] = *(const f32x4*)(bq + 8 * gq + 4 * kg);
-    f32x16 acc[4], sav[4];
+    f32x16 acc[NRB], sav[NRB];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
+    for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
 #pragma unroll
@@ -229,7 +233,7 @@ __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile)
       if (gc + 3 < NG * 8) load_chunk(gc + 3);
       if (c == 4 && splitk) {
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
+        for (int rb = 0; rb < NRB; ++rb) {
           sav[rb] = acc[rb];
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
@@ -240,7 +244,7 @@ __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile)
         const int ks = 2 * c + k;
         const bf16x8 w0 = ring[gc & 3][k][0], w1 = ring[gc & 3][k][1];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
+        for (int rb = 0; rb < NRB; ++rb) {
           const bf16x8 xh = *(const bf16x8*)(Ah + ao + rb * 32 * AP + ks * 16), xl = *(const bf16x8*)(Al + ao + rb * 32 * AP + ks * 16);
           acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xl, acc[rb], 0, 0, 0);
           acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xh, acc[rb], 0, 0, 0);
@@ -251,12 +255,12 @@ __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile)
     }
     if (splitk) {
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb] = sav[rb] + acc[rb];
+      for (int rb = 0; rb < NRB; ++rb) acc[rb] = sav[rb] + acc[rb];
     }
     if (gi == 0) RTS(3);
     // ---- epilogue of the group: bias (+ scale on q), split, fragment planes ----
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
+    for (int rb = 0; rb < NRB; ++rb) {
       if (!vblock) {
         const int m = row0 + rb * 32 + (lane & 31);
         if (m < Mg) {
@@ -298,15 +302,15 @@ __device__ __forceinline__ void qkv_rows_body(const RowsArgs& A, const int tile)
   RTS(5);
 }
 
-template <bool RING, bool PART>
+template <bool RING, bool PART, int TR>
 __global__ __launch_bounds__(NT) void qkv_rows_kernel(RowsArgs A) {
   const int blk = blockIdx.x;
   if (blk >= A.nt) {   // last layer: q over the newest frame's rows only
-    qkv_rows_body<RING, PART, 0, 1, true>(A, blk - A.nt);
+    qkv_rows_body<RING, PART, 0, 1, true, TR>(A, blk - A.nt);
   } else if (A.ng == 3) {
-    qkv_rows_body<RING, PART, 0, 3, false>(A, blk);
+    qkv_rows_body<RING, PART, 0, 3, false, TR>(A, blk);
   } else {
-    qkv_rows_body<RING, PART, 1, 2, false>(A, blk);
+    qkv_rows_body<RING, PART, 1, 2, false, TR>(A, blk);
   }
 }
 
@@ -535,8 +539,13 @@ int sf_attn_rows_ex(int mode, const float* xin, long long x_batch_stride, long l
   A.ring_frames = ring_frames; A.nslots = nslots; A.ln_g = w.norm1_g; A.ln_b = w.norm1_b; A.ln_eps = eps;
   A.wqkv_p = (const uint4*)w.attn_in_packed; A.bias = w.in_proj_b; A.planes = (__bf16*)planes; A.x2 = x2;
   A.B = B; A.L = L; A.Lq = Lq; A.dbg = ar_dbg();
-  A.nt = (B * L + TR - 1) / TR;
-  const int ntq = (B * Lq + TR - 1) / TR;
+  // rows per tile: 64 -- twice the workgroups of 128-row tiles at half the time each (the launch is a link of a dependent chain; a
+  // unit of 128 videos alone: 14.6 vs 17.6 ms, C2 417 vs 412 k frames/s, C5 385 vs 381 k) for twice the weight stream out of the
+  // L2s; SF_QKV_TILE_ROWS=128: one weight stream per 128 rows
+  static const int tr_env = getenv("SF_QKV_TILE_ROWS") ? atoi(getenv("SF_QKV_TILE_ROWS")) : 0;
+  const int TRr = tr_env == 128 ? 128 : 64;
+  A.nt = (B * L + TRr - 1) / TRr;
+  const int ntq = (B * Lq + TRr - 1) / TRr;
   int extra = 0;
   if (Lq == L) {
     A.ng = 3;
@@ -546,17 +555,25 @@ int sf_attn_rows_ex(int mode, const float* xin, long long x_batch_stride, long l
   }
   A.main_blocks = A.nt;
   const int blocks = A.nt + extra;
+  const size_t lds = (size_t)2 * TRr * AP * 2 + 2 * D * 4;
   sf_prof_begin(SF_K_MHA, st, 6.0 * B * L * (double)D * D + 4.0 * (double)B * NH * Lq * L * HD + 2.0 * B * Lq * (double)D * D);
-  if (mode == 2) {
-    SF_TRY(sf_ensure_dyn_lds((const void*)qkv_rows_kernel<true, false>, K1_LDS));
-    hipLaunchKernelGGL((qkv_rows_kernel<true, false>), dim3(blocks), dim3(NT), K1_LDS, st, A);
-  } else if (mode == 1) {
-    SF_TRY(sf_ensure_dyn_lds((const void*)qkv_rows_kernel<false, true>, K1_LDS));
-    hipLaunchKernelGGL((qkv_rows_kernel<false, true>), dim3(blocks), dim3(NT), K1_LDS, st, A);
-  } else {
-    SF_TRY(sf_ensure_dyn_lds((const void*)qkv_rows_kernel<false, false>, K1_LDS));
-    hipLaunchKernelGGL((qkv_rows_kernel<false, false>), dim3(blocks), dim3(NT), K1_LDS, st, A);
-  }
+#define SF_QKV_LAUNCH(RING_, PART_)                                                                                         \
+  do {                                                                                                                      \
+    if (TRr == 128) {                                                                                                       \
+      SF_TRY(sf_ensure_dyn_lds((const void*)qkv_rows_kernel<RING_, PART_, 128>, lds));                                      \
+      hipLaunchKernelGGL((qkv_rows_kernel<RING_, PART_, 128>), dim3(blocks), dim3(NT), lds, st, A);                         \
+    } else {                                                                                                                \
+      SF_TRY(sf_ensure_dyn_lds((const void*)qkv_rows_kernel<RING_, PART_, 64>, lds));                                       \
+      hipLaunchKernelGGL((qkv_rows_kernel<RING_, PART_, 64>), dim3(blocks), dim3(NT), lds, st, A);                          \
+    }                                                                                                                       \
+  } while (0)
+  if (mode == 2)
+    SF_QKV_LAUNCH(true, false);
+  else if (mode == 1)
+    SF_QKV_LAUNCH(false, true);
+  else
+    SF_QKV_LAUNCH(false, false);
+#undef SF_QKV_LAUNCH
   SF_CHECK_LAUNCH();
   CoreArgs C;
   C.planes = (const __bf16*)planes; C.wo_p = (const uint4*)w.attn_out_packed; C.bo = w.out_proj_b; C.x2 = x2; C.L = L; C.Lq = Lq;

@@ -25,7 +25,7 @@ constexpr int ROWS = 64;
 constexpr size_t PLANES = (size_t)2 * ROWS * AP * 2;   // hi | lo planes of 64 rows: 67,584 B
 constexpr size_t FT_LDS = 2 * PLANES;                  // LN2 planes + hidden planes
 static_assert(FT_LDS <= 160 * 1024, "LDS budget");
-constexpr int RD = 5;                              // weight ring depth in two-k-step chunks: RD - 1 in flight
+constexpr int RD = 4;                              // weight ring depth in two-k-step chunks: RD - 1 in flight
 
 __device__ __forceinline__ void split4(__bf16* hp, __bf16* lp, int off, f32x4 v) {
   const bf16x4 hi = __builtin_convertvector(v, bf16x4);
@@ -101,6 +101,37 @@ __global__ __launch_bounds__(NT) void ffn_tile_kernel(TileArgs A) {
   __syncthreads();   // LN2 planes
   FTS(1);
   const int ao = tok * AP + 8 * kg;
+  // a0 / a1 += W . P^T over 16 k-steps: fragments of planes (Ph, Pl) for both row blocks, weights from the ring (chunks gc0 .. gc0 + 7).
+  // The plane fragments of k-step ks + 1 are requested BEFORE the six MFMAs of k-step ks (two register buffers), so the LDS latency
+  // sits under the matrix pipe; stop_at_end: no weight requests across the end of this product (see chunk 0 below).
+  auto product = [&](const __bf16* Ph, const __bf16* Pl, const int gc0, const bool stop_at_end, f32x16& a0, f32x16& a1) {
+    bf16x8 xf[2][4];
+    auto read_x = [&](int ks, int buf) {
+      xf[buf][0] = *(const bf16x8*)(Ph + ao + ks * 16);
+      xf[buf][1] = *(const bf16x8*)(Pl + ao + ks * 16);
+      xf[buf][2] = *(const bf16x8*)(Ph + ao + 32 * AP + ks * 16);
+      xf[buf][3] = *(const bf16x8*)(Pl + ao + 32 * AP + ks * 16);
+    };
+    read_x(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int gc = gc0 + (ks >> 1), k = ks & 1;
+      const bool req = k == 0 && gc + RD - 1 < NGC && !(stop_at_end && (ks >> 1) + RD - 1 >= 8);
+      if (req) load_chunk(gc + RD - 1);
+      if (ks + 1 < 16) read_x(ks + 1, (ks + 1) & 1);
+      const bf16x8 w0 = ring[gc % RD][k][0], w1 = ring[gc % RD][k][1];
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[ks & 1][1], a0, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[ks & 1][0], a0, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[ks & 1][0], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[ks & 1][3], a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[ks & 1][2], a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[ks & 1][2], a1, 0, 0, 0);
+      if (req) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+      if (ks + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   f32x4 ysum[2][4];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -111,25 +142,7 @@ __global__ __launch_bounds__(NT) void ffn_tile_kernel(TileArgs A) {
     f32x16 a0, a1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) a0[r] = a1[r] = 0.f;
-#pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-      const int gc = (c * 2) * 8 + cc;
-      if (gc + RD - 1 < NGC) load_chunk(gc + RD - 1);
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int ks = 2 * cc + k;
-        const bf16x8 w0 = ring[gc % RD][k][0], w1 = ring[gc % RD][k][1];
-        const bf16x8 xh0 = *(const bf16x8*)(Xh + ao + ks * 16), xl0 = *(const bf16x8*)(Xl + ao + ks * 16);
-        const bf16x8 xh1 = *(const bf16x8*)(Xh + ao + 32 * AP + ks * 16), xl1 = *(const bf16x8*)(Xl + ao + 32 * AP + ks * 16);
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xl0, a0, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xh0, a0, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xh0, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xl1, a1, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xh1, a1, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xh1, a1, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    product(Xh, Xl, (c * 2) * 8, false, a0, a1);
     if (c > 0) __syncthreads();   // every wave has read the hidden planes of chunk c - 1 (its FFN2)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -148,47 +161,34 @@ __global__ __launch_bounds__(NT) void ffn_tile_kernel(TileArgs A) {
     // ---- FFN2 partial of chunk c: output columns 32 wave .. + 31, fresh accumulators ----
 #pragma unroll
     for (int r = 0; r < 16; ++r) a0[r] = a1[r] = 0.f;
-#pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-      const int gc = (c * 2 + 1) * 8 + cc;
-      // (chunk 0: no requests across its end -- the registers of the ring take the residual rows there, see below)
-      if (gc + RD - 1 < NGC && !(c == 0 && cc + RD - 1 >= 8)) load_chunk(gc + RD - 1);
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int ks = 2 * cc + k;
-        const bf16x8 w0 = ring[gc % RD][k][0], w1 = ring[gc % RD][k][1];
-        const bf16x8 xh0 = *(const bf16x8*)(Hh + ao + ks * 16), xl0 = *(const bf16x8*)(Hl + ao + ks * 16);
-        const bf16x8 xh1 = *(const bf16x8*)(Hh + ao + 32 * AP + ks * 16), xl1 = *(const bf16x8*)(Hl + ao + 32 * AP + ks * 16);
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xl0, a0, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xh0, a0, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xh0, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xl1, a1, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xh1, a1, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xh1, a1, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    product(Hh, Hl, (c * 2 + 1) * 8, c == 0, a0, a1);
     // running sum of the chunk partials: p0 = y0 + (x2 + b2), then (s + p1) + p2 ... -- the consumer's order
     if (c == 0) {
       // the residual + bias ride on chunk 0: the rows just read for the LayerNorm (L2 hits), requested together with the first
       // fragments of chunk 1 into the registers the ring has left (requested earlier they were spilled behind vmcnt(0) waits)
-#pragma unroll
-      for (int q = 0; q < RD - 1; ++q) load_chunk(16 + q);
       // (an opaque zero that depends on the last MFMA: the row requests cannot be hoisted into the loop above)
       int late = 0;
       asm volatile("" : "+v"(late) : "v"(a0[0]), "v"(a1[0]));
+      f32x4 b2v[4], r0[4], r1[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 b2v = *(const f32x4*)(A.b2 + nb + 8 * g + late);
-        const f32x4 r0 = *(const f32x4*)(A.x2 + (long long)min(row0 + tok, M - 1) * D + nb + 8 * g + late);
-        const f32x4 r1 = *(const f32x4*)(A.x2 + (long long)min(row0 + 32 + tok, M - 1) * D + nb + 8 * g + late);
+        b2v[g] = *(const f32x4*)(A.b2 + nb + 8 * g + late);
+        r0[g] = *(const f32x4*)(A.x2 + (long long)min(row0 + tok, M - 1) * D + nb + 8 * g + late);
+        r1[g] = *(const f32x4*)(A.x2 + (long long)min(row0 + 32 + tok, M - 1) * D + nb + 8 * g + late);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
         const f32x4 p0 = {a0[4 * g], a0[4 * g + 1], a0[4 * g + 2], a0[4 * g + 3]};
         const f32x4 p1 = {a1[4 * g], a1[4 * g + 1], a1[4 * g + 2], a1[4 * g + 3]};
-        ysum[0][g] = p0 + (r0 + b2v);
-        ysum[1][g] = p1 + (r1 + b2v);
+        ysum[0][g] = p0 + (r0[g] + b2v[g]);
+        ysum[1][g] = p1 + (r1[g] + b2v[g]);
         // (pinned here: left to the scheduler the sums sank to the end of the kernel and the rows were spilled meanwhile)
         asm volatile("" : "+v"(ysum[0][g]), "+v"(ysum[1][g]));
       }
+      // the first fragments of chunk 1 (behind the sums: their registers held the rows)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < RD - 1; ++q) load_chunk(16 + q);
     } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
