@@ -549,15 +549,20 @@ def main():
             'achieved': roll_flops / t_roll / 1e12, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': roll_flops / t_roll / 1e12 / peak_chip,
             'ms': 1e3 * t_roll, 'us_per_step': 1e6 * t_roll / T_ROLL, 'seam_timeouts': int(lib.sf_seam_timeouts()),
         }
+        # (the encode of the timed schedule replays from a hipGraph: the library's event brackets see nothing there -- `live` then comes from
+        #  the committed trace: the mean duration on the HIP queue with the MOST launches of the kernel = the CU-masked encode stream)
         conv = prof.get('conv_nhwc_implicit_gemm')
-        if conv:
+        iso = prof_iso.get('conv_nhwc_implicit_gemm')
+        if conv or iso:
+            pm = committed_profile('conv_nhwc_implicit_gemm') if args.config == 'C2' else {}
+            if not conv:
+                us_live = pm.get('avg_launch_us_trace_encode_queue') or iso['avg_us']
+                conv = {'work': iso['work'], 'launches': iso['launches'], 'avg_us': us_live}
             flops_live = conv['work'] / conv['launches']        # mean over the lanes' launches (each a share of the batch)
             ach = flops_live / (conv['avg_us'] * 1e-6) / 1e12
             # CUs one live launch runs on: the lanes work side by side, each on its own CUs
             enc_cus = pipe.encode_cus / len(pipe.lanes) if (overlap and pipe.cu_split) else 256
-            iso = prof_iso.get('conv_nhwc_implicit_gemm')
             flops_per_launch = iso['work'] / iso['launches'] if iso else flops_live
-            pm = committed_profile('conv_nhwc_implicit_gemm') if args.config == 'C2' else {}
             us_trace = pm.get('avg_launch_us_trace')
             us = us_trace or (iso['avg_us'] if iso else None)
             ach_iso = flops_per_launch / (us * 1e-6) / 1e12 if us else None
@@ -568,8 +573,9 @@ def main():
                 'achieved': ach_iso, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': (ach_iso / peak_chip) if ach_iso else None,
                 'avg_launch_us': us, 'avg_launch_us_rocprof': us_trace, 'avg_launch_us_events_isolated': iso['avg_us'] if iso else None,
                 'measured': 'flops_per_launch / avg_launch_us_rocprof (the whole-chip launches of the committed rocprof trace, default queue); '
-                            '`live` = HIP events (library brackets on the launch stream) in a second pass of the timed schedule, on the encode partition, '
-                            f'every {LIVE_EVERY}th launch',
+                            '`live` = the same kernel on the encode partition beside the rollouts: HIP events (library brackets, every '
+                            f'{LIVE_EVERY}th launch) in a second pass of the timed schedule when the encode launches eagerly, else the mean duration on the '
+                            'CU-masked encode queue of the committed trace (avg_launch_us_trace_encode_queue)',
                 'live': {'achieved': ach, 'cus': enc_cus, 'avg_launch_us': conv['avg_us'], 'launches': conv['launches'],
                          'flops_per_launch': flops_live, 'frac_of_partition_peak': ach / (peak_chip * enc_cus / 256.0),
                          'note': 'a pipelined pass of the timed schedule, beside the rollout graphs; stolen convolutions (rollout streams) are not part of this average'},
@@ -578,8 +584,11 @@ def main():
                 'algorithmic_bytes_per_launch': 2 * B * 4096 * 64 * 4 + 64 * 1600 * 4, 'flops_per_launch': flops_per_launch,
             }
         sa = prof.get('slot_attn_iter')
+        iso = prof_iso.get('slot_attn_iter')
+        if not sa and iso:
+            pm = committed_profile('slot_attn_iter') if args.config == 'C2' else {}
+            sa = {'work': iso['work'], 'launches': iso['launches'], 'avg_us': pm.get('avg_launch_us_trace_encode_queue') or iso['avg_us']}
         if sa:
-            iso = prof_iso.get('slot_attn_iter')
             ub = iso['work'] / iso['launches'] if iso else sa['work'] / sa['launches']   # unique bytes (library accounting: k == v counted once)
             pm = committed_profile('slot_attn_iter') if args.config == 'C2' else {}
             us_trace = pm.get('avg_launch_us_trace')

@@ -87,6 +87,22 @@ def stats_avg_us(pred):
     return min(avgs) if avgs else None
 
 
+def stats_encode_queue_us(pred):
+    """Mean duration (us) on the HIP queue with the MOST launches of the matching kernels: the CU-masked encode stream of the timed
+    region (the kernel beside the rollouts, on its partition)."""
+    f = find(f'{tag}_trace', '*kernel_trace.csv')
+    if not f:
+        return None
+    per = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if pred(r['Kernel_Name']):
+            per[r['Queue_Id']].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    if not per:
+        return None
+    v = max(per.values(), key=len)
+    return sum(v) / len(v) / 1e3
+
+
 def is_conv(name):  # conv5x5_halo_kernel, or sf_gemm_kernel<..., ALOAD=1 (NHWC im2col), LN, BF3>
     if 'conv5x5_halo' in name or 'conv5x5_rows4' in name:
         return True
@@ -159,6 +175,10 @@ for key, pred, whole_chip in (('conv_nhwc_implicit_gemm', is_conv, True), ('slot
                     'mfma_busy_us_per_simd': busy / 1024.0 / 2400.0, 'mfma_busy_frac': busy / 1024.0 / 2400.0 / dur})
         if names:
             ent['kernels'] = names
+    if whole_chip and ent:
+        eq = stats_encode_queue_us(pred)
+        if eq:
+            ent['avg_launch_us_trace_encode_queue'] = eq
     if ent:
         traffic[key] = ent
 json.dump(traffic, open(os.path.join(OUT, f'{tag}_pmc_traffic.json'), 'w'), indent=1)
