@@ -81,6 +81,11 @@ int sf_pack_conv_weight_f32(const float* w_oihw, float* w_ohwi, int Cout, int Ci
 /* 64 -> 64 channel 5 x 5 convolutions on a 64-pixel-wide grid: w_ohwi (above) -> split-bf16 copy in MFMA-fragment order,
  * sf_conv_frag_bytes(64, 64, 5) bytes; sf_conv5x5_frag_f32 is sf_conv2d_nhwc_f32 for that shape on the fragment copy (H % 4 == 0,
  * split-bf16 mode; csrc/conv_rows4.hip).  relu / add as sf_conv2d_nhwc_f32. */
+/* Per-pixel chain of the SAVi encoder up to the normalised Slot-Attention inputs (64 -> 128 -> 128 channels; savi.py:245-250, 66-70):
+ * feat [M][128] = LN(fc2(relu(fc1(LN(x))))), x [M][64]; torch-layout weights w1 [128][64], w2 [128][128].  form 0: one 128-pixel tile per
+ * workgroup, weights through LDS; form 1: weights resident in registers, four tiles per workgroup (csrc/pixel_mlp.hip).  Same bits. */
+int sf_pixel_feat_f32(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
+                      const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, int form, void* stream);
 size_t sf_conv_frag_bytes(int Cout, int Cin, int ks);
 int sf_pack_conv_frag_weights(const float* w_ohwi, void* frag, int Cout, int Cin, int ks, void* stream);
 int sf_conv5x5_frag_f32(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W,

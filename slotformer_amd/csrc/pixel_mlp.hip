@@ -10,6 +10,7 @@
 //
 // 8 waves: wave w owns rows 32*(w>>1) .. +31 and columns 64*(w&1) .. +63 of every 128-wide output (2 accumulators).
 #include "sf_internal.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -244,10 +245,16 @@ int sf_pixel_mlp_kv_ex(const float* x, const float* ln0_g, const float* ln0_b, c
 
 bool sf_pixel_mlp_feat_ok(int C0, int C1) { return C0 == PM_C0 && C1 == PM_C1; }
 
+static int sf_pixel_feat_stream_launch(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
+                                       const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st);
+
 // encoder_out_layer + norm_inputs only: feat [M][128] = LN(fc2(relu(fc1(LN(x)))))
 int sf_pixel_mlp_feat_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
                          const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st) {
   if (M <= 0) return 0;
+  // weights resident in registers, PF_TPW tiles per workgroup (pixel_feat_stream_kernel below); SF_PIXEL_MLP_STREAM=0: the tile-at-a-time kernel
+  static const int stream = getenv("SF_PIXEL_MLP_STREAM") ? atoi(getenv("SF_PIXEL_MLP_STREAM")) : 1;
+  if (stream) return sf_pixel_feat_stream_launch(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st);
   SF_TRY(sf_ensure_dyn_lds((const void*)pixel_mlp_kv_kernel<true>, (size_t)(PM_LDS)));
   sf_prof_begin(SF_K_LINEAR, st, 2.0 * M * (double)(PM_C0 * PM_C1 + PM_C1 * PM_C1));
   hipLaunchKernelGGL(pixel_mlp_kv_kernel<true>, dim3((M + PM_ROWS - 1) / PM_ROWS), dim3(PM_NT), PM_LDS, st, x, ln0_g, ln0_b, w1, b1, w2,
@@ -412,6 +419,227 @@ int sf_pixel_mlp_feat192_ex(const float* x, const float* ln0_g, const float* ln0
   hipLaunchKernelGGL(pixel_mlp_feat192_kernel, dim3((M + PW_ROWS - 1) / PW_ROWS), dim3(PW_NT), PW_LDS, st, x, ln0_g, ln0_b, (const uint4*)w1p, b1,
                      (const uint4*)w2p, b2, ln1_g, ln1_b, feat, M, eps);
   sf_prof_end(SF_K_LINEAR, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// ================================================================================================
+// The same per-pixel chain up to the normalised Slot-Attention inputs (FEAT form) with the weights RESIDENT IN REGISTERS:
+//   feat[M,128] = LN(128)( fc2( relu( fc1( LN(64)(x) ) ) ) )
+// pixel_mlp_kv_kernel<true> re-streams and re-splits fc1 / fc2 (96 KB of f32) for every 128-pixel tile, passes them through LDS
+// behind workgroup barriers and runs its phases one after the other (10 us per tile on its CU, 0.14 of the MFMA roof).  Here a
+// workgroup walks PF_TPW consecutive tiles: wave = (32-column block, half of the tile's rows) keeps ITS fragments of fc1 (4
+// k-steps) and fc2 (8 k-steps) as split-bf16 MFMA A operands in 96 registers for all of them -- read once from the f32 matrices, no
+// packed copy needed -- the rows of the next tile are requested while the current one is in fc1, and its LayerNorm(64) planes are
+// written while the current one is in fc2.  Same products in the same order, same LayerNorm reductions: the bits of
+// pixel_mlp_kv_kernel<true>.
+namespace {
+constexpr int PF_TPW = 4;                                  // tiles per workgroup
+constexpr size_t PF_A0 = (size_t)2 * PM_ROWS * PM_LB0 * 2;  // LN(64)(x) planes hi | lo: 36,864 B
+constexpr size_t PF_H1 = (size_t)2 * PM_ROWS * PM_LB1 * 2;  // relu(fc1) planes hi | lo: 69,632 B; later the f32 fc2 tile [128][PM_H2S]
+constexpr size_t PF_LDS = PF_A0 + PF_H1 + 4 * PM_C1 * sizeof(float);
+static_assert((size_t)PM_ROWS * PM_H2S * 4 <= PF_H1, "the f32 tile fits over the hidden planes");
+}  // namespace
+
+__global__ __launch_bounds__(PM_NT) void pixel_feat_stream_kernel(
+    const float* __restrict__ x, const float* __restrict__ ln0_g, const float* __restrict__ ln0_b, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ ln1_g,
+    const float* __restrict__ ln1_b, float* __restrict__ feat, int M, float eps) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+  __bf16* Ah = lds;                                   // [128][PM_LB0]
+  __bf16* Al = Ah + PM_ROWS * PM_LB0;
+  __bf16* Hh = (__bf16*)((char*)lds + PF_A0);         // [128][PM_LB1]
+  __bf16* Hl = Hh + PM_ROWS * PM_LB1;
+  float* H2 = (float*)Hh;                             // [128][PM_H2S] f32 (over the hidden planes)
+  float* PV = (float*)((char*)lds + PF_A0 + PF_H1);   // b1 | b2 | ln1 gamma | ln1 beta
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int cb = wave & 3, rh = wave >> 2;            // column block of the 128-wide outputs, half of the tile's rows
+  const int ntiles = (M + PM_ROWS - 1) / PM_ROWS;
+  const int tile0 = blockIdx.x * PF_TPW;
+
+  auto split4 = [&](f32x4 v, bf16x4& hi, bf16x4& lo) {
+    hi = __builtin_convertvector(v, bf16x4);
+    lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+  };
+  const int c4 = t & 15, r0 = t >> 4;
+  const f32x4 g0 = *(const f32x4*)(ln0_g + 4 * c4), be0 = *(const f32x4*)(ln0_b + 4 * c4);
+  {
+    const float* src = (t < 128) ? b1 : (t < 256) ? b2 : (t < 384) ? ln1_g : ln1_b;
+    PV[t] = src[t & 127];
+  }
+  f32x4 xr[4];
+  auto request = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = min(tile * PM_ROWS + r0 + 32 * i, M - 1);
+      xr[i] = *(const f32x4*)(x + (long long)row * PM_C0 + 4 * c4);
+    }
+  };
+  request(tile0);
+  // ---- this wave's weight fragments: element j of (matrix, k-step) = W[32 cb + (lane & 31)][16 ks + 8 (lane >> 5) + j] ----
+  bf16x8 w1f[4][2], w2f[8][2];
+  {
+    const float* p1 = w1 + (long long)(cb * 32 + (lane & 31)) * PM_C0 + 8 * (lane >> 5);
+    const float* p2 = w2 + (long long)(cb * 32 + (lane & 31)) * PM_C1 + 8 * (lane >> 5);
+    auto frag = [&](const float* p, bf16x8& hi, bf16x8& lo) {
+      const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+      bf16x4 ah, al, bh, bl;
+      split4(a, ah, al);
+      split4(b, bh, bl);
+      hi = __builtin_shufflevector(ah, bh, 0, 1, 2, 3, 4, 5, 6, 7);
+      lo = __builtin_shufflevector(al, bl, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) frag(p1 + 16 * ks, w1f[ks][0], w1f[ks][1]);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) frag(p2 + 16 * ks, w2f[ks][0], w2f[ks][1]);
+  }
+  // LayerNorm(64) of the rows in xr -> A planes (pixel_mlp_kv_kernel's arithmetic)
+  auto ln64 = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float s = sf_sum16((xr[i][0] + xr[i][1]) + (xr[i][2] + xr[i][3]));
+      const float mean = s * (1.0f / PM_C0);
+      const f32x4 dv = xr[i] - mean;
+      const float vs = sf_sum16((dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]));
+      const float rstd = 1.0f / sqrtf(vs * (1.0f / PM_C0) + eps);
+      bf16x4 hi, lo;
+      split4(dv * rstd * g0 + be0, hi, lo);
+      const int off = (r0 + 32 * i) * PM_LB0 + 4 * c4;
+      *(bf16x4*)(Ah + off) = hi;
+      *(bf16x4*)(Al + off) = lo;
+    }
+  };
+  ln64();
+  __syncthreads();   // A planes of the first tile, PV
+  const int tok = lane & 31, kg = lane >> 5;
+#pragma unroll 1
+  for (int ti = 0; ti < PF_TPW; ++ti) {
+    const int tile = tile0 + ti;
+    if (tile >= ntiles) break;
+    const bool more = ti + 1 < PF_TPW && tile + 1 < ntiles;
+    if (more) request(tile + 1);   // lands under fc1
+    // ---- fc1 + ReLU: rows 64 rh .. + 63 x columns 32 cb .. + 31 -> hidden planes ----
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ao = ((2 * rh + j) * 32 + tok) * PM_LB0 + 8 * kg + ks * 16;
+        const bf16x8 xh = *(const bf16x8*)(Ah + ao), xl = *(const bf16x8*)(Al + ao);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[ks][0], xl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[ks][1], xh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[ks][0], xh, acc[j], 0, 0, 0);
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (2 * rh + j) * 32 + tok;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = cb * 32 + 8 * g + 4 * kg;
+        const f32x4 bv = *(const f32x4*)(PV + n);
+        const f32x4 v = {fmaxf(acc[j][4 * g] + bv[0], 0.f), fmaxf(acc[j][4 * g + 1] + bv[1], 0.f), fmaxf(acc[j][4 * g + 2] + bv[2], 0.f),
+                         fmaxf(acc[j][4 * g + 3] + bv[3], 0.f)};
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        *(bf16x4*)(Hh + row * PM_LB1 + n) = hi;
+        *(bf16x4*)(Hl + row * PM_LB1 + n) = lo;
+      }
+    }
+    __syncthreads();   // hidden planes complete; every wave is done with the A planes
+    if (more) ln64();  // the next tile's A planes, under fc2
+    // ---- fc2 ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ao = ((2 * rh + j) * 32 + tok) * PM_LB1 + 8 * kg + ks * 16;
+        const bf16x8 xh = *(const bf16x8*)(Hh + ao), xl = *(const bf16x8*)(Hl + ao);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[ks][0], xl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[ks][1], xh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[ks][0], xh, acc[j], 0, 0, 0);
+      }
+    __syncthreads();   // every wave is done with the hidden planes: the f32 tile takes their place
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (2 * rh + j) * 32 + tok;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = cb * 32 + 8 * g + 4 * kg;
+        const f32x4 bv = *(const f32x4*)(PV + PM_C1 + n);
+        *(f32x4*)(H2 + row * PM_H2S + n) = f32x4{acc[j][4 * g] + bv[0], acc[j][4 * g + 1] + bv[1], acc[j][4 * g + 2] + bv[2],
+                                               acc[j][4 * g + 3] + bv[3]};
+      }
+    }
+    __syncthreads();
+    // ---- LayerNorm(128) of every row (4 threads per row, 32 channels each) -> feat ----
+    {
+      const int row = t >> 2, part = t & 3;
+      f32x4 hv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) hv[i] = *(const f32x4*)(H2 + row * PM_H2S + part * 32 + 4 * i);
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += (hv[i][0] + hv[i][1]) + (hv[i][2] + hv[i][3]);
+      s += sf_dpp<0xB1>(s);
+      s += sf_dpp<0x4E>(s);
+      const float mean = s * (1.0f / PM_C1);
+      float vs = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 dv = hv[i] - mean;
+        vs += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+      }
+      vs += sf_dpp<0xB1>(vs);
+      vs += sf_dpp<0x4E>(vs);
+      const float rstd = 1.0f / sqrtf(vs * (1.0f / PM_C1) + eps);
+      const int grow = tile * PM_ROWS + row;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = part * 32 + 4 * i;
+        const f32x4 g = *(const f32x4*)(PV + 2 * PM_C1 + c), be = *(const f32x4*)(PV + 3 * PM_C1 + c);
+        if (grow < M) *(f32x4*)(feat + (long long)grow * PM_C1 + c) = (hv[i] - mean) * rstd * g + be;
+      }
+    }
+    __syncthreads();   // the f32 tile is read: the next tile's hidden planes may be written (its A planes are complete)
+  }
+}
+
+static int sf_pixel_feat_stream_launch(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
+                                       const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st) {
+  static_assert(PF_LDS <= 160 * 1024, "LDS budget");
+  SF_TRY(sf_ensure_dyn_lds((const void*)pixel_feat_stream_kernel, PF_LDS));
+  const int ntiles = (M + PM_ROWS - 1) / PM_ROWS;
+  sf_prof_begin(SF_K_LINEAR, st, 2.0 * M * (double)(PM_C0 * PM_C1 + PM_C1 * PM_C1));
+  hipLaunchKernelGGL(pixel_feat_stream_kernel, dim3((ntiles + PF_TPW - 1) / PF_TPW), dim3(PM_NT), PF_LDS, st, x, ln0_g, ln0_b, w1, b1, w2, b2,
+                     ln1_g, ln1_b, feat, M, eps);
+  sf_prof_end(SF_K_LINEAR, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// Kernel-level entry point (include/slotformer_hip.h): feat [M][128] = LN(128)(fc2(relu(fc1(LN(64)(x))))) -- encoder_out_layer followed by
+// SlotAttention.norm_inputs (savi.py:245-250, 66-70).  form 0: one 128-pixel tile per workgroup, weights through LDS; 1: weights resident in
+// registers, four tiles per workgroup (the form the encode uses).  Same bits.
+extern "C" int sf_pixel_feat_f32(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
+                                 const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, int form, void* stream) {
+  SF_REQUIRE(x && ln0_g && ln0_b && w1 && b1 && w2 && b2 && ln1_g && ln1_b && feat && M > 0, "sf_pixel_feat_f32: null pointer / empty problem");
+  SF_REQUIRE(form == 0 || form == 1, "sf_pixel_feat_f32: form must be 0 or 1");
+  SF_REQUIRE(sf_get_precision() == 1, "sf_pixel_feat_f32: split-bf16 mode only");
+  hipStream_t st = (hipStream_t)stream;
+  if (form == 1) return sf_pixel_feat_stream_launch(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st);
+  SF_TRY(sf_ensure_dyn_lds((const void*)pixel_mlp_kv_kernel<true>, (size_t)(PM_LDS)));
+  hipLaunchKernelGGL(pixel_mlp_kv_kernel<true>, dim3((M + PM_ROWS - 1) / PM_ROWS), dim3(PM_NT), PM_LDS, st, x, ln0_g, ln0_b, w1, b1, w2, b2,
+                     ln1_g, ln1_b, nullptr, feat, M, eps);
   SF_CHECK_LAUNCH();
   return 0;
 }
