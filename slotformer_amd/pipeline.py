@@ -177,6 +177,7 @@ class EncodeRolloutPipeline:
             # leave too few tiles per launch: 172 vs 169 k.  Same bits.
             hist = getattr(self.roll, 'cond_len', None) or getattr(self.roll, 'history_len', self.T)
             tiles = wide and self.G * self.B * self.N * hist >= 4096
+            self._row_tiles = bool(tiles)
             rollout_opts['attn_rows'] = int(os.environ.get('SF_PIPE_ATTN_ROWS', '128' if tiles else '0'))
             rollout_opts['ffn_tile'] = int(os.environ.get('SF_PIPE_FFN_TILE', '1' if tiles else '0'))
         self.rollout_opts = engine.rollout_opts(rollout_opts)
@@ -247,7 +248,14 @@ class EncodeRolloutPipeline:
         # encode and the full units: 322 vs 376 k frames/s at 20 batches) -- off
         self.ramp = bool(int(os.environ.get('SF_PIPE_RAMP', '0')))
         self.fill_par = max(1, min(3, int(os.environ.get('SF_PIPE_FILL_PAR', '2'))))   # whole-chip encodes side by side during the fill
-        self.fill_batches = int(os.environ.get('SF_PIPE_FILL', '0'))   # 0: the batches of the first unit
+        # batches encoded on the WHOLE chip (unmasked streams, fill_par at a time) at the start of a run.  The first unit's had to be
+        # (nothing else runs yet); since the row-tile kernels the rollout streams have slack, and the unmasked encodes of the NEXT
+        # units -- 2.3 ms per batch beside the first rollouts instead of 3.9 on the encode partition -- build a backlog the masked lane
+        # then works from: two units by default (C4 172 -> 175 k, C5 381 -> 390 k frames/s at 20 batches), three where the encode lane is
+        # the bound of a balanced pair running row tiles (C2: 427 -> 445-447 k at 20 batches, 441 -> 460 k at 40; four or more units
+        # starve the rollouts: 432 / 410 k).  SF_PIPE_FILL overrides (batches)
+        fill_units = 3 if (getattr(self, '_row_tiles', False) and partition == 'pair' and self._encode_rows() == 4) else 2
+        self.fill_batches = int(os.environ.get('SF_PIPE_FILL', '0')) or (fill_units * self.G if partition == 'pair' else 0)
         self.fill_steal = int(os.environ.get('SF_PIPE_FILL_STEAL', '0'))
         # pre_steal[h]: time steps of convolutions of batch h of the NEXT unit computed on a rollout stream right before a unit
         # rolls out (group >= 2 only; batch 0 of the next unit starts encoding at once and cannot wait)
@@ -593,6 +601,12 @@ class EncodeRolloutPipeline:
                     fill_par = self.fill_par if self.s_free else 1
                     fi = j % fill_par
                     fs = cur if fi == 0 else self.s_free[(fi - 1) % len(self.s_free)]
+                    if j >= units[0][1] and self.s_free and fi == 0:
+                        # fill batches behind the first unit: a rollout is already enqueued, and the calling stream -- the legacy null
+                        # stream -- would wait for it.  Fill graph 0 (its fixed buffers) moves to an unmasked stream, behind its last use
+                        fs = self.s_free[-1]
+                    if j >= fill_par:
+                        fs.wait_event(ev_enc[j - fill_par][0])   # the previous batch through this fill graph / its buffers
                     with torch.cuda.stream(fs):
                         self._encode(img_of(j, fs), nz(j), dst, None, lane=('fill', fi) if fill_par > 1 else 0)
                         ev_enc[j][0].record(fs)
