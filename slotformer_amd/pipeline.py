@@ -169,14 +169,13 @@ class EncodeRolloutPipeline:
                             'ffn_rows': int(os.environ.get('SF_PIPE_FFN_ROWS', '128' if wide else '64')),
                             'attn_heads': int(os.environ.get('SF_PIPE_ATTN_HEADS', '8' if wide else '2')),
                             'attn_rows': 0, 'ffn_tile': 0}
-            # units of >= 4096 token rows (C2: 128 videos x 42 rows; C5: 256 x 48) run both blocks of a layer in their ROW-TILE
-            # forms: LN1 + q|k|v on 128-row tiles of the whole unit + one attention-core workgroup per video (attn_rows.hip), and
-            # the FFN as one workgroup per 64-row tile over all hidden chunks (ffn_tile.hip) -- rows packed across videos, each
+            # units of >= 2048 token rows (C2: 128 videos x 42 rows; C4: 64 x 36; C5: 256 x 48) run both blocks of a layer in their
+            # ROW-TILE forms: LN1 + q|k|v on 64-row tiles of the whole unit + one attention-core workgroup per video (attn_rows.hip),
+            # and the FFN as one workgroup per 64-row tile over all hidden chunks (ffn_tile.hip) -- rows packed across videos, each
             # row ingested and normalised once per block, weights streamed as fragments: about half the CU time of the all-heads /
-            # chunk-partial workgroups (C5 305 -> 383 k frames/s, C2 405 -> 415-419 k).  Smaller units (C4: 64 videos x 36 rows)
-            # leave too few tiles per launch: 172 vs 169 k.  Same bits.
+            # chunk-partial workgroups (C5 305 -> 383 k frames/s, C2 405 -> 415-419 k, C4 172 -> 180 k).  Same bits.
             hist = getattr(self.roll, 'cond_len', None) or getattr(self.roll, 'history_len', self.T)
-            tiles = wide and self.G * self.B * self.N * hist >= 4096
+            tiles = wide and self.G * self.B * self.N * hist >= 2048
             self._row_tiles = bool(tiles)
             rollout_opts['attn_rows'] = int(os.environ.get('SF_PIPE_ATTN_ROWS', '128' if tiles else '0'))
             rollout_opts['ffn_tile'] = int(os.environ.get('SF_PIPE_FFN_TILE', '1' if tiles else '0'))
