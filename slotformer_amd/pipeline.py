@@ -192,7 +192,10 @@ class EncodeRolloutPipeline:
         # batches, 399.5 vs 398.2 at 40) at the price of a 38 MB device copy of the frames into the fixed input buffer per batch
         self.encode_graph = bool(int(os.environ.get('SF_PIPE_ENCODE_GRAPH', '1'))) if encode_graph is None else bool(encode_graph)
         self._enc_graphs = {}
-        self.drain_latency_form = bool(int(os.environ.get('SF_PIPE_DRAIN_LAT', '1')))
+        # the last unit of a run rolls out alone on an unmasked stream: in the kernels' latency forms (head-pair attention, 64-row FFN
+        # workgroups) while a unit is small -- C4, 64 videos: 172 vs 165 k frames/s -- but a large unit fills the chip with its row tiles and
+        # four times the workgroups only queue: C5, 256 videos: 392 -> 435 k; C2, 128 videos: 436 / 440 k
+        self.drain_latency_form = bool(int(os.environ.get('SF_PIPE_DRAIN_LAT', '1' if self.G * self.B < 128 else '0')))
         self._key = ('pipe', id(self))
         self._plan = None
         self._sig = None

@@ -1,5 +1,7 @@
-mkdir -p gpurun_out; rm -f gpurun_out/b1.log
-for cfg in "rows4 12" "rows3 20" "rows2 20" "rows3 16" "rows3 12" "rows2 16"; do set -- $cfg
-SF_PIPE_CU_SPLIT=$1 SF_PIPE_FILL=$2 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('split $1 fill $2 @20', round(d['value']), d['ms_per_step'])" >> gpurun_out/b1.log
+mkdir -p gpurun_out; rm -f gpurun_out/b1.log gpurun_out/t1.log gpurun_out/p1.log
+timeout 900 python -m pytest tests/test_rollout_opts_gpu.py tests/test_pipeline_gpu.py -x -q -m gpu 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -3 > gpurun_out/t1.log
+SF_LF_DBG=16 timeout 300 python tools/attn_rows_probe.py 128 50 2>&1 | grep -v amdgpu | grep "row tiles\|attn_core" > gpurun_out/p1.log
+for cfg in "C2 1" "C2 2" "C5 1" "C5 2" "C4 1" "C4 2"; do set -- $cfg
+SF_CORE_VIDEOS=$2 timeout 600 python bench.py --config $1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$1 core videos $2 @20', round(d['value']), d['ms_per_step'], d['partitioned_ms']['rollout_unit_ms_on_its_cus'])" >> gpurun_out/b1.log
 done
-cat gpurun_out/b1.log
+cat gpurun_out/t1.log gpurun_out/p1.log gpurun_out/b1.log
