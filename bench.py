@@ -134,7 +134,7 @@ def committed_profile(key):
         return {}
 
 
-KERNEL_CLASS = {'conv5x5_halo': 'conv', 'ffn_tile_kernel': 'ffn_fused', 'ffn_partial_kernel': 'ffn_fused', 'ffn64_parts_kernel': 'ffn_fused', 'ffn_wide_parts_kernel': 'ffn_fused',
+KERNEL_CLASS = {'conv5x5_halo': 'conv', 'ffn_qkv_tile_kernel': 'ffn_fused', 'ffn_tile_kernel': 'ffn_fused', 'ffn_partial_kernel': 'ffn_fused', 'ffn64_parts_kernel': 'ffn_fused', 'ffn_wide_parts_kernel': 'ffn_fused',
                 'conv5x5_rows4_kernel': 'conv', 'qkv_rows_kernel': 'attention', 'attn_core_kernel': 'attention', 'attn_oproj_kernel': 'attention', 'attn_all_kernel': 'attention', 'seam_kernel': 'seam', 'sa_attn_mfma_kernel': 'slot_attn', 'sa_attn_fold_kernel': 'slot_attn'}
 
 
@@ -497,14 +497,22 @@ def main():
         #      command (profiles/r*_kernel_stats.csv), the others stay as secondary keys ----
         objs = {}
         W_FR = roll.cond_len if single else roll.history_len
-        tile_forms = pipe.rollout_opts is not None and pipe.rollout_opts.ffn_tile == 1
+        tile_forms = pipe.rollout_opts is not None and pipe.rollout_opts.ffn_tile >= 1
         rows_forms = pipe.rollout_opts is not None and pipe.rollout_opts.attn_qkv_rows == 128
-        for key, name in (('ffn_fused', ('ffn_tile_kernel (LN2 + FFN1 + ReLU + FFN2 over all four hidden chunks on a 64-row tile of finished rows, weights streamed as '
+        fused_next = pipe.rollout_opts is not None and pipe.rollout_opts.ffn_tile == 2 and rows_forms
+        for key, name in (('ffn_fused', ('ffn_qkv_tile_kernel (LN2 + FFN1 + ReLU + FFN2 over all four hidden chunks on a 64-row tile of finished rows AND LN1 + q|k|v of the '
+                                         'NEXT layer on the same rows, weights streamed as MFMA fragments; fragment planes + parked residual rows out: flops_per_launch '
+                                         'counts both) on the layers before the last, ffn_partial_kernel<1> (32-row tile x 256-wide hidden chunk, last-arriver reduction + '
+                                         'step boundary) on the last layer') if fused_next else
+                           ('ffn_tile_kernel (LN2 + FFN1 + ReLU + FFN2 over all four hidden chunks on a 64-row tile of finished rows, weights streamed as '
                                          'MFMA fragments; finished rows out) on the layers before the last, ffn_partial_kernel<1> (32-row tile x 256-wide hidden chunk, '
                                          'last-arriver reduction + step boundary) on the last layer') if tile_forms else
                            ('ffn_wide_parts_kernel<2> / <1> / ffn_partial_kernel (sum of the 4 head-pair partials + LN2 + FFN1 + ReLU + FFN2 on a '
                             '128- / 64- / 32-row tile x 256-wide hidden chunk; chunk partials out, last-arriver reduction + step boundary on the last layer)')),
-                          ('attention', ('qkv_rows_kernel (LN1 + q|k|v of all heads on 128-row tiles of the whole unit, weights streamed as MFMA fragments) + '
+                          ('attention', ('attn_core_kernel (one workgroup per video, wave = head: softmax(qk^T)v in registers from the fragment planes, out-projection + '
+                                         'residual: finished rows) -- alone on the layers whose q|k|v planes the previous FFN launch wrote, behind qkv_rows_kernel (LN1 + q|k|v '
+                                         'on 64-row tiles of the unit) on layer 0; flops_per_launch = mean over the blocks of a step (one with its projection, three without)') if fused_next else
+                           ('qkv_rows_kernel (LN1 + q|k|v of all heads on 64-row tiles of the whole unit, weights streamed as MFMA fragments) + '
                                          'attn_core_kernel (one workgroup per video, wave = head: softmax(qk^T)v in registers, out-projection + residual: finished '
                                          'rows) -- TWO launches per attention block, timed and counted as one') if rows_forms else
                            ('attn_all_kernel (LN1 + q|k|v + softmax(qk^T)v of all 8 heads + out-projection + residual: finished rows; one '

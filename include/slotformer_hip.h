@@ -353,7 +353,9 @@ typedef struct {
   int ffn_tile;      /* 0: default (off); 1: behind an attention block that writes finished rows (attn_heads_per_wg = 8 or attn_qkv_rows),
                       * the FFN block of the layers before the last as ONE workgroup per 64-row tile that runs all four hidden chunks
                       * on one ingest / LayerNorm with streamed weight fragments and writes finished rows (csrc/ffn_tile.hip) instead of
-                      * one workgroup per (tile, hidden chunk) and four partial tensors: the same bits, half the CU time */
+                      * one workgroup per (tile, hidden chunk) and four partial tensors: the same bits, half the CU time;
+                      * 2 (with attn_qkv_rows): that launch also runs LN1 + q|k|v of the NEXT layer on its tile -- the rows never leave
+                      * the workgroup, the next attention block is its core launch alone (one launch less per layer, the same bits) */
 } sf_rollout_opts;
 int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws, size_t ws_bytes,
                         void* stream, const sf_rollout_opts* opts); /* opts == NULL: sf_rollout_f32 */

@@ -523,6 +523,16 @@ static int ar_dbg() {
   return v;
 }
 
+static int launch_core(const sf_tfm_layer& w, float* x2, void* planes, int B, int L, int Lq, hipStream_t st) {
+  CoreArgs C;
+  C.planes = (const __bf16*)planes; C.wo_p = (const uint4*)w.attn_out_packed; C.bo = w.out_proj_b; C.x2 = x2; C.L = L; C.Lq = Lq;
+  C.dbg = ar_dbg();
+  SF_TRY(sf_ensure_dyn_lds((const void*)attn_core_kernel, K2_LDS));
+  hipLaunchKernelGGL(attn_core_kernel, dim3(B), dim3(NT), K2_LDS, st, C);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
 // x2 [B*Lq][256] = x + out_proj(MHA(LN1(x))) + b_o for the last Lq rows of every video, as two launches.
 //   mode 0: x [B][L][256] (x_batch_stride floats per video);  mode 1: the sum of four chunk partials xparts_stride floats apart;
 //   mode 2: ring rows + position table (layer 0 of a rollout step).
@@ -575,14 +585,20 @@ int sf_attn_rows_ex(int mode, const float* xin, long long x_batch_stride, long l
     SF_QKV_LAUNCH(false, false);
 #undef SF_QKV_LAUNCH
   SF_CHECK_LAUNCH();
-  CoreArgs C;
-  C.planes = (const __bf16*)planes; C.wo_p = (const uint4*)w.attn_out_packed; C.bo = w.out_proj_b; C.x2 = x2; C.L = L; C.Lq = Lq;
-  C.dbg = A.dbg;
-  SF_TRY(sf_ensure_dyn_lds((const void*)attn_core_kernel, K2_LDS));
-  hipLaunchKernelGGL(attn_core_kernel, dim3(B), dim3(NT), K2_LDS, st, C);
+  const int rc = launch_core(w, x2, planes, B, L, Lq, st);
   sf_prof_end(SF_K_MHA, st);
-  SF_CHECK_LAUNCH();
-  return 0;
+  return rc;
+}
+
+// The second launch of the row-tile attention block alone: q, k, v^T planes (written by qkv_rows_kernel or by the fused FFN + q|k|v tile
+// launch of ffn_tile.hip) and the parked residual rows in x2 -> finished rows x2 [B * Lq][256]
+int sf_attn_core_ex(const sf_tfm_layer& w, float* x2, void* planes, int B, int L, int Lq, hipStream_t st) {
+  if (!w.attn_out_packed || !planes || !x2 || L < 1 || L > 64 || Lq < 1 || Lq > L)
+    return sf_set_err(-1, "invalid argument: attention core needs packed out-projection weights, planes and 1 <= Lq <= L <= 64", __FILE__, __LINE__);
+  sf_prof_begin(SF_K_MHA, st, 4.0 * (double)B * NH * Lq * L * HD + 2.0 * B * Lq * (double)D * D);
+  const int rc = launch_core(w, x2, planes, B, L, Lq, st);
+  sf_prof_end(SF_K_MHA, st);
+  return rc;
 }
 
 extern "C" size_t sf_attn_rows_planes_bytes(int B) { return B > 0 ? sf_attn_rows_plane_bytes(B) : 0; }

@@ -220,7 +220,10 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   // and writes finished rows; the FFN behind it reads one row instead of four head-pair partials (layer_fused.hip)
   const bool all_heads = fused_layers && (sf_thread_opts().attn_heads == 8 || attn_rows);
   // row-tile form of the FFN block behind finished attention rows (per-call option ffn_tile, ffn_tile.hip): finished rows out
-  const bool ffn_tile = all_heads && sf_thread_opts().ffn_tile == 1;
+  const bool ffn_tile = all_heads && sf_thread_opts().ffn_tile >= 1;
+  // ... fused with LN1 + q|k|v of the NEXT layer on the same tiles (ffn_tile = 2, behind the row-tile attention form): the next attention
+  // block is then its core launch alone
+  const bool ffn_qkv = ffn_tile && attn_rows && sf_thread_opts().ffn_tile == 2;
   const int np = all_heads ? 1 : 4;
   if (ring_mode) {
     // in-projection (without PE) of the burn-in frames -> ring slots 0 .. n_in-1
@@ -267,13 +270,17 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
     if (ring_mode) {
       const float* cin = nullptr;
       bool parts_in = false;   // the current layer's input is still the previous layer's four FFN chunk partials in xpb
+      float* parked = nullptr; // ffn_qkv: the buffer the previous layer's fused launch parked this layer's residual rows in (planes written)
       for (int l = 0; l < m->num_layers; ++l) {
         const bool lastl = (l == m->num_layers - 1);
         const int Lq = lastl ? N : L;   // last layer: only the newest frame's rows are read (slotformer.py:121)
         const long long pst = (long long)B * Lq * d;
         float* xo = (cin == xa) ? xb2 : xa;
         float* apl = (l == 0) ? ap_l0 : apb;
-        if (attn_rows) {
+        if (parked) {
+          apl = parked;
+          SF_TRY(sf_attn_core_ex(m->layers[l], apl, planes, B, L, Lq, st));
+        } else if (attn_rows) {
           if (l == 0)
             SF_TRY(sf_attn_rows_ex(2, ring, (long long)RF * N * d, 0, m->pe_tok + (long long)pe_off * d, f0, RF, N, m->layers[l], 1e-5f, apl,
                                    planes, B, L, Lq, st));
@@ -319,6 +326,14 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
             ap_l0 = apb;
           }
           cin = nullptr;
+        } else if (ffn_qkv && !lastl) {
+          float* park = (apl == apb) ? apb2 : apb;
+          SF_TRY(sf_ffn_qkv_tile_ex(apl, m->layers[l], m->layers[l + 1], 1e-5f, park, planes, B, L, (l + 1 == m->num_layers - 1) ? N : L,
+                                    m->ffn_dim, st));
+          parked = park;
+          cin = nullptr;
+          parts_in = false;
+          if (l == 0) ap_l0 = apb;
         } else if (ffn_tile && !lastl) {
           SF_TRY(sf_ffn_tile_ex(apl, m->layers[l], 1e-5f, xo, B * Lq, m->ffn_dim, st));
           cin = xo;
@@ -351,12 +366,18 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
       // every layer is two launches: attention + out-proj head partials, then the FFN (which also finishes the sums)
       const float* cin = x;
       bool parts_in = false;
+      float* parked = nullptr;   // (as in the ring path)
+      float* apn = apb;          // attention output / FFN input of the current layer
       for (int l = 0; l < m->num_layers; ++l) {
         const bool lastl = (l == m->num_layers - 1);
         const int Lq = lastl ? N : L;
         const long long pst = (long long)B * Lq * d;
         float* xo = (cin == xa) ? xb2 : xa;
-        if (attn_rows) {
+        if (parked) {
+          apn = parked;
+          SF_TRY(sf_attn_core_ex(m->layers[l], apn, planes, B, L, Lq, st));
+        } else if (attn_rows) {
+          apn = apb;
           if (parts_in)
             SF_TRY(sf_attn_rows_ex(1, xpb, (long long)L * d, (long long)B * L * d, nullptr, 0, 1, 1, m->layers[l], 1e-5f, apb, planes, B, L,
                                    Lq, st));
@@ -372,15 +393,22 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
         } else {
           SF_TRY(sf_attn_oproj_ex(cin, m->layers[l], 1e-5f, apb, pst, B, L, Lq, st));
         }
-        if (!lastl && ffn_tile) {
-          SF_TRY(sf_ffn_tile_ex(apb, m->layers[l], 1e-5f, xo, B * Lq, m->ffn_dim, st));
+        if (!lastl && ffn_qkv) {
+          float* park = (apn == apb) ? apb2 : apb;
+          SF_TRY(sf_ffn_qkv_tile_ex(apn, m->layers[l], m->layers[l + 1], 1e-5f, park, planes, B, L, (l + 1 == m->num_layers - 1) ? N : L,
+                                    m->ffn_dim, st));
+          parked = park;
+          cin = nullptr;
+          parts_in = false;
+        } else if (!lastl && ffn_tile) {
+          SF_TRY(sf_ffn_tile_ex(apn, m->layers[l], 1e-5f, xo, B * Lq, m->ffn_dim, st));
           cin = xo;
           parts_in = false;
         } else if (!lastl) {
-          SF_TRY(sf_ffn_parts_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, B * Lq, m->ffn_dim, st, np));
+          SF_TRY(sf_ffn_parts_ex(apn, pst, m->layers[l], 1e-5f, xpb, pst, B * Lq, m->ffn_dim, st, np));
           parts_in = true;
         } else {
-          SF_TRY(sf_ffn_partial_ex(apb, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st, np));
+          SF_TRY(sf_ffn_partial_ex(apn, pst, m->layers[l], 1e-5f, xpb, pst, xo, counters, B * Lq, m->ffn_dim, st, np));
           cin = xo;
           parts_in = false;
         }
@@ -451,14 +479,14 @@ int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total,
   SF_REQUIRE(opts->attn_heads_per_wg == 0 || opts->attn_heads_per_wg == 2 || opts->attn_heads_per_wg == 8,
              "sf_rollout_opts: attn_heads_per_wg must be 0 (default), 2 or 8");
   SF_REQUIRE(opts->attn_qkv_rows == 0 || opts->attn_qkv_rows == 128, "sf_rollout_opts: attn_qkv_rows must be 0 (off) or 128");
-  SF_REQUIRE(opts->ffn_tile == 0 || opts->ffn_tile == 1, "sf_rollout_opts: ffn_tile must be 0 or 1");
+  SF_REQUIRE(opts->ffn_tile >= 0 && opts->ffn_tile <= 2, "sf_rollout_opts: ffn_tile must be 0, 1 or 2");
   SfThreadOpts o = sf_thread_opts();
   if (opts->precision >= 0) o.precision = opts->precision;
   if (opts->seam_fused >= 0) o.seam = opts->seam_fused ? 1 : 0;
   if (opts->ffn_rows > 0) o.ffn_rows = opts->ffn_rows;
   if (opts->attn_heads_per_wg > 0) o.attn_heads = opts->attn_heads_per_wg;
   if (opts->attn_qkv_rows > 0) o.attn_rows = opts->attn_qkv_rows;
-  if (opts->ffn_tile > 0) o.ffn_tile = 1;
+  if (opts->ffn_tile > 0) o.ffn_tile = opts->ffn_tile;
   OptsScope scope(o);
   const bool plain = (o.precision == 2 || o.precision == 3);
   const bool old_plain = t_plain_gemms;

@@ -50,7 +50,9 @@ struct TileArgs {
 __device__ long long ft_ts[16];
 #define FTS(i) do { if (A.dbg && blockIdx.x == 0 && threadIdx.x == 0) ft_ts[i] = wall_clock64(); } while (0)
 
-__global__ __launch_bounds__(NT) void ffn_tile_kernel(TileArgs A) {
+// The FFN of one 64-row tile: on return ysum[rb][g] holds y[row 32 rb + (lane & 31)][32 wave + 8 g + 4 (lane >> 5) .. + 3]; every wave has passed the
+// last FFN2 (no barrier behind it).  LDS: LN2 planes at 0, hidden planes at PLANES.
+__device__ __forceinline__ void ffn_tile_body(const TileArgs& A, f32x4 (&ysum)[2][4]) {
 #pragma clang fp contract(off)
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -132,7 +134,6 @@ __global__ __launch_bounds__(NT) void ffn_tile_kernel(TileArgs A) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  f32x4 ysum[2][4];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     // ---- FFN1 of chunk c: hidden columns c * 256 + 32 wave .. + 31 of both row blocks ----
@@ -201,12 +202,211 @@ __global__ __launch_bounds__(NT) void ffn_tile_kernel(TileArgs A) {
     if (c == 0) FTS(3);
   }
   FTS(4);
+}
+
+__global__ __launch_bounds__(NT) void ffn_tile_kernel(TileArgs A) {
+  f32x4 ysum[2][4];
+  ffn_tile_body(A, ysum);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tok = lane & 31, nb = wave * 32 + 4 * (lane >> 5), row0 = blockIdx.x * ROWS, M = A.M;
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
     const int row = row0 + 32 * rb + tok;
     if (row < M) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) *(f32x4*)(A.y + (long long)row * D + nb + 8 * g) = ysum[rb][g];
+    }
+  }
+  FTS(5);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FFN of layer l AND LN1 + q|k|v of layer l + 1 on the same 64-row tile in one launch (per-call option ffn_tile = 2, behind the
+// row-tile attention form): the finished rows y never leave the workgroup -- they go to an f32 tile in LDS (over the dead hidden
+// planes), are normalised with layer l + 1's LN1 into the (dead) LN2 plane region, and the three projection groups stream their
+// weight fragments exactly as qkv_rows_kernel does (attn_rows.hip: same products, same order, same plane layout).  The rows the next
+// attention core needs as its residual are parked in ITS output buffer (xpark, another buffer than x2: a parked row of the last
+// layer's shorter row space would land on rows another tile has not read yet).  One launch, one first-byte latency and one ingest
+// less per layer of a rollout step.
+namespace {
+constexpr int HD = 32, NH = 8, PL = 2048;      // head width, heads, bf16 elements of a fragment plane (attn_rows.hip)
+constexpr int YP = D + 4;                      // f32 pitch of the y tile
+static_assert((size_t)ROWS * YP * 4 <= PLANES, "the y tile fits over the hidden planes");
+constexpr size_t FQ_LDS = 2 * PLANES + 2 * D * 4;   // + LN1 gamma | beta
+static_assert(FQ_LDS <= 160 * 1024, "LDS budget");
+struct NextArgs {
+  const float *ln_g, *ln_b;     // LN1 of the next layer
+  const uint4* wqkv_p;          // its packed q|k|v weights (sf_pack_attn_weights)
+  const float* bias;            // its in_proj bias [768]
+  __bf16* planes;               // fragment planes [B][8][6][2048]
+  float* xpark;                 // [B * Lq][256]: residual rows of the next attention block
+  int B, L, Lq;                 // videos, rows per video, query rows per video of the NEXT attention block
+};
+__device__ __forceinline__ int vpos(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
+__device__ __forceinline__ int div_rows(int m, int L, float invL) {
+  int q = (int)((float)m * invL);
+  q -= (q * L > m);
+  q += ((q + 1) * L <= m);
+  return q;
+}
+}  // namespace
+
+__global__ __launch_bounds__(NT) void ffn_qkv_tile_kernel(TileArgs A, NextArgs N) {
+#pragma clang fp contract(off)
+  f32x4 ysum[2][4];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* GB = (float*)((char*)smem + 2 * PLANES);
+  if (t < 128) *(f32x4*)(GB + 4 * t) = *(const f32x4*)((t < 64 ? N.ln_g : N.ln_b) + 4 * (t & 63));   // (visible behind the FFN's barriers)
+  ffn_tile_body(A, ysum);
+  const int tok = lane & 31, kg = lane >> 5, nb = wave * 32 + 4 * kg, row0 = blockIdx.x * ROWS, M = A.M;
+  const int L = N.L, Lq = N.Lq, nq0 = L - Lq;
+  const float invL = 1.0f / (float)L;
+  // ---- weight ring of the projections (qkv_rows_kernel's): chunk gc = group * 8 + k-step pair, slot gc & 3 ----
+  bf16x8 ring[4][2][2];
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(N.wqkv_p), 0, 0x7fffffff, 0x00020000);
+  const unsigned hpb = (unsigned)(((wave >> 1) * 6 + 3 * (wave & 1)) * 16 * 2048);
+  auto load_chunk = [&](int gc) {
+    const int g = gc / 8, ks0 = (gc % 8) * 2;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        ring[gc & 3][k][pl] = __builtin_bit_cast(
+            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, (unsigned)(lane * 16), hpb + (unsigned)((g * 16 + ks0 + k) * 2048 + pl * 1024), 0));
+  };
+  load_chunk(0);
+  load_chunk(1);
+  load_chunk(2);
+  __syncthreads();   // every wave is done with the hidden planes (its last FFN2): the y tile takes their place
+  float* Y = (float*)((char*)smem + PLANES);       // [64][YP] f32
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int r = 32 * rb + tok, m = row0 + r;
+    int b = 0, tk = 0;
+    if (m < M) {
+      b = div_rows(m, L, invL);
+      tk = m - b * L;
+    }
+    const bool park = m < M && tk >= nq0;
+    float* dst = N.xpark + ((long long)b * Lq + (tk - nq0)) * D + nb;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *(f32x4*)(Y + r * YP + nb + 8 * g) = ysum[rb][g];
+      if (park) *(f32x4*)(dst + 8 * g) = ysum[rb][g];   // the residual of the next attention block's query rows
+    }
+  }
+  __syncthreads();   // y tile
+  // ---- LN1 of the next layer: qkv_rows_kernel's arithmetic (16 lanes per row, float4 column c4 of every 64-wide chunk) ----
+  __bf16* Ah = (__bf16*)smem;   // [64][AP] (the LN2 planes are dead)
+  __bf16* Al = Ah + ROWS * AP;
+  {
+    const int c4 = t & 15, r0 = t >> 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = 32 * p + r0;
+      const bool ok = row0 + r < M;
+      f32x4 vv[4];
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) vv[kc] = *(const f32x4*)(Y + min(r, M - 1 - row0) * YP + kc * 64 + 4 * c4);
+      float sm = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) sm += (vv[kc][0] + vv[kc][1]) + (vv[kc][2] + vv[kc][3]);
+      const float mu = sf_sum16(sm) / (float)D;
+      float vs = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        const f32x4 dv = vv[kc] - mu;
+        vs += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+      }
+      const float rs = 1.0f / sqrtf(sf_sum16(vs) / (float)D + A.ln_eps);
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        const int k = kc * 64 + 4 * c4;
+        const f32x4 gm = *(const f32x4*)(GB + k), be = *(const f32x4*)(GB + D + k);
+        split4(Ah, Al, r * AP + k, ok ? (vv[kc] - mu) * rs * gm + be : zero4);
+      }
+    }
+  }
+  __syncthreads();   // LN1 planes
+  // ---- q, k, v of head `wave` for the tile's rows (qkv_rows_body's group loop, two row blocks) ----
+  const float scale = 1.0f / sqrtf((float)HD);
+  const int ao = tok * AP + 8 * kg;
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const bool splitk = (wave & 1) && g >= 1;   // the k / v blocks of odd heads: lower + upper K half (attn_body)
+    const float* bq = N.bias + g * D + wave * HD;
+    f32x4 bv4[4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) bv4[gq] = *(const f32x4*)(bq + 8 * gq + 4 * kg);
+    f32x16 acc[2], sav[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int gc = g * 8 + c;
+      if (gc + 3 < 24) load_chunk(gc + 3);
+      if (c == 4 && splitk) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          sav[rb] = acc[rb];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int ks = 2 * c + k;
+        const bf16x8 w0 = ring[gc & 3][k][0], w1 = ring[gc & 3][k][1];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const bf16x8 xh = *(const bf16x8*)(Ah + ao + rb * 32 * AP + ks * 16), xl = *(const bf16x8*)(Al + ao + rb * 32 * AP + ks * 16);
+          acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xl, acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xh, acc[rb], 0, 0, 0);
+          acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xh, acc[rb], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (splitk) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) acc[rb] = sav[rb] + acc[rb];
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int m = row0 + rb * 32 + tok;
+      if (m >= M) continue;
+      const int b = div_rows(m, L, invL), tk = m - b * L;
+      if (g < 2) {
+        if (g == 0 && tk < nq0) continue;   // q of rows that are no query rows (last layer) is never read
+        __bf16* ph = N.planes + ((long long)(b * NH + wave) * 6 + 2 * g) * PL + tk * HD + 4 * kg;
+        const float mul = g == 0 ? scale : 1.f;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 bv = bv4[gq];
+          split4(ph, ph + PL, 8 * gq,
+                 f32x4{(acc[rb][4 * gq] + bv[0]) * mul, (acc[rb][4 * gq + 1] + bv[1]) * mul, (acc[rb][4 * gq + 2] + bv[2]) * mul,
+                       (acc[rb][4 * gq + 3] + bv[3]) * mul});
+        }
+      } else {
+        __bf16* pv = N.planes + ((long long)(b * NH + wave) * 6 + 4) * PL + vpos(tk);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 bv = bv4[gq];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float v = acc[rb][4 * gq + q] + bv[q];
+            const __bf16 h = (__bf16)v;
+            const int dim = 8 * gq + 4 * kg + q;
+            pv[dim * 64] = h;
+            pv[PL + dim * 64] = (__bf16)(v - (float)h);
+          }
+        }
+      }
     }
   }
   FTS(5);
@@ -223,6 +423,30 @@ int sf_ffn_tile_ex(const float* x2, const sf_tfm_layer& w, float eps, float* y, 
   SF_TRY(sf_ensure_dyn_lds((const void*)ffn_tile_kernel, FT_LDS));
   sf_prof_begin(SF_K_FFN, st, 4.0 * M * (double)D * ffn);
   hipLaunchKernelGGL(ffn_tile_kernel, dim3((M + ROWS - 1) / ROWS), dim3(NT), FT_LDS, st, A);
+  sf_prof_end(SF_K_FFN, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// FFN of layer `w` on finished rows x2 [M][256] fused with LN1 + q|k|v of layer `wn` (M = B * L rows of B videos): fragment planes + parked
+// residual rows (xpark [B * Lq][256], a buffer other than x2) for sf_attn_core_ex
+int sf_ffn_qkv_tile_ex(const float* x2, const sf_tfm_layer& w, const sf_tfm_layer& wn, float eps, float* xpark, void* planes, int B, int L, int Lq,
+                       int ffn, hipStream_t st) {
+  if (!w.lin1_packed || !w.lin2_packed || ffn != NCH * HC || !wn.attn_in_packed)
+    return sf_set_err(-1, "invalid argument: the fused FFN + q|k|v tile launch needs packed FFN and attention weights and ffn == 1024", __FILE__, __LINE__);
+  if (!planes || !xpark || xpark == x2 || L < 1 || L > 64 || Lq < 1 || Lq > L || (long long)B * L >= (1 << 22))
+    return sf_set_err(-1, "invalid argument: fused FFN + q|k|v tiles need planes, a parking buffer other than the input, 1 <= Lq <= L <= 64", __FILE__, __LINE__);
+  static const int dbg = getenv("SF_LF_DBG") ? (atoi(getenv("SF_LF_DBG")) & 16) : 0;
+  const int M = B * L;
+  TileArgs A;
+  A.x2 = x2; A.ln_g = w.norm2_g; A.ln_b = w.norm2_b; A.ln_eps = eps; A.w1p = (const uint4*)w.lin1_packed; A.b1 = w.lin1_b;
+  A.w2p = (const uint4*)w.lin2_packed; A.b2 = w.lin2_b; A.y = nullptr; A.M = M; A.dbg = dbg;
+  NextArgs N;
+  N.ln_g = wn.norm1_g; N.ln_b = wn.norm1_b; N.wqkv_p = (const uint4*)wn.attn_in_packed; N.bias = wn.in_proj_b; N.planes = (__bf16*)planes;
+  N.xpark = xpark; N.B = B; N.L = L; N.Lq = Lq;
+  SF_TRY(sf_ensure_dyn_lds((const void*)ffn_qkv_tile_kernel, FQ_LDS));
+  sf_prof_begin(SF_K_FFN, st, 4.0 * M * (double)D * ffn + 6.0 * M * (double)D * D);
+  hipLaunchKernelGGL(ffn_qkv_tile_kernel, dim3((M + ROWS - 1) / ROWS), dim3(NT), FQ_LDS, st, A, N);
   sf_prof_end(SF_K_FFN, st);
   SF_CHECK_LAUNCH();
   return 0;

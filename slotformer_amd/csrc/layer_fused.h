@@ -23,6 +23,10 @@ int sf_attn_all_parts_ex(const float* xparts, long long xparts_stride, const sf_
                          int Lq, hipStream_t st);
 int sf_attn_all_ring_ex(const float* ring, int ring_frames, int nslots, int f0, const float* pe, const sf_tfm_layer& w, float eps,
                         float* x2, int B, int L, int Lq, hipStream_t st);
+int sf_attn_core_ex(const sf_tfm_layer& w, float* x2, void* planes, int B, int L, int Lq, hipStream_t st);
+// FFN of layer w fused with LN1 + q|k|v of layer wn on 64-row tiles (ffn_tile.hip): planes + parked residual rows for sf_attn_core_ex
+int sf_ffn_qkv_tile_ex(const float* x2, const sf_tfm_layer& w, const sf_tfm_layer& wn, float eps, float* xpark, void* planes, int B, int L, int Lq,
+                       int ffn, hipStream_t st);
 // row-tile form of the FFN block (ffn_tile.hip): x2 [M][256] finished rows -> y [M][256] finished rows, one workgroup per 64 rows
 int sf_ffn_tile_ex(const float* x2, const sf_tfm_layer& w, float eps, float* y, int M, int ffn, hipStream_t st);
 // row-tile form (attn_rows.hip): q|k|v projection on 128-row tiles of the batch + one core / out-projection workgroup per video;

@@ -179,7 +179,7 @@ def rollouter_plan(r, packed=True):
 def rollout_opts(opts):
     """dict / None -> ctypes sf_rollout_opts (None).  Keys: precision ('f32' | 'bf16x3' | 'bf16' | 'fp16' (probe) | 0..3), seam (bool),
     ffn_rows (32 | 64 | 128), attn_heads (2 | 8: heads per attention workgroup), attn_rows (0 | 128: q|k|v projection on row tiles of
-    the batch + one core workgroup per video), ffn_tile (bool: the FFN block as one workgroup per 64-row tile, finished rows); per call and per thread, never process-wide."""
+    the batch + one core workgroup per video), ffn_tile (0 | 1 | 2: the FFN block as one workgroup per 64-row tile, finished rows; 2: fused with LN1 + q|k|v of the next layer); per call and per thread, never process-wide."""
     if opts is None:
         return None
     if isinstance(opts, _lib.sf_rollout_opts):
@@ -191,7 +191,7 @@ def rollout_opts(opts):
     prec = {'f32': 0, 'bf16x3': 1, 'bf16': 2, 'fp16': 3}.get(prec, prec)
     seam = opts.get('seam', None)
     return _lib.sf_rollout_opts(int(prec), -1 if seam is None else int(bool(seam)), int(opts.get('ffn_rows', 0)), int(opts.get('attn_heads', 0)),
-                                int(opts.get('attn_rows', 0)), int(bool(opts.get('ffn_tile', 0))))
+                                int(opts.get('attn_rows', 0)), int(opts.get('ffn_tile', 0)))
 
 
 def burn_in_of(r):

@@ -178,7 +178,9 @@ class EncodeRolloutPipeline:
             tiles = wide and self.G * self.B * self.N * hist >= 2048
             self._row_tiles = bool(tiles)
             rollout_opts['attn_rows'] = int(os.environ.get('SF_PIPE_ATTN_ROWS', '128' if tiles else '0'))
-            rollout_opts['ffn_tile'] = int(os.environ.get('SF_PIPE_FFN_TILE', '1' if tiles else '0'))
+            # (2: the FFN tile launch also runs LN1 + q|k|v of the next layer on its rows -- one launch less per layer: C2 441 -> 447 k,
+            #  C5 432 -> 446 k, C4 175 -> 181 k)
+            rollout_opts['ffn_tile'] = int(os.environ.get('SF_PIPE_FFN_TILE', '2' if tiles else '0'))
         self.rollout_opts = engine.rollout_opts(rollout_opts)
         # units of fewer batches (the ramp at both ends of a run) are on the critical path of fill and drain: the latency forms
         # of the kernels (head-pair attention workgroups, narrower FFN workgroups: more, shorter workgroups per launch) -- the

@@ -76,7 +76,8 @@ def test_row_tile_attention_form(dev, B):
     a = _roll(r, x, 9, {'attn_rows': 128, 'ffn_rows': 128, 'seam': False})
     assert torch.equal(a, ref), rel_err(a, ref)
     for opts in ({'attn_rows': 128, 'ffn_rows': 64}, {'attn_rows': 128, 'ffn_rows': 32}, {'attn_rows': 128, 'attn_heads': 8},
-                 {'attn_rows': 128, 'ffn_tile': True}, {'attn_heads': 8, 'ffn_tile': True}):
+                 {'attn_rows': 128, 'ffn_tile': True}, {'attn_heads': 8, 'ffn_tile': True}, {'attn_rows': 128, 'ffn_tile': 2},
+                 {'attn_rows': 128, 'ffn_tile': 2, 'seam': False}):
         assert torch.equal(_roll(r, x, 9, opts), a), opts
     sub = _roll(r, x[1:3].contiguous(), 9, {'attn_rows': 128})
     assert torch.equal(sub, a[1:3])
@@ -124,7 +125,7 @@ def test_attention_block_kernels(dev, L, Lq, B):
 
 @pytest.mark.parametrize('opts', [{'ffn_rows': 128, 'seam': False}, {'ffn_rows': 64, 'seam': False}, {'ffn_rows': 32, 'seam': True},
                                   {'attn_heads': 8, 'ffn_rows': 128, 'seam': False}, {'attn_heads': 8, 'ffn_rows': 64},
-                                  {'attn_rows': 128, 'ffn_rows': 128, 'seam': False}, {'attn_rows': 128, 'ffn_tile': True, 'seam': False}])
+                                  {'attn_rows': 128, 'ffn_rows': 128, 'seam': False}, {'attn_rows': 128, 'ffn_tile': True, 'seam': False}, {'attn_rows': 128, 'ffn_tile': 2, 'seam': False}])
 @torch.no_grad()
 def test_throughput_settings_vs_reference_fixture(dev, opts):
     """roll_c2 (6 + 50 steps, outputs of the reference's own SlotFormer) with the kernel settings of the pipelined bench:

@@ -24,7 +24,8 @@ FORMS = {'head pairs (default)': {'ffn_rows': 64, 'seam': False},
          'all heads': {'attn_heads': 8, 'ffn_rows': 128, 'seam': False},
          'row tiles': {'attn_rows': 128, 'ffn_rows': 128, 'seam': False},
          'row tiles + FFN tiles': {'attn_rows': 128, 'ffn_tile': True, 'seam': False},
-         'all heads + FFN tiles': {'attn_heads': 8, 'ffn_tile': True, 'seam': False}}
+         'all heads + FFN tiles': {'attn_heads': 8, 'ffn_tile': True, 'seam': False},
+         'row tiles, FFN + next q|k|v fused': {'attn_rows': 128, 'ffn_tile': 2, 'seam': False}}
 
 
 def fresh():
@@ -51,10 +52,10 @@ with torch.no_grad():
             g.replay()
         torch.cuda.synchronize()
         tg = (time.perf_counter() - t0) / 5
-        print(f'{name:22s} B={B}: graph {1e3 * tg:.3f} ms ({1e6 * tg / H:.1f} us/step)', flush=True)
+        print(f'{name:34s} B={B}: graph {1e3 * tg:.3f} ms ({1e6 * tg / H:.1f} us/step)', flush=True)
     ref = outs['head pairs (default)']
     for name, o in outs.items():
-        print(f'{name:22s} equal to default: {bool(torch.equal(o, ref))}  max abs diff {(o - ref).abs().max().item():.3e}  finite {bool(torch.isfinite(o).all())}')
+        print(f'{name:34s} equal to default: {bool(torch.equal(o, ref))}  max abs diff {(o - ref).abs().max().item():.3e}  finite {bool(torch.isfinite(o).all())}')
     if int(os.environ.get('SF_LF_DBG', '0')) & 16:
         engine.rollout(roll, fresh(), 6, 3, opts=FORMS['row tiles'])
         torch.cuda.synchronize()

@@ -34,7 +34,7 @@ if f:
     per = defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = short(r['Kernel_Name'])
-        if n.startswith(('pixel_feat_stream_kernel', 'conv5x5_rows4_kernel', 'qkv_rows_kernel', 'attn_core_kernel', 'ffn_tile_kernel', 'conv5x5_halo_kernel', 'sa_attn_mfma_kernel', 'pixel_mlp_kv_kernel', 'ffn_partial_kernel', 'ffn64_parts_kernel', 'ffn_wide_parts_kernel', 'attn_oproj_kernel', 'sa_attn_fold_kernel', 'sa_slot_update_kernel', 'conv5x5_halo256_kernel')):
+        if n.startswith(('ffn_qkv_tile_kernel', 'pixel_feat_stream_kernel', 'conv5x5_rows4_kernel', 'qkv_rows_kernel', 'attn_core_kernel', 'ffn_tile_kernel', 'conv5x5_halo_kernel', 'sa_attn_mfma_kernel', 'pixel_mlp_kv_kernel', 'ffn_partial_kernel', 'ffn64_parts_kernel', 'ffn_wide_parts_kernel', 'attn_oproj_kernel', 'sa_attn_fold_kernel', 'sa_slot_update_kernel', 'conv5x5_halo256_kernel')):
             per[(n, r['Queue_Id'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     lines.append('# per-queue durations of the encode kernels  [trace_kernel_trace.csv]  (queue with the most launches of a '
                  'kernel = the CU-masked encode stream of the timed region = bench.py roofline.avg_launch_us; the others = '
@@ -139,7 +139,7 @@ def _has(pat):
 
 ROWS_FORMS = _has('attn_core_kernel')
 is_attn = (lambda n: 'qkv_rows_kernel' in n or 'attn_core_kernel' in n) if ROWS_FORMS else (lambda n: 'attn_all_kernel' in n)  # noqa: E731
-is_ffn = (lambda n: 'ffn_tile_kernel' in n or 'ffn_partial_kernel<1>' in n) if _has('ffn_tile_kernel') else (lambda n: 'ffn_wide_parts_kernel<2, 1>' in n or 'ffn_partial_kernel<1>' in n)  # noqa: E731
+is_ffn = (lambda n: 'ffn_tile_kernel' in n or 'ffn_qkv_tile_kernel' in n or 'ffn_partial_kernel<1>' in n) if (_has('ffn_tile_kernel') or _has('ffn_qkv_tile_kernel')) else (lambda n: 'ffn_wide_parts_kernel<2, 1>' in n or 'ffn_partial_kernel<1>' in n)  # noqa: E731
 
 
 def per_block(key, total_per_launch_avg, pred):
