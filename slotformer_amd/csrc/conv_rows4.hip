@@ -28,8 +28,7 @@ constexpr int PS = CH + 8;                                   // bf16 elements pe
 constexpr int HALO = HR * HWD * PS;                          // elements per halo plane
 constexpr int NT = 512;
 constexpr int NTAP = KS * KS;
-constexpr int NCOPY = 1;                                     // copies of the packed weights (see sf_pack_conv_frag_weights)
-constexpr int COPY_BYTES = NTAP * 4 * 2 * 2 * 64 * 16 + 4096 + 256;   // 409,600 + a skew that moves every copy to other L2 channels
+constexpr int FRAG_BYTES = NTAP * 4 * 2 * 2 * 64 * 16;      // 409,600: one uint4 per (tap, k-step, cout block, plane, lane)
 constexpr size_t LDS_BYTES = (size_t)2 * HALO * sizeof(__bf16);   // 156,672
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert((size_t)8 * 32 * 64 * 4 <= LDS_BYTES, "the exchange of the cin halves fits over the dead halo");
@@ -81,10 +80,9 @@ __global__ __launch_bounds__(NT) void conv5x5_rows4_kernel(const float* __restri
   constexpr int RD = 6;   // ring depth in taps: RD - 1 in flight
   bf16x8 ring[RD][2][2];
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wf), 0, 0x7fffffff, 0x00020000);
-  // every workgroup walks the taps in step, so all CUs of an XCD want the same 16 KB at the same time: the two row-pair waves of a
-  // workgroup and alternate workgroups of an XCD read different COPIES of the fragments (other L2 channels)
-  const int copy = (2 * rp + ((blockIdx.x >> 3) & 1)) % NCOPY;
-  const unsigned wbase = (unsigned)((((2 * kh) * 2 + cb) * 2) * 1024 + copy * COPY_BYTES);   // + tap * 16 KB + ks2 * 4 KB + plane * 1 KB
+  // (every workgroup walks the taps in step -- all CUs of an XCD want the same 16 KB at the same time; four copies of the fragments read by
+  //  alternate waves / workgroups, i.e. other L2 channels, changed nothing: profiles/r03_probes.txt section 12)
+  const unsigned wbase = (unsigned)((((2 * kh) * 2 + cb) * 2) * 1024);   // + tap * 16 KB + ks2 * 4 KB + plane * 1 KB
   auto load_tap = [&](int tap) {
 #pragma unroll
     for (int k = 0; k < 2; ++k)
@@ -221,18 +219,15 @@ __global__ __launch_bounds__(NT) void conv5x5_rows4_kernel(const float* __restri
   CTS(7);
 }
 
-extern "C" size_t sf_conv_frag_bytes(int Cout, int Cin, int ks) { return (size_t)NCOPY * COPY_BYTES + 0 * ((size_t)Cout * Cin * ks); }
+extern "C" size_t sf_conv_frag_bytes(int Cout, int Cin, int ks) { return (Cout == CH && Cin == CH && ks == KS) ? (size_t)FRAG_BYTES : 0; }
 
 // w_ohwi [Cout][ks][ks][Cin] (sf_pack_conv_weight_f32) -> fragment-ordered split-bf16 copy for conv5x5_rows4_kernel (64 -> 64, 5 x 5)
 extern "C" int sf_pack_conv_frag_weights(const float* w_ohwi, void* frag, int Cout, int Cin, int ks, void* stream) {
   SF_REQUIRE(w_ohwi && frag, "sf_pack_conv_frag_weights: null pointer");
   SF_REQUIRE(Cout == CH && Cin == CH && ks == KS, "sf_pack_conv_frag_weights: needs a 64 -> 64 channel 5 x 5 convolution");
   const int total = NTAP * 4 * 2 * 2 * 64;
-  for (int c = 0; c < NCOPY; ++c) {
-    hipLaunchKernelGGL(pack_conv_frag_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_ohwi,
-                       (uint4*)((char*)frag + (size_t)c * COPY_BYTES));
-    SF_CHECK_LAUNCH();
-  }
+  hipLaunchKernelGGL(pack_conv_frag_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_ohwi, (uint4*)frag);
+  SF_CHECK_LAUNCH();
   return 0;
 }
 
