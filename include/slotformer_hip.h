@@ -87,6 +87,11 @@ int sf_pack_conv_weight_f32(const float* w_oihw, float* w_ohwi, int Cout, int Ci
 int sf_pixel_feat_f32(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
                       const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, int form, void* stream);
 size_t sf_conv_frag_bytes(int Cout, int Cin, int ks);
+/* Opt-in arithmetic of the fragment-weight convolution (process-wide; default 0 = split-bf16, three MFMAs per product, like every other bf16x3
+ * kernel): 1 = activations as two fp16 terms x weights rounded to ONE fp16 (2^-12 per weight), two MFMAs per product and half the weight stream.
+ * A measured trade (profiles/r03_probes.txt section 14), not the path the parity numbers are quoted on.  Also SF_CONV_FP16X2=1. */
+int sf_set_conv_fp16x2(int on);
+int sf_get_conv_fp16x2(void);
 int sf_pack_conv_frag_weights(const float* w_ohwi, void* frag, int Cout, int Cin, int ks, void* stream);
 int sf_conv5x5_frag_f32(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W,
                         int relu, void* stream);

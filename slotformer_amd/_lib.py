@@ -135,6 +135,8 @@ SIGNATURES = {
     'sf_pack_conv_weight_f32': (I, [FP, FP, I, I, I, VP]),
     'sf_pixel_feat_f32': (I, [FP] * 10 + [I, F32, I, VP]),
     'sf_conv_frag_bytes': (SZ, [I, I, I]),
+    'sf_set_conv_fp16x2': (I, [I]),
+    'sf_get_conv_fp16x2': (I, []),
     'sf_pack_conv_frag_weights': (I, [FP, VP, I, I, I, VP]),
     'sf_conv5x5_frag_f32': (I, [FP, VP, FP, FP, FP, I, I, I, I, VP]),
     'sf_conv_transpose2d_nhwc_f32': (I, [FP, FP, FP, FP, I, I, I, I, I, I, I, I, VP]),

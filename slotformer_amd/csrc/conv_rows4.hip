@@ -20,6 +20,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 constexpr int CH = 64, KS = 5, PAD = 2, TW = 64, TR = 4;     // channels, taps, tile width / rows
@@ -29,6 +31,7 @@ constexpr int HALO = HR * HWD * PS;                          // elements per hal
 constexpr int NT = 512;
 constexpr int NTAP = KS * KS;
 constexpr int FRAG_BYTES = NTAP * 4 * 2 * 2 * 64 * 16;      // 409,600: one uint4 per (tap, k-step, cout block, plane, lane)
+constexpr int FRAG16_BYTES = FRAG_BYTES / 2;                // + the single-fp16 copy (one plane)
 constexpr size_t LDS_BYTES = (size_t)2 * HALO * sizeof(__bf16);   // 156,672
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert((size_t)8 * 32 * 64 * 4 <= LDS_BYTES, "the exchange of the cin halves fits over the dead halo");
@@ -52,11 +55,25 @@ __global__ void pack_conv_frag_kernel(const float* __restrict__ w, uint4* __rest
     o.h[j] = plane ? (__bf16)(a - (float)ah) : ah;
   }
   out[idx] = o.u;
+  // the single-fp16 copy of the same fragments (F16X2 form of the kernel) behind the split-bf16 planes: uint4 index FRAG_BYTES / 16 + (((tap * 4 + ks) * 2 + cb) * 64 + lane)
+  if (plane == 0) {
+    union {
+      _Float16 h[8];
+      uint4 u;
+    } q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q.h[j] = (_Float16)src[j];
+    out[FRAG_BYTES / 16 + (((tap * 4 + ks) * 2 + cb) * 64 + lane)] = q.u;
+  }
 }
 
 __device__ long long cr_ts[16];   // phase timestamps of workgroup 0 (SF_CONV_DBG=1; sf_debug_read_ts_conv)
 #define CTS(i) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) cr_ts[i] = wall_clock64(); } while (0)
 
+// F16X2 (opt-in, sf_set_conv_fp16x2 / SF_CONV_FP16X2=1; NOT the default arithmetic): the activations split into two fp16 terms (22 mantissa
+// bits), the weights rounded to ONE fp16 (11 bits: 2^-12 relative per weight) -- two MFMAs per product instead of three and half the weight
+// stream.  Measured error and speed: profiles/r03_probes.txt section 14.
+template <bool F16X2>
 __global__ __launch_bounds__(NT) void conv5x5_rows4_kernel(const float* __restrict__ in, const uint4* __restrict__ wf,
                                                            const float* __restrict__ bias, const float* __restrict__ add,
                                                            float* __restrict__ out, int H, int relu, int dbg) {
@@ -78,18 +95,25 @@ __global__ __launch_bounds__(NT) void conv5x5_rows4_kernel(const float* __restri
 
   // ---- weight ring: slot = tap & 3 holds the tap's 2 k-steps x (hi, lo) of this wave's (cout block, cin half) ----
   constexpr int RD = 6;   // ring depth in taps: RD - 1 in flight
-  bf16x8 ring[RD][2][2];
+  bf16x8 ring[RD][2][2];   // (F16X2: [.][k][0] only, holding 8 fp16)
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wf), 0, 0x7fffffff, 0x00020000);
   // (every workgroup walks the taps in step -- all CUs of an XCD want the same 16 KB at the same time; four copies of the fragments read by
   //  alternate waves / workgroups, i.e. other L2 channels, changed nothing: profiles/r03_probes.txt section 12)
-  const unsigned wbase = (unsigned)((((2 * kh) * 2 + cb) * 2) * 1024);   // + tap * 16 KB + ks2 * 4 KB + plane * 1 KB
+  const unsigned wbase = F16X2 ? (unsigned)(FRAG_BYTES + ((2 * kh) * 2 + cb) * 1024)            // + tap * 8 KB + ks2 * 2 KB
+                               : (unsigned)((((2 * kh) * 2 + cb) * 2) * 1024);                  // + tap * 16 KB + ks2 * 4 KB + plane * 1 KB
   auto load_tap = [&](int tap) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 2; ++k) {
+      if constexpr (F16X2) {
+        ring[tap % RD][k][0] = __builtin_bit_cast(
+            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, (unsigned)(lane * 16), wbase + (unsigned)(tap * 8192 + k * 2048), 0));
+      } else {
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-        ring[tap % RD][k][pl] = __builtin_bit_cast(
-            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, (unsigned)(lane * 16), wbase + (unsigned)(tap * 16384 + k * 4096 + pl * 1024), 0));
+        for (int pl = 0; pl < 2; ++pl)
+          ring[tap % RD][k][pl] = __builtin_bit_cast(
+              bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, (unsigned)(lane * 16), wbase + (unsigned)(tap * 16384 + k * 4096 + pl * 1024), 0));
+      }
+    }
   };
   CTS(0);
 #pragma unroll
@@ -116,10 +140,17 @@ __global__ __launch_bounds__(NT) void conv5x5_rows4_kernel(const float* __restri
       const int idx = t + NT * i;
       if (idx < TOTAL) {
         const int off = (idx >> 4) * PS + 4 * (idx & 15);
-        const bf16x4 hi = __builtin_convertvector(hv[i], bf16x4);
-        const bf16x4 lo = __builtin_convertvector(hv[i] - __builtin_convertvector(hi, f32x4), bf16x4);
-        *(bf16x4*)(Hh + off) = hi;
-        *(bf16x4*)(Hl + off) = lo;
+        if constexpr (F16X2) {
+          const f16x4 hi = __builtin_convertvector(hv[i], f16x4);
+          const f16x4 lo = __builtin_convertvector(hv[i] - __builtin_convertvector(hi, f32x4), f16x4);
+          *(f16x4*)(Hh + off) = hi;
+          *(f16x4*)(Hl + off) = lo;
+        } else {
+          const bf16x4 hi = __builtin_convertvector(hv[i], bf16x4);
+          const bf16x4 lo = __builtin_convertvector(hv[i] - __builtin_convertvector(hi, f32x4), bf16x4);
+          *(bf16x4*)(Hh + off) = hi;
+          *(bf16x4*)(Hl + off) = lo;
+        }
       }
     }
   }
@@ -153,17 +184,29 @@ __global__ __launch_bounds__(NT) void conv5x5_rows4_kernel(const float* __restri
     const int tap = s >> 1, k = s & 1;
     if (k == 0 && tap + RD - 1 < NTAP) load_tap(tap + RD - 1);
     if (s + 1 < 2 * NTAP) read_x(s + 1, (s + 1) & 1);
-    const bf16x8 wh = ring[tap % RD][k][0], wl = ring[tap % RD][k][1];
+    if constexpr (F16X2) {
+      const f16x8 w = __builtin_bit_cast(f16x8, ring[tap % RD][k][0]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf[s & 1][i][1], acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xf[s & 1][i][0], acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf[s & 1][i][0], acc[i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, __builtin_bit_cast(f16x8, xf[s & 1][i][1]), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, __builtin_bit_cast(f16x8, xf[s & 1][i][0]), acc[i], 0, 0, 0);
+      }
+      if (k == 0 && tap + RD - 1 < NTAP) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      if (s + 1 < 2 * NTAP) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    } else {
+      const bf16x8 wh = ring[tap % RD][k][0], wl = ring[tap % RD][k][1];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf[s & 1][i][1], acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xf[s & 1][i][0], acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xf[s & 1][i][0], acc[i], 0, 0, 0);
+      }
+      // issue order inside the half-tap: the weight requests, the 8 fragment reads of the NEXT half-tap, then the 12 MFMAs
+      if (k == 0 && tap + RD - 1 < NTAP) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+      if (s + 1 < 2 * NTAP) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
     }
-    // issue order inside the half-tap: the weight requests, the 8 fragment reads of the NEXT half-tap, then the 12 MFMAs
-    if (k == 0 && tap + RD - 1 < NTAP) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
-    if (s + 1 < 2 * NTAP) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
     __builtin_amdgcn_sched_barrier(0);   // requests stay in their half-tap
     if (s == 9) CTS(3);
     if (s == 29) CTS(4);
@@ -219,7 +262,21 @@ __global__ __launch_bounds__(NT) void conv5x5_rows4_kernel(const float* __restri
   CTS(7);
 }
 
-extern "C" size_t sf_conv_frag_bytes(int Cout, int Cin, int ks) { return (Cout == CH && Cin == CH && ks == KS) ? (size_t)FRAG_BYTES : 0; }
+extern "C" size_t sf_conv_frag_bytes(int Cout, int Cin, int ks) { return (Cout == CH && Cin == CH && ks == KS) ? (size_t)FRAG_BYTES + FRAG16_BYTES : 0; }
+
+// opt-in arithmetic of the 4-row-tile convolution: 0 (default) split-bf16, three products; 1 activations as two fp16 terms x weights as ONE fp16, two products
+static int g_conv_fp16x2 = -1;
+extern "C" int sf_set_conv_fp16x2(int on) {
+  g_conv_fp16x2 = on ? 1 : 0;
+  return 0;
+}
+extern "C" int sf_get_conv_fp16x2(void) {
+  if (g_conv_fp16x2 < 0) {
+    const char* e = getenv("SF_CONV_FP16X2");
+    g_conv_fp16x2 = (e && e[0] == '1') ? 1 : 0;
+  }
+  return g_conv_fp16x2;
+}
 
 // w_ohwi [Cout][ks][ks][Cin] (sf_pack_conv_weight_f32) -> fragment-ordered split-bf16 copy for conv5x5_rows4_kernel (64 -> 64, 5 x 5)
 extern "C" int sf_pack_conv_frag_weights(const float* w_ohwi, void* frag, int Cout, int Cin, int ks, void* stream) {
@@ -235,10 +292,15 @@ extern "C" int sf_pack_conv_frag_weights(const float* w_ohwi, void* frag, int Co
 int sf_conv5x5_rows4_ex(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W,
                         int Cin, int Cout, int ks, int relu, hipStream_t st) {
   if (!w_frag || W != TW || Cin != CH || Cout != CH || ks != KS || (H % TR) != 0 || F <= 0 || sf_get_precision() != 1) return 1;
-  SF_TRY(sf_ensure_dyn_lds((const void*)conv5x5_rows4_kernel, LDS_BYTES));
-  sf_prof_begin(SF_K_CONV_NHWC, st, 2.0 * (double)F * H * W * Cout * ks * ks * Cin);
   static const int dbg = getenv("SF_CONV_DBG") ? atoi(getenv("SF_CONV_DBG")) : 0;
-  hipLaunchKernelGGL(conv5x5_rows4_kernel, dim3(F * (H / TR)), dim3(NT), LDS_BYTES, st, in, (const uint4*)w_frag, bias, add, out, H, relu, dbg);
+  sf_prof_begin(SF_K_CONV_NHWC, st, 2.0 * (double)F * H * W * Cout * ks * ks * Cin);
+  if (sf_get_conv_fp16x2()) {
+    SF_TRY(sf_ensure_dyn_lds((const void*)conv5x5_rows4_kernel<true>, LDS_BYTES));
+    hipLaunchKernelGGL(conv5x5_rows4_kernel<true>, dim3(F * (H / TR)), dim3(NT), LDS_BYTES, st, in, (const uint4*)w_frag, bias, add, out, H, relu, dbg);
+  } else {
+    SF_TRY(sf_ensure_dyn_lds((const void*)conv5x5_rows4_kernel<false>, LDS_BYTES));
+    hipLaunchKernelGGL(conv5x5_rows4_kernel<false>, dim3(F * (H / TR)), dim3(NT), LDS_BYTES, st, in, (const uint4*)w_frag, bias, add, out, H, relu, dbg);
+  }
   sf_prof_end(SF_K_CONV_NHWC, st);
   SF_CHECK_LAUNCH();
   return 0;

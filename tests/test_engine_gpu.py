@@ -71,6 +71,36 @@ def test_savi_golden(dev, name, cfg, B, T, seed, noise_seed):
     assert rel_err(out['post_slots'], g['post_slots']) < 5e-5
 
 
+@pytest.mark.parametrize('name,cfg,B,T,seed,noise_seed', [
+    ('savi_c1', gu.C1_SAVI, 2, 3, 101, None),
+    ('savi_c2', gu.C2_SAVI, 2, 3, 103, 7),
+])
+@torch.no_grad()
+def test_savi_golden_conv_fp16x2_optin(dev, name, cfg, B, T, seed, noise_seed):
+    """The same fixtures under the OPT-IN convolution arithmetic (two fp16 products, weights rounded to fp16; profiles/r03_probes.txt
+    section 14): inside the 1e-3 bar with a stated margin (measured 6.1e-5 / 4.7e-5), outside the default arithmetic's 5e-5."""
+    from slotformer_amd import _lib
+    lib = _lib.lib()
+    assert lib.sf_get_conv_fp16x2() == 0, 'the suite runs on the default arithmetic; SF_CONV_FP16X2 must not be set'
+    g = gu.load_golden(name)
+    m, sd = build(cfg, g, seed, dev)
+    m.testing = True
+    data = {'img': gu.seeded_img(B, T, cfg['resolution'][0]).to(dev)}
+    if noise_seed is not None:
+        N, D = cfg['slot_dict']['num_slots'], cfg['slot_dict']['slot_size']
+        data['noise'] = gu.seeded_normal((B, T, N, D), noise_seed).to(dev)
+    lib.sf_set_conv_fp16x2(1)
+    try:
+        out = m(data)
+        torch.cuda.synchronize()
+    finally:
+        lib.sf_set_conv_fp16x2(0)
+    e = rel_err(out['post_slots'], g['post_slots'])
+    print(name, 'fp16x2 rel err', e)
+    assert e < 1.5e-4
+    assert rel_err(m(data)['post_slots'], g['post_slots']) < 5e-5
+
+
 @torch.no_grad()
 def test_savi_chunked_golden(dev):
     """Long-video path (savi.py:431-463): golden produced by the reference's own chunking."""
