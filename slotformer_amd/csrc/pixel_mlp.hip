@@ -246,7 +246,8 @@ int sf_pixel_mlp_kv_ex(const float* x, const float* ln0_g, const float* ln0_b, c
 bool sf_pixel_mlp_feat_ok(int C0, int C1) { return C0 == PM_C0 && C1 == PM_C1; }
 
 static int sf_pixel_feat_stream_launch(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
-                                       const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st);
+                                       const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st,
+                                       int tile = 0);
 
 // encoder_out_layer + norm_inputs only: feat [M][128] = LN(fc2(relu(fc1(LN(x)))))
 int sf_pixel_mlp_feat_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
@@ -433,29 +434,39 @@ int sf_pixel_mlp_feat192_ex(const float* x, const float* ln0_g, const float* ln0
 // packed copy needed -- the rows of the next tile are requested while the current one is in fc1, and its LayerNorm(64) planes are
 // written while the current one is in fc2.  Same products in the same order, same LayerNorm reductions: the bits of
 // pixel_mlp_kv_kernel<true>.
+// TR = 64 (form 2): the same kernel on 64-pixel tiles with four waves (wave = column block, both row blocks), 55 KB of LDS and 256 threads: TWO
+// workgroups per CU, each on its own chain of barrier-separated phases -- one computes while the other waits.  Same bits (every row's arithmetic
+// is its own).
 namespace {
-constexpr int PF_TPW = 4;                                  // tiles per workgroup
-constexpr size_t PF_A0 = (size_t)2 * PM_ROWS * PM_LB0 * 2;  // LN(64)(x) planes hi | lo: 36,864 B
-constexpr size_t PF_H1 = (size_t)2 * PM_ROWS * PM_LB1 * 2;  // relu(fc1) planes hi | lo: 69,632 B; later the f32 fc2 tile [128][PM_H2S]
-constexpr size_t PF_LDS = PF_A0 + PF_H1 + 4 * PM_C1 * sizeof(float);
-static_assert((size_t)PM_ROWS * PM_H2S * 4 <= PF_H1, "the f32 tile fits over the hidden planes");
+constexpr int PF_PIX = 512;                                // pixels per workgroup (tiles per workgroup = PF_PIX / TR)
+template <int TR> struct PfCfg {
+  static constexpr int NT = 4 * TR;                                      // 512 threads for 128-pixel tiles, 256 for 64
+  static constexpr int TPW = PF_PIX / TR;
+  static constexpr size_t A0 = (size_t)2 * TR * PM_LB0 * 2;              // LN(64)(x) planes hi | lo: 36,864 B at TR = 128
+  static constexpr size_t H1 = (size_t)2 * TR * PM_LB1 * 2;              // relu(fc1) planes hi | lo: 69,632 B; later the f32 fc2 tile [TR][PM_H2S]
+  static constexpr size_t LDS = A0 + H1 + 4 * PM_C1 * sizeof(float);
+  static_assert((size_t)TR * PM_H2S * 4 <= H1, "the f32 tile fits over the hidden planes");
+};
 }  // namespace
 
-__global__ __launch_bounds__(PM_NT) void pixel_feat_stream_kernel(
+template <int TR>
+__global__ __launch_bounds__(PfCfg<TR>::NT) void pixel_feat_stream_kernel(
     const float* __restrict__ x, const float* __restrict__ ln0_g, const float* __restrict__ ln0_b, const float* __restrict__ w1,
     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ ln1_g,
-    const float* __restrict__ ln1_b, float* __restrict__ feat, int M, float eps) {
+    const float* __restrict__ ln1_b, float* __restrict__ feat, int M, float eps, int PF_TPW) {
+  constexpr int NT = PfCfg<TR>::NT, RPP = NT / 16;   // RPP: rows per LayerNorm(64) pass
+  constexpr size_t PF_A0 = PfCfg<TR>::A0, PF_H1 = PfCfg<TR>::H1;
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
-  __bf16* Ah = lds;                                   // [128][PM_LB0]
-  __bf16* Al = Ah + PM_ROWS * PM_LB0;
-  __bf16* Hh = (__bf16*)((char*)lds + PF_A0);         // [128][PM_LB1]
-  __bf16* Hl = Hh + PM_ROWS * PM_LB1;
-  float* H2 = (float*)Hh;                             // [128][PM_H2S] f32 (over the hidden planes)
+  __bf16* Ah = lds;                                   // [TR][PM_LB0]
+  __bf16* Al = Ah + TR * PM_LB0;
+  __bf16* Hh = (__bf16*)((char*)lds + PF_A0);         // [TR][PM_LB1]
+  __bf16* Hl = Hh + TR * PM_LB1;
+  float* H2 = (float*)Hh;                             // [TR][PM_H2S] f32 (over the hidden planes)
   float* PV = (float*)((char*)lds + PF_A0 + PF_H1);   // b1 | b2 | ln1 gamma | ln1 beta
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int cb = wave & 3, rh = wave >> 2;            // column block of the 128-wide outputs, half of the tile's rows
-  const int ntiles = (M + PM_ROWS - 1) / PM_ROWS;
+  const int ntiles = (M + TR - 1) / TR;
   const int tile0 = blockIdx.x * PF_TPW;
 
   auto split4 = [&](f32x4 v, bf16x4& hi, bf16x4& lo) {
@@ -464,15 +475,16 @@ __global__ __launch_bounds__(PM_NT) void pixel_feat_stream_kernel(
   };
   const int c4 = t & 15, r0 = t >> 4;
   const f32x4 g0 = *(const f32x4*)(ln0_g + 4 * c4), be0 = *(const f32x4*)(ln0_b + 4 * c4);
-  {
-    const float* src = (t < 128) ? b1 : (t < 256) ? b2 : (t < 384) ? ln1_g : ln1_b;
-    PV[t] = src[t & 127];
+#pragma unroll
+  for (int u = t; u < 512; u += NT) {
+    const float* src = (u < 128) ? b1 : (u < 256) ? b2 : (u < 384) ? ln1_g : ln1_b;
+    PV[u] = src[u & 127];
   }
   f32x4 xr[4];
   auto request = [&](int tile) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = min(tile * PM_ROWS + r0 + 32 * i, M - 1);
+      const int row = min(tile * TR + r0 + RPP * i, M - 1);
       xr[i] = *(const f32x4*)(x + (long long)row * PM_C0 + 4 * c4);
     }
   };
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(PM_NT) void pixel_feat_stream_kernel(
       const float rstd = 1.0f / sqrtf(vs * (1.0f / PM_C0) + eps);
       bf16x4 hi, lo;
       split4(dv * rstd * g0 + be0, hi, lo);
-      const int off = (r0 + 32 * i) * PM_LB0 + 4 * c4;
+      const int off = (r0 + RPP * i) * PM_LB0 + 4 * c4;
       *(bf16x4*)(Ah + off) = hi;
       *(bf16x4*)(Al + off) = lo;
     }
@@ -602,7 +614,7 @@ __global__ __launch_bounds__(PM_NT) void pixel_feat_stream_kernel(
       vs += sf_dpp<0xB1>(vs);
       vs += sf_dpp<0x4E>(vs);
       const float rstd = 1.0f / sqrtf(vs * (1.0f / PM_C1) + eps);
-      const int grow = tile * PM_ROWS + row;
+      const int grow = tile * TR + row;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int c = part * 32 + 4 * i;
@@ -614,29 +626,46 @@ __global__ __launch_bounds__(PM_NT) void pixel_feat_stream_kernel(
   }
 }
 
-static int sf_pixel_feat_stream_launch(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
-                                       const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st) {
-  static_assert(PF_LDS <= 160 * 1024, "LDS budget");
-  SF_TRY(sf_ensure_dyn_lds((const void*)pixel_feat_stream_kernel, PF_LDS));
-  const int ntiles = (M + PM_ROWS - 1) / PM_ROWS;
+template <int TR>
+static int sf_pixel_feat_stream_launch_t(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
+                                         const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st) {
+  using Cfg = PfCfg<TR>;
+  static_assert(Cfg::LDS <= 160 * 1024, "LDS budget");
+  SF_TRY(sf_ensure_dyn_lds((const void*)pixel_feat_stream_kernel<TR>, Cfg::LDS));
+  const int ntiles = (M + TR - 1) / TR;
   sf_prof_begin(SF_K_LINEAR, st, 2.0 * M * (double)(PM_C0 * PM_C1 + PM_C1 * PM_C1));
-  hipLaunchKernelGGL(pixel_feat_stream_kernel, dim3((ntiles + PF_TPW - 1) / PF_TPW), dim3(PM_NT), PF_LDS, st, x, ln0_g, ln0_b, w1, b1, w2, b2,
-                     ln1_g, ln1_b, feat, M, eps);
+  static const int env_pix = getenv("SF_PIXEL_PIX") ? atoi(getenv("SF_PIXEL_PIX")) : 0;
+  const int tpw = env_pix >= TR ? env_pix / TR : Cfg::TPW;
+  hipLaunchKernelGGL(pixel_feat_stream_kernel<TR>, dim3((ntiles + tpw - 1) / tpw), dim3(Cfg::NT), Cfg::LDS, st, x, ln0_g, ln0_b, w1, b1,
+                     w2, b2, ln1_g, ln1_b, feat, M, eps, tpw);
   sf_prof_end(SF_K_LINEAR, st);
   SF_CHECK_LAUNCH();
   return 0;
 }
 
+// tile: 128 (one workgroup per CU) or 64 (two); 0 = the default (SF_PIXEL_TILE overrides it)
+static int sf_pixel_feat_stream_launch(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
+                                       const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st,
+                                       int tile) {
+  static const int env_tile = [] {
+    const char* e = getenv("SF_PIXEL_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  if (tile == 0) tile = env_tile ? env_tile : 64;
+  if (tile == 64) return sf_pixel_feat_stream_launch_t<64>(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st);
+  return sf_pixel_feat_stream_launch_t<128>(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st);
+}
+
 // Kernel-level entry point (include/slotformer_hip.h): feat [M][128] = LN(128)(fc2(relu(fc1(LN(64)(x))))) -- encoder_out_layer followed by
 // SlotAttention.norm_inputs (savi.py:245-250, 66-70).  form 0: one 128-pixel tile per workgroup, weights through LDS; 1: weights resident in
-// registers, four tiles per workgroup (the form the encode uses).  Same bits.
+// registers, four tiles per workgroup; 2: the same on 64-pixel tiles, 256 threads, two workgroups per CU.  Same bits.
 extern "C" int sf_pixel_feat_f32(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
                                  const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, int form, void* stream) {
   SF_REQUIRE(x && ln0_g && ln0_b && w1 && b1 && w2 && b2 && ln1_g && ln1_b && feat && M > 0, "sf_pixel_feat_f32: null pointer / empty problem");
-  SF_REQUIRE(form == 0 || form == 1, "sf_pixel_feat_f32: form must be 0 or 1");
+  SF_REQUIRE(form >= 0 && form <= 2, "sf_pixel_feat_f32: form must be 0, 1 or 2");
   SF_REQUIRE(sf_get_precision() == 1, "sf_pixel_feat_f32: split-bf16 mode only");
   hipStream_t st = (hipStream_t)stream;
-  if (form == 1) return sf_pixel_feat_stream_launch(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st);
+  if (form >= 1) return sf_pixel_feat_stream_launch(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st, form == 1 ? 128 : 64);
   SF_TRY(sf_ensure_dyn_lds((const void*)pixel_mlp_kv_kernel<true>, (size_t)(PM_LDS)));
   hipLaunchKernelGGL(pixel_mlp_kv_kernel<true>, dim3((M + PM_ROWS - 1) / PM_ROWS), dim3(PM_NT), PM_LDS, st, x, ln0_g, ln0_b, w1, b1, w2, b2,
                      ln1_g, ln1_b, nullptr, feat, M, eps);

@@ -92,7 +92,7 @@ def test_conv_nhwc(dev, relu, with_add, precision):
 @pytest.mark.parametrize('M', [4096 * 3, 128 * 5 + 37, 100])
 def test_pixel_feat_forms(dev, M):
     """Per-pixel chain up to the normalised Slot-Attention inputs (pixel_mlp.hip): the tile-at-a-time kernel and the streaming kernel
-    (weights resident in registers, four tiles per workgroup; ragged last tile / last workgroup) against PyTorch, and bit for bit."""
+    (weights resident in registers, 128- or 64-pixel tiles; ragged last tile / last workgroup) against PyTorch, and bit for bit."""
     from slotformer_amd import _lib
     lib = _lib.lib()
     x = rnd(M, 64, seed=1)
@@ -103,13 +103,14 @@ def test_pixel_feat_forms(dev, M):
     ref = F.layer_norm(F.linear(F.relu(F.linear(F.layer_norm(x, (64, ), g0, b0), w1, bb1)), w2, bb2), (128, ), g1, b1)
     d = [v.to(dev).contiguous() for v in (x, g0, b0, w1, bb1, w2, bb2, g1, b1)]
     outs = []
-    for form in (0, 1):
+    for form in (0, 1, 2):
         out = torch.full((M, 128), float('nan'), device=dev)
         _lib.check(lib.sf_pixel_feat_f32(*[v.data_ptr() for v in d], out.data_ptr(), M, 1e-5, form, torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         close(out, ref, rtol=1e-4, atol=1e-4)
         outs.append(out)
     assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
+    assert torch.equal(outs[0], outs[2]), (outs[0] - outs[2]).abs().max().item()
 
 
 @pytest.mark.parametrize('relu,with_add,H', [(True, False, 64), (False, True, 64), (True, False, 8)])

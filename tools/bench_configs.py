@@ -47,8 +47,15 @@ def run(name, scfg, rcfg, B, T, H, single=False, steve=False):
     hist = rd['history_len']
     t_roll = timeit(lambda: roll(slots[:, -hist:].contiguous(), H))
     fps = B * (T + H) / (t_enc + t_roll)
+    x_in = slots[:, -hist:].contiguous()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y_g = roll(x_in, H)
+    t_graph = timeit(g.replay)
+    same = bool(torch.equal(y_g, roll(x_in, H)))
     print(f'{name:34s} B={B:3d} {res}x{res} T={T} H={H}: encode {1e3 * t_enc:7.2f} ms  rollout {1e3 * t_roll:7.2f} ms (eager)  '
-          f'-> {fps:9.0f} frames/s   [{1e6 * t_roll / H:.0f} us/step]')
+          f'-> {fps:9.0f} frames/s   [{1e6 * t_roll / H:.0f} us/step]   hipGraph replay of the same rollout {1e3 * t_graph:7.2f} ms '
+          f'[{1e6 * t_graph / H:.0f} us/step, same bits {same}]')
 
 
 if __name__ == '__main__':
