@@ -83,7 +83,8 @@ int sf_pack_conv_weight_f32(const float* w_oihw, float* w_ohwi, int Cout, int Ci
  * split-bf16 mode; csrc/conv_rows4.hip).  relu / add as sf_conv2d_nhwc_f32. */
 /* Per-pixel chain of the SAVi encoder up to the normalised Slot-Attention inputs (64 -> 128 -> 128 channels; savi.py:245-250, 66-70):
  * feat [M][128] = LN(fc2(relu(fc1(LN(x))))), x [M][64]; torch-layout weights w1 [128][64], w2 [128][128].  form 0: one 128-pixel tile per
- * workgroup, weights through LDS; form 1: weights resident in registers, four tiles per workgroup (csrc/pixel_mlp.hip).  Same bits. */
+ * workgroup, weights through LDS; form 1: weights resident in registers, four tiles per workgroup; form 2 (the one the encode uses): the same on
+ * 64-pixel tiles with 256 threads, two workgroups per CU (csrc/pixel_mlp.hip).  Same bits. */
 int sf_pixel_feat_f32(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
                       const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, int form, void* stream);
 size_t sf_conv_frag_bytes(int Cout, int Cin, int ks);
