@@ -331,6 +331,7 @@ __global__ __launch_bounds__(NT) void ffn_qkv_tile_kernel(TileArgs A, NextArgs N
     }
   }
   __syncthreads();   // LN1 planes
+  FTS(6);
   // ---- q, k, v of head `wave` for the tile's rows (qkv_rows_body's group loop, two row blocks) ----
   const float scale = 1.0f / sqrtf((float)HD);
   const int ao = tok * AP + 8 * kg;
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(NT) void ffn_qkv_tile_kernel(TileArgs A, NextArgs N
         }
       }
     }
+    FTS(7 + g);
   }
   FTS(5);
 }

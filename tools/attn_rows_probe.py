@@ -72,3 +72,9 @@ with torch.no_grad():
         lib.sf_debug_read_ts_ffn_tile(o2)
         t2 = list(o2)
         print('ffn_tile ticks (10 ns):', [t - t2[0] for t in t2[:6]], '(0 entry, 1 LN planes, 2 hidden planes of chunk 0, 3 chunk 0 done, 4 all chunks, 5 end)')
+        engine.rollout(roll, fresh(), 6, 3, opts=FORMS['row tiles, FFN + next q|k|v fused'])
+        torch.cuda.synchronize()
+        lib.sf_debug_read_ts_ffn_tile(o2)
+        t2 = list(o2)
+        print('ffn_qkv_tile ticks (10 ns):', [t - t2[0] for t in t2[:10]],
+              '(0 entry, 1 LN2 planes, 2 hidden planes of chunk 0, 3 chunk 0 done, 4 all chunks, 5 end, 6 y tile + LN1 planes, 7 / 8 / 9 q / k / v written)')
