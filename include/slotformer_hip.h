@@ -627,6 +627,8 @@ int sf_device_synchronize(void);
  * n_words 32-bit words): partitions the GPU between the encode of batch i+1 and the rollout of batch i. */
 int sf_stream_create_cu_mask(void** stream_out, const unsigned int* cu_mask, int n_words);
 int sf_stream_destroy(void* stream);
+/* One wave busy for `us` microseconds on `stream` (1..100000): two of them on two streams tell whether the streams share a hardware queue. */
+int sf_debug_spin(int us, void* stream);
 int sf_slot_attn_iter_f32_host(const float* k_host, const float* v_host, int ld, long long batch_stride,
                                const float* q_host, float* part_num_host, float* part_den_host, float* attn_out_host,
                                int B, int HW, int N, int D, float scale, float eps, void* stream);

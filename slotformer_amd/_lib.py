@@ -233,6 +233,7 @@ SIGNATURES = {
     'sf_device_download': (I, [VP, VP, SZ]),
     'sf_device_synchronize': (I, []),
     'sf_stream_create_cu_mask': (I, [C.POINTER(VP), C.POINTER(C.c_uint), I]),
+    'sf_debug_spin': (I, [I, VP]),
     'sf_stream_destroy': (I, [VP]),
     'sf_slot_attn_iter_f32_host': (I, [FP, FP, I, LL, FP, FP, FP, FP, I, I, I, I, F32, F32, VP]),
     'sf_rollout_f32_host': (I, [C.POINTER(sf_rollouter), FP, I, I, I, VP, SZ, VP]),

@@ -151,6 +151,19 @@ size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B) {
 extern "C" int sf_get_seam_fused(void);
 
 // a[0..n) = b[0..n) = 0 (n a multiple of 4, both 16-byte aligned)
+// One wave kept busy for a given time (wall_clock64: the constant 100 MHz counter).  The pipeline launches two of them on two streams to
+// find out whether the streams share a hardware queue (then they run one after the other): pipeline.py _pick_free_streams.
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+extern "C" int sf_debug_spin(int us, void* stream) {
+  SF_REQUIRE(us > 0 && us <= 100000, "sf_debug_spin: 1..100000 microseconds");
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)us * 100);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
 __global__ void zero_f32_kernel(float* a, float* b, long long n) {
   const long long i = 4 * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
   if (i < n) {

@@ -42,10 +42,17 @@ plan signature).
 import ctypes as C
 import math
 import os
+import threading
+import time
 
 import torch
 
 from . import _lib, engine
+
+_STREAMS = {}                      # process-wide stream pool (EncodeRolloutPipeline._masked_stream / _pool_stream)
+_STREAMS_LOCK = threading.Lock()
+_POOL = bool(int(os.environ.get('SF_PIPE_STREAM_POOL', '1')))
+_POOL_KINDS = os.environ.get('SF_POOL_KINDS', 'masked,free,side,out,copy,roll,lane').split(',')
 
 
 def encode_mask_words(spec):
@@ -145,7 +152,7 @@ class EncodeRolloutPipeline:
         if steal_steps is None:
             steal_steps = float(os.environ.get('SF_PIPE_STEAL', {'pair': 0, 'two': 1, 'three': 0}.get(partition, 1)))
         self.steal = max(0.0, min(float(steal_steps), float(self.T)))   # may be fractional: see _steal_of
-        self._masked = []
+        self._masked_taken = {}
         self._lib = _lib.lib()
         # 'pair': the encode partition's CU mask (the rollout streams get the complement)
         self._enc_words_pair = ENC_WORDS_P
@@ -237,13 +244,13 @@ class EncodeRolloutPipeline:
                 self._close_streams()
                 self.s_roll, self.lanes, self.roll_streams = None, [], []
         if self.s_roll is None:
-            self.s_roll = torch.cuda.Stream(device=self.dev, priority=-1)
-            self.lanes = [(torch.cuda.Stream(device=self.dev), 0, self.B)]
+            self.s_roll = self._pool_stream('roll', priority=-1)
+            self.lanes = [(self._pool_stream('lane'), 0, self.B)]
             self.encode_cus = self.rollout_cus = 256
         if not self.roll_streams:
             self.roll_streams = [self.s_roll]
         # unmasked streams for the drain units
-        self.s_free = [torch.cuda.Stream(device=self.dev) for _ in range(2)] if len(self.roll_streams) > 1 else []
+        self.s_free = self._pick_free_streams(2) if len(self.roll_streams) > 1 else []
         self.s_enc = self.lanes[0][0]
         self.fill_whole_chip = True      # the first encode(s) of a run on the calling stream (all CUs)
         # (group 1: a second whole-chip encode was measured worse, 311 vs 323 k frames/s at 20 steps; with group 2 the first
@@ -314,16 +321,66 @@ class EncodeRolloutPipeline:
         return 4 if share >= 0.4 else max(1, round(8 * share))
 
     def _masked_stream(self, words):
-        arr = (C.c_uint * 8)(*words)
-        h = C.c_void_p()
-        _lib.check(self._lib.sf_stream_create_cu_mask(C.byref(h), arr, 8))
-        self._masked.append(h)
-        return torch.cuda.ExternalStream(h.value, device=self.dev)
+        """A CU-masked stream from the process-wide pool (_STREAMS): the k-th stream with these mask words a pipeline asks for is the same
+        object for every pipeline of the process.  The streams a process creates FIRST get hardware queues of their own; a second
+        pipeline object with streams of its own ran at 405 k frames/s beside 455 k for the first one -- and at 373 k once the first was
+        closed (tools/two_pipes_probe.py): its queues share hardware queues.  Pipelines are used one call at a time; two of them alive
+        (the harness keeps one per shape) now run on the same queues, in call order."""
+        key = (self.dev.index, tuple(int(w) for w in words))
+        k = self._masked_taken.get(key, 0)
+        self._masked_taken[key] = k + 1
+        with _STREAMS_LOCK:
+            st = _STREAMS.get(('masked', ) + key + (k, )) if (_POOL and 'masked' in _POOL_KINDS) else None
+            if st is None:
+                arr = (C.c_uint * 8)(*words)
+                h = C.c_void_p()
+                _lib.check(self._lib.sf_stream_create_cu_mask(C.byref(h), arr, 8))
+                st = torch.cuda.ExternalStream(h.value, device=self.dev)
+                _STREAMS[('masked', ) + key + (k, )] = st
+        return st
+
+    def _pool_stream(self, kind, k=0, priority=0):
+        """an unmasked torch stream from the same pool (kind: 'free', 'side', 'out', 'copy', ...)"""
+        key = ('torch', self.dev.index, kind, k, priority)
+        with _STREAMS_LOCK:
+            st = _STREAMS.get(key) if (_POOL and kind in _POOL_KINDS) else None
+            if st is None:
+                st = _STREAMS[key] = torch.cuda.Stream(device=self.dev, priority=priority)
+        return st
+
+    def _pick_free_streams(self, n):
+        """n unmasked streams from the process-wide pool for the whole-chip fill encodes and the drain units.
+        WHICH hardware queue a stream lands on decides 10 % of the pipeline's throughput: the runtime gives a stream its queue on first
+        use, round-robin over four, and the same run takes 84 ms with the free streams on the first two queues behind the null stream's
+        (the streams PyTorch hands out first), 79.5 ms on the second and third, 94-97 ms when one of them shares the null stream's queue
+        (`profiles/r03_probes.txt` section 16: period four in the number of streams used before; C2 447 / 474 / 400 / 390 k frames/s).
+        So ONE pool stream is used (and parked) first and the next n are taken; dedicated queues (full CU masks) were measured no better
+        than the worst-but-one arrangement, and choosing by a collision test (two 300 us one-wave kernels per candidate pair) changed the
+        order of first use and landed on a slow arrangement -- the plain rule is what was validated in the bench, the harness and a
+        process with several pipeline objects (tools/two_pipes_probe.py, tools/pcie_probe.py)."""
+        key = ('free-set', self.dev.index, n)
+        with _STREAMS_LOCK:
+            got = _STREAMS.get(key)
+        if got is not None:
+            return list(got)
+        if int(os.environ.get('SF_PIPE_FREE_MASKED', '0')):
+            # (probe) streams with a full CU mask: the runtime gives every CU-masked stream a hardware queue of its own
+            for _ in range(int(os.environ.get('SF_PIPE_FREE_DUMMY', '0'))):
+                self._masked_stream([0xffffffff] * 8)
+            return [self._masked_stream([0xffffffff] * 8) for _ in range(n)]
+        for _ in range(int(os.environ.get('SF_PIPE_FREE_SKIP', '1'))):
+            sk = torch.cuda.Stream(device=self.dev)
+            _lib.check(self._lib.sf_debug_spin(1, sk.cuda_stream))   # (used: a stream gets its hardware queue on first use)
+            sk.synchronize()
+            with _STREAMS_LOCK:
+                _STREAMS[('parked', self.dev.index, len(_STREAMS))] = sk
+        picked = [torch.cuda.Stream(device=self.dev) for _ in range(n)]
+        with _STREAMS_LOCK:
+            _STREAMS[key] = tuple(picked)
+        return picked
 
     def _close_streams(self):
-        for h in self._masked:
-            self._lib.sf_stream_destroy(h)
-        self._masked = []
+        pass   # (the streams belong to the process-wide pool and live as long as the process)
 
     def close(self):
         self._close_streams()
@@ -421,7 +478,9 @@ class EncodeRolloutPipeline:
                   'noise': torch.zeros(nv, self.T, self.N, self.D, device=self.dev) if with_noise else None,
                   'feat': torch.zeros(k, nv, 64 * 64, cl, device=self.dev) if k else None}
             ws = self._key + ('encg', ) + key
-            side = torch.cuda.Stream(device=self.dev)   # (capture on a side stream: the caller may be inside a masked stream)
+            # capture on a side stream (the caller may be inside a masked stream) -- a FRESH one per graph: with every encode graph captured
+            # on one pooled stream the same run took 93 instead of 78 ms (tools/two_pipes_probe.py, SF_POOL_KINDS)
+            side = torch.cuda.Stream(device=self.dev)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws)   # workspace, plans
@@ -519,7 +578,7 @@ class EncodeRolloutPipeline:
             st.wait_stream(cur)
         if not out.is_cuda:
             if self._s_out is None:
-                self._s_out = torch.cuda.Stream(device=self.dev)
+                self._s_out = self._pool_stream('out')
             self._s_out.wait_stream(cur)
         trace = bool(int(os.environ.get('SF_PIPE_TRACE', '0')))   # timeline of a run (tools/pipe_timeline.py): timing events everywhere
         ev_enc = [[torch.cuda.Event(enable_timing=trace) for _ in range(nl)] for _ in range(n)]
@@ -534,7 +593,7 @@ class EncodeRolloutPipeline:
         if host_in:
             if self._stage is None or self._stage[0].shape != imgs[0].shape:
                 self._stage = [torch.empty(imgs[0].shape, device=self.dev) for _ in range(NS)]
-                self._s_copy = torch.cuda.Stream(device=self.dev)
+                self._s_copy = self._pool_stream('copy')
             self._s_copy.wait_stream(cur)
             ev_up = [torch.cuda.Event() for _ in range(n)]
 
