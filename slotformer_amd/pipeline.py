@@ -115,10 +115,12 @@ class EncodeRolloutPipeline:
     ('pair': no seam launches; 128-row FFN workgroups and all-heads attention workgroups -- the throughput settings -- when
     the two units in flight cover the rollout CUs with one attention workgroup per video, else 64-row / head-pair workgroups;
     the same bits as the library defaults either way; other partitions: the library defaults).
+    hybrid: behind the whole-chip fill, every hybrid-th batch is encoded on an unmasked stream beside the CU-masked lane (None = 5
+    for a balanced 'pair' on row tiles, 0 = never otherwise; bit-identical).
     """
 
     def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=None, use_graph=True,
-                 partition='pair', group=None, rollout_opts=None, encode_graph=None):
+                 partition='pair', group=None, rollout_opts=None, encode_graph=None, hybrid=None):
         self.savi, self.roll = savi, rollouter
         self.B, self.T, self.H = int(batch), int(burn_in), int(pred_len)
         p = next(rollouter.parameters())
@@ -258,6 +260,7 @@ class EncodeRolloutPipeline:
         # smaller units at the end of a run (_unit_plan): measured WORSE with group 4 (unmasked drain units take CUs from the
         # encode and the full units: 322 vs 376 k frames/s at 20 batches) -- off
         self.ramp = bool(int(os.environ.get('SF_PIPE_RAMP', '0')))
+        self._hybrid_arg = hybrid
         self.fill_par = max(1, min(3, int(os.environ.get('SF_PIPE_FILL_PAR', '2'))))   # whole-chip encodes side by side during the fill
         # batches encoded on the WHOLE chip (unmasked streams, fill_par at a time) at the start of a run.  The first unit's had to be
         # (nothing else runs yet); since the row-tile kernels the rollout streams have slack, and the unmasked encodes of the NEXT
@@ -265,7 +268,18 @@ class EncodeRolloutPipeline:
         # then works from: two units by default (C4 172 -> 175 k, C5 381 -> 390 k frames/s at 20 batches), three where the encode lane is
         # the bound of a balanced pair running row tiles (C2: 427 -> 445-447 k at 20 batches, 441 -> 460 k at 40; four or more units
         # starve the rollouts: 432 / 410 k).  SF_PIPE_FILL overrides (batches)
-        fill_units = 3 if (getattr(self, '_row_tiles', False) and partition == 'pair' and self._encode_rows() == 4) else 2
+        balanced = getattr(self, '_row_tiles', False) and partition == 'pair' and self._encode_rows() == 4
+        fill_units = 3 if balanced else 2
+        # hybrid lane: behind the fill every `hybrid`-th batch is encoded on an UNMASKED stream (the second fill graph) beside the CU-masked
+        # lane.  With the encode lane the bound (3.9 ms per batch against ~3.0-3.3 of rollout capacity) the rollout partition has slack to
+        # lend: C2 at 40 / 100 / 200 batches 484 / 489 / 487 -> 501 / 511 / 526 k frames/s with every 5th (4: 496 / 510, 6: 497 / 507), nothing
+        # at 20 (one such batch); C4 209 -> 212 k at 60; the rollout-bound C5 (one CU row for the encode) keeps the lane alone.  None
+        # among the last `hybrid` batches of a run: the lane is about to fall idle there.  Same bits (tests/test_pipeline_gpu.py).
+        if self._hybrid_arg is not None:
+            self.hybrid = int(self._hybrid_arg)
+        else:
+            self.hybrid = int(os.environ.get('SF_PIPE_HYBRID', '5' if balanced else '0'))
+        self.hybrid_tail = int(os.environ.get('SF_PIPE_HYBRID_TAIL', str(self.hybrid)))
         self.fill_batches = int(os.environ.get('SF_PIPE_FILL', '0')) or (fill_units * self.G if partition == 'pair' else 0)
         self.fill_steal = int(os.environ.get('SF_PIPE_FILL_STEAL', '0'))
         # pre_steal[h]: time steps of convolutions of batch h of the NEXT unit computed on a rollout stream right before a unit
@@ -650,12 +664,28 @@ class EncodeRolloutPipeline:
                         ev_roll[dui].record(self._s_out)
                     downloads.remove(d)
 
+        fill_last = {}   # fill graph index -> the last batch encoded through it
         for ui, (u0, nb, u, drain) in enumerate(units):
             download_ready(for_unit=u)
             for h in range(nb):
                 j = u0 + h
                 dst = u.buf[h * B:(h + 1) * B]
-                if j < n_fill:
+                hyb = (self.hybrid > 0 and j >= n_fill and n_fill > 0 and (j - n_fill) % self.hybrid == self.hybrid - 1
+                       and j + self.hybrid_tail < n and len(self.s_free) > 0 and self.fill_par > 1)
+                if hyb:
+                    # hybrid lane: every `hybrid`-th batch behind the fill is encoded on an UNMASKED stream (fill graph 1) beside the masked
+                    # lane -- the rollout partition has slack, the encode lane is the bound
+                    fs = self.s_free[0]
+                    if fill_last.get(1) is not None:
+                        fs.wait_event(ev_enc[fill_last[1]][0])
+                    if u.busy is not None:
+                        fs.wait_event(u.busy)
+                    with torch.cuda.stream(fs):
+                        self._encode(img_of(j, fs), nz(j), dst, None, lane=('fill', 1))
+                        ev_enc[j][0].record(fs)
+                    fill_last[1] = j
+                    ev_wait_j = ev_enc[j][:1]
+                elif j < n_fill:
                     # pipeline fill: the first encodes take the whole chip (unmasked streams); the masked lanes start after them.  One
                     # encode alone cannot fill 256 CUs (2.7 ms for 470 CU-ms of work), so `fill_par` of them run side by side,
                     # each from its own graph / buffers (380-382 vs 375-378 k frames/s at 20 batches).  The host waits: with the
@@ -673,6 +703,7 @@ class EncodeRolloutPipeline:
                     with torch.cuda.stream(fs):
                         self._encode(img_of(j, fs), nz(j), dst, None, lane=('fill', fi) if fill_par > 1 else 0)
                         ev_enc[j][0].record(fs)
+                    fill_last[fi] = j
                     if j == 0 and (steal or fill_k) and len(rolls) > 1:
                         # the rollout streams idle until the first unit is encoded: they compute the stolen features of the
                         # batches behind the fill now (round-robin), so that only the fill batches pay for their own convolutions

@@ -78,6 +78,31 @@ def test_pipeline_matches_serial(dev, B, steal, nbatch, partition):
         pipe.close()
 
 
+@pytest.mark.parametrize('hybrid,nbatch', [(2, 21), (5, 26), (0, 17)])
+def test_pipeline_hybrid_lane_matches_serial(dev, hybrid, nbatch):
+    """Runs long enough to leave the whole-chip fill (12 batches): behind it every hybrid-th batch is encoded on an unmasked stream
+    through the second fill graph, beside the CU-masked lane; unit buffers are reused (more than four units).  Bit for bit the
+    serial calls."""
+    from slotformer_amd.pipeline import EncodeRolloutPipeline
+    B, T, H = 32, 6, 8
+    savi, roll = _models(dev, gu.C2_SAVI, gu.C2_ROLL)
+    rs = np.random.RandomState(17)
+    base = [torch.from_numpy((rs.rand(B, T, 3, 128, 128) * 2 - 1).astype(np.float32)).to(dev) for _ in range(5)]
+    nz = [torch.from_numpy(rs.standard_normal((B, T, 7, 128)).astype(np.float32)).to(dev) for _ in range(7)]
+    imgs = [base[j % 5] for j in range(nbatch)]
+    noises = [nz[j % 7] for j in range(nbatch)]     # (35 distinct (frames, noise) pairs)
+    with torch.no_grad():
+        ref = _serial_reference(savi, roll, imgs, noises, T, H, PAIR_OPTS)
+        pipe = EncodeRolloutPipeline(savi, roll, B, T, H, hybrid=hybrid)
+        assert pipe.hybrid == hybrid and pipe.fill_batches == 12
+        for _ in range(2):
+            out = pipe.run(imgs, noises)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), (out - ref).abs().max().item()
+        pipe.close()
+    assert EncodeRolloutPipeline.__init__.__defaults__ is not None
+
+
 def test_pipeline_without_cu_partition_and_graph(dev):
     from slotformer_amd.pipeline import EncodeRolloutPipeline
     B, T, H, nbatch = 4, 6, 5, 4
