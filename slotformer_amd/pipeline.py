@@ -274,12 +274,12 @@ class EncodeRolloutPipeline:
         # lane.  With the encode lane the bound (3.9 ms per batch against ~3.0-3.3 of rollout capacity) the rollout partition has slack to
         # lend: C2 at 40 / 100 / 200 batches 484 / 489 / 487 -> 501 / 511 / 526 k frames/s with every 5th (4: 496 / 510, 6: 497 / 507), nothing
         # at 20 (one such batch); C4 209 -> 212 k at 60; the rollout-bound C5 (one CU row for the encode) keeps the lane alone.  None
-        # among the last `hybrid` batches of a run: the lane is about to fall idle there.  Same bits (tests/test_pipeline_gpu.py).
+        # among the last three batches of a run: the lane is about to fall idle there (C2 487.5 vs 480.5 at 20, 517.8 vs 513.2 at 100 against none among the last five).  Same bits (tests/test_pipeline_gpu.py).
         if self._hybrid_arg is not None:
             self.hybrid = int(self._hybrid_arg)
         else:
             self.hybrid = int(os.environ.get('SF_PIPE_HYBRID', '5' if balanced else '0'))
-        self.hybrid_tail = int(os.environ.get('SF_PIPE_HYBRID_TAIL', str(self.hybrid)))
+        self.hybrid_tail = int(os.environ.get('SF_PIPE_HYBRID_TAIL', str(min(self.hybrid, 3))))
         self.fill_batches = int(os.environ.get('SF_PIPE_FILL', '0')) or (fill_units * self.G if partition == 'pair' else 0)
         self.fill_steal = int(os.environ.get('SF_PIPE_FILL_STEAL', '0'))
         # pre_steal[h]: time steps of convolutions of batch h of the NEXT unit computed on a rollout stream right before a unit
