@@ -384,7 +384,8 @@ class EncodeRolloutPipeline:
             return [self._masked_stream([0xffffffff] * 8) for _ in range(n)]
         for _ in range(int(os.environ.get('SF_PIPE_FREE_SKIP', '1'))):
             sk = torch.cuda.Stream(device=self.dev)
-            _lib.check(self._lib.sf_debug_spin(1, sk.cuda_stream))   # (used: a stream gets its hardware queue on first use)
+            with torch.cuda.device(self.dev):
+                _lib.check(self._lib.sf_debug_spin(1, sk.cuda_stream))   # (used: a stream gets its hardware queue on first use)
             sk.synchronize()
             with _STREAMS_LOCK:
                 _STREAMS[('parked', self.dev.index, len(_STREAMS))] = sk
