@@ -304,6 +304,9 @@ def main():
     partition = os.environ.get('SF_BENCH_PARTITION', 'pair')   # 'pair' | 'three' | 'two' | 'none' (pipeline.EncodeRolloutPipeline)
     group = os.environ.get('SF_BENCH_GROUP')
     group = None if group is None else int(group)
+    if group is None:
+        from slotformer_amd.pipeline import unit_batches_for
+        group = unit_batches_for(roll, B, args.steps, T_BURN)   # (as harness.extract_and_rollout: larger units for long runs of small batches; None for C2 / C5)
 
     with torch.no_grad():
         log('building the pipeline (first eager rollouts + graph capture)')

@@ -123,6 +123,11 @@ def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises
     nfull = V // batch_size
     tail_opts = None
     if nfull:
+        if 'group' not in pipe_kw and pipe_kw.get('partition', 'pair') == 'pair':
+            from .pipeline import unit_batches_for
+            g = unit_batches_for(rollouter, batch_size, nfull, T)   # long runs of small batches: larger rollout units
+            if g:
+                pipe_kw = dict(pipe_kw, group=g)
         pipe = _pipeline_for(savi, rollouter, batch_size, T, pred_len, pipe_kw)
         tail_opts = pipe.rollout_opts   # the ragged tail runs the same kernel forms as the full batches
         imgs = [videos[j * batch_size:(j + 1) * batch_size] for j in range(nfull)]

@@ -98,6 +98,22 @@ class _Unit:
         self.latency_form = False   # captured with the kernels' latency forms (the drain unit of a run: alone on the whole chip)
 
 
+def unit_batches_for(rollouter, batch, n_batches, burn_in=None):
+    """Batches per rollout unit for a run of n_batches (None = the constructor's default of 4).  A unit's row-tile launches should fill ONE
+    round of the 64 CUs a rollout stream gets with 64-row tiles: 4096 token rows.  C2 (1344 rows per batch) and C5 (3072) stay at 4;
+    C4 (16 videos x 36 tokens = 576 rows per batch) takes 7 -- 63 tiles per launch instead of 36: 231 vs 209 k frames/s at 84 batches,
+    227 at 42 -- but only in runs of five units or more: at 20 batches the ragged last unit and the longer drain cost more (170 vs 199 k;
+    `profiles/r03_probes.txt` section 18)."""
+    hist = getattr(rollouter, 'cond_len', None) or getattr(rollouter, 'history_len', burn_in or 1)
+    rows = int(batch) * int(rollouter.num_slots) * int(hist)
+    g = max(4, min(8, 4096 // max(rows, 1)))
+    if g <= 4 or n_batches < 5 * g:
+        return None
+    from . import _lib as _l   # (units of several batches need the fused-layer path: its results do not depend on the batch size)
+    fused = bool(_l.lib().sf_rollout_is_fused(C.byref(engine.rollouter_plan(rollouter).struct)))
+    return g if fused else None
+
+
 class EncodeRolloutPipeline:
     """savi: StoSAVi / STEVE container (eval, testing=True); rollouter: SlotRollouter / SingleStepSlotRollouter container.
 

@@ -165,6 +165,33 @@ def test_extract_and_rollout_entry(dev):
         assert not harness._PIPES
 
 
+def test_unit_batches_for_long_runs(dev):
+    """Long runs of small batches take larger rollout units (pipeline.unit_batches_for, used by harness.extract_and_rollout and bench.py):
+    a unit's row-tile launches should fill one round of a rollout stream's 64 CUs.  The slots do not depend on the unit size."""
+    from slotformer_amd import harness
+    from slotformer_amd.pipeline import unit_batches_for
+    T, H = 6, 4
+    savi, roll = _models(dev, gu.C2_SAVI, gu.C2_ROLL, seed=9)
+    assert unit_batches_for(roll, 32, 100, T) is None and unit_batches_for(roll, 32, 20, T) is None     # C2: 1344 rows per batch
+    assert unit_batches_for(roll, 14, 40, T) == 6 and unit_batches_for(roll, 14, 29, T) is None         # 588 rows per batch (C4: 576 -> 7)
+    assert unit_batches_for(roll, 2, 40, T) == 8 and unit_batches_for(roll, 2, 39, T) is None
+    bs, V = 2, 83      # 41 full batches (units of 8) + 1 video
+    rs = np.random.RandomState(5)
+    base = torch.from_numpy((rs.rand(7, T, 3, 128, 128) * 2 - 1).astype(np.float32)).to(dev)
+    videos = base[torch.arange(V) % 7]
+    noises = torch.from_numpy(rs.standard_normal((V, T, 7, 128)).astype(np.float32)).to(dev)
+    with torch.no_grad():
+        out = harness.extract_and_rollout(savi, roll, videos, H, batch_size=bs, noises=noises)
+        pipe = next(iter(harness._PIPES.values()))[2]
+        assert pipe.G == 8
+        ref = harness.extract_and_rollout(savi, roll, videos, H, batch_size=bs, noises=noises, group=4)
+        assert next(iter(harness._PIPES.values()))[2].G == 4
+        assert torch.equal(out, ref)
+        one = _serial_reference(savi, roll, [videos[10:12]], [noises[10:12]], T, H, PAIR_OPTS)
+        assert torch.equal(out[10:12], one[0])
+        harness.release_pipelines()
+
+
 @pytest.mark.parametrize('group,partition,nbatch', [(1, 'pair', 7), (3, 'pair', 8), (2, 'two', 5), (2, 'none', 3), (2, 'pair', 1), (2, 'pair', 9), (4, 'pair', 21),
                                                     (4, 'pair', 7)])
 def test_pipeline_groups(dev, group, partition, nbatch):
