@@ -7,6 +7,7 @@ python bench.py --steps 100 --warmup 8 --no-cpu-baseline > gpurun_out/${TAG}_ben
 python bench.py --config C4 --steps 20 --warmup 8 > gpurun_out/${TAG}_bench_C4.json 2>/dev/null
 python bench.py --config C5 --steps 20 --warmup 8 > gpurun_out/${TAG}_bench_C5.json 2>/dev/null
 python bench.py --config C4 --steps 42 --warmup 8 --no-cpu-baseline > gpurun_out/${TAG}_bench_C4_42steps.json 2>/dev/null
+python bench.py --config C5 --batch 8 --steps 48 --warmup 8 --no-cpu-baseline > gpurun_out/${TAG}_bench_C5_b8_48steps.json 2>/dev/null
 python bench.py --config C5 --batch 8 --steps 20 --warmup 8 --no-cpu-baseline > gpurun_out/${TAG}_bench_C5_b8.json 2>/dev/null
 python bench.py --pcie --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_pcie.json 2>/dev/null
 for f in gpurun_out/${TAG}_bench_*.json; do python -c "
