@@ -294,7 +294,9 @@ class EncodeRolloutPipeline:
         if self._hybrid_arg is not None:
             self.hybrid = int(self._hybrid_arg)
         else:
-            self.hybrid = int(os.environ.get('SF_PIPE_HYBRID', '5' if balanced else '0'))
+            # (units of more than 4 batches -- unit_batches_for: long runs of small batches -- make the rollouts cheaper per batch and the encode the
+            #  bound by more: C4 with units of 7 at 84 batches, every 5th / 4th / 3rd / 2nd batch: 236.0 / 242.9 / 250.6 / 250.9 k)
+            self.hybrid = int(os.environ.get('SF_PIPE_HYBRID', ('3' if self.G > 4 else '5') if balanced else '0'))
         self.hybrid_tail = int(os.environ.get('SF_PIPE_HYBRID_TAIL', str(min(self.hybrid, 3))))
         self.fill_batches = int(os.environ.get('SF_PIPE_FILL', '0')) or (fill_units * self.G if partition == 'pair' else 0)
         self.fill_steal = int(os.environ.get('SF_PIPE_FILL_STEAL', '0'))
