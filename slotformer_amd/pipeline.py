@@ -52,7 +52,6 @@ from . import _lib, engine
 _STREAMS = {}                      # process-wide stream pool (EncodeRolloutPipeline._masked_stream / _pool_stream)
 _STREAMS_LOCK = threading.Lock()
 _POOL = bool(int(os.environ.get('SF_PIPE_STREAM_POOL', '1')))
-_POOL_KINDS = os.environ.get('SF_POOL_KINDS', 'masked,free,side,out,copy,roll,lane').split(',')
 
 
 def encode_mask_words(spec):
@@ -362,7 +361,7 @@ class EncodeRolloutPipeline:
         k = self._masked_taken.get(key, 0)
         self._masked_taken[key] = k + 1
         with _STREAMS_LOCK:
-            st = _STREAMS.get(('masked', ) + key + (k, )) if (_POOL and 'masked' in _POOL_KINDS) else None
+            st = _STREAMS.get(('masked', ) + key + (k, )) if _POOL else None
             if st is None:
                 arr = (C.c_uint * 8)(*words)
                 h = C.c_void_p()
@@ -372,10 +371,10 @@ class EncodeRolloutPipeline:
         return st
 
     def _pool_stream(self, kind, k=0, priority=0):
-        """an unmasked torch stream from the same pool (kind: 'free', 'side', 'out', 'copy', ...)"""
+        """an unmasked torch stream from the same pool (kind: 'out', 'copy', 'roll', 'lane')"""
         key = ('torch', self.dev.index, kind, k, priority)
         with _STREAMS_LOCK:
-            st = _STREAMS.get(key) if (_POOL and kind in _POOL_KINDS) else None
+            st = _STREAMS.get(key) if _POOL else None
             if st is None:
                 st = _STREAMS[key] = torch.cuda.Stream(device=self.dev, priority=priority)
         return st
@@ -512,7 +511,7 @@ class EncodeRolloutPipeline:
                   'feat': torch.zeros(k, nv, 64 * 64, cl, device=self.dev) if k else None}
             ws = self._key + ('encg', ) + key
             # capture on a side stream (the caller may be inside a masked stream) -- a FRESH one per graph: with every encode graph captured
-            # on one pooled stream the same run took 93 instead of 78 ms (tools/two_pipes_probe.py, SF_POOL_KINDS)
+            # on one pooled stream the same run took 93 instead of 78 ms (tools/two_pipes_probe.py)
             side = torch.cuda.Stream(device=self.dev)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
