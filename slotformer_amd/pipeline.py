@@ -399,7 +399,15 @@ class EncodeRolloutPipeline:
             for _ in range(int(os.environ.get('SF_PIPE_FREE_DUMMY', '0'))):
                 self._masked_stream([0xffffffff] * 8)
             return [self._masked_stream([0xffffffff] * 8) for _ in range(n)]
-        for _ in range(int(os.environ.get('SF_PIPE_FREE_SKIP', '1'))):
+        # (a process that has initialised RCCL already has that one stream in use -- RCCL's: with torch.distributed on the nccl backend
+        #  initialised before the pipeline, the bench's multi-GPU path, no parked stream 474 k, one 418 k, two / three 385 / 399 k)
+        rccl = False
+        try:
+            import torch.distributed as dist
+            rccl = dist.is_available() and dist.is_initialized() and 'nccl' in str(dist.get_backend())
+        except Exception:  # noqa: BLE001
+            rccl = False
+        for _ in range(int(os.environ.get('SF_PIPE_FREE_SKIP', '0' if rccl else '1'))):
             sk = torch.cuda.Stream(device=self.dev)
             with torch.cuda.device(self.dev):
                 _lib.check(self._lib.sf_debug_spin(1, sk.cuda_stream))   # (used: a stream gets its hardware queue on first use)
