@@ -126,9 +126,15 @@ def committed_profile(key):
     if not files:
         return {}
     try:
-        d = json.load(open(files[-1])).get(key, {})
-        d = dict(d)
+        full = json.load(open(files[-1]))
+        d = dict(full.get(key, {}))
         d['source'] = os.path.relpath(files[-1], ROOT)
+        # the trace describes the kernels of ONE source tree: a summary taken from other sources must not price this run
+        now = source_tree_hash()
+        if full.get('source_tree') != now and os.environ.get('SF_BENCH_ALLOW_STALE_TRACE') != '1':
+            # no number of a trace taken from OTHER kernel sources enters the line: the objects fall back to this run's HIP events
+            return {'stale_trace': os.path.relpath(files[-1], ROOT), 'trace_source_tree': full.get('source_tree'), 'source_tree': now}
+        d['source_tree'] = now
         return d
     except ValueError:
         return {}
@@ -247,6 +253,43 @@ def cpu_baseline(cfg, B_full, sample_B):
                 one_thread={'value': n1 * fr / dt1, 'videos': n1, 'cores': 1, 'seconds': dt1, 'passes': 1})
 
 
+def fail(msg, args, code=0):
+    """A run that cannot start: say why on stderr and as a JSON line without a value (never an assert)."""
+    print(f'[bench] {msg}', file=sys.stderr, flush=True)
+    if int(os.environ.get('RANK', 0)) == 0:
+        print(json.dumps({'metric': 'rollout frames/sec', 'value': None, 'unit': 'frames/s', 'n_gpus': args.gpus, 'steps': args.steps,
+                          'warmup': args.warmup, 'error': msg}), flush=True)
+    sys.exit(code)
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run (one rank per GPU over RCCL, rendezvous
+    on 127.0.0.1).  Needs N visible devices; says so cleanly otherwise."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        print(f'[bench] --gpus {n} needs {n} devices, {have} visible on this node: nothing run', file=sys.stderr, flush=True)
+        print(json.dumps({'metric': 'rollout frames/sec', 'value': None, 'unit': 'frames/s', 'n_gpus': n, 'devices_visible': have,
+                          'error': f'needs {n} devices, {have} visible'}), flush=True)
+        return 0
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f'[bench] launching {n} ranks: {" ".join(cmd)}', file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def source_tree_hash():
+    """sha256 over the kernel sources (slotformer_amd/csrc + the C-ABI header): ties a committed rocprof summary to the code it traced."""
+    from slotformer_amd.build import source_tree_hash as h
+    return h()
+
+
 def log(msg):
     if int(os.environ.get('RANK', 0)) == 0:
         print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
@@ -267,14 +310,23 @@ def main():
     ap.add_argument('--precision', choices=['bf16x3', 'f32'], default=None, help='matrix arithmetic mode (default: library default = bf16x3)')
     ap.add_argument('--pcie', action='store_true', help='also time a host-to-host (PCIe-inclusive) variant; reported separately')
     ap.add_argument('--breakdown', action='store_true', help='extra untimed pass with every kernel class timed')
+    ap.add_argument('--windows', type=int, default=5, help='timed windows of --steps steps each on the warm pipeline; value = the median window')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of its own N ranks (one process per GPU, the
+        # reference's launch shape: scripts/sbatch_run.sh:36-42) and passes rank 0's JSON line through
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get('RANK', 0))
     pipe_closed = False
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
-    assert torch.cuda.is_available(), 'bench.py needs a HIP device'
+    if world != args.gpus:
+        fail(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree', args, code=2)
+    if not torch.cuda.is_available():
+        fail('bench.py needs a HIP device (none visible)', args, code=2)
+    if torch.cuda.device_count() <= local:
+        fail(f'rank {rank} needs device {local}, {torch.cuda.device_count()} visible', args, code=2)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     use_dist = world > 1 or os.environ.get('SF_BENCH_FORCE_DIST') == '1'  # the latter: exercise the RCCL path on one GPU
@@ -334,13 +386,28 @@ def main():
         log('warmup done')
         # the timed region carries no measurement probes: HIP-event brackets around the conv / Slot-Attention launches of the encode
         # stream cost that stream ~5 % even when only every 4th launch is bracketed (341 vs 359 k frames/s)
-        barrier()
-        t0 = time.perf_counter()
-        run(args.steps, out_t)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        log(f'timed region done: {elapsed:.3f}s')
-        unit_done, unit_batches = (pipe.completion_events, pipe.completion_batches) if overlap else (None, None)
+        # R timed windows on the same warm pipeline, each EXACTLY args.steps steps bracketed by barrier + synchronize on both
+        # sides; `value` / `ms_per_step` come from the MEDIAN window, p10 / p90 over the windows beside it
+        windows, unit_gaps = [], []
+        for w in range(max(1, args.windows)):
+            barrier()
+            t0 = time.perf_counter()
+            run(args.steps, out_t)
+            barrier()
+            windows.append(time.perf_counter() - t0)
+            if overlap and len(pipe.completion_events) > 1:
+                # device time between the completions of consecutive rollout units (units on the unmasked drain streams may
+                # overtake their predecessors: the completion times are sorted first)
+                ev0 = pipe.completion_events[0]
+                done = sorted((ev0.elapsed_time(e), nb) for e, nb in zip(pipe.completion_events, pipe.completion_batches))
+                unit_gaps += [(done[j][0] - done[j - 1][0]) / max(done[j][1], 1) for j in range(1, len(done))]
+        windows_all = list(windows)
+        if use_dist:   # every window: the slowest rank's time
+            tw = torch.tensor(windows, device=dev, dtype=torch.float64)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            windows_all = tw.tolist()
+        elapsed = sorted(windows_all)[len(windows_all) // 2]
+        log(f'timed windows done: {[round(x, 4) for x in windows_all]} s')
         # conv + Slot-Attention launches LIVE: a second pass of the same schedule with library brackets (HIP events on the launch
         # stream) around every LIVE_EVERY-th launch of the two classes
         LIVE_EVERY = int(os.environ.get('SF_BENCH_LIVE_EVERY', '4'))
@@ -381,6 +448,15 @@ def main():
                 stream.synchronize()
             return (time.perf_counter() - t) / n
 
+        # one batch at a time (no pipelining, whole chip): the latency of ONE batch of B videos through encode + rollout
+        one_batch = []
+        for k in range(6):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            pipe.run([ring[k % 3]], None, serial=True)
+            torch.cuda.synchronize()
+            one_batch.append(time.perf_counter() - t1)
+        one_batch_ms = 1e3 * sorted(one_batch[1:])[len(one_batch[1:]) // 2]   # (the first call captures the one-batch unit's graph)
         torch.cuda.synchronize()
         lib.sf_profile_enable((1 << 0) | (1 << 3))
         t_enc = timed_on(torch.cuda.current_stream(), encode)
@@ -425,20 +501,24 @@ def main():
             lib.sf_profile_enable(0)
             breakdown = read_profile(lib)
 
+    per_rank = None
+    rccl_ranks, rccl_backend = None, None
     if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        # per-rank median window (the line's value uses the max over ranks of every window) + what the process group really is
+        mine = torch.tensor([sorted(windows)[len(windows) // 2]], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [B * (T_BURN + T_ROLL) * args.steps / x.item() for x in allr]
+        rccl_ranks, rccl_backend = dist.get_world_size(), str(dist.get_backend())
 
     if rank == 0:
         frames = world * B * (T_BURN + T_ROLL) * args.steps
         step_dist = None
-        if unit_done is not None and len(unit_done) > 2:
-            # device time between the completions of consecutive rollout units inside the timed region (rank 0), per batch
-            gaps = sorted(unit_done[j - 1].elapsed_time(unit_done[j]) / unit_batches[j] for j in range(1, len(unit_done)))
-            pick = lambda q: gaps[min(len(gaps) - 1, int(q * len(gaps)))]  # noqa: E731
-            step_dist = {'p10': pick(0.10), 'median': pick(0.50), 'p90': pick(0.90), 'n': len(gaps), 'batches_per_unit': G,
-                         'note': 'gap between the completions of consecutive rollout units / batches per unit'}
+        pick_of = lambda v, q: sorted(v)[min(len(v) - 1, int(q * len(v)))]  # noqa: E731
+        if len(unit_gaps) > 2:
+            step_dist = {'p10': pick_of(unit_gaps, 0.10), 'median': pick_of(unit_gaps, 0.50), 'p90': pick_of(unit_gaps, 0.90), 'n': len(unit_gaps),
+                         'batches_per_unit': G,
+                         'note': 'device time between the SORTED completion times of consecutive rollout units / batches per unit, all windows (rank 0)'}
         peak_chip = PEAK_BF16_MFMA_TFLOPS / 3.0 if prec == 'bf16x3' else PEAK_F32_MFMA_TFLOPS
         peak_note = ('split-bf16 MFMA: 3 bf16 MFMA flops per algorithmic flop -> roof = 2500/3 TFLOP/s' if prec == 'bf16x3'
                      else 'exact f32 MFMA')
@@ -457,6 +537,13 @@ def main():
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
+            'ms_per_step_windows': {'median': 1e3 * elapsed / args.steps, 'p10': 1e3 * pick_of(windows_all, 0.10) / args.steps,
+                                    'p90': 1e3 * pick_of(windows_all, 0.90) / args.steps, 'n': len(windows_all),
+                                    'all': [1e3 * x / args.steps for x in windows_all],
+                                    'note': 'windows of exactly `steps` steps each on the same warm pipeline, each bracketed by barrier + synchronize; '
+                                            'value / ms_per_step = the median window (max over ranks per window)'},
+            'timed_region_s': sum(windows_all),
+            'per_rank_frames_per_s': per_rank, 'rccl_ranks': rccl_ranks, 'process_group_backend': rccl_backend,
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
@@ -469,6 +556,7 @@ def main():
                 'parallelism': f'dp{world}: videos sharded on the batch axis, no collective on the timed path',
                 'inputs': 'ring of 3 different resident batches; the slots of every batch are copied out of the slot buffers',
                 'schedule': 'slotformer_amd.pipeline.EncodeRolloutPipeline (product code, tests/test_pipeline_gpu.py)',
+                'stream_placement': getattr(pipe, 'stream_placement', None),
                 'rollout_launch': (f'hipGraph replay, one graph per rollout unit of {G} batch(es) = {G * B} videos') if graph is not None else 'eager',
                 'rollout_opts': None if pipe.rollout_opts is None else {k: getattr(pipe.rollout_opts, k) for k, _ in pipe.rollout_opts._fields_},
                 'pipelining': ('encode of later batches (stream A) overlaps the rollout graphs of earlier units (streams B, C); every batch still '
@@ -483,6 +571,8 @@ def main():
                                  (f'encode stream on CU mask {cu_word if isinstance(cu_word, str) else hex(cu_word)} ({pipe.encode_cus} CUs, the same '
                                   'number in every XCD), rollout stream on the complement')) if (overlap and pipe.cu_split) else 'none',
             },
+            'one_batch_latency_ms': one_batch_ms,
+            'one_batch_frames_per_s': B * (T_BURN + T_ROLL) / (one_batch_ms * 1e-3),
             'encode_ms': 1e3 * t_enc,
             'rollout_ms': 1e3 * t_roll / G,
             'rollout_unit_ms': 1e3 * t_roll,
@@ -542,6 +632,11 @@ def main():
                 'avg_launch_us_rocprof': us_trace,
                 'avg_launch_us_events': (live or iso)['avg_us'], 'avg_launch_us_events_isolated': iso['avg_us'],
                 'frac_events': fl / ((live or iso)['avg_us'] * 1e-6) / 1e12 / peak_chip,
+                'frac_events_isolated': fl / (iso['avg_us'] * 1e-6) / 1e12 / peak_chip,
+                'frac_source': ('committed rocprof trace of this source tree (' + str(pm.get('source')) + ')') if us_trace else
+                               ('HIP events of this run' + (f" (the committed trace {pm['stale_trace']} is of source tree {pm['trace_source_tree']}, "
+                                                            f"this run's is {pm['source_tree']}: not used)" if pm.get('stale_trace') else '')),
+                'source_tree': pm.get('source_tree') or source_tree_hash(),
                 'launches_per_unit': iso['launches'], 'rows_per_launch_full_window': G * B * W_FR * N_SLOTS,
                 'cus_available': pipe.rollout_cus if pipe.cu_split else 256,
                 'traffic': pm.get('traffic_bytes_per_launch'),

@@ -30,6 +30,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_tree_hash():
+    """sha256 over the sources the library is built from (names + contents, in SOURCES / HEADERS order): what a committed
+    rocprof summary stores as `source_tree`, so that bench.py can tell whether its trace still describes these kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in SOURCES + HEADERS:
+        path = os.path.join(CSRC, name)
+        h.update(os.path.basename(name).encode())
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]

@@ -567,13 +567,22 @@ int sf_attn_rows_ex(int mode, const float* xin, long long x_batch_stride, long l
   const int blocks = A.nt + extra;
   const size_t lds = (size_t)2 * TRr * AP * 2 + 2 * D * 4;
   sf_prof_begin(SF_K_MHA, st, 6.0 * B * L * (double)D * D + 4.0 * (double)B * NH * Lq * L * HD + 2.0 * B * Lq * (double)D * D);
+  // (a failed LDS-attribute call closes the class timer's pending event before it returns)
+#define SF_QKV_TRY(x)                 \
+  do {                                \
+    const int rc_ = (x);              \
+    if (rc_) {                        \
+      sf_prof_end(SF_K_MHA, st);      \
+      return rc_;                     \
+    }                                 \
+  } while (0)
 #define SF_QKV_LAUNCH(RING_, PART_)                                                                                         \
   do {                                                                                                                      \
     if (TRr == 128) {                                                                                                       \
-      SF_TRY(sf_ensure_dyn_lds((const void*)qkv_rows_kernel<RING_, PART_, 128>, lds));                                      \
+      SF_QKV_TRY(sf_ensure_dyn_lds((const void*)qkv_rows_kernel<RING_, PART_, 128>, lds));                                  \
       hipLaunchKernelGGL((qkv_rows_kernel<RING_, PART_, 128>), dim3(blocks), dim3(NT), lds, st, A);                         \
     } else {                                                                                                                \
-      SF_TRY(sf_ensure_dyn_lds((const void*)qkv_rows_kernel<RING_, PART_, 64>, lds));                                       \
+      SF_QKV_TRY(sf_ensure_dyn_lds((const void*)qkv_rows_kernel<RING_, PART_, 64>, lds));                                   \
       hipLaunchKernelGGL((qkv_rows_kernel<RING_, PART_, 64>), dim3(blocks), dim3(NT), lds, st, A);                          \
     }                                                                                                                       \
   } while (0)
@@ -584,6 +593,7 @@ int sf_attn_rows_ex(int mode, const float* xin, long long x_batch_stride, long l
   else
     SF_QKV_LAUNCH(false, false);
 #undef SF_QKV_LAUNCH
+#undef SF_QKV_TRY
   SF_CHECK_LAUNCH();
   const int rc = launch_core(w, x2, planes, B, L, Lq, st);
   sf_prof_end(SF_K_MHA, st);

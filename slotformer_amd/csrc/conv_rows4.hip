@@ -293,14 +293,14 @@ int sf_conv5x5_rows4_ex(const float* in, const void* w_frag, const float* bias, 
                         int Cin, int Cout, int ks, int relu, hipStream_t st) {
   if (!w_frag || W != TW || Cin != CH || Cout != CH || ks != KS || (H % TR) != 0 || F <= 0 || sf_get_precision() != 1) return 1;
   static const int dbg = getenv("SF_CONV_DBG") ? atoi(getenv("SF_CONV_DBG")) : 0;
+  // (the LDS attribute first: a failure here must not leave the class timer's pending event open)
+  const bool f16 = sf_get_conv_fp16x2();
+  SF_TRY(sf_ensure_dyn_lds(f16 ? (const void*)conv5x5_rows4_kernel<true> : (const void*)conv5x5_rows4_kernel<false>, LDS_BYTES));
   sf_prof_begin(SF_K_CONV_NHWC, st, 2.0 * (double)F * H * W * Cout * ks * ks * Cin);
-  if (sf_get_conv_fp16x2()) {
-    SF_TRY(sf_ensure_dyn_lds((const void*)conv5x5_rows4_kernel<true>, LDS_BYTES));
+  if (f16)
     hipLaunchKernelGGL(conv5x5_rows4_kernel<true>, dim3(F * (H / TR)), dim3(NT), LDS_BYTES, st, in, (const uint4*)w_frag, bias, add, out, H, relu, dbg);
-  } else {
-    SF_TRY(sf_ensure_dyn_lds((const void*)conv5x5_rows4_kernel<false>, LDS_BYTES));
+  else
     hipLaunchKernelGGL(conv5x5_rows4_kernel<false>, dim3(F * (H / TR)), dim3(NT), LDS_BYTES, st, in, (const uint4*)w_frag, bias, add, out, H, relu, dbg);
-  }
   sf_prof_end(SF_K_CONV_NHWC, st);
   SF_CHECK_LAUNCH();
   return 0;

@@ -164,11 +164,20 @@ extern "C" int sf_debug_spin(int us, void* stream) {
   return 0;
 }
 
+// clears a[0..n) and b[0..n): float4 stores where both pointers are 16-byte aligned and four elements remain, scalars otherwise
+// (launch with ceil(n / 4) threads)
 __global__ void zero_f32_kernel(float* a, float* b, long long n) {
   const long long i = 4 * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
-  if (i < n) {
+  if (i >= n) return;
+  const bool vec = i + 4 <= n && ((((unsigned long long)(a + i)) | ((unsigned long long)(b + i))) & 15ull) == 0;
+  if (vec) {
     *(float4*)(a + i) = float4{0.f, 0.f, 0.f, 0.f};
     *(float4*)(b + i) = float4{0.f, 0.f, 0.f, 0.f};
+  } else {
+    for (long long j = i; j < n && j < i + 4; ++j) {
+      a[j] = 0.f;
+      b[j] = 0.f;
+    }
   }
 }
 
@@ -258,7 +267,7 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
     if (attn_rows) {
       // key positions >= L of the v^T planes meet probability 0 in the PV product: they must hold finite values
       const long long nfl = (long long)(sf_attn_rows_plane_bytes(B) / 4), half = nfl / 2;
-      hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((half / 4 + 255) / 256)), dim3(256), 0, st, planes, planes + half, half);
+      hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)(((half + 3) / 4 + 255) / 256)), dim3(256), 0, st, planes, planes + half, half);
       SF_CHECK_LAUNCH();
     }
   }
@@ -700,7 +709,7 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
     // (a KERNEL, not hipMemsetAsync: the encode may be captured into a hipGraph, and memset nodes were seen to stop clearing
     //  after an older graph exec had been destroyed -- see zero_words_kernel above; pipeline encode graphs hit it at once)
     const long long nz = (long long)R * m->pred_hidden;
-    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((nz / 4 + 255) / 256)), dim3(256), 0, st, lstm_h, lstm_c, nz);
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)(((nz + 3) / 4 + 255) / 256)), dim3(256), 0, st, lstm_h, lstm_c, nz);
     SF_CHECK_LAUNCH();
   }
   const long long frame_elems = (long long)3 * res * res;

@@ -103,8 +103,9 @@ def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises
     """Whole hot path over many videos: SAVi slot extraction of the burn-in frames followed by the SlotFormer rollout
     (extract_slots.py:19-38 + rollout_clevrer_slots.py:20-65 / test_phyre_planning.py:159-174 as one on-device call).
 
-    videos [V, T_burn, 3, H, W]: a device tensor, or a HOST tensor -- then the frames stay on the host (pinned) and are
-    uploaded batch by batch by the pipeline's copy stage ahead of the encode, never the whole set at once.  rollouter: the
+    videos [V, T_burn, 3, H, W]: a device tensor, or a HOST tensor -- then the frames stay on the host and are uploaded batch by
+    batch by the pipeline's copy stage ahead of the encode, never the whole set at once (pinned input is copied straight from where it
+    lies -- the fast path; pageable input passes through a small ring of page-locked staging buffers, one host memcpy per batch).  rollouter: the
     SlotRollouter / SingleStepSlotRollouter container (e.g. `slotformer.rollouter`).  Returns slots [V, T_burn + pred_len,
     N, D] on the device, or in pinned host memory with to_host=True (downloaded behind each rollout; what the reference's
     drivers do before pickling, extract_slots.py:36).  Full batches go through `pipeline.EncodeRolloutPipeline` (kept
@@ -115,8 +116,8 @@ def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises
     dev = next(rollouter.parameters()).device
     videos = videos.float()
     host_in = not videos.is_cuda
-    if host_in and not videos.is_pinned():
-        videos = videos.contiguous().pin_memory()
+    if host_in:
+        videos = videos.contiguous()   # (pageable input is staged batch by batch through the pipeline's ring of page-locked buffers)
     V, T = videos.shape[:2]
     N, D = rollouter.num_slots, rollouter.in_proj.in_features
     out = torch.empty(V, T + pred_len, N, D, pin_memory=True) if to_host else torch.empty(V, T + pred_len, N, D, device=dev)

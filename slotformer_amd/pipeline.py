@@ -267,6 +267,7 @@ class EncodeRolloutPipeline:
         if not self.roll_streams:
             self.roll_streams = [self.s_roll]
         # unmasked streams for the drain units
+        self.stream_placement = None
         self.s_free = self._pick_free_streams(2) if len(self.roll_streams) > 1 else []
         self.s_enc = self.lanes[0][0]
         self.fill_whole_chip = True      # the first encode(s) of a run on the calling stream (all CUs)
@@ -310,9 +311,16 @@ class EncodeRolloutPipeline:
         self._stage, self._s_copy, self._s_out = None, None, None   # staging ring + copy streams for host-resident inputs / outputs
         self.completion_events = []      # one event per unit of the last run() ...
         self.completion_batches = []     # ... and the number of batches it completed
+        # the encode graphs hold raw pointers into the SAVi encoder's plan (packed conv weights, folded Slot-Attention matrices,
+        # predictor fragments): the pipeline keeps that plan alive and re-captures when the encoder's parameters change (_check_plan)
+        self._enc_plan = engine.encoder_plan(self.savi)
+        self._enc_sig = self._enc_plan.sig
+        self._capture_encode_graphs()
+
+    def _capture_encode_graphs(self):
+        """Capture the encode graphs of the lanes a run uses NOW, not inside the first run that reaches them (a short warm-up only
+        touches the fill lanes): full batches, no stolen features."""
         if self.encode_graph and self.steal == 0 and not self.fill_steal and not self.pre_steal:
-            # the encode graphs of the lanes a run uses are captured NOW, not inside the first run that reaches them (a short
-            # warm-up only touches the fill lanes): full batches, no stolen features
             res = getattr(self.savi, 'resolution', (128, 128))[0]
             with_noise = engine.kernel_noise(self.savi, torch.empty(0), 1, self.T, self.dev) is not None   # (no draw: the gate only)
             with torch.no_grad():
@@ -392,7 +400,9 @@ class EncodeRolloutPipeline:
         key = ('free-set', self.dev.index, n)
         with _STREAMS_LOCK:
             got = _STREAMS.get(key)
+            placed = _STREAMS.get(('placement', self.dev.index))
         if got is not None:
+            self.stream_placement = placed
             return list(got)
         if int(os.environ.get('SF_PIPE_FREE_MASKED', '0')):
             # (probe) streams with a full CU mask: the runtime gives every CU-masked stream a hardware queue of its own
@@ -407,7 +417,18 @@ class EncodeRolloutPipeline:
             rccl = dist.is_available() and dist.is_initialized() and 'nccl' in str(dist.get_backend())
         except Exception:  # noqa: BLE001
             rccl = False
-        for _ in range(int(os.environ.get('SF_PIPE_FREE_SKIP', '0' if rccl else '1'))):
+        n_skip = int(os.environ.get('SF_PIPE_FREE_SKIP', '0' if rccl else '1'))
+        # what was chosen, for the bench line / the logs of every rank (the rule is tuned to this runtime's round-robin over four
+        # hardware queues; SF_PIPE_FREE_SKIP overrides)
+        self.stream_placement = {'parked_streams_before_the_free_ones': n_skip, 'free_streams': n, 'rccl_initialised': bool(rccl),
+                                 'rule': 'SF_PIPE_FREE_SKIP' if 'SF_PIPE_FREE_SKIP' in os.environ else ('rccl: none parked' if rccl else 'one parked'),
+                                 'rank': int(os.environ.get('RANK', '0')), 'device': self.dev.index}
+        if os.environ.get('SF_PIPE_LOG_PLACEMENT', '0') == '1' or int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            import sys
+            print(f'[slotformer_amd.pipeline] stream placement: {self.stream_placement}', file=sys.stderr, flush=True)
+        with _STREAMS_LOCK:
+            _STREAMS[('placement', self.dev.index)] = self.stream_placement
+        for _ in range(n_skip):
             sk = torch.cuda.Stream(device=self.dev)
             with torch.cuda.device(self.dev):
                 _lib.check(self._lib.sf_debug_spin(1, sk.cuda_stream))   # (used: a stream gets its hardware queue on first use)
@@ -464,11 +485,19 @@ class EncodeRolloutPipeline:
         return self._tails[(nb, k)]
 
     def _check_plan(self):
-        if engine._signature(self.roll) != self._sig:
+        if engine._signature(self.roll) != self._sig or getattr(self.roll, '_sf_plan', None) is not self._plan:
             # parameters changed since the capture (optimizer step, load_state_dict, invalidate): the graphs point at the
             # old packed weight copies
             torch.cuda.synchronize(self.dev)
             self._capture_all()
+        if engine._signature(self.savi) != self._enc_sig or getattr(self.savi, '_sf_plan', None) is not self._enc_plan:
+            # the same for the encoder: its graphs replay kernels with pointers into the OLD plan's packed / folded copies (and an
+            # eager savi_encode / savi_cnn call elsewhere may have rebuilt -- and freed -- that plan)
+            torch.cuda.synchronize(self.dev)
+            self._enc_graphs = {}
+            self._enc_plan = engine.encoder_plan(self.savi)
+            self._enc_sig = self._enc_plan.sig
+            self._capture_encode_graphs()
 
     def _steal_of(self, j):
         """time steps of convolutions stolen for batch j: integers that average to self.steal (1.25 -> 1, 1, 1, 2, ...)"""
@@ -630,10 +659,16 @@ class EncodeRolloutPipeline:
         # its videos from a DataLoader; this is the device side of that hand-over)
         NS = NF + 2
         ev_up, up_next = [], [0]
+        pinned_in = host_in and all(im.is_pinned() for im in imgs)
         if host_in:
             if self._stage is None or self._stage[0].shape != imgs[0].shape:
                 self._stage = [torch.empty(imgs[0].shape, device=self.dev) for _ in range(NS)]
                 self._s_copy = self._pool_stream('copy')
+                self._pin = None
+            if not pinned_in and getattr(self, '_pin', None) is None:
+                # pageable input: batches pass through a ring of NS page-locked staging buffers (never the whole set page-locked at once;
+                # the host pays one memcpy per batch -- pre-pinned input skips it)
+                self._pin = [torch.empty(imgs[0].shape, pin_memory=True) for _ in range(NS)]
             self._s_copy.wait_stream(cur)
             ev_up = [torch.cuda.Event() for _ in range(n)]
 
@@ -650,7 +685,13 @@ class EncodeRolloutPipeline:
                         # masked encode lane ran at 5.8 instead of 4.05 ms per batch with the wait on the stream)
                         for e in ev_enc[k - NS]:
                             e.synchronize() if os.environ.get('SF_PIPE_UPLOAD_WAIT', 'host') == 'host' else self._s_copy.wait_event(e)
-                    self._stage[k % NS].copy_(imgs[k], non_blocking=True)
+                    src = imgs[k]
+                    if not pinned_in:
+                        if k >= NS:
+                            ev_up[k - NS].synchronize()   # the upload out of this page-locked slot is done
+                        self._pin[k % NS].copy_(src)
+                        src = self._pin[k % NS]
+                    self._stage[k % NS].copy_(src, non_blocking=True)
                     ev_up[k].record(self._s_copy)
                 up_next[0] += 1
             stream.wait_event(ev_up[j])

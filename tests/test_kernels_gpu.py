@@ -278,7 +278,9 @@ def test_mha(dev, B, L, d, h, Lq):
 
 @pytest.mark.parametrize('B,L,d,h,Lq,ln', [(3, 42, 256, 8, 42, True), (3, 42, 256, 8, 7, True), (2, 48, 256, 8, 48, True),
                                            (2, 36, 128, 8, 36, True), (4, 6, 128, 4, 6, True), (2, 6, 192, 4, 6, True),
-                                           (2, 8, 128, 4, 8, False), (1, 64, 256, 4, 64, True), (2, 33, 128, 8, 5, True)])  # (d, hd) pairs the engine fuses
+                                           (2, 8, 128, 4, 8, False), (1, 64, 256, 4, 64, True), (2, 33, 128, 8, 5, True),
+                                           # windows of 65..128 tokens (four token blocks): the reference's own Physion window, 15 frames x 6 slots
+                                           (3, 90, 256, 8, 6, True), (2, 90, 256, 8, 90, True), (2, 128, 256, 8, 8, True), (2, 65, 256, 8, 5, True)])  # (d, hd) pairs the engine fuses
 def test_fused_qkv_attention(dev, B, L, d, h, Lq, ln):
     """LN -> in_proj -> MHA (before out_proj) vs torch fp32."""
     from slotformer_amd import ops

@@ -153,6 +153,8 @@ def test_extract_and_rollout_entry(dev):
         out_d = harness.extract_and_rollout(savi, roll, videos.to(dev), H, batch_size=bs, noises=noises)
         out_h = harness.extract_and_rollout(savi, roll, videos, H, batch_size=bs, noises=noises, to_host=True)
         assert torch.equal(out_d, out) and not out_h.is_cuda and out_h.is_pinned() and torch.equal(out_h, out.cpu())
+        # pre-pinned input (copied straight from where it lies) = pageable input (through the ring of page-locked staging buffers)
+        assert torch.equal(harness.extract_and_rollout(savi, roll, videos.pin_memory(), H, batch_size=bs, noises=noises), out)
         assert len(harness._PIPES) == n_pipes == 1
         # another shape: only the most recently used pipeline stays alive by default (MAX_PIPELINES = 1: idle hardware queues
         # are not free on this platform), the earlier one is closed -- and rebuilt, with the same results, when its shape returns
@@ -298,6 +300,44 @@ def test_pipeline_recaptures_after_a_weight_update(dev):
         assert torch.equal(out1, ref1) and not torch.equal(out1, out0)
         pipe.close()
         pipe2.close()
+
+
+def test_pipeline_recaptures_after_an_encoder_weight_update(dev):
+    """The ENCODE graphs point into the SAVi encoder's plan (packed conv weights, fragment copies, folded Slot-Attention matrices):
+    after an in-place update of an encoder parameter, a load_state_dict, or an `engine.invalidate` + eager encode that rebuilt (and
+    freed) the plan, run() must re-capture them instead of replaying the old packed copies."""
+    from slotformer_amd import engine
+    from slotformer_amd.pipeline import EncodeRolloutPipeline
+    B, T, H, nbatch = 4, 6, 4, 5
+    savi, roll = _models(dev, gu.C2_SAVI, gu.C2_ROLL, seed=9)
+    rs = np.random.RandomState(37)
+    imgs = [torch.from_numpy((rs.rand(B, T, 3, 128, 128) * 2 - 1).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    noises = [torch.from_numpy(rs.standard_normal((B, T, 7, 128)).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    with torch.no_grad():
+        pipe = EncodeRolloutPipeline(savi, roll, B, T, H, encode_graph=True)
+        assert len(pipe._enc_graphs) >= 1
+        out0 = pipe.run(imgs, noises).clone()
+        assert torch.equal(out0, _serial_reference(savi, roll, imgs, noises, T, H, PAIR_OPTS))
+        # (1) a packed weight (conv fragments), a folded one (project_k -> Wk^T Wq) and a plain vector, updated in place
+        savi.encoder[2][0].weight.mul_(1.25)
+        savi.slot_attention.project_k.weight.mul_(0.8)
+        savi.encoder_out_layer[0].bias.add_(0.1)
+        ref1 = _serial_reference(savi, roll, imgs, noises, T, H, PAIR_OPTS)
+        out1 = pipe.run(imgs, noises).clone()
+        assert torch.equal(out1, ref1) and not torch.equal(out1, out0)
+        # (2) a second checkpoint loaded into the same module
+        other, _ = _models(dev, gu.C2_SAVI, gu.C2_ROLL, seed=10)
+        savi.load_state_dict(other.state_dict())
+        ref2 = _serial_reference(savi, roll, imgs, noises, T, H, PAIR_OPTS)
+        out2 = pipe.run(imgs, noises).clone()
+        assert torch.equal(out2, ref2) and not torch.equal(out2, out1)
+        # (3) the plan dropped and rebuilt by an eager call elsewhere (same parameter values: same results, fresh graphs)
+        old = pipe._enc_plan
+        engine.invalidate(savi)
+        engine.savi_encode(savi, imgs[0], noise=noises[0])
+        out3 = pipe.run(imgs, noises)
+        assert pipe._enc_plan is not old and torch.equal(out3, ref2)
+        pipe.close()
 
 
 @pytest.mark.parametrize('name', ['C2', 'C5'])

@@ -83,7 +83,7 @@ def test_row_tile_attention_form(dev, B):
     assert torch.equal(sub, a[1:3])
 
 
-@pytest.mark.parametrize('L,Lq,B', [(42, 42, 5), (42, 7, 3), (48, 8, 2), (7, 7, 4), (64, 64, 2)])
+@pytest.mark.parametrize('L,Lq,B', [(42, 42, 5), (42, 7, 3), (48, 8, 2), (7, 7, 4), (64, 64, 2), (36, 36, 5), (36, 6, 16), (16, 8, 3)])   # (36: C4's window, 6 frames x 6 slots)
 @torch.no_grad()
 def test_attention_block_kernels(dev, L, Lq, B):
     """Kernel-level: both forms of the fused attention block (head-pair workgroups with four partial outputs; all-heads
@@ -139,6 +139,45 @@ def test_throughput_settings_vs_reference_fixture(dev, opts):
     e0, e1 = rel_err(out[:2], g['pred_slots']), rel_err(out[2:], g['pred_slots'])
     print('roll_c2 with', opts, 'rel err', e0, e1)
     assert e0 < 2e-4 and e1 < 2e-4
+
+
+def rel_err_elementwise(a, b, floor=1e-3):
+    """max over elements of |a - b| / max(|b|, floor * max|b|): an element-wise relative error with an absolute floor (elements near
+    zero would make a plain ratio meaningless for slots)"""
+    a, b = a.detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    return ((a - b).abs() / b.abs().clamp_min(floor * b.abs().max())).max().item()
+
+
+@pytest.mark.parametrize('name,cfg,seed,videos,H,at', [('roll_c4_full', gu.C4_ROLL, 224, 64, 40, 37), ('roll_c5_full', gu.C5_ROLL, 225, 256, 80, 201)])
+@torch.no_grad()
+def test_throughput_forms_vs_reference_fixture_c4_c5(dev, name, cfg, seed, videos, H, at):
+    """The kernel forms the pipeline picks for C4 (units of 4 x 16 = 64 videos: L = 36, slot size 192, 8 layers, 6 + 40) and C5 (4 x 64 =
+    256 videos: SingleStepSlotRollouter, window growing 8 -> 48 tokens, 1 + 80) -- row-tile q|k|v + attention core, FFN tiles fused with
+    the next layer's q|k|v, all-heads / 128-row forms below them -- against the REFERENCE's full-horizon fixture: the fixture video sits
+    at two places of a unit-sized batch of other videos (row tiles cut across videos), both copies vs the fixture over the whole horizon."""
+    from test_engine_gpu import build
+    from slotformer_amd import engine
+    from slotformer_amd.pipeline import EncodeRolloutPipeline  # noqa: F401  (the options below are pipeline.py's for these unit sizes)
+    g = gu.load_golden(name)
+    m, _ = build(cfg, g, seed, dev, vp=True)
+    roll = m.rollouter
+    rd = cfg['rollout_dict']
+    hist, N, C = rd['history_len'], rd['num_slots'], rd['slot_size']
+    T_in = engine.burn_in_of(roll)
+    x = gu.seeded_normal((videos, hist, N, C), seed + 60).to(dev)
+    fx = gu.seeded_normal((1, hist + H, N, C), seed + 1)[0, :hist].to(dev)
+    x[0], x[at] = fx, fx
+    x = x[:, :T_in].contiguous() if T_in < hist else x
+    opts = {'seam': False, 'ffn_rows': 128, 'attn_heads': 8, 'attn_rows': 128, 'ffn_tile': 2}
+    out = _roll(roll, x, H, opts)
+    assert torch.isfinite(out).all()
+    for i in (0, at):
+        e, ee = rel_err(out[i:i + 1], g['pred_slots']), rel_err_elementwise(out[i:i + 1], g['pred_slots'])
+        print(name, 'throughput forms, video', i, 'of', videos, ': rel err (max-norm)', e, ' element-wise (floor 1e-3 max|ref|)', ee)
+        assert e < 2e-4 and ee < 1e-3
+    assert torch.equal(out[0], out[at])            # a video's bits do not depend on where it sits in the unit
+    ref = _roll(roll, x[:3].contiguous(), H)        # the library defaults (latency forms) on a small batch: the same bits
+    assert torch.equal(ref[0], out[0])
 
 
 @torch.no_grad()

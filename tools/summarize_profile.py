@@ -108,7 +108,11 @@ def is_conv(name):  # conv5x5_halo_kernel, or sf_gemm_kernel<..., ALOAD=1 (NHWC 
     return bool(m) and m.group(1).replace(' ', '').split(',')[8] == '1'
 
 
+sys.path.insert(0, R)
+from slotformer_amd.build import source_tree_hash  # noqa: E402
 traffic = {'source': f'profiles/{tag}_profile_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)',
+           # sha256 over slotformer_amd/csrc + include/ at the time of the trace: bench.py uses these numbers only while it matches
+           'source_tree': source_tree_hash(),
            'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of wide coalesced reads)'}
 # MFMA-busy fraction: SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs that ran the kernel; GRBM_GUI_ACTIVE is
 # the launch duration in cycles -> busy / (active * 1024 SIMDs) = share of the chip's matrix-pipe time that was used
