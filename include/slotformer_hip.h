@@ -97,6 +97,20 @@ int sf_pack_conv_frag_weights(const float* w_ohwi, void* frag, int Cout, int Cin
 int sf_conv5x5_frag_f32(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W,
                         int relu, void* stream);
 
+/* 64 -> 64 channel 5 x 5 stride-2 transposed convolutions (padding 2, output_padding 1: H x W -> 2H x 2W; the decoder layers of savi.py:252-293):
+ * w_ohwi (sf_pack_deconv_weight_f32) -> split-bf16 copy in the kernel's consumption order, sf_deconv_frag_bytes(64, 64, 5, 2) bytes;
+ * sf_deconv5x5s2_frag_f32: in [R][H][W][64] -> out [R][2H][2W][64] (+ bias, relu 0 / 1), W in {16, 32, 64}, H % (256 / W) == 0;
+ * sf_deconv5x5s2_head_frag_f32 (W == 64): dec [R][2H * 2W][4] = head_w [4][64] . relu(deconv(in) + bias) + head_b [4] -- the last decoder layer with
+ * the 1x1 output convolution (savi.py:286-289) in its epilogue.  Split-bf16 mode only (csrc/deconv_s2.hip). */
+size_t sf_deconv_frag_bytes(int Cout, int Cin, int ks, int stride);
+int sf_pack_deconv_frag_weights(const float* w_ohwi, void* frag, int Cout, int Cin, int ks, int stride, void* stream);
+int sf_deconv5x5s2_frag_f32(const float* in, const void* w_frag, const float* bias, float* out, int R, int H, int W, int relu, void* stream);
+int sf_deconv5x5s2_head_frag_f32(const float* in, const void* w_frag, const float* bias, const float* head_w, const float* head_b, float* dec,
+                                 int R, int H, int W, void* stream);
+/* First decoder layer on its broadcast input (sf_savi_decoder.l0_weff / l0_posterm): out [R][2 res][2 res][C1] = relu(table[r][class(p)] + posterm[p]),
+ * table [R][25 * C1]. */
+int sf_decode_l0_expand_f32(const float* table, const float* posterm, float* out, int R, int res, int C1, void* stream);
+
 /* Decoder building blocks (savi.py:252-293,504-525).  ConvTranspose2d(k, stride, padding=k/2,
  * output_padding=stride-1) as a gather implicit GEMM: NHWC in [F,Hin,Win,Cin] -> [F,Hin*s,Win*s,Cout];
  * w_packed [Cout,ks,ks,Cin] from the torch weight [Cin,Cout,ks,ks] (sf_pack_deconv_weight_f32). */
@@ -572,6 +586,17 @@ typedef struct {
    * stride-1 transposed convolution is an ordinary convolution with the flipped kernel, which lets those layers run on
    * the encoder's halo-resident 5x5 kernel (64 -> 64 channels, 64 pixels wide). */
   const float* deconv_w_flipped[8];
+  /* optional (NULL = absent), per 64 -> 64 channel 5 x 5 stride-2 layer: sf_pack_deconv_frag_weights copies of deconv_w[i] (split-bf16,
+   * consumption order) for the parity-class kernel with streamed weights (csrc/deconv_s2.hip; split-bf16 mode, input 16 / 32 / 64 wide).
+   * On the last layer that kernel also applies the 1x1 head, and the [F*N, H, W, 64] activation never reaches memory. */
+  const void* deconv_w_frag[8];
+  /* optional (NULL = absent): the FIRST layer (5 x 5, stride 2) on its broadcast input.  Its input is slot + pos_table[p] (savi.py:512-517),
+   * so  out[r, p] = relu( (sum of the taps valid at p) . slot[r] + const[p] ):  l0_weff [25 * C1, slot_size] holds the tap sums of the 5 x 5
+   * border / parity classes of an output pixel (class of a coordinate o = 2 o2 + par: par 0 -> {0: o2 == 0, 1: interior, 2: o2 == res - 1},
+   * par 1 -> {3: o2 < res - 1, 4: o2 == res - 1}; row (vy * 5 + vx) * C1 + co), l0_posterm [(2 dec_res)^2, C1] the transposed convolution of
+   * the position table + bias.  One [F*N, D] x [D, 25 C1] product and an expansion replace 98 % of the layer's multiplications. */
+  const float* l0_weff;
+  const float* l0_posterm;
 } sf_savi_decoder;
 
 size_t sf_savi_decode_workspace_bytes(const sf_savi_decoder* m, int F);

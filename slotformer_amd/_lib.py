@@ -110,7 +110,7 @@ class sf_savi_decoder(C.Structure):
     _fields_ = ([('resolution', C.c_int), ('dec_layers', C.c_int), ('dec_channels', C.c_int * 9),
                  ('dec_strides', C.c_int * 8), ('dec_ks', C.c_int), ('dec_res', C.c_int), ('num_slots', C.c_int),
                  ('slot_size', C.c_int), ('deconv_w', FP * 8), ('deconv_b', FP * 8), ('out_w', FP), ('out_b', FP),
-                 ('pos_table', FP), ('deconv_w_flipped', FP * 8)])
+                 ('pos_table', FP), ('deconv_w_flipped', FP * 8), ('deconv_w_frag', C.c_void_p * 8), ('l0_weff', FP), ('l0_posterm', FP)])
 
 
 I, LL, F32, SZ, VP = C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_void_p
@@ -139,6 +139,11 @@ SIGNATURES = {
     'sf_get_conv_fp16x2': (I, []),
     'sf_pack_conv_frag_weights': (I, [FP, VP, I, I, I, VP]),
     'sf_conv5x5_frag_f32': (I, [FP, VP, FP, FP, FP, I, I, I, I, VP]),
+    'sf_deconv_frag_bytes': (SZ, [I, I, I, I]),
+    'sf_pack_deconv_frag_weights': (I, [FP, VP, I, I, I, I, VP]),
+    'sf_deconv5x5s2_frag_f32': (I, [FP, VP, FP, FP, I, I, I, I, VP]),
+    'sf_deconv5x5s2_head_frag_f32': (I, [FP, VP, FP, FP, FP, FP, I, I, I, VP]),
+    'sf_decode_l0_expand_f32': (I, [FP, FP, FP, I, I, I, VP]),
     'sf_conv_transpose2d_nhwc_f32': (I, [FP, FP, FP, FP, I, I, I, I, I, I, I, I, VP]),
     'sf_pack_deconv_weight_f32': (I, [FP, FP, I, I, I, VP]),
     'sf_slot_broadcast_f32': (I, [FP, FP, FP, I, I, I, VP]),

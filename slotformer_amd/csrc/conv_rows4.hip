@@ -73,10 +73,13 @@ __device__ long long cr_ts[16];   // phase timestamps of workgroup 0 (SF_CONV_DB
 // F16X2 (opt-in, sf_set_conv_fp16x2 / SF_CONV_FP16X2=1; NOT the default arithmetic): the activations split into two fp16 terms (22 mantissa
 // bits), the weights rounded to ONE fp16 (11 bits: 2^-12 relative per weight) -- two MFMAs per product instead of three and half the weight
 // stream.  Measured error and speed: profiles/r03_probes.txt section 14.
-template <bool F16X2>
+// HEAD (the SAVi decoder's stride-1 last layer at 64 x 64, savi.py:262-289: a convolution with the flipped kernel + ReLU, then the 1x1 output
+// convolution 64 -> 4): `add` = head_w [4][64], `head_b` [4], out = dec [F][H * 64][4] -- the 64-channel activation never reaches memory.
+template <bool F16X2, bool HEAD = false>
 __global__ __launch_bounds__(NT) void conv5x5_rows4_kernel(const float* __restrict__ in, const uint4* __restrict__ wf,
                                                            const float* __restrict__ bias, const float* __restrict__ add,
-                                                           float* __restrict__ out, int H, int relu, int dbg) {
+                                                           float* __restrict__ out, int H, int relu, int dbg,
+                                                           const float* __restrict__ head_b = nullptr) {
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
   __bf16* Hh = lds;
   __bf16* Hl = Hh + HALO;
@@ -234,6 +237,43 @@ __global__ __launch_bounds__(NT) void conv5x5_rows4_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) fin[i][r] += X[((pw * 2 + i) * 16 + r) * 64 + lane];
 
+  if constexpr (HEAD) {
+    // ---- epilogue with the 1x1 head: s[j] = sum_c head_w[j][c] relu(y[c] + b[c]) over the lane's 16 channels, the other half wave's
+    //      (lane ^ 32), then the other cout block's (wave ^ 1) through LDS; cout block 0 adds head_b and stores 16 bytes per pixel ----
+    float* XH = (float*)lds + 16 * 1024;   // behind the 64 KB exchange of the cin halves: [rp * 2 + kh][i][32 pixels][4]
+    const int c0h = cb * 32 + 4 * (lane >> 5);
+    const int yh = y0 + 2 * rp + kh;
+    f32x4 sums[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x4 sj = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = bias ? *(const f32x4*)(bias + c0h + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float yv = fmaxf(fin[i][4 * g + q] + bv[q], 0.f);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sj[j] = fmaf(yv, add[j * CH + c0h + 8 * g + q], sj[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sj[j] += __shfl_xor(sj[j], 32, 64);
+      sums[i] = sj;
+      if (cb == 1 && lane < 32) *(f32x4*)(XH + (((rp * 2 + kh) * 2 + i) * 32 + lane) * 4) = sj;
+    }
+    __syncthreads();
+    if (cb == 0 && lane < 32) {
+      const f32x4 hb = *(const f32x4*)head_b;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f32x4 oth = *(const f32x4*)(XH + (((rp * 2 + kh) * 2 + i) * 32 + lane) * 4);
+        *(f32x4*)(out + (((long long)f * H + yh) * TW + i * 32 + lane) * 4) = (sums[i] + oth) + hb;
+      }
+    }
+    CTS(7);
+    return;
+  }
   // ---- epilogue: bias, ReLU, optional per-position table, NHWC store (a lane holds 4 x 4 consecutive channels of one pixel) ----
   // relu == 2 (training, backward-data pass): `add` is the forward activation of the layer below, laid out like `out`, and
   // acts as its ReLU mask -- out = add > 0 ? conv : 0
@@ -301,6 +341,20 @@ int sf_conv5x5_rows4_ex(const float* in, const void* w_frag, const float* bias, 
     hipLaunchKernelGGL(conv5x5_rows4_kernel<true>, dim3(F * (H / TR)), dim3(NT), LDS_BYTES, st, in, (const uint4*)w_frag, bias, add, out, H, relu, dbg);
   else
     hipLaunchKernelGGL(conv5x5_rows4_kernel<false>, dim3(F * (H / TR)), dim3(NT), LDS_BYTES, st, in, (const uint4*)w_frag, bias, add, out, H, relu, dbg);
+  sf_prof_end(SF_K_CONV_NHWC, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+// The decoder's stride-1 last layer + 1x1 head (HEAD form above).  Returns 1 when the kernel does not apply.
+int sf_conv5x5_rows4_head_ex(const float* in, const void* w_frag, const float* bias, const float* head_w, const float* head_b, float* dec,
+                             int F, int H, int W, int Cin, int Cout, int ks, hipStream_t st) {
+  if (!w_frag || !head_w || !head_b || W != TW || Cin != CH || Cout != CH || ks != KS || (H % TR) != 0 || F <= 0 || sf_get_precision() != 1) return 1;
+  static const int dbg = getenv("SF_CONV_DBG") ? atoi(getenv("SF_CONV_DBG")) : 0;
+  SF_TRY(sf_ensure_dyn_lds((const void*)conv5x5_rows4_kernel<false, true>, LDS_BYTES));
+  sf_prof_begin(SF_K_CONV_NHWC, st, 2.0 * (double)F * H * W * Cout * ks * ks * Cin);
+  hipLaunchKernelGGL((conv5x5_rows4_kernel<false, true>), dim3(F * (H / TR)), dim3(NT), LDS_BYTES, st, in, (const uint4*)w_frag, bias, head_w, dec, H,
+                     1, dbg, head_b);
   sf_prof_end(SF_K_CONV_NHWC, st);
   SF_CHECK_LAUNCH();
   return 0;

@@ -307,6 +307,34 @@ __global__ void slot_broadcast_kernel(const float* __restrict__ slots, const flo
   out[idx] = slots[r * D + c] + table[(long long)pp * D + c];
 }
 
+// First decoder layer on its broadcast input (sf_savi_decoder.l0_weff / l0_posterm): a 5 x 5 stride-2 transposed convolution of
+// slot + pos_table[p] is  (sum of the taps that reach output pixel p from INSIDE the map) . slot + const[p]; the tap set depends on p only
+// through the parity and border class of its two coordinates (5 x 5 classes).  table [R][25 * C1] = slots . l0_weff^T (one GEMM),
+// out [R][2 res][2 res][C1] = relu(table[r][class(oy) * 5 + class(ox)] + posterm[oy][ox])   (savi.py:512-518 with nerv's deconv + ReLU)
+__device__ __forceinline__ int l0_class(int o, int res) {
+  const int o2 = o >> 1;
+  if (o & 1) return o2 == res - 1 ? 4 : 3;
+  return o2 == 0 ? 0 : (o2 == res - 1 ? 2 : 1);
+}
+__global__ void decode_l0_expand_kernel(const float* __restrict__ table, const float* __restrict__ posterm, float* __restrict__ out,
+                                        int R, int res, int C1) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 of channels
+  const int c4n = C1 / 4, W = 2 * res;
+  if (idx >= (long long)R * W * W * c4n) return;
+  const int c4 = idx % c4n;
+  const long long rp = idx / c4n;
+  const int pix = rp % (W * W);
+  const long long r = rp / (W * W);
+  const int oy = pix / W, ox = pix - oy * W;
+  const int cls = l0_class(oy, res) * 5 + l0_class(ox, res);
+  const f32x4 a = *(const f32x4*)(table + (r * 25 + cls) * C1 + 4 * c4);
+  const f32x4 b = *(const f32x4*)(posterm + (long long)pix * C1 + 4 * c4);
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = fmaxf(a[e] + b[e], 0.f);
+  *(f32x4*)(out + idx * 4) = v;
+}
+
 // decoder head (savi.py:519-525): dec [F*N, HW, 4] (r,g,b,mask-logit per slot) ->
 // masks = softmax over slots, recon_combined = sum_n recons * masks; all outputs NCHW-per-frame.
 __global__ void decode_combine_kernel(const float* __restrict__ dec, float* __restrict__ recon,
@@ -412,6 +440,16 @@ int sf_slot_broadcast_f32(const float* slots, const float* table, float* out, in
   if (total == 0) return 0;
   hipLaunchKernelGGL(slot_broadcast_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      slots, table, out, R, P, D);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
+int sf_decode_l0_expand_f32(const float* table, const float* posterm, float* out, int R, int res, int C1, void* stream) {
+  SF_REQUIRE(table && posterm && out && R >= 0 && res >= 2 && C1 > 0 && (C1 % 4) == 0, "bad l0-expand arguments");
+  const long long total = (long long)R * 4 * res * res * (C1 / 4);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(decode_l0_expand_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, posterm,
+                     out, R, res, C1);
   SF_CHECK_LAUNCH();
   return 0;
 }

@@ -911,10 +911,11 @@ static int dec_cmax(const sf_savi_decoder* m) {
   for (int i = 0; i <= m->dec_layers && i < 9; ++i) c = m->dec_channels[i] > c ? m->dec_channels[i] : c;
   return c;
 }
-// frames per chunk: keep one activation buffer around <= 256 MB
+// frames per chunk: one activation buffer <= 1 GiB (the largest map of a slot image is resolution^2 x channels floats; 32 frames of 7 slots
+// at 128 x 128 x 64 are 0.92 GB: one chunk -- 288 GB of HBM make chunks of 4 frames, the round-1 size, pointless)
 static int dec_chunk(const sf_savi_decoder* m, int F) {
   const double per_frame = (double)m->num_slots * m->resolution * m->resolution * dec_cmax(m);
-  int fc = (int)(64.0 * 1024 * 1024 / per_frame);
+  int fc = (int)(256.0 * 1024 * 1024 / per_frame);
   if (fc < 1) fc = 1;
   return fc < F ? fc : F;
 }
@@ -947,27 +948,57 @@ int sf_savi_decode_f32(const sf_savi_decoder* m, const float* slots, float* reco
   float* bufB = bp.take((size_t)Fc * N * HW * cmax);
   float* dec = bp.take((size_t)Fc * N * HW * 4);
   if (!bp.ok) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
+  const bool bf3 = sf_get_precision() == 1;
+  const int nl = m->dec_layers, Cl = m->dec_channels[nl];
   for (int f0 = 0; f0 < F; f0 += Fc) {
     const int nf = (F - f0 < Fc) ? (F - f0) : Fc, R = nf * N;
-    SF_TRY(sf_slot_broadcast_f32(slots + (long long)f0 * N * D, m->pos_table, bufA, R, m->dec_res * m->dec_res, D, st));
     float* cur = bufA;
     float* nxt = bufB;
     int hin = m->dec_res;
-    for (int i = 0; i < m->dec_layers; ++i) {
-      if (m->dec_strides[i] == 1 && m->deconv_w_flipped[i])   // = convolution with the flipped kernel (halo-resident 5x5 path)
-        SF_TRY(sf_conv2d_nhwc_f32(cur, m->deconv_w_flipped[i], m->deconv_b[i], nullptr, nxt, R, hin, hin, m->dec_channels[i],
-                                  m->dec_channels[i + 1], m->dec_ks, 1, st));
-      else
-        SF_TRY(sf_conv_transpose2d_nhwc_f32(cur, m->deconv_w[i], m->deconv_b[i], nxt, R, hin, hin, m->dec_channels[i],
-                                            m->dec_channels[i + 1], m->dec_ks, m->dec_strides[i], 1, st));
-      hin *= m->dec_strides[i];
+    bool head_done = false;
+    for (int i = 0; i < nl; ++i) {
+      const int Ci = m->dec_channels[i], Co = m->dec_channels[i + 1], sd = m->dec_strides[i];
+      const bool last = i == nl - 1;
+      int rc = 1;
+      if (i == 0) {
+        if (m->l0_weff && m->l0_posterm && sd == 2 && m->dec_ks == 5 && hin >= 2 && 25 * Co <= HW * cmax) {
+          // the first layer on its broadcast input: table [R][25 Co] = slots . l0_weff^T, then the expansion (include/slotformer_hip.h)
+          SF_TRY(sf_linear_ex(slots + (long long)f0 * N * D, sf_rows(D), m->l0_weff, nullptr, nullptr, nullptr, 0.f, nullptr, sf_rows(25 * Co), 0,
+                              nxt, sf_rows(25 * Co), R, 25 * Co, D, 0, st));
+          SF_TRY(sf_decode_l0_expand_f32(nxt, m->l0_posterm, cur, R, hin, Co, st));
+          hin *= sd;
+          continue;
+        }
+        SF_TRY(sf_slot_broadcast_f32(slots + (long long)f0 * N * D, m->pos_table, cur, R, m->dec_res * m->dec_res, D, st));
+      }
+      if (bf3 && sd == 2 && m->deconv_w_frag[i]) {
+        // parity-class kernel with streamed weight fragments; on the last layer with the 1x1 head in its epilogue (deconv_s2.hip)
+        const bool head = last && hin == 64 && Cl == 64;
+        rc = sf_deconv5x5s2_ex(cur, m->deconv_w_frag[i], m->deconv_b[i], head ? m->out_w : nullptr, head ? m->out_b : nullptr,
+                               head ? dec : nxt, R, hin, hin, Ci, Co, m->dec_ks, sd, 1, st);
+        if (rc < 0 || rc > 1) return rc;
+        if (rc == 0 && head) head_done = true;
+      }
+      if (rc == 1 && bf3 && sd == 1 && last && m->deconv_w_frag[i] && hin == 64) {
+        // stride-1 last layer (the 64 x 64 configurations): the encoder's 4-row-tile convolution on the flipped kernel, 1x1 head in the epilogue
+        rc = sf_conv5x5_rows4_head_ex(cur, m->deconv_w_frag[i], m->deconv_b[i], m->out_w, m->out_b, dec, R, hin, hin, Ci, Co, m->dec_ks, st);
+        if (rc < 0 || rc > 1) return rc;
+        if (rc == 0) head_done = true;
+      }
+      if (rc == 1) {
+        if (sd == 1 && m->deconv_w_flipped[i])   // = convolution with the flipped kernel (halo-resident 5x5 path)
+          SF_TRY(sf_conv2d_nhwc_f32(cur, m->deconv_w_flipped[i], m->deconv_b[i], nullptr, nxt, R, hin, hin, Ci, Co, m->dec_ks, 1, st));
+        else
+          SF_TRY(sf_conv_transpose2d_nhwc_f32(cur, m->deconv_w[i], m->deconv_b[i], nxt, R, hin, hin, Ci, Co, m->dec_ks, sd, 1, st));
+      }
+      hin *= sd;
       float* tmp = cur;
       cur = nxt;
       nxt = tmp;
     }
-    const int Cl = m->dec_channels[m->dec_layers];
-    SF_TRY(sf_linear_ex(cur, sf_rows(Cl), m->out_w, m->out_b, nullptr, nullptr, 0.f, nullptr, sf_rows(4), 0, dec,
-                        sf_rows(4), R * HW, 4, Cl, 0, st));
+    if (!head_done)
+      SF_TRY(sf_linear_ex(cur, sf_rows(Cl), m->out_w, m->out_b, nullptr, nullptr, 0.f, nullptr, sf_rows(4), 0, dec,
+                          sf_rows(4), R * HW, 4, Cl, 0, st));
     SF_TRY(sf_decode_combine_f32(dec, recon_combined + (long long)f0 * 3 * HW,
                                  recons ? recons + (long long)f0 * N * 3 * HW : nullptr,
                                  masks ? masks + (long long)f0 * N * HW : nullptr, nf, N, HW, st));

@@ -70,6 +70,11 @@ int sf_qkv_attn_ex(const float* x, const float* ln_g, const float* ln_b, float l
 extern "C" int sf_get_precision(void);
 int sf_conv5x5_rows4_ex(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W,
                         int Cin, int Cout, int ks, int relu, hipStream_t st);
+// decoder layers on fragment weights (deconv_s2.hip, conv_rows4.hip); return 1 when the kernel does not apply
+int sf_deconv5x5s2_ex(const float* in, const void* w_frag, const float* bias, const float* head_w, const float* head_b, float* out, int R,
+                      int H, int W, int Cin, int Cout, int ks, int stride, int relu, hipStream_t st);
+int sf_conv5x5_rows4_head_ex(const float* in, const void* w_frag, const float* bias, const float* head_w, const float* head_b, float* dec,
+                             int F, int H, int W, int Cin, int Cout, int ks, hipStream_t st);
 int sf_conv5x5_halo_ex(const float* in, const float* w_packed, const float* bias, const float* add, float* out, int F,
                        int H, int W, int Cin, int Cout, int ks, int relu, hipStream_t st);
 int sf_pixel_mlp_kv_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1,

@@ -459,6 +459,35 @@ def decoder_plan(m):
         if dc.stride[0] == 1:   # [Cout, ks, ks, Cin] flipped over both kernel axes: the equivalent convolution kernel
             s.deconv_w_flipped[i] = plan.dp(packed.flip(1, 2).contiguous())
         s.deconv_b[i] = plan.dp(dc.bias)
+        if packed.is_cuda and tuple(dc.weight.shape) == (64, 64, 5, 5):
+            st = torch.cuda.current_stream().cuda_stream
+            if dc.stride[0] == 2:
+                # consumption-ordered split-bf16 fragments: the parity-class kernel with streamed weights (deconv_s2.hip)
+                frag = torch.empty(lib().sf_deconv_frag_bytes(64, 64, 5, 2), dtype=torch.uint8, device=packed.device)
+                check(lib().sf_pack_deconv_frag_weights(packed.data_ptr(), frag.data_ptr(), 64, 64, 5, 2, st))
+                plan.keep.append(frag)
+                s.deconv_w_frag[i] = frag.data_ptr()
+            elif dc.stride[0] == 1 and i == n - 1:
+                # stride-1 last layer: the encoder's 4-row-tile convolution on the flipped kernel, 1x1 head in its epilogue (conv_rows4.hip)
+                frag = ops.pack_conv_frag(packed.flip(1, 2).contiguous())
+                plan.keep.append(frag)
+                s.deconv_w_frag[i] = frag.data_ptr()
+    dc0 = m.decoder[0][0]
+    if dc0.stride[0] == 2 and m.dec_ks == 5 and m.dec_resolution[0] >= 2 and dc0.bias is not None:
+        # the first layer acts on slot + pos_table[p]: tap sums per border / parity class + the transposed convolution of the position
+        # table (include/slotformer_hip.h, l0_weff / l0_posterm) -- a one-time fp64 fold on the host, exact algebra
+        res0 = m.dec_resolution[0]
+        w0 = dc0.weight.detach().double().cpu()                                  # [D, C1, 5, 5]
+        taps = ([0, 2], [0, 2, 4], [2, 4], [1, 3], [3])                          # class -> taps whose input lies inside the map
+        weff = torch.stack([torch.stack([w0[:, :, ky][:, :, :, kx].sum((2, 3)).t() for kx in taps]) for ky in taps])   # [5, 5, C1, D]
+        pe0 = m.decoder_pos_embedding
+        tab = ops.pos_embed_table(pe0.grid.detach().float(), pe0.dense.weight.detach().float().contiguous(),
+                                  pe0.dense.bias.detach().float().contiguous()).double().cpu()                        # [res^2, D]
+        pos_img = tab.view(res0, res0, -1).permute(2, 0, 1).unsqueeze(0)
+        post = torch.nn.functional.conv_transpose2d(pos_img, w0, dc0.bias.detach().double().cpu(), stride=2, padding=2, output_padding=1)
+        dev0 = dc0.weight.device
+        s.l0_weff = plan.dp(weff.reshape(25 * w0.shape[1], w0.shape[0]).float().contiguous().to(dev0))
+        s.l0_posterm = plan.dp(post[0].permute(1, 2, 0).reshape(4 * res0 * res0, w0.shape[1]).float().contiguous().to(dev0))
     head = m.decoder[n]
     s.out_w = plan.dp(head.weight.detach().float().reshape(head.out_channels, head.in_channels).contiguous())
     s.out_b = plan.dp(head.bias)

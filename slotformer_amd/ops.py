@@ -64,6 +64,35 @@ def pack_conv_frag(w_packed):
     return out
 
 
+def pack_deconv_frag(w_packed):
+    """[64,5,5,64] (pack_deconv_weight of a ConvTranspose2d weight) -> consumption-ordered split-bf16 fragments (uint8 buffer) for
+    deconv5x5s2_frag / deconv5x5s2_head."""
+    _chk(w_packed)
+    Cout, ks, _, Cin = w_packed.shape
+    out = torch.empty(lib().sf_deconv_frag_bytes(Cout, Cin, ks, 2), device=w_packed.device, dtype=torch.uint8)
+    check(lib().sf_pack_deconv_frag_weights(_p(w_packed), out.data_ptr(), Cout, Cin, ks, 2, _stream()))
+    return out
+
+
+def deconv5x5s2_frag(x, w_frag, bias, relu=True):
+    """x [R,H,W,64] NHWC, w_frag = pack_deconv_frag(...) -> [R,2H,2W,64]: ConvTranspose2d(64, 64, 5, stride 2, padding 2, output_padding 1)."""
+    _chk(x, bias)
+    R, H, W, _ = x.shape
+    out = torch.empty(R, 2 * H, 2 * W, 64, device=x.device, dtype=torch.float32)
+    check(lib().sf_deconv5x5s2_frag_f32(_p(x), w_frag.data_ptr(), _p(bias), _p(out), R, H, W, int(relu), _stream()))
+    return out
+
+
+def deconv5x5s2_head(x, w_frag, bias, head_w, head_b):
+    """x [R,H,64,64] NHWC -> dec [R, 2H * 128, 4] = head_w [4,64] . relu(deconv(x) + bias) + head_b: the last decoder layer with the 1x1
+    output convolution in its epilogue."""
+    _chk(x, bias, head_w, head_b)
+    R, H, W, _ = x.shape
+    dec = torch.empty(R, 4 * H * W, 4, device=x.device, dtype=torch.float32)
+    check(lib().sf_deconv5x5s2_head_frag_f32(_p(x), w_frag.data_ptr(), _p(bias), _p(head_w), _p(head_b), _p(dec), R, H, W, _stream()))
+    return dec
+
+
 def conv5x5_frag(x, w_frag, bias, relu=True, add=None):
     """x [F,H,64,64] NHWC, w_frag = pack_conv_frag(...) -> [F,H,64,64] (4-row tiles, streamed weight fragments)."""
     _chk(x, bias, add)

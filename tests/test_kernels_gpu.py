@@ -479,3 +479,39 @@ def test_slot_attn_iter_bf16_storage(dev):
     e = ((u16 - uf).abs().max() / uf.abs().max()).item()
     print('bf16-stored K/V vs f32 K/V: updates rel err', e)
     assert 1e-5 < e < 2e-2
+
+
+@pytest.mark.parametrize('R,H', [(3, 64), (5, 32), (9, 16), (1, 64)])
+def test_deconv5x5s2_frag(dev, R, H):
+    """Kernel-level: the parity-class transposed convolution with streamed weight fragments (deconv_s2.hip; the SAVi decoder's stride-2
+    layers, savi.py:262-277) against torch's ConvTranspose2d(64, 64, 5, stride 2, padding 2, output_padding 1) in fp32, with and without
+    ReLU; the generic transposed-convolution path gives the same values to rounding."""
+    from slotformer_amd import ops
+    x = rnd(R, H, H, 64, seed=H + R)
+    w, b = rnd(64, 64, 5, 5, seed=2, scale=(64 * 6.25)**-0.5), rnd(64, seed=3, scale=0.1)
+    ref = F.conv_transpose2d(x.permute(0, 3, 1, 2), w, b, stride=2, padding=2, output_padding=1).permute(0, 2, 3, 1)
+    wp = ops.pack_deconv_weight(w.to(dev))
+    frag = ops.pack_deconv_frag(wp)
+    out = ops.deconv5x5s2_frag(x.to(dev), frag, b.to(dev), relu=False)
+    assert out.shape == (R, 2 * H, 2 * H, 64)
+    close(out, ref, rtol=1e-4, atol=2e-5)
+    close(ops.deconv5x5s2_frag(x.to(dev), frag, b.to(dev), relu=True), F.relu(ref), rtol=1e-4, atol=2e-5)
+    e = ((out.cpu() - ref).abs().max() / ref.abs().max()).item()
+    print('deconv5x5s2 R', R, 'H', H, 'rel err', e)
+    assert e < 2e-5
+
+
+def test_deconv5x5s2_head(dev):
+    """The last decoder layer with the 1x1 output convolution in its epilogue (savi.py:286-289): dec = head(relu(deconv(x) + b))."""
+    from slotformer_amd import ops
+    R, H = 3, 64
+    x = rnd(R, H, H, 64, seed=11)
+    w, b = rnd(64, 64, 5, 5, seed=12, scale=(64 * 6.25)**-0.5), rnd(64, seed=13, scale=0.1)
+    hw, hb = rnd(4, 64, seed=14, scale=0.2), rnd(4, seed=15, scale=0.1)
+    y = F.relu(F.conv_transpose2d(x.permute(0, 3, 1, 2), w, b, stride=2, padding=2, output_padding=1))
+    ref = F.conv2d(y, hw.view(4, 64, 1, 1), hb).permute(0, 2, 3, 1).reshape(R, 4 * H * H, 4)
+    frag = ops.pack_deconv_frag(ops.pack_deconv_weight(w.to(dev)))
+    dec = ops.deconv5x5s2_head(x.to(dev), frag, b.to(dev), hw.to(dev), hb.to(dev))
+    e = ((dec.cpu() - ref).abs().max() / ref.abs().max()).item()
+    print('deconv5x5s2 + head rel err', e)
+    assert e < 2e-5

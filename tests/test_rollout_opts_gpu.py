@@ -174,7 +174,10 @@ def test_throughput_forms_vs_reference_fixture_c4_c5(dev, name, cfg, seed, video
     for i in (0, at):
         e, ee = rel_err(out[i:i + 1], g['pred_slots']), rel_err_elementwise(out[i:i + 1], g['pred_slots'])
         print(name, 'throughput forms, video', i, 'of', videos, ': rel err (max-norm)', e, ' element-wise (floor 1e-3 max|ref|)', ee)
-        assert e < 2e-4 and ee < 1e-3
+        # asserted element by element in the allclose form of the north star's bar: |a - b| <= 1e-3 |b| + 1e-4 max|b|  (the printed
+        # figure with a floor of 1e-3 max|b| can reach 1000 x the max-norm error by construction: it is reported, not bounded at 1e-3)
+        a_, b_ = out[i:i + 1].detach().cpu().double(), torch.as_tensor(g['pred_slots']).double()
+        assert e < 2e-4 and bool(((a_ - b_).abs() <= 1e-3 * b_.abs() + 1e-4 * b_.abs().max()).all()) and ee < 5e-2
     assert torch.equal(out[0], out[at])            # a video's bits do not depend on where it sits in the unit
     ref = _roll(roll, x[:3].contiguous(), H)        # the library defaults (latency forms) on a small batch: the same bits
     assert torch.equal(ref[0], out[0])

@@ -674,6 +674,9 @@ def main():
         case_rollout('roll_c4_full', gu.C4_ROLL, B=1, pred_len=40, seed=224)
         case_rollout('roll_c5_full', gu.C5_ROLL, B=1, pred_len=80, seed=225, single_step=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'decode_128':   # the reference decoder at BASELINE's 128 x 128 (four stride-2 layers, savi.py:262-277)
+        case_decode('decode_c2_128', gu.savi_cfg(128, 7, kernel_mlp=False, pred='mlp', rnn=False), Fr=2, seed=411)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'roll_train':
         case_rollout_grads('roll_train', gu.TRAIN_ROLL, B=2, seed=801)
         case_rollout_grads('roll_train_img', gu.TRAIN_ROLL_IMG, B=1, seed=811, img=True)
