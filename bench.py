@@ -43,7 +43,7 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak; bf16x3 issues 3 bf16 MFMA flops per algorithmic flop
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec peak (6.3 TB/s achievable)
-CLS_NAMES = ['conv_nhwc_implicit_gemm', 'conv_first', 'linear_gemm', 'slot_attn_iter', 'slot_update', 'attention', 'ffn_fused', 'seam']
+CLS_NAMES = ['conv_nhwc_implicit_gemm', 'conv_first', 'linear_gemm', 'slot_attn_iter', 'slot_update', 'attention', 'ffn_fused', 'seam', 'deconv_head']
 
 
 def bench_configs():
@@ -290,6 +290,106 @@ def source_tree_hash():
     return h()
 
 
+def decode_flops_per_slot_image(m):
+    """Algorithmic FLOPs of the spatial-broadcast decoder per slot image as the reference computes it (savi.py:252-293,504-525): every
+    transposed convolution 2 * out_pixels * Cout * Cin * k^2 / stride^2, + the 1x1 head (1.135 GFLOP at 128 x 128: SURVEY.md 8f N2)."""
+    ch, ks, size = list(m.dec_channels), m.dec_ks, m.dec_resolution[0]
+    f = 0.0
+    for i in range(len(ch) - 1):
+        st = m.decoder[i][0].stride[0]
+        size *= st
+        f += 2.0 * size * size * ch[i + 1] * ch[i] * ks * ks / (st * st)
+    return f + 2.0 * size * size * ch[-1] * 4
+
+
+def decode_leg(args, lib, savi, roll, ring, B, T, H, N, D, RES, dev, pipe, peak_chip, peak_note, world, elapsed_main):
+    """Row N2 on the clock: the pipeline with its decode stage -- encode + rollout + decode of ALL predicted frames of every batch
+    (reconstruction [B, H, 3, R, R] + uint8 postproc_mask segmentation [B, H, R, R]; per-slot tensors never materialised)."""
+    from slotformer_amd import engine
+    from slotformer_amd.pipeline import EncodeRolloutPipeline
+    pipe.close()
+    with torch.no_grad():
+        pd = EncodeRolloutPipeline(savi, roll, B, T, H, partition=pipe.partition if pipe.cu_split else 'none', group=pipe.G, decoder=savi)
+        K = max(2, args.decode_steps)
+        dec = {}
+        batches = [ring[j % 3] for j in range(K)]
+        out_d = torch.empty(K, B, T + H, N, D, device=dev)
+        pd.run(batches[:max(2, min(K, 4))], None, out=out_d[:max(2, min(K, 4))], decoded=None)   # warm the two front stages
+        pd.run(batches, None, out=out_d, decoded=dec)                                                # and the decode stage (workspaces)
+        torch.cuda.synchronize()
+        wins = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pd.run(batches, None, out=out_d, decoded=dec)
+            torch.cuda.synchronize()
+            wins.append(time.perf_counter() - t0)
+        assert torch.isfinite(dec['recon']).all() and int(dec['seg'].max()) < N
+        el = sorted(wins)[1]
+        # the decode alone: 32 frames (one frame-chunk of the library), and one whole batch's predicted frames
+        sl32 = out_d[0][:, T:].reshape(B * H, N, D)[:32].contiguous()
+        slB = out_d[0][:, T:].reshape(B * H, N, D).contiguous()
+
+        def timed(fn, n=5):
+            fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            return sorted(ts)[len(ts) // 2]
+
+        t32 = timed(lambda: engine.savi_decode(savi, sl32, want=('seg', ), seg_dtype=torch.uint8))
+        t32_full = timed(lambda: engine.savi_decode(savi, sl32))           # with recons + masks (the module API's outputs)
+        tB = timed(lambda: engine.savi_decode(savi, slB, want=('seg', ), seg_dtype=torch.uint8, out_recon=dec['recon'][0].view(B * H, 3, RES, RES),
+                                              out_seg=dec['seg'][0].view(B * H, RES, RES)), n=3)
+        # the head-fused last layer, event-timed (library brackets around eager launches; the decode stage is never graph-captured)
+        lib.sf_profile_enable((1 << 8) | (1 << 0))
+        read_profile(lib)
+        engine.savi_decode(savi, slB, want=('seg', ), seg_dtype=torch.uint8)
+        torch.cuda.synchronize()
+        lib.sf_profile_enable(0)
+        prof = read_profile(lib)
+        pd.close()
+    fl_img = decode_flops_per_slot_image(savi)
+    frames = world * B * (T + H) * K
+    obj = {
+        'note': 'SECONDARY line, never `value`: encode + rollout + decode of every predicted frame (test_vp.py-shaped use); the decode is '
+                f'{fl_img * N * H / 1e9:.0f} GFLOP per video against {(T * encode_flops_per_frame(savi) + rollout_flops(roll, T, H)) / 1e9:.0f} for encode + rollout',
+        'frames_per_s': frames / el, 'ms_per_step': 1e3 * el / K, 'steps': K, 'windows_ms_per_step': [1e3 * x / K for x in wins],
+        'decoded_frames_per_s': world * B * H * K / el, 'decoded_frames_per_step': B * H, 'resolution': RES,
+        'outputs': f'recon [B,{H},3,{RES},{RES}] f32 + postproc_mask segmentation [B,{H},{RES},{RES}] uint8 per batch; recons / masks not materialised',
+        'decode_alone_ms_32_frames': 1e3 * t32, 'decode_alone_ms_32_frames_with_recons_and_masks': 1e3 * t32_full,
+        'decode_alone_ms_per_batch': 1e3 * tB, 'decode_alone_frames_per_s': B * H / tB,
+        'decode_tflops': fl_img * N * B * H / tB / 1e12, 'decode_frac_of_roof': fl_img * N * B * H / tB / 1e12 / peak_chip,
+        'vs_without_decode': {'frames_per_s': world * B * (T + H) * args.steps / elapsed_main},
+        'schedule': 'decode of a unit on an unmasked stream of its own behind the unit\'s rollout (slotformer_amd/pipeline.py, decoder=...); '
+                    'bit-identical to the serial module calls (tests/test_pipeline_gpu.py::test_pipeline_with_the_decode_stage)',
+    }
+    roof = None
+    dh = prof.get('deconv_head')
+    if dh:
+        fl = dh['work'] / dh['launches']
+        pm = committed_profile('deconv_head') if args.config == 'C2' else {}
+        us_trace = pm.get('avg_launch_us_trace')
+        us = us_trace or dh['avg_us']
+        tf = fl / (us * 1e-6) / 1e12
+        # slot images per launch: the layer reads a [64, 64, 64] map per image and writes 16 bytes per output pixel
+        R_img = fl / (2.0 * 4096 * 64 * 64 * 25 + 2.0 * RES * RES * 64 * 4)
+        roof = {'kernel': ('deconv5x5s2_kernel<64, true>' if RES == 128 else 'conv5x5_rows4_kernel<false, true>') +
+                          ' (the last decoder layer: 5x5 transposed convolution 64 -> 64 to the output resolution + ReLU + the 1x1 head in the epilogue; ' + peak_note + ')',
+                'bound': 'mfma', 'achieved': tf, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': tf / peak_chip,
+                'flops_per_launch': fl, 'avg_launch_us': us, 'avg_launch_us_events': dh['avg_us'], 'avg_launch_us_rocprof': us_trace,
+                'frac_events': fl / (dh['avg_us'] * 1e-6) / 1e12 / peak_chip, 'launches': dh['launches'],
+                'frac_source': ('committed rocprof trace of this source tree (' + str(pm.get('source')) + ')') if us_trace else 'HIP events of this run (eager launches of one decode call)',
+                'traffic': pm.get('traffic_bytes_per_launch'), 'mfma_busy_frac': pm.get('mfma_busy_frac'),
+                'slot_images_per_launch': R_img, 'algorithmic_bytes_per_launch': R_img * (4096 * 64 * 4 + RES * RES * 16) + 409600,
+                'share_of_decode_flops': 2.0 * RES * RES * 64 * 64 * 25 / (4 if RES == 128 else 1) / fl_img}
+    return obj, roof
+
+
 def log(msg):
     if int(os.environ.get('RANK', 0)) == 0:
         print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
@@ -310,6 +410,9 @@ def main():
     ap.add_argument('--precision', choices=['bf16x3', 'f32'], default=None, help='matrix arithmetic mode (default: library default = bf16x3)')
     ap.add_argument('--pcie', action='store_true', help='also time a host-to-host (PCIe-inclusive) variant; reported separately')
     ap.add_argument('--breakdown', action='store_true', help='extra untimed pass with every kernel class timed')
+    ap.add_argument('--decode', action='store_true', help='also time encode + rollout + DECODE of every predicted frame (reconstruction + postproc_mask '
+                    'segmentation, what test_vp.py scores): a secondary object `decode_pipeline` + `roofline_decode`, never `value`')
+    ap.add_argument('--decode-steps', type=int, default=8, help='batches per timed window of the --decode leg')
     ap.add_argument('--windows', type=int, default=5, help='timed windows of --steps steps each on the warm pipeline; value = the median window')
     args = ap.parse_args()
 
@@ -724,11 +827,16 @@ def main():
             res['roofline_' + k] = v
         if breakdown:
             res['kernel_breakdown_one_unit'] = breakdown
+        if args.decode:
+            res['decode_pipeline'], res['roofline_decode'] = decode_leg(args, lib, savi, roll, ring, B, T_BURN, T_ROLL, N_SLOTS, SLOT_D, RES, dev, pipe,
+                                                                        peak_chip, peak_note, world, elapsed)
+            pipe_closed = True
         pcie = None
         if args.pcie:
             # (this process's own pipeline object is closed first: with two pipelines alive -- twice the CU-masked queues -- the
             #  same call takes 120 instead of 94 ms)
-            pipe.close()
+            if not pipe_closed:
+                pipe.close()
             pipe_closed = True
             # PCIe-inclusive variant (never `value`): frames start in pinned host memory and the slots end there
             from slotformer_amd import harness

@@ -34,7 +34,7 @@ int sf_set_precision(int mode);
 /* Optional per-kernel-class HIP-event timer (bench.py roofline): events bracket every launch of a
  * class on the launch stream while enabled (never during hipGraph capture).  Classes: 0 conv
  * NHWC implicit GEMM, 1 first conv, 2 linear, 3 slot-attention iteration, 4 slot update, 5 attention (incl. the fused
- * attention + out-proj kernel), 6 fused FFN.
+ * attention + out-proj kernel), 6 fused FFN, 7 seam launch, 8 the decoder's fragment-weight transposed convolutions / head-fused last layer.
  * sf_profile_read sums elapsed ms, launches and algorithmic work (FLOP, or bytes for class 3)
  * since the last read. */
 int sf_profile_enable(int class_mask); /* bit c enables class c; 0 disables */
@@ -123,6 +123,14 @@ int sf_slot_broadcast_f32(const float* slots, const float* table, float* out, in
  * recon_combined = sum_n recons*masks [F,3,H,W]  (savi.py:519-525); recons / masks may be NULL. */
 int sf_decode_combine_f32(const float* dec, float* recon_combined, float* recons, float* masks, int F, int N, int HW,
                           void* stream);
+/* ... followed by postproc_mask (vp_utils.py:20-41) on those masks: seg [F,H,W] = the slot with the smallest peak mask value over the frame
+ * (the background) where the best mask value is below fg_thre, else the argmax over slots; as int64 (the reference's dtype) and / or
+ * uint8, either may be NULL.  slot_max: [F * N] words of scratch.  recon_combined is always written; recons / masks may be NULL. */
+int sf_decode_combine_seg_f32(const float* dec, float* recon_combined, float* recons, float* masks, long long* seg_i64,
+                              unsigned char* seg_u8, float fg_thre, unsigned* slot_max, int F, int N, int HW, void* stream);
+/* postproc_mask (vp_utils.py:20-41) on given masks [F,N,HW] (any float values) -> seg [F,HW] int64 and / or uint8; slot_max: [F * N] words. */
+int sf_postproc_mask_f32(const float* masks, long long* seg_i64, unsigned char* seg_u8, float fg_thre, unsigned* slot_max, int F, int N,
+                         int HW, void* stream);
 
 /* table[HW,C] = dense(grid)  (SoftPositionEmbed, utils.py:52-63; grid [HW,4]). */
 int sf_pos_embed_table_f32(const float* grid, const float* dense_w, const float* dense_b, float* table, int HW,
@@ -603,6 +611,11 @@ size_t sf_savi_decode_workspace_bytes(const sf_savi_decoder* m, int F);
 /* slots [F,N,D] -> recon_combined [F,3,H,W], recons [F,N,3,H,W] (or NULL), masks [F,N,1,H,W] (or NULL). */
 int sf_savi_decode_f32(const sf_savi_decoder* m, const float* slots, float* recon_combined, float* recons,
                        float* masks, int F, void* ws, size_t ws_bytes, void* stream);
+/* The same + the segmentation test_vp.py scores (postproc_mask of the decoded masks, video_prediction/test_vp.py:55-63 -> vp_utils.py:20-41):
+ * seg_i64 / seg_u8 [F,H,W] (either or both NULL); recons / masks may be NULL -- a caller that only scores frames and segmentations never
+ * materialises the per-slot tensors.  Workspace as sf_savi_decode_f32. */
+int sf_savi_decode_seg_f32(const sf_savi_decoder* m, const float* slots, float* recon_combined, float* recons, float* masks,
+                           long long* seg_i64, unsigned char* seg_u8, float fg_thre, int F, void* ws, size_t ws_bytes, void* stream);
 
 /* Row N1: the same decoder under autograd, data gradient only (the image term of SlotFormer's training loss,
  * slotformer.py:313-326; the decoder is frozen there).  The forward keeps every layer output in the workspace; the

@@ -150,6 +150,9 @@ SIGNATURES = {
     'sf_decode_combine_f32': (I, [FP, FP, FP, FP, I, I, I, VP]),
     'sf_savi_decode_workspace_bytes': (SZ, [C.POINTER(sf_savi_decoder), I]),
     'sf_savi_decode_f32': (I, [C.POINTER(sf_savi_decoder), FP, FP, FP, FP, I, VP, SZ, VP]),
+    'sf_savi_decode_seg_f32': (I, [C.POINTER(sf_savi_decoder), FP, FP, FP, FP, VP, VP, F32, I, VP, SZ, VP]),
+    'sf_decode_combine_seg_f32': (I, [FP, FP, FP, FP, VP, VP, F32, VP, I, I, I, VP]),
+    'sf_postproc_mask_f32': (I, [FP, VP, VP, F32, VP, I, I, I, VP]),
     'sf_pos_embed_table_f32': (I, [FP, FP, FP, FP, I, I, VP]),
     'sf_slot_attn_num_partials': (I, [I]),
     'sf_slot_attn_iter_f32': (I, [FP, FP, I, LL, FP, FP, FP, FP, I, I, I, I, F32, F32, VP]),

@@ -352,10 +352,10 @@ int sf_conv5x5_rows4_head_ex(const float* in, const void* w_frag, const float* b
   if (!w_frag || !head_w || !head_b || W != TW || Cin != CH || Cout != CH || ks != KS || (H % TR) != 0 || F <= 0 || sf_get_precision() != 1) return 1;
   static const int dbg = getenv("SF_CONV_DBG") ? atoi(getenv("SF_CONV_DBG")) : 0;
   SF_TRY(sf_ensure_dyn_lds((const void*)conv5x5_rows4_kernel<false, true>, LDS_BYTES));
-  sf_prof_begin(SF_K_CONV_NHWC, st, 2.0 * (double)F * H * W * Cout * ks * ks * Cin);
+  sf_prof_begin(SF_K_DECONV, st, 2.0 * (double)F * H * W * Cout * ks * ks * Cin + 2.0 * (double)F * H * W * Cout * 4);
   hipLaunchKernelGGL((conv5x5_rows4_kernel<false, true>), dim3(F * (H / TR)), dim3(NT), LDS_BYTES, st, in, (const uint4*)w_frag, bias, head_w, dec, H,
                      1, dbg, head_b);
-  sf_prof_end(SF_K_CONV_NHWC, st);
+  sf_prof_end(SF_K_DECONV, st);
   SF_CHECK_LAUNCH();
   return 0;
 }

@@ -333,10 +333,12 @@ static int launch_deconv(const float* in, const void* wf, const float* bias, con
   const size_t lds = G::LDS + (HEAD ? HEAD_X_BYTES : 0);
   static_assert(Geo<WIN>::LDS + HEAD_X_BYTES <= 160 * 1024, "LDS budget");
   SF_TRY(sf_ensure_dyn_lds((const void*)deconv5x5s2_kernel<WIN, HEAD>, lds));
-  sf_prof_begin(SF_K_CONV_NHWC, st, 2.0 * (double)R * H * WIN * CH * CH * KS * KS);
+  // (class 8 = the head-fused last layer alone: the kernel the decode roofline is quoted on; the plain layers count as convolutions)
+  constexpr int cls = HEAD ? SF_K_DECONV : SF_K_CONV_NHWC;
+  sf_prof_begin(cls, st, 2.0 * (double)R * H * WIN * CH * CH * KS * KS + (HEAD ? 2.0 * (double)R * 4 * H * WIN * CH * 4 : 0.0));
   hipLaunchKernelGGL((deconv5x5s2_kernel<WIN, HEAD>), dim3(R * (H / G::TRI)), dim3(NT), lds, st, in, (const uint4*)wf, bias, head_w, head_b,
                      out, H, relu, dbg);
-  sf_prof_end(SF_K_CONV_NHWC, st);
+  sf_prof_end(cls, st);
   SF_CHECK_LAUNCH();
   return 0;
 }

@@ -307,6 +307,11 @@ __global__ void slot_broadcast_kernel(const float* __restrict__ slots, const flo
   out[idx] = slots[r * D + c] + table[(long long)pp * D + c];
 }
 
+__global__ void zero_u32_kernel(unsigned* p, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
 // First decoder layer on its broadcast input (sf_savi_decoder.l0_weff / l0_posterm): a 5 x 5 stride-2 transposed convolution of
 // slot + pos_table[p] is  (sum of the taps that reach output pixel p from INSIDE the map) . slot + const[p]; the tap set depends on p only
 // through the parity and border class of its two coordinates (5 x 5 classes).  table [R][25 * C1] = slots . l0_weff^T (one GEMM),
@@ -337,30 +342,125 @@ __global__ void decode_l0_expand_kernel(const float* __restrict__ table, const f
 
 // decoder head (savi.py:519-525): dec [F*N, HW, 4] (r,g,b,mask-logit per slot) ->
 // masks = softmax over slots, recon_combined = sum_n recons * masks; all outputs NCHW-per-frame.
+// slot_max != NULL (the segmentation of vp_utils.py:20-41 follows): also the per-(frame, slot) maximum of the mask over the pixels, as
+// float bits in unsigned words cleared before the launch (masks are positive: the bit patterns order like the values; max is
+// order-independent, so the atomics stay deterministic).
+__device__ __forceinline__ float slot_mask_of(const float* __restrict__ dec, long long f, int N, int HW, int pix, int n, float mx, float inv) {
+  return expf(dec[((f * N + n) * HW + pix) * 4 + 3] - mx) * inv;
+}
+__device__ __forceinline__ void slot_softmax_stats(const float* __restrict__ dec, long long f, int N, int HW, int pix, float& mx, float& inv) {
+  mx = -INFINITY;
+  for (int n = 0; n < N; ++n) mx = fmaxf(mx, dec[((f * N + n) * HW + pix) * 4 + 3]);
+  float sum = 0.f;
+  for (int n = 0; n < N; ++n) sum += expf(dec[((f * N + n) * HW + pix) * 4 + 3] - mx);
+  inv = 1.0f / sum;
+}
 __global__ void decode_combine_kernel(const float* __restrict__ dec, float* __restrict__ recon,
-                                      float* __restrict__ recons, float* __restrict__ masks, int F, int N, int HW) {
+                                      float* __restrict__ recons, float* __restrict__ masks, unsigned* __restrict__ slot_max, int F, int N,
+                                      int HW) {
+  const long long idx0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = idx0 < (long long)F * HW;
+  const long long idx = valid ? idx0 : (long long)F * HW - 1;
+  const int pix = idx % HW;
+  const long long f = idx / HW;
+  float mx, inv;
+  slot_softmax_stats(dec, f, N, HW, pix, mx, inv);
+  float acc[3] = {0.f, 0.f, 0.f};
+  const bool wave_one_frame = (HW % 64) == 0;   // a wave's 64 pixels lie in one frame: one atomic per wave and slot
+  for (int n = 0; n < N; ++n) {
+    const f32x4 v = *(const f32x4*)(dec + ((f * N + n) * HW + pix) * 4);
+    const float m = slot_mask_of(dec, f, N, HW, pix, n, mx, inv);
+    if (masks && valid) masks[(f * N + n) * HW + pix] = m;
+    if (slot_max) {
+      if (wave_one_frame) {
+        const float wm = sf_wave_max(valid ? m : 0.f);
+        if ((threadIdx.x & 63) == 0) atomicMax(slot_max + f * N + n, __float_as_uint(wm));
+      } else if (valid) {
+        atomicMax(slot_max + f * N + n, __float_as_uint(m));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (recons && valid) recons[((f * N + n) * 3 + c) * HW + pix] = v[c];
+      acc[c] = fmaf(v[c], m, acc[c]);
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) recon[(f * 3 + c) * HW + pix] = acc[c];
+  }
+}
+
+// postproc_mask (vp_utils.py:20-41) on the decoder's own masks, recomputed from dec with the expressions of decode_combine_kernel (the
+// same bits): the slot whose peak mask value over the frame is smallest is the background (first index on ties, as torch.argmin); a
+// pixel whose best mask value is below fg_thre goes to it, every other pixel to its argmax over slots (first index on ties).
+__global__ void decode_seg_kernel(const float* __restrict__ dec, const unsigned* __restrict__ slot_max, long long* __restrict__ seg64,
+                                  unsigned char* __restrict__ seg8, int F, int N, int HW, float thre) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)F * HW) return;
   const int pix = idx % HW;
   const long long f = idx / HW;
-  float mx = -INFINITY;
-  for (int n = 0; n < N; ++n) mx = fmaxf(mx, dec[((f * N + n) * HW + pix) * 4 + 3]);
-  float sum = 0.f;
-  for (int n = 0; n < N; ++n) sum += expf(dec[((f * N + n) * HW + pix) * 4 + 3] - mx);
-  const float inv = 1.0f / sum;
-  float acc[3] = {0.f, 0.f, 0.f};
+  float mx, inv;
+  slot_softmax_stats(dec, f, N, HW, pix, mx, inv);
+  int bg = 0, best = 0;
+  float bgv = __uint_as_float(slot_max[f * N]), bestv = -1.f;
   for (int n = 0; n < N; ++n) {
-    const f32x4 v = *(const f32x4*)(dec + ((f * N + n) * HW + pix) * 4);
-    const float m = expf(v[3] - mx) * inv;
-    if (masks) masks[(f * N + n) * HW + pix] = m;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      if (recons) recons[((f * N + n) * 3 + c) * HW + pix] = v[c];
-      acc[c] = fmaf(v[c], m, acc[c]);
+    const float sm = __uint_as_float(slot_max[f * N + n]);
+    if (sm < bgv) {
+      bgv = sm;
+      bg = n;
+    }
+    const float m = slot_mask_of(dec, f, N, HW, pix, n, mx, inv);
+    if (m > bestv) {
+      bestv = m;
+      best = n;
     }
   }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) recon[(f * 3 + c) * HW + pix] = acc[c];
+  const int out = bestv < thre ? bg : best;
+  if (seg64) seg64[idx] = out;
+  if (seg8) seg8[idx] = (unsigned char)out;
+}
+
+// postproc_mask on given masks [F][N][HW]: per-(frame, slot) maxima (one workgroup per row), then the rule above per pixel
+__global__ __launch_bounds__(256) void mask_rowmax_kernel(const float* __restrict__ masks, unsigned* __restrict__ slot_max, int HW) {
+  const float* row = masks + (long long)blockIdx.x * HW;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < HW; i += 256) m = fmaxf(m, row[i]);
+  m = sf_wave_max(m);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  // stored as an order-preserving key of the float (masks may be any float here): flip the sign bit / all bits
+  if (threadIdx.x == 0) {
+    const float r = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    const unsigned b = __float_as_uint(r);
+    slot_max[blockIdx.x] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  }
+}
+__global__ void mask_seg_kernel(const float* __restrict__ masks, const unsigned* __restrict__ slot_key, long long* __restrict__ seg64,
+                                unsigned char* __restrict__ seg8, int F, int N, int HW, float thre) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)F * HW) return;
+  const int pix = idx % HW;
+  const long long f = idx / HW;
+  int bg = 0, best = 0;
+  unsigned bgk = slot_key[f * N];
+  float bestv = masks[(f * N) * HW + pix];
+  for (int n = 1; n < N; ++n) {
+    const unsigned k = slot_key[f * N + n];
+    if (k < bgk) {
+      bgk = k;
+      bg = n;
+    }
+    const float m = masks[(f * N + n) * HW + pix];
+    if (m > bestv) {
+      bestv = m;
+      best = n;
+    }
+  }
+  const int out = bestv < thre ? bg : best;
+  if (seg64) seg64[idx] = out;
+  if (seg8) seg8[idx] = (unsigned char)out;
 }
 
 // table[p, c] = sum_j grid[p, j] * w[c, j] + b[c]      (SoftPositionEmbed, utils.py:52-63)
@@ -454,13 +554,45 @@ int sf_decode_l0_expand_f32(const float* table, const float* posterm, float* out
   return 0;
 }
 
-int sf_decode_combine_f32(const float* dec, float* recon_combined, float* recons, float* masks, int F, int N, int HW,
-                          void* stream) {
+int sf_decode_combine_seg_f32(const float* dec, float* recon_combined, float* recons, float* masks, long long* seg_i64,
+                              unsigned char* seg_u8, float fg_thre, unsigned* slot_max, int F, int N, int HW, void* stream) {
   SF_REQUIRE(dec && recon_combined && F >= 0 && N >= 1 && HW > 0, "bad combine arguments");
+  const bool seg = seg_i64 || seg_u8;
+  SF_REQUIRE(!seg || slot_max, "the segmentation needs the slot_max scratch ([F * N] words)");
+  SF_REQUIRE(!seg || N <= 255, "at most 255 slots");
   const long long total = (long long)F * HW;
   if (total == 0) return 0;
-  hipLaunchKernelGGL(decode_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     dec, recon_combined, recons, masks, F, N, HW);
+  hipStream_t st = (hipStream_t)stream;
+  if (seg) {
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)(((long long)F * N + 255) / 256)), dim3(256), 0, st, slot_max, (long long)F * N);
+    SF_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(decode_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dec, recon_combined, recons, masks,
+                     seg ? slot_max : nullptr, F, N, HW);
+  SF_CHECK_LAUNCH();
+  if (seg) {
+    hipLaunchKernelGGL(decode_seg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dec, slot_max, seg_i64, seg_u8, F, N, HW,
+                       fg_thre);
+    SF_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+int sf_decode_combine_f32(const float* dec, float* recon_combined, float* recons, float* masks, int F, int N, int HW,
+                          void* stream) {
+  return sf_decode_combine_seg_f32(dec, recon_combined, recons, masks, nullptr, nullptr, 0.5f, nullptr, F, N, HW, stream);
+}
+
+int sf_postproc_mask_f32(const float* masks, long long* seg_i64, unsigned char* seg_u8, float fg_thre, unsigned* slot_max, int F, int N,
+                         int HW, void* stream) {
+  SF_REQUIRE(masks && (seg_i64 || seg_u8) && slot_max && F >= 0 && N >= 1 && N <= 255 && HW > 0, "bad postproc arguments");
+  const long long total = (long long)F * HW;
+  if (total == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(mask_rowmax_kernel, dim3((unsigned)(F * N)), dim3(256), 0, st, masks, slot_max, HW);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mask_seg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, masks, slot_max, seg_i64, seg_u8, F, N, HW,
+                     fg_thre);
   SF_CHECK_LAUNCH();
   return 0;
 }

@@ -923,11 +923,16 @@ static int dec_chunk(const sf_savi_decoder* m, int F) {
 size_t sf_savi_decode_workspace_bytes(const sf_savi_decoder* m, int F) {
   if (!m || F <= 0) return 0;
   const size_t R = (size_t)dec_chunk(m, F) * m->num_slots, HW = (size_t)m->resolution * m->resolution;
-  return 2 * pad256(R * HW * dec_cmax(m)) + pad256(R * HW * 4) + 4096;
+  return 2 * pad256(R * HW * dec_cmax(m)) + pad256(R * HW * 4) + pad256(R) + 4096;
 }
 
 int sf_savi_decode_f32(const sf_savi_decoder* m, const float* slots, float* recon_combined, float* recons,
                        float* masks, int F, void* ws, size_t ws_bytes, void* stream) {
+  return sf_savi_decode_seg_f32(m, slots, recon_combined, recons, masks, nullptr, nullptr, 0.5f, F, ws, ws_bytes, stream);
+}
+
+int sf_savi_decode_seg_f32(const sf_savi_decoder* m, const float* slots, float* recon_combined, float* recons, float* masks,
+                           long long* seg_i64, unsigned char* seg_u8, float fg_thre, int F, void* ws, size_t ws_bytes, void* stream) {
   SF_REQUIRE(m && slots && recon_combined && ws, "null pointer");
   SF_REQUIRE(F >= 1 && m->dec_layers >= 1 && m->dec_layers <= 8 && m->num_slots >= 1 && m->dec_res >= 1 && (m->dec_ks & 1),
              "bad decoder config");
@@ -947,6 +952,7 @@ int sf_savi_decode_f32(const sf_savi_decoder* m, const float* slots, float* reco
   float* bufA = bp.take((size_t)Fc * N * HW * cmax);
   float* bufB = bp.take((size_t)Fc * N * HW * cmax);
   float* dec = bp.take((size_t)Fc * N * HW * 4);
+  unsigned* slot_max = (unsigned*)bp.take((size_t)Fc * N);
   if (!bp.ok) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
   const bool bf3 = sf_get_precision() == 1;
   const int nl = m->dec_layers, Cl = m->dec_channels[nl];
@@ -999,9 +1005,10 @@ int sf_savi_decode_f32(const sf_savi_decoder* m, const float* slots, float* reco
     if (!head_done)
       SF_TRY(sf_linear_ex(cur, sf_rows(Cl), m->out_w, m->out_b, nullptr, nullptr, 0.f, nullptr, sf_rows(4), 0, dec,
                           sf_rows(4), R * HW, 4, Cl, 0, st));
-    SF_TRY(sf_decode_combine_f32(dec, recon_combined + (long long)f0 * 3 * HW,
-                                 recons ? recons + (long long)f0 * N * 3 * HW : nullptr,
-                                 masks ? masks + (long long)f0 * N * HW : nullptr, nf, N, HW, st));
+    SF_TRY(sf_decode_combine_seg_f32(dec, recon_combined + (long long)f0 * 3 * HW,
+                                     recons ? recons + (long long)f0 * N * 3 * HW : nullptr,
+                                     masks ? masks + (long long)f0 * N * HW : nullptr, seg_i64 ? seg_i64 + (long long)f0 * HW : nullptr,
+                                     seg_u8 ? seg_u8 + (long long)f0 * HW : nullptr, fg_thre, slot_max, nf, N, HW, st));
   }
   return 0;
 }

@@ -499,8 +499,12 @@ def decoder_plan(m):
     return plan
 
 
-def savi_decode(m, slots, ws_slot=0):
-    """StoSAVi.decode on device: slots [F,N,D] -> (recon_combined [F,3,H,W], recons [F,N,3,H,W], masks [F,N,1,H,W])."""
+def savi_decode(m, slots, ws_slot=0, want=('recons', 'masks'), seg_dtype=torch.int64, fg_thre=0.5, out_recon=None, out_seg=None):
+    """StoSAVi.decode on device: slots [F,N,D] -> (recon_combined [F,3,H,W], recons [F,N,3,H,W], masks [F,N,1,H,W]).
+    `want`: which of the optional outputs to materialise -- 'recons', 'masks', 'seg' (postproc_mask of the decoded masks,
+    vp_utils.py:20-41: [F,H,W] in `seg_dtype` int64 (the reference's) or uint8); with 'seg' the call returns a 4-tuple (.., seg);
+    outputs not asked for are None and never written (a throughput caller that scores frames + segmentations skips 60 MB per frame).
+    out_recon / out_seg: preallocated contiguous destinations ([F,3,H,W] float32 / [F,H,W] seg_dtype) instead of fresh tensors."""
     if torch.is_grad_enabled() and (slots.requires_grad or any(p.requires_grad for p in m.decoder.parameters())):
         from . import train
         return train.decode_with_grad(m, slots)   # one autograd node, data gradient only (row N1)
@@ -511,12 +515,24 @@ def savi_decode(m, slots, ws_slot=0):
     F_, N, D = slots.shape
     H = plan.struct.resolution
     dev = slots.device
-    recon = torch.empty(F_, 3, H, H, device=dev, dtype=torch.float32)
-    recons = torch.empty(F_, N, 3, H, H, device=dev, dtype=torch.float32)
-    masks = torch.empty(F_, N, 1, H, H, device=dev, dtype=torch.float32)
+    recon = torch.empty(F_, 3, H, H, device=dev, dtype=torch.float32) if out_recon is None else out_recon
+    if out_recon is not None and (tuple(recon.shape) != (F_, 3, H, H) or recon.dtype != torch.float32 or not recon.is_contiguous() or recon.device != dev):
+        raise RuntimeError(f'out_recon must be a contiguous float32 [{F_},3,{H},{H}] tensor on {dev}')
+    recons = torch.empty(F_, N, 3, H, H, device=dev, dtype=torch.float32) if 'recons' in want else None
+    masks = torch.empty(F_, N, 1, H, H, device=dev, dtype=torch.float32) if 'masks' in want else None
+    seg = None
+    if 'seg' in want:
+        if seg_dtype not in (torch.int64, torch.uint8):
+            raise ValueError('slotformer_amd: seg_dtype must be torch.int64 or torch.uint8')
+        seg = torch.empty(F_, H, H, device=dev, dtype=seg_dtype) if out_seg is None else out_seg
+        if out_seg is not None and (tuple(seg.shape) != (F_, H, H) or seg.dtype != seg_dtype or not seg.is_contiguous() or seg.device != dev):
+            raise RuntimeError(f'out_seg must be a contiguous {seg_dtype} [{F_},{H},{H}] tensor on {dev}')
     need = lib().sf_savi_decode_workspace_bytes(C.byref(plan.struct), F_)
     ws = workspace(dev, need, ('dec', ws_slot))
-    check(lib().sf_savi_decode_f32(C.byref(plan.struct), slots.data_ptr(), recon.data_ptr(), recons.data_ptr(),
-                                   masks.data_ptr(), F_, ws.data_ptr(), ws.numel(),
-                                   torch.cuda.current_stream().cuda_stream))
+    P = ops._p
+    check(lib().sf_savi_decode_seg_f32(C.byref(plan.struct), slots.data_ptr(), recon.data_ptr(), P(recons), P(masks),
+                                       P(seg) if seg_dtype == torch.int64 else None, P(seg) if seg_dtype == torch.uint8 else None,
+                                       float(fg_thre), F_, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+    if 'seg' in want:
+        return recon, recons, masks, seg
     return recon, recons, masks

@@ -82,7 +82,7 @@ def _pipeline_for(savi, rollouter, batch_size, T, pred_len, pipe_kw):
     from .pipeline import EncodeRolloutPipeline
     for k in [k for k, (ws, wr, _) in _PIPES.items() if ws() is None or wr() is None]:
         _PIPES.pop(k)[2].close()
-    key = (id(savi), id(rollouter), batch_size, T, pred_len, tuple(sorted((k, repr(v)) for k, v in pipe_kw.items())))
+    key = (id(savi), id(rollouter), batch_size, T, pred_len, tuple(sorted((k, id(v) if isinstance(v, torch.nn.Module) else repr(v)) for k, v in pipe_kw.items())))
     ent = _PIPES.pop(key, None)
     if ent is None:
         while len(_PIPES) >= max(1, MAX_PIPELINES):      # least recently used first (dicts keep insertion order)
@@ -99,7 +99,8 @@ def release_pipelines():
 
 
 @torch.no_grad()
-def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises=None, pipelined=True, to_host=False, **pipe_kw):
+def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises=None, pipelined=True, to_host=False, decoder=None,
+                        seg_dtype=torch.uint8, **pipe_kw):
     """Whole hot path over many videos: SAVi slot extraction of the burn-in frames followed by the SlotFormer rollout
     (extract_slots.py:19-38 + rollout_clevrer_slots.py:20-65 / test_phyre_planning.py:159-174 as one on-device call).
 
@@ -111,8 +112,13 @@ def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises
     drivers do before pickling, extract_slots.py:36).  Full batches go through `pipeline.EncodeRolloutPipeline` (kept
     between calls: the rollout graphs are captured once per (models, shape)); a ragged last batch runs serially through the
     same kernels.  `noises` [V, T_burn, N, D] fixes the kernel noise (default: fresh N(0,1) per frame as the reference
-    draws it; ignored by models that sample nothing)."""
+    draws it; ignored by models that sample nothing).
+    decoder: a module holding the SAVi decoder (the StoSAVi, or the SlotFormer that copied its weights) -- the PREDICTED frames are then
+    also decoded behind their rollout (test_vp.py:55-63,145-146: reconstruction + postproc_mask segmentation) and the call returns
+    (slots, {'recon': [V, pred_len, 3, R, R] float32, 'seg': [V, pred_len, R, R] seg_dtype}) on the device."""
     from . import engine
+    if decoder is not None and to_host:
+        raise RuntimeError('slotformer_amd: decoder= keeps its outputs on the device (to_host=False)')
     dev = next(rollouter.parameters()).device
     videos = videos.float()
     host_in = not videos.is_cuda
@@ -123,6 +129,11 @@ def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises
     out = torch.empty(V, T + pred_len, N, D, pin_memory=True) if to_host else torch.empty(V, T + pred_len, N, D, device=dev)
     nfull = V // batch_size
     tail_opts = None
+    dec = None
+    if decoder is not None:
+        R = engine.decoder_plan(decoder).struct.resolution
+        dec = {'recon': torch.empty(V, pred_len, 3, R, R, device=dev), 'seg': torch.empty(V, pred_len, R, R, device=dev, dtype=seg_dtype)}
+        pipe_kw = dict(pipe_kw, decoder=decoder, seg_dtype=seg_dtype)
     if nfull:
         if 'group' not in pipe_kw and pipe_kw.get('partition', 'pair') == 'pair':
             from .pipeline import unit_batches_for
@@ -133,7 +144,8 @@ def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises
         tail_opts = pipe.rollout_opts   # the ragged tail runs the same kernel forms as the full batches
         imgs = [videos[j * batch_size:(j + 1) * batch_size] for j in range(nfull)]
         nz = None if noises is None else [noises[j * batch_size:(j + 1) * batch_size].float().to(dev).contiguous() for j in range(nfull)]
-        pipe.run(imgs, nz, out=out[:nfull * batch_size].view(nfull, batch_size, T + pred_len, N, D), serial=not pipelined or nfull < 2)
+        dv = None if dec is None else {k: v[:nfull * batch_size].view(nfull, batch_size, *v.shape[1:]) for k, v in dec.items()}
+        pipe.run(imgs, nz, out=out[:nfull * batch_size].view(nfull, batch_size, T + pred_len, N, D), serial=not pipelined or nfull < 2, decoded=dv)
     r0 = nfull * batch_size
     if r0 < V:
         nz = None if noises is None else noises[r0:].float().to(dev).contiguous()
@@ -143,6 +155,9 @@ def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises
         tail[:, :T] = post
         engine.rollout(rollouter, tail, T, pred_len, opts=tail_opts)
         out[r0:].copy_(tail)
+        if dec is not None:
+            engine.savi_decode(decoder, tail[:, T:].reshape((V - r0) * pred_len, N, D), want=('seg', ), seg_dtype=seg_dtype,
+                               out_recon=dec['recon'][r0:].view((V - r0) * pred_len, 3, R, R), out_seg=dec['seg'][r0:].view((V - r0) * pred_len, R, R))
     if to_host:
         torch.cuda.synchronize(dev)
-    return out
+    return out if dec is None else (out, dec)

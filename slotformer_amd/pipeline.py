@@ -132,11 +132,20 @@ class EncodeRolloutPipeline:
     the same bits as the library defaults either way; other partitions: the library defaults).
     hybrid: behind the whole-chip fill, every hybrid-th batch is encoded on an unmasked stream beside the CU-masked lane (None = 5
     for a balanced 'pair' on row tiles, 0 = never otherwise; bit-identical).
+    decoder: module holding the SAVi decoder weights (StoSAVi / SlotFormer); enables run(..., decoded={...}): the predicted frames of
+    every batch decoded to reconstruction + segmentation behind its rollout, on an unmasked stream of its own (the decode is 12x the
+    FLOPs of encode + rollout at C2: it bounds such a run, the other two stages hide beside it).  seg_dtype: uint8 (default) or int64.
     """
 
     def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=None, use_graph=True,
-                 partition='pair', group=None, rollout_opts=None, encode_graph=None, hybrid=None):
+                 partition='pair', group=None, rollout_opts=None, encode_graph=None, hybrid=None, decoder=None, seg_dtype=torch.uint8):
         self.savi, self.roll = savi, rollouter
+        # optional third stage (row N2; video_prediction/test_vp.py:55-63,145-146 -> slotformer.py:244-259 -> savi.py:504-525 ->
+        # vp_utils.py:20-41): the predicted frames of every batch are decoded behind its rollout -- spatial-broadcast decoder, softmax
+        # over slots, postproc_mask -- into the reconstruction and the segmentation test_vp.py scores.  decoder: the module that holds
+        # the (frozen) decoder weights: the StoSAVi itself or the SlotFormer that copied them (slotformer.py:203-210)
+        self.decoder, self.seg_dtype = decoder, seg_dtype
+        self._s_dec = None
         self.B, self.T, self.H = int(batch), int(burn_in), int(pred_len)
         p = next(rollouter.parameters())
         if not p.is_cuda:
@@ -600,13 +609,40 @@ class EncodeRolloutPipeline:
         return plan
 
     @torch.no_grad()
-    def run(self, imgs, noises=None, out=None, serial=False):
+    def _decoded_buffers(self, decoded, n):
+        """The decode stage's outputs: decoded['recon'] [n, B, pred_len, 3, R, R] float32 and decoded['seg'] [n, B, pred_len, R, R]
+        (allocated when the caller's dict does not hold them)."""
+        if self.decoder is None:
+            raise RuntimeError('slotformer_amd: run(decoded=...) needs a pipeline built with decoder=<module holding the SAVi decoder>')
+        R = engine.decoder_plan(self.decoder).struct.resolution
+        if decoded.get('recon') is None:
+            decoded['recon'] = torch.empty(n, self.B, self.H, 3, R, R, device=self.dev)
+        if decoded.get('seg') is None:
+            decoded['seg'] = torch.empty(n, self.B, self.H, R, R, device=self.dev, dtype=self.seg_dtype)
+        rc, sg = decoded['recon'], decoded['seg']
+        if tuple(rc.shape) != (n, self.B, self.H, 3, R, R) or tuple(sg.shape) != (n, self.B, self.H, R, R) or not rc.is_contiguous() or not sg.is_contiguous():
+            raise RuntimeError(f'decoded buffers must be contiguous [n,{self.B},{self.H},3,{R},{R}] / [n,{self.B},{self.H},{R},{R}]')
+        return rc, sg
+
+    def _decode(self, slots_all, recon, seg):
+        """predicted frames of one batch: slots_all [B, T + H, N, D] -> recon [B, H, 3, R, R], seg [B, H, R, R] on the current stream"""
+        sl = slots_all[:, self.T:].reshape(self.B * self.H, self.N, self.D)
+        engine.savi_decode(self.decoder, sl, ws_slot=self._key + ('dec', ), want=('seg', ), seg_dtype=self.seg_dtype,
+                           out_recon=recon.view(self.B * self.H, *recon.shape[2:]), out_seg=seg.view(self.B * self.H, *seg.shape[2:]))
+
+    @torch.no_grad()
+    def run(self, imgs, noises=None, out=None, serial=False, decoded=None):
         """imgs: sequence of n device tensors [B, burn_in, 3, H, W]; noises: None or n tensors [B, burn_in, N, D]
         (the kernel noise of every frame, for reproducible runs).  Returns out [n, B, burn_in + pred_len, N, D]; the
         pipelined schedule returns when the last batch is finished (the host waits for it, see the end of this function).
-        serial=True runs the same calls back to back on the calling stream (reference schedule for the tests)."""
+        serial=True runs the same calls back to back on the calling stream (reference schedule for the tests).
+        decoded: None, or a dict the decode stage fills (pipeline built with decoder=...): 'recon' [n, B, pred_len, 3, R, R] and
+        'seg' [n, B, pred_len, R, R] of the PREDICTED frames (test_vp.py's `pred` / `pred_mask`)."""
         n = len(imgs)
         B = self.B
+        rc_all, sg_all = self._decoded_buffers(decoded, n) if decoded is not None else (None, None)
+        if decoded is not None and out is not None and not out.is_cuda:
+            raise RuntimeError('slotformer_amd: the decode stage reads the slots from a device-resident `out`')
         host_in = n > 0 and not imgs[0].is_cuda
         for im in imgs:
             if tuple(im.shape[:2]) != (B, self.T) or im.is_cuda == host_in or im.dtype != torch.float32:
@@ -626,6 +662,8 @@ class EncodeRolloutPipeline:
                 self._rollout(u)
                 for h in range(nb):
                     out[u0 + h].copy_(u.buf[h * B:(h + 1) * B], non_blocking=True)
+                    if decoded is not None:
+                        self._decode(out[u0 + h], rc_all[u0 + h], sg_all[u0 + h])
             self._check_seam()
             return out
         G, NU, steal = self.G, self.NU, self.steal
@@ -649,6 +687,12 @@ class EncodeRolloutPipeline:
             if self._s_out is None:
                 self._s_out = self._pool_stream('out')
             self._s_out.wait_stream(cur)
+        ev_dec = None
+        if decoded is not None:
+            if self._s_dec is None:
+                self._s_dec = self._pool_stream('dec')
+            self._s_dec.wait_stream(cur)
+            ev_dec = torch.cuda.Event()
         trace = bool(int(os.environ.get('SF_PIPE_TRACE', '0')))   # timeline of a run (tools/pipe_timeline.py): timing events everywhere
         ev_enc = [[torch.cuda.Event(enable_timing=trace) for _ in range(nl)] for _ in range(n)]
         ev_roll = [torch.cuda.Event(enable_timing=True) for _ in range(nu)]   # also: completion time of every unit
@@ -830,6 +874,14 @@ class EncodeRolloutPipeline:
                     for h in range(nb):
                         out[u0 + h].copy_(u.buf[h * B:(h + 1) * B])
                     ev_roll[ui].record(s_roll)
+                    if decoded is not None:
+                        # decode stage: reads the unit's slots from `out` (the unit buffer is free for the next encode at once), on an
+                        # unmasked stream of its own, one batch after the other
+                        with torch.cuda.stream(self._s_dec):
+                            self._s_dec.wait_event(ev_roll[ui])
+                            for h in range(nb):
+                                self._decode(out[u0 + h], rc_all[u0 + h], sg_all[u0 + h])
+                            ev_dec.record(self._s_dec)
                 else:
                     # pinned host output: the downloads run on a torch-owned stream -- PyTorch's host allocator records an event
                     # on every stream a pinned block was used on when the block is freed, and the CU-masked streams of this
@@ -854,6 +906,9 @@ class EncodeRolloutPipeline:
         download_ready(everything=True)
         for e in ev_roll[-(len(rolls) + 4):]:   # (the drain units on the unmasked streams may overtake the units before them)
             e.synchronize()
+        if decoded is not None:
+            ev_dec.synchronize()   # (the last decode: the stage runs in order on one stream)
+            cur.wait_stream(self._s_dec)
         for st, _, _ in lanes:
             cur.wait_stream(st)
         for st in rolls + list(self.s_free) + ([self._s_copy] if host_in else []) + ([self._s_out] if not out.is_cuda else []):

@@ -367,3 +367,60 @@ def test_pipeline_with_the_encode_under_a_graph(dev, name):
             assert torch.equal(out, ref), (out - ref).abs().max().item()
         assert len(pipe._enc_graphs) >= 1
         pipe.close()
+
+
+@pytest.mark.parametrize('res', [128, 64])
+def test_pipeline_with_the_decode_stage(dev, res):
+    """decoder=...: the predicted frames of every batch decoded behind their rollout (reconstruction + postproc_mask segmentation, what
+    test_vp.py scores): bit-identical to the serial calls -- module decode + vp_utils.postproc_mask per batch -- through the pipelined
+    schedule, the serial one and harness.extract_and_rollout with a ragged tail; int64 and uint8 segmentations agree."""
+    from slotformer_amd import engine, harness
+    from slotformer_amd.base_slots import build_model
+    from slotformer_amd.pipeline import EncodeRolloutPipeline
+    from slotformer_amd.video_prediction.models import SlotRollouter
+    from slotformer_amd.video_prediction.vp_utils import postproc_mask
+    B, T, H, nbatch = 3, 6, 4, 5
+    torch.manual_seed(21)
+    savi = build_model(gu.ParamsView(gu.savi_cfg(res, 7, iters=2, kernel_mlp=False, pred='mlp', rnn=False, kld='var-0.01'))).eval().to(dev)
+    savi.testing = True
+    roll = SlotRollouter(**gu.C2_ROLL['rollout_dict']).eval().to(dev)
+    rs = np.random.RandomState(41)
+    imgs = [torch.from_numpy((rs.rand(B, T, 3, res, res) * 2 - 1).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    noises = [torch.from_numpy(rs.standard_normal((B, T, 7, 128)).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    with torch.no_grad():
+        ref = _serial_reference(savi, roll, imgs, noises, T, H, PAIR_OPTS)
+        ref_rec, ref_seg = [], []
+        for j in range(nbatch):
+            recon, _, masks, _ = savi.decode(ref[j][:, T:].reshape(B * H, 7, 128))
+            ref_rec.append(recon.view(B, H, 3, res, res))
+            ref_seg.append(postproc_mask(masks.view(B, H, 7, 1, res, res)))
+        ref_rec, ref_seg = torch.stack(ref_rec), torch.stack(ref_seg)
+        # the device postproc_mask = the reference formulation in torch ops on the same masks
+        mk = masks.view(B, H, 7, 1, res, res)
+        mc = mk.clone().reshape(B * H, 7, res * res)
+        bg = mc.max(-1)[0].argmin(-1)
+        weak = mc.max(1)[0] < 0.5
+        isbg = torch.zeros(B * H, 7, dtype=torch.bool, device=dev)
+        isbg[torch.arange(B * H, device=dev), bg] = True
+        mc[isbg.unsqueeze(-1) & weak.unsqueeze(1)] = 1.
+        assert torch.equal(postproc_mask(mk), mc.argmax(1).reshape(B, H, res, res))
+        assert torch.equal(postproc_mask(mk.cpu()), postproc_mask(mk).cpu())
+        for dtype in (torch.uint8, torch.int64):
+            pipe = EncodeRolloutPipeline(savi, roll, B, T, H, decoder=savi, seg_dtype=dtype)
+            for serial in (False, True):
+                d = {}
+                out = pipe.run(imgs, noises, serial=serial, decoded=d)
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref)
+                assert d['seg'].dtype == dtype and torch.equal(d['recon'], ref_rec) and torch.equal(d['seg'].long(), ref_seg), (dtype, serial)
+            pipe.close()
+        with pytest.raises(RuntimeError):
+            EncodeRolloutPipeline(savi, roll, B, T, H).run(imgs[:1], noises[:1], decoded={})
+        # the harness entry with a ragged tail
+        vids = torch.cat(imgs, 0)[:B * nbatch - 1]
+        nz = torch.cat(noises, 0)[:B * nbatch - 1]
+        o, dd = harness.extract_and_rollout(savi, roll, vids, H, batch_size=B, noises=nz, decoder=savi)
+        V = vids.shape[0]
+        assert torch.equal(o, ref.reshape(-1, T + H, 7, 128)[:V])
+        assert torch.equal(dd['recon'], ref_rec.reshape(-1, H, 3, res, res)[:V]) and torch.equal(dd['seg'].long(), ref_seg.reshape(-1, H, res, res)[:V])
+        harness.release_pipelines()
