@@ -531,8 +531,11 @@ def main():
         noise = engine.kernel_noise(savi, None, B, T_BURN, dev)
 
         def encode():
-            post, _, _ = engine.savi_encode(savi, ring[0], noise=noise)
+            post, _, _ = engine.savi_encode(savi, ring[0], noise=noise, side_stream=None)   # one stream: the kernels alone, for the rooflines
             unit0.buf[:B, :T_BURN].copy_(post)
+
+        def encode_forked():   # the direct module path's default: two branches (engine.savi_encode side_stream='auto')
+            engine.savi_encode(savi, ring[0], noise=noise)
 
         def rollout_eager():
             engine.rollout(roll, unit0.buf, T_BURN, T_ROLL, ws_slot=unit0.key, opts=pipe.rollout_opts)
@@ -565,6 +568,7 @@ def main():
         t_enc = timed_on(torch.cuda.current_stream(), encode)
         lib.sf_profile_enable(0)
         prof_iso = read_profile(lib)  # same kernels with nothing else on the GPU
+        t_enc_fork = timed_on(torch.cuda.current_stream(), encode_forked)
         t_roll = timed_on(torch.cuda.current_stream(), rollout)      # seconds per unit (G batches)
         part_ms = None
         if overlap and pipe.cu_split:
@@ -677,6 +681,7 @@ def main():
             'one_batch_latency_ms': one_batch_ms,
             'one_batch_frames_per_s': B * (T_BURN + T_ROLL) / (one_batch_ms * 1e-3),
             'encode_ms': 1e3 * t_enc,
+            'encode_ms_two_branches': 1e3 * t_enc_fork,
             'rollout_ms': 1e3 * t_roll / G,
             'rollout_unit_ms': 1e3 * t_roll,
             'partitioned_ms': part_ms,

@@ -576,6 +576,14 @@ int sf_savi_cnn_f32(const sf_savi_encoder* m, const float* img, int B, int T, in
 int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const float* feat_pre, int n_pre, const float* noise,
                            const float* prev_slots, float* lstm_h, float* lstm_c, int state_valid, float* post_slots,
                            float* kernel_dist, float* attn, int B, int T, void* ws, size_t ws_bytes, void* stream);
+/* The same as TWO branches: `stream` runs the image features (CNN + per-pixel chain) of all T steps back to back, `side_stream` follows one
+ * step behind with the slot branches (prologue, Slot-Attention iterations, slot updates), ordered by events; `stream` continues behind the
+ * last slot update.  Captured into a hipGraph the two are parallel branches.  side_stream NULL = sf_savi_encode_pre_f32.  Same bits.
+ * Workspace: sf_savi_encode_fork_workspace_bytes(m, B, T) (the Slot-Attention inputs of all T steps stay resident). */
+size_t sf_savi_encode_fork_workspace_bytes(const sf_savi_encoder* m, int B, int T);
+int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const float* feat_pre, int n_pre, const float* noise,
+                            const float* prev_slots, float* lstm_h, float* lstm_c, int state_valid, float* post_slots,
+                            float* kernel_dist, float* attn, int B, int T, void* ws, size_t ws_bytes, void* stream, void* side_stream);
 
 /* StoSAVi.decode (savi.py:504-525): spatial broadcast + position embedding -> transposed-conv stack -> 1x1 conv
  * -> softmax-over-slots recombination. */

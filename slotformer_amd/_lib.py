@@ -232,6 +232,9 @@ SIGNATURES = {
     'sf_savi_cnn_f32': (I, [C.POINTER(sf_savi_encoder), FP, I, I, I, I, FP, VP, SZ, VP]),
     'sf_savi_encode_pre_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, I, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
                                    VP]),
+    'sf_savi_encode_fork_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I, I]),
+    'sf_savi_encode_fork_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, I, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
+                                    VP, VP]),
     'sf_kv_producer_workspace_bytes': (SZ, [I, I]),
     'sf_kv_producer_f32': (I, [FP] * 11 + [I, I, I, I, F32, VP, SZ, VP]),
     # device-memory helpers + host-buffer twins (same signatures as the device entry points)

@@ -366,15 +366,22 @@ __global__ void decode_combine_kernel(const float* __restrict__ dec, float* __re
   float mx, inv;
   slot_softmax_stats(dec, f, N, HW, pix, mx, inv);
   float acc[3] = {0.f, 0.f, 0.f};
-  const bool wave_one_frame = (HW % 64) == 0;   // a wave's 64 pixels lie in one frame: one atomic per wave and slot
+  // a workgroup's 256 pixels lie in one frame when HW % 256 == 0: the waves meet in LDS, one global atomic per workgroup and slot
+  // (per wave they queued 256 deep on every (frame, slot) word: +0.18 ms per 32 frames)
+  const bool wg_one_frame = (HW % 256) == 0;
+  __shared__ unsigned wg_max[256];
+  if (slot_max && wg_one_frame) {
+    wg_max[threadIdx.x] = 0u;
+    __syncthreads();
+  }
   for (int n = 0; n < N; ++n) {
     const f32x4 v = *(const f32x4*)(dec + ((f * N + n) * HW + pix) * 4);
     const float m = slot_mask_of(dec, f, N, HW, pix, n, mx, inv);
     if (masks && valid) masks[(f * N + n) * HW + pix] = m;
     if (slot_max) {
-      if (wave_one_frame) {
+      if (wg_one_frame) {
         const float wm = sf_wave_max(valid ? m : 0.f);
-        if ((threadIdx.x & 63) == 0) atomicMax(slot_max + f * N + n, __float_as_uint(wm));
+        if ((threadIdx.x & 63) == 0) atomicMax(&wg_max[n], __float_as_uint(wm));
       } else if (valid) {
         atomicMax(slot_max + f * N + n, __float_as_uint(m));
       }
@@ -388,6 +395,11 @@ __global__ void decode_combine_kernel(const float* __restrict__ dec, float* __re
   if (valid) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) recon[(f * 3 + c) * HW + pix] = acc[c];
+  }
+  if (slot_max && wg_one_frame) {
+    __syncthreads();
+    const long long f0 = ((long long)blockIdx.x * blockDim.x) / HW;   // the workgroup's frame
+    if ((int)threadIdx.x < N && f0 < F) atomicMax(slot_max + f0 * N + threadIdx.x, wg_max[threadIdx.x]);
   }
 }
 

@@ -15,6 +15,7 @@
 // place by the out_proj GEMM epilogue.
 #include "../../include/slotformer_hip.h"
 #include "sf_internal.h"
+#include <vector>
 #include "layer_fused.h"
 #include <stdlib.h>
 
@@ -552,7 +553,14 @@ int sf_rollout_bf16(const sf_rollouter* m, float* slots, int B, int T_total, int
 // ---------------------------------------------------------------------------------------------
 static int enc_chunk(int B) { return B < 32 ? B : 32; }
 
-size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B) {
+static size_t enc_ws_bytes(const sf_savi_encoder* m, int B, int kv_steps);
+size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B) { return enc_ws_bytes(m, B, 1); }
+// the forked form keeps the Slot-Attention inputs of up to ENC_FORK_AHEAD time steps (the feature branch runs that far ahead of the slot branch)
+static constexpr int ENC_FORK_AHEAD = 4;
+static int enc_fork_steps(int T) { return T < ENC_FORK_AHEAD ? T : ENC_FORK_AHEAD; }
+size_t sf_savi_encode_fork_workspace_bytes(const sf_savi_encoder* m, int B, int T) { return T >= 1 ? enc_ws_bytes(m, B, enc_fork_steps(T)) : 0; }
+
+static size_t enc_ws_bytes(const sf_savi_encoder* m, int B, int kv_steps) {
   if (!m || B <= 0) return 0;
   const size_t HW = 64 * 64;
   int cmax = 0;
@@ -564,7 +572,7 @@ size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B) {
   size_t t = 0;
   t += 2 * pad256((size_t)Bc * HW * cmax);
   t += 2 * pad256((size_t)Bc * HW * Ce);
-  t += pad256((size_t)B * HW * 2 * D);
+  t += pad256((size_t)kv_steps * B * HW * 2 * D);
   t += 6 * pad256((size_t)R * D) + 2 * pad256((size_t)R * 2 * D);
   t += pad256((size_t)B * P * N * D) + pad256((size_t)B * P * N);
   t += tfm_ws_bytes(R, D, hidp) + pad256((size_t)R * 4 * (m->pred_hidden > 0 ? m->pred_hidden : 1));
@@ -651,7 +659,33 @@ int sf_savi_encode_f32(const sf_savi_encoder* m, const float* img, const float* 
 int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const float* feat_pre, int n_pre, const float* noise,
                            const float* prev_slots, float* lstm_h, float* lstm_c, int state_valid, float* post_slots,
                            float* kernel_dist, float* attn, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+  return sf_savi_encode_fork_f32(m, img, feat_pre, n_pre, noise, prev_slots, lstm_h, lstm_c, state_valid, post_slots, kernel_dist, attn,
+                                 B, T, ws, ws_bytes, stream, nullptr);
+}
+
+// fork / join events of the forked encode, per host thread (created on first use, kept for the life of the thread: the library's
+// only host-side objects; no device memory)
+static hipEvent_t enc_fork_event(int i) {
+  thread_local std::vector<hipEvent_t> ev;
+  while ((int)ev.size() <= i) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    ev.push_back(e);
+  }
+  return ev[i];
+}
+
+// The encode as TWO branches (side_stream != NULL).  The image features of a time step (CNN + per-pixel chain: ~420 us of dense
+// launches per step at C2) do not depend on the slots; the slot branch of a step (prologue, Slot-Attention iterations, slot updates:
+// ~140 us, half of it in seven-workgroup launches that leave the chip idle) needs only that step's features.  `stream` runs the
+// features of all T steps back to back; `side_stream` follows one step behind with the slot branches, ordered by events (fork after
+// the features of step t, join at the end: `stream` waits for the last slot update).  Captured into a hipGraph the two become parallel
+// branches of the graph.  Same kernels, same arguments, same bits.  Workspace: sf_savi_encode_fork_workspace_bytes(m, B, T).
+int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const float* feat_pre, int n_pre, const float* noise,
+                            const float* prev_slots, float* lstm_h, float* lstm_c, int state_valid, float* post_slots,
+                            float* kernel_dist, float* attn, int B, int T, void* ws, size_t ws_bytes, void* stream, void* side_stream) {
   SF_REQUIRE(m && img && post_slots && ws, "null pointer");
+  const bool fork = side_stream != nullptr && side_stream != stream;
   SF_REQUIRE(n_pre >= 0 && n_pre <= T && (n_pre == 0 || feat_pre != nullptr), "bad precomputed-feature arguments");
   SF_REQUIRE(B >= 1 && T >= 1, "bad batch / clip length");
   SF_REQUIRE(m->resolution == 64 || m->resolution == 128, "resolution must be 64 or 128 (savi.py:226,236)");
@@ -671,10 +705,12 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
   if (m->pred_rnn)
     SF_REQUIRE(lstm_h && lstm_c && m->pred_hidden > 0 && m->lstm_w_ih && m->lstm_w_hh && m->lstm_b_ih &&
                    m->lstm_b_hh && m->proj_w && m->proj_b, "null LSTM state / weight");
-  SF_REQUIRE(ws_bytes >= sf_savi_encode_workspace_bytes(m, B), "workspace too small");
+  const int KV = fork ? enc_fork_steps(T) : 1;   // resident Slot-Attention inputs: a ring of KV time steps
+  SF_REQUIRE(ws_bytes >= enc_ws_bytes(m, B, KV), "workspace too small");
   for (int i = 0; i < m->enc_layers; ++i) SF_REQUIRE(m->conv_w[i] != nullptr, "null conv weight");
 
-  hipStream_t st = (hipStream_t)stream;
+  hipStream_t st_main = (hipStream_t)stream, st_side = fork ? (hipStream_t)side_stream : (hipStream_t)stream;
+  hipStream_t st = st_main;
   const int HW = 64 * 64, res = m->resolution;
   const int N = m->num_slots, D = m->slot_size, Ce = m->enc_out_channels, Hm = m->slot_mlp_size;
   const int R = B * N, Bc = enc_chunk(B), P = sf_sa_pick_partials(HW);
@@ -687,7 +723,8 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
   float* featB = bp.take((size_t)Bc * HW * cmax);
   float* h1 = bp.take((size_t)Bc * HW * Ce);
   float* h2 = bp.take((size_t)Bc * HW * Ce);
-  float* kv = bp.take((size_t)B * HW * 2 * D);
+  float* kv_base = bp.take((size_t)KV * B * HW * 2 * D);
+  const size_t kv_step = fork ? (size_t)B * HW * 2 * D : 0;
   float* slotsA = bp.take((size_t)R * D);
   float* slotsB = bp.take((size_t)R * D);
   float* latents = bp.take((size_t)R * D);
@@ -725,8 +762,15 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
   const void* q_w_p = fold ? m->sa_fold_q_w_p : m->sa_q_w_p;
   const void* gru_ih_p = fold ? m->sa_fold_gru_ih_p : m->sa_gru_ih_p;
 
+  // time-step order; forked: the features of step t are enqueued on `stream`, its slot branch on `side_stream` behind them (event),
+  // and the features of step t + KV wait for the slot branch of step t to release its ring slot
   for (int t = 0; t < T; ++t) {
+    float* kv = kv_base + (size_t)(t % KV) * kv_step;
     // ---- CNN encoder + per-pixel MLP + K/V for the B frames of step t ---------------------
+    st = st_main;
+    if (fork && t >= KV) {   // the ring slot is free once the slot branch of step t - KV has read it
+      if (hipStreamWaitEvent(st_main, enc_fork_event(T + 1 + (t - KV)), 0) != hipSuccess) return sf_set_err((int)hipGetLastError(), "hipStreamWaitEvent", __FILE__, __LINE__);
+    }
     for (int b0 = 0; b0 < B; b0 += Bc) {
       const int nb = (B - b0 < Bc) ? (B - b0) : Bc;
       const int Cl0 = m->enc_channels[m->enc_layers];
@@ -767,6 +811,13 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
         SF_TRY(sf_linear_ex(h2, sf_rows(Ce), m->sa_kv_w, nullptr, m->sa_norm_in_g, m->sa_norm_in_b, ln_eps, nullptr,
                             sf_rows(2 * D), 0, kv_dst, sf_rows(2 * D), Mp, 2 * D, Ce, 0, st));
       }
+    }
+    if (fork) {
+      hipEvent_t e = enc_fork_event(t);
+      SF_REQUIRE(e != nullptr, "hipEventCreate failed");
+      if (hipEventRecord(e, st_main) != hipSuccess || hipStreamWaitEvent(st_side, e, 0) != hipSuccess)
+        return sf_set_err((int)hipGetLastError(), "fork event", __FILE__, __LINE__);
+      st = st_side;
     }
     // ---- one-launch slot prologue (CLEVRER configuration: residual-MLP predictor without LSTM, single-Linear kernel
     //      distribution): init / predictor -> kernel_dist -> sampling -> q of the first iteration (slot_attn.hip) ----
@@ -900,21 +951,39 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
     // keep it in `lnbuf`-independent storage (q is rewritten first, so use latents' twin `px`?)
     // -> simplest: the next step reads `prev` only before it writes slotsA/slotsB.
     prev = s_in;
+    if (fork && t + KV < T) {   // the features of step t + KV may overwrite this step's ring slot now
+      hipEvent_t e = enc_fork_event(T + 1 + t);
+      SF_REQUIRE(e != nullptr, "hipEventCreate failed");
+      if (hipEventRecord(e, st_side) != hipSuccess) return sf_set_err((int)hipGetLastError(), "hipEventRecord", __FILE__, __LINE__);
+    }
+  }
+  if (fork) {   // join: the calling stream continues behind the last slot update
+    hipEvent_t e = enc_fork_event(T);
+    SF_REQUIRE(e != nullptr, "hipEventCreate failed");
+    if (hipEventRecord(e, st_side) != hipSuccess || hipStreamWaitEvent(st_main, e, 0) != hipSuccess)
+      return sf_set_err((int)hipGetLastError(), "fork join", __FILE__, __LINE__);
   }
   return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
 // StoSAVi.decode (savi.py:504-525)
-static int dec_cmax(const sf_savi_decoder* m) {
-  int c = 0;
-  for (int i = 0; i <= m->dec_layers && i < 9; ++i) c = m->dec_channels[i] > c ? m->dec_channels[i] : c;
-  return c;
+// floats of the largest activation map of ONE slot image: max over the layers of size_i^2 x channels_i (the broadcast input, every layer output)
+static size_t dec_maxact(const sf_savi_decoder* m) {
+  size_t best = (size_t)m->dec_res * m->dec_res * m->dec_channels[0];
+  int size = m->dec_res;
+  for (int i = 0; i < m->dec_layers && i < 8; ++i) {
+    size *= m->dec_strides[i] > 0 ? m->dec_strides[i] : 1;
+    const size_t a = (size_t)size * size * m->dec_channels[i + 1];
+    best = a > best ? a : best;
+  }
+  const size_t tab = (size_t)25 * m->dec_channels[1];   // the first layer's class table
+  return best > tab ? best : tab;
 }
-// frames per chunk: one activation buffer <= 1 GiB (the largest map of a slot image is resolution^2 x channels floats; 32 frames of 7 slots
-// at 128 x 128 x 64 are 0.92 GB: one chunk -- 288 GB of HBM make chunks of 4 frames, the round-1 size, pointless)
+// frames per chunk: one activation buffer <= 1 GiB (7 slots at 128 x 128 x 64: 36 frames = 252 slot images per launch -- one round of
+// 16-pixel-wide tiles, four of 32-wide, sixteen of 64-wide; chunks of 4 frames, the round-1 size, left most of the chip idle in the small layers)
 static int dec_chunk(const sf_savi_decoder* m, int F) {
-  const double per_frame = (double)m->num_slots * m->resolution * m->resolution * dec_cmax(m);
+  const double per_frame = (double)m->num_slots * (double)dec_maxact(m);
   int fc = (int)(256.0 * 1024 * 1024 / per_frame);
   if (fc < 1) fc = 1;
   return fc < F ? fc : F;
@@ -923,7 +992,7 @@ static int dec_chunk(const sf_savi_decoder* m, int F) {
 size_t sf_savi_decode_workspace_bytes(const sf_savi_decoder* m, int F) {
   if (!m || F <= 0) return 0;
   const size_t R = (size_t)dec_chunk(m, F) * m->num_slots, HW = (size_t)m->resolution * m->resolution;
-  return 2 * pad256(R * HW * dec_cmax(m)) + pad256(R * HW * 4) + pad256(R) + 4096;
+  return 2 * pad256(R * dec_maxact(m)) + pad256(R * HW * 4) + pad256(R) + 4096;
 }
 
 int sf_savi_decode_f32(const sf_savi_decoder* m, const float* slots, float* recon_combined, float* recons,
@@ -947,10 +1016,11 @@ int sf_savi_decode_seg_f32(const sf_savi_decoder* m, const float* slots, float* 
   SF_REQUIRE(ws_bytes >= sf_savi_decode_workspace_bytes(m, F), "workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int N = m->num_slots, D = m->slot_size, res = m->resolution, HW = res * res;
-  const int Fc = dec_chunk(m, F), cmax = dec_cmax(m);
+  const int Fc = dec_chunk(m, F);
+  const size_t maxact = dec_maxact(m);
   Bump bp{(char*)ws, ws_bytes};
-  float* bufA = bp.take((size_t)Fc * N * HW * cmax);
-  float* bufB = bp.take((size_t)Fc * N * HW * cmax);
+  float* bufA = bp.take((size_t)Fc * N * maxact);
+  float* bufB = bp.take((size_t)Fc * N * maxact);
   float* dec = bp.take((size_t)Fc * N * HW * 4);
   unsigned* slot_max = (unsigned*)bp.take((size_t)Fc * N);
   if (!bp.ok) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
@@ -967,7 +1037,7 @@ int sf_savi_decode_seg_f32(const sf_savi_decoder* m, const float* slots, float* 
       const bool last = i == nl - 1;
       int rc = 1;
       if (i == 0) {
-        if (m->l0_weff && m->l0_posterm && sd == 2 && m->dec_ks == 5 && hin >= 2 && 25 * Co <= HW * cmax) {
+        if (m->l0_weff && m->l0_posterm && sd == 2 && m->dec_ks == 5 && hin >= 2) {
           // the first layer on its broadcast input: table [R][25 Co] = slots . l0_weff^T, then the expansion (include/slotformer_hip.h)
           SF_TRY(sf_linear_ex(slots + (long long)f0 * N * D, sf_rows(D), m->l0_weff, nullptr, nullptr, nullptr, 0.f, nullptr, sf_rows(25 * Co), 0,
                               nxt, sf_rows(25 * Co), R, 25 * Co, D, 0, st));

@@ -362,9 +362,30 @@ def encoder_plan(m):
     return plan
 
 
-def savi_encode(m, img, prev_slots=None, noise=None, want_attn=False, ws_slot=0, feat_pre=None):
+_FORK_STREAMS = {}
+
+
+def _auto_side_stream(dev):
+    """The second stream of direct (non-pipeline) encode calls: one per (device, host thread).  SF_ENCODE_FORK=0 turns the two-branch
+    form off; it is also off while the current stream is being captured (the pipeline decides for its own graphs)."""
+    if os.environ.get('SF_ENCODE_FORK', '1') == '0' or torch.cuda.is_current_stream_capturing():
+        return None
+    import threading
+    key = (dev.index, threading.get_ident())
+    st = _FORK_STREAMS.get(key)
+    if st is None:
+        st = _FORK_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def savi_encode(m, img, prev_slots=None, noise=None, want_attn=False, ws_slot=0, feat_pre=None, side_stream='auto'):
     """Run StoSAVi.encode / STEVE.encode on device.  feat_pre [n_pre,B,4096,C]: CNN features of the first n_pre time
     steps computed ahead of time by `savi_cnn` (possibly on another stream).
+    side_stream: a second torch stream -- the encode then runs as two branches (sf_savi_encode_fork_f32: the image features of the
+    time steps on the current stream, the slot branches behind them on `side_stream`; same bits); the current stream continues
+    behind both.  'auto' (default): a pooled stream per device and host thread (whole chip, nothing else running: 2.41 -> 2.17 ms per C2
+    batch; 3.25 -> 2.81 on a 128-CU mask); None: one stream (what the batch pipeline uses: beside its CU-masked rollout streams a fifth
+    busy hardware queue costs more than the fork saves, 497 -> 473 k frames/s, profiles/r04_probes.txt).
 
     Returns (post_slots [B,T,N,D], kernel_dist [B,T,N,2D] | None, attn [B,T,N,64*64] | None).
     The predictor's LSTM state lives on `m.predictor.hidden_state` exactly as in the reference.
@@ -396,7 +417,12 @@ def savi_encode(m, img, prev_slots=None, noise=None, want_attn=False, ws_slot=0,
             c = torch.empty_like(h)
         pred.hidden_state = (h, c)
         pred.step += T if prev_slots is not None else T - 1
-    need = lib().sf_savi_encode_workspace_bytes(C.byref(plan.struct), B)
+    if isinstance(side_stream, str):
+        side_stream = _auto_side_stream(dev) if side_stream == 'auto' else None
+    if side_stream is not None:
+        need = lib().sf_savi_encode_fork_workspace_bytes(C.byref(plan.struct), B, T)
+    else:
+        need = lib().sf_savi_encode_workspace_bytes(C.byref(plan.struct), B)
     ws = workspace(dev, need, ('enc', ws_slot))
     P = ops._p
     n_pre = 0
@@ -405,9 +431,9 @@ def savi_encode(m, img, prev_slots=None, noise=None, want_attn=False, ws_slot=0,
         n_pre = feat_pre.shape[0]
         if feat_pre.shape[1] != B or feat_pre.shape[2] != 64 * 64:
             raise RuntimeError(f'feat_pre must be [n_pre,{B},4096,C], got {tuple(feat_pre.shape)}')
-    check(lib().sf_savi_encode_pre_f32(C.byref(plan.struct), img.data_ptr(), P(feat_pre), n_pre, P(noise), P(prev_slots), P(h),
-                                       P(c), valid, post.data_ptr(), P(kdist), P(attn), B, T, ws.data_ptr(), ws.numel(),
-                                       torch.cuda.current_stream().cuda_stream))
+    check(lib().sf_savi_encode_fork_f32(C.byref(plan.struct), img.data_ptr(), P(feat_pre), n_pre, P(noise), P(prev_slots), P(h),
+                                        P(c), valid, post.data_ptr(), P(kdist), P(attn), B, T, ws.data_ptr(), ws.numel(),
+                                        torch.cuda.current_stream().cuda_stream, None if side_stream is None else side_stream.cuda_stream))
     return post, kdist, attn
 
 

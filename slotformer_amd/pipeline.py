@@ -138,7 +138,8 @@ class EncodeRolloutPipeline:
     """
 
     def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=None, use_graph=True,
-                 partition='pair', group=None, rollout_opts=None, encode_graph=None, hybrid=None, decoder=None, seg_dtype=torch.uint8):
+                 partition='pair', group=None, rollout_opts=None, encode_graph=None, hybrid=None, decoder=None, seg_dtype=torch.uint8,
+                 encode_fork=None):
         self.savi, self.roll = savi, rollouter
         # optional third stage (row N2; video_prediction/test_vp.py:55-63,145-146 -> slotformer.py:244-259 -> savi.py:504-525 ->
         # vp_utils.py:20-41): the predicted frames of every batch are decoded behind its rollout -- spatial-broadcast decoder, softmax
@@ -227,6 +228,7 @@ class EncodeRolloutPipeline:
         # batches, 399.5 vs 398.2 at 40) at the price of a 38 MB device copy of the frames into the fixed input buffer per batch
         self.encode_graph = bool(int(os.environ.get('SF_PIPE_ENCODE_GRAPH', '1'))) if encode_graph is None else bool(encode_graph)
         self._enc_graphs = {}
+        self.encode_fork = bool(int(os.environ.get('SF_PIPE_ENCODE_FORK', '0'))) if encode_fork is None else bool(encode_fork)
         # the last unit of a run rolls out alone on an unmasked stream: in the kernels' latency forms (head-pair attention, 64-row FFN
         # workgroups) while a unit is small -- C4, 64 videos: 172 vs 165 k frames/s -- but a large unit fills the chip with its row tiles and
         # four times the workgroups only queue: C5, 256 videos: 392 -> 435 k; C2, 128 videos: 436 / 440 k
@@ -543,8 +545,26 @@ class EncodeRolloutPipeline:
             eg['graph'].replay()
             dst[lo:hi, :self.T].copy_(eg['post'])
             return
-        post, _, _ = engine.savi_encode(self.savi, img, noise=noise, feat_pre=feat_pre, ws_slot=self._key + ('enc', lane))
+        side = None   # (one stream: see engine.savi_encode)
+        if self.encode_fork:
+            # (probe) eager two-branch encode: the slot branch on a second stream with the lane's own CU mask (an unmasked one for the fill lanes)
+            cache = self.__dict__.setdefault('_fork_side', {})
+            side = cache.get(lane)
+            if side is None:
+                if isinstance(lane, int) and self.cu_split:
+                    side = self._masked_stream(self._lane_words(lane))
+                else:
+                    side = self._pool_stream('fork', k=len(cache))
+                cache[lane] = side
+        post, _, _ = engine.savi_encode(self.savi, img, noise=noise, feat_pre=feat_pre, ws_slot=self._key + ('enc', lane), side_stream=side)
         dst[lo:hi, :self.T].copy_(post)
+
+    def _lane_words(self, lane):
+        if self.partition == 'pair':
+            return self._enc_words_pair
+        if self.partition == 'three':
+            return LANE0_WORDS_3 if lane == 0 else LANE1_WORDS_3
+        return [0xffffffff] * 8
 
     def _encode_graph_for(self, lane, nv, k, res, with_noise):
         key = (lane, nv, k, res, with_noise)
@@ -560,12 +580,15 @@ class EncodeRolloutPipeline:
             # on one pooled stream the same run took 93 instead of 78 ms (tools/two_pipes_probe.py)
             side = torch.cuda.Stream(device=self.dev)
             side.wait_stream(cur)
+            # encode_fork: the graph gets two parallel branches -- the image features of all time steps, and one step behind them the slot
+            # branches (engine.savi_encode side_stream=; the seven-workgroup launches of the slot branch no longer hold up the convolutions)
+            side2 = torch.cuda.Stream(device=self.dev) if self.encode_fork else None
             with torch.cuda.stream(side):
-                engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws)   # workspace, plans
+                engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws, side_stream=side2)   # workspace, plans
                 side.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
-                    post, _, _ = engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws)
+                    post, _, _ = engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws, side_stream=side2)
             cur.wait_stream(side)
             eg['graph'], eg['post'] = g, post
             self._enc_graphs[key] = eg

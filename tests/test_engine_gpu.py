@@ -589,3 +589,59 @@ def test_folded_slot_attention_at_width_192_matches_the_kv_path(dev):
     assert not torch.equal(a['slots'], b['slots'])
     assert rel_err(a['slots'], b['slots'].cpu()) < 5e-5
     assert (a['masks'] - b['masks']).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize('name', ['C2', 'C5', 'C4'])
+@torch.no_grad()
+def test_forked_encode_is_bit_identical(dev, name):
+    """engine.savi_encode(side_stream=...) = sf_savi_encode_fork_f32: the image features of all time steps on the calling stream, the slot
+    branches one step behind on a second stream (events) -- the same kernels with the same arguments: the same bits as the one-stream
+    encode, eager and captured into a hipGraph (two parallel branches), with injected kernel noise (C2), the predictor's LSTM state (C5)
+    and STEVE's masks (C4); also with precomputed features of the first steps."""
+    from slotformer_amd import engine
+    from slotformer_amd.base_slots import build_model
+    cfg = {'C2': gu.C2_SAVI, 'C5': gu.C5_SAVI, 'C4': None}[name]
+    if name == 'C4':
+        cfg = dict(gu.C4_STEVE)
+        cfg.update(dvae_dict=dict(down_factor=4, vocab_size=64, dvae_ckp_path=''), dec_dict=dict(dec_type='slate', dec_num_layers=1, dec_num_heads=4, dec_d_model=64),
+                   loss_dict=dict(use_img_recon_loss=False))
+    torch.manual_seed(31)
+    m = build_model(gu.ParamsView(cfg)).eval().to(dev)
+    m.testing = True
+    B, T = 5, 7   # (7 steps: the ring of four resident Slot-Attention inputs wraps)
+    img = gu.seeded_img(B, T, 128, seed=61).to(dev)
+    N, D = cfg['slot_dict']['num_slots'], cfg['slot_dict']['slot_size']
+    noise = engine.kernel_noise(m, gu.seeded_normal((B, T, N, D), 62).to(dev), B, T, dev)
+    side = torch.cuda.Stream(device=dev)
+    if hasattr(m.predictor, 'reset'):
+        m.predictor.reset()
+    ref = engine.savi_encode(m, img, noise=noise, want_attn=(name == 'C4'), ws_slot='fk0', side_stream=None)
+    torch.cuda.synchronize()
+    if hasattr(m.predictor, 'reset'):
+        m.predictor.reset()
+    out = engine.savi_encode(m, img, noise=noise, want_attn=(name == 'C4'), ws_slot='fk1', side_stream=side)
+    torch.cuda.synchronize()
+    for a, b in zip(out, ref):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+    # precomputed features of the first two steps
+    feat = engine.savi_cnn(m, img, 0, 2)
+    if hasattr(m.predictor, 'reset'):
+        m.predictor.reset()
+    out2 = engine.savi_encode(m, img, noise=noise, ws_slot='fk1', side_stream=side, feat_pre=feat)
+    torch.cuda.synchronize()
+    assert torch.equal(out2[0], ref[0])
+    # captured: a graph with two parallel branches, replayed twice
+    if name == 'C2':
+        cap, side2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(cap):
+            engine.savi_encode(m, img, noise=noise, ws_slot='fk2', side_stream=side2)
+            cap.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
+                post = engine.savi_encode(m, img, noise=noise, ws_slot='fk2', side_stream=side2)[0]
+        torch.cuda.synchronize()
+        for _ in range(2):
+            post.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(post, ref[0])
