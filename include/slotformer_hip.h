@@ -384,6 +384,8 @@ typedef struct {
                       * one workgroup per (tile, hidden chunk) and four partial tensors: the same bits, half the CU time;
                       * 2 (with attn_qkv_rows): that launch also runs LN1 + q|k|v of the NEXT layer on its tile -- the rows never leave
                       * the workgroup, the next attention block is its core launch alone (one launch less per layer, the same bits) */
+  int cus_available; /* 0: the whole chip; else the number of CUs the call's stream may use (its CU mask).  Seam launches hand rows over inside
+                      * a grid and need every workgroup of it resident at once: they are used only when the grid fits min(160, cus_available) */
 } sf_rollout_opts;
 int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws, size_t ws_bytes,
                         void* stream, const sf_rollout_opts* opts); /* opts == NULL: sf_rollout_f32 */

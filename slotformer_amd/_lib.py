@@ -27,7 +27,7 @@ class sf_rollouter(C.Structure):
 
 
 class sf_rollout_opts(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ('precision', 'seam_fused', 'ffn_rows', 'attn_heads_per_wg', 'attn_qkv_rows', 'ffn_tile')]
+    _fields_ = [(n, C.c_int) for n in ('precision', 'seam_fused', 'ffn_rows', 'attn_heads_per_wg', 'attn_qkv_rows', 'ffn_tile', 'cus_available')]
 
 
 class sf_tfm_layer_grads(C.Structure):

@@ -188,6 +188,14 @@ __global__ void zero_words_kernel(unsigned* a, unsigned* b) {
   if (p) p[threadIdx.x] = 0u;
 }
 
+// A seam launch hands rows over INSIDE a grid (consumers poll producers with a bounded wait): every workgroup of it must be resident at
+// once, one per CU.  160 fit the whole chip with room for neighbours; a caller whose stream carries a CU mask says how many CUs that is
+// (sf_rollout_opts.cus_available) and the seam is used only when the grid fits them -- otherwise the two launches it replaces.
+static int seam_capacity() {
+  const int cus = sf_thread_opts().cus;
+  return cus > 0 && cus < 160 ? cus : 160;
+}
+
 int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws,
                    size_t ws_bytes, void* stream) {
   SF_REQUIRE(m && slots && ws, "null pointer");
@@ -234,7 +242,7 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   // row-tile form of the attention block (per-call option attn_qkv_rows = 128, attn_rows.hip): q|k|v projection on 128-row tiles
   // of the batch + one core / out-projection workgroup per video; finished rows like the all-heads form
   const bool attn_rows = fused_layers && sf_thread_opts().attn_rows == 128;
-  const bool seam = boundary_fused && (seam_opt >= 0 ? seam_opt != 0 : sf_get_seam_fused() != 0) && sf_seam_blocks(B, N) <= 160 &&
+  const bool seam = boundary_fused && (seam_opt >= 0 ? seam_opt != 0 : sf_get_seam_fused() != 0) && sf_seam_blocks(B, N) <= seam_capacity() &&
                     sf_thread_opts().attn_heads != 8 && !attn_rows;
   // layers 0 .. n-2 leave their output as four FFN chunk partials that the next attention sums while loading (the last layer's
   // FFN sums them itself: its last-arriving workgroup)
@@ -503,6 +511,7 @@ int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total,
              "sf_rollout_opts: attn_heads_per_wg must be 0 (default), 2 or 8");
   SF_REQUIRE(opts->attn_qkv_rows == 0 || opts->attn_qkv_rows == 128, "sf_rollout_opts: attn_qkv_rows must be 0 (off) or 128");
   SF_REQUIRE(opts->ffn_tile >= 0 && opts->ffn_tile <= 2, "sf_rollout_opts: ffn_tile must be 0, 1 or 2");
+  SF_REQUIRE(opts->cus_available >= 0 && opts->cus_available <= 256, "sf_rollout_opts: cus_available must be 0 (whole chip) .. 256");
   SfThreadOpts o = sf_thread_opts();
   if (opts->precision >= 0) o.precision = opts->precision;
   if (opts->seam_fused >= 0) o.seam = opts->seam_fused ? 1 : 0;
@@ -510,6 +519,7 @@ int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total,
   if (opts->attn_heads_per_wg > 0) o.attn_heads = opts->attn_heads_per_wg;
   if (opts->attn_qkv_rows > 0) o.attn_rows = opts->attn_qkv_rows;
   if (opts->ffn_tile > 0) o.ffn_tile = opts->ffn_tile;
+  if (opts->cus_available > 0) o.cus = opts->cus_available;
   OptsScope scope(o);
   const bool plain = (o.precision == 2 || o.precision == 3);
   const bool old_plain = t_plain_gemms;
@@ -541,7 +551,7 @@ int sf_rollout_uses_seam(const sf_rollouter* m, int B) {
   return packed && sf_get_precision() >= 1 && m->norm_first &&
          sf_layer_fused_ok(m->d_model, m->num_heads, m->ffn_dim, m->window_len * m->num_slots) &&
          sf_step_boundary_ok(m->d_model, m->slot_size) && (seam_opt >= 0 ? seam_opt != 0 : sf_get_seam_fused() != 0) &&
-         sf_seam_blocks(B, m->num_slots) <= 160;
+         sf_seam_blocks(B, m->num_slots) <= seam_capacity();
 }
 
 int sf_rollout_bf16(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws, size_t ws_bytes,

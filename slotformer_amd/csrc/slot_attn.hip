@@ -191,16 +191,23 @@ __global__ __launch_bounds__(256) void sa_attn_mfma_kernel(
   float s[NS];
 #pragma unroll
   for (int n = 0; n < NS; ++n) s[n] = 0.f;
-  f32x4v nx[8];
+  // (round 4) ALL slabs of the wave's 64 rows are requested up front -- up to four (D <= 128: the whole tile, 128 registers; two waves
+  // per SIMD leave 256) -- instead of one slab ahead: the four dependent round trips of phase 1 (~2 us each from HBM) were most of a
+  // workgroup's ~19 us, and a workgroup's latency IS the launch time (one round of workgroups on the whole chip, two on a 128-CU mask)
+  constexpr int NSL = D / 32, PF = D <= 128 ? NSL : 1;   // (wider slots: one slab ahead as before -- the tile would not fit the registers)
+  f32x4v nx[PF][8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) nx[u] = sa_load4<KT>(kslab + (long long)(8 * u) * ld);
-#pragma unroll 1
-  for (int d0 = 0; d0 < D; d0 += 32) {
+  for (int c = 0; c < PF; ++c)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) *(f32x4v*)&s_k[wave][(lane >> 3) + 8 * u][4 * (lane & 7)] = nx[u];
-    if (d0 + 32 < D) {
+    for (int u = 0; u < 8; ++u) nx[c][u] = sa_load4<KT>(kslab + (long long)(8 * u) * ld + 32 * c);
+#pragma unroll(D <= 128 ? NSL : 1)
+  for (int sl = 0; sl < NSL; ++sl) {
+    const int d0 = 32 * sl;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) nx[u] = sa_load4<KT>(kslab + (long long)(8 * u) * ld + d0 + 32);
+    for (int u = 0; u < 8; ++u) *(f32x4v*)&s_k[wave][(lane >> 3) + 8 * u][4 * (lane & 7)] = nx[sl % PF][u];
+    if (sl + PF < NSL) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) nx[sl % PF][u] = sa_load4<KT>(kslab + (long long)(8 * u) * ld + d0 + 32 * PF);
     }
     __builtin_amdgcn_wave_barrier();
     f32x4v kx[8];
@@ -248,21 +255,23 @@ __global__ __launch_bounds__(256) void sa_attn_mfma_kernel(
   for (int j = 0; j < DB; ++j) acc[j] = f32x4a{0.f, 0.f, 0.f, 0.f};
   const int li = lane & 15, lk = lane >> 4;  // A: row i = li (channels DB*li..), k = lk (pixel in group of 4)
   const KT* vbase = v + (long long)b * batch_stride + (long long)(pix0 + lk) * ld + DB * li;
-#pragma unroll 4
-  for (int ks = 0; ks < 16; ++ks) {
-    const KT* vp = vbase + (long long)(4 * ks) * ld;
-    float vx[DB];
+  // (round 4) the 16 k-steps fully unrolled: every V row of the wave is requested before the first MFMA needs one (DB / 4 16-byte loads
+  // per k-step: 32 .. 64 registers in flight), instead of four k-steps at a time
+  // (wider slots: four k-steps at a time as before -- the whole tile would not fit the registers)
+  constexpr int PFV = D <= 128 ? 16 : 4;
 #pragma unroll
-    for (int j = 0; j < DB; j += 4) {
-      const f32x4v t4 = sa_load4<KT>(vp + j);
-      vx[j] = t4[0];
-      vx[j + 1] = t4[1];
-      vx[j + 2] = t4[2];
-      vx[j + 3] = t4[3];
+  for (int k0 = 0; k0 < 16; k0 += PFV) {
+    f32x4v vq[PFV][DB / 4];
+#pragma unroll
+    for (int ks = 0; ks < PFV; ++ks)
+#pragma unroll
+      for (int j4 = 0; j4 < DB / 4; ++j4) vq[ks][j4] = sa_load4<KT>(vbase + (long long)(4 * (k0 + ks)) * ld + 4 * j4);
+#pragma unroll
+    for (int ks = 0; ks < PFV; ++ks) {
+      const float bop = li < NS ? s_a[wave][4 * (k0 + ks) + lk][li] : 0.f;  // B[k = pixel][j = slot]
+#pragma unroll
+      for (int j = 0; j < DB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[ks][j >> 2][j & 3], bop, acc[j], 0, 0, 0);
     }
-    const float bop = li < NS ? s_a[wave][4 * ks + lk][li] : 0.f;  // B[k = pixel][j = slot]
-#pragma unroll
-    for (int j = 0; j < DB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vx[j], bop, acc[j], 0, 0, 0);
   }
   // acc[j][r]: channel d = DB * (4*lk + r) + j, slot = li
 #pragma unroll
@@ -884,6 +893,136 @@ extern "C" int sf_slot_attn_iter_bf16(const void* k, const void* v, int ld, long
   return 0;
 }
 
+// -----------------------------------------------------------------------------------------
+// One-pass form on matrix cores for keys == values (round 4; the folded Slot Attention of engine.hip).  The two-pass kernel fetches 1.8x
+// the unique bytes (its second walk over the rows misses L2), and the first one-pass form (above) lost because a 33 KB tile per wave left
+// four waves per CU.  Here a wave owns 32 pixels (16.5 KB tile, eight waves per workgroup of 256 pixels: two waves per SIMD as before):
+//   * the wave's 32 rows arrive with sixteen 16-byte loads per lane, two WHOLE rows per instruction (perfect coalescing), and are parked in
+//     an LDS tile of pitch D + 4 floats (conflict-free 16-byte row reads);
+//   * logits: X . Q^T on v_mfma_f32_16x16x4_f32 -- the tile rows are the A operand, the scaled queries (zero beyond N slots) sit in
+//     registers as the B operand.  One 16-byte LDS read feeds four MFMAs: MFMA e of a read contracts channels {16 s + 4 g + e}, g = lane >> 4
+//     (the contraction runs over all channels, so which instruction takes which channel is free as long as both operands agree);
+//   * softmax over slots: the 8 slots of a pixel are lanes 0..7 of a 16-lane row of the accumulator: two DPP all-reduces (max, sum);
+//   * weighted sums: A^T . X with the attention tile (through 2 KB of LDS, transposed) as A operand and the SAME LDS tile as B operand,
+//     again four MFMAs per 16-byte read (output column j of MFMA (h, e) is channel 64 h + 4 j + e).
+// 128 MFMAs of 32 cycles per wave and 32 pixels: 9.7 TB/s of rows at two waves per SIMD on the whole chip -- above the HBM roof.
+// Arithmetic: exact f32 products, f32 accumulation; the summation order differs from the VALU logits of sa_attn_mfma_kernel (rounding-level
+// differences, every fixture keeps its tolerance).
+template <int D>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void sa_attn_tile_kernel(const float* __restrict__ x, int ld, long long batch_stride,
+                                                           const float* __restrict__ q, float scale, float eps,
+                                                           float* __restrict__ part_num, float* __restrict__ part_den,
+                                                           float* __restrict__ attn_out, long long attn_bs, int HW, int N, int P) {
+  // a wave owns 32 pixels, processed as two halves of 16 through ONE 16-row LDS tile (8.4 KB per wave, 76 KB per workgroup: TWO
+  // workgroups per CU -- while one multiplies, the other's rows are in flight; with one workgroup per CU the chip alternated between a
+  // load phase and a compute phase in lockstep: 25.9 us per 32 frames, no better than the two-pass kernel)
+  constexpr int NS = SA_NMAX, XP = D + 4, NW = 8, TP = 16;   // tile pitch, waves, pixels per half
+  constexpr int NSLAB = D / 16, NH = D / 64;
+  extern __shared__ __attribute__((aligned(16))) float sa_lds[];
+  float* s_x = sa_lds;                          // [NW][TP][XP]
+  float* s_a = s_x + NW * TP * XP;              // [NW][TP][17]: attention tile, pixel-major (pitch 17: conflict-free column reads)
+  float* s_red = sa_lds;                        // [NW][NS][XP] over the dead tiles
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pix0 = chunk * (NW * 2 * TP) + wave * 2 * TP;
+  const int li = lane & 15, lg = lane >> 4;
+  typedef float f32x4a __attribute__((ext_vector_type(4)));
+  static_assert(D == 128, "sa_attn_tile_kernel: D = 128 (two whole rows per load instruction)");
+  // ---- the wave's 32 rows: instruction u brings rows 2 u and 2 u + 1 whole (lane & 31 = the 16-byte column); all 16 requested at once ----
+  const float* xs = x + (long long)b * batch_stride + (long long)(pix0 + (lane >> 5)) * ld + 4 * (lane & 31);
+  float* tile = s_x + wave * TP * XP;
+  f32x4v stage[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) stage[u] = *(const f32x4v*)(xs + (long long)(2 * u) * ld);
+  // the scaled queries as B operand: lane (k = lg, j = li) holds q[slot li][16 s + 4 lg + e] for every slab s
+  f32x4v qr[NSLAB];
+#pragma unroll
+  for (int sl = 0; sl < NSLAB; ++sl) {
+    f32x4v t = {0.f, 0.f, 0.f, 0.f};
+    if (li < N) t = *(const f32x4v*)(q + ((long long)b * N + li) * D + 16 * sl + 4 * lg);
+    qr[sl] = t * scale;
+  }
+  f32x4a nacc[NH][4];
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) nacc[h][e] = f32x4a{0.f, 0.f, 0.f, 0.f};
+  float den = 0.f;
+  float* at = s_a + wave * TP * 17;
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    // (the loads retire in order: the first eight cover half 0; half 1 is still in flight while half 0 is multiplied)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) *(f32x4v*)(tile + (2 * u + (lane >> 5)) * XP + 4 * (lane & 31)) = stage[8 * hf + u];
+    __builtin_amdgcn_wave_barrier();
+    // ---- logits[pixel][slot]: A = tile rows (i = li: pixel, k = lg), B = qr ----
+    f32x4a acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sl = 0; sl < NSLAB; ++sl) {
+      const f32x4v xa = *(const f32x4v*)(tile + li * XP + 16 * sl + 4 * lg);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[e], qr[sl][e], acc, 0, 0, 0);
+    }
+    // acc[r]: pixel 4 lg + r of the half, slot li.  Softmax over the slots (lanes li = 0..7 of every 16-lane row), + eps
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool live = li < N;
+      const float v = live ? acc[r] : -INFINITY;
+      const float mx = sf_max8(li < 8 ? v : -INFINITY);
+      const float ex = live ? expf(v - mx) : 0.f;
+      const float sum = sf_sum8(li < 8 ? ex : 0.f);
+      const float a0 = ex / sum;
+      const int pix = 4 * lg + r;
+      if (attn_out && live) attn_out[(long long)b * attn_bs + (long long)li * HW + pix0 + TP * hf + pix] = a0;
+      const float a = live ? a0 + eps : 0.f;
+      den += a;
+      at[pix * 17 + li] = a;   // (lanes li >= N: zero columns -- the padded slot rows of the A operand below)
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- num[slot][channel] += A^T . X: A (i = li: slot, k = lg: pixel 4 ks + lg) from the attention tile, B (k = lg: pixel, j = li) four
+    //      channels per 16-byte read: MFMA (h, e) column li is channel 64 h + 4 li + e ----
+#pragma unroll
+    for (int ks = 0; ks < TP / 4; ++ks) {
+      const float aop = at[(4 * ks + lg) * 17 + li];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const f32x4v xb = *(const f32x4v*)(tile + (4 * ks + lg) * XP + 64 * h + 4 * li);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) nacc[h][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, xb[e], nacc[h][e], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // the tile and the attention tile are rewritten by the next half
+  }
+  // den: the slot's sum over this wave's pixels = over the lanes with the same li
+  den += __shfl_xor(den, 16, 64);
+  den += __shfl_xor(den, 32, 64);
+  // ---- cross-wave reduction over the dead tiles: nacc[h][e][r] = num[slot 4 lg + r][channel 64 h + 4 li + e] (slots < 8: lg < 2) ----
+  __syncthreads();
+  if (lg < 2) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        f32x4v o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = nacc[h][e][r];
+        *(f32x4v*)(s_red + (wave * NS + 4 * lg + r) * XP + 64 * h + 4 * li) = o;
+      }
+  }
+  if (lg == 0 && li < NS) s_red[(wave * NS + li) * XP + D] = den;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < N * (D + 1); idx += 512) {
+    const int n = idx / (D + 1), d = idx - n * (D + 1);
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += s_red[(w * NS + n) * XP + d];
+    if (d < D)
+      part_num[(((long long)b * P + chunk) * N + n) * D + d] = t;
+    else
+      part_den[((long long)b * P + chunk) * N + n] = t;
+  }
+}
+
 int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch_stride, const float* q,
                          float* part_num, float* part_den, float* attn_out, long long attn_batch_stride, int B,
                          int HW, int N, int D, float scale, float eps, hipStream_t st) {
@@ -909,7 +1048,20 @@ int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch
     const char* e = getenv("SF_SA_ONEPASS");
     return e && e[0] == '1';
   }();
-  if (HW % 256 == 0 && k == v && D == 128 && fold_env) {
+  // (opt-in, SF_SA_TILE=1: measured no faster than the two-pass kernel -- 25.9 vs 24.2 us per 32 frames on the whole chip, 39.5 vs 38.5 on a
+  //  128-CU mask, profiles/r04_probes.txt: one workgroup per CU and a single tile per wave expose the whole load latency)
+  static const bool tile_off = [] {
+    const char* e = getenv("SF_SA_TILE");
+    return !(e && e[0] == '1');
+  }();
+  if (HW % 256 == 0 && k == v && D == 128 && P == HW / 256 && !tile_off && !fold_env) {
+    // keys == values: every row read once, both products on the matrix cores (sa_attn_tile_kernel)
+    constexpr size_t LDS = (size_t)(8 * 16 * (128 + 4) + 8 * 16 * 17) * sizeof(float);   // 76 KB: two workgroups per CU
+    static_assert(LDS <= 160 * 1024, "one-pass Slot Attention: LDS budget");
+    SF_TRY(sf_ensure_dyn_lds((const void*)sa_attn_tile_kernel<128>, LDS));
+    hipLaunchKernelGGL(sa_attn_tile_kernel<128>, grid, dim3(512), LDS, st, k, ld, batch_stride, q, scale, eps, part_num, part_den, attn_out,
+                       attn_batch_stride, HW, N, P);
+  } else if (HW % 256 == 0 && k == v && D == 128 && fold_env) {
     // keys == values: every row is read once (sa_attn_fold_kernel)
     constexpr size_t LDS = (size_t)(4 * 64 * (128 + 4) + SA_NMAX * 128 + 4 * 64 * (SA_NMAX + 1)) * sizeof(float);
     static_assert(LDS <= 160 * 1024, "one-pass Slot Attention: LDS budget");

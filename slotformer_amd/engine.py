@@ -83,7 +83,7 @@ class _Plan:
         return t.data_ptr()
 
 
-_PLAN_ATTRS = ('_sf_plan', '_sf_train_plan', '_sf_dec_plan', '_plan', '_cat', '_catw', '_slate_plan')
+_PLAN_ATTRS = ('_sf_plan', '_sf_train_plan', '_sf_dec_plan', '_sf_dec_train_plan', '_plan', '_cat', '_catw', '_slate_plan')
 
 
 def invalidate(module):
@@ -179,19 +179,19 @@ def rollouter_plan(r, packed=True):
 def rollout_opts(opts):
     """dict / None -> ctypes sf_rollout_opts (None).  Keys: precision ('f32' | 'bf16x3' | 'bf16' | 'fp16' (probe) | 0..3), seam (bool),
     ffn_rows (32 | 64 | 128), attn_heads (2 | 8: heads per attention workgroup), attn_rows (0 | 128: q|k|v projection on row tiles of
-    the batch + one core workgroup per video), ffn_tile (0 | 1 | 2: the FFN block as one workgroup per 64-row tile, finished rows; 2: fused with LN1 + q|k|v of the next layer); per call and per thread, never process-wide."""
+    the batch + one core workgroup per video), ffn_tile (0 | 1 | 2: the FFN block as one workgroup per 64-row tile, finished rows; 2: fused with LN1 + q|k|v of the next layer), cus (CUs the calling stream's mask leaves it: seam launches only when their grid fits); per call and per thread, never process-wide."""
     if opts is None:
         return None
     if isinstance(opts, _lib.sf_rollout_opts):
         return opts
-    unknown = set(opts) - {'precision', 'seam', 'ffn_rows', 'attn_heads', 'attn_rows', 'ffn_tile'}
+    unknown = set(opts) - {'precision', 'seam', 'ffn_rows', 'attn_heads', 'attn_rows', 'ffn_tile', 'cus'}
     if unknown:
         raise ValueError(f'slotformer_amd: unknown rollout options {sorted(unknown)}')
     prec = opts.get('precision', -1)
     prec = {'f32': 0, 'bf16x3': 1, 'bf16': 2, 'fp16': 3}.get(prec, prec)
     seam = opts.get('seam', None)
     return _lib.sf_rollout_opts(int(prec), -1 if seam is None else int(bool(seam)), int(opts.get('ffn_rows', 0)), int(opts.get('attn_heads', 0)),
-                                int(opts.get('attn_rows', 0)), int(opts.get('ffn_tile', 0)))
+                                int(opts.get('attn_rows', 0)), int(opts.get('ffn_tile', 0)), int(opts.get('cus', 0)))
 
 
 def burn_in_of(r):
@@ -460,10 +460,13 @@ def _module_sig(*mods):
     return tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
 
 
-def decoder_plan(m):
-    """m: StoSAVi or SlotFormer (both hold `decoder`, `decoder_pos_embedding`, dec_* attributes)."""
+def decoder_plan(m, inference=True):
+    """m: StoSAVi or SlotFormer (both hold `decoder`, `decoder_pos_embedding`, dec_* attributes).  inference=False (the training nodes,
+    whose parameters change every step): the torch-layout weights only -- no fragment-ordered copies, no fp64 fold of the first layer
+    (a plan rebuilt per optimizer step must stay cheap: with the fold in it a StoSAVi training step took 121 instead of 21 ms)."""
     sig = _module_sig(m.decoder, m.decoder_pos_embedding)
-    plan = getattr(m, '_sf_dec_plan', None)
+    attr = '_sf_dec_plan' if inference else '_sf_dec_train_plan'
+    plan = getattr(m, attr, None)
     if plan is not None and plan.sig == sig:
         return plan
     plan = _Plan()
@@ -485,7 +488,7 @@ def decoder_plan(m):
         if dc.stride[0] == 1:   # [Cout, ks, ks, Cin] flipped over both kernel axes: the equivalent convolution kernel
             s.deconv_w_flipped[i] = plan.dp(packed.flip(1, 2).contiguous())
         s.deconv_b[i] = plan.dp(dc.bias)
-        if packed.is_cuda and tuple(dc.weight.shape) == (64, 64, 5, 5):
+        if inference and packed.is_cuda and tuple(dc.weight.shape) == (64, 64, 5, 5):
             st = torch.cuda.current_stream().cuda_stream
             if dc.stride[0] == 2:
                 # consumption-ordered split-bf16 fragments: the parity-class kernel with streamed weights (deconv_s2.hip)
@@ -499,7 +502,7 @@ def decoder_plan(m):
                 plan.keep.append(frag)
                 s.deconv_w_frag[i] = frag.data_ptr()
     dc0 = m.decoder[0][0]
-    if dc0.stride[0] == 2 and m.dec_ks == 5 and m.dec_resolution[0] >= 2 and dc0.bias is not None:
+    if inference and dc0.stride[0] == 2 and m.dec_ks == 5 and m.dec_resolution[0] >= 2 and dc0.bias is not None:
         # the first layer acts on slot + pos_table[p]: tap sums per border / parity class + the transposed convolution of the position
         # table (include/slotformer_hip.h, l0_weff / l0_posterm) -- a one-time fp64 fold on the host, exact algebra
         res0 = m.dec_resolution[0]
@@ -521,7 +524,7 @@ def decoder_plan(m):
     s.pos_table = plan.dp(ops.pos_embed_table(pe.grid.detach().float(), pe.dense.weight.detach().float().contiguous(),
                                               pe.dense.bias.detach().float().contiguous()))
     plan.struct, plan.sig = s, sig
-    m._sf_dec_plan = plan
+    setattr(m, attr, plan)
     return plan
 
 

@@ -199,7 +199,8 @@ class EncodeRolloutPipeline:
             # the latency forms, four times the workgroups (224 vs 120 k frames/s at B = 8, 251 vs 219 k at B = 16).  Same bits.
             roll_cus = 256 - sum(bin(w).count('1') for w in self._enc_words_pair)
             wide = 2 * self.G * self.B >= roll_cus
-            rollout_opts = {'seam': bool(int(os.environ.get('SF_PIPE_SEAM', '0'))),
+            rollout_opts = {'cus': roll_cus,   # (seam launches -- off below anyway -- only when their grid fits the rollout CUs)
+                            'seam': bool(int(os.environ.get('SF_PIPE_SEAM', '0'))),
                             'ffn_rows': int(os.environ.get('SF_PIPE_FFN_ROWS', '128' if wide else '64')),
                             'attn_heads': int(os.environ.get('SF_PIPE_ATTN_HEADS', '8' if wide else '2')),
                             'attn_rows': 0, 'ffn_tile': 0}
@@ -215,6 +216,10 @@ class EncodeRolloutPipeline:
             # (2: the FFN tile launch also runs LN1 + q|k|v of the next layer on its rows -- one launch less per layer: C2 441 -> 447 k,
             #  C5 432 -> 446 k, C4 175 -> 181 k)
             rollout_opts['ffn_tile'] = int(os.environ.get('SF_PIPE_FFN_TILE', '2' if tiles else '0'))
+        if partition in ('three', 'two') and (rollout_opts is None or (isinstance(rollout_opts, dict) and 'cus' not in rollout_opts)):
+            # the library's seam launches need their whole grid resident on the CUs the rollout stream may use: tell it how many those are
+            cus = 168 if partition == 'three' else 256 - sum(bin(w).count('1') for w in encode_mask_words(encode_cu_word))
+            rollout_opts = dict(rollout_opts or {}, cus=cus)
         self.rollout_opts = engine.rollout_opts(rollout_opts)
         # units of fewer batches (the ramp at both ends of a run) are on the critical path of fill and drain: the latency forms
         # of the kernels (head-pair attention workgroups, narrower FFN workgroups: more, shorter workgroups per launch) -- the
@@ -222,7 +227,8 @@ class EncodeRolloutPipeline:
         self.tail_opts = self.rollout_opts
         if self.rollout_opts is not None and (self.rollout_opts.ffn_rows > 64 or self.rollout_opts.attn_heads_per_wg == 8 or
                                               self.rollout_opts.attn_qkv_rows or self.rollout_opts.ffn_tile):
-            self.tail_opts = _lib.sf_rollout_opts(self.rollout_opts.precision, self.rollout_opts.seam_fused, min(self.rollout_opts.ffn_rows or 64, 64), 2, 0, 0)
+            self.tail_opts = _lib.sf_rollout_opts(self.rollout_opts.precision, self.rollout_opts.seam_fused, min(self.rollout_opts.ffn_rows or 64, 64), 2, 0, 0,
+                                                  self.rollout_opts.cus_available)
         self.use_graph = bool(use_graph)
         # the encode under a hipGraph too: the gaps between its ~60 short launches shrink (374-377 vs 373 k frames/s at 20
         # batches, 399.5 vs 398.2 at 40) at the price of a 38 MB device copy of the frames into the fixed input buffer per batch

@@ -210,7 +210,7 @@ class _Decode(torch.autograd.Function):
         slots = slots.detach().float().contiguous()
         if not slots.is_cuda:
             raise RuntimeError('slotformer_amd: inputs must live on a HIP device; there is no CPU fallback')
-        plan = engine.decoder_plan(m)
+        plan = engine.decoder_plan(m, inference=False)
         if not hasattr(plan, 'bwd_w'):
             n = plan.struct.dec_layers
             plan.bwd_keep = [ops.pack_conv_weight(m.decoder[i][0].weight.detach().float().contiguous()) for i in range(n)]

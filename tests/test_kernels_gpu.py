@@ -210,6 +210,42 @@ def test_slot_attn_one_pass_for_keys_equal_values(dev, B, N, HW):
     assert torch.equal(pn1, pn2) and torch.equal(pd1, pd2) and torch.equal(at1, at2)
 
 
+@pytest.mark.parametrize('B,N,HW', [(3, 7, 4096), (2, 8, 4096), (5, 1, 1024), (2, 6, 256), (33, 7, 4096)])
+def test_slot_attn_tile_kernel_for_keys_equal_values(dev, B, N, HW):
+    """The opt-in one-pass kernel for keys and values being the SAME rows at slot size 128 (SF_SA_TILE=1; the folded Slot Attention of the
+    encode): every row read once, logits and weighted sums on the f32 matrix cores from one LDS tile (sa_attn_tile_kernel) -- against a plain PyTorch
+    reference of the op (savi.py:76-89) and against the two-pass kernel on separate copies of the rows (another summation order:
+    rounding-level differences)."""
+    import subprocess, sys, os  # noqa: E401
+    from slotformer_amd import ops
+    if os.environ.get('SF_SA_TILE') != '1':
+        # the tile kernel is opt-in (measured no faster than the two-pass kernel, profiles/r04_probes.txt; read once per process): run
+        # this test again in a child process with it on
+        env = dict(os.environ, SF_SA_TILE='1')
+        r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', f'{__file__}::test_slot_attn_tile_kernel_for_keys_equal_values[{B}-{N}-{HW}]'],
+                           env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
+    D = 128
+    x, q = rnd(B, HW, D, seed=31), rnd(B, N, D, seed=32)
+    xd = x.to(dev)
+    pn1, pd1, at1 = ops.slot_attn_iter(xd, xd, q.to(dev), want_attn=True)           # k is v: the tile kernel
+    pn2, pd2, at2 = ops.slot_attn_iter(xd, xd.clone(), q.to(dev), want_attn=True)   # separate buffers: the two-pass kernel
+    a = torch.softmax(D**-0.5 * torch.einsum('bnc,bmc->bnm', x, q), -1)
+    close(at1, a.permute(0, 2, 1), rtol=1e-5, atol=1e-6)
+    a = a + 1e-6
+    upd = torch.einsum('bnm,bnc->bmc', a / a.sum(1, keepdim=True), x)
+    close(pn1.sum(1) / pd1.sum(1).unsqueeze(-1), upd, rtol=1e-5, atol=1e-6)
+    close(pn1, pn2.cpu(), rtol=1e-4, atol=1e-4)
+    close(pd1, pd2.cpu(), rtol=1e-5, atol=1e-5)
+    close(at1, at2.cpu(), rtol=1e-5, atol=1e-6)
+    # deterministic, and a video's records do not depend on the batch it sits in
+    if B > 1:
+        xs = xd[1:2].contiguous()
+        pn3, pd3, _ = ops.slot_attn_iter(xs, xs, q[1:2].to(dev).contiguous())
+        assert torch.equal(pn3[0], pn1[1]) and torch.equal(pd3[0], pd1[1])
+
+
 @pytest.mark.parametrize('B,N,D,HW', [(3, 7, 128, 4096), (2, 6, 192, 4096), (2, 8, 128, 4096), (1, 1, 64, 4096),
                                       (2, 7, 128, 1024), (2, 5, 128, 2000), (1, 8, 256, 4096)])
 def test_slot_attn_iteration(dev, B, N, D, HW):
