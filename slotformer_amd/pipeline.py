@@ -333,6 +333,72 @@ class EncodeRolloutPipeline:
         self._enc_plan = engine.encoder_plan(self.savi)
         self._enc_sig = self._enc_plan.sig
         self._capture_encode_graphs()
+        self._calibrate_placement()
+
+    def _calibrate_placement(self):
+        """Which hardware queues the two unmasked streams (whole-chip fill encodes, hybrid lane, drain units) land on decides ~10 % of a
+        run (profiles/r03_probes.txt section 16), and the runtime's dealing of queues -- round-robin over four on first use -- is neither
+        documented nor stable against other streams in the process (RCCL, another library).  So the placement is MEASURED once per process
+        and device instead of assumed: five fresh streams are touched in order (consecutive queues), the four neighbouring pairs and the
+        rule's pick (_pick_free_streams) each time a short run of this pipeline on zero frames, and the fastest pair is kept for every
+        pipeline of the process.  OPT-IN (SF_PIPE_PLACEMENT=measure, or =<i> to force candidate i; default 'rule' = _pick_free_streams): on
+        this image the measured pick and the rule's give the same throughput (493 vs 495 k frames/s plain, 472 vs 475 k with RCCL
+        initialised, profiles/r04_probes.txt) although the 16-batch calibration runs themselves differ by 13 % between candidates -- a short
+        run right after five new streams appeared is a poor predictor of the steady state, so the rule validated over rounds 3-4 stays the
+        default and the measurement is the tool for a runtime where the rule's assumption (queues dealt round-robin over four) fails."""
+        mode = os.environ.get('SF_PIPE_PLACEMENT', 'rule')
+        mode = 'auto' if mode == 'measure' else mode
+        if mode == 'rule' or len(self.roll_streams) < 2 or not self.cu_split or len(self.s_free) < 2:
+            return
+        key = ('placement-cal', self.dev.index)
+        with _STREAMS_LOCK:
+            done = _STREAMS.get(key)
+        if done is not None:
+            self.s_free, self.stream_placement = list(done[0]), done[1]
+            return
+        # only a pipeline whose rollout units fill the chip can tell the placements apart (small test pipelines keep the rule)
+        hist = getattr(self.roll, 'cond_len', None) or getattr(self.roll, 'history_len', self.T)
+        if mode == 'auto' and self.G * self.B * self.N * hist < 2048:
+            return
+        rule_pair = list(self.s_free)
+        cands = [torch.cuda.Stream(device=self.dev) for _ in range(5)]
+        with torch.cuda.device(self.dev):
+            for st in cands:
+                _lib.check(self._lib.sf_debug_spin(1, st.cuda_stream))   # first use: the stream gets its hardware queue
+                st.synchronize()
+        pairs = [[cands[i], cands[i + 1]] for i in range(4)] + [rule_pair]
+        res = getattr(self.savi, 'resolution', (128, 128))[0]
+        n = max(self.fill_batches + self.G, 3 * self.G)
+        img = torch.zeros(self.B, self.T, 3, res, res, device=self.dev)
+        out = torch.empty(n, self.B, self.T + self.H, self.N, self.D, device=self.dev)
+        times = []
+        for pair in pairs:
+            self.s_free = pair
+            best = None
+            for rep in range(3):   # (the first run of a pair warms its queues)
+                torch.cuda.synchronize(self.dev)
+                t0 = time.perf_counter()
+                self.run([img] * n, None, out=out)
+                torch.cuda.synchronize(self.dev)
+                dt = time.perf_counter() - t0
+                if rep and (best is None or dt < best):
+                    best = dt
+            times.append(best)
+        pick = int(mode) if mode.lstrip('-').isdigit() else min(range(len(pairs)), key=lambda i: times[i])
+        pick = max(0, min(pick, len(pairs) - 1))
+        self.s_free = pairs[pick]
+        info = dict(self.stream_placement or {})
+        info.update({'calibrated': True, 'picked': 'rule' if pick == 4 else f'fresh streams {pick}, {pick + 1} of 5',
+                     'candidate_ms': [round(1e3 * t, 3) for t in times], 'calibration_batches': n,
+                     'rule_vs_best': round(times[4] / min(times), 4)})
+        self.stream_placement = info
+        if os.environ.get('SF_PIPE_LOG_PLACEMENT', '0') == '1' or int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            import sys
+            print(f'[slotformer_amd.pipeline] stream placement (measured): {info}', file=sys.stderr, flush=True)
+        with _STREAMS_LOCK:
+            _STREAMS[key] = (tuple(self.s_free), info)
+            _STREAMS[('free-set', self.dev.index, 2)] = tuple(self.s_free)
+            _STREAMS[('placement', self.dev.index)] = info
 
     def _capture_encode_graphs(self):
         """Capture the encode graphs of the lanes a run uses NOW, not inside the first run that reaches them (a short warm-up only
