@@ -345,16 +345,31 @@ __global__ void decode_l0_expand_kernel(const float* __restrict__ table, const f
 // slot_max != NULL (the segmentation of vp_utils.py:20-41 follows): also the per-(frame, slot) maximum of the mask over the pixels, as
 // float bits in unsigned words cleared before the launch (masks are positive: the bit patterns order like the values; max is
 // order-independent, so the atomics stay deterministic).
-__device__ __forceinline__ float slot_mask_of(const float* __restrict__ dec, long long f, int N, int HW, int pix, int n, float mx, float inv) {
-  return expf(dec[((f * N + n) * HW + pix) * 4 + 3] - mx) * inv;
-}
-__device__ __forceinline__ void slot_softmax_stats(const float* __restrict__ dec, long long f, int N, int HW, int pix, float& mx, float& inv) {
-  mx = -INFINITY;
-  for (int n = 0; n < N; ++n) mx = fmaxf(mx, dec[((f * N + n) * HW + pix) * 4 + 3]);
+// the N (<= DC_NMAX) head outputs of a pixel in registers: ONE 16-byte load per slot (the first version walked the slots three times --
+// max, sum, outputs -- with dependent loads: 32 us per 36 frames where the bytes need 15); masks[n] = exp(logit_n - max) / sum
+constexpr int DC_NMAX = 16;
+template <int NN>
+__device__ __forceinline__ void slot_softmax_regs(const float* __restrict__ dec, long long f, int N, int HW, int pix, f32x4 (&v)[NN], float (&m)[NN]) {
+  float mx = -INFINITY;
+#pragma unroll
+  for (int n = 0; n < NN; ++n) {
+    if (n < N) {
+      v[n] = *(const f32x4*)(dec + ((f * N + n) * HW + pix) * 4);
+      mx = fmaxf(mx, v[n][3]);
+    }
+  }
   float sum = 0.f;
-  for (int n = 0; n < N; ++n) sum += expf(dec[((f * N + n) * HW + pix) * 4 + 3] - mx);
-  inv = 1.0f / sum;
+#pragma unroll
+  for (int n = 0; n < NN; ++n) {
+    m[n] = n < N ? expf(v[n][3] - mx) : 0.f;
+    sum += m[n];
+  }
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int n = 0; n < NN; ++n) m[n] *= inv;
 }
+
+template <int NN>
 __global__ void decode_combine_kernel(const float* __restrict__ dec, float* __restrict__ recon,
                                       float* __restrict__ recons, float* __restrict__ masks, unsigned* __restrict__ slot_max, int F, int N,
                                       int HW) {
@@ -363,8 +378,9 @@ __global__ void decode_combine_kernel(const float* __restrict__ dec, float* __re
   const long long idx = valid ? idx0 : (long long)F * HW - 1;
   const int pix = idx % HW;
   const long long f = idx / HW;
-  float mx, inv;
-  slot_softmax_stats(dec, f, N, HW, pix, mx, inv);
+  f32x4 v[NN];
+  float m[NN];
+  slot_softmax_regs<NN>(dec, f, N, HW, pix, v, m);
   float acc[3] = {0.f, 0.f, 0.f};
   // a workgroup's 256 pixels lie in one frame when HW % 256 == 0: the waves meet in LDS, one global atomic per workgroup and slot
   // (per wave they queued 256 deep on every (frame, slot) word: +0.18 ms per 32 frames)
@@ -374,22 +390,22 @@ __global__ void decode_combine_kernel(const float* __restrict__ dec, float* __re
     wg_max[threadIdx.x] = 0u;
     __syncthreads();
   }
-  for (int n = 0; n < N; ++n) {
-    const f32x4 v = *(const f32x4*)(dec + ((f * N + n) * HW + pix) * 4);
-    const float m = slot_mask_of(dec, f, N, HW, pix, n, mx, inv);
-    if (masks && valid) masks[(f * N + n) * HW + pix] = m;
+#pragma unroll
+  for (int n = 0; n < NN; ++n) {
+    if (n >= N) break;
+    if (masks && valid) masks[(f * N + n) * HW + pix] = m[n];
     if (slot_max) {
       if (wg_one_frame) {
-        const float wm = sf_wave_max(valid ? m : 0.f);
+        const float wm = sf_wave_max(valid ? m[n] : 0.f);
         if ((threadIdx.x & 63) == 0) atomicMax(&wg_max[n], __float_as_uint(wm));
       } else if (valid) {
-        atomicMax(slot_max + f * N + n, __float_as_uint(m));
+        atomicMax(slot_max + f * N + n, __float_as_uint(m[n]));
       }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      if (recons && valid) recons[((f * N + n) * 3 + c) * HW + pix] = v[c];
-      acc[c] = fmaf(v[c], m, acc[c]);
+      if (recons && valid) recons[((f * N + n) * 3 + c) * HW + pix] = v[n][c];
+      acc[c] = fmaf(v[n][c], m[n], acc[c]);
     }
   }
   if (valid) {
@@ -406,25 +422,28 @@ __global__ void decode_combine_kernel(const float* __restrict__ dec, float* __re
 // postproc_mask (vp_utils.py:20-41) on the decoder's own masks, recomputed from dec with the expressions of decode_combine_kernel (the
 // same bits): the slot whose peak mask value over the frame is smallest is the background (first index on ties, as torch.argmin); a
 // pixel whose best mask value is below fg_thre goes to it, every other pixel to its argmax over slots (first index on ties).
+template <int NN>
 __global__ void decode_seg_kernel(const float* __restrict__ dec, const unsigned* __restrict__ slot_max, long long* __restrict__ seg64,
                                   unsigned char* __restrict__ seg8, int F, int N, int HW, float thre) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)F * HW) return;
   const int pix = idx % HW;
   const long long f = idx / HW;
-  float mx, inv;
-  slot_softmax_stats(dec, f, N, HW, pix, mx, inv);
+  f32x4 v[NN];
+  float m[NN];
+  slot_softmax_regs<NN>(dec, f, N, HW, pix, v, m);
   int bg = 0, best = 0;
   float bgv = __uint_as_float(slot_max[f * N]), bestv = -1.f;
-  for (int n = 0; n < N; ++n) {
+#pragma unroll
+  for (int n = 0; n < NN; ++n) {
+    if (n >= N) break;
     const float sm = __uint_as_float(slot_max[f * N + n]);
     if (sm < bgv) {
       bgv = sm;
       bg = n;
     }
-    const float m = slot_mask_of(dec, f, N, HW, pix, n, mx, inv);
-    if (m > bestv) {
-      bestv = m;
+    if (m[n] > bestv) {
+      bestv = m[n];
       best = n;
     }
   }
@@ -571,7 +590,7 @@ int sf_decode_combine_seg_f32(const float* dec, float* recon_combined, float* re
   SF_REQUIRE(dec && recon_combined && F >= 0 && N >= 1 && HW > 0, "bad combine arguments");
   const bool seg = seg_i64 || seg_u8;
   SF_REQUIRE(!seg || slot_max, "the segmentation needs the slot_max scratch ([F * N] words)");
-  SF_REQUIRE(!seg || N <= 255, "at most 255 slots");
+  SF_REQUIRE(N <= DC_NMAX, "at most 16 slots");
   const long long total = (long long)F * HW;
   if (total == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -579,12 +598,18 @@ int sf_decode_combine_seg_f32(const float* dec, float* recon_combined, float* re
     hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)(((long long)F * N + 255) / 256)), dim3(256), 0, st, slot_max, (long long)F * N);
     SF_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(decode_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dec, recon_combined, recons, masks,
-                     seg ? slot_max : nullptr, F, N, HW);
+  if (N <= 8)
+    hipLaunchKernelGGL(decode_combine_kernel<8>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dec, recon_combined, recons, masks,
+                       seg ? slot_max : nullptr, F, N, HW);
+  else
+    hipLaunchKernelGGL(decode_combine_kernel<DC_NMAX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dec, recon_combined, recons, masks,
+                       seg ? slot_max : nullptr, F, N, HW);
   SF_CHECK_LAUNCH();
   if (seg) {
-    hipLaunchKernelGGL(decode_seg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dec, slot_max, seg_i64, seg_u8, F, N, HW,
-                       fg_thre);
+    if (N <= 8)
+      hipLaunchKernelGGL(decode_seg_kernel<8>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dec, slot_max, seg_i64, seg_u8, F, N, HW, fg_thre);
+    else
+      hipLaunchKernelGGL(decode_seg_kernel<DC_NMAX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dec, slot_max, seg_i64, seg_u8, F, N, HW, fg_thre);
     SF_CHECK_LAUNCH();
   }
   return 0;
