@@ -368,6 +368,43 @@ def decode_leg(args, lib, savi, roll, ring, B, T, H, N, D, RES, dev, pipe, peak_
         'schedule': 'decode of a unit on an unmasked stream of its own behind the unit\'s rollout (slotformer_amd/pipeline.py, decoder=...); '
                     'bit-identical to the serial module calls (tests/test_pipeline_gpu.py::test_pipeline_with_the_decode_stage)',
     }
+    if args.config == 'C2' and RES == 128:
+        # the same leg at the reference's own CLEVRER resolution (stosavi_clevrer_params.py:33: 64 x 64; the first convolution has stride 1 there and
+        # the decoder ends in a stride-1 layer): a second StoSAVi of that resolution, the same rollouter
+        from slotformer_amd import configs
+        from slotformer_amd.base_slots import build_model
+        c64 = {k: (dict(v) if isinstance(v, dict) else v) for k, v in bench_configs()['C2'][0].items()}
+        c64['resolution'] = (64, 64)
+        torch.manual_seed(0)
+        savi64 = build_model(configs.ParamsView(c64)).eval().to(dev)
+        savi64.testing = True
+        ring64 = [synthetic_img(B, T, 64, seed=4321 + k).to(dev) for k in range(3)]
+        with torch.no_grad():
+            p64 = EncodeRolloutPipeline(savi64, roll, B, T, H, decoder=savi64)
+            d64, o64 = {}, torch.empty(K, B, T + H, N, D, device=dev)
+            b64 = [ring64[j % 3] for j in range(K)]
+            p64.run(b64, None, out=o64, decoded=d64)
+            torch.cuda.synchronize()
+            w64, w64n = [], []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                p64.run(b64, None, out=o64, decoded=d64)
+                torch.cuda.synchronize()
+                w64.append(time.perf_counter() - t0)
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                p64.run(b64, None, out=o64)
+                torch.cuda.synchronize()
+                w64n.append(time.perf_counter() - t0)
+            assert torch.isfinite(d64['recon']).all()
+            p64.close()
+        e64, e64n = sorted(w64)[1], sorted(w64n)[1]
+        obj['at_64x64'] = {'frames_per_s': world * B * (T + H) * K / e64, 'ms_per_step': 1e3 * e64 / K, 'decoded_frames_per_s': world * B * H * K / e64,
+                           'without_decode_frames_per_s': world * B * (T + H) * K / e64n, 'steps': K,
+                           'note': 'the reference trains / evaluates CLEVRER at 64 x 64 (stosavi_clevrer_params.py:33): StoSAVi of that resolution (stride-1 first convolution, '
+                                   'decoder 8 -> 16 -> 32 -> 64 + a stride-1 layer with the head in its epilogue), same rollouter, same schedule'}
     roof = None
     dh = prof.get('deconv_head')
     if dh:

@@ -234,7 +234,8 @@ class EncodeRolloutPipeline:
         # batches, 399.5 vs 398.2 at 40) at the price of a 38 MB device copy of the frames into the fixed input buffer per batch
         self.encode_graph = bool(int(os.environ.get('SF_PIPE_ENCODE_GRAPH', '1'))) if encode_graph is None else bool(encode_graph)
         self._enc_graphs = {}
-        self.encode_fork = bool(int(os.environ.get('SF_PIPE_ENCODE_FORK', '0'))) if encode_fork is None else bool(encode_fork)
+        ef = os.environ.get('SF_PIPE_ENCODE_FORK', '0')   # '1': every encode graph with two branches; 'fill': the whole-chip fill / hybrid graphs only
+        self.encode_fork = (ef == 'fill' or bool(int(ef))) if encode_fork is None else bool(encode_fork)
         # the last unit of a run rolls out alone on an unmasked stream: in the kernels' latency forms (head-pair attention, 64-row FFN
         # workgroups) while a unit is small -- C4, 64 videos: 172 vs 165 k frames/s -- but a large unit fills the chip with its row tiles and
         # four times the workgroups only queue: C5, 256 videos: 392 -> 435 k; C2, 128 videos: 436 / 440 k
@@ -654,7 +655,8 @@ class EncodeRolloutPipeline:
             side.wait_stream(cur)
             # encode_fork: the graph gets two parallel branches -- the image features of all time steps, and one step behind them the slot
             # branches (engine.savi_encode side_stream=; the seven-workgroup launches of the slot branch no longer hold up the convolutions)
-            side2 = torch.cuda.Stream(device=self.dev) if self.encode_fork else None
+            fork_here = self.encode_fork and (os.environ.get('SF_PIPE_ENCODE_FORK') != 'fill' or not isinstance(lane, int))
+            side2 = torch.cuda.Stream(device=self.dev) if fork_here else None
             with torch.cuda.stream(side):
                 engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws, side_stream=side2)   # workspace, plans
                 side.synchronize()
