@@ -583,6 +583,12 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
  * last slot update.  Captured into a hipGraph the two are parallel branches.  side_stream NULL = sf_savi_encode_pre_f32.  Same bits.
  * Workspace: sf_savi_encode_fork_workspace_bytes(m, B, T) (the Slot-Attention inputs of all T steps stay resident). */
 size_t sf_savi_encode_fork_workspace_bytes(const sf_savi_encoder* m, int B, int T);
+/* Order of a ONE-stream encode (process-wide; default 0, SF_ENC_INTERLEAVE=1: 1 -- measured +1.7 % on the encode lane only, csrc/engine.hip).  1: where the configuration allows it (folded Slot Attention at width 128,
+ * matrix-core slot update, at most 32 videos) the image features of time step t + 1 are computed inside the slot branch of step t, every fragment-weight
+ * convolution of them as ONE launch with a slot update of step t riding as its first workgroups (csrc/conv_rows4.hip: conv5x5_rows4_update_kernel).
+ * The same kernels' arithmetic in another launch order: bit-identical results. */
+int sf_set_encode_interleave(int on);
+int sf_get_encode_interleave(void);
 int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const float* feat_pre, int n_pre, const float* noise,
                             const float* prev_slots, float* lstm_h, float* lstm_c, int state_valid, float* post_slots,
                             float* kernel_dist, float* attn, int B, int T, void* ws, size_t ws_bytes, void* stream, void* side_stream);

@@ -233,6 +233,8 @@ SIGNATURES = {
     'sf_savi_encode_pre_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, I, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
                                    VP]),
     'sf_savi_encode_fork_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I, I]),
+    'sf_set_encode_interleave': (I, [I]),
+    'sf_get_encode_interleave': (I, []),
     'sf_savi_encode_fork_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, I, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
                                     VP, VP]),
     'sf_kv_producer_workspace_bytes': (SZ, [I, I]),

@@ -563,11 +563,28 @@ int sf_rollout_bf16(const sf_rollouter* m, float* slots, int B, int T_total, int
 // ---------------------------------------------------------------------------------------------
 static int enc_chunk(int B) { return B < 32 ? B : 32; }
 
+// interleaved order of the encode (sf_savi_encode_fork_f32 below): OPT-IN (SF_ENC_INTERLEAVE=1 / sf_set_encode_interleave(1)).  Measured: the encode lane
+// 3.326 -> 3.270 ms per C2 batch, the bench 503 -> 504 k frames/s (profiles/r04_probes.txt section 7): a convolution launch is 512 tiles = exactly four
+// rounds of the 128-CU partition, each CU filled by one tile (153 KB of LDS), so the seven slot-update workgroups that ride in front push seven tiles
+// into a fifth round -- the launch grows by about what the separate 22 us launch cost.  Bit-identical; kept as the measured answer to "hide the small launches".
+static int g_enc_interleave = -1;
+int sf_set_encode_interleave(int on) {
+  g_enc_interleave = on ? 1 : 0;
+  return 0;
+}
+int sf_get_encode_interleave(void) {
+  if (g_enc_interleave < 0) {
+    const char* e = getenv("SF_ENC_INTERLEAVE");
+    g_enc_interleave = (e && e[0] == '1') ? 1 : 0;
+  }
+  return g_enc_interleave;
+}
+
 static size_t enc_ws_bytes(const sf_savi_encoder* m, int B, int kv_steps);
-size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B) { return enc_ws_bytes(m, B, 1); }
+size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B) { return enc_ws_bytes(m, B, 2); }   // (two: the interleaved order below)
 // the forked form keeps the Slot-Attention inputs of up to ENC_FORK_AHEAD time steps (the feature branch runs that far ahead of the slot branch)
 static constexpr int ENC_FORK_AHEAD = 4;
-static int enc_fork_steps(int T) { return T < ENC_FORK_AHEAD ? T : ENC_FORK_AHEAD; }
+static int enc_fork_steps(int T) { return T < 2 ? 2 : (T < ENC_FORK_AHEAD ? T : ENC_FORK_AHEAD); }
 size_t sf_savi_encode_fork_workspace_bytes(const sf_savi_encoder* m, int B, int T) { return T >= 1 ? enc_ws_bytes(m, B, enc_fork_steps(T)) : 0; }
 
 static size_t enc_ws_bytes(const sf_savi_encoder* m, int B, int kv_steps) {
@@ -591,30 +608,39 @@ static size_t enc_ws_bytes(const sf_savi_encoder* m, int B, int kv_steps) {
 
 // CNN stack (savi.py:231-244: convs + soft position embedding) for `nb` frames: frame i at src + i*frame_stride;
 // the last conv writes into `dst` (NHWC [nb,64,64,C_last]); featA/featB are ping-pong scratch.
-static int run_cnn(const sf_savi_encoder* m, const float* src, long long frame_stride, int nb, float* dst, float* featA,
-                   float* featB, hipStream_t st) {
+// layers [i0, i1) of the stack; upd != NULL (i1 == i0 + 1, a fragment-weight layer): that layer's launch carries the slot update `upd` as its first
+// blocks (conv5x5_rows4_update_kernel); *upd_done says whether it did
+static int run_cnn_layers(const sf_savi_encoder* m, const float* src, long long frame_stride, int nb, float* dst, float* featA, float* featB,
+                          int i0, int i1, const SfSlotUpdateArgs* upd, bool* upd_done, hipStream_t st) {
   const int res = m->resolution;
-  const float* cur = nullptr;
-  for (int i = 0; i < m->enc_layers; ++i) {
+  for (int i = i0; i < i1; ++i) {
     const bool lastc = (i == m->enc_layers - 1);
     const int cin = m->enc_channels[i], cout = m->enc_channels[i + 1];
     const float* add = lastc ? m->pos_table : nullptr;
     float* out = lastc ? dst : ((i & 1) ? featB : featA);
+    const float* cur = i == 0 ? nullptr : (((i - 1) & 1) ? featB : featA);   // the previous layer's output
     if (i == 0) {
       SF_TRY(sf_conv2d_nchw_in_f32(src, frame_stride, m->conv_w[0], m->conv_b[0], add, out, nb, cin, res, res, cout,
                                    m->enc_ks, res == 128 ? 2 : 1, lastc ? 0 : 1, st));
     } else {
       // 64 -> 64 channels with a fragment-ordered weight copy: 4-row tiles, weights streamed as MFMA fragments (conv_rows4.hip)
       int rc = 1;
-      if (m->conv_w_frag[i])
+      if (m->conv_w_frag[i] && upd) {
+        rc = sf_conv5x5_rows4_update_ex(cur, m->conv_w_frag[i], m->conv_b[i], add, out, nb, 64, 64, cin, cout, m->enc_ks, lastc ? 0 : 1, *upd, st);
+        if (rc == 0 && upd_done) *upd_done = true;
+      }
+      if (rc == 1 && m->conv_w_frag[i])
         rc = sf_conv5x5_rows4_ex(cur, m->conv_w_frag[i], m->conv_b[i], add, out, nb, 64, 64, cin, cout, m->enc_ks, lastc ? 0 : 1, st);
       if (rc < 0 || rc > 1) return rc;
       if (rc == 1)
         SF_TRY(sf_conv2d_nhwc_f32(cur, m->conv_w[i], m->conv_b[i], add, out, nb, 64, 64, cin, cout, m->enc_ks, lastc ? 0 : 1, st));
     }
-    cur = out;
   }
   return 0;
+}
+static int run_cnn(const sf_savi_encoder* m, const float* src, long long frame_stride, int nb, float* dst, float* featA,
+                   float* featB, hipStream_t st) {
+  return run_cnn_layers(m, src, frame_stride, nb, dst, featA, featB, 0, m->enc_layers, nullptr, nullptr, st);
 }
 
 size_t sf_savi_cnn_workspace_bytes(const sf_savi_encoder* m, int B) {
@@ -715,7 +741,7 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
   if (m->pred_rnn)
     SF_REQUIRE(lstm_h && lstm_c && m->pred_hidden > 0 && m->lstm_w_ih && m->lstm_w_hh && m->lstm_b_ih &&
                    m->lstm_b_hh && m->proj_w && m->proj_b, "null LSTM state / weight");
-  const int KV = fork ? enc_fork_steps(T) : 1;   // resident Slot-Attention inputs: a ring of KV time steps
+  const int KV = fork ? enc_fork_steps(T) : 2;   // resident Slot-Attention inputs: a ring of KV time steps
   SF_REQUIRE(ws_bytes >= enc_ws_bytes(m, B, KV), "workspace too small");
   for (int i = 0; i < m->enc_layers; ++i) SF_REQUIRE(m->conv_w[i] != nullptr, "null conv weight");
 
@@ -734,7 +760,7 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
   float* h1 = bp.take((size_t)Bc * HW * Ce);
   float* h2 = bp.take((size_t)Bc * HW * Ce);
   float* kv_base = bp.take((size_t)KV * B * HW * 2 * D);
-  const size_t kv_step = fork ? (size_t)B * HW * 2 * D : 0;
+  const size_t kv_step = (size_t)B * HW * 2 * D;
   float* slotsA = bp.take((size_t)R * D);
   float* slotsB = bp.take((size_t)R * D);
   float* latents = bp.take((size_t)R * D);
@@ -772,6 +798,17 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
   const void* q_w_p = fold ? m->sa_fold_q_w_p : m->sa_q_w_p;
   const void* gru_ih_p = fold ? m->sa_fold_gru_ih_p : m->sa_gru_ih_p;
 
+  // slot update on the matrix cores (slot_update_mfma.hip) when the packed copies are there (slot size 128); otherwise the VALU kernel
+  const bool su_mfma = sf_get_precision() >= 1 && gru_ih_p && m->sa_gru_hh_p && m->sa_mlp_w1_p && m->sa_mlp_w2_p &&
+                       q_w_p && sf_slot_update_mfma_ok(D, Hm, P);
+  // INTERLEAVED order (round 4; one stream, the CLEVRER-shaped configuration: folded Slot Attention at width 128, matrix-core slot update, one
+  // chunk of frames): the image features of step t + 1 are computed INSIDE the slot branch of step t -- its first convolution behind the
+  // prologue, and every following fragment-weight convolution as ONE launch with a slot update (the update's seven workgroups ride as the first
+  // blocks of the convolution's 512 tiles, conv5x5_rows4_update_kernel) -- so the 22 us seven-workgroup launches no longer hold the partition.
+  // Same kernels' arithmetic, same bits.  Opt-in (see sf_get_encode_interleave above for what it measured).
+  const bool inter = sf_get_encode_interleave() && !fork && fold && !feat192 && su_mfma && B <= Bc && m->enc_layers >= 2 && T >= 2 && !t_plain_gemms;
+  const int Cl_feat = m->enc_channels[m->enc_layers];
+  float* const dst_feat = (m->enc_layers & 1) ? featA : featB;   // the buffer the last conv does not read
   // time-step order; forked: the features of step t are enqueued on `stream`, its slot branch on `side_stream` behind them (event),
   // and the features of step t + KV wait for the slot branch of step t to release its ring slot
   for (int t = 0; t < T; ++t) {
@@ -781,7 +818,7 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
     if (fork && t >= KV) {   // the ring slot is free once the slot branch of step t - KV has read it
       if (hipStreamWaitEvent(st_main, enc_fork_event(T + 1 + (t - KV)), 0) != hipSuccess) return sf_set_err((int)hipGetLastError(), "hipStreamWaitEvent", __FILE__, __LINE__);
     }
-    for (int b0 = 0; b0 < B; b0 += Bc) {
+    for (int b0 = 0; b0 < B && !(inter && t > 0); b0 += Bc) {   // (interleaved: the features of steps > 0 were computed inside the previous step)
       const int nb = (B - b0 < Bc) ? (B - b0) : Bc;
       const int Cl0 = m->enc_channels[m->enc_layers];
       const float* cur;
@@ -922,9 +959,15 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
     }
     // ---- Slot Attention iterations (savi.py:76-100) -------------------------------------------
     const float scale = 1.0f / sqrtf((float)D);
-    // slot update on the matrix cores (slot_update_mfma.hip) when the packed copies are there (slot size 128); otherwise the VALU kernel
-    const bool su_mfma = sf_get_precision() >= 1 && gru_ih_p && m->sa_gru_hh_p && m->sa_mlp_w1_p && m->sa_mlp_w2_p &&
-                         q_w_p && sf_slot_update_mfma_ok(D, Hm, P);
+    // interleaved: the next step's features start here (its first convolution), unless they were computed ahead of the call (feat_pre)
+    const bool next_feat = inter && t + 1 < T;
+    const bool next_cnn = next_feat && t + 1 >= n_pre;
+    const float* img_next = img + (long long)(t + 1) * frame_elems;
+    int next_layer = 0;   // the next convolution layer of step t + 1 still to run
+    if (next_cnn) {
+      SF_TRY(run_cnn_layers(m, img_next, (long long)T * frame_elems, B, dst_feat, featA, featB, 0, 1, nullptr, nullptr, st));
+      next_layer = 1;
+    }
     for (int it = 0; it < m->num_iterations; ++it) {
       const bool last_it = (it == m->num_iterations - 1);
       float* aout = (attn && last_it) ? attn + (long long)t * N * HW : nullptr;
@@ -935,10 +978,23 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
         SF_TRY(sf_slot_attn_iter_ex(kv, kv + D, 2 * D, (long long)HW * 2 * D, q, pnum, pden, aout,
                                     (long long)T * N * HW, B, HW, N, D, scale, m->sa_eps, st));
       if (su_mfma) {
-        SF_TRY(sf_slot_update_mfma_ex(pnum, pden, P, s_in, gru_ih_p, m->sa_gru_hh_p, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g,
-                                      m->mlp_ln_b, m->sa_mlp_w1_p, m->mlp_b1, m->sa_mlp_w2_p, m->mlp_b2, s_out,
-                                      last_it ? post_slots + (long long)t * N * D : nullptr, (long long)T * N * D, m->sa_q_ln_g,
-                                      m->sa_q_ln_b, q_w_p, last_it ? nullptr : q, B, N, ln_eps, st));
+        bool rode = false;
+        if (next_cnn && next_layer < m->enc_layers && m->conv_w_frag[next_layer]) {
+          // this slot update as the first blocks of the next step's convolution `next_layer`
+          SfSlotUpdateArgs u;
+          u.part_num = pnum; u.part_den = pden; u.P = P; u.slots_prev = s_in; u.gru_ih_p = gru_ih_p; u.gru_hh_p = m->sa_gru_hh_p;
+          u.gru_b_ih = m->gru_b_ih; u.gru_b_hh = m->gru_b_hh; u.ln_g = m->mlp_ln_g; u.ln_b = m->mlp_ln_b; u.w1_p = m->sa_mlp_w1_p; u.b1 = m->mlp_b1;
+          u.w2_p = m->sa_mlp_w2_p; u.b2 = m->mlp_b2; u.slots_out = s_out; u.out2 = last_it ? post_slots + (long long)t * N * D : nullptr;
+          u.out2_bs = (long long)T * N * D; u.q_ln_g = m->sa_q_ln_g; u.q_ln_b = m->sa_q_ln_b; u.q_w_p = q_w_p; u.q_out = last_it ? nullptr : q;
+          u.B = B; u.N = N; u.D = D; u.H = Hm; u.ln_eps = ln_eps;
+          SF_TRY(run_cnn_layers(m, img_next, (long long)T * frame_elems, B, dst_feat, featA, featB, next_layer, next_layer + 1, &u, &rode, st));
+          ++next_layer;
+        }
+        if (!rode)
+          SF_TRY(sf_slot_update_mfma_ex(pnum, pden, P, s_in, gru_ih_p, m->sa_gru_hh_p, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g,
+                                        m->mlp_ln_b, m->sa_mlp_w1_p, m->mlp_b1, m->sa_mlp_w2_p, m->mlp_b2, s_out,
+                                        last_it ? post_slots + (long long)t * N * D : nullptr, (long long)T * N * D, m->sa_q_ln_g,
+                                        m->sa_q_ln_b, q_w_p, last_it ? nullptr : q, B, N, ln_eps, st));
         float* tmp = s_in;
         s_in = s_out;
         s_out = tmp;
@@ -961,6 +1017,17 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
     // keep it in `lnbuf`-independent storage (q is rewritten first, so use latents' twin `px`?)
     // -> simplest: the next step reads `prev` only before it writes slotsA/slotsB.
     prev = s_in;
+    if (next_feat) {
+      // the rest of step t + 1's features: the convolutions no slot update rode on, then the per-pixel chain into the OTHER ring slot
+      const float* cur = feat_pre ? feat_pre + (long long)(t + 1) * B * HW * Cl_feat : nullptr;
+      if (next_cnn) {
+        if (next_layer < m->enc_layers)
+          SF_TRY(run_cnn_layers(m, img_next, (long long)T * frame_elems, B, dst_feat, featA, featB, next_layer, m->enc_layers, nullptr, nullptr, st));
+        cur = dst_feat;
+      }
+      SF_TRY(sf_pixel_mlp_feat_ex(cur, m->enc_ln_g, m->enc_ln_b, m->enc_fc1_w, m->enc_fc1_b, m->enc_fc2_w, m->enc_fc2_b, m->sa_norm_in_g,
+                                  m->sa_norm_in_b, kv_base + (size_t)((t + 1) % KV) * kv_step, B * HW, ln_eps, st));
+    }
     if (fork && t + KV < T) {   // the features of step t + KV may overwrite this step's ring slot now
       hipEvent_t e = enc_fork_event(T + 1 + t);
       SF_REQUIRE(e != nullptr, "hipEventCreate failed");

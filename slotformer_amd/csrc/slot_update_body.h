@@ -1,0 +1,335 @@
+// Body of the matrix-core slot update (slot_update_mfma.hip holds the description and the launch wrapper): shared between the stand-alone kernel and
+// the heterogeneous convolution + slot-update launch of conv_rows4.hip.
+#pragma once
+#include "sf_internal.h"
+
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int UM_D = 128, UM_H = 256, UM_ROWS = 32, UM_NT = 512;
+constexpr int UM_DP = UM_D + 8, UM_HP = UM_H + 8;   // bf16 plane strides (rows 272 / 528 B apart: 16-B aligned, bank-spread)
+constexpr int UM_FP = UM_D + 4;                     // f32 row stride
+// small parameter vectors, staged in LDS by the first requests of the kernel (a global load issued later would queue behind
+// the weight fragments: vmcnt retires in order)
+constexpr int UV_BIH = 0, UV_BHH = 3 * UM_D, UV_LNG = 6 * UM_D, UV_LNB = 7 * UM_D, UV_B1 = 8 * UM_D, UV_B2 = 8 * UM_D + UM_H,
+              UV_QG = 9 * UM_D + UM_H, UV_QB = 10 * UM_D + UM_H, UM_NV = 11 * UM_D + UM_H;
+
+__device__ __forceinline__ void um_split4(__bf16* hp, __bf16* lp, int off, f32x4 v) {
+  const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+  const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+  *(bf16x4*)(hp + off) = hi;
+  *(bf16x4*)(lp + off) = lo;
+}
+
+// sigmoid / tanh on the hardware exponential (v_exp_f32, ~1 ulp): the gate arithmetic of 32 x 128 elements runs on four waves, and
+// the libm forms took 5.6 us of a 20 us kernel; their error is far below the split-bf16 products feeding them
+__device__ __forceinline__ float um_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float um_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
+
+// fragment (ks, nb, plane) of a packed [N][K] matrix (pack_linear_kernel, layer_fused.hip): 64 lanes x 16 B
+__device__ __forceinline__ bf16x8 um_frag(const uint4* p, int nblocks, int nb, int ks, int pl, int lane) {
+  return __builtin_bit_cast(bf16x8, p[((long long)(ks * nblocks + nb) * 2 + pl) * 64 + lane]);
+}
+
+template <int NKS>
+struct UmFrags {
+  bf16x8 w[NKS][2];
+};
+
+template <int NKS>
+__device__ __forceinline__ void um_load(UmFrags<NKS>& f, const uint4* p, int nblocks, int nb, int ks0, int lane) {
+#pragma unroll
+  for (int k = 0; k < NKS; ++k) {
+    f.w[k][0] = um_frag(p, nblocks, nb, ks0 + k, 0, lane);
+    f.w[k][1] = um_frag(p, nblocks, nb, ks0 + k, 1, lane);
+  }
+}
+
+// acc[4 g + q] += out[token = lane & 31][column 32 nb + 8 g + 4 (lane >> 5) + q]; X planes [32][stride], k-steps ks0 .. ks0+NKS-1
+template <int NKS>
+__device__ __forceinline__ void um_gemm(f32x16& acc, const UmFrags<NKS>& f, const __bf16* Xh, const __bf16* Xl, int stride, int ks0,
+                                        int lane) {
+  const int ao = (lane & 31) * stride + 8 * (lane >> 5);
+#pragma unroll
+  for (int k = 0; k < NKS; ++k) {
+    const bf16x8 xh = *(const bf16x8*)(Xh + ao + (ks0 + k) * 16), xl = *(const bf16x8*)(Xl + ao + (ks0 + k) * 16);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[k][0], xl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[k][1], xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[k][0], xh, acc, 0, 0, 0);
+  }
+}
+
+struct UmArgs {
+  const float *part_num, *part_den;
+  int P;
+  const float* slots_prev;
+  const uint4 *w_ih_p, *w_hh_p;   // [3D][D] packed
+  const float *b_ih, *b_hh, *ln_g, *ln_b;
+  const uint4* w1_p;              // [H][D]
+  const float* b1;
+  const uint4* w2_p;              // [D][H]
+  const float* b2;
+  float* slots_out;
+  float* out2;                    // optional second destination: row (b, n) at out2 + b * out2_bs + n * D
+  long long out2_bs;
+  const float *q_ln_g, *q_ln_b;   // optional q projection (q_out NULL: off)
+  const uint4* q_w_p;             // [D][D]
+  float* q_out;
+  int R, N;
+  float ln_eps;
+};
+
+}  // namespace
+
+constexpr size_t UM_LDS = (size_t)(4 * UM_ROWS * UM_DP + 2 * UM_ROWS * UM_HP) * 2   // U, H/LN planes (hi, lo each) + hidden planes
+                          + (size_t)2 * UM_ROWS * UM_FP * 4                          // previous / new rows as f32
+                          + (size_t)4 * 2 * 16 * 64 * 4                              // wave-pair exchange: [4 blocks][2][16][64]
+                          + (size_t)UM_ROWS * 64 * 4                                 // denominators [32][64]
+                          + (size_t)UM_NV * 4;                                       // bias / LayerNorm vectors
+
+// The whole slot update of rows 32 * block .. + 31 by one 512-thread workgroup; um_lds: UM_LDS bytes of dynamic LDS.  A device function so that
+// the workgroups can also ride as extra blocks of another launch (conv_rows4.hip: conv5x5_rows4_update_kernel).
+__device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const int block) {
+  __bf16* Uh = (__bf16*)um_lds;                    // [32][DP]  updates
+  __bf16* Ul = Uh + UM_ROWS * UM_DP;
+  __bf16* Xh = Ul + UM_ROWS * UM_DP;               // [32][DP]  previous slots, later LN(h'), later LN_q(x)
+  __bf16* Xl = Xh + UM_ROWS * UM_DP;
+  __bf16* Hh = Xl + UM_ROWS * UM_DP;               // [32][HP]  relu hidden
+  __bf16* Hl = Hh + UM_ROWS * UM_HP;
+  float* Fp = (float*)(Hl + UM_ROWS * UM_HP);      // [32][FP]  previous slots (f32)
+  float* Fn = Fp + UM_ROWS * UM_FP;                // [32][FP]  h', later the finished rows
+  float* EX = Fn + UM_ROWS * UM_FP;                // [4][2][16][64] exchange between the two waves of a block
+  float* DN = EX + 4 * 2 * 16 * 64;                // [32][64] denominators of the partial records
+  float* PV = DN + UM_ROWS * 64;                   // parameter vectors (UV_* offsets)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int row0 = block * UM_ROWS;
+  const int cb = wave & 3, half = wave >> 2;
+  const int tok = lane & 31, kg = lane >> 5;
+
+  // ---- requests in the order they are needed: partial records, previous slots and the parameter vectors, THEN the weight
+  //      fragments (the loads retire in order) ----
+  float dnv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = t + UM_NT * i, r = idx >> 6, p = idx & 63, row = row0 + r;
+    dnv[i] = 0.f;
+    if (row < a.R && p < a.P) {
+      const int b = row / a.N, n = row - b * a.N;
+      dnv[i] = a.part_den[((long long)b * a.P + p) * a.N + n];
+    }
+  }
+  const int ur = t >> 4, uc = (t & 15) * 8;   // thread = (row, 8 features)
+  const bool rok = row0 + ur < a.R;
+  const int urow = min(row0 + ur, a.R - 1), ub = urow / a.N, un = urow - ub * a.N;
+  const float* pn = a.part_num + ((long long)ub * a.P * a.N + un) * UM_D + uc;
+  f32x4 pa[8][2];   // 8 partial records in flight at a time
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int pc = min(p, a.P - 1);
+    pa[p][0] = *(const f32x4*)(pn + (long long)pc * a.N * UM_D);
+    pa[p][1] = *(const f32x4*)(pn + (long long)pc * a.N * UM_D + 4);
+  }
+  const f32x4 h0 = *(const f32x4*)(a.slots_prev + (long long)urow * UM_D + uc), h1 = *(const f32x4*)(a.slots_prev + (long long)urow * UM_D + uc + 4);
+  float pvv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = t + UM_NT * i;   // UM_NV = 1664 <= 4 * 512
+    float v = 0.f;
+    if (j < UV_BHH) v = a.b_ih[j];
+    else if (j < UV_LNG) v = a.b_hh[j - UV_BHH];
+    else if (j < UV_LNB) v = a.ln_g[j - UV_LNG];
+    else if (j < UV_B1) v = a.ln_b[j - UV_LNB];
+    else if (j < UV_B2) v = a.b1[j - UV_B1];
+    else if (j < UV_QG) v = a.b2[j - UV_B2];
+    else if (j < UV_QB) v = a.q_out ? a.q_ln_g[j - UV_QG] : 0.f;
+    else if (j < UM_NV) v = a.q_out ? a.q_ln_b[j - UV_QB] : 0.f;
+    pvv[i] = v;
+  }
+  // the GRU fragments of this wave: half 0 = gate r (W_ir u + W_hr h) then W_in u; half 1 = gate z then W_hn h
+  UmFrags<8> fa, fb;
+  um_load(fa, a.w_ih_p, 12, half * 4 + cb, 0, lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    DN[t + UM_NT * i] = dnv[i];
+    if (t + UM_NT * i < UM_NV) PV[t + UM_NT * i] = pvv[i];
+  }
+  // ---- updates = sum_p num / sum_p den (records summed in order p = 0 .. P-1) ----
+  f32x4 n0 = {0.f, 0.f, 0.f, 0.f}, n1 = n0;
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+    if (p < a.P) {
+      n0 += pa[p][0];
+      n1 += pa[p][1];
+    }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int pc = min(8 + p, a.P - 1);
+    pa[p][0] = *(const f32x4*)(pn + (long long)pc * a.N * UM_D);
+    pa[p][1] = *(const f32x4*)(pn + (long long)pc * a.N * UM_D + 4);
+  }
+  um_load(fb, a.w_hh_p, 12, half * 4 + cb, 0, lane);
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+    if (8 + p < a.P) {
+      n0 += pa[p][0];
+      n1 += pa[p][1];
+    }
+  for (int p = 16; p < a.P; ++p) {
+    n0 += *(const f32x4*)(pn + (long long)p * a.N * UM_D);
+    n1 += *(const f32x4*)(pn + (long long)p * a.N * UM_D + 4);
+  }
+  __syncthreads();
+  {
+    float den = 0.f;
+    for (int p = 0; p < a.P; ++p) den += DN[ur * 64 + p];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    um_split4(Uh, Ul, ur * UM_DP + uc, rok ? n0 / den : zero4);
+    um_split4(Uh, Ul, ur * UM_DP + uc + 4, rok ? n1 / den : zero4);
+    um_split4(Xh, Xl, ur * UM_DP + uc, rok ? h0 : zero4);
+    um_split4(Xh, Xl, ur * UM_DP + uc + 4, rok ? h1 : zero4);
+    *(f32x4*)(Fp + ur * UM_FP + uc) = rok ? h0 : zero4;
+    *(f32x4*)(Fp + ur * UM_FP + uc + 4) = rok ? h1 : zero4;
+  }
+  __syncthreads();
+
+  // ---- GRU: gate accumulator of this half (r or z), then its share of the n gate ----
+  f32x16 g1, g2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) g1[r] = g2[r] = 0.f;
+  um_gemm(g1, fa, Uh, Ul, UM_DP, 0, lane);
+  um_load(fa, half == 0 ? a.w_ih_p : a.w_hh_p, 12, 8 + cb, 0, lane);   // n gate: W_in (half 0) / W_hn (half 1)
+  um_gemm(g1, fb, Xh, Xl, UM_DP, 0, lane);
+  UmFrags<8> fm;
+  um_load(fm, a.w1_p, 8, wave, 0, lane);                                 // MLP layer 1 of this wave (lands under the gate math)
+  um_gemm(g2, fa, half == 0 ? Uh : Xh, half == 0 ? Ul : Xl, UM_DP, 0, lane);
+  // biases: column c = 32 cb + 8 g + 4 kg + q
+  if (half == 1) {
+    // z = sigmoid(W_iz u + W_hz h + b_iz + b_hz), ghn = W_hn h + b_hn  -> exchange
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 32 * cb + 8 * g + 4 * kg;
+      const f32x4 bz = *(const f32x4*)(PV + UV_BIH + UM_D + c) + *(const f32x4*)(PV + UV_BHH + UM_D + c), bn = *(const f32x4*)(PV + UV_BHH + 2 * UM_D + c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        EX[((cb * 2 + 0) * 16 + 4 * g + q) * 64 + lane] = um_sigmoid(g1[4 * g + q] + bz[q]);
+        EX[((cb * 2 + 1) * 16 + 4 * g + q) * 64 + lane] = g2[4 * g + q] + bn[q];
+      }
+    }
+  }
+  __syncthreads();
+  if (half == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 32 * cb + 8 * g + 4 * kg;
+      const f32x4 br = *(const f32x4*)(PV + UV_BIH + c) + *(const f32x4*)(PV + UV_BHH + c), bn = *(const f32x4*)(PV + UV_BIH + 2 * UM_D + c);
+      const f32x4 hp = *(const f32x4*)(Fp + tok * UM_FP + c);
+      f32x4 hn;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float rr = um_sigmoid(g1[4 * g + q] + br[q]);
+        const float z = EX[((cb * 2 + 0) * 16 + 4 * g + q) * 64 + lane], ghn = EX[((cb * 2 + 1) * 16 + 4 * g + q) * 64 + lane];
+        const float nn = um_tanh(g2[4 * g + q] + bn[q] + rr * ghn);
+        hn[q] = (1.f - z) * nn + z * hp[q];
+      }
+      *(f32x4*)(Fn + tok * UM_FP + c) = hn;
+    }
+  }
+  __syncthreads();
+
+  // ---- LN(h') -> X planes (thread = (row, 8 features); a row is 16 consecutive lanes) ----
+  UmFrags<8> f2;
+  um_load(f2, a.w2_p, 4, cb, half * 8, lane);   // MLP layer 2: K half of this wave
+  {
+    const f32x4 v0 = *(const f32x4*)(Fn + ur * UM_FP + uc), v1 = *(const f32x4*)(Fn + ur * UM_FP + uc + 4);
+    const float mu = sf_sum16(((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]))) / (float)UM_D;
+    const f32x4 d0 = v0 - mu, d1 = v1 - mu;
+    const float var = sf_sum16(((d0[0] * d0[0] + d0[1] * d0[1]) + (d0[2] * d0[2] + d0[3] * d0[3])) +
+                               ((d1[0] * d1[0] + d1[1] * d1[1]) + (d1[2] * d1[2] + d1[3] * d1[3]))) / (float)UM_D;
+    const float rs = 1.0f / sqrtf(var + a.ln_eps);
+    um_split4(Xh, Xl, ur * UM_DP + uc, d0 * rs * *(const f32x4*)(PV + UV_LNG + uc) + *(const f32x4*)(PV + UV_LNB + uc));
+    um_split4(Xh, Xl, ur * UM_DP + uc + 4, d1 * rs * *(const f32x4*)(PV + UV_LNG + uc + 4) + *(const f32x4*)(PV + UV_LNB + uc + 4));
+  }
+  __syncthreads();
+
+  // ---- hidden = relu(W1 LN + b1): wave = hidden block ----
+#pragma unroll
+  for (int r = 0; r < 16; ++r) g1[r] = 0.f;
+  um_gemm(g1, fm, Xh, Xl, UM_DP, 0, lane);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c = 32 * wave + 8 * g + 4 * kg;
+    const f32x4 bb = *(const f32x4*)(PV + UV_B1 + c);
+    const f32x4 hv = {fmaxf(g1[4 * g] + bb[0], 0.f), fmaxf(g1[4 * g + 1] + bb[1], 0.f), fmaxf(g1[4 * g + 2] + bb[2], 0.f),
+                      fmaxf(g1[4 * g + 3] + bb[3], 0.f)};
+    um_split4(Hh, Hl, tok * UM_HP + c, hv);
+  }
+  __syncthreads();
+
+  // ---- x = h' + W2 hidden + b2: wave = (block, K half), halves meet in LDS ----
+  UmFrags<4> fq;
+  if (a.q_out) um_load(fq, a.q_w_p, 4, cb, half * 4, lane);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) g2[r] = 0.f;
+  um_gemm(g2, f2, Hh, Hl, UM_HP, half * 8, lane);
+  if (half == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) EX[(cb * 2 * 16 + r) * 64 + lane] = g2[r];
+  }
+  __syncthreads();
+  if (half == 0) {
+    const int row = row0 + tok;
+    const int b = min(row, a.R - 1) / a.N, n = min(row, a.R - 1) - b * a.N;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 32 * cb + 8 * g + 4 * kg;
+      const f32x4 bb = *(const f32x4*)(PV + UV_B2 + c), hn = *(const f32x4*)(Fn + tok * UM_FP + c);
+      f32x4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = hn[q] + (g2[4 * g + q] + EX[(cb * 2 * 16 + 4 * g + q) * 64 + lane]) + bb[q];
+      if (row < a.R) {
+        *(f32x4*)(a.slots_out + (long long)row * UM_D + c) = v;
+        if (a.out2) *(f32x4*)(a.out2 + (long long)b * a.out2_bs + (long long)n * UM_D + c) = v;
+      }
+      *(f32x4*)(Fp + tok * UM_FP + c) = v;   // (Fp is dead: the finished rows for the q projection)
+    }
+  }
+  if (a.q_out == nullptr) return;
+  __syncthreads();
+
+  // ---- q = LN_q(x) Wq^T ----
+  {
+    const f32x4 v0 = *(const f32x4*)(Fp + ur * UM_FP + uc), v1 = *(const f32x4*)(Fp + ur * UM_FP + uc + 4);
+    const float mu = sf_sum16(((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]))) / (float)UM_D;
+    const f32x4 d0 = v0 - mu, d1 = v1 - mu;
+    const float var = sf_sum16(((d0[0] * d0[0] + d0[1] * d0[1]) + (d0[2] * d0[2] + d0[3] * d0[3])) +
+                               ((d1[0] * d1[0] + d1[1] * d1[1]) + (d1[2] * d1[2] + d1[3] * d1[3]))) / (float)UM_D;
+    const float rs = 1.0f / sqrtf(var + a.ln_eps);
+    um_split4(Xh, Xl, ur * UM_DP + uc, d0 * rs * *(const f32x4*)(PV + UV_QG + uc) + *(const f32x4*)(PV + UV_QB + uc));
+    um_split4(Xh, Xl, ur * UM_DP + uc + 4, d1 * rs * *(const f32x4*)(PV + UV_QG + uc + 4) + *(const f32x4*)(PV + UV_QB + uc + 4));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) g1[r] = 0.f;
+  um_gemm(g1, fq, Xh, Xl, UM_DP, half * 4, lane);
+  if (half == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) EX[((cb * 2 + 1) * 16 + r) * 64 + lane] = g1[r];
+  }
+  __syncthreads();
+  if (half == 0 && row0 + tok < a.R) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 32 * cb + 8 * g + 4 * kg;
+      f32x4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = g1[4 * g + q] + EX[((cb * 2 + 1) * 16 + 4 * g + q) * 64 + lane];
+      *(f32x4*)(a.q_out + (long long)(row0 + tok) * UM_D + c) = v;
+    }
+  }
+}
+

@@ -645,3 +645,43 @@ def test_forked_encode_is_bit_identical(dev, name):
             g.replay()
             torch.cuda.synchronize()
             assert torch.equal(post, ref[0])
+
+
+@pytest.mark.parametrize('name', ['C2', 'C5'])
+@torch.no_grad()
+def test_interleaved_encode_is_bit_identical(dev, name):
+    """sf_set_encode_interleave(1) (opt-in): the features of time step t + 1 computed inside the slot branch of step t, its fragment-weight
+    convolutions launched together with the slot updates (the update's workgroups as the first blocks of the convolution launch,
+    conv5x5_rows4_update_kernel) -- against the plain order (0): the same bits, with injected kernel noise (C2), the Transformer + LSTM predictor
+    (C5 shapes at T = 4), precomputed features of the first steps, STEVE-style attention maps, and B = 1 / 32."""
+    from slotformer_amd import engine, _lib
+    from slotformer_amd.base_slots import build_model
+    lib = _lib.lib()
+    cfg = {'C2': gu.C2_SAVI, 'C5': gu.C5_SAVI}[name]
+    torch.manual_seed(41)
+    m = build_model(gu.ParamsView(cfg)).eval().to(dev)
+    m.testing = True
+    N, D = cfg['slot_dict']['num_slots'], cfg['slot_dict']['slot_size']
+    old = lib.sf_get_encode_interleave()
+    try:
+        for B, T in ((5, 4), (1, 3), (32, 2)):
+            img = gu.seeded_img(B, T, 128, seed=71 + B).to(dev)
+            noise = engine.kernel_noise(m, gu.seeded_normal((B, T, N, D), 72).to(dev), B, T, dev)
+            outs = {}
+            for mode in (0, 1):
+                lib.sf_set_encode_interleave(mode)
+                if hasattr(m.predictor, 'reset'):
+                    m.predictor.reset()
+                outs[mode] = engine.savi_encode(m, img, noise=noise, want_attn=True, ws_slot=('il', mode), side_stream=None)
+                torch.cuda.synchronize()
+            for a, b in zip(outs[0], outs[1]):
+                assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), (name, B, T)
+            feat = engine.savi_cnn(m, img, 0, 2)
+            lib.sf_set_encode_interleave(1)
+            if hasattr(m.predictor, 'reset'):
+                m.predictor.reset()
+            o2 = engine.savi_encode(m, img, noise=noise, ws_slot=('il', 1), side_stream=None, feat_pre=feat)
+            torch.cuda.synchronize()
+            assert torch.equal(o2[0], outs[0][0]), (name, B, T, 'feat_pre')
+    finally:
+        lib.sf_set_encode_interleave(old)
