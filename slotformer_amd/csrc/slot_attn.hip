@@ -909,39 +909,37 @@ extern "C" int sf_slot_attn_iter_bf16(const void* k, const void* v, int ld, long
 // Arithmetic: exact f32 products, f32 accumulation; the summation order differs from the VALU logits of sa_attn_mfma_kernel (rounding-level
 // differences, every fixture keeps its tolerance).
 template <int D>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void sa_attn_tile_kernel(const float* __restrict__ x, int ld, long long batch_stride,
-                                                           const float* __restrict__ q, float scale, float eps,
-                                                           float* __restrict__ part_num, float* __restrict__ part_den,
-                                                           float* __restrict__ attn_out, long long attn_bs, int HW, int N, int P) {
-  // a wave owns 32 pixels, processed as two halves of 16 through ONE 16-row LDS tile (8.4 KB per wave, 76 KB per workgroup: TWO
-  // workgroups per CU -- while one multiplies, the other's rows are in flight; with one workgroup per CU the chip alternated between a
-  // load phase and a compute phase in lockstep: 25.9 us per 32 frames, no better than the two-pass kernel)
-  constexpr int NS = SA_NMAX, XP = D + 4, NW = 8, TP = 16;   // tile pitch, waves, pixels per half
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void sa_attn_tile_kernel(
+    const float* __restrict__ x, int ld, long long batch_stride, const float* __restrict__ q, float scale, float eps,
+    float* __restrict__ part_num, float* __restrict__ part_den, float* __restrict__ attn_out, long long attn_bs, int HW, int N, int P) {
+  // A workgroup owns 512 pixels of one frame (TWO partial records: it writes its sums into the first and zeros into the second -- the slot
+  // update adds the records), a wave 64 of them as FOUR tiles of 16 rows through one 8.4 KB LDS tile, with the rows of the next two tiles
+  // in flight while a tile is multiplied (a register stage): the loads never stop while the matrix cores work.  80 KB of LDS: two workgroups per CU.
+  // (single-shot tiles -- every workgroup loads, then computes -- ran the chip in lockstep phases at 2.5 TB/s, profiles/r04_probes.txt section 3)
+  constexpr int NS = SA_NMAX, XP = D + 4, NW = 8, TP = 16, NT4 = 4;   // tile pitch, waves, pixels per tile, tiles per wave
   constexpr int NSLAB = D / 16, NH = D / 64;
   extern __shared__ __attribute__((aligned(16))) float sa_lds[];
   float* s_x = sa_lds;                          // [NW][TP][XP]
   float* s_a = s_x + NW * TP * XP;              // [NW][TP][17]: attention tile, pixel-major (pitch 17: conflict-free column reads)
+  float* s_q = s_a + NW * TP * 17;              // [NS][D]: the scaled queries
   float* s_red = sa_lds;                        // [NW][NS][XP] over the dead tiles
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pix0 = chunk * (NW * 2 * TP) + wave * 2 * TP;
+  const int pix0 = chunk * (NW * NT4 * TP) + wave * NT4 * TP;
   const int li = lane & 15, lg = lane >> 4;
   typedef float f32x4a __attribute__((ext_vector_type(4)));
   static_assert(D == 128, "sa_attn_tile_kernel: D = 128 (two whole rows per load instruction)");
-  // ---- the wave's 32 rows: instruction u brings rows 2 u and 2 u + 1 whole (lane & 31 = the 16-byte column); all 16 requested at once ----
+  // ---- rows: instruction u of a tile brings rows 2 u and 2 u + 1 whole (lane & 31 = the 16-byte column); two tiles requested at once ----
   const float* xs = x + (long long)b * batch_stride + (long long)(pix0 + (lane >> 5)) * ld + 4 * (lane & 31);
   float* tile = s_x + wave * TP * XP;
-  f32x4v stage[16];
+  f32x4v stage[8];   // (one tile ahead: with two stages in flight the kernel spilled at 128 registers -- four waves per SIMD are what two workgroups per CU need)
 #pragma unroll
-  for (int u = 0; u < 16; ++u) stage[u] = *(const f32x4v*)(xs + (long long)(2 * u) * ld);
-  // the scaled queries as B operand: lane (k = lg, j = li) holds q[slot li][16 s + 4 lg + e] for every slab s
-  f32x4v qr[NSLAB];
-#pragma unroll
-  for (int sl = 0; sl < NSLAB; ++sl) {
-    f32x4v t = {0.f, 0.f, 0.f, 0.f};
-    if (li < N) t = *(const f32x4v*)(q + ((long long)b * N + li) * D + 16 * sl + 4 * lg);
-    qr[sl] = t * scale;
+  for (int u = 0; u < 8; ++u) stage[u] = *(const f32x4v*)(xs + (long long)(2 * u) * ld);
+  for (int idx = threadIdx.x; idx < NS * D; idx += 512) {
+    const int n = idx / D, d = idx - n * D;
+    s_q[idx] = n < N ? q[((long long)b * N + n) * D + d] * scale : 0.f;
   }
+  __syncthreads();
   f32x4a nacc[NH][4];
 #pragma unroll
   for (int h = 0; h < NH; ++h)
@@ -949,21 +947,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int e = 0; e < 4; ++e) nacc[h][e] = f32x4a{0.f, 0.f, 0.f, 0.f};
   float den = 0.f;
   float* at = s_a + wave * TP * 17;
+#pragma unroll 1
+  for (int ti = 0; ti < NT4; ++ti) {
 #pragma unroll
-  for (int hf = 0; hf < 2; ++hf) {
-    // (the loads retire in order: the first eight cover half 0; half 1 is still in flight while half 0 is multiplied)
+    for (int u = 0; u < 8; ++u) *(f32x4v*)(tile + (2 * u + (lane >> 5)) * XP + 4 * (lane & 31)) = stage[u];
+    if (ti + 1 < NT4) {   // the stage is free: the rows of the next tile, in flight while this one is multiplied
 #pragma unroll
-    for (int u = 0; u < 8; ++u) *(f32x4v*)(tile + (2 * u + (lane >> 5)) * XP + 4 * (lane & 31)) = stage[8 * hf + u];
+      for (int u = 0; u < 8; ++u) stage[u] = *(const f32x4v*)(xs + (long long)(TP * (ti + 1) + 2 * u) * ld);
+    }
     __builtin_amdgcn_wave_barrier();
-    // ---- logits[pixel][slot]: A = tile rows (i = li: pixel, k = lg), B = qr ----
+    // ---- logits[pixel][slot]: A = tile rows (i = li: pixel, k = lg), B (k = lg, j = li: slot) = the scaled queries from LDS (zero beyond 8) ----
     f32x4a acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int sl = 0; sl < NSLAB; ++sl) {
       const f32x4v xa = *(const f32x4v*)(tile + li * XP + 16 * sl + 4 * lg);
+      f32x4v qb = *(const f32x4v*)(s_q + (li & 7) * D + 16 * sl + 4 * lg);
+      if (li >= NS) qb = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[e], qr[sl][e], acc, 0, 0, 0);
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[e], qb[e], acc, 0, 0, 0);
     }
-    // acc[r]: pixel 4 lg + r of the half, slot li.  Softmax over the slots (lanes li = 0..7 of every 16-lane row), + eps
+    // acc[r]: pixel 4 lg + r of the tile, slot li.  Softmax over the slots (lanes li = 0..7 of every 16-lane row), + eps
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool live = li < N;
@@ -973,7 +976,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const float sum = sf_sum8(li < 8 ? ex : 0.f);
       const float a0 = ex / sum;
       const int pix = 4 * lg + r;
-      if (attn_out && live) attn_out[(long long)b * attn_bs + (long long)li * HW + pix0 + TP * hf + pix] = a0;
+      if (attn_out && live) attn_out[(long long)b * attn_bs + (long long)li * HW + pix0 + TP * ti + pix] = a0;
       const float a = live ? a0 + eps : 0.f;
       den += a;
       at[pix * 17 + li] = a;   // (lanes li >= N: zero columns -- the padded slot rows of the A operand below)
@@ -991,7 +994,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int e = 0; e < 4; ++e) nacc[h][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, xb[e], nacc[h][e], 0, 0, 0);
       }
     }
-    __builtin_amdgcn_wave_barrier();   // the tile and the attention tile are rewritten by the next half
+    __builtin_amdgcn_wave_barrier();   // the tile and the attention tile are rewritten by the next tile
   }
   // den: the slot's sum over this wave's pixels = over the lanes with the same li
   den += __shfl_xor(den, 16, 64);
@@ -1011,15 +1014,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
   if (lg == 0 && li < NS) s_red[(wave * NS + li) * XP + D] = den;
   __syncthreads();
+  // the workgroup's sums go to record 2 chunk, zeros to record 2 chunk + 1 (P = HW / 256 records per frame, summed by the slot update)
   for (int idx = threadIdx.x; idx < N * (D + 1); idx += 512) {
     const int n = idx / (D + 1), d = idx - n * (D + 1);
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) t += s_red[(w * NS + n) * XP + d];
-    if (d < D)
-      part_num[(((long long)b * P + chunk) * N + n) * D + d] = t;
-    else
-      part_den[((long long)b * P + chunk) * N + n] = t;
+    if (d < D) {
+      part_num[(((long long)b * P + 2 * chunk) * N + n) * D + d] = t;
+      part_num[(((long long)b * P + 2 * chunk + 1) * N + n) * D + d] = 0.f;
+    } else {
+      part_den[((long long)b * P + 2 * chunk) * N + n] = t;
+      part_den[((long long)b * P + 2 * chunk + 1) * N + n] = 0.f;
+    }
   }
 }
 
@@ -1048,18 +1055,18 @@ int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch
     const char* e = getenv("SF_SA_ONEPASS");
     return e && e[0] == '1';
   }();
-  // (opt-in, SF_SA_TILE=1: measured no faster than the two-pass kernel -- 25.9 vs 24.2 us per 32 frames on the whole chip, 39.5 vs 38.5 on a
-  //  128-CU mask, profiles/r04_probes.txt: one workgroup per CU and a single tile per wave expose the whole load latency)
+  // (round 4, default for keys == values at width 128; SF_SA_TILE=0: the two-pass kernel.  32 frames: 21.3 vs 26.4 us on the whole chip, 31.2 vs 35.5
+  //  on a 128-CU mask, 67 instead of 120-132 MB fetched; its single-shot forms -- one tile per wave -- were no faster: profiles/r04_probes.txt section 3)
   static const bool tile_off = [] {
     const char* e = getenv("SF_SA_TILE");
-    return !(e && e[0] == '1');
+    return e && e[0] == '0';
   }();
-  if (HW % 256 == 0 && k == v && D == 128 && P == HW / 256 && !tile_off && !fold_env) {
-    // keys == values: every row read once, both products on the matrix cores (sa_attn_tile_kernel)
-    constexpr size_t LDS = (size_t)(8 * 16 * (128 + 4) + 8 * 16 * 17) * sizeof(float);   // 76 KB: two workgroups per CU
-    static_assert(LDS <= 160 * 1024, "one-pass Slot Attention: LDS budget");
+  if (HW % 512 == 0 && k == v && D == 128 && P == HW / 256 && !tile_off && !fold_env) {
+    // keys == values: every row read once, both products on the matrix cores (sa_attn_tile_kernel: 512 pixels per workgroup)
+    constexpr size_t LDS = (size_t)(8 * 16 * (128 + 4) + 8 * 16 * 17 + SA_NMAX * 128) * sizeof(float);   // 80,384 B: two workgroups per CU
+    static_assert(2 * LDS <= 160 * 1024, "one-pass Slot Attention: two workgroups per CU");
     SF_TRY(sf_ensure_dyn_lds((const void*)sa_attn_tile_kernel<128>, LDS));
-    hipLaunchKernelGGL(sa_attn_tile_kernel<128>, grid, dim3(512), LDS, st, k, ld, batch_stride, q, scale, eps, part_num, part_den, attn_out,
+    hipLaunchKernelGGL(sa_attn_tile_kernel<128>, dim3(HW / 512, B), dim3(512), LDS, st, k, ld, batch_stride, q, scale, eps, part_num, part_den, attn_out,
                        attn_batch_stride, HW, N, P);
   } else if (HW % 256 == 0 && k == v && D == 128 && fold_env) {
     // keys == values: every row is read once (sa_attn_fold_kernel)
