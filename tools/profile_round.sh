@@ -20,3 +20,6 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCL
 cd $R
 find $OUT -name "*.csv" | head -20
 python tools/summarize_profile.py $TAG
+# keep what is committed (stats csv, summaries), drop the raw traces: gpurun merges at most 64 MiB back
+cp $(find $OUT/${TAG}_trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv 2>/dev/null
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma

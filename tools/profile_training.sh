@@ -20,4 +20,5 @@ for name in "" "_savi" "_steve"; do
   PYTHONPATH=$R timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_train$name -o trace -- python $R/tools/bench_train$name.py --steps 5 --warmup 2 > $OUT/${TAG}_trace_train$name.log 2>&1
   f=$(find $OUT/${TAG}_trace_train$name -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${TAG}_training${name}_kernel_stats.csv && head -12 $f | cut -c1-150
+  rm -rf $OUT/${TAG}_trace_train$name
 done
