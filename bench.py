@@ -141,7 +141,7 @@ def committed_profile(key):
 
 
 KERNEL_CLASS = {'conv5x5_halo': 'conv', 'ffn_qkv_tile_kernel': 'ffn_fused', 'ffn_tile_kernel': 'ffn_fused', 'ffn_partial_kernel': 'ffn_fused', 'ffn64_parts_kernel': 'ffn_fused', 'ffn_wide_parts_kernel': 'ffn_fused',
-                'conv5x5_rows4_kernel': 'conv', 'qkv_rows_kernel': 'attention', 'attn_core_kernel': 'attention', 'attn_oproj_kernel': 'attention', 'attn_all_kernel': 'attention', 'seam_kernel': 'seam', 'sa_attn_mfma_kernel': 'slot_attn', 'sa_attn_fold_kernel': 'slot_attn'}
+                'conv5x5_rows4_kernel': 'conv', 'qkv_rows_kernel': 'attention', 'attn_core_kernel': 'attention', 'attn_oproj_kernel': 'attention', 'attn_all_kernel': 'attention', 'seam_kernel': 'seam', 'sa_attn_mfma_kernel': 'slot_attn', 'sa_attn_fold_kernel': 'slot_attn', 'sa_attn_tile_kernel': 'slot_attn'}
 
 
 def dominant_kernel():
@@ -156,6 +156,8 @@ def dominant_kernel():
     tot = {}
     try:
         for r in csv.DictReader(open(files[-1])):
+            if 'deconv5x5s2' in r['Name'] or 'rows4_kernel<false, true>' in r['Name'] or 'decode_' in r['Name']:
+                continue   # (the decode leg of the traced command: a secondary line, never the headline's dominant kernel)
             for pat, key in KERNEL_CLASS.items():
                 if pat in r['Name']:
                     tot[key] = tot.get(key, 0.0) + float(r['Percentage'])
@@ -277,7 +279,7 @@ def self_launch(n):
     sock.bind(('127.0.0.1', 0))
     port = sock.getsockname()[1]
     sock.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), SF_BENCH_FORCE_DIST='1')   # (a launched job always forms its RCCL group, also with one rank)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print(f'[bench] launching {n} ranks: {" ".join(cmd)}', file=sys.stderr, flush=True)
@@ -453,7 +455,8 @@ def main():
     ap.add_argument('--windows', type=int, default=5, help='timed windows of --steps steps each on the warm pipeline; value = the median window')
     args = ap.parse_args()
 
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    if (args.gpus > 1 or os.environ.get('SF_BENCH_SELF_LAUNCH') == '1') and 'WORLD_SIZE' not in os.environ:
+        # (SF_BENCH_SELF_LAUNCH=1: take the launcher path with --gpus 1 too -- how tests/test_dist_gpu.py runs it on the one GPU of the box)
         # plain `python bench.py --gpus N`: this process becomes the launcher of its own N ranks (one process per GPU, the
         # reference's launch shape: scripts/sbatch_run.sh:36-42) and passes rank 0's JSON line through
         sys.exit(self_launch(args.gpus))

@@ -37,6 +37,26 @@ def test_bench_under_rccl_process_group(dev):
     assert 'roofline' in d and d['roofline']['frac'] <= 1.0
 
 
+def test_bench_launches_its_own_ranks(dev):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (one rank per GPU, RCCL): the same code path
+    with N = 1 (SF_BENCH_SELF_LAUNCH=1) on the one GPU of the box -- the JSON line comes from rank 0 of the launched job with the process-group keys;
+    and `--gpus 2` on this box fails cleanly with a JSON line that says what is missing (exit code 0, no value)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(SF_BENCH_SELF_LAUNCH='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--windows', '2',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['value'] > 0 and d['rccl_ranks'] == 1 and 'nccl' in d['process_group_backend']
+    assert len(d['per_rank_frames_per_s']) == 1 and d['ms_per_step_windows']['n'] == 2 and d['config']['stream_placement']['rccl_initialised']
+    if torch.cuda.device_count() < 2:
+        env.pop('SF_BENCH_SELF_LAUNCH')
+        r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
+        assert r2.returncode == 0
+        d2 = json.loads([ln for ln in r2.stdout.strip().splitlines() if ln.startswith('{')][-1])
+        assert d2['value'] is None and 'needs 2 devices' in d2['error']
+
+
 def test_ddp_flat_bucket_under_one_rank_nccl(dev):
     """SlotFormer training with ddp_flat_bucket=True inside a 1-rank RCCL group: the in-backward all-reduce runs on the real
     backend and leaves the gradients unchanged (mean over one rank)."""
