@@ -492,6 +492,15 @@ def main():
     N_SLOTS, SLOT_D = roll.num_slots, roll.in_proj.in_features
     # a ring of three DIFFERENT resident inputs: consecutive batches never see the same frames
     ring = [synthetic_img(B, T_BURN, RES, seed=1234 + 1000 * k + rank).to(dev) for k in range(3)]
+    # small batches are ENCODED several at a time (E consecutive batches concatenated into one encode launch set of ~32 videos): the slot branch of an
+    # encode (predictor, Slot-Attention iterations, slot updates) is latency-bound and costs the same for 16 videos as for 32 (C4: 3.3 vs 2.5 ms per 16
+    # videos on the encode lane).  Every batch still runs its full encode + rollout inside the timed region; the concatenation is part of it.
+    from slotformer_amd.pipeline import encode_group_for
+    E = int(os.environ.get('SF_BENCH_ENC_GROUP', '0')) or encode_group_for(B, args.steps)
+    if args.steps % E or args.no_overlap:
+        E = 1
+    Bp = B * E                                                   # videos per pipeline batch
+    ringp = ring if E == 1 else [torch.cat([ring[(k + i) % 3] for i in range(E)], 0) for k in range(3)]   # (for the untimed extras)
     cu_word = os.environ.get('SF_BENCH_CU_SPLIT', 'ff')          # hex mask word, or rows<R> (pipeline.encode_mask_words)
     cu_word = cu_word if cu_word.startswith('rows') else int(cu_word, 16)
     steal = os.environ.get('SF_BENCH_STEAL')                   # None: the partition's default
@@ -501,19 +510,23 @@ def main():
     group = None if group is None else int(group)
     if group is None:
         from slotformer_amd.pipeline import unit_batches_for
-        group = unit_batches_for(roll, B, args.steps, T_BURN)   # (as harness.extract_and_rollout: larger units for long runs of small batches; None for C2 / C5)
+        group = unit_batches_for(roll, Bp, args.steps // E, T_BURN)   # (as harness.extract_and_rollout: larger units for long runs of small batches; None for C2 / C5)
 
     with torch.no_grad():
         log('building the pipeline (first eager rollouts + graph capture)')
-        pipe = EncodeRolloutPipeline(savi, roll, B, T_BURN, T_ROLL, encode_cu_word=cu_word, steal_steps=steal,
+        pipe = EncodeRolloutPipeline(savi, roll, Bp, T_BURN, T_ROLL, encode_cu_word=cu_word, steal_steps=steal,
                                      use_graph=not args.no_graph, partition=partition, group=group)
         overlap = not args.no_overlap
         G = pipe.G                      # batches per rollout graph
         unit0 = pipe.units[0]
         graph = unit0.graph
 
-        def run(n, out):
-            return pipe.run([ring[j % 3] for j in range(n)], None, out=out, serial=not overlap)
+        def run(n, out):   # n batches of B videos, E at a time
+            if E == 1:
+                return pipe.run([ring[j % 3] for j in range(n)], None, out=out, serial=not overlap)
+            ns = max(1, n // E)
+            return pipe.run([torch.cat([ring[(s * E + i) % 3] for i in range(E)], 0) for s in range(ns)], None,
+                            out=out.view(-1, Bp, *out.shape[2:])[:ns], serial=not overlap)
 
         def barrier():
             if use_dist:
@@ -521,7 +534,7 @@ def main():
             torch.cuda.synchronize()
 
         shape = (B, T_BURN + T_ROLL, N_SLOTS, SLOT_D)
-        out_w = torch.empty((max(args.warmup, 6), ) + shape, device=dev)
+        out_w = torch.empty((max(args.warmup, 6) + E, ) + shape, device=dev)
         out_t = torch.empty((args.steps, ) + shape, device=dev)
         run(args.warmup, out_w)
         torch.cuda.synchronize()
@@ -543,7 +556,7 @@ def main():
                 # overtake their predecessors: the completion times are sorted first)
                 ev0 = pipe.completion_events[0]
                 done = sorted((ev0.elapsed_time(e), nb) for e, nb in zip(pipe.completion_events, pipe.completion_batches))
-                unit_gaps += [(done[j][0] - done[j - 1][0]) / max(done[j][1], 1) for j in range(1, len(done))]
+                unit_gaps += [(done[j][0] - done[j - 1][0]) / max(done[j][1] * E, 1) for j in range(1, len(done))]
         windows_all = list(windows)
         if use_dist:   # every window: the slowest rank's time
             tw = torch.tensor(windows, device=dev, dtype=torch.float64)
@@ -569,6 +582,7 @@ def main():
 
         # ---- untimed extras: the two halves alone, per-kernel event timings ----
         noise = engine.kernel_noise(savi, None, B, T_BURN, dev)
+        noise_p = engine.kernel_noise(savi, None, Bp, T_BURN, dev)
 
         def encode():
             post, _, _ = engine.savi_encode(savi, ring[0], noise=noise, side_stream=None)   # one stream: the kernels alone, for the rooflines
@@ -599,7 +613,7 @@ def main():
         for k in range(6):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            pipe.run([ring[k % 3]], None, serial=True)
+            pipe.run([ringp[k % 3]], None, serial=True)
             torch.cuda.synchronize()
             one_batch.append(time.perf_counter() - t1)
         one_batch_ms = 1e3 * sorted(one_batch[1:])[len(one_batch[1:]) // 2]   # (the first call captures the one-batch unit's graph)
@@ -614,11 +628,11 @@ def main():
         if overlap and pipe.cu_split:
             def lane_encode(li):
                 st, lo, hi = pipe.lanes[li]
-                return lambda: pipe._encode(ring[0], noise, unit0.buf[:B], None, lo, hi, li)
+                return lambda: pipe._encode(ringp[0], noise_p, unit0.buf[:Bp], None, lo, hi, li)
 
             part_ms = {'encode_lane_ms_on_its_cus': [round(1e3 * timed_on(pipe.lanes[li][0], lane_encode(li)), 4) for li in range(len(pipe.lanes))],
                        'encode_lane_videos': [hi - lo for _, lo, hi in pipe.lanes],
-                       'rollout_unit_ms_on_its_cus': 1e3 * timed_on(pipe.s_roll, rollout), 'batches_per_rollout_unit': G}
+                       'rollout_unit_ms_on_its_cus': 1e3 * timed_on(pipe.s_roll, rollout), 'batches_per_rollout_unit': G * E}
             part_ms['encode_ms_on_its_cus'] = max(part_ms['encode_lane_ms_on_its_cus'])
         # the rollout layer kernels, event-timed: (a) alone on the whole chip in one eager rollout unit, (b) LIVE in a pipelined
         # pass with the product schedule (encode stream busy on its CUs) but eager launches -- inside the timed region they
@@ -633,7 +647,7 @@ def main():
             saved = [(u, u.graph) for u in pipe.units]
             for u in pipe.units:
                 u.graph = None
-            pipe.run([ring[j % 3] for j in range(4 * G)], None)
+            pipe.run([ringp[j % 3] for j in range(4 * G)], None)
             torch.cuda.synchronize()
             for u, g in saved:
                 u.graph = g
@@ -699,12 +713,12 @@ def main():
             'config': {
                 'workload': workload + '; random-init weights',
                 'name': args.config,
-                'batch_per_gpu': B, 'global_batch': B * world, 'burn_in': T_BURN, 'rollout': T_ROLL,
+                'batch_per_gpu': B, 'batches_per_encode': E, 'global_batch': B * world, 'burn_in': T_BURN, 'rollout': T_ROLL,
                 'parallelism': f'dp{world}: videos sharded on the batch axis, no collective on the timed path',
                 'inputs': 'ring of 3 different resident batches; the slots of every batch are copied out of the slot buffers',
                 'schedule': 'slotformer_amd.pipeline.EncodeRolloutPipeline (product code, tests/test_pipeline_gpu.py)',
                 'stream_placement': getattr(pipe, 'stream_placement', None),
-                'rollout_launch': (f'hipGraph replay, one graph per rollout unit of {G} batch(es) = {G * B} videos') if graph is not None else 'eager',
+                'rollout_launch': (f'hipGraph replay, one graph per rollout unit of {G * E} batch(es) = {G * Bp} videos') if graph is not None else 'eager',
                 'rollout_opts': None if pipe.rollout_opts is None else {k: getattr(pipe.rollout_opts, k) for k, _ in pipe.rollout_opts._fields_},
                 'pipelining': ('encode of later batches (stream A) overlaps the rollout graphs of earlier units (streams B, C); every batch still '
                                'runs its full encode + rollout inside the timed region') if overlap else 'none',
@@ -719,15 +733,15 @@ def main():
                                   'number in every XCD), rollout stream on the complement')) if (overlap and pipe.cu_split) else 'none',
             },
             'one_batch_latency_ms': one_batch_ms,
-            'one_batch_frames_per_s': B * (T_BURN + T_ROLL) / (one_batch_ms * 1e-3),
+            'one_batch_frames_per_s': Bp * (T_BURN + T_ROLL) / (one_batch_ms * 1e-3),
             'encode_ms': 1e3 * t_enc,
             'encode_ms_two_branches': 1e3 * t_enc_fork,
-            'rollout_ms': 1e3 * t_roll / G,
+            'rollout_ms': 1e3 * t_roll / (G * E),
             'rollout_unit_ms': 1e3 * t_roll,
             'partitioned_ms': part_ms,
             'ms_per_step_distribution': step_dist,
             'encoded_frames_per_s': B * T_BURN / t_enc,
-            'predicted_frames_per_s': G * B * T_ROLL / t_roll,
+            'predicted_frames_per_s': G * Bp * T_ROLL / t_roll,
             'whole_step_tflops': step_flops * args.steps * world / elapsed / 1e12,
             'whole_step_flops': step_flops,
             'whole_step_flops_without_folded_kv_projection': step_flops_fold,
@@ -785,7 +799,7 @@ def main():
                                ('HIP events of this run' + (f" (the committed trace {pm['stale_trace']} is of source tree {pm['trace_source_tree']}, "
                                                             f"this run's is {pm['source_tree']}: not used)" if pm.get('stale_trace') else '')),
                 'source_tree': pm.get('source_tree') or source_tree_hash(),
-                'launches_per_unit': iso['launches'], 'rows_per_launch_full_window': G * B * W_FR * N_SLOTS,
+                'launches_per_unit': iso['launches'], 'rows_per_launch_full_window': G * Bp * W_FR * N_SLOTS,
                 'cus_available': pipe.rollout_cus if pipe.cu_split else 256,
                 'traffic': pm.get('traffic_bytes_per_launch'),
                 'mfma_busy_frac': pm.get('mfma_busy_frac'), 'pmc_source': pm.get('source'),
@@ -796,10 +810,10 @@ def main():
                             'attention: a serial eight-wave workgroup per video -- per head pair 1.9 us of projection MFMAs inside 8.8 us of LDS '
                             'round trips, softmax and barriers (DESIGN.md 4, 5)'),
             }
-        roll_flops = roll_f * G * B
+        roll_flops = roll_f * G * Bp
         res['roofline_rollout_graph'] = {
-            'kernel': f'hipGraph of one rollout unit ({G} batches, {G * B} videos): ring init + per step {nl} x (attention + out-proj partials, fused FFN)',
-            'bound': f'latency ({sum(v["launches"] for v in prof_roll.values())} dependent launches, {G * B} videos per launch); MFMA roof shown for scale',
+            'kernel': f'hipGraph of one rollout unit ({G * E} batches, {G * Bp} videos): ring init + per step {nl} x (attention + out-proj partials, fused FFN)',
+            'bound': f'latency ({sum(v["launches"] for v in prof_roll.values())} dependent launches, {G * Bp} videos per launch); MFMA roof shown for scale',
             'achieved': roll_flops / t_roll / 1e12, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': roll_flops / t_roll / 1e12 / peak_chip,
             'ms': 1e3 * t_roll, 'us_per_step': 1e6 * t_roll / T_ROLL, 'seam_timeouts': int(lib.sf_seam_timeouts()),
         }

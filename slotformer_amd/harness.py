@@ -127,6 +127,10 @@ def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises
     V, T = videos.shape[:2]
     N, D = rollouter.num_slots, rollouter.in_proj.in_features
     out = torch.empty(V, T + pred_len, N, D, pin_memory=True) if to_host else torch.empty(V, T + pred_len, N, D, device=dev)
+    # small batches are handed to the pipeline several at a time (pipeline.encode_group_for: the latency-bound slot branch of an encode costs the
+    # same for 16 videos as for 32); the kernels are per video, so the slots do not depend on the grouping
+    from .pipeline import encode_group_for
+    batch_size = batch_size * encode_group_for(batch_size, V // batch_size) if pipelined and not pipe_kw.get('group') else batch_size
     nfull = V // batch_size
     tail_opts = None
     dec = None

@@ -97,6 +97,17 @@ class _Unit:
         self.latency_form = False   # captured with the kernels' latency forms (the drain unit of a run: alone on the whole chip)
 
 
+def encode_group_for(batch, n_batches):
+    """How many consecutive batches a caller should hand to the pipeline as ONE pipeline batch (harness.extract_and_rollout, bench.py): the slot
+    branch of an encode (predictor, Slot-Attention iterations, slot updates) is a chain of latency-bound launches that costs the same for 16 videos
+    as for 32 -- C4 (16 videos per batch): 3.3 ms per batch on the encode lane one at a time, 2.5 two at a time; with units of 160 videos 199 ->
+    253 k frames/s at 20 batches (profiles/r04_probes.txt section 8).  The largest E <= 32 // batch that divides the run and leaves >= 8 pipeline batches."""
+    for e in range(max(1, 32 // max(int(batch), 1)), 1, -1):
+        if n_batches % e == 0 and n_batches // e >= 8:
+            return e
+    return 1
+
+
 def unit_batches_for(rollouter, batch, n_batches, burn_in=None):
     """Batches per rollout unit for a run of n_batches (None = the constructor's default of 4).  A unit's row-tile launches should fill ONE
     round of the 64 CUs a rollout stream gets with 64-row tiles: 4096 token rows.  C2 (1344 rows per batch) and C5 (3072) stay at 4;
@@ -106,11 +117,19 @@ def unit_batches_for(rollouter, batch, n_batches, burn_in=None):
     hist = getattr(rollouter, 'cond_len', None) or getattr(rollouter, 'history_len', burn_in or 1)
     rows = int(batch) * int(rollouter.num_slots) * int(hist)
     g = max(4, min(8, 4096 // max(rows, 1)))
-    if g <= 4 or n_batches < 5 * g:
-        return None
     from . import _lib as _l   # (units of several batches need the fused-layer path: its results do not depend on the batch size)
-    fused = bool(_l.lib().sf_rollout_is_fused(C.byref(engine.rollouter_plan(rollouter).struct)))
-    return g if fused else None
+    fused = lambda: bool(_l.lib().sf_rollout_is_fused(C.byref(engine.rollouter_plan(rollouter).struct)))  # noqa: E731
+    if g > 4 and n_batches >= 5 * g:
+        return g if fused() else None
+    # SHORT runs of small batches (round 4): a rollout launch of such a unit is latency-bound -- a C4 unit of 64 videos (36 row tiles) and one of 128
+    # take the same 23.9 ms -- so the run is cut into an EVEN number (two rollout streams) of equal units of up to 8192 token rows: C4 at 20 batches of
+    # 16: units of 4 / 5 / 10 batches 199 / 196 / 228 k frames/s (253 k with two batches per encode, encode_group_for above); C2 (5376 rows in its default
+    # unit) and C5 keep 4: 493 / 490 k with 5 / 10 against 500+, 405 / 447 k against 445 (profiles/r04_probes.txt section 8)
+    if 4 * rows < 5376:
+        cands = [G for G in range(5, n_batches // 2 + 1) if n_batches % G == 0 and (n_batches // G) % 2 == 0 and G * rows <= 8192]
+        if cands:
+            return max(cands) if fused() else None
+    return None
 
 
 class EncodeRolloutPipeline:

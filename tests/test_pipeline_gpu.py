@@ -177,6 +177,10 @@ def test_unit_batches_for_long_runs(dev):
     assert unit_batches_for(roll, 32, 100, T) is None and unit_batches_for(roll, 32, 20, T) is None     # C2: 1344 rows per batch
     assert unit_batches_for(roll, 14, 40, T) == 6 and unit_batches_for(roll, 14, 29, T) is None         # 588 rows per batch (C4: 576 -> 7)
     assert unit_batches_for(roll, 2, 40, T) == 8 and unit_batches_for(roll, 2, 39, T) is None
+    # short runs of small batches: an even number of equal units of up to 8192 token rows (C4 at 20 batches: two units of 10)
+    assert unit_batches_for(roll, 14, 20, T) == 10 and unit_batches_for(roll, 14, 12, T) == 6 and unit_batches_for(roll, 14, 21, T) is None
+    from slotformer_amd.pipeline import encode_group_for
+    assert [encode_group_for(16, 20), encode_group_for(8, 48), encode_group_for(32, 20), encode_group_for(2, 41), encode_group_for(2, 16)] == [2, 4, 1, 1, 2]
     bs, V = 2, 83      # 41 full batches (units of 8) + 1 video
     rs = np.random.RandomState(5)
     base = torch.from_numpy((rs.rand(7, T, 3, 128, 128) * 2 - 1).astype(np.float32)).to(dev)
@@ -191,6 +195,9 @@ def test_unit_batches_for_long_runs(dev):
         assert torch.equal(out, ref)
         one = _serial_reference(savi, roll, [videos[10:12]], [noises[10:12]], T, H, PAIR_OPTS)
         assert torch.equal(out[10:12], one[0])
+        # 16 batches of 2: handed to the pipeline two at a time (encode_group_for): the same slots
+        out_e = harness.extract_and_rollout(savi, roll, videos[:32], H, batch_size=bs, noises=noises[:32])
+        assert next(iter(harness._PIPES.values()))[2].B == 2 * bs and torch.equal(out_e, out[:32])
         harness.release_pipelines()
 
 
