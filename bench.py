@@ -886,7 +886,10 @@ def main():
             res['roofline_' + k] = v
         if breakdown:
             res['kernel_breakdown_one_unit'] = breakdown
-        if args.decode:
+        if args.decode and (not hasattr(savi, 'decoder') or E != 1):
+            res['decode_pipeline'] = {'note': 'not run: --decode times the SAVi spatial-broadcast decoder stage (StoSAVi configurations, one batch per encode); '
+                                              'STEVE decodes through its dVAE + Transformer decoder (tools/bench_steve_decoder.py)'}
+        elif args.decode:
             res['decode_pipeline'], res['roofline_decode'] = decode_leg(args, lib, savi, roll, ring, B, T_BURN, T_ROLL, N_SLOTS, SLOT_D, RES, dev, pipe,
                                                                         peak_chip, peak_note, world, elapsed)
             pipe_closed = True

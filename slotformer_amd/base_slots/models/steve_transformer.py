@@ -214,12 +214,11 @@ class STEVETransformerDecoder(nn.Module):
         return tokens, logits.cpu()
 
     def generate(self, slots, steps, sample=False, temperature=1.0):
-        """Greedy autoregressive generation (steve_transformer.py:305-333): the whole prefix is re-run every step, as in
-        the reference; returns (tokens [B,steps] on device, logits [B,steps,V] on the CPU like the reference)."""
+        """Autoregressive generation (steve_transformer.py:305-333): the whole prefix is re-run every step, as in the reference;
+        greedy (sample=False: argmax) or sampled (sample=True: one draw per step from softmax(logits / temperature) -- the softmax a HIP
+        launch, the draw torch.multinomial on the device generator, as the reference draws it).  Returns (tokens [B,steps] on device,
+        logits [B,steps,V] on the CPU like the reference)."""
         assert not self.training
-        if sample:
-            raise NotImplementedError('multinomial sampling (sample=True) is not on the inference engine; the reference '
-                                      "callers use sample=False (steve_slotformer.py:92-93)")
         B = slots.shape[0]
         assert steps - 1 <= self.max_len
         idx_cond = torch.zeros((B, 0), dtype=torch.int64, device=slots.device)
@@ -227,6 +226,9 @@ class STEVETransformerDecoder(nn.Module):
         for _ in range(steps):
             logits = self.forward(slots, idx_cond)[:, -1].contiguous()   # [B,V]
             all_logits.append(logits.cpu())
-            ix = ops.argmax_rows(logits).unsqueeze(1)                     # argmax of softmax(logits / T) = argmax of logits
+            if sample:
+                ix = torch.multinomial(ops.softmax_rows(logits, scale=1.0 / float(temperature)), num_samples=1)
+            else:
+                ix = ops.argmax_rows(logits).unsqueeze(1)                 # argmax of softmax(logits / T) = argmax of logits
             idx_cond = torch.cat((idx_cond, ix), dim=1)
         return idx_cond, torch.stack(all_logits, dim=1)
