@@ -908,6 +908,9 @@ extern "C" int sf_slot_attn_iter_bf16(const void* k, const void* v, int ld, long
 // 128 MFMAs of 32 cycles per wave and 32 pixels: 9.7 TB/s of rows at two waves per SIMD on the whole chip -- above the HBM roof.
 // Arithmetic: exact f32 products, f32 accumulation; the summation order differs from the VALU logits of sa_attn_mfma_kernel (rounding-level
 // differences, every fixture keeps its tolerance).
+__device__ long long sa_ts[16];   // phase stamps of workgroup (0, 0), wave 0 (SF_SA_DBG=1; sf_debug_read_ts_sa)
+__device__ int sa_dbg_on;
+#define SATS(i) do { if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sa_ts[i] = wall_clock64(); } while (0)
 template <int D>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void sa_attn_tile_kernel(
     const float* __restrict__ x, int ld, long long batch_stride, const float* __restrict__ q, float scale, float eps,
@@ -916,6 +919,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // update adds the records), a wave 64 of them as FOUR tiles of 16 rows through one 8.4 KB LDS tile, with the rows of the next two tiles
   // in flight while a tile is multiplied (a register stage): the loads never stop while the matrix cores work.  80 KB of LDS: two workgroups per CU.
   // (single-shot tiles -- every workgroup loads, then computes -- ran the chip in lockstep phases at 2.5 TB/s, profiles/r04_probes.txt section 3)
+  const int dbg = sa_dbg_on;
+  SATS(0);
   constexpr int NS = SA_NMAX, XP = D + 4, NW = 8, TP = 16, NT4 = 4;   // tile pitch, waves, pixels per tile, tiles per wave
   constexpr int NSLAB = D / 16, NH = D / 64;
   extern __shared__ __attribute__((aligned(16))) float sa_lds[];
@@ -940,6 +945,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     s_q[idx] = n < N ? q[((long long)b * N + n) * D + d] * scale : 0.f;
   }
   __syncthreads();
+  SATS(1);
   f32x4a nacc[NH][4];
 #pragma unroll
   for (int h = 0; h < NH; ++h)
@@ -995,6 +1001,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
     }
     __builtin_amdgcn_wave_barrier();   // the tile and the attention tile are rewritten by the next tile
+    if (ti < 4) SATS(2 + ti);
   }
   // den: the slot's sum over this wave's pixels = over the lanes with the same li
   den += __shfl_xor(den, 16, 64);
@@ -1014,6 +1021,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
   if (lg == 0 && li < NS) s_red[(wave * NS + li) * XP + D] = den;
   __syncthreads();
+  SATS(6);
   // the workgroup's sums go to record 2 chunk, zeros to record 2 chunk + 1 (P = HW / 256 records per frame, summed by the slot update)
   for (int idx = threadIdx.x; idx < N * (D + 1); idx += 512) {
     const int n = idx / (D + 1), d = idx - n * (D + 1);
@@ -1028,6 +1036,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       part_den[((long long)b * P + 2 * chunk + 1) * N + n] = 0.f;
     }
   }
+  SATS(7);
 }
 
 int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch_stride, const float* q,
@@ -1153,3 +1162,12 @@ int sf_slot_update_f32(const float* part_num, const float* part_den, int P, cons
 }
 
 }  // extern "C"
+
+extern "C" int sf_debug_read_ts_sa(long long* out16) {
+  hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(sa_ts), sizeof(long long) * 16);
+  return e == hipSuccess ? 0 : (int)e;
+}
+extern "C" int sf_debug_sa_stamps(int on) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(sa_dbg_on), &on, sizeof(int));
+  return e == hipSuccess ? 0 : (int)e;
+}

@@ -29,3 +29,14 @@ for name, st in (('whole chip', torch.cuda.Stream(device=dev)), ('128-CU mask', 
         st.synchronize()
         dt = (time.perf_counter() - t0) / 50
     print(f'SF_SA_TILE={os.environ.get("SF_SA_TILE", "0")} {name:12s}: {1e6 * dt:6.1f} us per launch of {B} frames  ({B * HW * D * 4 / dt / 1e12:.2f} TB/s of unique bytes)', flush=True)
+
+if os.environ.get('SF_SA_DBG') == '1':
+    lib.sf_debug_sa_stamps(1)
+    for name, st in (('whole chip', torch.cuda.current_stream()), ('128-CU mask', masked)):
+        with torch.cuda.stream(st):
+            ops.slot_attn_iter(x, x, q)
+            st.synchronize()
+        o = (C.c_longlong * 16)()
+        lib.sf_debug_read_ts_sa(o)
+        ts = list(o)
+        print(name, 'sa_attn_tile_kernel ticks (10 ns), workgroup 0 wave 0:', [v - ts[0] for v in ts[:8]], '(0 entry, 1 queries staged + barrier, 2-5 tiles 0-3 done, 6 reduction summed, 7 end)')
