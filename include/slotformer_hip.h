@@ -489,6 +489,8 @@ typedef struct {
 typedef struct {
   float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;
   const sf_tfm_layer_grads* layers; /* HOST array [num_layers] */
+  float* pe_tok; /* [window_len * num_slots, d_model] gradient of the folded position table sf_rollouter.pe_tok (the caller sums it
+                    over slots / frames into enc_t_pe / enc_slots_pe, slotformer.py:103-109), or NULL: tables are fixed ('sin') */
 } sf_rollouter_grads;
 
 size_t sf_rollout_train_workspace_bytes(const sf_rollouter* m, int B, int pred_len);

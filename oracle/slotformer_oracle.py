@@ -387,6 +387,8 @@ def rollouter_forward_train(x, pred_len, sd, rcfg, drop, p='rollouter.'):
     H, nl = rcfg['num_heads'], rcfg['num_layers']
     in_x = x.flatten(1, 2)
     pe = sd[p + 'enc_t_pe'].unsqueeze(2).repeat(B, 1, N, 1).flatten(1, 2)
+    if rcfg.get('slots_pe'):   # slotformer.py:106-109
+        pe = pe + sd[p + 'enc_slots_pe'].unsqueeze(1).repeat(B, hist, 1, 1).flatten(1, 2)
     out = []
     for s in range(pred_len):
         h = F.linear(in_x, sd[p + 'in_proj.weight'], sd[p + 'in_proj.bias']) + pe

@@ -38,7 +38,7 @@ class sf_tfm_layer_grads(C.Structure):
 
 class sf_rollouter_grads(C.Structure):
     _fields_ = [(n, FP) for n in ('in_proj_w', 'in_proj_b', 'out_proj_w', 'out_proj_b')] + [
-        ('layers', C.POINTER(sf_tfm_layer_grads))]
+        ('layers', C.POINTER(sf_tfm_layer_grads)), ('pe_tok', FP)]
 
 
 _SA_LEAVES = ('norm_in_g', 'norm_in_b', 'wk', 'wv', 'q_ln_g', 'q_ln_b', 'wq', 'gru_w_ih', 'gru_w_hh', 'gru_b_ih', 'gru_b_hh',

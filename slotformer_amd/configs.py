@@ -94,6 +94,9 @@ TRAIN_SAVI = savi_cfg(64, 7, iters=2, kernel_mlp=False, pred='mlp', rnn=False, k
 TRAIN_ROLL = rollout_cfg(3, 64, 3, 64, 2, 2, 128, rollout_len=3)
 TRAIN_ROLL_IMG = rollout_cfg(3, 64, 3, 64, 2, 2, 128, rollout_len=2)   # with the image term (use_img_recon_loss=True)
 TRAIN_ROLL_IMG['loss_dict'] = dict(rollout_len=2, use_img_recon_loss=True)
+# trained position tables (build_pos_enc 'learnable', slotformer.py:19-29): no shipped config uses them, the constructor accepts them
+TRAIN_ROLL_PE = rollout_cfg(3, 64, 3, 64, 2, 2, 128, rollout_len=3)
+TRAIN_ROLL_PE['rollout_dict'].update(t_pe='learnable', slots_pe='learnable')
 
 
 class ParamsView:

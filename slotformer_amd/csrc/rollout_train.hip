@@ -101,6 +101,19 @@ __global__ __launch_bounds__(256) void window_scatter_kernel(const float* __rest
   *dst = t;
 }
 
+// adjoint of the "+ pe[l]" of the window assembly: dpe[l, :] += sum_b dx[b, l, :]   (one thread per (l, float4 column), the batch
+// in a loop: L * d / 4 <= 8192 threads, each reading B rows d floats apart in the same column -> coalesced across the workgroup)
+__global__ __launch_bounds__(256) void pe_grad_kernel(const float* __restrict__ dx, float* __restrict__ dpe, int B, int L, int d4) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= L * d4) return;
+  float4 a = reinterpret_cast<float4*>(dpe)[i];
+  for (int b = 0; b < B; ++b) {
+    const float4 g = reinterpret_cast<const float4*>(dx)[(long long)b * L * d4 + i];
+    a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+  }
+  reinterpret_cast<float4*>(dpe)[i] = a;
+}
+
 // y += x  (float4)
 __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, long long n4) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1317,6 +1330,10 @@ int sf_rollout_train_bwd_f32(const sf_rollouter* m, const float* d_pred, float* 
 
   hipError_t e = hipMemsetAsync(w.dtok, 0, (size_t)D.T * R * d * sizeof(float), st);
   if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+  if (g->pe_tok) {
+    e = hipMemsetAsync(g->pe_tok, 0, (size_t)D.L * d * sizeof(float), st);
+    if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+  }
   // d_pred [B,S,N,C] -> step-major dpred [S][R][C]
   for (int s = 0; s < D.S; ++s)
     SF_TRY(sf_copy_rows_ex(d_pred, sf_rows_batched(C, N, (long long)D.S * N * C, (long long)s * N * C),
@@ -1366,6 +1383,11 @@ int sf_rollout_train_bwd_f32(const sf_rollouter* m, const float* d_pred, float* 
     hipLaunchKernelGGL(window_scatter_kernel, dim3(cdiv(Md4, 256)), dim3(256), 0, st, dx, w.dtok + (size_t)D.f0(s) * R * d, B, L,
                        N, d / 4);
     SF_CHECK_LAUNCH();
+    if (g->pe_tok) {   // learnable position tables: this step's window used rows D.L - L .. D.L - 1 of the folded table
+      hipLaunchKernelGGL(pe_grad_kernel, dim3(cdiv((long long)L * d / 4, 256)), dim3(256), 0, st, dx, g->pe_tok + (size_t)(D.L - L) * d, B,
+                         L, d / 4);
+      SF_CHECK_LAUNCH();
+    }
   }
 
   // gradient w.r.t. the burn-in slots

@@ -43,13 +43,20 @@ def rollouter_parameters(r):
     return ps
 
 
-def _grad_descriptor(flat, params, num_layers):
-    """sf_rollouter_grads whose pointers are consecutive slices of `flat` (same order as rollouter_parameters)."""
+def learnable_tables(r):
+    """The position tables of a rollouter that are trained (t_pe / slots_pe = 'learnable', slotformer.py:19-29 build_pos_enc)."""
+    return [p for p in (getattr(r, 'enc_t_pe', None), getattr(r, 'enc_slots_pe', None)) if isinstance(p, torch.nn.Parameter) and p.requires_grad]
+
+
+def _grad_descriptor(flat, params, num_layers, pe_off=None):
+    """sf_rollouter_grads whose pointers are consecutive slices of `flat` (same order as rollouter_parameters); pe_off: where the
+    gradient of the folded position table goes (floats into `flat`), None = tables fixed."""
     ptrs, off = [], 0
     for p in params:
         ptrs.append(flat.data_ptr() + 4 * off)
         off += p.numel()
     g = sf_rollouter_grads()
+    g.pe_tok = None if pe_off is None else flat.data_ptr() + 4 * pe_off
     g.in_proj_w, g.in_proj_b, g.out_proj_w, g.out_proj_b = ptrs[:4]
     arr = (sf_tfm_layer_grads * num_layers)()
     for i in range(num_layers):
@@ -93,8 +100,13 @@ class _Rollout(torch.autograd.Function):
         B, pred_len, p_drop, seed, xshape = ctx.args
         r, plan, params = ctx.r, ctx.plan, ctx.params
         d_pred = d_pred.float().contiguous()
-        flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=d_pred.device)
-        g, keep = _grad_descriptor(flat, params, len(r.transformer_encoder.layers))
+        # the weights' gradients, then (learnable tables only) the gradient of the folded table pe_tok [window tokens, d_model]
+        tables = learnable_tables(r)
+        params = params[:len(params) - len(tables)]
+        nw = sum(p.numel() for p in params)
+        W, N, d = plan.struct.window_len, plan.struct.num_slots, plan.struct.d_model
+        flat = torch.empty(nw + (W * N * d if tables else 0), dtype=torch.float32, device=d_pred.device)
+        g, keep = _grad_descriptor(flat, params, len(r.transformer_encoder.layers), nw if tables else None)
         d_x = torch.empty(xshape, dtype=torch.float32, device=d_pred.device) if ctx.needs_input_grad[1] else None
         check(lib().sf_rollout_train_bwd_f32(C.byref(plan.struct), d_pred.data_ptr(), d_x.data_ptr() if d_x is not None else None,
                                              C.byref(g), B, pred_len, p_drop, seed, ctx.ws.data_ptr(), ctx.ws.numel(),
@@ -106,23 +118,23 @@ class _Rollout(torch.autograd.Function):
             parallel.allreduce_flat(flat)
         r.last_grad_bucket = flat
         grads = _split(flat, params)
+        if tables:
+            # pe_tok[t * N + n] = enc_t_pe[t] + enc_slots_pe[n]  (slotformer.py:103-109): sum the folded gradient over slots / frames
+            dpe = flat[nw:].view(W, N, d)
+            for p in tables:
+                grads.append((dpe.sum(1) if p is getattr(r, 'enc_t_pe', None) else dpe.sum(0)).view_as(p))
         return (None, d_x, None, None, None) + tuple(g_ if ctx.needs_input_grad[5 + i] else None for i, g_ in enumerate(grads))
 
 
 def rollout_with_grad(r, x, pred_len):
     """SlotRollouter.forward under autograd (slotformer.py:85-126).  x [B, history_len, N, C] -> [B, pred_len, N, C]."""
-    for name in ('enc_t_pe', 'enc_slots_pe'):
-        pe = getattr(r, name, None)
-        if isinstance(pe, torch.nn.Parameter) and pe.requires_grad:
-            # the position tables enter the kernels as one folded constant (engine.rollouter_plan: pe_tok) and
-            # sf_rollout_train_bwd_f32 produces no gradient for them: refuse rather than train with frozen tables
-            raise NotImplementedError(f'slotformer_amd: learnable position encodings ({name}.requires_grad) are not trained by the HIP '
-                                      "path; use t_pe='sin' / slots_pe='' (the reference's configs) or freeze the table")
     layer0 = r.transformer_encoder.layers[0]
     p_drop = float(layer0.dropout.p) if r.training else 0.0
     seed = int(torch.randint(0, 2**62, (1, )).item()) if p_drop > 0 else 0
     seed = getattr(r, 'dropout_seed_override', None) or seed
-    return _Rollout.apply(r, x, pred_len, p_drop, seed, *rollouter_parameters(r))
+    # (learnable position tables ride along as extra leaves: the kernels read them folded into pe_tok, engine.rollouter_plan, and
+    # sf_rollout_train_bwd_f32 returns the folded table's gradient)
+    return _Rollout.apply(r, x, pred_len, p_drop, seed, *rollouter_parameters(r), *learnable_tables(r))
 
 
 # ---------------------------------------------------------------------------------------------------------------------

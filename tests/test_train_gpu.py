@@ -77,6 +77,45 @@ def test_rollout_grads_golden(dev, precision):
     assert all(p.grad is None for n, p in m.named_parameters() if not n.startswith('rollouter.') or not p.requires_grad)
 
 
+def test_rollout_grads_with_learnable_position_tables(dev, precision):
+    """t_pe = slots_pe = 'learnable' (build_pos_enc, slotformer.py:19-29): the tables are parameters, the kernels read them folded into
+    one token table and the backward pass returns that table's gradient, summed here over slots / frames.  Fixture: the reference's own
+    training step with a non-zero temporal table."""
+    g = gu.load_golden('roll_train_pe')
+    cfg = gu.TRAIN_ROLL_PE
+    m, sd = build(cfg, g, 821, dev, vp=True)
+    with torch.no_grad():
+        m.rollouter.enc_t_pe.copy_(torch.from_numpy(g['closed::rollouter.enc_t_pe']).to(dev))
+    assert m.rollouter.enc_t_pe.requires_grad and m.rollouter.enc_slots_pe.requires_grad
+    m.train()
+    _no_dropout(m)
+    rd = cfg['rollout_dict']
+    slots = gu.seeded_normal((2, rd['history_len'] + 3, rd['num_slots'], rd['slot_size']), 822)
+    loss, pred, grads, d_slots = _engine_grads(m, slots, 0.9, dev)
+    assert abs(loss - float(g['loss'])) < 1e-5 * abs(float(g['loss']))
+    assert rel_err(pred, g['pred_slots']) < 1e-4
+    names = [str(n) for n in g['grad_names']]
+    assert sorted(names) == sorted(grads) and 'rollouter.enc_t_pe' in names and 'rollouter.enc_slots_pe' in names
+    for n in names:
+        assert grads[n] is not None, n
+        assert rel_err(grads[n], g['grad.' + n]) < GTOL, n
+    assert rel_err(d_slots, g['d_slots']) < GTOL
+    # an optimizer step moves the tables, and the next forward sees the moved tables (the plan is re-folded)
+    opt = torch.optim.SGD(m.rollouter.parameters(), lr=0.5)
+    before = m.rollouter.enc_t_pe.detach().clone()
+    opt.step()
+    assert not torch.equal(before, m.rollouter.enc_t_pe.detach())
+    loss2 = _engine_grads(m, slots, 0.9, dev)[0]
+    assert loss2 != loss
+    # inference kernels read the same (re-folded) tables
+    m.eval()
+    with torch.no_grad():
+        out = m({'slots': slots.to(dev)})['pred_slots']
+    sd2 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref = oracle.slotformer_forward(slots, sd2, cfg, 3)['pred_slots']
+    assert rel_err(out, ref) < 1e-4
+
+
 @pytest.mark.parametrize('B,S', [(3, 4), (1, 2)])
 def test_rollout_grads_c2_vs_oracle(dev, precision, B, S):
     """CLEVRER width (slotformer_clevrer_params.py: d_model 256, 4 layers, 8 heads, ffn 1024, 6 x 7 tokens)."""
@@ -263,12 +302,15 @@ def test_decoder_data_gradient_vs_oracle(dev, precision, Fr):
     assert l2_err(sg.grad, so.grad) < {'bf16x3': 1e-2, 'f32': 2e-3}[precision]
 
 
-def test_single_step_rollouter_grads_vs_oracle(dev, precision):
+@pytest.mark.parametrize('learn_pe', [False, True])
+def test_single_step_rollouter_grads_vs_oracle(dev, precision, learn_pe):
     """PHYRE's SingleStepSlotRollouter under autograd (single_step_slotformer.py:49-90): one burn-in frame, the window grows
-    to cond_len = 6 frames (8 .. 48 tokens) and then slides; 8 layers.  Gradients against autograd of the oracle."""
+    to cond_len = 6 frames (8 .. 48 tokens) and then slides; 8 layers.  Gradients against autograd of the oracle.  learn_pe: the
+    temporal table is trained too (a growing window reads the table's LAST rows only, :84-85)."""
     S, B = 8, 2
     cfg = {**gu.C5_ROLL, 'loss_dict': dict(rollout_len=S, use_img_recon_loss=False)}
     m, sd = build(cfg, gu.load_golden('roll_c5'), 205, dev, vp=True)
+    m.rollouter.enc_t_pe.requires_grad_(learn_pe)
     m.train()
     _no_dropout(m)
     slots = gu.seeded_normal((B, 1 + S, 8, 128), 970)
@@ -288,6 +330,7 @@ def test_single_step_rollouter_grads_vs_oracle(dev, precision):
     # the last layer's FFN only sees gradient on the 8 newest tokens of each window (128 rows in all), so one ReLU-kink
     # flip weighs more there than in the 4-layer sliding-window case: 2.5 x L2TOL
     tol = 2.5 * L2TOL[precision]
+    assert ('rollouter.enc_t_pe' in grads) == learn_pe
     for n in grads:
         assert l2_err(grads[n], osd[n].grad) < tol, n
     assert l2_err(x.grad, xo.grad) < tol

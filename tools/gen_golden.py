@@ -465,7 +465,7 @@ def case_rollout(name, cfg, B, pred_len, seed, single_step=False):
     return m, sd
 
 
-def case_rollout_grads(name, cfg, B, seed, decay=0.9, img=False):
+def case_rollout_grads(name, cfg, B, seed, decay=0.9, img=False, pe_seed=None):
     """Gradients of the reference's training loss (SlotFormer.forward + calc_train_loss in train() mode,
     slotformer.py:263-318, then loss.backward()) w.r.t. every rollouter parameter and the burn-in slots.  Dropout is the
     only random part of that path; its probability is set to 0 on the reference modules so the fixture is reproducible
@@ -474,6 +474,9 @@ def case_rollout_grads(name, cfg, B, seed, decay=0.9, img=False):
     with torch.enable_grad():
         m = build_slotformer(cfg)
         sd = load_seeded(m, seed)
+        if pe_seed is not None:   # learnable tables start at zero (slotformer.py:24-26): give the temporal one values, as after some training
+            m.rollouter.enc_t_pe.data.copy_(0.1 * gu.seeded_normal(tuple(m.rollouter.enc_t_pe.shape), pe_seed))
+            sd = {k: v.clone() for k, v in m.state_dict().items()}
         m.train()
         for mod in m.modules():
             if isinstance(mod, torch.nn.Dropout):
@@ -677,6 +680,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'decode_128':   # the reference decoder at BASELINE's 128 x 128 (four stride-2 layers, savi.py:262-277)
         case_decode('decode_c2_128', gu.savi_cfg(128, 7, kernel_mlp=False, pred='mlp', rnn=False), Fr=2, seed=411)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'roll_train_pe':
+        case_rollout_grads('roll_train_pe', gu.TRAIN_ROLL_PE, B=2, seed=821, pe_seed=823)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'roll_train':
         case_rollout_grads('roll_train', gu.TRAIN_ROLL, B=2, seed=801)
         case_rollout_grads('roll_train_img', gu.TRAIN_ROLL_IMG, B=1, seed=811, img=True)
@@ -701,6 +707,7 @@ def main():
     case_steve_slotformer('steve_slotformer', B=1, seed=701)
     case_rollout_grads('roll_train', gu.TRAIN_ROLL, B=2, seed=801)
     case_rollout_grads('roll_train_img', gu.TRAIN_ROLL_IMG, B=1, seed=811, img=True)
+    case_rollout_grads('roll_train_pe', gu.TRAIN_ROLL_PE, B=2, seed=821, pe_seed=823)
     case_savi_train('savi_train', gu.TRAIN_SAVI, B=1, T=2, seed=901, noise_seed=9)
     case_savi_train('savi_train_c1', gu.C1_SAVI, B=1, T=3, seed=911, noise_seed=None, no_dropout=True)
     case_steve_train('steve_train', B=1, T=2, seed=921)
