@@ -558,6 +558,11 @@ typedef struct {
    * conv_w[i].  With one, the conv runs on 4-row tiles with its weights streamed as MFMA fragments (csrc/conv_rows4.hip; split-bf16
    * mode) instead of the 2-row tile kernel that passes every tap's weights through LDS -- the same products in the same order. */
   const void* conv_w_frag[8];
+  /* optional (slot size 128; pred_type 0 without LSTM, kd_mode 1): sf_pack_linear_weights copies of the ResidualMLPPredictor's mlp[0].weight
+   * [2D, D] and mlp[2].weight [D, 2D] and of the kernel_dist Linear [2D, D].  With them and the matrix-core slot update (sa_*_p above), the slot
+   * prologue of time step t + 1 -- predictor, kernel distribution, sampling, first q (savi.py:393-402) -- runs at the tail of step t's last slot
+   * update instead of as its own launch (split-bf16 products, like the update's). */
+  const void *pm_w0_p, *pm_w2_p, *kd_w0_p;
 } sf_savi_encoder;
 
 size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B);
@@ -591,6 +596,12 @@ size_t sf_savi_encode_fork_workspace_bytes(const sf_savi_encoder* m, int B, int 
  * The same kernels' arithmetic in another launch order: bit-identical results. */
 int sf_set_encode_interleave(int on);
 int sf_get_encode_interleave(void);
+/* Where the slot prologue of time step t + 1 runs (process-wide; default 1, SF_ENC_FUSE_NEXT=0: 0).  1: with the packed predictor / kernel-distribution
+ * copies of sf_savi_encoder (pm_w0_p, pm_w2_p, kd_w0_p) and the matrix-core slot update, at the tail of step t's last slot update -- one launch fewer per
+ * time step, its products on the split-bf16 matrix path like the update's; 0: as its own launch on every step (fp32 thread-per-output products).  The
+ * two agree to split-bf16 rounding (~1e-6 relative), not bit for bit; step 0 of a call always takes the stand-alone launch. */
+int sf_set_encode_fuse_next(int on);
+int sf_get_encode_fuse_next(void);
 int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const float* feat_pre, int n_pre, const float* noise,
                             const float* prev_slots, float* lstm_h, float* lstm_c, int state_valid, float* post_slots,
                             float* kernel_dist, float* attn, int B, int T, void* ws, size_t ws_bytes, void* stream, void* side_stream);

@@ -92,7 +92,7 @@ class sf_savi_encoder(C.Structure):
          ('sa_gru_ih_p', C.c_void_p), ('sa_gru_hh_p', C.c_void_p), ('sa_mlp_w1_p', C.c_void_p), ('sa_mlp_w2_p', C.c_void_p),
          ('sa_q_w_p', C.c_void_p), ('sa_fold_q_w', FP), ('sa_fold_q_w_t', FP), ('sa_fold_gru_ih_t', FP), ('sa_fold_q_w_p', C.c_void_p),
          ('sa_fold_gru_ih_p', C.c_void_p), ('pred_packed', C.POINTER(C.c_void_p)), ('enc_fc1_p', C.c_void_p), ('enc_fc2_p', C.c_void_p),
-         ('conv_w_frag', C.c_void_p * 8)])
+         ('conv_w_frag', C.c_void_p * 8), ('pm_w0_p', C.c_void_p), ('pm_w2_p', C.c_void_p), ('kd_w0_p', C.c_void_p)])
 
 
 class sf_slate_block(C.Structure):
@@ -235,6 +235,8 @@ SIGNATURES = {
     'sf_savi_encode_fork_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I, I]),
     'sf_set_encode_interleave': (I, [I]),
     'sf_get_encode_interleave': (I, []),
+    'sf_set_encode_fuse_next': (I, [I]),
+    'sf_get_encode_fuse_next': (I, []),
     'sf_savi_encode_fork_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, I, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
                                     VP, VP]),
     'sf_kv_producer_workspace_bytes': (SZ, [I, I]),

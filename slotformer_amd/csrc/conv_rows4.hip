@@ -378,6 +378,7 @@ int sf_conv5x5_rows4_update_ex(const float* in, const void* w_frag, const float*
   static_assert(UM_LDS <= LDS_BYTES, "the slot update's LDS fits the convolution's");
   SF_TRY(sf_ensure_dyn_lds((const void*)conv5x5_rows4_update_kernel, LDS_BYTES));
   UmArgs a;
+  memset(&a, 0, sizeof(a));
   a.part_num = u.part_num; a.part_den = u.part_den; a.P = u.P; a.slots_prev = u.slots_prev;
   a.w_ih_p = (const uint4*)u.gru_ih_p; a.w_hh_p = (const uint4*)u.gru_hh_p; a.b_ih = u.gru_b_ih; a.b_hh = u.gru_b_hh; a.ln_g = u.ln_g; a.ln_b = u.ln_b;
   a.w1_p = (const uint4*)u.w1_p; a.b1 = u.b1; a.w2_p = (const uint4*)u.w2_p; a.b2 = u.b2; a.slots_out = u.slots_out; a.out2 = u.out2; a.out2_bs = u.out2_bs;

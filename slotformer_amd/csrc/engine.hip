@@ -580,6 +580,21 @@ int sf_get_encode_interleave(void) {
   return g_enc_interleave;
 }
 
+// the slot prologue of step t + 1 at the tail of step t's last slot update (slot_update_mfma.hip, NEXT form): on by default where it applies;
+// SF_ENC_FUSE_NEXT=0 / sf_set_encode_fuse_next(0): the prologue as its own launch (sa_slot_prologue_kernel) on every step
+static int g_enc_fuse_next = -1;
+int sf_set_encode_fuse_next(int on) {
+  g_enc_fuse_next = on ? 1 : 0;
+  return 0;
+}
+int sf_get_encode_fuse_next(void) {
+  if (g_enc_fuse_next < 0) {
+    const char* e = getenv("SF_ENC_FUSE_NEXT");
+    g_enc_fuse_next = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_enc_fuse_next;
+}
+
 static size_t enc_ws_bytes(const sf_savi_encoder* m, int B, int kv_steps);
 size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B) { return enc_ws_bytes(m, B, 2); }   // (two: the interleaved order below)
 // the forked form keeps the Slot-Attention inputs of up to ENC_FORK_AHEAD time steps (the feature branch runs that far ahead of the slot branch)
@@ -811,6 +826,12 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
   float* const dst_feat = (m->enc_layers & 1) ? featA : featB;   // the buffer the last conv does not read
   // time-step order; forked: the features of step t are enqueued on `stream`, its slot branch on `side_stream` behind them (event),
   // and the features of step t + KV wait for the slot branch of step t to release its ring slot
+  // the one-launch slot prologue applies (CLEVRER configuration); with packed copies of its three matrices and the matrix-core slot update, the
+  // prologue of step t + 1 runs at the tail of step t's last update (slot_update_mfma.hip, NEXT form; SF_ENC_FUSE_NEXT=0: as its own launch)
+  const bool can_prologue = m->pred_type == 0 && !m->pred_rnn && m->kd_mode == 1 && m->pm_w0_t && m->pm_w2_t && m->kd_w0_t && q_w_t;
+  const bool can_fuse_next = sf_get_encode_fuse_next() && can_prologue && su_mfma && m->pm_w0_p && m->pm_w2_p && m->kd_w0_p && m->pm_ln_g && m->pm_ln_b && m->pm_b0 &&
+                             m->pm_b2 && m->kd_b0;
+  bool next_done = false;
   for (int t = 0; t < T; ++t) {
     float* kv = kv_base + (size_t)(t % KV) * kv_step;
     // ---- CNN encoder + per-pixel MLP + K/V for the B frames of step t ---------------------
@@ -871,7 +892,10 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
     float* s_in = slotsA;
     float* s_out = slotsB;
     int prologue = 1;
-    if (m->pred_type == 0 && !m->pred_rnn && m->kd_mode == 1 && m->pm_w0_t && m->pm_w2_t && m->kd_w0_t && q_w_t)
+    if (next_done) {   // computed at the tail of the previous step's last slot update (NEXT form below)
+      prologue = 0;
+      next_done = false;
+    } else if (can_prologue)
       prologue = sf_slot_prologue_ex(prev, m->init_latents, m->pm_ln_g, m->pm_ln_b, m->pm_w0_t, m->pm_b0, m->pm_w2_t, m->pm_b2,
                                      m->pred_norm_first, m->kd_w0_t, m->kd_b0, noise ? noise + (long long)t * N * D : nullptr,
                                      (long long)T * N * D, kernel_dist ? kernel_dist + (long long)t * N * 2 * D : nullptr,
@@ -979,7 +1003,22 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
                                     (long long)T * N * HW, B, HW, N, D, scale, m->sa_eps, st));
       if (su_mfma) {
         bool rode = false;
-        if (next_cnn && next_layer < m->enc_layers && m->conv_w_frag[next_layer]) {
+        const bool fuse_next = can_fuse_next && last_it && t + 1 < T && prologue == 0;
+        if (fuse_next) {
+          SfNextStep nx;
+          nx.pm_ln_g = m->pm_ln_g; nx.pm_ln_b = m->pm_ln_b; nx.pm_w0_p = m->pm_w0_p; nx.pm_b0 = m->pm_b0; nx.pm_w2_p = m->pm_w2_p; nx.pm_b2 = m->pm_b2;
+          nx.norm_first = m->pred_norm_first; nx.kd_w_p = m->kd_w0_p; nx.kd_b = m->kd_b0;
+          nx.noise = noise ? noise + (long long)(t + 1) * N * D : nullptr; nx.noise_bs = (long long)T * N * D;
+          nx.kdist_out = kernel_dist ? kernel_dist + (long long)(t + 1) * N * 2 * D : nullptr; nx.kdist_bs = (long long)T * N * 2 * D;
+          nx.slots = slotsA;   // where the next step's iterations start
+          // (the finished rows of step t go to post_slots[:, t]; their ping-pong copy is not read again, and must not alias the sampled slots)
+          SF_TRY(sf_slot_update_mfma_ex(pnum, pden, P, s_in, gru_ih_p, m->sa_gru_hh_p, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g, m->mlp_ln_b,
+                                        m->sa_mlp_w1_p, m->mlp_b1, m->sa_mlp_w2_p, m->mlp_b2, s_out == slotsA ? latents : s_out,
+                                        post_slots + (long long)t * N * D, (long long)T * N * D, m->sa_q_ln_g, m->sa_q_ln_b, q_w_p, q, B, N, ln_eps, st,
+                                        &nx));
+          next_done = true;
+          rode = true;
+        } else if (next_cnn && next_layer < m->enc_layers && m->conv_w_frag[next_layer]) {
           // this slot update as the first blocks of the next step's convolution `next_layer`
           SfSlotUpdateArgs u;
           u.part_num = pnum; u.part_den = pden; u.P = P; u.slots_prev = s_in; u.gru_ih_p = gru_ih_p; u.gru_hh_p = m->sa_gru_hh_p;

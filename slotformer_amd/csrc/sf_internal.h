@@ -40,11 +40,28 @@ int sf_pixel_mlp_feat192_ex(const float* x, const float* ln0_g, const float* ln0
 int sf_pixel_mlp_feat_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
                          const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st);
 bool sf_slot_update_mfma_ok(int D, int H, int P);
+// The slot prologue of the NEXT time step (ResidualMLPPredictor -> kernel_dist Linear -> sampling; slot size 128) as the tail of a matrix-core slot
+// update: the three matrices as sf_pack_linear_weights copies; the update's q_out then holds project_q of the sampled slots (slot_update_body.h)
+struct SfNextStep {
+  const float *pm_ln_g, *pm_ln_b;
+  const void* pm_w0_p;
+  const float* pm_b0;
+  const void* pm_w2_p;
+  const float* pm_b2;
+  int norm_first;
+  const void* kd_w_p;
+  const float* kd_b;
+  const float* noise;   // row (b, n) at noise + b * noise_bs + n * D, or NULL
+  long long noise_bs;
+  float* kdist_out;     // row (b, n) at kdist_out + b * kdist_bs + n * 2D, or NULL
+  long long kdist_bs;
+  float* slots;         // [B * N][D] the sampled slots (must not alias the update's slots_out)
+};
 int sf_slot_update_mfma_ex(const float* part_num, const float* part_den, int P, const float* slots_prev, const void* gru_ih_p,
                            const void* gru_hh_p, const float* gru_b_ih, const float* gru_b_hh, const float* ln_g, const float* ln_b,
                            const void* w1_p, const float* b1, const void* w2_p, const float* b2, float* slots_out, float* out2,
                            long long out2_bs, const float* q_ln_g, const float* q_ln_b, const void* q_w_p, float* q_out, int B, int N,
-                           float ln_eps, hipStream_t st);
+                           float ln_eps, hipStream_t st, const SfNextStep* next = nullptr);
 int sf_slot_update_ex(const float* part_num, const float* part_den, int P, const float* slots_prev,
                       const float* gru_w_ih, const float* gru_w_hh, const float* gru_b_ih, const float* gru_b_hh,
                       const float* ln_g, const float* ln_b, const float* mlp_w1, const float* mlp_b1, const float* mlp_w2,

@@ -18,6 +18,11 @@ constexpr int UM_FP = UM_D + 4;                     // f32 row stride
 // the weight fragments: vmcnt retires in order)
 constexpr int UV_BIH = 0, UV_BHH = 3 * UM_D, UV_LNG = 6 * UM_D, UV_LNB = 7 * UM_D, UV_B1 = 8 * UM_D, UV_B2 = 8 * UM_D + UM_H,
               UV_QG = 9 * UM_D + UM_H, UV_QB = 10 * UM_D + UM_H, UM_NV = 11 * UM_D + UM_H;
+// the NEXT form (the slot prologue of the following time step at the tail of the update): LayerNorm and biases of the residual-MLP predictor,
+// bias of the kernel-distribution layer
+constexpr int UV_PG = UM_NV, UV_PBT = UV_PG + UM_D, UV_PB0 = UV_PBT + UM_D, UV_PB2 = UV_PB0 + UM_H, UV_KB = UV_PB2 + UM_D, UM_NV_NEXT = UV_KB + 2 * UM_D;
+constexpr int UM_KP = 2 * UM_D + 8;   // f32 pitch of the kernel-distribution rows (they take the place of the hidden planes)
+static_assert(UM_H == 2 * UM_D && UM_NV == 1664 && UM_NV_NEXT == 5 * 512, "parameter-vector staging");
 
 __device__ __forceinline__ void um_split4(__bf16* hp, __bf16* lp, int off, f32x4 v) {
   const bf16x4 hi = __builtin_convertvector(v, bf16x4);
@@ -82,6 +87,21 @@ struct UmArgs {
   float* q_out;
   int R, N;
   float ln_eps;
+  // NEXT form only (um_body<true>): ResidualMLPPredictor (predictor.py:65-73), kernel_dist_layer + sampling (savi.py:190-200,355-365,401-402) of the
+  // following time step; q_out then receives project_q of the SAMPLED slots
+  const float *pm_ln_g, *pm_ln_b;
+  const uint4* pm_w0_p;           // [2D][D]
+  const float* pm_b0;
+  const uint4* pm_w2_p;           // [D][2D]
+  const float* pm_b2;
+  int pm_norm_first;
+  const uint4* kd_w_p;            // [2D][D]
+  const float* kd_b;
+  const float* noise;             // row (b, n) at noise + b * noise_bs + n * D, or NULL: the mean
+  long long noise_bs;
+  float* kdist_out;               // row (b, n) at kdist_out + b * kdist_bs + n * 2D, or NULL
+  long long kdist_bs;
+  float* nx_slots;                // [R][D] the sampled slots
 };
 
 }  // namespace
@@ -91,9 +111,12 @@ constexpr size_t UM_LDS = (size_t)(4 * UM_ROWS * UM_DP + 2 * UM_ROWS * UM_HP) * 
                           + (size_t)4 * 2 * 16 * 64 * 4                              // wave-pair exchange: [4 blocks][2][16][64]
                           + (size_t)UM_ROWS * 64 * 4                                 // denominators [32][64]
                           + (size_t)UM_NV * 4;                                       // bias / LayerNorm vectors
+constexpr size_t UM_LDS_NEXT = UM_LDS + (size_t)(UM_NV_NEXT - UM_NV) * 4;
+static_assert((size_t)UM_ROWS * UM_KP * 4 <= (size_t)2 * UM_ROWS * UM_HP * 2, "kernel-distribution rows fit the hidden planes");
 
 // The whole slot update of rows 32 * block .. + 31 by one 512-thread workgroup; um_lds: UM_LDS bytes of dynamic LDS.  A device function so that
 // the workgroups can also ride as extra blocks of another launch (conv_rows4.hip: conv5x5_rows4_update_kernel).
+template <bool NEXT = false>
 __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const int block) {
   __bf16* Uh = (__bf16*)um_lds;                    // [32][DP]  updates
   __bf16* Ul = Uh + UM_ROWS * UM_DP;
@@ -135,10 +158,11 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
     pa[p][1] = *(const f32x4*)(pn + (long long)pc * a.N * UM_D + 4);
   }
   const f32x4 h0 = *(const f32x4*)(a.slots_prev + (long long)urow * UM_D + uc), h1 = *(const f32x4*)(a.slots_prev + (long long)urow * UM_D + uc + 4);
-  float pvv[4];
+  constexpr int NPV = NEXT ? 5 : 4;
+  float pvv[NPV];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = t + UM_NT * i;   // UM_NV = 1664 <= 4 * 512
+  for (int i = 0; i < NPV; ++i) {
+    const int j = t + UM_NT * i;   // UM_NV = 1664 <= 4 * 512; NEXT: 2560 = 5 * 512
     float v = 0.f;
     if (j < UV_BHH) v = a.b_ih[j];
     else if (j < UV_LNG) v = a.b_hh[j - UV_BHH];
@@ -148,6 +172,13 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
     else if (j < UV_QG) v = a.b2[j - UV_B2];
     else if (j < UV_QB) v = a.q_out ? a.q_ln_g[j - UV_QG] : 0.f;
     else if (j < UM_NV) v = a.q_out ? a.q_ln_b[j - UV_QB] : 0.f;
+    else if constexpr (NEXT) {
+      if (j < UV_PBT) v = a.pm_ln_g[j - UV_PG];
+      else if (j < UV_PB0) v = a.pm_ln_b[j - UV_PBT];
+      else if (j < UV_PB2) v = a.pm_b0[j - UV_PB0];
+      else if (j < UV_KB) v = a.pm_b2[j - UV_PB2];
+      else v = a.kd_b[j - UV_KB];
+    }
     pvv[i] = v;
   }
   // the GRU fragments of this wave: half 0 = gate r (W_ir u + W_hr h) then W_in u; half 1 = gate z then W_hn h
@@ -156,8 +187,9 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     DN[t + UM_NT * i] = dnv[i];
-    if (t + UM_NT * i < UM_NV) PV[t + UM_NT * i] = pvv[i];
+    if (t + UM_NT * i < (NEXT ? UM_NV_NEXT : UM_NV)) PV[t + UM_NT * i] = pvv[i];
   }
+  if constexpr (NEXT) PV[t + UM_NT * 4] = pvv[4];
   // ---- updates = sum_p num / sum_p den (records summed in order p = 0 .. P-1) ----
   f32x4 n0 = {0.f, 0.f, 0.f, 0.f}, n1 = n0;
 #pragma unroll
@@ -244,6 +276,7 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
   // ---- LN(h') -> X planes (thread = (row, 8 features); a row is 16 consecutive lanes) ----
   UmFrags<8> f2;
   um_load(f2, a.w2_p, 4, cb, half * 8, lane);   // MLP layer 2: K half of this wave
+  UmFrags<8> fp0, fp2, fk;                        // NEXT: predictor layer 1 / layer 2 (K half) / kernel distribution
   {
     const f32x4 v0 = *(const f32x4*)(Fn + ur * UM_FP + uc), v1 = *(const f32x4*)(Fn + ur * UM_FP + uc + 4);
     const float mu = sf_sum16(((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]))) / (float)UM_D;
@@ -273,9 +306,11 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
   // ---- x = h' + W2 hidden + b2: wave = (block, K half), halves meet in LDS ----
   UmFrags<4> fq;
   if (a.q_out) um_load(fq, a.q_w_p, 4, cb, half * 4, lane);
+  if constexpr (NEXT) um_load(fp0, a.pm_w0_p, 8, wave, 0, lane);   // (fm is dead: three fragment sets live at a time)
 #pragma unroll
   for (int r = 0; r < 16; ++r) g2[r] = 0.f;
   um_gemm(g2, f2, Hh, Hl, UM_HP, half * 8, lane);
+  if constexpr (NEXT) um_load(fp2, a.pm_w2_p, 4, cb, half * 8, lane);
   if (half == 1) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) EX[(cb * 2 * 16 + r) * 64 + lane] = g2[r];
@@ -300,6 +335,105 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
   }
   if (a.q_out == nullptr) return;
   __syncthreads();
+
+  if constexpr (NEXT) {
+    // ===== the slot prologue of the NEXT time step on the finished rows (rows are independent: no other workgroup is involved) =====
+    // noise of this thread's 8 features, requested now
+    f32x4 nz0 = {0.f, 0.f, 0.f, 0.f}, nz1 = nz0;
+    if (a.noise && rok) {
+      const float* np = a.noise + (long long)ub * a.noise_bs + (long long)un * UM_D + uc;
+      nz0 = *(const f32x4*)np;
+      nz1 = *(const f32x4*)(np + 4);
+    }
+    // ---- LN_p(x) -> X planes; the residual rows (LN_p(x) if norm_first, else x) -> Fn ----
+    {
+      const f32x4 v0 = *(const f32x4*)(Fp + ur * UM_FP + uc), v1 = *(const f32x4*)(Fp + ur * UM_FP + uc + 4);
+      const float mu = sf_sum16(((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]))) / (float)UM_D;
+      const f32x4 d0 = v0 - mu, d1 = v1 - mu;
+      const float var = sf_sum16(((d0[0] * d0[0] + d0[1] * d0[1]) + (d0[2] * d0[2] + d0[3] * d0[3])) +
+                                 ((d1[0] * d1[0] + d1[1] * d1[1]) + (d1[2] * d1[2] + d1[3] * d1[3]))) / (float)UM_D;
+      const float rs = 1.0f / sqrtf(var + a.ln_eps);
+      const f32x4 y0 = d0 * rs * *(const f32x4*)(PV + UV_PG + uc) + *(const f32x4*)(PV + UV_PBT + uc);
+      const f32x4 y1 = d1 * rs * *(const f32x4*)(PV + UV_PG + uc + 4) + *(const f32x4*)(PV + UV_PBT + uc + 4);
+      um_split4(Xh, Xl, ur * UM_DP + uc, y0);
+      um_split4(Xh, Xl, ur * UM_DP + uc + 4, y1);
+      *(f32x4*)(Fn + ur * UM_FP + uc) = a.pm_norm_first ? y0 : v0;
+      *(f32x4*)(Fn + ur * UM_FP + uc + 4) = a.pm_norm_first ? y1 : v1;
+    }
+    __syncthreads();
+    // ---- hidden = relu(W0 LN_p + b0): wave = hidden block ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g1[r] = 0.f;
+    um_gemm(g1, fp0, Xh, Xl, UM_DP, 0, lane);
+    um_load(fk, a.kd_w_p, 8, wave, 0, lane);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 32 * wave + 8 * g + 4 * kg;
+      const f32x4 bb = *(const f32x4*)(PV + UV_PB0 + c);
+      const f32x4 hv = {fmaxf(g1[4 * g] + bb[0], 0.f), fmaxf(g1[4 * g + 1] + bb[1], 0.f), fmaxf(g1[4 * g + 2] + bb[2], 0.f),
+                        fmaxf(g1[4 * g + 3] + bb[3], 0.f)};
+      um_split4(Hh, Hl, tok * UM_HP + c, hv);
+    }
+    __syncthreads();
+    // ---- lat = residual + W2 hidden + b2: wave = (block, K half), halves meet in LDS; lat -> X planes ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g2[r] = 0.f;
+    um_gemm(g2, fp2, Hh, Hl, UM_HP, half * 8, lane);
+    if (half == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) EX[(cb * 2 * 16 + r) * 64 + lane] = g2[r];
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 32 * cb + 8 * g + 4 * kg;
+        const f32x4 bb = *(const f32x4*)(PV + UV_PB2 + c), res = *(const f32x4*)(Fn + tok * UM_FP + c);
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (g2[4 * g + q] + EX[(cb * 2 * 16 + 4 * g + q) * 64 + lane]) + bb[q] + res[q];
+        um_split4(Xh, Xl, tok * UM_DP + c, v);
+      }
+    }
+    __syncthreads();
+    // ---- kernel distribution = Wkd lat + bkd: wave = 32 of its 2D columns; rows -> LDS (in place of the hidden planes) and kdist_out ----
+    float* KD = (float*)Hh;   // [32][UM_KP]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g1[r] = 0.f;
+    um_gemm(g1, fk, Xh, Xl, UM_DP, 0, lane);
+    {
+      const int row = row0 + tok;
+      const int b = min(row, a.R - 1) / a.N, n = min(row, a.R - 1) - b * a.N;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 32 * wave + 8 * g + 4 * kg;
+        const f32x4 bb = *(const f32x4*)(PV + UV_KB + c);
+        const f32x4 v = {g1[4 * g] + bb[0], g1[4 * g + 1] + bb[1], g1[4 * g + 2] + bb[2], g1[4 * g + 3] + bb[3]};
+        *(f32x4*)(KD + tok * UM_KP + c) = v;
+        if (a.kdist_out && row < a.R) *(f32x4*)(a.kdist_out + (long long)b * a.kdist_bs + (long long)n * 2 * UM_D + c) = v;
+      }
+    }
+    __syncthreads();
+    // ---- slots = mu + noise * exp(0.5 logvar)  (thread = (row, 8 features)); the rows replace x for the q projection below ----
+    {
+      const f32x4 m0 = *(const f32x4*)(KD + ur * UM_KP + uc), m1 = *(const f32x4*)(KD + ur * UM_KP + uc + 4);
+      const f32x4 l0 = *(const f32x4*)(KD + ur * UM_KP + UM_D + uc), l1 = *(const f32x4*)(KD + ur * UM_KP + UM_D + uc + 4);
+      f32x4 v0 = m0, v1 = m1;
+      if (a.noise) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v0[q] += nz0[q] * expf(l0[q] * 0.5f);
+          v1[q] += nz1[q] * expf(l1[q] * 0.5f);
+        }
+      }
+      *(f32x4*)(Fp + ur * UM_FP + uc) = v0;
+      *(f32x4*)(Fp + ur * UM_FP + uc + 4) = v1;
+      if (rok) {
+        *(f32x4*)(a.nx_slots + (long long)urow * UM_D + uc) = v0;
+        *(f32x4*)(a.nx_slots + (long long)urow * UM_D + uc + 4) = v1;
+      }
+    }
+  }
 
   // ---- q = LN_q(x) Wq^T ----
   {

@@ -16,9 +16,15 @@
 // MLP 16.3 / 18.1, q 19.9 us; 23 us per launch between events against 33 us for the VALU kernel.
 #include "slot_update_body.h"
 
+//
+// NEXT form (round 4): on a time step's LAST iteration the same workgroups go on with the slot prologue of the following step -- residual-MLP
+// predictor, kernel distribution, sampling, and the q of its first iteration from the sampled slots (savi.py:393-402; the stand-alone
+// sa_slot_prologue_kernel of slot_attn.hip: 26-30 us of thread-per-output products) -- as three more streamed-fragment products: rows are
+// independent, so nothing but the launch and its round trips goes away.
+template <bool NEXT>
 __global__ __launch_bounds__(UM_NT) void sa_slot_update_mfma_kernel(UmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float um_lds[];
-  um_body(a, um_lds, blockIdx.x);
+  um_body<NEXT>(a, um_lds, blockIdx.x);
 }
 
 bool sf_slot_update_mfma_ok(int D, int H, int P) { return D == UM_D && H == UM_H && P >= 1 && P <= 64; }
@@ -29,22 +35,37 @@ int sf_slot_update_mfma_ex(const float* part_num, const float* part_den, int P, 
                            const void* gru_hh_p, const float* gru_b_ih, const float* gru_b_hh, const float* ln_g, const float* ln_b,
                            const void* w1_p, const float* b1, const void* w2_p, const float* b2, float* slots_out, float* out2,
                            long long out2_bs, const float* q_ln_g, const float* q_ln_b, const void* q_w_p, float* q_out, int B, int N,
-                           float ln_eps, hipStream_t st) {
+                           float ln_eps, hipStream_t st, const SfNextStep* next) {
   SF_REQUIRE(part_num && part_den && slots_prev && slots_out && gru_ih_p && gru_hh_p && gru_b_ih && gru_b_hh && ln_g && ln_b && w1_p &&
                  b1 && w2_p && b2, "sf_slot_update_mfma_ex: null pointer");
+  SF_REQUIRE(!next || (q_out && next->pm_ln_g && next->pm_ln_b && next->pm_w0_p && next->pm_b0 && next->pm_w2_p && next->pm_b2 && next->kd_w_p &&
+                       next->kd_b && next->slots && next->slots != slots_out),
+             "sf_slot_update_mfma_ex: the next-step form needs q_out, the predictor / kernel-distribution operands and its own slot buffer");
   SF_REQUIRE(q_out == nullptr || (q_ln_g && q_ln_b && q_w_p), "q projection requested without its weights");
   SF_REQUIRE(N >= 1 && P >= 1 && P <= 64, "bad slot shape");
   if (B == 0) return 0;
-  static_assert(UM_LDS <= 160 * 1024, "slot update: LDS budget");
-  SF_TRY(sf_ensure_dyn_lds((const void*)sa_slot_update_mfma_kernel, (size_t)(UM_LDS)));
+  static_assert(UM_LDS_NEXT <= 160 * 1024, "slot update: LDS budget");
+  SF_TRY(next ? sf_ensure_dyn_lds((const void*)sa_slot_update_mfma_kernel<true>, (size_t)(UM_LDS_NEXT))
+              : sf_ensure_dyn_lds((const void*)sa_slot_update_mfma_kernel<false>, (size_t)(UM_LDS)));
   UmArgs a;
+  memset(&a, 0, sizeof(a));
   a.part_num = part_num; a.part_den = part_den; a.P = P; a.slots_prev = slots_prev;
   a.w_ih_p = (const uint4*)gru_ih_p; a.w_hh_p = (const uint4*)gru_hh_p; a.b_ih = gru_b_ih; a.b_hh = gru_b_hh; a.ln_g = ln_g; a.ln_b = ln_b;
   a.w1_p = (const uint4*)w1_p; a.b1 = b1; a.w2_p = (const uint4*)w2_p; a.b2 = b2; a.slots_out = slots_out; a.out2 = out2; a.out2_bs = out2_bs;
   a.q_ln_g = q_ln_g; a.q_ln_b = q_ln_b; a.q_w_p = (const uint4*)q_w_p; a.q_out = q_out; a.R = B * N; a.N = N; a.ln_eps = ln_eps;
   const int R = B * N;
-  sf_prof_begin(SF_K_SA_UPDATE, st, 2.0 * R * ((double)6 * UM_D * UM_D + 2.0 * UM_D * UM_H + (q_out ? (double)UM_D * UM_D : 0.0)));
-  hipLaunchKernelGGL(sa_slot_update_mfma_kernel, dim3((R + UM_ROWS - 1) / UM_ROWS), dim3(UM_NT), UM_LDS, st, a);
+  if (next) {
+    a.pm_ln_g = next->pm_ln_g; a.pm_ln_b = next->pm_ln_b; a.pm_w0_p = (const uint4*)next->pm_w0_p; a.pm_b0 = next->pm_b0;
+    a.pm_w2_p = (const uint4*)next->pm_w2_p; a.pm_b2 = next->pm_b2; a.pm_norm_first = next->norm_first; a.kd_w_p = (const uint4*)next->kd_w_p;
+    a.kd_b = next->kd_b; a.noise = next->noise; a.noise_bs = next->noise_bs; a.kdist_out = next->kdist_out; a.kdist_bs = next->kdist_bs;
+    a.nx_slots = next->slots;
+  }
+  sf_prof_begin(SF_K_SA_UPDATE, st,
+                2.0 * R * ((double)6 * UM_D * UM_D + 2.0 * UM_D * UM_H + (q_out ? (double)UM_D * UM_D : 0.0) + (next ? 6.0 * UM_D * UM_D : 0.0)));
+  if (next)
+    hipLaunchKernelGGL(sa_slot_update_mfma_kernel<true>, dim3((R + UM_ROWS - 1) / UM_ROWS), dim3(UM_NT), UM_LDS_NEXT, st, a);
+  else
+    hipLaunchKernelGGL(sa_slot_update_mfma_kernel<false>, dim3((R + UM_ROWS - 1) / UM_ROWS), dim3(UM_NT), UM_LDS, st, a);
   sf_prof_end(SF_K_SA_UPDATE, st);
   SF_CHECK_LAUNCH();
   return 0;

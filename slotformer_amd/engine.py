@@ -334,6 +334,15 @@ def encoder_plan(m):
         s.pm_w0, s.pm_b0 = plan.dp(base.mlp[0].weight), plan.dp(base.mlp[0].bias)
         s.pm_w2, s.pm_b2 = plan.dp(base.mlp[2].weight), plan.dp(base.mlp[2].bias)
         s.pm_w0_t, s.pm_w2_t = plan.dp(tr(base.mlp[0].weight)), plan.dp(tr(base.mlp[2].weight))
+        if s.sa_mlp_w1_p and s.kd_mode == 1 and not rnn and base.mlp[0].weight.is_cuda and tuple(base.mlp[0].weight.shape) == (256, 128):
+            # fragment-ordered copies for the next step's prologue at the tail of the matrix-core slot update (slot_update_mfma.hip, NEXT form)
+            st = torch.cuda.current_stream().cuda_stream
+            for name, w in (('pm_w0_p', base.mlp[0].weight), ('pm_w2_p', base.mlp[2].weight), ('kd_w0_p', kd[0].weight)):
+                n, k = w.shape
+                buf = torch.empty(lib().sf_packed_linear_bytes(n, k), dtype=torch.uint8, device=w.device)
+                check(lib().sf_pack_linear_weights(plan.dp(w), buf.data_ptr(), n, k, st))
+                plan.keep.append(buf)
+                setattr(s, name, buf.data_ptr())
     if rnn:
         s.pred_hidden = pred.hidden_size
         s.lstm_w_ih, s.lstm_w_hh = plan.dp(pred.rnn.weight_ih_l0), plan.dp(pred.rnn.weight_hh_l0)

@@ -658,6 +658,41 @@ def test_forked_encode_is_bit_identical(dev, name):
             assert torch.equal(post, ref[0])
 
 
+@torch.no_grad()
+def test_next_step_prologue_at_the_tail_of_the_slot_update(dev):
+    """sf_set_encode_fuse_next: the slot prologue of step t + 1 (ResidualMLPPredictor, kernel_dist, sampling, first q; savi.py:393-402) as the tail of
+    step t's last matrix-core slot update (1, the default) against the stand-alone launch on every step (0: fp32 thread-per-output products).  The two
+    differ by split-bf16 rounding only; both stay inside the fixture tolerance (test_savi_golden runs the default).  B = 1 / 5 / 32 (ragged last
+    workgroup: 7 and 35 rows), with and without injected noise, kernel_dist and the post slots compared."""
+    from slotformer_amd import engine, _lib
+    from slotformer_amd.base_slots import build_model
+    lib = _lib.lib()
+    cfg = gu.C2_SAVI
+    torch.manual_seed(43)
+    m = build_model(gu.ParamsView(cfg)).eval().to(dev)
+    m.testing = True
+    N, D = cfg['slot_dict']['num_slots'], cfg['slot_dict']['slot_size']
+    old = lib.sf_get_encode_fuse_next()
+    try:
+        for B, T, with_noise in ((5, 4, True), (1, 3, True), (32, 3, False)):
+            img = gu.seeded_img(B, T, 128, seed=91 + B).to(dev)
+            noise = engine.kernel_noise(m, gu.seeded_normal((B, T, N, D), 92).to(dev), B, T, dev) if with_noise else torch.zeros(B, T, N, D, device=dev)
+            outs = {}
+            for mode in (0, 1):
+                lib.sf_set_encode_fuse_next(mode)
+                outs[mode] = engine.savi_encode(m, img, noise=noise, want_attn=True, ws_slot=('fn', mode), side_stream=None)
+                torch.cuda.synchronize()
+            post0, kd0, at0 = outs[0]
+            post1, kd1, at1 = outs[1]
+            assert not torch.equal(post0[:, 1:], post1[:, 1:]), 'the two settings ran the same kernels: nothing was fused'
+            assert torch.equal(post0[:, 0], post1[:, 0]) and torch.equal(kd0[:, 0], kd1[:, 0])   # step 0: the stand-alone prologue either way
+            assert rel_err(post1, post0.cpu()) < 2e-5, (B, T, rel_err(post1, post0.cpu()))
+            assert rel_err(kd1, kd0.cpu()) < 2e-5, (B, T, rel_err(kd1, kd0.cpu()))
+            assert rel_err(at1, at0.cpu()) < 2e-5
+    finally:
+        lib.sf_set_encode_fuse_next(old)
+
+
 @pytest.mark.parametrize('name', ['C2', 'C5'])
 @torch.no_grad()
 def test_interleaved_encode_is_bit_identical(dev, name):
