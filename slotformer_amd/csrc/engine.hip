@@ -814,8 +814,9 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
   const void* gru_ih_p = fold ? m->sa_fold_gru_ih_p : m->sa_gru_ih_p;
 
   // slot update on the matrix cores (slot_update_mfma.hip) when the packed copies are there (slot size 128); otherwise the VALU kernel
-  const bool su_mfma = sf_get_precision() >= 1 && gru_ih_p && m->sa_gru_hh_p && m->sa_mlp_w1_p && m->sa_mlp_w2_p &&
-                       q_w_p && sf_slot_update_mfma_ok(D, Hm, P);
+  const bool su_packed = sf_get_precision() >= 1 && gru_ih_p && m->sa_gru_hh_p && m->sa_mlp_w1_p && m->sa_mlp_w2_p && q_w_p;
+  const bool su_mfma = su_packed && sf_slot_update_mfma_ok(D, Hm, P);
+  const bool su_wide = su_packed && sf_slot_update_wide_ok(D, Hm, P);   // slot size 192 (slot_update_wide.hip)
   // INTERLEAVED order (round 4; one stream, the CLEVRER-shaped configuration: folded Slot Attention at width 128, matrix-core slot update, one
   // chunk of frames): the image features of step t + 1 are computed INSIDE the slot branch of step t -- its first convolution behind the
   // prologue, and every following fragment-weight convolution as ONE launch with a slot update (the update's seven workgroups ride as the first
@@ -1034,6 +1035,16 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
                                         m->mlp_ln_b, m->sa_mlp_w1_p, m->mlp_b1, m->sa_mlp_w2_p, m->mlp_b2, s_out,
                                         last_it ? post_slots + (long long)t * N * D : nullptr, (long long)T * N * D, m->sa_q_ln_g,
                                         m->sa_q_ln_b, q_w_p, last_it ? nullptr : q, B, N, ln_eps, st));
+        float* tmp = s_in;
+        s_in = s_out;
+        s_out = tmp;
+        continue;
+      }
+      if (su_wide) {
+        SF_TRY(sf_slot_update_wide_ex(pnum, pden, P, s_in, gru_ih_p, m->sa_gru_hh_p, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g, m->mlp_ln_b,
+                                      m->sa_mlp_w1_p, m->mlp_b1, m->sa_mlp_w2_p, m->mlp_b2, s_out,
+                                      last_it ? post_slots + (long long)t * N * D : nullptr, (long long)T * N * D, m->sa_q_ln_g, m->sa_q_ln_b,
+                                      q_w_p, last_it ? nullptr : q, B, N, ln_eps, st));
         float* tmp = s_in;
         s_in = s_out;
         s_out = tmp;

@@ -62,6 +62,12 @@ int sf_slot_update_mfma_ex(const float* part_num, const float* part_den, int P, 
                            const void* w1_p, const float* b1, const void* w2_p, const float* b2, float* slots_out, float* out2,
                            long long out2_bs, const float* q_ln_g, const float* q_ln_b, const void* q_w_p, float* q_out, int B, int N,
                            float ln_eps, hipStream_t st, const SfNextStep* next = nullptr);
+// the same update at slot size 192 / slot MLP 384 (slot_update_wide.hip); operands as for sf_slot_update_mfma_ex
+bool sf_slot_update_wide_ok(int D, int H, int P);
+int sf_slot_update_wide_ex(const float* part_num, const float* part_den, int P, const float* slots_prev, const void* gru_ih_p, const void* gru_hh_p,
+                           const float* gru_b_ih, const float* gru_b_hh, const float* ln_g, const float* ln_b, const void* w1_p, const float* b1,
+                           const void* w2_p, const float* b2, float* slots_out, float* out2, long long out2_bs, const float* q_ln_g,
+                           const float* q_ln_b, const void* q_w_p, float* q_out, int B, int N, float ln_eps, hipStream_t st);
 int sf_slot_update_ex(const float* part_num, const float* part_den, int P, const float* slots_prev,
                       const float* gru_w_ih, const float* gru_w_hh, const float* gru_b_ih, const float* gru_b_hh,
                       const float* ln_g, const float* ln_b, const float* mlp_w1, const float* mlp_b1, const float* mlp_w2,

@@ -77,7 +77,12 @@ extern "C" int sf_slot_update_packed_f32(const float* part_num, const float* par
                                          const float* ln_b, const void* mlp_w1_packed, const float* mlp_b1, const void* mlp_w2_packed,
                                          const float* mlp_b2, float* slots_out, const float* q_ln_g, const float* q_ln_b,
                                          const void* q_w_packed, float* q_out, int B, int N, int D, int H, float ln_eps, void* stream) {
-  SF_REQUIRE(sf_slot_update_mfma_ok(D, H, P), "sf_slot_update_packed_f32: slot size 128, slot MLP size 256 and at most 64 partial records");
+  if (sf_slot_update_wide_ok(D, H, P))
+    return sf_slot_update_wide_ex(part_num, part_den, P, slots_prev, gru_ih_packed, gru_hh_packed, gru_b_ih, gru_b_hh, ln_g, ln_b, mlp_w1_packed,
+                                  mlp_b1, mlp_w2_packed, mlp_b2, slots_out, nullptr, 0, q_ln_g, q_ln_b, q_w_packed, q_out, B, N, ln_eps,
+                                  (hipStream_t)stream);
+  SF_REQUIRE(sf_slot_update_mfma_ok(D, H, P),
+             "sf_slot_update_packed_f32: slot size 128 with slot MLP size 256, or 192 with 384, and at most 64 partial records");
   return sf_slot_update_mfma_ex(part_num, part_den, P, slots_prev, gru_ih_packed, gru_hh_packed, gru_b_ih, gru_b_hh, ln_g, ln_b, mlp_w1_packed,
                                 mlp_b1, mlp_w2_packed, mlp_b2, slots_out, nullptr, 0, q_ln_g, q_ln_b, q_w_packed, q_out, B, N, ln_eps,
                                 (hipStream_t)stream);

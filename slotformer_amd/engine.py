@@ -271,8 +271,8 @@ def encoder_plan(m):
     s.mlp_ln_g, s.mlp_ln_b = plan.dp(sa.mlp[0].weight), plan.dp(sa.mlp[0].bias)
     s.mlp_w1, s.mlp_b1 = plan.dp(tr(sa.mlp[1].weight)), plan.dp(sa.mlp[1].bias)
     s.mlp_w2, s.mlp_b2 = plan.dp(tr(sa.mlp[3].weight)), plan.dp(sa.mlp[3].bias)
-    if m.slot_size == 128 and m.slot_mlp_size == 256 and sa.gru.weight_ih.is_cuda:
-        # fragment-ordered split-bf16 copies for the matrix-core slot update (slot_update_mfma.hip)
+    if (m.slot_size, m.slot_mlp_size) in ((128, 256), (192, 384)) and sa.gru.weight_ih.is_cuda:
+        # fragment-ordered split-bf16 copies for the matrix-core slot update (slot_update_mfma.hip; slot_update_wide.hip at 192)
         st = torch.cuda.current_stream().cuda_stream
         for name, w in (('sa_gru_ih_p', sa.gru.weight_ih), ('sa_gru_hh_p', sa.gru.weight_hh), ('sa_mlp_w1_p', sa.mlp[1].weight),
                         ('sa_mlp_w2_p', sa.mlp[3].weight), ('sa_q_w_p', sa.project_q[1].weight)):
@@ -296,7 +296,7 @@ def encoder_plan(m):
                 check(lib().sf_pack_linear_weights(plan.dp(w), buf.data_ptr(), n, k, st))
                 plan.keep.append(buf)
                 setattr(s, name, buf.data_ptr())
-        if mq.is_cuda and m.slot_size == 128:
+        if mq.is_cuda and (m.slot_size, m.slot_mlp_size) in ((128, 256), (192, 384)):
             st = torch.cuda.current_stream().cuda_stream
             for name, w in (('sa_fold_q_w_p', mq), ('sa_fold_gru_ih_p', gih)):
                 n, k = w.shape

@@ -267,12 +267,13 @@ def test_slot_attn_iteration(dev, B, N, D, HW):
     close(out, ref)
 
 
-@pytest.mark.parametrize('B,N,P', [(32, 7, 16), (5, 7, 16), (9, 8, 16), (1, 3, 4), (64, 8, 24)])
-def test_slot_update_on_the_matrix_cores(dev, B, N, P):
-    """sa_slot_update_mfma_kernel (split-bf16 MFMA, 32 rows per workgroup) against the torch-CPU restatement of
-    savi.py:95-100 + project_q, and against the VALU kernel on the same inputs; ragged row counts (B*N % 32 != 0)."""
+@pytest.mark.parametrize('B,N,P,D', [(32, 7, 16, 128), (5, 7, 16, 128), (9, 8, 16, 128), (1, 3, 4, 128), (64, 8, 24, 128),
+                                     (32, 6, 16, 192), (5, 6, 16, 192), (16, 6, 16, 192), (1, 3, 4, 192), (3, 7, 9, 192), (40, 8, 64, 192)])
+def test_slot_update_on_the_matrix_cores(dev, B, N, P, D):
+    """sa_slot_update_mfma_kernel (slot size 128) / sa_slot_update_wide_kernel (192) -- split-bf16 MFMA, 32 rows per workgroup -- against the
+    torch-CPU restatement of savi.py:95-100 + project_q, and against the VALU kernel on the same inputs; ragged row counts (B*N % 32 != 0)."""
     from slotformer_amd import ops
-    D, H = 128, 256
+    H = 2 * D
     pn, pd = rnd(B, P, N, D, seed=1), 0.5 + rnd(B, P, N, seed=2).abs()
     slots = rnd(B, N, D, seed=4)
     upd = pn.sum(1) / pd.sum(1).unsqueeze(-1)
