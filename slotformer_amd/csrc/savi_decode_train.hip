@@ -86,6 +86,7 @@ namespace {
 struct DecWs {
   float* act[9];   // act[0]: broadcast input, act[l+1]: output of transposed conv l (post-ReLU)
   float *dec, *ga, *gb, *wout_t, *partial, *dtab;
+  float* wf;       // fragment-ordered copy of a stride-1 64 -> 64 layer's weights (forward, then backward-data) for conv_rows4.hip
   size_t total;
 };
 size_t pad64(size_t n) { return (n + 63) & ~(size_t)63; }
@@ -122,8 +123,18 @@ DecWs carve(const sf_savi_decoder* m, int F, float* base) {
     w.partial = take(pf);
   }
   w.dtab = take((size_t)m->dec_res * m->dec_res * m->slot_size);
+  w.wf = take((sf_conv_frag_bytes(64, 64, 5) + 3) / 4);
   w.total = off;
   return w;
+}
+
+// stride-1 5x5 64 -> 64 layer on a 64-pixel-wide map: the 4-row-tile kernel on a fragment-ordered copy of the OHWI weights (conv_rows4.hip: the same
+// products in the same order as the halo kernel behind sf_conv2d_nhwc_f32); 1 = not that shape / arithmetic mode
+int conv5_rows4(const float* in, const float* w_ohwi, float* w_frag, const float* bias, const float* add, float* out, int R, int h, int cin, int cout,
+                int ks, int relu, hipStream_t st) {
+  if (!w_frag || h != 64 || sf_get_precision() != 1 || !sf_conv_frag_bytes(cout, cin, ks)) return 1;
+  SF_TRY(sf_pack_conv_frag_weights(w_ohwi, w_frag, cout, cin, ks, st));
+  return sf_conv5x5_rows4_ex(in, w_frag, bias, add, out, R, h, h, cin, cout, ks, relu, st);
 }
 
 int check(const sf_savi_decoder* m, int F) {
@@ -160,10 +171,14 @@ int sf_savi_decode_train_fwd_f32(const sf_savi_decoder* m, const float* slots, f
   SF_TRY(sf_slot_broadcast_f32(slots, m->pos_table, w.act[0], R, m->dec_res * m->dec_res, D, st));
   int hin = m->dec_res;
   for (int l = 0; l < m->dec_layers; ++l) {
-    if (m->dec_strides[l] == 1 && m->deconv_w_flipped[l])   // = convolution with the flipped kernel (halo-resident 5x5 path)
-      SF_TRY(sf_conv2d_nhwc_f32(w.act[l], m->deconv_w_flipped[l], m->deconv_b[l], nullptr, w.act[l + 1], R, hin, hin,
-                                m->dec_channels[l], m->dec_channels[l + 1], m->dec_ks, 1, st));
-    else
+    if (m->dec_strides[l] == 1 && m->deconv_w_flipped[l]) {   // = convolution with the flipped kernel (4-row-tile / halo-resident 5x5 paths)
+      int rc = conv5_rows4(w.act[l], m->deconv_w_flipped[l], w.wf, m->deconv_b[l], nullptr, w.act[l + 1], R, hin, m->dec_channels[l],
+                           m->dec_channels[l + 1], m->dec_ks, 1, st);
+      if (rc == 1)
+        rc = sf_conv2d_nhwc_f32(w.act[l], m->deconv_w_flipped[l], m->deconv_b[l], nullptr, w.act[l + 1], R, hin, hin, m->dec_channels[l],
+                                m->dec_channels[l + 1], m->dec_ks, 1, st);
+      SF_TRY(rc);
+    } else
       SF_TRY(sf_conv_transpose2d_nhwc_f32(w.act[l], m->deconv_w[l], m->deconv_b[l], w.act[l + 1], R, hin, hin, m->dec_channels[l],
                                           m->dec_channels[l + 1], m->dec_ks, m->dec_strides[l], 1, st));
     hin *= m->dec_strides[l];
@@ -223,8 +238,13 @@ int sf_savi_decode_train_bwd_f32(const sf_savi_decoder* m, const float* const* d
     }
     // adjoint of the transposed conv = strided conv of the gradient; its output is gated by the ReLU of the layer below
     // (act[0] is the broadcast input: no ReLU there)
-    SF_TRY(sf_conv2d_nhwc_strided_ex(g, deconv_w_bwd[l], nullptr, o, R, h, h, m->dec_channels[l + 1], m->dec_channels[l], m->dec_ks,
-                                     m->dec_strides[l], 0, st, l >= 1 ? w.act[l] : nullptr));
+    int rc = 1;
+    if (m->dec_strides[l] == 1 && l >= 1)
+      rc = conv5_rows4(g, deconv_w_bwd[l], w.wf, nullptr, w.act[l], o, R, h, m->dec_channels[l + 1], m->dec_channels[l], m->dec_ks, 2, st);
+    if (rc == 1)
+      rc = sf_conv2d_nhwc_strided_ex(g, deconv_w_bwd[l], nullptr, o, R, h, h, m->dec_channels[l + 1], m->dec_channels[l], m->dec_ks,
+                                     m->dec_strides[l], 0, st, l >= 1 ? w.act[l] : nullptr);
+    SF_TRY(rc);
     h /= m->dec_strides[l];
     float* t = g;
     g = o;

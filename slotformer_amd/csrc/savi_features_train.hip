@@ -350,6 +350,7 @@ struct FDims {
 struct FWs {
   float* wp[8];    // forward weights OHWI (layers >= 1)
   float* wb[8];    // backward-data weights (layers >= 1)
+  float* wf[8];    // fragment-ordered copy of the weights in use (forward, then backward-data) for the 4-row-tile kernel (conv_rows4.hip)
   float *table, *a[8], *xn, *h1, *g1, *ga, *gb, *w1t, *w2t, *dtab, *dw0, *partial;
   size_t total;
 };
@@ -366,6 +367,7 @@ FWs carve(const FDims& d, float* base) {
   for (int i = 1; i < d.L; ++i) {
     w.wp[i] = take(wsz);
     w.wb[i] = take(wsz);
+    w.wf[i] = take((sf_conv_frag_bytes((int)C, (int)C, 5) + 3) / 4);
   }
   w.table = take((size_t)4096 * C);
   for (int i = 0; i < d.L; ++i) w.a[i] = take(M * C);
@@ -400,6 +402,16 @@ int check(const sf_savi_features* m, FDims& d, int F) {
 int gemm(const float* A, const float* W, const float* bias, float* C, long long M, int N, int K, int relu, hipStream_t st) {
   return sf_linear_ex(A, sf_rows(K), W, bias, nullptr, nullptr, 0.f, nullptr, sf_rows(N), 0, C, sf_rows(N), (int)M, N, K, relu, st);
 }
+// 5x5 64 -> 64 convolution on the 64 x 64 grid: the 4-row-tile kernel on a fragment-ordered copy of the OHWI weights (conv_rows4.hip; the same
+// products in the same order as the halo kernel behind sf_conv2d_nhwc_f32, which stays the fallback for the arithmetic modes rows4 does not cover)
+int conv5(const float* in, const float* w_ohwi, float* w_frag, const float* bias, const float* add, float* out, int F, int C, int relu, hipStream_t st) {
+  if (w_frag && sf_get_precision() == 1 && sf_conv_frag_bytes(C, C, 5)) {
+    SF_TRY(sf_pack_conv_frag_weights(w_ohwi, w_frag, C, C, 5, st));
+    const int rc = sf_conv5x5_rows4_ex(in, w_frag, bias, add, out, F, 64, 64, C, C, 5, relu, st);
+    if (rc != 1) return rc;
+  }
+  return sf_conv2d_nhwc_f32(in, w_ohwi, bias, add, out, F, 64, 64, C, C, 5, relu, st);
+}
 }  // namespace
 
 extern "C" {
@@ -424,7 +436,7 @@ int sf_savi_features_train_fwd_f32(const sf_savi_features* m, const float* img, 
   SF_TRY(sf_conv2d_nchw_in_f32(img, frame_stride, m->conv_w[0], m->conv_b[0], nullptr, w.a[0], F, 3, d.res, d.res, C, 5, d.stride, 1, st));
   for (int i = 1; i < L; ++i) {
     const bool last = i == L - 1;
-    SF_TRY(sf_conv2d_nhwc_f32(w.a[i - 1], w.wp[i], m->conv_b[i], last ? w.table : nullptr, w.a[i], F, 64, 64, C, C, 5, last ? 0 : 1, st));
+    SF_TRY(conv5(w.a[i - 1], w.wp[i], w.wf[i], m->conv_b[i], last ? w.table : nullptr, w.a[i], F, C, last ? 0 : 1, st));
   }
   SF_TRY(sf_layernorm_ex(w.a[L - 1], sf_rows(C), m->ln_g, m->ln_b, w.xn, sf_rows(C), (int)d.M, C, 1e-5f, st));
   SF_TRY(gemm(w.xn, m->fc1_w, m->fc1_b, w.h1, d.M, d.Hd, C, 1, st));
@@ -463,7 +475,7 @@ int sf_savi_features_train_bwd_f32(const sf_savi_features* m, const float* img, 
     // data gradient: convolution with the flipped / transposed kernel, then the ReLU of the layer below
     hipLaunchKernelGGL(pack_conv_bwd_kernel, dim3((C * C * 25 + 255) / 256), dim3(256), 0, st, m->conv_w[i], w.wb[i], C, C, 5);
     SF_CHECK_LAUNCH();
-    SF_TRY(sf_conv2d_nhwc_f32(cur, w.wb[i], nullptr, w.a[i - 1], nxt, F, 64, 64, C, C, 5, 2, st));   // relu = 2: gated by a[i-1] > 0
+    SF_TRY(conv5(cur, w.wb[i], w.wf[i], nullptr, w.a[i - 1], nxt, F, C, 2, st));   // relu = 2: gated by a[i-1] > 0
     float* t = cur;
     cur = nxt;
     nxt = t;
