@@ -169,7 +169,7 @@ int sf_slot_update_f32(const float* part_num, const float* part_den, int P, cons
                        const float* mlp_b1, const float* mlp_w2, const float* mlp_b2, float* slots_out, int B,
                        int N, int D, int H, float ln_eps, void* stream);
 
-/* The same slot update on the matrix cores (split-bf16 products, slot size D = 128 and slot MLP size H = 256 only), plus the
+/* The same slot update on the matrix cores (split-bf16 products; slot size D = 128 with slot MLP size H = 256, or D = 192 with H = 384), plus the
  * next iteration's q = project_q(slots_out) (savi.py:45-48,79) when q_out is not NULL.  The five matrices are
  * sf_pack_linear_weights copies of the TORCH-layout weights: GRUCell weight_ih / weight_hh [3D, D], mlp[1].weight [H, D],
  * mlp[3].weight [D, H], project_q[1].weight [D, D]. */
