@@ -26,7 +26,10 @@ namespace {
 constexpr int TK_NT = 256, TK_D = 256, TK_F = 1024, TK_NHB = TK_F / 32, TK_WGT = 128;   // threads, widths, hidden blocks, tokens per workgroup
 constexpr int TK_STAGE = 64 * 1024;                                                      // bytes of a stage: 32 + 32 fragments of 1 KB
 constexpr int TK_NST = TK_NHB + 1;                                                       // stage j = W1 block j (j < 32) + W2 block j - 1 (j > 0)
-constexpr size_t TK_LDS = (size_t)2 * TK_STAGE + (size_t)(TK_F + 32) * 4;                // ring + lin1 bias (+ 32 zeros for the idle block)
+constexpr int TK_RP = 1024 + 16;                                                         // byte pitch of a staged f32 row (bank-spread for the 16-byte column pieces)
+constexpr size_t TK_ROWS_LDS = (size_t)TK_WGT * TK_RP;                                   // the workgroup's rows staged whole (prologue: x2, epilogue: y) over the ring
+constexpr size_t TK_LDS = TK_ROWS_LDS + (size_t)(TK_F + 32) * 4;                         // ring (128 KB) / staged rows (130 KB) + lin1 bias (+ 32 zeros for the idle block)
+static_assert(TK_ROWS_LDS >= (size_t)2 * TK_STAGE && TK_LDS <= 160 * 1024, "LDS budget");
 
 struct TokArgs {
   const float* x2;
@@ -91,7 +94,8 @@ __device__ long long tk_ts[8];   // phase cycles of workgroup 0, wave 0 (SF_TOK_
 __global__ __launch_bounds__(TK_NT) void ffn_tok_kernel(TokArgs A) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) char tk_lds[];
-  float* B1 = (float*)(tk_lds + 2 * TK_STAGE);
+  float* B1 = (float*)(tk_lds + TK_ROWS_LDS);
+  TKS(const long long w_entry = wall_clock64();)
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int n = lane & 31, h = lane >> 5;
@@ -109,18 +113,28 @@ __global__ __launch_bounds__(TK_NT) void ffn_tok_kernel(TokArgs A) {
 #pragma unroll
     for (int f = 0; f < 16; ++f) stage_piece(hb, f, hb & 1);
   };
-  stage_load(0);
+  // ---- the workgroup's rows, whole (one wave-instruction = one 1 KB row, global -> LDS), into the ring's space; lin1's bias behind it ----
+  char* rows = tk_lds + (size_t)(wave * 32) * TK_RP;   // this wave's 32 rows
+  {
+    const int r0 = blockIdx.x * TK_WGT + wave * 32;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      const char* src = (const char*)(A.x2 + (long long)min(r0 + r, M - 1) * TK_D) + lane * 16;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)(rows + r * TK_RP), 16, 0, 0);
+    }
+  }
   *(f32x4*)(B1 + 4 * t) = *(const f32x4*)(A.b1 + 4 * t);
   if (t < 8) *(f32x4*)(B1 + TK_F + 4 * t) = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();   // (drains the wave's own row requests; the rows are read by the wave that requested them)
   // ---- LN2 of the wave's 32 tokens: lane (token n, half h) holds channels 16 ks + 8 h .. + 7 of every k-step -> B-operand fragments ----
   bf16x8 xh[16], xl[16];
   {
-    const float* xr = A.x2 + (long long)tokc * TK_D + 8 * h;
+    const char* xr = rows + n * TK_RP + 32 * h;
     f32x4 v[16][2];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      v[ks][0] = *(const f32x4*)(xr + 16 * ks);
-      v[ks][1] = *(const f32x4*)(xr + 16 * ks + 4);
+      v[ks][0] = *(const f32x4*)(xr + 64 * ks);
+      v[ks][1] = *(const f32x4*)(xr + 64 * ks + 16);
     }
     float s = 0.f;
 #pragma unroll
@@ -147,6 +161,8 @@ __global__ __launch_bounds__(TK_NT) void ffn_tok_kernel(TokArgs A) {
       xl[ks] = cat8(l0, l1);
     }
   }
+  __syncthreads();   // every wave has its fragments: the staged rows make way for the weight ring
+  stage_load(0);
   f32x16 Y[8];
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob)
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(TK_NT) void ffn_tok_kernel(TokArgs A) {
     const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
     hh[0] = hh[1] = hl[0] = hl[1] = z8;
   }
-  TKS(long long c_bar = 0, c_p1 = 0, c_p2 = 0; const long long c_start = __builtin_readcyclecounter();)
+  TKS(long long c_bar = 0, c_p1 = 0, c_p2 = 0; const long long c_start = __builtin_readcyclecounter(); const long long w_start = wall_clock64();)
   for (int j = 0; j < TK_NST; ++j) {
     TKS(const long long c0 = __builtin_readcyclecounter();)
     __syncthreads();   // stage j has landed (the compiler drains vmcnt before the barrier); every wave is done with stage j - 1
@@ -251,20 +267,40 @@ __global__ __launch_bounds__(TK_NT) void ffn_tok_kernel(TokArgs A) {
     hh[0] = nh[0]; hh[1] = nh[1]; hl[0] = nl[0]; hl[1] = nl[1];
     TKS(const long long c3 = __builtin_readcyclecounter(); c_bar += c1 - c0; c_p1 += c2 - c1; c_p2 += c3 - c2;)
   }
-  TKS(if (blockIdx.x == 0 && t == 0) { tk_ts[0] = c_bar; tk_ts[1] = c_p1; tk_ts[2] = c_p2; tk_ts[3] = __builtin_readcyclecounter() - c_start; })
-  // ---- y = x2 + (Y + b2): lane (token n, half h) holds output columns 32 ob + 8 g + 4 h + q ----
-  if (tok < M) {
-    const float* xr = A.x2 + (long long)tok * TK_D + 4 * h;
-    float* yr = A.y + (long long)tok * TK_D + 4 * h;
+  TKS(if (blockIdx.x == 0 && t == 0) { tk_ts[0] = c_bar; tk_ts[1] = c_p1; tk_ts[2] = c_p2; tk_ts[3] = __builtin_readcyclecounter() - c_start; tk_ts[4] = wall_clock64() - w_start; tk_ts[5] = w_start - w_entry; })
+  // ---- y = x2 + (Y + b2): lane (token n, half h) holds output columns 32 ob + 8 g + 4 h + q.  The accumulators go to LDS as rows (over the dead ring; the
+  //      16-byte pieces of a lane are bank-spread by the row pitch), then every wave-instruction adds the residual row and the bias and stores ONE whole row ----
+  __syncthreads();   // every wave is done with the last stage
+  {
+    char* yr = rows + n * TK_RP + 16 * h;
 #pragma unroll
     for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int c = 32 * ob + 8 * g;
         const f32x4 p = {Y[ob][4 * g], Y[ob][4 * g + 1], Y[ob][4 * g + 2], Y[ob][4 * g + 3]};
-        *(f32x4*)(yr + c) = p + (*(const f32x4*)(xr + c) + *(const f32x4*)(A.b2 + c + 4 * h));
+        *(f32x4*)(yr + (32 * ob + 8 * g) * 4) = p;
       }
   }
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes (rows are read back by the wave that wrote them)
+  __builtin_amdgcn_wave_barrier();
+  {
+    const int r0 = blockIdx.x * TK_WGT + wave * 32;
+    const f32x4 b2v = *(const f32x4*)(A.b2 + 4 * lane);
+    // (the residual rows in two batches of 16 requests: one row per wave-instruction, all in flight before the first is used)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x4 res[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) res[i] = *(const f32x4*)(A.x2 + (long long)min(r0 + 16 * half + i, M - 1) * TK_D + 4 * lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = 16 * half + i;
+        const f32x4 acc = *(const f32x4*)(rows + r * TK_RP + lane * 16);
+        if (r0 + r < M) *(f32x4*)(A.y + (long long)(r0 + r) * TK_D + 4 * lane) = acc + (res[i] + b2v);
+      }
+    }
+  }
+  TKS(if (blockIdx.x == 0 && t == 0) tk_ts[6] = wall_clock64() - w_entry;)
 }
 
 extern "C" int sf_debug_read_ts_ffn_tok(long long* out8) {

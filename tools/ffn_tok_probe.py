@@ -56,4 +56,5 @@ for M in [int(a) for a in sys.argv[1:]] or [5376, 2304, 10752, 130]:
 ts = (C.c_longlong * 8)()
 lib.sf_debug_read_ts_ffn_tok(ts)
 if any(ts):
-    print('cycle counters of workgroup 0, wave 0 (s_memtime; -DTK_STAMPS build): barrier waits', ts[0], ' first product', ts[1], ' second product + conversion', ts[2], ' loop total', ts[3])
+    print('cycle counters of workgroup 0, wave 0 (s_memtime; -DTK_STAMPS build): barrier waits', ts[0], ' first product', ts[1], ' second product + conversion', ts[2], ' loop total', ts[3],
+          f' in {ts[4]} ticks of the 100 MHz wall clock -> shader clock {ts[3] / (ts[4] * 10.0):.3f} GHz; prologue {ts[5] / 100:.2f} us, entry to exit {ts[6] / 100:.2f} us')
