@@ -129,6 +129,14 @@ def unit_batches_for(rollouter, batch, n_batches, burn_in=None):
         cands = [G for G in range(5, n_batches // 2 + 1) if n_batches % G == 0 and (n_batches // G) % 2 == 0 and G * rows <= 8192]
         if cands:
             return max(cands) if fused() else None
+        # no even split into equal units (42 C4 batches = 21 encodes of 32 videos): the smallest even number of units of <= 8192 rows with a shorter
+        # last one (21 encodes: 6, 6, 6, 3) instead of falling back to units of 4 (C4 at 42 batches: 238 k frames/s with units of 4)
+        gmax = 8192 // max(rows, 1)
+        if gmax >= 5 and n_batches >= 10:
+            units = 2 * -(-n_batches // (2 * gmax))
+            G = -(-n_batches // units)
+            if G >= 5:
+                return G if fused() else None
     return None
 
 

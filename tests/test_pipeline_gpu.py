@@ -175,10 +175,12 @@ def test_unit_batches_for_long_runs(dev):
     T, H = 6, 4
     savi, roll = _models(dev, gu.C2_SAVI, gu.C2_ROLL, seed=9)
     assert unit_batches_for(roll, 32, 100, T) is None and unit_batches_for(roll, 32, 20, T) is None     # C2: 1344 rows per batch
-    assert unit_batches_for(roll, 14, 40, T) == 6 and unit_batches_for(roll, 14, 29, T) is None         # 588 rows per batch (C4: 576 -> 7)
-    assert unit_batches_for(roll, 2, 40, T) == 8 and unit_batches_for(roll, 2, 39, T) is None
+    assert unit_batches_for(roll, 14, 40, T) == 6 and unit_batches_for(roll, 2, 40, T) == 8             # 588 rows per batch (C4: 576 -> 7)
     # short runs of small batches: an even number of equal units of up to 8192 token rows (C4 at 20 batches: two units of 10)
-    assert unit_batches_for(roll, 14, 20, T) == 10 and unit_batches_for(roll, 14, 12, T) == 6 and unit_batches_for(roll, 14, 21, T) is None
+    assert unit_batches_for(roll, 14, 20, T) == 10 and unit_batches_for(roll, 14, 12, T) == 6
+    # no even split into equal units: the smallest even number of units of <= 8192 rows, the last one shorter (29 batches: 8, 8, 8, 5)
+    assert unit_batches_for(roll, 14, 29, T) == 8 and unit_batches_for(roll, 14, 21, T) == 11 and unit_batches_for(roll, 2, 39, T) == 20
+    assert unit_batches_for(roll, 14, 9, T) is None   # (short runs keep the default)
     from slotformer_amd.pipeline import encode_group_for
     assert [encode_group_for(16, 20), encode_group_for(8, 48), encode_group_for(32, 20), encode_group_for(2, 41), encode_group_for(2, 16)] == [2, 4, 1, 1, 2]
     bs, V = 2, 83      # 41 full batches (units of 8) + 1 video
