@@ -271,6 +271,9 @@ class EncodeRolloutPipeline:
         self._plan = None
         self._sig = None
         self.units = []
+        self.spread_remainder = os.environ.get('SF_PIPE_SPREAD', '1') != '0'
+        hist_ = getattr(rollouter, 'cond_len', None) or getattr(rollouter, 'history_len', None) or self.T
+        self._rows_per_batch = self.B * int(rollouter.num_slots) * int(hist_)
         self._tails = {}
         self._capture_all()
         self.cu_split = False
@@ -712,6 +715,22 @@ class EncodeRolloutPipeline:
                 tail.pop(0)
         rest = n - sum(tail)
         sizes = [G] * (rest // G) + ([rest % G] if rest % G else []) + tail
+        # The END of a run of row-tile units: a ragged remainder as a short unit of its own rolls out in the latency forms behind the last encode with
+        # nothing beside it (C2 at 21 / 22 / 23 batches: 452 / 464 / 476 k frames/s against 504 k at 20).  Instead the last TWO units take what the
+        # units of `group` batches in front of them leave, split evenly, each up to one round of row tiles (8192 token rows: 6 C2 batches) -- 20
+        # batches: 4, 4, 6, 6; 21: 4, 4, 4, 4, 5; 23: 4, 4, 4, 5, 6 (507-513 k at 20..27 batches; profiles/r04_probes.txt section 15).  Two units at
+        # most: a size has two unit objects, a third unit of it waits for the first (4, 4, 5, 5, 5: 413 k; 5, 5, 5, 5: 423 k).
+        gmax = 8192 // max(self._rows_per_batch, 1)
+        if not tail and self.spread_remainder and gmax > G and rest >= 3 * G:
+            x = 1
+            while rest - x * G > 2 * gmax:
+                x += 1
+            last = rest - x * G
+            if last >= 2 * G:
+                sizes = [G] * x + [last // 2, last - last // 2]
+        probe = os.environ.get('SF_PIPE_SIZES')   # (probe: an explicit unit plan, e.g. "4,4,6,6"; at most two units of a size other than `group` in a row)
+        if probe and sum(int(x) for x in probe.split(',')) == n:
+            sizes = [int(x) for x in probe.split(',')]
         plan, u0, nfull, ntail = [], 0, 0, {}
         n_drain = len(tail)
         for i, nb in enumerate(sizes):
