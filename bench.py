@@ -539,6 +539,9 @@ def main():
         run(args.warmup, out_w)
         torch.cuda.synchronize()
         assert torch.isfinite(out_w[:args.warmup]).all(), 'non-finite slots in the warmup batches'
+        if overlap:   # the graphs of the timed run's unit plan exist before the clock starts (a remainder's units are captured on first use otherwise)
+            unit_sizes = pipe.prepare(max(1, args.steps // E) if E > 1 else args.steps)
+            log(f'rollout units of the timed run: {unit_sizes}')
         log('warmup done')
         # the timed region carries no measurement probes: HIP-event brackets around the conv / Slot-Attention launches of the encode
         # stream cost that stream ~5 % even when only every 4th launch is bracketed (341 vs 359 k frames/s)

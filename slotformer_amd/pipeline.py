@@ -751,6 +751,12 @@ class EncodeRolloutPipeline:
             u0 += nb
         return plan
 
+    def prepare(self, n):
+        """Create (and capture) every rollout unit a run over n batches uses -- the units of a remainder are built on first use otherwise, inside
+        that run -- and return the unit sizes of the run."""
+        self._check_plan()
+        return [nb for _, nb, _, _ in self._unit_plan(int(n))]
+
     @torch.no_grad()
     def _decoded_buffers(self, decoded, n):
         """The decode stage's outputs: decoded['recon'] [n, B, pred_len, 3, R, R] float32 and decoded['seg'] [n, B, pred_len, R, R]
