@@ -140,6 +140,36 @@ def unit_batches_for(rollouter, batch, n_batches, burn_in=None):
     return None
 
 
+def unit_sizes_for(n, group, rows_per_batch, ramp=False, spread=True):
+    """Batches per rollout unit of a run over n batches (a pure function of the counts: tests/test_pipeline_plan.py).  Units of `group` batches;
+    with `ramp` the LAST batches go into ever smaller units (group 4: .., 4, 2, 1, 1); otherwise, where a unit may grow beyond `group` within one
+    round of row tiles (8192 token rows), the last TWO units split what the full units in front of them leave -- no short unit of its own behind
+    the last encode (it would roll out in the latency forms with nothing beside it: C2 at 21 / 22 / 23 batches 452 / 464 / 476 k frames/s against
+    504 k at 20; now 20: 4, 4, 6, 6; 21: 4, 4, 4, 4, 5; 23: 4, 4, 4, 5, 6 -- 507-515 k; profiles/r04_probes.txt section 15).  Two units at most: a
+    size other than `group` has two unit objects, a third unit of it in a row waits for the first (4, 4, 5, 5, 5: 413 k)."""
+    G, n = int(group), int(n)
+    tail = []
+    if ramp and G >= 2 and n >= 2 * G:
+        g = G // 2
+        while g >= 1:
+            tail.append(g)
+            g //= 2
+        tail.append(1)                      # G = 4: [2, 1, 1];  G = 2: [1, 1]
+        while sum(tail) > G:                # (G = 3: [1, 1, 1] -> [1, 1]; the tail replaces at most one full unit)
+            tail.pop(0)
+    rest = n - sum(tail)
+    sizes = [G] * (rest // G) + ([rest % G] if rest % G else []) + tail
+    gmax = 8192 // max(int(rows_per_batch), 1)
+    if not tail and spread and gmax > G and rest >= 3 * G:
+        x = 1
+        while rest - x * G > 2 * gmax:
+            x += 1
+        last = rest - x * G
+        if last >= 2 * G:
+            sizes = [G] * x + [last // 2, last - last // 2]
+    return sizes, len(tail)
+
+
 class EncodeRolloutPipeline:
     """savi: StoSAVi / STEVE container (eval, testing=True); rollouter: SlotRollouter / SingleStepSlotRollouter container.
 
@@ -704,35 +734,12 @@ class EncodeRolloutPipeline:
         is done, which nothing overlaps -- then ends with short units in the kernels' latency forms, and those units run on
         unmasked streams (the encode partition is about to fall idle)."""
         G = self.G
-        sizes, tail = [], []
-        if self.ramp and G >= 2 and n >= 2 * G:
-            g = G // 2
-            while g >= 1:
-                tail.append(g)
-                g //= 2
-            tail.append(1)                      # G = 4: [2, 1, 1];  G = 2: [1, 1]
-            while sum(tail) > G:                # (G = 3: [1, 1, 1] -> [1, 1]; the tail replaces at most one full unit)
-                tail.pop(0)
-        rest = n - sum(tail)
-        sizes = [G] * (rest // G) + ([rest % G] if rest % G else []) + tail
-        # The END of a run of row-tile units: a ragged remainder as a short unit of its own rolls out in the latency forms behind the last encode with
-        # nothing beside it (C2 at 21 / 22 / 23 batches: 452 / 464 / 476 k frames/s against 504 k at 20).  Instead the last TWO units take what the
-        # units of `group` batches in front of them leave, split evenly, each up to one round of row tiles (8192 token rows: 6 C2 batches) -- 20
-        # batches: 4, 4, 6, 6; 21: 4, 4, 4, 4, 5; 23: 4, 4, 4, 5, 6 (507-513 k at 20..27 batches; profiles/r04_probes.txt section 15).  Two units at
-        # most: a size has two unit objects, a third unit of it waits for the first (4, 4, 5, 5, 5: 413 k; 5, 5, 5, 5: 423 k).
-        gmax = 8192 // max(self._rows_per_batch, 1)
-        if not tail and self.spread_remainder and gmax > G and rest >= 3 * G:
-            x = 1
-            while rest - x * G > 2 * gmax:
-                x += 1
-            last = rest - x * G
-            if last >= 2 * G:
-                sizes = [G] * x + [last // 2, last - last // 2]
+        sizes, n_tail = unit_sizes_for(n, G, self._rows_per_batch, ramp=self.ramp, spread=self.spread_remainder)
         probe = os.environ.get('SF_PIPE_SIZES')   # (probe: an explicit unit plan, e.g. "4,4,6,6"; at most two units of a size other than `group` in a row)
         if probe and sum(int(x) for x in probe.split(',')) == n:
             sizes = [int(x) for x in probe.split(',')]
         plan, u0, nfull, ntail = [], 0, 0, {}
-        n_drain = len(tail)
+        n_drain = n_tail
         for i, nb in enumerate(sizes):
             if nb == G:
                 u = self.units[nfull % self.NU]
