@@ -433,3 +433,29 @@ def test_pipeline_with_the_decode_stage(dev, res):
         assert torch.equal(o, ref.reshape(-1, T + H, 7, 128)[:V])
         assert torch.equal(dd['recon'], ref_rec.reshape(-1, H, 3, res, res)[:V]) and torch.equal(dd['seg'].long(), ref_seg.reshape(-1, H, res, res)[:V])
         harness.release_pipelines()
+
+
+@torch.no_grad()
+def test_harness_edge_counts(dev):
+    """harness.extract_and_rollout on the edge counts of a data set: no video at all (an empty result, no launch), ONE video (the serial tail only),
+    one full batch + one video, and -- the plan of section 15 of the round-4 probes -- a batch count whose last two units take the remainder;
+    every result equals the plain module calls video by video (the kernels are per video)."""
+    from slotformer_amd import harness
+    T, H, bs = 6, 3, 2
+    savi, roll = _models(dev, gu.C2_SAVI, gu.C2_ROLL, seed=21)
+    rs = np.random.RandomState(8)
+    base = torch.from_numpy((rs.rand(5, T, 3, 128, 128) * 2 - 1).astype(np.float32)).to(dev)
+    nzb = torch.from_numpy(rs.standard_normal((5, T, 7, 128)).astype(np.float32)).to(dev)
+    try:
+        empty = harness.extract_and_rollout(savi, roll, base[:0], H, batch_size=bs, noises=nzb[:0])
+        assert tuple(empty.shape) == (0, T + H, 7, 128)
+        ref = _serial_reference(savi, roll, [base[i:i + 1] for i in range(5)], [nzb[i:i + 1] for i in range(5)], T, H)[:, 0]   # [5, T + H, N, D]
+        for V in (1, 3):
+            out = harness.extract_and_rollout(savi, roll, base[:V], H, batch_size=bs, noises=nzb[:V])
+            assert torch.equal(out, ref[:V]), V
+        V = 2 * 13 + 1          # 13 full batches: units 4, 4, 5 (the remainder goes into the last units) + a ragged last video
+        idx = torch.arange(V) % 5
+        out = harness.extract_and_rollout(savi, roll, base[idx], H, batch_size=bs, noises=nzb[idx])
+        assert torch.equal(out, ref[idx])
+    finally:
+        harness.release_pipelines()
