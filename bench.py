@@ -539,6 +539,7 @@ def main():
         run(args.warmup, out_w)
         torch.cuda.synchronize()
         assert torch.isfinite(out_w[:args.warmup]).all(), 'non-finite slots in the warmup batches'
+        unit_sizes = None
         if overlap:   # the graphs of the timed run's unit plan exist before the clock starts (a remainder's units are captured on first use otherwise)
             unit_sizes = pipe.prepare(max(1, args.steps // E) if E > 1 else args.steps)
             log(f'rollout units of the timed run: {unit_sizes}')
@@ -722,6 +723,7 @@ def main():
                 'schedule': 'slotformer_amd.pipeline.EncodeRolloutPipeline (product code, tests/test_pipeline_gpu.py)',
                 'stream_placement': getattr(pipe, 'stream_placement', None),
                 'rollout_launch': (f'hipGraph replay, one graph per rollout unit of {G * E} batch(es) = {G * Bp} videos') if graph is not None else 'eager',
+                'rollout_units_of_the_timed_run': ([u * E for u in unit_sizes] if overlap else None),   # batches per unit (the last two units take the remainder: pipeline.unit_sizes_for)
                 'rollout_opts': None if pipe.rollout_opts is None else {k: getattr(pipe.rollout_opts, k) for k, _ in pipe.rollout_opts._fields_},
                 'pipelining': ('encode of later batches (stream A) overlaps the rollout graphs of earlier units (streams B, C); every batch still '
                                'runs its full encode + rollout inside the timed region') if overlap else 'none',
