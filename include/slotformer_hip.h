@@ -301,6 +301,9 @@ typedef struct {
   const void *lin1_packed, *lin2_packed;
   /* optional, same rule: sf_pack_attn_weights() copies of in_proj_w / out_proj_w */
   const void *attn_in_packed, *attn_out_packed;
+  /* optional: sf_pack_layer_tok_weights() copy of all four matrices (the layer's fragments in consumption order) -- with it the rollout runs the layers
+   * before the last as ONE token-stationary launch each (csrc/layer_tok.hip; sf_rollout_opts.layer_tok) */
+  const void* tok_packed;
 } sf_tfm_layer;
 
 /* Pre-split attention weights (d_model 256, 8 heads) in MFMA-fragment order: in_packed needs
@@ -341,6 +344,16 @@ size_t sf_ffn_tok_packed_bytes(void);
 int sf_pack_ffn_tok_weights(const float* lin1_w, const float* lin2_w, void* packed, int d_model, int ffn, void* stream);
 int sf_ffn_block_tok_f32(const sf_tfm_layer* w, const void* tok_packed, const float* x2, float* y, int M, void* stream);
 int sf_debug_read_ts_ffn_tok(long long* out8);   /* phase cycle counts of workgroup 0 (debug builds with -DTK_STAMPS; zeros otherwise) */
+/* One whole pre-LN layer  y = x2 + lin2(relu(lin1(LN2(x2)))),  x2 = x + out_proj(MHA(LN1(x))) + b_o  on B sequences of L <= 64 tokens, x, y [B][L][256],
+ * in the token-stationary form (csrc/layer_tok.hip): a 128-token workgroup owns whole sequences, a wave 32 tokens; every product of the layer keeps its
+ * activations in registers (the accumulator layout of one product is the B operand of the next), the layer's weight fragments stream global -> LDS once per
+ * workgroup, only a head's keys / values cross waves.  tok_packed: sf_pack_layer_tok_weights copy (sf_layer_tok_packed_bytes() bytes).  A sequence's
+ * result does not depend on the other sequences of the call; it may differ in the last bits with its position modulo the sequences per workgroup. */
+size_t sf_layer_tok_packed_bytes(void);
+int sf_pack_layer_tok_weights(const float* in_proj_w, const float* out_proj_w, const float* lin1_w, const float* lin2_w, void* packed, int d_model,
+                              int num_heads, int ffn, void* stream);
+int sf_layer_tok_block_f32(const sf_tfm_layer* w, const float* x, float* y, int B, int L, void* stream);
+int sf_debug_read_ts_layer_tok(long long* out16);   /* wall-clock stamps (10 ns) of workgroup 0 with SF_LT_DBG=1 */
 size_t sf_attn_rows_planes_bytes(int B);
 int sf_attn_block_rows_f32(const sf_tfm_layer* w, const float* x, float* out, void* planes, int B, int L, int Lq, void* stream);
 
@@ -393,7 +406,14 @@ typedef struct {
                       * the workgroup, the next attention block is its core launch alone (one launch less per layer, the same bits) */
   int cus_available; /* 0: the whole chip; else the number of CUs the call's stream may use (its CU mask).  Seam launches hand rows over inside
                       * a grid and need every workgroup of it resident at once: they are used only when the grid fits min(160, cus_available) */
+  int layer_tok;     /* 0: default (sf_set_layer_tok / SF_LAYER_TOK; on); 1 / -1: on / off.  On (and every layer before the last has tok_packed, windows
+                      * of <= 64 tokens): those layers run as ONE token-stationary launch each (csrc/layer_tok.hip) -- a 128-token workgroup owns whole
+                      * videos, every product of the layer keeps its activations in registers -- instead of an attention-core launch per video plus an
+                      * FFN + q|k|v launch per 64-row tile; the row-pruned last layer keeps the row-tile forms.  Not bit-identical to the other forms
+                      * (one accumulator per output block instead of per-chunk partial sums): 1e-6-level differences per layer */
 } sf_rollout_opts;
+int sf_set_layer_tok(int on);   /* process default of sf_rollout_opts.layer_tok == 0 */
+int sf_get_layer_tok(void);
 int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws, size_t ws_bytes,
                         void* stream, const sf_rollout_opts* opts); /* opts == NULL: sf_rollout_f32 */
 /* 1 when sf_rollout_f32 runs this model's Transformer layers as the fused per-video / per-row launches (d_model 256, 8 heads,

@@ -15,7 +15,7 @@ FP = C.c_void_p  # device float*
 class sf_tfm_layer(C.Structure):
     _fields_ = [(n, FP) for n in (
         'norm1_g', 'norm1_b', 'in_proj_w', 'in_proj_b', 'out_proj_w', 'out_proj_b',
-        'norm2_g', 'norm2_b', 'lin1_w', 'lin1_b', 'lin2_w', 'lin2_b', 'lin1_packed', 'lin2_packed', 'attn_in_packed', 'attn_out_packed')]
+        'norm2_g', 'norm2_b', 'lin1_w', 'lin1_b', 'lin2_w', 'lin2_b', 'lin1_packed', 'lin2_packed', 'attn_in_packed', 'attn_out_packed', 'tok_packed')]
 
 
 class sf_rollouter(C.Structure):
@@ -27,7 +27,7 @@ class sf_rollouter(C.Structure):
 
 
 class sf_rollout_opts(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ('precision', 'seam_fused', 'ffn_rows', 'attn_heads_per_wg', 'attn_qkv_rows', 'ffn_tile', 'cus_available')]
+    _fields_ = [(n, C.c_int) for n in ('precision', 'seam_fused', 'ffn_rows', 'attn_heads_per_wg', 'attn_qkv_rows', 'ffn_tile', 'cus_available', 'layer_tok')]
 
 
 class sf_tfm_layer_grads(C.Structure):
@@ -175,6 +175,12 @@ SIGNATURES = {
     'sf_debug_read_ts_ffn_tok': (I, [C.POINTER(C.c_longlong)]),
     'sf_pack_ffn_tok_weights': (I, [FP, FP, VP, I, I, VP]),
     'sf_ffn_block_tok_f32': (I, [C.POINTER(sf_tfm_layer), VP, FP, FP, I, VP]),
+    'sf_set_layer_tok': (I, [I]),
+    'sf_get_layer_tok': (I, []),
+    'sf_layer_tok_packed_bytes': (SZ, []),
+    'sf_pack_layer_tok_weights': (I, [FP, FP, FP, FP, VP, I, I, I, VP]),
+    'sf_layer_tok_block_f32': (I, [C.POINTER(sf_tfm_layer), FP, FP, I, I, VP]),
+    'sf_debug_read_ts_layer_tok': (I, [C.POINTER(C.c_longlong)]),
     'sf_attn_rows_planes_bytes': (SZ, [I]),
     'sf_attn_block_rows_f32': (I, [C.POINTER(sf_tfm_layer), FP, FP, VP, I, I, I, VP]),
     'sf_slot_attn_iter_bwd_workspace_bytes': (SZ, [I, I, I, I]),

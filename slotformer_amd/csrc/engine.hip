@@ -150,6 +150,7 @@ size_t sf_rollout_workspace_bytes(const sf_rollouter* m, int B) {
 }
 
 extern "C" int sf_get_seam_fused(void);
+extern "C" int sf_get_layer_tok(void);
 
 // a[0..n) = b[0..n) = 0 (n a multiple of 4, both 16-byte aligned)
 // One wave kept busy for a given time (wall_clock64: the constant 100 MHz counter).  The pipeline launches two of them on two streams to
@@ -241,7 +242,15 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   const int seam_opt = sf_thread_opts().seam;
   // row-tile form of the attention block (per-call option attn_qkv_rows = 128, attn_rows.hip): q|k|v projection on 128-row tiles
   // of the batch + one core / out-projection workgroup per video; finished rows like the all-heads form
-  const bool attn_rows = fused_layers && sf_thread_opts().attn_rows == 128;
+  bool tok_packed = fused_layers && m->num_layers >= 2;
+  for (int l = 0; l + 1 < m->num_layers; ++l) tok_packed = tok_packed && m->layers[l].tok_packed;
+  {
+    const int lt = sf_thread_opts().layer_tok;
+    tok_packed = tok_packed && (lt > 0 || (lt == 0 && sf_get_layer_tok() != 0));
+    for (int nf = m->single_step ? 1 : W; nf <= W && tok_packed; ++nf) tok_packed = sf_layer_tok_ok(nf * N);
+  }
+  const bool tok_layers = tok_packed;
+  const bool attn_rows = fused_layers && (sf_thread_opts().attn_rows == 128 || tok_layers);
   const bool seam = boundary_fused && (seam_opt >= 0 ? seam_opt != 0 : sf_get_seam_fused() != 0) && sf_seam_blocks(B, N) <= seam_capacity() &&
                     sf_thread_opts().attn_heads != 8 && !attn_rows;
   // layers 0 .. n-2 leave their output as four FFN chunk partials that the next attention sums while loading (the last layer's
@@ -256,6 +265,9 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   // block is then its core launch alone
   const bool ffn_qkv = ffn_tile && attn_rows && sf_thread_opts().ffn_tile == 2;
   const int np = all_heads ? 1 : 4;
+  // token-stationary whole-layer launches for the layers before the last (per-call option layer_tok, layer_tok.hip): finished rows in, finished rows
+  // out; the (row-pruned) last layer runs in the row-tile forms behind them
+  const bool layer_tok = tok_layers;
   if (ring_mode) {
     // in-projection (without PE) of the burn-in frames -> ring slots 0 .. n_in-1
     SF_TRY(sf_ring_init_ex(m->out_proj_packed, m->out_proj_b, m->in_proj_packed, m->in_proj_b, slots,
@@ -308,6 +320,14 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
         const long long pst = (long long)B * Lq * d;
         float* xo = (cin == xa) ? xb2 : xa;
         float* apl = (l == 0) ? ap_l0 : apb;
+        if (layer_tok && !lastl) {
+          SF_TRY(sf_layer_tok_ex(l == 0 ? 1 : 0, cin, ring, RF, N, f0, m->pe_tok + (long long)pe_off * d, m->layers[l], 1e-5f, xo, B, L, st));
+          cin = xo;
+          parts_in = false;
+          if (l == 0) ap_l0 = apb;
+          attn0_done = false;
+          continue;
+        }
         if (parked) {
           apl = parked;
           SF_TRY(sf_attn_core_ex(m->layers[l], apl, planes, B, L, Lq, st));
@@ -404,6 +424,12 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
         const int Lq = lastl ? N : L;
         const long long pst = (long long)B * Lq * d;
         float* xo = (cin == xa) ? xb2 : xa;
+        if (layer_tok && !lastl) {
+          SF_TRY(sf_layer_tok_ex(0, cin, nullptr, 1, 1, 0, nullptr, m->layers[l], 1e-5f, xo, B, L, st));
+          cin = xo;
+          parts_in = false;
+          continue;
+        }
         if (parked) {
           apn = parked;
           SF_TRY(sf_attn_core_ex(m->layers[l], apn, planes, B, L, Lq, st));
@@ -476,6 +502,19 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
 // Seam launches on / off (default: on unless SF_SEAM_FUSED=0).  A seam launch saves a kernel boundary on the critical path of
 // ONE rollout chain; its 128 consumer workgroups spin until the 28 producers are done, which is CU time a second chain running
 // on the same CUs could use -- the 'pair' pipeline captures its graphs with the seam off.
+// Process default of the token-stationary layer launches (sf_rollout_opts.layer_tok == 0): on unless SF_LAYER_TOK=0
+static int g_layer_tok = -1;
+extern "C" int sf_get_layer_tok(void) {
+  if (g_layer_tok < 0) {
+    const char* e = getenv("SF_LAYER_TOK");
+    g_layer_tok = (e && e[0] == '1') ? 1 : 0;   // (off until the round's validation is complete)
+  }
+  return g_layer_tok;
+}
+extern "C" int sf_set_layer_tok(int on) {
+  g_layer_tok = on ? 1 : 0;
+  return 0;
+}
 static int g_seam_fused = -1;
 extern "C" int sf_get_seam_fused(void) {
   if (g_seam_fused < 0) {
@@ -520,6 +559,7 @@ int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total,
   if (opts->attn_qkv_rows > 0) o.attn_rows = opts->attn_qkv_rows;
   if (opts->ffn_tile > 0) o.ffn_tile = opts->ffn_tile;
   if (opts->cus_available > 0) o.cus = opts->cus_available;
+  if (opts->layer_tok != 0) o.layer_tok = opts->layer_tok > 0 ? 1 : -1;
   OptsScope scope(o);
   const bool plain = (o.precision == 2 || o.precision == 3);
   const bool old_plain = t_plain_gemms;

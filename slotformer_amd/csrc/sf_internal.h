@@ -13,6 +13,7 @@ struct SfThreadOpts {
   int attn_heads = 0;    // heads per workgroup of the layer attention launches: 2 (head pairs, four partials) / 8 (finished rows)
   int attn_rows = 0;     // 128: the attention block as q|k|v row tiles + one core workgroup per video (attn_rows.hip; finished rows)
   int ffn_tile = 0;      // 1: the FFN block as one workgroup per 64-row tile over all hidden chunks (ffn_tile.hip; finished rows)
+  int layer_tok = 0;     // 1 / -1: the layers before the last as one token-stationary launch each (layer_tok.hip) on / off; 0: the process default
   int cus = 0;           // CUs the call's stream may use (its CU mask); 0: the whole chip.  Seam launches need all their workgroups co-resident
 };
 SfThreadOpts& sf_thread_opts();

@@ -123,6 +123,13 @@ def _tfm_layers(plan, encoder, pack_ffn=False):
                                                  q1.data_ptr(), q2.data_ptr(), d, 8, torch.cuda.current_stream().cuda_stream))
                 plan.keep += [q1, q2]
                 a.attn_in_packed, a.attn_out_packed = q1.data_ptr(), q2.data_ptr()
+                # all four matrices as the fragment stream of the token-stationary layer launch (layer_tok.hip)
+                tp = torch.empty(lib().sf_layer_tok_packed_bytes(), dtype=torch.uint8, device=p1.device)
+                check(lib().sf_pack_layer_tok_weights(plan.dp(l.self_attn.in_proj_weight), plan.dp(l.self_attn.out_proj.weight),
+                                                      plan.dp(l.linear1.weight), plan.dp(l.linear2.weight), tp.data_ptr(), d, 8, ffn,
+                                                      torch.cuda.current_stream().cuda_stream))
+                plan.keep.append(tp)
+                a.tok_packed = tp.data_ptr()
         a.norm1_g, a.norm1_b = plan.dp(l.norm1.weight), plan.dp(l.norm1.bias)
         a.in_proj_w, a.in_proj_b = plan.dp(l.self_attn.in_proj_weight), plan.dp(l.self_attn.in_proj_bias)
         a.out_proj_w, a.out_proj_b = plan.dp(l.self_attn.out_proj.weight), plan.dp(l.self_attn.out_proj.bias)
@@ -184,14 +191,15 @@ def rollout_opts(opts):
         return None
     if isinstance(opts, _lib.sf_rollout_opts):
         return opts
-    unknown = set(opts) - {'precision', 'seam', 'ffn_rows', 'attn_heads', 'attn_rows', 'ffn_tile', 'cus'}
+    unknown = set(opts) - {'precision', 'seam', 'ffn_rows', 'attn_heads', 'attn_rows', 'ffn_tile', 'cus', 'layer_tok'}
     if unknown:
         raise ValueError(f'slotformer_amd: unknown rollout options {sorted(unknown)}')
     prec = opts.get('precision', -1)
     prec = {'f32': 0, 'bf16x3': 1, 'bf16': 2, 'fp16': 3}.get(prec, prec)
     seam = opts.get('seam', None)
     return _lib.sf_rollout_opts(int(prec), -1 if seam is None else int(bool(seam)), int(opts.get('ffn_rows', 0)), int(opts.get('attn_heads', 0)),
-                                int(opts.get('attn_rows', 0)), int(opts.get('ffn_tile', 0)), int(opts.get('cus', 0)))
+                                int(opts.get('attn_rows', 0)), int(opts.get('ffn_tile', 0)), int(opts.get('cus', 0)),
+                                {None: 0, True: 1, False: -1}[opts.get('layer_tok', None)])
 
 
 def burn_in_of(r):

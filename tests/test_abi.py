@@ -47,7 +47,7 @@ def test_struct_layouts_match_header():
     for cls, name in ((_lib.sf_tfm_layer, 'sf_tfm_layer'), (_lib.sf_rollouter, 'sf_rollouter'),
                       (_lib.sf_savi_encoder, 'sf_savi_encoder'), (_lib.sf_savi_decoder, 'sf_savi_decoder')):
         assert [f[0] for f in cls._fields_] == fields(name), name
-    assert ctypes.sizeof(_lib.sf_tfm_layer) == 16 * 8
+    assert ctypes.sizeof(_lib.sf_tfm_layer) == 17 * 8
 
 
 def test_argument_errors_without_gpu():
