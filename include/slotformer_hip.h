@@ -344,15 +344,16 @@ size_t sf_ffn_tok_packed_bytes(void);
 int sf_pack_ffn_tok_weights(const float* lin1_w, const float* lin2_w, void* packed, int d_model, int ffn, void* stream);
 int sf_ffn_block_tok_f32(const sf_tfm_layer* w, const void* tok_packed, const float* x2, float* y, int M, void* stream);
 int sf_debug_read_ts_ffn_tok(long long* out8);   /* phase cycle counts of workgroup 0 (debug builds with -DTK_STAMPS; zeros otherwise) */
-/* One whole pre-LN layer  y = x2 + lin2(relu(lin1(LN2(x2)))),  x2 = x + out_proj(MHA(LN1(x))) + b_o  on B sequences of L <= 64 tokens, x, y [B][L][256],
- * in the token-stationary form (csrc/layer_tok.hip): a 128-token workgroup owns whole sequences, a wave 32 tokens; every product of the layer keeps its
- * activations in registers (the accumulator layout of one product is the B operand of the next), the layer's weight fragments stream global -> LDS once per
- * workgroup, only a head's keys / values cross waves.  tok_packed: sf_pack_layer_tok_weights copy (sf_layer_tok_packed_bytes() bytes).  A sequence's
- * result does not depend on the other sequences of the call; it may differ in the last bits with its position modulo the sequences per workgroup. */
+/* Whole pre-LN layers  y = x2 + lin2(relu(lin1(LN2(x2)))),  x2 = x + out_proj(MHA(LN1(x))) + b_o  on B sequences of L <= 64 tokens, x, y [B][L][256],
+ * in the token-stationary form (csrc/layer_tok.hip): a 128-token workgroup owns whole sequences, a wave 32 tokens; every product of a layer keeps its
+ * activations in registers (the accumulator layout of one product is the B operand of the next), the weight fragments stream global -> LDS once per
+ * workgroup, only a head's keys / values cross waves; `nl` (1..8) consecutive layers w[0..nl) run in ONE launch (the rows never leave the registers
+ * between them).  tok_packed: sf_pack_layer_tok_weights copy of a layer (sf_layer_tok_packed_bytes() bytes: its four matrices as fragments in consumption
+ * order + its eight vectors).  A sequence's result does not depend on the other sequences of the call; it may differ in the last bits with its position
+ * modulo the sequences per workgroup. */
 size_t sf_layer_tok_packed_bytes(void);
-int sf_pack_layer_tok_weights(const float* in_proj_w, const float* out_proj_w, const float* lin1_w, const float* lin2_w, void* packed, int d_model,
-                              int num_heads, int ffn, void* stream);
-int sf_layer_tok_block_f32(const sf_tfm_layer* w, const float* x, float* y, int B, int L, void* stream);
+int sf_pack_layer_tok_weights(const sf_tfm_layer* w, void* packed, int d_model, int num_heads, int ffn, void* stream);
+int sf_layer_tok_block_f32(const sf_tfm_layer* w, int nl, const float* x, float* y, int B, int L, void* stream);
 int sf_debug_read_ts_layer_tok(long long* out16);   /* wall-clock stamps (10 ns) of workgroup 0 with SF_LT_DBG=1 */
 size_t sf_attn_rows_planes_bytes(int B);
 int sf_attn_block_rows_f32(const sf_tfm_layer* w, const float* x, float* out, void* planes, int B, int L, int Lq, void* stream);
@@ -419,6 +420,9 @@ int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total,
 /* 1 when sf_rollout_f32 runs this model's Transformer layers as the fused per-video / per-row launches (d_model 256, 8 heads,
  * ffn 1024, window <= 64 tokens, packed weights, split-bf16 mode): a video's result then does not depend on the batch it is in */
 int sf_rollout_is_fused(const sf_rollouter* m);
+/* 1 when the layers before the last can run as token-stationary launches (sf_rollout_opts.layer_tok): fused-layer path, tok_packed on those layers,
+ * every window of the rollout within the kernel's limits */
+int sf_rollout_tok_ok(const sf_rollouter* m);
 /* 1 when sf_rollout_f32 would run seam launches for this model / batch with the calling thread's defaults */
 int sf_rollout_uses_seam(const sf_rollouter* m, int B);
 
@@ -723,6 +727,9 @@ int sf_stream_create_cu_mask(void** stream_out, const unsigned int* cu_mask, int
 int sf_stream_destroy(void* stream);
 /* One wave busy for `us` microseconds on `stream` (1..100000): two of them on two streams tell whether the streams share a hardware queue. */
 int sf_debug_spin(int us, void* stream);
+/* One wave that counts shader cycles (out2[0]) over `us` microseconds of the constant 100 MHz counter (out2[1] ticks): the clock the chip sustains
+ * under whatever else is running (tools/clock_probe.py); out2: device buffer of two int64. */
+int sf_debug_clock_probe(int us, long long* out2, void* stream);
 int sf_slot_attn_iter_f32_host(const float* k_host, const float* v_host, int ld, long long batch_stride,
                                const float* q_host, float* part_num_host, float* part_den_host, float* attn_out_host,
                                int B, int HW, int N, int D, float scale, float eps, void* stream);

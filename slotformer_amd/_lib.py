@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libslotformer_hip.so')
+LIB_PATH = os.environ.get('SF_LIB_PATH') or os.path.join(_HERE, 'libslotformer_hip.so')   # (SF_LIB_PATH: a variant build, tools/ only)
 
 FP = C.c_void_p  # device float*
 
@@ -168,6 +168,7 @@ SIGNATURES = {
     'sf_rollout_opts_f32': (I, [C.POINTER(sf_rollouter), FP, I, I, I, VP, SZ, VP, C.POINTER(sf_rollout_opts)]),
     'sf_rollout_uses_seam': (I, [C.POINTER(sf_rollouter), I]),
     'sf_rollout_is_fused': (I, [C.POINTER(sf_rollouter)]),
+    'sf_rollout_tok_ok': (I, [C.POINTER(sf_rollouter)]),
     'sf_ffn_chunk_partials_f32': (I, [C.POINTER(sf_tfm_layer), FP, LL, FP, LL, I, I, I, VP]),
     'sf_attn_block_f32': (I, [C.POINTER(sf_tfm_layer), FP, FP, I, I, I, I, VP]),
     'sf_ffn_block_rows_f32': (I, [C.POINTER(sf_tfm_layer), FP, FP, I, I, VP]),
@@ -178,8 +179,8 @@ SIGNATURES = {
     'sf_set_layer_tok': (I, [I]),
     'sf_get_layer_tok': (I, []),
     'sf_layer_tok_packed_bytes': (SZ, []),
-    'sf_pack_layer_tok_weights': (I, [FP, FP, FP, FP, VP, I, I, I, VP]),
-    'sf_layer_tok_block_f32': (I, [C.POINTER(sf_tfm_layer), FP, FP, I, I, VP]),
+    'sf_pack_layer_tok_weights': (I, [C.POINTER(sf_tfm_layer), VP, I, I, I, VP]),
+    'sf_layer_tok_block_f32': (I, [C.POINTER(sf_tfm_layer), I, FP, FP, I, I, VP]),
     'sf_debug_read_ts_layer_tok': (I, [C.POINTER(C.c_longlong)]),
     'sf_attn_rows_planes_bytes': (SZ, [I]),
     'sf_attn_block_rows_f32': (I, [C.POINTER(sf_tfm_layer), FP, FP, VP, I, I, I, VP]),
@@ -259,6 +260,7 @@ SIGNATURES = {
     'sf_device_synchronize': (I, []),
     'sf_stream_create_cu_mask': (I, [C.POINTER(VP), C.POINTER(C.c_uint), I]),
     'sf_debug_spin': (I, [I, VP]),
+    'sf_debug_clock_probe': (I, [I, VP, VP]),
     'sf_stream_destroy': (I, [VP]),
     'sf_slot_attn_iter_f32_host': (I, [FP, FP, I, LL, FP, FP, FP, FP, I, I, I, I, F32, F32, VP]),
     'sf_rollout_f32_host': (I, [C.POINTER(sf_rollouter), FP, I, I, I, VP, SZ, VP]),

@@ -166,6 +166,28 @@ extern "C" int sf_debug_spin(int us, void* stream) {
   return 0;
 }
 
+// One wave that measures the shader clock: s_memtime (shader cycles) against the constant 100 MHz counter over `ticks` of the latter; out[0] = cycles,
+// out[1] = 10 ns ticks.  tools/clock_probe.py launches it on an idle stream while the pipeline runs: the clock the chip sustains under that load.
+__global__ void clock_probe_kernel(long long ticks, long long* out) {
+  const long long w0 = wall_clock64(), c0 = __builtin_readcyclecounter();
+  long long w1 = w0;
+  while (w1 - w0 < ticks) {
+    __builtin_amdgcn_s_sleep(8);
+    w1 = wall_clock64();
+  }
+  const long long c1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) {
+    out[0] = c1 - c0;
+    out[1] = w1 - w0;
+  }
+}
+extern "C" int sf_debug_clock_probe(int us, long long* out2, void* stream) {
+  SF_REQUIRE(us > 0 && us <= 100000 && out2, "sf_debug_clock_probe: 1..100000 microseconds, a device buffer of two int64");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)us * 100, out2);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
 // clears a[0..n) and b[0..n): float4 stores where both pointers are 16-byte aligned and four elements remain, scalars otherwise
 // (launch with ceil(n / 4) threads)
 __global__ void zero_f32_kernel(float* a, float* b, long long n) {
@@ -321,11 +343,14 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
         float* xo = (cin == xa) ? xb2 : xa;
         float* apl = (l == 0) ? ap_l0 : apb;
         if (layer_tok && !lastl) {
-          SF_TRY(sf_layer_tok_ex(l == 0 ? 1 : 0, cin, ring, RF, N, f0, m->pe_tok + (long long)pe_off * d, m->layers[l], 1e-5f, xo, B, L, st));
+          // all layers before the last in ONE launch (up to eight; the rows stay in registers between them)
+          const int nlt = (m->num_layers - 1 - l) < 8 ? (m->num_layers - 1 - l) : 8;
+          SF_TRY(sf_layer_tok_ex(l == 0 ? 1 : 0, cin, ring, RF, N, f0, m->pe_tok + (long long)pe_off * d, m->layers + l, nlt, 1e-5f, xo, B, L, st));
           cin = xo;
           parts_in = false;
           if (l == 0) ap_l0 = apb;
           attn0_done = false;
+          l += nlt - 1;
           continue;
         }
         if (parked) {
@@ -425,9 +450,11 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
         const long long pst = (long long)B * Lq * d;
         float* xo = (cin == xa) ? xb2 : xa;
         if (layer_tok && !lastl) {
-          SF_TRY(sf_layer_tok_ex(0, cin, nullptr, 1, 1, 0, nullptr, m->layers[l], 1e-5f, xo, B, L, st));
+          const int nlt = (m->num_layers - 1 - l) < 8 ? (m->num_layers - 1 - l) : 8;
+          SF_TRY(sf_layer_tok_ex(0, cin, nullptr, 1, 1, 0, nullptr, m->layers + l, nlt, 1e-5f, xo, B, L, st));
           cin = xo;
           parts_in = false;
+          l += nlt - 1;
           continue;
         }
         if (parked) {
@@ -578,6 +605,17 @@ int sf_rollout_is_fused(const sf_rollouter* m) {
   for (int l = 0; l < m->num_layers; ++l)
     packed = packed && m->layers[l].lin1_packed && m->layers[l].lin2_packed && m->layers[l].attn_in_packed && m->layers[l].attn_out_packed;
   return packed && sf_get_precision() >= 1 && m->norm_first && sf_layer_fused_ok(m->d_model, m->num_heads, m->ffn_dim, m->window_len * m->num_slots);
+}
+
+// 1 when sf_rollout_f32 can run this model's layers before the last as token-stationary launches (sf_rollout_opts.layer_tok): the fused-layer path,
+// sf_pack_layer_tok_weights fragments on every layer but the last, every window of the rollout inside the kernel's key-block limit
+int sf_rollout_tok_ok(const sf_rollouter* m) {
+  if (!sf_rollout_is_fused(m) || m->num_layers < 2) return 0;
+  for (int l = 0; l + 1 < m->num_layers; ++l)
+    if (!m->layers[l].tok_packed) return 0;
+  for (int nf = m->single_step ? 1 : m->window_len; nf <= m->window_len; ++nf)
+    if (!sf_layer_tok_ok(nf * m->num_slots)) return 0;
+  return 1;
 }
 
 // 1 when sf_rollout_f32 would use seam launches for this model / batch with the calling thread's defaults (a caller that

@@ -29,9 +29,10 @@ int sf_ffn_qkv_tile_ex(const float* x2, const sf_tfm_layer& w, const sf_tfm_laye
                        int ffn, hipStream_t st);
 // row-tile form of the FFN block (ffn_tile.hip): x2 [M][256] finished rows -> y [M][256] finished rows, one workgroup per 64 rows
 int sf_ffn_tile_ex(const float* x2, const sf_tfm_layer& w, float eps, float* y, int M, int ffn, hipStream_t st);
-// token-stationary whole layer (layer_tok.hip): mode 0: xin [B * L][256] rows; mode 1: layer 0 of a rollout step, x = ring rows + position table
+// token-stationary whole layers (layer_tok.hip): `nl` consecutive layers in one launch; mode 0: xin [B * L][256] rows; mode 1: the first is layer 0 of a
+// rollout step, x = ring rows + position table
 bool sf_layer_tok_ok(int L);
-int sf_layer_tok_ex(int mode, const float* xin, const float* ring, int ring_frames, int nslots, int f0, const float* pe, const sf_tfm_layer& w,
+int sf_layer_tok_ex(int mode, const float* xin, const float* ring, int ring_frames, int nslots, int f0, const float* pe, const sf_tfm_layer* layers, int nl,
                     float eps, float* y, int B, int L, hipStream_t st);
 // row-tile form (attn_rows.hip): q|k|v projection on 128-row tiles of the batch + one core / out-projection workgroup per video;
 // mode 0: x [B][L][256], 1: four chunk partials, 2: ring rows + position table.  planes: sf_attn_rows_plane_bytes(B) bytes

@@ -123,19 +123,18 @@ def _tfm_layers(plan, encoder, pack_ffn=False):
                                                  q1.data_ptr(), q2.data_ptr(), d, 8, torch.cuda.current_stream().cuda_stream))
                 plan.keep += [q1, q2]
                 a.attn_in_packed, a.attn_out_packed = q1.data_ptr(), q2.data_ptr()
-                # all four matrices as the fragment stream of the token-stationary layer launch (layer_tok.hip)
-                tp = torch.empty(lib().sf_layer_tok_packed_bytes(), dtype=torch.uint8, device=p1.device)
-                check(lib().sf_pack_layer_tok_weights(plan.dp(l.self_attn.in_proj_weight), plan.dp(l.self_attn.out_proj.weight),
-                                                      plan.dp(l.linear1.weight), plan.dp(l.linear2.weight), tp.data_ptr(), d, 8, ffn,
-                                                      torch.cuda.current_stream().cuda_stream))
-                plan.keep.append(tp)
-                a.tok_packed = tp.data_ptr()
         a.norm1_g, a.norm1_b = plan.dp(l.norm1.weight), plan.dp(l.norm1.bias)
         a.in_proj_w, a.in_proj_b = plan.dp(l.self_attn.in_proj_weight), plan.dp(l.self_attn.in_proj_bias)
         a.out_proj_w, a.out_proj_b = plan.dp(l.self_attn.out_proj.weight), plan.dp(l.self_attn.out_proj.bias)
         a.norm2_g, a.norm2_b = plan.dp(l.norm2.weight), plan.dp(l.norm2.bias)
         a.lin1_w, a.lin1_b = plan.dp(l.linear1.weight), plan.dp(l.linear1.bias)
         a.lin2_w, a.lin2_b = plan.dp(l.linear2.weight), plan.dp(l.linear2.bias)
+        if a.attn_in_packed:
+            # all four matrices as the fragment stream of the token-stationary layer launch + the layer's vectors (layer_tok.hip)
+            tp = torch.empty(lib().sf_layer_tok_packed_bytes(), dtype=torch.uint8, device=l.linear1.weight.device)
+            check(lib().sf_pack_layer_tok_weights(C.byref(a), tp.data_ptr(), d, 8, ffn, torch.cuda.current_stream().cuda_stream))
+            plan.keep.append(tp)
+            a.tok_packed = tp.data_ptr()
     plan.keep.append(arr)
     return arr
 

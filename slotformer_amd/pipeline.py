@@ -95,6 +95,7 @@ class _Unit:
         self.buf, self.key, self.graph = buf, key, None
         self.busy = None   # event of the last rollout + copy-out that used the buffer in the current run()
         self.latency_form = False   # captured with the kernels' latency forms (the drain unit of a run: alone on the whole chip)
+        self.row_form = False       # captured with the row-tile forms instead of the token-stationary launches (a drain unit: latency counts)
 
 
 def encode_group_for(batch, n_batches):
@@ -108,12 +109,31 @@ def encode_group_for(batch, n_batches):
     return 1
 
 
+def tok_unit_batches(rollouter, batch, burn_in=None):
+    """Batches per rollout unit when the layers before the last run as token-stationary launches (csrc/layer_tok.hip): a 128-token workgroup owns
+    128 // L whole videos and needs a CU to itself, so a unit should bring 64 workgroups -- two units side by side then fill the 128 CUs of the rollout
+    partition without queueing behind each other (C2: 6 batches of 32 videos = 64 workgroups; 592 k frames/s at 60 batches against 528 k with units of
+    4).  None when the rollouter cannot take that form, or the unit would stay below 96 videos (small batches: the latency forms)."""
+    from . import _lib as _l
+    if os.environ.get('SF_PIPE_TOK', '1') == '0' or not next(rollouter.parameters()).is_cuda:
+        return None
+    if not _l.lib().sf_rollout_tok_ok(C.byref(engine.rollouter_plan(rollouter).struct)):
+        return None
+    hist = getattr(rollouter, 'cond_len', None) or getattr(rollouter, 'history_len', burn_in or 1)
+    vpw = 128 // max(int(rollouter.num_slots) * int(hist), 1)
+    g = max(1, min(8, (64 * vpw) // max(int(batch), 1)))
+    return g if g * int(batch) >= 96 else None
+
+
 def unit_batches_for(rollouter, batch, n_batches, burn_in=None):
     """Batches per rollout unit for a run of n_batches (None = the constructor's default of 4).  A unit's row-tile launches should fill ONE
     round of the 64 CUs a rollout stream gets with 64-row tiles: 4096 token rows.  C2 (1344 rows per batch) and C5 (3072) stay at 4;
     C4 (16 videos x 36 tokens = 576 rows per batch) takes 7 -- 63 tiles per launch instead of 36: 231 vs 209 k frames/s at 84 batches,
     227 at 42 -- but only in runs of five units or more: at 20 batches the ragged last unit and the longer drain cost more (170 vs 199 k;
     `profiles/r03_probes.txt` section 18)."""
+    gt = tok_unit_batches(rollouter, batch, burn_in)
+    if gt is not None:
+        return gt
     hist = getattr(rollouter, 'cond_len', None) or getattr(rollouter, 'history_len', burn_in or 1)
     rows = int(batch) * int(rollouter.num_slots) * int(hist)
     g = max(4, min(8, 4096 // max(rows, 1)))
@@ -226,7 +246,12 @@ class EncodeRolloutPipeline:
         if group and int(group) > 1 and not self.fused:
             raise RuntimeError('slotformer_amd: group > 1 needs a rollouter on the fused-layer path (d_model 256, 8 heads, ffn 1024, '
                                'window <= 64 tokens): the generic path\'s results depend on the batch size')
-        self.G = int(group) if group else (int(os.environ.get('SF_PIPE_GROUP', '4')) if (partition == 'pair' and self.fused) else 1)
+        # token-stationary layer launches (csrc/layer_tok.hip) for the FULL units of a 'pair' pipeline: 64 workgroups per unit, two units side by side on
+        # the 128 rollout CUs; drain units and units of fewer batches keep the row-tile / latency forms (a unit alone is faster in them: 14.5 against
+        # 20.8 ms for 192 videos) -- whose results differ from the token-stationary ones in the last bits (1e-6 per layer, 5e-6 over 50 steps)
+        g_tok = tok_unit_batches(rollouter, self.B, self.T) if (partition == 'pair' and self.fused) else None
+        self.G = int(group) if group else (int(os.environ.get('SF_PIPE_GROUP', str(g_tok or 4))) if (partition == 'pair' and self.fused) else 1)
+        self.tok = g_tok is not None and self.G * self.B >= 96
         if self.G < 1:
             raise ValueError('slotformer_amd: group >= 1')
         nroll = 2 if partition == 'pair' else 1
@@ -273,11 +298,20 @@ class EncodeRolloutPipeline:
             # (2: the FFN tile launch also runs LN1 + q|k|v of the next layer on its rows -- one launch less per layer: C2 441 -> 447 k,
             #  C5 432 -> 446 k, C4 175 -> 181 k)
             rollout_opts['ffn_tile'] = int(os.environ.get('SF_PIPE_FFN_TILE', '2' if tiles else '0'))
+            rollout_opts['layer_tok'] = bool(self.tok)
         if partition in ('three', 'two') and (rollout_opts is None or (isinstance(rollout_opts, dict) and 'cus' not in rollout_opts)):
             # the library's seam launches need their whole grid resident on the CUs the rollout stream may use: tell it how many those are
             cus = 168 if partition == 'three' else 256 - sum(bin(w).count('1') for w in encode_mask_words(encode_cu_word))
             rollout_opts = dict(rollout_opts or {}, cus=cus)
+        if isinstance(rollout_opts, dict) and 'layer_tok' not in rollout_opts:
+            rollout_opts = dict(rollout_opts, layer_tok=False)   # (caller-given options: the token-stationary form only when asked for)
         self.rollout_opts = engine.rollout_opts(rollout_opts)
+        self.tok = self.tok and self.rollout_opts is not None and self.rollout_opts.layer_tok > 0
+        # the same options without the token-stationary launches: a full-size unit that rolls out alone (the drain of a run)
+        self.row_opts = self.rollout_opts
+        if self.tok:
+            o = self.rollout_opts
+            self.row_opts = _lib.sf_rollout_opts(o.precision, o.seam_fused, o.ffn_rows, o.attn_heads_per_wg, o.attn_qkv_rows, o.ffn_tile, o.cus_available, -1)
         # units of fewer batches (the ramp at both ends of a run) are on the critical path of fill and drain: the latency forms
         # of the kernels (head-pair attention workgroups, narrower FFN workgroups: more, shorter workgroups per launch) -- the
         # same bits
@@ -285,7 +319,7 @@ class EncodeRolloutPipeline:
         if self.rollout_opts is not None and (self.rollout_opts.ffn_rows > 64 or self.rollout_opts.attn_heads_per_wg == 8 or
                                               self.rollout_opts.attn_qkv_rows or self.rollout_opts.ffn_tile):
             self.tail_opts = _lib.sf_rollout_opts(self.rollout_opts.precision, self.rollout_opts.seam_fused, min(self.rollout_opts.ffn_rows or 64, 64), 2, 0, 0,
-                                                  self.rollout_opts.cus_available)
+                                                  self.rollout_opts.cus_available, -1)
         self.use_graph = bool(use_graph)
         # the encode under a hipGraph too: the gaps between its ~60 short launches shrink (374-377 vs 373 k frames/s at 20
         # batches, 399.5 vs 398.2 at 40) at the price of a 38 MB device copy of the frames into the fixed input buffer per batch
@@ -374,7 +408,8 @@ class EncodeRolloutPipeline:
         else:
             # (units of more than 4 batches -- unit_batches_for: long runs of small batches -- make the rollouts cheaper per batch and the encode the
             #  bound by more: C4 with units of 7 at 84 batches, every 5th / 4th / 3rd / 2nd batch: 236.0 / 242.9 / 250.6 / 250.9 k)
-            self.hybrid = int(os.environ.get('SF_PIPE_HYBRID', ('3' if self.G > 4 else '5') if balanced else '0'))
+            # (token-stationary units leave the rollout partition 40 % slack: every second batch -- C2 at 60 batches: 592 / 565 / 554 k with 2 / 3 / 4)
+            self.hybrid = int(os.environ.get('SF_PIPE_HYBRID', ('2' if self.tok else '3' if self.G > 4 else '5') if balanced else '0'))
         self.hybrid_tail = int(os.environ.get('SF_PIPE_HYBRID_TAIL', str(min(self.hybrid, 3))))
         self.fill_batches = int(os.environ.get('SF_PIPE_FILL', '0')) or (fill_units * self.G if partition == 'pair' else 0)
         self.fill_steal = int(os.environ.get('SF_PIPE_FILL_STEAL', '0'))
@@ -599,10 +634,10 @@ class EncodeRolloutPipeline:
             pass
 
     # ------------------------------------------------------------------------------------------------------------
-    def _new_unit(self, nb, tag, latency_form=False):
+    def _new_unit(self, nb, tag, latency_form=False, row_form=False):
         with torch.no_grad():
             u = _Unit(torch.zeros(nb * self.B, self.T + self.H, self.N, self.D, device=self.dev), self._key + (tag, ))
-            u.latency_form = latency_form
+            u.latency_form, u.row_form = latency_form, row_form
             self._rollout_eager(u)   # allocates its workspace, builds the plan
             torch.cuda.synchronize(self.dev)
             if self.use_graph:
@@ -619,6 +654,8 @@ class EncodeRolloutPipeline:
         self.units = [self._new_unit(self.G, k) for k in range(self.NU)]
         if self.G > 1 and self.NU > 2 and self.tail_opts is not self.rollout_opts and self.drain_latency_form:
             self._tails['drain'] = self._new_unit(self.G, ('drain', ), latency_form=True)   # (not inside a timed run)
+        elif self.G > 1 and self.NU > 2 and self.tok:
+            self._tails['drain'] = self._new_unit(self.G, ('drain', ), row_form=True)
         self._plan = engine.rollouter_plan(self.roll)   # keeps the packed weight copies the graphs point to alive
         self._sig = self._plan.sig
 
@@ -648,7 +685,12 @@ class EncodeRolloutPipeline:
         return int(math.floor(self.steal * (j + 1) + 1e-9) - math.floor(self.steal * j + 1e-9))
 
     def _rollout_eager(self, u):
-        opts = self.rollout_opts if (u.buf.shape[0] >= self.G * self.B and not u.latency_form) else self.tail_opts
+        if u.latency_form or (u.buf.shape[0] < self.G * self.B and not (self.tok and u.buf.shape[0] >= 128)):
+            opts = self.tail_opts        # small units: the latency forms
+        elif u.row_form or u.buf.shape[0] < self.G * self.B:
+            opts = self.row_opts         # a full-size unit alone on the chip / a remainder unit of >= 128 videos: row tiles
+        else:
+            opts = self.rollout_opts
         engine.rollout(self.roll, u.buf, self.T, self.H, ws_slot=u.key, opts=opts)
 
     def _rollout(self, u):
@@ -740,6 +782,12 @@ class EncodeRolloutPipeline:
             sizes = [int(x) for x in probe.split(',')]
         plan, u0, nfull, ntail = [], 0, 0, {}
         n_drain = n_tail
+        if self.tok and len(sizes) >= 3 and sizes[-1] <= getattr(self, 'hybrid_tail', 2):
+            # token-stationary units take 22.7 ms each whatever runs beside them: when the run ends in a SHORT unit, the last TWO units go to unmasked
+            # streams -- the third unit of the driver's 20 batches (6, 6, 6, 2) would otherwise wait 15 ms for a rollout stream (488 -> 550 k frames/s).
+            # Only when no hybrid-lane encode follows (the last unit's batches all take the masked lane): the first drain unit sits on that lane's
+            # stream (24 batches as 6, 6, 6, 6 with two drain units: 506 k; 60 batches: 538 against 580 k)
+            n_drain = max(n_drain, int(os.environ.get('SF_PIPE_DRAIN_UNITS', '2')))
         for i, nb in enumerate(sizes):
             if nb == G:
                 u = self.units[nfull % self.NU]
@@ -753,6 +801,11 @@ class EncodeRolloutPipeline:
                 # captured with the kernels' LATENCY forms (many short workgroups: 12.1 instead of 15.5 ms for 4 batches)
                 if 'drain' not in self._tails:
                     self._tails['drain'] = self._new_unit(G, ('drain', ), latency_form=True)
+                u = self._tails['drain']
+            elif drain and nb == G and len(sizes) > 1 and self.tok and i == len(sizes) - 1:
+                # ... with token-stationary full units: the LAST unit in the row-tile forms (alone on the chip 14.5 against 20.8 ms for 192 videos)
+                if 'drain' not in self._tails:
+                    self._tails['drain'] = self._new_unit(G, ('drain', ), row_form=True)
                 u = self._tails['drain']
             plan.append((u0, nb, u, drain))
             u0 += nb

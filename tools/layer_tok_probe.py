@@ -26,9 +26,10 @@ plan = engine.rollouter_plan(r)
 w = plan.struct.layers[1]
 layer = r.transformer_encoder.layers[1]
 st = torch.cuda.current_stream().cuda_stream
+NL = int(os.environ.get('LT_NL', '1'))   # consecutive layers per launch (layers 0 .. NL - 1 of the rollouter; 1: layer 1 alone)
 
 
-def reference(x):
+def reference(x, layer=layer):
     """x [B, L, 256] -> the layer in float64"""
     d = lambda t: t.detach().double()  # noqa: E731
     xx = x.double()
@@ -62,9 +63,15 @@ for B, L in shapes:
     g = torch.Generator().manual_seed(B * 100 + L)
     x = torch.randn(B, L, 256, generator=g).to(dev)
     with torch.no_grad():
-        ref = reference(x)
+        if NL == 1:
+            ref = reference(x)
+        else:
+            ref = x
+            for k in range(NL):
+                ref = reference(ref, r.transformer_encoder.layers[k])
     y = torch.full((B, L, 256), float('nan'), device=dev)
-    tok = lambda: _lib.check(lib.sf_layer_tok_block_f32(C.byref(w), x.data_ptr(), y.data_ptr(), B, L, st))  # noqa: E731
+    wp = C.byref(w) if NL == 1 else plan.struct.layers
+    tok = lambda: _lib.check(lib.sf_layer_tok_block_f32(wp, NL, x.data_ptr(), y.data_ptr(), B, L, st))  # noqa: E731
     tok()
     torch.cuda.synchronize()
     err = ((y.double() - ref).abs().max() / ref.abs().max()).item()
@@ -74,7 +81,7 @@ for B, L in shapes:
         x2 = x.clone()
         x2[5] = x[0]
         y2 = torch.empty_like(y)
-        _lib.check(lib.sf_layer_tok_block_f32(C.byref(w), x2.data_ptr(), y2.data_ptr(), B, L, st))
+        _lib.check(lib.sf_layer_tok_block_f32(wp, NL, x2.data_ptr(), y2.data_ptr(), B, L, st))
         torch.cuda.synchronize()
         msg = f'  video 0 at position 5: max |diff| {(y2[5] - y[0]).abs().max().item():.2e}, others unchanged: {bool((y2[:5] == y[:5]).all() and (y2[6:] == y[6:]).all())}'
     # the forms it replaces on the same rows
@@ -85,7 +92,7 @@ for B, L in shapes:
                    _lib.check(lib.sf_ffn_block_rows_f32(C.byref(w), x2b.data_ptr(), yb.data_ptr(), B * L, 1024, st)))
     old()
     torch.cuda.synchronize()
-    err_old = ((yb.view(B, L, 256).double() - ref).abs().max() / ref.abs().max()).item()
+    err_old = ((yb.view(B, L, 256).double() - ref).abs().max() / ref.abs().max()).item() if NL == 1 else float('nan')
     vpw = 128 // L
     print(f'B {B:4d} L {L:3d}: rel err token-stationary {err:.2e}  (row-tile forms {err_old:.2e}; between them {(yb.view(B, L, 256) - y).abs().max().item():.2e}){msg}\n'
           f'              us per launch: token-stationary ({(B + vpw - 1) // vpw} workgroups) {timeit(tok):7.2f}   attention rows + core + FFN tile {timeit(old):7.2f}', flush=True)
@@ -93,5 +100,8 @@ ts = (C.c_longlong * 16)()
 lib.sf_debug_read_ts_layer_tok(ts)
 if any(ts):
     t0 = ts[0]
-    print('wall-clock stamps of workgroup 0 (us from entry): rows + vectors requested, first stages out', (ts[1] - t0) / 100, ' LN1 + b_o', (ts[2] - t0) / 100,
-          ' attention block done', (ts[3] - t0) / 100, ' LN2 + b2', (ts[4] - t0) / 100, ' FFN block done', (ts[5] - t0) / 100, ' rows stored', (ts[6] - t0) / 100)
+    print('wall-clock stamps of workgroup 0 (us from entry): rows requested, first stages out', (ts[1] - t0) / 100, ' vectors in LDS', (ts[2] - t0) / 100, ' LN1 + b_o', (ts[3] - t0) / 100,
+          ' attention block done', (ts[4] - t0) / 100, ' LN2 + b2', (ts[5] - t0) / 100, ' FFN block done (first layer)', (ts[6] - t0) / 100, ' rows stored', (ts[7] - t0) / 100)
+    if any(ts[8:14]):
+        print(f'shader cycles of wave 0 (-DLT_STAMPS build), attention block: DMA waits {ts[8]}  barrier waits {ts[9]}  work {ts[10]}   '
+              f'FFN block: DMA waits {ts[11] - ts[8]}  barrier waits {ts[12] - ts[9]}  work {ts[13] - ts[10]}')
