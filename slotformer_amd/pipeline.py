@@ -119,7 +119,12 @@ def tok_unit_batches(rollouter, batch, burn_in=None):
         return None
     if not _l.lib().sf_rollout_tok_ok(C.byref(engine.rollouter_plan(rollouter).struct)):
         return None
-    hist = getattr(rollouter, 'cond_len', None) or getattr(rollouter, 'history_len', burn_in or 1)
+    # Measured where it pays (profiles/r05_probes.txt): C2 (4 layers, 32 videos per batch) 497 -> 550 k frames/s at 20 batches, 528 -> 580 k at 60.
+    # Not C5 (growing window of the single-step rollouter: 8-token windows leave a 128-token workgroup 16 videos, 80 rollout-bound steps: 450 -> 280 k)
+    # and not C4 at its 16-video batches (8 layers: 259 -> 246 k at 20 batches, 271 -> 283 k at 40): those keep the row-tile units.
+    if hasattr(rollouter, 'cond_len') or len(rollouter.transformer_encoder.layers) > 4 or int(batch) < 24:
+        return None
+    hist = getattr(rollouter, 'history_len', burn_in or 1)
     vpw = 128 // max(int(rollouter.num_slots) * int(hist), 1)
     g = max(1, min(8, (64 * vpw) // max(int(batch), 1)))
     return g if g * int(batch) >= 96 else None
@@ -158,6 +163,38 @@ def unit_batches_for(rollouter, batch, n_batches, burn_in=None):
             if G >= 5:
                 return G if fused() else None
     return None
+
+
+def pair_unit_options(rollouter, batch, group, roll_cus=128, tok=False, burn_in=None):
+    """The per-call kernel options (engine.rollout_opts keys) of the FULL rollout units of a 'pair' pipeline: `group` batches of `batch` videos per unit,
+    `roll_cus` CUs for the two rollout streams.  What EncodeRolloutPipeline uses when no options are given -- and what the tests of the kernel forms ask
+    for, so that they follow the pipeline's choice (tests/test_rollout_opts_gpu.py, tests/test_layer_tok_gpu.py)."""
+    # several chains share the rollout CUs: seam launches (consumers spinning on a CU each) cost more than they
+    # save.  When the attention workgroups of the two units in flight cover the rollout partition at one per video,
+    # the CUs are the bound: wide FFN workgroups (one load of the weight chunk per 128 rows) and one attention
+    # workgroup per video running all 8 heads (the layer input ingested and normalised once, finished rows out
+    # instead of four partials).  Smaller units (C5 at 8 or 16 videos per batch) would leave most of those CUs idle:
+    # the latency forms, four times the workgroups (224 vs 120 k frames/s at B = 8, 251 vs 219 k at B = 16).  Same bits.
+    wide = 2 * int(group) * int(batch) >= int(roll_cus)
+    opts = {'cus': int(roll_cus),   # (seam launches -- off below anyway -- only when their grid fits the rollout CUs)
+            'seam': bool(int(os.environ.get('SF_PIPE_SEAM', '0'))),
+            'ffn_rows': int(os.environ.get('SF_PIPE_FFN_ROWS', '128' if wide else '64')),
+            'attn_heads': int(os.environ.get('SF_PIPE_ATTN_HEADS', '8' if wide else '2')),
+            'attn_rows': 0, 'ffn_tile': 0}
+    # units of >= 2048 token rows (C2: 128 videos x 42 rows; C4: 64 x 36; C5: 256 x 48) run both blocks of a layer in their
+    # ROW-TILE forms: LN1 + q|k|v on 64-row tiles of the whole unit + one attention-core workgroup per video (attn_rows.hip),
+    # and the FFN as one workgroup per 64-row tile over all hidden chunks (ffn_tile.hip) -- rows packed across videos, each
+    # row ingested and normalised once per block, weights streamed as fragments: about half the CU time of the all-heads /
+    # chunk-partial workgroups (C5 305 -> 383 k frames/s, C2 405 -> 415-419 k, C4 172 -> 180 k).  Same bits.
+    hist = getattr(rollouter, 'cond_len', None) or getattr(rollouter, 'history_len', burn_in or 1)
+    tiles = wide and int(group) * int(batch) * int(rollouter.num_slots) * int(hist) >= 2048
+    opts['attn_rows'] = int(os.environ.get('SF_PIPE_ATTN_ROWS', '128' if tiles else '0'))
+    # (2: the FFN tile launch also runs LN1 + q|k|v of the next layer on its rows -- one launch less per layer: C2 441 -> 447 k,
+    #  C5 432 -> 446 k, C4 175 -> 181 k)
+    opts['ffn_tile'] = int(os.environ.get('SF_PIPE_FFN_TILE', '2' if tiles else '0'))
+    # the layers before the last as ONE token-stationary launch (layer_tok.hip) -- see tok_unit_batches; the last (row-pruned) layer keeps the forms above
+    opts['layer_tok'] = bool(tok)
+    return opts
 
 
 def unit_sizes_for(n, group, rows_per_batch, ramp=False, spread=True):
@@ -209,6 +246,11 @@ class EncodeRolloutPipeline:
     the same bits as the library defaults either way; other partitions: the library defaults).
     hybrid: behind the whole-chip fill, every hybrid-th batch is encoded on an unmasked stream beside the CU-masked lane (None = 5
     for a balanced 'pair' on row tiles, 0 = never otherwise; bit-identical).
+    tok: None (default) = the FULL rollout units of a 'pair' pipeline run the layers before the last as token-stationary launches (csrc/layer_tok.hip)
+    where the rollouter allows it and a unit reaches 96 videos (C2: units of 6 batches = 64 workgroups each, two side by side on the rollout CUs);
+    False = never (every unit in the row-tile / latency forms: bit-identical to the serial module calls); True = required.  With it the results agree
+    with the serial calls to ~5e-6 over 50 steps instead of bit for bit (one accumulator per output block instead of per-chunk partial sums), and are
+    bit-identical to run(serial=True) of the same object.
     decoder: module holding the SAVi decoder weights (StoSAVi / SlotFormer); enables run(..., decoded={...}): the predicted frames of
     every batch decoded to reconstruction + segmentation behind its rollout, on an unmasked stream of its own (the decode is 12x the
     FLOPs of encode + rollout at C2: it bounds such a run, the other two stages hide beside it).  seg_dtype: uint8 (default) or int64.
@@ -216,7 +258,7 @@ class EncodeRolloutPipeline:
 
     def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=None, use_graph=True,
                  partition='pair', group=None, rollout_opts=None, encode_graph=None, hybrid=None, decoder=None, seg_dtype=torch.uint8,
-                 encode_fork=None):
+                 encode_fork=None, tok=None):
         self.savi, self.roll = savi, rollouter
         # optional third stage (row N2; video_prediction/test_vp.py:55-63,145-146 -> slotformer.py:244-259 -> savi.py:504-525 ->
         # vp_utils.py:20-41): the predicted frames of every batch are decoded behind its rollout -- spatial-broadcast decoder, softmax
@@ -249,7 +291,10 @@ class EncodeRolloutPipeline:
         # token-stationary layer launches (csrc/layer_tok.hip) for the FULL units of a 'pair' pipeline: 64 workgroups per unit, two units side by side on
         # the 128 rollout CUs; drain units and units of fewer batches keep the row-tile / latency forms (a unit alone is faster in them: 14.5 against
         # 20.8 ms for 192 videos) -- whose results differ from the token-stationary ones in the last bits (1e-6 per layer, 5e-6 over 50 steps)
-        g_tok = tok_unit_batches(rollouter, self.B, self.T) if (partition == 'pair' and self.fused) else None
+        g_tok = tok_unit_batches(rollouter, self.B, self.T) if (partition == 'pair' and self.fused and tok is not False) else None
+        if tok and g_tok is None:
+            raise RuntimeError('slotformer_amd: tok=True needs the pair partition, a rollouter whose layers take the token-stationary form '
+                               '(d_model 256, 8 heads, ffn 1024, windows of <= 64 tokens) and units of >= 96 videos')
         self.G = int(group) if group else (int(os.environ.get('SF_PIPE_GROUP', str(g_tok or 4))) if (partition == 'pair' and self.fused) else 1)
         self.tok = g_tok is not None and self.G * self.B >= 96
         if self.G < 1:
@@ -273,32 +318,9 @@ class EncodeRolloutPipeline:
             elif self._encode_rows() != 4:
                 self._enc_words_pair = encode_mask_words(f'rows{self._encode_rows()}')
         if rollout_opts is None and partition == 'pair':
-            # several chains share the rollout CUs: seam launches (consumers spinning on a CU each) cost more than they
-            # save.  When the attention workgroups of the two units in flight cover the rollout partition at one per video,
-            # the CUs are the bound: wide FFN workgroups (one load of the weight chunk per 128 rows) and one attention
-            # workgroup per video running all 8 heads (the layer input ingested and normalised once, finished rows out
-            # instead of four partials).  Smaller units (C5 at 8 or 16 videos per batch) would leave most of those CUs idle:
-            # the latency forms, four times the workgroups (224 vs 120 k frames/s at B = 8, 251 vs 219 k at B = 16).  Same bits.
             roll_cus = 256 - sum(bin(w).count('1') for w in self._enc_words_pair)
-            wide = 2 * self.G * self.B >= roll_cus
-            rollout_opts = {'cus': roll_cus,   # (seam launches -- off below anyway -- only when their grid fits the rollout CUs)
-                            'seam': bool(int(os.environ.get('SF_PIPE_SEAM', '0'))),
-                            'ffn_rows': int(os.environ.get('SF_PIPE_FFN_ROWS', '128' if wide else '64')),
-                            'attn_heads': int(os.environ.get('SF_PIPE_ATTN_HEADS', '8' if wide else '2')),
-                            'attn_rows': 0, 'ffn_tile': 0}
-            # units of >= 2048 token rows (C2: 128 videos x 42 rows; C4: 64 x 36; C5: 256 x 48) run both blocks of a layer in their
-            # ROW-TILE forms: LN1 + q|k|v on 64-row tiles of the whole unit + one attention-core workgroup per video (attn_rows.hip),
-            # and the FFN as one workgroup per 64-row tile over all hidden chunks (ffn_tile.hip) -- rows packed across videos, each
-            # row ingested and normalised once per block, weights streamed as fragments: about half the CU time of the all-heads /
-            # chunk-partial workgroups (C5 305 -> 383 k frames/s, C2 405 -> 415-419 k, C4 172 -> 180 k).  Same bits.
-            hist = getattr(self.roll, 'cond_len', None) or getattr(self.roll, 'history_len', self.T)
-            tiles = wide and self.G * self.B * self.N * hist >= 2048
-            self._row_tiles = bool(tiles)
-            rollout_opts['attn_rows'] = int(os.environ.get('SF_PIPE_ATTN_ROWS', '128' if tiles else '0'))
-            # (2: the FFN tile launch also runs LN1 + q|k|v of the next layer on its rows -- one launch less per layer: C2 441 -> 447 k,
-            #  C5 432 -> 446 k, C4 175 -> 181 k)
-            rollout_opts['ffn_tile'] = int(os.environ.get('SF_PIPE_FFN_TILE', '2' if tiles else '0'))
-            rollout_opts['layer_tok'] = bool(self.tok)
+            rollout_opts = pair_unit_options(self.roll, self.B, self.G, roll_cus, self.tok, self.T)
+            self._row_tiles = bool(rollout_opts['attn_rows'])
         if partition in ('three', 'two') and (rollout_opts is None or (isinstance(rollout_opts, dict) and 'cus' not in rollout_opts)):
             # the library's seam launches need their whole grid resident on the CUs the rollout stream may use: tell it how many those are
             cus = 168 if partition == 'three' else 256 - sum(bin(w).count('1') for w in encode_mask_words(encode_cu_word))

@@ -148,39 +148,62 @@ def rel_err_elementwise(a, b, floor=1e-3):
     return ((a - b).abs() / b.abs().clamp_min(floor * b.abs().max())).max().item()
 
 
-@pytest.mark.parametrize('name,cfg,seed,videos,H,at', [('roll_c4_full', gu.C4_ROLL, 224, 64, 40, 37), ('roll_c5_full', gu.C5_ROLL, 225, 256, 80, 201)])
+@pytest.mark.parametrize('name,cfg,seed,batch,n_batches,H', [('roll_c4_full', gu.C4_ROLL, 224, 16, 20, 40), ('roll_c4_full', gu.C4_ROLL, 224, 16, 84, 40),
+                                                            ('roll_c5_full', gu.C5_ROLL, 225, 64, 20, 80), ('roll_c2', gu.C2_ROLL, 202, 32, 20, 50)])
 @torch.no_grad()
-def test_throughput_forms_vs_reference_fixture_c4_c5(dev, name, cfg, seed, videos, H, at):
-    """The kernel forms the pipeline picks for C4 (units of 4 x 16 = 64 videos: L = 36, slot size 192, 8 layers, 6 + 40) and C5 (4 x 64 =
-    256 videos: SingleStepSlotRollouter, window growing 8 -> 48 tokens, 1 + 80) -- row-tile q|k|v + attention core, FFN tiles fused with
-    the next layer's q|k|v, all-heads / 128-row forms below them -- against the REFERENCE's full-horizon fixture: the fixture video sits
-    at two places of a unit-sized batch of other videos (row tiles cut across videos), both copies vs the fixture over the whole horizon."""
+def test_pipeline_unit_forms_vs_reference_fixture(dev, name, cfg, seed, batch, n_batches, H):
+    """The kernel forms and the unit size the PIPELINE picks (pipeline.encode_group_for / unit_batches_for / pair_unit_options -- the functions
+    bench.py and harness.extract_and_rollout call, not a literal copy of their result) for C4 (16 videos per batch, 20 batches: two units of 160 videos;
+    84 batches: units of 224), C5 (64 videos per batch: units of 256, growing window 8 -> 48 tokens, 1 + 80) and C2 (32 videos per batch: token-stationary units of 192
+    videos) against the REFERENCE's full-horizon fixtures: the fixture video sits at two places of a unit-sized batch of other videos (row tiles cut
+    across videos; token-stationary workgroups hold three videos), both copies vs the fixture over the whole horizon."""
     from test_engine_gpu import build
-    from slotformer_amd import engine
-    from slotformer_amd.pipeline import EncodeRolloutPipeline  # noqa: F401  (the options below are pipeline.py's for these unit sizes)
+    from slotformer_amd import engine, pipeline
     g = gu.load_golden(name)
     m, _ = build(cfg, g, seed, dev, vp=True)
     roll = m.rollouter
     rd = cfg['rollout_dict']
     hist, N, C = rd['history_len'], rd['num_slots'], rd['slot_size']
     T_in = engine.burn_in_of(roll)
+    E = pipeline.encode_group_for(batch, n_batches)                      # batches per encode = per pipeline batch
+    Bp, nb = batch * E, n_batches // E
+    G = pipeline.unit_batches_for(roll, Bp, nb, T_in) or 4               # pipeline batches per rollout unit (4: the constructor's default)
+    tok = pipeline.tok_unit_batches(roll, Bp, T_in) is not None
+    opts = pipeline.pair_unit_options(roll, Bp, G, 128, tok, T_in)
+    videos = G * Bp
+    print(name, f'{batch} videos x {n_batches} batches -> {E} per encode, units of {G} x {Bp} = {videos} videos, options {opts}')
+    assert (name, batch, n_batches, videos) in (('roll_c4_full', 16, 20, 160), ('roll_c4_full', 16, 84, 224), ('roll_c5_full', 64, 20, 256), ('roll_c2', 32, 20, 192))
+    assert opts['layer_tok'] == (name == 'roll_c2') and opts['attn_rows'] == 128 and opts['ffn_tile'] == 2
+    fxv = gu.seeded_normal((g['pred_slots'].shape[0], hist + H, N, C), seed + 1)[:, :hist]
     x = gu.seeded_normal((videos, hist, N, C), seed + 60).to(dev)
-    fx = gu.seeded_normal((1, hist + H, N, C), seed + 1)[0, :hist].to(dev)
-    x[0], x[at] = fx, fx
+    at = videos - 28                                                      # (another row tile / another workgroup, another place inside it)
+    x[0], x[at] = fxv[0].to(dev), fxv[0].to(dev)
     x = x[:, :T_in].contiguous() if T_in < hist else x
-    opts = {'seam': False, 'ffn_rows': 128, 'attn_heads': 8, 'attn_rows': 128, 'ffn_tile': 2}
     out = _roll(roll, x, H, opts)
     assert torch.isfinite(out).all()
+    ref0 = torch.as_tensor(g['pred_slots'])[:1]
     for i in (0, at):
-        e, ee = rel_err(out[i:i + 1], g['pred_slots']), rel_err_elementwise(out[i:i + 1], g['pred_slots'])
-        print(name, 'throughput forms, video', i, 'of', videos, ': rel err (max-norm)', e, ' element-wise (floor 1e-3 max|ref|)', ee)
+        e, ee = rel_err(out[i:i + 1], ref0), rel_err_elementwise(out[i:i + 1], ref0)
+        print(name, 'pipeline forms, video', i, 'of', videos, ': rel err (max-norm)', e, ' element-wise (floor 1e-3 max|ref|)', ee)
         # asserted element by element in the allclose form of the north star's bar: |a - b| <= 1e-3 |b| + 1e-4 max|b|  (the printed
         # figure with a floor of 1e-3 max|b| can reach 1000 x the max-norm error by construction: it is reported, not bounded at 1e-3)
-        a_, b_ = out[i:i + 1].detach().cpu().double(), torch.as_tensor(g['pred_slots']).double()
+        a_, b_ = out[i:i + 1].detach().cpu().double(), ref0.double()
         assert e < 2e-4 and bool(((a_ - b_).abs() <= 1e-3 * b_.abs() + 1e-4 * b_.abs().max()).all()) and ee < 5e-2
-    assert torch.equal(out[0], out[at])            # a video's bits do not depend on where it sits in the unit
-    ref = _roll(roll, x[:3].contiguous(), H)        # the library defaults (latency forms) on a small batch: the same bits
-    assert torch.equal(ref[0], out[0])
+    small = _roll(roll, x[:3].contiguous(), H)     # the library defaults (latency forms) on a small batch
+    if opts['layer_tok']:
+        # token-stationary launches: a video's last bits depend on its place inside the three-video workgroup (the key blocks its scores are summed
+        # over) and differ from the other forms' (one accumulator per output block): rounding level, bounded here over the 50 steps
+        assert rel_err(out[at], out[0]) < 2e-5 and rel_err(out[0], small[0]) < 2e-5
+        again = _roll(roll, x, H, opts)
+        assert torch.equal(again, out)
+    else:
+        assert torch.equal(out[0], out[at])        # a video's bits do not depend on where it sits in the unit
+        if C == 128:
+            assert torch.equal(small[0], out[0])   # ... nor on the kernel form or the size of the batch
+        else:
+            # slot size 192 (C4): in_proj / out_proj run on the generic GEMM core, whose tile / split-K choice -- and with it the summation order --
+            # follows the row count: 160 videos and 3 agree to rounding (64 and 3 still took the same tiles in round 4's form of this test)
+            assert rel_err(small[0], out[0]) < 2e-5
 
 
 @torch.no_grad()
