@@ -425,6 +425,8 @@ int sf_rollout_is_fused(const sf_rollouter* m);
 int sf_rollout_tok_ok(const sf_rollouter* m);
 /* 1 when sf_rollout_f32 would run seam launches for this model / batch with the calling thread's defaults */
 int sf_rollout_uses_seam(const sf_rollouter* m, int B);
+/* ... with the options of the call in question (NULL: the thread's defaults): a caller on a CU-masked stream passes its cus_available */
+int sf_rollout_uses_seam_opts(const sf_rollouter* m, int B, const sf_rollout_opts* opts);
 
 /* ---- differentiable building blocks for the slot-level layers --------------------------------
  * (predictor, kernel distribution: savi.py:190-200, predictor.py:47-73).  Backward of y = act(x W^T + b): dW [N,K],

@@ -167,6 +167,7 @@ SIGNATURES = {
     'sf_rollout_f32': (I, [C.POINTER(sf_rollouter), FP, I, I, I, VP, SZ, VP]),
     'sf_rollout_opts_f32': (I, [C.POINTER(sf_rollouter), FP, I, I, I, VP, SZ, VP, C.POINTER(sf_rollout_opts)]),
     'sf_rollout_uses_seam': (I, [C.POINTER(sf_rollouter), I]),
+    'sf_rollout_uses_seam_opts': (I, [C.POINTER(sf_rollouter), I, C.POINTER(sf_rollout_opts)]),
     'sf_rollout_is_fused': (I, [C.POINTER(sf_rollouter)]),
     'sf_rollout_tok_ok': (I, [C.POINTER(sf_rollouter)]),
     'sf_ffn_chunk_partials_f32': (I, [C.POINTER(sf_tfm_layer), FP, LL, FP, LL, I, I, I, VP]),

@@ -15,6 +15,7 @@
 // place by the out_proj GEMM epilogue.
 #include "../../include/slotformer_hip.h"
 #include "sf_internal.h"
+#include <map>
 #include <vector>
 #include "layer_fused.h"
 #include <stdlib.h>
@@ -620,17 +621,29 @@ int sf_rollout_tok_ok(const sf_rollouter* m) {
 
 // 1 when sf_rollout_f32 would use seam launches for this model / batch with the calling thread's defaults (a caller that
 // wants to verify sf_seam_timeouts() after the call only needs to when this is non-zero)
-int sf_rollout_uses_seam(const sf_rollouter* m, int B) {
+int sf_rollout_uses_seam_opts(const sf_rollouter* m, int B, const sf_rollout_opts* opts) {
   if (!m || B <= 0 || !m->layers) return 0;
   bool packed = m->in_proj_packed && m->out_proj_packed;
   for (int l = 0; l < m->num_layers; ++l)
     packed = packed && m->layers[l].lin1_packed && m->layers[l].lin2_packed && m->layers[l].attn_in_packed && m->layers[l].attn_out_packed;
-  const int seam_opt = sf_thread_opts().seam;
+  // the call's own options where given (a CU-masked caller: cus_available bounds the grid a seam launch may have), else the thread's defaults
+  int seam_opt = sf_thread_opts().seam, cus = sf_thread_opts().cus, attn_heads = sf_thread_opts().attn_heads, attn_rows = sf_thread_opts().attn_rows;
+  int tok = sf_thread_opts().layer_tok;
+  if (opts) {
+    if (opts->seam_fused >= 0) seam_opt = opts->seam_fused ? 1 : 0;
+    if (opts->cus_available > 0) cus = opts->cus_available;
+    if (opts->attn_heads_per_wg > 0) attn_heads = opts->attn_heads_per_wg;
+    if (opts->attn_qkv_rows > 0) attn_rows = opts->attn_qkv_rows;
+    if (opts->layer_tok != 0) tok = opts->layer_tok > 0 ? 1 : -1;
+  }
+  const int cap = cus > 0 && cus < 160 ? cus : 160;
+  const bool tok_on = (tok > 0 || (tok == 0 && sf_get_layer_tok() != 0)) && sf_rollout_tok_ok(m);
   return packed && sf_get_precision() >= 1 && m->norm_first &&
          sf_layer_fused_ok(m->d_model, m->num_heads, m->ffn_dim, m->window_len * m->num_slots) &&
          sf_step_boundary_ok(m->d_model, m->slot_size) && (seam_opt >= 0 ? seam_opt != 0 : sf_get_seam_fused() != 0) &&
-         sf_seam_blocks(B, m->num_slots) <= seam_capacity();
+         sf_seam_blocks(B, m->num_slots) <= cap && attn_heads != 8 && attn_rows != 128 && !tok_on;
 }
+int sf_rollout_uses_seam(const sf_rollouter* m, int B) { return sf_rollout_uses_seam_opts(m, B, nullptr); }
 
 int sf_rollout_bf16(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws, size_t ws_bytes,
                     void* stream) {
@@ -795,7 +808,12 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
 // fork / join events of the forked encode, per host thread (created on first use, kept for the life of the thread: the library's
 // only host-side objects; no device memory)
 static hipEvent_t enc_fork_event(int i) {
-  thread_local std::vector<hipEvent_t> ev;
+  // keyed by the CURRENT device: an event belongs to the device it was created on, and one host thread may drive several GPUs (engine.py keeps its
+  // side streams per device); recording a device-0 event on a device-1 stream is hipErrorInvalidHandle
+  thread_local std::map<int, std::vector<hipEvent_t>> per_dev;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::vector<hipEvent_t>& ev = per_dev[dev];
   while ((int)ev.size() <= i) {
     hipEvent_t e = nullptr;
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;

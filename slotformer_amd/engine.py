@@ -558,6 +558,9 @@ def savi_decode(m, slots, ws_slot=0, want=('recons', 'masks'), seg_dtype=torch.i
     slots = slots.detach().float().contiguous()
     plan = decoder_plan(m)
     F_, N, D = slots.shape
+    if N > 16:
+        raise NotImplementedError(f'slotformer_amd: savi_decode handles at most 16 slots per frame (got {N}): the recombination kernels keep a pixel\'s '
+                                  'slot values in registers (csrc/elementwise.hip DC_NMAX)')
     H = plan.struct.resolution
     dev = slots.device
     recon = torch.empty(F_, 3, H, H, device=dev, dtype=torch.float32) if out_recon is None else out_recon

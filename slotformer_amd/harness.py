@@ -100,7 +100,7 @@ def release_pipelines():
 
 @torch.no_grad()
 def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises=None, pipelined=True, to_host=False, decoder=None,
-                        seg_dtype=torch.uint8, **pipe_kw):
+                        seg_dtype=torch.uint8, encode_group=None, **pipe_kw):
     """Whole hot path over many videos: SAVi slot extraction of the burn-in frames followed by the SlotFormer rollout
     (extract_slots.py:19-38 + rollout_clevrer_slots.py:20-65 / test_phyre_planning.py:159-174 as one on-device call).
 
@@ -130,7 +130,10 @@ def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises
     # small batches are handed to the pipeline several at a time (pipeline.encode_group_for: the latency-bound slot branch of an encode costs the
     # same for 16 videos as for 32); the kernels are per video, so the slots do not depend on the grouping
     from .pipeline import encode_group_for
-    batch_size = batch_size * encode_group_for(batch_size, V // batch_size) if pipelined and not pipe_kw.get('group') else batch_size
+    # (encode_group: None = that rule; 1 = every batch by itself; the rule depends on V only through 'does the run leave >= 8 pipeline batches')
+    if encode_group is None:
+        encode_group = encode_group_for(batch_size, V // batch_size) if pipelined and not pipe_kw.get('group') else 1
+    batch_size = batch_size * max(1, int(encode_group))
     nfull = V // batch_size
     tail_opts = None
     dec = None
@@ -145,7 +148,7 @@ def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises
             if g:
                 pipe_kw = dict(pipe_kw, group=g)
         pipe = _pipeline_for(savi, rollouter, batch_size, T, pred_len, pipe_kw)
-        tail_opts = pipe.rollout_opts   # the ragged tail runs the same kernel forms as the full batches
+        tail_opts = getattr(pipe, 'row_opts', pipe.rollout_opts)   # the ragged tail runs the kernel forms of the full batches (the row-tile ones where those are token-stationary)
         imgs = [videos[j * batch_size:(j + 1) * batch_size] for j in range(nfull)]
         nz = None if noises is None else [noises[j * batch_size:(j + 1) * batch_size].float().to(dev).contiguous() for j in range(nfull)]
         dv = None if dec is None else {k: v[:nfull * batch_size].view(nfull, batch_size, *v.shape[1:]) for k, v in dec.items()}

@@ -403,6 +403,7 @@ class EncodeRolloutPipeline:
         # unmasked streams for the drain units
         self.stream_placement = None
         self.s_free = self._pick_free_streams(2) if len(self.roll_streams) > 1 else []
+
         self.s_enc = self.lanes[0][0]
         self.fill_whole_chip = True      # the first encode(s) of a run on the calling stream (all CUs)
         # (group 1: a second whole-chip encode was measured worse, 311 vs 323 k frames/s at 20 steps; with group 2 the first
@@ -681,11 +682,13 @@ class EncodeRolloutPipeline:
         self._plan = engine.rollouter_plan(self.roll)   # keeps the packed weight copies the graphs point to alive
         self._sig = self._plan.sig
 
-    def _tail_unit(self, nb, k=0):
-        """a unit of fewer than `group` batches (the ramp at both ends of a run, a ragged remainder); k: which of the two"""
-        if (nb, k) not in self._tails:
-            self._tails[(nb, k)] = self._new_unit(nb, ('tail', nb, k))
-        return self._tails[(nb, k)]
+    def _tail_unit(self, nb, k=0, row_form=False):
+        """a unit of fewer than `group` batches (the ramp at both ends of a run, a ragged remainder); k: which of the two; row_form: the last unit of a
+        run of token-stationary units"""
+        key = (nb, k, bool(row_form))
+        if key not in self._tails:
+            self._tails[key] = self._new_unit(nb, ('tail', ) + key, row_form=bool(row_form))
+        return self._tails[key]
 
     def _check_plan(self):
         if engine._signature(self.roll) != self._sig or getattr(self.roll, '_sf_plan', None) is not self._plan:
@@ -707,12 +710,20 @@ class EncodeRolloutPipeline:
         return int(math.floor(self.steal * (j + 1) + 1e-9) - math.floor(self.steal * j + 1e-9))
 
     def _rollout_eager(self, u):
-        if u.latency_form or (u.buf.shape[0] < self.G * self.B and not (self.tok and u.buf.shape[0] >= 128)):
-            opts = self.tail_opts        # small units: the latency forms
-        elif u.row_form or u.buf.shape[0] < self.G * self.B:
-            opts = self.row_opts         # a full-size unit alone on the chip / a remainder unit of >= 128 videos: row tiles
-        else:
+        full = u.buf.shape[0] >= self.G * self.B
+        if self.tok:
+            # token-stationary launches for every unit of >= 96 videos but the LAST of a run (row_form: alone on the chip at the end, latency counts:
+            # row tiles, 14.5 against 20.8 ms for 192 videos); units below 96 videos in the latency forms
+            if u.buf.shape[0] < 96 or u.latency_form:
+                opts = self.tail_opts
+            elif u.row_form:
+                opts = self.row_opts
+            else:
+                opts = self.rollout_opts
+        elif full and not u.latency_form:
             opts = self.rollout_opts
+        else:
+            opts = self.tail_opts
         engine.rollout(self.roll, u.buf, self.T, self.H, ws_slot=u.key, opts=opts)
 
     def _rollout(self, u):
@@ -815,7 +826,7 @@ class EncodeRolloutPipeline:
                 u = self.units[nfull % self.NU]
                 nfull += 1
             else:
-                u = self._tail_unit(nb, ntail.get(nb, 0) % 2)
+                u = self._tail_unit(nb, ntail.get(nb, 0) % 2, row_form=self.tok and i == len(sizes) - 1)
                 ntail[nb] = ntail.get(nb, 0) + 1
             drain = i >= len(sizes) - max(n_drain, 1)
             if drain and nb == G and len(sizes) > 1 and self.tail_opts is not self.rollout_opts and self.drain_latency_form:
@@ -1161,7 +1172,7 @@ class EncodeRolloutPipeline:
         o = self.rollout_opts
         if o is not None and o.seam_fused == 0:
             return
-        if self._lib.sf_rollout_uses_seam(C.byref(self._plan.struct), self.G * self.B):
+        if self._lib.sf_rollout_uses_seam_opts(C.byref(self._plan.struct), self.G * self.B, None if self.rollout_opts is None else C.byref(self.rollout_opts)):
             t = self._lib.sf_seam_timeouts()
             if t != getattr(self, '_seam_seen', 0):
                 self._seam_seen = t

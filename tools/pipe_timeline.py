@@ -16,7 +16,7 @@ savi, roll = bench.build_models(dev, cfg)
 B, T, H = 32, 6, 50
 ring = [bench.synthetic_img(B, T, 128, seed=1234 + 1000 * k).to(dev) for k in range(3)]
 steal = os.environ.get('SF_BENCH_STEAL')
-group = os.environ.get('SF_BENCH_GROUP')
+group = os.environ.get("SF_BENCH_GROUP")
 cu = os.environ.get('SF_BENCH_CU_SPLIT', 'ff')
 with torch.no_grad():
     pipe = EncodeRolloutPipeline(savi, roll, B, T, H, steal_steps=None if steal is None else float(steal),
