@@ -43,7 +43,7 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak; bf16x3 issues 3 bf16 MFMA flops per algorithmic flop
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec peak (6.3 TB/s achievable)
-CLS_NAMES = ['conv_nhwc_implicit_gemm', 'conv_first', 'linear_gemm', 'slot_attn_iter', 'slot_update', 'attention', 'ffn_fused', 'seam', 'deconv_head']
+CLS_NAMES = ['conv_nhwc_implicit_gemm', 'conv_first', 'linear_gemm', 'slot_attn_iter', 'slot_update', 'attention', 'ffn_fused', 'seam', 'deconv_head', 'layer_tok']
 
 
 def bench_configs():
@@ -140,7 +140,7 @@ def committed_profile(key):
         return {}
 
 
-KERNEL_CLASS = {'conv5x5_halo': 'conv', 'ffn_qkv_tile_kernel': 'ffn_fused', 'ffn_tile_kernel': 'ffn_fused', 'ffn_partial_kernel': 'ffn_fused', 'ffn64_parts_kernel': 'ffn_fused', 'ffn_wide_parts_kernel': 'ffn_fused',
+KERNEL_CLASS = {'layer_tok_kernel': 'layer_tok', 'conv5x5_halo': 'conv', 'ffn_qkv_tile_kernel': 'ffn_fused', 'ffn_tile_kernel': 'ffn_fused', 'ffn_partial_kernel': 'ffn_fused', 'ffn64_parts_kernel': 'ffn_fused', 'ffn_wide_parts_kernel': 'ffn_fused',
                 'conv5x5_rows4_kernel': 'conv', 'qkv_rows_kernel': 'attention', 'attn_core_kernel': 'attention', 'attn_oproj_kernel': 'attention', 'attn_all_kernel': 'attention', 'seam_kernel': 'seam', 'sa_attn_mfma_kernel': 'slot_attn', 'sa_attn_fold_kernel': 'slot_attn', 'sa_attn_tile_kernel': 'slot_attn'}
 
 
@@ -460,6 +460,12 @@ def main():
         # plain `python bench.py --gpus N`: this process becomes the launcher of its own N ranks (one process per GPU, the
         # reference's launch shape: scripts/sbatch_run.sh:36-42) and passes rank 0's JSON line through
         sys.exit(self_launch(args.gpus))
+    # every SF_* variable of the environment must be one the library / pipeline / this script reads (slotformer_amd/switches.py); the ones that are set
+    # go into the line (config.switches): a number measured with a probe switch on says so
+    from slotformer_amd.switches import check_environment
+    switches_set, switches_unknown = check_environment()
+    if switches_unknown:
+        fail(f'unknown SF_* environment variable(s) {switches_unknown}: not in slotformer_amd/switches.py (a typo would silently measure the defaults)', args, code=2)
     rank = int(os.environ.get('RANK', 0))
     pipe_closed = False
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -641,7 +647,7 @@ def main():
         # the rollout layer kernels, event-timed: (a) alone on the whole chip in one eager rollout unit, (b) LIVE in a pipelined
         # pass with the product schedule (encode stream busy on its CUs) but eager launches -- inside the timed region they
         # replay from a hipGraph, where HIP events cannot be inserted between the kernels
-        lib.sf_profile_enable((1 << 5) | (1 << 6) | (1 << 7))
+        lib.sf_profile_enable((1 << 5) | (1 << 6) | (1 << 7) | (1 << 9))
         read_profile(lib)
         rollout_eager()
         torch.cuda.synchronize()
@@ -659,7 +665,7 @@ def main():
         lib.sf_profile_enable(0)
         breakdown = None
         if args.breakdown:
-            lib.sf_profile_enable(0xff)
+            lib.sf_profile_enable(0x3ff)
             encode()
             rollout_eager()
             torch.cuda.synchronize()
@@ -722,6 +728,10 @@ def main():
                 'inputs': 'ring of 3 different resident batches; the slots of every batch are copied out of the slot buffers',
                 'schedule': 'slotformer_amd.pipeline.EncodeRolloutPipeline (product code, tests/test_pipeline_gpu.py)',
                 'stream_placement': getattr(pipe, 'stream_placement', None),
+                'switches': switches_set,   # the SF_* environment variables set for this run ({}: every default)
+                'rollout_form': ('token-stationary layer launches (csrc/layer_tok.hip) for the layers before the last in the full units; row-tile forms for '
+                                 'the last layer, the last unit of a run and remainder units; latency forms below 96 videos') if getattr(pipe, 'tok', False) else
+                                'row-tile / latency forms (csrc/attn_rows.hip, ffn_tile.hip, layer_fused.hip)',
                 'rollout_launch': (f'hipGraph replay, one graph per rollout unit of {G * E} batch(es) = {G * Bp} videos') if graph is not None else 'eager',
                 'rollout_units_of_the_timed_run': ([u * E for u in unit_sizes] if overlap else None),   # batches per unit (the last two units take the remainder: pipeline.unit_sizes_for)
                 'rollout_opts': None if pipe.rollout_opts is None else {k: getattr(pipe.rollout_opts, k) for k, _ in pipe.rollout_opts._fields_},
@@ -756,11 +766,17 @@ def main():
         # ---- roofline objects, one per hot kernel; `roofline` = the one that dominates the committed rocprof summary of this
         #      command (profiles/r*_kernel_stats.csv), the others stay as secondary keys ----
         objs = {}
-        W_FR = roll.cond_len if single else roll.history_len
+        W_FR = W_FR_ = roll.cond_len if single else roll.history_len
         tile_forms = pipe.rollout_opts is not None and pipe.rollout_opts.ffn_tile >= 1
         rows_forms = pipe.rollout_opts is not None and pipe.rollout_opts.attn_qkv_rows == 128
         fused_next = pipe.rollout_opts is not None and pipe.rollout_opts.ffn_tile == 2 and rows_forms
-        for key, name in (('ffn_fused', ('ffn_qkv_tile_kernel (LN2 + FFN1 + ReLU + FFN2 over all four hidden chunks on a 64-row tile of finished rows AND LN1 + q|k|v of the '
+        tok_forms = pipe.rollout_opts is not None and pipe.rollout_opts.layer_tok > 0
+        for key, name in (('layer_tok', f'layer_tok_kernel: the {nl - 1} layers before the last of a rollout step in ONE token-stationary launch -- per layer LN1, q|k|v, scores, '
+                                        'softmax, PV, out-projection, LN2, FFN1, ReLU, FFN2 as one chain of register-resident split-bf16 MFMA products per 32-token wave (the '
+                                        'accumulator layout of a product is the B operand of the next), a 128-token workgroup = 128 // L whole videos on one CU, the '
+                                        f'weight fragments ({nl - 1} x 3 MB) streamed global -> LDS once per workgroup; {-(-G * Bp // max(128 // (W_FR_ * N_SLOTS), 1))} workgroups per unit launch '
+                                        '(two units side by side fill the rollout CUs)'),
+                          ('ffn_fused', ('ffn_qkv_tile_kernel (LN2 + FFN1 + ReLU + FFN2 over all four hidden chunks on a 64-row tile of finished rows AND LN1 + q|k|v of the '
                                          'NEXT layer on the same rows, weights streamed as MFMA fragments; fragment planes + parked residual rows out: flops_per_launch '
                                          'counts both) on the layers before the last, ffn_partial_kernel<1> (32-row tile x 256-wide hidden chunk, last-arriver reduction + '
                                          'step boundary) on the last layer') if fused_next else
@@ -791,6 +807,8 @@ def main():
             objs[key] = {
                 'kernel': name, 'bound': 'mfma', 'achieved': tf, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': tf / peak_chip,
                 'peak_note': peak_note + '; whole-chip roof',
+                # (`frac` is the average over the launches of the kernel CLASS; this key is the class's longest kernel alone where the committed trace lists it)
+                'frac_dominant_kernel': tf / peak_chip if key == 'layer_tok' else None,
                 'flops_per_launch': fl, 'avg_launch_us': us,
                 'measured': ('flops_per_launch (mean over the launches of one rollout unit, library accounting) / avg_launch_us_rocprof = the mean graph-replay '
                              f'duration of this kernel class in the committed rocprofv3 --kernel-trace of this command ({pm.get("source")}); '
@@ -806,9 +824,15 @@ def main():
                 'source_tree': pm.get('source_tree') or source_tree_hash(),
                 'launches_per_unit': iso['launches'], 'rows_per_launch_full_window': G * Bp * W_FR * N_SLOTS,
                 'cus_available': pipe.rollout_cus if pipe.cu_split else 256,
+                **({'workgroups_per_launch': -(-G * Bp // max(128 // (W_FR * N_SLOTS), 1)),
+                    'frac_of_occupied_cus': tf / (peak_chip * min(256, -(-G * Bp // max(128 // (W_FR * N_SLOTS), 1))) / 256.0)} if key == 'layer_tok' else {}),
                 'traffic': pm.get('traffic_bytes_per_launch'),
                 'mfma_busy_frac': pm.get('mfma_busy_frac'), 'pmc_source': pm.get('source'),
-                'limiter': ('row-tile forms: the matrix pipe inside the streamed products (q|k|v: 5.2 us per 128 rows x 256 columns = the MFMA bound; FFN: 7.1 us '
+                'limiter': ('one wave per SIMD issuing ~4900 MFMAs per layer at ~45 cycles each against the pipe\'s 32: per 32 KB weight stage (48 MFMAs) one workgroup barrier, '
+                            'the LDS latency of its first fragments, eight LDS-DMA issues (~40 cycles each) and the softmax / conversion VALU work of the neighbouring head '
+                            'between the MFMAs; a launch occupies ceil(videos / 3) CUs -- 64 of 256 for a unit of 192 videos -- so its whole-chip fraction is bounded by 0.25 '
+                            '(frac_of_occupied_cus prices the CUs it holds) (DESIGN.md 4, 5)') if key == 'layer_tok' else
+                           ('row-tile forms: the matrix pipe inside the streamed products (q|k|v: 5.2 us per 128 rows x 256 columns = the MFMA bound; FFN: 7.1 us '
                             'per 64 rows x hidden chunk against 5.1), the un-overlapped ingest + LayerNorm in front of them (8 / 3.5 us) and the plane / row '
                             'stores behind them; attention core: 9.5 us per video around 2 us of MFMAs (fragment + weight ingest) (DESIGN.md 4, 5)') if tile_forms else
                            ('FFN: per-CU ingest of weight fragments + rows (a CU takes in 70-100 GB/s) around ~10 us of MFMAs per 128-row workgroup; '

@@ -337,13 +337,6 @@ int sf_attn_block_f32(const sf_tfm_layer* w, const float* x, float* out, int B, 
  * sf_attn_rows_planes_bytes(B) bytes (q, k, v^T of every (sequence, head) as split-bf16 MFMA-fragment planes; cleared by the call). */
 /* The FFN block y = x2 + lin2(relu(lin1(LN2(x2)))) on finished rows x2 [M][256] in its row-tile form (sf_rollout_opts.ffn_tile). */
 int sf_ffn_block_rows_f32(const sf_tfm_layer* w, const float* x2, float* y, int M, int ffn, void* stream);
-/* The same FFN block in its token-stationary form (csrc/ffn_tok.hip; experimental, not dispatched by the rollout): a wave owns 32 tokens, the hidden
- * activations never leave its registers, the weight fragments of a 32-wide hidden block go global -> LDS once per 128-token workgroup.
- * tok_packed: sf_pack_ffn_tok_weights copy (sf_ffn_tok_packed_bytes() bytes) of lin1_w [1024, 256] / lin2_w [256, 1024]. */
-size_t sf_ffn_tok_packed_bytes(void);
-int sf_pack_ffn_tok_weights(const float* lin1_w, const float* lin2_w, void* packed, int d_model, int ffn, void* stream);
-int sf_ffn_block_tok_f32(const sf_tfm_layer* w, const void* tok_packed, const float* x2, float* y, int M, void* stream);
-int sf_debug_read_ts_ffn_tok(long long* out8);   /* phase cycle counts of workgroup 0 (debug builds with -DTK_STAMPS; zeros otherwise) */
 /* Whole pre-LN layers  y = x2 + lin2(relu(lin1(LN2(x2)))),  x2 = x + out_proj(MHA(LN1(x))) + b_o  on B sequences of L <= 64 tokens, x, y [B][L][256],
  * in the token-stationary form (csrc/layer_tok.hip): a 128-token workgroup owns whole sequences, a wave 32 tokens; every product of a layer keeps its
  * activations in registers (the accumulator layout of one product is the B operand of the next), the weight fragments stream global -> LDS once per

@@ -173,10 +173,6 @@ SIGNATURES = {
     'sf_ffn_chunk_partials_f32': (I, [C.POINTER(sf_tfm_layer), FP, LL, FP, LL, I, I, I, VP]),
     'sf_attn_block_f32': (I, [C.POINTER(sf_tfm_layer), FP, FP, I, I, I, I, VP]),
     'sf_ffn_block_rows_f32': (I, [C.POINTER(sf_tfm_layer), FP, FP, I, I, VP]),
-    'sf_ffn_tok_packed_bytes': (SZ, []),
-    'sf_debug_read_ts_ffn_tok': (I, [C.POINTER(C.c_longlong)]),
-    'sf_pack_ffn_tok_weights': (I, [FP, FP, VP, I, I, VP]),
-    'sf_ffn_block_tok_f32': (I, [C.POINTER(sf_tfm_layer), VP, FP, FP, I, VP]),
     'sf_set_layer_tok': (I, [I]),
     'sf_get_layer_tok': (I, []),
     'sf_layer_tok_packed_bytes': (SZ, []),

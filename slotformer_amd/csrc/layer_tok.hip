@@ -866,14 +866,14 @@ int sf_layer_tok_ex(int mode, const float* xin, const float* ring, int ring_fram
   const double flops = nl * ((double)B * L * (2.0 * LT_D * (3 * LT_D + LT_D + 2 * LT_F)) + (double)B * LT_NH * 4.0 * L * L * 32);
   if (mode == 0) {
     SF_TRY(sf_ensure_dyn_lds((const void*)layer_tok_kernel<0>, LT_LDS));
-    sf_prof_begin(SF_K_FFN, st, flops);
+    sf_prof_begin(SF_K_LAYER_TOK, st, flops);
     hipLaunchKernelGGL(layer_tok_kernel<0>, dim3(nwg), dim3(LT_NT), LT_LDS, st, A);
   } else {
     SF_TRY(sf_ensure_dyn_lds((const void*)layer_tok_kernel<1>, LT_LDS));
-    sf_prof_begin(SF_K_FFN, st, flops);
+    sf_prof_begin(SF_K_LAYER_TOK, st, flops);
     hipLaunchKernelGGL(layer_tok_kernel<1>, dim3(nwg), dim3(LT_NT), LT_LDS, st, A);
   }
-  sf_prof_end(SF_K_FFN, st);
+  sf_prof_end(SF_K_LAYER_TOK, st);
   SF_CHECK_LAUNCH();
   return 0;
 }

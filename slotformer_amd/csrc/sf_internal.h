@@ -86,7 +86,7 @@ int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch
 
 // kernel classes for the optional HIP-event timer (sf_runtime.cpp)
 enum { SF_K_CONV_NHWC = 0, SF_K_CONV_FIRST = 1, SF_K_LINEAR = 2, SF_K_SA_ITER = 3, SF_K_SA_UPDATE = 4,
-       SF_K_MHA = 5, SF_K_FFN = 6, SF_K_SEAM = 7, SF_K_DECONV = 8, SF_K_NUM = 9 };
+       SF_K_MHA = 5, SF_K_FFN = 6, SF_K_SEAM = 7, SF_K_DECONV = 8, SF_K_LAYER_TOK = 9, SF_K_NUM = 10 };
 void sf_prof_begin(int cls, hipStream_t st, double work);
 void sf_prof_end(int cls, hipStream_t st);
 void sf_prof_suppress(int on);

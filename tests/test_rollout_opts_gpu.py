@@ -333,34 +333,3 @@ def test_ffn_chunk_partials_kernel(dev, M):
                                              torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert torch.equal(yt, ((xp1[0] + xp1[1]) + xp1[2]) + xp1[3])
-
-
-@pytest.mark.parametrize('M', [2688, 1386, 130, 31])
-@torch.no_grad()
-def test_ffn_token_stationary_kernel(dev, M):
-    """Kernel-level: the experimental token-stationary FFN block (csrc/ffn_tok.hip: a wave owns 32 tokens, the hidden activations stay in its
-    registers, weight fragments through an LDS ring) against a plain PyTorch fp32 reference of the same op and against the row-tile form
-    (different summation order over the hidden dimension: a tolerance, not bit equality); ragged last workgroups."""
-    import ctypes as C
-    import torch.nn.functional as F
-    from slotformer_amd import _lib, engine
-    lib = _lib.lib()
-    r = _c2_rollouter(dev, seed=3)
-    plan = engine.rollouter_plan(r)
-    w = plan.struct.layers[1]
-    layer = r.transformer_encoder.layers[1]
-    st = torch.cuda.current_stream().cuda_stream
-    packed = torch.empty(lib.sf_ffn_tok_packed_bytes(), dtype=torch.uint8, device=dev)
-    _lib.check(lib.sf_pack_ffn_tok_weights(layer.linear1.weight.data_ptr(), layer.linear2.weight.data_ptr(), packed.data_ptr(), 256, 1024, st))
-    g = torch.Generator().manual_seed(M)
-    x2 = torch.randn(M, 256, generator=g).to(dev)
-    ref = x2 + F.linear(F.relu(F.linear(F.layer_norm(x2, (256, ), layer.norm2.weight, layer.norm2.bias), layer.linear1.weight, layer.linear1.bias)),
-                        layer.linear2.weight, layer.linear2.bias)
-    yk = torch.full((M, 256), float('nan'), device=dev)
-    yt = torch.full((M, 256), float('nan'), device=dev)
-    _lib.check(lib.sf_ffn_block_tok_f32(C.byref(w), packed.data_ptr(), x2.data_ptr(), yk.data_ptr(), M, st))
-    _lib.check(lib.sf_ffn_block_rows_f32(C.byref(w), x2.data_ptr(), yt.data_ptr(), M, 1024, st))
-    torch.cuda.synchronize()
-    assert torch.isfinite(yk).all()
-    assert rel_err(yk, ref.cpu()) < 3e-5, rel_err(yk, ref.cpu())
-    assert rel_err(yk, yt.cpu()) < 1e-5, rel_err(yk, yt.cpu())

@@ -157,7 +157,7 @@ def per_block(key, total_per_launch_avg, pred):
     blocks = sum(int(r['Calls']) for r in csv.DictReader(open(f)) if 'attn_core_kernel' in r['Name'])
     return total_per_launch_avg * calls / blocks if blocks else total_per_launch_avg
 for key, pred, whole_chip in (('conv_nhwc_implicit_gemm', is_conv, True), ('slot_attn_iter', lambda n: 'sa_attn_mfma' in n or 'sa_attn_fold' in n or 'sa_attn_tile' in n, True),
-                              ('ffn_fused', is_ffn, False), ('attention', is_attn, False), ('pixel_mlp', lambda n: 'pixel_mlp_kv_kernel' in n or 'pixel_feat_stream_kernel' in n, True),
+                              ('layer_tok', lambda n: 'layer_tok_kernel' in n, False), ('ffn_fused', is_ffn, False), ('attention', is_attn, False), ('pixel_mlp', lambda n: 'pixel_mlp_kv_kernel' in n or 'pixel_feat_stream_kernel' in n, True),
                               # the decoder's last layer with the 1x1 head in its epilogue (bench.py --decode): every launch is a whole-chip launch of the decode stream
                               ('deconv_head', lambda n: 'deconv5x5s2_kernel<64, true>' in n, False), ('deconv_head_64x64', lambda n: 'conv5x5_rows4_kernel<false, true>' in n, False)):
     fe, wr = counter_avg(f'{tag}_pmc_fetch', 'FETCH_SIZE', pred), counter_avg(f'{tag}_pmc_write', 'WRITE_SIZE', pred)
