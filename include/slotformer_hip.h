@@ -96,6 +96,13 @@ int sf_get_conv_fp16x2(void);
 int sf_pack_conv_frag_weights(const float* w_ohwi, void* frag, int Cout, int Cin, int ks, void* stream);
 int sf_conv5x5_frag_f32(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W,
                         int relu, void* stream);
+/* The same convolution on the same fragment copy with the WEIGHTS STATIONARY IN REGISTERS (csrc/conv_ws.hip): one four-wave workgroup per CU keeps the
+ * layer's 410 KB of split-bf16 fragments in its register file and walks its share of the F * H output rows through a ring of six halo rows in LDS --
+ * what the encode launches for layers i > 0 when a launch gives every CU of its stream at least four rows (savi.py:231-239).  Bit-identical to
+ * sf_conv5x5_frag_f32.  Any H >= 1; relu 0 / 1; n_workgroups 0 = one per CU of the stream (sf_stream_create_cu_mask streams: their CUs), else
+ * that many (any split of the rows gives the same bits). */
+int sf_conv5x5_ws_f32(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W,
+                      int relu, int n_workgroups, void* stream);
 
 /* 64 -> 64 channel 5 x 5 stride-2 transposed convolutions (padding 2, output_padding 1: H x W -> 2H x 2W; the decoder layers of savi.py:252-293):
  * w_ohwi (sf_pack_deconv_weight_f32) -> split-bf16 copy in the kernel's consumption order, sf_deconv_frag_bytes(64, 64, 5, 2) bytes;
@@ -719,6 +726,9 @@ int sf_device_synchronize(void);
 /* A HIP stream restricted to a subset of the CUs (hipExtStreamCreateWithCUMask; bit i of cu_mask = CU i,
  * n_words 32-bit words): partitions the GPU between the encode of batch i+1 and the rollout of batch i. */
 int sf_stream_create_cu_mask(void** stream_out, const unsigned int* cu_mask, int n_words);
+/* CUs a launch on `stream` may occupy: the popcount of the mask of a stream made by sf_stream_create_cu_mask, else the device's CU count.  The
+ * persistent kernels (csrc/conv_ws.hip) launch one workgroup per CU of their stream. */
+int sf_stream_cus(void* stream);
 int sf_stream_destroy(void* stream);
 /* One wave busy for `us` microseconds on `stream` (1..100000): two of them on two streams tell whether the streams share a hardware queue. */
 int sf_debug_spin(int us, void* stream);

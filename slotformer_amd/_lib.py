@@ -139,6 +139,7 @@ SIGNATURES = {
     'sf_get_conv_fp16x2': (I, []),
     'sf_pack_conv_frag_weights': (I, [FP, VP, I, I, I, VP]),
     'sf_conv5x5_frag_f32': (I, [FP, VP, FP, FP, FP, I, I, I, I, VP]),
+    'sf_conv5x5_ws_f32': (I, [FP, VP, FP, FP, FP, I, I, I, I, I, VP]),
     'sf_deconv_frag_bytes': (SZ, [I, I, I, I]),
     'sf_pack_deconv_frag_weights': (I, [FP, VP, I, I, I, I, VP]),
     'sf_deconv5x5s2_frag_f32': (I, [FP, VP, FP, FP, I, I, I, I, VP]),
@@ -256,6 +257,7 @@ SIGNATURES = {
     'sf_device_download': (I, [VP, VP, SZ]),
     'sf_device_synchronize': (I, []),
     'sf_stream_create_cu_mask': (I, [C.POINTER(VP), C.POINTER(C.c_uint), I]),
+    'sf_stream_cus': (I, [VP]),
     'sf_debug_spin': (I, [I, VP]),
     'sf_debug_clock_probe': (I, [I, VP, VP]),
     'sf_stream_destroy': (I, [VP]),

@@ -735,6 +735,9 @@ static int run_cnn_layers(const sf_savi_encoder* m, const float* src, long long 
         rc = sf_conv5x5_rows4_update_ex(cur, m->conv_w_frag[i], m->conv_b[i], add, out, nb, 64, 64, cin, cout, m->enc_ks, lastc ? 0 : 1, *upd, st);
         if (rc == 0 && upd_done) *upd_done = true;
       }
+      // (weights stationary in registers where the launch gives every CU of the stream its rows: conv_ws.hip -- the same bits)
+      if (rc == 1 && m->conv_w_frag[i])
+        rc = sf_conv5x5_ws_ex(cur, m->conv_w_frag[i], m->conv_b[i], add, out, nb, 64, 64, cin, cout, m->enc_ks, lastc ? 0 : 1, 0, st);
       if (rc == 1 && m->conv_w_frag[i])
         rc = sf_conv5x5_rows4_ex(cur, m->conv_w_frag[i], m->conv_b[i], add, out, nb, 64, 64, cin, cout, m->enc_ks, lastc ? 0 : 1, st);
       if (rc < 0 || rc > 1) return rc;

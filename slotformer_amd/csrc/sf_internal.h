@@ -93,6 +93,10 @@ void sf_prof_suppress(int on);
 int sf_qkv_attn_ex(const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* in_proj_w,
                    const float* in_proj_b, float* out, int B, int L, int Lq, int d, int nheads, hipStream_t st);
 extern "C" int sf_get_precision(void);
+// weights-stationary form of the same convolution (conv_ws.hip; the same bits); returns 1 when it does not apply
+int sf_conv5x5_ws_ex(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W, int Cin, int Cout, int ks,
+                     int relu, int n_workgroups, hipStream_t st);
+extern "C" int sf_stream_cus(void* stream);
 int sf_conv5x5_rows4_ex(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W,
                         int Cin, int Cout, int ks, int relu, hipStream_t st);
 // the arguments of sf_slot_update_mfma_ex as a struct: the slot update as the first blocks of a convolution launch (conv_rows4.hip)

@@ -22,6 +22,8 @@ unsigned g_seen[SF_K_NUM] = {0};
 std::vector<Rec> g_recs[SF_K_NUM];
 thread_local hipEvent_t t_pending = nullptr;
 thread_local int t_suppress = 0;
+std::mutex g_stream_mu;
+std::map<void*, int> g_stream_cus;   // CU count of the streams made by sf_stream_create_cu_mask
 }  // namespace
 
 SfThreadOpts& sf_thread_opts() {
@@ -84,11 +86,38 @@ int sf_stream_create_cu_mask(void** stream_out, const unsigned int* cu_mask, int
   hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, (const uint32_t*)cu_mask);
   if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
   *stream_out = (void*)st;
+  {
+    // the CU count of the stream: persistent kernels size their grid by it (sf_stream_cus; conv_ws.hip)
+    int c = 0;
+    for (int i = 0; i < n_words; ++i) c += __builtin_popcount(cu_mask[i]);
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    g_stream_cus[(void*)st] = c;
+  }
   return 0;
+}
+
+// CUs a launch on `stream` may occupy: the popcount of the mask of a stream made by sf_stream_create_cu_mask, else the whole device
+int sf_stream_cus(void* stream) {
+  static int dev_cus = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    auto it = g_stream_cus.find(stream);
+    if (it != g_stream_cus.end() && it->second > 0) return it->second;
+  }
+  if (!dev_cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) dev_cus = n;
+    else dev_cus = 256;
+  }
+  return dev_cus;
 }
 
 int sf_stream_destroy(void* stream) {
   if (!stream) return 0;
+  {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    g_stream_cus.erase(stream);
+  }
   hipError_t e = hipStreamDestroy((hipStream_t)stream);
   if (e != hipSuccess) return sf_set_err((int)e, hipGetErrorString(e), __FILE__, __LINE__);
   return 0;

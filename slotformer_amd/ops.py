@@ -102,6 +102,15 @@ def conv5x5_frag(x, w_frag, bias, relu=True, add=None):
     return out
 
 
+def conv5x5_ws(x, w_frag, bias, relu=True, add=None, n_workgroups=0):
+    """conv5x5_frag with the weights stationary in registers (csrc/conv_ws.hip): the same bits; any H; n_workgroups 0 = one per CU of the stream."""
+    _chk(x, bias, add)
+    F_, H, W, Cin = x.shape
+    out = torch.empty(F_, H, W, 64, device=x.device, dtype=torch.float32)
+    check(lib().sf_conv5x5_ws_f32(_p(x), w_frag.data_ptr(), _p(bias), _p(add), _p(out), F_, H, W, int(relu), int(n_workgroups), _stream()))
+    return out
+
+
 def pack_deconv_weight(w):
     """ConvTranspose2d weight [Cin,Cout,k,k] -> [Cout,k,k,Cin]."""
     _chk(w)

@@ -133,6 +133,42 @@ def test_conv5x5_frag(dev, relu, with_add, H):
     assert torch.equal(out, old), (out - old).abs().max().item()
 
 
+@pytest.mark.parametrize('F_,H,relu,with_add', [(3, 64, True, False), (3, 64, False, True), (5, 8, True, True), (2, 7, True, False), (40, 64, True, False)])
+def test_conv5x5_ws(dev, F_, H, relu, with_add):
+    """The weights-stationary convolution (conv_ws.hip: one four-wave workgroup per CU keeps the layer's fragments in registers and walks its rows
+    through a ring of halo rows) against torch's conv2d and bit for bit against the 4-row-tile kernel -- for any split of the rows over workgroups
+    (ranges that start and end inside frames, cross frame changes, single rows) and row counts the tile kernel does not take (H = 7)."""
+    from slotformer_amd import ops
+    x, w, b = rnd(F_, H, 64, 64, seed=1), rnd(64, 64, 5, 5, seed=2, scale=0.03), rnd(64, seed=3, scale=0.1)
+    add = rnd(H * 64, 64, seed=4) if with_add else None
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=2)
+    ref = (F.relu(ref) if relu else ref).permute(0, 2, 3, 1)
+    if with_add:
+        ref = ref + add.view(1, H, 64, 64)
+    wf = ops.pack_conv_frag(ops.pack_conv_weight(w.to(dev)))
+    addd = None if add is None else add.to(dev)
+    tiles = ops.conv5x5_frag(x.to(dev), wf, b.to(dev), relu=relu, add=addd) if H % 4 == 0 else None
+    for nwg in (0, 1, 7, 64, F_ * H):
+        if nwg == 1 and F_ * H > 400:
+            continue
+        out = ops.conv5x5_ws(x.to(dev), wf, b.to(dev), relu=relu, add=addd, n_workgroups=nwg)
+        close(out, ref, **tol("bf16x3"))
+        if tiles is not None:
+            assert torch.equal(out, tiles), (nwg, (out - tiles).abs().max().item())
+
+
+def test_stream_cus(dev):
+    """sf_stream_cus: the CU count of a CU-masked stream of the library, the device's for any other stream."""
+    import ctypes as C
+    from slotformer_amd import _lib
+    lib = _lib.lib()
+    assert lib.sf_stream_cus(None) == torch.cuda.get_device_properties(dev).multi_processor_count
+    h = C.c_void_p()
+    _lib.check(lib.sf_stream_create_cu_mask(C.byref(h), (C.c_uint * 8)(*([0xffffffff] * 3 + [0] * 5)), 8))
+    assert lib.sf_stream_cus(h) == 96
+    _lib.check(lib.sf_stream_destroy(h))
+
+
 @pytest.fixture
 def conv_fp16x2():
     """The opt-in two-fp16-product arithmetic of the fragment convolution, restored to the default (off) afterwards."""
