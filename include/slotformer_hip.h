@@ -623,6 +623,10 @@ int sf_savi_encode_pre_f32(const sf_savi_encoder* m, const float* img, const flo
  * last slot update.  Captured into a hipGraph the two are parallel branches.  side_stream NULL = sf_savi_encode_pre_f32.  Same bits.
  * Workspace: sf_savi_encode_fork_workspace_bytes(m, B, T) (the Slot-Attention inputs of all T steps stay resident). */
 size_t sf_savi_encode_fork_workspace_bytes(const sf_savi_encoder* m, int B, int T);
+/* Workspace of the one-stream encode (side_stream NULL) that runs the 64 -> 64 convolutions of ALL T time steps as one launch per layer (three
+ * buffers of B * T frames on top of sf_savi_encode_workspace_bytes): sf_savi_encode_fork_f32 takes that form when it is handed this much and the
+ * encoder has fragment weights on every layer behind the first (B <= 32, T >= 2, split-bf16); the same bits as the step-by-step order. */
+size_t sf_savi_encode_batched_workspace_bytes(const sf_savi_encoder* m, int B, int T);
 /* Order of a ONE-stream encode (process-wide; default 0, SF_ENC_INTERLEAVE=1: 1 -- measured +1.7 % on the encode lane only, csrc/engine.hip).  1: where the configuration allows it (folded Slot Attention at width 128,
  * matrix-core slot update, at most 32 videos) the image features of time step t + 1 are computed inside the slot branch of step t, every fragment-weight
  * convolution of them as ONE launch with a slot update of step t riding as its first workgroups (csrc/conv_rows4.hip: conv5x5_rows4_update_kernel).
@@ -729,6 +733,9 @@ int sf_stream_create_cu_mask(void** stream_out, const unsigned int* cu_mask, int
 /* CUs a launch on `stream` may occupy: the popcount of the mask of a stream made by sf_stream_create_cu_mask, else the device's CU count.  The
  * persistent kernels (csrc/conv_ws.hip) launch one workgroup per CU of their stream. */
 int sf_stream_cus(void* stream);
+/* The CU count the library is to assume for launches issued on `stream` (cus <= 0: forget): for a stream that captures a graph which will be replayed
+ * on a CU-masked stream. */
+int sf_stream_set_cus(void* stream, int cus);
 int sf_stream_destroy(void* stream);
 /* One wave busy for `us` microseconds on `stream` (1..100000): two of them on two streams tell whether the streams share a hardware queue. */
 int sf_debug_spin(int us, void* stream);

@@ -242,6 +242,7 @@ SIGNATURES = {
     'sf_savi_encode_pre_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, I, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
                                    VP]),
     'sf_savi_encode_fork_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I, I]),
+    'sf_savi_encode_batched_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I, I]),
     'sf_set_encode_interleave': (I, [I]),
     'sf_get_encode_interleave': (I, []),
     'sf_set_encode_fuse_next': (I, [I]),
@@ -258,6 +259,7 @@ SIGNATURES = {
     'sf_device_synchronize': (I, []),
     'sf_stream_create_cu_mask': (I, [C.POINTER(VP), C.POINTER(C.c_uint), I]),
     'sf_stream_cus': (I, [VP]),
+    'sf_stream_set_cus': (I, [VP, I]),
     'sf_debug_spin': (I, [I, VP]),
     'sf_debug_clock_probe': (I, [I, VP, VP]),
     'sf_stream_destroy': (I, [VP]),

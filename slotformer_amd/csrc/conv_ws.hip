@@ -341,8 +341,12 @@ int sf_conv5x5_ws_ex(const float* in, const void* w_frag, const float* bias, con
   if (nwg <= 0) {
     // one workgroup per CU of the stream; a launch too small to give each of them four rows does not pay for 410 KB of weights per workgroup
     static const bool on = []() { const char* e = getenv("SF_CONV_WS"); return !(e && e[0] == '0'); }();
-    nwg = sf_stream_cus((void*)st);
-    if (!on || rows < 4LL * nwg) return 1;
+    // ... of a stream whose CUs are its own: one made by sf_stream_create_cu_mask, or one that captures for such a stream (sf_stream_set_cus).  On any
+    // other stream the launch shares the chip with whatever else runs, and a workgroup that holds its CU for the whole launch (0.5 ms at 192 frames)
+    // keeps the latency-bound rollout launches and the masked encode lane waiting: those keep the 4-row tiles (27 us per workgroup) -- measured in
+    // the pipeline: hybrid-lane encodes with persistent workgroups cost 6 % at 60 batches
+    nwg = sf_stream_cus_known((void*)st);
+    if (!on || nwg <= 0 || rows < 4LL * nwg) return 1;
   }
   if (nwg > rows) nwg = (int)rows;
   const void* kfn = bias ? (add ? (const void*)conv5x5_ws_kernel<true, true> : (const void*)conv5x5_ws_kernel<true, false>)

@@ -692,6 +692,24 @@ size_t sf_savi_encode_workspace_bytes(const sf_savi_encoder* m, int B) { return 
 static constexpr int ENC_FORK_AHEAD = 4;
 static int enc_fork_steps(int T) { return T < 2 ? 2 : (T < ENC_FORK_AHEAD ? T : ENC_FORK_AHEAD); }
 size_t sf_savi_encode_fork_workspace_bytes(const sf_savi_encoder* m, int B, int T) { return T >= 1 ? enc_ws_bytes(m, B, enc_fork_steps(T)) : 0; }
+// One-stream encode with the convolutions of ALL T time steps as one launch per layer (the weights-stationary kernel of conv_ws.hip pays its 410 KB of
+// weights per workgroup once per launch: 81 instead of 99 us per time step and layer on a 128-CU partition): the activations of B * T frames in three
+// buffers on top of sf_savi_encode_workspace_bytes.  sf_savi_encode_fork_f32 (side_stream NULL) takes this form when it is handed that much workspace.
+static size_t enc_batched_extra(const sf_savi_encoder* m, int B, int T) {
+  int cmax = 0;
+  for (int i = 1; i <= m->enc_layers && i < 9; ++i) cmax = m->enc_channels[i] > cmax ? m->enc_channels[i] : cmax;
+  return 3 * pad256((size_t)B * T * 64 * 64 * cmax);
+}
+static bool enc_batched_ok(const sf_savi_encoder* m, int B, int T) {
+  if (!m || T < 2 || B > enc_chunk(B) || m->enc_layers < 2 || sf_get_precision() != 1) return false;
+  for (int i = 1; i < m->enc_layers; ++i)
+    if (!m->conv_w_frag[i] || m->enc_channels[i] != 64 || m->enc_channels[i + 1] != 64) return false;
+  return true;
+}
+size_t sf_savi_encode_batched_workspace_bytes(const sf_savi_encoder* m, int B, int T) {
+  if (!m || B <= 0 || T <= 0) return 0;
+  return enc_ws_bytes(m, B, 2) + (enc_batched_ok(m, B, T) ? enc_batched_extra(m, B, T) : 0);
+}
 
 static size_t enc_ws_bytes(const sf_savi_encoder* m, int B, int kv_steps) {
   if (!m || B <= 0) return 0;
@@ -889,6 +907,13 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
   bool ok = tfm_ws_take(bp, tw, R, D, hidp);
   float* gates = bp.take((size_t)R * 4 * (m->pred_hidden > 0 ? m->pred_hidden : 1));
   if (!ok || !bp.ok) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
+  // all T steps' convolutions as one launch per layer (sf_savi_encode_batched_workspace_bytes): when the caller brought the room for it
+  float* big[3] = {nullptr, nullptr, nullptr};
+  const bool batched = !fork && n_pre == 0 && enc_batched_ok(m, B, T) && ws_bytes >= enc_ws_bytes(m, B, KV) + enc_batched_extra(m, B, T);
+  if (batched) {
+    for (int i = 0; i < 3; ++i) big[i] = bp.take((size_t)B * T * HW * cmax);
+    if (!bp.ok) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
+  }
 
   const float* prev = prev_slots;
   if (m->pred_rnn && (prev == nullptr || !state_valid)) {
@@ -932,6 +957,16 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
   const bool can_fuse_next = sf_get_encode_fuse_next() && can_prologue && su_mfma && m->pm_w0_p && m->pm_w2_p && m->kd_w0_p && m->pm_ln_g && m->pm_ln_b && m->pm_b0 &&
                              m->pm_b2 && m->kd_b0;
   bool next_done = false;
+  if (batched) {
+    // layer 0 per time step (the frames of one step lie T frames apart), every later layer over the B * T frames in [t][b] order; the last one
+    // leaves the features of step t at big[2] + t * B * HW * Cl
+    const long long frame_elems0 = (long long)3 * res * res;
+    const int c1 = m->enc_channels[1];
+    for (int t = 0; t < T; ++t)
+      SF_TRY(sf_conv2d_nchw_in_f32(img + (long long)t * frame_elems0, (long long)T * frame_elems0, m->conv_w[0], m->conv_b[0], nullptr,
+                                   big[0] + (long long)t * B * HW * c1, B, m->enc_channels[0], res, res, c1, m->enc_ks, res == 128 ? 2 : 1, 1, st_main));
+    SF_TRY(run_cnn_layers(m, nullptr, 0, B * T, big[2], big[0], big[1], 1, m->enc_layers, nullptr, nullptr, st_main));
+  }
   for (int t = 0; t < T; ++t) {
     float* kv = kv_base + (size_t)(t % KV) * kv_step;
     // ---- CNN encoder + per-pixel MLP + K/V for the B frames of step t ---------------------
@@ -945,6 +980,8 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
       const float* cur;
       if (t < n_pre) {
         cur = feat_pre + ((long long)t * B + b0) * HW * Cl0;   // computed ahead of time by sf_savi_cnn_f32
+      } else if (batched) {
+        cur = big[2] + ((long long)t * B + b0) * HW * Cl0;
       } else {
         float* dstf = (m->enc_layers & 1) ? featA : featB;   // the buffer the last conv does not read
         SF_TRY(run_cnn(m, img + ((long long)b0 * T + t) * frame_elems, (long long)T * frame_elems, nb, dstf, featA, featB, st));

@@ -97,6 +97,7 @@ extern "C" int sf_get_precision(void);
 int sf_conv5x5_ws_ex(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W, int Cin, int Cout, int ks,
                      int relu, int n_workgroups, hipStream_t st);
 extern "C" int sf_stream_cus(void* stream);
+extern "C" int sf_stream_cus_known(void* stream);   // 0: not a stream of sf_stream_create_cu_mask / sf_stream_set_cus
 int sf_conv5x5_rows4_ex(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W,
                         int Cin, int Cout, int ks, int relu, hipStream_t st);
 // the arguments of sf_slot_update_mfma_ex as a struct: the slot update as the first blocks of a convolution launch (conv_rows4.hip)

@@ -112,6 +112,22 @@ int sf_stream_cus(void* stream) {
   return dev_cus;
 }
 
+// 0 for a stream the library knows nothing about (sf_stream_cus answers the whole device for those)
+int sf_stream_cus_known(void* stream) {
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  auto it = g_stream_cus.find(stream);
+  return it != g_stream_cus.end() ? it->second : 0;
+}
+
+// Tell the library how many CUs the launches issued on `stream` will run on when that is not the stream's own mask: a stream that CAPTURES a graph
+// replayed on a CU-masked stream (the pipeline's encode graphs).  cus <= 0 forgets the entry.
+int sf_stream_set_cus(void* stream, int cus) {
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  if (cus > 0) g_stream_cus[stream] = cus;
+  else g_stream_cus.erase(stream);
+  return 0;
+}
+
 int sf_stream_destroy(void* stream) {
   if (!stream) return 0;
   {

@@ -437,6 +437,9 @@ def savi_encode(m, img, prev_slots=None, noise=None, want_attn=False, ws_slot=0,
         side_stream = _auto_side_stream(dev) if side_stream == 'auto' else None
     if side_stream is not None:
         need = lib().sf_savi_encode_fork_workspace_bytes(C.byref(plan.struct), B, T)
+    elif feat_pre is None:
+        # (room for the convolutions of all T steps as one launch per layer: csrc/engine.hip, batched form)
+        need = lib().sf_savi_encode_batched_workspace_bytes(C.byref(plan.struct), B, T)
     else:
         need = lib().sf_savi_encode_workspace_bytes(C.byref(plan.struct), B)
     ws = workspace(dev, need, ('enc', ws_slot))

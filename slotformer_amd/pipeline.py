@@ -432,7 +432,7 @@ class EncodeRolloutPipeline:
             # (units of more than 4 batches -- unit_batches_for: long runs of small batches -- make the rollouts cheaper per batch and the encode the
             #  bound by more: C4 with units of 7 at 84 batches, every 5th / 4th / 3rd / 2nd batch: 236.0 / 242.9 / 250.6 / 250.9 k)
             # (token-stationary units leave the rollout partition 40 % slack: every second batch -- C2 at 60 batches: 592 / 565 / 554 k with 2 / 3 / 4)
-            self.hybrid = int(os.environ.get('SF_PIPE_HYBRID', ('2' if self.tok else '3' if self.G > 4 else '5') if balanced else '0'))
+            self.hybrid = int(os.environ.get('SF_PIPE_HYBRID', ('4' if self.tok else '3' if self.G > 4 else '5') if balanced else '0'))
         self.hybrid_tail = int(os.environ.get('SF_PIPE_HYBRID_TAIL', str(min(self.hybrid, 3))))
         self.fill_batches = int(os.environ.get('SF_PIPE_FILL', '0')) or (fill_units * self.G if partition == 'pair' else 0)
         self.fill_steal = int(os.environ.get('SF_PIPE_FILL_STEAL', '0'))
@@ -792,6 +792,16 @@ class EncodeRolloutPipeline:
             # branches (engine.savi_encode side_stream=; the seven-workgroup launches of the slot branch no longer hold up the convolutions)
             fork_here = self.encode_fork and (os.environ.get('SF_PIPE_ENCODE_FORK') != 'fill' or not isinstance(lane, int))
             side2 = torch.cuda.Stream(device=self.dev) if fork_here else None
+            # the graph of a CU-masked lane replays on that lane's CUs: the persistent kernels inside it (csrc/conv_ws.hip: one workgroup per CU)
+            # size their grids for those, not for the capture stream's whole chip
+            lane_cus = int(self.encode_cus // max(len(self.lanes), 1)) if (isinstance(lane, int) and self.cu_split) else 0
+            if not isinstance(lane, int) and self.cu_split and self.tok:
+                # the whole-chip fill / hybrid graphs of a pipeline whose rollout units hold their CUs for a whole launch anyway (token-stationary
+                # units): one persistent convolution workgroup per CU of the device -- C2 at 20 / 60 batches 545 -> 567 k, 551 -> 612 k frames/s with
+                # every 4th batch on the hybrid lane (192 / 384 / 512 workgroups: 574 / 559 / 565 k at 20; profiles/r05_probes.txt)
+                lane_cus = int(os.environ.get('SF_PIPE_FILL_WS', str(self._lib.sf_stream_cus(None))))
+            if lane_cus:
+                self._lib.sf_stream_set_cus(C.c_void_p(side.cuda_stream), lane_cus)
             with torch.cuda.stream(side):
                 engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws, side_stream=side2)   # workspace, plans
                 side.synchronize()
@@ -799,6 +809,8 @@ class EncodeRolloutPipeline:
                 with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
                     post, _, _ = engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws, side_stream=side2)
             cur.wait_stream(side)
+            if lane_cus:
+                self._lib.sf_stream_set_cus(C.c_void_p(side.cuda_stream), 0)
             eg['graph'], eg['post'] = g, post
             self._enc_graphs[key] = eg
         return eg

@@ -13,9 +13,10 @@ SWITCHES = {
     # ---- product: the batch pipeline ----
     'SF_PIPE_TOK': ('product', "0: the pipeline never uses the token-stationary layer launches (every unit bit-identical to the serial module calls)"),
     'SF_PIPE_GROUP': ('product', "batches per rollout unit (default: 6 for token-stationary units of 32-video batches, else 4 / unit_batches_for)"),
-    'SF_PIPE_HYBRID': ('product', "every k-th batch behind the fill is encoded on an unmasked stream beside the CU-masked lane (default 2 with token-stationary units, 3 / 5 / 0 otherwise)"),
+    'SF_PIPE_HYBRID': ('product', "every k-th batch behind the fill is encoded on an unmasked stream beside the CU-masked lane (default 4 with token-stationary units, 3 / 5 / 0 otherwise)"),
     'SF_PIPE_HYBRID_TAIL': ('probe', "no hybrid-lane encode among the last k batches of a run (default min(hybrid, 3))"),
     'SF_PIPE_FILL': ('product', "batches encoded on the whole chip at the start of a run (default: three units' worth)"),
+    'SF_PIPE_FILL_WS': ('probe', "workgroups of the weights-stationary convolution inside the whole-chip fill / hybrid encode graphs (default: the device's CU count in pipelines with token-stationary units, else 0 = the 4-row tiles)"),
     'SF_PIPE_FILL_PAR': ('probe', "whole-chip encodes side by side during the fill (default 2)"),
     'SF_PIPE_CU_SPLIT': ('product', "CU mask of the encode partition, e.g. rows4 (default: sized from the two sides' CU time)"),
     'SF_PIPE_ENCODE_GRAPH': ('product', "replay the encode of a batch from a hipGraph (1, default) or launch it eagerly (0)"),
@@ -63,6 +64,7 @@ SWITCHES = {
     'SF_PIXEL_TILE': ('probe', "pixels per workgroup of the per-pixel chain (64 default / 128)"),
     'SF_PIXEL_PIX': ('probe', "pixel tile of the 192-wide chain"),
     'SF_QKV_TILE_ROWS': ('probe', "128: one weight stream per 128 rows in the q|k|v row-tile kernel"),
+    'SF_CONV_WS': ('probe', "0: the 4-row-tile convolution everywhere (default: the weights-stationary kernel on streams with CUs of their own)"),
     'SF_CONV_HALO': ('probe', "0: the generic implicit-GEMM convolution instead of the halo / row-tile kernels"),
     'SF_CONV_FIRST': ('probe', "0: the generic path for the first convolution"),
     'SF_CONV_CFG': ('probe', "tile configuration of the implicit-GEMM convolution"),
