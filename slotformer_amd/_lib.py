@@ -279,6 +279,84 @@ SIGNATURES = {
 _lib = None
 
 
+class _CaptureGate:
+    """Stream capture and kernel launches from other host threads do not mix on this runtime: with a hipGraph capture under way on one thread
+    (thread-local capture mode) launches from other threads were seen to return wrong results, `invalid argument`, or to crash hipStreamEndCapture
+    (tests/test_rollout_opts_gpu.py::test_options_are_per_call_and_per_thread late in a long process).  So every call into the library holds this
+    gate SHARED and a capture (EncodeRolloutPipeline building its graphs) holds it EXCLUSIVE: launches of other threads wait the few milliseconds a
+    capture takes; the capturing thread's own calls pass."""
+
+    def __init__(self):
+        import threading
+        self._cond = threading.Condition()
+        self._readers = 0
+        self._writer = None
+        self._depth = 0
+        self._ident = threading.get_ident
+
+    def enter_shared(self):
+        me = self._ident()
+        with self._cond:
+            if self._writer == me:
+                return False
+            while self._writer is not None:
+                self._cond.wait()
+            self._readers += 1
+            return True
+
+    def exit_shared(self):
+        with self._cond:
+            self._readers -= 1
+            if self._readers == 0:
+                self._cond.notify_all()
+
+    def __enter__(self):
+        me = self._ident()
+        with self._cond:
+            if self._writer == me:
+                self._depth += 1
+                return self
+            while self._writer is not None or self._readers > 0:
+                self._cond.wait()
+            self._writer, self._depth = me, 1
+        return self
+
+    def __exit__(self, *exc):
+        with self._cond:
+            self._depth -= 1
+            if self._depth == 0:
+                self._writer = None
+                self._cond.notify_all()
+        return False
+
+
+CAPTURE_GATE = _CaptureGate()
+
+
+class _Gated:
+    """The loaded library with every entry point behind CAPTURE_GATE (shared)."""
+
+    def __init__(self, h):
+        self.__dict__['_h'] = h
+
+    def __getattr__(self, name):
+        f = getattr(self._h, name)
+        if not callable(f):
+            return f
+        gate = CAPTURE_GATE
+
+        def call(*a):
+            held = gate.enter_shared()
+            try:
+                return f(*a)
+            finally:
+                if held:
+                    gate.exit_shared()
+        call.__name__ = name
+        self.__dict__[name] = call
+        return call
+
+
 def lib():
     """Load the HIP library (once).  Fails loudly when it has not been built."""
     global _lib
@@ -294,7 +372,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)  # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
-        _lib = h
+        _lib = _Gated(h)
     return _lib
 
 

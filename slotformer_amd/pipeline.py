@@ -665,8 +665,9 @@ class EncodeRolloutPipeline:
             torch.cuda.synchronize(self.dev)
             if self.use_graph:
                 g = torch.cuda.CUDAGraph()
-                # (thread_local: other host threads may keep allocating / synchronising while this one captures)
-                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                # (thread_local: other host threads may keep allocating / synchronising while this one captures; their calls into the library
+                #  wait at _lib.CAPTURE_GATE: launches beside a capture are not safe on this runtime)
+                with _lib.CAPTURE_GATE, torch.cuda.graph(g, capture_error_mode='thread_local'):
                     self._rollout_eager(u)
                 u.graph = g
         return u
@@ -806,7 +807,7 @@ class EncodeRolloutPipeline:
                 engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws, side_stream=side2)   # workspace, plans
                 side.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
+                with _lib.CAPTURE_GATE, torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
                     post, _, _ = engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws, side_stream=side2)
             cur.wait_stream(side)
             if lane_cus:

@@ -264,9 +264,9 @@ def test_options_are_per_call_and_per_thread(dev):
         t.join()
     torch.cuda.synchronize()
     assert not errors, errors
-    assert all(torch.equal(o, ref_pipe) for o in results['pipe'])
-    assert all(torch.equal(o, ref_default) for o in results['default'])
-    assert all(torch.equal(o, ref_bf16) for o in results['bf16'])
+    for name, ref in (('pipe', ref_pipe), ('default', ref_default), ('bf16', ref_bf16)):
+        diffs = [(o - ref).abs().max().item() for o in results[name]]
+        assert all(torch.equal(o, ref) for o in results[name]), (name, diffs)
     assert (lib.sf_get_precision(), lib.sf_get_seam_fused(), lib.sf_get_ffn_rows64()) == before
 
 
