@@ -119,6 +119,9 @@ def rollout_flops(roll, T, H):
     return tot
 
 
+ALLOW_STALE_TRACE = '--allow-stale-trace' in sys.argv
+
+
 def committed_profile(key):
     """Entry `key` of the newest committed PMC summary (profiles/r*_pmc_traffic.json); {} when absent."""
     import glob
@@ -131,7 +134,7 @@ def committed_profile(key):
         d['source'] = os.path.relpath(files[-1], ROOT)
         # the trace describes the kernels of ONE source tree: a summary taken from other sources must not price this run
         now = source_tree_hash()
-        if full.get('source_tree') != now and os.environ.get('SF_BENCH_ALLOW_STALE_TRACE') != '1':
+        if full.get('source_tree') != now and not ALLOW_STALE_TRACE:
             # no number of a trace taken from OTHER kernel sources enters the line: the objects fall back to this run's HIP events
             return {'stale_trace': os.path.relpath(files[-1], ROOT), 'trace_source_tree': full.get('source_tree'), 'source_tree': now}
         d['source_tree'] = now
@@ -279,9 +282,9 @@ def self_launch(n):
     sock.bind(('127.0.0.1', 0))
     port = sock.getsockname()[1]
     sock.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), SF_BENCH_FORCE_DIST='1')   # (a launched job always forms its RCCL group, also with one rank)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           '--master-port', str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != '--self-launch'] + ['--force-dist']   # (a launched job always forms its RCCL group, also with one rank)
     print(f'[bench] launching {n} ranks: {" ".join(cmd)}', file=sys.stderr, flush=True)
     return subprocess.call(cmd, env=env)
 
@@ -452,11 +455,21 @@ def main():
     ap.add_argument('--decode', action='store_true', help='also time encode + rollout + DECODE of every predicted frame (reconstruction + postproc_mask '
                     'segmentation, what test_vp.py scores): a secondary object `decode_pipeline` + `roofline_decode`, never `value`')
     ap.add_argument('--decode-steps', type=int, default=8, help='batches per timed window of the --decode leg')
+    ap.add_argument('--group', type=int, default=None, help='batches per rollout unit of the pipeline (default: the pipeline\'s own choice)')
+    ap.add_argument('--enc-group', type=int, default=0, help='batches handed to the pipeline as one (default: pipeline.encode_group_for)')
+    ap.add_argument('--cu-split', default='ff', help='encode CU mask of the pipeline: hex word, or rows<R> (pipeline.encode_mask_words)')
+    ap.add_argument('--partition', choices=['pair', 'three', 'two', 'none'], default='pair')
+    ap.add_argument('--steal', type=float, default=None, help='time steps of convolutions per batch computed on the rollout streams (default: the partition\'s)')
+    ap.add_argument('--force-dist', action='store_true', help='form the RCCL process group with one rank too (the multi-GPU path on one GPU)')
+    ap.add_argument('--self-launch', action='store_true', help='take the torch.distributed.run self-launch path with --gpus 1 too')
+    ap.add_argument('--live-every', type=int, default=4, help='bracket every n-th conv / Slot-Attention launch with events in the untimed live pass')
+    ap.add_argument('--live-mask', type=int, default=(1 << 0) | (1 << 3), help='kernel classes of that pass')
+    ap.add_argument('--allow-stale-trace', action='store_true', help='use the committed rocprof summary although the kernel sources changed')
     ap.add_argument('--windows', type=int, default=5, help='timed windows of --steps steps each on the warm pipeline; value = the median window')
     args = ap.parse_args()
 
-    if (args.gpus > 1 or os.environ.get('SF_BENCH_SELF_LAUNCH') == '1') and 'WORLD_SIZE' not in os.environ:
-        # (SF_BENCH_SELF_LAUNCH=1: take the launcher path with --gpus 1 too -- how tests/test_dist_gpu.py runs it on the one GPU of the box)
+    if (args.gpus > 1 or args.self_launch) and 'WORLD_SIZE' not in os.environ:
+        # (--self-launch: take the launcher path with --gpus 1 too -- how tests/test_dist_gpu.py runs it on the one GPU of the box)
         # plain `python bench.py --gpus N`: this process becomes the launcher of its own N ranks (one process per GPU, the
         # reference's launch shape: scripts/sbatch_run.sh:36-42) and passes rank 0's JSON line through
         sys.exit(self_launch(args.gpus))
@@ -478,7 +491,7 @@ def main():
         fail(f'rank {rank} needs device {local}, {torch.cuda.device_count()} visible', args, code=2)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    use_dist = world > 1 or os.environ.get('SF_BENCH_FORCE_DIST') == '1'  # the latter: exercise the RCCL path on one GPU
+    use_dist = world > 1 or args.force_dist  # the latter: exercise the RCCL path on one GPU
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -502,17 +515,17 @@ def main():
     # encode (predictor, Slot-Attention iterations, slot updates) is latency-bound and costs the same for 16 videos as for 32 (C4: 3.3 vs 2.5 ms per 16
     # videos on the encode lane).  Every batch still runs its full encode + rollout inside the timed region; the concatenation is part of it.
     from slotformer_amd.pipeline import encode_group_for
-    E = int(os.environ.get('SF_BENCH_ENC_GROUP', '0')) or encode_group_for(B, args.steps)
+    E = int(args.enc_group) or encode_group_for(B, args.steps)
     if args.steps % E or args.no_overlap:
         E = 1
     Bp = B * E                                                   # videos per pipeline batch
     ringp = ring if E == 1 else [torch.cat([ring[(k + i) % 3] for i in range(E)], 0) for k in range(3)]   # (for the untimed extras)
-    cu_word = os.environ.get('SF_BENCH_CU_SPLIT', 'ff')          # hex mask word, or rows<R> (pipeline.encode_mask_words)
+    cu_word = args.cu_split          # hex mask word, or rows<R> (pipeline.encode_mask_words)
     cu_word = cu_word if cu_word.startswith('rows') else int(cu_word, 16)
-    steal = os.environ.get('SF_BENCH_STEAL')                   # None: the partition's default
+    steal = args.steal                   # None: the partition's default
     steal = None if steal is None else float(steal)
-    partition = os.environ.get('SF_BENCH_PARTITION', 'pair')   # 'pair' | 'three' | 'two' | 'none' (pipeline.EncodeRolloutPipeline)
-    group = os.environ.get('SF_BENCH_GROUP')
+    partition = args.partition   # 'pair' | 'three' | 'two' | 'none' (pipeline.EncodeRolloutPipeline)
+    group = args.group
     group = None if group is None else int(group)
     if group is None:
         from slotformer_amd.pipeline import unit_batches_for
@@ -576,9 +589,9 @@ def main():
         log(f'timed windows done: {[round(x, 4) for x in windows_all]} s')
         # conv + Slot-Attention launches LIVE: a second pass of the same schedule with library brackets (HIP events on the launch
         # stream) around every LIVE_EVERY-th launch of the two classes
-        LIVE_EVERY = int(os.environ.get('SF_BENCH_LIVE_EVERY', '4'))
+        LIVE_EVERY = int(args.live_every)
         lib.sf_profile_sample(LIVE_EVERY)
-        lib.sf_profile_enable(int(os.environ.get('SF_BENCH_LIVE_MASK', str((1 << 0) | (1 << 3)))))
+        lib.sf_profile_enable(int(args.live_mask))
         read_profile(lib)
         run(max(args.warmup, 6), out_w)
         torch.cuda.synchronize()

@@ -354,7 +354,7 @@ int sf_ffn_block_rows_f32(const sf_tfm_layer* w, const float* x2, float* y, int 
 size_t sf_layer_tok_packed_bytes(void);
 int sf_pack_layer_tok_weights(const sf_tfm_layer* w, void* packed, int d_model, int num_heads, int ffn, void* stream);
 int sf_layer_tok_block_f32(const sf_tfm_layer* w, int nl, const float* x, float* y, int B, int L, void* stream);
-int sf_debug_read_ts_layer_tok(long long* out16);   /* wall-clock stamps (10 ns) of workgroup 0 with SF_LT_DBG=1 */
+int sf_debug_read_ts_layer_tok(long long* out16);   /* wall-clock stamps (10 ns) of workgroup 0 with SF_DBG=lt */
 size_t sf_attn_rows_planes_bytes(int B);
 int sf_attn_block_rows_f32(const sf_tfm_layer* w, const float* x, float* out, void* planes, int B, int L, int Lq, void* stream);
 
@@ -627,13 +627,7 @@ size_t sf_savi_encode_fork_workspace_bytes(const sf_savi_encoder* m, int B, int 
  * buffers of B * T frames on top of sf_savi_encode_workspace_bytes): sf_savi_encode_fork_f32 takes that form when it is handed this much and the
  * encoder has fragment weights on every layer behind the first (B <= 32, T >= 2, split-bf16); the same bits as the step-by-step order. */
 size_t sf_savi_encode_batched_workspace_bytes(const sf_savi_encoder* m, int B, int T);
-/* Order of a ONE-stream encode (process-wide; default 0, SF_ENC_INTERLEAVE=1: 1 -- measured +1.7 % on the encode lane only, csrc/engine.hip).  1: where the configuration allows it (folded Slot Attention at width 128,
- * matrix-core slot update, at most 32 videos) the image features of time step t + 1 are computed inside the slot branch of step t, every fragment-weight
- * convolution of them as ONE launch with a slot update of step t riding as its first workgroups (csrc/conv_rows4.hip: conv5x5_rows4_update_kernel).
- * The same kernels' arithmetic in another launch order: bit-identical results. */
-int sf_set_encode_interleave(int on);
-int sf_get_encode_interleave(void);
-/* Where the slot prologue of time step t + 1 runs (process-wide; default 1, SF_ENC_FUSE_NEXT=0: 0).  1: with the packed predictor / kernel-distribution
+/* Where the slot prologue of time step t + 1 runs (process-wide; default 1).  1: with the packed predictor / kernel-distribution
  * copies of sf_savi_encoder (pm_w0_p, pm_w2_p, kd_w0_p) and the matrix-core slot update, at the tail of step t's last slot update -- one launch fewer per
  * time step, its products on the split-bf16 matrix path like the update's; 0: as its own launch on every step (fp32 thread-per-output products).  The
  * two agree to split-bf16 rounding (~1e-6 relative), not bit for bit; step 0 of a call always takes the stand-alone launch. */

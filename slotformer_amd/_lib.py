@@ -243,8 +243,6 @@ SIGNATURES = {
                                    VP]),
     'sf_savi_encode_fork_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I, I]),
     'sf_savi_encode_batched_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I, I]),
-    'sf_set_encode_interleave': (I, [I]),
-    'sf_get_encode_interleave': (I, []),
     'sf_set_encode_fuse_next': (I, [I]),
     'sf_get_encode_fuse_next': (I, []),
     'sf_savi_encode_fork_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, I, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,

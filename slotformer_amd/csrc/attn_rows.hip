@@ -78,7 +78,7 @@ __device__ __forceinline__ int div_rows(int m, int L, float invL) {
 }
 }  // namespace
 
-__device__ long long ar_ts[32];   // phase timestamps of workgroup 0 (SF_LF_DBG & 16)
+__device__ long long ar_ts[32];   // phase timestamps of workgroup 0 (SF_DBG=lf=16)
 #define RTS(i) do { if ((A.dbg & 16) && blockIdx.x == 0 && threadIdx.x == 0) ar_ts[i] = wall_clock64(); } while (0)
 
 // RING: the rows are the cached in-projections of the window's frames (ring of `ring_frames` frames per video) + the position table;
@@ -516,10 +516,7 @@ __global__ __launch_bounds__(NT) void attn_core_kernel(CoreArgs A) {
 size_t sf_attn_rows_plane_bytes(int B) { return (size_t)B * NH * 6 * PL * 2; }
 
 static int ar_dbg() {
-  static const int v = [] {
-    const char* e = getenv("SF_LF_DBG");
-    return e ? atoi(e) : 0;
-  }();
+  static const int v = sf_dbg("lf");
   return v;
 }
 
@@ -551,9 +548,8 @@ int sf_attn_rows_ex(int mode, const float* xin, long long x_batch_stride, long l
   A.B = B; A.L = L; A.Lq = Lq; A.dbg = ar_dbg();
   // rows per tile: 64 -- twice the workgroups of 128-row tiles at half the time each (the launch is a link of a dependent chain; a
   // unit of 128 videos alone: 14.6 vs 17.6 ms, C2 417 vs 412 k frames/s, C5 385 vs 381 k) for twice the weight stream out of the
-  // L2s; SF_QKV_TILE_ROWS=128: one weight stream per 128 rows
-  static const int tr_env = getenv("SF_QKV_TILE_ROWS") ? atoi(getenv("SF_QKV_TILE_ROWS")) : 0;
-  const int TRr = tr_env == 128 ? 128 : 64;
+  // L2s
+  const int TRr = 64;
   A.nt = (B * L + TRr - 1) / TRr;
   const int ntq = (B * Lq + TRr - 1) / TRr;
   int extra = 0;

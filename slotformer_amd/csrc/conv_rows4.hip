@@ -14,7 +14,6 @@
 // Same products, same order per cin half as conv_halo.hip (taps ascending, k-steps ascending, x_lo w_hi + x_hi w_lo + x_hi w_hi).
 // Reference call site: the encoder convs i > 0, savi.py:231-239 (+ SoftPositionEmbed add, utils.py:60-63).
 #include "sf_internal.h"
-#include "slot_update_body.h"
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -68,7 +67,7 @@ __global__ void pack_conv_frag_kernel(const float* __restrict__ w, uint4* __rest
   }
 }
 
-__device__ long long cr_ts[16];   // phase timestamps of workgroup 0 (SF_CONV_DBG=1; sf_debug_read_ts_conv)
+__device__ long long cr_ts[16];   // phase timestamps of workgroup 0 (SF_DBG=conv; sf_debug_read_ts_conv)
 #define CTS(i) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) cr_ts[i] = wall_clock64(); } while (0)
 
 // F16X2 (opt-in, sf_set_conv_fp16x2 / SF_CONV_FP16X2=1; NOT the default arithmetic): the activations split into two fp16 terms (22 mantissa
@@ -76,8 +75,6 @@ __device__ long long cr_ts[16];   // phase timestamps of workgroup 0 (SF_CONV_DB
 // stream.  Measured error and speed: profiles/r03_probes.txt section 14.
 // HEAD (the SAVi decoder's stride-1 last layer at 64 x 64, savi.py:262-289: a convolution with the flipped kernel + ReLU, then the 1x1 output
 // convolution 64 -> 4): `add` = head_w [4][64], `head_b` [4], out = dec [F][H * 64][4] -- the 64-channel activation never reaches memory.
-// (a device function: the tiles also run as the blocks behind the slot-update workgroups of conv5x5_rows4_update_kernel; bid0 / nb: the tile's
-//  block index and the number of tile blocks of the launch)
 template <bool F16X2, bool HEAD = false>
 __device__ __forceinline__ void conv5x5_rows4_body(const float* __restrict__ in, const uint4* __restrict__ wf,
                                                    const float* __restrict__ bias, const float* __restrict__ add,
@@ -310,21 +307,6 @@ __global__ __launch_bounds__(NT) void conv5x5_rows4_kernel(const float* __restri
   conv5x5_rows4_body<F16X2, HEAD>(in, wf, bias, add, out, H, relu, dbg, head_b, lds, blockIdx.x, gridDim.x);
 }
 
-// HETEROGENEOUS launch (round 4): blocks 0 .. n_upd - 1 run the matrix-core slot update of a Slot-Attention iteration (slot_update_body.h: 32
-// slot rows each, seven workgroups at C2), the blocks behind them the 4-row tiles of a convolution of the NEXT time step's image features.  The
-// slot update alone is a 22 us launch of seven workgroups that leaves the rest of the encode partition idle, 12 times per batch; as the first
-// blocks of a 512-tile convolution launch it costs seven CUs one tile slot.  The two bodies do not communicate: the launch is exactly the two
-// kernels side by side (same arithmetic, same bits), ordered like both by the stream.
-__global__ __launch_bounds__(NT) void conv5x5_rows4_update_kernel(const float* __restrict__ in, const uint4* __restrict__ wf,
-                                                                  const float* __restrict__ bias, const float* __restrict__ add,
-                                                                  float* __restrict__ out, int H, int relu, UmArgs ua, int n_upd) {
-  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
-  if ((int)blockIdx.x < n_upd)
-    um_body(ua, (float*)lds, blockIdx.x);
-  else
-    conv5x5_rows4_body<false, false>(in, wf, bias, add, out, H, relu, 0, nullptr, lds, blockIdx.x - n_upd, gridDim.x - n_upd);
-}
-
 extern "C" size_t sf_conv_frag_bytes(int Cout, int Cin, int ks) { return (Cout == CH && Cin == CH && ks == KS) ? (size_t)FRAG_BYTES + FRAG16_BYTES : 0; }
 
 // opt-in arithmetic of the 4-row-tile convolution: 0 (default) split-bf16, three products; 1 activations as two fp16 terms x weights as ONE fp16, two products
@@ -335,7 +317,7 @@ extern "C" int sf_set_conv_fp16x2(int on) {
 }
 extern "C" int sf_get_conv_fp16x2(void) {
   if (g_conv_fp16x2 < 0) {
-    const char* e = getenv("SF_CONV_FP16X2");
+    const char* e = getenv("SF_CONV_FP16X2");   // (a product switch: the opt-in arithmetic)
     g_conv_fp16x2 = (e && e[0] == '1') ? 1 : 0;
   }
   return g_conv_fp16x2;
@@ -355,7 +337,7 @@ extern "C" int sf_pack_conv_frag_weights(const float* w_ohwi, void* frag, int Co
 int sf_conv5x5_rows4_ex(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W,
                         int Cin, int Cout, int ks, int relu, hipStream_t st) {
   if (!w_frag || W != TW || Cin != CH || Cout != CH || ks != KS || (H % TR) != 0 || F <= 0 || sf_get_precision() != 1) return 1;
-  static const int dbg = getenv("SF_CONV_DBG") ? atoi(getenv("SF_CONV_DBG")) : 0;
+  static const int dbg = sf_dbg("conv");
   // (the LDS attribute first: a failure here must not leave the class timer's pending event open)
   const bool f16 = sf_get_conv_fp16x2();
   SF_TRY(sf_ensure_dyn_lds(f16 ? (const void*)conv5x5_rows4_kernel<true> : (const void*)conv5x5_rows4_kernel<false>, LDS_BYTES));
@@ -369,34 +351,11 @@ int sf_conv5x5_rows4_ex(const float* in, const void* w_frag, const float* bias, 
   return 0;
 }
 
-// The convolution with the slot update of sf_slot_update_mfma_ex riding as its first blocks (conv5x5_rows4_update_kernel).  Returns 1 when it does
-// not apply (the caller launches the two kernels one after the other).
-int sf_conv5x5_rows4_update_ex(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W, int Cin,
-                               int Cout, int ks, int relu, const SfSlotUpdateArgs& u, hipStream_t st) {
-  if (!w_frag || W != TW || Cin != CH || Cout != CH || ks != KS || (H % TR) != 0 || F <= 0 || sf_get_precision() != 1 || sf_get_conv_fp16x2()) return 1;
-  if (!sf_slot_update_mfma_ok(u.D, u.H, u.P) || u.B <= 0) return 1;
-  static_assert(UM_LDS <= LDS_BYTES, "the slot update's LDS fits the convolution's");
-  SF_TRY(sf_ensure_dyn_lds((const void*)conv5x5_rows4_update_kernel, LDS_BYTES));
-  UmArgs a;
-  memset(&a, 0, sizeof(a));
-  a.part_num = u.part_num; a.part_den = u.part_den; a.P = u.P; a.slots_prev = u.slots_prev;
-  a.w_ih_p = (const uint4*)u.gru_ih_p; a.w_hh_p = (const uint4*)u.gru_hh_p; a.b_ih = u.gru_b_ih; a.b_hh = u.gru_b_hh; a.ln_g = u.ln_g; a.ln_b = u.ln_b;
-  a.w1_p = (const uint4*)u.w1_p; a.b1 = u.b1; a.w2_p = (const uint4*)u.w2_p; a.b2 = u.b2; a.slots_out = u.slots_out; a.out2 = u.out2; a.out2_bs = u.out2_bs;
-  a.q_ln_g = u.q_ln_g; a.q_ln_b = u.q_ln_b; a.q_w_p = (const uint4*)u.q_w_p; a.q_out = u.q_out; a.R = u.B * u.N; a.N = u.N; a.ln_eps = u.ln_eps;
-  const int n_upd = (a.R + UM_ROWS - 1) / UM_ROWS;
-  sf_prof_begin(SF_K_CONV_NHWC, st, 2.0 * (double)F * H * W * Cout * ks * ks * Cin);
-  hipLaunchKernelGGL(conv5x5_rows4_update_kernel, dim3(n_upd + F * (H / TR)), dim3(NT), LDS_BYTES, st, in, (const uint4*)w_frag, bias, add, out, H, relu, a,
-                     n_upd);
-  sf_prof_end(SF_K_CONV_NHWC, st);
-  SF_CHECK_LAUNCH();
-  return 0;
-}
-
 // The decoder's stride-1 last layer + 1x1 head (HEAD form above).  Returns 1 when the kernel does not apply.
 int sf_conv5x5_rows4_head_ex(const float* in, const void* w_frag, const float* bias, const float* head_w, const float* head_b, float* dec,
                              int F, int H, int W, int Cin, int Cout, int ks, hipStream_t st) {
   if (!w_frag || !head_w || !head_b || W != TW || Cin != CH || Cout != CH || ks != KS || (H % TR) != 0 || F <= 0 || sf_get_precision() != 1) return 1;
-  static const int dbg = getenv("SF_CONV_DBG") ? atoi(getenv("SF_CONV_DBG")) : 0;
+  static const int dbg = sf_dbg("conv");
   SF_TRY(sf_ensure_dyn_lds((const void*)conv5x5_rows4_kernel<false, true>, LDS_BYTES));
   sf_prof_begin(SF_K_DECONV, st, 2.0 * (double)F * H * W * Cout * ks * ks * Cin + 2.0 * (double)F * H * W * Cout * 4);
   hipLaunchKernelGGL((conv5x5_rows4_kernel<false, true>), dim3(F * (H / TR)), dim3(NT), LDS_BYTES, st, in, (const uint4*)w_frag, bias, head_w, dec, H,

@@ -37,7 +37,7 @@ static_assert(LDS_B <= 160 * 1024, "LDS budget");
 static_assert(PLANE_B + (32 + 4) * PS * 2 + 64 < 65536, "lo-plane reads stay inside the ds immediate offset");
 }  // namespace
 
-__device__ long long cw_ts[16];   // phase time stamps of workgroup 0 (SF_CONV_DBG=1; sf_debug_read_ts_conv_ws)
+__device__ long long cw_ts[16];   // phase time stamps of workgroup 0 (SF_DBG=conv; sf_debug_read_ts_conv_ws)
 #define WTS(i) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) cw_ts[i] = wall_clock64(); } while (0)
 
 #define WS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(NT) void conv5x5_ws_kernel(CwArgs A) {
 int sf_conv5x5_ws_ex(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W, int Cin, int Cout, int ks,
                      int relu, int n_workgroups, hipStream_t st) {
   if (!w_frag || W != TW || Cin != CH || Cout != CH || ks != KS || H < 1 || F <= 0 || relu < 0 || relu > 1 || sf_get_precision() != 1) return 1;
-  static const int dbg = getenv("SF_CONV_DBG") ? atoi(getenv("SF_CONV_DBG")) : 0;
+  static const int dbg = sf_dbg("conv");
   const long long rows = (long long)F * H;
   int nwg = n_workgroups;
   if (nwg <= 0) {

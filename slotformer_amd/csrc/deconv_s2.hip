@@ -99,7 +99,7 @@ __global__ void pack_deconv_frag_kernel(const float* __restrict__ w, uint4* __re
   out[idx] = o.u4;
 }
 
-__device__ long long dc_ts[16];   // phase timestamps of workgroup 0 (SF_DECONV_DBG=1; sf_debug_read_ts_deconv)
+__device__ long long dc_ts[16];   // phase timestamps of workgroup 0 (SF_DBG=deconv; sf_debug_read_ts_deconv)
 #define DTS(i) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dc_ts[i] = wall_clock64(); } while (0)
 
 // in [R][H][WIN][64] f32 NHWC.  HEAD = false: out [R][2H][2WIN][64] = relu?(deconv + bias).
@@ -351,7 +351,7 @@ int sf_deconv5x5s2_ex(const float* in, const void* w_frag, const float* bias, co
   if (W != 64 && W != 32 && W != 16) return 1;
   if (H % (256 / W) != 0) return 1;
   if (head_w && (W != 64 || !head_b)) return 1;
-  static const int dbg = getenv("SF_DECONV_DBG") ? atoi(getenv("SF_DECONV_DBG")) : 0;
+  static const int dbg = sf_dbg("deconv");
   if (head_w) return launch_deconv<64, true>(in, w_frag, bias, head_w, head_b, out, R, H, relu, st, dbg);
   if (W == 64) return launch_deconv<64, false>(in, w_frag, bias, nullptr, nullptr, out, R, H, relu, st, dbg);
   if (W == 32) return launch_deconv<32, false>(in, w_frag, bias, nullptr, nullptr, out, R, H, relu, st, dbg);

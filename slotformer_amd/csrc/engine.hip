@@ -654,25 +654,8 @@ int sf_rollout_bf16(const sf_rollouter* m, float* slots, int B, int T_total, int
 // ---------------------------------------------------------------------------------------------
 static int enc_chunk(int B) { return B < 32 ? B : 32; }
 
-// interleaved order of the encode (sf_savi_encode_fork_f32 below): OPT-IN (SF_ENC_INTERLEAVE=1 / sf_set_encode_interleave(1)).  Measured: the encode lane
-// 3.326 -> 3.270 ms per C2 batch, the bench 503 -> 504 k frames/s (profiles/r04_probes.txt section 7): a convolution launch is 512 tiles = exactly four
-// rounds of the 128-CU partition, each CU filled by one tile (153 KB of LDS), so the seven slot-update workgroups that ride in front push seven tiles
-// into a fifth round -- the launch grows by about what the separate 22 us launch cost.  Bit-identical; kept as the measured answer to "hide the small launches".
-static int g_enc_interleave = -1;
-int sf_set_encode_interleave(int on) {
-  g_enc_interleave = on ? 1 : 0;
-  return 0;
-}
-int sf_get_encode_interleave(void) {
-  if (g_enc_interleave < 0) {
-    const char* e = getenv("SF_ENC_INTERLEAVE");
-    g_enc_interleave = (e && e[0] == '1') ? 1 : 0;
-  }
-  return g_enc_interleave;
-}
-
 // the slot prologue of step t + 1 at the tail of step t's last slot update (slot_update_mfma.hip, NEXT form): on by default where it applies;
-// SF_ENC_FUSE_NEXT=0 / sf_set_encode_fuse_next(0): the prologue as its own launch (sa_slot_prologue_kernel) on every step
+// sf_set_encode_fuse_next(0): the prologue as its own launch (sa_slot_prologue_kernel) on every step
 static int g_enc_fuse_next = -1;
 int sf_set_encode_fuse_next(int on) {
   g_enc_fuse_next = on ? 1 : 0;
@@ -680,8 +663,7 @@ int sf_set_encode_fuse_next(int on) {
 }
 int sf_get_encode_fuse_next(void) {
   if (g_enc_fuse_next < 0) {
-    const char* e = getenv("SF_ENC_FUSE_NEXT");
-    g_enc_fuse_next = (e && e[0] == '0') ? 0 : 1;
+    g_enc_fuse_next = 1;
   }
   return g_enc_fuse_next;
 }
@@ -732,10 +714,9 @@ static size_t enc_ws_bytes(const sf_savi_encoder* m, int B, int kv_steps) {
 
 // CNN stack (savi.py:231-244: convs + soft position embedding) for `nb` frames: frame i at src + i*frame_stride;
 // the last conv writes into `dst` (NHWC [nb,64,64,C_last]); featA/featB are ping-pong scratch.
-// layers [i0, i1) of the stack; upd != NULL (i1 == i0 + 1, a fragment-weight layer): that layer's launch carries the slot update `upd` as its first
-// blocks (conv5x5_rows4_update_kernel); *upd_done says whether it did
+// layers [i0, i1) of the stack
 static int run_cnn_layers(const sf_savi_encoder* m, const float* src, long long frame_stride, int nb, float* dst, float* featA, float* featB,
-                          int i0, int i1, const SfSlotUpdateArgs* upd, bool* upd_done, hipStream_t st) {
+                          int i0, int i1, hipStream_t st) {
   const int res = m->resolution;
   for (int i = i0; i < i1; ++i) {
     const bool lastc = (i == m->enc_layers - 1);
@@ -749,10 +730,6 @@ static int run_cnn_layers(const sf_savi_encoder* m, const float* src, long long 
     } else {
       // 64 -> 64 channels with a fragment-ordered weight copy: 4-row tiles, weights streamed as MFMA fragments (conv_rows4.hip)
       int rc = 1;
-      if (m->conv_w_frag[i] && upd) {
-        rc = sf_conv5x5_rows4_update_ex(cur, m->conv_w_frag[i], m->conv_b[i], add, out, nb, 64, 64, cin, cout, m->enc_ks, lastc ? 0 : 1, *upd, st);
-        if (rc == 0 && upd_done) *upd_done = true;
-      }
       // (weights stationary in registers where the launch gives every CU of the stream its rows: conv_ws.hip -- the same bits)
       if (rc == 1 && m->conv_w_frag[i])
         rc = sf_conv5x5_ws_ex(cur, m->conv_w_frag[i], m->conv_b[i], add, out, nb, 64, 64, cin, cout, m->enc_ks, lastc ? 0 : 1, 0, st);
@@ -767,7 +744,7 @@ static int run_cnn_layers(const sf_savi_encoder* m, const float* src, long long 
 }
 static int run_cnn(const sf_savi_encoder* m, const float* src, long long frame_stride, int nb, float* dst, float* featA,
                    float* featB, hipStream_t st) {
-  return run_cnn_layers(m, src, frame_stride, nb, dst, featA, featB, 0, m->enc_layers, nullptr, nullptr, st);
+  return run_cnn_layers(m, src, frame_stride, nb, dst, featA, featB, 0, m->enc_layers, st);
 }
 
 size_t sf_savi_cnn_workspace_bytes(const sf_savi_encoder* m, int B) {
@@ -941,18 +918,10 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
   const bool su_packed = sf_get_precision() >= 1 && gru_ih_p && m->sa_gru_hh_p && m->sa_mlp_w1_p && m->sa_mlp_w2_p && q_w_p;
   const bool su_mfma = su_packed && sf_slot_update_mfma_ok(D, Hm, P);
   const bool su_wide = su_packed && sf_slot_update_wide_ok(D, Hm, P);   // slot size 192 (slot_update_wide.hip)
-  // INTERLEAVED order (round 4; one stream, the CLEVRER-shaped configuration: folded Slot Attention at width 128, matrix-core slot update, one
-  // chunk of frames): the image features of step t + 1 are computed INSIDE the slot branch of step t -- its first convolution behind the
-  // prologue, and every following fragment-weight convolution as ONE launch with a slot update (the update's seven workgroups ride as the first
-  // blocks of the convolution's 512 tiles, conv5x5_rows4_update_kernel) -- so the 22 us seven-workgroup launches no longer hold the partition.
-  // Same kernels' arithmetic, same bits.  Opt-in (see sf_get_encode_interleave above for what it measured).
-  const bool inter = sf_get_encode_interleave() && !fork && fold && !feat192 && su_mfma && B <= Bc && m->enc_layers >= 2 && T >= 2 && !t_plain_gemms;
-  const int Cl_feat = m->enc_channels[m->enc_layers];
-  float* const dst_feat = (m->enc_layers & 1) ? featA : featB;   // the buffer the last conv does not read
   // time-step order; forked: the features of step t are enqueued on `stream`, its slot branch on `side_stream` behind them (event),
   // and the features of step t + KV wait for the slot branch of step t to release its ring slot
   // the one-launch slot prologue applies (CLEVRER configuration); with packed copies of its three matrices and the matrix-core slot update, the
-  // prologue of step t + 1 runs at the tail of step t's last update (slot_update_mfma.hip, NEXT form; SF_ENC_FUSE_NEXT=0: as its own launch)
+  // prologue of step t + 1 runs at the tail of step t's last update (slot_update_mfma.hip, NEXT form)
   const bool can_prologue = m->pred_type == 0 && !m->pred_rnn && m->kd_mode == 1 && m->pm_w0_t && m->pm_w2_t && m->kd_w0_t && q_w_t;
   const bool can_fuse_next = sf_get_encode_fuse_next() && can_prologue && su_mfma && m->pm_w0_p && m->pm_w2_p && m->kd_w0_p && m->pm_ln_g && m->pm_ln_b && m->pm_b0 &&
                              m->pm_b2 && m->kd_b0;
@@ -965,7 +934,7 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
     for (int t = 0; t < T; ++t)
       SF_TRY(sf_conv2d_nchw_in_f32(img + (long long)t * frame_elems0, (long long)T * frame_elems0, m->conv_w[0], m->conv_b[0], nullptr,
                                    big[0] + (long long)t * B * HW * c1, B, m->enc_channels[0], res, res, c1, m->enc_ks, res == 128 ? 2 : 1, 1, st_main));
-    SF_TRY(run_cnn_layers(m, nullptr, 0, B * T, big[2], big[0], big[1], 1, m->enc_layers, nullptr, nullptr, st_main));
+    SF_TRY(run_cnn_layers(m, nullptr, 0, B * T, big[2], big[0], big[1], 1, m->enc_layers, st_main));
   }
   for (int t = 0; t < T; ++t) {
     float* kv = kv_base + (size_t)(t % KV) * kv_step;
@@ -974,7 +943,7 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
     if (fork && t >= KV) {   // the ring slot is free once the slot branch of step t - KV has read it
       if (hipStreamWaitEvent(st_main, enc_fork_event(T + 1 + (t - KV)), 0) != hipSuccess) return sf_set_err((int)hipGetLastError(), "hipStreamWaitEvent", __FILE__, __LINE__);
     }
-    for (int b0 = 0; b0 < B && !(inter && t > 0); b0 += Bc) {   // (interleaved: the features of steps > 0 were computed inside the previous step)
+    for (int b0 = 0; b0 < B; b0 += Bc) {
       const int nb = (B - b0 < Bc) ? (B - b0) : Bc;
       const int Cl0 = m->enc_channels[m->enc_layers];
       const float* cur;
@@ -1120,15 +1089,6 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
     }
     // ---- Slot Attention iterations (savi.py:76-100) -------------------------------------------
     const float scale = 1.0f / sqrtf((float)D);
-    // interleaved: the next step's features start here (its first convolution), unless they were computed ahead of the call (feat_pre)
-    const bool next_feat = inter && t + 1 < T;
-    const bool next_cnn = next_feat && t + 1 >= n_pre;
-    const float* img_next = img + (long long)(t + 1) * frame_elems;
-    int next_layer = 0;   // the next convolution layer of step t + 1 still to run
-    if (next_cnn) {
-      SF_TRY(run_cnn_layers(m, img_next, (long long)T * frame_elems, B, dst_feat, featA, featB, 0, 1, nullptr, nullptr, st));
-      next_layer = 1;
-    }
     for (int it = 0; it < m->num_iterations; ++it) {
       const bool last_it = (it == m->num_iterations - 1);
       float* aout = (attn && last_it) ? attn + (long long)t * N * HW : nullptr;
@@ -1155,16 +1115,6 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
                                         &nx));
           next_done = true;
           rode = true;
-        } else if (next_cnn && next_layer < m->enc_layers && m->conv_w_frag[next_layer]) {
-          // this slot update as the first blocks of the next step's convolution `next_layer`
-          SfSlotUpdateArgs u;
-          u.part_num = pnum; u.part_den = pden; u.P = P; u.slots_prev = s_in; u.gru_ih_p = gru_ih_p; u.gru_hh_p = m->sa_gru_hh_p;
-          u.gru_b_ih = m->gru_b_ih; u.gru_b_hh = m->gru_b_hh; u.ln_g = m->mlp_ln_g; u.ln_b = m->mlp_ln_b; u.w1_p = m->sa_mlp_w1_p; u.b1 = m->mlp_b1;
-          u.w2_p = m->sa_mlp_w2_p; u.b2 = m->mlp_b2; u.slots_out = s_out; u.out2 = last_it ? post_slots + (long long)t * N * D : nullptr;
-          u.out2_bs = (long long)T * N * D; u.q_ln_g = m->sa_q_ln_g; u.q_ln_b = m->sa_q_ln_b; u.q_w_p = q_w_p; u.q_out = last_it ? nullptr : q;
-          u.B = B; u.N = N; u.D = D; u.H = Hm; u.ln_eps = ln_eps;
-          SF_TRY(run_cnn_layers(m, img_next, (long long)T * frame_elems, B, dst_feat, featA, featB, next_layer, next_layer + 1, &u, &rode, st));
-          ++next_layer;
         }
         if (!rode)
           SF_TRY(sf_slot_update_mfma_ex(pnum, pden, P, s_in, gru_ih_p, m->sa_gru_hh_p, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g,
@@ -1203,17 +1153,6 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
     // keep it in `lnbuf`-independent storage (q is rewritten first, so use latents' twin `px`?)
     // -> simplest: the next step reads `prev` only before it writes slotsA/slotsB.
     prev = s_in;
-    if (next_feat) {
-      // the rest of step t + 1's features: the convolutions no slot update rode on, then the per-pixel chain into the OTHER ring slot
-      const float* cur = feat_pre ? feat_pre + (long long)(t + 1) * B * HW * Cl_feat : nullptr;
-      if (next_cnn) {
-        if (next_layer < m->enc_layers)
-          SF_TRY(run_cnn_layers(m, img_next, (long long)T * frame_elems, B, dst_feat, featA, featB, next_layer, m->enc_layers, nullptr, nullptr, st));
-        cur = dst_feat;
-      }
-      SF_TRY(sf_pixel_mlp_feat_ex(cur, m->enc_ln_g, m->enc_ln_b, m->enc_fc1_w, m->enc_fc1_b, m->enc_fc2_w, m->enc_fc2_b, m->sa_norm_in_g,
-                                  m->sa_norm_in_b, kv_base + (size_t)((t + 1) % KV) * kv_step, B * HW, ln_eps, st));
-    }
     if (fork && t + KV < T) {   // the features of step t + KV may overwrite this step's ring slot now
       hipEvent_t e = enc_fork_event(T + 1 + t);
       SF_REQUIRE(e != nullptr, "hipEventCreate failed");

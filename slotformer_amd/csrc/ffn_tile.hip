@@ -418,7 +418,7 @@ __global__ __launch_bounds__(NT) void ffn_qkv_tile_kernel(TileArgs A, NextArgs N
 int sf_ffn_tile_ex(const float* x2, const sf_tfm_layer& w, float eps, float* y, int M, int ffn, hipStream_t st) {
   if (!w.lin1_packed || !w.lin2_packed || ffn != NCH * HC)
     return sf_set_err(-1, "invalid argument: the row-tile FFN needs packed weights (sf_pack_ffn_weights) and ffn == 1024", __FILE__, __LINE__);
-  static const int dbg = getenv("SF_LF_DBG") ? (atoi(getenv("SF_LF_DBG")) & 16) : 0;
+  static const int dbg = sf_dbg("lf") & 16;
   TileArgs A;
   A.x2 = x2; A.ln_g = w.norm2_g; A.ln_b = w.norm2_b; A.ln_eps = eps; A.w1p = (const uint4*)w.lin1_packed; A.b1 = w.lin1_b;
   A.w2p = (const uint4*)w.lin2_packed; A.b2 = w.lin2_b; A.y = y; A.M = M; A.dbg = dbg;
@@ -438,7 +438,7 @@ int sf_ffn_qkv_tile_ex(const float* x2, const sf_tfm_layer& w, const sf_tfm_laye
     return sf_set_err(-1, "invalid argument: the fused FFN + q|k|v tile launch needs packed FFN and attention weights and ffn == 1024", __FILE__, __LINE__);
   if (!planes || !xpark || xpark == x2 || L < 1 || L > 64 || Lq < 1 || Lq > L || (long long)B * L >= (1 << 22))
     return sf_set_err(-1, "invalid argument: fused FFN + q|k|v tiles need planes, a parking buffer other than the input, 1 <= Lq <= L <= 64", __FILE__, __LINE__);
-  static const int dbg = getenv("SF_LF_DBG") ? (atoi(getenv("SF_LF_DBG")) & 16) : 0;
+  static const int dbg = sf_dbg("lf") & 16;
   const int M = B * L;
   TileArgs A;
   A.x2 = x2; A.ln_g = w.norm2_g; A.ln_b = w.norm2_b; A.ln_eps = eps; A.w1p = (const uint4*)w.lin1_packed; A.b1 = w.lin1_b;

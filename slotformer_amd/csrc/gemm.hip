@@ -55,7 +55,7 @@ struct SfGemmArgs {
   int mask_mode;
   float mask_scale;
   int bf1;  // split-bf16 kernels: 1 = contract the hi parts only (precision mode 2); 2 = operands rounded to fp16, one fp16 MFMA (mode 3)
-  int dbg;  // ablation bits (SF_GEMM_DBG, tools only): 1 no MFMA, 2 no main-loop loads, 4 no LN stats, 8 no stores
+  int dbg;  // ablation bits (SF_DBG=gemm=<bits>, tools only): 1 no MFMA, 2 no main-loop loads, 4 no LN stats, 8 no stores
 };
 
 // BKT: k-chunk staged per barrier; KW waves split each chunk; PD: prefetch distance in chunks
@@ -598,13 +598,13 @@ static int launch_cfg(const SfGemmArgs& a, hipStream_t stream) {
   return 0;
 }
 
-// tuning override (tools/gemm_bench.py): SF_GEMM_CFG=<id> forces a tile configuration
+// tuning override (tools/gemm_bench.py): SF_DBG=gemmcfg=<id> forces a tile configuration
 static int forced_cfg() {
-  const char* e = getenv("SF_GEMM_CFG");
-  return e ? atoi(e) : -1;
+  static const int v = sf_dbg("gemmcfg");   // (SF_DBG=gemmcfg=<id>)
+  return v > 0 ? v : -1;
 }
 
-// Tile configurations (ids are what tools/gemm_bench.py sweeps via SF_GEMM_CFG).
+// Tile configurations (ids are what tools/gemm_bench.py sweeps via SF_DBG=gemmcfg).
 //   <BM, BN, WM, WN, KW, BKT, PD, NBUF>;  ids < 100: exact-f32 MFMA, ids >= 100: split-bf16 (BF3).
 template <int ALOAD, bool LN>
 static int launch_by_id(int id, const SfGemmArgs& a, hipStream_t st) {
@@ -683,7 +683,7 @@ static int dispatch_tiles(const SfGemmArgs& a, hipStream_t stream) {
     const bool bf3 = sf_get_precision() >= 1;
     // choices below come from tools/gemm_bench.py on MI355X (profiles/r01_gemm_configs.txt)
     if constexpr (ALOAD == ALOAD_CONV_NHWC || ALOAD == ALOAD_DECONV_NHWC) {
-      static const int conv_cfg = getenv("SF_CONV_CFG") ? atoi(getenv("SF_CONV_CFG")) : 132;
+      static const int conv_cfg = sf_dbg("convcfg") > 0 ? sf_dbg("convcfg") : 132;
       return launch_by_id<ALOAD, LN>(bf3 ? conv_cfg : 28, a, stream);
     } else {
       // big problems (tools/gemm_bench.py [train], profiles/r01_gemm_configs.txt): the single-buffered tiles win everywhere --
@@ -713,8 +713,7 @@ int sf_gemm_dispatch(const SfGemmArgs& a_in, int aload, hipStream_t stream) {
   if (a_in.M <= 0 || a_in.N <= 0) return 0;
   SfGemmArgs a = a_in;
   {
-    const char* e = getenv("SF_GEMM_DBG");
-    a.dbg = e ? atoi(e) : 0;
+    a.dbg = sf_dbg("gemm");
   }
   a.bf1 = sf_get_precision() == 2 ? 1 : (sf_get_precision() == 3 ? 2 : 0);
   const bool ln = a.ln_g != nullptr;
@@ -786,8 +785,8 @@ int sf_conv2d_nhwc_f32(const float* in, const float* w_packed, const float* bias
   SF_REQUIRE(in && w_packed && out, "null pointer");
   SF_REQUIRE(F >= 0 && H > 0 && W > 0 && Cin > 0 && (Cin % 4) == 0 && Cout > 0 && (ks & 1), "bad conv shape");
   if (sf_get_precision() >= 1 && forced_cfg() < 0) {
-    // encoder shape (5x5, 64->64, 64-wide rows): halo-resident kernel (conv_halo.hip); SF_CONV_HALO=0 disables
-    static const bool halo_on = []() { const char* e = getenv("SF_CONV_HALO"); return !(e && e[0] == '0'); }();
+    // encoder shape (5x5, 64->64, 64-wide rows): halo-resident kernel (conv_halo.hip)
+    constexpr bool halo_on = true;
     if (halo_on) {
       const int rc = sf_conv5x5_halo_ex(in, w_packed, bias, add, out, F, H, W, Cin, Cout, ks, relu, (hipStream_t)stream);
       if (rc != 1) return rc;
@@ -849,11 +848,7 @@ int sf_conv_transpose2d_nhwc_f32(const float* in, const float* w_packed, const f
   a.N = Cout; a.relu = relu;
   a.cInH = Hin; a.cInW = Win; a.cCin = Cin; a.cKs = ks; a.cStride = stride;
   a.cFrameStride = (long long)Hin * Win * Cin;
-  static int by_class = -1;   // SF_DECONV_CLASSES=0: the single-launch gather over all ks*ks taps (tools)
-  if (by_class < 0) {
-    const char* e = getenv("SF_DECONV_CLASSES");
-    by_class = (e && e[0] == '0') ? 0 : 1;
-  }
+  constexpr int by_class = 1;   // (0: the single-launch gather over all ks*ks taps)
   if (stride > 1 && by_class) {
     // one launch per output-parity class: an output (oy, ox) only receives the taps with ky = (oy + pad) mod stride
     // (mod stride), so the ks*ks-tap gather would multiply (stride^2 - 1) / stride^2 structural zeros
@@ -884,8 +879,8 @@ int sf_conv2d_nchw_in_f32(const float* img, long long frame_stride, const float*
   SF_REQUIRE(img && weight && out, "null pointer");
   SF_REQUIRE(F >= 0 && Cin > 0 && Hin > 0 && Win > 0 && Cout > 0 && (ks & 1) && stride >= 1, "bad conv shape");
   if (sf_get_precision() >= 1 && forced_cfg() < 0) {
-    // 3 -> 64 channels, 5x5, 64-wide output: input halo + patch matrix in LDS (conv_first.hip); SF_CONV_FIRST=0 disables
-    static const bool on = []() { const char* e = getenv("SF_CONV_FIRST"); return !(e && e[0] == '0'); }();
+    // 3 -> 64 channels, 5x5, 64-wide output: input halo + patch matrix in LDS (conv_first.hip)
+    constexpr bool on = true;
     if (on) {
       const int rc = sf_conv_first_ex(img, frame_stride, weight, bias, add, out, F, Cin, Hin, Win, Cout, ks, stride, relu,
                                       (hipStream_t)stream);

@@ -60,7 +60,7 @@ __device__ __forceinline__ void split4(__bf16* hp, __bf16* lp, int off, f32x4 v)
 }  // namespace
 
 __device__ unsigned lf_seam_timeouts;   // seam hand-offs that gave up waiting (sf_seam_timeouts): must stay 0
-__device__ long long lf_ts[64];   // phase timestamps of one workgroup (SF_LF_DBG & 16), read by sf_debug_read_ts
+__device__ long long lf_ts[64];   // phase timestamps of one workgroup (SF_DBG=lf=16), read by sf_debug_read_ts
 #define LF_TS(i) do { if ((dbg & 16) && blockIdx.x == 0 && threadIdx.x == 0) lf_ts[i] = wall_clock64(); } while (0)
 #define LF_TL(i) do { if ((dbg & 16) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 256) lf_ts[i + 10] = wall_clock64(); } while (0)
 #define LF_TQ(i) do { if constexpr (SEAM) { if ((dbg & 16) && hp == 0 && b == 0 && threadIdx.x == 0) lf_ts[i] = wall_clock64(); } } while (0)
@@ -1513,7 +1513,7 @@ __device__ __forceinline__ void ffn_body(const FfnArgs& F, const int blk) {
   LF_TS(8);
 }
 
-__device__ unsigned long long lf_wg[4 * 64];   // SF_LF_DBG & 32: {HW_ID, XCC_ID, start, end} of the first 64 FFN workgroups
+__device__ unsigned long long lf_wg[4 * 64];   // SF_DBG=lf=32: {HW_ID, XCC_ID, start, end} of the first 64 FFN workgroups
 template <int NP>
 __global__ __launch_bounds__(LF_NT) void ffn_partial_kernel(FfnArgs F) {
   const unsigned long long t0 = (F.dbg & 32) ? wall_clock64() : 0ull;
@@ -1897,10 +1897,7 @@ extern "C" int sf_get_ffn_rows64(void) { return g_ffn_rows64; }
 // timing ablations (wrong results): 1 FFN reads one head partial, 2 FFN skips the W2 loads, 4 attention reads one
 // input partial, 8 attention stores one column block
 static int lf_dbg() {
-  static const int v = [] {
-    const char* e = getenv("SF_LF_DBG");
-    return e ? atoi(e) : 0;
-  }();
+  static const int v = sf_dbg("lf");
   return v;
 }
 

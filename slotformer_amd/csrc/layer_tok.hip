@@ -382,7 +382,7 @@ __global__ void pack_layer_tok_kernel(const float* __restrict__ win, const float
   out[idx] = o.u;
 }
 
-__device__ long long lt_ts[16];   // wall-clock stamps of workgroup 0, wave 0 (SF_LT_DBG=1; sf_debug_read_ts_layer_tok)
+__device__ long long lt_ts[16];   // wall-clock stamps of workgroup 0, wave 0 (SF_DBG=lt; sf_debug_read_ts_layer_tok)
 #define LTS(i) do { if (A.dbg_ts && blockIdx.x == 0 && threadIdx.x == 0) lt_ts[i] = wall_clock64(); } while (0)
 
 template <int MODE>
@@ -857,7 +857,7 @@ int sf_layer_tok_ex(int mode, const float* xin, const float* ring, int ring_fram
   for (int l = 0; ok && l < nl; ++l) ok = layers[l].tok_packed != nullptr;
   if (!ok)
     return sf_set_err(-1, "invalid argument: the token-stationary layers need sf_pack_layer_tok_weights fragments, 1..8 layers and 1 <= L <= 64 rows per video", __FILE__, __LINE__);
-  static const int dbg = getenv("SF_LT_DBG") ? atoi(getenv("SF_LT_DBG")) : 0;
+  static const int dbg = sf_dbg("lt");
   LtArgs A;
   A.x = xin; A.ring = ring; A.pe = pe; A.y = y;
   for (int l = 0; l < LT_MAXL; ++l) A.blob[l] = (const char*)layers[l < nl ? l : nl - 1].tok_packed;

@@ -253,8 +253,8 @@ static int sf_pixel_feat_stream_launch(const float* x, const float* ln0_g, const
 int sf_pixel_mlp_feat_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
                          const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st) {
   if (M <= 0) return 0;
-  // weights resident in registers, PF_TPW tiles per workgroup (pixel_feat_stream_kernel below); SF_PIXEL_MLP_STREAM=0: the tile-at-a-time kernel
-  static const int stream = getenv("SF_PIXEL_MLP_STREAM") ? atoi(getenv("SF_PIXEL_MLP_STREAM")) : 1;
+  // weights resident in registers, PF_TPW tiles per workgroup (pixel_feat_stream_kernel below)
+  constexpr int stream = 1;
   if (stream) return sf_pixel_feat_stream_launch(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st);
   SF_TRY(sf_ensure_dyn_lds((const void*)pixel_mlp_kv_kernel<true>, (size_t)(PM_LDS)));
   sf_prof_begin(SF_K_LINEAR, st, 2.0 * M * (double)(PM_C0 * PM_C1 + PM_C1 * PM_C1));
@@ -634,7 +634,7 @@ static int sf_pixel_feat_stream_launch_t(const float* x, const float* ln0_g, con
   SF_TRY(sf_ensure_dyn_lds((const void*)pixel_feat_stream_kernel<TR>, Cfg::LDS));
   const int ntiles = (M + TR - 1) / TR;
   sf_prof_begin(SF_K_LINEAR, st, 2.0 * M * (double)(PM_C0 * PM_C1 + PM_C1 * PM_C1));
-  static const int env_pix = getenv("SF_PIXEL_PIX") ? atoi(getenv("SF_PIXEL_PIX")) : 0;
+  constexpr int env_pix = 0;
   const int tpw = env_pix >= TR ? env_pix / TR : Cfg::TPW;
   hipLaunchKernelGGL(pixel_feat_stream_kernel<TR>, dim3((ntiles + tpw - 1) / tpw), dim3(Cfg::NT), Cfg::LDS, st, x, ln0_g, ln0_b, w1, b1,
                      w2, b2, ln1_g, ln1_b, feat, M, eps, tpw);
@@ -643,15 +643,11 @@ static int sf_pixel_feat_stream_launch_t(const float* x, const float* ln0_g, con
   return 0;
 }
 
-// tile: 128 (one workgroup per CU) or 64 (two); 0 = the default (SF_PIXEL_TILE overrides it)
+// tile: 128 (one workgroup per CU) or 64 (two); 0 = the default
 static int sf_pixel_feat_stream_launch(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
                                        const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st,
                                        int tile) {
-  static const int env_tile = [] {
-    const char* e = getenv("SF_PIXEL_TILE");
-    return e ? atoi(e) : 0;
-  }();
-  if (tile == 0) tile = env_tile ? env_tile : 64;
+  if (tile == 0) tile = 64;
   if (tile == 64) return sf_pixel_feat_stream_launch_t<64>(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st);
   return sf_pixel_feat_stream_launch_t<128>(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st);
 }

@@ -974,14 +974,8 @@ int attn_lds_bytes(int L, int hd, bool bwd) {
   return (int)(((bwd ? 4 : 3) * L * (hd + 1) + (bwd ? 2 : 1) * L * (L + 1)) * sizeof(float));
 }
 
-// SF_TRAIN_ATTN=scalar forces the plain-FMA kernels (tools / tests)
 inline bool attn_use_mfma(int L, int hd) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("SF_TRAIN_ATTN");
-    forced = (e && strcmp(e, "scalar") == 0) ? 1 : 0;
-  }
-  return !forced && (hd == 32 || hd == 64) && L <= 96;
+  return (hd == 32 || hd == 64) && L <= 96;
 }
 template <class Kern>
 int set_lds(Kern kern, size_t bytes) {

@@ -305,7 +305,7 @@ int sf_conv_wgrad_ex(const float* A, int CA, int H, int W, const float* X, int H
   rps = (rps + 31) & ~31;
   const dim3 grid(ks * nt, splits);
   const int mode = sf_get_precision();
-  static const bool win_on = []() { const char* e = getenv("SF_WGRAD_WINDOW"); return !(e && e[0] == '0'); }();
+  constexpr bool win_on = true;
 #define CW_LAUNCH(KERN) hipLaunchKernelGGL(KERN, grid, dim3(256), 0, st, A, X, partial, rows, rps, H, W, CA, Hx, Wx)
   if (win_on && W % 32 == 0 && (s == 1 || s == 2)) {   // one LDS window per chunk instead of five shifted fetches
     if (s == 1) {

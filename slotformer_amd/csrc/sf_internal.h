@@ -97,30 +97,12 @@ extern "C" int sf_get_precision(void);
 int sf_conv5x5_ws_ex(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W, int Cin, int Cout, int ks,
                      int relu, int n_workgroups, hipStream_t st);
 extern "C" int sf_stream_cus(void* stream);
+// one environment variable for every in-kernel time stamp / tuning override of the tools: SF_DBG="conv,lt,lf=16,sa,deconv,gemm,gemmcfg=132" -> value of
+// `key` (1 when named without a value, 0 when absent)
+int sf_dbg(const char* key);
 extern "C" int sf_stream_cus_known(void* stream);   // 0: not a stream of sf_stream_create_cu_mask / sf_stream_set_cus
 int sf_conv5x5_rows4_ex(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W,
                         int Cin, int Cout, int ks, int relu, hipStream_t st);
-// the arguments of sf_slot_update_mfma_ex as a struct: the slot update as the first blocks of a convolution launch (conv_rows4.hip)
-struct SfSlotUpdateArgs {
-  const float *part_num, *part_den;
-  int P;
-  const float* slots_prev;
-  const void *gru_ih_p, *gru_hh_p;
-  const float *gru_b_ih, *gru_b_hh, *ln_g, *ln_b;
-  const void* w1_p;
-  const float* b1;
-  const void* w2_p;
-  const float* b2;
-  float *slots_out, *out2;
-  long long out2_bs;
-  const float *q_ln_g, *q_ln_b;
-  const void* q_w_p;
-  float* q_out;
-  int B, N, D, H;
-  float ln_eps;
-};
-int sf_conv5x5_rows4_update_ex(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W, int Cin,
-                               int Cout, int ks, int relu, const SfSlotUpdateArgs& u, hipStream_t st);
 // decoder layers on fragment weights (deconv_s2.hip, conv_rows4.hip); return 1 when the kernel does not apply
 int sf_deconv5x5s2_ex(const float* in, const void* w_frag, const float* bias, const float* head_w, const float* head_b, float* out, int R,
                       int H, int W, int Cin, int Cout, int ks, int stride, int relu, hipStream_t st);

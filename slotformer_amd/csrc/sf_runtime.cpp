@@ -1,8 +1,10 @@
 // Runtime bits of libslotformer_hip.so: error string, version, and the optional per-kernel-class
 // HIP-event timer used by bench.py for the roofline object (events are recorded on the stream the
 // kernel is launched on; nothing is recorded while the stream is being captured into a hipGraph).
+#include <stdlib.h>
 #include <map>
 #include <mutex>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -25,6 +27,26 @@ thread_local int t_suppress = 0;
 std::mutex g_stream_mu;
 std::map<void*, int> g_stream_cus;   // CU count of the streams made by sf_stream_create_cu_mask
 }  // namespace
+
+int sf_dbg(const char* key) {
+  static const std::map<std::string, int> vals = [] {
+    std::map<std::string, int> m;
+    const char* e = getenv("SF_DBG");
+    std::string s = e ? e : "";
+    size_t i = 0;
+    while (i < s.size()) {
+      size_t j = s.find(',', i);
+      if (j == std::string::npos) j = s.size();
+      std::string tok = s.substr(i, j - i);
+      size_t q = tok.find('=');
+      if (!tok.empty()) m[q == std::string::npos ? tok : tok.substr(0, q)] = q == std::string::npos ? 1 : atoi(tok.c_str() + q + 1);
+      i = j + 1;
+    }
+    return m;
+  }();
+  auto it = vals.find(key);
+  return it == vals.end() ? 0 : it->second;
+}
 
 SfThreadOpts& sf_thread_opts() {
   static thread_local SfThreadOpts o;

@@ -650,7 +650,7 @@ int sf_slate_attention_train_bwd_f32(const float* q, const float* k, const float
     hipLaunchKernelGGL((slate_attn_bwd_kernel<HDP, BF>), g2, dim3(256), lds2, st, a, head_dim);                                  \
   }
   const bool bf3 = sf_get_precision() >= 1;
-  static const bool bwd48 = !(getenv("SF_ATTN_BWD48") && getenv("SF_ATTN_BWD48")[0] == '0');
+  constexpr bool bwd48 = true;
   if (bf3 && head_dim > 32 && head_dim <= 48 && bwd48 && ldk % 4 == 0 && ldv % 4 == 0) {
     constexpr size_t lds48 = ((size_t)3 * 64 * 52 + 2 * 64 * 68 + 128) * sizeof(float);
     SF_TRY(sf_ensure_dyn_lds((const void*)slate_attn_bwd48_kernel, (size_t)(lds48)));

@@ -298,141 +298,6 @@ __global__ __launch_bounds__(256) void sa_attn_mfma_kernel(
 }
 
 // -----------------------------------------------------------------------------------------
-// One-pass form for keys == values (the folded Slot Attention of engine.hip: both are the normalised pixel features x,
-// savi.py:66-89 with project_k / project_v folded into project_q and the GRU input matrix).  sa_attn_mfma_kernel walks the
-// rows twice -- logits from `k` through an LDS slab, then the weighted sums from `v` out of global memory again (PMC: 104 MB
-// fetched per launch for 67 MB of unique bytes).  Here a wave loads its 64 pixel rows ONCE into a [64][D + 4] LDS tile
-// (8 lanes per row: 128 contiguous bytes per row and instruction), the lane-per-pixel logits / softmax read the tile row by
-// row, and the MFMA of the weighted sums takes its A operand (pixels x channels) from the same tile.  Same arithmetic in
-// the same order as the two-pass kernel: the same bits.  LDS: 4 waves x 33 KB + queries + attention tile = 149 KB (one
-// workgroup per CU; the tile region is reused for the cross-wave reduction).  MEASURED SLOWER than the two-pass kernel (half
-// the waves per CU): kept as an option, see the launch site.
-template <int D>
-__global__ __launch_bounds__(256) void sa_attn_fold_kernel(const float* __restrict__ x, int ld, long long batch_stride,
-                                                           const float* __restrict__ q, float scale, float eps,
-                                                           float* __restrict__ part_num, float* __restrict__ part_den,
-                                                           float* __restrict__ attn_out, long long attn_bs, int HW, int N, int P) {
-  constexpr int DB = D / 16, NS = SA_NMAX, XP = D + 4;   // tile pitch: 528 B (D = 128), conflict-free 16-byte row reads
-  extern __shared__ __attribute__((aligned(16))) float sa_lds[];
-  float* s_x = sa_lds;                               // [4 waves][64][XP]
-  float* s_q = s_x + 4 * 64 * XP;                    // [NS][D]
-  float* s_a = s_q + NS * D;                         // [4][64][NS + 1]
-  float* s_red = sa_lds;                             // [4][NS][D + 1] over the (dead) tiles
-  const int b = blockIdx.y, chunk = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pix0 = chunk * 256 + wave * 64;
-  // ---- the 64 rows of this wave, requested at once: row (lane >> 3) + 8 u, columns 4 (lane & 7) + 32 c ----
-  const float* xs = x + (long long)b * batch_stride + (long long)(pix0 + (lane >> 3)) * ld + 4 * (lane & 7);
-  float* tile = s_x + wave * 64 * XP;
-  constexpr int NC = D / 32;
-#pragma unroll
-  for (int c0 = 0; c0 < NC; c0 += 2) {   // two 32-channel slabs (16 float4 per lane) in flight
-    f32x4v nx[2][8];
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-      for (int u = 0; u < 8; ++u) nx[cc][u] = *(const f32x4v*)(xs + (long long)(8 * u) * ld + 32 * (c0 + cc));
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-      for (int u = 0; u < 8; ++u) *(f32x4v*)(tile + ((lane >> 3) + 8 * u) * XP + 32 * (c0 + cc) + 4 * (lane & 7)) = nx[cc][u];
-  }
-  for (int idx = threadIdx.x; idx < NS * D; idx += 256) {
-    const int n = idx / D, d = idx - n * D;
-    s_q[idx] = n < N ? q[((long long)b * N + n) * D + d] * scale : 0.f;
-  }
-  __syncthreads();
-  // ---- phase 1: lane = pixel, its row from the tile (the two-pass kernel's order of operations) ----
-  float s[NS];
-#pragma unroll
-  for (int n = 0; n < NS; ++n) s[n] = 0.f;
-#pragma unroll 1
-  for (int d0 = 0; d0 < D; d0 += 32) {
-    f32x4v kx[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) kx[u] = *(const f32x4v*)(tile + lane * XP + d0 + 4 * u);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-#pragma unroll
-      for (int n = 0; n < NS; ++n) {
-        const f32x4v qq = *(const f32x4v*)(s_q + n * D + d0 + 4 * u);
-        s[n] = fmaf(kx[u][0], qq[0], s[n]);
-        s[n] = fmaf(kx[u][1], qq[1], s[n]);
-        s[n] = fmaf(kx[u][2], qq[2], s[n]);
-        s[n] = fmaf(kx[u][3], qq[3], s[n]);
-      }
-    }
-  }
-  float mx = s[0];
-#pragma unroll
-  for (int n = 1; n < NS; ++n)
-    if (n < N) mx = fmaxf(mx, s[n]);
-  float sum = 0.f;
-#pragma unroll
-  for (int n = 0; n < NS; ++n) {
-    s[n] = n < N ? expf(s[n] - mx) : 0.f;
-    sum += s[n];
-  }
-  const float inv = 1.0f / sum;
-  float den[NS];
-  float* sa_w = s_a + wave * 64 * (NS + 1);
-#pragma unroll
-  for (int n = 0; n < NS; ++n) {
-    const float a0 = s[n] * inv;
-    if (attn_out && n < N) attn_out[(long long)b * attn_bs + (long long)n * HW + pix0 + lane] = a0;
-    const float a = n < N ? a0 + eps : 0.f;
-    den[n] = a;
-    sa_w[lane * (NS + 1) + n] = a;
-  }
-  __builtin_amdgcn_wave_barrier();
-  // ---- phase 2: num^T[d, n] += X^T . A on the f32 MFMA, X from the tile ----
-  typedef float f32x4a __attribute__((ext_vector_type(4)));
-  f32x4a acc[DB];
-#pragma unroll
-  for (int j = 0; j < DB; ++j) acc[j] = f32x4a{0.f, 0.f, 0.f, 0.f};
-  const int li = lane & 15, lk = lane >> 4;
-#pragma unroll 4
-  for (int ks = 0; ks < 16; ++ks) {
-    const float* vp = tile + (4 * ks + lk) * XP + DB * li;
-    float vx[DB];
-#pragma unroll
-    for (int j = 0; j < DB; j += 4) {
-      const f32x4v t4 = *(const f32x4v*)(vp + j);
-      vx[j] = t4[0];
-      vx[j + 1] = t4[1];
-      vx[j + 2] = t4[2];
-      vx[j + 3] = t4[3];
-    }
-    const float bop = li < NS ? sa_w[(4 * ks + lk) * (NS + 1) + li] : 0.f;
-#pragma unroll
-    for (int j = 0; j < DB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vx[j], bop, acc[j], 0, 0, 0);
-  }
-#pragma unroll
-  for (int n = 0; n < NS; ++n) den[n] = sf_wave_sum(den[n]);
-  __syncthreads();   // every wave is done with its tile: the reduction buffer takes the tiles' place
-  if (li < NS) {
-#pragma unroll
-    for (int j = 0; j < DB; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s_red[(wave * NS + li) * (D + 1) + DB * (4 * lk + r) + j] = acc[j][r];
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int n = 0; n < NS; ++n) s_red[(wave * NS + n) * (D + 1) + D] = den[n];
-  }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < N * (D + 1); idx += 256) {
-    const int n = idx / (D + 1), d = idx - n * (D + 1);
-    const float t = s_red[(0 * NS + n) * (D + 1) + d] + s_red[(1 * NS + n) * (D + 1) + d] + s_red[(2 * NS + n) * (D + 1) + d] +
-                    s_red[(3 * NS + n) * (D + 1) + d];
-    if (d < D)
-      part_num[(((long long)b * P + chunk) * N + n) * D + d] = t;
-    else
-      part_den[((long long)b * P + chunk) * N + n] = t;
-  }
-}
-
-// -----------------------------------------------------------------------------------------
 // Fused slot update.  One workgroup per (batch, slot) row, ONE THREAD PER OUTPUT FEATURE: the
 // weights are stored transposed ([in, out]) so consecutive threads read consecutive addresses
 // and every load of the k-loop is independent (deep unroll keeps them in flight); the input
@@ -908,7 +773,7 @@ extern "C" int sf_slot_attn_iter_bf16(const void* k, const void* v, int ld, long
 // 128 MFMAs of 32 cycles per wave and 32 pixels: 9.7 TB/s of rows at two waves per SIMD on the whole chip -- above the HBM roof.
 // Arithmetic: exact f32 products, f32 accumulation; the summation order differs from the VALU logits of sa_attn_mfma_kernel (rounding-level
 // differences, every fixture keeps its tolerance).
-__device__ long long sa_ts[16];   // phase stamps of workgroup (0, 0), wave 0 (SF_SA_DBG=1; sf_debug_read_ts_sa)
+__device__ long long sa_ts[16];   // phase stamps of workgroup (0, 0), wave 0 (sf_debug_sa_stamps(1); sf_debug_read_ts_sa)
 __device__ int sa_dbg_on;
 #define SATS(i) do { if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sa_ts[i] = wall_clock64(); } while (0)
 template <int D>
@@ -1057,32 +922,16 @@ int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch
   // algorithmic bytes: one read of K and V -- of the ONE feature array when keys and values are the same rows
   // (the folded form, engine.hip: k == v == the normalised pixel features)
   sf_prof_begin(SF_K_SA_ITER, st, (k == v ? 1.0 : 2.0) * (double)B * HW * D * sizeof(float));
-  // opt-in (SF_SA_ONEPASS=1): measured SLOWER than the two-pass kernel -- its 33 KB tile per wave leaves one workgroup (4
-  // waves) per CU, and with half the waves the loads of one workgroup no longer hide behind the arithmetic of another:
-  // encode 2.79 vs 2.72 ms alone, 3.86 vs 3.69 ms on the 128-CU encode partition (profiles/r03_probes.txt)
-  static const bool fold_env = [] {
-    const char* e = getenv("SF_SA_ONEPASS");
-    return e && e[0] == '1';
-  }();
-  // (round 4, default for keys == values at width 128; SF_SA_TILE=0: the two-pass kernel.  32 frames: 21.3 vs 26.4 us on the whole chip, 31.2 vs 35.5
+  // (a single-shot one-pass kernel -- one 33 KB tile per wave, one workgroup per CU -- measured slower than the two-pass kernel and is gone:
+  //  profiles/r03_probes.txt)
+  // (round 4, for keys == values at width 128.  32 frames: 21.3 vs 26.4 us on the whole chip, 31.2 vs 35.5
   //  on a 128-CU mask, 67 instead of 120-132 MB fetched; its single-shot forms -- one tile per wave -- were no faster: profiles/r04_probes.txt section 3)
-  static const bool tile_off = [] {
-    const char* e = getenv("SF_SA_TILE");
-    return e && e[0] == '0';
-  }();
-  if (HW % 512 == 0 && k == v && D == 128 && P == HW / 256 && !tile_off && !fold_env) {
+  if (HW % 512 == 0 && k == v && D == 128 && P == HW / 256) {
     // keys == values: every row read once, both products on the matrix cores (sa_attn_tile_kernel: 512 pixels per workgroup)
     constexpr size_t LDS = (size_t)(8 * 16 * (128 + 4) + 8 * 16 * 17 + SA_NMAX * 128) * sizeof(float);   // 80,384 B: two workgroups per CU
     static_assert(2 * LDS <= 160 * 1024, "one-pass Slot Attention: two workgroups per CU");
     SF_TRY(sf_ensure_dyn_lds((const void*)sa_attn_tile_kernel<128>, LDS));
     hipLaunchKernelGGL(sa_attn_tile_kernel<128>, dim3(HW / 512, B), dim3(512), LDS, st, k, ld, batch_stride, q, scale, eps, part_num, part_den, attn_out,
-                       attn_batch_stride, HW, N, P);
-  } else if (HW % 256 == 0 && k == v && D == 128 && fold_env) {
-    // keys == values: every row is read once (sa_attn_fold_kernel)
-    constexpr size_t LDS = (size_t)(4 * 64 * (128 + 4) + SA_NMAX * 128 + 4 * 64 * (SA_NMAX + 1)) * sizeof(float);
-    static_assert(LDS <= 160 * 1024, "one-pass Slot Attention: LDS budget");
-    SF_TRY(sf_ensure_dyn_lds((const void*)sa_attn_fold_kernel<128>, LDS));
-    hipLaunchKernelGGL(sa_attn_fold_kernel<128>, grid, block, LDS, st, k, ld, batch_stride, q, scale, eps, part_num, part_den, attn_out,
                        attn_batch_stride, HW, N, P);
   } else if (HW % 256 == 0) {
 #define SA_LAUNCH2(DD)                                                                                 \

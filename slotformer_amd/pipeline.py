@@ -51,7 +51,7 @@ from . import _lib, engine
 
 _STREAMS = {}                      # process-wide stream pool (EncodeRolloutPipeline._masked_stream / _pool_stream)
 _STREAMS_LOCK = threading.Lock()
-_POOL = bool(int(os.environ.get('SF_PIPE_STREAM_POOL', '1')))
+_POOL = True                        # one process-wide pool of streams (private streams per pipeline object share hardware queues: 405 vs 455 k frames/s)
 
 
 def encode_mask_words(spec):
@@ -177,9 +177,9 @@ def pair_unit_options(rollouter, batch, group, roll_cus=128, tok=False, burn_in=
     # the latency forms, four times the workgroups (224 vs 120 k frames/s at B = 8, 251 vs 219 k at B = 16).  Same bits.
     wide = 2 * int(group) * int(batch) >= int(roll_cus)
     opts = {'cus': int(roll_cus),   # (seam launches -- off below anyway -- only when their grid fits the rollout CUs)
-            'seam': bool(int(os.environ.get('SF_PIPE_SEAM', '0'))),
-            'ffn_rows': int(os.environ.get('SF_PIPE_FFN_ROWS', '128' if wide else '64')),
-            'attn_heads': int(os.environ.get('SF_PIPE_ATTN_HEADS', '8' if wide else '2')),
+            'seam': False,
+            'ffn_rows': 128 if wide else 64,
+            'attn_heads': 8 if wide else 2,
             'attn_rows': 0, 'ffn_tile': 0}
     # units of >= 2048 token rows (C2: 128 videos x 42 rows; C4: 64 x 36; C5: 256 x 48) run both blocks of a layer in their
     # ROW-TILE forms: LN1 + q|k|v on 64-row tiles of the whole unit + one attention-core workgroup per video (attn_rows.hip),
@@ -188,10 +188,10 @@ def pair_unit_options(rollouter, batch, group, roll_cus=128, tok=False, burn_in=
     # chunk-partial workgroups (C5 305 -> 383 k frames/s, C2 405 -> 415-419 k, C4 172 -> 180 k).  Same bits.
     hist = getattr(rollouter, 'cond_len', None) or getattr(rollouter, 'history_len', burn_in or 1)
     tiles = wide and int(group) * int(batch) * int(rollouter.num_slots) * int(hist) >= 2048
-    opts['attn_rows'] = int(os.environ.get('SF_PIPE_ATTN_ROWS', '128' if tiles else '0'))
+    opts['attn_rows'] = 128 if tiles else 0
     # (2: the FFN tile launch also runs LN1 + q|k|v of the next layer on its rows -- one launch less per layer: C2 441 -> 447 k,
     #  C5 432 -> 446 k, C4 175 -> 181 k)
-    opts['ffn_tile'] = int(os.environ.get('SF_PIPE_FFN_TILE', '2' if tiles else '0'))
+    opts['ffn_tile'] = 2 if tiles else 0
     # the layers before the last as ONE token-stationary launch (layer_tok.hip) -- see tok_unit_batches; the last (row-pruned) layer keeps the forms above
     opts['layer_tok'] = bool(tok)
     return opts
@@ -304,7 +304,7 @@ class EncodeRolloutPipeline:
         self.NU = 2 * nroll
         self.lead = 2 * nroll                    # stolen features of unit u are computed behind the rollout of unit u - lead
         if steal_steps is None:
-            steal_steps = float(os.environ.get('SF_PIPE_STEAL', {'pair': 0, 'two': 1, 'three': 0}.get(partition, 1)))
+            steal_steps = float({'pair': 0, 'two': 1, 'three': 0}.get(partition, 1))
         self.steal = max(0.0, min(float(steal_steps), float(self.T)))   # may be fractional: see _steal_of
         self._masked_taken = {}
         self._lib = _lib.lib()
@@ -347,17 +347,17 @@ class EncodeRolloutPipeline:
         # batches, 399.5 vs 398.2 at 40) at the price of a 38 MB device copy of the frames into the fixed input buffer per batch
         self.encode_graph = bool(int(os.environ.get('SF_PIPE_ENCODE_GRAPH', '1'))) if encode_graph is None else bool(encode_graph)
         self._enc_graphs = {}
-        ef = os.environ.get('SF_PIPE_ENCODE_FORK', '0')   # '1': every encode graph with two branches; 'fill': the whole-chip fill / hybrid graphs only
-        self.encode_fork = (ef == 'fill' or bool(int(ef))) if encode_fork is None else bool(encode_fork)
+        # (encode_fork=True: every encode graph with two branches; measured slower inside the pipeline -- the kwarg stays for measurements)
+        self.encode_fork = bool(encode_fork)
         # the last unit of a run rolls out alone on an unmasked stream: in the kernels' latency forms (head-pair attention, 64-row FFN
         # workgroups) while a unit is small -- C4, 64 videos: 172 vs 165 k frames/s -- but a large unit fills the chip with its row tiles and
         # four times the workgroups only queue: C5, 256 videos: 392 -> 435 k; C2, 128 videos: 436 / 440 k
-        self.drain_latency_form = bool(int(os.environ.get('SF_PIPE_DRAIN_LAT', '1' if self.G * self.B < 128 else '0')))
+        self.drain_latency_form = self.G * self.B < 128
         self._key = ('pipe', id(self))
         self._plan = None
         self._sig = None
         self.units = []
-        self.spread_remainder = os.environ.get('SF_PIPE_SPREAD', '1') != '0'
+        self.spread_remainder = True
         hist_ = getattr(rollouter, 'cond_len', None) or getattr(rollouter, 'history_len', None) or self.T
         self._rows_per_batch = self.B * int(rollouter.num_slots) * int(hist_)
         self._tails = {}
@@ -410,9 +410,9 @@ class EncodeRolloutPipeline:
         #  rollout cannot start before both batches of its unit are encoded)
         # smaller units at the end of a run (_unit_plan): measured WORSE with group 4 (unmasked drain units take CUs from the
         # encode and the full units: 322 vs 376 k frames/s at 20 batches) -- off
-        self.ramp = bool(int(os.environ.get('SF_PIPE_RAMP', '0')))
+        self.ramp = False
         self._hybrid_arg = hybrid
-        self.fill_par = max(1, min(3, int(os.environ.get('SF_PIPE_FILL_PAR', '2'))))   # whole-chip encodes side by side during the fill
+        self.fill_par = 2   # whole-chip encodes side by side during the fill (3: 495 vs 552 k frames/s)
         # batches encoded on the WHOLE chip (unmasked streams, fill_par at a time) at the start of a run.  The first unit's had to be
         # (nothing else runs yet); since the row-tile kernels the rollout streams have slack, and the unmasked encodes of the NEXT
         # units -- 2.3 ms per batch beside the first rollouts instead of 3.9 on the encode partition -- build a backlog the masked lane
@@ -433,12 +433,12 @@ class EncodeRolloutPipeline:
             #  bound by more: C4 with units of 7 at 84 batches, every 5th / 4th / 3rd / 2nd batch: 236.0 / 242.9 / 250.6 / 250.9 k)
             # (token-stationary units leave the rollout partition 40 % slack: every second batch -- C2 at 60 batches: 592 / 565 / 554 k with 2 / 3 / 4)
             self.hybrid = int(os.environ.get('SF_PIPE_HYBRID', ('4' if self.tok else '3' if self.G > 4 else '5') if balanced else '0'))
-        self.hybrid_tail = int(os.environ.get('SF_PIPE_HYBRID_TAIL', str(min(self.hybrid, 3))))
+        self.hybrid_tail = min(self.hybrid, 3)
         self.fill_batches = int(os.environ.get('SF_PIPE_FILL', '0')) or (fill_units * self.G if partition == 'pair' else 0)
-        self.fill_steal = int(os.environ.get('SF_PIPE_FILL_STEAL', '0'))
+        self.fill_steal = 0
         # pre_steal[h]: time steps of convolutions of batch h of the NEXT unit computed on a rollout stream right before a unit
         # rolls out (group >= 2 only; batch 0 of the next unit starts encoding at once and cannot wait)
-        ps = os.environ.get('SF_PIPE_PRE_STEAL', '')
+        ps = ''
         self.pre_steal = [int(x) for x in ps.split(',')] if ps else []   # (measured neutral at 20 batches: 381-383 k frames/s with [0,0,1,1] .. [0,1,1,1] and off)
         self.pre_steal = [min(k, self.T) for k in self.pre_steal]
         if not any(self.pre_steal):
@@ -452,72 +452,6 @@ class EncodeRolloutPipeline:
         self._enc_plan = engine.encoder_plan(self.savi)
         self._enc_sig = self._enc_plan.sig
         self._capture_encode_graphs()
-        self._calibrate_placement()
-
-    def _calibrate_placement(self):
-        """Which hardware queues the two unmasked streams (whole-chip fill encodes, hybrid lane, drain units) land on decides ~10 % of a
-        run (profiles/r03_probes.txt section 16), and the runtime's dealing of queues -- round-robin over four on first use -- is neither
-        documented nor stable against other streams in the process (RCCL, another library).  So the placement is MEASURED once per process
-        and device instead of assumed: five fresh streams are touched in order (consecutive queues), the four neighbouring pairs and the
-        rule's pick (_pick_free_streams) each time a short run of this pipeline on zero frames, and the fastest pair is kept for every
-        pipeline of the process.  OPT-IN (SF_PIPE_PLACEMENT=measure, or =<i> to force candidate i; default 'rule' = _pick_free_streams): on
-        this image the measured pick and the rule's give the same throughput (493 vs 495 k frames/s plain, 472 vs 475 k with RCCL
-        initialised, profiles/r04_probes.txt) although the 16-batch calibration runs themselves differ by 13 % between candidates -- a short
-        run right after five new streams appeared is a poor predictor of the steady state, so the rule validated over rounds 3-4 stays the
-        default and the measurement is the tool for a runtime where the rule's assumption (queues dealt round-robin over four) fails."""
-        mode = os.environ.get('SF_PIPE_PLACEMENT', 'rule')
-        mode = 'auto' if mode == 'measure' else mode
-        if mode == 'rule' or len(self.roll_streams) < 2 or not self.cu_split or len(self.s_free) < 2:
-            return
-        key = ('placement-cal', self.dev.index)
-        with _STREAMS_LOCK:
-            done = _STREAMS.get(key)
-        if done is not None:
-            self.s_free, self.stream_placement = list(done[0]), done[1]
-            return
-        # only a pipeline whose rollout units fill the chip can tell the placements apart (small test pipelines keep the rule)
-        hist = getattr(self.roll, 'cond_len', None) or getattr(self.roll, 'history_len', self.T)
-        if mode == 'auto' and self.G * self.B * self.N * hist < 2048:
-            return
-        rule_pair = list(self.s_free)
-        cands = [torch.cuda.Stream(device=self.dev) for _ in range(5)]
-        with torch.cuda.device(self.dev):
-            for st in cands:
-                _lib.check(self._lib.sf_debug_spin(1, st.cuda_stream))   # first use: the stream gets its hardware queue
-                st.synchronize()
-        pairs = [[cands[i], cands[i + 1]] for i in range(4)] + [rule_pair]
-        res = getattr(self.savi, 'resolution', (128, 128))[0]
-        n = max(self.fill_batches + self.G, 3 * self.G)
-        img = torch.zeros(self.B, self.T, 3, res, res, device=self.dev)
-        out = torch.empty(n, self.B, self.T + self.H, self.N, self.D, device=self.dev)
-        times = []
-        for pair in pairs:
-            self.s_free = pair
-            best = None
-            for rep in range(3):   # (the first run of a pair warms its queues)
-                torch.cuda.synchronize(self.dev)
-                t0 = time.perf_counter()
-                self.run([img] * n, None, out=out)
-                torch.cuda.synchronize(self.dev)
-                dt = time.perf_counter() - t0
-                if rep and (best is None or dt < best):
-                    best = dt
-            times.append(best)
-        pick = int(mode) if mode.lstrip('-').isdigit() else min(range(len(pairs)), key=lambda i: times[i])
-        pick = max(0, min(pick, len(pairs) - 1))
-        self.s_free = pairs[pick]
-        info = dict(self.stream_placement or {})
-        info.update({'calibrated': True, 'picked': 'rule' if pick == 4 else f'fresh streams {pick}, {pick + 1} of 5',
-                     'candidate_ms': [round(1e3 * t, 3) for t in times], 'calibration_batches': n,
-                     'rule_vs_best': round(times[4] / min(times), 4)})
-        self.stream_placement = info
-        if os.environ.get('SF_PIPE_LOG_PLACEMENT', '0') == '1' or int(os.environ.get('WORLD_SIZE', '1')) > 1:
-            import sys
-            print(f'[slotformer_amd.pipeline] stream placement (measured): {info}', file=sys.stderr, flush=True)
-        with _STREAMS_LOCK:
-            _STREAMS[key] = (tuple(self.s_free), info)
-            _STREAMS[('free-set', self.dev.index, 2)] = tuple(self.s_free)
-            _STREAMS[('placement', self.dev.index)] = info
 
     def _capture_encode_graphs(self):
         """Capture the encode graphs of the lanes a run uses NOW, not inside the first run that reaches them (a short warm-up only
@@ -606,11 +540,6 @@ class EncodeRolloutPipeline:
         if got is not None:
             self.stream_placement = placed
             return list(got)
-        if int(os.environ.get('SF_PIPE_FREE_MASKED', '0')):
-            # (probe) streams with a full CU mask: the runtime gives every CU-masked stream a hardware queue of its own
-            for _ in range(int(os.environ.get('SF_PIPE_FREE_DUMMY', '0'))):
-                self._masked_stream([0xffffffff] * 8)
-            return [self._masked_stream([0xffffffff] * 8) for _ in range(n)]
         # (a process that has initialised RCCL already has that one stream in use -- RCCL's: with torch.distributed on the nccl backend
         #  initialised before the pipeline, the bench's multi-GPU path, no parked stream 474 k, one 418 k, two / three 385 / 399 k)
         rccl = False
@@ -619,13 +548,13 @@ class EncodeRolloutPipeline:
             rccl = dist.is_available() and dist.is_initialized() and 'nccl' in str(dist.get_backend())
         except Exception:  # noqa: BLE001
             rccl = False
-        n_skip = int(os.environ.get('SF_PIPE_FREE_SKIP', '0' if rccl else '1'))
+        n_skip = 0 if rccl else 1
         # what was chosen, for the bench line / the logs of every rank (the rule is tuned to this runtime's round-robin over four
-        # hardware queues; SF_PIPE_FREE_SKIP overrides)
+        # hardware queues)
         self.stream_placement = {'parked_streams_before_the_free_ones': n_skip, 'free_streams': n, 'rccl_initialised': bool(rccl),
-                                 'rule': 'SF_PIPE_FREE_SKIP' if 'SF_PIPE_FREE_SKIP' in os.environ else ('rccl: none parked' if rccl else 'one parked'),
+                                 'rule': 'rccl: none parked' if rccl else 'one parked',
                                  'rank': int(os.environ.get('RANK', '0')), 'device': self.dev.index}
-        if os.environ.get('SF_PIPE_LOG_PLACEMENT', '0') == '1' or int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        if int(os.environ.get('WORLD_SIZE', '1')) > 1:
             import sys
             print(f'[slotformer_amd.pipeline] stream placement: {self.stream_placement}', file=sys.stderr, flush=True)
         with _STREAMS_LOCK:
@@ -791,7 +720,7 @@ class EncodeRolloutPipeline:
             side.wait_stream(cur)
             # encode_fork: the graph gets two parallel branches -- the image features of all time steps, and one step behind them the slot
             # branches (engine.savi_encode side_stream=; the seven-workgroup launches of the slot branch no longer hold up the convolutions)
-            fork_here = self.encode_fork and (os.environ.get('SF_PIPE_ENCODE_FORK') != 'fill' or not isinstance(lane, int))
+            fork_here = self.encode_fork
             side2 = torch.cuda.Stream(device=self.dev) if fork_here else None
             # the graph of a CU-masked lane replays on that lane's CUs: the persistent kernels inside it (csrc/conv_ws.hip: one workgroup per CU)
             # size their grids for those, not for the capture stream's whole chip
@@ -800,7 +729,7 @@ class EncodeRolloutPipeline:
                 # the whole-chip fill / hybrid graphs of a pipeline whose rollout units hold their CUs for a whole launch anyway (token-stationary
                 # units): one persistent convolution workgroup per CU of the device -- C2 at 20 / 60 batches 545 -> 567 k, 551 -> 612 k frames/s with
                 # every 4th batch on the hybrid lane (192 / 384 / 512 workgroups: 574 / 559 / 565 k at 20; profiles/r05_probes.txt)
-                lane_cus = int(os.environ.get('SF_PIPE_FILL_WS', str(self._lib.sf_stream_cus(None))))
+                lane_cus = int(self._lib.sf_stream_cus(None))
             if lane_cus:
                 self._lib.sf_stream_set_cus(C.c_void_p(side.cuda_stream), lane_cus)
             with torch.cuda.stream(side):
@@ -823,7 +752,7 @@ class EncodeRolloutPipeline:
         unmasked streams (the encode partition is about to fall idle)."""
         G = self.G
         sizes, n_tail = unit_sizes_for(n, G, self._rows_per_batch, ramp=self.ramp, spread=self.spread_remainder)
-        probe = os.environ.get('SF_PIPE_SIZES')   # (probe: an explicit unit plan, e.g. "4,4,6,6"; at most two units of a size other than `group` in a row)
+        probe = getattr(self, 'unit_sizes_override', None)   # (tools: an explicit unit plan, e.g. "4,4,6,6"; at most two units of a size other than `group` in a row)
         if probe and sum(int(x) for x in probe.split(',')) == n:
             sizes = [int(x) for x in probe.split(',')]
         plan, u0, nfull, ntail = [], 0, 0, {}
@@ -833,7 +762,7 @@ class EncodeRolloutPipeline:
             # streams -- the third unit of the driver's 20 batches (6, 6, 6, 2) would otherwise wait 15 ms for a rollout stream (488 -> 550 k frames/s).
             # Only when no hybrid-lane encode follows (the last unit's batches all take the masked lane): the first drain unit sits on that lane's
             # stream (24 batches as 6, 6, 6, 6 with two drain units: 506 k; 60 batches: 538 against 580 k)
-            n_drain = max(n_drain, int(os.environ.get('SF_PIPE_DRAIN_UNITS', '2')))
+            n_drain = max(n_drain, 2)
         for i, nb in enumerate(sizes):
             if nb == G:
                 u = self.units[nfull % self.NU]
@@ -983,7 +912,7 @@ class EncodeRolloutPipeline:
                         # stream: a queue parked in a cross-queue wait slows the queues that are running on this platform (the
                         # masked encode lane ran at 5.8 instead of 4.05 ms per batch with the wait on the stream)
                         for e in ev_enc[k - NS]:
-                            e.synchronize() if os.environ.get('SF_PIPE_UPLOAD_WAIT', 'host') == 'host' else self._s_copy.wait_event(e)
+                            e.synchronize()
                     src = imgs[k]
                     if not pinned_in:
                         if k >= NS:

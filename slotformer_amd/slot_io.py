@@ -26,6 +26,18 @@ def dump_slots(path, **splits):
         pickle.dump({k: v for k, v in splits.items()}, f)
 
 
+def link_slots(save_path, weight_path, subset=None):
+    """The soft link the reference leaves next to the weights a slot file was extracted with (extract_slots.py:86-93): `<weight dir>/slots.pkl`,
+    or `<weight dir>/<subset>_slots.pkl` for the Physion subsets -- where the video-prediction configs look for the slots.  An existing link is
+    replaced (the reference's `ln -s` fails silently there); returns the link's path."""
+    name = 'slots.pkl' if subset is None else f'{subset}_slots.pkl'
+    ln_path = os.path.join(os.path.dirname(os.path.abspath(weight_path)), name)
+    if os.path.islink(ln_path):
+        os.unlink(ln_path)
+    os.symlink(os.path.abspath(save_path), ln_path)
+    return ln_path
+
+
 def load_slots(path):
     with open(path, 'rb') as f:
         return pickle.load(f)

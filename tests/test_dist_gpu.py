@@ -1,5 +1,5 @@
 """RCCL on the GPU box, every round, although only one GPU is available: the process-group path of bench.py
-(`SF_BENCH_FORCE_DIST=1`: init + barrier + max-reduce of the elapsed time) and the flat-bucket gradient all-reduce of the
+(`bench.py --force-dist`: init + barrier + max-reduce of the elapsed time) and the flat-bucket gradient all-reduce of the
 training path under a 1-rank `nccl` group (scripts/sbatch_run.sh:36-42 launches the reference the same way, one process per
 GPU).  A 1 -> 8 GPU curve cannot be measured here; see DESIGN.md 6."""
 import json
@@ -26,10 +26,10 @@ def _free_port():
 
 
 def test_bench_under_rccl_process_group(dev):
-    env = dict(os.environ, SF_BENCH_FORCE_DIST='1', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
                MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
-                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+                        '--no-cpu-baseline', '--force-dist'], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')][-1]
     d = json.loads(line)
@@ -39,18 +39,17 @@ def test_bench_under_rccl_process_group(dev):
 
 def test_bench_launches_its_own_ranks(dev):
     """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (one rank per GPU, RCCL): the same code path
-    with N = 1 (SF_BENCH_SELF_LAUNCH=1) on the one GPU of the box -- the JSON line comes from rank 0 of the launched job with the process-group keys;
+    with N = 1 (--self-launch) on the one GPU of the box -- the JSON line comes from rank 0 of the launched job with the process-group keys;
     and `--gpus 2` on this box fails cleanly with a JSON line that says what is missing (exit code 0, no value)."""
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    env.update(SF_BENCH_SELF_LAUNCH='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--windows', '2',
-                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+                        '--no-cpu-baseline', '--self-launch'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')][-1])
     assert d['n_gpus'] == 1 and d['value'] > 0 and d['rccl_ranks'] == 1 and 'nccl' in d['process_group_backend']
     assert len(d['per_rank_frames_per_s']) == 1 and d['ms_per_step_windows']['n'] == 2 and d['config']['stream_placement']['rccl_initialised']
     if torch.cuda.device_count() < 2:
-        env.pop('SF_BENCH_SELF_LAUNCH')
         r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
         assert r2.returncode == 0
         d2 = json.loads([ln for ln in r2.stdout.strip().splitlines() if ln.startswith('{')][-1])

@@ -17,6 +17,12 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max()).item()
 
 
+def elementwise_close(a, b, rtol=RTOL, floor=1e-4):
+    """north star's 1e-3 rel, element by element in the allclose form: |a - b| <= rtol |b| + floor max|b| (slots cross zero: an absolute floor)"""
+    a, b = a.detach().cpu().double(), torch.as_tensor(b).double()
+    return bool(((a - b).abs() <= rtol * b.abs() + floor * b.abs().max()).all())
+
+
 def build(cfg, golden, seed, dev, vp=False):
     from slotformer_amd.base_slots import build_model as bb
     from slotformer_amd.video_prediction import build_model as bv
@@ -69,6 +75,8 @@ def test_savi_golden(dev, name, cfg, B, T, seed, noise_seed):
     assert rel_err(out['kernel_dist'], g['kernel_dist']) < RTOL
     # tighter: fp32 reorder noise only
     assert rel_err(out['post_slots'], g['post_slots']) < 5e-5
+    # and element by element, as the rollout fixtures are held (test_rollout_golden)
+    assert elementwise_close(out['post_slots'], g['post_slots']) and elementwise_close(out['kernel_dist'], g['kernel_dist'])
 
 
 @pytest.mark.parametrize('name,cfg,B,T,seed,noise_seed', [
@@ -126,6 +134,7 @@ def test_steve_golden_and_masks(dev):
     m.testing = True
     out = m({'img': gu.seeded_img(1, 2, 128).to(dev)})
     assert rel_err(out['slots'], g['slots']) < 5e-5
+    assert elementwise_close(out['slots'], g['slots'])
     masks = out['masks'].cpu()
     assert masks.shape == g['masks'].shape
     assert (masks - torch.from_numpy(g['masks'])).abs().max() < 1e-5
@@ -695,11 +704,12 @@ def test_next_step_prologue_at_the_tail_of_the_slot_update(dev):
 
 @pytest.mark.parametrize('name', ['C2', 'C5'])
 @torch.no_grad()
-def test_interleaved_encode_is_bit_identical(dev, name):
-    """sf_set_encode_interleave(1) (opt-in): the features of time step t + 1 computed inside the slot branch of step t, its fragment-weight
-    convolutions launched together with the slot updates (the update's workgroups as the first blocks of the convolution launch,
-    conv5x5_rows4_update_kernel) -- against the plain order (0): the same bits, with injected kernel noise (C2), the Transformer + LSTM predictor
-    (C5 shapes at T = 4), precomputed features of the first steps, STEVE-style attention maps, and B = 1 / 32."""
+def test_batched_encode_is_bit_identical(dev, name):
+    """The one-stream encode runs the 64 -> 64 convolutions of ALL time steps as one launch per layer (csrc/engine.hip, batched form; the
+    weights-stationary kernel on a CU-masked stream) -- against the step-by-step orders (two-branch form on a second stream; precomputed features of
+    the first steps): the same bits, with injected kernel noise (C2), the Transformer + LSTM predictor (C5 shapes at T = 4), STEVE-style attention
+    maps, B = 1 / 5 / 32, on a plain stream and on a stream with 96 CUs of its own."""
+    import ctypes as C
     from slotformer_amd import engine, _lib
     from slotformer_amd.base_slots import build_model
     lib = _lib.lib()
@@ -708,26 +718,26 @@ def test_interleaved_encode_is_bit_identical(dev, name):
     m = build_model(gu.ParamsView(cfg)).eval().to(dev)
     m.testing = True
     N, D = cfg['slot_dict']['num_slots'], cfg['slot_dict']['slot_size']
-    old = lib.sf_get_encode_interleave()
-    try:
-        for B, T in ((5, 4), (1, 3), (32, 2)):
-            img = gu.seeded_img(B, T, 128, seed=71 + B).to(dev)
-            noise = engine.kernel_noise(m, gu.seeded_normal((B, T, N, D), 72).to(dev), B, T, dev)
-            outs = {}
-            for mode in (0, 1):
-                lib.sf_set_encode_interleave(mode)
-                if hasattr(m.predictor, 'reset'):
-                    m.predictor.reset()
-                outs[mode] = engine.savi_encode(m, img, noise=noise, want_attn=True, ws_slot=('il', mode), side_stream=None)
-                torch.cuda.synchronize()
-            for a, b in zip(outs[0], outs[1]):
-                assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), (name, B, T)
-            feat = engine.savi_cnn(m, img, 0, 2)
-            lib.sf_set_encode_interleave(1)
+    h = C.c_void_p()
+    _lib.check(lib.sf_stream_create_cu_mask(C.byref(h), (C.c_uint * 8)(*([0xffffffff] * 3 + [0] * 5)), 8))
+    masked = torch.cuda.ExternalStream(h.value, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    for B, T in ((5, 4), (1, 3), (32, 2)):
+        img = gu.seeded_img(B, T, 128, seed=71 + B).to(dev)
+        noise = engine.kernel_noise(m, gu.seeded_normal((B, T, N, D), 72).to(dev), B, T, dev)
+        outs = {}
+        for mode in ('batched', 'batched_masked', 'two_branches', 'feat_pre'):
             if hasattr(m.predictor, 'reset'):
                 m.predictor.reset()
-            o2 = engine.savi_encode(m, img, noise=noise, ws_slot=('il', 1), side_stream=None, feat_pre=feat)
             torch.cuda.synchronize()
-            assert torch.equal(o2[0], outs[0][0]), (name, B, T, 'feat_pre')
-    finally:
-        lib.sf_set_encode_interleave(old)
+            if mode == 'batched_masked':
+                with torch.cuda.stream(masked):
+                    outs[mode] = engine.savi_encode(m, img, noise=noise, want_attn=True, ws_slot=('bt', mode), side_stream=None)
+            elif mode == 'feat_pre':
+                outs[mode] = engine.savi_encode(m, img, noise=noise, want_attn=True, ws_slot=('bt', mode), side_stream=None, feat_pre=engine.savi_cnn(m, img, 0, 2))
+            else:
+                outs[mode] = engine.savi_encode(m, img, noise=noise, want_attn=True, ws_slot=('bt', mode), side_stream=side if mode == 'two_branches' else None)
+            torch.cuda.synchronize()
+        for mode in ('batched_masked', 'two_branches', 'feat_pre'):
+            for a, b in zip(outs['batched'], outs[mode]):
+                assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), (name, B, T, mode)

@@ -208,3 +208,20 @@ def test_cu_mask_words_balance_every_shader_engine():
         pl.encode_mask_words('rows9')
     with pytest.raises(ValueError):
         pl.encode_mask_words([1, 2, 3])
+
+
+def test_slot_file_link_next_to_the_weights(tmp_path):
+    """extract_slots.py:86-93: the slot file is linked into the directory of the weights it was extracted with (`slots.pkl`, `<subset>_slots.pkl`)."""
+    import os
+    import numpy as np
+    from slotformer_amd import slot_io
+    wdir = tmp_path / 'ckpt'
+    wdir.mkdir()
+    weight = wdir / 'model_10.pth'
+    weight.write_bytes(b'x')
+    path = tmp_path / 'out' / 'clevrer_slots.pkl'
+    slot_io.dump_slots(str(path), train=slot_io.slots_to_dict(['a/v0.mp4'], np.zeros((1, 2, 3, 4), np.float32)))
+    ln = slot_io.link_slots(str(path), str(weight))
+    assert ln == str(wdir / 'slots.pkl') and os.path.islink(ln) and list(slot_io.load_slots(ln)['train']) == ['v0.mp4']
+    assert slot_io.link_slots(str(path), str(weight)) == ln     # replaced, not an error
+    assert slot_io.link_slots(str(path), str(weight), subset='Collide').endswith('Collide_slots.pkl')

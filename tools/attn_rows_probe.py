@@ -1,7 +1,7 @@
 """Row-tile attention form (csrc/attn_rows.hip) against the all-heads form: rollout-only timing of one unit under hipGraph replay,
-bit comparison, and (SF_LF_DBG=16) the in-kernel phase ticks of workgroup 0 of the two new kernels.
+bit comparison, and (SF_DBG=lf=16) the in-kernel phase ticks of workgroup 0 of the two new kernels.
 
-    [SF_LF_DBG=16] python tools/attn_rows_probe.py [videos] [steps]"""
+    [SF_DBG=lf=16] python tools/attn_rows_probe.py [videos] [steps]"""
 import ctypes as C
 import os
 import sys
@@ -56,7 +56,7 @@ with torch.no_grad():
     ref = outs['head pairs (default)']
     for name, o in outs.items():
         print(f'{name:34s} equal to default: {bool(torch.equal(o, ref))}  max abs diff {(o - ref).abs().max().item():.3e}  finite {bool(torch.isfinite(o).all())}')
-    if int(os.environ.get('SF_LF_DBG', '0')) & 16:
+    if 'lf=16' in os.environ.get('SF_DBG', ''):
         engine.rollout(roll, fresh(), 6, 3, opts=FORMS['row tiles'])
         torch.cuda.synchronize()
         out = (C.c_longlong * 32)()

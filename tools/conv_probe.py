@@ -38,7 +38,7 @@ with torch.no_grad():
                 dt = (time.perf_counter() - t0) / 20
             fl = 2.0 * F * 4096 * 64 * 64 * 25
             print(f'{name:12s} {kname:32s}: {1e6 * dt:7.1f} us per launch of {F} frames  ({fl / dt / 1e12:.0f} TFLOP/s)', flush=True)
-    if os.environ.get('SF_CONV_DBG'):
+    if ('conv' in os.environ.get('SF_DBG', '')):
         import ctypes as C
         from slotformer_amd import _lib
         lib = _lib.lib()

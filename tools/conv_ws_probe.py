@@ -1,5 +1,5 @@
 """Timing of the weights-stationary 5x5 convolution (csrc/conv_ws.hip) against the 4-row-tile kernel: whole chip and on a 128-CU masked stream, one time
-step (32 frames) and six (192 frames) per launch; phase stamps of workgroup 0 with SF_CONV_DBG=1.   python tools/conv_ws_probe.py"""
+step (32 frames) and six (192 frames) per launch; phase stamps of workgroup 0 with SF_DBG=conv.   python tools/conv_ws_probe.py"""
 import ctypes as C
 import os
 import sys
@@ -49,7 +49,7 @@ for F_ in (32, 192):
         cus = lib.sf_stream_cus(C.c_void_p(st.cuda_stream))
         roof = 2500.0 / 3 * cus / 256
         print(f'  {name:12s} ({cus} CUs): tiles {t_t:7.1f} us ({fl / t_t / 1e6 / roof:.3f} of the roof)   stationary {t_w:7.1f} us ({fl / t_w / 1e6 / roof:.3f})' + extra, flush=True)
-if os.environ.get('SF_CONV_DBG') == '1':
+if 'conv' in os.environ.get('SF_DBG', ''):
     ts = (C.c_longlong * 16)()
     x = torch.randn(32, 64, 64, 64, device=dev)
     ops.conv5x5_ws(x, wf, b)

@@ -1,5 +1,5 @@
 """The decoder's fragment-weight transposed convolution (deconv_s2.hip): microseconds per launch by input width / image count, and the
-in-kernel phase stamps of workgroup 0 (SF_DECONV_DBG=1).   python tools/deconv_probe.py [images]"""
+in-kernel phase stamps of workgroup 0 (SF_DBG=deconv).   python tools/deconv_probe.py [images]"""
 import ctypes as C
 import os
 import sys
@@ -42,7 +42,7 @@ with torch.no_grad():
                 dth = timed(lambda: ops.deconv5x5s2_head(x, frag, b, hw, hb))
                 line += f'   | head form {1e6 * dth:7.1f} us  {fl / dth / 1e12:6.1f} TFLOP/s = {fl / dth / 1e12 / 833.3:.3f}'
             print(line, flush=True)
-    if os.environ.get('SF_DECONV_DBG'):
+    if ('deconv' in os.environ.get('SF_DBG', '')):
         lib.sf_debug_read_ts_deconv.argtypes = [C.POINTER(C.c_longlong)]
         for name, fn in (('plain W 64', lambda: ops.deconv5x5s2_frag(torch.randn(R, 64, 64, 64, device=dev), frag, b)),
                          ('head  W 64', lambda: ops.deconv5x5s2_head(torch.randn(R, 64, 64, 64, device=dev), frag, b, hw, hb))):

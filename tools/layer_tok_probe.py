@@ -1,7 +1,7 @@
 """Token-stationary whole-layer launch (csrc/layer_tok.hip) against a float64 PyTorch restatement of nn.TransformerEncoderLayer (norm_first, relu) and
 against the row-tile forms it replaces (attention rows + core, FFN tile):  max relative error, us per launch.
 
-    [SF_LT_DBG=1] python tools/layer_tok_probe.py [B L ...]        (pairs; default: 128 42, 192 42, 64 36, 256 8, 256 48, 3 42, 1 42)"""
+    [SF_DBG=lt] python tools/layer_tok_probe.py [B L ...]        (pairs; default: 128 42, 192 42, 64 36, 256 8, 256 48, 3 42, 1 42)"""
 import ctypes as C
 import os
 import sys

@@ -1,5 +1,5 @@
 """Phase timestamps (100 MHz wall clock) of workgroup 0 of the fused rollout-layer kernels:
-   SF_LF_DBG=16 python tools/lf_phase_probe.py [B] [ffn_rows]"""
+   SF_DBG=lf=16 python tools/lf_phase_probe.py [B] [ffn_rows]"""
 import ctypes as C
 import os
 import sys

@@ -72,7 +72,7 @@ def run_roll(name, words):
     lib.sf_stream_destroy(h)
 
 
-if len(sys.argv) > 1 and sys.argv[1] == 'ffn':      # SF_LF_DBG=32: where and when the FFN workgroups of the last launch ran
+if len(sys.argv) > 1 and sys.argv[1] == 'ffn':      # SF_DBG=lf=32: where and when the FFN workgroups of the last launch ran
     from slotformer_amd.pipeline import encode_mask_words
     buf = torch.randn(32, 56, 7, 128, device=dev)
     for spec in ('rows2', 'rows3', 0xff):
@@ -104,7 +104,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'three':    # three-way split: rollout o
         run(f'{name}, {nb} videos', words)
     sys.exit(0)
 
-if len(sys.argv) > 1 and sys.argv[1] == 'gap':      # SF_LF_DBG=16: block 0 of the last attention and the last FFN launch, absolute ticks
+if len(sys.argv) > 1 and sys.argv[1] == 'gap':      # SF_DBG=lf=16: block 0 of the last attention and the last FFN launch, absolute ticks
     from slotformer_amd.pipeline import encode_mask_words
     buf = torch.randn(32, 56, 7, 128, device=dev)
     lib.sf_debug_read_ts.argtypes = [C.POINTER(C.c_longlong)]

@@ -1,5 +1,5 @@
 """Timeline of one pipelined run of the bench workload (device times of every encode end, rollout start / end):
-   SF_PIPE_TRACE=1 python tools/pipe_timeline.py [n_batches]     (+ the SF_PIPE_* / SF_BENCH_* knobs of bench.py)"""
+   SF_PIPE_TRACE=1 python tools/pipe_timeline.py [n_batches]     (+ the SF_PIPE_* switches of slotformer_amd/switches.py)"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,9 +15,9 @@ cfg = bench.bench_configs()['C2']
 savi, roll = bench.build_models(dev, cfg)
 B, T, H = 32, 6, 50
 ring = [bench.synthetic_img(B, T, 128, seed=1234 + 1000 * k).to(dev) for k in range(3)]
-steal = os.environ.get('SF_BENCH_STEAL')
-group = os.environ.get("SF_BENCH_GROUP")
-cu = os.environ.get('SF_BENCH_CU_SPLIT', 'ff')
+steal = None
+group = os.environ.get('SF_PIPE_GROUP')
+cu = 'ff'
 with torch.no_grad():
     pipe = EncodeRolloutPipeline(savi, roll, B, T, H, steal_steps=None if steal is None else float(steal),
                                  group=None if group is None else int(group), encode_cu_word=cu if cu.startswith('rows') else int(cu, 16))

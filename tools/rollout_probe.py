@@ -1,9 +1,9 @@
 """Rollout-only timing + phase timestamps + a quick cross-check for the C2 rollouter (B=32, 6+50):
 
-    [SF_LF_DBG=16] python tools/rollout_probe.py [B]
+    [SF_DBG=lf=16] python tools/rollout_probe.py [B]
 
 prints ms per 50-step rollout (eager and hipGraph replay), us/step, the max relative difference between the fused
-split-bf16 path and the exact-f32 GEMM path on the same input, and (with SF_LF_DBG=16) the in-kernel phase ticks."""
+split-bf16 path and the exact-f32 GEMM path on the same input, and (with SF_DBG=lf=16) the in-kernel phase ticks."""
 import ctypes as C
 import os
 import sys
@@ -59,7 +59,7 @@ with torch.no_grad():
     tg = (time.perf_counter() - t0) / 10
     print('seam timeouts:', lib.sf_seam_timeouts())
     print(f'B={B}: eager {1e3 * te:.3f} ms ({1e6 * te / 50:.1f} us/step)   graph {1e3 * tg:.3f} ms ({1e6 * tg / 50:.1f} us/step)')
-    if int(os.environ.get('SF_LF_DBG', '0')) & 16:
+    if 'lf=16' in os.environ.get('SF_DBG', ''):
         engine.rollout(roll, buf, 6, 3)
         torch.cuda.synchronize()
         out = (C.c_longlong * 32)()

@@ -30,7 +30,7 @@ for name, st in (('whole chip', torch.cuda.Stream(device=dev)), ('128-CU mask', 
         dt = (time.perf_counter() - t0) / 50
     print(f'SF_SA_TILE={os.environ.get("SF_SA_TILE", "0")} {name:12s}: {1e6 * dt:6.1f} us per launch of {B} frames  ({B * HW * D * 4 / dt / 1e12:.2f} TB/s of unique bytes)', flush=True)
 
-if os.environ.get('SF_SA_DBG') == '1':
+if 'sa' in os.environ.get('SF_DBG', ''):
     lib.sf_debug_sa_stamps(1)
     for name, st in (('whole chip', torch.cuda.current_stream()), ('128-CU mask', masked)):
         with torch.cuda.stream(st):
