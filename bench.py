@@ -144,7 +144,7 @@ def committed_profile(key):
 
 
 KERNEL_CLASS = {'layer_tok_kernel': 'layer_tok', 'conv5x5_halo': 'conv', 'ffn_qkv_tile_kernel': 'ffn_fused', 'ffn_tile_kernel': 'ffn_fused', 'ffn_partial_kernel': 'ffn_fused', 'ffn64_parts_kernel': 'ffn_fused', 'ffn_wide_parts_kernel': 'ffn_fused',
-                'conv5x5_rows4_kernel': 'conv', 'qkv_rows_kernel': 'attention', 'attn_core_kernel': 'attention', 'attn_oproj_kernel': 'attention', 'attn_all_kernel': 'attention', 'seam_kernel': 'seam', 'sa_attn_mfma_kernel': 'slot_attn', 'sa_attn_fold_kernel': 'slot_attn', 'sa_attn_tile_kernel': 'slot_attn'}
+                'conv5x5_rows4_kernel': 'conv', 'conv5x5_ws_kernel': 'conv', 'qkv_rows_kernel': 'attention', 'attn_core_kernel': 'attention', 'attn_oproj_kernel': 'attention', 'attn_all_kernel': 'attention', 'seam_kernel': 'seam', 'sa_attn_mfma_kernel': 'slot_attn', 'sa_attn_fold_kernel': 'slot_attn', 'sa_attn_tile_kernel': 'slot_attn'}
 
 
 def dominant_kernel():
@@ -877,9 +877,12 @@ def main():
             us = us_trace or (iso['avg_us'] if iso else None)
             ach_iso = flops_per_launch / (us * 1e-6) / 1e12 if us else None
             objs['conv'] = {
-                'kernel': ('conv5x5_rows4_kernel' if prec == 'bf16x3' else 'sf_gemm_kernel<128,64,...,conv_nhwc>') + ' (5x5 conv 64->64 @64x64; ' + peak_note + ')',
-                'bound': 'mfma (inside the 25 taps a wave issues an MFMA every ~59 cycles at 2.4 GHz whole-chip, two waves per SIMD share the pipe unevenly; '
-                         'the un-overlapped halo fill, the exchange of the cin halves and the epilogue take a third of a workgroup\'s time, DESIGN.md 4 and 7)',
+                'kernel': ('conv5x5_ws_kernel (weights stationary in registers, one four-wave workgroup per CU walking its rows through a ring of halo rows: the CU-masked '
+                           'encode lane and the fill / hybrid graphs) and conv5x5_rows4_kernel (4-row tiles, streamed weight fragments: plain streams) -- all '
+                           'time steps of a batch per launch' if prec == 'bf16x3' else 'sf_gemm_kernel<128,64,...,conv_nhwc>') + ' (5x5 conv 64->64 @64x64; ' + peak_note + ')',
+                'bound': 'mfma (weights-stationary kernel: per output row and wave 300 MFMAs in ~11.2 k cycles against 9.6 k of pipe time -- two workgroup barriers, '
+                         'the exchange of the cin halves through LDS and the fill / epilogue instructions between the MFMAs; the chip clocks ~2.1-2.2 GHz under this '
+                         'load, the roof is priced at 2.4; DESIGN.md round 5)',
                 'achieved': ach_iso, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': (ach_iso / peak_chip) if ach_iso else None,
                 'avg_launch_us': us, 'avg_launch_us_rocprof': us_trace, 'avg_launch_us_events_isolated': iso['avg_us'] if iso else None,
                 'measured': 'flops_per_launch / avg_launch_us_rocprof (the whole-chip launches of the committed rocprof trace, default queue); '
@@ -891,7 +894,8 @@ def main():
                          'note': 'a pipelined pass of the timed schedule, beside the rollout graphs; stolen convolutions (rollout streams) are not part of this average'},
                 'traffic': pm.get('traffic_bytes_per_launch'), 'mfma_busy_frac': pm.get('mfma_busy_frac'), 'pmc_source': pm.get('source'),
                 'traffic_unit': 'bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE)',
-                'algorithmic_bytes_per_launch': 2 * B * 4096 * 64 * 4 + 64 * 1600 * 4, 'flops_per_launch': flops_per_launch,
+                'algorithmic_bytes_per_launch': 2 * (flops_per_launch / (2.0 * 4096 * 64 * 1600)) * 4096 * 64 * 4 + 64 * 1600 * 4, 'flops_per_launch': flops_per_launch,
+                'frames_per_launch': flops_per_launch / (2.0 * 4096 * 64 * 1600),
             }
         sa = prof.get('slot_attn_iter')
         iso = prof_iso.get('slot_attn_iter')

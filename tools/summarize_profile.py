@@ -34,7 +34,7 @@ if f:
     per = defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = short(r['Kernel_Name'])
-        if n.startswith(('deconv5x5s2_kernel', 'decode_combine_kernel', 'decode_seg_kernel', 'ffn_qkv_tile_kernel', 'pixel_feat_stream_kernel', 'conv5x5_rows4_kernel', 'qkv_rows_kernel', 'attn_core_kernel', 'ffn_tile_kernel', 'conv5x5_halo_kernel', 'sa_attn_mfma_kernel', 'sa_attn_tile_kernel', 'pixel_mlp_kv_kernel', 'ffn_partial_kernel', 'ffn64_parts_kernel', 'ffn_wide_parts_kernel', 'attn_oproj_kernel', 'sa_attn_fold_kernel', 'sa_slot_update_kernel', 'conv5x5_halo256_kernel')):
+        if n.startswith(('deconv5x5s2_kernel', 'decode_combine_kernel', 'decode_seg_kernel', 'ffn_qkv_tile_kernel', 'pixel_feat_stream_kernel', 'conv5x5_rows4_kernel', 'conv5x5_ws_kernel', 'layer_tok_kernel', 'qkv_rows_kernel', 'attn_core_kernel', 'ffn_tile_kernel', 'conv5x5_halo_kernel', 'sa_attn_mfma_kernel', 'sa_attn_tile_kernel', 'pixel_mlp_kv_kernel', 'ffn_partial_kernel', 'ffn64_parts_kernel', 'ffn_wide_parts_kernel', 'attn_oproj_kernel', 'sa_attn_fold_kernel', 'sa_slot_update_kernel', 'conv5x5_halo256_kernel')):
             per[(n, r['Queue_Id'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     lines.append('# per-queue durations of the encode kernels  [trace_kernel_trace.csv]  (queue with the most launches of a '
                  'kernel = the CU-masked encode stream of the timed region = bench.py roofline.avg_launch_us; the others = '
@@ -104,7 +104,7 @@ def stats_encode_queue_us(pred):
 def is_conv(name):  # conv5x5_halo_kernel, or sf_gemm_kernel<..., ALOAD=1 (NHWC im2col), LN, BF3>
     if 'conv5x5_rows4_kernel<false, true>' in name:   # the decoder's head-fused stride-1 layer (64 x 64 decode leg): its own class
         return False
-    if 'conv5x5_halo' in name or 'conv5x5_rows4' in name:
+    if 'conv5x5_halo' in name or 'conv5x5_rows4' in name or 'conv5x5_ws' in name:
         return True
     m = re.search(r'sf_gemm_kernel<([^>]*)>', name)
     return bool(m) and m.group(1).replace(' ', '').split(',')[8] == '1'
