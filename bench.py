@@ -865,9 +865,14 @@ def main():
         iso = prof_iso.get('conv_nhwc_implicit_gemm')
         if conv or iso:
             pm = committed_profile('conv_nhwc_implicit_gemm') if args.config == 'C2' else {}
-            if not conv:
-                us_live = pm.get('avg_launch_us_trace_encode_queue') or iso['avg_us']
-                conv = {'work': iso['work'], 'launches': iso['launches'], 'avg_us': us_live}
+            live_src = 'HIP events (library brackets) in an eager pass of the timed schedule'
+            if pm.get('avg_launch_us_trace_encode_queue') and iso:
+                # (the committed trace of THIS source tree: the graph-replayed launches of the timed schedule on the slowest encode queue -- the eager event
+                #  pass runs without the rollout graphs beside it and at a higher clock: 404 us against 520-610 in the trace)
+                conv = {'work': iso['work'], 'launches': iso['launches'], 'avg_us': pm['avg_launch_us_trace_encode_queue']}
+                live_src = 'mean duration on the slowest encode queue of the committed rocprof trace (' + str(pm.get('source')) + ')'
+            elif not conv:
+                conv = {'work': iso['work'], 'launches': iso['launches'], 'avg_us': iso['avg_us']}
             flops_live = conv['work'] / conv['launches']        # mean over the lanes' launches (each a share of the batch)
             ach = flops_live / (conv['avg_us'] * 1e-6) / 1e12
             # CUs one live launch runs on: the lanes work side by side, each on its own CUs
@@ -890,7 +895,7 @@ def main():
                             f'{LIVE_EVERY}th launch) in a second pass of the timed schedule when the encode launches eagerly, else the mean duration on the '
                             'CU-masked encode queue of the committed trace (avg_launch_us_trace_encode_queue)',
                 'live': {'achieved': ach, 'cus': enc_cus, 'avg_launch_us': conv['avg_us'], 'launches': conv['launches'],
-                         'flops_per_launch': flops_live, 'frac_of_partition_peak': ach / (peak_chip * enc_cus / 256.0),
+                         'flops_per_launch': flops_live, 'frac_of_partition_peak': ach / (peak_chip * enc_cus / 256.0), 'source': live_src,
                          'note': 'a pipelined pass of the timed schedule, beside the rollout graphs; stolen convolutions (rollout streams) are not part of this average'},
                 'traffic': pm.get('traffic_bytes_per_launch'), 'mfma_busy_frac': pm.get('mfma_busy_frac'), 'pmc_source': pm.get('source'),
                 'traffic_unit': 'bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE)',
