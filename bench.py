@@ -641,6 +641,19 @@ def main():
             one_batch.append(time.perf_counter() - t1)
         one_batch_ms = 1e3 * sorted(one_batch[1:])[len(one_batch[1:]) // 2]   # (the first call captures the one-batch unit's graph)
         torch.cuda.synchronize()
+        # the same through the MODULE calls a reference script makes per batch (savi forward, then the rollouter: extract_slots.py:19-38 ->
+        # rollout_clevrer_slots.py:20-65; engine.savi_encode in its default two-branch form + engine.rollout in the library's default forms), eager
+        one_buf = torch.zeros(Bp, T_BURN + T_ROLL, N_SLOTS, SLOT_D, device=dev)
+        direct = []
+        for k in range(6):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            post_k, _, _ = engine.savi_encode(savi, ringp[k % 3], noise=noise_p)
+            one_buf[:, :T_BURN].copy_(post_k)
+            engine.rollout(roll, one_buf, T_BURN, T_ROLL, ws_slot=('bench', 'one'))
+            torch.cuda.synchronize()
+            direct.append(time.perf_counter() - t1)
+        one_batch_direct_ms = 1e3 * sorted(direct[1:])[len(direct[1:]) // 2]
         lib.sf_profile_enable((1 << 0) | (1 << 3))
         t_enc = timed_on(torch.cuda.current_stream(), encode)
         lib.sf_profile_enable(0)
@@ -760,7 +773,8 @@ def main():
                                  (f'encode stream on CU mask {cu_word if isinstance(cu_word, str) else hex(cu_word)} ({pipe.encode_cus} CUs, the same '
                                   'number in every XCD), rollout stream on the complement')) if (overlap and pipe.cu_split) else 'none',
             },
-            'one_batch_latency_ms': one_batch_ms,
+            'one_batch_latency_ms': one_batch_ms,   # pipeline object, one batch per run() call (graph replays, one stream)
+            'one_batch_latency_module_calls_ms': one_batch_direct_ms,   # savi forward + rollouter forward per batch, as the reference's scripts call them
             'one_batch_frames_per_s': Bp * (T_BURN + T_ROLL) / (one_batch_ms * 1e-3),
             'encode_ms': 1e3 * t_enc,
             'encode_ms_two_branches': 1e3 * t_enc_fork,

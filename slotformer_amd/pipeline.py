@@ -842,7 +842,10 @@ class EncodeRolloutPipeline:
             for u0, nb, u, _ in units:
                 for h in range(nb):
                     im = imgs[u0 + h].to(self.dev, non_blocking=True) if host_in else imgs[u0 + h]
-                    self._encode(im, nz(u0 + h), u.buf[h * B:(h + 1) * B], None)
+                    # (on the calling stream the encode has the whole chip: the fill graph -- one persistent convolution workgroup per CU of the
+                    #  device -- not the lane's, which is sized for the encode partition)
+                    whole = ('fill', 0) if (self.encode_graph and self.cu_split and self.fill_whole_chip and self.s_free and self.fill_par > 1) else 0
+                    self._encode(im, nz(u0 + h), u.buf[h * B:(h + 1) * B], None, lane=whole)
                 self._rollout(u)
                 for h in range(nb):
                     out[u0 + h].copy_(u.buf[h * B:(h + 1) * B], non_blocking=True)

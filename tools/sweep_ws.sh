@@ -5,20 +5,18 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 pm = d.get('partitioned_ms') or {}
 print('$tag', 'steps', d['steps'], 'value', round(d['value']/1e3,1), 'k  ms/step', round(d['ms_per_step'],3), 'units', d['config'].get('rollout_units_of_the_timed_run'), 'unit_ms', round(pm.get('rollout_unit_ms_on_its_cus') or 0, 2), 'enc lane', pm.get('encode_lane_ms_on_its_cus'), flush=True)
 " || tail -3 gpurun_out/sw_$tag.err; }
-STEPS=20
-run base
-run f256 SF_PIPE_FILL_WS=256
-run f256_h3 SF_PIPE_FILL_WS=256 SF_PIPE_HYBRID=3
-run f256_h4 SF_PIPE_FILL_WS=256 SF_PIPE_HYBRID=4
-run f384 SF_PIPE_FILL_WS=384
-run f512 SF_PIPE_FILL_WS=512
-run f192 SF_PIPE_FILL_WS=192
 STEPS=60
 run base
-run f256 SF_PIPE_FILL_WS=256
-run f256_h3 SF_PIPE_FILL_WS=256 SF_PIPE_HYBRID=3
-run f256_h4 SF_PIPE_FILL_WS=256 SF_PIPE_HYBRID=4
-run f512_h4 SF_PIPE_FILL_WS=512 SF_PIPE_HYBRID=4
-STEPS=100
-run f256_h4 SF_PIPE_FILL_WS=256 SF_PIPE_HYBRID=4
-run f256_h3 SF_PIPE_FILL_WS=256 SF_PIPE_HYBRID=3
+run g5 SF_PIPE_GROUP=5
+run g5_h3 SF_PIPE_GROUP=5 SF_PIPE_HYBRID=3
+run g5_h6 SF_PIPE_GROUP=5 SF_PIPE_HYBRID=6
+run g7 SF_PIPE_GROUP=7
+run h5 SF_PIPE_HYBRID=5
+run h6 SF_PIPE_HYBRID=6
+run h8 SF_PIPE_HYBRID=8
+STEPS=20
+run base
+run g5 SF_PIPE_GROUP=5
+run h6 SF_PIPE_HYBRID=6
+run fill12 SF_PIPE_FILL=12
+run fill24 SF_PIPE_FILL=24
