@@ -38,7 +38,7 @@ template <int STRIDE>
 __global__ __launch_bounds__(CF_NT) void conv_first_kernel(const float* __restrict__ img, long long frame_stride,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
                                                            const float* __restrict__ add, float* __restrict__ out, int Ho,
-                                                           int Hin, int Win, int relu) {
+                                                           int Hin, int Win, int relu, int fgroup, long long group_stride) {
   using G = CfGeo<STRIDE>;
   constexpr int HR = G::HR, HC = G::HC, HCP = G::HCP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -50,7 +50,8 @@ __global__ __launch_bounds__(CF_NT) void conv_first_kernel(const float* __restri
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int tiles = Ho / CF_TR;
   const int f = blockIdx.x / tiles, y0 = (blockIdx.x - f * tiles) * CF_TR;
-  const float* inf = img + (long long)f * frame_stride;
+  // frame f of the launch = frame f % fgroup of group f / fgroup (the batched encode: groups = time steps, frame_stride = T frames apart)
+  const float* inf = img + (long long)(f % fgroup) * frame_stride + (long long)(f / fgroup) * group_stride;
 
   // ---- weights [64][75] -> split planes, k 75..79 zero ----
   for (int idx = t; idx < CF_CO * (CF_KP / 4); idx += CF_NT) {
@@ -120,14 +121,14 @@ __global__ __launch_bounds__(CF_NT) void conv_first_kernel(const float* __restri
 
 template <int STRIDE>
 static int launch_cf(const float* img, long long frame_stride, const float* w, const float* bias, const float* add,
-                     float* out, int F, int Ho, int Hin, int Win, int relu, hipStream_t st) {
+                     float* out, int F, int Ho, int Hin, int Win, int relu, int fgroup, long long group_stride, hipStream_t st) {
   auto kern = conv_first_kernel<STRIDE>;
   constexpr size_t lds = CfGeo<STRIDE>::lds;
   static_assert(lds <= 80 * 1024, "first conv: two workgroups per CU");
   SF_TRY(sf_ensure_dyn_lds((const void*)kern, (size_t)(lds)));
   sf_prof_begin(SF_K_CONV_FIRST, st, 2.0 * (double)F * Ho * CF_TW * CF_CO * CF_K);
   hipLaunchKernelGGL(kern, dim3(F * (Ho / CF_TR)), dim3(CF_NT), lds, st, img, frame_stride, w, bias, add, out, Ho, Hin, Win,
-                     relu);
+                     relu, fgroup, group_stride);
   sf_prof_end(SF_K_CONV_FIRST, st);
   SF_CHECK_LAUNCH();
   return 0;
@@ -136,8 +137,13 @@ static int launch_cf(const float* img, long long frame_stride, const float* w, c
 // Returns 1 when the specialised kernel does not apply (caller uses the implicit-GEMM path).
 int sf_conv_first_ex(const float* img, long long frame_stride, const float* w, const float* bias, const float* add,
                      float* out, int F, int Cin, int Hin, int Win, int Cout, int ks, int stride, int relu, hipStream_t st) {
-  if (Cin != CF_CI || Cout != CF_CO || ks != CF_KS || F <= 0) return 1;
-  if (stride == 2 && Hin == 128 && Win == 128) return launch_cf<2>(img, frame_stride, w, bias, add, out, F, 64, Hin, Win, relu, st);
-  if (stride == 1 && Hin == 64 && Win == 64) return launch_cf<1>(img, frame_stride, w, bias, add, out, F, 64, Hin, Win, relu, st);
+  return sf_conv_first_grouped_ex(img, frame_stride, F > 0 ? F : 1, 0, w, bias, add, out, F, Cin, Hin, Win, Cout, ks, stride, relu, st);
+}
+// frames in groups: output frame i = input frame (i % fgroup) * frame_stride + (i / fgroup) * group_stride (one launch for all time steps of a batch)
+int sf_conv_first_grouped_ex(const float* img, long long frame_stride, int fgroup, long long group_stride, const float* w, const float* bias,
+                             const float* add, float* out, int F, int Cin, int Hin, int Win, int Cout, int ks, int stride, int relu, hipStream_t st) {
+  if (Cin != CF_CI || Cout != CF_CO || ks != CF_KS || F <= 0 || fgroup <= 0) return 1;
+  if (stride == 2 && Hin == 128 && Win == 128) return launch_cf<2>(img, frame_stride, w, bias, add, out, F, 64, Hin, Win, relu, fgroup, group_stride, st);
+  if (stride == 1 && Hin == 64 && Win == 64) return launch_cf<1>(img, frame_stride, w, bias, add, out, F, 64, Hin, Win, relu, fgroup, group_stride, st);
   return 1;
 }

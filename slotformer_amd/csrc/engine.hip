@@ -931,7 +931,12 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
     // leaves the features of step t at big[2] + t * B * HW * Cl
     const long long frame_elems0 = (long long)3 * res * res;
     const int c1 = m->enc_channels[1];
-    for (int t = 0; t < T; ++t)
+    int rc0 = 1;
+    if (sf_get_precision() >= 1)   // one launch for the B * T frames where the first-layer kernel applies (3 -> 64 channels at 128 x 128 / 64 x 64)
+      rc0 = sf_conv_first_grouped_ex(img, (long long)T * frame_elems0, B, frame_elems0, m->conv_w[0], m->conv_b[0], nullptr, big[0], B * T, m->enc_channels[0], res,
+                                     res, c1, m->enc_ks, res == 128 ? 2 : 1, 1, st_main);
+    if (rc0 < 0 || rc0 > 1) return rc0;
+    for (int t = 0; t < T && rc0 == 1; ++t)
       SF_TRY(sf_conv2d_nchw_in_f32(img + (long long)t * frame_elems0, (long long)T * frame_elems0, m->conv_w[0], m->conv_b[0], nullptr,
                                    big[0] + (long long)t * B * HW * c1, B, m->enc_channels[0], res, res, c1, m->enc_ks, res == 128 ? 2 : 1, 1, st_main));
     SF_TRY(run_cnn_layers(m, nullptr, 0, B * T, big[2], big[0], big[1], 1, m->enc_layers, st_main));

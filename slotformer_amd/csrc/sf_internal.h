@@ -116,6 +116,8 @@ int sf_pixel_mlp_kv_ex(const float* x, const float* ln0_g, const float* ln0_b, c
 
 // two-launch Transformer layer of the rollout (layer_fused.hip); sf_tfm_layer comes from the public header
 bool sf_layer_fused_ok(int d, int heads, int ffn, int L);
+int sf_conv_first_grouped_ex(const float* img, long long frame_stride, int fgroup, long long group_stride, const float* w, const float* bias,
+                             const float* add, float* out, int F, int Cin, int Hin, int Win, int Cout, int ks, int stride, int relu, hipStream_t st);
 int sf_conv_first_ex(const float* img, long long frame_stride, const float* w, const float* bias, const float* add,
                      float* out, int F, int Cin, int Hin, int Win, int Cout, int ks, int stride, int relu, hipStream_t st);
 
