@@ -1105,6 +1105,8 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
                                     (long long)T * N * HW, B, HW, N, D, scale, m->sa_eps, st));
       if (su_mfma) {
         bool rode = false;
+        // (the one-pass Slot-Attention kernel leaves every second partial record zero: the update reads the others -- eight, one round of requests)
+        const int p_step = (fold && P == HW / 256 && sf_slot_attn_sparse_records(kv, kv, HW, D)) ? 2 : 1;
         const bool fuse_next = can_fuse_next && last_it && t + 1 < T && prologue == 0;
         if (fuse_next) {
           SfNextStep nx;
@@ -1117,7 +1119,7 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
           SF_TRY(sf_slot_update_mfma_ex(pnum, pden, P, s_in, gru_ih_p, m->sa_gru_hh_p, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g, m->mlp_ln_b,
                                         m->sa_mlp_w1_p, m->mlp_b1, m->sa_mlp_w2_p, m->mlp_b2, s_out == slotsA ? latents : s_out,
                                         post_slots + (long long)t * N * D, (long long)T * N * D, m->sa_q_ln_g, m->sa_q_ln_b, q_w_p, q, B, N, ln_eps, st,
-                                        &nx));
+                                        &nx, p_step));
           next_done = true;
           rode = true;
         }
@@ -1125,7 +1127,7 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
           SF_TRY(sf_slot_update_mfma_ex(pnum, pden, P, s_in, gru_ih_p, m->sa_gru_hh_p, m->gru_b_ih, m->gru_b_hh, m->mlp_ln_g,
                                         m->mlp_ln_b, m->sa_mlp_w1_p, m->mlp_b1, m->sa_mlp_w2_p, m->mlp_b2, s_out,
                                         last_it ? post_slots + (long long)t * N * D : nullptr, (long long)T * N * D, m->sa_q_ln_g,
-                                        m->sa_q_ln_b, q_w_p, last_it ? nullptr : q, B, N, ln_eps, st));
+                                        m->sa_q_ln_b, q_w_p, last_it ? nullptr : q, B, N, ln_eps, st, nullptr, p_step));
         float* tmp = s_in;
         s_in = s_out;
         s_out = tmp;

@@ -62,7 +62,9 @@ int sf_slot_update_mfma_ex(const float* part_num, const float* part_den, int P, 
                            const void* gru_hh_p, const float* gru_b_ih, const float* gru_b_hh, const float* ln_g, const float* ln_b,
                            const void* w1_p, const float* b1, const void* w2_p, const float* b2, float* slots_out, float* out2,
                            long long out2_bs, const float* q_ln_g, const float* q_ln_b, const void* q_w_p, float* q_out, int B, int N,
-                           float ln_eps, hipStream_t st, const SfNextStep* next = nullptr);
+                           float ln_eps, hipStream_t st, const SfNextStep* next = nullptr, int p_step = 1);
+// 1 when sf_slot_attn_iter_ex takes its one-pass tile kernel for this shape (sums in the even partial records, zeros in the odd ones)
+bool sf_slot_attn_sparse_records(const float* k, const float* v, int HW, int D);
 // the same update at slot size 192 / slot MLP 384 (slot_update_wide.hip); operands as for sf_slot_update_mfma_ex
 bool sf_slot_update_wide_ok(int D, int H, int P);
 int sf_slot_update_wide_ex(const float* part_num, const float* part_den, int P, const float* slots_prev, const void* gru_ih_p, const void* gru_hh_p,

@@ -904,6 +904,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   SATS(7);
 }
 
+bool sf_slot_attn_sparse_records(const float* k, const float* v, int HW, int D) { return HW % 512 == 0 && k == v && D == 128; }
+
 int sf_slot_attn_iter_ex(const float* k, const float* v, int ld, long long batch_stride, const float* q,
                          float* part_num, float* part_den, float* attn_out, long long attn_batch_stride, int B,
                          int HW, int N, int D, float scale, float eps, hipStream_t st) {

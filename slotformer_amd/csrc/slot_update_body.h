@@ -9,6 +9,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef UM_STAMPS
+__device__ long long um_ts[16];
+#define UMTS(i) do { if (block == 0 && threadIdx.x == 0) um_ts[i] = wall_clock64(); } while (0)
+#else
+#define UMTS(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int UM_D = 128, UM_H = 256, UM_ROWS = 32, UM_NT = 512;
@@ -71,7 +78,8 @@ __device__ __forceinline__ void um_gemm(f32x16& acc, const UmFrags<NKS>& f, cons
 
 struct UmArgs {
   const float *part_num, *part_den;
-  int P;
+  int P;        // records READ per row: records 0, pstep, 2 pstep, .. of the P * pstep the producer wrote
+  int pstep;    // 2: the one-pass Slot-Attention kernel writes its sums into the even records and zeros into the odd ones (x + 0 = x: the same sums)
   const float* slots_prev;
   const uint4 *w_ih_p, *w_hh_p;   // [3D][D] packed
   const float *b_ih, *b_hh, *ln_g, *ln_b;
@@ -134,6 +142,7 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
   const int cb = wave & 3, half = wave >> 2;
   const int tok = lane & 31, kg = lane >> 5;
 
+  UMTS(0);
   // ---- requests in the order they are needed: partial records, previous slots and the parameter vectors, THEN the weight
   //      fragments (the loads retire in order) ----
   float dnv[4];
@@ -143,19 +152,20 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
     dnv[i] = 0.f;
     if (row < a.R && p < a.P) {
       const int b = row / a.N, n = row - b * a.N;
-      dnv[i] = a.part_den[((long long)b * a.P + p) * a.N + n];
+      dnv[i] = a.part_den[((long long)b * a.P * a.pstep + (long long)p * a.pstep) * a.N + n];
     }
   }
   const int ur = t >> 4, uc = (t & 15) * 8;   // thread = (row, 8 features)
   const bool rok = row0 + ur < a.R;
   const int urow = min(row0 + ur, a.R - 1), ub = urow / a.N, un = urow - ub * a.N;
-  const float* pn = a.part_num + ((long long)ub * a.P * a.N + un) * UM_D + uc;
+  const float* pn = a.part_num + ((long long)ub * a.P * a.pstep * a.N + un) * UM_D + uc;
+  const long long pst = (long long)a.pstep * a.N * UM_D;   // floats between two records read
   f32x4 pa[8][2];   // 8 partial records in flight at a time
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int pc = min(p, a.P - 1);
-    pa[p][0] = *(const f32x4*)(pn + (long long)pc * a.N * UM_D);
-    pa[p][1] = *(const f32x4*)(pn + (long long)pc * a.N * UM_D + 4);
+    pa[p][0] = *(const f32x4*)(pn + pc * pst);
+    pa[p][1] = *(const f32x4*)(pn + pc * pst + 4);
   }
   const f32x4 h0 = *(const f32x4*)(a.slots_prev + (long long)urow * UM_D + uc), h1 = *(const f32x4*)(a.slots_prev + (long long)urow * UM_D + uc + 4);
   constexpr int NPV = NEXT ? 5 : 4;
@@ -198,24 +208,30 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
       n0 += pa[p][0];
       n1 += pa[p][1];
     }
+  if (a.P > 8) {   // (a second round of requests only when there are more than eight records to read)
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int pc = min(8 + p, a.P - 1);
-    pa[p][0] = *(const f32x4*)(pn + (long long)pc * a.N * UM_D);
-    pa[p][1] = *(const f32x4*)(pn + (long long)pc * a.N * UM_D + 4);
+    for (int p = 0; p < 8; ++p) {
+      const int pc = min(8 + p, a.P - 1);
+      pa[p][0] = *(const f32x4*)(pn + pc * pst);
+      pa[p][1] = *(const f32x4*)(pn + pc * pst + 4);
+    }
   }
   um_load(fb, a.w_hh_p, 12, half * 4 + cb, 0, lane);
+  if (a.P > 8) {
 #pragma unroll
-  for (int p = 0; p < 8; ++p)
-    if (8 + p < a.P) {
-      n0 += pa[p][0];
-      n1 += pa[p][1];
+    for (int p = 0; p < 8; ++p)
+      if (8 + p < a.P) {
+        n0 += pa[p][0];
+        n1 += pa[p][1];
+      }
+    for (int p = 16; p < a.P; ++p) {
+      n0 += *(const f32x4*)(pn + p * pst);
+      n1 += *(const f32x4*)(pn + p * pst + 4);
     }
-  for (int p = 16; p < a.P; ++p) {
-    n0 += *(const f32x4*)(pn + (long long)p * a.N * UM_D);
-    n1 += *(const f32x4*)(pn + (long long)p * a.N * UM_D + 4);
   }
+  UMTS(1);
   __syncthreads();
+  UMTS(2);
   {
     float den = 0.f;
     for (int p = 0; p < a.P; ++p) den += DN[ur * 64 + p];
@@ -229,6 +245,7 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
   }
   __syncthreads();
 
+  UMTS(3);
   // ---- GRU: gate accumulator of this half (r or z), then its share of the n gate ----
   f32x16 g1, g2;
 #pragma unroll
@@ -239,6 +256,7 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
   UmFrags<8> fm;
   um_load(fm, a.w1_p, 8, wave, 0, lane);                                 // MLP layer 1 of this wave (lands under the gate math)
   um_gemm(g2, fa, half == 0 ? Uh : Xh, half == 0 ? Ul : Xl, UM_DP, 0, lane);
+  UMTS(4);
   // biases: column c = 32 cb + 8 g + 4 kg + q
   if (half == 1) {
     // z = sigmoid(W_iz u + W_hz h + b_iz + b_hz), ghn = W_hn h + b_hn  -> exchange
@@ -253,17 +271,27 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
       }
     }
   }
+  else {
+    // r = sigmoid(W_ir u + W_hr h + b_ir + b_hr) while the other half works on z (in place: g1 holds r behind the barrier)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 32 * cb + 8 * g + 4 * kg;
+      const f32x4 br = *(const f32x4*)(PV + UV_BIH + c) + *(const f32x4*)(PV + UV_BHH + c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g1[4 * g + q] = um_sigmoid(g1[4 * g + q] + br[q]);
+    }
+  }
   __syncthreads();
   if (half == 0) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int c = 32 * cb + 8 * g + 4 * kg;
-      const f32x4 br = *(const f32x4*)(PV + UV_BIH + c) + *(const f32x4*)(PV + UV_BHH + c), bn = *(const f32x4*)(PV + UV_BIH + 2 * UM_D + c);
+      const f32x4 bn = *(const f32x4*)(PV + UV_BIH + 2 * UM_D + c);
       const f32x4 hp = *(const f32x4*)(Fp + tok * UM_FP + c);
       f32x4 hn;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float rr = um_sigmoid(g1[4 * g + q] + br[q]);
+        const float rr = g1[4 * g + q];
         const float z = EX[((cb * 2 + 0) * 16 + 4 * g + q) * 64 + lane], ghn = EX[((cb * 2 + 1) * 16 + 4 * g + q) * 64 + lane];
         const float nn = um_tanh(g2[4 * g + q] + bn[q] + rr * ghn);
         hn[q] = (1.f - z) * nn + z * hp[q];
@@ -273,6 +301,7 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
   }
   __syncthreads();
 
+  UMTS(5);
   // ---- LN(h') -> X planes (thread = (row, 8 features); a row is 16 consecutive lanes) ----
   UmFrags<8> f2;
   um_load(f2, a.w2_p, 4, cb, half * 8, lane);   // MLP layer 2: K half of this wave
@@ -289,6 +318,7 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
   }
   __syncthreads();
 
+  UMTS(6);
   // ---- hidden = relu(W1 LN + b1): wave = hidden block ----
 #pragma unroll
   for (int r = 0; r < 16; ++r) g1[r] = 0.f;
@@ -303,6 +333,7 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
   }
   __syncthreads();
 
+  UMTS(7);
   // ---- x = h' + W2 hidden + b2: wave = (block, K half), halves meet in LDS ----
   UmFrags<4> fq;
   if (a.q_out) um_load(fq, a.q_w_p, 4, cb, half * 4, lane);
@@ -333,6 +364,7 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
       *(f32x4*)(Fp + tok * UM_FP + c) = v;   // (Fp is dead: the finished rows for the q projection)
     }
   }
+  UMTS(8);
   if (a.q_out == nullptr) return;
   __syncthreads();
 
@@ -435,6 +467,7 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
     }
   }
 
+  UMTS(9);
   // ---- q = LN_q(x) Wq^T ----
   {
     const f32x4 v0 = *(const f32x4*)(Fp + ur * UM_FP + uc), v1 = *(const f32x4*)(Fp + ur * UM_FP + uc + 4);
@@ -465,5 +498,5 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
       *(f32x4*)(a.q_out + (long long)(row0 + tok) * UM_D + c) = v;
     }
   }
+  UMTS(10);
 }
-

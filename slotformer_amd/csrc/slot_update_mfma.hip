@@ -35,21 +35,21 @@ int sf_slot_update_mfma_ex(const float* part_num, const float* part_den, int P, 
                            const void* gru_hh_p, const float* gru_b_ih, const float* gru_b_hh, const float* ln_g, const float* ln_b,
                            const void* w1_p, const float* b1, const void* w2_p, const float* b2, float* slots_out, float* out2,
                            long long out2_bs, const float* q_ln_g, const float* q_ln_b, const void* q_w_p, float* q_out, int B, int N,
-                           float ln_eps, hipStream_t st, const SfNextStep* next) {
+                           float ln_eps, hipStream_t st, const SfNextStep* next, int p_step) {
   SF_REQUIRE(part_num && part_den && slots_prev && slots_out && gru_ih_p && gru_hh_p && gru_b_ih && gru_b_hh && ln_g && ln_b && w1_p &&
                  b1 && w2_p && b2, "sf_slot_update_mfma_ex: null pointer");
   SF_REQUIRE(!next || (q_out && next->pm_ln_g && next->pm_ln_b && next->pm_w0_p && next->pm_b0 && next->pm_w2_p && next->pm_b2 && next->kd_w_p &&
                        next->kd_b && next->slots && next->slots != slots_out),
              "sf_slot_update_mfma_ex: the next-step form needs q_out, the predictor / kernel-distribution operands and its own slot buffer");
   SF_REQUIRE(q_out == nullptr || (q_ln_g && q_ln_b && q_w_p), "q projection requested without its weights");
-  SF_REQUIRE(N >= 1 && P >= 1 && P <= 64, "bad slot shape");
+  SF_REQUIRE(N >= 1 && P >= 1 && P <= 64 && (p_step == 1 || (p_step == 2 && P % 2 == 0)), "bad slot shape");
   if (B == 0) return 0;
   static_assert(UM_LDS_NEXT <= 160 * 1024, "slot update: LDS budget");
   SF_TRY(next ? sf_ensure_dyn_lds((const void*)sa_slot_update_mfma_kernel<true>, (size_t)(UM_LDS_NEXT))
               : sf_ensure_dyn_lds((const void*)sa_slot_update_mfma_kernel<false>, (size_t)(UM_LDS)));
   UmArgs a;
   memset(&a, 0, sizeof(a));
-  a.part_num = part_num; a.part_den = part_den; a.P = P; a.slots_prev = slots_prev;
+  a.part_num = part_num; a.part_den = part_den; a.P = P / p_step; a.pstep = p_step; a.slots_prev = slots_prev;
   a.w_ih_p = (const uint4*)gru_ih_p; a.w_hh_p = (const uint4*)gru_hh_p; a.b_ih = gru_b_ih; a.b_hh = gru_b_hh; a.ln_g = ln_g; a.ln_b = ln_b;
   a.w1_p = (const uint4*)w1_p; a.b1 = b1; a.w2_p = (const uint4*)w2_p; a.b2 = b2; a.slots_out = slots_out; a.out2 = out2; a.out2_bs = out2_bs;
   a.q_ln_g = q_ln_g; a.q_ln_b = q_ln_b; a.q_w_p = (const uint4*)q_w_p; a.q_out = q_out; a.R = B * N; a.N = N; a.ln_eps = ln_eps;
@@ -87,3 +87,10 @@ extern "C" int sf_slot_update_packed_f32(const float* part_num, const float* par
                                 mlp_b1, mlp_w2_packed, mlp_b2, slots_out, nullptr, 0, q_ln_g, q_ln_b, q_w_packed, q_out, B, N, ln_eps,
                                 (hipStream_t)stream);
 }
+
+#ifdef UM_STAMPS
+extern "C" int sf_debug_read_ts_um(long long* out16) {
+  hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(um_ts), sizeof(long long) * 16);
+  return e == hipSuccess ? 0 : (int)e;
+}
+#endif
