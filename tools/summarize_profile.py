@@ -101,10 +101,21 @@ def stats_encode_queue_us(pred):
     return max(avgs) if avgs else None
 
 
+_HAS_WS = None
+
+
 def is_conv(name):  # conv5x5_halo_kernel, or sf_gemm_kernel<..., ALOAD=1 (NHWC im2col), LN, BF3>
+    global _HAS_WS
+    if _HAS_WS is None:
+        f0 = find(f'{tag}_trace', '*kernel_stats.csv')
+        _HAS_WS = bool(f0) and any('conv5x5_ws_kernel' in r['Name'] for r in csv.DictReader(open(f0)))
     if 'conv5x5_rows4_kernel<false, true>' in name:   # the decoder's head-fused stride-1 layer (64 x 64 decode leg): its own class
         return False
-    if 'conv5x5_halo' in name or 'conv5x5_rows4' in name or 'conv5x5_ws' in name:
+    if _HAS_WS:
+        # the pipeline's convolution launches (all time steps of a batch per launch) run the weights-stationary kernel; the 4-row-tile launches of the
+        # same trace are the step-by-step passes of bench.py's untimed two-branch encode (a sixth of the frames per launch): not averaged with them
+        return 'conv5x5_ws_kernel' in name
+    if 'conv5x5_halo' in name or 'conv5x5_rows4' in name:
         return True
     m = re.search(r'sf_gemm_kernel<([^>]*)>', name)
     return bool(m) and m.group(1).replace(' ', '').split(',')[8] == '1'
