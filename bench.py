@@ -496,7 +496,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)  # RCCL
+        # RCCL, its communicator created at the first collective (no device_id): the pipeline's streams get their hardware queues before RCCL's does
+        # (worth 3 % on one rank: pipeline._pick_free_streams)
+        dist.init_process_group('nccl', rank=rank, world_size=world)
 
     from slotformer_amd import engine, _lib
     from slotformer_amd.pipeline import EncodeRolloutPipeline
@@ -549,7 +551,7 @@ def main():
 
         def barrier():
             if use_dist:
-                dist.barrier()
+                dist.barrier(device_ids=[dev.index])
             torch.cuda.synchronize()
 
         shape = (B, T_BURN + T_ROLL, N_SLOTS, SLOT_D)

@@ -542,17 +542,25 @@ class EncodeRolloutPipeline:
             return list(got)
         # (a process that has initialised RCCL already has that one stream in use -- RCCL's: with torch.distributed on the nccl backend
         #  initialised before the pipeline, the bench's multi-GPU path, no parked stream 474 k, one 418 k, two / three 385 / 399 k)
-        rccl = False
+        rccl = pg_nccl = False
         try:
             import torch.distributed as dist
-            rccl = dist.is_available() and dist.is_initialized() and 'nccl' in str(dist.get_backend())
+            rccl = pg_nccl = dist.is_available() and dist.is_initialized() and 'nccl' in str(dist.get_backend())
+            if rccl:
+                # what counts is whether RCCL's communicator -- and with it its stream -- EXISTS yet: a process group initialised without device_id creates it
+                # at its first collective; the pipeline's streams come first then, as in a process without RCCL (bench.py --force-dist, same box:
+                # communicator first 522-537 k frames/s, pipeline first 546-563 k, no process group 558-562 k; profiles/r05_probes.txt section 9)
+                try:
+                    rccl = bool(dist.distributed_c10d._get_default_group()._get_backend(torch.device('cuda', self.dev.index))._is_initialized())
+                except Exception:  # noqa: BLE001
+                    rccl = True
         except Exception:  # noqa: BLE001
             rccl = False
         n_skip = 0 if rccl else 1
         # what was chosen, for the bench line / the logs of every rank (the rule is tuned to this runtime's round-robin over four
         # hardware queues)
-        self.stream_placement = {'parked_streams_before_the_free_ones': n_skip, 'free_streams': n, 'rccl_initialised': bool(rccl),
-                                 'rule': 'rccl: none parked' if rccl else 'one parked',
+        self.stream_placement = {'parked_streams_before_the_free_ones': n_skip, 'free_streams': n, 'rccl_initialised': bool(pg_nccl), 'rccl_communicator_exists': bool(rccl),
+                                 'rule': 'rccl communicator exists: none parked' if rccl else 'one parked',
                                  'rank': int(os.environ.get('RANK', '0')), 'device': self.dev.index}
         if int(os.environ.get('WORLD_SIZE', '1')) > 1:
             import sys
