@@ -160,18 +160,6 @@ __global__ __launch_bounds__(NT) void conv5x5_ws_kernel(CwArgs A) {
         for (int pl = 0; pl < 2; ++pl)
           wt[tap][k][pl] = __builtin_bit_cast(
               bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, (unsigned)(lane * 16), wbase + (unsigned)(tap * 16384 + k * 4096 + pl * 1024), 0));
-#ifdef WS_DBG_W0
-#pragma unroll
-    for (int tap = 0; tap < NTAP; ++tap)
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-          f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          z[0] = __builtin_amdgcn_readfirstlane(A.dbg) > 99 ? 1.f : 0.f;
-          wt[tap][k][pl] = __builtin_bit_cast(bf16x8, z);
-        }
-#endif
   }
 
   // (the "previous row" of the first row is that row itself: its epilogue stores garbage where the row's own epilogue, one row later, stores the
