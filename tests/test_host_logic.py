@@ -225,3 +225,61 @@ def test_slot_file_link_next_to_the_weights(tmp_path):
     assert ln == str(wdir / 'slots.pkl') and os.path.islink(ln) and list(slot_io.load_slots(ln)['train']) == ['v0.mp4']
     assert slot_io.link_slots(str(path), str(weight)) == ln     # replaced, not an error
     assert slot_io.link_slots(str(path), str(weight), subset='Collide').endswith('Collide_slots.pkl')
+
+
+def test_switch_table_and_environment_check():
+    """slotformer_amd/switches.py: at most 15 SF_* variables, each with a kind and a description; check_environment separates the ones that are
+    set from the ones the table does not know (bench.py refuses to run with those)."""
+    from slotformer_amd import switches
+    assert 0 < len(switches.SWITCHES) <= 15
+    assert all(k.startswith('SF_') and kind in ('product', 'tools') and len(text) > 10 for k, (kind, text) in switches.SWITCHES.items())
+    known, unknown = switches.check_environment({'SF_PIPE_HYBRID': '3', 'SF_PIPE_HYBRD': '3', 'PATH': '/bin', 'SF_DBG': 'conv'})
+    assert known == {'SF_PIPE_HYBRID': '3', 'SF_DBG': 'conv'} and unknown == ['SF_PIPE_HYBRD']
+    assert switches.markdown_table().count('\n') == len(switches.SWITCHES) + 1
+    # every variable the Python side reads is in the table
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = set()
+    for rel in ('bench.py', 'slotformer_amd/pipeline.py', 'slotformer_amd/engine.py', 'slotformer_amd/_lib.py', 'slotformer_amd/harness.py', 'slotformer_amd/build.py'):
+        seen |= set(re.findall(r"environ(?:\.get)?[\[(]\s*'(SF_[A-Z0-9_]+)'", open(os.path.join(root, rel)).read()))
+    assert seen and seen <= set(switches.SWITCHES), sorted(seen - set(switches.SWITCHES))
+
+
+def test_capture_gate_orders_captures_and_calls():
+    """_lib.CAPTURE_GATE: calls hold it shared (many at once), a capture holds it exclusive (waits for the calls in flight, keeps new ones out, lets
+    the capturing thread's own calls through)."""
+    import threading
+    import time
+    from slotformer_amd._lib import _CaptureGate
+    gate = _CaptureGate()
+    log, lock = [], threading.Lock()
+
+    def call(tag, hold):
+        held = gate.enter_shared()
+        with lock:
+            log.append(('in', tag))
+        time.sleep(hold)
+        with lock:
+            log.append(('out', tag))
+        if held:
+            gate.exit_shared()
+
+    a = threading.Thread(target=call, args=('a', 0.2))
+    b = threading.Thread(target=call, args=('b', 0.2))
+    a.start(); b.start()
+    time.sleep(0.05)
+    assert [e for e in log if e[0] == 'in'] == [('in', 'a'), ('in', 'b')] or [e for e in log if e[0] == 'in'] == [('in', 'b'), ('in', 'a')]   # shared: both inside
+    with gate:                                   # exclusive: only once both are out
+        assert sorted(e for e in log if e[0] == 'out') == [('out', 'a'), ('out', 'b')]
+        c = threading.Thread(target=call, args=('c', 0.0))
+        c.start()
+        time.sleep(0.1)
+        assert ('in', 'c') not in log            # kept out while the capture lasts
+        assert gate.enter_shared() is False      # the capturing thread's own calls pass (and hold nothing)
+        with gate:                               # re-entrant
+            pass
+        assert ('in', 'c') not in log
+    c.join(2)
+    a.join(); b.join()
+    assert ('out', 'c') in log
