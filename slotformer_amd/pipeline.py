@@ -109,25 +109,31 @@ def encode_group_for(batch, n_batches):
     return 1
 
 
-def tok_unit_batches(rollouter, batch, burn_in=None):
+def tok_unit_batches(rollouter, batch, burn_in=None, n_batches=None):
     """Batches per rollout unit when the layers before the last run as token-stationary launches (csrc/layer_tok.hip): a 128-token workgroup owns
     128 // L whole videos and needs a CU to itself, so a unit should bring 64 workgroups -- two units side by side then fill the 128 CUs of the rollout
     partition without queueing behind each other (C2: 6 batches of 32 videos = 64 workgroups; 592 k frames/s at 60 batches against 528 k with units of
-    4).  None when the rollouter cannot take that form, or the unit would stay below 96 videos (small batches: the latency forms)."""
+    4).  None when the rollouter cannot take that form, or the unit would stay below 96 videos (small batches: the latency forms).  n_batches: pipeline
+    batches of the run, where known -- models of more than four layers take the form in runs of three units or more only."""
     from . import _lib as _l
     if os.environ.get('SF_PIPE_TOK', '1') == '0' or not next(rollouter.parameters()).is_cuda:
         return None
     if not _l.lib().sf_rollout_tok_ok(C.byref(engine.rollouter_plan(rollouter).struct)):
         return None
     # Measured where it pays (profiles/r05_probes.txt): C2 (4 layers, 32 videos per batch) 497 -> 550 k frames/s at 20 batches, 528 -> 580 k at 60.
-    # Not C5 (growing window of the single-step rollouter: 8-token windows leave a 128-token workgroup 16 videos, 80 rollout-bound steps: 450 -> 280 k)
-    # and not C4 at its 16-video batches (8 layers: 259 -> 246 k at 20 batches, 271 -> 283 k at 40): those keep the row-tile units.
-    if hasattr(rollouter, 'cond_len') or len(rollouter.transformer_encoder.layers) > 4 or int(batch) < 24:
+    # Not C5 (growing window of the single-step rollouter: 8-token windows leave a 128-token workgroup 16 videos, 80 rollout-bound steps: 450 -> 280 k).
+    # C4 (8 layers; two 16-video batches per encode): 250 -> 240 k at 20 batches (two units), but 257 -> 299 k at 40 and 262 -> 318 k at 80: the longer
+    # unit (8 layers x 118 us per step) needs a run of three units or more to pay.
+    if hasattr(rollouter, 'cond_len') or int(batch) < 24:
         return None
     hist = getattr(rollouter, 'history_len', burn_in or 1)
     vpw = 128 // max(int(rollouter.num_slots) * int(hist), 1)
     g = max(1, min(8, (64 * vpw) // max(int(batch), 1)))
-    return g if g * int(batch) >= 96 else None
+    if g * int(batch) < 96:
+        return None
+    if len(rollouter.transformer_encoder.layers) > 4 and (n_batches is None or int(n_batches) < 3 * g):
+        return None
+    return g
 
 
 def unit_batches_for(rollouter, batch, n_batches, burn_in=None):
@@ -136,7 +142,7 @@ def unit_batches_for(rollouter, batch, n_batches, burn_in=None):
     C4 (16 videos x 36 tokens = 576 rows per batch) takes 7 -- 63 tiles per launch instead of 36: 231 vs 209 k frames/s at 84 batches,
     227 at 42 -- but only in runs of five units or more: at 20 batches the ragged last unit and the longer drain cost more (170 vs 199 k;
     `profiles/r03_probes.txt` section 18)."""
-    gt = tok_unit_batches(rollouter, batch, burn_in)
+    gt = tok_unit_batches(rollouter, batch, burn_in, n_batches)
     if gt is not None:
         return gt
     hist = getattr(rollouter, 'cond_len', None) or getattr(rollouter, 'history_len', burn_in or 1)
@@ -292,6 +298,12 @@ class EncodeRolloutPipeline:
         # the 128 rollout CUs; drain units and units of fewer batches keep the row-tile / latency forms (a unit alone is faster in them: 14.5 against
         # 20.8 ms for 192 videos) -- whose results differ from the token-stationary ones in the last bits (1e-6 per layer, 5e-6 over 50 steps)
         g_tok = tok_unit_batches(rollouter, self.B, self.T) if (partition == 'pair' and self.fused and tok is not False) else None
+        if g_tok is None and partition == 'pair' and self.fused and tok is not False and (tok or group):
+            # models of more than four layers take the form in long runs only, and the run length is the caller's knowledge: units sized by
+            # unit_batches_for(.., n_batches) for such a run (bench.py, harness.extract_and_rollout), or tok=True, say so
+            g_long = tok_unit_batches(rollouter, self.B, self.T, n_batches=1 << 30)
+            if g_long is not None and (tok or int(group) == g_long):
+                g_tok = g_long
         if tok and g_tok is None:
             raise RuntimeError('slotformer_amd: tok=True needs the pair partition, a rollouter whose layers take the token-stationary form '
                                '(d_model 256, 8 heads, ffn 1024, windows of <= 64 tokens) and units of >= 96 videos')

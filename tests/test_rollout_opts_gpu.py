@@ -154,7 +154,7 @@ def rel_err_elementwise(a, b, floor=1e-3):
 def test_pipeline_unit_forms_vs_reference_fixture(dev, name, cfg, seed, batch, n_batches, H):
     """The kernel forms and the unit size the PIPELINE picks (pipeline.encode_group_for / unit_batches_for / pair_unit_options -- the functions
     bench.py and harness.extract_and_rollout call, not a literal copy of their result) for C4 (16 videos per batch, 20 batches: two units of 160 videos;
-    84 batches: units of 224), C5 (64 videos per batch: units of 256, growing window 8 -> 48 tokens, 1 + 80) and C2 (32 videos per batch: token-stationary units of 192
+    84 batches: token-stationary units of 192 -- eight layers take that form in runs of three units or more), C5 (64 videos per batch: units of 256, growing window 8 -> 48 tokens, 1 + 80) and C2 (32 videos per batch: token-stationary units of 192
     videos) against the REFERENCE's full-horizon fixtures: the fixture video sits at two places of a unit-sized batch of other videos (row tiles cut
     across videos; token-stationary workgroups hold three videos), both copies vs the fixture over the whole horizon."""
     from test_engine_gpu import build
@@ -168,12 +168,12 @@ def test_pipeline_unit_forms_vs_reference_fixture(dev, name, cfg, seed, batch, n
     E = pipeline.encode_group_for(batch, n_batches)                      # batches per encode = per pipeline batch
     Bp, nb = batch * E, n_batches // E
     G = pipeline.unit_batches_for(roll, Bp, nb, T_in) or 4               # pipeline batches per rollout unit (4: the constructor's default)
-    tok = pipeline.tok_unit_batches(roll, Bp, T_in) is not None
+    tok = pipeline.tok_unit_batches(roll, Bp, T_in, nb) is not None
     opts = pipeline.pair_unit_options(roll, Bp, G, 128, tok, T_in)
     videos = G * Bp
     print(name, f'{batch} videos x {n_batches} batches -> {E} per encode, units of {G} x {Bp} = {videos} videos, options {opts}')
-    assert (name, batch, n_batches, videos) in (('roll_c4_full', 16, 20, 160), ('roll_c4_full', 16, 84, 224), ('roll_c5_full', 64, 20, 256), ('roll_c2', 32, 20, 192))
-    assert opts['layer_tok'] == (name == 'roll_c2') and opts['attn_rows'] == 128 and opts['ffn_tile'] == 2
+    assert (name, batch, n_batches, videos) in (('roll_c4_full', 16, 20, 160), ('roll_c4_full', 16, 84, 192), ('roll_c5_full', 64, 20, 256), ('roll_c2', 32, 20, 192))
+    assert opts['layer_tok'] == (name == 'roll_c2' or (batch, n_batches) == (16, 84)) and opts['attn_rows'] == 128 and opts['ffn_tile'] == 2
     fxv = gu.seeded_normal((g['pred_slots'].shape[0], hist + H, N, C), seed + 1)[:, :hist]
     x = gu.seeded_normal((videos, hist, N, C), seed + 60).to(dev)
     at = videos - 28                                                      # (another row tile / another workgroup, another place inside it)
@@ -193,7 +193,8 @@ def test_pipeline_unit_forms_vs_reference_fixture(dev, name, cfg, seed, batch, n
     if opts['layer_tok']:
         # token-stationary launches: a video's last bits depend on its place inside the three-video workgroup (the key blocks its scores are summed
         # over) and differ from the other forms' (one accumulator per output block): rounding level, bounded here over the 50 steps
-        assert rel_err(out[at], out[0]) < 2e-5 and rel_err(out[0], small[0]) < 2e-5
+        tol_forms = 2e-5 if C == 128 else 5e-5   # (slot size 192: eight layers, and the in / out projections on the generic GEMM core)
+        assert rel_err(out[at], out[0]) < tol_forms and rel_err(out[0], small[0]) < tol_forms, (rel_err(out[at], out[0]), rel_err(out[0], small[0]))
         again = _roll(roll, x, H, opts)
         assert torch.equal(again, out)
     else:
