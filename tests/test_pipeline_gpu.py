@@ -207,6 +207,15 @@ def test_unit_batches_for_long_runs(dev):
     # no even split into equal units: the smallest even number of units of <= 8192 rows, the last one shorter (29 batches: 8, 8, 8, 5)
     assert unit_batches_for(roll, 14, 29, T) == 8 and unit_batches_for(roll, 14, 21, T) == 11 and unit_batches_for(roll, 2, 39, T) == 20
     assert unit_batches_for(roll, 14, 9, T) is None   # (short runs keep the default)
+    # a rollouter of more than four layers (C4: eight) takes the token-stationary units in runs of three units or more only, and the pipeline takes the
+    # form when its units were sized for such a run (or tok=True)
+    from slotformer_amd.pipeline import tok_unit_batches, EncodeRolloutPipeline
+    from slotformer_amd.video_prediction.models import SlotRollouter
+    torch.manual_seed(3)
+    deep = SlotRollouter(**gu.C4_ROLL['rollout_dict']).eval().to(dev)
+    assert len(deep.transformer_encoder.layers) == 8
+    assert tok_unit_batches(deep, 32, 6) is None and tok_unit_batches(deep, 32, 6, 10) is None and tok_unit_batches(deep, 32, 6, 18) == 6
+    assert unit_batches_for(deep, 32, 20, 6) == 6 and unit_batches_for(deep, 32, 10, 6) != 6
     from slotformer_amd.pipeline import encode_group_for
     assert [encode_group_for(16, 20), encode_group_for(8, 48), encode_group_for(32, 20), encode_group_for(2, 41), encode_group_for(2, 16)] == [2, 4, 1, 1, 2]
     bs, V = 2, 83      # 41 full batches (units of 8) + 1 video
