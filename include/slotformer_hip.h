@@ -633,6 +633,14 @@ size_t sf_savi_encode_batched_workspace_bytes(const sf_savi_encoder* m, int B, i
  * two agree to split-bf16 rounding (~1e-6 relative), not bit for bit; step 0 of a call always takes the stand-alone launch. */
 int sf_set_encode_fuse_next(int on);
 int sf_get_encode_fuse_next(void);
+/* The slot branch of a batched encode (all T steps' convolutions per launch, sf_savi_encode_batched_workspace_bytes) as ONE video-stationary launch
+ * (csrc/slot_chain.hip; savi.py:76-100, 393-402): one workgroup per video walks the T steps x num_iterations Slot-Attention iterations, their slot
+ * updates and the per-step prologues on feature rows kept as bf16 hi | lo -- 7 launches per encode instead of ~60.  Process default 1 (SF_SLOT_CHAIN=0 or
+ * sf_set_slot_chain(0): the per-iteration launches over the whole batch).  Applies to the CLEVRER shape of the slot branch (slot size 128, slot MLP 256,
+ * residual-MLP predictor, single-Linear kernel distribution, folded Slot Attention, up to 8 slots, HW a multiple of 256); everything else keeps the
+ * per-iteration launches.  The two forms agree to split-bf16 rounding (the attention products are split-bf16 here, exact f32 there). */
+int sf_set_slot_chain(int on);
+int sf_get_slot_chain(void);
 int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const float* feat_pre, int n_pre, const float* noise,
                             const float* prev_slots, float* lstm_h, float* lstm_c, int state_valid, float* post_slots,
                             float* kernel_dist, float* attn, int B, int T, void* ws, size_t ws_bytes, void* stream, void* side_stream);

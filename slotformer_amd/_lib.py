@@ -245,6 +245,8 @@ SIGNATURES = {
     'sf_savi_encode_batched_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I, I]),
     'sf_set_encode_fuse_next': (I, [I]),
     'sf_get_encode_fuse_next': (I, []),
+    'sf_set_slot_chain': (I, [I]),
+    'sf_get_slot_chain': (I, []),
     'sf_savi_encode_fork_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, I, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
                                     VP, VP]),
     'sf_kv_producer_workspace_bytes': (SZ, [I, I]),

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libslotformer_hip.so')
-SOURCES = ['gemm.hip', 'slot_attn.hip', 'slot_update_mfma.hip', 'slot_update_wide.hip', 'pred_step.hip', 'slot_attn_bwd.hip', 'slot_attn_train.hip', 'elementwise.hip', 'attn_fused.hip', 'conv_halo.hip', 'conv_rows4.hip', 'conv_ws.hip', 'deconv_s2.hip', 'conv_first.hip', 'pixel_mlp.hip', 'layer_fused.hip', 'attn_rows.hip', 'ffn_tile.hip', 'layer_tok.hip', 'rollout_train.hip', 'savi_decode_train.hip', 'savi_features_train.hip', 'steve_decoder.hip', 'slate_attn_bwd.hip', 'engine.hip', 'host_twins.hip', 'sf_runtime.cpp']
+SOURCES = ['gemm.hip', 'slot_attn.hip', 'slot_update_mfma.hip', 'slot_update_wide.hip', 'slot_chain.hip', 'pred_step.hip', 'slot_attn_bwd.hip', 'slot_attn_train.hip', 'elementwise.hip', 'attn_fused.hip', 'conv_halo.hip', 'conv_rows4.hip', 'conv_ws.hip', 'deconv_s2.hip', 'conv_first.hip', 'pixel_mlp.hip', 'layer_fused.hip', 'attn_rows.hip', 'ffn_tile.hip', 'layer_tok.hip', 'rollout_train.hip', 'savi_decode_train.hip', 'savi_features_train.hip', 'steve_decoder.hip', 'slate_attn_bwd.hip', 'engine.hip', 'host_twins.hip', 'sf_runtime.cpp']
 # every header of csrc/ (kernel bodies shared between translation units live in headers too: slot_update_body.h, stream_mfma.h) + the public one
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join('..', '..', 'include', 'slotformer_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']

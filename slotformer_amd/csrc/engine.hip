@@ -18,6 +18,7 @@
 #include <map>
 #include <vector>
 #include "layer_fused.h"
+#include "slot_chain.h"
 #include <stdlib.h>
 
 namespace {
@@ -654,6 +655,21 @@ int sf_rollout_bf16(const sf_rollouter* m, float* slots, int B, int T_total, int
 // ---------------------------------------------------------------------------------------------
 static int enc_chunk(int B) { return B < 32 ? B : 32; }
 
+// the slot branch of a batched encode as one video-stationary launch (slot_chain.hip): on by default; sf_set_slot_chain(0) / SF_SLOT_CHAIN=0 keeps the
+// per-iteration launches (Slot-Attention iteration over the batch + slot update)
+static int g_slot_chain = -1;
+int sf_get_slot_chain(void) {
+  if (g_slot_chain < 0) {
+    const char* e = getenv("SF_SLOT_CHAIN");
+    g_slot_chain = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_slot_chain;
+}
+int sf_set_slot_chain(int on) {
+  g_slot_chain = on ? 1 : 0;
+  return 0;
+}
+
 // the slot prologue of step t + 1 at the tail of step t's last slot update (slot_update_mfma.hip, NEXT form): on by default where it applies;
 // sf_set_encode_fuse_next(0): the prologue as its own launch (sa_slot_prologue_kernel) on every step
 static int g_enc_fuse_next = -1;
@@ -680,10 +696,12 @@ size_t sf_savi_encode_fork_workspace_bytes(const sf_savi_encoder* m, int B, int 
 static size_t enc_batched_extra(const sf_savi_encoder* m, int B, int T) {
   int cmax = 0;
   for (int i = 1; i <= m->enc_layers && i < 9; ++i) cmax = m->enc_channels[i] > cmax ? m->enc_channels[i] : cmax;
-  return 3 * pad256((size_t)B * T * 64 * 64 * cmax);
+  // + the Slot-Attention inputs of all B * T frames as bf16 hi | lo rows of 512 B (the video-stationary slot branch, slot_chain.hip)
+  return 3 * pad256((size_t)B * T * 64 * 64 * cmax) + pad256((size_t)B * T * 64 * 64 * 128);
 }
 static bool enc_batched_ok(const sf_savi_encoder* m, int B, int T) {
-  if (!m || T < 2 || B > enc_chunk(B) || m->enc_layers < 2 || sf_get_precision() != 1) return false;
+  // (at most 384 frames per call: 1.2 GB of activations + 0.8 GB of feature rows; longer clips keep the per-step order)
+  if (!m || T < 2 || B > enc_chunk(B) || (long long)B * T > 384 || m->enc_layers < 2 || sf_get_precision() != 1) return false;
   for (int i = 1; i < m->enc_layers; ++i)
     if (!m->conv_w_frag[i] || m->enc_channels[i] != 64 || m->enc_channels[i + 1] != 64) return false;
   return true;
@@ -887,8 +905,10 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
   // all T steps' convolutions as one launch per layer (sf_savi_encode_batched_workspace_bytes): when the caller brought the room for it
   float* big[3] = {nullptr, nullptr, nullptr};
   const bool batched = !fork && n_pre == 0 && enc_batched_ok(m, B, T) && ws_bytes >= enc_ws_bytes(m, B, KV) + enc_batched_extra(m, B, T);
+  float* planes = nullptr;
   if (batched) {
     for (int i = 0; i < 3; ++i) big[i] = bp.take((size_t)B * T * HW * cmax);
+    planes = bp.take((size_t)B * T * HW * 128);
     if (!bp.ok) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
   }
 
@@ -940,6 +960,25 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
       SF_TRY(sf_conv2d_nchw_in_f32(img + (long long)t * frame_elems0, (long long)T * frame_elems0, m->conv_w[0], m->conv_b[0], nullptr,
                                    big[0] + (long long)t * B * HW * c1, B, m->enc_channels[0], res, res, c1, m->enc_ks, res == 128 ? 2 : 1, 1, st_main));
     SF_TRY(run_cnn_layers(m, nullptr, 0, B * T, big[2], big[0], big[1], 1, m->enc_layers, st_main));
+    // ---- the slot branch of all T steps as ONE video-stationary launch (slot_chain.hip): the per-pixel chain of the B * T frames in one launch
+    //      (feature rows as bf16 hi | lo), the prologue of step 0, then one workgroup per video ----
+    if (sf_get_slot_chain() && fold && !feat192 && can_fuse_next && su_mfma && sf_slot_chain_ok(D, Hm, HW, N) && m->enc_channels[m->enc_layers] == 64) {
+      SF_TRY(sf_pixel_mlp_feat_planes_ex(big[2], m->enc_ln_g, m->enc_ln_b, m->enc_fc1_w, m->enc_fc1_b, m->enc_fc2_w, m->enc_fc2_b, m->sa_norm_in_g,
+                                         m->sa_norm_in_b, planes, B * T * HW, ln_eps, st_main));
+      const int pr = sf_slot_prologue_ex(prev, m->init_latents, m->pm_ln_g, m->pm_ln_b, m->pm_w0_t, m->pm_b0, m->pm_w2_t, m->pm_b2, m->pred_norm_first,
+                                         m->kd_w0_t, m->kd_b0, noise, (long long)T * N * D, kernel_dist, (long long)T * N * 2 * D, m->sa_q_ln_g,
+                                         m->sa_q_ln_b, q_w_t, slotsA, q, B, N, D, ln_eps, st_main);
+      if (pr < 0 || pr > 1) return pr;
+      if (pr == 0) {
+        SfChainWeights cw;
+        cw.gru_ih_p = gru_ih_p; cw.gru_hh_p = m->sa_gru_hh_p; cw.gru_b_ih = m->gru_b_ih; cw.gru_b_hh = m->gru_b_hh; cw.ln_g = m->mlp_ln_g; cw.ln_b = m->mlp_ln_b;
+        cw.w1_p = m->sa_mlp_w1_p; cw.b1 = m->mlp_b1; cw.w2_p = m->sa_mlp_w2_p; cw.b2 = m->mlp_b2; cw.q_ln_g = m->sa_q_ln_g; cw.q_ln_b = m->sa_q_ln_b; cw.q_w_p = q_w_p;
+        cw.pm_ln_g = m->pm_ln_g; cw.pm_ln_b = m->pm_ln_b; cw.pm_w0_p = m->pm_w0_p; cw.pm_b0 = m->pm_b0; cw.pm_w2_p = m->pm_w2_p; cw.pm_b2 = m->pm_b2;
+        cw.pm_norm_first = m->pred_norm_first; cw.kd_w_p = m->kd_w0_p; cw.kd_b = m->kd_b0;
+        return sf_slot_chain_ex(planes, B, T, HW, N, m->num_iterations, 1.0f / sqrtf((float)D), m->sa_eps, ln_eps, slotsA, slotsB, latents, q, pnum, pden,
+                                post_slots, attn, noise, kernel_dist, &cw, st_main);
+      }
+    }
   }
   for (int t = 0; t < T; ++t) {
     float* kv = kv_base + (size_t)(t % KV) * kv_step;

@@ -10,6 +10,7 @@
 //
 // 8 waves: wave w owns rows 32*(w>>1) .. +31 and columns 64*(w&1) .. +63 of every 128-wide output (2 accumulators).
 #include "sf_internal.h"
+#include "slot_chain.h"
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -449,7 +450,7 @@ template <int TR> struct PfCfg {
 };
 }  // namespace
 
-template <int TR>
+template <int TR, bool PLANES = false>
 __global__ __launch_bounds__(PfCfg<TR>::NT) void pixel_feat_stream_kernel(
     const float* __restrict__ x, const float* __restrict__ ln0_g, const float* __restrict__ ln0_b, const float* __restrict__ w1,
     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ ln1_g,
@@ -619,24 +620,36 @@ __global__ __launch_bounds__(PfCfg<TR>::NT) void pixel_feat_stream_kernel(
       for (int i = 0; i < 8; ++i) {
         const int c = part * 32 + 4 * i;
         const f32x4 g = *(const f32x4*)(PV + 2 * PM_C1 + c), be = *(const f32x4*)(PV + 3 * PM_C1 + c);
-        if (grow < M) *(f32x4*)(feat + (long long)grow * PM_C1 + c) = (hv[i] - mean) * rstd * g + be;
+        const f32x4 y = (hv[i] - mean) * rstd * g + be;
+        if constexpr (PLANES) {
+          // rows of 512 B: bf16 hi of the 128 channels | bf16 lo (what slot_chain.hip streams: no split inside its pixel loop)
+          bf16x4 hi, lo;
+          split4(y, hi, lo);
+          if (grow < M) {
+            __bf16* pr = (__bf16*)feat + (long long)grow * (2 * PM_C1);
+            *(bf16x4*)(pr + c) = hi;
+            *(bf16x4*)(pr + PM_C1 + c) = lo;
+          }
+        } else {
+          if (grow < M) *(f32x4*)(feat + (long long)grow * PM_C1 + c) = y;
+        }
       }
     }
     __syncthreads();   // the f32 tile is read: the next tile's hidden planes may be written (its A planes are complete)
   }
 }
 
-template <int TR>
+template <int TR, bool PLANES = false>
 static int sf_pixel_feat_stream_launch_t(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
                                          const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st) {
   using Cfg = PfCfg<TR>;
   static_assert(Cfg::LDS <= 160 * 1024, "LDS budget");
-  SF_TRY(sf_ensure_dyn_lds((const void*)pixel_feat_stream_kernel<TR>, Cfg::LDS));
+  SF_TRY(sf_ensure_dyn_lds((const void*)pixel_feat_stream_kernel<TR, PLANES>, Cfg::LDS));
   const int ntiles = (M + TR - 1) / TR;
   sf_prof_begin(SF_K_LINEAR, st, 2.0 * M * (double)(PM_C0 * PM_C1 + PM_C1 * PM_C1));
   constexpr int env_pix = 0;
   const int tpw = env_pix >= TR ? env_pix / TR : Cfg::TPW;
-  hipLaunchKernelGGL(pixel_feat_stream_kernel<TR>, dim3((ntiles + tpw - 1) / tpw), dim3(Cfg::NT), Cfg::LDS, st, x, ln0_g, ln0_b, w1, b1,
+  hipLaunchKernelGGL((pixel_feat_stream_kernel<TR, PLANES>), dim3((ntiles + tpw - 1) / tpw), dim3(Cfg::NT), Cfg::LDS, st, x, ln0_g, ln0_b, w1, b1,
                      w2, b2, ln1_g, ln1_b, feat, M, eps, tpw);
   sf_prof_end(SF_K_LINEAR, st);
   SF_CHECK_LAUNCH();
@@ -650,6 +663,12 @@ static int sf_pixel_feat_stream_launch(const float* x, const float* ln0_g, const
   if (tile == 0) tile = 64;
   if (tile == 64) return sf_pixel_feat_stream_launch_t<64>(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st);
   return sf_pixel_feat_stream_launch_t<128>(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st);
+}
+
+// the same with the result as bf16 hi | lo rows of 512 B (slot_chain.h): the Slot-Attention inputs of the video-stationary slot branch
+int sf_pixel_mlp_feat_planes_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
+                                const float* b2, const float* ln1_g, const float* ln1_b, void* planes, int M, float eps, hipStream_t st) {
+  return sf_pixel_feat_stream_launch_t<64, true>(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, (float*)planes, M, eps, st);
 }
 
 // Kernel-level entry point (include/slotformer_hip.h): feat [M][128] = LN(128)(fc2(relu(fc1(LN(64)(x))))) -- encoder_out_layer followed by

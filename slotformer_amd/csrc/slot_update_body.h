@@ -44,8 +44,11 @@ __device__ __forceinline__ float um_sigmoid(float x) { return __frcp_rn(1.0f + _
 __device__ __forceinline__ float um_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
 
 // fragment (ks, nb, plane) of a packed [N][K] matrix (pack_linear_kernel, layer_fused.hip): 64 lanes x 16 B
+// (an explicitly GLOBAL load: where the body runs inside a non-inlined function -- slot_chain.hip -- the pointer is generic, and a flat load counts on
+//  lgkmcnt as well: every LDS wait of the update would wait for the weight stream)
 __device__ __forceinline__ bf16x8 um_frag(const uint4* p, int nblocks, int nb, int ks, int pl, int lane) {
-  return __builtin_bit_cast(bf16x8, p[((long long)(ks * nblocks + nb) * 2 + pl) * 64 + lane]);
+  typedef const uint4 __attribute__((address_space(1))) * gptr;
+  return __builtin_bit_cast(bf16x8, ((gptr)p)[((long long)(ks * nblocks + nb) * 2 + pl) * 64 + lane]);
 }
 
 template <int NKS>
@@ -124,8 +127,28 @@ static_assert((size_t)UM_ROWS * UM_KP * 4 <= (size_t)2 * UM_ROWS * UM_HP * 2, "k
 
 // The whole slot update of rows 32 * block .. + 31 by one 512-thread workgroup; um_lds: UM_LDS bytes of dynamic LDS.  A device function so that
 // the workgroups can also ride as extra blocks of another launch (conv_rows4.hip: conv5x5_rows4_update_kernel).
-template <bool NEXT = false>
-__device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const int block) {
+// what differs between the rows a workgroup may be given: the stand-alone kernels take them from UmArgs (um_body below); the video-stationary slot chain
+// (slot_chain.hip) passes its video's rows -- the weights and vectors then stay where the launch put them (kernel arguments: scalar loads at the point of
+// use, not forty live registers)
+// explicitly GLOBAL accesses (see um_frag): G4 = f32x4 load / store target, GF = float load
+#define UM_G4(p) (*(f32x4 __attribute__((address_space(1)))*)(float __attribute__((address_space(1)))*)(p))
+#define UM_CG4(p) (*(const f32x4 __attribute__((address_space(1)))*)(const float __attribute__((address_space(1)))*)(p))
+#define UM_CGF(p) (*(const float __attribute__((address_space(1)))*)(p))
+struct UmVar {
+  const float *part_num, *part_den;
+  int P, pstep;
+  const float* slots_prev;
+  float *slots_out, *out2, *q_out;
+  const float* noise;
+  float *kdist_out, *nx_slots;
+  int R;
+};
+
+// ArgsT / VarT: UmArgs / UmVar, or their LDS-resident forms (address space 3) when the body runs inside a non-inlined function
+template <bool NEXT = false, class ArgsT = UmArgs, class VarT = UmVar>
+__device__ __forceinline__ void um_rows(const ArgsT& a, const VarT& rv, float* um_lds_generic, const int block) {
+  // (generic -> LDS -> generic: inside a non-inlined function the address-space inference then still makes every access below a DS instruction)
+  float* um_lds = (float*)(float __attribute__((address_space(3)))*)um_lds_generic;
   __bf16* Uh = (__bf16*)um_lds;                    // [32][DP]  updates
   __bf16* Ul = Uh + UM_ROWS * UM_DP;
   __bf16* Xh = Ul + UM_ROWS * UM_DP;               // [32][DP]  previous slots, later LN(h'), later LN_q(x)
@@ -150,44 +173,44 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
   for (int i = 0; i < 4; ++i) {
     const int idx = t + UM_NT * i, r = idx >> 6, p = idx & 63, row = row0 + r;
     dnv[i] = 0.f;
-    if (row < a.R && p < a.P) {
+    if (row < rv.R && p < rv.P) {
       const int b = row / a.N, n = row - b * a.N;
-      dnv[i] = a.part_den[((long long)b * a.P * a.pstep + (long long)p * a.pstep) * a.N + n];
+      dnv[i] = rv.part_den[((long long)b * rv.P * rv.pstep + (long long)p * rv.pstep) * a.N + n];
     }
   }
   const int ur = t >> 4, uc = (t & 15) * 8;   // thread = (row, 8 features)
-  const bool rok = row0 + ur < a.R;
-  const int urow = min(row0 + ur, a.R - 1), ub = urow / a.N, un = urow - ub * a.N;
-  const float* pn = a.part_num + ((long long)ub * a.P * a.pstep * a.N + un) * UM_D + uc;
-  const long long pst = (long long)a.pstep * a.N * UM_D;   // floats between two records read
+  const bool rok = row0 + ur < rv.R;
+  const int urow = min(row0 + ur, rv.R - 1), ub = urow / a.N, un = urow - ub * a.N;
+  const float* pn = rv.part_num + ((long long)ub * rv.P * rv.pstep * a.N + un) * UM_D + uc;
+  const long long pst = (long long)rv.pstep * a.N * UM_D;   // floats between two records read
   f32x4 pa[8][2];   // 8 partial records in flight at a time
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
-    const int pc = min(p, a.P - 1);
+    const int pc = min(p, rv.P - 1);
     pa[p][0] = *(const f32x4*)(pn + pc * pst);
     pa[p][1] = *(const f32x4*)(pn + pc * pst + 4);
   }
-  const f32x4 h0 = *(const f32x4*)(a.slots_prev + (long long)urow * UM_D + uc), h1 = *(const f32x4*)(a.slots_prev + (long long)urow * UM_D + uc + 4);
+  const f32x4 h0 = UM_CG4(rv.slots_prev + (long long)urow * UM_D + uc), h1 = UM_CG4(rv.slots_prev + (long long)urow * UM_D + uc + 4);
   constexpr int NPV = NEXT ? 5 : 4;
   float pvv[NPV];
 #pragma unroll
   for (int i = 0; i < NPV; ++i) {
     const int j = t + UM_NT * i;   // UM_NV = 1664 <= 4 * 512; NEXT: 2560 = 5 * 512
     float v = 0.f;
-    if (j < UV_BHH) v = a.b_ih[j];
-    else if (j < UV_LNG) v = a.b_hh[j - UV_BHH];
-    else if (j < UV_LNB) v = a.ln_g[j - UV_LNG];
-    else if (j < UV_B1) v = a.ln_b[j - UV_LNB];
-    else if (j < UV_B2) v = a.b1[j - UV_B1];
-    else if (j < UV_QG) v = a.b2[j - UV_B2];
-    else if (j < UV_QB) v = a.q_out ? a.q_ln_g[j - UV_QG] : 0.f;
-    else if (j < UM_NV) v = a.q_out ? a.q_ln_b[j - UV_QB] : 0.f;
+    if (j < UV_BHH) v = UM_CGF(a.b_ih + (j));
+    else if (j < UV_LNG) v = UM_CGF(a.b_hh + (j - UV_BHH));
+    else if (j < UV_LNB) v = UM_CGF(a.ln_g + (j - UV_LNG));
+    else if (j < UV_B1) v = UM_CGF(a.ln_b + (j - UV_LNB));
+    else if (j < UV_B2) v = UM_CGF(a.b1 + (j - UV_B1));
+    else if (j < UV_QG) v = UM_CGF(a.b2 + (j - UV_B2));
+    else if (j < UV_QB) v = rv.q_out ? UM_CGF(a.q_ln_g + (j - UV_QG)) : 0.f;
+    else if (j < UM_NV) v = rv.q_out ? UM_CGF(a.q_ln_b + (j - UV_QB)) : 0.f;
     else if constexpr (NEXT) {
-      if (j < UV_PBT) v = a.pm_ln_g[j - UV_PG];
-      else if (j < UV_PB0) v = a.pm_ln_b[j - UV_PBT];
-      else if (j < UV_PB2) v = a.pm_b0[j - UV_PB0];
-      else if (j < UV_KB) v = a.pm_b2[j - UV_PB2];
-      else v = a.kd_b[j - UV_KB];
+      if (j < UV_PBT) v = UM_CGF(a.pm_ln_g + (j - UV_PG));
+      else if (j < UV_PB0) v = UM_CGF(a.pm_ln_b + (j - UV_PBT));
+      else if (j < UV_PB2) v = UM_CGF(a.pm_b0 + (j - UV_PB0));
+      else if (j < UV_KB) v = UM_CGF(a.pm_b2 + (j - UV_PB2));
+      else v = UM_CGF(a.kd_b + (j - UV_KB));
     }
     pvv[i] = v;
   }
@@ -204,27 +227,27 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
   f32x4 n0 = {0.f, 0.f, 0.f, 0.f}, n1 = n0;
 #pragma unroll
   for (int p = 0; p < 8; ++p)
-    if (p < a.P) {
+    if (p < rv.P) {
       n0 += pa[p][0];
       n1 += pa[p][1];
     }
-  if (a.P > 8) {   // (a second round of requests only when there are more than eight records to read)
+  if (rv.P > 8) {   // (a second round of requests only when there are more than eight records to read)
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      const int pc = min(8 + p, a.P - 1);
+      const int pc = min(8 + p, rv.P - 1);
       pa[p][0] = *(const f32x4*)(pn + pc * pst);
       pa[p][1] = *(const f32x4*)(pn + pc * pst + 4);
     }
   }
   um_load(fb, a.w_hh_p, 12, half * 4 + cb, 0, lane);
-  if (a.P > 8) {
+  if (rv.P > 8) {
 #pragma unroll
     for (int p = 0; p < 8; ++p)
-      if (8 + p < a.P) {
+      if (8 + p < rv.P) {
         n0 += pa[p][0];
         n1 += pa[p][1];
       }
-    for (int p = 16; p < a.P; ++p) {
+    for (int p = 16; p < rv.P; ++p) {
       n0 += *(const f32x4*)(pn + p * pst);
       n1 += *(const f32x4*)(pn + p * pst + 4);
     }
@@ -234,7 +257,7 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
   UMTS(2);
   {
     float den = 0.f;
-    for (int p = 0; p < a.P; ++p) den += DN[ur * 64 + p];
+    for (int p = 0; p < rv.P; ++p) den += DN[ur * 64 + p];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     um_split4(Uh, Ul, ur * UM_DP + uc, rok ? n0 / den : zero4);
     um_split4(Uh, Ul, ur * UM_DP + uc + 4, rok ? n1 / den : zero4);
@@ -336,7 +359,7 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
   UMTS(7);
   // ---- x = h' + W2 hidden + b2: wave = (block, K half), halves meet in LDS ----
   UmFrags<4> fq;
-  if (a.q_out) um_load(fq, a.q_w_p, 4, cb, half * 4, lane);
+  if (rv.q_out) um_load(fq, a.q_w_p, 4, cb, half * 4, lane);
   if constexpr (NEXT) um_load(fp0, a.pm_w0_p, 8, wave, 0, lane);   // (fm is dead: three fragment sets live at a time)
 #pragma unroll
   for (int r = 0; r < 16; ++r) g2[r] = 0.f;
@@ -349,7 +372,7 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
   __syncthreads();
   if (half == 0) {
     const int row = row0 + tok;
-    const int b = min(row, a.R - 1) / a.N, n = min(row, a.R - 1) - b * a.N;
+    const int b = min(row, rv.R - 1) / a.N, n = min(row, rv.R - 1) - b * a.N;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int c = 32 * cb + 8 * g + 4 * kg;
@@ -357,25 +380,25 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
       f32x4 v;
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = hn[q] + (g2[4 * g + q] + EX[(cb * 2 * 16 + 4 * g + q) * 64 + lane]) + bb[q];
-      if (row < a.R) {
-        *(f32x4*)(a.slots_out + (long long)row * UM_D + c) = v;
-        if (a.out2) *(f32x4*)(a.out2 + (long long)b * a.out2_bs + (long long)n * UM_D + c) = v;
+      if (row < rv.R) {
+        UM_G4(rv.slots_out + (long long)row * UM_D + c) = v;
+        if (rv.out2) UM_G4(rv.out2 + (long long)b * a.out2_bs + (long long)n * UM_D + c) = v;
       }
       *(f32x4*)(Fp + tok * UM_FP + c) = v;   // (Fp is dead: the finished rows for the q projection)
     }
   }
   UMTS(8);
-  if (a.q_out == nullptr) return;
+  if (rv.q_out == nullptr) return;
   __syncthreads();
 
   if constexpr (NEXT) {
     // ===== the slot prologue of the NEXT time step on the finished rows (rows are independent: no other workgroup is involved) =====
     // noise of this thread's 8 features, requested now
     f32x4 nz0 = {0.f, 0.f, 0.f, 0.f}, nz1 = nz0;
-    if (a.noise && rok) {
-      const float* np = a.noise + (long long)ub * a.noise_bs + (long long)un * UM_D + uc;
-      nz0 = *(const f32x4*)np;
-      nz1 = *(const f32x4*)(np + 4);
+    if (rv.noise && rok) {
+      const float* np = rv.noise + (long long)ub * a.noise_bs + (long long)un * UM_D + uc;
+      nz0 = UM_CG4(np);
+      nz1 = UM_CG4(np + 4);
     }
     // ---- LN_p(x) -> X planes; the residual rows (LN_p(x) if norm_first, else x) -> Fn ----
     {
@@ -435,14 +458,14 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
     um_gemm(g1, fk, Xh, Xl, UM_DP, 0, lane);
     {
       const int row = row0 + tok;
-      const int b = min(row, a.R - 1) / a.N, n = min(row, a.R - 1) - b * a.N;
+      const int b = min(row, rv.R - 1) / a.N, n = min(row, rv.R - 1) - b * a.N;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int c = 32 * wave + 8 * g + 4 * kg;
         const f32x4 bb = *(const f32x4*)(PV + UV_KB + c);
         const f32x4 v = {g1[4 * g] + bb[0], g1[4 * g + 1] + bb[1], g1[4 * g + 2] + bb[2], g1[4 * g + 3] + bb[3]};
         *(f32x4*)(KD + tok * UM_KP + c) = v;
-        if (a.kdist_out && row < a.R) *(f32x4*)(a.kdist_out + (long long)b * a.kdist_bs + (long long)n * 2 * UM_D + c) = v;
+        if (rv.kdist_out && row < rv.R) UM_G4(rv.kdist_out + (long long)b * a.kdist_bs + (long long)n * 2 * UM_D + c) = v;
       }
     }
     __syncthreads();
@@ -451,7 +474,7 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
       const f32x4 m0 = *(const f32x4*)(KD + ur * UM_KP + uc), m1 = *(const f32x4*)(KD + ur * UM_KP + uc + 4);
       const f32x4 l0 = *(const f32x4*)(KD + ur * UM_KP + UM_D + uc), l1 = *(const f32x4*)(KD + ur * UM_KP + UM_D + uc + 4);
       f32x4 v0 = m0, v1 = m1;
-      if (a.noise) {
+      if (rv.noise) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           v0[q] += nz0[q] * expf(l0[q] * 0.5f);
@@ -461,8 +484,8 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
       *(f32x4*)(Fp + ur * UM_FP + uc) = v0;
       *(f32x4*)(Fp + ur * UM_FP + uc + 4) = v1;
       if (rok) {
-        *(f32x4*)(a.nx_slots + (long long)urow * UM_D + uc) = v0;
-        *(f32x4*)(a.nx_slots + (long long)urow * UM_D + uc + 4) = v1;
+        UM_G4(rv.nx_slots + (long long)urow * UM_D + uc) = v0;
+        UM_G4(rv.nx_slots + (long long)urow * UM_D + uc + 4) = v1;
       }
     }
   }
@@ -488,15 +511,22 @@ __device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const in
     for (int r = 0; r < 16; ++r) EX[((cb * 2 + 1) * 16 + r) * 64 + lane] = g1[r];
   }
   __syncthreads();
-  if (half == 0 && row0 + tok < a.R) {
+  if (half == 0 && row0 + tok < rv.R) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int c = 32 * cb + 8 * g + 4 * kg;
       f32x4 v;
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = g1[4 * g + q] + EX[((cb * 2 + 1) * 16 + 4 * g + q) * 64 + lane];
-      *(f32x4*)(a.q_out + (long long)(row0 + tok) * UM_D + c) = v;
+      *(f32x4*)(rv.q_out + (long long)(row0 + tok) * UM_D + c) = v;
     }
   }
   UMTS(10);
+}
+
+// the rows 32 * block .. + 31 of the launch's arguments
+template <bool NEXT = false>
+__device__ __forceinline__ void um_body(const UmArgs& a, float* um_lds, const int block) {
+  const UmVar rv{a.part_num, a.part_den, a.P, a.pstep, a.slots_prev, a.slots_out, a.out2, a.q_out, a.noise, a.kdist_out, a.nx_slots, a.R};
+  um_rows<NEXT>(a, rv, um_lds, block);
 }

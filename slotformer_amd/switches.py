@@ -1,4 +1,4 @@
-"""Every SF_* environment variable the library, the pipeline and bench.py read, with what it does (fourteen; the round-4 tree had seventy).  bench.py
+"""Every SF_* environment variable the library, the pipeline and bench.py read, with what it does (sixteen; the round-4 tree had seventy).  bench.py
 refuses to run with an SF_* variable that is not in this table and prints the ones that are set in `config.switches` of its line; INTEGRATION.md
 section 5 is generated from it (python -m slotformer_amd.switches).  Everything else that used to be an environment probe is either gone with the form
 it selected (measured dead: profiles/r02..r05_probes.txt) or a keyword argument / command-line flag of the object it belongs to
@@ -12,6 +12,7 @@ SWITCHES = {
     'SF_SEAM_FUSED': ('product', "process default of the seam launches of the latency forms (1; 0: two launches instead)"),
     'SF_CONV_FP16X2': ('product', "OPT-IN two-product fp16 form of the 5x5 convolutions (weights rounded to fp16: 3-6e-5 from the fixtures instead of 1e-5); default 0"),
     'SF_CONV_WS': ('product', "0: the 4-row-tile convolution everywhere (default 1: the weights-stationary kernel on streams with CUs of their own; the same bits)"),
+    'SF_SLOT_CHAIN': ('product', "0: the slot branch of a batched encode as per-iteration launches over the batch (default 1: one video-stationary launch, csrc/slot_chain.hip)"),
     'SF_ENCODE_FORK': ('product', "direct encode calls as two branches on two streams (1, default) or one stream (0)"),
     # ---- the batch pipeline ----
     'SF_PIPE_TOK': ('product', "0: the pipeline never uses the token-stationary layer launches (every unit bit-identical to the serial module calls)"),

@@ -17,6 +17,22 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max()).item()
 
 
+class slot_chain:
+    """with slot_chain(0): the slot branch of batched encodes as per-iteration launches (the forms whose bit identity the older tests pin)"""
+
+    def __init__(self, on):
+        self.on = int(on)
+
+    def __enter__(self):
+        from slotformer_amd import _lib
+        self.lib = _lib.lib()
+        self.old = self.lib.sf_get_slot_chain()
+        self.lib.sf_set_slot_chain(self.on)
+
+    def __exit__(self, *exc):
+        self.lib.sf_set_slot_chain(self.old)
+
+
 def elementwise_close(a, b, rtol=RTOL, floor=1e-4):
     """north star's 1e-3 rel, element by element in the allclose form: |a - b| <= rtol |b| + floor max|b| (slots cross zero: an absolute floor)"""
     a, b = a.detach().cpu().double(), torch.as_tensor(b).double()
@@ -614,6 +630,11 @@ def test_folded_slot_attention_at_width_192_matches_the_kv_path(dev):
 @pytest.mark.parametrize('name', ['C2', 'C5', 'C4'])
 @torch.no_grad()
 def test_forked_encode_is_bit_identical(dev, name):
+    with slot_chain(0):   # (the per-iteration forms: the video-stationary slot branch has its own test below)
+        _forked_encode_is_bit_identical(dev, name)
+
+
+def _forked_encode_is_bit_identical(dev, name):
     """engine.savi_encode(side_stream=...) = sf_savi_encode_fork_f32: the image features of all time steps on the calling stream, the slot
     branches one step behind on a second stream (events) -- the same kernels with the same arguments: the same bits as the one-stream
     encode, eager and captured into a hipGraph (two parallel branches), with injected kernel noise (C2), the predictor's LSTM state (C5)
@@ -669,6 +690,11 @@ def test_forked_encode_is_bit_identical(dev, name):
 
 @torch.no_grad()
 def test_next_step_prologue_at_the_tail_of_the_slot_update(dev):
+    with slot_chain(0):   # (the per-iteration forms: the video-stationary slot branch has its own test below)
+        _next_step_prologue_at_the_tail_of_the_slot_update(dev)
+
+
+def _next_step_prologue_at_the_tail_of_the_slot_update(dev):
     """sf_set_encode_fuse_next: the slot prologue of step t + 1 (ResidualMLPPredictor, kernel_dist, sampling, first q; savi.py:393-402) as the tail of
     step t's last matrix-core slot update (1, the default) against the stand-alone launch on every step (0: fp32 thread-per-output products).  The two
     differ by split-bf16 rounding only; both stay inside the fixture tolerance (test_savi_golden runs the default).  B = 1 / 5 / 32 (ragged last
@@ -705,6 +731,11 @@ def test_next_step_prologue_at_the_tail_of_the_slot_update(dev):
 @pytest.mark.parametrize('name', ['C2', 'C5'])
 @torch.no_grad()
 def test_batched_encode_is_bit_identical(dev, name):
+    with slot_chain(0):   # (the per-iteration forms: the video-stationary slot branch has its own test below)
+        _batched_encode_is_bit_identical(dev, name)
+
+
+def _batched_encode_is_bit_identical(dev, name):
     """The one-stream encode runs the 64 -> 64 convolutions of ALL time steps as one launch per layer (csrc/engine.hip, batched form; the
     weights-stationary kernel on a CU-masked stream) -- against the step-by-step orders (two-branch form on a second stream; precomputed features of
     the first steps): the same bits, with injected kernel noise (C2), the Transformer + LSTM predictor (C5 shapes at T = 4), STEVE-style attention
@@ -741,3 +772,45 @@ def test_batched_encode_is_bit_identical(dev, name):
         for mode in ('batched_masked', 'two_branches', 'feat_pre'):
             for a, b in zip(outs['batched'], outs[mode]):
                 assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), (name, B, T, mode)
+
+
+@torch.no_grad()
+def test_slot_chain_matches_the_per_iteration_launches(dev):
+    """The slot branch of a batched encode as ONE video-stationary launch (csrc/slot_chain.hip: sf_set_slot_chain(1), the default) against the per-iteration
+    launches over the batch (0): Slot Attention as split-bf16 products on feature rows kept as bf16 hi | lo there, exact-f32 products on f32 rows
+    here -- split-bf16 rounding apart (both inside the fixture tolerance: test_savi_golden runs the default).  B = 1 / 5 / 32, T = 2 .. 6, injected
+    noise, carried state (prev_slots: the chunked encode), post slots / kernel distribution / attention maps compared; plain and CU-masked streams."""
+    import ctypes as C
+    from slotformer_amd import engine, _lib
+    from slotformer_amd.base_slots import build_model
+    lib = _lib.lib()
+    cfg = gu.C2_SAVI
+    torch.manual_seed(47)
+    m = build_model(gu.ParamsView(cfg)).eval().to(dev)
+    m.testing = True
+    N, D = cfg['slot_dict']['num_slots'], cfg['slot_dict']['slot_size']
+    h = C.c_void_p()
+    _lib.check(lib.sf_stream_create_cu_mask(C.byref(h), (C.c_uint * 8)(*([0xffffffff] * 3 + [0] * 5)), 8))
+    masked = torch.cuda.ExternalStream(h.value, device=dev)
+    for B, T, with_noise in ((5, 4, True), (1, 6, True), (32, 2, False), (3, 3, True)):
+        img = gu.seeded_img(B, T, 128, seed=131 + B).to(dev)
+        noise = engine.kernel_noise(m, gu.seeded_normal((B, T, N, D), 132).to(dev), B, T, dev) if with_noise else torch.zeros(B, T, N, D, device=dev)
+        prev = gu.seeded_normal((B, N, D), 133).to(dev) if B == 3 else None
+        outs = {}
+        for mode in (0, 1, 'masked'):
+            with slot_chain(0 if mode == 0 else 1):
+                if mode == 'masked':
+                    with torch.cuda.stream(masked):
+                        outs[mode] = engine.savi_encode(m, img, noise=noise, want_attn=True, ws_slot=('sc', str(mode)), side_stream=None, prev_slots=prev)
+                else:
+                    outs[mode] = engine.savi_encode(m, img, noise=noise, want_attn=True, ws_slot=('sc', str(mode)), side_stream=None, prev_slots=prev)
+                torch.cuda.synchronize()
+        post0, kd0, at0 = outs[0]
+        post1, kd1, at1 = outs[1]
+        assert not torch.equal(post0, post1), 'the two settings ran the same kernels'
+        e = (rel_err(post1, post0.cpu()), rel_err(kd1, kd0.cpu()), rel_err(at1, at0.cpu()))
+        print(f'slot chain vs per-iteration launches B={B} T={T}: post {e[0]:.2e} kdist {e[1]:.2e} attn {e[2]:.2e}')
+        assert e[0] < 2e-5 and e[1] < 2e-5 and e[2] < 2e-5, (B, T, e)
+        assert elementwise_close(post1, post0.cpu(), rtol=1e-4, floor=2e-5)
+        for a, b in zip(outs[1], outs['masked']):
+            assert torch.equal(a, b), (B, T, 'CU-masked stream')
