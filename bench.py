@@ -666,7 +666,7 @@ def main():
         if overlap and pipe.cu_split:
             def lane_encode(li):
                 st, lo, hi = pipe.lanes[li]
-                return lambda: pipe._encode(ringp[0], noise_p, unit0.buf[:Bp], None, lo, hi, li)
+                return lambda: pipe._encode(ringp[0], noise_p, unit0.buf[:Bp], None, lo, hi, li, unit=(unit0, 0))
 
             part_ms = {'encode_lane_ms_on_its_cus': [round(1e3 * timed_on(pipe.lanes[li][0], lane_encode(li)), 4) for li in range(len(pipe.lanes))],
                        'encode_lane_videos': [hi - lo for _, lo, hi in pipe.lanes],

@@ -635,12 +635,29 @@ int sf_set_encode_fuse_next(int on);
 int sf_get_encode_fuse_next(void);
 /* The slot branch of a batched encode (all T steps' convolutions per launch, sf_savi_encode_batched_workspace_bytes) as ONE video-stationary launch
  * (csrc/slot_chain.hip; savi.py:76-100, 393-402): one workgroup per video walks the T steps x num_iterations Slot-Attention iterations, their slot
- * updates and the per-step prologues on feature rows kept as bf16 hi | lo -- 7 launches per encode instead of ~60.  Process default 1 (SF_SLOT_CHAIN=0 or
- * sf_set_slot_chain(0): the per-iteration launches over the whole batch).  Applies to the CLEVRER shape of the slot branch (slot size 128, slot MLP 256,
+ * updates and the per-step prologues on feature rows kept as bf16 hi | lo -- 7 launches per encode instead of ~60.  OPT-IN: process default 0
+ * (SF_SLOT_CHAIN=1 or sf_set_slot_chain(1)).  Measured (profiles/r06_probes.txt): 0.80 ms per batch of 32 videos x 6 frames on 32 CUs against 0.58 ms for
+ * the per-iteration launches on the whole chip and 1.2 ms on a 128-CU partition -- fewer CU-ms, more latency; the default keeps the per-iteration launches.  Applies to the CLEVRER shape of the slot branch (slot size 128, slot MLP 256,
  * residual-MLP predictor, single-Linear kernel distribution, folded Slot Attention, up to 8 slots, HW a multiple of 256); everything else keeps the
  * per-iteration launches.  The two forms agree to split-bf16 rounding (the attention products are split-bf16 here, exact f32 there). */
 int sf_set_slot_chain(int on);
 int sf_get_slot_chain(void);
+/* The encode in two halves, for callers that overlap them (the batch pipeline: features on the encode lane, the slot branch of a whole rollout unit in
+ * front of its rollout).  sf_savi_chain_ok: 1 when both apply to this model at B videos x T frames (the conditions of sf_set_slot_chain above).
+ *   sf_savi_features_planes_f32: CNN + encoder_out_layer + SlotAttention.norm_inputs (savi.py:231-250, 66) of B x T frames -> planes [T][B][64 * 64] rows
+ *     of 512 B (bf16 hi | lo of the 128 channels; sf_savi_planes_bytes); workspace sf_savi_features_workspace_bytes.
+ *   sf_savi_slots_chain_f32: the per-step chain of StoSAVi.encode (savi.py:393-416) with its Slot-Attention iterations (:76-100) for NB batches of B
+ *     videos from planes [NB][T][B][64 * 64][512 B]: noise NULL or [NB * B][T][N][D], prev_slots NULL or [NB * B][N][D]; video v's slots of step t ->
+ *     post + v * post_bs + t * N * D (post_bs in floats: a [NB * B][T + H][N][D] rollout buffer takes them in place); kernel_dist NULL or
+ *     [NB * B][T][N][2 D]; attn NULL or [NB * B][T][N][64 * 64]; workspace sf_savi_slots_chain_workspace_bytes(m, NB * B).
+ * The two in sequence are what sf_savi_encode_f32 runs when it is given sf_savi_encode_batched_workspace_bytes: the same bits. */
+int sf_savi_chain_ok(const sf_savi_encoder* m, int B, int T);
+size_t sf_savi_planes_bytes(const sf_savi_encoder* m, int B, int T);
+size_t sf_savi_features_workspace_bytes(const sf_savi_encoder* m, int B, int T);
+int sf_savi_features_planes_f32(const sf_savi_encoder* m, const float* img, int B, int T, void* planes, void* ws, size_t ws_bytes, void* stream);
+size_t sf_savi_slots_chain_workspace_bytes(const sf_savi_encoder* m, int videos);
+int sf_savi_slots_chain_f32(const sf_savi_encoder* m, const void* planes, const float* noise, const float* prev_slots, float* post, long long post_bs,
+                            float* kernel_dist, float* attn, int NB, int B, int T, void* ws, size_t ws_bytes, void* stream);
 int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const float* feat_pre, int n_pre, const float* noise,
                             const float* prev_slots, float* lstm_h, float* lstm_c, int state_valid, float* post_slots,
                             float* kernel_dist, float* attn, int B, int T, void* ws, size_t ws_bytes, void* stream, void* side_stream);

@@ -247,6 +247,12 @@ SIGNATURES = {
     'sf_get_encode_fuse_next': (I, []),
     'sf_set_slot_chain': (I, [I]),
     'sf_get_slot_chain': (I, []),
+    'sf_savi_chain_ok': (I, [C.POINTER(sf_savi_encoder), I, I]),
+    'sf_savi_planes_bytes': (SZ, [C.POINTER(sf_savi_encoder), I, I]),
+    'sf_savi_features_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I, I]),
+    'sf_savi_features_planes_f32': (I, [C.POINTER(sf_savi_encoder), FP, I, I, VP, VP, SZ, VP]),
+    'sf_savi_slots_chain_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I]),
+    'sf_savi_slots_chain_f32': (I, [C.POINTER(sf_savi_encoder), VP, FP, FP, FP, LL, FP, FP, I, I, I, VP, SZ, VP]),
     'sf_savi_encode_fork_f32': (I, [C.POINTER(sf_savi_encoder), FP, FP, I, FP, FP, FP, FP, I, FP, FP, FP, I, I, VP, SZ,
                                     VP, VP]),
     'sf_kv_producer_workspace_bytes': (SZ, [I, I]),

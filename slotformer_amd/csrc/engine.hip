@@ -655,13 +655,13 @@ int sf_rollout_bf16(const sf_rollouter* m, float* slots, int B, int T_total, int
 // ---------------------------------------------------------------------------------------------
 static int enc_chunk(int B) { return B < 32 ? B : 32; }
 
-// the slot branch of a batched encode as one video-stationary launch (slot_chain.hip): on by default; sf_set_slot_chain(0) / SF_SLOT_CHAIN=0 keeps the
-// per-iteration launches (Slot-Attention iteration over the batch + slot update)
+// the slot branch of a batched encode as one video-stationary launch (slot_chain.hip): OPT-IN (sf_set_slot_chain(1) / SF_SLOT_CHAIN=1); the default keeps
+// the per-iteration launches (Slot-Attention iteration over the batch + slot update), which are faster for a batch alone on its CUs
 static int g_slot_chain = -1;
 int sf_get_slot_chain(void) {
   if (g_slot_chain < 0) {
     const char* e = getenv("SF_SLOT_CHAIN");
-    g_slot_chain = (e && e[0] == '0') ? 0 : 1;
+    g_slot_chain = (e && e[0] == '1') ? 1 : 0;   // (opt-in: measured slower than the per-iteration launches inside sf_savi_encode_*, profiles/r06_probes.txt)
   }
   return g_slot_chain;
 }
@@ -803,6 +803,94 @@ int sf_savi_cnn_f32(const sf_savi_encoder* m, const float* img, int B, int T, in
     }
   sf_prof_suppress(0);
   return rc;
+}
+
+// ---- the encode in two halves (round 6): image features of a batch as bf16 hi | lo rows, and the slot branch of a GROUP of batches as one
+//      video-stationary launch (slot_chain.hip).  The batch pipeline runs the first on its encode lane and the second in front of the group's rollout, on
+//      the rollout stream: the slot branch is 32 workgroups of ~0.5 ms per batch that would leave the other 96 CUs of the lane idle. ----
+// model-level conditions of the video-stationary slot branch (the CLEVRER shape of StoSAVi: savi.py:76-100, 393-402)
+static bool enc_chain_model_ok(const sf_savi_encoder* m) {
+  if (!m || sf_get_precision() != 1) return false;
+  const int HW = 64 * 64, D = m->slot_size, Ce = m->enc_out_channels, Hm = m->slot_mlp_size, N = m->num_slots;
+  const int Cl = m->enc_channels[m->enc_layers];
+  const bool fold = m->sa_fold_q_w && m->sa_fold_q_w_t && m->sa_fold_gru_ih_t && Ce == D && Cl == 64 && sf_pixel_mlp_feat_ok(Cl, Ce);
+  const bool su = m->sa_fold_gru_ih_p && m->sa_gru_hh_p && m->sa_mlp_w1_p && m->sa_mlp_w2_p && m->sa_fold_q_w_p && sf_slot_update_mfma_ok(D, Hm, sf_sa_pick_partials(HW));
+  const bool prologue = m->pred_type == 0 && !m->pred_rnn && m->kd_mode == 1 && m->pm_w0_t && m->pm_w2_t && m->kd_w0_t && m->pm_w0_p && m->pm_w2_p && m->kd_w0_p &&
+                        m->pm_ln_g && m->pm_ln_b && m->pm_b0 && m->pm_b2 && m->kd_b0 && m->init_latents;
+  return fold && su && prologue && sf_get_encode_fuse_next() && sf_slot_chain_ok(D, Hm, HW, N) && m->enc_fc1_w && m->enc_fc2_w;
+}
+// prologue of step 0 + the chain, for NB batches of B videos; the four row buffers hold NB * B * N rows of D floats each
+static int enc_slots_chain(const sf_savi_encoder* m, const void* planes, const float* noise, const float* prev, float* post, long long post_bs, float* kernel_dist,
+                           float* attn, int NB, int B, int T, float* slotsA, float* slotsB, float* latents, float* q, hipStream_t st) {
+  const int N = m->num_slots, D = m->slot_size, HW = 64 * 64;
+  const float ln_eps = 1e-5f;
+  const int pr = sf_slot_prologue_ex(prev, m->init_latents, m->pm_ln_g, m->pm_ln_b, m->pm_w0_t, m->pm_b0, m->pm_w2_t, m->pm_b2, m->pred_norm_first, m->kd_w0_t,
+                                     m->kd_b0, noise, (long long)T * N * D, kernel_dist, (long long)T * N * 2 * D, m->sa_q_ln_g, m->sa_q_ln_b, m->sa_fold_q_w_t,
+                                     slotsA, q, NB * B, N, D, ln_eps, st);
+  if (pr != 0) return pr < 0 ? pr : sf_set_err(-1, "the one-launch slot prologue does not apply to this model", __FILE__, __LINE__);
+  SfChainWeights cw;
+  cw.gru_ih_p = m->sa_fold_gru_ih_p; cw.gru_hh_p = m->sa_gru_hh_p; cw.gru_b_ih = m->gru_b_ih; cw.gru_b_hh = m->gru_b_hh; cw.ln_g = m->mlp_ln_g; cw.ln_b = m->mlp_ln_b;
+  cw.w1_p = m->sa_mlp_w1_p; cw.b1 = m->mlp_b1; cw.w2_p = m->sa_mlp_w2_p; cw.b2 = m->mlp_b2; cw.q_ln_g = m->sa_q_ln_g; cw.q_ln_b = m->sa_q_ln_b; cw.q_w_p = m->sa_fold_q_w_p;
+  cw.pm_ln_g = m->pm_ln_g; cw.pm_ln_b = m->pm_ln_b; cw.pm_w0_p = m->pm_w0_p; cw.pm_b0 = m->pm_b0; cw.pm_w2_p = m->pm_w2_p; cw.pm_b2 = m->pm_b2;
+  cw.pm_norm_first = m->pred_norm_first; cw.kd_w_p = m->kd_w0_p; cw.kd_b = m->kd_b0;
+  return sf_slot_chain_ex(planes, NB, B, T, HW, N, m->num_iterations, 1.0f / sqrtf((float)D), m->sa_eps, ln_eps, slotsA, slotsB, latents, q, post, post_bs, attn,
+                          noise, kernel_dist, &cw, st);
+}
+
+int sf_savi_chain_ok(const sf_savi_encoder* m, int B, int T) { return (enc_chain_model_ok(m) && enc_batched_ok(m, B, T)) ? 1 : 0; }
+size_t sf_savi_planes_bytes(const sf_savi_encoder* m, int B, int T) { return (m && B > 0 && T > 0) ? (size_t)B * T * 64 * 64 * 512 : 0; }
+size_t sf_savi_features_workspace_bytes(const sf_savi_encoder* m, int B, int T) {
+  if (!m || B <= 0 || T <= 0) return 0;
+  int cmax = 0;
+  for (int i = 1; i <= m->enc_layers && i < 9; ++i) cmax = m->enc_channels[i] > cmax ? m->enc_channels[i] : cmax;
+  return 3 * pad256((size_t)B * T * 64 * 64 * cmax) + 4096;
+}
+// Image features of B videos x T frames as the Slot-Attention inputs of the video-stationary slot branch: CNN (savi.py:231-244), encoder_out_layer
+// (:245-250) and SlotAttention.norm_inputs (:66) -> planes [T][B][64 * 64] rows of 512 B (bf16 hi 128 | lo 128).  Independent of any slots.
+int sf_savi_features_planes_f32(const sf_savi_encoder* m, const float* img, int B, int T, void* planes, void* ws, size_t ws_bytes, void* stream) {
+  SF_REQUIRE(m && img && planes && ws, "sf_savi_features_planes_f32: null pointer");
+  SF_REQUIRE(B >= 1 && T >= 1 && sf_savi_chain_ok(m, B, T), "sf_savi_features_planes_f32: the video-stationary slot branch does not apply (sf_savi_chain_ok)");
+  SF_REQUIRE(ws_bytes >= sf_savi_features_workspace_bytes(m, B, T), "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int HW = 64 * 64, res = m->resolution;
+  int cmax = 0;
+  for (int i = 1; i <= m->enc_layers; ++i) cmax = m->enc_channels[i] > cmax ? m->enc_channels[i] : cmax;
+  Bump bp{(char*)ws, ws_bytes};
+  float* big[3];
+  for (int i = 0; i < 3; ++i) big[i] = bp.take((size_t)B * T * HW * cmax);
+  if (!bp.ok) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
+  const long long frame_elems0 = (long long)3 * res * res;
+  const int c1 = m->enc_channels[1];
+  int rc0 = sf_conv_first_grouped_ex(img, (long long)T * frame_elems0, B, frame_elems0, m->conv_w[0], m->conv_b[0], nullptr, big[0], B * T, m->enc_channels[0], res, res, c1,
+                                     m->enc_ks, res == 128 ? 2 : 1, 1, st);
+  if (rc0 < 0 || rc0 > 1) return rc0;
+  for (int t = 0; t < T && rc0 == 1; ++t)
+    SF_TRY(sf_conv2d_nchw_in_f32(img + (long long)t * frame_elems0, (long long)T * frame_elems0, m->conv_w[0], m->conv_b[0], nullptr,
+                                 big[0] + (long long)t * B * HW * c1, B, m->enc_channels[0], res, res, c1, m->enc_ks, res == 128 ? 2 : 1, 1, st));
+  SF_TRY(run_cnn_layers(m, nullptr, 0, B * T, big[2], big[0], big[1], 1, m->enc_layers, st));
+  return sf_pixel_mlp_feat_planes_ex(big[2], m->enc_ln_g, m->enc_ln_b, m->enc_fc1_w, m->enc_fc1_b, m->enc_fc2_w, m->enc_fc2_b, m->sa_norm_in_g, m->sa_norm_in_b, planes,
+                                     B * T * HW, 1e-5f, st);
+}
+size_t sf_savi_slots_chain_workspace_bytes(const sf_savi_encoder* m, int videos) {
+  return (m && videos > 0) ? 4 * pad256((size_t)videos * m->num_slots * m->slot_size) + 4096 : 0;
+}
+// The slot branch of NB batches of B videos over their T frames (StoSAVi.encode's per-step chain, savi.py:393-416, and the Slot-Attention iterations,
+// :76-100) from sf_savi_features_planes_f32 rows: planes [NB][T][B][64 * 64][256 bf16]; noise NULL or [NB * B][T][N][D]; prev_slots NULL or [NB * B][N][D];
+// video v's slots of step t -> post + v * post_bs + t * N * D; kernel_dist NULL or [NB * B][T][N][2 D]; attn NULL or [NB * B][T][N][64 * 64].
+int sf_savi_slots_chain_f32(const sf_savi_encoder* m, const void* planes, const float* noise, const float* prev_slots, float* post, long long post_bs,
+                            float* kernel_dist, float* attn, int NB, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+  SF_REQUIRE(m && planes && post && ws, "sf_savi_slots_chain_f32: null pointer");
+  SF_REQUIRE(NB >= 1 && B >= 1 && T >= 1 && enc_chain_model_ok(m), "sf_savi_slots_chain_f32: the video-stationary slot branch does not apply (sf_savi_chain_ok)");
+  SF_REQUIRE(noise == nullptr || m->kd_mode != 0, "noise given but the model has no kernel_dist layer");
+  SF_REQUIRE(ws_bytes >= sf_savi_slots_chain_workspace_bytes(m, NB * B), "workspace too small");
+  const size_t R = (size_t)NB * B * m->num_slots;
+  Bump bp{(char*)ws, ws_bytes};
+  float* sA = bp.take(R * m->slot_size);
+  float* sB = bp.take(R * m->slot_size);
+  float* lat = bp.take(R * m->slot_size);
+  float* q = bp.take(R * m->slot_size);
+  if (!bp.ok) return sf_set_err(-1, "workspace too small", __FILE__, __LINE__);
+  return enc_slots_chain(m, planes, noise, prev_slots, post, post_bs, kernel_dist, attn, NB, B, T, sA, sB, lat, q, (hipStream_t)stream);
 }
 
 int sf_savi_encode_f32(const sf_savi_encoder* m, const float* img, const float* noise, const float* prev_slots,
@@ -962,22 +1050,11 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
     SF_TRY(run_cnn_layers(m, nullptr, 0, B * T, big[2], big[0], big[1], 1, m->enc_layers, st_main));
     // ---- the slot branch of all T steps as ONE video-stationary launch (slot_chain.hip): the per-pixel chain of the B * T frames in one launch
     //      (feature rows as bf16 hi | lo), the prologue of step 0, then one workgroup per video ----
-    if (sf_get_slot_chain() && fold && !feat192 && can_fuse_next && su_mfma && sf_slot_chain_ok(D, Hm, HW, N) && m->enc_channels[m->enc_layers] == 64) {
+    if (sf_get_slot_chain() && enc_chain_model_ok(m)) {
       SF_TRY(sf_pixel_mlp_feat_planes_ex(big[2], m->enc_ln_g, m->enc_ln_b, m->enc_fc1_w, m->enc_fc1_b, m->enc_fc2_w, m->enc_fc2_b, m->sa_norm_in_g,
                                          m->sa_norm_in_b, planes, B * T * HW, ln_eps, st_main));
-      const int pr = sf_slot_prologue_ex(prev, m->init_latents, m->pm_ln_g, m->pm_ln_b, m->pm_w0_t, m->pm_b0, m->pm_w2_t, m->pm_b2, m->pred_norm_first,
-                                         m->kd_w0_t, m->kd_b0, noise, (long long)T * N * D, kernel_dist, (long long)T * N * 2 * D, m->sa_q_ln_g,
-                                         m->sa_q_ln_b, q_w_t, slotsA, q, B, N, D, ln_eps, st_main);
-      if (pr < 0 || pr > 1) return pr;
-      if (pr == 0) {
-        SfChainWeights cw;
-        cw.gru_ih_p = gru_ih_p; cw.gru_hh_p = m->sa_gru_hh_p; cw.gru_b_ih = m->gru_b_ih; cw.gru_b_hh = m->gru_b_hh; cw.ln_g = m->mlp_ln_g; cw.ln_b = m->mlp_ln_b;
-        cw.w1_p = m->sa_mlp_w1_p; cw.b1 = m->mlp_b1; cw.w2_p = m->sa_mlp_w2_p; cw.b2 = m->mlp_b2; cw.q_ln_g = m->sa_q_ln_g; cw.q_ln_b = m->sa_q_ln_b; cw.q_w_p = q_w_p;
-        cw.pm_ln_g = m->pm_ln_g; cw.pm_ln_b = m->pm_ln_b; cw.pm_w0_p = m->pm_w0_p; cw.pm_b0 = m->pm_b0; cw.pm_w2_p = m->pm_w2_p; cw.pm_b2 = m->pm_b2;
-        cw.pm_norm_first = m->pred_norm_first; cw.kd_w_p = m->kd_w0_p; cw.kd_b = m->kd_b0;
-        return sf_slot_chain_ex(planes, B, T, HW, N, m->num_iterations, 1.0f / sqrtf((float)D), m->sa_eps, ln_eps, slotsA, slotsB, latents, q, pnum, pden,
-                                post_slots, attn, noise, kernel_dist, &cw, st_main);
-      }
+      // (the chain's row buffers: the slot buffers of this function's workspace)
+      return enc_slots_chain(m, planes, noise, prev, post_slots, (long long)T * N * D, kernel_dist, attn, 1, B, T, slotsA, slotsB, latents, q, st_main);
     }
   }
   for (int t = 0; t < T; ++t) {

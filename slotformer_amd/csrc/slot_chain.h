@@ -24,12 +24,12 @@ struct SfChainWeights {
 
 // slot size 128, slot MLP 256, HW a multiple of 256, at most 8 slots
 bool sf_slot_chain_ok(int D, int H, int HW, int N);
-// One launch, one workgroup per video: T steps x iters Slot-Attention iterations with their slot updates and the per-step prologues
-// (savi.py:76-100, 393-402).  feat_planes: [T][B][HW] rows of 512 B (bf16 hi 128 | lo 128: sf_pixel_mlp_feat_planes_ex).  On entry slotsA / q hold the
-// sampled slots of step 0 and their project_q (sf_slot_prologue_ex); post [B][T][N][128] receives every step's slots; attn NULL or [B][T][N][HW];
-// noise NULL or [B][T][N][128]; kdist NULL or [B][T][N][256] (rows of steps >= 1).
-int sf_slot_chain_ex(const void* feat_planes, int B, int T, int HW, int N, int iters, float scale, float eps, float ln_eps, float* slotsA, float* slotsB,
-                     float* lat, float* q, float* pnum, float* pden, float* post, float* attn, const float* noise, float* kdist, const SfChainWeights* w,
+// One launch, one workgroup per video of NB batches of B videos: T steps x iters Slot-Attention iterations with their slot updates and the per-step
+// prologues (savi.py:76-100, 393-402).  feat_planes: [NB][T][B][HW] rows of 512 B (bf16 hi 128 | lo 128: sf_pixel_mlp_feat_planes_ex per batch).  On
+// entry slotsA / q hold the sampled slots of step 0 and their project_q for the NB * B videos (sf_slot_prologue_ex); video v's slots of step t go to
+// post + v * post_bs + t * N * 128; attn NULL or [NB * B][T][N][HW]; noise NULL or [NB * B][T][N][128]; kdist NULL or [NB * B][T][N][256] (steps >= 1).
+int sf_slot_chain_ex(const void* feat_planes, int NB, int B, int T, int HW, int N, int iters, float scale, float eps, float ln_eps, float* slotsA, float* slotsB,
+                     float* lat, float* q, float* post, long long post_bs, float* attn, const float* noise, float* kdist, const SfChainWeights* w,
                      hipStream_t st);
 // encoder_out_layer + SlotAttention.norm_inputs (sf_pixel_mlp_feat_ex) with the result as bf16 hi | lo rows of 512 B: planes [M][256] bf16
 int sf_pixel_mlp_feat_planes_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,

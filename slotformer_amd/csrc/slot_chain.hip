@@ -282,13 +282,13 @@ __device__ __forceinline__ void sc_put_var(LUmVar* lv, const UmVar& um) {
 }
 
 struct ScArgs {
-  const __bf16* feat;       // [T][B][HW][256] bf16: hi 128 | lo 128 per pixel (frame (t, b) at ((t * B + b) * HW) rows)
-  int B, T, HW, N, iters;
+  const __bf16* feat;       // [NB][T][B][HW][256] bf16: hi 128 | lo 128 per pixel (frame (t, b) of batch h at (((h * T + t) * B + b) * HW) rows)
+  int B, T, HW, N, iters;   // B: videos per BATCH (the launch has one workgroup per video of NB batches)
+  long long post_bs;        // floats between two videos' rows of `post`
   float scale, eps;
   float *slotsA, *slotsB, *lat;   // [B * N][128] each; slotsA holds the sampled slots of step 0 on entry
   float* q;                       // [B * N][128]: project_q of them on entry
-  float *pnum, *pden;             // [B][N][128], [B][N]
-  float* post;                    // [B][T][N][128]
+  float* post;                    // video v, step t at post + v * post_bs + t * N * 128
   float* attn;                    // NULL or [B][T][N][HW]: the last iteration's attention of every step
   const float* noise;             // NULL or [B][T][N][128]
   float* kdist;                   // NULL or [B][T][N][256]
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(SC_NT) void slot_chain_kernel(ScArgs A) {
   __syncthreads();
 #pragma unroll 1
   for (int t = 0; t < T; ++t) {
-    const __bf16* frame = A.feat + ((long long)t * A.B + v) * A.HW * 256;
+    const __bf16* frame = A.feat + (((long long)(v / A.B) * T + t) * A.B + (v % A.B)) * A.HW * 256;
     float* s_in = sA;
     float* s_out = sB;
 #pragma unroll 1
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(SC_NT) void slot_chain_kernel(ScArgs A) {
       __syncthreads();   // the record is complete (LDS); every wave is done with the reduction rows
       SCTS();
       um.slots_prev = s_in;
-      float* post_t = A.post + (((long long)v * T + t) * N) * SC_D;
+      float* post_t = A.post + (long long)v * A.post_bs + (long long)t * N * SC_D;
       if (last_it && t + 1 < T) {
         // the step's last update + the prologue of step t + 1 (predictor, kernel distribution, sampling, first q): um_body<true>
         um.slots_out = (s_out == sA) ? sL : s_out;
@@ -371,18 +371,18 @@ __global__ __launch_bounds__(SC_NT) void slot_chain_kernel(ScArgs A) {
 
 bool sf_slot_chain_ok(int D, int H, int HW, int N) { return D == SC_D && H == UM_H && HW >= 256 && HW % (SC_NW * SC_TP) == 0 && N >= 1 && N <= 8; }
 
-int sf_slot_chain_ex(const void* feat_planes, int B, int T, int HW, int N, int iters, float scale, float eps, float ln_eps, float* slotsA, float* slotsB,
-                     float* lat, float* q, float* pnum, float* pden, float* post, float* attn, const float* noise, float* kdist, const SfChainWeights* w,
+int sf_slot_chain_ex(const void* feat_planes, int NB, int B, int T, int HW, int N, int iters, float scale, float eps, float ln_eps, float* slotsA, float* slotsB,
+                     float* lat, float* q, float* post, long long post_bs, float* attn, const float* noise, float* kdist, const SfChainWeights* w,
                      hipStream_t st) {
-  SF_REQUIRE(feat_planes && slotsA && slotsB && lat && q && pnum && pden && post && w, "sf_slot_chain_ex: null pointer");
-  SF_REQUIRE(sf_slot_chain_ok(SC_D, UM_H, HW, N) && B >= 1 && T >= 1 && iters >= 1, "sf_slot_chain_ex: bad shape");
+  SF_REQUIRE(feat_planes && slotsA && slotsB && lat && q && post && w, "sf_slot_chain_ex: null pointer");
+  SF_REQUIRE(sf_slot_chain_ok(SC_D, UM_H, HW, N) && NB >= 1 && B >= 1 && T >= 1 && iters >= 1 && post_bs >= (long long)T * N * SC_D, "sf_slot_chain_ex: bad shape");
   SF_REQUIRE(w->gru_ih_p && w->gru_hh_p && w->gru_b_ih && w->gru_b_hh && w->ln_g && w->ln_b && w->w1_p && w->b1 && w->w2_p && w->b2 && w->q_ln_g && w->q_ln_b &&
                  w->q_w_p && w->pm_ln_g && w->pm_ln_b && w->pm_w0_p && w->pm_b0 && w->pm_w2_p && w->pm_b2 && w->kd_w_p && w->kd_b,
              "sf_slot_chain_ex: null weight");
   ScArgs A;
   memset(&A, 0, sizeof(A));
   A.feat = (const __bf16*)feat_planes; A.B = B; A.T = T; A.HW = HW; A.N = N; A.iters = iters; A.scale = scale; A.eps = eps;
-  A.slotsA = slotsA; A.slotsB = slotsB; A.lat = lat; A.q = q; A.pnum = pnum; A.pden = pden; A.post = post; A.attn = attn; A.noise = noise; A.kdist = kdist;
+  A.slotsA = slotsA; A.slotsB = slotsB; A.lat = lat; A.q = q; A.post = post; A.post_bs = post_bs; A.attn = attn; A.noise = noise; A.kdist = kdist;
   UmArgs& a = A.um;
   a.w_ih_p = (const uint4*)w->gru_ih_p; a.w_hh_p = (const uint4*)w->gru_hh_p; a.b_ih = w->gru_b_ih; a.b_hh = w->gru_b_hh; a.ln_g = w->ln_g; a.ln_b = w->ln_b;
   a.w1_p = (const uint4*)w->w1_p; a.b1 = w->b1; a.w2_p = (const uint4*)w->w2_p; a.b2 = w->b2; a.q_ln_g = w->q_ln_g; a.q_ln_b = w->q_ln_b;
@@ -391,8 +391,8 @@ int sf_slot_chain_ex(const void* feat_planes, int B, int T, int HW, int N, int i
   a.pm_norm_first = w->pm_norm_first; a.kd_w_p = (const uint4*)w->kd_w_p; a.kd_b = w->kd_b;
   SF_TRY(sf_ensure_dyn_lds((const void*)slot_chain_kernel, SC_LDS));
   // algorithmic bytes: every iteration reads its frame's feature rows once (one read of the Slot-Attention inputs per iteration)
-  sf_prof_begin(SF_K_SA_ITER, st, (double)B * T * iters * HW * 512.0);
-  hipLaunchKernelGGL(slot_chain_kernel, dim3(B), dim3(SC_NT), SC_LDS, st, A);
+  sf_prof_begin(SF_K_SA_ITER, st, (double)NB * B * T * iters * HW * 512.0);
+  hipLaunchKernelGGL(slot_chain_kernel, dim3(NB * B), dim3(SC_NT), SC_LDS, st, A);
   sf_prof_end(SF_K_SA_ITER, st);
   SF_CHECK_LAUNCH();
   return 0;

@@ -456,6 +456,49 @@ def savi_encode(m, img, prev_slots=None, noise=None, want_attn=False, ws_slot=0,
     return post, kdist, attn
 
 
+def savi_chain_ok(m, B, T):
+    """True when the encode of this model can run in two halves (`savi_features` + `savi_slots_chain`: csrc/slot_chain.hip, the CLEVRER shape of
+    StoSAVi's slot branch) at B videos x T frames."""
+    plan = encoder_plan(m)
+    return bool(lib().sf_savi_chain_ok(C.byref(plan.struct), int(B), int(T)))
+
+
+def savi_planes_bytes(m, B, T):
+    return int(lib().sf_savi_planes_bytes(C.byref(encoder_plan(m).struct), int(B), int(T)))
+
+
+def savi_features(m, img, out, ws_slot=0):
+    """First half of the encode (sf_savi_features_planes_f32): CNN + encoder_out_layer + SlotAttention.norm_inputs of img [B,T,3,R,R] -> `out`, a uint8
+    tensor of savi_planes_bytes(m, B, T) bytes ([T][B][4096] rows of 512 B: bf16 hi | lo of the 128 channels), on the current stream.  No slots involved."""
+    _require_inference(m, img)
+    ops._chk(img)
+    plan = encoder_plan(m)
+    B, T = img.shape[:2]
+    need = lib().sf_savi_features_workspace_bytes(C.byref(plan.struct), B, T)
+    ws = workspace(img.device, need, ('encf', ws_slot))
+    check(lib().sf_savi_features_planes_f32(C.byref(plan.struct), img.data_ptr(), B, T, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            torch.cuda.current_stream().cuda_stream))
+    return out
+
+
+def savi_slots_chain(m, planes, nb, B, T, post, noise=None, prev_slots=None, kdist=None, attn=None, ws_slot=0):
+    """Second half (sf_savi_slots_chain_f32): the slot branch of nb batches of B videos from `planes` ([nb][T][B][4096][512 B], uint8) as ONE launch of one
+    workgroup per video.  post: a float32 tensor [nb * B, T', N, D] with T' >= T whose first T steps receive the slots (a rollout unit's buffer takes
+    them in place); noise None or [nb * B, T, N, D]; prev_slots None or [nb * B, N, D]; kdist / attn: optional outputs [nb * B, T, N, 2 D] / [nb * B, T, N, 4096]."""
+    plan = encoder_plan(m)
+    s = plan.struct
+    ops._chk(post, noise, prev_slots, kdist, attn)
+    V = int(nb) * int(B)
+    if post.shape[0] != V or post.shape[1] < T or post.stride(0) < T * s.num_slots * s.slot_size or post.stride(1) != s.num_slots * s.slot_size:
+        raise RuntimeError(f'post must be [{V}, >= {T}, N, D] float32 with contiguous steps, got {tuple(post.shape)} strides {post.stride()}')
+    need = lib().sf_savi_slots_chain_workspace_bytes(C.byref(plan.struct), V)
+    ws = workspace(post.device, need, ('encs', ws_slot))
+    P = ops._p
+    check(lib().sf_savi_slots_chain_f32(C.byref(plan.struct), planes.data_ptr(), P(noise), P(prev_slots), post.data_ptr(), post.stride(0), P(kdist), P(attn),
+                                        int(nb), int(B), int(T), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+    return post
+
+
 def savi_cnn(m, img, t0, t1, out=None, ws_slot=0):
     """CNN features (convs + soft position embedding) of time steps [t0, t1): [t1-t0, B, 4096, C_last] on the current
     stream; they do not depend on the slots, so they can be produced ahead of `savi_encode(..., feat_pre=...)`."""

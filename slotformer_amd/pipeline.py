@@ -96,6 +96,8 @@ class _Unit:
         self.busy = None   # event of the last rollout + copy-out that used the buffer in the current run()
         self.latency_form = False   # captured with the kernels' latency forms (the drain unit of a run: alone on the whole chip)
         self.row_form = False       # captured with the row-tile forms instead of the token-stationary launches (a drain unit: latency counts)
+        self.planes = None          # split encode: the Slot-Attention inputs of the unit's batches ([nb][T][B][4096] rows of 512 B, uint8)
+        self.noise = None           # split encode: the kernel noise of the unit's videos [nb * B, T, N, D] (None: the model samples nothing)
 
 
 def encode_group_for(batch, n_batches):
@@ -257,6 +259,9 @@ class EncodeRolloutPipeline:
     False = never (every unit in the row-tile / latency forms: bit-identical to the serial module calls); True = required.  With it the results agree
     with the serial calls to ~5e-6 over 50 steps instead of bit for bit (one accumulator per output block instead of per-chunk partial sums), and are
     bit-identical to run(serial=True) of the same object.
+    split: True = the encode in two halves where the model allows it (image features on the encode lane, the slot branch of a whole unit as one
+    video-stationary launch behind the features of its last batch: csrc/slot_chain.hip; agrees with the default to split-bf16 rounding, ~5e-6);
+    None / False (default) = the whole encode on the lane -- measured faster (profiles/r06_probes.txt: the pipeline is bound by its rollout units).
     decoder: module holding the SAVi decoder weights (StoSAVi / SlotFormer); enables run(..., decoded={...}): the predicted frames of
     every batch decoded to reconstruction + segmentation behind its rollout, on an unmasked stream of its own (the decode is 12x the
     FLOPs of encode + rollout at C2: it bounds such a run, the other two stages hide beside it).  seg_dtype: uint8 (default) or int64.
@@ -264,7 +269,7 @@ class EncodeRolloutPipeline:
 
     def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=None, use_graph=True,
                  partition='pair', group=None, rollout_opts=None, encode_graph=None, hybrid=None, decoder=None, seg_dtype=torch.uint8,
-                 encode_fork=None, tok=None):
+                 encode_fork=None, tok=None, split=None):
         self.savi, self.roll = savi, rollouter
         # optional third stage (row N2; video_prediction/test_vp.py:55-63,145-146 -> slotformer.py:244-259 -> savi.py:504-525 ->
         # vp_utils.py:20-41): the predicted frames of every batch are decoded behind its rollout -- spatial-broadcast decoder, softmax
@@ -318,6 +323,7 @@ class EncodeRolloutPipeline:
         if steal_steps is None:
             steal_steps = float({'pair': 0, 'two': 1, 'three': 0}.get(partition, 1))
         self.steal = max(0.0, min(float(steal_steps), float(self.T)))   # may be fractional: see _steal_of
+        self._steal_arg = self.steal
         self._masked_taken = {}
         self._lib = _lib.lib()
         # 'pair': the encode partition's CU mask (the rollout streams get the complement)
@@ -366,6 +372,20 @@ class EncodeRolloutPipeline:
         # four times the workgroups only queue: C5, 256 videos: 392 -> 435 k; C2, 128 videos: 436 / 440 k
         self.drain_latency_form = self.G * self.B < 128
         self._key = ('pipe', id(self))
+        # The encode in two halves (round 6, csrc/slot_chain.hip): the image features of a batch on the encode lane (five dense launches), the slot
+        # branch of a WHOLE rollout unit as one video-stationary launch in front of the unit's rollout, on the rollout stream -- one workgroup per video
+        # for ~0.6 ms, which on the lane left 96 of its 128 CUs idle while nothing else could start.  Where the model's slot branch has that form
+        # (engine.savi_chain_ok) and the partition is 'pair'.  OPT-IN (split=True / SF_PIPE_SPLIT=1): the encode lane gets 22 % faster (2.83 -> 2.2 ms per
+        # C2 batch) but the rollout units, already slowed 25-40 % by whatever else runs on the chip, become the bound: 577 k against 626 k frames/s at 100
+        # batches (profiles/r06_probes.txt).
+        want_split = (os.environ.get('SF_PIPE_SPLIT', '0') == '1') if split is None else bool(split)
+        self.split = bool(want_split and partition == 'pair' and self.fused and engine.savi_chain_ok(savi, self.B, self.T))
+        self._with_noise = engine.kernel_noise(self.savi, torch.empty(0), 1, self.T, self.dev) is not None   # (no draw: the gate only)
+        # where the slot branch of a unit runs: 'enc' = behind the features of the unit's last batch, on that batch's stream (the encode side);
+        # 'roll' = at the head of the unit's rollout graph (the rollout stream)
+        self.chain_on = os.environ.get('SF_PIPE_CHAIN_ON', 'enc')
+        if self.split:
+            self.steal = 0.0   # (no stolen convolutions: the feature half IS the lane's work)
         self._plan = None
         self._sig = None
         self.units = []
@@ -468,6 +488,13 @@ class EncodeRolloutPipeline:
     def _capture_encode_graphs(self):
         """Capture the encode graphs of the lanes a run uses NOW, not inside the first run that reaches them (a short warm-up only
         touches the fill lanes): full batches, no stolen features."""
+        if self.split:
+            # the feature halves run eagerly (five launches per batch): only the persistent convolution needs to know how many CUs an UNMASKED
+            # stream of the fill / hybrid lanes may take (csrc/conv_ws.hip sizes its grid for the stream's CUs)
+            if self.cu_split and self.tok:
+                for st in list(self.s_free):
+                    self._lib.sf_stream_set_cus(C.c_void_p(st.cuda_stream), int(self._lib.sf_stream_cus(None)))
+            return
         if self.encode_graph and self.steal == 0 and not self.fill_steal and not self.pre_steal:
             res = getattr(self.savi, 'resolution', (128, 128))[0]
             with_noise = engine.kernel_noise(self.savi, torch.empty(0), 1, self.T, self.dev) is not None   # (no draw: the gate only)
@@ -610,6 +637,9 @@ class EncodeRolloutPipeline:
         with torch.no_grad():
             u = _Unit(torch.zeros(nb * self.B, self.T + self.H, self.N, self.D, device=self.dev), self._key + (tag, ))
             u.latency_form, u.row_form = latency_form, row_form
+            if self.split:
+                u.planes = torch.zeros(nb, engine.savi_planes_bytes(self.savi, self.B, self.T), dtype=torch.uint8, device=self.dev)
+                u.noise = torch.zeros(nb * self.B, self.T, self.N, self.D, device=self.dev) if self._with_noise else None
             self._rollout_eager(u)   # allocates its workspace, builds the plan
             torch.cuda.synchronize(self.dev)
             if self.use_graph:
@@ -653,13 +683,22 @@ class EncodeRolloutPipeline:
             self._enc_graphs = {}
             self._enc_plan = engine.encoder_plan(self.savi)
             self._enc_sig = self._enc_plan.sig
+            if self.split:
+                self._capture_all()   # (the unit graphs hold the slot branch: pointers into the encoder's packed copies)
             self._capture_encode_graphs()
 
     def _steal_of(self, j):
         """time steps of convolutions stolen for batch j: integers that average to self.steal (1.25 -> 1, 1, 1, 2, ...)"""
         return int(math.floor(self.steal * (j + 1) + 1e-9) - math.floor(self.steal * j + 1e-9))
 
+    def _chain(self, u):
+        """split encode: the slot branch of the unit's batches -- one launch, one workgroup per video; the slots of the burn-in frames land in the unit buffer"""
+        engine.savi_slots_chain(self.savi, u.planes, u.buf.shape[0] // self.B, self.B, self.T, u.buf, noise=u.noise, ws_slot=self._key + ('chain', ) + u.key[2:])
+
     def _rollout_eager(self, u):
+        if self.split and self.chain_on == 'roll':
+            # the slot branch of the unit's batches: one launch, one workgroup per video; the slots of the burn-in frames land in the unit buffer
+            engine.savi_slots_chain(self.savi, u.planes, u.buf.shape[0] // self.B, self.B, self.T, u.buf, noise=u.noise, ws_slot=self._key + ('chain', ) + u.key[2:])
         full = u.buf.shape[0] >= self.G * self.B
         if self.tok:
             # token-stationary launches for every unit of >= 96 videos but the LAST of a run (row_form: alone on the chip at the end, latency counts:
@@ -682,9 +721,16 @@ class EncodeRolloutPipeline:
         else:
             self._rollout_eager(u)
 
-    def _encode(self, img, noise, dst, feat_pre, lo=0, hi=None, lane=0):
-        """videos [lo, hi) of one batch -> dst[lo:hi, :burn_in] on the current stream"""
+    def _encode(self, img, noise, dst, feat_pre, lo=0, hi=None, lane=0, unit=None):
+        """videos [lo, hi) of one batch -> dst[lo:hi, :burn_in] on the current stream (split encode: the batch's feature rows -> slot h of the unit's
+        planes, its kernel noise -> the unit's noise rows; unit = (_Unit, h))"""
         hi = self.B if hi is None else hi
+        if self.split:
+            u, h = unit
+            if u.noise is not None:
+                u.noise[h * self.B:(h + 1) * self.B].copy_(engine.kernel_noise(self.savi, noise, self.B, self.T, self.dev))
+            engine.savi_features(self.savi, img, u.planes[h], ws_slot=self._key + ('feat', lane))
+            return
         if lo != 0 or hi != self.B:
             img = img[lo:hi]
             noise = None if noise is None else noise[lo:hi]
@@ -865,7 +911,9 @@ class EncodeRolloutPipeline:
                     # (on the calling stream the encode has the whole chip: the fill graph -- one persistent convolution workgroup per CU of the
                     #  device -- not the lane's, which is sized for the encode partition)
                     whole = ('fill', 0) if (self.encode_graph and self.cu_split and self.fill_whole_chip and self.s_free and self.fill_par > 1) else 0
-                    self._encode(im, nz(u0 + h), u.buf[h * B:(h + 1) * B], None, lane=whole)
+                    self._encode(im, nz(u0 + h), u.buf[h * B:(h + 1) * B], None, lane=whole, unit=(u, h))
+                if self.split and self.chain_on != 'roll':
+                    self._chain(u)
                 self._rollout(u)
                 for h in range(nb):
                     out[u0 + h].copy_(u.buf[h * B:(h + 1) * B], non_blocking=True)
@@ -999,9 +1047,10 @@ class EncodeRolloutPipeline:
                     if u.busy is not None:
                         fs.wait_event(u.busy)
                     with torch.cuda.stream(fs):
-                        self._encode(img_of(j, fs), nz(j), dst, None, lane=('fill', 1))
+                        self._encode(img_of(j, fs), nz(j), dst, None, lane=('fill', 1), unit=(u, h))
                         ev_enc[j][0].record(fs)
                     fill_last[1] = j
+                    last_stream = fs
                     ev_wait_j = ev_enc[j][:1]
                 elif j < n_fill:
                     # pipeline fill: the first encodes take the whole chip (unmasked streams); the masked lanes start after them.  One
@@ -1012,16 +1061,17 @@ class EncodeRolloutPipeline:
                     fill_par = self.fill_par if self.s_free else 1
                     fi = j % fill_par
                     fs = cur if fi == 0 else self.s_free[(fi - 1) % len(self.s_free)]
-                    if j >= units[0][1] and self.s_free and fi == 0:
+                    if (j >= units[0][1] or self.split) and self.s_free and fi == 0:
                         # fill batches behind the first unit: a rollout is already enqueued, and the calling stream -- the legacy null
                         # stream -- would wait for it.  Fill graph 0 (its fixed buffers) moves to an unmasked stream, behind its last use
                         fs = self.s_free[-1]
                     if j >= fill_par:
                         fs.wait_event(ev_enc[j - fill_par][0])   # the previous batch through this fill graph / its buffers
                     with torch.cuda.stream(fs):
-                        self._encode(img_of(j, fs), nz(j), dst, None, lane=('fill', fi) if fill_par > 1 else 0)
+                        self._encode(img_of(j, fs), nz(j), dst, None, lane=('fill', fi) if fill_par > 1 else 0, unit=(u, h))
                         ev_enc[j][0].record(fs)
                     fill_last[fi] = j
+                    last_stream = fs
                     if j == 0 and (steal or fill_k) and len(rolls) > 1:
                         # the rollout streams idle until the first unit is encoded: they compute the stolen features of the
                         # batches behind the fill now (round-robin), so that only the fill batches pay for their own convolutions
@@ -1050,12 +1100,23 @@ class EncodeRolloutPipeline:
                             if stolen[j]:
                                 st.wait_event(ev_pre[j])
                                 pre = self.feat_bufs[li][j % NF][:stolen[j]]
-                            self._encode(img_of(j, st), nz(j), dst, pre, lo, hi, li)
+                            self._encode(img_of(j, st), nz(j), dst, pre, lo, hi, li, unit=(u, h))
                             ev_enc[j][li].record(st)
+                    last_stream = lanes[0][0]
                     ev_wait_j = ev_enc[j]
                 if h == 0:
                     ev_wait = []
                 ev_wait = ev_wait + list(ev_wait_j)
+            if self.split and self.chain_on != 'roll':
+                # the slot branch of the unit on the stream that encoded its last batch, behind the features of all its batches
+                cst = last_stream
+                with torch.cuda.stream(cst):
+                    for e in ev_wait:
+                        cst.wait_event(e)
+                    self._chain(u)
+                    ev_c = torch.cuda.Event()
+                    ev_c.record(cst)
+                ev_wait = [ev_c]
             s_roll = rolls[ui % len(rolls)]
             if len(rolls) > 1 and drain and self.s_free:
                 # drain: the encode lane is (about to be) idle -- the last units take unmasked streams (all CUs) instead of queueing

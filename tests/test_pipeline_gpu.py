@@ -494,3 +494,40 @@ def test_harness_edge_counts(dev):
         assert torch.equal(out, ref[idx])
     finally:
         harness.release_pipelines()
+
+
+@pytest.mark.parametrize('chain_on,nbatch', [('enc', 14), ('roll', 9)])
+def test_pipeline_with_the_encode_in_two_halves(dev, monkeypatch, chain_on, nbatch):
+    """EncodeRolloutPipeline(split=True) (opt-in): image features of a batch on the encode lane (sf_savi_features_planes_f32), the slot branch of a whole rollout
+    unit as ONE video-stationary launch (sf_savi_slots_chain_f32, csrc/slot_chain.hip) behind the features of its last batch (`enc`) or at the head of its
+    rollout graph (`roll`).  Bit for bit with the serial schedule of the same object; 2e-5 from the default pipeline (split-bf16 rounding of the attention
+    products: 5e-6 measured on the encoded frames); with injected kernel noise; a run that ends in a short unit."""
+    from slotformer_amd.pipeline import EncodeRolloutPipeline
+    monkeypatch.setenv('SF_PIPE_CHAIN_ON', chain_on)
+    B, T, H = 32, 6, 12
+    savi, roll = _models(dev, gu.C2_SAVI, gu.C2_ROLL)
+    rs = np.random.RandomState(11)
+    imgs = [torch.from_numpy((rs.rand(B, T, 3, 128, 128) * 2 - 1).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    noises = [torch.from_numpy(rs.standard_normal((B, T, 7, 128)).astype(np.float32)).to(dev) for _ in range(nbatch)]
+    with torch.no_grad():
+        base = EncodeRolloutPipeline(savi, roll, B, T, H)
+        assert not base.split
+        ref = base.run(imgs, noises)
+        torch.cuda.synchronize()
+        base.close()
+        pipe = EncodeRolloutPipeline(savi, roll, B, T, H, split=True)
+        assert pipe.split and pipe.chain_on == chain_on and pipe.units[0].planes is not None
+        out = pipe.run(imgs, noises)
+        torch.cuda.synchronize()
+        out3 = pipe.run(imgs, noises, serial=True)
+        torch.cuda.synchronize()
+        assert torch.equal(out, out3), (out - out3).abs().max().item()
+        assert not torch.equal(out[:, :, :T], ref[:, :, :T])        # (another kernel form encoded the frames)
+        e_enc = ((out[:, :, :T] - ref[:, :, :T]).abs().max() / ref[:, :, :T].abs().max()).item()
+        assert e_enc < 2e-5, e_enc
+        assert _close(out, ref, tol=5e-5), ((out - ref).abs().max() / ref.abs().max()).item()
+        assert not torch.equal(out[0], out[1])
+        out2 = pipe.run(imgs, noises)
+        torch.cuda.synchronize()
+        assert torch.equal(out, out2)
+        pipe.close()
