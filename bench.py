@@ -460,6 +460,8 @@ def main():
     ap.add_argument('--cu-split', default='ff', help='encode CU mask of the pipeline: hex word, or rows<R> (pipeline.encode_mask_words)')
     ap.add_argument('--partition', choices=['pair', 'three', 'two', 'none'], default='pair')
     ap.add_argument('--steal', type=float, default=None, help='time steps of convolutions per batch computed on the rollout streams (default: the partition\'s)')
+    ap.add_argument('--split', choices=['enc', 'roll'], default=None,
+                    help='OPT-IN: the encode in two halves (csrc/slot_chain.hip): features on the encode lane, the slot branch of a rollout unit as one launch on the encode side (enc) or at the head of its rollout graph (roll)')
     ap.add_argument('--force-dist', action='store_true', help='form the RCCL process group with one rank too (the multi-GPU path on one GPU)')
     ap.add_argument('--self-launch', action='store_true', help='take the torch.distributed.run self-launch path with --gpus 1 too')
     ap.add_argument('--live-every', type=int, default=4, help='bracket every n-th conv / Slot-Attention launch with events in the untimed live pass')
@@ -536,7 +538,7 @@ def main():
     with torch.no_grad():
         log('building the pipeline (first eager rollouts + graph capture)')
         pipe = EncodeRolloutPipeline(savi, roll, Bp, T_BURN, T_ROLL, encode_cu_word=cu_word, steal_steps=steal,
-                                     use_graph=not args.no_graph, partition=partition, group=group)
+                                     use_graph=not args.no_graph, partition=partition, group=group, split=bool(args.split), chain_on=args.split or 'enc')
         overlap = not args.no_overlap
         G = pipe.G                      # batches per rollout graph
         unit0 = pipe.units[0]

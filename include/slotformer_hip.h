@@ -636,7 +636,7 @@ int sf_get_encode_fuse_next(void);
 /* The slot branch of a batched encode (all T steps' convolutions per launch, sf_savi_encode_batched_workspace_bytes) as ONE video-stationary launch
  * (csrc/slot_chain.hip; savi.py:76-100, 393-402): one workgroup per video walks the T steps x num_iterations Slot-Attention iterations, their slot
  * updates and the per-step prologues on feature rows kept as bf16 hi | lo -- 7 launches per encode instead of ~60.  OPT-IN: process default 0
- * (SF_SLOT_CHAIN=1 or sf_set_slot_chain(1)).  Measured (profiles/r06_probes.txt): 0.80 ms per batch of 32 videos x 6 frames on 32 CUs against 0.58 ms for
+ * (sf_set_slot_chain(1)).  Measured (profiles/r06_probes.txt): 0.80 ms per batch of 32 videos x 6 frames on 32 CUs against 0.58 ms for
  * the per-iteration launches on the whole chip and 1.2 ms on a 128-CU partition -- fewer CU-ms, more latency; the default keeps the per-iteration launches.  Applies to the CLEVRER shape of the slot branch (slot size 128, slot MLP 256,
  * residual-MLP predictor, single-Linear kernel distribution, folded Slot Attention, up to 8 slots, HW a multiple of 256); everything else keeps the
  * per-iteration launches.  The two forms agree to split-bf16 rounding (the attention products are split-bf16 here, exact f32 there). */

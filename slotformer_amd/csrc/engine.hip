@@ -655,16 +655,10 @@ int sf_rollout_bf16(const sf_rollouter* m, float* slots, int B, int T_total, int
 // ---------------------------------------------------------------------------------------------
 static int enc_chunk(int B) { return B < 32 ? B : 32; }
 
-// the slot branch of a batched encode as one video-stationary launch (slot_chain.hip): OPT-IN (sf_set_slot_chain(1) / SF_SLOT_CHAIN=1); the default keeps
+// the slot branch of a batched encode as one video-stationary launch (slot_chain.hip): OPT-IN (sf_set_slot_chain(1)); the default keeps
 // the per-iteration launches (Slot-Attention iteration over the batch + slot update), which are faster for a batch alone on its CUs
-static int g_slot_chain = -1;
-int sf_get_slot_chain(void) {
-  if (g_slot_chain < 0) {
-    const char* e = getenv("SF_SLOT_CHAIN");
-    g_slot_chain = (e && e[0] == '1') ? 1 : 0;   // (opt-in: measured slower than the per-iteration launches inside sf_savi_encode_*, profiles/r06_probes.txt)
-  }
-  return g_slot_chain;
-}
+static int g_slot_chain = 0;
+int sf_get_slot_chain(void) { return g_slot_chain; }
 int sf_set_slot_chain(int on) {
   g_slot_chain = on ? 1 : 0;
   return 0;

@@ -262,6 +262,8 @@ class EncodeRolloutPipeline:
     split: True = the encode in two halves where the model allows it (image features on the encode lane, the slot branch of a whole unit as one
     video-stationary launch behind the features of its last batch: csrc/slot_chain.hip; agrees with the default to split-bf16 rounding, ~5e-6);
     None / False (default) = the whole encode on the lane -- measured faster (profiles/r06_probes.txt: the pipeline is bound by its rollout units).
+    chain_on: with split, where a unit's slot branch runs: 'enc' (behind the features of its last batch, on that batch's stream) or 'roll' (at the head
+    of the unit's rollout graph).
     decoder: module holding the SAVi decoder weights (StoSAVi / SlotFormer); enables run(..., decoded={...}): the predicted frames of
     every batch decoded to reconstruction + segmentation behind its rollout, on an unmasked stream of its own (the decode is 12x the
     FLOPs of encode + rollout at C2: it bounds such a run, the other two stages hide beside it).  seg_dtype: uint8 (default) or int64.
@@ -269,7 +271,7 @@ class EncodeRolloutPipeline:
 
     def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=None, use_graph=True,
                  partition='pair', group=None, rollout_opts=None, encode_graph=None, hybrid=None, decoder=None, seg_dtype=torch.uint8,
-                 encode_fork=None, tok=None, split=None):
+                 encode_fork=None, tok=None, split=None, chain_on='enc'):
         self.savi, self.roll = savi, rollouter
         # optional third stage (row N2; video_prediction/test_vp.py:55-63,145-146 -> slotformer.py:244-259 -> savi.py:504-525 ->
         # vp_utils.py:20-41): the predicted frames of every batch are decoded behind its rollout -- spatial-broadcast decoder, softmax
@@ -375,15 +377,15 @@ class EncodeRolloutPipeline:
         # The encode in two halves (round 6, csrc/slot_chain.hip): the image features of a batch on the encode lane (five dense launches), the slot
         # branch of a WHOLE rollout unit as one video-stationary launch in front of the unit's rollout, on the rollout stream -- one workgroup per video
         # for ~0.6 ms, which on the lane left 96 of its 128 CUs idle while nothing else could start.  Where the model's slot branch has that form
-        # (engine.savi_chain_ok) and the partition is 'pair'.  OPT-IN (split=True / SF_PIPE_SPLIT=1): the encode lane gets 22 % faster (2.83 -> 2.2 ms per
+        # (engine.savi_chain_ok) and the partition is 'pair'.  OPT-IN (split=True; bench.py --split): the encode lane gets 22 % faster (2.83 -> 2.2 ms per
         # C2 batch) but the rollout units, already slowed 25-40 % by whatever else runs on the chip, become the bound: 577 k against 626 k frames/s at 100
         # batches (profiles/r06_probes.txt).
-        want_split = (os.environ.get('SF_PIPE_SPLIT', '0') == '1') if split is None else bool(split)
+        want_split = bool(split)
         self.split = bool(want_split and partition == 'pair' and self.fused and engine.savi_chain_ok(savi, self.B, self.T))
         self._with_noise = engine.kernel_noise(self.savi, torch.empty(0), 1, self.T, self.dev) is not None   # (no draw: the gate only)
         # where the slot branch of a unit runs: 'enc' = behind the features of the unit's last batch, on that batch's stream (the encode side);
         # 'roll' = at the head of the unit's rollout graph (the rollout stream)
-        self.chain_on = os.environ.get('SF_PIPE_CHAIN_ON', 'enc')
+        self.chain_on = 'roll' if chain_on == 'roll' else 'enc'
         if self.split:
             self.steal = 0.0   # (no stolen convolutions: the feature half IS the lane's work)
         self._plan = None

@@ -1,4 +1,4 @@
-"""Every SF_* environment variable the library, the pipeline and bench.py read, with what it does (eighteen; the round-4 tree had seventy).  bench.py
+"""Every SF_* environment variable the library, the pipeline and bench.py read, with what it does (fifteen; the round-4 tree had seventy).  bench.py
 refuses to run with an SF_* variable that is not in this table and prints the ones that are set in `config.switches` of its line; INTEGRATION.md
 section 5 is generated from it (python -m slotformer_amd.switches).  Everything else that used to be an environment probe is either gone with the form
 it selected (measured dead: profiles/r02..r05_probes.txt) or a keyword argument / command-line flag of the object it belongs to
@@ -12,11 +12,8 @@ SWITCHES = {
     'SF_SEAM_FUSED': ('product', "process default of the seam launches of the latency forms (1; 0: two launches instead)"),
     'SF_CONV_FP16X2': ('product', "OPT-IN two-product fp16 form of the 5x5 convolutions (weights rounded to fp16: 3-6e-5 from the fixtures instead of 1e-5); default 0"),
     'SF_CONV_WS': ('product', "0: the 4-row-tile convolution everywhere (default 1: the weights-stationary kernel on streams with CUs of their own; the same bits)"),
-    'SF_SLOT_CHAIN': ('product', "OPT-IN 1: the slot branch of a batched encode as one video-stationary launch (csrc/slot_chain.hip: one workgroup per video; fewer CU-ms, more latency); default 0: per-iteration launches over the batch"),
     'SF_ENCODE_FORK': ('product', "direct encode calls as two branches on two streams (1, default) or one stream (0)"),
     # ---- the batch pipeline ----
-    'SF_PIPE_SPLIT': ('product', "OPT-IN 1: the pipeline runs the encode in two halves (image features on the lane, the slot branch of a whole rollout unit as one video-stationary launch); default 0: the whole encode on the lane (measured faster: profiles/r06_probes.txt)"),
-    'SF_PIPE_CHAIN_ON': ('product', "with the encode in two halves: 'enc' (default) = the slot branch of a unit behind the features of its last batch on the encode side, 'roll' = at the head of the unit's rollout graph"),
     'SF_PIPE_TOK': ('product', "0: the pipeline never uses the token-stationary layer launches (every unit bit-identical to the serial module calls)"),
     'SF_PIPE_GROUP': ('product', "batches per rollout unit (default: 6 for token-stationary units of 32-video batches, else 4 / unit_batches_for)"),
     'SF_PIPE_HYBRID': ('product', "every k-th batch behind the fill is encoded on an unmasked stream beside the CU-masked lane (default 4 with token-stationary units, 3 / 5 / 0 otherwise)"),

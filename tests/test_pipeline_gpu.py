@@ -497,13 +497,12 @@ def test_harness_edge_counts(dev):
 
 
 @pytest.mark.parametrize('chain_on,nbatch', [('enc', 14), ('roll', 9)])
-def test_pipeline_with_the_encode_in_two_halves(dev, monkeypatch, chain_on, nbatch):
+def test_pipeline_with_the_encode_in_two_halves(dev, chain_on, nbatch):
     """EncodeRolloutPipeline(split=True) (opt-in): image features of a batch on the encode lane (sf_savi_features_planes_f32), the slot branch of a whole rollout
     unit as ONE video-stationary launch (sf_savi_slots_chain_f32, csrc/slot_chain.hip) behind the features of its last batch (`enc`) or at the head of its
     rollout graph (`roll`).  Bit for bit with the serial schedule of the same object; 2e-5 from the default pipeline (split-bf16 rounding of the attention
     products: 5e-6 measured on the encoded frames); with injected kernel noise; a run that ends in a short unit."""
     from slotformer_amd.pipeline import EncodeRolloutPipeline
-    monkeypatch.setenv('SF_PIPE_CHAIN_ON', chain_on)
     B, T, H = 32, 6, 12
     savi, roll = _models(dev, gu.C2_SAVI, gu.C2_ROLL)
     rs = np.random.RandomState(11)
@@ -515,7 +514,7 @@ def test_pipeline_with_the_encode_in_two_halves(dev, monkeypatch, chain_on, nbat
         ref = base.run(imgs, noises)
         torch.cuda.synchronize()
         base.close()
-        pipe = EncodeRolloutPipeline(savi, roll, B, T, H, split=True)
+        pipe = EncodeRolloutPipeline(savi, roll, B, T, H, split=True, chain_on=chain_on)
         assert pipe.split and pipe.chain_on == chain_on and pipe.units[0].planes is not None
         out = pipe.run(imgs, noises)
         torch.cuda.synchronize()

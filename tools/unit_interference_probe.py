@@ -4,7 +4,6 @@ import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault('SF_PIPE_SPLIT', '0')
 import torch  # noqa: E402
 import bench  # noqa: E402
 from slotformer_amd import engine, ops, _lib  # noqa: E402
