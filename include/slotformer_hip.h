@@ -386,7 +386,7 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
 
 /* Per-call options of a rollout: they apply to THIS call on the calling thread only (thread-local inside the library; the
  * reference drives forward() from one host thread per GPU, base_slots/extract_slots.py:128), whereas sf_set_precision /
- * sf_set_seam_fused / sf_set_ffn_rows64 set process-wide DEFAULTS.  Every choice is bit-identical except `precision`. */
+ * sf_set_seam_fused / sf_set_ffn_rows64 set process-wide DEFAULTS.  Every choice is bit-identical except `precision` and `layer_tok` (see there). */
 typedef struct {
   int precision;    /* -1: default; 0 exact f32, 1 split-bf16, 2 single-pass bf16 (= sf_rollout_bf16), 3 single-pass fp16 (a
                      * measurement probe: the linear layers on one fp16 MFMA per product, profiles/r03_probes.txt) */
@@ -407,7 +407,7 @@ typedef struct {
                       * the workgroup, the next attention block is its core launch alone (one launch less per layer, the same bits) */
   int cus_available; /* 0: the whole chip; else the number of CUs the call's stream may use (its CU mask).  Seam launches hand rows over inside
                       * a grid and need every workgroup of it resident at once: they are used only when the grid fits min(160, cus_available) */
-  int layer_tok;     /* 0: default (sf_set_layer_tok / SF_LAYER_TOK; on); 1 / -1: on / off.  On (and every layer before the last has tok_packed, windows
+  int layer_tok;     /* 0: the process default (sf_set_layer_tok / SF_LAYER_TOK=1; OFF unless set); 1 / -1: on / off.  On (and every layer before the last has tok_packed, windows
                       * of <= 64 tokens): those layers run as ONE token-stationary launch each (csrc/layer_tok.hip) -- a 128-token workgroup owns whole
                       * videos, every product of the layer keeps its activations in registers -- instead of an attention-core launch per video plus an
                       * FFN + q|k|v launch per 64-row tile; the row-pruned last layer keeps the row-tile forms.  Not bit-identical to the other forms
@@ -418,7 +418,8 @@ int sf_get_layer_tok(void);
 int sf_rollout_opts_f32(const sf_rollouter* m, float* slots, int B, int T_total, int pred_len, void* ws, size_t ws_bytes,
                         void* stream, const sf_rollout_opts* opts); /* opts == NULL: sf_rollout_f32 */
 /* 1 when sf_rollout_f32 runs this model's Transformer layers as the fused per-video / per-row launches (d_model 256, 8 heads,
- * ffn 1024, window <= 64 tokens, packed weights, split-bf16 mode): a video's result then does not depend on the batch it is in */
+ * ffn 1024, window <= 64 tokens, packed weights, split-bf16 mode): a video's result then does not depend on the batch it is in -- bit for bit in the
+ * row-tile / latency forms; with layer_tok on, to ~1e-6 per layer (a video's last bits depend on its position modulo the videos of a workgroup) */
 int sf_rollout_is_fused(const sf_rollouter* m);
 /* 1 when the layers before the last can run as token-stationary launches (sf_rollout_opts.layer_tok): fused-layer path, tok_packed on those layers,
  * every window of the rollout within the kernel's limits */

@@ -23,6 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+extern "C" int sf_get_conv_fp16x2(void);
 namespace {
 constexpr int CH = 64, KS = 5, TW = 64, NTAP = KS * KS;
 constexpr int HWD = TW + KS - 1;                  // 68 pixels per halo row
@@ -323,6 +324,8 @@ __global__ __launch_bounds__(NT) void conv5x5_ws_kernel(CwArgs A) {
 int sf_conv5x5_ws_ex(const float* in, const void* w_frag, const float* bias, const float* add, float* out, int F, int H, int W, int Cin, int Cout, int ks,
                      int relu, int n_workgroups, hipStream_t st) {
   if (!w_frag || W != TW || Cin != CH || Cout != CH || ks != KS || H < 1 || F <= 0 || relu < 0 || relu > 1 || sf_get_precision() != 1) return 1;
+  // (the opt-in two-product fp16 arithmetic lives in the 4-row-tile kernel only: with it on, every stream takes that kernel -- one arithmetic per process)
+  if (sf_get_conv_fp16x2()) return 1;
   static const int dbg = sf_dbg("conv");
   const long long rows = (long long)F * H;
   int nwg = n_workgroups;

@@ -531,7 +531,7 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
 // Seam launches on / off (default: on unless SF_SEAM_FUSED=0).  A seam launch saves a kernel boundary on the critical path of
 // ONE rollout chain; its 128 consumer workgroups spin until the 28 producers are done, which is CU time a second chain running
 // on the same CUs could use -- the 'pair' pipeline captures its graphs with the seam off.
-// Process default of the token-stationary layer launches (sf_rollout_opts.layer_tok == 0): on unless SF_LAYER_TOK=0
+// Process default of the token-stationary layer launches (sf_rollout_opts.layer_tok == 0): OFF unless SF_LAYER_TOK=1 / sf_set_layer_tok(1)
 static int g_layer_tok = -1;
 extern "C" int sf_get_layer_tok(void) {
   if (g_layer_tok < 0) {

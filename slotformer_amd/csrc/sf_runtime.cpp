@@ -120,18 +120,18 @@ int sf_stream_create_cu_mask(void** stream_out, const unsigned int* cu_mask, int
 
 // CUs a launch on `stream` may occupy: the popcount of the mask of a stream made by sf_stream_create_cu_mask, else the whole device
 int sf_stream_cus(void* stream) {
-  static int dev_cus = 0;
-  {
-    std::lock_guard<std::mutex> lk(g_stream_mu);
-    auto it = g_stream_cus.find(stream);
-    if (it != g_stream_cus.end() && it->second > 0) return it->second;
-  }
-  if (!dev_cus) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) dev_cus = n;
-    else dev_cus = 256;
-  }
-  return dev_cus;
+  static std::map<int, int> dev_cus;   // CU count per device (a host thread may drive several GPUs), under g_stream_mu
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  auto it = g_stream_cus.find(stream);
+  if (it != g_stream_cus.end() && it->second > 0) return it->second;
+  auto dc = dev_cus.find(dev);
+  if (dc != dev_cus.end()) return dc->second;
+  int n = 0;
+  if (!(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)) n = 256;
+  dev_cus[dev] = n;
+  return n;
 }
 
 // 0 for a stream the library knows nothing about (sf_stream_cus answers the whole device for those)

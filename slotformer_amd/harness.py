@@ -128,7 +128,8 @@ def extract_and_rollout(savi, rollouter, videos, pred_len, batch_size=32, noises
     N, D = rollouter.num_slots, rollouter.in_proj.in_features
     out = torch.empty(V, T + pred_len, N, D, pin_memory=True) if to_host else torch.empty(V, T + pred_len, N, D, device=dev)
     # small batches are handed to the pipeline several at a time (pipeline.encode_group_for: the latency-bound slot branch of an encode costs the
-    # same for 16 videos as for 32); the kernels are per video, so the slots do not depend on the grouping
+    # same for 16 videos as for 32); the kernels are per video, so the slots do not depend on the grouping in the row forms
+    # (token-stationary units of >= 96 videos: to ~5e-6)
     from .pipeline import encode_group_for
     # (encode_group: None = that rule; 1 = every batch by itself; the rule depends on V only through 'does the run leave >= 8 pipeline batches')
     if encode_group is None:

@@ -800,15 +800,18 @@ class EncodeRolloutPipeline:
                 lane_cus = int(self._lib.sf_stream_cus(None))
             if lane_cus:
                 self._lib.sf_stream_set_cus(C.c_void_p(side.cuda_stream), lane_cus)
-            with torch.cuda.stream(side):
-                engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws, side_stream=side2)   # workspace, plans
-                side.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with _lib.CAPTURE_GATE, torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
-                    post, _, _ = engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws, side_stream=side2)
-            cur.wait_stream(side)
-            if lane_cus:
-                self._lib.sf_stream_set_cus(C.c_void_p(side.cuda_stream), 0)
+            try:
+                with torch.cuda.stream(side):
+                    engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws, side_stream=side2)   # workspace, plans
+                    side.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with _lib.CAPTURE_GATE, torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
+                        post, _, _ = engine.savi_encode(self.savi, eg['img'], noise=eg['noise'], feat_pre=eg['feat'], ws_slot=ws, side_stream=side2)
+                cur.wait_stream(side)
+            finally:
+                # (a failed capture must not leave a CU count keyed by a stream handle torch hands out again)
+                if lane_cus:
+                    self._lib.sf_stream_set_cus(C.c_void_p(side.cuda_stream), 0)
             eg['graph'], eg['post'] = g, post
             self._enc_graphs[key] = eg
         return eg

@@ -111,4 +111,4 @@ def test_rollout_with_layer_tok_vs_reference_fixture(dev, name, cfg, B, pred_len
     engine.rollout(m.rollouter, other, T_in, pred_len, opts={'layer_tok': False})
     d = ((buf - other).abs().max() / ref.abs().max()).item()
     print(name, 'token-stationary layers vs the reference fixture', e, ' vs the default forms', d)
-    assert e < 2e-4 and 0 < d < 5e-5
+    assert e < 5e-5 and 0 < d < 5e-5   # (the reference fixtures: 5e-5 like the encode fixtures; measured 9e-6 .. 3.5e-5)
