@@ -467,7 +467,8 @@ def main():
     ap.add_argument('--live-every', type=int, default=4, help='bracket every n-th conv / Slot-Attention launch with events in the untimed live pass')
     ap.add_argument('--live-mask', type=int, default=(1 << 0) | (1 << 3), help='kernel classes of that pass')
     ap.add_argument('--allow-stale-trace', action='store_true', help='use the committed rocprof summary although the kernel sources changed')
-    ap.add_argument('--windows', type=int, default=5, help='timed windows of --steps steps each on the warm pipeline; value = the median window')
+    ap.add_argument('--windows', type=int, default=5, help='timed windows (at least) of --steps steps each on the warm pipeline; value = the median window')
+    ap.add_argument('--min-timed-s', type=float, default=1.0, help='keep adding windows until the timed region holds this many seconds (0: exactly --windows)')
     args = ap.parse_args()
 
     if (args.gpus > 1 or args.self_launch) and 'WORLD_SIZE' not in os.environ:
@@ -572,7 +573,17 @@ def main():
         # R timed windows on the same warm pipeline, each EXACTLY args.steps steps bracketed by barrier + synchronize on both
         # sides; `value` / `ms_per_step` come from the MEDIAN window, p10 / p90 over the windows beside it
         windows, unit_gaps = [], []
-        for w in range(max(1, args.windows)):
+        # at least --windows windows, and (unless --windows was given) as many more as it takes for the timed region to reach --min-timed-s seconds:
+        # the count is agreed between the ranks (rank 0's clock) so that every rank runs the same number of windows
+        w = 0
+        while True:
+            if w >= max(1, args.windows):
+                more = torch.tensor([1.0 if (sum(windows) < args.min_timed_s and w < 64) else 0.0], device=dev)
+                if use_dist:
+                    dist.broadcast(more, 0)
+                if more.item() == 0.0:
+                    break
+            w += 1
             barrier()
             t0 = time.perf_counter()
             run(args.steps, out_t)
@@ -833,12 +844,16 @@ def main():
             fl = iso['work'] / iso['launches']
             pm = committed_profile(key) if args.config == 'C2' else {}
             us_trace = pm.get('avg_launch_us_trace')
-            us = us_trace or (live or iso)['avg_us']
+            us_ev = (live or iso)['avg_us']          # measured in THIS run: HIP events around the launches, live in the pipeline where it has them
+            us = us_ev
             tf = fl / (us * 1e-6) / 1e12
+            tf_trace = fl / (us_trace * 1e-6) / 1e12 if us_trace else None
             objs[key] = {
                 'kernel': name, 'bound': 'mfma', 'achieved': tf, 'peak': peak_chip, 'unit': 'TFLOP/s', 'frac': tf / peak_chip,
                 'peak_note': peak_note + '; whole-chip roof',
-                # (`frac` is the average over the launches of the kernel CLASS; this key is the class's longest kernel alone where the committed trace lists it)
+                # `frac` / `achieved` / `avg_launch_us`: this run's HIP events (eager launches beside the running pipeline); the committed rocprof trace of
+                # graph replays beside them (`*_rocprof`)
+                'frac_rocprof': tf_trace / peak_chip if tf_trace else None, 'achieved_rocprof': tf_trace,
                 'frac_dominant_kernel': tf / peak_chip if key == 'layer_tok' else None,
                 'flops_per_launch': fl, 'avg_launch_us': us,
                 'measured': ('flops_per_launch (mean over the launches of one rollout unit, library accounting) / avg_launch_us_rocprof = the mean graph-replay '
@@ -856,7 +871,9 @@ def main():
                 'launches_per_unit': iso['launches'], 'rows_per_launch_full_window': G * Bp * W_FR * N_SLOTS,
                 'cus_available': pipe.rollout_cus if pipe.cu_split else 256,
                 **({'workgroups_per_launch': -(-G * Bp // max(128 // (W_FR * N_SLOTS), 1)),
-                    'frac_of_occupied_cus': tf / (peak_chip * min(256, -(-G * Bp // max(128 // (W_FR * N_SLOTS), 1))) / 256.0)} if key == 'layer_tok' else {}),
+                    'frac_of_occupied_cus': tf / (peak_chip * min(256, -(-G * Bp // max(128 // (W_FR * N_SLOTS), 1))) / 256.0),
+                    'frac_of_occupied_cus_rocprof': (tf_trace / (peak_chip * min(256, -(-G * Bp // max(128 // (W_FR * N_SLOTS), 1))) / 256.0)) if tf_trace else None}
+                   if key == 'layer_tok' else {}),
                 'traffic': pm.get('traffic_bytes_per_launch'),
                 'mfma_busy_frac': pm.get('mfma_busy_frac'), 'pmc_source': pm.get('source'),
                 'limiter': ('one wave per SIMD issuing ~4900 MFMAs per layer at ~45 cycles each against the pipe\'s 32: per 32 KB weight stage (48 MFMAs) one workgroup barrier, '

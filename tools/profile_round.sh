@@ -10,9 +10,9 @@ cd $R
 timeout 900 python bench.py --steps 40 --warmup 6 --breakdown --decode > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.log
 tail -c 600 $OUT/${TAG}_bench.json | head -c 300; echo
 cd /tmp && export TMPDIR=/tmp
-# the default bench command (hipGraph rollout, CU-partitioned pipeline), minus the CPU leg, so that the traced kernel
-# durations are the ones the bench line reports
-BENCH="python $R/bench.py --steps 8 --warmup 4 --no-cpu-baseline --decode --decode-steps 2"
+# the driver's bench command itself (--steps 20 --warmup 5: hipGraph rollout units, CU-partitioned pipeline; no decode stage), minus the CPU leg and
+# with three timed windows, so that the traced kernel durations and device-time shares are those of the headline's timed region
+BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --windows 3 --min-timed-s 0"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o trace -- $BENCH > $OUT/${TAG}_trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o pmc -- $BENCH > $OUT/${TAG}_pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o pmc -- $BENCH > $OUT/${TAG}_pmc_write.log 2>&1
@@ -29,7 +29,7 @@ import bench
 tag = sys.argv[1]
 fs = glob.glob(f'gpurun_out/{tag}_pmc_sq/**/*counter_collection.csv', recursive=True)
 print('# rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES (one pass, counters only)')
-print(f'# of python bench.py --steps 8 --warmup 4 --no-cpu-baseline --decode --decode-steps 2 [tools/profile_round.sh]; per-dispatch averages over the named kernel\'s launches (source tree {bench.source_tree_hash()}).')
+print(f'# of python bench.py --steps 20 --warmup 5 --no-cpu-baseline --windows 3 --min-timed-s 0 [tools/profile_round.sh]; per-dispatch averages over the named kernel\'s launches (source tree {bench.source_tree_hash()}).')
 print('# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves, SQ_VALU_MFMA_BUSY_CYCLES cycles summed over SIMDs, SQ_LDS_* LDS-array cycles summed over CUs (MI355X_MICROARCH.md).')
 if fs:
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
