@@ -22,7 +22,7 @@ def find(d, pat):
 lines = []
 f = find(f'{tag}_trace', '*kernel_stats.csv')
 if f:
-    lines.append(f'# rocprofv3 --kernel-trace --stats  (bench.py --steps 20 --warmup 5 --no-cpu-baseline --windows 3 --min-timed-s 0: the driver's command -- the default hipGraph + CU-partitioned pipeline, no decode stage)  [{os.path.basename(f)}]')
+    lines.append(f'# rocprofv3 --kernel-trace --stats  (bench.py --steps 20 --warmup 5 --no-cpu-baseline --windows 3 --min-timed-s 0: the command the driver runs -- the default hipGraph + CU-partitioned pipeline, no decode stage)  [{os.path.basename(f)}]')
     lines.append(f'{"kernel":72s} {"calls":>7s} {"total_us":>12s} {"avg_us":>10s} {"pct":>6s}')
     for r in csv.DictReader(open(f)):
         lines.append(f'{short(r["Name"]):72s} {r["Calls"]:>7s} {float(r["TotalDurationNs"]) / 1e3:12.1f} '
