@@ -643,6 +643,11 @@ int sf_get_encode_fuse_next(void);
  * per-iteration launches.  The two forms agree to split-bf16 rounding (the attention products are split-bf16 here, exact f32 there). */
 int sf_set_slot_chain(int on);
 int sf_get_slot_chain(void);
+/* The Slot-Attention iterations of sf_savi_encode_* (folded form, slot size 128, 4096 pixels) on feature rows kept as bf16 hi | lo: logits and weighted sums as
+ * split-bf16 v_mfma_f32_16x16x32_bf16 products (sa_attn_planes_kernel, csrc/slot_chain.hip) instead of exact-f32 16x16x4 MFMAs on f32 rows
+ * (sa_attn_tile_kernel) -- a third of the matrix-pipe time, the same records, split-bf16 rounding apart (~5e-6).  Process default 1; 0: the f32 rows. */
+int sf_set_slot_attn_planes(int on);
+int sf_get_slot_attn_planes(void);
 /* The encode in two halves, for callers that overlap them (the batch pipeline: features on the encode lane, the slot branch of a whole rollout unit in
  * front of its rollout).  sf_savi_chain_ok: 1 when both apply to this model at B videos x T frames (the conditions of sf_set_slot_chain above).
  *   sf_savi_features_planes_f32: CNN + encoder_out_layer + SlotAttention.norm_inputs (savi.py:231-250, 66) of B x T frames -> planes [T][B][64 * 64] rows

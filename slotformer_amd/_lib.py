@@ -247,6 +247,8 @@ SIGNATURES = {
     'sf_get_encode_fuse_next': (I, []),
     'sf_set_slot_chain': (I, [I]),
     'sf_get_slot_chain': (I, []),
+    'sf_set_slot_attn_planes': (I, [I]),
+    'sf_get_slot_attn_planes': (I, []),
     'sf_savi_chain_ok': (I, [C.POINTER(sf_savi_encoder), I, I]),
     'sf_savi_planes_bytes': (SZ, [C.POINTER(sf_savi_encoder), I, I]),
     'sf_savi_features_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I, I]),

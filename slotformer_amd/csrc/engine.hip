@@ -659,6 +659,14 @@ static int enc_chunk(int B) { return B < 32 ? B : 32; }
 // the per-iteration launches (Slot-Attention iteration over the batch + slot update), which are faster for a batch alone on its CUs
 static int g_slot_chain = 0;
 int sf_get_slot_chain(void) { return g_slot_chain; }
+// the Slot-Attention iterations of the per-step encode on feature rows kept as bf16 hi | lo (sa_attn_planes_kernel, slot_chain.hip: split-bf16 16x16x32
+// MFMAs) instead of f32 rows and the exact-f32 tile kernel: process default below; sf_set_slot_attn_planes(0 / 1)
+static int g_sa_planes = 1;
+int sf_get_slot_attn_planes(void) { return g_sa_planes; }
+int sf_set_slot_attn_planes(int on) {
+  g_sa_planes = on ? 1 : 0;
+  return 0;
+}
 int sf_set_slot_chain(int on) {
   g_slot_chain = on ? 1 : 0;
   return 0;
@@ -1010,6 +1018,8 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
   const bool feat192 = m->enc_channels[m->enc_layers] == 64 && Ce == 192 && m->enc_fc1_p && m->enc_fc2_p;
   const bool fold = sf_get_precision() >= 1 && m->sa_fold_q_w && m->sa_fold_q_w_t && m->sa_fold_gru_ih_t && Ce == D &&
                     (sf_pixel_mlp_feat_ok(m->enc_channels[m->enc_layers], Ce) || feat192);
+  const bool sa_planes = fold && !feat192 && sf_get_slot_attn_planes() && sf_slot_attn_planes_ok(HW, D, N) && m->enc_channels[m->enc_layers] == 64 &&
+                         P == HW / 256;
   const float* q_w = fold ? m->sa_fold_q_w : m->sa_q_w;
   const float* q_w_t = fold ? m->sa_fold_q_w_t : m->sa_q_w_t;
   const float* gru_ih_t = fold ? m->sa_fold_gru_ih_t : m->gru_w_ih;
@@ -1078,6 +1088,11 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
       if (fold && feat192) {
         SF_TRY(sf_pixel_mlp_feat192_ex(cur, m->enc_ln_g, m->enc_ln_b, m->enc_fc1_p, m->enc_fc1_b, m->enc_fc2_p, m->enc_fc2_b,
                                        m->sa_norm_in_g, m->sa_norm_in_b, kv + (long long)b0 * HW * Ce, Mp, ln_eps, st));
+        continue;
+      }
+      if (fold && sa_planes) {   // rows of 512 B (bf16 hi | lo): what sa_attn_planes_kernel streams
+        SF_TRY(sf_pixel_mlp_feat_planes_ex(cur, m->enc_ln_g, m->enc_ln_b, m->enc_fc1_w, m->enc_fc1_b, m->enc_fc2_w, m->enc_fc2_b, m->sa_norm_in_g, m->sa_norm_in_b,
+                                           (char*)kv + (size_t)b0 * HW * 512, Mp, ln_eps, st));
         continue;
       }
       if (fold) {
@@ -1207,7 +1222,9 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
     for (int it = 0; it < m->num_iterations; ++it) {
       const bool last_it = (it == m->num_iterations - 1);
       float* aout = (attn && last_it) ? attn + (long long)t * N * HW : nullptr;
-      if (fold)   // keys = values = the normalised features (q is Wk^T q here, the GRU input matrix is W_ih Wv)
+      if (fold && sa_planes)   // the same iteration on the bf16 hi | lo rows (split-bf16 MFMAs; the same records)
+        SF_TRY(sf_slot_attn_planes_ex(kv, HW, q, pnum, pden, aout, (long long)T * N * HW, B, HW, N, scale, m->sa_eps, st));
+      else if (fold)   // keys = values = the normalised features (q is Wk^T q here, the GRU input matrix is W_ih Wv)
         SF_TRY(sf_slot_attn_iter_ex(kv, kv, Ce, (long long)HW * Ce, q, pnum, pden, aout, (long long)T * N * HW, B, HW, N, D, scale,
                                     m->sa_eps, st));
       else
@@ -1216,7 +1233,7 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
       if (su_mfma) {
         bool rode = false;
         // (the one-pass Slot-Attention kernel leaves every second partial record zero: the update reads the others -- eight, one round of requests)
-        const int p_step = (fold && P == HW / 256 && sf_slot_attn_sparse_records(kv, kv, HW, D)) ? 2 : 1;
+        const int p_step = (fold && P == HW / 256 && (sa_planes || sf_slot_attn_sparse_records(kv, kv, HW, D))) ? 2 : 1;
         const bool fuse_next = can_fuse_next && last_it && t + 1 < T && prologue == 0;
         if (fuse_next) {
           SfNextStep nx;

@@ -31,6 +31,11 @@ bool sf_slot_chain_ok(int D, int H, int HW, int N);
 int sf_slot_chain_ex(const void* feat_planes, int NB, int B, int T, int HW, int N, int iters, float scale, float eps, float ln_eps, float* slotsA, float* slotsB,
                      float* lat, float* q, float* post, long long post_bs, float* attn, const float* noise, float* kdist, const SfChainWeights* w,
                      hipStream_t st);
+// One Slot-Attention iteration of B frames as a batch-wide launch on rows of 512 B (bf16 hi | lo): split-bf16 16x16x32 MFMAs instead of the exact-f32 ones of
+// sa_attn_tile_kernel; the same records (slot size 128, HW a multiple of 512)
+bool sf_slot_attn_planes_ok(int HW, int D, int N);
+int sf_slot_attn_planes_ex(const void* planes, long long batch_stride_rows, const float* q, float* part_num, float* part_den, float* attn_out,
+                           long long attn_batch_stride, int B, int HW, int N, float scale, float eps, hipStream_t st);
 // encoder_out_layer + SlotAttention.norm_inputs (sf_pixel_mlp_feat_ex) with the result as bf16 hi | lo rows of 512 B: planes [M][256] bf16
 int sf_pixel_mlp_feat_planes_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
                                 const float* b2, const float* ln1_g, const float* ln1_b, void* planes, int M, float eps, hipStream_t st);

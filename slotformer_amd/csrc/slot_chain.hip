@@ -56,23 +56,22 @@ __device__ int sc_tsn;
 #define SCTS() do { } while (0)
 #endif
 
-// One Slot-Attention pass of ONE frame by the whole workgroup: record num [N][128], den [N] -> memory (plain stores; the caller's barrier orders them).
-//   frame: [HW][256] bf16 (hi 128 | lo 128 per pixel);  qg: [N][128] f32 queries (unscaled; LDS);  pnum / pden: the record (LDS);  attn: NULL or this frame's [N][HW] rows
-template <bool ATTN>
-__device__ __attribute__((noinline)) void sc_attend(const __bf16* __restrict__ frame, const float* qg, float scale, float eps, int HW, int N,
-                                                    float* pnum, float* pden, float* __restrict__ attn, char* smem, int rev) {
+// One Slot-Attention pass over `NW * ppw` pixels of ONE frame by a workgroup of NW waves: the sums num [N][128], den [N] of those pixels.
+//   frame: [HW][256] bf16 (hi 128 | lo 128 per pixel);  pix_base: the workgroup's first pixel, ppw: pixels per wave (a multiple of 32);
+//   qg: [N][128] f32 queries (unscaled);  pnum / pden: where the sums go;  attn: NULL or this frame's [N][HW] rows.
+//   GIO false (the slot chain): queries and record in LDS;  true (the batch-wide launch): both in memory, and a second, zeroed record behind the first
+//   (the slot update reads every second record: slot_update_body.h, pstep 2).
+template <bool ATTN, int NW, bool GIO>
+__device__ __forceinline__ void sc_attend_core(const __bf16* __restrict__ frame, const float* qg, float scale, float eps, int HW, int N, int pix_base, int ppw,
+                                               float* pnum, float* pden, long long zero_off_num, long long zero_off_den, float* __restrict__ attn, char* smem,
+                                               int rev) {
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int i16 = lane & 15, kb = lane >> 4;
-  // (a non-inlined function receives even uniform arguments in vector registers: back into scalar registers)
-  HW = __builtin_amdgcn_readfirstlane(HW);
-  N = __builtin_amdgcn_readfirstlane(N);
-  rev = __builtin_amdgcn_readfirstlane(rev);
   SCTS();
   char* tile = smem + wave * SC_TILE;
-  __bf16* at = (__bf16*)(smem + SC_NW * SC_TILE + wave * SC_AT);
-  const int ppw = HW / SC_NW, ntiles = ppw / SC_TP;
-  const int pix0 = wave * ppw;
+  const int ntiles = ppw / SC_TP;
+  const int pix0 = pix_base + wave * ppw;
   // ---- rows: instruction u brings pixel rows 2 u and 2 u + 1 of a tile whole (512 B each: hi | lo); TWO tiles ahead in registers (one tile in flight per
   //      wave left the pass latency-bound: 2.2 us per tile, 60 GB/s per CU).  rev: the tiles in descending order -- the second iteration over a frame
   //      starts with the rows the first one read last (the ones still in this XCD's L2) ----
@@ -96,7 +95,7 @@ __device__ __attribute__((noinline)) void sc_attend(const __bf16* __restrict__ f
   typedef char __attribute__((address_space(3))) * lchr;
   typedef const bf16x8 __attribute__((address_space(3))) * lfrag;
   const lchr tileL = (lchr)tile;
-  const lflt atL = (lflt)(smem + SC_NW * SC_TILE + wave * SC_AT);   // attention tile a[pixel][slot] f32, pitch SC_ATP floats
+  const lflt atL = (lflt)(smem + NW * SC_TILE + wave * SC_AT);   // attention tile a[pixel][slot] f32, pitch SC_ATP floats
   // ---- queries as the A operand of the logits: lane (slot i = i16, k group kb) holds q[i][32 ks + 8 kb .. + 7] * scale * log2(e) (the softmax runs in
   //      base 2: one v_exp_f32 per value); zero beyond N slots ----
   // Slots 0-3 sit in rows 0-3 of the 16-row operand, slots 4-7 in rows 8-11: an accumulator then holds slots 0-3 in the lanes of 16-lane row 0 and
@@ -110,9 +109,15 @@ __device__ __attribute__((noinline)) void sc_attend(const __bf16* __restrict__ f
     for (int ks = 0; ks < 4; ++ks) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
       if (qslot < N) {
-        const lflt qp = qL + qslot * SC_D + 32 * ks + 8 * kb;
-        a = *(lvec)qp * s2;
-        b = *(lvec)(qp + 4) * s2;
+        const int qo = qslot * SC_D + 32 * ks + 8 * kb;
+        if constexpr (GIO) {
+          typedef const f32x4 __attribute__((address_space(1))) * gq;
+          a = *(gq)((const float __attribute__((address_space(1)))*)qg + qo) * s2;
+          b = *(gq)((const float __attribute__((address_space(1)))*)qg + qo + 4) * s2;
+        } else {
+          a = *(lvec)(qL + qo) * s2;
+          b = *(lvec)(qL + qo + 4) * s2;
+        }
       }
       sc_split8(a, b, qh[ks], ql[ks]);
     }
@@ -229,8 +234,8 @@ __device__ __attribute__((noinline)) void sc_attend(const __bf16* __restrict__ f
 #pragma unroll
   for (int r = 0; r < 4; ++r) den4[r] = sf_sum16(den4[r]);
   // ---- the eight waves' sums meet over the dead tiles: nacc[cb][r] = num[slot sl0 + r][channel 16 cb + i16] ----
-  float* red = (float*)smem;                                   // [8 waves][8 slots][REDP]
-  float* redd = red + SC_NW * 8 * SC_REDP;                     // [8 waves][8 slots]
+  float* red = (float*)smem;                                   // [NW waves][8 slots][REDP]
+  float* redd = red + NW * 8 * SC_REDP;                        // [NW waves][8 slots]
   __syncthreads();
   if (sl0 < 8) {   // (16-lane rows 0 and 2: slots 0-3 and 4-7)
 #pragma unroll
@@ -243,19 +248,40 @@ __device__ __attribute__((noinline)) void sc_attend(const __bf16* __restrict__ f
     for (int r = 0; r < 4; ++r) redd[wave * 8 + sl0 + r] = den4[r];
   }
   __syncthreads();
-  for (int idx = t; idx < N * SC_D; idx += SC_NT) {
+  for (int idx = t; idx < N * SC_D; idx += 64 * NW) {
     const int n = idx >> 7, d = idx & 127;
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < SC_NW; ++w) s += red[(w * 8 + n) * SC_REDP + d];
-    pnL[idx] = s;
+    for (int w = 0; w < NW; ++w) s += red[(w * 8 + n) * SC_REDP + d];
+    if constexpr (GIO) {
+      ((float __attribute__((address_space(1)))*)pnum)[idx] = s;
+      ((float __attribute__((address_space(1)))*)pnum)[zero_off_num + idx] = 0.f;
+    } else {
+      pnL[idx] = s;
+    }
   }
   if (t < N) {
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < SC_NW; ++w) s += redd[w * 8 + t];
-    pdL[t] = s;
+    for (int w = 0; w < NW; ++w) s += redd[w * 8 + t];
+    if constexpr (GIO) {
+      ((float __attribute__((address_space(1)))*)pden)[t] = s;
+      ((float __attribute__((address_space(1)))*)pden)[zero_off_den + t] = 0.f;
+    } else {
+      pdL[t] = s;
+    }
   }
+}
+
+// the chain's pass: the whole frame by the workgroup's eight waves, queries and record in LDS.  (A non-inlined function: see below; it receives even uniform
+// arguments in vector registers -- back into scalar registers.)
+template <bool ATTN>
+__device__ __attribute__((noinline)) void sc_attend(const __bf16* __restrict__ frame, const float* qg, float scale, float eps, int HW, int N, float* pnum,
+                                                    float* pden, float* __restrict__ attn, char* smem, int rev) {
+  HW = __builtin_amdgcn_readfirstlane(HW);
+  N = __builtin_amdgcn_readfirstlane(N);
+  rev = __builtin_amdgcn_readfirstlane(rev);
+  sc_attend_core<ATTN, SC_NW, false>(frame, qg, scale, eps, HW, N, 0, HW / SC_NW, pnum, pden, 0, 0, attn, smem, rev);
 }
 
 // The two phases are separate (non-inlined) functions: inlined into one kernel body the attention pass (two staged tiles: ~250 registers) and the update
@@ -367,6 +393,52 @@ __global__ __launch_bounds__(SC_NT) void slot_chain_kernel(ScArgs A) {
       s_out = tmp;
     }
   }
+}
+
+// ---- the same pass as a batch-wide launch (round 6): one Slot-Attention iteration of B frames on feature rows kept as bf16 hi | lo ----
+// sa_attn_tile_kernel (slot_attn.hip) runs logits and weighted sums as exact-f32 `16x16x4` MFMAs (256 flop per clock and CU, half of them on the zero rows that
+// pad 8 slots to 16): on a 128-CU partition it is bound by them (31 us for 32 frames against 21.5 on the whole chip).  Here the products are split-bf16
+// `16x16x32` MFMAs (a third of the pipe time) and the rows need no split inside the loop.  A workgroup of four waves owns 512 pixels of a frame (74 KB of LDS:
+// two workgroups per CU) and writes ONE record; the record behind it is zeroed (the slot update reads every second record: the launch replaces the tile
+// kernel without touching the update).
+constexpr int SP_NW = 4, SP_PIX = 512;
+constexpr size_t SP_LDS = (size_t)SP_NW * (SC_TILE + SC_AT);
+template <bool ATTN>
+__global__ __launch_bounds__(64 * SP_NW, 2) void sa_attn_planes_kernel(const __bf16* __restrict__ planes, long long batch_stride_rows, const float* __restrict__ q,
+                                                                       float scale, float eps, float* __restrict__ part_num, float* __restrict__ part_den,
+                                                                       float* __restrict__ attn, long long attn_bs, int HW, int N, int P) {
+  extern __shared__ __attribute__((aligned(16))) float sp_lds[];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const __bf16* frame = planes + (long long)b * batch_stride_rows * 256;
+  float* pn = part_num + (((long long)b * P + 2 * chunk) * N) * SC_D;
+  float* pd = part_den + ((long long)b * P + 2 * chunk) * N;
+  sc_attend_core<ATTN, SP_NW, true>(frame, q + (long long)b * N * SC_D, scale, eps, HW, N, chunk * SP_PIX, SP_PIX / SP_NW, pn, pd, (long long)N * SC_D, N,
+                                    ATTN ? attn + (long long)b * attn_bs : nullptr, (char*)sp_lds, 0);
+}
+
+bool sf_slot_attn_planes_ok(int HW, int D, int N) { return D == SC_D && HW % SP_PIX == 0 && N >= 1 && N <= 8; }
+
+// One Slot-Attention iteration of B frames from rows of 512 B (sf_pixel_mlp_feat_planes_ex): frame b at planes + b * batch_stride_rows rows; records as
+// sf_slot_attn_iter_ex writes them for keys == values at width 128 (P = HW / 256 per frame: sums in the even records, zeros in the odd ones).
+int sf_slot_attn_planes_ex(const void* planes, long long batch_stride_rows, const float* q, float* part_num, float* part_den, float* attn_out,
+                           long long attn_batch_stride, int B, int HW, int N, float scale, float eps, hipStream_t st) {
+  SF_REQUIRE(planes && q && part_num && part_den, "sf_slot_attn_planes_ex: null pointer");
+  SF_REQUIRE(sf_slot_attn_planes_ok(HW, SC_D, N) && B >= 0, "sf_slot_attn_planes_ex: slot size 128, HW a multiple of 512, at most 8 slots");
+  if (B == 0) return 0;
+  const int P = HW / 256;
+  sf_prof_begin(SF_K_SA_ITER, st, (double)B * HW * 512.0);
+  if (attn_out) {
+    SF_TRY(sf_ensure_dyn_lds((const void*)sa_attn_planes_kernel<true>, SP_LDS));
+    hipLaunchKernelGGL(sa_attn_planes_kernel<true>, dim3(HW / SP_PIX, B), dim3(64 * SP_NW), SP_LDS, st, (const __bf16*)planes, batch_stride_rows, q, scale, eps,
+                       part_num, part_den, attn_out, attn_batch_stride, HW, N, P);
+  } else {
+    SF_TRY(sf_ensure_dyn_lds((const void*)sa_attn_planes_kernel<false>, SP_LDS));
+    hipLaunchKernelGGL(sa_attn_planes_kernel<false>, dim3(HW / SP_PIX, B), dim3(64 * SP_NW), SP_LDS, st, (const __bf16*)planes, batch_stride_rows, q, scale, eps,
+                       part_num, part_den, nullptr, 0, HW, N, P);
+  }
+  sf_prof_end(SF_K_SA_ITER, st);
+  SF_CHECK_LAUNCH();
+  return 0;
 }
 
 bool sf_slot_chain_ok(int D, int H, int HW, int N) { return D == SC_D && H == UM_H && HW >= 256 && HW % (SC_NW * SC_TP) == 0 && N >= 1 && N <= 8; }

@@ -43,7 +43,7 @@ def test_bench_launches_its_own_ranks(dev):
     and `--gpus 2` on this box fails cleanly with a JSON line that says what is missing (exit code 0, no value)."""
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY='0')
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--windows', '2',
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--windows', '2', '--min-timed-s', '0',
                         '--no-cpu-baseline', '--self-launch'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')][-1])

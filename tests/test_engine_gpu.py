@@ -814,3 +814,37 @@ def test_slot_chain_matches_the_per_iteration_launches(dev):
         assert elementwise_close(post1, post0.cpu(), rtol=1e-4, floor=2e-5)
         for a, b in zip(outs[1], outs['masked']):
             assert torch.equal(a, b), (B, T, 'CU-masked stream')
+
+
+@torch.no_grad()
+def test_slot_attention_on_bf16_rows_matches_the_f32_rows(dev):
+    """sf_set_slot_attn_planes(1) (default): the Slot-Attention iterations of the encode as split-bf16 16x16x32 MFMA products on feature rows kept as bf16
+    hi | lo (sa_attn_planes_kernel) against exact-f32 products on f32 rows (0: sa_attn_tile_kernel) -- the same records, split-bf16 rounding apart.  Every encode
+    form (two branches, batched convolutions, precomputed features), B = 1 / 5 / 32, attention maps and kernel distribution compared; the fixtures hold either
+    (test_savi_golden runs the default)."""
+    from slotformer_amd import engine, _lib
+    from slotformer_amd.base_slots import build_model
+    lib = _lib.lib()
+    cfg = gu.C2_SAVI
+    torch.manual_seed(53)
+    m = build_model(gu.ParamsView(cfg)).eval().to(dev)
+    m.testing = True
+    N, D = cfg['slot_dict']['num_slots'], cfg['slot_dict']['slot_size']
+    side = torch.cuda.Stream(device=dev)
+    old = lib.sf_get_slot_attn_planes()
+    try:
+        for B, T, ss in ((5, 4, None), (1, 3, side), (32, 2, None), (3, 3, side)):
+            img = gu.seeded_img(B, T, 128, seed=141 + B).to(dev)
+            noise = engine.kernel_noise(m, gu.seeded_normal((B, T, N, D), 142).to(dev), B, T, dev)
+            outs = {}
+            for mode in (0, 1):
+                lib.sf_set_slot_attn_planes(mode)
+                outs[mode] = engine.savi_encode(m, img, noise=noise, want_attn=True, ws_slot=('sp', mode), side_stream=ss)
+                torch.cuda.synchronize()
+            e = [rel_err(a, b.cpu()) for a, b in zip(outs[1], outs[0])]
+            print(f'Slot Attention on bf16 rows vs f32 rows B={B} T={T}: post {e[0]:.2e} kdist {e[1]:.2e} attn {e[2]:.2e}')
+            assert not torch.equal(outs[0][0], outs[1][0]), 'the two settings ran the same kernels'
+            assert max(e) < 2e-5, (B, T, e)
+            assert elementwise_close(outs[1][0], outs[0][0].cpu(), rtol=1e-4, floor=2e-5)
+    finally:
+        lib.sf_set_slot_attn_planes(old)
