@@ -1038,6 +1038,7 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
   const bool can_fuse_next = sf_get_encode_fuse_next() && can_prologue && su_mfma && m->pm_w0_p && m->pm_w2_p && m->kd_w0_p && m->pm_ln_g && m->pm_ln_b && m->pm_b0 &&
                              m->pm_b2 && m->kd_b0;
   bool next_done = false;
+  const bool planes_all = false;
   if (batched) {
     // layer 0 per time step (the frames of one step lie T frames apart), every later layer over the B * T frames in [t][b] order; the last one
     // leaves the features of step t at big[2] + t * B * HW * Cl
@@ -1052,6 +1053,8 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
       SF_TRY(sf_conv2d_nchw_in_f32(img + (long long)t * frame_elems0, (long long)T * frame_elems0, m->conv_w[0], m->conv_b[0], nullptr,
                                    big[0] + (long long)t * B * HW * c1, B, m->enc_channels[0], res, res, c1, m->enc_ks, res == 128 ? 2 : 1, 1, st_main));
     SF_TRY(run_cnn_layers(m, nullptr, 0, B * T, big[2], big[0], big[1], 1, m->enc_layers, st_main));
+    // (the per-pixel chain stays per time step: as ONE launch for the B * T frames it takes 333 instead of 6 x 65 us on the lane, but the Slot-Attention
+    //  iterations then read their rows from HBM instead of the cache the launch in front of them left warm: 18.9 -> 20.8 us each -- no gain, probes r06)
     // ---- the slot branch of all T steps as ONE video-stationary launch (slot_chain.hip): the per-pixel chain of the B * T frames in one launch
     //      (feature rows as bf16 hi | lo), the prologue of step 0, then one workgroup per video ----
     if (sf_get_slot_chain() && enc_chain_model_ok(m)) {
@@ -1062,13 +1065,13 @@ int sf_savi_encode_fork_f32(const sf_savi_encoder* m, const float* img, const fl
     }
   }
   for (int t = 0; t < T; ++t) {
-    float* kv = kv_base + (size_t)(t % KV) * kv_step;
+    float* kv = planes_all ? (float*)((char*)planes + (size_t)t * B * HW * 512) : kv_base + (size_t)(t % KV) * kv_step;
     // ---- CNN encoder + per-pixel MLP + K/V for the B frames of step t ---------------------
     st = st_main;
     if (fork && t >= KV) {   // the ring slot is free once the slot branch of step t - KV has read it
       if (hipStreamWaitEvent(st_main, enc_fork_event(T + 1 + (t - KV)), 0) != hipSuccess) return sf_set_err((int)hipGetLastError(), "hipStreamWaitEvent", __FILE__, __LINE__);
     }
-    for (int b0 = 0; b0 < B; b0 += Bc) {
+    for (int b0 = 0; b0 < B && !planes_all; b0 += Bc) {
       const int nb = (B - b0 < Bc) ? (B - b0) : Bc;
       const int Cl0 = m->enc_channels[m->enc_layers];
       const float* cur;

@@ -466,7 +466,7 @@ class EncodeRolloutPipeline:
             # (units of more than 4 batches -- unit_batches_for: long runs of small batches -- make the rollouts cheaper per batch and the encode the
             #  bound by more: C4 with units of 7 at 84 batches, every 5th / 4th / 3rd / 2nd batch: 236.0 / 242.9 / 250.6 / 250.9 k)
             # (token-stationary units leave the rollout partition 40 % slack: every second batch -- C2 at 60 batches: 592 / 565 / 554 k with 2 / 3 / 4)
-            self.hybrid = int(os.environ.get('SF_PIPE_HYBRID', ('4' if self.tok else '3' if self.G > 4 else '5') if balanced else '0'))
+            self.hybrid = int(os.environ.get('SF_PIPE_HYBRID', ('6' if self.tok else '3' if self.G > 4 else '5') if balanced else '0'))
         self.hybrid_tail = min(self.hybrid, 3)
         self.fill_batches = int(os.environ.get('SF_PIPE_FILL', '0')) or (fill_units * self.G if partition == 'pair' else 0)
         self.fill_steal = 0
