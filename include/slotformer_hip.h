@@ -648,6 +648,11 @@ int sf_get_slot_chain(void);
  * (sa_attn_tile_kernel) -- a third of the matrix-pipe time, the same records, split-bf16 rounding apart (~5e-6).  Process default 1; 0: the f32 rows. */
 int sf_set_slot_attn_planes(int on);
 int sf_get_slot_attn_planes(void);
+/* The per-pixel chain of the encoder (encoder_out_layer + SlotAttention.norm_inputs, savi.py:245-250, 66; 64 -> 128 -> 128 channels) in its pixel-stationary
+ * form (pixel_feat_tok_kernel, csrc/pixel_mlp.hip: a wave owns 32 pixels for the whole chain, activations in registers, weights as fragments in LDS, no
+ * barrier behind the prologue).  Process default 1; 0: the tile kernels.  The two agree to split-bf16 rounding (different summation order). */
+int sf_set_pixel_tok(int on);
+int sf_get_pixel_tok(void);
 /* The encode in two halves, for callers that overlap them (the batch pipeline: features on the encode lane, the slot branch of a whole rollout unit in
  * front of its rollout).  sf_savi_chain_ok: 1 when both apply to this model at B videos x T frames (the conditions of sf_set_slot_chain above).
  *   sf_savi_features_planes_f32: CNN + encoder_out_layer + SlotAttention.norm_inputs (savi.py:231-250, 66) of B x T frames -> planes [T][B][64 * 64] rows

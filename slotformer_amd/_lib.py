@@ -249,6 +249,8 @@ SIGNATURES = {
     'sf_get_slot_chain': (I, []),
     'sf_set_slot_attn_planes': (I, [I]),
     'sf_get_slot_attn_planes': (I, []),
+    'sf_set_pixel_tok': (I, [I]),
+    'sf_get_pixel_tok': (I, []),
     'sf_savi_chain_ok': (I, [C.POINTER(sf_savi_encoder), I, I]),
     'sf_savi_planes_bytes': (SZ, [C.POINTER(sf_savi_encoder), I, I]),
     'sf_savi_features_workspace_bytes': (SZ, [C.POINTER(sf_savi_encoder), I, I]),

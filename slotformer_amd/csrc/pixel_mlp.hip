@@ -18,6 +18,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// the per-pixel chain in its pixel-stationary form (pixel_feat_tok_kernel below): process default; sf_set_pixel_tok(0): the tile kernels
+static int g_pixel_tok = 1;
+extern "C" int sf_get_pixel_tok(void) { return g_pixel_tok; }
+extern "C" int sf_set_pixel_tok(int on) {
+  g_pixel_tok = on ? 1 : 0;
+  return 0;
+}
+
 namespace {
 constexpr int PM_NT = 512, PM_ROWS = 128, PM_C0 = 64, PM_C1 = 128, PM_ND = 256;
 constexpr int PM_LB0 = PM_C0 + 8, PM_LB1 = PM_C1 + 8;                 // bf16 row strides (odd # of 16-B slots)
@@ -245,6 +253,9 @@ int sf_pixel_mlp_kv_ex(const float* x, const float* ln0_g, const float* ln0_b, c
 }
 
 bool sf_pixel_mlp_feat_ok(int C0, int C1) { return C0 == PM_C0 && C1 == PM_C1; }
+template <bool PLANES>
+static int sf_pixel_feat_tok_launch(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2, const float* b2,
+                                    const float* ln1_g, const float* ln1_b, void* out, int M, float eps, hipStream_t st);
 
 static int sf_pixel_feat_stream_launch(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
                                        const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, hipStream_t st,
@@ -256,6 +267,7 @@ int sf_pixel_mlp_feat_ex(const float* x, const float* ln0_g, const float* ln0_b,
   if (M <= 0) return 0;
   // weights resident in registers, PF_TPW tiles per workgroup (pixel_feat_stream_kernel below)
   constexpr int stream = 1;
+  if (sf_get_pixel_tok()) return sf_pixel_feat_tok_launch<false>(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st);
   if (stream) return sf_pixel_feat_stream_launch(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st);
   SF_TRY(sf_ensure_dyn_lds((const void*)pixel_mlp_kv_kernel<true>, (size_t)(PM_LDS)));
   sf_prof_begin(SF_K_LINEAR, st, 2.0 * M * (double)(PM_C0 * PM_C1 + PM_C1 * PM_C1));
@@ -665,21 +677,291 @@ static int sf_pixel_feat_stream_launch(const float* x, const float* ln0_g, const
   return sf_pixel_feat_stream_launch_t<128>(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st);
 }
 
+// ================================================================================================
+// PIXEL-STATIONARY form (round 6): the tile kernels above pay four workgroup barriers and three LDS round trips of the activations per 64 pixels -- 7.4 us
+// per tile for 72 MFMAs per wave (59 us per launch of 32 frames, 0.085 of the roof, whatever the tile size).  Here a wave owns 32 pixels for the whole chain:
+// every product runs transposed, D^T[feature][pixel] = W . A^T, with the pixels as the MFMA B operand in registers, and the accumulator layout of a 32 x 32
+// block (lane = (pixel, half h), register r = row 8 (r >> 2) + 4 h + (r & 3)) IS the B operand of the next product once that product's weight fragments are
+// packed in the matching k order (csrc/layer_tok.hip established this for the rollout layers):
+//   x[pixel][64] (a lane loads the 32 contiguous channels 32 h .. + 31 of its pixel: one cache line) -> LayerNorm(64) (in registers + one exchange with the
+//   lane 32 away) -> fc1 (4 blocks x 4 k-steps) + b1 + ReLU -> hi | lo fragments -> fc2 (4 blocks x 8 k-steps) + b2 -> LayerNorm(128) -> rows out.
+// The MFMA row order of fc2's output blocks is chosen so that a lane ends up with the 64 CONTIGUOUS features 64 h .. + 63 of its pixel (row m = 8 g + 4 h + q
+// of block ob = feature 64 h + 16 ob + 4 g + q): 128-byte segments out, f32 or bf16 hi | lo.
+// No activation ever touches LDS; the 96 KB of weight fragments (split from the f32 matrices by the workgroup itself) sit in LDS for the whole launch;
+// no barrier after the prologue.  Eight waves per workgroup (two per SIMD), one workgroup per CU of the stream, the rows of a wave's next tile in flight
+// while the current one is multiplied, two accumulators alternating in every product.
+namespace {
+constexpr int PT_NT = 512;
+constexpr int PT_W1 = 0, PT_W2 = 32 * 1024, PT_VEC = 96 * 1024;   // fc1 fragments [blk][ks][plane], fc2 fragments [ob][blk][s][plane] (1 KB each), vectors
+constexpr int PV_G0 = 0, PV_B0 = 64, PV_B1 = 128, PV_B2 = 256, PV_G1 = 384, PV_BE1 = 512, PV_N = 640;
+constexpr size_t PT_LDS = (size_t)PT_VEC + PV_N * 4;
+}  // namespace
+
+template <bool PLANES>
+__global__ __launch_bounds__(PT_NT) void pixel_feat_tok_kernel(const float* __restrict__ x, const float* __restrict__ ln0_g, const float* __restrict__ ln0_b,
+                                                               const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                               const float* __restrict__ b2, const float* __restrict__ ln1_g, const float* __restrict__ ln1_b,
+                                                               void* __restrict__ out, int M, float eps, int tpw) {
+  extern __shared__ __attribute__((aligned(16))) char pt_lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int n = lane & 31, h = lane >> 5;
+  // ---- weights -> split-bf16 fragments in LDS.  Fragment = 64 lanes x 16 B; lane (i, hh), element j:
+  //        fc1 (blk, ks):     W1[32 blk + i][32 hh + 8 ks + j]                         (k order of the input fragments: a lane holds channels 32 hh .. + 31)
+  //        fc2 (ob, blk, s):  W2[64 (i >> 2 & 1) ... see out_row][32 blk + 8 (2 s + (j >> 2)) + 4 hh + (j & 3)]
+  //      fc2's MFMA row m = 8 g + 4 h' + q of block ob is feature 64 h' + 16 ob + 4 g + q ----
+  {
+    // (all twelve row requests of a thread in flight before the first conversion: six dependent round trips otherwise)
+    f32x4 wa[6], wb[6];
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      const int f = t + it * PT_NT, fl = f & 63, fi = fl & 31, fh = fl >> 5, fr = f >> 6;
+      const float* p;
+      int second;
+      if (fr < 16) {
+        const int blk = fr >> 2, ks = fr & 3;
+        p = w1 + (long long)(32 * blk + fi) * PM_C0 + 32 * fh + 8 * ks;
+        second = 4;
+      } else {
+        const int g2 = fr - 16, ob = g2 >> 3, blk = (g2 >> 1) & 3, sx = g2 & 1;
+        const int orow = 64 * ((fi >> 2) & 1) + 16 * ob + 4 * (fi >> 3) + (fi & 3);
+        p = w2 + (long long)orow * PM_C1 + 32 * blk + 16 * sx + 4 * fh;
+        second = 8;
+      }
+      wa[it] = *(const f32x4*)p;              // j = 0..3
+      wb[it] = *(const f32x4*)(p + second);   // j = 4..7 (fc2: columns + 8 .. + 11)
+    }
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      const int f = t + it * PT_NT, fl = f & 63, fr = f >> 6;
+      const bf16x4 ah = __builtin_convertvector(wa[it], bf16x4), bh = __builtin_convertvector(wb[it], bf16x4);
+      const bf16x4 al = __builtin_convertvector(wa[it] - __builtin_convertvector(ah, f32x4), bf16x4);
+      const bf16x4 bl = __builtin_convertvector(wb[it] - __builtin_convertvector(bh, f32x4), bf16x4);
+      char* dst = pt_lds + (size_t)fr * 2048 + fl * 16;
+      *(bf16x8*)dst = __builtin_shufflevector(ah, bh, 0, 1, 2, 3, 4, 5, 6, 7);
+      *(bf16x8*)(dst + 1024) = __builtin_shufflevector(al, bl, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  }
+  float* PV = (float*)(pt_lds + PT_VEC);
+  for (int i = t; i < PV_N; i += PT_NT)
+    PV[i] = i < PV_B0 ? ln0_g[i] : i < PV_B1 ? ln0_b[i - PV_B0] : i < PV_B2 ? b1[i - PV_B1] : i < PV_G1 ? b2[i - PV_B2] : i < PV_BE1 ? ln1_g[i - PV_G1] : ln1_b[i - PV_BE1];
+  __syncthreads();
+  auto other = [&](float v) {   // the value of the lane 32 away (layer_tok.hip lt_xother)
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, h ? r2[0] : r2[1]);
+  };
+  auto pairsum = [&](float v) {
+    const float o = other(v);
+    return h ? o + v : v + o;   // (lower half first in both lanes: the two halves of a pixel get the same bits)
+  };
+  auto split8 = [](const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
+    const bf16x4 h0 = __builtin_convertvector(a, bf16x4), h1 = __builtin_convertvector(b, bf16x4);
+    const bf16x4 l0 = __builtin_convertvector(a - __builtin_convertvector(h0, f32x4), bf16x4);
+    const bf16x4 l1 = __builtin_convertvector(b - __builtin_convertvector(h1, f32x4), bf16x4);
+    hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  const char* wl = pt_lds + lane * 16;
+  // tile = 32 pixels; consecutive tiles go to consecutive WAVES (a workgroup covers 256 consecutive pixels per round: its stores fill whole rows together)
+  const long long ntile = ((long long)M + 31) / 32, tstep = (long long)gridDim.x * (PT_NT / 64);
+  long long tile = (long long)blockIdx.x * (PT_NT / 64) + wave;
+  auto row_of = [&](long long tl) {
+    const long long px = tl * 32 + n;
+    return px < M ? px : (long long)M - 1;
+  };
+  f32x4 xn[8];   // the NEXT tile's rows, requested while the current tile is multiplied
+  if (tile < ntile) {
+    const float* xr = x + row_of(tile) * PM_C0 + 32 * h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xn[i] = *(const f32x4*)(xr + 4 * i);
+  }
+#pragma unroll 1
+  for (int ti = 0; ti < tpw; ++ti, tile += tstep) {
+    if (tile >= ntile) break;
+    const long long p0 = tile * 32;
+    const long long pix = row_of(tile);
+    // ---- the pixel's channels 32 h .. + 31, LayerNorm(64) ----
+    f32x4 xv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xv[i] = xn[i];
+    if (tile + tstep < ntile) {
+      const float* xr = x + row_of(tile + tstep) * PM_C0 + 32 * h;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xn[i] = *(const f32x4*)(xr + 4 * i);
+    }
+    float s0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s0 += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+    const float mean = pairsum(s0) * (1.0f / PM_C0);
+    float v0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      xv[i] -= mean;
+      v0 += (xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1]) + (xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3]);
+    }
+    const float rstd = 1.0f / sqrtf(pairsum(v0) * (1.0f / PM_C0) + eps);
+    bf16x8 xh[4], xl[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = 32 * h + 8 * ks;
+      split8(xv[2 * ks] * rstd * *(const f32x4*)(PV + PV_G0 + c) + *(const f32x4*)(PV + PV_B0 + c),
+             xv[2 * ks + 1] * rstd * *(const f32x4*)(PV + PV_G0 + c + 4) + *(const f32x4*)(PV + PV_B0 + c + 4), xh[ks], xl[ks]);
+    }
+    // ---- fc1 + b1 + ReLU: hidden block blk -> the two virtual k-steps (blk, s) of fc2 ----
+    bf16x8 hh[8], hl[8];
+#pragma unroll
+    for (int bp = 0; bp < 2; ++bp) {   // two hidden blocks at a time: their accumulators alternate (no MFMA waits for the one in front of it)
+      f32x16 acc[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 wh[2], wlo[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const char* wp = wl + PT_W1 + ((2 * bp + e) * 4 + ks) * 2048;
+          wh[e] = *(const bf16x8*)wp;
+          wlo[e] = *(const bf16x8*)(wp + 1024);
+        }
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[0], xl[ks], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1], xl[ks], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[0], xh[ks], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[1], xh[ks], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[0], xh[ks], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1], xh[ks], acc[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler requests every fragment of the product first: 564 spilled registers)
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int blk = 2 * bp + e;
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          f32x4 u[2];
+#pragma unroll
+          for (int gg = 0; gg < 2; ++gg) {
+            const int g = 2 * sx + gg;
+            const f32x4 bb = *(const f32x4*)(PV + PV_B1 + 32 * blk + 8 * g + 4 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u[gg][q] = fmaxf(acc[e][4 * g + q] + bb[q], 0.f);
+          }
+          split8(u[0], u[1], hh[2 * blk + sx], hl[2 * blk + sx]);
+        }
+      }
+    }
+    // ---- fc2 + b2: output block ob = features 64 h + 16 ob + 4 g + q of this lane's pixel ----
+    f32x16 Y[4];
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Y[2 * op][r] = Y[2 * op + 1][r] = 0.f;
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        bf16x8 wh[2], wlo[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const char* wp = wl + PT_W2 + (((2 * op + e) * 4 + (k2 >> 1)) * 2 + (k2 & 1)) * 2048;
+          wh[e] = *(const bf16x8*)wp;
+          wlo[e] = *(const bf16x8*)(wp + 1024);
+        }
+        Y[2 * op] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[0], hl[k2], Y[2 * op], 0, 0, 0);
+        Y[2 * op + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1], hl[k2], Y[2 * op + 1], 0, 0, 0);
+        Y[2 * op] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[0], hh[k2], Y[2 * op], 0, 0, 0);
+        Y[2 * op + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[1], hh[k2], Y[2 * op + 1], 0, 0, 0);
+        Y[2 * op] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[0], hh[k2], Y[2 * op], 0, 0, 0);
+        Y[2 * op + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1], hh[k2], Y[2 * op + 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    float s1 = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bb = *(const f32x4*)(PV + PV_B2 + 64 * h + 16 * ob + 4 * g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          Y[ob][4 * g + q] += bb[q];
+          s1 += Y[ob][4 * g + q];
+        }
+      }
+    const float mean1 = pairsum(s1) * (1.0f / PM_C1);
+    float v1 = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        Y[ob][r] -= mean1;
+        v1 += Y[ob][r] * Y[ob][r];
+      }
+    const float rstd1 = 1.0f / sqrtf(pairsum(v1) * (1.0f / PM_C1) + eps);
+    const bool live = p0 + n < M;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        f32x4 y[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          const int g = 2 * gp + gg, c = 64 * h + 16 * ob + 4 * g;
+          const f32x4 ga = *(const f32x4*)(PV + PV_G1 + c), be = *(const f32x4*)(PV + PV_BE1 + c);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) y[gg][q] = Y[ob][4 * g + q] * rstd1 * ga[q] + be[q];
+        }
+        const int c0 = 64 * h + 16 * ob + 8 * gp;   // eight consecutive features
+        if (live) {
+          if constexpr (PLANES) {
+            bf16x8 yh, yl;
+            split8(y[0], y[1], yh, yl);
+            __bf16* pr = (__bf16*)out + pix * (2 * PM_C1);
+            *(bf16x8*)(pr + c0) = yh;
+            *(bf16x8*)(pr + PM_C1 + c0) = yl;
+          } else {
+            float* pr = (float*)out + pix * PM_C1;
+            *(f32x4*)(pr + c0) = y[0];
+            *(f32x4*)(pr + c0 + 4) = y[1];
+          }
+        }
+      }
+  }
+}
+
+template <bool PLANES>
+static int sf_pixel_feat_tok_launch(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2, const float* b2,
+                                    const float* ln1_g, const float* ln1_b, void* out, int M, float eps, hipStream_t st) {
+  static_assert(PT_LDS <= 160 * 1024, "LDS budget");
+  SF_TRY(sf_ensure_dyn_lds((const void*)pixel_feat_tok_kernel<PLANES>, PT_LDS));
+  // one workgroup per CU of the stream where the problem is that large (each pays 96 KB of weights once); consecutive tiles to consecutive waves
+  const long long ntile = ((long long)M + 31) / 32;
+  long long grid = (ntile + (PT_NT / 64) - 1) / (PT_NT / 64);
+  const int cus = sf_stream_cus((void*)st);
+  if (grid > cus) grid = cus;
+  const int tpw = (int)((ntile + grid * (PT_NT / 64) - 1) / (grid * (PT_NT / 64)));
+  sf_prof_begin(SF_K_LINEAR, st, 2.0 * M * (double)(PM_C0 * PM_C1 + PM_C1 * PM_C1));
+  hipLaunchKernelGGL(pixel_feat_tok_kernel<PLANES>, dim3((unsigned)grid), dim3(PT_NT), PT_LDS, st, x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, out, M, eps, tpw);
+  sf_prof_end(SF_K_LINEAR, st);
+  SF_CHECK_LAUNCH();
+  return 0;
+}
+
 // the same with the result as bf16 hi | lo rows of 512 B (slot_chain.h): the Slot-Attention inputs of the video-stationary slot branch
 int sf_pixel_mlp_feat_planes_ex(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
                                 const float* b2, const float* ln1_g, const float* ln1_b, void* planes, int M, float eps, hipStream_t st) {
+  if (sf_get_pixel_tok()) return sf_pixel_feat_tok_launch<true>(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, planes, M, eps, st);
   return sf_pixel_feat_stream_launch_t<64, true>(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, (float*)planes, M, eps, st);
 }
 
 // Kernel-level entry point (include/slotformer_hip.h): feat [M][128] = LN(128)(fc2(relu(fc1(LN(64)(x))))) -- encoder_out_layer followed by
 // SlotAttention.norm_inputs (savi.py:245-250, 66-70).  form 0: one 128-pixel tile per workgroup, weights through LDS; 1: weights resident in
-// registers, four tiles per workgroup; 2: the same on 64-pixel tiles, 256 threads, two workgroups per CU.  Same bits.
+// registers, four tiles per workgroup; 2: the same on 64-pixel tiles, 256 threads, two workgroups per CU (0-2: the same bits); 3: pixel-stationary
+// (pixel_feat_tok_kernel: another summation order, split-bf16 rounding apart).
 extern "C" int sf_pixel_feat_f32(const float* x, const float* ln0_g, const float* ln0_b, const float* w1, const float* b1, const float* w2,
                                  const float* b2, const float* ln1_g, const float* ln1_b, float* feat, int M, float eps, int form, void* stream) {
   SF_REQUIRE(x && ln0_g && ln0_b && w1 && b1 && w2 && b2 && ln1_g && ln1_b && feat && M > 0, "sf_pixel_feat_f32: null pointer / empty problem");
-  SF_REQUIRE(form >= 0 && form <= 2, "sf_pixel_feat_f32: form must be 0, 1 or 2");
+  SF_REQUIRE(form >= 0 && form <= 3, "sf_pixel_feat_f32: form must be 0 .. 3");
   SF_REQUIRE(sf_get_precision() == 1, "sf_pixel_feat_f32: split-bf16 mode only");
   hipStream_t st = (hipStream_t)stream;
+  if (form == 3) return sf_pixel_feat_tok_launch<false>(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st);   // pixel-stationary
   if (form >= 1) return sf_pixel_feat_stream_launch(x, ln0_g, ln0_b, w1, b1, w2, b2, ln1_g, ln1_b, feat, M, eps, st, form == 1 ? 128 : 64);
   SF_TRY(sf_ensure_dyn_lds((const void*)pixel_mlp_kv_kernel<true>, (size_t)(PM_LDS)));
   hipLaunchKernelGGL(pixel_mlp_kv_kernel<true>, dim3((M + PM_ROWS - 1) / PM_ROWS), dim3(PM_NT), PM_LDS, st, x, ln0_g, ln0_b, w1, b1, w2, b2,

@@ -111,6 +111,13 @@ def test_pixel_feat_forms(dev, M):
         outs.append(out)
     assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
     assert torch.equal(outs[0], outs[2]), (outs[0] - outs[2]).abs().max().item()
+    # form 3: the pixel-stationary kernel (a wave owns 32 pixels for the whole chain; ragged last tile) -- another summation order
+    out = torch.full((M, 128), float('nan'), device=dev)
+    _lib.check(lib.sf_pixel_feat_f32(*[v.data_ptr() for v in d], out.data_ptr(), M, 1e-5, 3, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    close(out, ref, rtol=1e-4, atol=1e-4)
+    e = ((out - outs[0]).abs().max() / outs[0].abs().max()).item()
+    assert 0 < e < 2e-5, e
 
 
 @pytest.mark.parametrize('relu,with_add,H', [(True, False, 64), (False, True, 64), (True, False, 8)])

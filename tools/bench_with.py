@@ -11,6 +11,6 @@ i = sys.argv.index('--')
 lib = _lib.lib()
 for kv in sys.argv[1:i]:
     k, v = kv.split('=')
-    {'sa_planes': lib.sf_set_slot_attn_planes, 'slot_chain': lib.sf_set_slot_chain}[k](int(v))
+    {'sa_planes': lib.sf_set_slot_attn_planes, 'slot_chain': lib.sf_set_slot_chain, 'pixel_tok': lib.sf_set_pixel_tok}[k](int(v))
 sys.argv = [os.path.join(ROOT, 'bench.py')] + sys.argv[i + 1:]
 runpy.run_path(sys.argv[0], run_name='__main__')

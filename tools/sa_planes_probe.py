@@ -20,8 +20,9 @@ _lib.check(lib.sf_stream_create_cu_mask(C.byref(h), (C.c_uint * 8)(*pl.ENC_WORDS
 masked = torch.cuda.ExternalStream(h.value, device=dev)
 with torch.no_grad():
     for name, st in (('whole chip', torch.cuda.current_stream()), ('128-CU mask', masked)):
-        for mode in (0, 1):
-            lib.sf_set_slot_attn_planes(mode)
+        for mode in (0, 1, 2):
+            lib.sf_set_slot_attn_planes(1 if mode else 0)
+            lib.sf_set_pixel_tok(1 if mode == 2 else 0)
             with torch.cuda.stream(st):
                 for _ in range(3):
                     engine.savi_encode(savi, img, noise=noise, side_stream=None, ws_slot=('sap', mode, name))
@@ -33,4 +34,4 @@ with torch.no_grad():
                 st.synchronize()
                 lib.sf_profile_enable(0)
             pr = bench.read_profile(lib)
-            print(f'{name:12s} planes={mode}: ' + '  '.join(f'{k} {v["avg_us"]:.1f} us x {v["launches"] // 3}' for k, v in pr.items() if k in ('slot_attn_iter', 'slot_update', 'linear_gemm')))
+            print(f'{name:12s} planes={min(mode, 1)} pixel_tok={int(mode == 2)}: ' + '  '.join(f'{k} {v["avg_us"]:.1f} us x {v["launches"] // 3}' for k, v in pr.items() if k in ('slot_attn_iter', 'slot_update', 'linear_gemm')))
