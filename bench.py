@@ -456,6 +456,8 @@ def main():
                     'segmentation, what test_vp.py scores): a secondary object `decode_pipeline` + `roofline_decode`, never `value`')
     ap.add_argument('--decode-steps', type=int, default=8, help='batches per timed window of the --decode leg')
     ap.add_argument('--group', type=int, default=None, help='batches per rollout unit of the pipeline (default: the pipeline\'s own choice)')
+    ap.add_argument('--roll-streams', type=int, default=2, help="rollout streams of the 'pair' partition (units side by side on the rollout CUs; default 2)")
+    ap.add_argument('--hybrid', type=int, default=None, help='every k-th batch behind the fill on an unmasked stream (default: the pipeline\'s own choice)')
     ap.add_argument('--enc-group', type=int, default=0, help='batches handed to the pipeline as one (default: pipeline.encode_group_for)')
     ap.add_argument('--cu-split', default='ff', help='encode CU mask of the pipeline: hex word, or rows<R> (pipeline.encode_mask_words)')
     ap.add_argument('--partition', choices=['pair', 'three', 'two', 'none'], default='pair')
@@ -539,7 +541,8 @@ def main():
     with torch.no_grad():
         log('building the pipeline (first eager rollouts + graph capture)')
         pipe = EncodeRolloutPipeline(savi, roll, Bp, T_BURN, T_ROLL, encode_cu_word=cu_word, steal_steps=steal,
-                                     use_graph=not args.no_graph, partition=partition, group=group, split=bool(args.split), chain_on=args.split or 'enc')
+                                     use_graph=not args.no_graph, partition=partition, group=group, split=bool(args.split), chain_on=args.split or 'enc',
+                                     roll_streams=args.roll_streams, hybrid=args.hybrid)
         overlap = not args.no_overlap
         G = pipe.G                      # batches per rollout graph
         unit0 = pipe.units[0]

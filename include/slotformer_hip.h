@@ -344,8 +344,9 @@ int sf_attn_block_f32(const sf_tfm_layer* w, const float* x, float* out, int B, 
  * sf_attn_rows_planes_bytes(B) bytes (q, k, v^T of every (sequence, head) as split-bf16 MFMA-fragment planes; cleared by the call). */
 /* The FFN block y = x2 + lin2(relu(lin1(LN2(x2)))) on finished rows x2 [M][256] in its row-tile form (sf_rollout_opts.ffn_tile). */
 int sf_ffn_block_rows_f32(const sf_tfm_layer* w, const float* x2, float* y, int M, int ffn, void* stream);
-/* Whole pre-LN layers  y = x2 + lin2(relu(lin1(LN2(x2)))),  x2 = x + out_proj(MHA(LN1(x))) + b_o  on B sequences of L <= 64 tokens, x, y [B][L][256],
- * in the token-stationary form (csrc/layer_tok.hip): a 128-token workgroup owns whole sequences, a wave 32 tokens; every product of a layer keeps its
+/* Whole pre-LN layers  y = x2 + lin2(relu(lin1(LN2(x2)))),  x2 = x + out_proj(MHA(LN1(x))) + b_o  on B sequences of L <= 96 tokens, x, y [B][L][256],
+ * in the token-stationary form (csrc/layer_tok.hip): a 128-token workgroup owns whole sequences (as many as keep the keys of a wave's rows inside three
+ * 32-key blocks: three of 42 tokens, one of 50 or of 65..96), a wave 32 tokens; every product of a layer keeps its
  * activations in registers (the accumulator layout of one product is the B operand of the next), the weight fragments stream global -> LDS once per
  * workgroup, only a head's keys / values cross waves; `nl` (1..8) consecutive layers w[0..nl) run in ONE launch (the rows never leave the registers
  * between them).  tok_packed: sf_pack_layer_tok_weights copy of a layer (sf_layer_tok_packed_bytes() bytes: its four matrices as fragments in consumption
@@ -408,7 +409,7 @@ typedef struct {
   int cus_available; /* 0: the whole chip; else the number of CUs the call's stream may use (its CU mask).  Seam launches hand rows over inside
                       * a grid and need every workgroup of it resident at once: they are used only when the grid fits min(160, cus_available) */
   int layer_tok;     /* 0: the process default (sf_set_layer_tok / SF_LAYER_TOK=1; OFF unless set); 1 / -1: on / off.  On (and every layer before the last has tok_packed, windows
-                      * of <= 64 tokens): those layers run as ONE token-stationary launch each (csrc/layer_tok.hip) -- a 128-token workgroup owns whole
+                      * of <= 96 tokens; 65..96 -- the reference's Physion window of 15 frames x 6 slots -- outside the pipeline's units): those layers run as ONE token-stationary launch each (csrc/layer_tok.hip) -- a 128-token workgroup owns whole
                       * videos, every product of the layer keeps its activations in registers -- instead of an attention-core launch per video plus an
                       * FFN + q|k|v launch per 64-row tile; the row-pruned last layer keeps the row-tile forms.  Not bit-identical to the other forms
                       * (one accumulator per output block instead of per-chunk partial sums): 1e-6-level differences per layer */

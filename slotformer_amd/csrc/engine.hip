@@ -302,6 +302,10 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
   // out-projection GEMM, and the fused FFN kernel on its finished rows
   const bool long_ffn = !fused_layers && packed && !t_plain_gemms && sf_get_precision() >= 1 && m->norm_first &&
                         sf_layer_fused_ok(d, m->num_heads, m->ffn_dim, 1) && Lmax > 64 && sf_ffn_tiles(B * Lmax) <= 1024;
+  // ... and the layers before the last of such a window as token-stationary launches (per-call option layer_tok; layer_tok.hip: one video per workgroup)
+  bool long_tok_packed = long_ffn && m->num_layers >= 2 && Lmax <= 96 && !m->single_step && sf_layer_tok_ok(Lmax);
+  for (int l = 0; l + 1 < m->num_layers; ++l) long_tok_packed = long_tok_packed && m->layers[l].tok_packed;
+  const bool long_tok = long_tok_packed && (sf_thread_opts().layer_tok > 0 || (sf_thread_opts().layer_tok == 0 && sf_get_layer_tok() != 0));
   if (fused_layers || long_ffn) {
     SF_REQUIRE(sf_ffn_tiles(B * Lmax) <= 1024, "batch too large for the fused-layer tile counters");
     // zeroed by a KERNEL, not hipMemsetAsync: the rollout is captured into hipGraphs, and the memset nodes of a graph were seen
@@ -505,7 +509,19 @@ int sf_rollout_f32(const sf_rollouter* m, float* slots, int B, int T_total, int 
     }
     float* cur = x;
     int Lc = L;
-    for (int l = 0; l < m->num_layers; ++l) {
+    int l0 = 0;
+    if (long_tok) {
+      // windows of 65..96 tokens (the reference's Physion window, slotformer_physion_params.py: 15 frames x 6 slots): the layers before the last as
+      // token-stationary launches of one video per workgroup, up to eight layers per launch; the row-pruned last layer in the long-window forms below
+      while (l0 + 1 < m->num_layers) {
+        const int nlt = (m->num_layers - 1 - l0) < 8 ? (m->num_layers - 1 - l0) : 8;
+        float* xo = (cur == xa) ? xb2 : xa;
+        SF_TRY(sf_layer_tok_ex(0, cur, nullptr, 1, 1, 0, nullptr, m->layers + l0, nlt, 1e-5f, xo, B, L, st));
+        cur = xo;
+        l0 += nlt;
+      }
+    }
+    for (int l = l0; l < m->num_layers; ++l) {
       const bool last = (l == m->num_layers - 1);
       const int Lq = (last && m->norm_first) ? N : Lc;
       float* outp = nullptr;

@@ -32,6 +32,7 @@ int sf_ffn_tile_ex(const float* x2, const sf_tfm_layer& w, float eps, float* y, 
 // token-stationary whole layers (layer_tok.hip): `nl` consecutive layers in one launch; mode 0: xin [B * L][256] rows; mode 1: the first is layer 0 of a
 // rollout step, x = ring rows + position table
 bool sf_layer_tok_ok(int L);
+int sf_layer_tok_vpw(int L);   // videos per 128-token workgroup for sequences of L tokens (0: refused)
 int sf_layer_tok_ex(int mode, const float* xin, const float* ring, int ring_frames, int nslots, int f0, const float* pe, const sf_tfm_layer* layers, int nl,
                     float eps, float* y, int B, int L, hipStream_t st);
 // row-tile form (attn_rows.hip): q|k|v projection on 128-row tiles of the batch + one core / out-projection workgroup per video;

@@ -89,8 +89,21 @@ __device__ __forceinline__ void lt_dma(const LtRing& R, int f) {
 #if defined(LT_NODMA) || defined(LT_BURST)
   return;
 #endif
+#ifndef LT_NOIMMOFF
+  // the instruction's immediate offset applies to BOTH addresses: pieces 4 k .. 4 k + 3 share one per-lane source address and one M0 value
+  // (354 instead of 365 us per 3-layer launch of 64 workgroups: three instructions less around every piece)
+  const void __attribute__((address_space(1)))* s = (const void __attribute__((address_space(1)))*)(R.src + (f >> 2) * 4096);
+  void __attribute__((address_space(3)))* d = (void __attribute__((address_space(3)))*)(R.dst + (f >> 2) * 4096);
+  switch (f & 3) {
+    case 0: __builtin_amdgcn_global_load_lds(s, d, 16, 0, 0); break;
+    case 1: __builtin_amdgcn_global_load_lds(s, d, 16, 1024, 0); break;
+    case 2: __builtin_amdgcn_global_load_lds(s, d, 16, 2048, 0); break;
+    default: __builtin_amdgcn_global_load_lds(s, d, 16, 3072, 0); break;
+  }
+#else
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(R.src + f * 1024),
                                    (void __attribute__((address_space(3)))*)(R.dst + f * 1024), 16, 0, 0);
+#endif
 }
 #define LT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 // keeps the MFMAs on either side in source order (every other class may cross): the scheduler otherwise groups the MFMAs of one accumulator, and a chain
@@ -836,18 +849,24 @@ extern "C" int sf_pack_layer_tok_weights(const sf_tfm_layer* w, void* packed, in
   return 0;
 }
 
-// Rows per video the token-stationary layer takes: whole videos per 128-token workgroup, and the keys of the videos a wave's 32 rows belong to inside
-// three 32-key blocks
-bool sf_layer_tok_ok(int L) {
-  if (L < 1 || L > 64) return false;
-  const int vpw = LT_TOK / L, nvalid = vpw * L;
-  for (int w = 0; w < 4; ++w) {
-    const int wf = w * 32 < nvalid ? w * 32 : nvalid - 1, wl = w * 32 + 31 < nvalid ? w * 32 + 31 : nvalid - 1;
-    const int kb0 = ((wf / L) * L) >> 5, kb1 = (((wl / L) * L) + L - 1) >> 5;
-    if (kb1 - kb0 + 1 > 3) return false;
+// Videos per 128-token workgroup for sequences of L tokens: the largest count of WHOLE videos for which the keys of the videos a wave's 32 rows belong to
+// lie inside three 32-key blocks (42 tokens: 3; 50 tokens: 1 -- two would put the keys of wave 1's rows in four blocks; 65..96 tokens, the reference's
+// Physion window of 15 frames x 6 slots: 1, the last wave(s) idle); 0: the sequence does not fit a workgroup
+int sf_layer_tok_vpw(int L) {
+  if (L < 1 || L > 96) return 0;
+  for (int vpw = LT_TOK / L; vpw >= 1; --vpw) {
+    const int nvalid = vpw * L;
+    bool ok = true;
+    for (int w = 0; w < 4 && ok; ++w) {
+      const int wf = w * 32 < nvalid ? w * 32 : nvalid - 1, wl = w * 32 + 31 < nvalid ? w * 32 + 31 : nvalid - 1;
+      const int kb0 = ((wf / L) * L) >> 5, kb1 = (((wl / L) * L) + L - 1) >> 5;
+      ok = kb1 - kb0 + 1 <= 3;
+    }
+    if (ok) return vpw;
   }
-  return true;
+  return 0;
 }
+bool sf_layer_tok_ok(int L) { return sf_layer_tok_vpw(L) > 0; }
 
 // `nl` consecutive layers in ONE launch.  mode 0: xin [B * L][256] rows;  mode 1: the first of them is layer 0 of a rollout step --
 // x = ring[b][(f0 + r / nslots) % ring_frames][r % nslots] + pe[r].  y [B * L][256] finished rows of the last of them.
@@ -856,12 +875,12 @@ int sf_layer_tok_ex(int mode, const float* xin, const float* ring, int ring_fram
   bool ok = layers && nl >= 1 && nl <= LT_MAXL && sf_layer_tok_ok(L) && B >= 1 && y && (mode == 0 ? xin != nullptr : (ring && pe && nslots >= 1 && ring_frames >= 1));
   for (int l = 0; ok && l < nl; ++l) ok = layers[l].tok_packed != nullptr;
   if (!ok)
-    return sf_set_err(-1, "invalid argument: the token-stationary layers need sf_pack_layer_tok_weights fragments, 1..8 layers and 1 <= L <= 64 rows per video", __FILE__, __LINE__);
+    return sf_set_err(-1, "invalid argument: the token-stationary layers need sf_pack_layer_tok_weights fragments, 1..8 layers and 1 <= L <= 96 rows per video", __FILE__, __LINE__);
   static const int dbg = sf_dbg("lt");
   LtArgs A;
   A.x = xin; A.ring = ring; A.pe = pe; A.y = y;
   for (int l = 0; l < LT_MAXL; ++l) A.blob[l] = (const char*)layers[l < nl ? l : nl - 1].tok_packed;
-  A.eps = eps; A.nl = nl; A.B = B; A.L = L; A.vpw = LT_TOK / L; A.RF = ring_frames; A.N = nslots; A.f0 = f0; A.dbg_ts = dbg;
+  A.eps = eps; A.nl = nl; A.B = B; A.L = L; A.vpw = sf_layer_tok_vpw(L); A.RF = ring_frames; A.N = nslots; A.f0 = f0; A.dbg_ts = dbg;
   const int nwg = (B + A.vpw - 1) / A.vpw;
   const double flops = nl * ((double)B * L * (2.0 * LT_D * (3 * LT_D + LT_D + 2 * LT_F)) + (double)B * LT_NH * 4.0 * L * L * 32);
   if (mode == 0) {

@@ -259,6 +259,7 @@ class EncodeRolloutPipeline:
     False = never (every unit in the row-tile / latency forms: bit-identical to the serial module calls); True = required.  With it the results agree
     with the serial calls to ~5e-6 over 50 steps instead of bit for bit (one accumulator per output block instead of per-chunk partial sums), and are
     bit-identical to run(serial=True) of the same object.
+    roll_streams: rollout streams of the 'pair' partition = units in flight on the rollout CUs (default 2).
     split: True = the encode in two halves where the model allows it (image features on the encode lane, the slot branch of a whole unit as one
     video-stationary launch behind the features of its last batch: csrc/slot_chain.hip; agrees with the default to split-bf16 rounding, ~5e-6);
     None / False (default) = the whole encode on the lane -- measured faster (profiles/r06_probes.txt: the pipeline is bound by its rollout units).
@@ -271,7 +272,7 @@ class EncodeRolloutPipeline:
 
     def __init__(self, savi, rollouter, batch, burn_in, pred_len, encode_cu_word=0xff, steal_steps=None, use_graph=True,
                  partition='pair', group=None, rollout_opts=None, encode_graph=None, hybrid=None, decoder=None, seg_dtype=torch.uint8,
-                 encode_fork=None, tok=None, split=None, chain_on='enc'):
+                 encode_fork=None, tok=None, split=None, chain_on='enc', roll_streams=2):
         self.savi, self.roll = savi, rollouter
         # optional third stage (row N2; video_prediction/test_vp.py:55-63,145-146 -> slotformer.py:244-259 -> savi.py:504-525 ->
         # vp_utils.py:20-41): the predicted frames of every batch are decoded behind its rollout -- spatial-broadcast decoder, softmax
@@ -318,7 +319,8 @@ class EncodeRolloutPipeline:
         self.tok = g_tok is not None and self.G * self.B >= 96
         if self.G < 1:
             raise ValueError('slotformer_amd: group >= 1')
-        nroll = 2 if partition == 'pair' else 1
+        nroll = max(1, int(roll_streams)) if partition == 'pair' else 1
+        self._nroll = nroll
         # unit buffers / graphs / workspaces: per rollout stream one rolling out + one being filled or spare
         self.NU = 2 * nroll
         self.lead = 2 * nroll                    # stolen features of unit u are computed behind the rollout of unit u - lead
@@ -406,7 +408,7 @@ class EncodeRolloutPipeline:
                 if partition == 'pair':
                     enc_words = self._enc_words_pair
                     roll_words = [~w & 0xffffffff for w in enc_words]
-                    self.roll_streams = [self._masked_stream(roll_words), self._masked_stream(roll_words)]
+                    self.roll_streams = [self._masked_stream(roll_words) for _ in range(self._nroll)]
                     self.s_roll = self.roll_streams[0]
                     self.lanes = [(self._masked_stream(enc_words), 0, self.B)]
                     self.encode_cus = sum(bin(w).count('1') for w in enc_words)

@@ -38,8 +38,10 @@ def _layer64(layer, x):
 
 
 # (videos, tokens per video): three videos per 128-token workgroup with two padding rows (42), 20 padding rows (36), two videos (48, 64), one key block per
-# video (8, 16, 32), a last workgroup with one / two videos, a single video
-@pytest.mark.parametrize('B,L', [(128, 42), (64, 36), (37, 48), (256, 8), (35, 16), (9, 32), (5, 64), (3, 42), (1, 42), (2, 7), (4, 24), (7, 40)])
+# video (8, 16, 32), a last workgroup with one / two videos, a single video; ONE video per workgroup where two would put a wave's keys in four key blocks
+# (50) and for windows of 65..96 tokens (70, 96, and 90 = the reference's Physion window of 15 frames x 6 slots: the last wave idle)
+@pytest.mark.parametrize('B,L', [(128, 42), (64, 36), (37, 48), (256, 8), (35, 16), (9, 32), (5, 64), (3, 42), (1, 42), (2, 7), (4, 24), (7, 40),
+                                 (4, 50), (2, 70), (33, 90), (3, 96), (1, 65)])
 @pytest.mark.parametrize('nl', [1, 3])
 @torch.no_grad()
 def test_layer_tok_block_vs_float64(dev, B, L, nl):
@@ -79,20 +81,22 @@ def test_layer_tok_argument_errors(dev):
     lib = _lib.lib()
     r = _rollouter(dev)
     plan = engine.rollouter_plan(r)
-    x = torch.zeros(2, 70, 256, device=dev)
+    x = torch.zeros(2, 97, 256, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    assert lib.sf_layer_tok_block_f32(plan.struct.layers, 1, x.data_ptr(), x.data_ptr(), 2, 70, st) != 0     # more than 64 tokens per sequence
+    assert lib.sf_layer_tok_block_f32(plan.struct.layers, 1, x.data_ptr(), x.data_ptr(), 2, 97, st) != 0     # more than 96 tokens per sequence
     assert lib.sf_layer_tok_block_f32(plan.struct.layers, 9, x.data_ptr(), x.data_ptr(), 2, 42, st) != 0     # more than 8 layers per launch
-    assert lib.sf_layer_tok_block_f32(plan.struct.layers, 1, x.data_ptr(), x.data_ptr(), 2, 50, st) != 0     # 50 tokens: a wave's keys would span four 32-key blocks
+    assert lib.sf_layer_tok_block_f32(plan.struct.layers, 0, x.data_ptr(), x.data_ptr(), 2, 42, st) != 0     # no layer
     assert lib.sf_rollout_tok_ok(C.byref(plan.struct)) == 1
     assert lib.sf_layer_tok_packed_bytes() == 96 * 32768 + 3328 * 4
 
 
-@pytest.mark.parametrize('name,cfg,B,pred_len,seed', [('roll_c2', gu.C2_ROLL, 2, 50, 202), ('roll_c4_full', gu.C4_ROLL, 1, 40, 224), ('roll_c5_full', gu.C5_ROLL, 1, 80, 225)])
+@pytest.mark.parametrize('name,cfg,B,pred_len,seed', [('roll_c2', gu.C2_ROLL, 2, 50, 202), ('roll_c4_full', gu.C4_ROLL, 1, 40, 224), ('roll_c5_full', gu.C5_ROLL, 1, 80, 225),
+                                                      ('roll_c4_ref', gu.C4_ROLL_REF, 1, 4, 214)])
 @torch.no_grad()
 def test_rollout_with_layer_tok_vs_reference_fixture(dev, name, cfg, B, pred_len, seed):
     """The rollout with the layers before the last as token-stationary launches against the reference's own outputs: C2 (projection ring, sliding window
-    of 42 tokens), C4 (slot size 192: no ring, 8 layers -> seven layers in ONE launch, 36 tokens), C5 (single-step rollouter: the window grows 8 -> 48)."""
+    of 42 tokens), C4 (slot size 192: no ring, 8 layers -> seven layers in ONE launch, 36 tokens), C5 (single-step rollouter: the window grows 8 -> 48),
+    C4 with the reference's own Physion window (slotformer_physion_params.py: 15 burn-in frames x 6 slots = 90 tokens: one video per workgroup)."""
     from test_engine_gpu import build
     from slotformer_amd import engine
     g = gu.load_golden(name)
