@@ -477,6 +477,240 @@ __global__ __launch_bounds__(256, 2) void slate_attn_bwd48_kernel(SabArgs p, int
   }
 }
 
+// The 48-wide kernel again with every LDS tile as two bf16 PLANES (hi, lo) instead of packed words, in the layouts the 32x32x16 MFMA operands want:
+//  * Q_i, dO_i (and K_j, V_j once, before the loop) query-major [64][56]: the A operands of S = Q K^T and dP = dO V^T are one ds_read_b128 per plane
+//    and k16-step; the B operands of the products that contract over QUERIES (dV += P^T dO, dK += dS^T Q) come out of the same tiles through
+//    ds_read_b64_tr_b16 (two transposing reads per plane and step: lane (i, kk) receives rows 8 kk .. 8 kk + 7 of column i);
+//  * P^T, dS^T key-major [64 keys][72]: written from the S / dP accumulators as they lie (a lane holds one key and runs of four consecutive queries:
+//    one ds_write_b64 per run and plane), read as A operands of dV / dK by ds_read_b128, and -- transposing -- as the A operand of dQ += dS K;
+//  * K_j's fragments for S (B operand, contraction over channels) and for dQ (B operand, contraction over keys) and V_j's for dP live in registers.
+// No conversion, no v_perm and no scalar LDS read in the loop: ~650 instructions per query block and wave instead of ~1650 (54 MFMAs either way).
+// exp runs in base 2 (Q' = Q scale log2(e), LSE' = LSE log2(e); dK is multiplied by ln 2 at the end).  65.5 KB of LDS: two workgroups per CU.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define SAB_LP(T, p) ((T __attribute__((address_space(3)))*)(p))
+namespace {
+constexpr int V2_QP = 112, V2_TP = 144;          // row pitches in BYTES: query-major tiles [64][56 bf16], key-major tiles [64][72 bf16]
+constexpr int V2_QT = 64 * V2_QP, V2_TT = 64 * V2_TP;
+constexpr int V2_QH = 0, V2_QL = V2_QT, V2_GH = 2 * V2_QT, V2_GL = 3 * V2_QT;
+constexpr int V2_PH = 4 * V2_QT, V2_PL = V2_PH + V2_TT, V2_DH = V2_PH + 2 * V2_TT, V2_DL = V2_PH + 3 * V2_TT;
+constexpr int V2_LS = V2_PH + 4 * V2_TT;         // lse' [64], dsum [64]
+constexpr int V2_LDS = V2_LS + 512 + 256;        // (+ slack: the transposing reads of the second channel tile run past column 55 of the last row)
+// two f32 -> packed bf16 hi pair and lo pair
+__device__ __forceinline__ void v2_split2(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{a, b}), bf16x2v));
+  const float fa = __builtin_bit_cast(float, hi << 16), fb = __builtin_bit_cast(float, hi & 0xffff0000u);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{a - fa, b - fb}), bf16x2v));
+}
+// prefetched rows (SabTile<48>: three float4 per thread) -> hi / lo planes of a query-major tile
+__device__ __forceinline__ void v2_put(const SabTile<48>& t, float mul, char* lds, int hoff, int loff) {
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const int i = threadIdx.x + 256 * n, r = i / 12, c = (i - r * 12) * 4;
+    const f32x4 v = t.v[n] * mul;
+    unsigned h0, l0, h1, l1;
+    v2_split2(v[0], v[1], h0, l0);
+    v2_split2(v[2], v[3], h1, l1);
+    *(u32x2*)(lds + hoff + r * V2_QP + c * 2) = u32x2{h0, h1};
+    *(u32x2*)(lds + loff + r * V2_QP + c * 2) = u32x2{l0, l1};
+  }
+}
+struct V2Frag {
+  bf16x8 h, l;
+};
+// operand fragment (lane (i, kk): eight consecutive k of row i) from a tile whose rows are i: one 16-byte read per plane
+__device__ __forceinline__ V2Frag v2_rd(const char* lds, int hoff, int loff, int pitch, int row0, int k0, int lane) {
+  const int o = (row0 + (lane & 31)) * pitch + (k0 + 8 * (lane >> 5)) * 2;
+  V2Frag f;
+  f.h = *(const bf16x8*)(lds + hoff + o);
+  f.l = *(const bf16x8*)(lds + loff + o);
+  return f;
+}
+// ... from a tile whose rows are k (columns i): two transposing reads per plane.  Lane l = (j = l & 15, g = l >> 4) of a 16-lane group points at row
+// k0 + 8 kk + (j >> 2) (+ 4 for the second read), columns col0 + 16 (g & 1) + 4 (j & 3) .. + 3 and receives column col0 + (l & 31) of four rows
+__device__ __forceinline__ V2Frag v2_rd_tr(const char* lds, int hoff, int loff, int pitch, int k0, int col0, int lane) {
+  const int j = lane & 15, g = lane >> 4, kk = lane >> 5;
+  const int o = (k0 + 8 * kk + (j >> 2)) * pitch + (col0 + 16 * (g & 1) + 4 * (j & 3)) * 2;
+  V2Frag f;
+  const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(SAB_LP(bf16x4, lds + hoff + o));
+  const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(SAB_LP(bf16x4, lds + hoff + o + 4 * pitch));
+  const bf16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(SAB_LP(bf16x4, lds + loff + o));
+  const bf16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(SAB_LP(bf16x4, lds + loff + o + 4 * pitch));
+  f.h = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+  f.l = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+  return f;
+}
+__device__ __forceinline__ void v2_mma(f32x16& acc, const V2Frag& a, const V2Frag& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+}
+}  // namespace
+#ifdef SAB_STAMPS
+__device__ long long sab_ts[16];
+#define SABT(i) do { if (stamp) { const long long c_ = __builtin_readcyclecounter(); acc_ts[i] += c_ - c_last; c_last = c_; } } while (0)
+#else
+#define SABT(i)
+#endif
+__global__ __launch_bounds__(256, 2) void slate_attn_bwd48v2_kernel(SabArgs p, int hd) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ls = (float*)(smem + V2_LS);
+  const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k0 = kb * 64;
+  const int ti = (wave >> 1) * 32, tj = (wave & 1) * 32;   // S / dP tile: queries ti.., keys tj..;  dV / dK tile: keys ti.., channels tj..;  dQ tile: queries ti.., channels tj..
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+#ifdef SAB_STAMPS
+  const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+  long long acc_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c_last = __builtin_readcyclecounter();
+#endif
+  // ---- K_j, V_j -> planes (in the Q / dO tiles' place), then their fragments -> registers ----
+  SabTile<48> tq, tg;
+  sab_fetch<48>(p.k + (long long)b * p.k_bs + h * hd, p.ldk, k0, p.Lk, hd, tq);
+  sab_fetch<48>(p.v + (long long)b * p.v_bs + h * hd, p.ldv, k0, p.Lk, hd, tg);
+  // (columns 48 .. 55 of the query-major planes feed only output columns >= 48, which are never stored -- but they must hold finite values)
+  for (int i = tid; i < 4 * 64; i += 256) *(uint4*)(smem + (i >> 6) * V2_QT + (i & 63) * V2_QP + 96) = uint4{0u, 0u, 0u, 0u};
+  v2_put(tq, 1.f, smem, V2_QH, V2_QL);
+  v2_put(tg, 1.f, smem, V2_GH, V2_GL);
+  __syncthreads();
+  V2Frag kf[3], vf[3], kq[4];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    kf[s] = v2_rd(smem, V2_QH, V2_QL, V2_QP, tj, 16 * s, lane);   // B operand of S: lane (key, kk) holds eight channels
+    vf[s] = v2_rd(smem, V2_GH, V2_GL, V2_QP, tj, 16 * s, lane);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) kq[s] = v2_rd_tr(smem, V2_QH, V2_QL, V2_QP, 16 * s, tj, lane);   // B operand of dQ: lane (channel, kk) holds eight keys
+  f32x16 dvacc, dkacc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dvacc[i] = dkacc[i] = 0.f;
+  const int nqb = (p.Lq + 63) / 64;
+  const float* qbase = p.q + (long long)b * p.q_bs + h * hd;
+  const float* gbase = p.dout + (long long)b * p.o_bs + h * hd;
+  const int qb0 = p.causal ? kb : 0;
+  float pl = 0.f, pd = 0.f;
+  auto prefetch = [&](int qbn) {
+    sab_fetch<48>(qbase, p.ldq, qbn * 64, p.Lq, hd, tq);
+    sab_fetch<48>(gbase, p.ldo, qbn * 64, p.Lq, hd, tg);
+    if (tid < 64) {
+      const long long idx = ((long long)b * p.H + h) * p.Lq + min(qbn * 64 + tid, p.Lq - 1);
+      pl = p.lse[idx];
+      pd = p.dsum[idx];
+    }
+  };
+  if (qb0 < nqb) prefetch(qb0);
+  const int kc = tj + (lane & 31), half = lane >> 5;   // this lane's key column of the S / dP tile
+  SABT(0);
+  for (int qb = qb0; qb < nqb; ++qb) {
+    const int q0 = qb * 64;
+    __syncthreads();
+    SABT(1);
+    v2_put(tq, p.scale * LOG2E, smem, V2_QH, V2_QL);
+    v2_put(tg, 1.f, smem, V2_GH, V2_GL);
+    if (tid < 64) {
+      ls[tid] = pl * LOG2E;
+      ls[64 + tid] = pd;
+    }
+    __syncthreads();
+    SABT(2);
+    if (qb + 1 < nqb) prefetch(qb + 1);
+    f32x16 s, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+      const V2Frag qa = v2_rd(smem, V2_QH, V2_QL, V2_QP, ti, 16 * st, lane);
+      const V2Frag ga = v2_rd(smem, V2_GH, V2_GL, V2_QP, ti, 16 * st, lane);
+      v2_mma(s, qa, kf[st]);
+      v2_mma(dp, ga, vf[st]);
+    }
+    SABT(3);
+    // ---- P = exp2(S' - LSE') (masked, dropped), dS = P (dP mask - D): this lane's key, four runs of four consecutive queries -> P^T / dS^T planes ----
+    const bool full = (!p.causal || qb > kb) && q0 + 64 <= p.Lq && k0 + 64 <= p.Lk;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int qr = ti + 8 * g4 + 4 * half;
+      const f32x4 l4 = *(const f32x4*)(ls + qr), d4 = *(const f32x4*)(ls + 64 + qr);
+      float pv[4], dsv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g4 + e;
+        float pe = __builtin_amdgcn_exp2f(s[r] - l4[e]);
+        if (!full) {
+          const int qi = q0 + qr + e, kj = k0 + kc;
+          const bool ok = qi < p.Lq && kj < p.Lk && (!p.causal || kj <= qi);
+          pe = ok ? pe : 0.f;
+        }
+        float mk = 1.f;
+        if (p.drop_thresh) mk = sab_drop(p, b, h, min(q0 + qr + e, p.Lq - 1), min(k0 + kc, p.Lk - 1));
+        pv[e] = pe * mk;
+        dsv[e] = pe * (dp[r] * mk - d4[e]);
+      }
+      unsigned ph0, pl0, ph1, pl1, dh0, dl0, dh1, dl1;
+      v2_split2(pv[0], pv[1], ph0, pl0);
+      v2_split2(pv[2], pv[3], ph1, pl1);
+      v2_split2(dsv[0], dsv[1], dh0, dl0);
+      v2_split2(dsv[2], dsv[3], dh1, dl1);
+      const int o = kc * V2_TP + qr * 2;
+      *(u32x2*)(smem + V2_PH + o) = u32x2{ph0, ph1};
+      *(u32x2*)(smem + V2_PL + o) = u32x2{pl0, pl1};
+      *(u32x2*)(smem + V2_DH + o) = u32x2{dh0, dh1};
+      *(u32x2*)(smem + V2_DL + o) = u32x2{dl0, dl1};
+    }
+    SABT(4);
+    __syncthreads();
+    SABT(5);
+    // ---- dV_j += P^T dO_i,  dK_j += dS^T Q'_i  (contraction over the 64 queries);  dQ_i += scale dS K_j  (contraction over the 64 keys) ----
+    f32x16 a3;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a3[i] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const V2Frag pa = v2_rd(smem, V2_PH, V2_PL, V2_TP, ti, 16 * st, lane);
+      const V2Frag gb = v2_rd_tr(smem, V2_GH, V2_GL, V2_QP, 16 * st, tj, lane);
+      v2_mma(dvacc, pa, gb);
+      const V2Frag da = v2_rd(smem, V2_DH, V2_DL, V2_TP, ti, 16 * st, lane);
+      const V2Frag qbf = v2_rd_tr(smem, V2_QH, V2_QL, V2_QP, 16 * st, tj, lane);
+      v2_mma(dkacc, da, qbf);
+      const V2Frag dsa = v2_rd_tr(smem, V2_DH, V2_DL, V2_TP, 16 * st, ti, lane);
+      v2_mma(a3, dsa, kq[st]);
+    }
+    SABT(6);
+    {
+      float* dqp = p.dq + (long long)b * p.q_bs + h * hd + tj + (lane & 31);
+      const bool cok = tj + (lane & 31) < hd;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = q0 + ti + SAB_ROW(r, lane);
+        if (qi < p.Lq && cok) atomicAdd(dqp + (long long)qi * p.ldq, a3[r] * p.scale);
+      }
+    }
+    SABT(7);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int kj = k0 + ti + SAB_ROW(r, lane), c = tj + (lane & 31);
+    if (kj < p.Lk && c < hd) {
+      p.dv[(long long)b * p.v_bs + (long long)kj * p.ldv + h * hd + c] = dvacc[r];
+      p.dk[(long long)b * p.k_bs + (long long)kj * p.ldk + h * hd + c] = dkacc[r] * LN2;   // (Q' carried log2(e))
+    }
+  }
+#ifdef SAB_STAMPS
+  if (stamp) {
+    for (int i = 0; i < 8; ++i) sab_ts[i] = acc_ts[i];
+    sab_ts[8] = nqb - qb0;
+  }
+#endif
+}
+#ifdef SAB_STAMPS
+extern "C" int sf_debug_read_ts_sab(long long* out16) {
+  hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(sab_ts), sizeof(long long) * 16);
+  return e == hipSuccess ? 0 : (int)e;
+}
+#endif
+
 // Training forward: the same attention with dropout on the weights and the row log-sum-exp kept for the backward pass.
 // One workgroup per (64-query block, head, sequence): S tiles -> LDS, online row max / sum, the (dropped) weights back to LDS,
 // O accumulated as 32x32 tiles in registers and rescaled per row when the running max moves.
@@ -653,9 +887,15 @@ int sf_slate_attention_train_bwd_f32(const float* q, const float* k, const float
   constexpr bool bwd48 = true;
   if (bf3 && head_dim > 32 && head_dim <= 48 && bwd48 && ldk % 4 == 0 && ldv % 4 == 0) {
     constexpr size_t lds48 = ((size_t)3 * 64 * 52 + 2 * 64 * 68 + 128) * sizeof(float);
-    SF_TRY(sf_ensure_dyn_lds((const void*)slate_attn_bwd48_kernel, (size_t)(lds48)));
+    static const bool v1 = getenv("SF_DBG") && strstr(getenv("SF_DBG"), "sab1");   // (probes: the packed-word kernel this one replaced)
     hipLaunchKernelGGL((slate_attn_stats_kernel<64, true>), g1, dim3(256), lds1, st, a, head_dim);
-    hipLaunchKernelGGL(slate_attn_bwd48_kernel, g2, dim3(256), lds48, st, a, head_dim);
+    if (v1) {
+      SF_TRY(sf_ensure_dyn_lds((const void*)slate_attn_bwd48_kernel, (size_t)(lds48)));
+      hipLaunchKernelGGL(slate_attn_bwd48_kernel, g2, dim3(256), lds48, st, a, head_dim);
+    } else {
+      SF_TRY(sf_ensure_dyn_lds((const void*)slate_attn_bwd48v2_kernel, (size_t)V2_LDS));
+      hipLaunchKernelGGL(slate_attn_bwd48v2_kernel, g2, dim3(256), (size_t)V2_LDS, st, a, head_dim);
+    }
   } else if (hdp == 32) {
     if (bf3) SAB_GO(32, true) else SAB_GO(32, false)
   } else {

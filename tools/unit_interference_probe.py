@@ -66,4 +66,12 @@ with torch.no_grad():
                 le0 = torch.cuda.Event(enable_timing=True)
                 torch.cuda.synchronize()
                 res = [a.elapsed_time(b) for a, b in evs]
-            print(f'{name:34s} units in flight {nunits}: ' + ' '.join(f'{t:6.2f} ms' for t in res))
+            msg = ''
+            if 'lt' in os.environ.get('SF_DBG', ''):
+                # (-DLT_STAMPS build through SF_LIB_PATH: shader cycles of workgroup 0's wave 0 over the first layer of the LAST launch)
+                import ctypes as C
+                ts = (C.c_longlong * 16)()
+                lib.sf_debug_read_ts_layer_tok(ts)
+                msg = (f'   layer 0 of the last launch: attention DMA waits {ts[8]} barrier waits {ts[9]} work {ts[10]} | FFN DMA waits {ts[11] - ts[8]} '
+                       f'barrier waits {ts[12] - ts[9]} work {ts[13] - ts[10]} | wall {(ts[6] - ts[0]) / 100:.1f} us')
+            print(f'{name:34s} units in flight {nunits}: ' + ' '.join(f'{t:6.2f} ms' for t in res) + msg)
