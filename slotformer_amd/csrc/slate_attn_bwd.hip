@@ -568,24 +568,6 @@ __global__ __launch_bounds__(256, 2) void slate_attn_bwd48v2_kernel(SabArgs p, i
 #endif
   // ---- K_j, V_j -> planes (in the Q / dO tiles' place), then their fragments -> registers ----
   SabTile<48> tq, tg;
-  sab_fetch<48>(p.k + (long long)b * p.k_bs + h * hd, p.ldk, k0, p.Lk, hd, tq);
-  sab_fetch<48>(p.v + (long long)b * p.v_bs + h * hd, p.ldv, k0, p.Lk, hd, tg);
-  // (columns 48 .. 55 of the query-major planes feed only output columns >= 48, which are never stored -- but they must hold finite values)
-  for (int i = tid; i < 4 * 64; i += 256) *(uint4*)(smem + (i >> 6) * V2_QT + (i & 63) * V2_QP + 96) = uint4{0u, 0u, 0u, 0u};
-  v2_put(tq, 1.f, smem, V2_QH, V2_QL);
-  v2_put(tg, 1.f, smem, V2_GH, V2_GL);
-  __syncthreads();
-  V2Frag kf[3], vf[3], kq[4];
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    kf[s] = v2_rd(smem, V2_QH, V2_QL, V2_QP, tj, 16 * s, lane);   // B operand of S: lane (key, kk) holds eight channels
-    vf[s] = v2_rd(smem, V2_GH, V2_GL, V2_QP, tj, 16 * s, lane);
-  }
-#pragma unroll
-  for (int s = 0; s < 4; ++s) kq[s] = v2_rd_tr(smem, V2_QH, V2_QL, V2_QP, 16 * s, tj, lane);   // B operand of dQ: lane (channel, kk) holds eight keys
-  f32x16 dvacc, dkacc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) dvacc[i] = dkacc[i] = 0.f;
   const int nqb = (p.Lq + 63) / 64;
   const float* qbase = p.q + (long long)b * p.q_bs + h * hd;
   const float* gbase = p.dout + (long long)b * p.o_bs + h * hd;
@@ -600,7 +582,28 @@ __global__ __launch_bounds__(256, 2) void slate_attn_bwd48v2_kernel(SabArgs p, i
       pd = p.dsum[idx];
     }
   };
-  if (qb0 < nqb) prefetch(qb0);
+  {
+    SabTile<48> tk, tv;
+    sab_fetch<48>(p.k + (long long)b * p.k_bs + h * hd, p.ldk, k0, p.Lk, hd, tk);
+    sab_fetch<48>(p.v + (long long)b * p.v_bs + h * hd, p.ldv, k0, p.Lk, hd, tv);
+    if (qb0 < nqb) prefetch(qb0);   // (the first query block's rows are on their way while K_j / V_j are laid out)
+    // (columns 48 .. 55 of the query-major planes feed only output columns >= 48, which are never stored -- but they must hold finite values)
+    for (int i = tid; i < 4 * 64; i += 256) *(uint4*)(smem + (i >> 6) * V2_QT + (i & 63) * V2_QP + 96) = uint4{0u, 0u, 0u, 0u};
+    v2_put(tk, 1.f, smem, V2_QH, V2_QL);
+    v2_put(tv, 1.f, smem, V2_GH, V2_GL);
+  }
+  __syncthreads();
+  V2Frag kf[3], vf[3], kq[4];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    kf[s] = v2_rd(smem, V2_QH, V2_QL, V2_QP, tj, 16 * s, lane);   // B operand of S: lane (key, kk) holds eight channels
+    vf[s] = v2_rd(smem, V2_GH, V2_GL, V2_QP, tj, 16 * s, lane);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) kq[s] = v2_rd_tr(smem, V2_QH, V2_QL, V2_QP, 16 * s, tj, lane);   // B operand of dQ: lane (channel, kk) holds eight keys
+  f32x16 dvacc, dkacc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dvacc[i] = dkacc[i] = 0.f;
   const int kc = tj + (lane & 31), half = lane >> 5;   // this lane's key column of the S / dP tile
   SABT(0);
   for (int qb = qb0; qb < nqb; ++qb) {

@@ -48,3 +48,20 @@ out = ops.slate_attention(qd, kd, vd, H, True)
 dq, dk, dv = ops.slate_attention_bwd(qd, kd, vd, out, go.to(dev), H, True)
 err = lambda a, b: ((a.cpu().double() - b).abs().max() / b.abs().max()).item()  # noqa: E731
 print(f'rel err vs float64 autograd: dq {err(dq, qo.grad):.2e} dk {err(dk, ko.grad):.2e} dv {err(dv, vo.grad):.2e}')
+if 'sabts' in os.environ.get('SF_DBG', ''):
+    # -DSAB_STAMPS build (SF_LIB_PATH): shader cycles of wave 0 of workgroup (0, 0, 0) per phase, summed over its query blocks
+    import ctypes as C
+    from slotformer_amd import _lib
+    B, Lq, H, hd = 72, 1025, 4, 48
+    d = H * hd
+    q, k, v, go = (torch.randn(B, Lq, d, device=dev) for _ in range(4))
+    out = ops.slate_attention(q, k, v, H, True)
+    ops.slate_attention_bwd(q, k, v, out, go, H, True)
+    torch.cuda.synchronize()
+    ts = (C.c_longlong * 16)()
+    lib = _lib.lib()
+    lib.sf_debug_read_ts_sab.argtypes = [C.POINTER(C.c_longlong)]
+    lib.sf_debug_read_ts_sab(ts)
+    n = max(ts[8], 1)
+    names = ['prologue', 'wait at loop top (barrier)', 'put Q / dO + barrier', 'S, dP products', 'exp / dS / split / writes', 'barrier', 'dV, dK, dQ products', 'atomics']
+    print(f'key block 0, {n} query blocks, cycles per query block: ' + ', '.join(f'{nm} {ts[i] / (n if i else 1):.0f}' for i, nm in enumerate(names)))
