@@ -134,11 +134,6 @@ int conv5_rows4(const float* in, const float* w_ohwi, float* w_frag, const float
                 int ks, int relu, hipStream_t st) {
   if (!w_frag || h != 64 || sf_get_precision() != 1 || !sf_conv_frag_bytes(cout, cin, ks)) return 1;
   SF_TRY(sf_pack_conv_frag_weights(w_ohwi, w_frag, cout, cin, ks, st));
-  // (a training step has the chip to itself: the weights-stationary kernel, one workgroup per CU, where it applies -- the same bits; conv_ws.hip)
-  if ((long long)R * h >= 8LL * sf_stream_cus((void*)st)) {
-    const int rcw = sf_conv5x5_ws_ex(in, w_frag, bias, add, out, R, h, h, cin, cout, ks, relu, sf_stream_cus((void*)st), st);
-    if (rcw != 1) return rcw;
-  }
   return sf_conv5x5_rows4_ex(in, w_frag, bias, add, out, R, h, h, cin, cout, ks, relu, st);
 }
 
