@@ -407,12 +407,6 @@ int gemm(const float* A, const float* W, const float* bias, float* C, long long 
 int conv5(const float* in, const float* w_ohwi, float* w_frag, const float* bias, const float* add, float* out, int F, int C, int relu, hipStream_t st) {
   if (w_frag && sf_get_precision() == 1 && sf_conv_frag_bytes(C, C, 5)) {
     SF_TRY(sf_pack_conv_frag_weights(w_ohwi, w_frag, C, C, 5, st));
-    // a training step has the chip to itself: the weights-stationary kernel with one workgroup per CU (conv_ws.hip: the same bits as the tile kernel;
-    // 96 frames: ~200 us against 535) where every workgroup gets at least eight rows, else the 4-row tiles
-    if ((long long)F * 64 >= 8LL * sf_stream_cus((void*)st)) {
-      const int rcw = sf_conv5x5_ws_ex(in, w_frag, bias, add, out, F, 64, 64, C, C, 5, relu, sf_stream_cus((void*)st), st);
-      if (rcw != 1) return rcw;
-    }
     const int rc = sf_conv5x5_rows4_ex(in, w_frag, bias, add, out, F, 64, 64, C, C, 5, relu, st);
     if (rc != 1) return rc;
   }
