@@ -144,7 +144,7 @@ def committed_profile(key):
 
 
 KERNEL_CLASS = {'layer_tok_kernel': 'layer_tok', 'conv5x5_halo': 'conv', 'ffn_qkv_tile_kernel': 'ffn_fused', 'ffn_tile_kernel': 'ffn_fused', 'ffn_partial_kernel': 'ffn_fused', 'ffn64_parts_kernel': 'ffn_fused', 'ffn_wide_parts_kernel': 'ffn_fused',
-                'conv5x5_rows4_kernel': 'conv', 'conv5x5_ws_kernel': 'conv', 'qkv_rows_kernel': 'attention', 'attn_core_kernel': 'attention', 'attn_oproj_kernel': 'attention', 'attn_all_kernel': 'attention', 'seam_kernel': 'seam', 'sa_attn_mfma_kernel': 'slot_attn', 'sa_attn_fold_kernel': 'slot_attn', 'sa_attn_tile_kernel': 'slot_attn'}
+                'conv5x5_rows4_kernel': 'conv', 'conv5x5_ws_kernel': 'conv', 'qkv_rows_kernel': 'attention', 'attn_core_kernel': 'attention', 'attn_oproj_kernel': 'attention', 'attn_all_kernel': 'attention', 'seam_kernel': 'seam', 'sa_attn_mfma_kernel': 'slot_attn', 'sa_attn_fold_kernel': 'slot_attn', 'sa_attn_tile_kernel': 'slot_attn', 'sa_attn_planes_kernel': 'slot_attn'}
 
 
 def dominant_kernel():

@@ -33,7 +33,7 @@ print(f'# of python bench.py --steps 20 --warmup 5 --no-cpu-baseline --windows 3
 print('# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves, SQ_VALU_MFMA_BUSY_CYCLES cycles summed over SIMDs, SQ_LDS_* LDS-array cycles summed over CUs (MI355X_MICROARCH.md).')
 if fs:
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
-    KS = ('layer_tok_kernel', 'ffn_qkv_tile', 'ffn_partial_kernel', 'attn_core', 'qkv_rows', 'conv5x5_ws', 'conv5x5_rows4', 'sa_attn_tile', 'sa_slot_update_mfma', 'pixel_feat_stream', 'conv_first')
+    KS = ('layer_tok_kernel', 'ffn_qkv_tile', 'ffn_partial_kernel', 'attn_core', 'qkv_rows', 'conv5x5_ws', 'conv5x5_rows4', 'sa_attn_tile', 'sa_attn_planes', 'sa_slot_update_mfma', 'pixel_feat_stream', 'pixel_feat_tok', 'conv_first')
     for r in csv.DictReader(open(fs[0])):
         for k in KS:
             if k in r['Kernel_Name']:

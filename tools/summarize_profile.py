@@ -34,7 +34,7 @@ if f:
     per = defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = short(r['Kernel_Name'])
-        if n.startswith(('deconv5x5s2_kernel', 'decode_combine_kernel', 'decode_seg_kernel', 'ffn_qkv_tile_kernel', 'pixel_feat_stream_kernel', 'conv5x5_rows4_kernel', 'conv5x5_ws_kernel', 'layer_tok_kernel', 'qkv_rows_kernel', 'attn_core_kernel', 'ffn_tile_kernel', 'conv5x5_halo_kernel', 'sa_attn_mfma_kernel', 'sa_attn_tile_kernel', 'pixel_mlp_kv_kernel', 'ffn_partial_kernel', 'ffn64_parts_kernel', 'ffn_wide_parts_kernel', 'attn_oproj_kernel', 'sa_attn_fold_kernel', 'sa_slot_update_kernel', 'conv5x5_halo256_kernel')):
+        if n.startswith(('deconv5x5s2_kernel', 'decode_combine_kernel', 'decode_seg_kernel', 'ffn_qkv_tile_kernel', 'pixel_feat_stream_kernel', 'conv5x5_rows4_kernel', 'conv5x5_ws_kernel', 'layer_tok_kernel', 'qkv_rows_kernel', 'attn_core_kernel', 'ffn_tile_kernel', 'conv5x5_halo_kernel', 'sa_attn_mfma_kernel', 'sa_attn_tile_kernel', 'sa_attn_planes_kernel', 'pixel_feat_tok_kernel', 'pixel_mlp_kv_kernel', 'ffn_partial_kernel', 'ffn64_parts_kernel', 'ffn_wide_parts_kernel', 'attn_oproj_kernel', 'sa_attn_fold_kernel', 'sa_slot_update_kernel', 'conv5x5_halo256_kernel')):
             per[(n, r['Queue_Id'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     lines.append('# per-queue durations of the encode kernels  [trace_kernel_trace.csv]  (queue with the most launches of a '
                  'kernel = the CU-masked encode stream of the timed region = bench.py roofline.avg_launch_us; the others = '
@@ -167,8 +167,8 @@ def per_block(key, total_per_launch_avg, pred):
     calls = sum(int(r['Calls']) for r in csv.DictReader(open(f)) if pred(r['Name']))
     blocks = sum(int(r['Calls']) for r in csv.DictReader(open(f)) if 'attn_core_kernel' in r['Name'])
     return total_per_launch_avg * calls / blocks if blocks else total_per_launch_avg
-for key, pred, whole_chip in (('conv_nhwc_implicit_gemm', is_conv, True), ('slot_attn_iter', lambda n: 'sa_attn_mfma' in n or 'sa_attn_fold' in n or 'sa_attn_tile' in n, True),
-                              ('layer_tok', lambda n: 'layer_tok_kernel' in n, False), ('ffn_fused', is_ffn, False), ('attention', is_attn, False), ('pixel_mlp', lambda n: 'pixel_mlp_kv_kernel' in n or 'pixel_feat_stream_kernel' in n, True),
+for key, pred, whole_chip in (('conv_nhwc_implicit_gemm', is_conv, True), ('slot_attn_iter', lambda n: 'sa_attn_mfma' in n or 'sa_attn_fold' in n or 'sa_attn_tile' in n or 'sa_attn_planes' in n, True),
+                              ('layer_tok', lambda n: 'layer_tok_kernel' in n, False), ('ffn_fused', is_ffn, False), ('attention', is_attn, False), ('pixel_mlp', lambda n: 'pixel_mlp_kv_kernel' in n or 'pixel_feat_stream_kernel' in n or 'pixel_feat_tok_kernel' in n, True),
                               # the decoder's last layer with the 1x1 head in its epilogue (bench.py --decode): every launch is a whole-chip launch of the decode stream
                               ('deconv_head', lambda n: 'deconv5x5s2_kernel<64, true>' in n, False), ('deconv_head_64x64', lambda n: 'conv5x5_rows4_kernel<false, true>' in n, False)):
     fe, wr = counter_avg(f'{tag}_pmc_fetch', 'FETCH_SIZE', pred), counter_avg(f'{tag}_pmc_write', 'WRITE_SIZE', pred)
