@@ -11,6 +11,7 @@
 
 #include "../../include/slotformer_hip.h"
 #include "sf_internal.h"
+#include "bf16_planes.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -486,11 +487,7 @@ __global__ __launch_bounds__(256, 2) void slate_attn_bwd48_kernel(SabArgs p, int
 //  * K_j's fragments for S (B operand, contraction over channels) and for dQ (B operand, contraction over keys) and V_j's for dP live in registers.
 // No conversion, no v_perm and no scalar LDS read in the loop: ~650 instructions per query block and wave instead of ~1650 (54 MFMAs either way).
 // exp runs in base 2 (Q' = Q scale log2(e), LSE' = LSE log2(e); dK is multiplied by ln 2 at the end).  65.5 KB of LDS: two workgroups per CU.
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-#define SAB_LP(T, p) ((T __attribute__((address_space(3)))*)(p))
 namespace {
 constexpr int V2_QP = 112, V2_TP = 144;          // row pitches in BYTES: query-major tiles [64][56 bf16], key-major tiles [64][72 bf16]
 constexpr int V2_QT = 64 * V2_QP, V2_TT = 64 * V2_TP;
@@ -498,12 +495,6 @@ constexpr int V2_QH = 0, V2_QL = V2_QT, V2_GH = 2 * V2_QT, V2_GL = 3 * V2_QT;
 constexpr int V2_PH = 4 * V2_QT, V2_PL = V2_PH + V2_TT, V2_DH = V2_PH + 2 * V2_TT, V2_DL = V2_PH + 3 * V2_TT;
 constexpr int V2_LS = V2_PH + 4 * V2_TT;         // lse' [64], dsum [64]
 constexpr int V2_LDS = V2_LS + 512 + 256;        // (+ slack: the transposing reads of the second channel tile run past column 55 of the last row)
-// two f32 -> packed bf16 hi pair and lo pair
-__device__ __forceinline__ void v2_split2(float a, float b, unsigned& hi, unsigned& lo) {
-  hi = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{a, b}), bf16x2v));
-  const float fa = __builtin_bit_cast(float, hi << 16), fb = __builtin_bit_cast(float, hi & 0xffff0000u);
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{a - fa, b - fb}), bf16x2v));
-}
 // prefetched rows (SabTile<48>: three float4 per thread) -> hi / lo planes of a query-major tile
 __device__ __forceinline__ void v2_put(const SabTile<48>& t, float mul, char* lds, int hoff, int loff) {
 #pragma unroll
@@ -511,41 +502,11 @@ __device__ __forceinline__ void v2_put(const SabTile<48>& t, float mul, char* ld
     const int i = threadIdx.x + 256 * n, r = i / 12, c = (i - r * 12) * 4;
     const f32x4 v = t.v[n] * mul;
     unsigned h0, l0, h1, l1;
-    v2_split2(v[0], v[1], h0, l0);
-    v2_split2(v[2], v[3], h1, l1);
+    pl_split2(v[0], v[1], h0, l0);
+    pl_split2(v[2], v[3], h1, l1);
     *(u32x2*)(lds + hoff + r * V2_QP + c * 2) = u32x2{h0, h1};
     *(u32x2*)(lds + loff + r * V2_QP + c * 2) = u32x2{l0, l1};
   }
-}
-struct V2Frag {
-  bf16x8 h, l;
-};
-// operand fragment (lane (i, kk): eight consecutive k of row i) from a tile whose rows are i: one 16-byte read per plane
-__device__ __forceinline__ V2Frag v2_rd(const char* lds, int hoff, int loff, int pitch, int row0, int k0, int lane) {
-  const int o = (row0 + (lane & 31)) * pitch + (k0 + 8 * (lane >> 5)) * 2;
-  V2Frag f;
-  f.h = *(const bf16x8*)(lds + hoff + o);
-  f.l = *(const bf16x8*)(lds + loff + o);
-  return f;
-}
-// ... from a tile whose rows are k (columns i): two transposing reads per plane.  Lane l = (j = l & 15, g = l >> 4) of a 16-lane group points at row
-// k0 + 8 kk + (j >> 2) (+ 4 for the second read), columns col0 + 16 (g & 1) + 4 (j & 3) .. + 3 and receives column col0 + (l & 31) of four rows
-__device__ __forceinline__ V2Frag v2_rd_tr(const char* lds, int hoff, int loff, int pitch, int k0, int col0, int lane) {
-  const int j = lane & 15, g = lane >> 4, kk = lane >> 5;
-  const int o = (k0 + 8 * kk + (j >> 2)) * pitch + (col0 + 16 * (g & 1) + 4 * (j & 3)) * 2;
-  V2Frag f;
-  const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(SAB_LP(bf16x4, lds + hoff + o));
-  const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(SAB_LP(bf16x4, lds + hoff + o + 4 * pitch));
-  const bf16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(SAB_LP(bf16x4, lds + loff + o));
-  const bf16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(SAB_LP(bf16x4, lds + loff + o + 4 * pitch));
-  f.h = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-  f.l = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-  return f;
-}
-__device__ __forceinline__ void v2_mma(f32x16& acc, const V2Frag& a, const V2Frag& b) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
 }
 }  // namespace
 #ifdef SAB_STAMPS
@@ -593,14 +554,14 @@ __global__ __launch_bounds__(256, 2) void slate_attn_bwd48v2_kernel(SabArgs p, i
     v2_put(tv, 1.f, smem, V2_GH, V2_GL);
   }
   __syncthreads();
-  V2Frag kf[3], vf[3], kq[4];
+  PlFrag kf[3], vf[3], kq[4];
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
-    kf[s] = v2_rd(smem, V2_QH, V2_QL, V2_QP, tj, 16 * s, lane);   // B operand of S: lane (key, kk) holds eight channels
-    vf[s] = v2_rd(smem, V2_GH, V2_GL, V2_QP, tj, 16 * s, lane);
+    kf[s] = pl_rd(smem, V2_QH, V2_QL, V2_QP, tj, 16 * s, lane);   // B operand of S: lane (key, kk) holds eight channels
+    vf[s] = pl_rd(smem, V2_GH, V2_GL, V2_QP, tj, 16 * s, lane);
   }
 #pragma unroll
-  for (int s = 0; s < 4; ++s) kq[s] = v2_rd_tr(smem, V2_QH, V2_QL, V2_QP, 16 * s, tj, lane);   // B operand of dQ: lane (channel, kk) holds eight keys
+  for (int s = 0; s < 4; ++s) kq[s] = pl_rd_tr(smem, V2_QH, V2_QL, V2_QP, 16 * s, tj, lane);   // B operand of dQ: lane (channel, kk) holds eight keys
   f32x16 dvacc, dkacc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) dvacc[i] = dkacc[i] = 0.f;
@@ -624,10 +585,10 @@ __global__ __launch_bounds__(256, 2) void slate_attn_bwd48v2_kernel(SabArgs p, i
     for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
 #pragma unroll
     for (int st = 0; st < 3; ++st) {
-      const V2Frag qa = v2_rd(smem, V2_QH, V2_QL, V2_QP, ti, 16 * st, lane);
-      const V2Frag ga = v2_rd(smem, V2_GH, V2_GL, V2_QP, ti, 16 * st, lane);
-      v2_mma(s, qa, kf[st]);
-      v2_mma(dp, ga, vf[st]);
+      const PlFrag qa = pl_rd(smem, V2_QH, V2_QL, V2_QP, ti, 16 * st, lane);
+      const PlFrag ga = pl_rd(smem, V2_GH, V2_GL, V2_QP, ti, 16 * st, lane);
+      pl_mma(s, qa, kf[st]);
+      pl_mma(dp, ga, vf[st]);
     }
     SABT(3);
     // ---- P = exp2(S' - LSE') (masked, dropped), dS = P (dP mask - D): this lane's key, four runs of four consecutive queries -> P^T / dS^T planes ----
@@ -652,10 +613,10 @@ __global__ __launch_bounds__(256, 2) void slate_attn_bwd48v2_kernel(SabArgs p, i
         dsv[e] = pe * (dp[r] * mk - d4[e]);
       }
       unsigned ph0, pl0, ph1, pl1, dh0, dl0, dh1, dl1;
-      v2_split2(pv[0], pv[1], ph0, pl0);
-      v2_split2(pv[2], pv[3], ph1, pl1);
-      v2_split2(dsv[0], dsv[1], dh0, dl0);
-      v2_split2(dsv[2], dsv[3], dh1, dl1);
+      pl_split2(pv[0], pv[1], ph0, pl0);
+      pl_split2(pv[2], pv[3], ph1, pl1);
+      pl_split2(dsv[0], dsv[1], dh0, dl0);
+      pl_split2(dsv[2], dsv[3], dh1, dl1);
       const int o = kc * V2_TP + qr * 2;
       *(u32x2*)(smem + V2_PH + o) = u32x2{ph0, ph1};
       *(u32x2*)(smem + V2_PL + o) = u32x2{pl0, pl1};
@@ -671,14 +632,14 @@ __global__ __launch_bounds__(256, 2) void slate_attn_bwd48v2_kernel(SabArgs p, i
     for (int i = 0; i < 16; ++i) a3[i] = 0.f;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      const V2Frag pa = v2_rd(smem, V2_PH, V2_PL, V2_TP, ti, 16 * st, lane);
-      const V2Frag gb = v2_rd_tr(smem, V2_GH, V2_GL, V2_QP, 16 * st, tj, lane);
-      v2_mma(dvacc, pa, gb);
-      const V2Frag da = v2_rd(smem, V2_DH, V2_DL, V2_TP, ti, 16 * st, lane);
-      const V2Frag qbf = v2_rd_tr(smem, V2_QH, V2_QL, V2_QP, 16 * st, tj, lane);
-      v2_mma(dkacc, da, qbf);
-      const V2Frag dsa = v2_rd_tr(smem, V2_DH, V2_DL, V2_TP, 16 * st, ti, lane);
-      v2_mma(a3, dsa, kq[st]);
+      const PlFrag pa = pl_rd(smem, V2_PH, V2_PL, V2_TP, ti, 16 * st, lane);
+      const PlFrag gb = pl_rd_tr(smem, V2_GH, V2_GL, V2_QP, 16 * st, tj, lane);
+      pl_mma(dvacc, pa, gb);
+      const PlFrag da = pl_rd(smem, V2_DH, V2_DL, V2_TP, ti, 16 * st, lane);
+      const PlFrag qbf = pl_rd_tr(smem, V2_QH, V2_QL, V2_QP, 16 * st, tj, lane);
+      pl_mma(dkacc, da, qbf);
+      const PlFrag dsa = pl_rd_tr(smem, V2_DH, V2_DL, V2_TP, 16 * st, ti, lane);
+      pl_mma(a3, dsa, kq[st]);
     }
     SABT(6);
     {

@@ -4,6 +4,7 @@
 // what is specific to these models.
 #include "../../include/slotformer_hip.h"
 #include "sf_internal.h"
+#include "bf16_planes.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -297,6 +298,200 @@ __global__ __launch_bounds__(256) void slate_flash_kernel(const float* __restric
       *(f32x4*)(out + (long long)b * o_bs + (long long)qi * ldo + h * HD + 4 * c4) = o;
     }
   }
+}
+
+// The same flash kernel on split-bf16 MFMAs (library precision modes 1 / 2; head_dim a multiple of 16): 21 MFMAs of 32 cycles per wave and key tile
+// instead of 56 exact-f32 MFMAs of 64.  K_j and V_j live in LDS as bf16 hi / lo planes [64 keys][HD + 8] (bf16_planes.h): the A operand of
+// S^T = K Q^T is one 16-byte read per plane, the A operand of O^T = V^T P^T comes out of the V planes through transposing reads in the ORDER THE
+// ACCUMULATORS HOLD THE KEYS (register 8 s + e of lane half h = key 16 s + 4 h + e, 8 s + 4 + e = key 16 s + 8 + 4 h + e), so the probabilities go from the
+// S^T accumulators into the PV product's B operand without leaving the registers; Q's fragments are loaded once.  exp in base 2 (log2(e) folded into Q).
+// The next key tile's rows are on their way (registers) while the current one is used.
+#ifndef SLATE_BF3_WPS
+#define SLATE_BF3_WPS 3
+#endif
+template <int HD, bool TRAIN>
+__global__ __launch_bounds__(256, SLATE_BF3_WPS) void slate_flash_bf3_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                              float* __restrict__ out, int ldq, int ldk, int ldv, int ldo, long long q_bs,
+                                                              long long k_bs, long long v_bs, long long o_bs, int L, float scale, SlateTrainArgs ta) {
+  constexpr int CB = (HD + 31) / 32, NS = HD / 16, PB = (HD + 8) * 2;   // channel blocks, k16 steps over the channels, row pitch of the planes (bytes)
+  constexpr int PT = 64 * PB;                                           // one plane
+  constexpr int PV = CB * 32 + 4;                                       // f32 pitch of the merge buffer
+  constexpr int KH = 0, KL = PT, VH = 2 * PT, VL = 3 * PT;              // (+ 64 bytes of slack behind VL: the transposing reads of the last channel block)
+  constexpr int NV = HD / 16;                                           // float4 per thread of a [64][HD] tile
+  extern __shared__ __attribute__((aligned(16))) char bsm[];
+  float* SM = (float*)bsm;                                              // [4][32] running max, [4][32] running sum: in the planes' place, after the loop
+  float* OT = SM + 2 * 4 * 32;                                          // [4 waves][32 queries][PV]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int q0 = qt * 64;
+  const float* qb_ = q + (long long)b * q_bs + h * HD;
+  const float* kb_ = k + (long long)b * k_bs + h * HD;
+  const float* vb_ = v + (long long)b * v_bs + h * HD;
+  const int qblk = wave >> 1, kh = wave & 1, half = lane >> 5;
+  const int qcol = q0 + qblk * 32 + (lane & 31);            // this lane's query
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  // Q fragments (B operand of S^T: lane (query, kk) holds channels 16 s + 8 kk .. + 7), scaled into the exponent's base
+  PlFrag qf[NS];
+  {
+    const float* qr = qb_ + (long long)min(qcol, L - 1) * ldq + 8 * half;
+    const float sc = scale * LOG2E;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const f32x4 a = *(const f32x4*)(qr + 16 * s) * sc, c = *(const f32x4*)(qr + 16 * s + 4) * sc;
+      unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+      pl_split2(a[0], a[1], h0, l0);
+      pl_split2(a[2], a[3], h1, l1);
+      pl_split2(c[0], c[1], h2, l2);
+      pl_split2(c[2], c[3], h3, l3);
+      typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+      qf[s].h = __builtin_bit_cast(pl_bf16x8, (u32x4_{h0, h1, h2, h3}));
+      qf[s].l = __builtin_bit_cast(pl_bf16x8, (u32x4_{l0, l1, l2, l3}));
+    }
+  }
+  // columns HD .. HD + 7 of the planes (+ the slack) feed only output channels >= HD: finite values
+  for (int i = t; i < 4 * 64; i += 256) *(uint4*)(bsm + (i >> 6) * PT + (i & 63) * PB + HD * 2) = uint4{0u, 0u, 0u, 0u};
+  if (t < 16) *(uint4*)(bsm + 4 * PT + 16 * t) = uint4{0u, 0u, 0u, 0u};
+  f32x16 oacc[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[cb][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const int ntiles = qt + 1;                                // causal: key tiles 0 .. qt
+  f32x4 tk[NV], tv[NV];
+  auto fetch = [&](int kt) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int i = t + 256 * n, r = i / (HD / 4), c = (i - r * (HD / 4)) * 4;
+      const int j = min(kt * 64 + r, L - 1);
+      tk[n] = *(const f32x4*)(kb_ + (long long)j * ldk + c);
+      tv[n] = *(const f32x4*)(vb_ + (long long)j * ldv + c);
+    }
+  };
+  auto put = [&](const f32x4 (&tt)[NV], int hoff, int loff) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int i = t + 256 * n, r = i / (HD / 4), c = (i - r * (HD / 4)) * 4;
+      unsigned h0, l0, h1, l1;
+      pl_split2(tt[n][0], tt[n][1], h0, l0);
+      pl_split2(tt[n][2], tt[n][3], h1, l1);
+      typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+      *(u32x2_*)(bsm + hoff + r * PB + c * 2) = u32x2_{h0, h1};
+      *(u32x2_*)(bsm + loff + r * PB + c * 2) = u32x2_{l0, l1};
+    }
+  };
+  fetch(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();                                        // previous tile fully consumed
+    const int k0 = kt * 64;
+    put(tk, KH, KL);
+    put(tv, VH, VL);
+    __syncthreads();
+    if (kt + 1 < ntiles) fetch(kt + 1);
+    // S^T block: keys k0 + 32 kh + .., queries of block qblk
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const PlFrag ka = pl_rd(bsm, KH, KL, PB, kh * 32, 16 * s, lane);
+      pl_mma(sacc, ka, qf[s]);
+    }
+    float mx = -INFINITY;
+    const bool full = kt < qt && k0 + 64 <= L;              // no key of this tile is masked for any query of the workgroup
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (!full) {
+        const int key = k0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        sacc[r] = (key <= qcol && key < L) ? sacc[r] : -INFINITY;
+      }
+      mx = fmaxf(mx, sacc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float corr = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mn);
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sacc[r] = (mn == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(sacc[r] - mn);
+      sum += sacc[r];
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    l = l * corr + sum;
+    m = mn;
+    if constexpr (TRAIN) {
+      if (ta.drop_thresh) {
+        const unsigned base = (unsigned)((((long long)b * gridDim.y + h) * L + min(qcol, L - 1)) * L);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          sacc[r] = (sf_mix32((base + (unsigned)key) ^ ta.drop_seed) >> 8) >= ta.drop_thresh ? sacc[r] * ta.drop_scale : 0.f;
+        }
+      }
+    }
+    // probabilities -> the PV product's B operand (registers 8 s .. 8 s + 7 = the keys of virtual k-step s)
+    PlFrag pf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+      pl_split2(sacc[8 * s], sacc[8 * s + 1], h0, l0);
+      pl_split2(sacc[8 * s + 2], sacc[8 * s + 3], h1, l1);
+      pl_split2(sacc[8 * s + 4], sacc[8 * s + 5], h2, l2);
+      pl_split2(sacc[8 * s + 6], sacc[8 * s + 7], h3, l3);
+      typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+      pf[s].h = __builtin_bit_cast(pl_bf16x8, (u32x4_{h0, h1, h2, h3}));
+      pf[s].l = __builtin_bit_cast(pl_bf16x8, (u32x4_{l0, l1, l2, l3}));
+    }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[cb][r] *= corr;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const PlFrag va = pl_rd_tr(bsm, VH, VL, PB, kh * 32 + 16 * s, cb * 32, lane, 4, 8);   // lane (channel, kk): keys 16 s + 4 kk + e, 16 s + 8 + 4 kk + e
+        pl_mma(oacc[cb], va, pf[s]);
+      }
+    }
+  }
+  // merge the two key halves of each query block
+  __syncthreads();                                          // (the merge buffers take the planes' place)
+  if (lane < 32) {
+    SM[wave * 32 + lane] = m;
+    SM[4 * 32 + wave * 32 + lane] = l;
+  }
+  __syncthreads();
+  {
+    const float m_o = SM[(wave ^ 1) * 32 + (lane & 31)], l_o = SM[4 * 32 + (wave ^ 1) * 32 + (lane & 31)];
+    const float mg = fmaxf(m, m_o);
+    const float fw = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mg), fo = (m_o == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_o - mg);
+    const float fsc = fw / (l * fw + l_o * fo);
+    if constexpr (TRAIN) {
+      if (kh == 0 && lane < 32 && qcol < L) ta.lse[((long long)b * gridDim.y + h) * L + qcol] = (mg + log2f(l * fw + l_o * fo)) * LN2;
+    }
+    float* od = OT + (wave * 32 + (lane & 31)) * PV + 4 * half;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(f32x4*)(od + cb * 32 + 8 * g) = f32x4{oacc[cb][4 * g] * fsc, oacc[cb][4 * g + 1] * fsc, oacc[cb][4 * g + 2] * fsc,
+                                               oacc[cb][4 * g + 3] * fsc};
+  }
+  __syncthreads();
+  for (int idx = t; idx < 64 * (HD / 4); idx += 256) {
+    const int r = idx / (HD / 4), c4 = idx - r * (HD / 4);
+    const int qi = q0 + r;
+    if (qi < L) {
+      const int w0 = (r >> 5) * 2, qq = r & 31;
+      const f32x4 o = *(const f32x4*)(OT + (w0 * 32 + qq) * PV + 4 * c4) + *(const f32x4*)(OT + ((w0 + 1) * 32 + qq) * PV + 4 * c4);
+      *(f32x4*)(out + (long long)b * o_bs + (long long)qi * ldo + h * HD + 4 * c4) = o;
+    }
+  }
+}
+template <int HD>
+constexpr size_t slate_flash_bf3_lds() {
+  const size_t planes = (size_t)4 * 64 * (HD + 8) * 2 + 256, merge = ((size_t)2 * 4 * 32 + (size_t)4 * 32 * (((HD + 31) / 32) * 32 + 4)) * sizeof(float);
+  return planes > merge ? planes : merge;
 }
 
 // Single-query attention (K/V-cached decoding, Lq == 1): one workgroup per (head, batch), the KEYS are spread over the
@@ -780,6 +975,13 @@ int sf_slate_attention_strided_f32(const float* q, const float* k, const float* 
   const float scale = 1.0f / sqrtf((float)head_dim);
   if (causal && Lq >= 128) {   // long causal self-attention: MFMA flash kernel
 #define SLATE_FLASH(HD_)                                                                                                     \
+  if (head_dim == HD_ && sf_get_precision() >= 1) {   /* split-bf16 modes: the bf16-plane kernel */                           \
+    SF_TRY(sf_ensure_dyn_lds((const void*)slate_flash_bf3_kernel<HD_, false>, slate_flash_bf3_lds<HD_>()));                    \
+    hipLaunchKernelGGL((slate_flash_bf3_kernel<HD_, false>), dim3((Lq + 63) / 64, num_heads, B), dim3(256), slate_flash_bf3_lds<HD_>(), st, q, k, v, \
+                       out, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, Lq, scale, SlateTrainArgs{nullptr, 0u, 0u, 1.f});     \
+    SF_CHECK_LAUNCH();                                                                                                       \
+    return 0;                                                                                                                \
+  }                                                                                                                          \
   if (head_dim == HD_) {                                                                                                     \
     constexpr int CB_ = (HD_ + 31) / 32;                                                                                     \
     constexpr size_t lds_ = ((size_t)2 * 64 * (HD_ + 4) + (size_t)64 * (CB_ * 32 + 4) + 2 * 4 * 32 +                          \
@@ -835,6 +1037,13 @@ int sf_slate_flash_train_ex(const float* q, const float* k, const float* v, floa
   const float scale = 1.0f / sqrtf((float)head_dim);
   const SlateTrainArgs ta{lse, drop_seed, drop_thresh, drop_scale};
 #define SLATE_FLASH_T(HD_)                                                                                                     \
+  if (head_dim == HD_ && sf_get_precision() >= 1) {                                                                            \
+    SF_TRY(sf_ensure_dyn_lds((const void*)slate_flash_bf3_kernel<HD_, true>, slate_flash_bf3_lds<HD_>()));                       \
+    hipLaunchKernelGGL((slate_flash_bf3_kernel<HD_, true>), dim3((L + 63) / 64, num_heads, B), dim3(256), slate_flash_bf3_lds<HD_>(), st, q, k, v, \
+                       out, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, L, scale, ta);                                          \
+    SF_CHECK_LAUNCH();                                                                                                         \
+    return 0;                                                                                                                  \
+  }                                                                                                                            \
   if (head_dim == HD_) {                                                                                                       \
     constexpr int CB_ = (HD_ + 31) / 32;                                                                                       \
     constexpr size_t lds_ = ((size_t)2 * 64 * (HD_ + 4) + (size_t)64 * (CB_ * 32 + 4) + 2 * 4 * 32 +                            \
