@@ -456,7 +456,8 @@ def test_slate_attention_backward(dev, precision, B, Lq, Lk, H, hd, causal):
     ref.backward(g)
     qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
     out = ops.slate_attention(qd, kd, vd, H, causal)
-    assert rel_err(out, ref) < 1e-5
+    # (split-bf16 modes: the long causal forward runs on split-bf16 MFMAs too -- slate_flash_bf3_kernel, 1.0e-5 measured; exact-f32 MFMA in the f32 mode)
+    assert rel_err(out, ref) < {'f32': 1e-5, 'bf16x3': 3e-5}[precision]
     dq, dk, dv = ops.slate_attention_bwd(qd, kd, vd, out, g.to(dev), H, causal)
     tol_ = {'f32': 2e-5, 'bf16x3': 2e-4}[precision]   # exact-f32 MFMA / split-bf16 tiles
     assert rel_err(dq, qo.grad) < tol_

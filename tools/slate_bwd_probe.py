@@ -65,3 +65,16 @@ if 'sabts' in os.environ.get('SF_DBG', ''):
     n = max(ts[8], 1)
     names = ['prologue', 'wait at loop top (barrier)', 'put Q / dO + barrier', 'S, dP products', 'exp / dS / split / writes', 'barrier', 'dV, dK, dQ products', 'atomics']
     print(f'key block 0, {n} query blocks, cycles per query block: ' + ', '.join(f'{nm} {ts[i] / (n if i else 1):.0f}' for i, nm in enumerate(names)))
+# forward (sf_slate_attention_f32: the flash kernel) at the decoder's shape
+for (B, L, H, hd) in [(72, 1025, 4, 48), (12, 1025, 4, 64)]:
+    d = H * hd
+    g = torch.Generator(device='cpu').manual_seed(3)
+    q, k, v = (torch.randn(B, L, d, generator=g).to(dev) for _ in range(3))
+    t = timeit(lambda: ops.slate_attention(q, k, v, H, True))
+    flops = 2 * 2.0 * B * H * L * L * hd * 0.5
+    o = ops.slate_attention(q[:2], k[:2], v[:2], H, True)
+    qh, kh, vh = (x[:2].double().cpu().view(2, L, H, hd).transpose(1, 2) for x in (q, k, v))
+    sc = (qh @ kh.transpose(-1, -2)) * hd ** -0.5
+    sc = sc.masked_fill(torch.triu(torch.ones(L, L, dtype=torch.bool), 1), float('-inf'))
+    ref = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(2, L, d)
+    print(f'forward B {B} L {L} H {H} hd {hd}: {t:8.1f} us per call  {flops / t / 1e6:7.1f} TFLOP/s algorithmic = {flops / t / 1e6 / 833.3:.3f} of the split-bf16 roof;  rel err vs float64 {err(o, ref):.2e}')
