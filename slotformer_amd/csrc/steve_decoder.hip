@@ -488,6 +488,11 @@ __global__ __launch_bounds__(256, SLATE_BF3_WPS) void slate_flash_bf3_kernel(con
     }
   }
 }
+// (probes: SF_DBG=flash1 keeps the exact-f32 flash kernel in the split-bf16 modes)
+static bool slate_flash_f32_forced() {
+  static const bool f = getenv("SF_DBG") && strstr(getenv("SF_DBG"), "flash1");
+  return f;
+}
 template <int HD>
 constexpr size_t slate_flash_bf3_lds() {
   const size_t planes = (size_t)4 * 64 * (HD + 8) * 2 + 256, merge = ((size_t)2 * 4 * 32 + (size_t)4 * 32 * (((HD + 31) / 32) * 32 + 4)) * sizeof(float);
@@ -975,7 +980,7 @@ int sf_slate_attention_strided_f32(const float* q, const float* k, const float* 
   const float scale = 1.0f / sqrtf((float)head_dim);
   if (causal && Lq >= 128) {   // long causal self-attention: MFMA flash kernel
 #define SLATE_FLASH(HD_)                                                                                                     \
-  if (head_dim == HD_ && sf_get_precision() >= 1) {   /* split-bf16 modes: the bf16-plane kernel */                           \
+  if (head_dim == HD_ && sf_get_precision() >= 1 && !slate_flash_f32_forced()) {   /* split-bf16 modes: the bf16-plane kernel */                           \
     SF_TRY(sf_ensure_dyn_lds((const void*)slate_flash_bf3_kernel<HD_, false>, slate_flash_bf3_lds<HD_>()));                    \
     hipLaunchKernelGGL((slate_flash_bf3_kernel<HD_, false>), dim3((Lq + 63) / 64, num_heads, B), dim3(256), slate_flash_bf3_lds<HD_>(), st, q, k, v, \
                        out, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, Lq, scale, SlateTrainArgs{nullptr, 0u, 0u, 1.f});     \
@@ -1037,7 +1042,7 @@ int sf_slate_flash_train_ex(const float* q, const float* k, const float* v, floa
   const float scale = 1.0f / sqrtf((float)head_dim);
   const SlateTrainArgs ta{lse, drop_seed, drop_thresh, drop_scale};
 #define SLATE_FLASH_T(HD_)                                                                                                     \
-  if (head_dim == HD_ && sf_get_precision() >= 1) {                                                                            \
+  if (head_dim == HD_ && sf_get_precision() >= 1 && !slate_flash_f32_forced()) {                                               \
     SF_TRY(sf_ensure_dyn_lds((const void*)slate_flash_bf3_kernel<HD_, true>, slate_flash_bf3_lds<HD_>()));                       \
     hipLaunchKernelGGL((slate_flash_bf3_kernel<HD_, true>), dim3((L + 63) / 64, num_heads, B), dim3(256), slate_flash_bf3_lds<HD_>(), st, q, k, v, \
                        out, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, L, scale, ta);                                          \
