@@ -23,7 +23,7 @@ SWITCHES = {
     # ---- tools ----
     'SF_PIPE_TRACE': ('tools', "record the device timeline of a run (tools/pipe_timeline.py)"),
     'SF_LIB_PATH': ('tools', "load another build of libslotformer_hip.so (tools/build_variant.sh: -D variants of a kernel)"),
-    'SF_DBG': ('tools', "in-kernel time stamps and tuning overrides of the probes, comma separated: conv, lt, lf=<bits>, deconv, gemm, gemmcfg=<id>, convcfg=<id> (tools/*_probe.py)"),
+    'SF_DBG': ('tools', "in-kernel time stamps and tuning overrides of the probes, comma separated: conv, lt, lf=<bits>, deconv, gemm, gemmcfg=<id>, convcfg=<id>, sab1 / flash1 (the packed-word attention backward / exact-f32 flash forward the bf16-plane kernels replaced), sabts (tools/*_probe.py)"),
 }
 
 
