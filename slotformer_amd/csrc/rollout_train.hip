@@ -21,6 +21,7 @@
 
 #include "../../include/slotformer_hip.h"
 #include "sf_internal.h"
+#include "bf16_planes.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -755,12 +756,17 @@ __device__ __forceinline__ void tn_split8(const f32x8 v, bf16x8& hi, bf16x8& lo)
   hi = __builtin_convertvector(v, bf16x8);
   lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
 }
+// The 32-row chunk of both operands lives in LDS as bf16 hi / lo PLANES (bf16_planes.h; every element split once, where it is staged, instead of once per
+// wave that reads it): the contraction index is the tile's ROW index, so the operand fragments come out through ds_read_b64_tr_b16 -- two transposing
+// reads per plane and k16 step instead of eight scalar reads + a conversion chain.  Row pitch 192 bytes: the four rows x two 16-column groups a
+// half-wave touches per read land on disjoint banks.
+#define TN_PB 192
 template <int MODE>   // 0: hi*hi + hi*lo + lo*hi + lo*lo, 1: without lo*lo (split-bf16), 2: hi*hi only (single-pass bf16)
 __global__ __launch_bounds__(256) void grad_gemm_tn_kernel(const float* __restrict__ Y, const float* __restrict__ X,
                                                            float* __restrict__ partial, long long rows, int rps, int N,
                                                            int K) {
-  __shared__ float Ys[32 * TN_P];
-  __shared__ float Xs[32 * TN_P];
+  constexpr int PT = 32 * TN_PB, YH = 0, YL = PT, XH = 2 * PT, XL = 3 * PT;
+  __shared__ __attribute__((aligned(16))) char tsm[4 * PT + 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tk = K / 64;
   const int n0 = (blockIdx.x / tk) * 64, k0 = (blockIdx.x % tk) * 64;
@@ -785,12 +791,20 @@ __global__ __launch_bounds__(256) void grad_gemm_tn_kernel(const float* __restri
     py1 = *reinterpret_cast<const float4*>(Yb + (long long)(lr + 16) * N);
     px1 = *reinterpret_cast<const float4*>(Xb + (long long)(lr + 16) * K);
   }
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  auto stage = [&](const float4 v, int hoff, int loff, int row) {
+    unsigned h0, l0, h1, l1;
+    pl_split2(v.x, v.y, h0, l0);
+    pl_split2(v.z, v.w, h1, l1);
+    *(u32x2_*)(tsm + hoff + row * TN_PB + lc * 2) = u32x2_{h0, h1};
+    if (MODE != 2) *(u32x2_*)(tsm + loff + row * TN_PB + lc * 2) = u32x2_{l0, l1};
+  };
   for (int rb = 0; rb < nrows; rb += 32) {
     __syncthreads();
-    *reinterpret_cast<float4*>(&Ys[lr * TN_P + lc]) = py0;
-    *reinterpret_cast<float4*>(&Ys[(lr + 16) * TN_P + lc]) = py1;
-    *reinterpret_cast<float4*>(&Xs[lr * TN_P + lc]) = px0;
-    *reinterpret_cast<float4*>(&Xs[(lr + 16) * TN_P + lc]) = px1;
+    stage(py0, YH, YL, lr);
+    stage(py1, YH, YL, lr + 16);
+    stage(px0, XH, XL, lr);
+    stage(px1, XH, XL, lr + 16);
     __syncthreads();
     py0 = py1 = px0 = px1 = zero4;
     const int ra = rb + 32 + lr;
@@ -804,23 +818,14 @@ __global__ __launch_bounds__(256) void grad_gemm_tn_kernel(const float* __restri
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const float* ya = &Ys[(16 * t + 8 * (lane >> 5)) * TN_P + wn + (lane & 31)];
-      const float* xa = &Xs[(16 * t + 8 * (lane >> 5)) * TN_P + wk + (lane & 31)];
-      f32x8 a, b;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        a[j] = ya[j * TN_P];
-        b[j] = xa[j * TN_P];
-      }
-      bf16x8 ah, al, bh, bl;
-      tn_split8(a, ah, al);
-      tn_split8(b, bh, bl);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+      const PlFrag a = pl_rd_tr(tsm, YH, MODE != 2 ? YL : YH, TN_PB, 16 * t, wn, lane);   // lane (n, kk): rows 16 t + 8 kk .. + 7 of column wn + n
+      const PlFrag b = pl_rd_tr(tsm, XH, MODE != 2 ? XL : XH, TN_PB, 16 * t, wk, lane);
       if (MODE != 2) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
       }
-      if (MODE == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc, 0, 0, 0);
+      if (MODE == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.l, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
     }
   }
   float* out = partial + (long long)blockIdx.y * N * K;
