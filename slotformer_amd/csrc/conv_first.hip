@@ -23,7 +23,7 @@ struct CfGeo {
   static constexpr int HR = (CF_TR - 1) * STRIDE + CF_KS;       // halo rows
   static constexpr int HC = (CF_TW - 1) * STRIDE + CF_KS;       // halo columns
   static constexpr int HCP = (HC + 3) / 4 * 4 + 4;              // padded row pitch (floats)
-  static constexpr size_t lds = (size_t)CF_CI * HR * HCP * 4 + (size_t)2 * (CF_TR * CF_TW + CF_CO) * CF_PP * 2;
+  static constexpr size_t lds = (size_t)(CF_CI * HR * HCP + 4) * 4 + (size_t)2 * (CF_TR * CF_TW + CF_CO) * CF_PP * 2;   // (+ four zero floats behind the halo: the padding entries of the patch matrix)
 };
 
 __device__ __forceinline__ void put4(__bf16* hp, __bf16* lp, int off, f32x4 v) {
@@ -34,26 +34,33 @@ __device__ __forceinline__ void put4(__bf16* hp, __bf16* lp, int off, f32x4 v) {
 }
 }  // namespace
 
+// PERSISTENT form (round 6): a workgroup walks tiles (2 output rows of a frame) blockIdx.x, + gridDim.x, ...: the weights are split into their planes ONCE,
+// the halo elements a thread fetches and the 20 patch entries it builds are located once (no index division inside the loop), and the halo of the NEXT
+// tile is in flight (registers) while the current one is multiplied.  Same products in the same order as the one-tile-per-workgroup form it replaces
+// (104 -> 76 us per 192 frames at 128 x 128 with the wrapper: 3.2 TB/s; the same bits).
+#ifndef CF_WPS
+#define CF_WPS 4   // waves per SIMD the register budget allows: 4 = two 8-wave workgroups per CU (128 registers, 34 spilled: 75.7 us per 192 frames), 2 = one (184 registers, no spill: 95.1 us)
+#endif
 template <int STRIDE>
-__global__ __launch_bounds__(CF_NT) void conv_first_kernel(const float* __restrict__ img, long long frame_stride,
+__global__ __launch_bounds__(CF_NT, CF_WPS) void conv_first_kernel(const float* __restrict__ img, long long frame_stride,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
                                                            const float* __restrict__ add, float* __restrict__ out, int Ho,
-                                                           int Hin, int Win, int relu, int fgroup, long long group_stride) {
+                                                           int Hin, int Win, int relu, int fgroup, long long group_stride, int ntiles) {
   using G = CfGeo<STRIDE>;
   constexpr int HR = G::HR, HC = G::HC, HCP = G::HCP;
+  constexpr int NH = (CF_CI * HR * HC + CF_NT - 1) / CF_NT;   // halo elements per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* In = smem;                                       // [3][HR][HCP]
-  __bf16* Ah = (__bf16*)(In + CF_CI * HR * HCP);          // [128][CF_PP] patch matrix
+  constexpr int ZERO = CF_CI * HR * HCP;                  // In[ZERO] = 0: the k >= 75 entries of the patch matrix
+  __bf16* Ah = (__bf16*)(In + ZERO + 4);                  // [128][CF_PP] patch matrix
   __bf16* Al = Ah + CF_TR * CF_TW * CF_PP;
   __bf16* Wh = Al + CF_TR * CF_TW * CF_PP;                // [64][CF_PP]
   __bf16* Wl = Wh + CF_CO * CF_PP;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int tiles = Ho / CF_TR;
-  const int f = blockIdx.x / tiles, y0 = (blockIdx.x - f * tiles) * CF_TR;
-  // frame f of the launch = frame f % fgroup of group f / fgroup (the batched encode: groups = time steps, frame_stride = T frames apart)
-  const float* inf = img + (long long)(f % fgroup) * frame_stride + (long long)(f / fgroup) * group_stride;
+  if (t < 4) In[ZERO + t] = 0.f;
 
-  // ---- weights [64][75] -> split planes, k 75..79 zero ----
+  // ---- weights [64][75] -> split planes, k 75..79 zero (once per workgroup) ----
   for (int idx = t; idx < CF_CO * (CF_KP / 4); idx += CF_NT) {
     const int co = idx / (CF_KP / 4), k4 = idx - co * (CF_KP / 4);
     f32x4 v;
@@ -64,58 +71,95 @@ __global__ __launch_bounds__(CF_NT) void conv_first_kernel(const float* __restri
     }
     put4(Wh, Wl, co * CF_PP + 4 * k4, v);
   }
-  // ---- input halo: rows 2*y0 - 2 .., columns -2 ..; zero outside the image ----
-  for (int idx = t; idx < CF_CI * HR * HC; idx += CF_NT) {
-    const int c = idx / (HR * HC), rem = idx - c * (HR * HC);
-    const int r = rem / HC, j = rem - r * HC;
-    const int gy = y0 * STRIDE - 2 + r, gx = j - 2;
-    const bool ok = (unsigned)gy < (unsigned)Hin && (unsigned)gx < (unsigned)Win;
-    const float v = inf[((long long)c * Hin + min(max(gy, 0), Hin - 1)) * Win + min(max(gx, 0), Win - 1)];
-    In[(c * HR + r) * HCP + j] = ok ? v : 0.f;
-  }
-  __syncthreads();
-  // ---- patch matrix: entry (p, k) = In[c][STRIDE*row + ky][STRIDE*x + kx], k = c*25 + ky*5 + kx ----
+  // ---- the 20 patch entries of this thread: entry (p, k) = In[c][STRIDE*row + ky][STRIDE*x + kx], k = c*25 + ky*5 + kx ----
+  const int p = t & 127, kg = t >> 7;          // pixel, group of 20 k values
+  unsigned poff[10];   // two 16-bit LDS offsets (floats) per word; ZERO: k >= 75
   {
-    const int p = t & 127, kg = t >> 7;          // pixel, group of 20 k values
-    const int row = p >> 6, x = p & 63;
+    const int prow = p >> 6, x = p & 63;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      unsigned pr[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int k = kg * 20 + 2 * q + e;
+        const int c = k / 25, r2 = k - c * 25, ky = r2 / 5, kx = r2 - ky * 5;
+        pr[e] = k < CF_K ? (unsigned)((c * HR + STRIDE * prow + ky) * HCP + STRIDE * x + kx) : (unsigned)ZERO;
+      }
+      poff[q] = pr[0] | (pr[1] << 16);
+    }
+  }
+  static_assert(CF_CI * HR * HCP < 0xffff, "16-bit patch offsets");
+  auto frame_of = [&](int tile) -> const float* {
+    const int f = tile / tiles;
+    // frame f of the launch = frame f % fgroup of group f / fgroup (the batched encode: groups = time steps, frame_stride = T frames apart)
+    return img + (long long)(f % fgroup) * frame_stride + (long long)(f / fgroup) * group_stride;
+  };
+  float hv[NH];
+  auto fetch = [&](int tile) {
+    const float* inf = frame_of(tile);
+    const int y0 = (tile % tiles) * CF_TR;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int idx = min(t + i * CF_NT, CF_CI * HR * HC - 1);   // (threads past the last element repeat it: same value to the same word)
+      const int c = idx / (HR * HC), rem = idx - c * (HR * HC);
+      const int r = rem / HC, j = rem - r * HC;
+      const int gy = y0 * STRIDE - 2 + r, gx = j - 2;
+      const bool ok = (unsigned)gy < (unsigned)Hin && (unsigned)gx < (unsigned)Win;
+      const float v = inf[((long long)c * Hin + min(max(gy, 0), Hin - 1)) * Win + min(max(gx, 0), Win - 1)];
+      hv[i] = ok ? v : 0.f;
+    }
+  };
+  auto put_halo = [&]() {
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int idx = min(t + i * CF_NT, CF_CI * HR * HC - 1);
+      const int c = idx / (HR * HC), rem = idx - c * (HR * HC);
+      const int r = rem / HC, j = rem - r * HC;
+      In[(c * HR + r) * HCP + j] = hv[i];
+    }
+  };
+  const int row = wave >> 2, pxb = ((wave >> 1) & 1) * 32, cb = (wave & 1) * 32;
+  const int ao = (row * 64 + pxb + (lane & 31)) * CF_PP + 8 * (lane >> 5);
+  const int bo = (cb + (lane & 31)) * CF_PP + 8 * (lane >> 5);
+  const int co = cb + (lane & 31);
+  const float bv = bias ? bias[co] : 0.f;
+  const float lo = relu ? 0.f : -INFINITY;
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+#pragma unroll 1
+  for (; tile < ntiles; tile += gridDim.x) {
+    put_halo();        // (every wave is past the previous tile's second barrier: its patch matrix is complete, the halo tile is free)
+    __syncthreads();   // the halo (and, the first time, the weight planes and the zero words) is in LDS; every wave is done with the previous patch planes
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);   // in flight while this tile is multiplied
+    // ---- patch matrix ----
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
       f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = kg * 20 + 4 * q + e;
-        const int c = k / 25, r2 = k - c * 25, ky = r2 / 5, kx = r2 - ky * 5;
-        v[e] = k < CF_K ? In[(c * HR + STRIDE * row + ky) * HCP + STRIDE * x + kx] : 0.f;
-      }
+      for (int e = 0; e < 4; ++e) v[e] = In[(poff[2 * q + (e >> 1)] >> (16 * (e & 1))) & 0xffffu];
       put4(Ah, Al, p * CF_PP + kg * 20 + 4 * q, v);
     }
-  }
-  __syncthreads();
-  // ---- [128 x 80] . [80 x 64]: wave = (row, 32-pixel block, 32-cout block) ----
-  const int row = wave >> 2, pxb = ((wave >> 1) & 1) * 32, cb = (wave & 1) * 32;
-  f32x16 acc;
+    __syncthreads();   // patch planes complete
+    // ---- [128 x 80] . [80 x 64]: wave = (row, 32-pixel block, 32-cout block) ----
+    f32x16 acc;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int ao = (row * 64 + pxb + (lane & 31)) * CF_PP + 8 * (lane >> 5);
-  const int bo = (cb + (lane & 31)) * CF_PP + 8 * (lane >> 5);
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-  for (int ks = 0; ks < CF_KP / 16; ++ks) {
-    const bf16x8 xh = *(const bf16x8*)(Ah + ao + ks * 16), xl = *(const bf16x8*)(Al + ao + ks * 16);
-    const bf16x8 yh = *(const bf16x8*)(Wh + bo + ks * 16), yl = *(const bf16x8*)(Wl + bo + ks * 16);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
-  }
-  const int co = cb + (lane & 31);
-  const float bv = bias ? bias[co] : 0.f;
-  const float lo = relu ? 0.f : -INFINITY;
-  const int y = y0 + row;
+    for (int ks = 0; ks < CF_KP / 16; ++ks) {
+      const bf16x8 xh = *(const bf16x8*)(Ah + ao + ks * 16), xl = *(const bf16x8*)(Al + ao + ks * 16);
+      const bf16x8 yh = *(const bf16x8*)(Wh + bo + ks * 16), yl = *(const bf16x8*)(Wl + bo + ks * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
+    }
+    const int f = tile / tiles, y = (tile % tiles) * CF_TR + row;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int px = pxb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    float v = fmaxf(acc[r] + bv, lo);
-    if (add) v += add[((long long)y * CF_TW + px) * CF_CO + co];
-    out[(((long long)f * Ho + y) * CF_TW + px) * CF_CO + co] = v;
+    for (int r = 0; r < 16; ++r) {
+      const int px = pxb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      float v = fmaxf(acc[r] + bv, lo);
+      if (add) v += add[((long long)y * CF_TW + px) * CF_CO + co];
+      out[(((long long)f * Ho + y) * CF_TW + px) * CF_CO + co] = v;
+    }
   }
 }
 
@@ -127,8 +171,12 @@ static int launch_cf(const float* img, long long frame_stride, const float* w, c
   static_assert(lds <= 80 * 1024, "first conv: two workgroups per CU");
   SF_TRY(sf_ensure_dyn_lds((const void*)kern, (size_t)(lds)));
   sf_prof_begin(SF_K_CONV_FIRST, st, 2.0 * (double)F * Ho * CF_TW * CF_CO * CF_K);
-  hipLaunchKernelGGL(kern, dim3(F * (Ho / CF_TR)), dim3(CF_NT), lds, st, img, frame_stride, w, bias, add, out, Ho, Hin, Win,
-                     relu, fgroup, group_stride);
+  // one workgroup (CF_WPS 4: two) per CU of the stream, each walking its share of the tiles (19 KB of weights are split once per workgroup)
+  const int ntiles = F * (Ho / CF_TR);
+  int grid = (CF_WPS / 2) * sf_stream_cus((void*)st);
+  if (grid > ntiles) grid = ntiles;   // (small launches: one tile per workgroup, as many workgroups as tiles)
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(CF_NT), lds, st, img, frame_stride, w, bias, add, out, Ho, Hin, Win, relu, fgroup, group_stride, ntiles);
   sf_prof_end(SF_K_CONV_FIRST, st);
   SF_CHECK_LAUNCH();
   return 0;
