@@ -694,18 +694,9 @@ namespace {
 constexpr int PT_NT = 512;
 constexpr int PT_W1 = 0, PT_W2 = 32 * 1024, PT_VEC = 96 * 1024;   // fc1 fragments [blk][ks][plane], fc2 fragments [ob][blk][s][plane] (1 KB each), vectors
 constexpr int PV_G0 = 0, PV_B0 = 64, PV_B1 = 128, PV_B2 = 256, PV_G1 = 384, PV_BE1 = 512, PV_N = 640;
-constexpr int PT_STG = PT_VEC + PV_N * 4;        // per-wave staging tiles of the stores: 8 pixel rows of 512 B (+ 16 B: the rows of a half-wave on disjoint banks)
-constexpr int PT_SROW = 528, PT_SWAVE = 8 * PT_SROW;
-constexpr size_t PT_LDS = (size_t)PT_STG + (PT_NT / 64) * PT_SWAVE;
+constexpr size_t PT_LDS = (size_t)PT_VEC + PV_N * 4;
 }  // namespace
 
-#ifdef PT_STAMPS
-__device__ long long pt_ts[16];
-#define PTS(i) do { if (stamp) { const long long c_ = __builtin_readcyclecounter(); pacc[i] += c_ - plast; plast = c_; } } while (0)
-extern "C" int sf_debug_read_ts_pixel_tok(long long* out16) { return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(pt_ts), sizeof(long long) * 16); }
-#else
-#define PTS(i)
-#endif
 template <bool PLANES>
 __global__ __launch_bounds__(PT_NT) void pixel_feat_tok_kernel(const float* __restrict__ x, const float* __restrict__ ln0_g, const float* __restrict__ ln0_b,
                                                                const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
@@ -715,10 +706,6 @@ __global__ __launch_bounds__(PT_NT) void pixel_feat_tok_kernel(const float* __re
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int n = lane & 31, h = lane >> 5;
-#ifdef PT_STAMPS
-  const bool stamp = blockIdx.x == 0 && t == 0;
-  long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = __builtin_readcyclecounter();
-#endif
   // ---- weights -> split-bf16 fragments in LDS.  Fragment = 64 lanes x 16 B; lane (i, hh), element j:
   //        fc1 (blk, ks):     W1[32 blk + i][32 hh + 8 ks + j]                         (k order of the input fragments: a lane holds channels 32 hh .. + 31)
   //        fc2 (ob, blk, s):  W2[64 (i >> 2 & 1) ... see out_row][32 blk + 8 (2 s + (j >> 2)) + 4 hh + (j & 3)]
@@ -776,7 +763,6 @@ __global__ __launch_bounds__(PT_NT) void pixel_feat_tok_kernel(const float* __re
     lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
   };
   const char* wl = pt_lds + lane * 16;
-  PTS(0);
   // tile = 32 pixels; consecutive tiles go to consecutive WAVES (a workgroup covers 256 consecutive pixels per round: its stores fill whole rows together)
   const long long ntile = ((long long)M + 31) / 32, tstep = (long long)gridDim.x * (PT_NT / 64);
   long long tile = (long long)blockIdx.x * (PT_NT / 64) + wave;
@@ -794,6 +780,7 @@ __global__ __launch_bounds__(PT_NT) void pixel_feat_tok_kernel(const float* __re
   for (int ti = 0; ti < tpw; ++ti, tile += tstep) {
     if (tile >= ntile) break;
     const long long p0 = tile * 32;
+    const long long pix = row_of(tile);
     // ---- the pixel's channels 32 h .. + 31, LayerNorm(64) ----
     f32x4 xv[8];
 #pragma unroll
@@ -806,7 +793,6 @@ __global__ __launch_bounds__(PT_NT) void pixel_feat_tok_kernel(const float* __re
     float s0 = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s0 += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
-    PTS(1);
     const float mean = pairsum(s0) * (1.0f / PM_C0);
     float v0 = 0.f;
 #pragma unroll
@@ -822,7 +808,6 @@ __global__ __launch_bounds__(PT_NT) void pixel_feat_tok_kernel(const float* __re
       split8(xv[2 * ks] * rstd * *(const f32x4*)(PV + PV_G0 + c) + *(const f32x4*)(PV + PV_B0 + c),
              xv[2 * ks + 1] * rstd * *(const f32x4*)(PV + PV_G0 + c + 4) + *(const f32x4*)(PV + PV_B0 + c + 4), xh[ks], xl[ks]);
     }
-    PTS(2);
     // ---- fc1 + b1 + ReLU: hidden block blk -> the two virtual k-steps (blk, s) of fc2 ----
     bf16x8 hh[8], hl[8];
 #pragma unroll
@@ -864,7 +849,6 @@ __global__ __launch_bounds__(PT_NT) void pixel_feat_tok_kernel(const float* __re
         }
       }
     }
-    PTS(3);
     // ---- fc2 + b2: output block ob = features 64 h + 16 ob + 4 g + q of this lane's pixel ----
     f32x16 Y[4];
 #pragma unroll
@@ -889,7 +873,6 @@ __global__ __launch_bounds__(PT_NT) void pixel_feat_tok_kernel(const float* __re
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    PTS(4);
     float s1 = 0.f;
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob)
@@ -912,66 +895,35 @@ __global__ __launch_bounds__(PT_NT) void pixel_feat_tok_kernel(const float* __re
         v1 += Y[ob][r] * Y[ob][r];
       }
     const float rstd1 = 1.0f / sqrtf(pairsum(v1) * (1.0f / PM_C1) + eps);
-    PTS(5);
-    // ---- scale, (split,) and store.  A lane holds 16 pieces of 16 bytes of ITS pixel's 512-byte row (pieces h * 8 .. + 7 of the hi and of the lo plane; f32
-    //      rows: pieces 16 h .. + 15): stored as they lie, every instruction would scatter 64 pieces over 64 rows (one 16-byte piece per 64-byte segment: the
-    //      store phase was half of a tile's time).  Instead eight pixels at a time pass through a staging tile of this wave in LDS and leave as whole rows:
-    //      one store instruction = two consecutive rows = 1 KB contiguous ----
-    {
-      typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
-      u32x4s pc[16];   // this lane's pieces, in row order of its half: planes form [plane][ob * 2 + gp]; f32 form [ob * 4 + 2 * gp + gg]
+    const bool live = p0 + n < M;
 #pragma unroll
-      for (int ob = 0; ob < 4; ++ob)
+    for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          f32x4 y[2];
+      for (int gp = 0; gp < 2; ++gp) {
+        f32x4 y[2];
 #pragma unroll
-          for (int gg = 0; gg < 2; ++gg) {
-            const int g = 2 * gp + gg, c = 64 * h + 16 * ob + 4 * g;
-            const f32x4 ga = *(const f32x4*)(PV + PV_G1 + c), be = *(const f32x4*)(PV + PV_BE1 + c);
+        for (int gg = 0; gg < 2; ++gg) {
+          const int g = 2 * gp + gg, c = 64 * h + 16 * ob + 4 * g;
+          const f32x4 ga = *(const f32x4*)(PV + PV_G1 + c), be = *(const f32x4*)(PV + PV_BE1 + c);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) y[gg][q] = Y[ob][4 * g + q] * rstd1 * ga[q] + be[q];
-          }
+          for (int q = 0; q < 4; ++q) y[gg][q] = Y[ob][4 * g + q] * rstd1 * ga[q] + be[q];
+        }
+        const int c0 = 64 * h + 16 * ob + 8 * gp;   // eight consecutive features
+        if (live) {
           if constexpr (PLANES) {
             bf16x8 yh, yl;
             split8(y[0], y[1], yh, yl);
-            pc[ob * 2 + gp] = __builtin_bit_cast(u32x4s, yh);
-            pc[8 + ob * 2 + gp] = __builtin_bit_cast(u32x4s, yl);
+            __bf16* pr = (__bf16*)out + pix * (2 * PM_C1);
+            *(bf16x8*)(pr + c0) = yh;
+            *(bf16x8*)(pr + PM_C1 + c0) = yl;
           } else {
-            pc[ob * 4 + 2 * gp] = __builtin_bit_cast(u32x4s, y[0]);
-            pc[ob * 4 + 2 * gp + 1] = __builtin_bit_cast(u32x4s, y[1]);
+            float* pr = (float*)out + pix * PM_C1;
+            *(f32x4*)(pr + c0) = y[0];
+            *(f32x4*)(pr + c0 + 4) = y[1];
           }
-        }
-      char* stg = pt_lds + PT_STG + wave * PT_SWAVE;
-      char* orow = (char*)out + p0 * 512;   // (both forms: 512 bytes per pixel)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if ((n >> 3) == j) {
-          char* wr = stg + (n & 7) * PT_SROW;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            // byte offset of piece i of this lane inside its pixel's row
-            const int off = PLANES ? ((i >> 3) * 256 + h * 128 + (i & 7) * 16) : (h * 256 + i * 16);
-            *(u32x4s*)(wr + off) = pc[i];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int q = 2 * i + (lane >> 5);                       // row of the staging tile
-          const u32x4s v = *(const u32x4s*)(stg + q * PT_SROW + (lane & 31) * 16);
-          const long long px = p0 + 8 * j + q;
-          if (px < M) *(u32x4s*)(orow + (long long)(8 * j + q) * 512 + (lane & 31) * 16) = v;
         }
       }
-    }
-    PTS(6);
   }
-#ifdef PT_STAMPS
-  if (stamp) {
-    for (int i = 0; i < 8; ++i) pt_ts[i] = pacc[i];
-    pt_ts[8] = tpw;
-  }
-#endif
 }
 
 template <bool PLANES>

@@ -31,10 +31,3 @@ for frames in (32, 192):
     e1.record()
     torch.cuda.synchronize()
     print(f'frames {frames}: {e0.elapsed_time(e1) * 1e3 / 30:7.1f} us per launch   checksum {out.double().sum().item():.10e} {out.abs().max().item():.8e}')
-if 'ptts' in os.environ.get('SF_DBG', ''):
-    import ctypes as C
-    ts = (C.c_longlong * 16)()
-    lib.sf_debug_read_ts_pixel_tok.argtypes = [C.POINTER(C.c_longlong)]
-    lib.sf_debug_read_ts_pixel_tok(ts)
-    names = ['prologue (weights -> LDS)', 'rows arrive + first sum', 'LayerNorm(64) + split', 'fc1 + ReLU + split', 'fc2', 'bias + LayerNorm(128) statistics', 'scale + split + stores']
-    print(f'wave 0 of workgroup 0, {ts[8]} tiles (the LAST launch: 192 frames), shader cycles: ' + ', '.join(f'{nm} {ts[i] / (1 if i == 0 else max(ts[8], 1)):.0f}' for i, nm in enumerate(names)))
