@@ -467,8 +467,9 @@ class EncodeRolloutPipeline:
         else:
             # (units of more than 4 batches -- unit_batches_for: long runs of small batches -- make the rollouts cheaper per batch and the encode the
             #  bound by more: C4 with units of 7 at 84 batches, every 5th / 4th / 3rd / 2nd batch: 236.0 / 242.9 / 250.6 / 250.9 k)
-            # (token-stationary units leave the rollout partition 40 % slack: every second batch -- C2 at 60 batches: 592 / 565 / 554 k with 2 / 3 / 4)
-            self.hybrid = int(os.environ.get('SF_PIPE_HYBRID', ('6' if self.tok else '3' if self.G > 4 else '5') if balanced else '0'))
+            # (token-stationary units: every 8th batch -- round 6, encode lane 2.55 ms per batch: C2 at 40 / 60 / 100 batches 593.7 / 612.0 / 632.8 k frames/s with 6,
+            #  601.7 / 621.6 / 643.2 k with 8, 639.6 k with 10 at 100; 20 batches 592.2 / 590.1 / 594.2 k with 6 / 8 / 4: neutral; profiles/r06_probes.txt section 21)
+            self.hybrid = int(os.environ.get('SF_PIPE_HYBRID', ('8' if self.tok else '3' if self.G > 4 else '5') if balanced else '0'))
         self.hybrid_tail = min(self.hybrid, 3)
         self.fill_batches = int(os.environ.get('SF_PIPE_FILL', '0')) or (fill_units * self.G if partition == 'pair' else 0)
         self.fill_steal = 0

@@ -16,7 +16,7 @@ SWITCHES = {
     # ---- the batch pipeline ----
     'SF_PIPE_TOK': ('product', "0: the pipeline never uses the token-stationary layer launches (every unit bit-identical to the serial module calls)"),
     'SF_PIPE_GROUP': ('product', "batches per rollout unit (default: 6 for token-stationary units of 32-video batches, else 4 / unit_batches_for)"),
-    'SF_PIPE_HYBRID': ('product', "every k-th batch behind the fill is encoded on an unmasked stream beside the CU-masked lane (default 6 with token-stationary units, 3 / 5 / 0 otherwise)"),
+    'SF_PIPE_HYBRID': ('product', "every k-th batch behind the fill is encoded on an unmasked stream beside the CU-masked lane (default 8 with token-stationary units, 3 / 5 / 0 otherwise)"),
     'SF_PIPE_FILL': ('product', "batches encoded on the whole chip at the start of a run (default: three units' worth)"),
     'SF_PIPE_CU_SPLIT': ('product', "CU mask of the encode partition, e.g. rows4 (default: sized from the two sides' CU time)"),
     'SF_PIPE_ENCODE_GRAPH': ('product', "replay the encode of a batch from a hipGraph (1, default) or launch it eagerly (0)"),

@@ -115,8 +115,8 @@ def test_pipeline_hybrid_lane_matches_serial(dev, hybrid, nbatch, tok):
     with torch.no_grad():
         ref = _serial_reference(savi, roll, imgs, noises, T, H, PAIR_OPTS)
         pipe = EncodeRolloutPipeline(savi, roll, B, T, H, hybrid=hybrid, tok=tok)
-        # (token-stationary full units -- the default at this batch size: units of 6 batches, every 6th batch on the hybrid lane, 18 fill batches)
-        assert pipe.tok == (tok is None) and pipe.hybrid == (6 if hybrid is None else hybrid) and pipe.fill_batches == (18 if pipe.tok else 12)
+        # (token-stationary full units -- the default at this batch size: units of 6 batches, every 8th batch on the hybrid lane, 18 fill batches)
+        assert pipe.tok == (tok is None) and pipe.hybrid == (8 if hybrid is None else hybrid) and pipe.fill_batches == (18 if pipe.tok else 12)
         serial = pipe.run(imgs, noises, serial=True) if pipe.tok else None
         for _ in range(2):
             out = pipe.run(imgs, noises)
