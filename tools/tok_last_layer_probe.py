@@ -1,5 +1,7 @@
 """The row-pruned LAST layer of a token-stationary rollout unit (192 videos, C2): ms per 50-step rollout (hipGraph replay, whole chip, alone) under the kernel forms
-the per-call options select for it.    python tools/tok_last_layer_probe.py"""
+the per-call options select for it.    python tools/tok_last_layer_probe.py
+(the all-heads variants need the engine switch of profiles/r06_probes.txt section 22, which was removed after the measurement: on the committed library every
+variant runs the row-tile form.)"""
 import os
 import sys
 import time
